@@ -1,0 +1,233 @@
+/* ovvc_hip.h -- C ABI of the MI355X (gfx950) reconstruction back-end for OpenVVC.
+ *
+ * This is the drop-in boundary: a plain-C shared library (libovvc_hip.so) that a host
+ * decoder written in C binds exactly where OpenVVC binds its x86/ARM back-ends -- the
+ * `struct RCNFunctions` dispatch table (reference: libovvc/rcn_structures.h:499-694, filled
+ * by rcn_init_functions(), libovvc/rcn.c:147-300).  The reference drives reconstruction one
+ * block per call, interleaved with CABAC parsing; a GPU cannot be driven that way, so the
+ * boundary is split in two layers (INTEGRATION.md shows the reference-side stub):
+ *
+ *   1. RECORDER  (host, no GPU needed): ovhip_rec_*() take the arguments the reference's
+ *      orchestrator slots receive (rcn_tu_st / rcn_mcp_b / ...), run the host-side control
+ *      logic those slots contain (transform-type selection, QP -> scale/shift, LFNST kernel
+ *      choice, MV clipping, identical-motion test, PU splitting) and append fixed-size
+ *      commands to per-picture buffers.
+ *   2. ENGINE    (device): ovhip_*_launch() run one frame-resident, stage-parallel HIP kernel
+ *      per stage over a whole command buffer (inverse quant + LFNST + inverse transform +
+ *      residual add; luma/chroma motion compensation; deblocking; SAO; ALF/CC-ALF).
+ *
+ * Signatures are plain pointers and sizes; no torch / C++ types.  Every engine entry point
+ * returns 0 on success or a negative OVHIP_E* code (the reference slots return void -- see
+ * SURVEY.md 8b "Error convention"; the shim latches the first error per picture) and fails
+ * loudly (OVHIP_ENODEV) when no HIP device is present: there is no CPU fallback.
+ *
+ * All sample planes are 16-bit (OVSample = uint16_t for 10-bit, libovvc/bitdepth.h:36-40),
+ * 4:2:0, strides in SAMPLES.  10-bit only, like the reference's x86 SIMD path (rcn.c:217).
+ */
+#ifndef OVVC_HIP_H
+#define OVVC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OVHIP_ABI_VERSION 1
+
+/* ---- error codes (negative, in the spirit of libovvc/overror.h:40-45) ---- */
+#define OVHIP_OK        0
+#define OVHIP_ENODEV   (-1)  /* no HIP device / runtime failure                  */
+#define OVHIP_ENOMEM   (-2)
+#define OVHIP_EINVAL   (-3)  /* malformed command / argument                      */
+#define OVHIP_ELAUNCH  (-4)  /* kernel launch or execution error (see last_error) */
+#define OVHIP_EUNSUP   (-5)  /* tool outside the supported hot path (e.g. RPR)    */
+
+/* ---- transform types: same numbering as enum DCTType, rcn_structures.h:87-93 ---- */
+enum { OVHIP_DST_VII = 0, OVHIP_DCT_VIII = 1, OVHIP_DCT_II = 2 };
+
+/* ------------------------------------------------------------------------------------
+ * Picture: three device-resident planes.  Mirrors what the rcn path sees of an OVFrame
+ * (libovvc/ovframe.h:84-124: data[3], linesize[3], width, height) -- tight planes, no
+ * padding (ovframepool.c set_plane_properties); reference windows that leave the picture
+ * are resolved by coordinate clamping on the device instead of emulate_block_border()
+ * (rcn_inter.c:148-225).
+ * ---------------------------------------------------------------------------------- */
+typedef struct ovhip_pic {
+    uint16_t *y, *cb, *cr;   /* DEVICE pointers                           */
+    int32_t   w, h;          /* luma size in samples (chroma = w/2 x h/2) */
+    int32_t   stride_y;      /* samples                                   */
+    int32_t   stride_c;      /* samples                                   */
+} ovhip_pic;
+
+/* ------------------------------------------------------------------------------------
+ * Transform-block command: one inverse-quantisation + (LFNST) + 2-pass inverse transform
+ * + residual-add.  Produced by ovhip_rec_tu(); replaces one pass through
+ * rcn_residual()/rcn_residual_c()/rcn_res_c()/rcn_jcbcr() + ict.add/ict.ict
+ * (rcn_transform_tree.c:415-506, :553-628, :720-867, :1228-1301; rcn_residuals.c:46-222).
+ * 32 bytes.
+ * ---------------------------------------------------------------------------------- */
+enum {                        /* ovhip_tb_cmd.kind */
+    OVHIP_TB_TR      = 0,     /* dequant -> [LFNST] -> vertical pass (>>7) -> horizontal (>>10) */
+    OVHIP_TB_DC      = 1,     /* DC-only shortcut, inverse_dct_ii_dc (rcn_transform.c:576-598)  */
+    OVHIP_TB_TS      = 2,     /* transform skip: de-scan + dequant_ts, no transform             */
+    OVHIP_TB_TS_RAW  = 3      /* transform skip, coefficients already raster + scaled (memcpy)  */
+};
+enum {                        /* ovhip_tb_cmd.res_mode: how the residual r is applied (rcn_residuals.c) */
+    OVHIP_RES_ADD      = 0,   /*  r        */
+    OVHIP_RES_SUB      = 1,   /* -r        */
+    OVHIP_RES_ADD_HALF = 2,   /*  r >> 1   */
+    OVHIP_RES_SUB_HALF = 3,   /* (-r) >> 1 */
+    OVHIP_RES_SCALE    = 4    /* flag: LMCS chroma residual scaling with c_scale (scale_* variants) */
+};
+#define OVHIP_TB_FLAG_RASTER 0x80  /* in .kind: coefficients stored raster (2xN / Nx2 chroma TBs) */
+
+typedef struct ovhip_tb_cmd {
+    uint16_t x, y;            /* top-left in samples of `plane`                                 */
+    uint8_t  plane;           /* 0 Y, 1 Cb, 2 Cr                                                */
+    uint8_t  log2_w, log2_h;  /* 1..6                                                           */
+    uint8_t  kind;            /* OVHIP_TB_* | OVHIP_TB_FLAG_RASTER                              */
+    uint8_t  tr_h, tr_v;      /* OVHIP_DST_VII / DCT_VIII / DCT_II                              */
+    uint8_t  lfnst;           /* bit0 on, bits1-2 kernel set (lfnst_mode_map), bit3 idx, bit4 transpose */
+    uint8_t  res_mode;        /* OVHIP_RES_*                                                    */
+    uint8_t  plane2;          /* 0xff none; else second destination (JCCR), same x,y            */
+    uint8_t  res_mode2;
+    uint8_t  dq_shift;        /* |shift| of struct IQScale (rcn_dequant.c:92-158)                */
+    uint8_t  dq_neg;          /* 1: c * (scale << shift)   0: (c*scale + add) >> shift          */
+    int16_t  dq_scale;
+    int16_t  c_scale;         /* LMCS chroma residual scale (1<<11 = none)                      */
+    uint32_t coef_off;        /* int16 index into the coefficient arena                         */
+    uint64_t sig_sb_map;      /* bit sb_y*8+sb_x; arena holds 16 int16 per SET bit, ascending   */
+} ovhip_tb_cmd;
+
+/* ------------------------------------------------------------------------------------
+ * Prediction-unit command ("MC unit"): <= 16x16 luma samples (+ the co-located 4:2:0 chroma)
+ * predicted from one or two reference pictures.  Produced by ovhip_rec_pu(), which performs
+ * clip_mv() (rcn_inter.c:96-109), the identical-motion test (:256-268), half-pel AMVR filter
+ * selection (:572-577) and BCW weight lookup (:89, :587-596) on the host, then splits the PU.
+ * Replaces rcn_mcp / rcn_mcp_b / rcn_mcp_b_l / rcn_mcp_b_c and the leaf kernels behind
+ * mc_l/mc_c.{unidir,bidir0,bidir1,bidir_w} (rcn_inter.c:520-602, :1391-1554, :2750-2966;
+ * rcn_mc.c:382-1610).  32 bytes.
+ * ---------------------------------------------------------------------------------- */
+enum {                        /* ovhip_mc_unit.flags */
+    OVHIP_MC_HPEL_FILT = 1,   /* prec_amvr == MV_PRECISION_HALF: frac 8 uses the 6-tap smoothing row */
+    OVHIP_MC_FILT_4x4  = 2,   /* the reference call was a 4x4 luma block: ov_mc_filters_4        */
+    OVHIP_MC_NO_LUMA   = 4,   /* rcn_mcp_b_c: chroma only                                        */
+    OVHIP_MC_NO_CHROMA = 8,   /* rcn_mcp_b_l: luma only                                          */
+    OVHIP_MC_LMCS      = 16   /* forward-reshape the luma prediction (lmcs_reshape_forward)      */
+};
+
+typedef struct ovhip_mc_unit {
+    uint16_t x, y;            /* luma position in the picture                                    */
+    uint8_t  w, h;            /* luma size, 4..16 (chroma w/2 x h/2)                             */
+    uint8_t  dir;             /* 1: ref0 only, 2: ref1 only, 3: bi                               */
+    uint8_t  flags;           /* OVHIP_MC_*                                                      */
+    uint8_t  ref0, ref1;      /* indices into the launch's reference-picture table               */
+    int8_t   w0, w1;          /* bi weights (4,4 = plain average path; else BCW, w0+w1 == 8)     */
+    int32_t  mv0x, mv0y;      /* 1/16 luma pel, ALREADY clipped (chroma uses the same at 1/32)   */
+    int32_t  mv1x, mv1y;
+    uint32_t aux;             /* reserved (PROF / GPM side data index)                           */
+} ovhip_mc_unit;
+
+/* ------------------------------------------------------------------------------------
+ * Recorder (host side, pure C, usable without a GPU).
+ * ---------------------------------------------------------------------------------- */
+typedef struct ovhip_recorder ovhip_recorder;
+
+/* Per-slice / per-CU state the reference keeps in OVCTUDec and that rcn_tu_st & co. read
+ * implicitly.  The shim snapshots it at slot-call time. */
+typedef struct ovhip_tu_state {
+    uint8_t qp_y, qp_cb, qp_cr, qp_jcbcr;                 /* ctudec->dequant_*.qp               */
+    uint8_t qp_y_skip, qp_cb_skip, qp_cr_skip, qp_jcbcr_skip;
+    uint8_t dep_quant;        /* residual_coding_l == residual_coding_dpq (rcn_transform_tree.c:399) */
+    uint8_t mts_implicit;     /* ctudec->mts_implicit (:435)                                      */
+    uint8_t sh_ts_disabled;   /* ctudec->sh_ts_disabled (:673)                                    */
+    uint8_t ict_type;         /* rcn_init_functions(ict_type): selects ict.ict[][] set (rcn_residuals.c:231) */
+    uint8_t lmcs_scale_c;     /* lmcs_info.scale_c_flag                                           */
+    uint8_t pad[3];
+    int16_t lmcs_chroma_scale;/* lmcs_info.lmcs_chroma_scale                                      */
+    int8_t  intra_mode;       /* ctudec->intra_mode (luma LFNST kernel choice, :461)              */
+    int8_t  lfnst_mode_c;     /* chroma: intra mode after derive_lfnst_mode_c's DM/LM substitution */
+} ovhip_tu_state;
+
+/* One transform unit as handed to tmp.rcn_tu_st / rcn_tu_l / rcn_tu_c (rcn_structures.h:475-486)
+ * together with its struct TUInfo (rcn_transform_tree.c:56-66). */
+typedef struct ovhip_tu_desc {
+    uint16_t x0, y0;          /* LUMA sample position in the picture (ctb origin already added)  */
+    uint8_t  log2_tb_w, log2_tb_h;  /* luma TU size (tree 2: chroma TU size, x0/y0 chroma units)  */
+    uint8_t  tree;            /* 0 single tree (rcn_tu_st), 1 luma (rcn_tu_l), 2 chroma (rcn_tu_c) */
+    uint8_t  cbf_mask;        /* 0x10 luma, 0x08 joint CbCr, 0x02 Cb, 0x01 Cr                     */
+    uint16_t cu_flags;        /* CUFlags bits (cu_utils.h:44-60)                                  */
+    uint8_t  tr_skip_mask;    /* 0x10 luma, 0x02 cb, 0x01 cr                                      */
+    uint8_t  cu_mts_flag, cu_mts_idx;
+    uint8_t  lfnst_flag, lfnst_idx;
+    uint8_t  pad;
+    uint16_t last_pos[3];     /* tb_info[0]=Cb/joint, [1]=Cr, [2]=luma   (y<<8 | x)               */
+    uint64_t sig_sb_map[3];
+    const int16_t *coef[3];   /* host pointers: residual_cb/cr/y + pos_offset, reference layout   */
+} ovhip_tu_desc;
+
+/* One prediction call as handed to rcn_mcp_b (rcn_structures.h:640-646). */
+typedef struct ovhip_pu_desc {
+    uint16_t x0, y0;          /* luma position in the picture                                    */
+    uint8_t  log2_w, log2_h;  /* PU size                                                          */
+    uint8_t  inter_dir;       /* 1, 2, 3                                                          */
+    uint8_t  ref_idx0, ref_idx1;
+    uint8_t  bcw_idx_plus1;   /* OVMV.bcw_idx_plus1 of mv0                                        */
+    uint8_t  prec_amvr_half;  /* inter_ctx->prec_amvr == MV_PRECISION_HALF                        */
+    uint8_t  planes;          /* 3 both (rcn_mcp_b), 1 luma only (rcn_mcp_b_l), 2 chroma only     */
+    uint8_t  lmcs;            /* luma forward reshaping active                                    */
+    uint8_t  pad;
+    int32_t  mv0x, mv0y, mv1x, mv1y;
+    int32_t  poc0, poc1;      /* rpl0[ref_idx0]->poc, rpl1[ref_idx1]->poc (identical-motion test) */
+    uint8_t  ref0, ref1;      /* slots of those pictures in the launch's reference table          */
+    uint8_t  pad2[2];
+} ovhip_pu_desc;
+
+ovhip_recorder *ovhip_rec_create(int32_t pic_w, int32_t pic_h);
+void  ovhip_rec_destroy(ovhip_recorder *rec);
+void  ovhip_rec_reset(ovhip_recorder *rec);
+/* Append the commands of one TU / PU.  Return number of commands appended or <0. */
+int   ovhip_rec_tu(ovhip_recorder *rec, const ovhip_tu_state *st, const ovhip_tu_desc *tu);
+int   ovhip_rec_pu(ovhip_recorder *rec, const ovhip_pu_desc *pu);
+/* Access to the recorded (host) buffers. */
+const ovhip_tb_cmd  *ovhip_rec_tb_cmds(const ovhip_recorder *rec, size_t *n);
+const int16_t       *ovhip_rec_coefs(const ovhip_recorder *rec, size_t *n_int16);
+const ovhip_mc_unit *ovhip_rec_mc_units(const ovhip_recorder *rec, size_t *n);
+
+/* ------------------------------------------------------------------------------------
+ * Engine (device side).
+ * ---------------------------------------------------------------------------------- */
+typedef struct ovhip_ctx ovhip_ctx;
+
+int  ovhip_abi_version(void);
+/* stream: a hipStream_t the caller owns (e.g. torch's current stream) or NULL to create one. */
+int  ovhip_ctx_create(ovhip_ctx **out, int device, void *stream);
+void ovhip_ctx_destroy(ovhip_ctx *ctx);
+int  ovhip_ctx_sync(ovhip_ctx *ctx);
+const char *ovhip_last_error(const ovhip_ctx *ctx);
+void *ovhip_ctx_stream(ovhip_ctx *ctx);
+
+/* device memory helpers (plain hipMalloc/hipMemcpyAsync on the context stream) */
+int  ovhip_malloc(ovhip_ctx *ctx, size_t bytes, void **dptr);
+int  ovhip_free(ovhip_ctx *ctx, void *dptr);
+int  ovhip_h2d(ovhip_ctx *ctx, void *dptr, const void *host, size_t bytes);
+int  ovhip_d2h(ovhip_ctx *ctx, void *host, const void *dptr, size_t bytes);
+int  ovhip_pic_alloc(ovhip_ctx *ctx, int32_t w, int32_t h, ovhip_pic *pic);
+int  ovhip_pic_free(ovhip_ctx *ctx, ovhip_pic *pic);
+int  ovhip_pic_upload(ovhip_ctx *ctx, const ovhip_pic *pic, const uint16_t *y, const uint16_t *cb,
+                      const uint16_t *cr, int32_t host_stride_y, int32_t host_stride_c);
+int  ovhip_pic_download(ovhip_ctx *ctx, const ovhip_pic *pic, uint16_t *y, uint16_t *cb,
+                        uint16_t *cr, int32_t host_stride_y, int32_t host_stride_c);
+
+/* Stage launches.  cmds / coefs / units are DEVICE pointers; asynchronous on the ctx stream. */
+int  ovhip_itx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_tb_cmd *d_cmds,
+                      uint32_t n_cmds, const int16_t *d_coefs);
+int  ovhip_mc_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs,
+                     const ovhip_mc_unit *d_units, uint32_t n_units, const uint16_t *d_lmcs_fwd_lut);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OVVC_HIP_H */

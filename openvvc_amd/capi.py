@@ -1,0 +1,201 @@
+"""ctypes binding of the C ABI declared in include/ovvc_hip.h.
+
+Host-side mirror used by the Python harness (tests, bench, smoke).  The structures below are
+field-for-field the C structs; `tests/test_capi.py` checks sizes against the library.  The
+library is the product: if libovvc_hip.so is missing this module raises -- there is no
+Python or CPU fallback for the engine entry points.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libovvc_hip.so"
+
+# ---- constants (include/ovvc_hip.h) ----
+OVHIP_ABI_VERSION = 1
+DST_VII, DCT_VIII, DCT_II = 0, 1, 2
+TB_TR, TB_DC, TB_TS, TB_TS_RAW = 0, 1, 2, 3
+TB_FLAG_RASTER = 0x80
+RES_ADD, RES_SUB, RES_ADD_HALF, RES_SUB_HALF, RES_SCALE = 0, 1, 2, 3, 4
+MC_HPEL_FILT, MC_FILT_4x4, MC_NO_LUMA, MC_NO_CHROMA, MC_LMCS = 1, 2, 4, 8, 16
+
+
+class Pic(C.Structure):
+    _fields_ = [("y", C.c_void_p), ("cb", C.c_void_p), ("cr", C.c_void_p),
+                ("w", C.c_int32), ("h", C.c_int32), ("stride_y", C.c_int32), ("stride_c", C.c_int32)]
+
+
+class TbCmd(C.Structure):
+    _fields_ = [("x", C.c_uint16), ("y", C.c_uint16), ("plane", C.c_uint8), ("log2_w", C.c_uint8),
+                ("log2_h", C.c_uint8), ("kind", C.c_uint8), ("tr_h", C.c_uint8), ("tr_v", C.c_uint8),
+                ("lfnst", C.c_uint8), ("res_mode", C.c_uint8), ("plane2", C.c_uint8),
+                ("res_mode2", C.c_uint8), ("dq_shift", C.c_uint8), ("dq_neg", C.c_uint8),
+                ("dq_scale", C.c_int16), ("c_scale", C.c_int16), ("coef_off", C.c_uint32),
+                ("sig_sb_map", C.c_uint64)]
+
+
+class McUnit(C.Structure):
+    _fields_ = [("x", C.c_uint16), ("y", C.c_uint16), ("w", C.c_uint8), ("h", C.c_uint8),
+                ("dir", C.c_uint8), ("flags", C.c_uint8), ("ref0", C.c_uint8), ("ref1", C.c_uint8),
+                ("w0", C.c_int8), ("w1", C.c_int8), ("mv0x", C.c_int32), ("mv0y", C.c_int32),
+                ("mv1x", C.c_int32), ("mv1y", C.c_int32), ("aux", C.c_uint32)]
+
+
+class TuState(C.Structure):
+    _fields_ = [("qp_y", C.c_uint8), ("qp_cb", C.c_uint8), ("qp_cr", C.c_uint8), ("qp_jcbcr", C.c_uint8),
+                ("qp_y_skip", C.c_uint8), ("qp_cb_skip", C.c_uint8), ("qp_cr_skip", C.c_uint8),
+                ("qp_jcbcr_skip", C.c_uint8), ("dep_quant", C.c_uint8), ("mts_implicit", C.c_uint8),
+                ("sh_ts_disabled", C.c_uint8), ("ict_type", C.c_uint8), ("lmcs_scale_c", C.c_uint8),
+                ("pad", C.c_uint8 * 3), ("lmcs_chroma_scale", C.c_int16), ("intra_mode", C.c_int8),
+                ("lfnst_mode_c", C.c_int8)]
+
+
+class TuDesc(C.Structure):
+    _fields_ = [("x0", C.c_uint16), ("y0", C.c_uint16), ("log2_tb_w", C.c_uint8), ("log2_tb_h", C.c_uint8),
+                ("tree", C.c_uint8), ("cbf_mask", C.c_uint8), ("cu_flags", C.c_uint16),
+                ("tr_skip_mask", C.c_uint8), ("cu_mts_flag", C.c_uint8), ("cu_mts_idx", C.c_uint8),
+                ("lfnst_flag", C.c_uint8), ("lfnst_idx", C.c_uint8), ("pad", C.c_uint8),
+                ("last_pos", C.c_uint16 * 3), ("sig_sb_map", C.c_uint64 * 3),
+                ("coef", C.c_void_p * 3)]
+
+
+class PuDesc(C.Structure):
+    _fields_ = [("x0", C.c_uint16), ("y0", C.c_uint16), ("log2_w", C.c_uint8), ("log2_h", C.c_uint8),
+                ("inter_dir", C.c_uint8), ("ref_idx0", C.c_uint8), ("ref_idx1", C.c_uint8),
+                ("bcw_idx_plus1", C.c_uint8), ("prec_amvr_half", C.c_uint8), ("planes", C.c_uint8),
+                ("lmcs", C.c_uint8), ("pad", C.c_uint8), ("mv0x", C.c_int32), ("mv0y", C.c_int32),
+                ("mv1x", C.c_int32), ("mv1y", C.c_int32), ("poc0", C.c_int32), ("poc1", C.c_int32),
+                ("ref0", C.c_uint8), ("ref1", C.c_uint8), ("pad2", C.c_uint8 * 2)]
+
+
+TB_CMD_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("plane", "u1"), ("log2_w", "u1"), ("log2_h", "u1"),
+                         ("kind", "u1"), ("tr_h", "u1"), ("tr_v", "u1"), ("lfnst", "u1"), ("res_mode", "u1"),
+                         ("plane2", "u1"), ("res_mode2", "u1"), ("dq_shift", "u1"), ("dq_neg", "u1"),
+                         ("dq_scale", "<i2"), ("c_scale", "<i2"), ("coef_off", "<u4"), ("sig_sb_map", "<u8")])
+MC_UNIT_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("w", "u1"), ("h", "u1"), ("dir", "u1"), ("flags", "u1"),
+                          ("ref0", "u1"), ("ref1", "u1"), ("w0", "i1"), ("w1", "i1"), ("mv0x", "<i4"),
+                          ("mv0y", "<i4"), ("mv1x", "<i4"), ("mv1y", "<i4"), ("aux", "<u4")])
+assert TB_CMD_DTYPE.itemsize == C.sizeof(TbCmd) == 32
+assert MC_UNIT_DTYPE.itemsize == C.sizeof(McUnit) == 32
+
+_lib = None
+
+
+def load(path: os.PathLike | None = None) -> C.CDLL:
+    """Load libovvc_hip.so (built in-tree by __graft_entry__.build()).  Fails loudly."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = Path(path) if path else LIB_PATH
+    if not p.exists():
+        raise RuntimeError(f"{p} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(the HIP engine has no CPU fallback)")
+    try:  # share torch's HIP runtime when torch is in the process (same SONAME libamdhip64.so.7)
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover
+        pass
+    lib = C.CDLL(str(p))
+    vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int32
+    P = C.POINTER
+    sigs = {
+        "ovhip_abi_version": (C.c_int, []),
+        "ovhip_rec_create": (vp, [i32, i32]),
+        "ovhip_rec_destroy": (None, [vp]),
+        "ovhip_rec_reset": (None, [vp]),
+        "ovhip_rec_tu": (C.c_int, [vp, P(TuState), P(TuDesc)]),
+        "ovhip_rec_pu": (C.c_int, [vp, P(PuDesc)]),
+        "ovhip_rec_tb_cmds": (vp, [vp, P(C.c_size_t)]),
+        "ovhip_rec_coefs": (vp, [vp, P(C.c_size_t)]),
+        "ovhip_rec_mc_units": (vp, [vp, P(C.c_size_t)]),
+        "ovhip_ctx_create": (C.c_int, [P(vp), C.c_int, vp]),
+        "ovhip_ctx_destroy": (None, [vp]),
+        "ovhip_ctx_sync": (C.c_int, [vp]),
+        "ovhip_last_error": (C.c_char_p, [vp]),
+        "ovhip_ctx_stream": (vp, [vp]),
+        "ovhip_malloc": (C.c_int, [vp, C.c_size_t, P(vp)]),
+        "ovhip_free": (C.c_int, [vp, vp]),
+        "ovhip_h2d": (C.c_int, [vp, vp, vp, C.c_size_t]),
+        "ovhip_d2h": (C.c_int, [vp, vp, vp, C.c_size_t]),
+        "ovhip_pic_alloc": (C.c_int, [vp, i32, i32, P(Pic)]),
+        "ovhip_pic_free": (C.c_int, [vp, P(Pic)]),
+        "ovhip_pic_upload": (C.c_int, [vp, P(Pic), vp, vp, vp, i32, i32]),
+        "ovhip_pic_download": (C.c_int, [vp, P(Pic), vp, vp, vp, i32, i32]),
+        "ovhip_itx_launch": (C.c_int, [vp, P(Pic), vp, u32, vp]),
+        "ovhip_mc_launch": (C.c_int, [vp, P(Pic), P(Pic), u32, vp, u32, vp]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)          # AttributeError = missing export: fail loudly
+        fn.restype, fn.argtypes = res, args
+    if lib.ovhip_abi_version() != OVHIP_ABI_VERSION:
+        raise RuntimeError("libovvc_hip.so ABI version mismatch")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "ovhip_abi_version", "ovhip_rec_create", "ovhip_rec_destroy", "ovhip_rec_reset", "ovhip_rec_tu",
+    "ovhip_rec_pu", "ovhip_rec_tb_cmds", "ovhip_rec_coefs", "ovhip_rec_mc_units", "ovhip_ctx_create",
+    "ovhip_ctx_destroy", "ovhip_ctx_sync", "ovhip_last_error", "ovhip_ctx_stream", "ovhip_malloc",
+    "ovhip_free", "ovhip_h2d", "ovhip_d2h", "ovhip_pic_alloc", "ovhip_pic_free", "ovhip_pic_upload",
+    "ovhip_pic_download", "ovhip_itx_launch", "ovhip_mc_launch",
+]
+
+
+class Recorder:
+    """Host-side recorder (ovhip_rec_*): turns reference-style TU/PU calls into command buffers."""
+
+    def __init__(self, pic_w: int, pic_h: int):
+        self.lib = load()
+        self.h = self.lib.ovhip_rec_create(pic_w, pic_h)
+        if not self.h:
+            raise MemoryError("ovhip_rec_create")
+        self._keep = []
+
+    def close(self):
+        if self.h:
+            self.lib.ovhip_rec_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        self.lib.ovhip_rec_reset(self.h)
+
+    def tu(self, st: TuState, d: TuDesc) -> int:
+        r = self.lib.ovhip_rec_tu(self.h, C.byref(st), C.byref(d))
+        if r < 0:
+            raise ValueError(f"ovhip_rec_tu -> {r}")
+        return r
+
+    def pu(self, d: PuDesc) -> int:
+        r = self.lib.ovhip_rec_pu(self.h, C.byref(d))
+        if r < 0:
+            raise ValueError(f"ovhip_rec_pu -> {r}")
+        return r
+
+    def _arr(self, fn, dtype):
+        n = C.c_size_t(0)
+        p = fn(self.h, C.byref(n))
+        if not n.value:
+            return np.zeros(0, dtype=dtype)
+        buf = (C.c_char * (n.value * np.dtype(dtype).itemsize)).from_address(p)
+        return np.frombuffer(buf, dtype=dtype).copy()
+
+    def tb_cmds(self) -> np.ndarray:
+        return self._arr(self.lib.ovhip_rec_tb_cmds, TB_CMD_DTYPE)
+
+    def coefs(self) -> np.ndarray:
+        return self._arr(self.lib.ovhip_rec_coefs, np.int16)
+
+    def mc_units(self) -> np.ndarray:
+        return self._arr(self.lib.ovhip_rec_mc_units, MC_UNIT_DTYPE)

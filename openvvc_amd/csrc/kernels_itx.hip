@@ -1,0 +1,290 @@
+// kernels_itx.hip -- K1..K4 on gfx950: inverse quantisation, LFNST, separable inverse
+// transform (DCT-II 2..64, DST-VII / DCT-VIII 4..32), residual add (+JCCR, +LMCS chroma scale).
+//
+// One wavefront (= one 64-thread workgroup) per transform block.  The coefficient tile is
+// de-scanned and de-quantised straight from the compact coefficient arena into LDS (one lane
+// per 4x4 sub-block, 32 contiguous bytes per lane -> coalesced), the two transform cores the
+// block needs are staged in LDS as int8, and both 1-D passes run out of LDS with 4-line
+// register blocking (one ds_read_b64 of 4 int16 feeds 4 MACs).  int16 x int8 -> int32 stencil
+// arithmetic on the VALU; no MFMA (exact clip16 rounding between the passes, K <= 32).
+//
+// Replaces, per block, the reference call chain
+//   dequant_tb_4x4 -> [compute_lfnst_*] -> tr.func[v] -> tr.func[h] -> ict.add / ict.ict
+// (libovvc/rcn_transform_tree.c:415-506, :553-628; rcn_dequant.c:160-312; rcn_lfnst.c:41-162;
+//  rcn_transform.c:44-598; rcn_residuals.c:46-222).  Every butterfly in rcn_transform.c is an
+// exact integer refactoring of the plain matrix product computed here.
+#include "ovvc_common.hip.h"
+#define OVT_ATTR __device__
+#include "vvc_tables.h"
+
+namespace {
+
+__device__ __forceinline__ const int8_t *tr_matrix(int type, int log2n)
+{
+    switch (type * 8 + log2n) {
+    case 0 * 8 + 2: return ovt_dst7_4;
+    case 0 * 8 + 3: return ovt_dst7_8;
+    case 0 * 8 + 4: return ovt_dst7_16;
+    case 0 * 8 + 5: return ovt_dst7_32;
+    case 1 * 8 + 2: return ovt_dct8_4;
+    case 1 * 8 + 3: return ovt_dct8_8;
+    case 1 * 8 + 4: return ovt_dct8_16;
+    case 1 * 8 + 5: return ovt_dct8_32;
+    case 2 * 8 + 1: return ovt_dct2_2;
+    case 2 * 8 + 2: return ovt_dct2_4;
+    case 2 * 8 + 3: return ovt_dct2_8;
+    case 2 * 8 + 4: return ovt_dct2_16;
+    case 2 * 8 + 5: return ovt_dct2_32;
+    default:        return ovt_dct2_64;
+    }
+}
+
+__device__ __forceinline__ int dequant1(int c, int scale, int shift, int neg)
+{
+    // rcn_dequant.c:160-312 -- int32 wrap-around arithmetic, then ov_clip_intp2(v, 16), which is
+    // the SYMMETRIC range [-32767, 32767] (ovutils.h:78-92)
+    if (neg) return ov_clip3((int)((uint32_t)c * (uint32_t)(scale << shift)), -32767, 32767);
+    return ov_clip3(((int)((uint32_t)c * (uint32_t)scale) + ((1 << shift) >> 1)) >> shift, -32767, 32767);
+}
+
+__device__ __forceinline__ int nb_rows_of(uint64_t map)   // derive_nb_rows, rcn_transform_tree.c:78-92
+{
+    uint32_t m = (uint32_t)map | (uint32_t)(map >> 32);
+    m |= m >> 16; m |= m >> 8;
+    m = (m & 0xff) | 1;
+    return (32 - __clz((int)m)) << 2;
+}
+__device__ __forceinline__ int nb_cols_of(uint64_t map)   // derive_nb_cols, :94-101
+{
+    return (8 - (__clzll((long long)(map | 1)) >> 3)) << 2;
+}
+
+// the eight variants of rcn_residuals.c:46-222 on one sample
+__device__ __forceinline__ int residual1(int pix, int r, int mode, int scale)
+{
+    int v = r;
+    switch (mode & 3) {
+    case OVHIP_RES_SUB:      v = -v; break;
+    case OVHIP_RES_ADD_HALF: v = v >> 1; break;
+    case OVHIP_RES_SUB_HALF: v = (-v) >> 1; break;
+    default: break;
+    }
+    if (mode & OVHIP_RES_SCALE) {
+        int sign = v & (1 << 15);
+        int a = ov_clip_bd(abs(v));
+        a = (a * scale + (1 << 10)) >> 11;
+        v = ov_clip3(sign ? -a : a, -(1 << 15), 1 << 15);
+    }
+    return ov_clip_bd(pix + v);
+}
+
+// One 1-D pass out of LDS:  out[i][j] = clip16((sum_k src[k*sstride + i] * M[k*N + j] + rnd) >> shift)
+// for i < lines (lines % IB == 0), j < N, k < kmax.  Lane owns column j and IB consecutive lines
+// (one ds_read_b64 / b32 of IB int16 feeds IB MACs).  FINAL = false: store int16 to dst[i*N + j]
+// (pass 1).  FINAL = true: fuse K4, the residual add into the frame (pass 2; lanes j -> contiguous
+// frame addresses).
+struct ResidualSink {
+    uint16_t *dst; int stride; int mode;
+    uint16_t *dst2; int stride2; int mode2;
+    int scale;
+};
+
+template <int IB, bool FINAL>
+__device__ __forceinline__ void tr_pass_lds(const int16_t *src, int sstride, const int8_t *mat, int log2n,
+                                             int kmax, int lines, int shift, int16_t *dst, int lane,
+                                             const ResidualSink &sink)
+{
+    const int n = 1 << log2n;
+    const int ntask = (lines / IB) << log2n;
+    const int rnd = 1 << (shift - 1);
+    for (int t = lane; t < ntask; t += 64) {
+        const int j = t & (n - 1);
+        const int i0 = (t >> log2n) * IB;
+        int acc[IB];
+#pragma unroll
+        for (int q = 0; q < IB; ++q) acc[q] = 0;
+        for (int k = 0; k < kmax; ++k) {
+            const int m = mat[(k << log2n) + j];
+            const int16_t *s = src + k * sstride + i0;
+            if (IB == 4) {
+                const int2 v = *reinterpret_cast<const int2 *>(s);
+                acc[0] += m * (int)(int16_t)(v.x & 0xffff);
+                acc[1] += m * (v.x >> 16);
+                acc[2] += m * (int)(int16_t)(v.y & 0xffff);
+                acc[3] += m * (v.y >> 16);
+            } else {
+                const int v = *reinterpret_cast<const int *>(s);
+                acc[0] += m * (int)(int16_t)(v & 0xffff);
+                acc[1] += m * (v >> 16);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < IB; ++q) {
+            const int r = ov_clip16((acc[q] + rnd) >> shift);
+            if (!FINAL) {
+                dst[((i0 + q) << log2n) + j] = (int16_t)r;
+            } else {
+                uint16_t *p = sink.dst + (i0 + q) * sink.stride + j;
+                *p = (uint16_t)residual1(*p, r, sink.mode, sink.scale);
+                if (sink.dst2) {
+                    uint16_t *p2 = sink.dst2 + (i0 + q) * sink.stride2 + j;
+                    *p2 = (uint16_t)residual1(*p2, r, sink.mode2, sink.scale);
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_itx(ovhip_pic pic, const ovhip_tb_cmd *__restrict__ cmds,
+                                             uint32_t n_cmds, const int16_t *__restrict__ arena)
+{
+    __shared__ __attribute__((aligned(16))) int16_t s_coef[32 * 32];
+    __shared__ __attribute__((aligned(16))) int16_t s_tmp[32 * 64];
+    __shared__ __attribute__((aligned(16))) int8_t s_mv[32 * 64];
+    __shared__ __attribute__((aligned(16))) int8_t s_mh[32 * 64];
+
+    const uint32_t bid = blockIdx.x;
+    if (bid >= n_cmds) return;
+    const int lane = threadIdx.x;
+    const ovhip_tb_cmd c = cmds[bid];
+
+    const int log2_w = c.log2_w, log2_h = c.log2_h;
+    const int tb_w = 1 << log2_w, tb_h = 1 << log2_h;
+    const int kind = c.kind & 0x7f;
+    const bool raster = c.kind & OVHIP_TB_FLAG_RASTER;
+    const int cw = min(tb_w, 32), ch = min(tb_h, 32);
+    const int16_t *src = arena + c.coef_off;
+
+    // ---- stage transform cores (only what this block needs) ----
+    const int kv = min(tb_h, 32), kh = min(tb_w, 32);
+    if (kind == OVHIP_TB_TR) {
+        const int8_t *mv = tr_matrix(c.tr_v, log2_h);
+        const int8_t *mh = tr_matrix(c.tr_h, log2_w);
+        for (int i = lane; i < (kv << log2_h); i += 64) s_mv[i] = mv[i];
+        for (int i = lane; i < (kh << log2_w); i += 64) s_mh[i] = mh[i];
+    }
+
+    // ---- K1: de-scan + de-quantise into LDS raster [ch][cw] ----
+    if (raster) {
+        for (int i = lane; i < tb_w * tb_h; i += 64)
+            s_coef[i] = kind == OVHIP_TB_TS_RAW ? src[i] : (int16_t)dequant1(src[i], c.dq_scale, c.dq_shift, c.dq_neg);
+    } else {
+        const int nx = cw >> 2, ny = ch >> 2;
+        if (lane < nx * ny) {
+            const int sx = lane % nx, sy = lane / nx;
+            const int bit = sy * 8 + sx;
+            const uint64_t map = c.sig_sb_map;
+            int16_t *d = s_coef + (sy * 4) * cw + sx * 4;
+            if ((map >> bit) & 1) {
+                const int rank = __popcll(map & ((1ull << bit) - 1));
+                const int4 *p = reinterpret_cast<const int4 *>(src + rank * 16);
+                int4 v0 = p[0], v1 = p[1];
+                int w[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        int word = w[r * 2 + (q >> 1)];
+                        int cv = (q & 1) ? (word >> 16) : (int)(int16_t)(word & 0xffff);
+                        d[r * cw + q] = (int16_t)dequant1(cv, c.dq_scale, c.dq_shift, c.dq_neg);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) d[r * cw + q] = 0;
+            }
+        }
+    }
+    __syncthreads();
+
+    ResidualSink sink;
+    sink.dst = ov_plane(pic, c.plane, sink.stride) + c.y * sink.stride + c.x;
+    sink.mode = c.res_mode;
+    sink.dst2 = nullptr; sink.stride2 = 0; sink.mode2 = c.res_mode2;
+    if (c.plane2 != 0xff) sink.dst2 = ov_plane(pic, c.plane2, sink.stride2) + c.y * sink.stride2 + c.x;
+    sink.scale = c.c_scale;
+
+    if (kind == OVHIP_TB_TR) {
+        int nb_row, nb_col;
+        if (raster) {
+            const int l2sw = log2_w > 2 ? 3 : 1, l2sh = log2_h > 2 ? 3 : 1;
+            nb_col = kv;
+            nb_row = (nb_rows_of(c.sig_sb_map) >> 2) << l2sw;
+        } else {
+            nb_row = nb_rows_of(c.sig_sb_map);
+            nb_col = nb_cols_of(c.sig_sb_map);     // rows of the tile that can hold non-zero data
+        }
+        // ---- K2: LFNST on the first sub-block (rcn_lfnst.c:41-162) ----
+        if (c.lfnst & 1) {
+            const bool is8 = log2_w >= 3 && log2_h >= 3;
+            const int set = (c.lfnst >> 1) & 3, idx = (c.lfnst >> 3) & 1, tr = (c.lfnst >> 4) & 1;
+            const int8_t *m = is8 ? ovt_lfnst_8x8[set][idx] : ovt_lfnst_4x4[set][idx];
+            const int nout = is8 ? 48 : 16;
+            const int nin = is8 ? 16 : (min(log2_w, 5) == min(log2_h, 5) ? 8 : 16);
+            int out = 0;
+            if (lane < nout) {
+                // diagonal scan of the 4x4 sub-block: constant 0xfbe7ad369c258140 (rcn_lfnst.c:46-53)
+                const uint64_t scan = 0xfbe7ad369c258140ull;
+                int s = 0;
+                for (int j = 0; j < nin; ++j) {
+                    const int pos = (int)((scan >> (4 * j)) & 0xf);
+                    s += (int)s_coef[(pos >> 2) * cw + (pos & 3)] * (int)m[lane + j * nout];
+                }
+                out = ov_clip3((s + 64) >> 7, -(1 << 15), 1 << 15);
+            }
+            __syncthreads();
+            if (lane < nout) {
+                int r, q;
+                if (!is8)           { r = lane >> 2; q = lane & 3; }
+                else if (lane < 32) { r = lane >> 3; q = lane & 7; }
+                else                { r = 4 + ((lane - 32) >> 2); q = lane & 3; }
+                if (tr) { int t = r; r = q; q = t; }
+                s_coef[r * cw + q] = (int16_t)out;
+            }
+            nb_row = 4 << (int)is8;               // rcn_transform_tree.c:474-475
+            nb_col = max(nb_col, nb_row);
+            __syncthreads();
+        }
+        nb_row = min(nb_row, tb_w);
+        const int k1 = min(nb_col, kv);
+        // ---- K3: vertical pass (shift 7): tmp[i*tb_h + j], i = coefficient column < nb_row ----
+        if (nb_row & 3) tr_pass_lds<2, false>(s_coef, cw, s_mv, log2_h, k1, nb_row, 7, s_tmp, lane, sink);
+        else            tr_pass_lds<4, false>(s_coef, cw, s_mv, log2_h, k1, nb_row, 7, s_tmp, lane, sink);
+        __syncthreads();
+        // ---- horizontal pass (shift 20 - bitdepth) fused with K4; tmp rows >= nb_row are zero ----
+        const int k2 = min(nb_row, kh);
+        if (tb_h & 3) tr_pass_lds<2, true>(s_tmp, tb_h, s_mh, log2_w, k2, tb_h, 20 - OV_BD, nullptr, lane, sink);
+        else          tr_pass_lds<4, true>(s_tmp, tb_h, s_mh, log2_w, k2, tb_h, 20 - OV_BD, nullptr, lane, sink);
+        return;
+    }
+
+    // ---- DC shortcut / transform skip: K4 directly ----
+    const bool flat = kind == OVHIP_TB_DC;
+    // inverse_dct_ii_dc, rcn_transform.c:576-598
+    const int flat_val = ov_clip16(((((int)s_coef[0] + 1) >> 1) + (1 << (14 - OV_BD - 1))) >> (14 - OV_BD));
+    for (int i = lane; i < tb_w * tb_h; i += 64) {
+        const int x = i & (tb_w - 1), y = i >> log2_w;
+        const int r = flat ? flat_val : (int)s_coef[y * tb_w + x];   // TS blocks are <= 32 wide: raster stride tb_w
+        uint16_t *p = sink.dst + y * sink.stride + x;
+        *p = (uint16_t)residual1(*p, r, sink.mode, sink.scale);
+        if (sink.dst2) {
+            uint16_t *p2 = sink.dst2 + y * sink.stride2 + x;
+            *p2 = (uint16_t)residual1(*p2, r, sink.mode2, sink.scale);
+        }
+    }
+}
+
+} // namespace
+
+extern "C" int ovhip_itx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_tb_cmd *d_cmds,
+                                uint32_t n_cmds, const int16_t *d_coefs)
+{
+    if (!ctx || !dst) return OVHIP_EINVAL;
+    if (!n_cmds) return OVHIP_OK;
+    if (!d_cmds || !d_coefs) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_itx_launch: null buffer", hipSuccess);
+    hipLaunchKernelGGL(k_itx, dim3(n_cmds), dim3(64), 0, ctx->stream, *dst, d_cmds, n_cmds, d_coefs);
+    OV_LAUNCH_CHECK(ctx, "k_itx");
+    return OVHIP_OK;
+}

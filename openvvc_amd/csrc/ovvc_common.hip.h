@@ -1,0 +1,45 @@
+// ovvc_common.hip.h -- shared device helpers and the engine context (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "ovvc_hip.h"
+
+#define OV_BD 10
+#define OV_PIX_MAX ((1 << OV_BD) - 1)
+
+struct ovhip_ctx {
+    int device;
+    hipStream_t stream;
+    int owns_stream;
+    char err[256];
+};
+
+static inline int ov_fail(ovhip_ctx *ctx, int code, const char *what, hipError_t e)
+{
+    if (ctx) snprintf(ctx->err, sizeof(ctx->err), "%s: %s", what, e == hipSuccess ? "invalid argument" : hipGetErrorString(e));
+    return code;
+}
+
+#define OV_HIP(ctx, call)                                                     \
+    do {                                                                      \
+        hipError_t e__ = (call);                                              \
+        if (e__ != hipSuccess) return ov_fail((ctx), OVHIP_ENODEV, #call, e__); \
+    } while (0)
+
+#define OV_LAUNCH_CHECK(ctx, name)                                            \
+    do {                                                                      \
+        hipError_t e__ = hipGetLastError();                                   \
+        if (e__ != hipSuccess) return ov_fail((ctx), OVHIP_ELAUNCH, name, e__); \
+    } while (0)
+
+__device__ __forceinline__ int ov_clip3(int v, int lo, int hi) { return min(max(v, lo), hi); }
+__device__ __forceinline__ int ov_clip16(int v) { return ov_clip3(v, -32768, 32767); }
+__device__ __forceinline__ int ov_clip_bd(int v) { return ov_clip3(v, 0, OV_PIX_MAX); }
+
+__device__ __forceinline__ uint16_t *ov_plane(const ovhip_pic &p, int plane, int &stride)
+{
+    stride = plane ? p.stride_c : p.stride_y;
+    return plane == 0 ? p.y : (plane == 1 ? p.cb : p.cr);
+}

@@ -1,0 +1,136 @@
+// ovvc_engine.hip -- context, device-memory and picture plumbing of the C ABI (include/ovvc_hip.h).
+// gfx950 only; every entry point fails loudly (OVHIP_ENODEV + ovhip_last_error) when the HIP
+// runtime or device is missing -- there is no CPU fallback in the product library.
+#include "ovvc_common.hip.h"
+#include <stdlib.h>
+
+extern "C" {
+
+int ovhip_abi_version(void) { return OVHIP_ABI_VERSION; }
+
+int ovhip_ctx_create(ovhip_ctx **out, int device, void *stream)
+{
+    if (!out) return OVHIP_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return OVHIP_ENODEV;
+    if (hipSetDevice(device) != hipSuccess) return OVHIP_ENODEV;
+    ovhip_ctx *ctx = (ovhip_ctx *)calloc(1, sizeof(*ctx));
+    if (!ctx) return OVHIP_ENOMEM;
+    ctx->device = device;
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { free(ctx); return OVHIP_ENODEV; }
+        ctx->owns_stream = 1;
+    }
+    *out = ctx;
+    return OVHIP_OK;
+}
+
+void ovhip_ctx_destroy(ovhip_ctx *ctx)
+{
+    if (!ctx) return;
+    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+    free(ctx);
+}
+
+int ovhip_ctx_sync(ovhip_ctx *ctx)
+{
+    if (!ctx) return OVHIP_EINVAL;
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return ov_fail(ctx, OVHIP_ELAUNCH, "hipStreamSynchronize", e);
+    return OVHIP_OK;
+}
+
+const char *ovhip_last_error(const ovhip_ctx *ctx) { return ctx ? ctx->err : "no context"; }
+void *ovhip_ctx_stream(ovhip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int ovhip_malloc(ovhip_ctx *ctx, size_t bytes, void **dptr)
+{
+    if (!ctx || !dptr) return OVHIP_EINVAL;
+    *dptr = nullptr;
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 16);
+    if (e != hipSuccess) return ov_fail(ctx, OVHIP_ENOMEM, "hipMalloc", e);
+    return OVHIP_OK;
+}
+
+int ovhip_free(ovhip_ctx *ctx, void *dptr)
+{
+    if (!ctx) return OVHIP_EINVAL;
+    if (dptr) OV_HIP(ctx, hipFree(dptr));
+    return OVHIP_OK;
+}
+
+int ovhip_h2d(ovhip_ctx *ctx, void *dptr, const void *host, size_t bytes)
+{
+    if (!ctx || (bytes && (!dptr || !host))) return OVHIP_EINVAL;
+    if (bytes) OV_HIP(ctx, hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return OVHIP_OK;
+}
+
+int ovhip_d2h(ovhip_ctx *ctx, void *host, const void *dptr, size_t bytes)
+{
+    if (!ctx || (bytes && (!dptr || !host))) return OVHIP_EINVAL;
+    if (bytes) {
+        OV_HIP(ctx, hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        OV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return OVHIP_OK;
+}
+
+int ovhip_pic_alloc(ovhip_ctx *ctx, int32_t w, int32_t h, ovhip_pic *pic)
+{
+    if (!ctx || !pic || w <= 0 || h <= 0 || (w & 1) || (h & 1)) return OVHIP_EINVAL;
+    memset(pic, 0, sizeof(*pic));
+    // one allocation, three tight planes (what the reference's frame pool hands out), each 256-B aligned
+    const size_t ysz = ((size_t)w * h * 2 + 255) & ~(size_t)255;
+    const size_t csz = ((size_t)(w / 2) * (h / 2) * 2 + 255) & ~(size_t)255;
+    void *base = nullptr;
+    hipError_t e = hipMalloc(&base, ysz + 2 * csz);
+    if (e != hipSuccess) return ov_fail(ctx, OVHIP_ENOMEM, "hipMalloc(picture)", e);
+    pic->y = (uint16_t *)base;
+    pic->cb = (uint16_t *)((char *)base + ysz);
+    pic->cr = (uint16_t *)((char *)base + ysz + csz);
+    pic->w = w; pic->h = h; pic->stride_y = w; pic->stride_c = w / 2;
+    return OVHIP_OK;
+}
+
+int ovhip_pic_free(ovhip_ctx *ctx, ovhip_pic *pic)
+{
+    if (!ctx || !pic) return OVHIP_EINVAL;
+    if (pic->y) OV_HIP(ctx, hipFree(pic->y));
+    memset(pic, 0, sizeof(*pic));
+    return OVHIP_OK;
+}
+
+static int copy_planes(ovhip_ctx *ctx, const ovhip_pic *pic, uint16_t *y, uint16_t *cb, uint16_t *cr,
+                       int32_t hs_y, int32_t hs_c, int to_device)
+{
+    if (!ctx || !pic || !pic->y) return OVHIP_EINVAL;
+    uint16_t *host[3] = { y, cb, cr };
+    uint16_t *dev[3] = { pic->y, pic->cb, pic->cr };
+    for (int p = 0; p < 3; ++p) {
+        if (!host[p]) continue;
+        const int w = p ? pic->w / 2 : pic->w, h = p ? pic->h / 2 : pic->h;
+        const size_t dpitch = (size_t)(p ? pic->stride_c : pic->stride_y) * 2, hpitch = (size_t)(p ? hs_c : hs_y) * 2;
+        if (to_device) OV_HIP(ctx, hipMemcpy2DAsync(dev[p], dpitch, host[p], hpitch, (size_t)w * 2, h, hipMemcpyHostToDevice, ctx->stream));
+        else           OV_HIP(ctx, hipMemcpy2DAsync(host[p], hpitch, dev[p], dpitch, (size_t)w * 2, h, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    OV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return OVHIP_OK;
+}
+
+int ovhip_pic_upload(ovhip_ctx *ctx, const ovhip_pic *pic, const uint16_t *y, const uint16_t *cb,
+                     const uint16_t *cr, int32_t hs_y, int32_t hs_c)
+{
+    return copy_planes(ctx, pic, (uint16_t *)y, (uint16_t *)cb, (uint16_t *)cr, hs_y, hs_c, 1);
+}
+
+int ovhip_pic_download(ovhip_ctx *ctx, const ovhip_pic *pic, uint16_t *y, uint16_t *cb, uint16_t *cr,
+                       int32_t hs_y, int32_t hs_c)
+{
+    return copy_planes(ctx, pic, y, cb, cr, hs_y, hs_c, 0);
+}
+
+} // extern "C"

@@ -1,0 +1,424 @@
+/* ovvc_record.c -- host-side recorder of the MI355X back-end (plain C, no GPU needed).
+ *
+ * The reference reconstructs each block inside the orchestrator slots of struct RCNFunctions,
+ * called from the CABAC parse loop.  The GPU path defers execution: these
+ * functions perform the *control* part of those orchestrators on the host -- everything that
+ * depends on decoder state rather than on samples -- and emit self-contained fixed-size
+ * commands for the device kernels.  Behaviour restated from (never copied):
+ *   rcn_tu_st / rcn_tu_l / rcn_tu_c        libovvc/rcn_transform_tree.c:1228-1382
+ *   rcn_residual / rcn_residual_c           libovvc/rcn_transform_tree.c:415-506, :553-628
+ *   rcn_res_c / rcn_jcbcr                   libovvc/rcn_transform_tree.c:720-867
+ *   transform-skip paths                    libovvc/rcn_transform_tree.c:672-716, :1208-1225
+ *   derive_dequant_{sdh,dpq,ts}             libovvc/rcn_dequant.c:92-158
+ *   drv_lfnst_mode_l / process_lfnst(_luma) libovvc/drv_lfnst.c:42-156
+ *   ict.ict[][] selection                   libovvc/rcn_residuals.c:231-331
+ *   rcn_mcp_b dispatch, clip_mv, identical motion, AMVR half-pel, BCW
+ *                                           libovvc/rcn_inter.c:89-109, :256-268, :520-602, :2769-2813
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "ovvc_hip.h"
+
+struct ovhip_recorder {
+    int32_t pic_w, pic_h;
+    ovhip_tb_cmd  *tb;    size_t n_tb,   cap_tb;
+    int16_t       *coef;  size_t n_coef, cap_coef;
+    ovhip_mc_unit *mc;    size_t n_mc,   cap_mc;
+};
+
+/* CUFlags bits this path looks at (libovvc/cu_utils.h:44-60) */
+#define CUF_PRED_MODE_INTRA   (1u << 1)
+#define CUF_MIP               (1u << 2)
+#define CUF_BDPCM_LUMA        (1u << 8)
+#define CUF_BDPCM_CHROMA      (1u << 9)
+
+ovhip_recorder *
+ovhip_rec_create(int32_t pic_w, int32_t pic_h)
+{
+    ovhip_recorder *r = (ovhip_recorder *)calloc(1, sizeof(*r));
+    if (!r) return NULL;
+    r->pic_w = pic_w;
+    r->pic_h = pic_h;
+    return r;
+}
+
+void
+ovhip_rec_destroy(ovhip_recorder *r)
+{
+    if (!r) return;
+    free(r->tb); free(r->coef); free(r->mc);
+    free(r);
+}
+
+void
+ovhip_rec_reset(ovhip_recorder *r)
+{
+    r->n_tb = r->n_coef = r->n_mc = 0;
+}
+
+const ovhip_tb_cmd *ovhip_rec_tb_cmds(const ovhip_recorder *r, size_t *n) { *n = r->n_tb; return r->tb; }
+const int16_t *ovhip_rec_coefs(const ovhip_recorder *r, size_t *n) { *n = r->n_coef; return r->coef; }
+const ovhip_mc_unit *ovhip_rec_mc_units(const ovhip_recorder *r, size_t *n) { *n = r->n_mc; return r->mc; }
+
+static int
+grow(void **p, size_t *cap, size_t need, size_t elem)
+{
+    if (need <= *cap) return 0;
+    size_t nc = *cap ? *cap : 1024;
+    while (nc < need) nc *= 2;
+    void *q = realloc(*p, nc * elem);
+    if (!q) return -1;
+    *p = q; *cap = nc;
+    return 0;
+}
+
+/* ---------------------------------------------------------------- dequantisation params */
+struct dq { int16_t scale; uint8_t shift, neg; };
+
+static const int16_t iq_scale[2][6] = { { 40, 45, 51, 57, 64, 72 }, { 57, 64, 72, 80, 90, 102 } };
+
+/* kind: 0 sdh (regular), 1 dep-quant, 2 transform skip.  BITDEPTH 10: 15 - 10 = 5. */
+static struct dq
+derive_dq(int kind, int qp, int log2_w, int log2_h)
+{
+    struct dq d;
+    int l2s = log2_w + log2_h;
+    int shift, scale;
+    if (kind == 2) {
+        shift = 6 - qp / 6;
+        scale = iq_scale[0][qp % 6];
+    } else if (kind == 1) {
+        shift = 6 + 1 - 5 - (qp + 1) / 6 + (l2s >> 1) + (l2s & 1);
+        scale = iq_scale[l2s & 1][(qp + 1) % 6];
+    } else {
+        shift = 6 - 5 - qp / 6 + (l2s >> 1) + (l2s & 1);
+        scale = iq_scale[l2s & 1][qp % 6];
+    }
+    d.scale = (int16_t)scale;
+    d.neg   = shift < 0;
+    d.shift = (uint8_t)(shift < 0 ? -shift : shift);
+    return d;
+}
+
+/* ---------------------------------------------------------------- LFNST kernel choice */
+static int
+lfnst_set_of_mode(int m)   /* the 95-entry lfnst_mode_map as ranges */
+{
+    if (m <= 1)  return 0;
+    if (m <= 12) return 1;
+    if (m <= 23) return 2;
+    if (m <= 44) return 3;
+    if (m <= 55) return 2;
+    return 1;
+}
+
+static int
+wide_angle_mode(int log2_w, int log2_h, int mode)
+{
+    static const uint8_t mode_shift[6] = { 0, 6, 10, 12, 14, 15 };
+    int d = log2_w - log2_h;
+    int ms = mode_shift[d < 0 ? -d : d];
+    if (log2_w > log2_h && mode < 2 + ms)        mode += 65;   /* VDIA - 1 */
+    else if (log2_h > log2_w && mode > 66 - ms)  mode -= 67;   /* VDIA + 1 */
+    return mode;
+}
+
+static int
+lfnst_mode_luma(int log2_w, int log2_h, int intra_mode)
+{
+    if (intra_mode > 1) intra_mode = wide_angle_mode(log2_w, log2_h, intra_mode);
+    if (intra_mode < 0)        intra_mode += 14 + 67;
+    else if (intra_mode >= 67) intra_mode += 14;
+    return intra_mode;
+}
+
+static uint8_t
+lfnst_field(int mode_idx, int lfnst_idx)
+{
+    int transpose = (mode_idx < 67 && mode_idx > 34) || mode_idx >= 67 + 14;
+    return (uint8_t)(1 | (lfnst_set_of_mode(mode_idx) << 1) | ((lfnst_idx & 1) << 3) | (transpose << 4));
+}
+
+/* ---------------------------------------------------------------- coefficient capture */
+static uint64_t
+valid_sb_mask(int log2_w, int log2_h)
+{
+    int nx = 1 << ((log2_w > 5 ? 5 : log2_w) - 2);
+    int ny = 1 << ((log2_h > 5 ? 5 : log2_h) - 2);
+    uint64_t row = (1ull << nx) - 1, m = 0;
+    for (int i = 0; i < ny; ++i) m |= row << (i * 8);
+    return m;
+}
+
+/* Copy the flagged 4x4 sub-blocks (reference layout: SB-major, SB (sx,sy) at
+ * src[sy*4*stride + sx*16], stride = min(32, tb_w); rcn_dequant.c:160-236) into the arena,
+ * 16 int16 per set bit in ascending bit order. */
+static int
+capture_sbs(ovhip_recorder *r, const int16_t *src, int log2_w, uint64_t map, uint32_t *off)
+{
+    int stride = 1 << (log2_w > 5 ? 5 : log2_w);
+    int n = __builtin_popcountll(map);
+    if (grow((void **)&r->coef, &r->cap_coef, r->n_coef + (size_t)n * 16, sizeof(int16_t))) return -1;
+    *off = (uint32_t)r->n_coef;
+    while (map) {
+        int b = __builtin_ctzll(map);
+        map &= map - 1;
+        memcpy(r->coef + r->n_coef, src + (b >> 3) * 4 * stride + (b & 7) * 16, 16 * sizeof(int16_t));
+        r->n_coef += 16;
+    }
+    return 0;
+}
+
+static int
+capture_raster(ovhip_recorder *r, const int16_t *src, int n, uint32_t *off)
+{
+    size_t pad = (size_t)(n + 15) & ~(size_t)15;   /* keep every TB 32-byte aligned in the arena */
+    if (grow((void **)&r->coef, &r->cap_coef, r->n_coef + pad, sizeof(int16_t))) return -1;
+    *off = (uint32_t)r->n_coef;
+    memcpy(r->coef + r->n_coef, src, (size_t)n * sizeof(int16_t));
+    memset(r->coef + r->n_coef + n, 0, (pad - (size_t)n) * sizeof(int16_t));
+    r->n_coef += pad;
+    return 0;
+}
+
+static ovhip_tb_cmd *
+new_tb(ovhip_recorder *r)
+{
+    if (grow((void **)&r->tb, &r->cap_tb, r->n_tb + 1, sizeof(ovhip_tb_cmd))) return NULL;
+    ovhip_tb_cmd *c = &r->tb[r->n_tb++];
+    memset(c, 0, sizeof(*c));
+    c->plane2 = 0xff;
+    c->c_scale = 1 << 11;
+    c->tr_h = c->tr_v = OVHIP_DCT_II;
+    return c;
+}
+
+/* ---------------------------------------------------------------- residual-add variants */
+/* ict.ict[log2w][k] for k = 0,1,2 under rcn_init_ict_functions(type) (rcn_residuals.c:231-331) */
+static uint8_t
+ict_mode(int ict_type, int k)
+{
+    static const uint8_t tab[4][3] = {
+        /* 0 */ { OVHIP_RES_ADD, OVHIP_RES_ADD, OVHIP_RES_ADD_HALF },
+        /* 1 */ { OVHIP_RES_ADD | OVHIP_RES_SCALE, OVHIP_RES_ADD | OVHIP_RES_SCALE, OVHIP_RES_ADD_HALF | OVHIP_RES_SCALE },
+        /* 2 */ { OVHIP_RES_ADD, OVHIP_RES_SUB, OVHIP_RES_SUB_HALF },
+        /* 3 */ { OVHIP_RES_ADD | OVHIP_RES_SCALE, OVHIP_RES_SUB | OVHIP_RES_SCALE, OVHIP_RES_SUB_HALF | OVHIP_RES_SCALE },
+    };
+    return tab[ict_type & 3][k];
+}
+
+/* ---------------------------------------------------------------- one transform block */
+struct tb_args {
+    int plane, x, y, log2_w, log2_h;
+    int is_luma;
+    int tr_skip;            /* transform skip selected for this TB                    */
+    int qp, qp_skip;
+    int lfnst_flag, lfnst_idx, lfnst_mode_idx;
+    int cu_mts_flag, cu_mts_idx;
+    int implicit_mts_ok;    /* luma: !is_mip && mts_implicit                           */
+    uint16_t last_pos;
+    uint64_t sig_sb_map;
+    const int16_t *coef;
+};
+
+static int
+emit_tb(ovhip_recorder *r, const ovhip_tu_state *st, const struct tb_args *a, ovhip_tb_cmd **out)
+{
+    ovhip_tb_cmd *c = new_tb(r);
+    if (!c) return OVHIP_ENOMEM;
+    c->x = (uint16_t)a->x; c->y = (uint16_t)a->y;
+    c->plane = (uint8_t)a->plane;
+    c->log2_w = (uint8_t)a->log2_w; c->log2_h = (uint8_t)a->log2_h;
+    *out = c;
+
+    int small = a->log2_w < 2 || a->log2_h < 2;        /* 2xN / Nx2 chroma TBs: raster storage */
+
+    if (a->tr_skip) {
+        if (!st->sh_ts_disabled) {
+            /* TS residual coding: coefficients are raster and final (memcpy in the reference) */
+            c->kind = OVHIP_TB_TS_RAW | OVHIP_TB_FLAG_RASTER;
+            return capture_raster(r, a->coef, 1 << (a->log2_w + a->log2_h), &c->coef_off) ? OVHIP_ENOMEM : 0;
+        }
+        struct dq d = derive_dq(2, a->qp_skip, a->log2_w, a->log2_h);
+        c->dq_scale = d.scale; c->dq_shift = d.shift; c->dq_neg = d.neg;
+        if (small) {
+            /* memcpy + dequant_sb() per 16 coefficients (rcn_transform_tree.c:700-706): blocks
+             * smaller than 16 samples (2x2, 2x4, 4x2) are therefore NOT de-quantised */
+            c->kind = ((a->log2_w + a->log2_h) >= 4 ? OVHIP_TB_TS : OVHIP_TB_TS_RAW) | OVHIP_TB_FLAG_RASTER;
+            return capture_raster(r, a->coef, 1 << (a->log2_w + a->log2_h), &c->coef_off) ? OVHIP_ENOMEM : 0;
+        }
+        c->kind = OVHIP_TB_TS;
+        c->sig_sb_map = (a->sig_sb_map | !a->sig_sb_map) & valid_sb_mask(a->log2_w, a->log2_h);
+        return capture_sbs(r, a->coef, a->log2_w, c->sig_sb_map, &c->coef_off) ? OVHIP_ENOMEM : 0;
+    }
+
+    struct dq d = derive_dq(st->dep_quant ? 1 : 0, a->qp, a->log2_w, a->log2_h);
+    c->dq_scale = d.scale; c->dq_shift = d.shift; c->dq_neg = d.neg;
+
+    if (small) {
+        c->kind = OVHIP_TB_FLAG_RASTER;
+        c->sig_sb_map = a->sig_sb_map;
+        if (capture_raster(r, a->coef, 1 << (a->log2_w + a->log2_h), &c->coef_off)) return OVHIP_ENOMEM;
+    } else {
+        c->sig_sb_map = (a->sig_sb_map | !a->sig_sb_map) & valid_sb_mask(a->log2_w, a->log2_h);
+        if (capture_sbs(r, a->coef, a->log2_w, c->sig_sb_map, &c->coef_off)) return OVHIP_ENOMEM;
+    }
+
+    int is_dc = !a->last_pos;
+    if (a->is_luma) {
+        if (a->implicit_mts_ok && !a->cu_mts_flag && (a->log2_w <= 4 || a->log2_h <= 4) && !a->lfnst_flag) {
+            c->tr_h = a->log2_w <= 4 ? OVHIP_DST_VII : OVHIP_DCT_II;
+            c->tr_v = a->log2_h <= 4 ? OVHIP_DST_VII : OVHIP_DCT_II;
+            c->kind |= OVHIP_TB_TR;
+        } else if (!a->cu_mts_flag) {
+            if (a->lfnst_flag) {
+                c->lfnst = lfnst_field(a->lfnst_mode_idx, a->lfnst_idx);
+                is_dc = 0;
+            }
+            c->kind |= is_dc ? OVHIP_TB_DC : OVHIP_TB_TR;
+        } else {
+            c->tr_h = (uint8_t)(a->cu_mts_idx & 1);
+            c->tr_v = (uint8_t)(a->cu_mts_idx >> 1);
+            c->kind |= OVHIP_TB_TR;
+        }
+    } else {
+        if (is_dc && !a->lfnst_flag) {
+            c->kind |= OVHIP_TB_DC;
+        } else {
+            if (a->lfnst_flag) c->lfnst = lfnst_field(a->lfnst_mode_idx, a->lfnst_idx);
+            c->kind |= OVHIP_TB_TR;
+        }
+    }
+    return 0;
+}
+
+int
+ovhip_rec_tu(ovhip_recorder *r, const ovhip_tu_state *st, const ovhip_tu_desc *tu)
+{
+    size_t n0 = r->n_tb;
+    int ret;
+    ovhip_tb_cmd *c;
+
+    if ((tu->cu_flags & CUF_BDPCM_LUMA) && (tu->tr_skip_mask & 0x10) && (tu->cbf_mask & 0x10)) return OVHIP_EUNSUP;
+    if ((tu->cu_flags & CUF_BDPCM_CHROMA) && (tu->tr_skip_mask & 0x3) && (tu->cbf_mask & 0xb)) return OVHIP_EUNSUP;
+
+    /* ---- luma (rcn_tu_st / rcn_tu_l) ---- */
+    if (tu->tree != 2 && (tu->cbf_mask & 0x10)) {
+        struct tb_args a;
+        memset(&a, 0, sizeof(a));
+        int is_intra = !!(tu->cu_flags & CUF_PRED_MODE_INTRA);
+        int is_mip = !!(tu->cu_flags & CUF_MIP) || !is_intra;
+        a.plane = 0; a.x = tu->x0; a.y = tu->y0; a.log2_w = tu->log2_tb_w; a.log2_h = tu->log2_tb_h;
+        a.is_luma = 1;
+        a.tr_skip = !!(tu->tr_skip_mask & 0x10);
+        a.qp = st->qp_y; a.qp_skip = st->qp_y_skip;
+        a.lfnst_flag = tu->lfnst_flag; a.lfnst_idx = tu->lfnst_idx;
+        a.lfnst_mode_idx = lfnst_mode_luma(tu->log2_tb_w, tu->log2_tb_h, is_mip ? 0 : st->intra_mode);
+        a.cu_mts_flag = tu->cu_mts_flag; a.cu_mts_idx = tu->cu_mts_idx;
+        a.implicit_mts_ok = !is_mip && st->mts_implicit;
+        a.last_pos = tu->last_pos[2]; a.sig_sb_map = tu->sig_sb_map[2]; a.coef = tu->coef[2];
+        if ((ret = emit_tb(r, st, &a, &c))) goto fail;
+        c->res_mode = OVHIP_RES_ADD;
+    }
+
+    /* ---- chroma ---- */
+    if (tu->tree != 1 && (tu->cbf_mask & 0xb)) {
+        int xc, yc, l2w, l2h, lfnst_flag;
+        if (tu->tree == 2) { xc = tu->x0; yc = tu->y0; l2w = tu->log2_tb_w; l2h = tu->log2_tb_h; lfnst_flag = tu->lfnst_flag; }
+        else { xc = tu->x0 >> 1; yc = tu->y0 >> 1; l2w = tu->log2_tb_w - 1; l2h = tu->log2_tb_h - 1; lfnst_flag = 0; }
+        int cbf_c = tu->cbf_mask & 0x3;
+        int16_t scale = st->lmcs_scale_c ? st->lmcs_chroma_scale : (int16_t)(1 << 11);
+        struct tb_args a;
+        memset(&a, 0, sizeof(a));
+        a.x = xc; a.y = yc; a.log2_w = l2w; a.log2_h = l2h;
+        a.lfnst_flag = lfnst_flag; a.lfnst_idx = tu->lfnst_idx; a.lfnst_mode_idx = st->lfnst_mode_c;
+
+        if (tu->cbf_mask & 0x8) {
+            /* joint CbCr: ONE residual (coded in the Cb slot), applied to both planes */
+            int first, second, k2;
+            a.tr_skip = !!(tu->tr_skip_mask & 0x1);
+            a.qp      = cbf_c == 3 ? st->qp_jcbcr : cbf_c == 1 ? st->qp_cr : st->qp_cb;
+            a.qp_skip = cbf_c == 3 ? st->qp_jcbcr_skip : cbf_c == 2 ? st->qp_cb_skip : st->qp_cr_skip;
+            a.last_pos = tu->last_pos[0]; a.sig_sb_map = tu->sig_sb_map[0]; a.coef = tu->coef[0];
+            if (cbf_c == 3)      { first = 1; second = 2; k2 = 1; }
+            else if (cbf_c == 2) { first = 1; second = 2; k2 = 2; }
+            else                 { first = 2; second = 1; k2 = 2; }
+            a.plane = first;
+            if ((ret = emit_tb(r, st, &a, &c))) goto fail;
+            c->c_scale   = (l2w + l2h == 2) ? (int16_t)(1 << 11) : scale;
+            c->res_mode  = ict_mode(st->ict_type, 0);
+            c->plane2    = (uint8_t)second;
+            c->res_mode2 = ict_mode(st->ict_type, k2);
+        } else {
+            for (int comp = 0; comp < 2; ++comp) {      /* 0: Cb (cbf 0x2), 1: Cr (cbf 0x1) */
+                int bit = comp ? 0x1 : 0x2;
+                if (!(cbf_c & bit)) continue;
+                a.plane = 1 + comp;
+                a.tr_skip = !!(tu->tr_skip_mask & bit);
+                a.qp      = comp ? st->qp_cr : st->qp_cb;
+                a.qp_skip = comp ? st->qp_cr_skip : st->qp_cb_skip;
+                a.last_pos = tu->last_pos[comp]; a.sig_sb_map = tu->sig_sb_map[comp]; a.coef = tu->coef[comp];
+                if ((ret = emit_tb(r, st, &a, &c))) goto fail;
+                if (l2w + l2h > 2) { c->res_mode = ict_mode(st->ict_type, 0); c->c_scale = scale; }
+                else               { c->res_mode = OVHIP_RES_ADD; }
+            }
+        }
+    }
+    return (int)(r->n_tb - n0);
+fail:
+    r->n_tb = n0;
+    return ret;
+}
+
+/* ---------------------------------------------------------------- prediction units */
+static int32_t clip3(int32_t v, int32_t lo, int32_t hi) { return v < lo ? lo : v > hi ? hi : v; }
+
+int
+ovhip_rec_pu(ovhip_recorder *r, const ovhip_pu_desc *pu)
+{
+    int pw = 1 << pu->log2_w, ph = 1 << pu->log2_h;
+    int dir = pu->inter_dir & 3;
+    if (!dir) return OVHIP_EINVAL;
+
+    /* rcn_mcp_b: bi with identical motion degenerates to uni-pred from list 1 */
+    if (dir == 3 && pu->poc0 == pu->poc1 && pu->mv0x == pu->mv1x && pu->mv0y == pu->mv1y) dir = 2;
+    else if (dir != 3 && (dir & 2)) dir = 2;
+
+    /* clip_mv(): keeps the reference window within [-(pb+3), pic+2] of the PU position */
+    int32_t x_max = (r->pic_w + 2 - pu->x0) << 4, y_max = (r->pic_h + 2 - pu->y0) << 4;
+    int32_t x_min = -((pw + 3 + pu->x0) << 4),    y_min = -((ph + 3 + pu->y0) << 4);
+    int32_t mv0x = clip3(pu->mv0x, x_min, x_max), mv0y = clip3(pu->mv0y, y_min, y_max);
+    int32_t mv1x = clip3(pu->mv1x, x_min, x_max), mv1y = clip3(pu->mv1y, y_min, y_max);
+
+    int8_t w0 = 4, w1 = 4;
+    if (dir == 3 && pu->bcw_idx_plus1 != 0 && pu->bcw_idx_plus1 != 3) {
+        static const int8_t bcw[5] = { -2, 3, 4, 5, 10 };
+        if (pu->bcw_idx_plus1 > 5) return OVHIP_EINVAL;
+        w1 = bcw[pu->bcw_idx_plus1 - 1];
+        w0 = (int8_t)(8 - w1);
+    }
+
+    uint8_t flags = 0;
+    if (pu->prec_amvr_half) flags |= OVHIP_MC_HPEL_FILT;
+    if (pw == 4 && ph == 4) flags |= OVHIP_MC_FILT_4x4;
+    if (!(pu->planes & 1))  flags |= OVHIP_MC_NO_LUMA;
+    if (!(pu->planes & 2))  flags |= OVHIP_MC_NO_CHROMA;
+    if (pu->lmcs)           flags |= OVHIP_MC_LMCS;
+
+    int uw = pw > 16 ? 16 : pw, uh = ph > 16 ? 16 : ph;
+    int nu = (pw / uw) * (ph / uh);
+    if (grow((void **)&r->mc, &r->cap_mc, r->n_mc + (size_t)nu, sizeof(ovhip_mc_unit))) return OVHIP_ENOMEM;
+    for (int uy = 0; uy < ph; uy += uh) {
+        for (int ux = 0; ux < pw; ux += uw) {
+            ovhip_mc_unit *u = &r->mc[r->n_mc++];
+            memset(u, 0, sizeof(*u));
+            u->x = (uint16_t)(pu->x0 + ux); u->y = (uint16_t)(pu->y0 + uy);
+            u->w = (uint8_t)uw; u->h = (uint8_t)uh;
+            u->dir = (uint8_t)dir; u->flags = flags;
+            u->ref0 = pu->ref0; u->ref1 = pu->ref1;
+            u->w0 = w0; u->w1 = w1;
+            u->mv0x = mv0x; u->mv0y = mv0y; u->mv1x = mv1x; u->mv1y = mv1y;
+        }
+    }
+    return nu;
+}

@@ -1,0 +1,368 @@
+/* gen_golden.c -- TEST INFRASTRUCTURE (this container only).
+ *
+ * Drives the COMPILED REFERENCE (oracle/_ref/libovvcref.so, built from /root/reference where it
+ * lies) through its own orchestrator slots on seeded inputs and writes small golden fixtures
+ * to tests/golden/*.ovg.  The inputs are stored in the vocabulary of include/ovvc_hip.h
+ * (ovhip_tu_state / ovhip_tu_desc / ovhip_pu_desc = what the slots receive), the expected
+ * outputs are the bytes the reference produced.  Nothing from the reference is copied; the
+ * reference does not travel to the GPU box, the fixtures do.
+ *
+ *   itx.ovg : tmp.rcn_tu_st / tmp.rcn_tu_c  (rcn_transform_tree.c:1228-1382)  -> K1..K4
+ *   mc.ovg  : rcn_mcp_b / rcn_mcp_b_l / rcn_mcp_b_c (rcn_inter.c:2769-2966)   -> K5, K6, K11
+ */
+#include "ref_common.h"
+#include "ovvc_hip.h"
+
+/* struct TUInfo is private to rcn_transform_tree.c:51-66 (and duplicated in
+ * vcl_transform_unit.c:47-75); the slot signature only forward-declares it. */
+struct TBInfo { uint16_t last_pos; uint64_t sig_sb_map; };
+struct TUInfo {
+    uint8_t is_sbt; uint8_t cbf_mask; uint16_t pos_offset; uint8_t tr_skip_mask;
+    uint8_t cu_mts_flag; uint8_t cu_mts_idx; uint8_t lfnst_flag; uint8_t lfnst_idx;
+    struct TBInfo tb_info[3];
+};
+
+extern uint64_t residual_coding_dpq(OVCTUDec *const, int16_t *const, uint8_t, uint8_t, uint16_t);
+
+static void stub_intra_pred_c(const struct OVRCNCtx *const r, uint8_t m, int x0, int y0, int lw, int lh, CUFlags f)
+{ (void)r; (void)m; (void)x0; (void)y0; (void)lw; (void)lh; (void)f; }
+
+static int16_t rnd_coef(void)
+{
+    int k = rnd_range(0, 15);
+    if (k < 9)  return (int16_t)rnd_range(-24, 24);
+    if (k < 13) return (int16_t)rnd_range(-900, 900);
+    if (k < 15) return (int16_t)rnd_range(-32768, 32767);
+    return (int16_t)(rnd_range(0, 1) ? 32767 : -32768);
+}
+
+/* fill one TB worth of coefficients in the reference layout; returns number of int16 used */
+static int
+make_coefs(int16_t *dst, int log2_w, int log2_h, int pattern, int raster, uint64_t *map, uint16_t *last_pos)
+{
+    int w = 1 << log2_w, h = 1 << log2_h;
+    if (raster) {
+        int n = w * h;
+        memset(dst, 0, n * 2);
+        if (pattern == 0) { dst[0] = rnd_coef(); *last_pos = 0; }
+        else { for (int i = 0; i < n; ++i) if (pattern == 2 || rnd_range(0, 2) == 0) dst[i] = rnd_coef(); *last_pos = 0x0101; }
+        *map = 1;
+        return n;
+    }
+    int cw = w > 32 ? 32 : w, ch = h > 32 ? 32 : h;
+    int nx = cw / 4, ny = ch / 4;
+    memset(dst, 0, cw * ch * 2);
+    *map = 0;
+    if (pattern == 0) {
+        dst[0] = rnd_coef();
+        if (!dst[0]) dst[0] = 7;
+        *last_pos = 0;
+        *map = rnd_range(0, 1);
+        return cw * ch;
+    }
+    int lim_x = pattern == 2 ? nx : rnd_range(1, nx), lim_y = pattern == 2 ? ny : rnd_range(1, ny);
+    for (int sy = 0; sy < lim_y; ++sy) {
+        for (int sx = 0; sx < lim_x; ++sx) {
+            if (pattern != 2 && (sx || sy) && rnd_range(0, 2) == 0) continue;
+            *map |= 1ull << (sy * 8 + sx);
+            int16_t *sb = dst + sy * 4 * cw + sx * 16;
+            for (int i = 0; i < 16; ++i) sb[i] = (pattern == 2 || rnd_range(0, 1)) ? rnd_coef() : 0;
+        }
+    }
+    *last_pos = 0x0302;
+    return cw * ch;
+}
+
+static void
+dump_rect(gbuf *exp, const uint16_t *p, int stride, int x, int y, int w, int h)
+{
+    for (int j = 0; j < h; ++j) gbuf_push(exp, p + (y + j) * stride + x, w);
+}
+
+/* derive_lfnst_mode_c (drv_lfnst.c:94-121) reads CTU-local luma mode maps; the shim performs
+ * this lookup at record time.  For the fixtures the chroma mode is an explicit angular mode. */
+static int shim_lfnst_mode_c(int log2_w, int log2_h, int mode)
+{
+    static const uint8_t ms_lut[6] = { 0, 6, 10, 12, 14, 15 };
+    if (mode > 1) {
+        int d = log2_w - log2_h; int ms = ms_lut[d < 0 ? -d : d];
+        if (log2_w > log2_h && mode < 2 + ms) mode += 65;
+        else if (log2_h > log2_w && mode > 66 - ms) mode -= 67;
+    }
+    return mode < 0 ? mode + 14 + 67 : mode >= 67 ? mode + 14 : mode;
+}
+
+static void
+gen_itx(const char *dir)
+{
+    static uint16_t pred_y[128 * 128], pred_cb[64 * 64], pred_cr[64 * 64];
+    gbuf b_state = { .type = T_U8 }, b_desc = { .type = T_U8 }, b_coff = { .type = T_U32 }, b_clen = { .type = T_U32 };
+    gbuf b_coefs = { .type = T_I16 }, b_eoff = { .type = T_U32 }, b_exp = { .type = T_U16 };
+    uint32_t n_cases = 0;
+    g_seed = 0x266;
+
+    fill_plane(pred_y, 128, 128, 128);
+    fill_plane(pred_cb, 64, 64, 64);
+    fill_plane(pred_cr, 64, 64, 64);
+    /* make clipping at both ends reachable */
+    for (int i = 0; i < 128 * 128; i += 37) pred_y[i] = (i & 1) ? 1023 : 0;
+    for (int i = 0; i < 64 * 64; i += 29) { pred_cb[i] = (i & 1) ? 1023 : 0; pred_cr[i] = (i & 1) ? 0 : 1023; }
+
+    OVCTUDec *c = ref_new_ctudec(0, 0);
+    c->rcn_funcs.intra_pred_c = stub_intra_pred_c;
+    const struct OVBuffInfo *cb = &c->rcn_ctx.ctu_buff;
+
+    for (int tree = 0; tree <= 2; tree += 2) {
+        int lmin = tree ? 1 : 2, lmax = tree ? 5 : 6;
+        for (int l2w = lmin; l2w <= lmax; ++l2w) {
+            for (int l2h = lmin; l2h <= lmax; ++l2h) {
+                int reps = tree ? 5 : 12;
+                for (int rep = 0; rep < reps; ++rep) {
+                    ovhip_tu_state st; ovhip_tu_desc d; struct TUInfo tu;
+                    memset(&st, 0, sizeof(st)); memset(&d, 0, sizeof(d)); memset(&tu, 0, sizeof(tu));
+                    int w = 1 << l2w, h = 1 << l2h;
+                    int unit = tree ? 2 : 4;
+                    int x0 = rnd_range(0, ((tree ? 64 : 128) - w) / unit) * unit;
+                    int y0 = rnd_range(0, ((tree ? 64 : 128) - h) / unit) * unit;
+                    /* chroma TB size seen by the chroma path */
+                    int cl2w = tree ? l2w : l2w - 1, cl2h = tree ? l2h : l2h - 1;
+
+                    st.qp_y = rnd_range(0, 75); st.qp_cb = rnd_range(0, 75); st.qp_cr = rnd_range(0, 75); st.qp_jcbcr = rnd_range(0, 75);
+                    st.qp_y_skip = st.qp_y < 16 ? 16 : st.qp_y; st.qp_cb_skip = st.qp_cb < 16 ? 16 : st.qp_cb;
+                    st.qp_cr_skip = st.qp_cr < 16 ? 16 : st.qp_cr; st.qp_jcbcr_skip = st.qp_jcbcr < 16 ? 16 : st.qp_jcbcr;
+                    st.dep_quant = rnd_range(0, 1);
+                    st.mts_implicit = rnd_range(0, 1);
+                    st.sh_ts_disabled = rnd_range(0, 1);
+                    st.ict_type = rnd_range(0, 3);
+                    st.lmcs_scale_c = rnd_range(0, 1);
+                    st.lmcs_chroma_scale = (int16_t)rnd_range(1200, 3400);
+                    st.intra_mode = (int8_t)rnd_range(0, 66);
+
+                    d.x0 = x0; d.y0 = y0; d.log2_tb_w = l2w; d.log2_tb_h = l2h; d.tree = tree;
+
+                    int variant = rep % 6;   /* 0 inter dct2, 1 implicit MTS intra, 2 explicit MTS, 3 LFNST, 4 TS, 5 inter */
+                    int max_l2 = l2w > l2h ? l2w : l2h;
+                    if (variant == 2 && (max_l2 > 5 || tree)) variant = 0;
+                    if (variant == 4 && max_l2 > 5) variant = 5;
+                    if (variant == 3 && tree && (l2w < 2 || l2h < 2)) variant = 0;
+                    if (variant == 1 || variant == 3) d.cu_flags |= 1u << 1;                  /* pred_mode_flag (intra) */
+                    if (variant == 2) { d.cu_mts_flag = 1; d.cu_mts_idx = rnd_range(0, 3); d.cu_flags |= (rnd_range(0, 1) << 1); }
+                    if (variant == 3) { d.lfnst_flag = 1; d.lfnst_idx = rnd_range(0, 1); }
+
+                    static const uint8_t cbf_st[8] = { 0x10, 0x12, 0x11, 0x13, 0x1b, 0x1a, 0x19, 0x0b };
+                    static const uint8_t cbf_c[6] = { 0x2, 0x1, 0x3, 0xb, 0xa, 0x9 };
+                    d.cbf_mask = tree ? cbf_c[rnd_range(0, 5)] : cbf_st[rnd_range(0, 7)];
+                    if (!tree && l2w + l2h < 6) d.cbf_mask &= 0x10;          /* no 2x2 / 2x4 chroma TBs in single tree */
+                    if (!d.cbf_mask) d.cbf_mask = 0x10;
+                    if (variant == 4) {
+                        d.tr_skip_mask = 0;
+                        if (d.cbf_mask & 0x10) d.tr_skip_mask |= 0x10;
+                        if (rnd_range(0, 1)) d.tr_skip_mask |= 0x3;
+                    }
+
+                    /* chroma LFNST only exists in the dual-tree chroma path */
+                    int c_mode = rnd_range(0, 66);
+                    st.lfnst_mode_c = (int8_t)shim_lfnst_mode_c(cl2w, cl2h, c_mode);
+
+                    /* ---- coefficients ---- */
+                    int16_t *res[3] = { c->residual_cb, c->residual_cr, c->residual_y };
+                    uint32_t off3[3] = { 0, 0, 0 }, len3[3] = { 0, 0, 0 };
+                    int pos_offset = rnd_range(0, 3) * 16;
+                    for (int comp = 0; comp < 3; ++comp) {
+                        int is_l = comp == 2;
+                        int used = is_l ? (d.cbf_mask & 0x10) && tree != 2
+                                        : (tree != 1) && ((d.cbf_mask & 0x8) ? comp == 0 : (d.cbf_mask & (comp ? 0x1 : 0x2)));
+                        if (!used) continue;
+                        int tl2w = is_l ? l2w : cl2w, tl2h = is_l ? l2h : cl2h;
+                        int ts = is_l ? !!(d.tr_skip_mask & 0x10)
+                                      : (d.cbf_mask & 0x8) ? !!(d.tr_skip_mask & 0x1) : !!(d.tr_skip_mask & (comp ? 0x1 : 0x2));
+                        int raster = (ts && !st.sh_ts_disabled) || tl2w < 2 || tl2h < 2;
+                        int pattern = variant == 3 ? 1 : rnd_range(0, 2);
+                        uint64_t map; uint16_t lp;
+                        int n = make_coefs(res[comp] + pos_offset, tl2w, tl2h, pattern, raster, &map, &lp);
+                        if (variant == 3) { map = 1; lp = 0x0101; }   /* LFNST: first sub-block only */
+                        if (variant == 3 && !raster) {
+                            int cw = (1 << tl2w) > 32 ? 32 : (1 << tl2w), ch = (1 << tl2h) > 32 ? 32 : (1 << tl2h);
+                            memset(res[comp] + pos_offset + 16, 0, (cw * ch - 16) * 2);
+                        }
+                        d.sig_sb_map[comp] = map; d.last_pos[comp] = lp;
+                        tu.tb_info[comp].sig_sb_map = map; tu.tb_info[comp].last_pos = lp;
+                        off3[comp] = (uint32_t)b_coefs.n; len3[comp] = (uint32_t)n;
+                        gbuf_push(&b_coefs, res[comp] + pos_offset, n);
+                    }
+
+                    /* ---- reference state ---- */
+                    rcn_init_ict_functions_10(&c->rcn_funcs, st.ict_type, 10);
+                    c->dequant_luma.qp = st.qp_y; c->dequant_cb.qp = st.qp_cb; c->dequant_cr.qp = st.qp_cr;
+                    c->dequant_joint_cb_cr.qp = st.qp_jcbcr;
+                    c->dequant_luma_skip.qp = st.qp_y_skip; c->dequant_cb_skip.qp = st.qp_cb_skip;
+                    c->dequant_cr_skip.qp = st.qp_cr_skip; c->dequant_jcbcr_skip.qp = st.qp_jcbcr_skip;
+                    c->residual_coding_l = st.dep_quant ? &residual_coding_dpq : NULL;
+                    c->mts_implicit = st.mts_implicit;
+                    c->sh_ts_disabled = st.sh_ts_disabled;
+                    c->lmcs_info.scale_c_flag = st.lmcs_scale_c;
+                    c->lmcs_info.lmcs_chroma_scale = (uint16_t)st.lmcs_chroma_scale;
+                    c->intra_mode = (uint8_t)st.intra_mode;
+                    c->intra_mode_c = (uint8_t)c_mode;
+                    c->qp_ctx.qp_bd_offset = 12;
+                    tu.cbf_mask = d.cbf_mask; tu.pos_offset = (uint16_t)pos_offset; tu.tr_skip_mask = d.tr_skip_mask;
+                    tu.cu_mts_flag = d.cu_mts_flag; tu.cu_mts_idx = d.cu_mts_idx;
+                    tu.lfnst_flag = d.lfnst_flag; tu.lfnst_idx = d.lfnst_idx;
+
+                    for (int j = 0; j < 128; ++j) memcpy(cb->y + j * cb->stride, pred_y + j * 128, 256);
+                    for (int j = 0; j < 64; ++j) {
+                        memcpy(cb->cb + j * cb->stride_c, pred_cb + j * 64, 128);
+                        memcpy(cb->cr + j * cb->stride_c, pred_cr + j * 64, 128);
+                    }
+                    memset(&c->dbf_info, 0, sizeof(c->dbf_info));
+
+                    if (tree == 0) c->rcn_funcs.tmp.rcn_tu_st(c, x0, y0, l2w, l2h, d.cu_flags, d.cbf_mask, &tu);
+                    else           c->rcn_funcs.tmp.rcn_tu_c(c, x0, y0, l2w, l2h, d.cu_flags, d.cbf_mask, &tu);
+
+                    uint32_t eoff[3] = { 0, 0, 0 };
+                    if (tree == 0) {
+                        eoff[0] = (uint32_t)b_exp.n; dump_rect(&b_exp, cb->y, cb->stride, x0, y0, w, h);
+                        eoff[1] = (uint32_t)b_exp.n; dump_rect(&b_exp, cb->cb, cb->stride_c, x0 >> 1, y0 >> 1, w >> 1, h >> 1);
+                        eoff[2] = (uint32_t)b_exp.n; dump_rect(&b_exp, cb->cr, cb->stride_c, x0 >> 1, y0 >> 1, w >> 1, h >> 1);
+                    } else {
+                        eoff[1] = (uint32_t)b_exp.n; dump_rect(&b_exp, cb->cb, cb->stride_c, x0, y0, w, h);
+                        eoff[2] = (uint32_t)b_exp.n; dump_rect(&b_exp, cb->cr, cb->stride_c, x0, y0, w, h);
+                    }
+                    gbuf_push(&b_state, &st, sizeof(st));
+                    gbuf_push(&b_desc, &d, sizeof(d));
+                    gbuf_push(&b_coff, off3, 3); gbuf_push(&b_clen, len3, 3); gbuf_push(&b_eoff, eoff, 3);
+                    n_cases++;
+                }
+            }
+        }
+    }
+
+    gfile g = gfile_open(dir, "itx.ovg");
+    uint32_t d2[2];
+    d2[0] = 128; d2[1] = 128; gfile_array(&g, "pred_y", T_U16, pred_y, 2, d2);
+    d2[0] = 64; d2[1] = 64;   gfile_array(&g, "pred_cb", T_U16, pred_cb, 2, d2);
+    gfile_array(&g, "pred_cr", T_U16, pred_cr, 2, d2);
+    d2[0] = n_cases; d2[1] = sizeof(ovhip_tu_state); gfile_array(&g, "state", T_U8, b_state.data, 2, d2);
+    d2[1] = sizeof(ovhip_tu_desc); gfile_array(&g, "desc", T_U8, b_desc.data, 2, d2);
+    d2[1] = 3; gfile_array(&g, "coef_off", T_U32, b_coff.data, 2, d2);
+    gfile_array(&g, "coef_len", T_U32, b_clen.data, 2, d2);
+    gfile_array(&g, "exp_off", T_U32, b_eoff.data, 2, d2);
+    gfile_buf(&g, "coefs", &b_coefs);
+    gfile_buf(&g, "exp", &b_exp);
+    gfile_close(&g);
+    fprintf(stderr, "itx.ovg: %u cases, %zu coef int16, %zu expected samples\n", n_cases, b_coefs.n, b_exp.n);
+}
+
+/* ====================================================================================== MC */
+#define MC_W 208
+#define MC_H 120
+
+static void
+gen_mc(const char *dir)
+{
+    gbuf b_desc = { .type = T_U8 }, b_eoff = { .type = T_U32 }, b_exp = { .type = T_U16 };
+    uint32_t n_cases = 0;
+    g_seed = 0x266 + 1;
+
+    OVCTUDec *c = ref_new_ctudec(0, 0);
+    struct InterDRVCtx *ic = &c->drv_ctx.inter_ctx;
+    OVPicture *ref[3];
+    for (int i = 0; i < 3; ++i) {
+        ref[i] = ref_new_picture(MC_W, MC_H, 8 * (i + 1));
+        fill_plane(ref[i]->frame->data[0], MC_W, MC_H, MC_W);
+        fill_plane(ref[i]->frame->data[1], MC_W / 2, MC_H / 2, MC_W / 2);
+        fill_plane(ref[i]->frame->data[2], MC_W / 2, MC_H / 2, MC_W / 2);
+    }
+    /* rpl0 = {ref0, ref1}, rpl1 = {ref2, ref0}: rpl0[0] and rpl1[1] are the SAME picture (identical-motion path) */
+    ic->rpl0[0] = ref[0]; ic->rpl0[1] = ref[1]; ic->rpl1[0] = ref[2]; ic->rpl1[1] = ref[0];
+    static const uint8_t slot0[2] = { 0, 1 }, slot1[2] = { 2, 0 };
+    for (int i = 0; i < 16; ++i) {
+        ic->scale_fact_rpl0[i][0] = ic->scale_fact_rpl0[i][1] = 1 << RPR_SCALE_BITS;
+        ic->scale_fact_rpl1[i][0] = ic->scale_fact_rpl1[i][1] = 1 << RPR_SCALE_BITS;
+    }
+    const struct OVBuffInfo *cb = &c->rcn_ctx.ctu_buff;
+
+    for (int l2w = 2; l2w <= 7; ++l2w) {
+        for (int l2h = 2; l2h <= 7; ++l2h) {
+            int w = 1 << l2w, h = 1 << l2h;
+            if (w > MC_W || h > MC_H) continue;
+            int reps = (w * h <= 256) ? 40 : (w * h <= 1024 ? 14 : 4);
+            for (int rep = 0; rep < reps; ++rep) {
+                ovhip_pu_desc d;
+                memset(&d, 0, sizeof(d));
+                /* position: anywhere on the 4-grid such that the PU is inside the picture and one CTU */
+                int px, py;
+                do {
+                    px = rnd_range(0, (MC_W - w) / 4) * 4;
+                    py = rnd_range(0, (MC_H - h) / 4) * 4;
+                } while ((px >> 7) != ((px + w - 1) >> 7) || (py >> 7) != ((py + h - 1) >> 7));
+                d.x0 = px; d.y0 = py; d.log2_w = l2w; d.log2_h = l2h;
+                d.inter_dir = rnd_range(1, 3);
+                d.ref_idx0 = rnd_range(0, 1); d.ref_idx1 = rnd_range(0, 1);
+                int range = rep % 4 == 0 ? 4000 : (rep % 4 == 1 ? 64 : 600);   /* far outside / tiny / normal, 1/16 pel */
+                d.mv0x = rnd_range(-range, range); d.mv0y = rnd_range(-range, range);
+                d.mv1x = rnd_range(-range, range); d.mv1y = rnd_range(-range, range);
+                if (rep % 7 == 3) { d.mv0x &= ~15; d.mv1y &= ~15; }            /* H-only / V-only / copy paths */
+                if (rep % 7 == 5) { d.mv0x &= ~15; d.mv0y &= ~15; d.mv1x &= ~15; }
+                if (rep % 9 == 4) { d.inter_dir = 3; d.ref_idx0 = 0; d.ref_idx1 = 1; d.mv1x = d.mv0x; d.mv1y = d.mv0y; } /* identical motion */
+                d.prec_amvr_half = rep % 5 == 2;
+                if (d.prec_amvr_half) { d.mv0x = (d.mv0x & ~15) | 8; d.mv1y = (d.mv1y & ~15) | 8; }
+                if (w == 4 && h == 4) d.prec_amvr_half = 0;
+                d.bcw_idx_plus1 = (rep % 3 == 1) ? rnd_range(1, 5) : 0;
+                d.planes = rep % 11 == 7 ? 1 : (rep % 11 == 9 ? 2 : 3);
+                d.poc0 = ic->rpl0[d.ref_idx0]->poc; d.poc1 = ic->rpl1[d.ref_idx1]->poc;
+                d.ref0 = slot0[d.ref_idx0]; d.ref1 = slot1[d.ref_idx1];
+
+                c->ctb_x = px >> 7; c->ctb_y = py >> 7;
+                int x0 = px & 127, y0 = py & 127;
+                ic->prec_amvr = d.prec_amvr_half ? MV_PRECISION_HALF : 0;
+                OVMV mv0 = { .x = d.mv0x, .y = d.mv0y, .ref_idx = d.ref_idx0, .bcw_idx_plus1 = d.bcw_idx_plus1 };
+                OVMV mv1 = { .x = d.mv1x, .y = d.mv1y, .ref_idx = d.ref_idx1, .bcw_idx_plus1 = d.bcw_idx_plus1 };
+                for (int j = 0; j < 128; ++j) memset(cb->y + j * cb->stride, 0xAB, 256);
+                for (int j = 0; j < 64; ++j) { memset(cb->cb + j * cb->stride_c, 0xAB, 128); memset(cb->cr + j * cb->stride_c, 0xAB, 128); }
+
+                if (d.planes == 3)
+                    c->rcn_funcs.rcn_mcp_b(c, *cb, ic, c->part_ctx, mv0, mv1, x0, y0, l2w, l2h, d.inter_dir, d.ref_idx0, d.ref_idx1);
+                else if (d.planes == 1)
+                    c->rcn_funcs.rcn_mcp_b_l(c, *cb, ic, c->part_ctx, mv0, mv1, x0, y0, l2w, l2h, d.inter_dir, d.ref_idx0, d.ref_idx1);
+                else
+                    c->rcn_funcs.rcn_mcp_b_c(c, *cb, ic, c->part_ctx, mv0, mv1, x0, y0, l2w, l2h, d.inter_dir, d.ref_idx0, d.ref_idx1);
+
+                uint32_t eoff[3];
+                eoff[0] = (uint32_t)b_exp.n; dump_rect(&b_exp, cb->y, cb->stride, x0, y0, w, h);
+                eoff[1] = (uint32_t)b_exp.n; dump_rect(&b_exp, cb->cb, cb->stride_c, x0 >> 1, y0 >> 1, w >> 1, h >> 1);
+                eoff[2] = (uint32_t)b_exp.n; dump_rect(&b_exp, cb->cr, cb->stride_c, x0 >> 1, y0 >> 1, w >> 1, h >> 1);
+                gbuf_push(&b_desc, &d, sizeof(d));
+                gbuf_push(&b_eoff, eoff, 3);
+                n_cases++;
+            }
+        }
+    }
+
+    gfile g = gfile_open(dir, "mc.ovg");
+    uint32_t d3[3] = { 3, MC_H, MC_W };
+    uint16_t *all = malloc(3 * MC_W * MC_H * 2);
+    for (int i = 0; i < 3; ++i) memcpy(all + i * MC_W * MC_H, ref[i]->frame->data[0], MC_W * MC_H * 2);
+    gfile_array(&g, "ref_y", T_U16, all, 3, d3);
+    d3[1] = MC_H / 2; d3[2] = MC_W / 2;
+    for (int i = 0; i < 3; ++i) memcpy(all + i * (MC_W / 2) * (MC_H / 2), ref[i]->frame->data[1], (MC_W / 2) * (MC_H / 2) * 2);
+    gfile_array(&g, "ref_cb", T_U16, all, 3, d3);
+    for (int i = 0; i < 3; ++i) memcpy(all + i * (MC_W / 2) * (MC_H / 2), ref[i]->frame->data[2], (MC_W / 2) * (MC_H / 2) * 2);
+    gfile_array(&g, "ref_cr", T_U16, all, 3, d3);
+    uint32_t d2[2] = { n_cases, sizeof(ovhip_pu_desc) };
+    gfile_array(&g, "desc", T_U8, b_desc.data, 2, d2);
+    d2[1] = 3; gfile_array(&g, "exp_off", T_U32, b_eoff.data, 2, d2);
+    gfile_buf(&g, "exp", &b_exp);
+    gfile_close(&g);
+    fprintf(stderr, "mc.ovg: %u cases, %zu expected samples\n", n_cases, b_exp.n);
+}
+
+int
+main(int argc, char **argv)
+{
+    const char *dir = argc > 1 ? argv[1] : "../tests/golden";
+    const char *only = argc > 2 ? argv[2] : NULL;
+    if (!only || !strcmp(only, "itx")) gen_itx(dir);
+    if (!only || !strcmp(only, "mc"))  gen_mc(dir);
+    return 0;
+}

@@ -1,0 +1,64 @@
+"""Turn the golden fixtures (reference inputs/outputs) into recorded command buffers.
+
+Every case of a fixture is laid out on its own 128-row band of one tall picture so that a whole
+fixture is ONE oracle call / ONE kernel launch."""
+import ctypes as C
+
+import numpy as np
+
+import golden_io
+from openvvc_amd import capi
+from oracle_lib import HostPic
+
+BAND = 128
+
+
+def itx_cases():
+    g = golden_io.load("itx.ovg")
+    n = g["desc"].shape[0]
+    pic = HostPic(128, BAND * n,
+                  np.tile(g["pred_y"], (n, 1)), np.tile(g["pred_cb"], (n, 1)), np.tile(g["pred_cr"], (n, 1)))
+    rec = capi.Recorder(128, BAND * n)
+    coefs = np.ascontiguousarray(g["coefs"])
+    rects = []       # (plane, x, y, w, h, expected_flat_offset)
+    for i in range(n):
+        st = capi.TuState.from_buffer_copy(g["state"][i].tobytes())
+        d = capi.TuDesc.from_buffer_copy(g["desc"][i].tobytes())
+        tree = d.tree
+        x0, y0, w, h = d.x0, d.y0, 1 << d.log2_tb_w, 1 << d.log2_tb_h
+        d.y0 = y0 + i * (BAND // 2 if tree == 2 else BAND)
+        for comp in range(3):
+            ln = int(g["coef_len"][i, comp])
+            d.coef[comp] = coefs[int(g["coef_off"][i, comp]):].ctypes.data if ln else None
+        rec.tu(st, d)
+        eo = g["exp_off"][i]
+        if tree == 0:
+            rects.append((0, x0, y0 + i * BAND, w, h, int(eo[0])))
+            rects.append((1, x0 >> 1, (y0 >> 1) + i * (BAND // 2), w >> 1, h >> 1, int(eo[1])))
+            rects.append((2, x0 >> 1, (y0 >> 1) + i * (BAND // 2), w >> 1, h >> 1, int(eo[2])))
+        else:
+            rects.append((1, x0, y0 + i * (BAND // 2), w, h, int(eo[1])))
+            rects.append((2, x0, y0 + i * (BAND // 2), w, h, int(eo[2])))
+    return pic, rec.tb_cmds(), rec.coefs(), rects, g["exp"]
+
+
+def mc_cases():
+    g = golden_io.load("mc.ovg")
+    n = g["desc"].shape[0]
+    _, rh, rw = g["ref_y"].shape
+    refs = [HostPic(rw, rh, g["ref_y"][k], g["ref_cb"][k], g["ref_cr"][k]) for k in range(3)]
+    descs = [capi.PuDesc.from_buffer_copy(g["desc"][i].tobytes()) for i in range(n)]
+    return refs, descs, g["exp_off"], g["exp"]
+
+
+def check_rects(pic: HostPic, rects, exp, what=""):
+    planes = pic.planes()
+    bad = []
+    for k, (p, x, y, w, h, off) in enumerate(rects):
+        if w == 0 or h == 0:
+            continue
+        got = planes[p][y:y + h, x:x + w]
+        want = exp[off:off + w * h].reshape(h, w)
+        if not np.array_equal(got, want):
+            bad.append((k, p, x, y, w, h, int(np.abs(got.astype(int) - want.astype(int)).max())))
+    assert not bad, f"{what}: {len(bad)} / {len(rects)} rectangles differ, first: {bad[:5]}"

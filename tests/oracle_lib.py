@@ -1,0 +1,71 @@
+"""TEST INFRASTRUCTURE: ctypes access to oracle/liboracle.so (the CPU restatement).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this."""
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+LIB = ROOT / "oracle" / "liboracle.so"
+
+
+class OPic(C.Structure):
+    _fields_ = [("y", C.c_void_p), ("cb", C.c_void_p), ("cr", C.c_void_p),
+                ("w", C.c_int32), ("h", C.c_int32), ("stride_y", C.c_int32), ("stride_c", C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not LIB.exists():
+            subprocess.check_call(["make", "-C", str(ROOT / "oracle"), "liboracle.so"])
+        _lib = C.CDLL(str(LIB))
+        vp = C.c_void_p
+        _lib.oracle_itx.argtypes = [C.POINTER(OPic), vp, C.c_uint32, vp]
+        _lib.oracle_itx.restype = None
+        _lib.oracle_mc.argtypes = [C.POINTER(OPic), C.POINTER(OPic), C.c_uint32, vp, C.c_uint32, vp]
+        _lib.oracle_mc.restype = None
+    return _lib
+
+
+class HostPic:
+    """Three contiguous uint16 planes in host memory + the struct the oracle takes."""
+
+    def __init__(self, w, h, y=None, cb=None, cr=None):
+        self.w, self.h = w, h
+        self.y = np.ascontiguousarray(y if y is not None else np.zeros((h, w), np.uint16), dtype=np.uint16)
+        self.cb = np.ascontiguousarray(cb if cb is not None else np.zeros((h // 2, w // 2), np.uint16), dtype=np.uint16)
+        self.cr = np.ascontiguousarray(cr if cr is not None else np.zeros((h // 2, w // 2), np.uint16), dtype=np.uint16)
+        assert self.y.shape == (h, w) and self.cb.shape == (h // 2, w // 2) and self.cr.shape == (h // 2, w // 2)
+
+    def struct(self):
+        return OPic(self.y.ctypes.data, self.cb.ctypes.data, self.cr.ctypes.data, self.w, self.h, self.w, self.w // 2)
+
+    def copy(self):
+        return HostPic(self.w, self.h, self.y.copy(), self.cb.copy(), self.cr.copy())
+
+    def planes(self):
+        return [self.y, self.cb, self.cr]
+
+
+def itx(pic: HostPic, cmds: np.ndarray, coefs: np.ndarray):
+    s = pic.struct()
+    cmds = np.ascontiguousarray(cmds)
+    coefs = np.ascontiguousarray(coefs, dtype=np.int16)
+    lib().oracle_itx(C.byref(s), cmds.ctypes.data, len(cmds), coefs.ctypes.data)
+
+
+def mc(dst: HostPic, refs, units: np.ndarray, lmcs_fwd=None):
+    s = dst.struct()
+    arr = (OPic * len(refs))(*[r.struct() for r in refs])
+    units = np.ascontiguousarray(units)
+    lut = None
+    if lmcs_fwd is not None:
+        lmcs_fwd = np.ascontiguousarray(lmcs_fwd, dtype=np.uint16)
+        lut = lmcs_fwd.ctypes.data
+    lib().oracle_mc(C.byref(s), arr, len(refs), units.ctypes.data, len(units), lut)

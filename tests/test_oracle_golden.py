@@ -1,0 +1,33 @@
+"""CPU: the oracle restatement + the host recorder reproduce the compiled reference bit-exactly
+on the committed golden fixtures (tests/golden/*.ovg, made by oracle/ref_harness/gen_golden.c from
+the reference's own rcn_tu_st / rcn_tu_c / rcn_mcp_b* slots)."""
+import numpy as np
+
+import golden_cases
+import oracle_lib
+from oracle_lib import HostPic
+from openvvc_amd import capi
+
+
+def test_itx_oracle_matches_reference(built_lib):
+    pic, cmds, coefs, rects, exp = golden_cases.itx_cases()
+    assert len(cmds) > 400
+    oracle_lib.itx(pic, cmds, coefs)
+    golden_cases.check_rects(pic, rects, exp, "itx oracle vs reference")
+
+
+def test_mc_oracle_matches_reference(built_lib):
+    refs, descs, exp_off, exp = golden_cases.mc_cases()
+    rw, rh = refs[0].w, refs[0].h
+    rec = capi.Recorder(rw, rh)
+    for i, d in enumerate(descs):
+        rec.reset()
+        rec.pu(d)
+        dst = HostPic(rw, rh)
+        dst.y[:] = 0xABAB; dst.cb[:] = 0xABAB; dst.cr[:] = 0xABAB
+        oracle_lib.mc(dst, refs, rec.mc_units())
+        w, h = 1 << d.log2_w, 1 << d.log2_h
+        rects = [(0, d.x0, d.y0, w, h, int(exp_off[i, 0])),
+                 (1, d.x0 >> 1, d.y0 >> 1, w >> 1, h >> 1, int(exp_off[i, 1])),
+                 (2, d.x0 >> 1, d.y0 >> 1, w >> 1, h >> 1, int(exp_off[i, 2]))]
+        golden_cases.check_rects(dst, rects, exp, f"mc case {i} dir={d.inter_dir} planes={d.planes}")
