@@ -1,0 +1,190 @@
+#!/usr/bin/env python
+"""bench.py -- decoded frames/s of the MI355X rcn back-end on one synthetic recorded picture.
+
+A "step" is one pass of the whole implemented hot path (prediction -> residual -> in-loop filters,
+one frame-wide HIP launch per stage) over one 3840x2160 10-bit 4:2:0 recorded inter picture
+(BASELINE.json configs[3]) whose reference pictures, command buffers and coefficient arena are
+already resident in HBM.  N > 1: one process per GPU, every rank decodes its own picture (frame
+sharding, `--framethr` style, weak scaling); after each step the rank pushes its reconstructed
+picture to the next rank over RCCL point-to-point, where it becomes a reference picture of the
+next step (the reference-picture exchange of SURVEY.md 8e) -- no collective on the data path.
+
+Prints ONE JSON line on rank 0 (contract in the task statement).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--seed", type=int, default=0x266)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from openvvc_amd import capi, engine, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    W, H = args.width, args.height
+    wl = synth.make_workload(W, H, args.seed + rank)
+    S = wl.frame_bytes
+
+    # the engine runs on a torch-owned stream made current, so that torch.cuda.Event brackets its
+    # kernels and RCCL point-to-point ops order against them (a NULL stream handle would make the
+    # engine create a private stream the events cannot see)
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream, "expected a non-default HIP stream"
+    ctx = engine.Context(local_rank, stream=stream.cuda_stream)
+
+    def torch_pic(planes=None):
+        """A picture stored in torch int16 tensors (so RCCL can move it), viewed as ovhip_pic."""
+        t = torch.empty(H * W * 3 // 2, dtype=torch.int16, device=dev)
+        ysz, csz = H * W, (H // 2) * (W // 2)
+        s = capi.Pic(t.data_ptr(), t.data_ptr() + 2 * ysz, t.data_ptr() + 2 * (ysz + csz), W, H, W, W // 2)
+        p = engine.DevPic(ctx, s, owns=False)
+        if planes is not None:
+            p.upload(*planes)
+        return t, p
+
+    ref_t, refs = zip(*[torch_pic(r) for r in wl.refs])
+    refs = list(refs)
+    dst_t, dst = torch_pic()
+    spare_t, spare = torch_pic(wl.refs[1])          # receive buffer for the exchanged reference picture
+    mc_units = ctx.upload(wl.mc_units)
+    tb_cmds = ctx.upload(wl.tb_cmds)
+    coefs = ctx.upload(wl.coefs)
+
+    stages = ["mc", "itx"]
+    evs = {k: [] for k in stages}
+
+    def step(timed):
+        nonlocal refs, spare, spare_t, ref_t
+        for name in stages:
+            if timed:
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+            if name == "mc":
+                ctx.mc(dst, refs, mc_units)
+            elif name == "itx":
+                ctx.itx(dst, tb_cmds, coefs)
+            if timed:
+                e1.record(stream)
+                evs[name].append((e0, e1))
+        if world > 1:
+            # push the reconstructed picture to the rank that lists it as a reference (ring), receive
+            # ours into the spare buffer, then swap it in as reference 1 of the next step
+            ops = [dist.P2POp(dist.isend, dst_t, (rank + 1) % world),
+                   dist.P2POp(dist.irecv, spare_t, (rank - 1) % world)]
+            for w_ in dist.batch_isend_irecv(ops):
+                w_.wait()
+            ref_list_t = list(ref_t)
+            ref_list_t[1], spare_t = spare_t, ref_list_t[1]
+            ref_t = tuple(ref_list_t)
+            refs[1], spare = spare, refs[1]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    ms_per_step = dt * 1e3 / args.steps
+    fps = world * args.steps / dt
+
+    if rank == 0:
+        # ---- per-kernel average launch duration (HIP events on the launch stream, timed region) ----
+        kdur = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) * 1e-3 for k, v in evs.items()}
+        st = wl.stats
+        u = wl.mc_units
+        tb = wl.tb_cmds
+        tb_samples = int((1 << (tb["log2_w"].astype(np.int64) + tb["log2_h"])).sum()
+                         + (1 << (tb["log2_w"].astype(np.int64) + tb["log2_h"]))[tb["plane2"] != 0xff].sum())
+        # algorithmic bytes per launch (DESIGN.md "Measurement"): SURVEY 8d terms split per kernel
+        alg = {
+            "mc": st["r_bar"] * S + S + u.nbytes,                 # r*S reference reads + S prediction writes + units
+            "itx": wl.coefs.nbytes + tb.nbytes + 2 * 2 * tb_samples,  # coefficients + commands + RMW of covered samples
+        }
+        dom = max(kdur, key=kdur.get)
+        achieved = alg[dom] / kdur[dom] / 1e9
+        roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                    "avg_launch_us": {k: round(v * 1e6, 2) for k, v in kdur.items()},
+                    "algorithmic_bytes": {k: int(v) for k, v in alg.items()}}
+
+        cpu = None
+        if not args.no_cpu_baseline:
+            import oracle_pipeline
+            reps, tc = 0, 0.0
+            while tc < 10.0 and reps < 64:                     # ~10 s of scalar CPU work
+                t1 = time.perf_counter()
+                oracle_pipeline.decode(wl)
+                tc += time.perf_counter() - t1
+                reps += 1
+            cpu = {"value": round(reps / tc, 4), "unit": "frames/s", "cores": 1, "kind": "port",
+                   "sample": f"oracle/liboracle.so (scalar C restatement, 1 thread) decoding the same {W}x{H} "
+                             f"recorded picture {reps}x in {tc:.2f} s on this box's host CPU "
+                             f"({os.cpu_count()} logical cores present)"}
+
+        out = {
+            "metric": "decoded frames/sec, rcn back-end (MC + inverse transform"
+                      + "), 4K 10-bit RA recorded picture, bit-exact vs oracle",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u16 samples / int16 coefficients / int32 accumulate", "data": "synthetic",
+            "config": {"workload": f"{W}x{H} 10-bit 4:2:0 synthetic recorded inter picture (BASELINE configs[3]), "
+                                   f"seed {hex(args.seed)}, stages {'+'.join(stages)}",
+                       "n_cu": st["n_cu"], "n_mc_units": st["n_mc_units"], "n_tb_cmds": st["n_tb_cmds"],
+                       "r_bar": round(st["r_bar"], 3), "coef_bytes": st["coef_bytes"],
+                       "parallelism": f"frames x{world}" + (" + RCCL p2p reference exchange" if world > 1 else "")},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

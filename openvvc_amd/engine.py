@@ -1,0 +1,150 @@
+"""Python host harness over the device engine (ovhip_ctx_* / ovhip_*_launch).
+
+Plumbing only: device buffers, picture upload/download and stage launches all go through the
+C ABI in libovvc_hip.so.  There is no Python or CPU implementation of any stage here."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class Context:
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self.lib = capi.load()
+        h = C.c_void_p()
+        r = self.lib.ovhip_ctx_create(C.byref(h), device, C.c_void_p(stream) if stream else None)
+        if r != 0:
+            raise EngineError(f"ovhip_ctx_create(device={device}) failed: {r} (no HIP device? the engine has no CPU fallback)")
+        self.h = h
+        self._bufs = []
+
+    def _chk(self, r, what):
+        if r != 0:
+            raise EngineError(f"{what}: {r}: {self.lib.ovhip_last_error(self.h).decode()}")
+
+    def sync(self):
+        self._chk(self.lib.ovhip_ctx_sync(self.h), "sync")
+
+    @property
+    def stream(self) -> int:
+        return self.lib.ovhip_ctx_stream(self.h) or 0
+
+    def close(self):
+        if self.h:
+            self.lib.ovhip_ctx_destroy(self.h)
+            self.h = None
+
+    # ---- raw buffers ----
+    def upload(self, arr: np.ndarray) -> "DevBuf":
+        arr = np.ascontiguousarray(arr)
+        p = C.c_void_p()
+        self._chk(self.lib.ovhip_malloc(self.h, arr.nbytes, C.byref(p)), "malloc")
+        if arr.nbytes:
+            self._chk(self.lib.ovhip_h2d(self.h, p, arr.ctypes.data, arr.nbytes), "h2d")
+            self.sync()
+        return DevBuf(self, p, arr.nbytes, len(arr))
+
+    # ---- pictures ----
+    def new_pic(self, w: int, h: int) -> "DevPic":
+        pic = capi.Pic()
+        self._chk(self.lib.ovhip_pic_alloc(self.h, w, h, C.byref(pic)), "pic_alloc")
+        return DevPic(self, pic, owns=True)
+
+    def upload_pic(self, y, cb, cr) -> "DevPic":
+        h, w = y.shape
+        p = self.new_pic(w, h)
+        p.upload(y, cb, cr)
+        return p
+
+    # ---- stages ----
+    def itx(self, dst: "DevPic", cmds: "DevBuf", coefs: "DevBuf", n: int | None = None):
+        n = cmds.count if n is None else n
+        self._chk(self.lib.ovhip_itx_launch(self.h, C.byref(dst.s), cmds.ptr, n, coefs.ptr), "itx_launch")
+
+    def mc(self, dst: "DevPic", refs: list, units: "DevBuf", lmcs_fwd: "DevBuf | None" = None, n: int | None = None):
+        n = units.count if n is None else n
+        arr = (capi.Pic * len(refs))(*[r.s for r in refs])
+        self._chk(self.lib.ovhip_mc_launch(self.h, C.byref(dst.s), arr, len(refs), units.ptr, n,
+                                           lmcs_fwd.ptr if lmcs_fwd else None), "mc_launch")
+
+
+class DevBuf:
+    def __init__(self, ctx: Context, ptr, nbytes: int, count: int):
+        self.ctx, self.ptr, self.nbytes, self.count = ctx, ptr, nbytes, count
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.ovhip_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+
+class DevPic:
+    def __init__(self, ctx: Context, s: capi.Pic, owns: bool):
+        self.ctx, self.s, self.owns = ctx, s, owns
+
+    @property
+    def w(self):
+        return self.s.w
+
+    @property
+    def h(self):
+        return self.s.h
+
+    def upload(self, y, cb, cr):
+        y, cb, cr = (np.ascontiguousarray(a, dtype=np.uint16) for a in (y, cb, cr))
+        self.ctx._chk(self.ctx.lib.ovhip_pic_upload(self.ctx.h, C.byref(self.s), y.ctypes.data, cb.ctypes.data,
+                                                    cr.ctypes.data, y.shape[1], cb.shape[1]), "pic_upload")
+
+    def download(self):
+        y = np.empty((self.h, self.w), np.uint16)
+        cb = np.empty((self.h // 2, self.w // 2), np.uint16)
+        cr = np.empty_like(cb)
+        self.ctx._chk(self.ctx.lib.ovhip_pic_download(self.ctx.h, C.byref(self.s), y.ctypes.data, cb.ctypes.data,
+                                                      cr.ctypes.data, self.w, self.w // 2), "pic_download")
+        return y, cb, cr
+
+    def band(self, y0: int, h: int) -> "DevPic":
+        """A view of rows [y0, y0+h) (luma) as its own picture (no copy)."""
+        s = capi.Pic(self.s.y + y0 * self.s.stride_y * 2, self.s.cb + (y0 // 2) * self.s.stride_c * 2,
+                     self.s.cr + (y0 // 2) * self.s.stride_c * 2, self.s.w, h, self.s.stride_y, self.s.stride_c)
+        return DevPic(self.ctx, s, owns=False)
+
+    def free(self):
+        if self.owns and self.s.y:
+            self.ctx.lib.ovhip_pic_free(self.ctx.h, C.byref(self.s))
+
+
+class ResidentPicture:
+    """A recorded picture resident in HBM: reference pictures, command buffers, coefficient arena and
+    the destination picture.  `decode()` enqueues every implemented stage of the rcn path in the
+    order the reference executes them per CTU (prediction -> residual -> in-loop filters), each as
+    one frame-wide launch on the context stream."""
+
+    def __init__(self, ctx: Context, wl):
+        self.ctx, self.wl = ctx, wl
+        self.refs = [ctx.upload_pic(*r) for r in wl.refs]
+        self.dst = ctx.new_pic(wl.w, wl.h)
+        self.mc_units = ctx.upload(wl.mc_units)
+        self.tb_cmds = ctx.upload(wl.tb_cmds)
+        self.coefs = ctx.upload(wl.coefs)
+
+    def decode(self):
+        self.ctx.mc(self.dst, self.refs, self.mc_units)
+        self.ctx.itx(self.dst, self.tb_cmds, self.coefs)
+
+    def result(self):
+        self.ctx.sync()
+        return self.dst.download()
+
+    def free(self):
+        for b in (self.mc_units, self.tb_cmds, self.coefs):
+            b.free()
+        for p in self.refs + [self.dst]:
+            p.free()

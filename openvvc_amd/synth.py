@@ -1,0 +1,238 @@
+"""Synthetic "recorded picture" generator: what the host side of the decoder
+(CABAC + drv) would hand to the rcn back-end for one inter picture, produced from a seed instead
+of a bitstream (no .266 stream exists in this environment).
+
+The generator speaks the reference's vocabulary -- coding units, prediction units with motion
+vectors in 1/16 pel, transform units with `struct TUInfo`-style flags and sub-block-major
+coefficient buffers -- and pushes every unit through the product's own host recorder
+(ovhip_rec_pu / ovhip_rec_tu), so benches and tests exercise the same host logic a shim would.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import capi
+
+DEFAULT_SEED = 0x266
+
+
+def smooth_plane(rs: np.random.RandomState, h: int, w: int) -> np.ndarray:
+    """Low-pass random 10-bit content (so filter decisions are non-degenerate) + a little noise."""
+    gh, gw = h // 16 + 2, w // 16 + 2
+    g = rs.randint(64, 960, size=(gh, gw)).astype(np.float32)
+    yy = np.linspace(0, gh - 1.001, h, dtype=np.float32)
+    xx = np.linspace(0, gw - 1.001, w, dtype=np.float32)
+    y0 = yy.astype(np.int32); x0 = xx.astype(np.int32)
+    fy = (yy - y0)[:, None]; fx = (xx - x0)[None, :]
+    a = g[y0][:, x0]; b = g[y0][:, x0 + 1]; c = g[y0 + 1][:, x0]; d = g[y0 + 1][:, x0 + 1]
+    p = (a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy
+    p += rs.randint(-12, 13, size=(h, w))
+    return np.clip(p, 0, 1023).astype(np.uint16)
+
+
+def random_picture(rs, w, h):
+    return smooth_plane(rs, h, w), smooth_plane(rs, h // 2, w // 2), smooth_plane(rs, h // 2, w // 2)
+
+
+def partition(rs: np.random.RandomState, pic_w: int, pic_h: int, ctu: int = 128, min_cu: int = 8):
+    """Random QT/BT partition of every CTU into CUs (x, y, log2w, log2h), RA-like size mix.
+    Blocks crossing the picture border are split until they fit (implicit split)."""
+    out = []
+    # split probability by max(log2w, log2h): favours 8..32 blocks like RA streams
+    p_split = {7: 0.93, 6: 0.82, 5: 0.62, 4: 0.38, 3: 0.0}
+
+    def rec(x, y, w, h):
+        if x >= pic_w or y >= pic_h:
+            return
+        if x + w > pic_w or y + h > pic_h:
+            if w > min_cu and h > min_cu:
+                hw, hh = w // 2, h // 2
+                rec(x, y, hw, hh); rec(x + hw, y, hw, hh); rec(x, y + hh, hw, hh); rec(x + hw, y + hh, hw, hh)
+            elif w > min_cu:
+                rec(x, y, w // 2, h); rec(x + w // 2, y, w // 2, h)
+            elif h > min_cu:
+                rec(x, y, w, h // 2); rec(x, y + h // 2, w, h // 2)
+            return
+        m = max(w, h)
+        l2 = m.bit_length() - 1
+        if m > min_cu and rs.random_sample() < p_split.get(l2, 0.0):
+            k = rs.randint(0, 4)
+            if k < 2 and w == h:
+                hw, hh = w // 2, h // 2
+                rec(x, y, hw, hh); rec(x + hw, y, hw, hh); rec(x, y + hh, hw, hh); rec(x + hw, y + hh, hw, hh)
+            elif (k == 2 and w > min_cu) or h <= min_cu:
+                rec(x, y, w // 2, h); rec(x + w // 2, y, w // 2, h)
+            else:
+                rec(x, y, w, h // 2); rec(x, y + h // 2, w, h // 2)
+            return
+        out.append((x, y, w.bit_length() - 1, h.bit_length() - 1))
+
+    for cy in range(0, pic_h, ctu):
+        for cx in range(0, pic_w, ctu):
+            rec(cx, cy, ctu, ctu)
+    return np.array(out, dtype=np.int32)
+
+
+@dataclass
+class Workload:
+    """One recorded inter picture, host side."""
+    w: int
+    h: int
+    seed: int
+    refs: list                      # [(y, cb, cr)] reference pictures
+    ref_pocs: list
+    cus: np.ndarray                 # (n, 4) x, y, log2w, log2h
+    mc_units: np.ndarray            # capi.MC_UNIT_DTYPE
+    tb_cmds: np.ndarray             # capi.TB_CMD_DTYPE
+    coefs: np.ndarray               # int16 arena
+    stats: dict = field(default_factory=dict)
+
+    @property
+    def frame_bytes(self) -> int:
+        return self.w * self.h * 3    # 4:2:0, 2 bytes / sample
+
+
+def _coef_values(rs, n):
+    """Laplacian-ish quantised levels: mostly small, occasionally large."""
+    mag = np.minimum(rs.geometric(0.35, size=n), 600).astype(np.int32)
+    big = rs.random_sample(n) < 0.01
+    mag = np.where(big, rs.randint(100, 4000, size=n), mag)
+    sign = np.where(rs.random_sample(n) < 0.5, -1, 1)
+    return (mag * sign).astype(np.int16)
+
+
+def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6, cbf_y: float = 0.5,
+                  cbf_c: float = 0.3, mv_range_px: int = 64) -> Workload:
+    rs = np.random.RandomState(seed & 0x7FFFFFFF)
+    refs = [random_picture(rs, w, h) for _ in range(2)]
+    pocs = [8, 24]                      # current picture would be POC 16
+    cus = partition(rs, w, h)
+    n = len(cus)
+    rec = capi.Recorder(w, h)
+
+    inter_dir = np.where(rs.random_sample(n) < bi_frac, 3, rs.randint(1, 3, size=n)).astype(np.int32)
+    small = (cus[:, 2] + cus[:, 3]) < 6          # 4x8 / 8x4 / ... : uni-pred only in VVC
+    inter_dir = np.where(small & (inter_dir == 3), 1, inter_dir)
+    mv = rs.randint(-mv_range_px * 16, mv_range_px * 16 + 1, size=(n, 4)).astype(np.int32)
+    integer = rs.random_sample((n, 4)) < 0.25     # a share of integer / half positions like real MV fields
+    mv = np.where(integer, mv & ~15, mv)
+    ridx = rs.randint(0, 2, size=(n, 2))
+    bcw = np.where((inter_dir == 3) & (rs.random_sample(n) < 0.1), rs.randint(1, 6, size=n), 0)
+    hpel = rs.random_sample(n) < 0.05
+
+    # rpl0 = [ref0, ref1], rpl1 = [ref1, ref0]
+    slot = np.array([[0, 1], [1, 0]])
+    pd = capi.PuDesc()
+    for i in range(n):
+        x, y, l2w, l2h = (int(v) for v in cus[i])
+        pd.x0, pd.y0, pd.log2_w, pd.log2_h = x, y, l2w, l2h
+        pd.inter_dir = int(inter_dir[i])
+        pd.ref_idx0, pd.ref_idx1 = int(ridx[i, 0]), int(ridx[i, 1])
+        pd.bcw_idx_plus1 = int(bcw[i]); pd.prec_amvr_half = int(hpel[i]); pd.planes = 3; pd.lmcs = 0
+        pd.mv0x, pd.mv0y, pd.mv1x, pd.mv1y = (int(v) for v in mv[i])
+        if hpel[i]:
+            pd.mv0x = (pd.mv0x & ~15) | 8; pd.mv1y = (pd.mv1y & ~15) | 8
+        pd.ref0 = int(slot[0, ridx[i, 0]]); pd.ref1 = int(slot[1, ridx[i, 1]])
+        pd.poc0 = pocs[pd.ref0]; pd.poc1 = pocs[pd.ref1]
+        rec.pu(pd)
+
+    # ---- transform units ----
+    st = capi.TuState()
+    st.dep_quant = 1; st.mts_implicit = 0; st.sh_ts_disabled = 0; st.ict_type = 2
+    st.lmcs_scale_c = 0; st.lmcs_chroma_scale = 1 << 11
+    td = capi.TuDesc()
+    n_tu = 0
+    coef_pool = _coef_values(rs, 1 << 20)
+    pool_pos = 0
+    bufs = [np.zeros(32 * 32, np.int16) for _ in range(3)]
+    for i in range(n):
+        x, y, l2w, l2h = (int(v) for v in cus[i])
+        qp = int(rs.randint(22, 38)) + 12
+        for ty in range(0, 1 << l2h, 64):
+            for tx in range(0, 1 << l2w, 64):
+                tl2w, tl2h = min(l2w, 6), min(l2h, 6)
+                r = rs.random_sample(6)
+                cbf = (0x10 if r[0] < cbf_y else 0)
+                if tl2w + tl2h >= 6:         # chroma TBs of at least 16 samples
+                    if r[1] < 0.1:
+                        cbf |= 0x8 | int(rs.randint(1, 4))
+                    else:
+                        cbf |= (0x2 if r[2] < cbf_c else 0) | (0x1 if r[3] < cbf_c else 0)
+                if not cbf:
+                    continue
+                td.x0, td.y0, td.log2_tb_w, td.log2_tb_h = x + tx, y + ty, tl2w, tl2h
+                td.tree = 0; td.cbf_mask = cbf; td.cu_flags = 0
+                td.tr_skip_mask = 0; td.cu_mts_flag = 0; td.cu_mts_idx = 0; td.lfnst_flag = 0; td.lfnst_idx = 0
+                if max(tl2w, tl2h) <= 5 and r[4] < 0.1:
+                    td.cu_mts_flag = 1; td.cu_mts_idx = int(rs.randint(0, 4))
+                elif max(tl2w, tl2h) <= 5 and r[4] < 0.13 and (cbf & 0x10):
+                    td.tr_skip_mask = 0x10
+                st.qp_y = qp; st.qp_cb = qp - 1; st.qp_cr = qp - 1; st.qp_jcbcr = qp - 2
+                st.qp_y_skip = max(qp, 16); st.qp_cb_skip = st.qp_cr_skip = st.qp_jcbcr_skip = max(qp - 1, 16)
+                for comp in range(3):
+                    is_l = comp == 2
+                    used = (cbf & 0x10) if is_l else ((comp == 0) if (cbf & 0x8) else (cbf & (0x1 if comp else 0x2)))
+                    if not used:
+                        td.coef[comp] = None
+                        continue
+                    cl2w = tl2w if is_l else tl2w - 1
+                    cl2h = tl2h if is_l else tl2h - 1
+                    buf = bufs[comp]
+                    if is_l and (td.tr_skip_mask & 0x10):
+                        nn = 1 << (cl2w + cl2h)          # TS residual coding: raster, final values
+                        buf[:nn] = 0
+                        k = min(nn, int(rs.randint(1, 9)))
+                        buf[rs.randint(0, nn, size=k)] = coef_pool[pool_pos:pool_pos + k] >> 1
+                        pool_pos = (pool_pos + k) % (len(coef_pool) - 4096)
+                        td.sig_sb_map[comp] = 1; td.last_pos[comp] = 0x0101
+                    elif cl2w < 2 or cl2h < 2:
+                        nn = 1 << (cl2w + cl2h)
+                        buf[:nn] = 0
+                        buf[0] = coef_pool[pool_pos]; pool_pos += 1
+                        td.sig_sb_map[comp] = 1; td.last_pos[comp] = 0
+                    else:
+                        cw, ch = min(32, 1 << cl2w), min(32, 1 << cl2h)
+                        buf[:cw * ch] = 0
+                        nx, ny = cw // 4, ch // 4
+                        u = rs.random_sample()
+                        if u < 0.25:                       # DC only
+                            buf[0] = coef_pool[pool_pos] or 3; pool_pos += 1
+                            td.sig_sb_map[comp] = 0; td.last_pos[comp] = 0
+                        else:
+                            # low-frequency cluster: SBs inside a small top-left rectangle
+                            lx = min(nx, 1 + int(rs.geometric(0.55))); ly = min(ny, 1 + int(rs.geometric(0.55)))
+                            m = 0
+                            for sy in range(ly):
+                                for sx in range(lx):
+                                    if (sx or sy) and rs.random_sample() < 0.35:
+                                        continue
+                                    m |= 1 << (sy * 8 + sx)
+                                    o = sy * 4 * cw + sx * 16
+                                    dens = 0.7 if (sx == 0 and sy == 0) else 0.3
+                                    vals = coef_pool[pool_pos:pool_pos + 16].copy(); pool_pos += 16
+                                    vals[rs.random_sample(16) > dens] = 0
+                                    buf[o:o + 16] = vals
+                            if buf[0] == 0:
+                                buf[0] = 1
+                            td.sig_sb_map[comp] = m; td.last_pos[comp] = 0x0101
+                        pool_pos %= (len(coef_pool) - 4096)
+                    td.coef[comp] = buf.ctypes.data
+                rec.tu(st, td)
+                n_tu += 1
+
+    wl = Workload(w, h, seed, refs, pocs, cus, rec.mc_units(), rec.tb_cmds(), rec.coefs())
+    u = wl.mc_units
+    bi = (u["dir"] == 3)
+    area = u["w"].astype(np.int64) * u["h"]
+    wl.stats = {
+        "n_cu": int(n), "n_tu": int(n_tu), "n_mc_units": int(len(u)), "n_tb_cmds": int(len(wl.tb_cmds)),
+        "coef_bytes": int(wl.coefs.nbytes),
+        "cmd_bytes": int(wl.mc_units.nbytes + wl.tb_cmds.nbytes),
+        # mean reference samples fetched per output sample (block window not counted), SURVEY 8d
+        "r_bar": float((area * np.where(bi, 2, 1)).sum() / max(1, area.sum())),
+    }
+    rec.close()
+    return wl
