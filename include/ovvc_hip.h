@@ -131,6 +131,59 @@ typedef struct ovhip_mc_unit {
 } ovhip_mc_unit;
 
 /* ------------------------------------------------------------------------------------
+ * Deblocking.  The reference filters one CTU per df.rcn_dbf_ctu() call from CTU-local bit maps
+ * (struct DBFInfo, libovvc/ctudec.h:130-170) that carry neighbour state between calls
+ * (dbf_load_info/dbf_store_info, drv_lines.c:618-761).  The recorder (ovhip_rec_dbf_ctu) runs the
+ * edge enumeration, bS / QP lookup and filter-length derivation of vvc_dbf_ctu_hor/_ver and
+ * vvc_dbf_chroma_hor/_ver (rcn_df.c:1151-1431, :1876-2167) WITHOUT touching samples and writes one
+ * 16-bit parameter word per 4-sample edge segment into picture-level planes; the device then
+ * filters all vertical edges of the picture, then all horizontal edges (ovhip_dbf_launch), which
+ * yields the same samples as the reference's per-CTU V-then-H order.
+ *
+ * luma word   : bits 0-1 bS (0 = edge not filtered), 2-4 max filter length P side (1,2,3,5,7),
+ *               5-7 max filter length Q side, 8-15 average QP byte of the two blocks
+ *               ((qp_p + qp_q + 1) >> 1 on the uint8 map entries, as the reference computes it).
+ * chroma word : bit 0 filtered, bit 1 bS==2, bit 2 "large" (strong filter allowed), bit 3 CTU-top
+ *               horizontal edge (is_ctb_b: one P-side line), bits 8-15 average chroma QP byte.
+ * Planes are indexed by 4x4-luma-sample unit: luma_v[uy*w4 + ux] = vertical edge at x = 4*ux, rows
+ * 4*uy..4*uy+3; luma_h[uy*w4 + ux] = horizontal edge at y = 4*uy, columns 4*ux..+3.  Chroma edges
+ * live on the 8-luma-sample grid: c*_v[uy*(w4/2) + ux/2], c*_h[(uy/2)*w4 + ux] (2 chroma samples).
+ * ---------------------------------------------------------------------------------- */
+#define OVHIP_DBF_LUMA(bs, lp, lq, qp)  ((uint16_t)((bs) | ((lp) << 2) | ((lq) << 5) | ((qp) << 8)))
+#define OVHIP_DBF_C_ON     1
+#define OVHIP_DBF_C_BS2    2
+#define OVHIP_DBF_C_LARGE  4
+#define OVHIP_DBF_C_CTB_B  8
+
+typedef struct ovhip_dbf_planes {
+    const uint16_t *luma_v, *luma_h;      /* [h4][w4]                      */
+    const uint16_t *cb_v, *cr_v;          /* [h4][w4c],  w4c = (w4+1)/2    */
+    const uint16_t *cb_h, *cr_h;          /* [h4c][w4],  h4c = (h4+1)/2    */
+    int32_t w4, h4;
+    int16_t beta_offset, tc_offset;       /* DBFInfo.beta_offset / tc_offset (per slice) */
+} ovhip_dbf_planes;
+
+/* What df.rcn_dbf_ctu / df.rcn_dbf_truncated_ctu receive (rcn_structures.h:408-413): a copy of the
+ * CTU's struct DBFInfo arrays (same element layout: 16+33 / 33 x uint64 masks, 34x33 QP bytes) AFTER
+ * the MV-based bS pre-pass (dbf_ctu_preproc_v/_h, rcn_df.c:1821-1874, stays on the host), plus the
+ * call arguments and ctudec->ctu_ngh_flags. */
+typedef struct ovhip_dbf_ctu {
+    uint64_t ctb_bound_ver[49], ctb_bound_hor[49], ctb_bound_ver_c[49], ctb_bound_hor_c[49];
+    uint64_t aff_edg_ver[49], aff_edg_hor[49];
+    uint64_t bs2_ver[33], bs2_hor[33], bs2c_ver[33], bs2c_hor[33];
+    uint64_t bs1_ver[33], bs1_hor[33], bs1cb_ver[33], bs1cb_hor[33], bs1cr_ver[33], bs1cr_hor[33];
+    uint64_t affine_ver[33], affine_hor[33];
+    uint8_t  qp_y[34 * 33], qp_cb[34 * 33], qp_cr[34 * 33];
+    int16_t  beta_offset, tc_offset;
+    uint8_t  disable_v, disable_h;
+    uint8_t  log2_ctu_s, last_x, last_y;  /* slot arguments                                    */
+    uint8_t  ctu_lft, ctu_abv;            /* ctu_ngh_flags & CTU_LFT_FLG / CTU_UP_FLG           */
+    uint8_t  pad;
+    uint16_t ctu_w, ctu_h;                /* samples; < 1<<log2_ctu_s selects the truncated slot */
+    uint16_t ctb_x, ctb_y;                /* CTU address in the picture                         */
+} ovhip_dbf_ctu;
+
+/* ------------------------------------------------------------------------------------
  * Recorder (host side, pure C, usable without a GPU).
  * ---------------------------------------------------------------------------------- */
 typedef struct ovhip_recorder ovhip_recorder;
@@ -191,6 +244,10 @@ void  ovhip_rec_reset(ovhip_recorder *rec);
 /* Append the commands of one TU / PU.  Return number of commands appended or <0. */
 int   ovhip_rec_tu(ovhip_recorder *rec, const ovhip_tu_state *st, const ovhip_tu_desc *tu);
 int   ovhip_rec_pu(ovhip_recorder *rec, const ovhip_pu_desc *pu);
+/* Convert one CTU's deblocking maps into the picture-level edge planes.  Returns 0 or <0. */
+int   ovhip_rec_dbf_ctu(ovhip_recorder *rec, const ovhip_dbf_ctu *ctu);
+/* Host copies of the edge planes (pointers valid until the next reset/destroy). */
+int   ovhip_rec_dbf_planes(const ovhip_recorder *rec, ovhip_dbf_planes *out);
 /* Access to the recorded (host) buffers. */
 const ovhip_tb_cmd  *ovhip_rec_tb_cmds(const ovhip_recorder *rec, size_t *n);
 const int16_t       *ovhip_rec_coefs(const ovhip_recorder *rec, size_t *n_int16);
@@ -226,6 +283,8 @@ int  ovhip_itx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_tb_cmd *
                       uint32_t n_cmds, const int16_t *d_coefs);
 int  ovhip_mc_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs,
                      const ovhip_mc_unit *d_units, uint32_t n_units, const uint16_t *d_lmcs_fwd_lut);
+/* planes->* are DEVICE pointers.  Filters `pic` in place: all vertical edges, then all horizontal. */
+int  ovhip_dbf_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_dbf_planes *planes);
 
 #ifdef __cplusplus
 }

@@ -73,6 +73,23 @@ class PuDesc(C.Structure):
                 ("ref0", C.c_uint8), ("ref1", C.c_uint8), ("pad2", C.c_uint8 * 2)]
 
 
+class DbfPlanes(C.Structure):
+    _fields_ = [("luma_v", C.c_void_p), ("luma_h", C.c_void_p), ("cb_v", C.c_void_p), ("cr_v", C.c_void_p),
+                ("cb_h", C.c_void_p), ("cr_h", C.c_void_p), ("w4", C.c_int32), ("h4", C.c_int32),
+                ("beta_offset", C.c_int16), ("tc_offset", C.c_int16)]
+
+
+DBF_CTU_SIZE = 8 * (49 * 6 + 33 * 12) + 3 * 34 * 33 + 2 * 2 + 2 + 3 + 2 + 1 + 4 * 2
+DBF_CTU_SIZE = (DBF_CTU_SIZE + 7) & ~7          # struct alignment (uint64 members)
+DBF_PLANE_NAMES = ("luma_v", "luma_h", "cb_v", "cr_v", "cb_h", "cr_h")
+
+
+def dbf_plane_shapes(w4: int, h4: int) -> dict:
+    w4c, h4c = (w4 + 1) // 2, (h4 + 1) // 2
+    return {"luma_v": (h4, w4), "luma_h": (h4, w4), "cb_v": (h4, w4c), "cr_v": (h4, w4c),
+            "cb_h": (h4c, w4), "cr_h": (h4c, w4)}
+
+
 TB_CMD_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("plane", "u1"), ("log2_w", "u1"), ("log2_h", "u1"),
                          ("kind", "u1"), ("tr_h", "u1"), ("tr_v", "u1"), ("lfnst", "u1"), ("res_mode", "u1"),
                          ("plane2", "u1"), ("res_mode2", "u1"), ("dq_shift", "u1"), ("dq_neg", "u1"),
@@ -109,6 +126,9 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_rec_reset": (None, [vp]),
         "ovhip_rec_tu": (C.c_int, [vp, P(TuState), P(TuDesc)]),
         "ovhip_rec_pu": (C.c_int, [vp, P(PuDesc)]),
+        "ovhip_rec_dbf_ctu": (C.c_int, [vp, vp]),
+        "ovhip_rec_dbf_planes": (C.c_int, [vp, P(DbfPlanes)]),
+        "ovhip_dbf_launch": (C.c_int, [vp, P(Pic), P(DbfPlanes)]),
         "ovhip_rec_tb_cmds": (vp, [vp, P(C.c_size_t)]),
         "ovhip_rec_coefs": (vp, [vp, P(C.c_size_t)]),
         "ovhip_rec_mc_units": (vp, [vp, P(C.c_size_t)]),
@@ -140,7 +160,7 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
 
 EXPORTED_SYMBOLS = [
     "ovhip_abi_version", "ovhip_rec_create", "ovhip_rec_destroy", "ovhip_rec_reset", "ovhip_rec_tu",
-    "ovhip_rec_pu", "ovhip_rec_tb_cmds", "ovhip_rec_coefs", "ovhip_rec_mc_units", "ovhip_ctx_create",
+    "ovhip_rec_pu", "ovhip_rec_dbf_ctu", "ovhip_rec_dbf_planes", "ovhip_dbf_launch", "ovhip_rec_tb_cmds", "ovhip_rec_coefs", "ovhip_rec_mc_units", "ovhip_ctx_create",
     "ovhip_ctx_destroy", "ovhip_ctx_sync", "ovhip_last_error", "ovhip_ctx_stream", "ovhip_malloc",
     "ovhip_free", "ovhip_h2d", "ovhip_d2h", "ovhip_pic_alloc", "ovhip_pic_free", "ovhip_pic_upload",
     "ovhip_pic_download", "ovhip_itx_launch", "ovhip_mc_launch",
@@ -182,6 +202,27 @@ class Recorder:
         if r < 0:
             raise ValueError(f"ovhip_rec_pu -> {r}")
         return r
+
+    def dbf_ctu(self, raw: bytes):
+        """raw: one ovhip_dbf_ctu struct (what df.rcn_dbf_ctu receives)."""
+        assert len(raw) == DBF_CTU_SIZE, (len(raw), DBF_CTU_SIZE)
+        buf = (C.c_char * len(raw)).from_buffer_copy(raw)
+        r = self.lib.ovhip_rec_dbf_ctu(self.h, C.addressof(buf))
+        if r < 0:
+            raise ValueError(f"ovhip_rec_dbf_ctu -> {r}")
+
+    def dbf_planes(self) -> dict:
+        """Host copies of the picture-level edge planes + offsets."""
+        pl = DbfPlanes()
+        r = self.lib.ovhip_rec_dbf_planes(self.h, C.byref(pl))
+        if r < 0:
+            raise ValueError(f"ovhip_rec_dbf_planes -> {r}")
+        out = {"w4": pl.w4, "h4": pl.h4, "beta_offset": pl.beta_offset, "tc_offset": pl.tc_offset}
+        for name, shape in dbf_plane_shapes(pl.w4, pl.h4).items():
+            n = shape[0] * shape[1]
+            buf = (C.c_uint16 * n).from_address(getattr(pl, name))
+            out[name] = np.frombuffer(buf, dtype=np.uint16).reshape(shape).copy()
+        return out
 
     def _arr(self, fn, dtype):
         n = C.c_size_t(0)

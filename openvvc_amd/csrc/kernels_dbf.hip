@@ -1,0 +1,268 @@
+// kernels_dbf.hip -- K12 on gfx950: VVC deblocking filter over picture-level edge planes.
+//
+// Two launches per picture: every vertical edge (luma + Cb + Cr), then every horizontal edge --
+// the picture-level order the reference's per-CTU "vertical edges, then horizontal edges shifted
+// 8 samples left" schedule reproduces (libovvc/rcn_df.c:2099-2106, :2169-2198).  One lane per
+// 4-sample edge segment (2 chroma lines): the lane reads its 16-bit parameter word (bS, maximum
+// filter lengths, average QP -- produced on the host by ovhip_rec_dbf_ctu), derives tc / beta
+// (Table 43), evaluates the on/off + strong/weak + long-filter decisions on lines 0 and 3 and
+// filters its 4 lines in place.  Segments of one direction never touch each other's samples
+// (H.266 8.8.3: filter lengths are bounded by half the distance to the next edge), so all lanes
+// run independently.  Horizontal edges map lanes to consecutive columns (coalesced rows);
+// vertical edges read 16 samples per line per lane from the same rows as their neighbours (L1/L2).
+//
+// Replaces filter_vertical_edge / filter_horizontal_edge(_c), use_strong_filter_*, the 22 long
+// filters filter_{h,v}_{3,5,7}_{3,5,7}, filter_luma_strong_small_*, filter_luma_weak_*,
+// filter_chroma_{strong,weak}_* (libovvc/rcn_df.c:77-1148, :1433-1510, :2008-2085).
+#include "ovvc_common.hip.h"
+#define OVT_ATTR __device__
+#include "vvc_dbf_tables.h"
+
+namespace {
+
+struct Lim { int tc, beta; };
+
+__device__ __forceinline__ Lim dbf_limits(int qp, int bs, int tc_off, int beta_off)
+{
+    Lim l;
+    l.tc = ovt_dbf_tc[ov_clip3(qp + 2 * (bs - 1) + tc_off, 0, 66)];
+    l.beta = (int)ovt_dbf_beta[ov_clip3(qp + beta_off, 0, 64)] << 2;
+    return l;
+}
+
+// One line across the edge held in registers: s[8 + i] = q_i, s[7 - i] = p_i.
+struct Line16 { int s[16]; };
+
+template <int NP, int NQ>
+__device__ __forceinline__ void load_line(const uint16_t *pix, int step, int *s)
+{
+#pragma unroll
+    for (int i = 0; i < NP; ++i) s[7 - i] = pix[(-1 - i) * step];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) s[8 + i] = pix[i * step];
+}
+#define P(i) s[7 - (i)]
+#define Q(i) s[8 + (i)]
+
+__device__ __forceinline__ int dp_of(const int *s, int o) { return abs(P(2 + o) - 2 * P(1 + o) + P(0 + o)); }
+__device__ __forceinline__ int dq_of(const int *s, int o) { return abs(Q(0 + o) - 2 * Q(1 + o) + Q(2 + o)); }
+
+__device__ __forceinline__ bool strong_large(const int *s, int beta, int tc, int lp, int lq)
+{
+    int sp3 = abs(P(3) - P(0)), sq3 = abs(Q(3) - Q(0));
+    if (lp == 7)      { sp3 += abs((P(4) - P(5)) - P(6) + P(7)); sp3 += abs(P(3) - P(7)) + 1; sp3 >>= 1; }
+    else if (lp == 5) { sp3 += abs(P(3) - P(5)) + 1; sp3 >>= 1; }
+    if (lq == 7)      { sq3 += abs((Q(4) - Q(5)) - Q(6) + Q(7)); sq3 += abs(Q(7) - Q(3)) + 1; sq3 >>= 1; }
+    else if (lq == 5) { sq3 += abs(Q(5) - Q(3)) + 1; sq3 >>= 1; }
+    return ((sp3 + sq3) < (beta * 3 >> 5)) && (abs(P(0) - Q(0)) < ((tc * 5 + 1) >> 1));
+}
+
+__device__ __forceinline__ bool strong_small(const int *s, int beta, int tc)
+{
+    return ((abs(P(3) - P(0)) + abs(Q(3) - Q(0))) < (beta >> 3)) && (abs(P(0) - Q(0)) < ((tc * 5 + 1) >> 1));
+}
+
+__device__ __forceinline__ void long_line(uint16_t *pix, int step, int tc, int lp, int lq)
+{
+    const int f7[7] = { 59, 50, 41, 32, 23, 14, 5 }, f5[5] = { 58, 45, 32, 19, 6 }, f3[3] = { 53, 32, 11 };
+    const int t7[7] = { 6, 5, 4, 3, 2, 1, 1 }, t3[3] = { 6, 4, 2 };
+    int s[16];
+    load_line<8, 8>(pix, step, s);
+    const int ref_p = (P(lp - 1) + P(lp) + 1) >> 1, ref_q = (Q(lq - 1) + Q(lq) + 1) >> 1;
+    int mid;
+    if (lp == lq && lp == 7)
+        mid = (2 * (P(0) + Q(0)) + P(1) + P(2) + P(3) + P(4) + P(5) + P(6) + Q(1) + Q(2) + Q(3) + Q(4) + Q(5) + Q(6) + 8) >> 4;
+    else if (lp == lq)
+        mid = (2 * (P(0) + P(1) + P(2) + Q(0) + Q(1) + Q(2)) + P(3) + P(4) + Q(3) + Q(4) + 8) >> 4;
+    else if (lp + lq == 12)
+        mid = (2 * (P(0) + P(1) + Q(0) + Q(1)) + P(2) + P(3) + P(4) + P(5) + Q(2) + Q(3) + Q(4) + Q(5) + 8) >> 4;
+    else if (lp + lq == 8)
+        mid = (P(0) + P(1) + P(2) + P(3) + Q(0) + Q(1) + Q(2) + Q(3) + 4) >> 3;
+    else if (lp == 7)
+        mid = (2 * (P(0) + Q(0)) + P(1) + P(2) + P(3) + P(4) + P(5) + P(6) + Q(0) + 3 * Q(1) + 2 * Q(2) + 8) >> 4;
+    else
+        mid = (2 * (P(0) + Q(0)) + Q(1) + Q(2) + Q(3) + Q(4) + Q(5) + Q(6) + P(0) + 3 * P(1) + 2 * P(2) + 8) >> 4;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        if (i < lp) {
+            const int f = lp == 7 ? f7[i] : (lp == 5 ? f5[i < 5 ? i : 0] : f3[i < 3 ? i : 0]);
+            const int cv = (tc * (lp == 3 ? t3[i < 3 ? i : 0] : t7[i])) >> 1;
+            pix[(-1 - i) * step] = (uint16_t)ov_clip3((mid * f + ref_p * (64 - f) + 32) >> 6, P(i) - cv, P(i) + cv);
+        }
+        if (i < lq) {
+            const int f = lq == 7 ? f7[i] : (lq == 5 ? f5[i < 5 ? i : 0] : f3[i < 3 ? i : 0]);
+            const int cv = (tc * (lq == 3 ? t3[i < 3 ? i : 0] : t7[i])) >> 1;
+            pix[i * step] = (uint16_t)ov_clip3((mid * f + ref_q * (64 - f) + 32) >> 6, Q(i) - cv, Q(i) + cv);
+        }
+    }
+}
+
+__device__ __forceinline__ void strong_line(uint16_t *pix, int step, int tc)
+{
+    int s[16];
+    load_line<4, 4>(pix, step, s);
+    const int p3 = P(3), p2 = P(2), p1 = P(1), p0 = P(0), q0 = Q(0), q1 = Q(1), q2 = Q(2), q3 = Q(3);
+    pix[-3 * step] = (uint16_t)ov_clip3((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3, p2 - tc, p2 + tc);
+    pix[-2 * step] = (uint16_t)ov_clip3((p2 + p1 + p0 + q0 + 2) >> 2, p1 - 2 * tc, p1 + 2 * tc);
+    pix[-1 * step] = (uint16_t)ov_clip3((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3, p0 - 3 * tc, p0 + 3 * tc);
+    pix[0]         = (uint16_t)ov_clip3((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3, q0 - 3 * tc, q0 + 3 * tc);
+    pix[1 * step]  = (uint16_t)ov_clip3((p0 + q0 + q1 + q2 + 2) >> 2, q1 - 2 * tc, q1 + 2 * tc);
+    pix[2 * step]  = (uint16_t)ov_clip3((p0 + q0 + q1 + 3 * q2 + 2 * q3 + 4) >> 3, q2 - tc, q2 + tc);
+}
+
+__device__ __forceinline__ void weak_line(uint16_t *pix, int step, int tc, bool ext_p, bool ext_q)
+{
+    int s[16];
+    load_line<3, 3>(pix, step, s);
+    const int p2 = P(2), p1 = P(1), p0 = P(0), q0 = Q(0), q1 = Q(1), q2 = Q(2);
+    const int tc2p = ext_p ? tc >> 1 : 0, tc2q = ext_q ? tc >> 1 : 0;
+    int delta = (9 * (q0 - p0) - 3 * (q1 - p1) + 8) >> 4;
+    if (abs(delta) < tc * 10) {
+        delta = ov_clip3(delta, -tc, tc);
+        const int d1 = ov_clip3((((p2 + p0 + 1) >> 1) - p1 + delta) >> 1, -tc2p, tc2p);
+        const int d2 = ov_clip3((((q2 + q0 + 1) >> 1) - q1 - delta) >> 1, -tc2q, tc2q);
+        pix[-2 * step] = (uint16_t)ov_clip_bd(p1 + d1);
+        pix[-1 * step] = (uint16_t)ov_clip_bd(p0 + delta);
+        pix[0]         = (uint16_t)ov_clip_bd(q0 - delta);
+        pix[1 * step]  = (uint16_t)ov_clip_bd(q1 + d2);
+    }
+}
+
+// filter_vertical_edge / filter_horizontal_edge (rcn_df.c:1433-1510, :2008-2085)
+__device__ __forceinline__ void luma_segment(uint16_t *pix0, int step, int lstep, Lim lim, int lp, int lq)
+{
+    const int beta = lim.beta, tc = lim.tc;
+    int a[16], b[16];                                 // lines 0 and 3
+    if (lp > 3 || lq > 3) { load_line<8, 8>(pix0, step, a); load_line<8, 8>(pix0 + 3 * lstep, step, b); }
+    else                  { load_line<4, 4>(pix0, step, a); load_line<4, 4>(pix0 + 3 * lstep, step, b); }
+    const int dp0 = dp_of(a, 0), dq0 = dq_of(a, 0), dp3 = dp_of(b, 0), dq3 = dq_of(b, 0);
+    const int d0 = dp0 + dq0, d3 = dp3 + dq3;
+    if (d0 + d3 >= beta) return;
+    bool sl = false;
+    if (lp > 3 || lq > 3) {
+        int dp0L = dp0, dq0L = dq0, dp3L = dp3, dq3L = dq3;
+        if (lp > 3) { dp0L = (dp0L + dp_of(a, 3) + 1) >> 1; dp3L = (dp3L + dp_of(b, 3) + 1) >> 1; }
+        if (lq > 3) { dq0L = (dq0L + dq_of(a, 3) + 1) >> 1; dq3L = (dq3L + dq_of(b, 3) + 1) >> 1; }
+        const int d0L = dp0L + dq0L, d3L = dp3L + dq3L;
+        sl = (d0L + d3L < beta) && (d0L < ((beta + 0x10) >> 5)) && (d3L < ((beta + 0x10) >> 5))
+             && strong_large(a, beta, tc, lp, lq) && strong_large(b, beta, tc, lp, lq);
+    }
+    if (sl) {
+#pragma unroll 1
+        for (int l = 0; l < 4; ++l) long_line(pix0 + l * lstep, step, tc, lp, lq);
+        return;
+    }
+    const bool sw = lp > 2 && (d0 < ((beta + 4) >> 3)) && (d3 < ((beta + 4) >> 3))
+                    && strong_small(a, beta, tc) && strong_small(b, beta, tc);
+    if (sw) {
+#pragma unroll 1
+        for (int l = 0; l < 4; ++l) strong_line(pix0 + l * lstep, step, tc);
+    } else {
+        const int side = (beta + (beta >> 1)) >> 3;
+        const bool ext_p = (dp0 + dp3) < side && lp > 1;
+        const bool ext_q = (dq0 + dq3) < side && lp > 1;   // sic: max_l_p gates the Q side too (rcn_df.c:1505, :2080)
+#pragma unroll 1
+        for (int l = 0; l < 4; ++l) weak_line(pix0 + l * lstep, step, tc, ext_p, ext_q);
+    }
+}
+
+// filter_veritcal_edge_c / filter_horizontal_edge_c (rcn_df.c:1107-1148, :1279-1319): 2 chroma lines
+__device__ __forceinline__ void chroma_segment(uint16_t *pix0, int step, int lstep, Lim lim, bool large, bool ctb_b)
+{
+    const int tc = lim.tc, beta = lim.beta;
+    if (tc == 0 || beta == 0) return;
+    int s0[16], s1[16];
+    load_line<4, 4>(pix0, step, s0);
+    load_line<4, 4>(pix0 + lstep, step, s1);
+    bool strong = false;
+    if (large) {
+        int d[2];
+        bool ok = true;
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            const int *s = l ? s1 : s0;
+            const int p3 = ctb_b ? P(1) : P(3);
+            const int dp = abs((ctb_b ? P(1) : P(2)) - 2 * P(1) + P(0));
+            d[l] = dp + dq_of(s, 0);
+            ok = ok && ((abs(p3 - P(0)) + abs(Q(3) - Q(0))) < (beta >> 3)) && (abs(P(0) - Q(0)) < ((tc * 5 + 1) >> 1));
+        }
+        strong = ok && (d[0] + d[1] < beta) && (2 * d[0] < (beta >> 2)) && (2 * d[1] < (beta >> 2));
+    }
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        const int *s = l ? s1 : s0;
+        uint16_t *pix = pix0 + l * lstep;
+        const int p3 = P(3), p2 = P(2), p1 = P(1), p0 = P(0), q0 = Q(0), q1 = Q(1), q2 = Q(2), q3 = Q(3);
+        if (strong) {
+            if (ctb_b) {
+                pix[-1 * step] = (uint16_t)ov_clip3((3 * p1 + 2 * p0 + q0 + q1 + q2 + 4) >> 3, p0 - tc, p0 + tc);
+                pix[0]         = (uint16_t)ov_clip3((2 * p1 + p0 + 2 * q0 + q1 + q2 + q3 + 4) >> 3, q0 - tc, q0 + tc);
+            } else {
+                pix[-3 * step] = (uint16_t)ov_clip3((3 * p3 + 2 * p2 + p1 + p0 + q0 + 4) >> 3, p2 - tc, p2 + tc);
+                pix[-2 * step] = (uint16_t)ov_clip3((2 * p3 + p2 + 2 * p1 + p0 + q0 + q1 + 4) >> 3, p1 - tc, p1 + tc);
+                pix[-1 * step] = (uint16_t)ov_clip3((p3 + p2 + p1 + 2 * p0 + q0 + q1 + q2 + 4) >> 3, p0 - tc, p0 + tc);
+                pix[0]         = (uint16_t)ov_clip3((p2 + p1 + p0 + 2 * q0 + q1 + q2 + q3 + 4) >> 3, q0 - tc, q0 + tc);
+            }
+            pix[1 * step] = (uint16_t)ov_clip3((p1 + p0 + q0 + 2 * q1 + q2 + 2 * q3 + 4) >> 3, q1 - tc, q1 + tc);
+            pix[2 * step] = (uint16_t)ov_clip3((p0 + q0 + q1 + 2 * q2 + 3 * q3 + 4) >> 3, q2 - tc, q2 + tc);
+        } else {
+            const int delta = ov_clip3(((q0 << 2) - (p0 << 2) + p1 - q1 + 4) >> 3, -tc, tc);
+            pix[-1 * step] = (uint16_t)ov_clip_bd(p0 + delta);
+            pix[0]         = (uint16_t)ov_clip_bd(q0 - delta);
+        }
+    }
+}
+#undef P
+#undef Q
+
+// DIR 0: vertical edges, DIR 1: horizontal edges.  blockIdx.y: 0 luma, 1 Cb, 2 Cr.
+template <int DIR>
+__global__ __launch_bounds__(256) void k_dbf(ovhip_pic pic, ovhip_dbf_planes pl)
+{
+    const int comp = blockIdx.y;
+    const int w4 = pl.w4, h4 = pl.h4;
+    const int tid = blockIdx.x * 256 + threadIdx.x;
+    if (comp == 0) {
+        if (tid >= w4 * h4) return;
+        const int ux = tid % w4, uy = tid / w4;
+        const int v = (DIR ? pl.luma_h : pl.luma_v)[tid];
+        if (!(v & 3)) return;
+        // never filter across the picture boundary (the recorder does not emit such edges)
+        if ((DIR ? uy : ux) == 0) return;
+        const Lim lim = dbf_limits(v >> 8, v & 3, pl.tc_offset, pl.beta_offset);
+        if (!(lim.tc || lim.beta)) return;
+        uint16_t *p = pic.y + (uy * 4) * pic.stride_y + ux * 4;
+        luma_segment(p, DIR ? pic.stride_y : 1, DIR ? 1 : pic.stride_y, lim, (v >> 2) & 7, (v >> 5) & 7);
+    } else {
+        // chroma edge planes: vertical [h4][w4c] (every second unit column), horizontal [h4c][w4]
+        const int cw = DIR ? w4 : (w4 + 1) >> 1, chh = DIR ? (h4 + 1) >> 1 : h4;
+        if (tid >= cw * chh) return;
+        const int cx = tid % cw, cy = tid / cw;
+        const uint16_t *plane = DIR ? (comp == 1 ? pl.cb_h : pl.cr_h) : (comp == 1 ? pl.cb_v : pl.cr_v);
+        const int v = plane[tid];
+        if (!(v & OVHIP_DBF_C_ON)) return;
+        const int ux = DIR ? cx : cx * 2, uy = DIR ? cy * 2 : cy;
+        if ((DIR ? uy : ux) == 0) return;
+        const Lim lim = dbf_limits(v >> 8, 1 + !!(v & OVHIP_DBF_C_BS2), pl.tc_offset, pl.beta_offset);
+        uint16_t *p = (comp == 1 ? pic.cb : pic.cr) + (uy * 2) * pic.stride_c + ux * 2;
+        chroma_segment(p, DIR ? pic.stride_c : 1, DIR ? 1 : pic.stride_c, lim, v & OVHIP_DBF_C_LARGE, v & OVHIP_DBF_C_CTB_B);
+    }
+}
+
+} // namespace
+
+extern "C" int ovhip_dbf_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_dbf_planes *pl)
+{
+    if (!ctx || !pic || !pl) return OVHIP_EINVAL;
+    if (!pl->luma_v || !pl->luma_h || !pl->cb_v || !pl->cr_v || !pl->cb_h || !pl->cr_h)
+        return ov_fail(ctx, OVHIP_EINVAL, "ovhip_dbf_launch: null edge plane", hipSuccess);
+    if (pl->w4 != (pic->w + 3) / 4 || pl->h4 != (pic->h + 3) / 4)
+        return ov_fail(ctx, OVHIP_EINVAL, "ovhip_dbf_launch: edge planes do not match the picture", hipSuccess);
+    const int n = pl->w4 * pl->h4;
+    dim3 grid((n + 255) / 256, 3);
+    hipLaunchKernelGGL(k_dbf<0>, grid, dim3(256), 0, ctx->stream, *pic, *pl);
+    OV_LAUNCH_CHECK(ctx, "k_dbf<v>");
+    hipLaunchKernelGGL(k_dbf<1>, grid, dim3(256), 0, ctx->stream, *pic, *pl);
+    OV_LAUNCH_CHECK(ctx, "k_dbf<h>");
+    return OVHIP_OK;
+}

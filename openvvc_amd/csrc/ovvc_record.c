@@ -18,13 +18,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "ovvc_hip.h"
-
-struct ovhip_recorder {
-    int32_t pic_w, pic_h;
-    ovhip_tb_cmd  *tb;    size_t n_tb,   cap_tb;
-    int16_t       *coef;  size_t n_coef, cap_coef;
-    ovhip_mc_unit *mc;    size_t n_mc,   cap_mc;
-};
+#include "ovvc_record_priv.h"
 
 /* CUFlags bits this path looks at (libovvc/cu_utils.h:44-60) */
 #define CUF_PRED_MODE_INTRA   (1u << 1)
@@ -47,6 +41,7 @@ ovhip_rec_destroy(ovhip_recorder *r)
 {
     if (!r) return;
     free(r->tb); free(r->coef); free(r->mc);
+    ovhip_rec_dbf_free_(r);
     free(r);
 }
 
@@ -54,6 +49,7 @@ void
 ovhip_rec_reset(ovhip_recorder *r)
 {
     r->n_tb = r->n_coef = r->n_mc = 0;
+    ovhip_rec_dbf_reset_(r);
 }
 
 const ovhip_tb_cmd *ovhip_rec_tb_cmds(const ovhip_recorder *r, size_t *n) { *n = r->n_tb; return r->tb; }

@@ -1,0 +1,209 @@
+/* ovvc_record_dbf.c -- host recorder, deblocking part (plain C, no GPU needed).
+ *
+ * Input: the CTU-local deblocking bit maps the reference hands to df.rcn_dbf_ctu()
+ * (struct DBFInfo, libovvc/ctudec.h:130-170, after dbf_load_info()'s neighbour rotation,
+ * drv_lines.c:618-761).  Output: one 16-bit parameter word per 4-sample edge segment in
+ * picture-level planes (include/ovvc_hip.h).  This file restates ONLY the control flow of
+ *   vvc_dbf_ctu_hor / vvc_dbf_ctu_ver            libovvc/rcn_df.c:1940-2167
+ *   set_edge_context / derive_filter_length      libovvc/rcn_df.c:1890-1938
+ *   vvc_dbf_chroma_hor / vvc_dbf_chroma_ver      libovvc/rcn_df.c:1151-1431
+ *   derive_size_3_map / derive_large_map_from_ngh libovvc/rcn_df.c:190-207, :1087-1105
+ * i.e. which segments are filtered, with which bS, average QP and maximum filter lengths.
+ * The sample arithmetic (decisions + filters) runs on the device (kernels_dbf.hip).
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "ovvc_hip.h"
+#include "ovvc_record_priv.h"
+
+static int
+dbf_alloc(ovhip_recorder *r)
+{
+    if (r->dbf_luma_v) return 0;
+    const int w4 = (r->pic_w + 3) >> 2, h4 = (r->pic_h + 3) >> 2;
+    const int w4c = (w4 + 1) >> 1, h4c = (h4 + 1) >> 1;
+    r->dbf_w4 = w4; r->dbf_h4 = h4;
+    r->dbf_luma_v = (uint16_t *)calloc((size_t)w4 * h4, 2);
+    r->dbf_luma_h = (uint16_t *)calloc((size_t)w4 * h4, 2);
+    r->dbf_cb_v = (uint16_t *)calloc((size_t)w4c * h4, 2);
+    r->dbf_cr_v = (uint16_t *)calloc((size_t)w4c * h4, 2);
+    r->dbf_cb_h = (uint16_t *)calloc((size_t)w4 * h4c, 2);
+    r->dbf_cr_h = (uint16_t *)calloc((size_t)w4 * h4c, 2);
+    if (!r->dbf_luma_v || !r->dbf_luma_h || !r->dbf_cb_v || !r->dbf_cr_v || !r->dbf_cb_h || !r->dbf_cr_h) return -1;
+    return 0;
+}
+
+void
+ovhip_rec_dbf_reset_(ovhip_recorder *r)
+{
+    if (!r->dbf_luma_v) return;
+    const size_t w4 = r->dbf_w4, h4 = r->dbf_h4, w4c = (w4 + 1) >> 1, h4c = (h4 + 1) >> 1;
+    memset(r->dbf_luma_v, 0, w4 * h4 * 2); memset(r->dbf_luma_h, 0, w4 * h4 * 2);
+    memset(r->dbf_cb_v, 0, w4c * h4 * 2);  memset(r->dbf_cr_v, 0, w4c * h4 * 2);
+    memset(r->dbf_cb_h, 0, w4 * h4c * 2);  memset(r->dbf_cr_h, 0, w4 * h4c * 2);
+}
+
+void
+ovhip_rec_dbf_free_(ovhip_recorder *r)
+{
+    free(r->dbf_luma_v); free(r->dbf_luma_h); free(r->dbf_cb_v); free(r->dbf_cr_v); free(r->dbf_cb_h); free(r->dbf_cr_h);
+    r->dbf_luma_v = r->dbf_luma_h = r->dbf_cb_v = r->dbf_cr_v = r->dbf_cb_h = r->dbf_cr_h = NULL;
+}
+
+int
+ovhip_rec_dbf_planes(const ovhip_recorder *r, ovhip_dbf_planes *out)
+{
+    if (!r || !out || !r->dbf_luma_v) return OVHIP_EINVAL;
+    out->luma_v = r->dbf_luma_v; out->luma_h = r->dbf_luma_h;
+    out->cb_v = r->dbf_cb_v; out->cr_v = r->dbf_cr_v; out->cb_h = r->dbf_cb_h; out->cr_h = r->dbf_cr_h;
+    out->w4 = r->dbf_w4; out->h4 = r->dbf_h4;
+    out->beta_offset = r->dbf_beta_offset; out->tc_offset = r->dbf_tc_offset;
+    return OVHIP_OK;
+}
+
+/* ~(OR of 7 consecutive map words): no edge within the next 7 units <=> block >= 32 samples */
+static uint64_t size_3_map(const uint64_t *m) { return ~(m[0] | m[1] | m[2] | m[3] | m[4] | m[5] | m[6]); }
+
+struct edge_ctx { uint64_t large_p, large_q, small, aff1; };
+
+static void
+edge_context(struct edge_ctx *e, const uint64_t *edg, const uint64_t *sb, int i, int p_allowed)
+{
+    e->large_p = (i % 4 || !p_allowed) ? 0 : size_3_map(&edg[i - 7]);
+    e->large_q = (i % 4) ? 0 : size_3_map(&edg[i + 1]);
+    e->small = edg[i - 1] | edg[i + 1] | sb[i - 1] | sb[i + 1];
+    e->aff1 = sb[i] & (edg[i - 2] | edg[i + 2]) & ~edg[i];
+    e->large_p &= ~(sb[i] & ~edg[i]);
+    e->large_q &= ~(sb[i] & ~edg[i]);
+}
+
+static void
+filter_length(const struct edge_ctx *e, uint64_t aff_p, uint64_t aff_q, uint64_t pos, int *lp, int *lq)
+{
+    if (e->small & pos) { *lp = *lq = 1; return; }
+    if (e->aff1 & pos)  { *lp = *lq = 2; return; }
+    *lp = *lq = 3;
+    if (e->large_p & pos) *lp = (aff_p & pos) ? 5 : 7;
+    if (e->large_q & pos) *lq = (aff_q & pos) ? 5 : 7;
+}
+
+static uint64_t large_from_ngh(const uint64_t *m) { return ~(m[-1] | m[1] | m[-2] | m[2] | m[-3] | m[3]); }
+
+int
+ovhip_rec_dbf_ctu(ovhip_recorder *r, const ovhip_dbf_ctu *c)
+{
+    if (!r || !c) return OVHIP_EINVAL;
+    if (c->log2_ctu_s < 5 || c->log2_ctu_s > 7) return OVHIP_EINVAL;
+    if (dbf_alloc(r)) return OVHIP_ENOMEM;
+    r->dbf_beta_offset = c->beta_offset; r->dbf_tc_offset = c->tc_offset;
+
+    const int w4 = r->dbf_w4, h4 = r->dbf_h4, w4c = (w4 + 1) >> 1;
+    const int nb_full = (1 << c->log2_ctu_s) >> 2;
+    const int nb_w = c->ctu_w ? c->ctu_w >> 2 : nb_full, nb_h = c->ctu_h ? c->ctu_h >> 2 : nb_full;
+    const int ux0 = c->ctb_x * nb_full, uy0 = c->ctb_y * nb_full;
+    const int skip_v = !c->ctu_lft, skip_h = !c->ctu_abv;
+    const uint64_t vmask = nb_h >= 64 ? ~0ull : ((1ull << nb_h) - 1);
+    const int hbits = nb_w + (c->last_x ? 2 : 0);
+    const uint64_t hmask = hbits >= 64 ? ~0ull : ((1ull << hbits) - 1);
+
+    /* ---------------- luma, vertical edges (vvc_dbf_ctu_hor) ---------------- */
+    if (!c->disable_h) {
+        const uint64_t *edg = &c->ctb_bound_ver[8], *sb = &c->aff_edg_ver[8];
+        for (int i = skip_v; i < nb_w; ++i) {
+            uint64_t m = (edg[i] | sb[i]) & vmask & (c->bs2_ver[i] | c->bs1_ver[i]);
+            if (!m) continue;
+            struct edge_ctx e;
+            edge_context(&e, edg, sb, i, 1);
+            while (m) {
+                int j = __builtin_ctzll(m);
+                m &= m - 1;
+                uint64_t pos = 1ull << j;
+                int bs = 1 + !!(c->bs2_ver[i] & pos);
+                const uint8_t *q = &c->qp_y[36 + i + 34 * j];
+                int qp = (q[-1] + q[0] + 1) >> 1, lp, lq;
+                filter_length(&e, c->affine_ver[i], c->affine_ver[i + 1], pos, &lp, &lq);
+                int ux = ux0 + i, uy = uy0 + j;
+                if (ux < w4 && uy < h4) r->dbf_luma_v[uy * w4 + ux] = OVHIP_DBF_LUMA(bs, lp, lq, qp & 255);
+            }
+        }
+    }
+    /* ---------------- luma, horizontal edges (vvc_dbf_ctu_ver), shifted 2 units left ---------------- */
+    if (!c->disable_v) {
+        const uint64_t *edg = &c->ctb_bound_hor[8], *sb = &c->aff_edg_hor[8];
+        for (int i = skip_h; i < nb_h; ++i) {
+            uint64_t m = (edg[i] | sb[i]) & hmask & (c->bs2_hor[i] | c->bs1_hor[i]);
+            if (!m) continue;
+            struct edge_ctx e;
+            edge_context(&e, edg, sb, i, i >= 7);
+            while (m) {
+                int k = __builtin_ctzll(m);
+                m &= m - 1;
+                uint64_t pos = 1ull << k;
+                int bs = 1 + !!(c->bs2_hor[i] & pos);
+                const uint8_t *q = &c->qp_y[34 * i + k];
+                int qp = (q[0] + q[34] + 1) >> 1, lp, lq;
+                filter_length(&e, c->affine_hor[i], c->affine_hor[i + 1], pos, &lp, &lq);
+                int ux = ux0 + k - 2, uy = uy0 + i;
+                if (ux >= 0 && ux < w4 && uy < h4) r->dbf_luma_h[uy * w4 + ux] = OVHIP_DBF_LUMA(bs, lp, lq, qp & 255);
+            }
+        }
+    }
+    /* ---------------- chroma, vertical edges on the 8-sample grid (vvc_dbf_chroma_hor) ---------------- */
+    if (!c->disable_h) {
+        const uint64_t *tab = &c->ctb_bound_ver_c[8];
+        const int nb_vedge = (nb_w + 3) >> 2;
+        for (int comp = 0; comp < 2; ++comp) {
+            const uint64_t *bs1v = comp ? c->bs1cr_ver : c->bs1cb_ver;
+            const uint8_t *qpm = comp ? c->qp_cr : c->qp_cb;
+            uint16_t *plane = comp ? r->dbf_cr_v : r->dbf_cb_v;
+            for (int i = skip_v; i < nb_vedge; ++i) {
+                const int idx = i << 2;
+                uint64_t bs2 = c->bs2c_ver[idx], bs1 = bs1v[idx];
+                uint64_t m = tab[idx] & vmask & (bs2 | bs1);
+                if (!m) continue;
+                uint64_t large = large_from_ngh(&tab[idx]);
+                m &= bs2 | (bs1 & large);
+                while (m) {
+                    int j = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const uint8_t *q = &qpm[36 + idx + 34 * j];
+                    int qp = (q[-1] + q[0] + 1) >> 1;
+                    int ux = ux0 + idx, uy = uy0 + j;
+                    if (ux < w4 && uy < h4)
+                        plane[uy * w4c + (ux >> 1)] = (uint16_t)(OVHIP_DBF_C_ON | (((bs2 >> j) & 1) ? OVHIP_DBF_C_BS2 : 0)
+                                                                 | (((large >> j) & 1) ? OVHIP_DBF_C_LARGE : 0) | ((qp & 255) << 8));
+                }
+            }
+        }
+    }
+    /* ---------------- chroma, horizontal edges (vvc_dbf_chroma_ver), shifted 2 units left ---------------- */
+    if (!c->disable_v) {
+        const uint64_t *tab = &c->ctb_bound_hor_c[8];
+        const int nb_hedge = (nb_h + 3) >> 2;
+        for (int comp = 0; comp < 2; ++comp) {
+            const uint64_t *bs1h = comp ? c->bs1cr_hor : c->bs1cb_hor;
+            const uint8_t *qpm = comp ? c->qp_cr : c->qp_cb;
+            uint16_t *plane = comp ? r->dbf_cr_h : r->dbf_cb_h;
+            for (int i = skip_h; i < nb_hedge; ++i) {
+                const int idx = i << 2;
+                uint64_t bs2 = c->bs2c_hor[idx], bs1 = bs1h[idx];
+                uint64_t m = tab[idx] & hmask & (bs2 | bs1);
+                if (!m) continue;
+                uint64_t large = large_from_ngh(&tab[idx]);
+                m &= bs2 | (bs1 & large);
+                while (m) {
+                    int k = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const uint8_t *q = &qpm[idx * 34 + k];
+                    int qp = (q[0] + q[34] + 1) >> 1;
+                    int ux = ux0 + k - 2, uy = uy0 + idx;
+                    if (ux >= 0 && ux < w4 && uy < h4)
+                        plane[(uy >> 1) * w4 + ux] = (uint16_t)(OVHIP_DBF_C_ON | (((bs2 >> k) & 1) ? OVHIP_DBF_C_BS2 : 0)
+                                                                | (((large >> k) & 1) ? OVHIP_DBF_C_LARGE : 0)
+                                                                | (i == 0 ? OVHIP_DBF_C_CTB_B : 0) | ((qp & 255) << 8));
+                }
+            }
+        }
+    }
+    return OVHIP_OK;
+}

@@ -1,0 +1,20 @@
+/* ovvc_record_priv.h -- recorder state shared by ovvc_record.c / ovvc_record_dbf.c (private). */
+#ifndef OVVC_RECORD_PRIV_H
+#define OVVC_RECORD_PRIV_H
+#include <stddef.h>
+#include "ovvc_hip.h"
+
+struct ovhip_recorder {
+    int32_t pic_w, pic_h;
+    ovhip_tb_cmd  *tb;    size_t n_tb,   cap_tb;
+    int16_t       *coef;  size_t n_coef, cap_coef;
+    ovhip_mc_unit *mc;    size_t n_mc,   cap_mc;
+    /* deblocking edge planes (ovvc_record_dbf.c) */
+    uint16_t *dbf_luma_v, *dbf_luma_h, *dbf_cb_v, *dbf_cr_v, *dbf_cb_h, *dbf_cr_h;
+    int32_t dbf_w4, dbf_h4;
+    int16_t dbf_beta_offset, dbf_tc_offset;
+};
+
+void ovhip_rec_dbf_reset_(ovhip_recorder *r);
+void ovhip_rec_dbf_free_(ovhip_recorder *r);
+#endif

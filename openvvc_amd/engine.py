@@ -68,11 +68,28 @@ class Context:
         n = cmds.count if n is None else n
         self._chk(self.lib.ovhip_itx_launch(self.h, C.byref(dst.s), cmds.ptr, n, coefs.ptr), "itx_launch")
 
+    def dbf(self, pic: "DevPic", planes: "DevDbfPlanes"):
+        self._chk(self.lib.ovhip_dbf_launch(self.h, C.byref(pic.s), C.byref(planes.s)), "dbf_launch")
+
     def mc(self, dst: "DevPic", refs: list, units: "DevBuf", lmcs_fwd: "DevBuf | None" = None, n: int | None = None):
         n = units.count if n is None else n
         arr = (capi.Pic * len(refs))(*[r.s for r in refs])
         self._chk(self.lib.ovhip_mc_launch(self.h, C.byref(dst.s), arr, len(refs), units.ptr, n,
                                            lmcs_fwd.ptr if lmcs_fwd else None), "mc_launch")
+
+
+class DevDbfPlanes:
+    """Deblocking edge planes resident on the device (ovhip_dbf_planes with device pointers)."""
+
+    def __init__(self, ctx: "Context", planes: dict):
+        self.bufs = {k: ctx.upload(np.ascontiguousarray(planes[k], dtype=np.uint16).ravel()) for k in capi.DBF_PLANE_NAMES}
+        self.s = capi.DbfPlanes(*[self.bufs[k].ptr for k in capi.DBF_PLANE_NAMES], planes["w4"], planes["h4"],
+                                planes["beta_offset"], planes["tc_offset"])
+        self.nbytes = sum(b.nbytes for b in self.bufs.values())
+
+    def free(self):
+        for b in self.bufs.values():
+            b.free()
 
 
 class DevBuf:

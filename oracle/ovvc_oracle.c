@@ -307,3 +307,223 @@ void oracle_mc(const oracle_pic *dst, const oracle_pic *refs, uint32_t n_refs,
         if (!(u->flags & OVHIP_MC_NO_CHROMA)) { mc_plane(dst, refs, u, 1, lmcs_fwd); mc_plane(dst, refs, u, 2, lmcs_fwd); }
     }
 }
+
+/* ====================================================================================
+ * K12: deblocking filter on picture-level edge planes
+ * ================================================================================== */
+#include "vvc_dbf_tables.h"
+
+typedef struct { int tc, beta; } dbf_lim;
+
+/* compute_dbf_limits, rcn_df.c:171-188 (BITDEPTH 10) */
+static dbf_lim dbf_limits(int qp, int bs, int tc_off, int beta_off)
+{
+    dbf_lim l;
+    l.tc = ovt_dbf_tc[clip3i(qp + 2 * (bs - 1) + tc_off, 0, 66)];
+    l.beta = ovt_dbf_beta[clip3i(qp + beta_off, 0, 64)] << 2;
+    return l;
+}
+
+/* sample accessor along the filtering direction: s(i) for i >= 0 is q_i, for i < 0 is p_{-i-1} */
+#define S(i) ((int)pix[(i) * step])
+
+static int dbf_dp(const uint16_t *pix, int step) { return abs(S(-3) - 2 * S(-2) + S(-1)); }
+static int dbf_dq(const uint16_t *pix, int step) { return abs(S(0) - 2 * S(1) + S(2)); }
+
+/* use_strong_filter_l0, rcn_df.c:77-123 */
+static int dbf_strong_large(const uint16_t *pix, int step, int beta, int tc, int lp, int lq)
+{
+    int sp3 = abs(S(-4) - S(-1)), sq3 = abs(S(3) - S(0));
+    if (lp == 7)      { sp3 += abs((S(-5) - S(-6)) - S(-7) + S(-8)); sp3 += abs(S(-4) - S(-8)) + 1; sp3 >>= 1; }
+    else if (lp == 5) { sp3 += abs(S(-4) - S(-6)) + 1; sp3 >>= 1; }
+    if (lq == 7)      { sq3 += abs((S(4) - S(5)) - S(6) + S(7)); sq3 += abs(S(7) - S(3)) + 1; sq3 >>= 1; }
+    else if (lq == 5) { sq3 += abs(S(5) - S(3)) + 1; sq3 >>= 1; }
+    return ((sp3 + sq3) < (beta * 3 >> 5)) && (abs(S(-1) - S(0)) < ((tc * 5 + 1) >> 1));
+}
+
+/* use_strong_filter_l1, rcn_df.c:125-139 */
+static int dbf_strong_small(const uint16_t *pix, int step, int beta, int tc)
+{
+    return ((abs(S(-4) - S(-1)) + abs(S(3) - S(0))) < (beta >> 3)) && (abs(S(-1) - S(0)) < ((tc * 5 + 1) >> 1));
+}
+
+/* one line of the long ("large block") luma filters filter_{h,v}_{3,5,7}_{3,5,7}, rcn_df.c:217-846 */
+static void dbf_long_line(uint16_t *pix, int step, int tc, int lp, int lq)
+{
+    static const int8_t f7[7] = { 59, 50, 41, 32, 23, 14, 5 }, f5[5] = { 58, 45, 32, 19, 6 }, f3[3] = { 53, 32, 11 };
+    static const int8_t t7[7] = { 6, 5, 4, 3, 2, 1, 1 }, t3[3] = { 6, 4, 2 };
+    int p[8], q[8];
+    for (int i = 0; i < 8; ++i) { p[i] = S(-1 - i); q[i] = S(i); }
+    int ref_p = (p[lp - 1] + p[lp] + 1) >> 1, ref_q = (q[lq - 1] + q[lq] + 1) >> 1, mid;
+    if (lp == lq && lp == 7)
+        mid = (2 * (p[0] + q[0]) + p[1] + p[2] + p[3] + p[4] + p[5] + p[6] + q[1] + q[2] + q[3] + q[4] + q[5] + q[6] + 8) >> 4;
+    else if (lp == lq)                      /* 5,5 */
+        mid = (2 * (p[0] + p[1] + p[2] + q[0] + q[1] + q[2]) + p[3] + p[4] + q[3] + q[4] + 8) >> 4;
+    else if (lp + lq == 12)                 /* 7,5 / 5,7 */
+        mid = (2 * (p[0] + p[1] + q[0] + q[1]) + p[2] + p[3] + p[4] + p[5] + q[2] + q[3] + q[4] + q[5] + 8) >> 4;
+    else if (lp + lq == 8)                  /* 5,3 / 3,5 */
+        mid = (p[0] + p[1] + p[2] + p[3] + q[0] + q[1] + q[2] + q[3] + 4) >> 3;
+    else if (lp == 7)                       /* 7,3 */
+        mid = (2 * (p[0] + q[0]) + p[1] + p[2] + p[3] + p[4] + p[5] + p[6] + q[0] + 3 * q[1] + 2 * q[2] + 8) >> 4;
+    else                                    /* 3,7 */
+        mid = (2 * (p[0] + q[0]) + q[1] + q[2] + q[3] + q[4] + q[5] + q[6] + p[0] + 3 * p[1] + 2 * p[2] + 8) >> 4;
+    const int8_t *fp = lp == 7 ? f7 : lp == 5 ? f5 : f3, *fq = lq == 7 ? f7 : lq == 5 ? f5 : f3;
+    const int8_t *tp = lp == 3 ? t3 : t7, *tq = lq == 3 ? t3 : t7;
+    for (int i = 0; i < lp; ++i) {
+        int cv = (tc * tp[i]) >> 1;
+        pix[(-1 - i) * step] = (uint16_t)clip3i((mid * fp[i] + ref_p * (64 - fp[i]) + 32) >> 6, p[i] - cv, p[i] + cv);
+    }
+    for (int i = 0; i < lq; ++i) {
+        int cv = (tc * tq[i]) >> 1;
+        pix[i * step] = (uint16_t)clip3i((mid * fq[i] + ref_q * (64 - fq[i]) + 32) >> 6, q[i] - cv, q[i] + cv);
+    }
+}
+
+/* filter_luma_strong_small_{h,v}, rcn_df.c:849-898 */
+static void dbf_strong_line(uint16_t *pix, int step, int tc)
+{
+    const int p3 = S(-4), p2 = S(-3), p1 = S(-2), p0 = S(-1), q0 = S(0), q1 = S(1), q2 = S(2), q3 = S(3);
+    pix[-3 * step] = (uint16_t)clip3i((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3, p2 - tc, p2 + tc);
+    pix[-2 * step] = (uint16_t)clip3i((p2 + p1 + p0 + q0 + 2) >> 2, p1 - 2 * tc, p1 + 2 * tc);
+    pix[-1 * step] = (uint16_t)clip3i((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3, p0 - 3 * tc, p0 + 3 * tc);
+    pix[0]         = (uint16_t)clip3i((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3, q0 - 3 * tc, q0 + 3 * tc);
+    pix[1 * step]  = (uint16_t)clip3i((p0 + q0 + q1 + q2 + 2) >> 2, q1 - 2 * tc, q1 + 2 * tc);
+    pix[2 * step]  = (uint16_t)clip3i((p0 + q0 + q1 + 3 * q2 + 2 * q3 + 4) >> 3, q2 - tc, q2 + tc);
+}
+
+/* filter_luma_weak_{h,v}, rcn_df.c:900-958 */
+static void dbf_weak_line(uint16_t *pix, int step, int tc, int ext_p, int ext_q)
+{
+    const int p2 = S(-3), p1 = S(-2), p0 = S(-1), q0 = S(0), q1 = S(1), q2 = S(2);
+    const int tc2p = ext_p ? tc >> 1 : 0, tc2q = ext_q ? tc >> 1 : 0;
+    int delta = (9 * (q0 - p0) - 3 * (q1 - p1) + 8) >> 4;
+    if (abs(delta) < tc * 10) {
+        delta = clip3i(delta, -tc, tc);
+        const int d1 = clip3i((((p2 + p0 + 1) >> 1) - p1 + delta) >> 1, -tc2p, tc2p);
+        const int d2 = clip3i((((q2 + q0 + 1) >> 1) - q1 - delta) >> 1, -tc2q, tc2q);
+        pix[-2 * step] = (uint16_t)clip_bd(p1 + d1);
+        pix[-1 * step] = (uint16_t)clip_bd(p0 + delta);
+        pix[0]         = (uint16_t)clip_bd(q0 - delta);
+        pix[1 * step]  = (uint16_t)clip_bd(q1 + d2);
+    }
+}
+
+/* filter_vertical_edge / filter_horizontal_edge, rcn_df.c:1433-1510, :2008-2085: one 4-line segment.
+ * step = distance between samples across the edge, lstep = distance between the 4 lines. */
+static void dbf_luma_segment(uint16_t *pix0, int step, int lstep, dbf_lim lim, int lp, int lq)
+{
+    const uint16_t *pix = pix0;
+    const int dp0 = dbf_dp(pix, step), dq0 = dbf_dq(pix, step);
+    pix = pix0 + 3 * lstep;
+    const int dp3 = dbf_dp(pix, step), dq3 = dbf_dq(pix, step);
+    const int d0 = dp0 + dq0, d3 = dp3 + dq3, beta = lim.beta, tc = lim.tc;
+    if (d0 + d3 >= beta) return;
+    int strong_large = 0;
+    if (lp > 3 || lq > 3) {
+        int dp0L = dp0, dq0L = dq0, dp3L = dp3, dq3L = dq3;
+        if (lp > 3) {
+            dp0L = (dp0L + dbf_dp(pix0 - 3 * step, step) + 1) >> 1;
+            dp3L = (dp3L + dbf_dp(pix0 + 3 * lstep - 3 * step, step) + 1) >> 1;
+        }
+        if (lq > 3) {
+            dq0L = (dq0L + dbf_dq(pix0 + 3 * step, step) + 1) >> 1;
+            dq3L = (dq3L + dbf_dq(pix0 + 3 * lstep + 3 * step, step) + 1) >> 1;
+        }
+        const int d0L = dp0L + dq0L, d3L = dp3L + dq3L;
+        strong_large = (d0L + d3L < beta) && (d0L < ((beta + 0x10) >> 5)) && (d3L < ((beta + 0x10) >> 5))
+            && dbf_strong_large(pix0, step, beta, tc, lp, lq) && dbf_strong_large(pix0 + 3 * lstep, step, beta, tc, lp, lq);
+    }
+    if (strong_large) {
+        for (int l = 0; l < 4; ++l) dbf_long_line(pix0 + l * lstep, step, tc, lp, lq);
+        return;
+    }
+    int sw = lp > 2 && (d0 < ((beta + 4) >> 3)) && (d3 < ((beta + 4) >> 3))
+        && dbf_strong_small(pix0, step, beta, tc) && dbf_strong_small(pix0 + 3 * lstep, step, beta, tc);
+    if (sw) {
+        for (int l = 0; l < 4; ++l) dbf_strong_line(pix0 + l * lstep, step, tc);
+    } else {
+        const int side = (beta + (beta >> 1)) >> 3;
+        const int ext_p = (dp0 + dp3) < side && lp > 1;
+        const int ext_q = (dq0 + dq3) < side && lp > 1;     /* sic: the reference tests max_l_p for Q too (rcn_df.c:1505) */
+        for (int l = 0; l < 4; ++l) dbf_weak_line(pix0 + l * lstep, step, tc, ext_p, ext_q);
+    }
+}
+
+/* filter_veritcal_edge_c / filter_horizontal_edge_c, rcn_df.c:1107-1148, :1279-1319: one 2-line chroma segment */
+static void dbf_chroma_segment(uint16_t *pix0, int step, int lstep, dbf_lim lim, int large, int ctb_b)
+{
+    const int tc = lim.tc, beta = lim.beta;
+    if (tc == 0 || beta == 0) return;
+    int strong = 0;
+    if (large) {
+        int d[2];
+        int ok = 1;
+        for (int l = 0; l < 2; ++l) {
+            const uint16_t *pix = pix0 + l * lstep;
+            const int p3 = ctb_b ? S(-2) : S(-4);     /* src[(-stride*4) >> is_ctb_b] */
+            const int dp = abs((ctb_b ? S(-2) : S(-3)) - 2 * S(-2) + S(-1));
+            d[l] = dp + dbf_dq(pix, step);
+            ok = ok && ((abs(p3 - S(-1)) + abs(S(3) - S(0))) < (beta >> 3)) && (abs(S(-1) - S(0)) < ((tc * 5 + 1) >> 1));
+        }
+        strong = ok && (d[0] + d[1] < beta) && (2 * d[0] < (beta >> 2)) && (2 * d[1] < (beta >> 2));
+    }
+    for (int l = 0; l < 2; ++l) {
+        uint16_t *pix = pix0 + l * lstep;
+        const int p3 = S(-4), p2 = S(-3), p1 = S(-2), p0 = S(-1), q0 = S(0), q1 = S(1), q2 = S(2), q3 = S(3);
+        if (strong) {
+            if (ctb_b) {
+                pix[-1 * step] = (uint16_t)clip3i((3 * p1 + 2 * p0 + q0 + q1 + q2 + 4) >> 3, p0 - tc, p0 + tc);
+                pix[0]         = (uint16_t)clip3i((2 * p1 + p0 + 2 * q0 + q1 + q2 + q3 + 4) >> 3, q0 - tc, q0 + tc);
+                pix[1 * step]  = (uint16_t)clip3i((p1 + p0 + q0 + 2 * q1 + q2 + 2 * q3 + 4) >> 3, q1 - tc, q1 + tc);
+                pix[2 * step]  = (uint16_t)clip3i((p0 + q0 + q1 + 2 * q2 + 3 * q3 + 4) >> 3, q2 - tc, q2 + tc);
+            } else {
+                pix[-3 * step] = (uint16_t)clip3i((3 * p3 + 2 * p2 + p1 + p0 + q0 + 4) >> 3, p2 - tc, p2 + tc);
+                pix[-2 * step] = (uint16_t)clip3i((2 * p3 + p2 + 2 * p1 + p0 + q0 + q1 + 4) >> 3, p1 - tc, p1 + tc);
+                pix[-1 * step] = (uint16_t)clip3i((p3 + p2 + p1 + 2 * p0 + q0 + q1 + q2 + 4) >> 3, p0 - tc, p0 + tc);
+                pix[0]         = (uint16_t)clip3i((p2 + p1 + p0 + 2 * q0 + q1 + q2 + q3 + 4) >> 3, q0 - tc, q0 + tc);
+                pix[1 * step]  = (uint16_t)clip3i((p1 + p0 + q0 + 2 * q1 + q2 + 2 * q3 + 4) >> 3, q1 - tc, q1 + tc);
+                pix[2 * step]  = (uint16_t)clip3i((p0 + q0 + q1 + 2 * q2 + 3 * q3 + 4) >> 3, q2 - tc, q2 + tc);
+            }
+        } else {
+            const int delta = clip3i(((q0 << 2) - (p0 << 2) + p1 - q1 + 4) >> 3, -tc, tc);
+            pix[-1 * step] = (uint16_t)clip_bd(p0 + delta);
+            pix[0]         = (uint16_t)clip_bd(q0 - delta);
+        }
+    }
+}
+#undef S
+
+/* rcn_dbf_ctu over the whole picture: every vertical edge, then every horizontal edge (rcn_df.c:2169-2198) */
+void oracle_dbf(const oracle_pic *pic, const ovhip_dbf_planes *pl)
+{
+    const int w4 = pl->w4, h4 = pl->h4, w4c = (w4 + 1) >> 1;
+    for (int dir = 0; dir < 2; ++dir) {
+        /* luma */
+        const uint16_t *lw = dir ? pl->luma_h : pl->luma_v;
+        for (int uy = 0; uy < h4; ++uy) {
+            for (int ux = 0; ux < w4; ++ux) {
+                const int v = lw[uy * w4 + ux];
+                if (!(v & 3)) continue;
+                dbf_lim lim = dbf_limits(v >> 8, v & 3, pl->tc_offset, pl->beta_offset);
+                if (!(lim.tc || lim.beta)) continue;
+                uint16_t *p = pic->y + (uy * 4) * pic->stride_y + ux * 4;
+                dbf_luma_segment(p, dir ? pic->stride_y : 1, dir ? 1 : pic->stride_y, lim, (v >> 2) & 7, (v >> 5) & 7);
+            }
+        }
+        /* chroma */
+        for (int comp = 0; comp < 2; ++comp) {
+            const uint16_t *cw = dir ? (comp ? pl->cr_h : pl->cb_h) : (comp ? pl->cr_v : pl->cb_v);
+            uint16_t *plane = comp ? pic->cr : pic->cb;
+            for (int uy = 0; uy < h4; uy += dir ? 2 : 1) {
+                for (int ux = 0; ux < w4; ux += dir ? 1 : 2) {
+                    const int v = dir ? cw[(uy >> 1) * w4 + ux] : cw[uy * w4c + (ux >> 1)];
+                    if (!(v & OVHIP_DBF_C_ON)) continue;
+                    dbf_lim lim = dbf_limits(v >> 8, 1 + !!(v & OVHIP_DBF_C_BS2), pl->tc_offset, pl->beta_offset);
+                    uint16_t *p = plane + (uy * 2) * pic->stride_c + ux * 2;
+                    dbf_chroma_segment(p, dir ? pic->stride_c : 1, dir ? 1 : pic->stride_c, lim,
+                                       !!(v & OVHIP_DBF_C_LARGE), !!(v & OVHIP_DBF_C_CTB_B));
+                }
+            }
+        }
+    }
+}

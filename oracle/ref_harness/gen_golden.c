@@ -357,6 +357,205 @@ gen_mc(const char *dir)
     fprintf(stderr, "mc.ovg: %u cases, %zu expected samples\n", n_cases, b_exp.n);
 }
 
+
+/* ====================================================================================== DBF */
+#include "dbf_utils.h"
+#include "drv_lines.h"
+#include "slicedec.h"
+
+static void
+snapshot_dbf(ovhip_dbf_ctu *o, const struct DBFInfo *d)
+{
+    memset(o, 0, sizeof(*o));
+    memcpy(o->ctb_bound_ver, d->ctb_bound_ver, sizeof(o->ctb_bound_ver));
+    memcpy(o->ctb_bound_hor, d->ctb_bound_hor, sizeof(o->ctb_bound_hor));
+    memcpy(o->ctb_bound_ver_c, d->ctb_bound_ver_c, sizeof(o->ctb_bound_ver_c));
+    memcpy(o->ctb_bound_hor_c, d->ctb_bound_hor_c, sizeof(o->ctb_bound_hor_c));
+    memcpy(o->aff_edg_ver, d->aff_edg_ver, sizeof(o->aff_edg_ver));
+    memcpy(o->aff_edg_hor, d->aff_edg_hor, sizeof(o->aff_edg_hor));
+    memcpy(o->bs2_ver, d->bs2_map.ver, sizeof(o->bs2_ver));       memcpy(o->bs2_hor, d->bs2_map.hor, sizeof(o->bs2_hor));
+    memcpy(o->bs2c_ver, d->bs2_map_c.ver, sizeof(o->bs2c_ver));   memcpy(o->bs2c_hor, d->bs2_map_c.hor, sizeof(o->bs2c_hor));
+    memcpy(o->bs1_ver, d->bs1_map.ver, sizeof(o->bs1_ver));       memcpy(o->bs1_hor, d->bs1_map.hor, sizeof(o->bs1_hor));
+    memcpy(o->bs1cb_ver, d->bs1_map_cb.ver, sizeof(o->bs1cb_ver)); memcpy(o->bs1cb_hor, d->bs1_map_cb.hor, sizeof(o->bs1cb_hor));
+    memcpy(o->bs1cr_ver, d->bs1_map_cr.ver, sizeof(o->bs1cr_ver)); memcpy(o->bs1cr_hor, d->bs1_map_cr.hor, sizeof(o->bs1cr_hor));
+    memcpy(o->affine_ver, d->affine_map.ver, sizeof(o->affine_ver)); memcpy(o->affine_hor, d->affine_map.hor, sizeof(o->affine_hor));
+    memcpy(o->qp_y, d->qp_map_y.hor, sizeof(o->qp_y));
+    memcpy(o->qp_cb, d->qp_map_cb.hor, sizeof(o->qp_cb));
+    memcpy(o->qp_cr, d->qp_map_cr.hor, sizeof(o->qp_cr));
+    o->beta_offset = d->beta_offset; o->tc_offset = d->tc_offset;
+    o->disable_v = d->disable_v; o->disable_h = d->disable_h;
+}
+
+/* random partition of a w x h region of one CTU into CUs; fills the deblocking maps the way the
+ * decoder's parse loop does (vcl_coding_unit.c:742, vcl_transform_unit.c:1093-1146, :1934-1957,
+ * rcn_transform_tree.c fill_bs_map calls, drv_affine_mvp.c:3052-3082) and paints a DC offset per CU
+ * into the unfiltered picture so that block edges are visible to the filter decisions */
+struct dbf_gen { struct DBFInfo *d; uint16_t *y, *cb, *cr; int stride, stride_c; int px, py; };
+
+static void
+gen_cu(struct dbf_gen *g, int x, int y, int w, int h)
+{
+    struct DBFInfo *d = g->d;
+    int l2w = 31 - __builtin_clz(w), l2h = 31 - __builtin_clz(h);
+    int qp = rnd_range(18, 50);
+    int intra = rnd_range(0, 9) == 0;
+    int affine = !intra && w >= 16 && h >= 16 && rnd_range(0, 5) == 0;
+    int off_y = rnd_range(-40, 40), off_c = rnd_range(-24, 24);
+    for (int j = 0; j < h; ++j) for (int i = 0; i < w; ++i) {
+        int v = g->y[(g->py + y + j) * g->stride + g->px + x + i] + off_y;
+        g->y[(g->py + y + j) * g->stride + g->px + x + i] = v < 0 ? 0 : v > 1023 ? 1023 : v;
+    }
+    for (int j = 0; j < h / 2; ++j) for (int i = 0; i < w / 2; ++i) {
+        int o = ((g->py + y) / 2 + j) * g->stride_c + (g->px + x) / 2 + i;
+        int v = g->cb[o] + off_c; g->cb[o] = v < 0 ? 0 : v > 1023 ? 1023 : v;
+        v = g->cr[o] - off_c;     g->cr[o] = v < 0 ? 0 : v > 1023 ? 1023 : v;
+    }
+    dbf_fill_cu_edge(&d->cu_edge, x >> 2, y >> 2, w >> 2, h >> 2);
+    if (intra) { fill_bs_map(&d->bs2_map, x, y, l2w, l2h); fill_bs_map(&d->bs2_map_c, x, y, l2w, l2h); }
+    if (rnd_range(0, 2) == 0) {           /* "motion differs from the neighbours" (what dbf_ctu_preproc_* derives) */
+        fill_bs_map(&d->bs1_map, x, y, l2w, l2h);
+        if (rnd_range(0, 1)) fill_bs_map(&d->bs1_map_cb, x, y, l2w, l2h);
+        if (rnd_range(0, 1)) fill_bs_map(&d->bs1_map_cr, x, y, l2w, l2h);
+    }
+    if (affine) {
+        int x0_u = x >> 2, y0_u = y >> 2, nw = w >> 2, nh = h >> 2;
+        uint64_t msk_v = (((uint64_t)1 << nh) - 1) << y0_u, msk_h = (((uint64_t)1 << nw) - 1) << (2 + x0_u);
+        for (int i = 2; i < nw; i += 2) { d->aff_edg_ver[8 + x0_u + i] |= msk_v; if (rnd_range(0, 1)) d->bs1_map.ver[x0_u + i] |= msk_v & ((uint64_t)rnd32() << 32 | rnd32() << 8 | rnd32()); }
+        for (int i = 2; i < nh; i += 2) { d->aff_edg_hor[8 + y0_u + i] |= msk_h; if (rnd_range(0, 1)) d->bs1_map.hor[y0_u + i] |= msk_h & ((uint64_t)rnd32() << 32 | rnd32() << 8 | rnd32()); }
+        dbf_fill_aff_map(&d->affine_map, x0_u, y0_u, nw, nh);
+    }
+    /* transform units: split at 64 */
+    for (int ty = 0; ty < h; ty += 64) for (int tx = 0; tx < w; tx += 64) {
+        int tl2w = l2w > 6 ? 6 : l2w, tl2h = l2h > 6 ? 6 : l2h;
+        fill_ctb_bound(d, x + tx, y + ty, tl2w, tl2h);
+        fill_ctb_bound_c(d, x + tx, y + ty, tl2w, tl2h);
+        dbf_fill_qp_map(&d->qp_map_y, x + tx, y + ty, tl2w, tl2h, qp);
+        dbf_fill_qp_map(&d->qp_map_cb, x + tx, y + ty, tl2w, tl2h, qp - rnd_range(0, 3));
+        dbf_fill_qp_map(&d->qp_map_cr, x + tx, y + ty, tl2w, tl2h, qp - rnd_range(0, 3));
+        if (rnd_range(0, 1)) fill_bs_map(&d->bs1_map, x + tx, y + ty, tl2w, tl2h);          /* cbf luma */
+        if (rnd_range(0, 2) == 0) fill_bs_map(&d->bs1_map_cb, x + tx, y + ty, tl2w, tl2h);  /* cbf cb   */
+        if (rnd_range(0, 2) == 0) fill_bs_map(&d->bs1_map_cr, x + tx, y + ty, tl2w, tl2h);  /* cbf cr   */
+    }
+}
+
+static void
+gen_part(struct dbf_gen *g, int x, int y, int w, int h, int lim_w, int lim_h)
+{
+    if (x >= lim_w || y >= lim_h) return;
+    if (x + w > lim_w || y + h > lim_h) {
+        if (w > 4 && x + w > lim_w && !(h > 4 && y + h > lim_h)) { gen_part(g, x, y, w / 2, h, lim_w, lim_h); gen_part(g, x + w / 2, y, w / 2, h, lim_w, lim_h); }
+        else if (h > 4 && y + h > lim_h && !(w > 4 && x + w > lim_w)) { gen_part(g, x, y, w, h / 2, lim_w, lim_h); gen_part(g, x, y + h / 2, w, h / 2, lim_w, lim_h); }
+        else { gen_part(g, x, y, w / 2, h / 2, lim_w, lim_h); gen_part(g, x + w / 2, y, w / 2, h / 2, lim_w, lim_h);
+               gen_part(g, x, y + h / 2, w / 2, h / 2, lim_w, lim_h); gen_part(g, x + w / 2, y + h / 2, w / 2, h / 2, lim_w, lim_h); }
+        return;
+    }
+    int m = w > h ? w : h;
+    static const int p_split[8] = { 0, 0, 0, 15, 45, 65, 85, 95 };   /* % by log2(max dim): 8->15 .. 128->95 */
+    if (m > 4 && rnd_range(0, 99) < p_split[31 - __builtin_clz(m)]) {
+        int k = rnd_range(0, 3);
+        if (k < 2 && w == h && w > 4) { gen_part(g, x, y, w / 2, h / 2, lim_w, lim_h); gen_part(g, x + w / 2, y, w / 2, h / 2, lim_w, lim_h);
+                                        gen_part(g, x, y + h / 2, w / 2, h / 2, lim_w, lim_h); gen_part(g, x + w / 2, y + h / 2, w / 2, h / 2, lim_w, lim_h); }
+        else if ((k == 2 && w > 4) || h <= 4) { gen_part(g, x, y, w / 2, h, lim_w, lim_h); gen_part(g, x + w / 2, y, w / 2, h, lim_w, lim_h); }
+        else { gen_part(g, x, y, w, h / 2, lim_w, lim_h); gen_part(g, x, y + h / 2, w, h / 2, lim_w, lim_h); }
+        return;
+    }
+    gen_cu(g, x, y, w, h);
+}
+
+static void
+gen_dbf(const char *dir)
+{
+    enum { NPIC = 2 };
+    static const int PW[NPIC] = { 304, 264 }, PH[NPIC] = { 200, 136 };
+    gfile g = gfile_open(dir, "dbf.ovg");
+    g_seed = 0x266 + 2;
+    for (int pi = 0; pi < NPIC; ++pi) {
+        const int W = PW[pi], H = PH[pi], nx = (W + 127) / 128, ny = (H + 127) / 128;
+        uint16_t *y = malloc(W * H * 2), *cb = malloc(W * H / 2), *cr = malloc(W * H / 2);
+        fill_plane(y, W, H, W); fill_plane(cb, W / 2, H / 2, W / 2); fill_plane(cr, W / 2, H / 2, W / 2);
+        /* very smooth content so that beta decisions pass often: low-pass once more */
+        for (int j = 0; j < H; ++j) for (int i = 1; i < W; ++i) y[j * W + i] = (y[j * W + i] + 3 * y[j * W + i - 1] + 2) >> 2;
+        for (int j = 1; j < H; ++j) for (int i = 0; i < W; ++i) y[j * W + i] = (y[j * W + i] + 3 * y[(j - 1) * W + i] + 2) >> 2;
+        for (int j = 0; j < H / 2; ++j) for (int i = 1; i < W / 2; ++i) { cb[j * (W / 2) + i] = (cb[j * (W / 2) + i] + 3 * cb[j * (W / 2) + i - 1] + 2) >> 2; cr[j * (W / 2) + i] = (cr[j * (W / 2) + i] + 3 * cr[j * (W / 2) + i - 1] + 2) >> 2; }
+        for (int j = 1; j < H / 2; ++j) for (int i = 0; i < W / 2; ++i) { cb[j * (W / 2) + i] = (cb[j * (W / 2) + i] + 3 * cb[(j - 1) * (W / 2) + i] + 2) >> 2; cr[j * (W / 2) + i] = (cr[j * (W / 2) + i] + 3 * cr[(j - 1) * (W / 2) + i] + 2) >> 2; }
+
+        OVCTUDec *c = ref_new_ctudec(0, 0);
+        struct DBFInfo *d = &c->dbf_info;
+        c->tmp_slice_type = 2;         /* the MV-based bS pre-pass is emulated by gen_cu() */
+        struct DBFLines L;
+        int npu = W / 4 + 40;
+        L.qp_x_map = calloc(npu, 1); L.qp_x_map_cb = calloc(npu, 1); L.qp_x_map_cr = calloc(npu, 1);
+        L.small_map = calloc(nx + 1, 8); L.dbf_bs2_hor = calloc(nx + 1, 8); L.dbf_bs2_hor_c = calloc(nx + 1, 8);
+        L.dbf_bs1_hor = calloc(nx + 1, 8); L.dbf_bs1_hor_cb = calloc(nx + 1, 8); L.dbf_bs1_hor_cr = calloc(nx + 1, 8);
+        L.dbf_affine = calloc(nx + 1, 8); L.large_map_c = calloc(nx + 1, 8);
+
+        /* the partition pass paints block offsets into the picture, so do it first for all CTUs
+         * into per-CTU map snapshots?  No: maps are CTU-local and rotated by load/store, so generate,
+         * filter and snapshot CTU by CTU exactly in decoding order; the unfiltered picture is captured
+         * from a second identical generation pass (same seed) that does not filter. */
+        uint16_t *y0 = malloc(W * H * 2), *cb0 = malloc(W * H / 2), *cr0 = malloc(W * H / 2);
+        gbuf b_ctu = { .type = T_U8 };
+        uint32_t n_ctu = 0;
+        for (int pass = 0; pass < 2; ++pass) {
+            uint32_t seed_save = g_seed;
+            uint16_t *ty = pass ? y : y0, *tcb = pass ? cb : cb0, *tcr = pass ? cr : cr0;
+            if (!pass) { memcpy(y0, y, W * H * 2); memcpy(cb0, cb, W * H / 2); memcpy(cr0, cr, W * H / 2); }
+            memset(d, 0, sizeof(*d));
+            d->beta_offset = (pi ? 2 : -2) * 2; d->tc_offset = (pi ? -1 : 3) * 2;
+            memset(L.qp_x_map, 0, npu); memset(L.qp_x_map_cb, 0, npu); memset(L.qp_x_map_cr, 0, npu);
+            memset(L.small_map, 0, (nx + 1) * 8); memset(L.dbf_bs2_hor, 0, (nx + 1) * 8); memset(L.dbf_bs2_hor_c, 0, (nx + 1) * 8);
+            memset(L.dbf_bs1_hor, 0, (nx + 1) * 8); memset(L.dbf_bs1_hor_cb, 0, (nx + 1) * 8); memset(L.dbf_bs1_hor_cr, 0, (nx + 1) * 8);
+            memset(L.dbf_affine, 0, (nx + 1) * 8); memset(L.large_map_c, 0, (nx + 1) * 8);
+            for (int cy = 0; cy < ny; ++cy) {
+                dbf_load_info(d, &L, 7, 0);
+                for (int cx = 0; cx < nx; ++cx) {
+                    int ctu_w = W - cx * 128 < 128 ? W - cx * 128 : 128, ctu_h = H - cy * 128 < 128 ? H - cy * 128 : 128;
+                    struct dbf_gen gg = { d, ty, tcb, tcr, W, W / 2, cx * 128, cy * 128 };
+                    gen_part(&gg, 0, 0, 128, 128, ctu_w, ctu_h);
+                    if (pass) {
+                        c->ctu_ngh_flags = (cx ? CTU_LFT_FLG : 0) | (cy ? CTU_UP_FLG : 0);
+                        c->rcn_ctx.frame_buff.y = y + cy * 128 * W + cx * 128;
+                        c->rcn_ctx.frame_buff.cb = cb + cy * 64 * (W / 2) + cx * 64;
+                        c->rcn_ctx.frame_buff.cr = cr + cy * 64 * (W / 2) + cx * 64;
+                        c->rcn_ctx.frame_buff.stride = W; c->rcn_ctx.frame_buff.stride_c = W / 2;
+                        int last_x = cx == nx - 1, last_y = cy == ny - 1;
+                        int truncated = ctu_w < 128 || ctu_h < 128;
+                        if (!truncated) c->rcn_funcs.df.rcn_dbf_ctu(&c->rcn_ctx, d, 7, last_x, last_y);
+                        else            c->rcn_funcs.df.rcn_dbf_truncated_ctu(&c->rcn_ctx, d, 7, last_x, last_y, ctu_w, ctu_h);
+                        ovhip_dbf_ctu o;
+                        snapshot_dbf(&o, d);
+                        o.log2_ctu_s = 7; o.last_x = last_x; o.last_y = last_y;
+                        o.ctu_lft = !!cx; o.ctu_abv = !!cy;
+                        o.ctu_w = truncated ? ctu_w : 0; o.ctu_h = truncated ? ctu_h : 0;
+                        o.ctb_x = cx; o.ctb_y = cy;
+                        gbuf_push(&b_ctu, &o, sizeof(o));
+                        n_ctu++;
+                    }
+                    dbf_store_info(d, &L, 7, cx);
+                    if (cx < nx - 1) dbf_load_info(d, &L, 7, cx + 1);
+                }
+            }
+            if (!pass) g_seed = seed_save;      /* replay the same partition in the filtering pass */
+        }
+        /* pass 0 painted y0; pass 1 painted y identically then filtered it */
+        char nm[32];
+        uint32_t d2[2] = { H, W };
+        snprintf(nm, 32, "p%d_in_y", pi); gfile_array(&g, nm, T_U16, y0, 2, d2);
+        snprintf(nm, 32, "p%d_exp_y", pi); gfile_array(&g, nm, T_U16, y, 2, d2);
+        d2[0] = H / 2; d2[1] = W / 2;
+        snprintf(nm, 32, "p%d_in_cb", pi); gfile_array(&g, nm, T_U16, cb0, 2, d2);
+        snprintf(nm, 32, "p%d_in_cr", pi); gfile_array(&g, nm, T_U16, cr0, 2, d2);
+        snprintf(nm, 32, "p%d_exp_cb", pi); gfile_array(&g, nm, T_U16, cb, 2, d2);
+        snprintf(nm, 32, "p%d_exp_cr", pi); gfile_array(&g, nm, T_U16, cr, 2, d2);
+        d2[0] = n_ctu; d2[1] = sizeof(ovhip_dbf_ctu);
+        snprintf(nm, 32, "p%d_ctus", pi); gfile_array(&g, nm, T_U8, b_ctu.data, 2, d2);
+        size_t diff = 0;
+        for (int i = 0; i < W * H; ++i) diff += y[i] != y0[i];
+        fprintf(stderr, "dbf.ovg: picture %d %dx%d, %u CTUs, %zu luma samples changed by the reference\n", pi, W, H, n_ctu, diff);
+    }
+    gfile_close(&g);
+}
+
 int
 main(int argc, char **argv)
 {
@@ -364,5 +563,6 @@ main(int argc, char **argv)
     const char *only = argc > 2 ? argv[2] : NULL;
     if (!only || !strcmp(only, "itx")) gen_itx(dir);
     if (!only || !strcmp(only, "mc"))  gen_mc(dir);
+    if (!only || !strcmp(only, "dbf")) gen_dbf(dir);
     return 0;
 }

@@ -62,3 +62,20 @@ def check_rects(pic: HostPic, rects, exp, what=""):
         if not np.array_equal(got, want):
             bad.append((k, p, x, y, w, h, int(np.abs(got.astype(int) - want.astype(int)).max())))
     assert not bad, f"{what}: {len(bad)} / {len(rects)} rectangles differ, first: {bad[:5]}"
+
+
+def dbf_cases():
+    """[(unfiltered HostPic, planes dict from the recorder, expected HostPic)] from dbf.ovg."""
+    g = golden_io.load("dbf.ovg")
+    out = []
+    pi = 0
+    while f"p{pi}_in_y" in g:
+        y = g[f"p{pi}_in_y"]
+        h, w = y.shape
+        rec = capi.Recorder(w, h)
+        for raw in g[f"p{pi}_ctus"]:
+            rec.dbf_ctu(raw.tobytes())
+        out.append((HostPic(w, h, y, g[f"p{pi}_in_cb"], g[f"p{pi}_in_cr"]), rec.dbf_planes(),
+                    HostPic(w, h, g[f"p{pi}_exp_y"], g[f"p{pi}_exp_cb"], g[f"p{pi}_exp_cr"])))
+        pi += 1
+    return out

@@ -30,6 +30,8 @@ def lib():
         _lib.oracle_itx.restype = None
         _lib.oracle_mc.argtypes = [C.POINTER(OPic), C.POINTER(OPic), C.c_uint32, vp, C.c_uint32, vp]
         _lib.oracle_mc.restype = None
+        _lib.oracle_dbf.argtypes = [C.POINTER(OPic), vp]
+        _lib.oracle_dbf.restype = None
     return _lib
 
 
@@ -69,3 +71,18 @@ def mc(dst: HostPic, refs, units: np.ndarray, lmcs_fwd=None):
         lmcs_fwd = np.ascontiguousarray(lmcs_fwd, dtype=np.uint16)
         lut = lmcs_fwd.ctypes.data
     lib().oracle_mc(C.byref(s), arr, len(refs), units.ctypes.data, len(units), lut)
+
+
+def dbf_planes_struct(planes: dict):
+    """planes: dict from capi.Recorder.dbf_planes() / synth (numpy uint16 arrays). Returns (struct, keepalive)."""
+    from openvvc_amd import capi
+    keep = {k: np.ascontiguousarray(planes[k], dtype=np.uint16) for k in capi.DBF_PLANE_NAMES}
+    s = capi.DbfPlanes(*[keep[k].ctypes.data for k in capi.DBF_PLANE_NAMES], planes["w4"], planes["h4"],
+                       planes["beta_offset"], planes["tc_offset"])
+    return s, keep
+
+
+def dbf(pic: HostPic, planes: dict):
+    s = pic.struct()
+    pl, keep = dbf_planes_struct(planes)
+    lib().oracle_dbf(C.byref(s), C.addressof(pl))

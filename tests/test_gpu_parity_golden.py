@@ -46,3 +46,14 @@ def test_mc_gpu_matches_reference(ctx):
     ctx.sync()
     y, cb, cr = tall.download()
     golden_cases.check_rects(HostPic(rw, rh * n, y, cb, cr), rects, exp, "mc HIP vs reference")
+
+
+def test_dbf_gpu_matches_reference(ctx):
+    for i, (pic, planes, exp) in enumerate(golden_cases.dbf_cases()):
+        d = ctx.upload_pic(pic.y, pic.cb, pic.cr)
+        ctx.dbf(d, engine.DevDbfPlanes(ctx, planes))
+        ctx.sync()
+        y, cb, cr = d.download()
+        for name, a, b in (("Y", y, exp.y), ("Cb", cb, exp.cb), ("Cr", cr, exp.cr)):
+            bad = np.argwhere(a != b)
+            assert len(bad) == 0, f"dbf HIP vs reference, picture {i} plane {name}: {len(bad)} differ, first {bad[:6].tolist()}"

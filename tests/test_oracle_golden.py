@@ -31,3 +31,15 @@ def test_mc_oracle_matches_reference(built_lib):
                  (1, d.x0 >> 1, d.y0 >> 1, w >> 1, h >> 1, int(exp_off[i, 1])),
                  (2, d.x0 >> 1, d.y0 >> 1, w >> 1, h >> 1, int(exp_off[i, 2]))]
         golden_cases.check_rects(dst, rects, exp, f"mc case {i} dir={d.inter_dir} planes={d.planes}")
+
+
+def test_dbf_oracle_matches_reference(built_lib):
+    cases = golden_cases.dbf_cases()
+    assert len(cases) == 2
+    for i, (pic, planes, exp) in enumerate(cases):
+        work = pic.copy()
+        oracle_lib.dbf(work, planes)
+        for name, a, b, c in (("Y", work.y, exp.y, pic.y), ("Cb", work.cb, exp.cb, pic.cb), ("Cr", work.cr, exp.cr, pic.cr)):
+            assert (b != c).sum() > 500, "fixture does not exercise the filter"
+            bad = np.argwhere(a != b)
+            assert len(bad) == 0, f"dbf picture {i} plane {name}: {len(bad)} samples differ, first at (y,x) {bad[:6].tolist()}"
