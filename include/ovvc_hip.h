@@ -184,6 +184,26 @@ typedef struct ovhip_dbf_ctu {
 } ovhip_dbf_ctu;
 
 /* ------------------------------------------------------------------------------------
+ * Sample adaptive offset.  One entry per CTU in raster order (index ctb_y * nb_ctu_w + ctb_x,
+ * nb_ctu_w = ceil(w / ctu)), a compact copy of what the SAO slots read from SAOParamsCtu
+ * (libovvc/dec_structures.h:263-274: type_idx, band_position, eo_class, offset_val).
+ * ovhip_sao_launch() reads the deblocked picture `src` and writes every sample of `dst` (copy
+ * where SAO is off): the frame-resident equivalent of the reference's filter_region copies
+ * (rcn_ctu.c:315-510) -- a sample is always filtered with the parameters of the CTU that
+ * contains it and picture-border samples whose neighbour is outside stay unmodified
+ * (rcn_sao.c:119-188, :190-293).
+ * ---------------------------------------------------------------------------------- */
+enum { OVHIP_SAO_OFF = 0, OVHIP_SAO_BAND = 1, OVHIP_SAO_EDGE = 2 };   /* = SAO_NOT_APPLIED / SAO_BAND / SAO_EDGE */
+typedef struct ovhip_sao_ctu {
+    uint8_t type[3];          /* per component Y, Cb, Cr                                  */
+    uint8_t band_position[3]; /* first of the 4 consecutive bands (of 32)                  */
+    uint8_t eo_class[3];      /* 0 horizontal, 1 vertical, 2 45 deg (135 in spec), 3 other diagonal */
+    uint8_t pad[3];
+    int16_t offset_val[3][5]; /* band: [0..3]; edge: indexed by 2 + sign(c-a) + sign(c-b) */
+    uint8_t pad2[2];
+} ovhip_sao_ctu;
+
+/* ------------------------------------------------------------------------------------
  * Recorder (host side, pure C, usable without a GPU).
  * ---------------------------------------------------------------------------------- */
 typedef struct ovhip_recorder ovhip_recorder;
@@ -285,6 +305,9 @@ int  ovhip_mc_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *refs
                      const ovhip_mc_unit *d_units, uint32_t n_units, const uint16_t *d_lmcs_fwd_lut);
 /* planes->* are DEVICE pointers.  Filters `pic` in place: all vertical edges, then all horizontal. */
 int  ovhip_dbf_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_dbf_planes *planes);
+/* d_params: DEVICE array of ceil(w/ctu)*ceil(h/ctu) entries.  dst and src must not alias. */
+int  ovhip_sao_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *src,
+                      const ovhip_sao_ctu *d_params, int32_t log2_ctu_s);
 
 #ifdef __cplusplus
 }

@@ -71,6 +71,9 @@ class Context:
     def dbf(self, pic: "DevPic", planes: "DevDbfPlanes"):
         self._chk(self.lib.ovhip_dbf_launch(self.h, C.byref(pic.s), C.byref(planes.s)), "dbf_launch")
 
+    def sao(self, dst: "DevPic", src: "DevPic", params: "DevBuf", log2_ctu: int = 7):
+        self._chk(self.lib.ovhip_sao_launch(self.h, C.byref(dst.s), C.byref(src.s), params.ptr, log2_ctu), "sao_launch")
+
     def mc(self, dst: "DevPic", refs: list, units: "DevBuf", lmcs_fwd: "DevBuf | None" = None, n: int | None = None):
         n = units.count if n is None else n
         arr = (capi.Pic * len(refs))(*[r.s for r in refs])

@@ -527,3 +527,46 @@ void oracle_dbf(const oracle_pic *pic, const ovhip_dbf_planes *pl)
         }
     }
 }
+
+/* ====================================================================================
+ * K13: sample adaptive offset
+ * ================================================================================== */
+/* sao_band_filter / sao_edge_filter / rcn_sao_ctu, rcn_sao.c:46-188.  Picture-level restatement:
+ * every sample uses the parameters of the CTU that contains it; samples on the picture border
+ * whose class neighbour lies outside are left unfiltered (the is_border row/column skips). */
+void oracle_sao(const oracle_pic *dst, const oracle_pic *src, const ovhip_sao_ctu *prm, int log2_ctu)
+{
+    static const int8_t pos[4][2][2] = { { { -1, 0 }, { 1, 0 } }, { { 0, -1 }, { 0, 1 } }, { { -1, -1 }, { 1, 1 } }, { { 1, -1 }, { -1, 1 } } };
+    const int nb_ctu_w = (src->w + (1 << log2_ctu) - 1) >> log2_ctu;
+    /* quirk kept: with a single CTU row rcn_sao_first_pix_rows() passes OV_BOUNDARY_BOTTOM_RECT for its
+     * 6-row band (rcn_sao.c:262), so the band's last row is skipped for non-horizontal edge classes */
+    const int one_row = src->h <= (1 << log2_ctu);
+    for (int c = 0; c < 3; ++c) {
+        const int sh = c ? 1 : 0, w = src->w >> sh, h = src->h >> sh, l2 = log2_ctu - sh;
+        int ss, ds;
+        const uint16_t *s = plane_ptr(src, c, &ss);
+        uint16_t *d = plane_ptr(dst, c, &ds);
+        for (int y = 0; y < h; ++y) {
+            for (int x = 0; x < w; ++x) {
+                const ovhip_sao_ctu *p = &prm[(y >> l2) * nb_ctu_w + (x >> l2)];
+                const int v = s[y * ss + x];
+                int o = v;
+                if (p->type[c] == OVHIP_SAO_BAND) {
+                    const int k = ((v >> (BD - 5)) - p->band_position[c]) & 31;
+                    if (k < 4) o = clip_bd(v + p->offset_val[c][k]);
+                } else if (p->type[c] == OVHIP_SAO_EDGE) {
+                    const int eo = p->eo_class[c];
+                    const int skip = (eo != 1 && (x == 0 || x == w - 1)) || (eo != 0 && (y == 0 || y == h - 1))
+                                     || (one_row && eo != 0 && y == (6 >> sh) - 1);
+                    if (!skip) {
+                        const int a = s[(y + pos[eo][0][1]) * ss + x + pos[eo][0][0]];
+                        const int b = s[(y + pos[eo][1][1]) * ss + x + pos[eo][1][0]];
+                        const int idx = 2 + (v > a) - (v < a) + (v > b) - (v < b);
+                        o = clip_bd(v + p->offset_val[c][idx]);
+                    }
+                }
+                d[y * ds + x] = (uint16_t)o;
+            }
+        }
+    }
+}

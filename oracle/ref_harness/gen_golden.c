@@ -556,6 +556,110 @@ gen_dbf(const char *dir)
     gfile_close(&g);
 }
 
+
+/* ====================================================================================== SAO */
+/* rcn_alloc_filter_buffers() (rcn_ctu.c:512-551) calls ov_malloc (ovmem.c is not built, see
+ * oracle/Makefile); the harness performs the same sizing with plain calloc. */
+static void
+harness_alloc_filter_buffers(struct OVRCNCtx *rcn_ctx, int nb_ctu_w, int margin, int log2_ctb_s)
+{
+    struct OVFilterBuffers *fb = &rcn_ctx->filter_buffers;
+    int ctu_s = 1 << log2_ctb_s;
+    fb->margin = margin;
+    for (int comp = 0; comp < 3; ++comp) {
+        int ratio = comp ? 2 : 1;
+        fb->filter_region_w[comp] = ctu_s / ratio;
+        fb->filter_region_h[comp] = ctu_s / ratio;
+        fb->filter_region_stride[comp] = ctu_s / ratio + 2 * margin;
+        fb->filter_region_offset[comp] = margin * fb->filter_region_stride[comp] + margin;
+        int ext = fb->filter_region_stride[comp] * (fb->filter_region_h[comp] + 2 * margin + 1);
+        fb->filter_region[comp] = calloc(ext, sizeof(OVSample));
+        fb->saved_cols[comp] = calloc(fb->filter_region_h[comp] * margin, sizeof(OVSample));
+        fb->saved_rows_stride[comp] = nb_ctu_w * ctu_s / ratio;
+        fb->saved_rows_sao[comp] = calloc(margin * fb->saved_rows_stride[comp], sizeof(OVSample));
+        fb->saved_rows_alf[comp] = calloc(margin * fb->saved_rows_stride[comp], sizeof(OVSample));
+    }
+}
+
+static OVFrame *
+harness_frame(int w, int h)
+{
+    OVPicture *p = ref_new_picture(w, h, 0);
+    fill_plane(p->frame->data[0], w, h, w);
+    fill_plane(p->frame->data[1], w / 2, h / 2, w / 2);
+    fill_plane(p->frame->data[2], w / 2, h / 2, w / 2);
+    return p->frame;
+}
+
+static void
+gen_sao(const char *dir)
+{
+    enum { NPIC = 3 };
+    static const int PW[NPIC] = { 304, 264, 136 }, PH[NPIC] = { 200, 264, 72 };
+    gfile g = gfile_open(dir, "sao.ovg");
+    g_seed = 0x266 + 3;
+    for (int pi = 0; pi < NPIC; ++pi) {
+        const int W = PW[pi], H = PH[pi], nx = (W + 127) / 128, ny = (H + 127) / 128;
+        OVFrame *f = harness_frame(W, H);
+        /* sprinkle extremes so clipping and every band are hit */
+        uint16_t *py = f->data[0];
+        for (int i = 0; i < W * H; i += 11) py[i] = (uint16_t)rnd_range(0, 1023);
+        char nm[32];
+        uint32_t d2[2] = { H, W };
+        snprintf(nm, 32, "p%d_in_y", pi); gfile_array(&g, nm, T_U16, f->data[0], 2, d2);
+        d2[0] = H / 2; d2[1] = W / 2;
+        snprintf(nm, 32, "p%d_in_cb", pi); gfile_array(&g, nm, T_U16, f->data[1], 2, d2);
+        snprintf(nm, 32, "p%d_in_cr", pi); gfile_array(&g, nm, T_U16, f->data[2], 2, d2);
+
+        OVCTUDec *c = ref_new_ctudec(0, 0);
+        c->pic_w = W; c->pic_h = H;
+        c->rcn_ctx.frame_start = f;
+        harness_alloc_filter_buffers(&c->rcn_ctx, nx, 3, 7);
+        c->sao_info.sao_luma_flag = 1; c->sao_info.sao_chroma_flag = 1; c->sao_info.chroma_format_idc = 1;
+        SAOParamsCtu *prm = calloc(nx * ny, sizeof(*prm));
+        ovhip_sao_ctu *mine = calloc(nx * ny, sizeof(*mine));
+        c->sao_info.sao_params = prm;
+        for (int i = 0; i < nx * ny; ++i) {
+            for (int comp = 0; comp < 3; ++comp) {
+                int t = rnd_range(0, 3); if (t == 3) t = 2;
+                prm[i].type_idx[comp] = t;
+                prm[i].band_position[comp] = rnd_range(0, 31);
+                prm[i].eo_class[comp] = rnd_range(0, 3);
+                for (int k = 0; k < 5; ++k) prm[i].offset_val[comp][k] = (int16_t)rnd_range(-31, 31);
+                if (t == 2) { prm[i].offset_val[comp][2] = 0; }
+                mine[i].type[comp] = t; mine[i].band_position[comp] = prm[i].band_position[comp];
+                mine[i].eo_class[comp] = prm[i].eo_class[comp];
+                memcpy(mine[i].offset_val[comp], prm[i].offset_val[comp], 10);
+            }
+        }
+        struct RectEntryInfo einfo;
+        memset(&einfo, 0, sizeof(einfo));
+        einfo.nb_ctu_w = nx; einfo.nb_ctu_h = ny;
+        /* call order of decode_ctu_line / decode_ctu_last_line (slicedec.c:934-956, :1058-1073) */
+        for (int cy = 0; cy < ny; ++cy) {
+            c->ctb_y = cy;
+            if (cy == 0) {
+                c->rcn_funcs.sao.rcn_sao_first_pix_rows(c, &einfo, 0);
+                if (ny == 1) c->rcn_funcs.sao.rcn_sao_filter_line(c, &einfo, 0);
+            } else if (cy == ny - 1) {
+                c->rcn_funcs.sao.rcn_sao_filter_line(c, &einfo, cy - 1);
+                c->rcn_funcs.sao.rcn_sao_filter_line(c, &einfo, cy);
+            } else {
+                c->rcn_funcs.sao.rcn_sao_filter_line(c, &einfo, cy - 1);
+            }
+        }
+        d2[0] = H; d2[1] = W;
+        snprintf(nm, 32, "p%d_exp_y", pi); gfile_array(&g, nm, T_U16, f->data[0], 2, d2);
+        d2[0] = H / 2; d2[1] = W / 2;
+        snprintf(nm, 32, "p%d_exp_cb", pi); gfile_array(&g, nm, T_U16, f->data[1], 2, d2);
+        snprintf(nm, 32, "p%d_exp_cr", pi); gfile_array(&g, nm, T_U16, f->data[2], 2, d2);
+        d2[0] = nx * ny; d2[1] = sizeof(ovhip_sao_ctu);
+        snprintf(nm, 32, "p%d_params", pi); gfile_array(&g, nm, T_U8, mine, 2, d2);
+        fprintf(stderr, "sao.ovg: picture %d %dx%d (%d CTUs)\n", pi, W, H, nx * ny);
+    }
+    gfile_close(&g);
+}
+
 int
 main(int argc, char **argv)
 {
@@ -564,5 +668,6 @@ main(int argc, char **argv)
     if (!only || !strcmp(only, "itx")) gen_itx(dir);
     if (!only || !strcmp(only, "mc"))  gen_mc(dir);
     if (!only || !strcmp(only, "dbf")) gen_dbf(dir);
+    if (!only || !strcmp(only, "sao")) gen_sao(dir);
     return 0;
 }

@@ -79,3 +79,17 @@ def dbf_cases():
                     HostPic(w, h, g[f"p{pi}_exp_y"], g[f"p{pi}_exp_cb"], g[f"p{pi}_exp_cr"])))
         pi += 1
     return out
+
+
+def sao_cases():
+    """[(deblocked HostPic, SAO params (structured array), expected HostPic)] from sao.ovg."""
+    g = golden_io.load("sao.ovg")
+    out, pi = [], 0
+    while f"p{pi}_in_y" in g:
+        y = g[f"p{pi}_in_y"]
+        h, w = y.shape
+        prm = np.frombuffer(g[f"p{pi}_params"].tobytes(), dtype=capi.SAO_CTU_DTYPE).copy()
+        out.append((HostPic(w, h, y, g[f"p{pi}_in_cb"], g[f"p{pi}_in_cr"]), prm,
+                    HostPic(w, h, g[f"p{pi}_exp_y"], g[f"p{pi}_exp_cb"], g[f"p{pi}_exp_cr"])))
+        pi += 1
+    return out

@@ -32,6 +32,8 @@ def lib():
         _lib.oracle_mc.restype = None
         _lib.oracle_dbf.argtypes = [C.POINTER(OPic), vp]
         _lib.oracle_dbf.restype = None
+        _lib.oracle_sao.argtypes = [C.POINTER(OPic), C.POINTER(OPic), vp, C.c_int]
+        _lib.oracle_sao.restype = None
     return _lib
 
 
@@ -86,3 +88,9 @@ def dbf(pic: HostPic, planes: dict):
     s = pic.struct()
     pl, keep = dbf_planes_struct(planes)
     lib().oracle_dbf(C.byref(s), C.addressof(pl))
+
+
+def sao(dst: HostPic, src: HostPic, params: np.ndarray, log2_ctu: int = 7):
+    d, s_ = dst.struct(), src.struct()
+    params = np.ascontiguousarray(params)
+    lib().oracle_sao(C.byref(d), C.byref(s_), params.ctypes.data, log2_ctu)

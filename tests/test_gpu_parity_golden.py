@@ -57,3 +57,15 @@ def test_dbf_gpu_matches_reference(ctx):
         for name, a, b in (("Y", y, exp.y), ("Cb", cb, exp.cb), ("Cr", cr, exp.cr)):
             bad = np.argwhere(a != b)
             assert len(bad) == 0, f"dbf HIP vs reference, picture {i} plane {name}: {len(bad)} differ, first {bad[:6].tolist()}"
+
+
+def test_sao_gpu_matches_reference(ctx):
+    for i, (pic, prm, exp) in enumerate(golden_cases.sao_cases()):
+        src = ctx.upload_pic(pic.y, pic.cb, pic.cr)
+        dst = ctx.new_pic(pic.w, pic.h)
+        ctx.sao(dst, src, ctx.upload(prm))
+        ctx.sync()
+        y, cb, cr = dst.download()
+        for name, a, b in (("Y", y, exp.y), ("Cb", cb, exp.cb), ("Cr", cr, exp.cr)):
+            bad = np.argwhere(a != b)
+            assert len(bad) == 0, f"sao HIP vs reference, picture {i} plane {name}: {len(bad)} differ, first {bad[:6].tolist()}"
