@@ -204,6 +204,36 @@ typedef struct ovhip_sao_ctu {
 } ovhip_sao_ctu;
 
 /* ------------------------------------------------------------------------------------
+ * Adaptive loop filter + cross-component ALF.  Per CTU: what alf.rcn_alf_filter_line reads from
+ * ALFParamsCtu (dec_structures.h:277-283) and alf_info.ctb_cc_alf_filter_idx (ctudec.h:184-215).
+ * Per picture: the coefficient / clip sets exactly as rcn_alf_reconstruct_coeff_APS() expands them
+ * on the host (struct RCNALF, rcn_alf.h:60-66: 16 fixed + 8 APS luma sets of 4 transposes x 25
+ * classes x 13 taps; 8 chroma alternatives x 7) and the CC-ALF coefficients of the two APS
+ * (OVALFData.alf_cc_mapped_coeff[2][4][8], nvcl_structures.h:668).  ovhip_alf_launch() reads the
+ * post-SAO picture `src` (clamped at the picture border = the replicate-padded filter_region,
+ * rcn_ctu.c:361-508) and writes every sample of `dst`.
+ * ---------------------------------------------------------------------------------- */
+#define OVHIP_ALF_LUMA_SET_SIZE (4 * 25 * 13)
+typedef struct ovhip_alf_ctu {
+    uint8_t flags;            /* ctb_alf_flag: bit2 luma, bit1 Cb, bit0 Cr                        */
+    uint8_t luma_set;         /* ctb_alf_idx: 0..15 fixed sets, 16.. APS sets                     */
+    uint8_t cb_alt, cr_alt;   /* chroma alternative filter index                                  */
+    uint8_t cc_cb_idx, cc_cr_idx; /* ctb_cc_alf_filter_idx (0 = off, else filter idx + 1)         */
+    uint8_t pad[2];
+} ovhip_alf_ctu;
+
+typedef struct ovhip_alf_pic {
+    const ovhip_alf_ctu *ctus;    /* DEVICE [ceil(w/ctu) * ceil(h/ctu)], raster                    */
+    const int16_t *luma_coeff;    /* DEVICE [24][OVHIP_ALF_LUMA_SET_SIZE]  RCNALF.filter_coeff_dec  */
+    const int16_t *luma_clip;     /* DEVICE [24][OVHIP_ALF_LUMA_SET_SIZE]  RCNALF.filter_clip_dec   */
+    const int16_t *chroma_coeff;  /* DEVICE [8][7]  RCNALF.chroma_coeff_final                      */
+    const int16_t *chroma_clip;   /* DEVICE [8][7]  RCNALF.chroma_clip_final                       */
+    const int16_t *cc_coeff;      /* DEVICE [2][4][8]  Cb APS / Cr APS alf_cc_mapped_coeff[c]      */
+    uint8_t *class_scratch;       /* DEVICE scratch, ceil(w/4) * ceil(h/4) bytes (class | transpose << 5) */
+    int32_t log2_ctu_s;
+} ovhip_alf_pic;
+
+/* ------------------------------------------------------------------------------------
  * Recorder (host side, pure C, usable without a GPU).
  * ---------------------------------------------------------------------------------- */
 typedef struct ovhip_recorder ovhip_recorder;
@@ -308,6 +338,8 @@ int  ovhip_dbf_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_dbf_plan
 /* d_params: DEVICE array of ceil(w/ctu)*ceil(h/ctu) entries.  dst and src must not alias. */
 int  ovhip_sao_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *src,
                       const ovhip_sao_ctu *d_params, int32_t log2_ctu_s);
+/* Classification + luma / chroma ALF + CC-ALF.  dst and src must not alias. */
+int  ovhip_alf_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *src, const ovhip_alf_pic *alf);
 
 #ifdef __cplusplus
 }

@@ -83,6 +83,20 @@ SAO_CTU_DTYPE = np.dtype([("type", "u1", 3), ("band_position", "u1", 3), ("eo_cl
                           ("offset_val", "<i2", (3, 5)), ("pad2", "u1", 2)])
 assert SAO_CTU_DTYPE.itemsize == 44
 
+ALF_CTU_DTYPE = np.dtype([("flags", "u1"), ("luma_set", "u1"), ("cb_alt", "u1"), ("cr_alt", "u1"),
+                          ("cc_cb_idx", "u1"), ("cc_cr_idx", "u1"), ("pad", "u1", 2)])
+ALF_LUMA_SET_SIZE = 4 * 25 * 13
+
+
+class AlfPic(C.Structure):
+    _fields_ = [("ctus", C.c_void_p), ("luma_coeff", C.c_void_p), ("luma_clip", C.c_void_p),
+                ("chroma_coeff", C.c_void_p), ("chroma_clip", C.c_void_p), ("cc_coeff", C.c_void_p),
+                ("class_scratch", C.c_void_p), ("log2_ctu_s", C.c_int32)]
+
+
+ALF_TABLES = (("ctus", ALF_CTU_DTYPE), ("luma_coeff", np.int16), ("luma_clip", np.int16), ("chroma_coeff", np.int16),
+              ("chroma_clip", np.int16), ("cc_coeff", np.int16))
+
 DBF_CTU_SIZE = 8 * (49 * 6 + 33 * 12) + 3 * 34 * 33 + 2 * 2 + 2 + 3 + 2 + 1 + 4 * 2
 DBF_CTU_SIZE = (DBF_CTU_SIZE + 7) & ~7          # struct alignment (uint64 members)
 DBF_PLANE_NAMES = ("luma_v", "luma_h", "cb_v", "cr_v", "cb_h", "cr_h")
@@ -134,6 +148,7 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_rec_dbf_planes": (C.c_int, [vp, P(DbfPlanes)]),
         "ovhip_dbf_launch": (C.c_int, [vp, P(Pic), P(DbfPlanes)]),
         "ovhip_sao_launch": (C.c_int, [vp, P(Pic), P(Pic), vp, i32]),
+        "ovhip_alf_launch": (C.c_int, [vp, P(Pic), P(Pic), P(AlfPic)]),
         "ovhip_rec_tb_cmds": (vp, [vp, P(C.c_size_t)]),
         "ovhip_rec_coefs": (vp, [vp, P(C.c_size_t)]),
         "ovhip_rec_mc_units": (vp, [vp, P(C.c_size_t)]),
@@ -165,7 +180,7 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
 
 EXPORTED_SYMBOLS = [
     "ovhip_abi_version", "ovhip_rec_create", "ovhip_rec_destroy", "ovhip_rec_reset", "ovhip_rec_tu",
-    "ovhip_rec_pu", "ovhip_rec_dbf_ctu", "ovhip_rec_dbf_planes", "ovhip_dbf_launch", "ovhip_sao_launch", "ovhip_rec_tb_cmds", "ovhip_rec_coefs", "ovhip_rec_mc_units", "ovhip_ctx_create",
+    "ovhip_rec_pu", "ovhip_rec_dbf_ctu", "ovhip_rec_dbf_planes", "ovhip_dbf_launch", "ovhip_sao_launch", "ovhip_alf_launch", "ovhip_rec_tb_cmds", "ovhip_rec_coefs", "ovhip_rec_mc_units", "ovhip_ctx_create",
     "ovhip_ctx_destroy", "ovhip_ctx_sync", "ovhip_last_error", "ovhip_ctx_stream", "ovhip_malloc",
     "ovhip_free", "ovhip_h2d", "ovhip_d2h", "ovhip_pic_alloc", "ovhip_pic_free", "ovhip_pic_upload",
     "ovhip_pic_download", "ovhip_itx_launch", "ovhip_mc_launch",

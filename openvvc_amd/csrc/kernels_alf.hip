@@ -1,0 +1,286 @@
+// kernels_alf.hip -- K14 on gfx950: adaptive loop filter (4x4 Laplacian classification, 7x7 luma
+// diamond, 5x5 chroma diamond, virtual-boundary handling) and cross-component ALF.
+//
+// Source = post-SAO picture, destination = output picture (ping-pong), so every tile is
+// independent.  Luma: one 256-thread workgroup per 32x32 tile (a tile never straddles a CTU).  The
+// 38x38 source window (3-sample halo, coordinates clamped at the picture border = the replicate
+// padded filter_region of libovvc/rcn_ctu.c:361-508) is staged once in LDS; 64 lanes classify the
+// tile's 64 4x4 blocks from LDS (8x8 Laplacian windows on the (r+c)-even lattice), then every lane
+// filters 4 consecutive samples of one block row with that block's 13 coefficient/clip pairs.
+// Chroma: 32x32 tile with a 2-sample halo in LDS, 5x5 diamond, then the CC-ALF term (7 luma taps
+// read through L1/L2) added in registers before the single store.
+//
+// Replaces alf.classif, alf.luma[2], alf.chroma[2], alf.ccalf[2] and the driver
+// rcn_alf_filter_line (libovvc/rcn_alf.c:283-1433).  Coefficient / clip sets are the arrays
+// rcn_alf_reconstruct_coeff_APS() builds on the host (struct RCNALF, rcn_alf.h:60-66).
+#include "ovvc_common.hip.h"
+
+namespace {
+
+#define TL 32           /* tile size               */
+#define LH 3            /* luma halo               */
+#define LW (TL + 2 * LH)
+#define CH 2            /* chroma halo             */
+#define CW (TL + 2 * CH)
+
+__device__ __forceinline__ int alf_clipd(int clip, int ref, int a, int b)
+{
+    return ov_clip3(a - ref, -clip, clip) + ov_clip3(b - ref, -clip, clip);
+}
+
+// alf_derive_filter_idx, rcn_alf.c:283-345
+__device__ __forceinline__ void filter_idx(uint32_t sum_h, uint32_t sum_v, uint32_t sum_d, uint32_t sum_b, bool is_vb,
+                                           int &cls, int &tr)
+{
+    const uint32_t scale = is_vb ? 96u : 64u;
+    const int act = min((int)(((sum_h + sum_v) * scale) >> (OV_BD + 4)), 15);
+    // th[] = {0,1,2,2,2,2,2,3,3,3,3,3,3,3,3,4}
+    int c = act == 0 ? 0 : act == 1 ? 1 : act <= 6 ? 2 : act <= 14 ? 3 : 4;
+    uint32_t max_hv, min_hv, max_db, min_db, max_dir, min_dir;
+    int dir_hv, dir_db, main_dir, sec_dir;
+    if (sum_v > sum_h) { max_hv = sum_v; min_hv = sum_h; dir_hv = 1; } else { max_hv = sum_h; min_hv = sum_v; dir_hv = 3; }
+    if (sum_d > sum_b) { max_db = sum_d; min_db = sum_b; dir_db = 0; } else { max_db = sum_b; min_db = sum_d; dir_db = 2; }
+    if (max_db * min_hv > max_hv * min_db) { max_dir = max_db; min_dir = min_db; main_dir = dir_db; sec_dir = dir_hv; }
+    else { max_dir = max_hv; min_dir = min_hv; main_dir = dir_hv; sec_dir = dir_db; }
+    if (max_dir * 2 > 9 * min_dir) c += (((main_dir & 1) << 1) + 2) * 5;
+    else if (max_dir > 2 * min_dir) c += (((main_dir & 1) << 1) + 1) * 5;
+    cls = c;
+    const int k = (main_dir << 1) + (sec_dir >> 1);      // tr_lut = {0,1,0,2,2,3,1,3}
+    tr = (0xDE84 >> (2 * k)) & 3;                        // packed 2-bit LUT
+}
+
+__global__ __launch_bounds__(256) void k_alf_luma(ovhip_pic dst, ovhip_pic src, ovhip_alf_pic alf, int nb_ctu_w)
+{
+    __shared__ uint16_t s_t[LW * LW];
+    __shared__ uint8_t s_cls[64];
+
+    const int W = src.w, H = src.h;
+    const int tx0 = blockIdx.x * TL, ty0 = blockIdx.y * TL;
+    const int tid = threadIdx.x;
+    const int ctu = 1 << alf.log2_ctu_s;
+    const ovhip_alf_ctu c = alf.ctus[(ty0 >> alf.log2_ctu_s) * nb_ctu_w + (tx0 >> alf.log2_ctu_s)];
+    const bool on = c.flags & 4;
+
+    // each lane owns 4 consecutive samples: block b = tid >> 2 (8x8 blocks of 4x4), row r = tid & 3
+    const int b = tid >> 2, r = tid & 3;
+    const int bx = (b & 7) * 4, by = (b >> 3) * 4;
+    const int ox = tx0 + bx, oy = ty0 + by + r;
+
+    if (!on) {          // ALF off for this CTU: plain copy (dst is a separate picture)
+        if (oy < H) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (ox + i < W) dst.y[oy * dst.stride_y + ox + i] = src.y[oy * src.stride_y + ox + i];
+        }
+        return;
+    }
+
+    for (int i = tid; i < LW * LW; i += 256) {
+        const int yy = i / LW, xx = i - yy * LW;
+        const int sy = ov_clip3(ty0 + yy - LH, 0, H - 1), sx = ov_clip3(tx0 + xx - LH, 0, W - 1);
+        s_t[i] = src.y[sy * src.stride_y + sx];
+    }
+    __syncthreads();
+
+    // Virtual boundary as the reference derives it (rcn_alf.c:722, :1346, :1274-1283): CTU-local row
+    // ctu - 4 for a full-height CTU, pic_h for a truncated one (then it only ever matches CTU-local rows
+    // in pictures of a single CTU row); the VB filter variant is selected by check_virtual_bound().
+    const int ctu_y0 = ty0 & ~(ctu - 1);
+    const bool truncated = ctu_y0 + ctu > H;
+    const int vbl = truncated ? H : ctu - 4;
+    const int last_local = (ctu_y0 + (truncated ? H - ctu_y0 : ctu) - 1) & (ctu - 1);
+    const bool req_vb = (last_local < vbl && last_local >= vbl - 4) || (last_local >= vbl && last_local <= vbl + 3);
+    const int vb = ctu_y0 + vbl;               // same boundary in picture rows
+
+    // ---- classification: lanes 0..63, one 4x4 block each ----
+    if (tid < 64) {
+        const int cbx = (tid & 7) * 4, cby = (tid >> 3) * 4;     // tile-local block origin
+        const int py = ty0 + cby;                                // picture row of the block
+        int first = 0, last = 3;
+        bool is_vb = false;
+        if (py == vb - 4) { last = 2; is_vb = true; }
+        if (py == vb)     { first = 1; is_vb = true; }
+        uint32_t sv = 0, sh = 0, sd = 0, sb = 0;
+#define T(x, y) ((int)s_t[((y) + LH) * LW + (x) + LH])
+        for (int k = first; k <= last; ++k) {
+            const int rr = cby - 2 + 2 * k;                      // tile-local first row of the pair
+            int above = rr - 1, below = rr + 2;
+            if (ty0 + rr + 2 == vb) below = rr + 1;
+            if (ty0 + rr == vb)     above = rr;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c0 = cbx - 2 + 2 * q, c1 = c0 + 1;
+                const int y1 = T(c0, rr) << 1, y2 = T(c1, rr + 1) << 1;
+                sv += abs(y1 - T(c0, above) - T(c0, rr + 1)) + abs(y2 - T(c1, rr) - T(c1, below));
+                sh += abs(y1 - T(c0 + 1, rr) - T(c0 - 1, rr)) + abs(y2 - T(c1 + 1, rr + 1) - T(c1 - 1, rr + 1));
+                sd += abs(y1 - T(c0 - 1, above) - T(c0 + 1, rr + 1)) + abs(y2 - T(c1 - 1, rr) - T(c1 + 1, below));
+                sb += abs(y1 - T(c0 - 1, rr + 1) - T(c0 + 1, above)) + abs(y2 - T(c1 - 1, below) - T(c1 + 1, rr));
+            }
+        }
+        int cls, tr;
+        filter_idx(sh, sv, sd, sb, is_vb, cls, tr);
+        s_cls[tid] = (uint8_t)(cls | (tr << 5));
+    }
+    __syncthreads();
+
+    if (oy >= H) return;
+    const int ct = s_cls[b];
+    const int cls = ct & 31, tr = ct >> 5;
+    const int16_t *f = alf.luma_coeff + c.luma_set * OVHIP_ALF_LUMA_SET_SIZE + tr * 25 * 13 + cls * 13;
+    const int16_t *cl = alf.luma_clip + c.luma_set * OVHIP_ALF_LUMA_SET_SIZE + tr * 25 * 13 + cls * 13;
+    int fc[12], cc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { fc[i] = f[i]; cc[i] = cl[i]; }
+
+    int d = 3;
+    bool near = false;
+    if (req_vb) {
+        if (oy < vb && oy >= vb - 4) d = vb - 1 - oy;
+        else if (oy >= vb && oy <= vb + 3) d = oy - vb;
+        near = (oy == vb - 1) || (oy == vb);
+    }
+    const int o1 = min(d, 1), o2 = min(d, 2), o3 = min(d, 3);
+    const int ly = by + r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int lx = bx + i;
+        const int cur = T(lx, ly);
+        int sum = 0;
+        sum += fc[0] * alf_clipd(cc[0], cur, T(lx, ly + o3), T(lx, ly - o3));
+        sum += fc[1] * alf_clipd(cc[1], cur, T(lx + 1, ly + o2), T(lx - 1, ly - o2));
+        sum += fc[2] * alf_clipd(cc[2], cur, T(lx, ly + o2), T(lx, ly - o2));
+        sum += fc[3] * alf_clipd(cc[3], cur, T(lx - 1, ly + o2), T(lx + 1, ly - o2));
+        sum += fc[4] * alf_clipd(cc[4], cur, T(lx + 2, ly + o1), T(lx - 2, ly - o1));
+        sum += fc[5] * alf_clipd(cc[5], cur, T(lx + 1, ly + o1), T(lx - 1, ly - o1));
+        sum += fc[6] * alf_clipd(cc[6], cur, T(lx, ly + o1), T(lx, ly - o1));
+        sum += fc[7] * alf_clipd(cc[7], cur, T(lx - 1, ly + o1), T(lx + 1, ly - o1));
+        sum += fc[8] * alf_clipd(cc[8], cur, T(lx - 2, ly + o1), T(lx + 2, ly - o1));
+        sum += fc[9] * alf_clipd(cc[9], cur, T(lx + 3, ly), T(lx - 3, ly));
+        sum += fc[10] * alf_clipd(cc[10], cur, T(lx + 2, ly), T(lx - 2, ly));
+        sum += fc[11] * alf_clipd(cc[11], cur, T(lx + 1, ly), T(lx - 1, ly));
+        sum = near ? (sum + 512) >> 10 : (sum + 64) >> 7;
+        if (ox + i < W) dst.y[oy * dst.stride_y + ox + i] = (uint16_t)ov_clip_bd(sum + cur);
+    }
+#undef T
+}
+
+// blockIdx.z: 0 Cb, 1 Cr
+__global__ __launch_bounds__(256) void k_alf_chroma(ovhip_pic dst, ovhip_pic src, ovhip_alf_pic alf, int nb_ctu_w)
+{
+    __shared__ uint16_t s_t[CW * CW];
+    const int comp = 1 + blockIdx.z;
+    const int W = src.w, H = src.h, Wc = W >> 1, Hc = H >> 1;
+    const int tx0 = blockIdx.x * TL, ty0 = blockIdx.y * TL;
+    const int tid = threadIdx.x;
+    const int ctu = 1 << alf.log2_ctu_s, ctuc = ctu >> 1;
+    const ovhip_alf_ctu c = alf.ctus[((ty0 * 2) >> alf.log2_ctu_s) * nb_ctu_w + ((tx0 * 2) >> alf.log2_ctu_s)];
+    const bool on = c.flags & (comp == 1 ? 2 : 1);
+    const int cc_idx = comp == 1 ? c.cc_cb_idx : c.cc_cr_idx;
+    const uint16_t *sp = comp == 1 ? src.cb : src.cr;
+    uint16_t *dp = comp == 1 ? dst.cb : dst.cr;
+
+    if (on) {
+        for (int i = tid; i < CW * CW; i += 256) {
+            const int yy = i / CW, xx = i - yy * CW;
+            const int sy = ov_clip3(ty0 + yy - CH, 0, Hc - 1), sx = ov_clip3(tx0 + xx - CH, 0, Wc - 1);
+            s_t[i] = sp[sy * src.stride_c + sx];
+        }
+        __syncthreads();
+    }
+
+    const int ctu_y0 = (ty0 * 2) & ~(ctu - 1);           // luma row of the CTU
+    const bool truncated = ctu_y0 + ctu > H;
+    int fc[6], cl[6];
+    if (on) {
+        const int alt = comp == 1 ? c.cb_alt : c.cr_alt;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { fc[i] = alf.chroma_coeff[alt * 7 + i]; cl[i] = alf.chroma_clip[alt * 7 + i]; }
+    }
+    int cf[7];
+    if (cc_idx) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) cf[i] = alf.cc_coeff[((comp - 1) * 4 + (cc_idx - 1)) * 8 + i];
+    }
+
+    // lane: 4 consecutive samples of one row: row = tid >> 3 (0..31), x segment = (tid & 7) * 4
+    const int ly = tid >> 3, lx0 = (tid & 7) * 4;
+    const int oy = ty0 + ly;
+    if (oy >= Hc) return;
+#define T(x, y) ((int)s_t[((y) + CH) * CW + (x) + CH])
+    int o1 = 1, o2 = 2;
+    bool near = false;
+    if (on) {
+        // alf_filter_cVB (always the VB variant: rcn_alf.c:1378-1386), vb compared with the CTU-local chroma row
+        const int vb = truncated ? H / 2 : (ctu - 4) / 2;
+        const int yl = oy & (ctuc - 1);
+        int d = 2;
+        if (yl < vb && yl >= vb - 2) d = vb - 1 - yl;
+        else if (yl >= vb && yl <= vb + 1) d = yl - vb;
+        near = (yl == vb - 1) || (yl == vb);
+        o1 = min(d, 1); o2 = min(d, 2);
+    }
+    // CC-ALF vertical offsets (rcn_alf.c:758-772); vbPos is in LUMA rows for full CTUs, pic_h/2 for truncated ones
+    int r1 = 1, r2 = -1, r3 = 2;
+    if (cc_idx) {
+        const int vbpos = truncated ? H / 2 : ctu - 4;
+        const int pos = (oy << 1) & (ctu - 1);
+        if (pos == vbpos - 2 || pos == vbpos + 1) r3 = r1;
+        else if (pos == vbpos - 1 || pos == vbpos) r1 = r2 = r3 = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int lx = lx0 + i, ox = tx0 + lx;
+        if (ox >= Wc) break;
+        int out;
+        if (on) {
+            const int cur = T(lx, ly);
+            int sum = 0;
+            sum += fc[0] * alf_clipd(cl[0], cur, T(lx, ly + o2), T(lx, ly - o2));
+            sum += fc[1] * alf_clipd(cl[1], cur, T(lx + 1, ly + o1), T(lx - 1, ly - o1));
+            sum += fc[2] * alf_clipd(cl[2], cur, T(lx, ly + o1), T(lx, ly - o1));
+            sum += fc[3] * alf_clipd(cl[3], cur, T(lx - 1, ly + o1), T(lx + 1, ly - o1));
+            sum += fc[4] * alf_clipd(cl[4], cur, T(lx + 2, ly), T(lx - 2, ly));
+            sum += fc[5] * alf_clipd(cl[5], cur, T(lx + 1, ly), T(lx - 1, ly));
+            sum = near ? (sum + 512) >> 10 : (sum + 64) >> 7;
+            out = ov_clip_bd(sum + cur);
+        } else {
+            out = sp[oy * src.stride_c + ox];
+        }
+        if (cc_idx) {
+            const int Lx = ox << 1, Ly = oy << 1;
+#define LU(dx, dy) ((int)src.y[ov_clip3(Ly + (dy), 0, H - 1) * src.stride_y + ov_clip3(Lx + (dx), 0, W - 1)])
+            const int cy = LU(0, 0);
+            int sum = 0;
+            sum += cf[0] * (LU(0, r2) - cy);
+            sum += cf[1] * (LU(-1, 0) - cy);
+            sum += cf[2] * (LU(1, 0) - cy);
+            sum += cf[3] * (LU(-1, r1) - cy);
+            sum += cf[4] * (LU(0, r1) - cy);
+            sum += cf[5] * (LU(1, r1) - cy);
+            sum += cf[6] * (LU(0, r3) - cy);
+#undef LU
+            sum = (sum + 64) >> 7;
+            sum = ov_clip_bd(sum + (1 << OV_BD >> 1));
+            out = ov_clip_bd(sum + out - (1 << OV_BD >> 1));
+        }
+        dp[oy * dst.stride_c + ox] = (uint16_t)out;
+    }
+#undef T
+}
+
+} // namespace
+
+extern "C" int ovhip_alf_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *src, const ovhip_alf_pic *alf)
+{
+    if (!ctx || !dst || !src || !alf) return OVHIP_EINVAL;
+    if (dst->w != src->w || dst->h != src->h || dst->y == src->y || alf->log2_ctu_s < 6 || alf->log2_ctu_s > 7 ||
+        !alf->ctus || !alf->luma_coeff || !alf->luma_clip || !alf->chroma_coeff || !alf->chroma_clip || !alf->cc_coeff)
+        return ov_fail(ctx, OVHIP_EINVAL, "ovhip_alf_launch: bad pictures / parameter tables", hipSuccess);
+    const int nb_ctu_w = (src->w + (1 << alf->log2_ctu_s) - 1) >> alf->log2_ctu_s;
+    dim3 gl((src->w + TL - 1) / TL, (src->h + TL - 1) / TL);
+    hipLaunchKernelGGL(k_alf_luma, gl, dim3(256), 0, ctx->stream, *dst, *src, *alf, nb_ctu_w);
+    OV_LAUNCH_CHECK(ctx, "k_alf_luma");
+    dim3 gc((src->w / 2 + TL - 1) / TL, (src->h / 2 + TL - 1) / TL, 2);
+    hipLaunchKernelGGL(k_alf_chroma, gc, dim3(256), 0, ctx->stream, *dst, *src, *alf, nb_ctu_w);
+    OV_LAUNCH_CHECK(ctx, "k_alf_chroma");
+    return OVHIP_OK;
+}

@@ -74,6 +74,9 @@ class Context:
     def sao(self, dst: "DevPic", src: "DevPic", params: "DevBuf", log2_ctu: int = 7):
         self._chk(self.lib.ovhip_sao_launch(self.h, C.byref(dst.s), C.byref(src.s), params.ptr, log2_ctu), "sao_launch")
 
+    def alf(self, dst: "DevPic", src: "DevPic", alf: "DevAlf"):
+        self._chk(self.lib.ovhip_alf_launch(self.h, C.byref(dst.s), C.byref(src.s), C.byref(alf.s)), "alf_launch")
+
     def mc(self, dst: "DevPic", refs: list, units: "DevBuf", lmcs_fwd: "DevBuf | None" = None, n: int | None = None):
         n = units.count if n is None else n
         arr = (capi.Pic * len(refs))(*[r.s for r in refs])
@@ -92,6 +95,21 @@ class DevDbfPlanes:
 
     def free(self):
         for b in self.bufs.values():
+            b.free()
+
+
+class DevAlf:
+    """ALF parameter tables resident on the device (ovhip_alf_pic with device pointers).
+    `alf`: dict with ctus (ALF_CTU_DTYPE), luma_coeff/luma_clip [24,1300], chroma_coeff/chroma_clip [8,7], cc_coeff [2,4,8]."""
+
+    def __init__(self, ctx: "Context", alf: dict, w: int, h: int, log2_ctu: int = 7):
+        self.bufs = {k: ctx.upload(np.ascontiguousarray(alf[k], dtype=dt).ravel()) for k, dt in capi.ALF_TABLES}
+        self.scratch = ctx.upload(np.zeros(((w + 3) // 4) * ((h + 3) // 4), np.uint8))
+        self.s = capi.AlfPic(*[self.bufs[k].ptr for k, _ in capi.ALF_TABLES], self.scratch.ptr, log2_ctu)
+        self.nbytes = sum(b.nbytes for b in self.bufs.values())
+
+    def free(self):
+        for b in list(self.bufs.values()) + [self.scratch]:
             b.free()
 
 

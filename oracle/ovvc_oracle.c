@@ -570,3 +570,202 @@ void oracle_sao(const oracle_pic *dst, const oracle_pic *src, const ovhip_sao_ct
         }
     }
 }
+
+/* ====================================================================================
+ * K14: adaptive loop filter (classification, luma 7x7, chroma 5x5) + CC-ALF
+ * ================================================================================== */
+typedef struct oracle_alf {       /* host twin of ovhip_alf_pic */
+    const ovhip_alf_ctu *ctus;
+    const int16_t *luma_coeff, *luma_clip, *chroma_coeff, *chroma_clip, *cc_coeff;
+    uint8_t *class_scratch;
+    int32_t log2_ctu_s;
+} oracle_alf;
+
+static inline int px(const uint16_t *p, int stride, int w, int h, int x, int y)
+{
+    return p[clip3i(y, 0, h - 1) * stride + clip3i(x, 0, w - 1)];
+}
+
+/* alf_derive_filter_idx, rcn_alf.c:283-345 */
+static void alf_filter_idx(uint32_t sum_h, uint32_t sum_v, uint32_t sum_d, uint32_t sum_b, int is_vb, int *cls, int *tr)
+{
+    static const int th[16] = { 0, 1, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 4 };
+    static const uint8_t tr_lut[8] = { 0, 1, 0, 2, 2, 3, 1, 3 };
+    const uint32_t scale = is_vb ? 96 : 64;
+    int c = th[clip3i((int)(((sum_h + sum_v) * scale) >> (BD + 4)), 0, 15)];
+    uint32_t max_hv, min_hv, max_db, min_db, max_dir, min_dir;
+    int dir_hv, dir_db, main_dir, sec_dir;
+    if (sum_v > sum_h) { max_hv = sum_v; min_hv = sum_h; dir_hv = 1; } else { max_hv = sum_h; min_hv = sum_v; dir_hv = 3; }
+    if (sum_d > sum_b) { max_db = sum_d; min_db = sum_b; dir_db = 0; } else { max_db = sum_b; min_db = sum_d; dir_db = 2; }
+    if (max_db * min_hv > max_hv * min_db) { max_dir = max_db; min_dir = min_db; main_dir = dir_db; sec_dir = dir_hv; }
+    else { max_dir = max_hv; min_dir = min_hv; main_dir = dir_hv; sec_dir = dir_db; }
+    if (max_dir * 2 > 9 * min_dir) c += (((main_dir & 1) << 1) + 2) * 5;
+    else if (max_dir > 2 * min_dir) c += (((main_dir & 1) << 1) + 1) * 5;
+    *cls = c;
+    *tr = tr_lut[(main_dir << 1) + (sec_dir >> 1)];
+}
+
+/* Laplacians of one row pair (r, r+1) over the 8 columns bx-2..bx+5, sub-sampled on the (r+c) even
+ * lattice; `above` / `below` are the rows used as vertical neighbours of r and r+1
+ * (rcn_alf_classif_{vbnd,novbnd}, rcn_alf.c:347-704) */
+static void alf_lap_pair(const uint16_t *p, int stride, int w, int h, int bx, int r, int above, int below, uint32_t s[4])
+{
+    for (int k = 0; k < 4; ++k) {
+        int c0 = bx - 2 + 2 * k, c1 = c0 + 1;
+        int y1 = px(p, stride, w, h, c0, r) << 1, y2 = px(p, stride, w, h, c1, r + 1) << 1;
+        s[0] += abs(y1 - px(p, stride, w, h, c0, above) - px(p, stride, w, h, c0, r + 1))            /* V */
+              + abs(y2 - px(p, stride, w, h, c1, r) - px(p, stride, w, h, c1, below));
+        s[1] += abs(y1 - px(p, stride, w, h, c0 + 1, r) - px(p, stride, w, h, c0 - 1, r))            /* H */
+              + abs(y2 - px(p, stride, w, h, c1 + 1, r + 1) - px(p, stride, w, h, c1 - 1, r + 1));
+        s[2] += abs(y1 - px(p, stride, w, h, c0 - 1, above) - px(p, stride, w, h, c0 + 1, r + 1))    /* D0 */
+              + abs(y2 - px(p, stride, w, h, c1 - 1, r) - px(p, stride, w, h, c1 + 1, below));
+        s[3] += abs(y1 - px(p, stride, w, h, c0 - 1, r + 1) - px(p, stride, w, h, c0 + 1, above))    /* D1 */
+              + abs(y2 - px(p, stride, w, h, c1 - 1, below) - px(p, stride, w, h, c1 + 1, r));
+    }
+}
+
+/* vb: virtual-boundary row in CTU-LOCAL luma rows as the reference derives it -- ctu_h - 4 for a
+ * full-height CTU, pic_h for a truncated one (rcn_alf.c:722, :1346); it is compared with CTU-local
+ * rows, so for truncated CTUs it only ever matches in pictures of a single CTU row. */
+static void alf_classify_block(const oracle_pic *src, int bx, int by, int vb, int ctu_y0, int *cls, int *tr)
+{
+    const int w = src->w, h = src->h;
+    const int lby = by - ctu_y0;
+    uint32_t s[4] = { 0, 0, 0, 0 };
+    int first = 0, last = 3, is_vb = 0;
+    if (lby == vb - 4) { last = 2; is_vb = 1; }
+    if (lby == vb)     { first = 1; is_vb = 1; }
+    for (int k = first; k <= last; ++k) {
+        const int r = by - 2 + 2 * k;
+        int above = r - 1, below = r + 2;
+        if (r - ctu_y0 + 2 == vb) below = r + 1;       /* pair (vb-2, vb-1): row vb is not available */
+        if (r - ctu_y0 == vb)     above = r;           /* pair (vb, vb+1): row vb-1 is not available */
+        alf_lap_pair(src->y, src->stride_y, w, h, bx, r, above, below, s);
+    }
+    alf_filter_idx(s[1], s[0], s[2], s[3], is_vb, cls, tr);
+}
+
+static inline int alf_clipd(int clip, int ref, int a, int b)
+{
+    return clip3i(a - ref, -clip, clip) + clip3i(b - ref, -clip, clip);
+}
+
+/* rcn_alf_filter_line over the whole picture, rcn_alf.c:1285-1433 */
+void oracle_alf_run(const oracle_pic *dst, const oracle_pic *src, const oracle_alf *a)
+{
+    const int ctu = 1 << a->log2_ctu_s, W = src->w, H = src->h;
+    const int nb_ctu_w = (W + ctu - 1) / ctu;
+    /* ---- luma ---- */
+    for (int y = 0; y < H; ++y) {
+        for (int x = 0; x < W; ++x) {
+            const ovhip_alf_ctu *c = &a->ctus[(y / ctu) * nb_ctu_w + x / ctu];
+            const int cur = src->y[y * src->stride_y + x];
+            int out = cur;
+            if (c->flags & 4) {
+                const int ctu_y0 = (y / ctu) * ctu, truncated = ctu_y0 + ctu > H;
+                const int vb = truncated ? H : ctu - 4;
+                const int ctu_h = truncated ? H - ctu_y0 : ctu;
+                const int last_local = (ctu_y0 + ctu_h - 1) & (ctu - 1);
+                /* check_virtual_bound, rcn_alf.c:1274-1283: selects alf.luma[1] (VB variant) */
+                const int req_vb = (last_local < vb && last_local >= vb - 4) || (last_local >= vb && last_local <= vb + 3);
+                int cls, tr;
+                alf_classify_block(src, x & ~3, y & ~3, vb, ctu_y0, &cls, &tr);
+                const int16_t *f = a->luma_coeff + c->luma_set * OVHIP_ALF_LUMA_SET_SIZE + tr * 25 * 13 + cls * 13;
+                const int16_t *cl = a->luma_clip + c->luma_set * OVHIP_ALF_LUMA_SET_SIZE + tr * 25 * 13 + cls * 13;
+                int d = 3, near = 0;
+                if (req_vb) {
+                    const int ly = y - ctu_y0;
+                    if (ly < vb && ly >= vb - 4) d = vb - 1 - ly;
+                    else if (ly >= vb && ly <= vb + 3) d = ly - vb;
+                    near = (ly == vb - 1) || (ly == vb);
+                }
+                const int o1 = d < 1 ? d : 1, o2 = d < 2 ? d : 2, o3 = d < 3 ? d : 3;
+                const uint16_t *p = src->y; const int st = src->stride_y;
+#define L(dx, dy) px(p, st, W, H, x + (dx), y + (dy))
+                int sum = 0;
+                sum += f[0] * alf_clipd(cl[0], cur, L(0, o3), L(0, -o3));
+                sum += f[1] * alf_clipd(cl[1], cur, L(1, o2), L(-1, -o2));
+                sum += f[2] * alf_clipd(cl[2], cur, L(0, o2), L(0, -o2));
+                sum += f[3] * alf_clipd(cl[3], cur, L(-1, o2), L(1, -o2));
+                sum += f[4] * alf_clipd(cl[4], cur, L(2, o1), L(-2, -o1));
+                sum += f[5] * alf_clipd(cl[5], cur, L(1, o1), L(-1, -o1));
+                sum += f[6] * alf_clipd(cl[6], cur, L(0, o1), L(0, -o1));
+                sum += f[7] * alf_clipd(cl[7], cur, L(-1, o1), L(1, -o1));
+                sum += f[8] * alf_clipd(cl[8], cur, L(-2, o1), L(2, -o1));
+                sum += f[9] * alf_clipd(cl[9], cur, L(3, 0), L(-3, 0));
+                sum += f[10] * alf_clipd(cl[10], cur, L(2, 0), L(-2, 0));
+                sum += f[11] * alf_clipd(cl[11], cur, L(1, 0), L(-1, 0));
+#undef L
+                sum = near ? (sum + 512) >> 10 : (sum + 64) >> 7;
+                out = clip_bd(sum + cur);
+            }
+            dst->y[y * dst->stride_y + x] = (uint16_t)out;
+        }
+    }
+    /* ---- chroma + CC-ALF ---- */
+    const int Wc = W / 2, Hc = H / 2, ctuc = ctu / 2;
+    for (int comp = 1; comp < 3; ++comp) {
+        const uint16_t *p = comp == 1 ? src->cb : src->cr;
+        uint16_t *o = comp == 1 ? dst->cb : dst->cr;
+        const int st = src->stride_c;
+        for (int y = 0; y < Hc; ++y) {
+            for (int x = 0; x < Wc; ++x) {
+                const ovhip_alf_ctu *c = &a->ctus[(y / ctuc) * nb_ctu_w + x / ctuc];
+                const int ctu_y0 = (y / ctuc) * ctu;                /* luma row of the CTU */
+                const int truncated = ctu_y0 + ctu > H;
+                const int cur = p[y * st + x];
+                int out = cur;
+                if (c->flags & (comp == 1 ? 2 : 1)) {
+                    const int alt = comp == 1 ? c->cb_alt : c->cr_alt;
+                    const int16_t *f = a->chroma_coeff + alt * 7, *cl = a->chroma_clip + alt * 7;
+                    const int vb = truncated ? H / 2 : (ctu - 4) / 2;
+                    const int ly = y & (ctuc - 1);
+                    int d = 2;
+                    if (ly < vb && ly >= vb - 2) d = vb - 1 - ly;
+                    else if (ly >= vb && ly <= vb + 1) d = ly - vb;
+                    const int near = (ly == vb - 1) || (ly == vb);
+                    const int o1 = d < 1 ? d : 1, o2 = d < 2 ? d : 2;
+#define Cc(dx, dy) px(p, st, Wc, Hc, x + (dx), y + (dy))
+                    int sum = 0;
+                    sum += f[0] * alf_clipd(cl[0], cur, Cc(0, o2), Cc(0, -o2));
+                    sum += f[1] * alf_clipd(cl[1], cur, Cc(1, o1), Cc(-1, -o1));
+                    sum += f[2] * alf_clipd(cl[2], cur, Cc(0, o1), Cc(0, -o1));
+                    sum += f[3] * alf_clipd(cl[3], cur, Cc(-1, o1), Cc(1, -o1));
+                    sum += f[4] * alf_clipd(cl[4], cur, Cc(2, 0), Cc(-2, 0));
+                    sum += f[5] * alf_clipd(cl[5], cur, Cc(1, 0), Cc(-1, 0));
+#undef Cc
+                    sum = near ? (sum + 512) >> 10 : (sum + 64) >> 7;
+                    out = clip_bd(sum + cur);
+                }
+                const int cc = comp == 1 ? c->cc_cb_idx : c->cc_cr_idx;
+                if (cc) {
+                    /* cc_alf_filterBlk, rcn_alf.c:740-804; vbPos is NOT divided by the chroma scale in the
+                     * non-truncated case (rcn_alf.c:1417) and is compared with the CTU-local LUMA row */
+                    const int16_t *f = a->cc_coeff + ((comp - 1) * 4 + (cc - 1)) * 8;
+                    const int vbpos = truncated ? H / 2 : ctu - 4;
+                    const int pos = (y << 1) & (ctu - 1);
+                    int r1 = 1, r2 = -1, r3 = 2;
+                    if (pos == vbpos - 2 || pos == vbpos + 1) r3 = r1;
+                    else if (pos == vbpos - 1 || pos == vbpos) r1 = r2 = r3 = 0;
+                    const int lx = x << 1, lyy = y << 1;
+#define Ly(dx, dy) px(src->y, src->stride_y, W, H, lx + (dx), lyy + (dy))
+                    const int cy = Ly(0, 0);
+                    int sum = 0;
+                    sum += f[0] * (Ly(0, r2) - cy);
+                    sum += f[1] * (Ly(-1, 0) - cy);
+                    sum += f[2] * (Ly(1, 0) - cy);
+                    sum += f[3] * (Ly(-1, r1) - cy);
+                    sum += f[4] * (Ly(0, r1) - cy);
+                    sum += f[5] * (Ly(1, r1) - cy);
+                    sum += f[6] * (Ly(0, r3) - cy);
+#undef Ly
+                    sum = (sum + 64) >> 7;
+                    sum = clip_bd(sum + (1 << BD >> 1));
+                    sum += out - (1 << BD >> 1);
+                    out = clip_bd(sum);
+                }
+                o[y * dst->stride_c + x] = (uint16_t)out;
+            }
+        }
+    }
+}

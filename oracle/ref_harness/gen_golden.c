@@ -660,6 +660,109 @@ gen_sao(const char *dir)
     gfile_close(&g);
 }
 
+
+/* ====================================================================================== ALF */
+static void
+rand_alf_aps(OVALFData *a)
+{
+    memset(a, 0, sizeof(*a));
+    int nf = rnd_range(1, 25);
+    a->alf_luma_num_filters_signalled_minus1 = nf - 1;
+    a->alf_luma_clip_flag = rnd_range(0, 1);
+    for (int c = 0; c < 25; ++c) a->alf_luma_coeff_delta_idx[c] = rnd_range(0, nf - 1);
+    for (int f = 0; f < 25; ++f) for (int k = 0; k < 12; ++k) {
+        a->alf_luma_coeff[f][k] = (int16_t)(rnd_range(0, 7) == 0 ? rnd_range(-127, 127) : rnd_range(-24, 24));
+        a->alf_luma_clip_idx[f][k] = rnd_range(0, 3);
+    }
+    a->alf_chroma_clip_flag = rnd_range(0, 1);
+    a->alf_chroma_num_alt_filters_minus1 = rnd_range(0, 7);
+    for (int f = 0; f < 8; ++f) for (int k = 0; k < 6; ++k) {
+        a->alf_chroma_coeff[f][k] = (int16_t)(rnd_range(0, 7) == 0 ? rnd_range(-127, 127) : rnd_range(-24, 24));
+        a->alf_chroma_clip_idx[f][k] = rnd_range(0, 3);
+    }
+    a->alf_cc_cb_filters_signalled_minus1 = 3; a->alf_cc_cr_filters_signalled_minus1 = 3;
+    for (int c = 0; c < 2; ++c) for (int f = 0; f < 4; ++f) for (int k = 0; k < 7; ++k) {
+        int m = rnd_range(0, 7);
+        int v = m == 0 ? 0 : 1 << (m - 1);
+        a->alf_cc_mapped_coeff[c][f][k] = (int16_t)(rnd_range(0, 1) ? -v : v);
+    }
+}
+
+static void
+gen_alf(const char *dir)
+{
+    enum { NPIC = 3 };
+    static const int PW[NPIC] = { 304, 264, 136 }, PH[NPIC] = { 200, 256, 72 };
+    gfile g = gfile_open(dir, "alf.ovg");
+    g_seed = 0x266 + 4;
+    for (int pi = 0; pi < NPIC; ++pi) {
+        const int W = PW[pi], H = PH[pi], nx = (W + 127) / 128, ny = (H + 127) / 128;
+        OVFrame *f = harness_frame(W, H);
+        uint16_t *py = f->data[0];
+        for (int i = 0; i < W * H; i += 13) py[i] = (uint16_t)rnd_range(0, 1023);
+        char nm[32];
+        uint32_t d2[2] = { H, W };
+        snprintf(nm, 32, "p%d_in_y", pi); gfile_array(&g, nm, T_U16, f->data[0], 2, d2);
+        d2[0] = H / 2; d2[1] = W / 2;
+        snprintf(nm, 32, "p%d_in_cb", pi); gfile_array(&g, nm, T_U16, f->data[1], 2, d2);
+        snprintf(nm, 32, "p%d_in_cr", pi); gfile_array(&g, nm, T_U16, f->data[2], 2, d2);
+
+        OVCTUDec *c = ref_new_ctudec(0, 0);
+        c->pic_w = W; c->pic_h = H;
+        c->rcn_ctx.frame_start = f;
+        harness_alloc_filter_buffers(&c->rcn_ctx, nx, 3, 7);
+        struct ALFInfo *ai = &c->alf_info;
+        static OVALFData aps[5];
+        for (int i = 0; i < 5; ++i) rand_alf_aps(&aps[i]);
+        ai->alf_luma_enabled_flag = ai->alf_cb_enabled_flag = ai->alf_cr_enabled_flag = 1;
+        ai->cc_alf_cb_enabled_flag = ai->cc_alf_cr_enabled_flag = 1;
+        ai->num_alf_aps_ids_luma = 2;
+        ai->aps_alf_data[0] = &aps[0]; ai->aps_alf_data[1] = &aps[1];
+        ai->aps_alf_data_c = &aps[2]; ai->aps_cc_alf_data_cb = &aps[3]; ai->aps_cc_alf_data_cr = &aps[4];
+        ai->ctb_alf_params = calloc(nx * ny, sizeof(ALFParamsCtu));
+        ai->ctb_cc_alf_filter_idx[0] = calloc(nx * ny, 1); ai->ctb_cc_alf_filter_idx[1] = calloc(nx * ny, 1);
+        c->rcn_funcs.alf.rcn_alf_reconstruct_coeff_APS(&ai->rcn_alf, c, 1, 1);
+        ovhip_alf_ctu *mine = calloc(nx * ny, sizeof(*mine));
+        for (int i = 0; i < nx * ny; ++i) {
+            ALFParamsCtu *p = &ai->ctb_alf_params[i];
+            p->ctb_alf_flag = rnd_range(0, 9) < 8 ? (rnd_range(0, 7) | (rnd_range(0, 2) ? 4 : 0)) : 0;
+            p->ctb_alf_idx = rnd_range(0, 17);
+            p->cb_alternative = rnd_range(0, aps[2].alf_chroma_num_alt_filters_minus1);
+            p->cr_alternative = rnd_range(0, aps[2].alf_chroma_num_alt_filters_minus1);
+            ai->ctb_cc_alf_filter_idx[0][i] = rnd_range(0, 4);
+            ai->ctb_cc_alf_filter_idx[1][i] = rnd_range(0, 4);
+            mine[i].flags = p->ctb_alf_flag; mine[i].luma_set = p->ctb_alf_idx;
+            mine[i].cb_alt = p->cb_alternative; mine[i].cr_alt = p->cr_alternative;
+            mine[i].cc_cb_idx = ai->ctb_cc_alf_filter_idx[0][i]; mine[i].cc_cr_idx = ai->ctb_cc_alf_filter_idx[1][i];
+        }
+        struct RectEntryInfo einfo;
+        memset(&einfo, 0, sizeof(einfo));
+        einfo.nb_ctu_w = nx; einfo.nb_ctu_h = ny;
+        for (int cy = 0; cy < ny; ++cy) { c->ctb_y = cy; c->rcn_funcs.alf.rcn_alf_filter_line(c, &einfo, cy); }
+
+        d2[0] = H; d2[1] = W;
+        snprintf(nm, 32, "p%d_exp_y", pi); gfile_array(&g, nm, T_U16, f->data[0], 2, d2);
+        d2[0] = H / 2; d2[1] = W / 2;
+        snprintf(nm, 32, "p%d_exp_cb", pi); gfile_array(&g, nm, T_U16, f->data[1], 2, d2);
+        snprintf(nm, 32, "p%d_exp_cr", pi); gfile_array(&g, nm, T_U16, f->data[2], 2, d2);
+        d2[0] = nx * ny; d2[1] = sizeof(ovhip_alf_ctu);
+        snprintf(nm, 32, "p%d_ctus", pi); gfile_array(&g, nm, T_U8, mine, 2, d2);
+        d2[0] = 24; d2[1] = OVHIP_ALF_LUMA_SET_SIZE;
+        snprintf(nm, 32, "p%d_luma_coeff", pi); gfile_array(&g, nm, T_I16, ai->rcn_alf.filter_coeff_dec, 2, d2);
+        snprintf(nm, 32, "p%d_luma_clip", pi); gfile_array(&g, nm, T_I16, ai->rcn_alf.filter_clip_dec, 2, d2);
+        d2[0] = 8; d2[1] = 7;
+        snprintf(nm, 32, "p%d_chroma_coeff", pi); gfile_array(&g, nm, T_I16, ai->rcn_alf.chroma_coeff_final, 2, d2);
+        snprintf(nm, 32, "p%d_chroma_clip", pi); gfile_array(&g, nm, T_I16, ai->rcn_alf.chroma_clip_final, 2, d2);
+        int16_t cc[2][4][8];
+        memcpy(cc[0], aps[3].alf_cc_mapped_coeff[0], sizeof(cc[0]));
+        memcpy(cc[1], aps[4].alf_cc_mapped_coeff[1], sizeof(cc[1]));
+        uint32_t d3[3] = { 2, 4, 8 };
+        snprintf(nm, 32, "p%d_cc_coeff", pi); gfile_array(&g, nm, T_I16, cc, 3, d3);
+        fprintf(stderr, "alf.ovg: picture %d %dx%d (%d CTUs)\n", pi, W, H, nx * ny);
+    }
+    gfile_close(&g);
+}
+
 int
 main(int argc, char **argv)
 {
@@ -669,5 +772,6 @@ main(int argc, char **argv)
     if (!only || !strcmp(only, "mc"))  gen_mc(dir);
     if (!only || !strcmp(only, "dbf")) gen_dbf(dir);
     if (!only || !strcmp(only, "sao")) gen_sao(dir);
+    if (!only || !strcmp(only, "alf")) gen_alf(dir);
     return 0;
 }

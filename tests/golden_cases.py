@@ -93,3 +93,19 @@ def sao_cases():
                     HostPic(w, h, g[f"p{pi}_exp_y"], g[f"p{pi}_exp_cb"], g[f"p{pi}_exp_cr"])))
         pi += 1
     return out
+
+
+def alf_cases():
+    """[(post-SAO HostPic, ALF tables dict, expected HostPic)] from alf.ovg."""
+    g = golden_io.load("alf.ovg")
+    out, pi = [], 0
+    while f"p{pi}_in_y" in g:
+        y = g[f"p{pi}_in_y"]
+        h, w = y.shape
+        alf = {"ctus": np.frombuffer(g[f"p{pi}_ctus"].tobytes(), dtype=capi.ALF_CTU_DTYPE).copy()}
+        for k in ("luma_coeff", "luma_clip", "chroma_coeff", "chroma_clip", "cc_coeff"):
+            alf[k] = g[f"p{pi}_{k}"]
+        out.append((HostPic(w, h, y, g[f"p{pi}_in_cb"], g[f"p{pi}_in_cr"]), alf,
+                    HostPic(w, h, g[f"p{pi}_exp_y"], g[f"p{pi}_exp_cb"], g[f"p{pi}_exp_cr"])))
+        pi += 1
+    return out

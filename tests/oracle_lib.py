@@ -34,6 +34,8 @@ def lib():
         _lib.oracle_dbf.restype = None
         _lib.oracle_sao.argtypes = [C.POINTER(OPic), C.POINTER(OPic), vp, C.c_int]
         _lib.oracle_sao.restype = None
+        _lib.oracle_alf_run.argtypes = [C.POINTER(OPic), C.POINTER(OPic), vp]
+        _lib.oracle_alf_run.restype = None
     return _lib
 
 
@@ -94,3 +96,12 @@ def sao(dst: HostPic, src: HostPic, params: np.ndarray, log2_ctu: int = 7):
     d, s_ = dst.struct(), src.struct()
     params = np.ascontiguousarray(params)
     lib().oracle_sao(C.byref(d), C.byref(s_), params.ctypes.data, log2_ctu)
+
+
+def alf(dst: HostPic, src: HostPic, alf: dict, log2_ctu: int = 7):
+    from openvvc_amd import capi
+    keep = [np.ascontiguousarray(alf[k], dtype=dt) for k, dt in capi.ALF_TABLES]
+    scratch = np.zeros(((src.w + 3) // 4) * ((src.h + 3) // 4), np.uint8)
+    st = capi.AlfPic(*[a.ctypes.data for a in keep], scratch.ctypes.data, log2_ctu)
+    d, s_ = dst.struct(), src.struct()
+    lib().oracle_alf_run(C.byref(d), C.byref(s_), C.addressof(st))

@@ -69,3 +69,15 @@ def test_sao_gpu_matches_reference(ctx):
         for name, a, b in (("Y", y, exp.y), ("Cb", cb, exp.cb), ("Cr", cr, exp.cr)):
             bad = np.argwhere(a != b)
             assert len(bad) == 0, f"sao HIP vs reference, picture {i} plane {name}: {len(bad)} differ, first {bad[:6].tolist()}"
+
+
+def test_alf_gpu_matches_reference(ctx):
+    for i, (pic, alf, exp) in enumerate(golden_cases.alf_cases()):
+        src = ctx.upload_pic(pic.y, pic.cb, pic.cr)
+        dst = ctx.new_pic(pic.w, pic.h)
+        ctx.alf(dst, src, engine.DevAlf(ctx, alf, pic.w, pic.h))
+        ctx.sync()
+        y, cb, cr = dst.download()
+        for name, a, b in (("Y", y, exp.y), ("Cb", cb, exp.cb), ("Cr", cr, exp.cr)):
+            bad = np.argwhere(a != b)
+            assert len(bad) == 0, f"alf HIP vs reference, picture {i} plane {name}: {len(bad)} differ, first {bad[:6].tolist()}"

@@ -55,3 +55,15 @@ def test_sao_oracle_matches_reference(built_lib):
             assert (b != c).sum() > 20, "fixture does not exercise SAO"
             bad = np.argwhere(a != b)
             assert len(bad) == 0, f"sao picture {i} plane {name}: {len(bad)} samples differ, first at (y,x) {bad[:6].tolist()}"
+
+
+def test_alf_oracle_matches_reference(built_lib):
+    cases = golden_cases.alf_cases()
+    assert len(cases) == 3
+    for i, (pic, alf, exp) in enumerate(cases):
+        out = HostPic(pic.w, pic.h)
+        oracle_lib.alf(out, pic, alf)
+        for name, a, b, c in (("Y", out.y, exp.y, pic.y), ("Cb", out.cb, exp.cb, pic.cb), ("Cr", out.cr, exp.cr, pic.cr)):
+            assert (b != c).sum() > 100, "fixture does not exercise ALF"
+            bad = np.argwhere(a != b)
+            assert len(bad) == 0, f"alf picture {i} plane {name}: {len(bad)} samples differ, first at (y,x) {bad[:6].tolist()}"
