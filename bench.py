@@ -76,27 +76,22 @@ def main():
             p.upload(*planes)
         return t, p
 
-    ref_t, refs = zip(*[torch_pic(r) for r in wl.refs])
-    refs = list(refs)
-    dst_t, dst = torch_pic()
+    rp = engine.ResidentPicture(ctx, wl)
+    # pictures that take part in the reference exchange live in torch tensors
+    dst_t, rp.dst = torch_pic()
+    ref1_t, rp.refs[1] = torch_pic(wl.refs[1])
     spare_t, spare = torch_pic(wl.refs[1])          # receive buffer for the exchanged reference picture
-    mc_units = ctx.upload(wl.mc_units)
-    tb_cmds = ctx.upload(wl.tb_cmds)
-    coefs = ctx.upload(wl.coefs)
 
-    stages = ["mc", "itx"]
+    stages = list(rp.STAGES)
     evs = {k: [] for k in stages}
 
     def step(timed):
-        nonlocal refs, spare, spare_t, ref_t
+        nonlocal spare, spare_t, ref1_t
         for name in stages:
             if timed:
                 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
-            if name == "mc":
-                ctx.mc(dst, refs, mc_units)
-            elif name == "itx":
-                ctx.itx(dst, tb_cmds, coefs)
+            rp.run_stage(name)
             if timed:
                 e1.record(stream)
                 evs[name].append((e0, e1))
@@ -107,10 +102,8 @@ def main():
                    dist.P2POp(dist.irecv, spare_t, (rank - 1) % world)]
             for w_ in dist.batch_isend_irecv(ops):
                 w_.wait()
-            ref_list_t = list(ref_t)
-            ref_list_t[1], spare_t = spare_t, ref_list_t[1]
-            ref_t = tuple(ref_list_t)
-            refs[1], spare = spare, refs[1]
+            ref1_t, spare_t = spare_t, ref1_t
+            rp.refs[1], spare = spare, rp.refs[1]
 
     def barrier():
         if world > 1:
@@ -141,10 +134,13 @@ def main():
         tb = wl.tb_cmds
         tb_samples = int((1 << (tb["log2_w"].astype(np.int64) + tb["log2_h"])).sum()
                          + (1 << (tb["log2_w"].astype(np.int64) + tb["log2_h"]))[tb["plane2"] != 0xff].sum())
-        # algorithmic bytes per launch (DESIGN.md "Measurement"): SURVEY 8d terms split per kernel
+        # algorithmic bytes per launch (DESIGN.md "Measurement"): SURVEY 8d terms split per stage
         alg = {
-            "mc": st["r_bar"] * S + S + u.nbytes,                 # r*S reference reads + S prediction writes + units
+            "mc": st["r_bar"] * S + S + u.nbytes,                     # r*S reference reads + S prediction writes + units
             "itx": wl.coefs.nbytes + tb.nbytes + 2 * 2 * tb_samples,  # coefficients + commands + RMW of covered samples
+            "dbf": 2 * S + rp.dbf_planes.nbytes,                      # read + write the picture, edge parameter planes
+            "sao": 2 * S + wl.sao_params.nbytes,
+            "alf": 2 * S + rp.alf.nbytes,
         }
         dom = max(kdur, key=kdur.get)
         achieved = alg[dom] / kdur[dom] / 1e9
@@ -168,8 +164,8 @@ def main():
                              f"({os.cpu_count()} logical cores present)"}
 
         out = {
-            "metric": "decoded frames/sec, rcn back-end (MC + inverse transform"
-                      + "), 4K 10-bit RA recorded picture, bit-exact vs oracle",
+            "metric": "decoded frames/sec, full rcn back-end (MC + inverse transform + deblocking + SAO + ALF/CC-ALF), "
+                      "4K 10-bit RA recorded picture, bit-exact vs oracle",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u16 samples / int16 coefficients / int32 accumulate", "data": "synthetic",
@@ -177,6 +173,7 @@ def main():
                                    f"seed {hex(args.seed)}, stages {'+'.join(stages)}",
                        "n_cu": st["n_cu"], "n_mc_units": st["n_mc_units"], "n_tb_cmds": st["n_tb_cmds"],
                        "r_bar": round(st["r_bar"], 3), "coef_bytes": st["coef_bytes"],
+                       "frame_algorithmic_bytes": int(sum(alg.values())),
                        "parallelism": f"frames x{world}" + (" + RCCL p2p reference exchange" if world > 1 else "")},
             "roofline": roofline,
             "cpu_baseline": cpu,

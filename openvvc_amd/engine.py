@@ -160,29 +160,51 @@ class DevPic:
 
 
 class ResidentPicture:
-    """A recorded picture resident in HBM: reference pictures, command buffers, coefficient arena and
-    the destination picture.  `decode()` enqueues every implemented stage of the rcn path in the
-    order the reference executes them per CTU (prediction -> residual -> in-loop filters), each as
-    one frame-wide launch on the context stream."""
+    """A recorded picture resident in HBM: reference pictures, command buffers, coefficient arena,
+    in-loop filter side information and two picture buffers.  `decode()` enqueues every stage of
+    the rcn path in the order the reference executes them (prediction -> residual -> deblocking ->
+    SAO -> ALF/CC-ALF), each as frame-wide launches on the context stream.  The reconstructed /
+    deblocked picture lives in `dst`, SAO writes `tmp`, ALF writes the final samples back to `dst`."""
 
-    def __init__(self, ctx: Context, wl):
-        self.ctx, self.wl = ctx, wl
+    STAGES = ("mc", "itx", "dbf", "sao", "alf")
+
+    def __init__(self, ctx: Context, wl, log2_ctu: int = 7):
+        self.ctx, self.wl, self.log2_ctu = ctx, wl, log2_ctu
         self.refs = [ctx.upload_pic(*r) for r in wl.refs]
         self.dst = ctx.new_pic(wl.w, wl.h)
+        self.tmp = ctx.new_pic(wl.w, wl.h)
         self.mc_units = ctx.upload(wl.mc_units)
         self.tb_cmds = ctx.upload(wl.tb_cmds)
         self.coefs = ctx.upload(wl.coefs)
+        self.dbf_planes = DevDbfPlanes(ctx, wl.dbf_planes)
+        self.sao_params = ctx.upload(wl.sao_params)
+        self.alf = DevAlf(ctx, wl.alf, wl.w, wl.h, log2_ctu)
 
-    def decode(self):
-        self.ctx.mc(self.dst, self.refs, self.mc_units)
-        self.ctx.itx(self.dst, self.tb_cmds, self.coefs)
+    def run_stage(self, name: str):
+        c = self.ctx
+        if name == "mc":
+            c.mc(self.dst, self.refs, self.mc_units)
+        elif name == "itx":
+            c.itx(self.dst, self.tb_cmds, self.coefs)
+        elif name == "dbf":
+            c.dbf(self.dst, self.dbf_planes)
+        elif name == "sao":
+            c.sao(self.tmp, self.dst, self.sao_params, self.log2_ctu)
+        elif name == "alf":
+            c.alf(self.dst, self.tmp, self.alf)
+        else:
+            raise ValueError(name)
+
+    def decode(self, stages=STAGES):
+        for s in stages:
+            self.run_stage(s)
 
     def result(self):
         self.ctx.sync()
         return self.dst.download()
 
     def free(self):
-        for b in (self.mc_units, self.tb_cmds, self.coefs):
+        for b in (self.mc_units, self.tb_cmds, self.coefs, self.sao_params, self.dbf_planes, self.alf):
             b.free()
-        for p in self.refs + [self.dst]:
+        for p in self.refs + [self.dst, self.tmp]:
             p.free()

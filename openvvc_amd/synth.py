@@ -88,6 +88,9 @@ class Workload:
     mc_units: np.ndarray            # capi.MC_UNIT_DTYPE
     tb_cmds: np.ndarray             # capi.TB_CMD_DTYPE
     coefs: np.ndarray               # int16 arena
+    dbf_planes: dict = None         # picture-level deblocking edge planes (include/ovvc_hip.h)
+    sao_params: np.ndarray = None   # capi.SAO_CTU_DTYPE per CTU
+    alf: dict = None                # ALF tables + per-CTU parameters
     stats: dict = field(default_factory=dict)
 
     @property
@@ -224,6 +227,9 @@ def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6
                 n_tu += 1
 
     wl = Workload(w, h, seed, refs, pocs, cus, rec.mc_units(), rec.tb_cmds(), rec.coefs())
+    wl.dbf_planes = make_dbf_planes(rs, w, h, cus)
+    wl.sao_params = make_sao_params(rs, w, h)
+    wl.alf = make_alf(rs, w, h)
     u = wl.mc_units
     bi = (u["dir"] == 3)
     area = u["w"].astype(np.int64) * u["h"]
@@ -236,3 +242,115 @@ def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6
     }
     rec.close()
     return wl
+
+
+# --------------------------------------------------------------------------------------------
+# in-loop filter side information (deblocking edge planes, SAO / ALF parameters)
+# --------------------------------------------------------------------------------------------
+def _edge_runs(E: np.ndarray):
+    """E[r, i] = an edge lies at the LEFT side of unit i (E[:, 0] is the picture border).  Returns the
+    distance in units to the previous edge (dP) and to the next edge or picture end (dQ)."""
+    n = E.shape[1]
+    idx = np.where(E, np.arange(n)[None, :], -1)
+    prev_incl = np.maximum.accumulate(idx, axis=1)                  # last edge at or before i
+    prev = np.concatenate([np.full((E.shape[0], 1), 0), prev_incl[:, :-1]], axis=1)   # strictly before i
+    idx2 = np.where(E, np.arange(n)[None, :], n)
+    nxt_incl = np.minimum.accumulate(idx2[:, ::-1], axis=1)[:, ::-1]
+    nxt = np.concatenate([nxt_incl[:, 1:], np.full((E.shape[0], 1), n)], axis=1)       # strictly after i
+    ar = np.arange(n)[None, :]
+    return ar - prev, nxt - ar
+
+
+def make_dbf_planes(rs, w, h, cus, ctu=128):
+    """Picture-level deblocking edge planes for a synthetic partition, following the rules the
+    reference derives per CTU (rcn_df.c:1890-1938): bS 1 on CU/TU edges with coded residual or motion
+    difference (random per CU), bS 2 around a few "intra" CUs, filter length 1 next to 4-sample
+    blocks, 7 on 16-sample-aligned edges of blocks >= 32 samples (3 at CTU-row tops for the P side), else 3;
+    chroma edges on the 8-sample grid, "large" when no other edge lies within 3 units."""
+    w4, h4 = (w + 3) // 4, (h + 3) // 4
+    cu_id = np.zeros((h4, w4), np.int32)
+    n = len(cus)
+    for i in range(n):
+        x, y, l2w, l2h = (int(v) for v in cus[i])
+        cu_id[y >> 2:(y + (1 << l2h)) >> 2, x >> 2:(x + (1 << l2w)) >> 2] = i
+    qp_cu = rs.randint(22, 46, size=n).astype(np.int32)
+    flag1 = rs.random_sample(n) < 0.55           # residual / motion difference -> bS 1
+    flag1c = rs.random_sample(n) < 0.35
+    intra = rs.random_sample(n) < 0.04           # bS 2
+    ux = np.arange(w4)[None, :]
+    uy = np.arange(h4)[:, None]
+    out = {"w4": w4, "h4": h4, "beta_offset": 0, "tc_offset": 0}
+    for d, name in ((0, "v"), (1, "h")):
+        ids = cu_id if d == 0 else cu_id.T
+        pos = (ux if d == 0 else uy.T) + np.zeros_like(ids)       # coordinate across the edge, in units
+        left = np.concatenate([ids[:, :1], ids[:, :-1]], axis=1)
+        E = (ids != left) | ((pos % 16) == 0)                       # CU edges + 64-sample TU grid
+        E[:, 0] = True
+        dP, dQ = _edge_runs(E)
+        edge = E.copy(); edge[:, 0] = False                        # the picture border is never filtered
+        bs2 = edge & (intra[ids] | intra[left])
+        bs1 = edge & (flag1[ids] | flag1[left]) & ~bs2
+        bs = np.where(bs2, 2, np.where(bs1, 1, 0))
+        qp = (qp_cu[ids] + qp_cu[left] + 1) >> 1
+        small = (dP == 1) | (dQ == 1)
+        aligned = (pos % 4) == 0
+        ctu_top = (pos % (ctu // 4)) == 0 if d == 1 else np.zeros_like(aligned)
+        lp = np.where(small, 1, np.where((dP >= 8) & aligned & ~ctu_top, 7, 3))
+        lq = np.where(small, 1, np.where((dQ >= 8) & aligned, 7, 3))
+        word = np.where(bs > 0, bs | (lp << 2) | (lq << 5) | (qp << 8), 0).astype(np.uint16)
+        out["luma_" + name] = np.ascontiguousarray(word if d == 0 else word.T)
+        # chroma: 8-sample grid, bS 2 or (bS 1 of the component and "large")
+        on_grid = (pos % 2) == 0
+        large = (dP >= 4) & (dQ >= 4)
+        for comp, cname in ((0, "cb"), (1, "cr")):
+            f1c = flag1c if comp == 0 else ~flag1c & flag1
+            b1 = edge & (f1c[ids] | f1c[left])
+            on = on_grid & (bs2 | (b1 & large))
+            qpc = np.maximum((qp_cu[ids] + qp_cu[left] + 1 >> 1) - 1 - comp, 0)
+            cw = np.where(on, 1 | np.where(bs2, 2, 0) | np.where(large, 4, 0) | np.where(ctu_top, 8, 0) | (qpc << 8), 0)
+            cw = cw.astype(np.uint16)
+            if d == 0:
+                out[cname + "_v"] = np.ascontiguousarray(cw[:, ::2])
+            else:
+                out[cname + "_h"] = np.ascontiguousarray(cw.T[::2, :])
+    return out
+
+
+def make_sao_params(rs, w, h, ctu=128):
+    n = ((w + ctu - 1) // ctu) * ((h + ctu - 1) // ctu)
+    p = np.zeros(n, capi.SAO_CTU_DTYPE)
+    t = rs.randint(0, 4, size=(n, 3))
+    p["type"] = np.where(t >= 2, t - 1, 0)                # 50 % off, 25 % band, 25 % edge
+    p["band_position"] = rs.randint(0, 32, size=(n, 3))
+    p["eo_class"] = rs.randint(0, 4, size=(n, 3))
+    off = rs.randint(0, 8, size=(n, 3, 5)).astype(np.int16)
+    band = (p["type"] == 1)[:, :, None]
+    sign = np.where(rs.random_sample((n, 3, 5)) < 0.5, -1, 1)
+    edge_sign = np.array([1, 1, 0, -1, -1], np.int16)[None, None, :]
+    p["offset_val"] = np.where(band, off * sign, off * edge_sign)
+    return p
+
+
+def make_alf(rs, w, h, ctu=128):
+    n = ((w + ctu - 1) // ctu) * ((h + ctu - 1) // ctu)
+    ctus = np.zeros(n, capi.ALF_CTU_DTYPE)
+    on = rs.random_sample((n, 3)) < 0.75
+    ctus["flags"] = (on[:, 0] * 4 + on[:, 1] * 2 + on[:, 2]).astype(np.uint8)
+    ctus["luma_set"] = rs.randint(0, 24, size=n)
+    ctus["cb_alt"] = rs.randint(0, 8, size=n)
+    ctus["cr_alt"] = rs.randint(0, 8, size=n)
+    ctus["cc_cb_idx"] = np.where(rs.random_sample(n) < 0.25, rs.randint(1, 5, size=n), 0)
+    ctus["cc_cr_idx"] = np.where(rs.random_sample(n) < 0.25, rs.randint(1, 5, size=n), 0)
+    clip_lut = np.array([1024, 128, 32, 8], np.int16)
+    luma_coeff = rs.randint(-12, 13, size=(24, 4 * 25, 13)).astype(np.int16)
+    luma_coeff[:, :, 12] = 128
+    luma_clip = clip_lut[rs.randint(0, 4, size=(24, 4 * 25, 13))]
+    luma_clip[:, :, 12] = 1024
+    chroma_coeff = rs.randint(-12, 13, size=(8, 7)).astype(np.int16)
+    chroma_coeff[:, 6] = 128
+    chroma_clip = clip_lut[rs.randint(0, 4, size=(8, 7))]
+    mag = rs.randint(0, 6, size=(2, 4, 8))
+    cc = np.where(mag == 0, 0, 1 << np.maximum(mag - 1, 0)) * np.where(rs.random_sample((2, 4, 8)) < 0.5, -1, 1)
+    cc[:, :, 7] = 0
+    return {"ctus": ctus, "luma_coeff": luma_coeff.reshape(24, -1), "luma_clip": luma_clip.reshape(24, -1).astype(np.int16),
+            "chroma_coeff": chroma_coeff, "chroma_clip": chroma_clip.astype(np.int16), "cc_coeff": cc.astype(np.int16)}

@@ -16,6 +16,6 @@ def run():
     for name, a, b in (("Y", y, ref.y), ("Cb", cb, ref.cb), ("Cr", cr, ref.cr)):
         assert np.array_equal(a, b), f"smoke: plane {name} differs from the oracle ({int((a != b).sum())} samples)"
     print(f"smoke ok: 416x240 recorded picture, {wl.stats['n_mc_units']} MC units, "
-          f"{wl.stats['n_tb_cmds']} TB commands, bit-exact vs oracle")
+          f"{wl.stats['n_tb_cmds']} TB commands, stages {'+'.join(rp.STAGES)}, bit-exact vs oracle")
     rp.free()
     ctx.close()

@@ -30,18 +30,49 @@ def test_picture_matches_oracle(ctx, w, h, seed):
     rp.free()
 
 
-def test_4k_idempotent_and_band_exact(ctx):
-    """3840x2160 (BASELINE configs[3]): decoding twice gives the same MD5 (every stage rewrites its
-    whole output), and the top two CTU rows equal the oracle run on that band."""
+def test_4k_full_pipeline(ctx):
+    """3840x2160 (BASELINE configs[3]): the whole rcn path (MC, inverse transform, deblocking, SAO,
+    ALF/CC-ALF) equals the oracle bit for bit; decoding twice gives the same MD5 (every stage rewrites
+    its whole output); MC+ITX alone equal the oracle on the top two CTU rows."""
     wl = synth.make_workload(3840, 2160, 0x266)
     rp = engine.ResidentPicture(ctx, wl)
+    rp.decode(("mc", "itx"))
+    a = rp.result()
+    ref = oracle_pipeline.decode(wl, rows=(0, 256), stages=("mc", "itx"))
+    assert np.array_equal(a[0][:256], ref.y[:256])
+    assert np.array_equal(a[1][:128], ref.cb[:128]) and np.array_equal(a[2][:128], ref.cr[:128])
     rp.decode()
     a = rp.result()
     rp.decode()
     b = rp.result()
     md5 = lambda planes: hashlib.md5(b"".join(p.tobytes() for p in planes)).hexdigest()
     assert md5(a) == md5(b)
-    ref = oracle_pipeline.decode(wl, rows=(0, 256))
-    assert np.array_equal(a[0][:256], ref.y[:256])
-    assert np.array_equal(a[1][:128], ref.cb[:128]) and np.array_equal(a[2][:128], ref.cr[:128])
+    full = oracle_pipeline.decode(wl)
+    for name, x, y in (("Y", a[0], full.y), ("Cb", a[1], full.cb), ("Cr", a[2], full.cr)):
+        assert np.array_equal(x, y), f"4K plane {name}: {int((x != y).sum())} samples differ from the oracle"
     rp.free()
+
+
+@pytest.mark.parametrize("stage", ["dbf", "sao", "alf"])
+def test_stage_isolated(ctx, stage):
+    """Each in-loop filter alone (1080p) on the oracle's input for that stage."""
+    wl = synth.make_workload(1920, 1080, 11)
+    order = list(oracle_pipeline.STAGES)
+    upto = order[:order.index(stage)]
+    before = oracle_pipeline.decode(wl, stages=tuple(upto))
+    after = oracle_pipeline.decode(wl, stages=tuple(upto + [stage]))
+    src = ctx.upload_pic(before.y, before.cb, before.cr)
+    dst = ctx.new_pic(wl.w, wl.h)
+    if stage == "dbf":
+        ctx.dbf(src, engine.DevDbfPlanes(ctx, wl.dbf_planes)); out = src
+    elif stage == "sao":
+        ctx.sao(dst, src, ctx.upload(wl.sao_params)); out = dst
+    else:
+        # oracle_pipeline keeps SAO output in a temporary when ALF follows: rebuild ALF input = SAO output
+        sao_out = oracle_pipeline.decode(wl, stages=("mc", "itx", "dbf", "sao"))
+        src = ctx.upload_pic(sao_out.y, sao_out.cb, sao_out.cr)
+        ctx.alf(dst, src, engine.DevAlf(ctx, wl.alf, wl.w, wl.h)); out = dst
+    ctx.sync()
+    y, cb, cr = out.download()
+    for name, a, b in (("Y", y, after.y), ("Cb", cb, after.cb), ("Cr", cr, after.cr)):
+        assert np.array_equal(a, b), f"{stage} plane {name}: {int((a != b).sum())} samples differ"
