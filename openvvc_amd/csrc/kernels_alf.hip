@@ -55,9 +55,12 @@ __global__ __launch_bounds__(256) void k_alf_luma(ovhip_pic dst, ovhip_pic src, 
     __shared__ uint8_t s_cls[64];
 
     const int W = src.w, H = src.h;
-    const int tx0 = blockIdx.x * TL, ty0 = blockIdx.y * TL;
     const int tid = threadIdx.x;
     const int ctu = 1 << alf.log2_ctu_s;
+    const int ntx = (W + TL - 1) / TL, ntiles = ntx * ((H + TL - 1) / TL);
+    // resident grid striding over the 32x32 tiles (workgroup dispatch is ~400 WG/us on this chip)
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, __syncthreads()) {
+    const int tx0 = (tile % ntx) * TL, ty0 = (tile / ntx) * TL;
     const ovhip_alf_ctu c = alf.ctus[(ty0 >> alf.log2_ctu_s) * nb_ctu_w + (tx0 >> alf.log2_ctu_s)];
     const bool on = c.flags & 4;
 
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(256) void k_alf_luma(ovhip_pic dst, ovhip_pic src, 
 #pragma unroll
             for (int i = 0; i < 4; ++i) if (ox + i < W) dst.y[oy * dst.stride_y + ox + i] = src.y[oy * src.stride_y + ox + i];
         }
-        return;
+        continue;
     }
 
     for (int i = tid; i < LW * LW; i += 256) {
@@ -91,38 +94,46 @@ __global__ __launch_bounds__(256) void k_alf_luma(ovhip_pic dst, ovhip_pic src, 
     const bool req_vb = (last_local < vbl && last_local >= vbl - 4) || (last_local >= vbl && last_local <= vbl + 3);
     const int vb = ctu_y0 + vbl;               // same boundary in picture rows
 
-    // ---- classification: lanes 0..63, one 4x4 block each ----
-    if (tid < 64) {
-        const int cbx = (tid & 7) * 4, cby = (tid >> 3) * 4;     // tile-local block origin
-        const int py = ty0 + cby;                                // picture row of the block
-        int first = 0, last = 3;
-        bool is_vb = false;
-        if (py == vb - 4) { last = 2; is_vb = true; }
-        if (py == vb)     { first = 1; is_vb = true; }
-        uint32_t sv = 0, sh = 0, sd = 0, sb = 0;
+    // ---- classification: 4 lanes per 4x4 block, one row pair of its 8x8 Laplacian window each ----
 #define T(x, y) ((int)s_t[((y) + LH) * LW + (x) + LH])
-        for (int k = first; k <= last; ++k) {
-            const int rr = cby - 2 + 2 * k;                      // tile-local first row of the pair
-            int above = rr - 1, below = rr + 2;
-            if (ty0 + rr + 2 == vb) below = rr + 1;
-            if (ty0 + rr == vb)     above = rr;
+    {
+        const int cb = tid >> 2, k = tid & 3;                    // block 0..63, row pair 0..3
+        const int cbx = (cb & 7) * 4, cby = (cb >> 3) * 4;       // tile-local block origin
+        const int rr = cby - 2 + 2 * k;                          // tile-local first row of the pair
+        int above = rr - 1, below = rr + 2;
+        if (ty0 + rr + 2 == vb) below = rr + 1;                  // pair (vb-2, vb-1): row vb is not available
+        if (ty0 + rr == vb)     above = rr;                      // pair (vb, vb+1): row vb-1 is not available
+        uint32_t sv = 0, sh = 0, sd = 0, sb = 0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c0 = cbx - 2 + 2 * q, c1 = c0 + 1;
-                const int y1 = T(c0, rr) << 1, y2 = T(c1, rr + 1) << 1;
-                sv += abs(y1 - T(c0, above) - T(c0, rr + 1)) + abs(y2 - T(c1, rr) - T(c1, below));
-                sh += abs(y1 - T(c0 + 1, rr) - T(c0 - 1, rr)) + abs(y2 - T(c1 + 1, rr + 1) - T(c1 - 1, rr + 1));
-                sd += abs(y1 - T(c0 - 1, above) - T(c0 + 1, rr + 1)) + abs(y2 - T(c1 - 1, rr) - T(c1 + 1, below));
-                sb += abs(y1 - T(c0 - 1, rr + 1) - T(c0 + 1, above)) + abs(y2 - T(c1 - 1, below) - T(c1 + 1, rr));
-            }
+        for (int q = 0; q < 4; ++q) {
+            const int c0 = cbx - 2 + 2 * q, c1 = c0 + 1;
+            const int y1 = T(c0, rr) << 1, y2 = T(c1, rr + 1) << 1;
+            sv += abs(y1 - T(c0, above) - T(c0, rr + 1)) + abs(y2 - T(c1, rr) - T(c1, below));
+            sh += abs(y1 - T(c0 + 1, rr) - T(c0 - 1, rr)) + abs(y2 - T(c1 + 1, rr + 1) - T(c1 - 1, rr + 1));
+            sd += abs(y1 - T(c0 - 1, above) - T(c0 + 1, rr + 1)) + abs(y2 - T(c1 - 1, rr) - T(c1 + 1, below));
+            sb += abs(y1 - T(c0 - 1, rr + 1) - T(c0 + 1, above)) + abs(y2 - T(c1 - 1, below) - T(c1 + 1, rr));
         }
-        int cls, tr;
-        filter_idx(sh, sv, sd, sb, is_vb, cls, tr);
-        s_cls[tid] = (uint8_t)(cls | (tr << 5));
+        // which pairs count: all four, or three next to the virtual boundary (rcn_alf.c:520-583)
+        const int py = ty0 + cby;
+        bool use = true, is_vb = false;
+        if (py == vb - 4) { is_vb = true; use = k < 3; }
+        if (py == vb)     { is_vb = true; use = k > 0; }
+        if (!use) sv = sh = sd = sb = 0;
+        // sum over the 4 lanes of the block (lanes 4b..4b+3 of one wave)
+#pragma unroll
+        for (int m = 1; m < 4; m <<= 1) {
+            sv += __shfl_xor((int)sv, m); sh += __shfl_xor((int)sh, m);
+            sd += __shfl_xor((int)sd, m); sb += __shfl_xor((int)sb, m);
+        }
+        if (k == 0) {
+            int cls, tr;
+            filter_idx(sh, sv, sd, sb, is_vb, cls, tr);
+            s_cls[cb] = (uint8_t)(cls | (tr << 5));
+        }
     }
     __syncthreads();
 
-    if (oy >= H) return;
+    if (oy >= H) continue;
     const int ct = s_cls[b];
     const int cls = ct & 31, tr = ct >> 5;
     const int16_t *f = alf.luma_coeff + c.luma_set * OVHIP_ALF_LUMA_SET_SIZE + tr * 25 * 13 + cls * 13;
@@ -160,6 +171,7 @@ __global__ __launch_bounds__(256) void k_alf_luma(ovhip_pic dst, ovhip_pic src, 
         sum = near ? (sum + 512) >> 10 : (sum + 64) >> 7;
         if (ox + i < W) dst.y[oy * dst.stride_y + ox + i] = (uint16_t)ov_clip_bd(sum + cur);
     }
+    }
 #undef T
 }
 
@@ -169,9 +181,11 @@ __global__ __launch_bounds__(256) void k_alf_chroma(ovhip_pic dst, ovhip_pic src
     __shared__ uint16_t s_t[CW * CW];
     const int comp = 1 + blockIdx.z;
     const int W = src.w, H = src.h, Wc = W >> 1, Hc = H >> 1;
-    const int tx0 = blockIdx.x * TL, ty0 = blockIdx.y * TL;
     const int tid = threadIdx.x;
     const int ctu = 1 << alf.log2_ctu_s, ctuc = ctu >> 1;
+    const int ntx = (Wc + TL - 1) / TL, ntiles = ntx * ((Hc + TL - 1) / TL);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, __syncthreads()) {
+    const int tx0 = (tile % ntx) * TL, ty0 = (tile / ntx) * TL;
     const ovhip_alf_ctu c = alf.ctus[((ty0 * 2) >> alf.log2_ctu_s) * nb_ctu_w + ((tx0 * 2) >> alf.log2_ctu_s)];
     const bool on = c.flags & (comp == 1 ? 2 : 1);
     const int cc_idx = comp == 1 ? c.cc_cb_idx : c.cc_cr_idx;
@@ -204,7 +218,7 @@ __global__ __launch_bounds__(256) void k_alf_chroma(ovhip_pic dst, ovhip_pic src
     // lane: 4 consecutive samples of one row: row = tid >> 3 (0..31), x segment = (tid & 7) * 4
     const int ly = tid >> 3, lx0 = (tid & 7) * 4;
     const int oy = ty0 + ly;
-    if (oy >= Hc) return;
+    if (oy >= Hc) continue;
 #define T(x, y) ((int)s_t[((y) + CH) * CW + (x) + CH])
     int o1 = 1, o2 = 2;
     bool near = false;
@@ -264,6 +278,7 @@ __global__ __launch_bounds__(256) void k_alf_chroma(ovhip_pic dst, ovhip_pic src
         }
         dp[oy * dst.stride_c + ox] = (uint16_t)out;
     }
+    }
 #undef T
 }
 
@@ -276,11 +291,11 @@ extern "C" int ovhip_alf_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhi
         !alf->ctus || !alf->luma_coeff || !alf->luma_clip || !alf->chroma_coeff || !alf->chroma_clip || !alf->cc_coeff)
         return ov_fail(ctx, OVHIP_EINVAL, "ovhip_alf_launch: bad pictures / parameter tables", hipSuccess);
     const int nb_ctu_w = (src->w + (1 << alf->log2_ctu_s) - 1) >> alf->log2_ctu_s;
-    dim3 gl((src->w + TL - 1) / TL, (src->h + TL - 1) / TL);
-    hipLaunchKernelGGL(k_alf_luma, gl, dim3(256), 0, ctx->stream, *dst, *src, *alf, nb_ctu_w);
+    const int nl = ((src->w + TL - 1) / TL) * ((src->h + TL - 1) / TL);
+    hipLaunchKernelGGL(k_alf_luma, dim3(nl), dim3(256), 0, ctx->stream, *dst, *src, *alf, nb_ctu_w);
     OV_LAUNCH_CHECK(ctx, "k_alf_luma");
-    dim3 gc((src->w / 2 + TL - 1) / TL, (src->h / 2 + TL - 1) / TL, 2);
-    hipLaunchKernelGGL(k_alf_chroma, gc, dim3(256), 0, ctx->stream, *dst, *src, *alf, nb_ctu_w);
+    const int nc = ((src->w / 2 + TL - 1) / TL) * ((src->h / 2 + TL - 1) / TL);
+    hipLaunchKernelGGL(k_alf_chroma, dim3(nc, 1, 2), dim3(256), 0, ctx->stream, *dst, *src, *alf, nb_ctu_w);
     OV_LAUNCH_CHECK(ctx, "k_alf_chroma");
     return OVHIP_OK;
 }

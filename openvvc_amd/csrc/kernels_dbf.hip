@@ -221,31 +221,34 @@ __global__ __launch_bounds__(256) void k_dbf(ovhip_pic pic, ovhip_dbf_planes pl)
 {
     const int comp = blockIdx.y;
     const int w4 = pl.w4, h4 = pl.h4;
-    const int tid = blockIdx.x * 256 + threadIdx.x;
+    const int nthreads = gridDim.x * 256;
+    // resident grid: every lane strides over the edge-parameter plane (most words are 0 = no edge)
     if (comp == 0) {
-        if (tid >= w4 * h4) return;
-        const int ux = tid % w4, uy = tid / w4;
-        const int v = (DIR ? pl.luma_h : pl.luma_v)[tid];
-        if (!(v & 3)) return;
-        // never filter across the picture boundary (the recorder does not emit such edges)
-        if ((DIR ? uy : ux) == 0) return;
-        const Lim lim = dbf_limits(v >> 8, v & 3, pl.tc_offset, pl.beta_offset);
-        if (!(lim.tc || lim.beta)) return;
-        uint16_t *p = pic.y + (uy * 4) * pic.stride_y + ux * 4;
-        luma_segment(p, DIR ? pic.stride_y : 1, DIR ? 1 : pic.stride_y, lim, (v >> 2) & 7, (v >> 5) & 7);
+        for (int tid = blockIdx.x * 256 + threadIdx.x; tid < w4 * h4; tid += nthreads) {
+            const int ux = tid % w4, uy = tid / w4;
+            const int v = (DIR ? pl.luma_h : pl.luma_v)[tid];
+            if (!(v & 3)) continue;
+            // never filter across the picture boundary (the recorder does not emit such edges)
+            if ((DIR ? uy : ux) == 0) continue;
+            const Lim lim = dbf_limits(v >> 8, v & 3, pl.tc_offset, pl.beta_offset);
+            if (!(lim.tc || lim.beta)) continue;
+            uint16_t *p = pic.y + (uy * 4) * pic.stride_y + ux * 4;
+            luma_segment(p, DIR ? pic.stride_y : 1, DIR ? 1 : pic.stride_y, lim, (v >> 2) & 7, (v >> 5) & 7);
+        }
     } else {
         // chroma edge planes: vertical [h4][w4c] (every second unit column), horizontal [h4c][w4]
         const int cw = DIR ? w4 : (w4 + 1) >> 1, chh = DIR ? (h4 + 1) >> 1 : h4;
-        if (tid >= cw * chh) return;
-        const int cx = tid % cw, cy = tid / cw;
         const uint16_t *plane = DIR ? (comp == 1 ? pl.cb_h : pl.cr_h) : (comp == 1 ? pl.cb_v : pl.cr_v);
-        const int v = plane[tid];
-        if (!(v & OVHIP_DBF_C_ON)) return;
-        const int ux = DIR ? cx : cx * 2, uy = DIR ? cy * 2 : cy;
-        if ((DIR ? uy : ux) == 0) return;
-        const Lim lim = dbf_limits(v >> 8, 1 + !!(v & OVHIP_DBF_C_BS2), pl.tc_offset, pl.beta_offset);
-        uint16_t *p = (comp == 1 ? pic.cb : pic.cr) + (uy * 2) * pic.stride_c + ux * 2;
-        chroma_segment(p, DIR ? pic.stride_c : 1, DIR ? 1 : pic.stride_c, lim, v & OVHIP_DBF_C_LARGE, v & OVHIP_DBF_C_CTB_B);
+        for (int tid = blockIdx.x * 256 + threadIdx.x; tid < cw * chh; tid += nthreads) {
+            const int cx = tid % cw, cy = tid / cw;
+            const int v = plane[tid];
+            if (!(v & OVHIP_DBF_C_ON)) continue;
+            const int ux = DIR ? cx : cx * 2, uy = DIR ? cy * 2 : cy;
+            if ((DIR ? uy : ux) == 0) continue;
+            const Lim lim = dbf_limits(v >> 8, 1 + !!(v & OVHIP_DBF_C_BS2), pl.tc_offset, pl.beta_offset);
+            uint16_t *p = (comp == 1 ? pic.cb : pic.cr) + (uy * 2) * pic.stride_c + ux * 2;
+            chroma_segment(p, DIR ? pic.stride_c : 1, DIR ? 1 : pic.stride_c, lim, v & OVHIP_DBF_C_LARGE, v & OVHIP_DBF_C_CTB_B);
+        }
     }
 }
 
@@ -259,7 +262,8 @@ extern "C" int ovhip_dbf_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhi
     if (pl->w4 != (pic->w + 3) / 4 || pl->h4 != (pic->h + 3) / 4)
         return ov_fail(ctx, OVHIP_EINVAL, "ovhip_dbf_launch: edge planes do not match the picture", hipSuccess);
     const int n = pl->w4 * pl->h4;
-    dim3 grid((n + 255) / 256, 3);
+    const int nb = (n + 255) / 256;
+    dim3 grid(nb, 3);                            // one lane per edge word measured faster than a capped resident grid
     hipLaunchKernelGGL(k_dbf<0>, grid, dim3(256), 0, ctx->stream, *pic, *pl);
     OV_LAUNCH_CHECK(ctx, "k_dbf<v>");
     hipLaunchKernelGGL(k_dbf<1>, grid, dim3(256), 0, ctx->stream, *pic, *pl);

@@ -14,6 +14,7 @@
 //  rcn_transform.c:44-598; rcn_residuals.c:46-222).  Every butterfly in rcn_transform.c is an
 // exact integer refactoring of the plain matrix product computed here.
 #include "ovvc_common.hip.h"
+#include <stdlib.h>
 #define OVT_ATTR __device__
 #include "vvc_tables.h"
 
@@ -101,8 +102,18 @@ __device__ __forceinline__ void tr_pass_lds(const int16_t *src, int sstride, con
         const int j = t & (n - 1);
         const int i0 = (t >> log2n) * IB;
         int acc[IB];
+        int old[IB], old2[IB];
 #pragma unroll
         for (int q = 0; q < IB; ++q) acc[q] = 0;
+        if (FINAL) {
+            // issue the frame reads of the read-modify-write BEFORE the MAC loop: independent loads in
+            // flight under the arithmetic instead of IB serialised load->store round trips at the end
+#pragma unroll
+            for (int q = 0; q < IB; ++q) {
+                old[q] = sink.dst[(i0 + q) * sink.stride + j];
+                old2[q] = sink.dst2 ? (int)sink.dst2[(i0 + q) * sink.stride2 + j] : 0;
+            }
+        }
         for (int k = 0; k < kmax; ++k) {
             const int m = mat[(k << log2n) + j];
             const int16_t *s = src + k * sstride + i0;
@@ -124,28 +135,23 @@ __device__ __forceinline__ void tr_pass_lds(const int16_t *src, int sstride, con
             if (!FINAL) {
                 dst[((i0 + q) << log2n) + j] = (int16_t)r;
             } else {
-                uint16_t *p = sink.dst + (i0 + q) * sink.stride + j;
-                *p = (uint16_t)residual1(*p, r, sink.mode, sink.scale);
-                if (sink.dst2) {
-                    uint16_t *p2 = sink.dst2 + (i0 + q) * sink.stride2 + j;
-                    *p2 = (uint16_t)residual1(*p2, r, sink.mode2, sink.scale);
-                }
+                sink.dst[(i0 + q) * sink.stride + j] = (uint16_t)residual1(old[q], r, sink.mode, sink.scale);
+                if (sink.dst2) sink.dst2[(i0 + q) * sink.stride2 + j] = (uint16_t)residual1(old2[q], r, sink.mode2, sink.scale);
             }
         }
     }
 }
 
 __global__ __launch_bounds__(64) void k_itx(ovhip_pic pic, const ovhip_tb_cmd *__restrict__ cmds,
-                                             uint32_t n_cmds, const int16_t *__restrict__ arena)
+                                             uint32_t n_cmds, const int16_t *__restrict__ arena, int ablate)
 {
     __shared__ __attribute__((aligned(16))) int16_t s_coef[32 * 32];
     __shared__ __attribute__((aligned(16))) int16_t s_tmp[32 * 64];
     __shared__ __attribute__((aligned(16))) int8_t s_mv[32 * 64];
     __shared__ __attribute__((aligned(16))) int8_t s_mh[32 * 64];
 
-    const uint32_t bid = blockIdx.x;
-    if (bid >= n_cmds) return;
     const int lane = threadIdx.x;
+    for (uint32_t bid = blockIdx.x; bid < n_cmds; bid += gridDim.x, __syncthreads()) {   // resident grid, see OV_RESIDENT_WAVES
     const ovhip_tb_cmd c = cmds[bid];
 
     const int log2_w = c.log2_w, log2_h = c.log2_h;
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(64) void k_itx(ovhip_pic pic, const ovhip_tb_cmd *_
 
     // ---- stage transform cores (only what this block needs) ----
     const int kv = min(tb_h, 32), kh = min(tb_w, 32);
-    if (kind == OVHIP_TB_TR) {
+    if (kind == OVHIP_TB_TR && !(ablate & 1)) {
         const int8_t *mv = tr_matrix(c.tr_v, log2_h);
         const int8_t *mh = tr_matrix(c.tr_h, log2_w);
         for (int i = lane; i < (kv << log2_h); i += 64) s_mv[i] = mv[i];
@@ -165,7 +171,8 @@ __global__ __launch_bounds__(64) void k_itx(ovhip_pic pic, const ovhip_tb_cmd *_
     }
 
     // ---- K1: de-scan + de-quantise into LDS raster [ch][cw] ----
-    if (raster) {
+    if (ablate & 2) {
+    } else if (raster) {
         for (int i = lane; i < tb_w * tb_h; i += 64)
             s_coef[i] = kind == OVHIP_TB_TS_RAW ? src[i] : (int16_t)dequant1(src[i], c.dq_scale, c.dq_shift, c.dq_neg);
     } else {
@@ -206,6 +213,7 @@ __global__ __launch_bounds__(64) void k_itx(ovhip_pic pic, const ovhip_tb_cmd *_
     if (c.plane2 != 0xff) sink.dst2 = ov_plane(pic, c.plane2, sink.stride2) + c.y * sink.stride2 + c.x;
     sink.scale = c.c_scale;
 
+    if (ablate & 4) continue;
     if (kind == OVHIP_TB_TR) {
         int nb_row, nb_col;
         if (raster) {
@@ -257,22 +265,36 @@ __global__ __launch_bounds__(64) void k_itx(ovhip_pic pic, const ovhip_tb_cmd *_
         const int k2 = min(nb_row, kh);
         if (tb_h & 3) tr_pass_lds<2, true>(s_tmp, tb_h, s_mh, log2_w, k2, tb_h, 20 - OV_BD, nullptr, lane, sink);
         else          tr_pass_lds<4, true>(s_tmp, tb_h, s_mh, log2_w, k2, tb_h, 20 - OV_BD, nullptr, lane, sink);
-        return;
+        continue;
     }
 
     // ---- DC shortcut / transform skip: K4 directly ----
     const bool flat = kind == OVHIP_TB_DC;
     // inverse_dct_ii_dc, rcn_transform.c:576-598
     const int flat_val = ov_clip16(((((int)s_coef[0] + 1) >> 1) + (1 << (14 - OV_BD - 1))) >> (14 - OV_BD));
-    for (int i = lane; i < tb_w * tb_h; i += 64) {
-        const int x = i & (tb_w - 1), y = i >> log2_w;
-        const int r = flat ? flat_val : (int)s_coef[y * tb_w + x];   // TS blocks are <= 32 wide: raster stride tb_w
-        uint16_t *p = sink.dst + y * sink.stride + x;
-        *p = (uint16_t)residual1(*p, r, sink.mode, sink.scale);
-        if (sink.dst2) {
-            uint16_t *p2 = sink.dst2 + y * sink.stride2 + x;
-            *p2 = (uint16_t)residual1(*p2, r, sink.mode2, sink.scale);
+    // 4 samples per lane and iteration; all frame reads of an iteration are issued before the first store
+    for (int i0 = lane; i0 < tb_w * tb_h; i0 += 256) {
+        int old[4], old2[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + 64 * q;
+            if (i < tb_w * tb_h) {
+                const int x = i & (tb_w - 1), y = i >> log2_w;
+                old[q] = sink.dst[y * sink.stride + x];
+                old2[q] = sink.dst2 ? (int)sink.dst2[y * sink.stride2 + x] : 0;
+            }
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + 64 * q;
+            if (i < tb_w * tb_h) {
+                const int x = i & (tb_w - 1), y = i >> log2_w;
+                const int r = flat ? flat_val : (int)s_coef[y * tb_w + x];   // TS blocks are <= 32 wide: raster stride tb_w
+                sink.dst[y * sink.stride + x] = (uint16_t)residual1(old[q], r, sink.mode, sink.scale);
+                if (sink.dst2) sink.dst2[y * sink.stride2 + x] = (uint16_t)residual1(old2[q], r, sink.mode2, sink.scale);
+            }
+        }
+    }
     }
 }
 
@@ -284,7 +306,11 @@ extern "C" int ovhip_itx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhi
     if (!ctx || !dst) return OVHIP_EINVAL;
     if (!n_cmds) return OVHIP_OK;
     if (!d_cmds || !d_coefs) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_itx_launch: null buffer", hipSuccess);
-    hipLaunchKernelGGL(k_itx, dim3(n_cmds), dim3(64), 0, ctx->stream, *dst, d_cmds, n_cmds, d_coefs);
+    // one single-wave workgroup per TB measured faster than a resident grid-stride grid (79 vs 119 us at 4K):
+    // the loop form stays for grids capped by the caller, the default launches n_cmds workgroups
+    static int cfg_ablate = -1;
+    if (cfg_ablate < 0) { const char *a = getenv("OVHIP_ITX_ABLATE"); cfg_ablate = a ? atoi(a) : 0; }   // profiling knob
+    hipLaunchKernelGGL(k_itx, dim3(n_cmds), dim3(64), 0, ctx->stream, *dst, d_cmds, n_cmds, d_coefs, cfg_ablate);
     OV_LAUNCH_CHECK(ctx, "k_itx");
     return OVHIP_OK;
 }

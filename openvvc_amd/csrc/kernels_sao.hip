@@ -9,56 +9,94 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void k_sao(ovhip_pic dst, ovhip_pic src, const ovhip_sao_ctu *__restrict__ prm,
-                                              int log2_ctu, int nb_ctu_w)
+#define SAO_TW 64      /* tile: 64 x 32 samples = 256 lanes x 8 samples; never straddles a CTU (luma 128, chroma 64) */
+#define SAO_TH 32
+
+struct Vec8 { int v[8]; };
+
+__device__ __forceinline__ void load8(const uint16_t *p, bool vec, int n, int v[8])
 {
-    const int c = blockIdx.z;
-    const int sh = c ? 1 : 0;
-    const int w = src.w >> sh, h = src.h >> sh, l2 = log2_ctu - sh;
-    const int y = blockIdx.y;
-    if (y >= h) return;
-    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 8;
-    if (x0 >= w) return;
-    int ss, ds;
-    const uint16_t *s = ov_plane(src, c, ss) + y * ss;
-    uint16_t *d = ov_plane(dst, c, ds) + y * ds;
-    const ovhip_sao_ctu p = prm[(y >> l2) * nb_ctu_w + (x0 >> l2)];   // 8 | ctu size: one CTU per lane
-    const int type = p.type[c];
-    const int n = min(8, w - x0);
-    int v[8];
+    if (vec) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(p);
+        v[0] = q.x & 0xffff; v[1] = q.x >> 16; v[2] = q.y & 0xffff; v[3] = q.y >> 16;
+        v[4] = q.z & 0xffff; v[5] = q.z >> 16; v[6] = q.w & 0xffff; v[7] = q.w >> 16;
+    } else {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = i < n ? s[x0 + i] : 0;
-    int o[8];
+        for (int i = 0; i < 8; ++i) v[i] = i < n ? p[i] : 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sao(ovhip_pic dst, ovhip_pic src, const ovhip_sao_ctu *__restrict__ prm,
+                                              int log2_ctu, int nb_ctu_w, int tiles_y, int tiles_c)
+{
+    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;          // 8 lanes x 8 samples per row, 32 rows
+    // resident grid striding over (plane, tile): luma tiles first, then Cb, then Cr
+    for (int t = blockIdx.x; t < tiles_y + 2 * tiles_c; t += gridDim.x) {
+        const int c = t < tiles_y ? 0 : (t < tiles_y + tiles_c ? 1 : 2);
+        const int tt = t - (c == 0 ? 0 : (c == 1 ? tiles_y : tiles_y + tiles_c));
+        const int sh = c ? 1 : 0;
+        const int w = src.w >> sh, h = src.h >> sh, l2 = log2_ctu - sh;
+        const int ntx = (w + SAO_TW - 1) / SAO_TW;
+        const int x0 = (tt % ntx) * SAO_TW + tx * 8, y = (tt / ntx) * SAO_TH + ty;
+        if (x0 >= w || y >= h) continue;
+        int ss, ds;
+        const uint16_t *s = ov_plane(src, c, ss) + y * ss;
+        uint16_t *d = ov_plane(dst, c, ds) + y * ds;
+        const ovhip_sao_ctu *p = &prm[(y >> l2) * nb_ctu_w + (x0 >> l2)];   // tile-uniform -> scalar loads
+        const int type = p->type[c];
+        const int n = min(8, w - x0);
+        const bool vec = n == 8 && !((ss | ds) & 7) && !(((uintptr_t)s | (uintptr_t)d) & 15);
+        int v[8], o[8];
+        load8(s + x0, vec, n, v);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = v[i];
-    if (type == OVHIP_SAO_BAND) {
-        const int bp = p.band_position[c];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int k = ((v[i] >> (OV_BD - 5)) - bp) & 31;
-            if (k < 4) o[i] = ov_clip_bd(v[i] + p.offset_val[c][k]);
-        }
-    } else if (type == OVHIP_SAO_EDGE) {
-        const int eo = p.eo_class[c];
-        const int dxa = eo == 1 ? 0 : (eo == 3 ? 1 : -1), dya = eo == 0 ? 0 : -1;
-        // last term: quirk of the reference for pictures of a single CTU row (rcn_sao.c:262): the first
-        // 6-row band is processed with the BOTTOM border flag, its last row is skipped
-        const bool rowskip = eo != 0 && (y == 0 || y == h - 1 || (src.h <= (1 << log2_ctu) && y == (6 >> sh) - 1));
-        if (!rowskip) {
-            const uint16_t *sa = s + dya * ss, *sb = s - dya * ss;
+        for (int i = 0; i < 8; ++i) o[i] = v[i];
+        if (type == OVHIP_SAO_BAND) {
+            const int bp = p->band_position[c];
+            const int o0 = p->offset_val[c][0], o1 = p->offset_val[c][1], o2 = p->offset_val[c][2], o3 = p->offset_val[c][3];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int x = x0 + i;
-                if (i < n && !(eo != 1 && (x == 0 || x == w - 1))) {
-                    const int a = sa[x + dxa], b = sb[x - dxa];
-                    const int idx = 2 + (v[i] > a) - (v[i] < a) + (v[i] > b) - (v[i] < b);
-                    o[i] = ov_clip_bd(v[i] + p.offset_val[c][idx]);
+                const int k = ((v[i] >> (OV_BD - 5)) - bp) & 31;
+                const int off = k == 0 ? o0 : k == 1 ? o1 : k == 2 ? o2 : k == 3 ? o3 : 0;
+                o[i] = ov_clip_bd(v[i] + off);
+            }
+        } else if (type == OVHIP_SAO_EDGE) {
+            const int eo = p->eo_class[c];
+            const int dxa = eo == 1 ? 0 : (eo == 3 ? 1 : -1), dya = eo == 0 ? 0 : -1;
+            // last term: quirk of the reference for pictures of a single CTU row (rcn_sao.c:262): the first
+            // 6-row band is processed with the BOTTOM border flag, its last row is skipped
+            const bool rowskip = eo != 0 && (y == 0 || y == h - 1 || (src.h <= (1 << log2_ctu) && y == (6 >> sh) - 1));
+            if (!rowskip) {
+                const int of0 = p->offset_val[c][0], of1 = p->offset_val[c][1], of2 = p->offset_val[c][2],
+                          of3 = p->offset_val[c][3], of4 = p->offset_val[c][4];
+                // neighbour rows: a = (x + dxa, y + dya), b = (x - dxa, y - dya); 8 centre-aligned samples plus
+                // one extra on each side cover every class
+                int ra[10], rb[10];
+                const uint16_t *sa = s + dya * ss, *sb = s - dya * ss;
+                load8(sa + x0, vec, n, ra + 1);
+                load8(sb + x0, vec, n, rb + 1);
+                ra[0] = x0 > 0 ? sa[x0 - 1] : 0; rb[0] = x0 > 0 ? sb[x0 - 1] : 0;
+                ra[9] = x0 + 8 < w ? sa[x0 + 8] : 0; rb[9] = x0 + 8 < w ? sb[x0 + 8] : 0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int x = x0 + i;
+                    if (i < n && !(eo != 1 && (x == 0 || x == w - 1))) {
+                        const int a = ra[1 + i + dxa], b = rb[1 + i - dxa];
+                        const int idx = 2 + (v[i] > a) - (v[i] < a) + (v[i] > b) - (v[i] < b);
+                        const int off = idx == 0 ? of0 : idx == 1 ? of1 : idx == 2 ? of2 : idx == 3 ? of3 : of4;
+                        o[i] = ov_clip_bd(v[i] + off);
+                    }
                 }
             }
         }
-    }
+        if (vec) {
+            uint4 q;
+            q.x = o[0] | (o[1] << 16); q.y = o[2] | (o[3] << 16); q.z = o[4] | (o[5] << 16); q.w = o[6] | (o[7] << 16);
+            *reinterpret_cast<uint4 *>(d + x0) = q;
+        } else {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) if (i < n) d[x0 + i] = (uint16_t)o[i];
+            for (int i = 0; i < 8; ++i) if (i < n) d[x0 + i] = (uint16_t)o[i];
+        }
+    }
 }
 
 } // namespace
@@ -70,8 +108,11 @@ extern "C" int ovhip_sao_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhi
     if (dst->w != src->w || dst->h != src->h || dst->y == src->y || log2_ctu_s < 5 || log2_ctu_s > 7)
         return ov_fail(ctx, OVHIP_EINVAL, "ovhip_sao_launch: bad pictures / CTU size", hipSuccess);
     const int nb_ctu_w = (src->w + (1 << log2_ctu_s) - 1) >> log2_ctu_s;
-    dim3 grid((src->w / 8 + 255) / 256 + 1, src->h, 3);
-    hipLaunchKernelGGL(k_sao, grid, dim3(256), 0, ctx->stream, *dst, *src, d_params, log2_ctu_s, nb_ctu_w);
+    const int tiles_y = ((src->w + SAO_TW - 1) / SAO_TW) * ((src->h + SAO_TH - 1) / SAO_TH);
+    const int tiles_c = ((src->w / 2 + SAO_TW - 1) / SAO_TW) * ((src->h / 2 + SAO_TH - 1) / SAO_TH);
+    const int total = tiles_y + 2 * tiles_c;
+    hipLaunchKernelGGL(k_sao, dim3(total < 2048 ? total : 2048), dim3(256), 0, ctx->stream, *dst, *src, d_params,
+                       log2_ctu_s, nb_ctu_w, tiles_y, tiles_c);
     OV_LAUNCH_CHECK(ctx, "k_sao");
     return OVHIP_OK;
 }
