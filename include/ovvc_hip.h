@@ -115,7 +115,14 @@ enum {                        /* ovhip_mc_unit.flags */
     OVHIP_MC_FILT_4x4  = 2,   /* the reference call was a 4x4 luma block: ov_mc_filters_4        */
     OVHIP_MC_NO_LUMA   = 4,   /* rcn_mcp_b_c: chroma only                                        */
     OVHIP_MC_NO_CHROMA = 8,   /* rcn_mcp_b_l: luma only                                          */
-    OVHIP_MC_LMCS      = 16   /* forward-reshape the luma prediction (lmcs_reshape_forward)      */
+    OVHIP_MC_LMCS      = 16,  /* forward-reshape the luma prediction (lmcs_reshape_forward)      */
+    /* "refined" units: only accepted by ovhip_mcx_launch(); dir == 3, plain average, w,h in {8,16}     */
+    OVHIP_MC_BDOF      = 32,  /* luma through bi-directional optical flow: rcn_bdof_mcp_l
+                               * (rcn_inter.c:1136-1250; rcn_prof_bdof.c:303-490)                  */
+    OVHIP_MC_DMVR      = 64   /* decoder-side MV refinement first: rcn_dmvr_mv_refine
+                               * (rcn_inter.c:872-1126).  mv0/mv1 are then NOT clipped (the device
+                               * applies clip_mv for the window anchor only, as the reference does);
+                               * with OVHIP_MC_BDOF = its apply_bdof argument                      */
 };
 
 typedef struct ovhip_mc_unit {
@@ -281,12 +288,17 @@ typedef struct ovhip_pu_desc {
     uint8_t  prec_amvr_half;  /* inter_ctx->prec_amvr == MV_PRECISION_HALF                        */
     uint8_t  planes;          /* 3 both (rcn_mcp_b), 1 luma only (rcn_mcp_b_l), 2 chroma only     */
     uint8_t  lmcs;            /* luma forward reshaping active                                    */
-    uint8_t  pad;
+    uint8_t  refine;          /* 0: rcn_mcp_b / _l / _c.  bit0 (OVHIP_PU_BDOF): the caller's bdof_enable,
+                               * bit1 (OVHIP_PU_DMVR): its dmvr_enable -- the PU is then the whole CU and is
+                               * cut into <=16x16 calls exactly as vcl_coding_unit.c:2450-2472 / :2598-2668 do */
     int32_t  mv0x, mv0y, mv1x, mv1y;
     int32_t  poc0, poc1;      /* rpl0[ref_idx0]->poc, rpl1[ref_idx1]->poc (identical-motion test) */
     uint8_t  ref0, ref1;      /* slots of those pictures in the launch's reference table          */
     uint8_t  pad2[2];
 } ovhip_pu_desc;
+
+#define OVHIP_PU_BDOF 1
+#define OVHIP_PU_DMVR 2
 
 ovhip_recorder *ovhip_rec_create(int32_t pic_w, int32_t pic_h);
 void  ovhip_rec_destroy(ovhip_recorder *rec);
@@ -302,6 +314,8 @@ int   ovhip_rec_dbf_planes(const ovhip_recorder *rec, ovhip_dbf_planes *out);
 const ovhip_tb_cmd  *ovhip_rec_tb_cmds(const ovhip_recorder *rec, size_t *n);
 const int16_t       *ovhip_rec_coefs(const ovhip_recorder *rec, size_t *n_int16);
 const ovhip_mc_unit *ovhip_rec_mc_units(const ovhip_recorder *rec, size_t *n);
+/* The refined (OVHIP_MC_BDOF / OVHIP_MC_DMVR) units, kept apart so that each list is one launch. */
+const ovhip_mc_unit *ovhip_rec_mcx_units(const ovhip_recorder *rec, size_t *n);
 
 /* ------------------------------------------------------------------------------------
  * Engine (device side).
@@ -333,6 +347,13 @@ int  ovhip_itx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_tb_cmd *
                       uint32_t n_cmds, const int16_t *d_coefs);
 int  ovhip_mc_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs,
                      const ovhip_mc_unit *d_units, uint32_t n_units, const uint16_t *d_lmcs_fwd_lut);
+/* Refined units (OVHIP_MC_BDOF / OVHIP_MC_DMVR).  d_mv_out: DEVICE array of 4 int32 per unit
+ * (mv0x, mv0y, mv1x, mv1y finally used), or NULL.  It replaces the `OVMV *mv0, *mv1` in/out
+ * arguments of rcn_dmvr_mv_refine (rcn_structures.h:628-632): the caller copies them into its
+ * TMVP motion field as vcl_coding_unit.c:2621-2645 does. */
+int  ovhip_mcx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs,
+                      const ovhip_mc_unit *d_units, uint32_t n_units, const uint16_t *d_lmcs_fwd_lut,
+                      int32_t *d_mv_out);
 /* planes->* are DEVICE pointers.  Filters `pic` in place: all vertical edges, then all horizontal. */
 int  ovhip_dbf_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_dbf_planes *planes);
 /* d_params: DEVICE array of ceil(w/ctu)*ceil(h/ctu) entries.  dst and src must not alias. */

@@ -22,7 +22,8 @@ DST_VII, DCT_VIII, DCT_II = 0, 1, 2
 TB_TR, TB_DC, TB_TS, TB_TS_RAW = 0, 1, 2, 3
 TB_FLAG_RASTER = 0x80
 RES_ADD, RES_SUB, RES_ADD_HALF, RES_SUB_HALF, RES_SCALE = 0, 1, 2, 3, 4
-MC_HPEL_FILT, MC_FILT_4x4, MC_NO_LUMA, MC_NO_CHROMA, MC_LMCS = 1, 2, 4, 8, 16
+MC_HPEL_FILT, MC_FILT_4x4, MC_NO_LUMA, MC_NO_CHROMA, MC_LMCS, MC_BDOF, MC_DMVR = 1, 2, 4, 8, 16, 32, 64
+PU_BDOF, PU_DMVR = 1, 2
 
 
 class Pic(C.Structure):
@@ -68,7 +69,7 @@ class PuDesc(C.Structure):
     _fields_ = [("x0", C.c_uint16), ("y0", C.c_uint16), ("log2_w", C.c_uint8), ("log2_h", C.c_uint8),
                 ("inter_dir", C.c_uint8), ("ref_idx0", C.c_uint8), ("ref_idx1", C.c_uint8),
                 ("bcw_idx_plus1", C.c_uint8), ("prec_amvr_half", C.c_uint8), ("planes", C.c_uint8),
-                ("lmcs", C.c_uint8), ("pad", C.c_uint8), ("mv0x", C.c_int32), ("mv0y", C.c_int32),
+                ("lmcs", C.c_uint8), ("refine", C.c_uint8), ("mv0x", C.c_int32), ("mv0y", C.c_int32),
                 ("mv1x", C.c_int32), ("mv1y", C.c_int32), ("poc0", C.c_int32), ("poc1", C.c_int32),
                 ("ref0", C.c_uint8), ("ref1", C.c_uint8), ("pad2", C.c_uint8 * 2)]
 
@@ -152,6 +153,7 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_rec_tb_cmds": (vp, [vp, P(C.c_size_t)]),
         "ovhip_rec_coefs": (vp, [vp, P(C.c_size_t)]),
         "ovhip_rec_mc_units": (vp, [vp, P(C.c_size_t)]),
+        "ovhip_rec_mcx_units": (vp, [vp, P(C.c_size_t)]),
         "ovhip_ctx_create": (C.c_int, [P(vp), C.c_int, vp]),
         "ovhip_ctx_destroy": (None, [vp]),
         "ovhip_ctx_sync": (C.c_int, [vp]),
@@ -167,6 +169,7 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_pic_download": (C.c_int, [vp, P(Pic), vp, vp, vp, i32, i32]),
         "ovhip_itx_launch": (C.c_int, [vp, P(Pic), vp, u32, vp]),
         "ovhip_mc_launch": (C.c_int, [vp, P(Pic), P(Pic), u32, vp, u32, vp]),
+        "ovhip_mcx_launch": (C.c_int, [vp, P(Pic), P(Pic), u32, vp, u32, vp, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)          # AttributeError = missing export: fail loudly
@@ -180,7 +183,7 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
 
 EXPORTED_SYMBOLS = [
     "ovhip_abi_version", "ovhip_rec_create", "ovhip_rec_destroy", "ovhip_rec_reset", "ovhip_rec_tu",
-    "ovhip_rec_pu", "ovhip_rec_dbf_ctu", "ovhip_rec_dbf_planes", "ovhip_dbf_launch", "ovhip_sao_launch", "ovhip_alf_launch", "ovhip_rec_tb_cmds", "ovhip_rec_coefs", "ovhip_rec_mc_units", "ovhip_ctx_create",
+    "ovhip_rec_pu", "ovhip_rec_dbf_ctu", "ovhip_rec_dbf_planes", "ovhip_dbf_launch", "ovhip_sao_launch", "ovhip_alf_launch", "ovhip_rec_tb_cmds", "ovhip_rec_coefs", "ovhip_rec_mc_units", "ovhip_rec_mcx_units", "ovhip_mcx_launch", "ovhip_ctx_create",
     "ovhip_ctx_destroy", "ovhip_ctx_sync", "ovhip_last_error", "ovhip_ctx_stream", "ovhip_malloc",
     "ovhip_free", "ovhip_h2d", "ovhip_d2h", "ovhip_pic_alloc", "ovhip_pic_free", "ovhip_pic_upload",
     "ovhip_pic_download", "ovhip_itx_launch", "ovhip_mc_launch",
@@ -260,3 +263,7 @@ class Recorder:
 
     def mc_units(self) -> np.ndarray:
         return self._arr(self.lib.ovhip_rec_mc_units, MC_UNIT_DTYPE)
+
+    def mcx_units(self) -> np.ndarray:
+        """The BDOF / DMVR units (ovhip_mcx_launch)."""
+        return self._arr(self.lib.ovhip_rec_mcx_units, MC_UNIT_DTYPE)

@@ -331,3 +331,10 @@ extern "C" int ovhip_mc_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip
     OV_LAUNCH_CHECK(ctx, "k_mc");
     return OVHIP_OK;
 }
+
+extern "C" int ovhip_mcx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs,
+                                const ovhip_mc_unit *d_units, uint32_t n_units, const uint16_t *d_lmcs_fwd_lut,
+                                int32_t *d_mv_out)
+{
+    return ov_fail(ctx, OVHIP_EINVAL, "ovhip_mcx_launch: not built", hipSuccess);
+}

@@ -40,7 +40,7 @@ void
 ovhip_rec_destroy(ovhip_recorder *r)
 {
     if (!r) return;
-    free(r->tb); free(r->coef); free(r->mc);
+    free(r->tb); free(r->coef); free(r->mc); free(r->mcx);
     ovhip_rec_dbf_free_(r);
     free(r);
 }
@@ -48,13 +48,14 @@ ovhip_rec_destroy(ovhip_recorder *r)
 void
 ovhip_rec_reset(ovhip_recorder *r)
 {
-    r->n_tb = r->n_coef = r->n_mc = 0;
+    r->n_tb = r->n_coef = r->n_mc = r->n_mcx = 0;
     ovhip_rec_dbf_reset_(r);
 }
 
 const ovhip_tb_cmd *ovhip_rec_tb_cmds(const ovhip_recorder *r, size_t *n) { *n = r->n_tb; return r->tb; }
 const int16_t *ovhip_rec_coefs(const ovhip_recorder *r, size_t *n) { *n = r->n_coef; return r->coef; }
 const ovhip_mc_unit *ovhip_rec_mc_units(const ovhip_recorder *r, size_t *n) { *n = r->n_mc; return r->mc; }
+const ovhip_mc_unit *ovhip_rec_mcx_units(const ovhip_recorder *r, size_t *n) { *n = r->n_mcx; return r->mcx; }
 
 static int
 grow(void **p, size_t *cap, size_t need, size_t elem)
@@ -369,12 +370,81 @@ fail:
 /* ---------------------------------------------------------------- prediction units */
 static int32_t clip3(int32_t v, int32_t lo, int32_t hi) { return v < lo ? lo : v > hi ? hi : v; }
 
+static void
+clip_mv(const ovhip_recorder *r, int px, int py, int pw, int ph, int32_t *mvx, int32_t *mvy)
+{
+    /* clip_mv(): keeps the reference window within [-(pb+3), pic+2] of the block position */
+    *mvx = clip3(*mvx, -((pw + 3 + px) << 4), (r->pic_w + 2 - px) << 4);
+    *mvy = clip3(*mvy, -((ph + 3 + py) << 4), (r->pic_h + 2 - py) << 4);
+}
+
+/* bdof_enable / dmvr_enable CUs: the reference's caller cuts the CU into <=16x16 blocks and hands each
+ * to rcn_bdof_mcp_l (+ one rcn_mcp_b_c for the CU's chroma) or rcn_dmvr_mv_refine
+ * (vcl_coding_unit.c:2450-2472, :2598-2668). */
+static int
+rec_pu_refined(ovhip_recorder *r, const ovhip_pu_desc *pu)
+{
+    const int pw = 1 << pu->log2_w, ph = 1 << pu->log2_h;
+    const int uw = pw > 16 ? 16 : pw, uh = ph > 16 ? 16 : ph;
+    const int dmvr = (pu->refine & OVHIP_PU_DMVR) != 0;
+    int n = 0;
+    if ((pu->inter_dir & 3) != 3 || pw < 8 || ph < 8 || pw * ph < 128) return OVHIP_EINVAL;   /* check_bdof() */
+
+    uint8_t flags = (pu->refine & OVHIP_PU_BDOF) ? OVHIP_MC_BDOF : 0;
+    if (dmvr) flags |= OVHIP_MC_DMVR;
+    if (pu->prec_amvr_half) flags |= OVHIP_MC_HPEL_FILT;
+    if (pu->lmcs)           flags |= OVHIP_MC_LMCS;
+
+    /* chroma of a BDOF-only CU: rcn_mcp_b_c clips the MVs against the CU, not the 16x16 block */
+    int32_t c0x = pu->mv0x, c0y = pu->mv0y, c1x = pu->mv1x, c1y = pu->mv1y;
+    clip_mv(r, pu->x0, pu->y0, pw, ph, &c0x, &c0y);
+    clip_mv(r, pu->x0, pu->y0, pw, ph, &c1x, &c1y);
+
+    /* ... and still applies its identical-motion shortcut (rcn_inter.c:2935-2951; never true for a
+     * conforming bdof_enable, whose references lie on opposite sides of the current picture) */
+    const int ident = pu->poc0 == pu->poc1 && pu->mv0x == pu->mv1x && pu->mv0y == pu->mv1y;
+
+    for (int uy = 0; uy < ph; uy += uh) {
+        for (int ux = 0; ux < pw; ux += uw) {
+            ovhip_mc_unit u;
+            memset(&u, 0, sizeof(u));
+            u.x = (uint16_t)(pu->x0 + ux); u.y = (uint16_t)(pu->y0 + uy);
+            u.w = (uint8_t)uw; u.h = (uint8_t)uh;
+            u.dir = 3; u.flags = flags;
+            u.ref0 = pu->ref0; u.ref1 = pu->ref1;
+            u.w0 = u.w1 = 4;
+            u.mv0x = pu->mv0x; u.mv0y = pu->mv0y; u.mv1x = pu->mv1x; u.mv1y = pu->mv1y;
+            int split_chroma = 0;
+            if (!dmvr) {
+                clip_mv(r, u.x, u.y, uw, uh, &u.mv0x, &u.mv0y);       /* rcn_bdof_mcp_l, rcn_inter.c:1166-1170 */
+                clip_mv(r, u.x, u.y, uw, uh, &u.mv1x, &u.mv1y);
+                split_chroma = ident || u.mv0x != c0x || u.mv0y != c0y || u.mv1x != c1x || u.mv1y != c1y;
+                if (split_chroma) u.flags |= OVHIP_MC_NO_CHROMA;
+            }
+            if (grow((void **)&r->mcx, &r->cap_mcx, r->n_mcx + 1, sizeof(u))) return OVHIP_ENOMEM;
+            r->mcx[r->n_mcx++] = u;
+            ++n;
+            if (split_chroma) {
+                /* the two clips disagree (block far outside the picture): chroma as a plain unit */
+                u.flags = (uint8_t)((flags & OVHIP_MC_HPEL_FILT) | OVHIP_MC_NO_LUMA);
+                if (ident) u.dir = 2;
+                u.mv0x = c0x; u.mv0y = c0y; u.mv1x = c1x; u.mv1y = c1y;
+                if (grow((void **)&r->mc, &r->cap_mc, r->n_mc + 1, sizeof(u))) return OVHIP_ENOMEM;
+                r->mc[r->n_mc++] = u;
+                ++n;
+            }
+        }
+    }
+    return n;
+}
+
 int
 ovhip_rec_pu(ovhip_recorder *r, const ovhip_pu_desc *pu)
 {
     int pw = 1 << pu->log2_w, ph = 1 << pu->log2_h;
     int dir = pu->inter_dir & 3;
     if (!dir) return OVHIP_EINVAL;
+    if (pu->refine) return rec_pu_refined(r, pu);
 
     /* rcn_mcp_b: bi with identical motion degenerates to uni-pred from list 1 */
     if (dir == 3 && pu->poc0 == pu->poc1 && pu->mv0x == pu->mv1x && pu->mv0y == pu->mv1y) dir = 2;

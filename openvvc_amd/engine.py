@@ -83,6 +83,15 @@ class Context:
         self._chk(self.lib.ovhip_mc_launch(self.h, C.byref(dst.s), arr, len(refs), units.ptr, n,
                                            lmcs_fwd.ptr if lmcs_fwd else None), "mc_launch")
 
+    def mcx(self, dst: "DevPic", refs: list, units: "DevBuf", lmcs_fwd: "DevBuf | None" = None,
+            mv_out: "DevBuf | None" = None, n: int | None = None):
+        """BDOF / DMVR units; mv_out: device int32[n][4] receiving the refined motion vectors."""
+        n = units.count if n is None else n
+        arr = (capi.Pic * len(refs))(*[r.s for r in refs])
+        self._chk(self.lib.ovhip_mcx_launch(self.h, C.byref(dst.s), arr, len(refs), units.ptr, n,
+                                            lmcs_fwd.ptr if lmcs_fwd else None,
+                                            mv_out.ptr if mv_out else None), "mcx_launch")
+
 
 class DevDbfPlanes:
     """Deblocking edge planes resident on the device (ovhip_dbf_planes with device pointers)."""

@@ -220,34 +220,75 @@ void oracle_itx(const oracle_pic *pic, const ovhip_tb_cmd *cmds, uint32_t n, con
  * K5/K6/K11: motion compensation, uni / bi / BCW, luma + chroma, LMCS forward reshape
  * ================================================================================== */
 
+/* Reference sample fetch.  Plain MC: coordinates clamped to the picture = emulate_block_border()
+ * (rcn_inter.c:148-225).  DMVR: the (w+7)x(h+7) [chroma (w+3)x(h+3)] window fetched at the INITIAL
+ * integer position is first replicated 2 samples outwards (padd_dmvr / padd_dmvr_c,
+ * rcn_inter.c:326-378) and the refined block reads THAT, so offsets are clamped to the window
+ * (win = 1) before the picture clamp. */
+typedef struct sampler {
+    const uint16_t *ref; int rstride, rw, rh;
+    int px, py;          /* window anchor: block position + initial integer MV             */
+    int dx, dy;          /* integer displacement of the block actually predicted (DMVR)    */
+    int win, lo, hi_x, hi_y;
+} sampler;
+
+static inline int smp(const sampler *s, int i, int j)
+{
+    i += s->dx; j += s->dy;
+    if (s->win) { i = clip3i(i, s->lo, s->hi_x); j = clip3i(j, s->lo, s->hi_y); }
+    return s->ref[clip3i(s->py + j, 0, s->rh - 1) * s->rstride + clip3i(s->px + i, 0, s->rw - 1)];
+}
+
 /* 14-bit intermediate prediction of one block, exactly as put_vvc_{pel,qpel,epel}*_{h,v,hv}
  * compute it (rcn_mc.c:402-420, :903-985, :1188-1270).  The four reference variants are one
  * separable filter whose integer-position row is the identity tap (see vvc_mc_taps.h):
- *   t = F_h(src) >> (BD-8);  P = F_v(t) >> 6.
- * Samples outside the picture are replicated (emulate_block_border, rcn_inter.c:148-225). */
-static void predict14(int16_t *out, int ow, const uint16_t *ref, int rstride, int rw, int rh,
-                      int px, int py, int w, int h, const int8_t *fh, const int8_t *fv, int ntaps)
+ *   t = F_h(src) >> (BD-8);  P = F_v(t) >> 6. */
+static void predict14(int16_t *out, int ow, const sampler *s, int w, int h, const int8_t *fh, const int8_t *fv, int ntaps)
 {
     const int before = ntaps == 8 ? 3 : 1;
     int32_t tmp[(16 + 7) * 16];
     for (int y = 0; y < h + ntaps - 1; ++y) {
-        int sy = clip3i(py + y - before, 0, rh - 1);
         for (int x = 0; x < w; ++x) {
-            int32_t s = 0;
-            for (int t = 0; t < ntaps; ++t) {
-                int sx = clip3i(px + x + t - before, 0, rw - 1);
-                s += fh[t] * (int32_t)ref[sy * rstride + sx];
-            }
-            tmp[y * 16 + x] = (int16_t)(s >> (BD - 8));
+            int32_t a = 0;
+            for (int t = 0; t < ntaps; ++t) a += fh[t] * (int32_t)smp(s, x + t - before, y - before);
+            tmp[y * 16 + x] = (int16_t)(a >> (BD - 8));
         }
     }
     for (int y = 0; y < h; ++y) {
         for (int x = 0; x < w; ++x) {
-            int32_t s = 0;
-            for (int t = 0; t < ntaps; ++t) s += fv[t] * tmp[(y + t) * 16 + x];
-            out[y * ow + x] = (int16_t)(s >> 6);
+            int32_t a = 0;
+            for (int t = 0; t < ntaps; ++t) a += fv[t] * tmp[(y + t) * 16 + x];
+            out[y * ow + x] = (int16_t)(a >> 6);
         }
     }
+}
+
+static void luma_filters(const ovhip_mc_unit *u, int mvx, int mvy, const int8_t **fh, const int8_t **fv, int *ext_x, int *ext_y)
+{
+    int fx = mvx & 15, fy = mvy & 15;
+    if (u->flags & OVHIP_MC_FILT_4x4) { *fh = ovt_mc_luma4[fx]; *fv = ovt_mc_luma4[fy]; }
+    else {
+        if (u->flags & OVHIP_MC_HPEL_FILT) { if (fx == 8) fx = 16; if (fy == 8) fy = 16; }   /* rcn_inter.c:572-577 */
+        *fh = ovt_mc_luma[fx]; *fv = ovt_mc_luma[fy];
+    }
+    if (ext_x) { *ext_x = (fx >> 3) != 0; *ext_y = (fy >> 3) != 0; }
+}
+
+static sampler plane_sampler(const oracle_pic *rp, int plane, int px, int py)
+{
+    sampler s;
+    memset(&s, 0, sizeof(s));
+    s.ref = plane_ptr(rp, plane, &s.rstride);
+    s.rw = rp->w >> (plane != 0); s.rh = rp->h >> (plane != 0);
+    s.px = px; s.py = py;
+    return s;
+}
+
+static int bi_combine(const ovhip_mc_unit *u, int p0, int p1)
+{
+    if (u->dir != 3) return clip_bd(((u->dir == 1 ? p0 : p1) + 8) >> 4);          /* uni: rcn_mc.c:448-533 */
+    if (u->w0 == 4 && u->w1 == 4) return clip_bd((p0 + p1 + 16) >> 5);            /* bi: rcn_mc.c:422-444, :987-1098 */
+    return clip_bd((p1 * u->w1 + p0 * u->w0 + 64) >> 7);                          /* BCW: rcn_mc.c:1480-1610 */
 }
 
 static void mc_plane(const oracle_pic *dst, const oracle_pic *refs, const ovhip_mc_unit *u, int plane,
@@ -264,48 +305,254 @@ static void mc_plane(const oracle_pic *dst, const oracle_pic *refs, const ovhip_
         if (!(u->dir & (1 << l))) continue;
         const oracle_pic *rp = &refs[l ? u->ref1 : u->ref0];
         int mvx = l ? u->mv1x : u->mv0x, mvy = l ? u->mv1y : u->mv0y;
-        int rstride;
-        const uint16_t *r = plane_ptr(rp, plane, &rstride);
         const int8_t *fh, *fv;
         if (!c) {
-            int fx = mvx & 15, fy = mvy & 15;
-            if (u->flags & OVHIP_MC_FILT_4x4) { fh = ovt_mc_luma4[fx]; fv = ovt_mc_luma4[fy]; }
-            else {
-                if (u->flags & OVHIP_MC_HPEL_FILT) { if (fx == 8) fx = 16; if (fy == 8) fy = 16; }
-                fh = ovt_mc_luma[fx]; fv = ovt_mc_luma[fy];
-            }
-            predict14(p[l], 16, r, rstride, rp->w, rp->h, x + (mvx >> 4), y + (mvy >> 4), w, h, fh, fv, 8);
+            sampler s = plane_sampler(rp, 0, x + (mvx >> 4), y + (mvy >> 4));
+            luma_filters(u, mvx, mvy, &fh, &fv, NULL, NULL);
+            predict14(p[l], 16, &s, w, h, fh, fv, 8);
         } else {
-            fh = ovt_mc_chroma[mvx & 31]; fv = ovt_mc_chroma[mvy & 31];
-            predict14(p[l], 16, r, rstride, rp->w >> 1, rp->h >> 1, x + (mvx >> 5), y + (mvy >> 5), w, h, fh, fv, 4);
+            sampler s = plane_sampler(rp, plane, x + (mvx >> 5), y + (mvy >> 5));
+            predict14(p[l], 16, &s, w, h, ovt_mc_chroma[mvx & 31], ovt_mc_chroma[mvy & 31], 4);
         }
     }
     for (int j = 0; j < h; ++j) {
         for (int i = 0; i < w; ++i) {
-            int v;
-            if (u->dir != 3) {
-                v = clip_bd((p[u->dir - 1][j * 16 + i] + 8) >> 4);                 /* uni: rcn_mc.c:448-533 */
-            } else if (u->w0 == 4 && u->w1 == 4) {
-                v = clip_bd((p[0][j * 16 + i] + p[1][j * 16 + i] + 16) >> 5);      /* bi: rcn_mc.c:422-444, :987-1098 */
-            } else {
-                v = clip_bd((p[1][j * 16 + i] * u->w1 + p[0][j * 16 + i] * u->w0 + 64) >> 7); /* BCW: rcn_mc.c:1480-1610 */
-            }
+            int v = bi_combine(u, p[0][j * 16 + i], p[1][j * 16 + i]);
             if (!c && (u->flags & OVHIP_MC_LMCS) && lmcs_fwd) v = lmcs_fwd[v & PIX_MAX]; /* rcn_lmcs.c:275-295 */
             d[j * dstride + i] = (uint16_t)v;
         }
     }
 }
 
-/* rcn_mcp_l/_c, rcn_motion_compensation_b_l/_c (rcn_inter.c:520-602, :1391-1554, :1822-1904) */
-void oracle_mc(const oracle_pic *dst, const oracle_pic *refs, uint32_t n_refs,
-               const ovhip_mc_unit *units, uint32_t n, const uint16_t *lmcs_fwd)
+/* ---- K8: BDOF on one <=16x16 luma block (rcn_bdof_mcp_l rcn_inter.c:1136-1250; rcn_prof_bdof.c:303-490).
+ * p0/p1: 14-bit predictions (stride 16); s0/s1: samplers positioned on the predicted blocks. */
+#define BDOF_RS 18
+static int floor_log2u(uint32_t v) { int r = -1; while (v) { v >>= 1; ++r; } return r; }
+
+static void bdof_block(uint16_t *d, int dstride, const int16_t *p0, const int16_t *p1, const sampler *s0, const sampler *s1,
+                       const int ext[2][2], int w, int h)
+{
+    int16_t R[2][BDOF_RS * BDOF_RS], GX[2][BDOF_RS * BDOF_RS], GY[2][BDOF_RS * BDOF_RS];
+    const int16_t *p[2] = { p0, p1 };
+    const sampler *s[2] = { s0, s1 };
+    for (int l = 0; l < 2; ++l) {
+        int16_t *r = R[l];
+        /* interior = prediction; ring = integer reference samples << 4 (extend_bdof_buff, rcn_prof_bdof.c:303-352) */
+        for (int j = 0; j < h + 2; ++j)
+            for (int i = 0; i < w + 2; ++i) {
+                int in = i >= 1 && i <= w && j >= 1 && j <= h;
+                r[j * BDOF_RS + i] = in ? p[l][(j - 1) * 16 + i - 1]
+                                        : (int16_t)(smp(s[l], i - 1 + ext[l][0], j - 1 + ext[l][1]) << (14 - BD));
+            }
+        /* gradients of the interior (compute_prof_grad, rcn_prof_bdof.c:152-172) */
+        for (int j = 1; j <= h; ++j)
+            for (int i = 1; i <= w; ++i) {
+                int16_t gy = (int16_t)((r[(j + 1) * BDOF_RS + i] - (1 << 13)) >> 6);
+                gy -= (int16_t)((r[(j - 1) * BDOF_RS + i] - (1 << 13)) >> 6);
+                int16_t gx = (int16_t)((r[j * BDOF_RS + i + 1] - (1 << 13)) >> 6);
+                gx -= (int16_t)((r[j * BDOF_RS + i - 1] - (1 << 13)) >> 6);
+                GX[l][j * BDOF_RS + i] = gx; GY[l][j * BDOF_RS + i] = gy;
+            }
+        /* replicate gradients AND predictions one sample outwards (extend_bdof_grad, rcn_inter.c:840-869) */
+        int16_t *planes[3] = { GX[l], GY[l], r };
+        for (int k = 0; k < 3; ++k) {
+            int16_t *a = planes[k];
+            for (int j = 1; j <= h; ++j) { a[j * BDOF_RS] = a[j * BDOF_RS + 1]; a[j * BDOF_RS + w + 1] = a[j * BDOF_RS + w]; }
+            for (int i = 0; i < w + 2; ++i) { a[i] = a[BDOF_RS + i]; a[(h + 1) * BDOF_RS + i] = a[h * BDOF_RS + i]; }
+        }
+    }
+    for (int sy = 0; sy < h; sy += 4) {
+        for (int sx = 0; sx < w; sx += 4) {
+            /* derive_bdof_weights (rcn_prof_bdof.c:355-428): 6x6 window whose top-left is the padded (sx, sy) */
+            int sum_ax = 0, sum_ay = 0, sum_dx = 0, sum_dy = 0, sum_xy = 0, wx = 0, wy = 0;
+            for (int j = 0; j < 6; ++j)
+                for (int i = 0; i < 6; ++i) {
+                    int o = (sy + j) * BDOF_RS + sx + i;
+                    int32_t ax = (GX[0][o] + GX[1][o]) >> 1, ay = (GY[0][o] + GY[1][o]) >> 1;
+                    int32_t dr = ((R[1][o] - (1 << 13)) >> 4) - ((R[0][o] - (1 << 13)) >> 4);
+                    sum_ax += abs(ax); sum_ay += abs(ay);
+                    sum_xy += ay < 0 ? -ax : (ay == 0 ? 0 : ax);
+                    sum_dx += ax < 0 ? -dr : (ax == 0 ? 0 : dr);
+                    sum_dy += ay < 0 ? -dr : (ay == 0 ? 0 : dr);
+                }
+            if (sum_ax) wx = clip3i((sum_dx * 4) >> floor_log2u(sum_ax), -15, 15);
+            if (sum_ay) {
+                int x_off = 0;
+                if (wx) {
+                    int high = sum_xy >> 12, low = sum_xy & 4095;
+                    x_off = (((wx * high) * 4096) + (wx * low)) >> 1;
+                }
+                wy = clip3i(((sum_dy * 4) - x_off) >> floor_log2u(sum_ay), -15, 15);
+            }
+            /* rcn_apply_bdof_subblock (rcn_prof_bdof.c:59-103) */
+            for (int j = 0; j < 4; ++j)
+                for (int i = 0; i < 4; ++i) {
+                    int o = (sy + j + 1) * BDOF_RS + sx + i + 1;
+                    int32_t b = wx * (GX[0][o] - GX[1][o]) + wy * (GY[0][o] - GY[1][o]);
+                    int16_t v = (int16_t)((R[0][o] + R[1][o] + b + 16) >> 5);
+                    d[(sy + j) * dstride + sx + i] = (uint16_t)clip_bd(v);
+                }
+        }
+    }
+}
+
+/* ---- K7: DMVR (rcn_dmvr_mv_refine rcn_inter.c:872-1126) ---- */
+static void clip_mv(int pos_x, int pos_y, int pic_w, int pic_h, int pb_w, int pb_h, int *mvx, int *mvy)
+{   /* rcn_inter.c:96-109 */
+    *mvx = clip3i(*mvx, -((pb_w + 3 + pos_x) << 4), (pic_w + 2 - pos_x) << 4);
+    *mvy = clip3i(*mvy, -((pb_h + 3 + pos_y) << 4), (pic_h + 2 - pos_y) << 4);
+}
+
+/* put_vvc_{pel_bilinear_pixels,qpel_bilinear_h,_v,_hv} (rcn_mc.c:788-899) on the (w+4)x(h+4) block that
+ * starts 2 samples up-left of the prediction block; out stride 20 */
+static void dmvr_bilinear(int16_t *out, const sampler *s, int w, int h, int fx, int fy)
+{
+    int16_t t[21 * 20];
+    for (int j = 0; j < h + 5; ++j)
+        for (int i = 0; i < w + 4; ++i)
+            t[j * 20 + i] = fx ? (int16_t)(((16 - fx) * smp(s, i - 2, j - 2) + fx * smp(s, i - 1, j - 2) + 8) >> 4)
+                               : (int16_t)smp(s, i - 2, j - 2);
+    for (int j = 0; j < h + 4; ++j)
+        for (int i = 0; i < w + 4; ++i)
+            out[j * 20 + i] = fy ? (int16_t)(((16 - fy) * t[j * 20 + i] + fy * t[(j + 1) * 20 + i] + 8) >> 4) : t[j * 20 + i];
+}
+
+/* rcn_dmvr_sad_8/_16 (rcn_inter.c:614-664): every second row */
+static uint64_t dmvr_sad(const int16_t *b0, const int16_t *b1, int w, int h)
+{
+    uint64_t sum = 0;
+    for (int j = 0; j < h; j += 2)
+        for (int i = 0; i < w; ++i) sum += (uint64_t)abs(b0[j * 20 + i] - b1[j * 20 + i]);
+    return sum;
+}
+
+static int32_t div_for_maxq7(int64_t num, int64_t den)
+{   /* rcn_inter.c:758-797: 3-bit restoring division, result in 1/16 pel, |q| <= 7 */
+    int32_t sign = 0, q = 0;
+    if (num < 0) { sign = 1; num = -num; }
+    den <<= 3;
+    if (num >= den) { num -= den; q++; }
+    q <<= 1; den >>= 1;
+    if (num >= den) { num -= den; q++; }
+    q <<= 1;
+    if (num >= (den >> 1)) q++;
+    return sign ? -q : q;
+}
+
+/* One BDOF and/or DMVR unit (luma <= 16x16 + chroma): rcn_bdof_mcp_l (rcn_inter.c:1136-1250) followed
+ * by the chroma of rcn_mcp_b_c, or rcn_dmvr_mv_refine (rcn_inter.c:872-1126). */
+static void mc_refined_unit(const oracle_pic *dst, const oracle_pic *refs, const ovhip_mc_unit *u,
+                            const uint16_t *lmcs_fwd, int32_t *mv_out)
+{
+    const int w = u->w, h = u->h;
+    const int dmvr = (u->flags & OVHIP_MC_DMVR) != 0;
+    int use_bdof = (u->flags & OVHIP_MC_BDOF) != 0;
+    int mv[2][2] = { { u->mv0x, u->mv0y }, { u->mv1x, u->mv1y } };
+    int ini[2][2];
+    sampler sl[2];
+    memcpy(ini, mv, sizeof(ini));
+
+    for (int l = 0; l < 2; ++l) {
+        const oracle_pic *rp = &refs[l ? u->ref1 : u->ref0];
+        int cx = mv[l][0], cy = mv[l][1];
+        if (dmvr) clip_mv(u->x, u->y, rp->w, rp->h, w, h, &cx, &cy);   /* derive_dmvr_ref_buf_y, rcn_inter.c:431-471 */
+        sl[l] = plane_sampler(rp, 0, u->x + (cx >> 4), u->y + (cy >> 4));
+        if (dmvr) { sl[l].win = 1; sl[l].lo = -3; sl[l].hi_x = w + 3; sl[l].hi_y = h + 3; }
+    }
+
+    if (dmvr) {
+        int16_t B[2][24 * 20];
+        for (int l = 0; l < 2; ++l) dmvr_bilinear(B[l], &sl[l], w, h, ini[l][0] & 15, ini[l][1] & 15);
+        uint64_t sad_c = dmvr_sad(B[0] + 2 * 20 + 2, B[1] + 2 * 20 + 2, w, h);
+        uint64_t min_cost = sad_c - (sad_c >> 2);
+        if (min_cost >= (uint64_t)(w * h)) {
+            uint64_t sad[25], best = (uint64_t)-1;
+            int idx = 12;
+            sad[12] = min_cost;
+            for (int k = 0; k < 25; ++k) {
+                if (k == 12) continue;
+                int dx = k % 5 - 2, dy = k / 5 - 2;                         /* dmvr_mv_x/_y, rcn_inter.c:63-87 */
+                sad[k] = dmvr_sad(B[0] + (2 + dy) * 20 + 2 + dx, B[1] + (2 - dy) * 20 + 2 - dx, w, h);
+            }
+            for (int k = 0; k < 25; ++k)                                    /* dmvr_compute_sads_*, rcn_inter.c:666-754 */
+                if (sad[k] < best || (k == 12 && sad[k] <= best)) { best = sad[k]; idx = k; }
+            int dh = (idx % 5 - 2) << 4, dv = (idx / 5 - 2) << 4;
+            min_cost = sad[idx];
+            if (abs(dh) != 32 && abs(dv) != 32) {                           /* refine_mv, rcn_inter.c:799-833 */
+                uint64_t s0 = sad[idx], s1 = sad[idx - 1], s3 = sad[idx + 1], s2 = sad[idx - 5], s4 = sad[idx + 5];
+                int64_t den_h = (int64_t)(s1 + s3 - (s0 << 1)), den_v = (int64_t)(s2 + s4 - (s0 << 1));
+                if (den_h) dh += (s1 != s0 && s3 != s0) ? div_for_maxq7((int64_t)(s1 << 4) - (int64_t)(s3 << 4), den_h) : (s1 == s0 ? -8 : 8);
+                if (den_v) dv += (s2 != s0 && s4 != s0) ? div_for_maxq7((int64_t)((s2 - s4) << 4), den_v) : (s2 == s0 ? -8 : 8);
+            }
+            mv[0][0] = clip3i(mv[0][0] + dh, -(1 << 17), (1 << 17) - 1); mv[0][1] = clip3i(mv[0][1] + dv, -(1 << 17), (1 << 17) - 1);
+            mv[1][0] = clip3i(mv[1][0] - dh, -(1 << 17), (1 << 17) - 1); mv[1][1] = clip3i(mv[1][1] - dv, -(1 << 17), (1 << 17) - 1);
+        }
+        if (use_bdof && min_cost < (uint64_t)(2 * w * h)) use_bdof = 0;
+    }
+    if (mv_out) { mv_out[0] = mv[0][0]; mv_out[1] = mv[0][1]; mv_out[2] = mv[1][0]; mv_out[3] = mv[1][1]; }
+
+    if (!(u->flags & OVHIP_MC_NO_LUMA)) {
+        int16_t p[2][16 * 16];
+        int ext[2][2];
+        for (int l = 0; l < 2; ++l) {
+            const int8_t *fh, *fv;
+            luma_filters(u, mv[l][0], mv[l][1], &fh, &fv, &ext[l][0], &ext[l][1]);
+            sl[l].dx = (mv[l][0] >> 4) - (ini[l][0] >> 4);
+            sl[l].dy = (mv[l][1] >> 4) - (ini[l][1] >> 4);
+            predict14(p[l], 16, &sl[l], w, h, fh, fv, 8);
+        }
+        uint16_t *d = dst->y + u->y * dst->stride_y + u->x;
+        if (use_bdof) bdof_block(d, dst->stride_y, p[0], p[1], &sl[0], &sl[1], ext, w, h);
+        else
+            for (int j = 0; j < h; ++j)
+                for (int i = 0; i < w; ++i) d[j * dst->stride_y + i] = (uint16_t)clip_bd((p[0][j * 16 + i] + p[1][j * 16 + i] + 16) >> 5);
+        if ((u->flags & OVHIP_MC_LMCS) && lmcs_fwd)
+            for (int j = 0; j < h; ++j)
+                for (int i = 0; i < w; ++i) d[j * dst->stride_y + i] = lmcs_fwd[d[j * dst->stride_y + i] & PIX_MAX];
+    }
+    if (!(u->flags & OVHIP_MC_NO_CHROMA)) {
+        const int wc = w >> 1, hc = h >> 1;
+        for (int plane = 1; plane < 3; ++plane) {
+            int16_t p[2][16 * 16];
+            for (int l = 0; l < 2; ++l) {
+                const oracle_pic *rp = &refs[l ? u->ref1 : u->ref0];
+                int cx = ini[l][0], cy = ini[l][1];
+                if (dmvr) clip_mv(u->x, u->y, rp->w, rp->h, w, h, &cx, &cy);   /* derive_dmvr_ref_buf_c, rcn_inter.c:473-517 */
+                sampler s = plane_sampler(rp, plane, (u->x >> 1) + (cx >> 5), (u->y >> 1) + (cy >> 5));
+                if (dmvr) { s.win = 1; s.lo = -1; s.hi_x = wc + 1; s.hi_y = hc + 1; }
+                s.dx = (mv[l][0] >> 5) - (ini[l][0] >> 5);
+                s.dy = (mv[l][1] >> 5) - (ini[l][1] >> 5);
+                predict14(p[l], 16, &s, wc, hc, ovt_mc_chroma[mv[l][0] & 31], ovt_mc_chroma[mv[l][1] & 31], 4);
+            }
+            int dstride;
+            uint16_t *d = plane_ptr(dst, plane, &dstride) + (u->y >> 1) * dstride + (u->x >> 1);
+            for (int j = 0; j < hc; ++j)
+                for (int i = 0; i < wc; ++i) d[j * dstride + i] = (uint16_t)clip_bd((p[0][j * 16 + i] + p[1][j * 16 + i] + 16) >> 5);
+        }
+    }
+}
+
+/* rcn_mcp_l/_c, rcn_motion_compensation_b_l/_c (rcn_inter.c:520-602, :1391-1554, :1822-1904);
+ * units flagged OVHIP_MC_BDOF / OVHIP_MC_DMVR go through mc_refined_unit.  mv_out (may be NULL):
+ * 4 int32 per unit, the motion vectors finally used (DMVR write-back for TMVP,
+ * vcl_coding_unit.c:2621-2645). */
+void oracle_mc_ex(const oracle_pic *dst, const oracle_pic *refs, uint32_t n_refs,
+                  const ovhip_mc_unit *units, uint32_t n, const uint16_t *lmcs_fwd, int32_t *mv_out)
 {
     (void)n_refs;
     for (uint32_t i = 0; i < n; ++i) {
         const ovhip_mc_unit *u = &units[i];
+        if (u->flags & (OVHIP_MC_BDOF | OVHIP_MC_DMVR)) { mc_refined_unit(dst, refs, u, lmcs_fwd, mv_out ? mv_out + 4 * i : NULL); continue; }
+        if (mv_out) { mv_out[4 * i] = u->mv0x; mv_out[4 * i + 1] = u->mv0y; mv_out[4 * i + 2] = u->mv1x; mv_out[4 * i + 3] = u->mv1y; }
         if (!(u->flags & OVHIP_MC_NO_LUMA)) mc_plane(dst, refs, u, 0, lmcs_fwd);
         if (!(u->flags & OVHIP_MC_NO_CHROMA)) { mc_plane(dst, refs, u, 1, lmcs_fwd); mc_plane(dst, refs, u, 2, lmcs_fwd); }
     }
+}
+
+void oracle_mc(const oracle_pic *dst, const oracle_pic *refs, uint32_t n_refs,
+               const ovhip_mc_unit *units, uint32_t n, const uint16_t *lmcs_fwd)
+{
+    oracle_mc_ex(dst, refs, n_refs, units, n, lmcs_fwd, NULL);
 }
 
 /* ====================================================================================

@@ -358,6 +358,134 @@ gen_mc(const char *dir)
 }
 
 
+/* ====================================================================================== MCX
+ * mcx.ovg : rcn_bdof_mcp_l (+ rcn_mcp_b_c) and rcn_dmvr_mv_refine driven the way their caller does
+ *           (vcl_coding_unit.c:2450-2472, :2598-2668)                          -> K7, K8
+ * Reference pictures: R0 smooth random; R1 = R0 displaced by a per-64x64-region integer shift plus a
+ * per-region noise level (0 = exact copy: exercises DMVR's early exit and the BDOF disable);
+ * R2 independent.  rpl0 = {R0, R2}, rpl1 = {R1, R0}. */
+static void
+gen_mcx(const char *dir)
+{
+    gbuf b_desc = { .type = T_U8 }, b_eoff = { .type = T_U32 }, b_exp = { .type = T_U16 }, b_mv = { .type = T_I32 };
+    uint32_t n_cases = 0;
+    g_seed = 0x266 + 77;
+
+    OVCTUDec *c = ref_new_ctudec(0, 0);
+    struct InterDRVCtx *ic = &c->drv_ctx.inter_ctx;
+    OVPicture *ref[3];
+    for (int i = 0; i < 3; ++i) {
+        ref[i] = ref_new_picture(MC_W, MC_H, i == 0 ? 8 : (i == 1 ? 24 : 4));
+        for (int p = 0; p < 3; ++p) fill_plane(ref[i]->frame->data[p], MC_W >> !!p, MC_H >> !!p, MC_W >> !!p);
+    }
+    for (int p = 0; p < 3; ++p) {
+        int w = MC_W >> !!p, h = MC_H >> !!p, rs = p ? 32 : 64;
+        uint16_t *a = (uint16_t *)ref[0]->frame->data[p], *b = (uint16_t *)ref[1]->frame->data[p];
+        static int shx[16], shy[16], nz[16];
+        if (!p) for (int k = 0; k < 16; ++k) { shx[k] = rnd_range(-2, 2); shy[k] = rnd_range(-2, 2); nz[k] = k % 3 == 0 ? 0 : (k % 3 == 1 ? 2 : 12); }
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) {
+                int k = ((y / rs) * 4 + x / rs) & 15;
+                int sx = x + (p ? shx[k] / 2 : shx[k]), sy = y + (p ? shy[k] / 2 : shy[k]);
+                sx = sx < 0 ? 0 : sx >= w ? w - 1 : sx; sy = sy < 0 ? 0 : sy >= h ? h - 1 : sy;
+                int v = a[sy * w + sx] + (nz[k] ? rnd_range(-nz[k], nz[k]) : 0);
+                b[y * w + x] = (uint16_t)(v < 0 ? 0 : v > 1023 ? 1023 : v);
+            }
+    }
+    ic->rpl0[0] = ref[0]; ic->rpl0[1] = ref[2]; ic->rpl1[0] = ref[1]; ic->rpl1[1] = ref[0];
+    static const uint8_t slot0[2] = { 0, 2 }, slot1[2] = { 1, 0 };
+    for (int i = 0; i < 16; ++i) {
+        ic->scale_fact_rpl0[i][0] = ic->scale_fact_rpl0[i][1] = 1 << RPR_SCALE_BITS;
+        ic->scale_fact_rpl1[i][0] = ic->scale_fact_rpl1[i][1] = 1 << RPR_SCALE_BITS;
+    }
+    const struct OVBuffInfo *cb = &c->rcn_ctx.ctu_buff;
+
+    for (int l2w = 3; l2w <= 6; ++l2w) {
+        for (int l2h = 3; l2h <= 6; ++l2h) {
+            int w = 1 << l2w, h = 1 << l2h;
+            if (l2w + l2h < 7 || w > MC_W || h > MC_H) continue;
+            int reps = (w * h <= 256) ? 60 : (w * h <= 1024 ? 18 : 8);
+            for (int rep = 0; rep < reps; ++rep) {
+                ovhip_pu_desc d;
+                memset(&d, 0, sizeof(d));
+                int px, py;
+                do {
+                    px = rnd_range(0, (MC_W - w) / 4) * 4;
+                    py = rnd_range(0, (MC_H - h) / 4) * 4;
+                } while ((px >> 7) != ((px + w - 1) >> 7) || (py >> 7) != ((py + h - 1) >> 7));
+                if (rep % 10 == 6) px = 0;
+                if (rep % 10 == 8) py = 0;
+                d.x0 = px; d.y0 = py; d.log2_w = l2w; d.log2_h = l2h;
+                d.inter_dir = 3;
+                d.ref_idx0 = rep % 6 == 5; d.ref_idx1 = rep % 8 == 7;
+                int range = rep % 9 == 0 ? 4000 : (rep % 3 == 1 ? 40 : 300);
+                d.mv0x = rnd_range(-range, range); d.mv0y = rnd_range(-range, range);
+                if (rep % 4 != 3) { d.mv1x = -d.mv0x + rnd_range(-20, 20); d.mv1y = -d.mv0y + rnd_range(-20, 20); }   /* mirrored + jitter */
+                else              { d.mv1x = rnd_range(-range, range); d.mv1y = rnd_range(-range, range); }
+                if (rep % 7 == 3) { d.mv0x &= ~15; d.mv1y &= ~15; }
+                if (rep % 7 == 5) { d.mv0x &= ~15; d.mv0y &= ~15; d.mv1x &= ~15; d.mv1y &= ~15; }
+                d.prec_amvr_half = rep % 5 == 2;
+                if (d.prec_amvr_half) { d.mv0x = (d.mv0x & ~15) | 8; d.mv1y = (d.mv1y & ~15) | 8; }
+                d.planes = 3;
+                d.refine = (uint8_t)(1 + rep % 3);                  /* BDOF, DMVR, DMVR + BDOF */
+                d.poc0 = ic->rpl0[d.ref_idx0]->poc; d.poc1 = ic->rpl1[d.ref_idx1]->poc;
+                d.ref0 = slot0[d.ref_idx0]; d.ref1 = slot1[d.ref_idx1];
+
+                c->ctb_x = px >> 7; c->ctb_y = py >> 7;
+                int x0 = px & 127, y0 = py & 127;
+                ic->prec_amvr = d.prec_amvr_half ? MV_PRECISION_HALF : 0;
+                OVMV mv0 = { .x = d.mv0x, .y = d.mv0y, .ref_idx = d.ref_idx0 };
+                OVMV mv1 = { .x = d.mv1x, .y = d.mv1y, .ref_idx = d.ref_idx1 };
+                for (int j = 0; j < 128; ++j) memset(cb->y + j * cb->stride, 0xAB, 256);
+                for (int j = 0; j < 64; ++j) { memset(cb->cb + j * cb->stride_c, 0xAB, 128); memset(cb->cr + j * cb->stride_c, 0xAB, 128); }
+
+                int l2sw = l2w < 4 ? l2w : 4, l2sh = l2h < 4 ? l2h : 4;
+                uint32_t mv_off = (uint32_t)b_mv.n;
+                for (int i = 0; i < (h >> l2sh); ++i)
+                    for (int j = 0; j < (w >> l2sw); ++j) {
+                        OVMV m0 = mv0, m1 = mv1;
+                        if (d.refine & OVHIP_PU_DMVR)
+                            c->rcn_funcs.rcn_dmvr_mv_refine(c, *cb, x0 + j * 16, y0 + i * 16, l2sw, l2sh, &m0, &m1,
+                                                            d.ref_idx0, d.ref_idx1, d.refine & OVHIP_PU_BDOF);
+                        else
+                            c->rcn_funcs.rcn_bdof_mcp_l(c, *cb, x0 + j * 16, y0 + i * 16, l2sw, l2sh, m0, m1, d.ref_idx0, d.ref_idx1);
+                        int32_t o[4] = { m0.x, m0.y, m1.x, m1.y };
+                        gbuf_push(&b_mv, o, 4);
+                    }
+                if (!(d.refine & OVHIP_PU_DMVR))
+                    c->rcn_funcs.rcn_mcp_b_c(c, *cb, ic, c->part_ctx, mv0, mv1, x0, y0, l2w, l2h, 3, d.ref_idx0, d.ref_idx1);
+
+                uint32_t eoff[4];
+                eoff[0] = (uint32_t)b_exp.n; dump_rect(&b_exp, cb->y, cb->stride, x0, y0, w, h);
+                eoff[1] = (uint32_t)b_exp.n; dump_rect(&b_exp, cb->cb, cb->stride_c, x0 >> 1, y0 >> 1, w >> 1, h >> 1);
+                eoff[2] = (uint32_t)b_exp.n; dump_rect(&b_exp, cb->cr, cb->stride_c, x0 >> 1, y0 >> 1, w >> 1, h >> 1);
+                eoff[3] = mv_off;
+                gbuf_push(&b_desc, &d, sizeof(d));
+                gbuf_push(&b_eoff, eoff, 4);
+                n_cases++;
+            }
+        }
+    }
+
+    gfile g = gfile_open(dir, "mcx.ovg");
+    uint32_t d3[3] = { 3, MC_H, MC_W };
+    uint16_t *all = malloc(3 * MC_W * MC_H * 2);
+    for (int i = 0; i < 3; ++i) memcpy(all + i * MC_W * MC_H, ref[i]->frame->data[0], MC_W * MC_H * 2);
+    gfile_array(&g, "ref_y", T_U16, all, 3, d3);
+    d3[1] = MC_H / 2; d3[2] = MC_W / 2;
+    for (int i = 0; i < 3; ++i) memcpy(all + i * (MC_W / 2) * (MC_H / 2), ref[i]->frame->data[1], (MC_W / 2) * (MC_H / 2) * 2);
+    gfile_array(&g, "ref_cb", T_U16, all, 3, d3);
+    for (int i = 0; i < 3; ++i) memcpy(all + i * (MC_W / 2) * (MC_H / 2), ref[i]->frame->data[2], (MC_W / 2) * (MC_H / 2) * 2);
+    gfile_array(&g, "ref_cr", T_U16, all, 3, d3);
+    uint32_t d2[2] = { n_cases, sizeof(ovhip_pu_desc) };
+    gfile_array(&g, "desc", T_U8, b_desc.data, 2, d2);
+    d2[1] = 4; gfile_array(&g, "exp_off", T_U32, b_eoff.data, 2, d2);
+    gfile_buf(&g, "exp", &b_exp);
+    gfile_buf(&g, "exp_mv", &b_mv);
+    gfile_close(&g);
+    fprintf(stderr, "mcx.ovg: %u cases, %zu expected samples, %zu refined MVs\n", n_cases, b_exp.n, b_mv.n / 4);
+}
+
 /* ====================================================================================== DBF */
 #include "dbf_utils.h"
 #include "drv_lines.h"
@@ -770,6 +898,7 @@ main(int argc, char **argv)
     const char *only = argc > 2 ? argv[2] : NULL;
     if (!only || !strcmp(only, "itx")) gen_itx(dir);
     if (!only || !strcmp(only, "mc"))  gen_mc(dir);
+    if (!only || !strcmp(only, "mcx")) gen_mcx(dir);
     if (!only || !strcmp(only, "dbf")) gen_dbf(dir);
     if (!only || !strcmp(only, "sao")) gen_sao(dir);
     if (!only || !strcmp(only, "alf")) gen_alf(dir);

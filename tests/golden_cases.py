@@ -51,6 +51,16 @@ def mc_cases():
     return refs, descs, g["exp_off"], g["exp"]
 
 
+def mcx_cases():
+    """BDOF / DMVR: (refs, descs, exp_off [n,4] (Y, Cb, Cr sample offsets + index of the first refined MV), exp, exp_mv [m,4])."""
+    g = golden_io.load("mcx.ovg")
+    n = g["desc"].shape[0]
+    _, rh, rw = g["ref_y"].shape
+    refs = [HostPic(rw, rh, g["ref_y"][k], g["ref_cb"][k], g["ref_cr"][k]) for k in range(3)]
+    descs = [capi.PuDesc.from_buffer_copy(g["desc"][i].tobytes()) for i in range(n)]
+    return refs, descs, g["exp_off"], g["exp"], g["exp_mv"].reshape(-1, 4)
+
+
 def check_rects(pic: HostPic, rects, exp, what=""):
     planes = pic.planes()
     bad = []

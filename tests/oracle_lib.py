@@ -30,6 +30,8 @@ def lib():
         _lib.oracle_itx.restype = None
         _lib.oracle_mc.argtypes = [C.POINTER(OPic), C.POINTER(OPic), C.c_uint32, vp, C.c_uint32, vp]
         _lib.oracle_mc.restype = None
+        _lib.oracle_mc_ex.argtypes = [C.POINTER(OPic), C.POINTER(OPic), C.c_uint32, vp, C.c_uint32, vp, vp]
+        _lib.oracle_mc_ex.restype = None
         _lib.oracle_dbf.argtypes = [C.POINTER(OPic), vp]
         _lib.oracle_dbf.restype = None
         _lib.oracle_sao.argtypes = [C.POINTER(OPic), C.POINTER(OPic), vp, C.c_int]
@@ -75,6 +77,20 @@ def mc(dst: HostPic, refs, units: np.ndarray, lmcs_fwd=None):
         lmcs_fwd = np.ascontiguousarray(lmcs_fwd, dtype=np.uint16)
         lut = lmcs_fwd.ctypes.data
     lib().oracle_mc(C.byref(s), arr, len(refs), units.ctypes.data, len(units), lut)
+
+
+def mc_ex(dst: HostPic, refs, units: np.ndarray, lmcs_fwd=None) -> np.ndarray:
+    """Plain + BDOF / DMVR units; returns the int32 [n, 4] motion vectors finally used."""
+    s = dst.struct()
+    arr = (OPic * len(refs))(*[r.struct() for r in refs])
+    units = np.ascontiguousarray(units)
+    lut = None
+    if lmcs_fwd is not None:
+        lmcs_fwd = np.ascontiguousarray(lmcs_fwd, dtype=np.uint16)
+        lut = lmcs_fwd.ctypes.data
+    mv = np.zeros((len(units), 4), np.int32)
+    lib().oracle_mc_ex(C.byref(s), arr, len(refs), units.ctypes.data, len(units), lut, mv.ctypes.data)
+    return mv
 
 
 def dbf_planes_struct(planes: dict):

@@ -33,6 +33,34 @@ def test_mc_oracle_matches_reference(built_lib):
         golden_cases.check_rects(dst, rects, exp, f"mc case {i} dir={d.inter_dir} planes={d.planes}")
 
 
+def test_mcx_oracle_matches_reference(built_lib):
+    """BDOF (rcn_bdof_mcp_l + rcn_mcp_b_c) and DMVR (rcn_dmvr_mv_refine, incl. the MV write-back)."""
+    refs, descs, exp_off, exp, exp_mv = golden_cases.mcx_cases()
+    rw, rh = refs[0].w, refs[0].h
+    rec = capi.Recorder(rw, rh)
+    n_moved = n_bdof = 0
+    for i, d in enumerate(descs):
+        rec.reset()
+        rec.pu(d)
+        dst = HostPic(rw, rh)
+        dst.y[:] = 0xABAB; dst.cb[:] = 0xABAB; dst.cr[:] = 0xABAB
+        ux = rec.mcx_units()
+        oracle_lib.mc(dst, refs, rec.mc_units())
+        mv = oracle_lib.mc_ex(dst, refs, ux)
+        w, h = 1 << d.log2_w, 1 << d.log2_h
+        rects = [(0, d.x0, d.y0, w, h, int(exp_off[i, 0])),
+                 (1, d.x0 >> 1, d.y0 >> 1, w >> 1, h >> 1, int(exp_off[i, 1])),
+                 (2, d.x0 >> 1, d.y0 >> 1, w >> 1, h >> 1, int(exp_off[i, 2]))]
+        golden_cases.check_rects(dst, rects, exp, f"mcx case {i} refine={d.refine} {w}x{h} @({d.x0},{d.y0})")
+        if d.refine & capi.PU_DMVR:
+            want = exp_mv[int(exp_off[i, 3]) // 4:int(exp_off[i, 3]) // 4 + len(ux)]
+            assert np.array_equal(mv, want), f"mcx case {i}: refined MVs differ {mv.tolist()} vs {want.tolist()}"
+            n_moved += int((mv != np.array([d.mv0x, d.mv0y, d.mv1x, d.mv1y])).any(axis=1).sum())
+        else:
+            n_bdof += len(ux)
+    assert n_moved > 100 and n_bdof > 100, "fixture does not exercise DMVR / BDOF"
+
+
 def test_dbf_oracle_matches_reference(built_lib):
     cases = golden_cases.dbf_cases()
     assert len(cases) == 2
