@@ -15,183 +15,10 @@
 // Replaces mc_l/mc_c.{unidir,bidir0,bidir1,bidir_w}[hv][] and their drivers rcn_mcp_l/_c,
 // rcn_motion_compensation_b_l/_c (libovvc/rcn_mc.c:382-1610; rcn_inter.c:520-602, :1391-1554,
 // :1822-1904) and lmcs_reshape_forward (rcn_lmcs.c:275-295).
-#include "ovvc_common.hip.h"
+#include "mc_common.hip.h"
 #include <stdlib.h>
-#define OVT_ATTR __device__
-#include "vvc_mc_taps.h"
 
 namespace {
-
-#define MC_MAX_REFS 16
-struct RefTable { ovhip_pic p[MC_MAX_REFS]; };
-
-typedef short short2v __attribute__((ext_vector_type(2)));
-
-#define WIN_STRIDE 28   /* luma window row in LDS: 7 aligned qwords (<= 3 + 23 samples) = 56 B            */
-#define CWIN_STRIDE 16  /* chroma window row: 4 aligned qwords (<= 3 + 11 samples) = 32 B                 */
-#define LUMA_WIN (23 * WIN_STRIDE)
-#define CHR_WIN  (11 * CWIN_STRIDE)
-#define HT_STRIDE 28    /* transposed H-pass tile: one COLUMN per row of HT_STRIDE int16 (h + 7 <= 23), 8-B aligned rows */
-#define CHT_STRIDE 12
-
-// ---- stage 1: reference window -> LDS.  Fast path (window inside the picture): every lane loads one
-// ALIGNED 8-byte group of 4 samples -- QW lanes per window row, 64/QW rows per instruction: 3
-// instructions for a 23x23 luma window, 1 for an 11x11 chroma window -- and parks it with one
-// ds_write_b64; the sub-group offset `off` (0..3 samples) is resolved by the horizontal pass.
-// Slow path (window crosses the picture border): per-sample loads with clamped coordinates
-// = emulate_block_border() (rcn_inter.c:148-225), parked at off = 0. ----
-template <int QW, int NIT, int COLS, int NITS>
-struct WinStage {
-    uint2 q[NIT];
-    bool fast;
-    int off;
-
-    __device__ __forceinline__ void issue(const uint16_t *__restrict__ ref, int rstride, int rw, int rh, int sx0, int sy0,
-                                          int ww, int wh, int lane, uint16_t *s_win, int wstride)
-    {
-        const int ax = sx0 & ~3;
-        off = sx0 - ax;
-        const int nq = (off + ww + 3) >> 2;
-        fast = ax >= 0 && ax + 4 * nq <= rw && sy0 >= 0 && sy0 + wh <= rh && !(rstride & 3);
-        if (fast) {
-            const int c = lane & (QW - 1), r0 = lane / QW;
-#pragma unroll
-            for (int k = 0; k < NIT; ++k) {
-                const int r = (64 / QW) * k + r0;
-                if (c < nq && r < wh) q[k] = *reinterpret_cast<const uint2 *>(ref + (sy0 + r) * rstride + ax + 4 * c);
-            }
-        } else {
-            // rare: load + park immediately (keeps the register footprint of the fast path small)
-            off = 0;
-            const int c = lane & (COLS - 1), r0 = lane / COLS;
-            const int sx = ov_clip3(sx0 + c, 0, rw - 1);
-#pragma unroll 1
-            for (int k = 0; k < NITS; ++k) {
-                const int r = (64 / COLS) * k + r0;
-                if (c < ww && r < wh) s_win[r * wstride + c] = ref[ov_clip3(sy0 + r, 0, rh - 1) * rstride + sx];
-            }
-        }
-    }
-
-    __device__ __forceinline__ void park(uint16_t *s_win, int wstride, int ww, int wh, int lane) const
-    {
-        if (fast) {
-            const int nq = (off + ww + 3) >> 2;
-            const int c = lane & (QW - 1), r0 = lane / QW;
-#pragma unroll
-            for (int k = 0; k < NIT; ++k) {
-                const int r = (64 / QW) * k + r0;
-                if (c < nq && r < wh) *reinterpret_cast<uint2 *>(s_win + r * wstride + 4 * c) = q[k];
-            }
-        }
-    }
-};
-typedef WinStage<8, 3, 32, 12> LumaStage;
-typedef WinStage<4, 1, 16, 3> ChromaStage;
-
-// ---- 4 outputs of an NT-tap FIR over a packed int16 row: out[o] = sum_k taps[k] * s[o + k].
-// d[j] = (s[2j], s[2j+1]); even outputs use the dwords as they are, odd outputs the dwords shifted by
-// one sample (v_alignbit); every dword pair is one v_dot2c_i32_i16 (2 MACs). ----
-template <int NT>
-__device__ __forceinline__ void fir4(const int d[NT / 2 + 2], const int tp[NT / 2], int out[4])
-{
-    int e[NT / 2 + 1];
-#pragma unroll
-    for (int j = 0; j < NT / 2 + 1; ++j) e[j] = (int)__builtin_amdgcn_alignbit((uint32_t)d[j + 1], (uint32_t)d[j], 16);
-#pragma unroll
-    for (int o = 0; o < 4; ++o) {
-        int acc = 0;
-#pragma unroll
-        for (int m = 0; m < NT / 2; ++m) {
-            const int v = (o & 1) ? e[(o >> 1) + m] : d[(o >> 1) + m];
-            acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, v), __builtin_bit_cast(short2v, tp[m]), acc, false);
-        }
-        out[o] = acc;
-    }
-}
-
-template <int NT>
-__device__ __forceinline__ void pack_taps(const int8_t *f, int tp[NT / 2])
-{
-#pragma unroll
-    for (int m = 0; m < NT / 2; ++m) tp[m] = ((int)f[2 * m] & 0xffff) | ((int)f[2 * m + 1] << 16);
-}
-
-template <int NT>
-__device__ __forceinline__ void load_row(const void *p, int d[NT / 2 + 2])
-{
-    // segment starts are 8-byte aligned in LDS (strides are multiples of 4 samples)
-    const int2 *q = reinterpret_cast<const int2 *>(p);
-#pragma unroll
-    for (int j = 0; j < (NT / 2 + 2) / 2; ++j) { const int2 v = q[j]; d[2 * j] = v.x; d[2 * j + 1] = v.y; }
-}
-
-// same, starting at an arbitrary SAMPLE index s0 of a dword-aligned row (window rows keep their
-// aligned-group offset): dword loads + one v_alignbit per dword when s0 is odd
-template <int NT>
-__device__ __forceinline__ void load_row_at(const uint16_t *row, int s0, int d[NT / 2 + 2])
-{
-    const int *q = reinterpret_cast<const int *>(row) + (s0 >> 1);
-    int D[NT / 2 + 2];
-#pragma unroll
-    for (int j = 0; j < NT / 2 + 2; ++j) D[j] = q[j];
-    if (s0 & 1) {
-#pragma unroll
-        for (int j = 0; j < NT / 2 + 1; ++j) d[j] = (int)__builtin_amdgcn_alignbit((uint32_t)D[j + 1], (uint32_t)D[j], 16);
-        d[NT / 2 + 1] = (int)((uint32_t)D[NT / 2 + 1] >> 16);
-    } else {
-#pragma unroll
-        for (int j = 0; j < NT / 2 + 2; ++j) d[j] = D[j];
-    }
-}
-
-// ---- stage 2: horizontal pass LDS -> LDS (transposed).  One task = one window row x 4 consecutive
-// outputs.  t = F_h(src) >> (BITDEPTH - 8), stored column-major so that stage 3 reads rows again. ----
-template <int NT>
-__device__ __forceinline__ void h_pass(const uint16_t *s_win, int wstride, int off, int16_t *s_ht, int htstride, int log2w,
-                                       int wh, const int8_t *fh, int lane)
-{
-    int tp[NT / 2];
-    pack_taps<NT>(fh, tp);
-    const int w = 1 << log2w;
-    const int log2seg = log2w > 2 ? log2w - 2 : 0;          // 4-sample segments per row
-    const int nout = w < 4 ? w : 4;
-    const bool ident = fh[NT / 2 - 1] == 64;                // integer position: t = s << 4, no FIR
-    for (int t = lane; t < (wh << log2seg); t += 64) {
-        const int r = t >> log2seg, x0 = (t & ((1 << log2seg) - 1)) << 2;
-        int d[NT / 2 + 2], out[4];
-        if (ident) {
-            const uint16_t *sp = s_win + r * wstride + off + x0 + NT / 2 - 1;
-#pragma unroll
-            for (int o = 0; o < 4; ++o) out[o] = (int)sp[o] << 6;
-        } else {
-            load_row_at<NT>(s_win + r * wstride, off + x0, d);
-            fir4<NT>(d, tp, out);
-        }
-#pragma unroll
-        for (int o = 0; o < 4; ++o)
-            if (o < nout) s_ht[(x0 + o) * htstride + r] = (int16_t)(out[o] >> (OV_BD - 8));
-    }
-}
-
-// ---- stage 3: vertical pass LDS -> registers.  Lane = one column x 4 consecutive rows (group g):
-// P[j] = F_v(t)[x][4g + j] >> 6, the 14-bit intermediate of put_vvc_{qpel,epel}_*. ----
-template <int NT>
-__device__ __forceinline__ void v_pass(const int16_t *s_ht, int htstride, int log2w, int h, const int8_t *fv, int lane, int P[4])
-{
-    int tp[NT / 2];
-    pack_taps<NT>(fv, tp);
-    const int w = 1 << log2w;
-    const int ngrp = (h + 3) >> 2;
-    if (lane < (ngrp << log2w)) {
-        const int x = lane & (w - 1), g = lane >> log2w;
-        int d[NT / 2 + 2];
-        load_row<NT>(s_ht + x * htstride + 4 * g, d);
-        fir4<NT>(d, tp, P);
-#pragma unroll
-        for (int o = 0; o < 4; ++o) P[o] >>= 6;
-    }
-}
 
 __device__ __forceinline__ int mc_combine(const ovhip_mc_unit &u, int p0, int p1)
 {
@@ -330,11 +157,4 @@ extern "C" int ovhip_mc_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip
     hipLaunchKernelGGL(k_mc, dim3(grid), dim3(64), 0, ctx->stream, *dst, t, d_units, n_units, d_lmcs_fwd_lut, cfg_ablate);
     OV_LAUNCH_CHECK(ctx, "k_mc");
     return OVHIP_OK;
-}
-
-extern "C" int ovhip_mcx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs,
-                                const ovhip_mc_unit *d_units, uint32_t n_units, const uint16_t *d_lmcs_fwd_lut,
-                                int32_t *d_mv_out)
-{
-    return ov_fail(ctx, OVHIP_EINVAL, "ovhip_mcx_launch: not built", hipSuccess);
 }

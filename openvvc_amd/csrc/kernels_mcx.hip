@@ -1,0 +1,351 @@
+// kernels_mcx.hip -- K7/K8 on gfx950: "refined" bi-predicted units -- decoder-side motion-vector
+// refinement (DMVR) and bi-directional optical flow (BDOF) -- one wavefront per <=16x16 unit.
+//
+// Replaces rcn_dmvr_mv_refine (libovvc/rcn_inter.c:872-1126: bilinear pre-interpolation
+// rcn_mc.c:788-899, 25-point SAD search rcn_inter.c:614-754, parametric sub-pel step :758-833,
+// window padding :326-378) and rcn_bdof_mcp_l (rcn_inter.c:1136-1250; gradients, weights and the
+// per-4x4 correction rcn_prof_bdof.c:59-103, :152-172, :303-490), plus the chroma of the same CU.
+//
+// Data flow per unit (everything stays in LDS / registers between the window load and the store):
+//   1. both lists' (w+7)x(h+7) luma and (w/2+3)x(h/2+3) chroma windows -> LDS, with a 2-sample apron;
+//      DMVR anchors them at clip_mv(initial MV) exactly like derive_dmvr_ref_buf_y/_c
+//   2. DMVR: replicate the apron (padd_dmvr), bilinear (w+4)x(h+4) blocks, 25 SADs on every second
+//      row (lane = search point x row half), wave arg-min with the reference's tie rule, error-surface
+//      step; the refined MVs are lane-uniform and written back for the caller's TMVP field
+//   3. 8-tap / 4-tap separable interpolation at the refined position, reading the padded window
+//   4. BDOF (unless DMVR's cost test switched it off): 14-bit predictions + integer-sample ring in an
+//      18x18 LDS tile, per-sample gradients, 6x6 window sums by 4 lanes per 4x4 block, +-15 weights,
+//      corrected average; otherwise the plain average
+#include "mc_common.hip.h"
+#include <stdlib.h>
+
+namespace {
+
+#define XWIN_STRIDE  32    /* 4 (aligned apron slot) + off(<=3) + 23 + 2                                */
+#define XCWIN_STRIDE 20    /* 4 + off(<=3) + 11 + 2                                                     */
+#define XWIN_ROWS    28    /* 2 + 23 + 2, +1 row of slack for the FIR's whole-dword over-read            */
+#define XCWIN_ROWS   16
+#define BIL_STRIDE   20
+#define R_STRIDE     18
+
+__device__ __forceinline__ void clip_mv_dev(int px, int py, int pic_w, int pic_h, int pw, int ph, int &mvx, int &mvy)
+{
+    mvx = ov_clip3(mvx, -((pw + 3 + px) << 4), (pic_w + 2 - px) << 4);
+    mvy = ov_clip3(mvy, -((ph + 3 + py) << 4), (pic_h + 2 - py) << 4);
+}
+
+// replicate a (ww x wh) window held at `win` (row 0 / col 0 = first window sample) 2 samples outwards
+__device__ __forceinline__ void pad_sides(uint16_t *win, int stride, int ww, int wh, int lane)
+{
+    if (lane < wh) {
+        uint16_t *r = win + lane * stride;
+        const uint16_t a = r[0], b = r[ww - 1];
+        r[-1] = a; r[-2] = a; r[ww] = b; r[ww + 1] = b;
+    }
+}
+__device__ __forceinline__ void pad_rows(uint16_t *win, int stride, int ww, int wh, int lane)
+{
+    if (lane < ww + 4) {
+        uint16_t *c = win + lane - 2;
+        const uint16_t a = c[0], b = c[(wh - 1) * stride];
+        c[-stride] = a; c[-2 * stride] = a; c[wh * stride] = b; c[(wh + 1) * stride] = b;
+    }
+}
+
+__device__ __forceinline__ int div_for_maxq7(int num, int den)
+{
+    int sign = 0, q = 0;
+    if (num < 0) { sign = 1; num = -num; }
+    den <<= 3;
+    if (num >= den) { num -= den; q++; }
+    q <<= 1; den >>= 1;
+    if (num >= den) { num -= den; q++; }
+    q <<= 1;
+    if (num >= (den >> 1)) q++;
+    return sign ? -q : q;
+}
+
+__global__ __launch_bounds__(64) void k_mcx(ovhip_pic dst, RefTable refs, const ovhip_mc_unit *__restrict__ units,
+                                             uint32_t n_units, const uint16_t *__restrict__ lmcs_fwd, int32_t *__restrict__ mv_out)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t s_wl[2][XWIN_ROWS * XWIN_STRIDE];
+    __shared__ __attribute__((aligned(16))) uint16_t s_wc[2][2][XCWIN_ROWS * XCWIN_STRIDE];   // [Cb/Cr][list]
+    __shared__ __attribute__((aligned(16))) int16_t  s_hl[2][16 * HT_STRIDE];
+    __shared__ __attribute__((aligned(16))) int16_t  s_hc[2][2][8 * CHT_STRIDE];
+    __shared__ __attribute__((aligned(16))) int16_t  s_x[2][24 * BIL_STRIDE];                 // DMVR bilinear blocks, then BDOF R tiles
+    int   *const s_avg = reinterpret_cast<int *>(s_wl[0]);                                     // BDOF (avg_gx | avg_gy << 16), 16x16
+    int16_t *const s_dr = reinterpret_cast<int16_t *>(s_wl[1]);                                // BDOF delta_ref, 16x16
+
+    const int lane = threadIdx.x;
+    for (uint32_t bid = blockIdx.x; bid < n_units; bid += gridDim.x) {
+    const ovhip_mc_unit u = units[bid];
+    const bool dmvr = u.flags & OVHIP_MC_DMVR;
+    bool use_bdof = u.flags & OVHIP_MC_BDOF;
+    const bool do_l = !(u.flags & OVHIP_MC_NO_LUMA), do_c = !(u.flags & OVHIP_MC_NO_CHROMA);
+    const int w = u.w, h = u.h, wc = w >> 1, hc = h >> 1;
+    const int log2w = 31 - __clz(w), log2wc = log2w - 1;
+
+    int mv[2][2] = { { u.mv0x, u.mv0y }, { u.mv1x, u.mv1y } };
+    int ini[2][2] = { { u.mv0x, u.mv0y }, { u.mv1x, u.mv1y } };
+
+    // ---- 1. windows ----
+    LumaStage sl[2];
+    ChromaStage sc[2][2];
+    uint16_t *wl[2], *wcp[2][2];          // first window sample (row 0, col 0) of each staged window
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        const ovhip_pic &rp = refs.p[l ? u.ref1 : u.ref0];
+        int ax = mv[l][0], ay = mv[l][1];
+        if (dmvr) clip_mv_dev(u.x, u.y, rp.w, rp.h, w, h, ax, ay);
+        uint16_t *bl = s_wl[l] + 2 * XWIN_STRIDE + 4;
+        if (do_l) sl[l].issue(rp.y, rp.stride_y, rp.w, rp.h, u.x + (ax >> 4) - 3, u.y + (ay >> 4) - 3, w + 7, h + 7, lane, bl, XWIN_STRIDE);
+        if (do_c) {
+            const int px = (u.x >> 1) + (ax >> 5) - 1, py = (u.y >> 1) + (ay >> 5) - 1;
+            sc[0][l].issue(rp.cb, rp.stride_c, rp.w >> 1, rp.h >> 1, px, py, wc + 3, hc + 3, lane, s_wc[0][l] + 2 * XCWIN_STRIDE + 4, XCWIN_STRIDE);
+            sc[1][l].issue(rp.cr, rp.stride_c, rp.w >> 1, rp.h >> 1, px, py, wc + 3, hc + 3, lane, s_wc[1][l] + 2 * XCWIN_STRIDE + 4, XCWIN_STRIDE);
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        if (do_l) { sl[l].park(s_wl[l] + 2 * XWIN_STRIDE + 4, XWIN_STRIDE, w + 7, h + 7, lane); wl[l] = s_wl[l] + 2 * XWIN_STRIDE + 4 + sl[l].off; }
+        if (do_c) {
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                sc[cc][l].park(s_wc[cc][l] + 2 * XCWIN_STRIDE + 4, XCWIN_STRIDE, wc + 3, hc + 3, lane);
+                wcp[cc][l] = s_wc[cc][l] + 2 * XCWIN_STRIDE + 4 + sc[cc][l].off;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 2. DMVR ----
+    if (dmvr) {
+        // 2a. apron (padd_dmvr / padd_dmvr_c): sides of the window rows, then whole rows
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            if (do_l) pad_sides(wl[l], XWIN_STRIDE, w + 7, h + 7, lane);
+            if (do_c) { pad_sides(wcp[0][l], XCWIN_STRIDE, wc + 3, hc + 3, lane); pad_sides(wcp[1][l], XCWIN_STRIDE, wc + 3, hc + 3, lane); }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            if (do_l) pad_rows(wl[l], XWIN_STRIDE, w + 7, h + 7, lane);
+            if (do_c) { pad_rows(wcp[0][l], XCWIN_STRIDE, wc + 3, hc + 3, lane); pad_rows(wcp[1][l], XCWIN_STRIDE, wc + 3, hc + 3, lane); }
+        }
+        // 2b. bilinear blocks B_l[j][i], i, j = 0 .. w+3 / h+3 <-> sample offsets -2 .. : lane = (list, column)
+        {
+            const int l = lane >= 32, i = lane & 31;
+            if (i < w + 4) {
+                const int fx = ini[l][0] & 15, fy = ini[l][1] & 15;
+                const uint16_t *src = wl[l] + XWIN_STRIDE + i + 1;            // offset -2 = window index 1
+                int16_t *o = s_x[l] + i;
+                int tp = 0;
+                for (int j = 0; j < h + 5; ++j) {
+                    const int a = src[j * XWIN_STRIDE], b = src[j * XWIN_STRIDE + 1];
+                    const int t = fx ? ((16 - fx) * a + fx * b + 8) >> 4 : a;
+                    if (j) o[(j - 1) * BIL_STRIDE] = (int16_t)(fy ? ((16 - fy) * tp + fy * t + 8) >> 4 : tp);
+                    tp = t;
+                }
+            }
+        }
+        __syncthreads();
+        // 2c. SADs on every second row: lane = search point k (0..24) x row half
+        int sad = 0;
+        {
+            const int k = lane < 25 ? lane : lane - 25, half = lane >= 25;
+            if (lane < 50) {
+                const int dx = k % 5 - 2, dy = k / 5 - 2;
+                const int16_t *b0 = s_x[0] + (2 + dy) * BIL_STRIDE + 2 + dx, *b1 = s_x[1] + (2 - dy) * BIL_STRIDE + 2 - dx;
+                const int nrow = h >> 2;                                   // rows per half (of the h/2 used)
+                for (int jj = 0; jj < nrow; ++jj) {
+                    const int j = 2 * (half * nrow + jj);
+                    for (int x = 0; x < w; ++x) sad += abs((int)b0[j * BIL_STRIDE + x] - (int)b1[j * BIL_STRIDE + x]);
+                }
+            }
+            sad += __shfl(sad, lane + 25 < 64 ? lane + 25 : lane);
+        }
+        const int sad_c = __shfl(sad, 12);
+        int min_cost = sad_c - (sad_c >> 2);
+        if (min_cost >= w * h) {
+            if (lane == 12) sad = min_cost;
+            // arg-min with dmvr_compute_sads_*'s tie rule: lowest cost; the centre wins a tie, then the lowest index
+            int key = lane < 25 ? (sad << 5) + (lane == 12 ? 0 : lane + 1) : 0x7fffffff;
+#pragma unroll
+            for (int m = 1; m < 32; m <<= 1) key = min(key, __shfl_xor(key, m));
+            const int kk = key & 31, idx = kk ? kk - 1 : 12;
+            int dh = (idx % 5 - 2) << 4, dv = (idx / 5 - 2) << 4;
+            min_cost = key >> 5;
+            const int s0 = min_cost;
+            const int s1 = __shfl(sad, max(idx - 1, 0)), s3 = __shfl(sad, min(idx + 1, 24));
+            const int s2 = __shfl(sad, max(idx - 5, 0)), s4 = __shfl(sad, min(idx + 5, 24));
+            if (abs(dh) != 32 && abs(dv) != 32) {
+                const int den_h = s1 + s3 - 2 * s0, den_v = s2 + s4 - 2 * s0;
+                if (den_h) dh += (s1 != s0 && s3 != s0) ? div_for_maxq7((s1 - s3) << 4, den_h) : (s1 == s0 ? -8 : 8);
+                if (den_v) dv += (s2 != s0 && s4 != s0) ? div_for_maxq7((s2 - s4) << 4, den_v) : (s2 == s0 ? -8 : 8);
+            }
+            dh = __builtin_amdgcn_readfirstlane(dh); dv = __builtin_amdgcn_readfirstlane(dv);
+            mv[0][0] = ov_clip3(mv[0][0] + dh, -(1 << 17), (1 << 17) - 1); mv[0][1] = ov_clip3(mv[0][1] + dv, -(1 << 17), (1 << 17) - 1);
+            mv[1][0] = ov_clip3(mv[1][0] - dh, -(1 << 17), (1 << 17) - 1); mv[1][1] = ov_clip3(mv[1][1] - dv, -(1 << 17), (1 << 17) - 1);
+        }
+        min_cost = __builtin_amdgcn_readfirstlane(min_cost);
+        if (use_bdof && min_cost < 2 * w * h) use_bdof = false;
+        __syncthreads();
+    }
+    if (mv_out && lane == 0) {
+        int4 o; o.x = mv[0][0]; o.y = mv[0][1]; o.z = mv[1][0]; o.w = mv[1][1];
+        *reinterpret_cast<int4 *>(mv_out + 4 * (size_t)bid) = o;
+    }
+
+    // ---- 3. horizontal passes at the refined position ----
+    const int8_t *fvl[2], *fvc[2];
+    int ldx[2], ldy[2], ext[2][2];
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        int fx = mv[l][0] & 15, fy = mv[l][1] & 15;
+        if (u.flags & OVHIP_MC_HPEL_FILT) { if (fx == 8) fx = 16; if (fy == 8) fy = 16; }
+        ext[l][0] = fx >= 8; ext[l][1] = fy >= 8;
+        fvl[l] = ovt_mc_luma[fy];
+        fvc[l] = ovt_mc_chroma[mv[l][1] & 31];
+        ldx[l] = (mv[l][0] >> 4) - (ini[l][0] >> 4); ldy[l] = (mv[l][1] >> 4) - (ini[l][1] >> 4);
+        const int cdx = (mv[l][0] >> 5) - (ini[l][0] >> 5), cdy = (mv[l][1] >> 5) - (ini[l][1] >> 5);
+        if (do_l) h_pass<8>(s_wl[l] + (2 + ldy[l]) * XWIN_STRIDE, XWIN_STRIDE, 4 + sl[l].off + ldx[l], s_hl[l], HT_STRIDE, log2w, h + 7, ovt_mc_luma[fx], lane);
+        if (do_c) {
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+                h_pass<4>(s_wc[cc][l] + (2 + cdy) * XCWIN_STRIDE, XCWIN_STRIDE, 4 + sc[cc][l].off + cdx, s_hc[cc][l], CHT_STRIDE, log2wc, hc + 3,
+                          ovt_mc_chroma[mv[l][0] & 31], lane);
+        }
+    }
+    __syncthreads();
+
+    // ---- 4. luma: vertical passes, then BDOF or the plain average ----
+    if (do_l) {
+        int P[2][4];
+        v_pass<8>(s_hl[0], HT_STRIDE, log2w, h, fvl[0], lane, P[0]);
+        v_pass<8>(s_hl[1], HT_STRIDE, log2w, h, fvl[1], lane, P[1]);
+        const bool act = lane < ((h >> 2) << log2w);
+        const int x = lane & (w - 1), g = lane >> log2w;
+        int out[4];
+        if (use_bdof) {
+            // 4a. R tiles: interior = prediction, ring = integer reference samples << 4 (extend_bdof_buff)
+            if (act) {
+#pragma unroll
+                for (int l = 0; l < 2; ++l)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s_x[l][(4 * g + j + 1) * R_STRIDE + x + 1] = (int16_t)P[l][j];
+            }
+            const int nring = 2 * (w + 2) + 2 * h;
+            for (int t = lane; t < 2 * nring; t += 64) {
+                const int l = t >= nring, e = l ? t - nring : t;
+                int i, j;
+                if (e < w + 2)            { i = e; j = 0; }
+                else if (e < 2 * (w + 2)) { i = e - (w + 2); j = h + 1; }
+                else if (e < 2 * (w + 2) + h) { i = 0; j = e - 2 * (w + 2) + 1; }
+                else                      { i = w + 1; j = e - 2 * (w + 2) - h + 1; }
+                const uint16_t *sp = wl[l] + (3 + ldy[l] + j - 1 + ext[l][1]) * XWIN_STRIDE + 3 + ldx[l] + i - 1 + ext[l][0];
+                s_x[l][j * R_STRIDE + i] = (int16_t)(*sp << 4);
+            }
+            __syncthreads();
+            // 4b. gradients of the lane's 4 samples (compute_prof_grad), their list averages / differences
+            int dgx[4], dgy[4];
+            if (act) {
+                int col[2][6];
+#pragma unroll
+                for (int l = 0; l < 2; ++l)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) col[l][j] = s_x[l][(4 * g + j) * R_STRIDE + x + 1] >> 6;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int o = (4 * g + j + 1) * R_STRIDE + x + 1;
+                    const int gx0 = (s_x[0][o + 1] >> 6) - (s_x[0][o - 1] >> 6), gx1 = (s_x[1][o + 1] >> 6) - (s_x[1][o - 1] >> 6);
+                    const int gy0 = col[0][j + 2] - col[0][j], gy1 = col[1][j + 2] - col[1][j];
+                    dgx[j] = gx0 - gx1; dgy[j] = gy0 - gy1;
+                    const int ax = (gx0 + gx1) >> 1, ay = (gy0 + gy1) >> 1;
+                    s_avg[(4 * g + j) * 16 + x] = (ax & 0xffff) | (ay << 16);
+                    s_dr[(4 * g + j) * 16 + x] = (int16_t)((P[1][j] >> 4) - (P[0][j] >> 4));
+                }
+            }
+            __syncthreads();
+            // 4c. 6x6 window sums (derive_bdof_weights): the 4 lanes of a 4x4 block take 9 window samples each;
+            //     gradients and predictions are replicated outside the block (extend_bdof_grad)
+            int wx = 0, wy = 0;
+            if (act) {
+                const int q = x & 3, sx = x & ~3, sy = 4 * g;
+                int s_ax = 0, s_ay = 0, s_xy = 0, s_dx = 0, s_dy = 0;
+#pragma unroll
+                for (int e9 = 0; e9 < 9; ++e9) {
+                    const int e = 9 * q + e9, r = e / 6, c = e - 6 * r;
+                    const int px = ov_clip3(sx - 1 + c, 0, w - 1), py = ov_clip3(sy - 1 + r, 0, h - 1);
+                    const int pk = s_avg[py * 16 + px];
+                    const int ax = (int)(int16_t)(pk & 0xffff), ay = pk >> 16, dr = s_dr[py * 16 + px];
+                    s_ax += abs(ax); s_ay += abs(ay);
+                    s_xy += ay < 0 ? -ax : (ay == 0 ? 0 : ax);
+                    s_dx += ax < 0 ? -dr : (ax == 0 ? 0 : dr);
+                    s_dy += ay < 0 ? -dr : (ay == 0 ? 0 : dr);
+                }
+#pragma unroll
+                for (int m = 1; m < 4; m <<= 1) {
+                    s_ax += __shfl_xor(s_ax, m); s_ay += __shfl_xor(s_ay, m); s_xy += __shfl_xor(s_xy, m);
+                    s_dx += __shfl_xor(s_dx, m); s_dy += __shfl_xor(s_dy, m);
+                }
+                if (s_ax) wx = ov_clip3((s_dx * 4) >> (31 - __clz(s_ax)), -15, 15);
+                if (s_ay) {
+                    const int x_off = wx ? (wx * s_xy) >> 1 : 0;
+                    wy = ov_clip3(((s_dy * 4) - x_off) >> (31 - __clz(s_ay)), -15, 15);
+                }
+            }
+            // 4d. rcn_apply_bdof_subblock
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[j] = ov_clip_bd((int)(int16_t)((P[0][j] + P[1][j] + wx * dgx[j] + wy * dgy[j] + 16) >> 5));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[j] = ov_clip_bd((P[0][j] + P[1][j] + 16) >> 5);
+        }
+        if (act) {
+            uint16_t *d = dst.y + (u.y + 4 * g) * dst.stride_y + u.x + x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int v = out[j];
+                if ((u.flags & OVHIP_MC_LMCS) && lmcs_fwd) v = lmcs_fwd[v];
+                d[j * dst.stride_y] = (uint16_t)v;
+            }
+        }
+    }
+    // ---- 5. chroma: plain average ----
+    if (do_c) {
+#pragma unroll
+        for (int comp = 0; comp < 2; ++comp) {
+            int P[2][4];
+            v_pass<4>(s_hc[comp][0], CHT_STRIDE, log2wc, hc, fvc[0], lane, P[0]);
+            v_pass<4>(s_hc[comp][1], CHT_STRIDE, log2wc, hc, fvc[1], lane, P[1]);
+            if (lane < (((hc + 3) >> 2) << log2wc)) {
+                const int x = lane & (wc - 1), g = lane >> log2wc;
+                uint16_t *d = (comp ? dst.cr : dst.cb) + ((u.y >> 1) + 4 * g) * dst.stride_c + (u.x >> 1) + x;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (4 * g + j < hc) d[j * dst.stride_c] = (uint16_t)ov_clip_bd((P[0][j] + P[1][j] + 16) >> 5);
+            }
+        }
+    }
+    __syncthreads();          // LDS is reused by the next unit
+    }
+}
+
+} // namespace
+
+extern "C" int ovhip_mcx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs,
+                                const ovhip_mc_unit *d_units, uint32_t n_units, const uint16_t *d_lmcs_fwd_lut,
+                                int32_t *d_mv_out)
+{
+    if (!ctx || !dst) return OVHIP_EINVAL;
+    if (!n_units) return OVHIP_OK;
+    if (!refs || !n_refs || n_refs > MC_MAX_REFS || !d_units)
+        return ov_fail(ctx, OVHIP_EINVAL, "ovhip_mcx_launch: bad reference table / units", hipSuccess);
+    RefTable t;
+    memset(&t, 0, sizeof(t));
+    for (uint32_t i = 0; i < n_refs; ++i) t.p[i] = refs[i];
+    for (uint32_t i = n_refs; i < MC_MAX_REFS; ++i) t.p[i] = refs[0];
+    hipLaunchKernelGGL(k_mcx, dim3(n_units), dim3(64), 0, ctx->stream, *dst, t, d_units, n_units, d_lmcs_fwd_lut, d_mv_out);
+    OV_LAUNCH_CHECK(ctx, "k_mcx");
+    return OVHIP_OK;
+}

@@ -57,6 +57,11 @@ class Context:
         self._chk(self.lib.ovhip_pic_alloc(self.h, w, h, C.byref(pic)), "pic_alloc")
         return DevPic(self, pic, owns=True)
 
+    def alloc(self, nbytes: int) -> "DevBuf":
+        p = C.c_void_p()
+        self._chk(self.lib.ovhip_malloc(self.h, max(int(nbytes), 16), C.byref(p)), "malloc")
+        return DevBuf(self, p, int(nbytes), int(nbytes))
+
     def upload_pic(self, y, cb, cr) -> "DevPic":
         h, w = y.shape
         p = self.new_pic(w, h)
@@ -130,6 +135,13 @@ class DevBuf:
         if self.ptr:
             self.ctx.lib.ovhip_free(self.ctx.h, self.ptr)
             self.ptr = None
+
+    def download(self, dtype=np.uint8) -> np.ndarray:
+        """Synchronous device -> host copy of the whole buffer."""
+        out = np.empty(self.nbytes // np.dtype(dtype).itemsize, dtype)
+        if self.nbytes:
+            self.ctx._chk(self.ctx.lib.ovhip_d2h(self.ctx.h, out.ctypes.data, self.ptr, self.nbytes), "d2h")
+        return out
 
 
 class DevPic:

@@ -48,6 +48,43 @@ def test_mc_gpu_matches_reference(ctx):
     golden_cases.check_rects(HostPic(rw, rh * n, y, cb, cr), rects, exp, "mc HIP vs reference")
 
 
+def test_mcx_gpu_matches_reference(ctx):
+    """BDOF / DMVR units through ovhip_mcx_launch vs the reference's rcn_bdof_mcp_l / rcn_dmvr_mv_refine,
+    samples and the refined motion vectors."""
+    refs, descs, exp_off, exp, exp_mv = golden_cases.mcx_cases()
+    rw, rh = refs[0].w, refs[0].h
+    n = len(descs)
+    drefs = [ctx.upload_pic(r.y, r.cb, r.cr) for r in refs]
+    fill = np.full((rh * n, rw), 0xABAB, np.uint16)
+    tall = ctx.upload_pic(fill, fill[: rh * n // 2, : rw // 2], fill[: rh * n // 2, : rw // 2])
+    rec = capi.Recorder(rw, rh)
+    rects, mv_checks = [], []
+    for i, d in enumerate(descs):
+        rec.reset()
+        rec.pu(d)
+        band = tall.band(i * rh, rh)
+        if len(rec.mc_units()):
+            ctx.mc(band, drefs, ctx.upload(rec.mc_units()))
+        ux = rec.mcx_units()
+        mv = ctx.alloc(len(ux) * 16)
+        ctx.mcx(band, drefs, ctx.upload(ux), mv_out=mv)
+        if d.refine & capi.PU_DMVR:
+            mv_checks.append((i, mv, exp_mv[int(exp_off[i, 3]) // 4:int(exp_off[i, 3]) // 4 + len(ux)]))
+        w, h = 1 << d.log2_w, 1 << d.log2_h
+        rects += [(0, d.x0, d.y0 + i * rh, w, h, int(exp_off[i, 0])),
+                  (1, d.x0 >> 1, (d.y0 >> 1) + i * (rh // 2), w >> 1, h >> 1, int(exp_off[i, 1])),
+                  (2, d.x0 >> 1, (d.y0 >> 1) + i * (rh // 2), w >> 1, h >> 1, int(exp_off[i, 2]))]
+    ctx.sync()
+    bad_mv = []
+    for i, buf, want in mv_checks:
+        got = buf.download(np.int32).reshape(-1, 4)
+        if not np.array_equal(got, want):
+            bad_mv.append((i, got.tolist(), want.tolist()))
+    assert not bad_mv, f"refined MVs differ in {len(bad_mv)} / {len(mv_checks)} DMVR cases, first: {bad_mv[:3]}"
+    y, cb, cr = tall.download()
+    golden_cases.check_rects(HostPic(rw, rh * n, y, cb, cr), rects, exp, "mcx HIP vs reference")
+
+
 def test_dbf_gpu_matches_reference(ctx):
     for i, (pic, planes, exp) in enumerate(golden_cases.dbf_cases()):
         d = ctx.upload_pic(pic.y, pic.cb, pic.cr)
