@@ -138,6 +138,42 @@ typedef struct ovhip_mc_unit {
 } ovhip_mc_unit;
 
 /* ------------------------------------------------------------------------------------
+ * Affine unit: <= 16x16 luma samples of an affine CU, every 4x4 luma sub-block with its own
+ * motion vectors and (optionally) prediction refinement with optical flow (PROF); the chroma of
+ * the same area as 4x4-chroma blocks with the averaged motion vector.  Produced by
+ * ovhip_rec_affine_cu().  Replaces the per-sub-block calls of rcn_affine_mcp_b_l /
+ * rcn_affine_prof_mcp_b_l / rcn_affine_mcp_b_c (drv_affine_mvp.c:3264-3411) into
+ * rcn_mcp_b_l(2,2) / rcn_prof_mcp_b_l / rcn_mcp_b_c(3,3) and the leaf code behind them:
+ * rcn_prof_motion_compensation_b_l, rcn_prof_mcp_l (rcn_inter.c:1252-1386, :1631-1722),
+ * extend_prof_buff / compute_prof_grad / rcn_prof (rcn_prof_bdof.c:152-290).  32 bytes.
+ *
+ * Side arena (int32): at side_off, for each luma sub-block in raster order 4 words
+ * {mv0x, mv0y, mv1x, mv1y} (clip_mv() already applied for a 4x4 block), then for each
+ * 8x8-luma chroma block 4 words (clip_mv() for the 8x8 block).  At prof_off (CU-wide, only
+ * read when OVHIP_AFF_PROF is set): struct PROFInfo = 64 int16 {h0[16], v0[16], h1[16], v1[16]}.
+ * ---------------------------------------------------------------------------------- */
+enum {                        /* ovhip_aff_unit.flags */
+    OVHIP_AFF_PROF      = 1,  /* the CU went through rcn_affine_prof_mcp_b_l                      */
+    OVHIP_AFF_LMCS      = 16, /* = OVHIP_MC_LMCS                                                  */
+    OVHIP_AFF_NO_CHROMA = 8   /* = OVHIP_MC_NO_CHROMA                                             */
+};
+
+typedef struct ovhip_aff_unit {
+    uint16_t x, y;            /* luma position in the picture                                    */
+    uint8_t  w, h;            /* luma size, multiples of 8, <= 16                                 */
+    uint8_t  dir;             /* 1, 2, 3                                                         */
+    uint8_t  flags;           /* OVHIP_AFF_*                                                     */
+    uint8_t  ref0, ref1;
+    int8_t   w0, w1;          /* bi weights as in ovhip_mc_unit                                  */
+    uint8_t  prof_dir;        /* bi-prediction: lists refined by PROF (bit0 L0, bit1 L1)         */
+    uint8_t  ident_c;         /* per chroma block: identical motion -> uni-prediction from L1    */
+    uint16_t ident_l;         /* per luma sub-block (no PROF only): same, rcn_inter.c:256-268    */
+    uint32_t side_off;        /* int32 index of the unit's motion vectors in the side arena      */
+    uint32_t prof_off;        /* int32 index of the CU's PROFInfo in the side arena              */
+    uint32_t pad[2];
+} ovhip_aff_unit;
+
+/* ------------------------------------------------------------------------------------
  * Deblocking.  The reference filters one CTU per df.rcn_dbf_ctu() call from CTU-local bit maps
  * (struct DBFInfo, libovvc/ctudec.h:130-170) that carry neighbour state between calls
  * (dbf_load_info/dbf_store_info, drv_lines.c:618-761).  The recorder (ovhip_rec_dbf_ctu) runs the
@@ -297,6 +333,23 @@ typedef struct ovhip_pu_desc {
     uint8_t  pad2[2];
 } ovhip_pu_desc;
 
+/* One affine CU as rcn_affine_mcp_b_l / rcn_affine_prof_mcp_b_l / rcn_affine_mcp_b_c receive it
+ * (drv_affine_mvp.c:3264-3411): the sub-block motion field the driver wrote into
+ * inter_ctx->mv_ctx0/1 and, when prof_dir != 0, the PROFInfo compute_prof_dmv_scale() derived. */
+typedef struct ovhip_affine_desc {
+    uint16_t x0, y0;          /* luma position in the picture                                    */
+    uint8_t  log2_w, log2_h;  /* CU size, >= 8x8                                                 */
+    uint8_t  inter_dir;
+    uint8_t  bcw_idx_plus1;
+    uint8_t  prof_dir;        /* 0: rcn_affine_mcp_b_l, else rcn_affine_prof_mcp_b_l(prof_dir)    */
+    uint8_t  lmcs;
+    uint8_t  ref0, ref1;      /* slots in the launch's reference table                           */
+    int32_t  poc0, poc1;
+    int32_t  mv_stride;       /* in motion vectors (34 in the reference's mv_ctx)                 */
+    const int32_t *mv0, *mv1; /* host: (x, y) pairs per 4x4 sub-block, row stride mv_stride      */
+    int16_t  dmv_scale[4][16];/* struct PROFInfo: h0, v0, h1, v1                                  */
+} ovhip_affine_desc;
+
 #define OVHIP_PU_BDOF 1
 #define OVHIP_PU_DMVR 2
 
@@ -306,6 +359,7 @@ void  ovhip_rec_reset(ovhip_recorder *rec);
 /* Append the commands of one TU / PU.  Return number of commands appended or <0. */
 int   ovhip_rec_tu(ovhip_recorder *rec, const ovhip_tu_state *st, const ovhip_tu_desc *tu);
 int   ovhip_rec_pu(ovhip_recorder *rec, const ovhip_pu_desc *pu);
+int   ovhip_rec_affine_cu(ovhip_recorder *rec, const ovhip_affine_desc *cu);
 /* Convert one CTU's deblocking maps into the picture-level edge planes.  Returns 0 or <0. */
 int   ovhip_rec_dbf_ctu(ovhip_recorder *rec, const ovhip_dbf_ctu *ctu);
 /* Host copies of the edge planes (pointers valid until the next reset/destroy). */
@@ -316,6 +370,8 @@ const int16_t       *ovhip_rec_coefs(const ovhip_recorder *rec, size_t *n_int16)
 const ovhip_mc_unit *ovhip_rec_mc_units(const ovhip_recorder *rec, size_t *n);
 /* The refined (OVHIP_MC_BDOF / OVHIP_MC_DMVR) units, kept apart so that each list is one launch. */
 const ovhip_mc_unit *ovhip_rec_mcx_units(const ovhip_recorder *rec, size_t *n);
+const ovhip_aff_unit *ovhip_rec_aff_units(const ovhip_recorder *rec, size_t *n);
+const int32_t        *ovhip_rec_aff_side(const ovhip_recorder *rec, size_t *n_int32);
 
 /* ------------------------------------------------------------------------------------
  * Engine (device side).
@@ -354,6 +410,10 @@ int  ovhip_mc_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *refs
 int  ovhip_mcx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs,
                       const ovhip_mc_unit *d_units, uint32_t n_units, const uint16_t *d_lmcs_fwd_lut,
                       int32_t *d_mv_out);
+/* Affine units; d_side: the DEVICE copy of ovhip_rec_aff_side(). */
+int  ovhip_mca_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs,
+                      const ovhip_aff_unit *d_units, uint32_t n_units, const int32_t *d_side,
+                      const uint16_t *d_lmcs_fwd_lut);
 /* planes->* are DEVICE pointers.  Filters `pic` in place: all vertical edges, then all horizontal. */
 int  ovhip_dbf_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_dbf_planes *planes);
 /* d_params: DEVICE array of ceil(w/ctu)*ceil(h/ctu) entries.  dst and src must not alias. */

@@ -74,6 +74,13 @@ class PuDesc(C.Structure):
                 ("ref0", C.c_uint8), ("ref1", C.c_uint8), ("pad2", C.c_uint8 * 2)]
 
 
+class AffineDesc(C.Structure):
+    _fields_ = [("x0", C.c_uint16), ("y0", C.c_uint16), ("log2_w", C.c_uint8), ("log2_h", C.c_uint8),
+                ("inter_dir", C.c_uint8), ("bcw_idx_plus1", C.c_uint8), ("prof_dir", C.c_uint8), ("lmcs", C.c_uint8),
+                ("ref0", C.c_uint8), ("ref1", C.c_uint8), ("poc0", C.c_int32), ("poc1", C.c_int32),
+                ("mv_stride", C.c_int32), ("mv0", C.c_void_p), ("mv1", C.c_void_p), ("dmv_scale", (C.c_int16 * 16) * 4)]
+
+
 class DbfPlanes(C.Structure):
     _fields_ = [("luma_v", C.c_void_p), ("luma_h", C.c_void_p), ("cb_v", C.c_void_p), ("cr_v", C.c_void_p),
                 ("cb_h", C.c_void_p), ("cr_h", C.c_void_p), ("w4", C.c_int32), ("h4", C.c_int32),
@@ -118,6 +125,12 @@ MC_UNIT_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("w", "u1"), ("h", "u1"), 
                           ("mv0y", "<i4"), ("mv1x", "<i4"), ("mv1y", "<i4"), ("aux", "<u4")])
 assert TB_CMD_DTYPE.itemsize == C.sizeof(TbCmd) == 32
 assert MC_UNIT_DTYPE.itemsize == C.sizeof(McUnit) == 32
+AFF_UNIT_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("w", "u1"), ("h", "u1"), ("dir", "u1"), ("flags", "u1"),
+                           ("ref0", "u1"), ("ref1", "u1"), ("w0", "i1"), ("w1", "i1"), ("prof_dir", "u1"),
+                           ("ident_c", "u1"), ("ident_l", "<u2"), ("side_off", "<u4"), ("prof_off", "<u4"),
+                           ("pad", "<u4", 2)])
+assert AFF_UNIT_DTYPE.itemsize == 32
+AFF_PROF, AFF_NO_CHROMA, AFF_LMCS = 1, 8, 16
 
 _lib = None
 
@@ -154,6 +167,9 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_rec_coefs": (vp, [vp, P(C.c_size_t)]),
         "ovhip_rec_mc_units": (vp, [vp, P(C.c_size_t)]),
         "ovhip_rec_mcx_units": (vp, [vp, P(C.c_size_t)]),
+        "ovhip_rec_affine_cu": (C.c_int, [vp, P(AffineDesc)]),
+        "ovhip_rec_aff_units": (vp, [vp, P(C.c_size_t)]),
+        "ovhip_rec_aff_side": (vp, [vp, P(C.c_size_t)]),
         "ovhip_ctx_create": (C.c_int, [P(vp), C.c_int, vp]),
         "ovhip_ctx_destroy": (None, [vp]),
         "ovhip_ctx_sync": (C.c_int, [vp]),
@@ -170,6 +186,7 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_itx_launch": (C.c_int, [vp, P(Pic), vp, u32, vp]),
         "ovhip_mc_launch": (C.c_int, [vp, P(Pic), P(Pic), u32, vp, u32, vp]),
         "ovhip_mcx_launch": (C.c_int, [vp, P(Pic), P(Pic), u32, vp, u32, vp, vp]),
+        "ovhip_mca_launch": (C.c_int, [vp, P(Pic), P(Pic), u32, vp, u32, vp, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)          # AttributeError = missing export: fail loudly
@@ -183,7 +200,7 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
 
 EXPORTED_SYMBOLS = [
     "ovhip_abi_version", "ovhip_rec_create", "ovhip_rec_destroy", "ovhip_rec_reset", "ovhip_rec_tu",
-    "ovhip_rec_pu", "ovhip_rec_dbf_ctu", "ovhip_rec_dbf_planes", "ovhip_dbf_launch", "ovhip_sao_launch", "ovhip_alf_launch", "ovhip_rec_tb_cmds", "ovhip_rec_coefs", "ovhip_rec_mc_units", "ovhip_rec_mcx_units", "ovhip_mcx_launch", "ovhip_ctx_create",
+    "ovhip_rec_pu", "ovhip_rec_dbf_ctu", "ovhip_rec_dbf_planes", "ovhip_dbf_launch", "ovhip_sao_launch", "ovhip_alf_launch", "ovhip_rec_tb_cmds", "ovhip_rec_coefs", "ovhip_rec_mc_units", "ovhip_rec_mcx_units", "ovhip_mcx_launch", "ovhip_rec_affine_cu", "ovhip_rec_aff_units", "ovhip_rec_aff_side", "ovhip_mca_launch", "ovhip_ctx_create",
     "ovhip_ctx_destroy", "ovhip_ctx_sync", "ovhip_last_error", "ovhip_ctx_stream", "ovhip_malloc",
     "ovhip_free", "ovhip_h2d", "ovhip_d2h", "ovhip_pic_alloc", "ovhip_pic_free", "ovhip_pic_upload",
     "ovhip_pic_download", "ovhip_itx_launch", "ovhip_mc_launch",
@@ -226,6 +243,17 @@ class Recorder:
             raise ValueError(f"ovhip_rec_pu -> {r}")
         return r
 
+    def affine_cu(self, d: AffineDesc, mv0: np.ndarray, mv1: np.ndarray) -> int:
+        """mv0 / mv1: int32 [rows, mv_stride, 2] sub-block motion fields (host)."""
+        mv0 = np.ascontiguousarray(mv0, dtype=np.int32)
+        mv1 = np.ascontiguousarray(mv1, dtype=np.int32)
+        d.mv0, d.mv1 = mv0.ctypes.data, mv1.ctypes.data
+        r = self.lib.ovhip_rec_affine_cu(self.h, C.byref(d))
+        d.mv0 = d.mv1 = None
+        if r < 0:
+            raise ValueError(f"ovhip_rec_affine_cu -> {r}")
+        return r
+
     def dbf_ctu(self, raw: bytes):
         """raw: one ovhip_dbf_ctu struct (what df.rcn_dbf_ctu receives)."""
         assert len(raw) == DBF_CTU_SIZE, (len(raw), DBF_CTU_SIZE)
@@ -263,6 +291,12 @@ class Recorder:
 
     def mc_units(self) -> np.ndarray:
         return self._arr(self.lib.ovhip_rec_mc_units, MC_UNIT_DTYPE)
+
+    def aff_units(self) -> np.ndarray:
+        return self._arr(self.lib.ovhip_rec_aff_units, AFF_UNIT_DTYPE)
+
+    def aff_side(self) -> np.ndarray:
+        return self._arr(self.lib.ovhip_rec_aff_side, np.dtype("<i4"))
 
     def mcx_units(self) -> np.ndarray:
         """The BDOF / DMVR units (ovhip_mcx_launch)."""

@@ -349,3 +349,10 @@ extern "C" int ovhip_mcx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhi
     OV_LAUNCH_CHECK(ctx, "k_mcx");
     return OVHIP_OK;
 }
+
+extern "C" int ovhip_mca_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs,
+                                const ovhip_aff_unit *d_units, uint32_t n_units, const int32_t *d_side,
+                                const uint16_t *d_lmcs_fwd_lut)
+{
+    return ov_fail(ctx, OVHIP_EINVAL, "ovhip_mca_launch: not built", hipSuccess);
+}

@@ -40,7 +40,7 @@ void
 ovhip_rec_destroy(ovhip_recorder *r)
 {
     if (!r) return;
-    free(r->tb); free(r->coef); free(r->mc); free(r->mcx);
+    free(r->tb); free(r->coef); free(r->mc); free(r->mcx); free(r->aff); free(r->aff_side);
     ovhip_rec_dbf_free_(r);
     free(r);
 }
@@ -48,7 +48,7 @@ ovhip_rec_destroy(ovhip_recorder *r)
 void
 ovhip_rec_reset(ovhip_recorder *r)
 {
-    r->n_tb = r->n_coef = r->n_mc = r->n_mcx = 0;
+    r->n_tb = r->n_coef = r->n_mc = r->n_mcx = r->n_aff = r->n_side = 0;
     ovhip_rec_dbf_reset_(r);
 }
 
@@ -56,6 +56,8 @@ const ovhip_tb_cmd *ovhip_rec_tb_cmds(const ovhip_recorder *r, size_t *n) { *n =
 const int16_t *ovhip_rec_coefs(const ovhip_recorder *r, size_t *n) { *n = r->n_coef; return r->coef; }
 const ovhip_mc_unit *ovhip_rec_mc_units(const ovhip_recorder *r, size_t *n) { *n = r->n_mc; return r->mc; }
 const ovhip_mc_unit *ovhip_rec_mcx_units(const ovhip_recorder *r, size_t *n) { *n = r->n_mcx; return r->mcx; }
+const ovhip_aff_unit *ovhip_rec_aff_units(const ovhip_recorder *r, size_t *n) { *n = r->n_aff; return r->aff; }
+const int32_t *ovhip_rec_aff_side(const ovhip_recorder *r, size_t *n) { *n = r->n_side; return r->aff_side; }
 
 static int
 grow(void **p, size_t *cap, size_t need, size_t elem)
@@ -487,4 +489,85 @@ ovhip_rec_pu(ovhip_recorder *r, const ovhip_pu_desc *pu)
         }
     }
     return nu;
+}
+
+/* ---------------------------------------------------------------- affine CUs
+ * rcn_affine_mcp_b_l / rcn_affine_prof_mcp_b_l / rcn_affine_mcp_b_c (drv_affine_mvp.c:3264-3411):
+ * every 4x4 luma sub-block is predicted with its own motion vector, every 4x4 chroma block with
+ * the average of the top-left and bottom-right sub-block vectors of its 8x8 luma area. */
+int
+ovhip_rec_affine_cu(ovhip_recorder *r, const ovhip_affine_desc *cu)
+{
+    const int cw = 1 << cu->log2_w, ch = 1 << cu->log2_h;
+    int dir = cu->inter_dir & 3;
+    if (!dir || cw < 8 || ch < 8 || !cu->mv0 || !cu->mv1 || cu->mv_stride < (cw >> 2)) return OVHIP_EINVAL;
+    if (dir != 3 && (dir & 2)) dir = 2;
+
+    int8_t w0 = 4, w1 = 4;
+    if (dir == 3 && cu->bcw_idx_plus1 != 0 && cu->bcw_idx_plus1 != 3) {
+        static const int8_t bcw[5] = { -2, 3, 4, 5, 10 };
+        if (cu->bcw_idx_plus1 > 5) return OVHIP_EINVAL;
+        w1 = bcw[cu->bcw_idx_plus1 - 1];
+        w0 = (int8_t)(8 - w1);
+    }
+
+    uint32_t prof_off = 0;
+    if (cu->prof_dir) {
+        if (grow((void **)&r->aff_side, &r->cap_side, r->n_side + 32, sizeof(int32_t))) return OVHIP_ENOMEM;
+        prof_off = (uint32_t)r->n_side;
+        memcpy(r->aff_side + r->n_side, cu->dmv_scale, 128);
+        r->n_side += 32;
+    }
+
+    const int uw = cw > 16 ? 16 : cw, uh = ch > 16 ? 16 : ch;
+    int n = 0;
+    for (int uy = 0; uy < ch; uy += uh) {
+        for (int ux = 0; ux < cw; ux += uw) {
+            const int nl = (uw >> 2) * (uh >> 2), nc = (uw >> 3) * (uh >> 3);
+            if (grow((void **)&r->aff, &r->cap_aff, r->n_aff + 1, sizeof(ovhip_aff_unit))) return OVHIP_ENOMEM;
+            if (grow((void **)&r->aff_side, &r->cap_side, r->n_side + 4 * (size_t)(nl + nc), sizeof(int32_t))) return OVHIP_ENOMEM;
+            ovhip_aff_unit *u = &r->aff[r->n_aff++];
+            memset(u, 0, sizeof(*u));
+            u->x = (uint16_t)(cu->x0 + ux); u->y = (uint16_t)(cu->y0 + uy);
+            u->w = (uint8_t)uw; u->h = (uint8_t)uh;
+            u->dir = (uint8_t)dir;
+            u->flags = (uint8_t)((cu->prof_dir ? OVHIP_AFF_PROF : 0) | (cu->lmcs ? OVHIP_AFF_LMCS : 0));
+            u->ref0 = cu->ref0; u->ref1 = cu->ref1;
+            u->w0 = w0; u->w1 = w1;
+            u->prof_dir = cu->prof_dir;
+            u->side_off = (uint32_t)r->n_side;
+            u->prof_off = prof_off;
+            int32_t *o = r->aff_side + r->n_side;
+            for (int sy = 0; sy < uh; sy += 4) {
+                for (int sx = 0; sx < uw; sx += 4) {
+                    const int k = ((uy + sy) >> 2) * cu->mv_stride + ((ux + sx) >> 2);
+                    int32_t m[4] = { cu->mv0[2 * k], cu->mv0[2 * k + 1], cu->mv1[2 * k], cu->mv1[2 * k + 1] };
+                    /* rcn_mcp_b_l's identical-motion shortcut; rcn_prof_mcp_b_l has none (rcn_inter.c:2864-2918) */
+                    if (!cu->prof_dir && dir == 3 && cu->poc0 == cu->poc1 && m[0] == m[2] && m[1] == m[3])
+                        u->ident_l |= (uint16_t)(1u << ((sy >> 2) * (uw >> 2) + (sx >> 2)));
+                    clip_mv(r, u->x + sx, u->y + sy, 4, 4, &m[0], &m[1]);
+                    clip_mv(r, u->x + sx, u->y + sy, 4, 4, &m[2], &m[3]);
+                    memcpy(o, m, sizeof(m));
+                    o += 4;
+                }
+            }
+            for (int sy = 0; sy < uh; sy += 8) {
+                for (int sx = 0; sx < uw; sx += 8) {
+                    const int k = ((uy + sy) >> 2) * cu->mv_stride + ((ux + sx) >> 2), k2 = k + cu->mv_stride + 1;
+                    int32_t m[4] = { cu->mv0[2 * k] + cu->mv0[2 * k2], cu->mv0[2 * k + 1] + cu->mv0[2 * k2 + 1],
+                                     cu->mv1[2 * k] + cu->mv1[2 * k2], cu->mv1[2 * k + 1] + cu->mv1[2 * k2 + 1] };
+                    for (int c = 0; c < 4; ++c) { m[c] += m[c] < 0; m[c] >>= 1; }
+                    if (dir == 3 && cu->poc0 == cu->poc1 && m[0] == m[2] && m[1] == m[3])
+                        u->ident_c |= (uint8_t)(1u << ((sy >> 3) * (uw >> 3) + (sx >> 3)));
+                    clip_mv(r, u->x + sx, u->y + sy, 8, 8, &m[0], &m[1]);
+                    clip_mv(r, u->x + sx, u->y + sy, 8, 8, &m[2], &m[3]);
+                    memcpy(o, m, sizeof(m));
+                    o += 4;
+                }
+            }
+            r->n_side += 4 * (size_t)(nl + nc);
+            ++n;
+        }
+    }
+    return n;
 }

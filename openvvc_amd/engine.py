@@ -88,6 +88,14 @@ class Context:
         self._chk(self.lib.ovhip_mc_launch(self.h, C.byref(dst.s), arr, len(refs), units.ptr, n,
                                            lmcs_fwd.ptr if lmcs_fwd else None), "mc_launch")
 
+    def mca(self, dst: "DevPic", refs: list, units: "DevBuf", side: "DevBuf", lmcs_fwd: "DevBuf | None" = None,
+            n: int | None = None):
+        """Affine (+PROF) units; side: device copy of the recorder's affine side arena."""
+        n = units.count if n is None else n
+        arr = (capi.Pic * len(refs))(*[r.s for r in refs])
+        self._chk(self.lib.ovhip_mca_launch(self.h, C.byref(dst.s), arr, len(refs), units.ptr, n, side.ptr,
+                                            lmcs_fwd.ptr if lmcs_fwd else None), "mca_launch")
+
     def mcx(self, dst: "DevPic", refs: list, units: "DevBuf", lmcs_fwd: "DevBuf | None" = None,
             mv_out: "DevBuf | None" = None, n: int | None = None):
         """BDOF / DMVR units; mv_out: device int32[n][4] receiving the refined motion vectors."""

@@ -555,6 +555,85 @@ void oracle_mc(const oracle_pic *dst, const oracle_pic *refs, uint32_t n_refs,
     oracle_mc_ex(dst, refs, n_refs, units, n, lmcs_fwd, NULL);
 }
 
+/* ---- K9: affine sub-block prediction + PROF ----
+ * One 4x4 luma sub-block: rcn_mcp_b_l(2,2) -> rcn_mcp_l / rcn_motion_compensation_b_l, or
+ * rcn_prof_mcp_b_l -> rcn_prof_mcp_l / rcn_prof_motion_compensation_b_l (rcn_inter.c:1252-1386,
+ * :1631-1722, :2864-2918). */
+static void prof_refine(int16_t *p /* 4x4, stride 16 */, const sampler *s, int ext_x, int ext_y,
+                        const int16_t *dmv_h, const int16_t *dmv_v)
+{
+    int16_t t[6 * 6];
+    /* extend_prof_buff (rcn_prof_bdof.c:174-223): ring of integer reference samples << 4 */
+    for (int j = 0; j < 6; ++j)
+        for (int i = 0; i < 6; ++i) {
+            int in = i >= 1 && i <= 4 && j >= 1 && j <= 4;
+            t[j * 6 + i] = in ? p[(j - 1) * 16 + i - 1] : (int16_t)(smp(s, i - 1 + ext_x, j - 1 + ext_y) << (14 - BD));
+        }
+    for (int j = 1; j <= 4; ++j)
+        for (int i = 1; i <= 4; ++i) {
+            /* compute_prof_grad (rcn_prof_bdof.c:152-172) */
+            int16_t gy = (int16_t)((t[(j + 1) * 6 + i] - (1 << 13)) >> 6);
+            gy -= (int16_t)((t[(j - 1) * 6 + i] - (1 << 13)) >> 6);
+            int16_t gx = (int16_t)((t[j * 6 + i + 1] - (1 << 13)) >> 6);
+            gx -= (int16_t)((t[j * 6 + i - 1] - (1 << 13)) >> 6);
+            /* rcn_prof (rcn_prof_bdof.c:225-280) */
+            int idx = (j - 1) * 4 + i - 1;
+            int32_t add = clip3i(dmv_h[idx] * gx + dmv_v[idx] * gy, -(1 << 13), (1 << 13) - 1);
+            p[(j - 1) * 16 + i - 1] = (int16_t)(t[j * 6 + i] + add);
+        }
+}
+
+/* rcn_affine_mcp_b_l / rcn_affine_prof_mcp_b_l / rcn_affine_mcp_b_c (drv_affine_mvp.c:3264-3411) */
+void oracle_mca(const oracle_pic *dst, const oracle_pic *refs, uint32_t n_refs,
+                const ovhip_aff_unit *units, uint32_t n, const int32_t *side, const uint16_t *lmcs_fwd)
+{
+    (void)n_refs;
+    for (uint32_t ui = 0; ui < n; ++ui) {
+        const ovhip_aff_unit *u = &units[ui];
+        const int32_t *mvs = side + u->side_off;
+        const int16_t *prof = (const int16_t *)(side + u->prof_off);
+        const int nsx = u->w >> 2;
+        for (int sb = 0; sb < (u->w >> 2) * (u->h >> 2); ++sb, mvs += 4) {
+            const int x = u->x + 4 * (sb % nsx), y = u->y + 4 * (sb / nsx);
+            int dir = u->dir;
+            if ((u->ident_l >> sb) & 1) dir = 2;
+            ovhip_mc_unit m;
+            memset(&m, 0, sizeof(m));
+            m.dir = (uint8_t)dir; m.w0 = u->w0; m.w1 = u->w1;
+            int16_t p[2][16 * 16];
+            for (int l = 0; l < 2; ++l) {
+                if (!(dir & (1 << l))) continue;
+                const oracle_pic *rp = &refs[l ? u->ref1 : u->ref0];
+                const int mvx = mvs[2 * l], mvy = mvs[2 * l + 1], fx = mvx & 15, fy = mvy & 15;
+                sampler s = plane_sampler(rp, 0, x + (mvx >> 4), y + (mvy >> 4));
+                predict14(p[l], 16, &s, 4, 4, ovt_mc_luma4[fx], ovt_mc_luma4[fy], 8);
+                if ((u->flags & OVHIP_AFF_PROF) && (dir != 3 || ((u->prof_dir >> l) & 1)))
+                    prof_refine(p[l], &s, fx >> 3, fy >> 3, prof + 32 * l, prof + 32 * l + 16);
+            }
+            for (int j = 0; j < 4; ++j)
+                for (int i = 0; i < 4; ++i) {
+                    int v = bi_combine(&m, p[0][j * 16 + i], p[1][j * 16 + i]);
+                    if ((u->flags & OVHIP_AFF_LMCS) && lmcs_fwd) v = lmcs_fwd[v & PIX_MAX];
+                    dst->y[(y + j) * dst->stride_y + x + i] = (uint16_t)v;
+                }
+        }
+        if (u->flags & OVHIP_AFF_NO_CHROMA) continue;
+        const int ncx = u->w >> 3;
+        for (int cbk = 0; cbk < (u->w >> 3) * (u->h >> 3); ++cbk, mvs += 4) {
+            ovhip_mc_unit m;
+            memset(&m, 0, sizeof(m));
+            m.x = (uint16_t)(u->x + 8 * (cbk % ncx)); m.y = (uint16_t)(u->y + 8 * (cbk / ncx));
+            m.w = m.h = 8;
+            m.dir = ((u->ident_c >> cbk) & 1) ? 2 : u->dir;
+            m.flags = OVHIP_MC_NO_LUMA;
+            m.ref0 = u->ref0; m.ref1 = u->ref1; m.w0 = u->w0; m.w1 = u->w1;
+            m.mv0x = mvs[0]; m.mv0y = mvs[1]; m.mv1x = mvs[2]; m.mv1y = mvs[3];
+            mc_plane(dst, refs, &m, 1, NULL);
+            mc_plane(dst, refs, &m, 2, NULL);
+        }
+    }
+}
+
 /* ====================================================================================
  * K12: deblocking filter on picture-level edge planes
  * ================================================================================== */

@@ -486,6 +486,143 @@ gen_mcx(const char *dir)
     fprintf(stderr, "mcx.ovg: %u cases, %zu expected samples, %zu refined MVs\n", n_cases, b_exp.n, b_mv.n / 4);
 }
 
+/* ====================================================================================== MCA
+ * mca.ovg : affine CUs the way rcn_affine_mcp_b_l / rcn_affine_prof_mcp_b_l / rcn_affine_mcp_b_c
+ *           (drv_affine_mvp.c:3264-3411) drive rcn_mcp_b_l(2,2) / rcn_prof_mcp_b_l / rcn_mcp_b_c(3,3)  -> K9
+ * struct PROFInfo is private to rcn_inter.c:1128-1134; the slot only forward-declares it. */
+struct PROFInfo { int16_t dmv_scale_h_0[16], dmv_scale_v_0[16], dmv_scale_h_1[16], dmv_scale_v_1[16]; };
+
+static void
+gen_mca(const char *dir)
+{
+    gbuf b_desc = { .type = T_U8 }, b_eoff = { .type = T_U32 }, b_exp = { .type = T_U16 }, b_mv = { .type = T_I32 };
+    uint32_t n_cases = 0;
+    g_seed = 0x266 + 99;
+
+    OVCTUDec *c = ref_new_ctudec(0, 0);
+    struct InterDRVCtx *ic = &c->drv_ctx.inter_ctx;
+    OVPicture *ref[3];
+    for (int i = 0; i < 3; ++i) {
+        ref[i] = ref_new_picture(MC_W, MC_H, 8 * (i + 1));
+        for (int p = 0; p < 3; ++p) fill_plane(ref[i]->frame->data[p], MC_W >> !!p, MC_H >> !!p, MC_W >> !!p);
+    }
+    ic->rpl0[0] = ref[0]; ic->rpl0[1] = ref[1]; ic->rpl1[0] = ref[2]; ic->rpl1[1] = ref[0];
+    static const uint8_t slot0[2] = { 0, 1 }, slot1[2] = { 2, 0 };
+    for (int i = 0; i < 16; ++i) {
+        ic->scale_fact_rpl0[i][0] = ic->scale_fact_rpl0[i][1] = 1 << RPR_SCALE_BITS;
+        ic->scale_fact_rpl1[i][0] = ic->scale_fact_rpl1[i][1] = 1 << RPR_SCALE_BITS;
+    }
+    ic->prec_amvr = 0;                                        /* drv_affine_mvp.c:3508 */
+    const struct OVBuffInfo *cb = &c->rcn_ctx.ctu_buff;
+
+    for (int l2w = 3; l2w <= 6; ++l2w) {
+        for (int l2h = 3; l2h <= 6; ++l2h) {
+            int w = 1 << l2w, h = 1 << l2h;
+            if (w > MC_W || h > MC_H) continue;
+            int reps = (w * h <= 256) ? 36 : (w * h <= 1024 ? 14 : 6);
+            for (int rep = 0; rep < reps; ++rep) {
+                ovhip_affine_desc d;
+                memset(&d, 0, sizeof(d));
+                int px, py;
+                do {
+                    px = rnd_range(0, (MC_W - w) / 4) * 4;
+                    py = rnd_range(0, (MC_H - h) / 4) * 4;
+                } while ((px >> 7) != ((px + w - 1) >> 7) || (py >> 7) != ((py + h - 1) >> 7));
+                if (rep % 10 == 6) px = 0;
+                if (rep % 10 == 8) py = MC_H - h;
+                d.x0 = px; d.y0 = py; d.log2_w = l2w; d.log2_h = l2h;
+                d.inter_dir = rnd_range(1, 3);
+                int ri0 = rnd_range(0, 1), ri1 = rnd_range(0, 1);
+                if (rep % 9 == 4) { d.inter_dir = 3; ri0 = 0; ri1 = 1; }          /* same picture in both lists */
+                d.bcw_idx_plus1 = (rep % 4 == 1) ? rnd_range(1, 5) : 0;
+                d.prof_dir = rep % 3 == 0 ? 0 : (d.inter_dir == 3 ? rnd_range(1, 3) : d.inter_dir);
+                d.ref0 = slot0[ri0]; d.ref1 = slot1[ri1];
+                d.poc0 = ic->rpl0[ri0]->poc; d.poc1 = ic->rpl1[ri1]->poc;
+                d.mv_stride = w >> 2;
+                for (int t = 0; t < 4; ++t)
+                    for (int k = 0; k < 16; ++k) d.dmv_scale[t][k] = (int16_t)(rep % 5 == 3 ? (rnd_range(0, 1) ? 31 : -31) : rnd_range(-31, 31));
+
+                /* a 6-parameter motion field per list, 1/16 pel; occasionally far outside the picture */
+                int nsx = w >> 2, nsy = h >> 2;
+                int32_t *mvs = calloc((size_t)nsx * nsy * 4, sizeof(int32_t));
+                int32_t *m0 = mvs, *m1 = mvs + 2 * nsx * nsy;
+                int range = rep % 8 == 0 ? 3000 : 300;
+                for (int l = 0; l < 2; ++l) {
+                    int bx = rnd_range(-range, range), by = rnd_range(-range, range);
+                    int ax = rnd_range(-24, 24), ay = rnd_range(-24, 24), cx = rnd_range(-24, 24), cy = rnd_range(-24, 24);
+                    if (rep % 7 == 2) { ax = ay = cx = cy = 0; bx &= ~15; by &= ~15; }          /* integer translation */
+                    int32_t *m = l ? m1 : m0;
+                    for (int j = 0; j < nsy; ++j)
+                        for (int i = 0; i < nsx; ++i) {
+                            m[2 * (j * nsx + i)] = bx + ((ax * i + cx * j) >> 1);
+                            m[2 * (j * nsx + i) + 1] = by + ((ay * i + cy * j) >> 1);
+                        }
+                }
+                if (rep % 9 == 4) memcpy(m1, m0, (size_t)nsx * nsy * 8);                       /* identical motion */
+                d.mv0 = m0; d.mv1 = m1;
+
+                c->ctb_x = px >> 7; c->ctb_y = py >> 7;
+                int x0 = px & 127, y0 = py & 127;
+                for (int j = 0; j < 128; ++j) memset(cb->y + j * cb->stride, 0xAB, 256);
+                for (int j = 0; j < 64; ++j) { memset(cb->cb + j * cb->stride_c, 0xAB, 128); memset(cb->cr + j * cb->stride_c, 0xAB, 128); }
+
+                struct PROFInfo pi;
+                memcpy(&pi, d.dmv_scale, sizeof(pi));
+                for (int j = 0; j < nsy; ++j)
+                    for (int i = 0; i < nsx; ++i) {
+                        int k = j * nsx + i;
+                        OVMV mv0 = { .x = m0[2 * k], .y = m0[2 * k + 1], .ref_idx = ri0, .bcw_idx_plus1 = d.bcw_idx_plus1 };
+                        OVMV mv1 = { .x = m1[2 * k], .y = m1[2 * k + 1], .ref_idx = ri1, .bcw_idx_plus1 = d.bcw_idx_plus1 };
+                        if (!d.prof_dir)
+                            c->rcn_funcs.rcn_mcp_b_l(c, *cb, ic, c->part_ctx, mv0, mv1, x0 + 4 * i, y0 + 4 * j, 2, 2, d.inter_dir, ri0, ri1);
+                        else
+                            c->rcn_funcs.rcn_prof_mcp_b_l(c, *cb, ic, c->part_ctx, mv0, mv1, x0 + 4 * i, y0 + 4 * j, 2, 2, d.inter_dir, ri0, ri1,
+                                                          d.prof_dir, (const void *)&pi);
+                    }
+                for (int j = 0; j < nsy; j += 2)
+                    for (int i = 0; i < nsx; i += 2) {
+                        int k = j * nsx + i, k2 = k + nsx + 1;
+                        OVMV mv0 = { .x = m0[2 * k] + m0[2 * k2], .y = m0[2 * k + 1] + m0[2 * k2 + 1], .ref_idx = ri0, .bcw_idx_plus1 = d.bcw_idx_plus1 };
+                        OVMV mv1 = { .x = m1[2 * k] + m1[2 * k2], .y = m1[2 * k + 1] + m1[2 * k2 + 1], .ref_idx = ri1, .bcw_idx_plus1 = d.bcw_idx_plus1 };
+                        mv0.x += mv0.x < 0; mv0.y += mv0.y < 0; mv0.x >>= 1; mv0.y >>= 1;
+                        mv1.x += mv1.x < 0; mv1.y += mv1.y < 0; mv1.x >>= 1; mv1.y >>= 1;
+                        c->rcn_funcs.rcn_mcp_b_c(c, *cb, ic, c->part_ctx, mv0, mv1, x0 + 4 * i, y0 + 4 * j, 3, 3, d.inter_dir, ri0, ri1);
+                    }
+
+                uint32_t eoff[4];
+                eoff[0] = (uint32_t)b_exp.n; dump_rect(&b_exp, cb->y, cb->stride, x0, y0, w, h);
+                eoff[1] = (uint32_t)b_exp.n; dump_rect(&b_exp, cb->cb, cb->stride_c, x0 >> 1, y0 >> 1, w >> 1, h >> 1);
+                eoff[2] = (uint32_t)b_exp.n; dump_rect(&b_exp, cb->cr, cb->stride_c, x0 >> 1, y0 >> 1, w >> 1, h >> 1);
+                eoff[3] = (uint32_t)b_mv.n;
+                gbuf_push(&b_mv, mvs, (size_t)nsx * nsy * 4);
+                d.mv0 = d.mv1 = NULL;
+                gbuf_push(&b_desc, &d, sizeof(d));
+                gbuf_push(&b_eoff, eoff, 4);
+                free(mvs);
+                n_cases++;
+            }
+        }
+    }
+
+    gfile g = gfile_open(dir, "mca.ovg");
+    uint32_t d3[3] = { 3, MC_H, MC_W };
+    uint16_t *all = malloc(3 * MC_W * MC_H * 2);
+    for (int i = 0; i < 3; ++i) memcpy(all + i * MC_W * MC_H, ref[i]->frame->data[0], MC_W * MC_H * 2);
+    gfile_array(&g, "ref_y", T_U16, all, 3, d3);
+    d3[1] = MC_H / 2; d3[2] = MC_W / 2;
+    for (int i = 0; i < 3; ++i) memcpy(all + i * (MC_W / 2) * (MC_H / 2), ref[i]->frame->data[1], (MC_W / 2) * (MC_H / 2) * 2);
+    gfile_array(&g, "ref_cb", T_U16, all, 3, d3);
+    for (int i = 0; i < 3; ++i) memcpy(all + i * (MC_W / 2) * (MC_H / 2), ref[i]->frame->data[2], (MC_W / 2) * (MC_H / 2) * 2);
+    gfile_array(&g, "ref_cr", T_U16, all, 3, d3);
+    uint32_t d2[2] = { n_cases, sizeof(ovhip_affine_desc) };
+    gfile_array(&g, "desc", T_U8, b_desc.data, 2, d2);
+    d2[1] = 4; gfile_array(&g, "exp_off", T_U32, b_eoff.data, 2, d2);
+    gfile_buf(&g, "exp", &b_exp);
+    gfile_buf(&g, "mvs", &b_mv);
+    gfile_close(&g);
+    fprintf(stderr, "mca.ovg: %u cases, %zu expected samples\n", n_cases, b_exp.n);
+}
+
 /* ====================================================================================== DBF */
 #include "dbf_utils.h"
 #include "drv_lines.h"
@@ -899,6 +1036,7 @@ main(int argc, char **argv)
     if (!only || !strcmp(only, "itx")) gen_itx(dir);
     if (!only || !strcmp(only, "mc"))  gen_mc(dir);
     if (!only || !strcmp(only, "mcx")) gen_mcx(dir);
+    if (!only || !strcmp(only, "mca")) gen_mca(dir);
     if (!only || !strcmp(only, "dbf")) gen_dbf(dir);
     if (!only || !strcmp(only, "sao")) gen_sao(dir);
     if (!only || !strcmp(only, "alf")) gen_alf(dir);

@@ -61,6 +61,22 @@ def mcx_cases():
     return refs, descs, g["exp_off"], g["exp"], g["exp_mv"].reshape(-1, 4)
 
 
+def mca_cases():
+    """Affine CUs: (refs, [(AffineDesc, mv0 [rows, cols, 2], mv1)], exp_off [n,4], exp)."""
+    g = golden_io.load("mca.ovg")
+    n = g["desc"].shape[0]
+    _, rh, rw = g["ref_y"].shape
+    refs = [HostPic(rw, rh, g["ref_y"][k], g["ref_cb"][k], g["ref_cr"][k]) for k in range(3)]
+    cases = []
+    for i in range(n):
+        d = capi.AffineDesc.from_buffer_copy(g["desc"][i].tobytes())
+        nsx, nsy = (1 << d.log2_w) >> 2, (1 << d.log2_h) >> 2
+        o = int(g["exp_off"][i, 3])
+        mv = g["mvs"][o:o + 4 * nsx * nsy].reshape(2, nsy, nsx, 2)
+        cases.append((d, mv[0].copy(), mv[1].copy()))
+    return refs, cases, g["exp_off"], g["exp"]
+
+
 def check_rects(pic: HostPic, rects, exp, what=""):
     planes = pic.planes()
     bad = []

@@ -32,6 +32,8 @@ def lib():
         _lib.oracle_mc.restype = None
         _lib.oracle_mc_ex.argtypes = [C.POINTER(OPic), C.POINTER(OPic), C.c_uint32, vp, C.c_uint32, vp, vp]
         _lib.oracle_mc_ex.restype = None
+        _lib.oracle_mca.argtypes = [C.POINTER(OPic), C.POINTER(OPic), C.c_uint32, vp, C.c_uint32, vp, vp]
+        _lib.oracle_mca.restype = None
         _lib.oracle_dbf.argtypes = [C.POINTER(OPic), vp]
         _lib.oracle_dbf.restype = None
         _lib.oracle_sao.argtypes = [C.POINTER(OPic), C.POINTER(OPic), vp, C.c_int]
@@ -77,6 +79,19 @@ def mc(dst: HostPic, refs, units: np.ndarray, lmcs_fwd=None):
         lmcs_fwd = np.ascontiguousarray(lmcs_fwd, dtype=np.uint16)
         lut = lmcs_fwd.ctypes.data
     lib().oracle_mc(C.byref(s), arr, len(refs), units.ctypes.data, len(units), lut)
+
+
+def mca(dst: HostPic, refs, units: np.ndarray, side: np.ndarray, lmcs_fwd=None):
+    """Affine (+PROF) units."""
+    s = dst.struct()
+    arr = (OPic * len(refs))(*[r.struct() for r in refs])
+    units = np.ascontiguousarray(units)
+    side = np.ascontiguousarray(side, dtype=np.int32)
+    lut = None
+    if lmcs_fwd is not None:
+        lmcs_fwd = np.ascontiguousarray(lmcs_fwd, dtype=np.uint16)
+        lut = lmcs_fwd.ctypes.data
+    lib().oracle_mca(C.byref(s), arr, len(refs), units.ctypes.data, len(units), side.ctypes.data, lut)
 
 
 def mc_ex(dst: HostPic, refs, units: np.ndarray, lmcs_fwd=None) -> np.ndarray:

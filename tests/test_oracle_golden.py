@@ -61,6 +61,27 @@ def test_mcx_oracle_matches_reference(built_lib):
     assert n_moved > 100 and n_bdof > 100, "fixture does not exercise DMVR / BDOF"
 
 
+def test_mca_oracle_matches_reference(built_lib):
+    """Affine sub-block MC + PROF (rcn_mcp_b_l(2,2) / rcn_prof_mcp_b_l / rcn_mcp_b_c(3,3))."""
+    refs, cases, exp_off, exp = golden_cases.mca_cases()
+    rw, rh = refs[0].w, refs[0].h
+    rec = capi.Recorder(rw, rh)
+    n_prof = 0
+    for i, (d, mv0, mv1) in enumerate(cases):
+        rec.reset()
+        rec.affine_cu(d, mv0, mv1)
+        dst = HostPic(rw, rh)
+        dst.y[:] = 0xABAB; dst.cb[:] = 0xABAB; dst.cr[:] = 0xABAB
+        oracle_lib.mca(dst, refs, rec.aff_units(), rec.aff_side())
+        w, h = 1 << d.log2_w, 1 << d.log2_h
+        rects = [(0, d.x0, d.y0, w, h, int(exp_off[i, 0])),
+                 (1, d.x0 >> 1, d.y0 >> 1, w >> 1, h >> 1, int(exp_off[i, 1])),
+                 (2, d.x0 >> 1, d.y0 >> 1, w >> 1, h >> 1, int(exp_off[i, 2]))]
+        golden_cases.check_rects(dst, rects, exp, f"mca case {i} dir={d.inter_dir} prof={d.prof_dir} {w}x{h} @({d.x0},{d.y0})")
+        n_prof += d.prof_dir != 0
+    assert n_prof > 100
+
+
 def test_dbf_oracle_matches_reference(built_lib):
     cases = golden_cases.dbf_cases()
     assert len(cases) == 2
