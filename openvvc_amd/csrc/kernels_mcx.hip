@@ -350,9 +350,231 @@ extern "C" int ovhip_mcx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhi
     return OVHIP_OK;
 }
 
+// =====================================================================================================
+// K9: affine units.  One wavefront per <=16x16 luma area = up to 16 4x4 sub-blocks with their own motion
+// vectors (+ up to 4 4x4 chroma blocks).  lane = (sub-block, column): the 4 lanes of a sub-block stage
+// its 9x9 window (the 4x4-block filter ov_mc_filters_4 is 6-tap, rcn_mc.c:125-142), run the horizontal
+// pass on 3 rows each, then each lane owns one output column: vertical pass, PROF gradient/refinement
+// on a 6x6 LDS tile (extend_prof_buff / compute_prof_grad / rcn_prof, rcn_prof_bdof.c:152-290), bi / BCW
+// combine, LMCS, store.  Replaces the per-sub-block calls of rcn_affine_mcp_b_l / _prof_mcp_b_l / _mcp_b_c
+// (drv_affine_mvp.c:3264-3411).
+// =====================================================================================================
+namespace {
+
+#define AWS 12     /* luma window row: <= 3 aligned qwords                     */
+#define AHS 12     /* transposed H tile: 9 rows per column, 8-byte aligned     */
+#define ACS 12     /* chroma window row: off(<=3) + 7 -> 3 qwords              */
+#define ACHS 8     /* chroma transposed H tile: 7 rows per column              */
+
+__device__ __forceinline__ int aff_combine(int dir, int w0, int w1, int p0, int p1)
+{
+    if (dir != 3)           return ov_clip_bd(((dir == 1 ? p0 : p1) + 8) >> 4);
+    if (w0 == 4 && w1 == 4) return ov_clip_bd((p0 + p1 + 16) >> 5);
+    return ov_clip_bd((p1 * w1 + p0 * w0 + 64) >> 7);
+}
+
+// window of ROWS x COLS samples -> LDS rows of 12 samples.  4 lanes (c = 0..3) per window.
+template <int ROWS, int COLS>
+__device__ __forceinline__ int aff_stage(const uint16_t *__restrict__ ref, int rstride, int rw, int rh, int sx0, int sy0,
+                                         int c, uint16_t *win)
+{
+    const int ax = sx0 & ~3;
+    int off = sx0 - ax;
+    const int nq = (off + COLS + 3) >> 2;
+    const bool fast = ax >= 0 && ax + 4 * nq <= rw && sy0 >= 0 && sy0 + ROWS <= rh && !(rstride & 3);
+    if (fast) {
+        if (c < nq) {
+            uint2 q[ROWS];
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) q[r] = *reinterpret_cast<const uint2 *>(ref + (sy0 + r) * rstride + ax + 4 * c);
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) *reinterpret_cast<uint2 *>(win + r * 12 + 4 * c) = q[r];
+        }
+    } else {
+        off = 0;
+        for (int i = c; i < COLS; i += 4) {
+            const int sx = ov_clip3(sx0 + i, 0, rw - 1);
+#pragma unroll 1
+            for (int r = 0; r < ROWS; ++r) win[r * 12 + i] = ref[ov_clip3(sy0 + r, 0, rh - 1) * rstride + sx];
+        }
+    }
+    return off;
+}
+
+__global__ __launch_bounds__(64) void k_mca(ovhip_pic dst, RefTable refs, const ovhip_aff_unit *__restrict__ units,
+                                             uint32_t n_units, const int32_t *__restrict__ side, const uint16_t *__restrict__ lmcs_fwd)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t s_win[2][16][9 * AWS];
+    __shared__ __attribute__((aligned(16))) int16_t  s_ht[2][16][4 * AHS];
+    __shared__ __attribute__((aligned(16))) int16_t  s_t[2][16][40];
+    __shared__ __attribute__((aligned(16))) uint16_t s_cwin[2][8][7 * ACS];       // [list][comp * 4 + block]
+    __shared__ __attribute__((aligned(16))) int16_t  s_cht[2][8][4 * ACHS];
+
+    const int lane = threadIdx.x;
+    for (uint32_t bid = blockIdx.x; bid < n_units; bid += gridDim.x) {
+    const ovhip_aff_unit u = units[bid];
+    const int nsx = u.w >> 2, nsb = nsx * (u.h >> 2), ncx = u.w >> 3, ncb = ncx * (u.h >> 3);
+    const bool do_c = !(u.flags & OVHIP_AFF_NO_CHROMA);
+    const int4 *mvs = reinterpret_cast<const int4 *>(side + u.side_off);
+
+    // ---- luma lane state: sub-block sb, column / window slice c ----
+    const int sb = lane >> 2, c = lane & 3;
+    const bool act = sb < nsb;
+    const int bx = u.x + 4 * (sb % nsx), by = u.y + 4 * (sb / nsx);
+    int4 m = make_int4(0, 0, 0, 0);
+    if (act) m = mvs[sb];
+    int off[2] = { 0, 0 };
+    // ---- chroma lane state: list cl, window cw = comp * 4 + block, slice cc ----
+    const int cl = lane >> 5, cwi = (lane >> 2) & 7, cblk = cwi & 3, ccomp = cwi >> 2, cc = lane & 3;
+    const bool cact = do_c && cblk < ncb && (u.dir & (1 << cl));
+    int4 cm = make_int4(0, 0, 0, 0);
+    if (do_c && cblk < ncb) cm = mvs[nsb + cblk];
+    const int cbx = (u.x >> 1) + 4 * (cblk % ncx), cby = (u.y >> 1) + 4 * (cblk / ncx);
+    int coff = 0;
+
+    // ---- 1. windows ----
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        if (!(u.dir & (1 << l)) || !act) continue;
+        const ovhip_pic &rp = refs.p[l ? u.ref1 : u.ref0];
+        const int mvx = l ? m.z : m.x, mvy = l ? m.w : m.y;
+        off[l] = aff_stage<9, 9>(rp.y, rp.stride_y, rp.w, rp.h, bx + (mvx >> 4) - 2, by + (mvy >> 4) - 2, c, s_win[l][sb]);
+    }
+    if (cact) {
+        const ovhip_pic &rp = refs.p[cl ? u.ref1 : u.ref0];
+        const int mvx = cl ? cm.z : cm.x, mvy = cl ? cm.w : cm.y;
+        coff = aff_stage<7, 7>(ccomp ? rp.cr : rp.cb, rp.stride_c, rp.w >> 1, rp.h >> 1, cbx + (mvx >> 5) - 1, cby + (mvy >> 5) - 1, cc,
+                               s_cwin[cl][cwi]);
+    }
+    __syncthreads();
+
+    // ---- 2. horizontal passes: rows c, c+4, c+8 of the sub-block's window, 4 outputs each ----
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        if (!(u.dir & (1 << l)) || !act) continue;
+        const int mvx = l ? m.z : m.x;
+        int tp[3];
+        pack_taps<6>(ovt_mc_luma4[mvx & 15] + 1, tp);
+        for (int r = c; r < 9; r += 4) {
+            int d[5], out[4];
+            load_row_at<6>(s_win[l][sb] + r * AWS, off[l], d);
+            fir4<6>(d, tp, out);
+#pragma unroll
+            for (int o = 0; o < 4; ++o) s_ht[l][sb][o * AHS + r] = (int16_t)(out[o] >> (OV_BD - 8));
+        }
+    }
+    if (cact) {
+        const int mvx = cl ? cm.z : cm.x;
+        int tp[2];
+        pack_taps<4>(ovt_mc_chroma[mvx & 31], tp);
+        for (int r = cc; r < 7; r += 4) {
+            int d[4], out[4];
+            load_row_at<4>(s_cwin[cl][cwi] + r * ACS, coff, d);
+            fir4<4>(d, tp, out);
+#pragma unroll
+            for (int o = 0; o < 4; ++o) s_cht[cl][cwi][o * ACHS + r] = (int16_t)(out[o] >> (OV_BD - 8));
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. luma: vertical pass, PROF, combine ----
+    int P[2][4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
+    bool prof[2] = { false, false };
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        if (!(u.dir & (1 << l)) || !act) continue;
+        const int mvx = l ? m.z : m.x, mvy = l ? m.w : m.y;
+        int tp[3], d[5];
+        pack_taps<6>(ovt_mc_luma4[mvy & 15] + 1, tp);
+        const int *q = reinterpret_cast<const int *>(s_ht[l][sb] + c * AHS);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) d[j] = q[j];
+        fir4<6>(d, tp, P[l]);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) P[l][o] >>= 6;
+        prof[l] = (u.flags & OVHIP_AFF_PROF) && (u.dir != 3 || ((u.prof_dir >> l) & 1));
+        if (prof[l]) {
+            // 6x6 tile: interior = prediction column, ring = integer reference samples << 4 (5 ring samples per lane)
+            int16_t *t = s_t[l][sb];
+            const int ex = (mvx & 15) >> 3, ey = (mvy & 15) >> 3;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[(j + 1) * 6 + c + 1] = (int16_t)P[l][j];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int e = 5 * c + k;
+                int i, j;
+                if (e < 6)       { i = e; j = 0; }
+                else if (e < 12) { i = e - 6; j = 5; }
+                else if (e < 16) { i = 0; j = e - 11; }
+                else             { i = 5; j = e - 15; }
+                t[j * 6 + i] = (int16_t)(s_win[l][sb][(j + 1 + ey) * AWS + off[l] + i + 1 + ex] << 4);
+            }
+        }
+    }
+    __syncthreads();
+    if (act) {
+        const int16_t *pt = reinterpret_cast<const int16_t *>(side + u.prof_off);
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            if (!prof[l]) continue;
+            const int16_t *t = s_t[l][sb];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int o = (j + 1) * 6 + c + 1;
+                const int gx = (t[o + 1] >> 6) - (t[o - 1] >> 6), gy = (t[o + 6] >> 6) - (t[o - 6] >> 6);
+                const int add = ov_clip3(pt[32 * l + 4 * j + c] * gx + pt[32 * l + 16 + 4 * j + c] * gy, -(1 << 13), (1 << 13) - 1);
+                P[l][j] = (int)(int16_t)(P[l][j] + add);
+            }
+        }
+        const int dir = ((u.ident_l >> sb) & 1) ? 2 : u.dir;
+        uint16_t *d = dst.y + by * dst.stride_y + bx + c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int v = aff_combine(dir, u.w0, u.w1, P[0][j], P[1][j]);
+            if ((u.flags & OVHIP_AFF_LMCS) && lmcs_fwd) v = lmcs_fwd[v];
+            d[j * dst.stride_y] = (uint16_t)v;
+        }
+    }
+    // ---- 4. chroma: lanes 0..31 = (comp, block, column), both lists ----
+    if (do_c && lane < 32 && cblk < ncb) {
+        int Pc[2][4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            if (!(u.dir & (1 << l))) continue;
+            const int mvy = l ? cm.w : cm.y;
+            int tp[2], d[4];
+            pack_taps<4>(ovt_mc_chroma[mvy & 31], tp);
+            const int *q = reinterpret_cast<const int *>(s_cht[l][cwi] + cc * ACHS);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[j] = q[j];
+            fir4<4>(d, tp, Pc[l]);
+#pragma unroll
+            for (int o = 0; o < 4; ++o) Pc[l][o] >>= 6;
+        }
+        const int dir = ((u.ident_c >> cblk) & 1) ? 2 : u.dir;
+        uint16_t *d = (ccomp ? dst.cr : dst.cb) + cby * dst.stride_c + cbx + cc;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j * dst.stride_c] = (uint16_t)aff_combine(dir, u.w0, u.w1, Pc[0][j], Pc[1][j]);
+    }
+    __syncthreads();
+    }
+}
+
+} // namespace
+
 extern "C" int ovhip_mca_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs,
                                 const ovhip_aff_unit *d_units, uint32_t n_units, const int32_t *d_side,
                                 const uint16_t *d_lmcs_fwd_lut)
 {
-    return ov_fail(ctx, OVHIP_EINVAL, "ovhip_mca_launch: not built", hipSuccess);
+    if (!ctx || !dst) return OVHIP_EINVAL;
+    if (!n_units) return OVHIP_OK;
+    if (!refs || !n_refs || n_refs > MC_MAX_REFS || !d_units || !d_side)
+        return ov_fail(ctx, OVHIP_EINVAL, "ovhip_mca_launch: bad reference table / units / side arena", hipSuccess);
+    RefTable t;
+    memset(&t, 0, sizeof(t));
+    for (uint32_t i = 0; i < n_refs; ++i) t.p[i] = refs[i];
+    for (uint32_t i = n_refs; i < MC_MAX_REFS; ++i) t.p[i] = refs[0];
+    hipLaunchKernelGGL(k_mca, dim3(n_units), dim3(64), 0, ctx->stream, *dst, t, d_units, n_units, d_side, d_lmcs_fwd_lut);
+    OV_LAUNCH_CHECK(ctx, "k_mca");
+    return OVHIP_OK;
 }

@@ -85,6 +85,30 @@ def test_mcx_gpu_matches_reference(ctx):
     golden_cases.check_rects(HostPic(rw, rh * n, y, cb, cr), rects, exp, "mcx HIP vs reference")
 
 
+def test_mca_gpu_matches_reference(ctx):
+    """Affine sub-block prediction + PROF through ovhip_mca_launch vs the reference's rcn_mcp_b_l(2,2) /
+    rcn_prof_mcp_b_l / rcn_mcp_b_c(3,3) call sequence."""
+    refs, cases, exp_off, exp = golden_cases.mca_cases()
+    rw, rh = refs[0].w, refs[0].h
+    n = len(cases)
+    drefs = [ctx.upload_pic(r.y, r.cb, r.cr) for r in refs]
+    fill = np.full((rh * n, rw), 0xABAB, np.uint16)
+    tall = ctx.upload_pic(fill, fill[: rh * n // 2, : rw // 2], fill[: rh * n // 2, : rw // 2])
+    rec = capi.Recorder(rw, rh)
+    rects = []
+    for i, (d, mv0, mv1) in enumerate(cases):
+        rec.reset()
+        rec.affine_cu(d, mv0, mv1)
+        ctx.mca(tall.band(i * rh, rh), drefs, ctx.upload(rec.aff_units()), ctx.upload(rec.aff_side()))
+        w, h = 1 << d.log2_w, 1 << d.log2_h
+        rects += [(0, d.x0, d.y0 + i * rh, w, h, int(exp_off[i, 0])),
+                  (1, d.x0 >> 1, (d.y0 >> 1) + i * (rh // 2), w >> 1, h >> 1, int(exp_off[i, 1])),
+                  (2, d.x0 >> 1, (d.y0 >> 1) + i * (rh // 2), w >> 1, h >> 1, int(exp_off[i, 2]))]
+    ctx.sync()
+    y, cb, cr = tall.download()
+    golden_cases.check_rects(HostPic(rw, rh * n, y, cb, cr), rects, exp, "mca HIP vs reference")
+
+
 def test_dbf_gpu_matches_reference(ctx):
     for i, (pic, planes, exp) in enumerate(golden_cases.dbf_cases()):
         d = ctx.upload_pic(pic.y, pic.cb, pic.cr)
