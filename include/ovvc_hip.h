@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define OVHIP_ABI_VERSION 1
+#define OVHIP_ABI_VERSION 2
 
 /* ---- error codes (negative, in the spirit of libovvc/overror.h:40-45) ---- */
 #define OVHIP_OK        0
@@ -79,7 +79,9 @@ enum {                        /* ovhip_tb_cmd.res_mode: how the residual r is ap
     OVHIP_RES_SUB      = 1,   /* -r        */
     OVHIP_RES_ADD_HALF = 2,   /*  r >> 1   */
     OVHIP_RES_SUB_HALF = 3,   /* (-r) >> 1 */
-    OVHIP_RES_SCALE    = 4    /* flag: LMCS chroma residual scaling with c_scale (scale_* variants) */
+    OVHIP_RES_SCALE    = 4,   /* flag: LMCS chroma residual scaling with c_scale (scale_* variants) */
+    OVHIP_RES_SCALE_IDX = 8   /* flag (with OVHIP_RES_SCALE): c_scale is an INDEX into the launch's table of
+                               * device-derived scales (ovhip_lmcs_scale_launch), not the scale itself */
 };
 #define OVHIP_TB_FLAG_RASTER 0x80  /* in .kind: coefficients stored raster (2xN / Nx2 chroma TBs) */
 
@@ -172,6 +174,39 @@ typedef struct ovhip_aff_unit {
     uint32_t prof_off;        /* int32 index of the CU's PROFInfo in the side arena              */
     uint32_t pad[2];
 } ovhip_aff_unit;
+
+/* ------------------------------------------------------------------------------------
+ * LMCS (luma mapping with chroma scaling), rcn_lmcs.c.
+ *   ovhip_lmcs_build()      = rcn_init_lmcs -> init_lmcs_lut (rcn_lmcs.c:93-179, :352-370): host, per APS
+ *   forward reshape          : fused into the MC kernels (OVHIP_MC_LMCS + fwd LUT)
+ *   ovhip_lmcs_scale_launch = rcn_lmcs_compute_chroma_scale (rcn_lmcs.c:204-350) for every 64-aligned CU
+ *                             (vcl_coding_unit.c:724-730), on the reshaped-domain reconstruction
+ *   ovhip_lmcs_inverse_launch = lmcs_reshape_backward over the picture (slicedec.c:746-750, :799-803)
+ * ---------------------------------------------------------------------------------- */
+typedef struct ovhip_lmcs_data {       /* struct OVLMCSData (nvcl_structures.h:671-680) with the signs applied */
+    uint8_t  min_bin_idx;              /* lmcs_min_bin_idx                                                  */
+    uint8_t  delta_max_bin_idx;        /* lmcs_delta_max_bin_idx                                            */
+    int16_t  crs_offset;               /* +-lmcs_delta_abs_crs                                              */
+    int16_t  cw_delta[16];             /* +-lmcs_delta_abs_cw[i]                                            */
+} ovhip_lmcs_data;
+
+typedef struct ovhip_lmcs_luts {       /* struct LMCSLUTs + the LMCSInfo scalars (rcn_lmcs.c:75-81, rcn_lmcs.h:40-49) */
+    uint16_t fwd_lut[1024];
+    uint16_t bwd_lut[1024];
+    uint16_t wnd_bnd[17];
+    uint8_t  min_idx, max_idx;
+    int16_t  crs_offset;
+    uint16_t pad;
+} ovhip_lmcs_luts;
+
+typedef struct ovhip_lmcs_region {     /* one rcn_lmcs_compute_chroma_scale() call, 8 bytes */
+    uint16_t x, y;                     /* luma position of the 64-aligned CU in the picture                 */
+    uint8_t  n_abv, n_lft;             /* available 4-sample units above / left (bit length of the masks)    */
+    uint8_t  pad[2];
+} ovhip_lmcs_region;
+
+int ovhip_lmcs_build(const ovhip_lmcs_data *data, ovhip_lmcs_luts *out);
+
 
 /* ------------------------------------------------------------------------------------
  * Deblocking.  The reference filters one CTU per df.rcn_dbf_ctu() call from CTU-local bit maps
@@ -290,7 +325,8 @@ typedef struct ovhip_tu_state {
     uint8_t mts_implicit;     /* ctudec->mts_implicit (:435)                                      */
     uint8_t sh_ts_disabled;   /* ctudec->sh_ts_disabled (:673)                                    */
     uint8_t ict_type;         /* rcn_init_functions(ict_type): selects ict.ict[][] set (rcn_residuals.c:231) */
-    uint8_t lmcs_scale_c;     /* lmcs_info.scale_c_flag                                           */
+    uint8_t lmcs_scale_c;     /* lmcs_info.scale_c_flag: 1 = lmcs_chroma_scale below is the value;
+                               * 2 = use the scale of the last ovhip_rec_lmcs_region() (derived on the device) */
     uint8_t pad[3];
     int16_t lmcs_chroma_scale;/* lmcs_info.lmcs_chroma_scale                                      */
     int8_t  intra_mode;       /* ctudec->intra_mode (luma LFNST kernel choice, :461)              */
@@ -360,12 +396,20 @@ void  ovhip_rec_reset(ovhip_recorder *rec);
 int   ovhip_rec_tu(ovhip_recorder *rec, const ovhip_tu_state *st, const ovhip_tu_desc *tu);
 int   ovhip_rec_pu(ovhip_recorder *rec, const ovhip_pu_desc *pu);
 int   ovhip_rec_affine_cu(ovhip_recorder *rec, const ovhip_affine_desc *cu);
+/* rcn_lmcs_compute_chroma_scale(lmcs_info, stride, progress_field, ctu_buff.y, x0, y0): abv_mask / lft_mask are
+ * the two 16-bit availability masks it derives from progress_field (rcn_lmcs.c:327-332).  Returns the
+ * region index; TUs recorded afterwards with lmcs_scale_c == 2 refer to it. */
+int   ovhip_rec_lmcs_region(ovhip_recorder *rec, int32_t x0, int32_t y0, uint32_t abv_mask, uint32_t lft_mask);
 /* Convert one CTU's deblocking maps into the picture-level edge planes.  Returns 0 or <0. */
 int   ovhip_rec_dbf_ctu(ovhip_recorder *rec, const ovhip_dbf_ctu *ctu);
 /* Host copies of the edge planes (pointers valid until the next reset/destroy). */
 int   ovhip_rec_dbf_planes(const ovhip_recorder *rec, ovhip_dbf_planes *out);
 /* Access to the recorded (host) buffers. */
 const ovhip_tb_cmd  *ovhip_rec_tb_cmds(const ovhip_recorder *rec, size_t *n);
+/* The same commands reordered luma first (n_luma of them), then chroma: with device-derived chroma
+ * scales the chroma commands must run after ovhip_lmcs_scale_launch, which must run after the luma ones. */
+const ovhip_tb_cmd  *ovhip_rec_tb_cmds_split(ovhip_recorder *rec, size_t *n_luma, size_t *n);
+const ovhip_lmcs_region *ovhip_rec_lmcs_regions(const ovhip_recorder *rec, size_t *n);
 const int16_t       *ovhip_rec_coefs(const ovhip_recorder *rec, size_t *n_int16);
 const ovhip_mc_unit *ovhip_rec_mc_units(const ovhip_recorder *rec, size_t *n);
 /* The refined (OVHIP_MC_BDOF / OVHIP_MC_DMVR) units, kept apart so that each list is one launch. */
@@ -400,7 +444,12 @@ int  ovhip_pic_download(ovhip_ctx *ctx, const ovhip_pic *pic, uint16_t *y, uint1
 
 /* Stage launches.  cmds / coefs / units are DEVICE pointers; asynchronous on the ctx stream. */
 int  ovhip_itx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_tb_cmd *d_cmds,
-                      uint32_t n_cmds, const int16_t *d_coefs);
+                      uint32_t n_cmds, const int16_t *d_coefs, const int16_t *d_lmcs_scales);
+/* d_regions, d_scales: DEVICE; d_scales[i] receives lmcs_chroma_scale of region i.  luts: HOST. */
+int  ovhip_lmcs_scale_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_lmcs_region *d_regions,
+                             uint32_t n_regions, const ovhip_lmcs_luts *luts, int16_t *d_scales);
+/* Maps the luma plane through d_bwd_lut (DEVICE, 1024 entries) in place. */
+int  ovhip_lmcs_inverse_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const uint16_t *d_bwd_lut);
 int  ovhip_mc_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs,
                      const ovhip_mc_unit *d_units, uint32_t n_units, const uint16_t *d_lmcs_fwd_lut);
 /* Refined units (OVHIP_MC_BDOF / OVHIP_MC_DMVR).  d_mv_out: DEVICE array of 4 int32 per unit

@@ -17,7 +17,7 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libovvc_hip.so"
 
 # ---- constants (include/ovvc_hip.h) ----
-OVHIP_ABI_VERSION = 1
+OVHIP_ABI_VERSION = 2
 DST_VII, DCT_VIII, DCT_II = 0, 1, 2
 TB_TR, TB_DC, TB_TS, TB_TS_RAW = 0, 1, 2, 3
 TB_FLAG_RASTER = 0x80
@@ -81,6 +81,20 @@ class AffineDesc(C.Structure):
                 ("mv_stride", C.c_int32), ("mv0", C.c_void_p), ("mv1", C.c_void_p), ("dmv_scale", (C.c_int16 * 16) * 4)]
 
 
+class LmcsData(C.Structure):
+    _fields_ = [("min_bin_idx", C.c_uint8), ("delta_max_bin_idx", C.c_uint8), ("crs_offset", C.c_int16),
+                ("cw_delta", C.c_int16 * 16)]
+
+
+class LmcsLuts(C.Structure):
+    _fields_ = [("fwd_lut", C.c_uint16 * 1024), ("bwd_lut", C.c_uint16 * 1024), ("wnd_bnd", C.c_uint16 * 17),
+                ("min_idx", C.c_uint8), ("max_idx", C.c_uint8), ("crs_offset", C.c_int16), ("pad", C.c_uint16)]
+
+
+LMCS_REGION_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("n_abv", "u1"), ("n_lft", "u1"), ("pad", "u1", 2)])
+assert LMCS_REGION_DTYPE.itemsize == 8
+
+
 class DbfPlanes(C.Structure):
     _fields_ = [("luma_v", C.c_void_p), ("luma_h", C.c_void_p), ("cb_v", C.c_void_p), ("cr_v", C.c_void_p),
                 ("cb_h", C.c_void_p), ("cr_h", C.c_void_p), ("w4", C.c_int32), ("h4", C.c_int32),
@@ -135,6 +149,15 @@ AFF_PROF, AFF_NO_CHROMA, AFF_LMCS = 1, 8, 16
 _lib = None
 
 
+def lmcs_build(data: "LmcsData") -> "LmcsLuts":
+    """Host: the LMCS tables of one APS (rcn_init_lmcs)."""
+    out = LmcsLuts()
+    r = load().ovhip_lmcs_build(C.byref(data), C.byref(out))
+    if r < 0:
+        raise ValueError(f"ovhip_lmcs_build -> {r}")
+    return out
+
+
 def load(path: os.PathLike | None = None) -> C.CDLL:
     """Load libovvc_hip.so (built in-tree by __graft_entry__.build()).  Fails loudly."""
     global _lib
@@ -168,6 +191,12 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_rec_mc_units": (vp, [vp, P(C.c_size_t)]),
         "ovhip_rec_mcx_units": (vp, [vp, P(C.c_size_t)]),
         "ovhip_rec_affine_cu": (C.c_int, [vp, P(AffineDesc)]),
+        "ovhip_rec_lmcs_region": (C.c_int, [vp, C.c_int32, C.c_int32, u32, u32]),
+        "ovhip_rec_lmcs_regions": (vp, [vp, P(C.c_size_t)]),
+        "ovhip_rec_tb_cmds_split": (vp, [vp, P(C.c_size_t), P(C.c_size_t)]),
+        "ovhip_lmcs_build": (C.c_int, [P(LmcsData), P(LmcsLuts)]),
+        "ovhip_lmcs_scale_launch": (C.c_int, [vp, P(Pic), vp, u32, P(LmcsLuts), vp]),
+        "ovhip_lmcs_inverse_launch": (C.c_int, [vp, P(Pic), vp]),
         "ovhip_rec_aff_units": (vp, [vp, P(C.c_size_t)]),
         "ovhip_rec_aff_side": (vp, [vp, P(C.c_size_t)]),
         "ovhip_ctx_create": (C.c_int, [P(vp), C.c_int, vp]),
@@ -183,7 +212,7 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_pic_free": (C.c_int, [vp, P(Pic)]),
         "ovhip_pic_upload": (C.c_int, [vp, P(Pic), vp, vp, vp, i32, i32]),
         "ovhip_pic_download": (C.c_int, [vp, P(Pic), vp, vp, vp, i32, i32]),
-        "ovhip_itx_launch": (C.c_int, [vp, P(Pic), vp, u32, vp]),
+        "ovhip_itx_launch": (C.c_int, [vp, P(Pic), vp, u32, vp, vp]),
         "ovhip_mc_launch": (C.c_int, [vp, P(Pic), P(Pic), u32, vp, u32, vp]),
         "ovhip_mcx_launch": (C.c_int, [vp, P(Pic), P(Pic), u32, vp, u32, vp, vp]),
         "ovhip_mca_launch": (C.c_int, [vp, P(Pic), P(Pic), u32, vp, u32, vp, vp]),
@@ -200,7 +229,7 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
 
 EXPORTED_SYMBOLS = [
     "ovhip_abi_version", "ovhip_rec_create", "ovhip_rec_destroy", "ovhip_rec_reset", "ovhip_rec_tu",
-    "ovhip_rec_pu", "ovhip_rec_dbf_ctu", "ovhip_rec_dbf_planes", "ovhip_dbf_launch", "ovhip_sao_launch", "ovhip_alf_launch", "ovhip_rec_tb_cmds", "ovhip_rec_coefs", "ovhip_rec_mc_units", "ovhip_rec_mcx_units", "ovhip_mcx_launch", "ovhip_rec_affine_cu", "ovhip_rec_aff_units", "ovhip_rec_aff_side", "ovhip_mca_launch", "ovhip_ctx_create",
+    "ovhip_rec_pu", "ovhip_rec_dbf_ctu", "ovhip_rec_dbf_planes", "ovhip_dbf_launch", "ovhip_sao_launch", "ovhip_alf_launch", "ovhip_rec_tb_cmds", "ovhip_rec_coefs", "ovhip_rec_mc_units", "ovhip_rec_mcx_units", "ovhip_mcx_launch", "ovhip_rec_affine_cu", "ovhip_rec_lmcs_region", "ovhip_rec_lmcs_regions", "ovhip_rec_tb_cmds_split", "ovhip_lmcs_build", "ovhip_lmcs_scale_launch", "ovhip_lmcs_inverse_launch", "ovhip_rec_aff_units", "ovhip_rec_aff_side", "ovhip_mca_launch", "ovhip_ctx_create",
     "ovhip_ctx_destroy", "ovhip_ctx_sync", "ovhip_last_error", "ovhip_ctx_stream", "ovhip_malloc",
     "ovhip_free", "ovhip_h2d", "ovhip_d2h", "ovhip_pic_alloc", "ovhip_pic_free", "ovhip_pic_upload",
     "ovhip_pic_download", "ovhip_itx_launch", "ovhip_mc_launch",
@@ -291,6 +320,24 @@ class Recorder:
 
     def mc_units(self) -> np.ndarray:
         return self._arr(self.lib.ovhip_rec_mc_units, MC_UNIT_DTYPE)
+
+    def lmcs_region(self, x0: int, y0: int, abv_mask: int, lft_mask: int) -> int:
+        r = self.lib.ovhip_rec_lmcs_region(self.h, x0, y0, abv_mask, lft_mask)
+        if r < 0:
+            raise ValueError(f"ovhip_rec_lmcs_region -> {r}")
+        return r
+
+    def lmcs_regions(self) -> np.ndarray:
+        return self._arr(self.lib.ovhip_rec_lmcs_regions, LMCS_REGION_DTYPE)
+
+    def tb_cmds_split(self):
+        """(commands reordered luma first, number of luma commands)."""
+        nl, n = C.c_size_t(), C.c_size_t()
+        p = self.lib.ovhip_rec_tb_cmds_split(self.h, C.byref(nl), C.byref(n))
+        if not n.value:
+            return np.zeros(0, TB_CMD_DTYPE), 0
+        buf = (C.c_char * (n.value * TB_CMD_DTYPE.itemsize)).from_address(p)
+        return np.frombuffer(buf, dtype=TB_CMD_DTYPE).copy(), nl.value
 
     def aff_units(self) -> np.ndarray:
         return self._arr(self.lib.ovhip_rec_aff_units, AFF_UNIT_DTYPE)

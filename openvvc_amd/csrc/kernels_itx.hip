@@ -143,7 +143,8 @@ __device__ __forceinline__ void tr_pass_lds(const int16_t *src, int sstride, con
 }
 
 __global__ __launch_bounds__(64) void k_itx(ovhip_pic pic, const ovhip_tb_cmd *__restrict__ cmds,
-                                             uint32_t n_cmds, const int16_t *__restrict__ arena, int ablate)
+                                             uint32_t n_cmds, const int16_t *__restrict__ arena,
+                                             const int16_t *__restrict__ lmcs_scales, int ablate)
 {
     __shared__ __attribute__((aligned(16))) int16_t s_coef[32 * 32];
     __shared__ __attribute__((aligned(16))) int16_t s_tmp[32 * 64];
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(64) void k_itx(ovhip_pic pic, const ovhip_tb_cmd *_
     sink.mode = c.res_mode;
     sink.dst2 = nullptr; sink.stride2 = 0; sink.mode2 = c.res_mode2;
     if (c.plane2 != 0xff) sink.dst2 = ov_plane(pic, c.plane2, sink.stride2) + c.y * sink.stride2 + c.x;
-    sink.scale = c.c_scale;
+    sink.scale = (c.res_mode & OVHIP_RES_SCALE_IDX) ? lmcs_scales[c.c_scale] : c.c_scale;   // device-derived chroma scale (K11)
 
     if (ablate & 4) continue;
     if (kind == OVHIP_TB_TR) {
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(64) void k_itx(ovhip_pic pic, const ovhip_tb_cmd *_
 } // namespace
 
 extern "C" int ovhip_itx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_tb_cmd *d_cmds,
-                                uint32_t n_cmds, const int16_t *d_coefs)
+                                uint32_t n_cmds, const int16_t *d_coefs, const int16_t *d_lmcs_scales)
 {
     if (!ctx || !dst) return OVHIP_EINVAL;
     if (!n_cmds) return OVHIP_OK;
@@ -310,7 +311,7 @@ extern "C" int ovhip_itx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhi
     // the loop form stays for grids capped by the caller, the default launches n_cmds workgroups
     static int cfg_ablate = -1;
     if (cfg_ablate < 0) { const char *a = getenv("OVHIP_ITX_ABLATE"); cfg_ablate = a ? atoi(a) : 0; }   // profiling knob
-    hipLaunchKernelGGL(k_itx, dim3(n_cmds), dim3(64), 0, ctx->stream, *dst, d_cmds, n_cmds, d_coefs, cfg_ablate);
+    hipLaunchKernelGGL(k_itx, dim3(n_cmds), dim3(64), 0, ctx->stream, *dst, d_cmds, n_cmds, d_coefs, d_lmcs_scales, cfg_ablate);
     OV_LAUNCH_CHECK(ctx, "k_itx");
     return OVHIP_OK;
 }

@@ -1,0 +1,99 @@
+// kernels_lmcs.hip -- K11 on gfx950: the two per-sample / per-region LMCS steps that need the
+// reconstructed picture (the forward map is fused into the MC kernels, the tables are built on the
+// host by ovvc_lmcs.c).
+//
+//   k_lmcs_scale   : rcn_lmcs_compute_chroma_scale (libovvc/rcn_lmcs.c:204-350), called by the
+//                    reference once per 64-aligned CU (vcl_coding_unit.c:724-730): average of the
+//                    <= 64 + 64 reshaped-domain luma samples above / left of the region (padded with
+//                    the last available sample to 16 units per side), window lookup, division.
+//                    One wavefront per region: lane = neighbour sample, wave reduction.
+//   k_lmcs_inverse : lmcs_reshape_backward over the whole luma plane (slicedec.c:746-750): one 16-byte
+//                    vector of 8 samples per lane, LUT (2 KB) staged in LDS.  Pure HBM stream: 2 bytes
+//                    read + 2 bytes written per luma sample.
+#include "ovvc_common.hip.h"
+
+namespace {
+
+struct LmcsWnd { uint16_t bnd[17]; int min_idx, max_idx, crs_offset; };
+
+__global__ __launch_bounds__(64) void k_lmcs_scale(ovhip_pic pic, const ovhip_lmcs_region *__restrict__ regs, uint32_t n,
+                                                   LmcsWnd wnd, int16_t *__restrict__ scales)
+{
+    const uint32_t bid = blockIdx.x;
+    if (bid >= n) return;
+    const ovhip_lmcs_region g = regs[bid];
+    const int lane = threadIdx.x;
+    // the reference sums sample k of every unit into luma_sum[k & 3]; only the total is used
+    int sum = 0;
+    const uint16_t *src = pic.y + (size_t)g.y * pic.stride_y + g.x;
+    if (g.n_abv) {
+        const int navail = 4 * g.n_abv;                       // samples actually read; the rest repeats the last one
+        sum += src[-pic.stride_y + min(lane, navail - 1)];
+    }
+    if (g.n_lft) {
+        const int navail = 4 * g.n_lft;
+        sum += src[(size_t)min(lane, navail - 1) * pic.stride_y - 1];
+    }
+#pragma unroll
+    for (int m = 32; m; m >>= 1) sum += __shfl_xor(sum, m);
+    if (lane == 0) {
+        const int nb_units = (g.n_abv ? 16 : 0) + (g.n_lft ? 16 : 0);
+        int log2_nb = 0;
+        for (int v = nb_units; v; v >>= 1) ++log2_nb;         // 16 -> 5, 32 -> 6, as the reference counts
+        const int avg = log2_nb ? (sum + (1 << log2_nb)) >> (log2_nb + 1) : 512;
+        int idx = wnd.min_idx;                                // get_bwd_idx (rcn_lmcs.c:83-93)
+        for (; idx < wnd.max_idx; ++idx)
+            if (avg < wnd.bnd[idx + 1]) break;
+        idx = min(idx, 15);
+        const int wnd_sz = (int)wnd.bnd[idx + 1] - (int)wnd.bnd[idx];
+        scales[bid] = (int16_t)(wnd_sz == 0 ? 1 << 11 : (1 << (OV_BD - 4 + 11)) / (wnd_sz + wnd.crs_offset));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lmcs_inverse(ovhip_pic pic, const uint16_t *__restrict__ lut)
+{
+    __shared__ uint16_t s_lut[1024];
+    for (int i = threadIdx.x; i < 512; i += 256) reinterpret_cast<uint32_t *>(s_lut)[i] = reinterpret_cast<const uint32_t *>(lut)[i];
+    __syncthreads();
+    const int nvx = pic.w >> 3;                               // full 8-sample vectors per row
+    const int tail = pic.w & 7;
+    for (int y = blockIdx.y; y < pic.h; y += gridDim.y) {
+        uint16_t *row = pic.y + (size_t)y * pic.stride_y;
+        for (int v = blockIdx.x * 256 + threadIdx.x; v < nvx; v += gridDim.x * 256) {
+            uint4 q = *reinterpret_cast<uint4 *>(row + 8 * v);
+            uint32_t *d = reinterpret_cast<uint32_t *>(&q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[k] = s_lut[d[k] & 1023] | ((uint32_t)s_lut[(d[k] >> 16) & 1023] << 16);
+            *reinterpret_cast<uint4 *>(row + 8 * v) = q;
+        }
+        if (tail && blockIdx.x == 0 && threadIdx.x < tail) row[8 * nvx + threadIdx.x] = s_lut[row[8 * nvx + threadIdx.x] & 1023];
+    }
+}
+
+} // namespace
+
+extern "C" int ovhip_lmcs_scale_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_lmcs_region *d_regions,
+                                       uint32_t n_regions, const ovhip_lmcs_luts *luts, int16_t *d_scales)
+{
+    if (!ctx || !pic || !luts) return OVHIP_EINVAL;
+    if (!n_regions) return OVHIP_OK;
+    if (!d_regions || !d_scales) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_lmcs_scale_launch: null buffer", hipSuccess);
+    LmcsWnd w;
+    for (int i = 0; i < 17; ++i) w.bnd[i] = luts->wnd_bnd[i];
+    w.min_idx = luts->min_idx; w.max_idx = luts->max_idx; w.crs_offset = luts->crs_offset;
+    hipLaunchKernelGGL(k_lmcs_scale, dim3(n_regions), dim3(64), 0, ctx->stream, *pic, d_regions, n_regions, w, d_scales);
+    OV_LAUNCH_CHECK(ctx, "k_lmcs_scale");
+    return OVHIP_OK;
+}
+
+extern "C" int ovhip_lmcs_inverse_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const uint16_t *d_bwd_lut)
+{
+    if (!ctx || !pic || !d_bwd_lut) return OVHIP_EINVAL;
+    if ((pic->stride_y & 7) || ((uintptr_t)pic->y & 15))
+        return ov_fail(ctx, OVHIP_EINVAL, "ovhip_lmcs_inverse_launch: luma plane must be 16-byte aligned with stride % 8 == 0", hipSuccess);
+    const int nvx = pic->w >> 3;
+    dim3 grid((nvx + 255) / 256 > 0 ? (nvx + 255) / 256 : 1, pic->h < 2048 ? pic->h : 2048);
+    hipLaunchKernelGGL(k_lmcs_inverse, grid, dim3(256), 0, ctx->stream, *pic, d_bwd_lut);
+    OV_LAUNCH_CHECK(ctx, "k_lmcs_inverse");
+    return OVHIP_OK;
+}

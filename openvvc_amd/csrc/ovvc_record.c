@@ -40,7 +40,7 @@ void
 ovhip_rec_destroy(ovhip_recorder *r)
 {
     if (!r) return;
-    free(r->tb); free(r->coef); free(r->mc); free(r->mcx); free(r->aff); free(r->aff_side);
+    free(r->tb); free(r->coef); free(r->mc); free(r->mcx); free(r->aff); free(r->aff_side); free(r->reg); free(r->tb_split);
     ovhip_rec_dbf_free_(r);
     free(r);
 }
@@ -48,7 +48,7 @@ ovhip_rec_destroy(ovhip_recorder *r)
 void
 ovhip_rec_reset(ovhip_recorder *r)
 {
-    r->n_tb = r->n_coef = r->n_mc = r->n_mcx = r->n_aff = r->n_side = 0;
+    r->n_tb = r->n_coef = r->n_mc = r->n_mcx = r->n_aff = r->n_side = r->n_reg = 0;
     ovhip_rec_dbf_reset_(r);
 }
 
@@ -327,6 +327,12 @@ ovhip_rec_tu(ovhip_recorder *r, const ovhip_tu_state *st, const ovhip_tu_desc *t
         else { xc = tu->x0 >> 1; yc = tu->y0 >> 1; l2w = tu->log2_tb_w - 1; l2h = tu->log2_tb_h - 1; lfnst_flag = 0; }
         int cbf_c = tu->cbf_mask & 0x3;
         int16_t scale = st->lmcs_scale_c ? st->lmcs_chroma_scale : (int16_t)(1 << 11);
+        /* lmcs_scale_c == 2: the scale is derived on the device; the command carries the region index */
+        const int indirect = st->lmcs_scale_c == 2;
+        if (indirect) {
+            if (!r->n_reg) return OVHIP_EINVAL;
+            scale = (int16_t)(r->n_reg - 1);
+        }
         struct tb_args a;
         memset(&a, 0, sizeof(a));
         a.x = xc; a.y = yc; a.log2_w = l2w; a.log2_h = l2h;
@@ -348,6 +354,7 @@ ovhip_rec_tu(ovhip_recorder *r, const ovhip_tu_state *st, const ovhip_tu_desc *t
             c->res_mode  = ict_mode(st->ict_type, 0);
             c->plane2    = (uint8_t)second;
             c->res_mode2 = ict_mode(st->ict_type, k2);
+            if (indirect && l2w + l2h != 2 && (c->res_mode & OVHIP_RES_SCALE)) { c->res_mode |= OVHIP_RES_SCALE_IDX; c->res_mode2 |= OVHIP_RES_SCALE_IDX; }
         } else {
             for (int comp = 0; comp < 2; ++comp) {      /* 0: Cb (cbf 0x2), 1: Cr (cbf 0x1) */
                 int bit = comp ? 0x1 : 0x2;
@@ -358,7 +365,10 @@ ovhip_rec_tu(ovhip_recorder *r, const ovhip_tu_state *st, const ovhip_tu_desc *t
                 a.qp_skip = comp ? st->qp_cr_skip : st->qp_cb_skip;
                 a.last_pos = tu->last_pos[comp]; a.sig_sb_map = tu->sig_sb_map[comp]; a.coef = tu->coef[comp];
                 if ((ret = emit_tb(r, st, &a, &c))) goto fail;
-                if (l2w + l2h > 2) { c->res_mode = ict_mode(st->ict_type, 0); c->c_scale = scale; }
+                if (l2w + l2h > 2) {
+                    c->res_mode = ict_mode(st->ict_type, 0); c->c_scale = scale;
+                    if (indirect && (c->res_mode & OVHIP_RES_SCALE)) c->res_mode |= OVHIP_RES_SCALE_IDX;
+                }
                 else               { c->res_mode = OVHIP_RES_ADD; }
             }
         }
@@ -570,4 +580,39 @@ ovhip_rec_affine_cu(ovhip_recorder *r, const ovhip_affine_desc *cu)
         }
     }
     return n;
+}
+
+/* ---------------------------------------------------------------- LMCS chroma-scale regions */
+static int bit_length(uint32_t v) { int n = 0; while (v) { ++n; v >>= 1; } return n; }
+
+int
+ovhip_rec_lmcs_region(ovhip_recorder *r, int32_t x0, int32_t y0, uint32_t abv_mask, uint32_t lft_mask)
+{
+    if (x0 < 0 || y0 < 0 || x0 >= r->pic_w || y0 >= r->pic_h || r->n_reg >= 32767) return OVHIP_EINVAL;
+    if (grow((void **)&r->reg, &r->cap_reg, r->n_reg + 1, sizeof(*r->reg))) return OVHIP_ENOMEM;
+    ovhip_lmcs_region *g = &r->reg[r->n_reg];
+    memset(g, 0, sizeof(*g));
+    g->x = (uint16_t)x0; g->y = (uint16_t)y0;
+    /* lmcs_compute_luma_average walks each mask until it is exhausted (rcn_lmcs.c:219-246) */
+    g->n_abv = (uint8_t)bit_length(abv_mask & 0xffff);
+    g->n_lft = (uint8_t)bit_length(lft_mask & 0xffff);
+    return (int)r->n_reg++;
+}
+
+const ovhip_lmcs_region *ovhip_rec_lmcs_regions(const ovhip_recorder *r, size_t *n) { *n = r->n_reg; return r->reg; }
+
+const ovhip_tb_cmd *
+ovhip_rec_tb_cmds_split(ovhip_recorder *r, size_t *n_luma, size_t *n)
+{
+    *n = r->n_tb; *n_luma = 0;
+    if (!r->n_tb) return r->tb;
+    if (grow((void **)&r->tb_split, &r->cap_split, r->n_tb, sizeof(ovhip_tb_cmd))) { *n = 0; return NULL; }
+    size_t nl = 0, k;
+    for (size_t i = 0; i < r->n_tb; ++i) nl += r->tb[i].plane == 0;
+    k = nl; *n_luma = nl; nl = 0;
+    for (size_t i = 0; i < r->n_tb; ++i) {
+        if (r->tb[i].plane == 0) r->tb_split[nl++] = r->tb[i];
+        else                     r->tb_split[k++] = r->tb[i];
+    }
+    return r->tb_split;
 }

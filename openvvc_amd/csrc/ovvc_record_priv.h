@@ -12,6 +12,8 @@ struct ovhip_recorder {
     ovhip_mc_unit *mcx;   size_t n_mcx,  cap_mcx;   /* BDOF / DMVR units */
     ovhip_aff_unit *aff;  size_t n_aff,  cap_aff;   /* affine units */
     int32_t *aff_side;    size_t n_side, cap_side;
+    ovhip_lmcs_region *reg; size_t n_reg, cap_reg;
+    ovhip_tb_cmd *tb_split; size_t cap_split;
     /* deblocking edge planes (ovvc_record_dbf.c) */
     uint16_t *dbf_luma_v, *dbf_luma_h, *dbf_cb_v, *dbf_cr_v, *dbf_cb_h, *dbf_cr_h;
     int32_t dbf_w4, dbf_h4;

@@ -69,9 +69,21 @@ class Context:
         return p
 
     # ---- stages ----
-    def itx(self, dst: "DevPic", cmds: "DevBuf", coefs: "DevBuf", n: int | None = None):
-        n = cmds.count if n is None else n
-        self._chk(self.lib.ovhip_itx_launch(self.h, C.byref(dst.s), cmds.ptr, n, coefs.ptr), "itx_launch")
+    def itx(self, dst: "DevPic", cmds: "DevBuf", coefs: "DevBuf", n: int | None = None, first: int = 0,
+            lmcs_scales: "DevBuf | None" = None):
+        """n commands starting at command `first`; lmcs_scales: device-derived chroma scales (lmcs_scale)."""
+        n = cmds.count - first if n is None else n
+        ptr = C.c_void_p(cmds.ptr.value + first * capi.TB_CMD_DTYPE.itemsize) if first else cmds.ptr
+        self._chk(self.lib.ovhip_itx_launch(self.h, C.byref(dst.s), ptr, n, coefs.ptr,
+                                            lmcs_scales.ptr if lmcs_scales else None), "itx_launch")
+
+    def lmcs_scale(self, pic: "DevPic", regions: "DevBuf", luts: "capi.LmcsLuts", scales: "DevBuf", n: int | None = None):
+        n = regions.count if n is None else n
+        self._chk(self.lib.ovhip_lmcs_scale_launch(self.h, C.byref(pic.s), regions.ptr, n, C.byref(luts), scales.ptr),
+                  "lmcs_scale_launch")
+
+    def lmcs_inverse(self, pic: "DevPic", bwd_lut: "DevBuf"):
+        self._chk(self.lib.ovhip_lmcs_inverse_launch(self.h, C.byref(pic.s), bwd_lut.ptr), "lmcs_inverse_launch")
 
     def dbf(self, pic: "DevPic", planes: "DevDbfPlanes"):
         self._chk(self.lib.ovhip_dbf_launch(self.h, C.byref(pic.s), C.byref(planes.s)), "dbf_launch")

@@ -146,7 +146,7 @@ static void residual_apply(uint16_t *dst, int dstride, const int16_t *res, int w
 
 /* One transform block.  rcn_residual (rcn_transform_tree.c:415-506), rcn_residual_c (:553-628),
  * transform-skip (:672-716, :1208-1225), ict.add / ict.ict (:1262, :750-756, :846-866). */
-static void itx_one(const oracle_pic *pic, const ovhip_tb_cmd *c, const int16_t *arena)
+static void itx_one(const oracle_pic *pic, const ovhip_tb_cmd *c, const int16_t *arena, const int16_t *lmcs_scales)
 {
     const int log2_w = c->log2_w, log2_h = c->log2_h;
     const int tb_w = 1 << log2_w, tb_h = 1 << log2_h;
@@ -204,16 +204,63 @@ static void itx_one(const oracle_pic *pic, const ovhip_tb_cmd *c, const int16_t 
 
     int stride;
     uint16_t *d = plane_ptr(pic, c->plane, &stride) + c->y * stride + c->x;
-    residual_apply(d, stride, res, tb_w, tb_h, c->res_mode, c->c_scale);
+    /* OVHIP_RES_SCALE_IDX: the scale was derived from the reconstruction (oracle_lmcs_scale) */
+    const int scale = (c->res_mode & OVHIP_RES_SCALE_IDX) ? lmcs_scales[c->c_scale] : c->c_scale;
+    residual_apply(d, stride, res, tb_w, tb_h, c->res_mode, scale);
     if (c->plane2 != 0xff) {
         d = plane_ptr(pic, c->plane2, &stride) + c->y * stride + c->x;
-        residual_apply(d, stride, res, tb_w, tb_h, c->res_mode2, c->c_scale);
+        residual_apply(d, stride, res, tb_w, tb_h, c->res_mode2, scale);
     }
+}
+
+void oracle_itx_ex(const oracle_pic *pic, const ovhip_tb_cmd *cmds, uint32_t n, const int16_t *arena, const int16_t *lmcs_scales)
+{
+    for (uint32_t i = 0; i < n; ++i) itx_one(pic, &cmds[i], arena, lmcs_scales);
 }
 
 void oracle_itx(const oracle_pic *pic, const ovhip_tb_cmd *cmds, uint32_t n, const int16_t *arena)
 {
-    for (uint32_t i = 0; i < n; ++i) itx_one(pic, &cmds[i], arena);
+    oracle_itx_ex(pic, cmds, n, arena, NULL);
+}
+
+/* ====================================================================================
+ * K11: LMCS chroma-scale derivation and inverse luma mapping
+ * ================================================================================== */
+
+/* rcn_lmcs_compute_chroma_scale + lmcs_compute_luma_average + get_bwd_idx (rcn_lmcs.c:83-93, :204-350) */
+void oracle_lmcs_scale(const oracle_pic *pic, const ovhip_lmcs_region *regs, uint32_t n,
+                       const ovhip_lmcs_luts *luts, int16_t *scales)
+{
+    for (uint32_t r = 0; r < n; ++r) {
+        const ovhip_lmcs_region *g = &regs[r];
+        const uint16_t *src = pic->y + g->y * pic->stride_y + g->x;
+        uint32_t s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+        int nb_abv = 0, nb_lft = 0, nb_units, log2_nb = 0;
+        const uint16_t *p = src - pic->stride_y;
+        for (int u = 0; u < g->n_abv; ++u, p += 4, ++nb_abv) { s1 += p[0]; s2 += p[1]; s3 += p[2]; s4 += p[3]; }
+        if (nb_abv) { uint32_t pad = p[-1] * (16 - nb_abv); s1 += pad; s2 += pad; s3 += pad; s4 += pad; nb_abv = 16; }
+        p = src - 1;
+        for (int u = 0; u < g->n_lft; ++u, p += 4 * pic->stride_y, ++nb_lft) {
+            s1 += p[0]; s2 += p[pic->stride_y]; s3 += p[2 * pic->stride_y]; s4 += p[3 * pic->stride_y];
+        }
+        if (nb_lft) { uint32_t pad = p[-pic->stride_y] * (16 - nb_lft); s1 += pad; s2 += pad; s3 += pad; s4 += pad; nb_lft = 16; }
+        nb_units = nb_abv + nb_lft;
+        while (nb_units) { ++log2_nb; nb_units >>= 1; }
+        uint32_t avg = log2_nb ? ((s1 + s2) + (s3 + s4) + (1u << log2_nb)) >> (log2_nb + 1) : 1u << (BD - 1);
+        int idx = luts->min_idx;
+        for (; idx < luts->max_idx; ++idx)
+            if (avg < luts->wnd_bnd[idx + 1]) break;
+        if (idx > 15) idx = 15;
+        int32_t wnd_sz = (int32_t)luts->wnd_bnd[idx + 1] - (int32_t)luts->wnd_bnd[idx];
+        scales[r] = (int16_t)(wnd_sz == 0 ? 1 << 11 : (1 << (BD - 4 + 11)) / (wnd_sz + luts->crs_offset));
+    }
+}
+
+/* lmcs_reshape_backward over the picture (rcn_lmcs.c:273-301; slicedec.c:746-750) */
+void oracle_lmcs_inverse(const oracle_pic *pic, const uint16_t *bwd_lut)
+{
+    for (int y = 0; y < pic->h; ++y)
+        for (int x = 0; x < pic->w; ++x) pic->y[y * pic->stride_y + x] = bwd_lut[pic->y[y * pic->stride_y + x] & PIX_MAX];
 }
 
 /* ====================================================================================

@@ -623,6 +623,103 @@ gen_mca(const char *dir)
     fprintf(stderr, "mca.ovg: %u cases, %zu expected samples\n", n_cases, b_exp.n);
 }
 
+/* ====================================================================================== LMCS
+ * lmcs.ovg : rcn_init_lmcs (table construction), rcn_lmcs_compute_chroma_scale, lmcs_reshape_backward  -> K11
+ * struct LMCSLUTs is private to rcn_lmcs.c:75-81. */
+#include "rcn_lmcs.h"
+struct LMCSLUTs { OVSample fwd_lut[1024]; OVSample bwd_lut[1024]; OVSample wnd_bnd[17]; };
+#define LM_W 256
+#define LM_H 128
+
+static void
+gen_lmcs(const char *dir)
+{
+    gbuf b_data = { .type = T_U8 }, b_luts = { .type = T_U8 }, b_reg = { .type = T_I32 }, b_inv = { .type = T_U16 };
+    g_seed = 0x266 + 111;
+    OVCTUDec *c = ref_new_ctudec(0, 1);
+    const struct OVBuffInfo *cb = &c->rcn_ctx.ctu_buff;
+    uint16_t *pic = malloc(LM_W * LM_H * 2);
+    fill_plane(pic, LM_W, LM_H, LM_W);
+    int n_sets = 0;
+
+    for (int set = 0; set < 24; ++set) {
+        struct OVLMCSData ld;
+        memset(&ld, 0, sizeof(ld));
+        ld.lmcs_min_bin_idx = rnd_range(0, 4);
+        ld.lmcs_delta_max_bin_idx = rnd_range(0, 4);
+        int amp = set % 4 == 0 ? 0 : (set % 4 == 1 ? 8 : (set % 4 == 2 ? 30 : 60));
+        for (int i = 0; i < 16; ++i) {
+            ld.lmcs_delta_abs_cw[i] = rnd_range(0, amp);
+            ld.lmcs_delta_sign_cw_flag[i] = rnd_range(0, 1);
+        }
+        if (set % 6 == 5) { ld.lmcs_delta_abs_cw[7] = 64; ld.lmcs_delta_sign_cw_flag[7] = 1; }   /* an empty window */
+        ld.lmcs_delta_abs_crs = rnd_range(0, 7);
+        ld.lmcs_delta_sign_crs_flag = rnd_range(0, 1);
+
+        struct LMCSInfo *li = &c->lmcs_info;
+        if (!li->luts) li->luts = calloc(1, sizeof(struct LMCSLUTs));   /* keeps rcn_init_lmcs off ov_malloc (ovmem.c is not built) */
+        c->rcn_funcs.rcn_init_lmcs(li, &ld);
+
+        ovhip_lmcs_data hd;
+        memset(&hd, 0, sizeof(hd));
+        hd.min_bin_idx = ld.lmcs_min_bin_idx; hd.delta_max_bin_idx = ld.lmcs_delta_max_bin_idx;
+        hd.crs_offset = ld.lmcs_delta_sign_crs_flag ? -ld.lmcs_delta_abs_crs : ld.lmcs_delta_abs_crs;
+        for (int i = 0; i < 16; ++i) hd.cw_delta[i] = ld.lmcs_delta_sign_cw_flag[i] ? -ld.lmcs_delta_abs_cw[i] : ld.lmcs_delta_abs_cw[i];
+        gbuf_push(&b_data, &hd, sizeof(hd));
+
+        ovhip_lmcs_luts hl;
+        memset(&hl, 0, sizeof(hl));
+        memcpy(hl.fwd_lut, li->luts->fwd_lut, 2048); memcpy(hl.bwd_lut, li->luts->bwd_lut, 2048);
+        memcpy(hl.wnd_bnd, li->luts->wnd_bnd, 34);
+        hl.min_idx = li->min_idx; hl.max_idx = li->max_idx; hl.crs_offset = li->lmcs_chroma_scaling_offset;
+        gbuf_push(&b_luts, &hl, sizeof(hl));
+
+        /* chroma scale of every 64x64 region of the 2-CTU picture under several availability patterns */
+        for (int ctb = 0; ctb < 2; ++ctb) {
+            /* CTU scratch = picture samples incl. the row above / column left of the CTU (zero outside the picture) */
+            for (int j = -1; j < 128; ++j)
+                for (int i = -1; i < 128; ++i) {
+                    int px = ctb * 128 + i, py = j;
+                    cb->y[j * cb->stride + i] = (px < 0 || py < 0) ? 0 : pic[py * LM_W + px];
+                }
+            for (int k = 0; k < 12; ++k) {
+                int x0 = (k & 1) * 64, y0 = ((k >> 1) & 1) * 64;
+                int n_abv = k < 4 ? 16 : rnd_range(0, 16), n_lft = k < 4 ? 16 : rnd_range(0, 16);
+                if (y0 == 0) n_abv = 0;
+                if (ctb == 0 && x0 == 0) n_lft = 0;
+                struct CTUBitField pf;
+                memset(&pf, 0, sizeof(pf));
+                uint64_t am = n_abv ? ((1ull << n_abv) - 1) : 0, lm = n_lft ? ((1ull << n_lft) - 1) : 0;
+                pf.hfield[y0 >> 2] = am << ((x0 >> 2) + 1);
+                pf.vfield[x0 >> 2] = lm << ((y0 >> 2) + 1);
+                li->lmcs_chroma_scale = 0;
+                c->rcn_funcs.rcn_lmcs_compute_chroma_scale(li, cb->stride, &pf, cb->y, x0, y0);
+                int32_t rec[6] = { set, ctb * 128 + x0, y0, (int32_t)am, (int32_t)lm, li->lmcs_chroma_scale };
+                gbuf_push(&b_reg, rec, 6);
+            }
+        }
+        /* inverse mapping of the whole picture, CTU by CTU (every 6th table set keeps the fixture small) */
+        for (int ctb = 0; ctb < 2 && set % 6 == 1; ++ctb) {
+            uint16_t *blk = malloc(128 * 128 * 2);
+            for (int j = 0; j < 128; ++j) memcpy(blk + j * 128, pic + j * LM_W + ctb * 128, 256);
+            c->rcn_funcs.lmcs_reshape_backward(blk, 128, li->luts, 128, 128);
+            gbuf_push(&b_inv, blk, 128 * 128);
+            free(blk);
+        }
+        n_sets++;
+    }
+
+    gfile g = gfile_open(dir, "lmcs.ovg");
+    uint32_t d2[2] = { LM_H, LM_W };
+    gfile_array(&g, "pic_y", T_U16, pic, 2, d2);
+    d2[0] = n_sets; d2[1] = sizeof(ovhip_lmcs_data);  gfile_array(&g, "data", T_U8, b_data.data, 2, d2);
+    d2[1] = sizeof(ovhip_lmcs_luts);                   gfile_array(&g, "luts", T_U8, b_luts.data, 2, d2);
+    d2[0] = (uint32_t)(b_reg.n / 6); d2[1] = 6;        gfile_array(&g, "regions", T_I32, b_reg.data, 2, d2);
+    uint32_t d4[4] = { (uint32_t)(b_inv.n / (2 * 128 * 128)), 2, 128, 128 };          gfile_array(&g, "inverse", T_U16, b_inv.data, 4, d4);
+    gfile_close(&g);
+    fprintf(stderr, "lmcs.ovg: %d table sets, %zu chroma-scale regions\n", n_sets, b_reg.n / 6);
+}
+
 /* ====================================================================================== DBF */
 #include "dbf_utils.h"
 #include "drv_lines.h"
@@ -1037,6 +1134,7 @@ main(int argc, char **argv)
     if (!only || !strcmp(only, "mc"))  gen_mc(dir);
     if (!only || !strcmp(only, "mcx")) gen_mcx(dir);
     if (!only || !strcmp(only, "mca")) gen_mca(dir);
+    if (!only || !strcmp(only, "lmcs")) gen_lmcs(dir);
     if (!only || !strcmp(only, "dbf")) gen_dbf(dir);
     if (!only || !strcmp(only, "sao")) gen_sao(dir);
     if (!only || !strcmp(only, "alf")) gen_alf(dir);

@@ -77,6 +77,14 @@ def mca_cases():
     return refs, cases, g["exp_off"], g["exp"]
 
 
+def lmcs_cases():
+    """(luma picture, [(LmcsData, LmcsLuts expected)], regions int32 [n,6] = (set, x, y, abv_mask, lft_mask, scale), inverse [k,2,128,128])."""
+    g = golden_io.load("lmcs.ovg")
+    sets = [(capi.LmcsData.from_buffer_copy(g["data"][i].tobytes()), capi.LmcsLuts.from_buffer_copy(g["luts"][i].tobytes()))
+            for i in range(g["data"].shape[0])]
+    return g["pic_y"], sets, g["regions"], g["inverse"]
+
+
 def check_rects(pic: HostPic, rects, exp, what=""):
     planes = pic.planes()
     bad = []

@@ -32,6 +32,12 @@ def lib():
         _lib.oracle_mc.restype = None
         _lib.oracle_mc_ex.argtypes = [C.POINTER(OPic), C.POINTER(OPic), C.c_uint32, vp, C.c_uint32, vp, vp]
         _lib.oracle_mc_ex.restype = None
+        _lib.oracle_itx_ex.argtypes = [C.POINTER(OPic), vp, C.c_uint32, vp, vp]
+        _lib.oracle_itx_ex.restype = None
+        _lib.oracle_lmcs_scale.argtypes = [C.POINTER(OPic), vp, C.c_uint32, vp, vp]
+        _lib.oracle_lmcs_scale.restype = None
+        _lib.oracle_lmcs_inverse.argtypes = [C.POINTER(OPic), vp]
+        _lib.oracle_lmcs_inverse.restype = None
         _lib.oracle_mca.argtypes = [C.POINTER(OPic), C.POINTER(OPic), C.c_uint32, vp, C.c_uint32, vp, vp]
         _lib.oracle_mca.restype = None
         _lib.oracle_dbf.argtypes = [C.POINTER(OPic), vp]
@@ -68,6 +74,29 @@ def itx(pic: HostPic, cmds: np.ndarray, coefs: np.ndarray):
     cmds = np.ascontiguousarray(cmds)
     coefs = np.ascontiguousarray(coefs, dtype=np.int16)
     lib().oracle_itx(C.byref(s), cmds.ctypes.data, len(cmds), coefs.ctypes.data)
+
+
+def itx_ex(pic: HostPic, cmds: np.ndarray, coefs: np.ndarray, lmcs_scales: np.ndarray):
+    s = pic.struct()
+    cmds = np.ascontiguousarray(cmds)
+    coefs = np.ascontiguousarray(coefs, dtype=np.int16)
+    lmcs_scales = np.ascontiguousarray(lmcs_scales, dtype=np.int16)
+    lib().oracle_itx_ex(C.byref(s), cmds.ctypes.data, len(cmds), coefs.ctypes.data, lmcs_scales.ctypes.data)
+
+
+def lmcs_scale(pic: HostPic, regions: np.ndarray, luts) -> np.ndarray:
+    """regions: capi.LMCS_REGION_DTYPE array; luts: capi.LmcsLuts.  Returns int16 scales."""
+    s = pic.struct()
+    regions = np.ascontiguousarray(regions)
+    out = np.zeros(len(regions), np.int16)
+    lib().oracle_lmcs_scale(C.byref(s), regions.ctypes.data, len(regions), C.addressof(luts), out.ctypes.data)
+    return out
+
+
+def lmcs_inverse(pic: HostPic, bwd_lut: np.ndarray):
+    s = pic.struct()
+    bwd_lut = np.ascontiguousarray(bwd_lut, dtype=np.uint16)
+    lib().oracle_lmcs_inverse(C.byref(s), bwd_lut.ctypes.data)
 
 
 def mc(dst: HostPic, refs, units: np.ndarray, lmcs_fwd=None):

@@ -109,6 +109,34 @@ def test_mca_gpu_matches_reference(ctx):
     golden_cases.check_rects(HostPic(rw, rh * n, y, cb, cr), rects, exp, "mca HIP vs reference")
 
 
+def test_lmcs_gpu_matches_reference(ctx):
+    """K11: device chroma-scale derivation vs rcn_lmcs_compute_chroma_scale, device inverse map vs lmcs_reshape_backward."""
+    pic_y, sets, regions, inverse = golden_cases.lmcs_cases()
+    h, w = pic_y.shape
+    zc = np.zeros((h // 2, w // 2), np.uint16)
+    rec = capi.Recorder(w, h)
+    n_inv = 0
+    for si, (data, want) in enumerate(sets):
+        luts = capi.lmcs_build(data)
+        rows = regions[regions[:, 0] == si]
+        rec.reset()
+        for r in rows:
+            rec.lmcs_region(int(r[1]), int(r[2]), int(r[3]), int(r[4]))
+        d = ctx.upload_pic(pic_y, zc, zc)
+        scales = ctx.alloc(2 * len(rows))
+        ctx.lmcs_scale(d, ctx.upload(rec.lmcs_regions()), luts, scales)
+        got = scales.download(np.int16)
+        assert np.array_equal(got, rows[:, 5].astype(np.int16)), f"chroma scales of set {si}: {got.tolist()} vs {rows[:, 5].tolist()}"
+        if si % 6 == 1:
+            ctx.lmcs_inverse(d, ctx.upload(np.frombuffer(bytes(luts), np.uint16)[1024:2048].copy()))
+            ctx.sync()
+            y, _, _ = d.download()
+            exp = np.concatenate([inverse[n_inv, 0], inverse[n_inv, 1]], axis=1)
+            assert np.array_equal(y, exp), f"inverse map of set {si} differs"
+            n_inv += 1
+    assert n_inv == len(inverse)
+
+
 def test_dbf_gpu_matches_reference(ctx):
     for i, (pic, planes, exp) in enumerate(golden_cases.dbf_cases()):
         d = ctx.upload_pic(pic.y, pic.cb, pic.cr)

@@ -82,6 +82,31 @@ def test_mca_oracle_matches_reference(built_lib):
     assert n_prof > 100
 
 
+def test_lmcs_host_tables_and_oracle_match_reference(built_lib):
+    """K11: ovhip_lmcs_build (host) == rcn_init_lmcs; oracle chroma scale == rcn_lmcs_compute_chroma_scale;
+    oracle inverse map == lmcs_reshape_backward."""
+    pic_y, sets, regions, inverse = golden_cases.lmcs_cases()
+    h, w = pic_y.shape
+    rec = capi.Recorder(w, h)
+    n_inv = 0
+    for si, (data, want) in enumerate(sets):
+        got = capi.lmcs_build(data)
+        assert bytes(got) == bytes(want), f"LMCS tables of set {si} differ"
+        rows = regions[regions[:, 0] == si]
+        rec.reset()
+        for r in rows:
+            rec.lmcs_region(int(r[1]), int(r[2]), int(r[3]), int(r[4]))
+        pic = HostPic(w, h, pic_y.copy())
+        scales = oracle_lib.lmcs_scale(pic, rec.lmcs_regions(), got)
+        assert np.array_equal(scales, rows[:, 5].astype(np.int16)), f"chroma scales of set {si}: {scales.tolist()} vs {rows[:, 5].tolist()}"
+        if si % 6 == 1:
+            oracle_lib.lmcs_inverse(pic, np.frombuffer(bytes(got), np.uint16)[1024:2048])
+            exp = np.concatenate([inverse[n_inv, 0], inverse[n_inv, 1]], axis=1)
+            assert np.array_equal(pic.y, exp), f"inverse map of set {si} differs"
+            n_inv += 1
+    assert n_inv == len(inverse) and len(np.unique(regions[:, 5])) > 10
+
+
 def test_dbf_oracle_matches_reference(built_lib):
     cases = golden_cases.dbf_cases()
     assert len(cases) == 2
