@@ -121,6 +121,11 @@ enum {                        /* ovhip_mc_unit.flags */
     /* "refined" units: only accepted by ovhip_mcx_launch(); dir == 3, plain average, w,h in {8,16}     */
     OVHIP_MC_BDOF      = 32,  /* luma through bi-directional optical flow: rcn_bdof_mcp_l
                                * (rcn_inter.c:1136-1250; rcn_prof_bdof.c:303-490)                  */
+    OVHIP_MC_GPM       = 128, /* geometric partitioning (rcn_gpm_b, rcn_inter.c:3118-3143): dir == 3, ref0/mv0 and
+                               * ref1/mv1 are the two uni-predictions, blended with the per-sample weight
+                               * w = clip3(0, 8, (K + A*x + B*y) >> 3): (p0*w + p1*(8-w) + 64) >> 7,
+                               * put_weighted_gpm_bi_pixels (rcn_mc.c:1630-1655); aux = (K & 0xffff) | (A & 0xff) << 16 | (B & 0xff) << 24,
+                               * x, y relative to the unit (chroma samples use 2x, 2y)             */
     OVHIP_MC_DMVR      = 64   /* decoder-side MV refinement first: rcn_dmvr_mv_refine
                                * (rcn_inter.c:872-1126).  mv0/mv1 are then NOT clipped (the device
                                * applies clip_mv for the window anchor only, as the reference does);
@@ -136,7 +141,7 @@ typedef struct ovhip_mc_unit {
     int8_t   w0, w1;          /* bi weights (4,4 = plain average path; else BCW, w0+w1 == 8)     */
     int32_t  mv0x, mv0y;      /* 1/16 luma pel, ALREADY clipped (chroma uses the same at 1/32)   */
     int32_t  mv1x, mv1y;
-    uint32_t aux;             /* reserved (PROF / GPM side data index)                           */
+    uint32_t aux;             /* OVHIP_MC_GPM: packed weight plane (see the flag); else 0        */
 } ovhip_mc_unit;
 
 /* ------------------------------------------------------------------------------------
@@ -174,6 +179,20 @@ typedef struct ovhip_aff_unit {
     uint32_t prof_off;        /* int32 index of the CU's PROFInfo in the side arena              */
     uint32_t pad[2];
 } ovhip_aff_unit;
+
+/* ------------------------------------------------------------------------------------
+ * CIIP blend unit: dst = (intra * wt + inter * (4 - wt) + 2) >> 2 over one CU, luma and chroma
+ * (put_weighted_ciip_pixels rcn_mc.c:1611-1628 driven by rcn_ciip_weighted_sum rcn_inter.c:2968-3009).
+ * The inter prediction is what the MC launch left in `dst` (rcn_ciip / rcn_ciip_b record the PU
+ * as usual); the intra (planar) prediction comes from the caller's intra path in a second picture.
+ * 8 bytes.
+ * ---------------------------------------------------------------------------------- */
+typedef struct ovhip_ciip_unit {
+    uint16_t x, y;            /* luma position in the picture                                    */
+    uint8_t  log2_w, log2_h;  /* CU size                                                         */
+    uint8_t  wt;              /* 1 + (above CU intra) + (left CU intra)                           */
+    uint8_t  chroma_inter;    /* log2_w <= 2: chroma keeps the inter prediction (rcn_inter.c:2998)*/
+} ovhip_ciip_unit;
 
 /* ------------------------------------------------------------------------------------
  * LMCS (luma mapping with chroma scaling), rcn_lmcs.c.
@@ -366,7 +385,8 @@ typedef struct ovhip_pu_desc {
     int32_t  mv0x, mv0y, mv1x, mv1y;
     int32_t  poc0, poc1;      /* rpl0[ref_idx0]->poc, rpl1[ref_idx1]->poc (identical-motion test) */
     uint8_t  ref0, ref1;      /* slots of those pictures in the launch's reference table          */
-    uint8_t  pad2[2];
+    uint8_t  gpm_split_dir;   /* OVHIP_PU_GPM: gpm_ctx->split_dir (merge_gpm_partition_idx), 0..63  */
+    uint8_t  pad2;
 } ovhip_pu_desc;
 
 /* One affine CU as rcn_affine_mcp_b_l / rcn_affine_prof_mcp_b_l / rcn_affine_mcp_b_c receive it
@@ -388,6 +408,7 @@ typedef struct ovhip_affine_desc {
 
 #define OVHIP_PU_BDOF 1
 #define OVHIP_PU_DMVR 2
+#define OVHIP_PU_GPM  4       /* rcn_gpm_b: mv0/ref0 and mv1/ref1 are gpm_ctx->mv0 / mv1 and their pictures */
 
 ovhip_recorder *ovhip_rec_create(int32_t pic_w, int32_t pic_h);
 void  ovhip_rec_destroy(ovhip_recorder *rec);
@@ -396,6 +417,10 @@ void  ovhip_rec_reset(ovhip_recorder *rec);
 int   ovhip_rec_tu(ovhip_recorder *rec, const ovhip_tu_state *st, const ovhip_tu_desc *tu);
 int   ovhip_rec_pu(ovhip_recorder *rec, const ovhip_pu_desc *pu);
 int   ovhip_rec_affine_cu(ovhip_recorder *rec, const ovhip_affine_desc *cu);
+/* rcn_ciip_weighted_sum: mode_abv / mode_lft = part_map.cu_mode_x[x_right >> log2_min_cb] /
+ * cu_mode_y[y_bottom >> log2_min_cb] as enum CUMode (cu_utils.h:132-139). */
+int   ovhip_rec_ciip(ovhip_recorder *rec, int32_t x0, int32_t y0, int32_t log2_w, int32_t log2_h,
+                     int32_t mode_abv, int32_t mode_lft);
 /* rcn_lmcs_compute_chroma_scale(lmcs_info, stride, progress_field, ctu_buff.y, x0, y0): abv_mask / lft_mask are
  * the two 16-bit availability masks it derives from progress_field (rcn_lmcs.c:327-332).  Returns the
  * region index; TUs recorded afterwards with lmcs_scale_c == 2 refer to it. */
@@ -415,6 +440,7 @@ const ovhip_mc_unit *ovhip_rec_mc_units(const ovhip_recorder *rec, size_t *n);
 /* The refined (OVHIP_MC_BDOF / OVHIP_MC_DMVR) units, kept apart so that each list is one launch. */
 const ovhip_mc_unit *ovhip_rec_mcx_units(const ovhip_recorder *rec, size_t *n);
 const ovhip_aff_unit *ovhip_rec_aff_units(const ovhip_recorder *rec, size_t *n);
+const ovhip_ciip_unit *ovhip_rec_ciip_units(const ovhip_recorder *rec, size_t *n);
 const int32_t        *ovhip_rec_aff_side(const ovhip_recorder *rec, size_t *n_int32);
 
 /* ------------------------------------------------------------------------------------
@@ -459,6 +485,9 @@ int  ovhip_mc_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *refs
 int  ovhip_mcx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs,
                       const ovhip_mc_unit *d_units, uint32_t n_units, const uint16_t *d_lmcs_fwd_lut,
                       int32_t *d_mv_out);
+/* CIIP: blends the intra prediction held in `intra` into `dst` (which holds the inter prediction). */
+int  ovhip_ciip_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *intra,
+                       const ovhip_ciip_unit *d_units, uint32_t n_units);
 /* Affine units; d_side: the DEVICE copy of ovhip_rec_aff_side(). */
 int  ovhip_mca_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs,
                       const ovhip_aff_unit *d_units, uint32_t n_units, const int32_t *d_side,

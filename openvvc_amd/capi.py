@@ -23,7 +23,8 @@ TB_TR, TB_DC, TB_TS, TB_TS_RAW = 0, 1, 2, 3
 TB_FLAG_RASTER = 0x80
 RES_ADD, RES_SUB, RES_ADD_HALF, RES_SUB_HALF, RES_SCALE = 0, 1, 2, 3, 4
 MC_HPEL_FILT, MC_FILT_4x4, MC_NO_LUMA, MC_NO_CHROMA, MC_LMCS, MC_BDOF, MC_DMVR = 1, 2, 4, 8, 16, 32, 64
-PU_BDOF, PU_DMVR = 1, 2
+PU_BDOF, PU_DMVR, PU_GPM = 1, 2, 4
+MC_GPM = 128
 
 
 class Pic(C.Structure):
@@ -71,7 +72,7 @@ class PuDesc(C.Structure):
                 ("bcw_idx_plus1", C.c_uint8), ("prec_amvr_half", C.c_uint8), ("planes", C.c_uint8),
                 ("lmcs", C.c_uint8), ("refine", C.c_uint8), ("mv0x", C.c_int32), ("mv0y", C.c_int32),
                 ("mv1x", C.c_int32), ("mv1y", C.c_int32), ("poc0", C.c_int32), ("poc1", C.c_int32),
-                ("ref0", C.c_uint8), ("ref1", C.c_uint8), ("pad2", C.c_uint8 * 2)]
+                ("ref0", C.c_uint8), ("ref1", C.c_uint8), ("gpm_split_dir", C.c_uint8), ("pad2", C.c_uint8)]
 
 
 class AffineDesc(C.Structure):
@@ -91,6 +92,8 @@ class LmcsLuts(C.Structure):
                 ("min_idx", C.c_uint8), ("max_idx", C.c_uint8), ("crs_offset", C.c_int16), ("pad", C.c_uint16)]
 
 
+CIIP_UNIT_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("log2_w", "u1"), ("log2_h", "u1"), ("wt", "u1"), ("chroma_inter", "u1")])
+assert CIIP_UNIT_DTYPE.itemsize == 8
 LMCS_REGION_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("n_abv", "u1"), ("n_lft", "u1"), ("pad", "u1", 2)])
 assert LMCS_REGION_DTYPE.itemsize == 8
 
@@ -192,6 +195,9 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_rec_mcx_units": (vp, [vp, P(C.c_size_t)]),
         "ovhip_rec_affine_cu": (C.c_int, [vp, P(AffineDesc)]),
         "ovhip_rec_lmcs_region": (C.c_int, [vp, C.c_int32, C.c_int32, u32, u32]),
+        "ovhip_rec_ciip": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+        "ovhip_rec_ciip_units": (vp, [vp, P(C.c_size_t)]),
+        "ovhip_ciip_launch": (C.c_int, [vp, P(Pic), P(Pic), vp, u32]),
         "ovhip_rec_lmcs_regions": (vp, [vp, P(C.c_size_t)]),
         "ovhip_rec_tb_cmds_split": (vp, [vp, P(C.c_size_t), P(C.c_size_t)]),
         "ovhip_lmcs_build": (C.c_int, [P(LmcsData), P(LmcsLuts)]),
@@ -229,7 +235,7 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
 
 EXPORTED_SYMBOLS = [
     "ovhip_abi_version", "ovhip_rec_create", "ovhip_rec_destroy", "ovhip_rec_reset", "ovhip_rec_tu",
-    "ovhip_rec_pu", "ovhip_rec_dbf_ctu", "ovhip_rec_dbf_planes", "ovhip_dbf_launch", "ovhip_sao_launch", "ovhip_alf_launch", "ovhip_rec_tb_cmds", "ovhip_rec_coefs", "ovhip_rec_mc_units", "ovhip_rec_mcx_units", "ovhip_mcx_launch", "ovhip_rec_affine_cu", "ovhip_rec_lmcs_region", "ovhip_rec_lmcs_regions", "ovhip_rec_tb_cmds_split", "ovhip_lmcs_build", "ovhip_lmcs_scale_launch", "ovhip_lmcs_inverse_launch", "ovhip_rec_aff_units", "ovhip_rec_aff_side", "ovhip_mca_launch", "ovhip_ctx_create",
+    "ovhip_rec_pu", "ovhip_rec_dbf_ctu", "ovhip_rec_dbf_planes", "ovhip_dbf_launch", "ovhip_sao_launch", "ovhip_alf_launch", "ovhip_rec_tb_cmds", "ovhip_rec_coefs", "ovhip_rec_mc_units", "ovhip_rec_mcx_units", "ovhip_mcx_launch", "ovhip_rec_affine_cu", "ovhip_rec_lmcs_region", "ovhip_rec_ciip", "ovhip_rec_ciip_units", "ovhip_ciip_launch", "ovhip_rec_lmcs_regions", "ovhip_rec_tb_cmds_split", "ovhip_lmcs_build", "ovhip_lmcs_scale_launch", "ovhip_lmcs_inverse_launch", "ovhip_rec_aff_units", "ovhip_rec_aff_side", "ovhip_mca_launch", "ovhip_ctx_create",
     "ovhip_ctx_destroy", "ovhip_ctx_sync", "ovhip_last_error", "ovhip_ctx_stream", "ovhip_malloc",
     "ovhip_free", "ovhip_h2d", "ovhip_d2h", "ovhip_pic_alloc", "ovhip_pic_free", "ovhip_pic_upload",
     "ovhip_pic_download", "ovhip_itx_launch", "ovhip_mc_launch",
@@ -326,6 +332,15 @@ class Recorder:
         if r < 0:
             raise ValueError(f"ovhip_rec_lmcs_region -> {r}")
         return r
+
+    def ciip(self, x0: int, y0: int, log2_w: int, log2_h: int, mode_abv: int, mode_lft: int) -> int:
+        r = self.lib.ovhip_rec_ciip(self.h, x0, y0, log2_w, log2_h, mode_abv, mode_lft)
+        if r < 0:
+            raise ValueError(f"ovhip_rec_ciip -> {r}")
+        return r
+
+    def ciip_units(self) -> np.ndarray:
+        return self._arr(self.lib.ovhip_rec_ciip_units, CIIP_UNIT_DTYPE)
 
     def lmcs_regions(self) -> np.ndarray:
         return self._arr(self.lib.ovhip_rec_lmcs_regions, LMCS_REGION_DTYPE)

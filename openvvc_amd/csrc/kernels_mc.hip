@@ -20,6 +20,14 @@
 
 namespace {
 
+// geometric partitioning: w = clip3(0, 8, (K + A*x + B*y) >> 3), put_weighted_gpm_bi_pixels (rcn_mc.c:1630-1655)
+__device__ __forceinline__ int mc_gpm(uint32_t aux, int x, int y, int p0, int p1)
+{
+    const int k = (int16_t)(aux & 0xffff), a = (int8_t)((aux >> 16) & 0xff), b = (int8_t)(aux >> 24);
+    const int wgt = ov_clip3((k + a * x + b * y) >> 3, 0, 8);
+    return ov_clip_bd((p1 * (8 - wgt) + p0 * wgt + 64) >> 7);
+}
+
 __device__ __forceinline__ int mc_combine(const ovhip_mc_unit &u, int p0, int p1)
 {
     if (u.dir != 3)                  return ov_clip_bd(((u.dir == 1 ? p0 : p1) + 8) >> 4);
@@ -107,7 +115,7 @@ __global__ __launch_bounds__(64) void k_mc(ovhip_pic dst, RefTable refs, const o
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (4 * g + j < h) {
-                    int v = mc_combine(u, P[0][j], P[1][j]);
+                    int v = (u.flags & OVHIP_MC_GPM) ? mc_gpm(u.aux, x, 4 * g + j, P[0][j], P[1][j]) : mc_combine(u, P[0][j], P[1][j]);
                     if ((u.flags & OVHIP_MC_LMCS) && lmcs_fwd) v = lmcs_fwd[v];
                     d[j * dst.stride_y] = (uint16_t)v;
                 }
@@ -125,7 +133,9 @@ __global__ __launch_bounds__(64) void k_mc(ovhip_pic dst, RefTable refs, const o
                 uint16_t *d = (comp ? dst.cr : dst.cb) + ((u.y >> 1) + 4 * g) * dst.stride_c + (u.x >> 1) + x;
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (4 * g + j < hc) d[j * dst.stride_c] = (uint16_t)mc_combine(u, P[0][j], P[1][j]);
+                    if (4 * g + j < hc)
+                        d[j * dst.stride_c] = (uint16_t)((u.flags & OVHIP_MC_GPM) ? mc_gpm(u.aux, 2 * x, 2 * (4 * g + j), P[0][j], P[1][j])
+                                                                                  : mc_combine(u, P[0][j], P[1][j]));
             }
         }
     }
@@ -133,7 +143,40 @@ __global__ __launch_bounds__(64) void k_mc(ovhip_pic dst, RefTable refs, const o
     }
 }
 
+// ---- K10: CIIP blend.  One 256-thread workgroup per CU: dst = (intra * wt + inter * (4 - wt) + 2) >> 2
+// (put_weighted_ciip_pixels rcn_mc.c:1611-1628, rcn_ciip_weighted_sum rcn_inter.c:2968-3009). ----
+__global__ __launch_bounds__(256) void k_ciip(ovhip_pic dst, ovhip_pic intra, const ovhip_ciip_unit *__restrict__ units, uint32_t n)
+{
+    for (uint32_t bid = blockIdx.x; bid < n; bid += gridDim.x) {
+        const ovhip_ciip_unit u = units[bid];
+#pragma unroll
+        for (int plane = 0; plane < 3; ++plane) {
+            const int c = plane != 0;
+            if (c && u.chroma_inter) continue;
+            const int lw = u.log2_w - c, w = 1 << lw, npix = w << (u.log2_h - c);
+            int ds, is;
+            uint16_t *d = ov_plane(dst, plane, ds) + (u.y >> c) * ds + (u.x >> c);
+            const uint16_t *s = ov_plane(intra, plane, is) + (u.y >> c) * is + (u.x >> c);
+            for (int t = threadIdx.x; t < npix; t += 256) {
+                const int x = t & (w - 1), y = t >> lw;
+                d[y * ds + x] = (uint16_t)ov_clip_bd((s[y * is + x] * u.wt + d[y * ds + x] * (4 - u.wt) + 2) >> 2);
+            }
+        }
+    }
+}
+
 } // namespace
+
+extern "C" int ovhip_ciip_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *intra,
+                                 const ovhip_ciip_unit *d_units, uint32_t n_units)
+{
+    if (!ctx || !dst || !intra) return OVHIP_EINVAL;
+    if (!n_units) return OVHIP_OK;
+    if (!d_units) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_ciip_launch: null units", hipSuccess);
+    hipLaunchKernelGGL(k_ciip, dim3(n_units), dim3(256), 0, ctx->stream, *dst, *intra, d_units, n_units);
+    OV_LAUNCH_CHECK(ctx, "k_ciip");
+    return OVHIP_OK;
+}
 
 extern "C" int ovhip_mc_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs,
                                const ovhip_mc_unit *d_units, uint32_t n_units, const uint16_t *d_lmcs_fwd_lut)

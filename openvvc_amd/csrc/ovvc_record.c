@@ -40,7 +40,7 @@ void
 ovhip_rec_destroy(ovhip_recorder *r)
 {
     if (!r) return;
-    free(r->tb); free(r->coef); free(r->mc); free(r->mcx); free(r->aff); free(r->aff_side); free(r->reg); free(r->tb_split);
+    free(r->tb); free(r->coef); free(r->mc); free(r->mcx); free(r->aff); free(r->aff_side); free(r->reg); free(r->tb_split); free(r->ciip);
     ovhip_rec_dbf_free_(r);
     free(r);
 }
@@ -48,7 +48,7 @@ ovhip_rec_destroy(ovhip_recorder *r)
 void
 ovhip_rec_reset(ovhip_recorder *r)
 {
-    r->n_tb = r->n_coef = r->n_mc = r->n_mcx = r->n_aff = r->n_side = r->n_reg = 0;
+    r->n_tb = r->n_coef = r->n_mc = r->n_mcx = r->n_aff = r->n_side = r->n_reg = r->n_ciip = 0;
     ovhip_rec_dbf_reset_(r);
 }
 
@@ -450,12 +450,67 @@ rec_pu_refined(ovhip_recorder *r, const ovhip_pu_desc *pu)
     return n;
 }
 
+/* rcn_gpm_b (rcn_inter.c:3118-3143) -> rcn_mc_rpr_b_l/_c with gpm_ctx: two uni-predictions of the whole CU
+ * (rcn_mcp_bidir0_l/_c: clip_mv against the CU) blended by put_weighted_gpm_bi_pixels with the weight plane
+ * of rcn_gpm_weights_and_steps.  The reference walks mirrored pre-stored masks (rcn_gpm.c:149-205); the plane
+ * is affine in the sample position, so the command carries it in closed form (H.266 8.5.7.2):
+ *   weightIdx = ((x + offX) * 2 + 1) * dis[angle] + ((y + offY) * 2 + 1) * dis[angle + 8]
+ *   w = clip3(0, 8, ((partFlip ? 32 + weightIdx : 32 - weightIdx) + 4) >> 3) */
+#include "vvc_gpm_tables.h"
+static int
+rec_pu_gpm(ovhip_recorder *r, const ovhip_pu_desc *pu)
+{
+    const int pw = 1 << pu->log2_w, ph = 1 << pu->log2_h;
+    if (pu->gpm_split_dir > 63 || pu->log2_w < 3 || pu->log2_h < 3 || pu->log2_w > 6 || pu->log2_h > 6) return OVHIP_EINVAL;
+
+    const int angle = ovt_gpm_params[pu->gpm_split_dir][0], dist = ovt_gpm_params[pu->gpm_split_dir][1];
+    const int dx = ovt_gpm_dis[angle], dy = ovt_gpm_dis[(angle + 8) & 31];
+    const int flip = (angle >= 13 && angle <= 27) ? 0 : 1;
+    const int shift_hor = (angle % 16 == 8 || (angle % 16 != 0 && ph >= pw)) ? 0 : 1;
+    int off_x = -(pw >> 1), off_y = -(ph >> 1);
+    if (dist > 0) {
+        if (!shift_hor) off_y += angle < 16 ? (dist * ph) >> 3 : -((dist * ph) >> 3);
+        else            off_x += angle < 16 ? (dist * pw) >> 3 : -((dist * pw) >> 3);
+    }
+    const int sgn = flip ? 1 : -1;
+    const int A = sgn * 2 * dx, B = sgn * 2 * dy;
+    const int K = 36 + sgn * ((2 * off_x + 1) * dx + (2 * off_y + 1) * dy);
+
+    int32_t mv0x = pu->mv0x, mv0y = pu->mv0y, mv1x = pu->mv1x, mv1y = pu->mv1y;
+    clip_mv(r, pu->x0, pu->y0, pw, ph, &mv0x, &mv0y);
+    clip_mv(r, pu->x0, pu->y0, pw, ph, &mv1x, &mv1y);
+
+    uint8_t flags = OVHIP_MC_GPM;
+    if (pu->prec_amvr_half) flags |= OVHIP_MC_HPEL_FILT;
+    if (pu->lmcs)           flags |= OVHIP_MC_LMCS;
+    const int uw = pw > 16 ? 16 : pw, uh = ph > 16 ? 16 : ph;
+    int n = 0;
+    for (int uy = 0; uy < ph; uy += uh) {
+        for (int ux = 0; ux < pw; ux += uw) {
+            if (grow((void **)&r->mc, &r->cap_mc, r->n_mc + 1, sizeof(ovhip_mc_unit))) return OVHIP_ENOMEM;
+            ovhip_mc_unit *u = &r->mc[r->n_mc++];
+            memset(u, 0, sizeof(*u));
+            u->x = (uint16_t)(pu->x0 + ux); u->y = (uint16_t)(pu->y0 + uy);
+            u->w = (uint8_t)uw; u->h = (uint8_t)uh;
+            u->dir = 3; u->flags = flags;
+            u->ref0 = pu->ref0; u->ref1 = pu->ref1;
+            u->w0 = u->w1 = 4;
+            u->mv0x = mv0x; u->mv0y = mv0y; u->mv1x = mv1x; u->mv1y = mv1y;
+            const int k = K + A * ux + B * uy;
+            u->aux = ((uint32_t)k & 0xffff) | ((uint32_t)(A & 0xff) << 16) | ((uint32_t)(B & 0xff) << 24);
+            ++n;
+        }
+    }
+    return n;
+}
+
 int
 ovhip_rec_pu(ovhip_recorder *r, const ovhip_pu_desc *pu)
 {
     int pw = 1 << pu->log2_w, ph = 1 << pu->log2_h;
     int dir = pu->inter_dir & 3;
     if (!dir) return OVHIP_EINVAL;
+    if (pu->refine & OVHIP_PU_GPM) return rec_pu_gpm(r, pu);
     if (pu->refine) return rec_pu_refined(r, pu);
 
     /* rcn_mcp_b: bi with identical motion degenerates to uni-pred from list 1 */
@@ -616,3 +671,21 @@ ovhip_rec_tb_cmds_split(ovhip_recorder *r, size_t *n_luma, size_t *n)
     }
     return r->tb_split;
 }
+
+/* ---------------------------------------------------------------- CIIP blend (rcn_ciip_weighted_sum) */
+int
+ovhip_rec_ciip(ovhip_recorder *r, int32_t x0, int32_t y0, int32_t log2_w, int32_t log2_h, int32_t mode_abv, int32_t mode_lft)
+{
+    if (x0 < 0 || y0 < 0 || log2_w < 2 || log2_h < 2 || log2_w > 6 || log2_h > 6) return OVHIP_EINVAL;
+    if (grow((void **)&r->ciip, &r->cap_ciip, r->n_ciip + 1, sizeof(*r->ciip))) return OVHIP_ENOMEM;
+    ovhip_ciip_unit *u = &r->ciip[r->n_ciip++];
+    /* OV_INTRA = 2, OV_MIP = 4 (cu_utils.h:132-139) */
+    const int intra_abv = mode_abv == 2 || mode_abv == 4, intra_lft = mode_lft == 2 || mode_lft == 4;
+    u->x = (uint16_t)x0; u->y = (uint16_t)y0;
+    u->log2_w = (uint8_t)log2_w; u->log2_h = (uint8_t)log2_h;
+    u->wt = (uint8_t)(1 + intra_abv + intra_lft);
+    u->chroma_inter = log2_w <= 2;
+    return 1;
+}
+
+const ovhip_ciip_unit *ovhip_rec_ciip_units(const ovhip_recorder *r, size_t *n) { *n = r->n_ciip; return r->ciip; }

@@ -13,6 +13,7 @@ struct ovhip_recorder {
     ovhip_aff_unit *aff;  size_t n_aff,  cap_aff;   /* affine units */
     int32_t *aff_side;    size_t n_side, cap_side;
     ovhip_lmcs_region *reg; size_t n_reg, cap_reg;
+    ovhip_ciip_unit *ciip; size_t n_ciip, cap_ciip;
     ovhip_tb_cmd *tb_split; size_t cap_split;
     /* deblocking edge planes (ovvc_record_dbf.c) */
     uint16_t *dbf_luma_v, *dbf_luma_h, *dbf_cb_v, *dbf_cr_v, *dbf_cb_h, *dbf_cr_h;

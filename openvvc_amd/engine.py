@@ -100,6 +100,10 @@ class Context:
         self._chk(self.lib.ovhip_mc_launch(self.h, C.byref(dst.s), arr, len(refs), units.ptr, n,
                                            lmcs_fwd.ptr if lmcs_fwd else None), "mc_launch")
 
+    def ciip(self, dst: "DevPic", intra: "DevPic", units: "DevBuf", n: int | None = None):
+        n = units.count if n is None else n
+        self._chk(self.lib.ovhip_ciip_launch(self.h, C.byref(dst.s), C.byref(intra.s), units.ptr, n), "ciip_launch")
+
     def mca(self, dst: "DevPic", refs: list, units: "DevBuf", side: "DevBuf", lmcs_fwd: "DevBuf | None" = None,
             n: int | None = None):
         """Affine (+PROF) units; side: device copy of the recorder's affine side arena."""

@@ -331,6 +331,12 @@ static sampler plane_sampler(const oracle_pic *rp, int plane, int px, int py)
     return s;
 }
 
+static int gpm_weight(uint32_t aux, int x, int y)
+{
+    const int k = (int16_t)(aux & 0xffff), a = (int8_t)((aux >> 16) & 0xff), b = (int8_t)(aux >> 24);
+    return clip3i((k + a * x + b * y) >> 3, 0, 8);
+}
+
 static int bi_combine(const ovhip_mc_unit *u, int p0, int p1)
 {
     if (u->dir != 3) return clip_bd(((u->dir == 1 ? p0 : p1) + 8) >> 4);          /* uni: rcn_mc.c:448-533 */
@@ -365,6 +371,10 @@ static void mc_plane(const oracle_pic *dst, const oracle_pic *refs, const ovhip_
     for (int j = 0; j < h; ++j) {
         for (int i = 0; i < w; ++i) {
             int v = bi_combine(u, p[0][j * 16 + i], p[1][j * 16 + i]);
+            if (u->flags & OVHIP_MC_GPM) {                                        /* put_weighted_gpm_bi_pixels, rcn_mc.c:1630-1655 */
+                const int wgt = gpm_weight(u->aux, i << c, j << c);
+                v = clip_bd((p[1][j * 16 + i] * (8 - wgt) + p[0][j * 16 + i] * wgt + 64) >> 7);
+            }
             if (!c && (u->flags & OVHIP_MC_LMCS) && lmcs_fwd) v = lmcs_fwd[v & PIX_MAX]; /* rcn_lmcs.c:275-295 */
             d[j * dstride + i] = (uint16_t)v;
         }
@@ -677,6 +687,24 @@ void oracle_mca(const oracle_pic *dst, const oracle_pic *refs, uint32_t n_refs,
             m.mv0x = mvs[0]; m.mv0y = mvs[1]; m.mv1x = mvs[2]; m.mv1y = mvs[3];
             mc_plane(dst, refs, &m, 1, NULL);
             mc_plane(dst, refs, &m, 2, NULL);
+        }
+    }
+}
+
+/* ---- K10: CIIP blend (rcn_ciip_weighted_sum rcn_inter.c:2968-3009, put_weighted_ciip_pixels rcn_mc.c:1611-1628) ---- */
+void oracle_ciip(const oracle_pic *dst, const oracle_pic *intra, const ovhip_ciip_unit *units, uint32_t n)
+{
+    for (uint32_t k = 0; k < n; ++k) {
+        const ovhip_ciip_unit *u = &units[k];
+        for (int plane = 0; plane < 3; ++plane) {
+            const int c = plane != 0;
+            if (c && u->chroma_inter) continue;
+            int ds, is;
+            uint16_t *d = plane_ptr(dst, plane, &ds) + (u->y >> c) * ds + (u->x >> c);
+            const uint16_t *s = plane_ptr(intra, plane, &is) + (u->y >> c) * is + (u->x >> c);
+            for (int j = 0; j < (1 << u->log2_h) >> c; ++j)
+                for (int i = 0; i < (1 << u->log2_w) >> c; ++i)
+                    d[j * ds + i] = (uint16_t)clip_bd((s[j * is + i] * u->wt + d[j * ds + i] * (4 - u->wt) + 2) >> 2);
         }
     }
 }

@@ -720,6 +720,155 @@ gen_lmcs(const char *dir)
     fprintf(stderr, "lmcs.ovg: %d table sets, %zu chroma-scale regions\n", n_sets, b_reg.n / 6);
 }
 
+/* ====================================================================================== GPM / CIIP
+ * gpm.ovg : rcn_gpm_b (rcn_inter.c:3118-3143) for every merge_gpm_partition_idx, and rcn_ciip_b
+ *           (rcn_inter.c:3011-3037) with the intra slots replaced by a stub that delivers a known
+ *           "planar" prediction (intra prediction itself is outside the path)          -> K10 */
+extern void rcn_init_gpm_params(void);
+static uint16_t *g_ciip_intra[3];
+static OVCTUDec *g_ciip_c;
+static void stub_ciip_intra_l(const struct OVRCNCtx *const r, const struct OVBuffInfo *b, uint8_t m, int x0, int y0, int lw, int lh, CUFlags f)
+{
+    (void)r; (void)m; (void)f;
+    int px = (g_ciip_c->ctb_x << 7) + x0, py = (g_ciip_c->ctb_y << 7) + y0;
+    for (int j = 0; j < (1 << lh); ++j)
+        for (int i = 0; i < (1 << lw); ++i) b->y[(y0 + j) * b->stride + x0 + i] = g_ciip_intra[0][(py + j) * MC_W + px + i];
+}
+static void stub_ciip_intra_c(const struct OVRCNCtx *const r, uint8_t m, int x0, int y0, int lw, int lh, CUFlags f)
+{
+    (void)m; (void)f;
+    const struct OVBuffInfo *b = &r->ctu_buff;
+    int px = (g_ciip_c->ctb_x << 6) + x0, py = (g_ciip_c->ctb_y << 6) + y0;
+    for (int j = 0; j < (1 << lh); ++j)
+        for (int i = 0; i < (1 << lw); ++i) {
+            b->cb[(y0 + j) * b->stride_c + x0 + i] = g_ciip_intra[1][(py + j) * (MC_W / 2) + px + i];
+            b->cr[(y0 + j) * b->stride_c + x0 + i] = g_ciip_intra[2][(py + j) * (MC_W / 2) + px + i];
+        }
+}
+
+static void
+gen_gpm(const char *dir)
+{
+    gbuf b_desc = { .type = T_U8 }, b_eoff = { .type = T_U32 }, b_exp = { .type = T_U16 }, b_ciip = { .type = T_I32 };
+    uint32_t n_cases = 0, n_gpm = 0;
+    g_seed = 0x266 + 131;
+    rcn_init_gpm_params();
+
+    OVCTUDec *c = ref_new_ctudec(0, 0);
+    g_ciip_c = c;
+    struct InterDRVCtx *ic = &c->drv_ctx.inter_ctx;
+    OVPicture *ref[3];
+    for (int i = 0; i < 3; ++i) {
+        ref[i] = ref_new_picture(MC_W, MC_H, 8 * (i + 1));
+        for (int p = 0; p < 3; ++p) fill_plane(ref[i]->frame->data[p], MC_W >> !!p, MC_H >> !!p, MC_W >> !!p);
+    }
+    for (int p = 0; p < 3; ++p) {
+        g_ciip_intra[p] = malloc((MC_W >> !!p) * (MC_H >> !!p) * 2);
+        fill_plane(g_ciip_intra[p], MC_W >> !!p, MC_H >> !!p, MC_W >> !!p);
+    }
+    ic->rpl0[0] = ref[0]; ic->rpl0[1] = ref[1]; ic->rpl1[0] = ref[2]; ic->rpl1[1] = ref[0];
+    static const uint8_t slot[2][2] = { { 0, 1 }, { 2, 0 } };            /* [list][ref_idx] -> picture slot */
+    for (int i = 0; i < 16; ++i) {
+        ic->scale_fact_rpl0[i][0] = ic->scale_fact_rpl0[i][1] = 1 << RPR_SCALE_BITS;
+        ic->scale_fact_rpl1[i][0] = ic->scale_fact_rpl1[i][1] = 1 << RPR_SCALE_BITS;
+    }
+    c->rcn_funcs.intra_pred = stub_ciip_intra_l;
+    c->rcn_funcs.intra_pred_c = stub_ciip_intra_c;
+    c->part_map.cu_mode_x = calloc(64, 1);
+    const struct OVBuffInfo *cb = &c->rcn_ctx.ctu_buff;
+
+    for (int pass = 0; pass < 2; ++pass) {                                /* 0: GPM, 1: CIIP */
+        int n_iter = pass == 0 ? 64 * 3 : 150;
+        for (int it = 0; it < n_iter; ++it) {
+            ovhip_pu_desc d;
+            memset(&d, 0, sizeof(d));
+            int l2w, l2h;
+            if (pass == 0) { l2w = rnd_range(3, 6); l2h = rnd_range(3, 6); }
+            else { do { l2w = rnd_range(2, 6); l2h = rnd_range(2, 6); } while (l2w + l2h < 6); }
+            int w = 1 << l2w, h = 1 << l2h, px, py;
+            do {
+                px = rnd_range(0, (MC_W - w) / 4) * 4;
+                py = rnd_range(0, (MC_H - h) / 4) * 4;
+            } while ((px >> 7) != ((px + w - 1) >> 7) || (py >> 7) != ((py + h - 1) >> 7));
+            d.x0 = px; d.y0 = py; d.log2_w = l2w; d.log2_h = l2h;
+            int range = it % 9 == 0 ? 4000 : 400;
+            d.mv0x = rnd_range(-range, range); d.mv0y = rnd_range(-range, range);
+            d.mv1x = rnd_range(-range, range); d.mv1y = rnd_range(-range, range);
+            if (it % 7 == 3) { d.mv0x &= ~15; d.mv1y &= ~15; }
+            d.planes = 3;
+            d.ref_idx0 = rnd_range(0, 1); d.ref_idx1 = rnd_range(0, 1);
+            c->ctb_x = px >> 7; c->ctb_y = py >> 7;
+            int x0 = px & 127, y0 = py & 127;
+            for (int j = 0; j < 128; ++j) memset(cb->y + j * cb->stride, 0xAB, 256);
+            for (int j = 0; j < 64; ++j) { memset(cb->cb + j * cb->stride_c, 0xAB, 128); memset(cb->cr + j * cb->stride_c, 0xAB, 128); }
+            int32_t cargs[2] = { 0, 0 };
+
+            if (pass == 0) {
+                struct VVCGPM *g = &ic->gpm_ctx;
+                memset(g, 0, sizeof(*g));
+                g->split_dir = it % 64;
+                g->inter_dir0 = rnd_range(1, 2); g->inter_dir1 = rnd_range(1, 2);
+                g->mv0 = (OVMV){ .x = d.mv0x, .y = d.mv0y, .ref_idx = d.ref_idx0 };
+                g->mv1 = (OVMV){ .x = d.mv1x, .y = d.mv1y, .ref_idx = d.ref_idx1 };
+                d.inter_dir = 3; d.refine = OVHIP_PU_GPM; d.gpm_split_dir = (uint8_t)g->split_dir;
+                d.ref0 = slot[g->inter_dir0 - 1][d.ref_idx0]; d.ref1 = slot[g->inter_dir1 - 1][d.ref_idx1];
+                d.prec_amvr_half = it % 5 == 2;
+                ic->prec_amvr = d.prec_amvr_half ? MV_PRECISION_HALF : 0;
+                c->rcn_funcs.rcn_gpm_b(c, g, x0, y0, l2w, l2h);
+                n_gpm++;
+            } else {
+                d.inter_dir = rnd_range(1, 3);
+                d.bcw_idx_plus1 = 0;
+                d.poc0 = ic->rpl0[d.ref_idx0]->poc; d.poc1 = ic->rpl1[d.ref_idx1]->poc;
+                d.ref0 = slot[0][d.ref_idx0]; d.ref1 = slot[1][d.ref_idx1];
+                ic->prec_amvr = 0;
+                cargs[0] = (int32_t[]){ OV_INTER, OV_INTRA, OV_MIP, OV_INTER_SKIP }[rnd_range(0, 3)];
+                cargs[1] = (int32_t[]){ OV_INTER, OV_INTRA, OV_MIP, OV_INTER_SKIP }[rnd_range(0, 3)];
+                c->part_map.cu_mode_x[(x0 + w - 1) >> 2] = (uint8_t)cargs[0];
+                c->part_map.cu_mode_y[(y0 + h - 1) >> 2] = (uint8_t)cargs[1];
+                OVMV mv0 = { .x = d.mv0x, .y = d.mv0y, .ref_idx = d.ref_idx0 };
+                OVMV mv1 = { .x = d.mv1x, .y = d.mv1y, .ref_idx = d.ref_idx1 };
+                if (d.inter_dir == 1 && it % 2)
+                    c->rcn_funcs.rcn_ciip(c, x0, y0, l2w, l2h, mv0, d.ref_idx0);              /* P-slice entry point */
+                else
+                    c->rcn_funcs.rcn_ciip_b(c, mv0, mv1, x0, y0, l2w, l2h, d.inter_dir, d.ref_idx0, d.ref_idx1);
+            }
+            uint32_t eoff[3];
+            eoff[0] = (uint32_t)b_exp.n; dump_rect(&b_exp, cb->y, cb->stride, x0, y0, w, h);
+            eoff[1] = (uint32_t)b_exp.n; dump_rect(&b_exp, cb->cb, cb->stride_c, x0 >> 1, y0 >> 1, w >> 1, h >> 1);
+            eoff[2] = (uint32_t)b_exp.n; dump_rect(&b_exp, cb->cr, cb->stride_c, x0 >> 1, y0 >> 1, w >> 1, h >> 1);
+            gbuf_push(&b_desc, &d, sizeof(d));
+            gbuf_push(&b_eoff, eoff, 3);
+            gbuf_push(&b_ciip, cargs, 2);
+            n_cases++;
+        }
+    }
+
+    gfile g = gfile_open(dir, "gpm.ovg");
+    uint32_t d3[3] = { 3, MC_H, MC_W };
+    uint16_t *all = malloc(3 * MC_W * MC_H * 2);
+    for (int i = 0; i < 3; ++i) memcpy(all + i * MC_W * MC_H, ref[i]->frame->data[0], MC_W * MC_H * 2);
+    gfile_array(&g, "ref_y", T_U16, all, 3, d3);
+    d3[1] = MC_H / 2; d3[2] = MC_W / 2;
+    for (int i = 0; i < 3; ++i) memcpy(all + i * (MC_W / 2) * (MC_H / 2), ref[i]->frame->data[1], (MC_W / 2) * (MC_H / 2) * 2);
+    gfile_array(&g, "ref_cb", T_U16, all, 3, d3);
+    for (int i = 0; i < 3; ++i) memcpy(all + i * (MC_W / 2) * (MC_H / 2), ref[i]->frame->data[2], (MC_W / 2) * (MC_H / 2) * 2);
+    gfile_array(&g, "ref_cr", T_U16, all, 3, d3);
+    uint32_t di[2] = { MC_H, MC_W };
+    gfile_array(&g, "intra_y", T_U16, g_ciip_intra[0], 2, di);
+    di[0] = MC_H / 2; di[1] = MC_W / 2;
+    gfile_array(&g, "intra_cb", T_U16, g_ciip_intra[1], 2, di);
+    gfile_array(&g, "intra_cr", T_U16, g_ciip_intra[2], 2, di);
+    uint32_t d2[2] = { n_cases, sizeof(ovhip_pu_desc) };
+    gfile_array(&g, "desc", T_U8, b_desc.data, 2, d2);
+    d2[1] = 3; gfile_array(&g, "exp_off", T_U32, b_eoff.data, 2, d2);
+    d2[1] = 2; gfile_array(&g, "ciip_modes", T_I32, b_ciip.data, 2, d2);
+    uint32_t one = n_gpm; gfile_array(&g, "n_gpm", T_U32, &one, 1, (uint32_t[]){ 1 });
+    gfile_buf(&g, "exp", &b_exp);
+    gfile_close(&g);
+    fprintf(stderr, "gpm.ovg: %u GPM + %u CIIP cases, %zu expected samples\n", n_gpm, n_cases - n_gpm, b_exp.n);
+}
+
 /* ====================================================================================== DBF */
 #include "dbf_utils.h"
 #include "drv_lines.h"
@@ -1135,6 +1284,7 @@ main(int argc, char **argv)
     if (!only || !strcmp(only, "mcx")) gen_mcx(dir);
     if (!only || !strcmp(only, "mca")) gen_mca(dir);
     if (!only || !strcmp(only, "lmcs")) gen_lmcs(dir);
+    if (!only || !strcmp(only, "gpm")) gen_gpm(dir);
     if (!only || !strcmp(only, "dbf")) gen_dbf(dir);
     if (!only || !strcmp(only, "sao")) gen_sao(dir);
     if (!only || !strcmp(only, "alf")) gen_alf(dir);

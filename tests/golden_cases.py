@@ -85,6 +85,17 @@ def lmcs_cases():
     return g["pic_y"], sets, g["regions"], g["inverse"]
 
 
+def gpm_cases():
+    """GPM + CIIP: (refs, intra HostPic, descs, ciip_modes [n,2], n_gpm, exp_off, exp); the first n_gpm cases are GPM."""
+    g = golden_io.load("gpm.ovg")
+    n = g["desc"].shape[0]
+    _, rh, rw = g["ref_y"].shape
+    refs = [HostPic(rw, rh, g["ref_y"][k], g["ref_cb"][k], g["ref_cr"][k]) for k in range(3)]
+    intra = HostPic(rw, rh, g["intra_y"], g["intra_cb"], g["intra_cr"])
+    descs = [capi.PuDesc.from_buffer_copy(g["desc"][i].tobytes()) for i in range(n)]
+    return refs, intra, descs, g["ciip_modes"], int(g["n_gpm"][0]), g["exp_off"], g["exp"]
+
+
 def check_rects(pic: HostPic, rects, exp, what=""):
     planes = pic.planes()
     bad = []

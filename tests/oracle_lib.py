@@ -38,6 +38,8 @@ def lib():
         _lib.oracle_lmcs_scale.restype = None
         _lib.oracle_lmcs_inverse.argtypes = [C.POINTER(OPic), vp]
         _lib.oracle_lmcs_inverse.restype = None
+        _lib.oracle_ciip.argtypes = [C.POINTER(OPic), C.POINTER(OPic), vp, C.c_uint32]
+        _lib.oracle_ciip.restype = None
         _lib.oracle_mca.argtypes = [C.POINTER(OPic), C.POINTER(OPic), C.c_uint32, vp, C.c_uint32, vp, vp]
         _lib.oracle_mca.restype = None
         _lib.oracle_dbf.argtypes = [C.POINTER(OPic), vp]
@@ -108,6 +110,12 @@ def mc(dst: HostPic, refs, units: np.ndarray, lmcs_fwd=None):
         lmcs_fwd = np.ascontiguousarray(lmcs_fwd, dtype=np.uint16)
         lut = lmcs_fwd.ctypes.data
     lib().oracle_mc(C.byref(s), arr, len(refs), units.ctypes.data, len(units), lut)
+
+
+def ciip(dst: HostPic, intra: HostPic, units: np.ndarray):
+    d, s = dst.struct(), intra.struct()
+    units = np.ascontiguousarray(units)
+    lib().oracle_ciip(C.byref(d), C.byref(s), units.ctypes.data, len(units))
 
 
 def mca(dst: HostPic, refs, units: np.ndarray, side: np.ndarray, lmcs_fwd=None):

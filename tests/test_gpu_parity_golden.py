@@ -137,6 +137,34 @@ def test_lmcs_gpu_matches_reference(ctx):
     assert n_inv == len(inverse)
 
 
+def test_gpm_ciip_gpu_matches_reference(ctx):
+    """K10: GPM units through ovhip_mc_launch, CIIP = plain MC + ovhip_ciip_launch, vs rcn_gpm_b / rcn_ciip(_b)."""
+    refs, intra, descs, modes, n_gpm, exp_off, exp = golden_cases.gpm_cases()
+    rw, rh = refs[0].w, refs[0].h
+    n = len(descs)
+    drefs = [ctx.upload_pic(r.y, r.cb, r.cr) for r in refs]
+    dintra = ctx.upload_pic(intra.y, intra.cb, intra.cr)
+    fill = np.full((rh * n, rw), 0xABAB, np.uint16)
+    tall = ctx.upload_pic(fill, fill[: rh * n // 2, : rw // 2], fill[: rh * n // 2, : rw // 2])
+    rec = capi.Recorder(rw, rh)
+    rects = []
+    for i, d in enumerate(descs):
+        rec.reset()
+        rec.pu(d)
+        band = tall.band(i * rh, rh)
+        ctx.mc(band, drefs, ctx.upload(rec.mc_units()))
+        if i >= n_gpm:
+            rec.ciip(d.x0, d.y0, d.log2_w, d.log2_h, int(modes[i, 0]), int(modes[i, 1]))
+            ctx.ciip(band, dintra, ctx.upload(rec.ciip_units()))
+        w, h = 1 << d.log2_w, 1 << d.log2_h
+        rects += [(0, d.x0, d.y0 + i * rh, w, h, int(exp_off[i, 0])),
+                  (1, d.x0 >> 1, (d.y0 >> 1) + i * (rh // 2), w >> 1, h >> 1, int(exp_off[i, 1])),
+                  (2, d.x0 >> 1, (d.y0 >> 1) + i * (rh // 2), w >> 1, h >> 1, int(exp_off[i, 2]))]
+    ctx.sync()
+    y, cb, cr = tall.download()
+    golden_cases.check_rects(HostPic(rw, rh * n, y, cb, cr), rects, exp, "gpm/ciip HIP vs reference")
+
+
 def test_dbf_gpu_matches_reference(ctx):
     for i, (pic, planes, exp) in enumerate(golden_cases.dbf_cases()):
         d = ctx.upload_pic(pic.y, pic.cb, pic.cr)

@@ -107,6 +107,29 @@ def test_lmcs_host_tables_and_oracle_match_reference(built_lib):
     assert n_inv == len(inverse) and len(np.unique(regions[:, 5])) > 10
 
 
+def test_gpm_ciip_oracle_matches_reference(built_lib):
+    """K10: geometric partitioning (rcn_gpm_b, all 64 partition indices) and the CIIP blend (rcn_ciip / rcn_ciip_b)."""
+    refs, intra, descs, modes, n_gpm, exp_off, exp = golden_cases.gpm_cases()
+    rw, rh = refs[0].w, refs[0].h
+    rec = capi.Recorder(rw, rh)
+    for i, d in enumerate(descs):
+        rec.reset()
+        rec.pu(d)
+        dst = HostPic(rw, rh)
+        dst.y[:] = 0xABAB; dst.cb[:] = 0xABAB; dst.cr[:] = 0xABAB
+        oracle_lib.mc(dst, refs, rec.mc_units())
+        if i >= n_gpm:
+            rec.ciip(d.x0, d.y0, d.log2_w, d.log2_h, int(modes[i, 0]), int(modes[i, 1]))
+            oracle_lib.ciip(dst, intra, rec.ciip_units())
+        w, h = 1 << d.log2_w, 1 << d.log2_h
+        rects = [(0, d.x0, d.y0, w, h, int(exp_off[i, 0])),
+                 (1, d.x0 >> 1, d.y0 >> 1, w >> 1, h >> 1, int(exp_off[i, 1])),
+                 (2, d.x0 >> 1, d.y0 >> 1, w >> 1, h >> 1, int(exp_off[i, 2]))]
+        what = f"GPM split {d.gpm_split_dir}" if i < n_gpm else f"CIIP modes {modes[i].tolist()} dir {d.inter_dir}"
+        golden_cases.check_rects(dst, rects, exp, f"case {i} {what} {w}x{h} @({d.x0},{d.y0})")
+    assert n_gpm >= 192 and len(descs) - n_gpm >= 100
+
+
 def test_dbf_oracle_matches_reference(built_lib):
     cases = golden_cases.dbf_cases()
     assert len(cases) == 2
