@@ -82,7 +82,10 @@ def main():
     ref1_t, rp.refs[1] = torch_pic(wl.refs[1])
     spare_t, spare = torch_pic(wl.refs[1])          # receive buffer for the exchanged reference picture
 
-    stages = list(rp.STAGES)
+    # one entry per kernel launch of the frame; launches a picture has no work for are dropped
+    present = {"mcx": rp.mcx_units, "mca": rp.aff_units, "ciip": rp.ciip_units, "lmcs_scale": rp.lmcs_regions,
+               "lmcs_inv": rp.lmcs_bwd, "itx_c": rp.n_luma < rp.tb_cmds.count}
+    stages = [k for k in rp.SUBSTAGES if present.get(k, True)]
     evs = {k: [] for k in stages}
 
     def step(timed):
@@ -130,21 +133,42 @@ def main():
         # ---- per-kernel average launch duration (HIP events on the launch stream, timed region) ----
         kdur = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) * 1e-3 for k, v in evs.items()}
         st = wl.stats
-        u = wl.mc_units
         tb = wl.tb_cmds
-        tb_samples = int((1 << (tb["log2_w"].astype(np.int64) + tb["log2_h"])).sum()
-                         + (1 << (tb["log2_w"].astype(np.int64) + tb["log2_h"]))[tb["plane2"] != 0xff].sum())
-        # algorithmic bytes per launch (DESIGN.md "Measurement"): SURVEY 8d terms split per stage
+        area = lambda a: int((a["w"].astype(np.int64) * a["h"]).sum())
+        nref_area = lambda a: int((a["w"].astype(np.int64) * a["h"] * np.where(a["dir"] == 3, 2, 1)).sum())
+
+        def itx_bytes(c):
+            """coefficients actually stored + commands + read-modify-write of the covered samples"""
+            n_samples = 1 << (c["log2_w"].astype(np.int64) + c["log2_h"])
+            raster = (c["kind"] & 0x80) != 0
+            sbs = np.array([bin(int(m)).count("1") for m in c["sig_sb_map"]], np.int64)
+            coef = np.where(raster, 2 * n_samples, 32 * sbs).sum()
+            covered = n_samples.sum() + n_samples[c["plane2"] != 0xff].sum()
+            return int(coef + c.nbytes + 2 * 2 * covered)
+
+        # algorithmic bytes per launch (DESIGN.md "Measurement"): SURVEY 8d terms split per kernel.  A luma
+        # sample with its 4:2:0 chroma is 3 bytes; prediction reads nref reference blocks and writes one.
+        ciip_area = int((1 << (wl.ciip_units["log2_w"].astype(np.int64) + wl.ciip_units["log2_h"])).sum()) if len(wl.ciip_units) else 0
         alg = {
-            "mc": st["r_bar"] * S + S + u.nbytes,                     # r*S reference reads + S prediction writes + units
-            "itx": wl.coefs.nbytes + tb.nbytes + 2 * 2 * tb_samples,  # coefficients + commands + RMW of covered samples
-            "dbf": 2 * S + rp.dbf_planes.nbytes,                      # read + write the picture, edge parameter planes
+            "mcp": 3 * (nref_area(wl.mc_units) + area(wl.mc_units)) + wl.mc_units.nbytes,
+            "mcx": 3 * 3 * area(wl.mcx_units) + wl.mcx_units.nbytes + 16 * len(wl.mcx_units),
+            "mca": 3 * (nref_area(wl.aff_units) + area(wl.aff_units)) + wl.aff_units.nbytes + wl.aff_side.nbytes,
+            "ciip": 3 * 3 * ciip_area + wl.ciip_units.nbytes,              # intra read + inter read-modify-write
+            "itx_l": itx_bytes(tb[:rp.n_luma]),
+            "lmcs_scale": st["n_lmcs_regions"] * (128 * 2 + 8 + 2),
+            "itx_c": itx_bytes(tb[rp.n_luma:]),
+            "lmcs_inv": 2 * 2 * W * H,                                     # luma plane read + write
+            "dbf": 2 * S + rp.dbf_planes.nbytes,                           # read + write the picture, edge parameter planes
             "sao": 2 * S + wl.sao_params.nbytes,
             "alf": 2 * S + rp.alf.nbytes,
         }
+        alg = {k: v for k, v in alg.items() if k in kdur}
         dom = max(kdur, key=kdur.get)
         achieved = alg[dom] / kdur[dom] / 1e9
-        roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+        kname = {"mcp": "k_mc", "mcx": "k_mcx", "mca": "k_mca", "ciip": "k_ciip", "itx_l": "k_itx (luma commands)",
+                 "itx_c": "k_itx (chroma commands)", "lmcs_scale": "k_lmcs_scale", "lmcs_inv": "k_lmcs_inverse",
+                 "dbf": "k_dbf<0> + k_dbf<1>", "sao": "k_sao", "alf": "k_alf_luma + k_alf_chroma"}
+        roofline = {"bound": "hbm", "kernel": kname[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
                     "avg_launch_us": {k: round(v * 1e6, 2) for k, v in kdur.items()},
                     "algorithmic_bytes": {k: int(v) for k, v in alg.items()}}
@@ -164,14 +188,15 @@ def main():
                              f"({os.cpu_count()} logical cores present)"}
 
         out = {
-            "metric": "decoded frames/sec, full rcn back-end (MC + inverse transform + deblocking + SAO + ALF/CC-ALF), "
-                      "4K 10-bit RA recorded picture, bit-exact vs oracle",
+            "metric": "decoded frames/sec, full rcn back-end (MC incl. BDOF/DMVR/affine-PROF/GPM/CIIP + LMCS + inverse "
+                      "transform + deblocking + SAO + ALF/CC-ALF), 4K 10-bit RA recorded picture, bit-exact vs oracle",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u16 samples / int16 coefficients / int32 accumulate", "data": "synthetic",
             "config": {"workload": f"{W}x{H} 10-bit 4:2:0 synthetic recorded inter picture (BASELINE configs[3]), "
                                    f"seed {hex(args.seed)}, stages {'+'.join(stages)}",
-                       "n_cu": st["n_cu"], "n_mc_units": st["n_mc_units"], "n_tb_cmds": st["n_tb_cmds"],
+                       "n_cu": st["n_cu"], "cu_modes": st["cu_modes"], "n_mc_units": st["n_mc_units"],
+                       "n_mcx_units": st["n_mcx_units"], "n_aff_units": st["n_aff_units"], "n_tb_cmds": st["n_tb_cmds"],
                        "r_bar": round(st["r_bar"], 3), "coef_bytes": st["coef_bytes"],
                        "frame_algorithmic_bytes": int(sum(alg.values())),
                        "parallelism": f"frames x{world}" + (" + RCCL p2p reference exchange" if world > 1 else "")},

@@ -207,11 +207,19 @@ class DevPic:
 class ResidentPicture:
     """A recorded picture resident in HBM: reference pictures, command buffers, coefficient arena,
     in-loop filter side information and two picture buffers.  `decode()` enqueues every stage of
-    the rcn path in the order the reference executes them (prediction -> residual -> deblocking ->
-    SAO -> ALF/CC-ALF), each as frame-wide launches on the context stream.  The reconstructed /
-    deblocked picture lives in `dst`, SAO writes `tmp`, ALF writes the final samples back to `dst`."""
+    the rcn path in the order the reference executes them (prediction -> residual -> inverse luma
+    mapping -> deblocking -> SAO -> ALF/CC-ALF), each as frame-wide launches on the context stream.
+    The reconstructed / deblocked picture lives in `dst`, SAO writes `tmp`, ALF writes the final
+    samples back to `dst`.
+
+    Launch order inside the two composite stages:
+      "mc"  = plain / GPM units, BDOF / DMVR units (+ refined-MV write-back), affine units, CIIP blend
+      "itx" = luma TBs, LMCS chroma-scale derivation (reads the luma just reconstructed), chroma TBs,
+              inverse luma mapping"""
 
     STAGES = ("mc", "itx", "dbf", "sao", "alf")
+    SUBSTAGES = ("mcp", "mcx", "mca", "ciip", "itx_l", "lmcs_scale", "itx_c", "lmcs_inv", "dbf", "sao", "alf")
+    _GROUPS = {"mc": ("mcp", "mcx", "mca", "ciip"), "itx": ("itx_l", "lmcs_scale", "itx_c", "lmcs_inv")}
 
     def __init__(self, ctx: Context, wl, log2_ctu: int = 7):
         self.ctx, self.wl, self.log2_ctu = ctx, wl, log2_ctu
@@ -224,13 +232,51 @@ class ResidentPicture:
         self.dbf_planes = DevDbfPlanes(ctx, wl.dbf_planes)
         self.sao_params = ctx.upload(wl.sao_params)
         self.alf = DevAlf(ctx, wl.alf, wl.w, wl.h, log2_ctu)
+        self.bufs = [self.mc_units, self.tb_cmds, self.coefs, self.sao_params]
+        up = lambda a: self._keep(ctx.upload(a)) if a is not None and len(a) else None
+        self.mcx_units = up(wl.mcx_units)
+        self.mv_out = self._keep(ctx.alloc(16 * len(wl.mcx_units))) if self.mcx_units else None
+        self.aff_units, self.aff_side = up(wl.aff_units), up(wl.aff_side)
+        self.ciip_units = up(wl.ciip_units)
+        self.intra = ctx.upload_pic(*wl.intra) if wl.intra is not None else None
+        self.lmcs = wl.lmcs
+        self.lmcs_fwd = up(wl.lmcs_fwd)
+        self.lmcs_bwd = up(wl.lmcs_bwd)
+        self.lmcs_regions = up(wl.lmcs_regions)
+        self.lmcs_scales = self._keep(ctx.alloc(2 * len(wl.lmcs_regions))) if self.lmcs_regions else None
+        self.n_luma = wl.n_luma_cmds if self.lmcs is not None else len(wl.tb_cmds)
+
+    def _keep(self, b):
+        self.bufs.append(b)
+        return b
 
     def run_stage(self, name: str):
         c = self.ctx
-        if name == "mc":
-            c.mc(self.dst, self.refs, self.mc_units)
-        elif name == "itx":
-            c.itx(self.dst, self.tb_cmds, self.coefs)
+        if name in self._GROUPS:
+            for sub in self._GROUPS[name]:
+                self.run_stage(sub)
+        elif name == "mcp":
+            c.mc(self.dst, self.refs, self.mc_units, self.lmcs_fwd)
+        elif name == "mcx":
+            if self.mcx_units:
+                c.mcx(self.dst, self.refs, self.mcx_units, self.lmcs_fwd, self.mv_out)
+        elif name == "mca":
+            if self.aff_units:
+                c.mca(self.dst, self.refs, self.aff_units, self.aff_side, self.lmcs_fwd)
+        elif name == "ciip":
+            if self.ciip_units:
+                c.ciip(self.dst, self.intra, self.ciip_units)
+        elif name == "itx_l":
+            c.itx(self.dst, self.tb_cmds, self.coefs, n=self.n_luma)
+        elif name == "lmcs_scale":
+            if self.lmcs_regions:
+                c.lmcs_scale(self.dst, self.lmcs_regions, self.lmcs, self.lmcs_scales)
+        elif name == "itx_c":
+            if self.n_luma < self.tb_cmds.count:
+                c.itx(self.dst, self.tb_cmds, self.coefs, first=self.n_luma, lmcs_scales=self.lmcs_scales)
+        elif name == "lmcs_inv":
+            if self.lmcs is not None:
+                c.lmcs_inverse(self.dst, self.lmcs_bwd)
         elif name == "dbf":
             c.dbf(self.dst, self.dbf_planes)
         elif name == "sao":
@@ -248,8 +294,13 @@ class ResidentPicture:
         self.ctx.sync()
         return self.dst.download()
 
+    def refined_mvs(self) -> np.ndarray:
+        """int32 [n_mcx_units, 4]: the motion vectors the BDOF / DMVR units finally used."""
+        self.ctx.sync()
+        return self.mv_out.download(np.int32).reshape(-1, 4) if self.mv_out else np.zeros((0, 4), np.int32)
+
     def free(self):
-        for b in (self.mc_units, self.tb_cmds, self.coefs, self.sao_params, self.dbf_planes, self.alf):
+        for b in self.bufs + [self.dbf_planes, self.alf]:
             b.free()
-        for p in self.refs + [self.dst, self.tmp]:
+        for p in self.refs + [self.dst, self.tmp] + ([self.intra] if self.intra else []):
             p.free()

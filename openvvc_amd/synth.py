@@ -85,9 +85,17 @@ class Workload:
     refs: list                      # [(y, cb, cr)] reference pictures
     ref_pocs: list
     cus: np.ndarray                 # (n, 4) x, y, log2w, log2h
-    mc_units: np.ndarray            # capi.MC_UNIT_DTYPE
-    tb_cmds: np.ndarray             # capi.TB_CMD_DTYPE
+    mc_units: np.ndarray            # capi.MC_UNIT_DTYPE: plain uni / bi / BCW / GPM units
+    tb_cmds: np.ndarray             # capi.TB_CMD_DTYPE, luma commands first (n_luma_cmds), then chroma
     coefs: np.ndarray               # int16 arena
+    n_luma_cmds: int = 0
+    mcx_units: np.ndarray = None    # BDOF / DMVR units
+    aff_units: np.ndarray = None    # affine (+PROF) units and their side arena
+    aff_side: np.ndarray = None
+    ciip_units: np.ndarray = None   # CIIP blends; `intra` stands in for the caller's planar prediction
+    intra: tuple = None
+    lmcs: "capi.LmcsLuts" = None    # None: LMCS off
+    lmcs_regions: np.ndarray = None
     dbf_planes: dict = None         # picture-level deblocking edge planes (include/ovvc_hip.h)
     sao_params: np.ndarray = None   # capi.SAO_CTU_DTYPE per CTU
     alf: dict = None                # ALF tables + per-CTU parameters
@@ -96,6 +104,14 @@ class Workload:
     @property
     def frame_bytes(self) -> int:
         return self.w * self.h * 3    # 4:2:0, 2 bytes / sample
+
+    @property
+    def lmcs_fwd(self):
+        return None if self.lmcs is None else np.frombuffer(bytes(self.lmcs), np.uint16)[:1024].copy()
+
+    @property
+    def lmcs_bwd(self):
+        return None if self.lmcs is None else np.frombuffer(bytes(self.lmcs), np.uint16)[1024:2048].copy()
 
 
 def _coef_values(rs, n):
@@ -107,17 +123,42 @@ def _coef_values(rs, n):
     return (mag * sign).astype(np.int16)
 
 
+def _lmcs_tables(rs) -> "capi.LmcsLuts":
+    """A mild piecewise-linear luma mapping (16 windows), like CTC HDR/SDR LMCS parameter sets."""
+    d = capi.LmcsData()
+    d.min_bin_idx, d.delta_max_bin_idx = 1, 1
+    d.crs_offset = int(rs.randint(-3, 4))
+    for i in range(16):
+        d.cw_delta[i] = int(rs.randint(-14, 15))
+    return capi.lmcs_build(d)
+
+
+# coding tools of an inter picture; "base" = translational uni / bi / BCW prediction only
+ALL_TOOLS = ("bdof", "dmvr", "affine", "gpm", "ciip", "lmcs")
+
+
 def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6, cbf_y: float = 0.5,
-                  cbf_c: float = 0.3, mv_range_px: int = 64) -> Workload:
+                  cbf_c: float = 0.3, mv_range_px: int = 64, tools=ALL_TOOLS) -> Workload:
+    """tools: subset of ALL_TOOLS.  Rates follow JVET CTC random-access statistics in spirit: of the
+    bi-predicted CUs that satisfy check_bdof() (vcl_coding_unit.c:2019-2027) and whose references lie on
+    opposite sides of the picture, ~45 % use BDOF alone and ~35 % DMVR (+BDOF); ~8 % of the CUs >= 16x16
+    are affine (70 % of them with PROF), ~3 % GPM, ~3 % CIIP."""
+    tools = set(tools)
     rs = np.random.RandomState(seed & 0x7FFFFFFF)
-    refs = [random_picture(rs, w, h) for _ in range(2)]
+    ref0 = random_picture(rs, w, h)
+    # the second reference is a displaced, slightly noisy copy of the first (so that DMVR's search and
+    # BDOF's gradients see correlated content, as between two real pictures of a sequence)
+    ref1 = tuple(np.clip(np.roll(p, (1, 2), axis=(0, 1)).astype(np.int32) + rs.randint(-3, 4, size=p.shape), 0, 1023).astype(np.uint16)
+                 for p in ref0)
+    refs = [ref0, ref1]
     pocs = [8, 24]                      # current picture would be POC 16
     cus = partition(rs, w, h)
     n = len(cus)
     rec = capi.Recorder(w, h)
+    lw, lh = cus[:, 2], cus[:, 3]
 
     inter_dir = np.where(rs.random_sample(n) < bi_frac, 3, rs.randint(1, 3, size=n)).astype(np.int32)
-    small = (cus[:, 2] + cus[:, 3]) < 6          # 4x8 / 8x4 / ... : uni-pred only in VVC
+    small = (lw + lh) < 6                        # 4x8 / 8x4 / ... : uni-pred only in VVC
     inter_dir = np.where(small & (inter_dir == 3), 1, inter_dir)
     mv = rs.randint(-mv_range_px * 16, mv_range_px * 16 + 1, size=(n, 4)).astype(np.int32)
     integer = rs.random_sample((n, 4)) < 0.25     # a share of integer / half positions like real MV fields
@@ -125,27 +166,82 @@ def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6
     ridx = rs.randint(0, 2, size=(n, 2))
     bcw = np.where((inter_dir == 3) & (rs.random_sample(n) < 0.1), rs.randint(1, 6, size=n), 0)
     hpel = rs.random_sample(n) < 0.05
+    lmcs_on = "lmcs" in tools
+
+    # ---- coding mode per CU ----
+    PLAIN, BDOF, DMVR, AFFINE, GPM, CIIP = range(6)
+    mode = np.zeros(n, np.int32)
+    r = rs.random_sample((n, 3))
+    if "affine" in tools:
+        mode = np.where((lw >= 4) & (lh >= 4) & (r[:, 0] < 0.08), AFFINE, mode)
+    if "gpm" in tools:
+        mode = np.where((mode == PLAIN) & (lw >= 3) & (lh >= 3) & (lw <= 6) & (lh <= 6) & (r[:, 0] > 0.97), GPM, mode)
+    if "ciip" in tools:
+        mode = np.where((mode == PLAIN) & (lw + lh >= 6) & (lw <= 6) & (lh <= 6) & (r[:, 0] > 0.94) & (r[:, 0] <= 0.97), CIIP, mode)
+    elig = (mode == PLAIN) & (inter_dir == 3) & (lw >= 3) & (lh >= 3) & (lw + lh >= 7) & (bcw == 0) & (ridx[:, 0] == ridx[:, 1])
+    if "dmvr" in tools:
+        mode = np.where(elig & (r[:, 1] < 0.35), DMVR, mode)
+    if "bdof" in tools:
+        mode = np.where(elig & (mode == PLAIN) & (r[:, 1] < 0.80), BDOF, mode)
+    bcw = np.where(np.isin(mode, (GPM, CIIP)), 0, bcw)
+    hpel = np.where(np.isin(mode, (AFFINE,)) | ((lw == 2) & (lh == 2)), False, hpel)
+    # merge-mode (DMVR) motion is close to mirrored between the two lists
+    mirrored = -mv[:, :2] + rs.randint(-24, 25, size=(n, 2))
+    mv[:, 2:] = np.where((mode == DMVR)[:, None], mirrored, mv[:, 2:])
 
     # rpl0 = [ref0, ref1], rpl1 = [ref1, ref0]
     slot = np.array([[0, 1], [1, 0]])
     pd = capi.PuDesc()
+    ad = capi.AffineDesc()
+    cu_modes = (1, 2, 4, 6)             # OV_INTER, OV_INTRA, OV_MIP, OV_INTER_SKIP (cu_utils.h:132-139)
     for i in range(n):
         x, y, l2w, l2h = (int(v) for v in cus[i])
+        m = int(mode[i])
+        ref0s, ref1s = int(slot[0, ridx[i, 0]]), int(slot[1, ridx[i, 1]])
+        if m == AFFINE:
+            nsx, nsy = (1 << l2w) >> 2, (1 << l2h) >> 2
+            ad.x0, ad.y0, ad.log2_w, ad.log2_h = x, y, l2w, l2h
+            ad.inter_dir = int(inter_dir[i]); ad.bcw_idx_plus1 = int(bcw[i]); ad.lmcs = int(lmcs_on)
+            ad.prof_dir = 0 if rs.random_sample() < 0.3 else (int(rs.randint(1, 4)) if inter_dir[i] == 3 else int(inter_dir[i]))
+            ad.ref0, ad.ref1, ad.poc0, ad.poc1 = ref0s, ref1s, pocs[ref0s], pocs[ref1s]
+            ad.mv_stride = nsx
+            for t in range(4):
+                for k in range(16):
+                    ad.dmv_scale[t][k] = int(rs.randint(-12, 13))
+            gx = rs.randint(-10, 11, size=(2, 2, 2))          # [list][d/dx, d/dy][mv component], 1/16 pel per sub-block
+            ii, jj = np.meshgrid(np.arange(nsx), np.arange(nsy))
+            fields = []
+            for l in range(2):
+                fx = mv[i, 2 * l] + ((gx[l, 0, 0] * ii + gx[l, 1, 0] * jj) >> 1)
+                fy = mv[i, 2 * l + 1] + ((gx[l, 0, 1] * ii + gx[l, 1, 1] * jj) >> 1)
+                fields.append(np.stack([fx, fy], axis=-1).astype(np.int32))
+            rec.affine_cu(ad, fields[0], fields[1])
+            continue
         pd.x0, pd.y0, pd.log2_w, pd.log2_h = x, y, l2w, l2h
         pd.inter_dir = int(inter_dir[i])
         pd.ref_idx0, pd.ref_idx1 = int(ridx[i, 0]), int(ridx[i, 1])
-        pd.bcw_idx_plus1 = int(bcw[i]); pd.prec_amvr_half = int(hpel[i]); pd.planes = 3; pd.lmcs = 0
+        pd.bcw_idx_plus1 = int(bcw[i]); pd.prec_amvr_half = int(hpel[i]); pd.planes = 3; pd.lmcs = int(lmcs_on)
         pd.mv0x, pd.mv0y, pd.mv1x, pd.mv1y = (int(v) for v in mv[i])
         if hpel[i]:
             pd.mv0x = (pd.mv0x & ~15) | 8; pd.mv1y = (pd.mv1y & ~15) | 8
-        pd.ref0 = int(slot[0, ridx[i, 0]]); pd.ref1 = int(slot[1, ridx[i, 1]])
+        pd.ref0, pd.ref1 = ref0s, ref1s
         pd.poc0 = pocs[pd.ref0]; pd.poc1 = pocs[pd.ref1]
+        pd.refine = 0; pd.gpm_split_dir = 0
+        if m == BDOF:
+            pd.refine = capi.PU_BDOF
+        elif m == DMVR:
+            pd.refine = capi.PU_DMVR | (capi.PU_BDOF if rs.random_sample() < 0.8 else 0)
+        elif m == GPM:
+            pd.refine = capi.PU_GPM; pd.inter_dir = 3; pd.gpm_split_dir = int(rs.randint(0, 64))
         rec.pu(pd)
+        if m == CIIP:
+            rec.ciip(x, y, l2w, l2h, cu_modes[rs.randint(0, 4)], cu_modes[rs.randint(0, 4)])
 
     # ---- transform units ----
     st = capi.TuState()
-    st.dep_quant = 1; st.mts_implicit = 0; st.sh_ts_disabled = 0; st.ict_type = 2
-    st.lmcs_scale_c = 0; st.lmcs_chroma_scale = 1 << 11
+    st.dep_quant = 1; st.mts_implicit = 0; st.sh_ts_disabled = 0
+    st.ict_type = 3 if lmcs_on else 2
+    st.lmcs_scale_c = 2 if lmcs_on else 0; st.lmcs_chroma_scale = 1 << 11
     td = capi.TuDesc()
     n_tu = 0
     coef_pool = _coef_values(rs, 1 << 20)
@@ -153,6 +249,12 @@ def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6
     bufs = [np.zeros(32 * 32, np.int16) for _ in range(3)]
     for i in range(n):
         x, y, l2w, l2h = (int(v) for v in cus[i])
+        if lmcs_on and not (x & 63) and not (y & 63):
+            # rcn_lmcs_compute_chroma_scale at every 64-aligned CU (vcl_coding_unit.c:724-730); neighbours are
+            # available up to the picture edge
+            n_abv = min(16, (w - x) >> 2) if y > 0 else 0
+            n_lft = min(16, (h - y) >> 2) if x > 0 else 0
+            rec.lmcs_region(x, y, (1 << n_abv) - 1, (1 << n_lft) - 1)
         qp = int(rs.randint(22, 38)) + 12
         for ty in range(0, 1 << l2h, 64):
             for tx in range(0, 1 << l2w, 64):
@@ -226,19 +328,30 @@ def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6
                 rec.tu(st, td)
                 n_tu += 1
 
-    wl = Workload(w, h, seed, refs, pocs, cus, rec.mc_units(), rec.tb_cmds(), rec.coefs())
+    cmds, n_luma = rec.tb_cmds_split()
+    wl = Workload(w, h, seed, refs, pocs, cus, rec.mc_units(), cmds, rec.coefs(), n_luma_cmds=n_luma)
+    wl.mcx_units, wl.aff_units, wl.aff_side, wl.ciip_units = rec.mcx_units(), rec.aff_units(), rec.aff_side(), rec.ciip_units()
+    if len(wl.ciip_units):
+        wl.intra = random_picture(rs, w, h)
+    if lmcs_on:
+        wl.lmcs = _lmcs_tables(rs)
+        wl.lmcs_regions = rec.lmcs_regions()
     wl.dbf_planes = make_dbf_planes(rs, w, h, cus)
     wl.sao_params = make_sao_params(rs, w, h)
     wl.alf = make_alf(rs, w, h)
-    u = wl.mc_units
-    bi = (u["dir"] == 3)
-    area = u["w"].astype(np.int64) * u["h"]
+    u, ux, ua = wl.mc_units, wl.mcx_units, wl.aff_units
+    area = lambda a: a["w"].astype(np.int64) * a["h"]
+    nref = lambda a: np.where(a["dir"] == 3, 2, 1)
+    tot = area(u).sum() + area(ux).sum() + area(ua).sum()
     wl.stats = {
-        "n_cu": int(n), "n_tu": int(n_tu), "n_mc_units": int(len(u)), "n_tb_cmds": int(len(wl.tb_cmds)),
+        "n_cu": int(n), "n_tu": int(n_tu), "n_mc_units": int(len(u)), "n_mcx_units": int(len(ux)),
+        "n_aff_units": int(len(ua)), "n_ciip_units": int(len(wl.ciip_units)), "n_tb_cmds": int(len(wl.tb_cmds)),
+        "n_luma_cmds": int(n_luma), "n_lmcs_regions": 0 if wl.lmcs_regions is None else int(len(wl.lmcs_regions)),
+        "cu_modes": {k: int((mode == v).sum()) for k, v in (("plain", PLAIN), ("bdof", BDOF), ("dmvr", DMVR), ("affine", AFFINE), ("gpm", GPM), ("ciip", CIIP))},
         "coef_bytes": int(wl.coefs.nbytes),
-        "cmd_bytes": int(wl.mc_units.nbytes + wl.tb_cmds.nbytes),
+        "cmd_bytes": int(u.nbytes + ux.nbytes + ua.nbytes + wl.aff_side.nbytes + wl.tb_cmds.nbytes),
         # mean reference samples fetched per output sample (block window not counted), SURVEY 8d
-        "r_bar": float((area * np.where(bi, 2, 1)).sum() / max(1, area.sum())),
+        "r_bar": float(((area(u) * nref(u)).sum() + 2 * area(ux).sum() + (area(ua) * nref(ua)).sum()) / max(1, tot)),
     }
     rec.close()
     return wl

@@ -8,21 +8,45 @@ from oracle_lib import HostPic
 STAGES = ("mc", "itx", "dbf", "sao", "alf")
 
 
-def decode(wl, rows=None, stages=STAGES):
-    """rows=(y0, y1): only the MC / ITX commands whose blocks start inside luma rows [y0, y1)
-    (used by band checks before the in-loop filters); the picture buffers stay full size."""
+def _rows(a, y0, y1, scale_chroma=False):
+    if a is None or not len(a):
+        return a
+    y = a["y"].astype(np.int32)
+    if scale_chroma:
+        y = np.where(a["plane"] == 0, y, y * 2)
+    return a[(y >= y0) & (y < y1)]
+
+
+def decode(wl, rows=None, stages=STAGES, want_mvs=False):
+    """rows=(y0, y1): only the prediction / transform commands whose blocks start inside luma rows [y0, y1)
+    (used by band checks before the in-loop filters; meaningful without LMCS chroma scaling only when the
+    band starts at row 0).  The picture buffers stay full size."""
     refs = [HostPic(wl.w, wl.h, *r) for r in wl.refs]
     dst = HostPic(wl.w, wl.h)
-    units, cmds = wl.mc_units, wl.tb_cmds
+    units, ux, ua, uc, cmds = wl.mc_units, wl.mcx_units, wl.aff_units, wl.ciip_units, wl.tb_cmds
+    luma, chroma = cmds[:wl.n_luma_cmds], cmds[wl.n_luma_cmds:]
+    regions = wl.lmcs_regions
     if rows is not None:
         y0, y1 = rows
-        units = units[(units["y"] >= y0) & (units["y"] < y1)]
-        ly = np.where(cmds["plane"] == 0, cmds["y"], cmds["y"].astype(np.int32) * 2)
-        cmds = cmds[(ly >= y0) & (ly < y1)]
+        units, ux, ua, uc = (_rows(a, y0, y1) for a in (units, ux, ua, uc))
+        luma, chroma = _rows(luma, y0, y1, True), _rows(chroma, y0, y1, True)
+    mvs = None
     if "mc" in stages:
-        oracle_lib.mc(dst, refs, units)
+        oracle_lib.mc(dst, refs, units, wl.lmcs_fwd)
+        if ux is not None and len(ux):
+            mvs = oracle_lib.mc_ex(dst, refs, ux, wl.lmcs_fwd)
+        if ua is not None and len(ua):
+            oracle_lib.mca(dst, refs, ua, wl.aff_side, wl.lmcs_fwd)
+        if uc is not None and len(uc):
+            oracle_lib.ciip(dst, HostPic(wl.w, wl.h, *wl.intra), uc)
     if "itx" in stages:
-        oracle_lib.itx(dst, cmds, wl.coefs)
+        if wl.lmcs is None:
+            oracle_lib.itx(dst, cmds if rows is None else np.concatenate([luma, chroma]), wl.coefs)
+        else:
+            oracle_lib.itx(dst, luma, wl.coefs)
+            scales = oracle_lib.lmcs_scale(dst, regions, wl.lmcs)
+            oracle_lib.itx_ex(dst, chroma, wl.coefs, scales)
+            oracle_lib.lmcs_inverse(dst, wl.lmcs_bwd)
     if "dbf" in stages:
         oracle_lib.dbf(dst, wl.dbf_planes)
     if "sao" in stages:
@@ -32,4 +56,4 @@ def decode(wl, rows=None, stages=STAGES):
             oracle_lib.alf(dst, tmp, wl.alf)
         else:
             dst = tmp
-    return dst
+    return (dst, mvs) if want_mvs else dst

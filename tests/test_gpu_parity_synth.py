@@ -24,9 +24,24 @@ def test_picture_matches_oracle(ctx, w, h, seed):
     rp = engine.ResidentPicture(ctx, wl)
     rp.decode()
     y, cb, cr = rp.result()
-    ref = oracle_pipeline.decode(wl)
+    ref, mvs = oracle_pipeline.decode(wl, want_mvs=True)
     for name, a, b in (("Y", y, ref.y), ("Cb", cb, ref.cb), ("Cr", cr, ref.cr)):
         assert np.array_equal(a, b), f"{w}x{h} seed {seed}: plane {name}: {int((a != b).sum())} samples differ"
+    # every coding tool is present in the picture, and DMVR's motion-vector write-back agrees
+    assert all(v > 0 for v in wl.stats["cu_modes"].values()), wl.stats["cu_modes"]
+    assert np.array_equal(rp.refined_mvs(), mvs)
+    rp.free()
+
+
+def test_picture_matches_oracle_base_tools(ctx):
+    """Translational uni / bi / BCW prediction only, LMCS off (the round-1 workload)."""
+    wl = synth.make_workload(832, 480, 5, tools=())
+    rp = engine.ResidentPicture(ctx, wl)
+    rp.decode()
+    y, cb, cr = rp.result()
+    ref = oracle_pipeline.decode(wl)
+    for name, a, b in (("Y", y, ref.y), ("Cb", cb, ref.cb), ("Cr", cr, ref.cr)):
+        assert np.array_equal(a, b), f"plane {name}: {int((a != b).sum())} samples differ"
     rp.free()
 
 

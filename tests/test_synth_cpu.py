@@ -1,0 +1,40 @@
+"""CPU: the synthetic recorded-picture generator and the oracle pipeline (no GPU): every coding tool is
+present, the pipeline is deterministic, DMVR moves motion vectors, LMCS chroma scales vary."""
+import hashlib
+
+import numpy as np
+
+import oracle_lib
+import oracle_pipeline
+from oracle_lib import HostPic
+from openvvc_amd import capi, synth
+
+
+def test_workload_has_every_tool_and_oracle_is_deterministic(built_lib):
+    wl = synth.make_workload(416, 240, 0x266)
+    assert all(v > 0 for v in wl.stats["cu_modes"].values()), wl.stats["cu_modes"]
+    assert wl.n_luma_cmds and (wl.tb_cmds["plane"][:wl.n_luma_cmds] == 0).all() and (wl.tb_cmds["plane"][wl.n_luma_cmds:] != 0).all()
+    a, mv_a = oracle_pipeline.decode(wl, want_mvs=True)
+    b, mv_b = oracle_pipeline.decode(wl, want_mvs=True)
+    md5 = lambda p: hashlib.md5(p.y.tobytes() + p.cb.tobytes() + p.cr.tobytes()).hexdigest()
+    assert md5(a) == md5(b) and np.array_equal(mv_a, mv_b)
+    # DMVR refined at least some motion vectors; BDOF-only units report their input vectors
+    ux = wl.mcx_units
+    moved = (mv_a != np.stack([ux["mv0x"], ux["mv0y"], ux["mv1x"], ux["mv1y"]], axis=1)).any(axis=1)
+    dm = (ux["flags"] & capi.MC_DMVR) != 0
+    assert moved[dm].sum() > 0 and not moved[~dm & ((ux["flags"] & capi.MC_BDOF) != 0)].any()
+    # the same picture without the new tools differs (they are not no-ops)
+    base = oracle_pipeline.decode(synth.make_workload(416, 240, 0x266, tools=()))
+    assert md5(base) != md5(a)
+
+
+def test_lmcs_chroma_scales_follow_the_luma(built_lib):
+    wl = synth.make_workload(416, 240, 3)
+    refs = [HostPic(wl.w, wl.h, *r) for r in wl.refs]
+    dst = HostPic(wl.w, wl.h)
+    oracle_lib.mc(dst, refs, wl.mc_units, wl.lmcs_fwd)
+    scales = oracle_lib.lmcs_scale(dst, wl.lmcs_regions, wl.lmcs)
+    assert len(scales) == wl.stats["n_lmcs_regions"] > 8
+    assert len(np.unique(scales)) > 2 and scales.min() > 1000 and scales.max() < 4500
+    idx = (wl.tb_cmds["res_mode"] & 8) != 0
+    assert idx.any() and wl.tb_cmds["c_scale"][idx].max() < len(scales)
