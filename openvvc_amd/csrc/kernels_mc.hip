@@ -36,7 +36,7 @@ __device__ __forceinline__ int mc_combine(const ovhip_mc_unit &u, int p0, int p1
 }
 
 __global__ __launch_bounds__(64) void k_mc(ovhip_pic dst, RefTable refs, const ovhip_mc_unit *__restrict__ units,
-                                            uint32_t n_units, const uint16_t *__restrict__ lmcs_fwd, int ablate)
+                                            uint32_t n_units, const uint16_t *__restrict__ lmcs_fwd, int ablate, int xcd)
 {
     __shared__ __attribute__((aligned(16))) uint16_t s_wl[2][LUMA_WIN];          // luma windows, list 0 / 1
     __shared__ __attribute__((aligned(16))) uint16_t s_wc[2][2][CHR_WIN];        // chroma windows [Cb/Cr][list]
@@ -46,7 +46,10 @@ __global__ __launch_bounds__(64) void k_mc(ovhip_pic dst, RefTable refs, const o
     const int lane = threadIdx.x;
     // grid-stride over units: the chip launches ~400 workgroups/us, so one workgroup per unit would be
     // dispatch-bound; a resident grid of single-wave workgroups walks the unit list instead
-    for (uint32_t bid = blockIdx.x; bid < n_units; bid += gridDim.x) {
+    for (uint32_t wg = blockIdx.x; wg < n_units; wg += gridDim.x) {
+    // XCD-aware order: workgroup i runs on XCD i % 8, so XCD k walks the k-th contiguous eighth of the
+    // unit list (= a compact area of the picture) and neighbouring reference windows meet in ITS L2
+    const uint32_t bid = xcd ? ov_xcd_slot(wg, n_units) : wg;
     const ovhip_mc_unit u = units[bid];
 
     const bool do_l = !(u.flags & OVHIP_MC_NO_LUMA), do_c = !(u.flags & OVHIP_MC_NO_CHROMA);
@@ -189,15 +192,16 @@ extern "C" int ovhip_mc_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip
     memset(&t, 0, sizeof(t));
     for (uint32_t i = 0; i < n_refs; ++i) t.p[i] = refs[i];
     for (uint32_t i = n_refs; i < MC_MAX_REFS; ++i) t.p[i] = refs[0];
-    static int cfg_grid = -1, cfg_ablate = 0;
+    static int cfg_grid = -1, cfg_ablate = 0, cfg_xcd = 1;
     if (cfg_grid < 0) {                       // developer knobs (profiling experiments only)
-        const char *g = getenv("OVHIP_MC_GRID"), *a = getenv("OVHIP_MC_ABLATE");
+        const char *g = getenv("OVHIP_MC_GRID"), *a = getenv("OVHIP_MC_ABLATE"), *x = getenv("OVHIP_MC_XCD");
         cfg_grid = g ? atoi(g) : 0;
         cfg_ablate = a ? atoi(a) : 0;
+        cfg_xcd = x ? atoi(x) : 1;
     }
     uint32_t grid = cfg_grid > 0 ? (uint32_t)cfg_grid : n_units;
     if (grid > n_units) grid = n_units;
-    hipLaunchKernelGGL(k_mc, dim3(grid), dim3(64), 0, ctx->stream, *dst, t, d_units, n_units, d_lmcs_fwd_lut, cfg_ablate);
+    hipLaunchKernelGGL(k_mc, dim3(grid), dim3(64), 0, ctx->stream, *dst, t, d_units, n_units, d_lmcs_fwd_lut, cfg_ablate, cfg_grid > 0 ? 0 : cfg_xcd);
     OV_LAUNCH_CHECK(ctx, "k_mc");
     return OVHIP_OK;
 }

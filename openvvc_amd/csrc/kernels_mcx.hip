@@ -77,7 +77,8 @@ __global__ __launch_bounds__(64) void k_mcx(ovhip_pic dst, RefTable refs, const 
     int16_t *const s_dr = reinterpret_cast<int16_t *>(s_wl[1]);                                // BDOF delta_ref, 16x16
 
     const int lane = threadIdx.x;
-    for (uint32_t bid = blockIdx.x; bid < n_units; bid += gridDim.x) {
+    for (uint32_t wg = blockIdx.x; wg < n_units; wg += gridDim.x) {
+    const uint32_t bid = gridDim.x == n_units ? ov_xcd_slot(wg, n_units) : wg;      // XCD-aware order, see k_mc
     const ovhip_mc_unit u = units[bid];
     const bool dmvr = u.flags & OVHIP_MC_DMVR;
     bool use_bdof = u.flags & OVHIP_MC_BDOF;
@@ -411,7 +412,8 @@ __global__ __launch_bounds__(64) void k_mca(ovhip_pic dst, RefTable refs, const 
     __shared__ __attribute__((aligned(16))) int16_t  s_cht[2][8][4 * ACHS];
 
     const int lane = threadIdx.x;
-    for (uint32_t bid = blockIdx.x; bid < n_units; bid += gridDim.x) {
+    for (uint32_t wg = blockIdx.x; wg < n_units; wg += gridDim.x) {
+    const uint32_t bid = gridDim.x == n_units ? ov_xcd_slot(wg, n_units) : wg;      // XCD-aware order, see k_mc
     const ovhip_aff_unit u = units[bid];
     const int nsx = u.w >> 2, nsb = nsx * (u.h >> 2), ncx = u.w >> 3, ncb = ncx * (u.h >> 3);
     const bool do_c = !(u.flags & OVHIP_AFF_NO_CHROMA);

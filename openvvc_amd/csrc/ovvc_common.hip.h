@@ -40,6 +40,16 @@ static inline int ov_fail(ovhip_ctx *ctx, int code, const char *what, hipError_t
         if (e__ != hipSuccess) return ov_fail((ctx), OVHIP_ELAUNCH, name, e__); \
     } while (0)
 
+// Workgroups are dealt to the 8 XCDs round-robin (workgroup i -> XCD i % 8).  Map workgroup i of a grid of
+// n to item slot: XCD k = i % 8 takes the k-th contiguous chunk of the item list, in order.
+#define OV_NUM_XCD 8
+__device__ __forceinline__ uint32_t ov_xcd_slot(uint32_t i, uint32_t n)
+{
+    const uint32_t k = i % OV_NUM_XCD, j = i / OV_NUM_XCD;
+    const uint32_t base = n / OV_NUM_XCD, rem = n % OV_NUM_XCD;          // chunks 0..rem-1 hold base + 1 items
+    return k * base + (k < rem ? k : rem) + j;
+}
+
 __device__ __forceinline__ int ov_clip3(int v, int lo, int hi) { return min(max(v, lo), hi); }
 __device__ __forceinline__ int ov_clip16(int v) { return ov_clip3(v, -32768, 32767); }
 __device__ __forceinline__ int ov_clip_bd(int v) { return ov_clip3(v, 0, OV_PIX_MAX); }
