@@ -41,7 +41,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from openvvc_amd import capi, engine, synth
+    from openvvc_amd import capi, engine, frames, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -102,10 +102,7 @@ def main():
         if world > 1:
             # push the reconstructed picture to the rank that lists it as a reference (ring), receive
             # ours into the spare buffer, then swap it in as reference 1 of the next step
-            ops = [dist.P2POp(dist.isend, dst_t, (rank + 1) % world),
-                   dist.P2POp(dist.irecv, spare_t, (rank - 1) % world)]
-            for w_ in dist.batch_isend_irecv(ops):
-                w_.wait()
+            frames.ring_exchange(dist, dst_t, spare_t, rank, world)
             ref1_t, spare_t = spare_t, ref1_t
             rp.refs[1], spare = spare, rp.refs[1]
 
