@@ -431,9 +431,11 @@ int   ovhip_rec_dbf_ctu(ovhip_recorder *rec, const ovhip_dbf_ctu *ctu);
 int   ovhip_rec_dbf_planes(const ovhip_recorder *rec, ovhip_dbf_planes *out);
 /* Access to the recorded (host) buffers. */
 const ovhip_tb_cmd  *ovhip_rec_tb_cmds(const ovhip_recorder *rec, size_t *n);
-/* The same commands reordered luma first (n_luma of them), then chroma: with device-derived chroma
- * scales the chroma commands must run after ovhip_lmcs_scale_launch, which must run after the luma ones. */
-const ovhip_tb_cmd  *ovhip_rec_tb_cmds_split(ovhip_recorder *rec, size_t *n_luma, size_t *n);
+/* The same commands reordered into four classes: luma blocks with a side > 16, luma blocks <= 16x16, chroma
+ * blocks with a side > 16, chroma blocks <= 16x16 (counts[0..3]).  Luma first because with device-derived
+ * chroma scales the chroma commands must run after ovhip_lmcs_scale_launch, which must run after the luma
+ * ones; by size because ovhip_itx_launch_classes gives big and small blocks different workgroup shapes. */
+const ovhip_tb_cmd  *ovhip_rec_tb_cmds_split(ovhip_recorder *rec, size_t counts[4], size_t *n);
 const ovhip_lmcs_region *ovhip_rec_lmcs_regions(const ovhip_recorder *rec, size_t *n);
 const int16_t       *ovhip_rec_coefs(const ovhip_recorder *rec, size_t *n_int16);
 const ovhip_mc_unit *ovhip_rec_mc_units(const ovhip_recorder *rec, size_t *n);
@@ -471,6 +473,11 @@ int  ovhip_pic_download(ovhip_ctx *ctx, const ovhip_pic *pic, uint16_t *y, uint1
 /* Stage launches.  cmds / coefs / units are DEVICE pointers; asynchronous on the ctx stream. */
 int  ovhip_itx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_tb_cmd *d_cmds,
                       uint32_t n_cmds, const int16_t *d_coefs, const int16_t *d_lmcs_scales);
+/* Same, for a command list sorted by ovhip_rec_tb_cmds_split: the first n_large commands may have any size,
+ * the following n_small commands must all be <= 16x16. */
+int  ovhip_itx_launch_classes(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_tb_cmd *d_cmds,
+                              uint32_t n_large, uint32_t n_small, const int16_t *d_coefs,
+                              const int16_t *d_lmcs_scales);
 /* d_regions, d_scales: DEVICE; d_scales[i] receives lmcs_chroma_scale of region i.  luts: HOST. */
 int  ovhip_lmcs_scale_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_lmcs_region *d_regions,
                              uint32_t n_regions, const ovhip_lmcs_luts *luts, int16_t *d_scales);

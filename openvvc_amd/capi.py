@@ -199,7 +199,8 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_rec_ciip_units": (vp, [vp, P(C.c_size_t)]),
         "ovhip_ciip_launch": (C.c_int, [vp, P(Pic), P(Pic), vp, u32]),
         "ovhip_rec_lmcs_regions": (vp, [vp, P(C.c_size_t)]),
-        "ovhip_rec_tb_cmds_split": (vp, [vp, P(C.c_size_t), P(C.c_size_t)]),
+        "ovhip_rec_tb_cmds_split": (vp, [vp, C.c_size_t * 4, P(C.c_size_t)]),
+        "ovhip_itx_launch_classes": (C.c_int, [vp, P(Pic), vp, u32, u32, vp, vp]),
         "ovhip_lmcs_build": (C.c_int, [P(LmcsData), P(LmcsLuts)]),
         "ovhip_lmcs_scale_launch": (C.c_int, [vp, P(Pic), vp, u32, P(LmcsLuts), vp]),
         "ovhip_lmcs_inverse_launch": (C.c_int, [vp, P(Pic), vp]),
@@ -235,7 +236,7 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
 
 EXPORTED_SYMBOLS = [
     "ovhip_abi_version", "ovhip_rec_create", "ovhip_rec_destroy", "ovhip_rec_reset", "ovhip_rec_tu",
-    "ovhip_rec_pu", "ovhip_rec_dbf_ctu", "ovhip_rec_dbf_planes", "ovhip_dbf_launch", "ovhip_sao_launch", "ovhip_alf_launch", "ovhip_rec_tb_cmds", "ovhip_rec_coefs", "ovhip_rec_mc_units", "ovhip_rec_mcx_units", "ovhip_mcx_launch", "ovhip_rec_affine_cu", "ovhip_rec_lmcs_region", "ovhip_rec_ciip", "ovhip_rec_ciip_units", "ovhip_ciip_launch", "ovhip_rec_lmcs_regions", "ovhip_rec_tb_cmds_split", "ovhip_lmcs_build", "ovhip_lmcs_scale_launch", "ovhip_lmcs_inverse_launch", "ovhip_rec_aff_units", "ovhip_rec_aff_side", "ovhip_mca_launch", "ovhip_ctx_create",
+    "ovhip_rec_pu", "ovhip_rec_dbf_ctu", "ovhip_rec_dbf_planes", "ovhip_dbf_launch", "ovhip_sao_launch", "ovhip_alf_launch", "ovhip_rec_tb_cmds", "ovhip_rec_coefs", "ovhip_rec_mc_units", "ovhip_rec_mcx_units", "ovhip_mcx_launch", "ovhip_rec_affine_cu", "ovhip_rec_lmcs_region", "ovhip_rec_ciip", "ovhip_rec_ciip_units", "ovhip_ciip_launch", "ovhip_rec_lmcs_regions", "ovhip_rec_tb_cmds_split", "ovhip_itx_launch_classes", "ovhip_lmcs_build", "ovhip_lmcs_scale_launch", "ovhip_lmcs_inverse_launch", "ovhip_rec_aff_units", "ovhip_rec_aff_side", "ovhip_mca_launch", "ovhip_ctx_create",
     "ovhip_ctx_destroy", "ovhip_ctx_sync", "ovhip_last_error", "ovhip_ctx_stream", "ovhip_malloc",
     "ovhip_free", "ovhip_h2d", "ovhip_d2h", "ovhip_pic_alloc", "ovhip_pic_free", "ovhip_pic_upload",
     "ovhip_pic_download", "ovhip_itx_launch", "ovhip_mc_launch",
@@ -346,13 +347,13 @@ class Recorder:
         return self._arr(self.lib.ovhip_rec_lmcs_regions, LMCS_REGION_DTYPE)
 
     def tb_cmds_split(self):
-        """(commands reordered luma first, number of luma commands)."""
-        nl, n = C.c_size_t(), C.c_size_t()
-        p = self.lib.ovhip_rec_tb_cmds_split(self.h, C.byref(nl), C.byref(n))
+        """(commands reordered [luma > 16, luma <= 16x16, chroma > 16, chroma <= 16x16], the four counts)."""
+        counts, n = (C.c_size_t * 4)(), C.c_size_t()
+        p = self.lib.ovhip_rec_tb_cmds_split(self.h, counts, C.byref(n))
         if not n.value:
-            return np.zeros(0, TB_CMD_DTYPE), 0
+            return np.zeros(0, TB_CMD_DTYPE), (0, 0, 0, 0)
         buf = (C.c_char * (n.value * TB_CMD_DTYPE.itemsize)).from_address(p)
-        return np.frombuffer(buf, dtype=TB_CMD_DTYPE).copy(), nl.value
+        return np.frombuffer(buf, dtype=TB_CMD_DTYPE).copy(), tuple(int(c) for c in counts)
 
     def aff_units(self) -> np.ndarray:
         return self._arr(self.lib.ovhip_rec_aff_units, AFF_UNIT_DTYPE)

@@ -90,7 +90,7 @@ struct ResidualSink {
     int scale;
 };
 
-template <int IB, bool FINAL>
+template <int IB, bool FINAL, int NT>
 __device__ __forceinline__ void tr_pass_lds(const int16_t *src, int sstride, const int8_t *mat, int log2n,
                                              int kmax, int lines, int shift, int16_t *dst, int lane,
                                              const ResidualSink &sink)
@@ -98,7 +98,7 @@ __device__ __forceinline__ void tr_pass_lds(const int16_t *src, int sstride, con
     const int n = 1 << log2n;
     const int ntask = (lines / IB) << log2n;
     const int rnd = 1 << (shift - 1);
-    for (int t = lane; t < ntask; t += 64) {
+    for (int t = lane; t < ntask; t += NT) {
         const int j = t & (n - 1);
         const int i0 = (t >> log2n) * IB;
         int acc[IB];
@@ -142,14 +142,19 @@ __device__ __forceinline__ void tr_pass_lds(const int16_t *src, int sstride, con
     }
 }
 
-__global__ __launch_bounds__(64) void k_itx(ovhip_pic pic, const ovhip_tb_cmd *__restrict__ cmds,
+// Two instantiations: <6, 256> any block up to 64x64, four waves per block (a 64x64 block is ~200k MACs: one
+// wave alone would be the tail of the launch); <4, 64> blocks up to 16x16, one wave and 1.5 KB of LDS per
+// block so that 32 blocks are resident per CU and hide each other's load latency.
+template <int ML2, int NT>
+__global__ __launch_bounds__(NT) void k_itx(ovhip_pic pic, const ovhip_tb_cmd *__restrict__ cmds,
                                              uint32_t n_cmds, const int16_t *__restrict__ arena,
                                              const int16_t *__restrict__ lmcs_scales, int ablate)
 {
-    __shared__ __attribute__((aligned(16))) int16_t s_coef[32 * 32];
-    __shared__ __attribute__((aligned(16))) int16_t s_tmp[32 * 64];
-    __shared__ __attribute__((aligned(16))) int8_t s_mv[32 * 64];
-    __shared__ __attribute__((aligned(16))) int8_t s_mh[32 * 64];
+    constexpr int MC = ML2 > 5 ? 32 : (1 << ML2);                      // stored coefficient extent per dimension
+    __shared__ __attribute__((aligned(16))) int16_t s_coef[MC * MC];
+    __shared__ __attribute__((aligned(16))) int16_t s_tmp[MC << ML2];
+    __shared__ __attribute__((aligned(16))) int8_t s_mv[MC << ML2];
+    __shared__ __attribute__((aligned(16))) int8_t s_mh[MC << ML2];
 
     const int lane = threadIdx.x;
     for (uint32_t bid = blockIdx.x; bid < n_cmds; bid += gridDim.x, __syncthreads()) {   // resident grid, see OV_RESIDENT_WAVES
@@ -167,14 +172,14 @@ __global__ __launch_bounds__(64) void k_itx(ovhip_pic pic, const ovhip_tb_cmd *_
     if (kind == OVHIP_TB_TR && !(ablate & 1)) {
         const int8_t *mv = tr_matrix(c.tr_v, log2_h);
         const int8_t *mh = tr_matrix(c.tr_h, log2_w);
-        for (int i = lane; i < (kv << log2_h); i += 64) s_mv[i] = mv[i];
-        for (int i = lane; i < (kh << log2_w); i += 64) s_mh[i] = mh[i];
+        for (int i = lane; i < (kv << log2_h); i += NT) s_mv[i] = mv[i];
+        for (int i = lane; i < (kh << log2_w); i += NT) s_mh[i] = mh[i];
     }
 
     // ---- K1: de-scan + de-quantise into LDS raster [ch][cw] ----
     if (ablate & 2) {
     } else if (raster) {
-        for (int i = lane; i < tb_w * tb_h; i += 64)
+        for (int i = lane; i < tb_w * tb_h; i += NT)
             s_coef[i] = kind == OVHIP_TB_TS_RAW ? src[i] : (int16_t)dequant1(src[i], c.dq_scale, c.dq_shift, c.dq_neg);
     } else {
         const int nx = cw >> 2, ny = ch >> 2;
@@ -259,13 +264,13 @@ __global__ __launch_bounds__(64) void k_itx(ovhip_pic pic, const ovhip_tb_cmd *_
         nb_row = min(nb_row, tb_w);
         const int k1 = min(nb_col, kv);
         // ---- K3: vertical pass (shift 7): tmp[i*tb_h + j], i = coefficient column < nb_row ----
-        if (nb_row & 3) tr_pass_lds<2, false>(s_coef, cw, s_mv, log2_h, k1, nb_row, 7, s_tmp, lane, sink);
-        else            tr_pass_lds<4, false>(s_coef, cw, s_mv, log2_h, k1, nb_row, 7, s_tmp, lane, sink);
+        if (nb_row & 3) tr_pass_lds<2, false, NT>(s_coef, cw, s_mv, log2_h, k1, nb_row, 7, s_tmp, lane, sink);
+        else            tr_pass_lds<4, false, NT>(s_coef, cw, s_mv, log2_h, k1, nb_row, 7, s_tmp, lane, sink);
         __syncthreads();
         // ---- horizontal pass (shift 20 - bitdepth) fused with K4; tmp rows >= nb_row are zero ----
         const int k2 = min(nb_row, kh);
-        if (tb_h & 3) tr_pass_lds<2, true>(s_tmp, tb_h, s_mh, log2_w, k2, tb_h, 20 - OV_BD, nullptr, lane, sink);
-        else          tr_pass_lds<4, true>(s_tmp, tb_h, s_mh, log2_w, k2, tb_h, 20 - OV_BD, nullptr, lane, sink);
+        if (tb_h & 3) tr_pass_lds<2, true, NT>(s_tmp, tb_h, s_mh, log2_w, k2, tb_h, 20 - OV_BD, nullptr, lane, sink);
+        else          tr_pass_lds<4, true, NT>(s_tmp, tb_h, s_mh, log2_w, k2, tb_h, 20 - OV_BD, nullptr, lane, sink);
         continue;
     }
 
@@ -274,11 +279,11 @@ __global__ __launch_bounds__(64) void k_itx(ovhip_pic pic, const ovhip_tb_cmd *_
     // inverse_dct_ii_dc, rcn_transform.c:576-598
     const int flat_val = ov_clip16(((((int)s_coef[0] + 1) >> 1) + (1 << (14 - OV_BD - 1))) >> (14 - OV_BD));
     // 4 samples per lane and iteration; all frame reads of an iteration are issued before the first store
-    for (int i0 = lane; i0 < tb_w * tb_h; i0 += 256) {
+    for (int i0 = lane; i0 < tb_w * tb_h; i0 += 4 * NT) {
         int old[4], old2[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int i = i0 + 64 * q;
+            const int i = i0 + NT * q;
             if (i < tb_w * tb_h) {
                 const int x = i & (tb_w - 1), y = i >> log2_w;
                 old[q] = sink.dst[y * sink.stride + x];
@@ -287,7 +292,7 @@ __global__ __launch_bounds__(64) void k_itx(ovhip_pic pic, const ovhip_tb_cmd *_
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int i = i0 + 64 * q;
+            const int i = i0 + NT * q;
             if (i < tb_w * tb_h) {
                 const int x = i & (tb_w - 1), y = i >> log2_w;
                 const int r = flat ? flat_val : (int)s_coef[y * tb_w + x];   // TS blocks are <= 32 wide: raster stride tb_w
@@ -301,17 +306,38 @@ __global__ __launch_bounds__(64) void k_itx(ovhip_pic pic, const ovhip_tb_cmd *_
 
 } // namespace
 
+static int itx_ablate()
+{
+    static int cfg_ablate = -1;
+    if (cfg_ablate < 0) { const char *a = getenv("OVHIP_ITX_ABLATE"); cfg_ablate = a ? atoi(a) : 0; }   // profiling knob
+    return cfg_ablate;
+}
+
+extern "C" int ovhip_itx_launch_classes(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_tb_cmd *d_cmds,
+                                        uint32_t n_large, uint32_t n_small, const int16_t *d_coefs,
+                                        const int16_t *d_lmcs_scales)
+{
+    if (!ctx || !dst) return OVHIP_EINVAL;
+    if (!n_large && !n_small) return OVHIP_OK;
+    if (!d_cmds || !d_coefs) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_itx_launch: null buffer", hipSuccess);
+    // one workgroup per TB measured faster than a resident grid-stride grid (79 vs 119 us at 4K): the loop form
+    // stays for grids capped by the caller, the default launches one workgroup per command.  Large blocks go
+    // first: they are the long jobs.
+    if (n_large) {
+        hipLaunchKernelGGL((k_itx<6, 256>), dim3(n_large), dim3(256), 0, ctx->stream, *dst, d_cmds, n_large, d_coefs,
+                           d_lmcs_scales, itx_ablate());
+        OV_LAUNCH_CHECK(ctx, "k_itx<6,256>");
+    }
+    if (n_small) {
+        hipLaunchKernelGGL((k_itx<4, 64>), dim3(n_small), dim3(64), 0, ctx->stream, *dst, d_cmds + n_large, n_small, d_coefs,
+                           d_lmcs_scales, itx_ablate());
+        OV_LAUNCH_CHECK(ctx, "k_itx<4,64>");
+    }
+    return OVHIP_OK;
+}
+
 extern "C" int ovhip_itx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_tb_cmd *d_cmds,
                                 uint32_t n_cmds, const int16_t *d_coefs, const int16_t *d_lmcs_scales)
 {
-    if (!ctx || !dst) return OVHIP_EINVAL;
-    if (!n_cmds) return OVHIP_OK;
-    if (!d_cmds || !d_coefs) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_itx_launch: null buffer", hipSuccess);
-    // one single-wave workgroup per TB measured faster than a resident grid-stride grid (79 vs 119 us at 4K):
-    // the loop form stays for grids capped by the caller, the default launches n_cmds workgroups
-    static int cfg_ablate = -1;
-    if (cfg_ablate < 0) { const char *a = getenv("OVHIP_ITX_ABLATE"); cfg_ablate = a ? atoi(a) : 0; }   // profiling knob
-    hipLaunchKernelGGL(k_itx, dim3(n_cmds), dim3(64), 0, ctx->stream, *dst, d_cmds, n_cmds, d_coefs, d_lmcs_scales, cfg_ablate);
-    OV_LAUNCH_CHECK(ctx, "k_itx");
-    return OVHIP_OK;
+    return ovhip_itx_launch_classes(ctx, dst, d_cmds, n_cmds, 0, d_coefs, d_lmcs_scales);
 }

@@ -657,18 +657,18 @@ ovhip_rec_lmcs_region(ovhip_recorder *r, int32_t x0, int32_t y0, uint32_t abv_ma
 const ovhip_lmcs_region *ovhip_rec_lmcs_regions(const ovhip_recorder *r, size_t *n) { *n = r->n_reg; return r->reg; }
 
 const ovhip_tb_cmd *
-ovhip_rec_tb_cmds_split(ovhip_recorder *r, size_t *n_luma, size_t *n)
+ovhip_rec_tb_cmds_split(ovhip_recorder *r, size_t counts[4], size_t *n)
 {
-    *n = r->n_tb; *n_luma = 0;
+    size_t start[4], k;
+    *n = r->n_tb;
+    counts[0] = counts[1] = counts[2] = counts[3] = 0;
     if (!r->n_tb) return r->tb;
     if (grow((void **)&r->tb_split, &r->cap_split, r->n_tb, sizeof(ovhip_tb_cmd))) { *n = 0; return NULL; }
-    size_t nl = 0, k;
-    for (size_t i = 0; i < r->n_tb; ++i) nl += r->tb[i].plane == 0;
-    k = nl; *n_luma = nl; nl = 0;
-    for (size_t i = 0; i < r->n_tb; ++i) {
-        if (r->tb[i].plane == 0) r->tb_split[nl++] = r->tb[i];
-        else                     r->tb_split[k++] = r->tb[i];
-    }
+#define TB_CLASS(c) (((c)->plane != 0) * 2 + ((c)->log2_w <= 4 && (c)->log2_h <= 4))
+    for (size_t i = 0; i < r->n_tb; ++i) counts[TB_CLASS(&r->tb[i])]++;
+    for (k = 0, start[0] = 0; k < 3; ++k) start[k + 1] = start[k] + counts[k];
+    for (size_t i = 0; i < r->n_tb; ++i) r->tb_split[start[TB_CLASS(&r->tb[i])]++] = r->tb[i];
+#undef TB_CLASS
     return r->tb_split;
 }
 

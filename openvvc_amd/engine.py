@@ -77,6 +77,13 @@ class Context:
         self._chk(self.lib.ovhip_itx_launch(self.h, C.byref(dst.s), ptr, n, coefs.ptr,
                                             lmcs_scales.ptr if lmcs_scales else None), "itx_launch")
 
+    def itx_classes(self, dst: "DevPic", cmds: "DevBuf", coefs: "DevBuf", first: int, n_large: int, n_small: int,
+                    lmcs_scales: "DevBuf | None" = None):
+        """Commands [first, first + n_large) of any size, then n_small commands all <= 16x16 (recorder's split order)."""
+        ptr = C.c_void_p(cmds.ptr.value + first * capi.TB_CMD_DTYPE.itemsize) if first else cmds.ptr
+        self._chk(self.lib.ovhip_itx_launch_classes(self.h, C.byref(dst.s), ptr, n_large, n_small, coefs.ptr,
+                                                    lmcs_scales.ptr if lmcs_scales else None), "itx_launch_classes")
+
     def lmcs_scale(self, pic: "DevPic", regions: "DevBuf", luts: "capi.LmcsLuts", scales: "DevBuf", n: int | None = None):
         n = regions.count if n is None else n
         self._chk(self.lib.ovhip_lmcs_scale_launch(self.h, C.byref(pic.s), regions.ptr, n, C.byref(luts), scales.ptr),
@@ -244,7 +251,7 @@ class ResidentPicture:
         self.lmcs_bwd = up(wl.lmcs_bwd)
         self.lmcs_regions = up(wl.lmcs_regions)
         self.lmcs_scales = self._keep(ctx.alloc(2 * len(wl.lmcs_regions))) if self.lmcs_regions else None
-        self.n_luma = wl.n_luma_cmds if self.lmcs is not None else len(wl.tb_cmds)
+        self.n_luma = wl.n_luma_cmds
 
     def _keep(self, b):
         self.bufs.append(b)
@@ -267,13 +274,15 @@ class ResidentPicture:
             if self.ciip_units:
                 c.ciip(self.dst, self.intra, self.ciip_units)
         elif name == "itx_l":
-            c.itx(self.dst, self.tb_cmds, self.coefs, n=self.n_luma)
+            k = self.wl.tb_classes
+            c.itx_classes(self.dst, self.tb_cmds, self.coefs, 0, k[0], k[1])
         elif name == "lmcs_scale":
             if self.lmcs_regions:
                 c.lmcs_scale(self.dst, self.lmcs_regions, self.lmcs, self.lmcs_scales)
         elif name == "itx_c":
-            if self.n_luma < self.tb_cmds.count:
-                c.itx(self.dst, self.tb_cmds, self.coefs, first=self.n_luma, lmcs_scales=self.lmcs_scales)
+            k = self.wl.tb_classes
+            if k[2] + k[3]:
+                c.itx_classes(self.dst, self.tb_cmds, self.coefs, k[0] + k[1], k[2], k[3], self.lmcs_scales)
         elif name == "lmcs_inv":
             if self.lmcs is not None:
                 c.lmcs_inverse(self.dst, self.lmcs_bwd)

@@ -89,6 +89,7 @@ class Workload:
     tb_cmds: np.ndarray             # capi.TB_CMD_DTYPE, luma commands first (n_luma_cmds), then chroma
     coefs: np.ndarray               # int16 arena
     n_luma_cmds: int = 0
+    tb_classes: tuple = (0, 0, 0, 0)  # counts: luma > 16, luma <= 16x16, chroma > 16, chroma <= 16x16
     mcx_units: np.ndarray = None    # BDOF / DMVR units
     aff_units: np.ndarray = None    # affine (+PROF) units and their side arena
     aff_side: np.ndarray = None
@@ -328,8 +329,9 @@ def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6
                 rec.tu(st, td)
                 n_tu += 1
 
-    cmds, n_luma = rec.tb_cmds_split()
-    wl = Workload(w, h, seed, refs, pocs, cus, rec.mc_units(), cmds, rec.coefs(), n_luma_cmds=n_luma)
+    cmds, classes = rec.tb_cmds_split()
+    n_luma = classes[0] + classes[1]
+    wl = Workload(w, h, seed, refs, pocs, cus, rec.mc_units(), cmds, rec.coefs(), n_luma_cmds=n_luma, tb_classes=classes)
     wl.mcx_units, wl.aff_units, wl.aff_side, wl.ciip_units = rec.mcx_units(), rec.aff_units(), rec.aff_side(), rec.ciip_units()
     if len(wl.ciip_units):
         wl.intra = random_picture(rs, w, h)
