@@ -146,6 +146,197 @@ __global__ __launch_bounds__(64) void k_mc(ovhip_pic dst, RefTable refs, const o
     }
 }
 
+// =====================================================================================================
+// k_mc2: same arithmetic as k_mc, work laid out so that the wave's 64 lanes stay busy for every unit
+// shape (SQ counters showed k_mc bound by VALU issue at ~57 % of the chip with most passes running at
+// 10-50 % lane occupancy for 8x8 / 16x8 units):
+//   * horizontal pass: ONE loop over the tasks of both lists (luma), one over both lists x both chroma planes
+//   * vertical pass: lane = (column, group of NOUT rows) with NOUT = max(1, w*h/64) so that 64 lanes cover
+//     the whole block once; each lane runs both lists for its samples and combines in registers; chroma:
+//     both planes in the same pass
+// =====================================================================================================
+template <int NT>
+__device__ __forceinline__ void h_task(const uint16_t *wrow, int off, int x0, const int tp[NT / 2], bool ident, int16_t *ht,
+                                       int htstride, int r, int nout)
+{
+    int d[NT / 2 + 2], out[4];
+    if (ident) {
+        const uint16_t *sp = wrow + off + x0 + NT / 2 - 1;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) out[o] = (int)sp[o] << 6;
+    } else {
+        load_row_at<NT>(wrow, off + x0, d);
+        fir4<NT>(d, tp, out);
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+        if (o < nout) ht[(x0 + o) * htstride + r] = (int16_t)(out[o] >> (OV_BD - 8));
+}
+
+template <int NT, int NOUT>
+__device__ __forceinline__ void v_outputs(const int16_t *col, int s0, const int tp[NT / 2], int P[NOUT])
+{
+    int d[(NT + NOUT) / 2];
+    load_span<NT, NOUT>(col, s0, d);
+    firn<NT, NOUT>(d, tp, P);
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) P[o] >>= 6;
+}
+
+template <int NOUT>
+__device__ __forceinline__ void luma_finish(const ovhip_mc_unit &u, const ovhip_pic &dst, const int16_t *s_hl, const int tv[2][4],
+                                            int lane, int log2w, const uint16_t *__restrict__ lmcs_fwd)
+{
+    const int w = 1 << log2w;
+    const int x = lane & (w - 1), yg = lane >> log2w, y0 = yg * NOUT;
+    if (y0 >= u.h) return;
+    int P[2][NOUT];
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) P[l][o] = 0;
+        if (u.dir & (1 << l)) v_outputs<8, NOUT>(s_hl + l * 16 * HT_STRIDE + x * HT_STRIDE, y0, tv[l], P[l]);
+    }
+    uint16_t *d = dst.y + (u.y + y0) * dst.stride_y + u.x + x;
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) {
+        int v = (u.flags & OVHIP_MC_GPM) ? mc_gpm(u.aux, x, y0 + j, P[0][j], P[1][j]) : mc_combine(u, P[0][j], P[1][j]);
+        if ((u.flags & OVHIP_MC_LMCS) && lmcs_fwd) v = lmcs_fwd[v];
+        d[j * dst.stride_y] = (uint16_t)v;
+    }
+}
+
+template <int NOUT>
+__device__ __forceinline__ void chroma_finish(const ovhip_mc_unit &u, const ovhip_pic &dst, const int16_t *s_hc, const int tv[2][2],
+                                              int lane, int log2wc, int hc)
+{
+    const int wc = 1 << log2wc;
+    const int per_plane = (wc * hc) / NOUT;                   // lanes per plane (power of two, <= 32)
+    const int plane = lane >= per_plane, ll = lane - plane * per_plane;
+    if (lane >= 2 * per_plane) return;
+    const int x = ll & (wc - 1), y0 = (ll >> log2wc) * NOUT;
+    int P[2][NOUT];
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) P[l][o] = 0;
+        if (u.dir & (1 << l)) v_outputs<4, NOUT>(s_hc + (plane * 2 + l) * 8 * CHT_STRIDE + x * CHT_STRIDE, y0, tv[l], P[l]);
+    }
+    uint16_t *d = (plane ? dst.cr : dst.cb) + ((u.y >> 1) + y0) * dst.stride_c + (u.x >> 1) + x;
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j)
+        d[j * dst.stride_c] = (uint16_t)((u.flags & OVHIP_MC_GPM) ? mc_gpm(u.aux, 2 * x, 2 * (y0 + j), P[0][j], P[1][j])
+                                                                  : mc_combine(u, P[0][j], P[1][j]));
+}
+
+__global__ __launch_bounds__(64) void k_mc2(ovhip_pic dst, RefTable refs, const ovhip_mc_unit *__restrict__ units,
+                                             uint32_t n_units, const uint16_t *__restrict__ lmcs_fwd, int xcd)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t s_wl[2 * LUMA_WIN + 8];       // luma windows, list 0 / 1 (+ dword over-read slack)
+    __shared__ __attribute__((aligned(16))) uint16_t s_wc[4 * CHR_WIN + 8];        // chroma windows [plane * 2 + list]
+    __shared__ __attribute__((aligned(16))) int16_t  s_hl[2 * 16 * HT_STRIDE + 8]; // transposed H-pass tiles [list]
+    __shared__ __attribute__((aligned(16))) int16_t  s_hc[4 * 8 * CHT_STRIDE + 8]; // [plane * 2 + list]
+
+    const int lane = threadIdx.x;
+    for (uint32_t wg = blockIdx.x; wg < n_units; wg += gridDim.x) {
+    const uint32_t bid = xcd ? ov_xcd_slot(wg, n_units) : wg;
+    const ovhip_mc_unit u = units[bid];
+
+    const bool do_l = !(u.flags & OVHIP_MC_NO_LUMA), do_c = !(u.flags & OVHIP_MC_NO_CHROMA);
+    const int w = u.w, h = u.h, wc = w >> 1, hc = h >> 1;
+    const int log2w = 31 - __clz(w), log2wc = log2w - 1;
+    const int nl = u.dir == 3 ? 2 : 1, l0 = u.dir == 2 ? 1 : 0;      // lists present: l0 .. l0 + nl - 1
+
+    // ---- windows: issue all loads, then park ----
+    LumaStage sl[2];
+    ChromaStage sc[2][2];
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        if (!(u.dir & (1 << l))) continue;
+        const ovhip_pic &rp = refs.p[l ? u.ref1 : u.ref0];
+        const int mvx = l ? u.mv1x : u.mv0x, mvy = l ? u.mv1y : u.mv0y;
+        if (do_l) sl[l].issue(rp.y, rp.stride_y, rp.w, rp.h, u.x + (mvx >> 4) - 3, u.y + (mvy >> 4) - 3, w + 7, h + 7, lane, s_wl + l * LUMA_WIN, WIN_STRIDE);
+        if (do_c) {
+            const int px = (u.x >> 1) + (mvx >> 5) - 1, py = (u.y >> 1) + (mvy >> 5) - 1;
+            sc[0][l].issue(rp.cb, rp.stride_c, rp.w >> 1, rp.h >> 1, px, py, wc + 3, hc + 3, lane, s_wc + l * CHR_WIN, CWIN_STRIDE);
+            sc[1][l].issue(rp.cr, rp.stride_c, rp.w >> 1, rp.h >> 1, px, py, wc + 3, hc + 3, lane, s_wc + (2 + l) * CHR_WIN, CWIN_STRIDE);
+        }
+    }
+    int offl[2] = { 0, 0 }, offc[2][2] = { { 0, 0 }, { 0, 0 } };
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        if (!(u.dir & (1 << l))) continue;
+        if (do_l) { sl[l].park(s_wl + l * LUMA_WIN, WIN_STRIDE, w + 7, h + 7, lane); offl[l] = sl[l].off; }
+        if (do_c) {
+            sc[0][l].park(s_wc + l * CHR_WIN, CWIN_STRIDE, wc + 3, hc + 3, lane);       offc[0][l] = sc[0][l].off;
+            sc[1][l].park(s_wc + (2 + l) * CHR_WIN, CWIN_STRIDE, wc + 3, hc + 3, lane); offc[1][l] = sc[1][l].off;
+        }
+    }
+    // ---- filter taps of both lists (wave-uniform) ----
+    int thl[2][4], tvl[2][4], thc[2][2], tvc[2][2];
+    bool identl[2], identc[2];
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        const int mvx = l ? u.mv1x : u.mv0x, mvy = l ? u.mv1y : u.mv0y;
+        int fx = mvx & 15, fy = mvy & 15;
+        const int8_t *fh, *fv;
+        if (u.flags & OVHIP_MC_FILT_4x4) { fh = ovt_mc_luma4[fx]; fv = ovt_mc_luma4[fy]; }
+        else {
+            if (u.flags & OVHIP_MC_HPEL_FILT) { if (fx == 8) fx = 16; if (fy == 8) fy = 16; }
+            fh = ovt_mc_luma[fx]; fv = ovt_mc_luma[fy];
+        }
+        pack_taps<8>(fh, thl[l]); pack_taps<8>(fv, tvl[l]);
+        pack_taps<4>(ovt_mc_chroma[mvx & 31], thc[l]); pack_taps<4>(ovt_mc_chroma[mvy & 31], tvc[l]);
+        identl[l] = fx == 0; identc[l] = (mvx & 31) == 0;
+    }
+    __syncthreads();
+
+    // ---- horizontal passes: one task = one window row x 4 outputs ----
+    if (do_l) {
+        const int log2seg = log2w > 2 ? log2w - 2 : 0, nout = w < 4 ? w : 4;
+        const int TY = (h + 7) << log2seg;
+        for (int t = lane; t < nl * TY; t += 64) {
+            const int li = t >= TY, l = l0 + li, tt = t - li * TY;
+            const int r = tt >> log2seg, x0 = (tt & ((1 << log2seg) - 1)) << 2;
+            int tp[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) tp[m] = l ? thl[1][m] : thl[0][m];
+            h_task<8>(s_wl + l * LUMA_WIN + r * WIN_STRIDE, l ? offl[1] : offl[0], x0, tp, l ? identl[1] : identl[0],
+                      s_hl + l * 16 * HT_STRIDE, HT_STRIDE, r, nout);
+        }
+    }
+    if (do_c) {
+        const int log2seg = log2wc > 2 ? log2wc - 2 : 0, nout = wc < 4 ? wc : 4;
+        const int TC = (hc + 3) << log2seg;
+        for (int t = lane; t < 2 * nl * TC; t += 64) {
+            const int qi = (t >= TC) + (t >= 2 * TC) + (t >= 3 * TC), tt = t - qi * TC;
+            const int plane = nl == 2 ? qi >> 1 : qi, l = l0 + (nl == 2 ? (qi & 1) : 0);
+            const int r = tt >> log2seg, x0 = (tt & ((1 << log2seg) - 1)) << 2;
+            int tp[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) tp[m] = l ? thc[1][m] : thc[0][m];
+            const int off = plane ? (l ? offc[1][1] : offc[1][0]) : (l ? offc[0][1] : offc[0][0]);
+            h_task<4>(s_wc + (plane * 2 + l) * CHR_WIN + r * CWIN_STRIDE, off, x0, tp, l ? identc[1] : identc[0],
+                      s_hc + (plane * 2 + l) * 8 * CHT_STRIDE, CHT_STRIDE, r, nout);
+        }
+    }
+    __syncthreads();
+
+    // ---- vertical passes + combine + store: every lane finishes NOUT samples of one column ----
+    if (do_l) {
+        const int npix = w * h;
+        if (npix >= 256)      luma_finish<4>(u, dst, s_hl, tvl, lane, log2w, lmcs_fwd);
+        else if (npix >= 128) luma_finish<2>(u, dst, s_hl, tvl, lane, log2w, lmcs_fwd);
+        else                  luma_finish<1>(u, dst, s_hl, tvl, lane, log2w, lmcs_fwd);
+    }
+    if (do_c) {
+        if (wc * hc >= 64) chroma_finish<2>(u, dst, s_hc, tvc, lane, log2wc, hc);
+        else               chroma_finish<1>(u, dst, s_hc, tvc, lane, log2wc, hc);
+    }
+    __syncthreads();          // LDS tiles are reused by the next unit
+    }
+}
+
 // ---- K10: CIIP blend.  One 256-thread workgroup per CU: dst = (intra * wt + inter * (4 - wt) + 2) >> 2
 // (put_weighted_ciip_pixels rcn_mc.c:1611-1628, rcn_ciip_weighted_sum rcn_inter.c:2968-3009). ----
 __global__ __launch_bounds__(256) void k_ciip(ovhip_pic dst, ovhip_pic intra, const ovhip_ciip_unit *__restrict__ units, uint32_t n)
@@ -192,15 +383,22 @@ extern "C" int ovhip_mc_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip
     memset(&t, 0, sizeof(t));
     for (uint32_t i = 0; i < n_refs; ++i) t.p[i] = refs[i];
     for (uint32_t i = n_refs; i < MC_MAX_REFS; ++i) t.p[i] = refs[0];
-    static int cfg_grid = -1, cfg_ablate = 0, cfg_xcd = 1;
+    static int cfg_grid = -1, cfg_ablate = 0, cfg_xcd = 1, cfg_ver = 2;
     if (cfg_grid < 0) {                       // developer knobs (profiling experiments only)
         const char *g = getenv("OVHIP_MC_GRID"), *a = getenv("OVHIP_MC_ABLATE"), *x = getenv("OVHIP_MC_XCD");
         cfg_grid = g ? atoi(g) : 0;
         cfg_ablate = a ? atoi(a) : 0;
         cfg_xcd = x ? atoi(x) : 1;
+        const char *v = getenv("OVHIP_MC_KERNEL");          // 1: k_mc (one pass per list / plane), 2: k_mc2 (merged passes)
+        cfg_ver = v ? atoi(v) : 2;
     }
     uint32_t grid = cfg_grid > 0 ? (uint32_t)cfg_grid : n_units;
     if (grid > n_units) grid = n_units;
+    if (cfg_ver == 2 && !cfg_ablate) {
+        hipLaunchKernelGGL(k_mc2, dim3(grid), dim3(64), 0, ctx->stream, *dst, t, d_units, n_units, d_lmcs_fwd_lut, cfg_grid > 0 ? 0 : cfg_xcd);
+        OV_LAUNCH_CHECK(ctx, "k_mc2");
+        return OVHIP_OK;
+    }
     hipLaunchKernelGGL(k_mc, dim3(grid), dim3(64), 0, ctx->stream, *dst, t, d_units, n_units, d_lmcs_fwd_lut, cfg_ablate, cfg_grid > 0 ? 0 : cfg_xcd);
     OV_LAUNCH_CHECK(ctx, "k_mc");
     return OVHIP_OK;

@@ -180,4 +180,40 @@ __device__ __forceinline__ void v_pass(const int16_t *s_ht, int htstride, int lo
 }
 
 
+
+// ---- NOUT (1, 2 or 4) outputs of an NT-tap FIR over packed int16 dwords d[0 .. (NT + NOUT) / 2] (see fir4) ----
+template <int NT, int NOUT>
+__device__ __forceinline__ void firn(const int *d, const int tp[NT / 2], int out[NOUT])
+{
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+        int acc = 0;
+#pragma unroll
+        for (int m = 0; m < NT / 2; ++m) {
+            const int j = (o >> 1) + m;
+            const int v = (o & 1) ? (int)__builtin_amdgcn_alignbit((uint32_t)d[j + 1], (uint32_t)d[j], 16) : d[j];
+            acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, v), __builtin_bit_cast(short2v, tp[m]), acc, false);
+        }
+        out[o] = acc;
+    }
+}
+
+// NT + NOUT - 1 samples starting at SAMPLE index s0 of a dword-aligned row, as packed dwords (last one may be half used)
+template <int NT, int NOUT>
+__device__ __forceinline__ void load_span(const int16_t *row, int s0, int d[(NT + NOUT) / 2])
+{
+    constexpr int ND = (NT + NOUT) / 2;                // dwords covering NT + NOUT - 1 samples from an even start
+    const int *q = reinterpret_cast<const int *>(row) + (s0 >> 1);
+    int D[ND + 1];
+#pragma unroll
+    for (int j = 0; j < ND + 1; ++j) D[j] = q[j];
+    if (s0 & 1) {
+#pragma unroll
+        for (int j = 0; j < ND; ++j) d[j] = (int)__builtin_amdgcn_alignbit((uint32_t)D[j + 1], (uint32_t)D[j], 16);
+    } else {
+#pragma unroll
+        for (int j = 0; j < ND; ++j) d[j] = D[j];
+    }
+}
+
 } // namespace
