@@ -65,6 +65,23 @@ __device__ __forceinline__ int div_for_maxq7(int num, int den)
     return sign ? -q : q;
 }
 
+template <int NOUT>
+__device__ __forceinline__ void chroma_avg(const ovhip_mc_unit &u, const ovhip_pic &dst, const int16_t *s_hc, const int tv[2][2],
+                                           int lane, int log2wc, int hc)
+{
+    const int wc = 1 << log2wc;
+    const int per_plane = (wc * hc) / NOUT;
+    const int plane = lane >= per_plane, ll = lane - plane * per_plane;
+    if (lane >= 2 * per_plane) return;
+    const int x = ll & (wc - 1), y0 = (ll >> log2wc) * NOUT;
+    int P[2][NOUT];
+#pragma unroll
+    for (int l = 0; l < 2; ++l) v_outputs<4, NOUT>(s_hc + (plane * 2 + l) * 8 * CHT_STRIDE + x * CHT_STRIDE, y0, tv[l], P[l]);
+    uint16_t *d = (plane ? dst.cr : dst.cb) + ((u.y >> 1) + y0) * dst.stride_c + (u.x >> 1) + x;
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) d[j * dst.stride_c] = (uint16_t)ov_clip_bd((P[0][j] + P[1][j] + 16) >> 5);
+}
+
 __global__ __launch_bounds__(64) void k_mcx(ovhip_pic dst, RefTable refs, const ovhip_mc_unit *__restrict__ units,
                                              uint32_t n_units, const uint16_t *__restrict__ lmcs_fwd, int32_t *__restrict__ mv_out)
 {
@@ -197,24 +214,48 @@ __global__ __launch_bounds__(64) void k_mcx(ovhip_pic dst, RefTable refs, const 
         *reinterpret_cast<int4 *>(mv_out + 4 * (size_t)bid) = o;
     }
 
-    // ---- 3. horizontal passes at the refined position ----
-    const int8_t *fvl[2], *fvc[2];
-    int ldx[2], ldy[2], ext[2][2];
+    // ---- 3. horizontal passes at the refined position: both lists (and both chroma planes) in one task loop ----
+    const int8_t *fvl[2];
+    int ldx[2], ldy[2], cdx[2], cdy[2], ext[2][2];
+    int thl[2][4], thc[2][2], tvc[2][2];
+    bool identl[2], identc[2];
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
         int fx = mv[l][0] & 15, fy = mv[l][1] & 15;
         if (u.flags & OVHIP_MC_HPEL_FILT) { if (fx == 8) fx = 16; if (fy == 8) fy = 16; }
         ext[l][0] = fx >= 8; ext[l][1] = fy >= 8;
         fvl[l] = ovt_mc_luma[fy];
-        fvc[l] = ovt_mc_chroma[mv[l][1] & 31];
         ldx[l] = (mv[l][0] >> 4) - (ini[l][0] >> 4); ldy[l] = (mv[l][1] >> 4) - (ini[l][1] >> 4);
-        const int cdx = (mv[l][0] >> 5) - (ini[l][0] >> 5), cdy = (mv[l][1] >> 5) - (ini[l][1] >> 5);
-        if (do_l) h_pass<8>(s_wl[l] + (2 + ldy[l]) * XWIN_STRIDE, XWIN_STRIDE, 4 + sl[l].off + ldx[l], s_hl[l], HT_STRIDE, log2w, h + 7, ovt_mc_luma[fx], lane);
-        if (do_c) {
+        cdx[l] = (mv[l][0] >> 5) - (ini[l][0] >> 5); cdy[l] = (mv[l][1] >> 5) - (ini[l][1] >> 5);
+        pack_taps<8>(ovt_mc_luma[fx], thl[l]);
+        pack_taps<4>(ovt_mc_chroma[mv[l][0] & 31], thc[l]); pack_taps<4>(ovt_mc_chroma[mv[l][1] & 31], tvc[l]);
+        identl[l] = fx == 0; identc[l] = (mv[l][0] & 31) == 0;
+    }
+    if (do_l) {
+        const int log2seg = log2w - 2, TY = (h + 7) << log2seg;
+        for (int t = lane; t < 2 * TY; t += 64) {
+            const int l = t >= TY, tt = t - l * TY;
+            const int r = tt >> log2seg, x0 = (tt & ((1 << log2seg) - 1)) << 2;
+            int tp[4];
 #pragma unroll
-            for (int cc = 0; cc < 2; ++cc)
-                h_pass<4>(s_wc[cc][l] + (2 + cdy) * XCWIN_STRIDE, XCWIN_STRIDE, 4 + sc[cc][l].off + cdx, s_hc[cc][l], CHT_STRIDE, log2wc, hc + 3,
-                          ovt_mc_chroma[mv[l][0] & 31], lane);
+            for (int m = 0; m < 4; ++m) tp[m] = l ? thl[1][m] : thl[0][m];
+            h_task<8>(s_wl[0] + l * (XWIN_ROWS * XWIN_STRIDE) + (2 + (l ? ldy[1] : ldy[0]) + r) * XWIN_STRIDE,
+                      4 + (l ? sl[1].off + ldx[1] : sl[0].off + ldx[0]), x0, tp, l ? identl[1] : identl[0],
+                      s_hl[0] + l * 16 * HT_STRIDE, HT_STRIDE, r, 4);
+        }
+    }
+    if (do_c) {
+        const int log2seg = log2wc > 2 ? log2wc - 2 : 0, TC = (hc + 3) << log2seg;
+        for (int t = lane; t < 4 * TC; t += 64) {
+            const int qi = (t >= TC) + (t >= 2 * TC) + (t >= 3 * TC), tt = t - qi * TC;
+            const int l = qi & 1;                                        // window qi = plane * 2 + list
+            const int r = tt >> log2seg, x0 = (tt & ((1 << log2seg) - 1)) << 2;
+            int tp[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) tp[m] = l ? thc[1][m] : thc[0][m];
+            h_task<4>(s_wc[0][0] + qi * (XCWIN_ROWS * XCWIN_STRIDE) + (2 + (l ? cdy[1] : cdy[0]) + r) * XCWIN_STRIDE,
+                      4 + (l ? sc[0][1].off + cdx[1] : sc[0][0].off + cdx[0]), x0, tp, l ? identc[1] : identc[0],
+                      s_hc[0][0] + qi * 8 * CHT_STRIDE, CHT_STRIDE, r, 4);
         }
     }
     __syncthreads();
@@ -312,21 +353,10 @@ __global__ __launch_bounds__(64) void k_mcx(ovhip_pic dst, RefTable refs, const 
             }
         }
     }
-    // ---- 5. chroma: plain average ----
+    // ---- 5. chroma: plain average; both planes in one pass, NOUT rows per lane so that the lanes cover both ----
     if (do_c) {
-#pragma unroll
-        for (int comp = 0; comp < 2; ++comp) {
-            int P[2][4];
-            v_pass<4>(s_hc[comp][0], CHT_STRIDE, log2wc, hc, fvc[0], lane, P[0]);
-            v_pass<4>(s_hc[comp][1], CHT_STRIDE, log2wc, hc, fvc[1], lane, P[1]);
-            if (lane < (((hc + 3) >> 2) << log2wc)) {
-                const int x = lane & (wc - 1), g = lane >> log2wc;
-                uint16_t *d = (comp ? dst.cr : dst.cb) + ((u.y >> 1) + 4 * g) * dst.stride_c + (u.x >> 1) + x;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (4 * g + j < hc) d[j * dst.stride_c] = (uint16_t)ov_clip_bd((P[0][j] + P[1][j] + 16) >> 5);
-            }
-        }
+        if (wc * hc >= 64) chroma_avg<2>(u, dst, s_hc[0][0], tvc, lane, log2wc, hc);
+        else               chroma_avg<1>(u, dst, s_hc[0][0], tvc, lane, log2wc, hc);
     }
     __syncthreads();          // LDS is reused by the next unit
     }

@@ -216,4 +216,36 @@ __device__ __forceinline__ void load_span(const int16_t *row, int s0, int d[(NT 
     }
 }
 
+
+// ---- merged-pass building blocks (k_mc2, k_mcx): one horizontal task = one window row x 4 outputs; one
+// vertical call = NOUT consecutive outputs of one transposed-tile column ----
+template <int NT>
+__device__ __forceinline__ void h_task(const uint16_t *wrow, int off, int x0, const int tp[NT / 2], bool ident, int16_t *ht,
+                                       int htstride, int r, int nout)
+{
+    int d[NT / 2 + 2], out[4];
+    if (ident) {
+        const uint16_t *sp = wrow + off + x0 + NT / 2 - 1;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) out[o] = (int)sp[o] << 6;
+    } else {
+        load_row_at<NT>(wrow, off + x0, d);
+        fir4<NT>(d, tp, out);
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+        if (o < nout) ht[(x0 + o) * htstride + r] = (int16_t)(out[o] >> (OV_BD - 8));
+}
+
+template <int NT, int NOUT>
+__device__ __forceinline__ void v_outputs(const int16_t *col, int s0, const int tp[NT / 2], int P[NOUT])
+{
+    int d[(NT + NOUT) / 2];
+    load_span<NT, NOUT>(col, s0, d);
+    firn<NT, NOUT>(d, tp, P);
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) P[o] >>= 6;
+}
+
+
 } // namespace
