@@ -52,6 +52,25 @@ __device__ __forceinline__ void pad_rows(uint16_t *win, int stride, int ww, int 
     }
 }
 
+// sum |a - b| over 2 * ND samples of two packed-dword rows (optionally starting one sample into the first dword)
+template <int ND>
+__device__ __forceinline__ uint32_t sad_row(const int *a, const int *b, bool odd, uint32_t acc)
+{
+    uint32_t A[ND + 1], B[ND + 1];
+#pragma unroll
+    for (int k = 0; k < ND + 1; ++k) { A[k] = (uint32_t)a[k]; B[k] = (uint32_t)b[k]; }
+    if (odd) {
+#pragma unroll
+        for (int k = 0; k < ND; ++k) {
+            A[k] = __builtin_amdgcn_alignbit(A[k + 1], A[k], 16);
+            B[k] = __builtin_amdgcn_alignbit(B[k + 1], B[k], 16);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < ND; ++k) acc = __builtin_amdgcn_sad_u16(A[k], B[k], acc);
+    return acc;
+}
+
 __device__ __forceinline__ int div_for_maxq7(int num, int den)
 {
     int sign = 0, q = 0;
@@ -150,35 +169,45 @@ __global__ __launch_bounds__(64) void k_mcx(ovhip_pic dst, RefTable refs, const 
             if (do_l) pad_rows(wl[l], XWIN_STRIDE, w + 7, h + 7, lane);
             if (do_c) { pad_rows(wcp[0][l], XCWIN_STRIDE, wc + 3, hc + 3, lane); pad_rows(wcp[1][l], XCWIN_STRIDE, wc + 3, hc + 3, lane); }
         }
-        // 2b. bilinear blocks B_l[j][i], i, j = 0 .. w+3 / h+3 <-> sample offsets -2 .. : lane = (list, column)
+        // 2b. bilinear blocks B_l[j][i], i, j = 0 .. w+3 / h+3 <-> sample offsets -2 .. : lane = (list, column).
+        //     The right-hand sample of column i is the left-hand sample of column i + 1: one LDS read per row and
+        //     a DPP wave shift instead of two reads (lane w+4 of each list only supplies that neighbour).
         {
             const int l = lane >= 32, i = lane & 31;
-            if (i < w + 4) {
+            if (i <= w + 4) {
                 const int fx = ini[l][0] & 15, fy = ini[l][1] & 15;
                 const uint16_t *src = wl[l] + XWIN_STRIDE + i + 1;            // offset -2 = window index 1
                 int16_t *o = s_x[l] + i;
                 int tp = 0;
                 for (int j = 0; j < h + 5; ++j) {
-                    const int a = src[j * XWIN_STRIDE], b = src[j * XWIN_STRIDE + 1];
+                    const int a = src[j * XWIN_STRIDE];
+                    const int b = __builtin_amdgcn_update_dpp(0, a, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
                     const int t = fx ? ((16 - fx) * a + fx * b + 8) >> 4 : a;
-                    if (j) o[(j - 1) * BIL_STRIDE] = (int16_t)(fy ? ((16 - fy) * tp + fy * t + 8) >> 4 : tp);
+                    if (j && i < w + 4) o[(j - 1) * BIL_STRIDE] = (int16_t)(fy ? ((16 - fy) * tp + fy * t + 8) >> 4 : tp);
                     tp = t;
                 }
             }
         }
         __syncthreads();
-        // 2c. SADs on every second row: lane = search point k (0..24) x row half
+        // 2c. SADs on every second row: lane = search point k (0..24) x row half.  Rows are read as packed dwords
+        //     (odd start columns re-aligned with v_alignbit) and accumulated two samples at a time with v_sad_u16.
         int sad = 0;
         {
             const int k = lane < 25 ? lane : lane - 25, half = lane >= 25;
             if (lane < 50) {
                 const int dx = k % 5 - 2, dy = k / 5 - 2;
-                const int16_t *b0 = s_x[0] + (2 + dy) * BIL_STRIDE + 2 + dx, *b1 = s_x[1] + (2 - dy) * BIL_STRIDE + 2 - dx;
+                const int c0 = 2 + dx, c1 = 2 - dx;                       // same parity
+                const bool odd = c0 & 1;
+                const int *r0 = reinterpret_cast<const int *>(s_x[0] + (2 + dy) * BIL_STRIDE) + (c0 >> 1);
+                const int *r1 = reinterpret_cast<const int *>(s_x[1] + (2 - dy) * BIL_STRIDE) + (c1 >> 1);
                 const int nrow = h >> 2;                                   // rows per half (of the h/2 used)
+                uint32_t acc = 0;
                 for (int jj = 0; jj < nrow; ++jj) {
-                    const int j = 2 * (half * nrow + jj);
-                    for (int x = 0; x < w; ++x) sad += abs((int)b0[j * BIL_STRIDE + x] - (int)b1[j * BIL_STRIDE + x]);
+                    const int ro = 2 * (half * nrow + jj) * (BIL_STRIDE / 2);
+                    if (w == 16) acc = sad_row<8>(r0 + ro, r1 + ro, odd, acc);
+                    else         acc = sad_row<4>(r0 + ro, r1 + ro, odd, acc);
                 }
+                sad = (int)acc;
             }
             sad += __shfl(sad, lane + 25 < 64 ? lane + 25 : lane);
         }
