@@ -20,6 +20,8 @@ namespace {
 #define TL 32           /* tile size               */
 #define LH 3            /* luma halo               */
 #define LW (TL + 2 * LH)
+#define LPAD 4          /* luma tile in LDS: 4 samples left of the tile (3 used) so that rows are 16-byte groups */
+#define LWS 40          /* luma LDS row stride = 5 x 8 samples                                                   */
 #define CH 2            /* chroma halo             */
 #define CW (TL + 2 * CH)
 
@@ -51,7 +53,7 @@ __device__ __forceinline__ void filter_idx(uint32_t sum_h, uint32_t sum_v, uint3
 
 __global__ __launch_bounds__(256) void k_alf_luma(ovhip_pic dst, ovhip_pic src, ovhip_alf_pic alf, int nb_ctu_w)
 {
-    __shared__ uint16_t s_t[LW * LW];
+    __shared__ __attribute__((aligned(16))) uint16_t s_t[LW * LWS];
     __shared__ uint8_t s_cls[64];
 
     const int W = src.w, H = src.h;
@@ -77,10 +79,19 @@ __global__ __launch_bounds__(256) void k_alf_luma(ovhip_pic dst, ovhip_pic src, 
         continue;
     }
 
-    for (int i = tid; i < LW * LW; i += 256) {
-        const int yy = i / LW, xx = i - yy * LW;
-        const int sy = ov_clip3(ty0 + yy - LH, 0, H - 1), sx = ov_clip3(tx0 + xx - LH, 0, W - 1);
-        s_t[i] = src.y[sy * src.stride_y + sx];
+    // 38 rows x 40 samples (tile + halo, 4 samples left so that the row is five 16-byte groups)
+    if (tx0 >= LPAD && tx0 + TL + LPAD <= W && ty0 >= LH && ty0 + TL + LH <= H && !(src.stride_y & 7)) {
+        if (tid < LW * 5) {                                           // interior tile: one 16-byte load per lane
+            const int yy = tid / 5, q = tid - yy * 5;
+            *reinterpret_cast<uint4 *>(s_t + yy * LWS + 8 * q) =
+                *reinterpret_cast<const uint4 *>(src.y + (ty0 + yy - LH) * src.stride_y + tx0 - LPAD + 8 * q);
+        }
+    } else {
+        for (int i = tid; i < LW * LWS; i += 256) {                   // picture border: clamped coordinates
+            const int yy = i / LWS, xx = i - yy * LWS;
+            const int sy = ov_clip3(ty0 + yy - LH, 0, H - 1), sx = ov_clip3(tx0 + xx - LPAD, 0, W - 1);
+            s_t[i] = src.y[sy * src.stride_y + sx];
+        }
     }
     __syncthreads();
 
@@ -95,7 +106,7 @@ __global__ __launch_bounds__(256) void k_alf_luma(ovhip_pic dst, ovhip_pic src, 
     const int vb = ctu_y0 + vbl;               // same boundary in picture rows
 
     // ---- classification: 4 lanes per 4x4 block, one row pair of its 8x8 Laplacian window each ----
-#define T(x, y) ((int)s_t[((y) + LH) * LW + (x) + LH])
+#define T(x, y) ((int)s_t[((y) + LH) * LWS + (x) + LPAD])
     {
         const int cb = tid >> 2, k = tid & 3;                    // block 0..63, row pair 0..3
         const int cbx = (cb & 7) * 4, cby = (cb >> 3) * 4;       // tile-local block origin
@@ -151,26 +162,73 @@ __global__ __launch_bounds__(256) void k_alf_luma(ovhip_pic dst, ovhip_pic src, 
     }
     const int o1 = min(d, 1), o2 = min(d, 2), o3 = min(d, 3);
     const int ly = by + r;
+    // The lane's 4 outputs need columns bx-3 .. bx+6 of 7 rows: fetch the 12-sample groups bx-4 .. bx+7 of those
+    // rows as 8-byte LDS reads (17 reads instead of ~100 two-byte ones) and pick samples out of registers.
+    uint32_t r0[6], p1[6], m1[6], p2[6], m2[6], p3[2], m3[2];
+    {
+        const uint16_t *base = s_t + LH * LWS + bx;                   // column bx - 4 of tile row 0
+        auto row3 = [&](int y, uint32_t d6[6]) {
+            const uint2 *q = reinterpret_cast<const uint2 *>(base + y * LWS);
+            const uint2 a = q[0], b_ = q[1], c_ = q[2];
+            d6[0] = a.x; d6[1] = a.y; d6[2] = b_.x; d6[3] = b_.y; d6[4] = c_.x; d6[5] = c_.y;
+        };
+        auto row1 = [&](int y, uint32_t d2[2]) {
+            const uint2 a = reinterpret_cast<const uint2 *>(base + y * LWS)[1];
+            d2[0] = a.x; d2[1] = a.y;
+        };
+        row3(ly, r0); row3(ly + o1, p1); row3(ly - o1, m1); row3(ly + o2, p2); row3(ly - o2, m2);
+        row1(ly + o3, p3); row1(ly - o3, m3);
+    }
+    // sample at column bx + c (c = -4 .. 7) of a 6-dword row group / (c = 0 .. 3) of a 2-dword group
+#define S6(d6, c) ((((c) + 4) & 1) ? (int)((d6)[((c) + 4) >> 1] >> 16) : (int)((d6)[((c) + 4) >> 1] & 0xffff))
+#define S2(d2, c) (((c) & 1) ? (int)((d2)[(c) >> 1] >> 16) : (int)((d2)[(c) >> 1] & 0xffff))
+    // Clip value 1 << bitdepth never clips a 10-bit difference: filter sets without non-linear clipping (the 16
+    // fixed sets, APS sets with alf_luma_clip_flag = 0, rcn_alf.c:196-240) take the linear form
+    //   sum_i f_i * (a_i + b_i) - 2 * cur * sum_i f_i   (same integers, a third of the arithmetic)
+    int cmin = cc[0], fsum = 0;
+#pragma unroll
+    for (int i = 1; i < 12; ++i) cmin = min(cmin, cc[i]);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) fsum += fc[i];
+    const bool linear = __all(cmin > OV_PIX_MAX);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int lx = bx + i;
-        const int cur = T(lx, ly);
-        int sum = 0;
-        sum += fc[0] * alf_clipd(cc[0], cur, T(lx, ly + o3), T(lx, ly - o3));
-        sum += fc[1] * alf_clipd(cc[1], cur, T(lx + 1, ly + o2), T(lx - 1, ly - o2));
-        sum += fc[2] * alf_clipd(cc[2], cur, T(lx, ly + o2), T(lx, ly - o2));
-        sum += fc[3] * alf_clipd(cc[3], cur, T(lx - 1, ly + o2), T(lx + 1, ly - o2));
-        sum += fc[4] * alf_clipd(cc[4], cur, T(lx + 2, ly + o1), T(lx - 2, ly - o1));
-        sum += fc[5] * alf_clipd(cc[5], cur, T(lx + 1, ly + o1), T(lx - 1, ly - o1));
-        sum += fc[6] * alf_clipd(cc[6], cur, T(lx, ly + o1), T(lx, ly - o1));
-        sum += fc[7] * alf_clipd(cc[7], cur, T(lx - 1, ly + o1), T(lx + 1, ly - o1));
-        sum += fc[8] * alf_clipd(cc[8], cur, T(lx - 2, ly + o1), T(lx + 2, ly - o1));
-        sum += fc[9] * alf_clipd(cc[9], cur, T(lx + 3, ly), T(lx - 3, ly));
-        sum += fc[10] * alf_clipd(cc[10], cur, T(lx + 2, ly), T(lx - 2, ly));
-        sum += fc[11] * alf_clipd(cc[11], cur, T(lx + 1, ly), T(lx - 1, ly));
+        const int cur = S6(r0, i);
+        int sum;
+        if (linear) {
+            sum = -2 * cur * fsum;
+            sum += fc[0] * (S2(p3, i) + S2(m3, i));
+            sum += fc[1] * (S6(p2, i + 1) + S6(m2, i - 1));
+            sum += fc[2] * (S6(p2, i) + S6(m2, i));
+            sum += fc[3] * (S6(p2, i - 1) + S6(m2, i + 1));
+            sum += fc[4] * (S6(p1, i + 2) + S6(m1, i - 2));
+            sum += fc[5] * (S6(p1, i + 1) + S6(m1, i - 1));
+            sum += fc[6] * (S6(p1, i) + S6(m1, i));
+            sum += fc[7] * (S6(p1, i - 1) + S6(m1, i + 1));
+            sum += fc[8] * (S6(p1, i - 2) + S6(m1, i + 2));
+            sum += fc[9] * (S6(r0, i + 3) + S6(r0, i - 3));
+            sum += fc[10] * (S6(r0, i + 2) + S6(r0, i - 2));
+            sum += fc[11] * (S6(r0, i + 1) + S6(r0, i - 1));
+        } else {
+            sum = 0;
+            sum += fc[0] * alf_clipd(cc[0], cur, S2(p3, i), S2(m3, i));
+            sum += fc[1] * alf_clipd(cc[1], cur, S6(p2, i + 1), S6(m2, i - 1));
+            sum += fc[2] * alf_clipd(cc[2], cur, S6(p2, i), S6(m2, i));
+            sum += fc[3] * alf_clipd(cc[3], cur, S6(p2, i - 1), S6(m2, i + 1));
+            sum += fc[4] * alf_clipd(cc[4], cur, S6(p1, i + 2), S6(m1, i - 2));
+            sum += fc[5] * alf_clipd(cc[5], cur, S6(p1, i + 1), S6(m1, i - 1));
+            sum += fc[6] * alf_clipd(cc[6], cur, S6(p1, i), S6(m1, i));
+            sum += fc[7] * alf_clipd(cc[7], cur, S6(p1, i - 1), S6(m1, i + 1));
+            sum += fc[8] * alf_clipd(cc[8], cur, S6(p1, i - 2), S6(m1, i + 2));
+            sum += fc[9] * alf_clipd(cc[9], cur, S6(r0, i + 3), S6(r0, i - 3));
+            sum += fc[10] * alf_clipd(cc[10], cur, S6(r0, i + 2), S6(r0, i - 2));
+            sum += fc[11] * alf_clipd(cc[11], cur, S6(r0, i + 1), S6(r0, i - 1));
+        }
         sum = near ? (sum + 512) >> 10 : (sum + 64) >> 7;
         if (ox + i < W) dst.y[oy * dst.stride_y + ox + i] = (uint16_t)ov_clip_bd(sum + cur);
     }
+#undef S6
+#undef S2
     }
 #undef T
 }

@@ -459,7 +459,12 @@ def make_alf(rs, w, h, ctu=128):
     clip_lut = np.array([1024, 128, 32, 8], np.int16)
     luma_coeff = rs.randint(-12, 13, size=(24, 4 * 25, 13)).astype(np.int16)
     luma_coeff[:, :, 12] = 128
+    # Non-linear clipping only exists in APS filter sets whose alf_luma_clip_flag is set (rcn_alf.c:196-240); the
+    # 16 fixed sets (luma_set < 16) and the other APS sets carry clip = 1 << bitdepth, i.e. no clipping.
     luma_clip = clip_lut[rs.randint(0, 4, size=(24, 4 * 25, 13))]
+    aps_clip_flag = rs.random_sample(8) < 0.5
+    luma_clip[:16] = 1024
+    luma_clip[16:][~aps_clip_flag] = 1024
     luma_clip[:, :, 12] = 1024
     chroma_coeff = rs.randint(-12, 13, size=(8, 7)).astype(np.int16)
     chroma_coeff[:, 6] = 128
