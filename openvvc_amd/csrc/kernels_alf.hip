@@ -191,6 +191,7 @@ __global__ __launch_bounds__(256) void k_alf_luma(ovhip_pic dst, ovhip_pic src, 
 #pragma unroll
     for (int i = 0; i < 12; ++i) fsum += fc[i];
     const bool linear = __all(cmin > OV_PIX_MAX);
+    int outv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int cur = S6(r0, i);
@@ -225,10 +226,20 @@ __global__ __launch_bounds__(256) void k_alf_luma(ovhip_pic dst, ovhip_pic src, 
             sum += fc[11] * alf_clipd(cc[11], cur, S6(r0, i + 1), S6(r0, i - 1));
         }
         sum = near ? (sum + 512) >> 10 : (sum + 64) >> 7;
-        if (ox + i < W) dst.y[oy * dst.stride_y + ox + i] = (uint16_t)ov_clip_bd(sum + cur);
+        outv[i] = ov_clip_bd(sum + cur);
     }
 #undef S6
 #undef S2
+    {
+        uint16_t *o = dst.y + oy * dst.stride_y + ox;
+        if (ox + 3 < W && !(dst.stride_y & 3)) {
+            uint2 v; v.x = (uint32_t)outv[0] | ((uint32_t)outv[1] << 16); v.y = (uint32_t)outv[2] | ((uint32_t)outv[3] << 16);
+            *reinterpret_cast<uint2 *>(o) = v;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (ox + i < W) o[i] = (uint16_t)outv[i];
+        }
+    }
     }
 #undef T
 }
@@ -236,7 +247,7 @@ __global__ __launch_bounds__(256) void k_alf_luma(ovhip_pic dst, ovhip_pic src, 
 // blockIdx.z: 0 Cb, 1 Cr
 __global__ __launch_bounds__(256) void k_alf_chroma(ovhip_pic dst, ovhip_pic src, ovhip_alf_pic alf, int nb_ctu_w)
 {
-    __shared__ uint16_t s_t[CW * CW];
+    __shared__ __attribute__((aligned(16))) uint16_t s_t[CW * LWS];
     const int comp = 1 + blockIdx.z;
     const int W = src.w, H = src.h, Wc = W >> 1, Hc = H >> 1;
     const int tid = threadIdx.x;
@@ -251,10 +262,19 @@ __global__ __launch_bounds__(256) void k_alf_chroma(ovhip_pic dst, ovhip_pic src
     uint16_t *dp = comp == 1 ? dst.cb : dst.cr;
 
     if (on) {
-        for (int i = tid; i < CW * CW; i += 256) {
-            const int yy = i / CW, xx = i - yy * CW;
-            const int sy = ov_clip3(ty0 + yy - CH, 0, Hc - 1), sx = ov_clip3(tx0 + xx - CH, 0, Wc - 1);
-            s_t[i] = sp[sy * src.stride_c + sx];
+        // 36 rows x 40 samples (tile + halo, 4 samples left so that a row is five 16-byte groups)
+        if (tx0 >= LPAD && tx0 + TL + LPAD <= Wc && ty0 >= CH && ty0 + TL + CH <= Hc && !(src.stride_c & 7)) {
+            if (tid < CW * 5) {
+                const int yy = tid / 5, q = tid - yy * 5;
+                *reinterpret_cast<uint4 *>(s_t + yy * LWS + 8 * q) =
+                    *reinterpret_cast<const uint4 *>(sp + (ty0 + yy - CH) * src.stride_c + tx0 - LPAD + 8 * q);
+            }
+        } else {
+            for (int i = tid; i < CW * LWS; i += 256) {
+                const int yy = i / LWS, xx = i - yy * LWS;
+                const int sy = ov_clip3(ty0 + yy - CH, 0, Hc - 1), sx = ov_clip3(tx0 + xx - LPAD, 0, Wc - 1);
+                s_t[i] = sp[sy * src.stride_c + sx];
+            }
         }
         __syncthreads();
     }
@@ -277,7 +297,6 @@ __global__ __launch_bounds__(256) void k_alf_chroma(ovhip_pic dst, ovhip_pic src
     const int ly = tid >> 3, lx0 = (tid & 7) * 4;
     const int oy = ty0 + ly;
     if (oy >= Hc) continue;
-#define T(x, y) ((int)s_t[((y) + CH) * CW + (x) + CH])
     int o1 = 1, o2 = 2;
     bool near = false;
     if (on) {
@@ -298,20 +317,53 @@ __global__ __launch_bounds__(256) void k_alf_chroma(ovhip_pic dst, ovhip_pic src
         if (pos == vbpos - 2 || pos == vbpos + 1) r3 = r1;
         else if (pos == vbpos - 1 || pos == vbpos) r1 = r2 = r3 = 0;
     }
+    const bool cc_inside = tx0 > 0 && ty0 > 0 && tx0 + TL < Wc && ty0 + TL < Hc;
+    // 5 rows of the 12-sample group lx0-4 .. lx0+7 as 8-byte LDS reads (see k_alf_luma)
+    uint32_t r0[6], p1[6], m1[6], p2[2], m2[2];
+    int cmin = 0x7fff, fsum = 0;
+    if (on) {
+        const uint16_t *base = s_t + CH * LWS + lx0;                 // column lx0 - 4 of tile row 0
+        auto row3 = [&](int y, uint32_t d6[6]) {
+            const uint2 *q = reinterpret_cast<const uint2 *>(base + y * LWS);
+            const uint2 a = q[0], b_ = q[1], c_ = q[2];
+            d6[0] = a.x; d6[1] = a.y; d6[2] = b_.x; d6[3] = b_.y; d6[4] = c_.x; d6[5] = c_.y;
+        };
+        auto row1 = [&](int y, uint32_t d2[2]) {
+            const uint2 a = reinterpret_cast<const uint2 *>(base + y * LWS)[1];
+            d2[0] = a.x; d2[1] = a.y;
+        };
+        row3(ly, r0); row3(ly + o1, p1); row3(ly - o1, m1); row1(ly + o2, p2); row1(ly - o2, m2);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { cmin = min(cmin, cl[i]); fsum += fc[i]; }
+    }
+    const bool linear = on && cmin > OV_PIX_MAX;                     // `on`, the filter and its clips are workgroup-uniform
+#define S6(d6, c) ((((c) + 4) & 1) ? (int)((d6)[((c) + 4) >> 1] >> 16) : (int)((d6)[((c) + 4) >> 1] & 0xffff))
+#define S2(d2, c) (((c) & 1) ? (int)((d2)[(c) >> 1] >> 16) : (int)((d2)[(c) >> 1] & 0xffff))
+    int outv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int lx = lx0 + i, ox = tx0 + lx;
-        if (ox >= Wc) break;
+        const int ox = min(tx0 + lx0 + i, Wc - 1);                    // columns past the picture are computed and dropped
         int out;
         if (on) {
-            const int cur = T(lx, ly);
-            int sum = 0;
-            sum += fc[0] * alf_clipd(cl[0], cur, T(lx, ly + o2), T(lx, ly - o2));
-            sum += fc[1] * alf_clipd(cl[1], cur, T(lx + 1, ly + o1), T(lx - 1, ly - o1));
-            sum += fc[2] * alf_clipd(cl[2], cur, T(lx, ly + o1), T(lx, ly - o1));
-            sum += fc[3] * alf_clipd(cl[3], cur, T(lx - 1, ly + o1), T(lx + 1, ly - o1));
-            sum += fc[4] * alf_clipd(cl[4], cur, T(lx + 2, ly), T(lx - 2, ly));
-            sum += fc[5] * alf_clipd(cl[5], cur, T(lx + 1, ly), T(lx - 1, ly));
+            const int cur = S6(r0, i);
+            int sum;
+            if (linear) {
+                sum = -2 * cur * fsum;
+                sum += fc[0] * (S2(p2, i) + S2(m2, i));
+                sum += fc[1] * (S6(p1, i + 1) + S6(m1, i - 1));
+                sum += fc[2] * (S6(p1, i) + S6(m1, i));
+                sum += fc[3] * (S6(p1, i - 1) + S6(m1, i + 1));
+                sum += fc[4] * (S6(r0, i + 2) + S6(r0, i - 2));
+                sum += fc[5] * (S6(r0, i + 1) + S6(r0, i - 1));
+            } else {
+                sum = 0;
+                sum += fc[0] * alf_clipd(cl[0], cur, S2(p2, i), S2(m2, i));
+                sum += fc[1] * alf_clipd(cl[1], cur, S6(p1, i + 1), S6(m1, i - 1));
+                sum += fc[2] * alf_clipd(cl[2], cur, S6(p1, i), S6(m1, i));
+                sum += fc[3] * alf_clipd(cl[3], cur, S6(p1, i - 1), S6(m1, i + 1));
+                sum += fc[4] * alf_clipd(cl[4], cur, S6(r0, i + 2), S6(r0, i - 2));
+                sum += fc[5] * alf_clipd(cl[5], cur, S6(r0, i + 1), S6(r0, i - 1));
+            }
             sum = near ? (sum + 512) >> 10 : (sum + 64) >> 7;
             out = ov_clip_bd(sum + cur);
         } else {
@@ -319,25 +371,46 @@ __global__ __launch_bounds__(256) void k_alf_chroma(ovhip_pic dst, ovhip_pic src
         }
         if (cc_idx) {
             const int Lx = ox << 1, Ly = oy << 1;
+            int cy, sum = 0;
+            if (cc_inside) {                                            // tile away from the picture border: no clamping
+                const uint16_t *lp = src.y + Ly * src.stride_y + Lx;
+                cy = lp[0];
+                sum += cf[0] * ((int)lp[r2 * src.stride_y] - cy);
+                sum += cf[1] * ((int)lp[-1] - cy);
+                sum += cf[2] * ((int)lp[1] - cy);
+                sum += cf[3] * ((int)lp[r1 * src.stride_y - 1] - cy);
+                sum += cf[4] * ((int)lp[r1 * src.stride_y] - cy);
+                sum += cf[5] * ((int)lp[r1 * src.stride_y + 1] - cy);
+                sum += cf[6] * ((int)lp[r3 * src.stride_y] - cy);
+            } else {
 #define LU(dx, dy) ((int)src.y[ov_clip3(Ly + (dy), 0, H - 1) * src.stride_y + ov_clip3(Lx + (dx), 0, W - 1)])
-            const int cy = LU(0, 0);
-            int sum = 0;
-            sum += cf[0] * (LU(0, r2) - cy);
-            sum += cf[1] * (LU(-1, 0) - cy);
-            sum += cf[2] * (LU(1, 0) - cy);
-            sum += cf[3] * (LU(-1, r1) - cy);
-            sum += cf[4] * (LU(0, r1) - cy);
-            sum += cf[5] * (LU(1, r1) - cy);
-            sum += cf[6] * (LU(0, r3) - cy);
+                cy = LU(0, 0);
+                sum += cf[0] * (LU(0, r2) - cy);
+                sum += cf[1] * (LU(-1, 0) - cy);
+                sum += cf[2] * (LU(1, 0) - cy);
+                sum += cf[3] * (LU(-1, r1) - cy);
+                sum += cf[4] * (LU(0, r1) - cy);
+                sum += cf[5] * (LU(1, r1) - cy);
+                sum += cf[6] * (LU(0, r3) - cy);
 #undef LU
+            }
             sum = (sum + 64) >> 7;
             sum = ov_clip_bd(sum + (1 << OV_BD >> 1));
             out = ov_clip_bd(sum + out - (1 << OV_BD >> 1));
         }
-        dp[oy * dst.stride_c + ox] = (uint16_t)out;
+        outv[i] = out;
+    }
+#undef S6
+#undef S2
+    uint16_t *o = dp + oy * dst.stride_c + tx0 + lx0;
+    if (tx0 + lx0 + 3 < Wc && !(dst.stride_c & 3)) {
+        uint2 v; v.x = (uint32_t)outv[0] | ((uint32_t)outv[1] << 16); v.y = (uint32_t)outv[2] | ((uint32_t)outv[3] << 16);
+        *reinterpret_cast<uint2 *>(o) = v;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (tx0 + lx0 + i < Wc) o[i] = (uint16_t)outv[i];
     }
     }
-#undef T
 }
 
 } // namespace
