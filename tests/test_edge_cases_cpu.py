@@ -1,0 +1,94 @@
+"""CPU: host-side edge cases of the recorder and the C ABI (no device work)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from openvvc_amd import capi, synth
+
+
+def test_struct_layouts_match_header():
+    """Sizes the device kernels rely on (include/ovvc_hip.h)."""
+    assert capi.AFF_UNIT_DTYPE.itemsize == 32 and capi.CIIP_UNIT_DTYPE.itemsize == 8
+    assert capi.LMCS_REGION_DTYPE.itemsize == 8 and capi.SAO_CTU_DTYPE.itemsize == 44 and capi.ALF_CTU_DTYPE.itemsize == 8
+    assert C.sizeof(capi.LmcsLuts) == 2 * 1024 * 2 + 17 * 2 + 2 + 2 + 2
+    assert C.sizeof(capi.LmcsData) == 4 + 32
+
+
+def test_recorder_rejects_bad_descriptors(built_lib):
+    rec = capi.Recorder(256, 128)
+    d = capi.PuDesc()
+    d.x0, d.y0, d.log2_w, d.log2_h, d.planes = 0, 0, 4, 4, 3
+    d.inter_dir = 0
+    with pytest.raises(ValueError):
+        rec.pu(d)                                   # no prediction direction
+    d.inter_dir = 3; d.bcw_idx_plus1 = 9; d.poc0, d.poc1 = 8, 24
+    with pytest.raises(ValueError):
+        rec.pu(d)                                   # BCW index out of range
+    d.bcw_idx_plus1 = 0; d.refine = capi.PU_BDOF; d.log2_w = 2
+    with pytest.raises(ValueError):
+        rec.pu(d)                                   # BDOF needs >= 8x8 and >= 128 samples (check_bdof)
+    d.refine = capi.PU_GPM; d.log2_w = 3; d.log2_h = 3; d.gpm_split_dir = 64
+    with pytest.raises(ValueError):
+        rec.pu(d)                                   # partition index out of range
+    with pytest.raises(ValueError):
+        rec.lmcs_region(300, 0, 0, 0)               # outside the picture
+    with pytest.raises(ValueError):
+        rec.ciip(0, 0, 7, 3, 1, 1)                  # CIIP CUs are < 128 wide
+    assert len(rec.mc_units()) == 0 and len(rec.mcx_units()) == 0 and len(rec.ciip_units()) == 0
+    st = capi.TuState(); td = capi.TuDesc()
+    st.lmcs_scale_c = 2; st.ict_type = 3
+    td.log2_tb_w = td.log2_tb_h = 3; td.cbf_mask = 0x2; td.tree = 0
+    buf = np.ones(64, np.int16)
+    td.coef[0] = buf.ctypes.data; td.sig_sb_map[0] = 1
+    with pytest.raises(ValueError):
+        rec.tu(st, td)                              # indirect chroma scale without a recorded LMCS region
+    rec.close()
+
+
+def test_empty_and_reset(built_lib):
+    rec = capi.Recorder(64, 64)
+    cmds, classes = rec.tb_cmds_split()
+    assert len(cmds) == 0 and classes == (0, 0, 0, 0)
+    assert len(rec.aff_units()) == 0 and len(rec.aff_side()) == 0 and len(rec.lmcs_regions()) == 0
+    rec.lmcs_region(0, 0, 0, 0)
+    rec.ciip(0, 0, 3, 3, 2, 4)
+    assert rec.ciip_units()["wt"][0] == 3           # both neighbours intra (OV_INTRA, OV_MIP)
+    rec.reset()
+    assert len(rec.lmcs_regions()) == 0 and len(rec.ciip_units()) == 0
+    rec.close()
+
+
+def test_tb_class_split_is_a_stable_partition(built_lib):
+    wl = synth.make_workload(416, 240, 21)
+    c, k = wl.tb_cmds, wl.tb_classes
+    big = (c["log2_w"] > 4) | (c["log2_h"] > 4)
+    luma = c["plane"] == 0
+    o = np.cumsum((0,) + k)
+    assert luma[:o[2]].all() and not luma[o[2]:].any()
+    assert big[o[0]:o[1]].all() and not big[o[1]:o[2]].any() and big[o[2]:o[3]].all() and not big[o[3]:o[4]].any()
+    # stable: coefficient offsets stay ascending inside every class (recording order)
+    for a, b in zip(o[:-1], o[1:]):
+        assert (np.diff(c["coef_off"][a:b].astype(np.int64)) > 0).all()
+
+
+def test_lmcs_identity_tables(built_lib):
+    d = capi.LmcsData()                             # no deltas: 16 equal windows = identity mapping
+    luts = capi.lmcs_build(d)
+    ident = np.arange(1024, dtype=np.uint16)
+    assert np.array_equal(np.frombuffer(bytes(luts), np.uint16)[:1024], ident)
+    assert np.array_equal(np.frombuffer(bytes(luts), np.uint16)[1024:2048], ident)
+    d.min_bin_idx = 16
+    with pytest.raises(ValueError):
+        capi.lmcs_build(d)
+
+
+def test_launch_argument_checks_need_no_device(built_lib):
+    """NULL context / picture arguments are rejected before any HIP call."""
+    lib = built_lib
+    assert lib.ovhip_itx_launch(None, None, None, 0, None, None) < 0
+    assert lib.ovhip_mc_launch(None, None, None, 0, None, 0, None) < 0
+    assert lib.ovhip_mcx_launch(None, None, None, 0, None, 0, None, None) < 0
+    assert lib.ovhip_mca_launch(None, None, None, 0, None, 0, None, None) < 0
+    assert lib.ovhip_ciip_launch(None, None, None, None, 0) < 0
+    assert lib.ovhip_lmcs_inverse_launch(None, None, None) < 0

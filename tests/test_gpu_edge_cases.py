@@ -1,0 +1,52 @@
+"""GPU: empty launches, pictures that are not a multiple of the CTU / tile sizes, a picture smaller than one CTU."""
+import numpy as np
+import pytest
+
+import oracle_pipeline
+from openvvc_amd import capi, engine, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(built_lib):
+    c = engine.Context(0)
+    yield c
+    c.close()
+
+
+def test_empty_launches_are_noops(ctx):
+    pic = ctx.new_pic(64, 64)
+    empty = ctx.alloc(0)
+    lib, h, s = ctx.lib, ctx.h, pic.s
+    import ctypes as C
+    refs = (capi.Pic * 1)(s)
+    assert lib.ovhip_itx_launch(h, C.byref(s), None, 0, None, None) == 0
+    assert lib.ovhip_itx_launch_classes(h, C.byref(s), None, 0, 0, None, None) == 0
+    assert lib.ovhip_mc_launch(h, C.byref(s), refs, 1, None, 0, None) == 0
+    assert lib.ovhip_mcx_launch(h, C.byref(s), refs, 1, None, 0, None, None) == 0
+    assert lib.ovhip_mca_launch(h, C.byref(s), refs, 1, None, 0, None, None) == 0
+    assert lib.ovhip_ciip_launch(h, C.byref(s), C.byref(s), None, 0) == 0
+    luts = capi.lmcs_build(capi.LmcsData())
+    assert lib.ovhip_lmcs_scale_launch(h, C.byref(s), None, 0, C.byref(luts), None) == 0
+    # a non-empty launch with a NULL buffer is an error, reported through ovhip_last_error
+    assert lib.ovhip_mc_launch(h, C.byref(s), refs, 1, None, 5, None) < 0
+    assert b"ovhip_mc_launch" in lib.ovhip_last_error(h)
+    ctx.sync()
+    empty.free()
+
+
+@pytest.mark.parametrize("w,h,seed", [(264, 136, 1), (200, 120, 2), (128, 64, 3), (72, 200, 4)])
+def test_ragged_pictures_match_oracle(ctx, w, h, seed):
+    """Widths / heights that are not multiples of the 128-sample CTU, the 64-sample LMCS region, the 32-sample
+    ALF / SAO tiles or the 16-sample MC unit; one picture lower than a CTU."""
+    wl = synth.make_workload(w, h, seed)
+    rp = engine.ResidentPicture(ctx, wl)
+    rp.decode()
+    y, cb, cr = rp.result()
+    ref, mvs = oracle_pipeline.decode(wl, want_mvs=True)
+    for name, a, b in (("Y", y, ref.y), ("Cb", cb, ref.cb), ("Cr", cr, ref.cr)):
+        assert np.array_equal(a, b), f"{w}x{h}: plane {name}: {int((a != b).sum())} samples differ"
+    if mvs is not None:
+        assert np.array_equal(rp.refined_mvs(), mvs)
+    rp.free()
