@@ -123,10 +123,12 @@ __device__ __forceinline__ void tr_pass_lds(const int16_t *src, int sstride, con
                 acc[1] += m * (v.x >> 16);
                 acc[2] += m * (int)(int16_t)(v.y & 0xffff);
                 acc[3] += m * (v.y >> 16);
-            } else {
+            } else if (IB == 2) {
                 const int v = *reinterpret_cast<const int *>(s);
                 acc[0] += m * (int)(int16_t)(v & 0xffff);
                 acc[1] += m * (v >> 16);
+            } else {
+                acc[0] += m * (int)s[0];
             }
         }
 #pragma unroll
@@ -264,13 +266,18 @@ __global__ __launch_bounds__(NT) void k_itx(ovhip_pic pic, const ovhip_tb_cmd *_
         nb_row = min(nb_row, tb_w);
         const int k1 = min(nb_col, kv);
         // ---- K3: vertical pass (shift 7): tmp[i*tb_h + j], i = coefficient column < nb_row ----
-        if (nb_row & 3) tr_pass_lds<2, false, NT>(s_coef, cw, s_mv, log2_h, k1, nb_row, 7, s_tmp, lane, sink);
-        else            tr_pass_lds<4, false, NT>(s_coef, cw, s_mv, log2_h, k1, nb_row, 7, s_tmp, lane, sink);
+        // lines per task: as many as keeps every lane busy (these blocks are latency-bound, not ALU-bound)
+        if ((nb_row << log2_h) <= NT)          tr_pass_lds<1, false, NT>(s_coef, cw, s_mv, log2_h, k1, nb_row, 7, s_tmp, lane, sink);
+        else if ((nb_row & 3) || (nb_row << log2_h) <= 2 * NT)
+                                               tr_pass_lds<2, false, NT>(s_coef, cw, s_mv, log2_h, k1, nb_row, 7, s_tmp, lane, sink);
+        else                                   tr_pass_lds<4, false, NT>(s_coef, cw, s_mv, log2_h, k1, nb_row, 7, s_tmp, lane, sink);
         __syncthreads();
         // ---- horizontal pass (shift 20 - bitdepth) fused with K4; tmp rows >= nb_row are zero ----
         const int k2 = min(nb_row, kh);
-        if (tb_h & 3) tr_pass_lds<2, true, NT>(s_tmp, tb_h, s_mh, log2_w, k2, tb_h, 20 - OV_BD, nullptr, lane, sink);
-        else          tr_pass_lds<4, true, NT>(s_tmp, tb_h, s_mh, log2_w, k2, tb_h, 20 - OV_BD, nullptr, lane, sink);
+        if ((tb_h << log2_w) <= NT)            tr_pass_lds<1, true, NT>(s_tmp, tb_h, s_mh, log2_w, k2, tb_h, 20 - OV_BD, nullptr, lane, sink);
+        else if ((tb_h & 3) || (tb_h << log2_w) <= 2 * NT)
+                                               tr_pass_lds<2, true, NT>(s_tmp, tb_h, s_mh, log2_w, k2, tb_h, 20 - OV_BD, nullptr, lane, sink);
+        else                                   tr_pass_lds<4, true, NT>(s_tmp, tb_h, s_mh, log2_w, k2, tb_h, 20 - OV_BD, nullptr, lane, sink);
         continue;
     }
 
