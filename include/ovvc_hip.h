@@ -425,6 +425,19 @@ int   ovhip_rec_ciip(ovhip_recorder *rec, int32_t x0, int32_t y0, int32_t log2_w
  * the two 16-bit availability masks it derives from progress_field (rcn_lmcs.c:327-332).  Returns the
  * region index; TUs recorded afterwards with lmcs_scale_c == 2 refer to it. */
 int   ovhip_rec_lmcs_region(ovhip_recorder *rec, int32_t x0, int32_t y0, uint32_t abv_mask, uint32_t lft_mask);
+/* Compact form of the edge planes: only the 4-sample segments that carry an edge, in raster order, luma
+ * first, then Cb, then Cr (8 bytes each).  A lane of the device kernel then always has an edge to filter
+ * (in the dense planes ~3/4 of the words are 0).  ux, uy: position in 4-luma-sample units. */
+typedef struct ovhip_dbf_edge {
+    uint16_t ux, uy;
+    uint16_t word;            /* OVHIP_DBF_LUMA(...) or the chroma word, as in the planes          */
+    uint8_t  comp;            /* 0 Y, 1 Cb, 2 Cr                                                   */
+    uint8_t  pad;
+} ovhip_dbf_edge;
+/* dir 0: vertical edges, 1: horizontal.  planes: HOST pointers.  Writes at most cap entries to out (may be
+ * NULL to count) and returns the number of edges, or <0. */
+int64_t ovhip_dbf_compact(const ovhip_dbf_planes *planes, int dir, ovhip_dbf_edge *out, size_t cap);
+
 /* Convert one CTU's deblocking maps into the picture-level edge planes.  Returns 0 or <0. */
 int   ovhip_rec_dbf_ctu(ovhip_recorder *rec, const ovhip_dbf_ctu *ctu);
 /* Host copies of the edge planes (pointers valid until the next reset/destroy). */
@@ -501,6 +514,9 @@ int  ovhip_mca_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *ref
                       const uint16_t *d_lmcs_fwd_lut);
 /* planes->* are DEVICE pointers.  Filters `pic` in place: all vertical edges, then all horizontal. */
 int  ovhip_dbf_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_dbf_planes *planes);
+/* Same filter driven by the compact lists of ovhip_dbf_compact (DEVICE pointers). */
+int  ovhip_dbf_launch_edges(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_dbf_edge *d_edges_v, uint32_t n_v,
+                            const ovhip_dbf_edge *d_edges_h, uint32_t n_h, int32_t beta_offset, int32_t tc_offset);
 /* d_params: DEVICE array of ceil(w/ctu)*ceil(h/ctu) entries.  dst and src must not alias. */
 int  ovhip_sao_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *src,
                       const ovhip_sao_ctu *d_params, int32_t log2_ctu_s);

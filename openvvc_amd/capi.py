@@ -92,6 +92,8 @@ class LmcsLuts(C.Structure):
                 ("min_idx", C.c_uint8), ("max_idx", C.c_uint8), ("crs_offset", C.c_int16), ("pad", C.c_uint16)]
 
 
+DBF_EDGE_DTYPE = np.dtype([("ux", "<u2"), ("uy", "<u2"), ("word", "<u2"), ("comp", "u1"), ("pad", "u1")])
+assert DBF_EDGE_DTYPE.itemsize == 8
 CIIP_UNIT_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("log2_w", "u1"), ("log2_h", "u1"), ("wt", "u1"), ("chroma_inter", "u1")])
 assert CIIP_UNIT_DTYPE.itemsize == 8
 LMCS_REGION_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("n_abv", "u1"), ("n_lft", "u1"), ("pad", "u1", 2)])
@@ -152,6 +154,20 @@ AFF_PROF, AFF_NO_CHROMA, AFF_LMCS = 1, 8, 16
 _lib = None
 
 
+def dbf_compact(planes: dict, direction: int) -> np.ndarray:
+    """Host: compact edge list (DBF_EDGE_DTYPE) of one direction from the dense planes dict (numpy uint16 arrays)."""
+    keep = {k: np.ascontiguousarray(planes[k], dtype=np.uint16) for k in DBF_PLANE_NAMES}
+    s = DbfPlanes(*[keep[k].ctypes.data for k in DBF_PLANE_NAMES], planes["w4"], planes["h4"],
+                  planes["beta_offset"], planes["tc_offset"])
+    n = load().ovhip_dbf_compact(C.byref(s), direction, None, 0)
+    if n < 0:
+        raise ValueError(f"ovhip_dbf_compact -> {n}")
+    out = np.zeros(n, DBF_EDGE_DTYPE)
+    if n:
+        load().ovhip_dbf_compact(C.byref(s), direction, out.ctypes.data, n)
+    return out
+
+
 def lmcs_build(data: "LmcsData") -> "LmcsLuts":
     """Host: the LMCS tables of one APS (rcn_init_lmcs)."""
     out = LmcsLuts()
@@ -195,6 +211,8 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_rec_mcx_units": (vp, [vp, P(C.c_size_t)]),
         "ovhip_rec_affine_cu": (C.c_int, [vp, P(AffineDesc)]),
         "ovhip_rec_lmcs_region": (C.c_int, [vp, C.c_int32, C.c_int32, u32, u32]),
+        "ovhip_dbf_compact": (C.c_int64, [P(DbfPlanes), C.c_int, vp, C.c_size_t]),
+        "ovhip_dbf_launch_edges": (C.c_int, [vp, P(Pic), vp, u32, vp, u32, C.c_int32, C.c_int32]),
         "ovhip_rec_ciip": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
         "ovhip_rec_ciip_units": (vp, [vp, P(C.c_size_t)]),
         "ovhip_ciip_launch": (C.c_int, [vp, P(Pic), P(Pic), vp, u32]),
@@ -236,7 +254,7 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
 
 EXPORTED_SYMBOLS = [
     "ovhip_abi_version", "ovhip_rec_create", "ovhip_rec_destroy", "ovhip_rec_reset", "ovhip_rec_tu",
-    "ovhip_rec_pu", "ovhip_rec_dbf_ctu", "ovhip_rec_dbf_planes", "ovhip_dbf_launch", "ovhip_sao_launch", "ovhip_alf_launch", "ovhip_rec_tb_cmds", "ovhip_rec_coefs", "ovhip_rec_mc_units", "ovhip_rec_mcx_units", "ovhip_mcx_launch", "ovhip_rec_affine_cu", "ovhip_rec_lmcs_region", "ovhip_rec_ciip", "ovhip_rec_ciip_units", "ovhip_ciip_launch", "ovhip_rec_lmcs_regions", "ovhip_rec_tb_cmds_split", "ovhip_itx_launch_classes", "ovhip_lmcs_build", "ovhip_lmcs_scale_launch", "ovhip_lmcs_inverse_launch", "ovhip_rec_aff_units", "ovhip_rec_aff_side", "ovhip_mca_launch", "ovhip_ctx_create",
+    "ovhip_rec_pu", "ovhip_rec_dbf_ctu", "ovhip_rec_dbf_planes", "ovhip_dbf_launch", "ovhip_sao_launch", "ovhip_alf_launch", "ovhip_rec_tb_cmds", "ovhip_rec_coefs", "ovhip_rec_mc_units", "ovhip_rec_mcx_units", "ovhip_mcx_launch", "ovhip_rec_affine_cu", "ovhip_rec_lmcs_region", "ovhip_dbf_compact", "ovhip_dbf_launch_edges", "ovhip_rec_ciip", "ovhip_rec_ciip_units", "ovhip_ciip_launch", "ovhip_rec_lmcs_regions", "ovhip_rec_tb_cmds_split", "ovhip_itx_launch_classes", "ovhip_lmcs_build", "ovhip_lmcs_scale_launch", "ovhip_lmcs_inverse_launch", "ovhip_rec_aff_units", "ovhip_rec_aff_side", "ovhip_mca_launch", "ovhip_ctx_create",
     "ovhip_ctx_destroy", "ovhip_ctx_sync", "ovhip_last_error", "ovhip_ctx_stream", "ovhip_malloc",
     "ovhip_free", "ovhip_h2d", "ovhip_d2h", "ovhip_pic_alloc", "ovhip_pic_free", "ovhip_pic_upload",
     "ovhip_pic_download", "ovhip_itx_launch", "ovhip_mc_launch",

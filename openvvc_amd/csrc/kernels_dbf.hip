@@ -252,7 +252,45 @@ __global__ __launch_bounds__(256) void k_dbf(ovhip_pic pic, ovhip_dbf_planes pl)
     }
 }
 
+// The same filter over the compact edge lists (ovhip_dbf_compact): every lane has an edge.
+template <int DIR>
+__global__ __launch_bounds__(256) void k_dbf_list(ovhip_pic pic, const ovhip_dbf_edge *__restrict__ edges, uint32_t n,
+                                                  int tc_offset, int beta_offset)
+{
+    const uint32_t tid = blockIdx.x * 256 + threadIdx.x;
+    if (tid >= n) return;
+    const ovhip_dbf_edge e = edges[tid];
+    const int v = e.word;
+    if (e.comp == 0) {
+        const Lim lim = dbf_limits(v >> 8, v & 3, tc_offset, beta_offset);
+        if (!(lim.tc || lim.beta)) return;
+        uint16_t *p = pic.y + (e.uy * 4) * pic.stride_y + e.ux * 4;
+        luma_segment(p, DIR ? pic.stride_y : 1, DIR ? 1 : pic.stride_y, lim, (v >> 2) & 7, (v >> 5) & 7);
+    } else {
+        const Lim lim = dbf_limits(v >> 8, 1 + !!(v & OVHIP_DBF_C_BS2), tc_offset, beta_offset);
+        uint16_t *p = (e.comp == 1 ? pic.cb : pic.cr) + (e.uy * 2) * pic.stride_c + e.ux * 2;
+        chroma_segment(p, DIR ? pic.stride_c : 1, DIR ? 1 : pic.stride_c, lim, v & OVHIP_DBF_C_LARGE, v & OVHIP_DBF_C_CTB_B);
+    }
+}
+
 } // namespace
+
+extern "C" int ovhip_dbf_launch_edges(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_dbf_edge *d_edges_v, uint32_t n_v,
+                                      const ovhip_dbf_edge *d_edges_h, uint32_t n_h, int32_t beta_offset, int32_t tc_offset)
+{
+    if (!ctx || !pic) return OVHIP_EINVAL;
+    if ((n_v && !d_edges_v) || (n_h && !d_edges_h))
+        return ov_fail(ctx, OVHIP_EINVAL, "ovhip_dbf_launch_edges: null edge list", hipSuccess);
+    if (n_v) {
+        hipLaunchKernelGGL(k_dbf_list<0>, dim3((n_v + 255) / 256), dim3(256), 0, ctx->stream, *pic, d_edges_v, n_v, tc_offset, beta_offset);
+        OV_LAUNCH_CHECK(ctx, "k_dbf_list<v>");
+    }
+    if (n_h) {
+        hipLaunchKernelGGL(k_dbf_list<1>, dim3((n_h + 255) / 256), dim3(256), 0, ctx->stream, *pic, d_edges_h, n_h, tc_offset, beta_offset);
+        OV_LAUNCH_CHECK(ctx, "k_dbf_list<h>");
+    }
+    return OVHIP_OK;
+}
 
 extern "C" int ovhip_dbf_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_dbf_planes *pl)
 {

@@ -207,3 +207,39 @@ ovhip_rec_dbf_ctu(ovhip_recorder *r, const ovhip_dbf_ctu *c)
     }
     return OVHIP_OK;
 }
+
+/* ---------------------------------------------------------------- compact edge lists
+ * The planes are dense (one word per 4-sample segment); about three quarters of the words are 0.  The device
+ * kernel driven by the planes spends most lanes on "no edge here"; the lists keep only the segments to filter.
+ * The skip rules are the ones k_dbf applies: bS 0 / chroma bit off, and never across the picture boundary. */
+int64_t
+ovhip_dbf_compact(const ovhip_dbf_planes *pl, int dir, ovhip_dbf_edge *out, size_t cap)
+{
+    if (!pl || (dir != 0 && dir != 1) || pl->w4 <= 0 || pl->h4 <= 0) return OVHIP_EINVAL;
+    const int w4 = pl->w4, h4 = pl->h4;
+    size_t n = 0;
+    const uint16_t *luma = dir ? pl->luma_h : pl->luma_v;
+    if (!luma) return OVHIP_EINVAL;
+    for (int uy = 0; uy < h4; ++uy)
+        for (int ux = 0; ux < w4; ++ux) {
+            const uint16_t v = luma[uy * w4 + ux];
+            if (!(v & 3) || (dir ? uy : ux) == 0) continue;
+            if (out && n < cap) { ovhip_dbf_edge e = { (uint16_t)ux, (uint16_t)uy, v, 0, 0 }; out[n] = e; }
+            ++n;
+        }
+    /* chroma planes: vertical [h4][ceil(w4/2)] (every second unit column), horizontal [ceil(h4/2)][w4] */
+    const int cw = dir ? w4 : (w4 + 1) >> 1, chh = dir ? (h4 + 1) >> 1 : h4;
+    for (int comp = 1; comp < 3; ++comp) {
+        const uint16_t *plane = dir ? (comp == 1 ? pl->cb_h : pl->cr_h) : (comp == 1 ? pl->cb_v : pl->cr_v);
+        if (!plane) return OVHIP_EINVAL;
+        for (int cy = 0; cy < chh; ++cy)
+            for (int cx = 0; cx < cw; ++cx) {
+                const uint16_t v = plane[cy * cw + cx];
+                const int ux = dir ? cx : cx * 2, uy = dir ? cy * 2 : cy;
+                if (!(v & OVHIP_DBF_C_ON) || (dir ? uy : ux) == 0) continue;
+                if (out && n < cap) { ovhip_dbf_edge e = { (uint16_t)ux, (uint16_t)uy, v, (uint8_t)comp, 0 }; out[n] = e; }
+                ++n;
+            }
+    }
+    return (int64_t)n;
+}

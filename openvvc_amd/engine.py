@@ -95,6 +95,11 @@ class Context:
     def dbf(self, pic: "DevPic", planes: "DevDbfPlanes"):
         self._chk(self.lib.ovhip_dbf_launch(self.h, C.byref(pic.s), C.byref(planes.s)), "dbf_launch")
 
+    def dbf_edges(self, pic: "DevPic", edges_v: "DevBuf", edges_h: "DevBuf", beta_offset: int = 0, tc_offset: int = 0):
+        """Deblocking driven by the compact edge lists (capi.dbf_compact)."""
+        self._chk(self.lib.ovhip_dbf_launch_edges(self.h, C.byref(pic.s), edges_v.ptr, edges_v.count, edges_h.ptr,
+                                                  edges_h.count, beta_offset, tc_offset), "dbf_launch_edges")
+
     def sao(self, dst: "DevPic", src: "DevPic", params: "DevBuf", log2_ctu: int = 7):
         self._chk(self.lib.ovhip_sao_launch(self.h, C.byref(dst.s), C.byref(src.s), params.ptr, log2_ctu), "sao_launch")
 
@@ -237,9 +242,11 @@ class ResidentPicture:
         self.tb_cmds = ctx.upload(wl.tb_cmds)
         self.coefs = ctx.upload(wl.coefs)
         self.dbf_planes = DevDbfPlanes(ctx, wl.dbf_planes)
+        self.dbf_v = ctx.upload(capi.dbf_compact(wl.dbf_planes, 0))
+        self.dbf_h = ctx.upload(capi.dbf_compact(wl.dbf_planes, 1))
         self.sao_params = ctx.upload(wl.sao_params)
         self.alf = DevAlf(ctx, wl.alf, wl.w, wl.h, log2_ctu)
-        self.bufs = [self.mc_units, self.tb_cmds, self.coefs, self.sao_params]
+        self.bufs = [self.mc_units, self.tb_cmds, self.coefs, self.sao_params, self.dbf_v, self.dbf_h]
         up = lambda a: self._keep(ctx.upload(a)) if a is not None and len(a) else None
         self.mcx_units = up(wl.mcx_units)
         self.mv_out = self._keep(ctx.alloc(16 * len(wl.mcx_units))) if self.mcx_units else None
@@ -287,7 +294,7 @@ class ResidentPicture:
             if self.lmcs is not None:
                 c.lmcs_inverse(self.dst, self.lmcs_bwd)
         elif name == "dbf":
-            c.dbf(self.dst, self.dbf_planes)
+            c.dbf_edges(self.dst, self.dbf_v, self.dbf_h, self.wl.dbf_planes["beta_offset"], self.wl.dbf_planes["tc_offset"])
         elif name == "sao":
             c.sao(self.tmp, self.dst, self.sao_params, self.log2_ctu)
         elif name == "alf":

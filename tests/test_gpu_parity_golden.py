@@ -166,14 +166,21 @@ def test_gpm_ciip_gpu_matches_reference(ctx):
 
 
 def test_dbf_gpu_matches_reference(ctx):
+    """Both drivers of the deblocking kernel: dense edge planes and the compact edge lists."""
     for i, (pic, planes, exp) in enumerate(golden_cases.dbf_cases()):
-        d = ctx.upload_pic(pic.y, pic.cb, pic.cr)
-        ctx.dbf(d, engine.DevDbfPlanes(ctx, planes))
-        ctx.sync()
-        y, cb, cr = d.download()
-        for name, a, b in (("Y", y, exp.y), ("Cb", cb, exp.cb), ("Cr", cr, exp.cr)):
-            bad = np.argwhere(a != b)
-            assert len(bad) == 0, f"dbf HIP vs reference, picture {i} plane {name}: {len(bad)} differ, first {bad[:6].tolist()}"
+        for mode in ("planes", "edges"):
+            d = ctx.upload_pic(pic.y, pic.cb, pic.cr)
+            if mode == "planes":
+                ctx.dbf(d, engine.DevDbfPlanes(ctx, planes))
+            else:
+                ev, eh = capi.dbf_compact(planes, 0), capi.dbf_compact(planes, 1)
+                assert 0 < len(ev) < planes["w4"] * planes["h4"] and len(eh) > 0
+                ctx.dbf_edges(d, ctx.upload(ev), ctx.upload(eh), planes["beta_offset"], planes["tc_offset"])
+            ctx.sync()
+            y, cb, cr = d.download()
+            for name, a, b in (("Y", y, exp.y), ("Cb", cb, exp.cb), ("Cr", cr, exp.cr)):
+                bad = np.argwhere(a != b)
+                assert len(bad) == 0, f"dbf HIP ({mode}) vs reference, picture {i} plane {name}: {len(bad)} differ, first {bad[:6].tolist()}"
 
 
 def test_sao_gpu_matches_reference(ctx):
