@@ -88,17 +88,25 @@ def main():
     stages = [k for k in rp.SUBSTAGES if present.get(k, True)]
     evs = {k: [] for k in stages}
 
-    def step(timed=()):
-        """timed: names of the launches to bracket with HIP events (each pair costs ~7 us of stream time)."""
+    def step(timed=(), overlap=False):
+        """timed: names of the launches to bracket with HIP events (each pair costs ~7 us of stream time).  overlap:
+        put the independent launches of the prediction stage on side streams (measured slower, see engine.py)."""
         nonlocal spare, spare_t, ref1_t
-        for name in stages:
-            if name in timed:
-                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-                e0.record(stream)
-            rp.run_stage(name)
-            if name in timed:
-                e1.record(stream)
-                evs[name].append((e0, e1))
+        pending = {}
+
+        def hook(name, phase):
+            if name not in timed:
+                return
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(stream)
+            if phase == "begin":
+                pending[name] = e
+            else:
+                evs[name].append((pending.pop(name), e))
+
+        rp.overlap = overlap
+        for name in rp.STAGES:
+            rp.run_stage(name, hook)
         if world > 1:
             # push the reconstructed picture to the rank that lists it as a reference (ring), receive
             # ours into the spare buffer, then swap it in as reference 1 of the next step
@@ -117,7 +125,7 @@ def main():
     # launches costs ~80 us of stream time per frame (measured), so the timed region below keeps the events
     # of the dominant kernel only; the survey averages are reported as `survey_launch_us`.
     for _ in range(min(20, max(args.steps, 1))):
-        step(tuple(stages))
+        step(tuple(stages), overlap=False)          # serial, so that every launch can be bracketed on the main stream
     barrier()
     survey = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) * 1e-3 for k, v in evs.items()}
     dom = max(survey, key=survey.get)

@@ -469,6 +469,10 @@ int  ovhip_ctx_create(ovhip_ctx **out, int device, void *stream);
 void ovhip_ctx_destroy(ovhip_ctx *ctx);
 int  ovhip_ctx_sync(ovhip_ctx *ctx);
 const char *ovhip_last_error(const ovhip_ctx *ctx);
+/* Overlap of independent launches inside one stage: route the following launches to side stream k (1..3), or back
+ * to the main stream (0); join makes the main stream wait for every side stream used since the last join. */
+int  ovhip_ctx_fork(ovhip_ctx *ctx, int k);
+int  ovhip_ctx_join(ovhip_ctx *ctx);
 void *ovhip_ctx_stream(ovhip_ctx *ctx);
 
 /* device memory helpers (plain hipMalloc/hipMemcpyAsync on the context stream) */

@@ -227,6 +227,8 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_ctx_create": (C.c_int, [P(vp), C.c_int, vp]),
         "ovhip_ctx_destroy": (None, [vp]),
         "ovhip_ctx_sync": (C.c_int, [vp]),
+        "ovhip_ctx_fork": (C.c_int, [vp, C.c_int]),
+        "ovhip_ctx_join": (C.c_int, [vp]),
         "ovhip_last_error": (C.c_char_p, [vp]),
         "ovhip_ctx_stream": (vp, [vp]),
         "ovhip_malloc": (C.c_int, [vp, C.c_size_t, P(vp)]),
@@ -255,7 +257,7 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
 EXPORTED_SYMBOLS = [
     "ovhip_abi_version", "ovhip_rec_create", "ovhip_rec_destroy", "ovhip_rec_reset", "ovhip_rec_tu",
     "ovhip_rec_pu", "ovhip_rec_dbf_ctu", "ovhip_rec_dbf_planes", "ovhip_dbf_launch", "ovhip_sao_launch", "ovhip_alf_launch", "ovhip_rec_tb_cmds", "ovhip_rec_coefs", "ovhip_rec_mc_units", "ovhip_rec_mcx_units", "ovhip_mcx_launch", "ovhip_rec_affine_cu", "ovhip_rec_lmcs_region", "ovhip_dbf_compact", "ovhip_dbf_launch_edges", "ovhip_rec_ciip", "ovhip_rec_ciip_units", "ovhip_ciip_launch", "ovhip_rec_lmcs_regions", "ovhip_rec_tb_cmds_split", "ovhip_itx_launch_classes", "ovhip_lmcs_build", "ovhip_lmcs_scale_launch", "ovhip_lmcs_inverse_launch", "ovhip_rec_aff_units", "ovhip_rec_aff_side", "ovhip_mca_launch", "ovhip_ctx_create",
-    "ovhip_ctx_destroy", "ovhip_ctx_sync", "ovhip_last_error", "ovhip_ctx_stream", "ovhip_malloc",
+    "ovhip_ctx_destroy", "ovhip_ctx_sync", "ovhip_ctx_fork", "ovhip_ctx_join", "ovhip_last_error", "ovhip_ctx_stream", "ovhip_malloc",
     "ovhip_free", "ovhip_h2d", "ovhip_d2h", "ovhip_pic_alloc", "ovhip_pic_free", "ovhip_pic_upload",
     "ovhip_pic_download", "ovhip_itx_launch", "ovhip_mc_launch",
 ]

@@ -15,10 +15,16 @@
 #define OV_BD 10
 #define OV_PIX_MAX ((1 << OV_BD) - 1)
 
+#define OV_MAX_LANES 4
 struct ovhip_ctx {
     int device;
-    hipStream_t stream;
+    hipStream_t stream;            // the stream launches go to: the main stream, or a side lane after ovhip_ctx_fork
     int owns_stream;
+    hipStream_t main_stream;       // what the caller passed / what ctx_create made
+    hipStream_t lane[OV_MAX_LANES];// side streams for independent launches of one stage (created on first use)
+    hipEvent_t ev_fork, ev_lane[OV_MAX_LANES];
+    int lane_used[OV_MAX_LANES];
+    int have_events;
     char err[256];
 };
 

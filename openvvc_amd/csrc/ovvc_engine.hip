@@ -24,6 +24,7 @@ int ovhip_ctx_create(ovhip_ctx **out, int device, void *stream)
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { free(ctx); return OVHIP_ENODEV; }
         ctx->owns_stream = 1;
     }
+    ctx->main_stream = ctx->stream;
     *out = ctx;
     return OVHIP_OK;
 }
@@ -31,20 +32,64 @@ int ovhip_ctx_create(ovhip_ctx **out, int device, void *stream)
 void ovhip_ctx_destroy(ovhip_ctx *ctx)
 {
     if (!ctx) return;
-    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+    for (int i = 0; i < OV_MAX_LANES; ++i) {
+        if (ctx->lane[i]) (void)hipStreamDestroy(ctx->lane[i]);
+        if (ctx->have_events) (void)hipEventDestroy(ctx->ev_lane[i]);
+    }
+    if (ctx->have_events) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->main_stream);
     free(ctx);
+}
+
+/* Independent launches of one stage (plain / refined / affine prediction units write disjoint samples; the two
+ * size classes of transform blocks likewise) may overlap: ovhip_ctx_fork(ctx, k) routes the following launches to
+ * side stream k (k = 1 .. 3; k = 0 = back to the main stream) after everything enqueued on the main stream so far;
+ * ovhip_ctx_join(ctx) makes the main stream wait for every side stream used since the last join.  Side streams
+ * only fill the ramp-up / tail gaps of the main kernel -- the data dependencies stay those of the stage order. */
+int ovhip_ctx_fork(ovhip_ctx *ctx, int k)
+{
+    if (!ctx || k < 0 || k >= OV_MAX_LANES) return OVHIP_EINVAL;
+    if (k == 0) { ctx->stream = ctx->main_stream; return OVHIP_OK; }
+    if (!ctx->have_events) {
+        OV_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        for (int i = 0; i < OV_MAX_LANES; ++i) OV_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_lane[i], hipEventDisableTiming));
+        ctx->have_events = 1;
+    }
+    if (!ctx->lane[k]) OV_HIP(ctx, hipStreamCreateWithFlags(&ctx->lane[k], hipStreamNonBlocking));
+    if (!ctx->lane_used[k]) {
+        OV_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->main_stream));
+        OV_HIP(ctx, hipStreamWaitEvent(ctx->lane[k], ctx->ev_fork, 0));
+        ctx->lane_used[k] = 1;
+    }
+    ctx->stream = ctx->lane[k];
+    return OVHIP_OK;
+}
+
+int ovhip_ctx_join(ovhip_ctx *ctx)
+{
+    if (!ctx) return OVHIP_EINVAL;
+    ctx->stream = ctx->main_stream;
+    for (int k = 1; k < OV_MAX_LANES; ++k) {
+        if (!ctx->lane_used[k]) continue;
+        OV_HIP(ctx, hipEventRecord(ctx->ev_lane[k], ctx->lane[k]));
+        OV_HIP(ctx, hipStreamWaitEvent(ctx->main_stream, ctx->ev_lane[k], 0));
+        ctx->lane_used[k] = 0;
+    }
+    return OVHIP_OK;
 }
 
 int ovhip_ctx_sync(ovhip_ctx *ctx)
 {
     if (!ctx) return OVHIP_EINVAL;
-    hipError_t e = hipStreamSynchronize(ctx->stream);
+    int r = ovhip_ctx_join(ctx);
+    if (r != OVHIP_OK) return r;
+    hipError_t e = hipStreamSynchronize(ctx->main_stream);
     if (e != hipSuccess) return ov_fail(ctx, OVHIP_ELAUNCH, "hipStreamSynchronize", e);
     return OVHIP_OK;
 }
 
 const char *ovhip_last_error(const ovhip_ctx *ctx) { return ctx ? ctx->err : "no context"; }
-void *ovhip_ctx_stream(ovhip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+void *ovhip_ctx_stream(ovhip_ctx *ctx) { return ctx ? (void *)ctx->main_stream : nullptr; }
 
 int ovhip_malloc(ovhip_ctx *ctx, size_t bytes, void **dptr)
 {

@@ -68,6 +68,13 @@ class Context:
         p.upload(y, cb, cr)
         return p
 
+    def fork(self, k: int):
+        """Route the following launches to side stream k (1..3); 0 = back to the main stream."""
+        self._chk(self.lib.ovhip_ctx_fork(self.h, k), "ctx_fork")
+
+    def join(self):
+        self._chk(self.lib.ovhip_ctx_join(self.h), "ctx_join")
+
     # ---- stages ----
     def itx(self, dst: "DevPic", cmds: "DevBuf", coefs: "DevBuf", n: int | None = None, first: int = 0,
             lmcs_scales: "DevBuf | None" = None):
@@ -233,8 +240,8 @@ class ResidentPicture:
     SUBSTAGES = ("mcp", "mcx", "mca", "ciip", "itx_l", "lmcs_scale", "itx_c", "lmcs_inv", "dbf", "sao", "alf")
     _GROUPS = {"mc": ("mcp", "mcx", "mca", "ciip"), "itx": ("itx_l", "lmcs_scale", "itx_c", "lmcs_inv")}
 
-    def __init__(self, ctx: Context, wl, log2_ctu: int = 7):
-        self.ctx, self.wl, self.log2_ctu = ctx, wl, log2_ctu
+    def __init__(self, ctx: Context, wl, log2_ctu: int = 7, overlap: bool = False):
+        self.ctx, self.wl, self.log2_ctu, self.overlap = ctx, wl, log2_ctu, overlap
         self.refs = [ctx.upload_pic(*r) for r in wl.refs]
         self.dst = ctx.new_pic(wl.w, wl.h)
         self.tmp = ctx.new_pic(wl.w, wl.h)
@@ -264,12 +271,36 @@ class ResidentPicture:
         self.bufs.append(b)
         return b
 
-    def run_stage(self, name: str):
+    def run_stage(self, name: str, on_sub=None):
+        """on_sub(sub_stage_name, "begin" | "end"): optional hook around every launch that goes to the main stream."""
         c = self.ctx
+        if name == "mc" and self.overlap:
+            # plain, refined and affine units write disjoint samples: the three kernels may share the GPU, the CIIP
+            # blend follows once all of them are done.  Measured on MI355X: the two cross-stream event waits cost more
+            # (frame 0.353 ms) than the overlap of ramp-up / tail gains (serial 0.324 ms), hence off by default.
+            self._sub("mcp", on_sub)
+            for k, sub in enumerate(("mcx", "mca"), start=1):
+                c.fork(k)
+                self._launch(sub)
+            c.join()
+            self._sub("ciip", on_sub)
+            return
         if name in self._GROUPS:
             for sub in self._GROUPS[name]:
-                self.run_stage(sub)
-        elif name == "mcp":
+                self._sub(sub, on_sub)
+            return
+        self._sub(name, on_sub)
+
+    def _sub(self, name, on_sub):
+        if on_sub:
+            on_sub(name, "begin")
+        self._launch(name)
+        if on_sub:
+            on_sub(name, "end")
+
+    def _launch(self, name: str):
+        c = self.ctx
+        if name == "mcp":
             c.mc(self.dst, self.refs, self.mc_units, self.lmcs_fwd)
         elif name == "mcx":
             if self.mcx_units:

@@ -50,3 +50,16 @@ def test_ragged_pictures_match_oracle(ctx, w, h, seed):
     if mvs is not None:
         assert np.array_equal(rp.refined_mvs(), mvs)
     rp.free()
+
+
+def test_side_stream_overlap_gives_the_same_picture(ctx):
+    """ovhip_ctx_fork / ovhip_ctx_join: the prediction kernels on three streams produce the same samples."""
+    wl = synth.make_workload(416, 240, 9)
+    outs = []
+    for overlap in (False, True):
+        rp = engine.ResidentPicture(ctx, wl, overlap=overlap)
+        rp.decode()
+        outs.append(rp.result())
+        rp.free()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
