@@ -169,8 +169,9 @@ def main():
         # algorithmic bytes per launch (DESIGN.md "Measurement"): SURVEY 8d terms split per kernel.  A luma
         # sample with its 4:2:0 chroma is 3 bytes; prediction reads nref reference blocks and writes one.
         ciip_area = int((1 << (wl.ciip_units["log2_w"].astype(np.int64) + wl.ciip_units["log2_h"])).sum()) if len(wl.ciip_units) else 0
+        fused = wl.mc_units[((wl.mc_units["flags"] & 128) == 0) & (wl.mc_units["aux"] != 0)]      # CIIP blend fused into k_mc2
         alg = {
-            "mcp": 3 * (nref_area(wl.mc_units) + area(wl.mc_units)) + wl.mc_units.nbytes,
+            "mcp": 3 * (nref_area(wl.mc_units) + area(wl.mc_units) + area(fused)) + wl.mc_units.nbytes,   # + planar samples read
             "mcx": 3 * 3 * area(wl.mcx_units) + wl.mcx_units.nbytes + 16 * len(wl.mcx_units),
             "mca": 3 * (nref_area(wl.aff_units) + area(wl.aff_units)) + wl.aff_units.nbytes + wl.aff_side.nbytes,
             "ciip": 3 * 3 * ciip_area + wl.ciip_units.nbytes,              # intra read + inter read-modify-write

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define OVHIP_ABI_VERSION 2
+#define OVHIP_ABI_VERSION 3
 
 /* ---- error codes (negative, in the spirit of libovvc/overror.h:40-45) ---- */
 #define OVHIP_OK        0
@@ -141,7 +141,8 @@ typedef struct ovhip_mc_unit {
     int8_t   w0, w1;          /* bi weights (4,4 = plain average path; else BCW, w0+w1 == 8)     */
     int32_t  mv0x, mv0y;      /* 1/16 luma pel, ALREADY clipped (chroma uses the same at 1/32)   */
     int32_t  mv1x, mv1y;
-    uint32_t aux;             /* OVHIP_MC_GPM: packed weight plane (see the flag); else 0        */
+    uint32_t aux;             /* OVHIP_MC_GPM: packed weight plane (see the flag).  Otherwise 0, or the fused CIIP
+                               * blend: bits 0-2 wt (1..3), bit 8 = chroma keeps the inter prediction            */
 } ovhip_mc_unit;
 
 /* ------------------------------------------------------------------------------------
@@ -386,7 +387,9 @@ typedef struct ovhip_pu_desc {
     int32_t  poc0, poc1;      /* rpl0[ref_idx0]->poc, rpl1[ref_idx1]->poc (identical-motion test) */
     uint8_t  ref0, ref1;      /* slots of those pictures in the launch's reference table          */
     uint8_t  gpm_split_dir;   /* OVHIP_PU_GPM: gpm_ctx->split_dir (merge_gpm_partition_idx), 0..63  */
-    uint8_t  pad2;
+    uint8_t  ciip_wt;         /* 0: not a CIIP CU; 1..3 = ovhip_ciip_weight(): the units of this PU blend the
+                               * caller's planar prediction in as they are stored (rcn_ciip / rcn_ciip_b),
+                               * no separate ovhip_rec_ciip / ovhip_ciip_launch needed                 */
 } ovhip_pu_desc;
 
 /* One affine CU as rcn_affine_mcp_b_l / rcn_affine_prof_mcp_b_l / rcn_affine_mcp_b_c receive it
@@ -421,6 +424,8 @@ int   ovhip_rec_affine_cu(ovhip_recorder *rec, const ovhip_affine_desc *cu);
  * cu_mode_y[y_bottom >> log2_min_cb] as enum CUMode (cu_utils.h:132-139). */
 int   ovhip_rec_ciip(ovhip_recorder *rec, int32_t x0, int32_t y0, int32_t log2_w, int32_t log2_h,
                      int32_t mode_abv, int32_t mode_lft);
+/* The CIIP weight 1 + (above CU intra) + (left CU intra) (rcn_inter.c:2977-2981) for ovhip_pu_desc.ciip_wt. */
+int   ovhip_ciip_weight(int32_t mode_abv, int32_t mode_lft);
 /* rcn_lmcs_compute_chroma_scale(lmcs_info, stride, progress_field, ctu_buff.y, x0, y0): abv_mask / lft_mask are
  * the two 16-bit availability masks it derives from progress_field (rcn_lmcs.c:327-332).  Returns the
  * region index; TUs recorded afterwards with lmcs_scale_c == 2 refer to it. */
@@ -500,8 +505,10 @@ int  ovhip_lmcs_scale_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_l
                              uint32_t n_regions, const ovhip_lmcs_luts *luts, int16_t *d_scales);
 /* Maps the luma plane through d_bwd_lut (DEVICE, 1024 entries) in place. */
 int  ovhip_lmcs_inverse_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const uint16_t *d_bwd_lut);
+/* intra: the picture holding the caller's planar prediction for units with a fused CIIP blend, or NULL. */
 int  ovhip_mc_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs,
-                     const ovhip_mc_unit *d_units, uint32_t n_units, const uint16_t *d_lmcs_fwd_lut);
+                     const ovhip_mc_unit *d_units, uint32_t n_units, const uint16_t *d_lmcs_fwd_lut,
+                     const ovhip_pic *intra);
 /* Refined units (OVHIP_MC_BDOF / OVHIP_MC_DMVR).  d_mv_out: DEVICE array of 4 int32 per unit
  * (mv0x, mv0y, mv1x, mv1y finally used), or NULL.  It replaces the `OVMV *mv0, *mv1` in/out
  * arguments of rcn_dmvr_mv_refine (rcn_structures.h:628-632): the caller copies them into its

@@ -17,7 +17,7 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libovvc_hip.so"
 
 # ---- constants (include/ovvc_hip.h) ----
-OVHIP_ABI_VERSION = 2
+OVHIP_ABI_VERSION = 3
 DST_VII, DCT_VIII, DCT_II = 0, 1, 2
 TB_TR, TB_DC, TB_TS, TB_TS_RAW = 0, 1, 2, 3
 TB_FLAG_RASTER = 0x80
@@ -72,7 +72,7 @@ class PuDesc(C.Structure):
                 ("bcw_idx_plus1", C.c_uint8), ("prec_amvr_half", C.c_uint8), ("planes", C.c_uint8),
                 ("lmcs", C.c_uint8), ("refine", C.c_uint8), ("mv0x", C.c_int32), ("mv0y", C.c_int32),
                 ("mv1x", C.c_int32), ("mv1y", C.c_int32), ("poc0", C.c_int32), ("poc1", C.c_int32),
-                ("ref0", C.c_uint8), ("ref1", C.c_uint8), ("gpm_split_dir", C.c_uint8), ("pad2", C.c_uint8)]
+                ("ref0", C.c_uint8), ("ref1", C.c_uint8), ("gpm_split_dir", C.c_uint8), ("ciip_wt", C.c_uint8)]
 
 
 class AffineDesc(C.Structure):
@@ -240,7 +240,8 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_pic_upload": (C.c_int, [vp, P(Pic), vp, vp, vp, i32, i32]),
         "ovhip_pic_download": (C.c_int, [vp, P(Pic), vp, vp, vp, i32, i32]),
         "ovhip_itx_launch": (C.c_int, [vp, P(Pic), vp, u32, vp, vp]),
-        "ovhip_mc_launch": (C.c_int, [vp, P(Pic), P(Pic), u32, vp, u32, vp]),
+        "ovhip_mc_launch": (C.c_int, [vp, P(Pic), P(Pic), u32, vp, u32, vp, P(Pic)]),
+        "ovhip_ciip_weight": (C.c_int, [C.c_int32, C.c_int32]),
         "ovhip_mcx_launch": (C.c_int, [vp, P(Pic), P(Pic), u32, vp, u32, vp, vp]),
         "ovhip_mca_launch": (C.c_int, [vp, P(Pic), P(Pic), u32, vp, u32, vp, vp]),
     }
@@ -256,7 +257,7 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
 
 EXPORTED_SYMBOLS = [
     "ovhip_abi_version", "ovhip_rec_create", "ovhip_rec_destroy", "ovhip_rec_reset", "ovhip_rec_tu",
-    "ovhip_rec_pu", "ovhip_rec_dbf_ctu", "ovhip_rec_dbf_planes", "ovhip_dbf_launch", "ovhip_sao_launch", "ovhip_alf_launch", "ovhip_rec_tb_cmds", "ovhip_rec_coefs", "ovhip_rec_mc_units", "ovhip_rec_mcx_units", "ovhip_mcx_launch", "ovhip_rec_affine_cu", "ovhip_rec_lmcs_region", "ovhip_dbf_compact", "ovhip_dbf_launch_edges", "ovhip_rec_ciip", "ovhip_rec_ciip_units", "ovhip_ciip_launch", "ovhip_rec_lmcs_regions", "ovhip_rec_tb_cmds_split", "ovhip_itx_launch_classes", "ovhip_lmcs_build", "ovhip_lmcs_scale_launch", "ovhip_lmcs_inverse_launch", "ovhip_rec_aff_units", "ovhip_rec_aff_side", "ovhip_mca_launch", "ovhip_ctx_create",
+    "ovhip_rec_pu", "ovhip_rec_dbf_ctu", "ovhip_rec_dbf_planes", "ovhip_dbf_launch", "ovhip_sao_launch", "ovhip_alf_launch", "ovhip_rec_tb_cmds", "ovhip_rec_coefs", "ovhip_rec_mc_units", "ovhip_rec_mcx_units", "ovhip_mcx_launch", "ovhip_rec_affine_cu", "ovhip_rec_lmcs_region", "ovhip_dbf_compact", "ovhip_dbf_launch_edges", "ovhip_rec_ciip", "ovhip_ciip_weight", "ovhip_rec_ciip_units", "ovhip_ciip_launch", "ovhip_rec_lmcs_regions", "ovhip_rec_tb_cmds_split", "ovhip_itx_launch_classes", "ovhip_lmcs_build", "ovhip_lmcs_scale_launch", "ovhip_lmcs_inverse_launch", "ovhip_rec_aff_units", "ovhip_rec_aff_side", "ovhip_mca_launch", "ovhip_ctx_create",
     "ovhip_ctx_destroy", "ovhip_ctx_sync", "ovhip_ctx_fork", "ovhip_ctx_join", "ovhip_last_error", "ovhip_ctx_stream", "ovhip_malloc",
     "ovhip_free", "ovhip_h2d", "ovhip_d2h", "ovhip_pic_alloc", "ovhip_pic_free", "ovhip_pic_upload",
     "ovhip_pic_download", "ovhip_itx_launch", "ovhip_mc_launch",

@@ -155,9 +155,12 @@ __global__ __launch_bounds__(64) void k_mc(ovhip_pic dst, RefTable refs, const o
 //     the whole block once; each lane runs both lists for its samples and combines in registers; chroma:
 //     both planes in the same pass
 // =====================================================================================================
+// fused CIIP blend: (intra * wt + inter * (4 - wt) + 2) >> 2, put_weighted_ciip_pixels (rcn_mc.c:1611-1628)
+__device__ __forceinline__ int ciip_blend(int inter, int intra, int wt) { return ov_clip_bd((intra * wt + inter * (4 - wt) + 2) >> 2); }
+
 template <int NOUT>
 __device__ __forceinline__ void luma_finish(const ovhip_mc_unit &u, const ovhip_pic &dst, const int16_t *s_hl, const int tv[2][4],
-                                            int lane, int log2w, const uint16_t *__restrict__ lmcs_fwd)
+                                            int lane, int log2w, const uint16_t *__restrict__ lmcs_fwd, const ovhip_pic &intra)
 {
     const int w = 1 << log2w;
     const int x = lane & (w - 1), yg = lane >> log2w, y0 = yg * NOUT;
@@ -174,13 +177,14 @@ __device__ __forceinline__ void luma_finish(const ovhip_mc_unit &u, const ovhip_
     for (int j = 0; j < NOUT; ++j) {
         int v = (u.flags & OVHIP_MC_GPM) ? mc_gpm(u.aux, x, y0 + j, P[0][j], P[1][j]) : mc_combine(u, P[0][j], P[1][j]);
         if ((u.flags & OVHIP_MC_LMCS) && lmcs_fwd) v = lmcs_fwd[v];
+        if (!(u.flags & OVHIP_MC_GPM) && u.aux) v = ciip_blend(v, intra.y[(u.y + y0 + j) * intra.stride_y + u.x + x], u.aux & 7);
         d[j * dst.stride_y] = (uint16_t)v;
     }
 }
 
 template <int NOUT>
 __device__ __forceinline__ void chroma_finish(const ovhip_mc_unit &u, const ovhip_pic &dst, const int16_t *s_hc, const int tv[2][2],
-                                              int lane, int log2wc, int hc)
+                                              int lane, int log2wc, int hc, const ovhip_pic &intra)
 {
     const int wc = 1 << log2wc;
     const int per_plane = (wc * hc) / NOUT;                   // lanes per plane (power of two, <= 32)
@@ -195,14 +199,18 @@ __device__ __forceinline__ void chroma_finish(const ovhip_mc_unit &u, const ovhi
         if (u.dir & (1 << l)) v_outputs<4, NOUT>(s_hc + (plane * 2 + l) * 8 * CHT_STRIDE + x * CHT_STRIDE, y0, tv[l], P[l]);
     }
     uint16_t *d = (plane ? dst.cr : dst.cb) + ((u.y >> 1) + y0) * dst.stride_c + (u.x >> 1) + x;
+    const bool ciip = !(u.flags & OVHIP_MC_GPM) && u.aux && !(u.aux & 0x100);
+    const uint16_t *ip = ciip ? (plane ? intra.cr : intra.cb) + ((u.y >> 1) + y0) * intra.stride_c + (u.x >> 1) + x : nullptr;
 #pragma unroll
-    for (int j = 0; j < NOUT; ++j)
-        d[j * dst.stride_c] = (uint16_t)((u.flags & OVHIP_MC_GPM) ? mc_gpm(u.aux, 2 * x, 2 * (y0 + j), P[0][j], P[1][j])
-                                                                  : mc_combine(u, P[0][j], P[1][j]));
+    for (int j = 0; j < NOUT; ++j) {
+        int v = (u.flags & OVHIP_MC_GPM) ? mc_gpm(u.aux, 2 * x, 2 * (y0 + j), P[0][j], P[1][j]) : mc_combine(u, P[0][j], P[1][j]);
+        if (ciip) v = ciip_blend(v, ip[j * intra.stride_c], u.aux & 7);
+        d[j * dst.stride_c] = (uint16_t)v;
+    }
 }
 
 __global__ __launch_bounds__(64) void k_mc2(ovhip_pic dst, RefTable refs, const ovhip_mc_unit *__restrict__ units,
-                                             uint32_t n_units, const uint16_t *__restrict__ lmcs_fwd, int xcd)
+                                             uint32_t n_units, const uint16_t *__restrict__ lmcs_fwd, int xcd, ovhip_pic intra)
 {
     __shared__ __attribute__((aligned(16))) uint16_t s_wl[2 * LUMA_WIN + 8];       // luma windows, list 0 / 1 (+ dword over-read slack)
     __shared__ __attribute__((aligned(16))) uint16_t s_wc[4 * CHR_WIN + 8];        // chroma windows [plane * 2 + list]
@@ -297,13 +305,13 @@ __global__ __launch_bounds__(64) void k_mc2(ovhip_pic dst, RefTable refs, const 
     // ---- vertical passes + combine + store: every lane finishes NOUT samples of one column ----
     if (do_l) {
         const int npix = w * h;
-        if (npix >= 256)      luma_finish<4>(u, dst, s_hl, tvl, lane, log2w, lmcs_fwd);
-        else if (npix >= 128) luma_finish<2>(u, dst, s_hl, tvl, lane, log2w, lmcs_fwd);
-        else                  luma_finish<1>(u, dst, s_hl, tvl, lane, log2w, lmcs_fwd);
+        if (npix >= 256)      luma_finish<4>(u, dst, s_hl, tvl, lane, log2w, lmcs_fwd, intra);
+        else if (npix >= 128) luma_finish<2>(u, dst, s_hl, tvl, lane, log2w, lmcs_fwd, intra);
+        else                  luma_finish<1>(u, dst, s_hl, tvl, lane, log2w, lmcs_fwd, intra);
     }
     if (do_c) {
-        if (wc * hc >= 64) chroma_finish<2>(u, dst, s_hc, tvc, lane, log2wc, hc);
-        else               chroma_finish<1>(u, dst, s_hc, tvc, lane, log2wc, hc);
+        if (wc * hc >= 64) chroma_finish<2>(u, dst, s_hc, tvc, lane, log2wc, hc, intra);
+        else               chroma_finish<1>(u, dst, s_hc, tvc, lane, log2wc, hc, intra);
     }
     __syncthreads();          // LDS tiles are reused by the next unit
     }
@@ -345,7 +353,8 @@ extern "C" int ovhip_ciip_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovh
 }
 
 extern "C" int ovhip_mc_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs,
-                               const ovhip_mc_unit *d_units, uint32_t n_units, const uint16_t *d_lmcs_fwd_lut)
+                               const ovhip_mc_unit *d_units, uint32_t n_units, const uint16_t *d_lmcs_fwd_lut,
+                               const ovhip_pic *intra)
 {
     if (!ctx || !dst) return OVHIP_EINVAL;
     if (!n_units) return OVHIP_OK;
@@ -366,8 +375,10 @@ extern "C" int ovhip_mc_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip
     }
     uint32_t grid = cfg_grid > 0 ? (uint32_t)cfg_grid : n_units;
     if (grid > n_units) grid = n_units;
-    if (cfg_ver == 2 && !cfg_ablate) {
-        hipLaunchKernelGGL(k_mc2, dim3(grid), dim3(64), 0, ctx->stream, *dst, t, d_units, n_units, d_lmcs_fwd_lut, cfg_grid > 0 ? 0 : cfg_xcd);
+    if ((cfg_ver == 2 && !cfg_ablate) || intra) {      // the first-generation kernel has no fused CIIP blend
+        // units with a fused CIIP blend read `intra`; without such units the argument is never dereferenced
+        hipLaunchKernelGGL(k_mc2, dim3(grid), dim3(64), 0, ctx->stream, *dst, t, d_units, n_units, d_lmcs_fwd_lut, cfg_grid > 0 ? 0 : cfg_xcd,
+                           intra ? *intra : *dst);
         OV_LAUNCH_CHECK(ctx, "k_mc2");
         return OVHIP_OK;
     }

@@ -510,6 +510,7 @@ ovhip_rec_pu(ovhip_recorder *r, const ovhip_pu_desc *pu)
     int pw = 1 << pu->log2_w, ph = 1 << pu->log2_h;
     int dir = pu->inter_dir & 3;
     if (!dir) return OVHIP_EINVAL;
+    if (pu->ciip_wt > 3 || (pu->ciip_wt && pu->refine)) return OVHIP_EINVAL;
     if (pu->refine & OVHIP_PU_GPM) return rec_pu_gpm(r, pu);
     if (pu->refine) return rec_pu_refined(r, pu);
 
@@ -551,6 +552,8 @@ ovhip_rec_pu(ovhip_recorder *r, const ovhip_pu_desc *pu)
             u->ref0 = pu->ref0; u->ref1 = pu->ref1;
             u->w0 = w0; u->w1 = w1;
             u->mv0x = mv0x; u->mv0y = mv0y; u->mv1x = mv1x; u->mv1y = mv1y;
+            /* fused CIIP blend (rcn_ciip_weighted_sum): chroma of a CU 4 luma samples wide keeps the inter prediction */
+            if (pu->ciip_wt) u->aux = (uint32_t)(pu->ciip_wt & 7) | (pu->log2_w <= 2 ? 0x100u : 0u);
         }
     }
     return nu;
@@ -686,6 +689,13 @@ ovhip_rec_ciip(ovhip_recorder *r, int32_t x0, int32_t y0, int32_t log2_w, int32_
     u->wt = (uint8_t)(1 + intra_abv + intra_lft);
     u->chroma_inter = log2_w <= 2;
     return 1;
+}
+
+int
+ovhip_ciip_weight(int32_t mode_abv, int32_t mode_lft)
+{
+    /* OV_INTRA = 2, OV_MIP = 4 (cu_utils.h:132-139) */
+    return 1 + (mode_abv == 2 || mode_abv == 4) + (mode_lft == 2 || mode_lft == 4);
 }
 
 const ovhip_ciip_unit *ovhip_rec_ciip_units(const ovhip_recorder *r, size_t *n) { *n = r->n_ciip; return r->ciip; }

@@ -113,11 +113,13 @@ class Context:
     def alf(self, dst: "DevPic", src: "DevPic", alf: "DevAlf"):
         self._chk(self.lib.ovhip_alf_launch(self.h, C.byref(dst.s), C.byref(src.s), C.byref(alf.s)), "alf_launch")
 
-    def mc(self, dst: "DevPic", refs: list, units: "DevBuf", lmcs_fwd: "DevBuf | None" = None, n: int | None = None):
+    def mc(self, dst: "DevPic", refs: list, units: "DevBuf", lmcs_fwd: "DevBuf | None" = None, n: int | None = None,
+           intra: "DevPic | None" = None):
+        """intra: picture with the planar prediction of the CIIP CUs whose blend is fused into the units (aux != 0)."""
         n = units.count if n is None else n
         arr = (capi.Pic * len(refs))(*[r.s for r in refs])
         self._chk(self.lib.ovhip_mc_launch(self.h, C.byref(dst.s), arr, len(refs), units.ptr, n,
-                                           lmcs_fwd.ptr if lmcs_fwd else None), "mc_launch")
+                                           lmcs_fwd.ptr if lmcs_fwd else None, C.byref(intra.s) if intra else None), "mc_launch")
 
     def ciip(self, dst: "DevPic", intra: "DevPic", units: "DevBuf", n: int | None = None):
         n = units.count if n is None else n
@@ -301,7 +303,7 @@ class ResidentPicture:
     def _launch(self, name: str):
         c = self.ctx
         if name == "mcp":
-            c.mc(self.dst, self.refs, self.mc_units, self.lmcs_fwd)
+            c.mc(self.dst, self.refs, self.mc_units, self.lmcs_fwd, intra=self.intra)
         elif name == "mcx":
             if self.mcx_units:
                 c.mcx(self.dst, self.refs, self.mcx_units, self.lmcs_fwd, self.mv_out)

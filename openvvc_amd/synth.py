@@ -234,9 +234,11 @@ def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6
             pd.refine = capi.PU_DMVR | (capi.PU_BDOF if rs.random_sample() < 0.8 else 0)
         elif m == GPM:
             pd.refine = capi.PU_GPM; pd.inter_dir = 3; pd.gpm_split_dir = int(rs.randint(0, 64))
-        rec.pu(pd)
+        pd.ciip_wt = 0
         if m == CIIP:
-            rec.ciip(x, y, l2w, l2h, cu_modes[rs.randint(0, 4)], cu_modes[rs.randint(0, 4)])
+            # rcn_ciip(_b): inter prediction + blend with the planar prediction (caller-supplied picture), fused into the units
+            pd.ciip_wt = capi.load().ovhip_ciip_weight(cu_modes[rs.randint(0, 4)], cu_modes[rs.randint(0, 4)])
+        rec.pu(pd)
 
     # ---- transform units ----
     st = capi.TuState()
@@ -333,7 +335,7 @@ def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6
     n_luma = classes[0] + classes[1]
     wl = Workload(w, h, seed, refs, pocs, cus, rec.mc_units(), cmds, rec.coefs(), n_luma_cmds=n_luma, tb_classes=classes)
     wl.mcx_units, wl.aff_units, wl.aff_side, wl.ciip_units = rec.mcx_units(), rec.aff_units(), rec.aff_side(), rec.ciip_units()
-    if len(wl.ciip_units):
+    if len(wl.ciip_units) or (mode == CIIP).any():
         wl.intra = random_picture(rs, w, h)
     if lmcs_on:
         wl.lmcs = _lmcs_tables(rs)

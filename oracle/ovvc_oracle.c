@@ -345,7 +345,7 @@ static int bi_combine(const ovhip_mc_unit *u, int p0, int p1)
 }
 
 static void mc_plane(const oracle_pic *dst, const oracle_pic *refs, const ovhip_mc_unit *u, int plane,
-                     const uint16_t *lmcs_fwd)
+                     const uint16_t *lmcs_fwd, const oracle_pic *intra)
 {
     const int c = plane != 0;
     const int w = u->w >> c, h = u->h >> c;
@@ -376,6 +376,13 @@ static void mc_plane(const oracle_pic *dst, const oracle_pic *refs, const ovhip_
                 v = clip_bd((p[1][j * 16 + i] * (8 - wgt) + p[0][j * 16 + i] * wgt + 64) >> 7);
             }
             if (!c && (u->flags & OVHIP_MC_LMCS) && lmcs_fwd) v = lmcs_fwd[v & PIX_MAX]; /* rcn_lmcs.c:275-295 */
+            if (!(u->flags & OVHIP_MC_GPM) && u->aux && intra && !(c && (u->aux & 0x100))) {
+                /* fused CIIP blend: rcn_ciip_weighted_sum + put_weighted_ciip_pixels (rcn_inter.c:2968-3009, rcn_mc.c:1611-1628) */
+                int is;
+                const uint16_t *ip = plane_ptr(intra, plane, &is) + y * is + x;
+                const int wt = u->aux & 7;
+                v = clip_bd((ip[j * is + i] * wt + v * (4 - wt) + 2) >> 2);
+            }
             d[j * dstride + i] = (uint16_t)v;
         }
     }
@@ -593,17 +600,23 @@ static void mc_refined_unit(const oracle_pic *dst, const oracle_pic *refs, const
  * units flagged OVHIP_MC_BDOF / OVHIP_MC_DMVR go through mc_refined_unit.  mv_out (may be NULL):
  * 4 int32 per unit, the motion vectors finally used (DMVR write-back for TMVP,
  * vcl_coding_unit.c:2621-2645). */
-void oracle_mc_ex(const oracle_pic *dst, const oracle_pic *refs, uint32_t n_refs,
-                  const ovhip_mc_unit *units, uint32_t n, const uint16_t *lmcs_fwd, int32_t *mv_out)
+void oracle_mc_full(const oracle_pic *dst, const oracle_pic *refs, uint32_t n_refs,
+                    const ovhip_mc_unit *units, uint32_t n, const uint16_t *lmcs_fwd, int32_t *mv_out, const oracle_pic *intra)
 {
     (void)n_refs;
     for (uint32_t i = 0; i < n; ++i) {
         const ovhip_mc_unit *u = &units[i];
         if (u->flags & (OVHIP_MC_BDOF | OVHIP_MC_DMVR)) { mc_refined_unit(dst, refs, u, lmcs_fwd, mv_out ? mv_out + 4 * i : NULL); continue; }
         if (mv_out) { mv_out[4 * i] = u->mv0x; mv_out[4 * i + 1] = u->mv0y; mv_out[4 * i + 2] = u->mv1x; mv_out[4 * i + 3] = u->mv1y; }
-        if (!(u->flags & OVHIP_MC_NO_LUMA)) mc_plane(dst, refs, u, 0, lmcs_fwd);
-        if (!(u->flags & OVHIP_MC_NO_CHROMA)) { mc_plane(dst, refs, u, 1, lmcs_fwd); mc_plane(dst, refs, u, 2, lmcs_fwd); }
+        if (!(u->flags & OVHIP_MC_NO_LUMA)) mc_plane(dst, refs, u, 0, lmcs_fwd, intra);
+        if (!(u->flags & OVHIP_MC_NO_CHROMA)) { mc_plane(dst, refs, u, 1, lmcs_fwd, intra); mc_plane(dst, refs, u, 2, lmcs_fwd, intra); }
     }
+}
+
+void oracle_mc_ex(const oracle_pic *dst, const oracle_pic *refs, uint32_t n_refs,
+                  const ovhip_mc_unit *units, uint32_t n, const uint16_t *lmcs_fwd, int32_t *mv_out)
+{
+    oracle_mc_full(dst, refs, n_refs, units, n, lmcs_fwd, mv_out, NULL);
 }
 
 void oracle_mc(const oracle_pic *dst, const oracle_pic *refs, uint32_t n_refs,
@@ -685,8 +698,8 @@ void oracle_mca(const oracle_pic *dst, const oracle_pic *refs, uint32_t n_refs,
             m.flags = OVHIP_MC_NO_LUMA;
             m.ref0 = u->ref0; m.ref1 = u->ref1; m.w0 = u->w0; m.w1 = u->w1;
             m.mv0x = mvs[0]; m.mv0y = mvs[1]; m.mv1x = mvs[2]; m.mv1y = mvs[3];
-            mc_plane(dst, refs, &m, 1, NULL);
-            mc_plane(dst, refs, &m, 2, NULL);
+            mc_plane(dst, refs, &m, 1, NULL, NULL);
+            mc_plane(dst, refs, &m, 2, NULL, NULL);
         }
     }
 }

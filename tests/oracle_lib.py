@@ -30,6 +30,8 @@ def lib():
         _lib.oracle_itx.restype = None
         _lib.oracle_mc.argtypes = [C.POINTER(OPic), C.POINTER(OPic), C.c_uint32, vp, C.c_uint32, vp]
         _lib.oracle_mc.restype = None
+        _lib.oracle_mc_full.argtypes = [C.POINTER(OPic), C.POINTER(OPic), C.c_uint32, vp, C.c_uint32, vp, vp, C.POINTER(OPic)]
+        _lib.oracle_mc_full.restype = None
         _lib.oracle_mc_ex.argtypes = [C.POINTER(OPic), C.POINTER(OPic), C.c_uint32, vp, C.c_uint32, vp, vp]
         _lib.oracle_mc_ex.restype = None
         _lib.oracle_itx_ex.argtypes = [C.POINTER(OPic), vp, C.c_uint32, vp, vp]
@@ -101,7 +103,8 @@ def lmcs_inverse(pic: HostPic, bwd_lut: np.ndarray):
     lib().oracle_lmcs_inverse(C.byref(s), bwd_lut.ctypes.data)
 
 
-def mc(dst: HostPic, refs, units: np.ndarray, lmcs_fwd=None):
+def mc(dst: HostPic, refs, units: np.ndarray, lmcs_fwd=None, intra: "HostPic | None" = None):
+    """intra: planar-prediction picture for units that carry a fused CIIP blend (aux != 0)."""
     s = dst.struct()
     arr = (OPic * len(refs))(*[r.struct() for r in refs])
     units = np.ascontiguousarray(units)
@@ -109,7 +112,8 @@ def mc(dst: HostPic, refs, units: np.ndarray, lmcs_fwd=None):
     if lmcs_fwd is not None:
         lmcs_fwd = np.ascontiguousarray(lmcs_fwd, dtype=np.uint16)
         lut = lmcs_fwd.ctypes.data
-    lib().oracle_mc(C.byref(s), arr, len(refs), units.ctypes.data, len(units), lut)
+    ip = intra.struct() if intra is not None else None
+    lib().oracle_mc_full(C.byref(s), arr, len(refs), units.ctypes.data, len(units), lut, None, C.byref(ip) if ip else None)
 
 
 def ciip(dst: HostPic, intra: HostPic, units: np.ndarray):

@@ -32,7 +32,7 @@ def decode(wl, rows=None, stages=STAGES, want_mvs=False):
         luma, chroma = _rows(luma, y0, y1, True), _rows(chroma, y0, y1, True)
     mvs = None
     if "mc" in stages:
-        oracle_lib.mc(dst, refs, units, wl.lmcs_fwd)
+        oracle_lib.mc(dst, refs, units, wl.lmcs_fwd, intra=HostPic(wl.w, wl.h, *wl.intra) if wl.intra is not None else None)
         if ux is not None and len(ux):
             mvs = oracle_lib.mc_ex(dst, refs, ux, wl.lmcs_fwd)
         if ua is not None and len(ua):

@@ -87,7 +87,7 @@ def test_launch_argument_checks_need_no_device(built_lib):
     """NULL context / picture arguments are rejected before any HIP call."""
     lib = built_lib
     assert lib.ovhip_itx_launch(None, None, None, 0, None, None) < 0
-    assert lib.ovhip_mc_launch(None, None, None, 0, None, 0, None) < 0
+    assert lib.ovhip_mc_launch(None, None, None, 0, None, 0, None, None) < 0
     assert lib.ovhip_mcx_launch(None, None, None, 0, None, 0, None, None) < 0
     assert lib.ovhip_mca_launch(None, None, None, 0, None, 0, None, None) < 0
     assert lib.ovhip_ciip_launch(None, None, None, None, 0) < 0

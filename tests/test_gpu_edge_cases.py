@@ -23,14 +23,14 @@ def test_empty_launches_are_noops(ctx):
     refs = (capi.Pic * 1)(s)
     assert lib.ovhip_itx_launch(h, C.byref(s), None, 0, None, None) == 0
     assert lib.ovhip_itx_launch_classes(h, C.byref(s), None, 0, 0, None, None) == 0
-    assert lib.ovhip_mc_launch(h, C.byref(s), refs, 1, None, 0, None) == 0
+    assert lib.ovhip_mc_launch(h, C.byref(s), refs, 1, None, 0, None, None) == 0
     assert lib.ovhip_mcx_launch(h, C.byref(s), refs, 1, None, 0, None, None) == 0
     assert lib.ovhip_mca_launch(h, C.byref(s), refs, 1, None, 0, None, None) == 0
     assert lib.ovhip_ciip_launch(h, C.byref(s), C.byref(s), None, 0) == 0
     luts = capi.lmcs_build(capi.LmcsData())
     assert lib.ovhip_lmcs_scale_launch(h, C.byref(s), None, 0, C.byref(luts), None) == 0
     # a non-empty launch with a NULL buffer is an error, reported through ovhip_last_error
-    assert lib.ovhip_mc_launch(h, C.byref(s), refs, 1, None, 5, None) < 0
+    assert lib.ovhip_mc_launch(h, C.byref(s), refs, 1, None, 5, None, None) < 0
     assert b"ovhip_mc_launch" in lib.ovhip_last_error(h)
     ctx.sync()
     empty.free()

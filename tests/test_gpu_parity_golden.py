@@ -152,10 +152,18 @@ def test_gpm_ciip_gpu_matches_reference(ctx):
         rec.reset()
         rec.pu(d)
         band = tall.band(i * rh, rh)
-        ctx.mc(band, drefs, ctx.upload(rec.mc_units()))
-        if i >= n_gpm:
-            rec.ciip(d.x0, d.y0, d.log2_w, d.log2_h, int(modes[i, 0]), int(modes[i, 1]))
-            ctx.ciip(band, dintra, ctx.upload(rec.ciip_units()))
+        if i >= n_gpm and i % 2:
+            # CIIP, route 2: the blend fused into the prediction units (ovhip_pu_desc.ciip_wt + intra picture)
+            d.ciip_wt = ctx.lib.ovhip_ciip_weight(int(modes[i, 0]), int(modes[i, 1]))
+            rec.reset()
+            rec.pu(d)
+            ctx.mc(band, drefs, ctx.upload(rec.mc_units()), intra=dintra)
+            d.ciip_wt = 0
+        else:
+            ctx.mc(band, drefs, ctx.upload(rec.mc_units()))
+            if i >= n_gpm:                      # CIIP, route 1: separate blend launch
+                rec.ciip(d.x0, d.y0, d.log2_w, d.log2_h, int(modes[i, 0]), int(modes[i, 1]))
+                ctx.ciip(band, dintra, ctx.upload(rec.ciip_units()))
         w, h = 1 << d.log2_w, 1 << d.log2_h
         rects += [(0, d.x0, d.y0 + i * rh, w, h, int(exp_off[i, 0])),
                   (1, d.x0 >> 1, (d.y0 >> 1) + i * (rh // 2), w >> 1, h >> 1, int(exp_off[i, 1])),

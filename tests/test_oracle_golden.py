@@ -127,6 +127,16 @@ def test_gpm_ciip_oracle_matches_reference(built_lib):
                  (2, d.x0 >> 1, d.y0 >> 1, w >> 1, h >> 1, int(exp_off[i, 2]))]
         what = f"GPM split {d.gpm_split_dir}" if i < n_gpm else f"CIIP modes {modes[i].tolist()} dir {d.inter_dir}"
         golden_cases.check_rects(dst, rects, exp, f"case {i} {what} {w}x{h} @({d.x0},{d.y0})")
+        if i >= n_gpm:
+            # second route: the blend fused into the prediction units (ovhip_pu_desc.ciip_wt)
+            d.ciip_wt = capi.load().ovhip_ciip_weight(int(modes[i, 0]), int(modes[i, 1]))
+            rec.reset()
+            rec.pu(d)
+            assert len(rec.ciip_units()) == 0 and (rec.mc_units()["aux"] != 0).all()
+            dst = HostPic(rw, rh)
+            oracle_lib.mc(dst, refs, rec.mc_units(), intra=intra)
+            golden_cases.check_rects(dst, rects, exp, f"case {i} fused {what} {w}x{h}")
+            d.ciip_wt = 0
     assert n_gpm >= 192 and len(descs) - n_gpm >= 100
 
 
