@@ -35,121 +35,10 @@ __device__ __forceinline__ int mc_combine(const ovhip_mc_unit &u, int p0, int p1
     return ov_clip_bd((p1 * u.w1 + p0 * u.w0 + 64) >> 7);
 }
 
-__global__ __launch_bounds__(64) void k_mc(ovhip_pic dst, RefTable refs, const ovhip_mc_unit *__restrict__ units,
-                                            uint32_t n_units, const uint16_t *__restrict__ lmcs_fwd, int ablate, int xcd)
-{
-    __shared__ __attribute__((aligned(16))) uint16_t s_wl[2][LUMA_WIN];          // luma windows, list 0 / 1
-    __shared__ __attribute__((aligned(16))) uint16_t s_wc[2][2][CHR_WIN];        // chroma windows [Cb/Cr][list]
-    __shared__ __attribute__((aligned(16))) int16_t  s_hl[2][16 * HT_STRIDE];    // transposed H-pass tiles
-    __shared__ __attribute__((aligned(16))) int16_t  s_hc[2][2][8 * CHT_STRIDE];
-
-    const int lane = threadIdx.x;
-    // grid-stride over units: the chip launches ~400 workgroups/us, so one workgroup per unit would be
-    // dispatch-bound; a resident grid of single-wave workgroups walks the unit list instead
-    for (uint32_t wg = blockIdx.x; wg < n_units; wg += gridDim.x) {
-    // XCD-aware order: workgroup i runs on XCD i % 8, so XCD k walks the k-th contiguous eighth of the
-    // unit list (= a compact area of the picture) and neighbouring reference windows meet in ITS L2
-    const uint32_t bid = xcd ? ov_xcd_slot(wg, n_units) : wg;
-    const ovhip_mc_unit u = units[bid];
-
-    const bool do_l = !(u.flags & OVHIP_MC_NO_LUMA), do_c = !(u.flags & OVHIP_MC_NO_CHROMA);
-    const int w = u.w, h = u.h, wc = w >> 1, hc = h >> 1;
-    const int log2w = 31 - __clz(w), log2wc = log2w - 1;
-
-    // ---- issue all loads, then park ----
-    LumaStage sl[2];
-    ChromaStage sc[2][2];
-#pragma unroll
-    for (int l = 0; l < 2; ++l) {
-        if (!(u.dir & (1 << l))) continue;
-        const ovhip_pic &rp = refs.p[l ? u.ref1 : u.ref0];
-        const int mvx = l ? u.mv1x : u.mv0x, mvy = l ? u.mv1y : u.mv0y;
-        if (ablate & 1) continue;
-        if (do_l) sl[l].issue(rp.y, rp.stride_y, rp.w, rp.h, u.x + (mvx >> 4) - 3, u.y + (mvy >> 4) - 3, w + 7, h + 7, lane, s_wl[l], WIN_STRIDE);
-        if (do_c) {
-            const int px = (u.x >> 1) + (mvx >> 5) - 1, py = (u.y >> 1) + (mvy >> 5) - 1;
-            sc[0][l].issue(rp.cb, rp.stride_c, rp.w >> 1, rp.h >> 1, px, py, wc + 3, hc + 3, lane, s_wc[0][l], CWIN_STRIDE);
-            sc[1][l].issue(rp.cr, rp.stride_c, rp.w >> 1, rp.h >> 1, px, py, wc + 3, hc + 3, lane, s_wc[1][l], CWIN_STRIDE);
-        }
-    }
-#pragma unroll
-    for (int l = 0; l < 2; ++l) {
-        if (!(u.dir & (1 << l)) || (ablate & 1)) continue;
-        if (do_l) sl[l].park(s_wl[l], WIN_STRIDE, w + 7, h + 7, lane);
-        if (do_c) {
-            sc[0][l].park(s_wc[0][l], CWIN_STRIDE, wc + 3, hc + 3, lane);
-            sc[1][l].park(s_wc[1][l], CWIN_STRIDE, wc + 3, hc + 3, lane);
-        }
-    }
-    __syncthreads();
-
-    // ---- horizontal passes ----
-    const int8_t *fvl[2], *fvc[2];
-#pragma unroll
-    for (int l = 0; l < 2; ++l) {
-        if (!(u.dir & (1 << l))) continue;
-        const int mvx = l ? u.mv1x : u.mv0x, mvy = l ? u.mv1y : u.mv0y;
-        int fx = mvx & 15, fy = mvy & 15;
-        const int8_t *fh;
-        if (u.flags & OVHIP_MC_FILT_4x4) { fh = ovt_mc_luma4[fx]; fvl[l] = ovt_mc_luma4[fy]; }
-        else {
-            if (u.flags & OVHIP_MC_HPEL_FILT) { if (fx == 8) fx = 16; if (fy == 8) fy = 16; }
-            fh = ovt_mc_luma[fx]; fvl[l] = ovt_mc_luma[fy];
-        }
-        fvc[l] = ovt_mc_chroma[mvy & 31];
-        if (ablate & 2) continue;
-        if (do_l) h_pass<8>(s_wl[l], WIN_STRIDE, sl[l].off, s_hl[l], HT_STRIDE, log2w, h + 7, fh, lane);
-        if (do_c) {
-            h_pass<4>(s_wc[0][l], CWIN_STRIDE, sc[0][l].off, s_hc[0][l], CHT_STRIDE, log2wc, hc + 3, ovt_mc_chroma[mvx & 31], lane);
-            h_pass<4>(s_wc[1][l], CWIN_STRIDE, sc[1][l].off, s_hc[1][l], CHT_STRIDE, log2wc, hc + 3, ovt_mc_chroma[mvx & 31], lane);
-        }
-    }
-    __syncthreads();
-
-    // ---- vertical passes + combine + store ----
-    if (ablate & 4) continue;
-    if (do_l) {
-        int P[2][4];
-#pragma unroll
-        for (int l = 0; l < 2; ++l) if (u.dir & (1 << l)) v_pass<8>(s_hl[l], HT_STRIDE, log2w, h, fvl[l], lane, P[l]);
-        if (lane < (((h + 3) >> 2) << log2w)) {
-            const int x = lane & (w - 1), g = lane >> log2w;
-            uint16_t *d = dst.y + (u.y + 4 * g) * dst.stride_y + u.x + x;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (4 * g + j < h) {
-                    int v = (u.flags & OVHIP_MC_GPM) ? mc_gpm(u.aux, x, 4 * g + j, P[0][j], P[1][j]) : mc_combine(u, P[0][j], P[1][j]);
-                    if ((u.flags & OVHIP_MC_LMCS) && lmcs_fwd) v = lmcs_fwd[v];
-                    d[j * dst.stride_y] = (uint16_t)v;
-                }
-            }
-        }
-    }
-    if (do_c) {
-#pragma unroll
-        for (int comp = 0; comp < 2; ++comp) {
-            int P[2][4];
-#pragma unroll
-            for (int l = 0; l < 2; ++l) if (u.dir & (1 << l)) v_pass<4>(s_hc[comp][l], CHT_STRIDE, log2wc, hc, fvc[l], lane, P[l]);
-            if (lane < (((hc + 3) >> 2) << log2wc)) {
-                const int x = lane & (wc - 1), g = lane >> log2wc;
-                uint16_t *d = (comp ? dst.cr : dst.cb) + ((u.y >> 1) + 4 * g) * dst.stride_c + (u.x >> 1) + x;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (4 * g + j < hc)
-                        d[j * dst.stride_c] = (uint16_t)((u.flags & OVHIP_MC_GPM) ? mc_gpm(u.aux, 2 * x, 2 * (4 * g + j), P[0][j], P[1][j])
-                                                                                  : mc_combine(u, P[0][j], P[1][j]));
-            }
-        }
-    }
-    __syncthreads();          // LDS tiles are reused by the next unit
-    }
-}
-
 // =====================================================================================================
-// k_mc2: same arithmetic as k_mc, work laid out so that the wave's 64 lanes stay busy for every unit
-// shape (SQ counters showed k_mc bound by VALU issue at ~57 % of the chip with most passes running at
-// 10-50 % lane occupancy for 8x8 / 16x8 units):
+// k_mc2 (the first version, k_mc, ran one pass per list and per plane with 4 rows per lane: SQ counters showed it
+// bound by VALU issue at ~57 % of the chip with most passes at 10-50 % lane occupancy for 8x8 / 16x8 units; this
+// layout keeps the wave's 64 lanes busy for every unit shape, 82 -> 67 us at 4K):
 //   * horizontal pass: ONE loop over the tasks of both lists (luma), one over both lists x both chroma planes
 //   * vertical pass: lane = (column, group of NOUT rows) with NOUT = max(1, w*h/64) so that 64 lanes cover
 //     the whole block once; each lane runs both lists for its samples and combines in registers; chroma:
@@ -364,25 +253,12 @@ extern "C" int ovhip_mc_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip
     memset(&t, 0, sizeof(t));
     for (uint32_t i = 0; i < n_refs; ++i) t.p[i] = refs[i];
     for (uint32_t i = n_refs; i < MC_MAX_REFS; ++i) t.p[i] = refs[0];
-    static int cfg_grid = -1, cfg_ablate = 0, cfg_xcd = 1, cfg_ver = 2;
-    if (cfg_grid < 0) {                       // developer knobs (profiling experiments only)
-        const char *g = getenv("OVHIP_MC_GRID"), *a = getenv("OVHIP_MC_ABLATE"), *x = getenv("OVHIP_MC_XCD");
-        cfg_grid = g ? atoi(g) : 0;
-        cfg_ablate = a ? atoi(a) : 0;
-        cfg_xcd = x ? atoi(x) : 1;
-        const char *v = getenv("OVHIP_MC_KERNEL");          // 1: k_mc (one pass per list / plane), 2: k_mc2 (merged passes)
-        cfg_ver = v ? atoi(v) : 2;
-    }
-    uint32_t grid = cfg_grid > 0 ? (uint32_t)cfg_grid : n_units;
-    if (grid > n_units) grid = n_units;
-    if ((cfg_ver == 2 && !cfg_ablate) || intra) {      // the first-generation kernel has no fused CIIP blend
-        // units with a fused CIIP blend read `intra`; without such units the argument is never dereferenced
-        hipLaunchKernelGGL(k_mc2, dim3(grid), dim3(64), 0, ctx->stream, *dst, t, d_units, n_units, d_lmcs_fwd_lut, cfg_grid > 0 ? 0 : cfg_xcd,
-                           intra ? *intra : *dst);
-        OV_LAUNCH_CHECK(ctx, "k_mc2");
-        return OVHIP_OK;
-    }
-    hipLaunchKernelGGL(k_mc, dim3(grid), dim3(64), 0, ctx->stream, *dst, t, d_units, n_units, d_lmcs_fwd_lut, cfg_ablate, cfg_grid > 0 ? 0 : cfg_xcd);
-    OV_LAUNCH_CHECK(ctx, "k_mc");
+    static int cfg_xcd = -1;
+    if (cfg_xcd < 0) { const char *x = getenv("OVHIP_MC_XCD"); cfg_xcd = x ? atoi(x) : 1; }   // experiment knob: XCD-aware unit order
+    // one single-wave workgroup per unit (measured faster than a resident grid-stride grid).  Units with a fused CIIP
+    // blend read `intra`; without such units the argument is never dereferenced.
+    hipLaunchKernelGGL(k_mc2, dim3(n_units), dim3(64), 0, ctx->stream, *dst, t, d_units, n_units, d_lmcs_fwd_lut, cfg_xcd,
+                       intra ? *intra : *dst);
+    OV_LAUNCH_CHECK(ctx, "k_mc2");
     return OVHIP_OK;
 }

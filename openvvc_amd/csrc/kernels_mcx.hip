@@ -114,7 +114,7 @@ __global__ __launch_bounds__(64) void k_mcx(ovhip_pic dst, RefTable refs, const 
 
     const int lane = threadIdx.x;
     for (uint32_t wg = blockIdx.x; wg < n_units; wg += gridDim.x) {
-    const uint32_t bid = gridDim.x == n_units ? ov_xcd_slot(wg, n_units) : wg;      // XCD-aware order, see k_mc
+    const uint32_t bid = gridDim.x == n_units ? ov_xcd_slot(wg, n_units) : wg;      // XCD-aware order, see k_mc2
     const ovhip_mc_unit u = units[bid];
     const bool dmvr = u.flags & OVHIP_MC_DMVR;
     bool use_bdof = u.flags & OVHIP_MC_BDOF;
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(64) void k_mca(ovhip_pic dst, RefTable refs, const 
 
     const int lane = threadIdx.x;
     for (uint32_t wg = blockIdx.x; wg < n_units; wg += gridDim.x) {
-    const uint32_t bid = gridDim.x == n_units ? ov_xcd_slot(wg, n_units) : wg;      // XCD-aware order, see k_mc
+    const uint32_t bid = gridDim.x == n_units ? ov_xcd_slot(wg, n_units) : wg;      // XCD-aware order, see k_mc2
     const ovhip_aff_unit u = units[bid];
     const int nsx = u.w >> 2, nsb = nsx * (u.h >> 2), ncx = u.w >> 3, ncb = ncx * (u.h >> 3);
     const bool do_c = !(u.flags & OVHIP_AFF_NO_CHROMA);

@@ -131,35 +131,6 @@ __device__ __forceinline__ void load_row_at(const uint16_t *row, int s0, int d[N
     }
 }
 
-// ---- stage 2: horizontal pass LDS -> LDS (transposed).  One task = one window row x 4 consecutive
-// outputs.  t = F_h(src) >> (BITDEPTH - 8), stored column-major so that stage 3 reads rows again. ----
-template <int NT>
-__device__ __forceinline__ void h_pass(const uint16_t *s_win, int wstride, int off, int16_t *s_ht, int htstride, int log2w,
-                                       int wh, const int8_t *fh, int lane)
-{
-    int tp[NT / 2];
-    pack_taps<NT>(fh, tp);
-    const int w = 1 << log2w;
-    const int log2seg = log2w > 2 ? log2w - 2 : 0;          // 4-sample segments per row
-    const int nout = w < 4 ? w : 4;
-    const bool ident = fh[NT / 2 - 1] == 64;                // integer position: t = s << 4, no FIR
-    for (int t = lane; t < (wh << log2seg); t += 64) {
-        const int r = t >> log2seg, x0 = (t & ((1 << log2seg) - 1)) << 2;
-        int d[NT / 2 + 2], out[4];
-        if (ident) {
-            const uint16_t *sp = s_win + r * wstride + off + x0 + NT / 2 - 1;
-#pragma unroll
-            for (int o = 0; o < 4; ++o) out[o] = (int)sp[o] << 6;
-        } else {
-            load_row_at<NT>(s_win + r * wstride, off + x0, d);
-            fir4<NT>(d, tp, out);
-        }
-#pragma unroll
-        for (int o = 0; o < 4; ++o)
-            if (o < nout) s_ht[(x0 + o) * htstride + r] = (int16_t)(out[o] >> (OV_BD - 8));
-    }
-}
-
 // ---- stage 3: vertical pass LDS -> registers.  Lane = one column x 4 consecutive rows (group g):
 // P[j] = F_v(t)[x][4g + j] >> 6, the 14-bit intermediate of put_vvc_{qpel,epel}_*. ----
 template <int NT>
