@@ -84,6 +84,9 @@ enum {                        /* ovhip_tb_cmd.res_mode: how the residual r is ap
                                * device-derived scales (ovhip_lmcs_scale_launch), not the scale itself */
 };
 #define OVHIP_TB_FLAG_RASTER 0x80  /* in .kind: coefficients stored raster (2xN / Nx2 chroma TBs) */
+#define OVHIP_TB_FLAG_BDPCM  0x40  /* in .kind (with TS / TS_RAW): block DPCM, rcn_bdpcm_tb (rcn_transform_tree.c:631-688):
+                                    * the LEVELS are accumulated along rows (tr_h = 0) or columns (tr_h = 1) with int16
+                                    * saturation, THEN de-quantised (TS) or taken as they are (TS_RAW)               */
 
 typedef struct ovhip_tb_cmd {
     uint16_t x, y;            /* top-left in samples of `plane`                                 */

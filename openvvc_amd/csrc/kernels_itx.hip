@@ -164,8 +164,8 @@ __global__ __launch_bounds__(NT) void k_itx(ovhip_pic pic, const ovhip_tb_cmd *_
 
     const int log2_w = c.log2_w, log2_h = c.log2_h;
     const int tb_w = 1 << log2_w, tb_h = 1 << log2_h;
-    const int kind = c.kind & 0x7f;
-    const bool raster = c.kind & OVHIP_TB_FLAG_RASTER;
+    const int kind = c.kind & 0x3f;
+    const bool raster = c.kind & OVHIP_TB_FLAG_RASTER, bdpcm = c.kind & OVHIP_TB_FLAG_BDPCM;
     const int cw = min(tb_w, 32), ch = min(tb_h, 32);
     const int16_t *src = arena + c.coef_off;
 
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(NT) void k_itx(ovhip_pic pic, const ovhip_tb_cmd *_
     if (ablate & 2) {
     } else if (raster) {
         for (int i = lane; i < tb_w * tb_h; i += NT)
-            s_coef[i] = kind == OVHIP_TB_TS_RAW ? src[i] : (int16_t)dequant1(src[i], c.dq_scale, c.dq_shift, c.dq_neg);
+            s_coef[i] = (kind == OVHIP_TB_TS_RAW || bdpcm) ? src[i] : (int16_t)dequant1(src[i], c.dq_scale, c.dq_shift, c.dq_neg);
     } else {
         const int nx = cw >> 2, ny = ch >> 2;
         if (lane < nx * ny) {
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(NT) void k_itx(ovhip_pic pic, const ovhip_tb_cmd *_
                     for (int q = 0; q < 4; ++q) {
                         int word = w[r * 2 + (q >> 1)];
                         int cv = (q & 1) ? (word >> 16) : (int)(int16_t)(word & 0xffff);
-                        d[r * cw + q] = (int16_t)dequant1(cv, c.dq_scale, c.dq_shift, c.dq_neg);
+                        d[r * cw + q] = bdpcm ? (int16_t)cv : (int16_t)dequant1(cv, c.dq_scale, c.dq_shift, c.dq_neg);
                     }
                 }
             } else {
@@ -279,6 +279,24 @@ __global__ __launch_bounds__(NT) void k_itx(ovhip_pic pic, const ovhip_tb_cmd *_
                                                tr_pass_lds<2, true, NT>(s_tmp, tb_h, s_mh, log2_w, k2, tb_h, 20 - OV_BD, nullptr, lane, sink);
         else                                   tr_pass_lds<4, true, NT>(s_tmp, tb_h, s_mh, log2_w, k2, tb_h, 20 - OV_BD, nullptr, lane, sink);
         continue;
+    }
+
+    // ---- block DPCM (rcn_bdpcm_tb, rcn_transform_tree.c:631-688): running sum of the LEVELS along a row / column with
+    // int16 saturation (lane = one row / column: the saturation makes the scan order-dependent), then de-quantisation ----
+    if (bdpcm) {
+        if (c.tr_h == 0) {
+            if (lane < tb_h) {
+                int acc = s_coef[lane * tb_w];
+                for (int x = 1; x < tb_w; ++x) { acc = ov_clip3(acc + s_coef[lane * tb_w + x], -(1 << 15), (1 << 15) - 1); s_coef[lane * tb_w + x] = (int16_t)acc; }
+            }
+        } else if (lane < tb_w) {
+            int acc = s_coef[lane];
+            for (int y = 1; y < tb_h; ++y) { acc = ov_clip3(acc + s_coef[y * tb_w + lane], -(1 << 15), (1 << 15) - 1); s_coef[y * tb_w + lane] = (int16_t)acc; }
+        }
+        __syncthreads();
+        if (kind == OVHIP_TB_TS)
+            for (int i = lane; i < tb_w * tb_h; i += NT) s_coef[i] = (int16_t)dequant1(s_coef[i], c.dq_scale, c.dq_shift, c.dq_neg);
+        __syncthreads();
     }
 
     // ---- DC shortcut / transform skip: K4 directly ----

@@ -25,6 +25,8 @@
 #define CUF_MIP               (1u << 2)
 #define CUF_BDPCM_LUMA        (1u << 8)
 #define CUF_BDPCM_CHROMA      (1u << 9)
+#define CUF_BDPCM_LUMA_DIR    (1u << 10)
+#define CUF_BDPCM_CHROMA_DIR  (1u << 11)
 
 ovhip_recorder *
 ovhip_rec_create(int32_t pic_w, int32_t pic_h)
@@ -211,6 +213,7 @@ struct tb_args {
     int plane, x, y, log2_w, log2_h;
     int is_luma;
     int tr_skip;            /* transform skip selected for this TB                    */
+    int bdpcm;              /* 0 none, 1 horizontal (along a row), 2 vertical          */
     int qp, qp_skip;
     int lfnst_flag, lfnst_idx, lfnst_mode_idx;
     int cu_mts_flag, cu_mts_idx;
@@ -232,6 +235,23 @@ emit_tb(ovhip_recorder *r, const ovhip_tu_state *st, const struct tb_args *a, ov
 
     int small = a->log2_w < 2 || a->log2_h < 2;        /* 2xN / Nx2 chroma TBs: raster storage */
 
+    if (a->tr_skip && a->bdpcm) {
+        /* rcn_bdpcm_tb (rcn_transform_tree.c:665-688): levels de-scanned only when the slice uses regular residual
+         * coding for TS blocks AND the block has 4x4 sub-blocks; accumulated; then dequant_sb() per 16 samples */
+        struct dq d = derive_dq(2, a->qp_skip, a->log2_w, a->log2_h);
+        c->dq_scale = d.scale; c->dq_shift = d.shift; c->dq_neg = d.neg;
+        c->tr_h = (uint8_t)(a->bdpcm - 1);
+        const int n16 = (a->log2_w + a->log2_h) >= 4;
+        if (st->sh_ts_disabled && !small) {
+            c->kind = OVHIP_TB_TS | OVHIP_TB_FLAG_BDPCM;
+            /* reorder_tb_4x4 takes the map as it is: a DC-only block with an empty map contributes nothing
+             * (the "force the first sub-block" line is commented out there, rcn_transform_tree.c:143-144) */
+            c->sig_sb_map = a->sig_sb_map & valid_sb_mask(a->log2_w, a->log2_h);
+            return capture_sbs(r, a->coef, a->log2_w, c->sig_sb_map, &c->coef_off) ? OVHIP_ENOMEM : 0;
+        }
+        c->kind = (n16 ? OVHIP_TB_TS : OVHIP_TB_TS_RAW) | OVHIP_TB_FLAG_RASTER | OVHIP_TB_FLAG_BDPCM;
+        return capture_raster(r, a->coef, 1 << (a->log2_w + a->log2_h), &c->coef_off) ? OVHIP_ENOMEM : 0;
+    }
     if (a->tr_skip) {
         if (!st->sh_ts_disabled) {
             /* TS residual coding: coefficients are raster and final (memcpy in the reference) */
@@ -298,8 +318,6 @@ ovhip_rec_tu(ovhip_recorder *r, const ovhip_tu_state *st, const ovhip_tu_desc *t
     int ret;
     ovhip_tb_cmd *c;
 
-    if ((tu->cu_flags & CUF_BDPCM_LUMA) && (tu->tr_skip_mask & 0x10) && (tu->cbf_mask & 0x10)) return OVHIP_EUNSUP;
-    if ((tu->cu_flags & CUF_BDPCM_CHROMA) && (tu->tr_skip_mask & 0x3) && (tu->cbf_mask & 0xb)) return OVHIP_EUNSUP;
 
     /* ---- luma (rcn_tu_st / rcn_tu_l) ---- */
     if (tu->tree != 2 && (tu->cbf_mask & 0x10)) {
@@ -310,6 +328,7 @@ ovhip_rec_tu(ovhip_recorder *r, const ovhip_tu_state *st, const ovhip_tu_desc *t
         a.plane = 0; a.x = tu->x0; a.y = tu->y0; a.log2_w = tu->log2_tb_w; a.log2_h = tu->log2_tb_h;
         a.is_luma = 1;
         a.tr_skip = !!(tu->tr_skip_mask & 0x10);
+        a.bdpcm = (tu->cu_flags & CUF_BDPCM_LUMA) ? 1 + !!(tu->cu_flags & CUF_BDPCM_LUMA_DIR) : 0;   /* rcn_transform_skip_tb_l */
         a.qp = st->qp_y; a.qp_skip = st->qp_y_skip;
         a.lfnst_flag = tu->lfnst_flag; a.lfnst_idx = tu->lfnst_idx;
         a.lfnst_mode_idx = lfnst_mode_luma(tu->log2_tb_w, tu->log2_tb_h, is_mip ? 0 : st->intra_mode);
@@ -337,6 +356,7 @@ ovhip_rec_tu(ovhip_recorder *r, const ovhip_tu_state *st, const ovhip_tu_desc *t
         memset(&a, 0, sizeof(a));
         a.x = xc; a.y = yc; a.log2_w = l2w; a.log2_h = l2h;
         a.lfnst_flag = lfnst_flag; a.lfnst_idx = tu->lfnst_idx; a.lfnst_mode_idx = st->lfnst_mode_c;
+        a.bdpcm = (tu->cu_flags & CUF_BDPCM_CHROMA) ? 1 + !!(tu->cu_flags & CUF_BDPCM_CHROMA_DIR) : 0;   /* rcn_transform_skip_tb_c */
 
         if (tu->cbf_mask & 0x8) {
             /* joint CbCr: ONE residual (coded in the Cb slot), applied to both planes */

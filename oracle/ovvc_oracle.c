@@ -150,7 +150,7 @@ static void itx_one(const oracle_pic *pic, const ovhip_tb_cmd *c, const int16_t 
 {
     const int log2_w = c->log2_w, log2_h = c->log2_h;
     const int tb_w = 1 << log2_w, tb_h = 1 << log2_h;
-    const int kind = c->kind & 0x7f, raster = !!(c->kind & OVHIP_TB_FLAG_RASTER);
+    const int kind = c->kind & 0x3f, raster = !!(c->kind & OVHIP_TB_FLAG_RASTER), bdpcm = !!(c->kind & OVHIP_TB_FLAG_BDPCM);
     const int cw = tb_w > 32 ? 32 : tb_w, ch = tb_h > 32 ? 32 : tb_h;   /* stored coefficient extent */
     const int16_t *src = arena + c->coef_off;
     static _Thread_local int16_t coef[32 * 32], tmp[64 * 64], res[64 * 64];
@@ -158,7 +158,7 @@ static void itx_one(const oracle_pic *pic, const ovhip_tb_cmd *c, const int16_t 
     memset(coef, 0, sizeof(int16_t) * cw * ch);
     if (raster) {
         for (int i = 0; i < tb_w * tb_h; ++i)
-            coef[i] = kind == OVHIP_TB_TS_RAW ? src[i] : dequant1(src[i], c->dq_scale, c->dq_shift, c->dq_neg);
+            coef[i] = (kind == OVHIP_TB_TS_RAW || bdpcm) ? src[i] : dequant1(src[i], c->dq_scale, c->dq_shift, c->dq_neg);
     } else {
         uint64_t map = c->sig_sb_map;
         int n = 0;
@@ -168,9 +168,22 @@ static void itx_one(const oracle_pic *pic, const ovhip_tb_cmd *c, const int16_t 
             int16_t *d = coef + (b >> 3) * 4 * cw + (b & 7) * 4;
             for (int r = 0; r < 4; ++r)
                 for (int q = 0; q < 4; ++q)
-                    d[r * cw + q] = dequant1(src[n * 16 + r * 4 + q], c->dq_scale, c->dq_shift, c->dq_neg);
+                    d[r * cw + q] = bdpcm ? src[n * 16 + r * 4 + q] : dequant1(src[n * 16 + r * 4 + q], c->dq_scale, c->dq_shift, c->dq_neg);
             ++n;
         }
+    }
+    if (bdpcm) {
+        /* rcn_bdpcm_tb (rcn_transform_tree.c:631-688): accumulate the LEVELS along a row (apply_bdpcm_1) or a column
+         * (apply_bdpcm_2) with int16 saturation, then dequant_sb() per 16 samples (none for blocks < 16 samples) */
+        if (c->tr_h == 0) {
+            for (int y = 0; y < tb_h; ++y)
+                for (int x = 1; x < tb_w; ++x) coef[y * tb_w + x] = (int16_t)clip3i(coef[y * tb_w + x - 1] + coef[y * tb_w + x], -(1 << 15), (1 << 15) - 1);
+        } else {
+            for (int y = 1; y < tb_h; ++y)
+                for (int x = 0; x < tb_w; ++x) coef[y * tb_w + x] = (int16_t)clip3i(coef[(y - 1) * tb_w + x] + coef[y * tb_w + x], -(1 << 15), (1 << 15) - 1);
+        }
+        if (kind == OVHIP_TB_TS)
+            for (int i = 0; i < tb_w * tb_h; ++i) coef[i] = dequant1(coef[i], c->dq_scale, c->dq_shift, c->dq_neg);
     }
 
     if (kind == OVHIP_TB_TS || kind == OVHIP_TB_TS_RAW) {

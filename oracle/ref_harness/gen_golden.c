@@ -158,6 +158,12 @@ gen_itx(const char *dir)
                         d.tr_skip_mask = 0;
                         if (d.cbf_mask & 0x10) d.tr_skip_mask |= 0x10;
                         if (rnd_range(0, 1)) d.tr_skip_mask |= 0x3;
+                        if (rep >= 6 || (tree && rnd_range(0, 1))) {
+                            /* block DPCM (intra CUs): transform skip is implied, direction random */
+                            d.cu_flags |= 1u << 1;
+                            if (d.tr_skip_mask & 0x10) d.cu_flags |= (1u << 8) | ((uint32_t)rnd_range(0, 1) << 10);
+                            if (d.tr_skip_mask & 0x3)  d.cu_flags |= (1u << 9) | ((uint32_t)rnd_range(0, 1) << 11);
+                        }
                     }
 
                     /* chroma LFNST only exists in the dual-tree chroma path */
