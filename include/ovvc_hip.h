@@ -265,9 +265,8 @@ typedef struct ovhip_dbf_planes {
 } ovhip_dbf_planes;
 
 /* What df.rcn_dbf_ctu / df.rcn_dbf_truncated_ctu receive (rcn_structures.h:408-413): a copy of the
- * CTU's struct DBFInfo arrays (same element layout: 16+33 / 33 x uint64 masks, 34x33 QP bytes) AFTER
- * the MV-based bS pre-pass (dbf_ctu_preproc_v/_h, rcn_df.c:1821-1874, stays on the host), plus the
- * call arguments and ctudec->ctu_ngh_flags. */
+ * CTU's struct DBFInfo arrays (same element layout: 16+33 / 33 x uint64 masks, 34x33 QP bytes), after
+ * ovhip_rec_dbf_mv_prepass() in P / B slices, plus the call arguments and ctudec->ctu_ngh_flags. */
 typedef struct ovhip_dbf_ctu {
     uint64_t ctb_bound_ver[49], ctb_bound_hor[49], ctb_bound_ver_c[49], ctb_bound_hor_c[49];
     uint64_t aff_edg_ver[49], aff_edg_hor[49];
@@ -283,6 +282,23 @@ typedef struct ovhip_dbf_ctu {
     uint16_t ctu_w, ctu_h;                /* samples; < 1<<log2_ctu_s selects the truncated slot */
     uint16_t ctb_x, ctb_y;                /* CTU address in the picture                         */
 } ovhip_dbf_ctu;
+
+/* The MV-based boundary-strength pre-pass rcn_dbf_ctu runs first in P / B slices (dbf_ctu_preproc_v/_h ->
+ * dbf_mv_set_vedges/_hedges -> check_dbf_enabled(_p), mv_threshold_check; rcn_df.c:1512-1874): CU and affine
+ * sub-block edges that carry no bS yet get bS 1 when the motion on the two sides differs (different reference
+ * pictures, or a vector component >= 8 in 1/16 units apart).  Host work on the CTU's 34x34 motion grids. */
+typedef struct ovhip_dbf_mv_ctx {
+    uint64_t cu_edge_ver[33], cu_edge_hor[33];           /* dbf_info->cu_edge (dbf_utils.h:60-73)                     */
+    uint64_t map0_h[33], map0_v[33];                     /* inter_ctx->mv_ctx0.map.hfield / vfield (ctudec.h:298-302)  */
+    uint64_t map1_h[33], map1_v[33];                     /* inter_ctx->mv_ctx1.map                                    */
+    uint64_t ibc_h[33], ibc_v[33];                       /* dbf_info->ibc_ctx->ctu_map (all 0 without IBC)             */
+    int16_t  dist_ref0[16], dist_ref1[16];               /* inter_ctx->dist_ref_0 / _1                                */
+    const void *mvs0, *mvs1;                             /* inter_ctx->mv_ctx0.mvs / mv_ctx1.mvs: OVMV[34 * 34]        */
+    int32_t  mv_bytes;                                   /* sizeof(OVMV): x, y int32 at offset 0 / 4, ref_idx int8 at 8 */
+} ovhip_dbf_mv_ctx;
+/* Updates ctu->bs1_ver / bs1_hor in place (what the slot does to dbf_info->bs1_map); call it before
+ * ovhip_rec_dbf_ctu for slices other than I. */
+int ovhip_rec_dbf_mv_prepass(ovhip_dbf_ctu *ctu, const ovhip_dbf_mv_ctx *mv);
 
 /* ------------------------------------------------------------------------------------
  * Sample adaptive offset.  One entry per CTU in raster order (index ctb_y * nb_ctu_w + ctb_x,

@@ -100,6 +100,14 @@ LMCS_REGION_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("n_abv", "u1"), ("n_l
 assert LMCS_REGION_DTYPE.itemsize == 8
 
 
+class DbfMvCtx(C.Structure):
+    _fields_ = [("cu_edge_ver", C.c_uint64 * 33), ("cu_edge_hor", C.c_uint64 * 33),
+                ("map0_h", C.c_uint64 * 33), ("map0_v", C.c_uint64 * 33), ("map1_h", C.c_uint64 * 33), ("map1_v", C.c_uint64 * 33),
+                ("ibc_h", C.c_uint64 * 33), ("ibc_v", C.c_uint64 * 33),
+                ("dist_ref0", C.c_int16 * 16), ("dist_ref1", C.c_int16 * 16),
+                ("mvs0", C.c_void_p), ("mvs1", C.c_void_p), ("mv_bytes", C.c_int32)]
+
+
 class DbfPlanes(C.Structure):
     _fields_ = [("luma_v", C.c_void_p), ("luma_h", C.c_void_p), ("cb_v", C.c_void_p), ("cr_v", C.c_void_p),
                 ("cb_h", C.c_void_p), ("cr_h", C.c_void_p), ("w4", C.c_int32), ("h4", C.c_int32),
@@ -212,6 +220,7 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_rec_affine_cu": (C.c_int, [vp, P(AffineDesc)]),
         "ovhip_rec_lmcs_region": (C.c_int, [vp, C.c_int32, C.c_int32, u32, u32]),
         "ovhip_dbf_compact": (C.c_int64, [P(DbfPlanes), C.c_int, vp, C.c_size_t]),
+        "ovhip_rec_dbf_mv_prepass": (C.c_int, [vp, P(DbfMvCtx)]),
         "ovhip_dbf_launch_edges": (C.c_int, [vp, P(Pic), vp, u32, vp, u32, C.c_int32, C.c_int32]),
         "ovhip_rec_ciip": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
         "ovhip_rec_ciip_units": (vp, [vp, P(C.c_size_t)]),
@@ -257,7 +266,7 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
 
 EXPORTED_SYMBOLS = [
     "ovhip_abi_version", "ovhip_rec_create", "ovhip_rec_destroy", "ovhip_rec_reset", "ovhip_rec_tu",
-    "ovhip_rec_pu", "ovhip_rec_dbf_ctu", "ovhip_rec_dbf_planes", "ovhip_dbf_launch", "ovhip_sao_launch", "ovhip_alf_launch", "ovhip_rec_tb_cmds", "ovhip_rec_coefs", "ovhip_rec_mc_units", "ovhip_rec_mcx_units", "ovhip_mcx_launch", "ovhip_rec_affine_cu", "ovhip_rec_lmcs_region", "ovhip_dbf_compact", "ovhip_dbf_launch_edges", "ovhip_rec_ciip", "ovhip_ciip_weight", "ovhip_rec_ciip_units", "ovhip_ciip_launch", "ovhip_rec_lmcs_regions", "ovhip_rec_tb_cmds_split", "ovhip_itx_launch_classes", "ovhip_lmcs_build", "ovhip_lmcs_scale_launch", "ovhip_lmcs_inverse_launch", "ovhip_rec_aff_units", "ovhip_rec_aff_side", "ovhip_mca_launch", "ovhip_ctx_create",
+    "ovhip_rec_pu", "ovhip_rec_dbf_ctu", "ovhip_rec_dbf_planes", "ovhip_dbf_launch", "ovhip_sao_launch", "ovhip_alf_launch", "ovhip_rec_tb_cmds", "ovhip_rec_coefs", "ovhip_rec_mc_units", "ovhip_rec_mcx_units", "ovhip_mcx_launch", "ovhip_rec_affine_cu", "ovhip_rec_lmcs_region", "ovhip_dbf_compact", "ovhip_rec_dbf_mv_prepass", "ovhip_dbf_launch_edges", "ovhip_rec_ciip", "ovhip_ciip_weight", "ovhip_rec_ciip_units", "ovhip_ciip_launch", "ovhip_rec_lmcs_regions", "ovhip_rec_tb_cmds_split", "ovhip_itx_launch_classes", "ovhip_lmcs_build", "ovhip_lmcs_scale_launch", "ovhip_lmcs_inverse_launch", "ovhip_rec_aff_units", "ovhip_rec_aff_side", "ovhip_mca_launch", "ovhip_ctx_create",
     "ovhip_ctx_destroy", "ovhip_ctx_sync", "ovhip_ctx_fork", "ovhip_ctx_join", "ovhip_last_error", "ovhip_ctx_stream", "ovhip_malloc",
     "ovhip_free", "ovhip_h2d", "ovhip_d2h", "ovhip_pic_alloc", "ovhip_pic_free", "ovhip_pic_upload",
     "ovhip_pic_download", "ovhip_itx_launch", "ovhip_mc_launch",
@@ -311,10 +320,22 @@ class Recorder:
             raise ValueError(f"ovhip_rec_affine_cu -> {r}")
         return r
 
-    def dbf_ctu(self, raw: bytes):
-        """raw: one ovhip_dbf_ctu struct (what df.rcn_dbf_ctu receives)."""
+    def dbf_ctu(self, raw: bytes, mvctx: bytes | None = None):
+        """raw: one ovhip_dbf_ctu struct (what df.rcn_dbf_ctu receives).  mvctx (P / B slices): one ovhip_dbf_mv_ctx
+        followed by the two OVMV[34 * 34] motion arrays; the MV-based bS pre-pass is applied to the CTU first."""
         assert len(raw) == DBF_CTU_SIZE, (len(raw), DBF_CTU_SIZE)
         buf = (C.c_char * len(raw)).from_buffer_copy(raw)
+        if mvctx is not None:
+            hs = C.sizeof(DbfMvCtx)
+            mc = DbfMvCtx.from_buffer_copy(mvctx[:hs])
+            n = 34 * 34 * mc.mv_bytes
+            assert len(mvctx) == hs + 2 * n, (len(mvctx), hs, n)
+            m0 = (C.c_char * n).from_buffer_copy(mvctx[hs:hs + n])
+            m1 = (C.c_char * n).from_buffer_copy(mvctx[hs + n:])
+            mc.mvs0, mc.mvs1 = C.addressof(m0), C.addressof(m1)
+            r = self.lib.ovhip_rec_dbf_mv_prepass(C.addressof(buf), C.byref(mc))
+            if r < 0:
+                raise ValueError(f"ovhip_rec_dbf_mv_prepass -> {r}")
         r = self.lib.ovhip_rec_dbf_ctu(self.h, C.addressof(buf))
         if r < 0:
             raise ValueError(f"ovhip_rec_dbf_ctu -> {r}")

@@ -243,3 +243,111 @@ ovhip_dbf_compact(const ovhip_dbf_planes *pl, int dir, ovhip_dbf_edge *out, size
     }
     return (int64_t)n;
 }
+
+/* ---------------------------------------------------------------- MV-based bS pre-pass (P / B slices)
+ * dbf_ctu_preproc_h/_v (rcn_df.c:1821-1874): for every unit row / column, the CU and affine sub-block edges
+ * that have neither bS 2 nor bS 1 yet are examined with the motion on their two sides. */
+typedef struct { int32_t x, y; int ref; } mvq;
+
+static mvq mv_at(const void *base, int bytes, int idx)
+{
+    const uint8_t *p = (const uint8_t *)base + (size_t)idx * bytes;
+    mvq m;
+    memcpy(&m.x, p, 4); memcpy(&m.y, p + 4, 4);
+    m.ref = (int8_t)p[8];
+    return m;
+}
+
+static int mv_far(mvq a, mvq b)          /* mv_threshold_check, rcn_df.c:1513-1522 */
+{
+    int64_t dx = (int64_t)a.x - b.x, dy = (int64_t)a.y - b.y;
+    if (dx < 0) dx = -dx;
+    if (dy < 0) dy = -dy;
+    return dx >= 8 || dy >= 8;
+}
+
+/* check_dbf_enabled (rcn_df.c:1542-1576): both sides bi-predicted */
+static int bs_bi(const ovhip_dbf_mv_ctx *c, mvq p0, mvq p1, mvq q0, mvq q1)
+{
+    const int r0p = c->dist_ref0[p0.ref], r1p = c->dist_ref1[p1.ref], r0q = c->dist_ref0[q0.ref], r1q = c->dist_ref1[q1.ref];
+    const int paired = r0p == r0q && r1p == r1q, swapped = r0p == r1q && r1p == r0q;
+    int bs = 1;
+    if (r0p == r1p && paired) {
+        bs  = mv_far(q0, p0) || mv_far(q1, p1);
+        bs &= mv_far(q1, p0) || mv_far(q0, p1);
+    } else if (paired) {
+        bs = mv_far(q0, p0) | mv_far(q1, p1);
+    } else if (swapped) {
+        bs = mv_far(q1, p0) | mv_far(q0, p1);
+    }
+    return bs;
+}
+
+/* One row (dir = 1, horizontal edges above unit row y) or column (dir = 0, vertical edges left of unit column x):
+ * dbf_mv_set_hedges / dbf_mv_set_vedges (rcn_df.c:1578-1819).  `todo` = edges without a strength yet. */
+static uint64_t
+mv_edges(const ovhip_dbf_mv_ctx *c, int dir, int pos, int n_units, uint64_t todo)
+{
+    const uint64_t *f0 = dir ? c->map0_h : c->map0_v, *f1 = dir ? c->map1_h : c->map1_v, *fi = dir ? c->ibc_h : c->ibc_v;
+    const uint64_t unit_msk = ((uint64_t)1 << n_units) - 1;
+    const int sh = dir ? 2 : 0;                       /* horizontal maps carry a 2-unit left margin */
+    const uint64_t p0 = (f0[pos] >> 1) & unit_msk, p1 = (f1[pos] >> 1) & unit_msk, pi = (fi[pos] >> 1) & unit_msk;
+    const uint64_t q0 = (f0[pos + 1] >> 1) & unit_msk, q1 = (f1[pos + 1] >> 1) & unit_msk, qi = (fi[pos + 1] >> 1) & unit_msk;
+
+    uint64_t keep = ((~todo) >> sh) & unit_msk;       /* edges that already have a strength (or are no edge) */
+    keep |= pi & (q1 | q0);                           /* IBC against inter: always bS 1 */
+    keep |= qi & (p1 | p0);
+
+    const uint64_t q_b = q0 & q1, q_l0 = q0 & ~q1, q_l1 = q1 & ~q0;
+    const uint64_t p_b = p0 & p1, p_l0 = p0 & ~p1, p_l1 = p1 & ~p0;
+    const uint64_t both_ibc = pi & qi;
+    uint64_t chk_b = q_b & p_b, chk_l0 = q_l0 & (p_l0 | p_l1), chk_l1 = q_l1 & (p_l0 | p_l1);
+    chk_b &= ~(keep | both_ibc) & unit_msk;
+    chk_l0 &= ~(keep | both_ibc) & unit_msk;
+    chk_l1 &= ~(keep | both_ibc) & unit_msk;
+
+    /* everything that is not compared below gets bS 1, except IBC against IBC */
+    uint64_t out = both_ibc ^ (~(chk_l0 | chk_l1 | chk_b) & unit_msk);
+
+    /* motion of unit k on the P side (previous row / column) and the Q side: index 35 + x + 34 * y with a 1-unit border */
+    const int step = dir ? 1 : 34;
+    const int ip = dir ? 35 + 34 * (pos - 1) : 35 + (pos - 1), iq = dir ? 35 + 34 * pos : 35 + pos;
+    for (int k = 0; k < n_units; ++k) {
+        const uint64_t bit = (uint64_t)1 << k;
+        if (chk_b & bit) {
+            const int bs = bs_bi(c, mv_at(c->mvs0, c->mv_bytes, ip + k * step), mv_at(c->mvs1, c->mv_bytes, ip + k * step),
+                                 mv_at(c->mvs0, c->mv_bytes, iq + k * step), mv_at(c->mvs1, c->mv_bytes, iq + k * step));
+            out |= (uint64_t)bs << k;
+        }
+        if ((chk_l0 | chk_l1) & bit) {
+            /* check_dbf_enabled_p (rcn_df.c:1526-1539): one list on each side */
+            const int p_is_l0 = !!(p_l0 & bit), q_is_l0 = !!(chk_l0 & bit);
+            const mvq mp = mv_at(p_is_l0 ? c->mvs0 : c->mvs1, c->mv_bytes, ip + k * step);
+            const mvq mq = mv_at(q_is_l0 ? c->mvs0 : c->mvs1, c->mv_bytes, iq + k * step);
+            const int rp = (p_is_l0 ? c->dist_ref0 : c->dist_ref1)[mp.ref], rq = (q_is_l0 ? c->dist_ref0 : c->dist_ref1)[mq.ref];
+            const int bs = rp == rq ? mv_far(mq, mp) : 1;
+            out |= (uint64_t)bs << k;
+        }
+    }
+    return ((out | keep) << sh) & todo;
+}
+
+int
+ovhip_rec_dbf_mv_prepass(ovhip_dbf_ctu *ctu, const ovhip_dbf_mv_ctx *mv)
+{
+    if (!ctu || !mv || !mv->mvs0 || !mv->mvs1 || mv->mv_bytes < 9) return OVHIP_EINVAL;
+    const int full = 1 << ctu->log2_ctu_s;
+    const int nb_w = (ctu->ctu_w && ctu->ctu_w < full ? ctu->ctu_w : full) >> 2;
+    const int nb_h = (ctu->ctu_h && ctu->ctu_h < full ? ctu->ctu_h : full) >> 2;
+    for (int i = 0; i < nb_h; ++i) {                                   /* dbf_ctu_preproc_h */
+        const uint64_t edges = mv->cu_edge_hor[i] | ctu->aff_edg_hor[8 + i];
+        const uint64_t todo = edges ^ ((ctu->bs2_hor[i] | ctu->bs1_hor[i]) & edges);
+        if (todo) ctu->bs1_hor[i] |= mv_edges(mv, 1, i, nb_w, todo);
+    }
+    for (int i = 0; i < nb_w; ++i) {                                   /* dbf_ctu_preproc_v */
+        const uint64_t edges = mv->cu_edge_ver[i] | ctu->aff_edg_ver[8 + i];
+        const uint64_t todo = edges ^ ((ctu->bs2_ver[i] | ctu->bs1_ver[i]) & edges);
+        if (todo) ctu->bs1_ver[i] |= mv_edges(mv, 0, i, nb_h, todo);
+    }
+    return OVHIP_OK;
+}

@@ -907,7 +907,33 @@ snapshot_dbf(ovhip_dbf_ctu *o, const struct DBFInfo *d)
  * decoder's parse loop does (vcl_coding_unit.c:742, vcl_transform_unit.c:1093-1146, :1934-1957,
  * rcn_transform_tree.c fill_bs_map calls, drv_affine_mvp.c:3052-3082) and paints a DC offset per CU
  * into the unfiltered picture so that block edges are visible to the filter decisions */
-struct dbf_gen { struct DBFInfo *d; uint16_t *y, *cb, *cr; int stride, stride_c; int px, py; };
+struct dbf_gen { struct DBFInfo *d; uint16_t *y, *cb, *cr; int stride, stride_c; int px, py; OVCTUDec *c; int bmode; struct IBCMVCtx *ibc; };
+
+/* B-slice mode: the CU's motion goes into inter_ctx->mv_ctx0/1 (maps + 34x34 vectors, PB_POS_IN_BUF layout) the way
+ * update_mv_ctx_b does; the MV-based bS pre-pass inside rcn_dbf_ctu then derives bS 1 itself */
+static void
+gen_cu_motion(struct dbf_gen *g, int x, int y, int w, int h, int intra)
+{
+    struct InterDRVCtx *ic = &g->c->drv_ctx.inter_ctx;
+    int x0 = x >> 2, y0 = y >> 2, nw = w >> 2, nh = h >> 2;
+    uint64_t mh = (((uint64_t)1 << nw) - 1) << (x0 + 1), mv_ = (((uint64_t)1 << nh) - 1) << (y0 + 1);
+    if (intra) return;
+    if (rnd_range(0, 15) == 0) {                       /* IBC CU: no inter motion, IBC map set */
+        for (int j = 0; j < nh; ++j) g->ibc->ctu_map.hfield[y0 + 1 + j] |= mh;
+        for (int i = 0; i < nw; ++i) g->ibc->ctu_map.vfield[x0 + 1 + i] |= mv_;
+        return;
+    }
+    static const int pal[3][2] = { { 40, -24 }, { 44, -20 }, { -96, 130 } };
+    int lists = rnd_range(1, 3);
+    for (int l = 0; l < 2; ++l) {
+        if (!(lists & (1 << l))) continue;
+        struct OVMVCtx *m = l ? &ic->mv_ctx1 : &ic->mv_ctx0;
+        int k = rnd_range(0, 2);
+        OVMV mv = { .x = pal[k][0] + rnd_range(-6, 6), .y = pal[k][1] + rnd_range(-6, 6), .ref_idx = rnd_range(0, 2) };
+        for (int j = 0; j < nh; ++j) { m->map.hfield[y0 + 1 + j] |= mh; for (int i = 0; i < nw; ++i) m->mvs[35 + x0 + i + (y0 + j) * 34] = mv; }
+        for (int i = 0; i < nw; ++i) m->map.vfield[x0 + 1 + i] |= mv_;
+    }
+}
 
 static void
 gen_cu(struct dbf_gen *g, int x, int y, int w, int h)
@@ -929,7 +955,8 @@ gen_cu(struct dbf_gen *g, int x, int y, int w, int h)
     }
     dbf_fill_cu_edge(&d->cu_edge, x >> 2, y >> 2, w >> 2, h >> 2);
     if (intra) { fill_bs_map(&d->bs2_map, x, y, l2w, l2h); fill_bs_map(&d->bs2_map_c, x, y, l2w, l2h); }
-    if (rnd_range(0, 2) == 0) {           /* "motion differs from the neighbours" (what dbf_ctu_preproc_* derives) */
+    if (g->bmode) gen_cu_motion(g, x, y, w, h, intra);
+    else if (rnd_range(0, 2) == 0) {      /* "motion differs from the neighbours" (what dbf_ctu_preproc_* derives) */
         fill_bs_map(&d->bs1_map, x, y, l2w, l2h);
         if (rnd_range(0, 1)) fill_bs_map(&d->bs1_map_cb, x, y, l2w, l2h);
         if (rnd_range(0, 1)) fill_bs_map(&d->bs1_map_cr, x, y, l2w, l2h);
@@ -982,8 +1009,8 @@ gen_part(struct dbf_gen *g, int x, int y, int w, int h, int lim_w, int lim_h)
 static void
 gen_dbf(const char *dir)
 {
-    enum { NPIC = 2 };
-    static const int PW[NPIC] = { 304, 264 }, PH[NPIC] = { 200, 136 };
+    enum { NPIC = 3 };
+    static const int PW[NPIC] = { 304, 264, 256 }, PH[NPIC] = { 200, 136, 192 };     /* picture 2: B slice, motion-derived bS */
     gfile g = gfile_open(dir, "dbf.ovg");
     g_seed = 0x266 + 2;
     for (int pi = 0; pi < NPIC; ++pi) {
@@ -998,7 +1025,14 @@ gen_dbf(const char *dir)
 
         OVCTUDec *c = ref_new_ctudec(0, 0);
         struct DBFInfo *d = &c->dbf_info;
-        c->tmp_slice_type = 2;         /* the MV-based bS pre-pass is emulated by gen_cu() */
+        const int bmode = pi == 2;
+        c->tmp_slice_type = bmode ? 0 : 2;     /* I: the MV-based bS pre-pass is emulated by gen_cu(); B: rcn_dbf_ctu derives it */
+        static struct IBCMVCtx ibc;
+        d->ibc_ctx = &ibc;
+        struct InterDRVCtx *ic = &c->drv_ctx.inter_ctx;
+        static const int16_t dr0[16] = { -8, -16, 8, -24 }, dr1[16] = { 8, -8, 16, -16 };   /* POC distances: lists share pictures */
+        memcpy(ic->dist_ref_0, dr0, sizeof(dr0)); memcpy(ic->dist_ref_1, dr1, sizeof(dr1));
+        gbuf b_mv = { .type = T_U8 };
         struct DBFLines L;
         int npu = W / 4 + 40;
         L.qp_x_map = calloc(npu, 1); L.qp_x_map_cb = calloc(npu, 1); L.qp_x_map_cr = calloc(npu, 1);
@@ -1018,6 +1052,7 @@ gen_dbf(const char *dir)
             uint16_t *ty = pass ? y : y0, *tcb = pass ? cb : cb0, *tcr = pass ? cr : cr0;
             if (!pass) { memcpy(y0, y, W * H * 2); memcpy(cb0, cb, W * H / 2); memcpy(cr0, cr, W * H / 2); }
             memset(d, 0, sizeof(*d));
+            d->ibc_ctx = &ibc;
             d->beta_offset = (pi ? 2 : -2) * 2; d->tc_offset = (pi ? -1 : 3) * 2;
             memset(L.qp_x_map, 0, npu); memset(L.qp_x_map_cb, 0, npu); memset(L.qp_x_map_cr, 0, npu);
             memset(L.small_map, 0, (nx + 1) * 8); memset(L.dbf_bs2_hor, 0, (nx + 1) * 8); memset(L.dbf_bs2_hor_c, 0, (nx + 1) * 8);
@@ -1027,7 +1062,21 @@ gen_dbf(const char *dir)
                 dbf_load_info(d, &L, 7, 0);
                 for (int cx = 0; cx < nx; ++cx) {
                     int ctu_w = W - cx * 128 < 128 ? W - cx * 128 : 128, ctu_h = H - cy * 128 < 128 ? H - cy * 128 : 128;
-                    struct dbf_gen gg = { d, ty, tcb, tcr, W, W / 2, cx * 128, cy * 128 };
+                    struct dbf_gen gg = { d, ty, tcb, tcr, W, W / 2, cx * 128, cy * 128, c, bmode, &ibc };
+                    if (bmode) {
+                        /* fresh CTU motion context; the 1-unit border (row above / column left) stands in for what
+                         * the line buffers would bring in from the neighbouring CTUs */
+                        memset(&ic->mv_ctx0, 0, sizeof(ic->mv_ctx0)); memset(&ic->mv_ctx1, 0, sizeof(ic->mv_ctx1)); memset(&ibc, 0, sizeof(ibc));
+                        for (int l = 0; l < 2; ++l) {
+                            struct OVMVCtx *m = l ? &ic->mv_ctx1 : &ic->mv_ctx0;
+                            for (int k = 0; k < 33; ++k) {
+                                if (cy && rnd_range(0, 2)) { m->map.hfield[0] |= (uint64_t)1 << (k + 1); m->map.vfield[k + 1] |= 1;
+                                                             m->mvs[1 + k] = (OVMV){ .x = 40 + rnd_range(-8, 8), .y = -24 + rnd_range(-8, 8), .ref_idx = rnd_range(0, 2) }; }
+                                if (cx && rnd_range(0, 2)) { m->map.vfield[0] |= (uint64_t)1 << (k + 1); m->map.hfield[k + 1] |= 1;
+                                                             m->mvs[34 + 34 * k] = (OVMV){ .x = 44 + rnd_range(-8, 8), .y = -20 + rnd_range(-8, 8), .ref_idx = rnd_range(0, 2) }; }
+                            }
+                        }
+                    }
                     gen_part(&gg, 0, 0, 128, 128, ctu_w, ctu_h);
                     if (pass) {
                         c->ctu_ngh_flags = (cx ? CTU_LFT_FLG : 0) | (cy ? CTU_UP_FLG : 0);
@@ -1037,10 +1086,23 @@ gen_dbf(const char *dir)
                         c->rcn_ctx.frame_buff.stride = W; c->rcn_ctx.frame_buff.stride_c = W / 2;
                         int last_x = cx == nx - 1, last_y = cy == ny - 1;
                         int truncated = ctu_w < 128 || ctu_h < 128;
+                        ovhip_dbf_ctu o;
+                        snapshot_dbf(&o, d);            /* BEFORE the slot: in a B slice it adds the motion-derived bS 1 to d */
+                        if (bmode) {
+                            ovhip_dbf_mv_ctx mc;
+                            memset(&mc, 0, sizeof(mc));
+                            memcpy(mc.cu_edge_ver, d->cu_edge.ver, sizeof(mc.cu_edge_ver)); memcpy(mc.cu_edge_hor, d->cu_edge.hor, sizeof(mc.cu_edge_hor));
+                            memcpy(mc.map0_h, ic->mv_ctx0.map.hfield, sizeof(mc.map0_h)); memcpy(mc.map0_v, ic->mv_ctx0.map.vfield, sizeof(mc.map0_v));
+                            memcpy(mc.map1_h, ic->mv_ctx1.map.hfield, sizeof(mc.map1_h)); memcpy(mc.map1_v, ic->mv_ctx1.map.vfield, sizeof(mc.map1_v));
+                            memcpy(mc.ibc_h, ibc.ctu_map.hfield, sizeof(mc.ibc_h)); memcpy(mc.ibc_v, ibc.ctu_map.vfield, sizeof(mc.ibc_v));
+                            memcpy(mc.dist_ref0, ic->dist_ref_0, sizeof(mc.dist_ref0)); memcpy(mc.dist_ref1, ic->dist_ref_1, sizeof(mc.dist_ref1));
+                            mc.mv_bytes = sizeof(OVMV);
+                            gbuf_push(&b_mv, &mc, sizeof(mc));
+                            gbuf_push(&b_mv, ic->mv_ctx0.mvs, sizeof(ic->mv_ctx0.mvs));
+                            gbuf_push(&b_mv, ic->mv_ctx1.mvs, sizeof(ic->mv_ctx1.mvs));
+                        }
                         if (!truncated) c->rcn_funcs.df.rcn_dbf_ctu(&c->rcn_ctx, d, 7, last_x, last_y);
                         else            c->rcn_funcs.df.rcn_dbf_truncated_ctu(&c->rcn_ctx, d, 7, last_x, last_y, ctu_w, ctu_h);
-                        ovhip_dbf_ctu o;
-                        snapshot_dbf(&o, d);
                         o.log2_ctu_s = 7; o.last_x = last_x; o.last_y = last_y;
                         o.ctu_lft = !!cx; o.ctu_abv = !!cy;
                         o.ctu_w = truncated ? ctu_w : 0; o.ctu_h = truncated ? ctu_h : 0;
@@ -1066,6 +1128,7 @@ gen_dbf(const char *dir)
         snprintf(nm, 32, "p%d_exp_cr", pi); gfile_array(&g, nm, T_U16, cr, 2, d2);
         d2[0] = n_ctu; d2[1] = sizeof(ovhip_dbf_ctu);
         snprintf(nm, 32, "p%d_ctus", pi); gfile_array(&g, nm, T_U8, b_ctu.data, 2, d2);
+        if (bmode) { d2[1] = (uint32_t)(b_mv.n / n_ctu); snprintf(nm, 32, "p%d_mvctx", pi); gfile_array(&g, nm, T_U8, b_mv.data, 2, d2); }
         size_t diff = 0;
         for (int i = 0; i < W * H; ++i) diff += y[i] != y0[i];
         fprintf(stderr, "dbf.ovg: picture %d %dx%d, %u CTUs, %zu luma samples changed by the reference\n", pi, W, H, n_ctu, diff);

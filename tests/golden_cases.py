@@ -118,8 +118,9 @@ def dbf_cases():
         y = g[f"p{pi}_in_y"]
         h, w = y.shape
         rec = capi.Recorder(w, h)
-        for raw in g[f"p{pi}_ctus"]:
-            rec.dbf_ctu(raw.tobytes())
+        mv = g.get(f"p{pi}_mvctx")                    # B-slice picture: motion contexts for the MV-based bS pre-pass
+        for k, raw in enumerate(g[f"p{pi}_ctus"]):
+            rec.dbf_ctu(raw.tobytes(), mv[k].tobytes() if mv is not None else None)
         out.append((HostPic(w, h, y, g[f"p{pi}_in_cb"], g[f"p{pi}_in_cr"]), rec.dbf_planes(),
                     HostPic(w, h, g[f"p{pi}_exp_y"], g[f"p{pi}_exp_cb"], g[f"p{pi}_exp_cr"])))
         pi += 1

@@ -142,7 +142,7 @@ def test_gpm_ciip_oracle_matches_reference(built_lib):
 
 def test_dbf_oracle_matches_reference(built_lib):
     cases = golden_cases.dbf_cases()
-    assert len(cases) == 2
+    assert len(cases) == 3
     for i, (pic, planes, exp) in enumerate(cases):
         work = pic.copy()
         oracle_lib.dbf(work, planes)
