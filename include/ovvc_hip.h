@@ -389,6 +389,30 @@ typedef struct ovhip_tu_desc {
     const int16_t *coef[3];   /* host pointers: residual_cb/cr/y + pos_offset, reference layout   */
 } ovhip_tu_desc;
 
+/* One coding unit's transform tree as handed to tmp.rcn_transform_tree (rcn_structures.h:464-468;
+ * rcn_transform_tree.c:1454-1506): the CU is cut at the maximum transform size (and 128-wide CUs at 64 first) and
+ * every leaf goes to rcn_tu_st / rcn_tu_l / rcn_tu_c with its own struct TUInfo out of the caller's array of up to
+ * 16.  The reference's walker calls those leaves directly (not through the table), so this is the entry a shim
+ * has to override; intra CUs additionally need rcn_intra_tu before every leaf, which is the caller's business. */
+typedef struct ovhip_tu_info {   /* struct TUInfo (rcn_transform_tree.c:56-66) without the SBT flag */
+    uint8_t  cbf_mask, tr_skip_mask, cu_mts_flag, cu_mts_idx, lfnst_flag, lfnst_idx;
+    uint16_t pos_offset;          /* int16 offset of this TU's coefficients in ctudec->residual_y / _cb / _cr */
+    uint16_t last_pos[3];         /* tb_info[0] = Cb / joint, [1] = Cr, [2] = luma                             */
+    uint16_t pad;
+    uint64_t sig_sb_map[3];
+} ovhip_tu_info;
+
+typedef struct ovhip_tt_desc {
+    uint16_t x0, y0;              /* luma position of the CU in the picture (tree 2: chroma units)             */
+    uint8_t  log2_w, log2_h;      /* CU size (tree 2: chroma size)                                             */
+    uint8_t  log2_max_tb_s;       /* part_ctx->log2_max_tb_s                                                   */
+    uint8_t  tree;                /* ctu_dec->transform_unit: 0 transform_unit_st, 1 _l, 2 _c                  */
+    uint16_t cu_flags;
+    uint16_t pad;
+    const ovhip_tu_info *tu_info; /* the caller's array, indexed as the reference does                          */
+    const int16_t *residual[3];   /* ctudec->residual_cb, residual_cr, residual_y (bases, pos_offset not applied) */
+} ovhip_tt_desc;
+
 /* One prediction call as handed to rcn_mcp_b (rcn_structures.h:640-646). */
 typedef struct ovhip_pu_desc {
     uint16_t x0, y0;          /* luma position in the picture                                    */
@@ -437,6 +461,9 @@ void  ovhip_rec_destroy(ovhip_recorder *rec);
 void  ovhip_rec_reset(ovhip_recorder *rec);
 /* Append the commands of one TU / PU.  Return number of commands appended or <0. */
 int   ovhip_rec_tu(ovhip_recorder *rec, const ovhip_tu_state *st, const ovhip_tu_desc *tu);
+/* tmp.rcn_transform_tree: walks the tree and records every leaf with ovhip_rec_tu.  Returns the number of
+ * commands appended or <0. */
+int   ovhip_rec_transform_tree(ovhip_recorder *rec, const ovhip_tu_state *st, const ovhip_tt_desc *tt);
 int   ovhip_rec_pu(ovhip_recorder *rec, const ovhip_pu_desc *pu);
 int   ovhip_rec_affine_cu(ovhip_recorder *rec, const ovhip_affine_desc *cu);
 /* rcn_ciip_weighted_sum: mode_abv / mode_lft = part_map.cu_mode_x[x_right >> log2_min_cb] /

@@ -66,6 +66,18 @@ class TuDesc(C.Structure):
                 ("coef", C.c_void_p * 3)]
 
 
+class TuInfo(C.Structure):
+    _fields_ = [("cbf_mask", C.c_uint8), ("tr_skip_mask", C.c_uint8), ("cu_mts_flag", C.c_uint8), ("cu_mts_idx", C.c_uint8),
+                ("lfnst_flag", C.c_uint8), ("lfnst_idx", C.c_uint8), ("pos_offset", C.c_uint16),
+                ("last_pos", C.c_uint16 * 3), ("pad", C.c_uint16), ("sig_sb_map", C.c_uint64 * 3)]
+
+
+class TtDesc(C.Structure):
+    _fields_ = [("x0", C.c_uint16), ("y0", C.c_uint16), ("log2_w", C.c_uint8), ("log2_h", C.c_uint8),
+                ("log2_max_tb_s", C.c_uint8), ("tree", C.c_uint8), ("cu_flags", C.c_uint16), ("pad", C.c_uint16),
+                ("tu_info", C.c_void_p), ("residual", C.c_void_p * 3)]
+
+
 class PuDesc(C.Structure):
     _fields_ = [("x0", C.c_uint16), ("y0", C.c_uint16), ("log2_w", C.c_uint8), ("log2_h", C.c_uint8),
                 ("inter_dir", C.c_uint8), ("ref_idx0", C.c_uint8), ("ref_idx1", C.c_uint8),
@@ -218,6 +230,7 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_rec_mc_units": (vp, [vp, P(C.c_size_t)]),
         "ovhip_rec_mcx_units": (vp, [vp, P(C.c_size_t)]),
         "ovhip_rec_affine_cu": (C.c_int, [vp, P(AffineDesc)]),
+        "ovhip_rec_transform_tree": (C.c_int, [vp, P(TuState), P(TtDesc)]),
         "ovhip_rec_lmcs_region": (C.c_int, [vp, C.c_int32, C.c_int32, u32, u32]),
         "ovhip_dbf_compact": (C.c_int64, [P(DbfPlanes), C.c_int, vp, C.c_size_t]),
         "ovhip_rec_dbf_mv_prepass": (C.c_int, [vp, P(DbfMvCtx)]),
@@ -266,7 +279,7 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
 
 EXPORTED_SYMBOLS = [
     "ovhip_abi_version", "ovhip_rec_create", "ovhip_rec_destroy", "ovhip_rec_reset", "ovhip_rec_tu",
-    "ovhip_rec_pu", "ovhip_rec_dbf_ctu", "ovhip_rec_dbf_planes", "ovhip_dbf_launch", "ovhip_sao_launch", "ovhip_alf_launch", "ovhip_rec_tb_cmds", "ovhip_rec_coefs", "ovhip_rec_mc_units", "ovhip_rec_mcx_units", "ovhip_mcx_launch", "ovhip_rec_affine_cu", "ovhip_rec_lmcs_region", "ovhip_dbf_compact", "ovhip_rec_dbf_mv_prepass", "ovhip_dbf_launch_edges", "ovhip_rec_ciip", "ovhip_ciip_weight", "ovhip_rec_ciip_units", "ovhip_ciip_launch", "ovhip_rec_lmcs_regions", "ovhip_rec_tb_cmds_split", "ovhip_itx_launch_classes", "ovhip_lmcs_build", "ovhip_lmcs_scale_launch", "ovhip_lmcs_inverse_launch", "ovhip_rec_aff_units", "ovhip_rec_aff_side", "ovhip_mca_launch", "ovhip_ctx_create",
+    "ovhip_rec_pu", "ovhip_rec_dbf_ctu", "ovhip_rec_dbf_planes", "ovhip_dbf_launch", "ovhip_sao_launch", "ovhip_alf_launch", "ovhip_rec_tb_cmds", "ovhip_rec_coefs", "ovhip_rec_mc_units", "ovhip_rec_mcx_units", "ovhip_mcx_launch", "ovhip_rec_affine_cu", "ovhip_rec_transform_tree", "ovhip_rec_lmcs_region", "ovhip_dbf_compact", "ovhip_rec_dbf_mv_prepass", "ovhip_dbf_launch_edges", "ovhip_rec_ciip", "ovhip_ciip_weight", "ovhip_rec_ciip_units", "ovhip_ciip_launch", "ovhip_rec_lmcs_regions", "ovhip_rec_tb_cmds_split", "ovhip_itx_launch_classes", "ovhip_lmcs_build", "ovhip_lmcs_scale_launch", "ovhip_lmcs_inverse_launch", "ovhip_rec_aff_units", "ovhip_rec_aff_side", "ovhip_mca_launch", "ovhip_ctx_create",
     "ovhip_ctx_destroy", "ovhip_ctx_sync", "ovhip_ctx_fork", "ovhip_ctx_join", "ovhip_last_error", "ovhip_ctx_stream", "ovhip_malloc",
     "ovhip_free", "ovhip_h2d", "ovhip_d2h", "ovhip_pic_alloc", "ovhip_pic_free", "ovhip_pic_upload",
     "ovhip_pic_download", "ovhip_itx_launch", "ovhip_mc_launch",
@@ -301,6 +314,19 @@ class Recorder:
         r = self.lib.ovhip_rec_tu(self.h, C.byref(st), C.byref(d))
         if r < 0:
             raise ValueError(f"ovhip_rec_tu -> {r}")
+        return r
+
+    def transform_tree(self, st: "TuState", d: TtDesc, infos: bytes, res_cb: np.ndarray, res_cr: np.ndarray, res_y: np.ndarray) -> int:
+        """tmp.rcn_transform_tree: infos = 16 ovhip_tu_info structs, res_* = the CTU's residual_cb / _cr / _y buffers."""
+        ib = (C.c_char * len(infos)).from_buffer_copy(infos)
+        keep = [np.ascontiguousarray(a, dtype=np.int16) for a in (res_cb, res_cr, res_y)]
+        d.tu_info = C.addressof(ib)
+        for k in range(3):
+            d.residual[k] = keep[k].ctypes.data
+        r = self.lib.ovhip_rec_transform_tree(self.h, C.byref(st), C.byref(d))
+        d.tu_info = None
+        if r < 0:
+            raise ValueError(f"ovhip_rec_transform_tree -> {r}")
         return r
 
     def pu(self, d: PuDesc) -> int:

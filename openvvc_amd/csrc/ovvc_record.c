@@ -399,6 +399,65 @@ fail:
     return ret;
 }
 
+/* ---------------------------------------------------------------- transform tree of one CU
+ * rcn_transform_tree + rcn_res_wrap (rcn_transform_tree.c:1432-1506). */
+static int
+tt_walk(ovhip_recorder *r, const ovhip_tu_state *st, const ovhip_tt_desc *tt, int x0, int y0, int log2_w, int log2_h,
+        int depth, const ovhip_tu_info *ti)
+{
+    const int max = tt->log2_max_tb_s;
+    const int split_v = log2_w > max, split_h = log2_h > max;
+    const int nsub = depth ? 1 : (1 << (split_v + split_h));
+    int n = 0, k;
+
+    /* a 128-sample side next to a shorter one is first cut into two 64-sample halves: TUInfo slots 0 and 8 */
+    if (log2_w > 6 && log2_h < 7) {
+        if ((k = tt_walk(r, st, tt, x0, y0, 6, log2_h, depth + 1, ti)) < 0) return k;
+        n += k;
+        if ((k = tt_walk(r, st, tt, x0 + 64, y0, 6, log2_h, depth + 1, ti + 8)) < 0) return k;
+        return n + k;
+    }
+    if (log2_h > 6 && log2_w < 7) {
+        if ((k = tt_walk(r, st, tt, x0, y0, log2_w, 6, depth + 1, ti)) < 0) return k;
+        n += k;
+        if ((k = tt_walk(r, st, tt, x0, y0 + 64, log2_w, 6, depth + 1, ti + 8)) < 0) return k;
+        return n + k;
+    }
+    if (split_v || split_h) {
+        const int w1 = (1 << log2_w) >> split_v, h1 = (1 << log2_h) >> split_h;
+        const int l2w1 = log2_w - split_v, l2h1 = log2_h - split_h;
+        if ((k = tt_walk(r, st, tt, x0, y0, l2w1, l2h1, depth + 1, ti)) < 0) return k;
+        n += k;
+        if (split_v) { if ((k = tt_walk(r, st, tt, x0 + w1, y0, l2w1, l2h1, depth + 1, ti + 1 * nsub)) < 0) return k; n += k; }
+        if (split_h) { if ((k = tt_walk(r, st, tt, x0, y0 + h1, l2w1, l2h1, depth + 1, ti + 2 * nsub)) < 0) return k; n += k; }
+        if (split_h && split_v) { if ((k = tt_walk(r, st, tt, x0 + w1, y0 + h1, l2w1, l2h1, depth + 1, ti + 3 * nsub)) < 0) return k; n += k; }
+        return n;
+    }
+    /* leaf: rcn_res_wrap -> rcn_tu_st / rcn_tu_l / rcn_tu_c */
+    ovhip_tu_desc d;
+    memset(&d, 0, sizeof(d));
+    d.x0 = (uint16_t)x0; d.y0 = (uint16_t)y0; d.log2_tb_w = (uint8_t)log2_w; d.log2_tb_h = (uint8_t)log2_h;
+    d.tree = tt->tree; d.cbf_mask = ti->cbf_mask; d.cu_flags = tt->cu_flags;
+    d.tr_skip_mask = ti->tr_skip_mask; d.cu_mts_flag = ti->cu_mts_flag; d.cu_mts_idx = ti->cu_mts_idx;
+    d.lfnst_flag = ti->lfnst_flag; d.lfnst_idx = ti->lfnst_idx;
+    for (int c = 0; c < 3; ++c) {
+        d.last_pos[c] = ti->last_pos[c]; d.sig_sb_map[c] = ti->sig_sb_map[c];
+        d.coef[c] = tt->residual[c] ? tt->residual[c] + ti->pos_offset : NULL;
+    }
+    if (!d.cbf_mask) return 0;
+    return ovhip_rec_tu(r, st, &d);
+}
+
+int
+ovhip_rec_transform_tree(ovhip_recorder *r, const ovhip_tu_state *st, const ovhip_tt_desc *tt)
+{
+    if (!r || !st || !tt || !tt->tu_info || tt->tree > 2 || tt->log2_w > 7 || tt->log2_h > 7 || tt->log2_max_tb_s > 6) return OVHIP_EINVAL;
+    const size_t n0 = r->n_tb, c0 = r->n_coef;
+    const int n = tt_walk(r, st, tt, tt->x0, tt->y0, tt->log2_w, tt->log2_h, 0, tt->tu_info);
+    if (n < 0) { r->n_tb = n0; r->n_coef = c0; }
+    return n;
+}
+
 /* ---------------------------------------------------------------- prediction units */
 static int32_t clip3(int32_t v, int32_t lo, int32_t hi) { return v < lo ? lo : v > hi ? hi : v; }
 

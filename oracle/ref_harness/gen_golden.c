@@ -92,6 +92,23 @@ static int shim_lfnst_mode_c(int log2_w, int log2_h, int mode)
     return mode < 0 ? mode + 14 + 67 : mode >= 67 ? mode + 14 : mode;
 }
 
+/* TUInfo slots tmp.rcn_transform_tree visits for a CU (index arithmetic of rcn_transform_tree.c:1454-1506) */
+static void
+tt_slots(int l2w, int l2h, int max_tb, int depth, int base, int *out, int *n)
+{
+    int sv = l2w > max_tb, sh = l2h > max_tb, nsub = depth ? 1 : (1 << (sv + sh));
+    if (l2w > 6 && l2h < 7) { tt_slots(6, l2h, max_tb, depth + 1, base, out, n); tt_slots(6, l2h, max_tb, depth + 1, base + 8, out, n); return; }
+    if (l2h > 6 && l2w < 7) { tt_slots(l2w, 6, max_tb, depth + 1, base, out, n); tt_slots(l2w, 6, max_tb, depth + 1, base + 8, out, n); return; }
+    if (sv || sh) {
+        tt_slots(l2w - sv, l2h - sh, max_tb, depth + 1, base, out, n);
+        if (sv) tt_slots(l2w - sv, l2h - sh, max_tb, depth + 1, base + nsub, out, n);
+        if (sh) tt_slots(l2w - sv, l2h - sh, max_tb, depth + 1, base + 2 * nsub, out, n);
+        if (sv && sh) tt_slots(l2w - sv, l2h - sh, max_tb, depth + 1, base + 3 * nsub, out, n);
+        return;
+    }
+    out[(*n)++] = base;
+}
+
 static void
 gen_itx(const char *dir)
 {
@@ -243,8 +260,81 @@ gen_itx(const char *dir)
         }
     }
 
+    /* ---- whole transform trees through tmp.rcn_transform_tree (rcn_transform_tree.c:1454-1506): inter CUs up to
+     * 128x128, maximum transform size 64 or 32, one struct TUInfo per leaf as the caller lays them out ---- */
+    gbuf t_state = { .type = T_U8 }, t_desc = { .type = T_U8 }, t_info = { .type = T_U8 }, t_coef = { .type = T_I16 };
+    gbuf t_coff = { .type = T_U32 }, t_eoff = { .type = T_U32 };
+    uint32_t n_tt = 0;
+    {
+        extern int transform_unit_st(OVCTUDec *const, unsigned int, unsigned int, unsigned int, unsigned int, uint8_t, CUFlags, uint8_t, struct TUInfo *const);
+        c->transform_unit = (void *)&transform_unit_st;
+        static const uint8_t shapes[][3] = { {6,6,6}, {7,6,6}, {6,7,6}, {7,7,6}, {7,5,6}, {5,7,6}, {6,6,5}, {6,5,5}, {7,7,5}, {5,5,6}, {7,4,6}, {6,6,6} };
+        for (unsigned sc = 0; sc < sizeof(shapes) / 3; ++sc) {
+            const int l2w = shapes[sc][0], l2h = shapes[sc][1], max_tb = shapes[sc][2];
+            ovhip_tu_state st; ovhip_tt_desc td; ovhip_tu_info ti[16]; struct TUInfo tu[16];
+            memset(&st, 0, sizeof(st)); memset(&td, 0, sizeof(td)); memset(ti, 0, sizeof(ti)); memset(tu, 0, sizeof(tu));
+            st.qp_y = rnd_range(20, 60); st.qp_cb = rnd_range(20, 60); st.qp_cr = rnd_range(20, 60); st.qp_jcbcr = rnd_range(20, 60);
+            st.qp_y_skip = st.qp_y; st.qp_cb_skip = st.qp_cb; st.qp_cr_skip = st.qp_cr; st.qp_jcbcr_skip = st.qp_jcbcr;
+            st.dep_quant = rnd_range(0, 1); st.ict_type = rnd_range(0, 3); st.lmcs_scale_c = rnd_range(0, 1);
+            st.lmcs_chroma_scale = (int16_t)rnd_range(1200, 3400);
+            td.x0 = 0; td.y0 = 0; td.log2_w = l2w; td.log2_h = l2h; td.log2_max_tb_s = max_tb; td.tree = 0; td.cu_flags = 0;
+            memset(c->residual_y, 0, sizeof(c->residual_y)); memset(c->residual_cb, 0, sizeof(c->residual_cb)); memset(c->residual_cr, 0, sizeof(c->residual_cr));
+            /* leaf geometry: what the walker will hand out, in its own visiting order per TUInfo slot */
+            const int lw = l2w > max_tb ? max_tb : l2w, lh = l2h > max_tb ? max_tb : l2h;
+            uint32_t used = 0;
+            int slots[64], n_slots = 0;
+            tt_slots(l2w, l2h, max_tb, 0, 0, slots, &n_slots);
+            const uint32_t leaf_sz = (uint32_t)(1 << ((lw > 5 ? 5 : lw) + (lh > 5 ? 5 : lh)));
+            for (int q = 0; q < n_slots; ++q) {
+                const int k = slots[q];
+                if (k > 15 || ti[k].pos_offset || tu[k].cbf_mask) continue;      /* a slot may be visited twice (depth > 1): keep the first fill */
+                static const uint8_t cbfs[6] = { 0x10, 0x13, 0x1b, 0x12, 0x00, 0x11 };
+                ti[k].cbf_mask = cbfs[rnd_range(0, 5)];
+                ti[k].pos_offset = (uint16_t)used;
+                int16_t *res[3] = { c->residual_cb, c->residual_cr, c->residual_y };
+                for (int comp = 0; comp < 3; ++comp) {
+                    int is_l = comp == 2;
+                    int use = is_l ? (ti[k].cbf_mask & 0x10) : ((ti[k].cbf_mask & 0x8) ? comp == 0 : (ti[k].cbf_mask & (comp ? 0x1 : 0x2)));
+                    if (!use) continue;
+                    uint64_t map; uint16_t lp;
+                    make_coefs(res[comp] + ti[k].pos_offset, is_l ? lw : lw - 1, is_l ? lh : lh - 1, rnd_range(0, 2), 0, &map, &lp);
+                    ti[k].sig_sb_map[comp] = map; ti[k].last_pos[comp] = lp;
+                    tu[k].tb_info[comp].sig_sb_map = map; tu[k].tb_info[comp].last_pos = lp;
+                }
+                tu[k].cbf_mask = ti[k].cbf_mask; tu[k].pos_offset = ti[k].pos_offset;
+                used += leaf_sz;
+            }
+            rcn_init_ict_functions_10(&c->rcn_funcs, st.ict_type, 10);
+            c->dequant_luma.qp = st.qp_y; c->dequant_cb.qp = st.qp_cb; c->dequant_cr.qp = st.qp_cr; c->dequant_joint_cb_cr.qp = st.qp_jcbcr;
+            c->dequant_luma_skip.qp = st.qp_y_skip; c->dequant_cb_skip.qp = st.qp_cb_skip; c->dequant_cr_skip.qp = st.qp_cr_skip; c->dequant_jcbcr_skip.qp = st.qp_jcbcr_skip;
+            c->residual_coding_l = st.dep_quant ? &residual_coding_dpq : NULL;
+            c->mts_implicit = 0; c->sh_ts_disabled = 0; c->tmp_ciip = 0;
+            c->lmcs_info.scale_c_flag = st.lmcs_scale_c; c->lmcs_info.lmcs_chroma_scale = (uint16_t)st.lmcs_chroma_scale;
+            for (int j = 0; j < 128; ++j) memcpy(cb->y + j * cb->stride, pred_y + j * 128, 256);
+            for (int j = 0; j < 64; ++j) { memcpy(cb->cb + j * cb->stride_c, pred_cb + j * 64, 128); memcpy(cb->cr + j * cb->stride_c, pred_cr + j * 64, 128); }
+            memset(&c->dbf_info, 0, sizeof(c->dbf_info));
+            c->rcn_funcs.tmp.rcn_transform_tree(c, 0, 0, l2w, l2h, max_tb, 0, 0, tu);
+
+            uint32_t coff = (uint32_t)t_coef.n, eoff[3];
+            gbuf_push(&t_coef, c->residual_cb, used); gbuf_push(&t_coef, c->residual_cr, used); gbuf_push(&t_coef, c->residual_y, used);
+            uint32_t co[2] = { coff, used };
+            eoff[0] = (uint32_t)b_exp.n; dump_rect(&b_exp, cb->y, cb->stride, 0, 0, 1 << l2w, 1 << l2h);
+            eoff[1] = (uint32_t)b_exp.n; dump_rect(&b_exp, cb->cb, cb->stride_c, 0, 0, 1 << (l2w - 1), 1 << (l2h - 1));
+            eoff[2] = (uint32_t)b_exp.n; dump_rect(&b_exp, cb->cr, cb->stride_c, 0, 0, 1 << (l2w - 1), 1 << (l2h - 1));
+            gbuf_push(&t_state, &st, sizeof(st)); gbuf_push(&t_desc, &td, sizeof(td)); gbuf_push(&t_info, ti, sizeof(ti));
+            gbuf_push(&t_coff, co, 2); gbuf_push(&t_eoff, eoff, 3);
+            n_tt++;
+        }
+    }
+
     gfile g = gfile_open(dir, "itx.ovg");
     uint32_t d2[2];
+    d2[0] = n_tt; d2[1] = sizeof(ovhip_tu_state); gfile_array(&g, "tt_state", T_U8, t_state.data, 2, d2);
+    d2[1] = sizeof(ovhip_tt_desc);  gfile_array(&g, "tt_desc", T_U8, t_desc.data, 2, d2);
+    d2[1] = 16 * sizeof(ovhip_tu_info); gfile_array(&g, "tt_info", T_U8, t_info.data, 2, d2);
+    d2[1] = 2; gfile_array(&g, "tt_coef_off", T_U32, t_coff.data, 2, d2);
+    d2[1] = 3; gfile_array(&g, "tt_exp_off", T_U32, t_eoff.data, 2, d2);
+    gfile_buf(&g, "tt_coefs", &t_coef);
     d2[0] = 128; d2[1] = 128; gfile_array(&g, "pred_y", T_U16, pred_y, 2, d2);
     d2[0] = 64; d2[1] = 64;   gfile_array(&g, "pred_cb", T_U16, pred_cb, 2, d2);
     gfile_array(&g, "pred_cr", T_U16, pred_cr, 2, d2);

@@ -42,6 +42,29 @@ def itx_cases():
     return pic, rec.tb_cmds(), rec.coefs(), rects, g["exp"]
 
 
+def tt_cases():
+    """Whole transform trees (tmp.rcn_transform_tree): (picture, commands, coefficient arena, rects, expected)."""
+    g = golden_io.load("itx.ovg")
+    n = g["tt_desc"].shape[0]
+    pic = HostPic(128, BAND * n,
+                  np.tile(g["pred_y"], (n, 1)), np.tile(g["pred_cb"], (n, 1)), np.tile(g["pred_cr"], (n, 1)))
+    rec = capi.Recorder(128, BAND * n)
+    rects = []
+    for i in range(n):
+        st = capi.TuState.from_buffer_copy(g["tt_state"][i].tobytes())
+        d = capi.TtDesc.from_buffer_copy(g["tt_desc"][i].tobytes())
+        off, used = (int(v) for v in g["tt_coef_off"][i])
+        co = g["tt_coefs"][off:off + 3 * used]
+        d.y0 = i * BAND
+        rec.transform_tree(st, d, g["tt_info"][i].tobytes(), co[:used], co[used:2 * used], co[2 * used:])
+        w, h = 1 << d.log2_w, 1 << d.log2_h
+        eo = g["tt_exp_off"][i]
+        rects.append((0, 0, i * BAND, w, h, int(eo[0])))
+        rects.append((1, 0, i * (BAND // 2), w >> 1, h >> 1, int(eo[1])))
+        rects.append((2, 0, i * (BAND // 2), w >> 1, h >> 1, int(eo[2])))
+    return pic, rec.tb_cmds(), rec.coefs(), rects, g["exp"]
+
+
 def mc_cases():
     g = golden_io.load("mc.ovg")
     n = g["desc"].shape[0]

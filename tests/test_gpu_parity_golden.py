@@ -26,6 +26,15 @@ def test_itx_gpu_matches_reference(ctx):
     golden_cases.check_rects(HostPic(pic.w, pic.h, y, cb, cr), rects, exp, "itx HIP vs reference")
 
 
+def test_transform_tree_gpu_matches_reference(ctx):
+    pic, cmds, coefs, rects, exp = golden_cases.tt_cases()
+    d = ctx.upload_pic(pic.y, pic.cb, pic.cr)
+    ctx.itx(d, ctx.upload(cmds), ctx.upload(coefs))
+    ctx.sync()
+    y, cb, cr = d.download()
+    golden_cases.check_rects(HostPic(pic.w, pic.h, y, cb, cr), rects, exp, "transform tree HIP vs reference")
+
+
 def test_mc_gpu_matches_reference(ctx):
     refs, descs, exp_off, exp = golden_cases.mc_cases()
     rw, rh = refs[0].w, refs[0].h

@@ -16,6 +16,14 @@ def test_itx_oracle_matches_reference(built_lib):
     golden_cases.check_rects(pic, rects, exp, "itx oracle vs reference")
 
 
+def test_transform_tree_oracle_matches_reference(built_lib):
+    """tmp.rcn_transform_tree: CUs up to 128x128 cut at the maximum transform size, one TUInfo per leaf."""
+    pic, cmds, coefs, rects, exp = golden_cases.tt_cases()
+    assert len(rects) == 36 and len(cmds) > 60
+    oracle_lib.itx(pic, cmds, coefs)
+    golden_cases.check_rects(pic, rects, exp, "transform tree oracle vs reference")
+
+
 def test_mc_oracle_matches_reference(built_lib):
     refs, descs, exp_off, exp = golden_cases.mc_cases()
     rw, rh = refs[0].w, refs[0].h
