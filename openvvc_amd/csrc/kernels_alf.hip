@@ -115,14 +115,27 @@ __global__ __launch_bounds__(256) void k_alf_luma(ovhip_pic dst, ovhip_pic src, 
         if (ty0 + rr + 2 == vb) below = rr + 1;                  // pair (vb-2, vb-1): row vb is not available
         if (ty0 + rr == vb)     above = rr;                      // pair (vb, vb+1): row vb-1 is not available
         uint32_t sv = 0, sh = 0, sd = 0, sb = 0;
+        {
+            // the pair's 4 rows (above, rr, rr + 1, below), columns cbx-4 .. cbx+7, as 8-byte LDS reads
+            uint32_t ra[6], r0[6], r1[6], rb[6];
+            const uint16_t *base = s_t + LH * LWS + cbx;
+            auto row3 = [&](int y, uint32_t d6[6]) {
+                const uint2 *q2 = reinterpret_cast<const uint2 *>(base + y * LWS);
+                const uint2 a = q2[0], b_ = q2[1], c_ = q2[2];
+                d6[0] = a.x; d6[1] = a.y; d6[2] = b_.x; d6[3] = b_.y; d6[4] = c_.x; d6[5] = c_.y;
+            };
+            row3(above, ra); row3(rr, r0); row3(rr + 1, r1); row3(below, rb);
+#define S6(d6, c) ((((c) + 4) & 1) ? (int)((d6)[((c) + 4) >> 1] >> 16) : (int)((d6)[((c) + 4) >> 1] & 0xffff))
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int c0 = cbx - 2 + 2 * q, c1 = c0 + 1;
-            const int y1 = T(c0, rr) << 1, y2 = T(c1, rr + 1) << 1;
-            sv += abs(y1 - T(c0, above) - T(c0, rr + 1)) + abs(y2 - T(c1, rr) - T(c1, below));
-            sh += abs(y1 - T(c0 + 1, rr) - T(c0 - 1, rr)) + abs(y2 - T(c1 + 1, rr + 1) - T(c1 - 1, rr + 1));
-            sd += abs(y1 - T(c0 - 1, above) - T(c0 + 1, rr + 1)) + abs(y2 - T(c1 - 1, rr) - T(c1 + 1, below));
-            sb += abs(y1 - T(c0 - 1, rr + 1) - T(c0 + 1, above)) + abs(y2 - T(c1 - 1, below) - T(c1 + 1, rr));
+            for (int q = 0; q < 4; ++q) {
+                const int c0 = 2 * q - 2, c1 = c0 + 1;             // columns relative to the block
+                const int y1 = S6(r0, c0) << 1, y2 = S6(r1, c1) << 1;
+                sv += abs(y1 - S6(ra, c0) - S6(r1, c0)) + abs(y2 - S6(r0, c1) - S6(rb, c1));
+                sh += abs(y1 - S6(r0, c0 + 1) - S6(r0, c0 - 1)) + abs(y2 - S6(r1, c1 + 1) - S6(r1, c1 - 1));
+                sd += abs(y1 - S6(ra, c0 - 1) - S6(r1, c0 + 1)) + abs(y2 - S6(r0, c1 - 1) - S6(rb, c1 + 1));
+                sb += abs(y1 - S6(r1, c0 - 1) - S6(ra, c0 + 1)) + abs(y2 - S6(rb, c1 - 1) - S6(r0, c1 + 1));
+            }
+#undef S6
         }
         // which pairs count: all four, or three next to the virtual boundary (rcn_alf.c:520-583)
         const int py = ty0 + cby;
