@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_alf_luma(ovhip_pic dst, ovhip_pic src, 
     const int tid = threadIdx.x;
     const int ctu = 1 << alf.log2_ctu_s;
     const int ntx = (W + TL - 1) / TL, ntiles = ntx * ((H + TL - 1) / TL);
-    // resident grid striding over the 32x32 tiles (workgroup dispatch is ~400 WG/us on this chip)
+    // loop form for capped grids; launched with one workgroup per 32x32 tile
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, __syncthreads()) {
     const int tx0 = (tile % ntx) * TL, ty0 = (tile / ntx) * TL;
     const ovhip_alf_ctu c = alf.ctus[(ty0 >> alf.log2_ctu_s) * nb_ctu_w + (tx0 >> alf.log2_ctu_s)];

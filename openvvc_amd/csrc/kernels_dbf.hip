@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void k_dbf(ovhip_pic pic, ovhip_dbf_planes pl)
     const int comp = blockIdx.y;
     const int w4 = pl.w4, h4 = pl.h4;
     const int nthreads = gridDim.x * 256;
-    // resident grid: every lane strides over the edge-parameter plane (most words are 0 = no edge)
+    // every lane strides over the edge-parameter plane (most words are 0 = no edge; k_dbf_list takes the compact lists)
     if (comp == 0) {
         for (int tid = blockIdx.x * 256 + threadIdx.x; tid < w4 * h4; tid += nthreads) {
             const int ux = tid % w4, uy = tid / w4;

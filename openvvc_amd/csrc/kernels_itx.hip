@@ -159,7 +159,7 @@ __global__ __launch_bounds__(NT) void k_itx(ovhip_pic pic, const ovhip_tb_cmd *_
     __shared__ __attribute__((aligned(16))) int8_t s_mh[MC << ML2];
 
     const int lane = threadIdx.x;
-    for (uint32_t bid = blockIdx.x; bid < n_cmds; bid += gridDim.x, __syncthreads()) {   // resident grid, see OV_RESIDENT_WAVES
+    for (uint32_t bid = blockIdx.x; bid < n_cmds; bid += gridDim.x, __syncthreads()) {   // loop form for capped grids; launched with one workgroup per block
     const ovhip_tb_cmd c = cmds[bid];
 
     const int log2_w = c.log2_w, log2_h = c.log2_h;

@@ -6,6 +6,7 @@
 // through the scalar cache.  Replaces sao.band / sao.edge and the drivers rcn_sao_ctu,
 // rcn_sao_filter_line, rcn_sao_first_pix_rows (libovvc/rcn_sao.c:46-293).
 #include "ovvc_common.hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(256) void k_sao(ovhip_pic dst, ovhip_pic src, const
                                               int log2_ctu, int nb_ctu_w, int tiles_y, int tiles_c)
 {
     const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;          // 8 lanes x 8 samples per row, 32 rows
-    // resident grid striding over (plane, tile): luma tiles first, then Cb, then Cr
+    // (plane, tile): luma tiles first, then Cb, then Cr; loop form for capped grids
     for (int t = blockIdx.x; t < tiles_y + 2 * tiles_c; t += gridDim.x) {
         const int c = t < tiles_y ? 0 : (t < tiles_y + tiles_c ? 1 : 2);
         const int tt = t - (c == 0 ? 0 : (c == 1 ? tiles_y : tiles_y + tiles_c));
@@ -111,7 +112,8 @@ extern "C" int ovhip_sao_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhi
     const int tiles_y = ((src->w + SAO_TW - 1) / SAO_TW) * ((src->h + SAO_TH - 1) / SAO_TH);
     const int tiles_c = ((src->w / 2 + SAO_TW - 1) / SAO_TW) * ((src->h / 2 + SAO_TH - 1) / SAO_TH);
     const int total = tiles_y + 2 * tiles_c;
-    hipLaunchKernelGGL(k_sao, dim3(total < 2048 ? total : 2048), dim3(256), 0, ctx->stream, *dst, *src, d_params,
+    // one workgroup per tile (measured: 18.7 us; a resident grid of 2048 workgroups 22.4 us, 1024: 26.5 us)
+    hipLaunchKernelGGL(k_sao, dim3(total), dim3(256), 0, ctx->stream, *dst, *src, d_params,
                        log2_ctu_s, nb_ctu_w, tiles_y, tiles_c);
     OV_LAUNCH_CHECK(ctx, "k_sao");
     return OVHIP_OK;

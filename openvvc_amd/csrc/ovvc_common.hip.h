@@ -6,11 +6,10 @@
 #include <string.h>
 #include "ovvc_hip.h"
 
-// Measured on MI355X (profiles/r01c_*): an empty one-wave workgroup per item costs ~0.4 ns/item
-// (48.9k workgroups in ~20 us incl. the command fetch); capping the grid to a resident set and
-// striding was SLOWER for every latency-bound kernel here (fewer loads in flight), so the kernels keep
-// their grid-stride loops but are launched with one workgroup per item.
-#define OV_RESIDENT_WAVES (256 * 24)
+// Measured on MI355X: an empty one-wave workgroup per item costs ~0.4 ns/item (48.9k workgroups in ~20 us incl.
+// the command fetch); capping the grid to a resident set and striding was SLOWER for every latency-bound kernel
+// here (fewer loads in flight), so the kernels keep their grid-stride loops but are launched with one workgroup
+// per item.
 
 #define OV_BD 10
 #define OV_PIX_MAX ((1 << OV_BD) - 1)
