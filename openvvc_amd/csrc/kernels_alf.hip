@@ -15,6 +15,17 @@
 // rcn_alf_reconstruct_coeff_APS() builds on the host (struct RCNALF, rcn_alf.h:60-66).
 #include "ovvc_common.hip.h"
 
+// Occupancy hint (waves per SIMD the register allocator must leave room for; 0 = compiler default).
+// -DOV_WPE_ALF=n overrides it for sweeps.
+#ifndef OV_WPE_ALF
+#define OV_WPE_ALF 0
+#endif
+#if OV_WPE_ALF > 0
+#define OV_OCC_ALF __attribute__((amdgpu_waves_per_eu(OV_WPE_ALF)))
+#else
+#define OV_OCC_ALF
+#endif
+
 namespace {
 
 #define TL 32           /* tile size               */
@@ -51,7 +62,7 @@ __device__ __forceinline__ void filter_idx(uint32_t sum_h, uint32_t sum_v, uint3
     tr = (0xDE84 >> (2 * k)) & 3;                        // packed 2-bit LUT
 }
 
-__global__ __launch_bounds__(256) void k_alf_luma(ovhip_pic dst, ovhip_pic src, ovhip_alf_pic alf, int nb_ctu_w)
+__global__ __launch_bounds__(256) OV_OCC_ALF void k_alf_luma(ovhip_pic dst, ovhip_pic src, ovhip_alf_pic alf, int nb_ctu_w)
 {
     __shared__ __attribute__((aligned(16))) uint16_t s_t[LW * LWS];
     __shared__ uint8_t s_cls[64];
@@ -258,7 +269,7 @@ __global__ __launch_bounds__(256) void k_alf_luma(ovhip_pic dst, ovhip_pic src, 
 }
 
 // blockIdx.z: 0 Cb, 1 Cr
-__global__ __launch_bounds__(256) void k_alf_chroma(ovhip_pic dst, ovhip_pic src, ovhip_alf_pic alf, int nb_ctu_w)
+__global__ __launch_bounds__(256) OV_OCC_ALF void k_alf_chroma(ovhip_pic dst, ovhip_pic src, ovhip_alf_pic alf, int nb_ctu_w)
 {
     __shared__ __attribute__((aligned(16))) uint16_t s_t[CW * LWS];
     const int comp = 1 + blockIdx.z;

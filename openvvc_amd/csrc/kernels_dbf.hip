@@ -18,6 +18,17 @@
 #define OVT_ATTR __device__
 #include "vvc_dbf_tables.h"
 
+// Occupancy hint (waves per SIMD the register allocator must leave room for; 0 = compiler default).
+// -DOV_WPE_DBF=n overrides it for sweeps.
+#ifndef OV_WPE_DBF
+#define OV_WPE_DBF 0
+#endif
+#if OV_WPE_DBF > 0
+#define OV_OCC_DBF __attribute__((amdgpu_waves_per_eu(OV_WPE_DBF)))
+#else
+#define OV_OCC_DBF
+#endif
+
 namespace {
 
 struct Lim { int tc, beta; };
@@ -254,7 +265,7 @@ __global__ __launch_bounds__(256) void k_dbf(ovhip_pic pic, ovhip_dbf_planes pl)
 
 // The same filter over the compact edge lists (ovhip_dbf_compact): every lane has an edge.
 template <int DIR>
-__global__ __launch_bounds__(256) void k_dbf_list(ovhip_pic pic, const ovhip_dbf_edge *__restrict__ edges, uint32_t n,
+__global__ __launch_bounds__(256) OV_OCC_DBF void k_dbf_list(ovhip_pic pic, const ovhip_dbf_edge *__restrict__ edges, uint32_t n,
                                                   int tc_offset, int beta_offset)
 {
     const uint32_t tid = blockIdx.x * 256 + threadIdx.x;

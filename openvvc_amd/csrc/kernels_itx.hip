@@ -18,6 +18,17 @@
 #define OVT_ATTR __device__
 #include "vvc_tables.h"
 
+// Occupancy hint (waves per SIMD the register allocator must leave room for; 0 = compiler default).
+// -DOV_WPE_ITX=n overrides it for sweeps.
+#ifndef OV_WPE_ITX
+#define OV_WPE_ITX 0
+#endif
+#if OV_WPE_ITX > 0
+#define OV_OCC_ITX __attribute__((amdgpu_waves_per_eu(OV_WPE_ITX)))
+#else
+#define OV_OCC_ITX
+#endif
+
 namespace {
 
 __device__ __forceinline__ const int8_t *tr_matrix(int type, int log2n)
@@ -148,7 +159,7 @@ __device__ __forceinline__ void tr_pass_lds(const int16_t *src, int sstride, con
 // wave alone would be the tail of the launch); <4, 64> blocks up to 16x16, one wave and 1.5 KB of LDS per
 // block so that 32 blocks are resident per CU and hide each other's load latency.
 template <int ML2, int NT>
-__global__ __launch_bounds__(NT) void k_itx(ovhip_pic pic, const ovhip_tb_cmd *__restrict__ cmds,
+__global__ __launch_bounds__(NT) OV_OCC_ITX void k_itx(ovhip_pic pic, const ovhip_tb_cmd *__restrict__ cmds,
                                              uint32_t n_cmds, const int16_t *__restrict__ arena,
                                              const int16_t *__restrict__ lmcs_scales, int ablate)
 {

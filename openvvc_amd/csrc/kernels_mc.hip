@@ -18,6 +18,17 @@
 #include "mc_common.hip.h"
 #include <stdlib.h>
 
+// Occupancy hint (waves per SIMD the register allocator must leave room for; 0 = compiler default).
+// -DOV_WPE_MC=n overrides it for sweeps.
+#ifndef OV_WPE_MC
+#define OV_WPE_MC 0
+#endif
+#if OV_WPE_MC > 0
+#define OV_OCC_MC __attribute__((amdgpu_waves_per_eu(OV_WPE_MC)))
+#else
+#define OV_OCC_MC
+#endif
+
 namespace {
 
 // geometric partitioning: w = clip3(0, 8, (K + A*x + B*y) >> 3), put_weighted_gpm_bi_pixels (rcn_mc.c:1630-1655)
@@ -98,7 +109,7 @@ __device__ __forceinline__ void chroma_finish(const ovhip_mc_unit &u, const ovhi
     }
 }
 
-__global__ __launch_bounds__(64) void k_mc2(ovhip_pic dst, RefTable refs, const ovhip_mc_unit *__restrict__ units,
+__global__ __launch_bounds__(64) OV_OCC_MC void k_mc2(ovhip_pic dst, RefTable refs, const ovhip_mc_unit *__restrict__ units,
                                              uint32_t n_units, const uint16_t *__restrict__ lmcs_fwd, int xcd, ovhip_pic intra)
 {
     __shared__ __attribute__((aligned(16))) uint16_t s_wl[2 * LUMA_WIN + 8];       // luma windows, list 0 / 1 (+ dword over-read slack)

@@ -19,6 +19,17 @@
 #include "mc_common.hip.h"
 #include <stdlib.h>
 
+// Occupancy hint (waves per SIMD the register allocator must leave room for; 0 = compiler default).
+// -DOV_WPE_MCX=n overrides it for sweeps.
+#ifndef OV_WPE_MCX
+#define OV_WPE_MCX 4
+#endif
+#if OV_WPE_MCX > 0
+#define OV_OCC_MCX __attribute__((amdgpu_waves_per_eu(OV_WPE_MCX)))
+#else
+#define OV_OCC_MCX
+#endif
+
 namespace {
 
 #define XWIN_STRIDE  32    /* 4 (aligned apron slot) + off(<=3) + 23 + 2                                */
@@ -101,14 +112,18 @@ __device__ __forceinline__ void chroma_avg(const ovhip_mc_unit &u, const ovhip_p
     for (int j = 0; j < NOUT; ++j) d[j * dst.stride_c] = (uint16_t)ov_clip_bd((P[0][j] + P[1][j] + 16) >> 5);
 }
 
-__global__ __launch_bounds__(64) void k_mcx(ovhip_pic dst, RefTable refs, const ovhip_mc_unit *__restrict__ units,
+__global__ __launch_bounds__(64) OV_OCC_MCX void k_mcx(ovhip_pic dst, RefTable refs, const ovhip_mc_unit *__restrict__ units,
                                              uint32_t n_units, const uint16_t *__restrict__ lmcs_fwd, int32_t *__restrict__ mv_out)
 {
     __shared__ __attribute__((aligned(16))) uint16_t s_wl[2][XWIN_ROWS * XWIN_STRIDE];
     __shared__ __attribute__((aligned(16))) uint16_t s_wc[2][2][XCWIN_ROWS * XCWIN_STRIDE];   // [Cb/Cr][list]
-    __shared__ __attribute__((aligned(16))) int16_t  s_hl[2][16 * HT_STRIDE];
-    __shared__ __attribute__((aligned(16))) int16_t  s_hc[2][2][8 * CHT_STRIDE];
-    __shared__ __attribute__((aligned(16))) int16_t  s_x[2][24 * BIL_STRIDE];                 // DMVR bilinear blocks, then BDOF R tiles
+    // H-pass tiles; the same bytes first hold DMVR's bilinear blocks (dead before the H pass writes) and later BDOF's
+    // R tiles (written after the V pass has read the luma tiles: one wave, LDS traffic in program order)
+    __shared__ __attribute__((aligned(16))) int16_t  s_h[2 * 16 * HT_STRIDE + 4 * 8 * CHT_STRIDE];
+    int16_t (*const s_hl)[16 * HT_STRIDE] = reinterpret_cast<int16_t (*)[16 * HT_STRIDE]>(s_h);
+    int16_t (*const s_hc)[2][8 * CHT_STRIDE] = reinterpret_cast<int16_t (*)[2][8 * CHT_STRIDE]>(s_h + 2 * 16 * HT_STRIDE);
+    int16_t (*const s_x)[24 * BIL_STRIDE] = reinterpret_cast<int16_t (*)[24 * BIL_STRIDE]>(s_h);
+    static_assert(2 * 24 * BIL_STRIDE <= 2 * 16 * HT_STRIDE + 4 * 8 * CHT_STRIDE, "bilinear blocks must fit the H tiles");
     int   *const s_avg = reinterpret_cast<int *>(s_wl[0]);                                     // BDOF (avg_gx | avg_gy << 16), 16x16
     int16_t *const s_dr = reinterpret_cast<int16_t *>(s_wl[1]);                                // BDOF delta_ref, 16x16
 
@@ -281,7 +296,7 @@ __global__ __launch_bounds__(64) void k_mcx(ovhip_pic dst, RefTable refs, const 
             const int r = tt >> log2seg, x0 = (tt & ((1 << log2seg) - 1)) << 2;
             int tp[2];
 #pragma unroll
-            for (int m = 0; m < 2; ++m) tp[m] = l ? thc[1][m] : thc[0][m];
+            for (int m = 0; m < 2; ++m) tp[m] = thc[0][m] ^ ((thc[0][m] ^ thc[1][m]) & -l);   // arithmetic select: keeps the taps in registers
             h_task<4>(s_wc[0][0] + qi * (XCWIN_ROWS * XCWIN_STRIDE) + (2 + (l ? cdy[1] : cdy[0]) + r) * XCWIN_STRIDE,
                       4 + (l ? sc[0][1].off + cdx[1] : sc[0][0].off + cdx[0]), x0, tp, l ? identc[1] : identc[0],
                       s_hc[0][0] + qi * 8 * CHT_STRIDE, CHT_STRIDE, r, 4);
