@@ -109,47 +109,96 @@ __device__ __forceinline__ void chroma_finish(const ovhip_mc_unit &u, const ovhi
     }
 }
 
+#ifdef OV_MC_PHASES
+// Debug build only (-DOV_MC_PHASES): per-phase shader-clock totals of k_mc2, summed over waves.
+#define OV_MC_PHASE_UNITS 65536
+__device__ unsigned int g_mc_phase[OV_MC_PHASE_UNITS * 8];
+#define OV_PHASE(i) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_readcyclecounter(); \
+                         ph[i] = t_ - tprev; tprev = t_; } while (0)
+#else
+#define OV_PHASE(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(64) OV_OCC_MC void k_mc2(ovhip_pic dst, RefTable refs, const ovhip_mc_unit *__restrict__ units,
                                              uint32_t n_units, const uint16_t *__restrict__ lmcs_fwd, int xcd, ovhip_pic intra)
 {
     __shared__ __attribute__((aligned(16))) uint16_t s_wl[2 * LUMA_WIN + 8];       // luma windows, list 0 / 1 (+ dword over-read slack)
     __shared__ __attribute__((aligned(16))) uint16_t s_wc[4 * CHR_WIN + 8];        // chroma windows [plane * 2 + list]
     __shared__ __attribute__((aligned(16))) int16_t  s_hl[2 * 16 * HT_STRIDE + 8]; // transposed H-pass tiles [list]
-    __shared__ __attribute__((aligned(16))) int16_t  s_hc[4 * 8 * CHT_STRIDE + 8]; // [plane * 2 + list]
+    // chroma H tiles [plane * 2 + list] reuse the luma windows, which are dead once the luma H pass has run: the
+    // workgroup then fits 6400 B of LDS, the step at which a CU holds 24 of these waves instead of 21 (measured)
+    int16_t *const s_hc = reinterpret_cast<int16_t *>(s_wl);
+    static_assert(4 * 8 * CHT_STRIDE + 8 <= 2 * LUMA_WIN + 8, "chroma H tiles must fit the luma windows");
 
     const int lane = threadIdx.x;
     for (uint32_t wg = blockIdx.x; wg < n_units; wg += gridDim.x) {
     const uint32_t bid = xcd ? ov_xcd_slot(wg, n_units) : wg;
+#ifdef OV_MC_PHASES
+    unsigned long long ph[8] = {}, tprev = __builtin_readcyclecounter();
+#endif
     const ovhip_mc_unit u = units[bid];
+    OV_PHASE(0);
 
     const bool do_l = !(u.flags & OVHIP_MC_NO_LUMA), do_c = !(u.flags & OVHIP_MC_NO_CHROMA);
     const int w = u.w, h = u.h, wc = w >> 1, hc = h >> 1;
     const int log2w = 31 - __clz(w), log2wc = log2w - 1;
     const int nl = u.dir == 3 ? 2 : 1, l0 = u.dir == 2 ? 1 : 0;      // lists present: l0 .. l0 + nl - 1
 
-    // ---- windows: issue all loads, then park ----
-    LumaStage sl[2];
-    ChromaStage sc[2][2];
+    // ---- windows: issue all loads, then park.  Every reference picture has dst's geometry (checked at launch), so
+    // only the three plane pointers of each list come from the table -- fetched for both lists before first use. ----
+    const int ri0 = (u.dir & 1) ? u.ref0 : u.ref1, ri1 = (u.dir & 2) ? u.ref1 : u.ref0;
+    const uint16_t *const ry[2]  = { refs.p[ri0].y,  refs.p[ri1].y };
+    const uint16_t *const rcb[2] = { refs.p[ri0].cb, refs.p[ri1].cb };
+    const uint16_t *const rcr[2] = { refs.p[ri0].cr, refs.p[ri1].cr };
+    const int pw = dst.w, phh = dst.h, pwc = dst.w >> 1, phc = dst.h >> 1;
+    int lx[2], ly[2], cx[2], cy[2];
+    bool fast = !((dst.stride_y | dst.stride_c) & 3);
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
-        if (!(u.dir & (1 << l))) continue;
-        const ovhip_pic &rp = refs.p[l ? u.ref1 : u.ref0];
         const int mvx = l ? u.mv1x : u.mv0x, mvy = l ? u.mv1y : u.mv0y;
-        if (do_l) sl[l].issue(rp.y, rp.stride_y, rp.w, rp.h, u.x + (mvx >> 4) - 3, u.y + (mvy >> 4) - 3, w + 7, h + 7, lane, s_wl + l * LUMA_WIN, WIN_STRIDE);
-        if (do_c) {
-            const int px = (u.x >> 1) + (mvx >> 5) - 1, py = (u.y >> 1) + (mvy >> 5) - 1;
-            sc[0][l].issue(rp.cb, rp.stride_c, rp.w >> 1, rp.h >> 1, px, py, wc + 3, hc + 3, lane, s_wc + l * CHR_WIN, CWIN_STRIDE);
-            sc[1][l].issue(rp.cr, rp.stride_c, rp.w >> 1, rp.h >> 1, px, py, wc + 3, hc + 3, lane, s_wc + (2 + l) * CHR_WIN, CWIN_STRIDE);
+        lx[l] = u.x + (mvx >> 4) - 3;        ly[l] = u.y + (mvy >> 4) - 3;
+        cx[l] = (u.x >> 1) + (mvx >> 5) - 1; cy[l] = (u.y >> 1) + (mvy >> 5) - 1;
+        if (!(u.dir & (1 << l))) continue;
+        if (do_l) fast = fast && LumaStage::interior(lx[l], ly[l], w + 7, h + 7, pw, phh);
+        if (do_c) fast = fast && ChromaStage::interior(cx[l], cy[l], wc + 3, hc + 3, pwc, phc);
+    }
+    LumaStage sl[2];
+    ChromaStage sc[2][2];
+    if (fast) {
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            if (!(u.dir & (1 << l))) continue;
+            if (do_l) sl[l].issue_fast(ry[l], dst.stride_y, lx[l], ly[l], w + 7, h + 7, lane);
+            if (do_c) {
+                sc[0][l].issue_fast(rcb[l], dst.stride_c, cx[l], cy[l], wc + 3, hc + 3, lane);
+                sc[1][l].issue_fast(rcr[l], dst.stride_c, cx[l], cy[l], wc + 3, hc + 3, lane);
+            }
+        }
+    } else {
+        // rare (window crosses the picture border): clamped per-sample loads, parked at once
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            if (!(u.dir & (1 << l))) continue;
+            if (do_l) sl[l].issue_slow(ry[l], dst.stride_y, pw, phh, lx[l], ly[l], w + 7, h + 7, lane, s_wl + l * LUMA_WIN, WIN_STRIDE);
+            if (do_c) {
+                sc[0][l].issue_slow(rcb[l], dst.stride_c, pwc, phc, cx[l], cy[l], wc + 3, hc + 3, lane, s_wc + l * CHR_WIN, CWIN_STRIDE);
+                sc[1][l].issue_slow(rcr[l], dst.stride_c, pwc, phc, cx[l], cy[l], wc + 3, hc + 3, lane, s_wc + (2 + l) * CHR_WIN, CWIN_STRIDE);
+            }
         }
     }
     int offl[2] = { 0, 0 }, offc[2][2] = { { 0, 0 }, { 0, 0 } };
+#ifdef OV_MC_PHASES
+    { const unsigned long long t_ = __builtin_readcyclecounter(); ph[1] = t_ - tprev; tprev = t_; }   // issue only, no wait
+#endif
+    if (fast) {
 #pragma unroll
-    for (int l = 0; l < 2; ++l) {
-        if (!(u.dir & (1 << l))) continue;
-        if (do_l) { sl[l].park(s_wl + l * LUMA_WIN, WIN_STRIDE, w + 7, h + 7, lane); offl[l] = sl[l].off; }
-        if (do_c) {
-            sc[0][l].park(s_wc + l * CHR_WIN, CWIN_STRIDE, wc + 3, hc + 3, lane);       offc[0][l] = sc[0][l].off;
-            sc[1][l].park(s_wc + (2 + l) * CHR_WIN, CWIN_STRIDE, wc + 3, hc + 3, lane); offc[1][l] = sc[1][l].off;
+        for (int l = 0; l < 2; ++l) {
+            if (!(u.dir & (1 << l))) continue;
+            if (do_l) { sl[l].park(s_wl + l * LUMA_WIN, WIN_STRIDE, w + 7, h + 7, lane); offl[l] = sl[l].off; }
+            if (do_c) {
+                sc[0][l].park(s_wc + l * CHR_WIN, CWIN_STRIDE, wc + 3, hc + 3, lane);       offc[0][l] = sc[0][l].off;
+                sc[1][l].park(s_wc + (2 + l) * CHR_WIN, CWIN_STRIDE, wc + 3, hc + 3, lane); offc[1][l] = sc[1][l].off;
+            }
         }
     }
     // ---- filter taps of both lists (wave-uniform) ----
@@ -170,6 +219,7 @@ __global__ __launch_bounds__(64) OV_OCC_MC void k_mc2(ovhip_pic dst, RefTable re
         identl[l] = fx == 0; identc[l] = (mvx & 31) == 0;
     }
     __syncthreads();
+    OV_PHASE(2);
 
     // ---- horizontal passes: one task = one window row x 4 outputs ----
     if (do_l) {
@@ -185,6 +235,7 @@ __global__ __launch_bounds__(64) OV_OCC_MC void k_mc2(ovhip_pic dst, RefTable re
                       s_hl + l * 16 * HT_STRIDE, HT_STRIDE, r, nout);
         }
     }
+    __syncthreads();          // s_hc aliases s_wl
     if (do_c) {
         const int log2seg = log2wc > 2 ? log2wc - 2 : 0, nout = wc < 4 ? wc : 4;
         const int TC = (hc + 3) << log2seg;
@@ -201,6 +252,7 @@ __global__ __launch_bounds__(64) OV_OCC_MC void k_mc2(ovhip_pic dst, RefTable re
         }
     }
     __syncthreads();
+    OV_PHASE(3);
 
     // ---- vertical passes + combine + store: every lane finishes NOUT samples of one column ----
     if (do_l) {
@@ -214,6 +266,15 @@ __global__ __launch_bounds__(64) OV_OCC_MC void k_mc2(ovhip_pic dst, RefTable re
         else               chroma_finish<1>(u, dst, s_hc, tvc, lane, log2wc, hc, intra);
     }
     __syncthreads();          // LDS tiles are reused by the next unit
+#ifdef OV_MC_PHASES
+    { const unsigned long long t_ = __builtin_readcyclecounter(); ph[4] = t_ - tprev; tprev = t_; }   // V pass, stores issued
+    OV_PHASE(5);                                                                                      // stores drained
+    if (lane == 0 && bid < OV_MC_PHASE_UNITS) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) g_mc_phase[bid * 8 + i] = (unsigned int)ph[i];
+        g_mc_phase[bid * 8 + 7] = 1;
+    }
+#endif
     }
 }
 
@@ -241,6 +302,13 @@ __global__ __launch_bounds__(256) void k_ciip(ovhip_pic dst, ovhip_pic intra, co
 
 } // namespace
 
+#ifdef OV_MC_PHASES
+extern "C" int ovhip_debug_mc_phases(unsigned int *out /* [65536][8] */)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mc_phase), sizeof(unsigned int) * OV_MC_PHASE_UNITS * 8) == hipSuccess ? OVHIP_OK : OVHIP_ELAUNCH;
+}
+#endif
+
 extern "C" int ovhip_ciip_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *intra,
                                  const ovhip_ciip_unit *d_units, uint32_t n_units)
 {
@@ -262,7 +330,12 @@ extern "C" int ovhip_mc_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip
         return ov_fail(ctx, OVHIP_EINVAL, "ovhip_mc_launch: bad reference table / units", hipSuccess);
     RefTable t;
     memset(&t, 0, sizeof(t));
-    for (uint32_t i = 0; i < n_refs; ++i) t.p[i] = refs[i];
+    for (uint32_t i = 0; i < n_refs; ++i) {
+        // k_mc2 takes the window geometry from dst: references of another size are RPR, outside this path
+        if (refs[i].w != dst->w || refs[i].h != dst->h || refs[i].stride_y != dst->stride_y || refs[i].stride_c != dst->stride_c)
+            return ov_fail(ctx, OVHIP_EUNSUP, "ovhip_mc_launch: reference picture geometry differs from dst (RPR)", hipSuccess);
+        t.p[i] = refs[i];
+    }
     for (uint32_t i = n_refs; i < MC_MAX_REFS; ++i) t.p[i] = refs[0];
     static int cfg_xcd = -1;
     if (cfg_xcd < 0) { const char *x = getenv("OVHIP_MC_XCD"); cfg_xcd = x ? atoi(x) : 1; }   // experiment knob: XCD-aware unit order

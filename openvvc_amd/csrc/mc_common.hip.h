@@ -59,6 +59,36 @@ struct WinStage {
         }
     }
 
+    // The three pieces of issue() for callers that decide fast/slow once per unit (k_mc2).
+    static __device__ __forceinline__ bool interior(int sx0, int sy0, int ww, int wh, int rw, int rh)
+    {
+        const int ax = sx0 & ~3, nq = (sx0 - ax + ww + 3) >> 2;
+        return ax >= 0 && ax + 4 * nq <= rw && sy0 >= 0 && sy0 + wh <= rh;
+    }
+    __device__ __forceinline__ void issue_fast(const uint16_t *__restrict__ ref, int rstride, int sx0, int sy0, int ww, int wh, int lane)
+    {
+        const int ax = sx0 & ~3;
+        off = sx0 - ax; fast = true;
+        const int nq = (off + ww + 3) >> 2;
+        const int c = lane & (QW - 1), r0 = lane / QW;
+        const uint16_t *base = ref + (sy0 + r0) * rstride + ax + 4 * c;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k)
+            if (c < nq && (64 / QW) * k + r0 < wh) q[k] = *reinterpret_cast<const uint2 *>(base + (64 / QW) * k * rstride);
+    }
+    __device__ __forceinline__ void issue_slow(const uint16_t *__restrict__ ref, int rstride, int rw, int rh, int sx0, int sy0,
+                                               int ww, int wh, int lane, uint16_t *s_win, int wstride)
+    {
+        off = 0; fast = false;
+        const int c = lane & (COLS - 1), r0 = lane / COLS;
+        const int sx = ov_clip3(sx0 + c, 0, rw - 1);
+#pragma unroll 1
+        for (int k = 0; k < NITS; ++k) {
+            const int r = (64 / COLS) * k + r0;
+            if (c < ww && r < wh) s_win[r * wstride + c] = ref[ov_clip3(sy0 + r, 0, rh - 1) * rstride + sx];
+        }
+    }
+
     __device__ __forceinline__ void park(uint16_t *s_win, int wstride, int ww, int wh, int lane) const
     {
         if (fast) {
