@@ -150,57 +150,18 @@ __global__ __launch_bounds__(64) OV_OCC_MC void k_mc2(ovhip_pic dst, RefTable re
     const uint16_t *const ry[2]  = { refs.p[ri0].y,  refs.p[ri1].y };
     const uint16_t *const rcb[2] = { refs.p[ri0].cb, refs.p[ri1].cb };
     const uint16_t *const rcr[2] = { refs.p[ri0].cr, refs.p[ri1].cr };
-    const int pw = dst.w, phh = dst.h, pwc = dst.w >> 1, phc = dst.h >> 1;
     int lx[2], ly[2], cx[2], cy[2];
-    bool fast = !((dst.stride_y | dst.stride_c) & 3);
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
         const int mvx = l ? u.mv1x : u.mv0x, mvy = l ? u.mv1y : u.mv0y;
         lx[l] = u.x + (mvx >> 4) - 3;        ly[l] = u.y + (mvy >> 4) - 3;
         cx[l] = (u.x >> 1) + (mvx >> 5) - 1; cy[l] = (u.y >> 1) + (mvy >> 5) - 1;
-        if (!(u.dir & (1 << l))) continue;
-        if (do_l) fast = fast && LumaStage::interior(lx[l], ly[l], w + 7, h + 7, pw, phh);
-        if (do_c) fast = fast && ChromaStage::interior(cx[l], cy[l], wc + 3, hc + 3, pwc, phc);
     }
-    LumaStage sl[2];
-    ChromaStage sc[2][2];
-    if (fast) {
-#pragma unroll
-        for (int l = 0; l < 2; ++l) {
-            if (!(u.dir & (1 << l))) continue;
-            if (do_l) sl[l].issue_fast(ry[l], dst.stride_y, lx[l], ly[l], w + 7, h + 7, lane);
-            if (do_c) {
-                sc[0][l].issue_fast(rcb[l], dst.stride_c, cx[l], cy[l], wc + 3, hc + 3, lane);
-                sc[1][l].issue_fast(rcr[l], dst.stride_c, cx[l], cy[l], wc + 3, hc + 3, lane);
-            }
-        }
-    } else {
-        // rare (window crosses the picture border): clamped per-sample loads, parked at once
-#pragma unroll
-        for (int l = 0; l < 2; ++l) {
-            if (!(u.dir & (1 << l))) continue;
-            if (do_l) sl[l].issue_slow(ry[l], dst.stride_y, pw, phh, lx[l], ly[l], w + 7, h + 7, lane, s_wl + l * LUMA_WIN, WIN_STRIDE);
-            if (do_c) {
-                sc[0][l].issue_slow(rcb[l], dst.stride_c, pwc, phc, cx[l], cy[l], wc + 3, hc + 3, lane, s_wc + l * CHR_WIN, CWIN_STRIDE);
-                sc[1][l].issue_slow(rcr[l], dst.stride_c, pwc, phc, cx[l], cy[l], wc + 3, hc + 3, lane, s_wc + (2 + l) * CHR_WIN, CWIN_STRIDE);
-            }
-        }
-    }
-    int offl[2] = { 0, 0 }, offc[2][2] = { { 0, 0 }, { 0, 0 } };
-#ifdef OV_MC_PHASES
-    { const unsigned long long t_ = __builtin_readcyclecounter(); ph[1] = t_ - tprev; tprev = t_; }   // issue only, no wait
-#endif
-    if (fast) {
-#pragma unroll
-        for (int l = 0; l < 2; ++l) {
-            if (!(u.dir & (1 << l))) continue;
-            if (do_l) { sl[l].park(s_wl + l * LUMA_WIN, WIN_STRIDE, w + 7, h + 7, lane); offl[l] = sl[l].off; }
-            if (do_c) {
-                sc[0][l].park(s_wc + l * CHR_WIN, CWIN_STRIDE, wc + 3, hc + 3, lane);       offc[0][l] = sc[0][l].off;
-                sc[1][l].park(s_wc + (2 + l) * CHR_WIN, CWIN_STRIDE, wc + 3, hc + 3, lane); offc[1][l] = sc[1][l].off;
-            }
-        }
-    }
+    uint16_t *const lwin[2] = { s_wl, s_wl + LUMA_WIN };
+    uint16_t *const cwin[4] = { s_wc, s_wc + CHR_WIN, s_wc + 2 * CHR_WIN, s_wc + 3 * CHR_WIN };
+    int offl[2], offc1[2];
+    stage_unit_windows(dst, ry, rcb, rcr, lx, ly, cx, cy, w, h, u.dir, do_l, do_c, lane, lwin, WIN_STRIDE, cwin, CWIN_STRIDE, offl, offc1);
+    const int offc[2][2] = { { offc1[0], offc1[1] }, { offc1[0], offc1[1] } };
     // ---- filter taps of both lists (wave-uniform) ----
     int thl[2][4], tvl[2][4], thc[2][2], tvc[2][2];
     bool identl[2], identc[2];

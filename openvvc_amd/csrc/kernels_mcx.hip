@@ -140,32 +140,29 @@ __global__ __launch_bounds__(64) OV_OCC_MCX void k_mcx(ovhip_pic dst, RefTable r
     int mv[2][2] = { { u.mv0x, u.mv0y }, { u.mv1x, u.mv1y } };
     int ini[2][2] = { { u.mv0x, u.mv0y }, { u.mv1x, u.mv1y } };
 
-    // ---- 1. windows ----
-    LumaStage sl[2];
-    ChromaStage sc[2][2];
+    // ---- 1. windows (reference geometry = dst's, checked at launch) ----
     uint16_t *wl[2], *wcp[2][2];          // first window sample (row 0, col 0) of each staged window
+    int offl[2], offc[2];
+    {
+        const uint16_t *const ry[2]  = { refs.p[u.ref0].y,  refs.p[u.ref1].y };
+        const uint16_t *const rcb[2] = { refs.p[u.ref0].cb, refs.p[u.ref1].cb };
+        const uint16_t *const rcr[2] = { refs.p[u.ref0].cr, refs.p[u.ref1].cr };
+        int lx[2], ly[2], cx[2], cy[2];
 #pragma unroll
-    for (int l = 0; l < 2; ++l) {
-        const ovhip_pic &rp = refs.p[l ? u.ref1 : u.ref0];
-        int ax = mv[l][0], ay = mv[l][1];
-        if (dmvr) clip_mv_dev(u.x, u.y, rp.w, rp.h, w, h, ax, ay);
-        uint16_t *bl = s_wl[l] + 2 * XWIN_STRIDE + 4;
-        if (do_l) sl[l].issue(rp.y, rp.stride_y, rp.w, rp.h, u.x + (ax >> 4) - 3, u.y + (ay >> 4) - 3, w + 7, h + 7, lane, bl, XWIN_STRIDE);
-        if (do_c) {
-            const int px = (u.x >> 1) + (ax >> 5) - 1, py = (u.y >> 1) + (ay >> 5) - 1;
-            sc[0][l].issue(rp.cb, rp.stride_c, rp.w >> 1, rp.h >> 1, px, py, wc + 3, hc + 3, lane, s_wc[0][l] + 2 * XCWIN_STRIDE + 4, XCWIN_STRIDE);
-            sc[1][l].issue(rp.cr, rp.stride_c, rp.w >> 1, rp.h >> 1, px, py, wc + 3, hc + 3, lane, s_wc[1][l] + 2 * XCWIN_STRIDE + 4, XCWIN_STRIDE);
+        for (int l = 0; l < 2; ++l) {
+            int ax = mv[l][0], ay = mv[l][1];
+            if (dmvr) clip_mv_dev(u.x, u.y, dst.w, dst.h, w, h, ax, ay);
+            lx[l] = u.x + (ax >> 4) - 3;        ly[l] = u.y + (ay >> 4) - 3;
+            cx[l] = (u.x >> 1) + (ax >> 5) - 1; cy[l] = (u.y >> 1) + (ay >> 5) - 1;
         }
-    }
+        uint16_t *const lwin[2] = { s_wl[0] + 2 * XWIN_STRIDE + 4, s_wl[1] + 2 * XWIN_STRIDE + 4 };
+        uint16_t *const cwin[4] = { s_wc[0][0] + 2 * XCWIN_STRIDE + 4, s_wc[0][1] + 2 * XCWIN_STRIDE + 4,
+                                    s_wc[1][0] + 2 * XCWIN_STRIDE + 4, s_wc[1][1] + 2 * XCWIN_STRIDE + 4 };
+        stage_unit_windows(dst, ry, rcb, rcr, lx, ly, cx, cy, w, h, 3, do_l, do_c, lane, lwin, XWIN_STRIDE, cwin, XCWIN_STRIDE, offl, offc);
 #pragma unroll
-    for (int l = 0; l < 2; ++l) {
-        if (do_l) { sl[l].park(s_wl[l] + 2 * XWIN_STRIDE + 4, XWIN_STRIDE, w + 7, h + 7, lane); wl[l] = s_wl[l] + 2 * XWIN_STRIDE + 4 + sl[l].off; }
-        if (do_c) {
-#pragma unroll
-            for (int cc = 0; cc < 2; ++cc) {
-                sc[cc][l].park(s_wc[cc][l] + 2 * XCWIN_STRIDE + 4, XCWIN_STRIDE, wc + 3, hc + 3, lane);
-                wcp[cc][l] = s_wc[cc][l] + 2 * XCWIN_STRIDE + 4 + sc[cc][l].off;
-            }
+        for (int l = 0; l < 2; ++l) {
+            wl[l] = lwin[l] + offl[l];
+            wcp[0][l] = cwin[l] + offc[l]; wcp[1][l] = cwin[2 + l] + offc[l];
         }
     }
     __syncthreads();
@@ -284,7 +281,7 @@ __global__ __launch_bounds__(64) OV_OCC_MCX void k_mcx(ovhip_pic dst, RefTable r
 #pragma unroll
             for (int m = 0; m < 4; ++m) tp[m] = l ? thl[1][m] : thl[0][m];
             h_task<8>(s_wl[0] + l * (XWIN_ROWS * XWIN_STRIDE) + (2 + (l ? ldy[1] : ldy[0]) + r) * XWIN_STRIDE,
-                      4 + (l ? sl[1].off + ldx[1] : sl[0].off + ldx[0]), x0, tp, l ? identl[1] : identl[0],
+                      4 + (l ? offl[1] + ldx[1] : offl[0] + ldx[0]), x0, tp, l ? identl[1] : identl[0],
                       s_hl[0] + l * 16 * HT_STRIDE, HT_STRIDE, r, 4);
         }
     }
@@ -298,7 +295,7 @@ __global__ __launch_bounds__(64) OV_OCC_MCX void k_mcx(ovhip_pic dst, RefTable r
 #pragma unroll
             for (int m = 0; m < 2; ++m) tp[m] = thc[0][m] ^ ((thc[0][m] ^ thc[1][m]) & -l);   // arithmetic select: keeps the taps in registers
             h_task<4>(s_wc[0][0] + qi * (XCWIN_ROWS * XCWIN_STRIDE) + (2 + (l ? cdy[1] : cdy[0]) + r) * XCWIN_STRIDE,
-                      4 + (l ? sc[0][1].off + cdx[1] : sc[0][0].off + cdx[0]), x0, tp, l ? identc[1] : identc[0],
+                      4 + (l ? offc[1] + cdx[1] : offc[0] + cdx[0]), x0, tp, l ? identc[1] : identc[0],
                       s_hc[0][0] + qi * 8 * CHT_STRIDE, CHT_STRIDE, r, 4);
         }
     }
@@ -418,7 +415,11 @@ extern "C" int ovhip_mcx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhi
         return ov_fail(ctx, OVHIP_EINVAL, "ovhip_mcx_launch: bad reference table / units", hipSuccess);
     RefTable t;
     memset(&t, 0, sizeof(t));
-    for (uint32_t i = 0; i < n_refs; ++i) t.p[i] = refs[i];
+    for (uint32_t i = 0; i < n_refs; ++i) {
+        if (refs[i].w != dst->w || refs[i].h != dst->h || refs[i].stride_y != dst->stride_y || refs[i].stride_c != dst->stride_c)
+            return ov_fail(ctx, OVHIP_EUNSUP, "ovhip_mcx_launch: reference picture geometry differs from dst (RPR)", hipSuccess);
+        t.p[i] = refs[i];
+    }
     for (uint32_t i = n_refs; i < MC_MAX_REFS; ++i) t.p[i] = refs[0];
     hipLaunchKernelGGL(k_mcx, dim3(n_units), dim3(64), 0, ctx->stream, *dst, t, d_units, n_units, d_lmcs_fwd_lut, d_mv_out);
     OV_LAUNCH_CHECK(ctx, "k_mcx");
@@ -465,6 +466,21 @@ __device__ __forceinline__ int aff_stage(const uint16_t *__restrict__ ref, int r
 #pragma unroll
             for (int r = 0; r < ROWS; ++r) *reinterpret_cast<uint2 *>(win + r * 12 + 4 * c) = q[r];
         }
+    } else if (!((rstride | rw) & 3)) {
+        // border, aligned geometry: clamped rows, outside groups = replicated edge sample (see WinStage)
+        if (c < nq) {
+            const int qx = ax + 4 * c, side = qx < 0 ? -1 : qx >= rw ? 1 : 0;
+            const uint16_t *base = ref + ov_clip3(qx, 0, rw - 4);
+            uint2 q[ROWS];
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) q[r] = *reinterpret_cast<const uint2 *>(base + ov_clip3(sy0 + r, 0, rh - 1) * rstride);
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                uint2 v = q[r];
+                if (side) { const uint32_t e = (side < 0 ? v.x & 0xffffu : v.y >> 16) * 0x10001u; v.x = e; v.y = e; }
+                *reinterpret_cast<uint2 *>(win + r * 12 + 4 * c) = v;
+            }
+        }
     } else {
         off = 0;
         for (int i = c; i < COLS; i += 4) {
@@ -476,19 +492,82 @@ __device__ __forceinline__ int aff_stage(const uint16_t *__restrict__ ref, int r
     return off;
 }
 
+#ifdef OV_MCA_PHASES
+// Debug build only (-DOV_MCA_PHASES): per-unit shader-clock phase times of k_mca (tools/probe_mc_phases.py).
+#define OV_MCA_PHASE_UNITS 65536
+__device__ unsigned int g_mca_phase[OV_MCA_PHASE_UNITS * 8];
+#define OV_APHASE(i) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_readcyclecounter(); \
+                          ph[i] = (unsigned int)(t_ - tprev); tprev = t_; } while (0)
+#else
+#define OV_APHASE(i) do { } while (0)
+#endif
+
+// Luma window of one sub-block and list, split into issue (loads into registers) and park (registers -> LDS) so that
+// list 1's loads are in flight while list 0 is being filtered.  Geometry that is not a multiple of 4 samples is
+// fetched sample by sample with clamped coordinates at park time.
+struct AffLumaStage {
+    uint2 q[9];
+    const uint16_t *ref;
+    int sx0, sy0, off, side;
+    bool fast;
+
+    __device__ __forceinline__ void issue(const uint16_t *__restrict__ r, int rstride, int rw, int rh, int x0, int y0, int c)
+    {
+        ref = r; sx0 = x0; sy0 = y0;
+        const int ax = sx0 & ~3;
+        off = sx0 - ax;
+        const int nq = (off + 9 + 3) >> 2;
+        fast = !((rstride | rw) & 3);
+        if (fast && c < nq) {
+            // rows clamp per lane; an aligned group outside the picture = the edge sample replicated (see WinStage)
+            const int qx = ax + 4 * c;
+            side = qx < 0 ? -1 : qx >= rw ? 1 : 0;
+            const uint16_t *base = ref + ov_clip3(qx, 0, rw - 4);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) q[k] = *reinterpret_cast<const uint2 *>(base + ov_clip3(sy0 + k, 0, rh - 1) * rstride);
+        }
+    }
+    __device__ __forceinline__ int park(int rstride, int rw, int rh, int c, uint16_t *win)
+    {
+        if (fast) {
+            if (c < ((off + 9 + 3) >> 2)) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    uint2 v = q[k];
+                    if (side) { const uint32_t e = (side < 0 ? v.x & 0xffffu : v.y >> 16) * 0x10001u; v.x = e; v.y = e; }
+                    *reinterpret_cast<uint2 *>(win + k * AWS + 4 * c) = v;
+                }
+            }
+            return off;
+        }
+        for (int i = c; i < 9; i += 4) {
+            const int sx = ov_clip3(sx0 + i, 0, rw - 1);
+#pragma unroll 1
+            for (int k = 0; k < 9; ++k) win[k * AWS + i] = ref[ov_clip3(sy0 + k, 0, rh - 1) * rstride + sx];
+        }
+        return 0;
+    }
+};
+
 __global__ __launch_bounds__(64) void k_mca(ovhip_pic dst, RefTable refs, const ovhip_aff_unit *__restrict__ units,
                                              uint32_t n_units, const int32_t *__restrict__ side, const uint16_t *__restrict__ lmcs_fwd)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t s_win[2][16][9 * AWS];
-    __shared__ __attribute__((aligned(16))) int16_t  s_ht[2][16][4 * AHS];
-    __shared__ __attribute__((aligned(16))) int16_t  s_t[2][16][40];
+    // Luma tiles hold ONE list at a time (list 1 is filtered after list 0, its window waiting in registers): with both
+    // lists resident the 16 KB workgroup allowed 10 per CU and a 4K picture's affine units needed two rounds.
+    __shared__ __attribute__((aligned(16))) uint16_t s_win[16][9 * AWS];
+    __shared__ __attribute__((aligned(16))) int16_t  s_ht[16][4 * AHS];
+    __shared__ __attribute__((aligned(16))) int16_t  s_t[16][40];
     __shared__ __attribute__((aligned(16))) uint16_t s_cwin[2][8][7 * ACS];       // [list][comp * 4 + block]
     __shared__ __attribute__((aligned(16))) int16_t  s_cht[2][8][4 * ACHS];
 
     const int lane = threadIdx.x;
     for (uint32_t wg = blockIdx.x; wg < n_units; wg += gridDim.x) {
     const uint32_t bid = gridDim.x == n_units ? ov_xcd_slot(wg, n_units) : wg;      // XCD-aware order, see k_mc2
+#ifdef OV_MCA_PHASES
+    unsigned int ph[8] = {}; unsigned long long tprev = __builtin_readcyclecounter();
+#endif
     const ovhip_aff_unit u = units[bid];
+    OV_APHASE(0);
     const int nsx = u.w >> 2, nsb = nsx * (u.h >> 2), ncx = u.w >> 3, ncb = ncx * (u.h >> 3);
     const bool do_c = !(u.flags & OVHIP_AFF_NO_CHROMA);
     const int4 *mvs = reinterpret_cast<const int4 *>(side + u.side_off);
@@ -499,7 +578,6 @@ __global__ __launch_bounds__(64) void k_mca(ovhip_pic dst, RefTable refs, const 
     const int bx = u.x + 4 * (sb % nsx), by = u.y + 4 * (sb / nsx);
     int4 m = make_int4(0, 0, 0, 0);
     if (act) m = mvs[sb];
-    int off[2] = { 0, 0 };
     // ---- chroma lane state: list cl, window cw = comp * 4 + block, slice cc ----
     const int cl = lane >> 5, cwi = (lane >> 2) & 7, cblk = cwi & 3, ccomp = cwi >> 2, cc = lane & 3;
     const bool cact = do_c && cblk < ncb && (u.dir & (1 << cl));
@@ -508,13 +586,15 @@ __global__ __launch_bounds__(64) void k_mca(ovhip_pic dst, RefTable refs, const 
     const int cbx = (u.x >> 1) + 4 * (cblk % ncx), cby = (u.y >> 1) + 4 * (cblk / ncx);
     int coff = 0;
 
-    // ---- 1. windows ----
-#pragma unroll
-    for (int l = 0; l < 2; ++l) {
-        if (!(u.dir & (1 << l)) || !act) continue;
-        const ovhip_pic &rp = refs.p[l ? u.ref1 : u.ref0];
-        const int mvx = l ? m.z : m.x, mvy = l ? m.w : m.y;
-        off[l] = aff_stage<9, 9>(rp.y, rp.stride_y, rp.w, rp.h, bx + (mvx >> 4) - 2, by + (mvy >> 4) - 2, c, s_win[l][sb]);
+    OV_APHASE(1);
+
+    // ---- 1. windows: the first luma list into registers, chroma straight to LDS; PROF offsets prefetched ----
+    AffLumaStage st;
+    const int rsy = dst.stride_y, rpw = dst.w, rph = dst.h;               // reference geometry = dst's (checked at launch)
+    const int lfirst = (u.dir & 1) ? 0 : 1;
+    if (act) {
+        const int mvx = lfirst ? m.z : m.x, mvy = lfirst ? m.w : m.y;
+        st.issue(refs.p[lfirst ? u.ref1 : u.ref0].y, rsy, rpw, rph, bx + (mvx >> 4) - 2, by + (mvy >> 4) - 2, c);
     }
     if (cact) {
         const ovhip_pic &rp = refs.p[cl ? u.ref1 : u.ref0];
@@ -522,56 +602,69 @@ __global__ __launch_bounds__(64) void k_mca(ovhip_pic dst, RefTable refs, const 
         coff = aff_stage<7, 7>(ccomp ? rp.cr : rp.cb, rp.stride_c, rp.w >> 1, rp.h >> 1, cbx + (mvx >> 5) - 1, cby + (mvy >> 5) - 1, cc,
                                s_cwin[cl][cwi]);
     }
-    __syncthreads();
-
-    // ---- 2. horizontal passes: rows c, c+4, c+8 of the sub-block's window, 4 outputs each ----
+    bool prof[2];
+    int pdx[2][4], pdy[2][4];
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
-        if (!(u.dir & (1 << l)) || !act) continue;
-        const int mvx = l ? m.z : m.x;
-        int tp[3];
-        pack_taps<6>(ovt_mc_luma4[mvx & 15] + 1, tp);
-        for (int r = c; r < 9; r += 4) {
-            int d[5], out[4];
-            load_row_at<6>(s_win[l][sb] + r * AWS, off[l], d);
-            fir4<6>(d, tp, out);
+        prof[l] = act && (u.dir & (1 << l)) && (u.flags & OVHIP_AFF_PROF) && (u.dir != 3 || ((u.prof_dir >> l) & 1));
+        if (prof[l]) {
+            const int16_t *pt = reinterpret_cast<const int16_t *>(side + u.prof_off) + 32 * l;
 #pragma unroll
-            for (int o = 0; o < 4; ++o) s_ht[l][sb][o * AHS + r] = (int16_t)(out[o] >> (OV_BD - 8));
+            for (int j = 0; j < 4; ++j) { pdx[l][j] = pt[4 * j + c]; pdy[l][j] = pt[16 + 4 * j + c]; }
         }
     }
-    if (cact) {
-        const int mvx = cl ? cm.z : cm.x;
-        int tp[2];
-        pack_taps<4>(ovt_mc_chroma[mvx & 31], tp);
-        for (int r = cc; r < 7; r += 4) {
-            int d[4], out[4];
-            load_row_at<4>(s_cwin[cl][cwi] + r * ACS, coff, d);
-            fir4<4>(d, tp, out);
-#pragma unroll
-            for (int o = 0; o < 4; ++o) s_cht[cl][cwi][o * ACHS + r] = (int16_t)(out[o] >> (OV_BD - 8));
-        }
-    }
-    __syncthreads();
+    OV_APHASE(2);
 
-    // ---- 3. luma: vertical pass, PROF, combine ----
+    // ---- 2. luma, one list after the other: park, horizontal pass (rows c, c+4, c+8 of the sub-block's window,
+    //         4 outputs each), vertical pass, PROF.  The chroma horizontal pass rides along with list 0's. ----
     int P[2][4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
-    bool prof[2] = { false, false };
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
-        if (!(u.dir & (1 << l)) || !act) continue;
+        const bool on = (u.dir & (1 << l)) && act;
         const int mvx = l ? m.z : m.x, mvy = l ? m.w : m.y;
-        int tp[3], d[5];
-        pack_taps<6>(ovt_mc_luma4[mvy & 15] + 1, tp);
-        const int *q = reinterpret_cast<const int *>(s_ht[l][sb] + c * AHS);
+        int off = 0;
+        if (l) __syncthreads();                         // list 0's tiles are dead
+        if (on) off = st.park(rsy, rpw, rph, c, s_win[sb]);
+        if (l == 0 && u.dir == 3 && act)                // list 1's window flies while list 0 is filtered
+            st.issue(refs.p[u.ref1].y, rsy, rpw, rph, bx + (m.z >> 4) - 2, by + (m.w >> 4) - 2, c);
+        __syncthreads();
+        if (on) {
+            int tp[3];
+            pack_taps<6>(ovt_mc_luma4[mvx & 15] + 1, tp);
+            for (int r = c; r < 9; r += 4) {
+                int d[5], out[4];
+                load_row_at<6>(s_win[sb] + r * AWS, off, d);
+                fir4<6>(d, tp, out);
 #pragma unroll
-        for (int j = 0; j < 5; ++j) d[j] = q[j];
-        fir4<6>(d, tp, P[l]);
+                for (int o = 0; o < 4; ++o) s_ht[sb][o * AHS + r] = (int16_t)(out[o] >> (OV_BD - 8));
+            }
+        }
+        if (l == 0 && cact) {
+            const int cmvx = cl ? cm.z : cm.x;
+            int tp[2];
+            pack_taps<4>(ovt_mc_chroma[cmvx & 31], tp);
+            for (int r = cc; r < 7; r += 4) {
+                int d[4], out[4];
+                load_row_at<4>(s_cwin[cl][cwi] + r * ACS, coff, d);
+                fir4<4>(d, tp, out);
 #pragma unroll
-        for (int o = 0; o < 4; ++o) P[l][o] >>= 6;
-        prof[l] = (u.flags & OVHIP_AFF_PROF) && (u.dir != 3 || ((u.prof_dir >> l) & 1));
+                for (int o = 0; o < 4; ++o) s_cht[cl][cwi][o * ACHS + r] = (int16_t)(out[o] >> (OV_BD - 8));
+            }
+        }
+        __syncthreads();
+        if (on) {
+            int tp[3], d[5];
+            pack_taps<6>(ovt_mc_luma4[mvy & 15] + 1, tp);
+            const int *q = reinterpret_cast<const int *>(s_ht[sb] + c * AHS);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) d[j] = q[j];
+            fir4<6>(d, tp, P[l]);
+#pragma unroll
+            for (int o = 0; o < 4; ++o) P[l][o] >>= 6;
+        }
         if (prof[l]) {
             // 6x6 tile: interior = prediction column, ring = integer reference samples << 4 (5 ring samples per lane)
-            int16_t *t = s_t[l][sb];
+            int16_t *t = s_t[sb];
             const int ex = (mvx & 15) >> 3, ey = (mvy & 15) >> 3;
 #pragma unroll
             for (int j = 0; j < 4; ++j) t[(j + 1) * 6 + c + 1] = (int16_t)P[l][j];
@@ -583,25 +676,23 @@ __global__ __launch_bounds__(64) void k_mca(ovhip_pic dst, RefTable refs, const 
                 else if (e < 12) { i = e - 6; j = 5; }
                 else if (e < 16) { i = 0; j = e - 11; }
                 else             { i = 5; j = e - 15; }
-                t[j * 6 + i] = (int16_t)(s_win[l][sb][(j + 1 + ey) * AWS + off[l] + i + 1 + ex] << 4);
+                t[j * 6 + i] = (int16_t)(s_win[sb][(j + 1 + ey) * AWS + off + i + 1 + ex] << 4);
             }
         }
-    }
-    __syncthreads();
-    if (act) {
-        const int16_t *pt = reinterpret_cast<const int16_t *>(side + u.prof_off);
-#pragma unroll
-        for (int l = 0; l < 2; ++l) {
-            if (!prof[l]) continue;
-            const int16_t *t = s_t[l][sb];
+        __syncthreads();
+        if (prof[l]) {
+            const int16_t *t = s_t[sb];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int o = (j + 1) * 6 + c + 1;
                 const int gx = (t[o + 1] >> 6) - (t[o - 1] >> 6), gy = (t[o + 6] >> 6) - (t[o - 6] >> 6);
-                const int add = ov_clip3(pt[32 * l + 4 * j + c] * gx + pt[32 * l + 16 + 4 * j + c] * gy, -(1 << 13), (1 << 13) - 1);
+                const int add = ov_clip3(pdx[l][j] * gx + pdy[l][j] * gy, -(1 << 13), (1 << 13) - 1);
                 P[l][j] = (int)(int16_t)(P[l][j] + add);
             }
         }
+    }
+    OV_APHASE(4);
+    if (act) {
         const int dir = ((u.ident_l >> sb) & 1) ? 2 : u.dir;
         uint16_t *d = dst.y + by * dst.stride_y + bx + c;
 #pragma unroll
@@ -611,6 +702,7 @@ __global__ __launch_bounds__(64) void k_mca(ovhip_pic dst, RefTable refs, const 
             d[j * dst.stride_y] = (uint16_t)v;
         }
     }
+    OV_APHASE(5);
     // ---- 4. chroma: lanes 0..31 = (comp, block, column), both lists ----
     if (do_c && lane < 32 && cblk < ncb) {
         int Pc[2][4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
@@ -633,10 +725,25 @@ __global__ __launch_bounds__(64) void k_mca(ovhip_pic dst, RefTable refs, const 
         for (int j = 0; j < 4; ++j) d[j * dst.stride_c] = (uint16_t)aff_combine(dir, u.w0, u.w1, Pc[0][j], Pc[1][j]);
     }
     __syncthreads();
+#ifdef OV_MCA_PHASES
+    OV_APHASE(6);
+    if (lane == 0 && bid < OV_MCA_PHASE_UNITS) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) g_mca_phase[bid * 8 + i] = ph[i];
+        g_mca_phase[bid * 8 + 7] = 1;
+    }
+#endif
     }
 }
 
 } // namespace
+
+#ifdef OV_MCA_PHASES
+extern "C" int ovhip_debug_mca_phases(unsigned int *out /* [65536][8] */)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mca_phase), sizeof(unsigned int) * OV_MCA_PHASE_UNITS * 8) == hipSuccess ? OVHIP_OK : OVHIP_ELAUNCH;
+}
+#endif
 
 extern "C" int ovhip_mca_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs,
                                 const ovhip_aff_unit *d_units, uint32_t n_units, const int32_t *d_side,
@@ -648,7 +755,11 @@ extern "C" int ovhip_mca_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhi
         return ov_fail(ctx, OVHIP_EINVAL, "ovhip_mca_launch: bad reference table / units / side arena", hipSuccess);
     RefTable t;
     memset(&t, 0, sizeof(t));
-    for (uint32_t i = 0; i < n_refs; ++i) t.p[i] = refs[i];
+    for (uint32_t i = 0; i < n_refs; ++i) {
+        if (refs[i].w != dst->w || refs[i].h != dst->h || refs[i].stride_y != dst->stride_y || refs[i].stride_c != dst->stride_c)
+            return ov_fail(ctx, OVHIP_EUNSUP, "ovhip_mca_launch: reference picture geometry differs from dst (RPR)", hipSuccess);
+        t.p[i] = refs[i];
+    }
     for (uint32_t i = n_refs; i < MC_MAX_REFS; ++i) t.p[i] = refs[0];
     hipLaunchKernelGGL(k_mca, dim3(n_units), dim3(64), 0, ctx->stream, *dst, t, d_units, n_units, d_side, d_lmcs_fwd_lut);
     OV_LAUNCH_CHECK(ctx, "k_mca");

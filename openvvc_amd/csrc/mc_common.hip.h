@@ -20,46 +20,22 @@ typedef short short2v __attribute__((ext_vector_type(2)));
 #define HT_STRIDE 28    /* transposed H-pass tile: one COLUMN per row of HT_STRIDE int16 (h + 7 <= 23), 8-B aligned rows */
 #define CHT_STRIDE 12
 
-// ---- stage 1: reference window -> LDS.  Fast path (window inside the picture): every lane loads one
-// ALIGNED 8-byte group of 4 samples -- QW lanes per window row, 64/QW rows per instruction: 3
-// instructions for a 23x23 luma window, 1 for an 11x11 chroma window -- and parks it with one
-// ds_write_b64; the sub-group offset `off` (0..3 samples) is resolved by the horizontal pass.
-// Slow path (window crosses the picture border): per-sample loads with clamped coordinates
-// = emulate_block_border() (rcn_inter.c:148-225), parked at off = 0. ----
+// ---- stage 1: reference window -> LDS.  Every lane loads one ALIGNED 8-byte group of 4 samples -- QW lanes per
+// window row, 64/QW rows per instruction: 3 instructions for a 23x23 luma window, 1 for an 11x11 chroma window --
+// and parks it with one ds_write_b64; the sub-group offset `off` (0..3 samples) is resolved by the horizontal pass.
+// Three ways to fill the registers, all equal to emulate_block_border() (rcn_inter.c:148-225) where it applies:
+//   interior  window inside the picture: plain loads;
+//   clamped   window crosses a border of a picture whose width and stride are multiples of 4 samples (every VVC
+//             4:2:0 picture in buffers of this library): rows clamp per lane, and an aligned group lies either
+//             wholly inside or wholly outside the picture, so an outside group is the nearest inside group's edge
+//             sample replicated -- same loads as the interior path, no extra latency;
+//   slow      any other geometry: per-sample loads with clamped coordinates, parked at off = 0. ----
 template <int QW, int NIT, int COLS, int NITS>
 struct WinStage {
     uint2 q[NIT];
     bool fast;
-    int off;
+    int off, side;          // side: -1 / +1 = this lane's groups lie left / right of the picture
 
-    __device__ __forceinline__ void issue(const uint16_t *__restrict__ ref, int rstride, int rw, int rh, int sx0, int sy0,
-                                          int ww, int wh, int lane, uint16_t *s_win, int wstride)
-    {
-        const int ax = sx0 & ~3;
-        off = sx0 - ax;
-        const int nq = (off + ww + 3) >> 2;
-        fast = ax >= 0 && ax + 4 * nq <= rw && sy0 >= 0 && sy0 + wh <= rh && !(rstride & 3);
-        if (fast) {
-            const int c = lane & (QW - 1), r0 = lane / QW;
-#pragma unroll
-            for (int k = 0; k < NIT; ++k) {
-                const int r = (64 / QW) * k + r0;
-                if (c < nq && r < wh) q[k] = *reinterpret_cast<const uint2 *>(ref + (sy0 + r) * rstride + ax + 4 * c);
-            }
-        } else {
-            // rare: load + park immediately (keeps the register footprint of the fast path small)
-            off = 0;
-            const int c = lane & (COLS - 1), r0 = lane / COLS;
-            const int sx = ov_clip3(sx0 + c, 0, rw - 1);
-#pragma unroll 1
-            for (int k = 0; k < NITS; ++k) {
-                const int r = (64 / COLS) * k + r0;
-                if (c < ww && r < wh) s_win[r * wstride + c] = ref[ov_clip3(sy0 + r, 0, rh - 1) * rstride + sx];
-            }
-        }
-    }
-
-    // The three pieces of issue() for callers that decide fast/slow once per unit (k_mc2).
     static __device__ __forceinline__ bool interior(int sx0, int sy0, int ww, int wh, int rw, int rh)
     {
         const int ax = sx0 & ~3, nq = (sx0 - ax + ww + 3) >> 2;
@@ -68,7 +44,7 @@ struct WinStage {
     __device__ __forceinline__ void issue_fast(const uint16_t *__restrict__ ref, int rstride, int sx0, int sy0, int ww, int wh, int lane)
     {
         const int ax = sx0 & ~3;
-        off = sx0 - ax; fast = true;
+        off = sx0 - ax; fast = true; side = 0;
         const int nq = (off + ww + 3) >> 2;
         const int c = lane & (QW - 1), r0 = lane / QW;
         const uint16_t *base = ref + (sy0 + r0) * rstride + ax + 4 * c;
@@ -76,10 +52,26 @@ struct WinStage {
         for (int k = 0; k < NIT; ++k)
             if (c < nq && (64 / QW) * k + r0 < wh) q[k] = *reinterpret_cast<const uint2 *>(base + (64 / QW) * k * rstride);
     }
+    __device__ __forceinline__ void issue_clamped(const uint16_t *__restrict__ ref, int rstride, int rw, int rh, int sx0, int sy0,
+                                                  int ww, int wh, int lane)
+    {
+        const int ax = sx0 & ~3;
+        off = sx0 - ax; fast = true;
+        const int nq = (off + ww + 3) >> 2;
+        const int c = lane & (QW - 1), r0 = lane / QW;
+        const int qx = ax + 4 * c;
+        side = qx < 0 ? -1 : qx >= rw ? 1 : 0;
+        const uint16_t *base = ref + ov_clip3(qx, 0, rw - 4);
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int r = (64 / QW) * k + r0;
+            if (c < nq && r < wh) q[k] = *reinterpret_cast<const uint2 *>(base + ov_clip3(sy0 + r, 0, rh - 1) * rstride);
+        }
+    }
     __device__ __forceinline__ void issue_slow(const uint16_t *__restrict__ ref, int rstride, int rw, int rh, int sx0, int sy0,
                                                int ww, int wh, int lane, uint16_t *s_win, int wstride)
     {
-        off = 0; fast = false;
+        off = 0; fast = false; side = 0;
         const int c = lane & (COLS - 1), r0 = lane / COLS;
         const int sx = ov_clip3(sx0 + c, 0, rw - 1);
 #pragma unroll 1
@@ -88,7 +80,7 @@ struct WinStage {
             if (c < ww && r < wh) s_win[r * wstride + c] = ref[ov_clip3(sy0 + r, 0, rh - 1) * rstride + sx];
         }
     }
-
+    template <bool FIX = true>
     __device__ __forceinline__ void park(uint16_t *s_win, int wstride, int ww, int wh, int lane) const
     {
         if (fast) {
@@ -97,13 +89,90 @@ struct WinStage {
 #pragma unroll
             for (int k = 0; k < NIT; ++k) {
                 const int r = (64 / QW) * k + r0;
-                if (c < nq && r < wh) *reinterpret_cast<uint2 *>(s_win + r * wstride + 4 * c) = q[k];
+                if (c < nq && r < wh) {
+                    uint2 v = q[k];
+                    if (FIX && side) { const uint32_t e = (side < 0 ? v.x & 0xffffu : v.y >> 16) * 0x10001u; v.x = e; v.y = e; }
+                    *reinterpret_cast<uint2 *>(s_win + r * wstride + 4 * c) = v;
+                }
             }
         }
     }
 };
 typedef WinStage<8, 3, 32, 12> LumaStage;
 typedef WinStage<4, 1, 16, 3> ChromaStage;
+
+// All reference windows of one unit (<= 16x16 luma, both lists, Cb and Cr) -> LDS.  The path is chosen once per unit:
+// every window interior -> all loads issued, then all parked; a border unit goes list by list (rolled, so that the
+// rare path does not raise the kernel's register budget).  `geom` is the geometry shared by dst and every reference.
+// lwin[l] / cwin[plane * 2 + l] are the LDS windows; offl / offc receive the sub-group offsets.
+__device__ __forceinline__ void stage_unit_windows(const ovhip_pic &geom, const uint16_t *const ry[2], const uint16_t *const rcb[2],
+                                                   const uint16_t *const rcr[2], const int lx[2], const int ly[2],
+                                                   const int cx[2], const int cy[2], int w, int h, int dir, bool do_l, bool do_c,
+                                                   int lane, uint16_t *const lwin[2], int lstride, uint16_t *const cwin[4], int cstride,
+                                                   int offl[2], int offc[2])
+{
+    const int wc = w >> 1, hc = h >> 1, pw = geom.w, ph = geom.h, pwc = geom.w >> 1, phc = geom.h >> 1;
+    const bool aligned = !((geom.stride_y | geom.stride_c | pw | pwc) & 3);
+    bool fast = aligned;
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        if (!(dir & (1 << l))) continue;
+        if (do_l) fast = fast && LumaStage::interior(lx[l], ly[l], w + 7, h + 7, pw, ph);
+        if (do_c) fast = fast && ChromaStage::interior(cx[l], cy[l], wc + 3, hc + 3, pwc, phc);
+    }
+    offl[0] = offl[1] = offc[0] = offc[1] = 0;
+    if (fast) {
+        LumaStage sl[2];
+        ChromaStage sc[2][2];
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            if (!(dir & (1 << l))) continue;
+            if (do_l) sl[l].issue_fast(ry[l], geom.stride_y, lx[l], ly[l], w + 7, h + 7, lane);
+            if (do_c) {
+                sc[0][l].issue_fast(rcb[l], geom.stride_c, cx[l], cy[l], wc + 3, hc + 3, lane);
+                sc[1][l].issue_fast(rcr[l], geom.stride_c, cx[l], cy[l], wc + 3, hc + 3, lane);
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            if (!(dir & (1 << l))) continue;
+            if (do_l) { sl[l].park<false>(lwin[l], lstride, w + 7, h + 7, lane); offl[l] = sl[l].off; }
+            if (do_c) {
+                sc[0][l].park<false>(cwin[l], cstride, wc + 3, hc + 3, lane);
+                sc[1][l].park<false>(cwin[2 + l], cstride, wc + 3, hc + 3, lane);
+                offc[l] = sc[0][l].off;
+            }
+        }
+        return;
+    }
+#pragma unroll 1
+    for (int l = 0; l < 2; ++l) {
+        if (!(dir & (1 << l))) continue;
+        const uint16_t *y = l ? ry[1] : ry[0], *cb = l ? rcb[1] : rcb[0], *cr = l ? rcr[1] : rcr[0];
+        const int x0 = l ? lx[1] : lx[0], y0 = l ? ly[1] : ly[0], xc = l ? cx[1] : cx[0], yc = l ? cy[1] : cy[0];
+        uint16_t *wl = l ? lwin[1] : lwin[0], *wb = l ? cwin[1] : cwin[0], *wr = l ? cwin[3] : cwin[2];
+        LumaStage a;
+        ChromaStage b0, b1;
+        a.off = b0.off = 0;
+        if (aligned) {
+            if (do_l) a.issue_clamped(y, geom.stride_y, pw, ph, x0, y0, w + 7, h + 7, lane);
+            if (do_c) {
+                b0.issue_clamped(cb, geom.stride_c, pwc, phc, xc, yc, wc + 3, hc + 3, lane);
+                b1.issue_clamped(cr, geom.stride_c, pwc, phc, xc, yc, wc + 3, hc + 3, lane);
+            }
+            if (do_l) a.park<true>(wl, lstride, w + 7, h + 7, lane);
+            if (do_c) { b0.park<true>(wb, cstride, wc + 3, hc + 3, lane); b1.park<true>(wr, cstride, wc + 3, hc + 3, lane); }
+        } else {
+            if (do_l) a.issue_slow(y, geom.stride_y, pw, ph, x0, y0, w + 7, h + 7, lane, wl, lstride);
+            if (do_c) {
+                b0.issue_slow(cb, geom.stride_c, pwc, phc, xc, yc, wc + 3, hc + 3, lane, wb, cstride);
+                b1.issue_slow(cr, geom.stride_c, pwc, phc, xc, yc, wc + 3, hc + 3, lane, wr, cstride);
+            }
+        }
+        if (l) { offl[1] = do_l ? a.off : 0; offc[1] = do_c ? b0.off : 0; }
+        else   { offl[0] = do_l ? a.off : 0; offc[0] = do_c ? b0.off : 0; }
+    }
+}
 
 // ---- 4 outputs of an NT-tap FIR over a packed int16 row: out[o] = sum_k taps[k] * s[o + k].
 // d[j] = (s[2j], s[2j+1]); even outputs use the dwords as they are, odd outputs the dwords shifted by
