@@ -58,6 +58,7 @@ __device__ __forceinline__ int mc_combine(const ovhip_mc_unit &u, int p0, int p1
 // fused CIIP blend: (intra * wt + inter * (4 - wt) + 2) >> 2, put_weighted_ciip_pixels (rcn_mc.c:1611-1628)
 __device__ __forceinline__ int ciip_blend(int inter, int intra, int wt) { return ov_clip_bd((intra * wt + inter * (4 - wt) + 2) >> 2); }
 
+#define HLS 26   /* k_mc2's transposed luma H tile: odd dword stride (conflict-free columns), rows h + 7 <= 23 */
 template <int NOUT>
 __device__ __forceinline__ void luma_finish(const ovhip_mc_unit &u, const ovhip_pic &dst, const int16_t *s_hl, const int tv[2][4],
                                             int lane, int log2w, const uint16_t *__restrict__ lmcs_fwd, const ovhip_pic &intra)
@@ -70,7 +71,7 @@ __device__ __forceinline__ void luma_finish(const ovhip_mc_unit &u, const ovhip_
     for (int l = 0; l < 2; ++l) {
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) P[l][o] = 0;
-        if (u.dir & (1 << l)) v_outputs<8, NOUT>(s_hl + l * 16 * HT_STRIDE + x * HT_STRIDE, y0, tv[l], P[l]);
+        if (u.dir & (1 << l)) v_outputs<8, NOUT>(s_hl + l * 16 * HLS + x * HLS, y0, tv[l], P[l]);
     }
     uint16_t *d = dst.y + (u.y + y0) * dst.stride_y + u.x + x;
 #pragma unroll
@@ -122,13 +123,18 @@ __device__ unsigned int g_mc_phase[OV_MC_PHASE_UNITS * 8];
 __global__ __launch_bounds__(64) OV_OCC_MC void k_mc2(ovhip_pic dst, RefTable refs, const ovhip_mc_unit *__restrict__ units,
                                              uint32_t n_units, const uint16_t *__restrict__ lmcs_fwd, int xcd, ovhip_pic intra)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t s_wl[2 * LUMA_WIN + 8];       // luma windows, list 0 / 1 (+ dword over-read slack)
-    __shared__ __attribute__((aligned(16))) uint16_t s_wc[4 * CHR_WIN + 8];        // chroma windows [plane * 2 + list]
-    __shared__ __attribute__((aligned(16))) int16_t  s_hl[2 * 16 * HT_STRIDE + 8]; // transposed H-pass tiles [list]
-    // chroma H tiles [plane * 2 + list] reuse the luma windows, which are dead once the luma H pass has run: the
-    // workgroup then fits 6400 B of LDS, the step at which a CU holds 24 of these waves instead of 21 (measured)
-    int16_t *const s_hc = reinterpret_cast<int16_t *>(s_wl);
-    static_assert(4 * 8 * CHT_STRIDE + 8 <= 2 * LUMA_WIN + 8, "chroma H tiles must fit the luma windows");
+    // One LDS block of 5024 B -- under the 5120 B step at which a CU holds 32 of these single-wave workgroups (measured:
+    // 5632..6400 B -> 24, 6608 B -> 21):  [ luma windows, list 0 / 1 | chroma windows, later the luma H tiles | chroma H tiles ].
+    // The chroma H pass runs first so that the luma H tiles can take over the chroma windows.  Whole-dword over-reads
+    // past a region land in the next one (or the slack at the end) and are never used.
+    constexpr int HL_STRIDE = HLS;
+    constexpr int R2 = 2 * 16 * HL_STRIDE > 4 * CHR_WIN ? 2 * 16 * HL_STRIDE : 4 * CHR_WIN;
+    __shared__ __attribute__((aligned(16))) uint16_t s_all[2 * LUMA_WIN + R2 + 4 * 8 * CHT_STRIDE + 8];
+    uint16_t *const s_wl = s_all;                                                      // [list]
+    uint16_t *const s_wc = s_all + 2 * LUMA_WIN;                                       // [plane * 2 + list]
+    int16_t  *const s_hl = reinterpret_cast<int16_t *>(s_all + 2 * LUMA_WIN);          // [list], aliases s_wc
+    int16_t  *const s_hc = reinterpret_cast<int16_t *>(s_all + 2 * LUMA_WIN + R2);     // [plane * 2 + list]
+    static_assert(sizeof(s_all) <= 5120, "k_mc2 LDS block must stay under the 32-workgroups-per-CU step");
 
     const int lane = threadIdx.x;
     for (uint32_t wg = blockIdx.x; wg < n_units; wg += gridDim.x) {
@@ -182,21 +188,7 @@ __global__ __launch_bounds__(64) OV_OCC_MC void k_mc2(ovhip_pic dst, RefTable re
     __syncthreads();
     OV_PHASE(2);
 
-    // ---- horizontal passes: one task = one window row x 4 outputs ----
-    if (do_l) {
-        const int log2seg = log2w > 2 ? log2w - 2 : 0, nout = w < 4 ? w : 4;
-        const int TY = (h + 7) << log2seg;
-        for (int t = lane; t < nl * TY; t += 64) {
-            const int li = t >= TY, l = l0 + li, tt = t - li * TY;
-            const int r = tt >> log2seg, x0 = (tt & ((1 << log2seg) - 1)) << 2;
-            int tp[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) tp[m] = l ? thl[1][m] : thl[0][m];
-            h_task<8>(s_wl + l * LUMA_WIN + r * WIN_STRIDE, l ? offl[1] : offl[0], x0, tp, l ? identl[1] : identl[0],
-                      s_hl + l * 16 * HT_STRIDE, HT_STRIDE, r, nout);
-        }
-    }
-    __syncthreads();          // s_hc aliases s_wl
+    // ---- horizontal passes: one task = one window row x 4 outputs.  Chroma first (see the LDS layout) ----
     if (do_c) {
         const int log2seg = log2wc > 2 ? log2wc - 2 : 0, nout = wc < 4 ? wc : 4;
         const int TC = (hc + 3) << log2seg;
@@ -210,6 +202,20 @@ __global__ __launch_bounds__(64) OV_OCC_MC void k_mc2(ovhip_pic dst, RefTable re
             const int off = plane ? (l ? offc[1][1] : offc[1][0]) : (l ? offc[0][1] : offc[0][0]);
             h_task<4>(s_wc + (plane * 2 + l) * CHR_WIN + r * CWIN_STRIDE, off, x0, tp, l ? identc[1] : identc[0],
                       s_hc + (plane * 2 + l) * 8 * CHT_STRIDE, CHT_STRIDE, r, nout);
+        }
+    }
+    __syncthreads();          // the chroma windows are dead: s_hl takes their place
+    if (do_l) {
+        const int log2seg = log2w > 2 ? log2w - 2 : 0, nout = w < 4 ? w : 4;
+        const int TY = (h + 7) << log2seg;
+        for (int t = lane; t < nl * TY; t += 64) {
+            const int li = t >= TY, l = l0 + li, tt = t - li * TY;
+            const int r = tt >> log2seg, x0 = (tt & ((1 << log2seg) - 1)) << 2;
+            int tp[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) tp[m] = l ? thl[1][m] : thl[0][m];
+            h_task<8>(s_wl + l * LUMA_WIN + r * WIN_STRIDE, l ? offl[1] : offl[0], x0, tp, l ? identl[1] : identl[0],
+                      s_hl + l * 16 * HL_STRIDE, HL_STRIDE, r, nout);
         }
     }
     __syncthreads();
