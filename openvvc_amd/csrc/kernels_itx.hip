@@ -158,6 +158,20 @@ __device__ __forceinline__ void tr_pass_lds(const int16_t *src, int sstride, con
 // Two instantiations: <6, 256> any block up to 64x64, four waves per block (a 64x64 block is ~200k MACs: one
 // wave alone would be the tail of the launch); <4, 64> blocks up to 16x16, one wave and 1.5 KB of LDS per
 // block so that 32 blocks are resident per CU and hide each other's load latency.
+#ifdef OV_ITX_PHASES
+// Debug build only (-DOV_ITX_PHASES=64 or 256: which instantiation records): per-block shader-clock phase times of
+// k_itx (tools/probe_mc_phases.py).
+#define OV_ITX_PHASE_UNITS 65536
+__device__ unsigned int g_itx_phase[OV_ITX_PHASE_UNITS * 8];
+#define OV_IPHASE(i) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_readcyclecounter(); \
+                          ph[i] = (unsigned int)(t_ - tprev); tprev = t_; } while (0)
+#define OV_IPHASE_END() do { OV_IPHASE(4); if (NT == OV_ITX_PHASES && lane == 0 && bid < OV_ITX_PHASE_UNITS) { \
+        for (int i_ = 0; i_ < 5; ++i_) g_itx_phase[bid * 8 + i_] = ph[i_]; g_itx_phase[bid * 8 + 7] = 1; } } while (0)
+#else
+#define OV_IPHASE(i) do { } while (0)
+#define OV_IPHASE_END() do { } while (0)
+#endif
+
 template <int ML2, int NT>
 __global__ __launch_bounds__(NT) OV_OCC_ITX void k_itx(ovhip_pic pic, const ovhip_tb_cmd *__restrict__ cmds,
                                              uint32_t n_cmds, const int16_t *__restrict__ arena,
@@ -171,7 +185,11 @@ __global__ __launch_bounds__(NT) OV_OCC_ITX void k_itx(ovhip_pic pic, const ovhi
 
     const int lane = threadIdx.x;
     for (uint32_t bid = blockIdx.x; bid < n_cmds; bid += gridDim.x, __syncthreads()) {   // loop form for capped grids; launched with one workgroup per block
+#ifdef OV_ITX_PHASES
+    unsigned int ph[8] = {}; unsigned long long tprev = __builtin_readcyclecounter();
+#endif
     const ovhip_tb_cmd c = cmds[bid];
+    OV_IPHASE(0);
 
     const int log2_w = c.log2_w, log2_h = c.log2_h;
     const int tb_w = 1 << log2_w, tb_h = 1 << log2_h;
@@ -180,13 +198,29 @@ __global__ __launch_bounds__(NT) OV_OCC_ITX void k_itx(ovhip_pic pic, const ovhi
     const int cw = min(tb_w, 32), ch = min(tb_h, 32);
     const int16_t *src = arena + c.coef_off;
 
-    // ---- stage transform cores (only what this block needs) ----
+    // ---- K1 loads first: the lane's 4x4 sub-block of levels (HBM), then the transform cores (L2-resident tables,
+    //      only what this block needs), so that both round trips overlap ----
+    const int l2nx = max(min(log2_w, 5) - 2, 0), nx = 1 << l2nx, ny = ch >> 2;   // blocks narrower than 4 arrive in raster order
+    const int sx = lane & (nx - 1), sy = lane >> l2nx, bit = sy * 8 + sx;
+    const bool descan = !raster && !(ablate & 2) && cw >= 4 && lane < nx * ny;
+    const bool sig = descan && ((c.sig_sb_map >> bit) & 1);
+    int4 v0 = make_int4(0, 0, 0, 0), v1 = v0;
+    if (sig) {
+        const int rank = __popcll(c.sig_sb_map & ((1ull << bit) - 1));
+        const int4 *p = reinterpret_cast<const int4 *>(src + rank * 16);
+        v0 = p[0]; v1 = p[1];
+    }
     const int kv = min(tb_h, 32), kh = min(tb_w, 32);
     if (kind == OVHIP_TB_TR && !(ablate & 1)) {
-        const int8_t *mv = tr_matrix(c.tr_v, log2_h);
-        const int8_t *mh = tr_matrix(c.tr_h, log2_w);
-        for (int i = lane; i < (kv << log2_h); i += NT) s_mv[i] = mv[i];
-        for (int i = lane; i < (kh << log2_w); i += NT) s_mh[i] = mh[i];
+        // 16-byte copies (tables are 16-byte aligned and padded to 16 bytes); at most 2048 / 16 = 128 <= NT of them each
+        const uint4 *mv4 = reinterpret_cast<const uint4 *>(tr_matrix(c.tr_v, log2_h));
+        const uint4 *mh4 = reinterpret_cast<const uint4 *>(tr_matrix(c.tr_h, log2_w));
+        const int nv = ((kv << log2_h) + 15) >> 4, nh = ((kh << log2_w) + 15) >> 4;
+        uint4 a = make_uint4(0, 0, 0, 0), b = a;
+        if (lane < nv) a = mv4[lane];
+        if (lane < nh) b = mh4[lane];
+        if (lane < nv) reinterpret_cast<uint4 *>(s_mv)[lane] = a;
+        if (lane < nh) reinterpret_cast<uint4 *>(s_mh)[lane] = b;
     }
 
     // ---- K1: de-scan + de-quantise into LDS raster [ch][cw] ----
@@ -194,36 +228,26 @@ __global__ __launch_bounds__(NT) OV_OCC_ITX void k_itx(ovhip_pic pic, const ovhi
     } else if (raster) {
         for (int i = lane; i < tb_w * tb_h; i += NT)
             s_coef[i] = (kind == OVHIP_TB_TS_RAW || bdpcm) ? src[i] : (int16_t)dequant1(src[i], c.dq_scale, c.dq_shift, c.dq_neg);
-    } else {
-        const int nx = cw >> 2, ny = ch >> 2;
-        if (lane < nx * ny) {
-            const int sx = lane % nx, sy = lane / nx;
-            const int bit = sy * 8 + sx;
-            const uint64_t map = c.sig_sb_map;
-            int16_t *d = s_coef + (sy * 4) * cw + sx * 4;
-            if ((map >> bit) & 1) {
-                const int rank = __popcll(map & ((1ull << bit) - 1));
-                const int4 *p = reinterpret_cast<const int4 *>(src + rank * 16);
-                int4 v0 = p[0], v1 = p[1];
-                int w[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
+    } else if (descan) {
+        int16_t *d = s_coef + (sy * 4) * cw + sx * 4;
+        const int w[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };       // zeros for an empty sub-block
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < 4; ++r) {
+            int o[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        int word = w[r * 2 + (q >> 1)];
-                        int cv = (q & 1) ? (word >> 16) : (int)(int16_t)(word & 0xffff);
-                        d[r * cw + q] = bdpcm ? (int16_t)cv : (int16_t)dequant1(cv, c.dq_scale, c.dq_shift, c.dq_neg);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) d[r * cw + q] = 0;
+            for (int q = 0; q < 4; ++q) {
+                const int word = w[r * 2 + (q >> 1)];
+                const int cv = (q & 1) ? (word >> 16) : (int)(int16_t)(word & 0xffff);
+                o[q] = (bdpcm || !sig) ? cv : dequant1(cv, c.dq_scale, c.dq_shift, c.dq_neg);
             }
+            uint2 pk;
+            pk.x = (uint32_t)(o[0] & 0xffff) | ((uint32_t)o[1] << 16);
+            pk.y = (uint32_t)(o[2] & 0xffff) | ((uint32_t)o[3] << 16);
+            *reinterpret_cast<uint2 *>(d + r * cw) = pk;                            // cw and sx * 4 are multiples of 4: 8-byte aligned
         }
     }
     __syncthreads();
+    OV_IPHASE(1);
 
     ResidualSink sink;
     sink.dst = ov_plane(pic, c.plane, sink.stride) + c.y * sink.stride + c.x;
@@ -283,12 +307,17 @@ __global__ __launch_bounds__(NT) OV_OCC_ITX void k_itx(ovhip_pic pic, const ovhi
                                                tr_pass_lds<2, false, NT>(s_coef, cw, s_mv, log2_h, k1, nb_row, 7, s_tmp, lane, sink);
         else                                   tr_pass_lds<4, false, NT>(s_coef, cw, s_mv, log2_h, k1, nb_row, 7, s_tmp, lane, sink);
         __syncthreads();
+        OV_IPHASE(2);
         // ---- horizontal pass (shift 20 - bitdepth) fused with K4; tmp rows >= nb_row are zero ----
         const int k2 = min(nb_row, kh);
         if ((tb_h << log2_w) <= NT)            tr_pass_lds<1, true, NT>(s_tmp, tb_h, s_mh, log2_w, k2, tb_h, 20 - OV_BD, nullptr, lane, sink);
         else if ((tb_h & 3) || (tb_h << log2_w) <= 2 * NT)
                                                tr_pass_lds<2, true, NT>(s_tmp, tb_h, s_mh, log2_w, k2, tb_h, 20 - OV_BD, nullptr, lane, sink);
         else                                   tr_pass_lds<4, true, NT>(s_tmp, tb_h, s_mh, log2_w, k2, tb_h, 20 - OV_BD, nullptr, lane, sink);
+#ifdef OV_ITX_PHASES
+        { const unsigned long long t_ = __builtin_readcyclecounter(); ph[3] = (unsigned int)(t_ - tprev); tprev = t_; }
+#endif
+        OV_IPHASE_END();
         continue;
     }
 
@@ -337,10 +366,21 @@ __global__ __launch_bounds__(NT) OV_OCC_ITX void k_itx(ovhip_pic pic, const ovhi
             }
         }
     }
+#ifdef OV_ITX_PHASES
+    { const unsigned long long t_ = __builtin_readcyclecounter(); ph[3] = (unsigned int)(t_ - tprev); tprev = t_; }
+#endif
+    OV_IPHASE_END();
     }
 }
 
 } // namespace
+
+#ifdef OV_ITX_PHASES
+extern "C" int ovhip_debug_itx_phases(unsigned int *out /* [65536][8] */)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_itx_phase), sizeof(unsigned int) * OV_ITX_PHASE_UNITS * 8) == hipSuccess ? OVHIP_OK : OVHIP_ELAUNCH;
+}
+#endif
 
 static int itx_ablate()
 {

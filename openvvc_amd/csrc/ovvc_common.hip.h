@@ -17,6 +17,7 @@
 #define OV_MAX_LANES 4
 struct ovhip_ctx {
     int device;
+    int num_cus;                   // compute units of the device (sizes the resident grids of the pipelined kernels)
     hipStream_t stream;            // the stream launches go to: the main stream, or a side lane after ovhip_ctx_fork
     int owns_stream;
     hipStream_t main_stream;       // what the caller passed / what ctx_create made

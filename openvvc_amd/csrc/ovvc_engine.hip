@@ -18,6 +18,8 @@ int ovhip_ctx_create(ovhip_ctx **out, int device, void *stream)
     ovhip_ctx *ctx = (ovhip_ctx *)calloc(1, sizeof(*ctx));
     if (!ctx) return OVHIP_ENOMEM;
     ctx->device = device;
+    if (hipDeviceGetAttribute(&ctx->num_cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ctx->num_cus <= 0)
+        ctx->num_cus = 256;
     if (stream) {
         ctx->stream = (hipStream_t)stream;
     } else {
