@@ -1,12 +1,14 @@
 // kernels_itx.hip -- K1..K4 on gfx950: inverse quantisation, LFNST, separable inverse
 // transform (DCT-II 2..64, DST-VII / DCT-VIII 4..32), residual add (+JCCR, +LMCS chroma scale).
 //
-// One wavefront (= one 64-thread workgroup) per transform block.  The coefficient tile is
+// One workgroup per transform block (one wave up to 16x16, four above).  The coefficient tile is
 // de-scanned and de-quantised straight from the compact coefficient arena into LDS (one lane
 // per 4x4 sub-block, 32 contiguous bytes per lane -> coalesced), the two transform cores the
-// block needs are staged in LDS as int8, and both 1-D passes run out of LDS with 4-line
-// register blocking (one ds_read_b64 of 4 int16 feeds 4 MACs).  int16 x int8 -> int32 stencil
-// arithmetic on the VALU; no MFMA (exact clip16 rounding between the passes, K <= 32).
+// block needs are staged in LDS, and both 1-D passes run out of LDS.  Everything a pass multiplies
+// is laid out with the summation index k contiguous -- coefficient tile TRANSPOSED, cores as
+// int16 [output][k] -- so that one ds_read_b64 of each operand feeds two v_dot2_i32_i16 (4 MACs,
+// int32 wrap-around accumulation as in the reference).  No MFMA: exact clip16 rounding between
+// the passes, K <= 32.
 //
 // Replaces, per block, the reference call chain
 //   dequant_tb_4x4 -> [compute_lfnst_*] -> tr.func[v] -> tr.func[h] -> ict.add / ict.ict
@@ -31,25 +33,62 @@
 
 namespace {
 
-__device__ __forceinline__ const int8_t *tr_matrix(int type, int log2n)
+// ---- transform cores as the passes read them: int16, transposed, T[j * KS + k] = M[k * n + j] for the K = min(n, 32)
+// live input rows, zero up to the row length KS = max(K, 8).  Derived from the int8 tables at compile time. ----
+constexpr int core_ks(int log2n)   { const int n = 1 << log2n, K = n < 32 ? n : 32; return K < 8 ? 8 : K; }
+constexpr int core_size(int log2n) { return (1 << log2n) * core_ks(log2n); }
+constexpr int core_off(int type, int log2n)          // type: 0 DST-VII, 1 DCT-VIII (4..32), 2 DCT-II (2..64)
+{
+    int off = 0;
+    for (int t = 0; t < 3; ++t)
+        for (int l = (t == 2 ? 1 : 2); l <= (t == 2 ? 6 : 5); ++l) {
+            if (t == type && l == log2n) return off;
+            off += core_size(l);
+        }
+    return off;
+}
+constexpr int CORE_TOTAL = core_off(3, 0);
+struct CoreT16 { int16_t v[CORE_TOTAL]; };
+constexpr CoreT16 build_cores()
+{
+    CoreT16 t{};
+    const int8_t *const tabs[3][7] = {
+        { nullptr, nullptr, ovt_dst7_4, ovt_dst7_8, ovt_dst7_16, ovt_dst7_32, nullptr },
+        { nullptr, nullptr, ovt_dct8_4, ovt_dct8_8, ovt_dct8_16, ovt_dct8_32, nullptr },
+        { nullptr, ovt_dct2_2, ovt_dct2_4, ovt_dct2_8, ovt_dct2_16, ovt_dct2_32, ovt_dct2_64 } };
+    for (int ty = 0; ty < 3; ++ty)
+        for (int l = 1; l <= 6; ++l) {
+            if (!tabs[ty][l]) continue;
+            const int n = 1 << l, K = n < 32 ? n : 32, KS = core_ks(l), off = core_off(ty, l);
+            for (int j = 0; j < n; ++j)
+                for (int k = 0; k < K; ++k) t.v[off + j * KS + k] = tabs[ty][l][k * n + j];
+        }
+    return t;
+}
+__device__ const CoreT16 __attribute__((aligned(16))) g_cores = build_cores();
+
+__device__ __forceinline__ const int16_t *tr_core(int type, int log2n)
 {
     switch (type * 8 + log2n) {
-    case 0 * 8 + 2: return ovt_dst7_4;
-    case 0 * 8 + 3: return ovt_dst7_8;
-    case 0 * 8 + 4: return ovt_dst7_16;
-    case 0 * 8 + 5: return ovt_dst7_32;
-    case 1 * 8 + 2: return ovt_dct8_4;
-    case 1 * 8 + 3: return ovt_dct8_8;
-    case 1 * 8 + 4: return ovt_dct8_16;
-    case 1 * 8 + 5: return ovt_dct8_32;
-    case 2 * 8 + 1: return ovt_dct2_2;
-    case 2 * 8 + 2: return ovt_dct2_4;
-    case 2 * 8 + 3: return ovt_dct2_8;
-    case 2 * 8 + 4: return ovt_dct2_16;
-    case 2 * 8 + 5: return ovt_dct2_32;
-    default:        return ovt_dct2_64;
+    case 0 * 8 + 2: return g_cores.v + core_off(0, 2);
+    case 0 * 8 + 3: return g_cores.v + core_off(0, 3);
+    case 0 * 8 + 4: return g_cores.v + core_off(0, 4);
+    case 0 * 8 + 5: return g_cores.v + core_off(0, 5);
+    case 1 * 8 + 2: return g_cores.v + core_off(1, 2);
+    case 1 * 8 + 3: return g_cores.v + core_off(1, 3);
+    case 1 * 8 + 4: return g_cores.v + core_off(1, 4);
+    case 1 * 8 + 5: return g_cores.v + core_off(1, 5);
+    case 2 * 8 + 1: return g_cores.v + core_off(2, 1);
+    case 2 * 8 + 2: return g_cores.v + core_off(2, 2);
+    case 2 * 8 + 3: return g_cores.v + core_off(2, 3);
+    case 2 * 8 + 4: return g_cores.v + core_off(2, 4);
+    case 2 * 8 + 5: return g_cores.v + core_off(2, 5);
+    default:        return g_cores.v + core_off(2, 6);
     }
 }
+// LDS row length of a k-contiguous tile whose rows hold K values: the padding keeps the ds_read_b64 of 16 rows apart
+__device__ __forceinline__ int tile_stride(int K) { return K < 8 ? 8 : K + (K >= 16 ? 4 : 0); }
+constexpr int tile_stride_c(int K) { return K < 8 ? 8 : K + (K >= 16 ? 4 : 0); }
 
 __device__ __forceinline__ int dequant1(int c, int scale, int shift, int neg)
 {
@@ -90,67 +129,48 @@ __device__ __forceinline__ int residual1(int pix, int r, int mode, int scale)
     return ov_clip_bd(pix + v);
 }
 
-// One 1-D pass out of LDS:  out[i][j] = clip16((sum_k src[k*sstride + i] * M[k*N + j] + rnd) >> shift)
-// for i < lines (lines % IB == 0), j < N, k < kmax.  Lane owns column j and IB consecutive lines
-// (one ds_read_b64 / b32 of IB int16 feeds IB MACs).  FINAL = false: store int16 to dst[i*N + j]
-// (pass 1).  FINAL = true: fuse K4, the residual add into the frame (pass 2; lanes j -> contiguous
-// frame addresses).
 struct ResidualSink {
     uint16_t *dst; int stride; int mode;
     uint16_t *dst2; int stride2; int mode2;
     int scale;
 };
+typedef short short2v __attribute__((ext_vector_type(2)));
 
-template <int IB, bool FINAL, int NT>
-__device__ __forceinline__ void tr_pass_lds(const int16_t *src, int sstride, const int8_t *mat, int log2n,
-                                             int kmax, int lines, int shift, int16_t *dst, int lane,
+// One 1-D pass out of LDS:  out[i][j] = clip16((sum_{k < kmax} src[i * sstride + k] * core[j * cstride + k] + rnd) >> shift)
+// for i < lines, j < n; both operands are k-contiguous (kmax is rounded up to 4: the operands are zero there).
+// Lane = one output.  FINAL = false: store int16 to dst[j * dstride + i] (pass 1: the transposed tile pass 2
+// reads).  FINAL = true: fuse K4, the residual add into the frame (pass 2: lanes j -> contiguous frame addresses).
+template <bool FINAL, int NT>
+__device__ __forceinline__ void tr_pass_lds(const int16_t *src, int sstride, const int16_t *core, int cstride, int log2n,
+                                             int kmax, int lines, int shift, int16_t *dst, int dstride, int lane,
                                              const ResidualSink &sink)
 {
     const int n = 1 << log2n;
-    const int ntask = (lines / IB) << log2n;
+    const int ntask = lines << log2n;
     const int rnd = 1 << (shift - 1);
+    const int nk4 = (kmax + 3) >> 2;
     for (int t = lane; t < ntask; t += NT) {
-        const int j = t & (n - 1);
-        const int i0 = (t >> log2n) * IB;
-        int acc[IB];
-        int old[IB], old2[IB];
-#pragma unroll
-        for (int q = 0; q < IB; ++q) acc[q] = 0;
+        const int j = t & (n - 1), i = t >> log2n;
+        int old = 0, old2 = 0;
         if (FINAL) {
-            // issue the frame reads of the read-modify-write BEFORE the MAC loop: independent loads in
-            // flight under the arithmetic instead of IB serialised load->store round trips at the end
-#pragma unroll
-            for (int q = 0; q < IB; ++q) {
-                old[q] = sink.dst[(i0 + q) * sink.stride + j];
-                old2[q] = sink.dst2 ? (int)sink.dst2[(i0 + q) * sink.stride2 + j] : 0;
-            }
+            // the frame reads of the read-modify-write go out BEFORE the MAC loop
+            old = sink.dst[i * sink.stride + j];
+            if (sink.dst2) old2 = sink.dst2[i * sink.stride2 + j];
         }
-        for (int k = 0; k < kmax; ++k) {
-            const int m = mat[(k << log2n) + j];
-            const int16_t *s = src + k * sstride + i0;
-            if (IB == 4) {
-                const int2 v = *reinterpret_cast<const int2 *>(s);
-                acc[0] += m * (int)(int16_t)(v.x & 0xffff);
-                acc[1] += m * (v.x >> 16);
-                acc[2] += m * (int)(int16_t)(v.y & 0xffff);
-                acc[3] += m * (v.y >> 16);
-            } else if (IB == 2) {
-                const int v = *reinterpret_cast<const int *>(s);
-                acc[0] += m * (int)(int16_t)(v & 0xffff);
-                acc[1] += m * (v >> 16);
-            } else {
-                acc[0] += m * (int)s[0];
-            }
+        const int2 *sp = reinterpret_cast<const int2 *>(src + i * sstride);
+        const int2 *cp = reinterpret_cast<const int2 *>(core + j * cstride);
+        int acc = 0;
+        for (int k4 = 0; k4 < nk4; ++k4) {
+            const int2 a = sp[k4], m = cp[k4];
+            acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a.x), __builtin_bit_cast(short2v, m.x), acc, false);
+            acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a.y), __builtin_bit_cast(short2v, m.y), acc, false);
         }
-#pragma unroll
-        for (int q = 0; q < IB; ++q) {
-            const int r = ov_clip16((acc[q] + rnd) >> shift);
-            if (!FINAL) {
-                dst[((i0 + q) << log2n) + j] = (int16_t)r;
-            } else {
-                sink.dst[(i0 + q) * sink.stride + j] = (uint16_t)residual1(old[q], r, sink.mode, sink.scale);
-                if (sink.dst2) sink.dst2[(i0 + q) * sink.stride2 + j] = (uint16_t)residual1(old2[q], r, sink.mode2, sink.scale);
-            }
+        const int r = ov_clip16((acc + rnd) >> shift);
+        if (!FINAL) {
+            dst[j * dstride + i] = (int16_t)r;
+        } else {
+            sink.dst[i * sink.stride + j] = (uint16_t)residual1(old, r, sink.mode, sink.scale);
+            if (sink.dst2) sink.dst2[i * sink.stride2 + j] = (uint16_t)residual1(old2, r, sink.mode2, sink.scale);
         }
     }
 }
@@ -178,10 +198,12 @@ __global__ __launch_bounds__(NT) OV_OCC_ITX void k_itx(ovhip_pic pic, const ovhi
                                              const int16_t *__restrict__ lmcs_scales, int ablate)
 {
     constexpr int MC = ML2 > 5 ? 32 : (1 << ML2);                      // stored coefficient extent per dimension
-    __shared__ __attribute__((aligned(16))) int16_t s_coef[MC * MC];
-    __shared__ __attribute__((aligned(16))) int16_t s_tmp[MC << ML2];
-    __shared__ __attribute__((aligned(16))) int8_t s_mv[MC << ML2];
-    __shared__ __attribute__((aligned(16))) int8_t s_mh[MC << ML2];
+    constexpr int MS = tile_stride_c(MC);                              // longest k-contiguous row
+    // s_coef: transform blocks [column][row] (stride tile_stride(ch)), everything else raster [row][column] (stride tb_w)
+    __shared__ __attribute__((aligned(16))) int16_t s_coef[MC * MS];
+    __shared__ __attribute__((aligned(16))) int16_t s_tmp[(1 << ML2) * MS];     // pass 1 -> pass 2: [row][column k]
+    __shared__ __attribute__((aligned(16))) int16_t s_mv[(1 << ML2) * MS];      // cores [output][k]
+    __shared__ __attribute__((aligned(16))) int16_t s_mh[(1 << ML2) * MS];
 
     const int lane = threadIdx.x;
     for (uint32_t bid = blockIdx.x; bid < n_cmds; bid += gridDim.x, __syncthreads()) {   // loop form for capped grids; launched with one workgroup per block
@@ -211,39 +233,66 @@ __global__ __launch_bounds__(NT) OV_OCC_ITX void k_itx(ovhip_pic pic, const ovhi
         v0 = p[0]; v1 = p[1];
     }
     const int kv = min(tb_h, 32), kh = min(tb_w, 32);
-    if (kind == OVHIP_TB_TR && !(ablate & 1)) {
-        // 16-byte copies (tables are 16-byte aligned and padded to 16 bytes); at most 2048 / 16 = 128 <= NT of them each
-        const uint4 *mv4 = reinterpret_cast<const uint4 *>(tr_matrix(c.tr_v, log2_h));
-        const uint4 *mh4 = reinterpret_cast<const uint4 *>(tr_matrix(c.tr_h, log2_w));
-        const int nv = ((kv << log2_h) + 15) >> 4, nh = ((kh << log2_w) + 15) >> 4;
+    const bool is_tr = kind == OVHIP_TB_TR;
+    const int cs = tile_stride(ch);                       // s_coef row length of a transform block
+    const int msv = tile_stride(kv), msh = tile_stride(kh);
+    if (is_tr && !(ablate & 1)) {
+        // 16-byte chunks (8 values of one core row): at most 64 * 32 / 8 = 256 <= NT per core for <6, 256>, 32 for <4, 64>
+        const int l2cv = kv >= 32 ? 2 : kv >= 16 ? 1 : 0, l2ch = kh >= 32 ? 2 : kh >= 16 ? 1 : 0;   // chunks per row
+        const int nv = tb_h << l2cv, nh = tb_w << l2ch;
+        const uint4 *mv4 = reinterpret_cast<const uint4 *>(tr_core(c.tr_v, log2_h));
+        const uint4 *mh4 = reinterpret_cast<const uint4 *>(tr_core(c.tr_h, log2_w));
         uint4 a = make_uint4(0, 0, 0, 0), b = a;
         if (lane < nv) a = mv4[lane];
         if (lane < nh) b = mh4[lane];
-        if (lane < nv) reinterpret_cast<uint4 *>(s_mv)[lane] = a;
-        if (lane < nh) reinterpret_cast<uint4 *>(s_mh)[lane] = b;
+        if (lane < nv) {
+            uint2 *d = reinterpret_cast<uint2 *>(s_mv + (lane >> l2cv) * msv + ((lane & ((1 << l2cv) - 1)) << 3));
+            d[0] = make_uint2(a.x, a.y); d[1] = make_uint2(a.z, a.w);
+        }
+        if (lane < nh) {
+            uint2 *d = reinterpret_cast<uint2 *>(s_mh + (lane >> l2ch) * msh + ((lane & ((1 << l2ch) - 1)) << 3));
+            d[0] = make_uint2(b.x, b.y); d[1] = make_uint2(b.z, b.w);
+        }
     }
 
     // ---- K1: de-scan + de-quantise into LDS raster [ch][cw] ----
     if (ablate & 2) {
     } else if (raster) {
-        for (int i = lane; i < tb_w * tb_h; i += NT)
-            s_coef[i] = (kind == OVHIP_TB_TS_RAW || bdpcm) ? src[i] : (int16_t)dequant1(src[i], c.dq_scale, c.dq_shift, c.dq_neg);
+        if (is_tr) {
+            // (blocks narrower than 4): transposed, rows padded with zeros to the 4 values a pass step reads
+            for (int i = lane; i < tb_w * tb_h; i += NT) {
+                const int x = i & (tb_w - 1), y = i >> log2_w;
+                s_coef[x * cs + y] = (int16_t)dequant1(src[i], c.dq_scale, c.dq_shift, c.dq_neg);
+                if (tb_h < 4 && y == 0) { s_coef[x * cs + 2] = 0; s_coef[x * cs + 3] = 0; }
+            }
+        } else {
+            for (int i = lane; i < tb_w * tb_h; i += NT)
+                s_coef[i] = (kind == OVHIP_TB_TS_RAW || bdpcm) ? src[i] : (int16_t)dequant1(src[i], c.dq_scale, c.dq_shift, c.dq_neg);
+        }
     } else if (descan) {
-        int16_t *d = s_coef + (sy * 4) * cw + sx * 4;
         const int w[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };       // zeros for an empty sub-block
+        int o[4][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int o[4];
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int word = w[r * 2 + (q >> 1)];
                 const int cv = (q & 1) ? (word >> 16) : (int)(int16_t)(word & 0xffff);
-                o[q] = (bdpcm || !sig) ? cv : dequant1(cv, c.dq_scale, c.dq_shift, c.dq_neg);
+                o[r][q] = (bdpcm || !sig) ? cv : dequant1(cv, c.dq_scale, c.dq_shift, c.dq_neg);
             }
+        // one 8-byte store per row (raster) or per column (transform blocks: transposed tile); all 8-byte aligned
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
             uint2 pk;
-            pk.x = (uint32_t)(o[0] & 0xffff) | ((uint32_t)o[1] << 16);
-            pk.y = (uint32_t)(o[2] & 0xffff) | ((uint32_t)o[3] << 16);
-            *reinterpret_cast<uint2 *>(d + r * cw) = pk;                            // cw and sx * 4 are multiples of 4: 8-byte aligned
+            if (is_tr) {
+                pk.x = (uint32_t)(o[0][a] & 0xffff) | ((uint32_t)o[1][a] << 16);
+                pk.y = (uint32_t)(o[2][a] & 0xffff) | ((uint32_t)o[3][a] << 16);
+                *reinterpret_cast<uint2 *>(s_coef + (sx * 4 + a) * cs + sy * 4) = pk;
+            } else {
+                pk.x = (uint32_t)(o[a][0] & 0xffff) | ((uint32_t)o[a][1] << 16);
+                pk.y = (uint32_t)(o[a][2] & 0xffff) | ((uint32_t)o[a][3] << 16);
+                *reinterpret_cast<uint2 *>(s_coef + (sy * 4 + a) * cw + sx * 4) = pk;
+            }
         }
     }
     __syncthreads();
@@ -281,7 +330,7 @@ __global__ __launch_bounds__(NT) OV_OCC_ITX void k_itx(ovhip_pic pic, const ovhi
                 int s = 0;
                 for (int j = 0; j < nin; ++j) {
                     const int pos = (int)((scan >> (4 * j)) & 0xf);
-                    s += (int)s_coef[(pos >> 2) * cw + (pos & 3)] * (int)m[lane + j * nout];
+                    s += (int)s_coef[(pos & 3) * cs + (pos >> 2)] * (int)m[lane + j * nout];
                 }
                 out = ov_clip3((s + 64) >> 7, -(1 << 15), 1 << 15);
             }
@@ -292,7 +341,7 @@ __global__ __launch_bounds__(NT) OV_OCC_ITX void k_itx(ovhip_pic pic, const ovhi
                 else if (lane < 32) { r = lane >> 3; q = lane & 7; }
                 else                { r = 4 + ((lane - 32) >> 2); q = lane & 3; }
                 if (tr) { int t = r; r = q; q = t; }
-                s_coef[r * cw + q] = (int16_t)out;
+                s_coef[q * cs + r] = (int16_t)out;
             }
             nb_row = 4 << (int)is8;               // rcn_transform_tree.c:474-475
             nb_col = max(nb_col, nb_row);
@@ -300,20 +349,16 @@ __global__ __launch_bounds__(NT) OV_OCC_ITX void k_itx(ovhip_pic pic, const ovhi
         }
         nb_row = min(nb_row, tb_w);
         const int k1 = min(nb_col, kv);
-        // ---- K3: vertical pass (shift 7): tmp[i*tb_h + j], i = coefficient column < nb_row ----
-        // lines per task: as many as keeps every lane busy (these blocks are latency-bound, not ALU-bound)
-        if ((nb_row << log2_h) <= NT)          tr_pass_lds<1, false, NT>(s_coef, cw, s_mv, log2_h, k1, nb_row, 7, s_tmp, lane, sink);
-        else if ((nb_row & 3) || (nb_row << log2_h) <= 2 * NT)
-                                               tr_pass_lds<2, false, NT>(s_coef, cw, s_mv, log2_h, k1, nb_row, 7, s_tmp, lane, sink);
-        else                                   tr_pass_lds<4, false, NT>(s_coef, cw, s_mv, log2_h, k1, nb_row, 7, s_tmp, lane, sink);
+        // ---- K3: vertical pass (shift 7) of the coefficient columns i < nb_row:  tmp[row j][i] ----
+        const int ts = tile_stride(kh);
+        if ((nb_row & 3) && lane < tb_h)                     // pass 2 reads 4 values per step: zero the tail of a short row
+            for (int e = nb_row; e < ((nb_row + 3) & ~3); ++e) s_tmp[lane * ts + e] = 0;
+        tr_pass_lds<false, NT>(s_coef, cs, s_mv, msv, log2_h, k1, nb_row, 7, s_tmp, ts, lane, sink);
         __syncthreads();
         OV_IPHASE(2);
-        // ---- horizontal pass (shift 20 - bitdepth) fused with K4; tmp rows >= nb_row are zero ----
+        // ---- horizontal pass (shift 20 - bitdepth) fused with K4; columns >= nb_row of tmp are zero: not read ----
         const int k2 = min(nb_row, kh);
-        if ((tb_h << log2_w) <= NT)            tr_pass_lds<1, true, NT>(s_tmp, tb_h, s_mh, log2_w, k2, tb_h, 20 - OV_BD, nullptr, lane, sink);
-        else if ((tb_h & 3) || (tb_h << log2_w) <= 2 * NT)
-                                               tr_pass_lds<2, true, NT>(s_tmp, tb_h, s_mh, log2_w, k2, tb_h, 20 - OV_BD, nullptr, lane, sink);
-        else                                   tr_pass_lds<4, true, NT>(s_tmp, tb_h, s_mh, log2_w, k2, tb_h, 20 - OV_BD, nullptr, lane, sink);
+        tr_pass_lds<true, NT>(s_tmp, ts, s_mh, msh, log2_w, k2, tb_h, 20 - OV_BD, nullptr, 0, lane, sink);
 #ifdef OV_ITX_PHASES
         { const unsigned long long t_ = __builtin_readcyclecounter(); ph[3] = (unsigned int)(t_ - tprev); tprev = t_; }
 #endif
