@@ -73,12 +73,11 @@ __device__ __forceinline__ bool strong_small(const int *s, int beta, int tc)
     return ((abs(P(3) - P(0)) + abs(Q(3) - Q(0))) < (beta >> 3)) && (abs(P(0) - Q(0)) < ((tc * 5 + 1) >> 1));
 }
 
-__device__ __forceinline__ void long_line(uint16_t *pix, int step, int tc, int lp, int lq)
+// the three line filters work on a line already in registers (s) and store only the samples they modify
+__device__ __forceinline__ void long_regs(const int *s, uint16_t *pix, int step, int tc, int lp, int lq)
 {
     const int f7[7] = { 59, 50, 41, 32, 23, 14, 5 }, f5[5] = { 58, 45, 32, 19, 6 }, f3[3] = { 53, 32, 11 };
     const int t7[7] = { 6, 5, 4, 3, 2, 1, 1 }, t3[3] = { 6, 4, 2 };
-    int s[16];
-    load_line<8, 8>(pix, step, s);
     const int ref_p = (P(lp - 1) + P(lp) + 1) >> 1, ref_q = (Q(lq - 1) + Q(lq) + 1) >> 1;
     int mid;
     if (lp == lq && lp == 7)
@@ -108,10 +107,15 @@ __device__ __forceinline__ void long_line(uint16_t *pix, int step, int tc, int l
     }
 }
 
-__device__ __forceinline__ void strong_line(uint16_t *pix, int step, int tc)
+__device__ __forceinline__ void long_line(uint16_t *pix, int step, int tc, int lp, int lq)
 {
     int s[16];
-    load_line<4, 4>(pix, step, s);
+    load_line<8, 8>(pix, step, s);
+    long_regs(s, pix, step, tc, lp, lq);
+}
+
+__device__ __forceinline__ void strong_regs(const int *s, uint16_t *pix, int step, int tc)
+{
     const int p3 = P(3), p2 = P(2), p1 = P(1), p0 = P(0), q0 = Q(0), q1 = Q(1), q2 = Q(2), q3 = Q(3);
     pix[-3 * step] = (uint16_t)ov_clip3((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3, p2 - tc, p2 + tc);
     pix[-2 * step] = (uint16_t)ov_clip3((p2 + p1 + p0 + q0 + 2) >> 2, p1 - 2 * tc, p1 + 2 * tc);
@@ -121,10 +125,15 @@ __device__ __forceinline__ void strong_line(uint16_t *pix, int step, int tc)
     pix[2 * step]  = (uint16_t)ov_clip3((p0 + q0 + q1 + 3 * q2 + 2 * q3 + 4) >> 3, q2 - tc, q2 + tc);
 }
 
-__device__ __forceinline__ void weak_line(uint16_t *pix, int step, int tc, bool ext_p, bool ext_q)
+__device__ __forceinline__ void strong_line(uint16_t *pix, int step, int tc)
 {
     int s[16];
-    load_line<3, 3>(pix, step, s);
+    load_line<4, 4>(pix, step, s);
+    strong_regs(s, pix, step, tc);
+}
+
+__device__ __forceinline__ void weak_regs(const int *s, uint16_t *pix, int step, int tc, bool ext_p, bool ext_q)
+{
     const int p2 = P(2), p1 = P(1), p0 = P(0), q0 = Q(0), q1 = Q(1), q2 = Q(2);
     const int tc2p = ext_p ? tc >> 1 : 0, tc2q = ext_q ? tc >> 1 : 0;
     int delta = (9 * (q0 - p0) - 3 * (q1 - p1) + 8) >> 4;
@@ -136,6 +145,114 @@ __device__ __forceinline__ void weak_line(uint16_t *pix, int step, int tc, bool 
         pix[-1 * step] = (uint16_t)ov_clip_bd(p0 + delta);
         pix[0]         = (uint16_t)ov_clip_bd(q0 - delta);
         pix[1 * step]  = (uint16_t)ov_clip_bd(q1 + d2);
+    }
+}
+
+__device__ __forceinline__ void weak_line(uint16_t *pix, int step, int tc, bool ext_p, bool ext_q)
+{
+    int s[16];
+    load_line<3, 3>(pix, step, s);
+    weak_regs(s, pix, step, tc, ext_p, ext_q);
+}
+
+// ---- quad form (k_dbf_list): the 4 lanes of a quad hold the 4 lines of one segment, one line each, loaded ONCE;
+// the decisions, which the reference takes on lines 0 and 3 (chroma: 0 and 1), travel by DPP quad broadcast.
+// One memory round trip per segment instead of five (two decision lines, then four filtered lines one by one). ----
+template <int SEL> __device__ __forceinline__ int quad_bcast(int v)
+{
+    return __builtin_amdgcn_mov_dpp(v, SEL * 0x55, 0xf, 0xf, true);      // quad_perm [SEL, SEL, SEL, SEL]
+}
+
+// line of NS samples each side of the edge; DIR 0 (vertical edge): the line is contiguous in memory and 8-byte
+// aligned on both sides (x = 4 * ux), DIR 1: one sample per row -- a wave's lanes are adjacent columns
+template <int DIR, int NS>
+__device__ __forceinline__ void load_line_q(const uint16_t *pix, int step, int *s)
+{
+    if (DIR == 0 && !(reinterpret_cast<uintptr_t>(pix) & 7)) {
+#pragma unroll
+        for (int g = 0; g < NS / 4; ++g) {
+            const uint2 a = *reinterpret_cast<const uint2 *>(pix - 4 * (g + 1));   // p(4g+3) .. p(4g)
+            const uint2 b = *reinterpret_cast<const uint2 *>(pix + 4 * g);         // q(4g) .. q(4g+3)
+            s[7 - (4 * g + 3)] = a.x & 0xffff; s[7 - (4 * g + 2)] = a.x >> 16; s[7 - (4 * g + 1)] = a.y & 0xffff; s[7 - 4 * g] = a.y >> 16;
+            s[8 + 4 * g] = b.x & 0xffff; s[8 + 4 * g + 1] = b.x >> 16; s[8 + 4 * g + 2] = b.y & 0xffff; s[8 + 4 * g + 3] = b.y >> 16;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) { s[7 - i] = pix[(-1 - i) * step]; s[8 + i] = pix[i * step]; }
+    }
+}
+
+// filter_vertical_edge / filter_horizontal_edge (rcn_df.c:1433-1510, :2008-2085), lane = line `l` of the segment
+template <int DIR>
+__device__ __forceinline__ void luma_quad(uint16_t *pix, int step, Lim lim, int lp, int lq)
+{
+    const int beta = lim.beta, tc = lim.tc;
+    const bool big = lp > 3 || lq > 3;
+    int s[16];
+    if (big) load_line_q<DIR, 8>(pix, step, s);
+    else     load_line_q<DIR, 4>(pix, step, s);
+    const int dp = dp_of(s, 0), dq = dq_of(s, 0);
+    const int dp0 = quad_bcast<0>(dp), dq0 = quad_bcast<0>(dq), dp3 = quad_bcast<3>(dp), dq3 = quad_bcast<3>(dq);
+    const int d0 = dp0 + dq0, d3 = dp3 + dq3;
+    if (d0 + d3 >= beta) return;
+    if (big) {
+        int dpL = dp, dqL = dq;
+        if (lp > 3) dpL = (dpL + dp_of(s, 3) + 1) >> 1;
+        if (lq > 3) dqL = (dqL + dq_of(s, 3) + 1) >> 1;
+        const int dL = dpL + dqL;
+        const int ok = (dL < ((beta + 0x10) >> 5)) && strong_large(s, beta, tc, lp, lq);
+        const int d0L = quad_bcast<0>(dL), d3L = quad_bcast<3>(dL);
+        if ((d0L + d3L < beta) && quad_bcast<0>(ok) && quad_bcast<3>(ok)) { long_regs(s, pix, step, tc, lp, lq); return; }
+    }
+    const int oks = strong_small(s, beta, tc);
+    const bool sw = lp > 2 && (d0 < ((beta + 4) >> 3)) && (d3 < ((beta + 4) >> 3)) && quad_bcast<0>(oks) && quad_bcast<3>(oks);
+    if (sw) {
+        strong_regs(s, pix, step, tc);
+    } else {
+        const int side = (beta + (beta >> 1)) >> 3;
+        const bool ext_p = (dp0 + dp3) < side && lp > 1;
+        const bool ext_q = (dq0 + dq3) < side && lp > 1;   // sic: max_l_p gates the Q side too (rcn_df.c:1505, :2080)
+        weak_regs(s, pix, step, tc, ext_p, ext_q);
+    }
+}
+
+// filter_veritcal_edge_c / filter_horizontal_edge_c (rcn_df.c:1107-1148, :1279-1319): 2 chroma lines per segment;
+// lanes 2 and 3 of the quad shadow lanes 0 and 1 (same loads, no stores) so that the quad stays convergent
+template <int DIR>
+__device__ __forceinline__ void chroma_quad(uint16_t *pix, int step, Lim lim, bool large, bool ctb_b, bool store)
+{
+    const int tc = lim.tc, beta = lim.beta;
+    if (tc == 0 || beta == 0) return;
+    int s[16];
+    load_line_q<DIR, 4>(pix, step, s);
+    bool strong = false;
+    if (large) {
+        const int p3 = ctb_b ? P(1) : P(3);
+        const int dpv = abs((ctb_b ? P(1) : P(2)) - 2 * P(1) + P(0));
+        const int d = dpv + dq_of(s, 0);
+        const int ok = ((abs(p3 - P(0)) + abs(Q(3) - Q(0))) < (beta >> 3)) && (abs(P(0) - Q(0)) < ((tc * 5 + 1) >> 1))
+                       && (2 * d < (beta >> 2));
+        const int da = quad_bcast<0>(d), db = quad_bcast<1>(d);
+        strong = quad_bcast<0>(ok) && quad_bcast<1>(ok) && (da + db < beta);
+    }
+    if (!store) return;
+    const int p3 = P(3), p2 = P(2), p1 = P(1), p0 = P(0), q0 = Q(0), q1 = Q(1), q2 = Q(2), q3 = Q(3);
+    if (strong) {
+        if (ctb_b) {
+            pix[-1 * step] = (uint16_t)ov_clip3((3 * p1 + 2 * p0 + q0 + q1 + q2 + 4) >> 3, p0 - tc, p0 + tc);
+            pix[0]         = (uint16_t)ov_clip3((2 * p1 + p0 + 2 * q0 + q1 + q2 + q3 + 4) >> 3, q0 - tc, q0 + tc);
+        } else {
+            pix[-3 * step] = (uint16_t)ov_clip3((3 * p3 + 2 * p2 + p1 + p0 + q0 + 4) >> 3, p2 - tc, p2 + tc);
+            pix[-2 * step] = (uint16_t)ov_clip3((2 * p3 + p2 + 2 * p1 + p0 + q0 + q1 + 4) >> 3, p1 - tc, p1 + tc);
+            pix[-1 * step] = (uint16_t)ov_clip3((p3 + p2 + p1 + 2 * p0 + q0 + q1 + q2 + 4) >> 3, p0 - tc, p0 + tc);
+            pix[0]         = (uint16_t)ov_clip3((p2 + p1 + p0 + 2 * q0 + q1 + q2 + q3 + 4) >> 3, q0 - tc, q0 + tc);
+        }
+        pix[1 * step] = (uint16_t)ov_clip3((p1 + p0 + q0 + 2 * q1 + q2 + 2 * q3 + 4) >> 3, q1 - tc, q1 + tc);
+        pix[2 * step] = (uint16_t)ov_clip3((p0 + q0 + q1 + 2 * q2 + 3 * q3 + 4) >> 3, q2 - tc, q2 + tc);
+    } else {
+        const int delta = ov_clip3(((q0 << 2) - (p0 << 2) + p1 - q1 + 4) >> 3, -tc, tc);
+        pix[-1 * step] = (uint16_t)ov_clip_bd(p0 + delta);
+        pix[0]         = (uint16_t)ov_clip_bd(q0 - delta);
     }
 }
 
@@ -263,24 +380,26 @@ __global__ __launch_bounds__(256) void k_dbf(ovhip_pic pic, ovhip_dbf_planes pl)
     }
 }
 
-// The same filter over the compact edge lists (ovhip_dbf_compact): every lane has an edge.
+// The same filter over the compact edge lists (ovhip_dbf_compact): 4 lanes per edge, one per line of the segment.
 template <int DIR>
 __global__ __launch_bounds__(256) OV_OCC_DBF void k_dbf_list(ovhip_pic pic, const ovhip_dbf_edge *__restrict__ edges, uint32_t n,
                                                   int tc_offset, int beta_offset)
 {
     const uint32_t tid = blockIdx.x * 256 + threadIdx.x;
-    if (tid >= n) return;
-    const ovhip_dbf_edge e = edges[tid];
+    const uint32_t ei = tid >> 2;
+    const int l = tid & 3;
+    if (ei >= n) return;                                   // whole quads leave together
+    const ovhip_dbf_edge e = edges[ei];
     const int v = e.word;
     if (e.comp == 0) {
         const Lim lim = dbf_limits(v >> 8, v & 3, tc_offset, beta_offset);
         if (!(lim.tc || lim.beta)) return;
-        uint16_t *p = pic.y + (e.uy * 4) * pic.stride_y + e.ux * 4;
-        luma_segment(p, DIR ? pic.stride_y : 1, DIR ? 1 : pic.stride_y, lim, (v >> 2) & 7, (v >> 5) & 7);
+        uint16_t *p = pic.y + (e.uy * 4) * pic.stride_y + e.ux * 4 + l * (DIR ? 1 : pic.stride_y);
+        luma_quad<DIR>(p, DIR ? pic.stride_y : 1, lim, (v >> 2) & 7, (v >> 5) & 7);
     } else {
         const Lim lim = dbf_limits(v >> 8, 1 + !!(v & OVHIP_DBF_C_BS2), tc_offset, beta_offset);
-        uint16_t *p = (e.comp == 1 ? pic.cb : pic.cr) + (e.uy * 2) * pic.stride_c + e.ux * 2;
-        chroma_segment(p, DIR ? pic.stride_c : 1, DIR ? 1 : pic.stride_c, lim, v & OVHIP_DBF_C_LARGE, v & OVHIP_DBF_C_CTB_B);
+        uint16_t *p = (e.comp == 1 ? pic.cb : pic.cr) + (e.uy * 2) * pic.stride_c + e.ux * 2 + (l & 1) * (DIR ? 1 : pic.stride_c);
+        chroma_quad<DIR>(p, DIR ? pic.stride_c : 1, lim, v & OVHIP_DBF_C_LARGE, v & OVHIP_DBF_C_CTB_B, l < 2);
     }
 }
 
@@ -293,11 +412,11 @@ extern "C" int ovhip_dbf_launch_edges(ovhip_ctx *ctx, const ovhip_pic *pic, cons
     if ((n_v && !d_edges_v) || (n_h && !d_edges_h))
         return ov_fail(ctx, OVHIP_EINVAL, "ovhip_dbf_launch_edges: null edge list", hipSuccess);
     if (n_v) {
-        hipLaunchKernelGGL(k_dbf_list<0>, dim3((n_v + 255) / 256), dim3(256), 0, ctx->stream, *pic, d_edges_v, n_v, tc_offset, beta_offset);
+        hipLaunchKernelGGL(k_dbf_list<0>, dim3((n_v + 63) / 64), dim3(256), 0, ctx->stream, *pic, d_edges_v, n_v, tc_offset, beta_offset);
         OV_LAUNCH_CHECK(ctx, "k_dbf_list<v>");
     }
     if (n_h) {
-        hipLaunchKernelGGL(k_dbf_list<1>, dim3((n_h + 255) / 256), dim3(256), 0, ctx->stream, *pic, d_edges_h, n_h, tc_offset, beta_offset);
+        hipLaunchKernelGGL(k_dbf_list<1>, dim3((n_h + 63) / 64), dim3(256), 0, ctx->stream, *pic, d_edges_h, n_h, tc_offset, beta_offset);
         OV_LAUNCH_CHECK(ctx, "k_dbf_list<h>");
     }
     return OVHIP_OK;
