@@ -187,7 +187,7 @@ def main():
         achieved = alg[dom] / kdur[dom] / 1e9
         kname = {"mcp": "k_mc2", "mcx": "k_mcx", "mca": "k_mca", "ciip": "k_ciip", "itx_l": "k_itx (luma commands)",
                  "itx_c": "k_itx (chroma commands)", "lmcs_scale": "k_lmcs_scale", "lmcs_inv": "k_lmcs_inverse",
-                 "dbf": "k_dbf_list<0> + k_dbf_list<1>", "sao": "k_sao", "alf": "k_alf_luma + k_alf_chroma"}
+                 "dbf": "k_dbf_list<0> + k_dbf_list<1>", "sao": "k_sao", "alf": "k_alf"}
         # HBM traffic of the dominant kernel: rocprofv3 PMC passes of this same command cannot run inside the timed
         # process, so the committed summary of the latest pass (profiles/traffic.json, per dispatch) is quoted when it
         # was taken on this workload; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950.

@@ -62,17 +62,16 @@ __device__ __forceinline__ void filter_idx(uint32_t sum_h, uint32_t sum_v, uint3
     tr = (0xDE84 >> (2 * k)) & 3;                        // packed 2-bit LUT
 }
 
-__global__ __launch_bounds__(256) OV_OCC_ALF void k_alf_luma(ovhip_pic dst, ovhip_pic src, ovhip_alf_pic alf, int nb_ctu_w)
+// one 32x32 luma tile (workgroup `tile0` of the luma part of k_alf)
+__device__ __forceinline__ void alf_luma_tile(const ovhip_pic &dst, const ovhip_pic &src, const ovhip_alf_pic &alf, int nb_ctu_w,
+                                              int tile0, uint16_t *s_t, uint8_t *s_cls)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t s_t[LW * LWS];
-    __shared__ uint8_t s_cls[64];
 
     const int W = src.w, H = src.h;
     const int tid = threadIdx.x;
     const int ctu = 1 << alf.log2_ctu_s;
     const int ntx = (W + TL - 1) / TL, ntiles = ntx * ((H + TL - 1) / TL);
-    // loop form for capped grids; launched with one workgroup per 32x32 tile
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, __syncthreads()) {
+    for (int tile = tile0; tile < ntiles; tile = ntiles) {          // one pass; `continue` leaves the tile
     const int tx0 = (tile % ntx) * TL, ty0 = (tile / ntx) * TL;
     const ovhip_alf_ctu c = alf.ctus[(ty0 >> alf.log2_ctu_s) * nb_ctu_w + (tx0 >> alf.log2_ctu_s)];
     const bool on = c.flags & 4;
@@ -268,16 +267,15 @@ __global__ __launch_bounds__(256) OV_OCC_ALF void k_alf_luma(ovhip_pic dst, ovhi
 #undef T
 }
 
-// blockIdx.z: 0 Cb, 1 Cr
-__global__ __launch_bounds__(256) OV_OCC_ALF void k_alf_chroma(ovhip_pic dst, ovhip_pic src, ovhip_alf_pic alf, int nb_ctu_w)
+// one 32x32 tile of chroma plane `comp` (1 Cb, 2 Cr)
+__device__ __forceinline__ void alf_chroma_tile(const ovhip_pic &dst, const ovhip_pic &src, const ovhip_alf_pic &alf, int nb_ctu_w,
+                                                int tile0, int comp, uint16_t *s_t)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t s_t[CW * LWS];
-    const int comp = 1 + blockIdx.z;
     const int W = src.w, H = src.h, Wc = W >> 1, Hc = H >> 1;
     const int tid = threadIdx.x;
     const int ctu = 1 << alf.log2_ctu_s, ctuc = ctu >> 1;
     const int ntx = (Wc + TL - 1) / TL, ntiles = ntx * ((Hc + TL - 1) / TL);
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, __syncthreads()) {
+    for (int tile = tile0; tile < ntiles; tile = ntiles) {
     const int tx0 = (tile % ntx) * TL, ty0 = (tile / ntx) * TL;
     const ovhip_alf_ctu c = alf.ctus[((ty0 * 2) >> alf.log2_ctu_s) * nb_ctu_w + ((tx0 * 2) >> alf.log2_ctu_s)];
     const bool on = c.flags & (comp == 1 ? 2 : 1);
@@ -437,6 +435,17 @@ __global__ __launch_bounds__(256) OV_OCC_ALF void k_alf_chroma(ovhip_pic dst, ov
     }
 }
 
+// Luma and both chroma planes in ONE launch (they only share their input): workgroups [0, nl) take luma tiles,
+// [nl, nl + 2 * nc) the Cb then Cr tiles.  One kernel boundary less, and the chroma tiles fill the luma tail.
+__global__ __launch_bounds__(256) OV_OCC_ALF void k_alf(ovhip_pic dst, ovhip_pic src, ovhip_alf_pic alf, int nb_ctu_w, int nl, int nc)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t s_t[(LW > CW ? LW : CW) * LWS];
+    __shared__ uint8_t s_cls[64];
+    const int b = blockIdx.x;
+    if (b < nl) alf_luma_tile(dst, src, alf, nb_ctu_w, b, s_t, s_cls);
+    else        alf_chroma_tile(dst, src, alf, nb_ctu_w, (b - nl) % nc, 1 + (b - nl) / nc, s_t);
+}
+
 } // namespace
 
 extern "C" int ovhip_alf_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *src, const ovhip_alf_pic *alf)
@@ -447,10 +456,8 @@ extern "C" int ovhip_alf_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhi
         return ov_fail(ctx, OVHIP_EINVAL, "ovhip_alf_launch: bad pictures / parameter tables", hipSuccess);
     const int nb_ctu_w = (src->w + (1 << alf->log2_ctu_s) - 1) >> alf->log2_ctu_s;
     const int nl = ((src->w + TL - 1) / TL) * ((src->h + TL - 1) / TL);
-    hipLaunchKernelGGL(k_alf_luma, dim3(nl), dim3(256), 0, ctx->stream, *dst, *src, *alf, nb_ctu_w);
-    OV_LAUNCH_CHECK(ctx, "k_alf_luma");
     const int nc = ((src->w / 2 + TL - 1) / TL) * ((src->h / 2 + TL - 1) / TL);
-    hipLaunchKernelGGL(k_alf_chroma, dim3(nc, 1, 2), dim3(256), 0, ctx->stream, *dst, *src, *alf, nb_ctu_w);
-    OV_LAUNCH_CHECK(ctx, "k_alf_chroma");
+    hipLaunchKernelGGL(k_alf, dim3(nl + 2 * nc), dim3(256), 0, ctx->stream, *dst, *src, *alf, nb_ctu_w, nl, nc);
+    OV_LAUNCH_CHECK(ctx, "k_alf");
     return OVHIP_OK;
 }
