@@ -83,7 +83,8 @@ def main():
     spare_t, spare = torch_pic(wl.refs[1])          # receive buffer for the exchanged reference picture
 
     # one entry per kernel launch of the frame; launches a picture has no work for are dropped
-    present = {"mcx": rp.mcx_units, "mca": rp.aff_units, "ciip": rp.ciip_units, "lmcs_scale": rp.lmcs_regions,
+    merged = bool(rp.mcx_units and rp.aff_units)            # k_mcxa: refined + affine units in one launch ("mcx" entry)
+    present = {"mcx": rp.mcx_units, "mca": rp.aff_units and not merged, "ciip": rp.ciip_units, "lmcs_scale": rp.lmcs_regions,
                "lmcs_inv": rp.lmcs_bwd, "itx_c": rp.n_luma < rp.tb_cmds.count}
     stages = [k for k in rp.SUBSTAGES if present.get(k, True)]
     evs = {k: [] for k in stages}
@@ -183,9 +184,11 @@ def main():
             "sao": 2 * S + wl.sao_params.nbytes,
             "alf": 2 * S + rp.alf.nbytes,
         }
+        if merged:
+            alg["mcx"] += alg.pop("mca")
         alg = {k: v for k, v in alg.items() if k in kdur}
         achieved = alg[dom] / kdur[dom] / 1e9
-        kname = {"mcp": "k_mc2", "mcx": "k_mcx", "mca": "k_mca", "ciip": "k_ciip", "itx_l": "k_itx (luma commands)",
+        kname = {"mcp": "k_mc2", "mcx": "k_mcxa" if merged else "k_mcx", "mca": "k_mca", "ciip": "k_ciip", "itx_l": "k_itx (luma commands)",
                  "itx_c": "k_itx (chroma commands)", "lmcs_scale": "k_lmcs_scale", "lmcs_inv": "k_lmcs_inverse",
                  "dbf": "k_dbf_list<0> + k_dbf_list<1>", "sao": "k_sao", "alf": "k_alf"}
         # HBM traffic of the dominant kernel: rocprofv3 PMC passes of this same command cannot run inside the timed

@@ -569,6 +569,12 @@ int  ovhip_ciip_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *in
 int  ovhip_mca_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs,
                       const ovhip_aff_unit *d_units, uint32_t n_units, const int32_t *d_side,
                       const uint16_t *d_lmcs_fwd_lut);
+/* The refined and the affine units of a picture in ONE launch (they write disjoint blocks and read only the
+ * references): equal to ovhip_mcx_launch + ovhip_mca_launch, one kernel boundary and one launch tail cheaper. */
+int  ovhip_mcxa_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs,
+                       const ovhip_mc_unit *d_xunits, uint32_t n_xunits, int32_t *d_mv_out,
+                       const ovhip_aff_unit *d_aunits, uint32_t n_aunits, const int32_t *d_side,
+                       const uint16_t *d_lmcs_fwd_lut);
 /* planes->* are DEVICE pointers.  Filters `pic` in place: all vertical edges, then all horizontal. */
 int  ovhip_dbf_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_dbf_planes *planes);
 /* Same filter driven by the compact lists of ovhip_dbf_compact (DEVICE pointers). */

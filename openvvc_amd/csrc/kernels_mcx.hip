@@ -112,14 +112,22 @@ __device__ __forceinline__ void chroma_avg(const ovhip_mc_unit &u, const ovhip_p
     for (int j = 0; j < NOUT; ++j) d[j * dst.stride_c] = (uint16_t)ov_clip_bd((P[0][j] + P[1][j] + 16) >> 5);
 }
 
-__global__ __launch_bounds__(64) OV_OCC_MCX void k_mcx(ovhip_pic dst, RefTable refs, const ovhip_mc_unit *__restrict__ units,
-                                             uint32_t n_units, const uint16_t *__restrict__ lmcs_fwd, int32_t *__restrict__ mv_out)
+// LDS of one refined unit: luma windows [list], chroma windows [Cb/Cr][list], H-pass tiles
+#define MCX_LDS_WL (2 * XWIN_ROWS * XWIN_STRIDE * 2)
+#define MCX_LDS_WC (4 * XCWIN_ROWS * XCWIN_STRIDE * 2)
+#define MCX_LDS    (MCX_LDS_WL + MCX_LDS_WC + (2 * 16 * HT_STRIDE + 4 * 8 * CHT_STRIDE) * 2)
+
+// units wg0, wg0 + wstride, ... (one single-wave workgroup; `lds` = MCX_LDS bytes, 16-byte aligned)
+__device__ __forceinline__ void mcx_units(const ovhip_pic &dst, const RefTable &refs, const ovhip_mc_unit *__restrict__ units,
+                                          uint32_t n_units, const uint16_t *__restrict__ lmcs_fwd, int32_t *__restrict__ mv_out,
+                                          uint32_t wg0, uint32_t wstride, char *lds)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t s_wl[2][XWIN_ROWS * XWIN_STRIDE];
-    __shared__ __attribute__((aligned(16))) uint16_t s_wc[2][2][XCWIN_ROWS * XCWIN_STRIDE];   // [Cb/Cr][list]
+    uint16_t (*const s_wl)[XWIN_ROWS * XWIN_STRIDE] = reinterpret_cast<uint16_t (*)[XWIN_ROWS * XWIN_STRIDE]>(lds);
+    uint16_t (*const s_wc)[2][XCWIN_ROWS * XCWIN_STRIDE] =
+        reinterpret_cast<uint16_t (*)[2][XCWIN_ROWS * XCWIN_STRIDE]>(lds + MCX_LDS_WL);        // [Cb/Cr][list]
     // H-pass tiles; the same bytes first hold DMVR's bilinear blocks (dead before the H pass writes) and later BDOF's
     // R tiles (written after the V pass has read the luma tiles: one wave, LDS traffic in program order)
-    __shared__ __attribute__((aligned(16))) int16_t  s_h[2 * 16 * HT_STRIDE + 4 * 8 * CHT_STRIDE];
+    int16_t *const s_h = reinterpret_cast<int16_t *>(lds + MCX_LDS_WL + MCX_LDS_WC);
     int16_t (*const s_hl)[16 * HT_STRIDE] = reinterpret_cast<int16_t (*)[16 * HT_STRIDE]>(s_h);
     int16_t (*const s_hc)[2][8 * CHT_STRIDE] = reinterpret_cast<int16_t (*)[2][8 * CHT_STRIDE]>(s_h + 2 * 16 * HT_STRIDE);
     int16_t (*const s_x)[24 * BIL_STRIDE] = reinterpret_cast<int16_t (*)[24 * BIL_STRIDE]>(s_h);
@@ -128,8 +136,8 @@ __global__ __launch_bounds__(64) OV_OCC_MCX void k_mcx(ovhip_pic dst, RefTable r
     int16_t *const s_dr = reinterpret_cast<int16_t *>(s_wl[1]);                                // BDOF delta_ref, 16x16
 
     const int lane = threadIdx.x;
-    for (uint32_t wg = blockIdx.x; wg < n_units; wg += gridDim.x) {
-    const uint32_t bid = gridDim.x == n_units ? ov_xcd_slot(wg, n_units) : wg;      // XCD-aware order, see k_mc2
+    for (uint32_t wg = wg0; wg < n_units; wg += wstride) {
+    const uint32_t bid = wstride >= n_units ? ov_xcd_slot(wg, n_units) : wg;        // XCD-aware order, see k_mc2
     const ovhip_mc_unit u = units[bid];
     const bool dmvr = u.flags & OVHIP_MC_DMVR;
     bool use_bdof = u.flags & OVHIP_MC_BDOF;
@@ -405,26 +413,6 @@ __global__ __launch_bounds__(64) OV_OCC_MCX void k_mcx(ovhip_pic dst, RefTable r
 
 } // namespace
 
-extern "C" int ovhip_mcx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs,
-                                const ovhip_mc_unit *d_units, uint32_t n_units, const uint16_t *d_lmcs_fwd_lut,
-                                int32_t *d_mv_out)
-{
-    if (!ctx || !dst) return OVHIP_EINVAL;
-    if (!n_units) return OVHIP_OK;
-    if (!refs || !n_refs || n_refs > MC_MAX_REFS || !d_units)
-        return ov_fail(ctx, OVHIP_EINVAL, "ovhip_mcx_launch: bad reference table / units", hipSuccess);
-    RefTable t;
-    memset(&t, 0, sizeof(t));
-    for (uint32_t i = 0; i < n_refs; ++i) {
-        if (refs[i].w != dst->w || refs[i].h != dst->h || refs[i].stride_y != dst->stride_y || refs[i].stride_c != dst->stride_c)
-            return ov_fail(ctx, OVHIP_EUNSUP, "ovhip_mcx_launch: reference picture geometry differs from dst (RPR)", hipSuccess);
-        t.p[i] = refs[i];
-    }
-    for (uint32_t i = n_refs; i < MC_MAX_REFS; ++i) t.p[i] = refs[0];
-    hipLaunchKernelGGL(k_mcx, dim3(n_units), dim3(64), 0, ctx->stream, *dst, t, d_units, n_units, d_lmcs_fwd_lut, d_mv_out);
-    OV_LAUNCH_CHECK(ctx, "k_mcx");
-    return OVHIP_OK;
-}
 
 // =====================================================================================================
 // K9: affine units.  One wavefront per <=16x16 luma area = up to 16 4x4 sub-blocks with their own motion
@@ -549,20 +537,28 @@ struct AffLumaStage {
     }
 };
 
-__global__ __launch_bounds__(64) void k_mca(ovhip_pic dst, RefTable refs, const ovhip_aff_unit *__restrict__ units,
-                                             uint32_t n_units, const int32_t *__restrict__ side, const uint16_t *__restrict__ lmcs_fwd)
+#define MCA_LDS_WIN  (16 * 9 * AWS * 2)
+#define MCA_LDS_HT   (16 * 4 * AHS * 2)
+#define MCA_LDS_T    (16 * 40 * 2)
+#define MCA_LDS_CWIN (2 * 8 * 7 * ACS * 2)
+#define MCA_LDS      (MCA_LDS_WIN + MCA_LDS_HT + MCA_LDS_T + MCA_LDS_CWIN + 2 * 8 * 4 * ACHS * 2)
+
+// units wg0, wg0 + wstride, ... (one single-wave workgroup; `lds` = MCA_LDS bytes, 16-byte aligned)
+__device__ __forceinline__ void mca_units(const ovhip_pic &dst, const RefTable &refs, const ovhip_aff_unit *__restrict__ units,
+                                          uint32_t n_units, const int32_t *__restrict__ side, const uint16_t *__restrict__ lmcs_fwd,
+                                          uint32_t wg0, uint32_t wstride, char *lds)
 {
     // Luma tiles hold ONE list at a time (list 1 is filtered after list 0, its window waiting in registers): with both
     // lists resident the 16 KB workgroup allowed 10 per CU and a 4K picture's affine units needed two rounds.
-    __shared__ __attribute__((aligned(16))) uint16_t s_win[16][9 * AWS];
-    __shared__ __attribute__((aligned(16))) int16_t  s_ht[16][4 * AHS];
-    __shared__ __attribute__((aligned(16))) int16_t  s_t[16][40];
-    __shared__ __attribute__((aligned(16))) uint16_t s_cwin[2][8][7 * ACS];       // [list][comp * 4 + block]
-    __shared__ __attribute__((aligned(16))) int16_t  s_cht[2][8][4 * ACHS];
+    uint16_t (*const s_win)[9 * AWS] = reinterpret_cast<uint16_t (*)[9 * AWS]>(lds);
+    int16_t  (*const s_ht)[4 * AHS]  = reinterpret_cast<int16_t (*)[4 * AHS]>(lds + MCA_LDS_WIN);
+    int16_t  (*const s_t)[40]        = reinterpret_cast<int16_t (*)[40]>(lds + MCA_LDS_WIN + MCA_LDS_HT);
+    uint16_t (*const s_cwin)[8][7 * ACS] = reinterpret_cast<uint16_t (*)[8][7 * ACS]>(lds + MCA_LDS_WIN + MCA_LDS_HT + MCA_LDS_T);   // [list][comp * 4 + block]
+    int16_t  (*const s_cht)[8][4 * ACHS] = reinterpret_cast<int16_t (*)[8][4 * ACHS]>(lds + MCA_LDS_WIN + MCA_LDS_HT + MCA_LDS_T + MCA_LDS_CWIN);
 
     const int lane = threadIdx.x;
-    for (uint32_t wg = blockIdx.x; wg < n_units; wg += gridDim.x) {
-    const uint32_t bid = gridDim.x == n_units ? ov_xcd_slot(wg, n_units) : wg;      // XCD-aware order, see k_mc2
+    for (uint32_t wg = wg0; wg < n_units; wg += wstride) {
+    const uint32_t bid = wstride >= n_units ? ov_xcd_slot(wg, n_units) : wg;        // XCD-aware order, see k_mc2
 #ifdef OV_MCA_PHASES
     unsigned int ph[8] = {}; unsigned long long tprev = __builtin_readcyclecounter();
 #endif
@@ -736,6 +732,31 @@ __global__ __launch_bounds__(64) void k_mca(ovhip_pic dst, RefTable refs, const 
     }
 }
 
+__global__ __launch_bounds__(64) OV_OCC_MCX void k_mcx(ovhip_pic dst, RefTable refs, const ovhip_mc_unit *__restrict__ units,
+                                             uint32_t n_units, const uint16_t *__restrict__ lmcs_fwd, int32_t *__restrict__ mv_out)
+{
+    __shared__ __attribute__((aligned(16))) char lds[MCX_LDS];
+    mcx_units(dst, refs, units, n_units, lmcs_fwd, mv_out, blockIdx.x, gridDim.x, lds);
+}
+
+__global__ __launch_bounds__(64) OV_OCC_MCX void k_mca(ovhip_pic dst, RefTable refs, const ovhip_aff_unit *__restrict__ units,
+                                             uint32_t n_units, const int32_t *__restrict__ side, const uint16_t *__restrict__ lmcs_fwd)
+{
+    __shared__ __attribute__((aligned(16))) char lds[MCA_LDS];
+    mca_units(dst, refs, units, n_units, side, lmcs_fwd, blockIdx.x, gridDim.x, lds);
+}
+
+// Both kinds of unit in ONE launch: workgroups [0, n_a) take the affine units (few, long, latency-bound -- first, so that
+// the refined units hide them), [n_a, n_a + n_x) the BDOF / DMVR units.  One kernel boundary and one tail less.
+__global__ __launch_bounds__(64) OV_OCC_MCX void k_mcxa(ovhip_pic dst, RefTable refs, const ovhip_mc_unit *__restrict__ xunits, uint32_t n_x,
+                                              int32_t *__restrict__ mv_out, const ovhip_aff_unit *__restrict__ aunits, uint32_t n_a,
+                                              const int32_t *__restrict__ side, const uint16_t *__restrict__ lmcs_fwd)
+{
+    __shared__ __attribute__((aligned(16))) char lds[MCX_LDS > MCA_LDS ? MCX_LDS : MCA_LDS];
+    if (blockIdx.x < n_a) mca_units(dst, refs, aunits, n_a, side, lmcs_fwd, blockIdx.x, n_a, lds);
+    else                  mcx_units(dst, refs, xunits, n_x, lmcs_fwd, mv_out, blockIdx.x - n_a, n_x, lds);
+}
+
 } // namespace
 
 #ifdef OV_MCA_PHASES
@@ -744,6 +765,27 @@ extern "C" int ovhip_debug_mca_phases(unsigned int *out /* [65536][8] */)
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mca_phase), sizeof(unsigned int) * OV_MCA_PHASE_UNITS * 8) == hipSuccess ? OVHIP_OK : OVHIP_ELAUNCH;
 }
 #endif
+
+extern "C" int ovhip_mcx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs,
+                                const ovhip_mc_unit *d_units, uint32_t n_units, const uint16_t *d_lmcs_fwd_lut,
+                                int32_t *d_mv_out)
+{
+    if (!ctx || !dst) return OVHIP_EINVAL;
+    if (!n_units) return OVHIP_OK;
+    if (!refs || !n_refs || n_refs > MC_MAX_REFS || !d_units)
+        return ov_fail(ctx, OVHIP_EINVAL, "ovhip_mcx_launch: bad reference table / units", hipSuccess);
+    RefTable t;
+    memset(&t, 0, sizeof(t));
+    for (uint32_t i = 0; i < n_refs; ++i) {
+        if (refs[i].w != dst->w || refs[i].h != dst->h || refs[i].stride_y != dst->stride_y || refs[i].stride_c != dst->stride_c)
+            return ov_fail(ctx, OVHIP_EUNSUP, "ovhip_mcx_launch: reference picture geometry differs from dst (RPR)", hipSuccess);
+        t.p[i] = refs[i];
+    }
+    for (uint32_t i = n_refs; i < MC_MAX_REFS; ++i) t.p[i] = refs[0];
+    hipLaunchKernelGGL(k_mcx, dim3(n_units), dim3(64), 0, ctx->stream, *dst, t, d_units, n_units, d_lmcs_fwd_lut, d_mv_out);
+    OV_LAUNCH_CHECK(ctx, "k_mcx");
+    return OVHIP_OK;
+}
 
 extern "C" int ovhip_mca_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs,
                                 const ovhip_aff_unit *d_units, uint32_t n_units, const int32_t *d_side,
@@ -763,5 +805,29 @@ extern "C" int ovhip_mca_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhi
     for (uint32_t i = n_refs; i < MC_MAX_REFS; ++i) t.p[i] = refs[0];
     hipLaunchKernelGGL(k_mca, dim3(n_units), dim3(64), 0, ctx->stream, *dst, t, d_units, n_units, d_side, d_lmcs_fwd_lut);
     OV_LAUNCH_CHECK(ctx, "k_mca");
+    return OVHIP_OK;
+}
+
+extern "C" int ovhip_mcxa_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs,
+                                 const ovhip_mc_unit *d_xunits, uint32_t n_xunits, int32_t *d_mv_out,
+                                 const ovhip_aff_unit *d_aunits, uint32_t n_aunits, const int32_t *d_side,
+                                 const uint16_t *d_lmcs_fwd_lut)
+{
+    if (!ctx || !dst) return OVHIP_EINVAL;
+    if (!n_aunits) return ovhip_mcx_launch(ctx, dst, refs, n_refs, d_xunits, n_xunits, d_lmcs_fwd_lut, d_mv_out);
+    if (!n_xunits) return ovhip_mca_launch(ctx, dst, refs, n_refs, d_aunits, n_aunits, d_side, d_lmcs_fwd_lut);
+    if (!refs || !n_refs || n_refs > MC_MAX_REFS || !d_xunits || !d_aunits || !d_side)
+        return ov_fail(ctx, OVHIP_EINVAL, "ovhip_mcxa_launch: bad reference table / units / side arena", hipSuccess);
+    RefTable t;
+    memset(&t, 0, sizeof(t));
+    for (uint32_t i = 0; i < n_refs; ++i) {
+        if (refs[i].w != dst->w || refs[i].h != dst->h || refs[i].stride_y != dst->stride_y || refs[i].stride_c != dst->stride_c)
+            return ov_fail(ctx, OVHIP_EUNSUP, "ovhip_mcxa_launch: reference picture geometry differs from dst (RPR)", hipSuccess);
+        t.p[i] = refs[i];
+    }
+    for (uint32_t i = n_refs; i < MC_MAX_REFS; ++i) t.p[i] = refs[0];
+    hipLaunchKernelGGL(k_mcxa, dim3(n_aunits + n_xunits), dim3(64), 0, ctx->stream, *dst, t, d_xunits, n_xunits, d_mv_out,
+                       d_aunits, n_aunits, d_side, d_lmcs_fwd_lut);
+    OV_LAUNCH_CHECK(ctx, "k_mcxa");
     return OVHIP_OK;
 }

@@ -133,6 +133,14 @@ class Context:
         self._chk(self.lib.ovhip_mca_launch(self.h, C.byref(dst.s), arr, len(refs), units.ptr, n, side.ptr,
                                             lmcs_fwd.ptr if lmcs_fwd else None), "mca_launch")
 
+    def mcxa(self, dst: "DevPic", refs: list, xunits: "DevBuf", aunits: "DevBuf", side: "DevBuf",
+             lmcs_fwd: "DevBuf | None" = None, mv_out: "DevBuf | None" = None):
+        """BDOF / DMVR units and affine units in one launch (ovhip_mcxa_launch)."""
+        arr = (capi.Pic * len(refs))(*[r.s for r in refs])
+        self._chk(self.lib.ovhip_mcxa_launch(self.h, C.byref(dst.s), arr, len(refs), xunits.ptr, xunits.count,
+                                             mv_out.ptr if mv_out else None, aunits.ptr, aunits.count, side.ptr,
+                                             lmcs_fwd.ptr if lmcs_fwd else None), "mcxa_launch")
+
     def mcx(self, dst: "DevPic", refs: list, units: "DevBuf", lmcs_fwd: "DevBuf | None" = None,
             mv_out: "DevBuf | None" = None, n: int | None = None):
         """BDOF / DMVR units; mv_out: device int32[n][4] receiving the refined motion vectors."""
@@ -305,10 +313,12 @@ class ResidentPicture:
         if name == "mcp":
             c.mc(self.dst, self.refs, self.mc_units, self.lmcs_fwd, intra=self.intra)
         elif name == "mcx":
-            if self.mcx_units:
+            if self.mcx_units and self.aff_units:       # both kinds: one launch (the "mca" sub-stage is then empty)
+                c.mcxa(self.dst, self.refs, self.mcx_units, self.aff_units, self.aff_side, self.lmcs_fwd, self.mv_out)
+            elif self.mcx_units:
                 c.mcx(self.dst, self.refs, self.mcx_units, self.lmcs_fwd, self.mv_out)
         elif name == "mca":
-            if self.aff_units:
+            if self.aff_units and not self.mcx_units:
                 c.mca(self.dst, self.refs, self.aff_units, self.aff_side, self.lmcs_fwd)
         elif name == "ciip":
             if self.ciip_units:
