@@ -85,7 +85,8 @@ def main():
     # one entry per kernel launch of the frame; launches a picture has no work for are dropped
     merged = bool(rp.mcx_units and rp.aff_units)            # k_mcxa: refined + affine units in one launch ("mcx" entry)
     present = {"mcx": rp.mcx_units, "mca": rp.aff_units and not merged, "ciip": rp.ciip_units, "lmcs_scale": rp.lmcs_regions,
-               "lmcs_inv": rp.lmcs_bwd, "itx_c": rp.n_luma < rp.tb_cmds.count}
+               "lmcs_inv": rp.lmcs_bwd and not wl.tb_classes[3],      # else it rides in the chroma ITX launch
+               "itx_c": rp.n_luma < rp.tb_cmds.count}
     stages = [k for k in rp.SUBSTAGES if present.get(k, True)]
     evs = {k: [] for k in stages}
 
@@ -186,6 +187,8 @@ def main():
         }
         if merged:
             alg["mcx"] += alg.pop("mca")
+        if "lmcs_inv" not in kdur and rp.lmcs_bwd:
+            alg["itx_c"] += alg.pop("lmcs_inv")
         alg = {k: v for k, v in alg.items() if k in kdur}
         achieved = alg[dom] / kdur[dom] / 1e9
         kname = {"mcp": "k_mc2", "mcx": "k_mcxa" if merged else "k_mcx", "mca": "k_mca", "ciip": "k_ciip", "itx_l": "k_itx (luma commands)",

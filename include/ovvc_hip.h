@@ -546,6 +546,12 @@ int  ovhip_itx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_tb_cmd *
 int  ovhip_itx_launch_classes(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_tb_cmd *d_cmds,
                               uint32_t n_large, uint32_t n_small, const int16_t *d_coefs,
                               const int16_t *d_lmcs_scales);
+/* The CHROMA commands of a picture (same classes) plus, riding in the same launch, the inverse LMCS mapping of the
+ * luma plane (= ovhip_lmcs_inverse_launch).  Legal once the luma commands and ovhip_lmcs_scale_launch have run:
+ * the commands must not address plane 0. */
+int  ovhip_itx_launch_chroma_lmcs(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_tb_cmd *d_cmds,
+                                  uint32_t n_large, uint32_t n_small, const int16_t *d_coefs,
+                                  const int16_t *d_lmcs_scales, const uint16_t *d_bwd_lut);
 /* d_regions, d_scales: DEVICE; d_scales[i] receives lmcs_chroma_scale of region i.  luts: HOST. */
 int  ovhip_lmcs_scale_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_lmcs_region *d_regions,
                              uint32_t n_regions, const ovhip_lmcs_luts *luts, int16_t *d_scales);

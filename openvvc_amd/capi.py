@@ -241,6 +241,7 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_rec_lmcs_regions": (vp, [vp, P(C.c_size_t)]),
         "ovhip_rec_tb_cmds_split": (vp, [vp, C.c_size_t * 4, P(C.c_size_t)]),
         "ovhip_itx_launch_classes": (C.c_int, [vp, P(Pic), vp, u32, u32, vp, vp]),
+        "ovhip_itx_launch_chroma_lmcs": (C.c_int, [vp, P(Pic), vp, u32, u32, vp, vp, vp]),
         "ovhip_lmcs_build": (C.c_int, [P(LmcsData), P(LmcsLuts)]),
         "ovhip_lmcs_scale_launch": (C.c_int, [vp, P(Pic), vp, u32, P(LmcsLuts), vp]),
         "ovhip_lmcs_inverse_launch": (C.c_int, [vp, P(Pic), vp]),
@@ -280,7 +281,7 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
 
 EXPORTED_SYMBOLS = [
     "ovhip_abi_version", "ovhip_rec_create", "ovhip_rec_destroy", "ovhip_rec_reset", "ovhip_rec_tu",
-    "ovhip_rec_pu", "ovhip_rec_dbf_ctu", "ovhip_rec_dbf_planes", "ovhip_dbf_launch", "ovhip_sao_launch", "ovhip_alf_launch", "ovhip_rec_tb_cmds", "ovhip_rec_coefs", "ovhip_rec_mc_units", "ovhip_rec_mcx_units", "ovhip_mcx_launch", "ovhip_rec_affine_cu", "ovhip_rec_transform_tree", "ovhip_rec_lmcs_region", "ovhip_dbf_compact", "ovhip_rec_dbf_mv_prepass", "ovhip_dbf_launch_edges", "ovhip_rec_ciip", "ovhip_ciip_weight", "ovhip_rec_ciip_units", "ovhip_ciip_launch", "ovhip_rec_lmcs_regions", "ovhip_rec_tb_cmds_split", "ovhip_itx_launch_classes", "ovhip_lmcs_build", "ovhip_lmcs_scale_launch", "ovhip_lmcs_inverse_launch", "ovhip_rec_aff_units", "ovhip_rec_aff_side", "ovhip_mca_launch", "ovhip_mcxa_launch", "ovhip_ctx_create",
+    "ovhip_rec_pu", "ovhip_rec_dbf_ctu", "ovhip_rec_dbf_planes", "ovhip_dbf_launch", "ovhip_sao_launch", "ovhip_alf_launch", "ovhip_rec_tb_cmds", "ovhip_rec_coefs", "ovhip_rec_mc_units", "ovhip_rec_mcx_units", "ovhip_mcx_launch", "ovhip_rec_affine_cu", "ovhip_rec_transform_tree", "ovhip_rec_lmcs_region", "ovhip_dbf_compact", "ovhip_rec_dbf_mv_prepass", "ovhip_dbf_launch_edges", "ovhip_rec_ciip", "ovhip_ciip_weight", "ovhip_rec_ciip_units", "ovhip_ciip_launch", "ovhip_rec_lmcs_regions", "ovhip_rec_tb_cmds_split", "ovhip_itx_launch_classes", "ovhip_itx_launch_chroma_lmcs", "ovhip_lmcs_build", "ovhip_lmcs_scale_launch", "ovhip_lmcs_inverse_launch", "ovhip_rec_aff_units", "ovhip_rec_aff_side", "ovhip_mca_launch", "ovhip_mcxa_launch", "ovhip_ctx_create",
     "ovhip_ctx_destroy", "ovhip_ctx_sync", "ovhip_ctx_fork", "ovhip_ctx_join", "ovhip_last_error", "ovhip_ctx_stream", "ovhip_malloc",
     "ovhip_free", "ovhip_h2d", "ovhip_d2h", "ovhip_pic_alloc", "ovhip_pic_free", "ovhip_pic_upload",
     "ovhip_pic_download", "ovhip_itx_launch", "ovhip_mc_launch",

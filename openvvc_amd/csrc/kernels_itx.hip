@@ -192,10 +192,34 @@ __device__ unsigned int g_itx_phase[OV_ITX_PHASE_UNITS * 8];
 #define OV_IPHASE_END() do { } while (0)
 #endif
 
+// Rider of the chroma launch: inverse LMCS mapping of the luma plane (rcn_lmcs_reshape_backward, rcn_lmcs.c:219-231) by
+// workgroups n_cmds .. n_cmds + n_extra - 1.  Luma is final once the luma commands and k_lmcs_scale have run and the
+// chroma commands never touch it, so the two share a launch instead of paying a kernel boundary each.
+template <int NT>
+__device__ __forceinline__ void lmcs_inverse_rows(const ovhip_pic &pic, const uint16_t *__restrict__ lut, uint32_t e, uint32_t n_extra,
+                                                  uint16_t *s_lut)
+{
+    for (int i = threadIdx.x; i < 512; i += NT) reinterpret_cast<uint32_t *>(s_lut)[i] = reinterpret_cast<const uint32_t *>(lut)[i];
+    __syncthreads();
+    const int nvx = pic.w >> 3, tail = pic.w & 7;             // full 8-sample vectors per row (plane 16-byte aligned, stride % 8 == 0)
+    for (int y = (int)e; y < pic.h; y += (int)n_extra) {
+        uint16_t *row = pic.y + (size_t)y * pic.stride_y;
+        for (int v = threadIdx.x; v < nvx; v += NT) {
+            uint4 q = *reinterpret_cast<uint4 *>(row + 8 * v);
+            uint32_t *d = reinterpret_cast<uint32_t *>(&q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[k] = s_lut[d[k] & 1023] | ((uint32_t)s_lut[(d[k] >> 16) & 1023] << 16);
+            *reinterpret_cast<uint4 *>(row + 8 * v) = q;
+        }
+        if ((int)threadIdx.x < tail) row[8 * nvx + threadIdx.x] = s_lut[row[8 * nvx + threadIdx.x] & 1023];
+    }
+}
+
 template <int ML2, int NT>
 __global__ __launch_bounds__(NT) OV_OCC_ITX void k_itx(ovhip_pic pic, const ovhip_tb_cmd *__restrict__ cmds,
                                              uint32_t n_cmds, const int16_t *__restrict__ arena,
-                                             const int16_t *__restrict__ lmcs_scales, int ablate)
+                                             const int16_t *__restrict__ lmcs_scales, int ablate,
+                                             const uint16_t *__restrict__ lmcs_inv_lut, uint32_t n_extra)
 {
     constexpr int MC = ML2 > 5 ? 32 : (1 << ML2);                      // stored coefficient extent per dimension
     constexpr int MS = tile_stride_c(MC);                              // longest k-contiguous row
@@ -206,6 +230,11 @@ __global__ __launch_bounds__(NT) OV_OCC_ITX void k_itx(ovhip_pic pic, const ovhi
     __shared__ __attribute__((aligned(16))) int16_t s_mh[(1 << ML2) * MS];
 
     const int lane = threadIdx.x;
+    if (ML2 == 4 && blockIdx.x >= n_cmds) {
+        __shared__ __attribute__((aligned(16))) uint16_t s_lut[ML2 == 4 ? 1024 : 1];      // +2 KB: 4.6 KB per workgroup, still > 32 per CU
+        lmcs_inverse_rows<NT>(pic, lmcs_inv_lut, blockIdx.x - n_cmds, n_extra, s_lut);
+        return;
+    }
     for (uint32_t bid = blockIdx.x; bid < n_cmds; bid += gridDim.x, __syncthreads()) {   // loop form for capped grids; launched with one workgroup per block
 #ifdef OV_ITX_PHASES
     unsigned int ph[8] = {}; unsigned long long tprev = __builtin_readcyclecounter();
@@ -434,6 +463,27 @@ static int itx_ablate()
     return cfg_ablate;
 }
 
+static int itx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_tb_cmd *d_cmds, uint32_t n_large, uint32_t n_small,
+                      const int16_t *d_coefs, const int16_t *d_lmcs_scales, const uint16_t *d_bwd_lut)
+{
+    // one workgroup per TB measured faster than a resident grid-stride grid (79 vs 119 us at 4K; and again with the
+    // next block's loads software-pipelined: the kernels are issue-bound, not latency-bound).  Large blocks go first:
+    // they are the long jobs.
+    if (n_large) {
+        hipLaunchKernelGGL((k_itx<6, 256>), dim3(n_large), dim3(256), 0, ctx->stream, *dst, d_cmds, n_large, d_coefs,
+                           d_lmcs_scales, itx_ablate(), (const uint16_t *)nullptr, 0u);
+        OV_LAUNCH_CHECK(ctx, "k_itx<6,256>");
+    }
+    // the inverse-LMCS rider: two luma rows per workgroup
+    const uint32_t n_extra = d_bwd_lut ? (uint32_t)(dst->h + 1) / 2 : 0;
+    if (n_small + n_extra) {
+        hipLaunchKernelGGL((k_itx<4, 64>), dim3(n_small + n_extra), dim3(64), 0, ctx->stream, *dst, d_cmds + n_large, n_small, d_coefs,
+                           d_lmcs_scales, itx_ablate(), d_bwd_lut, n_extra);
+        OV_LAUNCH_CHECK(ctx, "k_itx<4,64>");
+    }
+    return OVHIP_OK;
+}
+
 extern "C" int ovhip_itx_launch_classes(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_tb_cmd *d_cmds,
                                         uint32_t n_large, uint32_t n_small, const int16_t *d_coefs,
                                         const int16_t *d_lmcs_scales)
@@ -441,20 +491,18 @@ extern "C" int ovhip_itx_launch_classes(ovhip_ctx *ctx, const ovhip_pic *dst, co
     if (!ctx || !dst) return OVHIP_EINVAL;
     if (!n_large && !n_small) return OVHIP_OK;
     if (!d_cmds || !d_coefs) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_itx_launch: null buffer", hipSuccess);
-    // one workgroup per TB measured faster than a resident grid-stride grid (79 vs 119 us at 4K): the loop form
-    // stays for grids capped by the caller, the default launches one workgroup per command.  Large blocks go
-    // first: they are the long jobs.
-    if (n_large) {
-        hipLaunchKernelGGL((k_itx<6, 256>), dim3(n_large), dim3(256), 0, ctx->stream, *dst, d_cmds, n_large, d_coefs,
-                           d_lmcs_scales, itx_ablate());
-        OV_LAUNCH_CHECK(ctx, "k_itx<6,256>");
-    }
-    if (n_small) {
-        hipLaunchKernelGGL((k_itx<4, 64>), dim3(n_small), dim3(64), 0, ctx->stream, *dst, d_cmds + n_large, n_small, d_coefs,
-                           d_lmcs_scales, itx_ablate());
-        OV_LAUNCH_CHECK(ctx, "k_itx<4,64>");
-    }
-    return OVHIP_OK;
+    return itx_launch(ctx, dst, d_cmds, n_large, n_small, d_coefs, d_lmcs_scales, nullptr);
+}
+
+extern "C" int ovhip_itx_launch_chroma_lmcs(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_tb_cmd *d_cmds,
+                                            uint32_t n_large, uint32_t n_small, const int16_t *d_coefs,
+                                            const int16_t *d_lmcs_scales, const uint16_t *d_bwd_lut)
+{
+    if (!ctx || !dst || !d_bwd_lut) return OVHIP_EINVAL;
+    if ((n_large || n_small) && (!d_cmds || !d_coefs)) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_itx_launch_chroma_lmcs: null buffer", hipSuccess);
+    if ((dst->stride_y & 7) || ((uintptr_t)dst->y & 15))
+        return ov_fail(ctx, OVHIP_EINVAL, "ovhip_itx_launch_chroma_lmcs: luma plane must be 16-byte aligned with stride % 8 == 0", hipSuccess);
+    return itx_launch(ctx, dst, d_cmds, n_large, n_small, d_coefs, d_lmcs_scales, d_bwd_lut);
 }
 
 extern "C" int ovhip_itx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_tb_cmd *d_cmds,

@@ -91,6 +91,14 @@ class Context:
         self._chk(self.lib.ovhip_itx_launch_classes(self.h, C.byref(dst.s), ptr, n_large, n_small, coefs.ptr,
                                                     lmcs_scales.ptr if lmcs_scales else None), "itx_launch_classes")
 
+    def itx_chroma_lmcs(self, dst: "DevPic", cmds: "DevBuf", coefs: "DevBuf", first: int, n_large: int, n_small: int,
+                        lmcs_scales: "DevBuf | None", bwd_lut: "DevBuf"):
+        """The chroma commands plus the inverse LMCS mapping of luma in the same launch (ovhip_itx_launch_chroma_lmcs)."""
+        ptr = C.c_void_p(cmds.ptr.value + first * capi.TB_CMD_DTYPE.itemsize) if first else cmds.ptr
+        self._chk(self.lib.ovhip_itx_launch_chroma_lmcs(self.h, C.byref(dst.s), ptr, n_large, n_small, coefs.ptr,
+                                                        lmcs_scales.ptr if lmcs_scales else None, bwd_lut.ptr),
+                  "itx_launch_chroma_lmcs")
+
     def lmcs_scale(self, pic: "DevPic", regions: "DevBuf", luts: "capi.LmcsLuts", scales: "DevBuf", n: int | None = None):
         n = regions.count if n is None else n
         self._chk(self.lib.ovhip_lmcs_scale_launch(self.h, C.byref(pic.s), regions.ptr, n, C.byref(luts), scales.ptr),
@@ -331,10 +339,12 @@ class ResidentPicture:
                 c.lmcs_scale(self.dst, self.lmcs_regions, self.lmcs, self.lmcs_scales)
         elif name == "itx_c":
             k = self.wl.tb_classes
-            if k[2] + k[3]:
+            if self.lmcs is not None and k[3]:          # the inverse mapping rides in the chroma launch ("lmcs_inv" is then empty)
+                c.itx_chroma_lmcs(self.dst, self.tb_cmds, self.coefs, k[0] + k[1], k[2], k[3], self.lmcs_scales, self.lmcs_bwd)
+            elif k[2] + k[3]:
                 c.itx_classes(self.dst, self.tb_cmds, self.coefs, k[0] + k[1], k[2], k[3], self.lmcs_scales)
         elif name == "lmcs_inv":
-            if self.lmcs is not None:
+            if self.lmcs is not None and not self.wl.tb_classes[3]:
                 c.lmcs_inverse(self.dst, self.lmcs_bwd)
         elif name == "dbf":
             c.dbf_edges(self.dst, self.dbf_v, self.dbf_h, self.wl.dbf_planes["beta_offset"], self.wl.dbf_planes["tc_offset"])
