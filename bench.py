@@ -191,8 +191,8 @@ def main():
             alg["itx_c"] += alg.pop("lmcs_inv")
         alg = {k: v for k, v in alg.items() if k in kdur}
         achieved = alg[dom] / kdur[dom] / 1e9
-        kname = {"mcp": "k_mc2", "mcx": "k_mcxa" if merged else "k_mcx", "mca": "k_mca", "ciip": "k_ciip", "itx_l": "k_itx (luma commands)",
-                 "itx_c": "k_itx (chroma commands)", "lmcs_scale": "k_lmcs_scale", "lmcs_inv": "k_lmcs_inverse",
+        kname = {"mcp": "k_mc2", "mcx": "k_mcxa" if merged else "k_mcx", "mca": "k_mca", "ciip": "k_ciip", "itx_l": "k_itx_all (luma commands)",
+                 "itx_c": "k_itx_all (chroma commands + inverse-LMCS rider)", "lmcs_scale": "k_lmcs_scale", "lmcs_inv": "k_lmcs_inverse",
                  "dbf": "k_dbf_list<0> + k_dbf_list<1>", "sao": "k_sao", "alf": "k_alf"}
         # HBM traffic of the dominant kernel: rocprofv3 PMC passes of this same command cannot run inside the timed
         # process, so the committed summary of the latest pass (profiles/traffic.json, per dispatch) is quoted when it

@@ -175,23 +175,6 @@ __device__ __forceinline__ void tr_pass_lds(const int16_t *src, int sstride, con
     }
 }
 
-// Two instantiations: <6, 256> any block up to 64x64, four waves per block (a 64x64 block is ~200k MACs: one
-// wave alone would be the tail of the launch); <4, 64> blocks up to 16x16, one wave and 1.5 KB of LDS per
-// block so that 32 blocks are resident per CU and hide each other's load latency.
-#ifdef OV_ITX_PHASES
-// Debug build only (-DOV_ITX_PHASES=64 or 256: which instantiation records): per-block shader-clock phase times of
-// k_itx (tools/probe_mc_phases.py).
-#define OV_ITX_PHASE_UNITS 65536
-__device__ unsigned int g_itx_phase[OV_ITX_PHASE_UNITS * 8];
-#define OV_IPHASE(i) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_readcyclecounter(); \
-                          ph[i] = (unsigned int)(t_ - tprev); tprev = t_; } while (0)
-#define OV_IPHASE_END() do { OV_IPHASE(4); if (NT == OV_ITX_PHASES && lane == 0 && bid < OV_ITX_PHASE_UNITS) { \
-        for (int i_ = 0; i_ < 5; ++i_) g_itx_phase[bid * 8 + i_] = ph[i_]; g_itx_phase[bid * 8 + 7] = 1; } } while (0)
-#else
-#define OV_IPHASE(i) do { } while (0)
-#define OV_IPHASE_END() do { } while (0)
-#endif
-
 // Rider of the chroma launch: inverse LMCS mapping of the luma plane (rcn_lmcs_reshape_backward, rcn_lmcs.c:219-231) by
 // workgroups n_cmds .. n_cmds + n_extra - 1.  Luma is final once the luma commands and k_lmcs_scale have run and the
 // chroma commands never touch it, so the two share a launch instead of paying a kernel boundary each.
@@ -215,32 +198,25 @@ __device__ __forceinline__ void lmcs_inverse_rows(const ovhip_pic &pic, const ui
     }
 }
 
-template <int ML2, int NT>
-__global__ __launch_bounds__(NT) OV_OCC_ITX void k_itx(ovhip_pic pic, const ovhip_tb_cmd *__restrict__ cmds,
-                                             uint32_t n_cmds, const int16_t *__restrict__ arena,
-                                             const int16_t *__restrict__ lmcs_scales, int ablate,
-                                             const uint16_t *__restrict__ lmcs_inv_lut, uint32_t n_extra)
-{
-    constexpr int MC = ML2 > 5 ? 32 : (1 << ML2);                      // stored coefficient extent per dimension
-    constexpr int MS = tile_stride_c(MC);                              // longest k-contiguous row
-    // s_coef: transform blocks [column][row] (stride tile_stride(ch)), everything else raster [row][column] (stride tb_w)
-    __shared__ __attribute__((aligned(16))) int16_t s_coef[MC * MS];
-    __shared__ __attribute__((aligned(16))) int16_t s_tmp[(1 << ML2) * MS];     // pass 1 -> pass 2: [row][column k]
-    __shared__ __attribute__((aligned(16))) int16_t s_mv[(1 << ML2) * MS];      // cores [output][k]
-    __shared__ __attribute__((aligned(16))) int16_t s_mh[(1 << ML2) * MS];
+// LDS of one block, int16 entries: s_coef (transform blocks [column][row], stride tile_stride(ch); everything else raster
+// [row][column], stride tb_w), s_tmp (pass 1 -> pass 2: [row][column k]), s_mv and s_mh (cores [output][k]).
+template <int ML2> struct ItxLds {
+    static constexpr int MC = ML2 > 5 ? 32 : (1 << ML2);               // stored coefficient extent per dimension
+    static constexpr int MS = tile_stride_c(MC);                       // longest k-contiguous row
+    static constexpr int COEF = MC * MS, TILE = (1 << ML2) * MS, TOTAL = COEF + 3 * TILE;
+};
 
-    const int lane = threadIdx.x;
-    if (ML2 == 4 && blockIdx.x >= n_cmds) {
-        __shared__ __attribute__((aligned(16))) uint16_t s_lut[ML2 == 4 ? 1024 : 1];      // +2 KB: 4.6 KB per workgroup, still > 32 per CU
-        lmcs_inverse_rows<NT>(pic, lmcs_inv_lut, blockIdx.x - n_cmds, n_extra, s_lut);
-        return;
-    }
-    for (uint32_t bid = blockIdx.x; bid < n_cmds; bid += gridDim.x, __syncthreads()) {   // loop form for capped grids; launched with one workgroup per block
-#ifdef OV_ITX_PHASES
-    unsigned int ph[8] = {}; unsigned long long tprev = __builtin_readcyclecounter();
-#endif
-    const ovhip_tb_cmd c = cmds[bid];
-    OV_IPHASE(0);
+// One transform block by NT threads (lane 0 .. NT-1): <6, 256> any block up to 64x64, four waves per block (a 64x64
+// block is ~200k MACs: one wave alone would be the tail of the launch); <4, 64> blocks up to 16x16, one wave and
+// 2.5 KB of LDS.  EVERY path runs the same four barriers, whatever the block needs (LFNST, BDPCM, nothing): that is
+// what lets four waves with four different small blocks share a 256-thread workgroup (k_itx_all); a wave without a
+// block (valid = false) only keeps the barriers company.
+template <int ML2, int NT>
+__device__ __forceinline__ void itx_block(const ovhip_pic &pic, const ovhip_tb_cmd &c, bool valid, const int16_t *__restrict__ arena,
+                                          const int16_t *__restrict__ lmcs_scales, int ablate, int lane, int16_t *lds)
+{
+    typedef ItxLds<ML2> L;
+    int16_t *const s_coef = lds, *const s_tmp = lds + L::COEF, *const s_mv = s_tmp + L::TILE, *const s_mh = s_mv + L::TILE;
 
     const int log2_w = c.log2_w, log2_h = c.log2_h;
     const int tb_w = 1 << log2_w, tb_h = 1 << log2_h;
@@ -256,7 +232,7 @@ __global__ __launch_bounds__(NT) OV_OCC_ITX void k_itx(ovhip_pic pic, const ovhi
     const bool descan = !raster && !(ablate & 2) && cw >= 4 && lane < nx * ny;
     const bool sig = descan && ((c.sig_sb_map >> bit) & 1);
     int4 v0 = make_int4(0, 0, 0, 0), v1 = v0;
-    if (sig) {
+    if (valid && sig) {
         const int rank = __popcll(c.sig_sb_map & ((1ull << bit) - 1));
         const int4 *p = reinterpret_cast<const int4 *>(src + rank * 16);
         v0 = p[0]; v1 = p[1];
@@ -265,7 +241,7 @@ __global__ __launch_bounds__(NT) OV_OCC_ITX void k_itx(ovhip_pic pic, const ovhi
     const bool is_tr = kind == OVHIP_TB_TR;
     const int cs = tile_stride(ch);                       // s_coef row length of a transform block
     const int msv = tile_stride(kv), msh = tile_stride(kh);
-    if (is_tr && !(ablate & 1)) {
+    if (valid && is_tr && !(ablate & 1)) {
         // 16-byte chunks (8 values of one core row): at most 64 * 32 / 8 = 256 <= NT per core for <6, 256>, 32 for <4, 64>
         const int l2cv = kv >= 32 ? 2 : kv >= 16 ? 1 : 0, l2ch = kh >= 32 ? 2 : kh >= 16 ? 1 : 0;   // chunks per row
         const int nv = tb_h << l2cv, nh = tb_w << l2ch;
@@ -285,7 +261,7 @@ __global__ __launch_bounds__(NT) OV_OCC_ITX void k_itx(ovhip_pic pic, const ovhi
     }
 
     // ---- K1: de-scan + de-quantise into LDS raster [ch][cw] ----
-    if (ablate & 2) {
+    if (!valid || (ablate & 2)) {
     } else if (raster) {
         if (is_tr) {
             // (blocks narrower than 4): transposed, rows padded with zeros to the 4 values a pass step reads
@@ -324,8 +300,7 @@ __global__ __launch_bounds__(NT) OV_OCC_ITX void k_itx(ovhip_pic pic, const ovhi
             }
         }
     }
-    __syncthreads();
-    OV_IPHASE(1);
+    __syncthreads();                                   // barrier 1: tiles staged
 
     ResidualSink sink;
     sink.dst = ov_plane(pic, c.plane, sink.stride) + c.y * sink.stride + c.x;
@@ -334,70 +309,40 @@ __global__ __launch_bounds__(NT) OV_OCC_ITX void k_itx(ovhip_pic pic, const ovhi
     if (c.plane2 != 0xff) sink.dst2 = ov_plane(pic, c.plane2, sink.stride2) + c.y * sink.stride2 + c.x;
     sink.scale = (c.res_mode & OVHIP_RES_SCALE_IDX) ? lmcs_scales[c.c_scale] : c.c_scale;   // device-derived chroma scale (K11)
 
-    if (ablate & 4) continue;
-    if (kind == OVHIP_TB_TR) {
-        int nb_row, nb_col;
+    if (ablate & 4) valid = false;
+    const bool tr = valid && is_tr, lf = tr && (c.lfnst & 1), bd = valid && !is_tr && bdpcm;
+    int nb_row = 0, nb_col = 0;
+    if (tr) {
         if (raster) {
-            const int l2sw = log2_w > 2 ? 3 : 1, l2sh = log2_h > 2 ? 3 : 1;
+            const int l2sw = log2_w > 2 ? 3 : 1;
             nb_col = kv;
             nb_row = (nb_rows_of(c.sig_sb_map) >> 2) << l2sw;
         } else {
             nb_row = nb_rows_of(c.sig_sb_map);
             nb_col = nb_cols_of(c.sig_sb_map);     // rows of the tile that can hold non-zero data
         }
-        // ---- K2: LFNST on the first sub-block (rcn_lfnst.c:41-162) ----
-        if (c.lfnst & 1) {
-            const bool is8 = log2_w >= 3 && log2_h >= 3;
-            const int set = (c.lfnst >> 1) & 3, idx = (c.lfnst >> 3) & 1, tr = (c.lfnst >> 4) & 1;
-            const int8_t *m = is8 ? ovt_lfnst_8x8[set][idx] : ovt_lfnst_4x4[set][idx];
-            const int nout = is8 ? 48 : 16;
-            const int nin = is8 ? 16 : (min(log2_w, 5) == min(log2_h, 5) ? 8 : 16);
-            int out = 0;
-            if (lane < nout) {
-                // diagonal scan of the 4x4 sub-block: constant 0xfbe7ad369c258140 (rcn_lfnst.c:46-53)
-                const uint64_t scan = 0xfbe7ad369c258140ull;
-                int s = 0;
-                for (int j = 0; j < nin; ++j) {
-                    const int pos = (int)((scan >> (4 * j)) & 0xf);
-                    s += (int)s_coef[(pos & 3) * cs + (pos >> 2)] * (int)m[lane + j * nout];
-                }
-                out = ov_clip3((s + 64) >> 7, -(1 << 15), 1 << 15);
-            }
-            __syncthreads();
-            if (lane < nout) {
-                int r, q;
-                if (!is8)           { r = lane >> 2; q = lane & 3; }
-                else if (lane < 32) { r = lane >> 3; q = lane & 7; }
-                else                { r = 4 + ((lane - 32) >> 2); q = lane & 3; }
-                if (tr) { int t = r; r = q; q = t; }
-                s_coef[q * cs + r] = (int16_t)out;
-            }
-            nb_row = 4 << (int)is8;               // rcn_transform_tree.c:474-475
-            nb_col = max(nb_col, nb_row);
-            __syncthreads();
-        }
-        nb_row = min(nb_row, tb_w);
-        const int k1 = min(nb_col, kv);
-        // ---- K3: vertical pass (shift 7) of the coefficient columns i < nb_row:  tmp[row j][i] ----
-        const int ts = tile_stride(kh);
-        if ((nb_row & 3) && lane < tb_h)                     // pass 2 reads 4 values per step: zero the tail of a short row
-            for (int e = nb_row; e < ((nb_row + 3) & ~3); ++e) s_tmp[lane * ts + e] = 0;
-        tr_pass_lds<false, NT>(s_coef, cs, s_mv, msv, log2_h, k1, nb_row, 7, s_tmp, ts, lane, sink);
-        __syncthreads();
-        OV_IPHASE(2);
-        // ---- horizontal pass (shift 20 - bitdepth) fused with K4; columns >= nb_row of tmp are zero: not read ----
-        const int k2 = min(nb_row, kh);
-        tr_pass_lds<true, NT>(s_tmp, ts, s_mh, msh, log2_w, k2, tb_h, 20 - OV_BD, nullptr, 0, lane, sink);
-#ifdef OV_ITX_PHASES
-        { const unsigned long long t_ = __builtin_readcyclecounter(); ph[3] = (unsigned int)(t_ - tprev); tprev = t_; }
-#endif
-        OV_IPHASE_END();
-        continue;
     }
-
-    // ---- block DPCM (rcn_bdpcm_tb, rcn_transform_tree.c:631-688): running sum of the LEVELS along a row / column with
-    // int16 saturation (lane = one row / column: the saturation makes the scan order-dependent), then de-quantisation ----
-    if (bdpcm) {
+    // ---- K2: LFNST on the first sub-block (rcn_lfnst.c:41-162): products first, written back after the barrier ----
+    const bool is8 = log2_w >= 3 && log2_h >= 3;
+    const int nout = is8 ? 48 : 16;
+    int out = 0;
+    if (lf) {
+        const int set = (c.lfnst >> 1) & 3, idx = (c.lfnst >> 3) & 1;
+        const int8_t *m = is8 ? ovt_lfnst_8x8[set][idx] : ovt_lfnst_4x4[set][idx];
+        const int nin = is8 ? 16 : (min(log2_w, 5) == min(log2_h, 5) ? 8 : 16);
+        if (lane < nout) {
+            // diagonal scan of the 4x4 sub-block: constant 0xfbe7ad369c258140 (rcn_lfnst.c:46-53)
+            const uint64_t scan = 0xfbe7ad369c258140ull;
+            int s = 0;
+            for (int j = 0; j < nin; ++j) {
+                const int pos = (int)((scan >> (4 * j)) & 0xf);
+                s += (int)s_coef[(pos & 3) * cs + (pos >> 2)] * (int)m[lane + j * nout];
+            }
+            out = ov_clip3((s + 64) >> 7, -(1 << 15), 1 << 15);
+        }
+    } else if (bd) {
+        // ---- block DPCM (rcn_bdpcm_tb, rcn_transform_tree.c:631-688): running sum of the LEVELS along a row / column with
+        // int16 saturation (lane = one row / column: the saturation makes the scan order-dependent), then de-quantisation ----
         if (c.tr_h == 0) {
             if (lane < tb_h) {
                 int acc = s_coef[lane * tb_w];
@@ -407,11 +352,41 @@ __global__ __launch_bounds__(NT) OV_OCC_ITX void k_itx(ovhip_pic pic, const ovhi
             int acc = s_coef[lane];
             for (int y = 1; y < tb_h; ++y) { acc = ov_clip3(acc + s_coef[y * tb_w + lane], -(1 << 15), (1 << 15) - 1); s_coef[y * tb_w + lane] = (int16_t)acc; }
         }
-        __syncthreads();
-        if (kind == OVHIP_TB_TS)
-            for (int i = lane; i < tb_w * tb_h; i += NT) s_coef[i] = (int16_t)dequant1(s_coef[i], c.dq_scale, c.dq_shift, c.dq_neg);
-        __syncthreads();
     }
+    __syncthreads();                                   // barrier 2
+    if (lf) {
+        const int tr_flag = (c.lfnst >> 4) & 1;
+        if (lane < nout) {
+            int r, q;
+            if (!is8)           { r = lane >> 2; q = lane & 3; }
+            else if (lane < 32) { r = lane >> 3; q = lane & 7; }
+            else                { r = 4 + ((lane - 32) >> 2); q = lane & 3; }
+            if (tr_flag) { int t = r; r = q; q = t; }
+            s_coef[q * cs + r] = (int16_t)out;
+        }
+        nb_row = 4 << (int)is8;               // rcn_transform_tree.c:474-475
+        nb_col = max(nb_col, nb_row);
+    } else if (bd && kind == OVHIP_TB_TS) {
+        for (int i = lane; i < tb_w * tb_h; i += NT) s_coef[i] = (int16_t)dequant1(s_coef[i], c.dq_scale, c.dq_shift, c.dq_neg);
+    }
+    __syncthreads();                                   // barrier 3
+    const int ts = tile_stride(kh);
+    if (tr) {
+        nb_row = min(nb_row, tb_w);
+        const int k1 = min(nb_col, kv);
+        // ---- K3: vertical pass (shift 7) of the coefficient columns i < nb_row:  tmp[row j][i] ----
+        if ((nb_row & 3) && lane < tb_h)                     // pass 2 reads 4 values per step: zero the tail of a short row
+            for (int e = nb_row; e < ((nb_row + 3) & ~3); ++e) s_tmp[lane * ts + e] = 0;
+        tr_pass_lds<false, NT>(s_coef, cs, s_mv, msv, log2_h, k1, nb_row, 7, s_tmp, ts, lane, sink);
+    }
+    __syncthreads();                                   // barrier 4
+    if (tr) {
+        // ---- horizontal pass (shift 20 - bitdepth) fused with K4; columns >= nb_row of tmp are zero: not read ----
+        const int k2 = min(nb_row, kh);
+        tr_pass_lds<true, NT>(s_tmp, ts, s_mh, msh, log2_w, k2, tb_h, 20 - OV_BD, nullptr, 0, lane, sink);
+        return;
+    }
+    if (!valid) return;
 
     // ---- DC shortcut / transform skip: K4 directly ----
     const bool flat = kind == OVHIP_TB_DC;
@@ -440,21 +415,34 @@ __global__ __launch_bounds__(NT) OV_OCC_ITX void k_itx(ovhip_pic pic, const ovhi
             }
         }
     }
-#ifdef OV_ITX_PHASES
-    { const unsigned long long t_ = __builtin_readcyclecounter(); ph[3] = (unsigned int)(t_ - tprev); tprev = t_; }
-#endif
-    OV_IPHASE_END();
+}
+
+// ONE launch for a sorted command list (ovhip_rec_tb_cmds_split): workgroups [0, n_large) take one block of any size
+// each, four waves on it; the next ceil(n_small / 4) take FOUR blocks <= 16x16 each, one per wave, each wave with its own
+// 2.5 KB slice of LDS; n_extra more are the inverse-LMCS rider.  (Big and small blocks used to be two launches: the
+// kernel boundary and the second launch tail cost more than the barriers the small blocks now share.)
+__global__ __launch_bounds__(256) OV_OCC_ITX void k_itx_all(ovhip_pic pic, const ovhip_tb_cmd *__restrict__ cmds, uint32_t n_large,
+                                                  uint32_t n_small, const int16_t *__restrict__ arena,
+                                                  const int16_t *__restrict__ lmcs_scales, int ablate,
+                                                  const uint16_t *__restrict__ lmcs_inv_lut, uint32_t n_extra)
+{
+    __shared__ __attribute__((aligned(16))) int16_t lds[ItxLds<6>::TOTAL];
+    static_assert(4 * ItxLds<4>::TOTAL <= ItxLds<6>::TOTAL && 2048 <= 2 * ItxLds<6>::TOTAL, "slices must fit the big block's tiles");
+    const uint32_t b = blockIdx.x, n_quads = (n_small + 3) >> 2;
+    if (b < n_large) {
+        itx_block<6, 256>(pic, cmds[b], true, arena, lmcs_scales, ablate, threadIdx.x, lds);
+    } else if (b < n_large + n_quads) {
+        const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // wave-uniform: the command stays in SGPRs
+        const uint32_t i = (b - n_large) * 4 + w;
+        const bool valid = i < n_small;
+        itx_block<4, 64>(pic, cmds[n_large + (valid ? i : 0)], valid, arena, lmcs_scales, ablate, threadIdx.x & 63,
+                         lds + w * ItxLds<4>::TOTAL);
+    } else {
+        lmcs_inverse_rows<256>(pic, lmcs_inv_lut, b - n_large - n_quads, n_extra, reinterpret_cast<uint16_t *>(lds));
     }
 }
 
 } // namespace
-
-#ifdef OV_ITX_PHASES
-extern "C" int ovhip_debug_itx_phases(unsigned int *out /* [65536][8] */)
-{
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_itx_phase), sizeof(unsigned int) * OV_ITX_PHASE_UNITS * 8) == hipSuccess ? OVHIP_OK : OVHIP_ELAUNCH;
-}
-#endif
 
 static int itx_ablate()
 {
@@ -466,21 +454,14 @@ static int itx_ablate()
 static int itx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_tb_cmd *d_cmds, uint32_t n_large, uint32_t n_small,
                       const int16_t *d_coefs, const int16_t *d_lmcs_scales, const uint16_t *d_bwd_lut)
 {
-    // one workgroup per TB measured faster than a resident grid-stride grid (79 vs 119 us at 4K; and again with the
-    // next block's loads software-pipelined: the kernels are issue-bound, not latency-bound).  Large blocks go first:
-    // they are the long jobs.
-    if (n_large) {
-        hipLaunchKernelGGL((k_itx<6, 256>), dim3(n_large), dim3(256), 0, ctx->stream, *dst, d_cmds, n_large, d_coefs,
-                           d_lmcs_scales, itx_ablate(), (const uint16_t *)nullptr, 0u);
-        OV_LAUNCH_CHECK(ctx, "k_itx<6,256>");
-    }
-    // the inverse-LMCS rider: two luma rows per workgroup
-    const uint32_t n_extra = d_bwd_lut ? (uint32_t)(dst->h + 1) / 2 : 0;
-    if (n_small + n_extra) {
-        hipLaunchKernelGGL((k_itx<4, 64>), dim3(n_small + n_extra), dim3(64), 0, ctx->stream, *dst, d_cmds + n_large, n_small, d_coefs,
-                           d_lmcs_scales, itx_ablate(), d_bwd_lut, n_extra);
-        OV_LAUNCH_CHECK(ctx, "k_itx<4,64>");
-    }
+    // one workgroup per big block / per four small blocks measured faster than a resident grid-stride grid (79 vs 119 us
+    // at 4K; and again with the next block's loads software-pipelined: the kernel is issue-bound, not latency-bound)
+    const uint32_t n_extra = d_bwd_lut ? (uint32_t)(dst->h + 3) / 4 : 0;      // the inverse-LMCS rider: four luma rows per workgroup
+    const uint32_t grid = n_large + (n_small + 3) / 4 + n_extra;
+    if (!grid) return OVHIP_OK;
+    hipLaunchKernelGGL(k_itx_all, dim3(grid), dim3(256), 0, ctx->stream, *dst, d_cmds, n_large, n_small, d_coefs,
+                       d_lmcs_scales, itx_ablate(), d_bwd_lut, n_extra);
+    OV_LAUNCH_CHECK(ctx, "k_itx_all");
     return OVHIP_OK;
 }
 

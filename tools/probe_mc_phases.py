@@ -34,5 +34,3 @@ probe("mcp", "ovhip_debug_mc_phases",
       ["unit fetch", "window issue", "window wait+park+taps", "H passes", "V+combine (stores issued)", "store drain"])
 probe("mca", "ovhip_debug_mca_phases",
       ["unit fetch", "sub-block MVs", "windows", "H passes", "V + PROF tiles", "PROF + luma store", "chroma + drain"])
-for st in ("itx_l", "itx_c"):
-    probe(st, "ovhip_debug_itx_phases", ["cmd fetch", "cores + de-scan/de-quant", "LFNST + V pass", "H pass + RMW (stores issued)", "store drain"])
