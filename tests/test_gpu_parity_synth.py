@@ -91,3 +91,33 @@ def test_stage_isolated(ctx, stage):
     y, cb, cr = out.download()
     for name, a, b in (("Y", y, after.y), ("Cb", cb, after.cb), ("Cr", cr, after.cr)):
         assert np.array_equal(a, b), f"{stage} plane {name}: {int((a != b).sum())} samples differ"
+
+
+def test_merged_launches_equal_standalone(ctx):
+    """ovhip_mcxa_launch == ovhip_mcx_launch + ovhip_mca_launch, and ovhip_itx_launch_chroma_lmcs ==
+    ovhip_itx_launch_classes(chroma) + ovhip_lmcs_inverse_launch: same picture, same refined MVs."""
+    wl = synth.make_workload(832, 480, 21)
+    rp = engine.ResidentPicture(ctx, wl)          # merged path (what decode() uses when both kinds of unit are present)
+    assert rp.mcx_units and rp.aff_units and rp.lmcs is not None and wl.tb_classes[3]
+    rp.decode(("mc", "itx"))
+    merged = rp.result()
+    mv_merged = rp.refined_mvs().copy()
+    # the same stages through the stand-alone entry points
+    c = rp.ctx
+    c.mc(rp.dst, rp.refs, rp.mc_units, rp.lmcs_fwd, intra=rp.intra)
+    c.mcx(rp.dst, rp.refs, rp.mcx_units, rp.lmcs_fwd, rp.mv_out)
+    c.mca(rp.dst, rp.refs, rp.aff_units, rp.aff_side, rp.lmcs_fwd)
+    if rp.ciip_units:
+        c.ciip(rp.dst, rp.intra, rp.ciip_units)
+    k = wl.tb_classes
+    c.itx_classes(rp.dst, rp.tb_cmds, rp.coefs, 0, k[0], k[1])
+    c.lmcs_scale(rp.dst, rp.lmcs_regions, rp.lmcs, rp.lmcs_scales)
+    c.itx_classes(rp.dst, rp.tb_cmds, rp.coefs, k[0] + k[1], k[2], k[3], rp.lmcs_scales)
+    c.lmcs_inverse(rp.dst, rp.lmcs_bwd)
+    alone = rp.result()
+    for name, a, b in zip("Y Cb Cr".split(), merged, alone):
+        assert np.array_equal(a, b), f"plane {name}: {int((a != b).sum())} samples differ"
+    assert np.array_equal(mv_merged, rp.refined_mvs())
+    ref = oracle_pipeline.decode(wl, stages=("mc", "itx"))
+    assert np.array_equal(alone[0], ref.y) and np.array_equal(alone[1], ref.cb) and np.array_equal(alone[2], ref.cr)
+    rp.free()
