@@ -41,6 +41,32 @@ __device__ __forceinline__ int alf_clipd(int clip, int ref, int a, int b)
     return ov_clip3(a - ref, -clip, clip) + ov_clip3(b - ref, -clip, clip);
 }
 
+// ---- packed form of one filter tap.  The two neighbours of a symmetric tap are picked out of the row-group registers
+// straight into one dword (v_perm_b32); difference to the centre sample, both clips and the multiply-accumulate are
+// then one packed instruction each (v_pk_sub_i16, v_pk_max_i16, v_pk_min_i16, v_dot2_i32_i16): 5 instructions per
+// tap and sample instead of 8.  Differences of 10-bit samples and clip values up to 1 << 10 fit int16. ----
+typedef short alf_s2 __attribute__((ext_vector_type(2)));
+// group dword / half of column c: 6-dword groups start at column -4, 2-dword groups at column 0
+#define A6I(c) (((c) + 4) >> 1)
+#define A6H(c) (((c) + 4) & 1)
+#define A2I(c) ((c) >> 1)
+#define A2H(c) ((c) & 1)
+// low half = half ha of dword da, high half = half hb of dword db
+#define ALF_PK(da, ha, db, hb) __builtin_amdgcn_perm((db), (da), (uint32_t)((2 * (ha)) | ((2 * (ha) + 1) << 8) | ((4 + 2 * (hb)) << 16) | ((5 + 2 * (hb)) << 24)))
+#define ALF_PK66(A, ca, B, cb) ALF_PK((A)[A6I(ca)], A6H(ca), (B)[A6I(cb)], A6H(cb))
+#define ALF_PK22(A, ca, B, cb) ALF_PK((A)[A2I(ca)], A2H(ca), (B)[A2I(cb)], A2H(cb))
+__device__ __forceinline__ uint32_t alf_dup(int v) { return __builtin_amdgcn_perm((uint32_t)v, (uint32_t)v, 0x01000100u); }   // (v, v) as int16 pair
+__device__ __forceinline__ int alf_tap(uint32_t pair, uint32_t cur2, uint32_t c2, uint32_t nc2, uint32_t f2, int sum)
+{
+    alf_s2 d = __builtin_bit_cast(alf_s2, pair) - __builtin_bit_cast(alf_s2, cur2);
+    d = __builtin_elementwise_min(__builtin_elementwise_max(d, __builtin_bit_cast(alf_s2, nc2)), __builtin_bit_cast(alf_s2, c2));
+    return __builtin_amdgcn_sdot2(d, __builtin_bit_cast(alf_s2, f2), sum, false);
+}
+__device__ __forceinline__ int alf_tap_lin(uint32_t pair, uint32_t f2, int sum)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(alf_s2, pair), __builtin_bit_cast(alf_s2, f2), sum, false);
+}
+
 // alf_derive_filter_idx, rcn_alf.c:283-345
 __device__ __forceinline__ void filter_idx(uint32_t sum_h, uint32_t sum_v, uint32_t sum_d, uint32_t sum_b, bool is_vb,
                                            int &cls, int &tr)
@@ -135,17 +161,23 @@ __device__ __forceinline__ void alf_luma_tile(const ovhip_pic &dst, const ovhip_
                 d6[0] = a.x; d6[1] = a.y; d6[2] = b_.x; d6[3] = b_.y; d6[4] = c_.x; d6[5] = c_.y;
             };
             row3(above, ra); row3(rr, r0); row3(rr + 1, r1); row3(below, rb);
-#define S6(d6, c) ((((c) + 4) & 1) ? (int)((d6)[((c) + 4) >> 1] >> 16) : (int)((d6)[((c) + 4) >> 1] & 0xffff))
+            // The two Laplacian positions of a step, (rr, c0) and (rr + 1, c0 + 1), ride in one dword: per direction the
+            // neighbour sums are one v_pk_add_u16 and both |2 c - a - b| terms one v_sad_u16 that accumulates (all < 2^16).
+            typedef unsigned short alf_u2 __attribute__((ext_vector_type(2)));
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int c0 = 2 * q - 2, c1 = c0 + 1;             // columns relative to the block
-                const int y1 = S6(r0, c0) << 1, y2 = S6(r1, c1) << 1;
-                sv += abs(y1 - S6(ra, c0) - S6(r1, c0)) + abs(y2 - S6(r0, c1) - S6(rb, c1));
-                sh += abs(y1 - S6(r0, c0 + 1) - S6(r0, c0 - 1)) + abs(y2 - S6(r1, c1 + 1) - S6(r1, c1 - 1));
-                sd += abs(y1 - S6(ra, c0 - 1) - S6(r1, c0 + 1)) + abs(y2 - S6(r0, c1 - 1) - S6(rb, c1 + 1));
-                sb += abs(y1 - S6(r1, c0 - 1) - S6(ra, c0 + 1)) + abs(y2 - S6(rb, c1 - 1) - S6(r0, c1 + 1));
+                const alf_u2 ctr = __builtin_bit_cast(alf_u2, ALF_PK66(r0, c0, r1, c1));
+                const uint32_t y2 = __builtin_bit_cast(uint32_t, ctr + ctr);
+#define LAP(acc, A, ca, B, cb, C, cc_, D, cd)                                                                      \
+                acc = __builtin_amdgcn_sad_u16(y2, __builtin_bit_cast(uint32_t, __builtin_bit_cast(alf_u2, ALF_PK66(A, ca, B, cb)) + \
+                                                                               __builtin_bit_cast(alf_u2, ALF_PK66(C, cc_, D, cd))), acc)
+                LAP(sv, ra, c0, r0, c1, r1, c0, rb, c1);
+                LAP(sh, r0, c0 + 1, r1, c1 + 1, r0, c0 - 1, r1, c1 - 1);
+                LAP(sd, ra, c0 - 1, r0, c1 - 1, r1, c0 + 1, rb, c1 + 1);
+                LAP(sb, r1, c0 - 1, rb, c1 - 1, ra, c0 + 1, r0, c1 + 1);
+#undef LAP
             }
-#undef S6
         }
         // which pairs count: all four, or three next to the virtual boundary (rcn_alf.c:520-583)
         const int py = ty0 + cby;
@@ -214,39 +246,37 @@ __device__ __forceinline__ void alf_luma_tile(const ovhip_pic &dst, const ovhip_
 #pragma unroll
     for (int i = 0; i < 12; ++i) fsum += fc[i];
     const bool linear = __all(cmin > OV_PIX_MAX);
+    uint32_t f2[12], c2[12], nc2[12];                    // (f, f), (clip, clip), (-clip, -clip) as int16 pairs
+#pragma unroll
+    for (int i = 0; i < 12; ++i) f2[i] = alf_dup(fc[i]);
+    if (!linear) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            c2[i] = alf_dup(cc[i]);
+            nc2[i] = __builtin_bit_cast(uint32_t, (alf_s2)(0) - __builtin_bit_cast(alf_s2, c2[i]));
+        }
+    }
     int outv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int cur = S6(r0, i);
+        // the 12 symmetric neighbour pairs of sample i (same taps as alf_clipd's arguments above)
+        const uint32_t n[12] = {
+            ALF_PK22(p3, i, m3, i),
+            ALF_PK66(p2, i + 1, m2, i - 1), ALF_PK66(p2, i, m2, i), ALF_PK66(p2, i - 1, m2, i + 1),
+            ALF_PK66(p1, i + 2, m1, i - 2), ALF_PK66(p1, i + 1, m1, i - 1), ALF_PK66(p1, i, m1, i),
+            ALF_PK66(p1, i - 1, m1, i + 1), ALF_PK66(p1, i - 2, m1, i + 2),
+            ALF_PK66(r0, i + 3, r0, i - 3), ALF_PK66(r0, i + 2, r0, i - 2), ALF_PK66(r0, i + 1, r0, i - 1) };
         int sum;
         if (linear) {
             sum = -2 * cur * fsum;
-            sum += fc[0] * (S2(p3, i) + S2(m3, i));
-            sum += fc[1] * (S6(p2, i + 1) + S6(m2, i - 1));
-            sum += fc[2] * (S6(p2, i) + S6(m2, i));
-            sum += fc[3] * (S6(p2, i - 1) + S6(m2, i + 1));
-            sum += fc[4] * (S6(p1, i + 2) + S6(m1, i - 2));
-            sum += fc[5] * (S6(p1, i + 1) + S6(m1, i - 1));
-            sum += fc[6] * (S6(p1, i) + S6(m1, i));
-            sum += fc[7] * (S6(p1, i - 1) + S6(m1, i + 1));
-            sum += fc[8] * (S6(p1, i - 2) + S6(m1, i + 2));
-            sum += fc[9] * (S6(r0, i + 3) + S6(r0, i - 3));
-            sum += fc[10] * (S6(r0, i + 2) + S6(r0, i - 2));
-            sum += fc[11] * (S6(r0, i + 1) + S6(r0, i - 1));
+#pragma unroll
+            for (int k = 0; k < 12; ++k) sum = alf_tap_lin(n[k], f2[k], sum);
         } else {
+            const uint32_t cur2 = ALF_PK66(r0, i, r0, i);
             sum = 0;
-            sum += fc[0] * alf_clipd(cc[0], cur, S2(p3, i), S2(m3, i));
-            sum += fc[1] * alf_clipd(cc[1], cur, S6(p2, i + 1), S6(m2, i - 1));
-            sum += fc[2] * alf_clipd(cc[2], cur, S6(p2, i), S6(m2, i));
-            sum += fc[3] * alf_clipd(cc[3], cur, S6(p2, i - 1), S6(m2, i + 1));
-            sum += fc[4] * alf_clipd(cc[4], cur, S6(p1, i + 2), S6(m1, i - 2));
-            sum += fc[5] * alf_clipd(cc[5], cur, S6(p1, i + 1), S6(m1, i - 1));
-            sum += fc[6] * alf_clipd(cc[6], cur, S6(p1, i), S6(m1, i));
-            sum += fc[7] * alf_clipd(cc[7], cur, S6(p1, i - 1), S6(m1, i + 1));
-            sum += fc[8] * alf_clipd(cc[8], cur, S6(p1, i - 2), S6(m1, i + 2));
-            sum += fc[9] * alf_clipd(cc[9], cur, S6(r0, i + 3), S6(r0, i - 3));
-            sum += fc[10] * alf_clipd(cc[10], cur, S6(r0, i + 2), S6(r0, i - 2));
-            sum += fc[11] * alf_clipd(cc[11], cur, S6(r0, i + 1), S6(r0, i - 1));
+#pragma unroll
+            for (int k = 0; k < 12; ++k) sum = alf_tap(n[k], cur2, c2[k], nc2[k], f2[k], sum);
         }
         sum = near ? (sum + 512) >> 10 : (sum + 64) >> 7;
         outv[i] = ov_clip_bd(sum + cur);
@@ -359,6 +389,13 @@ __device__ __forceinline__ void alf_chroma_tile(const ovhip_pic &dst, const ovhi
         for (int i = 0; i < 6; ++i) { cmin = min(cmin, cl[i]); fsum += fc[i]; }
     }
     const bool linear = on && cmin > OV_PIX_MAX;                     // `on`, the filter and its clips are workgroup-uniform
+    uint32_t f2[6], c2[6], nc2[6];                                   // (f, f), (clip, clip), (-clip, -clip) as int16 pairs
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        f2[i] = alf_dup(fc[i]);
+        c2[i] = alf_dup(cl[i]);
+        nc2[i] = __builtin_bit_cast(uint32_t, (alf_s2)(0) - __builtin_bit_cast(alf_s2, c2[i]));
+    }
 #define S6(d6, c) ((((c) + 4) & 1) ? (int)((d6)[((c) + 4) >> 1] >> 16) : (int)((d6)[((c) + 4) >> 1] & 0xffff))
 #define S2(d2, c) (((c) & 1) ? (int)((d2)[(c) >> 1] >> 16) : (int)((d2)[(c) >> 1] & 0xffff))
     int outv[4];
@@ -369,22 +406,18 @@ __device__ __forceinline__ void alf_chroma_tile(const ovhip_pic &dst, const ovhi
         if (on) {
             const int cur = S6(r0, i);
             int sum;
+            const uint32_t n[6] = { ALF_PK22(p2, i, m2, i),
+                                    ALF_PK66(p1, i + 1, m1, i - 1), ALF_PK66(p1, i, m1, i), ALF_PK66(p1, i - 1, m1, i + 1),
+                                    ALF_PK66(r0, i + 2, r0, i - 2), ALF_PK66(r0, i + 1, r0, i - 1) };
             if (linear) {
                 sum = -2 * cur * fsum;
-                sum += fc[0] * (S2(p2, i) + S2(m2, i));
-                sum += fc[1] * (S6(p1, i + 1) + S6(m1, i - 1));
-                sum += fc[2] * (S6(p1, i) + S6(m1, i));
-                sum += fc[3] * (S6(p1, i - 1) + S6(m1, i + 1));
-                sum += fc[4] * (S6(r0, i + 2) + S6(r0, i - 2));
-                sum += fc[5] * (S6(r0, i + 1) + S6(r0, i - 1));
+#pragma unroll
+                for (int k = 0; k < 6; ++k) sum = alf_tap_lin(n[k], f2[k], sum);
             } else {
+                const uint32_t cur2 = ALF_PK66(r0, i, r0, i);
                 sum = 0;
-                sum += fc[0] * alf_clipd(cl[0], cur, S2(p2, i), S2(m2, i));
-                sum += fc[1] * alf_clipd(cl[1], cur, S6(p1, i + 1), S6(m1, i - 1));
-                sum += fc[2] * alf_clipd(cl[2], cur, S6(p1, i), S6(m1, i));
-                sum += fc[3] * alf_clipd(cl[3], cur, S6(p1, i - 1), S6(m1, i + 1));
-                sum += fc[4] * alf_clipd(cl[4], cur, S6(r0, i + 2), S6(r0, i - 2));
-                sum += fc[5] * alf_clipd(cl[5], cur, S6(r0, i + 1), S6(r0, i - 1));
+#pragma unroll
+                for (int k = 0; k < 6; ++k) sum = alf_tap(n[k], cur2, c2[k], nc2[k], f2[k], sum);
             }
             sum = near ? (sum + 512) >> 10 : (sum + 64) >> 7;
             out = ov_clip_bd(sum + cur);
