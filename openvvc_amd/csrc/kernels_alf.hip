@@ -204,9 +204,12 @@ __device__ __forceinline__ void alf_luma_tile(const ovhip_pic &dst, const ovhip_
     const int cls = ct & 31, tr = ct >> 5;
     const int16_t *f = alf.luma_coeff + c.luma_set * OVHIP_ALF_LUMA_SET_SIZE + tr * 25 * 13 + cls * 13;
     const int16_t *cl = alf.luma_clip + c.luma_set * OVHIP_ALF_LUMA_SET_SIZE + tr * 25 * 13 + cls * 13;
-    int fc[12], cc[12];
+    // the 12 coefficients / clip values of the class as 6 dwords each (rows of 13 int16 are only 2-byte aligned: the
+    // loads are unaligned dword loads, which gfx9 global memory supports)
+    typedef uint32_t alf_u32a2 __attribute__((aligned(2)));
+    uint32_t fw[6], cw6[6];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) { fc[i] = f[i]; cc[i] = cl[i]; }
+    for (int j = 0; j < 6; ++j) { fw[j] = *reinterpret_cast<const alf_u32a2 *>(f + 2 * j); cw6[j] = *reinterpret_cast<const alf_u32a2 *>(cl + 2 * j); }
 
     int d = 3;
     bool near = false;
@@ -240,21 +243,26 @@ __device__ __forceinline__ void alf_luma_tile(const ovhip_pic &dst, const ovhip_
     // Clip value 1 << bitdepth never clips a 10-bit difference: filter sets without non-linear clipping (the 16
     // fixed sets, APS sets with alf_luma_clip_flag = 0, rcn_alf.c:196-240) take the linear form
     //   sum_i f_i * (a_i + b_i) - 2 * cur * sum_i f_i   (same integers, a third of the arithmetic)
-    int cmin = cc[0], fsum = 0;
+    alf_s2 cm2 = __builtin_bit_cast(alf_s2, cw6[0]);
+    int fsum = 0;
 #pragma unroll
-    for (int i = 1; i < 12; ++i) cmin = min(cmin, cc[i]);
+    for (int j = 1; j < 6; ++j) cm2 = __builtin_elementwise_min(cm2, __builtin_bit_cast(alf_s2, cw6[j]));
 #pragma unroll
-    for (int i = 0; i < 12; ++i) fsum += fc[i];
+    for (int j = 0; j < 6; ++j) fsum = __builtin_amdgcn_sdot2(__builtin_bit_cast(alf_s2, fw[j]), (alf_s2)(1), fsum, false);
+    const int cmin = min((int)cm2.x, (int)cm2.y);
     const bool linear = __all(cmin > OV_PIX_MAX);
     uint32_t f2[12], c2[12], nc2[12];                    // (f, f), (clip, clip), (-clip, -clip) as int16 pairs
 #pragma unroll
-    for (int i = 0; i < 12; ++i) f2[i] = alf_dup(fc[i]);
+    for (int j = 0; j < 6; ++j) {
+        f2[2 * j] = __builtin_amdgcn_perm(fw[j], fw[j], 0x01000100u); f2[2 * j + 1] = __builtin_amdgcn_perm(fw[j], fw[j], 0x03020302u);
+    }
     if (!linear) {
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            c2[i] = alf_dup(cc[i]);
-            nc2[i] = __builtin_bit_cast(uint32_t, (alf_s2)(0) - __builtin_bit_cast(alf_s2, c2[i]));
+        for (int j = 0; j < 6; ++j) {
+            c2[2 * j] = __builtin_amdgcn_perm(cw6[j], cw6[j], 0x01000100u); c2[2 * j + 1] = __builtin_amdgcn_perm(cw6[j], cw6[j], 0x03020302u);
         }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) nc2[i] = __builtin_bit_cast(uint32_t, (alf_s2)(0) - __builtin_bit_cast(alf_s2, c2[i]));
     }
     int outv[4];
 #pragma unroll
