@@ -429,11 +429,13 @@ __global__ __launch_bounds__(256) OV_OCC_ITX void k_itx_all(ovhip_pic pic, const
     __shared__ __attribute__((aligned(16))) int16_t lds[ItxLds<6>::TOTAL];
     static_assert(4 * ItxLds<4>::TOTAL <= ItxLds<6>::TOTAL && 2048 <= 2 * ItxLds<6>::TOTAL, "slices must fit the big block's tiles");
     const uint32_t b = blockIdx.x, n_quads = (n_small + 3) >> 2;
+    // XCD-aware order (see k_mc2): each XCD takes a contiguous chunk of the sorted list, so blocks that share frame
+    // cache lines meet in one L2
     if (b < n_large) {
-        itx_block<6, 256>(pic, cmds[b], true, arena, lmcs_scales, ablate, threadIdx.x, lds);
+        itx_block<6, 256>(pic, cmds[ov_xcd_slot(b, n_large)], true, arena, lmcs_scales, ablate, threadIdx.x, lds);
     } else if (b < n_large + n_quads) {
         const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // wave-uniform: the command stays in SGPRs
-        const uint32_t i = (b - n_large) * 4 + w;
+        const uint32_t i = ov_xcd_slot(b - n_large, n_quads) * 4 + w;
         const bool valid = i < n_small;
         itx_block<4, 64>(pic, cmds[n_large + (valid ? i : 0)], valid, arena, lmcs_scales, ablate, threadIdx.x & 63,
                          lds + w * ItxLds<4>::TOTAL);
