@@ -121,3 +121,25 @@ def test_merged_launches_equal_standalone(ctx):
     ref = oracle_pipeline.decode(wl, stages=("mc", "itx"))
     assert np.array_equal(alone[0], ref.y) and np.array_equal(alone[1], ref.cb) and np.array_equal(alone[2], ref.cr)
     rp.free()
+
+
+def test_two_pictures_in_flight(built_lib):
+    """Two contexts on two streams, launches interleaved picture by picture (bench.py's default mode): both pictures
+    equal the oracle -- the engine keeps no state outside the context and the picture's own buffers."""
+    import torch
+    dev = torch.device("cuda", 0)
+    streams = [torch.cuda.Stream(dev) for _ in range(2)]
+    ctxs = [engine.Context(0, stream=s.cuda_stream) for s in streams]
+    wls = [synth.make_workload(832, 480, 31), synth.make_workload(832, 480, 32)]
+    rps = [engine.ResidentPicture(c, w) for c, w in zip(ctxs, wls)]
+    for _ in range(3):                                    # several rounds back to back, no synchronisation in between
+        for rp in rps:
+            rp.decode()
+    torch.cuda.synchronize()
+    for rp, wl in zip(rps, wls):
+        y, cb, cr = rp.result()
+        ref = oracle_pipeline.decode(wl)
+        assert np.array_equal(y, ref.y) and np.array_equal(cb, ref.cb) and np.array_equal(cr, ref.cr)
+        rp.free()
+    for c in ctxs:
+        c.close()
