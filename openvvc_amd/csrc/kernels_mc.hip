@@ -175,14 +175,14 @@ __global__ __launch_bounds__(64) OV_OCC_MC void k_mc2(ovhip_pic dst, RefTable re
     for (int l = 0; l < 2; ++l) {
         const int mvx = l ? u.mv1x : u.mv0x, mvy = l ? u.mv1y : u.mv0y;
         int fx = mvx & 15, fy = mvy & 15;
-        const int8_t *fh, *fv;
-        if (u.flags & OVHIP_MC_FILT_4x4) { fh = ovt_mc_luma4[fx]; fv = ovt_mc_luma4[fy]; }
+        const uint32_t *fh, *fv;
+        if (u.flags & OVHIP_MC_FILT_4x4) { fh = g_taps.luma4[fx]; fv = g_taps.luma4[fy]; }
         else {
             if (u.flags & OVHIP_MC_HPEL_FILT) { if (fx == 8) fx = 16; if (fy == 8) fy = 16; }
-            fh = ovt_mc_luma[fx]; fv = ovt_mc_luma[fy];
+            fh = g_taps.luma[fx]; fv = g_taps.luma[fy];
         }
-        pack_taps<8>(fh, thl[l]); pack_taps<8>(fv, tvl[l]);
-        pack_taps<4>(ovt_mc_chroma[mvx & 31], thc[l]); pack_taps<4>(ovt_mc_chroma[mvy & 31], tvc[l]);
+        load_taps<4>(fh, thl[l]); load_taps<4>(fv, tvl[l]);
+        load_taps<2>(g_taps.chroma[mvx & 31], thc[l]); load_taps<2>(g_taps.chroma[mvy & 31], tvc[l]);
         identl[l] = fx == 0; identc[l] = (mvx & 31) == 0;
     }
     __syncthreads();

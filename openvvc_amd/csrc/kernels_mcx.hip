@@ -264,7 +264,7 @@ __device__ __forceinline__ void mcx_units(const ovhip_pic &dst, const RefTable &
     }
 
     // ---- 3. horizontal passes at the refined position: both lists (and both chroma planes) in one task loop ----
-    const int8_t *fvl[2];
+    const uint32_t *fvl[2];
     int ldx[2], ldy[2], cdx[2], cdy[2], ext[2][2];
     int thl[2][4], thc[2][2], tvc[2][2];
     bool identl[2], identc[2];
@@ -273,11 +273,11 @@ __device__ __forceinline__ void mcx_units(const ovhip_pic &dst, const RefTable &
         int fx = mv[l][0] & 15, fy = mv[l][1] & 15;
         if (u.flags & OVHIP_MC_HPEL_FILT) { if (fx == 8) fx = 16; if (fy == 8) fy = 16; }
         ext[l][0] = fx >= 8; ext[l][1] = fy >= 8;
-        fvl[l] = ovt_mc_luma[fy];
+        fvl[l] = g_taps.luma[fy];
         ldx[l] = (mv[l][0] >> 4) - (ini[l][0] >> 4); ldy[l] = (mv[l][1] >> 4) - (ini[l][1] >> 4);
         cdx[l] = (mv[l][0] >> 5) - (ini[l][0] >> 5); cdy[l] = (mv[l][1] >> 5) - (ini[l][1] >> 5);
-        pack_taps<8>(ovt_mc_luma[fx], thl[l]);
-        pack_taps<4>(ovt_mc_chroma[mv[l][0] & 31], thc[l]); pack_taps<4>(ovt_mc_chroma[mv[l][1] & 31], tvc[l]);
+        load_taps<4>(g_taps.luma[fx], thl[l]);
+        load_taps<2>(g_taps.chroma[mv[l][0] & 31], thc[l]); load_taps<2>(g_taps.chroma[mv[l][1] & 31], tvc[l]);
         identl[l] = fx == 0; identc[l] = (mv[l][0] & 31) == 0;
     }
     if (do_l) {
@@ -626,7 +626,7 @@ __device__ __forceinline__ void mca_units(const ovhip_pic &dst, const RefTable &
         __syncthreads();
         if (on) {
             int tp[3];
-            pack_taps<6>(ovt_mc_luma4[mvx & 15] + 1, tp);
+            load_taps<3>(g_taps.luma6[mvx & 15], tp);
             for (int r = c; r < 9; r += 4) {
                 int d[5], out[4];
                 load_row_at<6>(s_win[sb] + r * AWS, off, d);
@@ -638,7 +638,7 @@ __device__ __forceinline__ void mca_units(const ovhip_pic &dst, const RefTable &
         if (l == 0 && cact) {
             const int cmvx = cl ? cm.z : cm.x;
             int tp[2];
-            pack_taps<4>(ovt_mc_chroma[cmvx & 31], tp);
+            load_taps<2>(g_taps.chroma[cmvx & 31], tp);
             for (int r = cc; r < 7; r += 4) {
                 int d[4], out[4];
                 load_row_at<4>(s_cwin[cl][cwi] + r * ACS, coff, d);
@@ -650,7 +650,7 @@ __device__ __forceinline__ void mca_units(const ovhip_pic &dst, const RefTable &
         __syncthreads();
         if (on) {
             int tp[3], d[5];
-            pack_taps<6>(ovt_mc_luma4[mvy & 15] + 1, tp);
+            load_taps<3>(g_taps.luma6[mvy & 15], tp);
             const int *q = reinterpret_cast<const int *>(s_ht[sb] + c * AHS);
 #pragma unroll
             for (int j = 0; j < 5; ++j) d[j] = q[j];
@@ -707,7 +707,7 @@ __device__ __forceinline__ void mca_units(const ovhip_pic &dst, const RefTable &
             if (!(u.dir & (1 << l))) continue;
             const int mvy = l ? cm.w : cm.y;
             int tp[2], d[4];
-            pack_taps<4>(ovt_mc_chroma[mvy & 31], tp);
+            load_taps<2>(g_taps.chroma[mvy & 31], tp);
             const int *q = reinterpret_cast<const int *>(s_cht[l][cwi] + cc * ACHS);
 #pragma unroll
             for (int j = 0; j < 4; ++j) d[j] = q[j];

@@ -202,6 +202,34 @@ __device__ __forceinline__ void pack_taps(const int8_t *f, int tp[NT / 2])
     for (int m = 0; m < NT / 2; ++m) tp[m] = ((int)f[2 * m] & 0xffff) | ((int)f[2 * m + 1] << 16);
 }
 
+// The same pairs ((f[2m], f[2m+1]) as int16 halves of one dword, what v_dot2_i32_i16 multiplies), packed at COMPILE time:
+// a wave-uniform filter is then one scalar load instead of 8 byte loads, 8 sign extensions and 12 shift / or (the tap
+// set-up was a fifth of k_mc2's scalar instructions).  luma6 = the 6 taps 1..6 of the 4x4-block luma filter.
+struct PackedTaps { uint32_t luma[17][4], luma4[16][4], luma6[16][4], chroma[32][2]; };
+constexpr uint32_t pack_pair(int a, int b) { return ((uint32_t)a & 0xffffu) | ((uint32_t)b << 16); }
+constexpr PackedTaps build_packed_taps()
+{
+    PackedTaps t{};
+    for (int f = 0; f < 17; ++f)
+        for (int m = 0; m < 4; ++m) t.luma[f][m] = pack_pair(ovt_mc_luma[f][2 * m], ovt_mc_luma[f][2 * m + 1]);
+    for (int f = 0; f < 16; ++f)
+        for (int m = 0; m < 4; ++m) {
+            t.luma4[f][m] = pack_pair(ovt_mc_luma4[f][2 * m], ovt_mc_luma4[f][2 * m + 1]);
+            t.luma6[f][m] = m < 3 ? pack_pair(ovt_mc_luma4[f][2 * m + 1], ovt_mc_luma4[f][2 * m + 2]) : 0u;
+        }
+    for (int f = 0; f < 32; ++f)
+        for (int m = 0; m < 2; ++m) t.chroma[f][m] = pack_pair(ovt_mc_chroma[f][2 * m], ovt_mc_chroma[f][2 * m + 1]);
+    return t;
+}
+__device__ const PackedTaps __attribute__((aligned(16))) g_taps = build_packed_taps();
+
+template <int ND>
+__device__ __forceinline__ void load_taps(const uint32_t *row, int tp[ND])
+{
+#pragma unroll
+    for (int m = 0; m < ND; ++m) tp[m] = (int)row[m];
+}
+
 template <int NT>
 __device__ __forceinline__ void load_row(const void *p, int d[NT / 2 + 2])
 {
@@ -233,10 +261,10 @@ __device__ __forceinline__ void load_row_at(const uint16_t *row, int s0, int d[N
 // ---- stage 3: vertical pass LDS -> registers.  Lane = one column x 4 consecutive rows (group g):
 // P[j] = F_v(t)[x][4g + j] >> 6, the 14-bit intermediate of put_vvc_{qpel,epel}_*. ----
 template <int NT>
-__device__ __forceinline__ void v_pass(const int16_t *s_ht, int htstride, int log2w, int h, const int8_t *fv, int lane, int P[4])
+__device__ __forceinline__ void v_pass(const int16_t *s_ht, int htstride, int log2w, int h, const uint32_t *fv_packed, int lane, int P[4])
 {
     int tp[NT / 2];
-    pack_taps<NT>(fv, tp);
+    load_taps<NT / 2>(fv_packed, tp);
     const int w = 1 << log2w;
     const int ngrp = (h + 3) >> 2;
     if (lane < (ngrp << log2w)) {

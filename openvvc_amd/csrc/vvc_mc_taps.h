@@ -12,9 +12,16 @@
 #ifndef OVT_ATTR
 #define OVT_ATTR
 #endif
+#ifndef OVT_CONST
+#ifdef __cplusplus
+#define OVT_CONST static constexpr /* the device derives its packed tap tables at compile time */
+#else
+#define OVT_CONST static const
+#endif
+#endif
 
 /* luma, 8 taps at integer offsets -3..+4, index = 1/16 fraction (16 = half-pel smoothing) */
-OVT_ATTR static const int8_t ovt_mc_luma[17][8] = {
+OVT_ATTR OVT_CONST int8_t ovt_mc_luma[17][8] = {
     {  0, 0,   0, 64,  0,   0, 0,  0 },
     {  0, 1,  -3, 63,  4,  -2, 1,  0 },
     { -1, 2,  -5, 62,  8,  -3, 1,  0 },
@@ -35,7 +42,7 @@ OVT_ATTR static const int8_t ovt_mc_luma[17][8] = {
 };
 
 /* luma 4x4 blocks (affine sub-blocks): 6-tap variants */
-OVT_ATTR static const int8_t ovt_mc_luma4[16][8] = {
+OVT_ATTR OVT_CONST int8_t ovt_mc_luma4[16][8] = {
     { 0, 0,   0, 64,  0,   0, 0, 0 },
     { 0, 1,  -3, 63,  4,  -2, 1, 0 },
     { 0, 1,  -5, 62,  8,  -3, 1, 0 },
@@ -55,7 +62,7 @@ OVT_ATTR static const int8_t ovt_mc_luma4[16][8] = {
 };
 
 /* chroma, 4 taps at offsets -1..+2, index = 1/32 fraction */
-OVT_ATTR static const int8_t ovt_mc_chroma[32][4] = {
+OVT_ATTR OVT_CONST int8_t ovt_mc_chroma[32][4] = {
     {  0, 64,  0,  0 }, { -1, 63,  2,  0 }, { -2, 62,  4,  0 }, { -2, 60,  7, -1 },
     { -2, 58, 10, -2 }, { -3, 57, 12, -2 }, { -4, 56, 14, -2 }, { -4, 55, 15, -2 },
     { -4, 54, 16, -2 }, { -5, 53, 18, -2 }, { -6, 52, 20, -2 }, { -6, 49, 24, -3 },
