@@ -39,12 +39,19 @@ __device__ __forceinline__ int mc_gpm(uint32_t aux, int x, int y, int p0, int p1
     return ov_clip_bd((p1 * (8 - wgt) + p0 * wgt + 64) >> 7);
 }
 
-__device__ __forceinline__ int mc_combine(const ovhip_mc_unit &u, int p0, int p1)
+// uni (p + 8) >> 4, bi average (p0 + p1 + 16) >> 5, BCW (p1 w1 + p0 w0 + 64) >> 7 (put_vvc_uni/bi(_w)_*): one
+// weighted form whose constants are chosen ONCE per unit -- per-sample three-way branches on wave-uniform unit
+// fields cost scalar issue slots, which is what bounds this kernel
+struct Combine { int a0, a1, rnd, sh; };
+__device__ __forceinline__ Combine mc_combine_of(const ovhip_mc_unit &u)
 {
-    if (u.dir != 3)                  return ov_clip_bd(((u.dir == 1 ? p0 : p1) + 8) >> 4);
-    if (u.w0 == 4 && u.w1 == 4)      return ov_clip_bd((p0 + p1 + 16) >> 5);
-    return ov_clip_bd((p1 * u.w1 + p0 * u.w0 + 64) >> 7);
+    Combine c;
+    if (u.dir != 3)                 { c.a0 = u.dir == 1; c.a1 = u.dir != 1; c.rnd = 8; c.sh = 4; }
+    else if (u.w0 == 4 && u.w1 == 4) { c.a0 = 1; c.a1 = 1; c.rnd = 16; c.sh = 5; }
+    else                            { c.a0 = u.w0; c.a1 = u.w1; c.rnd = 64; c.sh = 7; }
+    return c;
 }
+__device__ __forceinline__ int mc_combine(const Combine &c, int p0, int p1) { return ov_clip_bd((p1 * c.a1 + p0 * c.a0 + c.rnd) >> c.sh); }
 
 // =====================================================================================================
 // k_mc2 (the first version, k_mc, ran one pass per list and per plane with 4 rows per lane: SQ counters showed it
@@ -74,13 +81,27 @@ __device__ __forceinline__ void luma_finish(const ovhip_mc_unit &u, const ovhip_
         if (u.dir & (1 << l)) v_outputs<8, NOUT>(s_hl + l * 16 * HLS + x * HLS, y0, tv[l], P[l]);
     }
     uint16_t *d = dst.y + (u.y + y0) * dst.stride_y + u.x + x;
+    // every wave-uniform decision once, not once per sample
+    int v[NOUT];
+    if (u.flags & OVHIP_MC_GPM) {
 #pragma unroll
-    for (int j = 0; j < NOUT; ++j) {
-        int v = (u.flags & OVHIP_MC_GPM) ? mc_gpm(u.aux, x, y0 + j, P[0][j], P[1][j]) : mc_combine(u, P[0][j], P[1][j]);
-        if ((u.flags & OVHIP_MC_LMCS) && lmcs_fwd) v = lmcs_fwd[v];
-        if (!(u.flags & OVHIP_MC_GPM) && u.aux) v = ciip_blend(v, intra.y[(u.y + y0 + j) * intra.stride_y + u.x + x], u.aux & 7);
-        d[j * dst.stride_y] = (uint16_t)v;
+        for (int j = 0; j < NOUT; ++j) v[j] = mc_gpm(u.aux, x, y0 + j, P[0][j], P[1][j]);
+    } else {
+        const Combine cmb = mc_combine_of(u);
+#pragma unroll
+        for (int j = 0; j < NOUT; ++j) v[j] = mc_combine(cmb, P[0][j], P[1][j]);
     }
+    if ((u.flags & OVHIP_MC_LMCS) && lmcs_fwd) {
+#pragma unroll
+        for (int j = 0; j < NOUT; ++j) v[j] = lmcs_fwd[v[j]];
+    }
+    if (!(u.flags & OVHIP_MC_GPM) && u.aux) {
+        const uint16_t *ip = intra.y + (u.y + y0) * intra.stride_y + u.x + x;
+#pragma unroll
+        for (int j = 0; j < NOUT; ++j) v[j] = ciip_blend(v[j], ip[j * intra.stride_y], u.aux & 7);
+    }
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) d[j * dst.stride_y] = (uint16_t)v[j];
 }
 
 template <int NOUT>
@@ -102,12 +123,21 @@ __device__ __forceinline__ void chroma_finish(const ovhip_mc_unit &u, const ovhi
     uint16_t *d = (plane ? dst.cr : dst.cb) + ((u.y >> 1) + y0) * dst.stride_c + (u.x >> 1) + x;
     const bool ciip = !(u.flags & OVHIP_MC_GPM) && u.aux && !(u.aux & 0x100);
     const uint16_t *ip = ciip ? (plane ? intra.cr : intra.cb) + ((u.y >> 1) + y0) * intra.stride_c + (u.x >> 1) + x : nullptr;
+    int v[NOUT];
+    if (u.flags & OVHIP_MC_GPM) {
 #pragma unroll
-    for (int j = 0; j < NOUT; ++j) {
-        int v = (u.flags & OVHIP_MC_GPM) ? mc_gpm(u.aux, 2 * x, 2 * (y0 + j), P[0][j], P[1][j]) : mc_combine(u, P[0][j], P[1][j]);
-        if (ciip) v = ciip_blend(v, ip[j * intra.stride_c], u.aux & 7);
-        d[j * dst.stride_c] = (uint16_t)v;
+        for (int j = 0; j < NOUT; ++j) v[j] = mc_gpm(u.aux, 2 * x, 2 * (y0 + j), P[0][j], P[1][j]);
+    } else {
+        const Combine cmb = mc_combine_of(u);
+#pragma unroll
+        for (int j = 0; j < NOUT; ++j) v[j] = mc_combine(cmb, P[0][j], P[1][j]);
     }
+    if (ciip) {
+#pragma unroll
+        for (int j = 0; j < NOUT; ++j) v[j] = ciip_blend(v[j], ip[j * intra.stride_c], u.aux & 7);
+    }
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) d[j * dst.stride_c] = (uint16_t)v[j];
 }
 
 #ifdef OV_MC_PHASES
