@@ -220,7 +220,7 @@ __global__ __launch_bounds__(64) OV_OCC_MC void k_mc2(ovhip_pic dst, RefTable re
 
     // ---- horizontal passes: one task = one window row x 4 outputs.  Chroma first (see the LDS layout) ----
     if (do_c) {
-        const int log2seg = log2wc > 2 ? log2wc - 2 : 0, nout = wc < 4 ? wc : 4;
+        const int log2seg = log2wc > 2 ? log2wc - 2 : 0;
         const int TC = (hc + 3) << log2seg;
         for (int t = lane; t < 2 * nl * TC; t += 64) {
             const int qi = (t >= TC) + (t >= 2 * TC) + (t >= 3 * TC), tt = t - qi * TC;
@@ -231,12 +231,12 @@ __global__ __launch_bounds__(64) OV_OCC_MC void k_mc2(ovhip_pic dst, RefTable re
             for (int m = 0; m < 2; ++m) tp[m] = l ? thc[1][m] : thc[0][m];
             const int off = plane ? (l ? offc[1][1] : offc[1][0]) : (l ? offc[0][1] : offc[0][0]);
             h_task<4>(s_wc + (plane * 2 + l) * CHR_WIN + r * CWIN_STRIDE, off, x0, tp, l ? identc[1] : identc[0],
-                      s_hc + (plane * 2 + l) * 8 * CHT_STRIDE, CHT_STRIDE, r, nout);
+                      s_hc + (plane * 2 + l) * 8 * CHT_STRIDE, CHT_STRIDE, r);
         }
     }
     __syncthreads();          // the chroma windows are dead: s_hl takes their place
     if (do_l) {
-        const int log2seg = log2w > 2 ? log2w - 2 : 0, nout = w < 4 ? w : 4;
+        const int log2seg = log2w > 2 ? log2w - 2 : 0;
         const int TY = (h + 7) << log2seg;
         for (int t = lane; t < nl * TY; t += 64) {
             const int li = t >= TY, l = l0 + li, tt = t - li * TY;
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(64) OV_OCC_MC void k_mc2(ovhip_pic dst, RefTable re
 #pragma unroll
             for (int m = 0; m < 4; ++m) tp[m] = l ? thl[1][m] : thl[0][m];
             h_task<8>(s_wl + l * LUMA_WIN + r * WIN_STRIDE, l ? offl[1] : offl[0], x0, tp, l ? identl[1] : identl[0],
-                      s_hl + l * 16 * HL_STRIDE, HL_STRIDE, r, nout);
+                      s_hl + l * 16 * HL_STRIDE, HL_STRIDE, r);
         }
     }
     __syncthreads();

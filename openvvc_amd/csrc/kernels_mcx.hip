@@ -290,7 +290,7 @@ __device__ __forceinline__ void mcx_units(const ovhip_pic &dst, const RefTable &
             for (int m = 0; m < 4; ++m) tp[m] = l ? thl[1][m] : thl[0][m];
             h_task<8>(s_wl[0] + l * (XWIN_ROWS * XWIN_STRIDE) + (2 + (l ? ldy[1] : ldy[0]) + r) * XWIN_STRIDE,
                       4 + (l ? offl[1] + ldx[1] : offl[0] + ldx[0]), x0, tp, l ? identl[1] : identl[0],
-                      s_hl[0] + l * 16 * HT_STRIDE, HT_STRIDE, r, 4);
+                      s_hl[0] + l * 16 * HT_STRIDE, HT_STRIDE, r);
         }
     }
     if (do_c) {
@@ -304,7 +304,7 @@ __device__ __forceinline__ void mcx_units(const ovhip_pic &dst, const RefTable &
             for (int m = 0; m < 2; ++m) tp[m] = thc[0][m] ^ ((thc[0][m] ^ thc[1][m]) & -l);   // arithmetic select: keeps the taps in registers
             h_task<4>(s_wc[0][0] + qi * (XCWIN_ROWS * XCWIN_STRIDE) + (2 + (l ? cdy[1] : cdy[0]) + r) * XCWIN_STRIDE,
                       4 + (l ? offc[1] + cdx[1] : offc[0] + cdx[0]), x0, tp, l ? identc[1] : identc[0],
-                      s_hc[0][0] + qi * 8 * CHT_STRIDE, CHT_STRIDE, r, 4);
+                      s_hc[0][0] + qi * 8 * CHT_STRIDE, CHT_STRIDE, r);
         }
     }
     __syncthreads();

@@ -36,10 +36,12 @@ struct WinStage {
     bool fast;
     int off, side;          // side: -1 / +1 = this lane's groups lie left / right of the picture
 
-    static __device__ __forceinline__ bool interior(int sx0, int sy0, int ww, int wh, int rw, int rh)
+    // (bitwise on purpose: short-circuit && on wave-uniform values turns into scalar branches, and scalar issue is what
+    // bounds k_mc2)
+    static __device__ __forceinline__ int interior(int sx0, int sy0, int ww, int wh, int rw, int rh)
     {
         const int ax = sx0 & ~3, nq = (sx0 - ax + ww + 3) >> 2;
-        return ax >= 0 && ax + 4 * nq <= rw && sy0 >= 0 && sy0 + wh <= rh;
+        return (int)(ax >= 0) & (int)(ax + 4 * nq <= rw) & (int)(sy0 >= 0) & (int)(sy0 + wh <= rh);
     }
     __device__ __forceinline__ void issue_fast(const uint16_t *__restrict__ ref, int rstride, int sx0, int sy0, int ww, int wh, int lane)
     {
@@ -113,13 +115,14 @@ __device__ __forceinline__ void stage_unit_windows(const ovhip_pic &geom, const 
 {
     const int wc = w >> 1, hc = h >> 1, pw = geom.w, ph = geom.h, pwc = geom.w >> 1, phc = geom.h >> 1;
     const bool aligned = !((geom.stride_y | geom.stride_c | pw | pwc) & 3);
-    bool fast = aligned;
+    int all_in = aligned;
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
-        if (!(dir & (1 << l))) continue;
-        if (do_l) fast = fast && LumaStage::interior(lx[l], ly[l], w + 7, h + 7, pw, ph);
-        if (do_c) fast = fast && ChromaStage::interior(cx[l], cy[l], wc + 3, hc + 3, pwc, phc);
+        const int need_l = ((dir >> l) & 1) & (int)do_l, need_c = ((dir >> l) & 1) & (int)do_c;
+        all_in &= (need_l ^ 1) | LumaStage::interior(lx[l], ly[l], w + 7, h + 7, pw, ph);
+        all_in &= (need_c ^ 1) | ChromaStage::interior(cx[l], cy[l], wc + 3, hc + 3, pwc, phc);
     }
+    const bool fast = all_in;
     offl[0] = offl[1] = offc[0] = offc[1] = 0;
     if (fast) {
         LumaStage sl[2];
@@ -319,7 +322,7 @@ __device__ __forceinline__ void load_span(const int16_t *row, int s0, int d[(NT 
 // vertical call = NOUT consecutive outputs of one transposed-tile column ----
 template <int NT>
 __device__ __forceinline__ void h_task(const uint16_t *wrow, int off, int x0, const int tp[NT / 2], bool ident, int16_t *ht,
-                                       int htstride, int r, int nout)
+                                       int htstride, int r)
 {
     int d[NT / 2 + 2], out[4];
     if (ident) {
@@ -332,7 +335,7 @@ __device__ __forceinline__ void h_task(const uint16_t *wrow, int off, int x0, co
     }
 #pragma unroll
     for (int o = 0; o < 4; ++o)
-        if (o < nout) ht[(x0 + o) * htstride + r] = (int16_t)(out[o] >> (OV_BD - 8));
+        ht[(x0 + o) * htstride + r] = (int16_t)(out[o] >> (OV_BD - 8));      // a 2-wide chroma block also fills columns 2, 3: never read
 }
 
 template <int NT, int NOUT>
