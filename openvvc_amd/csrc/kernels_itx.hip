@@ -67,24 +67,22 @@ constexpr CoreT16 build_cores()
 }
 __device__ const CoreT16 __attribute__((aligned(16))) g_cores = build_cores();
 
+// offset of a core in g_cores, in units of 16 values, relative to its type's first core: one byte per log2n, so that the
+// lookup is a shift and a mask (a 14-way switch on wave-uniform values is ~50 scalar instructions per core)
+constexpr uint64_t core_lut(int type)
+{
+    uint64_t v = 0;
+    for (int l = (type == 2 ? 1 : 2); l <= (type == 2 ? 6 : 5); ++l)
+        v |= (uint64_t)((core_off(type, l) - core_off(type, type == 2 ? 1 : 2)) / 16) << (8 * l);
+    return v;
+}
+static_assert(core_lut(0) == core_lut(1) && (core_off(2, 6) - core_off(2, 1)) / 16 < 256 && core_off(1, 2) % 16 == 0 && core_off(2, 1) % 16 == 0,
+              "core offsets must fit the byte table");
 __device__ __forceinline__ const int16_t *tr_core(int type, int log2n)
 {
-    switch (type * 8 + log2n) {
-    case 0 * 8 + 2: return g_cores.v + core_off(0, 2);
-    case 0 * 8 + 3: return g_cores.v + core_off(0, 3);
-    case 0 * 8 + 4: return g_cores.v + core_off(0, 4);
-    case 0 * 8 + 5: return g_cores.v + core_off(0, 5);
-    case 1 * 8 + 2: return g_cores.v + core_off(1, 2);
-    case 1 * 8 + 3: return g_cores.v + core_off(1, 3);
-    case 1 * 8 + 4: return g_cores.v + core_off(1, 4);
-    case 1 * 8 + 5: return g_cores.v + core_off(1, 5);
-    case 2 * 8 + 1: return g_cores.v + core_off(2, 1);
-    case 2 * 8 + 2: return g_cores.v + core_off(2, 2);
-    case 2 * 8 + 3: return g_cores.v + core_off(2, 3);
-    case 2 * 8 + 4: return g_cores.v + core_off(2, 4);
-    case 2 * 8 + 5: return g_cores.v + core_off(2, 5);
-    default:        return g_cores.v + core_off(2, 6);
-    }
+    const uint64_t lut = type == 2 ? core_lut(2) : core_lut(0);
+    const int base = type == 2 ? core_off(2, 1) : type == 1 ? core_off(1, 2) : 0;
+    return g_cores.v + base + 16 * (int)((lut >> (8 * log2n)) & 0xff);
 }
 // LDS row length of a k-contiguous tile whose rows hold K values: the padding keeps the ds_read_b64 of 16 rows apart
 __device__ __forceinline__ int tile_stride(int K) { return K < 8 ? 8 : K + (K >= 16 ? 4 : 0); }
