@@ -35,8 +35,8 @@ namespace {
 __device__ __forceinline__ int mc_gpm(uint32_t aux, int x, int y, int p0, int p1)
 {
     const int k = (int16_t)(aux & 0xffff), a = (int8_t)((aux >> 16) & 0xff), b = (int8_t)(aux >> 24);
-    const int wgt = ov_clip3((k + a * x + b * y) >> 3, 0, 8);
-    return ov_clip_bd((p1 * (8 - wgt) + p0 * wgt + 64) >> 7);
+    const int wgt = ov_clip3((k + __mul24(a, x) + __mul24(b, y)) >> 3, 0, 8);
+    return ov_clip_bd((__mul24(p1, 8 - wgt) + __mul24(p0, wgt) + 64) >> 7);
 }
 
 // uni (p + 8) >> 4, bi average (p0 + p1 + 16) >> 5, BCW (p1 w1 + p0 w0 + 64) >> 7 (put_vvc_uni/bi(_w)_*): one
@@ -51,7 +51,8 @@ __device__ __forceinline__ Combine mc_combine_of(const ovhip_mc_unit &u)
     else                            { c.a0 = u.w0; c.a1 = u.w1; c.rnd = 64; c.sh = 7; }
     return c;
 }
-__device__ __forceinline__ int mc_combine(const Combine &c, int p0, int p1) { return ov_clip_bd((p1 * c.a1 + p0 * c.a0 + c.rnd) >> c.sh); }
+// (24-bit multiplies: the 14-bit intermediates and the weights fit, and v_mad_i32_i24 is full rate where v_mul_lo_u32 is not)
+__device__ __forceinline__ int mc_combine(const Combine &c, int p0, int p1) { return ov_clip_bd((__mul24(p1, c.a1) + __mul24(p0, c.a0) + c.rnd) >> c.sh); }
 
 // =====================================================================================================
 // k_mc2 (the first version, k_mc, ran one pass per list and per plane with 4 rows per lane: SQ counters showed it
@@ -63,7 +64,7 @@ __device__ __forceinline__ int mc_combine(const Combine &c, int p0, int p1) { re
 //     both planes in the same pass
 // =====================================================================================================
 // fused CIIP blend: (intra * wt + inter * (4 - wt) + 2) >> 2, put_weighted_ciip_pixels (rcn_mc.c:1611-1628)
-__device__ __forceinline__ int ciip_blend(int inter, int intra, int wt) { return ov_clip_bd((intra * wt + inter * (4 - wt) + 2) >> 2); }
+__device__ __forceinline__ int ciip_blend(int inter, int intra, int wt) { return ov_clip_bd((__mul24(intra, wt) + __mul24(inter, 4 - wt) + 2) >> 2); }
 
 #define HLS 26   /* k_mc2's transposed luma H tile: odd dword stride (conflict-free columns), rows h + 7 <= 23 */
 template <int NOUT>
@@ -80,7 +81,7 @@ __device__ __forceinline__ void luma_finish(const ovhip_mc_unit &u, const ovhip_
         for (int o = 0; o < NOUT; ++o) P[l][o] = 0;
         if (u.dir & (1 << l)) v_outputs<8, NOUT>(s_hl + l * 16 * HLS + x * HLS, y0, tv[l], P[l]);
     }
-    uint16_t *d = dst.y + (u.y + y0) * dst.stride_y + u.x + x;
+    uint16_t *d = dst.y + ov_rowoff(u.y + y0, dst.stride_y) + u.x + x;
     // every wave-uniform decision once, not once per sample
     int v[NOUT];
     if (u.flags & OVHIP_MC_GPM) {
@@ -96,7 +97,7 @@ __device__ __forceinline__ void luma_finish(const ovhip_mc_unit &u, const ovhip_
         for (int j = 0; j < NOUT; ++j) v[j] = lmcs_fwd[v[j]];
     }
     if (!(u.flags & OVHIP_MC_GPM) && u.aux) {
-        const uint16_t *ip = intra.y + (u.y + y0) * intra.stride_y + u.x + x;
+        const uint16_t *ip = intra.y + ov_rowoff(u.y + y0, intra.stride_y) + u.x + x;
 #pragma unroll
         for (int j = 0; j < NOUT; ++j) v[j] = ciip_blend(v[j], ip[j * intra.stride_y], u.aux & 7);
     }
@@ -120,9 +121,9 @@ __device__ __forceinline__ void chroma_finish(const ovhip_mc_unit &u, const ovhi
         for (int o = 0; o < NOUT; ++o) P[l][o] = 0;
         if (u.dir & (1 << l)) v_outputs<4, NOUT>(s_hc + (plane * 2 + l) * 8 * CHT_STRIDE + x * CHT_STRIDE, y0, tv[l], P[l]);
     }
-    uint16_t *d = (plane ? dst.cr : dst.cb) + ((u.y >> 1) + y0) * dst.stride_c + (u.x >> 1) + x;
+    uint16_t *d = (plane ? dst.cr : dst.cb) + ov_rowoff((u.y >> 1) + y0, dst.stride_c) + (u.x >> 1) + x;
     const bool ciip = !(u.flags & OVHIP_MC_GPM) && u.aux && !(u.aux & 0x100);
-    const uint16_t *ip = ciip ? (plane ? intra.cr : intra.cb) + ((u.y >> 1) + y0) * intra.stride_c + (u.x >> 1) + x : nullptr;
+    const uint16_t *ip = ciip ? (plane ? intra.cr : intra.cb) + ov_rowoff((u.y >> 1) + y0, intra.stride_c) + (u.x >> 1) + x : nullptr;
     int v[NOUT];
     if (u.flags & OVHIP_MC_GPM) {
 #pragma unroll

@@ -107,7 +107,7 @@ __device__ __forceinline__ void chroma_avg(const ovhip_mc_unit &u, const ovhip_p
     int P[2][NOUT];
 #pragma unroll
     for (int l = 0; l < 2; ++l) v_outputs<4, NOUT>(s_hc + (plane * 2 + l) * 8 * CHT_STRIDE + x * CHT_STRIDE, y0, tv[l], P[l]);
-    uint16_t *d = (plane ? dst.cr : dst.cb) + ((u.y >> 1) + y0) * dst.stride_c + (u.x >> 1) + x;
+    uint16_t *d = (plane ? dst.cr : dst.cb) + ov_rowoff((u.y >> 1) + y0, dst.stride_c) + (u.x >> 1) + x;
 #pragma unroll
     for (int j = 0; j < NOUT; ++j) d[j * dst.stride_c] = (uint16_t)ov_clip_bd((P[0][j] + P[1][j] + 16) >> 5);
 }
@@ -393,7 +393,7 @@ __device__ __forceinline__ void mcx_units(const ovhip_pic &dst, const RefTable &
             for (int j = 0; j < 4; ++j) out[j] = ov_clip_bd((P[0][j] + P[1][j] + 16) >> 5);
         }
         if (act) {
-            uint16_t *d = dst.y + (u.y + 4 * g) * dst.stride_y + u.x + x;
+            uint16_t *d = dst.y + ov_rowoff(u.y + 4 * g, dst.stride_y) + u.x + x;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 int v = out[j];
@@ -450,7 +450,7 @@ __device__ __forceinline__ int aff_stage(const uint16_t *__restrict__ ref, int r
         if (c < nq) {
             uint2 q[ROWS];
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r) q[r] = *reinterpret_cast<const uint2 *>(ref + (sy0 + r) * rstride + ax + 4 * c);
+            for (int r = 0; r < ROWS; ++r) q[r] = *reinterpret_cast<const uint2 *>(ref + ov_rowoff(sy0 + r, rstride) + ax + 4 * c);
 #pragma unroll
             for (int r = 0; r < ROWS; ++r) *reinterpret_cast<uint2 *>(win + r * 12 + 4 * c) = q[r];
         }
@@ -461,7 +461,7 @@ __device__ __forceinline__ int aff_stage(const uint16_t *__restrict__ ref, int r
             const uint16_t *base = ref + ov_clip3(qx, 0, rw - 4);
             uint2 q[ROWS];
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r) q[r] = *reinterpret_cast<const uint2 *>(base + ov_clip3(sy0 + r, 0, rh - 1) * rstride);
+            for (int r = 0; r < ROWS; ++r) q[r] = *reinterpret_cast<const uint2 *>(base + ov_rowoff(ov_clip3(sy0 + r, 0, rh - 1), rstride));
 #pragma unroll
             for (int r = 0; r < ROWS; ++r) {
                 uint2 v = q[r];
@@ -512,7 +512,7 @@ struct AffLumaStage {
             side = qx < 0 ? -1 : qx >= rw ? 1 : 0;
             const uint16_t *base = ref + ov_clip3(qx, 0, rw - 4);
 #pragma unroll
-            for (int k = 0; k < 9; ++k) q[k] = *reinterpret_cast<const uint2 *>(base + ov_clip3(sy0 + k, 0, rh - 1) * rstride);
+            for (int k = 0; k < 9; ++k) q[k] = *reinterpret_cast<const uint2 *>(base + ov_rowoff(ov_clip3(sy0 + k, 0, rh - 1), rstride));
         }
     }
     __device__ __forceinline__ int park(int rstride, int rw, int rh, int c, uint16_t *win)
@@ -690,7 +690,7 @@ __device__ __forceinline__ void mca_units(const ovhip_pic &dst, const RefTable &
     OV_APHASE(4);
     if (act) {
         const int dir = ((u.ident_l >> sb) & 1) ? 2 : u.dir;
-        uint16_t *d = dst.y + by * dst.stride_y + bx + c;
+        uint16_t *d = dst.y + ov_rowoff(by, dst.stride_y) + bx + c;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int v = aff_combine(dir, u.w0, u.w1, P[0][j], P[1][j]);
@@ -716,7 +716,7 @@ __device__ __forceinline__ void mca_units(const ovhip_pic &dst, const RefTable &
             for (int o = 0; o < 4; ++o) Pc[l][o] >>= 6;
         }
         const int dir = ((u.ident_c >> cblk) & 1) ? 2 : u.dir;
-        uint16_t *d = (ccomp ? dst.cr : dst.cb) + cby * dst.stride_c + cbx + cc;
+        uint16_t *d = (ccomp ? dst.cr : dst.cb) + ov_rowoff(cby, dst.stride_c) + cbx + cc;
 #pragma unroll
         for (int j = 0; j < 4; ++j) d[j * dst.stride_c] = (uint16_t)aff_combine(dir, u.w0, u.w1, Pc[0][j], Pc[1][j]);
     }

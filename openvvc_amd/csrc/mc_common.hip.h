@@ -49,7 +49,7 @@ struct WinStage {
         off = sx0 - ax; fast = true; side = 0;
         const int nq = (off + ww + 3) >> 2;
         const int c = lane & (QW - 1), r0 = lane / QW;
-        const uint16_t *base = ref + (sy0 + r0) * rstride + ax + 4 * c;
+        const uint16_t *base = ref + ov_rowoff(sy0 + r0, rstride) + ax + 4 * c;
 #pragma unroll
         for (int k = 0; k < NIT; ++k)
             if (c < nq && (64 / QW) * k + r0 < wh) q[k] = *reinterpret_cast<const uint2 *>(base + (64 / QW) * k * rstride);
@@ -67,7 +67,7 @@ struct WinStage {
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
             const int r = (64 / QW) * k + r0;
-            if (c < nq && r < wh) q[k] = *reinterpret_cast<const uint2 *>(base + ov_clip3(sy0 + r, 0, rh - 1) * rstride);
+            if (c < nq && r < wh) q[k] = *reinterpret_cast<const uint2 *>(base + ov_rowoff(ov_clip3(sy0 + r, 0, rh - 1), rstride));
         }
     }
     __device__ __forceinline__ void issue_slow(const uint16_t *__restrict__ ref, int rstride, int rw, int rh, int sx0, int sy0,

@@ -56,6 +56,10 @@ __device__ __forceinline__ uint32_t ov_xcd_slot(uint32_t i, uint32_t n)
     return k * base + (k < rem ? k : rem) + j;
 }
 
+// row * stride for sample addressing: both fit 24 bits, and v_mul_i32_i24 / v_mad_i32_i24 are full rate where the 32-bit
+// v_mul_lo_u32 takes four issue slots
+__device__ __forceinline__ int ov_rowoff(int row, int stride) { return __mul24(row, stride); }
+
 __device__ __forceinline__ int ov_clip3(int v, int lo, int hi) { return min(max(v, lo), hi); }
 __device__ __forceinline__ int ov_clip16(int v) { return ov_clip3(v, -32768, 32767); }
 __device__ __forceinline__ int ov_clip_bd(int v) { return ov_clip3(v, 0, OV_PIX_MAX); }
