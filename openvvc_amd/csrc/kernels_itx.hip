@@ -111,13 +111,10 @@ __device__ __forceinline__ int nb_cols_of(uint64_t map)   // derive_nb_cols, :94
 // the eight variants of rcn_residuals.c:46-222 on one sample
 __device__ __forceinline__ int residual1(int pix, int r, int mode, int scale)
 {
-    int v = r;
-    switch (mode & 3) {
-    case OVHIP_RES_SUB:      v = -v; break;
-    case OVHIP_RES_ADD_HALF: v = v >> 1; break;
-    case OVHIP_RES_SUB_HALF: v = (-v) >> 1; break;
-    default: break;
-    }
+    // r, -r, r >> 1, (-r) >> 1 without a branch (mode is wave-uniform: a switch here is scalar compares and branches per
+    // sample): bit 0 negates, bit 1 halves
+    const int neg = -(mode & 1);
+    int v = ((r ^ neg) - neg) >> ((mode >> 1) & 1);
     if (mode & OVHIP_RES_SCALE) {
         int sign = v & (1 << 15);
         int a = ov_clip_bd(abs(v));
