@@ -378,7 +378,7 @@ __device__ __forceinline__ void alf_chroma_tile(const ovhip_pic &dst, const ovhi
         else if (pos == vbpos - 1 || pos == vbpos) r1 = r2 = r3 = 0;
     }
     const bool cc_inside = tx0 > 0 && ty0 > 0 && tx0 + TL < Wc && ty0 + TL < Hc;
-    // 5 rows of the 12-sample group lx0-4 .. lx0+7 as 8-byte LDS reads (see k_alf_luma)
+    // 5 rows of the 12-sample group lx0-4 .. lx0+7 as 8-byte LDS reads (see alf_luma_tile)
     uint32_t r0[6], p1[6], m1[6], p2[2], m2[2];
     int cmin = 0x7fff, fsum = 0;
     if (on) {
