@@ -132,8 +132,11 @@ __device__ __forceinline__ void mcx_units(const ovhip_pic &dst, const RefTable &
     int16_t (*const s_hc)[2][8 * CHT_STRIDE] = reinterpret_cast<int16_t (*)[2][8 * CHT_STRIDE]>(s_h + 2 * 16 * HT_STRIDE);
     int16_t (*const s_x)[24 * BIL_STRIDE] = reinterpret_cast<int16_t (*)[24 * BIL_STRIDE]>(s_h);
     static_assert(2 * 24 * BIL_STRIDE <= 2 * 16 * HT_STRIDE + 4 * 8 * CHT_STRIDE, "bilinear blocks must fit the H tiles");
-    int   *const s_avg = reinterpret_cast<int *>(s_wl[0]);                                     // BDOF (avg_gx | avg_gy << 16), 16x16
-    int16_t *const s_dr = reinterpret_cast<int16_t *>(s_wl[1]);                                // BDOF delta_ref, 16x16
+    // BDOF per-sample terms of derive_bdof_weights, 16x16 each, over the (dead) luma windows:
+    uint32_t *const s_ba = reinterpret_cast<uint32_t *>(s_wl[0]);                              // |ax| | |ay| << 16
+    uint32_t *const s_bb = s_ba + 256;                                                         // sign(ay) ax | sign(ax) dr << 16
+    int16_t  *const s_bc = reinterpret_cast<int16_t *>(s_bb + 256);                            // sign(ay) dr
+    static_assert(2 * XWIN_ROWS * XWIN_STRIDE * 2 >= 2 * 1024 + 512, "BDOF terms must fit the luma windows");
 
     const int lane = threadIdx.x;
     for (uint32_t wg = wg0; wg < n_units; wg += wstride) {
@@ -351,9 +354,15 @@ __device__ __forceinline__ void mcx_units(const ovhip_pic &dst, const RefTable &
                     const int gx0 = (s_x[0][o + 1] >> 6) - (s_x[0][o - 1] >> 6), gx1 = (s_x[1][o + 1] >> 6) - (s_x[1][o - 1] >> 6);
                     const int gy0 = col[0][j + 2] - col[0][j], gy1 = col[1][j + 2] - col[1][j];
                     dgx[j] = gx0 - gx1; dgy[j] = gy0 - gy1;
-                    const int ax = (gx0 + gx1) >> 1, ay = (gy0 + gy1) >> 1;
-                    s_avg[(4 * g + j) * 16 + x] = (ax & 0xffff) | (ay << 16);
-                    s_dr[(4 * g + j) * 16 + x] = (int16_t)((P[1][j] >> 4) - (P[0][j] >> 4));
+                    const int ax = (gx0 + gx1) >> 1, ay = (gy0 + gy1) >> 1, dr = (P[1][j] >> 4) - (P[0][j] >> 4);
+                    // the five terms a 6x6 window sums, once per SAMPLE here instead of once per window that holds it
+                    const int t_xy = ay < 0 ? -ax : (ay == 0 ? 0 : ax);
+                    const int t_dx = ax < 0 ? -dr : (ax == 0 ? 0 : dr);
+                    const int t_dy = ay < 0 ? -dr : (ay == 0 ? 0 : dr);
+                    const int idx = (4 * g + j) * 16 + x;
+                    s_ba[idx] = (uint32_t)abs(ax) | ((uint32_t)abs(ay) << 16);
+                    s_bb[idx] = ((uint32_t)t_xy & 0xffffu) | ((uint32_t)t_dx << 16);
+                    s_bc[idx] = (int16_t)t_dy;
                 }
             }
             __syncthreads();
@@ -361,19 +370,25 @@ __device__ __forceinline__ void mcx_units(const ovhip_pic &dst, const RefTable &
             //     gradients and predictions are replicated outside the block (extend_bdof_grad)
             int wx = 0, wy = 0;
             if (act) {
+                // lane q of the block takes the half-rows 3q .. 3q+2 of the 6x6 window (3 samples each); a lane's 9 terms
+                // fit int16 (|ax|, |ay| < 2^10, |dr| < 2^11), so the partial sums are packed adds
+                typedef short bd_s2 __attribute__((ext_vector_type(2)));
                 const int q = x & 3, sx = x & ~3, sy = 4 * g;
-                int s_ax = 0, s_ay = 0, s_xy = 0, s_dx = 0, s_dy = 0;
+                bd_s2 a2 = (bd_s2)(0), b2 = (bd_s2)(0);
+                int s_dy = 0;
 #pragma unroll
-                for (int e9 = 0; e9 < 9; ++e9) {
-                    const int e = 9 * q + e9, r = e / 6, c = e - 6 * r;
-                    const int px = ov_clip3(sx - 1 + c, 0, w - 1), py = ov_clip3(sy - 1 + r, 0, h - 1);
-                    const int pk = s_avg[py * 16 + px];
-                    const int ax = (int)(int16_t)(pk & 0xffff), ay = pk >> 16, dr = s_dr[py * 16 + px];
-                    s_ax += abs(ax); s_ay += abs(ay);
-                    s_xy += ay < 0 ? -ax : (ay == 0 ? 0 : ax);
-                    s_dx += ax < 0 ? -dr : (ax == 0 ? 0 : dr);
-                    s_dy += ay < 0 ? -dr : (ay == 0 ? 0 : dr);
+                for (int t = 0; t < 3; ++t) {
+                    const int hr = 3 * q + t, r = hr >> 1, c0 = (hr & 1) * 3;
+                    const int py = ov_clip3(sy - 1 + r, 0, h - 1);
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) {
+                        const int px = ov_clip3(sx - 1 + c0 + cc, 0, w - 1), idx = py * 16 + px;
+                        a2 += __builtin_bit_cast(bd_s2, s_ba[idx]);
+                        b2 += __builtin_bit_cast(bd_s2, s_bb[idx]);
+                        s_dy += s_bc[idx];
+                    }
                 }
+                int s_ax = (unsigned short)a2.x, s_ay = (unsigned short)a2.y, s_xy = b2.x, s_dx = b2.y;
 #pragma unroll
                 for (int m = 1; m < 4; m <<= 1) {
                     s_ax += __shfl_xor(s_ax, m); s_ay += __shfl_xor(s_ay, m); s_xy += __shfl_xor(s_xy, m);
