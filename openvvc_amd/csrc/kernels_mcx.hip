@@ -205,8 +205,9 @@ __device__ __forceinline__ void mcx_units(const ovhip_pic &dst, const RefTable &
                 for (int j = 0; j < h + 5; ++j) {
                     const int a = src[j * XWIN_STRIDE];
                     const int b = __builtin_amdgcn_update_dpp(0, a, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-                    const int t = fx ? ((16 - fx) * a + fx * b + 8) >> 4 : a;
-                    if (j && i < w + 4) o[(j - 1) * BIL_STRIDE] = (int16_t)(fy ? ((16 - fy) * tp + fy * t + 8) >> 4 : tp);
+                    // (24-bit multiplies are full rate; v_mul_lo_u32 takes four issue slots)
+                    const int t = fx ? (__mul24(16 - fx, a) + __mul24(fx, b) + 8) >> 4 : a;
+                    if (j && i < w + 4) o[(j - 1) * BIL_STRIDE] = (int16_t)(fy ? (__mul24(16 - fy, tp) + __mul24(fy, t) + 8) >> 4 : tp);
                     tp = t;
                 }
             }
@@ -402,7 +403,7 @@ __device__ __forceinline__ void mcx_units(const ovhip_pic &dst, const RefTable &
             }
             // 4d. rcn_apply_bdof_subblock
 #pragma unroll
-            for (int j = 0; j < 4; ++j) out[j] = ov_clip_bd((int)(int16_t)((P[0][j] + P[1][j] + wx * dgx[j] + wy * dgy[j] + 16) >> 5));
+            for (int j = 0; j < 4; ++j) out[j] = ov_clip_bd((int)(int16_t)((P[0][j] + P[1][j] + __mul24(wx, dgx[j]) + __mul24(wy, dgy[j]) + 16) >> 5));
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) out[j] = ov_clip_bd((P[0][j] + P[1][j] + 16) >> 5);
@@ -449,7 +450,7 @@ __device__ __forceinline__ int aff_combine(int dir, int w0, int w1, int p0, int 
 {
     if (dir != 3)           return ov_clip_bd(((dir == 1 ? p0 : p1) + 8) >> 4);
     if (w0 == 4 && w1 == 4) return ov_clip_bd((p0 + p1 + 16) >> 5);
-    return ov_clip_bd((p1 * w1 + p0 * w0 + 64) >> 7);
+    return ov_clip_bd((__mul24(p1, w1) + __mul24(p0, w0) + 64) >> 7);
 }
 
 // window of ROWS x COLS samples -> LDS rows of 12 samples.  4 lanes (c = 0..3) per window.
@@ -697,7 +698,7 @@ __device__ __forceinline__ void mca_units(const ovhip_pic &dst, const RefTable &
             for (int j = 0; j < 4; ++j) {
                 const int o = (j + 1) * 6 + c + 1;
                 const int gx = (t[o + 1] >> 6) - (t[o - 1] >> 6), gy = (t[o + 6] >> 6) - (t[o - 6] >> 6);
-                const int add = ov_clip3(pdx[l][j] * gx + pdy[l][j] * gy, -(1 << 13), (1 << 13) - 1);
+                const int add = ov_clip3(__mul24(pdx[l][j], gx) + __mul24(pdy[l][j], gy), -(1 << 13), (1 << 13) - 1);
                 P[l][j] = (int)(int16_t)(P[l][j] + add);
             }
         }
