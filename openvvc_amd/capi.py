@@ -18,6 +18,7 @@ LIB_PATH = _PKG / "libovvc_hip.so"
 
 # ---- constants (include/ovvc_hip.h) ----
 OVHIP_ABI_VERSION = 3
+OVHIP_OK, OVHIP_ENODEV, OVHIP_ENOMEM, OVHIP_EINVAL, OVHIP_ELAUNCH, OVHIP_EUNSUP = 0, -1, -2, -3, -4, -5
 DST_VII, DCT_VIII, DCT_II = 0, 1, 2
 TB_TR, TB_DC, TB_TS, TB_TS_RAW = 0, 1, 2, 3
 TB_FLAG_RASTER = 0x80

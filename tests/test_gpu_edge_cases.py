@@ -29,11 +29,34 @@ def test_empty_launches_are_noops(ctx):
     assert lib.ovhip_ciip_launch(h, C.byref(s), C.byref(s), None, 0) == 0
     luts = capi.lmcs_build(capi.LmcsData())
     assert lib.ovhip_lmcs_scale_launch(h, C.byref(s), None, 0, C.byref(luts), None) == 0
+    assert lib.ovhip_mcxa_launch(h, C.byref(s), refs, 1, None, 0, None, None, 0, None, None) == 0
     # a non-empty launch with a NULL buffer is an error, reported through ovhip_last_error
     assert lib.ovhip_mc_launch(h, C.byref(s), refs, 1, None, 5, None, None) < 0
     assert b"ovhip_mc_launch" in lib.ovhip_last_error(h)
+    assert lib.ovhip_mcxa_launch(h, C.byref(s), refs, 1, None, 3, None, None, 2, None, None) < 0
+    assert lib.ovhip_itx_launch_chroma_lmcs(h, C.byref(s), None, 0, 0, None, None, None) < 0      # the rider needs its table
     ctx.sync()
     empty.free()
+
+
+def test_reference_of_another_geometry_is_rejected(ctx):
+    """The MC kernels take the window geometry from dst: a reference picture of another size or stride is reference
+    picture resampling, outside this path -> OVHIP_EUNSUP, nothing launched."""
+    import ctypes as C
+    wl = synth.make_workload(416, 240, 13)
+    rp = engine.ResidentPicture(ctx, wl)
+    other = ctx.new_pic(wl.w + 64, wl.h)
+    refs = (capi.Pic * 2)(rp.refs[0].s, other.s)
+    lib, h = ctx.lib, ctx.h
+    assert lib.ovhip_mc_launch(h, C.byref(rp.dst.s), refs, 2, rp.mc_units.ptr, rp.mc_units.count, None, None) == capi.OVHIP_EUNSUP
+    assert b"geometry" in lib.ovhip_last_error(h)
+    assert lib.ovhip_mcx_launch(h, C.byref(rp.dst.s), refs, 2, rp.mcx_units.ptr, rp.mcx_units.count, None, None) == capi.OVHIP_EUNSUP
+    assert lib.ovhip_mca_launch(h, C.byref(rp.dst.s), refs, 2, rp.aff_units.ptr, rp.aff_units.count, rp.aff_side.ptr, None) == capi.OVHIP_EUNSUP
+    assert lib.ovhip_mcxa_launch(h, C.byref(rp.dst.s), refs, 2, rp.mcx_units.ptr, rp.mcx_units.count, None,
+                                 rp.aff_units.ptr, rp.aff_units.count, rp.aff_side.ptr, None) == capi.OVHIP_EUNSUP
+    ctx.sync()
+    other.free()
+    rp.free()
 
 
 @pytest.mark.parametrize("w,h,seed", [(264, 136, 1), (200, 120, 2), (128, 64, 3), (72, 200, 4)])
