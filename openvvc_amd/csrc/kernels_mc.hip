@@ -167,8 +167,11 @@ __global__ __launch_bounds__(64) OV_OCC_MC void k_mc2(ovhip_pic dst, RefTable re
     int16_t  *const s_hc = reinterpret_cast<int16_t *>(s_all + 2 * LUMA_WIN + R2);     // [plane * 2 + list]
     static_assert(sizeof(s_all) <= 5120, "k_mc2 LDS block must stay under the 32-workgroups-per-CU step");
 
+    // one unit per workgroup (no grid-stride loop: the loop-carried scalars cost SGPRs this kernel does not have)
     const int lane = threadIdx.x;
-    for (uint32_t wg = blockIdx.x; wg < n_units; wg += gridDim.x) {
+    {
+    const uint32_t wg = blockIdx.x;
+    if (wg >= n_units) return;
     const uint32_t bid = xcd ? ov_xcd_slot(wg, n_units) : wg;
 #ifdef OV_MC_PHASES
     unsigned long long ph[8] = {}, tprev = __builtin_readcyclecounter();
@@ -200,20 +203,18 @@ __global__ __launch_bounds__(64) OV_OCC_MC void k_mc2(ovhip_pic dst, RefTable re
     stage_unit_windows(dst, ry, rcb, rcr, lx, ly, cx, cy, w, h, u.dir, do_l, do_c, lane, lwin, WIN_STRIDE, cwin, CWIN_STRIDE, offl, offc1);
     const int offc[2][2] = { { offc1[0], offc1[1] }, { offc1[0], offc1[1] } };
     // ---- filter taps of both lists (wave-uniform) ----
-    int thl[2][4], tvl[2][4], thc[2][2], tvc[2][2];
+    // (horizontal taps here, vertical taps right before the vertical pass: 12 fewer live SGPRs through the H pass)
+    int thl[2][4], thc[2][2];
     bool identl[2], identc[2];
+    const uint32_t (*const ltab)[4] = (u.flags & OVHIP_MC_FILT_4x4) ? g_taps.luma4 : g_taps.luma;
+    const bool hpel = !(u.flags & OVHIP_MC_FILT_4x4) && (u.flags & OVHIP_MC_HPEL_FILT);
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
-        const int mvx = l ? u.mv1x : u.mv0x, mvy = l ? u.mv1y : u.mv0y;
-        int fx = mvx & 15, fy = mvy & 15;
-        const uint32_t *fh, *fv;
-        if (u.flags & OVHIP_MC_FILT_4x4) { fh = g_taps.luma4[fx]; fv = g_taps.luma4[fy]; }
-        else {
-            if (u.flags & OVHIP_MC_HPEL_FILT) { if (fx == 8) fx = 16; if (fy == 8) fy = 16; }
-            fh = g_taps.luma[fx]; fv = g_taps.luma[fy];
-        }
-        load_taps<4>(fh, thl[l]); load_taps<4>(fv, tvl[l]);
-        load_taps<2>(g_taps.chroma[mvx & 31], thc[l]); load_taps<2>(g_taps.chroma[mvy & 31], tvc[l]);
+        const int mvx = l ? u.mv1x : u.mv0x;
+        int fx = mvx & 15;
+        if (hpel && fx == 8) fx = 16;
+        load_taps<4>(ltab[fx], thl[l]);
+        load_taps<2>(g_taps.chroma[mvx & 31], thc[l]);
         identl[l] = fx == 0; identc[l] = (mvx & 31) == 0;
     }
     __syncthreads();
@@ -253,6 +254,15 @@ __global__ __launch_bounds__(64) OV_OCC_MC void k_mc2(ovhip_pic dst, RefTable re
     OV_PHASE(3);
 
     // ---- vertical passes + combine + store: every lane finishes NOUT samples of one column ----
+    int tvl[2][4], tvc[2][2];
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        const int mvy = l ? u.mv1y : u.mv0y;
+        int fy = mvy & 15;
+        if (hpel && fy == 8) fy = 16;
+        load_taps<4>(ltab[fy], tvl[l]);
+        load_taps<2>(g_taps.chroma[mvy & 31], tvc[l]);
+    }
     if (do_l) {
         const int npix = w * h;
         if (npix >= 256)      luma_finish<4>(u, dst, s_hl, tvl, lane, log2w, lmcs_fwd, intra);
