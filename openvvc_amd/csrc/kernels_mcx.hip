@@ -139,7 +139,9 @@ __device__ __forceinline__ void mcx_units(const ovhip_pic &dst, const RefTable &
     static_assert(2 * XWIN_ROWS * XWIN_STRIDE * 2 >= 2 * 1024 + 512, "BDOF terms must fit the luma windows");
 
     const int lane = threadIdx.x;
-    for (uint32_t wg = wg0; wg < n_units; wg += wstride) {
+    {   // one unit per workgroup (a grid-stride loop's carried scalars cost SGPRs; see k_mc2)
+    const uint32_t wg = wg0;
+    if (wg >= n_units) return;
     const uint32_t bid = wstride >= n_units ? ov_xcd_slot(wg, n_units) : wg;        // XCD-aware order, see k_mc2
     const ovhip_mc_unit u = units[bid];
     const bool dmvr = u.flags & OVHIP_MC_DMVR;
@@ -270,7 +272,7 @@ __device__ __forceinline__ void mcx_units(const ovhip_pic &dst, const RefTable &
     // ---- 3. horizontal passes at the refined position: both lists (and both chroma planes) in one task loop ----
     const uint32_t *fvl[2];
     int ldx[2], ldy[2], cdx[2], cdy[2], ext[2][2];
-    int thl[2][4], thc[2][2], tvc[2][2];
+    int thl[2][4], thc[2][2];
     bool identl[2], identc[2];
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
@@ -281,7 +283,7 @@ __device__ __forceinline__ void mcx_units(const ovhip_pic &dst, const RefTable &
         ldx[l] = (mv[l][0] >> 4) - (ini[l][0] >> 4); ldy[l] = (mv[l][1] >> 4) - (ini[l][1] >> 4);
         cdx[l] = (mv[l][0] >> 5) - (ini[l][0] >> 5); cdy[l] = (mv[l][1] >> 5) - (ini[l][1] >> 5);
         load_taps<4>(g_taps.luma[fx], thl[l]);
-        load_taps<2>(g_taps.chroma[mv[l][0] & 31], thc[l]); load_taps<2>(g_taps.chroma[mv[l][1] & 31], tvc[l]);
+        load_taps<2>(g_taps.chroma[mv[l][0] & 31], thc[l]);
         identl[l] = fx == 0; identc[l] = (mv[l][0] & 31) == 0;
     }
     if (do_l) {
@@ -420,6 +422,8 @@ __device__ __forceinline__ void mcx_units(const ovhip_pic &dst, const RefTable &
     }
     // ---- 5. chroma: plain average; both planes in one pass, NOUT rows per lane so that the lanes cover both ----
     if (do_c) {
+        int tvc[2][2];                                   // vertical chroma taps, loaded where they are used
+        load_taps<2>(g_taps.chroma[mv[0][1] & 31], tvc[0]); load_taps<2>(g_taps.chroma[mv[1][1] & 31], tvc[1]);
         if (wc * hc >= 64) chroma_avg<2>(u, dst, s_hc[0][0], tvc, lane, log2wc, hc);
         else               chroma_avg<1>(u, dst, s_hc[0][0], tvc, lane, log2wc, hc);
     }
@@ -573,7 +577,9 @@ __device__ __forceinline__ void mca_units(const ovhip_pic &dst, const RefTable &
     int16_t  (*const s_cht)[8][4 * ACHS] = reinterpret_cast<int16_t (*)[8][4 * ACHS]>(lds + MCA_LDS_WIN + MCA_LDS_HT + MCA_LDS_T + MCA_LDS_CWIN);
 
     const int lane = threadIdx.x;
-    for (uint32_t wg = wg0; wg < n_units; wg += wstride) {
+    {   // one unit per workgroup
+    const uint32_t wg = wg0;
+    if (wg >= n_units) return;
     const uint32_t bid = wstride >= n_units ? ov_xcd_slot(wg, n_units) : wg;        // XCD-aware order, see k_mc2
 #ifdef OV_MCA_PHASES
     unsigned int ph[8] = {}; unsigned long long tprev = __builtin_readcyclecounter();
