@@ -31,8 +31,8 @@ __global__ __launch_bounds__(256) void k_sao(ovhip_pic dst, ovhip_pic src, const
                                               int log2_ctu, int nb_ctu_w, int tiles_y, int tiles_c)
 {
     const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;          // 8 lanes x 8 samples per row, 32 rows
-    // (plane, tile): luma tiles first, then Cb, then Cr; loop form for capped grids
-    for (int t = blockIdx.x; t < tiles_y + 2 * tiles_c; t += gridDim.x) {
+    // (plane, tile): luma tiles first, then Cb, then Cr; one tile per workgroup (single pass: `continue` leaves the tile)
+    for (int t = blockIdx.x; t < tiles_y + 2 * tiles_c; t = tiles_y + 2 * tiles_c) {
         const int c = t < tiles_y ? 0 : (t < tiles_y + tiles_c ? 1 : 2);
         const int tt = t - (c == 0 ? 0 : (c == 1 ? tiles_y : tiles_y + tiles_c));
         const int sh = c ? 1 : 0;
