@@ -35,3 +35,16 @@ def test_no_cpu_fallback(built_lib):
     from openvvc_amd import engine
     with pytest.raises(engine.EngineError):
         engine.Context(0)
+
+
+def test_bench_and_entry_scripts_parse():
+    """bench.py / __graft_entry__.py compile, and bench.py's command line is the driver's contract (no GPU needed for --help)."""
+    import py_compile, subprocess, sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    for f in ("bench.py", "__graft_entry__.py"):
+        py_compile.compile(str(root / f), doraise=True)
+    out = subprocess.run([sys.executable, str(root / "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup", "--in-flight"):
+        assert flag in out.stdout
