@@ -23,7 +23,7 @@
 // Occupancy hint (waves per SIMD the register allocator must leave room for; 0 = compiler default).
 // -DOV_WPE_ITX=n overrides it for sweeps.
 #ifndef OV_WPE_ITX
-#define OV_WPE_ITX 0
+#define OV_WPE_ITX 8      /* measured (tools/sweep_occupancy.sh, two pictures in flight): itx 61.8 -> 59.0 us */
 #endif
 #if OV_WPE_ITX > 0
 #define OV_OCC_ITX __attribute__((amdgpu_waves_per_eu(OV_WPE_ITX)))

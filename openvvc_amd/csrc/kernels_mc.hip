@@ -21,7 +21,7 @@
 // Occupancy hint (waves per SIMD the register allocator must leave room for; 0 = compiler default).
 // -DOV_WPE_MC=n overrides it for sweeps.
 #ifndef OV_WPE_MC
-#define OV_WPE_MC 0
+#define OV_WPE_MC 8       /* measured (tools/sweep_occupancy.sh): k_mc2 48.5 -> 46.5 us */
 #endif
 #if OV_WPE_MC > 0
 #define OV_OCC_MC __attribute__((amdgpu_waves_per_eu(OV_WPE_MC)))
