@@ -90,7 +90,7 @@ __device__ __forceinline__ void filter_idx(uint32_t sum_h, uint32_t sum_v, uint3
 
 // one 32x32 luma tile (workgroup `tile0` of the luma part of k_alf)
 __device__ __forceinline__ void alf_luma_tile(const ovhip_pic &dst, const ovhip_pic &src, const ovhip_alf_pic &alf, int nb_ctu_w,
-                                              int tile0, uint16_t *s_t, uint8_t *s_cls)
+                                              int tile0, uint16_t *s_t, uint8_t *s_cls, uint4 *s_sum)
 {
 
     const int W = src.w, H = src.h;
@@ -185,17 +185,20 @@ __device__ __forceinline__ void alf_luma_tile(const ovhip_pic &dst, const ovhip_
         if (py == vb - 4) { is_vb = true; use = k < 3; }
         if (py == vb)     { is_vb = true; use = k > 0; }
         if (!use) sv = sh = sd = sb = 0;
-        // sum over the 4 lanes of the block (lanes 4b..4b+3 of one wave)
-#pragma unroll
-        for (int m = 1; m < 4; m <<= 1) {
-            sv += __shfl_xor((int)sv, m); sh += __shfl_xor((int)sh, m);
-            sd += __shfl_xor((int)sd, m); sb += __shfl_xor((int)sb, m);
-        }
-        if (k == 0) {
-            int cls, tr;
-            filter_idx(sh, sv, sd, sb, is_vb, cls, tr);
-            s_cls[cb] = (uint8_t)(cls | (tr << 5));
-        }
+        // Every lane parks its row pair's sums; ONE wave then adds the four pairs of each of the tile's 64 blocks and derives
+        // class and transpose (alf_derive_filter_idx is ~45 instructions whatever the number of active lanes: run by all
+        // four waves with a quarter of their lanes it cost four times as much).
+        (void)is_vb;
+        s_sum[tid] = make_uint4(sv, sh, sd, sb);
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const uint4 p0 = s_sum[4 * tid], p1 = s_sum[4 * tid + 1], p2 = s_sum[4 * tid + 2], p3 = s_sum[4 * tid + 3];
+        const int py = ty0 + (tid >> 3) * 4;
+        int cls, tr;
+        filter_idx(p0.y + p1.y + p2.y + p3.y, p0.x + p1.x + p2.x + p3.x, p0.z + p1.z + p2.z + p3.z, p0.w + p1.w + p2.w + p3.w,
+                   py == vb - 4 || py == vb, cls, tr);
+        s_cls[tid] = (uint8_t)(cls | (tr << 5));
     }
     __syncthreads();
 
@@ -482,8 +485,9 @@ __global__ __launch_bounds__(256) OV_OCC_ALF void k_alf(ovhip_pic dst, ovhip_pic
 {
     __shared__ __attribute__((aligned(16))) uint16_t s_t[(LW > CW ? LW : CW) * LWS];
     __shared__ uint8_t s_cls[64];
+    __shared__ __attribute__((aligned(16))) uint4 s_sum[256];          // luma classification: one row pair's Laplacian sums per lane
     const int b = blockIdx.x;
-    if (b < nl) alf_luma_tile(dst, src, alf, nb_ctu_w, b, s_t, s_cls);
+    if (b < nl) alf_luma_tile(dst, src, alf, nb_ctu_w, b, s_t, s_cls, s_sum);
     else        alf_chroma_tile(dst, src, alf, nb_ctu_w, (b - nl) % nc, 1 + (b - nl) / nc, s_t);
 }
 
