@@ -495,8 +495,8 @@ int   ovhip_rec_dbf_ctu(ovhip_recorder *rec, const ovhip_dbf_ctu *ctu);
 int   ovhip_rec_dbf_planes(const ovhip_recorder *rec, ovhip_dbf_planes *out);
 /* Access to the recorded (host) buffers. */
 const ovhip_tb_cmd  *ovhip_rec_tb_cmds(const ovhip_recorder *rec, size_t *n);
-/* The same commands reordered into four classes: luma blocks with a side > 16, luma blocks <= 16x16, chroma
- * blocks with a side > 16, chroma blocks <= 16x16 (counts[0..3]).  Luma first because with device-derived
+/* The same commands reordered into four classes: big luma blocks, small luma blocks, big chroma blocks, small chroma
+ * blocks (counts[0..3]); small = at most 256 samples and no side above 32 (16x16, 32x8, 8x32, 32x4, ...).  Luma first because with device-derived
  * chroma scales the chroma commands must run after ovhip_lmcs_scale_launch, which must run after the luma
  * ones; by size because ovhip_itx_launch_classes gives big and small blocks different workgroup shapes. */
 const ovhip_tb_cmd  *ovhip_rec_tb_cmds_split(ovhip_recorder *rec, size_t counts[4], size_t *n);
@@ -542,7 +542,7 @@ int  ovhip_pic_download(ovhip_ctx *ctx, const ovhip_pic *pic, uint16_t *y, uint1
 int  ovhip_itx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_tb_cmd *d_cmds,
                       uint32_t n_cmds, const int16_t *d_coefs, const int16_t *d_lmcs_scales);
 /* Same, for a command list sorted by ovhip_rec_tb_cmds_split: the first n_large commands may have any size,
- * the following n_small commands must all be <= 16x16. */
+ * the following n_small commands must all be small in the sense of ovhip_rec_tb_cmds_split. */
 int  ovhip_itx_launch_classes(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_tb_cmd *d_cmds,
                               uint32_t n_large, uint32_t n_small, const int16_t *d_coefs,
                               const int16_t *d_lmcs_scales);

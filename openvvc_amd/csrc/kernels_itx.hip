@@ -193,26 +193,22 @@ __device__ __forceinline__ void lmcs_inverse_rows(const ovhip_pic &pic, const ui
     }
 }
 
-// LDS of one block, int16 entries: s_coef (transform blocks [column][row], stride tile_stride(ch); everything else raster
-// [row][column], stride tb_w), s_tmp (pass 1 -> pass 2: [row][column k]), s_mv and s_mh (cores [output][k]).
-template <int ML2> struct ItxLds {
-    static constexpr int MC = ML2 > 5 ? 32 : (1 << ML2);               // stored coefficient extent per dimension
-    static constexpr int MS = tile_stride_c(MC);                       // longest k-contiguous row
-    static constexpr int COEF = MC * MS, TILE = (1 << ML2) * MS, TOTAL = COEF + 3 * TILE;
-};
+// LDS of one block, int16 entries, carved at run time from the block's own dimensions: s_coef (transform blocks
+// [column][row], stride tile_stride(ch); everything else raster [row][column], stride tb_w), s_tmp (pass 1 -> pass 2:
+// [row][column k]), s_mv and s_mh (cores [output][k]).  A 64x64 block needs 32*36 + 3 * 64*36 = 8064 entries; a block
+// of at most 256 samples with no side above 32 (16x16, 32x8, 8x32, 32x4, ...) at most 1760: its slice is 2048.
+#define ITX_LDS_BIG   8064
+#define ITX_LDS_SLICE 2048
 
-// One transform block by NT threads (lane 0 .. NT-1): <6, 256> any block up to 64x64, four waves per block (a 64x64
-// block is ~200k MACs: one wave alone would be the tail of the launch); <4, 64> blocks up to 16x16, one wave and
-// 2.5 KB of LDS.  EVERY path runs the same four barriers, whatever the block needs (LFNST, BDPCM, nothing): that is
+// One transform block by NT threads (lane 0 .. NT-1): <256> any block up to 64x64, four waves per block (a 64x64
+// block is ~200k MACs: one wave alone would be the tail of the launch); <64> blocks of at most 256 samples, one wave and
+// a 4 KB slice of LDS.  EVERY path runs the same four barriers, whatever the block needs (LFNST, BDPCM, nothing): that is
 // what lets four waves with four different small blocks share a 256-thread workgroup (k_itx_all); a wave without a
 // block (valid = false) only keeps the barriers company.
-template <int ML2, int NT>
+template <int NT>
 __device__ __forceinline__ void itx_block(const ovhip_pic &pic, const ovhip_tb_cmd &c, bool valid, const int16_t *__restrict__ arena,
                                           const int16_t *__restrict__ lmcs_scales, int ablate, int lane, int16_t *lds)
 {
-    typedef ItxLds<ML2> L;
-    int16_t *const s_coef = lds, *const s_tmp = lds + L::COEF, *const s_mv = s_tmp + L::TILE, *const s_mh = s_mv + L::TILE;
-
     const int log2_w = c.log2_w, log2_h = c.log2_h;
     const int tb_w = 1 << log2_w, tb_h = 1 << log2_h;
     const int kind = c.kind & 0x3f;
@@ -236,22 +232,28 @@ __device__ __forceinline__ void itx_block(const ovhip_pic &pic, const ovhip_tb_c
     const bool is_tr = kind == OVHIP_TB_TR;
     const int cs = tile_stride(ch);                       // s_coef row length of a transform block
     const int msv = tile_stride(kv), msh = tile_stride(kh);
+    // the four tiles (sizes rounded to 8 entries: every tile starts 16-byte aligned)
+    const int n_coef = (max(cw * cs, is_tr ? 0 : tb_w * tb_h) + 7) & ~7, n_tmp = (tb_h * msh + 7) & ~7, n_mv = (tb_h * msv + 7) & ~7;
+    int16_t *const s_coef = lds, *const s_tmp = lds + n_coef, *const s_mv = s_tmp + n_tmp, *const s_mh = s_mv + n_mv;
     if (valid && is_tr && !(ablate & 1)) {
         // 16-byte chunks (8 values of one core row): at most 64 * 32 / 8 = 256 <= NT per core for <6, 256>, 32 for <4, 64>
         const int l2cv = kv >= 32 ? 2 : kv >= 16 ? 1 : 0, l2ch = kh >= 32 ? 2 : kh >= 16 ? 1 : 0;   // chunks per row
         const int nv = tb_h << l2cv, nh = tb_w << l2ch;
         const uint4 *mv4 = reinterpret_cast<const uint4 *>(tr_core(c.tr_v, log2_h));
         const uint4 *mh4 = reinterpret_cast<const uint4 *>(tr_core(c.tr_h, log2_w));
-        uint4 a = make_uint4(0, 0, 0, 0), b = a;
-        if (lane < nv) a = mv4[lane];
-        if (lane < nh) b = mh4[lane];
-        if (lane < nv) {
-            uint2 *d = reinterpret_cast<uint2 *>(s_mv + (lane >> l2cv) * msv + ((lane & ((1 << l2cv) - 1)) << 3));
-            d[0] = make_uint2(a.x, a.y); d[1] = make_uint2(a.z, a.w);
-        }
-        if (lane < nh) {
-            uint2 *d = reinterpret_cast<uint2 *>(s_mh + (lane >> l2ch) * msh + ((lane & ((1 << l2ch) - 1)) << 3));
-            d[0] = make_uint2(b.x, b.y); d[1] = make_uint2(b.z, b.w);
+        // (one pass for NT = 256; a 32-point core of a one-wave block is 128 chunks: two passes)
+        for (int i = lane; i < max(nv, nh); i += NT) {
+            uint4 a = make_uint4(0, 0, 0, 0), b = a;
+            if (i < nv) a = mv4[i];
+            if (i < nh) b = mh4[i];
+            if (i < nv) {
+                uint2 *d = reinterpret_cast<uint2 *>(s_mv + (i >> l2cv) * msv + ((i & ((1 << l2cv) - 1)) << 3));
+                d[0] = make_uint2(a.x, a.y); d[1] = make_uint2(a.z, a.w);
+            }
+            if (i < nh) {
+                uint2 *d = reinterpret_cast<uint2 *>(s_mh + (i >> l2ch) * msh + ((i & ((1 << l2ch) - 1)) << 3));
+                d[0] = make_uint2(b.x, b.y); d[1] = make_uint2(b.z, b.w);
+            }
         }
     }
 
@@ -421,19 +423,18 @@ __global__ __launch_bounds__(256) OV_OCC_ITX void k_itx_all(ovhip_pic pic, const
                                                   const int16_t *__restrict__ lmcs_scales, int ablate,
                                                   const uint16_t *__restrict__ lmcs_inv_lut, uint32_t n_extra)
 {
-    __shared__ __attribute__((aligned(16))) int16_t lds[ItxLds<6>::TOTAL];
-    static_assert(4 * ItxLds<4>::TOTAL <= ItxLds<6>::TOTAL && 2048 <= 2 * ItxLds<6>::TOTAL, "slices must fit the big block's tiles");
+    __shared__ __attribute__((aligned(16))) int16_t lds[ITX_LDS_BIG > 4 * ITX_LDS_SLICE ? ITX_LDS_BIG : 4 * ITX_LDS_SLICE];
     const uint32_t b = blockIdx.x, n_quads = (n_small + 3) >> 2;
     // XCD-aware order (see k_mc2): each XCD takes a contiguous chunk of the sorted list, so blocks that share frame
     // cache lines meet in one L2
     if (b < n_large) {
-        itx_block<6, 256>(pic, cmds[ov_xcd_slot(b, n_large)], true, arena, lmcs_scales, ablate, threadIdx.x, lds);
+        itx_block<256>(pic, cmds[ov_xcd_slot(b, n_large)], true, arena, lmcs_scales, ablate, threadIdx.x, lds);
     } else if (b < n_large + n_quads) {
         const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // wave-uniform: the command stays in SGPRs
         const uint32_t i = ov_xcd_slot(b - n_large, n_quads) * 4 + w;
         const bool valid = i < n_small;
-        itx_block<4, 64>(pic, cmds[n_large + (valid ? i : 0)], valid, arena, lmcs_scales, ablate, threadIdx.x & 63,
-                         lds + w * ItxLds<4>::TOTAL);
+        itx_block<64>(pic, cmds[n_large + (valid ? i : 0)], valid, arena, lmcs_scales, ablate, threadIdx.x & 63,
+                      lds + w * ITX_LDS_SLICE);
     } else {
         lmcs_inverse_rows<256>(pic, lmcs_inv_lut, b - n_large - n_quads, n_extra, reinterpret_cast<uint16_t *>(lds));
     }

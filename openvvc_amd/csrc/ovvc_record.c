@@ -746,7 +746,8 @@ ovhip_rec_tb_cmds_split(ovhip_recorder *r, size_t counts[4], size_t *n)
     counts[0] = counts[1] = counts[2] = counts[3] = 0;
     if (!r->n_tb) return r->tb;
     if (grow((void **)&r->tb_split, &r->cap_split, r->n_tb, sizeof(ovhip_tb_cmd))) { *n = 0; return NULL; }
-#define TB_CLASS(c) (((c)->plane != 0) * 2 + ((c)->log2_w <= 4 && (c)->log2_h <= 4))
+    /* "small" = what one wavefront and a 4 KB slice of LDS take: at most 256 samples, no side above 32 */
+#define TB_CLASS(c) (((c)->plane != 0) * 2 + ((c)->log2_w + (c)->log2_h <= 8 && (c)->log2_w <= 5 && (c)->log2_h <= 5))
     for (size_t i = 0; i < r->n_tb; ++i) counts[TB_CLASS(&r->tb[i])]++;
     for (k = 0, start[0] = 0; k < 3; ++k) start[k + 1] = start[k] + counts[k];
     for (size_t i = 0; i < r->n_tb; ++i) r->tb_split[start[TB_CLASS(&r->tb[i])]++] = r->tb[i];

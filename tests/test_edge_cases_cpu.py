@@ -62,7 +62,8 @@ def test_empty_and_reset(built_lib):
 def test_tb_class_split_is_a_stable_partition(built_lib):
     wl = synth.make_workload(416, 240, 21)
     c, k = wl.tb_cmds, wl.tb_classes
-    big = (c["log2_w"] > 4) | (c["log2_h"] > 4)
+    # small = what one wavefront takes: at most 256 samples, no side above 32 (ovhip_rec_tb_cmds_split)
+    big = (c["log2_w"].astype(int) + c["log2_h"] > 8) | (c["log2_w"] > 5) | (c["log2_h"] > 5)
     luma = c["plane"] == 0
     o = np.cumsum((0,) + k)
     assert luma[:o[2]].all() and not luma[o[2]:].any()
