@@ -220,35 +220,40 @@ __global__ __launch_bounds__(64) OV_OCC_MC void k_mc2(ovhip_pic dst, RefTable re
     __syncthreads();
     OV_PHASE(2);
 
-    // ---- horizontal passes: one task = one window row x 4 outputs.  Chroma first (see the LDS layout) ----
+    // ---- horizontal passes: one task = one window row x 4 outputs.  Chroma first (see the LDS layout).
+    // The lanes are dealt to the windows in equal groups (luma: 64 or 2 x 32 lanes, chroma: 2 x 32 or 4 x 16), so that
+    // everything a task needs except its row -- list, taps, alignment, tile -- is fixed per lane and leaves the loop
+    // (a loop over one merged task list spent a quarter of this kernel's vector instructions on that bookkeeping); the
+    // iteration counts are the same as for the merged list in every common unit shape. ----
     if (do_c) {
         const int log2seg = log2wc > 2 ? log2wc - 2 : 0;
-        const int TC = (hc + 3) << log2seg;
-        for (int t = lane; t < 2 * nl * TC; t += 64) {
-            const int qi = (t >= TC) + (t >= 2 * TC) + (t >= 3 * TC), tt = t - qi * TC;
-            const int plane = nl == 2 ? qi >> 1 : qi, l = l0 + (nl == 2 ? (qi & 1) : 0);
-            const int r = tt >> log2seg, x0 = (tt & ((1 << log2seg) - 1)) << 2;
-            int tp[2];
+        const int l2per = nl == 2 ? 4 : 5;                                // lanes per window: 16 (4 windows) or 32 (2)
+        const int qi = lane >> l2per, tl = lane & ((1 << l2per) - 1);
+        const int plane = nl == 2 ? qi >> 1 : qi, l = l0 + (nl == 2 ? (qi & 1) : 0);
+        int tp[2];
 #pragma unroll
-            for (int m = 0; m < 2; ++m) tp[m] = l ? thc[1][m] : thc[0][m];
-            const int off = plane ? (l ? offc[1][1] : offc[1][0]) : (l ? offc[0][1] : offc[0][0]);
-            h_task<4>(s_wc + (plane * 2 + l) * CHR_WIN + r * CWIN_STRIDE, off, x0, tp, l ? identc[1] : identc[0],
-                      s_hc + (plane * 2 + l) * 8 * CHT_STRIDE, CHT_STRIDE, r);
-        }
+        for (int m = 0; m < 2; ++m) tp[m] = l ? thc[1][m] : thc[0][m];
+        const int off = plane ? (l ? offc[1][1] : offc[1][0]) : (l ? offc[0][1] : offc[0][0]);
+        const bool ident = l ? identc[1] : identc[0];
+        const uint16_t *src = s_wc + (plane * 2 + l) * CHR_WIN;
+        int16_t *ht = s_hc + (plane * 2 + l) * 8 * CHT_STRIDE;
+        const int x0 = (tl & ((1 << log2seg) - 1)) << 2, rstep = (1 << l2per) >> log2seg;
+        for (int r = tl >> log2seg; r < hc + 3; r += rstep) h_task<4>(src + r * CWIN_STRIDE, off, x0, tp, ident, ht, CHT_STRIDE, r);
     }
     __syncthreads();          // the chroma windows are dead: s_hl takes their place
     if (do_l) {
         const int log2seg = log2w > 2 ? log2w - 2 : 0;
-        const int TY = (h + 7) << log2seg;
-        for (int t = lane; t < nl * TY; t += 64) {
-            const int li = t >= TY, l = l0 + li, tt = t - li * TY;
-            const int r = tt >> log2seg, x0 = (tt & ((1 << log2seg) - 1)) << 2;
-            int tp[4];
+        const int l2per = nl == 2 ? 5 : 6;                                // lanes per window: 32 (2 lists) or 64
+        const int li = lane >> l2per, tl = lane & ((1 << l2per) - 1), l = l0 + li;
+        int tp[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) tp[m] = l ? thl[1][m] : thl[0][m];
-            h_task<8>(s_wl + l * LUMA_WIN + r * WIN_STRIDE, l ? offl[1] : offl[0], x0, tp, l ? identl[1] : identl[0],
-                      s_hl + l * 16 * HL_STRIDE, HL_STRIDE, r);
-        }
+        for (int m = 0; m < 4; ++m) tp[m] = l ? thl[1][m] : thl[0][m];
+        const int off = l ? offl[1] : offl[0];
+        const bool ident = l ? identl[1] : identl[0];
+        const uint16_t *src = s_wl + l * LUMA_WIN;
+        int16_t *ht = s_hl + l * 16 * HL_STRIDE;
+        const int x0 = (tl & ((1 << log2seg) - 1)) << 2, rstep = (1 << l2per) >> log2seg;
+        for (int r = tl >> log2seg; r < h + 7; r += rstep) h_task<8>(src + r * WIN_STRIDE, off, x0, tp, ident, ht, HL_STRIDE, r);
     }
     __syncthreads();
     OV_PHASE(3);
