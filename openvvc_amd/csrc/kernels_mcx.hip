@@ -286,32 +286,32 @@ __device__ __forceinline__ void mcx_units(const ovhip_pic &dst, const RefTable &
         load_taps<2>(g_taps.chroma[mv[l][0] & 31], thc[l]);
         identl[l] = fx == 0; identc[l] = (mv[l][0] & 31) == 0;
     }
+    // lanes dealt to the windows in fixed groups (luma 2 x 32, chroma 4 x 16), as in k_mc2: only the row changes in the loops
     if (do_l) {
-        const int log2seg = log2w - 2, TY = (h + 7) << log2seg;
-        for (int t = lane; t < 2 * TY; t += 64) {
-            const int l = t >= TY, tt = t - l * TY;
-            const int r = tt >> log2seg, x0 = (tt & ((1 << log2seg) - 1)) << 2;
-            int tp[4];
+        const int log2seg = log2w - 2;
+        const int l = lane >> 5, tl = lane & 31;
+        int tp[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) tp[m] = l ? thl[1][m] : thl[0][m];
-            h_task<8>(s_wl[0] + l * (XWIN_ROWS * XWIN_STRIDE) + (2 + (l ? ldy[1] : ldy[0]) + r) * XWIN_STRIDE,
-                      4 + (l ? offl[1] + ldx[1] : offl[0] + ldx[0]), x0, tp, l ? identl[1] : identl[0],
-                      s_hl[0] + l * 16 * HT_STRIDE, HT_STRIDE, r);
-        }
+        for (int m = 0; m < 4; ++m) tp[m] = l ? thl[1][m] : thl[0][m];
+        const uint16_t *src = s_wl[0] + l * (XWIN_ROWS * XWIN_STRIDE) + (2 + (l ? ldy[1] : ldy[0])) * XWIN_STRIDE;
+        const int off = 4 + (l ? offl[1] + ldx[1] : offl[0] + ldx[0]);
+        const bool ident = l ? identl[1] : identl[0];
+        int16_t *ht = s_hl[0] + l * 16 * HT_STRIDE;
+        const int x0 = (tl & ((1 << log2seg) - 1)) << 2, rstep = 32 >> log2seg;
+        for (int r = tl >> log2seg; r < h + 7; r += rstep) h_task<8>(src + r * XWIN_STRIDE, off, x0, tp, ident, ht, HT_STRIDE, r);
     }
     if (do_c) {
-        const int log2seg = log2wc > 2 ? log2wc - 2 : 0, TC = (hc + 3) << log2seg;
-        for (int t = lane; t < 4 * TC; t += 64) {
-            const int qi = (t >= TC) + (t >= 2 * TC) + (t >= 3 * TC), tt = t - qi * TC;
-            const int l = qi & 1;                                        // window qi = plane * 2 + list
-            const int r = tt >> log2seg, x0 = (tt & ((1 << log2seg) - 1)) << 2;
-            int tp[2];
+        const int log2seg = log2wc > 2 ? log2wc - 2 : 0;
+        const int qi = lane >> 4, tl = lane & 15, l = qi & 1;            // window qi = plane * 2 + list
+        int tp[2];
 #pragma unroll
-            for (int m = 0; m < 2; ++m) tp[m] = thc[0][m] ^ ((thc[0][m] ^ thc[1][m]) & -l);   // arithmetic select: keeps the taps in registers
-            h_task<4>(s_wc[0][0] + qi * (XCWIN_ROWS * XCWIN_STRIDE) + (2 + (l ? cdy[1] : cdy[0]) + r) * XCWIN_STRIDE,
-                      4 + (l ? offc[1] + cdx[1] : offc[0] + cdx[0]), x0, tp, l ? identc[1] : identc[0],
-                      s_hc[0][0] + qi * 8 * CHT_STRIDE, CHT_STRIDE, r);
-        }
+        for (int m = 0; m < 2; ++m) tp[m] = thc[0][m] ^ ((thc[0][m] ^ thc[1][m]) & -l);   // arithmetic select: keeps the taps in registers
+        const uint16_t *src = s_wc[0][0] + qi * (XCWIN_ROWS * XCWIN_STRIDE) + (2 + (l ? cdy[1] : cdy[0])) * XCWIN_STRIDE;
+        const int off = 4 + (l ? offc[1] + cdx[1] : offc[0] + cdx[0]);
+        const bool ident = l ? identc[1] : identc[0];
+        int16_t *ht = s_hc[0][0] + qi * 8 * CHT_STRIDE;
+        const int x0 = (tl & ((1 << log2seg) - 1)) << 2, rstep = 16 >> log2seg;
+        for (int r = tl >> log2seg; r < hc + 3; r += rstep) h_task<4>(src + r * XCWIN_STRIDE, off, x0, tp, ident, ht, CHT_STRIDE, r);
     }
     __syncthreads();
 
