@@ -197,26 +197,25 @@ __global__ __launch_bounds__(64) OV_OCC_MC void k_mc2(ovhip_pic dst, RefTable re
         lx[l] = u.x + (mvx >> 4) - 3;        ly[l] = u.y + (mvy >> 4) - 3;
         cx[l] = (u.x >> 1) + (mvx >> 5) - 1; cy[l] = (u.y >> 1) + (mvy >> 5) - 1;
     }
+    // Horizontal taps: every lane works for ONE window in the H passes (see there), so it fetches that list's filter itself
+    // -- a broadcast vector load issued here, ahead of the window loads, instead of both lists' taps in SGPRs and a select
+    // per tap (the kernel is short of SGPRs; vertical taps, which every lane needs for both lists, stay scalar).
+    const uint32_t (*const ltab)[4] = (u.flags & OVHIP_MC_FILT_4x4) ? g_taps.luma4 : g_taps.luma;
+    const bool hpel = !(u.flags & OVHIP_MC_FILT_4x4) && (u.flags & OVHIP_MC_HPEL_FILT);
+    const int hl_l = l0 + (nl == 2 ? lane >> 5 : 0);                          // list of this lane's luma window
+    const int hc_q = lane >> (nl == 2 ? 4 : 5);                               // chroma window: plane * 2 + list (2 lists) / plane
+    const int hc_l = l0 + (nl == 2 ? (hc_q & 1) : 0);
+    int fxl = (hl_l ? u.mv1x : u.mv0x) & 15;
+    if (hpel && fxl == 8) fxl = 16;
+    const int fxc = (hc_l ? u.mv1x : u.mv0x) & 31;
+    const uint4 hl_tp = *reinterpret_cast<const uint4 *>(ltab[fxl]);
+    const uint2 hc_tp = *reinterpret_cast<const uint2 *>(g_taps.chroma[fxc]);
     uint16_t *const lwin[2] = { s_wl, s_wl + LUMA_WIN };
     uint16_t *const cwin[4] = { s_wc, s_wc + CHR_WIN, s_wc + 2 * CHR_WIN, s_wc + 3 * CHR_WIN };
     int offl[2], offc1[2];
     stage_unit_windows(dst, ry, rcb, rcr, lx, ly, cx, cy, w, h, u.dir, do_l, do_c, lane, lwin, WIN_STRIDE, cwin, CWIN_STRIDE, offl, offc1);
     const int offc[2][2] = { { offc1[0], offc1[1] }, { offc1[0], offc1[1] } };
     // ---- filter taps of both lists (wave-uniform) ----
-    // (horizontal taps here, vertical taps right before the vertical pass: 12 fewer live SGPRs through the H pass)
-    int thl[2][4], thc[2][2];
-    bool identl[2], identc[2];
-    const uint32_t (*const ltab)[4] = (u.flags & OVHIP_MC_FILT_4x4) ? g_taps.luma4 : g_taps.luma;
-    const bool hpel = !(u.flags & OVHIP_MC_FILT_4x4) && (u.flags & OVHIP_MC_HPEL_FILT);
-#pragma unroll
-    for (int l = 0; l < 2; ++l) {
-        const int mvx = l ? u.mv1x : u.mv0x;
-        int fx = mvx & 15;
-        if (hpel && fx == 8) fx = 16;
-        load_taps<4>(ltab[fx], thl[l]);
-        load_taps<2>(g_taps.chroma[mvx & 31], thc[l]);
-        identl[l] = fx == 0; identc[l] = (mvx & 31) == 0;
-    }
     __syncthreads();
     OV_PHASE(2);
 
@@ -228,13 +227,11 @@ __global__ __launch_bounds__(64) OV_OCC_MC void k_mc2(ovhip_pic dst, RefTable re
     if (do_c) {
         const int log2seg = log2wc > 2 ? log2wc - 2 : 0;
         const int l2per = nl == 2 ? 4 : 5;                                // lanes per window: 16 (4 windows) or 32 (2)
-        const int qi = lane >> l2per, tl = lane & ((1 << l2per) - 1);
-        const int plane = nl == 2 ? qi >> 1 : qi, l = l0 + (nl == 2 ? (qi & 1) : 0);
-        int tp[2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) tp[m] = l ? thc[1][m] : thc[0][m];
+        const int qi = hc_q, tl = lane & ((1 << l2per) - 1);
+        const int plane = nl == 2 ? qi >> 1 : qi, l = hc_l;
+        const int tp[2] = { (int)hc_tp.x, (int)hc_tp.y };
         const int off = plane ? (l ? offc[1][1] : offc[1][0]) : (l ? offc[0][1] : offc[0][0]);
-        const bool ident = l ? identc[1] : identc[0];
+        const bool ident = fxc == 0;
         const uint16_t *src = s_wc + (plane * 2 + l) * CHR_WIN;
         int16_t *ht = s_hc + (plane * 2 + l) * 8 * CHT_STRIDE;
         const int x0 = (tl & ((1 << log2seg) - 1)) << 2, rstep = (1 << l2per) >> log2seg;
@@ -244,12 +241,10 @@ __global__ __launch_bounds__(64) OV_OCC_MC void k_mc2(ovhip_pic dst, RefTable re
     if (do_l) {
         const int log2seg = log2w > 2 ? log2w - 2 : 0;
         const int l2per = nl == 2 ? 5 : 6;                                // lanes per window: 32 (2 lists) or 64
-        const int li = lane >> l2per, tl = lane & ((1 << l2per) - 1), l = l0 + li;
-        int tp[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) tp[m] = l ? thl[1][m] : thl[0][m];
+        const int tl = lane & ((1 << l2per) - 1), l = hl_l;
+        const int tp[4] = { (int)hl_tp.x, (int)hl_tp.y, (int)hl_tp.z, (int)hl_tp.w };
         const int off = l ? offl[1] : offl[0];
-        const bool ident = l ? identl[1] : identl[0];
+        const bool ident = fxl == 0;
         const uint16_t *src = s_wl + l * LUMA_WIN;
         int16_t *ht = s_hl + l * 16 * HL_STRIDE;
         const int x0 = (tl & ((1 << log2seg) - 1)) << 2, rstep = (1 << l2per) >> log2seg;
