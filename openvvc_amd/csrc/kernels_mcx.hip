@@ -272,8 +272,7 @@ __device__ __forceinline__ void mcx_units(const ovhip_pic &dst, const RefTable &
     // ---- 3. horizontal passes at the refined position: both lists (and both chroma planes) in one task loop ----
     const uint32_t *fvl[2];
     int ldx[2], ldy[2], cdx[2], cdy[2], ext[2][2];
-    int thl[2][4], thc[2][2];
-    bool identl[2], identc[2];
+    int fxs[2];
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
         int fx = mv[l][0] & 15, fy = mv[l][1] & 15;
@@ -282,20 +281,20 @@ __device__ __forceinline__ void mcx_units(const ovhip_pic &dst, const RefTable &
         fvl[l] = g_taps.luma[fy];
         ldx[l] = (mv[l][0] >> 4) - (ini[l][0] >> 4); ldy[l] = (mv[l][1] >> 4) - (ini[l][1] >> 4);
         cdx[l] = (mv[l][0] >> 5) - (ini[l][0] >> 5); cdy[l] = (mv[l][1] >> 5) - (ini[l][1] >> 5);
-        load_taps<4>(g_taps.luma[fx], thl[l]);
-        load_taps<2>(g_taps.chroma[mv[l][0] & 31], thc[l]);
-        identl[l] = fx == 0; identc[l] = (mv[l][0] & 31) == 0;
+        fxs[l] = fx;
     }
+    // horizontal taps per lane (its window's list), as in k_mc2
+    const int hfx = (lane >> 5) ? fxs[1] : fxs[0], hfc = ((lane >> 4) & 1 ? mv[1][0] : mv[0][0]) & 31;
+    const uint4 hl_tp = *reinterpret_cast<const uint4 *>(g_taps.luma[hfx]);
+    const uint2 hc_tp = *reinterpret_cast<const uint2 *>(g_taps.chroma[hfc]);
     // lanes dealt to the windows in fixed groups (luma 2 x 32, chroma 4 x 16), as in k_mc2: only the row changes in the loops
     if (do_l) {
         const int log2seg = log2w - 2;
         const int l = lane >> 5, tl = lane & 31;
-        int tp[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) tp[m] = l ? thl[1][m] : thl[0][m];
+        const int tp[4] = { (int)hl_tp.x, (int)hl_tp.y, (int)hl_tp.z, (int)hl_tp.w };
         const uint16_t *src = s_wl[0] + l * (XWIN_ROWS * XWIN_STRIDE) + (2 + (l ? ldy[1] : ldy[0])) * XWIN_STRIDE;
         const int off = 4 + (l ? offl[1] + ldx[1] : offl[0] + ldx[0]);
-        const bool ident = l ? identl[1] : identl[0];
+        const bool ident = hfx == 0;
         int16_t *ht = s_hl[0] + l * 16 * HT_STRIDE;
         const int x0 = (tl & ((1 << log2seg) - 1)) << 2, rstep = 32 >> log2seg;
         for (int r = tl >> log2seg; r < h + 7; r += rstep) h_task<8>(src + r * XWIN_STRIDE, off, x0, tp, ident, ht, HT_STRIDE, r);
@@ -303,12 +302,10 @@ __device__ __forceinline__ void mcx_units(const ovhip_pic &dst, const RefTable &
     if (do_c) {
         const int log2seg = log2wc > 2 ? log2wc - 2 : 0;
         const int qi = lane >> 4, tl = lane & 15, l = qi & 1;            // window qi = plane * 2 + list
-        int tp[2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) tp[m] = thc[0][m] ^ ((thc[0][m] ^ thc[1][m]) & -l);   // arithmetic select: keeps the taps in registers
+        const int tp[2] = { (int)hc_tp.x, (int)hc_tp.y };
         const uint16_t *src = s_wc[0][0] + qi * (XCWIN_ROWS * XCWIN_STRIDE) + (2 + (l ? cdy[1] : cdy[0])) * XCWIN_STRIDE;
         const int off = 4 + (l ? offc[1] + cdx[1] : offc[0] + cdx[0]);
-        const bool ident = l ? identc[1] : identc[0];
+        const bool ident = hfc == 0;
         int16_t *ht = s_hc[0][0] + qi * 8 * CHT_STRIDE;
         const int x0 = (tl & ((1 << log2seg) - 1)) << 2, rstep = 16 >> log2seg;
         for (int r = tl >> log2seg; r < hc + 3; r += rstep) h_task<4>(src + r * XCWIN_STRIDE, off, x0, tp, ident, ht, CHT_STRIDE, r);
