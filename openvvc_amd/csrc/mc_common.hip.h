@@ -198,14 +198,7 @@ __device__ __forceinline__ void fir4(const int d[NT / 2 + 2], const int tp[NT / 
     }
 }
 
-template <int NT>
-__device__ __forceinline__ void pack_taps(const int8_t *f, int tp[NT / 2])
-{
-#pragma unroll
-    for (int m = 0; m < NT / 2; ++m) tp[m] = ((int)f[2 * m] & 0xffff) | ((int)f[2 * m + 1] << 16);
-}
-
-// The same pairs ((f[2m], f[2m+1]) as int16 halves of one dword, what v_dot2_i32_i16 multiplies), packed at COMPILE time:
+// Filter taps as pairs ((f[2m], f[2m+1]) = int16 halves of one dword, what v_dot2_i32_i16 multiplies), packed at COMPILE time:
 // a wave-uniform filter is then one scalar load instead of 8 byte loads, 8 sign extensions and 12 shift / or (the tap
 // set-up was a fifth of k_mc2's scalar instructions).  luma6 = the 6 taps 1..6 of the 4x4-block luma filter.
 struct PackedTaps { uint32_t luma[17][4], luma4[16][4], luma6[16][4], chroma[32][2]; };
