@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define OVHIP_ABI_VERSION 3
+#define OVHIP_ABI_VERSION 4
 
 /* ---- error codes (negative, in the spirit of libovvc/overror.h:40-45) ---- */
 #define OVHIP_OK        0
@@ -457,6 +457,16 @@ typedef struct ovhip_affine_desc {
 #define OVHIP_PU_GPM  4       /* rcn_gpm_b: mv0/ref0 and mv1/ref1 are gpm_ctx->mv0 / mv1 and their pictures */
 
 ovhip_recorder *ovhip_rec_create(int32_t pic_w, int32_t pic_h);
+/* The recorder's arrays from a caller-supplied allocator: the engine passes page-locked host memory so that the
+ * per-picture flush (ovhip_job_flush) is plain asynchronous DMA out of the arrays the slots wrote. */
+typedef struct ovhip_allocator {
+    void *(*alloc)(void *user, size_t bytes);
+    void  (*free)(void *user, void *p);
+    void  *user;
+} ovhip_allocator;
+ovhip_recorder *ovhip_rec_create_ex(int32_t pic_w, int32_t pic_h, const ovhip_allocator *a);
+/* on (default): ovhip_rec_dbf_ctu also maintains the dense edge planes of ovhip_rec_dbf_planes; off: edge lists only */
+void  ovhip_rec_set_dense_dbf_planes(ovhip_recorder *rec, int on);
 void  ovhip_rec_destroy(ovhip_recorder *rec);
 void  ovhip_rec_reset(ovhip_recorder *rec);
 /* Append the commands of one TU / PU.  Return number of commands appended or <0. */
@@ -483,8 +493,15 @@ typedef struct ovhip_dbf_edge {
     uint16_t ux, uy;
     uint16_t word;            /* OVHIP_DBF_LUMA(...) or the chroma word, as in the planes          */
     uint8_t  comp;            /* 0 Y, 1 Cb, 2 Cr                                                   */
-    uint8_t  pad;
+    uint8_t  pad;             /* offset-pair index, see ovhip_dbf_offsets; ovhip_dbf_compact writes 0 */
 } ovhip_dbf_edge;
+/* The deblocking offsets are slice-level state (DBFInfo.beta_offset / tc_offset = sh_luma_*_offset_div2 * 2,
+ * slicedec.c:1416-1417): ovhip_rec_dbf_ctu gives every distinct pair of a picture an index, which travels in
+ * ovhip_dbf_edge.pad.  More than OVHIP_DBF_MAX_OFFSETS distinct pairs in one picture: OVHIP_EUNSUP. */
+#define OVHIP_DBF_MAX_OFFSETS 8
+typedef struct ovhip_dbf_offsets { int8_t beta[OVHIP_DBF_MAX_OFFSETS], tc[OVHIP_DBF_MAX_OFFSETS]; } ovhip_dbf_offsets;
+/* The edge lists ovhip_rec_dbf_ctu emitted so far (CTU by CTU, no sorting needed), dir 0 vertical / 1 horizontal. */
+const ovhip_dbf_edge *ovhip_rec_dbf_edges(const ovhip_recorder *rec, int dir, size_t *n, ovhip_dbf_offsets *offsets);
 /* dir 0: vertical edges, 1: horizontal.  planes: HOST pointers.  Writes at most cap entries to out (may be
  * NULL to count) and returns the number of edges, or <0. */
 int64_t ovhip_dbf_compact(const ovhip_dbf_planes *planes, int dir, ovhip_dbf_edge *out, size_t cap);
@@ -493,6 +510,11 @@ int64_t ovhip_dbf_compact(const ovhip_dbf_planes *planes, int dir, ovhip_dbf_edg
 int   ovhip_rec_dbf_ctu(ovhip_recorder *rec, const ovhip_dbf_ctu *ctu);
 /* Host copies of the edge planes (pointers valid until the next reset/destroy). */
 int   ovhip_rec_dbf_planes(const ovhip_recorder *rec, ovhip_dbf_planes *out);
+/* Bulk append of already-recorded commands to an EMPTY recorder (replay of a stored command stream). */
+enum { OVHIP_REC_TB = 0, OVHIP_REC_COEF, OVHIP_REC_MC, OVHIP_REC_MCX, OVHIP_REC_AFF, OVHIP_REC_SIDE, OVHIP_REC_REGION,
+       OVHIP_REC_CIIP, OVHIP_REC_EDGE_V, OVHIP_REC_EDGE_H, OVHIP_REC_ITASK };
+int   ovhip_rec_append_raw(ovhip_recorder *rec, int which, const void *data, size_t n);
+int   ovhip_rec_set_dbf_offsets(ovhip_recorder *rec, const ovhip_dbf_offsets *offsets, int n);
 /* Access to the recorded (host) buffers. */
 const ovhip_tb_cmd  *ovhip_rec_tb_cmds(const ovhip_recorder *rec, size_t *n);
 /* The same commands reordered into four classes: big luma blocks, small luma blocks, big chroma blocks, small chroma
@@ -568,6 +590,10 @@ int  ovhip_mc_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *refs
 int  ovhip_mcx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs,
                       const ovhip_mc_unit *d_units, uint32_t n_units, const uint16_t *d_lmcs_fwd_lut,
                       int32_t *d_mv_out);
+/* The decoder-side MV refinement of the units that carry OVHIP_MC_DMVR alone: refined vectors to d_mv_out (4 int32 per
+ * unit of the list, other units' entries untouched), no sample written.  geom: any picture of the references' size. */
+int  ovhip_dmvr_search_launch(ovhip_ctx *ctx, const ovhip_pic *geom, const ovhip_pic *refs, uint32_t n_refs,
+                              const ovhip_mc_unit *d_units, uint32_t n_units, int32_t *d_mv_out);
 /* CIIP: blends the intra prediction held in `intra` into `dst` (which holds the inter prediction). */
 int  ovhip_ciip_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *intra,
                        const ovhip_ciip_unit *d_units, uint32_t n_units);
@@ -586,11 +612,72 @@ int  ovhip_dbf_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_dbf_plan
 /* Same filter driven by the compact lists of ovhip_dbf_compact (DEVICE pointers). */
 int  ovhip_dbf_launch_edges(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_dbf_edge *d_edges_v, uint32_t n_v,
                             const ovhip_dbf_edge *d_edges_h, uint32_t n_h, int32_t beta_offset, int32_t tc_offset);
+/* Same with the per-slice offset table of ovhip_rec_dbf_edges (edge.pad selects the pair). */
+int  ovhip_dbf_launch_edges_ex(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_dbf_edge *d_edges_v, uint32_t n_v,
+                               const ovhip_dbf_edge *d_edges_h, uint32_t n_h, const ovhip_dbf_offsets *offsets);
 /* d_params: DEVICE array of ceil(w/ctu)*ceil(h/ctu) entries.  dst and src must not alias. */
 int  ovhip_sao_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *src,
                       const ovhip_sao_ctu *d_params, int32_t log2_ctu_s);
 /* Classification + luma / chroma ALF + CC-ALF.  dst and src must not alias. */
 int  ovhip_alf_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *src, const ovhip_alf_pic *alf);
+
+/* ------------------------------------------------------------------------------------
+ * Picture job: the per-picture "flush" in C.  One job = one picture in flight on one context (= one HIP stream, one
+ * decoder frame thread): a recorder whose arrays are page-locked, the device copies of its buffers, and the launch
+ * chain of the whole rcn path.  This is what the reference-side shim (shim/rcn_hip.c) calls from the LAST
+ * alf.rcn_alf_filter_line of a picture (slicedec.c:940-955), before ovdpb_report_decoded_ctu_line publishes it:
+ *
+ *   ovhip_job_begin      rcn_attach_frame_buff (rcn_ctu.c:570): new picture, recorder reset
+ *   ovhip_job_recorder   the recorder the slots append to while the picture is parsed
+ *   ovhip_job_dmvr_rows  eager decoder-side MV refinement of the DMVR units recorded so far: search only, refined
+ *                        vectors back on the host when it returns -- called from EVERY alf.rcn_alf_filter_line so that
+ *                        the TMVP motion field of a CTU row is final before that row is published (the reference
+ *                        stores the vectors right after each rcn_dmvr_mv_refine call, vcl_coding_unit.c:2621-2645)
+ *   ovhip_job_flush      async H2D of commands / coefficients / edge lists / parameters, every stage launch, async D2H
+ *                        of the refined vectors; returns without waiting
+ *   ovhip_job_wait       blocks until the flush has completed on the device
+ * ---------------------------------------------------------------------------------- */
+typedef struct ovhip_job ovhip_job;
+
+enum {                                   /* ovhip_job_params.stages (0 = all) */
+    OVHIP_STAGE_MC = 1, OVHIP_STAGE_ITX = 2, OVHIP_STAGE_DBF = 4, OVHIP_STAGE_SAO = 8, OVHIP_STAGE_ALF = 16,
+    OVHIP_STAGE_INTRA = 32
+};
+
+typedef struct ovhip_job_params {        /* picture-level side information; HOST pointers, copied by ovhip_job_flush */
+    const ovhip_lmcs_luts *lmcs;         /* NULL: LMCS off                                                         */
+    const ovhip_sao_ctu   *sao;          /* [n_ctu] raster, NULL: SAO off (stage skipped, dst stays deblocked)      */
+    const ovhip_alf_ctu   *alf_ctus;     /* [n_ctu] raster, NULL: ALF off                                           */
+    const int16_t *alf_luma_coeff, *alf_luma_clip;      /* [24][OVHIP_ALF_LUMA_SET_SIZE]                           */
+    const int16_t *alf_chroma_coeff, *alf_chroma_clip;  /* [8][7]                                                  */
+    const int16_t *alf_cc_coeff;                         /* [2][4][8]                                               */
+    int32_t  log2_ctu_s;
+    uint32_t stages;                     /* OVHIP_STAGE_* mask, 0 = all                                              */
+} ovhip_job_params;
+
+typedef struct ovhip_job_stats {         /* what the last flush moved and launched */
+    uint64_t h2d_bytes, d2h_bytes;
+    uint32_t n_launches, n_h2d;
+    uint32_t n_tb, n_mc, n_mcx, n_aff, n_edges_v, n_edges_h, n_regions, n_itasks, n_ilevels;
+} ovhip_job_stats;
+
+int  ovhip_job_create(ovhip_ctx *ctx, int32_t pic_w, int32_t pic_h, ovhip_job **out);
+void ovhip_job_destroy(ovhip_job *job);
+ovhip_recorder *ovhip_job_recorder(ovhip_job *job);
+/* Waits until the previous flush no longer reads the recorder's arrays, then resets the recorder. */
+int  ovhip_job_begin(ovhip_job *job);
+/* dst: the picture being decoded; refs[n_refs]: the table ovhip_pu_desc.ref0/ref1 index; intra: picture with the
+ * caller's planar prediction for fused CIIP blends, or NULL.  All DEVICE pictures of the job's size. */
+int  ovhip_job_flush(ovhip_job *job, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs,
+                     const ovhip_pic *intra, const ovhip_job_params *params);
+int  ovhip_job_wait(ovhip_job *job);
+/* int32 [n][4] (mv0x, mv0y, mv1x, mv1y per refined unit, recorder order): valid after ovhip_job_wait, or, for the
+ * units covered, after ovhip_job_dmvr_rows. */
+const int32_t *ovhip_job_refined_mvs(ovhip_job *job, size_t *n_units);
+/* Search-only pass over the refined units [first, current count) that carry OVHIP_MC_DMVR; synchronous: when it
+ * returns the vectors are in ovhip_job_refined_mvs()[first..].  Returns the new `first` (= unit count) or <0. */
+int64_t ovhip_job_dmvr_rows(ovhip_job *job, const ovhip_pic *refs, uint32_t n_refs);
+int  ovhip_job_last_stats(const ovhip_job *job, ovhip_job_stats *out);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,7 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libovvc_hip.so"
 
 # ---- constants (include/ovvc_hip.h) ----
-OVHIP_ABI_VERSION = 3
+OVHIP_ABI_VERSION = 4
 OVHIP_OK, OVHIP_ENODEV, OVHIP_ENOMEM, OVHIP_EINVAL, OVHIP_ELAUNCH, OVHIP_EUNSUP = 0, -1, -2, -3, -4, -5
 DST_VII, DCT_VIII, DCT_II = 0, 1, 2
 TB_TR, TB_DC, TB_TS, TB_TS_RAW = 0, 1, 2, 3
@@ -150,6 +150,29 @@ DBF_CTU_SIZE = (DBF_CTU_SIZE + 7) & ~7          # struct alignment (uint64 membe
 DBF_PLANE_NAMES = ("luma_v", "luma_h", "cb_v", "cr_v", "cb_h", "cr_h")
 
 
+class DbfOffsets(C.Structure):
+    _fields_ = [("beta", C.c_int8 * 8), ("tc", C.c_int8 * 8)]
+
+
+class JobParams(C.Structure):
+    """ovhip_job_params: picture-level side information (host pointers)."""
+    _fields_ = [("lmcs", C.c_void_p), ("sao", C.c_void_p), ("alf_ctus", C.c_void_p),
+                ("alf_luma_coeff", C.c_void_p), ("alf_luma_clip", C.c_void_p),
+                ("alf_chroma_coeff", C.c_void_p), ("alf_chroma_clip", C.c_void_p), ("alf_cc_coeff", C.c_void_p),
+                ("log2_ctu_s", C.c_int32), ("stages", C.c_uint32)]
+
+
+class JobStats(C.Structure):
+    _fields_ = [("h2d_bytes", C.c_uint64), ("d2h_bytes", C.c_uint64), ("n_launches", C.c_uint32), ("n_h2d", C.c_uint32),
+                ("n_tb", C.c_uint32), ("n_mc", C.c_uint32), ("n_mcx", C.c_uint32), ("n_aff", C.c_uint32),
+                ("n_edges_v", C.c_uint32), ("n_edges_h", C.c_uint32), ("n_regions", C.c_uint32),
+                ("n_itasks", C.c_uint32), ("n_ilevels", C.c_uint32)]
+
+
+REC_TB, REC_COEF, REC_MC, REC_MCX, REC_AFF, REC_SIDE, REC_REGION, REC_CIIP, REC_EDGE_V, REC_EDGE_H, REC_ITASK = range(11)
+STAGE_MC, STAGE_ITX, STAGE_DBF, STAGE_SAO, STAGE_ALF, STAGE_INTRA = 1, 2, 4, 8, 16, 32
+
+
 def dbf_plane_shapes(w4: int, h4: int) -> dict:
     w4c, h4c = (w4 + 1) // 2, (h4 + 1) // 2
     return {"luma_v": (h4, w4), "luma_h": (h4, w4), "cb_v": (h4, w4c), "cr_v": (h4, w4c),
@@ -269,6 +292,22 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_mcx_launch": (C.c_int, [vp, P(Pic), P(Pic), u32, vp, u32, vp, vp]),
         "ovhip_mca_launch": (C.c_int, [vp, P(Pic), P(Pic), u32, vp, u32, vp, vp]),
         "ovhip_mcxa_launch": (C.c_int, [vp, P(Pic), P(Pic), u32, vp, u32, vp, vp, u32, vp, vp]),
+        "ovhip_rec_create_ex": (vp, [i32, i32, vp]),
+        "ovhip_rec_set_dense_dbf_planes": (None, [vp, C.c_int]),
+        "ovhip_rec_dbf_edges": (vp, [vp, C.c_int, P(C.c_size_t), P(DbfOffsets)]),
+        "ovhip_dbf_launch_edges_ex": (C.c_int, [vp, P(Pic), vp, u32, vp, u32, P(DbfOffsets)]),
+        "ovhip_dmvr_search_launch": (C.c_int, [vp, P(Pic), P(Pic), u32, vp, u32, vp]),
+        "ovhip_rec_append_raw": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
+        "ovhip_rec_set_dbf_offsets": (C.c_int, [vp, P(DbfOffsets), C.c_int]),
+        "ovhip_job_create": (C.c_int, [vp, i32, i32, P(vp)]),
+        "ovhip_job_destroy": (None, [vp]),
+        "ovhip_job_recorder": (vp, [vp]),
+        "ovhip_job_begin": (C.c_int, [vp]),
+        "ovhip_job_flush": (C.c_int, [vp, P(Pic), P(Pic), u32, P(Pic), P(JobParams)]),
+        "ovhip_job_wait": (C.c_int, [vp]),
+        "ovhip_job_refined_mvs": (vp, [vp, P(C.c_size_t)]),
+        "ovhip_job_dmvr_rows": (C.c_int64, [vp, P(Pic), u32]),
+        "ovhip_job_last_stats": (C.c_int, [vp, P(JobStats)]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)          # AttributeError = missing export: fail loudly
@@ -286,6 +325,9 @@ EXPORTED_SYMBOLS = [
     "ovhip_ctx_destroy", "ovhip_ctx_sync", "ovhip_ctx_fork", "ovhip_ctx_join", "ovhip_last_error", "ovhip_ctx_stream", "ovhip_malloc",
     "ovhip_free", "ovhip_h2d", "ovhip_d2h", "ovhip_pic_alloc", "ovhip_pic_free", "ovhip_pic_upload",
     "ovhip_pic_download", "ovhip_itx_launch", "ovhip_mc_launch",
+    "ovhip_rec_create_ex", "ovhip_rec_set_dense_dbf_planes", "ovhip_rec_dbf_edges", "ovhip_dbf_launch_edges_ex",
+    "ovhip_dmvr_search_launch", "ovhip_rec_append_raw", "ovhip_rec_set_dbf_offsets", "ovhip_job_create", "ovhip_job_destroy", "ovhip_job_recorder", "ovhip_job_begin",
+    "ovhip_job_flush", "ovhip_job_wait", "ovhip_job_refined_mvs", "ovhip_job_dmvr_rows", "ovhip_job_last_stats",
 ]
 
 
@@ -368,6 +410,22 @@ class Recorder:
         r = self.lib.ovhip_rec_dbf_ctu(self.h, C.addressof(buf))
         if r < 0:
             raise ValueError(f"ovhip_rec_dbf_ctu -> {r}")
+
+    def dbf_edges(self, direction: int):
+        """The compact edge list (DBF_EDGE_DTYPE) ovhip_rec_dbf_ctu emitted for one direction + the offset table."""
+        n = C.c_size_t()
+        offs = DbfOffsets()
+        p = self.lib.ovhip_rec_dbf_edges(self.h, direction, C.byref(n), C.byref(offs))
+        if not n.value:
+            return np.zeros(0, DBF_EDGE_DTYPE), offs
+        buf = (C.c_char * (n.value * DBF_EDGE_DTYPE.itemsize)).from_address(p)
+        return np.frombuffer(buf, dtype=DBF_EDGE_DTYPE).copy(), offs
+
+    def append_raw(self, which: int, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        r = self.lib.ovhip_rec_append_raw(self.h, which, arr.ctypes.data, len(arr))
+        if r < 0:
+            raise ValueError(f"ovhip_rec_append_raw({which}) -> {r}")
 
     def dbf_planes(self) -> dict:
         """Host copies of the picture-level edge planes + offsets."""

@@ -496,6 +496,7 @@ __global__ __launch_bounds__(256) OV_OCC_ALF void k_alf(ovhip_pic dst, ovhip_pic
 extern "C" int ovhip_alf_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *src, const ovhip_alf_pic *alf)
 {
     if (!ctx || !dst || !src || !alf) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
     if (dst->w != src->w || dst->h != src->h || dst->y == src->y || alf->log2_ctu_s < 6 || alf->log2_ctu_s > 7 ||
         !alf->ctus || !alf->luma_coeff || !alf->luma_clip || !alf->chroma_coeff || !alf->chroma_clip || !alf->cc_coeff)
         return ov_fail(ctx, OVHIP_EINVAL, "ovhip_alf_launch: bad pictures / parameter tables", hipSuccess);

@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void k_dbf(ovhip_pic pic, ovhip_dbf_planes pl)
 // The same filter over the compact edge lists (ovhip_dbf_compact): 4 lanes per edge, one per line of the segment.
 template <int DIR>
 __global__ __launch_bounds__(256) OV_OCC_DBF void k_dbf_list(ovhip_pic pic, const ovhip_dbf_edge *__restrict__ edges, uint32_t n,
-                                                  int tc_offset, int beta_offset)
+                                                  uint64_t tc_pack, uint64_t beta_pack)
 {
     const uint32_t tid = blockIdx.x * 256 + threadIdx.x;
     const uint32_t ei = tid >> 2;
@@ -391,6 +391,9 @@ __global__ __launch_bounds__(256) OV_OCC_DBF void k_dbf_list(ovhip_pic pic, cons
     if (ei >= n) return;                                   // whole quads leave together
     const ovhip_dbf_edge e = edges[ei];
     const int v = e.word;
+    // slice-level offsets (DBFInfo.tc_offset / beta_offset): 8 signed bytes each, the edge carries the index
+    const int osh = (e.pad & 7) * 8;
+    const int tc_offset = (int8_t)(tc_pack >> osh), beta_offset = (int8_t)(beta_pack >> osh);
     if (e.comp == 0) {
         const Lim lim = dbf_limits(v >> 8, v & 3, tc_offset, beta_offset);
         if (!(lim.tc || lim.beta)) return;
@@ -405,26 +408,39 @@ __global__ __launch_bounds__(256) OV_OCC_DBF void k_dbf_list(ovhip_pic pic, cons
 
 } // namespace
 
-extern "C" int ovhip_dbf_launch_edges(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_dbf_edge *d_edges_v, uint32_t n_v,
-                                      const ovhip_dbf_edge *d_edges_h, uint32_t n_h, int32_t beta_offset, int32_t tc_offset)
+extern "C" int ovhip_dbf_launch_edges_ex(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_dbf_edge *d_edges_v, uint32_t n_v,
+                                         const ovhip_dbf_edge *d_edges_h, uint32_t n_h, const ovhip_dbf_offsets *offsets)
 {
-    if (!ctx || !pic) return OVHIP_EINVAL;
+    if (!ctx || !pic || !offsets) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
     if ((n_v && !d_edges_v) || (n_h && !d_edges_h))
         return ov_fail(ctx, OVHIP_EINVAL, "ovhip_dbf_launch_edges: null edge list", hipSuccess);
+    uint64_t tc_pack, beta_pack;
+    memcpy(&tc_pack, offsets->tc, 8); memcpy(&beta_pack, offsets->beta, 8);
     if (n_v) {
-        hipLaunchKernelGGL(k_dbf_list<0>, dim3((n_v + 63) / 64), dim3(256), 0, ctx->stream, *pic, d_edges_v, n_v, tc_offset, beta_offset);
+        hipLaunchKernelGGL(k_dbf_list<0>, dim3((n_v + 63) / 64), dim3(256), 0, ctx->stream, *pic, d_edges_v, n_v, tc_pack, beta_pack);
         OV_LAUNCH_CHECK(ctx, "k_dbf_list<v>");
     }
     if (n_h) {
-        hipLaunchKernelGGL(k_dbf_list<1>, dim3((n_h + 63) / 64), dim3(256), 0, ctx->stream, *pic, d_edges_h, n_h, tc_offset, beta_offset);
+        hipLaunchKernelGGL(k_dbf_list<1>, dim3((n_h + 63) / 64), dim3(256), 0, ctx->stream, *pic, d_edges_h, n_h, tc_pack, beta_pack);
         OV_LAUNCH_CHECK(ctx, "k_dbf_list<h>");
     }
     return OVHIP_OK;
 }
 
+extern "C" int ovhip_dbf_launch_edges(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_dbf_edge *d_edges_v, uint32_t n_v,
+                                      const ovhip_dbf_edge *d_edges_h, uint32_t n_h, int32_t beta_offset, int32_t tc_offset)
+{
+    if (beta_offset < -128 || beta_offset > 127 || tc_offset < -128 || tc_offset > 127) return OVHIP_EINVAL;
+    ovhip_dbf_offsets o;
+    for (int i = 0; i < OVHIP_DBF_MAX_OFFSETS; ++i) { o.beta[i] = (int8_t)beta_offset; o.tc[i] = (int8_t)tc_offset; }
+    return ovhip_dbf_launch_edges_ex(ctx, pic, d_edges_v, n_v, d_edges_h, n_h, &o);
+}
+
 extern "C" int ovhip_dbf_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_dbf_planes *pl)
 {
     if (!ctx || !pic || !pl) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
     if (!pl->luma_v || !pl->luma_h || !pl->cb_v || !pl->cr_v || !pl->cb_h || !pl->cr_h)
         return ov_fail(ctx, OVHIP_EINVAL, "ovhip_dbf_launch: null edge plane", hipSuccess);
     if (pl->w4 != (pic->w + 3) / 4 || pl->h4 != (pic->h + 3) / 4)

@@ -468,6 +468,7 @@ extern "C" int ovhip_itx_launch_classes(ovhip_ctx *ctx, const ovhip_pic *dst, co
                                         const int16_t *d_lmcs_scales)
 {
     if (!ctx || !dst) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
     if (!n_large && !n_small) return OVHIP_OK;
     if (!d_cmds || !d_coefs) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_itx_launch: null buffer", hipSuccess);
     return itx_launch(ctx, dst, d_cmds, n_large, n_small, d_coefs, d_lmcs_scales, nullptr);
@@ -478,6 +479,7 @@ extern "C" int ovhip_itx_launch_chroma_lmcs(ovhip_ctx *ctx, const ovhip_pic *dst
                                             const int16_t *d_lmcs_scales, const uint16_t *d_bwd_lut)
 {
     if (!ctx || !dst || !d_bwd_lut) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
     if ((n_large || n_small) && (!d_cmds || !d_coefs)) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_itx_launch_chroma_lmcs: null buffer", hipSuccess);
     if ((dst->stride_y & 7) || ((uintptr_t)dst->y & 15))
         return ov_fail(ctx, OVHIP_EINVAL, "ovhip_itx_launch_chroma_lmcs: luma plane must be 16-byte aligned with stride % 8 == 0", hipSuccess);

@@ -76,6 +76,7 @@ extern "C" int ovhip_lmcs_scale_launch(ovhip_ctx *ctx, const ovhip_pic *pic, con
                                        uint32_t n_regions, const ovhip_lmcs_luts *luts, int16_t *d_scales)
 {
     if (!ctx || !pic || !luts) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
     if (!n_regions) return OVHIP_OK;
     if (!d_regions || !d_scales) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_lmcs_scale_launch: null buffer", hipSuccess);
     LmcsWnd w;
@@ -89,6 +90,7 @@ extern "C" int ovhip_lmcs_scale_launch(ovhip_ctx *ctx, const ovhip_pic *pic, con
 extern "C" int ovhip_lmcs_inverse_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const uint16_t *d_bwd_lut)
 {
     if (!ctx || !pic || !d_bwd_lut) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
     if ((pic->stride_y & 7) || ((uintptr_t)pic->y & 15))
         return ov_fail(ctx, OVHIP_EINVAL, "ovhip_lmcs_inverse_launch: luma plane must be 16-byte aligned with stride % 8 == 0", hipSuccess);
     const int nvx = pic->w >> 3;

@@ -321,6 +321,7 @@ extern "C" int ovhip_ciip_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovh
                                  const ovhip_ciip_unit *d_units, uint32_t n_units)
 {
     if (!ctx || !dst || !intra) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
     if (!n_units) return OVHIP_OK;
     if (!d_units) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_ciip_launch: null units", hipSuccess);
     hipLaunchKernelGGL(k_ciip, dim3(n_units), dim3(256), 0, ctx->stream, *dst, *intra, d_units, n_units);
@@ -333,6 +334,7 @@ extern "C" int ovhip_mc_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip
                                const ovhip_pic *intra)
 {
     if (!ctx || !dst) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
     if (!n_units) return OVHIP_OK;
     if (!refs || !n_refs || n_refs > MC_MAX_REFS || !d_units)
         return ov_fail(ctx, OVHIP_EINVAL, "ovhip_mc_launch: bad reference table / units", hipSuccess);

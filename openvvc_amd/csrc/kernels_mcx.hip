@@ -118,6 +118,10 @@ __device__ __forceinline__ void chroma_avg(const ovhip_mc_unit &u, const ovhip_p
 #define MCX_LDS    (MCX_LDS_WL + MCX_LDS_WC + (2 * 16 * HT_STRIDE + 4 * 8 * CHT_STRIDE) * 2)
 
 // units wg0, wg0 + wstride, ... (one single-wave workgroup; `lds` = MCX_LDS bytes, 16-byte aligned)
+// SEARCH_ONLY: the decoder-side MV refinement alone (steps 1-2) for the units that carry OVHIP_MC_DMVR, refined vectors
+// to mv_out, nothing written to dst -- the eager per-CTU-row pass that keeps the host's TMVP motion field final before
+// a row is published (ovhip_job_dmvr_rows).
+template <bool SEARCH_ONLY>
 __device__ __forceinline__ void mcx_units(const ovhip_pic &dst, const RefTable &refs, const ovhip_mc_unit *__restrict__ units,
                                           uint32_t n_units, const uint16_t *__restrict__ lmcs_fwd, int32_t *__restrict__ mv_out,
                                           uint32_t wg0, uint32_t wstride, char *lds)
@@ -145,6 +149,7 @@ __device__ __forceinline__ void mcx_units(const ovhip_pic &dst, const RefTable &
     const uint32_t bid = wstride >= n_units ? ov_xcd_slot(wg, n_units) : wg;        // XCD-aware order, see k_mc2
     const ovhip_mc_unit u = units[bid];
     const bool dmvr = u.flags & OVHIP_MC_DMVR;
+    if (SEARCH_ONLY && !dmvr) return;
     bool use_bdof = u.flags & OVHIP_MC_BDOF;
     const bool do_l = !(u.flags & OVHIP_MC_NO_LUMA), do_c = !(u.flags & OVHIP_MC_NO_CHROMA);
     const int w = u.w, h = u.h, wc = w >> 1, hc = h >> 1;
@@ -268,6 +273,7 @@ __device__ __forceinline__ void mcx_units(const ovhip_pic &dst, const RefTable &
         int4 o; o.x = mv[0][0]; o.y = mv[0][1]; o.z = mv[1][0]; o.w = mv[1][1];
         *reinterpret_cast<int4 *>(mv_out + 4 * (size_t)bid) = o;
     }
+    if (SEARCH_ONLY) return;
 
     // ---- 3. horizontal passes at the refined position: both lists (and both chroma planes) in one task loop ----
     const uint32_t *fvl[2];
@@ -755,7 +761,14 @@ __global__ __launch_bounds__(64) OV_OCC_MCX void k_mcx(ovhip_pic dst, RefTable r
                                              uint32_t n_units, const uint16_t *__restrict__ lmcs_fwd, int32_t *__restrict__ mv_out)
 {
     __shared__ __attribute__((aligned(16))) char lds[MCX_LDS];
-    mcx_units(dst, refs, units, n_units, lmcs_fwd, mv_out, blockIdx.x, gridDim.x, lds);
+    mcx_units<false>(dst, refs, units, n_units, lmcs_fwd, mv_out, blockIdx.x, gridDim.x, lds);
+}
+
+__global__ __launch_bounds__(64) OV_OCC_MCX void k_dmvr_search(ovhip_pic geom, RefTable refs, const ovhip_mc_unit *__restrict__ units,
+                                                     uint32_t n_units, int32_t *__restrict__ mv_out)
+{
+    __shared__ __attribute__((aligned(16))) char lds[MCX_LDS];
+    mcx_units<true>(geom, refs, units, n_units, nullptr, mv_out, blockIdx.x, gridDim.x, lds);
 }
 
 __global__ __launch_bounds__(64) OV_OCC_MCX void k_mca(ovhip_pic dst, RefTable refs, const ovhip_aff_unit *__restrict__ units,
@@ -773,7 +786,7 @@ __global__ __launch_bounds__(64) OV_OCC_MCX void k_mcxa(ovhip_pic dst, RefTable 
 {
     __shared__ __attribute__((aligned(16))) char lds[MCX_LDS > MCA_LDS ? MCX_LDS : MCA_LDS];
     if (blockIdx.x < n_a) mca_units(dst, refs, aunits, n_a, side, lmcs_fwd, blockIdx.x, n_a, lds);
-    else                  mcx_units(dst, refs, xunits, n_x, lmcs_fwd, mv_out, blockIdx.x - n_a, n_x, lds);
+    else                  mcx_units<false>(dst, refs, xunits, n_x, lmcs_fwd, mv_out, blockIdx.x - n_a, n_x, lds);
 }
 
 } // namespace
@@ -790,6 +803,7 @@ extern "C" int ovhip_mcx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhi
                                 int32_t *d_mv_out)
 {
     if (!ctx || !dst) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
     if (!n_units) return OVHIP_OK;
     if (!refs || !n_refs || n_refs > MC_MAX_REFS || !d_units)
         return ov_fail(ctx, OVHIP_EINVAL, "ovhip_mcx_launch: bad reference table / units", hipSuccess);
@@ -806,11 +820,33 @@ extern "C" int ovhip_mcx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhi
     return OVHIP_OK;
 }
 
+extern "C" int ovhip_dmvr_search_launch(ovhip_ctx *ctx, const ovhip_pic *geom, const ovhip_pic *refs, uint32_t n_refs,
+                                        const ovhip_mc_unit *d_units, uint32_t n_units, int32_t *d_mv_out)
+{
+    if (!ctx || !geom) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
+    if (!n_units) return OVHIP_OK;
+    if (!refs || !n_refs || n_refs > MC_MAX_REFS || !d_units || !d_mv_out)
+        return ov_fail(ctx, OVHIP_EINVAL, "ovhip_dmvr_search_launch: bad reference table / units", hipSuccess);
+    RefTable t;
+    memset(&t, 0, sizeof(t));
+    for (uint32_t i = 0; i < n_refs; ++i) {
+        if (refs[i].w != geom->w || refs[i].h != geom->h || refs[i].stride_y != geom->stride_y || refs[i].stride_c != geom->stride_c)
+            return ov_fail(ctx, OVHIP_EUNSUP, "ovhip_dmvr_search_launch: reference picture geometry differs (RPR)", hipSuccess);
+        t.p[i] = refs[i];
+    }
+    for (uint32_t i = n_refs; i < MC_MAX_REFS; ++i) t.p[i] = refs[0];
+    hipLaunchKernelGGL(k_dmvr_search, dim3(n_units), dim3(64), 0, ctx->stream, *geom, t, d_units, n_units, d_mv_out);
+    OV_LAUNCH_CHECK(ctx, "k_dmvr_search");
+    return OVHIP_OK;
+}
+
 extern "C" int ovhip_mca_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs,
                                 const ovhip_aff_unit *d_units, uint32_t n_units, const int32_t *d_side,
                                 const uint16_t *d_lmcs_fwd_lut)
 {
     if (!ctx || !dst) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
     if (!n_units) return OVHIP_OK;
     if (!refs || !n_refs || n_refs > MC_MAX_REFS || !d_units || !d_side)
         return ov_fail(ctx, OVHIP_EINVAL, "ovhip_mca_launch: bad reference table / units / side arena", hipSuccess);
@@ -833,6 +869,7 @@ extern "C" int ovhip_mcxa_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovh
                                  const uint16_t *d_lmcs_fwd_lut)
 {
     if (!ctx || !dst) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
     if (!n_aunits) return ovhip_mcx_launch(ctx, dst, refs, n_refs, d_xunits, n_xunits, d_lmcs_fwd_lut, d_mv_out);
     if (!n_xunits) return ovhip_mca_launch(ctx, dst, refs, n_refs, d_aunits, n_aunits, d_side, d_lmcs_fwd_lut);
     if (!refs || !n_refs || n_refs > MC_MAX_REFS || !d_xunits || !d_aunits || !d_side)

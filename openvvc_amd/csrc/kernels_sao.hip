@@ -106,6 +106,7 @@ extern "C" int ovhip_sao_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhi
                                 const ovhip_sao_ctu *d_params, int32_t log2_ctu_s)
 {
     if (!ctx || !dst || !src || !d_params) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
     if (dst->w != src->w || dst->h != src->h || dst->y == src->y || log2_ctu_s < 5 || log2_ctu_s > 7)
         return ov_fail(ctx, OVHIP_EINVAL, "ovhip_sao_launch: bad pictures / CTU size", hipSuccess);
     const int nb_ctu_w = (src->w + (1 << log2_ctu_s) - 1) >> log2_ctu_s;

@@ -40,6 +40,15 @@ static inline int ov_fail(ovhip_ctx *ctx, int code, const char *what, hipError_t
         if (e__ != hipSuccess) return ov_fail((ctx), OVHIP_ENODEV, #call, e__); \
     } while (0)
 
+// The HIP current device is per THREAD: a context created on one decoder thread and driven from another (one ctx per
+// frame thread) must re-select its device in every entry point, or allocations and launches land on
+// device 0.  hipSetDevice on the already-current device is a thread-local compare.
+#define OV_DEVICE(ctx)                                                        \
+    do {                                                                      \
+        hipError_t e__ = hipSetDevice((ctx)->device);                         \
+        if (e__ != hipSuccess) return ov_fail((ctx), OVHIP_ENODEV, "hipSetDevice", e__); \
+    } while (0)
+
 #define OV_LAUNCH_CHECK(ctx, name)                                            \
     do {                                                                      \
         hipError_t e__ = hipGetLastError();                                   \

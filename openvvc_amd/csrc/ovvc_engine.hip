@@ -51,6 +51,7 @@ void ovhip_ctx_destroy(ovhip_ctx *ctx)
 int ovhip_ctx_fork(ovhip_ctx *ctx, int k)
 {
     if (!ctx || k < 0 || k >= OV_MAX_LANES) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
     if (k == 0) { ctx->stream = ctx->main_stream; return OVHIP_OK; }
     if (!ctx->have_events) {
         OV_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
@@ -58,11 +59,11 @@ int ovhip_ctx_fork(ovhip_ctx *ctx, int k)
         ctx->have_events = 1;
     }
     if (!ctx->lane[k]) OV_HIP(ctx, hipStreamCreateWithFlags(&ctx->lane[k], hipStreamNonBlocking));
-    if (!ctx->lane_used[k]) {
-        OV_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->main_stream));
-        OV_HIP(ctx, hipStreamWaitEvent(ctx->lane[k], ctx->ev_fork, 0));
-        ctx->lane_used[k] = 1;
-    }
+    // every fork orders the lane behind everything enqueued on the main stream so far (header contract), also a
+    // second fork(k) before the join
+    OV_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->main_stream));
+    OV_HIP(ctx, hipStreamWaitEvent(ctx->lane[k], ctx->ev_fork, 0));
+    ctx->lane_used[k] = 1;
     ctx->stream = ctx->lane[k];
     return OVHIP_OK;
 }
@@ -70,6 +71,7 @@ int ovhip_ctx_fork(ovhip_ctx *ctx, int k)
 int ovhip_ctx_join(ovhip_ctx *ctx)
 {
     if (!ctx) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
     ctx->stream = ctx->main_stream;
     for (int k = 1; k < OV_MAX_LANES; ++k) {
         if (!ctx->lane_used[k]) continue;
@@ -83,6 +85,7 @@ int ovhip_ctx_join(ovhip_ctx *ctx)
 int ovhip_ctx_sync(ovhip_ctx *ctx)
 {
     if (!ctx) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
     int r = ovhip_ctx_join(ctx);
     if (r != OVHIP_OK) return r;
     hipError_t e = hipStreamSynchronize(ctx->main_stream);
@@ -96,6 +99,7 @@ void *ovhip_ctx_stream(ovhip_ctx *ctx) { return ctx ? (void *)ctx->main_stream :
 int ovhip_malloc(ovhip_ctx *ctx, size_t bytes, void **dptr)
 {
     if (!ctx || !dptr) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
     *dptr = nullptr;
     hipError_t e = hipMalloc(dptr, bytes ? bytes : 16);
     if (e != hipSuccess) return ov_fail(ctx, OVHIP_ENOMEM, "hipMalloc", e);
@@ -105,6 +109,7 @@ int ovhip_malloc(ovhip_ctx *ctx, size_t bytes, void **dptr)
 int ovhip_free(ovhip_ctx *ctx, void *dptr)
 {
     if (!ctx) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
     if (dptr) OV_HIP(ctx, hipFree(dptr));
     return OVHIP_OK;
 }
@@ -112,6 +117,7 @@ int ovhip_free(ovhip_ctx *ctx, void *dptr)
 int ovhip_h2d(ovhip_ctx *ctx, void *dptr, const void *host, size_t bytes)
 {
     if (!ctx || (bytes && (!dptr || !host))) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
     if (bytes) OV_HIP(ctx, hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
     return OVHIP_OK;
 }
@@ -119,6 +125,7 @@ int ovhip_h2d(ovhip_ctx *ctx, void *dptr, const void *host, size_t bytes)
 int ovhip_d2h(ovhip_ctx *ctx, void *host, const void *dptr, size_t bytes)
 {
     if (!ctx || (bytes && (!dptr || !host))) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
     if (bytes) {
         OV_HIP(ctx, hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
         OV_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -129,6 +136,7 @@ int ovhip_d2h(ovhip_ctx *ctx, void *host, const void *dptr, size_t bytes)
 int ovhip_pic_alloc(ovhip_ctx *ctx, int32_t w, int32_t h, ovhip_pic *pic)
 {
     if (!ctx || !pic || w <= 0 || h <= 0 || (w & 1) || (h & 1)) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
     memset(pic, 0, sizeof(*pic));
     // one allocation, three tight planes (what the reference's frame pool hands out), each 256-B aligned
     const size_t ysz = ((size_t)w * h * 2 + 255) & ~(size_t)255;
@@ -146,6 +154,7 @@ int ovhip_pic_alloc(ovhip_ctx *ctx, int32_t w, int32_t h, ovhip_pic *pic)
 int ovhip_pic_free(ovhip_ctx *ctx, ovhip_pic *pic)
 {
     if (!ctx || !pic) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
     if (pic->y) OV_HIP(ctx, hipFree(pic->y));
     memset(pic, 0, sizeof(*pic));
     return OVHIP_OK;
@@ -155,6 +164,7 @@ static int copy_planes(ovhip_ctx *ctx, const ovhip_pic *pic, uint16_t *y, uint16
                        int32_t hs_y, int32_t hs_c, int to_device)
 {
     if (!ctx || !pic || !pic->y) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
     uint16_t *host[3] = { y, cb, cr };
     uint16_t *dev[3] = { pic->y, pic->cb, pic->cr };
     for (int p = 0; p < 3; ++p) {

@@ -1,0 +1,377 @@
+// ovvc_picture.hip -- the per-picture flush of the rcn back-end, in C (include/ovvc_hip.h "Picture job").
+//
+// The reference reconstructs block by block while it parses (coding_unit() -> rcn slots, vcl_coding_unit.c:711-840);
+// the device path defers: the slots record, and the LAST alf.rcn_alf_filter_line of a picture (slicedec.c:940-955) hands
+// the recorded picture over.  This file is that hand-over: asynchronous H2D of the recorder's page-locked arrays, the
+// launch chain prediction -> residual -> (ordered intra pass) -> inverse luma mapping -> deblocking -> SAO -> ALF, and
+// the D2H of the motion vectors DMVR refined (the `OVMV *mv0, *mv1` in/out contract of rcn_dmvr_mv_refine,
+// rcn_structures.h:628-632).  Host code above the launches is plain C; nothing here falls back to a CPU path.
+#include "ovvc_common.hip.h"
+#include <stdlib.h>
+
+extern "C" int ovhip_dmvr_search_launch(ovhip_ctx *ctx, const ovhip_pic *geom, const ovhip_pic *refs, uint32_t n_refs,
+                                        const ovhip_mc_unit *d_units, uint32_t n_units, int32_t *d_mv_out);
+
+namespace {
+
+struct DevBuf { void *p; size_t cap; };
+
+enum { B_TB, B_COEF, B_MC, B_MCX, B_MV, B_AFF, B_SIDE, B_REG, B_SCALE, B_EV, B_EH, B_PARAM, B_CLASS, B_COUNT };
+
+// layout of the parameter block (one pinned staging copy, one H2D)
+struct ParamLayout { size_t sao, alf_ctus, lcoef, lclip, ccoef, cclip, cc, fwd, bwd, total; };
+
+} // namespace
+
+struct ovhip_job {
+    ovhip_ctx *ctx;
+    int32_t w, h;
+    ovhip_recorder *rec;
+    DevBuf dev[B_COUNT];
+    ovhip_pic tmp;                       // SAO destination / ALF source
+    char *param_host; size_t param_cap;  // pinned staging of the picture-level tables
+    int32_t *mv_host; size_t mv_cap;     // pinned: refined vectors, 4 int32 per refined unit
+    size_t n_mv;                         // units covered by the last flush / eager pass
+    size_t dmvr_first;                   // refined units [0, dmvr_first) already went through the eager search
+    hipEvent_t ev_h2d, ev_done;
+    int flushed;                         // ev_* recorded at least once
+    ovhip_job_stats st;
+};
+
+namespace {
+
+void *pinned_alloc(void *user, size_t bytes)
+{
+    (void)user;
+    void *p = nullptr;
+    return hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+}
+void pinned_free(void *user, void *p) { (void)user; if (p) (void)hipHostFree(p); }
+
+int dev_reserve(ovhip_job *j, int k, size_t bytes)
+{
+    DevBuf &b = j->dev[k];
+    if (bytes <= b.cap) return OVHIP_OK;
+    size_t nc = b.cap ? b.cap : (size_t)1 << 16;
+    while (nc < bytes) nc *= 2;
+    // growth is rare (first pictures of a sequence); hipFree synchronises the device, which is what makes it safe here
+    if (b.p) OV_HIP(j->ctx, hipFree(b.p));
+    b.p = nullptr; b.cap = 0;
+    hipError_t e = hipMalloc(&b.p, nc);
+    if (e != hipSuccess) return ov_fail(j->ctx, OVHIP_ENOMEM, "hipMalloc(job buffer)", e);
+    b.cap = nc;
+    return OVHIP_OK;
+}
+
+int h2d(ovhip_job *j, int k, const void *host, size_t bytes)
+{
+    if (!bytes) return OVHIP_OK;
+    int r = dev_reserve(j, k, bytes);
+    if (r) return r;
+    OV_HIP(j->ctx, hipMemcpyAsync(j->dev[k].p, host, bytes, hipMemcpyHostToDevice, j->ctx->stream));
+    j->st.h2d_bytes += bytes; j->st.n_h2d++;
+    return OVHIP_OK;
+}
+
+int pinned_reserve(ovhip_job *j, void **p, size_t *cap, size_t bytes)
+{
+    if (bytes <= *cap) return OVHIP_OK;
+    size_t nc = *cap ? *cap : 4096;
+    while (nc < bytes) nc *= 2;
+    void *q = pinned_alloc(nullptr, nc);
+    if (!q) return ov_fail(j->ctx, OVHIP_ENOMEM, "hipHostMalloc", hipSuccess);
+    if (*p) { memcpy(q, *p, *cap); pinned_free(nullptr, *p); }
+    *p = q; *cap = nc;
+    return OVHIP_OK;
+}
+
+#define CHK(x) do { int r__ = (x); if (r__ != OVHIP_OK) return r__; } while (0)
+
+// plane-wise device copy (the two pictures may come from different allocators)
+int copy_pic(ovhip_ctx *ctx, const ovhip_pic *d, const ovhip_pic *s)
+{
+    uint16_t *dp[3] = { d->y, d->cb, d->cr };
+    uint16_t *sp[3] = { s->y, s->cb, s->cr };
+    for (int p = 0; p < 3; ++p) {
+        const int w = p ? d->w / 2 : d->w, h = p ? d->h / 2 : d->h;
+        OV_HIP(ctx, hipMemcpy2DAsync(dp[p], (size_t)(p ? d->stride_c : d->stride_y) * 2, sp[p], (size_t)(p ? s->stride_c : s->stride_y) * 2,
+                                     (size_t)w * 2, h, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return OVHIP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int ovhip_job_create(ovhip_ctx *ctx, int32_t w, int32_t h, ovhip_job **out)
+{
+    if (!ctx || !out || w <= 0 || h <= 0 || (w & 1) || (h & 1)) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
+    *out = nullptr;
+    ovhip_job *j = (ovhip_job *)calloc(1, sizeof(*j));
+    if (!j) return OVHIP_ENOMEM;
+    j->ctx = ctx; j->w = w; j->h = h;
+    const ovhip_allocator al = { pinned_alloc, pinned_free, nullptr };
+    j->rec = ovhip_rec_create_ex(w, h, &al);
+    if (!j->rec) { free(j); return OVHIP_ENOMEM; }
+    ovhip_rec_set_dense_dbf_planes(j->rec, 0);
+    int r = ovhip_pic_alloc(ctx, w, h, &j->tmp);
+    if (r == OVHIP_OK && hipEventCreateWithFlags(&j->ev_h2d, hipEventDisableTiming) != hipSuccess) r = OVHIP_ENODEV;
+    if (r == OVHIP_OK && hipEventCreateWithFlags(&j->ev_done, hipEventDisableTiming) != hipSuccess) r = OVHIP_ENODEV;
+    if (r != OVHIP_OK) { ovhip_job_destroy(j); return r; }
+    *out = j;
+    return OVHIP_OK;
+}
+
+void ovhip_job_destroy(ovhip_job *j)
+{
+    if (!j) return;
+    (void)hipSetDevice(j->ctx->device);
+    if (j->flushed) (void)hipEventSynchronize(j->ev_done);
+    for (int k = 0; k < B_COUNT; ++k) if (j->dev[k].p) (void)hipFree(j->dev[k].p);
+    if (j->tmp.y) (void)ovhip_pic_free(j->ctx, &j->tmp);
+    pinned_free(nullptr, j->param_host); pinned_free(nullptr, j->mv_host);
+    if (j->ev_h2d) (void)hipEventDestroy(j->ev_h2d);
+    if (j->ev_done) (void)hipEventDestroy(j->ev_done);
+    ovhip_rec_destroy(j->rec);
+    free(j);
+}
+
+ovhip_recorder *ovhip_job_recorder(ovhip_job *j) { return j ? j->rec : nullptr; }
+
+int ovhip_job_begin(ovhip_job *j)
+{
+    if (!j) return OVHIP_EINVAL;
+    OV_DEVICE(j->ctx);
+    // the DMA engines may still be reading the recorder's arrays and the parameter staging block
+    if (j->flushed) OV_HIP(j->ctx, hipEventSynchronize(j->ev_h2d));
+    ovhip_rec_reset(j->rec);
+    j->dmvr_first = 0; j->n_mv = 0;
+    return OVHIP_OK;
+}
+
+int ovhip_job_wait(ovhip_job *j)
+{
+    if (!j) return OVHIP_EINVAL;
+    OV_DEVICE(j->ctx);
+    if (!j->flushed) return OVHIP_OK;
+    hipError_t e = hipEventSynchronize(j->ev_done);
+    if (e != hipSuccess) return ov_fail(j->ctx, OVHIP_ELAUNCH, "hipEventSynchronize(job)", e);
+    return OVHIP_OK;
+}
+
+const int32_t *ovhip_job_refined_mvs(ovhip_job *j, size_t *n_units)
+{
+    if (!j || !n_units) return nullptr;
+    *n_units = j->n_mv;
+    return j->mv_host;
+}
+
+int ovhip_job_last_stats(const ovhip_job *j, ovhip_job_stats *out)
+{
+    if (!j || !out) return OVHIP_EINVAL;
+    *out = j->st;
+    return OVHIP_OK;
+}
+
+int64_t ovhip_job_dmvr_rows(ovhip_job *j, const ovhip_pic *refs, uint32_t n_refs)
+{
+    if (!j) return OVHIP_EINVAL;
+    ovhip_ctx *ctx = j->ctx;
+    OV_DEVICE(ctx);
+    size_t n = 0;
+    const ovhip_mc_unit *u = ovhip_rec_mcx_units(j->rec, &n);
+    const size_t first = j->dmvr_first;
+    if (n <= first) return (int64_t)n;
+    int any = 0;
+    for (size_t i = first; i < n && !any; ++i) any = (u[i].flags & OVHIP_MC_DMVR) != 0;
+    if (any) {
+        // the device copy of the unit list and the vector buffer keep the recorder's indexing: [first, n) lands at first
+        CHK(pinned_reserve(j, (void **)&j->mv_host, &j->mv_cap, n * 16));
+        if (j->dev[B_MCX].cap < n * sizeof(ovhip_mc_unit) || j->dev[B_MV].cap < n * 16) {
+            // grow to the picture's upper bound at once so that earlier rows' results are never moved: one refined unit
+            // covers at least 8x8 luma samples
+            const size_t ub = (size_t)((j->w + 7) / 8) * ((j->h + 7) / 8);
+            CHK(dev_reserve(j, B_MCX, (ub > n ? ub : n) * sizeof(ovhip_mc_unit)));
+            CHK(dev_reserve(j, B_MV, (ub > n ? ub : n) * 16));
+        }
+        char *d_units = (char *)j->dev[B_MCX].p + first * sizeof(ovhip_mc_unit);
+        int32_t *d_mv = (int32_t *)j->dev[B_MV].p + 4 * first;
+        OV_HIP(ctx, hipMemcpyAsync(d_units, u + first, (n - first) * sizeof(ovhip_mc_unit), hipMemcpyHostToDevice, ctx->stream));
+        ovhip_pic geom = j->tmp;
+        CHK(ovhip_dmvr_search_launch(ctx, &geom, refs, n_refs, (const ovhip_mc_unit *)d_units, (uint32_t)(n - first), d_mv));
+        OV_HIP(ctx, hipMemcpyAsync(j->mv_host + 4 * first, d_mv, (n - first) * 16, hipMemcpyDeviceToHost, ctx->stream));
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return ov_fail(ctx, OVHIP_ELAUNCH, "hipStreamSynchronize(dmvr rows)", e);
+        if (n > j->n_mv) j->n_mv = n;
+    }
+    j->dmvr_first = n;
+    return (int64_t)n;
+}
+
+int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs, const ovhip_pic *intra,
+                    const ovhip_job_params *pr)
+{
+    if (!j || !dst || !pr) return OVHIP_EINVAL;
+    ovhip_ctx *ctx = j->ctx;
+    OV_DEVICE(ctx);
+    if (dst->w != j->w || dst->h != j->h) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_job_flush: picture size differs from the job's", hipSuccess);
+    const uint32_t stages = pr->stages ? pr->stages : 0xffffffffu;
+    const int log2_ctu = pr->log2_ctu_s ? pr->log2_ctu_s : 7;
+    if (log2_ctu < 5 || log2_ctu > 7) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_job_flush: log2_ctu_s", hipSuccess);
+    const size_t n_ctu = (size_t)((j->w + (1 << log2_ctu) - 1) >> log2_ctu) * ((j->h + (1 << log2_ctu) - 1) >> log2_ctu);
+    memset(&j->st, 0, sizeof(j->st));
+    ovhip_recorder *rec = j->rec;
+
+    // ---- host: class split of the transform blocks (luma first; big / small), recorder arrays ----
+    size_t cls[4] = { 0, 0, 0, 0 }, n_tb = 0, n_coef = 0, n_mc = 0, n_mcx = 0, n_aff = 0, n_side = 0, n_reg = 0, n_ev = 0, n_eh = 0;
+    const ovhip_tb_cmd *tb = ovhip_rec_tb_cmds_split(rec, cls, &n_tb);
+    if (!tb && n_tb) return ov_fail(ctx, OVHIP_ENOMEM, "ovhip_rec_tb_cmds_split", hipSuccess);
+    const int16_t *coef = ovhip_rec_coefs(rec, &n_coef);
+    const ovhip_mc_unit *mc = ovhip_rec_mc_units(rec, &n_mc);
+    const ovhip_mc_unit *mcx = ovhip_rec_mcx_units(rec, &n_mcx);
+    const ovhip_aff_unit *aff = ovhip_rec_aff_units(rec, &n_aff);
+    const int32_t *side = ovhip_rec_aff_side(rec, &n_side);
+    const ovhip_lmcs_region *reg = ovhip_rec_lmcs_regions(rec, &n_reg);
+    ovhip_dbf_offsets offs;
+    const ovhip_dbf_edge *ev = ovhip_rec_dbf_edges(rec, 0, &n_ev, &offs);
+    const ovhip_dbf_edge *eh = ovhip_rec_dbf_edges(rec, 1, &n_eh, nullptr);
+    j->st.n_tb = (uint32_t)n_tb; j->st.n_mc = (uint32_t)n_mc; j->st.n_mcx = (uint32_t)n_mcx; j->st.n_aff = (uint32_t)n_aff;
+    j->st.n_edges_v = (uint32_t)n_ev; j->st.n_edges_h = (uint32_t)n_eh; j->st.n_regions = (uint32_t)n_reg;
+
+    // ---- host: picture-level tables into one staging block ----
+    const int sao_on = pr->sao && (stages & OVHIP_STAGE_SAO), alf_on = pr->alf_ctus && (stages & OVHIP_STAGE_ALF);
+    if (alf_on && (!pr->alf_luma_coeff || !pr->alf_luma_clip || !pr->alf_chroma_coeff || !pr->alf_chroma_clip || !pr->alf_cc_coeff))
+        return ov_fail(ctx, OVHIP_EINVAL, "ovhip_job_flush: ALF tables missing", hipSuccess);
+    ParamLayout L;
+    size_t o = 0;
+    auto put = [&o](size_t bytes) { size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
+    L.sao = put(sao_on ? n_ctu * sizeof(ovhip_sao_ctu) : 0);
+    L.alf_ctus = put(alf_on ? n_ctu * sizeof(ovhip_alf_ctu) : 0);
+    L.lcoef = put(alf_on ? 24 * OVHIP_ALF_LUMA_SET_SIZE * 2 : 0);
+    L.lclip = put(alf_on ? 24 * OVHIP_ALF_LUMA_SET_SIZE * 2 : 0);
+    L.ccoef = put(alf_on ? 8 * 7 * 2 : 0);
+    L.cclip = put(alf_on ? 8 * 7 * 2 : 0);
+    L.cc = put(alf_on ? 2 * 4 * 8 * 2 : 0);
+    L.fwd = put(pr->lmcs ? 2048 : 0);
+    L.bwd = put(pr->lmcs ? 2048 : 0);
+    L.total = o;
+    if (L.total) {
+        CHK(pinned_reserve(j, (void **)&j->param_host, &j->param_cap, L.total));
+        char *ph = j->param_host;
+        if (sao_on) memcpy(ph + L.sao, pr->sao, n_ctu * sizeof(ovhip_sao_ctu));
+        if (alf_on) {
+            memcpy(ph + L.alf_ctus, pr->alf_ctus, n_ctu * sizeof(ovhip_alf_ctu));
+            memcpy(ph + L.lcoef, pr->alf_luma_coeff, 24 * OVHIP_ALF_LUMA_SET_SIZE * 2);
+            memcpy(ph + L.lclip, pr->alf_luma_clip, 24 * OVHIP_ALF_LUMA_SET_SIZE * 2);
+            memcpy(ph + L.ccoef, pr->alf_chroma_coeff, 8 * 7 * 2);
+            memcpy(ph + L.cclip, pr->alf_chroma_clip, 8 * 7 * 2);
+            memcpy(ph + L.cc, pr->alf_cc_coeff, 2 * 4 * 8 * 2);
+        }
+        if (pr->lmcs) { memcpy(ph + L.fwd, pr->lmcs->fwd_lut, 2048); memcpy(ph + L.bwd, pr->lmcs->bwd_lut, 2048); }
+    }
+
+    // ---- H2D (asynchronous DMA out of page-locked memory, in stage order so that prediction can start early) ----
+    CHK(h2d(j, B_PARAM, j->param_host, L.total));
+    CHK(h2d(j, B_MC, mc, n_mc * sizeof(*mc)));
+    if (n_mcx) {
+        // (units that went through the eager per-row search are uploaded again with the rest: the list is small and the
+        // full kernel repeats the search with the identical result)
+        CHK(h2d(j, B_MCX, mcx, n_mcx * sizeof(*mcx)));
+        CHK(dev_reserve(j, B_MV, n_mcx * 16));
+        CHK(pinned_reserve(j, (void **)&j->mv_host, &j->mv_cap, n_mcx * 16));
+    }
+    CHK(h2d(j, B_AFF, aff, n_aff * sizeof(*aff)));
+    CHK(h2d(j, B_SIDE, side, n_side * sizeof(*side)));
+    CHK(h2d(j, B_TB, tb, n_tb * sizeof(*tb)));
+    CHK(h2d(j, B_COEF, coef, n_coef * sizeof(*coef)));
+    CHK(h2d(j, B_REG, reg, n_reg * sizeof(*reg)));
+    if (n_reg) CHK(dev_reserve(j, B_SCALE, n_reg * 2));
+    if (stages & OVHIP_STAGE_DBF) {
+        CHK(h2d(j, B_EV, ev, n_ev * sizeof(*ev)));
+        CHK(h2d(j, B_EH, eh, n_eh * sizeof(*eh)));
+    }
+    OV_HIP(ctx, hipEventRecord(j->ev_h2d, ctx->stream));
+
+    const char *dp = (const char *)j->dev[B_PARAM].p;
+    const uint16_t *d_fwd = pr->lmcs ? (const uint16_t *)(dp + L.fwd) : nullptr;
+    const uint16_t *d_bwd = pr->lmcs ? (const uint16_t *)(dp + L.bwd) : nullptr;
+    const int16_t *d_scales = n_reg ? (const int16_t *)j->dev[B_SCALE].p : nullptr;
+
+    // ---- prediction ----
+    if (stages & OVHIP_STAGE_MC) {
+        CHK(ovhip_mc_launch(ctx, dst, refs, n_refs, (const ovhip_mc_unit *)j->dev[B_MC].p, (uint32_t)n_mc, d_fwd, intra));
+        j->st.n_launches += n_mc != 0;
+        if (n_mcx || n_aff) {
+            CHK(ovhip_mcxa_launch(ctx, dst, refs, n_refs, (const ovhip_mc_unit *)j->dev[B_MCX].p, (uint32_t)n_mcx,
+                                  (int32_t *)j->dev[B_MV].p, (const ovhip_aff_unit *)j->dev[B_AFF].p, (uint32_t)n_aff,
+                                  (const int32_t *)j->dev[B_SIDE].p, d_fwd));
+            j->st.n_launches++;
+        }
+        if (n_mcx) {
+            // refined vectors back to the host as early as the stream allows (the decoder's TMVP field needs them)
+            OV_HIP(ctx, hipMemcpyAsync(j->mv_host, j->dev[B_MV].p, n_mcx * 16, hipMemcpyDeviceToHost, ctx->stream));
+            j->st.d2h_bytes += n_mcx * 16;
+        }
+        j->n_mv = n_mcx;
+    }
+    // ---- residual: luma blocks, chroma-scale derivation on the reconstructed luma, chroma blocks (+ inverse mapping) ----
+    const int ordered = 0;   // pictures with an ordered (intra) pass keep the luma plane in the mapped domain until it has run
+    if (stages & OVHIP_STAGE_ITX) {
+        const ovhip_tb_cmd *d_tb = (const ovhip_tb_cmd *)j->dev[B_TB].p;
+        const int16_t *d_coef = (const int16_t *)j->dev[B_COEF].p;
+        if (cls[0] + cls[1]) {
+            CHK(ovhip_itx_launch_classes(ctx, dst, d_tb, (uint32_t)cls[0], (uint32_t)cls[1], d_coef, nullptr));
+            j->st.n_launches++;
+        }
+        if (n_reg) {
+            if (!pr->lmcs) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_job_flush: chroma-scale regions recorded without LMCS tables", hipSuccess);
+            CHK(ovhip_lmcs_scale_launch(ctx, dst, (const ovhip_lmcs_region *)j->dev[B_REG].p, (uint32_t)n_reg, pr->lmcs,
+                                        (int16_t *)j->dev[B_SCALE].p));
+            j->st.n_launches++;
+        }
+        const ovhip_tb_cmd *d_tbc = d_tb + cls[0] + cls[1];
+        if (pr->lmcs && cls[3] && !ordered) {
+            CHK(ovhip_itx_launch_chroma_lmcs(ctx, dst, d_tbc, (uint32_t)cls[2], (uint32_t)cls[3], d_coef, d_scales, d_bwd));
+            j->st.n_launches++;
+        } else {
+            if (cls[2] + cls[3]) {
+                CHK(ovhip_itx_launch_classes(ctx, dst, d_tbc, (uint32_t)cls[2], (uint32_t)cls[3], d_coef, d_scales));
+                j->st.n_launches++;
+            }
+            if (pr->lmcs && !ordered) { CHK(ovhip_lmcs_inverse_launch(ctx, dst, d_bwd)); j->st.n_launches++; }
+        }
+    }
+    // ---- in-loop filters ----
+    if (stages & OVHIP_STAGE_DBF) {
+        CHK(ovhip_dbf_launch_edges_ex(ctx, dst, (const ovhip_dbf_edge *)j->dev[B_EV].p, (uint32_t)n_ev,
+                                      (const ovhip_dbf_edge *)j->dev[B_EH].p, (uint32_t)n_eh, &offs));
+        j->st.n_launches += (n_ev != 0) + (n_eh != 0);
+    }
+    // SAO writes tmp, ALF writes dst; with only one of the two the result is copied back so that dst always holds it
+    if (sao_on) {
+        CHK(ovhip_sao_launch(ctx, &j->tmp, dst, (const ovhip_sao_ctu *)(dp + L.sao), log2_ctu));
+        j->st.n_launches++;
+    }
+    if (alf_on) {
+        CHK(dev_reserve(j, B_CLASS, (size_t)((j->w + 3) / 4) * ((j->h + 3) / 4)));
+        ovhip_alf_pic ap;
+        ap.ctus = (const ovhip_alf_ctu *)(dp + L.alf_ctus);
+        ap.luma_coeff = (const int16_t *)(dp + L.lcoef); ap.luma_clip = (const int16_t *)(dp + L.lclip);
+        ap.chroma_coeff = (const int16_t *)(dp + L.ccoef); ap.chroma_clip = (const int16_t *)(dp + L.cclip);
+        ap.cc_coeff = (const int16_t *)(dp + L.cc);
+        ap.class_scratch = (uint8_t *)j->dev[B_CLASS].p;
+        ap.log2_ctu_s = log2_ctu;
+        if (!sao_on) CHK(copy_pic(ctx, &j->tmp, dst));
+        CHK(ovhip_alf_launch(ctx, dst, &j->tmp, &ap));
+        j->st.n_launches++;
+    } else if (sao_on) {
+        CHK(copy_pic(ctx, dst, &j->tmp));
+    }
+    OV_HIP(ctx, hipEventRecord(j->ev_done, ctx->stream));
+    j->flushed = 1;
+    return OVHIP_OK;
+}
+
+} // extern "C"

@@ -29,20 +29,33 @@
 #define CUF_BDPCM_CHROMA_DIR  (1u << 11)
 
 ovhip_recorder *
-ovhip_rec_create(int32_t pic_w, int32_t pic_h)
+ovhip_rec_create_ex(int32_t pic_w, int32_t pic_h, const ovhip_allocator *a)
 {
+    if (pic_w <= 0 || pic_h <= 0 || (a && (!a->alloc || !a->free))) return NULL;
     ovhip_recorder *r = (ovhip_recorder *)calloc(1, sizeof(*r));
     if (!r) return NULL;
     r->pic_w = pic_w;
     r->pic_h = pic_h;
+    r->dense_planes = 1;
+    if (a) { r->al = *a; r->has_al = 1; }
     return r;
+}
+
+ovhip_recorder *ovhip_rec_create(int32_t pic_w, int32_t pic_h) { return ovhip_rec_create_ex(pic_w, pic_h, NULL); }
+
+void
+ovhip_rec_free_(ovhip_recorder *r, void *p)
+{
+    if (!p) return;
+    if (r->has_al) r->al.free(r->al.user, p); else free(p);
 }
 
 void
 ovhip_rec_destroy(ovhip_recorder *r)
 {
     if (!r) return;
-    free(r->tb); free(r->coef); free(r->mc); free(r->mcx); free(r->aff); free(r->aff_side); free(r->reg); free(r->tb_split); free(r->ciip);
+    void *bufs[] = { r->tb, r->coef, r->mc, r->mcx, r->aff, r->aff_side, r->reg, r->tb_split, r->ciip, r->edge_v, r->edge_h };
+    for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); ++i) ovhip_rec_free_(r, bufs[i]);
     ovhip_rec_dbf_free_(r);
     free(r);
 }
@@ -50,27 +63,80 @@ ovhip_rec_destroy(ovhip_recorder *r)
 void
 ovhip_rec_reset(ovhip_recorder *r)
 {
+    if (!r) return;
     r->n_tb = r->n_coef = r->n_mc = r->n_mcx = r->n_aff = r->n_side = r->n_reg = r->n_ciip = 0;
+    r->n_edge_v = r->n_edge_h = 0;
+    r->n_dbf_off = 0;
     ovhip_rec_dbf_reset_(r);
 }
 
-const ovhip_tb_cmd *ovhip_rec_tb_cmds(const ovhip_recorder *r, size_t *n) { *n = r->n_tb; return r->tb; }
-const int16_t *ovhip_rec_coefs(const ovhip_recorder *r, size_t *n) { *n = r->n_coef; return r->coef; }
-const ovhip_mc_unit *ovhip_rec_mc_units(const ovhip_recorder *r, size_t *n) { *n = r->n_mc; return r->mc; }
-const ovhip_mc_unit *ovhip_rec_mcx_units(const ovhip_recorder *r, size_t *n) { *n = r->n_mcx; return r->mcx; }
-const ovhip_aff_unit *ovhip_rec_aff_units(const ovhip_recorder *r, size_t *n) { *n = r->n_aff; return r->aff; }
-const int32_t *ovhip_rec_aff_side(const ovhip_recorder *r, size_t *n) { *n = r->n_side; return r->aff_side; }
+void ovhip_rec_set_dense_dbf_planes(ovhip_recorder *r, int on) { if (r) r->dense_planes = !!on; }
 
-static int
-grow(void **p, size_t *cap, size_t need, size_t elem)
+#define ACCESSOR(type, name, arr, cnt) \
+    const type *name(const ovhip_recorder *r, size_t *n) { if (!r || !n) return NULL; *n = r->cnt; return r->arr; }
+ACCESSOR(ovhip_tb_cmd, ovhip_rec_tb_cmds, tb, n_tb)
+ACCESSOR(int16_t, ovhip_rec_coefs, coef, n_coef)
+ACCESSOR(ovhip_mc_unit, ovhip_rec_mc_units, mc, n_mc)
+ACCESSOR(ovhip_mc_unit, ovhip_rec_mcx_units, mcx, n_mcx)
+ACCESSOR(ovhip_aff_unit, ovhip_rec_aff_units, aff, n_aff)
+ACCESSOR(int32_t, ovhip_rec_aff_side, aff_side, n_side)
+
+/* Arrays grow geometrically; with a caller-supplied allocator (pinned host memory in the engine, so that the flush
+ * is plain asynchronous DMA) growth is allocate + copy + free, since such memory cannot be realloc'ed. */
+int
+ovhip_rec_grow_(ovhip_recorder *r, void **p, size_t *cap, size_t need, size_t elem)
 {
     if (need <= *cap) return 0;
     size_t nc = *cap ? *cap : 1024;
     while (nc < need) nc *= 2;
-    void *q = realloc(*p, nc * elem);
-    if (!q) return -1;
+    void *q;
+    if (r->has_al) {
+        q = r->al.alloc(r->al.user, nc * elem);
+        if (!q) return -1;
+        if (*p) { memcpy(q, *p, *cap * elem); r->al.free(r->al.user, *p); }
+    } else {
+        q = realloc(*p, nc * elem);
+        if (!q) return -1;
+    }
     *p = q; *cap = nc;
     return 0;
+}
+#define grow(p, cap, need, elem) ovhip_rec_grow_(r, p, cap, need, elem)
+
+/* Bulk append of already-recorded commands (replaying a stored command stream: fixtures, benchmarks, a picture
+ * recorded by another recorder).  Offsets inside the commands (coef_off, side_off, region indices) are taken as they
+ * are, i.e. the stream must be appended to an empty recorder, arena first. */
+int
+ovhip_rec_append_raw(ovhip_recorder *r, int which, const void *data, size_t n)
+{
+    if (!r || (n && !data)) return OVHIP_EINVAL;
+    void **p; size_t *cnt, *cap, elem;
+    switch (which) {
+    case OVHIP_REC_TB:     p = (void **)&r->tb;       cnt = &r->n_tb;     cap = &r->cap_tb;     elem = sizeof(ovhip_tb_cmd); break;
+    case OVHIP_REC_COEF:   p = (void **)&r->coef;     cnt = &r->n_coef;   cap = &r->cap_coef;   elem = sizeof(int16_t); break;
+    case OVHIP_REC_MC:     p = (void **)&r->mc;       cnt = &r->n_mc;     cap = &r->cap_mc;     elem = sizeof(ovhip_mc_unit); break;
+    case OVHIP_REC_MCX:    p = (void **)&r->mcx;      cnt = &r->n_mcx;    cap = &r->cap_mcx;    elem = sizeof(ovhip_mc_unit); break;
+    case OVHIP_REC_AFF:    p = (void **)&r->aff;      cnt = &r->n_aff;    cap = &r->cap_aff;    elem = sizeof(ovhip_aff_unit); break;
+    case OVHIP_REC_SIDE:   p = (void **)&r->aff_side; cnt = &r->n_side;   cap = &r->cap_side;   elem = sizeof(int32_t); break;
+    case OVHIP_REC_REGION: p = (void **)&r->reg;      cnt = &r->n_reg;    cap = &r->cap_reg;    elem = sizeof(ovhip_lmcs_region); break;
+    case OVHIP_REC_CIIP:   p = (void **)&r->ciip;     cnt = &r->n_ciip;   cap = &r->cap_ciip;   elem = sizeof(ovhip_ciip_unit); break;
+    case OVHIP_REC_EDGE_V: p = (void **)&r->edge_v;   cnt = &r->n_edge_v; cap = &r->cap_edge_v; elem = sizeof(ovhip_dbf_edge); break;
+    case OVHIP_REC_EDGE_H: p = (void **)&r->edge_h;   cnt = &r->n_edge_h; cap = &r->cap_edge_h; elem = sizeof(ovhip_dbf_edge); break;
+    default: return OVHIP_EINVAL;
+    }
+    if (grow(p, cap, *cnt + n, elem)) return OVHIP_ENOMEM;
+    if (n) memcpy((char *)*p + *cnt * elem, data, n * elem);
+    *cnt += n;
+    return OVHIP_OK;
+}
+
+/* The deblocking offsets of a replayed stream (ovhip_rec_dbf_ctu collects them itself). */
+int
+ovhip_rec_set_dbf_offsets(ovhip_recorder *r, const ovhip_dbf_offsets *o, int n)
+{
+    if (!r || !o || n < 0 || n > OVHIP_DBF_MAX_OFFSETS) return OVHIP_EINVAL;
+    r->dbf_off = *o; r->n_dbf_off = n;
+    return OVHIP_OK;
 }
 
 /* ---------------------------------------------------------------- dequantisation params */
@@ -314,10 +380,10 @@ emit_tb(ovhip_recorder *r, const ovhip_tu_state *st, const struct tb_args *a, ov
 int
 ovhip_rec_tu(ovhip_recorder *r, const ovhip_tu_state *st, const ovhip_tu_desc *tu)
 {
-    size_t n0 = r->n_tb;
+    if (!r || !st || !tu) return OVHIP_EINVAL;
+    const size_t n0 = r->n_tb, c0 = r->n_coef;
     int ret;
     ovhip_tb_cmd *c;
-
 
     /* ---- luma (rcn_tu_st / rcn_tu_l) ---- */
     if (tu->tree != 2 && (tu->cbf_mask & 0x10)) {
@@ -349,7 +415,7 @@ ovhip_rec_tu(ovhip_recorder *r, const ovhip_tu_state *st, const ovhip_tu_desc *t
         /* lmcs_scale_c == 2: the scale is derived on the device; the command carries the region index */
         const int indirect = st->lmcs_scale_c == 2;
         if (indirect) {
-            if (!r->n_reg) return OVHIP_EINVAL;
+            if (!r->n_reg) { ret = OVHIP_EINVAL; goto fail; }
             scale = (int16_t)(r->n_reg - 1);
         }
         struct tb_args a;
@@ -396,6 +462,7 @@ ovhip_rec_tu(ovhip_recorder *r, const ovhip_tu_state *st, const ovhip_tu_desc *t
     return (int)(r->n_tb - n0);
 fail:
     r->n_tb = n0;
+    r->n_coef = c0;
     return ret;
 }
 
@@ -736,7 +803,7 @@ ovhip_rec_lmcs_region(ovhip_recorder *r, int32_t x0, int32_t y0, uint32_t abv_ma
     return (int)r->n_reg++;
 }
 
-const ovhip_lmcs_region *ovhip_rec_lmcs_regions(const ovhip_recorder *r, size_t *n) { *n = r->n_reg; return r->reg; }
+ACCESSOR(ovhip_lmcs_region, ovhip_rec_lmcs_regions, reg, n_reg)
 
 const ovhip_tb_cmd *
 ovhip_rec_tb_cmds_split(ovhip_recorder *r, size_t counts[4], size_t *n)
@@ -778,4 +845,4 @@ ovhip_ciip_weight(int32_t mode_abv, int32_t mode_lft)
     return 1 + (mode_abv == 2 || mode_abv == 4) + (mode_lft == 2 || mode_lft == 4);
 }
 
-const ovhip_ciip_unit *ovhip_rec_ciip_units(const ovhip_recorder *r, size_t *n) { *n = r->n_ciip; return r->ciip; }
+ACCESSOR(ovhip_ciip_unit, ovhip_rec_ciip_units, ciip, n_ciip)

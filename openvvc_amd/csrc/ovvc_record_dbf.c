@@ -19,10 +19,10 @@
 static int
 dbf_alloc(ovhip_recorder *r)
 {
-    if (r->dbf_luma_v) return 0;
     const int w4 = (r->pic_w + 3) >> 2, h4 = (r->pic_h + 3) >> 2;
     const int w4c = (w4 + 1) >> 1, h4c = (h4 + 1) >> 1;
     r->dbf_w4 = w4; r->dbf_h4 = h4;
+    if (r->dbf_luma_v || !r->dense_planes) return 0;
     r->dbf_luma_v = (uint16_t *)calloc((size_t)w4 * h4, 2);
     r->dbf_luma_h = (uint16_t *)calloc((size_t)w4 * h4, 2);
     r->dbf_cb_v = (uint16_t *)calloc((size_t)w4c * h4, 2);
@@ -54,6 +54,7 @@ int
 ovhip_rec_dbf_planes(const ovhip_recorder *r, ovhip_dbf_planes *out)
 {
     if (!r || !out || !r->dbf_luma_v) return OVHIP_EINVAL;
+    if (r->n_dbf_off > 1) return OVHIP_EUNSUP;   /* the dense planes carry one (beta, tc) pair: use the edge lists */
     out->luma_v = r->dbf_luma_v; out->luma_h = r->dbf_luma_h;
     out->cb_v = r->dbf_cb_v; out->cr_v = r->dbf_cr_v; out->cb_h = r->dbf_cb_h; out->cr_h = r->dbf_cr_h;
     out->w4 = r->dbf_w4; out->h4 = r->dbf_h4;
@@ -89,13 +90,44 @@ filter_length(const struct edge_ctx *e, uint64_t aff_p, uint64_t aff_q, uint64_t
 
 static uint64_t large_from_ngh(const uint64_t *m) { return ~(m[-1] | m[1] | m[-2] | m[2] | m[-3] | m[3]); }
 
+/* One segment: into the compact list the device kernel consumes (never an edge ON the picture boundary, the rule
+ * ovhip_dbf_compact applies too) and, when kept, into the dense plane. */
+static int
+emit_edge(ovhip_recorder *r, int dir, int comp, int ux, int uy, uint16_t word, int off_idx, uint16_t *plane_word)
+{
+    if (plane_word) *plane_word = word;
+    if ((dir ? uy : ux) == 0) return 0;
+    ovhip_dbf_edge **list = dir ? &r->edge_h : &r->edge_v;
+    size_t *n = dir ? &r->n_edge_h : &r->n_edge_v, *cap = dir ? &r->cap_edge_h : &r->cap_edge_v;
+    if (ovhip_rec_grow_(r, (void **)list, cap, *n + 1, sizeof(ovhip_dbf_edge))) return -1;
+    ovhip_dbf_edge e = { (uint16_t)ux, (uint16_t)uy, word, (uint8_t)comp, (uint8_t)off_idx };
+    (*list)[(*n)++] = e;
+    return 0;
+}
+
+/* The (beta, tc) offsets are slice-level state (slicedec.c:1416-1417): every distinct pair of the picture gets an index
+ * that travels in the edge record. */
+static int
+offset_index(ovhip_recorder *r, int beta, int tc)
+{
+    for (int i = 0; i < r->n_dbf_off; ++i)
+        if (r->dbf_off.beta[i] == beta && r->dbf_off.tc[i] == tc) return i;
+    if (r->n_dbf_off >= OVHIP_DBF_MAX_OFFSETS || beta < -128 || beta > 127 || tc < -128 || tc > 127) return -1;
+    r->dbf_off.beta[r->n_dbf_off] = (int8_t)beta; r->dbf_off.tc[r->n_dbf_off] = (int8_t)tc;
+    return r->n_dbf_off++;
+}
+
 int
 ovhip_rec_dbf_ctu(ovhip_recorder *r, const ovhip_dbf_ctu *c)
 {
     if (!r || !c) return OVHIP_EINVAL;
     if (c->log2_ctu_s < 5 || c->log2_ctu_s > 7) return OVHIP_EINVAL;
     if (dbf_alloc(r)) return OVHIP_ENOMEM;
+    const int oi = offset_index(r, c->beta_offset, c->tc_offset);
+    if (oi < 0) return OVHIP_EUNSUP;         /* more than OVHIP_DBF_MAX_OFFSETS distinct slice offset pairs */
+    /* the dense planes (legacy launch) carry ONE pair: only valid while the picture has a single one */
     r->dbf_beta_offset = c->beta_offset; r->dbf_tc_offset = c->tc_offset;
+    const int dense = r->dense_planes;
 
     const int w4 = r->dbf_w4, h4 = r->dbf_h4, w4c = (w4 + 1) >> 1;
     const int nb_full = (1 << c->log2_ctu_s) >> 2;
@@ -123,7 +155,8 @@ ovhip_rec_dbf_ctu(ovhip_recorder *r, const ovhip_dbf_ctu *c)
                 int qp = (q[-1] + q[0] + 1) >> 1, lp, lq;
                 filter_length(&e, c->affine_ver[i], c->affine_ver[i + 1], pos, &lp, &lq);
                 int ux = ux0 + i, uy = uy0 + j;
-                if (ux < w4 && uy < h4) r->dbf_luma_v[uy * w4 + ux] = OVHIP_DBF_LUMA(bs, lp, lq, qp & 255);
+                if (ux < w4 && uy < h4 && emit_edge(r, 0, 0, ux, uy, OVHIP_DBF_LUMA(bs, lp, lq, qp & 255), oi,
+                                                    dense ? &r->dbf_luma_v[uy * w4 + ux] : NULL)) return OVHIP_ENOMEM;
             }
         }
     }
@@ -144,7 +177,8 @@ ovhip_rec_dbf_ctu(ovhip_recorder *r, const ovhip_dbf_ctu *c)
                 int qp = (q[0] + q[34] + 1) >> 1, lp, lq;
                 filter_length(&e, c->affine_hor[i], c->affine_hor[i + 1], pos, &lp, &lq);
                 int ux = ux0 + k - 2, uy = uy0 + i;
-                if (ux >= 0 && ux < w4 && uy < h4) r->dbf_luma_h[uy * w4 + ux] = OVHIP_DBF_LUMA(bs, lp, lq, qp & 255);
+                if (ux >= 0 && ux < w4 && uy < h4 && emit_edge(r, 1, 0, ux, uy, OVHIP_DBF_LUMA(bs, lp, lq, qp & 255), oi,
+                                                               dense ? &r->dbf_luma_h[uy * w4 + ux] : NULL)) return OVHIP_ENOMEM;
             }
         }
     }
@@ -169,9 +203,10 @@ ovhip_rec_dbf_ctu(ovhip_recorder *r, const ovhip_dbf_ctu *c)
                     const uint8_t *q = &qpm[36 + idx + 34 * j];
                     int qp = (q[-1] + q[0] + 1) >> 1;
                     int ux = ux0 + idx, uy = uy0 + j;
-                    if (ux < w4 && uy < h4)
-                        plane[uy * w4c + (ux >> 1)] = (uint16_t)(OVHIP_DBF_C_ON | (((bs2 >> j) & 1) ? OVHIP_DBF_C_BS2 : 0)
-                                                                 | (((large >> j) & 1) ? OVHIP_DBF_C_LARGE : 0) | ((qp & 255) << 8));
+                    const uint16_t word = (uint16_t)(OVHIP_DBF_C_ON | (((bs2 >> j) & 1) ? OVHIP_DBF_C_BS2 : 0)
+                                                     | (((large >> j) & 1) ? OVHIP_DBF_C_LARGE : 0) | ((qp & 255) << 8));
+                    if (ux < w4 && uy < h4 && emit_edge(r, 0, 1 + comp, ux, uy, word, oi,
+                                                        dense ? &plane[uy * w4c + (ux >> 1)] : NULL)) return OVHIP_ENOMEM;
                 }
             }
         }
@@ -197,15 +232,25 @@ ovhip_rec_dbf_ctu(ovhip_recorder *r, const ovhip_dbf_ctu *c)
                     const uint8_t *q = &qpm[idx * 34 + k];
                     int qp = (q[0] + q[34] + 1) >> 1;
                     int ux = ux0 + k - 2, uy = uy0 + idx;
-                    if (ux >= 0 && ux < w4 && uy < h4)
-                        plane[(uy >> 1) * w4 + ux] = (uint16_t)(OVHIP_DBF_C_ON | (((bs2 >> k) & 1) ? OVHIP_DBF_C_BS2 : 0)
-                                                                | (((large >> k) & 1) ? OVHIP_DBF_C_LARGE : 0)
-                                                                | (i == 0 ? OVHIP_DBF_C_CTB_B : 0) | ((qp & 255) << 8));
+                    const uint16_t word = (uint16_t)(OVHIP_DBF_C_ON | (((bs2 >> k) & 1) ? OVHIP_DBF_C_BS2 : 0)
+                                                     | (((large >> k) & 1) ? OVHIP_DBF_C_LARGE : 0)
+                                                     | (i == 0 ? OVHIP_DBF_C_CTB_B : 0) | ((qp & 255) << 8));
+                    if (ux >= 0 && ux < w4 && uy < h4 && emit_edge(r, 1, 1 + comp, ux, uy, word, oi,
+                                                                   dense ? &plane[(uy >> 1) * w4 + ux] : NULL)) return OVHIP_ENOMEM;
                 }
             }
         }
     }
     return OVHIP_OK;
+}
+
+const ovhip_dbf_edge *
+ovhip_rec_dbf_edges(const ovhip_recorder *r, int dir, size_t *n, ovhip_dbf_offsets *offsets)
+{
+    if (!r || !n || (dir != 0 && dir != 1)) return NULL;
+    *n = dir ? r->n_edge_h : r->n_edge_v;
+    if (offsets) *offsets = r->dbf_off;
+    return dir ? r->edge_h : r->edge_v;
 }
 
 /* ---------------------------------------------------------------- compact edge lists

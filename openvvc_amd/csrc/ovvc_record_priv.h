@@ -6,6 +6,7 @@
 
 struct ovhip_recorder {
     int32_t pic_w, pic_h;
+    ovhip_allocator al; int has_al;     /* arrays below come from it (pinned host memory in the engine) */
     ovhip_tb_cmd  *tb;    size_t n_tb,   cap_tb;
     int16_t       *coef;  size_t n_coef, cap_coef;
     ovhip_mc_unit *mc;    size_t n_mc,   cap_mc;
@@ -19,7 +20,14 @@ struct ovhip_recorder {
     uint16_t *dbf_luma_v, *dbf_luma_h, *dbf_cb_v, *dbf_cr_v, *dbf_cb_h, *dbf_cr_h;
     int32_t dbf_w4, dbf_h4;
     int16_t dbf_beta_offset, dbf_tc_offset;
+    int dense_planes;                   /* also maintain the dense planes above (ovhip_rec_dbf_planes) */
+    /* compact edge lists, emitted directly per CTU (what the device kernel consumes) */
+    ovhip_dbf_edge *edge_v, *edge_h; size_t n_edge_v, cap_edge_v, n_edge_h, cap_edge_h;
+    ovhip_dbf_offsets dbf_off; int n_dbf_off;   /* distinct (beta, tc) offset pairs of the picture's slices */
 };
+
+int  ovhip_rec_grow_(ovhip_recorder *r, void **p, size_t *cap, size_t need, size_t elem);
+void ovhip_rec_free_(ovhip_recorder *r, void *p);
 
 void ovhip_rec_dbf_reset_(ovhip_recorder *r);
 void ovhip_rec_dbf_free_(ovhip_recorder *r);

@@ -144,7 +144,9 @@ def dbf_cases():
         mv = g.get(f"p{pi}_mvctx")                    # B-slice picture: motion contexts for the MV-based bS pre-pass
         for k, raw in enumerate(g[f"p{pi}_ctus"]):
             rec.dbf_ctu(raw.tobytes(), mv[k].tobytes() if mv is not None else None)
-        out.append((HostPic(w, h, y, g[f"p{pi}_in_cb"], g[f"p{pi}_in_cr"]), rec.dbf_planes(),
+        planes = rec.dbf_planes()
+        planes["edges"] = [rec.dbf_edges(0), rec.dbf_edges(1)]        # what the per-CTU recorder emitted directly
+        out.append((HostPic(w, h, y, g[f"p{pi}_in_cb"], g[f"p{pi}_in_cr"]), planes,
                     HostPic(w, h, g[f"p{pi}_exp_y"], g[f"p{pi}_exp_cb"], g[f"p{pi}_exp_cr"])))
         pi += 1
     return out

@@ -160,6 +160,19 @@ def test_dbf_oracle_matches_reference(built_lib):
             assert len(bad) == 0, f"dbf picture {i} plane {name}: {len(bad)} samples differ, first at (y,x) {bad[:6].tolist()}"
 
 
+def test_dbf_edge_lists_equal_compacted_planes(built_lib):
+    """The edge lists ovhip_rec_dbf_ctu emits CTU by CTU (what ovhip_job_flush uploads) hold exactly the segments
+    ovhip_dbf_compact extracts from the dense planes the reference-pinned oracle test consumes."""
+    for i, (_, planes, _) in enumerate(golden_cases.dbf_cases()):
+        for d in (0, 1):
+            direct, offs = planes["edges"][d]
+            compact = capi.dbf_compact(planes, d)
+            key = lambda a: sorted(zip(a["comp"].tolist(), a["uy"].tolist(), a["ux"].tolist(), a["word"].tolist()))
+            assert key(direct) == key(compact), f"picture {i} dir {d}"
+            assert len(direct) > 100 and (direct["pad"] == 0).all()
+            assert offs.beta[0] == planes["beta_offset"] and offs.tc[0] == planes["tc_offset"]
+
+
 def test_sao_oracle_matches_reference(built_lib):
     cases = golden_cases.sao_cases()
     assert len(cases) == 3
