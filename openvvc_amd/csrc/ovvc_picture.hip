@@ -16,7 +16,7 @@ namespace {
 
 struct DevBuf { void *p; size_t cap; };
 
-enum { B_TB, B_COEF, B_MC, B_MCX, B_MV, B_AFF, B_SIDE, B_REG, B_SCALE, B_EV, B_EH, B_PARAM, B_CLASS, B_COUNT };
+enum { B_TB, B_COEF, B_MC, B_MCX, B_MV, B_AFF, B_SIDE, B_REG, B_SCALE, B_EV, B_EH, B_PARAM, B_CLASS, B_CIIP, B_COUNT };
 
 // layout of the parameter block (one pinned staging copy, one H2D)
 struct ParamLayout { size_t sao, alf_ctus, lcoef, lclip, ccoef, cclip, cc, fwd, bwd, total; };
@@ -234,6 +234,10 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
     const ovhip_aff_unit *aff = ovhip_rec_aff_units(rec, &n_aff);
     const int32_t *side = ovhip_rec_aff_side(rec, &n_side);
     const ovhip_lmcs_region *reg = ovhip_rec_lmcs_regions(rec, &n_reg);
+    size_t n_ciip = 0;
+    const ovhip_ciip_unit *ciip = ovhip_rec_ciip_units(rec, &n_ciip);
+    if (n_ciip && !intra)
+        return ov_fail(ctx, OVHIP_EUNSUP, "ovhip_job_flush: CIIP blend units recorded but no picture with their intra prediction", hipSuccess);
     ovhip_dbf_offsets offs;
     const ovhip_dbf_edge *ev = ovhip_rec_dbf_edges(rec, 0, &n_ev, &offs);
     const ovhip_dbf_edge *eh = ovhip_rec_dbf_edges(rec, 1, &n_eh, nullptr);
@@ -282,6 +286,7 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
         CHK(dev_reserve(j, B_MV, n_mcx * 16));
         CHK(pinned_reserve(j, (void **)&j->mv_host, &j->mv_cap, n_mcx * 16));
     }
+    CHK(h2d(j, B_CIIP, ciip, n_ciip * sizeof(*ciip)));
     CHK(h2d(j, B_AFF, aff, n_aff * sizeof(*aff)));
     CHK(h2d(j, B_SIDE, side, n_side * sizeof(*side)));
     CHK(h2d(j, B_TB, tb, n_tb * sizeof(*tb)));
@@ -315,6 +320,7 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
             j->st.d2h_bytes += n_mcx * 16;
         }
         j->n_mv = n_mcx;
+        if (n_ciip) { CHK(ovhip_ciip_launch(ctx, dst, intra, (const ovhip_ciip_unit *)j->dev[B_CIIP].p, (uint32_t)n_ciip)); j->st.n_launches++; }
     }
     // ---- residual: luma blocks, chroma-scale derivation on the reconstructed luma, chroma blocks (+ inverse mapping) ----
     const int ordered = 0;   // pictures with an ordered (intra) pass keep the luma plane in the mapped domain until it has run

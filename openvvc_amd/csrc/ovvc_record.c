@@ -578,6 +578,7 @@ rec_pu_refined(ovhip_recorder *r, const ovhip_pu_desc *pu)
                 clip_mv(r, u.x, u.y, uw, uh, &u.mv1x, &u.mv1y);
                 split_chroma = ident || u.mv0x != c0x || u.mv0y != c0y || u.mv1x != c1x || u.mv1y != c1y;
                 if (split_chroma) u.flags |= OVHIP_MC_NO_CHROMA;
+                if (!(pu->planes & 2)) { u.flags |= OVHIP_MC_NO_CHROMA; split_chroma = 0; }   /* rcn_bdof_mcp_l alone */
             }
             if (grow((void **)&r->mcx, &r->cap_mcx, r->n_mcx + 1, sizeof(u))) return OVHIP_ENOMEM;
             r->mcx[r->n_mcx++] = u;

@@ -373,3 +373,85 @@ class ResidentPicture:
             b.free()
         for p in self.refs + [self.dst, self.tmp] + ([self.intra] if self.intra else []):
             p.free()
+
+
+class Job:
+    """One picture in flight through the C-side flush (ovhip_job_*): the recorder's arrays are page-locked, `flush`
+    enqueues H2D + every stage launch + the D2H of the refined motion vectors and returns without waiting."""
+
+    def __init__(self, ctx: Context, w: int, h: int):
+        self.ctx, self.lib, self.w, self.h = ctx, ctx.lib, w, h
+        j = C.c_void_p()
+        ctx._chk(self.lib.ovhip_job_create(ctx.h, w, h, C.byref(j)), "job_create")
+        self.j = j
+        self.rec = capi.Recorder.__new__(capi.Recorder)          # a view of the job's recorder (not owned)
+        self.rec.lib, self.rec.h, self.rec._keep = self.lib, self.lib.ovhip_job_recorder(j), []
+        self._keep = {}
+
+    def close(self):
+        if self.j:
+            self.rec.h = None
+            self.lib.ovhip_job_destroy(self.j)
+            self.j = None
+
+    def begin(self):
+        self.ctx._chk(self.lib.ovhip_job_begin(self.j), "job_begin")
+
+    def load_workload(self, wl):
+        """Replay a recorded picture (synth.Workload) into the job's recorder: commands, arena, edge lists."""
+        self.begin()
+        r = self.rec
+        for which, arr in ((capi.REC_COEF, wl.coefs), (capi.REC_TB, wl.tb_cmds), (capi.REC_MC, wl.mc_units),
+                           (capi.REC_MCX, wl.mcx_units), (capi.REC_AFF, wl.aff_units), (capi.REC_SIDE, wl.aff_side),
+                           (capi.REC_REGION, wl.lmcs_regions), (capi.REC_CIIP, wl.ciip_units),
+                           (capi.REC_EDGE_V, capi.dbf_compact(wl.dbf_planes, 0)), (capi.REC_EDGE_H, capi.dbf_compact(wl.dbf_planes, 1))):
+            if arr is not None and len(arr):
+                r.append_raw(which, arr)
+        offs = capi.DbfOffsets()
+        for i in range(8):
+            offs.beta[i], offs.tc[i] = wl.dbf_planes["beta_offset"], wl.dbf_planes["tc_offset"]
+        self.ctx._chk(self.lib.ovhip_rec_set_dbf_offsets(r.h, C.byref(offs), 1), "set_dbf_offsets")
+        self.params = self.make_params(wl)
+
+    def make_params(self, wl, log2_ctu: int = 7, stages: int = 0) -> "capi.JobParams":
+        keep = self._keep
+        keep["sao"] = np.ascontiguousarray(wl.sao_params)
+        keep["alf"] = {k: np.ascontiguousarray(wl.alf[k], dtype=dt) for k, dt in capi.ALF_TABLES}
+        keep["lmcs"] = wl.lmcs
+        a = keep["alf"]
+        p = capi.JobParams()
+        p.lmcs = C.addressof(wl.lmcs) if wl.lmcs is not None else None
+        p.sao = keep["sao"].ctypes.data
+        p.alf_ctus = a["ctus"].ctypes.data
+        p.alf_luma_coeff, p.alf_luma_clip = a["luma_coeff"].ctypes.data, a["luma_clip"].ctypes.data
+        p.alf_chroma_coeff, p.alf_chroma_clip = a["chroma_coeff"].ctypes.data, a["chroma_clip"].ctypes.data
+        p.alf_cc_coeff = a["cc_coeff"].ctypes.data
+        p.log2_ctu_s, p.stages = log2_ctu, stages
+        return p
+
+    def flush(self, dst: "DevPic", refs: list, intra: "DevPic | None" = None, params=None):
+        arr = (capi.Pic * max(len(refs), 1))(*[r.s for r in refs])
+        self.ctx._chk(self.lib.ovhip_job_flush(self.j, C.byref(dst.s), arr, len(refs), C.byref(intra.s) if intra else None,
+                                               C.byref(params if params is not None else self.params)), "job_flush")
+
+    def wait(self):
+        self.ctx._chk(self.lib.ovhip_job_wait(self.j), "job_wait")
+
+    def dmvr_rows(self, refs: list) -> int:
+        arr = (capi.Pic * max(len(refs), 1))(*[r.s for r in refs])
+        n = self.lib.ovhip_job_dmvr_rows(self.j, arr, len(refs))
+        if n < 0:
+            self.ctx._chk(int(n), "job_dmvr_rows")
+        return int(n)
+
+    def refined_mvs(self) -> np.ndarray:
+        n = C.c_size_t()
+        p = self.lib.ovhip_job_refined_mvs(self.j, C.byref(n))
+        if not n.value:
+            return np.zeros((0, 4), np.int32)
+        return np.frombuffer((C.c_int32 * (4 * n.value)).from_address(p), dtype=np.int32).reshape(-1, 4).copy()
+
+    def stats(self) -> "capi.JobStats":
+        s = capi.JobStats()
+        self.lib.ovhip_job_last_stats(self.j, C.byref(s))
+        return s

@@ -12,6 +12,7 @@
  */
 #include "ref_common.h"
 #include "ovvc_hip.h"
+#include "shim_stream.h"
 
 /* struct TUInfo is private to rcn_transform_tree.c:51-66 (and duplicated in
  * vcl_transform_unit.c:47-75); the slot signature only forward-declares it. */
@@ -128,6 +129,9 @@ gen_itx(const char *dir)
     OVCTUDec *c = ref_new_ctudec(0, 0);
     c->rcn_funcs.intra_pred_c = stub_intra_pred_c;
     const struct OVBuffInfo *cb = &c->rcn_ctx.ctu_buff;
+    struct shim_stream S, ST;
+    shim_stream_init(&S); shim_stream_init(&ST);
+    if (g_shim) shim_bind(c, 128, 128, 0, 0);
 
     for (int tree = 0; tree <= 2; tree += 2) {
         int lmin = tree ? 1 : 2, lmax = tree ? 5 : 6;
@@ -216,6 +220,7 @@ gen_itx(const char *dir)
 
                     /* ---- reference state ---- */
                     rcn_init_ict_functions_10(&c->rcn_funcs, st.ict_type, 10);
+                    if (g_shim) rcn_init_functions_hip(&c->rcn_funcs, st.ict_type, 1, 0, 0, 10);   /* per slice in the decoder (slicedec.c:1462) */
                     c->dequant_luma.qp = st.qp_y; c->dequant_cb.qp = st.qp_cb; c->dequant_cr.qp = st.qp_cr;
                     c->dequant_joint_cb_cr.qp = st.qp_jcbcr;
                     c->dequant_luma_skip.qp = st.qp_y_skip; c->dequant_cb_skip.qp = st.qp_cb_skip;
@@ -239,8 +244,13 @@ gen_itx(const char *dir)
                     }
                     memset(&c->dbf_info, 0, sizeof(c->dbf_info));
 
+                    if (g_shim && tree == 2 && d.lfnst_flag) {
+                        /* derive_lfnst_mode_c's inputs as the decoder holds them: an explicit angular chroma mode */
+                        c->part_ctx_c = &g_part;
+                    }
                     if (tree == 0) c->rcn_funcs.tmp.rcn_tu_st(c, x0, y0, l2w, l2h, d.cu_flags, d.cbf_mask, &tu);
                     else           c->rcn_funcs.tmp.rcn_tu_c(c, x0, y0, l2w, l2h, d.cu_flags, d.cbf_mask, &tu);
+                    if (g_shim) shim_case_end(c, &S, "itx");
 
                     uint32_t eoff[3] = { 0, 0, 0 };
                     if (tree == 0) {
@@ -305,6 +315,7 @@ gen_itx(const char *dir)
                 used += leaf_sz;
             }
             rcn_init_ict_functions_10(&c->rcn_funcs, st.ict_type, 10);
+            if (g_shim) rcn_init_functions_hip(&c->rcn_funcs, st.ict_type, 1, 0, 0, 10);
             c->dequant_luma.qp = st.qp_y; c->dequant_cb.qp = st.qp_cb; c->dequant_cr.qp = st.qp_cr; c->dequant_joint_cb_cr.qp = st.qp_jcbcr;
             c->dequant_luma_skip.qp = st.qp_y_skip; c->dequant_cb_skip.qp = st.qp_cb_skip; c->dequant_cr_skip.qp = st.qp_cr_skip; c->dequant_jcbcr_skip.qp = st.qp_jcbcr_skip;
             c->residual_coding_l = st.dep_quant ? &residual_coding_dpq : NULL;
@@ -314,6 +325,7 @@ gen_itx(const char *dir)
             for (int j = 0; j < 64; ++j) { memcpy(cb->cb + j * cb->stride_c, pred_cb + j * 64, 128); memcpy(cb->cr + j * cb->stride_c, pred_cr + j * 64, 128); }
             memset(&c->dbf_info, 0, sizeof(c->dbf_info));
             c->rcn_funcs.tmp.rcn_transform_tree(c, 0, 0, l2w, l2h, max_tb, 0, 0, tu);
+            if (g_shim) shim_case_end(c, &ST, "itx tree");
 
             uint32_t coff = (uint32_t)t_coef.n, eoff[3];
             gbuf_push(&t_coef, c->residual_cb, used); gbuf_push(&t_coef, c->residual_cr, used); gbuf_push(&t_coef, c->residual_y, used);
@@ -327,6 +339,11 @@ gen_itx(const char *dir)
         }
     }
 
+    if (g_shim) {
+        shim_stream_write(dir, "shim_itx.ovg", &S, c, NULL, 0);
+        shim_stream_write(dir, "shim_itx_tree.ovg", &ST, c, NULL, 0);
+        return;
+    }
     gfile g = gfile_open(dir, "itx.ovg");
     uint32_t d2[2];
     d2[0] = n_tt; d2[1] = sizeof(ovhip_tu_state); gfile_array(&g, "tt_state", T_U8, t_state.data, 2, d2);
@@ -377,6 +394,9 @@ gen_mc(const char *dir)
         ic->scale_fact_rpl1[i][0] = ic->scale_fact_rpl1[i][1] = 1 << RPR_SCALE_BITS;
     }
     const struct OVBuffInfo *cb = &c->rcn_ctx.ctu_buff;
+    struct shim_stream S;
+    shim_stream_init(&S);
+    if (g_shim) shim_bind(c, MC_W, MC_H, 0, 0);
 
     for (int l2w = 2; l2w <= 7; ++l2w) {
         for (int l2h = 2; l2h <= 7; ++l2h) {
@@ -423,6 +443,7 @@ gen_mc(const char *dir)
                     c->rcn_funcs.rcn_mcp_b_l(c, *cb, ic, c->part_ctx, mv0, mv1, x0, y0, l2w, l2h, d.inter_dir, d.ref_idx0, d.ref_idx1);
                 else
                     c->rcn_funcs.rcn_mcp_b_c(c, *cb, ic, c->part_ctx, mv0, mv1, x0, y0, l2w, l2h, d.inter_dir, d.ref_idx0, d.ref_idx1);
+                if (g_shim) shim_case_end(c, &S, "mc");
 
                 uint32_t eoff[3];
                 eoff[0] = (uint32_t)b_exp.n; dump_rect(&b_exp, cb->y, cb->stride, x0, y0, w, h);
@@ -435,6 +456,7 @@ gen_mc(const char *dir)
         }
     }
 
+    if (g_shim) { shim_stream_write(dir, "shim_mc.ovg", &S, c, ref, 3); return; }
     gfile g = gfile_open(dir, "mc.ovg");
     uint32_t d3[3] = { 3, MC_H, MC_W };
     uint16_t *all = malloc(3 * MC_W * MC_H * 2);
@@ -495,6 +517,19 @@ gen_mcx(const char *dir)
         ic->scale_fact_rpl1[i][0] = ic->scale_fact_rpl1[i][1] = 1 << RPR_SCALE_BITS;
     }
     const struct OVBuffInfo *cb = &c->rcn_ctx.ctu_buff;
+    struct shim_stream S;
+    shim_stream_init(&S);
+    /* shim mode: a picture-level TMVP motion plane per list, as ovdpb_init_picture allocates them (mvpool.c), so that the
+     * write-back of the refined vectors can be checked against where the reference's caller + tmvp_store_mv put them */
+    struct MVPlane pl0, pl1;
+    const int nb_ctb_w = (MC_W + 127) / 128, nb_ctb_h = (MC_H + 127) / 128, pln_stride = 16 * nb_ctb_w;
+    if (g_shim) {
+        shim_bind(c, MC_W, MC_H, 0, 0);
+        memset(&pl0, 0, sizeof(pl0)); memset(&pl1, 0, sizeof(pl1));
+        pl0.mvs = calloc((size_t)pln_stride * 16 * nb_ctb_h, sizeof(OVMV)); pl1.mvs = calloc((size_t)pln_stride * 16 * nb_ctb_h, sizeof(OVMV));
+        ic->tmvp_ctx.plane0 = &pl0; ic->tmvp_ctx.plane1 = &pl1;
+        c->nb_ctb_pic_w = nb_ctb_w;
+    }
 
     for (int l2w = 3; l2w <= 6; ++l2w) {
         for (int l2h = 3; l2h <= 6; ++l2h) {
@@ -550,6 +585,48 @@ gen_mcx(const char *dir)
                     }
                 if (!(d.refine & OVHIP_PU_DMVR))
                     c->rcn_funcs.rcn_mcp_b_c(c, *cb, ic, c->part_ctx, mv0, mv1, x0, y0, l2w, l2h, 3, d.ref_idx0, d.ref_idx1);
+                if (g_shim) {
+                    if (d.refine & OVHIP_PU_DMVR) {
+                        /* vectors "from the device" for this case's units: a recognisable value per unit and component;
+                         * then every entry the reference's flow would have written must hold it, and no other entry */
+                        const int nu = (h >> l2sh) * (w >> l2sw);
+                        int32_t fake[64 * 4];
+                        for (int u = 0; u < nu; ++u) for (int k = 0; k < 4; ++k) fake[4 * u + k] = 100000 + (int32_t)n_cases * 1000 + u * 8 + k;
+                        memset(pl0.mvs, 0, (size_t)pln_stride * 16 * nb_ctb_h * sizeof(OVMV)); memset(pl1.mvs, 0, (size_t)pln_stride * 16 * nb_ctb_h * sizeof(OVMV));
+                        ovhip_shim_apply_refined_mvs(c, fake, 0, nu);
+                        int32_t checked = 0, bad = 0;
+                        static OVMV exp0[16 * 16], exp1[16 * 16];      /* the CTU-local tmvp_mv[] arrays of the caller */
+                        memset(exp0, 0, sizeof(exp0)); memset(exp1, 0, sizeof(exp1));
+                        for (int i = 0, u = 0; i < (h >> l2sh); ++i)
+                            for (int j = 0; j < (w >> l2sw); ++j, ++u) {
+                                /* vcl_coding_unit.c:2629-2645 */
+                                const int b = ((x0 + 7 + j * 16) >> 3) + ((y0 + 7 + i * 16) >> 3) * 16;
+                                for (int dy = 0; dy <= (l2sh > 3); ++dy) for (int dx = 0; dx <= (l2sw > 3); ++dx) {
+                                    if (((x0 + 7 + j * 16) >> 3) + dx > 15 || ((y0 + 7 + i * 16) >> 3) + dy > 15) continue;
+                                    exp0[b + dx + 16 * dy].x = fake[4 * u]; exp0[b + dx + 16 * dy].y = fake[4 * u + 1];
+                                    exp1[b + dx + 16 * dy].x = fake[4 * u + 2]; exp1[b + dx + 16 * dy].y = fake[4 * u + 3];
+                                }
+                            }
+                        /* tmvp_store_mv (drv_lines.c:270-330): row i of the CTU array -> plane->mvs + ctb_offset + i * pln_stride */
+                        const int ctb_off = (c->ctb_x + c->ctb_y * pln_stride) * 16;
+                        for (int py2 = 0; py2 < 16 * nb_ctb_h; ++py2)
+                            for (int px2 = 0; px2 < pln_stride; ++px2) {
+                                const int lx = px2 - c->ctb_x * 16, ly = py2 - c->ctb_y * 16;
+                                OVMV e0 = { 0 }, e1 = { 0 };
+                                if (lx >= 0 && lx < 16 && ly >= 0 && ly < 16) { e0 = exp0[lx + 16 * ly]; e1 = exp1[lx + 16 * ly]; }
+                                const OVMV *g0 = &pl0.mvs[py2 * pln_stride + px2], *g1 = &pl1.mvs[py2 * pln_stride + px2];
+                                (void)ctb_off;
+                                if (g0->x != e0.x || g0->y != e0.y || g1->x != e1.x || g1->y != e1.y) bad++;
+                                checked += e0.x != 0;
+                            }
+                        if (bad) { fprintf(stderr, "shim: refined-MV write-back differs from the reference's flow in %d entries (case %u)\n", bad, n_cases); exit(1); }
+                        gbuf_push(&S.mv_chk, &checked, 1);
+                    }
+                    shim_case_end(c, &S, "mcx");
+                    /* next case: fresh patch list, as a new picture would */
+                    extern void ovhip_shim_new_picture_for_test(OVCTUDec *);
+                    ovhip_shim_new_picture_for_test(c);
+                }
 
                 uint32_t eoff[4];
                 eoff[0] = (uint32_t)b_exp.n; dump_rect(&b_exp, cb->y, cb->stride, x0, y0, w, h);
@@ -563,6 +640,7 @@ gen_mcx(const char *dir)
         }
     }
 
+    if (g_shim) { shim_stream_write(dir, "shim_mcx.ovg", &S, c, ref, 3); return; }
     gfile g = gfile_open(dir, "mcx.ovg");
     uint32_t d3[3] = { 3, MC_H, MC_W };
     uint16_t *all = malloc(3 * MC_W * MC_H * 2);
@@ -610,6 +688,9 @@ gen_mca(const char *dir)
     }
     ic->prec_amvr = 0;                                        /* drv_affine_mvp.c:3508 */
     const struct OVBuffInfo *cb = &c->rcn_ctx.ctu_buff;
+    struct shim_stream S;
+    shim_stream_init(&S);
+    if (g_shim) shim_bind(c, MC_W, MC_H, 0, 0);
 
     for (int l2w = 3; l2w <= 6; ++l2w) {
         for (int l2h = 3; l2h <= 6; ++l2h) {
@@ -684,6 +765,7 @@ gen_mca(const char *dir)
                         mv1.x += mv1.x < 0; mv1.y += mv1.y < 0; mv1.x >>= 1; mv1.y >>= 1;
                         c->rcn_funcs.rcn_mcp_b_c(c, *cb, ic, c->part_ctx, mv0, mv1, x0 + 4 * i, y0 + 4 * j, 3, 3, d.inter_dir, ri0, ri1);
                     }
+                if (g_shim) shim_case_end(c, &S, "mca");
 
                 uint32_t eoff[4];
                 eoff[0] = (uint32_t)b_exp.n; dump_rect(&b_exp, cb->y, cb->stride, x0, y0, w, h);
@@ -700,6 +782,7 @@ gen_mca(const char *dir)
         }
     }
 
+    if (g_shim) { shim_stream_write(dir, "shim_mca.ovg", &S, c, ref, 3); return; }
     gfile g = gfile_open(dir, "mca.ovg");
     uint32_t d3[3] = { 3, MC_H, MC_W };
     uint16_t *all = malloc(3 * MC_W * MC_H * 2);
@@ -734,6 +817,10 @@ gen_lmcs(const char *dir)
     g_seed = 0x266 + 111;
     OVCTUDec *c = ref_new_ctudec(0, 1);
     const struct OVBuffInfo *cb = &c->rcn_ctx.ctu_buff;
+    struct shim_stream S;
+    shim_stream_init(&S);
+    gbuf s_luts = { .type = T_U8 };
+    if (g_shim) shim_bind(c, LM_W, LM_H, 0, 1);
     uint16_t *pic = malloc(LM_W * LM_H * 2);
     fill_plane(pic, LM_W, LM_H, LM_W);
     int n_sets = 0;
@@ -755,6 +842,7 @@ gen_lmcs(const char *dir)
         struct LMCSInfo *li = &c->lmcs_info;
         if (!li->luts) li->luts = calloc(1, sizeof(struct LMCSLUTs));   /* keeps rcn_init_lmcs off ov_malloc (ovmem.c is not built) */
         c->rcn_funcs.rcn_init_lmcs(li, &ld);
+        if (g_shim) gbuf_push(&s_luts, ovhip_shim_lmcs(c), sizeof(ovhip_lmcs_luts));
 
         ovhip_lmcs_data hd;
         memset(&hd, 0, sizeof(hd));
@@ -789,7 +877,9 @@ gen_lmcs(const char *dir)
                 pf.hfield[y0 >> 2] = am << ((x0 >> 2) + 1);
                 pf.vfield[x0 >> 2] = lm << ((y0 >> 2) + 1);
                 li->lmcs_chroma_scale = 0;
+                c->ctb_x = ctb; c->ctb_y = 0;
                 c->rcn_funcs.rcn_lmcs_compute_chroma_scale(li, cb->stride, &pf, cb->y, x0, y0);
+                if (g_shim) shim_case_end(c, &S, "lmcs region");
                 int32_t rec[6] = { set, ctb * 128 + x0, y0, (int32_t)am, (int32_t)lm, li->lmcs_chroma_scale };
                 gbuf_push(&b_reg, rec, 6);
             }
@@ -805,6 +895,16 @@ gen_lmcs(const char *dir)
         n_sets++;
     }
 
+    if (g_shim) {
+        gfile gs = gfile_open(dir, "shim_lmcs.ovg");
+        uint32_t ds[2] = { (uint32_t)n_sets, sizeof(ovhip_lmcs_luts) };
+        gfile_array(&gs, "luts", T_U8, s_luts.data, 2, ds);
+        ds[0] = (uint32_t)(S.arr[OVHIP_REC_REGION].n / sizeof(ovhip_lmcs_region)); ds[1] = sizeof(ovhip_lmcs_region);
+        gfile_array(&gs, "region", T_U8, S.arr[OVHIP_REC_REGION].data, 2, ds);
+        gfile_close(&gs);
+        fprintf(stderr, "shim_lmcs.ovg: %d table sets, %u regions\n", n_sets, ds[0]);
+        return;
+    }
     gfile g = gfile_open(dir, "lmcs.ovg");
     uint32_t d2[2] = { LM_H, LM_W };
     gfile_array(&g, "pic_y", T_U16, pic, 2, d2);
@@ -872,6 +972,9 @@ gen_gpm(const char *dir)
     c->rcn_funcs.intra_pred_c = stub_ciip_intra_c;
     c->part_map.cu_mode_x = calloc(64, 1);
     const struct OVBuffInfo *cb = &c->rcn_ctx.ctu_buff;
+    struct shim_stream S;
+    shim_stream_init(&S);
+    if (g_shim) shim_bind(c, MC_W, MC_H, 0, 0);
 
     for (int pass = 0; pass < 2; ++pass) {                                /* 0: GPM, 1: CIIP */
         int n_iter = pass == 0 ? 64 * 3 : 150;
@@ -929,6 +1032,7 @@ gen_gpm(const char *dir)
                 else
                     c->rcn_funcs.rcn_ciip_b(c, mv0, mv1, x0, y0, l2w, l2h, d.inter_dir, d.ref_idx0, d.ref_idx1);
             }
+            if (g_shim) shim_case_end(c, &S, "gpm / ciip");
             uint32_t eoff[3];
             eoff[0] = (uint32_t)b_exp.n; dump_rect(&b_exp, cb->y, cb->stride, x0, y0, w, h);
             eoff[1] = (uint32_t)b_exp.n; dump_rect(&b_exp, cb->cb, cb->stride_c, x0 >> 1, y0 >> 1, w >> 1, h >> 1);
@@ -940,6 +1044,7 @@ gen_gpm(const char *dir)
         }
     }
 
+    if (g_shim) { shim_stream_write(dir, "shim_gpm.ovg", &S, c, ref, 3); return; }
     gfile g = gfile_open(dir, "gpm.ovg");
     uint32_t d3[3] = { 3, MC_H, MC_W };
     uint16_t *all = malloc(3 * MC_W * MC_H * 2);
@@ -1101,7 +1206,7 @@ gen_dbf(const char *dir)
 {
     enum { NPIC = 3 };
     static const int PW[NPIC] = { 304, 264, 256 }, PH[NPIC] = { 200, 136, 192 };     /* picture 2: B slice, motion-derived bS */
-    gfile g = gfile_open(dir, "dbf.ovg");
+    gfile g = gfile_open(dir, g_shim ? "shim_dbf.ovg" : "dbf.ovg");
     g_seed = 0x266 + 2;
     for (int pi = 0; pi < NPIC; ++pi) {
         const int W = PW[pi], H = PH[pi], nx = (W + 127) / 128, ny = (H + 127) / 128;
@@ -1114,6 +1219,7 @@ gen_dbf(const char *dir)
         for (int j = 1; j < H / 2; ++j) for (int i = 0; i < W / 2; ++i) { cb[j * (W / 2) + i] = (cb[j * (W / 2) + i] + 3 * cb[(j - 1) * (W / 2) + i] + 2) >> 2; cr[j * (W / 2) + i] = (cr[j * (W / 2) + i] + 3 * cr[(j - 1) * (W / 2) + i] + 2) >> 2; }
 
         OVCTUDec *c = ref_new_ctudec(0, 0);
+        if (g_shim) shim_bind(c, W, H, 0, 0);
         struct DBFInfo *d = &c->dbf_info;
         const int bmode = pi == 2;
         c->tmp_slice_type = bmode ? 0 : 2;     /* I: the MV-based bS pre-pass is emulated by gen_cu(); B: rcn_dbf_ctu derives it */
@@ -1170,6 +1276,7 @@ gen_dbf(const char *dir)
                     gen_part(&gg, 0, 0, 128, 128, ctu_w, ctu_h);
                     if (pass) {
                         c->ctu_ngh_flags = (cx ? CTU_LFT_FLG : 0) | (cy ? CTU_UP_FLG : 0);
+                        c->ctb_x = cx; c->ctb_y = cy;
                         c->rcn_ctx.frame_buff.y = y + cy * 128 * W + cx * 128;
                         c->rcn_ctx.frame_buff.cb = cb + cy * 64 * (W / 2) + cx * 64;
                         c->rcn_ctx.frame_buff.cr = cr + cy * 64 * (W / 2) + cx * 64;
@@ -1208,6 +1315,21 @@ gen_dbf(const char *dir)
         }
         /* pass 0 painted y0; pass 1 painted y identically then filtered it */
         char nm[32];
+        if (g_shim) {
+            /* what the installed df.rcn_dbf_ctu / rcn_dbf_truncated_ctu slots recorded for the whole picture */
+            if (ovhip_shim_last_error(c)) { fprintf(stderr, "shim: dbf picture %d latched %d\n", pi, ovhip_shim_last_error(c)); exit(1); }
+            ovhip_recorder *r = ovhip_shim_recorder(c);
+            ovhip_dbf_offsets offs;
+            for (int dir2 = 0; dir2 < 2; ++dir2) {
+                size_t ne = 0;
+                const ovhip_dbf_edge *ed = ovhip_rec_dbf_edges(r, dir2, &ne, &offs);
+                uint32_t de[2] = { (uint32_t)ne, sizeof(ovhip_dbf_edge) };
+                snprintf(nm, 32, "p%d_edges_%c", pi, dir2 ? 'h' : 'v'); gfile_array(&g, nm, T_U8, ne ? (const void *)ed : (const void *)"", 2, de);
+            }
+            uint32_t dof = sizeof(offs);
+            snprintf(nm, 32, "p%d_offsets", pi); gfile_array(&g, nm, T_I8, &offs, 1, &dof);
+            continue;
+        }
         uint32_t d2[2] = { H, W };
         snprintf(nm, 32, "p%d_in_y", pi); gfile_array(&g, nm, T_U16, y0, 2, d2);
         snprintf(nm, 32, "p%d_exp_y", pi); gfile_array(&g, nm, T_U16, y, 2, d2);
@@ -1266,7 +1388,7 @@ gen_sao(const char *dir)
 {
     enum { NPIC = 3 };
     static const int PW[NPIC] = { 304, 264, 136 }, PH[NPIC] = { 200, 264, 72 };
-    gfile g = gfile_open(dir, "sao.ovg");
+    gfile g = gfile_open(dir, g_shim ? "shim_sao.ovg" : "sao.ovg");
     g_seed = 0x266 + 3;
     for (int pi = 0; pi < NPIC; ++pi) {
         const int W = PW[pi], H = PH[pi], nx = (W + 127) / 128, ny = (H + 127) / 128;
@@ -1276,12 +1398,15 @@ gen_sao(const char *dir)
         for (int i = 0; i < W * H; i += 11) py[i] = (uint16_t)rnd_range(0, 1023);
         char nm[32];
         uint32_t d2[2] = { H, W };
+        if (!g_shim) {
         snprintf(nm, 32, "p%d_in_y", pi); gfile_array(&g, nm, T_U16, f->data[0], 2, d2);
         d2[0] = H / 2; d2[1] = W / 2;
         snprintf(nm, 32, "p%d_in_cb", pi); gfile_array(&g, nm, T_U16, f->data[1], 2, d2);
         snprintf(nm, 32, "p%d_in_cr", pi); gfile_array(&g, nm, T_U16, f->data[2], 2, d2);
+        }
 
         OVCTUDec *c = ref_new_ctudec(0, 0);
+        if (g_shim) shim_bind(c, W, H, 0, 0);
         c->pic_w = W; c->pic_h = H;
         c->rcn_ctx.frame_start = f;
         harness_alloc_filter_buffers(&c->rcn_ctx, nx, 3, 7);
@@ -1317,6 +1442,14 @@ gen_sao(const char *dir)
             } else {
                 c->rcn_funcs.sao.rcn_sao_filter_line(c, &einfo, cy - 1);
             }
+        }
+        if (g_shim) {
+            size_t nc = 0;
+            const ovhip_sao_ctu *sp = ovhip_shim_sao_params(c, &nc);
+            if (!sp || nc != (size_t)(nx * ny) || ovhip_shim_last_error(c)) { fprintf(stderr, "shim: sao picture %d: no parameters captured\n", pi); exit(1); }
+            d2[0] = nx * ny; d2[1] = sizeof(ovhip_sao_ctu);
+            snprintf(nm, 32, "p%d_params", pi); gfile_array(&g, nm, T_U8, sp, 2, d2);
+            continue;
         }
         d2[0] = H; d2[1] = W;
         snprintf(nm, 32, "p%d_exp_y", pi); gfile_array(&g, nm, T_U16, f->data[0], 2, d2);
@@ -1363,7 +1496,7 @@ gen_alf(const char *dir)
 {
     enum { NPIC = 3 };
     static const int PW[NPIC] = { 304, 264, 136 }, PH[NPIC] = { 200, 256, 72 };
-    gfile g = gfile_open(dir, "alf.ovg");
+    gfile g = gfile_open(dir, g_shim ? "shim_alf.ovg" : "alf.ovg");
     g_seed = 0x266 + 4;
     for (int pi = 0; pi < NPIC; ++pi) {
         const int W = PW[pi], H = PH[pi], nx = (W + 127) / 128, ny = (H + 127) / 128;
@@ -1372,12 +1505,15 @@ gen_alf(const char *dir)
         for (int i = 0; i < W * H; i += 13) py[i] = (uint16_t)rnd_range(0, 1023);
         char nm[32];
         uint32_t d2[2] = { H, W };
+        if (!g_shim) {
         snprintf(nm, 32, "p%d_in_y", pi); gfile_array(&g, nm, T_U16, f->data[0], 2, d2);
         d2[0] = H / 2; d2[1] = W / 2;
         snprintf(nm, 32, "p%d_in_cb", pi); gfile_array(&g, nm, T_U16, f->data[1], 2, d2);
         snprintf(nm, 32, "p%d_in_cr", pi); gfile_array(&g, nm, T_U16, f->data[2], 2, d2);
+        }
 
         OVCTUDec *c = ref_new_ctudec(0, 0);
+        if (g_shim) shim_bind(c, W, H, 0, 0);
         c->pic_w = W; c->pic_h = H;
         c->rcn_ctx.frame_start = f;
         harness_alloc_filter_buffers(&c->rcn_ctx, nx, 3, 7);
@@ -1410,6 +1546,20 @@ gen_alf(const char *dir)
         einfo.nb_ctu_w = nx; einfo.nb_ctu_h = ny;
         for (int cy = 0; cy < ny; ++cy) { c->ctb_y = cy; c->rcn_funcs.alf.rcn_alf_filter_line(c, &einfo, cy); }
 
+        if (g_shim) {
+            size_t nc = 0, nt = 0;
+            const ovhip_alf_ctu *ap = ovhip_shim_alf_params(c, &nc);
+            if (!ap || nc != (size_t)(nx * ny) || ovhip_shim_last_error(c)) { fprintf(stderr, "shim: alf picture %d: no parameters captured\n", pi); exit(1); }
+            d2[0] = nx * ny; d2[1] = sizeof(ovhip_alf_ctu);
+            snprintf(nm, 32, "p%d_ctus", pi); gfile_array(&g, nm, T_U8, ap, 2, d2);
+            static const char *tn[5] = { "luma_coeff", "luma_clip", "chroma_coeff", "chroma_clip", "cc_coeff" };
+            for (int t = 0; t < 5; ++t) {
+                const int16_t *tp = ovhip_shim_alf_table(c, t, &nt);
+                uint32_t dt = (uint32_t)nt;
+                snprintf(nm, 32, "p%d_%s", pi, tn[t]); gfile_array(&g, nm, T_I16, tp, 1, &dt);
+            }
+            continue;
+        }
         d2[0] = H; d2[1] = W;
         snprintf(nm, 32, "p%d_exp_y", pi); gfile_array(&g, nm, T_U16, f->data[0], 2, d2);
         d2[0] = H / 2; d2[1] = W / 2;
@@ -1438,6 +1588,7 @@ main(int argc, char **argv)
 {
     const char *dir = argc > 1 ? argv[1] : "../tests/golden";
     const char *only = argc > 2 ? argv[2] : NULL;
+    if (only && !strcmp(only, "shim")) { g_shim = 1; only = argc > 3 ? argv[3] : NULL; }
     if (!only || !strcmp(only, "itx")) gen_itx(dir);
     if (!only || !strcmp(only, "mc"))  gen_mc(dir);
     if (!only || !strcmp(only, "mcx")) gen_mcx(dir);

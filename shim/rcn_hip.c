@@ -1,0 +1,1159 @@
+/* rcn_hip.c -- MI355X override block for OpenVVC's struct RCNFunctions (see rcn_hip.h).
+ *
+ * Compiled with the reference's OWN headers (-I$(REF)/libovvc -DBITDEPTH=10), exactly like the x86 / ARM back-ends
+ * (libovvc/x86/rcn_*_sse.c include ctudec.h + rcn_structures.h), and linked against libovvc_hip.so
+ * (include/ovvc_hip.h).  Nothing of the reference is copied: every hook snapshots the OVCTUDec fields its scalar
+ * counterpart reads implicitly into the descriptors of include/ovvc_hip.h and performs the
+ * host-side bookkeeping that counterpart also does for the REST of the decoder (deblocking edge / bS maps, progress
+ * bit-fields), which later slots and the parse loop depend on.
+ *
+ * Call order the hooks rely on (slicedec.c:1299-1336, :815-975):
+ *   rcn_attach_frame_buff -> per CTU { coding_tree -> prediction / transform slots ; rcn_write_ctu_to_frame ;
+ *   lmcs_reshape_backward ; df.rcn_dbf_ctu } -> per CTU row { sao lines ; alf.rcn_alf_filter_line } -> publish row.
+ */
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "ovdefs.h"
+#include "ovframe.h"
+#include "ovdpb.h"
+#include "dec_structures.h"
+#include "ctudec.h"
+#include "rcn_structures.h"
+#include "rcn.h"
+#include "drv.h"
+#include "drv_utils.h"
+#include "dbf_utils.h"
+#include "slicedec.h"
+#include "nvcl_structures.h"
+#include "ovlog.h"
+
+#include "ovvc_hip.h"
+#include "rcn_hip.h"
+
+#ifndef BITDEPTH
+#error "compile with -DBITDEPTH=10 (the table's sample type is a compile-time macro, bitdepth.h:36-40)"
+#endif
+
+/* ------------------------------------------------------------------------------------ ABI check
+ * The table is embedded by value in OVCTUDec; a back-end compiled against another layout would scribble over the
+ * decoder.  Measured on the reference: 744 pointer-sized slots. */
+_Static_assert(sizeof(void *) == 8, "LP64 only");
+_Static_assert(sizeof(struct RCNFunctions) == 5952, "struct RCNFunctions layout changed: re-check every override below");
+_Static_assert(offsetof(struct RCNFunctions, mc_l) == 0, "mc_l is the first member");
+_Static_assert(offsetof(struct RCNFunctions, rcn_gpm_b) == 5952 - 3 * sizeof(void *), "rcn_gpm_b, rcn_ibc_l, rcn_ibc_c close the table");
+_Static_assert(offsetof(struct RCNFunctions, rcn_dmvr_mv_refine) + 12 * sizeof(void *) == 5952, "12 prediction slots at the end");
+_Static_assert(offsetof(struct RCNFunctions, tmp) + sizeof(struct TMPBDCompat) + 4 * sizeof(void *) == offsetof(struct RCNFunctions, rcn_update_ctu_border),
+               "tmp (dequant + transform-tree orchestrators) is followed by the four intra_pred* slots");
+_Static_assert(sizeof(OVMV) == 12 && offsetof(OVMV, y) == 4 && offsetof(OVMV, ref_idx) == 8, "OVMV layout (ovhip_dbf_mv_ctx.mv_bytes)");
+_Static_assert(sizeof(((struct DBFInfo *)0)->ctb_bound_ver) == sizeof(((ovhip_dbf_ctu *)0)->ctb_bound_ver), "DBFInfo edge maps");
+_Static_assert(sizeof(struct DBFQPMap) == sizeof(((ovhip_dbf_ctu *)0)->qp_y), "DBFInfo QP maps");
+_Static_assert(sizeof(struct DBFMap) == 2 * 33 * sizeof(uint64_t), "DBFMap = ver[33] + hor[33]");
+
+/* struct TUInfo / struct PROFInfo are private to the reference's .c files (rcn_transform_tree.c:51-66 and
+ * vcl_transform_unit.c:47-75; drv_affine_mvp.c:3303-3308 and rcn_inter.c:1128-1134): the slot prototypes only
+ * forward-declare them, a back-end has to restate the layout. */
+struct TBInfo { uint16_t last_pos; uint64_t sig_sb_map; };
+struct TUInfo {
+    uint8_t is_sbt; uint8_t cbf_mask; uint16_t pos_offset; uint8_t tr_skip_mask;
+    uint8_t cu_mts_flag; uint8_t cu_mts_idx; uint8_t lfnst_flag; uint8_t lfnst_idx;
+    struct TBInfo tb_info[3];
+};
+struct PROFInfo { int16_t dmv_scale_h_0[16], dmv_scale_v_0[16], dmv_scale_h_1[16], dmv_scale_v_1[16]; };
+
+extern uint64_t residual_coding_dpq(OVCTUDec *const, int16_t *const, uint8_t, uint8_t, uint16_t);
+extern int transform_unit_st(OVCTUDec *const, unsigned int, unsigned int, unsigned int, unsigned int, uint8_t, CUFlags, uint8_t, struct TUInfo *const);
+extern int transform_unit_l(OVCTUDec *const, unsigned int, unsigned int, unsigned int, unsigned int, uint8_t, CUFlags, uint8_t, struct TUInfo *const);
+extern int transform_unit_c(OVCTUDec *const, unsigned int, unsigned int, unsigned int, unsigned int, uint8_t, CUFlags, uint8_t, struct TUInfo *const);
+
+#ifndef LOG2_MIN_CU_S
+#define LOG2_MIN_CU_S 2                             /* rcn_transform_tree.c:45 */
+#endif
+#define MV_POS(xu, yu) (35 + (xu) + (yu) * 34)          /* PB_POS_IN_BUF, rcn_df.c:1524 */
+
+/* ------------------------------------------------------------------------------------ side table */
+enum { PEND_NONE = 0, PEND_AFFINE, PEND_BDOF };
+
+struct dmvr_patch { OVMV *dst0[4], *dst1[4]; uint8_t n; };
+
+struct hip_entry {
+    const OVCTUDec *key;
+    struct RCNFunctions scalar;          /* the table as the scalar fill left it */
+    uint8_t ict_type, lmcs_flag;
+    ovhip_recorder *rec;                 /* job's recorder, or the bound one in record-only mode */
+    int record_only;
+    ovhip_ctx *ctx; ovhip_job *job;
+    int pic_w, pic_h, log2_ctu, nb_ctu_w, nb_ctu_h;
+    const OVFrame *frame;                /* picture being decoded */
+    int err;
+    const OVPicture *refs[16]; int n_refs;
+    ovhip_lmcs_luts luts; int have_luts, lmcs_region_live;
+    ovhip_sao_ctu *sao; ovhip_alf_ctu *alf; size_t n_ctu; int sao_on, alf_on;
+    int16_t alf_cc[2][4][8];
+    struct dmvr_patch *patch; size_t n_patch, cap_patch;     /* one per refined unit recorded (n == 0: not a DMVR unit) */
+    size_t dmvr_done;                    /* refined units whose vectors are already applied */
+    /* prediction calls being collected into one CU */
+    struct {
+        int kind, x0, y0, n, cols, rows_done, cur_col;
+        uint8_t inter_dir, prof_dir, bcw, ref_idx0, ref_idx1;
+        int32_t mv0[32 * 32 * 2], mv1[32 * 32 * 2];       /* affine: sub-block field, row stride 32 */
+        struct PROFInfo prof;
+        OVMV bmv0, bmv1; int bx[64], by[64], bl2w, bl2h;  /* BDOF blocks */
+    } pend;
+    /* the luma of an affine CU has been recorded (with its chroma): the rcn_mcp_b_c(3,3) calls of the SAME CU that follow
+     * carry nothing new.  Rectangle in CTU-local luma samples; any other slot call ends it. */
+    int aff_c_live, aff_c_x0, aff_c_y0, aff_c_x1, aff_c_y1;
+};
+
+static struct hip_entry *g_entries[256];
+static pthread_mutex_t g_mtx = PTHREAD_MUTEX_INITIALIZER;
+
+static struct hip_entry *
+entry_of(const OVCTUDec *c, int create)
+{
+    struct hip_entry *e = NULL;
+    int free_slot = -1;
+    pthread_mutex_lock(&g_mtx);
+    for (int i = 0; i < 256; ++i) {
+        if (g_entries[i] && g_entries[i]->key == c) { e = g_entries[i]; break; }
+        if (!g_entries[i] && free_slot < 0) free_slot = i;
+    }
+    if (!e && create && free_slot >= 0) {
+        e = calloc(1, sizeof(*e));
+        if (e) { e->key = c; g_entries[free_slot] = e; }
+    }
+    pthread_mutex_unlock(&g_mtx);
+    return e;
+}
+
+static void
+latch(struct hip_entry *e, int code, const char *what)
+{
+    if (code >= 0 || e->err) return;
+    e->err = code;
+    ov_log(NULL, OVLOG_ERROR, "rcn_hip: %s failed (%d)%s%s\n", what, code, e->ctx ? ": " : "", e->ctx ? ovhip_last_error(e->ctx) : "");
+}
+
+static inline OVCTUDec *ctudec_of_lmcs(struct LMCSInfo *li) { return (OVCTUDec *)((char *)li - offsetof(OVCTUDec, lmcs_info)); }
+
+/* ------------------------------------------------------------------------------------ helpers */
+static int
+ref_slot(struct hip_entry *e, const OVPicture *p)
+{
+    for (int i = 0; i < e->n_refs; ++i) if (e->refs[i] == p) return i;
+    if (e->n_refs >= 16) { latch(e, OVHIP_EUNSUP, "more than 16 distinct reference pictures"); return 0; }
+    e->refs[e->n_refs] = p;
+    return e->n_refs++;
+}
+
+static void
+fill_pu(struct hip_entry *e, const OVCTUDec *c, ovhip_pu_desc *d, int x0, int y0, int log2_w, int log2_h, int inter_dir,
+        OVMV mv0, OVMV mv1, const OVPicture *p0, const OVPicture *p1)
+{
+    const struct InterDRVCtx *ic = &c->drv_ctx.inter_ctx;
+    const int l2 = c->part_ctx->log2_ctu_s;
+    memset(d, 0, sizeof(*d));
+    d->x0 = (uint16_t)((c->ctb_x << l2) + x0); d->y0 = (uint16_t)((c->ctb_y << l2) + y0);
+    d->log2_w = (uint8_t)log2_w; d->log2_h = (uint8_t)log2_h;
+    d->inter_dir = (uint8_t)inter_dir;
+    d->ref_idx0 = (uint8_t)mv0.ref_idx; d->ref_idx1 = (uint8_t)mv1.ref_idx;
+    d->bcw_idx_plus1 = mv0.bcw_idx_plus1;
+    d->prec_amvr_half = ic->prec_amvr == MV_PRECISION_HALF;
+    d->planes = 3;
+    d->lmcs = c->lmcs_info.lmcs_enabled_flag;
+    d->mv0x = mv0.x; d->mv0y = mv0.y; d->mv1x = mv1.x; d->mv1y = mv1.y;
+    if (p0 && (inter_dir & 1)) { d->poc0 = p0->poc; d->ref0 = (uint8_t)ref_slot(e, p0); }
+    if (p1 && (inter_dir & 2)) { d->poc1 = p1->poc; d->ref1 = (uint8_t)ref_slot(e, p1); }
+    if (inter_dir == 1) { d->ref1 = d->ref0; d->poc1 = d->poc0 + 1; }      /* keep the identical-motion test off */
+    if (inter_dir == 2) { d->ref0 = d->ref1; d->poc0 = d->poc1 + 1; }
+}
+
+static void pend_close(struct hip_entry *e, OVCTUDec *c);
+
+/* every hook that is not part of the CU being collected closes it first */
+#define ENTER(c)                                               \
+    struct hip_entry *e = entry_of((c), 0);                    \
+    if (!e || !e->rec) return;                                 \
+    e->aff_c_live = 0;                                         \
+    if (e->pend.kind) pend_close(e, (OVCTUDec *)(c))
+
+/* ------------------------------------------------------------------------------------ transform units */
+static void
+fill_tu_state(const struct hip_entry *e, const OVCTUDec *c, ovhip_tu_state *st)
+{
+    memset(st, 0, sizeof(*st));
+    st->qp_y = c->dequant_luma.qp; st->qp_cb = c->dequant_cb.qp; st->qp_cr = c->dequant_cr.qp;
+    st->qp_jcbcr = c->dequant_joint_cb_cr.qp;
+    st->qp_y_skip = c->dequant_luma_skip.qp; st->qp_cb_skip = c->dequant_cb_skip.qp;
+    st->qp_cr_skip = c->dequant_cr_skip.qp; st->qp_jcbcr_skip = c->dequant_jcbcr_skip.qp;
+    st->dep_quant = c->residual_coding_l == &residual_coding_dpq;          /* rcn_transform_tree.c:399 */
+    st->mts_implicit = c->mts_implicit;
+    st->sh_ts_disabled = c->sh_ts_disabled;
+    st->ict_type = e->ict_type;
+    /* scale derived on the device from the region the last rcn_lmcs_compute_chroma_scale call recorded */
+    st->lmcs_scale_c = c->lmcs_info.scale_c_flag ? (e->lmcs_region_live ? 2 : 1) : 0;
+    st->lmcs_chroma_scale = (int16_t)c->lmcs_info.lmcs_chroma_scale;
+    st->intra_mode = (int8_t)c->intra_mode;
+}
+
+/* derive_lfnst_mode_c (drv_lfnst.c:94-121): DM / LM chroma modes take the co-located luma mode; then the wide-angle
+ * remap of the CHROMA block shape */
+static int8_t
+lfnst_mode_c(const OVCTUDec *c, int log2_w, int log2_h, int x0, int y0)
+{
+    static const uint8_t shift_lut[6] = { 0, 6, 10, 12, 14, 15 };
+    const int l2 = c->part_ctx_c->log2_min_cb_s;
+    const int xu = x0 >> l2, yu = y0 >> l2, nw = (1 << log2_w) >> l2, nh = (1 << log2_h) >> l2;
+    int m = c->intra_mode_c;
+    if (m == OVINTRA_DM_CHROMA || (m >= OVINTRA_LM_CHROMA && m <= OVINTRA_MDLM_TOP))
+        m = c->drv_ctx.intra_info.luma_modes[xu + ((yu + (nh >> 1)) << 5) + (nw >> 1)];
+    if (m > OVINTRA_DC) {
+        const int d = log2_w - log2_h, ms = shift_lut[d < 0 ? -d : d];
+        if (log2_w > log2_h && m < 2 + ms) m += OVINTRA_VDIA - 1;
+        else if (log2_h > log2_w && m > OVINTRA_VDIA - ms) m -= OVINTRA_VDIA + 1;
+    }
+    return (int8_t)(m < 0 ? m + 14 + 67 : m >= 67 ? m + 14 : m);
+}
+
+static void
+record_tu(struct hip_entry *e, OVCTUDec *c, int tree, int x0, int y0, int log2_w, int log2_h, CUFlags cu_flags, uint8_t cbf_mask,
+          const struct TUInfo *tu)
+{
+    const int l2 = c->part_ctx->log2_ctu_s;
+    ovhip_tu_state st;
+    ovhip_tu_desc d;
+    fill_tu_state(e, c, &st);
+    memset(&d, 0, sizeof(d));
+    /* tree 2 (rcn_tu_c): x0, y0 and the size are in chroma samples; the picture offset likewise */
+    d.x0 = (uint16_t)(((c->ctb_x << l2) >> (tree == 2)) + x0); d.y0 = (uint16_t)(((c->ctb_y << l2) >> (tree == 2)) + y0);
+    d.log2_tb_w = (uint8_t)log2_w; d.log2_tb_h = (uint8_t)log2_h; d.tree = (uint8_t)tree;
+    d.cbf_mask = cbf_mask; d.cu_flags = (uint16_t)cu_flags;
+    d.tr_skip_mask = tu->tr_skip_mask; d.cu_mts_flag = tu->cu_mts_flag; d.cu_mts_idx = tu->cu_mts_idx;
+    d.lfnst_flag = tu->lfnst_flag; d.lfnst_idx = tu->lfnst_idx;
+    for (int k = 0; k < 3; ++k) { d.last_pos[k] = tu->tb_info[k].last_pos; d.sig_sb_map[k] = tu->tb_info[k].sig_sb_map; }
+    d.coef[0] = c->residual_cb + tu->pos_offset; d.coef[1] = c->residual_cr + tu->pos_offset; d.coef[2] = c->residual_y + tu->pos_offset;
+    if (tree == 2 && tu->lfnst_flag) st.lfnst_mode_c = lfnst_mode_c(c, log2_w, log2_h, x0, y0);
+    latch(e, ovhip_rec_tu(e->rec, &st, &d), "ovhip_rec_tu");
+}
+
+/* tmp.rcn_tu_st (rcn_structures.h:481-486; rcn_transform_tree.c:1228-1301) */
+static void
+hip_rcn_tu_st(OVCTUDec *const c, uint8_t x0, uint8_t y0, uint8_t log2_tb_w, uint8_t log2_tb_h, CUFlags cu_flags, uint8_t cbf_mask,
+              const struct TUInfo *const tu)
+{
+    ENTER(c);
+    record_tu(e, c, 0, x0, y0, log2_tb_w, log2_tb_h, cu_flags, cbf_mask, tu);
+    /* what the scalar orchestrator leaves behind for deblocking (:1262-1267, :1299-1300; rcn_res_c / rcn_jcbcr
+     * :757-759, :793-795, :860-866) */
+    if (cbf_mask & 0x10) fill_bs_map(&c->dbf_info.bs1_map, x0, y0, log2_tb_w, log2_tb_h);
+    if (!(cu_flags & flg_intra_bdpcm_chroma_flag)) {
+        if (cbf_mask & 0x8) {
+            fill_bs_map(&c->dbf_info.bs1_map_cb, x0, y0, log2_tb_w, log2_tb_h);
+            fill_bs_map(&c->dbf_info.bs1_map_cr, x0, y0, log2_tb_w, log2_tb_h);
+        } else {
+            if (cbf_mask & 0x2) fill_bs_map(&c->dbf_info.bs1_map_cb, x0, y0, log2_tb_w, log2_tb_h);
+            if (cbf_mask & 0x1) fill_bs_map(&c->dbf_info.bs1_map_cr, x0, y0, log2_tb_w, log2_tb_h);
+        }
+    }
+    fill_ctb_bound(&c->dbf_info, x0, y0, log2_tb_w, log2_tb_h);
+    fill_ctb_bound_c(&c->dbf_info, x0, y0, log2_tb_w, log2_tb_h);
+}
+
+/* tmp.rcn_tu_c (rcn_structures.h:475-479; rcn_transform_tree.c:1349-1382): dual-tree chroma, always intra */
+static void
+hip_rcn_tu_c(OVCTUDec *const c, uint8_t x0, uint8_t y0, uint8_t log2_tb_w, uint8_t log2_tb_h, CUFlags cu_flags, uint8_t cbf_mask,
+             const struct TUInfo *const tu)
+{
+    ENTER(c);
+    ctu_field_set_rect_bitfield(&c->rcn_ctx.progress_field_c, (x0 << 1) >> LOG2_MIN_CU_S, (y0 << 1) >> LOG2_MIN_CU_S,
+                                (2 << log2_tb_w) >> LOG2_MIN_CU_S, (2 << log2_tb_h) >> LOG2_MIN_CU_S);
+    fill_ctb_bound_c(&c->dbf_info, x0 << 1, y0 << 1, log2_tb_w + 1, log2_tb_h + 1);
+    if (!(cu_flags & flg_intra_bdpcm_chroma_flag)) fill_bs_map(&c->dbf_info.bs2_map_c, x0 << 1, y0 << 1, log2_tb_w + 1, log2_tb_h + 1);
+    record_tu(e, c, 2, x0, y0, log2_tb_w, log2_tb_h, cu_flags, cbf_mask, tu);
+    if (!(cu_flags & flg_intra_bdpcm_chroma_flag)) {
+        if (cbf_mask & 0x8) {
+            fill_bs_map(&c->dbf_info.bs1_map_cb, x0 << 1, y0 << 1, log2_tb_w + 1, log2_tb_h + 1);
+            fill_bs_map(&c->dbf_info.bs1_map_cr, x0 << 1, y0 << 1, log2_tb_w + 1, log2_tb_h + 1);
+        } else {
+            if (cbf_mask & 0x2) fill_bs_map(&c->dbf_info.bs1_map_cb, x0 << 1, y0 << 1, log2_tb_w + 1, log2_tb_h + 1);
+            if (cbf_mask & 0x1) fill_bs_map(&c->dbf_info.bs1_map_cr, x0 << 1, y0 << 1, log2_tb_w + 1, log2_tb_h + 1);
+        }
+    }
+}
+
+/* tmp.rcn_transform_tree (rcn_structures.h:464-468; rcn_transform_tree.c:1454-1518): the walker calls its leaves
+ * directly, not through the table, so the whole walk is restated here around the two leaf hooks. */
+static void
+hip_rcn_transform_tree(OVCTUDec *const c, uint8_t x0, uint8_t y0, uint8_t log2_tb_w, uint8_t log2_tb_h, uint8_t log2_max_tb_s,
+                       uint8_t tr_depth, CUFlags cu_flags, const struct TUInfo *const tu)
+{
+    const int split_v = log2_tb_w > log2_max_tb_s, split_h = log2_tb_h > log2_max_tb_s;
+    const int nsub = tr_depth ? 1 : (1 << (split_v + split_h));
+    if (log2_tb_w > 6 && log2_tb_h < 7) {
+        hip_rcn_transform_tree(c, x0, y0, 6, log2_tb_h, log2_max_tb_s, tr_depth + 1, cu_flags, &tu[0]);
+        hip_rcn_transform_tree(c, x0 + 64, y0, 6, log2_tb_h, log2_max_tb_s, tr_depth + 1, cu_flags, &tu[8]);
+        return;
+    }
+    if (log2_tb_h > 6 && log2_tb_w < 7) {
+        hip_rcn_transform_tree(c, x0, y0, log2_tb_w, 6, log2_max_tb_s, tr_depth + 1, cu_flags, &tu[0]);
+        hip_rcn_transform_tree(c, x0, y0 + 64, log2_tb_w, 6, log2_max_tb_s, tr_depth + 1, cu_flags, &tu[8]);
+        return;
+    }
+    if (split_v || split_h) {
+        const int w1 = (1 << log2_tb_w) >> split_v, h1 = (1 << log2_tb_h) >> split_h;
+        const int l2w1 = log2_tb_w - split_v, l2h1 = log2_tb_h - split_h;
+        hip_rcn_transform_tree(c, x0, y0, l2w1, l2h1, log2_max_tb_s, tr_depth + 1, cu_flags, &tu[0]);
+        if (split_v) hip_rcn_transform_tree(c, x0 + w1, y0, l2w1, l2h1, log2_max_tb_s, tr_depth + 1, cu_flags, &tu[1 * nsub]);
+        if (split_h) hip_rcn_transform_tree(c, x0, y0 + h1, l2w1, l2h1, log2_max_tb_s, tr_depth + 1, cu_flags, &tu[2 * nsub]);
+        if (split_h && split_v) hip_rcn_transform_tree(c, x0 + w1, y0 + h1, l2w1, l2h1, log2_max_tb_s, tr_depth + 1, cu_flags, &tu[3 * nsub]);
+        return;
+    }
+    /* leaf: rcn_res_wrap (:1432-1451) */
+    if (c->transform_unit == (void *)&transform_unit_c) {
+        hip_rcn_tu_c(c, x0, y0, log2_tb_w, log2_tb_h, cu_flags, tu->cbf_mask, tu);
+    } else {
+        struct hip_entry *e = entry_of(c, 0);
+        if (e && (cu_flags & flg_pred_mode_flag)) latch(e, OVHIP_EUNSUP, "intra coding unit (device intra path not bound)");
+        if (c->transform_unit == (void *)&transform_unit_st) {
+            hip_rcn_tu_st(c, x0, y0, log2_tb_w, log2_tb_h, cu_flags, tu->cbf_mask, tu);
+        } else {
+            /* dual-tree luma: rcn_tu_l (:1305-1346) = the luma half of rcn_tu_st */
+            if (e && e->rec) {
+                if (e->pend.kind) pend_close(e, c);
+                if (tu->cbf_mask) {
+                    record_tu(e, c, 1, x0, y0, log2_tb_w, log2_tb_h, cu_flags, 0x10, tu);
+                    fill_bs_map(&c->dbf_info.bs1_map, x0, y0, log2_tb_w, log2_tb_h);
+                }
+                fill_ctb_bound(&c->dbf_info, x0, y0, log2_tb_w, log2_tb_h);
+            }
+        }
+    }
+    if (c->tmp_ciip) {
+        fill_bs_map(&c->dbf_info.bs2_map, x0, y0, log2_tb_w, log2_tb_h);
+        fill_bs_map(&c->dbf_info.bs2_map_c, x0, y0, log2_tb_w, log2_tb_h);
+    }
+}
+
+/* ------------------------------------------------------------------------------------ prediction units */
+/* rcn_mcp_b (rcn_structures.h:640-646; rcn_inter.c:2769-2813) */
+static void
+hip_rcn_mcp_b(OVCTUDec *const c, struct OVBuffInfo dst, struct InterDRVCtx *const ic, const OVPartInfo *const part_ctx,
+              const OVMV mv0, const OVMV mv1, unsigned int x0, unsigned int y0, unsigned int log2_pb_w, unsigned int log2_pb_h,
+              uint8_t inter_dir, uint8_t ref_idx0, uint8_t ref_idx1)
+{
+    (void)dst; (void)part_ctx;
+    ENTER(c);
+    ovhip_pu_desc d;
+    OVMV m0 = mv0, m1 = mv1;
+    m0.ref_idx = (int8_t)ref_idx0; m1.ref_idx = (int8_t)ref_idx1;
+    fill_pu(e, c, &d, x0, y0, log2_pb_w, log2_pb_h, inter_dir, m0, m1, ic->rpl0[ref_idx0], ic->rpl1[ref_idx1]);
+    latch(e, ovhip_rec_pu(e->rec, &d), "ovhip_rec_pu");
+}
+
+/* rcn_mcp (rcn_structures.h:636-638; rcn_inter.c:2750-2767): uni-prediction, type 0 = list 0 */
+static void
+hip_rcn_mcp(OVCTUDec *const c, struct OVBuffInfo dst, int x0, int y0, int log2_pu_w, int log2_pu_h, OVMV mv, uint8_t type, uint8_t ref_idx)
+{
+    (void)dst;
+    ENTER(c);
+    struct InterDRVCtx *ic = &c->drv_ctx.inter_ctx;
+    ovhip_pu_desc d;
+    mv.ref_idx = (int8_t)ref_idx;
+    fill_pu(e, c, &d, x0, y0, log2_pu_w, log2_pu_h, type ? 2 : 1, mv, mv, type ? NULL : ic->rpl0[ref_idx], type ? ic->rpl1[ref_idx] : NULL);
+    d.bcw_idx_plus1 = 0;
+    latch(e, ovhip_rec_pu(e->rec, &d), "ovhip_rec_pu");
+}
+
+/* ---- CUs the reference's callers cut into sub-block calls: collected back into one descriptor ---- */
+static void
+pend_close(struct hip_entry *e, OVCTUDec *c)
+{
+    const struct InterDRVCtx *ic = &c->drv_ctx.inter_ctx;
+    const int kind = e->pend.kind;
+    e->pend.kind = PEND_NONE;
+    if (kind == PEND_AFFINE) {
+        /* luma sub-blocks arrived in raster order: cols x rows of 4x4 */
+        const int cols = e->pend.cols ? e->pend.cols : e->pend.cur_col, rows = e->pend.n / (cols ? cols : 1);
+        int log2_w = 2, log2_h = 2;
+        while ((1 << log2_w) < cols * 4) ++log2_w;
+        while ((1 << log2_h) < rows * 4) ++log2_h;
+        if (cols * rows != e->pend.n || (4 << (log2_w - 2)) != cols * 4 || (4 << (log2_h - 2)) != rows * 4 || cols < 2 || rows < 2) {
+            /* not the affine drivers' pattern: each call is what the slot says it is, a 4x4 luma prediction */
+            if (e->pend.prof_dir) { latch(e, OVHIP_EINVAL, "PROF sub-block calls do not form a CU"); return; }
+            for (int i = 0; i < e->pend.n; ++i) {
+                const int row = cols ? i / cols : 0, col = cols ? i % cols : i, k = (row * 32 + col) * 2;
+                OVMV m0 = { .x = e->pend.mv0[k], .y = e->pend.mv0[k + 1], .ref_idx = (int8_t)e->pend.ref_idx0, .bcw_idx_plus1 = e->pend.bcw };
+                OVMV m1 = { .x = e->pend.mv1[k], .y = e->pend.mv1[k + 1], .ref_idx = (int8_t)e->pend.ref_idx1, .bcw_idx_plus1 = e->pend.bcw };
+                ovhip_pu_desc d;
+                fill_pu(e, c, &d, e->pend.x0 + 4 * col, e->pend.y0 + 4 * row, 2, 2, e->pend.inter_dir, m0, m1,
+                        ic->rpl0[e->pend.ref_idx0], ic->rpl1[e->pend.ref_idx1]);
+                d.planes = 1;
+                latch(e, ovhip_rec_pu(e->rec, &d), "ovhip_rec_pu(4x4 luma)");
+            }
+            return;
+        }
+        ovhip_affine_desc d;
+        const int l2 = c->part_ctx->log2_ctu_s;
+        memset(&d, 0, sizeof(d));
+        d.x0 = (uint16_t)((c->ctb_x << l2) + e->pend.x0); d.y0 = (uint16_t)((c->ctb_y << l2) + e->pend.y0);
+        d.log2_w = (uint8_t)log2_w; d.log2_h = (uint8_t)log2_h;
+        d.inter_dir = e->pend.inter_dir; d.bcw_idx_plus1 = e->pend.bcw; d.prof_dir = e->pend.prof_dir;
+        d.lmcs = c->lmcs_info.lmcs_enabled_flag;
+        const OVPicture *p0 = (e->pend.inter_dir & 1) ? ic->rpl0[e->pend.ref_idx0] : NULL;
+        const OVPicture *p1 = (e->pend.inter_dir & 2) ? ic->rpl1[e->pend.ref_idx1] : NULL;
+        if (p0) { d.ref0 = (uint8_t)ref_slot(e, p0); d.poc0 = p0->poc; }
+        if (p1) { d.ref1 = (uint8_t)ref_slot(e, p1); d.poc1 = p1->poc; }
+        if (!p0) { d.ref0 = d.ref1; d.poc0 = d.poc1 + 1; }
+        if (!p1) { d.ref1 = d.ref0; d.poc1 = d.poc0 + 1; }
+        d.mv_stride = 32; d.mv0 = e->pend.mv0; d.mv1 = e->pend.mv1;
+        memcpy(d.dmv_scale[0], e->pend.prof.dmv_scale_h_0, 32); memcpy(d.dmv_scale[1], e->pend.prof.dmv_scale_v_0, 32);
+        memcpy(d.dmv_scale[2], e->pend.prof.dmv_scale_h_1, 32); memcpy(d.dmv_scale[3], e->pend.prof.dmv_scale_v_1, 32);
+        latch(e, ovhip_rec_affine_cu(e->rec, &d), "ovhip_rec_affine_cu");
+    } else if (kind == PEND_BDOF) {
+        /* BDOF blocks without the CU's chroma call (never issued by the reference's callers): luma only */
+        for (int i = 0; i < e->pend.n; ++i) {
+            ovhip_pu_desc d;
+            fill_pu(e, c, &d, e->pend.bx[i], e->pend.by[i], e->pend.bl2w, e->pend.bl2h, 3, e->pend.bmv0, e->pend.bmv1,
+                    ic->rpl0[e->pend.ref_idx0], ic->rpl1[e->pend.ref_idx1]);
+            d.refine = OVHIP_PU_BDOF; d.planes = 1;
+            latch(e, ovhip_rec_pu(e->rec, &d), "ovhip_rec_pu(bdof block)");
+        }
+    }
+}
+
+static void
+pend_affine_add(struct hip_entry *e, OVCTUDec *c, int x0, int y0, OVMV mv0, OVMV mv1, uint8_t inter_dir, uint8_t ref_idx0,
+                uint8_t ref_idx1, uint8_t prof_dir, const struct PROFInfo *prof)
+{
+    e->aff_c_live = 0;
+    if (e->pend.kind == PEND_AFFINE) {
+        /* next sub-block in raster order?  (x advances by 4; a row ends when x returns to the CU's left edge) */
+        const int exp_x = e->pend.x0 + 4 * e->pend.cur_col, exp_y = e->pend.y0 + 4 * e->pend.rows_done;
+        const int wrap = x0 == e->pend.x0 && y0 == exp_y + 4 && e->pend.cur_col >= 2 && (!e->pend.cols || e->pend.cols == e->pend.cur_col);
+        if (wrap) { e->pend.cols = e->pend.cur_col; e->pend.rows_done++; e->pend.cur_col = 0; }
+        else if (!(x0 == exp_x && y0 == exp_y && (!e->pend.cols || e->pend.cur_col < e->pend.cols)) || prof_dir != e->pend.prof_dir
+                 || inter_dir != e->pend.inter_dir || e->pend.n >= 1024)
+            pend_close(e, c);
+    } else if (e->pend.kind) {
+        pend_close(e, c);
+    }
+    if (!e->pend.kind) {
+        e->pend.kind = PEND_AFFINE; e->pend.x0 = x0; e->pend.y0 = y0; e->pend.n = 0; e->pend.cols = 0; e->pend.rows_done = 0;
+        e->pend.cur_col = 0;
+        e->pend.inter_dir = inter_dir; e->pend.prof_dir = prof_dir; e->pend.bcw = mv0.bcw_idx_plus1;
+        e->pend.ref_idx0 = ref_idx0; e->pend.ref_idx1 = ref_idx1;
+        if (prof) e->pend.prof = *prof; else memset(&e->pend.prof, 0, sizeof(e->pend.prof));
+    }
+    const int k = (e->pend.rows_done * 32 + e->pend.cur_col) * 2;
+    e->pend.mv0[k] = mv0.x; e->pend.mv0[k + 1] = mv0.y; e->pend.mv1[k] = mv1.x; e->pend.mv1[k + 1] = mv1.y;
+    e->pend.cur_col++; e->pend.n++;
+}
+
+/* rcn_mcp_b_l (rcn_structures.h:648-654; rcn_inter.c:2815-2862).  The reference's only callers are the affine drivers,
+ * one 4x4 sub-block per call (drv_affine_mvp.c:3264-3300). */
+static void
+hip_rcn_mcp_b_l(OVCTUDec *const c, struct OVBuffInfo dst, struct InterDRVCtx *const ic, const OVPartInfo *const part_ctx,
+                const OVMV mv0, const OVMV mv1, unsigned int x0, unsigned int y0, unsigned int log2_pb_w, unsigned int log2_pb_h,
+                uint8_t inter_dir, uint8_t ref_idx0, uint8_t ref_idx1)
+{
+    (void)dst; (void)part_ctx;
+    struct hip_entry *e = entry_of(c, 0);
+    if (!e || !e->rec) return;
+    if (log2_pb_w == 2 && log2_pb_h == 2) { pend_affine_add(e, c, x0, y0, mv0, mv1, inter_dir, ref_idx0, ref_idx1, 0, NULL); return; }
+    if (e->pend.kind) pend_close(e, c);
+    ovhip_pu_desc d;
+    OVMV m0 = mv0, m1 = mv1;
+    m0.ref_idx = (int8_t)ref_idx0; m1.ref_idx = (int8_t)ref_idx1;
+    fill_pu(e, c, &d, x0, y0, log2_pb_w, log2_pb_h, inter_dir, m0, m1, ic->rpl0[ref_idx0], ic->rpl1[ref_idx1]);
+    d.planes = 1;
+    latch(e, ovhip_rec_pu(e->rec, &d), "ovhip_rec_pu(luma)");
+}
+
+/* rcn_prof_mcp_b_l (rcn_structures.h:656-663; rcn_inter.c:2864-2918): 4x4 affine sub-block with PROF */
+static void
+hip_rcn_prof_mcp_b_l(OVCTUDec *const c, struct OVBuffInfo dst, struct InterDRVCtx *const ic, const OVPartInfo *const part_ctx,
+                     const OVMV mv0, const OVMV mv1, unsigned int x0, unsigned int y0, unsigned int log2_pb_w, unsigned int log2_pb_h,
+                     uint8_t inter_dir, uint8_t ref_idx0, uint8_t ref_idx1, uint8_t prof_dir, const struct PROFInfo *const prof_info)
+{
+    (void)dst; (void)ic; (void)part_ctx; (void)log2_pb_w; (void)log2_pb_h;
+    struct hip_entry *e = entry_of(c, 0);
+    if (!e || !e->rec) return;
+    pend_affine_add(e, c, x0, y0, mv0, mv1, inter_dir, ref_idx0, ref_idx1, prof_dir, prof_info);
+}
+
+/* rcn_mcp_b_c (rcn_structures.h:665-671 region; rcn_inter.c:2920-2966): the chroma of an affine CU (8x8 luma area per
+ * call, drv_affine_mvp.c:3371-3411), of a BDOF CU (whole CU, vcl_coding_unit.c:2469, :2664), or stand-alone */
+static void
+hip_rcn_mcp_b_c(OVCTUDec *const c, struct OVBuffInfo dst, struct InterDRVCtx *const ic, const OVPartInfo *const part_ctx,
+                const OVMV mv0, const OVMV mv1, unsigned int x0, unsigned int y0, unsigned int log2_pb_w, unsigned int log2_pb_h,
+                uint8_t inter_dir, uint8_t ref_idx0, uint8_t ref_idx1)
+{
+    (void)dst; (void)part_ctx;
+    struct hip_entry *e = entry_of(c, 0);
+    if (!e || !e->rec) return;
+    if (e->pend.kind == PEND_AFFINE && log2_pb_w == 3 && log2_pb_h == 3 && (int)x0 == e->pend.x0 && (int)y0 == e->pend.y0) {
+        /* first chroma call of the affine CU being collected closes its luma; the recorder derives the chroma vectors
+         * of the whole CU itself (same averaging), so the remaining (3,3) calls inside the CU carry nothing new */
+        const int cols = e->pend.cols ? e->pend.cols : e->pend.cur_col, rows = e->pend.n / (cols ? cols : 1);
+        e->aff_c_x0 = e->pend.x0; e->aff_c_y0 = e->pend.y0; e->aff_c_x1 = e->pend.x0 + 4 * cols; e->aff_c_y1 = e->pend.y0 + 4 * rows;
+        pend_close(e, c);
+        e->aff_c_live = 1;
+        return;
+    }
+    if (e->aff_c_live && log2_pb_w == 3 && log2_pb_h == 3 && (int)x0 >= e->aff_c_x0 && (int)x0 < e->aff_c_x1
+        && (int)y0 >= e->aff_c_y0 && (int)y0 < e->aff_c_y1)
+        return;
+    e->aff_c_live = 0;
+    if (e->pend.kind == PEND_BDOF) {
+        /* the CU's chroma call: now the CU size is known -> one descriptor for the whole BDOF CU */
+        const int w = 1 << log2_pb_w, h = 1 << log2_pb_h, bw = w > 16 ? 16 : w, bh = h > 16 ? 16 : h;
+        int ok = (int)x0 == e->pend.bx[0] && (int)y0 == e->pend.by[0] && e->pend.n == (w / bw) * (h / bh) && (1 << e->pend.bl2w) == bw
+                 && (1 << e->pend.bl2h) == bh && mv0.x == e->pend.bmv0.x && mv0.y == e->pend.bmv0.y && mv1.x == e->pend.bmv1.x
+                 && mv1.y == e->pend.bmv1.y;
+        if (ok) {
+            e->pend.kind = PEND_NONE;
+            ovhip_pu_desc d;
+            fill_pu(e, c, &d, x0, y0, log2_pb_w, log2_pb_h, 3, e->pend.bmv0, e->pend.bmv1, ic->rpl0[ref_idx0], ic->rpl1[ref_idx1]);
+            d.refine = OVHIP_PU_BDOF;
+            latch(e, ovhip_rec_pu(e->rec, &d), "ovhip_rec_pu(bdof cu)");
+            return;
+        }
+        pend_close(e, c);
+    } else if (e->pend.kind) {
+        pend_close(e, c);
+    }
+    ovhip_pu_desc d;
+    OVMV m0 = mv0, m1 = mv1;
+    m0.ref_idx = (int8_t)ref_idx0; m1.ref_idx = (int8_t)ref_idx1;
+    fill_pu(e, c, &d, x0, y0, log2_pb_w, log2_pb_h, inter_dir, m0, m1, ic->rpl0[ref_idx0], ic->rpl1[ref_idx1]);
+    d.planes = 2;
+    latch(e, ovhip_rec_pu(e->rec, &d), "ovhip_rec_pu(chroma)");
+}
+
+/* rcn_bdof_mcp_l (rcn_structures.h:634-636 region; rcn_inter.c:1136-1250): one <=16x16 luma block of a BDOF CU */
+static void
+hip_rcn_bdof_mcp_l(OVCTUDec *const c, struct OVBuffInfo dst, uint8_t x0, uint8_t y0, uint8_t log2_pu_w, uint8_t log2_pu_h,
+                   OVMV mv0, OVMV mv1, uint8_t ref_idx0, uint8_t ref_idx1)
+{
+    (void)dst;
+    struct hip_entry *e = entry_of(c, 0);
+    if (!e || !e->rec) return;
+    e->aff_c_live = 0;
+    if (e->pend.kind == PEND_BDOF && (e->pend.n >= 64 || log2_pu_w != e->pend.bl2w || log2_pu_h != e->pend.bl2h || mv0.x != e->pend.bmv0.x
+                                      || mv0.y != e->pend.bmv0.y || mv1.x != e->pend.bmv1.x || mv1.y != e->pend.bmv1.y))
+        pend_close(e, c);
+    else if (e->pend.kind && e->pend.kind != PEND_BDOF)
+        pend_close(e, c);
+    if (!e->pend.kind) {
+        e->pend.kind = PEND_BDOF; e->pend.n = 0; e->pend.bl2w = log2_pu_w; e->pend.bl2h = log2_pu_h;
+        e->pend.bmv0 = mv0; e->pend.bmv1 = mv1; e->pend.bmv0.ref_idx = (int8_t)ref_idx0; e->pend.bmv1.ref_idx = (int8_t)ref_idx1;
+        e->pend.ref_idx0 = ref_idx0; e->pend.ref_idx1 = ref_idx1;
+    }
+    e->pend.bx[e->pend.n] = x0; e->pend.by[e->pend.n] = y0; e->pend.n++;
+}
+
+/* rcn_dmvr_mv_refine (rcn_structures.h:628-632; rcn_inter.c:872-1126).
+ *
+ * The `OVMV *mv0, *mv1` in/out contract: the reference refines synchronously and its caller copies the result into the
+ * CTU's TMVP storage (vcl_coding_unit.c:2629-2645), which store_inter_maps moves into the picture's MV plane at the end
+ * of the CTU (drv_lines.c:270-330).  Here the search runs on the device at the end of the CTU ROW (the
+ * alf.rcn_alf_filter_line hook below -> ovhip_job_dmvr_rows): the slot returns the vectors unrefined and remembers
+ * where the caller's stores end up in the picture's MV plane; the hook patches those entries BEFORE the row is published
+ * (ovdpb_report_decoded_ctu_line, slicedec.c:940-955), so every reader of the collocated motion field (tmvp of later
+ * pictures, drv_mvp.c:281-345) sees refined vectors exactly when the reference guarantees them. */
+static uint8_t
+hip_rcn_dmvr_mv_refine(OVCTUDec *const c, struct OVBuffInfo dst, uint8_t x0, uint8_t y0, uint8_t log2_pu_w, uint8_t log2_pu_h,
+                       OVMV *mv0, OVMV *mv1, uint8_t ref_idx0, uint8_t ref_idx1, uint8_t apply_bdof)
+{
+    (void)dst;
+    struct hip_entry *e = entry_of(c, 0);
+    if (!e || !e->rec) return 0;
+    e->aff_c_live = 0;
+    if (e->pend.kind) pend_close(e, c);
+    struct InterDRVCtx *ic = &c->drv_ctx.inter_ctx;
+    ovhip_pu_desc d;
+    OVMV m0 = *mv0, m1 = *mv1;
+    m0.ref_idx = (int8_t)ref_idx0; m1.ref_idx = (int8_t)ref_idx1;
+    fill_pu(e, c, &d, x0, y0, log2_pu_w, log2_pu_h, 3, m0, m1, ic->rpl0[ref_idx0], ic->rpl1[ref_idx1]);
+    d.refine = OVHIP_PU_DMVR | (apply_bdof ? OVHIP_PU_BDOF : 0);
+    size_t n_before = 0, n_after = 0;
+    ovhip_rec_mcx_units(e->rec, &n_before);
+    int r = ovhip_rec_pu(e->rec, &d);
+    latch(e, r, "ovhip_rec_pu(dmvr)");
+    ovhip_rec_mcx_units(e->rec, &n_after);
+    if (r < 0 || n_after != n_before + 1) return 0;
+    /* one refined unit <-> where its vectors live in the picture's TMVP planes (8x8 grid): the caller writes
+     * tmvp_mv[l].mvs[((x0 + 7) >> 3) + ((y0 + 7) >> 3) * 16] and its right / lower neighbours for 16-wide / 16-high
+     * blocks; tmvp_store_mv copies row i of that 16x16 array to plane->mvs + ctb_offset + i * pln_stride */
+    if (n_after > e->cap_patch) {
+        size_t nc = e->cap_patch ? e->cap_patch * 2 : 1024;
+        while (nc < n_after) nc *= 2;
+        struct dmvr_patch *q = realloc(e->patch, nc * sizeof(*q));
+        if (!q) { latch(e, OVHIP_ENOMEM, "dmvr patch list"); return 0; }
+        memset(q + e->cap_patch, 0, (nc - e->cap_patch) * sizeof(*q));
+        e->patch = q; e->cap_patch = nc;
+    }
+    for (size_t i = e->n_patch; i < n_after; ++i) e->patch[i].n = 0;
+    struct dmvr_patch *p = &e->patch[n_before];
+    const struct MVPlane *pl0 = ic->tmvp_ctx.plane0, *pl1 = ic->tmvp_ctx.plane1;
+    if (pl0 && pl1 && pl0->mvs && pl1->mvs) {
+        const int nb_tmvp = (1 << c->part_ctx->log2_ctu_s) >> 3;
+        const int32_t stride = nb_tmvp * c->nb_ctb_pic_w;
+        const int32_t ctb_off = (c->ctb_x + c->ctb_y * stride) * nb_tmvp;
+        const int ux = (x0 + 7) >> 3, uy = (y0 + 7) >> 3;
+        for (int dy = 0; dy <= (log2_pu_h > 3); ++dy)
+            for (int dx = 0; dx <= (log2_pu_w > 3); ++dx) {
+                if (ux + dx >= nb_tmvp || uy + dy >= nb_tmvp) continue;       /* outside what tmvp_store_mv copies */
+                p->dst0[p->n] = pl0->mvs + ctb_off + (uy + dy) * stride + ux + dx;
+                p->dst1[p->n] = pl1->mvs + ctb_off + (uy + dy) * stride + ux + dx;
+                p->n++;
+            }
+    }
+    e->n_patch = n_after;
+    return 0;      /* disable_bdof: unused by the caller (vcl_coding_unit.c:2621) */
+}
+
+int
+ovhip_shim_apply_refined_mvs(OVCTUDec *c, const int32_t *mv, size_t first, size_t n)
+{
+    struct hip_entry *e = entry_of(c, 0);
+    if (!e || !mv) return OVHIP_EINVAL;
+    for (size_t i = first; i < first + n && i < e->n_patch; ++i) {
+        const struct dmvr_patch *p = &e->patch[i];
+        for (int k = 0; k < p->n; ++k) {
+            p->dst0[k]->x = mv[4 * i + 0]; p->dst0[k]->y = mv[4 * i + 1];
+            p->dst1[k]->x = mv[4 * i + 2]; p->dst1[k]->y = mv[4 * i + 3];
+        }
+    }
+    return OVHIP_OK;
+}
+
+/* rcn_gpm_b (rcn_structures.h:687-688; rcn_inter.c:3118-3143) */
+static void
+hip_rcn_gpm_b(OVCTUDec *const c, struct VVCGPM *g, int x0, int y0, int log2_pb_w, int log2_pb_h)
+{
+    ENTER(c);
+    struct InterDRVCtx *ic = &c->drv_ctx.inter_ctx;
+    const OVPicture *p0 = g->inter_dir0 == 1 ? ic->rpl0[g->mv0.ref_idx] : ic->rpl1[g->mv0.ref_idx];
+    const OVPicture *p1 = g->inter_dir1 == 1 ? ic->rpl0[g->mv1.ref_idx] : ic->rpl1[g->mv1.ref_idx];
+    ovhip_pu_desc d;
+    fill_pu(e, c, &d, x0, y0, log2_pb_w, log2_pb_h, 3, g->mv0, g->mv1, p0, p1);
+    d.bcw_idx_plus1 = 0;
+    d.refine = OVHIP_PU_GPM; d.gpm_split_dir = (uint8_t)g->split_dir;
+    latch(e, ovhip_rec_pu(e->rec, &d), "ovhip_rec_pu(gpm)");
+}
+
+/* rcn_ciip_b / rcn_ciip (rcn_structures.h:673-683; rcn_inter.c:3011-3067): inter part + planar intra + blend */
+static void
+ciip_common(struct hip_entry *e, OVCTUDec *c, ovhip_pu_desc *d, int x0, int y0, int log2_pb_w, int log2_pb_h)
+{
+    const int l2 = c->part_ctx->log2_min_cb_s;
+    const int mode_abv = c->part_map.cu_mode_x[(x0 + (1 << log2_pb_w) - 1) >> l2];
+    const int mode_lft = c->part_map.cu_mode_y[(y0 + (1 << log2_pb_h) - 1) >> l2];
+    latch(e, ovhip_rec_pu(e->rec, d), "ovhip_rec_pu(ciip)");
+    /* the planar prediction of this CU comes from the ordered (intra) pass on the device; the blend with it is
+     * recorded as its own unit */
+    latch(e, ovhip_rec_ciip(e->rec, d->x0, d->y0, log2_pb_w, log2_pb_h, mode_abv, mode_lft), "ovhip_rec_ciip");
+}
+
+static void
+hip_rcn_ciip_b(OVCTUDec *const c, const OVMV mv0, const OVMV mv1, unsigned int x0, unsigned int y0, unsigned int log2_pb_w,
+               unsigned int log2_pb_h, uint8_t inter_dir, uint8_t ref_idx0, uint8_t ref_idx1)
+{
+    ENTER(c);
+    struct InterDRVCtx *ic = &c->drv_ctx.inter_ctx;
+    ovhip_pu_desc d;
+    OVMV m0 = mv0, m1 = mv1;
+    m0.ref_idx = (int8_t)ref_idx0; m1.ref_idx = (int8_t)ref_idx1;
+    fill_pu(e, c, &d, x0, y0, log2_pb_w, log2_pb_h, inter_dir, m0, m1, ic->rpl0[ref_idx0], ic->rpl1[ref_idx1]);
+    ciip_common(e, c, &d, x0, y0, log2_pb_w, log2_pb_h);
+}
+
+static void
+hip_rcn_ciip(OVCTUDec *const c, int x0, int y0, int log2_pb_w, int log2_pb_h, OVMV mv, uint8_t ref_idx)
+{
+    ENTER(c);
+    struct InterDRVCtx *ic = &c->drv_ctx.inter_ctx;
+    ovhip_pu_desc d;
+    mv.ref_idx = (int8_t)ref_idx;
+    fill_pu(e, c, &d, x0, y0, log2_pb_w, log2_pb_h, 1, mv, mv, ic->rpl0[ref_idx], NULL);
+    d.bcw_idx_plus1 = 0;
+    ciip_common(e, c, &d, x0, y0, log2_pb_w, log2_pb_h);
+}
+
+/* ------------------------------------------------------------------------------------ LMCS */
+/* rcn_init_lmcs (rcn_structures.h:540; rcn_lmcs.c:345-361): the scalar one keeps filling lmcs_info (the parse loop
+ * reads it); the device tables are built from the same APS data */
+static void
+hip_rcn_init_lmcs(struct LMCSInfo *li, const struct OVLMCSData *const ld)
+{
+    OVCTUDec *c = ctudec_of_lmcs(li);
+    struct hip_entry *e = entry_of(c, 0);
+    if (!e) return;
+    e->scalar.rcn_init_lmcs(li, ld);
+    ovhip_lmcs_data hd;
+    memset(&hd, 0, sizeof(hd));
+    hd.min_bin_idx = ld->lmcs_min_bin_idx; hd.delta_max_bin_idx = ld->lmcs_delta_max_bin_idx;
+    hd.crs_offset = (int16_t)(ld->lmcs_delta_sign_crs_flag ? -ld->lmcs_delta_abs_crs : ld->lmcs_delta_abs_crs);
+    for (int i = 0; i < 16; ++i) hd.cw_delta[i] = (int16_t)(ld->lmcs_delta_sign_cw_flag[i] ? -ld->lmcs_delta_abs_cw[i] : ld->lmcs_delta_abs_cw[i]);
+    latch(e, ovhip_lmcs_build(&hd, &e->luts), "ovhip_lmcs_build");
+    e->have_luts = 1;
+}
+
+/* rcn_lmcs_compute_chroma_scale (rcn_structures.h:535-538; rcn_lmcs.c:320-343): needs RECONSTRUCTED luma around the
+ * 64x64 region, which only exists on the device -> record the region; the TUs that follow refer to it */
+static void
+hip_lmcs_chroma_scale(struct LMCSInfo *const li, int16_t stride, const struct CTUBitField *const pf, const OVSample *ctu_y,
+                      uint8_t x0, uint8_t y0)
+{
+    (void)stride; (void)ctu_y;
+    OVCTUDec *c = ctudec_of_lmcs(li);
+    ENTER(c);
+    const int l2 = c->part_ctx->log2_ctu_s;
+    const uint32_t abv = (uint32_t)((pf->hfield[y0 >> 2] >> ((x0 >> 2) + 1)) & 0xffff);
+    const uint32_t lft = (uint32_t)((pf->vfield[x0 >> 2] >> ((y0 >> 2) + 1)) & 0xffff);
+    int r = ovhip_rec_lmcs_region(e->rec, (c->ctb_x << l2) + x0, (c->ctb_y << l2) + y0, abv, lft);
+    latch(e, r, "ovhip_rec_lmcs_region");
+    e->lmcs_region_live = r >= 0;
+}
+
+/* lmcs_reshape_backward per CTU (slicedec.c:746-750): one launch per picture in the flush instead */
+static void hip_noop_reshape(OVSample *dst, ptrdiff_t stride, const struct LMCSLUTs *const luts, int w, int h)
+{ (void)dst; (void)stride; (void)luts; (void)w; (void)h; }
+
+/* ------------------------------------------------------------------------------------ deblocking */
+static void
+snapshot_dbf(ovhip_dbf_ctu *o, const struct DBFInfo *d)
+{
+    memset(o, 0, sizeof(*o));
+    memcpy(o->ctb_bound_ver, d->ctb_bound_ver, sizeof(o->ctb_bound_ver));
+    memcpy(o->ctb_bound_hor, d->ctb_bound_hor, sizeof(o->ctb_bound_hor));
+    memcpy(o->ctb_bound_ver_c, d->ctb_bound_ver_c, sizeof(o->ctb_bound_ver_c));
+    memcpy(o->ctb_bound_hor_c, d->ctb_bound_hor_c, sizeof(o->ctb_bound_hor_c));
+    memcpy(o->aff_edg_ver, d->aff_edg_ver, sizeof(o->aff_edg_ver));
+    memcpy(o->aff_edg_hor, d->aff_edg_hor, sizeof(o->aff_edg_hor));
+    memcpy(o->bs2_ver, d->bs2_map.ver, sizeof(o->bs2_ver));          memcpy(o->bs2_hor, d->bs2_map.hor, sizeof(o->bs2_hor));
+    memcpy(o->bs2c_ver, d->bs2_map_c.ver, sizeof(o->bs2c_ver));      memcpy(o->bs2c_hor, d->bs2_map_c.hor, sizeof(o->bs2c_hor));
+    memcpy(o->bs1_ver, d->bs1_map.ver, sizeof(o->bs1_ver));          memcpy(o->bs1_hor, d->bs1_map.hor, sizeof(o->bs1_hor));
+    memcpy(o->bs1cb_ver, d->bs1_map_cb.ver, sizeof(o->bs1cb_ver));   memcpy(o->bs1cb_hor, d->bs1_map_cb.hor, sizeof(o->bs1cb_hor));
+    memcpy(o->bs1cr_ver, d->bs1_map_cr.ver, sizeof(o->bs1cr_ver));   memcpy(o->bs1cr_hor, d->bs1_map_cr.hor, sizeof(o->bs1cr_hor));
+    memcpy(o->affine_ver, d->affine_map.ver, sizeof(o->affine_ver)); memcpy(o->affine_hor, d->affine_map.hor, sizeof(o->affine_hor));
+    memcpy(o->qp_y, d->qp_map_y.hor, sizeof(o->qp_y));
+    memcpy(o->qp_cb, d->qp_map_cb.hor, sizeof(o->qp_cb));
+    memcpy(o->qp_cr, d->qp_map_cr.hor, sizeof(o->qp_cr));
+    o->beta_offset = d->beta_offset; o->tc_offset = d->tc_offset;
+    o->disable_v = d->disable_v; o->disable_h = d->disable_h;
+}
+
+static void
+dbf_ctu(const struct OVRCNCtx *const r, struct DBFInfo *const dbf, uint8_t log2_ctu_s, uint8_t last_x, uint8_t last_y, int ctu_w, int ctu_h)
+{
+    OVCTUDec *c = r->ctudec;
+    ENTER(c);
+    ovhip_dbf_ctu s;
+    snapshot_dbf(&s, dbf);
+    s.log2_ctu_s = log2_ctu_s; s.last_x = last_x; s.last_y = last_y;
+    s.ctu_lft = !!(c->ctu_ngh_flags & CTU_LFT_FLG); s.ctu_abv = !!(c->ctu_ngh_flags & CTU_UP_FLG);
+    s.ctu_w = (uint16_t)ctu_w; s.ctu_h = (uint16_t)ctu_h;
+    s.ctb_x = c->ctb_x; s.ctb_y = c->ctb_y;
+    if (c->tmp_slice_type != 2) {
+        /* P / B slices: the slot's own MV-based boundary-strength pre-pass (dbf_ctu_preproc_v/_h, rcn_df.c:1821-1874;
+         * static there) on the CTU's motion grids.  The scalar slot also leaves the result in dbf_info->bs1_map, which
+         * dbf_store_info() carries to the neighbouring CTUs (slicedec.c:872-877): write it back. */
+        const struct InterDRVCtx *ic = &c->drv_ctx.inter_ctx;
+        ovhip_dbf_mv_ctx mc;
+        memset(&mc, 0, sizeof(mc));
+        memcpy(mc.cu_edge_ver, dbf->cu_edge.ver, sizeof(mc.cu_edge_ver)); memcpy(mc.cu_edge_hor, dbf->cu_edge.hor, sizeof(mc.cu_edge_hor));
+        memcpy(mc.map0_h, ic->mv_ctx0.map.hfield, sizeof(mc.map0_h)); memcpy(mc.map0_v, ic->mv_ctx0.map.vfield, sizeof(mc.map0_v));
+        memcpy(mc.map1_h, ic->mv_ctx1.map.hfield, sizeof(mc.map1_h)); memcpy(mc.map1_v, ic->mv_ctx1.map.vfield, sizeof(mc.map1_v));
+        if (dbf->ibc_ctx) { memcpy(mc.ibc_h, dbf->ibc_ctx->ctu_map.hfield, sizeof(mc.ibc_h)); memcpy(mc.ibc_v, dbf->ibc_ctx->ctu_map.vfield, sizeof(mc.ibc_v)); }
+        memcpy(mc.dist_ref0, ic->dist_ref_0, sizeof(mc.dist_ref0)); memcpy(mc.dist_ref1, ic->dist_ref_1, sizeof(mc.dist_ref1));
+        mc.mvs0 = ic->mv_ctx0.mvs; mc.mvs1 = ic->mv_ctx1.mvs; mc.mv_bytes = sizeof(OVMV);
+        latch(e, ovhip_rec_dbf_mv_prepass(&s, &mc), "ovhip_rec_dbf_mv_prepass");
+        memcpy(dbf->bs1_map.ver, s.bs1_ver, sizeof(s.bs1_ver)); memcpy(dbf->bs1_map.hor, s.bs1_hor, sizeof(s.bs1_hor));
+    }
+    latch(e, ovhip_rec_dbf_ctu(e->rec, &s), "ovhip_rec_dbf_ctu");
+}
+
+/* df.rcn_dbf_ctu / df.rcn_dbf_truncated_ctu (rcn_structures.h:408-413; rcn_df.c:2169-2231) */
+static void hip_rcn_dbf_ctu(const struct OVRCNCtx *const r, struct DBFInfo *const dbf, uint8_t log2_ctu_s, uint8_t last_x, uint8_t last_y)
+{ dbf_ctu(r, dbf, log2_ctu_s, last_x, last_y, 0, 0); }
+static void hip_rcn_dbf_truncated_ctu(const struct OVRCNCtx *const r, struct DBFInfo *const dbf, uint8_t log2_ctu_s, uint8_t last_x,
+                                      uint8_t last_y, uint8_t ctu_w, uint8_t ctu_h)
+{ dbf_ctu(r, dbf, log2_ctu_s, last_x, last_y, ctu_w, ctu_h); }
+
+/* ------------------------------------------------------------------------------------ SAO / ALF: parameter capture */
+static int
+params_alloc(struct hip_entry *e, const OVCTUDec *c, const struct RectEntryInfo *einfo)
+{
+    const int l2 = c->part_ctx->log2_ctu_s;
+    const int nw = (e->pic_w + (1 << l2) - 1) >> l2, nh = (e->pic_h + (1 << l2) - 1) >> l2;
+    if (einfo->ctb_x || einfo->ctb_y || einfo->nb_ctu_w != nw || einfo->nb_ctu_h != nh) {
+        latch(e, OVHIP_EUNSUP, "rect entry smaller than the picture (tiles)");
+        return -1;
+    }
+    e->log2_ctu = l2; e->nb_ctu_w = nw; e->nb_ctu_h = nh;
+    if (e->n_ctu != (size_t)nw * nh) {
+        free(e->sao); free(e->alf);
+        e->n_ctu = (size_t)nw * nh;
+        e->sao = calloc(e->n_ctu, sizeof(*e->sao)); e->alf = calloc(e->n_ctu, sizeof(*e->alf));
+        if (!e->sao || !e->alf) { latch(e, OVHIP_ENOMEM, "filter parameter arrays"); return -1; }
+    }
+    return 0;
+}
+
+static void
+sao_row(struct hip_entry *e, const OVCTUDec *c, const struct RectEntryInfo *einfo, int ctb_y)
+{
+    if (ctb_y < 0 || ctb_y >= einfo->nb_ctu_h || params_alloc(e, c, einfo)) return;
+    const struct SAOInfo *si = &c->sao_info;
+    for (int x = 0; x < einfo->nb_ctu_w; ++x) {
+        const SAOParamsCtu *s = &si->sao_params[ctb_y * einfo->nb_ctu_w + x];
+        ovhip_sao_ctu *o = &e->sao[ctb_y * e->nb_ctu_w + x];
+        memset(o, 0, sizeof(*o));
+        for (int k = 0; k < (si->chroma_format_idc ? 3 : 1); ++k) {
+            o->type[k] = s->type_idx[k]; o->band_position[k] = s->band_position[k]; o->eo_class[k] = s->eo_class[k];
+            memcpy(o->offset_val[k], s->offset_val[k], sizeof(o->offset_val[k]));
+        }
+    }
+    e->sao_on = 1;
+}
+
+/* sao.rcn_sao_filter_line / rcn_sao_first_pix_rows (rcn_structures.h:344-350; rcn_sao.c:190-293): line ctb_y filters
+ * the band [128 ctb_y + 6, 128 (ctb_y + 1) + 6) with the parameters of rows ctb_y and ctb_y + 1; on the device every
+ * sample takes the parameters of the CTU that contains it (same result) */
+static void
+hip_sao_filter_line(OVCTUDec *const c, const struct RectEntryInfo *const einfo, uint16_t ctb_y)
+{
+    ENTER(c);
+    if (!c->sao_info.sao_luma_flag && !c->sao_info.sao_chroma_flag) return;
+    sao_row(e, c, einfo, ctb_y);
+    sao_row(e, c, einfo, ctb_y + 1);
+}
+
+static void
+hip_sao_first_pix_rows(OVCTUDec *const c, const struct RectEntryInfo *const einfo, uint16_t ctb_y)
+{
+    ENTER(c);
+    if (!c->sao_info.sao_luma_flag && !c->sao_info.sao_chroma_flag) return;
+    sao_row(e, c, einfo, ctb_y);
+}
+
+static void flush_picture(struct hip_entry *e, OVCTUDec *c);
+
+/* alf.rcn_alf_filter_line (rcn_structures.h:333; rcn_alf.c:1285-1433): the LAST slot call before a CTU row is published
+ * (slicedec.c:934-956).  Captures the row's ALF parameters, refines the DMVR vectors recorded so far (so that the row's
+ * TMVP field is final), and for the last row of the picture runs the flush. */
+static void
+hip_alf_filter_line(OVCTUDec *const c, const struct RectEntryInfo *const einfo, uint16_t ctb_y)
+{
+    ENTER(c);
+    const struct ALFInfo *ai = &c->alf_info;
+    if (params_alloc(e, c, einfo)) return;
+    if (ai->alf_luma_enabled_flag || ai->alf_cb_enabled_flag || ai->alf_cr_enabled_flag) {
+        for (int x = 0; x < einfo->nb_ctu_w; ++x) {
+            const int i = ctb_y * einfo->nb_ctu_w + x;
+            const ALFParamsCtu *p = &ai->ctb_alf_params[i];
+            ovhip_alf_ctu *o = &e->alf[i];
+            o->flags = p->ctb_alf_flag; o->luma_set = p->ctb_alf_idx; o->cb_alt = p->cb_alternative; o->cr_alt = p->cr_alternative;
+            o->cc_cb_idx = ai->cc_alf_cb_enabled_flag ? ai->ctb_cc_alf_filter_idx[0][i] : 0;
+            o->cc_cr_idx = ai->cc_alf_cr_enabled_flag ? ai->ctb_cc_alf_filter_idx[1][i] : 0;
+        }
+        if (ai->aps_cc_alf_data_cb) memcpy(e->alf_cc[0], ai->aps_cc_alf_data_cb->alf_cc_mapped_coeff[0], sizeof(e->alf_cc[0]));
+        if (ai->aps_cc_alf_data_cr) memcpy(e->alf_cc[1], ai->aps_cc_alf_data_cr->alf_cc_mapped_coeff[1], sizeof(e->alf_cc[1]));
+        e->alf_on = 1;
+    }
+    if (e->record_only) return;
+    /* eager DMVR: rows up to this one */
+    if (e->n_patch > e->dmvr_done && e->job) {
+        ovhip_pic refs[16];
+        /* (reference pictures are complete on the device before any of their rows was published to this thread) */
+        int n = 0;
+        extern int rcn_hip_device_refs_(struct hip_entry *, ovhip_pic *, int *);
+        if (rcn_hip_device_refs_(e, refs, &n) == 0) {
+            const size_t first = e->dmvr_done;
+            int64_t done = ovhip_job_dmvr_rows(e->job, refs, (uint32_t)n);
+            if (done < 0) latch(e, (int)done, "ovhip_job_dmvr_rows");
+            else {
+                size_t nm = 0;
+                const int32_t *mv = ovhip_job_refined_mvs(e->job, &nm);
+                ovhip_shim_apply_refined_mvs(c, mv, first, (size_t)done - first);
+                e->dmvr_done = (size_t)done;
+            }
+        }
+    }
+    if (ctb_y == einfo->nb_ctu_h - 1) flush_picture(e, c);
+}
+
+/* ------------------------------------------------------------------------------------ picture begin / flush / plumbing */
+/* Device pictures of the decoder's frames: process-wide mirror of the DPB, keyed by OVFrame. */
+#define DPB_SLOTS 64
+static struct { const OVFrame *frame; ovhip_pic pic; int w, h; int submitted; } g_dpb[DPB_SLOTS];
+static pthread_mutex_t g_dpb_mtx = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t g_dpb_cnd = PTHREAD_COND_INITIALIZER;
+
+static int
+dpb_slot(struct hip_entry *e, const OVFrame *f, int create)
+{
+    int slot = -1, free_slot = -1;
+    pthread_mutex_lock(&g_dpb_mtx);
+    for (int i = 0; i < DPB_SLOTS; ++i) {
+        if (g_dpb[i].frame == f) { slot = i; break; }
+        if (!g_dpb[i].frame && free_slot < 0) free_slot = i;
+    }
+    if (slot < 0 && create && free_slot >= 0) {
+        slot = free_slot;
+        if (!g_dpb[slot].pic.y || g_dpb[slot].w != e->pic_w || g_dpb[slot].h != e->pic_h) {
+            if (g_dpb[slot].pic.y) ovhip_pic_free(e->ctx, &g_dpb[slot].pic);
+            if (ovhip_pic_alloc(e->ctx, e->pic_w, e->pic_h, &g_dpb[slot].pic) != OVHIP_OK) slot = -1;
+            else { g_dpb[slot].w = e->pic_w; g_dpb[slot].h = e->pic_h; }
+        }
+        if (slot >= 0) g_dpb[slot].frame = f;
+    }
+    if (slot >= 0 && create) g_dpb[slot].submitted = 0;
+    pthread_mutex_unlock(&g_dpb_mtx);
+    return slot;
+}
+
+int
+rcn_hip_device_refs_(struct hip_entry *e, ovhip_pic *refs, int *n)
+{
+    for (int i = 0; i < e->n_refs; ++i) {
+        const int s = dpb_slot(e, e->refs[i]->frame, 0);
+        if (s < 0) { latch(e, OVHIP_EINVAL, "reference picture was not decoded on this device"); return -1; }
+        /* the device analogue of ovdpb_synchro_ref_decoded_ctus (dpb.c:1242-1270): wait until the producer thread has
+         * SUBMITTED the picture; its launches are then ordered before ours because every context's flush ends in
+         * ovhip_job_wait before the producer publishes (see flush_picture) */
+        pthread_mutex_lock(&g_dpb_mtx);
+        while (!g_dpb[s].submitted) pthread_cond_wait(&g_dpb_cnd, &g_dpb_mtx);
+        pthread_mutex_unlock(&g_dpb_mtx);
+        refs[i] = g_dpb[s].pic;
+    }
+    *n = e->n_refs;
+    return 0;
+}
+
+static void
+flush_picture(struct hip_entry *e, OVCTUDec *c)
+{
+    if (!e->job || e->err) return;
+    ovhip_pic refs[16];
+    int n_refs = 0;
+    if (e->n_refs && rcn_hip_device_refs_(e, refs, &n_refs)) return;
+    const int slot = dpb_slot(e, e->frame, 0);
+    if (slot < 0) { latch(e, OVHIP_EINVAL, "current picture has no device buffer"); return; }
+    ovhip_job_params pr;
+    memset(&pr, 0, sizeof(pr));
+    pr.lmcs = (c->lmcs_info.lmcs_enabled_flag && e->have_luts) ? &e->luts : NULL;
+    pr.sao = e->sao_on ? e->sao : NULL;
+    if (e->alf_on) {
+        const RCNALF *ra = &c->alf_info.rcn_alf;
+        pr.alf_ctus = e->alf;
+        pr.alf_luma_coeff = &ra->filter_coeff_dec[0][0]; pr.alf_luma_clip = &ra->filter_clip_dec[0][0];
+        pr.alf_chroma_coeff = &ra->chroma_coeff_final[0][0]; pr.alf_chroma_clip = &ra->chroma_clip_final[0][0];
+        pr.alf_cc_coeff = &e->alf_cc[0][0][0];
+    }
+    pr.log2_ctu_s = e->log2_ctu;
+    ovhip_pic dst = g_dpb[slot].pic;
+    latch(e, ovhip_job_flush(e->job, &dst, n_refs ? refs : NULL, (uint32_t)n_refs, NULL, &pr), "ovhip_job_flush");
+    /* the decoder's output path and any host-side reader expect the samples in the OVFrame (dectest.c:372-409) */
+    if (!e->err) {
+        const OVFrame *f = e->frame;
+        latch(e, ovhip_pic_download(e->ctx, &dst, (uint16_t *)f->data[0], (uint16_t *)f->data[1], (uint16_t *)f->data[2],
+                                    (int32_t)(f->linesize[0] / 2), (int32_t)(f->linesize[1] / 2)), "ovhip_pic_download");
+    }
+    latch(e, ovhip_job_wait(e->job), "ovhip_job_wait");
+    /* remaining refined vectors (last row) */
+    size_t nm = 0;
+    const int32_t *mv = ovhip_job_refined_mvs(e->job, &nm);
+    if (mv && nm > e->dmvr_done) ovhip_shim_apply_refined_mvs(c, mv, e->dmvr_done, nm - e->dmvr_done);
+    e->dmvr_done = nm;
+    pthread_mutex_lock(&g_dpb_mtx);
+    g_dpb[slot].submitted = 1;
+    pthread_cond_broadcast(&g_dpb_cnd);
+    pthread_mutex_unlock(&g_dpb_mtx);
+}
+
+static void
+begin_picture(struct hip_entry *e, const OVFrame *f)
+{
+    e->frame = f;
+    e->err = 0;
+    e->n_refs = 0;
+    e->sao_on = e->alf_on = 0;
+    e->lmcs_region_live = 0;
+    e->n_patch = 0; e->dmvr_done = 0;
+    e->pend.kind = PEND_NONE; e->aff_c_live = 0;
+    if (e->n_ctu) { memset(e->sao, 0, e->n_ctu * sizeof(*e->sao)); memset(e->alf, 0, e->n_ctu * sizeof(*e->alf)); }
+    if (e->record_only) { ovhip_rec_reset(e->rec); return; }
+    if (!e->ctx) {
+        const char *dev = getenv("OVVC_HIP_DEVICE");
+        int r = ovhip_ctx_create(&e->ctx, dev ? atoi(dev) : 0, NULL);
+        if (r != OVHIP_OK) { e->ctx = NULL; latch(e, r, "ovhip_ctx_create (the HIP back-end has no CPU fallback)"); return; }
+    }
+    if (e->job && (e->pic_w != (int)f->width || e->pic_h != (int)f->height)) { ovhip_job_destroy(e->job); e->job = NULL; e->rec = NULL; }
+    e->pic_w = f->width; e->pic_h = f->height;
+    if (!e->job) {
+        int r = ovhip_job_create(e->ctx, e->pic_w, e->pic_h, &e->job);
+        if (r != OVHIP_OK) { e->job = NULL; latch(e, r, "ovhip_job_create"); return; }
+        e->rec = ovhip_job_recorder(e->job);
+    }
+    latch(e, ovhip_job_begin(e->job), "ovhip_job_begin");
+    if (dpb_slot(e, f, 1) < 0) latch(e, OVHIP_ENOMEM, "device picture");
+}
+
+/* rcn_attach_frame_buff (rcn_structures.h:622-623; rcn_ctu.c:570-594) = begin picture for this entry thread */
+static void
+hip_attach_frame_buff(struct OVRCNCtx *const rcn_ctx, const OVFrame *const f, const struct RectEntryInfo *const einfo, uint8_t log2_ctb_s)
+{
+    OVCTUDec *c = rcn_ctx->ctudec;
+    struct hip_entry *e = entry_of(c, 0);
+    if (!e) return;
+    /* the scalar attach keeps rcn_ctx->frame_buff / frame_start valid for every host-side reader */
+    e->scalar.rcn_attach_frame_buff(rcn_ctx, f, einfo, log2_ctb_s);
+    begin_picture(e, f);
+}
+
+/* CTU scratch <-> frame copies, intra line buffer, filter-region halo (rcn_structures.h:595-626; rcn_ctu.c:41-626): the
+ * picture is reconstructed in place on the device, there is no CTU scratch to move */
+static void hip_noop_rcn_u8(const struct OVRCNCtx *const r, uint8_t l) { (void)r; (void)l; }
+static void hip_noop_rcn_u8_nc(struct OVRCNCtx *r, uint8_t l) { (void)r; (void)l; }
+static void hip_noop_line(const struct OVRCNCtx *const r, int x_l, uint8_t l) { (void)r; (void)x_l; (void)l; }
+static void hip_noop_write_border(const struct OVRCNCtx *const r, int w, int h) { (void)r; (void)w; (void)h; }
+static void hip_noop_save_cols(struct OVRCNCtx *const r, int x, int y, uint8_t b) { (void)r; (void)x; (void)y; (void)b; }
+static void hip_noop_save_rows(struct OVRCNCtx *const r, OVSample **s, int x_l, int x, int y, uint8_t b) { (void)r; (void)s; (void)x_l; (void)x; (void)y; (void)b; }
+static void hip_noop_extend(struct OVRCNCtx *const r, OVSample **s, int x_l, int x, int y, uint8_t b) { (void)r; (void)s; (void)x_l; (void)x; (void)y; (void)b; }
+
+/* rcn_buff_uninit (rcn_structures.h:611; ctudec.c:217-219): end of this entry thread's life */
+static void
+hip_buff_uninit(struct OVRCNCtx *const rcn_ctx)
+{
+    struct hip_entry *e = entry_of(rcn_ctx->ctudec, 0);
+    if (e) e->scalar.rcn_buff_uninit(rcn_ctx);
+    ovhip_shim_release(rcn_ctx->ctudec);
+}
+
+/* ------------------------------------------------------------------------------------ install */
+void
+rcn_init_functions_hip(struct RCNFunctions *f, uint8_t ict_type, uint8_t lm_chroma_enabled, uint8_t chroma_vcolloc,
+                       uint8_t lmcs_flag, uint8_t bitdepth)
+{
+    (void)lm_chroma_enabled; (void)chroma_vcolloc;
+    if (bitdepth != 10) return;                       /* like the x86 path (rcn.c:217) */
+    OVCTUDec *c = (OVCTUDec *)((char *)f - offsetof(OVCTUDec, rcn_funcs));
+    struct hip_entry *e = entry_of(c, 1);
+    if (!e) return;
+    e->scalar = *f;
+    e->ict_type = ict_type; e->lmcs_flag = lmcs_flag;
+
+    f->tmp.rcn_transform_tree = &hip_rcn_transform_tree;
+    f->tmp.rcn_tu_st = &hip_rcn_tu_st;
+    f->tmp.rcn_tu_c  = &hip_rcn_tu_c;
+    f->rcn_mcp = &hip_rcn_mcp;
+    f->rcn_mcp_b = &hip_rcn_mcp_b;
+    f->rcn_mcp_b_l = &hip_rcn_mcp_b_l;
+    f->rcn_mcp_b_c = &hip_rcn_mcp_b_c;
+    f->rcn_prof_mcp_b_l = &hip_rcn_prof_mcp_b_l;
+    f->rcn_bdof_mcp_l = &hip_rcn_bdof_mcp_l;
+    f->rcn_dmvr_mv_refine = &hip_rcn_dmvr_mv_refine;
+    f->rcn_gpm_b = &hip_rcn_gpm_b;
+    f->rcn_ciip_b = &hip_rcn_ciip_b;
+    f->rcn_ciip = &hip_rcn_ciip;
+    f->rcn_init_lmcs = &hip_rcn_init_lmcs;
+    f->rcn_lmcs_compute_chroma_scale = &hip_lmcs_chroma_scale;
+    f->lmcs_reshape_backward = &hip_noop_reshape;
+    f->df.rcn_dbf_ctu = &hip_rcn_dbf_ctu;
+    f->df.rcn_dbf_truncated_ctu = &hip_rcn_dbf_truncated_ctu;
+    f->sao.rcn_sao_filter_line = &hip_sao_filter_line;
+    f->sao.rcn_sao_first_pix_rows = &hip_sao_first_pix_rows;
+    f->alf.rcn_alf_filter_line = &hip_alf_filter_line;
+    /* alf.rcn_alf_reconstruct_coeff_APS stays scalar: host-side expansion of the APS into RCNALF, read by the flush */
+    f->rcn_attach_frame_buff = &hip_attach_frame_buff;
+    f->rcn_write_ctu_to_frame = &hip_noop_rcn_u8;
+    f->rcn_write_ctu_to_frame_border = &hip_noop_write_border;
+    f->rcn_ctu_to_intra_line = &hip_noop_line;
+    f->rcn_intra_line_to_ctu = &hip_noop_line;
+    f->rcn_update_ctu_border = &hip_noop_rcn_u8_nc;
+    f->rcn_extend_filter_region = &hip_noop_extend;
+    f->rcn_save_last_rows = &hip_noop_save_rows;
+    f->rcn_save_last_cols = &hip_noop_save_cols;
+    f->rcn_buff_uninit = &hip_buff_uninit;
+}
+
+/* ------------------------------------------------------------------------------------ management */
+int
+ovhip_shim_bind_recorder(const OVCTUDec *c, ovhip_recorder *rec, int pic_w, int pic_h)
+{
+    struct hip_entry *e = entry_of(c, 0);
+    if (!e || !rec || e->job) return OVHIP_EINVAL;
+    e->rec = rec; e->record_only = 1; e->pic_w = pic_w; e->pic_h = pic_h;
+    e->err = 0; e->n_refs = 0; e->pend.kind = PEND_NONE;
+    return OVHIP_OK;
+}
+
+int
+ovhip_shim_ref_pictures(const OVCTUDec *c, const void **out, int cap)
+{
+    struct hip_entry *e = entry_of(c, 0);
+    if (!e) return 0;
+    for (int i = 0; i < e->n_refs && i < cap; ++i) out[i] = e->refs[i];
+    return e->n_refs < cap ? e->n_refs : cap;
+}
+
+/* record-only harness: forget the refined-unit bookkeeping of the previous case (begin_picture does it in the decoder) */
+void
+ovhip_shim_new_picture_for_test(OVCTUDec *c)
+{
+    struct hip_entry *e = entry_of(c, 0);
+    if (e && e->record_only) { e->n_patch = 0; e->dmvr_done = 0; }
+}
+
+ovhip_recorder *ovhip_shim_recorder(const OVCTUDec *c) { struct hip_entry *e = entry_of(c, 0); return e ? e->rec : NULL; }
+int ovhip_shim_last_error(const OVCTUDec *c) { struct hip_entry *e = entry_of(c, 0); return e ? e->err : OVHIP_EINVAL; }
+
+void
+ovhip_shim_flush_pending(OVCTUDec *c)
+{
+    struct hip_entry *e = entry_of(c, 0);
+    if (e && e->rec && e->pend.kind) pend_close(e, c);
+    if (e) e->aff_c_live = 0;
+}
+
+const ovhip_sao_ctu *ovhip_shim_sao_params(const OVCTUDec *c, size_t *n)
+{ struct hip_entry *e = entry_of(c, 0); if (!e || !e->sao_on) return NULL; if (n) *n = e->n_ctu; return e->sao; }
+const ovhip_alf_ctu *ovhip_shim_alf_params(const OVCTUDec *c, size_t *n)
+{ struct hip_entry *e = entry_of(c, 0); if (!e || !e->alf_on) return NULL; if (n) *n = e->n_ctu; return e->alf; }
+const ovhip_lmcs_luts *ovhip_shim_lmcs(const OVCTUDec *c) { struct hip_entry *e = entry_of(c, 0); return e && e->have_luts ? &e->luts : NULL; }
+
+const int16_t *
+ovhip_shim_alf_table(const OVCTUDec *c, int which, size_t *n)
+{
+    struct hip_entry *e = entry_of(c, 0);
+    if (!e) return NULL;
+    const RCNALF *ra = &c->alf_info.rcn_alf;
+    switch (which) {
+    case 0: if (n) *n = sizeof(ra->filter_coeff_dec) / 2; return &ra->filter_coeff_dec[0][0];
+    case 1: if (n) *n = sizeof(ra->filter_clip_dec) / 2; return &ra->filter_clip_dec[0][0];
+    case 2: if (n) *n = sizeof(ra->chroma_coeff_final) / 2; return &ra->chroma_coeff_final[0][0];
+    case 3: if (n) *n = sizeof(ra->chroma_clip_final) / 2; return &ra->chroma_clip_final[0][0];
+    case 4: if (n) *n = sizeof(e->alf_cc) / 2; return &e->alf_cc[0][0][0];
+    }
+    return NULL;
+}
+
+void
+ovhip_shim_release(const OVCTUDec *c)
+{
+    struct hip_entry *e = NULL;
+    pthread_mutex_lock(&g_mtx);
+    for (int i = 0; i < 256; ++i)
+        if (g_entries[i] && g_entries[i]->key == c) { e = g_entries[i]; g_entries[i] = NULL; break; }
+    pthread_mutex_unlock(&g_mtx);
+    if (!e) return;
+    if (e->job) ovhip_job_destroy(e->job);
+    if (e->ctx) ovhip_ctx_destroy(e->ctx);
+    free(e->sao); free(e->alf); free(e->patch);
+    free(e);
+}

@@ -1,0 +1,54 @@
+/* rcn_hip.h -- the MI355X back-end's override block for OpenVVC's reconstruction dispatch table.
+ *
+ * This is the file a maintainer adds to the reference tree: it is compiled WITH the reference's own
+ * headers (ctudec.h, rcn_structures.h, ...) and linked against libovvc_hip.so.  It replaces the orchestrator slots of
+ * struct RCNFunctions (libovvc/rcn_structures.h:499-694) -- the same boundary the SSE4/AVX2/NEON back-ends bind to
+ * (rcn.c:214-299) -- with recorders, and the last alf.rcn_alf_filter_line of a picture with the device flush.
+ */
+#ifndef OVVC_RCN_HIP_H
+#define OVVC_RCN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+struct RCNFunctions;
+struct OVCTUDec;
+struct ovhip_recorder;
+
+/* Same signature and call site as rcn_init_functions() (libovvc/rcn.c:147-149): called right after the scalar fill
+ * (rcn.c:172) on the table embedded in an OVCTUDec (ctudec.h:651).  bitdepth != 10 leaves the table untouched, like
+ * the x86 SIMD path (rcn.c:217). */
+void rcn_init_functions_hip(struct RCNFunctions *rcn_func, uint8_t ict_type, uint8_t lm_chroma_enabled,
+                            uint8_t sps_chroma_vertical_collocated_flag, uint8_t lmcs_flag, uint8_t bitdepth);
+
+/* ---- management (the table has no user pointer: state lives in a side table keyed by the OVCTUDec) ---- */
+
+/* Record-only mode: bind a caller-owned recorder for a pic_w x pic_h picture instead of a device job.  The slots then
+ * record, nothing is launched (command-stream capture for tests and offline replay).  Without this call the first
+ * rcn_attach_frame_buff creates the device context + job and fails loudly when no HIP device is present. */
+int  ovhip_shim_bind_recorder(const struct OVCTUDec *ctudec, struct ovhip_recorder *rec, int pic_w, int pic_h);
+struct ovhip_recorder *ovhip_shim_recorder(const struct OVCTUDec *ctudec);
+/* The reference-picture table of the current picture (OVPicture pointers, order of first use = the indices the recorded
+ * units carry in ref0 / ref1). */
+int  ovhip_shim_ref_pictures(const struct OVCTUDec *ctudec, const void **out, int cap);
+/* Close the prediction calls still being collected into one CU (affine sub-blocks, BDOF blocks): done implicitly by
+ * every other slot, needed explicitly only before reading the recorder directly. */
+void ovhip_shim_flush_pending(struct OVCTUDec *ctudec);
+/* First error latched since the picture began (0 = none; negative OVHIP_E*): the slots return void. */
+int  ovhip_shim_last_error(const struct OVCTUDec *ctudec);
+/* The refined motion vectors of refined units [first, first + n) (4 int32 each: mv0x, mv0y, mv1x, mv1y), as
+ * ovhip_job_refined_mvs() returns them: written into the decoder's TMVP motion storage where the reference's caller
+ * stores what rcn_dmvr_mv_refine returned (vcl_coding_unit.c:2629-2645; drv_lines.c:270-330).  Called by the shim's
+ * own alf.rcn_alf_filter_line hook; exposed for the record-only harness. */
+int  ovhip_shim_apply_refined_mvs(struct OVCTUDec *ctudec, const int32_t *mv, size_t first, size_t n);
+/* Picture-level side information the filter slots collected (valid until the next picture begins). */
+struct ovhip_sao_ctu;
+struct ovhip_alf_ctu;
+struct ovhip_lmcs_luts;
+const struct ovhip_sao_ctu *ovhip_shim_sao_params(const struct OVCTUDec *ctudec, size_t *n_ctu);
+const struct ovhip_alf_ctu *ovhip_shim_alf_params(const struct OVCTUDec *ctudec, size_t *n_ctu);
+const int16_t *ovhip_shim_alf_table(const struct OVCTUDec *ctudec, int which /* 0 luma coeff, 1 luma clip, 2 chroma coeff, 3 chroma clip, 4 cc */, size_t *n);
+const struct ovhip_lmcs_luts *ovhip_shim_lmcs(const struct OVCTUDec *ctudec);
+void ovhip_shim_release(const struct OVCTUDec *ctudec);
+
+#endif

@@ -1,0 +1,128 @@
+"""GPU: the C-side per-picture flush (ovhip_job_*: page-locked recorder arrays -> async H2D -> launch chain -> D2H of the
+refined motion vectors) reproduces the oracle bit for bit, from any thread, and the eager per-row DMVR search returns the
+vectors the full pass finally uses."""
+import threading
+
+import numpy as np
+import pytest
+
+import oracle_pipeline
+from openvvc_amd import capi, engine, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(built_lib):
+    c = engine.Context(0)
+    yield c
+    c.close()
+
+
+def _check(wl, planes, what):
+    ref, mvs = oracle_pipeline.decode(wl, want_mvs=True)
+    for name, a, b in (("Y", planes[0], ref.y), ("Cb", planes[1], ref.cb), ("Cr", planes[2], ref.cr)):
+        assert np.array_equal(a, b), f"{what}: plane {name}: {int((a != b).sum())} samples differ"
+    return mvs
+
+
+@pytest.mark.parametrize("w,h,seed", [(416, 240, 0x266), (1920, 1080, 0x266)])
+def test_job_flush_matches_oracle(ctx, w, h, seed):
+    wl = synth.make_workload(w, h, seed)
+    job = engine.Job(ctx, w, h)
+    refs = [ctx.upload_pic(*r) for r in wl.refs]
+    intra = ctx.upload_pic(*wl.intra) if wl.intra is not None else None
+    dst = ctx.new_pic(w, h)
+    for rep in range(2):                       # the second flush reuses every device buffer
+        job.load_workload(wl)
+        job.flush(dst, refs, intra)
+        job.wait()
+        mvs = _check(wl, dst.download(), f"{w}x{h} flush {rep}")
+        assert np.array_equal(job.refined_mvs(), mvs)
+    st = job.stats()
+    assert st.n_launches >= 8 and st.h2d_bytes > wl.coefs.nbytes and st.d2h_bytes == 16 * len(wl.mcx_units)
+    assert st.n_edges_v > 0 and st.n_edges_h > 0
+    job.close()
+
+
+def test_job_eager_dmvr_rows(ctx):
+    """ovhip_job_dmvr_rows after a part of the refined units has been recorded: the search-only kernel returns for the
+    DMVR units exactly the vectors the full flush writes later (what the shim patches into the TMVP planes before a CTU
+    row is published)."""
+    w, h = 832, 480
+    wl = synth.make_workload(w, h, 3)
+    job = engine.Job(ctx, w, h)
+    refs = [ctx.upload_pic(*r) for r in wl.refs]
+    intra = ctx.upload_pic(*wl.intra) if wl.intra is not None else None
+    dst = ctx.new_pic(w, h)
+    job.begin()
+    ux = wl.mcx_units
+    half = len(ux) // 2
+    assert half > 20
+    job.rec.append_raw(capi.REC_MCX, ux[:half])
+    assert job.dmvr_rows(refs) == half
+    early = job.refined_mvs()[:half].copy()
+    job.rec.append_raw(capi.REC_MCX, ux[half:])
+    assert job.dmvr_rows(refs) == len(ux)
+    early2 = job.refined_mvs().copy()
+    # now the whole picture
+    job.load_workload(wl)
+    job.flush(dst, refs, intra)
+    job.wait()
+    final = job.refined_mvs()
+    is_dmvr = (ux["flags"] & 64) != 0
+    assert is_dmvr.sum() > 10
+    assert np.array_equal(early[is_dmvr[:half]], final[:half][is_dmvr[:half]])
+    assert np.array_equal(early2[is_dmvr], final[is_dmvr])
+    assert (final[is_dmvr] != np.stack([ux["mv0x"], ux["mv0y"], ux["mv1x"], ux["mv1y"]], axis=1)[is_dmvr]).any()
+    _check(wl, dst.download(), "after eager rows")
+    job.close()
+
+
+def test_context_used_from_another_thread(ctx):
+    """The HIP current device is per thread: every entry point re-selects the context's device (one context per decoder
+    frame thread, possibly created elsewhere)."""
+    w, h = 416, 240
+    wl = synth.make_workload(w, h, 9)
+    out = {}
+
+    def worker():
+        try:
+            job = engine.Job(ctx, w, h)
+            refs = [ctx.upload_pic(*r) for r in wl.refs]
+            intra = ctx.upload_pic(*wl.intra) if wl.intra is not None else None
+            dst = ctx.new_pic(w, h)
+            job.load_workload(wl)
+            job.flush(dst, refs, intra)
+            job.wait()
+            out["planes"] = dst.download()
+            job.close()
+        except Exception as e:          # noqa: BLE001
+            out["err"] = e
+
+    t = threading.Thread(target=worker)
+    t.start(); t.join()
+    assert "err" not in out, out.get("err")
+    _check(wl, out["planes"], "flush from a second thread")
+
+
+def test_stage_mask_and_filters_off(ctx):
+    """stages mask / SAO and ALF switched off: dst always holds the result of the last stage that ran."""
+    w, h = 416, 240
+    wl = synth.make_workload(w, h, 21)
+    job = engine.Job(ctx, w, h)
+    refs = [ctx.upload_pic(*r) for r in wl.refs]
+    intra = ctx.upload_pic(*wl.intra) if wl.intra is not None else None
+    dst = ctx.new_pic(w, h)
+    for stages, names in ((capi.STAGE_MC | capi.STAGE_ITX, ("mc", "itx")),
+                          (capi.STAGE_MC | capi.STAGE_ITX | capi.STAGE_DBF, ("mc", "itx", "dbf")),
+                          (capi.STAGE_MC | capi.STAGE_ITX | capi.STAGE_DBF | capi.STAGE_SAO, ("mc", "itx", "dbf", "sao"))):
+        job.load_workload(wl)
+        job.params.stages = stages
+        job.flush(dst, refs, intra)
+        job.wait()
+        ref = oracle_pipeline.decode(wl, stages=names)
+        got = dst.download()
+        for name, a, b in (("Y", got[0], ref.y), ("Cb", got[1], ref.cb), ("Cr", got[2], ref.cr)):
+            assert np.array_equal(a, b), f"stages {names}: plane {name} differs"
+    job.close()

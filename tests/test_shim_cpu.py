@@ -1,0 +1,192 @@
+"""CPU: the reference-side override block (shim/rcn_hip.c -> rcn_init_functions_hip) is pinned on the reference.
+
+The command streams the INSTALLED slots recorded (tests/golden/shim_*.ovg, see shim_cases.py) are executed by the oracle
+and compared with the bytes the reference's scalar slots produced for the same seeded decoder states (tests/golden/*.ovg).
+Also: the shim compiles against the reference's headers with its layout assertions (only where /root/reference exists)."""
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import golden_cases
+import golden_io
+import oracle_lib
+from oracle_lib import HostPic
+from openvvc_amd import capi
+from shim_cases import ShimStream
+
+ROOT = Path(__file__).resolve().parent.parent
+REF = Path("/root/reference/libovvc/rcn_structures.h")
+
+
+@pytest.mark.skipif(not REF.exists(), reason="the reference tree is only present in the build container")
+def test_shim_builds_against_reference_headers(built_lib):
+    """sizeof(struct RCNFunctions) == 5952 and the slot offsets are _Static_asserts in shim/rcn_hip.c; the library must
+    export the installer with the signature of rcn_init_functions()."""
+    subprocess.check_call(["make", "-C", str(ROOT / "shim")], stdout=subprocess.DEVNULL)
+    out = subprocess.run(["nm", "-D", "--defined-only", str(ROOT / "shim" / "_build" / "librcn_hip.so")], capture_output=True, text=True, check=True).stdout
+    for sym in ("rcn_init_functions_hip", "ovhip_shim_bind_recorder", "ovhip_shim_apply_refined_mvs"):
+        assert f" T {sym}" in out, sym
+
+
+@pytest.mark.skipif(not REF.exists(), reason="the reference tree is only present in the build container")
+def test_shim_fixtures_regenerate_identically(built_lib, tmp_path):
+    """The committed shim_*.ovg are what the harness produces from the current shim + recorder sources."""
+    subprocess.check_call(["make", "-C", str(ROOT / "oracle")], stdout=subprocess.DEVNULL)
+    subprocess.check_call([str(ROOT / "oracle" / "_ref" / "gen_golden"), str(tmp_path), "shim"], stderr=subprocess.DEVNULL)
+    for f in sorted((ROOT / "tests" / "golden").glob("shim_*.ovg")):
+        assert (tmp_path / f.name).read_bytes() == f.read_bytes(), f.name
+
+
+def _pred_pic(g):
+    return HostPic(128, 128, g["pred_y"].copy(), g["pred_cb"].copy(), g["pred_cr"].copy())
+
+
+def test_shim_tu_slots_match_reference(built_lib):
+    """tmp.rcn_tu_st / tmp.rcn_tu_c through the installed table: 425 TUs."""
+    g = golden_io.load("itx.ovg")
+    s = ShimStream("shim_itx.ovg")
+    assert s.n == g["desc"].shape[0] == 425
+    n_cmds = 0
+    for i in range(s.n):
+        d = capi.TuDesc.from_buffer_copy(g["desc"][i].tobytes())
+        c = s.case(i)
+        pic = _pred_pic(g)
+        oracle_lib.itx(pic, c["tb"], c["coef"])
+        n_cmds += len(c["tb"])
+        x0, y0, w, h = d.x0, d.y0, 1 << d.log2_tb_w, 1 << d.log2_tb_h
+        eo = g["exp_off"][i]
+        if d.tree == 0:
+            rects = [(0, x0, y0, w, h, int(eo[0])), (1, x0 >> 1, y0 >> 1, w >> 1, h >> 1, int(eo[1])), (2, x0 >> 1, y0 >> 1, w >> 1, h >> 1, int(eo[2]))]
+        else:
+            rects = [(1, x0, y0, w, h, int(eo[1])), (2, x0, y0, w, h, int(eo[2]))]
+        golden_cases.check_rects(pic, rects, g["exp"], f"shim tu case {i} tree={d.tree}")
+    assert n_cmds > 600
+
+
+def test_shim_transform_tree_slot_matches_reference(built_lib):
+    g = golden_io.load("itx.ovg")
+    s = ShimStream("shim_itx_tree.ovg")
+    assert s.n == g["tt_desc"].shape[0] == 12
+    for i in range(s.n):
+        d = capi.TtDesc.from_buffer_copy(g["tt_desc"][i].tobytes())
+        c = s.case(i)
+        pic = _pred_pic(g)
+        oracle_lib.itx(pic, c["tb"], c["coef"])
+        w, h = 1 << d.log2_w, 1 << d.log2_h
+        eo = g["tt_exp_off"][i]
+        golden_cases.check_rects(pic, [(0, 0, 0, w, h, int(eo[0])), (1, 0, 0, w >> 1, h >> 1, int(eo[1])), (2, 0, 0, w >> 1, h >> 1, int(eo[2]))],
+                                 g["exp"], f"shim transform tree {i}")
+
+
+def _pu_rects(d, exp_off, i):
+    w, h = 1 << d.log2_w, 1 << d.log2_h
+    return [(0, d.x0, d.y0, w, h, int(exp_off[i, 0])), (1, d.x0 >> 1, d.y0 >> 1, w >> 1, h >> 1, int(exp_off[i, 1])),
+            (2, d.x0 >> 1, d.y0 >> 1, w >> 1, h >> 1, int(exp_off[i, 2]))]
+
+
+def _blank(rw, rh):
+    dst = HostPic(rw, rh)
+    dst.y[:] = 0xABAB; dst.cb[:] = 0xABAB; dst.cr[:] = 0xABAB
+    return dst
+
+
+def test_shim_mcp_slots_match_reference(built_lib):
+    """rcn_mcp_b / rcn_mcp_b_l / rcn_mcp_b_c through the installed table: 750 PUs."""
+    refs, descs, exp_off, exp = golden_cases.mc_cases()
+    s = ShimStream("shim_mc.ovg")
+    assert s.n == len(descs) == 750
+    srefs = s.refs(refs)
+    for i, d in enumerate(descs):
+        dst = _blank(refs[0].w, refs[0].h)
+        oracle_lib.mc(dst, srefs, s.case(i)["mc"])
+        golden_cases.check_rects(dst, _pu_rects(d, exp_off, i), exp, f"shim mc case {i} dir={d.inter_dir} planes={d.planes}")
+
+
+def test_shim_refined_slots_match_reference(built_lib):
+    """rcn_bdof_mcp_l (+ rcn_mcp_b_c) and rcn_dmvr_mv_refine through the installed table, incl. the refined vectors; the
+    harness has already checked that ovhip_shim_apply_refined_mvs writes exactly the TMVP plane entries the reference's
+    caller + tmvp_store_mv write (mv_patch_checked = entries compared per DMVR case)."""
+    refs, descs, exp_off, exp, exp_mv = golden_cases.mcx_cases()
+    s = ShimStream("shim_mcx.ovg")
+    assert s.n == len(descs) == 450
+    srefs = s.refs(refs)
+    n_dmvr = 0
+    for i, d in enumerate(descs):
+        c = s.case(i)
+        dst = _blank(refs[0].w, refs[0].h)
+        oracle_lib.mc(dst, srefs, c["mc"])
+        mv = oracle_lib.mc_ex(dst, srefs, c["mcx"])
+        golden_cases.check_rects(dst, _pu_rects(d, exp_off, i), exp, f"shim mcx case {i} refine={d.refine}")
+        if d.refine & capi.PU_DMVR:
+            want = exp_mv[int(exp_off[i, 3]) // 4:int(exp_off[i, 3]) // 4 + len(c["mcx"])]
+            assert np.array_equal(mv, want), f"shim mcx case {i}: refined MVs differ"
+            n_dmvr += 1
+    chk = s.g["mv_patch_checked"]
+    assert len(chk) == n_dmvr and chk.min() >= 1 and chk.sum() > 600
+
+
+def test_shim_affine_slots_match_reference(built_lib):
+    """The affine drivers' per-4x4 rcn_mcp_b_l / rcn_prof_mcp_b_l and per-8x8 rcn_mcp_b_c calls, collected back into CUs."""
+    refs, cases, exp_off, exp = golden_cases.mca_cases()
+    s = ShimStream("shim_mca.ovg")
+    assert s.n == len(cases) == 332
+    srefs = s.refs(refs)
+    for i, (d, _, _) in enumerate(cases):
+        c = s.case(i)
+        assert len(c["mc"]) == 0 and len(c["aff"]) >= 1
+        dst = _blank(refs[0].w, refs[0].h)
+        oracle_lib.mca(dst, srefs, c["aff"], c["side"])
+        golden_cases.check_rects(dst, _pu_rects(d, exp_off, i), exp, f"shim mca case {i} dir={d.inter_dir} prof={d.prof_dir}")
+
+
+def test_shim_gpm_ciip_slots_match_reference(built_lib):
+    refs, intra, descs, modes, n_gpm, exp_off, exp = golden_cases.gpm_cases()
+    s = ShimStream("shim_gpm.ovg")
+    assert s.n == len(descs)
+    srefs = s.refs(refs)
+    for i, d in enumerate(descs):
+        c = s.case(i)
+        dst = _blank(refs[0].w, refs[0].h)
+        oracle_lib.mc(dst, srefs, c["mc"])
+        if i >= n_gpm:
+            assert len(c["ciip"]) == 1
+            oracle_lib.ciip(dst, intra, c["ciip"])
+        golden_cases.check_rects(dst, _pu_rects(d, exp_off, i), exp, f"shim {'gpm' if i < n_gpm else 'ciip'} case {i}")
+
+
+def test_shim_lmcs_slots_match_reference(built_lib):
+    """rcn_init_lmcs -> device tables; rcn_lmcs_compute_chroma_scale -> regions whose device-derived scale equals the
+    reference's."""
+    pic_y, sets, regions, _ = golden_cases.lmcs_cases()
+    g = golden_io.load("shim_lmcs.ovg")
+    assert g["luts"].shape[0] == len(sets)
+    reg = np.frombuffer(g["region"].tobytes(), dtype=capi.LMCS_REGION_DTYPE)
+    assert len(reg) == len(regions)
+    h, w = pic_y.shape
+    for si, (_, want) in enumerate(sets):
+        assert g["luts"][si].tobytes() == bytes(want), f"LMCS tables of set {si} differ"
+        sel = np.nonzero(regions[:, 0] == si)[0]
+        scales = oracle_lib.lmcs_scale(HostPic(w, h, pic_y.copy()), reg[sel], want)
+        assert np.array_equal(scales, regions[sel, 5].astype(np.int16)), f"set {si}"
+
+
+def test_shim_filter_slots_match_reference(built_lib):
+    """df.rcn_dbf_ctu(_truncated): the edge lists equal the ones the reference-pinned recorder test derives; sao / alf
+    lines: the captured parameters equal the reference's SAOParamsCtu / ALFParamsCtu / RCNALF contents."""
+    gd = golden_io.load("shim_dbf.ovg")
+    for i, (_, planes, _) in enumerate(golden_cases.dbf_cases()):
+        for d, name in ((0, "v"), (1, "h")):
+            want, offs = planes["edges"][d]
+            got = np.frombuffer(gd[f"p{i}_edges_{name}"].tobytes(), dtype=capi.DBF_EDGE_DTYPE)
+            assert np.array_equal(got, want), f"dbf picture {i} dir {name}"
+        o = gd[f"p{i}_offsets"]
+        assert o[0] == planes["beta_offset"] and o[8] == planes["tc_offset"]
+    gs, gr = golden_io.load("shim_sao.ovg"), golden_io.load("sao.ovg")
+    for i in range(3):
+        assert gs[f"p{i}_params"].tobytes() == gr[f"p{i}_params"].tobytes(), f"sao picture {i}"
+    ga, gr = golden_io.load("shim_alf.ovg"), golden_io.load("alf.ovg")
+    for i in range(3):
+        for k in ("ctus", "luma_coeff", "luma_clip", "chroma_coeff", "chroma_clip", "cc_coeff"):
+            assert ga[f"p{i}_{k}"].tobytes() == gr[f"p{i}_{k}"].tobytes(), f"alf picture {i} {k}"
