@@ -1,24 +1,28 @@
 #!/usr/bin/env python
-"""bench.py -- decoded frames/s of the MI355X rcn back-end on one synthetic recorded picture.
+"""bench.py -- decoded frames/s of the MI355X rcn back-end, one DECODE STEP per picture.
 
-A "step" is one pass of the whole implemented hot path (prediction -> residual -> in-loop filters,
-one frame-wide HIP launch per stage) over one 3840x2160 10-bit 4:2:0 recorded inter picture
-(BASELINE.json configs[3]) whose reference pictures, command buffers and coefficient arena are
-already resident in HBM.  `--in-flight S` (default 2) pictures are kept in flight per GPU, each on its own HIP stream with its
-own buffers and no dependency between them -- the frame-level parallelism of the reference's frame threads (`--framethr`,
-ovdec.c:188-248; in a random-access GOP at least every second picture is a non-reference picture): the launch tails, ramps
-and latency-bound kernels of one picture are filled by the other's.  N > 1: one process per GPU, every rank decodes its own picture (frame
-sharding, `--framethr` style, weak scaling); after each step the rank pushes its reconstructed
-picture to the next rank over RCCL point-to-point, where it becomes a reference picture of the
-next step (the reference-picture exchange of SURVEY.md 8e) -- no collective on the data path.
+A "step" is what the reference-side shim does at the end of a parsed picture (shim/rcn_hip.c flush_picture ->
+ovhip_job_flush, all in C): asynchronous H2D of the picture's recorded command buffers + coefficient arena + deblocking
+edge lists + filter parameters out of page-locked memory, the launch chain of the whole rcn path (prediction incl.
+BDOF / DMVR / affine-PROF / GPM / CIIP + LMCS, inverse quantisation / LFNST / transforms + residual, deblocking, SAO,
+ALF / CC-ALF), and the D2H of the DMVR-refined motion vectors.  The workload is a synthetic recorded 3840x2160 10-bit 4:2:0
+random-access inter picture (BASELINE.json configs[3]).
+
+Nothing is replayed out of cache: the steps rotate over `--sets` picture sets (reference pictures, intra picture,
+destination, command buffers; distinct addresses, `--contents` distinct recorded pictures), sized so that the working
+set is several times the 256 MiB Infinity Cache.  `--in-flight S` pictures are in flight per GPU (one HIP stream + one
+host thread each: the reference's frame threads, ovdec.c:188-248).
+
+N > 1: one process per GPU, frames sharded --framethr style; reference pictures move between ranks with RCCL
+point-to-point only where the GOP's reference lists need them (openvvc_amd/gop.py); no collective on the data path.
 
 Prints ONE JSON line on rank 0 (contract in the task statement).
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys
+import threading
 import time
 from pathlib import Path
 
@@ -30,22 +34,60 @@ sys.path.insert(0, str(ROOT / "tests"))
 
 HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
+KNAME = {"mc": "k_mc2", "mcxa": "k_mcxa", "itx_luma": "k_itx_all (luma commands)", "lmcs_scale": "k_lmcs_scale",
+         "itx_chroma": "k_itx_all (chroma commands + inverse-LMCS rider)", "dbf": "k_dbf_list<0> + k_dbf_list<1>",
+         "sao": "k_sao", "alf": "k_alf", "intra": "k_intra_level (all levels)", "h2d": "H2D copies"}
+
+
+def algorithmic_bytes(wl, S):
+    """SURVEY 8d terms split per launch group, from the actual command buffers of one recorded picture."""
+    from openvvc_amd import capi
+    tb = wl.tb_cmds
+    area = lambda a: int((a["w"].astype(np.int64) * a["h"]).sum()) if a is not None and len(a) else 0
+    nref_area = lambda a: int((a["w"].astype(np.int64) * a["h"] * np.where(a["dir"] == 3, 2, 1)).sum()) if a is not None and len(a) else 0
+
+    def itx_bytes(c):
+        n_samples = 1 << (c["log2_w"].astype(np.int64) + c["log2_h"])
+        raster = (c["kind"] & 0x80) != 0
+        sbs = np.array([bin(int(m)).count("1") for m in c["sig_sb_map"]], np.int64)
+        coef = np.where(raster, 2 * n_samples, 32 * sbs).sum()
+        covered = n_samples.sum() + n_samples[c["plane2"] != 0xff].sum()
+        return int(coef + c.nbytes + 2 * 2 * covered)
+
+    fused = wl.mc_units[((wl.mc_units["flags"] & 128) == 0) & (wl.mc_units["aux"] != 0)]
+    ev, eh = capi.dbf_compact(wl.dbf_planes, 0), capi.dbf_compact(wl.dbf_planes, 1)
+    alf_tables = sum(np.asarray(wl.alf[k]).nbytes for k, _ in capi.ALF_TABLES)
+    return {
+        "mc": 3 * (nref_area(wl.mc_units) + area(wl.mc_units) + area(fused)) + wl.mc_units.nbytes,
+        "mcxa": 3 * 3 * area(wl.mcx_units) + wl.mcx_units.nbytes + 16 * len(wl.mcx_units)
+                + 3 * (nref_area(wl.aff_units) + area(wl.aff_units)) + wl.aff_units.nbytes + wl.aff_side.nbytes,
+        "itx_luma": itx_bytes(tb[:wl.n_luma_cmds]),
+        "lmcs_scale": len(wl.lmcs_regions) * (128 * 2 + 8 + 2) if wl.lmcs_regions is not None else 0,
+        "itx_chroma": itx_bytes(tb[wl.n_luma_cmds:]) + (2 * 2 * wl.w * wl.h if wl.lmcs is not None else 0),
+        "dbf": 2 * S + ev.nbytes + eh.nbytes,
+        "sao": 2 * S + wl.sao_params.nbytes,
+        "alf": 2 * S + alf_tables,
+    }
+
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=240)
+    ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--seed", type=int, default=0x266)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=2, help="independent pictures in flight per GPU (one HIP stream each)")
+    ap.add_argument("--in-flight", type=int, default=2, help="pictures in flight per GPU (one HIP stream + one host thread each)")
+    ap.add_argument("--sets", type=int, default=6, help="picture sets the steps rotate over (distinct addresses; working set = sets x ~130 MB at 4K)")
+    ap.add_argument("--contents", type=int, default=2, help="distinct recorded pictures (seeds) among the sets")
+    ap.add_argument("--host-threads", type=int, default=-1, help="host threads issuing the flushes (-1: one per picture in flight)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from openvvc_amd import capi, engine, frames, synth
+    from openvvc_amd import capi, engine, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -59,17 +101,17 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     W, H = args.width, args.height
-    wl = synth.make_workload(W, H, args.seed + rank)
-    S = wl.frame_bytes
+    S = max(1, args.in_flight)
+    K = max(S, (args.sets + S - 1) // S * S)
+    wls = [synth.make_workload(W, H, args.seed + 1000 * c + rank) for c in range(max(1, min(args.contents, K)))]
+    FB = wls[0].frame_bytes
 
-    # Every picture slot runs on a torch-owned stream made current while it is driven, so that torch.cuda.Event brackets
-    # its kernels and RCCL point-to-point ops order against them (a NULL stream handle would make the engine create a
-    # private stream the events cannot see).
-    class Slot:
-        pass
+    # ---- picture sets: every set has its own reference pictures, intra picture, destination and job (= command buffers,
+    # tmp picture), at distinct addresses.  Pictures live in torch tensors so that RCCL can move them (N > 1).
+    ctxs = [engine.Context(local_rank) for _ in range(S)]
+    ext = [torch.cuda.ExternalStream(c.stream, device=dev) for c in ctxs]
 
     def torch_pic(ctx, planes=None):
-        """A picture stored in torch int16 tensors (so RCCL can move it), viewed as ovhip_pic."""
         t = torch.empty(H * W * 3 // 2, dtype=torch.int16, device=dev)
         ysz, csz = H * W, (H // 2) * (W // 2)
         s = capi.Pic(t.data_ptr(), t.data_ptr() + 2 * ysz, t.data_ptr() + 2 * (ysz + csz), W, H, W, W // 2)
@@ -78,197 +120,213 @@ def main():
             p.upload(*planes)
         return t, p
 
-    def make_slot():
-        sl = Slot()
-        sl.stream = torch.cuda.Stream(dev)
-        assert sl.stream.cuda_stream, "expected a non-default HIP stream"
-        torch.cuda.set_stream(sl.stream)
-        sl.ctx = engine.Context(local_rank, stream=sl.stream.cuda_stream)
-        sl.rp = engine.ResidentPicture(sl.ctx, wl)
-        # pictures that take part in the reference exchange live in torch tensors
-        sl.dst_t, sl.rp.dst = torch_pic(sl.ctx)
-        sl.ref1_t, sl.rp.refs[1] = torch_pic(sl.ctx, wl.refs[1])
-        sl.spare_t, sl.spare = torch_pic(sl.ctx, wl.refs[1])      # receive buffer for the exchanged reference picture
-        return sl
+    class Set:
+        pass
 
-    n_slots = max(1, args.in_flight)
-    slots = [make_slot() for _ in range(n_slots)]
-    rp = slots[0].rp
+    sets = []
+    for k in range(K):
+        st = Set()
+        st.slot = k % S
+        st.ctx = ctxs[st.slot]
+        st.wl = wls[k % len(wls)]
+        st.job = engine.Job(st.ctx, W, H)
+        st.job.load_workload(st.wl)
+        st.ref_t, st.refs = zip(*[torch_pic(st.ctx, r) for r in st.wl.refs])
+        st.ref_t, st.refs = list(st.ref_t), list(st.refs)
+        st.intra = torch_pic(st.ctx, st.wl.intra)[1] if st.wl.intra is not None else None
+        st.dst_t, st.dst = torch_pic(st.ctx)
+        st.spare_t, st.spare = torch_pic(st.ctx, st.wl.refs[1]) if world > 1 else (None, None)
+        sets.append(st)
     torch.cuda.synchronize(dev)
+    working_set = K * ((len(wls[0].refs) + 2 + (wls[0].intra is not None)) * FB)
 
-    # one entry per kernel launch of the frame; launches a picture has no work for are dropped
-    merged = bool(rp.mcx_units and rp.aff_units)            # k_mcxa: refined + affine units in one launch ("mcx" entry)
-    present = {"mcx": rp.mcx_units, "mca": rp.aff_units and not merged, "ciip": rp.ciip_units, "lmcs_scale": rp.lmcs_regions,
-               "lmcs_inv": rp.lmcs_bwd and not wl.tb_classes[3],      # else it rides in the chroma ITX launch
-               "itx_c": rp.n_luma < rp.tb_cmds.count}
-    stages = [k for k in rp.SUBSTAGES if present.get(k, True)]
-    evs = {k: [] for k in stages}
+    # ---- N > 1: frames shard across ranks; a decoded picture is pushed to the next rank, where it replaces reference 1
+    # of that slot's next picture -- issued on the slot's stream, never waited for on the host
+    def exchange(st):
+        with torch.cuda.stream(ext[st.slot]):
+            ops = [dist.P2POp(dist.isend, st.dst_t, (rank + 1) % world), dist.P2POp(dist.irecv, st.spare_t, (rank - 1) % world)]
+            dist.batch_isend_irecv(ops)
+        st.ref_t[1], st.spare_t = st.spare_t, st.ref_t[1]
+        st.refs[1], st.spare = st.spare, st.refs[1]
 
-    def step(k, timed=(), overlap=False):
-        """Picture k (slot k mod S).  timed: names of the launches to bracket with HIP events (each pair costs ~7 us of
-        stream time).  overlap: put the independent launches of the prediction stage on side streams (measured slower,
-        see engine.py)."""
-        sl = slots[k % n_slots]
-        torch.cuda.set_stream(sl.stream)
-        pending = {}
+    def run_steps(first, n, resident=False):
+        """Steps [first, first + n): step i decodes picture set i mod K.  One host thread per picture in flight."""
+        def one(i):
+            st = sets[i % K]
+            st.job.params.stages = (capi.STAGE_ALL | capi.STAGE_RESIDENT) if resident else 0
+            st.job.flush(st.dst, st.refs, st.intra)
+            if world > 1:
+                exchange(st)
+        nthreads = S if args.host_threads < 0 else max(1, min(args.host_threads, S))
+        if nthreads == 1 or world > 1:
+            for i in range(first, first + n):
+                one(i)
+            return
+        errs = []
 
-        def hook(name, phase):
-            if name not in timed:
-                return
-            e = torch.cuda.Event(enable_timing=True)
-            e.record(sl.stream)
-            if phase == "begin":
-                pending[name] = e
-            else:
-                evs[name].append((pending.pop(name), e))
-
-        sl.rp.overlap = overlap
-        for name in sl.rp.STAGES:
-            sl.rp.run_stage(name, hook)
-        if world > 1:
-            # push the reconstructed picture to the rank that lists it as a reference (ring), receive
-            # ours into the spare buffer, then swap it in as reference 1 of this slot's next picture
-            frames.ring_exchange(dist, sl.dst_t, sl.spare_t, rank, world)
-            sl.ref1_t, sl.spare_t = sl.spare_t, sl.ref1_t
-            sl.rp.refs[1], sl.spare = sl.spare, sl.rp.refs[1]
+        def worker(slot):
+            try:
+                for i in range(first, first + n):
+                    if i % K % S == slot:
+                        one(i)
+            except Exception as e:          # noqa: BLE001
+                errs.append(e)
+        th = [threading.Thread(target=worker, args=(s,)) for s in range(S)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        if errs:
+            raise errs[0]
 
     def barrier():
         if world > 1:
             dist.barrier()
+        for c in ctxs:
+            c.sync()
         torch.cuda.synchronize(dev)
 
-    for k in range(args.warmup):
-        step(k)
-    # Untimed survey pass: every launch bracketed by events, to find the dominant kernel.  Bracketing all 11
-    # launches costs ~80 us of stream time per frame (measured), so the timed region below keeps the events
-    # of the dominant kernel only; the survey averages are reported as `survey_launch_us`.
-    barrier()
-    for _ in range(min(20, max(args.steps, 1))):
-        step(0, tuple(stages), overlap=False)       # one picture at a time on slot 0: isolated launch durations
-    barrier()
-    survey = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) * 1e-3 for k, v in evs.items()}
-    dom = max(survey, key=survey.get)
-    if world > 1:                                   # all ranks bracket the same launch
-        pick = torch.tensor([stages.index(dom)], dtype=torch.int64, device=dev)
-        dist.broadcast(pick, 0)
-        dom = stages[int(pick.item())]
-    evs[dom] = []
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k, (dom,))
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(n, resident=False):
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(0, n, resident)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
 
+    def set_timer(name):
+        for st in sets:
+            st.job.time_stage(name)
+
+    def read_timer():
+        tot, cnt = 0.0, 0
+        for st in sets:
+            s, n = st.job.stage_time()
+            tot += s; cnt += n
+        return tot / max(cnt, 1)
+
+    run_steps(0, args.warmup)
+    barrier()
+
+    # ---- untimed survey IN THE TIMED CONFIGURATION (same rotation, same pictures in flight): each launch group bracketed
+    # in turn by a HIP-event pair on its stream (bracketing all of them at once would cost ~80 us of stream time per picture)
+    stats0 = sets[0].job.stats()
+    present = ["mc", "mcxa", "itx_luma", "lmcs_scale", "itx_chroma", "dbf", "sao", "alf", "h2d"]
+    if not stats0.n_regions:
+        present.remove("lmcs_scale")
+    survey = {}
+    for name in present:
+        set_timer(name)
+        run_steps(0, 2 * K)
+        barrier()
+        survey[name] = read_timer()
+    kern = {k: v for k, v in survey.items() if k != "h2d"}
+    dom = max(kern, key=kern.get)
+    if world > 1:
+        pick = torch.tensor([present.index(dom)], dtype=torch.int64, device=dev)
+        dist.broadcast(pick, 0)
+        dom = present[int(pick.item())]
+
+    # ---- timed region: EXACTLY --steps decode steps, only the dominant launch group bracketed
+    set_timer(dom)
+    dt = timed(args.steps)
+    dom_avg = read_timer()
+    set_timer(None)
     ms_per_step = dt * 1e3 / args.steps
     fps = world * args.steps / dt
 
+    # secondary figure: the round-1 measurement (device-resident replay of the same command buffers, no H2D / D2H)
+    dt_res = timed(min(args.steps, 120), resident=True)
+    fps_res = world * min(args.steps, 120) / dt_res
+
     if rank == 0:
-        # ---- per-kernel average launch duration (HIP events on the launch stream, timed region) ----
-        kdur = dict(survey)
-        kdur[dom] = float(np.mean([a.elapsed_time(b) for a, b in evs[dom]])) * 1e-3     # timed-region average
-        st = wl.stats
-        tb = wl.tb_cmds
-        area = lambda a: int((a["w"].astype(np.int64) * a["h"]).sum())
-        nref_area = lambda a: int((a["w"].astype(np.int64) * a["h"] * np.where(a["dir"] == 3, 2, 1)).sum())
-
-        def itx_bytes(c):
-            """coefficients actually stored + commands + read-modify-write of the covered samples"""
-            n_samples = 1 << (c["log2_w"].astype(np.int64) + c["log2_h"])
-            raster = (c["kind"] & 0x80) != 0
-            sbs = np.array([bin(int(m)).count("1") for m in c["sig_sb_map"]], np.int64)
-            coef = np.where(raster, 2 * n_samples, 32 * sbs).sum()
-            covered = n_samples.sum() + n_samples[c["plane2"] != 0xff].sum()
-            return int(coef + c.nbytes + 2 * 2 * covered)
-
-        # algorithmic bytes per launch (DESIGN.md "Measurement"): SURVEY 8d terms split per kernel.  A luma
-        # sample with its 4:2:0 chroma is 3 bytes; prediction reads nref reference blocks and writes one.
-        ciip_area = int((1 << (wl.ciip_units["log2_w"].astype(np.int64) + wl.ciip_units["log2_h"])).sum()) if len(wl.ciip_units) else 0
-        fused = wl.mc_units[((wl.mc_units["flags"] & 128) == 0) & (wl.mc_units["aux"] != 0)]      # CIIP blend fused into k_mc2
-        alg = {
-            "mcp": 3 * (nref_area(wl.mc_units) + area(wl.mc_units) + area(fused)) + wl.mc_units.nbytes,   # + planar samples read
-            "mcx": 3 * 3 * area(wl.mcx_units) + wl.mcx_units.nbytes + 16 * len(wl.mcx_units),
-            "mca": 3 * (nref_area(wl.aff_units) + area(wl.aff_units)) + wl.aff_units.nbytes + wl.aff_side.nbytes,
-            "ciip": 3 * 3 * ciip_area + wl.ciip_units.nbytes,              # intra read + inter read-modify-write
-            "itx_l": itx_bytes(tb[:rp.n_luma]),
-            "lmcs_scale": st["n_lmcs_regions"] * (128 * 2 + 8 + 2),
-            "itx_c": itx_bytes(tb[rp.n_luma:]),
-            "lmcs_inv": 2 * 2 * W * H,                                     # luma plane read + write
-            "dbf": 2 * S + rp.dbf_v.nbytes + rp.dbf_h.nbytes,                # read + write the picture, compact edge lists
-            "sao": 2 * S + wl.sao_params.nbytes,
-            "alf": 2 * S + rp.alf.nbytes,
-        }
-        if merged:
-            alg["mcx"] += alg.pop("mca")
-        if "lmcs_inv" not in kdur and rp.lmcs_bwd:
-            alg["itx_c"] += alg.pop("lmcs_inv")
-        alg = {k: v for k, v in alg.items() if k in kdur}
-        achieved = alg[dom] / kdur[dom] / 1e9
-        kname = {"mcp": "k_mc2", "mcx": "k_mcxa" if merged else "k_mcx", "mca": "k_mca", "ciip": "k_ciip", "itx_l": "k_itx_all (luma commands)",
-                 "itx_c": "k_itx_all (chroma commands + inverse-LMCS rider)", "lmcs_scale": "k_lmcs_scale", "lmcs_inv": "k_lmcs_inverse",
-                 "dbf": "k_dbf_list<0> + k_dbf_list<1>", "sao": "k_sao", "alf": "k_alf"}
-        # HBM traffic of the dominant kernel: rocprofv3 PMC passes of this same command cannot run inside the timed
-        # process, so the committed summary of the latest pass (profiles/traffic.json, per dispatch) is quoted when it
-        # was taken on this workload; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950.
+        algs = [algorithmic_bytes(wl, FB) for wl in wls]
+        use = np.bincount([k % len(wls) for k in range(K)], minlength=len(wls)).astype(np.float64)
+        use /= use.sum()
+        alg = {k: float(sum(u * a[k] for u, a in zip(use, algs))) for k in algs[0]}
+        alg = {k: v for k, v in alg.items() if k in kern}
+        achieved = alg[dom] / dom_avg / 1e9
         traffic = None
         try:
             tj = json.loads((ROOT / "profiles" / "traffic.json").read_text())
             if tj["workload"] == {"width": W, "height": H, "seed": args.seed}:
-                names = [n.strip() for n in kname[dom].split("(")[0].split("+")]
+                names = [n.strip() for n in KNAME[dom].split("(")[0].split("+")]
                 ks = [tj["kernels"][n] for n in names]
                 traffic = int(sum(2 * k["fetch_kib"] + k["write_kib"] for k in ks) * 1024)
         except (OSError, KeyError, ValueError):
             traffic = None
-        # `achieved` is what the spec asks for: algorithmic bytes / the launch duration seen in the timed region -- with
-        # S > 1 pictures in flight the kernel shares the chip with the other pictures' kernels, so its own launch stretches
-        # while the chip delivers more frames; `isolated_*` is the same kernel alone on the chip (survey pass).
-        roofline = {"bound": "hbm", "kernel": kname[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+        roofline = {"bound": "hbm", "kernel": KNAME[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                    "avg_launch_us": round(kdur[dom] * 1e6, 2),
-                    "isolated_launch_us": round(survey[dom] * 1e6, 2),
-                    "isolated_frac": round(alg[dom] / survey[dom] / 1e9 / HBM_PEAK_GBPS, 5),
+                    "avg_launch_us": round(dom_avg * 1e6, 2),
+                    "picked_from": "survey in the timed configuration (same rotation and pictures in flight)",
                     "survey_launch_us": {k: round(v * 1e6, 2) for k, v in survey.items()},
-                    "algorithmic_bytes": {k: int(v) for k, v in alg.items()}}
+                    "frac_per_kernel": {k: round(alg[k] / kern[k] / 1e9 / HBM_PEAK_GBPS, 5) for k in alg},
+                    "algorithmic_bytes": {k: int(v) for k, v in alg.items()},
+                    "frame_frac": round(sum(alg.values()) * fps / world / 1e9 / HBM_PEAK_GBPS, 5)}
 
         cpu = None
         if not args.no_cpu_baseline:
             import oracle_pipeline
-            reps, tc = 0, 0.0
-            while tc < 10.0 and reps < 64:                     # ~10 s of scalar CPU work
-                t1 = time.perf_counter()
-                oracle_pipeline.decode(wl)
-                tc += time.perf_counter() - t1
-                reps += 1
-            cpu = {"value": round(reps / tc, 4), "unit": "frames/s", "cores": 1, "kind": "port",
-                   "sample": f"oracle/liboracle.so (scalar C restatement, 1 thread) decoding the same {W}x{H} "
-                             f"recorded picture {reps}x in {tc:.2f} s on this box's host CPU "
-                             f"({os.cpu_count()} logical cores present)"}
+            wl0 = wls[0]
+            t1 = time.perf_counter()
+            oracle_pipeline.decode(wl0)
+            t_one = time.perf_counter() - t1
+            # all host cores: frame-level parallelism (one picture per thread, the reference's --framethr), bounded sample
+            ncpu = os.cpu_count() or 1
+            nthr = max(1, min(ncpu, 64))
+            t1 = time.perf_counter()
+            th = [threading.Thread(target=oracle_pipeline.decode, args=(wl0,)) for _ in range(nthr)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+            t_all = time.perf_counter() - t1
+            cpu = {"value": round(nthr / t_all, 3), "unit": "frames/s", "cores": nthr, "kind": "port",
+                   "value_1_thread": round(1.0 / t_one, 4),
+                   "sample": f"oracle/liboracle.so (scalar C restatement of the rcn path) decoding the same {W}x{H} recorded "
+                             f"picture: once on 1 thread ({t_one:.2f} s), then {nthr} pictures on {nthr} threads, one picture "
+                             f"per thread as the reference's frame threads do ({t_all:.2f} s); {ncpu} logical cores present",
+                   "calibration": _calibration()}
 
+        st = wls[0].stats
+        js = sets[0].job.stats()
         out = {
-            "metric": "decoded frames/sec, full rcn back-end (MC incl. BDOF/DMVR/affine-PROF/GPM/CIIP + LMCS + inverse "
-                      "transform + deblocking + SAO + ALF/CC-ALF), 4K 10-bit RA recorded picture, bit-exact vs oracle",
+            "metric": "decoded frames/sec, full rcn back-end decode step (H2D of the recorded picture + MC incl. BDOF/DMVR/"
+                      "affine-PROF/GPM/CIIP + LMCS + inverse transform + deblocking + SAO + ALF/CC-ALF + D2H of refined MVs), "
+                      "4K 10-bit RA recorded picture, bit-exact vs oracle",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u16 samples / int16 coefficients / int32 accumulate", "data": "synthetic",
-            "config": {"workload": f"{W}x{H} 10-bit 4:2:0 synthetic recorded inter picture (BASELINE configs[3]), "
-                                   f"seed {hex(args.seed)}, stages {'+'.join(stages)}",
+            "config": {"workload": f"{W}x{H} 10-bit 4:2:0 synthetic recorded inter picture (BASELINE configs[3]), seeds "
+                                   f"{[hex(w.seed) for w in wls]}, per-picture flush in C (ovhip_job_flush)",
+                       "h2d_bytes_per_step": int(js.h2d_bytes), "d2h_bytes_per_step": int(js.d2h_bytes),
+                       "launches_per_step": int(js.n_launches), "h2d_copies_per_step": int(js.n_h2d),
+                       "distinct_pictures": K, "distinct_contents": len(wls), "working_set_bytes": int(working_set),
+                       "pictures_in_flight_per_gpu": S,
+                       "host_threads": 1 if world > 1 else (S if args.host_threads < 0 else args.host_threads),
+                       "recorder_in_timed_region": False,
                        "n_cu": st["n_cu"], "cu_modes": st["cu_modes"], "n_mc_units": st["n_mc_units"],
                        "n_mcx_units": st["n_mcx_units"], "n_aff_units": st["n_aff_units"], "n_tb_cmds": st["n_tb_cmds"],
                        "r_bar": round(st["r_bar"], 3), "coef_bytes": st["coef_bytes"],
                        "frame_algorithmic_bytes": int(sum(alg.values())),
-                       "pictures_in_flight_per_gpu": n_slots,
-                       "parallelism": f"frames x{world}" + (" + RCCL p2p reference exchange" if world > 1 else "")
-                                      + f", {n_slots} independent pictures in flight per GPU (one HIP stream each)"},
+                       "resident_replay_fps": round(fps_res, 2),
+                       "parallelism": f"frames x{world}" + (" + RCCL p2p reference push on the picture's stream" if world > 1 else "")
+                                      + f", {S} pictures in flight per GPU"},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def _calibration():
+    """Reference scalar C vs the oracle port on identical slot-level cases, timed in the build container (committed; the
+    reference does not travel to the GPU box)."""
+    try:
+        return json.loads((ROOT / "profiles" / "cpu_calibration.json").read_text())
+    except (OSError, ValueError):
+        return None
 
 
 if __name__ == "__main__":

@@ -641,7 +641,8 @@ typedef struct ovhip_job ovhip_job;
 
 enum {                                   /* ovhip_job_params.stages (0 = all) */
     OVHIP_STAGE_MC = 1, OVHIP_STAGE_ITX = 2, OVHIP_STAGE_DBF = 4, OVHIP_STAGE_SAO = 8, OVHIP_STAGE_ALF = 16,
-    OVHIP_STAGE_INTRA = 32
+    OVHIP_STAGE_INTRA = 32,
+    OVHIP_STAGE_RESIDENT = 0x40000000    /* measurement only: no H2D / D2H, the device copies of the previous flush are replayed */
 };
 
 typedef struct ovhip_job_params {        /* picture-level side information; HOST pointers, copied by ovhip_job_flush */
@@ -678,6 +679,12 @@ const int32_t *ovhip_job_refined_mvs(ovhip_job *job, size_t *n_units);
  * returns the vectors are in ovhip_job_refined_mvs()[first..].  Returns the new `first` (= unit count) or <0. */
 int64_t ovhip_job_dmvr_rows(ovhip_job *job, const ovhip_pic *refs, uint32_t n_refs);
 int  ovhip_job_last_stats(const ovhip_job *job, ovhip_job_stats *out);
+/* Measurement: bracket ONE launch group of every following flush with a HIP-event pair on the launch stream (stage -1:
+ * off) and read back the accumulated duration.  A pair costs a few microseconds of stream time, hence one at a time. */
+enum { OVHIP_TIME_MC = 0, OVHIP_TIME_MCXA, OVHIP_TIME_ITX_LUMA, OVHIP_TIME_LMCS_SCALE, OVHIP_TIME_ITX_CHROMA, OVHIP_TIME_DBF,
+       OVHIP_TIME_SAO, OVHIP_TIME_ALF, OVHIP_TIME_INTRA, OVHIP_TIME_H2D, OVHIP_TIME_COUNT };
+int  ovhip_job_time_stage(ovhip_job *job, int stage);
+int  ovhip_job_stage_time(ovhip_job *job, double *sum_ms, uint64_t *count);
 
 #ifdef __cplusplus
 }

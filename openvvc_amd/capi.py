@@ -170,7 +170,9 @@ class JobStats(C.Structure):
 
 
 REC_TB, REC_COEF, REC_MC, REC_MCX, REC_AFF, REC_SIDE, REC_REGION, REC_CIIP, REC_EDGE_V, REC_EDGE_H, REC_ITASK = range(11)
+TIME_STAGES = ("mc", "mcxa", "itx_luma", "lmcs_scale", "itx_chroma", "dbf", "sao", "alf", "intra", "h2d")
 STAGE_MC, STAGE_ITX, STAGE_DBF, STAGE_SAO, STAGE_ALF, STAGE_INTRA = 1, 2, 4, 8, 16, 32
+STAGE_ALL, STAGE_RESIDENT = 63, 0x40000000
 
 
 def dbf_plane_shapes(w4: int, h4: int) -> dict:
@@ -308,6 +310,8 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_job_refined_mvs": (vp, [vp, P(C.c_size_t)]),
         "ovhip_job_dmvr_rows": (C.c_int64, [vp, P(Pic), u32]),
         "ovhip_job_last_stats": (C.c_int, [vp, P(JobStats)]),
+        "ovhip_job_time_stage": (C.c_int, [vp, C.c_int]),
+        "ovhip_job_stage_time": (C.c_int, [vp, P(C.c_double), P(C.c_uint64)]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)          # AttributeError = missing export: fail loudly
@@ -327,7 +331,7 @@ EXPORTED_SYMBOLS = [
     "ovhip_pic_download", "ovhip_itx_launch", "ovhip_mc_launch",
     "ovhip_rec_create_ex", "ovhip_rec_set_dense_dbf_planes", "ovhip_rec_dbf_edges", "ovhip_dbf_launch_edges_ex",
     "ovhip_dmvr_search_launch", "ovhip_rec_append_raw", "ovhip_rec_set_dbf_offsets", "ovhip_job_create", "ovhip_job_destroy", "ovhip_job_recorder", "ovhip_job_begin",
-    "ovhip_job_flush", "ovhip_job_wait", "ovhip_job_refined_mvs", "ovhip_job_dmvr_rows", "ovhip_job_last_stats",
+    "ovhip_job_flush", "ovhip_job_wait", "ovhip_job_refined_mvs", "ovhip_job_dmvr_rows", "ovhip_job_last_stats", "ovhip_job_time_stage", "ovhip_job_stage_time",
 ]
 
 

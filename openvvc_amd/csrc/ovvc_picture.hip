@@ -35,7 +35,12 @@ struct ovhip_job {
     size_t dmvr_first;                   // refined units [0, dmvr_first) already went through the eager search
     hipEvent_t ev_h2d, ev_done;
     int flushed;                         // ev_* recorded at least once
+    int resident;                        // this flush reuses the device copies of the previous one (OVHIP_STAGE_RESIDENT)
     ovhip_job_stats st;
+    // optional: HIP-event bracket around ONE launch group of the flush (ovhip_job_time_stage)
+    int t_stage;                         // OVHIP_TIME_* or -1
+    hipEvent_t t_ev[32][2]; uint8_t t_pending[32]; int t_next;
+    double t_sum_ms; uint64_t t_count;
 };
 
 namespace {
@@ -66,6 +71,7 @@ int dev_reserve(ovhip_job *j, int k, size_t bytes)
 int h2d(ovhip_job *j, int k, const void *host, size_t bytes)
 {
     if (!bytes) return OVHIP_OK;
+    if (j->resident) return j->dev[k].cap >= bytes ? OVHIP_OK : ov_fail(j->ctx, OVHIP_EINVAL, "resident flush before a full one", hipSuccess);
     int r = dev_reserve(j, k, bytes);
     if (r) return r;
     OV_HIP(j->ctx, hipMemcpyAsync(j->dev[k].p, host, bytes, hipMemcpyHostToDevice, j->ctx->stream));
@@ -86,6 +92,33 @@ int pinned_reserve(ovhip_job *j, void **p, size_t *cap, size_t bytes)
 }
 
 #define CHK(x) do { int r__ = (x); if (r__ != OVHIP_OK) return r__; } while (0)
+
+int t_collect(ovhip_job *j, int k)
+{
+    if (!j->t_pending[k]) return OVHIP_OK;
+    float ms = 0.f;
+    OV_HIP(j->ctx, hipEventSynchronize(j->t_ev[k][1]));
+    OV_HIP(j->ctx, hipEventElapsedTime(&ms, j->t_ev[k][0], j->t_ev[k][1]));
+    j->t_sum_ms += ms; j->t_count++;
+    j->t_pending[k] = 0;
+    return OVHIP_OK;
+}
+
+// bracket the launches of `stage` with an event pair on the launch stream (a pair costs a few us of stream time, which
+// is why only ONE stage is bracketed at a time)
+struct StageTimer {
+    ovhip_job *j; int k;
+    StageTimer(ovhip_job *job, int stage) : j(job), k(-1)
+    {
+        if (j->t_stage != stage) return;
+        k = j->t_next; j->t_next = (j->t_next + 1) % 32;
+        if (t_collect(j, k) != OVHIP_OK || hipEventRecord(j->t_ev[k][0], j->ctx->stream) != hipSuccess) k = -1;
+    }
+    ~StageTimer()
+    {
+        if (k >= 0 && hipEventRecord(j->t_ev[k][1], j->ctx->stream) == hipSuccess) j->t_pending[k] = 1;
+    }
+};
 
 // plane-wise device copy (the two pictures may come from different allocators)
 int copy_pic(ovhip_ctx *ctx, const ovhip_pic *d, const ovhip_pic *s)
@@ -111,7 +144,7 @@ int ovhip_job_create(ovhip_ctx *ctx, int32_t w, int32_t h, ovhip_job **out)
     *out = nullptr;
     ovhip_job *j = (ovhip_job *)calloc(1, sizeof(*j));
     if (!j) return OVHIP_ENOMEM;
-    j->ctx = ctx; j->w = w; j->h = h;
+    j->ctx = ctx; j->w = w; j->h = h; j->t_stage = -1;
     const ovhip_allocator al = { pinned_alloc, pinned_free, nullptr };
     j->rec = ovhip_rec_create_ex(w, h, &al);
     if (!j->rec) { free(j); return OVHIP_ENOMEM; }
@@ -132,6 +165,7 @@ void ovhip_job_destroy(ovhip_job *j)
     for (int k = 0; k < B_COUNT; ++k) if (j->dev[k].p) (void)hipFree(j->dev[k].p);
     if (j->tmp.y) (void)ovhip_pic_free(j->ctx, &j->tmp);
     pinned_free(nullptr, j->param_host); pinned_free(nullptr, j->mv_host);
+    for (int k = 0; k < 32; ++k) for (int q = 0; q < 2; ++q) if (j->t_ev[k][q]) (void)hipEventDestroy(j->t_ev[k][q]);
     if (j->ev_h2d) (void)hipEventDestroy(j->ev_h2d);
     if (j->ev_done) (void)hipEventDestroy(j->ev_done);
     ovhip_rec_destroy(j->rec);
@@ -172,6 +206,28 @@ int ovhip_job_last_stats(const ovhip_job *j, ovhip_job_stats *out)
 {
     if (!j || !out) return OVHIP_EINVAL;
     *out = j->st;
+    return OVHIP_OK;
+}
+
+int ovhip_job_time_stage(ovhip_job *j, int stage)
+{
+    if (!j || stage < -1 || stage >= OVHIP_TIME_COUNT) return OVHIP_EINVAL;
+    OV_DEVICE(j->ctx);
+    for (int k = 0; k < 32; ++k) {
+        CHK(t_collect(j, k));
+        for (int q = 0; q < 2 && stage >= 0; ++q)
+            if (!j->t_ev[k][q]) OV_HIP(j->ctx, hipEventCreate(&j->t_ev[k][q]));
+    }
+    j->t_stage = stage; j->t_sum_ms = 0.0; j->t_count = 0;
+    return OVHIP_OK;
+}
+
+int ovhip_job_stage_time(ovhip_job *j, double *sum_ms, uint64_t *count)
+{
+    if (!j || !sum_ms || !count) return OVHIP_EINVAL;
+    OV_DEVICE(j->ctx);
+    for (int k = 0; k < 32; ++k) CHK(t_collect(j, k));
+    *sum_ms = j->t_sum_ms; *count = j->t_count;
     return OVHIP_OK;
 }
 
@@ -222,6 +278,7 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
     if (log2_ctu < 5 || log2_ctu > 7) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_job_flush: log2_ctu_s", hipSuccess);
     const size_t n_ctu = (size_t)((j->w + (1 << log2_ctu) - 1) >> log2_ctu) * ((j->h + (1 << log2_ctu) - 1) >> log2_ctu);
     memset(&j->st, 0, sizeof(j->st));
+    j->resident = (stages & OVHIP_STAGE_RESIDENT) && pr->stages;
     ovhip_recorder *rec = j->rec;
 
     // ---- host: class split of the transform blocks (luma first; big / small), recorder arrays ----
@@ -277,6 +334,8 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
     }
 
     // ---- H2D (asynchronous DMA out of page-locked memory, in stage order so that prediction can start early) ----
+    {
+    StageTimer t_(j, OVHIP_TIME_H2D);
     CHK(h2d(j, B_PARAM, j->param_host, L.total));
     CHK(h2d(j, B_MC, mc, n_mc * sizeof(*mc)));
     if (n_mcx) {
@@ -297,6 +356,7 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
         CHK(h2d(j, B_EV, ev, n_ev * sizeof(*ev)));
         CHK(h2d(j, B_EH, eh, n_eh * sizeof(*eh)));
     }
+    }
     OV_HIP(ctx, hipEventRecord(j->ev_h2d, ctx->stream));
 
     const char *dp = (const char *)j->dev[B_PARAM].p;
@@ -306,15 +366,17 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
 
     // ---- prediction ----
     if (stages & OVHIP_STAGE_MC) {
-        CHK(ovhip_mc_launch(ctx, dst, refs, n_refs, (const ovhip_mc_unit *)j->dev[B_MC].p, (uint32_t)n_mc, d_fwd, intra));
+        { StageTimer t_(j, OVHIP_TIME_MC);
+        CHK(ovhip_mc_launch(ctx, dst, refs, n_refs, (const ovhip_mc_unit *)j->dev[B_MC].p, (uint32_t)n_mc, d_fwd, intra)); }
         j->st.n_launches += n_mc != 0;
         if (n_mcx || n_aff) {
+            StageTimer t_(j, OVHIP_TIME_MCXA);
             CHK(ovhip_mcxa_launch(ctx, dst, refs, n_refs, (const ovhip_mc_unit *)j->dev[B_MCX].p, (uint32_t)n_mcx,
                                   (int32_t *)j->dev[B_MV].p, (const ovhip_aff_unit *)j->dev[B_AFF].p, (uint32_t)n_aff,
                                   (const int32_t *)j->dev[B_SIDE].p, d_fwd));
             j->st.n_launches++;
         }
-        if (n_mcx) {
+        if (n_mcx && !j->resident) {
             // refined vectors back to the host as early as the stream allows (the decoder's TMVP field needs them)
             OV_HIP(ctx, hipMemcpyAsync(j->mv_host, j->dev[B_MV].p, n_mcx * 16, hipMemcpyDeviceToHost, ctx->stream));
             j->st.d2h_bytes += n_mcx * 16;
@@ -328,16 +390,19 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
         const ovhip_tb_cmd *d_tb = (const ovhip_tb_cmd *)j->dev[B_TB].p;
         const int16_t *d_coef = (const int16_t *)j->dev[B_COEF].p;
         if (cls[0] + cls[1]) {
+            StageTimer t_(j, OVHIP_TIME_ITX_LUMA);
             CHK(ovhip_itx_launch_classes(ctx, dst, d_tb, (uint32_t)cls[0], (uint32_t)cls[1], d_coef, nullptr));
             j->st.n_launches++;
         }
         if (n_reg) {
             if (!pr->lmcs) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_job_flush: chroma-scale regions recorded without LMCS tables", hipSuccess);
+            StageTimer t_(j, OVHIP_TIME_LMCS_SCALE);
             CHK(ovhip_lmcs_scale_launch(ctx, dst, (const ovhip_lmcs_region *)j->dev[B_REG].p, (uint32_t)n_reg, pr->lmcs,
                                         (int16_t *)j->dev[B_SCALE].p));
             j->st.n_launches++;
         }
         const ovhip_tb_cmd *d_tbc = d_tb + cls[0] + cls[1];
+        StageTimer t_(j, OVHIP_TIME_ITX_CHROMA);
         if (pr->lmcs && cls[3] && !ordered) {
             CHK(ovhip_itx_launch_chroma_lmcs(ctx, dst, d_tbc, (uint32_t)cls[2], (uint32_t)cls[3], d_coef, d_scales, d_bwd));
             j->st.n_launches++;
@@ -351,12 +416,14 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
     }
     // ---- in-loop filters ----
     if (stages & OVHIP_STAGE_DBF) {
+        StageTimer t_(j, OVHIP_TIME_DBF);
         CHK(ovhip_dbf_launch_edges_ex(ctx, dst, (const ovhip_dbf_edge *)j->dev[B_EV].p, (uint32_t)n_ev,
                                       (const ovhip_dbf_edge *)j->dev[B_EH].p, (uint32_t)n_eh, &offs));
         j->st.n_launches += (n_ev != 0) + (n_eh != 0);
     }
     // SAO writes tmp, ALF writes dst; with only one of the two the result is copied back so that dst always holds it
     if (sao_on) {
+        StageTimer t_(j, OVHIP_TIME_SAO);
         CHK(ovhip_sao_launch(ctx, &j->tmp, dst, (const ovhip_sao_ctu *)(dp + L.sao), log2_ctu));
         j->st.n_launches++;
     }
@@ -370,6 +437,7 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
         ap.class_scratch = (uint8_t *)j->dev[B_CLASS].p;
         ap.log2_ctu_s = log2_ctu;
         if (!sao_on) CHK(copy_pic(ctx, &j->tmp, dst));
+        StageTimer t_(j, OVHIP_TIME_ALF);
         CHK(ovhip_alf_launch(ctx, dst, &j->tmp, &ap));
         j->st.n_launches++;
     } else if (sao_on) {

@@ -455,3 +455,12 @@ class Job:
         s = capi.JobStats()
         self.lib.ovhip_job_last_stats(self.j, C.byref(s))
         return s
+
+    def time_stage(self, name: "str | None"):
+        self.ctx._chk(self.lib.ovhip_job_time_stage(self.j, capi.TIME_STAGES.index(name) if name else -1), "job_time_stage")
+
+    def stage_time(self):
+        """(sum of the bracketed launch group's durations in seconds, number of flushes measured)"""
+        s, n = C.c_double(), C.c_uint64()
+        self.ctx._chk(self.lib.ovhip_job_stage_time(self.j, C.byref(s), C.byref(n)), "job_stage_time")
+        return s.value * 1e-3, n.value

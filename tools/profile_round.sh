@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
-cmd="python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline"   # the timed region (pictures in flight) dominates the averages
+cmd="python $R/bench.py --steps 120 --warmup 12 --no-cpu-baseline"   # the timed region (pictures in flight) dominates the averages
 rocprofv3 --kernel-trace --stats -d $O/prof_${tag}_trace -o ${tag} -- $cmd > $O/${tag}_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $O/prof_${tag}_f -o ${tag} -- $cmd > $O/${tag}_f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/prof_${tag}_w -o ${tag} -- $cmd > $O/${tag}_w.log 2>&1
@@ -17,6 +17,6 @@ for k in trace f w sq1 sq2; do
   db=$(find $O/prof_${tag}_$k -name "*_results.db" | head -1)
   [ -n "$db" ] && python $R/tools/rocprof_summary.py $db > $O/${tag}_$k.txt 2>&1
 done
-python $R/bench.py --steps 200 --warmup 20 > $O/${tag}_bench.json 2> $O/${tag}_bench.err
+python $R/bench.py > $O/${tag}_bench.json 2> $O/${tag}_bench.err
 rm -rf $O/prof_${tag}_*
 ls -la $O | tail -12
