@@ -35,6 +35,7 @@ struct ovhip_job {
     size_t dmvr_first;                   // refined units [0, dmvr_first) already went through the eager search
     hipEvent_t ev_h2d, ev_done;
     int flushed;                         // ev_* recorded at least once
+    const void *packed_prev[16];         // where the last full flush placed the arrays that rode in the parameter block
     int resident;                        // this flush reuses the device copies of the previous one (OVHIP_STAGE_RESIDENT)
     ovhip_job_stats st;
     // optional: HIP-event bracket around ONE launch group of the flush (ovhip_job_time_stage)
@@ -317,10 +318,22 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
     L.cc = put(alf_on ? 2 * 4 * 8 * 2 : 0);
     L.fwd = put(pr->lmcs ? 2048 : 0);
     L.bwd = put(pr->lmcs ? 2048 : 0);
+    // every DMA has ~10 us of fixed latency on this platform (tools/micro/h2d_rate.py: 5.6 MB as one copy 107 us, as eleven
+    // 216 us): arrays below PACK_LIMIT ride in the staging block instead of getting a copy of their own
+    const size_t PACK_LIMIT = 128 << 10;
+    struct Small { const void *host; size_t bytes; int buf; size_t at; } small[] = {
+        { mcx, n_mcx * sizeof(*mcx), B_MCX, 0 }, { ciip, n_ciip * sizeof(*ciip), B_CIIP, 0 }, { aff, n_aff * sizeof(*aff), B_AFF, 0 },
+        { side, n_side * sizeof(*side), B_SIDE, 0 }, { reg, n_reg * sizeof(*reg), B_REG, 0 },
+        { ev, (stages & OVHIP_STAGE_DBF) ? n_ev * sizeof(*ev) : 0, B_EV, 0 }, { eh, (stages & OVHIP_STAGE_DBF) ? n_eh * sizeof(*eh) : 0, B_EH, 0 },
+    };
+    static_assert(B_COUNT <= 16, "packed_prev");
+    const void *packed[16] = { nullptr };           // device address of a packed array (inside the parameter block)
+    for (auto &sm : small) if (sm.bytes && sm.bytes <= PACK_LIMIT && !j->resident) sm.at = put(sm.bytes) + 1;
     L.total = o;
     if (L.total) {
         CHK(pinned_reserve(j, (void **)&j->param_host, &j->param_cap, L.total));
         char *ph = j->param_host;
+        for (auto &sm : small) if (sm.at) memcpy(ph + sm.at - 1, sm.host, sm.bytes);
         if (sao_on) memcpy(ph + L.sao, pr->sao, n_ctu * sizeof(ovhip_sao_ctu));
         if (alf_on) {
             memcpy(ph + L.alf_ctus, pr->alf_ctus, n_ctu * sizeof(ovhip_alf_ctu));
@@ -339,24 +352,23 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
     CHK(h2d(j, B_PARAM, j->param_host, L.total));
     CHK(h2d(j, B_MC, mc, n_mc * sizeof(*mc)));
     if (n_mcx) {
-        // (units that went through the eager per-row search are uploaded again with the rest: the list is small and the
-        // full kernel repeats the search with the identical result)
-        CHK(h2d(j, B_MCX, mcx, n_mcx * sizeof(*mcx)));
         CHK(dev_reserve(j, B_MV, n_mcx * 16));
         CHK(pinned_reserve(j, (void **)&j->mv_host, &j->mv_cap, n_mcx * 16));
     }
-    CHK(h2d(j, B_CIIP, ciip, n_ciip * sizeof(*ciip)));
-    CHK(h2d(j, B_AFF, aff, n_aff * sizeof(*aff)));
-    CHK(h2d(j, B_SIDE, side, n_side * sizeof(*side)));
     CHK(h2d(j, B_TB, tb, n_tb * sizeof(*tb)));
     CHK(h2d(j, B_COEF, coef, n_coef * sizeof(*coef)));
-    CHK(h2d(j, B_REG, reg, n_reg * sizeof(*reg)));
     if (n_reg) CHK(dev_reserve(j, B_SCALE, n_reg * 2));
-    if (stages & OVHIP_STAGE_DBF) {
-        CHK(h2d(j, B_EV, ev, n_ev * sizeof(*ev)));
-        CHK(h2d(j, B_EH, eh, n_eh * sizeof(*eh)));
+    // (refined units that went through the eager per-row search are uploaded again with the rest: the list is small and
+    // the full kernel repeats the search with the identical result)
+    for (auto &sm : small) {
+        if (j->resident) continue;
+        if (sm.at) packed[sm.buf] = (const char *)j->dev[B_PARAM].p + sm.at - 1;
+        else CHK(h2d(j, sm.buf, sm.host, sm.bytes));
     }
     }
+    // a resident replay re-uses the placement of the flush before it
+    if (j->resident) memcpy(packed, j->packed_prev, sizeof(packed)); else memcpy(j->packed_prev, packed, sizeof(packed));
+    auto DEV = [&](int k) -> const void * { return packed[k] ? packed[k] : j->dev[k].p; };
     OV_HIP(ctx, hipEventRecord(j->ev_h2d, ctx->stream));
 
     const char *dp = (const char *)j->dev[B_PARAM].p;
@@ -371,9 +383,9 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
         j->st.n_launches += n_mc != 0;
         if (n_mcx || n_aff) {
             StageTimer t_(j, OVHIP_TIME_MCXA);
-            CHK(ovhip_mcxa_launch(ctx, dst, refs, n_refs, (const ovhip_mc_unit *)j->dev[B_MCX].p, (uint32_t)n_mcx,
-                                  (int32_t *)j->dev[B_MV].p, (const ovhip_aff_unit *)j->dev[B_AFF].p, (uint32_t)n_aff,
-                                  (const int32_t *)j->dev[B_SIDE].p, d_fwd));
+            CHK(ovhip_mcxa_launch(ctx, dst, refs, n_refs, (const ovhip_mc_unit *)DEV(B_MCX), (uint32_t)n_mcx,
+                                  (int32_t *)j->dev[B_MV].p, (const ovhip_aff_unit *)DEV(B_AFF), (uint32_t)n_aff,
+                                  (const int32_t *)DEV(B_SIDE), d_fwd));
             j->st.n_launches++;
         }
         if (n_mcx && !j->resident) {
@@ -382,7 +394,7 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
             j->st.d2h_bytes += n_mcx * 16;
         }
         j->n_mv = n_mcx;
-        if (n_ciip) { CHK(ovhip_ciip_launch(ctx, dst, intra, (const ovhip_ciip_unit *)j->dev[B_CIIP].p, (uint32_t)n_ciip)); j->st.n_launches++; }
+        if (n_ciip) { CHK(ovhip_ciip_launch(ctx, dst, intra, (const ovhip_ciip_unit *)DEV(B_CIIP), (uint32_t)n_ciip)); j->st.n_launches++; }
     }
     // ---- residual: luma blocks, chroma-scale derivation on the reconstructed luma, chroma blocks (+ inverse mapping) ----
     const int ordered = 0;   // pictures with an ordered (intra) pass keep the luma plane in the mapped domain until it has run
@@ -397,7 +409,7 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
         if (n_reg) {
             if (!pr->lmcs) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_job_flush: chroma-scale regions recorded without LMCS tables", hipSuccess);
             StageTimer t_(j, OVHIP_TIME_LMCS_SCALE);
-            CHK(ovhip_lmcs_scale_launch(ctx, dst, (const ovhip_lmcs_region *)j->dev[B_REG].p, (uint32_t)n_reg, pr->lmcs,
+            CHK(ovhip_lmcs_scale_launch(ctx, dst, (const ovhip_lmcs_region *)DEV(B_REG), (uint32_t)n_reg, pr->lmcs,
                                         (int16_t *)j->dev[B_SCALE].p));
             j->st.n_launches++;
         }
@@ -417,8 +429,8 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
     // ---- in-loop filters ----
     if (stages & OVHIP_STAGE_DBF) {
         StageTimer t_(j, OVHIP_TIME_DBF);
-        CHK(ovhip_dbf_launch_edges_ex(ctx, dst, (const ovhip_dbf_edge *)j->dev[B_EV].p, (uint32_t)n_ev,
-                                      (const ovhip_dbf_edge *)j->dev[B_EH].p, (uint32_t)n_eh, &offs));
+        CHK(ovhip_dbf_launch_edges_ex(ctx, dst, (const ovhip_dbf_edge *)DEV(B_EV), (uint32_t)n_ev,
+                                      (const ovhip_dbf_edge *)DEV(B_EH), (uint32_t)n_eh, &offs));
         j->st.n_launches += (n_ev != 0) + (n_eh != 0);
     }
     // SAO writes tmp, ALF writes dst; with only one of the two the result is copied back so that dst always holds it
