@@ -80,8 +80,11 @@ enum {                        /* ovhip_tb_cmd.res_mode: how the residual r is ap
     OVHIP_RES_ADD_HALF = 2,   /*  r >> 1   */
     OVHIP_RES_SUB_HALF = 3,   /* (-r) >> 1 */
     OVHIP_RES_SCALE    = 4,   /* flag: LMCS chroma residual scaling with c_scale (scale_* variants) */
-    OVHIP_RES_SCALE_IDX = 8   /* flag (with OVHIP_RES_SCALE): c_scale is an INDEX into the launch's table of
+    OVHIP_RES_SCALE_IDX = 8,  /* flag (with OVHIP_RES_SCALE): c_scale is an INDEX into the launch's table of
                                * device-derived scales (ovhip_lmcs_scale_launch), not the scale itself */
+    OVHIP_RES_STORE = 16      /* the block belongs to an ordered task (ovhip_itask): r (after the sign / half variant,
+                               * before any chroma scaling) is STORED into the residual picture of the launch, saturated
+                               * to int16, instead of being added -- the ordered pass adds it to its prediction */
 };
 #define OVHIP_TB_FLAG_RASTER 0x80  /* in .kind: coefficients stored raster (2xN / Nx2 chroma TBs) */
 #define OVHIP_TB_FLAG_BDPCM  0x40  /* in .kind (with TS / TS_RAW): block DPCM, rcn_bdpcm_tb (rcn_transform_tree.c:631-688):
@@ -349,6 +352,49 @@ typedef struct ovhip_alf_pic {
     uint8_t *class_scratch;       /* DEVICE scratch, ceil(w/4) * ceil(h/4) bytes (class | transpose << 5) */
     int32_t log2_ctu_s;
 } ovhip_alf_pic;
+
+/* ------------------------------------------------------------------------------------
+ * Ordered tasks: everything whose INPUT is reconstructed samples of the same picture -- intra prediction
+ * (vvc_intra_pred, vvc_intra_pred_chroma, intra_pred_mrl, rcn_intra_mip, cclm.*: rcn_structures.h:507-524, :558-593;
+ * rcn_intra.c:484-1180, rcn_intra_cclm.c, rcn_intra_mip.c, rcn_fill_ref.c), CIIP's planar part (rcn_inter.c:3011-3067), and
+ * the chroma-scale regions / chroma residuals that depend on such blocks.  The reference runs them in decoding order,
+ * interleaved with everything else; the recorder gives each task a LEVEL = 1 + the highest level among the tasks that
+ * produce its inputs (0 = inputs come from inter blocks only), and the device runs level after level, all tasks of a level
+ * in one launch, after the stage-parallel prediction / residual launches.  One task = one prediction block (one
+ * transform block of an intra CU): predict, add the residual the transform stage STOREd for it, clip, write.  32 bytes.
+ * ---------------------------------------------------------------------------------- */
+enum { OVHIP_IT_LUMA = 0,     /* luma block                                                                          */
+       OVHIP_IT_CHROMA = 1,   /* Cb + Cr block (x, y, size in chroma samples)                                        */
+       OVHIP_IT_REGION = 2,   /* rcn_lmcs_compute_chroma_scale of region c_scale (needs ordered luma around it)      */
+       OVHIP_IT_RES_C = 3 };  /* chroma residual add of an already predicted block whose scale is an ordered region's */
+enum {                        /* ovhip_itask.flags */
+    OVHIP_IF_CORNER = 1,      /* the above-left neighbour unit is available                                          */
+    OVHIP_IF_MIP = 2,         /* matrix-based intra prediction, mode = mip mode; OVHIP_IF_MIP_TR: transposed          */
+    OVHIP_IF_MIP_TR = 4,
+    OVHIP_IF_BDPCM = 8,       /* block-DPCM CU: pure horizontal copy, OVHIP_IF_BDPCM_VER: vertical                    */
+    OVHIP_IF_BDPCM_VER = 16,
+    OVHIP_IF_RES_Y = 32, OVHIP_IF_RES_CB = 64, OVHIP_IF_RES_CR = 128,   /* a STOREd residual exists for that plane    */
+    OVHIP_IF_RES_SCALE = 256, /* chroma residual is LMCS-scaled with c_scale ...                                     */
+    OVHIP_IF_SCALE_IDX = 512  /* ... which is the index of a chroma-scale region                                      */
+};
+typedef struct ovhip_itask {
+    uint16_t x, y;            /* top-left in samples of the task's plane(s), picture coordinates                      */
+    uint8_t  log2_w, log2_h;
+    uint8_t  kind;            /* OVHIP_IT_*                                                                           */
+    uint8_t  mode;            /* 0 planar, 1 DC, 2..66 angular (before the wide-angle remap); chroma also 67 LM, 68 MDLM
+                               * left, 69 MDLM top; OVHIP_IF_MIP: the MIP mode                                        */
+    uint16_t flags;           /* OVHIP_IF_*                                                                           */
+    uint8_t  avl_lft, avl_abv;/* available neighbour units (4 luma / 2 chroma samples) below / right of the corner, as the
+                               * reference counts them: position of the highest available unit (rcn_fill_ref.c: 64 -
+                               * clz(avl_map) - 1).  LM modes: 67: 0/1 flags; 68: avl_lft = contiguous units, avl_abv flag;
+                               * 69: avl_abv = contiguous units, avl_lft flag (rcn_intra_cclm.c:56-68, :770-776, :843-849) */
+    uint8_t  mrl_idx;         /* multi-reference-line index 0..2                                                      */
+    uint8_t  ciip_wt;         /* != 0: CIIP CU, the (planar) prediction is blended into the inter prediction with this
+                               * weight before the residual (ovhip_ciip_weight)                                        */
+    int16_t  c_scale;         /* chroma residual scale, or region index (OVHIP_IF_SCALE_IDX, OVHIP_IT_REGION)          */
+    uint16_t level;           /* >= 1                                                                                 */
+    uint16_t pad[7];
+} ovhip_itask;
 
 /* ------------------------------------------------------------------------------------
  * Recorder (host side, pure C, usable without a GPU).

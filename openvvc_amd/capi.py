@@ -113,6 +113,14 @@ LMCS_REGION_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("n_abv", "u1"), ("n_l
 assert LMCS_REGION_DTYPE.itemsize == 8
 
 
+ITASK_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("log2_w", "u1"), ("log2_h", "u1"), ("kind", "u1"), ("mode", "u1"),
+                        ("flags", "<u2"), ("avl_lft", "u1"), ("avl_abv", "u1"), ("mrl_idx", "u1"), ("ciip_wt", "u1"),
+                        ("c_scale", "<i2"), ("level", "<u2"), ("pad", "<u2", 7)])
+assert ITASK_DTYPE.itemsize == 32
+IT_LUMA, IT_CHROMA, IT_REGION, IT_RES_C = 0, 1, 2, 3
+IF_CORNER, IF_MIP, IF_MIP_TR, IF_BDPCM, IF_BDPCM_VER, IF_RES_Y, IF_RES_CB, IF_RES_CR, IF_RES_SCALE, IF_SCALE_IDX = (1 << k for k in range(10))
+
+
 class DbfMvCtx(C.Structure):
     _fields_ = [("cu_edge_ver", C.c_uint64 * 33), ("cu_edge_hor", C.c_uint64 * 33),
                 ("map0_h", C.c_uint64 * 33), ("map0_v", C.c_uint64 * 33), ("map1_h", C.c_uint64 * 33), ("map1_v", C.c_uint64 * 33),

@@ -1196,3 +1196,8 @@ void oracle_alf_run(const oracle_pic *dst, const oracle_pic *src, const oracle_a
         }
     }
 }
+
+/* ====================================================================================
+ * Intra prediction and the ordered pass
+ * ================================================================================== */
+#include "ovvc_oracle_intra.c"

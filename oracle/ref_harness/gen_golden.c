@@ -1583,6 +1583,146 @@ gen_alf(const char *dir)
     gfile_close(&g);
 }
 
+/* ====================================================================================== INTRA
+ * intra.ovg : the reference's intra prediction slots on one CTU of a 2x2-CTU neighbourhood:
+ *   intra_pred (planar / DC / 65 angular incl. wide angles, reference smoothing, fC / fG, PDPC, luma BDPCM),
+ *   intra_pred_mrl, mip.rcn_intra_mip (+ transposed), intra_pred_c (planar / DC / angular / BDPCM) and cclm.{cclm,
+ *   mdlm_left, mdlm_top} behind it                                  (rcn_structures.h:507-524, :558-593)
+ * with every neighbour-availability pattern the progress bit-fields can express.  Inputs in the vocabulary of
+ * include/ovvc_hip.h (ovhip_itask on a picture), outputs = the predicted block(s).
+ * Picture = what the slots see of the CTU scratch (rcn_ctu.c:553-568, ctb_x = 1): the current CTU at luma (128, 128),
+ * the previous CTU's columns to its left, one reconstructed row above, 64 columns of the CTU to the right. */
+#define IN_W 328
+#define IN_H 264
+#define IN_OX 128
+#define IN_OY 128
+
+static void
+gen_intra(const char *dir)
+{
+    gbuf b_task = { .type = T_U8 }, b_eoff = { .type = T_U32 }, b_exp = { .type = T_U16 };
+    uint32_t n_cases = 0;
+    g_seed = 0x266 + 555;
+    OVCTUDec *c = ref_new_ctudec(0, 0);
+    c->rcn_funcs.rcn_attach_ctu_buff(&c->rcn_ctx, 7, 1);
+    const struct OVBuffInfo *cb = &c->rcn_ctx.ctu_buff;
+    struct OVRCNCtx *r = &c->rcn_ctx;
+    static uint16_t py[IN_W * IN_H], pcb[(IN_W / 2) * (IN_H / 2)], pcr[(IN_W / 2) * (IN_H / 2)];
+    fill_plane(py, IN_W, IN_H, IN_W); fill_plane(pcb, IN_W / 2, IN_H / 2, IN_W / 2); fill_plane(pcr, IN_W / 2, IN_H / 2, IN_W / 2);
+    for (int i = 0; i < IN_W * IN_H; i += 41) py[i] = (i & 1) ? 1023 : 0;
+    /* CTU scratch <- picture: rows -1 .. 131, columns -128 .. 195 (what the buffer holds around the CTU) */
+    #define LOAD_SCRATCH() do { \
+        for (int j = -1; j < 132; ++j) for (int i = -128; i < 196; ++i) cb->y[j * cb->stride + i] = py[(IN_OY + j) * IN_W + IN_OX + i]; \
+        for (int j = -1; j < 66; ++j) for (int i = -64; i < 98; ++i) { \
+            cb->cb[j * cb->stride_c + i] = pcb[(IN_OY / 2 + j) * (IN_W / 2) + IN_OX / 2 + i]; \
+            cb->cr[j * cb->stride_c + i] = pcr[(IN_OY / 2 + j) * (IN_W / 2) + IN_OX / 2 + i]; } } while (0)
+
+    /* kind: 0 luma regular, 1 luma MRL, 2 MIP, 3 chroma regular, 4 chroma LM, 5 luma BDPCM, 6 chroma BDPCM */
+    for (int kind = 0; kind < 7; ++kind) {
+        const int chroma = kind == 3 || kind == 4 || kind == 6;
+        const int lmin = chroma ? 1 : 2, lmax = chroma ? 5 : 6;
+        for (int l2w = lmin; l2w <= lmax; ++l2w) {
+            for (int l2h = lmin; l2h <= lmax; ++l2h) {
+                if (chroma && l2w + l2h < 3) continue;                   /* no 2x2 chroma blocks */
+                if (kind == 2 && (l2w > 6 || l2h > 6)) continue;
+                if ((kind == 5 || kind == 6) && (l2w > 5 || l2h > 5)) continue;
+                const int w = 1 << l2w, h = 1 << l2h, unit = chroma ? 2 : 4, ctu = chroma ? 64 : 128;
+                int n_modes = kind == 0 || kind == 3 ? 67 : kind == 1 ? 67 : kind == 2 ? 32 : kind == 4 ? 3 : 2;
+                int reps = kind == 0 ? (w * h <= 256 ? 3 : 2) : kind == 4 ? (w * h >= 256 ? 3 : 6) : 1;
+                for (int mi = 0; mi < n_modes; ++mi) {
+                    /* keep the fixture small: big blocks take every third (fifth) mode plus the structurally special ones */
+                    const int key_mode = mi <= 2 || mi == 18 || mi == 34 || mi == 50 || mi == 66;
+                    const int thin = w * h >= 2048 ? 5 : w * h >= 512 ? 3 : (kind == 1 && w * h >= 128 ? 2 : 1);
+                    if ((kind == 0 || kind == 1 || kind == 3) && !key_mode && (mi % thin) != ((l2w * 3 + l2h) % thin)) continue;
+                    if (kind == 2 && w * h >= 1024 && (mi & 1) != ((l2w + l2h) & 1)) continue;
+                    for (int rep = 0; rep < (w * h >= 512 && kind != 4 ? 1 : reps); ++rep) {
+                        ovhip_itask t;
+                        memset(&t, 0, sizeof(t));
+                        int mode = mi, mrl = 0, mip_tr = 0;
+                        if (kind == 1) { if (mode == 0 || mode == 1) { if (rep) continue; } mrl = 1 + ((mi + rep) & 1); }
+                        if (kind == 2) {
+                            const int n_mip = (l2w == 2 && l2h == 2) ? 16 : (l2h == 2 || l2w == 2 || (l2h <= 3 && l2w <= 3)) ? 8 : 6;
+                            mode = mi % n_mip; mip_tr = (mi / n_mip) & 1;
+                            if (mi >= 2 * n_mip) continue;
+                        }
+                        if (kind == 4) mode = 67 + mi;
+                        /* position inside the CTU, availability pattern */
+                        int x0, y0;
+                        x0 = rnd_range(0, (ctu - w) / unit) * unit; y0 = rnd_range(0, (ctu - h) / unit) * unit;
+                        if (rep % 3 == 1 || (kind != 0 && rnd_range(0, 3) == 0)) { if (rnd_range(0, 1)) x0 = 0; else y0 = 0; }
+                        if (kind == 1 && y0 < 4) y0 = 4 * rnd_range(1, (ctu - h) / 4 > 1 ? (ctu - h) / 4 : 1);
+                        if (kind == 1 && y0 + h > ctu) continue;
+                        int max_abv = 2 * w / unit, max_lft = 2 * h / unit;
+                        int cap_abv = ((chroma ? 96 : 192) - x0) / unit, cap_lft = ((chroma ? 64 : 128) - y0) / unit;
+                        if (max_abv > cap_abv) max_abv = cap_abv;
+                        if (max_lft > cap_lft) max_lft = cap_lft;
+                        int corner = 1, avl_abv = max_abv, avl_lft = max_lft;
+                        /* the availability states a decoder can be in (decoding order + slice / picture borders) */
+                        int pat = rnd_range(0, 9);
+                        if (kind == 1 && pat < 3) pat += 3;                                       /* MRL is not signalled on the first CTU row */
+                        if (pat == 0) { corner = 0; avl_abv = 0; avl_lft = 0; }                  /* nothing (picture / slice corner) */
+                        else if (pat == 1) { corner = 0; avl_abv = 0; }                           /* top row */
+                        else if (pat == 2) { corner = 0; avl_lft = 0; }                           /* left column */
+                        else if (pat <= 5) { avl_abv = rnd_range(w / unit < max_abv ? w / unit : max_abv, max_abv);
+                                             avl_lft = rnd_range(h / unit < max_lft ? h / unit : max_lft, max_lft); }
+                        else if (pat == 6) { avl_abv = w / unit < max_abv ? w / unit : max_abv; avl_lft = h / unit < max_lft ? h / unit : max_lft; }
+                        else if (pat == 7 && kind != 1) { corner = 0; }                          /* a slice starts at the CTU above */
+                        /* progress bit-fields: bit (unit + 1) of hfield[row above] / vfield[column left]; bit `unit` = the corner */
+                        struct CTUBitField *pf = chroma ? &r->progress_field_c : &r->progress_field;
+                        memset(pf, 0, sizeof(*pf));
+                        const int xu = x0 / unit, yu = y0 / unit;
+                        pf->hfield[yu] = (((uint64_t)corner) | ((((uint64_t)1 << avl_abv) - 1) << 1)) << xu;
+                        pf->vfield[xu] = (((uint64_t)corner) | ((((uint64_t)1 << avl_lft) - 1) << 1)) << yu;
+                        LOAD_SCRATCH();
+                        CUFlags fl = flg_pred_mode_flag;
+                        t.x = (uint16_t)((chroma ? IN_OX / 2 : IN_OX) + x0); t.y = (uint16_t)((chroma ? IN_OY / 2 : IN_OY) + y0);
+                        t.log2_w = l2w; t.log2_h = l2h; t.kind = chroma ? OVHIP_IT_CHROMA : OVHIP_IT_LUMA;
+                        t.mode = (uint8_t)mode; t.flags = corner ? OVHIP_IF_CORNER : 0;
+                        t.avl_lft = avl_lft; t.avl_abv = avl_abv; t.mrl_idx = mrl; t.level = 1;
+                        switch (kind) {
+                        case 0: c->rcn_funcs.intra_pred(r, cb, mode, x0, y0, l2w, l2h, fl); break;
+                        case 1: c->rcn_funcs.intra_pred_mrl(c, cb->y, cb->stride, mode, x0, y0, l2w, l2h, mrl); break;
+                        case 2: t.flags |= OVHIP_IF_MIP | (mip_tr ? OVHIP_IF_MIP_TR : 0);
+                                c->rcn_funcs.mip.rcn_intra_mip(r, x0, y0, l2w, l2h, (uint8_t)(mode | (mip_tr << 7))); break;
+                        case 5: fl |= flg_intra_bdpcm_luma_flag | (mi ? flg_intra_bdpcm_luma_dir : 0);
+                                t.flags |= OVHIP_IF_BDPCM | (mi ? OVHIP_IF_BDPCM_VER : 0); t.mode = 0;
+                                c->rcn_funcs.intra_pred(r, cb, 0, x0, y0, l2w, l2h, fl); break;
+                        case 6: fl |= flg_intra_bdpcm_chroma_flag | (mi ? flg_intra_bdpcm_chroma_dir : 0);
+                                t.flags |= OVHIP_IF_BDPCM | (mi ? OVHIP_IF_BDPCM_VER : 0); t.mode = 0;
+                                c->rcn_funcs.intra_pred_c(r, 0, x0, y0, l2w, l2h, fl); break;
+                        case 4: {
+                            /* the LM modes read their own availability: abv / lft "any unit" flags, MDLM: contiguous units
+                             * over w + min(w, h) (h + min(w, h)) samples (rcn_intra_cclm.c:56-68, :770-776, :843-849) */
+                            const int any_abv = avl_abv > 0, any_lft = avl_lft > 0;
+                            int need_a = (w + (w < h ? w : h)) / 2, need_l = (h + (w < h ? w : h)) / 2;
+                            t.avl_abv = mode == 69 ? (avl_abv < need_a ? avl_abv : need_a) : any_abv;
+                            t.avl_lft = mode == 68 ? (avl_lft < need_l ? avl_lft : need_l) : any_lft;
+                            c->rcn_funcs.intra_pred_c(r, mode, x0, y0, l2w, l2h, fl); break; }
+                        default: c->rcn_funcs.intra_pred_c(r, mode, x0, y0, l2w, l2h, fl); break;
+                        }
+                        uint32_t eoff[2] = { 0, 0 };
+                        if (!chroma) { eoff[0] = (uint32_t)b_exp.n; dump_rect(&b_exp, cb->y, cb->stride, x0, y0, w, h); }
+                        else { eoff[0] = (uint32_t)b_exp.n; dump_rect(&b_exp, cb->cb, cb->stride_c, x0, y0, w, h);
+                               eoff[1] = (uint32_t)b_exp.n; dump_rect(&b_exp, cb->cr, cb->stride_c, x0, y0, w, h); }
+                        gbuf_push(&b_task, &t, sizeof(t)); gbuf_push(&b_eoff, eoff, 2);
+                        n_cases++;
+                    }
+                }
+            }
+        }
+    }
+    gfile g = gfile_open(dir, "intra.ovg");
+    uint32_t d2[2] = { IN_H, IN_W };
+    gfile_array(&g, "pic_y", T_U16, py, 2, d2);
+    d2[0] = IN_H / 2; d2[1] = IN_W / 2;
+    gfile_array(&g, "pic_cb", T_U16, pcb, 2, d2); gfile_array(&g, "pic_cr", T_U16, pcr, 2, d2);
+    d2[0] = n_cases; d2[1] = sizeof(ovhip_itask); gfile_array(&g, "task", T_U8, b_task.data, 2, d2);
+    d2[1] = 2; gfile_array(&g, "exp_off", T_U32, b_eoff.data, 2, d2);
+    gfile_buf(&g, "exp", &b_exp);
+    gfile_close(&g);
+    fprintf(stderr, "intra.ovg: %u cases, %zu expected samples\n", n_cases, b_exp.n);
+}
+
 int
 main(int argc, char **argv)
 {
@@ -1598,5 +1738,6 @@ main(int argc, char **argv)
     if (!only || !strcmp(only, "dbf")) gen_dbf(dir);
     if (!only || !strcmp(only, "sao")) gen_sao(dir);
     if (!only || !strcmp(only, "alf")) gen_alf(dir);
+    if ((!only || !strcmp(only, "intra")) && !g_shim) gen_intra(dir);
     return 0;
 }

@@ -66,6 +66,16 @@ ref_fill_table(struct RCNFunctions *f, uint8_t ict_type, uint8_t lmcs_flag)
     rcn_init_tr_functions_10(f);
     rcn_init_dc_planar_functions_10(f);
     rcn_init_ict_functions_10(f, ict_type, 10);
+    {   /* rcn_init_intra_angular_functions(rcn_func, 10) is static in rcn.c (:69-110): the nine exported function tables */
+        extern const struct IntraAngularFunctions angular_gauss_h_10, angular_gauss_v_10, angular_cubic_h_10, angular_cubic_v_10,
+                                                   angular_c_h_10, angular_c_v_10, angular_nofrac_v_10, angular_nofrac_h_10;
+        extern const struct IntraMRLFunctions mrl_func_10;
+        f->intra_angular_gauss_h = &angular_gauss_h_10; f->intra_angular_gauss_v = &angular_gauss_v_10;
+        f->intra_angular_cubic_h = &angular_cubic_h_10; f->intra_angular_cubic_v = &angular_cubic_v_10;
+        f->intra_angular_c_h = &angular_c_h_10; f->intra_angular_c_v = &angular_c_v_10;
+        f->intra_angular_nofrac_v = &angular_nofrac_v_10; f->intra_angular_nofrac_h = &angular_nofrac_h_10;
+        f->intra_mrl = &mrl_func_10;
+    }
     rcn_init_lfnst_functions(f);
     rcn_init_mip_functions_10(f);
     rcn_init_alf_functions_10(f);

@@ -50,7 +50,28 @@ def lib():
         _lib.oracle_sao.restype = None
         _lib.oracle_alf_run.argtypes = [C.POINTER(OPic), C.POINTER(OPic), vp]
         _lib.oracle_alf_run.restype = None
+        _lib.oracle_intra_tasks.argtypes = [C.POINTER(OPic), vp, vp, C.c_uint32, vp, vp, vp, C.c_int]
+        _lib.oracle_intra_tasks.restype = None
     return _lib
+
+
+class ORes(C.Structure):
+    """int16 residual planes the transform stage STOREd for the ordered tasks (oracle_res)."""
+    _fields_ = [("y", C.c_void_p), ("cb", C.c_void_p), ("cr", C.c_void_p), ("stride_y", C.c_int32), ("stride_c", C.c_int32)]
+
+
+def intra_tasks(pic: "HostPic", tasks: np.ndarray, res=None, regions=None, luts=None, scales=None, log2_ctu: int = 7):
+    """The ordered pass: tasks (capi.ITASK_DTYPE) in recording order; res = (y, cb, cr) int16 arrays or None."""
+    s = pic.struct()
+    r = None
+    if res is not None:
+        res = [np.ascontiguousarray(a, dtype=np.int16) for a in res]
+        r = ORes(res[0].ctypes.data, res[1].ctypes.data, res[2].ctypes.data, res[0].shape[1], res[1].shape[1])
+    tasks = np.ascontiguousarray(tasks)
+    reg = np.ascontiguousarray(regions) if regions is not None and len(regions) else None
+    lib().oracle_intra_tasks(C.byref(s), C.byref(r) if r is not None else None, tasks.ctypes.data, len(tasks),
+                             reg.ctypes.data if reg is not None else None, C.byref(luts) if luts is not None else None,
+                             scales.ctypes.data if scales is not None else None, log2_ctu)
 
 
 class HostPic:

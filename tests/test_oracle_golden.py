@@ -212,3 +212,32 @@ def test_fixtures_regenerate_from_the_compiled_reference(tmp_path):
     assert len(names) >= 9
     for n in names:
         assert (tmp_path / n).read_bytes() == (root / "tests" / "golden" / n).read_bytes(), f"{n} differs from a fresh run of the reference"
+
+
+def test_intra_oracle_matches_reference(built_lib):
+    """Intra prediction: the reference's intra_pred / intra_pred_mrl / mip.rcn_intra_mip / intra_pred_c (+ cclm.*) slots on
+    every mode, block shape and neighbour-availability state vs the oracle's ordered-task executor."""
+    import golden_io
+    g = golden_io.load("intra.ovg")
+    tasks = np.frombuffer(g["task"].tobytes(), dtype=capi.ITASK_DTYPE)
+    H, W = g["pic_y"].shape
+    kinds = {"luma": 0, "mrl": 0, "mip": 0, "chroma": 0, "lm": 0, "bdpcm": 0}
+    bad = []
+    for i, t in enumerate(tasks):
+        pic = HostPic(W, H, g["pic_y"].copy(), g["pic_cb"].copy(), g["pic_cr"].copy())
+        oracle_lib.intra_tasks(pic, tasks[i:i + 1])
+        w, h, x, y = 1 << int(t["log2_w"]), 1 << int(t["log2_h"]), int(t["x"]), int(t["y"])
+        eo = g["exp_off"][i]
+        if t["kind"] == capi.IT_LUMA:
+            ok = np.array_equal(pic.y[y:y + h, x:x + w], g["exp"][eo[0]:eo[0] + w * h].reshape(h, w))
+        else:
+            ok = (np.array_equal(pic.cb[y:y + h, x:x + w], g["exp"][eo[0]:eo[0] + w * h].reshape(h, w))
+                  and np.array_equal(pic.cr[y:y + h, x:x + w], g["exp"][eo[1]:eo[1] + w * h].reshape(h, w)))
+        fl = int(t["flags"])
+        k = ("mip" if fl & capi.IF_MIP else "bdpcm" if fl & capi.IF_BDPCM else "mrl" if t["mrl_idx"] else
+             "lm" if t["mode"] >= 67 else "luma" if t["kind"] == capi.IT_LUMA else "chroma")
+        kinds[k] += 1
+        if not ok:
+            bad.append((i, k, int(t["mode"]), w, h, x, y, fl, int(t["avl_lft"]), int(t["avl_abv"])))
+    assert not bad, f"{len(bad)} / {len(tasks)} intra cases differ from the reference, first: {bad[:6]}"
+    assert kinds["luma"] > 2500 and kinds["mrl"] > 500 and kinds["mip"] > 200 and kinds["chroma"] > 1000 and kinds["lm"] > 200 and kinds["bdpcm"] > 50
