@@ -228,7 +228,9 @@ typedef struct ovhip_lmcs_luts {       /* struct LMCSLUTs + the LMCSInfo scalars
 typedef struct ovhip_lmcs_region {     /* one rcn_lmcs_compute_chroma_scale() call, 8 bytes */
     uint16_t x, y;                     /* luma position of the 64-aligned CU in the picture                 */
     uint8_t  n_abv, n_lft;             /* available 4-sample units above / left (bit length of the masks)    */
-    uint8_t  pad[2];
+    uint8_t  ordered;                  /* 1: luma around the region comes from ordered tasks -- ovhip_lmcs_scale_launch skips
+                                        * it, an OVHIP_IT_REGION task derives the scale in the ordered pass  */
+    uint8_t  pad;
 } ovhip_lmcs_region;
 
 int ovhip_lmcs_build(const ovhip_lmcs_data *data, ovhip_lmcs_luts *out);
@@ -517,6 +519,19 @@ void  ovhip_rec_destroy(ovhip_recorder *rec);
 void  ovhip_rec_reset(ovhip_recorder *rec);
 /* Append the commands of one TU / PU.  Return number of commands appended or <0. */
 int   ovhip_rec_tu(ovhip_recorder *rec, const ovhip_tu_state *st, const ovhip_tu_desc *tu);
+/* A TU of a CU that has ordered tasks: intra_l / intra_c (either may be NULL) describe the luma / chroma prediction the
+ * reference runs right before the TU's luma / chroma residual (rcn_intra_tu -> rcn_tu_st -> intra_pred_c,
+ * rcn_transform_tree.c:1384-1430, :1269-1287; rcn_tu_c :1349-1382): fill x, y, log2_w, log2_h, kind, mode, the OVHIP_IF_CORNER /
+ * MIP / BDPCM flags, avl_lft, avl_abv, mrl_idx, ciip_wt.  The recorder computes the level, stores the tasks in decoding
+ * order, marks the TU's transform blocks OVHIP_RES_STORE and sets the tasks' OVHIP_IF_RES_* / scale fields.  A chroma
+ * block that only needs an ordered chroma scale (inter CU below an ordered region) becomes an OVHIP_IT_RES_C task by itself.
+ * Returns the number of transform-block commands appended or <0. */
+int   ovhip_rec_tu_intra(ovhip_recorder *rec, const ovhip_tu_state *st, const ovhip_tu_desc *tu, const ovhip_itask *intra_l,
+                         const ovhip_itask *intra_c);
+/* The ordered tasks in decoding order, and sorted by level: level_start[l] .. level_start[l + 1] are the tasks of level
+ * l + 1 (n_levels + 1 entries).  Sorting happens in the call. */
+const ovhip_itask *ovhip_rec_itasks(const ovhip_recorder *rec, size_t *n);
+const ovhip_itask *ovhip_rec_itasks_sorted(ovhip_recorder *rec, size_t *n, const uint32_t **level_start, uint32_t *n_levels);
 /* tmp.rcn_transform_tree: walks the tree and records every leaf with ovhip_rec_tu.  Returns the number of
  * commands appended or <0. */
 int   ovhip_rec_transform_tree(ovhip_recorder *rec, const ovhip_tu_state *st, const ovhip_tt_desc *tt);
@@ -614,6 +629,10 @@ int  ovhip_itx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_tb_cmd *
 int  ovhip_itx_launch_classes(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_tb_cmd *d_cmds,
                               uint32_t n_large, uint32_t n_small, const int16_t *d_coefs,
                               const int16_t *d_lmcs_scales);
+/* Same for a picture with ordered tasks: the OVHIP_RES_STORE commands write their residual (int16 bits) at the block's position
+ * of `res`, a picture of dst's geometry (ovhip_pic_alloc(w, h)); the others add to dst as usual. */
+int  ovhip_itx_launch_classes_res(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *res, const ovhip_tb_cmd *d_cmds,
+                                  uint32_t n_large, uint32_t n_small, const int16_t *d_coefs, const int16_t *d_lmcs_scales);
 /* The CHROMA commands of a picture (same classes) plus, riding in the same launch, the inverse LMCS mapping of the
  * luma plane (= ovhip_lmcs_inverse_launch).  Legal once the luma commands and ovhip_lmcs_scale_launch have run:
  * the commands must not address plane 0. */
@@ -653,6 +672,12 @@ int  ovhip_mcxa_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *re
                        const ovhip_mc_unit *d_xunits, uint32_t n_xunits, int32_t *d_mv_out,
                        const ovhip_aff_unit *d_aunits, uint32_t n_aunits, const int32_t *d_side,
                        const uint16_t *d_lmcs_fwd_lut);
+/* One LEVEL of the ordered pass (ovhip_itask): d_tasks = the n tasks of that level (DEVICE), all mutually independent; the
+ * launch boundary to the next level makes their stores visible to it.  res: the residual picture the OVHIP_RES_STORE
+ * commands wrote; d_regions / luts / d_scales as in ovhip_lmcs_scale_launch (NULL without LMCS chroma scaling): ordered regions
+ * write their scale, scaled chroma residuals read it. */
+int  ovhip_intra_level_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_pic *res, const ovhip_itask *d_tasks, uint32_t n,
+                              const ovhip_lmcs_region *d_regions, const ovhip_lmcs_luts *luts, int16_t *d_scales, int32_t log2_ctu_s);
 /* planes->* are DEVICE pointers.  Filters `pic` in place: all vertical edges, then all horizontal. */
 int  ovhip_dbf_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_dbf_planes *planes);
 /* Same filter driven by the compact lists of ovhip_dbf_compact (DEVICE pointers). */

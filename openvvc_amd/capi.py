@@ -109,7 +109,7 @@ DBF_EDGE_DTYPE = np.dtype([("ux", "<u2"), ("uy", "<u2"), ("word", "<u2"), ("comp
 assert DBF_EDGE_DTYPE.itemsize == 8
 CIIP_UNIT_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("log2_w", "u1"), ("log2_h", "u1"), ("wt", "u1"), ("chroma_inter", "u1")])
 assert CIIP_UNIT_DTYPE.itemsize == 8
-LMCS_REGION_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("n_abv", "u1"), ("n_lft", "u1"), ("pad", "u1", 2)])
+LMCS_REGION_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("n_abv", "u1"), ("n_lft", "u1"), ("ordered", "u1"), ("pad", "u1")])
 assert LMCS_REGION_DTYPE.itemsize == 8
 
 
@@ -119,6 +119,16 @@ ITASK_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("log2_w", "u1"), ("log2_h",
 assert ITASK_DTYPE.itemsize == 32
 IT_LUMA, IT_CHROMA, IT_REGION, IT_RES_C = 0, 1, 2, 3
 IF_CORNER, IF_MIP, IF_MIP_TR, IF_BDPCM, IF_BDPCM_VER, IF_RES_Y, IF_RES_CB, IF_RES_CR, IF_RES_SCALE, IF_SCALE_IDX = (1 << k for k in range(10))
+
+
+class ITask(C.Structure):
+    """ovhip_itask (include/ovvc_hip.h)."""
+    _fields_ = [("x", C.c_uint16), ("y", C.c_uint16), ("log2_w", C.c_uint8), ("log2_h", C.c_uint8), ("kind", C.c_uint8), ("mode", C.c_uint8),
+                ("flags", C.c_uint16), ("avl_lft", C.c_uint8), ("avl_abv", C.c_uint8), ("mrl_idx", C.c_uint8), ("ciip_wt", C.c_uint8),
+                ("c_scale", C.c_int16), ("level", C.c_uint16), ("pad", C.c_uint16 * 7)]
+
+
+assert C.sizeof(ITask) == 32
 
 
 class DbfMvCtx(C.Structure):
@@ -308,6 +318,11 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_dbf_launch_edges_ex": (C.c_int, [vp, P(Pic), vp, u32, vp, u32, P(DbfOffsets)]),
         "ovhip_dmvr_search_launch": (C.c_int, [vp, P(Pic), P(Pic), u32, vp, u32, vp]),
         "ovhip_rec_append_raw": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
+        "ovhip_itx_launch_classes_res": (C.c_int, [vp, P(Pic), P(Pic), vp, u32, u32, vp, vp]),
+        "ovhip_intra_level_launch": (C.c_int, [vp, P(Pic), P(Pic), vp, u32, vp, vp, vp, i32]),
+        "ovhip_rec_tu_intra": (C.c_int, [vp, P(TuState), P(TuDesc), P(ITask), P(ITask)]),
+        "ovhip_rec_itasks": (vp, [vp, P(C.c_size_t)]),
+        "ovhip_rec_itasks_sorted": (vp, [vp, P(C.c_size_t), P(P(C.c_uint32)), P(C.c_uint32)]),
         "ovhip_rec_set_dbf_offsets": (C.c_int, [vp, P(DbfOffsets), C.c_int]),
         "ovhip_job_create": (C.c_int, [vp, i32, i32, P(vp)]),
         "ovhip_job_destroy": (None, [vp]),
@@ -338,7 +353,7 @@ EXPORTED_SYMBOLS = [
     "ovhip_free", "ovhip_h2d", "ovhip_d2h", "ovhip_pic_alloc", "ovhip_pic_free", "ovhip_pic_upload",
     "ovhip_pic_download", "ovhip_itx_launch", "ovhip_mc_launch",
     "ovhip_rec_create_ex", "ovhip_rec_set_dense_dbf_planes", "ovhip_rec_dbf_edges", "ovhip_dbf_launch_edges_ex",
-    "ovhip_dmvr_search_launch", "ovhip_rec_append_raw", "ovhip_rec_set_dbf_offsets", "ovhip_job_create", "ovhip_job_destroy", "ovhip_job_recorder", "ovhip_job_begin",
+    "ovhip_dmvr_search_launch", "ovhip_rec_append_raw", "ovhip_rec_set_dbf_offsets", "ovhip_rec_tu_intra", "ovhip_rec_itasks", "ovhip_rec_itasks_sorted", "ovhip_itx_launch_classes_res", "ovhip_intra_level_launch", "ovhip_job_create", "ovhip_job_destroy", "ovhip_job_recorder", "ovhip_job_begin",
     "ovhip_job_flush", "ovhip_job_wait", "ovhip_job_refined_mvs", "ovhip_job_dmvr_rows", "ovhip_job_last_stats", "ovhip_job_time_stage", "ovhip_job_stage_time",
 ]
 
@@ -372,6 +387,26 @@ class Recorder:
         if r < 0:
             raise ValueError(f"ovhip_rec_tu -> {r}")
         return r
+
+    def tu_intra(self, st: TuState, d: TuDesc, task_l: "ITask | None", task_c: "ITask | None") -> int:
+        """A TU with the ordered (intra / CIIP) prediction tasks the reference runs around its residuals."""
+        r = self.lib.ovhip_rec_tu_intra(self.h, C.byref(st), C.byref(d), C.byref(task_l) if task_l is not None else None,
+                                        C.byref(task_c) if task_c is not None else None)
+        if r < 0:
+            raise ValueError(f"ovhip_rec_tu_intra -> {r}")
+        return r
+
+    def itasks(self) -> np.ndarray:
+        return self._arr(self.lib.ovhip_rec_itasks, ITASK_DTYPE)
+
+    def itasks_sorted(self):
+        """(tasks sorted by level, level_start uint32 [n_levels + 1])"""
+        n, nl, ls = C.c_size_t(), C.c_uint32(), C.POINTER(C.c_uint32)()
+        p = self.lib.ovhip_rec_itasks_sorted(self.h, C.byref(n), C.byref(ls), C.byref(nl))
+        if not n.value:
+            return np.zeros(0, ITASK_DTYPE), np.zeros(1, np.uint32)
+        t = np.frombuffer((C.c_char * (n.value * 32)).from_address(p), dtype=ITASK_DTYPE).copy()
+        return t, np.array([ls[i] for i in range(nl.value + 1)], np.uint32)
 
     def transform_tree(self, st: "TuState", d: TtDesc, infos: bytes, res_cb: np.ndarray, res_cr: np.ndarray, res_y: np.ndarray) -> int:
         """tmp.rcn_transform_tree: infos = 16 ovhip_tu_info structs, res_* = the CTU's residual_cb / _cr / _y buffers."""

@@ -115,6 +115,8 @@ __device__ __forceinline__ int residual1(int pix, int r, int mode, int scale)
     // sample): bit 0 negates, bit 1 halves
     const int neg = -(mode & 1);
     int v = ((r ^ neg) - neg) >> ((mode >> 1) & 1);
+    // block of an ordered task: the residual itself goes out (to the residual picture, see ResDelta), saturated to int16
+    if (mode & OVHIP_RES_STORE) return ov_clip16(v) & 0xffff;
     if (mode & OVHIP_RES_SCALE) {
         int sign = v & (1 << 15);
         int a = ov_clip_bd(abs(v));
@@ -123,6 +125,10 @@ __device__ __forceinline__ int residual1(int pix, int r, int mode, int scale)
     }
     return ov_clip_bd(pix + v);
 }
+
+// Where OVHIP_RES_STORE blocks go: the residual picture has the geometry of the picture being decoded, so it is addressed as
+// "same position, other allocation": byte distance of each of its planes from the picture's (0 when there is none).
+struct ResDelta { long long d[3]; };
 
 struct ResidualSink {
     uint16_t *dst; int stride; int mode;
@@ -206,7 +212,7 @@ __device__ __forceinline__ void lmcs_inverse_rows(const ovhip_pic &pic, const ui
 // what lets four waves with four different small blocks share a 256-thread workgroup (k_itx_all); a wave without a
 // block (valid = false) only keeps the barriers company.
 template <int NT>
-__device__ __forceinline__ void itx_block(const ovhip_pic &pic, const ovhip_tb_cmd &c, bool valid, const int16_t *__restrict__ arena,
+__device__ __forceinline__ void itx_block(const ovhip_pic &pic, const ResDelta &rd, const ovhip_tb_cmd &c, bool valid, const int16_t *__restrict__ arena,
                                           const int16_t *__restrict__ lmcs_scales, int ablate, int lane, int16_t *lds)
 {
     const int log2_w = c.log2_w, log2_h = c.log2_h;
@@ -304,6 +310,14 @@ __device__ __forceinline__ void itx_block(const ovhip_pic &pic, const ovhip_tb_c
     sink.mode = c.res_mode;
     sink.dst2 = nullptr; sink.stride2 = 0; sink.mode2 = c.res_mode2;
     if (c.plane2 != 0xff) sink.dst2 = ov_plane(pic, c.plane2, sink.stride2) + c.y * sink.stride2 + c.x;
+    if (c.res_mode & OVHIP_RES_STORE) {
+        const long long d1 = c.plane == 0 ? rd.d[0] : (c.plane == 1 ? rd.d[1] : rd.d[2]);
+        sink.dst = reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(sink.dst) + d1);
+        if (sink.dst2) {
+            const long long d2 = c.plane2 == 0 ? rd.d[0] : (c.plane2 == 1 ? rd.d[1] : rd.d[2]);
+            sink.dst2 = reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(sink.dst2) + d2);
+        }
+    }
     sink.scale = (c.res_mode & OVHIP_RES_SCALE_IDX) ? lmcs_scales[c.c_scale] : c.c_scale;   // device-derived chroma scale (K11)
 
     if (ablate & 4) valid = false;
@@ -421,19 +435,19 @@ __device__ __forceinline__ void itx_block(const ovhip_pic &pic, const ovhip_tb_c
 __global__ __launch_bounds__(256) OV_OCC_ITX void k_itx_all(ovhip_pic pic, const ovhip_tb_cmd *__restrict__ cmds, uint32_t n_large,
                                                   uint32_t n_small, const int16_t *__restrict__ arena,
                                                   const int16_t *__restrict__ lmcs_scales, int ablate,
-                                                  const uint16_t *__restrict__ lmcs_inv_lut, uint32_t n_extra)
+                                                  const uint16_t *__restrict__ lmcs_inv_lut, uint32_t n_extra, ResDelta rd)
 {
     __shared__ __attribute__((aligned(16))) int16_t lds[ITX_LDS_BIG > 4 * ITX_LDS_SLICE ? ITX_LDS_BIG : 4 * ITX_LDS_SLICE];
     const uint32_t b = blockIdx.x, n_quads = (n_small + 3) >> 2;
     // XCD-aware order (see k_mc2): each XCD takes a contiguous chunk of the sorted list, so blocks that share frame
     // cache lines meet in one L2
     if (b < n_large) {
-        itx_block<256>(pic, cmds[ov_xcd_slot(b, n_large)], true, arena, lmcs_scales, ablate, threadIdx.x, lds);
+        itx_block<256>(pic, rd, cmds[ov_xcd_slot(b, n_large)], true, arena, lmcs_scales, ablate, threadIdx.x, lds);
     } else if (b < n_large + n_quads) {
         const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // wave-uniform: the command stays in SGPRs
         const uint32_t i = ov_xcd_slot(b - n_large, n_quads) * 4 + w;
         const bool valid = i < n_small;
-        itx_block<64>(pic, cmds[n_large + (valid ? i : 0)], valid, arena, lmcs_scales, ablate, threadIdx.x & 63,
+        itx_block<64>(pic, rd, cmds[n_large + (valid ? i : 0)], valid, arena, lmcs_scales, ablate, threadIdx.x & 63,
                       lds + w * ITX_LDS_SLICE);
     } else {
         lmcs_inverse_rows<256>(pic, lmcs_inv_lut, b - n_large - n_quads, n_extra, reinterpret_cast<uint16_t *>(lds));
@@ -450,15 +464,21 @@ static int itx_ablate()
 }
 
 static int itx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_tb_cmd *d_cmds, uint32_t n_large, uint32_t n_small,
-                      const int16_t *d_coefs, const int16_t *d_lmcs_scales, const uint16_t *d_bwd_lut)
+                      const int16_t *d_coefs, const int16_t *d_lmcs_scales, const uint16_t *d_bwd_lut, const ovhip_pic *res = nullptr)
 {
+    ResDelta rd = { { 0, 0, 0 } };
+    if (res) {
+        if (res->w != dst->w || res->h != dst->h || res->stride_y != dst->stride_y || res->stride_c != dst->stride_c)
+            return ov_fail(ctx, OVHIP_EINVAL, "itx launch: the residual picture must have the picture's geometry", hipSuccess);
+        rd.d[0] = (char *)res->y - (char *)dst->y; rd.d[1] = (char *)res->cb - (char *)dst->cb; rd.d[2] = (char *)res->cr - (char *)dst->cr;
+    }
     // one workgroup per big block / per four small blocks measured faster than a resident grid-stride grid (79 vs 119 us
     // at 4K; and again with the next block's loads software-pipelined: the kernel is issue-bound, not latency-bound)
     const uint32_t n_extra = d_bwd_lut ? (uint32_t)(dst->h + 3) / 4 : 0;      // the inverse-LMCS rider: four luma rows per workgroup
     const uint32_t grid = n_large + (n_small + 3) / 4 + n_extra;
     if (!grid) return OVHIP_OK;
     hipLaunchKernelGGL(k_itx_all, dim3(grid), dim3(256), 0, ctx->stream, *dst, d_cmds, n_large, n_small, d_coefs,
-                       d_lmcs_scales, itx_ablate(), d_bwd_lut, n_extra);
+                       d_lmcs_scales, itx_ablate(), d_bwd_lut, n_extra, rd);
     OV_LAUNCH_CHECK(ctx, "k_itx_all");
     return OVHIP_OK;
 }
@@ -472,6 +492,17 @@ extern "C" int ovhip_itx_launch_classes(ovhip_ctx *ctx, const ovhip_pic *dst, co
     if (!n_large && !n_small) return OVHIP_OK;
     if (!d_cmds || !d_coefs) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_itx_launch: null buffer", hipSuccess);
     return itx_launch(ctx, dst, d_cmds, n_large, n_small, d_coefs, d_lmcs_scales, nullptr);
+}
+
+extern "C" int ovhip_itx_launch_classes_res(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *res, const ovhip_tb_cmd *d_cmds,
+                                            uint32_t n_large, uint32_t n_small, const int16_t *d_coefs,
+                                            const int16_t *d_lmcs_scales)
+{
+    if (!ctx || !dst || !res) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
+    if ((n_large + n_small) && (!d_cmds || !d_coefs))
+        return ov_fail(ctx, OVHIP_EINVAL, "ovhip_itx_launch_classes_res: null commands / coefficients", hipSuccess);
+    return itx_launch(ctx, dst, d_cmds, n_large, n_small, d_coefs, d_lmcs_scales, nullptr, res);
 }
 
 extern "C" int ovhip_itx_launch_chroma_lmcs(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_tb_cmd *d_cmds,

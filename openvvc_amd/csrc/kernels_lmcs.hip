@@ -22,6 +22,7 @@ __global__ __launch_bounds__(64) void k_lmcs_scale(ovhip_pic pic, const ovhip_lm
     const uint32_t bid = blockIdx.x;
     if (bid >= n) return;
     const ovhip_lmcs_region g = regs[bid];
+    if (g.ordered) return;                                    // luma around it comes from ordered tasks: k_intra_level derives it
     const int lane = threadIdx.x;
     // the reference sums sample k of every unit into luma_sum[k & 3]; only the total is used
     int sum = 0;

@@ -16,7 +16,7 @@ namespace {
 
 struct DevBuf { void *p; size_t cap; };
 
-enum { B_TB, B_COEF, B_MC, B_MCX, B_MV, B_AFF, B_SIDE, B_REG, B_SCALE, B_EV, B_EH, B_PARAM, B_CLASS, B_CIIP, B_COUNT };
+enum { B_TB, B_COEF, B_MC, B_MCX, B_MV, B_AFF, B_SIDE, B_REG, B_SCALE, B_EV, B_EH, B_PARAM, B_CLASS, B_CIIP, B_ITASK, B_COUNT };
 
 // layout of the parameter block (one pinned staging copy, one H2D)
 struct ParamLayout { size_t sao, alf_ctus, lcoef, lclip, ccoef, cclip, cc, fwd, bwd, total; };
@@ -29,6 +29,7 @@ struct ovhip_job {
     ovhip_recorder *rec;
     DevBuf dev[B_COUNT];
     ovhip_pic tmp;                       // SAO destination / ALF source
+    ovhip_pic res;                       // residuals of the ordered tasks (allocated with the first picture that has any)
     char *param_host; size_t param_cap;  // pinned staging of the picture-level tables
     int32_t *mv_host; size_t mv_cap;     // pinned: refined vectors, 4 int32 per refined unit
     size_t n_mv;                         // units covered by the last flush / eager pass
@@ -165,6 +166,7 @@ void ovhip_job_destroy(ovhip_job *j)
     if (j->flushed) (void)hipEventSynchronize(j->ev_done);
     for (int k = 0; k < B_COUNT; ++k) if (j->dev[k].p) (void)hipFree(j->dev[k].p);
     if (j->tmp.y) (void)ovhip_pic_free(j->ctx, &j->tmp);
+    if (j->res.y) (void)ovhip_pic_free(j->ctx, &j->res);
     pinned_free(nullptr, j->param_host); pinned_free(nullptr, j->mv_host);
     for (int k = 0; k < 32; ++k) for (int q = 0; q < 2; ++q) if (j->t_ev[k][q]) (void)hipEventDestroy(j->t_ev[k][q]);
     if (j->ev_h2d) (void)hipEventDestroy(j->ev_h2d);
@@ -296,6 +298,15 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
     const ovhip_ciip_unit *ciip = ovhip_rec_ciip_units(rec, &n_ciip);
     if (n_ciip && !intra)
         return ov_fail(ctx, OVHIP_EUNSUP, "ovhip_job_flush: CIIP blend units recorded but no picture with their intra prediction", hipSuccess);
+    size_t n_it = 0; uint32_t n_lv = 0; const uint32_t *lv_start = nullptr;
+    const ovhip_itask *it = ovhip_rec_itasks_sorted(rec, &n_it, &lv_start, &n_lv);
+    if (n_it && !it) return ov_fail(ctx, OVHIP_ENOMEM, "ovhip_rec_itasks_sorted", hipSuccess);
+    if (!(stages & OVHIP_STAGE_INTRA)) { n_it = 0; n_lv = 0; }
+    const int ordered = n_it != 0;       // a picture with an ordered pass keeps its luma in the mapped domain until the pass has run
+    if (ordered && !j->res.y) CHK(ovhip_pic_alloc(ctx, j->w, j->h, &j->res));
+    if (ordered && (dst->stride_y != j->res.stride_y || dst->stride_c != j->res.stride_c))
+        return ov_fail(ctx, OVHIP_EUNSUP, "ovhip_job_flush: pictures with ordered tasks need tight planes (stride = width)", hipSuccess);
+    j->st.n_itasks = (uint32_t)n_it; j->st.n_ilevels = n_lv;
     ovhip_dbf_offsets offs;
     const ovhip_dbf_edge *ev = ovhip_rec_dbf_edges(rec, 0, &n_ev, &offs);
     const ovhip_dbf_edge *eh = ovhip_rec_dbf_edges(rec, 1, &n_eh, nullptr);
@@ -357,6 +368,7 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
     }
     CHK(h2d(j, B_TB, tb, n_tb * sizeof(*tb)));
     CHK(h2d(j, B_COEF, coef, n_coef * sizeof(*coef)));
+    CHK(h2d(j, B_ITASK, it, n_it * sizeof(*it)));
     if (n_reg) CHK(dev_reserve(j, B_SCALE, n_reg * 2));
     // (refined units that went through the eager per-row search are uploaded again with the rest: the list is small and
     // the full kernel repeats the search with the identical result)
@@ -397,12 +409,13 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
         if (n_ciip) { CHK(ovhip_ciip_launch(ctx, dst, intra, (const ovhip_ciip_unit *)DEV(B_CIIP), (uint32_t)n_ciip)); j->st.n_launches++; }
     }
     // ---- residual: luma blocks, chroma-scale derivation on the reconstructed luma, chroma blocks (+ inverse mapping) ----
-    const int ordered = 0;   // pictures with an ordered (intra) pass keep the luma plane in the mapped domain until it has run
     if (stages & OVHIP_STAGE_ITX) {
         const ovhip_tb_cmd *d_tb = (const ovhip_tb_cmd *)j->dev[B_TB].p;
         const int16_t *d_coef = (const int16_t *)j->dev[B_COEF].p;
         if (cls[0] + cls[1]) {
             StageTimer t_(j, OVHIP_TIME_ITX_LUMA);
+            if (ordered) CHK(ovhip_itx_launch_classes_res(ctx, dst, &j->res, d_tb, (uint32_t)cls[0], (uint32_t)cls[1], d_coef, nullptr));
+            else
             CHK(ovhip_itx_launch_classes(ctx, dst, d_tb, (uint32_t)cls[0], (uint32_t)cls[1], d_coef, nullptr));
             j->st.n_launches++;
         }
@@ -420,11 +433,27 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
             j->st.n_launches++;
         } else {
             if (cls[2] + cls[3]) {
-                CHK(ovhip_itx_launch_classes(ctx, dst, d_tbc, (uint32_t)cls[2], (uint32_t)cls[3], d_coef, d_scales));
+                if (ordered) CHK(ovhip_itx_launch_classes_res(ctx, dst, &j->res, d_tbc, (uint32_t)cls[2], (uint32_t)cls[3], d_coef, d_scales));
+                else CHK(ovhip_itx_launch_classes(ctx, dst, d_tbc, (uint32_t)cls[2], (uint32_t)cls[3], d_coef, d_scales));
                 j->st.n_launches++;
             }
             if (pr->lmcs && !ordered) { CHK(ovhip_lmcs_inverse_launch(ctx, dst, d_bwd)); j->st.n_launches++; }
         }
+    }
+    // ---- ordered pass: one launch per level (the launch boundary is the inter-level synchronisation), then the inverse
+    // luma mapping it had to wait for ----
+    if (ordered) {
+        StageTimer t_(j, OVHIP_TIME_INTRA);
+        const ovhip_itask *d_it = (const ovhip_itask *)j->dev[B_ITASK].p;
+        for (uint32_t l = 0; l < n_lv; ++l) {
+            const uint32_t a = lv_start[l], b = lv_start[l + 1];
+            if (b > a) {
+                CHK(ovhip_intra_level_launch(ctx, dst, &j->res, d_it + a, b - a, (const ovhip_lmcs_region *)DEV(B_REG), pr->lmcs,
+                                             (int16_t *)j->dev[B_SCALE].p, log2_ctu));
+                j->st.n_launches++;
+            }
+        }
+        if (pr->lmcs && (stages & OVHIP_STAGE_ITX)) { CHK(ovhip_lmcs_inverse_launch(ctx, dst, d_bwd)); j->st.n_launches++; }
     }
     // ---- in-loop filters ----
     if (stages & OVHIP_STAGE_DBF) {

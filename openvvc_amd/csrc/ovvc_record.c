@@ -54,7 +54,10 @@ void
 ovhip_rec_destroy(ovhip_recorder *r)
 {
     if (!r) return;
-    void *bufs[] = { r->tb, r->coef, r->mc, r->mcx, r->aff, r->aff_side, r->reg, r->tb_split, r->ciip, r->edge_v, r->edge_h };
+    void *bufs[] = { r->tb, r->coef, r->mc, r->mcx, r->aff, r->aff_side, r->reg, r->tb_split, r->ciip, r->edge_v, r->edge_h,
+                     r->itask, r->itask_sorted };
+    free(r->ilevel_start);
+    ovhip_rec_intra_free_(r);
     for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); ++i) ovhip_rec_free_(r, bufs[i]);
     ovhip_rec_dbf_free_(r);
     free(r);
@@ -67,6 +70,7 @@ ovhip_rec_reset(ovhip_recorder *r)
     r->n_tb = r->n_coef = r->n_mc = r->n_mcx = r->n_aff = r->n_side = r->n_reg = r->n_ciip = 0;
     r->n_edge_v = r->n_edge_h = 0;
     r->n_dbf_off = 0;
+    ovhip_rec_intra_reset_(r);
     ovhip_rec_dbf_reset_(r);
 }
 
@@ -122,6 +126,7 @@ ovhip_rec_append_raw(ovhip_recorder *r, int which, const void *data, size_t n)
     case OVHIP_REC_CIIP:   p = (void **)&r->ciip;     cnt = &r->n_ciip;   cap = &r->cap_ciip;   elem = sizeof(ovhip_ciip_unit); break;
     case OVHIP_REC_EDGE_V: p = (void **)&r->edge_v;   cnt = &r->n_edge_v; cap = &r->cap_edge_v; elem = sizeof(ovhip_dbf_edge); break;
     case OVHIP_REC_EDGE_H: p = (void **)&r->edge_h;   cnt = &r->n_edge_h; cap = &r->cap_edge_h; elem = sizeof(ovhip_dbf_edge); break;
+    case OVHIP_REC_ITASK:  p = (void **)&r->itask;    cnt = &r->n_itask;  cap = &r->cap_itask;  elem = sizeof(ovhip_itask); break;
     default: return OVHIP_EINVAL;
     }
     if (grow(p, cap, *cnt + n, elem)) return OVHIP_ENOMEM;
@@ -380,10 +385,23 @@ emit_tb(ovhip_recorder *r, const ovhip_tu_state *st, const struct tb_args *a, ov
 int
 ovhip_rec_tu(ovhip_recorder *r, const ovhip_tu_state *st, const ovhip_tu_desc *tu)
 {
+    return ovhip_rec_tu_intra(r, st, tu, NULL, NULL);
+}
+
+int
+ovhip_rec_tu_intra(ovhip_recorder *r, const ovhip_tu_state *st, const ovhip_tu_desc *tu, const ovhip_itask *intra_l, const ovhip_itask *intra_c)
+{
     if (!r || !st || !tu) return OVHIP_EINVAL;
-    const size_t n0 = r->n_tb, c0 = r->n_coef;
+    const size_t n0 = r->n_tb, c0 = r->n_coef, t0 = r->n_itask;
     int ret;
     ovhip_tb_cmd *c;
+    int ti_l = -1, ti_c = -1;
+    if ((intra_l && (intra_l->kind != OVHIP_IT_LUMA || tu->tree == 2)) || (intra_c && (intra_c->kind != OVHIP_IT_CHROMA || tu->tree == 1)))
+        return OVHIP_EINVAL;
+    /* the luma prediction comes first (rcn_intra_tu before rcn_tu_st, rcn_transform_tree.c:1437-1441) */
+    if (intra_l) {
+        if ((ti_l = ovhip_rec_itask_add_(r, intra_l, 0)) < 0) return ti_l;
+    }
 
     /* ---- luma (rcn_tu_st / rcn_tu_l) ---- */
     if (tu->tree != 2 && (tu->cbf_mask & 0x10)) {
@@ -403,10 +421,11 @@ ovhip_rec_tu(ovhip_recorder *r, const ovhip_tu_state *st, const ovhip_tu_desc *t
         a.last_pos = tu->last_pos[2]; a.sig_sb_map = tu->sig_sb_map[2]; a.coef = tu->coef[2];
         if ((ret = emit_tb(r, st, &a, &c))) goto fail;
         c->res_mode = OVHIP_RES_ADD;
+        if (ti_l >= 0) { c->res_mode |= OVHIP_RES_STORE; r->itask[ti_l].flags |= OVHIP_IF_RES_Y; }
     }
 
     /* ---- chroma ---- */
-    if (tu->tree != 1 && (tu->cbf_mask & 0xb)) {
+    if (tu->tree != 1 && ((tu->cbf_mask & 0xb) || intra_c)) {
         int xc, yc, l2w, l2h, lfnst_flag;
         if (tu->tree == 2) { xc = tu->x0; yc = tu->y0; l2w = tu->log2_tb_w; l2h = tu->log2_tb_h; lfnst_flag = tu->lfnst_flag; }
         else { xc = tu->x0 >> 1; yc = tu->y0 >> 1; l2w = tu->log2_tb_w - 1; l2h = tu->log2_tb_h - 1; lfnst_flag = 0; }
@@ -414,9 +433,25 @@ ovhip_rec_tu(ovhip_recorder *r, const ovhip_tu_state *st, const ovhip_tu_desc *t
         int16_t scale = st->lmcs_scale_c ? st->lmcs_chroma_scale : (int16_t)(1 << 11);
         /* lmcs_scale_c == 2: the scale is derived on the device; the command carries the region index */
         const int indirect = st->lmcs_scale_c == 2;
+        uint16_t reg_lvl = 0;
         if (indirect) {
             if (!r->n_reg) { ret = OVHIP_EINVAL; goto fail; }
             scale = (int16_t)(r->n_reg - 1);
+            reg_lvl = r->reg_level ? r->reg_level[r->n_reg - 1] : 0;
+        }
+        /* the chroma prediction of an intra CU sits between the TU's luma and chroma residuals (rcn_tu_st :1269-1287);
+         * a chroma block of any other CU becomes ordered when its residual scale comes from an ordered region */
+        {
+            const int has_res = (tu->cbf_mask & 0xb) != 0;
+            const int scaled = (l2w + l2h != 2) && (st->ict_type & 1) && has_res;
+            if (intra_c) {
+                if ((ti_c = ovhip_rec_itask_add_(r, intra_c, scaled && indirect ? (uint16_t)(reg_lvl ? reg_lvl : 0) : 0)) < 0) { ret = ti_c; goto fail; }
+            } else if (scaled && indirect && reg_lvl && has_res) {
+                ovhip_itask t;
+                memset(&t, 0, sizeof(t));
+                t.x = (uint16_t)xc; t.y = (uint16_t)yc; t.log2_w = (uint8_t)l2w; t.log2_h = (uint8_t)l2h; t.kind = OVHIP_IT_RES_C;
+                if ((ti_c = ovhip_rec_itask_add_(r, &t, reg_lvl)) < 0) { ret = ti_c; goto fail; }
+            }
         }
         struct tb_args a;
         memset(&a, 0, sizeof(a));
@@ -441,6 +476,12 @@ ovhip_rec_tu(ovhip_recorder *r, const ovhip_tu_state *st, const ovhip_tu_desc *t
             c->plane2    = (uint8_t)second;
             c->res_mode2 = ict_mode(st->ict_type, k2);
             if (indirect && l2w + l2h != 2 && (c->res_mode & OVHIP_RES_SCALE)) { c->res_mode |= OVHIP_RES_SCALE_IDX; c->res_mode2 |= OVHIP_RES_SCALE_IDX; }
+            if (ti_c >= 0) {
+                ovhip_itask *t = &r->itask[ti_c];
+                t->flags |= OVHIP_IF_RES_CB | OVHIP_IF_RES_CR;
+                if (c->res_mode & OVHIP_RES_SCALE) { t->flags |= OVHIP_IF_RES_SCALE | (indirect ? OVHIP_IF_SCALE_IDX : 0); t->c_scale = c->c_scale; }
+                c->res_mode |= OVHIP_RES_STORE; c->res_mode2 |= OVHIP_RES_STORE;
+            }
         } else {
             for (int comp = 0; comp < 2; ++comp) {      /* 0: Cb (cbf 0x2), 1: Cr (cbf 0x1) */
                 int bit = comp ? 0x1 : 0x2;
@@ -456,6 +497,12 @@ ovhip_rec_tu(ovhip_recorder *r, const ovhip_tu_state *st, const ovhip_tu_desc *t
                     if (indirect && (c->res_mode & OVHIP_RES_SCALE)) c->res_mode |= OVHIP_RES_SCALE_IDX;
                 }
                 else               { c->res_mode = OVHIP_RES_ADD; }
+                if (ti_c >= 0) {
+                    ovhip_itask *t = &r->itask[ti_c];
+                    t->flags |= comp ? OVHIP_IF_RES_CR : OVHIP_IF_RES_CB;
+                    if (c->res_mode & OVHIP_RES_SCALE) { t->flags |= OVHIP_IF_RES_SCALE | (indirect ? OVHIP_IF_SCALE_IDX : 0); t->c_scale = c->c_scale; }
+                    c->res_mode |= OVHIP_RES_STORE;
+                }
             }
         }
     }
@@ -463,6 +510,7 @@ ovhip_rec_tu(ovhip_recorder *r, const ovhip_tu_state *st, const ovhip_tu_desc *t
 fail:
     r->n_tb = n0;
     r->n_coef = c0;
+    r->n_itask = t0;          /* (the level maps keep the marks of the dropped tasks: harmless, levels only grow) */
     return ret;
 }
 
@@ -801,6 +849,22 @@ ovhip_rec_lmcs_region(ovhip_recorder *r, int32_t x0, int32_t y0, uint32_t abv_ma
     /* lmcs_compute_luma_average walks each mask until it is exhausted (rcn_lmcs.c:219-246) */
     g->n_abv = (uint8_t)bit_length(abv_mask & 0xffff);
     g->n_lft = (uint8_t)bit_length(lft_mask & 0xffff);
+    /* luma around the region reconstructed by ordered tasks: the scale is derived in the ordered pass */
+    if (r->cap_reglvl < r->cap_reg) {
+        uint16_t *q = (uint16_t *)realloc(r->reg_level, r->cap_reg * sizeof(uint16_t));
+        if (!q) return OVHIP_ENOMEM;
+        r->reg_level = q; r->cap_reglvl = r->cap_reg;
+    }
+    const uint16_t lvl = ovhip_rec_region_level_(r, x0, y0, g->n_abv, g->n_lft);
+    r->reg_level[r->n_reg] = lvl;
+    if (lvl) {
+        ovhip_itask t;
+        memset(&t, 0, sizeof(t));
+        t.x = g->x; t.y = g->y; t.kind = OVHIP_IT_REGION; t.c_scale = (int16_t)r->n_reg;
+        int ti = ovhip_rec_itask_add_(r, &t, (uint16_t)(lvl - 1));
+        if (ti < 0) return ti;
+        g->ordered = 1;
+    }
     return (int)r->n_reg++;
 }
 

@@ -1,0 +1,174 @@
+/* ovvc_record_intra.c -- host recorder, ordered tasks (plain C, no GPU needed).
+ *
+ * The reference reconstructs in decoding order, so an intra block simply finds its neighbours reconstructed
+ * (rcn_intra_tu -> intra_pred -> rcn_tu_st, rcn_transform_tree.c:1384-1451).  The device path runs everything that does
+ * not read the current picture first, stage-parallel; what does -- intra prediction, CIIP's planar part, chroma-scale
+ * regions next to such blocks and the chroma residuals scaled by them -- is recorded here as ovhip_itask with a LEVEL:
+ * 1 + the highest level among the tasks that produce the samples it reads.  Level maps on the 4x4-luma grid (one for luma,
+ * one for the chroma pair) hold the level of the task that last wrote each unit (0: written by the unordered launches).
+ * Availability (which neighbours exist at all) is the caller's information (progress bit-fields, rcn_fill_ref.h:40-64);
+ * only available neighbours create dependencies.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "ovvc_hip.h"
+#include "ovvc_record_priv.h"
+
+static int
+maps_ready(ovhip_recorder *r)
+{
+    const int w4 = (r->pic_w + 3) >> 2, h4 = (r->pic_h + 3) >> 2;
+    if (!r->lvl_y) {
+        r->lvl_y = (uint16_t *)calloc((size_t)w4 * h4, 2);
+        r->lvl_c = (uint16_t *)calloc((size_t)w4 * h4, 2);
+        if (!r->lvl_y || !r->lvl_c) return -1;
+        r->lvl_w4 = w4; r->lvl_h4 = h4; r->lvl_dirty = 0;
+    }
+    if (r->lvl_dirty) {
+        memset(r->lvl_y, 0, (size_t)w4 * h4 * 2); memset(r->lvl_c, 0, (size_t)w4 * h4 * 2);
+        r->lvl_dirty = 0;
+    }
+    return 0;
+}
+
+int
+ovhip_rec_intra_reset_(ovhip_recorder *r)
+{
+    r->n_itask = 0; r->n_ilevels = 0;
+    if (r->lvl_y) r->lvl_dirty = 1;          /* cleared lazily: pictures without ordered tasks never touch the maps */
+    return 0;
+}
+
+void
+ovhip_rec_intra_free_(ovhip_recorder *r)
+{
+    free(r->lvl_y); free(r->lvl_c); free(r->reg_level);
+    r->lvl_y = r->lvl_c = NULL; r->reg_level = NULL;
+}
+
+/* highest level over the units [ux0, ux0 + nx) x [uy0, uy0 + ny) of a map, clipped to the picture */
+static int
+max_level(const ovhip_recorder *r, const uint16_t *map, int ux0, int uy0, int nx, int ny)
+{
+    int m = 0;
+    int x1 = ux0 + nx, y1 = uy0 + ny;
+    if (ux0 < 0) ux0 = 0;
+    if (uy0 < 0) uy0 = 0;
+    if (x1 > r->lvl_w4) x1 = r->lvl_w4;
+    if (y1 > r->lvl_h4) y1 = r->lvl_h4;
+    for (int y = uy0; y < y1; ++y)
+        for (int x = ux0; x < x1; ++x)
+            if (map[y * r->lvl_w4 + x] > m) m = map[y * r->lvl_w4 + x];
+    return m;
+}
+
+static void
+set_level(ovhip_recorder *r, uint16_t *map, int ux0, int uy0, int nx, int ny, int level)
+{
+    int x1 = ux0 + nx, y1 = uy0 + ny;
+    if (x1 > r->lvl_w4) x1 = r->lvl_w4;
+    if (y1 > r->lvl_h4) y1 = r->lvl_h4;
+    for (int y = uy0; y < y1; ++y)
+        for (int x = ux0; x < x1; ++x) map[y * r->lvl_w4 + x] = (uint16_t)level;
+}
+
+uint16_t
+ovhip_rec_region_level_(ovhip_recorder *r, int32_t x0, int32_t y0, int n_abv, int n_lft)
+{
+    if (!r->n_itask || maps_ready(r)) return 0;
+    const int ux = x0 >> 2, uy = y0 >> 2;
+    int m = 0, k;
+    if (n_abv && (k = max_level(r, r->lvl_y, ux, uy - 1, n_abv, 1)) > m) m = k;
+    if (n_lft && (k = max_level(r, r->lvl_y, ux - 1, uy, 1, n_lft)) > m) m = k;
+    return (uint16_t)(m ? m + 1 : 0);
+}
+
+/* Appends a task; its level = 1 + max(levels of the units it reads, extra_level).  Returns the task index or <0. */
+int
+ovhip_rec_itask_add_(ovhip_recorder *r, const ovhip_itask *in, uint16_t extra_level)
+{
+    if (maps_ready(r)) return OVHIP_ENOMEM;
+    if (ovhip_rec_grow_(r, (void **)&r->itask, &r->cap_itask, r->n_itask + 1, sizeof(ovhip_itask))) return OVHIP_ENOMEM;
+    ovhip_itask t = *in;
+    const int w = 1 << t.log2_w, h = 1 << t.log2_h;
+    int m = extra_level, k;
+    if (t.kind == OVHIP_IT_LUMA) {
+        const int ux = t.x >> 2, uy = t.y >> 2, nx = (w + 3) >> 2, ny = (h + 3) >> 2;
+        if ((t.flags & OVHIP_IF_CORNER) && (k = max_level(r, r->lvl_y, ux - 1, uy - 1, 1, 1)) > m) m = k;
+        if (t.avl_abv && (k = max_level(r, r->lvl_y, ux, uy - 1, t.avl_abv, 1)) > m) m = k;
+        if (t.avl_lft && (k = max_level(r, r->lvl_y, ux - 1, uy, 1, t.avl_lft)) > m) m = k;
+        if (t.ciip_wt && (k = max_level(r, r->lvl_y, ux, uy, nx, ny)) > m) m = k;     /* blends into what is there */
+        if (m >= 65534) return OVHIP_EUNSUP;
+        t.level = (uint16_t)(m + 1);
+        set_level(r, r->lvl_y, ux, uy, nx, ny, t.level);
+    } else if (t.kind == OVHIP_IT_CHROMA || t.kind == OVHIP_IT_RES_C) {
+        /* chroma units are 2 chroma samples = the same 4x4-luma grid */
+        const int ux = t.x >> 1, uy = t.y >> 1, nx = (w + 1) >> 1, ny = (h + 1) >> 1;
+        if (t.kind == OVHIP_IT_CHROMA) {
+            if (t.mode >= 67) {
+                /* CCLM / MDLM: the co-located reconstructed luma block and the luma + chroma lines around it the parameter
+                 * derivation may read (up to w + min(w, h) above, h + min(w, h) left; rcn_intra_cclm.c:660-880) */
+                const int ext = w < h ? w : h;
+                const int na = (w + ext + 1) >> 1, nl = (h + ext + 1) >> 1;
+                if ((k = max_level(r, r->lvl_y, ux, uy, nx, ny)) > m) m = k;
+                if (t.avl_abv) { if ((k = max_level(r, r->lvl_y, ux - 1, uy - 1, na + 1, 1)) > m) m = k; if ((k = max_level(r, r->lvl_c, ux, uy - 1, na, 1)) > m) m = k; }
+                if (t.avl_lft) { if ((k = max_level(r, r->lvl_y, ux - 1, uy - 1, 1, nl + 1)) > m) m = k; if ((k = max_level(r, r->lvl_c, ux - 1, uy, 1, nl)) > m) m = k; }
+            } else {
+                if ((t.flags & OVHIP_IF_CORNER) && (k = max_level(r, r->lvl_c, ux - 1, uy - 1, 1, 1)) > m) m = k;
+                if (t.avl_abv && (k = max_level(r, r->lvl_c, ux, uy - 1, t.avl_abv, 1)) > m) m = k;
+                if (t.avl_lft && (k = max_level(r, r->lvl_c, ux - 1, uy, 1, t.avl_lft)) > m) m = k;
+            }
+        }
+        if ((t.kind == OVHIP_IT_RES_C || t.ciip_wt) && (k = max_level(r, r->lvl_c, ux, uy, nx, ny)) > m) m = k;
+        if (m >= 65534) return OVHIP_EUNSUP;
+        t.level = (uint16_t)(m + 1);
+        set_level(r, r->lvl_c, ux, uy, nx, ny, t.level);
+    } else if (t.kind == OVHIP_IT_REGION) {
+        if (m >= 65534) return OVHIP_EUNSUP;
+        t.level = (uint16_t)(m + 1);          /* extra_level = what ovhip_rec_region_level_ found, minus one */
+    } else {
+        return OVHIP_EINVAL;
+    }
+    r->itask[r->n_itask] = t;
+    return (int)r->n_itask++;
+}
+
+const ovhip_itask *
+ovhip_rec_itasks(const ovhip_recorder *r, size_t *n)
+{
+    if (!r || !n) return NULL;
+    *n = r->n_itask;
+    return r->itask;
+}
+
+/* counting sort by level (stable: decoding order inside a level) */
+const ovhip_itask *
+ovhip_rec_itasks_sorted(ovhip_recorder *r, size_t *n, const uint32_t **level_start, uint32_t *n_levels)
+{
+    if (!r || !n || !level_start || !n_levels) return NULL;
+    *n = r->n_itask; *n_levels = 0; *level_start = NULL;
+    if (!r->n_itask) return r->itask;
+    uint32_t maxl = 0;
+    for (size_t i = 0; i < r->n_itask; ++i) if (r->itask[i].level > maxl) maxl = r->itask[i].level;
+    if (ovhip_rec_grow_(r, (void **)&r->itask_sorted, &r->cap_isorted, r->n_itask, sizeof(ovhip_itask))) { *n = 0; return NULL; }
+    {   /* level table: plain host memory */
+        if (r->cap_ilevel < maxl + 2) {
+            uint32_t *q = (uint32_t *)realloc(r->ilevel_start, (size_t)(maxl + 2) * 2 * sizeof(uint32_t));
+            if (!q) { *n = 0; return NULL; }
+            r->ilevel_start = q; r->cap_ilevel = (size_t)(maxl + 2) * 2;
+        }
+    }
+    uint32_t *start = r->ilevel_start;
+    memset(start, 0, (maxl + 2) * sizeof(uint32_t));
+    for (size_t i = 0; i < r->n_itask; ++i) start[r->itask[i].level]++;         /* counts at [level], level >= 1 */
+    uint32_t acc = 0;
+    for (uint32_t l = 1; l <= maxl; ++l) { const uint32_t c = start[l]; start[l] = acc; acc += c; }
+    start[maxl + 1] = acc;
+    uint32_t *fill = start + maxl + 2;                                          /* second half: running positions */
+    memcpy(fill, start, (maxl + 2) * sizeof(uint32_t));
+    for (size_t i = 0; i < r->n_itask; ++i) r->itask_sorted[fill[r->itask[i].level]++] = r->itask[i];
+    r->n_ilevels = maxl;
+    *n_levels = maxl;
+    *level_start = start + 1;                                                   /* entry l = first task of level l + 1 */
+    return r->itask_sorted;
+}

@@ -24,7 +24,20 @@ struct ovhip_recorder {
     /* compact edge lists, emitted directly per CTU (what the device kernel consumes) */
     ovhip_dbf_edge *edge_v, *edge_h; size_t n_edge_v, cap_edge_v, n_edge_h, cap_edge_h;
     ovhip_dbf_offsets dbf_off; int n_dbf_off;   /* distinct (beta, tc) offset pairs of the picture's slices */
+    /* ordered tasks (ovvc_record_intra.c) */
+    ovhip_itask *itask; size_t n_itask, cap_itask;
+    ovhip_itask *itask_sorted; size_t cap_isorted;
+    uint32_t *ilevel_start; size_t cap_ilevel; uint32_t n_ilevels;
+    uint16_t *lvl_y, *lvl_c;            /* level of the ordered task covering each 4x4-luma unit (0: none), luma / chroma */
+    int32_t lvl_w4, lvl_h4; int lvl_dirty;
+    uint16_t *reg_level; size_t cap_reglvl;     /* level of each chroma-scale region (0: derived by the unordered launch) */
 };
+
+int  ovhip_rec_intra_reset_(ovhip_recorder *r);
+void ovhip_rec_intra_free_(ovhip_recorder *r);
+/* recorder-internal: the ordered tasks of one TU, called by ovhip_rec_tu_intra around its transform blocks */
+int  ovhip_rec_itask_add_(ovhip_recorder *r, const ovhip_itask *t, uint16_t extra_level);
+uint16_t ovhip_rec_region_level_(ovhip_recorder *r, int32_t x0, int32_t y0, int n_abv, int n_lft);
 
 int  ovhip_rec_grow_(ovhip_recorder *r, void **p, size_t *cap, size_t need, size_t elem);
 void ovhip_rec_free_(ovhip_recorder *r, void *p);

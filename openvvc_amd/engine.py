@@ -107,6 +107,14 @@ class Context:
     def lmcs_inverse(self, pic: "DevPic", bwd_lut: "DevBuf"):
         self._chk(self.lib.ovhip_lmcs_inverse_launch(self.h, C.byref(pic.s), bwd_lut.ptr), "lmcs_inverse_launch")
 
+    def intra_level(self, pic: "DevPic", res: "DevPic", tasks: "DevBuf", first: int, n: int, regions: "DevBuf | None" = None,
+                    luts=None, scales: "DevBuf | None" = None, log2_ctu: int = 7):
+        """One level of the ordered pass: tasks [first, first + n) of the device task list."""
+        ptr = C.c_void_p(tasks.ptr.value + first * 32)
+        self._chk(self.lib.ovhip_intra_level_launch(self.h, C.byref(pic.s), C.byref(res.s), ptr, n, regions.ptr if regions else None,
+                                                    C.byref(luts) if luts is not None else None, scales.ptr if scales else None, log2_ctu),
+                  "intra_level_launch")
+
     def dbf(self, pic: "DevPic", planes: "DevDbfPlanes"):
         self._chk(self.lib.ovhip_dbf_launch(self.h, C.byref(pic.s), C.byref(planes.s)), "dbf_launch")
 
@@ -403,7 +411,7 @@ class Job:
         r = self.rec
         for which, arr in ((capi.REC_COEF, wl.coefs), (capi.REC_TB, wl.tb_cmds), (capi.REC_MC, wl.mc_units),
                            (capi.REC_MCX, wl.mcx_units), (capi.REC_AFF, wl.aff_units), (capi.REC_SIDE, wl.aff_side),
-                           (capi.REC_REGION, wl.lmcs_regions), (capi.REC_CIIP, wl.ciip_units),
+                           (capi.REC_REGION, wl.lmcs_regions), (capi.REC_CIIP, wl.ciip_units), (capi.REC_ITASK, wl.itasks),
                            (capi.REC_EDGE_V, capi.dbf_compact(wl.dbf_planes, 0)), (capi.REC_EDGE_H, capi.dbf_compact(wl.dbf_planes, 1))):
             if arr is not None and len(arr):
                 r.append_raw(which, arr)

@@ -100,6 +100,7 @@ class Workload:
     dbf_planes: dict = None         # picture-level deblocking edge planes (include/ovvc_hip.h)
     sao_params: np.ndarray = None   # capi.SAO_CTU_DTYPE per CTU
     alf: dict = None                # ALF tables + per-CTU parameters
+    itasks: np.ndarray = None       # capi.ITASK_DTYPE, decoding order: intra / CIIP / ordered-scale tasks (None: none)
     stats: dict = field(default_factory=dict)
 
     @property
@@ -136,10 +137,13 @@ def _lmcs_tables(rs) -> "capi.LmcsLuts":
 
 # coding tools of an inter picture; "base" = translational uni / bi / BCW prediction only
 ALL_TOOLS = ("bdof", "dmvr", "affine", "gpm", "ciip", "lmcs")
+# + "intra": intra CUs (intra_frac of the CUs <= 64x64; 1.0 = an I picture) predicted on the device in dependency order,
+# and CIIP's planar part computed there too instead of being read from a caller-supplied picture
+INTRA_TOOLS = ALL_TOOLS + ("intra",)
 
 
 def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6, cbf_y: float = 0.5,
-                  cbf_c: float = 0.3, mv_range_px: int = 64, tools=ALL_TOOLS) -> Workload:
+                  cbf_c: float = 0.3, mv_range_px: int = 64, tools=ALL_TOOLS, intra_frac: float = 0.12) -> Workload:
     """tools: subset of ALL_TOOLS.  Rates follow JVET CTC random-access statistics in spirit: of the
     bi-predicted CUs that satisfy check_bdof() (vcl_coding_unit.c:2019-2027) and whose references lie on
     opposite sides of the picture, ~45 % use BDOF alone and ~35 % DMVR (+BDOF); ~8 % of the CUs >= 16x16
@@ -170,9 +174,20 @@ def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6
     lmcs_on = "lmcs" in tools
 
     # ---- coding mode per CU ----
-    PLAIN, BDOF, DMVR, AFFINE, GPM, CIIP = range(6)
+    PLAIN, BDOF, DMVR, AFFINE, GPM, CIIP, INTRA = range(7)
     mode = np.zeros(n, np.int32)
     r = rs.random_sample((n, 3))
+    dev_intra = "intra" in tools
+    if dev_intra:
+        # intra CUs come in clusters in real pictures (occlusions, new content): one draw per 32x32 area + per-CU noise
+        gx, gy = (w + 31) // 32, (h + 31) // 32
+        area_hot = rs.random_sample((gy, gx)) < intra_frac * 0.8
+        hot = area_hot[cus[:, 1] // 32, cus[:, 0] // 32]
+        is_intra = ((hot & (rs.random_sample(n) < 0.85)) | (rs.random_sample(n) < intra_frac * 0.3) | (intra_frac >= 1.0)) & (lw <= 6) & (lh <= 6)
+        if intra_frac >= 1.0:
+            assert is_intra.all() or (lw.max() > 6 or lh.max() > 6)
+    else:
+        is_intra = np.zeros(n, bool)
     if "affine" in tools:
         mode = np.where((lw >= 4) & (lh >= 4) & (r[:, 0] < 0.08), AFFINE, mode)
     if "gpm" in tools:
@@ -184,6 +199,7 @@ def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6
         mode = np.where(elig & (r[:, 1] < 0.35), DMVR, mode)
     if "bdof" in tools:
         mode = np.where(elig & (mode == PLAIN) & (r[:, 1] < 0.80), BDOF, mode)
+    mode = np.where(is_intra, INTRA, mode)
     bcw = np.where(np.isin(mode, (GPM, CIIP)), 0, bcw)
     hpel = np.where(np.isin(mode, (AFFINE,)) | ((lw == 2) & (lh == 2)), False, hpel)
     # merge-mode (DMVR) motion is close to mirrored between the two lists
@@ -195,9 +211,12 @@ def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6
     pd = capi.PuDesc()
     ad = capi.AffineDesc()
     cu_modes = (1, 2, 4, 6)             # OV_INTER, OV_INTRA, OV_MIP, OV_INTER_SKIP (cu_utils.h:132-139)
+    ciip_wt = np.zeros(n, np.int32)
     for i in range(n):
         x, y, l2w, l2h = (int(v) for v in cus[i])
         m = int(mode[i])
+        if m == INTRA:
+            continue
         ref0s, ref1s = int(slot[0, ridx[i, 0]]), int(slot[1, ridx[i, 1]])
         if m == AFFINE:
             nsx, nsy = (1 << l2w) >> 2, (1 << l2h) >> 2
@@ -236,8 +255,11 @@ def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6
             pd.refine = capi.PU_GPM; pd.inter_dir = 3; pd.gpm_split_dir = int(rs.randint(0, 64))
         pd.ciip_wt = 0
         if m == CIIP:
-            # rcn_ciip(_b): inter prediction + blend with the planar prediction (caller-supplied picture), fused into the units
-            pd.ciip_wt = capi.load().ovhip_ciip_weight(cu_modes[rs.randint(0, 4)], cu_modes[rs.randint(0, 4)])
+            # rcn_ciip(_b): inter prediction + blend with the planar prediction; without device intra the planar prediction
+            # comes from a caller-supplied picture and the blend is fused into the units, with it the blend is an ordered task
+            ciip_wt[i] = capi.load().ovhip_ciip_weight(cu_modes[rs.randint(0, 4)], cu_modes[rs.randint(0, 4)])
+            if not dev_intra:
+                pd.ciip_wt = int(ciip_wt[i])
         rec.pu(pd)
 
     # ---- transform units ----
@@ -250,13 +272,36 @@ def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6
     coef_pool = _coef_values(rs, 1 << 20)
     pool_pos = 0
     bufs = [np.zeros(32 * 32, np.int16) for _ in range(3)]
+    w4, h4 = (w + 3) // 4, (h + 3) // 4
+    done = np.zeros((h4 + 1, w4 + 1), bool)          # decoding progress on the 4x4 grid (what the progress bit-fields hold)
+
+    def avail(ux, uy, nw, nh):
+        """(corner, units available above from ux, units available left from uy): neighbours decoded before this block"""
+        corner = bool(ux > 0 and uy > 0 and done[uy - 1, ux - 1])
+        a = 0
+        if uy > 0:
+            while a < 2 * nw and ux + a < w4 and done[uy - 1, ux + a]:
+                a += 1
+        l = 0
+        if ux > 0:
+            while l < 2 * nh and uy + l < h4 and done[uy + l, ux - 1]:
+                l += 1
+        return corner, a, l
+
     for i in range(n):
         x, y, l2w, l2h = (int(v) for v in cus[i])
+        cu_intra, cu_ciip = mode[i] == INTRA, (mode[i] == CIIP and dev_intra)
         if lmcs_on and not (x & 63) and not (y & 63):
             # rcn_lmcs_compute_chroma_scale at every 64-aligned CU (vcl_coding_unit.c:724-730); neighbours are
             # available up to the picture edge
-            n_abv = min(16, (w - x) >> 2) if y > 0 else 0
-            n_lft = min(16, (h - y) >> 2) if x > 0 else 0
+            # available = decoded before this CU (the progress bit-fields of the reference, rcn_lmcs.c:327-332)
+            n_abv = n_lft = 0
+            if y > 0:
+                while n_abv < 16 and (x >> 2) + n_abv < w4 and done[(y >> 2) - 1, (x >> 2) + n_abv]:
+                    n_abv += 1
+            if x > 0:
+                while n_lft < 16 and (y >> 2) + n_lft < h4 and done[(y >> 2) + n_lft, (x >> 2) - 1]:
+                    n_lft += 1
             rec.lmcs_region(x, y, (1 << n_abv) - 1, (1 << n_lft) - 1)
         qp = int(rs.randint(22, 38)) + 12
         for ty in range(0, 1 << l2h, 64):
@@ -269,7 +314,7 @@ def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6
                         cbf |= 0x8 | int(rs.randint(1, 4))
                     else:
                         cbf |= (0x2 if r[2] < cbf_c else 0) | (0x1 if r[3] < cbf_c else 0)
-                if not cbf:
+                if not cbf and not (cu_intra or cu_ciip):
                     continue
                 td.x0, td.y0, td.log2_tb_w, td.log2_tb_h = x + tx, y + ty, tl2w, tl2h
                 td.tree = 0; td.cbf_mask = cbf; td.cu_flags = 0
@@ -278,6 +323,56 @@ def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6
                     td.cu_mts_flag = 1; td.cu_mts_idx = int(rs.randint(0, 4))
                 elif max(tl2w, tl2h) <= 5 and r[4] < 0.13 and (cbf & 0x10):
                     td.tr_skip_mask = 0x10
+                task_l = task_c = None
+                if cu_intra or cu_ciip:
+                    ux, uy, nw, nh = (x + tx) >> 2, (y + ty) >> 2, (1 << tl2w) >> 2, (1 << tl2h) >> 2
+                    corner, a_abv, a_lft = avail(ux, uy, nw, nh)
+                    task_l = capi.ITask()
+                    task_l.x, task_l.y, task_l.log2_w, task_l.log2_h, task_l.kind = x + tx, y + ty, tl2w, tl2h, capi.IT_LUMA
+                    task_l.flags = capi.IF_CORNER if corner else 0
+                    task_l.avl_abv, task_l.avl_lft = a_abv, a_lft
+                    task_c = capi.ITask()
+                    task_c.x, task_c.y, task_c.log2_w, task_c.log2_h, task_c.kind = (x + tx) >> 1, (y + ty) >> 1, tl2w - 1, tl2h - 1, capi.IT_CHROMA
+                    task_c.flags = task_l.flags
+                    task_c.avl_abv, task_c.avl_lft = a_abv, a_lft          # 2-chroma-sample units = the same grid
+                    if cu_ciip:
+                        task_l.mode = 0; task_l.ciip_wt = int(ciip_wt[i])
+                        task_c.mode = 0; task_c.ciip_wt = int(ciip_wt[i])
+                        if tl2w <= 2:
+                            task_c = None                                   # chroma of a 4-wide CIIP CU keeps the inter prediction
+                    else:
+                        td.cu_flags = 1 << 1                                # pred_mode_flag
+                        q = rs.random_sample(4)
+                        lmode = 0 if q[0] < 0.25 else 1 if q[0] < 0.35 else int(rs.randint(2, 67))
+                        st.intra_mode = lmode
+                        task_l.mode = lmode
+                        if q[1] < 0.08:                                      # matrix-based intra prediction
+                            n_mip = 16 if (tl2w == 2 and tl2h == 2) else 8 if (tl2h == 2 or tl2w == 2 or (tl2h <= 3 and tl2w <= 3)) else 6
+                            task_l.flags |= capi.IF_MIP | (capi.IF_MIP_TR if q[2] < 0.5 else 0)
+                            task_l.mode = int(rs.randint(0, n_mip)); td.cu_flags |= 1 << 2; lmode = 0
+                        elif q[1] < 0.14 and ((y + ty) & 127) and corner and a_abv:
+                            task_l.mrl_idx = int(rs.randint(1, 3))           # multi reference line (never on the first CTU row)
+                            if lmode < 2:
+                                task_l.mode = lmode = int(rs.randint(2, 67))
+                                st.intra_mode = lmode
+                        elif q[1] < 0.17 and max(tl2w, tl2h) <= 5 and (cbf & 0x10):
+                            vert = int(rs.randint(0, 2))                     # block DPCM: transform skip implied
+                            task_l.flags |= capi.IF_BDPCM | (capi.IF_BDPCM_VER if vert else 0); task_l.mode = 0
+                            td.cu_flags |= (1 << 8) | (vert << 10); td.tr_skip_mask = 0x10; td.cu_mts_flag = 0
+                        # chroma: derived (= luma mode), one of the fixed modes, or a cross-component linear model
+                        cq = rs.random_sample()
+                        if cq < 0.35:
+                            cm = int(rs.randint(67, 70))
+                            ext = min(1 << (tl2w - 1), 1 << (tl2h - 1))
+                            if cm == 67:
+                                task_c.avl_abv, task_c.avl_lft = int(a_abv > 0), int(a_lft > 0)
+                            elif cm == 69:
+                                task_c.avl_abv = min(a_abv, ((1 << (tl2w - 1)) + ext) >> 1); task_c.avl_lft = int(a_lft > 0)
+                            else:
+                                task_c.avl_lft = min(a_lft, ((1 << (tl2h - 1)) + ext) >> 1); task_c.avl_abv = int(a_abv > 0)
+                        else:
+                            cm = lmode if cq < 0.7 else (0, 1, 18, 50)[int(rs.randint(0, 4))]
+                        task_c.mode = cm
                 st.qp_y = qp; st.qp_cb = qp - 1; st.qp_cr = qp - 1; st.qp_jcbcr = qp - 2
                 st.qp_y_skip = max(qp, 16); st.qp_cb_skip = st.qp_cr_skip = st.qp_jcbcr_skip = max(qp - 1, 16)
                 for comp in range(3):
@@ -328,15 +423,21 @@ def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6
                             td.sig_sb_map[comp] = m; td.last_pos[comp] = 0x0101
                         pool_pos %= (len(coef_pool) - 4096)
                     td.coef[comp] = buf.ctypes.data
-                rec.tu(st, td)
+                if task_l is not None or task_c is not None:
+                    rec.tu_intra(st, td, task_l, task_c)
+                else:
+                    rec.tu(st, td)
                 n_tu += 1
+        done[y >> 2:(y + (1 << l2h)) >> 2, x >> 2:(x + (1 << l2w)) >> 2] = True
 
     cmds, classes = rec.tb_cmds_split()
     n_luma = classes[0] + classes[1]
     wl = Workload(w, h, seed, refs, pocs, cus, rec.mc_units(), cmds, rec.coefs(), n_luma_cmds=n_luma, tb_classes=classes)
     wl.mcx_units, wl.aff_units, wl.aff_side, wl.ciip_units = rec.mcx_units(), rec.aff_units(), rec.aff_side(), rec.ciip_units()
-    if len(wl.ciip_units) or (mode == CIIP).any():
+    if (len(wl.ciip_units) or (mode == CIIP).any()) and not dev_intra:
         wl.intra = random_picture(rs, w, h)
+    if dev_intra:
+        wl.itasks = rec.itasks()
     if lmcs_on:
         wl.lmcs = _lmcs_tables(rs)
         wl.lmcs_regions = rec.lmcs_regions()
@@ -351,7 +452,10 @@ def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6
         "n_cu": int(n), "n_tu": int(n_tu), "n_mc_units": int(len(u)), "n_mcx_units": int(len(ux)),
         "n_aff_units": int(len(ua)), "n_ciip_units": int(len(wl.ciip_units)), "n_tb_cmds": int(len(wl.tb_cmds)),
         "n_luma_cmds": int(n_luma), "n_lmcs_regions": 0 if wl.lmcs_regions is None else int(len(wl.lmcs_regions)),
-        "cu_modes": {k: int((mode == v).sum()) for k, v in (("plain", PLAIN), ("bdof", BDOF), ("dmvr", DMVR), ("affine", AFFINE), ("gpm", GPM), ("ciip", CIIP))},
+        "cu_modes": {k: int((mode == v).sum()) for k, v in (("plain", PLAIN), ("bdof", BDOF), ("dmvr", DMVR), ("affine", AFFINE), ("gpm", GPM), ("ciip", CIIP))
+                     + ((("intra", INTRA),) if dev_intra else ())},
+        "n_itasks": 0 if wl.itasks is None else int(len(wl.itasks)),
+        "n_ilevels": 0 if wl.itasks is None or not len(wl.itasks) else int(wl.itasks["level"].max()),
         "coef_bytes": int(wl.coefs.nbytes),
         "cmd_bytes": int(u.nbytes + ux.nbytes + ua.nbytes + wl.aff_side.nbytes + wl.tb_cmds.nbytes),
         # mean reference samples fetched per output sample (block window not counted), SURVEY 8d

@@ -146,7 +146,7 @@ static void residual_apply(uint16_t *dst, int dstride, const int16_t *res, int w
 
 /* One transform block.  rcn_residual (rcn_transform_tree.c:415-506), rcn_residual_c (:553-628),
  * transform-skip (:672-716, :1208-1225), ict.add / ict.ict (:1262, :750-756, :846-866). */
-static void itx_one(const oracle_pic *pic, const ovhip_tb_cmd *c, const int16_t *arena, const int16_t *lmcs_scales)
+static void itx_one(const oracle_pic *pic, const ovhip_tb_cmd *c, const int16_t *arena, const int16_t *lmcs_scales, const oracle_pic *respic)
 {
     const int log2_w = c->log2_w, log2_h = c->log2_h;
     const int tb_w = 1 << log2_w, tb_h = 1 << log2_h;
@@ -216,6 +216,26 @@ static void itx_one(const oracle_pic *pic, const ovhip_tb_cmd *c, const int16_t 
     }
 
     int stride;
+    if (c->res_mode & OVHIP_RES_STORE) {
+        /* block of an ordered task: the residual (after the sign / half variant, before chroma scaling) goes to the residual
+         * picture, saturated to int16; oracle_intra_tasks adds it to the prediction */
+        for (int k = 0; k < 1 + (c->plane2 != 0xff); ++k) {
+            const int plane = k ? c->plane2 : c->plane, mode = k ? c->res_mode2 : c->res_mode;
+            int16_t *d = (int16_t *)plane_ptr(respic, plane, &stride) + c->y * stride + c->x;
+            for (int y = 0; y < tb_h; ++y)
+                for (int x = 0; x < tb_w; ++x) {
+                    int32_t v = res[y * tb_w + x];
+                    switch (mode & 3) {
+                    case OVHIP_RES_SUB:      v = -v; break;
+                    case OVHIP_RES_ADD_HALF: v = v >> 1; break;
+                    case OVHIP_RES_SUB_HALF: v = (-v) >> 1; break;
+                    default: break;
+                    }
+                    d[y * stride + x] = (int16_t)clip16(v);
+                }
+        }
+        return;
+    }
     uint16_t *d = plane_ptr(pic, c->plane, &stride) + c->y * stride + c->x;
     /* OVHIP_RES_SCALE_IDX: the scale was derived from the reconstruction (oracle_lmcs_scale) */
     const int scale = (c->res_mode & OVHIP_RES_SCALE_IDX) ? lmcs_scales[c->c_scale] : c->c_scale;
@@ -226,9 +246,16 @@ static void itx_one(const oracle_pic *pic, const ovhip_tb_cmd *c, const int16_t 
     }
 }
 
+/* respic: int16 planes of the picture's geometry receiving the OVHIP_RES_STORE blocks (NULL: none expected) */
+void oracle_itx_res(const oracle_pic *pic, const ovhip_tb_cmd *cmds, uint32_t n, const int16_t *arena, const int16_t *lmcs_scales,
+                    const oracle_pic *respic)
+{
+    for (uint32_t i = 0; i < n; ++i) itx_one(pic, &cmds[i], arena, lmcs_scales, respic);
+}
+
 void oracle_itx_ex(const oracle_pic *pic, const ovhip_tb_cmd *cmds, uint32_t n, const int16_t *arena, const int16_t *lmcs_scales)
 {
-    for (uint32_t i = 0; i < n; ++i) itx_one(pic, &cmds[i], arena, lmcs_scales);
+    oracle_itx_res(pic, cmds, n, arena, lmcs_scales, NULL);
 }
 
 void oracle_itx(const oracle_pic *pic, const ovhip_tb_cmd *cmds, uint32_t n, const int16_t *arena)
@@ -241,11 +268,22 @@ void oracle_itx(const oracle_pic *pic, const ovhip_tb_cmd *cmds, uint32_t n, con
  * ================================================================================== */
 
 /* rcn_lmcs_compute_chroma_scale + lmcs_compute_luma_average + get_bwd_idx (rcn_lmcs.c:83-93, :204-350) */
+static void lmcs_scale_regions(const oracle_pic *pic, const ovhip_lmcs_region *regs, uint32_t n, const ovhip_lmcs_luts *luts,
+                               int16_t *scales, int ordered_too);
+
+/* the regions marked `ordered` are left to the ordered pass (oracle_intra_tasks) */
 void oracle_lmcs_scale(const oracle_pic *pic, const ovhip_lmcs_region *regs, uint32_t n,
                        const ovhip_lmcs_luts *luts, int16_t *scales)
 {
+    lmcs_scale_regions(pic, regs, n, luts, scales, 0);
+}
+
+static void lmcs_scale_regions(const oracle_pic *pic, const ovhip_lmcs_region *regs, uint32_t n, const ovhip_lmcs_luts *luts,
+                               int16_t *scales, int ordered_too)
+{
     for (uint32_t r = 0; r < n; ++r) {
         const ovhip_lmcs_region *g = &regs[r];
+        if (g->ordered && !ordered_too) continue;
         const uint16_t *src = pic->y + g->y * pic->stride_y + g->x;
         uint32_t s1 = 0, s2 = 0, s3 = 0, s4 = 0;
         int nb_abv = 0, nb_lft = 0, nb_units, log2_nb = 0;

@@ -466,7 +466,6 @@ store_block(uint16_t *dst, int dstride, const uint16_t *pred, const int16_t *res
         }
 }
 
-void oracle_lmcs_scale(const oracle_pic *pic, const ovhip_lmcs_region *regs, uint32_t n, const ovhip_lmcs_luts *luts, int16_t *scales);
 
 /* Executes the ordered tasks in array order (the recorder emits them in decoding order = a valid topological order; the
  * device runs them level by level).  res: the residuals the transform stage STOREd for these blocks; scales: in/out, the
@@ -499,7 +498,7 @@ oracle_intra_tasks(const oracle_pic *pic, const oracle_res *res, const ovhip_ita
             break;
         }
         case OVHIP_IT_REGION:
-            oracle_lmcs_scale(pic, &regs[t->c_scale], 1, luts, &scales[t->c_scale]);
+            lmcs_scale_regions(pic, &regs[t->c_scale], 1, luts, &scales[t->c_scale], 1);
             break;
         case OVHIP_IT_RES_C: {
             /* chroma residual of a block predicted earlier (inter), whose scale only became known in the ordered pass */

@@ -50,6 +50,8 @@ def lib():
         _lib.oracle_sao.restype = None
         _lib.oracle_alf_run.argtypes = [C.POINTER(OPic), C.POINTER(OPic), vp]
         _lib.oracle_alf_run.restype = None
+        _lib.oracle_itx_res.argtypes = [C.POINTER(OPic), vp, C.c_uint32, vp, vp, C.POINTER(OPic)]
+        _lib.oracle_itx_res.restype = None
         _lib.oracle_intra_tasks.argtypes = [C.POINTER(OPic), vp, vp, C.c_uint32, vp, vp, vp, C.c_int]
         _lib.oracle_intra_tasks.restype = None
     return _lib
@@ -107,6 +109,16 @@ def itx_ex(pic: HostPic, cmds: np.ndarray, coefs: np.ndarray, lmcs_scales: np.nd
     coefs = np.ascontiguousarray(coefs, dtype=np.int16)
     lmcs_scales = np.ascontiguousarray(lmcs_scales, dtype=np.int16)
     lib().oracle_itx_ex(C.byref(s), cmds.ctypes.data, len(cmds), coefs.ctypes.data, lmcs_scales.ctypes.data)
+
+
+def itx_res(pic: HostPic, cmds: np.ndarray, coefs: np.ndarray, lmcs_scales, respic: HostPic):
+    """Transform blocks incl. those of ordered tasks (OVHIP_RES_STORE -> respic, whose uint16 planes hold int16 bits)."""
+    if not len(cmds):
+        return
+    cmds, coefs = np.ascontiguousarray(cmds), np.ascontiguousarray(coefs)
+    s, rs = pic.struct(), respic.struct()
+    sc = np.ascontiguousarray(lmcs_scales, dtype=np.int16) if lmcs_scales is not None else None
+    lib().oracle_itx_res(C.byref(s), cmds.ctypes.data, len(cmds), coefs.ctypes.data, sc.ctypes.data if sc is not None else None, C.byref(rs))
 
 
 def lmcs_scale(pic: HostPic, regions: np.ndarray, luts) -> np.ndarray:

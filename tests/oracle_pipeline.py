@@ -39,7 +39,20 @@ def decode(wl, rows=None, stages=STAGES, want_mvs=False):
             oracle_lib.mca(dst, refs, ua, wl.aff_side, wl.lmcs_fwd)
         if uc is not None and len(uc):
             oracle_lib.ciip(dst, HostPic(wl.w, wl.h, *wl.intra), uc)
-    if "itx" in stages:
+    if "itx" in stages and wl.itasks is not None and len(wl.itasks):
+        # picture with ordered tasks: the blocks of those tasks STORE their residual; then the ordered pass in decoding
+        # order (the device: level by level); the inverse luma mapping only after it
+        assert rows is None
+        res = HostPic(wl.w, wl.h)                 # uint16 planes holding int16 bits
+        scales = np.zeros(max(1, 0 if regions is None else len(regions)), np.int16)
+        oracle_lib.itx_res(dst, luma, wl.coefs, None, res)
+        if wl.lmcs is not None and regions is not None and len(regions):
+            scales = oracle_lib.lmcs_scale(dst, regions, wl.lmcs)       # skips the regions marked `ordered`
+        oracle_lib.itx_res(dst, chroma, wl.coefs, scales, res)
+        oracle_lib.intra_tasks(dst, wl.itasks, (res.y.view(np.int16), res.cb.view(np.int16), res.cr.view(np.int16)), regions, wl.lmcs, scales)
+        if wl.lmcs is not None:
+            oracle_lib.lmcs_inverse(dst, wl.lmcs_bwd)
+    elif "itx" in stages:
         if wl.lmcs is None:
             oracle_lib.itx(dst, cmds if rows is None else np.concatenate([luma, chroma]), wl.coefs)
         else:

@@ -38,3 +38,26 @@ def test_lmcs_chroma_scales_follow_the_luma(built_lib):
     assert len(np.unique(scales)) > 2 and scales.min() > 1000 and scales.max() < 4500
     idx = (wl.tb_cmds["res_mode"] & 8) != 0
     assert idx.any() and wl.tb_cmds["c_scale"][idx].max() < len(scales)
+
+
+def test_level_order_equals_decoding_order():
+    """The recorder's levels (ovhip_itask.level) are a valid schedule: executing the ordered tasks level by level -- inside a
+    level in REVERSED decoding order, the worst case for a missed dependency -- gives the picture the decoding-order execution
+    gives, for B-like pictures and an I picture."""
+    import copy
+    import numpy as np
+    import oracle_pipeline
+    from openvvc_amd import synth
+    for seed, frac in ((1, 0.12), (2, 0.4), (3, 1.0)):
+        wl = synth.make_workload(416, 240, seed, tools=synth.INTRA_TOOLS, intra_frac=frac)
+        t = wl.itasks
+        assert len(t) > 100 and set(np.unique(t["kind"])) >= {0, 1}
+        a = oracle_pipeline.decode(wl, stages=("mc", "itx"))
+        order = np.argsort(t["level"], kind="stable")
+        lv = t["level"][order]
+        rev = np.concatenate([order[lv == l][::-1] for l in np.unique(lv)])
+        wl2 = copy.copy(wl)
+        wl2.itasks = t[rev]
+        b = oracle_pipeline.decode(wl2, stages=("mc", "itx"))
+        for x, y in zip(a.planes(), b.planes()):
+            assert np.array_equal(x, y), f"seed {seed} intra_frac {frac}: level order differs from decoding order"
