@@ -20,13 +20,13 @@ def ctx(built_lib):
 
 def test_intra_tasks_gpu_match_reference(ctx):
     """6506 cases of intra_pred / intra_pred_mrl / mip.rcn_intra_mip / intra_pred_c (+ cclm.*): every case predicts on its own
-    copy of the picture (one band of a tall picture), 512 cases per launch."""
+    copy of the picture (one band of a tall picture), 160 cases per launch (ovhip_itask.y is 16 bits)."""
     g = golden_io.load("intra.ovg")
     tasks = np.frombuffer(g["task"].tobytes(), dtype=capi.ITASK_DTYPE)
     H, W = g["pic_y"].shape
     base = [np.zeros((BAND, W), np.uint16), np.zeros((BAND // 2, W // 2), np.uint16), np.zeros((BAND // 2, W // 2), np.uint16)]
     base[0][:H] = g["pic_y"]; base[1][:H // 2] = g["pic_cb"]; base[2][:H // 2] = g["pic_cr"]
-    NB = 512
+    NB = 160
     tall_planes = [np.tile(p, (NB, 1)) for p in base]
     res = ctx.new_pic(W, BAND * NB)
     bad = []
