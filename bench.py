@@ -5,8 +5,9 @@ A "step" is what the reference-side shim does at the end of a parsed picture (sh
 ovhip_job_flush, all in C): asynchronous H2D of the picture's recorded command buffers + coefficient arena + deblocking
 edge lists + filter parameters out of page-locked memory, the launch chain of the whole rcn path (prediction incl.
 BDOF / DMVR / affine-PROF / GPM / CIIP + LMCS, inverse quantisation / LFNST / transforms + residual, deblocking, SAO,
-ALF / CC-ALF), and the D2H of the DMVR-refined motion vectors.  The workload is a synthetic recorded 3840x2160 10-bit 4:2:0
-random-access inter picture (BASELINE.json configs[3]).
+ALF / CC-ALF; intra prediction of the picture's intra CUs as a dependency-ordered pass), and the D2H of the DMVR-refined
+motion vectors.  The workload is a synthetic recorded 3840x2160 10-bit 4:2:0 random-access stream (BASELINE.json
+configs[3]): B pictures with `--intra-frac` of their CUs intra, and `--i-sets` of the picture sets an I picture.
 
 Nothing is replayed out of cache: the steps rotate over `--sets` picture sets (reference pictures, intra picture,
 destination, command buffers; distinct addresses, `--contents` distinct recorded pictures), sized so that the working
@@ -54,6 +55,19 @@ def algorithmic_bytes(wl, S):
         covered = n_samples.sum() + n_samples[c["plane2"] != 0xff].sum()
         return int(coef + c.nbytes + 2 * 2 * covered)
 
+    def intra_bytes(t):
+        """per ordered task: the block written once per plane, its residual read, the two reference arms (2w + 2h + 1
+        samples) read, the task itself; a cross-component task also reads the co-located luma block (4x the area)."""
+        if t is None or not len(t):
+            return 0
+        a = (1 << (t["log2_w"].astype(np.int64) + t["log2_h"]))
+        arms = 2 * ((1 << t["log2_w"].astype(np.int64)) + (1 << t["log2_h"].astype(np.int64))) + 1
+        luma = t["kind"] == capi.IT_LUMA
+        pred = (t["kind"] == capi.IT_LUMA) | (t["kind"] == capi.IT_CHROMA)
+        lm = (t["kind"] == capi.IT_CHROMA) & (t["mode"] >= 67)
+        planes = np.where(luma, 1, 2)
+        return int((planes * a * (2 + 2) + np.where(pred, planes * arms * 2, 0) + np.where(lm, 8 * a, 0)).sum() + t.nbytes)
+
     fused = wl.mc_units[((wl.mc_units["flags"] & 128) == 0) & (wl.mc_units["aux"] != 0)]
     ev, eh = capi.dbf_compact(wl.dbf_planes, 0), capi.dbf_compact(wl.dbf_planes, 1)
     alf_tables = sum(np.asarray(wl.alf[k]).nbytes for k, _ in capi.ALF_TABLES)
@@ -67,6 +81,7 @@ def algorithmic_bytes(wl, S):
         "dbf": 2 * S + ev.nbytes + eh.nbytes,
         "sao": 2 * S + wl.sao_params.nbytes,
         "alf": 2 * S + alf_tables,
+        "intra": intra_bytes(wl.itasks),
     }
 
 
@@ -82,6 +97,8 @@ def main():
     ap.add_argument("--in-flight", type=int, default=4, help="pictures in flight per GPU (one HIP stream + one host thread each)")
     ap.add_argument("--sets", type=int, default=12, help="picture sets the steps rotate over (distinct addresses; working set = sets x ~130 MB at 4K)")
     ap.add_argument("--contents", type=int, default=2, help="distinct recorded pictures (seeds) among the sets")
+    ap.add_argument("--intra-frac", type=float, default=0.12, help="share of intra CUs in the B pictures")
+    ap.add_argument("--i-sets", type=int, default=1, help="picture sets that hold an I picture (all CUs intra)")
     ap.add_argument("--host-threads", type=int, default=-1, help="host threads issuing the flushes (-1: one per picture in flight)")
     args = ap.parse_args()
 
@@ -103,7 +120,13 @@ def main():
     W, H = args.width, args.height
     S = max(1, args.in_flight)
     K = max(S, (args.sets + S - 1) // S * S)
-    wls = [synth.make_workload(W, H, args.seed + 1000 * c + rank) for c in range(max(1, min(args.contents, K)))]
+    tools = synth.INTRA_TOOLS if (args.intra_frac > 0 or args.i_sets) else synth.ALL_TOOLS
+    wls = [synth.make_workload(W, H, args.seed + 1000 * c + rank, tools=tools, intra_frac=args.intra_frac)
+           for c in range(max(1, min(args.contents, K)))]
+    n_b = len(wls)
+    if args.i_sets:
+        wls.append(synth.make_workload(W, H, args.seed + 7777 + rank, tools=synth.INTRA_TOOLS, intra_frac=1.0))
+    content_of = [n_b if k < args.i_sets else k % n_b for k in range(K)]       # set 0.. i_sets-1: the I picture
     FB = wls[0].frame_bytes
 
     # ---- picture sets: every set has its own reference pictures, intra picture, destination and job (= command buffers,
@@ -128,7 +151,7 @@ def main():
         st = Set()
         st.slot = k % S
         st.ctx = ctxs[st.slot]
-        st.wl = wls[k % len(wls)]
+        st.wl = wls[content_of[k]]
         st.job = engine.Job(st.ctx, W, H)
         st.job.load_workload(st.wl)
         st.ref_t, st.refs = zip(*[torch_pic(st.ctx, r) for r in st.wl.refs])
@@ -209,14 +232,18 @@ def main():
 
     run_steps(0, args.warmup)
     barrier()
-    flush_stats = sets[0].job.stats()          # of a full (non-resident) flush
+    all_stats = [st.job.stats() for st in sets]          # of full (non-resident) flushes
+    flush_stats = all_stats[-1]                          # a B picture
+    mean_stat = lambda f: float(np.mean([getattr(a, f) for a in all_stats]))
 
     # ---- untimed survey IN THE TIMED CONFIGURATION (same rotation, same pictures in flight): each launch group bracketed
     # in turn by a HIP-event pair on its stream (bracketing all of them at once would cost ~80 us of stream time per picture)
     stats0 = flush_stats
-    present = ["mc", "mcxa", "itx_luma", "lmcs_scale", "itx_chroma", "dbf", "sao", "alf", "h2d"]
+    present = ["mc", "mcxa", "itx_luma", "lmcs_scale", "itx_chroma", "intra", "dbf", "sao", "alf", "h2d"]
     if not stats0.n_regions:
         present.remove("lmcs_scale")
+    if not any(len(w.itasks) for w in wls):
+        present.remove("intra")
     survey = {}
     for name in present:
         set_timer(name)
@@ -244,7 +271,7 @@ def main():
 
     if rank == 0:
         algs = [algorithmic_bytes(wl, FB) for wl in wls]
-        use = np.bincount([k % len(wls) for k in range(K)], minlength=len(wls)).astype(np.float64)
+        use = np.bincount(content_of, minlength=len(wls)).astype(np.float64)
         use /= use.sum()
         alg = {k: float(sum(u * a[k] for u, a in zip(use, algs))) for k in algs[0]}
         alg = {k: v for k, v in alg.items() if k in kern}
@@ -293,15 +320,20 @@ def main():
         js = flush_stats
         out = {
             "metric": "decoded frames/sec, full rcn back-end decode step (H2D of the recorded picture + MC incl. BDOF/DMVR/"
-                      "affine-PROF/GPM/CIIP + LMCS + inverse transform + deblocking + SAO + ALF/CC-ALF + D2H of refined MVs), "
+                      "affine-PROF/GPM/CIIP + LMCS + inverse transform + ordered intra pass + deblocking + SAO + ALF/CC-ALF + D2H of refined MVs), "
                       "4K 10-bit RA recorded picture, bit-exact vs oracle",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u16 samples / int16 coefficients / int32 accumulate", "data": "synthetic",
-            "config": {"workload": f"{W}x{H} 10-bit 4:2:0 synthetic recorded inter picture (BASELINE configs[3]), seeds "
+            "config": {"workload": f"{W}x{H} 10-bit 4:2:0 synthetic recorded RA pictures (BASELINE configs[3]): {K - args.i_sets} B "
+                                   f"picture sets with {args.intra_frac:.0%} intra CUs + {args.i_sets} I picture set(s), seeds "
                                    f"{[hex(w.seed) for w in wls]}, per-picture flush in C (ovhip_job_flush)",
-                       "h2d_bytes_per_step": int(js.h2d_bytes), "d2h_bytes_per_step": int(js.d2h_bytes),
-                       "launches_per_step": int(js.n_launches), "h2d_copies_per_step": int(js.n_h2d),
+                       "intra_tasks_per_b_picture": st["n_itasks"], "intra_levels_per_b_picture": st["n_ilevels"],
+                       "intra_levels_per_i_picture": wls[-1].stats["n_ilevels"] if args.i_sets else None,
+                       "h2d_bytes_per_step": int(mean_stat("h2d_bytes")), "d2h_bytes_per_step": int(mean_stat("d2h_bytes")),
+                       "launches_per_step": round(mean_stat("n_launches"), 1), "h2d_copies_per_step": round(mean_stat("n_h2d"), 1),
+                       "launches_per_b_picture": int(js.n_launches),
+                       "launches_per_i_picture": int(all_stats[0].n_launches) if args.i_sets else None,
                        "distinct_pictures": K, "distinct_contents": len(wls), "working_set_bytes": int(working_set),
                        "pictures_in_flight_per_gpu": S,
                        "host_threads": 1 if world > 1 else (S if args.host_threads < 0 else args.host_threads),

@@ -532,6 +532,16 @@ int   ovhip_rec_tu_intra(ovhip_recorder *rec, const ovhip_tu_state *st, const ov
  * l + 1 (n_levels + 1 entries).  Sorting happens in the call. */
 const ovhip_itask *ovhip_rec_itasks(const ovhip_recorder *rec, size_t *n);
 const ovhip_itask *ovhip_rec_itasks_sorted(ovhip_recorder *rec, size_t *n, const uint32_t **level_start, uint32_t *n_levels);
+/* The ordered tasks grouped by the CTU their block lies in (CTUs in raster order, inside a CTU by level, inside a level in
+ * decoding order), with one descriptor per CTU that holds any.  deps: bit 0 left, 1 above-left, 2 above, 3 above-right
+ * neighbour CTU holds ordered tasks too (its samples are not final before its own tasks ran). */
+typedef struct ovhip_ictu {
+    uint16_t cx, cy;          /* CTU column / row */
+    uint32_t first, n;        /* its tasks in the returned array */
+    uint32_t deps;
+} ovhip_ictu;
+uint32_t ovhip_rec_itask_levels(const ovhip_recorder *rec);      /* highest level recorded so far */
+const ovhip_itask *ovhip_rec_itasks_by_ctu(ovhip_recorder *rec, int32_t log2_ctu_s, size_t *n, const ovhip_ictu **ctus, size_t *n_ctus);
 /* tmp.rcn_transform_tree: walks the tree and records every leaf with ovhip_rec_tu.  Returns the number of
  * commands appended or <0. */
 int   ovhip_rec_transform_tree(ovhip_recorder *rec, const ovhip_tu_state *st, const ovhip_tt_desc *tt);
@@ -675,9 +685,27 @@ int  ovhip_mcxa_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *re
 /* One LEVEL of the ordered pass (ovhip_itask): d_tasks = the n tasks of that level (DEVICE), all mutually independent; the
  * launch boundary to the next level makes their stores visible to it.  res: the residual picture the OVHIP_RES_STORE
  * commands wrote; d_regions / luts / d_scales as in ovhip_lmcs_scale_launch (NULL without LMCS chroma scaling): ordered regions
- * write their scale, scaled chroma residuals read it. */
+ * write their scale, scaled chroma residuals read it.  geom: the launch geometry (strips of the largest block, one or two
+ * colour planes) from ovhip_intra_level_geom() on the HOST copy of the same tasks, or OVHIP_INTRA_GEOM_ANY (always valid,
+ * launches up to 8x the workgroups, most of which leave at once). */
+#define OVHIP_INTRA_GEOM_ANY 0x12u
+uint32_t ovhip_intra_level_geom(const ovhip_itask *tasks, size_t n);
 int  ovhip_intra_level_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_pic *res, const ovhip_itask *d_tasks, uint32_t n,
-                              const ovhip_lmcs_region *d_regions, const ovhip_lmcs_luts *luts, int16_t *d_scales, int32_t log2_ctu_s);
+                              const ovhip_lmcs_region *d_regions, const ovhip_lmcs_luts *luts, int16_t *d_scales, int32_t log2_ctu_s,
+                              uint32_t geom);
+/* The WHOLE ordered pass in one launch: a workgroup per CTU that holds ordered tasks keeps the CTU's samples in LDS and runs
+ * its tasks level by level; CTUs wait for their left / above-left / above / above-right neighbours (those that hold tasks)
+ * through one flag word each, as the reference's wavefront threads do.  d_tasks / d_ctus: DEVICE copies of what
+ * ovhip_rec_itasks_by_ctu() returned.  d_sync: ovhip_intra_sync_words() 32-bit words of device memory, zeroed once by its
+ * owner; epoch: != 0 and different from every epoch this d_sync saw before (a picture counter).  The waits are bounded: on
+ * expiry d_sync[0] becomes non-zero (1 + index of the CTU that gave up), the launch ends, the picture is incomplete -- the
+ * owner must look at d_sync[0] after the launch; abort_mirror (may be NULL) is a second, device-writable address that receives the
+ * same code, e.g. a page-locked host word (ovhip_job_wait reads that one and returns OVHIP_ELAUNCH).  Picture width must be a
+ * multiple of 8, the planes 8-byte aligned. */
+size_t ovhip_intra_sync_words(int32_t width, int32_t height, int32_t log2_ctu_s);
+int  ovhip_intra_ctu_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_pic *res, const ovhip_itask *d_tasks, const ovhip_ictu *d_ctus,
+                            uint32_t n_ctus, const ovhip_lmcs_region *d_regions, const ovhip_lmcs_luts *luts, int16_t *d_scales,
+                            int32_t log2_ctu_s, uint32_t *d_sync, uint32_t epoch, uint32_t *abort_mirror);
 /* planes->* are DEVICE pointers.  Filters `pic` in place: all vertical edges, then all horizontal. */
 int  ovhip_dbf_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_dbf_planes *planes);
 /* Same filter driven by the compact lists of ovhip_dbf_compact (DEVICE pointers). */
@@ -713,6 +741,8 @@ typedef struct ovhip_job ovhip_job;
 enum {                                   /* ovhip_job_params.stages (0 = all) */
     OVHIP_STAGE_MC = 1, OVHIP_STAGE_ITX = 2, OVHIP_STAGE_DBF = 4, OVHIP_STAGE_SAO = 8, OVHIP_STAGE_ALF = 16,
     OVHIP_STAGE_INTRA = 32,
+    OVHIP_STAGE_INTRA_LEVELS = 0x20000000,  /* with OVHIP_STAGE_INTRA: the ordered pass as one launch per level (ovhip_intra_level_launch)
+                                            * instead of the one-launch CTU wavefront (ovhip_intra_ctu_launch); comparison / fallback */
     OVHIP_STAGE_RESIDENT = 0x40000000    /* measurement only: no H2D / D2H, the device copies of the previous flush are replayed */
 };
 

@@ -117,6 +117,8 @@ ITASK_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("log2_w", "u1"), ("log2_h",
                         ("flags", "<u2"), ("avl_lft", "u1"), ("avl_abv", "u1"), ("mrl_idx", "u1"), ("ciip_wt", "u1"),
                         ("c_scale", "<i2"), ("level", "<u2"), ("pad", "<u2", 7)])
 assert ITASK_DTYPE.itemsize == 32
+ICTU_DTYPE = np.dtype([("cx", "<u2"), ("cy", "<u2"), ("first", "<u4"), ("n", "<u4"), ("deps", "<u4")])
+assert ICTU_DTYPE.itemsize == 16
 IT_LUMA, IT_CHROMA, IT_REGION, IT_RES_C = 0, 1, 2, 3
 IF_CORNER, IF_MIP, IF_MIP_TR, IF_BDPCM, IF_BDPCM_VER, IF_RES_Y, IF_RES_CB, IF_RES_CR, IF_RES_SCALE, IF_SCALE_IDX = (1 << k for k in range(10))
 
@@ -190,7 +192,7 @@ class JobStats(C.Structure):
 REC_TB, REC_COEF, REC_MC, REC_MCX, REC_AFF, REC_SIDE, REC_REGION, REC_CIIP, REC_EDGE_V, REC_EDGE_H, REC_ITASK = range(11)
 TIME_STAGES = ("mc", "mcxa", "itx_luma", "lmcs_scale", "itx_chroma", "dbf", "sao", "alf", "intra", "h2d")
 STAGE_MC, STAGE_ITX, STAGE_DBF, STAGE_SAO, STAGE_ALF, STAGE_INTRA = 1, 2, 4, 8, 16, 32
-STAGE_ALL, STAGE_RESIDENT = 63, 0x40000000
+STAGE_ALL, STAGE_RESIDENT, STAGE_INTRA_LEVELS = 63, 0x40000000, 0x20000000
 
 
 def dbf_plane_shapes(w4: int, h4: int) -> dict:
@@ -319,7 +321,12 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_dmvr_search_launch": (C.c_int, [vp, P(Pic), P(Pic), u32, vp, u32, vp]),
         "ovhip_rec_append_raw": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
         "ovhip_itx_launch_classes_res": (C.c_int, [vp, P(Pic), P(Pic), vp, u32, u32, vp, vp]),
-        "ovhip_intra_level_launch": (C.c_int, [vp, P(Pic), P(Pic), vp, u32, vp, vp, vp, i32]),
+        "ovhip_intra_level_launch": (C.c_int, [vp, P(Pic), P(Pic), vp, u32, vp, vp, vp, i32, u32]),
+        "ovhip_intra_level_geom": (u32, [vp, C.c_size_t]),
+        "ovhip_intra_sync_words": (C.c_size_t, [i32, i32, i32]),
+        "ovhip_intra_ctu_launch": (C.c_int, [vp, P(Pic), P(Pic), vp, vp, u32, vp, vp, vp, i32, vp, u32, vp]),
+        "ovhip_rec_itask_levels": (u32, [vp]),
+        "ovhip_rec_itasks_by_ctu": (vp, [vp, i32, P(C.c_size_t), P(vp), P(C.c_size_t)]),
         "ovhip_rec_tu_intra": (C.c_int, [vp, P(TuState), P(TuDesc), P(ITask), P(ITask)]),
         "ovhip_rec_itasks": (vp, [vp, P(C.c_size_t)]),
         "ovhip_rec_itasks_sorted": (vp, [vp, P(C.c_size_t), P(P(C.c_uint32)), P(C.c_uint32)]),
@@ -353,7 +360,8 @@ EXPORTED_SYMBOLS = [
     "ovhip_free", "ovhip_h2d", "ovhip_d2h", "ovhip_pic_alloc", "ovhip_pic_free", "ovhip_pic_upload",
     "ovhip_pic_download", "ovhip_itx_launch", "ovhip_mc_launch",
     "ovhip_rec_create_ex", "ovhip_rec_set_dense_dbf_planes", "ovhip_rec_dbf_edges", "ovhip_dbf_launch_edges_ex",
-    "ovhip_dmvr_search_launch", "ovhip_rec_append_raw", "ovhip_rec_set_dbf_offsets", "ovhip_rec_tu_intra", "ovhip_rec_itasks", "ovhip_rec_itasks_sorted", "ovhip_itx_launch_classes_res", "ovhip_intra_level_launch", "ovhip_job_create", "ovhip_job_destroy", "ovhip_job_recorder", "ovhip_job_begin",
+    "ovhip_dmvr_search_launch", "ovhip_rec_append_raw", "ovhip_rec_set_dbf_offsets", "ovhip_rec_tu_intra", "ovhip_rec_itasks", "ovhip_rec_itasks_sorted", "ovhip_itx_launch_classes_res", "ovhip_intra_level_launch", "ovhip_intra_level_geom", "ovhip_intra_sync_words", "ovhip_intra_ctu_launch",
+    "ovhip_rec_itask_levels", "ovhip_rec_itasks_by_ctu", "ovhip_job_create", "ovhip_job_destroy", "ovhip_job_recorder", "ovhip_job_begin",
     "ovhip_job_flush", "ovhip_job_wait", "ovhip_job_refined_mvs", "ovhip_job_dmvr_rows", "ovhip_job_last_stats", "ovhip_job_time_stage", "ovhip_job_stage_time",
 ]
 
@@ -407,6 +415,16 @@ class Recorder:
             return np.zeros(0, ITASK_DTYPE), np.zeros(1, np.uint32)
         t = np.frombuffer((C.c_char * (n.value * 32)).from_address(p), dtype=ITASK_DTYPE).copy()
         return t, np.array([ls[i] for i in range(nl.value + 1)], np.uint32)
+
+    def itasks_by_ctu(self, log2_ctu: int = 7):
+        """(tasks grouped by CTU, CTU descriptors ICTU_DTYPE)"""
+        n, nc, cp = C.c_size_t(), C.c_size_t(), C.c_void_p()
+        p = self.lib.ovhip_rec_itasks_by_ctu(self.h, log2_ctu, C.byref(n), C.byref(cp), C.byref(nc))
+        if not n.value:
+            return np.zeros(0, ITASK_DTYPE), np.zeros(0, ICTU_DTYPE)
+        t = np.frombuffer((C.c_char * (n.value * 32)).from_address(p), dtype=ITASK_DTYPE).copy()
+        c = np.frombuffer((C.c_char * (nc.value * 16)).from_address(cp.value), dtype=ICTU_DTYPE).copy()
+        return t, c
 
     def transform_tree(self, st: "TuState", d: TtDesc, infos: bytes, res_cb: np.ndarray, res_cr: np.ndarray, res_y: np.ndarray) -> int:
         """tmp.rcn_transform_tree: infos = 16 ovhip_tu_info structs, res_* = the CTU's residual_cb / _cr / _y buffers."""

@@ -10,9 +10,13 @@
 // of its inputs, a level's tasks are mutually independent, and the launch boundary between levels is what makes one
 // level's stores visible to the next (per-XCD L2s are not coherent inside a launch).
 //
-// Mapping: lane = sample (w * h / 64 samples per lane).  Reference samples of the block are fetched once into LDS with the
-// substitution rules of 8.4.5.2.8 (availability = unit counts from the recorder), smoothed copies next to them when the mode
-// asks for them; every prediction mode then reads LDS only.  int16 / int32 arithmetic, no MFMA: per-sample stencils.
+// Mapping: one 64-lane workgroup per (task, strip of 1024 samples, colour plane); lane = sample (<= 16 samples per lane).
+// A level is LATENCY bound (few, small, mutually independent tasks; the next level waits for all of them), so the kernel is
+// arranged around the number of dependent memory round trips: task -> {reference samples, residual, CIIP's inter samples:
+// all issued together} -> prediction out of LDS into an LDS tile -> epilogue (blend, residual, clip, store).
+// Reference samples of the block are fetched once into LDS with the substitution rules of 8.4.5.2.8 (availability = unit
+// counts from the recorder), smoothed copies next to them when the mode asks for them; every prediction mode then reads
+// LDS only.  int16 / int32 arithmetic, no MFMA: per-sample stencils.
 #include "ovvc_common.hip.h"
 #define OVT_ATTR __device__
 #include "vvc_mip_tables.h"
@@ -36,41 +40,70 @@ struct IntraLds {
     uint16_t abv[IR_LEN], lft[IR_LEN];   // index IR_NEG = outermost corner sample of the reference line
     uint16_t fabv[IR_LEN], flft[IR_LEN]; // [1 2 1]-smoothed copies
     uint16_t red[64], hup[8 * 64];       // MIP: reduced prediction, horizontally up-sampled rows
-    int      par[16];                    // CCLM parameters / MIP boundary
+    int      par[16];                    // CCLM neighbour samples / MIP boundary
+    uint16_t pred[1024];                 // the strip's predicted samples
 };
+#define STRIP 1024
+#define NPL   (STRIP / 64)
+
+struct Strip { int p0, p1; };            // raster sample range [p0, p1) of the block this workgroup predicts
 
 __device__ __forceinline__ int pdpc_wgt(int i, int scale) { const int sh = (i << 1) >> scale; return sh > 5 ? 0 : 32 >> sh; }
 __device__ __forceinline__ int ilog2(int v) { return 31 - __clz(v); }
 
+// Where the reconstructed samples of a plane are read from, in the plane's picture coordinates: the picture itself (level
+// kernel) or the CTU tile in LDS with its borders (CTU kernel; row -1 of the tile lives in `top`, which is longer: above-right).
+struct PlaneAcc {
+    const uint16_t *p; int stride;
+    __device__ __forceinline__ int ld(int x, int y) const { return p[y * stride + x]; }
+};
+struct TileAcc {
+    const uint16_t *tile, *top; int stride, ox, oy;          // tile[0] = sample (ox - 4, oy); top[0] = sample (ox - 4, oy - 1)
+    __device__ __forceinline__ int ld(int x, int y) const { x -= ox - 4; y -= oy; return y < 0 ? top[x] : tile[y * stride + x]; }
+};
+
+// all cross-lane traffic of a task goes through the LDS of ONE wave: program order of the wave's DS instructions is enough
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // reference samples with substitution: see fetch_refs in oracle/ovvc_oracle_intra.c for the sequential form; with the availability
 // the recorder hands over (corner flag + unit counts from the corner outwards) every sample's source is known in closed form
-__device__ void fetch_refs(IntraLds &s, const uint16_t *__restrict__ plane, int stride, int x0, int y0, int w, int h, int unit, bool corner,
-                           int avl_abv, int avl_lft, int mrl, int lane)
+template <class Acc>
+__device__ __forceinline__ void fetch_refs(IntraLds &s, const Acc acc, int x0, int y0, int w, int h, int unit, bool corner,
+                                           int avl_abv, int avl_lft, int mrl, int lane)
 {
     const int na = 2 * w + mrl + 1, nl = 2 * h + mrl + 1;
-    const uint16_t *org = plane + (y0 - 1 - mrl) * stride + (x0 - 1 - mrl);       // sample (k = 0) of both arms
+    const int cx = x0 - 1 - mrl, cy = y0 - 1 - mrl;                               // sample (k = 0) of both arms
+#define ABV(k) acc.ld(cx + (k), cy)
+#define LFT(k) acc.ld(cx, cy + (k))
     // fall-back values (wave-uniform): first sample of each arm's block part, bottom-most corner sample
-    const int a1 = avl_abv ? org[mrl + 1] : 0, l1 = avl_lft ? org[(mrl + 1) * stride] : 0;
+    const int a1 = avl_abv ? ABV(mrl + 1) : 0, l1 = avl_lft ? LFT(mrl + 1) : 0;
     const int none = !corner && !avl_abv && !avl_lft;
     const int la = min(mrl + avl_abv * unit, na - 1), ll = min(mrl + avl_lft * unit, nl - 1);   // last available sample per arm
     for (int k = lane; k < na + 24; k += 64) {
         int v;
         const int kk = min(k, na - 1);
         if (none) v = 1 << (OV_BD - 1);
-        else if (kk <= mrl) v = corner ? org[kk] : ((mrl == 0 && avl_abv && avl_lft) ? a1 : (avl_lft ? l1 : a1));
-        else if ((kk - mrl - 1) / unit < avl_abv) v = org[kk];
-        else v = avl_abv ? org[la] : (corner ? org[mrl] : l1);
+        else if (kk <= mrl) v = corner ? ABV(kk) : ((mrl == 0 && avl_abv && avl_lft) ? a1 : (avl_lft ? l1 : a1));
+        else if ((kk - mrl - 1) / unit < avl_abv) v = ABV(kk);
+        else v = avl_abv ? ABV(la) : (corner ? ABV(mrl) : l1);
         s.abv[IR_NEG + k] = (uint16_t)v;
     }
     for (int k = lane; k < nl + 24; k += 64) {
         int v;
         const int kk = min(k, nl - 1);
         if (none) v = 1 << (OV_BD - 1);
-        else if (kk <= mrl) v = corner ? org[kk * stride] : (avl_lft ? l1 : a1);
-        else if ((kk - mrl - 1) / unit < avl_lft) v = org[kk * stride];
-        else v = avl_lft ? org[ll * stride] : (corner ? org[mrl * stride] : a1);
+        else if (kk <= mrl) v = corner ? LFT(kk) : (avl_lft ? l1 : a1);
+        else if ((kk - mrl - 1) / unit < avl_lft) v = LFT(kk);
+        else v = avl_lft ? LFT(ll) : (corner ? LFT(mrl) : a1);
         s.lft[IR_NEG + k] = (uint16_t)v;
     }
+#undef ABV
+#undef LFT
 }
 
 // filter_ref_samples (rcn_fill_ref.c:41-68) on both arms: [0] from the two arms, [1 2 1] up to len - 1, the rest copied
@@ -88,12 +121,6 @@ __device__ void smooth_refs(IntraLds &s, int len_a, int len_l, int lane)
     }
 }
 
-struct Sink {                 // where a predicted sample goes: blend (CIIP), residual, clip, store
-    uint16_t *dst; int dstride;
-    const int16_t *res; int rstride;     // nullptr: no residual
-    int scaled, scale, ciip_wt;
-};
-
 __device__ __forceinline__ int res_scale(int v, int scale)
 {
     const int sign = v & (1 << 15);
@@ -101,20 +128,8 @@ __device__ __forceinline__ int res_scale(int v, int scale)
     return ov_clip3(sign ? -a : a, -(1 << 15), 1 << 15);
 }
 
-__device__ __forceinline__ void emit(const Sink &k, int x, int y, int v)
-{
-    uint16_t *d = k.dst + y * k.dstride + x;
-    if (k.ciip_wt) v = (v * k.ciip_wt + (int)*d * (4 - k.ciip_wt) + 2) >> 2;
-    if (k.res) {
-        int r = k.res[y * k.rstride + x];
-        if (k.scaled) r = res_scale(r, k.scale);
-        v = ov_clip_bd(v + r);
-    }
-    *d = (uint16_t)v;
-}
-
 // planar / DC / angular / BDPCM prediction of one plane's block out of the LDS references
-__device__ void pred_regular(IntraLds &s, const ovhip_itask &t, bool is_luma, const Sink &sink, int lane)
+__device__ void pred_regular(IntraLds &s, const ovhip_itask &t, bool is_luma, const Strip st, int lane)
 {
     const int l2w = t.log2_w, l2h = t.log2_h, w = 1 << l2w, h = 1 << l2h, n = w * h;
     const int mrl = is_luma ? t.mrl_idx : 0;
@@ -123,21 +138,21 @@ __device__ void pred_regular(IntraLds &s, const ovhip_itask &t, bool is_luma, co
     const uint16_t *abv = s.abv + IR_NEG, *lft = s.lft + IR_NEG;
     if (bdpcm) {
         const bool ver = t.flags & OVHIP_IF_BDPCM_VER;
-        for (int p = lane; p < n; p += 64) { const int x = p & (w - 1), y = p >> l2w; emit(sink, x, y, ver ? abv[1 + x] : lft[1 + y]); }
+        for (int p = st.p0 + lane; p < st.p1; p += 64) { const int x = p & (w - 1), y = p >> l2w; s.pred[p - st.p0] = ver ? abv[1 + x] : lft[1 + y]; }
         return;
     }
     int mode = t.mode;
     if (mode == 0) {
         const uint16_t *a = abv + mrl, *l = lft + mrl;
-        if (is_luma && !mrl && l2w + l2h > 5) { smooth_refs(s, w + 4, h + 4, lane); __syncthreads(); a = s.fabv + IR_NEG; l = s.flft + IR_NEG; }
+        if (is_luma && !mrl && l2w + l2h > 5) { smooth_refs(s, w + 4, h + 4, lane); wave_sync(); a = s.fabv + IR_NEG; l = s.flft + IR_NEG; }
         const int scale = (l2w + l2h - 2) >> 2;
-        for (int p = lane; p < n; p += 64) {
+        for (int p = st.p0 + lane; p < st.p1; p += 64) {
             const int x = p & (w - 1), y = p >> l2w;
             const int pv = ((h - 1 - y) * a[1 + x] + (y + 1) * l[1 + h]) << l2w;
             const int ph = ((w - 1 - x) * l[1 + y] + (x + 1) * a[1 + w]) << l2h;
             int v = (pv + ph + n) >> (l2w + l2h + 1);
             if (pdpc_ok) { const int wt = pdpc_wgt(y, scale), wl = pdpc_wgt(x, scale); v = ov_clip_bd((l[1 + y] * wl + a[1 + x] * wt + (64 - wl - wt) * v + 32) >> 6); }
-            emit(sink, x, y, v);
+            s.pred[p - st.p0] = (uint16_t)v;
         }
         return;
     }
@@ -150,11 +165,11 @@ __device__ void pred_regular(IntraLds &s, const ovhip_itask &t, bool is_luma, co
         for (int m = 32; m; m >>= 1) sum += __shfl_xor(sum, m);
         const int dc = w == h ? (sum + w) >> (l2w + 1) : (w > h ? (sum + (w >> 1)) >> l2w : (sum + (h >> 1)) >> l2h);
         const int scale = (l2w + l2h - 2) >> 2;
-        for (int p = lane; p < n; p += 64) {
+        for (int p = st.p0 + lane; p < st.p1; p += 64) {
             const int x = p & (w - 1), y = p >> l2w;
             int v = dc;
             if (pdpc_ok) { const int wt = pdpc_wgt(y, scale), wl = pdpc_wgt(x, scale); v = ov_clip_bd((l[1 + y] * wl + a[1 + x] * wt + (64 - wl - wt) * v + 32) >> 6); }
-            emit(sink, x, y, v);
+            s.pred[p - st.p0] = (uint16_t)v;
         }
         return;
     }
@@ -170,7 +185,7 @@ __device__ void pred_regular(IntraLds &s, const ovhip_itask &t, bool is_luma, co
     const int angle = midx < 0 ? -angle_abs : angle_abs;
     bool use_fg = false, smoothed = false;
     if (is_luma && !mrl && l2w + l2h > 5 && am > g_hv_thres[(l2w + l2h) >> 1]) {
-        if (!(angle_abs & 31)) { smooth_refs(s, 2 * w, 2 * h, lane); __syncthreads(); smoothed = true; }
+        if (!(angle_abs & 31)) { smooth_refs(s, 2 * w, 2 * h, lane); wave_sync(); smoothed = true; }
         else use_fg = true;
     }
     uint16_t *mainr = (vertical ? (smoothed ? s.fabv : s.abv) : (smoothed ? s.flft : s.lft)) + IR_NEG;
@@ -178,7 +193,7 @@ __device__ void pred_regular(IntraLds &s, const ovhip_itask &t, bool is_luma, co
     const int mw = vertical ? w : h, mh = vertical ? h : w, l2mh = vertical ? l2h : l2w;     // block in the mode's own orientation
     if (midx < 0) {
         for (int k = 1 + lane; k <= mh; k += 64) { int si = (256 + k * inv) >> 9; si = min(si, mh); mainr[-k] = side[si]; }
-        __syncthreads();
+        wave_sync();
     }
     int nscale = -1;
     if (pdpc_ok) {
@@ -186,9 +201,9 @@ __device__ void pred_regular(IntraLds &s, const ovhip_itask &t, bool is_luma, co
         else if (midx > 0) nscale = min(2, l2mh - (ilog2(3 * inv - 2) - 8));
     }
     const int tl = s.abv[IR_NEG];                         // pure-direction PDPC subtracts the ABOVE array's corner (rcn_intra_angular.c:308, :328)
-    const int l2mw = vertical ? l2w : l2h;
-    for (int p = lane; p < n; p += 64) {
-        const int mx = p & (mw - 1), my = p >> l2mw;     // position in the mode's orientation
+    for (int p = st.p0 + lane; p < st.p1; p += 64) {
+        const int x = p & (w - 1), y = p >> l2w;
+        const int mx = vertical ? x : y, my = vertical ? y : x;     // position in the mode's orientation
         const int pos = (my + 1 + mrl) * angle;
         const int iidx = (pos >> 5) + mrl, ifact = pos & 31;
         const uint16_t *r = mainr + mx + iidx;
@@ -211,12 +226,12 @@ __device__ void pred_regular(IntraLds &s, const ovhip_itask &t, bool is_luma, co
                 v = ov_clip_bd((side[1 + dy] * wl + (64 - wl) * v + 32) >> 6);
             }
         }
-        emit(sink, vertical ? mx : my, vertical ? my : mx, v);
+        s.pred[p - st.p0] = (uint16_t)v;
     }
 }
 
 // matrix-based intra prediction (rcn_intra_mip.c:44-400)
-__device__ void pred_mip(IntraLds &s, const ovhip_itask &t, const Sink &sink, int lane)
+__device__ void pred_mip(IntraLds &s, const ovhip_itask &t, const Strip st, int lane)
 {
     const int l2w = t.log2_w, l2h = t.log2_h, w = 1 << l2w, h = 1 << l2h;
     const bool tr = t.flags & OVHIP_IF_MIP_TR;
@@ -232,7 +247,7 @@ __device__ void pred_mip(IntraLds &s, const ovhip_itask &t, const Sink &sink, in
         const int v = (sum + ((1 << l2) >> 1)) >> l2;
         s.par[(is_abv != tr) ? j : nb + j] = v;                // transposed: left boundary first
     }
-    __syncthreads();
+    wave_sync();
     const int in_off = s.par[0];
     int bnd[8], sum = 0;
 #pragma unroll
@@ -254,7 +269,7 @@ __device__ void pred_mip(IntraLds &s, const ovhip_itask &t, const Sink &sink, in
         const int pos = tr ? ((lane & ((1 << l2rh) - 1)) << l2rw) + (lane >> l2rh) : lane;
         s.red[pos] = (uint16_t)v;
     }
-    __syncthreads();
+    wave_sync();
     const int sxs = l2w - l2rw, sys = l2h - l2rh, rw = 1 << l2rw, rh = 1 << l2rh;
     // horizontal up-sampling of the rh reduced rows (boundary = the left reference at that row), then vertical (boundary = above)
     for (int p = lane; p < rh * w; p += 64) {
@@ -268,8 +283,8 @@ __device__ void pred_mip(IntraLds &s, const ovhip_itask &t, const Sink &sink, in
         }
         s.hup[i * 64 + x] = (uint16_t)v;
     }
-    __syncthreads();
-    for (int p = lane; p < w * h; p += 64) {
+    wave_sync();
+    for (int p = st.p0 + lane; p < st.p1; p += 64) {
         const int x = p & (w - 1), y = p >> l2w;
         int v;
         if (!sys) v = s.hup[y * 64 + x];
@@ -278,7 +293,7 @@ __device__ void pred_mip(IntraLds &s, const ovhip_itask &t, const Sink &sink, in
             const int before = i ? s.hup[(i - 1) * 64 + x] : abv[1 + x], after = s.hup[i * 64 + x];
             v = (before * ((1 << sys) - pos) + after * pos + (1 << (sys - 1))) >> sys;
         }
-        emit(sink, x, y, v);
+        s.pred[p - st.p0] = (uint16_t)v;
     }
 }
 
@@ -295,106 +310,97 @@ __device__ LmPar lm_params(int min_l, int min_c, int max_c, int v, int l2rng)
     return p;
 }
 
-// cross-component linear model (rcn_intra_cclm.c:56-880, the non-collocated variant)
-__device__ void pred_cclm(IntraLds &s, const ovhip_pic &pic, const ovhip_itask &t, int log2_ctu, const Sink &kcb, const Sink &kcr, int lane)
+// cross-component linear model (rcn_intra_cclm.c:56-880, the non-collocated variant), one chroma plane.  The up to four
+// neighbour positions are sampled by lanes 0..3 in parallel (above positions first, as the reference orders them).
+template <class Acc>
+__device__ __forceinline__ void pred_cclm(IntraLds &s, const Acc ya, const Acc ca, const ovhip_itask &t, int log2_ctu, const Strip st, int lane)
 {
     const int l2w = t.log2_w, w = 1 << l2w, h = 1 << t.log2_h, x0 = t.x, y0 = t.y;
-    const int sl = pic.stride_y, sc = pic.stride_c;
-    const uint16_t *sy = pic.y + (y0 * 2) * sl + x0 * 2, *scb = pic.cb + y0 * sc + x0, *scr = pic.cr + y0 * sc + x0;
+#define Y(dx, dy) ya.ld(2 * x0 + (dx), 2 * y0 + (dy))
     const int mode = t.mode;
     const bool lft_avail = t.avl_lft > 0, abv_avail = t.avl_abv > 0;
-    if (lane == 0) {
-        const bool first_line = !((y0 * 2) & ((1 << log2_ctu) - 1));
-        int py[4], pcb[4], pcr[4], n = 0;
-        int n_abv = 0, abv_step = 1, n_lft = 0, lft_step = 1;
-        if (mode == 67) {
-            if (abv_avail) { const int l2n = 1 + !lft_avail; abv_step = max(1, w >> l2n); n_abv = min(w, (1 + !lft_avail) << 1); }
-            if (lft_avail) { const int l2n = 1 + !abv_avail; lft_step = max(1, h >> l2n); n_lft = min(h, (1 + !abv_avail) << 1); }
-        } else if (mode == 69 && abv_avail) { const int len = t.avl_abv << 1; n_abv = min(len, 4); abv_step = max(1, len >> 2); }
-        else if (mode == 68 && lft_avail) { const int len = t.avl_lft << 1; n_lft = min(len, 4); lft_step = max(1, len >> 2); }
-        {
-            const int sp = abv_step >> 1;
-            const uint16_t *q = first_line ? sy - sl + (sp << 1) : sy - 2 * sl + (sp << 1);
-            int pad_left = sp == 0 && !lft_avail;
-            for (int i = 0; i < n_abv; ++i) {
-                const int v = first_line ? (2 + q[-(!pad_left)] + 2 * q[0] + q[1]) >> 2
-                                         : (4 + q[-(!pad_left)] + 2 * q[0] + q[1] + q[sl - (!pad_left)] + 2 * q[sl] + q[sl + 1]) >> 3;
-                py[n] = v; pcb[n] = scb[-sc + sp + i * abv_step]; pcr[n] = scr[-sc + sp + i * abv_step]; ++n;
-                q += abv_step << 1; pad_left = 0;
-            }
+    const bool first_line = !((y0 * 2) & ((1 << log2_ctu) - 1));
+    int n_abv = 0, abv_step = 1, n_lft = 0, lft_step = 1;
+    if (mode == 67) {
+        if (abv_avail) { const int l2n = 1 + !lft_avail; abv_step = max(1, w >> l2n); n_abv = min(w, (1 + !lft_avail) << 1); }
+        if (lft_avail) { const int l2n = 1 + !abv_avail; lft_step = max(1, h >> l2n); n_lft = min(h, (1 + !abv_avail) << 1); }
+    } else if (mode == 69 && abv_avail) { const int len = t.avl_abv << 1; n_abv = min(len, 4); abv_step = max(1, len >> 2); }
+    else if (mode == 68 && lft_avail) { const int len = t.avl_lft << 1; n_lft = min(len, 4); lft_step = max(1, len >> 2); }
+    const int n = n_abv + n_lft;
+    if (lane < n) {
+        int v, c;
+        if (lane < n_abv) {
+            const int pos = (abv_step >> 1) + lane * abv_step, qx = pos << 1;
+            const int pl = pos == 0 && !lft_avail;
+            v = first_line ? (2 + Y(qx - !pl, -1) + 2 * Y(qx, -1) + Y(qx + 1, -1)) >> 2
+                           : (4 + Y(qx - !pl, -2) + 2 * Y(qx, -2) + Y(qx + 1, -2) + Y(qx - !pl, -1) + 2 * Y(qx, -1) + Y(qx + 1, -1)) >> 3;
+            c = ca.ld(x0 + pos, y0 - 1);
+        } else {
+            const int pos = (lft_step >> 1) + (lane - n_abv) * lft_step, qy = pos * 2;
+            v = (4 + 2 * Y(-2, qy) + Y(-1, qy) + Y(-3, qy) + 2 * Y(-2, qy + 1) + Y(-1, qy + 1) + Y(-3, qy + 1)) >> 3;
+            c = ca.ld(x0 - 1, y0 + pos);
         }
-        {
-            const int sp = lft_step >> 1;
-            const uint16_t *q = sy - 2 + sp * 2 * sl;
-            for (int i = 0; i < n_lft; ++i) {
-                py[n] = (4 + 2 * q[0] + q[1] + q[-1] + 2 * q[sl] + q[sl + 1] + q[sl - 1]) >> 3;
-                pcb[n] = scb[-1 + (sp + i * lft_step) * sc]; pcr[n] = scr[-1 + (sp + i * lft_step) * sc]; ++n;
-                q += 2 * sl * lft_step;
-            }
-        }
-        LmPar pb = { 0, 1 << (OV_BD - 1), 0 }, pr = { 0, 1 << (OV_BD - 1), 0 };
-        if (n) {
-            int min_l, max_l, min_cb, max_cb, min_cr, max_cr;
-            if (n == 2) {
-                const int mi = py[0] >= py[1], ma = !mi;
-                min_l = py[mi]; max_l = py[ma]; min_cb = pcb[mi]; max_cb = pcb[ma]; min_cr = pcr[mi]; max_cr = pcr[ma];
-            } else {
-                int i0 = 0, i1 = 2, j0 = 1, j1 = 3, tt;         // (i0, i1) = minima pair, (j0, j1) = maxima pair
-                if (py[i0] > py[i1]) { tt = i0; i0 = i1; i1 = tt; }
-                if (py[j0] > py[j1]) { tt = j0; j0 = j1; j1 = tt; }
-                if (py[i0] > py[j1]) { tt = i0; i0 = j0; j0 = tt; tt = i1; i1 = j1; j1 = tt; }
-                if (py[i1] > py[j0]) { tt = i1; i1 = j0; j0 = tt; }
-                min_l = (py[i0] + py[i1] + 1) >> 1; max_l = (py[j0] + py[j1] + 1) >> 1;
-                min_cb = (pcb[i0] + pcb[i1] + 1) >> 1; max_cb = (pcb[j0] + pcb[j1] + 1) >> 1;
-                min_cr = (pcr[i0] + pcr[i1] + 1) >> 1; max_cr = (pcr[j0] + pcr[j1] + 1) >> 1;
-            }
-            pb.a = 0; pb.b = min_cb; pb.shift = 0; pr.a = 0; pr.b = min_cr; pr.shift = 0;
-            const int rl = max_l - min_l;
-            if (rl) {
-                const unsigned long long div_lut = 0x0111122334455670ull;     // {0,7,6,5,5,4,4,3,3,2,2,1,1,1,1,0}, nibble i
-                int l2r = ilog2(rl);
-                const int nd = ((rl << 4) >> l2r) & 15, v = (int)((div_lut >> (4 * nd)) & 15) | 8;
-                l2r += nd != 0;
-                pb = lm_params(min_l, min_cb, max_cb, v, l2r);
-                pr = lm_params(min_l, min_cr, max_cr, v, l2r);
-            }
-        }
-        s.par[0] = pb.a; s.par[1] = pb.b; s.par[2] = pb.shift; s.par[3] = pr.a; s.par[4] = pr.b; s.par[5] = pr.shift;
+        s.par[lane] = v; s.par[4 + lane] = c;
     }
-    __syncthreads();
-    const int a_cb = s.par[0], b_cb = s.par[1], s_cb = s.par[2], a_cr = s.par[3], b_cr = s.par[4], s_cr = s.par[5];
-    for (int p = lane; p < w * h; p += 64) {
+    wave_sync();
+    LmPar pp = { 0, 1 << (OV_BD - 1), 0 };
+    if (n) {
+        int py[4], pc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { py[k] = s.par[k]; pc[k] = s.par[4 + k]; }
+        int min_l, max_l, min_c, max_c;
+        if (n == 2) {
+            const bool sw = py[0] >= py[1];
+            min_l = sw ? py[1] : py[0]; max_l = sw ? py[0] : py[1]; min_c = sw ? pc[1] : pc[0]; max_c = sw ? pc[0] : pc[1];
+        } else {
+            // the reference's four-sample network: (i0, i1) = minima pair, (j0, j1) = maxima pair, carried as values
+            int l0 = py[0], l1 = py[2], m0 = py[1], m1 = py[3], c0 = pc[0], c1 = pc[2], d0 = pc[1], d1 = pc[3], tt;
+            if (l0 > l1) { tt = l0; l0 = l1; l1 = tt; tt = c0; c0 = c1; c1 = tt; }
+            if (m0 > m1) { tt = m0; m0 = m1; m1 = tt; tt = d0; d0 = d1; d1 = tt; }
+            if (l0 > m1) { tt = l0; l0 = m0; m0 = tt; tt = c0; c0 = d0; d0 = tt; tt = l1; l1 = m1; m1 = tt; tt = c1; c1 = d1; d1 = tt; }
+            if (l1 > m0) { tt = l1; l1 = m0; m0 = tt; tt = c1; c1 = d0; d0 = tt; }
+            min_l = (l0 + l1 + 1) >> 1; max_l = (m0 + m1 + 1) >> 1; min_c = (c0 + c1 + 1) >> 1; max_c = (d0 + d1 + 1) >> 1;
+        }
+        pp.a = 0; pp.b = min_c; pp.shift = 0;
+        const int rl = max_l - min_l;
+        if (rl) {
+            const unsigned long long div_lut = 0x0111122334455670ull;     // {0,7,6,5,5,4,4,3,3,2,2,1,1,1,1,0}, nibble i
+            int l2r = ilog2(rl);
+            const int nd = ((rl << 4) >> l2r) & 15, v = (int)((div_lut >> (4 * nd)) & 15) | 8;
+            l2r += nd != 0;
+            pp = lm_params(min_l, min_c, max_c, v, l2r);
+        }
+    }
+    for (int p = st.p0 + lane; p < st.p1; p += 64) {
         const int i = p & (w - 1), j = p >> l2w;
-        const uint16_t *q = sy + 2 * j * sl + 2 * i;
         const int pl = i == 0 && !lft_avail;
-        const int v = (4 + q[1] + q[-(!pl)] + 2 * q[0] + 2 * q[sl] + q[sl + 1] + q[sl - (!pl)]) >> 3;
-        emit(kcb, i, j, ov_clip_bd(((v * a_cb) >> s_cb) + b_cb));
-        emit(kcr, i, j, ov_clip_bd(((v * a_cr) >> s_cr) + b_cr));
+        const int v = (4 + Y(2 * i + 1, 2 * j) + Y(2 * i - !pl, 2 * j) + 2 * Y(2 * i, 2 * j) + 2 * Y(2 * i, 2 * j + 1) + Y(2 * i + 1, 2 * j + 1)
+                       + Y(2 * i - !pl, 2 * j + 1)) >> 3;
+        s.pred[p - st.p0] = (uint16_t)ov_clip_bd(((v * pp.a) >> pp.shift) + pp.b);
     }
+#undef Y
 }
 
 struct LmcsWnd { uint16_t bnd[17]; int min_idx, max_idx, crs_offset; };
 
 // rcn_lmcs_compute_chroma_scale for one region (same arithmetic as k_lmcs_scale, kernels_lmcs.hip)
-__device__ void region_scale(const ovhip_pic &pic, const ovhip_lmcs_region &g, const LmcsWnd &wnd, int16_t *out, int lane)
+template <class Acc>
+__device__ __forceinline__ int region_scale(const Acc ya, const ovhip_lmcs_region &g, const LmcsWnd &wnd, int lane)
 {
     int sum = 0;
-    const uint16_t *src = pic.y + (size_t)g.y * pic.stride_y + g.x;
-    if (g.n_abv) sum += src[-pic.stride_y + min(lane, 4 * g.n_abv - 1)];
-    if (g.n_lft) sum += src[(size_t)min(lane, 4 * g.n_lft - 1) * pic.stride_y - 1];
+    if (g.n_abv) sum += ya.ld(g.x + min(lane, 4 * g.n_abv - 1), g.y - 1);
+    if (g.n_lft) sum += ya.ld(g.x - 1, g.y + min(lane, 4 * g.n_lft - 1));
 #pragma unroll
     for (int m = 32; m; m >>= 1) sum += __shfl_xor(sum, m);
-    if (lane == 0) {
-        const int nb_units = (g.n_abv ? 16 : 0) + (g.n_lft ? 16 : 0);
-        int log2_nb = 0;
-        for (int v = nb_units; v; v >>= 1) ++log2_nb;
-        const int avg = log2_nb ? (sum + (1 << log2_nb)) >> (log2_nb + 1) : 512;
-        int idx = wnd.min_idx;
-        for (; idx < wnd.max_idx; ++idx) if (avg < wnd.bnd[idx + 1]) break;
-        idx = min(idx, 15);
-        const int wnd_sz = (int)wnd.bnd[idx + 1] - (int)wnd.bnd[idx];
-        *out = (int16_t)(wnd_sz == 0 ? 1 << 11 : (1 << (OV_BD - 4 + 11)) / (wnd_sz + wnd.crs_offset));
-    }
+    const int nb_units = (g.n_abv ? 16 : 0) + (g.n_lft ? 16 : 0);
+    int log2_nb = 0;
+    for (int v = nb_units; v; v >>= 1) ++log2_nb;
+    const int avg = log2_nb ? (sum + (1 << log2_nb)) >> (log2_nb + 1) : 512;
+    int idx = wnd.min_idx;
+    for (; idx < wnd.max_idx; ++idx) if (avg < wnd.bnd[idx + 1]) break;
+    idx = min(idx, 15);
+    const int wnd_sz = (int)wnd.bnd[idx + 1] - (int)wnd.bnd[idx];
+    return wnd_sz == 0 ? 1 << 11 : (1 << (OV_BD - 4 + 11)) / (wnd_sz + wnd.crs_offset);
 }
 
 __global__ __launch_bounds__(64) void k_intra_level(ovhip_pic pic, ovhip_pic res, const ovhip_itask *__restrict__ tasks, uint32_t n,
@@ -403,65 +409,353 @@ __global__ __launch_bounds__(64) void k_intra_level(ovhip_pic pic, ovhip_pic res
 {
     __shared__ IntraLds s;
     const uint32_t bid = blockIdx.x;
+    const int strip = blockIdx.y, comp = blockIdx.z;
     if (bid >= n) return;
     const ovhip_itask t = tasks[bid];
     const int lane = threadIdx.x;
-    const int w = 1 << t.log2_w, h = 1 << t.log2_h;
-    const bool scaled = t.flags & OVHIP_IF_RES_SCALE;
+    const int l2w = t.log2_w, w = 1 << l2w, h = 1 << t.log2_h, npx = w * h;
+    const PlaneAcc ya = { pic.y, pic.stride_y };
+    if (t.kind == OVHIP_IT_REGION) {
+        if (!strip && !comp) { const int v = region_scale(ya, regs[t.c_scale], wnd, lane); if (lane == 0) scales[t.c_scale] = (int16_t)v; }
+        return;
+    }
+    const bool luma = t.kind == OVHIP_IT_LUMA;
+    Strip st; st.p0 = strip * STRIP; st.p1 = min(npx, st.p0 + STRIP);
+    if (st.p0 >= npx || (luma && comp)) return;
+    const bool has_res = t.flags & (luma ? OVHIP_IF_RES_Y : (comp ? OVHIP_IF_RES_CR : OVHIP_IF_RES_CB));
+    const bool res_only = t.kind == OVHIP_IT_RES_C;
+    if (res_only && !has_res) return;
+    uint16_t *pl = luma ? pic.y : (comp ? pic.cr : pic.cb);
+    const int dstride = luma ? pic.stride_y : pic.stride_c, rstride = luma ? res.stride_y : res.stride_c;
+    uint16_t *dst = pl + t.y * dstride + t.x;
+    const int16_t *rp = reinterpret_cast<const int16_t *>(luma ? res.y : (comp ? res.cr : res.cb)) + t.y * rstride + t.x;
+    const int ciip_wt = res_only ? 0 : t.ciip_wt;
+    const bool need_d = ciip_wt || res_only;
+
+    // everything the epilogue needs from memory is requested before the prediction starts
+    int rv[NPL], dv[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int p = st.p0 + lane + 64 * i, x = p & (w - 1), y = p >> l2w;
+        rv[i] = (has_res && p < st.p1) ? rp[y * rstride + x] : 0;
+        dv[i] = (need_d && p < st.p1) ? dst[y * dstride + x] : 0;
+    }
+    const bool scaled = !luma && (t.flags & OVHIP_IF_RES_SCALE);
     const int scale = scaled ? ((t.flags & OVHIP_IF_SCALE_IDX) ? scales[t.c_scale] : t.c_scale) : 0;
-    if (t.kind == OVHIP_IT_REGION) { region_scale(pic, regs[t.c_scale], wnd, scales + t.c_scale, lane); return; }
-    if (t.kind == OVHIP_IT_LUMA) {
-        Sink k;
-        k.dst = pic.y + t.y * pic.stride_y + t.x; k.dstride = pic.stride_y;
-        k.res = (t.flags & OVHIP_IF_RES_Y) ? reinterpret_cast<const int16_t *>(res.y) + t.y * res.stride_y + t.x : nullptr; k.rstride = res.stride_y;
-        k.scaled = 0; k.scale = 0; k.ciip_wt = t.ciip_wt;
-        fetch_refs(s, pic.y, pic.stride_y, t.x, t.y, w, h, 4, t.flags & OVHIP_IF_CORNER, t.avl_abv, t.avl_lft, (t.flags & OVHIP_IF_MIP) ? 0 : t.mrl_idx, lane);
-        __syncthreads();
-        if (t.flags & OVHIP_IF_MIP) pred_mip(s, t, k, lane);
-        else pred_regular(s, t, true, k, lane);
-        return;
-    }
-    // chroma: Cb then Cr
-    Sink kcb, kcr;
-    kcb.dst = pic.cb + t.y * pic.stride_c + t.x; kcr.dst = pic.cr + t.y * pic.stride_c + t.x; kcb.dstride = kcr.dstride = pic.stride_c;
-    kcb.res = (t.flags & OVHIP_IF_RES_CB) ? reinterpret_cast<const int16_t *>(res.cb) + t.y * res.stride_c + t.x : nullptr;
-    kcr.res = (t.flags & OVHIP_IF_RES_CR) ? reinterpret_cast<const int16_t *>(res.cr) + t.y * res.stride_c + t.x : nullptr;
-    kcb.rstride = kcr.rstride = res.stride_c;
-    kcb.scaled = kcr.scaled = scaled; kcb.scale = kcr.scale = scale; kcb.ciip_wt = kcr.ciip_wt = t.ciip_wt;
-    if (t.kind == OVHIP_IT_RES_C) {
-        // residual of an already predicted block: prediction = what is there
-        for (int p = lane; p < w * h; p += 64) {
-            const int x = p & (w - 1), y = p >> t.log2_w;
-            if (kcb.res) { Sink q = kcb; q.ciip_wt = 0; emit(q, x, y, kcb.dst[y * kcb.dstride + x]); }
-            if (kcr.res) { Sink q = kcr; q.ciip_wt = 0; emit(q, x, y, kcr.dst[y * kcr.dstride + x]); }
+
+    if (!res_only) {
+        if (luma) {
+            fetch_refs(s, ya, t.x, t.y, w, h, 4, t.flags & OVHIP_IF_CORNER, t.avl_abv, t.avl_lft, (t.flags & OVHIP_IF_MIP) ? 0 : t.mrl_idx, lane);
+            wave_sync();
+            if (t.flags & OVHIP_IF_MIP) pred_mip(s, t, st, lane);
+            else pred_regular(s, t, true, st, lane);
+        } else {
+            const PlaneAcc ca = { pl, pic.stride_c };
+            if (t.mode >= 67) pred_cclm(s, ya, ca, t, log2_ctu, st, lane);
+            else {
+                fetch_refs(s, ca, t.x, t.y, w, h, 2, t.flags & OVHIP_IF_CORNER, t.avl_abv, t.avl_lft, 0, lane);
+                wave_sync();
+                pred_regular(s, t, false, st, lane);
+            }
         }
+        wave_sync();
+    }
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int p = st.p0 + lane + 64 * i, x = p & (w - 1), y = p >> l2w;
+        if (p >= st.p1) break;
+        int v = res_only ? dv[i] : s.pred[p - st.p0];
+        if (ciip_wt) v = (v * ciip_wt + dv[i] * (4 - ciip_wt) + 2) >> 2;
+        if (has_res) v = ov_clip_bd(v + (scaled ? res_scale(rv[i], scale) : rv[i]));
+        dst[y * dstride + x] = (uint16_t)v;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The ordered pass as ONE launch: a workgroup per CTU that holds ordered tasks, the CTU's samples in LDS.
+//
+// Inside a CTU the dependent hops (1809 levels across a 4K I picture, 28 per CTU) cost an LDS round trip instead of a launch
+// boundary; between CTUs the reference's own wavefront rule applies (a CTU needs its left, above-left, above and above-right
+// neighbours: ctudec's WPP, ovthreads / slicedec), carried by one flag word per CTU:
+//   producer: tile stored write-through (agent-scope 8-byte stores), every wave drains, barrier, ONE relaxed agent flag store;
+//   consumer: lanes 0..3 of wave 0 poll their neighbour's flag (relaxed, agent, s_sleep, BOUNDED), one agent acquire, barrier,
+//             plain loads.
+// A workgroup waits only for workgroups with a lower index (the list is in raster order); the hardware starts workgroups in
+// index order, but nothing promises it, so the wait is bounded: on expiry the picture's abort word is set, every other
+// waiter leaves too, and the host reports OVHIP_EHIP -- never a hang.
+#define CT_S     128                        // largest CTU
+#define CT_YS    (4 + CT_S)                 // luma tile row: 4 border samples + the CTU
+#define CT_CS    (4 + CT_S / 2)
+#define CT_CHUNK 128                        // tasks staged in LDS at a time
+#define SYNC_FLAGS 16                       // sync[0] = abort code; flags from word 16
+#define SPIN_LIMIT (1u << 21)
+
+struct CtuLds {
+    uint16_t ty[CT_S][CT_YS], top_y[4 + 2 * CT_S + 4];
+    uint16_t tc[2][CT_S / 2][CT_CS], top_c[2][4 + CT_S + 4];
+    ovhip_itask task[CT_CHUNK];
+    IntraLds w[4];
+    int sc_idx[4], sc_val[4], n_sc, abort;
+};
+
+typedef unsigned long long u64;
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+__device__ __forceinline__ ovhip_itask uniform_task(const ovhip_itask *p)
+{
+    union { ovhip_itask t; unsigned u[8]; } v;
+    const unsigned *q = reinterpret_cast<const unsigned *>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v.u[i] = __builtin_amdgcn_readfirstlane(q[i]);
+    return v.t;
+}
+
+// one (task, strip, plane) item by one wave; samples from / to the tile
+__device__ void ctu_item(CtuLds &L, IntraLds &s, const ovhip_itask &t, int strip, int comp, const ovhip_pic &res, int X0, int Y0,
+                         const ovhip_lmcs_region *__restrict__ regs, const LmcsWnd &wnd, int16_t *__restrict__ scales, int log2_ctu, int lane)
+{
+    const int l2w = t.log2_w, w = 1 << l2w, h = 1 << t.log2_h, npx = w * h;
+    const TileAcc ya = { &L.ty[0][0], L.top_y, CT_YS, X0, Y0 };
+    if (t.kind == OVHIP_IT_REGION) {
+        const int v = region_scale(ya, regs[t.c_scale], wnd, lane);
+        if (lane == 0) { const int k = atomicAdd(&L.n_sc, 1) & 3; L.sc_idx[k] = t.c_scale; L.sc_val[k] = v; scales[t.c_scale] = (int16_t)v; }
         return;
     }
-    if (t.mode >= 67) { pred_cclm(s, pic, t, log2_ctu, kcb, kcr, lane); return; }
-    fetch_refs(s, pic.cb, pic.stride_c, t.x, t.y, w, h, 2, t.flags & OVHIP_IF_CORNER, t.avl_abv, t.avl_lft, 0, lane);
+    const bool luma = t.kind == OVHIP_IT_LUMA;
+    Strip st; st.p0 = strip * STRIP; st.p1 = min(npx, st.p0 + STRIP);
+    const bool has_res = t.flags & (luma ? OVHIP_IF_RES_Y : (comp ? OVHIP_IF_RES_CR : OVHIP_IF_RES_CB));
+    const bool res_only = t.kind == OVHIP_IT_RES_C;
+    if (res_only && !has_res) return;
+    const int rstride = luma ? res.stride_y : res.stride_c;
+    const int16_t *rp = reinterpret_cast<const int16_t *>(luma ? res.y : (comp ? res.cr : res.cb)) + t.y * rstride + t.x;
+    int rv[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int p = st.p0 + lane + 64 * i, x = p & (w - 1), y = p >> l2w;
+        rv[i] = (has_res && p < st.p1) ? rp[y * rstride + x] : 0;
+    }
+    const bool scaled = !luma && (t.flags & OVHIP_IF_RES_SCALE);
+    int scale = 0;
+    if (scaled) {
+        if (t.flags & OVHIP_IF_SCALE_IDX) {
+            int found = -1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (k < min(L.n_sc, 4) && L.sc_idx[k] == t.c_scale) found = L.sc_val[k];
+            scale = found >= 0 ? found : scales[t.c_scale];          // not from this CTU: k_lmcs_scale wrote it before this launch
+        } else scale = t.c_scale;
+    }
+    const int tx = (luma ? t.x - X0 : t.x - (X0 >> 1)) + 4, ty = luma ? t.y - Y0 : t.y - (Y0 >> 1);
+    uint16_t *dst = luma ? &L.ty[ty][tx] : &L.tc[comp][ty][tx];
+    const int dstride = luma ? CT_YS : CT_CS;
+    const int ciip_wt = res_only ? 0 : t.ciip_wt;
+    if (!res_only) {
+        if (luma) {
+            fetch_refs(s, ya, t.x, t.y, w, h, 4, t.flags & OVHIP_IF_CORNER, t.avl_abv, t.avl_lft, (t.flags & OVHIP_IF_MIP) ? 0 : t.mrl_idx, lane);
+            wave_sync();
+            if (t.flags & OVHIP_IF_MIP) pred_mip(s, t, st, lane);
+            else pred_regular(s, t, true, st, lane);
+        } else {
+            const TileAcc ca = { &L.tc[comp][0][0], L.top_c[comp], CT_CS, X0 >> 1, Y0 >> 1 };
+            if (t.mode >= 67) pred_cclm(s, ya, ca, t, log2_ctu, st, lane);
+            else {
+                fetch_refs(s, ca, t.x, t.y, w, h, 2, t.flags & OVHIP_IF_CORNER, t.avl_abv, t.avl_lft, 0, lane);
+                wave_sync();
+                pred_regular(s, t, false, st, lane);
+            }
+        }
+        wave_sync();
+    }
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int p = st.p0 + lane + 64 * i, x = p & (w - 1), y = p >> l2w;
+        if (p >= st.p1) break;
+        uint16_t *d = dst + y * dstride + x;
+        int v = res_only ? (int)*d : (int)s.pred[p - st.p0];
+        if (ciip_wt) v = (v * ciip_wt + (int)*d * (4 - ciip_wt) + 2) >> 2;
+        if (has_res) v = ov_clip_bd(v + (scaled ? res_scale(rv[i], scale) : rv[i]));
+        *d = (uint16_t)v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_intra_ctu(ovhip_pic pic, ovhip_pic res, const ovhip_itask *__restrict__ tasks,
+                                                   const ovhip_ictu *__restrict__ ctus, const ovhip_lmcs_region *__restrict__ regs, LmcsWnd wnd,
+                                                   int16_t *__restrict__ scales, int log2_ctu, unsigned *sync, unsigned epoch, int ncx,
+                                                   unsigned *abort_mirror)
+{
+    __shared__ CtuLds L;
+    const ovhip_ictu c = ctus[blockIdx.x];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int S = 1 << log2_ctu, X0 = c.cx << log2_ctu, Y0 = c.cy << log2_ctu;
+    const int cw = min(S, pic.w - X0), ch = min(S, pic.h - Y0);
+    const int wc = pic.w >> 1, hc = pic.h >> 1, Sc = S >> 1, X0c = X0 >> 1, Y0c = Y0 >> 1, cwc = cw >> 1, chc = ch >> 1;
+    unsigned *flags = sync + SYNC_FLAGS;
+    if (tid == 0) { L.n_sc = 0; L.abort = 0; }
     __syncthreads();
-    pred_regular(s, t, false, kcb, lane);
+
+    // ---- 1. the neighbours this CTU reads must have published their tiles ----
+    if (c.deps) {
+        if (wave == 0) {
+            bool ok = true;
+            if (lane < 4 && ((c.deps >> lane) & 1)) {
+                const int nx = c.cx + (lane == 3 ? 1 : (lane == 2 ? 0 : -1)), ny = c.cy - (lane != 0);
+                unsigned *f = flags + ny * ncx + nx;
+                unsigned spins = 0;
+                while (__hip_atomic_load(f, RLX_AGENT) != epoch) {
+                    if (++spins > SPIN_LIMIT || __hip_atomic_load(sync, RLX_AGENT) != 0) { ok = false; break; }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+            if (!__all(ok)) {
+                if (lane == 0) {
+                    __hip_atomic_store(sync, 1u + blockIdx.x, RLX_AGENT);
+                    if (abort_mirror) __hip_atomic_store(abort_mirror, 1u + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    L.abort = 1;
+                }
+            }
+            else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        if (L.abort) return;
+    }
+
+    // ---- 2. the CTU and its borders into LDS (8-byte granules; widths are multiples of 8) ----
+    {
+        const int gx0 = X0 ? -1 : 0;                                   // first granule: the left border
+        const int ng = (cw >> 2) - gx0;
+        for (int i = tid; i < ch * ng; i += 256) {
+            const int r = i / ng, g = i - r * ng + gx0;
+            *reinterpret_cast<u64 *>(&L.ty[r][4 + 4 * g]) = *reinterpret_cast<const u64 *>(pic.y + (size_t)(Y0 + r) * pic.stride_y + X0 + 4 * g);
+        }
+        const int ngc = (cwc >> 2) - gx0;
+        for (int i = tid; i < 2 * chc * ngc; i += 256) {
+            const int pl = i >= chc * ngc, k = i - pl * chc * ngc, r = k / ngc, g = k - r * ngc + gx0;
+            const uint16_t *src = pl ? pic.cr : pic.cb;
+            *reinterpret_cast<u64 *>(&L.tc[pl][r][4 + 4 * g]) = *reinterpret_cast<const u64 *>(src + (size_t)(Y0c + r) * pic.stride_c + X0c + 4 * g);
+        }
+        if (Y0) {
+            const int nt = (min(pic.w, X0 + cw + S) - X0) / 4 - gx0, ntc = (min(wc, X0c + cwc + Sc) - X0c) / 4 - gx0;
+            for (int i = tid; i < nt + 2 * ntc; i += 256) {
+                if (i < nt) {
+                    const int g = i + gx0;
+                    *reinterpret_cast<u64 *>(&L.top_y[4 + 4 * g]) = *reinterpret_cast<const u64 *>(pic.y + (size_t)(Y0 - 1) * pic.stride_y + X0 + 4 * g);
+                } else {
+                    const int k = i - nt, pl = k >= ntc, g = k - pl * ntc + gx0;
+                    const uint16_t *src = pl ? pic.cr : pic.cb;
+                    *reinterpret_cast<u64 *>(&L.top_c[pl][4 + 4 * g]) = *reinterpret_cast<const u64 *>(src + (size_t)(Y0c - 1) * pic.stride_c + X0c + 4 * g);
+                }
+            }
+        }
+    }
+
+    // ---- 3. the CTU's tasks: runs of equal level, the items of a run spread over the four waves ----
+    for (unsigned base = 0; base < c.n; base += CT_CHUNK) {
+        const int nchunk = (int)min((unsigned)CT_CHUNK, c.n - base);
+        __syncthreads();
+        if (tid < 2 * nchunk) reinterpret_cast<uint4 *>(L.task)[tid] = reinterpret_cast<const uint4 *>(tasks + c.first + base)[tid];
+        __syncthreads();
+        int i = 0;
+        while (i < nchunk) {
+            const int lvl = __builtin_amdgcn_readfirstlane((int)L.task[i].level);
+            int cnt = 0, j = i;
+            for (; j < nchunk; ++j) {
+                const ovhip_itask t = uniform_task(&L.task[j]);
+                if (t.level != lvl) break;
+                const int npx = 1 << (t.log2_w + t.log2_h);
+                const int strips = t.kind == OVHIP_IT_REGION ? 1 : (npx + STRIP - 1) / STRIP, comps = (t.kind == OVHIP_IT_CHROMA || t.kind == OVHIP_IT_RES_C) ? 2 : 1;
+                for (int st = 0; st < strips; ++st)
+                    for (int cp = 0; cp < comps; ++cp)
+                        if ((cnt++ & 3) == wave) ctu_item(L, L.w[wave], t, st, cp, res, X0, Y0, regs, wnd, scales, log2_ctu, lane);
+            }
+            __syncthreads();
+            i = j;
+        }
+    }
+
+    // ---- 4. publish: write-through stores, every wave drains, one flag ----
+    {
+        const int ng = cw >> 2;
+        for (int i = tid; i < ch * ng; i += 256) {
+            const int r = i / ng, g = i - r * ng;
+            __hip_atomic_store(reinterpret_cast<u64 *>(pic.y + (size_t)(Y0 + r) * pic.stride_y + X0 + 4 * g), *reinterpret_cast<const u64 *>(&L.ty[r][4 + 4 * g]), RLX_AGENT);
+        }
+        const int ngc = cwc >> 2;
+        for (int i = tid; i < 2 * chc * ngc; i += 256) {
+            const int pl = i >= chc * ngc, k = i - pl * chc * ngc, r = k / ngc, g = k - r * ngc;
+            uint16_t *dstp = pl ? pic.cr : pic.cb;
+            __hip_atomic_store(reinterpret_cast<u64 *>(dstp + (size_t)(Y0c + r) * pic.stride_c + X0c + 4 * g), *reinterpret_cast<const u64 *>(&L.tc[pl][r][4 + 4 * g]), RLX_AGENT);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    fetch_refs(s, pic.cr, pic.stride_c, t.x, t.y, w, h, 2, t.flags & OVHIP_IF_CORNER, t.avl_abv, t.avl_lft, 0, lane);
-    __syncthreads();
-    pred_regular(s, t, false, kcr, lane);
+    if (tid == 0) __hip_atomic_store(flags + c.cy * ncx + c.cx, epoch, RLX_AGENT);
+    (void)hc;
 }
 
 } // namespace
 
+// Launch geometry of a level from its tasks (HOST memory): bits 0-1 = log2 of the strips of the largest block (1024 samples
+// each), bit 4 = some task covers both chroma planes.
+extern "C" uint32_t ovhip_intra_level_geom(const ovhip_itask *tasks, size_t n)
+{
+    uint32_t l2s = 0, two = 0;
+    for (size_t i = 0; tasks && i < n; ++i) {
+        if (tasks[i].kind == OVHIP_IT_REGION) continue;
+        const int l2 = tasks[i].log2_w + tasks[i].log2_h;
+        if (l2 > 10 && (uint32_t)(l2 - 10) > l2s) l2s = (uint32_t)(l2 - 10);
+        two |= tasks[i].kind != OVHIP_IT_LUMA;
+    }
+    return (l2s > 2 ? 2 : l2s) | (two << 4);
+}
+
 // One level of the ordered pass.  d_tasks: DEVICE, the n tasks of this level.  res: residual picture written by
 // ovhip_itx_launch_classes_res.  d_regions / luts / d_scales: as ovhip_lmcs_scale_launch (may be NULL without LMCS chroma scaling).
+// geom: ovhip_intra_level_geom() of the same tasks, or OVHIP_INTRA_GEOM_ANY.
 extern "C" int ovhip_intra_level_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_pic *res, const ovhip_itask *d_tasks, uint32_t n,
-                                        const ovhip_lmcs_region *d_regions, const ovhip_lmcs_luts *luts, int16_t *d_scales, int32_t log2_ctu_s)
+                                        const ovhip_lmcs_region *d_regions, const ovhip_lmcs_luts *luts, int16_t *d_scales, int32_t log2_ctu_s,
+                                        uint32_t geom)
 {
     if (!ctx || !pic || !res) return OVHIP_EINVAL;
     OV_DEVICE(ctx);
     if (!n) return OVHIP_OK;
-    if (!d_tasks || log2_ctu_s < 5 || log2_ctu_s > 7) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_intra_level_launch: bad arguments", hipSuccess);
+    if (!d_tasks || log2_ctu_s < 5 || log2_ctu_s > 7 || (geom & 3) == 3)
+        return ov_fail(ctx, OVHIP_EINVAL, "ovhip_intra_level_launch: bad arguments", hipSuccess);
     LmcsWnd wnd;
     memset(&wnd, 0, sizeof(wnd));
     if (luts) { memcpy(wnd.bnd, luts->wnd_bnd, sizeof(wnd.bnd)); wnd.min_idx = luts->min_idx; wnd.max_idx = luts->max_idx; wnd.crs_offset = luts->crs_offset; }
-    hipLaunchKernelGGL(k_intra_level, dim3(n), dim3(64), 0, ctx->stream, *pic, *res, d_tasks, n, d_regions, wnd, d_scales, log2_ctu_s);
+    hipLaunchKernelGGL(k_intra_level, dim3(n, 1u << (geom & 3), (geom & 16) ? 2 : 1), dim3(64), 0, ctx->stream, *pic, *res, d_tasks, n, d_regions, wnd,
+                       d_scales, log2_ctu_s);
     OV_LAUNCH_CHECK(ctx, "k_intra_level");
+    return OVHIP_OK;
+}
+
+// Words of the synchronisation block ovhip_intra_ctu_launch needs for a w x h picture (device memory, zeroed ONCE by the owner).
+extern "C" size_t ovhip_intra_sync_words(int32_t width, int32_t height, int32_t log2_ctu_s)
+{
+    if (width <= 0 || height <= 0 || log2_ctu_s < 5 || log2_ctu_s > 7) return 0;
+    const size_t s = (size_t)1 << log2_ctu_s;
+    return SYNC_FLAGS + ((width + s - 1) / s) * ((height + s - 1) / s);
+}
+
+// The whole ordered pass in one launch (see k_intra_ctu).  d_tasks / d_ctus: DEVICE copies of ovhip_rec_itasks_by_ctu().
+// d_sync: ovhip_intra_sync_words() words; epoch: a value this d_sync has not seen before and != 0 (a per-picture counter).
+extern "C" int ovhip_intra_ctu_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_pic *res, const ovhip_itask *d_tasks, const ovhip_ictu *d_ctus,
+                                      uint32_t n_ctus, const ovhip_lmcs_region *d_regions, const ovhip_lmcs_luts *luts, int16_t *d_scales,
+                                      int32_t log2_ctu_s, uint32_t *d_sync, uint32_t epoch, uint32_t *abort_mirror)
+{
+    if (!ctx || !pic || !res) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
+    if (!n_ctus) return OVHIP_OK;
+    if (!d_tasks || !d_ctus || !d_sync || !epoch || log2_ctu_s < 5 || log2_ctu_s > 7)
+        return ov_fail(ctx, OVHIP_EINVAL, "ovhip_intra_ctu_launch: bad arguments", hipSuccess);
+    if ((pic->w & 7) || (pic->h & 1) || (pic->stride_y & 3) || (pic->stride_c & 3) || ((uintptr_t)pic->y & 7) || ((uintptr_t)pic->cb & 7) || ((uintptr_t)pic->cr & 7))
+        return ov_fail(ctx, OVHIP_EUNSUP, "ovhip_intra_ctu_launch: picture width must be a multiple of 8 and the planes 8-byte aligned", hipSuccess);
+    LmcsWnd wnd;
+    memset(&wnd, 0, sizeof(wnd));
+    if (luts) { memcpy(wnd.bnd, luts->wnd_bnd, sizeof(wnd.bnd)); wnd.min_idx = luts->min_idx; wnd.max_idx = luts->max_idx; wnd.crs_offset = luts->crs_offset; }
+    const int ncx = (pic->w + (1 << log2_ctu_s) - 1) >> log2_ctu_s;
+    hipLaunchKernelGGL(k_intra_ctu, dim3(n_ctus), dim3(256), 0, ctx->stream, *pic, *res, d_tasks, d_ctus, d_regions, wnd, d_scales, log2_ctu_s, d_sync, epoch, ncx,
+                       abort_mirror);
+    OV_LAUNCH_CHECK(ctx, "k_intra_ctu");
     return OVHIP_OK;
 }

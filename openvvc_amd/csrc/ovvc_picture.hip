@@ -16,7 +16,7 @@ namespace {
 
 struct DevBuf { void *p; size_t cap; };
 
-enum { B_TB, B_COEF, B_MC, B_MCX, B_MV, B_AFF, B_SIDE, B_REG, B_SCALE, B_EV, B_EH, B_PARAM, B_CLASS, B_CIIP, B_ITASK, B_COUNT };
+enum { B_TB, B_COEF, B_MC, B_MCX, B_MV, B_AFF, B_SIDE, B_REG, B_SCALE, B_EV, B_EH, B_PARAM, B_CLASS, B_CIIP, B_ITASK, B_ICTU, B_COUNT };
 
 // layout of the parameter block (one pinned staging copy, one H2D)
 struct ParamLayout { size_t sao, alf_ctus, lcoef, lclip, ccoef, cclip, cc, fwd, bwd, total; };
@@ -30,6 +30,8 @@ struct ovhip_job {
     DevBuf dev[B_COUNT];
     ovhip_pic tmp;                       // SAO destination / ALF source
     ovhip_pic res;                       // residuals of the ordered tasks (allocated with the first picture that has any)
+    uint32_t *d_sync; uint32_t epoch;    // CTU flags of the one-launch ordered pass (zeroed once; a new epoch per picture)
+    uint32_t *abort_host;                // pinned word the ordered pass writes when a bounded wait expired
     char *param_host; size_t param_cap;  // pinned staging of the picture-level tables
     int32_t *mv_host; size_t mv_cap;     // pinned: refined vectors, 4 int32 per refined unit
     size_t n_mv;                         // units covered by the last flush / eager pass
@@ -167,6 +169,8 @@ void ovhip_job_destroy(ovhip_job *j)
     for (int k = 0; k < B_COUNT; ++k) if (j->dev[k].p) (void)hipFree(j->dev[k].p);
     if (j->tmp.y) (void)ovhip_pic_free(j->ctx, &j->tmp);
     if (j->res.y) (void)ovhip_pic_free(j->ctx, &j->res);
+    if (j->d_sync) (void)hipFree(j->d_sync);
+    pinned_free(nullptr, j->abort_host);
     pinned_free(nullptr, j->param_host); pinned_free(nullptr, j->mv_host);
     for (int k = 0; k < 32; ++k) for (int q = 0; q < 2; ++q) if (j->t_ev[k][q]) (void)hipEventDestroy(j->t_ev[k][q]);
     if (j->ev_h2d) (void)hipEventDestroy(j->ev_h2d);
@@ -195,6 +199,12 @@ int ovhip_job_wait(ovhip_job *j)
     if (!j->flushed) return OVHIP_OK;
     hipError_t e = hipEventSynchronize(j->ev_done);
     if (e != hipSuccess) return ov_fail(j->ctx, OVHIP_ELAUNCH, "hipEventSynchronize(job)", e);
+    if (j->abort_host && *(volatile uint32_t *)j->abort_host) {
+        // a CTU of the ordered pass gave up waiting for a neighbour: the picture is incomplete.  Re-arm and report.
+        *(volatile uint32_t *)j->abort_host = 0;
+        (void)hipMemset(j->d_sync, 0, sizeof(uint32_t));
+        return ov_fail(j->ctx, OVHIP_ELAUNCH, "ordered pass: a CTU's bounded wait for its neighbours expired (picture incomplete)", hipSuccess);
+    }
     return OVHIP_OK;
 }
 
@@ -298,10 +308,14 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
     const ovhip_ciip_unit *ciip = ovhip_rec_ciip_units(rec, &n_ciip);
     if (n_ciip && !intra)
         return ov_fail(ctx, OVHIP_EUNSUP, "ovhip_job_flush: CIIP blend units recorded but no picture with their intra prediction", hipSuccess);
-    size_t n_it = 0; uint32_t n_lv = 0; const uint32_t *lv_start = nullptr;
-    const ovhip_itask *it = ovhip_rec_itasks_sorted(rec, &n_it, &lv_start, &n_lv);
-    if (n_it && !it) return ov_fail(ctx, OVHIP_ENOMEM, "ovhip_rec_itasks_sorted", hipSuccess);
-    if (!(stages & OVHIP_STAGE_INTRA)) { n_it = 0; n_lv = 0; }
+    // ordered tasks: grouped by CTU for the one-launch pass, or sorted by level for one launch per level
+    size_t n_it = 0, n_ictu = 0; uint32_t n_lv = 0; const uint32_t *lv_start = nullptr; const ovhip_ictu *ictu = nullptr;
+    const int by_level = (stages & OVHIP_STAGE_INTRA_LEVELS) != 0;
+    const ovhip_itask *it = by_level ? ovhip_rec_itasks_sorted(rec, &n_it, &lv_start, &n_lv)
+                                     : ovhip_rec_itasks_by_ctu(rec, pr->log2_ctu_s ? pr->log2_ctu_s : 7, &n_it, &ictu, &n_ictu);
+    if (!it && ovhip_rec_itask_levels(rec)) return ov_fail(ctx, OVHIP_ENOMEM, "ovhip_job_flush: sorting the ordered tasks", hipSuccess);
+    if (!by_level) n_lv = ovhip_rec_itask_levels(rec);
+    if (!(stages & OVHIP_STAGE_INTRA)) { n_it = 0; n_lv = 0; n_ictu = 0; }
     const int ordered = n_it != 0;       // a picture with an ordered pass keeps its luma in the mapped domain until the pass has run
     if (ordered && !j->res.y) CHK(ovhip_pic_alloc(ctx, j->w, j->h, &j->res));
     if (ordered && (dst->stride_y != j->res.stride_y || dst->stride_c != j->res.stride_c))
@@ -369,6 +383,7 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
     CHK(h2d(j, B_TB, tb, n_tb * sizeof(*tb)));
     CHK(h2d(j, B_COEF, coef, n_coef * sizeof(*coef)));
     CHK(h2d(j, B_ITASK, it, n_it * sizeof(*it)));
+    CHK(h2d(j, B_ICTU, ictu, n_ictu * sizeof(*ictu)));
     if (n_reg) CHK(dev_reserve(j, B_SCALE, n_reg * 2));
     // (refined units that went through the eager per-row search are uploaded again with the rest: the list is small and
     // the full kernel repeats the search with the identical result)
@@ -440,16 +455,31 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
             if (pr->lmcs && !ordered) { CHK(ovhip_lmcs_inverse_launch(ctx, dst, d_bwd)); j->st.n_launches++; }
         }
     }
-    // ---- ordered pass: one launch per level (the launch boundary is the inter-level synchronisation), then the inverse
-    // luma mapping it had to wait for ----
+    // ---- ordered pass: ONE launch (a workgroup per CTU with tasks, CTU samples in LDS, neighbour CTUs chained by flags), or
+    // one launch per level; then the inverse luma mapping it had to wait for ----
     if (ordered) {
         StageTimer t_(j, OVHIP_TIME_INTRA);
         const ovhip_itask *d_it = (const ovhip_itask *)j->dev[B_ITASK].p;
-        for (uint32_t l = 0; l < n_lv; ++l) {
+        if (!by_level) {
+            if (!j->d_sync) {
+                const size_t words = ovhip_intra_sync_words(j->w, j->h, 5);          // the smallest CTU: enough for every size
+                OV_HIP(ctx, hipMalloc((void **)&j->d_sync, words * sizeof(uint32_t)));
+                OV_HIP(ctx, hipMemsetAsync(j->d_sync, 0, words * sizeof(uint32_t), ctx->stream));
+                j->abort_host = (uint32_t *)pinned_alloc(nullptr, 64);
+                if (!j->abort_host) return ov_fail(ctx, OVHIP_ENOMEM, "ovhip_job_flush: pinned abort word", hipSuccess);
+                *j->abort_host = 0;
+            }
+            if (!++j->epoch) ++j->epoch;
+            CHK(ovhip_intra_ctu_launch(ctx, dst, &j->res, d_it, (const ovhip_ictu *)j->dev[B_ICTU].p, (uint32_t)n_ictu,
+                                       (const ovhip_lmcs_region *)DEV(B_REG), pr->lmcs, (int16_t *)j->dev[B_SCALE].p, log2_ctu, j->d_sync, j->epoch,
+                                       j->abort_host));
+            j->st.n_launches++;
+        }
+        for (uint32_t l = 0; by_level && l < n_lv; ++l) {
             const uint32_t a = lv_start[l], b = lv_start[l + 1];
             if (b > a) {
                 CHK(ovhip_intra_level_launch(ctx, dst, &j->res, d_it + a, b - a, (const ovhip_lmcs_region *)DEV(B_REG), pr->lmcs,
-                                             (int16_t *)j->dev[B_SCALE].p, log2_ctu));
+                                             (int16_t *)j->dev[B_SCALE].p, log2_ctu, ovhip_intra_level_geom(it + a, b - a)));
                 j->st.n_launches++;
             }
         }

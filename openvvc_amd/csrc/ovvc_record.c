@@ -55,8 +55,8 @@ ovhip_rec_destroy(ovhip_recorder *r)
 {
     if (!r) return;
     void *bufs[] = { r->tb, r->coef, r->mc, r->mcx, r->aff, r->aff_side, r->reg, r->tb_split, r->ciip, r->edge_v, r->edge_h,
-                     r->itask, r->itask_sorted };
-    free(r->ilevel_start);
+                     r->itask, r->itask_sorted, r->itask_ctu, r->ictu };
+    free(r->ilevel_start); free(r->ctu_count);
     ovhip_rec_intra_free_(r);
     for (size_t i = 0; i < sizeof(bufs) / sizeof(bufs[0]); ++i) ovhip_rec_free_(r, bufs[i]);
     ovhip_rec_dbf_free_(r);

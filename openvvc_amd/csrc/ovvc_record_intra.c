@@ -34,7 +34,7 @@ maps_ready(ovhip_recorder *r)
 int
 ovhip_rec_intra_reset_(ovhip_recorder *r)
 {
-    r->n_itask = 0; r->n_ilevels = 0;
+    r->n_itask = 0; r->n_ilevels = 0; r->max_ilevel = 0;
     if (r->lvl_y) r->lvl_dirty = 1;          /* cleared lazily: pictures without ordered tasks never touch the maps */
     return 0;
 }
@@ -130,7 +130,17 @@ ovhip_rec_itask_add_(ovhip_recorder *r, const ovhip_itask *in, uint16_t extra_le
         return OVHIP_EINVAL;
     }
     r->itask[r->n_itask] = t;
+    if (t.level > r->max_ilevel) r->max_ilevel = t.level;
     return (int)r->n_itask++;
+}
+
+uint32_t
+ovhip_rec_itask_levels(const ovhip_recorder *r)
+{
+    if (!r) return 0;
+    uint32_t m = r->max_ilevel;
+    if (!m) for (size_t i = 0; i < r->n_itask; ++i) if (r->itask[i].level > m) m = r->itask[i].level;    /* appended raw */
+    return m;
 }
 
 const ovhip_itask *
@@ -171,4 +181,62 @@ ovhip_rec_itasks_sorted(ovhip_recorder *r, size_t *n, const uint32_t **level_sta
     *n_levels = maxl;
     *level_start = start + 1;                                                   /* entry l = first task of level l + 1 */
     return r->itask_sorted;
+}
+
+/* Grouped by CTU for the one-launch ordered pass (k_intra_ctu): counting sort of the level-sorted list by CTU index, so a
+ * CTU's tasks stay in level order, decoding order inside a level. */
+const ovhip_itask *
+ovhip_rec_itasks_by_ctu(ovhip_recorder *r, int32_t log2_ctu_s, size_t *n, const ovhip_ictu **ctus, size_t *n_ctus)
+{
+    if (!r || !n || !ctus || !n_ctus || log2_ctu_s < 5 || log2_ctu_s > 7) return NULL;
+    *n = 0; *ctus = NULL; *n_ctus = 0;
+    if (!r->n_itask) return r->itask;
+    const uint32_t *lv; uint32_t nlv; size_t nt;
+    const ovhip_itask *sorted = ovhip_rec_itasks_sorted(r, &nt, &lv, &nlv);
+    if (!sorted) return NULL;
+    const int ncx = (r->pic_w + (1 << log2_ctu_s) - 1) >> log2_ctu_s, ncy = (r->pic_h + (1 << log2_ctu_s) - 1) >> log2_ctu_s;
+    const size_t nctu = (size_t)ncx * ncy;
+    if (r->cap_ctu_count < 2 * nctu + 1) {
+        uint32_t *q = (uint32_t *)realloc(r->ctu_count, (2 * nctu + 1) * sizeof(uint32_t));
+        if (!q) return NULL;
+        r->ctu_count = q; r->cap_ctu_count = 2 * nctu + 1;
+    }
+    if (ovhip_rec_grow_(r, (void **)&r->itask_ctu, &r->cap_itask_ctu, nt, sizeof(ovhip_itask))) return NULL;
+    uint32_t *start = r->ctu_count, *fill = r->ctu_count + nctu + 1;
+    memset(start, 0, (nctu + 1) * sizeof(uint32_t));
+#define CTU_OF(t) ((size_t)(((t).kind == OVHIP_IT_CHROMA || (t).kind == OVHIP_IT_RES_C ? (t).y * 2 : (t).y) >> log2_ctu_s) * ncx \
+                   + (((t).kind == OVHIP_IT_CHROMA || (t).kind == OVHIP_IT_RES_C ? (t).x * 2 : (t).x) >> log2_ctu_s))
+    size_t used = 0;
+    for (size_t i = 0; i < nt; ++i) {
+        const size_t c = CTU_OF(sorted[i]);
+        if (c >= nctu) return NULL;
+        if (!start[c]++) ++used;
+    }
+    if (ovhip_rec_grow_(r, (void **)&r->ictu, &r->cap_ictu, used, sizeof(ovhip_ictu))) return NULL;
+    uint32_t acc = 0; size_t k = 0;
+    for (size_t c = 0; c < nctu; ++c) {
+        const uint32_t cnt = start[c];
+        fill[c] = acc;
+        if (cnt) {
+            const int cx = (int)(c % ncx), cy = (int)(c / ncx);
+            ovhip_ictu d = { (uint16_t)cx, (uint16_t)cy, acc, cnt, 0 };
+            r->ictu[k++] = d;
+        }
+        acc += cnt;
+    }
+    /* neighbour masks from the raw counts (start[] still holds them) */
+    for (size_t i = 0; i < used; ++i) {
+        ovhip_ictu *d = &r->ictu[i];
+        const int cx = d->cx, cy = d->cy;
+        uint32_t m = 0;
+        if (cx > 0 && start[(size_t)cy * ncx + cx - 1]) m |= 1;
+        if (cx > 0 && cy > 0 && start[(size_t)(cy - 1) * ncx + cx - 1]) m |= 2;
+        if (cy > 0 && start[(size_t)(cy - 1) * ncx + cx]) m |= 4;
+        if (cy > 0 && cx + 1 < ncx && start[(size_t)(cy - 1) * ncx + cx + 1]) m |= 8;
+        d->deps = m;
+    }
+    for (size_t i = 0; i < nt; ++i) r->itask_ctu[fill[CTU_OF(sorted[i])]++] = sorted[i];
+#undef CTU_OF
+    *n = nt; *ctus = r->ictu; *n_ctus = used;
+    return r->itask_ctu;
 }

@@ -27,7 +27,10 @@ struct ovhip_recorder {
     /* ordered tasks (ovvc_record_intra.c) */
     ovhip_itask *itask; size_t n_itask, cap_itask;
     ovhip_itask *itask_sorted; size_t cap_isorted;
-    uint32_t *ilevel_start; size_t cap_ilevel; uint32_t n_ilevels;
+    uint32_t *ilevel_start; size_t cap_ilevel; uint32_t n_ilevels, max_ilevel;
+    ovhip_itask *itask_ctu; size_t cap_itask_ctu;       /* grouped by CTU (ovhip_rec_itasks_by_ctu) */
+    ovhip_ictu *ictu; size_t cap_ictu;
+    uint32_t *ctu_count; size_t cap_ctu_count;
     uint16_t *lvl_y, *lvl_c;            /* level of the ordered task covering each 4x4-luma unit (0: none), luma / chroma */
     int32_t lvl_w4, lvl_h4; int lvl_dirty;
     uint16_t *reg_level; size_t cap_reglvl;     /* level of each chroma-scale region (0: derived by the unordered launch) */

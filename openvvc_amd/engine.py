@@ -108,12 +108,20 @@ class Context:
         self._chk(self.lib.ovhip_lmcs_inverse_launch(self.h, C.byref(pic.s), bwd_lut.ptr), "lmcs_inverse_launch")
 
     def intra_level(self, pic: "DevPic", res: "DevPic", tasks: "DevBuf", first: int, n: int, regions: "DevBuf | None" = None,
-                    luts=None, scales: "DevBuf | None" = None, log2_ctu: int = 7):
+                    luts=None, scales: "DevBuf | None" = None, log2_ctu: int = 7, geom: int = 0x12):
         """One level of the ordered pass: tasks [first, first + n) of the device task list."""
         ptr = C.c_void_p(tasks.ptr.value + first * 32)
         self._chk(self.lib.ovhip_intra_level_launch(self.h, C.byref(pic.s), C.byref(res.s), ptr, n, regions.ptr if regions else None,
-                                                    C.byref(luts) if luts is not None else None, scales.ptr if scales else None, log2_ctu),
+                                                    C.byref(luts) if luts is not None else None, scales.ptr if scales else None, log2_ctu, geom),
                   "intra_level_launch")
+
+    def intra_ctu(self, pic: "DevPic", res: "DevPic", tasks: "DevBuf", ctus: "DevBuf", n_ctus: int, sync: "DevBuf", epoch: int,
+                  regions: "DevBuf | None" = None, luts=None, scales: "DevBuf | None" = None, log2_ctu: int = 7):
+        """The whole ordered pass in one launch (tasks / ctus: device copies of Recorder.itasks_by_ctu()).  sync: a zeroed
+        device buffer of ovhip_intra_sync_words() uint32; epoch: fresh and != 0 for every launch on the same sync."""
+        self._chk(self.lib.ovhip_intra_ctu_launch(self.h, C.byref(pic.s), C.byref(res.s), tasks.ptr, ctus.ptr, n_ctus,
+                                                  regions.ptr if regions else None, C.byref(luts) if luts is not None else None,
+                                                  scales.ptr if scales else None, log2_ctu, sync.ptr, epoch, None), "intra_ctu_launch")
 
     def dbf(self, pic: "DevPic", planes: "DevDbfPlanes"):
         self._chk(self.lib.ovhip_dbf_launch(self.h, C.byref(pic.s), C.byref(planes.s)), "dbf_launch")

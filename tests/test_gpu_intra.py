@@ -53,22 +53,93 @@ def test_intra_tasks_gpu_match_reference(ctx):
     assert not bad, f"{len(bad)} / {len(tasks)} intra cases differ from the reference on the GPU, first: {bad[:8]}"
 
 
-@pytest.mark.parametrize("w,h,seed,frac", [(416, 240, 5, 0.12), (416, 240, 6, 1.0), (832, 480, 7, 0.3), (1920, 1080, 0x266, 0.12)])
-def test_picture_with_intra_matches_oracle(ctx, w, h, seed, frac):
+def _inside_ctu_geometry(t):
+    """The fixture draws availability at random; a decoder never marks samples available that lie right of the CTU below its
+    first row, or below the CTU (not decoded yet) -- the only samples the CTU tile does not hold."""
+    chroma = t["kind"] != capi.IT_LUMA
+    S, unit = (64, 2) if chroma else (128, 4)
+    x0, y0 = int(t["x"]), int(t["y"])
+    X0, Y0 = x0 & ~(S - 1), y0 & ~(S - 1)
+    mrl = 0 if (chroma or t["flags"] & capi.IF_MIP) else int(t["mrl_idx"])
+    if y0 == Y0 and mrl:
+        return False
+    if y0 > Y0 and x0 + unit * int(t["avl_abv"]) > X0 + S:
+        return False
+    return y0 + unit * int(t["avl_lft"]) <= Y0 + S
+
+
+def test_intra_tasks_ctu_kernel_match_reference(ctx):
+    """The same cases through the one-launch pass (k_intra_ctu): every case is the only task of its CTU (no waits), the
+    picture comes from / goes back through the CTU tile in LDS."""
+    g = golden_io.load("intra.ovg")
+    tasks = np.frombuffer(g["task"].tobytes(), dtype=capi.ITASK_DTYPE)
+    H, W = g["pic_y"].shape
+    base = [np.zeros((BAND, W), np.uint16), np.zeros((BAND // 2, W // 2), np.uint16), np.zeros((BAND // 2, W // 2), np.uint16)]
+    base[0][:H] = g["pic_y"]; base[1][:H // 2] = g["pic_cb"]; base[2][:H // 2] = g["pic_cr"]
+    NB = 160
+    tall_planes = [np.tile(p, (NB, 1)) for p in base]
+    res = ctx.new_pic(W, BAND * NB)
+    sync = ctx.upload(np.zeros(int(ctx.lib.ovhip_intra_sync_words(W, BAND * NB, 7)), np.uint32))
+    bad, n_checked = [], 0
+    for epoch, b0 in enumerate(range(0, len(tasks), NB), 1):
+        t = tasks[b0:b0 + NB].copy()
+        k = np.arange(len(t))
+        t["y"] += np.where(t["kind"] == capi.IT_LUMA, k * BAND, k * (BAND // 2)).astype(np.uint16)
+        rec = capi.Recorder(W, BAND * NB)
+        rec.append_raw(capi.REC_ITASK, t)
+        ts, cs = rec.itasks_by_ctu(7)
+        rec.close()
+        assert len(cs) == len(t) and not cs["deps"].any()
+        pic = ctx.upload_pic(*tall_planes)
+        ctx.intra_ctu(pic, res, ctx.upload(ts), ctx.upload(cs), len(cs), sync, epoch)
+        ctx.sync()
+        y, cb, cr = pic.download()
+        pic.free()
+        for i in range(len(t)):
+            tt = t[i]
+            w, h, x, yy = 1 << int(tt["log2_w"]), 1 << int(tt["log2_h"]), int(tt["x"]), int(tt["y"])
+            eo = g["exp_off"][b0 + i]
+            if tt["kind"] == capi.IT_LUMA:
+                ok = np.array_equal(y[yy:yy + h, x:x + w], g["exp"][eo[0]:eo[0] + w * h].reshape(h, w))
+            else:
+                ok = (np.array_equal(cb[yy:yy + h, x:x + w], g["exp"][eo[0]:eo[0] + w * h].reshape(h, w))
+                      and np.array_equal(cr[yy:yy + h, x:x + w], g["exp"][eo[1]:eo[1] + w * h].reshape(h, w)))
+            if not ok and _inside_ctu_geometry(tasks[b0 + i]):
+                bad.append((b0 + i, int(tt["kind"]), int(tt["mode"]), w, h, int(tt["flags"]), int(tt["avl_lft"]), int(tt["avl_abv"]), int(tt["mrl_idx"])))
+            n_checked += int(_inside_ctu_geometry(tasks[b0 + i]))
+        # nothing but the task's block may change
+        if not bad:
+            for a, b, name in ((y, tall_planes[0], "Y"), (cb, tall_planes[1], "Cb"), (cr, tall_planes[2], "Cr")):
+                d = a != b
+                for i in range(len(t)):
+                    tt = t[i]
+                    if (tt["kind"] == capi.IT_LUMA) == (name == "Y"):
+                        d[int(tt["y"]):int(tt["y"]) + (1 << int(tt["log2_h"])), int(tt["x"]):int(tt["x"]) + (1 << int(tt["log2_w"]))] = False
+                assert not d.any(), f"plane {name}: samples outside the tasks' blocks changed"
+    assert n_checked > 5500
+    assert not bad, f"{len(bad)} / {n_checked} intra cases differ from the reference through k_intra_ctu, first: {bad[:8]}"
+
+
+@pytest.mark.parametrize("levels", [False, True])
+@pytest.mark.parametrize("w,h,seed,frac", [(416, 240, 5, 0.12), (416, 240, 6, 1.0), (832, 480, 7, 0.3), (1920, 1080, 0x266, 0.12), (1920, 1080, 0x267, 1.0)])
+def test_picture_with_intra_matches_oracle(ctx, w, h, seed, frac, levels):
     """Recorded pictures with intra CUs (MIP, MRL, BDPCM, CCLM / MDLM, CIIP blended on the device, ordered chroma-scale
-    regions) through the C flush: level-ordered launches == the oracle's decoding-order execution, all stages."""
+    regions) through the C flush, ordered pass as the one-launch CTU wavefront and as one launch per level: both == the
+    oracle's decoding-order execution, all stages."""
     wl = synth.make_workload(w, h, seed, tools=synth.INTRA_TOOLS, intra_frac=frac)
     assert wl.stats["n_itasks"] > 50 and wl.stats["n_ilevels"] > 5
     job = engine.Job(ctx, w, h)
     refs = [ctx.upload_pic(*r) for r in wl.refs]
     dst = ctx.new_pic(w, h)
     job.load_workload(wl)
+    if levels:
+        job.params.stages = capi.STAGE_ALL | capi.STAGE_INTRA_LEVELS
     job.flush(dst, refs, None)
     job.wait()
     got = dst.download()
     ref, mvs = oracle_pipeline.decode(wl, want_mvs=True)
     for name, a, b in (("Y", got[0], ref.y), ("Cb", got[1], ref.cb), ("Cr", got[2], ref.cr)):
-        assert np.array_equal(a, b), f"{w}x{h} intra_frac {frac}: plane {name}: {int((a != b).sum())} samples differ"
+        assert np.array_equal(a, b), f"{w}x{h} intra_frac {frac} levels={levels}: plane {name}: {int((a != b).sum())} samples differ"
     st = job.stats()
     assert st.n_itasks == wl.stats["n_itasks"] and st.n_ilevels == wl.stats["n_ilevels"]
     if mvs is not None:

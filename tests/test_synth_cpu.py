@@ -61,3 +61,39 @@ def test_level_order_equals_decoding_order():
         b = oracle_pipeline.decode(wl2, stages=("mc", "itx"))
         for x, y in zip(a.planes(), b.planes()):
             assert np.array_equal(x, y), f"seed {seed} intra_frac {frac}: level order differs from decoding order"
+
+
+def test_by_ctu_grouping_is_a_valid_order():
+    """ovhip_rec_itasks_by_ctu: every task once, a CTU's tasks contiguous and in level order, the neighbour masks right, and the
+    sequential execution CTU after CTU (raster) gives the decoding-order picture (what k_intra_ctu's wavefront relies on)."""
+    import copy
+    import numpy as np
+    import oracle_pipeline
+    from openvvc_amd import capi, synth
+    for seed, frac in ((4, 0.15), (5, 1.0)):
+        wl = synth.make_workload(416, 240, seed, tools=synth.INTRA_TOOLS, intra_frac=frac)
+        rec = capi.Recorder(416, 240)
+        rec.append_raw(capi.REC_ITASK, wl.itasks)
+        t, c = rec.itasks_by_ctu(7)
+        assert len(t) == len(wl.itasks) and int(c["n"].sum()) == len(t)
+        ncx = (416 + 127) // 128
+        has = {(int(d["cx"]), int(d["cy"])) for d in c}
+        prev = -1
+        for d in c:
+            idx = int(d["cy"]) * ncx + int(d["cx"])
+            assert idx > prev
+            prev = idx
+            tt = t[int(d["first"]):int(d["first"]) + int(d["n"])]
+            assert np.all(np.diff(tt["level"].astype(np.int64)) >= 0)
+            sh = np.where((tt["kind"] == capi.IT_CHROMA) | (tt["kind"] == capi.IT_RES_C), 1, 0)
+            assert np.all((tt["x"].astype(np.int64) << sh) >> 7 == d["cx"]) and np.all((tt["y"].astype(np.int64) << sh) >> 7 == d["cy"])
+            cx, cy = int(d["cx"]), int(d["cy"])
+            want = sum(bit for bit, n in ((1, (cx - 1, cy)), (2, (cx - 1, cy - 1)), (4, (cx, cy - 1)), (8, (cx + 1, cy - 1))) if n in has)
+            assert int(d["deps"]) == want
+        a = oracle_pipeline.decode(wl, stages=("mc", "itx"))
+        wl2 = copy.copy(wl)
+        wl2.itasks = t
+        b = oracle_pipeline.decode(wl2, stages=("mc", "itx"))
+        for x, y in zip(a.planes(), b.planes()):
+            assert np.array_equal(x, y)
+        rec.close()
