@@ -95,10 +95,11 @@ def main():
     ap.add_argument("--seed", type=int, default=0x266)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--in-flight", type=int, default=4, help="pictures in flight per GPU (one HIP stream + one host thread each)")
-    ap.add_argument("--sets", type=int, default=12, help="picture sets the steps rotate over (distinct addresses; working set = sets x ~130 MB at 4K)")
+    ap.add_argument("--sets", type=int, default=32, help="picture sets the steps rotate over = one intra period (distinct addresses; working set = sets x ~100 MB at 4K)")
     ap.add_argument("--contents", type=int, default=2, help="distinct recorded pictures (seeds) among the sets")
     ap.add_argument("--intra-frac", type=float, default=0.12, help="share of intra CUs in the B pictures")
     ap.add_argument("--i-sets", type=int, default=1, help="picture sets that hold an I picture (all CUs intra)")
+    ap.add_argument("--intra-ctu", action="store_true", help="ordered pass as the one-launch CTU wavefront instead of one launch per level")
     ap.add_argument("--host-threads", type=int, default=-1, help="host threads issuing the flushes (-1: one per picture in flight)")
     args = ap.parse_args()
 
@@ -172,11 +173,13 @@ def main():
         st.ref_t[1], st.spare_t = st.spare_t, st.ref_t[1]
         st.refs[1], st.spare = st.spare, st.refs[1]
 
+    lv = capi.STAGE_INTRA_CTU if args.intra_ctu else 0
+
     def run_steps(first, n, resident=False):
         """Steps [first, first + n): step i decodes picture set i mod K.  One host thread per picture in flight."""
         def one(i):
             st = sets[i % K]
-            st.job.params.stages = (capi.STAGE_ALL | capi.STAGE_RESIDENT) if resident else 0
+            st.job.params.stages = ((capi.STAGE_ALL | capi.STAGE_RESIDENT) if resident else capi.STAGE_ALL) | lv
             st.job.flush(st.dst, st.refs, st.intra)
             if world > 1:
                 exchange(st)

@@ -395,7 +395,9 @@ typedef struct ovhip_itask {
                                * weight before the residual (ovhip_ciip_weight)                                        */
     int16_t  c_scale;         /* chroma residual scale, or region index (OVHIP_IF_SCALE_IDX, OVHIP_IT_REGION)          */
     uint16_t level;           /* >= 1                                                                                 */
-    uint16_t pad[7];
+    uint16_t ctu_deps;        /* set by the recorder: 0x8000 | log2_ctu << 8 | neighbour CTUs (bit 0 left, 1 above-left, 2 above,
+                               * 3 above-right) holding ordered tasks whose samples this task reads; 0 = unknown            */
+    uint16_t pad[6];
 } ovhip_itask;
 
 /* ------------------------------------------------------------------------------------
@@ -534,12 +536,15 @@ const ovhip_itask *ovhip_rec_itasks(const ovhip_recorder *rec, size_t *n);
 const ovhip_itask *ovhip_rec_itasks_sorted(ovhip_recorder *rec, size_t *n, const uint32_t **level_start, uint32_t *n_levels);
 /* The ordered tasks grouped by the CTU their block lies in (CTUs in raster order, inside a CTU by level, inside a level in
  * decoding order), with one descriptor per CTU that holds any.  deps: bit 0 left, 1 above-left, 2 above, 3 above-right
- * neighbour CTU holds ordered tasks too (its samples are not final before its own tasks ran). */
+ * neighbour CTU must have finished its own tasks first: the union of its tasks' ctu_deps when every task carries them for
+ * this CTU size, otherwise every such neighbour that holds ordered tasks at all. */
 typedef struct ovhip_ictu {
     uint16_t cx, cy;          /* CTU column / row */
     uint32_t first, n;        /* its tasks in the returned array */
     uint32_t deps;
 } ovhip_ictu;
+/* CTU size (log2, 5..7; 7 when never called) the recorder relates ovhip_itask.ctu_deps to; call before the picture's first TU. */
+int   ovhip_rec_set_ctu_size(ovhip_recorder *rec, int32_t log2_ctu_s);
 uint32_t ovhip_rec_itask_levels(const ovhip_recorder *rec);      /* highest level recorded so far */
 const ovhip_itask *ovhip_rec_itasks_by_ctu(ovhip_recorder *rec, int32_t log2_ctu_s, size_t *n, const ovhip_ictu **ctus, size_t *n_ctus);
 /* tmp.rcn_transform_tree: walks the tree and records every leaf with ovhip_rec_tu.  Returns the number of
@@ -741,8 +746,9 @@ typedef struct ovhip_job ovhip_job;
 enum {                                   /* ovhip_job_params.stages (0 = all) */
     OVHIP_STAGE_MC = 1, OVHIP_STAGE_ITX = 2, OVHIP_STAGE_DBF = 4, OVHIP_STAGE_SAO = 8, OVHIP_STAGE_ALF = 16,
     OVHIP_STAGE_INTRA = 32,
-    OVHIP_STAGE_INTRA_LEVELS = 0x20000000,  /* with OVHIP_STAGE_INTRA: the ordered pass as one launch per level (ovhip_intra_level_launch)
-                                            * instead of the one-launch CTU wavefront (ovhip_intra_ctu_launch); comparison / fallback */
+    OVHIP_STAGE_INTRA_CTU = 0x20000000,  /* with OVHIP_STAGE_INTRA: the ordered pass as the one-launch CTU wavefront
+                                          * (ovhip_intra_ctu_launch) instead of one launch per level (ovhip_intra_level_launch, the
+                                          * default: measured faster on B and I pictures) */
     OVHIP_STAGE_RESIDENT = 0x40000000    /* measurement only: no H2D / D2H, the device copies of the previous flush are replayed */
 };
 

@@ -494,6 +494,7 @@ __global__ __launch_bounds__(64) void k_intra_level(ovhip_pic pic, ovhip_pic res
 struct CtuLds {
     uint16_t ty[CT_S][CT_YS], top_y[4 + 2 * CT_S + 4];
     uint16_t tc[2][CT_S / 2][CT_CS], top_c[2][4 + CT_S + 4];
+    int16_t ry[CT_S][CT_S], rc[2][CT_S / 2][CT_S / 2];      // the CTU's stored residuals (a global round trip per level otherwise)
     ovhip_itask task[CT_CHUNK];
     IntraLds w[4];
     int sc_idx[4], sc_val[4], n_sc, abort;
@@ -512,7 +513,7 @@ __device__ __forceinline__ ovhip_itask uniform_task(const ovhip_itask *p)
 }
 
 // one (task, strip, plane) item by one wave; samples from / to the tile
-__device__ void ctu_item(CtuLds &L, IntraLds &s, const ovhip_itask &t, int strip, int comp, const ovhip_pic &res, int X0, int Y0,
+__device__ void ctu_item(CtuLds &L, IntraLds &s, const ovhip_itask &t, int strip, int comp, int X0, int Y0,
                          const ovhip_lmcs_region *__restrict__ regs, const LmcsWnd &wnd, int16_t *__restrict__ scales, int log2_ctu, int lane)
 {
     const int l2w = t.log2_w, w = 1 << l2w, h = 1 << t.log2_h, npx = w * h;
@@ -527,14 +528,6 @@ __device__ void ctu_item(CtuLds &L, IntraLds &s, const ovhip_itask &t, int strip
     const bool has_res = t.flags & (luma ? OVHIP_IF_RES_Y : (comp ? OVHIP_IF_RES_CR : OVHIP_IF_RES_CB));
     const bool res_only = t.kind == OVHIP_IT_RES_C;
     if (res_only && !has_res) return;
-    const int rstride = luma ? res.stride_y : res.stride_c;
-    const int16_t *rp = reinterpret_cast<const int16_t *>(luma ? res.y : (comp ? res.cr : res.cb)) + t.y * rstride + t.x;
-    int rv[NPL];
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-        const int p = st.p0 + lane + 64 * i, x = p & (w - 1), y = p >> l2w;
-        rv[i] = (has_res && p < st.p1) ? rp[y * rstride + x] : 0;
-    }
     const bool scaled = !luma && (t.flags & OVHIP_IF_RES_SCALE);
     int scale = 0;
     if (scaled) {
@@ -547,7 +540,8 @@ __device__ void ctu_item(CtuLds &L, IntraLds &s, const ovhip_itask &t, int strip
     }
     const int tx = (luma ? t.x - X0 : t.x - (X0 >> 1)) + 4, ty = luma ? t.y - Y0 : t.y - (Y0 >> 1);
     uint16_t *dst = luma ? &L.ty[ty][tx] : &L.tc[comp][ty][tx];
-    const int dstride = luma ? CT_YS : CT_CS;
+    const int16_t *rp = luma ? &L.ry[ty][tx - 4] : &L.rc[comp][ty][tx - 4];
+    const int dstride = luma ? CT_YS : CT_CS, rstride = luma ? CT_S : CT_S / 2;
     const int ciip_wt = res_only ? 0 : t.ciip_wt;
     if (!res_only) {
         if (luma) {
@@ -573,7 +567,7 @@ __device__ void ctu_item(CtuLds &L, IntraLds &s, const ovhip_itask &t, int strip
         uint16_t *d = dst + y * dstride + x;
         int v = res_only ? (int)*d : (int)s.pred[p - st.p0];
         if (ciip_wt) v = (v * ciip_wt + (int)*d * (4 - ciip_wt) + 2) >> 2;
-        if (has_res) v = ov_clip_bd(v + (scaled ? res_scale(rv[i], scale) : rv[i]));
+        if (has_res) { const int r = rp[y * rstride + x]; v = ov_clip_bd(v + (scaled ? res_scale(r, scale) : r)); }
         *d = (uint16_t)v;
     }
 }
@@ -633,6 +627,16 @@ __global__ __launch_bounds__(256) void k_intra_ctu(ovhip_pic pic, ovhip_pic res,
             const uint16_t *src = pl ? pic.cr : pic.cb;
             *reinterpret_cast<u64 *>(&L.tc[pl][r][4 + 4 * g]) = *reinterpret_cast<const u64 *>(src + (size_t)(Y0c + r) * pic.stride_c + X0c + 4 * g);
         }
+        const int nr = cw >> 2, nrc = cwc >> 2;                        // residuals: written by the launches before this one
+        for (int i = tid; i < ch * nr; i += 256) {
+            const int r = i / nr, g = i - r * nr;
+            *reinterpret_cast<u64 *>(&L.ry[r][4 * g]) = *reinterpret_cast<const u64 *>(res.y + (size_t)(Y0 + r) * res.stride_y + X0 + 4 * g);
+        }
+        for (int i = tid; i < 2 * chc * nrc; i += 256) {
+            const int pl = i >= chc * nrc, k = i - pl * chc * nrc, r = k / nrc, g = k - r * nrc;
+            const uint16_t *src = pl ? res.cr : res.cb;
+            *reinterpret_cast<u64 *>(&L.rc[pl][r][4 * g]) = *reinterpret_cast<const u64 *>(src + (size_t)(Y0c + r) * res.stride_c + X0c + 4 * g);
+        }
         if (Y0) {
             const int nt = (min(pic.w, X0 + cw + S) - X0) / 4 - gx0, ntc = (min(wc, X0c + cwc + Sc) - X0c) / 4 - gx0;
             for (int i = tid; i < nt + 2 * ntc; i += 256) {
@@ -665,7 +669,7 @@ __global__ __launch_bounds__(256) void k_intra_ctu(ovhip_pic pic, ovhip_pic res,
                 const int strips = t.kind == OVHIP_IT_REGION ? 1 : (npx + STRIP - 1) / STRIP, comps = (t.kind == OVHIP_IT_CHROMA || t.kind == OVHIP_IT_RES_C) ? 2 : 1;
                 for (int st = 0; st < strips; ++st)
                     for (int cp = 0; cp < comps; ++cp)
-                        if ((cnt++ & 3) == wave) ctu_item(L, L.w[wave], t, st, cp, res, X0, Y0, regs, wnd, scales, log2_ctu, lane);
+                        if ((cnt++ & 3) == wave) ctu_item(L, L.w[wave], t, st, cp, X0, Y0, regs, wnd, scales, log2_ctu, lane);
             }
             __syncthreads();
             i = j;

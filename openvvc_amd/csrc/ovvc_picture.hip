@@ -310,7 +310,7 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
         return ov_fail(ctx, OVHIP_EUNSUP, "ovhip_job_flush: CIIP blend units recorded but no picture with their intra prediction", hipSuccess);
     // ordered tasks: grouped by CTU for the one-launch pass, or sorted by level for one launch per level
     size_t n_it = 0, n_ictu = 0; uint32_t n_lv = 0; const uint32_t *lv_start = nullptr; const ovhip_ictu *ictu = nullptr;
-    const int by_level = (stages & OVHIP_STAGE_INTRA_LEVELS) != 0;
+    const int by_level = !(pr->stages && (stages & OVHIP_STAGE_INTRA_CTU));
     const ovhip_itask *it = by_level ? ovhip_rec_itasks_sorted(rec, &n_it, &lv_start, &n_lv)
                                      : ovhip_rec_itasks_by_ctu(rec, pr->log2_ctu_s ? pr->log2_ctu_s : 7, &n_it, &ictu, &n_ictu);
     if (!it && ovhip_rec_itask_levels(rec)) return ov_fail(ctx, OVHIP_ENOMEM, "ovhip_job_flush: sorting the ordered tasks", hipSuccess);
@@ -455,8 +455,8 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
             if (pr->lmcs && !ordered) { CHK(ovhip_lmcs_inverse_launch(ctx, dst, d_bwd)); j->st.n_launches++; }
         }
     }
-    // ---- ordered pass: ONE launch (a workgroup per CTU with tasks, CTU samples in LDS, neighbour CTUs chained by flags), or
-    // one launch per level; then the inverse luma mapping it had to wait for ----
+    // ---- ordered pass: one launch per level (the launch boundary is the inter-level synchronisation) or, on request, ONE launch
+    // (a workgroup per CTU with tasks, CTU samples in LDS, neighbour CTUs chained by flags); then the inverse luma mapping ----
     if (ordered) {
         StageTimer t_(j, OVHIP_TIME_INTRA);
         const ovhip_itask *d_it = (const ovhip_itask *)j->dev[B_ITASK].p;

@@ -37,6 +37,7 @@ ovhip_rec_create_ex(int32_t pic_w, int32_t pic_h, const ovhip_allocator *a)
     r->pic_w = pic_w;
     r->pic_h = pic_h;
     r->dense_planes = 1;
+    r->log2_ctu = 7;
     if (a) { r->al = *a; r->has_al = 1; }
     return r;
 }

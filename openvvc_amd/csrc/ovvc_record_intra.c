@@ -46,20 +46,40 @@ ovhip_rec_intra_free_(ovhip_recorder *r)
     r->lvl_y = r->lvl_c = NULL; r->reg_level = NULL;
 }
 
-/* highest level over the units [ux0, ux0 + nx) x [uy0, uy0 + ny) of a map, clipped to the picture */
+/* highest level over the units [ux0, ux0 + nx) x [uy0, uy0 + ny) of a map, clipped to the picture.  Units written by an
+ * ordered task (level > 0) that lie in ANOTHER CTU than the scanning task's add that CTU to r->scan_deps (bit 0 left,
+ * 1 above-left, 2 above, 3 above-right): what the one-launch pass (k_intra_ctu) must wait for. */
 static int
-max_level(const ovhip_recorder *r, const uint16_t *map, int ux0, int uy0, int nx, int ny)
+max_level(ovhip_recorder *r, const uint16_t *map, int ux0, int uy0, int nx, int ny)
 {
     int m = 0;
     int x1 = ux0 + nx, y1 = uy0 + ny;
+    const int sh = r->log2_ctu - 2;
     if (ux0 < 0) ux0 = 0;
     if (uy0 < 0) uy0 = 0;
     if (x1 > r->lvl_w4) x1 = r->lvl_w4;
     if (y1 > r->lvl_h4) y1 = r->lvl_h4;
     for (int y = uy0; y < y1; ++y)
-        for (int x = ux0; x < x1; ++x)
-            if (map[y * r->lvl_w4 + x] > m) m = map[y * r->lvl_w4 + x];
+        for (int x = ux0; x < x1; ++x) {
+            const int l = map[y * r->lvl_w4 + x];
+            if (!l) continue;
+            if (l > m) m = l;
+            const int dx = (x >> sh) - r->scan_cx, dy = (y >> sh) - r->scan_cy;
+            if (dx | dy) {
+                if (dy == 0 && dx == -1) r->scan_deps |= 1;
+                else if (dy == -1 && dx == -1) r->scan_deps |= 2;
+                else if (dy == -1 && dx == 0) r->scan_deps |= 4;
+                else if (dy == -1 && dx == 1) r->scan_deps |= 8;
+                else r->scan_deps |= 0x10;           /* not a wavefront neighbour: the CTU pass cannot serve this picture */
+            }
+        }
     return m;
+}
+
+static void
+scan_begin(ovhip_recorder *r, int luma_x, int luma_y)
+{
+    r->scan_cx = luma_x >> r->log2_ctu; r->scan_cy = luma_y >> r->log2_ctu; r->scan_deps = 0;
 }
 
 static void
@@ -75,11 +95,14 @@ set_level(ovhip_recorder *r, uint16_t *map, int ux0, int uy0, int nx, int ny, in
 uint16_t
 ovhip_rec_region_level_(ovhip_recorder *r, int32_t x0, int32_t y0, int n_abv, int n_lft)
 {
+    r->region_deps = 0;
     if (!r->n_itask || maps_ready(r)) return 0;
     const int ux = x0 >> 2, uy = y0 >> 2;
     int m = 0, k;
+    scan_begin(r, x0, y0);
     if (n_abv && (k = max_level(r, r->lvl_y, ux, uy - 1, n_abv, 1)) > m) m = k;
     if (n_lft && (k = max_level(r, r->lvl_y, ux - 1, uy, 1, n_lft)) > m) m = k;
+    r->region_deps = r->scan_deps;
     return (uint16_t)(m ? m + 1 : 0);
 }
 
@@ -92,6 +115,9 @@ ovhip_rec_itask_add_(ovhip_recorder *r, const ovhip_itask *in, uint16_t extra_le
     ovhip_itask t = *in;
     const int w = 1 << t.log2_w, h = 1 << t.log2_h;
     int m = extra_level, k;
+    const int cs = t.kind == OVHIP_IT_CHROMA || t.kind == OVHIP_IT_RES_C;
+    scan_begin(r, t.x << cs, t.y << cs);
+    if (t.kind == OVHIP_IT_REGION) r->scan_deps = r->region_deps;
     if (t.kind == OVHIP_IT_LUMA) {
         const int ux = t.x >> 2, uy = t.y >> 2, nx = (w + 3) >> 2, ny = (h + 3) >> 2;
         if ((t.flags & OVHIP_IF_CORNER) && (k = max_level(r, r->lvl_y, ux - 1, uy - 1, 1, 1)) > m) m = k;
@@ -129,9 +155,18 @@ ovhip_rec_itask_add_(ovhip_recorder *r, const ovhip_itask *in, uint16_t extra_le
     } else {
         return OVHIP_EINVAL;
     }
+    t.ctu_deps = (uint16_t)(0x8000u | ((unsigned)r->log2_ctu << 8) | (r->scan_deps & 0x1f));
     r->itask[r->n_itask] = t;
     if (t.level > r->max_ilevel) r->max_ilevel = t.level;
     return (int)r->n_itask++;
+}
+
+int
+ovhip_rec_set_ctu_size(ovhip_recorder *r, int32_t log2_ctu_s)
+{
+    if (!r || log2_ctu_s < 5 || log2_ctu_s > 7) return OVHIP_EINVAL;
+    r->log2_ctu = log2_ctu_s;
+    return OVHIP_OK;
 }
 
 uint32_t
@@ -207,10 +242,13 @@ ovhip_rec_itasks_by_ctu(ovhip_recorder *r, int32_t log2_ctu_s, size_t *n, const 
 #define CTU_OF(t) ((size_t)(((t).kind == OVHIP_IT_CHROMA || (t).kind == OVHIP_IT_RES_C ? (t).y * 2 : (t).y) >> log2_ctu_s) * ncx \
                    + (((t).kind == OVHIP_IT_CHROMA || (t).kind == OVHIP_IT_RES_C ? (t).x * 2 : (t).x) >> log2_ctu_s))
     size_t used = 0;
+    int precise = 1;                 /* every task carries the CTUs it reads ordered samples from, for this CTU size */
     for (size_t i = 0; i < nt; ++i) {
         const size_t c = CTU_OF(sorted[i]);
         if (c >= nctu) return NULL;
         if (!start[c]++) ++used;
+        const unsigned d = sorted[i].ctu_deps;
+        if (!(d & 0x8000u) || ((d >> 8) & 7) != (unsigned)log2_ctu_s || (d & 0x10)) precise = 0;
     }
     if (ovhip_rec_grow_(r, (void **)&r->ictu, &r->cap_ictu, used, sizeof(ovhip_ictu))) return NULL;
     uint32_t acc = 0; size_t k = 0;
@@ -233,9 +271,14 @@ ovhip_rec_itasks_by_ctu(ovhip_recorder *r, int32_t log2_ctu_s, size_t *n, const 
         if (cx > 0 && cy > 0 && start[(size_t)(cy - 1) * ncx + cx - 1]) m |= 2;
         if (cy > 0 && start[(size_t)(cy - 1) * ncx + cx]) m |= 4;
         if (cy > 0 && cx + 1 < ncx && start[(size_t)(cy - 1) * ncx + cx + 1]) m |= 8;
-        d->deps = m;
+        d->deps = precise ? 0 : m;
     }
     for (size_t i = 0; i < nt; ++i) r->itask_ctu[fill[CTU_OF(sorted[i])]++] = sorted[i];
+    if (precise)
+        for (size_t i = 0; i < used; ++i) {
+            ovhip_ictu *d = &r->ictu[i];
+            for (uint32_t k = 0; k < d->n; ++k) d->deps |= r->itask_ctu[d->first + k].ctu_deps & 0xf;
+        }
 #undef CTU_OF
     *n = nt; *ctus = r->ictu; *n_ctus = used;
     return r->itask_ctu;

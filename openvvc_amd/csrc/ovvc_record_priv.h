@@ -33,6 +33,8 @@ struct ovhip_recorder {
     uint32_t *ctu_count; size_t cap_ctu_count;
     uint16_t *lvl_y, *lvl_c;            /* level of the ordered task covering each 4x4-luma unit (0: none), luma / chroma */
     int32_t lvl_w4, lvl_h4; int lvl_dirty;
+    int log2_ctu;                       /* CTU size the tasks' ctu_deps refer to (ovhip_rec_set_ctu_size; 7 by default) */
+    int scan_cx, scan_cy; uint32_t scan_deps, region_deps;
     uint16_t *reg_level; size_t cap_reglvl;     /* level of each chroma-scale region (0: derived by the unordered launch) */
 };
 

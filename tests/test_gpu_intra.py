@@ -120,11 +120,11 @@ def test_intra_tasks_ctu_kernel_match_reference(ctx):
     assert not bad, f"{len(bad)} / {n_checked} intra cases differ from the reference through k_intra_ctu, first: {bad[:8]}"
 
 
-@pytest.mark.parametrize("levels", [False, True])
+@pytest.mark.parametrize("one_launch", [False, True])
 @pytest.mark.parametrize("w,h,seed,frac", [(416, 240, 5, 0.12), (416, 240, 6, 1.0), (832, 480, 7, 0.3), (1920, 1080, 0x266, 0.12), (1920, 1080, 0x267, 1.0)])
-def test_picture_with_intra_matches_oracle(ctx, w, h, seed, frac, levels):
+def test_picture_with_intra_matches_oracle(ctx, w, h, seed, frac, one_launch):
     """Recorded pictures with intra CUs (MIP, MRL, BDPCM, CCLM / MDLM, CIIP blended on the device, ordered chroma-scale
-    regions) through the C flush, ordered pass as the one-launch CTU wavefront and as one launch per level: both == the
+    regions) through the C flush, ordered pass as one launch per level (default) and as the one-launch CTU wavefront: both == the
     oracle's decoding-order execution, all stages."""
     wl = synth.make_workload(w, h, seed, tools=synth.INTRA_TOOLS, intra_frac=frac)
     assert wl.stats["n_itasks"] > 50 and wl.stats["n_ilevels"] > 5
@@ -132,14 +132,14 @@ def test_picture_with_intra_matches_oracle(ctx, w, h, seed, frac, levels):
     refs = [ctx.upload_pic(*r) for r in wl.refs]
     dst = ctx.new_pic(w, h)
     job.load_workload(wl)
-    if levels:
-        job.params.stages = capi.STAGE_ALL | capi.STAGE_INTRA_LEVELS
+    if one_launch:
+        job.params.stages = capi.STAGE_ALL | capi.STAGE_INTRA_CTU
     job.flush(dst, refs, None)
     job.wait()
     got = dst.download()
     ref, mvs = oracle_pipeline.decode(wl, want_mvs=True)
     for name, a, b in (("Y", got[0], ref.y), ("Cb", got[1], ref.cb), ("Cr", got[2], ref.cr)):
-        assert np.array_equal(a, b), f"{w}x{h} intra_frac {frac} levels={levels}: plane {name}: {int((a != b).sum())} samples differ"
+        assert np.array_equal(a, b), f"{w}x{h} intra_frac {frac} one_launch={one_launch}: plane {name}: {int((a != b).sum())} samples differ"
     st = job.stats()
     assert st.n_itasks == wl.stats["n_itasks"] and st.n_ilevels == wl.stats["n_ilevels"]
     if mvs is not None:
