@@ -94,7 +94,7 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--seed", type=int, default=0x266)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=4, help="pictures in flight per GPU (one HIP stream + one host thread each)")
+    ap.add_argument("--in-flight", type=int, default=6, help="pictures in flight per GPU (one HIP stream + one host thread each)")
     ap.add_argument("--sets", type=int, default=32, help="picture sets the steps rotate over = one intra period (distinct addresses; working set = sets x ~100 MB at 4K)")
     ap.add_argument("--contents", type=int, default=2, help="distinct recorded pictures (seeds) among the sets")
     ap.add_argument("--intra-frac", type=float, default=0.12, help="share of intra CUs in the B pictures")
@@ -152,6 +152,7 @@ def main():
         st = Set()
         st.slot = k % S
         st.ctx = ctxs[st.slot]
+        st.lock = threading.Lock()
         st.wl = wls[content_of[k]]
         st.job = engine.Job(st.ctx, W, H)
         st.job.load_workload(st.wl)
@@ -166,38 +167,48 @@ def main():
 
     # ---- N > 1: frames shard across ranks; a decoded picture is pushed to the next rank, where it replaces reference 1
     # of that slot's next picture -- issued on the slot's stream, never waited for on the host
-    def exchange(st):
-        with torch.cuda.stream(ext[st.slot]):
+    def exchange(st, slot):
+        with torch.cuda.stream(ext[slot]):
             ops = [dist.P2POp(dist.isend, st.dst_t, (rank + 1) % world), dist.P2POp(dist.irecv, st.spare_t, (rank - 1) % world)]
             dist.batch_isend_irecv(ops)
         st.ref_t[1], st.spare_t = st.spare_t, st.ref_t[1]
         st.refs[1], st.spare = st.spare, st.refs[1]
 
     lv = capi.STAGE_INTRA_CTU if args.intra_ctu else 0
+    nthreads = S if args.host_threads < 0 else max(1, min(args.host_threads, S))
 
     def run_steps(first, n, resident=False):
-        """Steps [first, first + n): step i decodes picture set i mod K.  One host thread per picture in flight."""
-        def one(i):
+        """Steps [first, first + n): step i decodes picture set i mod K.  One host thread per picture in flight, each with its
+        own HIP stream; a thread that became free takes the next picture (the reference's frame threads, ovdec.c:188-248) and,
+        like the shim's flush_picture, waits for its picture before it takes another."""
+        def one(i, slot, wait):
             st = sets[i % K]
-            st.job.params.stages = ((capi.STAGE_ALL | capi.STAGE_RESIDENT) if resident else capi.STAGE_ALL) | lv
-            st.job.flush(st.dst, st.refs, st.intra)
-            if world > 1:
-                exchange(st)
-        nthreads = S if args.host_threads < 0 else max(1, min(args.host_threads, S))
+            with st.lock:
+                st.job.bind(ctxs[slot])
+                st.job.params.stages = ((capi.STAGE_ALL | capi.STAGE_RESIDENT) if resident else capi.STAGE_ALL) | lv
+                st.job.flush(st.dst, st.refs, st.intra)
+                if world > 1:
+                    exchange(st, slot)
+                if wait:
+                    st.job.wait()
         if nthreads == 1 or world > 1:
             for i in range(first, first + n):
-                one(i)
+                one(i, i % S, False)
             return
-        errs = []
+        errs, nxt, nlock = [], [first], threading.Lock()
 
         def worker(slot):
             try:
-                for i in range(first, first + n):
-                    if i % K % S == slot:
-                        one(i)
+                while True:
+                    with nlock:
+                        i = nxt[0]
+                        nxt[0] += 1
+                    if i >= first + n:
+                        return
+                    one(i, slot, True)
             except Exception as e:          # noqa: BLE001
                 errs.append(e)
-        th = [threading.Thread(target=worker, args=(s,)) for s in range(S)]
+        th = [threading.Thread(target=worker, args=(s,)) for s in range(nthreads)]
         [t.start() for t in th]
         [t.join() for t in th]
         if errs:
@@ -233,7 +244,7 @@ def main():
             tot += s; cnt += n
         return tot / max(cnt, 1)
 
-    run_steps(0, args.warmup)
+    run_steps(0, max(args.warmup, K))            # every picture set flushed at least once
     barrier()
     all_stats = [st.job.stats() for st in sets]          # of full (non-resident) flushes
     flush_stats = all_stats[-1]                          # a B picture
@@ -339,7 +350,9 @@ def main():
                        "launches_per_i_picture": int(all_stats[0].n_launches) if args.i_sets else None,
                        "distinct_pictures": K, "distinct_contents": len(wls), "working_set_bytes": int(working_set),
                        "pictures_in_flight_per_gpu": S,
-                       "host_threads": 1 if world > 1 else (S if args.host_threads < 0 else args.host_threads),
+                       "host_threads": 1 if world > 1 else nthreads,
+                       "picture_assignment": "static round-robin, asynchronous" if (world > 1 or nthreads == 1)
+                                             else "a free host thread takes the next picture, flushes it and waits for it (as the shim does)",
                        "recorder_in_timed_region": False,
                        "n_cu": st["n_cu"], "cu_modes": st["cu_modes"], "n_mc_units": st["n_mc_units"],
                        "n_mcx_units": st["n_mcx_units"], "n_aff_units": st["n_aff_units"], "n_tb_cmds": st["n_tb_cmds"],

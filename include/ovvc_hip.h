@@ -774,6 +774,9 @@ void ovhip_job_destroy(ovhip_job *job);
 ovhip_recorder *ovhip_job_recorder(ovhip_job *job);
 /* Waits until the previous flush no longer reads the recorder's arrays, then resets the recorder. */
 int  ovhip_job_begin(ovhip_job *job);
+/* Issues the job's next flushes on another context (= HIP stream) of the same device: a frame thread that became free takes
+ * over a picture.  Waits for the job's previous flush first. */
+int  ovhip_job_bind(ovhip_job *job, ovhip_ctx *ctx);
 /* dst: the picture being decoded; refs[n_refs]: the table ovhip_pu_desc.ref0/ref1 index; intra: picture with the
  * caller's planar prediction for fused CIIP blends, or NULL.  All DEVICE pictures of the job's size. */
 int  ovhip_job_flush(ovhip_job *job, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs,

@@ -326,6 +326,7 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_intra_sync_words": (C.c_size_t, [i32, i32, i32]),
         "ovhip_intra_ctu_launch": (C.c_int, [vp, P(Pic), P(Pic), vp, vp, u32, vp, vp, vp, i32, vp, u32, vp]),
         "ovhip_rec_itask_levels": (u32, [vp]),
+        "ovhip_job_bind": (C.c_int, [vp, vp]),
         "ovhip_rec_set_ctu_size": (C.c_int, [vp, i32]),
         "ovhip_rec_itasks_by_ctu": (vp, [vp, i32, P(C.c_size_t), P(vp), P(C.c_size_t)]),
         "ovhip_rec_tu_intra": (C.c_int, [vp, P(TuState), P(TuDesc), P(ITask), P(ITask)]),
@@ -362,7 +363,7 @@ EXPORTED_SYMBOLS = [
     "ovhip_pic_download", "ovhip_itx_launch", "ovhip_mc_launch",
     "ovhip_rec_create_ex", "ovhip_rec_set_dense_dbf_planes", "ovhip_rec_dbf_edges", "ovhip_dbf_launch_edges_ex",
     "ovhip_dmvr_search_launch", "ovhip_rec_append_raw", "ovhip_rec_set_dbf_offsets", "ovhip_rec_tu_intra", "ovhip_rec_itasks", "ovhip_rec_itasks_sorted", "ovhip_itx_launch_classes_res", "ovhip_intra_level_launch", "ovhip_intra_level_geom", "ovhip_intra_sync_words", "ovhip_intra_ctu_launch",
-    "ovhip_rec_itask_levels", "ovhip_rec_itasks_by_ctu", "ovhip_rec_set_ctu_size", "ovhip_job_create", "ovhip_job_destroy", "ovhip_job_recorder", "ovhip_job_begin",
+    "ovhip_rec_itask_levels", "ovhip_rec_itasks_by_ctu", "ovhip_rec_set_ctu_size", "ovhip_job_bind", "ovhip_job_create", "ovhip_job_destroy", "ovhip_job_recorder", "ovhip_job_begin",
     "ovhip_job_flush", "ovhip_job_wait", "ovhip_job_refined_mvs", "ovhip_job_dmvr_rows", "ovhip_job_last_stats", "ovhip_job_time_stage", "ovhip_job_stage_time",
 ]
 

@@ -26,8 +26,7 @@ namespace {
 __device__ const short g_ang[32] = { 0, 1, 2, 3, 4, 6, 8, 10, 12, 14, 16, 18, 20, 23, 26, 29, 32, 35, 39, 45, 51, 57, 64, 73, 86, 102, 128, 171, 256, 341, 512, 1024 };
 __device__ const short g_inv_ang[32] = { 0, 16384, 8192, 5461, 4096, 2731, 2048, 1638, 1365, 1170, 1024, 910, 819, 712, 630, 565, 512, 468, 420, 364,
                                          321, 287, 256, 224, 191, 161, 128, 96, 64, 48, 32, 16 };
-__device__ const unsigned char g_hv_thres[8] = { 24, 24, 24, 14, 2, 0, 0, 0 };
-__device__ const signed char g_fc[32][4] = {
+__device__ __attribute__((aligned(4))) const signed char g_fc[32][4] = {
     { 0, 64, 0, 0 }, { -1, 63, 2, 0 }, { -2, 62, 4, 0 }, { -2, 60, 7, -1 }, { -2, 58, 10, -2 }, { -3, 57, 12, -2 }, { -4, 56, 14, -2 },
     { -4, 55, 15, -2 }, { -4, 54, 16, -2 }, { -5, 53, 18, -2 }, { -6, 52, 20, -2 }, { -6, 49, 24, -3 }, { -6, 46, 28, -4 }, { -5, 44, 29, -4 },
     { -4, 42, 30, -4 }, { -4, 39, 33, -4 }, { -4, 36, 36, -4 }, { -4, 33, 39, -4 }, { -4, 30, 42, -4 }, { -4, 29, 44, -5 }, { -4, 28, 46, -6 },
@@ -41,12 +40,24 @@ struct IntraLds {
     uint16_t fabv[IR_LEN], flft[IR_LEN]; // [1 2 1]-smoothed copies
     uint16_t red[64], hup[8 * 64];       // MIP: reduced prediction, horizontally up-sampled rows
     int      par[16];                    // CCLM neighbour samples / MIP boundary
+    short    ang[32], inv_ang[32];       // the angle tables, staged by load_tables() next to the task load (not behind it)
+    signed char fc[32][4];
     uint16_t pred[1024];                 // the strip's predicted samples
 };
 #define STRIP 1024
 #define NPL   (STRIP / 64)
 
 struct Strip { int p0, p1; };            // raster sample range [p0, p1) of the block this workgroup predicts
+
+// One memory round trip less on the critical path of a task: the tables do not depend on the task, so they are requested
+// before it is known which entries will be needed.
+__device__ __forceinline__ void load_tables(IntraLds &s, int lane)
+{
+    if (lane < 32) {
+        s.ang[lane] = g_ang[lane]; s.inv_ang[lane] = g_inv_ang[lane];
+        *reinterpret_cast<int *>(s.fc[lane]) = *reinterpret_cast<const int *>(g_fc[lane]);
+    }
+}
 
 __device__ __forceinline__ int pdpc_wgt(int i, int scale) { const int sh = (i << 1) >> scale; return sh > 5 ? 0 : 32 >> sh; }
 __device__ __forceinline__ int ilog2(int v) { return 31 - __clz(v); }
@@ -181,10 +192,10 @@ __device__ void pred_regular(IntraLds &s, const ovhip_itask &t, bool is_luma, co
     }
     const bool vertical = mode >= 34;
     const int midx = vertical ? mode - 50 : 18 - mode, am = abs(midx);
-    const int angle_abs = g_ang[am], inv = g_inv_ang[am];
+    const int angle_abs = s.ang[am], inv = s.inv_ang[am];
     const int angle = midx < 0 ? -angle_abs : angle_abs;
     bool use_fg = false, smoothed = false;
-    if (is_luma && !mrl && l2w + l2h > 5 && am > g_hv_thres[(l2w + l2h) >> 1]) {
+    if (is_luma && !mrl && l2w + l2h > 5 && am > (int)((0x000000020E181818ull >> (8 * ((l2w + l2h) >> 1))) & 0xff)) {
         if (!(angle_abs & 31)) { smooth_refs(s, 2 * w, 2 * h, lane); wave_sync(); smoothed = true; }
         else use_fg = true;
     }
@@ -213,7 +224,7 @@ __device__ void pred_regular(IntraLds &s, const ovhip_itask &t, bool is_luma, co
             else {
                 int f0, f1, f2, f3;
                 if (use_fg) { f0 = 16 - (ifact >> 1); f1 = 32 - (ifact >> 1); f2 = 16 + (ifact >> 1); f3 = ifact >> 1; }
-                else { f0 = g_fc[ifact][0]; f1 = g_fc[ifact][1]; f2 = g_fc[ifact][2]; f3 = g_fc[ifact][3]; }
+                else { f0 = s.fc[ifact][0]; f1 = s.fc[ifact][1]; f2 = s.fc[ifact][2]; f3 = s.fc[ifact][3]; }
                 v = ov_clip_bd((f0 * r[0] + f1 * r[1] + f2 * r[2] + f3 * r[3] + 32) >> 6);
             }
         } else {
@@ -411,8 +422,9 @@ __global__ __launch_bounds__(64) void k_intra_level(ovhip_pic pic, ovhip_pic res
     const uint32_t bid = blockIdx.x;
     const int strip = blockIdx.y, comp = blockIdx.z;
     if (bid >= n) return;
-    const ovhip_itask t = tasks[bid];
     const int lane = threadIdx.x;
+    load_tables(s, lane);
+    const ovhip_itask t = tasks[bid];
     const int l2w = t.log2_w, w = 1 << l2w, h = 1 << t.log2_h, npx = w * h;
     const PlaneAcc ya = { pic.y, pic.stride_y };
     if (t.kind == OVHIP_IT_REGION) {
@@ -585,6 +597,7 @@ __global__ __launch_bounds__(256) void k_intra_ctu(ovhip_pic pic, ovhip_pic res,
     const int wc = pic.w >> 1, hc = pic.h >> 1, Sc = S >> 1, X0c = X0 >> 1, Y0c = Y0 >> 1, cwc = cw >> 1, chc = ch >> 1;
     unsigned *flags = sync + SYNC_FLAGS;
     if (tid == 0) { L.n_sc = 0; L.abort = 0; }
+    load_tables(L.w[wave], lane);
     __syncthreads();
 
     // ---- 1. the neighbours this CTU reads must have published their tiles ----

@@ -192,6 +192,16 @@ int ovhip_job_begin(ovhip_job *j)
     return OVHIP_OK;
 }
 
+int ovhip_job_bind(ovhip_job *j, ovhip_ctx *ctx)
+{
+    if (!j || !ctx) return OVHIP_EINVAL;
+    if (ctx->device != j->ctx->device) return ov_fail(j->ctx, OVHIP_EINVAL, "ovhip_job_bind: context of another device", hipSuccess);
+    OV_DEVICE(j->ctx);
+    if (j->flushed) OV_HIP(j->ctx, hipEventSynchronize(j->ev_done));
+    j->ctx = ctx;
+    return OVHIP_OK;
+}
+
 int ovhip_job_wait(ovhip_job *j)
 {
     if (!j) return OVHIP_EINVAL;

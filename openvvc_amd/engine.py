@@ -453,6 +453,11 @@ class Job:
     def wait(self):
         self.ctx._chk(self.lib.ovhip_job_wait(self.j), "job_wait")
 
+    def bind(self, ctx: "Context"):
+        """The next flushes go to ctx's stream (a free frame thread takes the picture over)."""
+        self.ctx._chk(self.lib.ovhip_job_bind(self.j, ctx.h), "job_bind")
+        self.ctx = ctx
+
     def dmvr_rows(self, refs: list) -> int:
         arr = (capi.Pic * max(len(refs), 1))(*[r.s for r in refs])
         n = self.lib.ovhip_job_dmvr_rows(self.j, arr, len(refs))
