@@ -968,16 +968,27 @@ gen_gpm(const char *dir)
         ic->scale_fact_rpl0[i][0] = ic->scale_fact_rpl0[i][1] = 1 << RPR_SCALE_BITS;
         ic->scale_fact_rpl1[i][0] = ic->scale_fact_rpl1[i][1] = 1 << RPR_SCALE_BITS;
     }
+    void *real_intra_l = (void *)c->rcn_funcs.intra_pred, *real_intra_c = (void *)c->rcn_funcs.intra_pred_c;
     c->rcn_funcs.intra_pred = stub_ciip_intra_l;
     c->rcn_funcs.intra_pred_c = stub_ciip_intra_c;
+    uint16_t *cur[3];                                                     /* pass 2: the picture being decoded */
+    for (int p = 0; p < 3; ++p) { cur[p] = malloc((MC_W >> !!p) * (MC_H >> !!p) * 2); }
     c->part_map.cu_mode_x = calloc(64, 1);
     const struct OVBuffInfo *cb = &c->rcn_ctx.ctu_buff;
     struct shim_stream S;
     shim_stream_init(&S);
     if (g_shim) shim_bind(c, MC_W, MC_H, 0, 0);
 
-    for (int pass = 0; pass < 2; ++pass) {                                /* 0: GPM, 1: CIIP */
-        int n_iter = pass == 0 ? 64 * 3 : 150;
+    uint32_t n_ciip2 = 0;
+    for (int pass = 0; pass < 3; ++pass) {                                /* 0: GPM, 1: CIIP (planar stubbed), 2: CIIP, real planar */
+        int n_iter = pass == 0 ? 64 * 3 : pass == 1 ? 150 : 120;
+        if (pass == 2) {
+            /* the real slots: intra_pred / intra_pred_c read the CTU scratch around the block, as in a decoder */
+            c->rcn_funcs.intra_pred = real_intra_l; c->rcn_funcs.intra_pred_c = real_intra_c;
+            c->rcn_funcs.rcn_attach_ctu_buff(&c->rcn_ctx, 7, 1);
+            cb = &c->rcn_ctx.ctu_buff;
+            for (int p = 0; p < 3; ++p) fill_plane(cur[p], MC_W >> !!p, MC_H >> !!p, MC_W >> !!p);
+        }
         for (int it = 0; it < n_iter; ++it) {
             ovhip_pu_desc d;
             memset(&d, 0, sizeof(d));
@@ -998,8 +1009,34 @@ gen_gpm(const char *dir)
             d.ref_idx0 = rnd_range(0, 1); d.ref_idx1 = rnd_range(0, 1);
             c->ctb_x = px >> 7; c->ctb_y = py >> 7;
             int x0 = px & 127, y0 = py & 127;
-            for (int j = 0; j < 128; ++j) memset(cb->y + j * cb->stride, 0xAB, 256);
-            for (int j = 0; j < 64; ++j) { memset(cb->cb + j * cb->stride_c, 0xAB, 128); memset(cb->cr + j * cb->stride_c, 0xAB, 128); }
+            if (pass < 2) {
+                for (int j = 0; j < 128; ++j) memset(cb->y + j * cb->stride, 0xAB, 256);
+                for (int j = 0; j < 64; ++j) { memset(cb->cb + j * cb->stride_c, 0xAB, 128); memset(cb->cr + j * cb->stride_c, 0xAB, 128); }
+            } else {
+                /* CTU scratch <- current picture (clamped at the picture border: what lies outside is never available);
+                 * progress: the decoder's CTU start, every row of the CTU above the block, and the part of the block's rows
+                 * (and some below) left of it */
+                const int ox = c->ctb_x << 7, oy = c->ctb_y << 7;
+                #define CLAMP(v, lo, hi) ((v) < (lo) ? (lo) : (v) > (hi) ? (hi) : (v))
+                for (int j = -1; j < 132; ++j) for (int i = -128; i < 196; ++i)
+                    cb->y[j * cb->stride + i] = cur[0][CLAMP(oy + j, 0, MC_H - 1) * MC_W + CLAMP(ox + i, 0, MC_W - 1)];
+                for (int j = -1; j < 66; ++j) for (int i = -64; i < 98; ++i) {
+                    const int yy = CLAMP(oy / 2 + j, 0, MC_H / 2 - 1), xx = CLAMP(ox / 2 + i, 0, MC_W / 2 - 1);
+                    cb->cb[j * cb->stride_c + i] = cur[1][yy * (MC_W / 2) + xx]; cb->cr[j * cb->stride_c + i] = cur[2][yy * (MC_W / 2) + xx];
+                }
+                struct OVRCNCtx *r = &c->rcn_ctx;
+                memset(&r->progress_field, 0, sizeof(r->progress_field)); memset(&r->progress_field_c, 0, sizeof(r->progress_field_c));
+                init_ctu_bitfield(r, (c->ctb_x ? CTU_LFT_FLG : 0) | (c->ctb_y ? CTU_UP_FLG : 0), 7);
+                const int xu = x0 >> 2, yu = y0 >> 2, hu = h >> 2;
+                const int wu = (MC_W - ox) >> 2 < 32 ? (MC_W - ox) >> 2 : 32;          /* the CTU's columns inside the picture */
+                if (yu) { ctu_field_set_rect_bitfield(&r->progress_field, 0, 0, wu, yu); ctu_field_set_rect_bitfield(&r->progress_field_c, 0, 0, wu, yu); }
+                if (xu) {
+                    int nl = rnd_range(hu, 2 * hu);
+                    if (yu + nl > (MC_H >> 2)) nl = (MC_H >> 2) - yu;
+                    if (yu + nl > 32) nl = 32 - yu;
+                    ctu_field_set_rect_bitfield(&r->progress_field, 0, yu, xu, nl); ctu_field_set_rect_bitfield(&r->progress_field_c, 0, yu, xu, nl);
+                }
+            }
             int32_t cargs[2] = { 0, 0 };
 
             if (pass == 0) {
@@ -1033,6 +1070,7 @@ gen_gpm(const char *dir)
                     c->rcn_funcs.rcn_ciip_b(c, mv0, mv1, x0, y0, l2w, l2h, d.inter_dir, d.ref_idx0, d.ref_idx1);
             }
             if (g_shim) shim_case_end(c, &S, "gpm / ciip");
+            if (pass == 2) n_ciip2++;
             uint32_t eoff[3];
             eoff[0] = (uint32_t)b_exp.n; dump_rect(&b_exp, cb->y, cb->stride, x0, y0, w, h);
             eoff[1] = (uint32_t)b_exp.n; dump_rect(&b_exp, cb->cb, cb->stride_c, x0 >> 1, y0 >> 1, w >> 1, h >> 1);
@@ -1065,9 +1103,12 @@ gen_gpm(const char *dir)
     d2[1] = 3; gfile_array(&g, "exp_off", T_U32, b_eoff.data, 2, d2);
     d2[1] = 2; gfile_array(&g, "ciip_modes", T_I32, b_ciip.data, 2, d2);
     uint32_t one = n_gpm; gfile_array(&g, "n_gpm", T_U32, &one, 1, (uint32_t[]){ 1 });
+    one = n_ciip2; gfile_array(&g, "n_ciip_planar", T_U32, &one, 1, (uint32_t[]){ 1 });
+    di[0] = MC_H; di[1] = MC_W; gfile_array(&g, "cur_y", T_U16, cur[0], 2, di);
+    di[0] = MC_H / 2; di[1] = MC_W / 2; gfile_array(&g, "cur_cb", T_U16, cur[1], 2, di); gfile_array(&g, "cur_cr", T_U16, cur[2], 2, di);
     gfile_buf(&g, "exp", &b_exp);
     gfile_close(&g);
-    fprintf(stderr, "gpm.ovg: %u GPM + %u CIIP cases, %zu expected samples\n", n_gpm, n_cases - n_gpm, b_exp.n);
+    fprintf(stderr, "gpm.ovg: %u GPM + %u CIIP (planar stubbed) + %u CIIP cases, %zu expected samples\n", n_gpm, n_cases - n_gpm - n_ciip2, n_ciip2, b_exp.n);
 }
 
 /* ====================================================================================== DBF */
@@ -1723,6 +1764,187 @@ gen_intra(const char *dir)
     fprintf(stderr, "intra.ovg: %u cases, %zu expected samples\n", n_cases, b_exp.n);
 }
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * K12  whole intra CTUs through tmp.rcn_transform_tree (rcn_transform_tree.c:1454-1518 -> rcn_res_wrap -> rcn_intra_tu /
+ *      rcn_tu_st / rcn_tu_l / rcn_tu_c): a random partition of the CTU at (128, 128), CUs in decoding order, every CU intra
+ *      (regular / MRL / MIP / BDPCM luma, DC / planar / angular / DM / LM / MDLM chroma, with residuals: DCT-2, implicit MTS,
+ *      LFNST, transform skip) or left as it is ("decoded before", as an inter CU would be).  Single tree and dual tree.
+ *      Reference mode: intra_ctu.ovg = the start picture + the CTU each case ends with.
+ *      Shim mode: shim_intra_ctu.ovg = what the installed slots recorded for the same CTUs (commands, coefficients, ordered
+ *      tasks).  Executing the stream on the start picture must give the reference's CTU. */
+struct ictu_cu { int x, y, l2w, l2h; };
+static void
+ictu_part(struct ictu_cu *out, int *n, int x, int y, int l2w, int l2h)
+{
+    const int w = 1 << l2w, h = 1 << l2h;
+    int choice = 0;                                  /* 0 leaf, 1 quad, 2 vertical, 3 horizontal */
+    if (w > 64 || h > 64) choice = 1;
+    else {
+        const int r = rnd_range(0, 99);
+        const int p_leaf = w * h >= 2048 ? 25 : w * h >= 512 ? 45 : w * h >= 128 ? 60 : 85;
+        if (r >= p_leaf) {
+            int opts[3], no = 0;
+            if (l2w == l2h && l2w >= 4) opts[no++] = 1;
+            if (l2w >= 4) opts[no++] = 2;
+            if (l2h >= 3) opts[no++] = 3;
+            if (no) choice = opts[rnd_range(0, no - 1)];
+        }
+    }
+    if (choice == 0) { out[*n] = (struct ictu_cu){ x, y, l2w, l2h }; ++*n; return; }
+    if (choice == 1) {
+        ictu_part(out, n, x, y, l2w - 1, l2h - 1); ictu_part(out, n, x + w / 2, y, l2w - 1, l2h - 1);
+        ictu_part(out, n, x, y + h / 2, l2w - 1, l2h - 1); ictu_part(out, n, x + w / 2, y + h / 2, l2w - 1, l2h - 1);
+    } else if (choice == 2) { ictu_part(out, n, x, y, l2w - 1, l2h); ictu_part(out, n, x + w / 2, y, l2w - 1, l2h); }
+    else { ictu_part(out, n, x, y, l2w, l2h - 1); ictu_part(out, n, x, y + h / 2, l2w, l2h - 1); }
+}
+
+static void
+gen_intra_ctu(const char *dir)
+{
+    extern int transform_unit_st(OVCTUDec *const, unsigned int, unsigned int, unsigned int, unsigned int, uint8_t, CUFlags, uint8_t, struct TUInfo *const);
+    extern int transform_unit_l(OVCTUDec *const, unsigned int, unsigned int, unsigned int, unsigned int, uint8_t, CUFlags, uint8_t, struct TUInfo *const);
+    extern int transform_unit_c(OVCTUDec *const, unsigned int, unsigned int, unsigned int, unsigned int, uint8_t, CUFlags, uint8_t, struct TUInfo *const);
+    gbuf b_exp = { .type = T_U16 }, b_info = { .type = T_I32 };
+    uint32_t n_cases = 0;
+    g_seed = 0x266 + 777;
+    OVCTUDec *c = ref_new_ctudec(0, 0);
+    c->rcn_funcs.rcn_attach_ctu_buff(&c->rcn_ctx, 7, 1);
+    const struct OVBuffInfo *cb = &c->rcn_ctx.ctu_buff;
+    struct OVRCNCtx *r = &c->rcn_ctx;
+    static uint16_t py[IN_W * IN_H], pcb[(IN_W / 2) * (IN_H / 2)], pcr[(IN_W / 2) * (IN_H / 2)];
+    fill_plane(py, IN_W, IN_H, IN_W); fill_plane(pcb, IN_W / 2, IN_H / 2, IN_W / 2); fill_plane(pcr, IN_W / 2, IN_H / 2, IN_W / 2);
+    struct shim_stream S;
+    shim_stream_init(&S);
+    c->ctb_x = IN_OX >> 7; c->ctb_y = IN_OY >> 7;
+    if (g_shim) shim_bind(c, IN_W, IN_H, 0, 0);
+
+    for (int ci = 0; ci < 36; ++ci) {
+        const int dual = ci % 3 == 2;
+        struct ictu_cu cus[1024]; int n_cu = 0;
+        ictu_part(cus, &n_cu, 0, 0, 7, 7);
+        const int ict_type = rnd_range(0, 3);
+        rcn_init_ict_functions_10(&c->rcn_funcs, ict_type, 10);
+        if (g_shim) rcn_init_functions_hip(&c->rcn_funcs, ict_type, 1, 0, 0, 10);
+        c->dequant_luma.qp = rnd_range(18, 50); c->dequant_cb.qp = rnd_range(18, 50); c->dequant_cr.qp = rnd_range(18, 50);
+        c->dequant_joint_cb_cr.qp = rnd_range(18, 50);
+        c->dequant_luma_skip.qp = c->dequant_luma.qp; c->dequant_cb_skip.qp = c->dequant_cb.qp; c->dequant_cr_skip.qp = c->dequant_cr.qp;
+        c->dequant_jcbcr_skip.qp = c->dequant_joint_cb_cr.qp;
+        c->residual_coding_l = rnd_range(0, 1) ? &residual_coding_dpq : NULL;
+        c->mts_implicit = rnd_range(0, 1); c->sh_ts_disabled = 0; c->tmp_ciip = 0;
+        c->lmcs_info.scale_c_flag = rnd_range(0, 1); c->lmcs_info.lmcs_chroma_scale = (uint16_t)rnd_range(1200, 3400);
+        memset(&c->dbf_info, 0, sizeof(c->dbf_info));
+        /* the CTU scratch holds the picture around the CTU; the neighbours that exist: left and above CTUs, and the part of the
+         * above-right one inside the picture */
+        for (int j = -1; j < 132; ++j) for (int i = -128; i < 196; ++i) cb->y[j * cb->stride + i] = py[(IN_OY + j) * IN_W + IN_OX + i];
+        for (int j = -1; j < 66; ++j) for (int i = -64; i < 98; ++i) {
+            cb->cb[j * cb->stride_c + i] = pcb[(IN_OY / 2 + j) * (IN_W / 2) + IN_OX / 2 + i];
+            cb->cr[j * cb->stride_c + i] = pcr[(IN_OY / 2 + j) * (IN_W / 2) + IN_OX / 2 + i];
+        }
+        /* the decoder's own CTU start (decode_ctu, slicedec.c:731-737): left, above and above-right CTUs exist, the last one
+         * only as far as the picture goes */
+        memset(&r->progress_field, 0, sizeof(r->progress_field)); memset(&r->progress_field_c, 0, sizeof(r->progress_field_c));
+        init_ctu_bitfield(r, CTU_LFT_FLG | CTU_UP_FLG | CTU_UPRGT_FLG, 7);
+        {
+            const uint64_t mask = ((uint64_t)1 << ((((IN_W - IN_OX - 128) + 128) >> 2) + 1)) - 1;
+            r->progress_field_c.hfield[0] &= mask; r->progress_field.hfield[0] &= mask;
+        }
+        int n_intra = 0;
+        uint8_t luma_mode_of[1024];
+        for (int pass = 0; pass < (dual ? 2 : 1); ++pass) {
+            c->transform_unit = dual ? (pass ? (void *)&transform_unit_c : (void *)&transform_unit_l) : (void *)&transform_unit_st;
+            for (int k = 0; k < n_cu; ++k) {
+                const int x0 = cus[k].x, y0 = cus[k].y, l2w = cus[k].l2w, l2h = cus[k].l2h, w = 1 << l2w, h = 1 << l2h;
+                struct TUInfo tu;
+                memset(&tu, 0, sizeof(tu));
+                /* "decoded before": the same CUs in both passes of a dual tree */
+
+                const int skip = ((cus[k].x * 31 + cus[k].y * 17 + ci * 7) % 100) < 22;
+                if (skip) {
+                    struct CTUBitField *pf = (dual && pass) ? &r->progress_field_c : &r->progress_field;
+                    ctu_field_set_rect_bitfield(pf, x0 >> 2, y0 >> 2, w >> 2, h >> 2);
+                    if (!dual) ctu_field_set_rect_bitfield(&r->progress_field_c, x0 >> 2, y0 >> 2, w >> 2, h >> 2);
+                    continue;
+                }
+                CUFlags fl = flg_pred_mode_flag;
+                int kind = rnd_range(0, 99);                      /* luma: regular / MRL / MIP / BDPCM */
+                kind = kind < 50 ? 0 : kind < 65 ? 1 : kind < 82 ? 2 : 3;
+                if (kind == 1 && y0 == 0) kind = 0;               /* MRL is not signalled on the first line of a CTU */
+                if (kind == 3 && (l2w > 5 || l2h > 5)) kind = 0;
+                int mode = rnd_range(0, 66), mode_c;
+                int bdpcm_c = 0;
+                if (!(dual && pass)) {
+                    c->cu_opaque = 0;
+                    if (kind == 1) { fl |= flg_mrl_flag; c->cu_opaque = (uint8_t)rnd_range(1, 2); }
+                    if (kind == 2) {
+                        const int n_mip = (l2w == 2 && l2h == 2) ? 16 : (l2h == 2 || l2w == 2 || (l2h <= 3 && l2w <= 3)) ? 8 : 6;
+                        fl |= flg_mip_flag; c->cu_opaque = (uint8_t)(rnd_range(0, n_mip - 1) | (rnd_range(0, 1) << 7));
+                        mode = 0;
+                    }
+                    if (kind == 3) { fl |= flg_intra_bdpcm_luma_flag | (rnd_range(0, 1) ? flg_intra_bdpcm_luma_dir : 0); mode = (fl & flg_intra_bdpcm_luma_dir) ? 50 : 18; }
+                    luma_mode_of[k] = (uint8_t)mode;
+                } else {
+                    mode = luma_mode_of[k];
+                }
+                c->intra_mode = (uint8_t)mode;
+                {
+                    static const uint8_t cm[8] = { 0, 1, 18, 50, 255, 67, 68, 69 };
+                    mode_c = cm[rnd_range(0, 7)];
+                    if (mode_c == 255) mode_c = mode;             /* DM */
+                    if (kind == 3 && l2w <= 5 && l2h <= 5 && rnd_range(0, 1)) { bdpcm_c = 1; fl |= flg_intra_bdpcm_chroma_flag | (rnd_range(0, 1) ? flg_intra_bdpcm_chroma_dir : 0); }
+                }
+                c->intra_mode_c = (uint8_t)mode_c;
+                /* residual */
+                const int has_l = !(dual && pass) && rnd_range(0, 99) < 70;
+                static const uint8_t cbf_c[7] = { 0, 0x2, 0x1, 0x3, 0xb, 0xa, 0x9 };
+                int cbfc = (dual && !pass) ? 0 : cbf_c[rnd_range(0, 6)];
+                if (bdpcm_c) cbfc &= 0x3;
+                tu.cbf_mask = (uint8_t)((has_l ? 0x10 : 0) | cbfc);
+                int lfnst = !(fl & (flg_intra_bdpcm_luma_flag)) && has_l && rnd_range(0, 3) == 0;
+                if (lfnst) { tu.lfnst_flag = 1; tu.lfnst_idx = (uint8_t)rnd_range(0, 1); }
+                if (fl & flg_intra_bdpcm_luma_flag) tu.tr_skip_mask |= 0x10;
+                if (bdpcm_c) tu.tr_skip_mask |= 0x3;
+                int16_t *res[3] = { c->residual_cb, c->residual_cr, c->residual_y };
+                const int cl2w = (dual && pass) ? l2w - 1 : l2w - 1, cl2h = l2h - 1;
+                for (int comp = 0; comp < 3; ++comp) {
+                    const int is_l = comp == 2;
+                    const int used = is_l ? has_l : ((cbfc & 0x8) ? comp == 0 : !!(cbfc & (comp ? 0x1 : 0x2)));
+                    if (!used) continue;
+                    const int tl2w = is_l ? l2w : cl2w, tl2h = is_l ? l2h : cl2h;
+                    const int ts = is_l ? !!(tu.tr_skip_mask & 0x10) : (cbfc & 0x8) ? !!(tu.tr_skip_mask & 0x1) : !!(tu.tr_skip_mask & (comp ? 0x1 : 0x2));
+                    const int raster = ts || tl2w < 2 || tl2h < 2;
+                    uint64_t map; uint16_t lp;
+                    make_coefs(res[comp], tl2w, tl2h, (is_l && lfnst) ? 1 : rnd_range(0, 2), raster, &map, &lp);
+                    if (is_l && lfnst) {
+                        map = 1; lp = 0x0101;
+                        if (!raster) { int cw = (1 << tl2w) > 32 ? 32 : (1 << tl2w), ch = (1 << tl2h) > 32 ? 32 : (1 << tl2h); memset(res[comp] + 16, 0, (cw * ch - 16) * 2); }
+                    }
+                    tu.tb_info[comp].sig_sb_map = map; tu.tb_info[comp].last_pos = lp;
+                }
+                if (dual && pass) c->rcn_funcs.tmp.rcn_transform_tree(c, x0 >> 1, y0 >> 1, l2w - 1, l2h - 1, 5, 0, fl, &tu);
+                else c->rcn_funcs.tmp.rcn_transform_tree(c, x0, y0, l2w, l2h, 6, 0, fl, &tu);
+                ++n_intra;
+            }
+        }
+        if (g_shim) shim_case_end(c, &S, "intra ctu");
+        int32_t info[4] = { dual, n_cu, n_intra, (int32_t)b_exp.n };
+        gbuf_push(&b_info, info, 4);
+        dump_rect(&b_exp, cb->y, cb->stride, 0, 0, 128, 128);
+        dump_rect(&b_exp, cb->cb, cb->stride_c, 0, 0, 64, 64);
+        dump_rect(&b_exp, cb->cr, cb->stride_c, 0, 0, 64, 64);
+        n_cases++;
+    }
+    if (g_shim) { shim_stream_write(dir, "shim_intra_ctu.ovg", &S, c, NULL, 0); return; }
+    gfile g = gfile_open(dir, "intra_ctu.ovg");
+    uint32_t d2[2] = { IN_H, IN_W };
+    gfile_array(&g, "pic_y", T_U16, py, 2, d2);
+    d2[0] = IN_H / 2; d2[1] = IN_W / 2;
+    gfile_array(&g, "pic_cb", T_U16, pcb, 2, d2); gfile_array(&g, "pic_cr", T_U16, pcr, 2, d2);
+    d2[0] = n_cases; d2[1] = 4; gfile_array(&g, "info", T_I32, b_info.data, 2, d2);
+    gfile_buf(&g, "exp", &b_exp);
+    gfile_close(&g);
+    fprintf(stderr, "intra_ctu.ovg: %u CTUs, %zu expected samples\n", n_cases, b_exp.n);
+}
+
 int
 main(int argc, char **argv)
 {
@@ -1739,5 +1961,6 @@ main(int argc, char **argv)
     if (!only || !strcmp(only, "sao")) gen_sao(dir);
     if (!only || !strcmp(only, "alf")) gen_alf(dir);
     if ((!only || !strcmp(only, "intra")) && !g_shim) gen_intra(dir);
+    if (!only || !strcmp(only, "intra_ctu")) gen_intra_ctu(dir);
     return 0;
 }

@@ -13,13 +13,13 @@
 
 static int g_shim;
 
-#define SHIM_NARR 10            /* OVHIP_REC_TB .. OVHIP_REC_EDGE_H */
+#define SHIM_NARR 11            /* OVHIP_REC_TB .. OVHIP_REC_ITASK */
 struct shim_stream { gbuf arr[SHIM_NARR]; gbuf off; uint32_t n_cases; gbuf mv_chk; };
 
 static void
 shim_stream_init(struct shim_stream *s)
 {
-    static const int t[SHIM_NARR] = { T_U8, T_I16, T_U8, T_U8, T_U8, T_I32, T_U8, T_U8, T_U8, T_U8 };
+    static const int t[SHIM_NARR] = { T_U8, T_I16, T_U8, T_U8, T_U8, T_I32, T_U8, T_U8, T_U8, T_U8, T_U8 };
     memset(s, 0, sizeof(*s));
     for (int i = 0; i < SHIM_NARR; ++i) s->arr[i].type = t[i];
     s->off.type = T_U32; s->mv_chk.type = T_I32;
@@ -37,7 +37,7 @@ static size_t
 shim_elem(int which)
 {
     static const size_t e[SHIM_NARR] = { sizeof(ovhip_tb_cmd), 2, sizeof(ovhip_mc_unit), sizeof(ovhip_mc_unit), sizeof(ovhip_aff_unit), 4,
-                                         sizeof(ovhip_lmcs_region), sizeof(ovhip_ciip_unit), sizeof(ovhip_dbf_edge), sizeof(ovhip_dbf_edge) };
+                                         sizeof(ovhip_lmcs_region), sizeof(ovhip_ciip_unit), sizeof(ovhip_dbf_edge), sizeof(ovhip_dbf_edge), sizeof(ovhip_itask) };
     return e[which];
 }
 
@@ -60,6 +60,7 @@ shim_case_end(OVCTUDec *c, struct shim_stream *s, const char *what)
     p[OVHIP_REC_CIIP] = ovhip_rec_ciip_units(r, &n[OVHIP_REC_CIIP]);
     p[OVHIP_REC_EDGE_V] = ovhip_rec_dbf_edges(r, 0, &n[OVHIP_REC_EDGE_V], NULL);
     p[OVHIP_REC_EDGE_H] = ovhip_rec_dbf_edges(r, 1, &n[OVHIP_REC_EDGE_H], NULL);
+    p[OVHIP_REC_ITASK] = ovhip_rec_itasks(r, &n[OVHIP_REC_ITASK]);
     for (int i = 0; i < SHIM_NARR; ++i) {
         const size_t es = shim_elem(i) / g_tsize[s->arr[i].type];
         start[i] = (uint32_t)(s->arr[i].n / es);
@@ -74,7 +75,7 @@ shim_case_end(OVCTUDec *c, struct shim_stream *s, const char *what)
 static void
 shim_stream_write(const char *dir, const char *name, struct shim_stream *s, OVCTUDec *c, OVPicture **refs, int n_refs)
 {
-    static const char *nm[SHIM_NARR] = { "tb", "coef", "mc", "mcx", "aff", "side", "region", "ciip", "edge_v", "edge_h" };
+    static const char *nm[SHIM_NARR] = { "tb", "coef", "mc", "mcx", "aff", "side", "region", "ciip", "edge_v", "edge_h", "itask" };
     gfile g = gfile_open(dir, name);
     uint32_t end[SHIM_NARR];
     for (int i = 0; i < SHIM_NARR; ++i) {

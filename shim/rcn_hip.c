@@ -105,6 +105,9 @@ struct hip_entry {
     /* the luma of an affine CU has been recorded (with its chroma): the rcn_mcp_b_c(3,3) calls of the SAME CU that follow
      * carry nothing new.  Rectangle in CTU-local luma samples; any other slot call ends it. */
     int aff_c_live, aff_c_x0, aff_c_y0, aff_c_x1, aff_c_y1;
+    /* a CIIP CU whose planar tasks wait for the CU's transform unit (which carries their residual); closed without one by
+     * the next slot call that is not that transform unit */
+    struct { int live, x0, y0, log2_w, log2_h, has_c; ovhip_itask tl, tc; } ciip;
 };
 
 static struct hip_entry *g_entries[256];
@@ -171,12 +174,14 @@ fill_pu(struct hip_entry *e, const OVCTUDec *c, ovhip_pu_desc *d, int x0, int y0
 }
 
 static void pend_close(struct hip_entry *e, OVCTUDec *c);
+static void ciip_close(struct hip_entry *e, OVCTUDec *c);
 
 /* every hook that is not part of the CU being collected closes it first */
 #define ENTER(c)                                               \
     struct hip_entry *e = entry_of((c), 0);                    \
     if (!e || !e->rec) return;                                 \
     e->aff_c_live = 0;                                         \
+    if (e->ciip.live) ciip_close(e, (OVCTUDec *)(c));          \
     if (e->pend.kind) pend_close(e, (OVCTUDec *)(c))
 
 /* ------------------------------------------------------------------------------------ transform units */
@@ -217,9 +222,76 @@ lfnst_mode_c(const OVCTUDec *c, int log2_w, int log2_h, int x0, int y0)
     return (int8_t)(m < 0 ? m + 14 + 67 : m >= 67 ? m + 14 : m);
 }
 
+
+/* ------------------------------------------------------------------------------------ ordered (intra) tasks */
+/* Availability of the two reference arms as the reference's fill_ref_* read it out of the progress bit-fields
+ * (rcn_fill_ref.h:41-64; rcn_fill_ref.c:71-100, :166-190, :228-260): bit 0 of the shifted map = the corner unit, the
+ * highest set bit = how far the arm is read. */
+static inline int top_bit(uint64_t m) { return m ? 64 - __builtin_clzll(m) : 0; }
+
+static void
+task_avl(const struct CTUBitField *pf, int x0, int y0, int log2_w, int log2_h, int log2_unit, ovhip_itask *t)
+{
+    const int nb_a = ((1 << (log2_w + 1)) >> log2_unit) + 1, nb_l = ((1 << (log2_h + 1)) >> log2_unit) + 1;
+    const uint64_t ma = (pf->hfield[y0 >> log2_unit] >> (x0 >> log2_unit)) & ((1llu << (nb_a + 1)) - 1);
+    const uint64_t ml = (pf->vfield[x0 >> log2_unit] >> (y0 >> log2_unit)) & ((1llu << (nb_l + 1)) - 1);
+    t->avl_abv = (uint8_t)top_bit(ma >> 1); t->avl_lft = (uint8_t)top_bit(ml >> 1);
+    if ((ma | ml) & 1) t->flags |= OVHIP_IF_CORNER;
+}
+
+static void
+luma_task(const OVCTUDec *c, int x0, int y0, int log2_w, int log2_h, CUFlags cu_flags, int mode, int ciip_wt, ovhip_itask *t)
+{
+    const int l2 = c->part_ctx->log2_ctu_s;
+    memset(t, 0, sizeof(*t));
+    t->kind = OVHIP_IT_LUMA;
+    t->x = (uint16_t)((c->ctb_x << l2) + x0); t->y = (uint16_t)((c->ctb_y << l2) + y0);
+    t->log2_w = (uint8_t)log2_w; t->log2_h = (uint8_t)log2_h;
+    t->mode = (uint8_t)mode; t->ciip_wt = (uint8_t)ciip_wt;
+    if (cu_flags & flg_mip_flag) {                                   /* rcn_intra_mip.c:388-402 */
+        t->flags |= OVHIP_IF_MIP | ((c->cu_opaque >> 7) & 1 ? OVHIP_IF_MIP_TR : 0);
+        t->mode = c->cu_opaque & 0x3f;
+    } else if (cu_flags & flg_intra_bdpcm_luma_flag) {
+        t->flags |= OVHIP_IF_BDPCM | ((cu_flags & flg_intra_bdpcm_luma_dir) ? OVHIP_IF_BDPCM_VER : 0);
+        t->mode = 0;
+    } else if (cu_flags & flg_mrl_flag) {
+        t->mrl_idx = c->cu_opaque;
+    }
+    task_avl(&c->rcn_ctx.progress_field, x0, y0, log2_w, log2_h, 2, t);
+}
+
+/* x0, y0, size in CHROMA samples */
+static void
+chroma_task(const OVCTUDec *c, int x0, int y0, int log2_w, int log2_h, CUFlags cu_flags, int mode, int ciip_wt, ovhip_itask *t)
+{
+    const int l2 = c->part_ctx->log2_ctu_s - 1;
+    const struct CTUBitField *pf = &c->rcn_ctx.progress_field_c;
+    memset(t, 0, sizeof(*t));
+    t->kind = OVHIP_IT_CHROMA;
+    t->x = (uint16_t)((c->ctb_x << l2) + x0); t->y = (uint16_t)((c->ctb_y << l2) + y0);
+    t->log2_w = (uint8_t)log2_w; t->log2_h = (uint8_t)log2_h;
+    t->mode = (uint8_t)mode; t->ciip_wt = (uint8_t)ciip_wt;
+    if (cu_flags & flg_intra_bdpcm_chroma_flag) {
+        t->flags |= OVHIP_IF_BDPCM | ((cu_flags & flg_intra_bdpcm_chroma_dir) ? OVHIP_IF_BDPCM_VER : 0);
+        t->mode = 0;
+    }
+    if (!(t->flags & OVHIP_IF_BDPCM) && mode >= OVINTRA_LM_CHROMA && mode <= OVINTRA_MDLM_TOP) {
+        /* the linear-model modes read their own availability (rcn_intra_cclm.c:56-68, :770-776, :843-849) */
+        const int w = 1 << log2_w, h = 1 << log2_h, ext = w < h ? w : h;
+        const uint64_t abv = pf->hfield[y0 >> 1] >> ((x0 >> 1) + 1), lft = pf->vfield[x0 >> 1] >> ((y0 >> 1) + 1);
+        const int any_abv = !!(abv & ((1llu << (w >> 1)) - 1)), any_lft = !!(lft & ((1llu << (h >> 1)) - 1));
+        t->mode = (uint8_t)(67 + (mode - OVINTRA_LM_CHROMA));
+        t->avl_abv = (uint8_t)any_abv; t->avl_lft = (uint8_t)any_lft;
+        if (mode == OVINTRA_MDLM_TOP && any_abv) t->avl_abv = (uint8_t)__builtin_ctzll(~(abv & ((1llu << ((w + ext) >> 1)) - 1)));
+        if (mode == OVINTRA_MDLM_LEFT && any_lft) t->avl_lft = (uint8_t)__builtin_ctzll(~(lft & ((1llu << ((h + ext) >> 1)) - 1)));
+        return;
+    }
+    task_avl(pf, x0, y0, log2_w, log2_h, 1, t);
+}
+
 static void
 record_tu(struct hip_entry *e, OVCTUDec *c, int tree, int x0, int y0, int log2_w, int log2_h, CUFlags cu_flags, uint8_t cbf_mask,
-          const struct TUInfo *tu)
+          const struct TUInfo *tu, const ovhip_itask *task_l, const ovhip_itask *task_c)
 {
     const int l2 = c->part_ctx->log2_ctu_s;
     ovhip_tu_state st;
@@ -235,19 +307,30 @@ record_tu(struct hip_entry *e, OVCTUDec *c, int tree, int x0, int y0, int log2_w
     for (int k = 0; k < 3; ++k) { d.last_pos[k] = tu->tb_info[k].last_pos; d.sig_sb_map[k] = tu->tb_info[k].sig_sb_map; }
     d.coef[0] = c->residual_cb + tu->pos_offset; d.coef[1] = c->residual_cr + tu->pos_offset; d.coef[2] = c->residual_y + tu->pos_offset;
     if (tree == 2 && tu->lfnst_flag) st.lfnst_mode_c = lfnst_mode_c(c, log2_w, log2_h, x0, y0);
-    latch(e, ovhip_rec_tu(e->rec, &st, &d), "ovhip_rec_tu");
+    latch(e, ovhip_rec_tu_intra(e->rec, &st, &d, task_l, task_c), "ovhip_rec_tu_intra");
 }
 
-/* tmp.rcn_tu_st (rcn_structures.h:481-486; rcn_transform_tree.c:1228-1301) */
+/* rcn_tu_st (rcn_transform_tree.c:1228-1301) with the luma task rcn_intra_tu made before it (or a CIIP CU's two tasks) */
 static void
-hip_rcn_tu_st(OVCTUDec *const c, uint8_t x0, uint8_t y0, uint8_t log2_tb_w, uint8_t log2_tb_h, CUFlags cu_flags, uint8_t cbf_mask,
-              const struct TUInfo *const tu)
+tu_st_common(struct hip_entry *e, OVCTUDec *c, int x0, int y0, int log2_tb_w, int log2_tb_h, CUFlags cu_flags, uint8_t cbf_mask,
+             const struct TUInfo *const tu, const ovhip_itask *task_l, const ovhip_itask *task_c)
 {
-    ENTER(c);
-    record_tu(e, c, 0, x0, y0, log2_tb_w, log2_tb_h, cu_flags, cbf_mask, tu);
+    ovhip_itask tc;
+    if (cu_flags & flg_pred_mode_flag) {
+        /* :1270-1287: the chroma prediction of an intra CU sits between the TU's luma and chroma residuals */
+        ctu_field_set_rect_bitfield(&c->rcn_ctx.progress_field_c, x0 >> LOG2_MIN_CU_S, y0 >> LOG2_MIN_CU_S,
+                                    (1 << log2_tb_w) >> LOG2_MIN_CU_S, (1 << log2_tb_h) >> LOG2_MIN_CU_S);
+        if (!(cu_flags & flg_intra_bdpcm_chroma_flag)) fill_bs_map(&c->dbf_info.bs2_map_c, x0, y0, log2_tb_w, log2_tb_h);
+        chroma_task(c, x0 >> 1, y0 >> 1, log2_tb_w - 1, log2_tb_h - 1, cu_flags, c->intra_mode_c, 0, &tc);
+        task_c = &tc;
+    }
+    record_tu(e, c, 0, x0, y0, log2_tb_w, log2_tb_h, cu_flags, cbf_mask, tu, task_l, task_c);
     /* what the scalar orchestrator leaves behind for deblocking (:1262-1267, :1299-1300; rcn_res_c / rcn_jcbcr
      * :757-759, :793-795, :860-866) */
-    if (cbf_mask & 0x10) fill_bs_map(&c->dbf_info.bs1_map, x0, y0, log2_tb_w, log2_tb_h);
+    if (cbf_mask & 0x10) {
+        fill_bs_map(&c->dbf_info.bs1_map, x0, y0, log2_tb_w, log2_tb_h);
+        if ((cu_flags & flg_pred_mode_flag) && !(cu_flags & flg_intra_bdpcm_luma_flag)) fill_bs_map(&c->dbf_info.bs2_map, x0, y0, log2_tb_w, log2_tb_h);
+    }
     if (!(cu_flags & flg_intra_bdpcm_chroma_flag)) {
         if (cbf_mask & 0x8) {
             fill_bs_map(&c->dbf_info.bs1_map_cb, x0, y0, log2_tb_w, log2_tb_h);
@@ -261,17 +344,29 @@ hip_rcn_tu_st(OVCTUDec *const c, uint8_t x0, uint8_t y0, uint8_t log2_tb_w, uint
     fill_ctb_bound_c(&c->dbf_info, x0, y0, log2_tb_w, log2_tb_h);
 }
 
-/* tmp.rcn_tu_c (rcn_structures.h:475-479; rcn_transform_tree.c:1349-1382): dual-tree chroma, always intra */
+/* tmp.rcn_tu_st (rcn_structures.h:481-486): called through the table by the SBT paths (vcl_transform_unit.c:1113-1299) */
+static void
+hip_rcn_tu_st(OVCTUDec *const c, uint8_t x0, uint8_t y0, uint8_t log2_tb_w, uint8_t log2_tb_h, CUFlags cu_flags, uint8_t cbf_mask,
+              const struct TUInfo *const tu)
+{
+    ENTER(c);
+    tu_st_common(e, c, x0, y0, log2_tb_w, log2_tb_h, cu_flags, cbf_mask, tu, NULL, NULL);
+}
+
+/* tmp.rcn_tu_c (rcn_structures.h:475-479; rcn_transform_tree.c:1349-1382): dual-tree chroma and the chroma of an ISP CU,
+ * always intra (x0, y0, size in chroma samples) */
 static void
 hip_rcn_tu_c(OVCTUDec *const c, uint8_t x0, uint8_t y0, uint8_t log2_tb_w, uint8_t log2_tb_h, CUFlags cu_flags, uint8_t cbf_mask,
              const struct TUInfo *const tu)
 {
     ENTER(c);
+    ovhip_itask tc;
     ctu_field_set_rect_bitfield(&c->rcn_ctx.progress_field_c, (x0 << 1) >> LOG2_MIN_CU_S, (y0 << 1) >> LOG2_MIN_CU_S,
                                 (2 << log2_tb_w) >> LOG2_MIN_CU_S, (2 << log2_tb_h) >> LOG2_MIN_CU_S);
+    chroma_task(c, x0, y0, log2_tb_w, log2_tb_h, cu_flags, c->intra_mode_c, 0, &tc);
     fill_ctb_bound_c(&c->dbf_info, x0 << 1, y0 << 1, log2_tb_w + 1, log2_tb_h + 1);
     if (!(cu_flags & flg_intra_bdpcm_chroma_flag)) fill_bs_map(&c->dbf_info.bs2_map_c, x0 << 1, y0 << 1, log2_tb_w + 1, log2_tb_h + 1);
-    record_tu(e, c, 2, x0, y0, log2_tb_w, log2_tb_h, cu_flags, cbf_mask, tu);
+    record_tu(e, c, 2, x0, y0, log2_tb_w, log2_tb_h, cu_flags, cbf_mask, tu, NULL, &tc);
     if (!(cu_flags & flg_intra_bdpcm_chroma_flag)) {
         if (cbf_mask & 0x8) {
             fill_bs_map(&c->dbf_info.bs1_map_cb, x0 << 1, y0 << 1, log2_tb_w + 1, log2_tb_h + 1);
@@ -284,7 +379,7 @@ hip_rcn_tu_c(OVCTUDec *const c, uint8_t x0, uint8_t y0, uint8_t log2_tb_w, uint8
 }
 
 /* tmp.rcn_transform_tree (rcn_structures.h:464-468; rcn_transform_tree.c:1454-1518): the walker calls its leaves
- * directly, not through the table, so the whole walk is restated here around the two leaf hooks. */
+ * directly, not through the table, so the whole walk is restated here around the leaf hooks. */
 static void
 hip_rcn_transform_tree(OVCTUDec *const c, uint8_t x0, uint8_t y0, uint8_t log2_tb_w, uint8_t log2_tb_h, uint8_t log2_max_tb_s,
                        uint8_t tr_depth, CUFlags cu_flags, const struct TUInfo *const tu)
@@ -315,16 +410,35 @@ hip_rcn_transform_tree(OVCTUDec *const c, uint8_t x0, uint8_t y0, uint8_t log2_t
         hip_rcn_tu_c(c, x0, y0, log2_tb_w, log2_tb_h, cu_flags, tu->cbf_mask, tu);
     } else {
         struct hip_entry *e = entry_of(c, 0);
-        if (e && (cu_flags & flg_pred_mode_flag)) latch(e, OVHIP_EUNSUP, "intra coding unit (device intra path not bound)");
-        if (c->transform_unit == (void *)&transform_unit_st) {
-            hip_rcn_tu_st(c, x0, y0, log2_tb_w, log2_tb_h, cu_flags, tu->cbf_mask, tu);
-        } else {
-            /* dual-tree luma: rcn_tu_l (:1305-1346) = the luma half of rcn_tu_st */
-            if (e && e->rec) {
-                if (e->pend.kind) pend_close(e, c);
+        if (e && e->rec) {
+            ovhip_itask tl;
+            const ovhip_itask *task_l = NULL, *task_c = NULL;
+            e->aff_c_live = 0;
+            if (e->pend.kind) pend_close(e, c);
+            if (e->ciip.live) {
+                /* the transform unit of the CIIP CU recorded last carries the residual of its two planar tasks */
+                if (c->tmp_ciip && e->ciip.x0 == x0 && e->ciip.y0 == y0 && e->ciip.log2_w == log2_tb_w && e->ciip.log2_h == log2_tb_h) {
+                    task_l = &e->ciip.tl; task_c = e->ciip.has_c ? &e->ciip.tc : NULL;
+                    e->ciip.live = 0;
+                } else {
+                    ciip_close(e, c);
+                }
+            }
+            if (cu_flags & flg_pred_mode_flag) {
+                /* rcn_intra_tu (:1384-1430): the prediction reads the progress field, then extends it */
+                if (!(cu_flags & flg_isp_flag)) { luma_task(c, x0, y0, log2_tb_w, log2_tb_h, cu_flags, c->intra_mode, 0, &tl); task_l = &tl; }
+                if (!(cu_flags & flg_intra_bdpcm_luma_flag)) fill_bs_map(&c->dbf_info.bs2_map, x0, y0, log2_tb_w, log2_tb_h);
+                ctu_field_set_rect_bitfield(&c->rcn_ctx.progress_field, x0 >> LOG2_MIN_CU_S, y0 >> LOG2_MIN_CU_S,
+                                            (1 << log2_tb_w) >> LOG2_MIN_CU_S, (1 << log2_tb_h) >> LOG2_MIN_CU_S);
+            }
+            if (c->transform_unit == (void *)&transform_unit_st) {
+                tu_st_common(e, c, x0, y0, log2_tb_w, log2_tb_h, cu_flags, tu->cbf_mask, tu, task_l, task_c);
+            } else {
+                /* dual-tree luma: rcn_tu_l (:1305-1346) = the luma half of rcn_tu_st */
+                if (tu->cbf_mask || task_l) record_tu(e, c, 1, x0, y0, log2_tb_w, log2_tb_h, cu_flags, tu->cbf_mask ? 0x10 : 0, tu, task_l, NULL);
                 if (tu->cbf_mask) {
-                    record_tu(e, c, 1, x0, y0, log2_tb_w, log2_tb_h, cu_flags, 0x10, tu);
                     fill_bs_map(&c->dbf_info.bs1_map, x0, y0, log2_tb_w, log2_tb_h);
+                    if ((cu_flags & flg_pred_mode_flag) && !(cu_flags & flg_intra_bdpcm_luma_flag)) fill_bs_map(&c->dbf_info.bs2_map, x0, y0, log2_tb_w, log2_tb_h);
                 }
                 fill_ctb_bound(&c->dbf_info, x0, y0, log2_tb_w, log2_tb_h);
             }
@@ -334,6 +448,19 @@ hip_rcn_transform_tree(OVCTUDec *const c, uint8_t x0, uint8_t y0, uint8_t log2_t
         fill_bs_map(&c->dbf_info.bs2_map, x0, y0, log2_tb_w, log2_tb_h);
         fill_bs_map(&c->dbf_info.bs2_map_c, x0, y0, log2_tb_w, log2_tb_h);
     }
+}
+
+/* a CIIP CU without residual (no transform unit followed): its planar tasks alone */
+static void
+ciip_close(struct hip_entry *e, OVCTUDec *c)
+{
+    ovhip_tu_state st;
+    ovhip_tu_desc d;
+    e->ciip.live = 0;
+    fill_tu_state(e, c, &st);
+    memset(&d, 0, sizeof(d));
+    d.x0 = e->ciip.tl.x; d.y0 = e->ciip.tl.y; d.log2_tb_w = (uint8_t)e->ciip.log2_w; d.log2_tb_h = (uint8_t)e->ciip.log2_h;
+    latch(e, ovhip_rec_tu_intra(e->rec, &st, &d, &e->ciip.tl, e->ciip.has_c ? &e->ciip.tc : NULL), "ovhip_rec_tu_intra(ciip)");
 }
 
 /* ------------------------------------------------------------------------------------ prediction units */
@@ -652,10 +779,15 @@ ciip_common(struct hip_entry *e, OVCTUDec *c, ovhip_pu_desc *d, int x0, int y0, 
     const int l2 = c->part_ctx->log2_min_cb_s;
     const int mode_abv = c->part_map.cu_mode_x[(x0 + (1 << log2_pb_w) - 1) >> l2];
     const int mode_lft = c->part_map.cu_mode_y[(y0 + (1 << log2_pb_h) - 1) >> l2];
+    const int wt = 1 + (mode_abv == OV_INTRA || mode_abv == OV_MIP) + (mode_lft == OV_INTRA || mode_lft == OV_MIP);    /* rcn_inter.c:2975-2981 */
     latch(e, ovhip_rec_pu(e->rec, d), "ovhip_rec_pu(ciip)");
-    /* the planar prediction of this CU comes from the ordered (intra) pass on the device; the blend with it is
-     * recorded as its own unit */
-    latch(e, ovhip_rec_ciip(e->rec, d->x0, d->y0, log2_pb_w, log2_pb_h, mode_abv, mode_lft), "ovhip_rec_ciip");
+    /* the planar predictions (intra_pred / intra_pred_c with mode 0 and no CU flags, rcn_inter.c:3026-3028) and the blend
+     * belong to the ordered pass: two tasks with the CU's weight, the references read out of the progress fields as they
+     * are now; chroma blocks 2 samples wide keep the inter prediction (:2997-2999) */
+    e->ciip.live = 1; e->ciip.x0 = x0; e->ciip.y0 = y0; e->ciip.log2_w = log2_pb_w; e->ciip.log2_h = log2_pb_h;
+    luma_task(c, x0, y0, log2_pb_w, log2_pb_h, 0, OVINTRA_PLANAR, wt, &e->ciip.tl);
+    e->ciip.has_c = log2_pb_w > 2;
+    if (e->ciip.has_c) chroma_task(c, x0 >> 1, y0 >> 1, log2_pb_w - 1, log2_pb_h - 1, 0, OVINTRA_PLANAR, wt, &e->ciip.tc);
 }
 
 static void
@@ -985,7 +1117,8 @@ begin_picture(struct hip_entry *e, const OVFrame *f)
     e->sao_on = e->alf_on = 0;
     e->lmcs_region_live = 0;
     e->n_patch = 0; e->dmvr_done = 0;
-    e->pend.kind = PEND_NONE; e->aff_c_live = 0;
+    e->pend.kind = PEND_NONE; e->aff_c_live = 0; e->ciip.live = 0;
+    if (e->rec && e->key->part_ctx) (void)ovhip_rec_set_ctu_size(e->rec, e->key->part_ctx->log2_ctu_s);
     if (e->n_ctu) { memset(e->sao, 0, e->n_ctu * sizeof(*e->sao)); memset(e->alf, 0, e->n_ctu * sizeof(*e->alf)); }
     if (e->record_only) { ovhip_rec_reset(e->rec); return; }
     if (!e->ctx) {
@@ -1089,6 +1222,7 @@ ovhip_shim_bind_recorder(const OVCTUDec *c, ovhip_recorder *rec, int pic_w, int 
     struct hip_entry *e = entry_of(c, 0);
     if (!e || !rec || e->job) return OVHIP_EINVAL;
     e->rec = rec; e->record_only = 1; e->pic_w = pic_w; e->pic_h = pic_h;
+    if (c->part_ctx) (void)ovhip_rec_set_ctu_size(rec, c->part_ctx->log2_ctu_s);
     e->err = 0; e->n_refs = 0; e->pend.kind = PEND_NONE;
     return OVHIP_OK;
 }
@@ -1117,6 +1251,7 @@ void
 ovhip_shim_flush_pending(OVCTUDec *c)
 {
     struct hip_entry *e = entry_of(c, 0);
+    if (e && e->rec && e->ciip.live) ciip_close(e, c);
     if (e && e->rec && e->pend.kind) pend_close(e, c);
     if (e) e->aff_c_live = 0;
 }

@@ -108,8 +108,17 @@ def lmcs_cases():
     return g["pic_y"], sets, g["regions"], g["inverse"]
 
 
+def ciip_planar_cases():
+    """The CIIP cases of gpm.ovg that ran the reference's real planar prediction: (current picture HostPic, first case index)."""
+    g = golden_io.load("gpm.ovg")
+    h, w = g["cur_y"].shape
+    return HostPic(w, h, g["cur_y"], g["cur_cb"], g["cur_cr"]), g["desc"].shape[0] - int(g["n_ciip_planar"][0])
+
+
 def gpm_cases():
-    """GPM + CIIP: (refs, intra HostPic, descs, ciip_modes [n,2], n_gpm, exp_off, exp); the first n_gpm cases are GPM."""
+    """GPM + CIIP: (refs, intra HostPic, descs, ciip_modes [n,2], n_gpm, exp_off, exp); the first n_gpm cases are GPM, the
+    last n_ciip_planar ones CIIP with the real planar prediction (ciip_planar_cases), the ones between CIIP with the
+    reference's intra slots replaced by a stub that delivers the `intra` picture."""
     g = golden_io.load("gpm.ovg")
     n = g["desc"].shape[0]
     _, rh, rw = g["ref_y"].shape

@@ -10,10 +10,10 @@ import numpy as np
 import golden_io
 from openvvc_amd import capi
 
-ARRAYS = ("tb", "coef", "mc", "mcx", "aff", "side", "region", "ciip", "edge_v", "edge_h")
+ARRAYS = ("tb", "coef", "mc", "mcx", "aff", "side", "region", "ciip", "edge_v", "edge_h", "itask")
 DTYPES = {"tb": capi.TB_CMD_DTYPE, "coef": np.dtype("<i2"), "mc": capi.MC_UNIT_DTYPE, "mcx": capi.MC_UNIT_DTYPE,
           "aff": capi.AFF_UNIT_DTYPE, "side": np.dtype("<i4"), "region": capi.LMCS_REGION_DTYPE, "ciip": capi.CIIP_UNIT_DTYPE,
-          "edge_v": capi.DBF_EDGE_DTYPE, "edge_h": capi.DBF_EDGE_DTYPE}
+          "edge_v": capi.DBF_EDGE_DTYPE, "edge_h": capi.DBF_EDGE_DTYPE, "itask": capi.ITASK_DTYPE}
 
 
 class ShimStream:

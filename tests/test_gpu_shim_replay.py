@@ -27,7 +27,7 @@ def test_shim_tu_streams_gpu(ctx):
         s = ShimStream(stream)
         n = s.n
         tall = ctx.upload_pic(np.tile(g["pred_y"], (n, 1)), np.tile(g["pred_cb"], (n, 1)), np.tile(g["pred_cr"], (n, 1)))
-        cmds, coefs, rects, coef_base = [], [], [], 0
+        cmds, coefs, rects, coef_base, tasks = [], [], [], 0, []
         for i in range(n):
             c = s.case(i)
             tb = c["tb"]
@@ -35,6 +35,12 @@ def test_shim_tu_streams_gpu(ctx):
             tb["coef_off"] += coef_base
             coef_base += len(c["coef"])
             cmds.append(tb); coefs.append(c["coef"])
+            # TUs of intra CUs: the chroma prediction task keeps its residual half only (the reference run behind itx.ovg had
+            # intra_pred_c stubbed out, test_shim_cpu.run_tu_stream)
+            t = c["itask"]
+            t["kind"] = capi.IT_RES_C
+            t["y"] += np.uint16(i * (BAND // 2))
+            tasks.append(t)
             if tree_of is None:
                 d = capi.TuDesc.from_buffer_copy(g["desc"][i].tobytes())
                 x0, y0, w, h, eo = d.x0, d.y0, 1 << d.log2_tb_w, 1 << d.log2_tb_h, g["exp_off"][i]
@@ -47,8 +53,18 @@ def test_shim_tu_streams_gpu(ctx):
                 d = capi.TtDesc.from_buffer_copy(g["tt_desc"][i].tobytes())
                 w, h, eo = 1 << d.log2_w, 1 << d.log2_h, g["tt_exp_off"][i]
                 rects += [(0, 0, i * BAND, w, h, int(eo[0])), (1, 0, i * 64, w >> 1, h >> 1, int(eo[1])), (2, 0, i * 64, w >> 1, h >> 1, int(eo[2]))]
-        ctx.itx(tall, ctx.upload(np.concatenate(cmds)), ctx.upload(np.concatenate(coefs)))
-        ctx.sync()
+        # through the C flush (residual launches, STORE mode for the blocks of ordered tasks, then the ordered pass)
+        job = engine.Job(ctx, 128, BAND * n)
+        job.begin()
+        job.rec.append_raw(capi.REC_COEF, np.concatenate(coefs))
+        job.rec.append_raw(capi.REC_TB, np.concatenate(cmds))
+        job.rec.append_raw(capi.REC_ITASK, np.concatenate(tasks))
+        p = capi.JobParams()
+        p.log2_ctu_s = 7
+        p.stages = capi.STAGE_ITX | capi.STAGE_INTRA
+        job.flush(tall, [], None, params=p)
+        job.wait()
+        job.close()
         y, cb, cr = tall.download()
         golden_cases.check_rects(HostPic(128, BAND * n, y, cb, cr), rects, g["exp"], f"{stream} HIP vs reference")
 
@@ -77,13 +93,31 @@ def test_shim_prediction_streams_gpu(ctx):
         rw, rh, n = refs[0].w, refs[0].h, len(descs)
         drefs = s.refs([ctx.upload_pic(r.y, r.cb, r.cr) for r in refs])
         tall = _tall(ctx, rw, rh, n)
+        first_planar = n
+        if loader == "gpm":
+            # the CIIP cases with the real planar prediction start from the current picture
+            cur, first_planar = golden_cases.ciip_planar_cases()
+            fy, fcb, fcr = tall.download()
+            for i in range(first_planar, n):
+                fy[i * rh:(i + 1) * rh] = cur.y; fcb[i * rh // 2:(i + 1) * rh // 2] = cur.cb; fcr[i * rh // 2:(i + 1) * rh // 2] = cur.cr
+            tall.upload(fy, fcb, fcr)
+            res = ctx.new_pic(rw, rh)
         rects = []
         for i, d in enumerate(descs):
             c = s.case(i)
             band = tall.band(i * rh, rh)
             ctx.mc(band, drefs, ctx.upload(c["mc"]))
-            if len(c["ciip"]):
-                ctx.ciip(band, intra, ctx.upload(c["ciip"]))
+            t = c["itask"]
+            if len(t) and i < first_planar:
+                # planar stubbed in the reference run: the task's geometry and weight through the fused blend
+                u = np.zeros(1, capi.CIIP_UNIT_DTYPE)
+                u["x"], u["y"], u["log2_w"], u["log2_h"], u["wt"], u["chroma_inter"] = d.x0, d.y0, d.log2_w, d.log2_h, t[0]["ciip_wt"], d.log2_w <= 2
+                ctx.ciip(band, intra, ctx.upload(u))
+            elif len(t):
+                lv = t["level"]
+                for l in np.unique(lv):
+                    tl = t[lv == l]
+                    ctx.intra_level(band, res, ctx.upload(tl), 0, len(tl))
             rects += _rects(d, exp_off, i, rh)
         ctx.sync()
         y, cb, cr = tall.download()
@@ -141,3 +175,34 @@ def test_shim_dbf_edge_lists_gpu(ctx):
         y, cb, cr = d.download()
         for name, a, b in (("Y", y, exp.y), ("Cb", cb, exp.cb), ("Cr", cr, exp.cr)):
             assert np.array_equal(a, b), f"dbf picture {i} plane {name}: {int((a != b).sum())} samples differ"
+
+
+def test_shim_intra_ctus_gpu(ctx):
+    """The 36 intra CTUs the installed slots recorded (shim_intra_ctu.ovg) through the C flush (prediction-free picture, residual
+    launches in STORE mode, ordered pass by level and as the one-launch CTU pass): the CTU the reference's slots left."""
+    from test_shim_cpu import intra_ctu_cases
+    base, cases = intra_ctu_cases()
+    s = ShimStream("shim_intra_ctu.ovg")
+    h, w = base[0].shape
+    job = engine.Job(ctx, w, h)
+    dst = ctx.new_pic(w, h)
+    for one_launch in (False, True):
+        for i, (dual, n_intra, ey, ecb, ecr) in enumerate(cases):
+            c = s.case(i)
+            dst.upload(*base)
+            job.begin()
+            job.rec.append_raw(capi.REC_COEF, c["coef"])
+            job.rec.append_raw(capi.REC_TB, c["tb"])
+            job.rec.append_raw(capi.REC_ITASK, c["itask"])
+            p = capi.JobParams()
+            p.log2_ctu_s = 7
+            p.stages = capi.STAGE_ITX | capi.STAGE_INTRA | (capi.STAGE_INTRA_CTU if one_launch else 0)
+            job.flush(dst, [], None, params=p)
+            job.wait()
+            y, cb, cr = dst.download()
+            for name, got, exp in (("Y", y[128:256, 128:256], ey), ("Cb", cb[64:128, 64:128], ecb), ("Cr", cr[64:128, 64:128], ecr)):
+                assert np.array_equal(got, exp), f"intra CTU {i} (dual={dual}, one_launch={one_launch}) plane {name}: {int((got != exp).sum())} samples differ"
+            # nothing outside the CTU changes
+            y[128:256, 128:256] = base[0][128:256, 128:256]
+            assert np.array_equal(y, base[0])
+    job.close()

@@ -43,17 +43,31 @@ def _pred_pic(g):
     return HostPic(128, 128, g["pred_y"].copy(), g["pred_cb"].copy(), g["pred_cr"].copy())
 
 
+def run_tu_stream(pic, c):
+    """A recorded TU on `pic`.  TUs of intra CUs carry the chroma prediction as an ordered task; the reference run behind
+    itx.ovg had intra_pred_c stubbed out (the fixture isolates the residual paths), so the task keeps only its residual half
+    (OVHIP_IT_RES_C: prediction = what is there).  The prediction half is pinned by intra.ovg / intra_ctu.ovg."""
+    t = c["itask"].copy()
+    assert (t["kind"] == capi.IT_CHROMA).all()
+    t["kind"] = capi.IT_RES_C
+    res = HostPic(pic.w, pic.h)
+    oracle_lib.itx_res(pic, c["tb"], c["coef"], None, res)
+    if len(t):
+        oracle_lib.intra_tasks(pic, t, (res.y.view(np.int16), res.cb.view(np.int16), res.cr.view(np.int16)))
+    return len(t)
+
+
 def test_shim_tu_slots_match_reference(built_lib):
     """tmp.rcn_tu_st / tmp.rcn_tu_c through the installed table: 425 TUs."""
     g = golden_io.load("itx.ovg")
     s = ShimStream("shim_itx.ovg")
     assert s.n == g["desc"].shape[0] == 425
-    n_cmds = 0
+    n_cmds = n_tasks = 0
     for i in range(s.n):
         d = capi.TuDesc.from_buffer_copy(g["desc"][i].tobytes())
         c = s.case(i)
         pic = _pred_pic(g)
-        oracle_lib.itx(pic, c["tb"], c["coef"])
+        n_tasks += run_tu_stream(pic, c)
         n_cmds += len(c["tb"])
         x0, y0, w, h = d.x0, d.y0, 1 << d.log2_tb_w, 1 << d.log2_tb_h
         eo = g["exp_off"][i]
@@ -62,7 +76,7 @@ def test_shim_tu_slots_match_reference(built_lib):
         else:
             rects = [(1, x0, y0, w, h, int(eo[1])), (2, x0, y0, w, h, int(eo[2]))]
         golden_cases.check_rects(pic, rects, g["exp"], f"shim tu case {i} tree={d.tree}")
-    assert n_cmds > 600
+    assert n_cmds > 600 and n_tasks > 200
 
 
 def test_shim_transform_tree_slot_matches_reference(built_lib):
@@ -142,17 +156,32 @@ def test_shim_affine_slots_match_reference(built_lib):
 
 
 def test_shim_gpm_ciip_slots_match_reference(built_lib):
+    """rcn_gpm_b, rcn_ciip_b / rcn_ciip through the installed table.  A CIIP CU is recorded as its inter unit + two planar
+    ordered tasks carrying the blend weight.  Cases [n_gpm, first_planar) come from a reference run whose intra slots were
+    stubbed (a known "planar" picture): there the tasks are checked through their geometry and weight only (fed to the fused
+    blend with that picture); cases from first_planar on ran the real intra_pred / intra_pred_c and are executed as recorded."""
     refs, intra, descs, modes, n_gpm, exp_off, exp = golden_cases.gpm_cases()
+    cur, first_planar = golden_cases.ciip_planar_cases()
     s = ShimStream("shim_gpm.ovg")
-    assert s.n == len(descs)
+    assert s.n == len(descs) and n_gpm < first_planar < s.n
     srefs = s.refs(refs)
     for i, d in enumerate(descs):
         c = s.case(i)
-        dst = _blank(refs[0].w, refs[0].h)
+        t = c["itask"]
+        dst = _blank(refs[0].w, refs[0].h) if i < first_planar else HostPic(cur.w, cur.h, cur.y.copy(), cur.cb.copy(), cur.cr.copy())
         oracle_lib.mc(dst, srefs, c["mc"])
-        if i >= n_gpm:
-            assert len(c["ciip"]) == 1
-            oracle_lib.ciip(dst, intra, c["ciip"])
+        if i < n_gpm:
+            assert len(t) == 0
+        else:
+            lw = int(d.log2_w)
+            assert len(t) == (2 if lw > 2 else 1) and t[0]["kind"] == capi.IT_LUMA and t[0]["mode"] == 0 and 1 <= t[0]["ciip_wt"] <= 3
+            assert (t[0]["x"], t[0]["y"], t[0]["log2_w"], t[0]["log2_h"]) == (d.x0, d.y0, d.log2_w, d.log2_h)
+            if i < first_planar:
+                u = np.zeros(1, capi.CIIP_UNIT_DTYPE)
+                u["x"], u["y"], u["log2_w"], u["log2_h"], u["wt"], u["chroma_inter"] = d.x0, d.y0, d.log2_w, d.log2_h, t[0]["ciip_wt"], lw <= 2
+                oracle_lib.ciip(dst, intra, u)
+            else:
+                oracle_lib.intra_tasks(dst, t)
         golden_cases.check_rects(dst, _pu_rects(d, exp_off, i), exp, f"shim {'gpm' if i < n_gpm else 'ciip'} case {i}")
 
 
@@ -190,3 +219,43 @@ def test_shim_filter_slots_match_reference(built_lib):
     for i in range(3):
         for k in ("ctus", "luma_coeff", "luma_clip", "chroma_coeff", "chroma_clip", "cc_coeff"):
             assert ga[f"p{i}_{k}"].tobytes() == gr[f"p{i}_{k}"].tobytes(), f"alf picture {i} {k}"
+
+
+def intra_ctu_cases():
+    """(start picture planes, [(dual, expected Y / Cb / Cr of the CTU at (128, 128))]) from intra_ctu.ovg."""
+    g = golden_io.load("intra_ctu.ovg")
+    out = []
+    for dual, n_cu, n_intra, off in g["info"]:
+        e = g["exp"][int(off):int(off) + 128 * 128 + 2 * 64 * 64]
+        out.append((int(dual), int(n_intra), e[:16384].reshape(128, 128), e[16384:20480].reshape(64, 64), e[20480:].reshape(64, 64)))
+    return (g["pic_y"], g["pic_cb"], g["pic_cr"]), out
+
+
+def test_shim_intra_ctus_match_reference(built_lib):
+    """tmp.rcn_transform_tree on intra CUs (-> rcn_intra_tu + rcn_tu_st, rcn_tu_l, rcn_tu_c): the installed slots turn every
+    CU into ordered tasks (availability out of the progress bit-fields, MIP / MRL / BDPCM / LM parameters out of the ctudec) +
+    STORE-mode transform blocks; the recorder levels them.  Executing each recorded CTU on the start picture gives the CTU
+    the reference's own slots left, 36 CTUs (single and dual tree), ~2000 tasks."""
+    base, cases = intra_ctu_cases()
+    s = ShimStream("shim_intra_ctu.ovg")
+    assert s.n == len(cases) == 36
+    h, w = base[0].shape
+    n_tasks = 0
+    for i, (dual, n_intra, ey, ecb, ecr) in enumerate(cases):
+        c = s.case(i)
+        t = c["itask"]
+        assert len(t) >= n_intra and len(c["mc"]) == 0
+        n_tasks += len(t)
+        dst = HostPic(w, h, base[0].copy(), base[1].copy(), base[2].copy())
+        res = HostPic(w, h)
+        oracle_lib.itx_res(dst, c["tb"], c["coef"], None, res)
+        oracle_lib.intra_tasks(dst, t, (res.y.view(np.int16), res.cb.view(np.int16), res.cr.view(np.int16)))
+        for name, got, exp in (("Y", dst.y[128:256, 128:256], ey), ("Cb", dst.cb[64:128, 64:128], ecb), ("Cr", dst.cr[64:128, 64:128], ecr)):
+            assert np.array_equal(got, exp), f"intra CTU {i} (dual={dual}) plane {name}: {int((got != exp).sum())} samples differ"
+        # level order == decoding order for what the shim recorded
+        order = np.argsort(t["level"], kind="stable")
+        dst2 = HostPic(w, h, base[0].copy(), base[1].copy(), base[2].copy())
+        oracle_lib.itx_res(dst2, c["tb"], c["coef"], None, res)
+        oracle_lib.intra_tasks(dst2, t[order], (res.y.view(np.int16), res.cb.view(np.int16), res.cr.view(np.int16)))
+        assert np.array_equal(dst2.y, dst.y) and np.array_equal(dst2.cb, dst.cb) and np.array_equal(dst2.cr, dst.cr)
+    assert n_tasks > 1500
