@@ -197,7 +197,7 @@ ovhip_rec_itasks_sorted(ovhip_recorder *r, size_t *n, const uint32_t **level_sta
     for (size_t i = 0; i < r->n_itask; ++i) if (r->itask[i].level > maxl) maxl = r->itask[i].level;
     if (ovhip_rec_grow_(r, (void **)&r->itask_sorted, &r->cap_isorted, r->n_itask, sizeof(ovhip_itask))) { *n = 0; return NULL; }
     {   /* level table: plain host memory */
-        if (r->cap_ilevel < maxl + 2) {
+        if (r->cap_ilevel < (size_t)(maxl + 2) * 2) {
             uint32_t *q = (uint32_t *)realloc(r->ilevel_start, (size_t)(maxl + 2) * 2 * sizeof(uint32_t));
             if (!q) { *n = 0; return NULL; }
             r->ilevel_start = q; r->cap_ilevel = (size_t)(maxl + 2) * 2;

@@ -149,6 +149,7 @@ def test_lmcs_gpu_matches_reference(ctx):
 def test_gpm_ciip_gpu_matches_reference(ctx):
     """K10: GPM units through ovhip_mc_launch, CIIP = plain MC + ovhip_ciip_launch, vs rcn_gpm_b / rcn_ciip(_b)."""
     refs, intra, descs, modes, n_gpm, exp_off, exp = golden_cases.gpm_cases()
+    descs = descs[:golden_cases.ciip_planar_cases()[1]]        # the rest: CIIP through ordered tasks (test_gpu_shim_replay)
     rw, rh = refs[0].w, refs[0].h
     n = len(descs)
     drefs = [ctx.upload_pic(r.y, r.cb, r.cr) for r in refs]

@@ -115,3 +115,22 @@ def test_by_ctu_grouping_is_a_valid_order():
         for x, y in zip(a.planes(), b.planes()):
             assert np.array_equal(x, y), f"seed {seed} intra_frac {frac}"
         rec.close()
+
+
+def test_level_table_grows_between_pictures():
+    """A recorder reused for a picture with more levels than the one before (the level table is reallocated)."""
+    import numpy as np
+    from openvvc_amd import capi
+    rec = capi.Recorder(256, 256)
+    for nlev in (5, 11, 12, 40, 3):
+        rec.reset()
+        t = np.zeros(nlev * 3, capi.ITASK_DTYPE)
+        t["level"] = np.repeat(np.arange(1, nlev + 1), 3)[::-1]
+        t["log2_w"] = t["log2_h"] = 2
+        t["x"] = (np.arange(len(t)) % 32) * 4
+        rec.append_raw(capi.REC_ITASK, t)
+        ts, ls = rec.itasks_sorted()
+        assert len(ls) == nlev + 1 and ls[-1] == len(t) and np.all(np.diff(ts["level"].astype(int)) >= 0)
+        tc, cs = rec.itasks_by_ctu(7)
+        assert int(cs["n"].sum()) == len(t)
+    rec.close()
