@@ -9,13 +9,16 @@ ALF / CC-ALF; intra prediction of the picture's intra CUs as a dependency-ordere
 motion vectors.  The workload is a synthetic recorded 3840x2160 10-bit 4:2:0 random-access stream (BASELINE.json
 configs[3]): B pictures with `--intra-frac` of their CUs intra, and `--i-sets` of the picture sets an I picture.
 
-Nothing is replayed out of cache: the steps rotate over `--sets` picture sets (reference pictures, intra picture,
-destination, command buffers; distinct addresses, `--contents` distinct recorded pictures), sized so that the working
-set is several times the 256 MiB Infinity Cache.  `--in-flight S` pictures are in flight per GPU (one HIP stream + one
-host thread each: the reference's frame threads, ovdec.c:188-248).
+The steps are the pictures of a random-access stream in decoding order (openvvc_amd/gop.py: GOP `--gop`, hierarchical B, an I
+picture every `--intra-period`): a picture's reference pictures ARE the decoded pictures its reference lists name, so a picture
+starts when they are done (stream events) -- the dependency structure a decoder's frame threads live with.  Nothing is
+replayed out of cache: every position of the GOP has its own command buffers, job and destination picture (distinct addresses,
+`--contents` distinct recorded pictures; working set several times the 256 MiB Infinity Cache).  `--in-flight S` pictures are
+in flight per GPU (one HIP stream + one host thread each: the reference's frame threads, ovdec.c:188-248).
 
-N > 1: one process per GPU, frames sharded --framethr style; reference pictures move between ranks with RCCL
-point-to-point only where the GOP's reference lists need them (openvvc_amd/gop.py); no collective on the data path.
+N > 1: one process per GPU, a GOP per GPU; the only picture of a GOP another GPU needs is its key picture, sent to the owner
+of the next GOP with RCCL point-to-point on a communication stream (no collective on the data path, nothing waited for on the
+host).  Every rank decodes --steps pictures: the stream grows with N ("weak").
 
 Prints ONE JSON line on rank 0 (contract in the task statement).
 """
@@ -95,17 +98,17 @@ def main():
     ap.add_argument("--seed", type=int, default=0x266)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--in-flight", type=int, default=6, help="pictures in flight per GPU (one HIP stream + one host thread each)")
-    ap.add_argument("--sets", type=int, default=32, help="picture sets the steps rotate over = one intra period (distinct addresses; working set = sets x ~100 MB at 4K)")
     ap.add_argument("--contents", type=int, default=2, help="distinct recorded pictures (seeds) among the sets")
     ap.add_argument("--intra-frac", type=float, default=0.12, help="share of intra CUs in the B pictures")
-    ap.add_argument("--i-sets", type=int, default=1, help="picture sets that hold an I picture (all CUs intra)")
+    ap.add_argument("--gop", type=int, default=32, help="GOP size (hierarchical B, JVET random-access decoding order) = picture sets of the rotation")
+    ap.add_argument("--intra-period", type=int, default=32, help="every key picture at a multiple of this POC is an I picture (a multiple of --gop)")
     ap.add_argument("--intra-ctu", action="store_true", help="ordered pass as the one-launch CTU wavefront instead of one launch per level")
     ap.add_argument("--host-threads", type=int, default=-1, help="host threads issuing the flushes (-1: one per picture in flight)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from openvvc_amd import capi, engine, synth
+    from openvvc_amd import capi, engine, gop, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -120,20 +123,23 @@ def main():
 
     W, H = args.width, args.height
     S = max(1, args.in_flight)
-    K = max(S, (args.sets + S - 1) // S * S)
-    tools = synth.INTRA_TOOLS if (args.intra_frac > 0 or args.i_sets) else synth.ALL_TOOLS
+    G = args.gop                                   # pictures per GOP = picture sets of the rotation
+    IP = args.intra_period
+    K = G
+    tools = synth.INTRA_TOOLS if args.intra_frac > 0 else synth.ALL_TOOLS
     wls = [synth.make_workload(W, H, args.seed + 1000 * c + rank, tools=tools, intra_frac=args.intra_frac)
            for c in range(max(1, min(args.contents, K)))]
     n_b = len(wls)
-    if args.i_sets:
-        wls.append(synth.make_workload(W, H, args.seed + 7777 + rank, tools=synth.INTRA_TOOLS, intra_frac=1.0))
-    content_of = [n_b if k < args.i_sets else k % n_b for k in range(K)]       # set 0.. i_sets-1: the I picture
+    wls.append(synth.make_workload(W, H, args.seed + 7777 + rank, tools=synth.INTRA_TOOLS, intra_frac=1.0))      # the I picture
     FB = wls[0].frame_bytes
+    n_ref_slots = len(wls[0].refs)
 
-    # ---- picture sets: every set has its own reference pictures, intra picture, destination and job (= command buffers,
-    # tmp picture), at distinct addresses.  Pictures live in torch tensors so that RCCL can move them (N > 1).
+    # ---- the stream: an RA sequence of GOPs (openvvc_amd/gop.py), GOP g decoded by rank g mod world.  Position j of the
+    # GOP's decoding order <-> picture set j (own command buffers, job, destination picture at its own address); the key
+    # picture (j = 0) rotates over three buffers because the previous GOP's pictures still read the previous key.
     ctxs = [engine.Context(local_rank) for _ in range(S)]
     ext = [torch.cuda.ExternalStream(c.stream, device=dev) for c in ctxs]
+    comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
 
     def torch_pic(ctx, planes=None):
         t = torch.empty(H * W * 3 // 2, dtype=torch.int16, device=dev)
@@ -147,55 +153,100 @@ def main():
     class Set:
         pass
 
-    sets = []
-    for k in range(K):
+    def new_job(wl):
         st = Set()
-        st.slot = k % S
-        st.ctx = ctxs[st.slot]
+        st.wl = wl
+        st.job = engine.Job(ctxs[0], W, H)
+        st.job.load_workload(wl)
         st.lock = threading.Lock()
-        st.wl = wls[content_of[k]]
-        st.job = engine.Job(st.ctx, W, H)
-        st.job.load_workload(st.wl)
-        st.ref_t, st.refs = zip(*[torch_pic(st.ctx, r) for r in st.wl.refs])
-        st.ref_t, st.refs = list(st.ref_t), list(st.refs)
-        st.intra = torch_pic(st.ctx, st.wl.intra)[1] if st.wl.intra is not None else None
-        st.dst_t, st.dst = torch_pic(st.ctx)
-        st.spare_t, st.spare = torch_pic(st.ctx, st.wl.refs[1]) if world > 1 else (None, None)
-        sets.append(st)
-    torch.cuda.synchronize(dev)
-    working_set = K * ((len(wls[0].refs) + 2 + (wls[0].intra is not None)) * FB)
+        return st
 
-    # ---- N > 1: frames shard across ranks; a decoded picture is pushed to the next rank, where it replaces reference 1
-    # of that slot's next picture -- issued on the slot's stream, never waited for on the host
-    def exchange(st, slot):
-        with torch.cuda.stream(ext[slot]):
-            ops = [dist.P2POp(dist.isend, st.dst_t, (rank + 1) % world), dist.P2POp(dist.irecv, st.spare_t, (rank - 1) % world)]
-            dist.batch_isend_irecv(ops)
-        st.ref_t[1], st.spare_t = st.spare_t, st.ref_t[1]
-        st.refs[1], st.spare = st.spare, st.refs[1]
+    order = gop.gop_decode_order(G)
+    sets = [new_job(wls[n_b]) if j == 0 else new_job(wls[j % n_b]) for j in range(K)]         # set 0: the key picture as I picture
+    key_b = new_job(wls[0]) if IP > G else None                                              # ... and as inter key picture
+    all_jobs = sets + ([key_b] if key_b else [])
+    bufs_b = [torch_pic(ctxs[0]) for _ in range(K)]                    # destination of GOP position j (j >= 1)
+    bufs_key = [torch_pic(ctxs[0], wls[0].refs[k % n_ref_slots]) for k in range(3)]
+    bufs_recv = [torch_pic(ctxs[0], wls[0].refs[k % n_ref_slots]) for k in range(2)] if world > 1 else []
+    torch.cuda.synchronize(dev)
+    working_set = (K + 3 + len(bufs_recv)) * FB + len(all_jobs) * FB            # destinations + each job's SAO picture
 
     lv = capi.STAGE_INTRA_CTU if args.intra_ctu else 0
     nthreads = S if args.host_threads < 0 else max(1, min(args.host_threads, S))
+    gop_base = [0]                                 # GOPs this rank has decoded so far (keeps the key-buffer rotation going)
+    keep_work = []
 
-    def run_steps(first, n, resident=False):
-        """Steps [first, first + n): step i decodes picture set i mod K.  One host thread per picture in flight, each with its
-        own HIP stream; a thread that became free takes the next picture (the reference's frame threads, ovdec.c:188-248) and,
-        like the shim's flush_picture, waits for its picture before it takes another."""
-        def one(i, slot, wait):
-            st = sets[i % K]
+    def run_steps(n, resident=False):
+        """The next n pictures of this rank's share of the stream, in decoding order.  One host thread per picture in flight,
+        each with its own HIP stream; a thread that became free takes the next picture (the reference's frame threads,
+        ovdec.c:188-248) and, like the shim's flush_picture, waits for it before it takes another.  A picture starts when the
+        pictures of its reference lists are decoded (stream events; RCCL point-to-point for a key picture decoded on another
+        GPU), and not before the readers of the buffer it overwrites are done."""
+        n_gops_rank = (n + G - 1) // G
+        pics = gop.build_stream(n_gops_rank * world, G, IP, world)
+        mine = [p for p in pics if p.owner == rank and p.gop >= 0][:n]
+        first_gop = gop_base[0]
+        gop_base[0] += n_gops_rank
+        # buffers: picture idx -> (tensor, DevPic)
+        buf = {}
+        local_gop = lambda p: first_gop + p.gop // world
+        for p in pics:
+            if p.gop < 0:
+                # the picture before the first GOP: for rank 0 the key buffer its previous GOP left, else whatever is there
+                if rank == 0:
+                    buf[p.idx] = bufs_key[(first_gop - 1) % 3]
+            elif p.owner == rank:
+                buf[p.idx] = bufs_key[local_gop(p) % 3] if p.layer == 0 else bufs_b[order.index((p.poc - p.gop * G, p.layer))]
+            elif rank in p.sends:
+                buf[p.idx] = bufs_recv[(first_gop + (p.gop + 1) // world) % 2]
+        # who reads what (on this rank), who occupied a buffer before
+        readers = {}
+        for p in mine:
+            for r in p.refs:
+                readers.setdefault(r, []).append(p.idx)
+        prog = gop.rank_program(pics, rank)
+        issued = {p.idx: threading.Event() for p in pics}
+        done_ev = {}
+        prev_occ, occ = {}, {}
+        for op in prog:
+            if op[0] in ("decode", "recv") and op[1] in buf:
+                key = buf[op[1]][0].data_ptr()
+                if key in occ:
+                    prev_occ[op[1]] = occ[key]
+                occ[key] = op[1]
+        for p in pics:
+            if p.gop < 0 or (p.owner != rank and rank not in p.sends) or p.idx not in [q.idx for q in mine] and p.owner == rank:
+                issued[p.idx].set()                   # not part of this run: final already
+        mine_idx = {p.idx for p in mine}
+        errs = []
+
+        def wait_for(stream, idxs):
+            for q in idxs:
+                if q in mine_idx or (pics[q].owner != rank and q in buf):
+                    issued[q].wait()
+                    ev = done_ev.get(q)
+                    if ev is not None:
+                        stream.wait_event(ev)
+
+        def decode(p, slot):
+            j = order.index((p.poc - p.gop * G, p.layer))
+            st = sets[j] if (j or p.intra or key_b is None) else key_b
+            stream = ext[slot]
+            wait_for(stream, p.refs)
+            if p.idx in prev_occ:
+                wait_for(stream, [prev_occ[p.idx]] + readers.get(prev_occ[p.idx], []))
+            refs = [buf[p.refs[k % len(p.refs)]][1] for k in range(n_ref_slots)] if p.refs else []
             with st.lock:
                 st.job.bind(ctxs[slot])
                 st.job.params.stages = ((capi.STAGE_ALL | capi.STAGE_RESIDENT) if resident else capi.STAGE_ALL) | lv
-                st.job.flush(st.dst, st.refs, st.intra)
-                if world > 1:
-                    exchange(st, slot)
-                if wait:
-                    st.job.wait()
-        if nthreads == 1 or world > 1:
-            for i in range(first, first + n):
-                one(i, i % S, False)
-            return
-        errs, nxt, nlock = [], [first], threading.Lock()
+                st.job.flush(buf[p.idx][1], refs, None)
+                ev = torch.cuda.Event()
+                stream.record_event(ev)
+                done_ev[p.idx] = ev
+                issued[p.idx].set()
+                st.job.wait()
+
+        nxt, nlock = [0], threading.Lock()
 
         def worker(slot):
             try:
@@ -203,14 +254,44 @@ def main():
                     with nlock:
                         i = nxt[0]
                         nxt[0] += 1
-                    if i >= first + n:
+                    if i >= len(mine):
                         return
-                    one(i, slot, True)
+                    decode(mine[i], slot)
             except Exception as e:          # noqa: BLE001
                 errs.append(e)
+                for evt in issued.values():
+                    evt.set()
+
+        def comm():
+            """This rank's sends and receives in the global transfer order, on the communication stream; nothing is waited
+            for on the host except that the producing flush has been enqueued."""
+            try:
+                with torch.cuda.stream(comm_stream):
+                    for op in prog:
+                        if op[0] == "send" and op[1] in mine_idx:
+                            wait_for(comm_stream, [op[1]])
+                            keep_work.append(dist.isend(buf[op[1]][0], op[2]))
+                        elif op[0] == "recv" and op[1] in buf and any(op[1] in q.refs for q in mine):
+                            if op[1] in prev_occ:
+                                wait_for(comm_stream, [prev_occ[op[1]]] + readers.get(prev_occ[op[1]], []))
+                            w = dist.irecv(buf[op[1]][0], op[2])
+                            w.wait()          # NCCL: orders the communication stream behind the transfer, the host does not block
+                            keep_work.append(w)
+                            ev = torch.cuda.Event()
+                            comm_stream.record_event(ev)
+                            done_ev[op[1]] = ev
+                            issued[op[1]].set()
+            except Exception as e:          # noqa: BLE001
+                errs.append(e)
+                for evt in issued.values():
+                    evt.set()
+
         th = [threading.Thread(target=worker, args=(s,)) for s in range(nthreads)]
+        if world > 1:
+            th.append(threading.Thread(target=comm))
         [t.start() for t in th]
         [t.join() for t in th]
+        del keep_work[:-64]
         if errs:
             raise errs[0]
 
@@ -224,7 +305,7 @@ def main():
     def timed(n, resident=False):
         barrier()
         t0 = time.perf_counter()
-        run_steps(0, n, resident)
+        run_steps(n, resident)
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -234,17 +315,17 @@ def main():
         return dt
 
     def set_timer(name):
-        for st in sets:
+        for st in all_jobs:
             st.job.time_stage(name)
 
     def read_timer():
         tot, cnt = 0.0, 0
-        for st in sets:
+        for st in all_jobs:
             s, n = st.job.stage_time()
             tot += s; cnt += n
         return tot / max(cnt, 1)
 
-    run_steps(0, max(args.warmup, K))            # every picture set flushed at least once
+    run_steps(max(args.warmup, (2 if key_b else 1) * K))            # every picture set flushed at least once
     barrier()
     all_stats = [st.job.stats() for st in sets]          # of full (non-resident) flushes
     flush_stats = all_stats[-1]                          # a B picture
@@ -261,7 +342,7 @@ def main():
     survey = {}
     for name in present:
         set_timer(name)
-        run_steps(0, 2 * K)
+        run_steps(2 * K)
         barrier()
         survey[name] = read_timer()
     kern = {k: v for k, v in survey.items() if k != "h2d"}
@@ -285,7 +366,9 @@ def main():
 
     if rank == 0:
         algs = [algorithmic_bytes(wl, FB) for wl in wls]
-        use = np.bincount(content_of, minlength=len(wls)).astype(np.float64)
+        use = np.bincount([len(wls) - 1 if (j == 0 and G % IP == 0) else j % n_b for j in range(K)], minlength=len(wls)).astype(np.float64)
+        if IP > G:
+            use[len(wls) - 1] *= G / IP; use[0] += 1.0 - G / IP
         use /= use.sum()
         alg = {k: float(sum(u * a[k] for u, a in zip(use, algs))) for k in algs[0]}
         alg = {k: v for k, v in alg.items() if k in kern}
@@ -296,7 +379,8 @@ def main():
             if tj["workload"] == {"width": W, "height": H, "seed": args.seed}:
                 names = [n.strip() for n in KNAME[dom].split("(")[0].split("+")]
                 ks = [tj["kernels"][n] for n in names]
-                traffic = int(sum(2 * k["fetch_kib"] + k["write_kib"] for k in ks) * 1024)
+                per_group = mean_stat("n_ilevels") if dom == "intra" else (2 if dom in ("itx_luma", "itx_chroma") else 1)   # dispatches per launch group
+                traffic = int(sum(2 * k["fetch_kib"] + k["write_kib"] for k in ks) * 1024 * (per_group if dom == "intra" else 1))
         except (OSError, KeyError, ValueError):
             traffic = None
         roofline = {"bound": "hbm", "kernel": KNAME[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
@@ -339,28 +423,33 @@ def main():
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u16 samples / int16 coefficients / int32 accumulate", "data": "synthetic",
-            "config": {"workload": f"{W}x{H} 10-bit 4:2:0 synthetic recorded RA pictures (BASELINE configs[3]): {K - args.i_sets} B "
-                                   f"picture sets with {args.intra_frac:.0%} intra CUs + {args.i_sets} I picture set(s), seeds "
+            "config": {"workload": f"{W}x{H} 10-bit 4:2:0 synthetic recorded random-access stream (BASELINE configs[3]): GOP {G} "
+                                   f"(hierarchical B, JVET decoding order), intra period {IP}: per GOP {G - 1} B pictures with "
+                                   f"{args.intra_frac:.0%} intra CUs + the key picture ({'I' if G % IP == 0 else 'I every ' + str(IP // G) + ' GOPs, else B'}); "
+                                   f"reference pictures = the decoded pictures of the GOP structure; seeds "
                                    f"{[hex(w.seed) for w in wls]}, per-picture flush in C (ovhip_job_flush)",
+                       "gop_size": G, "intra_period": IP,
+                       "dependency_critical_path_pictures": round(gop.critical_path(gop.build_stream(4 * world, G, IP, world)), 1),
                        "intra_tasks_per_b_picture": st["n_itasks"], "intra_levels_per_b_picture": st["n_ilevels"],
-                       "intra_levels_per_i_picture": wls[-1].stats["n_ilevels"] if args.i_sets else None,
+                       "intra_levels_per_i_picture": wls[-1].stats["n_ilevels"],
                        "h2d_bytes_per_step": int(mean_stat("h2d_bytes")), "d2h_bytes_per_step": int(mean_stat("d2h_bytes")),
                        "launches_per_step": round(mean_stat("n_launches"), 1), "h2d_copies_per_step": round(mean_stat("n_h2d"), 1),
                        "launches_per_b_picture": int(js.n_launches),
-                       "launches_per_i_picture": int(all_stats[0].n_launches) if args.i_sets else None,
+                       "launches_per_i_picture": int(all_stats[0].n_launches),
                        "distinct_pictures": K, "distinct_contents": len(wls), "working_set_bytes": int(working_set),
                        "pictures_in_flight_per_gpu": S,
-                       "host_threads": 1 if world > 1 else nthreads,
-                       "picture_assignment": "static round-robin, asynchronous" if (world > 1 or nthreads == 1)
-                                             else "a free host thread takes the next picture, flushes it and waits for it (as the shim does)",
+                       "host_threads": nthreads,
+                       "picture_assignment": "decoding order; a free host thread takes the next picture, waits (stream events) for "
+                                             "its reference pictures, flushes it and waits for it (as the shim does)",
                        "recorder_in_timed_region": False,
                        "n_cu": st["n_cu"], "cu_modes": st["cu_modes"], "n_mc_units": st["n_mc_units"],
                        "n_mcx_units": st["n_mcx_units"], "n_aff_units": st["n_aff_units"], "n_tb_cmds": st["n_tb_cmds"],
                        "r_bar": round(st["r_bar"], 3), "coef_bytes": st["coef_bytes"],
                        "frame_algorithmic_bytes": int(sum(alg.values())),
                        "resident_replay_fps": round(fps_res, 2),
-                       "parallelism": f"frames x{world}" + (" + RCCL p2p reference push on the picture's stream" if world > 1 else "")
-                                      + f", {S} pictures in flight per GPU"},
+                       "parallelism": f"{S} pictures in flight per GPU" + (f"; a GOP per GPU over {world} GPUs, the key picture of a GOP "
+                                      "sent to the owner of the next GOP with RCCL point-to-point on a communication stream (no "
+                                      "collective, nothing waited for on the host)" if world > 1 else "")},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

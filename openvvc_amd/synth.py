@@ -37,7 +37,7 @@ def random_picture(rs, w, h):
     return smooth_plane(rs, h, w), smooth_plane(rs, h // 2, w // 2), smooth_plane(rs, h // 2, w // 2)
 
 
-def partition(rs: np.random.RandomState, pic_w: int, pic_h: int, ctu: int = 128, min_cu: int = 8):
+def partition(rs: np.random.RandomState, pic_w: int, pic_h: int, ctu: int = 128, min_cu: int = 8, max_cu: int = 128):
     """Random QT/BT partition of every CTU into CUs (x, y, log2w, log2h), RA-like size mix.
     Blocks crossing the picture border are split until they fit (implicit split)."""
     out = []
@@ -58,7 +58,7 @@ def partition(rs: np.random.RandomState, pic_w: int, pic_h: int, ctu: int = 128,
             return
         m = max(w, h)
         l2 = m.bit_length() - 1
-        if m > min_cu and rs.random_sample() < p_split.get(l2, 0.0):
+        if m > min_cu and (m > max_cu or rs.random_sample() < p_split.get(l2, 0.0)):
             k = rs.randint(0, 4)
             if k < 2 and w == h:
                 hw, hh = w // 2, h // 2
@@ -157,7 +157,7 @@ def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6
                  for p in ref0)
     refs = [ref0, ref1]
     pocs = [8, 24]                      # current picture would be POC 16
-    cus = partition(rs, w, h)
+    cus = partition(rs, w, h, max_cu=64 if ("intra" in set(tools) and intra_frac >= 1.0) else 128)      # an I picture: intra CUs are at most 64x64
     n = len(cus)
     rec = capi.Recorder(w, h)
     lw, lh = cus[:, 2], cus[:, 3]
@@ -185,7 +185,7 @@ def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6
         hot = area_hot[cus[:, 1] // 32, cus[:, 0] // 32]
         is_intra = ((hot & (rs.random_sample(n) < 0.85)) | (rs.random_sample(n) < intra_frac * 0.3) | (intra_frac >= 1.0)) & (lw <= 6) & (lh <= 6)
         if intra_frac >= 1.0:
-            assert is_intra.all() or (lw.max() > 6 or lh.max() > 6)
+            assert is_intra.all()
     else:
         is_intra = np.zeros(n, bool)
     if "affine" in tools:

@@ -13,6 +13,16 @@
 #include "ref_common.h"
 #include "ovvc_hip.h"
 #include "shim_stream.h"
+#include <time.h>
+
+/* "time" mode: seconds spent inside the reference's slots per stage (profiles/cpu_calibration.json: the oracle port is timed on
+ * the same cases from Python, tools/cpu_calibration.py) */
+enum { TS_ITX, TS_MC, TS_MCX, TS_MCA, TS_DBF, TS_SAO, TS_ALF, TS_INTRA, TS_N };
+static const char *g_ts_name[TS_N] = { "itx", "mc", "mcx", "mca", "dbf", "sao", "alf", "intra" };
+static double g_ts[TS_N];
+static int g_time;
+static inline double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
+#define TIMED(k, stmt) do { if (g_time) { const double t0_ = now_s(); stmt; g_ts[k] += now_s() - t0_; } else { stmt; } } while (0)
 
 /* struct TUInfo is private to rcn_transform_tree.c:51-66 (and duplicated in
  * vcl_transform_unit.c:47-75); the slot signature only forward-declares it. */
@@ -248,8 +258,8 @@ gen_itx(const char *dir)
                         /* derive_lfnst_mode_c's inputs as the decoder holds them: an explicit angular chroma mode */
                         c->part_ctx_c = &g_part;
                     }
-                    if (tree == 0) c->rcn_funcs.tmp.rcn_tu_st(c, x0, y0, l2w, l2h, d.cu_flags, d.cbf_mask, &tu);
-                    else           c->rcn_funcs.tmp.rcn_tu_c(c, x0, y0, l2w, l2h, d.cu_flags, d.cbf_mask, &tu);
+                    if (tree == 0) TIMED(TS_ITX, c->rcn_funcs.tmp.rcn_tu_st(c, x0, y0, l2w, l2h, d.cu_flags, d.cbf_mask, &tu));
+                    else           TIMED(TS_ITX, c->rcn_funcs.tmp.rcn_tu_c(c, x0, y0, l2w, l2h, d.cu_flags, d.cbf_mask, &tu));
                     if (g_shim) shim_case_end(c, &S, "itx");
 
                     uint32_t eoff[3] = { 0, 0, 0 };
@@ -438,11 +448,11 @@ gen_mc(const char *dir)
                 for (int j = 0; j < 64; ++j) { memset(cb->cb + j * cb->stride_c, 0xAB, 128); memset(cb->cr + j * cb->stride_c, 0xAB, 128); }
 
                 if (d.planes == 3)
-                    c->rcn_funcs.rcn_mcp_b(c, *cb, ic, c->part_ctx, mv0, mv1, x0, y0, l2w, l2h, d.inter_dir, d.ref_idx0, d.ref_idx1);
+                    TIMED(TS_MC, c->rcn_funcs.rcn_mcp_b(c, *cb, ic, c->part_ctx, mv0, mv1, x0, y0, l2w, l2h, d.inter_dir, d.ref_idx0, d.ref_idx1));
                 else if (d.planes == 1)
-                    c->rcn_funcs.rcn_mcp_b_l(c, *cb, ic, c->part_ctx, mv0, mv1, x0, y0, l2w, l2h, d.inter_dir, d.ref_idx0, d.ref_idx1);
+                    TIMED(TS_MC, c->rcn_funcs.rcn_mcp_b_l(c, *cb, ic, c->part_ctx, mv0, mv1, x0, y0, l2w, l2h, d.inter_dir, d.ref_idx0, d.ref_idx1));
                 else
-                    c->rcn_funcs.rcn_mcp_b_c(c, *cb, ic, c->part_ctx, mv0, mv1, x0, y0, l2w, l2h, d.inter_dir, d.ref_idx0, d.ref_idx1);
+                    TIMED(TS_MC, c->rcn_funcs.rcn_mcp_b_c(c, *cb, ic, c->part_ctx, mv0, mv1, x0, y0, l2w, l2h, d.inter_dir, d.ref_idx0, d.ref_idx1));
                 if (g_shim) shim_case_end(c, &S, "mc");
 
                 uint32_t eoff[3];
@@ -1339,8 +1349,8 @@ gen_dbf(const char *dir)
                             gbuf_push(&b_mv, ic->mv_ctx0.mvs, sizeof(ic->mv_ctx0.mvs));
                             gbuf_push(&b_mv, ic->mv_ctx1.mvs, sizeof(ic->mv_ctx1.mvs));
                         }
-                        if (!truncated) c->rcn_funcs.df.rcn_dbf_ctu(&c->rcn_ctx, d, 7, last_x, last_y);
-                        else            c->rcn_funcs.df.rcn_dbf_truncated_ctu(&c->rcn_ctx, d, 7, last_x, last_y, ctu_w, ctu_h);
+                        if (!truncated) TIMED(TS_DBF, c->rcn_funcs.df.rcn_dbf_ctu(&c->rcn_ctx, d, 7, last_x, last_y));
+                        else            TIMED(TS_DBF, c->rcn_funcs.df.rcn_dbf_truncated_ctu(&c->rcn_ctx, d, 7, last_x, last_y, ctu_w, ctu_h));
                         o.log2_ctu_s = 7; o.last_x = last_x; o.last_y = last_y;
                         o.ctu_lft = !!cx; o.ctu_abv = !!cy;
                         o.ctu_w = truncated ? ctu_w : 0; o.ctu_h = truncated ? ctu_h : 0;
@@ -1475,13 +1485,13 @@ gen_sao(const char *dir)
         for (int cy = 0; cy < ny; ++cy) {
             c->ctb_y = cy;
             if (cy == 0) {
-                c->rcn_funcs.sao.rcn_sao_first_pix_rows(c, &einfo, 0);
-                if (ny == 1) c->rcn_funcs.sao.rcn_sao_filter_line(c, &einfo, 0);
+                TIMED(TS_SAO, c->rcn_funcs.sao.rcn_sao_first_pix_rows(c, &einfo, 0));
+                if (ny == 1) TIMED(TS_SAO, c->rcn_funcs.sao.rcn_sao_filter_line(c, &einfo, 0));
             } else if (cy == ny - 1) {
-                c->rcn_funcs.sao.rcn_sao_filter_line(c, &einfo, cy - 1);
-                c->rcn_funcs.sao.rcn_sao_filter_line(c, &einfo, cy);
+                TIMED(TS_SAO, c->rcn_funcs.sao.rcn_sao_filter_line(c, &einfo, cy - 1));
+                TIMED(TS_SAO, c->rcn_funcs.sao.rcn_sao_filter_line(c, &einfo, cy));
             } else {
-                c->rcn_funcs.sao.rcn_sao_filter_line(c, &einfo, cy - 1);
+                TIMED(TS_SAO, c->rcn_funcs.sao.rcn_sao_filter_line(c, &einfo, cy - 1));
             }
         }
         if (g_shim) {
@@ -1585,7 +1595,7 @@ gen_alf(const char *dir)
         struct RectEntryInfo einfo;
         memset(&einfo, 0, sizeof(einfo));
         einfo.nb_ctu_w = nx; einfo.nb_ctu_h = ny;
-        for (int cy = 0; cy < ny; ++cy) { c->ctb_y = cy; c->rcn_funcs.alf.rcn_alf_filter_line(c, &einfo, cy); }
+        for (int cy = 0; cy < ny; ++cy) { c->ctb_y = cy; TIMED(TS_ALF, c->rcn_funcs.alf.rcn_alf_filter_line(c, &einfo, cy)); }
 
         if (g_shim) {
             size_t nc = 0, nt = 0;
@@ -1720,6 +1730,7 @@ gen_intra(const char *dir)
                         t.log2_w = l2w; t.log2_h = l2h; t.kind = chroma ? OVHIP_IT_CHROMA : OVHIP_IT_LUMA;
                         t.mode = (uint8_t)mode; t.flags = corner ? OVHIP_IF_CORNER : 0;
                         t.avl_lft = avl_lft; t.avl_abv = avl_abv; t.mrl_idx = mrl; t.level = 1;
+                        const double t_in = g_time ? now_s() : 0.0;
                         switch (kind) {
                         case 0: c->rcn_funcs.intra_pred(r, cb, mode, x0, y0, l2w, l2h, fl); break;
                         case 1: c->rcn_funcs.intra_pred_mrl(c, cb->y, cb->stride, mode, x0, y0, l2w, l2h, mrl); break;
@@ -1741,6 +1752,7 @@ gen_intra(const char *dir)
                             c->rcn_funcs.intra_pred_c(r, mode, x0, y0, l2w, l2h, fl); break; }
                         default: c->rcn_funcs.intra_pred_c(r, mode, x0, y0, l2w, l2h, fl); break;
                         }
+                        if (g_time) g_ts[TS_INTRA] += now_s() - t_in;
                         uint32_t eoff[2] = { 0, 0 };
                         if (!chroma) { eoff[0] = (uint32_t)b_exp.n; dump_rect(&b_exp, cb->y, cb->stride, x0, y0, w, h); }
                         else { eoff[0] = (uint32_t)b_exp.n; dump_rect(&b_exp, cb->cb, cb->stride_c, x0, y0, w, h);
@@ -1951,6 +1963,22 @@ main(int argc, char **argv)
     const char *dir = argc > 1 ? argv[1] : "../tests/golden";
     const char *only = argc > 2 ? argv[2] : NULL;
     if (only && !strcmp(only, "shim")) { g_shim = 1; only = argc > 3 ? argv[3] : NULL; }
+    if (only && !strcmp(only, "time")) {
+        /* five passes over the generators, the best time per stage; fixtures go to `dir` (use a scratch directory) */
+        double best[TS_N];
+        for (int k = 0; k < TS_N; ++k) best[k] = 1e30;
+        g_time = 1;
+        for (int pass = 0; pass < 5; ++pass) {
+            memset(g_ts, 0, sizeof(g_ts));
+            gen_itx(dir); gen_mc(dir); gen_dbf(dir); gen_sao(dir); gen_alf(dir); gen_intra(dir);
+            for (int k = 0; k < TS_N; ++k) if (g_ts[k] > 0 && g_ts[k] < best[k]) best[k] = g_ts[k];
+        }
+        printf("{");
+        int first = 1;
+        for (int k = 0; k < TS_N; ++k) if (best[k] < 1e29) { printf("%s\"%s\": %.6f", first ? "" : ", ", g_ts_name[k], best[k]); first = 0; }
+        printf("}\n");
+        return 0;
+    }
     if (!only || !strcmp(only, "itx")) gen_itx(dir);
     if (!only || !strcmp(only, "mc"))  gen_mc(dir);
     if (!only || !strcmp(only, "mcx")) gen_mcx(dir);

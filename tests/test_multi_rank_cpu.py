@@ -1,8 +1,7 @@
-"""CPU, 2 ranks over gloo: the frame-sharded N > 1 path of bench.py (openvvc_amd/frames.py).  Every rank
-decodes its own recorded picture (here with the oracle standing in for the HIP engine -- this test is about
-the exchange protocol, not the kernels), pushes the result to the next rank where it becomes reference
-picture 1 of that rank's next step, and after two steps every rank must hold exactly what a single-process
-simulation of the same schedule produces."""
+"""CPU: the random-access GOP schedule of the N > 1 path (openvvc_amd/gop.py): static properties for 1..8 ranks, and the schedule
+EXECUTED by 2 ranks over gloo -- every rank runs its program (receive / decode / send), decoding with the oracle standing in
+for the HIP engine (this test is about the schedule and the exchange, not the kernels), and every picture must come out exactly
+as a single-process decode of the same stream in decoding order produces it."""
 import hashlib
 import os
 import socket
@@ -16,17 +15,59 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = Path(__file__).resolve().parent.parent
-W, H, STEPS = 192, 128, 2
+sys.path.insert(0, str(ROOT))
+W, H = 192, 128
+N_GOPS, GOP, IP = 4, 4, 8          # 17 pictures: I, then four GOPs of four, every second key picture intra
 
 
-def _decode(seed, ref1_planes):
-    """One step of one rank: recorded picture `seed`, reference 1 replaced by `ref1_planes` if given."""
-    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+def test_gop_decode_order_and_references():
+    from openvvc_amd import gop
+    assert [p for p, _ in gop.gop_decode_order(16)] == [16, 8, 4, 2, 1, 3, 6, 5, 7, 12, 10, 9, 11, 14, 13, 15]
+    assert [l for _, l in gop.gop_decode_order(8)] == [0, 1, 2, 3, 3, 2, 3, 3]
+    pics = gop.build_stream(3, 16, 32, world=1)
+    assert len(pics) == 49 and pics[0].intra and pics[0].poc == 0
+    for p in pics:
+        assert all(r < p.idx for r in p.refs)                       # references are decoded before
+        if p.intra:
+            assert not p.refs
+        else:
+            pocs = [pics[r].poc for r in p.refs]
+            assert any(q < p.poc for q in pocs) and (p.layer == 0 or any(q > p.poc for q in pocs))
+            assert all(pics[r].layer <= p.layer or pics[r].gop == p.gop for r in p.refs)
+    keys = [p for p in pics if p.layer == 0 and p.gop >= 0]
+    assert [k.poc for k in keys] == [16, 32, 48] and [k.intra for k in keys] == [False, True, False]
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
+@pytest.mark.parametrize("gop_size,intra_period", [(16, 32), (32, 32), (32, 64), (4, 8)])
+def test_schedule_is_consistent(world, gop_size, intra_period):
+    """Only key pictures cross GPUs, one transfer per GOP; sends and receives pair up in one global order; the programs run to
+    completion under rendezvous semantics."""
+    from openvvc_amd import gop
+    pics = gop.build_stream(3 * world + 1, gop_size, intra_period, world)
+    gop.check_programs(pics, world)
+    tr = gop.transfers(pics)
+    assert all(pics[i].layer == 0 for i, _, _ in tr)
+    if world > 1:
+        assert len(tr) == 3 * world + 1 - 1 + (1 if world > 1 else 0) or len(tr) <= 3 * world + 1
+        assert all((d - s) % world == 1 or pics[i].gop == -1 for i, s, d in tr)
+    else:
+        assert not tr
+    # frame-level parallelism: with a GOP per GPU the dependency chain is the key pictures only where they are not intra
+    seq = float(len(pics))
+    cp = gop.critical_path(pics)
+    assert cp <= seq / min(world, 2) + gop_size or world == 1
+
+
+def _decode(pics, p, planes_of):
+    """Picture p of the stream: recorded picture seeded by its POC, reference pictures = the decoded pictures the schedule names."""
+    sys.path.insert(0, str(ROOT / "tests"))
     import oracle_pipeline
     from openvvc_amd import synth
-    wl = synth.make_workload(W, H, seed)
-    if ref1_planes is not None:
-        wl.refs[1] = ref1_planes
+    wl = synth.make_workload(W, H, 100 + p.poc)
+    if p.refs:
+        for k in range(len(wl.refs)):
+            wl.refs[k] = planes_of[p.refs[k % len(p.refs)]]
     out = oracle_pipeline.decode(wl)
     return out.y.copy(), out.cb.copy(), out.cr.copy()
 
@@ -38,26 +79,36 @@ def _pack(planes):
 def _unpack(t):
     a = t.numpy().astype(np.uint16)
     ys, cs = W * H, (W // 2) * (H // 2)
-    return a[:ys].reshape(H, W), a[ys:ys + cs].reshape(H // 2, W // 2), a[ys + cs:].reshape(H // 2, W // 2)
+    return a[:ys].reshape(H, W).copy(), a[ys:ys + cs].reshape(H // 2, W // 2).copy(), a[ys + cs:].reshape(H // 2, W // 2).copy()
+
+
+def _md5(planes):
+    return hashlib.md5(b"".join(p.tobytes() for p in planes)).hexdigest()
 
 
 def _rank_main(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, str(ROOT))
-    from openvvc_amd import frames
-    ref1 = None
-    recv = torch.empty(W * H * 3 // 2, dtype=torch.int16)
-    for step in range(STEPS):
-        out = _decode(100 + rank, ref1)
-        frames.ring_exchange(dist, _pack(out), recv, rank, world)
-        ref1 = tuple(p.copy() for p in _unpack(recv))
+    from openvvc_amd import gop
+    pics = gop.build_stream(N_GOPS, GOP, IP, world)
+    planes, digests = {}, {}
+    for op in gop.rank_program(pics, rank):
+        if op[0] == "recv":
+            t = torch.empty(W * H * 3 // 2, dtype=torch.int16)
+            dist.recv(t, src=op[2])
+            planes[op[1]] = _unpack(t)
+        elif op[0] == "send":
+            dist.send(_pack(planes[op[1]]), dst=op[2])
+        else:
+            planes[op[1]] = _decode(pics, pics[op[1]], planes)
+            digests[op[1]] = _md5(planes[op[1]])
     dist.barrier()
-    q.put((rank, hashlib.md5(b"".join(p.tobytes() for p in out)).hexdigest()))
+    q.put((rank, digests))
     dist.destroy_process_group()
 
 
-def test_two_rank_reference_exchange(built_lib):
+def test_two_rank_gop_schedule_executes(built_lib):
     world = 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -67,22 +118,19 @@ def test_two_rank_reference_exchange(built_lib):
     procs = [ctx.Process(target=_rank_main, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=600) for _ in range(world))
+    got = {}
+    for _ in range(world):
+        r, d = q.get(timeout=900)
+        assert not set(d) & set(got)
+        got.update(d)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    # single-process simulation of the same schedule
-    outs = [None] * world
-    ref1 = [None] * world
-    for step in range(STEPS):
-        outs = [_decode(100 + r, ref1[r]) for r in range(world)]
-        ref1 = [outs[(r - 1) % world] for r in range(world)]
-    want = {r: hashlib.md5(b"".join(p.tobytes() for p in outs[r])).hexdigest() for r in range(world)}
-    assert got == want
-    assert got[0] != got[1]
-
-
-def test_frame_owner():
-    sys.path.insert(0, str(ROOT))
-    from openvvc_amd import frames
-    assert [frames.frame_owner(k, 4) for k in range(6)] == [0, 1, 2, 3, 0, 1]
+    # single process, decoding order
+    from openvvc_amd import gop
+    pics = gop.build_stream(N_GOPS, GOP, IP, 1)
+    planes, want = {}, {}
+    for p in pics:
+        planes[p.idx] = _decode(pics, p, planes)
+        want[p.idx] = _md5(planes[p.idx])
+    assert got == want and len(set(want.values())) == len(pics)
