@@ -23,6 +23,7 @@ host).  Every rank decodes --steps pictures: the stream grows with N ("weak").
 Prints ONE JSON line on rank 0 (contract in the task statement).
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -97,12 +98,14 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--seed", type=int, default=0x266)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=6, help="pictures in flight per GPU (one HIP stream + one host thread each)")
+    ap.add_argument("--in-flight", type=int, default=16, help="pictures in flight per GPU (one HIP stream + one host thread each)")
     ap.add_argument("--contents", type=int, default=2, help="distinct recorded pictures (seeds) among the sets")
     ap.add_argument("--intra-frac", type=float, default=0.12, help="share of intra CUs in the B pictures")
     ap.add_argument("--gop", type=int, default=32, help="GOP size (hierarchical B, JVET random-access decoding order) = picture sets of the rotation")
-    ap.add_argument("--intra-period", type=int, default=32, help="every key picture at a multiple of this POC is an I picture (a multiple of --gop)")
+    ap.add_argument("--intra-period", type=int, default=64, help="every key picture at a multiple of this POC is an I picture (a multiple of --gop; JVET CTC: about one second, 64 at 50 / 60 Hz)")
     ap.add_argument("--intra-ctu", action="store_true", help="ordered pass as the one-launch CTU wavefront instead of one launch per level")
+    ap.add_argument("--device-waits", action="store_true", help="reference pictures as stream waits (barrier packets) instead of host waits before the launches")
+    ap.add_argument("--trace-gop", action="store_true", help="debug: host timeline of the pictures of the last run on stderr")
     ap.add_argument("--host-threads", type=int, default=-1, help="host threads issuing the flushes (-1: one per picture in flight)")
     args = ap.parse_args()
 
@@ -163,8 +166,9 @@ def main():
 
     order = gop.gop_decode_order(G)
     sets = [new_job(wls[n_b]) if j == 0 else new_job(wls[j % n_b]) for j in range(K)]         # set 0: the key picture as I picture
+    key_i = [sets[0], new_job(wls[n_b]), new_job(wls[n_b])]                                  # consecutive key pictures overlap: own jobs
     key_b = new_job(wls[0]) if IP > G else None                                              # ... and as inter key picture
-    all_jobs = sets + ([key_b] if key_b else [])
+    all_jobs = sets + key_i[1:] + ([key_b] if key_b else [])
     bufs_b = [torch_pic(ctxs[0]) for _ in range(K)]                    # destination of GOP position j (j >= 1)
     bufs_key = [torch_pic(ctxs[0], wls[0].refs[k % n_ref_slots]) for k in range(3)]
     bufs_recv = [torch_pic(ctxs[0], wls[0].refs[k % n_ref_slots]) for k in range(2)] if world > 1 else []
@@ -220,31 +224,57 @@ def main():
         mine_idx = {p.idx for p in mine}
         errs = []
 
-        def wait_for(stream, idxs):
+        def wait_for(stream, idxs, collect=None):
+            """Host: until the producers' flushes have been enqueued.  Device: `stream` behind their completion events -- or,
+            with `collect`, the events are handed to the flush, which waits for them after its uploads."""
             for q in idxs:
                 if q in mine_idx or (pics[q].owner != rank and q in buf):
                     issued[q].wait()
                     ev = done_ev.get(q)
                     if ev is not None:
-                        stream.wait_event(ev)
+                        if collect is not None:
+                            collect.append(ev)
+                        else:
+                            stream.wait_event(ev)
 
         def decode(p, slot):
+            t_pull = time.perf_counter()
             j = order.index((p.poc - p.gop * G, p.layer))
-            st = sets[j] if (j or p.intra or key_b is None) else key_b
+            st = sets[j] if j else (key_i[local_gop(p) % 3] if (p.intra or key_b is None) else key_b)
             stream = ext[slot]
-            wait_for(stream, p.refs)
+            evs = []
+            wait_for(stream, p.refs, evs)
             if p.idx in prev_occ:
-                wait_for(stream, [prev_occ[p.idx]] + readers.get(prev_occ[p.idx], []))
+                wait_for(stream, [prev_occ[p.idx]] + readers.get(prev_occ[p.idx], []), evs)
             refs = [buf[p.refs[k % len(p.refs)]][1] for k in range(n_ref_slots)] if p.refs else []
+            t_dep = time.perf_counter()
             with st.lock:
                 st.job.bind(ctxs[slot])
+                t_bind = time.perf_counter()
                 st.job.params.stages = ((capi.STAGE_ALL | capi.STAGE_RESIDENT) if resident else capi.STAGE_ALL) | lv
+                if args.device_waits:
+                    handles = (C.c_void_p * max(1, len(evs)))(*[e.cuda_event for e in evs])
+                    st.job.params.wait_events = C.cast(handles, C.POINTER(C.c_void_p))
+                    st.job.params.n_wait_events = len(evs)
+                    st.job.params.before_launch = None
+                else:
+                    # the frame thread waits for its reference pictures itself (ovdpb_frame_synchro), after its uploads are under way
+                    def host_wait(_user, evs=evs):
+                        for e in evs:
+                            e.synchronize()
+                        return 0
+                    cb = capi.BEFORE_LAUNCH_FN(host_wait)
+                    st.job.params.n_wait_events = 0
+                    st.job.params.before_launch = C.cast(cb, C.c_void_p)
                 st.job.flush(buf[p.idx][1], refs, None)
                 ev = torch.cuda.Event()
                 stream.record_event(ev)
                 done_ev[p.idx] = ev
                 issued[p.idx].set()
+                t_iss = time.perf_counter()
                 st.job.wait()
+            if args.trace_gop:
+                trace.append((p.idx, p.poc, p.layer, slot, t_pull, t_dep, t_bind, t_iss, time.perf_counter()))
 
         nxt, nlock = [0], threading.Lock()
 
@@ -286,6 +316,7 @@ def main():
                 for evt in issued.values():
                     evt.set()
 
+        trace = []
         th = [threading.Thread(target=worker, args=(s,)) for s in range(nthreads)]
         if world > 1:
             th.append(threading.Thread(target=comm))
@@ -294,6 +325,11 @@ def main():
         del keep_work[:-64]
         if errs:
             raise errs[0]
+        if args.trace_gop and rank == 0:
+            t0 = min(t[4] for t in trace)
+            for t in sorted(trace)[:2 * G]:
+                print("pic %3d poc %3d L%d slot %2d  pull %7.2f  deps %7.2f  bound %7.2f  issued %7.2f  done %7.2f ms" %
+                      (t[0], t[1], t[2], t[3], *[(x - t0) * 1e3 for x in t[4:]]), file=sys.stderr)
 
     def barrier():
         if world > 1:

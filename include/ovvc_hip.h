@@ -761,6 +761,17 @@ typedef struct ovhip_job_params {        /* picture-level side information; HOST
     const int16_t *alf_cc_coeff;                         /* [2][4][8]                                               */
     int32_t  log2_ctu_s;
     uint32_t stages;                     /* OVHIP_STAGE_* mask, 0 = all                                              */
+    /* HIP events (hipEvent_t handles) the LAUNCH chain waits for on the job's stream, after the uploads have been enqueued:
+     * the reference pictures (and the previous readers of dst) finishing on other streams.  The uploads do not depend on
+     * them and so overlap the pictures this one waits for.  NULL / 0: none. */
+    void *const *wait_events;
+    uint32_t n_wait_events;
+    /* Called by ovhip_job_flush on the flushing thread after the uploads have been enqueued and before the first launch: the
+     * place to wait ON THE HOST for the reference pictures (what the reference's frame threads do, ovdpb_frame_synchro,
+     * rcn_inter.c:131) while the uploads already run.  Unlike wait_events this leaves no barrier in the stream: a blocked
+     * stream blocks the hardware queue it shares with other streams.  Non-zero return aborts the flush with OVHIP_EINVAL. */
+    int (*before_launch)(void *user);
+    void *before_launch_user;
 } ovhip_job_params;
 
 typedef struct ovhip_job_stats {         /* what the last flush moved and launched */

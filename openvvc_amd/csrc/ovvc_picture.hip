@@ -407,6 +407,11 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
     if (j->resident) memcpy(packed, j->packed_prev, sizeof(packed)); else memcpy(j->packed_prev, packed, sizeof(packed));
     auto DEV = [&](int k) -> const void * { return packed[k] ? packed[k] : j->dev[k].p; };
     OV_HIP(ctx, hipEventRecord(j->ev_h2d, ctx->stream));
+    // everything below reads or writes pictures: behind the pictures this one depends on
+    for (uint32_t i = 0; i < pr->n_wait_events; ++i)
+        if (pr->wait_events && pr->wait_events[i]) OV_HIP(ctx, hipStreamWaitEvent(ctx->stream, (hipEvent_t)pr->wait_events[i], 0));
+    if (pr->before_launch && pr->before_launch(pr->before_launch_user))
+        return ov_fail(ctx, OVHIP_EINVAL, "ovhip_job_flush: before_launch callback failed", hipSuccess);
 
     const char *dp = (const char *)j->dev[B_PARAM].p;
     const uint16_t *d_fwd = pr->lmcs ? (const uint16_t *)(dp + L.fwd) : nullptr;

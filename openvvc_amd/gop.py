@@ -57,18 +57,23 @@ def build_stream(n_gops: int, gop_size: int = 32, intra_period: int = 32, world:
     for g in range(n_gops):
         base = g * gop_size
         decoded = {base: by_poc[base]}                       # POC -> idx of what this GOP may reference: the previous key ...
+        layer_of = {base: 0}
         for off, layer in gop_decode_order(gop_size):
             poc = base + off
             intra = layer == 0 and poc % intra_period == 0
             refs = []
             if not intra:
-                before = sorted((p for p in decoded if p < poc), reverse=True)[:refs_per_list]
-                after = sorted(p for p in decoded if p > poc)[:refs_per_list]
+                # only pictures of a LOWER temporal layer are reference pictures (the highest layer is never referenced):
+                # what makes the pictures of one layer independent of each other
+                ok = [p for p in decoded if layer_of[p] < layer or layer == 0]
+                before = sorted((p for p in ok if p < poc), reverse=True)[:refs_per_list]
+                after = sorted(p for p in ok if p > poc)[:refs_per_list]
                 refs = [decoded[p] for p in before] + [decoded[p] for p in after]
             idx = len(pics)
             pics.append(Picture(idx, g, poc, layer, intra, refs, g % world))
             by_poc[poc] = idx
             decoded[poc] = idx                               # ... and its own pictures decoded so far
+            layer_of[poc] = layer
     for p in pics:
         for r in p.refs:
             q = pics[r]

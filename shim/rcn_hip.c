@@ -167,6 +167,10 @@ fill_pu(struct hip_entry *e, const OVCTUDec *c, ovhip_pu_desc *d, int x0, int y0
     d->planes = 3;
     d->lmcs = c->lmcs_info.lmcs_enabled_flag;
     d->mv0x = mv0.x; d->mv0y = mv0.y; d->mv1x = mv1.x; d->mv1y = mv1.y;
+    /* reference picture resampling (rcn_mcp_rpr_*, rcn_inter.c:2769-2800): not on the device path */
+    if (((inter_dir & 1) && (ic->scale_fact_rpl0[mv0.ref_idx & 15][0] != (1 << RPR_SCALE_BITS) || ic->scale_fact_rpl0[mv0.ref_idx & 15][1] != (1 << RPR_SCALE_BITS)))
+        || ((inter_dir & 2) && (ic->scale_fact_rpl1[mv1.ref_idx & 15][0] != (1 << RPR_SCALE_BITS) || ic->scale_fact_rpl1[mv1.ref_idx & 15][1] != (1 << RPR_SCALE_BITS))))
+        latch(e, OVHIP_EUNSUP, "reference picture resampling (scaled reference picture)");
     if (p0 && (inter_dir & 1)) { d->poc0 = p0->poc; d->ref0 = (uint8_t)ref_slot(e, p0); }
     if (p1 && (inter_dir & 2)) { d->poc1 = p1->poc; d->ref1 = (uint8_t)ref_slot(e, p1); }
     if (inter_dir == 1) { d->ref1 = d->ref0; d->poc1 = d->poc0 + 1; }      /* keep the identical-motion test off */
@@ -448,6 +452,26 @@ hip_rcn_transform_tree(OVCTUDec *const c, uint8_t x0, uint8_t y0, uint8_t log2_t
         fill_bs_map(&c->dbf_info.bs2_map, x0, y0, log2_tb_w, log2_tb_h);
         fill_bs_map(&c->dbf_info.bs2_map_c, x0, y0, log2_tb_w, log2_tb_h);
     }
+}
+
+/* Tools the device path does not implement yet.  The scalar slots would reconstruct into the CTU scratch, which this back-end
+ * never copies to the frame: the picture would be silently wrong.  Latch an error instead (the picture is then not flushed and
+ * ovhip_shim_last_error() / the decoder log say why). */
+static void
+hip_recon_isp_subtree(OVCTUDec *const c, unsigned int x0, unsigned int y0, unsigned int log2_cb_w, unsigned int log2_cb_h, uint8_t intra_mode,
+                      const struct ISPTUInfo *const tu)
+{
+    (void)x0; (void)y0; (void)log2_cb_w; (void)log2_cb_h; (void)intra_mode; (void)tu;
+    struct hip_entry *e = entry_of(c, 0);
+    if (e) latch(e, OVHIP_EUNSUP, "intra sub-partition (ISP) coding unit");
+}
+
+static void
+hip_rcn_ibc(OVCTUDec *const c, int16_t x0, int16_t y0, uint8_t log2_cu_w, uint8_t log2_cu_h, uint8_t log2_ctu_s, IBCMV mv)
+{
+    (void)x0; (void)y0; (void)log2_cu_w; (void)log2_cu_h; (void)log2_ctu_s; (void)mv;
+    struct hip_entry *e = entry_of(c, 0);
+    if (e) latch(e, OVHIP_EUNSUP, "intra block copy (IBC) coding unit");
 }
 
 /* a CIIP CU without residual (no transform unit followed): its planar tasks alone */
@@ -1184,6 +1208,10 @@ rcn_init_functions_hip(struct RCNFunctions *f, uint8_t ict_type, uint8_t lm_chro
     f->tmp.rcn_transform_tree = &hip_rcn_transform_tree;
     f->tmp.rcn_tu_st = &hip_rcn_tu_st;
     f->tmp.rcn_tu_c  = &hip_rcn_tu_c;
+    f->tmp.recon_isp_subtree_h = &hip_recon_isp_subtree;
+    f->tmp.recon_isp_subtree_v = &hip_recon_isp_subtree;
+    f->rcn_ibc_l = &hip_rcn_ibc;
+    f->rcn_ibc_c = &hip_rcn_ibc;
     f->rcn_mcp = &hip_rcn_mcp;
     f->rcn_mcp_b = &hip_rcn_mcp_b;
     f->rcn_mcp_b_l = &hip_rcn_mcp_b_l;

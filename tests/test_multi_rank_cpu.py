@@ -33,7 +33,11 @@ def test_gop_decode_order_and_references():
         else:
             pocs = [pics[r].poc for r in p.refs]
             assert any(q < p.poc for q in pocs) and (p.layer == 0 or any(q > p.poc for q in pocs))
-            assert all(pics[r].layer <= p.layer or pics[r].gop == p.gop for r in p.refs)
+            assert all(pics[r].layer < p.layer or p.layer == 0 for r in p.refs)          # references come from lower temporal layers
+    depth = {}
+    for p in pics:
+        depth[p.idx] = 1 + max([depth[r] for r in p.refs if pics[r].gop == p.gop], default=0)
+    assert max(depth.values()) == 5                                                     # key + four B layers
     keys = [p for p in pics if p.layer == 0 and p.gop >= 0]
     assert [k.poc for k in keys] == [16, 32, 48] and [k.intra for k in keys] == [False, True, False]
 
