@@ -88,6 +88,7 @@ __device__ __forceinline__ void fetch_refs(IntraLds &s, const Acc acc, int x0, i
                                            int avl_abv, int avl_lft, int mrl, int lane)
 {
     const int na = 2 * w + mrl + 1, nl = 2 * h + mrl + 1;
+    const int l2u = unit == 4 ? 2 : 1;                                           // units are 4 luma / 2 chroma samples
     const int cx = x0 - 1 - mrl, cy = y0 - 1 - mrl;                               // sample (k = 0) of both arms
 #define ABV(k) acc.ld(cx + (k), cy)
 #define LFT(k) acc.ld(cx, cy + (k))
@@ -100,7 +101,7 @@ __device__ __forceinline__ void fetch_refs(IntraLds &s, const Acc acc, int x0, i
         const int kk = min(k, na - 1);
         if (none) v = 1 << (OV_BD - 1);
         else if (kk <= mrl) v = corner ? ABV(kk) : ((mrl == 0 && avl_abv && avl_lft) ? a1 : (avl_lft ? l1 : a1));
-        else if ((kk - mrl - 1) / unit < avl_abv) v = ABV(kk);
+        else if (((kk - mrl - 1) >> l2u) < avl_abv) v = ABV(kk);
         else v = avl_abv ? ABV(la) : (corner ? ABV(mrl) : l1);
         s.abv[IR_NEG + k] = (uint16_t)v;
     }
@@ -109,7 +110,7 @@ __device__ __forceinline__ void fetch_refs(IntraLds &s, const Acc acc, int x0, i
         const int kk = min(k, nl - 1);
         if (none) v = 1 << (OV_BD - 1);
         else if (kk <= mrl) v = corner ? LFT(kk) : (avl_lft ? l1 : a1);
-        else if ((kk - mrl - 1) / unit < avl_lft) v = LFT(kk);
+        else if (((kk - mrl - 1) >> l2u) < avl_lft) v = LFT(kk);
         else v = avl_lft ? LFT(ll) : (corner ? LFT(mrl) : a1);
         s.lft[IR_NEG + k] = (uint16_t)v;
     }
@@ -513,6 +514,13 @@ struct CtuLds {
 };
 
 typedef unsigned long long u64;
+// OVHIP_CTU_PROBE (debug builds only, tools/debug/ctu_probe.py): per-CTU wall-clock stamps (100 MHz) of the phases
+#ifdef OVHIP_CTU_PROBE
+__device__ u64 *g_probe;
+#define PROBE(k) do { if (tid == 0 && g_probe && blockIdx.x < 64 && (k) < 256) g_probe[blockIdx.x * 256 + (k)] = wall_clock64(); } while (0)
+#else
+#define PROBE(k) do { } while (0)
+#endif
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 __device__ __forceinline__ ovhip_itask uniform_task(const ovhip_itask *p)
@@ -626,6 +634,7 @@ __global__ __launch_bounds__(256) void k_intra_ctu(ovhip_pic pic, ovhip_pic res,
         if (L.abort) return;
     }
 
+    PROBE(0);
     // ---- 2. the CTU and its borders into LDS (8-byte granules; widths are multiples of 8) ----
     {
         const int gx0 = X0 ? -1 : 0;                                   // first granule: the left border
@@ -665,7 +674,9 @@ __global__ __launch_bounds__(256) void k_intra_ctu(ovhip_pic pic, ovhip_pic res,
         }
     }
 
+    PROBE(1);
     // ---- 3. the CTU's tasks: runs of equal level, the items of a run spread over the four waves ----
+    int n_run = 0;
     for (unsigned base = 0; base < c.n; base += CT_CHUNK) {
         const int nchunk = (int)min((unsigned)CT_CHUNK, c.n - base);
         __syncthreads();
@@ -686,8 +697,10 @@ __global__ __launch_bounds__(256) void k_intra_ctu(ovhip_pic pic, ovhip_pic res,
             }
             __syncthreads();
             i = j;
+            PROBE(4 + n_run); ++n_run;
         }
     }
+    PROBE(2);
 
     // ---- 4. publish: write-through stores, every wave drains, one flag ----
     {
@@ -706,7 +719,8 @@ __global__ __launch_bounds__(256) void k_intra_ctu(ovhip_pic pic, ovhip_pic res,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) __hip_atomic_store(flags + c.cy * ncx + c.cx, epoch, RLX_AGENT);
-    (void)hc;
+    PROBE(3);
+    (void)hc; (void)n_run;
 }
 
 } // namespace
@@ -745,6 +759,14 @@ extern "C" int ovhip_intra_level_launch(ovhip_ctx *ctx, const ovhip_pic *pic, co
     OV_LAUNCH_CHECK(ctx, "k_intra_level");
     return OVHIP_OK;
 }
+
+#ifdef OVHIP_CTU_PROBE
+extern "C" int ovhip_debug_set_ctu_probe(void *d_buf)
+{
+    u64 *p = (u64 *)d_buf;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_probe), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // Words of the synchronisation block ovhip_intra_ctu_launch needs for a w x h picture (device memory, zeroed ONCE by the owner).
 extern "C" size_t ovhip_intra_sync_words(int32_t width, int32_t height, int32_t log2_ctu_s)
