@@ -415,8 +415,9 @@ def main():
             if tj["workload"] == {"width": W, "height": H, "seed": args.seed}:
                 names = [n.strip() for n in KNAME[dom].split("(")[0].split("+")]
                 ks = [tj["kernels"][n] for n in names]
-                per_group = mean_stat("n_ilevels") if dom == "intra" else (2 if dom in ("itx_luma", "itx_chroma") else 1)   # dispatches per launch group
-                traffic = int(sum(2 * k["fetch_kib"] + k["write_kib"] for k in ks) * 1024 * (per_group if dom == "intra" else 1))
+                # a launch group = one dispatch, except the ordered pass: one per level, averaged over the intra period
+                per_group = (wls[-1].stats["n_ilevels"] + (IP - 1) * wls[0].stats["n_ilevels"]) / IP if dom == "intra" else 1
+                traffic = int(sum(2 * k["fetch_kib"] + k["write_kib"] for k in ks) * 1024 * per_group)
         except (OSError, KeyError, ValueError):
             traffic = None
         roofline = {"bound": "hbm", "kernel": KNAME[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
@@ -469,7 +470,8 @@ def main():
                        "intra_tasks_per_b_picture": st["n_itasks"], "intra_levels_per_b_picture": st["n_ilevels"],
                        "intra_levels_per_i_picture": wls[-1].stats["n_ilevels"],
                        "h2d_bytes_per_step": int(mean_stat("h2d_bytes")), "d2h_bytes_per_step": int(mean_stat("d2h_bytes")),
-                       "launches_per_step": round(mean_stat("n_launches"), 1), "h2d_copies_per_step": round(mean_stat("n_h2d"), 1),
+                       "launches_per_step": round((int(all_stats[0].n_launches) + (IP - 1) * int(js.n_launches)) / IP, 1),
+                       "h2d_copies_per_step": round(mean_stat("n_h2d"), 1),
                        "launches_per_b_picture": int(js.n_launches),
                        "launches_per_i_picture": int(all_stats[0].n_launches),
                        "distinct_pictures": K, "distinct_contents": len(wls), "working_set_bytes": int(working_set),
