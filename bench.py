@@ -118,11 +118,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU fallback")
+    # OVVC_BENCH_DEBUG_GLOO=1 (development only): all ranks on GPU 0, pictures exchanged through host memory over gloo -- runs
+    # the N > 1 control flow (schedule, communication thread, events) on a one-GPU box.  Never set by the driver.
+    debug_gloo = os.environ.get("OVVC_BENCH_DEBUG_GLOO") == "1"
+    if debug_gloo:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if debug_gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     W, H = args.width, args.height
     S = max(1, args.in_flight)
@@ -300,13 +308,23 @@ def main():
                     for op in prog:
                         if op[0] == "send" and op[1] in mine_idx:
                             wait_for(comm_stream, [op[1]])
+                            if debug_gloo:
+                                comm_stream.synchronize()
+                                dist.send(buf[op[1]][0].cpu(), op[2])
+                                continue
                             keep_work.append(dist.isend(buf[op[1]][0], op[2]))
                         elif op[0] == "recv" and op[1] in buf and any(op[1] in q.refs for q in mine):
                             if op[1] in prev_occ:
                                 wait_for(comm_stream, [prev_occ[op[1]]] + readers.get(prev_occ[op[1]], []))
-                            w = dist.irecv(buf[op[1]][0], op[2])
-                            w.wait()          # NCCL: orders the communication stream behind the transfer, the host does not block
-                            keep_work.append(w)
+                            if debug_gloo:
+                                comm_stream.synchronize()
+                                t_host = torch.empty(buf[op[1]][0].shape, dtype=torch.int16)
+                                dist.recv(t_host, op[2])
+                                buf[op[1]][0].copy_(t_host)
+                            else:
+                                w = dist.irecv(buf[op[1]][0], op[2])
+                                w.wait()      # NCCL: orders the communication stream behind the transfer, the host does not block
+                                keep_work.append(w)
                             ev = torch.cuda.Event()
                             comm_stream.record_event(ev)
                             done_ev[op[1]] = ev
@@ -345,7 +363,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=None if debug_gloo else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
@@ -384,7 +402,7 @@ def main():
     kern = {k: v for k, v in survey.items() if k != "h2d"}
     dom = max(kern, key=kern.get)
     if world > 1:
-        pick = torch.tensor([present.index(dom)], dtype=torch.int64, device=dev)
+        pick = torch.tensor([present.index(dom)], dtype=torch.int64, device=None if debug_gloo else dev)
         dist.broadcast(pick, 0)
         dom = present[int(pick.item())]
 

@@ -377,7 +377,13 @@ enum {                        /* ovhip_itask.flags */
     OVHIP_IF_BDPCM_VER = 16,
     OVHIP_IF_RES_Y = 32, OVHIP_IF_RES_CB = 64, OVHIP_IF_RES_CR = 128,   /* a STOREd residual exists for that plane    */
     OVHIP_IF_RES_SCALE = 256, /* chroma residual is LMCS-scaled with c_scale ...                                     */
-    OVHIP_IF_SCALE_IDX = 512  /* ... which is the index of a chroma-scale region                                      */
+    OVHIP_IF_SCALE_IDX = 512, /* ... which is the index of a chroma-scale region                                      */
+    OVHIP_IF_CORNER_L = 2048, /* ISP only: the corner unit as the LEFT arm's progress map sees it (OVHIP_IF_CORNER: as the above
+                               * arm's map sees it; for every other task the two coincide)                                */
+    OVHIP_IF_ISP = 1024       /* a prediction call of an intra-sub-partition CU (intra_pred_isp, rcn_intra.c:566-640): the
+                               * reference arms are the CODING UNIT's (isp_* fields), shifted by the partition's offset; always
+                               * the 4-tap cubic filter, no reference smoothing, wide angles by the CU's shape, PDPC only for
+                               * blocks at least 4 samples high                                                           */
 };
 typedef struct ovhip_itask {
     uint16_t x, y;            /* top-left in samples of the task's plane(s), picture coordinates                      */
@@ -397,7 +403,14 @@ typedef struct ovhip_itask {
     uint16_t level;           /* >= 1                                                                                 */
     uint16_t ctu_deps;        /* set by the recorder: 0x8000 | log2_ctu << 8 | neighbour CTUs (bit 0 left, 1 above-left, 2 above,
                                * 3 above-right) holding ordered tasks whose samples this task reads; 0 = unknown            */
-    uint16_t pad[6];
+    uint8_t  isp_log2_cb_w, isp_log2_cb_h;   /* OVHIP_IF_ISP: the coding unit's size ...                                       */
+    uint8_t  isp_off_x, isp_off_y;           /* ... and this block's offset inside it; avl_abv / avl_lft / the corner flag then
+                                              * describe the CU's arms (above arm from (x - off_x - 1, y - 1), 2 cb_w + 1 long;
+                                              * left arm from (x - 1, y - off_y - 1), 2 cb_h + 1 long)                         */
+    uint8_t  isp_log2_pb;     /* OVHIP_IF_ISP: width of one partition inside this block (vertical partitions narrower than 4 are
+                               * predicted 4 columns at a time) and ...                                                  */
+    uint8_t  isp_res_mask;    /* ... which of them carry a residual (bit = x >> isp_log2_pb); the others add nothing        */
+    uint16_t pad[3];
 } ovhip_itask;
 
 /* ------------------------------------------------------------------------------------
@@ -530,6 +543,32 @@ int   ovhip_rec_tu(ovhip_recorder *rec, const ovhip_tu_state *st, const ovhip_tu
  * Returns the number of transform-block commands appended or <0. */
 int   ovhip_rec_tu_intra(ovhip_recorder *rec, const ovhip_tu_state *st, const ovhip_tu_desc *tu, const ovhip_itask *intra_l,
                          const ovhip_itask *intra_c);
+/* tmp.recon_isp_subtree_v / _h (rcn_structures.h:480-491; rcn_transform_tree.c:1087-1205): an intra-sub-partition CU -- 2 or
+ * 4 partitions side by side (vertical) or stacked; prediction and residual alternate partition by partition, so every
+ * prediction call becomes an ordered task and every partition's transform block a STORE-mode command.  The partition
+ * geometry, the transform types (DST-VII where mts_enabled and the side is 4..16) and the 1xN / 2xN / Nx1 / Nx2 block
+ * paths are derived here as the reference derives them.  Vertical partitions narrower than 4 are predicted 4 columns at a
+ * time (:1123-1138).  Returns the number of commands appended or <0. */
+typedef struct ovhip_isp_desc {
+    uint16_t x0, y0;                  /* luma position of the CU in the picture                                          */
+    uint8_t  log2_cb_w, log2_cb_h;
+    uint8_t  vertical;                /* 1: recon_isp_subtree_v, 0: recon_isp_subtree_h                                    */
+    uint8_t  intra_mode;
+    uint8_t  cbf_mask;                /* ISPTUInfo.cbf_mask: bit (nb_partitions - 1 - i) = partition i                     */
+    uint8_t  lfnst_flag, lfnst_idx;
+    uint8_t  mts_enabled;             /* ctudec->mts_enabled (:1110, :1180)                                                */
+    /* per PREDICTION call, in call order (vertical: one per 4 columns; horizontal: one per partition): what fill_ref_left_0 /
+     * fill_ref_above_0 read out of the progress bit-fields with the CU's geometry (rcn_intra.c:584-594) */
+    uint8_t  corner[4];               /* bit 0: the above arm's map, bit 1: the left arm's map                                  */
+    uint8_t  avl_abv[4], avl_lft[4];
+    uint16_t last_pos[4];             /* ISPTUInfo.tb_info[i]                                                              */
+    uint64_t sig_sb_map[4];
+    const int16_t *coef;              /* ctudec->residual_y: partition i at i << (log2_tb_w + log2_tb_h)                   */
+} ovhip_isp_desc;
+int   ovhip_rec_isp_cu(ovhip_recorder *rec, const ovhip_tu_state *st, const ovhip_isp_desc *cu);
+/* Number and size of the partitions and of the prediction calls of an ISP CU, as recon_isp_subtree_* derive them. */
+void  ovhip_isp_geometry(int32_t log2_cb_w, int32_t log2_cb_h, int32_t vertical, int32_t *log2_pb, int32_t *n_pb, int32_t *log2_pred,
+                         int32_t *n_pred);
 /* The ordered tasks in decoding order, and sorted by level: level_start[l] .. level_start[l + 1] are the tasks of level
  * l + 1 (n_levels + 1 entries).  Sorting happens in the call. */
 const ovhip_itask *ovhip_rec_itasks(const ovhip_recorder *rec, size_t *n);

@@ -115,19 +115,21 @@ assert LMCS_REGION_DTYPE.itemsize == 8
 
 ITASK_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("log2_w", "u1"), ("log2_h", "u1"), ("kind", "u1"), ("mode", "u1"),
                         ("flags", "<u2"), ("avl_lft", "u1"), ("avl_abv", "u1"), ("mrl_idx", "u1"), ("ciip_wt", "u1"),
-                        ("c_scale", "<i2"), ("level", "<u2"), ("ctu_deps", "<u2"), ("pad", "<u2", 6)])
+                        ("c_scale", "<i2"), ("level", "<u2"), ("ctu_deps", "<u2"),
+                        ("isp_log2_cb_w", "u1"), ("isp_log2_cb_h", "u1"), ("isp_off_x", "u1"), ("isp_off_y", "u1"), ("isp_log2_pb", "u1"), ("isp_res_mask", "u1"), ("pad", "<u2", 3)])
 assert ITASK_DTYPE.itemsize == 32
 ICTU_DTYPE = np.dtype([("cx", "<u2"), ("cy", "<u2"), ("first", "<u4"), ("n", "<u4"), ("deps", "<u4")])
 assert ICTU_DTYPE.itemsize == 16
 IT_LUMA, IT_CHROMA, IT_REGION, IT_RES_C = 0, 1, 2, 3
-IF_CORNER, IF_MIP, IF_MIP_TR, IF_BDPCM, IF_BDPCM_VER, IF_RES_Y, IF_RES_CB, IF_RES_CR, IF_RES_SCALE, IF_SCALE_IDX = (1 << k for k in range(10))
+IF_CORNER, IF_MIP, IF_MIP_TR, IF_BDPCM, IF_BDPCM_VER, IF_RES_Y, IF_RES_CB, IF_RES_CR, IF_RES_SCALE, IF_SCALE_IDX, IF_ISP, IF_CORNER_L = (1 << k for k in range(12))
 
 
 class ITask(C.Structure):
     """ovhip_itask (include/ovvc_hip.h)."""
     _fields_ = [("x", C.c_uint16), ("y", C.c_uint16), ("log2_w", C.c_uint8), ("log2_h", C.c_uint8), ("kind", C.c_uint8), ("mode", C.c_uint8),
                 ("flags", C.c_uint16), ("avl_lft", C.c_uint8), ("avl_abv", C.c_uint8), ("mrl_idx", C.c_uint8), ("ciip_wt", C.c_uint8),
-                ("c_scale", C.c_int16), ("level", C.c_uint16), ("ctu_deps", C.c_uint16), ("pad", C.c_uint16 * 6)]
+                ("c_scale", C.c_int16), ("level", C.c_uint16), ("ctu_deps", C.c_uint16),
+                ("isp_log2_cb_w", C.c_uint8), ("isp_log2_cb_h", C.c_uint8), ("isp_off_x", C.c_uint8), ("isp_off_y", C.c_uint8), ("isp_log2_pb", C.c_uint8), ("isp_res_mask", C.c_uint8), ("pad", C.c_uint16 * 3)]
 
 
 assert C.sizeof(ITask) == 32
@@ -330,6 +332,8 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_intra_sync_words": (C.c_size_t, [i32, i32, i32]),
         "ovhip_intra_ctu_launch": (C.c_int, [vp, P(Pic), P(Pic), vp, vp, u32, vp, vp, vp, i32, vp, u32, vp]),
         "ovhip_rec_itask_levels": (u32, [vp]),
+        "ovhip_rec_isp_cu": (C.c_int, [vp, vp, vp]),
+        "ovhip_isp_geometry": (None, [i32, i32, i32, P(i32), P(i32), P(i32), P(i32)]),
         "ovhip_job_bind": (C.c_int, [vp, vp]),
         "ovhip_rec_set_ctu_size": (C.c_int, [vp, i32]),
         "ovhip_rec_itasks_by_ctu": (vp, [vp, i32, P(C.c_size_t), P(vp), P(C.c_size_t)]),
@@ -367,7 +371,7 @@ EXPORTED_SYMBOLS = [
     "ovhip_pic_download", "ovhip_itx_launch", "ovhip_mc_launch",
     "ovhip_rec_create_ex", "ovhip_rec_set_dense_dbf_planes", "ovhip_rec_dbf_edges", "ovhip_dbf_launch_edges_ex",
     "ovhip_dmvr_search_launch", "ovhip_rec_append_raw", "ovhip_rec_set_dbf_offsets", "ovhip_rec_tu_intra", "ovhip_rec_itasks", "ovhip_rec_itasks_sorted", "ovhip_itx_launch_classes_res", "ovhip_intra_level_launch", "ovhip_intra_level_geom", "ovhip_intra_sync_words", "ovhip_intra_ctu_launch",
-    "ovhip_rec_itask_levels", "ovhip_rec_itasks_by_ctu", "ovhip_rec_set_ctu_size", "ovhip_job_bind", "ovhip_job_create", "ovhip_job_destroy", "ovhip_job_recorder", "ovhip_job_begin",
+    "ovhip_rec_itask_levels", "ovhip_rec_isp_cu", "ovhip_isp_geometry", "ovhip_rec_itasks_by_ctu", "ovhip_rec_set_ctu_size", "ovhip_job_bind", "ovhip_job_create", "ovhip_job_destroy", "ovhip_job_recorder", "ovhip_job_begin",
     "ovhip_job_flush", "ovhip_job_wait", "ovhip_job_refined_mvs", "ovhip_job_dmvr_rows", "ovhip_job_last_stats", "ovhip_job_time_stage", "ovhip_job_stage_time",
 ]
 

@@ -118,6 +118,39 @@ __device__ __forceinline__ void fetch_refs(IntraLds &s, const Acc acc, int x0, i
 #undef LFT
 }
 
+// Reference arms of an ISP prediction call (OVHIP_IF_ISP): the CODING UNIT's arms as fill_ref_above_0 / fill_ref_left_0 build
+// them (rcn_fill_ref.c:71-150, :320-390), shifted by the block's offset and cut at cb + pb samples (intra_pred_isp,
+// rcn_intra.c:584-603).  Per arm and in closed form: S(k) = sample k steps from the CU arm's corner, c = corner unit available in
+// this arm's map, a = units available behind it, other = the other arm has anything, F = the other arm's first sample here.
+template <class Acc>
+__device__ __forceinline__ void fetch_refs_isp(IntraLds &s, const Acc acc, const ovhip_itask &t, int lane)
+{
+    const int w = 1 << t.log2_w, h = 1 << t.log2_h, cbw = 1 << t.isp_log2_cb_w, cbh = 1 << t.isp_log2_cb_h;
+    const int ox = t.isp_off_x, oy = t.isp_off_y, x0 = t.x, y0 = t.y;
+    const bool ca = t.flags & OVHIP_IF_CORNER, cl = t.flags & OVHIP_IF_CORNER_L;
+    const int aa = t.avl_abv, al = t.avl_lft;
+    for (int arm = 0; arm < 2; ++arm) {
+        const int cb = arm ? cbh : cbw, pb = arm ? h : w, off = arm ? oy : ox, a = arm ? al : aa;
+        const bool c = arm ? cl : ca, other = arm ? (ca || aa) : (cl || al);
+        const int n_cu = 2 * cb + 1, nb_ref = (2 * cb) / 4 + 1, len = cb + pb, last = min(4 * a, n_cu + 3);
+        uint16_t *out = (arm ? s.lft : s.abv) + IR_NEG;
+        for (int k = lane; k < len + 1 + 24; k += 64) {
+            const int kk = min(k, len) + off;
+            int v;
+            if (c && a >= nb_ref) {
+                const int q = min(kk, n_cu - 1);
+                v = arm ? acc.ld(x0 - 1, y0 - oy - 1 + q) : acc.ld(x0 - ox - 1 + q, y0 - 1);
+            } else if (c || a) {
+                const int q = kk == 0 ? (c ? 0 : 1) : (a ? min(kk, last) : 0);
+                v = arm ? acc.ld(x0 - 1, y0 - oy - 1 + q) : acc.ld(x0 - ox - 1 + q, y0 - 1);
+            } else {
+                v = other ? (arm ? acc.ld(x0, y0 - 1) : acc.ld(x0 - 1, y0)) : 1 << (OV_BD - 1);
+            }
+            out[k] = (uint16_t)v;
+        }
+    }
+}
+
 // filter_ref_samples (rcn_fill_ref.c:41-68) on both arms: [0] from the two arms, [1 2 1] up to len - 1, the rest copied
 __device__ void smooth_refs(IntraLds &s, int len_a, int len_l, int lane)
 {
@@ -144,9 +177,10 @@ __device__ __forceinline__ int res_scale(int v, int scale)
 __device__ void pred_regular(IntraLds &s, const ovhip_itask &t, bool is_luma, const Strip st, int lane)
 {
     const int l2w = t.log2_w, l2h = t.log2_h, w = 1 << l2w, h = 1 << l2h, n = w * h;
-    const int mrl = is_luma ? t.mrl_idx : 0;
+    const bool isp = t.flags & OVHIP_IF_ISP;          // always cubic, never smoothed, PDPC from 4 rows on, wide angles by the CU
+    const int mrl = (is_luma && !isp) ? t.mrl_idx : 0;
     const bool bdpcm = t.flags & OVHIP_IF_BDPCM;
-    const bool pdpc_ok = !mrl && !bdpcm && (is_luma || (l2w > 1 && l2h > 1));
+    const bool pdpc_ok = isp ? l2h > 1 : (!mrl && !bdpcm && (is_luma || (l2w > 1 && l2h > 1)));
     const uint16_t *abv = s.abv + IR_NEG, *lft = s.lft + IR_NEG;
     if (bdpcm) {
         const bool ver = t.flags & OVHIP_IF_BDPCM_VER;
@@ -156,7 +190,7 @@ __device__ void pred_regular(IntraLds &s, const ovhip_itask &t, bool is_luma, co
     int mode = t.mode;
     if (mode == 0) {
         const uint16_t *a = abv + mrl, *l = lft + mrl;
-        if (is_luma && !mrl && l2w + l2h > 5) { smooth_refs(s, w + 4, h + 4, lane); wave_sync(); a = s.fabv + IR_NEG; l = s.flft + IR_NEG; }
+        if (is_luma && !isp && !mrl && l2w + l2h > 5) { smooth_refs(s, w + 4, h + 4, lane); wave_sync(); a = s.fabv + IR_NEG; l = s.flft + IR_NEG; }
         const int scale = (l2w + l2h - 2) >> 2;
         for (int p = st.p0 + lane; p < st.p1; p += 64) {
             const int x = p & (w - 1), y = p >> l2w;
@@ -186,17 +220,20 @@ __device__ void pred_regular(IntraLds &s, const ovhip_itask &t, bool is_luma, co
         return;
     }
     // wide-angle remap (derive_wide_angular_mode, rcn_intra.c:54-66; the reference's numbering below mode 2)
-    if (l2w != l2h) {
-        const int r = abs(l2w - l2h);
-        if (l2w > l2h && mode < (r > 1 ? 8 + 2 * r : 8)) mode += 65;
-        else if (l2h > l2w && mode > (r > 1 ? 60 - 2 * r : 60)) mode -= 65;
+    {
+        const int sw = isp ? t.isp_log2_cb_w : l2w, sh = isp ? t.isp_log2_cb_h : l2h;
+        if (sw != sh) {
+            const int r = abs(sw - sh);
+            if (sw > sh && mode < (r > 1 ? 8 + 2 * r : 8)) mode += 65;
+            else if (sh > sw && mode > (r > 1 ? 60 - 2 * r : 60)) mode -= 65;
+        }
     }
     const bool vertical = mode >= 34;
     const int midx = vertical ? mode - 50 : 18 - mode, am = abs(midx);
     const int angle_abs = s.ang[am], inv = s.inv_ang[am];
     const int angle = midx < 0 ? -angle_abs : angle_abs;
     bool use_fg = false, smoothed = false;
-    if (is_luma && !mrl && l2w + l2h > 5 && am > (int)((0x000000020E181818ull >> (8 * ((l2w + l2h) >> 1))) & 0xff)) {
+    if (is_luma && !isp && !mrl && l2w + l2h > 5 && am > (int)((0x000000020E181818ull >> (8 * ((l2w + l2h) >> 1))) & 0xff)) {
         if (!(angle_abs & 31)) { smooth_refs(s, 2 * w, 2 * h, lane); wave_sync(); smoothed = true; }
         else use_fg = true;
     }
@@ -445,12 +482,14 @@ __global__ __launch_bounds__(64) void k_intra_level(ovhip_pic pic, ovhip_pic res
     const int ciip_wt = res_only ? 0 : t.ciip_wt;
     const bool need_d = ciip_wt || res_only;
 
+    // ISP blocks of several thin partitions: only those that carry a residual add one
+    const int res_mask = (t.flags & OVHIP_IF_ISP) ? t.isp_res_mask : 0xff, res_l2pb = (t.flags & OVHIP_IF_ISP) ? t.isp_log2_pb : 6;
     // everything the epilogue needs from memory is requested before the prediction starts
     int rv[NPL], dv[NPL];
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
         const int p = st.p0 + lane + 64 * i, x = p & (w - 1), y = p >> l2w;
-        rv[i] = (has_res && p < st.p1) ? rp[y * rstride + x] : 0;
+        rv[i] = (has_res && p < st.p1 && ((res_mask >> (x >> res_l2pb)) & 1)) ? rp[y * rstride + x] : 0;
         dv[i] = (need_d && p < st.p1) ? dst[y * dstride + x] : 0;
     }
     const bool scaled = !luma && (t.flags & OVHIP_IF_RES_SCALE);
@@ -458,7 +497,8 @@ __global__ __launch_bounds__(64) void k_intra_level(ovhip_pic pic, ovhip_pic res
 
     if (!res_only) {
         if (luma) {
-            fetch_refs(s, ya, t.x, t.y, w, h, 4, t.flags & OVHIP_IF_CORNER, t.avl_abv, t.avl_lft, (t.flags & OVHIP_IF_MIP) ? 0 : t.mrl_idx, lane);
+            if (t.flags & OVHIP_IF_ISP) fetch_refs_isp(s, ya, t, lane);
+            else fetch_refs(s, ya, t.x, t.y, w, h, 4, t.flags & OVHIP_IF_CORNER, t.avl_abv, t.avl_lft, (t.flags & OVHIP_IF_MIP) ? 0 : t.mrl_idx, lane);
             wave_sync();
             if (t.flags & OVHIP_IF_MIP) pred_mip(s, t, st, lane);
             else pred_regular(s, t, true, st, lane);
@@ -562,10 +602,12 @@ __device__ void ctu_item(CtuLds &L, IntraLds &s, const ovhip_itask &t, int strip
     uint16_t *dst = luma ? &L.ty[ty][tx] : &L.tc[comp][ty][tx];
     const int16_t *rp = luma ? &L.ry[ty][tx - 4] : &L.rc[comp][ty][tx - 4];
     const int dstride = luma ? CT_YS : CT_CS, rstride = luma ? CT_S : CT_S / 2;
+    const int res_mask = (t.flags & OVHIP_IF_ISP) ? t.isp_res_mask : 0xff, res_l2pb = (t.flags & OVHIP_IF_ISP) ? t.isp_log2_pb : 6;
     const int ciip_wt = res_only ? 0 : t.ciip_wt;
     if (!res_only) {
         if (luma) {
-            fetch_refs(s, ya, t.x, t.y, w, h, 4, t.flags & OVHIP_IF_CORNER, t.avl_abv, t.avl_lft, (t.flags & OVHIP_IF_MIP) ? 0 : t.mrl_idx, lane);
+            if (t.flags & OVHIP_IF_ISP) fetch_refs_isp(s, ya, t, lane);
+            else fetch_refs(s, ya, t.x, t.y, w, h, 4, t.flags & OVHIP_IF_CORNER, t.avl_abv, t.avl_lft, (t.flags & OVHIP_IF_MIP) ? 0 : t.mrl_idx, lane);
             wave_sync();
             if (t.flags & OVHIP_IF_MIP) pred_mip(s, t, st, lane);
             else pred_regular(s, t, true, st, lane);
@@ -587,7 +629,7 @@ __device__ void ctu_item(CtuLds &L, IntraLds &s, const ovhip_itask &t, int strip
         uint16_t *d = dst + y * dstride + x;
         int v = res_only ? (int)*d : (int)s.pred[p - st.p0];
         if (ciip_wt) v = (v * ciip_wt + (int)*d * (4 - ciip_wt) + 2) >> 2;
-        if (has_res) { const int r = rp[y * rstride + x]; v = ov_clip_bd(v + (scaled ? res_scale(r, scale) : r)); }
+        if (has_res && ((res_mask >> (x >> res_l2pb)) & 1)) { const int r = rp[y * rstride + x]; v = ov_clip_bd(v + (scaled ? res_scale(r, scale) : r)); }
         *d = (uint16_t)v;
     }
 }

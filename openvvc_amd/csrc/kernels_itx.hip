@@ -235,7 +235,10 @@ __device__ __forceinline__ void itx_block(const ovhip_pic &pic, const ResDelta &
         v0 = p[0]; v1 = p[1];
     }
     const int kv = min(tb_h, 32), kh = min(tb_w, 32);
-    const bool is_tr = kind == OVHIP_TB_TR;
+    // 1 x N / N x 1 blocks of intra sub-partitions (rcn_1xX_tb, rcn_Xx1_tb, rcn_transform_tree.c:947-962, :1011-1027): ONE
+    // transform along the long side with the second pass's shift + 1; staged raster like a transform-skip block
+    const bool one_d = kind == OVHIP_TB_TR && (log2_w == 0 || log2_h == 0);
+    const bool is_tr = kind == OVHIP_TB_TR && !one_d;
     const int cs = tile_stride(ch);                       // s_coef row length of a transform block
     const int msv = tile_stride(kv), msh = tile_stride(kh);
     // the four tiles (sizes rounded to 8 entries: every tile starts 16-byte aligned)
@@ -390,6 +393,15 @@ __device__ __forceinline__ void itx_block(const ovhip_pic &pic, const ResDelta &
             for (int e = nb_row; e < ((nb_row + 3) & ~3); ++e) s_tmp[lane * ts + e] = 0;
         tr_pass_lds<false, NT>(s_coef, cs, s_mv, msv, log2_h, k1, nb_row, 7, s_tmp, ts, lane, sink);
     }
+    if (valid && one_d) {
+        const int l2n = log2_w == 0 ? log2_h : log2_w, n = 1 << l2n, kmax = min(n, 32), ks = core_ks(l2n);
+        const int16_t *core = tr_core(log2_w == 0 ? c.tr_v : c.tr_h, l2n);
+        if (lane < n) {
+            int acc = 0;
+            for (int k = 0; k < kmax; ++k) acc += (int)s_coef[k] * (int)core[lane * ks + k];
+            s_tmp[lane] = (int16_t)ov_clip16((acc + (1 << (20 - OV_BD))) >> (20 - OV_BD + 1));
+        }
+    }
     __syncthreads();                                   // barrier 4
     if (tr) {
         // ---- horizontal pass (shift 20 - bitdepth) fused with K4; columns >= nb_row of tmp are zero: not read ----
@@ -420,7 +432,7 @@ __device__ __forceinline__ void itx_block(const ovhip_pic &pic, const ResDelta &
             const int i = i0 + NT * q;
             if (i < tb_w * tb_h) {
                 const int x = i & (tb_w - 1), y = i >> log2_w;
-                const int r = flat ? flat_val : (int)s_coef[y * tb_w + x];   // TS blocks are <= 32 wide: raster stride tb_w
+                const int r = flat ? flat_val : one_d ? (int)s_tmp[i] : (int)s_coef[y * tb_w + x];   // TS blocks are <= 32 wide: raster stride tb_w
                 sink.dst[y * sink.stride + x] = (uint16_t)residual1(old[q], r, sink.mode, sink.scale);
                 if (sink.dst2) sink.dst2[y * sink.stride2 + x] = (uint16_t)residual1(old2[q], r, sink.mode2, sink.scale);
             }

@@ -389,6 +389,92 @@ ovhip_rec_tu(ovhip_recorder *r, const ovhip_tu_state *st, const ovhip_tu_desc *t
     return ovhip_rec_tu_intra(r, st, tu, NULL, NULL);
 }
 
+/* ---- intra sub-partitions (recon_isp_subtree_v / _h, rcn_transform_tree.c:1087-1205) ---- */
+void
+ovhip_isp_geometry(int32_t log2_cb_w, int32_t log2_cb_h, int32_t vertical, int32_t *log2_pb, int32_t *n_pb, int32_t *log2_pred, int32_t *n_pred)
+{
+    const int l2s = vertical ? log2_cb_w : log2_cb_h, l2o = vertical ? log2_cb_h : log2_cb_w;    /* split / other side */
+    int l2p = l2s - 2;
+    if (l2o < 4 && l2p <= 4 - l2o) l2p = 4 - l2o;                 /* :1102-1104, :1172-1174: at least 16 samples per partition */
+    *log2_pb = l2p; *n_pb = (1 << l2s) >> l2p;
+    /* vertical partitions are predicted at least 4 columns at a time (:1127-1134); horizontal ones one by one */
+    *log2_pred = (vertical && l2p < 2) ? 2 : l2p;
+    *n_pred = (1 << l2s) >> *log2_pred;
+}
+
+int
+ovhip_rec_isp_cu(ovhip_recorder *r, const ovhip_tu_state *st, const ovhip_isp_desc *cu)
+{
+    if (!r || !st || !cu || cu->log2_cb_w < 2 || cu->log2_cb_w > 6 || cu->log2_cb_h < 2 || cu->log2_cb_h > 6 || cu->log2_cb_w + cu->log2_cb_h < 5)
+        return OVHIP_EINVAL;
+    const size_t n0 = r->n_tb, c0 = r->n_coef, t0 = r->n_itask;
+    int32_t l2p, n_pb, l2pred, n_pred;
+    ovhip_isp_geometry(cu->log2_cb_w, cu->log2_cb_h, cu->vertical, &l2p, &n_pb, &l2pred, &n_pred);
+    const int l2tw = cu->vertical ? l2p : cu->log2_cb_w, l2th = cu->vertical ? cu->log2_cb_h : l2p;     /* transform block */
+    /* 64x2 partitions: the reference de-quantises them with a row stride of 32 and transforms with 64 (rcn_Xx2_tb,
+     * rcn_transform_tree.c:985-1009; dequant_tb :119-132): its result depends on memory nothing wrote */
+    if (l2tw == 6 && l2th == 1 && cu->cbf_mask) return OVHIP_EUNSUP;
+    const int pb = 1 << l2p;
+    /* transform types (:1110-1111, :1180-1181) */
+    const int long_dst = cu->mts_enabled;
+    int type_h, type_v;
+    if (cu->vertical) { type_h = long_dst && l2p <= 4 && l2p > 1; type_v = long_dst && cu->log2_cb_h <= 4; }
+    else              { type_h = long_dst && cu->log2_cb_w <= 4;  type_v = long_dst && l2p <= 4 && l2p > 1; }
+    const int lfnst_mode = lfnst_mode_luma(cu->log2_cb_w, cu->log2_cb_h, cu->intra_mode);       /* drv_lfnst_mode_l on the CU's shape (:1117) */
+    int ret, ti = -1, n_added = 0;
+    for (int i = 0; i < n_pb; ++i) {
+        const int off = i * pb;
+        const int x = cu->x0 + (cu->vertical ? off : 0), y = cu->y0 + (cu->vertical ? 0 : off);
+        const int cbf = (cu->cbf_mask >> (n_pb - i - 1)) & 1;
+        if (!cu->vertical || !(off & 3)) {
+            /* prediction call: the task of this partition (or of this group of 4 columns) */
+            const int k = cu->vertical ? off >> l2pred : i;
+            ovhip_itask t;
+            memset(&t, 0, sizeof(t));
+            t.kind = OVHIP_IT_LUMA; t.x = (uint16_t)x; t.y = (uint16_t)y;
+            t.log2_w = (uint8_t)(cu->vertical ? l2pred : cu->log2_cb_w); t.log2_h = (uint8_t)(cu->vertical ? cu->log2_cb_h : l2p);
+            t.mode = cu->intra_mode;
+            t.flags = (uint16_t)(OVHIP_IF_ISP | ((cu->corner[k] & 1) ? OVHIP_IF_CORNER : 0) | ((cu->corner[k] & 2) ? OVHIP_IF_CORNER_L : 0));
+            t.avl_abv = cu->avl_abv[k]; t.avl_lft = cu->avl_lft[k];
+            t.isp_log2_cb_w = cu->log2_cb_w; t.isp_log2_cb_h = cu->log2_cb_h;
+            t.isp_off_x = (uint8_t)(cu->vertical ? off : 0); t.isp_off_y = (uint8_t)(cu->vertical ? 0 : off);
+            t.isp_log2_pb = (uint8_t)(cu->vertical ? l2p : cu->log2_cb_w);
+            /* at least one level after the CU's previous prediction call (it reads what that one and its residuals left) */
+            const uint16_t prev_level = ti >= 0 ? r->itask[ti].level : 0;
+            if ((ti = ovhip_rec_itask_add_(r, &t, prev_level)) < 0) { ret = ti; goto fail; }
+        }
+        if (!cbf) continue;
+        ovhip_tb_cmd *c = new_tb(r);
+        if (!c) { ret = OVHIP_ENOMEM; goto fail; }
+        c->x = (uint16_t)x; c->y = (uint16_t)y; c->plane = 0; c->log2_w = (uint8_t)l2tw; c->log2_h = (uint8_t)l2th;
+        const struct dq d = derive_dq(st->dep_quant ? 1 : 0, st->qp_y, l2tw, l2th);
+        c->dq_scale = d.scale; c->dq_shift = d.shift; c->dq_neg = d.neg;
+        const int16_t *src = cu->coef + ((size_t)i << (l2tw + l2th));
+        c->tr_h = (uint8_t)(type_h ? OVHIP_DST_VII : OVHIP_DCT_II); c->tr_v = (uint8_t)(type_v ? OVHIP_DST_VII : OVHIP_DCT_II);
+        c->kind = OVHIP_TB_TR;
+        if (l2tw < 2 || l2th < 2) {
+            /* rcn_2xX_tb / rcn_1xX_tb / rcn_Xx2_tb / rcn_Xx1_tb (:919-1061): the whole block raster, de-quantised as a whole */
+            c->kind |= OVHIP_TB_FLAG_RASTER;
+            c->sig_sb_map = cu->sig_sb_map[i];
+            if (capture_raster(r, src, 1 << (l2tw + l2th), &c->coef_off)) { ret = OVHIP_ENOMEM; goto fail; }
+        } else {
+            /* rcn_isp_tu (:869-917): sub-block storage, optional LFNST (which forces DCT-II), never the DC shortcut */
+            c->sig_sb_map = (cu->sig_sb_map[i] | !cu->sig_sb_map[i]) & valid_sb_mask(l2tw, l2th);
+            if (capture_sbs(r, src, l2tw, c->sig_sb_map, &c->coef_off)) { ret = OVHIP_ENOMEM; goto fail; }
+            if (cu->lfnst_flag) { c->lfnst = lfnst_field(lfnst_mode, cu->lfnst_idx); c->tr_h = c->tr_v = OVHIP_DCT_II; }
+        }
+        c->res_mode = OVHIP_RES_ADD | OVHIP_RES_STORE;
+        c->plane2 = 0xff;
+        r->itask[ti].flags |= OVHIP_IF_RES_Y;
+        r->itask[ti].isp_res_mask |= (uint8_t)(1u << (cu->vertical ? (off & 3) >> l2p : 0));
+        ++n_added;
+    }
+    return n_added;
+fail:
+    r->n_tb = n0; r->n_coef = c0; r->n_itask = t0;
+    return ret;
+}
+
 int
 ovhip_rec_tu_intra(ovhip_recorder *r, const ovhip_tu_state *st, const ovhip_tu_desc *tu, const ovhip_itask *intra_l, const ovhip_itask *intra_c)
 {

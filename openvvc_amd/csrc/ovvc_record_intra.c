@@ -120,9 +120,13 @@ ovhip_rec_itask_add_(ovhip_recorder *r, const ovhip_itask *in, uint16_t extra_le
     if (t.kind == OVHIP_IT_REGION) r->scan_deps = r->region_deps;
     if (t.kind == OVHIP_IT_LUMA) {
         const int ux = t.x >> 2, uy = t.y >> 2, nx = (w + 3) >> 2, ny = (h + 3) >> 2;
-        if ((t.flags & OVHIP_IF_CORNER) && (k = max_level(r, r->lvl_y, ux - 1, uy - 1, 1, 1)) > m) m = k;
-        if (t.avl_abv && (k = max_level(r, r->lvl_y, ux, uy - 1, t.avl_abv, 1)) > m) m = k;
-        if (t.avl_lft && (k = max_level(r, r->lvl_y, ux - 1, uy, 1, t.avl_lft)) > m) m = k;
+        /* ISP: the arms are the coding unit's -- above from the CU's left edge, left from the CU's top edge (the partitions of
+         * the CU itself are chained by ovhip_rec_isp_cu through extra_level) */
+        const int isp = !!(t.flags & OVHIP_IF_ISP);
+        const int uxa = isp ? (t.x - t.isp_off_x) >> 2 : ux, uyl = isp ? (t.y - t.isp_off_y) >> 2 : uy;
+        if ((t.flags & OVHIP_IF_CORNER) && (k = max_level(r, r->lvl_y, uxa - 1, uy - 1, 1, 1)) > m) m = k;
+        if (t.avl_abv && (k = max_level(r, r->lvl_y, uxa, uy - 1, t.avl_abv, 1)) > m) m = k;
+        if (t.avl_lft && (k = max_level(r, r->lvl_y, ux - 1, uyl, 1, t.avl_lft)) > m) m = k;
         if (t.ciip_wt && (k = max_level(r, r->lvl_y, ux, uy, nx, ny)) > m) m = k;     /* blends into what is there */
         if (m >= 65534) return OVHIP_EUNSUP;
         t.level = (uint16_t)(m + 1);

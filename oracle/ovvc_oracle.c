@@ -211,8 +211,15 @@ static void itx_one(const oracle_pic *pic, const ovhip_tb_cmd *c, const int16_t 
         (void)nb_col;
         if (nb_row > tb_w) nb_row = tb_w;
         memset(tmp, 0, sizeof(int16_t) * tb_w * tb_h);
-        tr_pass(coef, tmp, cw, c->tr_v, log2_h, nb_row, 7);          /* TR_SHIFT_V */
-        tr_pass(tmp, res, tb_h, c->tr_h, log2_w, tb_h, 20 - BD);     /* TR_SHIFT_H */
+        if (log2_w == 0) {
+            /* rcn_1xX_tb (rcn_transform_tree.c:947-962): ONE vertical transform with the second pass's shift + 1 */
+            tr_pass(coef, res, 1, c->tr_v, log2_h, 1, 20 - BD + 1);
+        } else if (log2_h == 0) {
+            tr_pass(coef, res, 1, c->tr_h, log2_w, 1, 20 - BD + 1);              /* rcn_Xx1_tb (:1011-1027) */
+        } else {
+            tr_pass(coef, tmp, cw, c->tr_v, log2_h, nb_row, 7);          /* TR_SHIFT_V */
+            tr_pass(tmp, res, tb_h, c->tr_h, log2_w, tb_h, 20 - BD);     /* TR_SHIFT_H */
+        }
     }
 
     int stride;

@@ -266,6 +266,58 @@ pred_regular(const uint16_t *plane, int stride, const ovhip_itask *t, int is_lum
     else          pred_angular_v(m, s, h, w, l2h, l2w, midx, is_luma, use_fg, mrl, pdpc_ok, abv[0], out, w, 1);
 }
 
+/* ---------------------------------------------------------------- intra sub-partitions (intra_pred_isp, rcn_intra.c:566-640)
+ * One reference arm of an ISP prediction call, as fill_ref_above_0 / fill_ref_left_0 (rcn_fill_ref.c:71-150, :320-390) build it
+ * for the CODING UNIT's geometry and intra_pred_isp then shifts it by the partition's offset:
+ *   S(k)  = the sample k steps along the CU's arm from its corner (above: (cu_x - 1 + k, y - 1); left: (x - 1, cu_y - 1 + k))
+ *   c     = the corner unit is available in this arm's own progress map, a = units available behind it (highest set bit)
+ *   other = the other arm's map has any bit set, F = first sample of the other arm at this partition ((x - 1, y) / (x, y - 1))
+ *   out[k] = value(k + off) for k <= cb + pb, replicated beyond (rcn_intra.c:597-603) */
+static void
+isp_arm(const uint16_t *p0, int step, int cb, int pb, int off, int c, int a, int other, int F, uint16_t *out)
+{
+    const int n_cu = 2 * cb + 1, nb_ref = (2 * cb) / 4 + 1, len = cb + pb;
+    uint16_t cu[2 * 64 + 1 + 8];
+#define S(k) p0[(k) * step]
+    if (c && a >= nb_ref) {
+        for (int k = 0; k < n_cu; ++k) cu[k] = S(k);
+    } else if (c || a) {
+        int last = 4 * a < n_cu + 3 ? 4 * a : n_cu + 3;
+        cu[0] = c ? S(0) : S(1);
+        for (int k = 1; k <= last; ++k) cu[k] = S(k);
+        for (int k = last + 1; k < n_cu + 4; ++k) cu[k] = cu[last];
+    } else {
+        for (int k = 0; k < n_cu + 4; ++k) cu[k] = (uint16_t)(other ? F : 1 << (BD - 1));
+    }
+#undef S
+    for (int k = n_cu; k < n_cu + 8; ++k) cu[k] = cu[n_cu - 1];                 /* "padding for wide angle" */
+    for (int k = 0; k <= len; ++k) out[k] = cu[k + off];
+    for (int k = len + 1; k < len + 1 + REF_PAD; ++k) out[k] = out[len];
+}
+
+static void
+pred_isp(const uint16_t *plane, int stride, const ovhip_itask *t, uint16_t *out)
+{
+    const int l2w = t->log2_w, l2h = t->log2_h, w = 1 << l2w, h = 1 << l2h;
+    const int cbw = 1 << t->isp_log2_cb_w, cbh = 1 << t->isp_log2_cb_h, ox = t->isp_off_x, oy = t->isp_off_y;
+    const int ca = !!(t->flags & OVHIP_IF_CORNER), cl = !!(t->flags & OVHIP_IF_CORNER_L);
+    static ref_bufs R;
+    uint16_t *abv = R.a + REF_PAD, *lft = R.l + REF_PAD;
+    const uint16_t *here = plane + t->y * stride + t->x;
+    isp_arm(here - stride - ox - 1, 1, cbw, w, ox, ca, t->avl_abv, cl || t->avl_lft, here[-1], abv);
+    isp_arm(here - (oy + 1) * stride - 1, stride, cbh, h, oy, cl, t->avl_lft, ca || t->avl_abv, here[-stride], lft);
+    const int pdpc_ok = l2h > 1;                       /* rcn_intra.c:608, :618; cubic_v / cubic_h: log2_pb_h > 1 */
+    int mode = t->mode;
+    if (mode == 0) { pred_planar(abv, lft, l2w, l2h, pdpc_ok, out); return; }
+    if (mode == 1) { pred_dc(abv, lft, l2w, l2h, pdpc_ok, out); return; }
+    mode = wide_angle(t->isp_log2_cb_w, t->isp_log2_cb_h, mode);         /* by the CU's shape (:627) */
+    const int vertical = mode >= 34;
+    const int midx = vertical ? mode - 50 : 18 - mode;
+    /* always the cubic filter, never smoothed references (intra_angular_cubic_v / _h) */
+    if (vertical) pred_angular_v(abv, lft, w, h, l2w, l2h, midx, 1, 0, 0, pdpc_ok, abv[0], out, 1, w);
+    else          pred_angular_v(lft, abv, h, w, l2h, l2w, midx, 1, 0, 0, pdpc_ok, abv[0], out, w, 1);
+}
+
 /* ---------------------------------------------------------------- matrix-based intra prediction (rcn_intra_mip.c:44-400) */
 static void
 mip_upsample(uint16_t *dst, const uint16_t *src, const uint16_t *ref, int l2_up_src, int l2_opp, int src_step, int src_stride,
@@ -482,8 +534,21 @@ oracle_intra_tasks(const oracle_pic *pic, const oracle_res *res, const ovhip_ita
         const int scale = scaled ? ((t->flags & OVHIP_IF_SCALE_IDX) ? scales[t->c_scale] : t->c_scale) : 0;
         switch (t->kind) {
         case OVHIP_IT_LUMA: {
-            if (t->flags & OVHIP_IF_MIP) pred_mip(pic->y, pic->stride_y, t, pa);
+            if (t->flags & OVHIP_IF_ISP) pred_isp(pic->y, pic->stride_y, t, pa);
+            else if (t->flags & OVHIP_IF_MIP) pred_mip(pic->y, pic->stride_y, t, pa);
             else pred_regular(pic->y, pic->stride_y, t, 1, pa);
+            if ((t->flags & OVHIP_IF_ISP) && (t->flags & OVHIP_IF_RES_Y)) {
+                /* only the partitions that carry a residual add one (the residual picture holds nothing defined elsewhere) */
+                const int pbw = 1 << t->isp_log2_pb;
+                for (int x = 0; x < w; x += pbw) {
+                    const int on = (t->isp_res_mask >> (x >> t->isp_log2_pb)) & 1;
+                    uint16_t col[64 * 64];
+                    for (int y = 0; y < h; ++y) for (int q = 0; q < pbw; ++q) col[y * pbw + q] = pa[y * w + x + q];
+                    store_block(pic->y + t->y * pic->stride_y + t->x + x, pic->stride_y, col,
+                                on ? res->y + t->y * res->stride_y + t->x + x : NULL, res->stride_y, pbw, h, 0, 0, 0);
+                }
+                break;
+            }
             store_block(pic->y + t->y * pic->stride_y + t->x, pic->stride_y, pa,
                         (t->flags & OVHIP_IF_RES_Y) ? res->y + t->y * res->stride_y + t->x : NULL, res ? res->stride_y : 0, w, h, 0, 0, t->ciip_wt);
             break;

@@ -1957,6 +1957,118 @@ gen_intra_ctu(const char *dir)
     fprintf(stderr, "intra_ctu.ovg: %u CTUs, %zu expected samples\n", n_cases, b_exp.n);
 }
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * K13  intra sub-partitions: tmp.recon_isp_subtree_v / _h (rcn_transform_tree.c:1087-1205 -> intra_pred_isp, rcn_isp_tu,
+ *      rcn_2xX_tb / rcn_1xX_tb / rcn_Xx2_tb / rcn_Xx1_tb): every CU shape ISP exists for (4x8 ... 64x64), both split
+ *      directions, planar / DC / angular modes incl. wide angles, DST-VII on and off, LFNST, random cbf patterns; the CU sits in
+ *      a CTU whose surroundings are partly decoded.  isp.ovg = start picture + the CU each case ends with; shim mode:
+ *      shim_isp.ovg = what the installed slots recorded. */
+struct ISPTUInfo_h { uint8_t cbf_mask, tr_skip_mask, cu_mts_flag, cu_mts_idx, lfnst_flag, lfnst_idx; struct TBInfo tb_info[4]; };
+static void
+gen_isp(const char *dir)
+{
+    gbuf b_exp = { .type = T_U16 }, b_info = { .type = T_I32 };
+    uint32_t n_cases = 0;
+    g_seed = 0x266 + 999;
+    OVCTUDec *c = ref_new_ctudec(0, 0);
+    c->rcn_funcs.rcn_attach_ctu_buff(&c->rcn_ctx, 7, 1);
+    const struct OVBuffInfo *cb = &c->rcn_ctx.ctu_buff;
+    struct OVRCNCtx *r = &c->rcn_ctx;
+    static uint16_t py[IN_W * IN_H], pcb[(IN_W / 2) * (IN_H / 2)], pcr[(IN_W / 2) * (IN_H / 2)];
+    fill_plane(py, IN_W, IN_H, IN_W); fill_plane(pcb, IN_W / 2, IN_H / 2, IN_W / 2); fill_plane(pcr, IN_W / 2, IN_H / 2, IN_W / 2);
+    struct shim_stream S;
+    shim_stream_init(&S);
+    c->ctb_x = IN_OX >> 7; c->ctb_y = IN_OY >> 7;
+    if (g_shim) shim_bind(c, IN_W, IN_H, 0, 0);
+    for (int l2w = 2; l2w <= 6; ++l2w)
+        for (int l2h = 2; l2h <= 6; ++l2h) {
+            if (l2w + l2h < 5) continue;                                 /* no ISP for 4x4 */
+            for (int vertical = 0; vertical < 2; ++vertical) {
+                /* the standard forbids a split that would leave partitions wider / higher than the maximum transform size only;
+                 * both directions exist for every shape here */
+                const int reps = (l2w + l2h <= 8) ? 10 : 6;
+                /* 64x8 split horizontally = 64x2 partitions: rcn_Xx2_tb de-quantises with a row stride of 32 (dequant_tb, min(5,
+                 * log2_tb_w)) but transforms with a stride of 64, reading stack memory nothing initialised (:985-1009): the
+                 * reference's output for these is not a function of its inputs, there is nothing to pin (the recorder refuses them) */
+                if (!vertical && l2w == 6 && l2h == 3) continue;
+                for (int rep = 0; rep < reps; ++rep) {
+                    const int w = 1 << l2w, h = 1 << l2h;
+                    int32_t l2p, n_pb, l2pred, n_pred;
+                    ovhip_isp_geometry(l2w, l2h, vertical, &l2p, &n_pb, &l2pred, &n_pred);
+                    const int l2tw = vertical ? l2p : l2w, l2th = vertical ? l2h : l2p;
+                    int x0 = rnd_range(0, (128 - w) / 4) * 4, y0 = rnd_range(0, (128 - h) / 4) * 4;
+                    if (rep % 4 == 1) { if (rnd_range(0, 1)) x0 = 0; else y0 = 0; }
+                    static const uint8_t key[8] = { 0, 1, 2, 18, 34, 50, 66, 0 };
+                    const int mode = rep < 7 ? key[rep] : rnd_range(2, 66);
+                    const int mode2 = (rep & 1) ? rnd_range(2, 66) : mode;
+                    const uint8_t intra_mode = (uint8_t)(rep >= 3 && rep < 7 ? mode2 : mode);
+                    c->dequant_luma.qp = rnd_range(18, 50); c->dequant_luma_skip.qp = c->dequant_luma.qp;
+                    c->residual_coding_l = rnd_range(0, 1) ? &residual_coding_dpq : NULL;
+                    c->mts_enabled = (uint8_t)rnd_range(0, 1); c->mts_implicit = 0; c->sh_ts_disabled = 0; c->tmp_ciip = 0;
+                    c->intra_mode = intra_mode;
+                    memset(&c->dbf_info, 0, sizeof(c->dbf_info));
+                    for (int j = -1; j < 132; ++j) for (int i = -128; i < 196; ++i) cb->y[j * cb->stride + i] = py[(IN_OY + j) * IN_W + IN_OX + i];
+                    /* progress: the decoder's CTU start, the rows above the CU and the columns left of it inside the CTU decoded
+                     * (with some of the left part further down), then the CU itself (vcl_transform_unit.c:1878) */
+                    memset(&r->progress_field, 0, sizeof(r->progress_field)); memset(&r->progress_field_c, 0, sizeof(r->progress_field_c));
+                    int flags = CTU_LFT_FLG | CTU_UP_FLG | CTU_UPRGT_FLG;
+                    if (rep % 5 == 2) flags &= ~CTU_UP_FLG & ~CTU_UPRGT_FLG;
+                    if (rep % 5 == 3) flags &= ~CTU_LFT_FLG;
+                    init_ctu_bitfield(r, (uint8_t)flags, 7);
+                    { const uint64_t mask = ((uint64_t)1 << ((((IN_W - IN_OX - 128) + 128) >> 2) + 1)) - 1; r->progress_field.hfield[0] &= mask; }
+                    const int xu = x0 >> 2, yu = y0 >> 2, wu = w >> 2, hu = h >> 2;
+                    if (yu) ctu_field_set_rect_bitfield(&r->progress_field, 0, 0, rnd_range(0, 2) ? 32 : (xu + wu < 32 ? xu + wu : 32), yu);
+                    if (xu) { int nl = rnd_range(hu, 2 * hu); if (yu + nl > 32) nl = 32 - yu; ctu_field_set_rect_bitfield(&r->progress_field, 0, yu, xu, nl); }
+                    ctu_field_set_rect_bitfield(&r->progress_field, xu, yu, wu, hu);
+                    /* residual */
+                    struct ISPTUInfo_h tu;
+                    memset(&tu, 0, sizeof(tu));
+                    memset(c->residual_y, 0, sizeof(c->residual_y));
+                    tu.cbf_mask = (uint8_t)rnd_range(1, (1 << n_pb) - 1);
+                    const int can_lfnst = l2tw >= 2 && l2th >= 2;
+                    if (can_lfnst && rnd_range(0, 3) == 0) { tu.lfnst_flag = 1; tu.lfnst_idx = (uint8_t)rnd_range(0, 1); }
+                    for (int i = 0; i < n_pb; ++i) {
+                        if (!((tu.cbf_mask >> (n_pb - i - 1)) & 1)) continue;
+                        int16_t *dst = c->residual_y + (i << (l2tw + l2th));
+                        uint64_t map; uint16_t lp;
+                        if (l2tw >= 2 && l2th >= 2) {
+                            make_coefs(dst, l2tw, l2th, tu.lfnst_flag ? 1 : rnd_range(0, 2), 0, &map, &lp);
+                            if (tu.lfnst_flag) { map = 1; lp = 0x0101; int cw = (1 << l2tw) > 32 ? 32 : (1 << l2tw), ch = (1 << l2th) > 32 ? 32 : (1 << l2th); memset(dst + 16, 0, (cw * ch - 16) * 2); }
+                        } else {
+                            /* thin blocks: raster; the sub-block map of 2x8 / 8x2 (1x16 / 16x1) coefficient groups along the long side */
+                            const int n = 1 << (l2tw + l2th);
+                            const int pattern = rnd_range(0, 2);
+                            for (int k = 0; k < n; ++k) dst[k] = (pattern == 2 || (pattern == 1 && rnd_range(0, 2) == 0) || k == 0) ? rnd_coef() : 0;
+                            const int n_sb = n >> 4;                     /* 16 coefficients per group */
+                            map = 0;
+                            for (int sb = 0; sb < (n_sb ? n_sb : 1); ++sb) map |= (uint64_t)1 << (vertical ? sb * 8 : sb);
+                            if (pattern == 0) { map = 1; for (int k = 1; k < n; ++k) dst[k] = 0; }
+                            lp = (uint16_t)(pattern == 0 ? 0 : (vertical ? ((((1 << l2th) - 1) & 0x1f) << 8) | (((1 << l2th) - 1) & 0x1f) : ((1 << l2tw) - 1) & 0x1f));
+                        }
+                        tu.tb_info[i].sig_sb_map = map; tu.tb_info[i].last_pos = lp;
+                    }
+                    rcn_init_ict_functions_10(&c->rcn_funcs, 0, 10);
+                    if (g_shim) rcn_init_functions_hip(&c->rcn_funcs, 0, 1, 0, 0, 10);
+                    if (vertical) c->rcn_funcs.tmp.recon_isp_subtree_v(c, x0, y0, l2w, l2h, intra_mode, (const void *)&tu);
+                    else          c->rcn_funcs.tmp.recon_isp_subtree_h(c, x0, y0, l2w, l2h, intra_mode, (const void *)&tu);
+                    if (g_shim) shim_case_end(c, &S, "isp");
+                    int32_t info[8] = { IN_OX + x0, IN_OY + y0, l2w, l2h, vertical, intra_mode, tu.cbf_mask | (tu.lfnst_flag << 8) | (c->mts_enabled << 9), (int32_t)b_exp.n };
+                    gbuf_push(&b_info, info, 8);
+                    dump_rect(&b_exp, cb->y, cb->stride, x0, y0, w, h);
+                    n_cases++;
+                }
+            }
+        }
+    if (g_shim) { shim_stream_write(dir, "shim_isp.ovg", &S, c, NULL, 0); return; }
+    gfile g = gfile_open(dir, "isp.ovg");
+    uint32_t d2[2] = { IN_H, IN_W };
+    gfile_array(&g, "pic_y", T_U16, py, 2, d2);
+    d2[0] = n_cases; d2[1] = 8; gfile_array(&g, "info", T_I32, b_info.data, 2, d2);
+    gfile_buf(&g, "exp", &b_exp);
+    gfile_close(&g);
+    fprintf(stderr, "isp.ovg: %u CUs, %zu expected samples\n", n_cases, b_exp.n);
+}
+
 int
 main(int argc, char **argv)
 {
@@ -1990,5 +2102,6 @@ main(int argc, char **argv)
     if (!only || !strcmp(only, "alf")) gen_alf(dir);
     if ((!only || !strcmp(only, "intra")) && !g_shim) gen_intra(dir);
     if (!only || !strcmp(only, "intra_ctu")) gen_intra_ctu(dir);
+    if (!only || !strcmp(only, "isp")) gen_isp(dir);
     return 0;
 }

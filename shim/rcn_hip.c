@@ -61,6 +61,7 @@ struct TUInfo {
     uint8_t cu_mts_flag; uint8_t cu_mts_idx; uint8_t lfnst_flag; uint8_t lfnst_idx;
     struct TBInfo tb_info[3];
 };
+struct ISPTUInfo { uint8_t cbf_mask, tr_skip_mask, cu_mts_flag, cu_mts_idx, lfnst_flag, lfnst_idx; struct TBInfo tb_info[4]; };   /* rcn_transform_tree.c:68-76 */
 struct PROFInfo { int16_t dmv_scale_h_0[16], dmv_scale_v_0[16], dmv_scale_h_1[16], dmv_scale_v_1[16]; };
 
 extern uint64_t residual_coding_dpq(OVCTUDec *const, int16_t *const, uint8_t, uint8_t, uint16_t);
@@ -454,18 +455,59 @@ hip_rcn_transform_tree(OVCTUDec *const c, uint8_t x0, uint8_t y0, uint8_t log2_t
     }
 }
 
-/* Tools the device path does not implement yet.  The scalar slots would reconstruct into the CTU scratch, which this back-end
- * never copies to the frame: the picture would be silently wrong.  Latch an error instead (the picture is then not flushed and
- * ovhip_shim_last_error() / the decoder log say why). */
+/* tmp.recon_isp_subtree_v / _h (rcn_structures.h:480-491; rcn_transform_tree.c:1087-1205).  The caller has already marked the
+ * whole CU in the progress field (vcl_transform_unit.c:1878), so the partitions see each other as available. */
 static void
-hip_recon_isp_subtree(OVCTUDec *const c, unsigned int x0, unsigned int y0, unsigned int log2_cb_w, unsigned int log2_cb_h, uint8_t intra_mode,
-                      const struct ISPTUInfo *const tu)
+isp_subtree(OVCTUDec *const c, unsigned int x0, unsigned int y0, unsigned int log2_cb_w, unsigned int log2_cb_h, uint8_t intra_mode,
+            const struct ISPTUInfo *const tu, int vertical)
 {
-    (void)x0; (void)y0; (void)log2_cb_w; (void)log2_cb_h; (void)intra_mode; (void)tu;
-    struct hip_entry *e = entry_of(c, 0);
-    if (e) latch(e, OVHIP_EUNSUP, "intra sub-partition (ISP) coding unit");
+    ENTER(c);
+    const int l2 = c->part_ctx->log2_ctu_s;
+    const struct CTUBitField *pf = &c->rcn_ctx.progress_field;
+    ovhip_tu_state st;
+    ovhip_isp_desc d;
+    int32_t l2p, n_pb, l2pred, n_pred;
+    fill_tu_state(e, c, &st);
+    memset(&d, 0, sizeof(d));
+    ovhip_isp_geometry((int32_t)log2_cb_w, (int32_t)log2_cb_h, vertical, &l2p, &n_pb, &l2pred, &n_pred);
+    d.x0 = (uint16_t)((c->ctb_x << l2) + x0); d.y0 = (uint16_t)((c->ctb_y << l2) + y0);
+    d.log2_cb_w = (uint8_t)log2_cb_w; d.log2_cb_h = (uint8_t)log2_cb_h; d.vertical = (uint8_t)vertical; d.intra_mode = intra_mode;
+    d.cbf_mask = tu->cbf_mask; d.lfnst_flag = tu->lfnst_flag; d.lfnst_idx = tu->lfnst_idx; d.mts_enabled = c->mts_enabled;
+    d.coef = c->residual_y;
+    for (int i = 0; i < n_pb && i < 4; ++i) { d.last_pos[i] = tu->tb_info[i].last_pos; d.sig_sb_map[i] = tu->tb_info[i].sig_sb_map; }
+    const int nb_a = ((2 << log2_cb_w) >> 2) + 1, nb_l = ((2 << log2_cb_h) >> 2) + 1;
+    for (int k = 0; k < n_pred && k < 4; ++k) {
+        /* the maps intra_pred_isp hands to fill_ref_above_0 / fill_ref_left_0 for this call (rcn_intra.c:584-594) */
+        const int off = k << l2pred, px = (int)x0 + (vertical ? off : 0), py = (int)y0 + (vertical ? 0 : off), off_y = vertical ? 0 : off;
+        const uint64_t ma = (pf->hfield[(py >> 2) + !!(off_y % 4)] >> (x0 >> 2)) & ((1llu << (nb_a + 1)) - 1);
+        const uint64_t ml = (pf->vfield[px >> 2] >> (y0 >> 2)) & ((1llu << (nb_l + 1)) - 1);
+        d.corner[k] = (uint8_t)((ma & 1) | ((ml & 1) << 1));
+        d.avl_abv[k] = (uint8_t)top_bit(ma >> 1); d.avl_lft[k] = (uint8_t)top_bit(ml >> 1);
+        /* deblocking bookkeeping of the scalar orchestrator (:1136-1137, :1189-1192) */
+        if (vertical) {
+            fill_ctb_bound(&c->dbf_info, px, py, l2pred, log2_cb_h);
+            fill_bs_map(&c->dbf_info.bs2_map, px, py, l2pred, log2_cb_h);
+        } else if (!(off_y & 3)) {
+            fill_ctb_bound(&c->dbf_info, px, py, log2_cb_w, l2p >= 2 ? l2p : 2);
+            fill_bs_map(&c->dbf_info.bs2_map, px, py, log2_cb_w, l2p >= 2 ? l2p : 2);
+        }
+    }
+    latch(e, ovhip_rec_isp_cu(e->rec, &st, &d), "ovhip_rec_isp_cu");
 }
 
+static void
+hip_recon_isp_subtree_v(OVCTUDec *const c, unsigned int x0, unsigned int y0, unsigned int log2_cb_w, unsigned int log2_cb_h, uint8_t intra_mode,
+                        const struct ISPTUInfo *const tu)
+{ isp_subtree(c, x0, y0, log2_cb_w, log2_cb_h, intra_mode, tu, 1); }
+
+static void
+hip_recon_isp_subtree_h(OVCTUDec *const c, unsigned int x0, unsigned int y0, unsigned int log2_cb_w, unsigned int log2_cb_h, uint8_t intra_mode,
+                        const struct ISPTUInfo *const tu)
+{ isp_subtree(c, x0, y0, log2_cb_w, log2_cb_h, intra_mode, tu, 0); }
+
+/* Tools the device path does not implement.  The scalar slots would reconstruct into the CTU scratch, which this back-end never
+ * copies to the frame: the picture would be silently wrong.  Latch an error instead (the picture is then not flushed and
+ * ovhip_shim_last_error() / the decoder log say why). */
 static void
 hip_rcn_ibc(OVCTUDec *const c, int16_t x0, int16_t y0, uint8_t log2_cu_w, uint8_t log2_cu_h, uint8_t log2_ctu_s, IBCMV mv)
 {
@@ -1208,8 +1250,8 @@ rcn_init_functions_hip(struct RCNFunctions *f, uint8_t ict_type, uint8_t lm_chro
     f->tmp.rcn_transform_tree = &hip_rcn_transform_tree;
     f->tmp.rcn_tu_st = &hip_rcn_tu_st;
     f->tmp.rcn_tu_c  = &hip_rcn_tu_c;
-    f->tmp.recon_isp_subtree_h = &hip_recon_isp_subtree;
-    f->tmp.recon_isp_subtree_v = &hip_recon_isp_subtree;
+    f->tmp.recon_isp_subtree_h = &hip_recon_isp_subtree_h;
+    f->tmp.recon_isp_subtree_v = &hip_recon_isp_subtree_v;
     f->rcn_ibc_l = &hip_rcn_ibc;
     f->rcn_ibc_c = &hip_rcn_ibc;
     f->rcn_mcp = &hip_rcn_mcp;

@@ -206,3 +206,34 @@ def test_shim_intra_ctus_gpu(ctx):
             y[128:256, 128:256] = base[0][128:256, 128:256]
             assert np.array_equal(y, base[0])
     job.close()
+
+
+def test_shim_isp_cus_gpu(ctx):
+    """The 394 intra-sub-partition CUs the installed recon_isp_subtree_v / _h slots recorded (shim_isp.ovg) through the C flush:
+    thin (1xN, 2xN, Nx1, Nx2) and regular transform blocks in STORE mode, the partitions' prediction calls as chained ordered tasks."""
+    from test_shim_cpu import isp_cases
+    base, info, exp = isp_cases()
+    s = ShimStream("shim_isp.ovg")
+    h, w = base.shape
+    cb = np.full((h // 2, w // 2), 512, np.uint16)
+    job = engine.Job(ctx, w, h)
+    dst = ctx.new_pic(w, h)
+    bad = []
+    for i, (x, y, l2w, l2h, vertical, mode, bits, off) in enumerate(info):
+        c = s.case(i)
+        dst.upload(base, cb, cb)
+        job.begin()
+        job.rec.append_raw(capi.REC_COEF, c["coef"])
+        job.rec.append_raw(capi.REC_TB, c["tb"])
+        job.rec.append_raw(capi.REC_ITASK, c["itask"])
+        p = capi.JobParams()
+        p.log2_ctu_s = 7
+        p.stages = capi.STAGE_ITX | capi.STAGE_INTRA | (capi.STAGE_INTRA_CTU if i % 2 else 0)
+        job.flush(dst, [], None, params=p)
+        job.wait()
+        yy = dst.download()[0]
+        bw, bh = 1 << int(l2w), 1 << int(l2h)
+        if not np.array_equal(yy[y:y + bh, x:x + bw], exp[int(off):int(off) + bw * bh].reshape(bh, bw)):
+            bad.append((i, bw, bh, int(vertical), int(mode), hex(int(bits))))
+    job.close()
+    assert not bad, f"{len(bad)} / {len(info)} ISP CUs differ from the reference on the GPU, first: {bad[:10]}"

@@ -259,3 +259,34 @@ def test_shim_intra_ctus_match_reference(built_lib):
         oracle_lib.intra_tasks(dst2, t[order], (res.y.view(np.int16), res.cb.view(np.int16), res.cr.view(np.int16)))
         assert np.array_equal(dst2.y, dst.y) and np.array_equal(dst2.cb, dst.cb) and np.array_equal(dst2.cr, dst.cr)
     assert n_tasks > 1500
+
+
+def isp_cases():
+    g = golden_io.load("isp.ovg")
+    return g["pic_y"], g["info"], g["exp"]
+
+
+def test_shim_isp_slots_match_reference(built_lib):
+    """tmp.recon_isp_subtree_v / _h through the installed table: 394 intra-sub-partition CUs (4x8 ... 64x64, both directions,
+    1xN / 2xN / Nx1 / Nx2 and regular transform blocks, DST-VII, LFNST).  Each prediction call is an ordered task with the CU's
+    arms, chained partition after partition; executing the recorded stream gives the CU the reference's slot left."""
+    base, info, exp = isp_cases()
+    s = ShimStream("shim_isp.ovg")
+    assert s.n == len(info) == 394
+    h, w = base.shape
+    bad = []
+    for i, (x, y, l2w, l2h, vertical, mode, bits, off) in enumerate(info):
+        c = s.case(i)
+        t = c["itask"]
+        assert len(t) >= 1 and (t["flags"] & capi.IF_ISP).all() and np.all(np.diff(t["level"].astype(int)) > 0)
+        dst = HostPic(w, h, base.copy())
+        res = HostPic(w, h)
+        res.y[:] = 0x1234                  # the residual picture is only defined where a transform block stored into it
+        oracle_lib.itx_res(dst, c["tb"], c["coef"], None, res)
+        oracle_lib.intra_tasks(dst, t, (res.y.view(np.int16), res.cb.view(np.int16), res.cr.view(np.int16)))
+        bw, bh = 1 << int(l2w), 1 << int(l2h)
+        got = dst.y[y:y + bh, x:x + bw]
+        want = exp[int(off):int(off) + bw * bh].reshape(bh, bw)
+        if not np.array_equal(got, want):
+            bad.append((i, bw, bh, int(vertical), int(mode), hex(int(bits)), int((got != want).sum())))
+    assert not bad, f"{len(bad)} / {len(info)} ISP CUs differ from the reference, first: {bad[:10]}"
