@@ -750,6 +750,16 @@ size_t ovhip_intra_sync_words(int32_t width, int32_t height, int32_t log2_ctu_s)
 int  ovhip_intra_ctu_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_pic *res, const ovhip_itask *d_tasks, const ovhip_ictu *d_ctus,
                             uint32_t n_ctus, const ovhip_lmcs_region *d_regions, const ovhip_lmcs_luts *luts, int16_t *d_scales,
                             int32_t log2_ctu_s, uint32_t *d_sync, uint32_t epoch, uint32_t *abort_mirror);
+/* The ordered pass in one launch, dependencies per 4x4 unit: every (task, strip, plane) item is a workgroup that polls the state
+ * words of the units its reference arms cover, reads them with agent-scope loads, predicts, stores write-through and marks its
+ * own units.  d_tasks: the LEVEL-SORTED tasks (ovhip_rec_itasks_sorted); d_items: ovhip_intra_flow_items() of that list (host
+ * helper; 0 = the picture cannot take this path).  d_state: ovhip_intra_flow_words() words of device memory zeroed once;
+ * epoch, abort_mirror and the bounded waits as for ovhip_intra_ctu_launch (d_state[0] = abort word). */
+size_t ovhip_intra_flow_words(int32_t width, int32_t height);
+size_t ovhip_intra_flow_items(const ovhip_itask *sorted, size_t n, uint32_t *items, size_t cap);
+int  ovhip_intra_flow_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_pic *res, const ovhip_itask *d_tasks, uint32_t n_tasks,
+                             const uint32_t *d_items, uint32_t n_items, const ovhip_lmcs_region *d_regions, const ovhip_lmcs_luts *luts,
+                             int16_t *d_scales, int32_t log2_ctu_s, uint32_t *d_state, uint32_t epoch, uint32_t *abort_mirror);
 /* planes->* are DEVICE pointers.  Filters `pic` in place: all vertical edges, then all horizontal. */
 int  ovhip_dbf_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_dbf_planes *planes);
 /* Same filter driven by the compact lists of ovhip_dbf_compact (DEVICE pointers). */
@@ -788,6 +798,8 @@ enum {                                   /* ovhip_job_params.stages (0 = all) */
     OVHIP_STAGE_INTRA_CTU = 0x20000000,  /* with OVHIP_STAGE_INTRA: the ordered pass as the one-launch CTU wavefront
                                           * (ovhip_intra_ctu_launch) instead of one launch per level (ovhip_intra_level_launch, the
                                           * default: measured faster on B and I pictures) */
+    OVHIP_STAGE_INTRA_FLOW = 0x10000000, /* with OVHIP_STAGE_INTRA: the ordered pass as one launch with per-unit dependency flags
+                                          * (ovhip_intra_flow_launch) */
     OVHIP_STAGE_RESIDENT = 0x40000000    /* measurement only: no H2D / D2H, the device copies of the previous flush are replayed */
 };
 

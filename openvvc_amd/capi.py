@@ -198,7 +198,7 @@ class JobStats(C.Structure):
 REC_TB, REC_COEF, REC_MC, REC_MCX, REC_AFF, REC_SIDE, REC_REGION, REC_CIIP, REC_EDGE_V, REC_EDGE_H, REC_ITASK = range(11)
 TIME_STAGES = ("mc", "mcxa", "itx_luma", "lmcs_scale", "itx_chroma", "dbf", "sao", "alf", "intra", "h2d")
 STAGE_MC, STAGE_ITX, STAGE_DBF, STAGE_SAO, STAGE_ALF, STAGE_INTRA = 1, 2, 4, 8, 16, 32
-STAGE_ALL, STAGE_RESIDENT, STAGE_INTRA_CTU = 63, 0x40000000, 0x20000000
+STAGE_ALL, STAGE_RESIDENT, STAGE_INTRA_CTU, STAGE_INTRA_FLOW = 63, 0x40000000, 0x20000000, 0x10000000
 
 
 def dbf_plane_shapes(w4: int, h4: int) -> dict:
@@ -330,6 +330,9 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_intra_level_launch": (C.c_int, [vp, P(Pic), P(Pic), vp, u32, vp, vp, vp, i32, u32]),
         "ovhip_intra_level_geom": (u32, [vp, C.c_size_t]),
         "ovhip_intra_sync_words": (C.c_size_t, [i32, i32, i32]),
+        "ovhip_intra_flow_words": (C.c_size_t, [i32, i32]),
+        "ovhip_intra_flow_items": (C.c_size_t, [vp, C.c_size_t, vp, C.c_size_t]),
+        "ovhip_intra_flow_launch": (C.c_int, [vp, P(Pic), P(Pic), vp, u32, vp, u32, vp, vp, vp, i32, vp, u32, vp]),
         "ovhip_intra_ctu_launch": (C.c_int, [vp, P(Pic), P(Pic), vp, vp, u32, vp, vp, vp, i32, vp, u32, vp]),
         "ovhip_rec_itask_levels": (u32, [vp]),
         "ovhip_rec_isp_cu": (C.c_int, [vp, vp, vp]),
@@ -370,7 +373,7 @@ EXPORTED_SYMBOLS = [
     "ovhip_free", "ovhip_h2d", "ovhip_d2h", "ovhip_pic_alloc", "ovhip_pic_free", "ovhip_pic_upload",
     "ovhip_pic_download", "ovhip_itx_launch", "ovhip_mc_launch",
     "ovhip_rec_create_ex", "ovhip_rec_set_dense_dbf_planes", "ovhip_rec_dbf_edges", "ovhip_dbf_launch_edges_ex",
-    "ovhip_dmvr_search_launch", "ovhip_rec_append_raw", "ovhip_rec_set_dbf_offsets", "ovhip_rec_tu_intra", "ovhip_rec_itasks", "ovhip_rec_itasks_sorted", "ovhip_itx_launch_classes_res", "ovhip_intra_level_launch", "ovhip_intra_level_geom", "ovhip_intra_sync_words", "ovhip_intra_ctu_launch",
+    "ovhip_dmvr_search_launch", "ovhip_rec_append_raw", "ovhip_rec_set_dbf_offsets", "ovhip_rec_tu_intra", "ovhip_rec_itasks", "ovhip_rec_itasks_sorted", "ovhip_itx_launch_classes_res", "ovhip_intra_level_launch", "ovhip_intra_level_geom", "ovhip_intra_sync_words", "ovhip_intra_ctu_launch", "ovhip_intra_flow_words", "ovhip_intra_flow_items", "ovhip_intra_flow_launch",
     "ovhip_rec_itask_levels", "ovhip_rec_isp_cu", "ovhip_isp_geometry", "ovhip_rec_itasks_by_ctu", "ovhip_rec_set_ctu_size", "ovhip_job_bind", "ovhip_job_create", "ovhip_job_destroy", "ovhip_job_recorder", "ovhip_job_begin",
     "ovhip_job_flush", "ovhip_job_wait", "ovhip_job_refined_mvs", "ovhip_job_dmvr_rows", "ovhip_job_last_stats", "ovhip_job_time_stage", "ovhip_job_stage_time",
 ]

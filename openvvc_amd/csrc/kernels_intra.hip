@@ -765,6 +765,187 @@ __global__ __launch_bounds__(256) void k_intra_ctu(ovhip_pic pic, ovhip_pic res,
     (void)hc; (void)n_run;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The ordered pass as ONE launch with per-unit dependency flags ("flow").
+//
+// Items = (task, strip, plane) in LEVEL order, one 64-lane workgroup each.  Every 4x4-luma unit of every plane has a state word:
+// 2 * epoch = "an ordered task of this picture will write it" (set by k_intra_flow_prepare before this launch),
+// 2 * epoch + 1 = "written".  An item polls the units its reference arms cover (all of them at once, one per lane), reads the
+// samples with agent-scope loads (bypass L1; the producer stored write-through), predicts, stores write-through, drains, and
+// marks its own units.  No launch boundary per level, no cold fetch of the task record on the critical path (the workgroup
+// has it long before its inputs are ready).  Forward progress: an item waits only for items of a LOWER level = lower index;
+// workgroups start in index order on this hardware, nothing promises it -- the wait is bounded and aborts the launch.
+struct AgentAcc {
+    const uint16_t *p; int stride;
+    __device__ __forceinline__ int ld(int x, int y) const { return __hip_atomic_load(p + y * stride + x, RLX_AGENT); }
+};
+struct FlowState { unsigned *y, *c[2], *reg; int w4; };
+#define FLOW_MAX_FP 448
+
+__global__ __launch_bounds__(64) void k_intra_flow_prepare(const ovhip_itask *__restrict__ tasks, uint32_t n, FlowState fs, unsigned epoch)
+{
+    if (blockIdx.x >= n) return;
+    const ovhip_itask t = tasks[blockIdx.x];
+    const int lane = threadIdx.x;
+    const unsigned mark = 2 * epoch;
+    if (t.kind == OVHIP_IT_REGION) { if (lane == 0) fs.reg[t.c_scale] = mark; return; }
+    const bool luma = t.kind == OVHIP_IT_LUMA;
+    const int sh = luma ? 2 : 1, w = 1 << t.log2_w, h = 1 << t.log2_h;
+    const int ux0 = t.x >> sh, uy0 = t.y >> sh, nx = max(1, w >> sh), ny = max(1, h >> sh);
+    for (int i = lane; i < nx * ny; i += 64) {
+        const int u = (uy0 + i / nx) * fs.w4 + ux0 + i % nx;
+        if (luma) fs.y[u] = mark;
+        else {
+            if (t.kind == OVHIP_IT_CHROMA || (t.flags & OVHIP_IF_RES_CB)) fs.c[0][u] = mark;
+            if (t.kind == OVHIP_IT_CHROMA || (t.flags & OVHIP_IF_RES_CR)) fs.c[1][u] = mark;
+        }
+    }
+}
+
+struct FlowLds { IntraLds s; unsigned *fp[FLOW_MAX_FP]; int abort; };
+
+__global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res, const ovhip_itask *__restrict__ tasks, const uint32_t *__restrict__ items,
+                                                   uint32_t n_items, const ovhip_lmcs_region *__restrict__ regs, LmcsWnd wnd, int16_t *scales,
+                                                   int log2_ctu, FlowState fs, unsigned epoch, unsigned *sync, unsigned *abort_mirror)
+{
+    __shared__ FlowLds L;
+    IntraLds &s = L.s;
+    if (blockIdx.x >= n_items) return;
+    const int lane = threadIdx.x;
+    load_tables(s, lane);
+    const uint32_t item = items[blockIdx.x];
+    const ovhip_itask t = tasks[item & 0xffffff];
+    const int strip = (item >> 24) & 0xf, comp = (item >> 28) & 1;
+    const int l2w = t.log2_w, w = 1 << l2w, h = 1 << t.log2_h, npx = w * h;
+    const bool luma = t.kind == OVHIP_IT_LUMA, region = t.kind == OVHIP_IT_REGION, res_only = t.kind == OVHIP_IT_RES_C;
+    const bool lm = t.kind == OVHIP_IT_CHROMA && t.mode >= 67 && !(t.flags & OVHIP_IF_BDPCM);
+    const unsigned pending = 2 * epoch;
+    const int w4 = fs.w4;
+    Strip st; st.p0 = strip * STRIP; st.p1 = min(npx, st.p0 + STRIP);
+    const bool has_res = t.flags & (luma ? OVHIP_IF_RES_Y : (comp ? OVHIP_IF_RES_CR : OVHIP_IF_RES_CB));
+    if (res_only && !has_res) return;
+
+    // ---- what this item reads: unit state words, all polled at once ----
+    int nfp = 0;
+    auto add_run = [&](unsigned *base, int ux, int uy, int count, int dx, int dy) {
+        // count units from (ux, uy) in steps of (dx, dy); clipped to the table (count is wave-uniform)
+        count = min(count, FLOW_MAX_FP - nfp);
+        for (int i = lane; i < count; i += 64) L.fp[nfp + i] = base + (uy + i * dy) * w4 + ux + i * dx;
+        nfp += max(count, 0);
+    };
+    if (region) {
+        const ovhip_lmcs_region g = regs[t.c_scale];
+        if (g.n_abv) add_run(fs.y, g.x >> 2, (g.y >> 2) - 1, g.n_abv, 1, 0);
+        if (g.n_lft) add_run(fs.y, (g.x >> 2) - 1, g.y >> 2, g.n_lft, 0, 1);
+    } else if (luma) {
+        const bool isp = t.flags & OVHIP_IF_ISP;
+        const int ux = t.x >> 2, uy = t.y >> 2, uxa = isp ? (t.x - t.isp_off_x) >> 2 : ux, uyl = isp ? (t.y - t.isp_off_y) >> 2 : uy;
+        if (t.flags & OVHIP_IF_CORNER) add_run(fs.y, uxa - 1, uy - 1, 1, 1, 0);
+        if (isp && (t.flags & OVHIP_IF_CORNER_L)) add_run(fs.y, ux - 1, uyl - 1, 1, 1, 0);
+        add_run(fs.y, uxa, uy - 1, t.avl_abv, 1, 0);
+        add_run(fs.y, ux - 1, uyl, t.avl_lft, 0, 1);
+    } else {
+        unsigned *fc = fs.c[comp];
+        const int ux = t.x >> 1, uy = t.y >> 1, nux = max(1, w >> 1), nuy = max(1, h >> 1);
+        if (!res_only) {
+            if (lm) {
+                // co-located luma, its left / above margin, and the chroma + luma neighbours the parameters are derived from
+                const int na = t.mode == 69 ? t.avl_abv : (t.avl_abv ? nux : 0), nl = t.mode == 68 ? t.avl_lft : (t.avl_lft ? nuy : 0);
+                for (int r = 0; r < nuy && nfp < FLOW_MAX_FP; ++r) add_run(fs.y, ux, uy + r, nux, 1, 0);
+                if (t.avl_lft) { add_run(fs.y, ux - 1, uy - (t.avl_abv ? 1 : 0), max(nl, nuy) + (t.avl_abv ? 1 : 0), 0, 1); add_run(fc, ux - 1, uy, nl, 0, 1); }
+                if (t.avl_abv) { add_run(fs.y, ux, uy - 1, max(na, nux), 1, 0); add_run(fc, ux, uy - 1, na, 1, 0); }
+            } else {
+                if (t.flags & OVHIP_IF_CORNER) add_run(fc, ux - 1, uy - 1, 1, 1, 0);
+                add_run(fc, ux, uy - 1, t.avl_abv, 1, 0);
+                add_run(fc, ux - 1, uy, t.avl_lft, 0, 1);
+            }
+        }
+        if ((t.flags & OVHIP_IF_RES_SCALE) && (t.flags & OVHIP_IF_SCALE_IDX)) add_run(fs.reg, t.c_scale, 0, 1, 1, 0);
+    }
+    wave_sync();
+    {
+        bool ok = true;
+        for (int i = lane; i < nfp; i += 64) {
+            unsigned *f = L.fp[i];
+            unsigned spins = 0;
+            while (__hip_atomic_load(f, RLX_AGENT) == pending) {
+                if (++spins > SPIN_LIMIT || __hip_atomic_load(sync, RLX_AGENT) != 0) { ok = false; break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+        }
+        if (!__all(ok)) {
+            if (lane == 0) {
+                __hip_atomic_store(sync, 1u + blockIdx.x, RLX_AGENT);
+                if (abort_mirror) __hip_atomic_store(abort_mirror, 1u + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return;
+        }
+    }
+
+    const AgentAcc ya = { pic.y, pic.stride_y };
+    if (region) {
+        const int v = region_scale(ya, regs[t.c_scale], wnd, lane);
+        if (lane == 0) {
+            __hip_atomic_store(scales + t.c_scale, (int16_t)v, RLX_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(fs.reg + t.c_scale, pending + 1, RLX_AGENT);
+        }
+        return;
+    }
+    uint16_t *pl = luma ? pic.y : (comp ? pic.cr : pic.cb);
+    const int dstride = luma ? pic.stride_y : pic.stride_c, rstride = luma ? res.stride_y : res.stride_c;
+    uint16_t *dst = pl + t.y * dstride + t.x;
+    const int16_t *rp = reinterpret_cast<const int16_t *>(luma ? res.y : (comp ? res.cr : res.cb)) + t.y * rstride + t.x;
+    const int ciip_wt = res_only ? 0 : t.ciip_wt;
+    const bool need_d = ciip_wt || res_only;
+    const int res_mask = (t.flags & OVHIP_IF_ISP) ? t.isp_res_mask : 0xff, res_l2pb = (t.flags & OVHIP_IF_ISP) ? t.isp_log2_pb : 6;
+    int rv[NPL], dv[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int p = st.p0 + lane + 64 * i, x = p & (w - 1), y = p >> l2w;
+        rv[i] = (has_res && p < st.p1 && ((res_mask >> (x >> res_l2pb)) & 1)) ? rp[y * rstride + x] : 0;     // residuals: the launches before
+        dv[i] = (need_d && p < st.p1) ? dst[y * dstride + x] : 0;                                               // inter prediction: likewise
+    }
+    const bool scaled = !luma && (t.flags & OVHIP_IF_RES_SCALE);
+    const int scale = scaled ? ((t.flags & OVHIP_IF_SCALE_IDX) ? (int)__hip_atomic_load(scales + t.c_scale, RLX_AGENT) : t.c_scale) : 0;
+    if (!res_only) {
+        if (luma) {
+            if (t.flags & OVHIP_IF_ISP) fetch_refs_isp(s, ya, t, lane);
+            else fetch_refs(s, ya, t.x, t.y, w, h, 4, t.flags & OVHIP_IF_CORNER, t.avl_abv, t.avl_lft, (t.flags & OVHIP_IF_MIP) ? 0 : t.mrl_idx, lane);
+            wave_sync();
+            if (t.flags & OVHIP_IF_MIP) pred_mip(s, t, st, lane);
+            else pred_regular(s, t, true, st, lane);
+        } else {
+            const AgentAcc ca = { pl, pic.stride_c };
+            if (lm) pred_cclm(s, ya, ca, t, log2_ctu, st, lane);
+            else {
+                fetch_refs(s, ca, t.x, t.y, w, h, 2, t.flags & OVHIP_IF_CORNER, t.avl_abv, t.avl_lft, 0, lane);
+                wave_sync();
+                pred_regular(s, t, false, st, lane);
+            }
+        }
+        wave_sync();
+    }
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int p = st.p0 + lane + 64 * i, x = p & (w - 1), y = p >> l2w;
+        if (p >= st.p1) break;
+        int v = res_only ? dv[i] : s.pred[p - st.p0];
+        if (ciip_wt) v = (v * ciip_wt + dv[i] * (4 - ciip_wt) + 2) >> 2;
+        if (has_res) v = ov_clip_bd(v + (scaled ? res_scale(rv[i], scale) : rv[i]));
+        __hip_atomic_store(dst + y * dstride + x, (uint16_t)v, RLX_AGENT);                  // write-through
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- this strip's units are written ----
+    {
+        const int sh = luma ? 2 : 1, y0s = st.p0 >> l2w, y1s = (st.p1 + w - 1) >> l2w;
+        const int ux0 = t.x >> sh, uy0 = (t.y + y0s) >> sh, nx = max(1, w >> sh), ny = max(1, (y1s - y0s) >> sh);
+        unsigned *fb = luma ? fs.y : fs.c[comp];
+        for (int i = lane; i < nx * ny; i += 64) __hip_atomic_store(fb + (uy0 + i / nx) * w4 + ux0 + i % nx, pending + 1, RLX_AGENT);
+    }
+}
+
 } // namespace
 
 // Launch geometry of a level from its tasks (HOST memory): bits 0-1 = log2 of the strips of the largest block (1024 samples
@@ -838,5 +1019,57 @@ extern "C" int ovhip_intra_ctu_launch(ovhip_ctx *ctx, const ovhip_pic *pic, cons
     hipLaunchKernelGGL(k_intra_ctu, dim3(n_ctus), dim3(256), 0, ctx->stream, *pic, *res, d_tasks, d_ctus, d_regions, wnd, d_scales, log2_ctu_s, d_sync, epoch, ncx,
                        abort_mirror);
     OV_LAUNCH_CHECK(ctx, "k_intra_ctu");
+    return OVHIP_OK;
+}
+
+// Items of the flow launch from the level-sorted tasks (HOST): one per (task, 1024-sample strip, plane).  Returns the count
+// (<= cap) or 0 when the picture cannot take this path (a prediction block less than a unit high: horizontal ISP partitions of 1 or
+// 2 rows share a state word with their neighbours).
+extern "C" size_t ovhip_intra_flow_items(const ovhip_itask *sorted, size_t n, uint32_t *items, size_t cap)
+{
+    size_t k = 0;
+    for (size_t i = 0; sorted && i < n; ++i) {
+        const ovhip_itask &t = sorted[i];
+        if (i >= (1u << 24)) return 0;
+        if (t.kind == OVHIP_IT_REGION) { if (k < cap) items[k] = (uint32_t)i; ++k; continue; }
+        if (t.kind == OVHIP_IT_LUMA && t.log2_h < 2) return 0;
+        const int npx = 1 << (t.log2_w + t.log2_h), strips = (npx + STRIP - 1) / STRIP, comps = t.kind == OVHIP_IT_LUMA ? 1 : 2;
+        for (int st = 0; st < strips; ++st)
+            for (int c = 0; c < comps; ++c) { if (k < cap) items[k] = (uint32_t)i | ((uint32_t)st << 24) | ((uint32_t)c << 28); ++k; }
+    }
+    return k <= cap ? k : 0;
+}
+
+// Words of the state block of ovhip_intra_flow_launch for a w x h picture (device memory, zeroed once by the owner).
+extern "C" size_t ovhip_intra_flow_words(int32_t width, int32_t height)
+{
+    if (width <= 0 || height <= 0) return 0;
+    return SYNC_FLAGS + 4 * (size_t)((width + 3) / 4) * ((height + 3) / 4);
+}
+
+// The whole ordered pass in one launch with per-unit dependency flags (k_intra_flow).  d_tasks: the level-sorted tasks;
+// d_items: ovhip_intra_flow_items() of the same list (both DEVICE).  d_state: ovhip_intra_flow_words() words, zeroed once;
+// epoch as for ovhip_intra_ctu_launch (d_state[0] = abort word, abort_mirror likewise).
+extern "C" int ovhip_intra_flow_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_pic *res, const ovhip_itask *d_tasks, uint32_t n_tasks,
+                                       const uint32_t *d_items, uint32_t n_items, const ovhip_lmcs_region *d_regions, const ovhip_lmcs_luts *luts,
+                                       int16_t *d_scales, int32_t log2_ctu_s, uint32_t *d_state, uint32_t epoch, uint32_t *abort_mirror)
+{
+    if (!ctx || !pic || !res) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
+    if (!n_items) return OVHIP_OK;
+    if (!d_tasks || !d_items || !d_state || !epoch || epoch >= 0x7fffffffu || log2_ctu_s < 5 || log2_ctu_s > 7)
+        return ov_fail(ctx, OVHIP_EINVAL, "ovhip_intra_flow_launch: bad arguments", hipSuccess);
+    LmcsWnd wnd;
+    memset(&wnd, 0, sizeof(wnd));
+    if (luts) { memcpy(wnd.bnd, luts->wnd_bnd, sizeof(wnd.bnd)); wnd.min_idx = luts->min_idx; wnd.max_idx = luts->max_idx; wnd.crs_offset = luts->crs_offset; }
+    FlowState fs;
+    const size_t nu = (size_t)((pic->w + 3) / 4) * ((pic->h + 3) / 4);
+    fs.w4 = (pic->w + 3) / 4;
+    fs.y = d_state + SYNC_FLAGS; fs.c[0] = fs.y + nu; fs.c[1] = fs.c[0] + nu; fs.reg = fs.c[1] + nu;
+    hipLaunchKernelGGL(k_intra_flow_prepare, dim3(n_tasks), dim3(64), 0, ctx->stream, d_tasks, n_tasks, fs, epoch);
+    OV_LAUNCH_CHECK(ctx, "k_intra_flow_prepare");
+    hipLaunchKernelGGL(k_intra_flow, dim3(n_items), dim3(64), 0, ctx->stream, *pic, *res, d_tasks, d_items, n_items, d_regions, wnd, d_scales, log2_ctu_s, fs,
+                       epoch, d_state, abort_mirror);
+    OV_LAUNCH_CHECK(ctx, "k_intra_flow");
     return OVHIP_OK;
 }

@@ -16,7 +16,7 @@ namespace {
 
 struct DevBuf { void *p; size_t cap; };
 
-enum { B_TB, B_COEF, B_MC, B_MCX, B_MV, B_AFF, B_SIDE, B_REG, B_SCALE, B_EV, B_EH, B_PARAM, B_CLASS, B_CIIP, B_ITASK, B_ICTU, B_COUNT };
+enum { B_TB, B_COEF, B_MC, B_MCX, B_MV, B_AFF, B_SIDE, B_REG, B_SCALE, B_EV, B_EH, B_PARAM, B_CLASS, B_CIIP, B_ITASK, B_ICTU, B_IITEM, B_COUNT };
 
 // layout of the parameter block (one pinned staging copy, one H2D)
 struct ParamLayout { size_t sao, alf_ctus, lcoef, lclip, ccoef, cclip, cc, fwd, bwd, total; };
@@ -31,6 +31,8 @@ struct ovhip_job {
     ovhip_pic tmp;                       // SAO destination / ALF source
     ovhip_pic res;                       // residuals of the ordered tasks (allocated with the first picture that has any)
     uint32_t *d_sync; uint32_t epoch;    // CTU flags of the one-launch ordered pass (zeroed once; a new epoch per picture)
+    uint32_t *d_flow;                    // unit state words of the flow launch (zeroed once)
+    uint32_t *items_host; size_t items_cap;   // pinned: items of the flow launch
     uint32_t *abort_host;                // pinned word the ordered pass writes when a bounded wait expired
     char *param_host; size_t param_cap;  // pinned staging of the picture-level tables
     int32_t *mv_host; size_t mv_cap;     // pinned: refined vectors, 4 int32 per refined unit
@@ -38,7 +40,7 @@ struct ovhip_job {
     size_t dmvr_first;                   // refined units [0, dmvr_first) already went through the eager search
     hipEvent_t ev_h2d, ev_done;
     int flushed;                         // ev_* recorded at least once
-    const void *packed_prev[16];         // where the last full flush placed the arrays that rode in the parameter block
+    const void *packed_prev[24];         // where the last full flush placed the arrays that rode in the parameter block
     int resident;                        // this flush reuses the device copies of the previous one (OVHIP_STAGE_RESIDENT)
     ovhip_job_stats st;
     // optional: HIP-event bracket around ONE launch group of the flush (ovhip_job_time_stage)
@@ -170,6 +172,8 @@ void ovhip_job_destroy(ovhip_job *j)
     if (j->tmp.y) (void)ovhip_pic_free(j->ctx, &j->tmp);
     if (j->res.y) (void)ovhip_pic_free(j->ctx, &j->res);
     if (j->d_sync) (void)hipFree(j->d_sync);
+    if (j->d_flow) (void)hipFree(j->d_flow);
+    pinned_free(nullptr, j->items_host);
     pinned_free(nullptr, j->abort_host);
     pinned_free(nullptr, j->param_host); pinned_free(nullptr, j->mv_host);
     for (int k = 0; k < 32; ++k) for (int q = 0; q < 2; ++q) if (j->t_ev[k][q]) (void)hipEventDestroy(j->t_ev[k][q]);
@@ -210,9 +214,10 @@ int ovhip_job_wait(ovhip_job *j)
     hipError_t e = hipEventSynchronize(j->ev_done);
     if (e != hipSuccess) return ov_fail(j->ctx, OVHIP_ELAUNCH, "hipEventSynchronize(job)", e);
     if (j->abort_host && *(volatile uint32_t *)j->abort_host) {
-        // a CTU of the ordered pass gave up waiting for a neighbour: the picture is incomplete.  Re-arm and report.
+        // a workgroup of the ordered pass gave up waiting for its inputs: the picture is incomplete.  Re-arm and report.
         *(volatile uint32_t *)j->abort_host = 0;
-        (void)hipMemset(j->d_sync, 0, sizeof(uint32_t));
+        if (j->d_sync) (void)hipMemset(j->d_sync, 0, sizeof(uint32_t));
+        if (j->d_flow) (void)hipMemset(j->d_flow, 0, sizeof(uint32_t));
         return ov_fail(j->ctx, OVHIP_ELAUNCH, "ordered pass: a CTU's bounded wait for its neighbours expired (picture incomplete)", hipSuccess);
     }
     return OVHIP_OK;
@@ -320,9 +325,22 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
         return ov_fail(ctx, OVHIP_EUNSUP, "ovhip_job_flush: CIIP blend units recorded but no picture with their intra prediction", hipSuccess);
     // ordered tasks: grouped by CTU for the one-launch pass, or sorted by level for one launch per level
     size_t n_it = 0, n_ictu = 0; uint32_t n_lv = 0; const uint32_t *lv_start = nullptr; const ovhip_ictu *ictu = nullptr;
-    const int by_level = !(pr->stages && (stages & OVHIP_STAGE_INTRA_CTU));
+    const int by_ctu = pr->stages && (stages & OVHIP_STAGE_INTRA_CTU);
+    int by_flow = pr->stages && (stages & OVHIP_STAGE_INTRA_FLOW) && !by_ctu;
+    const int by_level = !by_ctu;          // the flow launch also takes the level-sorted list
     const ovhip_itask *it = by_level ? ovhip_rec_itasks_sorted(rec, &n_it, &lv_start, &n_lv)
                                      : ovhip_rec_itasks_by_ctu(rec, pr->log2_ctu_s ? pr->log2_ctu_s : 7, &n_it, &ictu, &n_ictu);
+    size_t n_items = 0;
+    if (by_flow && n_it) {
+        if (j->items_cap < 4 * n_it + 16) {
+            pinned_free(nullptr, j->items_host);
+            j->items_cap = 8 * n_it + 1024;
+            j->items_host = (uint32_t *)pinned_alloc(nullptr, j->items_cap * sizeof(uint32_t));
+            if (!j->items_host) { j->items_cap = 0; return ov_fail(ctx, OVHIP_ENOMEM, "ovhip_job_flush: item list", hipSuccess); }
+        }
+        n_items = ovhip_intra_flow_items(it, n_it, j->items_host, j->items_cap);
+        if (!n_items) by_flow = 0;           // a block less than a unit high: per-level launches
+    }
     if (!it && ovhip_rec_itask_levels(rec)) return ov_fail(ctx, OVHIP_ENOMEM, "ovhip_job_flush: sorting the ordered tasks", hipSuccess);
     if (!by_level) n_lv = ovhip_rec_itask_levels(rec);
     if (!(stages & OVHIP_STAGE_INTRA)) { n_it = 0; n_lv = 0; n_ictu = 0; }
@@ -361,8 +379,8 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
         { side, n_side * sizeof(*side), B_SIDE, 0 }, { reg, n_reg * sizeof(*reg), B_REG, 0 },
         { ev, (stages & OVHIP_STAGE_DBF) ? n_ev * sizeof(*ev) : 0, B_EV, 0 }, { eh, (stages & OVHIP_STAGE_DBF) ? n_eh * sizeof(*eh) : 0, B_EH, 0 },
     };
-    static_assert(B_COUNT <= 16, "packed_prev");
-    const void *packed[16] = { nullptr };           // device address of a packed array (inside the parameter block)
+    static_assert(B_COUNT <= 24, "packed_prev");
+    const void *packed[24] = { nullptr };           // device address of a packed array (inside the parameter block)
     for (auto &sm : small) if (sm.bytes && sm.bytes <= PACK_LIMIT && !j->resident) sm.at = put(sm.bytes) + 1;
     L.total = o;
     if (L.total) {
@@ -394,6 +412,7 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
     CHK(h2d(j, B_COEF, coef, n_coef * sizeof(*coef)));
     CHK(h2d(j, B_ITASK, it, n_it * sizeof(*it)));
     CHK(h2d(j, B_ICTU, ictu, n_ictu * sizeof(*ictu)));
+    if (by_flow) CHK(h2d(j, B_IITEM, j->items_host, n_items * sizeof(uint32_t)));
     if (n_reg) CHK(dev_reserve(j, B_SCALE, n_reg * 2));
     // (refined units that went through the eager per-row search are uploaded again with the rest: the list is small and
     // the full kernel repeats the search with the identical result)
@@ -480,17 +499,36 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
                 const size_t words = ovhip_intra_sync_words(j->w, j->h, 5);          // the smallest CTU: enough for every size
                 OV_HIP(ctx, hipMalloc((void **)&j->d_sync, words * sizeof(uint32_t)));
                 OV_HIP(ctx, hipMemsetAsync(j->d_sync, 0, words * sizeof(uint32_t), ctx->stream));
+            }
+            if (!j->abort_host) {
                 j->abort_host = (uint32_t *)pinned_alloc(nullptr, 64);
                 if (!j->abort_host) return ov_fail(ctx, OVHIP_ENOMEM, "ovhip_job_flush: pinned abort word", hipSuccess);
                 *j->abort_host = 0;
             }
-            if (!++j->epoch) ++j->epoch;
+            if (++j->epoch >= 0x7ffffff0u) j->epoch = 1;
             CHK(ovhip_intra_ctu_launch(ctx, dst, &j->res, d_it, (const ovhip_ictu *)j->dev[B_ICTU].p, (uint32_t)n_ictu,
                                        (const ovhip_lmcs_region *)DEV(B_REG), pr->lmcs, (int16_t *)j->dev[B_SCALE].p, log2_ctu, j->d_sync, j->epoch,
                                        j->abort_host));
             j->st.n_launches++;
         }
-        for (uint32_t l = 0; by_level && l < n_lv; ++l) {
+        if (by_flow && n_items) {
+            if (!j->d_flow) {
+                const size_t words = ovhip_intra_flow_words(j->w, j->h);
+                OV_HIP(ctx, hipMalloc((void **)&j->d_flow, words * sizeof(uint32_t)));
+                OV_HIP(ctx, hipMemsetAsync(j->d_flow, 0, words * sizeof(uint32_t), ctx->stream));
+            }
+            if (!j->abort_host) {
+                j->abort_host = (uint32_t *)pinned_alloc(nullptr, 64);
+                if (!j->abort_host) return ov_fail(ctx, OVHIP_ENOMEM, "ovhip_job_flush: pinned abort word", hipSuccess);
+                *j->abort_host = 0;
+            }
+            if (++j->epoch >= 0x7ffffff0u) j->epoch = 1;
+            CHK(ovhip_intra_flow_launch(ctx, dst, &j->res, d_it, (uint32_t)n_it, (const uint32_t *)j->dev[B_IITEM].p, (uint32_t)n_items,
+                                        (const ovhip_lmcs_region *)DEV(B_REG), pr->lmcs, (int16_t *)j->dev[B_SCALE].p, log2_ctu, j->d_flow, j->epoch,
+                                        j->abort_host));
+            j->st.n_launches += 2;
+        }
+        for (uint32_t l = 0; by_level && !by_flow && l < n_lv; ++l) {
             const uint32_t a = lv_start[l], b = lv_start[l + 1];
             if (b > a) {
                 CHK(ovhip_intra_level_launch(ctx, dst, &j->res, d_it + a, b - a, (const ovhip_lmcs_region *)DEV(B_REG), pr->lmcs,
