@@ -41,7 +41,7 @@ HBM_PEAK_GBPS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 KNAME = {"mc": "k_mc2", "mcxa": "k_mcxa", "itx_luma": "k_itx_all (luma commands)", "lmcs_scale": "k_lmcs_scale",
          "itx_chroma": "k_itx_all (chroma commands + inverse-LMCS rider)", "dbf": "k_dbf_list<0> + k_dbf_list<1>",
-         "sao": "k_sao", "alf": "k_alf", "intra": "k_intra_level (all levels)", "h2d": "H2D copies"}
+         "sao": "k_sao", "alf": "k_alf", "intra": "k_intra_flow", "h2d": "H2D copies"}
 
 
 def algorithmic_bytes(wl, S):
@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--gop", type=int, default=32, help="GOP size (hierarchical B, JVET random-access decoding order) = picture sets of the rotation")
     ap.add_argument("--intra-period", type=int, default=64, help="every key picture at a multiple of this POC is an I picture (a multiple of --gop; JVET CTC: about one second, 64 at 50 / 60 Hz)")
     ap.add_argument("--intra-ctu", action="store_true", help="ordered pass as the one-launch CTU wavefront instead of one launch per level")
+    ap.add_argument("--intra-levels", action="store_true", help="ordered pass as one launch per level instead of one launch with per-unit dependency flags")
     ap.add_argument("--device-waits", action="store_true", help="reference pictures as stream waits (barrier packets) instead of host waits before the launches")
     ap.add_argument("--trace-gop", action="store_true", help="debug: host timeline of the pictures of the last run on stderr")
     ap.add_argument("--host-threads", type=int, default=-1, help="host threads issuing the flushes (-1: one per picture in flight)")
@@ -183,7 +184,7 @@ def main():
     torch.cuda.synchronize(dev)
     working_set = (K + 3 + len(bufs_recv)) * FB + len(all_jobs) * FB            # destinations + each job's SAO picture
 
-    lv = capi.STAGE_INTRA_CTU if args.intra_ctu else 0
+    lv = capi.STAGE_INTRA_CTU if args.intra_ctu else (capi.STAGE_INTRA_LEVELS if args.intra_levels else 0)
     nthreads = S if args.host_threads < 0 else max(1, min(args.host_threads, S))
     gop_base = [0]                                 # GOPs this rank has decoded so far (keeps the key-buffer rotation going)
     keep_work = []

@@ -796,10 +796,10 @@ enum {                                   /* ovhip_job_params.stages (0 = all) */
     OVHIP_STAGE_MC = 1, OVHIP_STAGE_ITX = 2, OVHIP_STAGE_DBF = 4, OVHIP_STAGE_SAO = 8, OVHIP_STAGE_ALF = 16,
     OVHIP_STAGE_INTRA = 32,
     OVHIP_STAGE_INTRA_CTU = 0x20000000,  /* with OVHIP_STAGE_INTRA: the ordered pass as the one-launch CTU wavefront
-                                          * (ovhip_intra_ctu_launch) instead of one launch per level (ovhip_intra_level_launch, the
-                                          * default: measured faster on B and I pictures) */
-    OVHIP_STAGE_INTRA_FLOW = 0x10000000, /* with OVHIP_STAGE_INTRA: the ordered pass as one launch with per-unit dependency flags
-                                          * (ovhip_intra_flow_launch) */
+                                          * (ovhip_intra_ctu_launch): measured slower than both others, DESIGN.md 4.1 */
+    OVHIP_STAGE_INTRA_LEVELS = 0x10000000, /* with OVHIP_STAGE_INTRA: the ordered pass as one launch per level (ovhip_intra_level_launch)
+                                            * instead of the default, one launch with per-unit dependency flags
+                                            * (ovhip_intra_flow_launch; pictures it cannot take fall back to the levels) */
     OVHIP_STAGE_RESIDENT = 0x40000000    /* measurement only: no H2D / D2H, the device copies of the previous flush are replayed */
 };
 

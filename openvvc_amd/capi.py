@@ -198,7 +198,7 @@ class JobStats(C.Structure):
 REC_TB, REC_COEF, REC_MC, REC_MCX, REC_AFF, REC_SIDE, REC_REGION, REC_CIIP, REC_EDGE_V, REC_EDGE_H, REC_ITASK = range(11)
 TIME_STAGES = ("mc", "mcxa", "itx_luma", "lmcs_scale", "itx_chroma", "dbf", "sao", "alf", "intra", "h2d")
 STAGE_MC, STAGE_ITX, STAGE_DBF, STAGE_SAO, STAGE_ALF, STAGE_INTRA = 1, 2, 4, 8, 16, 32
-STAGE_ALL, STAGE_RESIDENT, STAGE_INTRA_CTU, STAGE_INTRA_FLOW = 63, 0x40000000, 0x20000000, 0x10000000
+STAGE_ALL, STAGE_RESIDENT, STAGE_INTRA_CTU, STAGE_INTRA_LEVELS = 63, 0x40000000, 0x20000000, 0x10000000
 
 
 def dbf_plane_shapes(w4: int, h4: int) -> dict:

@@ -17,6 +17,7 @@
 // Reference samples of the block are fetched once into LDS with the substitution rules of 8.4.5.2.8 (availability = unit
 // counts from the recorder), smoothed copies next to them when the mode asks for them; every prediction mode then reads
 // LDS only.  int16 / int32 arithmetic, no MFMA: per-sample stencils.
+#include <stdlib.h>
 #include "ovvc_common.hip.h"
 #define OVT_ATTR __device__
 #include "vvc_mip_tables.h"
@@ -807,7 +808,7 @@ struct FlowLds { IntraLds s; unsigned *fp[FLOW_MAX_FP]; int abort; };
 
 __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res, const ovhip_itask *__restrict__ tasks, const uint32_t *__restrict__ items,
                                                    uint32_t n_items, const ovhip_lmcs_region *__restrict__ regs, LmcsWnd wnd, int16_t *scales,
-                                                   int log2_ctu, FlowState fs, unsigned epoch, unsigned *sync, unsigned *abort_mirror)
+                                                   int log2_ctu, FlowState fs, unsigned epoch, unsigned *sync, unsigned *abort_mirror, int nap)
 {
     __shared__ FlowLds L;
     IntraLds &s = L.s;
@@ -871,7 +872,10 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
             unsigned spins = 0;
             while (__hip_atomic_load(f, RLX_AGENT) == pending) {
                 if (++spins > SPIN_LIMIT || __hip_atomic_load(sync, RLX_AGENT) != 0) { ok = false; break; }
-                __builtin_amdgcn_s_sleep(4);
+                if (nap == 0) __builtin_amdgcn_s_sleep(4);
+                else if (nap == 1) __builtin_amdgcn_s_sleep(16);
+                else if (nap == 2) __builtin_amdgcn_s_sleep(64);
+                else { if (spins < 8) __builtin_amdgcn_s_sleep(4); else if (spins < 32) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(64); }
             }
         }
         if (!__all(ok)) {
@@ -1068,8 +1072,9 @@ extern "C" int ovhip_intra_flow_launch(ovhip_ctx *ctx, const ovhip_pic *pic, con
     fs.y = d_state + SYNC_FLAGS; fs.c[0] = fs.y + nu; fs.c[1] = fs.c[0] + nu; fs.reg = fs.c[1] + nu;
     hipLaunchKernelGGL(k_intra_flow_prepare, dim3(n_tasks), dim3(64), 0, ctx->stream, d_tasks, n_tasks, fs, epoch);
     OV_LAUNCH_CHECK(ctx, "k_intra_flow_prepare");
+    const int nap = 0;          // poll back-off variant: 0 = s_sleep 4 between polls (16 the same; 64 and exponential back-off measured 6 % slower)
     hipLaunchKernelGGL(k_intra_flow, dim3(n_items), dim3(64), 0, ctx->stream, *pic, *res, d_tasks, d_items, n_items, d_regions, wnd, d_scales, log2_ctu_s, fs,
-                       epoch, d_state, abort_mirror);
+                       epoch, d_state, abort_mirror, nap);
     OV_LAUNCH_CHECK(ctx, "k_intra_flow");
     return OVHIP_OK;
 }

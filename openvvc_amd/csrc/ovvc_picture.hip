@@ -326,7 +326,7 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
     // ordered tasks: grouped by CTU for the one-launch pass, or sorted by level for one launch per level
     size_t n_it = 0, n_ictu = 0; uint32_t n_lv = 0; const uint32_t *lv_start = nullptr; const ovhip_ictu *ictu = nullptr;
     const int by_ctu = pr->stages && (stages & OVHIP_STAGE_INTRA_CTU);
-    int by_flow = pr->stages && (stages & OVHIP_STAGE_INTRA_FLOW) && !by_ctu;
+    int by_flow = !by_ctu && !(pr->stages && (stages & OVHIP_STAGE_INTRA_LEVELS));
     const int by_level = !by_ctu;          // the flow launch also takes the level-sorted list
     const ovhip_itask *it = by_level ? ovhip_rec_itasks_sorted(rec, &n_it, &lv_start, &n_lv)
                                      : ovhip_rec_itasks_by_ctu(rec, pr->log2_ctu_s ? pr->log2_ctu_s : 7, &n_it, &ictu, &n_ictu);

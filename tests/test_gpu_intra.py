@@ -120,7 +120,7 @@ def test_intra_tasks_ctu_kernel_match_reference(ctx):
     assert not bad, f"{len(bad)} / {n_checked} intra cases differ from the reference through k_intra_ctu, first: {bad[:8]}"
 
 
-@pytest.mark.parametrize("one_launch", [0, capi.STAGE_INTRA_CTU, capi.STAGE_INTRA_FLOW])
+@pytest.mark.parametrize("one_launch", [0, capi.STAGE_INTRA_CTU, capi.STAGE_INTRA_LEVELS])
 @pytest.mark.parametrize("w,h,seed,frac", [(416, 240, 5, 0.12), (416, 240, 6, 1.0), (832, 480, 7, 0.3), (1920, 1080, 0x266, 0.12), (1920, 1080, 0x267, 1.0)])
 def test_picture_with_intra_matches_oracle(ctx, w, h, seed, frac, one_launch):
     """Recorded pictures with intra CUs (MIP, MRL, BDPCM, CCLM / MDLM, CIIP blended on the device, ordered chroma-scale

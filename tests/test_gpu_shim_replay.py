@@ -186,7 +186,7 @@ def test_shim_intra_ctus_gpu(ctx):
     h, w = base[0].shape
     job = engine.Job(ctx, w, h)
     dst = ctx.new_pic(w, h)
-    for one_launch in (0, capi.STAGE_INTRA_CTU, capi.STAGE_INTRA_FLOW):
+    for one_launch in (0, capi.STAGE_INTRA_CTU, capi.STAGE_INTRA_LEVELS):
         for i, (dual, n_intra, ey, ecb, ecr) in enumerate(cases):
             c = s.case(i)
             dst.upload(*base)
@@ -228,7 +228,7 @@ def test_shim_isp_cus_gpu(ctx):
         job.rec.append_raw(capi.REC_ITASK, c["itask"])
         p = capi.JobParams()
         p.log2_ctu_s = 7
-        p.stages = capi.STAGE_ITX | capi.STAGE_INTRA | (0, capi.STAGE_INTRA_CTU, capi.STAGE_INTRA_FLOW)[i % 3]
+        p.stages = capi.STAGE_ITX | capi.STAGE_INTRA | (0, capi.STAGE_INTRA_CTU, capi.STAGE_INTRA_LEVELS)[i % 3]
         job.flush(dst, [], None, params=p)
         job.wait()
         yy = dst.download()[0]
