@@ -754,12 +754,15 @@ int  ovhip_intra_ctu_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_pi
  * words of the units its reference arms cover, reads them with agent-scope loads, predicts, stores write-through and marks its
  * own units.  d_tasks: the LEVEL-SORTED tasks (ovhip_rec_itasks_sorted); d_items: ovhip_intra_flow_items() of that list (host
  * helper; 0 = the picture cannot take this path).  d_state: ovhip_intra_flow_words() words of device memory zeroed once;
- * epoch, abort_mirror and the bounded waits as for ovhip_intra_ctu_launch (d_state[0] = abort word). */
+ * epoch, abort_mirror and the bounded waits as for ovhip_intra_ctu_launch (d_state[0] = abort word).  The items may be launched
+ * in several calls (consecutive ranges that end on level boundaries, same epoch): prepare != 0 only on the first, which marks the
+ * units of ALL n_tasks tasks.  Fewer workgroups resident and polling at a time leave LDS and issue slots to the kernels of the
+ * other pictures in flight. */
 size_t ovhip_intra_flow_words(int32_t width, int32_t height);
 size_t ovhip_intra_flow_items(const ovhip_itask *sorted, size_t n, uint32_t *items, size_t cap);
 int  ovhip_intra_flow_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_pic *res, const ovhip_itask *d_tasks, uint32_t n_tasks,
                              const uint32_t *d_items, uint32_t n_items, const ovhip_lmcs_region *d_regions, const ovhip_lmcs_luts *luts,
-                             int16_t *d_scales, int32_t log2_ctu_s, uint32_t *d_state, uint32_t epoch, uint32_t *abort_mirror);
+                             int16_t *d_scales, int32_t log2_ctu_s, uint32_t *d_state, uint32_t epoch, uint32_t *abort_mirror, int32_t prepare);
 /* planes->* are DEVICE pointers.  Filters `pic` in place: all vertical edges, then all horizontal. */
 int  ovhip_dbf_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_dbf_planes *planes);
 /* Same filter driven by the compact lists of ovhip_dbf_compact (DEVICE pointers). */

@@ -332,7 +332,7 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_intra_sync_words": (C.c_size_t, [i32, i32, i32]),
         "ovhip_intra_flow_words": (C.c_size_t, [i32, i32]),
         "ovhip_intra_flow_items": (C.c_size_t, [vp, C.c_size_t, vp, C.c_size_t]),
-        "ovhip_intra_flow_launch": (C.c_int, [vp, P(Pic), P(Pic), vp, u32, vp, u32, vp, vp, vp, i32, vp, u32, vp]),
+        "ovhip_intra_flow_launch": (C.c_int, [vp, P(Pic), P(Pic), vp, u32, vp, u32, vp, vp, vp, i32, vp, u32, vp, i32]),
         "ovhip_intra_ctu_launch": (C.c_int, [vp, P(Pic), P(Pic), vp, vp, u32, vp, vp, vp, i32, vp, u32, vp]),
         "ovhip_rec_itask_levels": (u32, [vp]),
         "ovhip_rec_isp_cu": (C.c_int, [vp, vp, vp]),

@@ -1056,7 +1056,7 @@ extern "C" size_t ovhip_intra_flow_words(int32_t width, int32_t height)
 // epoch as for ovhip_intra_ctu_launch (d_state[0] = abort word, abort_mirror likewise).
 extern "C" int ovhip_intra_flow_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_pic *res, const ovhip_itask *d_tasks, uint32_t n_tasks,
                                        const uint32_t *d_items, uint32_t n_items, const ovhip_lmcs_region *d_regions, const ovhip_lmcs_luts *luts,
-                                       int16_t *d_scales, int32_t log2_ctu_s, uint32_t *d_state, uint32_t epoch, uint32_t *abort_mirror)
+                                       int16_t *d_scales, int32_t log2_ctu_s, uint32_t *d_state, uint32_t epoch, uint32_t *abort_mirror, int32_t prepare)
 {
     if (!ctx || !pic || !res) return OVHIP_EINVAL;
     OV_DEVICE(ctx);
@@ -1070,8 +1070,10 @@ extern "C" int ovhip_intra_flow_launch(ovhip_ctx *ctx, const ovhip_pic *pic, con
     const size_t nu = (size_t)((pic->w + 3) / 4) * ((pic->h + 3) / 4);
     fs.w4 = (pic->w + 3) / 4;
     fs.y = d_state + SYNC_FLAGS; fs.c[0] = fs.y + nu; fs.c[1] = fs.c[0] + nu; fs.reg = fs.c[1] + nu;
-    hipLaunchKernelGGL(k_intra_flow_prepare, dim3(n_tasks), dim3(64), 0, ctx->stream, d_tasks, n_tasks, fs, epoch);
-    OV_LAUNCH_CHECK(ctx, "k_intra_flow_prepare");
+    if (prepare) {
+        hipLaunchKernelGGL(k_intra_flow_prepare, dim3(n_tasks), dim3(64), 0, ctx->stream, d_tasks, n_tasks, fs, epoch);
+        OV_LAUNCH_CHECK(ctx, "k_intra_flow_prepare");
+    }
     const int nap = 0;          // poll back-off variant: 0 = s_sleep 4 between polls (16 the same; 64 and exponential back-off measured 6 % slower)
     hipLaunchKernelGGL(k_intra_flow, dim3(n_items), dim3(64), 0, ctx->stream, *pic, *res, d_tasks, d_items, n_items, d_regions, wnd, d_scales, log2_ctu_s, fs,
                        epoch, d_state, abort_mirror, nap);
