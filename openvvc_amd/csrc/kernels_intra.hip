@@ -91,32 +91,35 @@ __device__ __forceinline__ void fetch_refs(IntraLds &s, const Acc acc, int x0, i
     const int na = 2 * w + mrl + 1, nl = 2 * h + mrl + 1;
     const int l2u = unit == 4 ? 2 : 1;                                           // units are 4 luma / 2 chroma samples
     const int cx = x0 - 1 - mrl, cy = y0 - 1 - mrl;                               // sample (k = 0) of both arms
-#define ABV(k) acc.ld(cx + (k), cy)
-#define LFT(k) acc.ld(cx, cy + (k))
-    // fall-back values (wave-uniform): first sample of each arm's block part, bottom-most corner sample
-    const int a1 = avl_abv ? ABV(mrl + 1) : 0, l1 = avl_lft ? LFT(mrl + 1) : 0;
-    const int none = !corner && !avl_abv && !avl_lft;
+    // Every reference sample, substituted or not, is a copy of ONE picture sample: pick its coordinates first, then load -- all
+    // loads of both arms are independent (one memory round trip on the critical path of an ordered task instead of two).
+    const bool none = !corner && !avl_abv && !avl_lft;
     const int la = min(mrl + avl_abv * unit, na - 1), ll = min(mrl + avl_lft * unit, nl - 1);   // last available sample per arm
+    const int ax1 = cx + mrl + 1, ay1 = cy, lx1 = cx, ly1 = cy + mrl + 1;   // first sample of each arm's block part
     for (int k = lane; k < na + 24; k += 64) {
-        int v;
         const int kk = min(k, na - 1);
-        if (none) v = 1 << (OV_BD - 1);
-        else if (kk <= mrl) v = corner ? ABV(kk) : ((mrl == 0 && avl_abv && avl_lft) ? a1 : (avl_lft ? l1 : a1));
-        else if (((kk - mrl - 1) >> l2u) < avl_abv) v = ABV(kk);
-        else v = avl_abv ? ABV(la) : (corner ? ABV(mrl) : l1);
-        s.abv[IR_NEG + k] = (uint16_t)v;
+        int sx = cx + kk, sy = cy;
+        if (kk <= mrl) {
+            if (!corner) { const bool fa = (mrl == 0 && avl_abv && avl_lft) || !avl_lft; sx = fa ? ax1 : lx1; sy = fa ? ay1 : ly1; }
+        } else if (((kk - mrl - 1) >> l2u) >= avl_abv) {
+            if (avl_abv) sx = cx + la;
+            else if (corner) sx = cx + mrl;
+            else { sx = lx1; sy = ly1; }
+        }
+        s.abv[IR_NEG + k] = (uint16_t)(none ? 1 << (OV_BD - 1) : acc.ld(sx, sy));
     }
     for (int k = lane; k < nl + 24; k += 64) {
-        int v;
         const int kk = min(k, nl - 1);
-        if (none) v = 1 << (OV_BD - 1);
-        else if (kk <= mrl) v = corner ? LFT(kk) : (avl_lft ? l1 : a1);
-        else if (((kk - mrl - 1) >> l2u) < avl_lft) v = LFT(kk);
-        else v = avl_lft ? LFT(ll) : (corner ? LFT(mrl) : a1);
-        s.lft[IR_NEG + k] = (uint16_t)v;
+        int sx = cx, sy = cy + kk;
+        if (kk <= mrl) {
+            if (!corner) { sx = avl_lft ? lx1 : ax1; sy = avl_lft ? ly1 : ay1; }
+        } else if (((kk - mrl - 1) >> l2u) >= avl_lft) {
+            if (avl_lft) sy = cy + ll;
+            else if (corner) sy = cy + mrl;
+            else { sx = ax1; sy = ay1; }
+        }
+        s.lft[IR_NEG + k] = (uint16_t)(none ? 1 << (OV_BD - 1) : acc.ld(sx, sy));
     }
-#undef ABV
-#undef LFT
 }
 
 // Reference arms of an ISP prediction call (OVHIP_IF_ISP): the CODING UNIT's arms as fill_ref_above_0 / fill_ref_left_0 build
@@ -827,6 +830,21 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
     const bool has_res = t.flags & (luma ? OVHIP_IF_RES_Y : (comp ? OVHIP_IF_RES_CR : OVHIP_IF_RES_CB));
     if (res_only && !has_res) return;
 
+    // ---- what does not depend on the other ordered tasks (residual, inter prediction): requested before the wait ----
+    uint16_t *pl = luma ? pic.y : (comp ? pic.cr : pic.cb);
+    const int dstride = luma ? pic.stride_y : pic.stride_c, rstride = luma ? res.stride_y : res.stride_c;
+    uint16_t *dst = pl + t.y * dstride + t.x;
+    const int16_t *rp = reinterpret_cast<const int16_t *>(luma ? res.y : (comp ? res.cr : res.cb)) + t.y * rstride + t.x;
+    const int ciip_wt = res_only ? 0 : t.ciip_wt;
+    const bool need_d = ciip_wt || res_only;
+    const int res_mask = (t.flags & OVHIP_IF_ISP) ? t.isp_res_mask : 0xff, res_l2pb = (t.flags & OVHIP_IF_ISP) ? t.isp_log2_pb : 6;
+    int rv[NPL], dv[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int p = st.p0 + lane + 64 * i, x = p & (w - 1), y = p >> l2w;
+        rv[i] = (!region && has_res && p < st.p1 && ((res_mask >> (x >> res_l2pb)) & 1)) ? rp[y * rstride + x] : 0;     // residuals: the launches before
+        dv[i] = (!region && need_d && p < st.p1) ? dst[y * dstride + x] : 0;                                               // inter prediction: likewise
+    }
     // ---- what this item reads: unit state words, all polled at once ----
     int nfp = 0;
     auto add_run = [&](unsigned *base, int ux, int uy, int count, int dx, int dy) {
@@ -896,20 +914,6 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
             __hip_atomic_store(fs.reg + t.c_scale, pending + 1, RLX_AGENT);
         }
         return;
-    }
-    uint16_t *pl = luma ? pic.y : (comp ? pic.cr : pic.cb);
-    const int dstride = luma ? pic.stride_y : pic.stride_c, rstride = luma ? res.stride_y : res.stride_c;
-    uint16_t *dst = pl + t.y * dstride + t.x;
-    const int16_t *rp = reinterpret_cast<const int16_t *>(luma ? res.y : (comp ? res.cr : res.cb)) + t.y * rstride + t.x;
-    const int ciip_wt = res_only ? 0 : t.ciip_wt;
-    const bool need_d = ciip_wt || res_only;
-    const int res_mask = (t.flags & OVHIP_IF_ISP) ? t.isp_res_mask : 0xff, res_l2pb = (t.flags & OVHIP_IF_ISP) ? t.isp_log2_pb : 6;
-    int rv[NPL], dv[NPL];
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-        const int p = st.p0 + lane + 64 * i, x = p & (w - 1), y = p >> l2w;
-        rv[i] = (has_res && p < st.p1 && ((res_mask >> (x >> res_l2pb)) & 1)) ? rp[y * rstride + x] : 0;     // residuals: the launches before
-        dv[i] = (need_d && p < st.p1) ? dst[y * dstride + x] : 0;                                               // inter prediction: likewise
     }
     const bool scaled = !luma && (t.flags & OVHIP_IF_RES_SCALE);
     const int scale = scaled ? ((t.flags & OVHIP_IF_SCALE_IDX) ? (int)__hip_atomic_load(scales + t.c_scale, RLX_AGENT) : t.c_scale) : 0;
