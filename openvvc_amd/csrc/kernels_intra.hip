@@ -807,6 +807,8 @@ __global__ __launch_bounds__(64) void k_intra_flow_prepare(const ovhip_itask *__
     }
 }
 
+typedef uint32_t flow_u4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t flow_u2 __attribute__((ext_vector_type(2), aligned(4)));
 struct FlowLds { IntraLds s; unsigned *fp[FLOW_MAX_FP]; int abort; };
 
 __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res, const ovhip_itask *__restrict__ tasks, const uint32_t *__restrict__ items,
@@ -838,12 +840,54 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
     const int ciip_wt = res_only ? 0 : t.ciip_wt;
     const bool need_d = ciip_wt || res_only;
     const int res_mask = (t.flags & OVHIP_IF_ISP) ? t.isp_res_mask : 0xff, res_l2pb = (t.flags & OVHIP_IF_ISP) ? t.isp_log2_pb : 6;
+    // A lane owns runs of G consecutive samples of a row (G = 8, 4 or 1 by block width): residual and output move as 16- / 8-byte
+    // accesses -- a write-through store is one fabric write whatever its size, and 2-byte ones cost 12x the time per byte
+    const int l2g = w >= 8 ? 3 : (w == 4 ? 2 : 0);
+    auto p_of = [&](int i) { return st.p0 + (((lane + 64 * (i >> l2g)) << l2g) | (i & ((1 << l2g) - 1))); };
     int rv[NPL], dv[NPL];
 #pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-        const int p = st.p0 + lane + 64 * i, x = p & (w - 1), y = p >> l2w;
-        rv[i] = (!region && has_res && p < st.p1 && ((res_mask >> (x >> res_l2pb)) & 1)) ? rp[y * rstride + x] : 0;     // residuals: the launches before
-        dv[i] = (!region && need_d && p < st.p1) ? dst[y * dstride + x] : 0;                                               // inter prediction: likewise
+    for (int i = 0; i < NPL; ++i) { rv[i] = 0; dv[i] = 0; }
+    if (!region && (has_res || need_d)) {
+        if (l2g == 3) {
+#pragma unroll
+            for (int j = 0; j < NPL / 8; ++j) {
+                const int p = p_of(8 * j), x = p & (w - 1), y = p >> l2w;
+                if (p >= st.p1) break;
+                if (has_res) {
+                    const flow_u4 q = *reinterpret_cast<const flow_u4 *>(rp + y * rstride + x);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) rv[8 * j + e] = ((res_mask >> ((x + e) >> res_l2pb)) & 1) ? (int)(int16_t)(q[e >> 1] >> (16 * (e & 1))) : 0;
+                }
+                if (need_d) {
+                    const flow_u4 q = *reinterpret_cast<const flow_u4 *>(dst + y * dstride + x);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dv[8 * j + e] = (int)((q[e >> 1] >> (16 * (e & 1))) & 0xffff);
+                }
+            }
+        } else if (l2g == 2) {
+#pragma unroll
+            for (int j = 0; j < NPL / 4; ++j) {
+                const int p = p_of(4 * j), x = p & (w - 1), y = p >> l2w;
+                if (p >= st.p1) break;
+                if (has_res) {
+                    const flow_u2 q = *reinterpret_cast<const flow_u2 *>(rp + y * rstride + x);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rv[4 * j + e] = ((res_mask >> ((x + e) >> res_l2pb)) & 1) ? (int)(int16_t)(q[e >> 1] >> (16 * (e & 1))) : 0;
+                }
+                if (need_d) {
+                    const flow_u2 q = *reinterpret_cast<const flow_u2 *>(dst + y * dstride + x);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dv[4 * j + e] = (int)((q[e >> 1] >> (16 * (e & 1))) & 0xffff);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) {
+                const int p = p_of(i), x = p & (w - 1), y = p >> l2w;
+                rv[i] = (has_res && p < st.p1 && ((res_mask >> (x >> res_l2pb)) & 1)) ? rp[y * rstride + x] : 0;     // residuals: the launches before
+                dv[i] = (need_d && p < st.p1) ? dst[y * dstride + x] : 0;                                               // inter prediction: likewise
+            }
+        }
     }
     // ---- what this item reads: unit state words, all polled at once ----
     int nfp = 0;
@@ -935,14 +979,39 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
         }
         wave_sync();
     }
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-        const int p = st.p0 + lane + 64 * i, x = p & (w - 1), y = p >> l2w;
-        if (p >= st.p1) break;
+    auto sample = [&](int i, int p) {
         int v = res_only ? dv[i] : s.pred[p - st.p0];
         if (ciip_wt) v = (v * ciip_wt + dv[i] * (4 - ciip_wt) + 2) >> 2;
         if (has_res) v = ov_clip_bd(v + (scaled ? res_scale(rv[i], scale) : rv[i]));
-        __hip_atomic_store(dst + y * dstride + x, (uint16_t)v, RLX_AGENT);                  // write-through
+        return (uint32_t)v;
+    };
+    if (l2g == 3) {
+#pragma unroll
+        for (int j = 0; j < NPL / 8; ++j) {
+            const int p = p_of(8 * j), x = p & (w - 1), y = p >> l2w;
+            if (p >= st.p1) break;
+            flow_u4 q;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q[e] = sample(8 * j + 2 * e, p + 2 * e) | (sample(8 * j + 2 * e + 1, p + 2 * e + 1) << 16);
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst + y * dstride + x), "v"(q) : "memory");      // write-through
+        }
+    } else if (l2g == 2) {
+#pragma unroll
+        for (int j = 0; j < NPL / 4; ++j) {
+            const int p = p_of(4 * j), x = p & (w - 1), y = p >> l2w;
+            if (p >= st.p1) break;
+            flow_u2 q;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) q[e] = sample(4 * j + 2 * e, p + 2 * e) | (sample(4 * j + 2 * e + 1, p + 2 * e + 1) << 16);
+            asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(dst + y * dstride + x), "v"(q) : "memory");
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const int p = p_of(i), x = p & (w - 1), y = p >> l2w;
+            if (p >= st.p1) break;
+            __hip_atomic_store(dst + y * dstride + x, (uint16_t)sample(i, p), RLX_AGENT);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ---- this strip's units are written ----
