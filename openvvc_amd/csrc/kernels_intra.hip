@@ -565,6 +565,13 @@ __device__ u64 *g_probe;
 #else
 #define PROBE(k) do { } while (0)
 #endif
+// the same switch stamps the phases of every item of the flow launch (tools/debug/flow_probe.py): 8 stamps per item
+#ifdef OVHIP_CTU_PROBE
+__device__ const uint32_t *g_probe_items;      // the picture's first item: launches of later chunks index the stamps from it
+#define FPROBE(k) do { if (lane == 0 && g_probe) g_probe[(size_t)(items + blockIdx.x - g_probe_items) * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define FPROBE(k) do { } while (0)
+#endif
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 __device__ __forceinline__ ovhip_itask uniform_task(const ovhip_itask *p)
@@ -786,6 +793,11 @@ struct AgentAcc {
 };
 struct FlowState { unsigned *y, *c[2], *reg; int w4; };
 #define FLOW_MAX_FP 448
+#define FSTRIP 256                          // samples per item: one wave predicts a 1024-sample strip in ~2 us, the critical path of a hop
+#define FNPL   (FSTRIP / 64)
+#define FJ8    ((FSTRIP + 511) / 512)        // runs of 8 / of 4 samples per lane
+#define FJ4    ((FSTRIP + 255) / 256)
+#define FREG   (8 * FJ8 > FNPL ? 8 * FJ8 : FNPL)
 
 __global__ __launch_bounds__(64) void k_intra_flow_prepare(const ovhip_itask *__restrict__ tasks, uint32_t n, FlowState fs, unsigned epoch)
 {
@@ -828,7 +840,7 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
     const bool lm = t.kind == OVHIP_IT_CHROMA && t.mode >= 67 && !(t.flags & OVHIP_IF_BDPCM);
     const unsigned pending = 2 * epoch;
     const int w4 = fs.w4;
-    Strip st; st.p0 = strip * STRIP; st.p1 = min(npx, st.p0 + STRIP);
+    Strip st; st.p0 = strip * FSTRIP; st.p1 = min(npx, st.p0 + FSTRIP);
     const bool has_res = t.flags & (luma ? OVHIP_IF_RES_Y : (comp ? OVHIP_IF_RES_CR : OVHIP_IF_RES_CB));
     if (res_only && !has_res) return;
 
@@ -844,13 +856,13 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
     // accesses -- a write-through store is one fabric write whatever its size, and 2-byte ones cost 12x the time per byte
     const int l2g = w >= 8 ? 3 : (w == 4 ? 2 : 0);
     auto p_of = [&](int i) { return st.p0 + (((lane + 64 * (i >> l2g)) << l2g) | (i & ((1 << l2g) - 1))); };
-    int rv[NPL], dv[NPL];
+    int rv[FREG], dv[FREG];
 #pragma unroll
-    for (int i = 0; i < NPL; ++i) { rv[i] = 0; dv[i] = 0; }
+    for (int i = 0; i < FREG; ++i) { rv[i] = 0; dv[i] = 0; }
     if (!region && (has_res || need_d)) {
         if (l2g == 3) {
 #pragma unroll
-            for (int j = 0; j < NPL / 8; ++j) {
+            for (int j = 0; j < FJ8; ++j) {
                 const int p = p_of(8 * j), x = p & (w - 1), y = p >> l2w;
                 if (p >= st.p1) break;
                 if (has_res) {
@@ -866,7 +878,7 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
             }
         } else if (l2g == 2) {
 #pragma unroll
-            for (int j = 0; j < NPL / 4; ++j) {
+            for (int j = 0; j < FJ4; ++j) {
                 const int p = p_of(4 * j), x = p & (w - 1), y = p >> l2w;
                 if (p >= st.p1) break;
                 if (has_res) {
@@ -882,7 +894,7 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < NPL; ++i) {
+            for (int i = 0; i < FNPL; ++i) {
                 const int p = p_of(i), x = p & (w - 1), y = p >> l2w;
                 rv[i] = (has_res && p < st.p1 && ((res_mask >> (x >> res_l2pb)) & 1)) ? rp[y * rstride + x] : 0;     // residuals: the launches before
                 dv[i] = (need_d && p < st.p1) ? dst[y * dstride + x] : 0;                                               // inter prediction: likewise
@@ -890,6 +902,7 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
         }
     }
     // ---- what this item reads: unit state words, all polled at once ----
+    FPROBE(0);
     int nfp = 0;
     auto add_run = [&](unsigned *base, int ux, int uy, int count, int dx, int dy) {
         // count units from (ux, uy) in steps of (dx, dy); clipped to the table (count is wave-uniform)
@@ -927,6 +940,7 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
         if ((t.flags & OVHIP_IF_RES_SCALE) && (t.flags & OVHIP_IF_SCALE_IDX)) add_run(fs.reg, t.c_scale, 0, 1, 1, 0);
     }
     wave_sync();
+    FPROBE(1);
     {
         bool ok = true;
         for (int i = lane; i < nfp; i += 64) {
@@ -948,6 +962,7 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
             return;
         }
     }
+    FPROBE(2);
 
     const AgentAcc ya = { pic.y, pic.stride_y };
     if (region) {
@@ -966,6 +981,7 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
             if (t.flags & OVHIP_IF_ISP) fetch_refs_isp(s, ya, t, lane);
             else fetch_refs(s, ya, t.x, t.y, w, h, 4, t.flags & OVHIP_IF_CORNER, t.avl_abv, t.avl_lft, (t.flags & OVHIP_IF_MIP) ? 0 : t.mrl_idx, lane);
             wave_sync();
+            FPROBE(3);
             if (t.flags & OVHIP_IF_MIP) pred_mip(s, t, st, lane);
             else pred_regular(s, t, true, st, lane);
         } else {
@@ -979,6 +995,7 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
         }
         wave_sync();
     }
+    FPROBE(4);
     auto sample = [&](int i, int p) {
         int v = res_only ? dv[i] : s.pred[p - st.p0];
         if (ciip_wt) v = (v * ciip_wt + dv[i] * (4 - ciip_wt) + 2) >> 2;
@@ -987,7 +1004,7 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
     };
     if (l2g == 3) {
 #pragma unroll
-        for (int j = 0; j < NPL / 8; ++j) {
+        for (int j = 0; j < FJ8; ++j) {
             const int p = p_of(8 * j), x = p & (w - 1), y = p >> l2w;
             if (p >= st.p1) break;
             flow_u4 q;
@@ -997,7 +1014,7 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
         }
     } else if (l2g == 2) {
 #pragma unroll
-        for (int j = 0; j < NPL / 4; ++j) {
+        for (int j = 0; j < FJ4; ++j) {
             const int p = p_of(4 * j), x = p & (w - 1), y = p >> l2w;
             if (p >= st.p1) break;
             flow_u2 q;
@@ -1007,20 +1024,24 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < NPL; ++i) {
+        for (int i = 0; i < FNPL; ++i) {
             const int p = p_of(i), x = p & (w - 1), y = p >> l2w;
             if (p >= st.p1) break;
             __hip_atomic_store(dst + y * dstride + x, (uint16_t)sample(i, p), RLX_AGENT);
         }
     }
+    FPROBE(5);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FPROBE(6);
     // ---- this strip's units are written ----
     {
         const int sh = luma ? 2 : 1, y0s = st.p0 >> l2w, y1s = (st.p1 + w - 1) >> l2w;
         const int ux0 = t.x >> sh, uy0 = (t.y + y0s) >> sh, nx = max(1, w >> sh), ny = max(1, (y1s - y0s) >> sh);
         unsigned *fb = luma ? fs.y : fs.c[comp];
-        for (int i = lane; i < nx * ny; i += 64) __hip_atomic_store(fb + (uy0 + i / nx) * w4 + ux0 + i % nx, pending + 1, RLX_AGENT);
+        const int l2nx = ilog2(nx);                                             // block widths are powers of two
+        for (int i = lane; i < nx * ny; i += 64) __hip_atomic_store(fb + (uy0 + (i >> l2nx)) * w4 + ux0 + (i & (nx - 1)), pending + 1, RLX_AGENT);
     }
+    FPROBE(7);
 }
 
 } // namespace
@@ -1110,7 +1131,7 @@ extern "C" size_t ovhip_intra_flow_items(const ovhip_itask *sorted, size_t n, ui
         if (i >= (1u << 24)) return 0;
         if (t.kind == OVHIP_IT_REGION) { if (k < cap) items[k] = (uint32_t)i; ++k; continue; }
         if (t.kind == OVHIP_IT_LUMA && t.log2_h < 2) return 0;
-        const int npx = 1 << (t.log2_w + t.log2_h), strips = (npx + STRIP - 1) / STRIP, comps = t.kind == OVHIP_IT_LUMA ? 1 : 2;
+        const int npx = 1 << (t.log2_w + t.log2_h), strips = (npx + FSTRIP - 1) / FSTRIP, comps = t.kind == OVHIP_IT_LUMA ? 1 : 2;
         for (int st = 0; st < strips; ++st)
             for (int c = 0; c < comps; ++c) { if (k < cap) items[k] = (uint32_t)i | ((uint32_t)st << 24) | ((uint32_t)c << 28); ++k; }
     }
@@ -1147,6 +1168,9 @@ extern "C" int ovhip_intra_flow_launch(ovhip_ctx *ctx, const ovhip_pic *pic, con
         hipLaunchKernelGGL(k_intra_flow_prepare, dim3(n_tasks), dim3(64), 0, ctx->stream, d_tasks, n_tasks, fs, epoch);
         OV_LAUNCH_CHECK(ctx, "k_intra_flow_prepare");
     }
+#ifdef OVHIP_CTU_PROBE
+    if (prepare && hipMemcpyToSymbolAsync(HIP_SYMBOL(g_probe_items), &d_items, sizeof(d_items), 0, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return OVHIP_ELAUNCH;
+#endif
     const int nap = 0;          // poll back-off variant: 0 = s_sleep 4 between polls (16 the same; 64 and exponential back-off measured 6 % slower)
     hipLaunchKernelGGL(k_intra_flow, dim3(n_items), dim3(64), 0, ctx->stream, *pic, *res, d_tasks, d_items, n_items, d_regions, wnd, d_scales, log2_ctu_s, fs,
                        epoch, d_state, abort_mirror, nap);
