@@ -861,6 +861,39 @@ enum { OVHIP_TIME_MC = 0, OVHIP_TIME_MCXA, OVHIP_TIME_ITX_LUMA, OVHIP_TIME_LMCS_
 int  ovhip_job_time_stage(ovhip_job *job, int stage);
 int  ovhip_job_stage_time(ovhip_job *job, double *sum_ms, uint64_t *count);
 
+/* ------------------------------------------------------------------------------------
+ * Output path.  Replaces the per-frame copy-out of examples/dectest.c:372-409
+ * (write_decoded_frame_to_file): the conformance window is cropped and the three planes are packed, on the device,
+ * into the byte layout that function writes -- 16-bit little-endian samples, the cropped Y rows, then Cb, then Cr, no
+ * padding -- so that ONE contiguous D2H (or none, when only a digest is wanted) replaces three pitched plane copies.
+ * `ovhip_window` = OVFrame.output_window (libovvc/ovframe.h): offsets in CHROMA sample units, as dectest.c:383-388
+ * applies them (luma offsets are twice that).
+ *
+ * Digest: the reference's CI hashes the output FILE (CI/checkMD5.sh, md5sum); MD5 is a serial chain, so a whole frame
+ * cannot be hashed by more than one lane.  ovhip_output_row_md5_launch hashes every cropped ROW independently (RFC
+ * 1321 MD5 of the row's bytes, one lane per row); ovhip_pic_digest() returns the MD5 of the concatenated row digests
+ * (Y rows, Cb rows, Cr rows): a per-picture fingerprint any host can recompute from the written file with
+ * hashlib/md5sum per row, without the 25 MB frame leaving the device.  ovhip_md5_* is the plain host MD5 for callers
+ * that do want the file's md5sum from the packed frames.
+ * ---------------------------------------------------------------------------------- */
+typedef struct ovhip_window { uint16_t offset_lft, offset_rgt, offset_abv, offset_blw; } ovhip_window;
+/* Bytes of the cropped frame / number of cropped rows (luma + 2 x chroma); 0 if the window leaves nothing. */
+size_t ovhip_output_bytes(int32_t w, int32_t h, const ovhip_window *win);
+size_t ovhip_output_rows(int32_t w, int32_t h, const ovhip_window *win);
+/* d_out: DEVICE, ovhip_output_bytes() bytes.  Asynchronous on the ctx stream. */
+int  ovhip_output_pack_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_window *win, uint16_t *d_out);
+/* d_digests: DEVICE, 16 bytes per cropped row in the order Y rows, Cb rows, Cr rows.  Asynchronous. */
+int  ovhip_output_row_md5_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_window *win, uint8_t *d_digests);
+/* Synchronous conveniences: pack + one D2H into host_dst (ovhip_output_bytes() bytes, pinned or pageable); row
+ * digests + D2H + MD5 over them into out[16]. */
+int  ovhip_pic_output(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_window *win, void *host_dst);
+int  ovhip_pic_digest(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_window *win, uint8_t out[16]);
+/* Host MD5 (RFC 1321). */
+typedef struct ovhip_md5_state { uint32_t h[4]; uint64_t n_bytes; uint8_t buf[64]; } ovhip_md5_state;
+void ovhip_md5_init(ovhip_md5_state *st);
+void ovhip_md5_update(ovhip_md5_state *st, const void *data, size_t n);
+void ovhip_md5_final(ovhip_md5_state *st, uint8_t out[16]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -249,6 +249,27 @@ def lmcs_build(data: "LmcsData") -> "LmcsLuts":
     return out
 
 
+class Window(C.Structure):
+    """ovhip_window = OVFrame.output_window: offsets in chroma sample units"""
+    _fields_ = [("offset_lft", C.c_uint16), ("offset_rgt", C.c_uint16), ("offset_abv", C.c_uint16), ("offset_blw", C.c_uint16)]
+
+
+class Md5State(C.Structure):
+    _fields_ = [("h", C.c_uint32 * 4), ("n_bytes", C.c_uint64), ("buf", C.c_uint8 * 64)]
+
+
+def md5(data: bytes) -> bytes:
+    """ovhip_md5_* over a byte string (what the library uses for the digest of the row digests)"""
+    lib = load()
+    st = Md5State()
+    lib.ovhip_md5_init(C.byref(st))
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data) if data else None
+    lib.ovhip_md5_update(C.byref(st), buf, len(data))
+    out = (C.c_uint8 * 16)()
+    lib.ovhip_md5_final(C.byref(st), out)
+    return bytes(out)
+
+
 def load(path: os.PathLike | None = None) -> C.CDLL:
     """Load libovvc_hip.so (built in-tree by __graft_entry__.build()).  Fails loudly."""
     global _lib
@@ -355,6 +376,15 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_job_last_stats": (C.c_int, [vp, P(JobStats)]),
         "ovhip_job_time_stage": (C.c_int, [vp, C.c_int]),
         "ovhip_job_stage_time": (C.c_int, [vp, P(C.c_double), P(C.c_uint64)]),
+        "ovhip_output_bytes": (C.c_size_t, [i32, i32, P(Window)]),
+        "ovhip_output_rows": (C.c_size_t, [i32, i32, P(Window)]),
+        "ovhip_output_pack_launch": (C.c_int, [vp, P(Pic), P(Window), vp]),
+        "ovhip_output_row_md5_launch": (C.c_int, [vp, P(Pic), P(Window), vp]),
+        "ovhip_pic_output": (C.c_int, [vp, P(Pic), P(Window), vp]),
+        "ovhip_pic_digest": (C.c_int, [vp, P(Pic), P(Window), vp]),
+        "ovhip_md5_init": (None, [P(Md5State)]),
+        "ovhip_md5_update": (None, [P(Md5State), vp, C.c_size_t]),
+        "ovhip_md5_final": (None, [P(Md5State), vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)          # AttributeError = missing export: fail loudly
@@ -376,6 +406,8 @@ EXPORTED_SYMBOLS = [
     "ovhip_dmvr_search_launch", "ovhip_rec_append_raw", "ovhip_rec_set_dbf_offsets", "ovhip_rec_tu_intra", "ovhip_rec_itasks", "ovhip_rec_itasks_sorted", "ovhip_itx_launch_classes_res", "ovhip_intra_level_launch", "ovhip_intra_level_geom", "ovhip_intra_sync_words", "ovhip_intra_ctu_launch", "ovhip_intra_flow_words", "ovhip_intra_flow_items", "ovhip_intra_flow_launch",
     "ovhip_rec_itask_levels", "ovhip_rec_isp_cu", "ovhip_isp_geometry", "ovhip_rec_itasks_by_ctu", "ovhip_rec_set_ctu_size", "ovhip_job_bind", "ovhip_job_create", "ovhip_job_destroy", "ovhip_job_recorder", "ovhip_job_begin",
     "ovhip_job_flush", "ovhip_job_wait", "ovhip_job_refined_mvs", "ovhip_job_dmvr_rows", "ovhip_job_last_stats", "ovhip_job_time_stage", "ovhip_job_stage_time",
+    "ovhip_output_bytes", "ovhip_output_rows", "ovhip_output_pack_launch", "ovhip_output_row_md5_launch", "ovhip_pic_output", "ovhip_pic_digest",
+    "ovhip_md5_init", "ovhip_md5_update", "ovhip_md5_final",
 ]
 
 

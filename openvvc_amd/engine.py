@@ -246,6 +246,34 @@ class DevPic:
                                                       cr.ctypes.data, self.w, self.w // 2), "pic_download")
         return y, cb, cr
 
+    def output(self, window=(0, 0, 0, 0)) -> np.ndarray:
+        """The cropped frame in the byte layout dectest.c:372-409 writes (uint16 LE: Y rows, Cb rows, Cr rows), packed on the
+        device and fetched with one D2H.  window = (lft, rgt, abv, blw) in chroma sample units."""
+        win = capi.Window(*window)
+        n = self.ctx.lib.ovhip_output_bytes(self.w, self.h, C.byref(win))
+        if not n:
+            raise EngineError("output window leaves nothing")
+        out = np.empty(n // 2, np.uint16)
+        self.ctx._chk(self.ctx.lib.ovhip_pic_output(self.ctx.h, C.byref(self.s), C.byref(win), out.ctypes.data), "pic_output")
+        return out
+
+    def digest(self, window=(0, 0, 0, 0)) -> bytes:
+        """MD5 over the per-row MD5 digests (computed on the device) of the cropped frame"""
+        win = capi.Window(*window)
+        out = (C.c_uint8 * 16)()
+        self.ctx._chk(self.ctx.lib.ovhip_pic_digest(self.ctx.h, C.byref(self.s), C.byref(win), out), "pic_digest")
+        return bytes(out)
+
+    def row_digests(self, window=(0, 0, 0, 0)) -> np.ndarray:
+        win = capi.Window(*window)
+        rows = self.ctx.lib.ovhip_output_rows(self.w, self.h, C.byref(win))
+        buf = self.ctx.alloc(rows * 16)
+        self.ctx._chk(self.ctx.lib.ovhip_output_row_md5_launch(self.ctx.h, C.byref(self.s), C.byref(win), buf.ptr), "row_md5")
+        self.ctx.sync()
+        d = buf.download(np.uint8).reshape(rows, 16).copy()
+        buf.free()
+        return d
+
     def band(self, y0: int, h: int) -> "DevPic":
         """A view of rows [y0, y0+h) (luma) as its own picture (no copy)."""
         s = capi.Pic(self.s.y + y0 * self.s.stride_y * 2, self.s.cb + (y0 // 2) * self.s.stride_c * 2,

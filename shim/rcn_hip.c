@@ -1133,6 +1133,54 @@ rcn_hip_device_refs_(struct hip_entry *e, ovhip_pic *refs, int *n)
     return 0;
 }
 
+/* Output path: what examples/dectest.c:372-409 (write_decoded_frame_to_file) copies out of the OVFrame plane by plane, taken
+ * from the device picture of that frame instead -- cropped to frame->output_window and packed by one launch, fetched with
+ * one D2H; or only fingerprinted (MD5 over the per-row MD5 digests computed on the device), nothing but 16 bytes leaving. */
+static int
+dpb_find_decoded(const OVFrame *f, ovhip_pic *pic)
+{
+    int found = 0;
+    pthread_mutex_lock(&g_dpb_mtx);
+    for (int i = 0; i < DPB_SLOTS; ++i)
+        if (g_dpb[i].frame == f && g_dpb[i].submitted) { *pic = g_dpb[i].pic; found = 1; break; }
+    pthread_mutex_unlock(&g_dpb_mtx);
+    return found;
+}
+
+static ovhip_window
+frame_window(const OVFrame *f)
+{
+    ovhip_window w = { f->output_window.offset_lft, f->output_window.offset_rgt, f->output_window.offset_abv, f->output_window.offset_blw };
+    return w;
+}
+
+size_t
+ovhip_shim_frame_bytes(const OVFrame *frame)
+{
+    const ovhip_window w = frame_window(frame);
+    return ovhip_output_bytes(frame->width, frame->height, &w);
+}
+
+int
+ovhip_shim_frame_output(const OVCTUDec *c, const OVFrame *frame, void *dst)
+{
+    struct hip_entry *e = entry_of(c, 0);
+    ovhip_pic pic;
+    if (!e || !e->ctx || !frame || !dst || !dpb_find_decoded(frame, &pic)) return OVHIP_EINVAL;
+    const ovhip_window w = frame_window(frame);
+    return ovhip_pic_output(e->ctx, &pic, &w, dst);
+}
+
+int
+ovhip_shim_frame_digest(const OVCTUDec *c, const OVFrame *frame, uint8_t out[16])
+{
+    struct hip_entry *e = entry_of(c, 0);
+    ovhip_pic pic;
+    if (!e || !e->ctx || !frame || !out || !dpb_find_decoded(frame, &pic)) return OVHIP_EINVAL;
+    const ovhip_window w = frame_window(frame);
+    return ovhip_pic_digest(e->ctx, &pic, &w, out);
+}
+
 static void
 flush_picture(struct hip_entry *e, OVCTUDec *c)
 {

@@ -51,4 +51,13 @@ const int16_t *ovhip_shim_alf_table(const struct OVCTUDec *ctudec, int which /* 
 const struct ovhip_lmcs_luts *ovhip_shim_lmcs(const struct OVCTUDec *ctudec);
 void ovhip_shim_release(const struct OVCTUDec *ctudec);
 
+/* ---- output path (replaces the plane-by-plane copy-out of examples/dectest.c:372-409) ---- */
+struct Frame;
+/* Bytes of `frame` cropped to its output_window, in the layout write_decoded_frame_to_file writes. */
+size_t ovhip_shim_frame_bytes(const struct Frame *frame);
+/* The decoded frame's device picture, cropped and packed on the device, into dst (ovhip_shim_frame_bytes() bytes). */
+int  ovhip_shim_frame_output(const struct OVCTUDec *ctudec, const struct Frame *frame, void *dst);
+/* MD5 over the per-row MD5 digests of the cropped frame (include/ovvc_hip.h, "Output path"): only 16 bytes leave the device. */
+int  ovhip_shim_frame_digest(const struct OVCTUDec *ctudec, const struct Frame *frame, uint8_t out[16]);
+
 #endif

@@ -19,7 +19,7 @@ items = []
 for i in order:
     tt = t[i]
     if tt["kind"] == capi.IT_REGION: items.append((i, 0, 0)); continue
-    npx = 1 << (int(tt["log2_w"]) + int(tt["log2_h"])); strips = (npx + 1023) // 1024; comps = 1 if tt["kind"] == capi.IT_LUMA else 2
+    npx = 1 << (int(tt["log2_w"]) + int(tt["log2_h"])); strips = (npx + 255) // 256; comps = 1 if tt["kind"] == capi.IT_LUMA else 2
     for s in range(strips):
         for c in range(comps): items.append((i, s, c))
 n = len(items)
@@ -40,10 +40,11 @@ owner = np.full(((H + 3) // 4, uw), -1, np.int64)
 luma = []
 for k, (i, s, c) in enumerate(items):
     tt = t[i]
-    if tt["kind"] != capi.IT_LUMA or (int(tt["log2_w"]) + int(tt["log2_h"])) > 10 or int(tt["flags"]) & capi.IF_ISP: continue
+    if tt["kind"] != capi.IT_LUMA or (int(tt["log2_w"]) + int(tt["log2_h"])) > 8 or int(tt["flags"]) & capi.IF_ISP: continue
     x, y, w, h = int(tt["x"]), int(tt["y"]), 1 << int(tt["log2_w"]), 1 << int(tt["log2_h"])
     owner[y >> 2:(y + h + 3) >> 2, x >> 2:(x + w + 3) >> 2] = k
     luma.append(k)
+area = {}
 ph = {"poll begin->ready": [], "ready->refs": [], "refs->pred": [], "pred->issued": [], "issued->acked": [], "acked->marked": [], "producer marked->ready": [], "producer acked->ready": []}
 waited = 0
 for k in luma:
@@ -62,6 +63,7 @@ for k in luma:
     last7 = max(p[q][7] for q in prods); last6 = max(p[q][6] for q in prods)
     if last7 < r[1]: continue                      # inputs were ready before this item looked: not on a critical hop
     waited += 1
+    area.setdefault((int(tt["log2_w"]) + int(tt["log2_h"]), "mip" if int(tt["flags"]) & capi.IF_MIP else ("pl/dc" if int(tt["mode"]) < 2 else "ang")), []).append((r[3] - r[2], r[4] - r[3], r[5] - r[4], r[6] - r[5], r[7] - r[6], r[2] - last7))
     ph["poll begin->ready"].append(r[2] - r[1]); ph["ready->refs"].append(r[3] - r[2]); ph["refs->pred"].append(r[4] - r[3])
     ph["pred->issued"].append(r[5] - r[4]); ph["issued->acked"].append(r[6] - r[5]); ph["acked->marked"].append(r[7] - r[6])
     ph["producer marked->ready"].append(r[2] - last7); ph["producer acked->ready"].append(r[2] - last6)
@@ -71,3 +73,8 @@ for name, v in ph.items():
     print(f"  {name:28s} median {np.median(v):6.2f}  mean {v.mean():6.2f}  p90 {np.percentile(v, 90):6.2f} us")
 hop = us(np.array(ph["producer marked->ready"]) + np.array(ph["ready->refs"]) + np.array(ph["refs->pred"]) + np.array(ph["pred->issued"]) + np.array(ph["issued->acked"]) + np.array(ph["acked->marked"]))
 print("  hop (producer marked -> this item marked): median %.2f mean %.2f us" % (np.median(hop), hop.mean()))
+
+print("by log2 area, kind: n, ready->refs, refs->pred, pred->issued, issued->acked, acked->marked, detect (median us)")
+for k in sorted(area):
+    a = np.array(area[k]) / 100.0
+    print(" ", k, len(a), np.round(np.median(a, axis=0), 2).tolist())
