@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define OVHIP_ABI_VERSION 4
+#define OVHIP_ABI_VERSION 5
 
 /* ---- error codes (negative, in the spirit of libovvc/overror.h:40-45) ---- */
 #define OVHIP_OK        0
@@ -826,6 +826,10 @@ typedef struct ovhip_job_params {        /* picture-level side information; HOST
      * stream blocks the hardware queue it shares with other streams.  Non-zero return aborts the flush with OVHIP_EINVAL. */
     int (*before_launch)(void *user);
     void *before_launch_user;
+    /* != 0: the flush also derives the TMVP plane cells of the refined units (ovhip_tmvp_cells_launch) and brings them back
+     * with the refined vectors: ovhip_job_tmvp_cells().  nb_ctb_w of the plane = ceil(picture width / CTU size). */
+    uint32_t tmvp_cells;
+    uint32_t pad_;
 } ovhip_job_params;
 
 typedef struct ovhip_job_stats {         /* what the last flush moved and launched */
@@ -893,6 +897,26 @@ typedef struct ovhip_md5_state { uint32_t h[4]; uint64_t n_bytes; uint8_t buf[64
 void ovhip_md5_init(ovhip_md5_state *st);
 void ovhip_md5_update(ovhip_md5_state *st, const void *data, size_t n);
 void ovhip_md5_final(ovhip_md5_state *st, uint8_t out[16]);
+
+/* ------------------------------------------------------------------------------------
+ * TMVP motion plane.  The reference's caller stores what rcn_dmvr_mv_refine returned into the CTU-local
+ * 16x16 array of 8x8 cells tmvp_mv[l].mvs (vcl_coding_unit.c:2629-2645: cell ((x0 + 7) >> 3, (y0 + 7) >> 3) of the <= 16x16
+ * block, its right neighbour for 16-wide and lower neighbour(s) for 16-high blocks), and tmvp_store_mv copies rows
+ * 0 .. nb_tmvp_unit-1 of that array into the picture's plane (drv_lines.c:270-330: plane->mvs + ctb_offset + i * pln_stride,
+ * pln_stride = nb_tmvp_unit * nb_ctb_w, nb_tmvp_unit = ctu >> 3).  ovhip_tmvp_cells_launch does that address arithmetic
+ * on the device: for every refined unit with OVHIP_MC_DMVR it emits the plane cells the refined vectors belong in, in
+ * PICTURE-LEVEL plane coordinates, so that the host applies a per-picture (or per-CTU-row) delta to the plane without
+ * keeping per-CU bookkeeping -- the compressed-plane hand-over of the decoded picture's motion field.
+ * out: 4 entries per unit (entry 4 * u + k; cell == OVHIP_TMVP_NONE: unused).
+ * ---------------------------------------------------------------------------------- */
+#define OVHIP_TMVP_NONE 0xffffffffu
+typedef struct ovhip_tmvp_cell { uint32_t cell; int32_t mv0x, mv0y, mv1x, mv1y; } ovhip_tmvp_cell;
+/* d_units / d_refined (4 int32 per unit: ovhip_mcx_launch's mv_out) / d_out: DEVICE.  Asynchronous on the ctx stream. */
+int  ovhip_tmvp_cells_launch(ovhip_ctx *ctx, const ovhip_mc_unit *d_units, uint32_t n_units, const int32_t *d_refined,
+                             int32_t log2_ctu_s, int32_t nb_ctb_w, ovhip_tmvp_cell *d_out);
+/* After ovhip_job_wait of a flush with ovhip_job_params.tmvp_cells != 0: the cells of the picture's refined units (4 per
+ * unit, recorder order), valid until the job's next begin. */
+const ovhip_tmvp_cell *ovhip_job_tmvp_cells(ovhip_job *job, size_t *n_entries);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,7 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libovvc_hip.so"
 
 # ---- constants (include/ovvc_hip.h) ----
-OVHIP_ABI_VERSION = 4
+OVHIP_ABI_VERSION = 5
 OVHIP_OK, OVHIP_ENODEV, OVHIP_ENOMEM, OVHIP_EINVAL, OVHIP_ELAUNCH, OVHIP_EUNSUP = 0, -1, -2, -3, -4, -5
 DST_VII, DCT_VIII, DCT_II = 0, 1, 2
 TB_TR, TB_DC, TB_TS, TB_TS_RAW = 0, 1, 2, 3
@@ -182,7 +182,7 @@ class JobParams(C.Structure):
                 ("alf_luma_coeff", C.c_void_p), ("alf_luma_clip", C.c_void_p),
                 ("alf_chroma_coeff", C.c_void_p), ("alf_chroma_clip", C.c_void_p), ("alf_cc_coeff", C.c_void_p),
                 ("log2_ctu_s", C.c_int32), ("stages", C.c_uint32), ("wait_events", C.POINTER(C.c_void_p)), ("n_wait_events", C.c_uint32),
-                ("before_launch", C.c_void_p), ("before_launch_user", C.c_void_p)]
+                ("before_launch", C.c_void_p), ("before_launch_user", C.c_void_p), ("tmvp_cells", C.c_uint32), ("pad_", C.c_uint32)]
 
 
 BEFORE_LAUNCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
@@ -195,6 +195,8 @@ class JobStats(C.Structure):
                 ("n_itasks", C.c_uint32), ("n_ilevels", C.c_uint32)]
 
 
+TMVP_CELL_DTYPE = np.dtype([("cell", "<u4"), ("mv0x", "<i4"), ("mv0y", "<i4"), ("mv1x", "<i4"), ("mv1y", "<i4")])
+TMVP_NONE = 0xffffffff
 REC_TB, REC_COEF, REC_MC, REC_MCX, REC_AFF, REC_SIDE, REC_REGION, REC_CIIP, REC_EDGE_V, REC_EDGE_H, REC_ITASK = range(11)
 TIME_STAGES = ("mc", "mcxa", "itx_luma", "lmcs_scale", "itx_chroma", "dbf", "sao", "alf", "intra", "h2d")
 STAGE_MC, STAGE_ITX, STAGE_DBF, STAGE_SAO, STAGE_ALF, STAGE_INTRA = 1, 2, 4, 8, 16, 32
@@ -376,6 +378,8 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_job_last_stats": (C.c_int, [vp, P(JobStats)]),
         "ovhip_job_time_stage": (C.c_int, [vp, C.c_int]),
         "ovhip_job_stage_time": (C.c_int, [vp, P(C.c_double), P(C.c_uint64)]),
+        "ovhip_tmvp_cells_launch": (C.c_int, [vp, vp, u32, vp, i32, i32, vp]),
+        "ovhip_job_tmvp_cells": (vp, [vp, P(C.c_size_t)]),
         "ovhip_output_bytes": (C.c_size_t, [i32, i32, P(Window)]),
         "ovhip_output_rows": (C.c_size_t, [i32, i32, P(Window)]),
         "ovhip_output_pack_launch": (C.c_int, [vp, P(Pic), P(Window), vp]),
@@ -407,7 +411,7 @@ EXPORTED_SYMBOLS = [
     "ovhip_rec_itask_levels", "ovhip_rec_isp_cu", "ovhip_isp_geometry", "ovhip_rec_itasks_by_ctu", "ovhip_rec_set_ctu_size", "ovhip_job_bind", "ovhip_job_create", "ovhip_job_destroy", "ovhip_job_recorder", "ovhip_job_begin",
     "ovhip_job_flush", "ovhip_job_wait", "ovhip_job_refined_mvs", "ovhip_job_dmvr_rows", "ovhip_job_last_stats", "ovhip_job_time_stage", "ovhip_job_stage_time",
     "ovhip_output_bytes", "ovhip_output_rows", "ovhip_output_pack_launch", "ovhip_output_row_md5_launch", "ovhip_pic_output", "ovhip_pic_digest",
-    "ovhip_md5_init", "ovhip_md5_update", "ovhip_md5_final",
+    "ovhip_md5_init", "ovhip_md5_update", "ovhip_md5_final", "ovhip_tmvp_cells_launch", "ovhip_job_tmvp_cells",
 ]
 
 

@@ -16,7 +16,7 @@ namespace {
 
 struct DevBuf { void *p; size_t cap; };
 
-enum { B_TB, B_COEF, B_MC, B_MCX, B_MV, B_AFF, B_SIDE, B_REG, B_SCALE, B_EV, B_EH, B_PARAM, B_CLASS, B_CIIP, B_ITASK, B_ICTU, B_IITEM, B_COUNT };
+enum { B_TB, B_COEF, B_MC, B_MCX, B_MV, B_AFF, B_SIDE, B_REG, B_SCALE, B_EV, B_EH, B_PARAM, B_CLASS, B_CIIP, B_ITASK, B_ICTU, B_IITEM, B_TMVP, B_COUNT };
 
 // layout of the parameter block (one pinned staging copy, one H2D)
 struct ParamLayout { size_t sao, alf_ctus, lcoef, lclip, ccoef, cclip, cc, fwd, bwd, total; };
@@ -36,6 +36,7 @@ struct ovhip_job {
     uint32_t *abort_host;                // pinned word the ordered pass writes when a bounded wait expired
     char *param_host; size_t param_cap;  // pinned staging of the picture-level tables
     int32_t *mv_host; size_t mv_cap;     // pinned: refined vectors, 4 int32 per refined unit
+    ovhip_tmvp_cell *tmvp_host; size_t tmvp_cap, n_tmvp;   // pinned: TMVP plane cells of the refined units (ovhip_job_params.tmvp_cells)
     size_t n_mv;                         // units covered by the last flush / eager pass
     size_t dmvr_first;                   // refined units [0, dmvr_first) already went through the eager search
     hipEvent_t ev_h2d, ev_done;
@@ -175,7 +176,7 @@ void ovhip_job_destroy(ovhip_job *j)
     if (j->d_flow) (void)hipFree(j->d_flow);
     pinned_free(nullptr, j->items_host);
     pinned_free(nullptr, j->abort_host);
-    pinned_free(nullptr, j->param_host); pinned_free(nullptr, j->mv_host);
+    pinned_free(nullptr, j->param_host); pinned_free(nullptr, j->mv_host); pinned_free(nullptr, j->tmvp_host);
     for (int k = 0; k < 32; ++k) for (int q = 0; q < 2; ++q) if (j->t_ev[k][q]) (void)hipEventDestroy(j->t_ev[k][q]);
     if (j->ev_h2d) (void)hipEventDestroy(j->ev_h2d);
     if (j->ev_done) (void)hipEventDestroy(j->ev_done);
@@ -228,6 +229,13 @@ const int32_t *ovhip_job_refined_mvs(ovhip_job *j, size_t *n_units)
     if (!j || !n_units) return nullptr;
     *n_units = j->n_mv;
     return j->mv_host;
+}
+
+const ovhip_tmvp_cell *ovhip_job_tmvp_cells(ovhip_job *j, size_t *n_entries)
+{
+    if (!j || !n_entries) return nullptr;
+    *n_entries = j->n_tmvp;
+    return j->tmvp_host;
 }
 
 int ovhip_job_last_stats(const ovhip_job *j, ovhip_job_stats *out)
@@ -455,6 +463,18 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
             j->st.d2h_bytes += n_mcx * 16;
         }
         j->n_mv = n_mcx;
+        j->n_tmvp = 0;
+        if (n_mcx && pr->tmvp_cells) {
+            // the same vectors as a delta of the picture's collocated motion plane
+            const size_t bytes = 4 * n_mcx * sizeof(ovhip_tmvp_cell);
+            CHK(dev_reserve(j, B_TMVP, bytes));
+            CHK(pinned_reserve(j, (void **)&j->tmvp_host, &j->tmvp_cap, bytes));
+            CHK(ovhip_tmvp_cells_launch(ctx, (const ovhip_mc_unit *)DEV(B_MCX), (uint32_t)n_mcx, (const int32_t *)j->dev[B_MV].p, log2_ctu,
+                                        (j->w + (1 << log2_ctu) - 1) >> log2_ctu, (ovhip_tmvp_cell *)j->dev[B_TMVP].p));
+            OV_HIP(ctx, hipMemcpyAsync(j->tmvp_host, j->dev[B_TMVP].p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+            j->st.n_launches++; j->st.d2h_bytes += bytes;
+            j->n_tmvp = 4 * n_mcx;
+        }
         if (n_ciip) { CHK(ovhip_ciip_launch(ctx, dst, intra, (const ovhip_ciip_unit *)DEV(B_CIIP), (uint32_t)n_ciip)); j->st.n_launches++; }
     }
     // ---- residual: luma blocks, chroma-scale derivation on the reconstructed luma, chroma blocks (+ inverse mapping) ----

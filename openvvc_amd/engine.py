@@ -123,6 +123,14 @@ class Context:
                                                   regions.ptr if regions else None, C.byref(luts) if luts is not None else None,
                                                   scales.ptr if scales else None, log2_ctu, sync.ptr, epoch, None), "intra_ctu_launch")
 
+    def tmvp_cells(self, units: "DevBuf", n: int, refined: "DevBuf", log2_ctu: int, nb_ctb_w: int) -> np.ndarray:
+        out = self.alloc(4 * n * capi.TMVP_CELL_DTYPE.itemsize)
+        self._chk(self.lib.ovhip_tmvp_cells_launch(self.h, units.ptr, n, refined.ptr, log2_ctu, nb_ctb_w, out.ptr), "tmvp_cells")
+        self.sync()
+        r = out.download(np.uint8).view(capi.TMVP_CELL_DTYPE).copy()
+        out.free()
+        return r
+
     def dbf(self, pic: "DevPic", planes: "DevDbfPlanes"):
         self._chk(self.lib.ovhip_dbf_launch(self.h, C.byref(pic.s), C.byref(planes.s)), "dbf_launch")
 
@@ -499,6 +507,14 @@ class Job:
         if not n.value:
             return np.zeros((0, 4), np.int32)
         return np.frombuffer((C.c_int32 * (4 * n.value)).from_address(p), dtype=np.int32).reshape(-1, 4).copy()
+
+    def tmvp_cells(self) -> np.ndarray:
+        """ovhip_job_tmvp_cells after wait(): capi.TMVP_CELL_DTYPE, 4 entries per refined unit (cell == capi.TMVP_NONE: unused)"""
+        n = C.c_size_t()
+        p = self.lib.ovhip_job_tmvp_cells(self.j, C.byref(n))
+        if not n.value:
+            return np.zeros(0, capi.TMVP_CELL_DTYPE)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (n.value * capi.TMVP_CELL_DTYPE.itemsize,)).view(capi.TMVP_CELL_DTYPE).copy()
 
     def stats(self) -> "capi.JobStats":
         s = capi.JobStats()

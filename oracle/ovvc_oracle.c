@@ -1243,6 +1243,43 @@ void oracle_alf_run(const oracle_pic *dst, const oracle_pic *src, const oracle_a
 }
 
 /* ====================================================================================
+ * TMVP motion plane: where the refined vectors go
+ * ================================================================================== */
+/* The sequential form of what the reference does per CTU: the caller overwrites entries of the CTU-local array
+ * tmvp_mv[l].mvs[16 * 16] with what rcn_dmvr_mv_refine returned (vcl_coding_unit.c:2629-2645: entry
+ * ((x0 + 7 + j * 16) >> 3) + ((y0 + 7 + i * 16) >> 3) * 16, + 1 for 16-wide, + 16 for 16-high blocks, + 17 for both), then
+ * tmvp_store_mv copies the first nb_tmvp_unit entries of the first nb_tmvp_unit rows of that array into the picture's plane
+ * at ctb_offset + i * pln_stride (drv_lines.c:288-310).  units: the refined units (<= 16x16 each, picture coordinates);
+ * out: 4 entries per unit as ovhip_tmvp_cells_launch writes them. */
+void oracle_tmvp_cells(const ovhip_mc_unit *units, uint32_t n, const int32_t *refined, int log2_ctu, int nb_ctb_w, ovhip_tmvp_cell *out)
+{
+    const int nb_tmvp_unit = (1 << log2_ctu) >> 3, pln_stride = nb_tmvp_unit * nb_ctb_w;
+    for (uint32_t u = 0; u < n; ++u) {
+        const ovhip_mc_unit *t = &units[u];
+        for (int k = 0; k < 4; ++k) { out[4 * u + k].cell = OVHIP_TMVP_NONE; out[4 * u + k].mv0x = out[4 * u + k].mv0y = out[4 * u + k].mv1x = out[4 * u + k].mv1y = 0; }
+        if (!(t->flags & OVHIP_MC_DMVR)) continue;
+        const int ctb_x = t->x >> log2_ctu, ctb_y = t->y >> log2_ctu;
+        const int x0 = t->x - (ctb_x << log2_ctu), y0 = t->y - (ctb_y << log2_ctu);
+        const int log2_w = t->w > 8 ? 4 : 3, log2_h = t->h > 8 ? 4 : 3;
+        const int base = ((x0 + 7) >> 3) + ((y0 + 7) >> 3) * 16;
+        int idx[4], n_idx = 0;
+        idx[n_idx++] = base;
+        if (log2_w > 3) idx[n_idx++] = base + 1;
+        if (log2_h > 3) { idx[n_idx++] = base + 16; if (log2_w > 3) idx[n_idx++] = base + 16 + 1; }
+        const int ctb_offset = (ctb_x + ctb_y * pln_stride) * nb_tmvp_unit;
+        for (int q = 0; q < n_idx; ++q) {
+            const int row = idx[q] >> 4, col = idx[q] & 15;           /* entry of the 16-stride array */
+            if (row >= nb_tmvp_unit || col >= nb_tmvp_unit) continue; /* not among what tmvp_store_mv copies */
+            /* slot: 0 base, 1 right, 2 below, 3 below-right (the order of ovhip_tmvp_cells_launch) */
+            const int slot = (idx[q] - base == 1) ? 1 : (idx[q] - base == 16 ? 2 : (idx[q] - base == 17 ? 3 : 0));
+            ovhip_tmvp_cell *c = &out[4 * u + slot];
+            c->cell = (uint32_t)(ctb_offset + row * pln_stride + col);
+            c->mv0x = refined[4 * u]; c->mv0y = refined[4 * u + 1]; c->mv1x = refined[4 * u + 2]; c->mv1y = refined[4 * u + 3];
+        }
+    }
+}
+
+/* ====================================================================================
  * Intra prediction and the ordered pass
  * ================================================================================== */
 #include "ovvc_oracle_intra.c"

@@ -628,6 +628,11 @@ gen_mcx(const char *dir)
                                 (void)ctb_off;
                                 if (g0->x != e0.x || g0->y != e0.y || g1->x != e1.x || g1->y != e1.y) bad++;
                                 checked += e0.x != 0;
+                                if (e0.x != 0) {
+                                    /* which unit of the case the entry belongs to is encoded in the recognisable value */
+                                    int32_t rec[3] = { (int32_t)S.n_cases, py2 * pln_stride + px2, (e0.x - 100000 - (int32_t)n_cases * 1000) / 8 };
+                                    gbuf_push(&S.tmvp_exp, rec, 3);
+                                }
                             }
                         if (bad) { fprintf(stderr, "shim: refined-MV write-back differs from the reference's flow in %d entries (case %u)\n", bad, n_cases); exit(1); }
                         gbuf_push(&S.mv_chk, &checked, 1);

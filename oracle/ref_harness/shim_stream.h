@@ -14,7 +14,7 @@
 static int g_shim;
 
 #define SHIM_NARR 11            /* OVHIP_REC_TB .. OVHIP_REC_ITASK */
-struct shim_stream { gbuf arr[SHIM_NARR]; gbuf off; uint32_t n_cases; gbuf mv_chk; };
+struct shim_stream { gbuf arr[SHIM_NARR]; gbuf off; uint32_t n_cases; gbuf mv_chk; gbuf tmvp_exp; };
 
 static void
 shim_stream_init(struct shim_stream *s)
@@ -22,7 +22,7 @@ shim_stream_init(struct shim_stream *s)
     static const int t[SHIM_NARR] = { T_U8, T_I16, T_U8, T_U8, T_U8, T_I32, T_U8, T_U8, T_U8, T_U8, T_U8 };
     memset(s, 0, sizeof(*s));
     for (int i = 0; i < SHIM_NARR; ++i) s->arr[i].type = t[i];
-    s->off.type = T_U32; s->mv_chk.type = T_I32;
+    s->off.type = T_U32; s->mv_chk.type = T_I32; s->tmvp_exp.type = T_I32;
 }
 
 static void
@@ -99,6 +99,8 @@ shim_stream_write(const char *dir, const char *name, struct shim_stream *s, OVCT
     uint32_t d1 = (uint32_t)np;
     gfile_array(&g, "ref_map", T_I32, np ? (const void *)map : (const void *)"", 1, &d1);
     if (s->mv_chk.n) gfile_buf(&g, "mv_patch_checked", &s->mv_chk);
+    /* per plane entry the reference's flow writes: case, cell in the picture's plane, the unit whose vectors it holds */
+    if (s->tmvp_exp.n) gfile_buf(&g, "tmvp_expected", &s->tmvp_exp);
     gfile_close(&g);
     fprintf(stderr, "%s: %u cases", name, s->n_cases);
     for (int i = 0; i < SHIM_NARR; ++i) if (end[i]) fprintf(stderr, ", %u %s", end[i], nm[i]);

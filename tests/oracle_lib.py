@@ -34,6 +34,8 @@ def lib():
         _lib.oracle_mc_full.restype = None
         _lib.oracle_mc_ex.argtypes = [C.POINTER(OPic), C.POINTER(OPic), C.c_uint32, vp, C.c_uint32, vp, vp]
         _lib.oracle_mc_ex.restype = None
+        _lib.oracle_tmvp_cells.argtypes = [vp, C.c_uint32, vp, C.c_int, C.c_int, vp]
+        _lib.oracle_tmvp_cells.restype = None
         _lib.oracle_itx_ex.argtypes = [C.POINTER(OPic), vp, C.c_uint32, vp, vp]
         _lib.oracle_itx_ex.restype = None
         _lib.oracle_lmcs_scale.argtypes = [C.POINTER(OPic), vp, C.c_uint32, vp, vp]
@@ -210,3 +212,13 @@ def alf(dst: HostPic, src: HostPic, alf: dict, log2_ctu: int = 7):
     st = capi.AlfPic(*[a.ctypes.data for a in keep], scratch.ctypes.data, log2_ctu)
     d, s_ = dst.struct(), src.struct()
     lib().oracle_alf_run(C.byref(d), C.byref(s_), C.addressof(st))
+
+
+def tmvp_cells(units: np.ndarray, refined: np.ndarray, log2_ctu: int, nb_ctb_w: int) -> np.ndarray:
+    """oracle_tmvp_cells: the plane cells the refined vectors of the DMVR units go to (4 entries per unit)"""
+    from openvvc_amd import capi
+    units = np.ascontiguousarray(units)
+    refined = np.ascontiguousarray(refined, dtype=np.int32)
+    out = np.zeros(4 * len(units), capi.TMVP_CELL_DTYPE)
+    lib().oracle_tmvp_cells(units.ctypes.data, len(units), refined.ctypes.data, log2_ctu, nb_ctb_w, out.ctypes.data)
+    return out

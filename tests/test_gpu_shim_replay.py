@@ -237,3 +237,44 @@ def test_shim_isp_cus_gpu(ctx):
             bad.append((i, bw, bh, int(vertical), int(mode), hex(int(bits))))
     job.close()
     assert not bad, f"{len(bad)} / {len(info)} ISP CUs differ from the reference on the GPU, first: {bad[:10]}"
+
+
+@pytest.mark.gpu
+def test_tmvp_plane_cells_gpu(ctx):
+    """the device's plane-cell derivation for the refined units == the entries the reference's flow wrote (fixture
+    tmvp_expected) and == the oracle, for every DMVR case; then the same through the job (ovhip_job_params.tmvp_cells) on a
+    synthetic 1080p picture, where the cells must carry the vectors the flush refined."""
+    import oracle_lib
+    from openvvc_amd import synth
+    refs, descs, exp_off, exp, exp_mv = golden_cases.mcx_cases()
+    s = ShimStream("shim_mcx.ovg")
+    nb_ctb_w = (refs[0].w + 127) // 128
+    e = np.asarray(s.g["tmvp_expected"]).reshape(-1, 3)
+    n = 0
+    for i, d in enumerate(descs):
+        units = s.case(i)["mcx"]
+        if not len(units):
+            continue
+        fake = (1000 + 8 * np.arange(len(units))[:, None] + np.arange(4)[None, :]).astype(np.int32)
+        got = ctx.tmvp_cells(ctx.upload(units), len(units), ctx.upload(fake), 7, nb_ctb_w)
+        assert np.array_equal(got, oracle_lib.tmvp_cells(units, fake, 7, nb_ctb_w)), f"case {i}"
+        have = {(int(c["cell"]), int((c["mv0x"] - 1000) // 8)) for c in got if c["cell"] != capi.TMVP_NONE}
+        assert have == {(int(c), int(u)) for k, c, u in e if k == i}, f"case {i}"
+        n += len(have)
+    assert n > 600
+    # through the job
+    w, h = 1920, 1080
+    wl = synth.make_workload(w, h, 0x515)
+    job = engine.Job(ctx, w, h)
+    drefs = [ctx.upload_pic(*r) for r in wl.refs]
+    dst = ctx.new_pic(w, h)
+    job.load_workload(wl)
+    job.params.tmvp_cells = 1
+    job.flush(dst, drefs, None)
+    job.wait()
+    mv = job.refined_mvs()
+    cells = job.tmvp_cells()
+    assert len(cells) == 4 * len(mv) and len(mv) == len(wl.mcx_units)
+    assert np.array_equal(cells, oracle_lib.tmvp_cells(wl.mcx_units, mv, 7, (w + 127) // 128))
+    used = cells[cells["cell"] != capi.TMVP_NONE]
+    assert len(used) > 100 and used["cell"].max() < 16 * ((w + 127) // 128) * 16 * ((h + 127) // 128)

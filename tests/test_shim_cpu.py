@@ -141,6 +141,36 @@ def test_shim_refined_slots_match_reference(built_lib):
     assert len(chk) == n_dmvr and chk.min() >= 1 and chk.sum() > 600
 
 
+def _tmvp_expected(s, i):
+    e = np.asarray(s.g["tmvp_expected"]).reshape(-1, 3)
+    return {(int(c), int(u)) for k, c, u in e if k == i}
+
+
+def test_tmvp_plane_cells_match_reference_flow(built_lib):
+    """Where the refined vectors go in the picture's collocated motion plane: the oracle's sequential restatement
+    of the caller's stores + tmvp_store_mv against the entries the harness saw the reference's flow write (tmvp_expected:
+    case, plane cell, unit), for every DMVR case of the shim-recorded stream."""
+    refs, descs, exp_off, exp, exp_mv = golden_cases.mcx_cases()
+    s = ShimStream("shim_mcx.ovg")
+    nb_ctb_w = (refs[0].w + 127) // 128
+    n = 0
+    for i, d in enumerate(descs):
+        if not d.refine & capi.PU_DMVR:
+            assert not _tmvp_expected(s, i)
+            continue
+        units = s.case(i)["mcx"]
+        fake = (1000 + 8 * np.arange(len(units))[:, None] + np.arange(4)[None, :]).astype(np.int32)
+        got = oracle_lib.tmvp_cells(units, fake, 7, nb_ctb_w)
+        have = {(int(c["cell"]), int((c["mv0x"] - 1000) // 8)) for c in got if c["cell"] != capi.TMVP_NONE}
+        assert have == _tmvp_expected(s, i), f"case {i}"
+        for c in got:
+            if c["cell"] != capi.TMVP_NONE:
+                u = (int(c["mv0x"]) - 1000) // 8
+                assert [c["mv0x"], c["mv0y"], c["mv1x"], c["mv1y"]] == fake[u].tolist()
+        n += len(have)
+    assert n > 600
+
+
 def test_shim_affine_slots_match_reference(built_lib):
     """The affine drivers' per-4x4 rcn_mcp_b_l / rcn_prof_mcp_b_l and per-8x8 rcn_mcp_b_c calls, collected back into CUs."""
     refs, cases, exp_off, exp = golden_cases.mca_cases()
