@@ -189,6 +189,7 @@ def main():
 
     lv = capi.STAGE_INTRA_CTU if args.intra_ctu else (capi.STAGE_INTRA_LEVELS if args.intra_levels else 0)
     nthreads = S if args.host_threads < 0 else max(1, min(args.host_threads, S))
+    one_at_a_time = [False]        # survey of the kernels alone on the device: one host thread, one picture in flight
     gop_base = [0]                                 # GOPs this rank has decoded so far (keeps the key-buffer rotation going)
     keep_work = []
 
@@ -339,7 +340,7 @@ def main():
                     evt.set()
 
         trace = []
-        th = [threading.Thread(target=worker, args=(s,)) for s in range(nthreads)]
+        th = [threading.Thread(target=worker, args=(s,)) for s in range(1 if one_at_a_time[0] else nthreads)]
         if world > 1:
             th.append(threading.Thread(target=comm))
         [t.start() for t in th]
@@ -404,7 +405,23 @@ def main():
         barrier()
         survey[name] = read_timer()
     kern = {k: v for k, v in survey.items() if k != "h2d"}
-    dom = max(kern, key=kern.get)
+    # The roofline kernel = the largest launch group among the kernels the HBM roofline applies to.  The ordered pass is a
+    # dependency chain: hops x latency per hop, neither bytes nor flops bound it; it is reported beside the roofline
+    # ("ordered_pass"), not as its subject.
+    dom = max((k for k in kern if k != "intra"), key=kern.get)
+    # the same groups with ONE picture in flight (same rotation, nothing resident): what a launch takes when it has the device
+    # to itself -- the timed configuration stretches every launch by the 15 other pictures it shares the device with
+    isolated = {}
+    if rank == 0 or world > 1:
+        one_at_a_time[0] = True
+        for name in present:
+            if name == "h2d":
+                continue
+            set_timer(name)
+            run_steps(K)
+            barrier()
+            isolated[name] = read_timer()
+        one_at_a_time[0] = False
     if world > 1:
         pick = torch.tensor([present.index(dom)], dtype=torch.int64, device=None if debug_gloo else dev)
         dist.broadcast(pick, 0)
@@ -452,6 +469,14 @@ def main():
                     "picked_from": "survey in the timed configuration (same rotation and pictures in flight)",
                     "survey_launch_us": {k: round(v * 1e6, 2) for k, v in survey.items()},
                     "frac_per_kernel": {k: round(alg[k] / kern[k] / 1e9 / HBM_PEAK_GBPS, 5) for k in alg},
+                    "isolated_launch_us": {k: round(v * 1e6, 2) for k, v in isolated.items()},
+                    "frac_isolated_per_kernel": {k: round(alg[k] / isolated[k] / 1e9 / HBM_PEAK_GBPS, 5) for k in alg if k in isolated and k != "intra"},
+                    "frac_isolated": round(alg[dom] / isolated[dom] / 1e9 / HBM_PEAK_GBPS, 5) if dom in isolated else None,
+                    "ordered_pass": ({"kernel": KNAME["intra"], "bound": "latency (dependency chain, DESIGN 4.1)",
+                                      "avg_us_per_picture_timed": round(kern["intra"] * 1e6, 2),
+                                      "avg_us_per_picture_isolated": round(isolated.get("intra", 0.0) * 1e6, 2),
+                                      "levels_per_i_picture": int(wls[-1].stats["n_ilevels"]), "levels_per_b_picture": int(wls[0].stats["n_ilevels"])}
+                                     if "intra" in kern else None),
                     "algorithmic_bytes": {k: int(v) for k, v in alg.items()},
                     "frame_frac": round(sum(alg.values()) * fps / world / 1e9 / HBM_PEAK_GBPS, 5)}
 
