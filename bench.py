@@ -189,6 +189,7 @@ def main():
 
     lv = capi.STAGE_INTRA_CTU if args.intra_ctu else (capi.STAGE_INTRA_LEVELS if args.intra_levels else 0)
     nthreads = S if args.host_threads < 0 else max(1, min(args.host_threads, S))
+    second_passes = [0]            # pictures ovhip_job_wait had to decode a second time (flow launch gave up), whole run
     one_at_a_time = [False]        # survey of the kernels alone on the device: one host thread, one picture in flight
     gop_base = [0]                                 # GOPs this rank has decoded so far (keeps the key-buffer rotation going)
     keep_work = []
@@ -286,6 +287,7 @@ def main():
                 issued[p.idx].set()
                 t_iss = time.perf_counter()
                 st.job.wait()
+                second_passes[0] += int(st.job.stats().n_ordered_retries)
             if args.trace_gop:
                 trace.append((p.idx, p.poc, p.layer, slot, t_pull, t_dep, t_bind, t_iss, time.perf_counter()))
 
@@ -522,6 +524,7 @@ def main():
                        "intra_tasks_per_b_picture": st["n_itasks"], "intra_levels_per_b_picture": st["n_ilevels"],
                        "intra_levels_per_i_picture": wls[-1].stats["n_ilevels"],
                        "h2d_bytes_per_step": int(mean_stat("h2d_bytes")), "d2h_bytes_per_step": int(mean_stat("d2h_bytes")),
+                       "ordered_pass_second_passes": second_passes[0],
                        "launches_per_step": round((int(all_stats[0].n_launches) + (IP - 1) * int(js.n_launches)) / IP, 1),
                        "h2d_copies_per_step": round(mean_stat("n_h2d"), 1),
                        "launches_per_b_picture": int(js.n_launches),

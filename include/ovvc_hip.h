@@ -836,6 +836,7 @@ typedef struct ovhip_job_stats {         /* what the last flush moved and launch
     uint64_t h2d_bytes, d2h_bytes;
     uint32_t n_launches, n_h2d;
     uint32_t n_tb, n_mc, n_mcx, n_aff, n_edges_v, n_edges_h, n_regions, n_itasks, n_ilevels;
+    uint32_t n_ordered_retries;          /* 1: ovhip_job_wait decoded the picture a second time, one launch per level (see there) */
 } ovhip_job_stats;
 
 int  ovhip_job_create(ovhip_ctx *ctx, int32_t pic_w, int32_t pic_h, ovhip_job **out);
@@ -850,6 +851,10 @@ int  ovhip_job_bind(ovhip_job *job, ovhip_ctx *ctx);
  * caller's planar prediction for fused CIIP blends, or NULL.  All DEVICE pictures of the job's size. */
 int  ovhip_job_flush(ovhip_job *job, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs,
                      const ovhip_pic *intra, const ovhip_job_params *params);
+/* Waits for the flush.  If the ordered pass's flow launch gave up (bounded wait of a workgroup for its inputs: the launches of
+ * several pictures can starve each other of compute-unit slots), the picture is decoded a second time right here with one
+ * launch per level, from the recorder's arrays: ovhip_job_params' tables and the pictures passed to ovhip_job_flush must
+ * stay valid until this call returns.  OVHIP_ELAUNCH only if that fails too. */
 int  ovhip_job_wait(ovhip_job *job);
 /* int32 [n][4] (mv0x, mv0y, mv1x, mv1y per refined unit, recorder order): valid after ovhip_job_wait, or, for the
  * units covered, after ovhip_job_dmvr_rows. */

@@ -192,7 +192,7 @@ class JobStats(C.Structure):
     _fields_ = [("h2d_bytes", C.c_uint64), ("d2h_bytes", C.c_uint64), ("n_launches", C.c_uint32), ("n_h2d", C.c_uint32),
                 ("n_tb", C.c_uint32), ("n_mc", C.c_uint32), ("n_mcx", C.c_uint32), ("n_aff", C.c_uint32),
                 ("n_edges_v", C.c_uint32), ("n_edges_h", C.c_uint32), ("n_regions", C.c_uint32),
-                ("n_itasks", C.c_uint32), ("n_ilevels", C.c_uint32)]
+                ("n_itasks", C.c_uint32), ("n_ilevels", C.c_uint32), ("n_ordered_retries", C.c_uint32)]
 
 
 TMVP_CELL_DTYPE = np.dtype([("cell", "<u4"), ("mv0x", "<i4"), ("mv0y", "<i4"), ("mv1x", "<i4"), ("mv1y", "<i4")])

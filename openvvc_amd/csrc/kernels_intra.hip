@@ -546,7 +546,7 @@ __global__ __launch_bounds__(64) void k_intra_level(ovhip_pic pic, ovhip_pic res
 #define CT_CS    (4 + CT_S / 2)
 #define CT_CHUNK 128                        // tasks staged in LDS at a time
 #define SYNC_FLAGS 16                       // sync[0] = abort code; flags from word 16
-#define SPIN_LIMIT (1u << 21)
+#define SPIN_LIMIT (1u << 17)              // polls before a workgroup gives up (>= 40 ms; a legitimate wait is a few ms): ovhip_job_wait then decodes the picture per level
 
 struct CtuLds {
     uint16_t ty[CT_S][CT_YS], top_y[4 + 2 * CT_S + 4];
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(256) void k_intra_ctu(ovhip_pic pic, ovhip_pic res,
                 unsigned *f = flags + ny * ncx + nx;
                 unsigned spins = 0;
                 while (__hip_atomic_load(f, RLX_AGENT) != epoch) {
-                    if (++spins > SPIN_LIMIT || __hip_atomic_load(sync, RLX_AGENT) != 0) { ok = false; break; }
+                    if (++spins > (SPIN_LIMIT << 4) || __hip_atomic_load(sync, RLX_AGENT) != 0) { ok = false; break; }
                     __builtin_amdgcn_s_sleep(8);
                 }
             }

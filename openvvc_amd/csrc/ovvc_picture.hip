@@ -36,6 +36,8 @@ struct ovhip_job {
     uint32_t *abort_host;                // pinned word the ordered pass writes when a bounded wait expired
     char *param_host; size_t param_cap;  // pinned staging of the picture-level tables
     int32_t *mv_host; size_t mv_cap;     // pinned: refined vectors, 4 int32 per refined unit
+    struct { int valid, has_intra; ovhip_pic dst, refs[16], intra; uint32_t n_refs; ovhip_job_params pr; } again;   // the last flush's arguments
+    uint32_t n_retries;                  // second passes of the last picture (ovhip_job_wait)
     ovhip_tmvp_cell *tmvp_host; size_t tmvp_cap, n_tmvp;   // pinned: TMVP plane cells of the refined units (ovhip_job_params.tmvp_cells)
     size_t n_mv;                         // units covered by the last flush / eager pass
     size_t dmvr_first;                   // refined units [0, dmvr_first) already went through the eager search
@@ -207,6 +209,9 @@ int ovhip_job_bind(ovhip_job *j, ovhip_ctx *ctx)
     return OVHIP_OK;
 }
 
+static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs, const ovhip_pic *intra,
+                          const ovhip_job_params *pr);
+
 int ovhip_job_wait(ovhip_job *j)
 {
     if (!j) return OVHIP_EINVAL;
@@ -215,10 +220,24 @@ int ovhip_job_wait(ovhip_job *j)
     hipError_t e = hipEventSynchronize(j->ev_done);
     if (e != hipSuccess) return ov_fail(j->ctx, OVHIP_ELAUNCH, "hipEventSynchronize(job)", e);
     if (j->abort_host && *(volatile uint32_t *)j->abort_host) {
-        // a workgroup of the ordered pass gave up waiting for its inputs: the picture is incomplete.  Re-arm and report.
+        // a workgroup of the ordered pass gave up waiting for its inputs (workgroups of several pictures' flow launches can
+        // fill the compute units with pollers whose producers then find no slot): the picture is incomplete.  Re-arm, and decode
+        // the picture again with one launch per level -- no workgroup of such a launch waits for another -- from the recorder's
+        // arrays, which are untouched until the next ovhip_job_begin.  Every sample of dst is rewritten by a flush.
         *(volatile uint32_t *)j->abort_host = 0;
         if (j->d_sync) (void)hipMemset(j->d_sync, 0, sizeof(uint32_t));
         if (j->d_flow) (void)hipMemset(j->d_flow, 0, sizeof(uint32_t));
+        if (j->again.valid && j->n_retries == 0) {
+            j->n_retries = 1;
+            ovhip_job_params pr = j->again.pr;
+            pr.stages = ((pr.stages ? pr.stages : (uint32_t)(OVHIP_STAGE_MC | OVHIP_STAGE_ITX | OVHIP_STAGE_DBF | OVHIP_STAGE_SAO | OVHIP_STAGE_ALF | OVHIP_STAGE_INTRA)) | OVHIP_STAGE_INTRA_LEVELS) & ~(uint32_t)OVHIP_STAGE_INTRA_CTU;
+            pr.wait_events = nullptr; pr.n_wait_events = 0; pr.before_launch = nullptr;      // the references were done the first time
+            int r = job_flush_impl(j, &j->again.dst, j->again.refs, j->again.n_refs, j->again.has_intra ? &j->again.intra : nullptr, &pr);
+            if (r) return r;
+            e = hipEventSynchronize(j->ev_done);
+            if (e != hipSuccess) return ov_fail(j->ctx, OVHIP_ELAUNCH, "hipEventSynchronize(job, second pass)", e);
+            return OVHIP_OK;
+        }
         return ov_fail(j->ctx, OVHIP_ELAUNCH, "ordered pass: a CTU's bounded wait for its neighbours expired (picture incomplete)", hipSuccess);
     }
     return OVHIP_OK;
@@ -302,10 +321,30 @@ int64_t ovhip_job_dmvr_rows(ovhip_job *j, const ovhip_pic *refs, uint32_t n_refs
     return (int64_t)n;
 }
 
+static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs, const ovhip_pic *intra,
+                          const ovhip_job_params *pr);
+
 int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs, const ovhip_pic *intra,
                     const ovhip_job_params *pr)
 {
     if (!j || !dst || !pr) return OVHIP_EINVAL;
+    // what a second flush of the same picture needs (ovhip_job_wait re-runs the picture with one launch per level when the
+    // flow launch gave up): the pictures by value, the parameter block as the caller passed it (its tables stay the caller's
+    // until ovhip_job_wait has returned)
+    j->again.valid = n_refs <= 16;
+    j->again.dst = *dst;
+    for (uint32_t i = 0; i < n_refs && i < 16; ++i) j->again.refs[i] = refs[i];
+    j->again.n_refs = n_refs;
+    j->again.has_intra = intra != nullptr;
+    if (intra) j->again.intra = *intra;
+    j->again.pr = *pr;
+    j->n_retries = 0;
+    return job_flush_impl(j, dst, refs, n_refs, intra, pr);
+}
+
+static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs, const ovhip_pic *intra,
+                          const ovhip_job_params *pr)
+{
     ovhip_ctx *ctx = j->ctx;
     OV_DEVICE(ctx);
     if (dst->w != j->w || dst->h != j->h) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_job_flush: picture size differs from the job's", hipSuccess);
@@ -314,6 +353,7 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
     if (log2_ctu < 5 || log2_ctu > 7) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_job_flush: log2_ctu_s", hipSuccess);
     const size_t n_ctu = (size_t)((j->w + (1 << log2_ctu) - 1) >> log2_ctu) * ((j->h + (1 << log2_ctu) - 1) >> log2_ctu);
     memset(&j->st, 0, sizeof(j->st));
+    j->st.n_ordered_retries = j->n_retries;
     j->resident = (stages & OVHIP_STAGE_RESIDENT) && pr->stages;
     ovhip_recorder *rec = j->rec;
 
@@ -543,11 +583,14 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
                 *j->abort_host = 0;
             }
             if (++j->epoch >= 0x7ffffff0u) j->epoch = 1;
+            // test hook: behave as if a workgroup of this picture's flow launch had given up (ovhip_job_wait's second pass)
+            if (getenv("OVHIP_TEST_FORCE_SECOND_PASS") && j->n_retries == 0) *(volatile uint32_t *)j->abort_host = 1;
             // in chunks of whole levels, at least FLOW_CHUNK items each.  The workgroups of a launch are resident and polling while
             // they wait, each holding 9 KB of LDS the other pictures' kernels then do not get; a chunk bounds that, but every
             // chunk boundary is a drain of the dependency front (measured at 4K, 16 pictures in flight: 1024 items 1724 fps,
             // 2048 1856, 4096 1896, 8192 1937, one launch 1943)
-            const size_t FLOW_CHUNK = 8192;
+            // (OVHIP_FLOW_CHUNK: tuning knob, read once)
+            static const size_t FLOW_CHUNK = getenv("OVHIP_FLOW_CHUNK") && atol(getenv("OVHIP_FLOW_CHUNK")) > 0 ? (size_t)atol(getenv("OVHIP_FLOW_CHUNK")) : 8192;
             size_t a = 0;
             int first = 1;
             while (a < n_items) {

@@ -145,3 +145,30 @@ def test_picture_with_intra_matches_oracle(ctx, w, h, seed, frac, one_launch):
     if mvs is not None:
         assert np.array_equal(job.refined_mvs(), mvs)
     job.close()
+
+
+@pytest.mark.gpu
+def test_second_pass_after_an_abandoned_flow_launch(ctx, monkeypatch):
+    """ovhip_job_wait decodes the picture again with one launch per level when the flow launch reports an expired wait (forced
+    here through the library's test hook): same samples and vectors as the oracle, and the statistics say so."""
+    w, h = 832, 480
+    wl = synth.make_workload(w, h, 0x31, tools=synth.INTRA_TOOLS, intra_frac=0.3)
+    job = engine.Job(ctx, w, h)
+    refs = [ctx.upload_pic(*r) for r in wl.refs]
+    dst = ctx.new_pic(w, h)
+    job.load_workload(wl)
+    monkeypatch.setenv("OVHIP_TEST_FORCE_SECOND_PASS", "1")
+    job.flush(dst, refs, None)
+    job.wait()
+    monkeypatch.delenv("OVHIP_TEST_FORCE_SECOND_PASS")
+    assert job.stats().n_ordered_retries == 1
+    got = dst.download()
+    ref, mvs = oracle_pipeline.decode(wl, want_mvs=True)
+    for name, a, b in (("Y", got[0], ref.y), ("Cb", got[1], ref.cb), ("Cr", got[2], ref.cr)):
+        assert np.array_equal(a, b), f"second pass: plane {name}: {int((a != b).sum())} samples differ"
+    assert np.array_equal(job.refined_mvs(), mvs)
+    # and the next picture of the job takes the flow launch again
+    job.begin(); job.load_workload(wl)
+    job.flush(dst, refs, None); job.wait()
+    assert job.stats().n_ordered_retries == 0
+    assert np.array_equal(dst.download()[0], ref.y)
