@@ -107,6 +107,9 @@ def main():
     ap.add_argument("--intra-levels", action="store_true", help="ordered pass as one launch per level instead of one launch with per-unit dependency flags")
     ap.add_argument("--device-waits", action="store_true", help="reference pictures as stream waits (barrier packets) instead of host waits before the launches")
     ap.add_argument("--trace-gop", action="store_true", help="debug: host timeline of the pictures of the last run on stderr")
+    ap.add_argument("--gop-rotation", type=int, default=1,
+                    help="GOPs of picture sets / destination buffers in the rotation: with 1 a picture of GOP g + 1 overwrites the buffer of the same "
+                         "position of GOP g and waits for its readers, which bounds the look-ahead to one GOP whatever --in-flight says")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="N > 1: weak = every rank decodes --steps pictures (the stream grows with N); strong = the stream is --steps pictures in total, "
                          "its GOPs dealt to the ranks (each rank times --steps / N pictures)")
@@ -177,15 +180,17 @@ def main():
         return st
 
     order = gop.gop_decode_order(G)
-    sets = [new_job(wls[n_b]) if j == 0 else new_job(wls[j % n_b]) for j in range(K)]         # set 0: the key picture as I picture
-    key_i = [sets[0], new_job(wls[n_b]), new_job(wls[n_b])]                                  # consecutive key pictures overlap: own jobs
-    key_b = new_job(wls[0]) if IP > G else None                                              # ... and as inter key picture
-    all_jobs = sets + key_i[1:] + ([key_b] if key_b else [])
-    bufs_b = [torch_pic(ctxs[0]) for _ in range(K)]                    # destination of GOP position j (j >= 1)
-    bufs_key = [torch_pic(ctxs[0], wls[0].refs[k % n_ref_slots]) for k in range(3)]
+    R = max(1, args.gop_rotation)                                                            # GOPs in the rotation
+    NK = R + 2                                                                               # key pictures alive at a time
+    sets = [new_job(wls[n_b]) if j % K == 0 else new_job(wls[j % n_b]) for j in range(R * K)]     # position 0: the key picture as I picture
+    key_i = [sets[0]] + [new_job(wls[n_b]) for _ in range(NK - 1)]                           # consecutive key pictures overlap: own jobs
+    key_b = [new_job(wls[0]) for _ in range(NK)] if IP > G else None                         # ... and as inter key pictures
+    all_jobs = sets + key_i[1:] + (key_b if key_b else [])
+    bufs_b = [torch_pic(ctxs[0]) for _ in range(R * K)]                # destination of GOP position j (j >= 1) of rotation slot r: [r * K + j]
+    bufs_key = [torch_pic(ctxs[0], wls[0].refs[k % n_ref_slots]) for k in range(NK)]
     bufs_recv = [torch_pic(ctxs[0], wls[0].refs[k % n_ref_slots]) for k in range(2)] if world > 1 else []
     torch.cuda.synchronize(dev)
-    working_set = (K + 3 + len(bufs_recv)) * FB + len(all_jobs) * FB            # destinations + each job's SAO picture
+    working_set = (R * K + NK + len(bufs_recv)) * FB + len(all_jobs) * FB            # destinations + each job's SAO picture
 
     lv = capi.STAGE_INTRA_CTU if args.intra_ctu else (capi.STAGE_INTRA_LEVELS if args.intra_levels else 0)
     nthreads = S if args.host_threads < 0 else max(1, min(args.host_threads, S))
@@ -212,9 +217,9 @@ def main():
             if p.gop < 0:
                 # the picture before the first GOP: for rank 0 the key buffer its previous GOP left, else whatever is there
                 if rank == 0:
-                    buf[p.idx] = bufs_key[(first_gop - 1) % 3]
+                    buf[p.idx] = bufs_key[(first_gop - 1) % NK]
             elif p.owner == rank:
-                buf[p.idx] = bufs_key[local_gop(p) % 3] if p.layer == 0 else bufs_b[order.index((p.poc - p.gop * G, p.layer))]
+                buf[p.idx] = bufs_key[local_gop(p) % NK] if p.layer == 0 else bufs_b[(local_gop(p) % R) * K + order.index((p.poc - p.gop * G, p.layer))]
             elif rank in p.sends:
                 buf[p.idx] = bufs_recv[(first_gop + (p.gop + 1) // world) % 2]
         # who reads what (on this rank), who occupied a buffer before
@@ -254,7 +259,7 @@ def main():
         def decode(p, slot):
             t_pull = time.perf_counter()
             j = order.index((p.poc - p.gop * G, p.layer))
-            st = sets[j] if j else (key_i[local_gop(p) % 3] if (p.intra or key_b is None) else key_b)
+            st = sets[(local_gop(p) % R) * K + j] if j else (key_i[local_gop(p) % NK] if (p.intra or key_b is None) else key_b[local_gop(p) % NK])
             stream = ext[slot]
             evs = []
             wait_for(stream, p.refs, evs)
@@ -386,7 +391,7 @@ def main():
             tot += s; cnt += n
         return tot / max(cnt, 1)
 
-    run_steps(max(args.warmup, (2 if key_b else 1) * K))            # every picture set flushed at least once
+    run_steps(max(args.warmup, (2 if key_b else 1) * K * max(R, NK if key_b else 1)))            # every picture set flushed at least once
     barrier()
     all_stats = [st.job.stats() for st in sets]          # of full (non-resident) flushes
     flush_stats = all_stats[-1]                          # a B picture
