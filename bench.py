@@ -271,20 +271,13 @@ def main():
                 st.job.bind(ctxs[slot])
                 t_bind = time.perf_counter()
                 st.job.params.stages = ((capi.STAGE_ALL | capi.STAGE_RESIDENT) if resident else capi.STAGE_ALL) | lv
-                if args.device_waits:
-                    handles = (C.c_void_p * max(1, len(evs)))(*[e.cuda_event for e in evs])
-                    st.job.params.wait_events = C.cast(handles, C.POINTER(C.c_void_p))
-                    st.job.params.n_wait_events = len(evs)
-                    st.job.params.before_launch = None
-                else:
-                    # the frame thread waits for its reference pictures itself (ovdpb_frame_synchro), after its uploads are under way
-                    def host_wait(_user, evs=evs):
-                        for e in evs:
-                            e.synchronize()
-                        return 0
-                    cb = capi.BEFORE_LAUNCH_FN(host_wait)
-                    st.job.params.n_wait_events = 0
-                    st.job.params.before_launch = C.cast(cb, C.c_void_p)
+                # the frame thread waits for its reference pictures itself (ovdpb_frame_synchro), after its uploads are under way:
+                # on the host, in the flush (wait_on_host) -- or, --device-waits, as barriers in the stream
+                handles = (C.c_void_p * max(1, len(evs)))(*[e.cuda_event for e in evs])
+                st.job.params.wait_events = C.cast(handles, C.POINTER(C.c_void_p))
+                st.job.params.n_wait_events = len(evs)
+                st.job.params.wait_on_host = 0 if args.device_waits else 1
+                st.job.params.before_launch = None
                 st.job.flush(buf[p.idx][1], refs, None)
                 ev = torch.cuda.Event()
                 stream.record_event(ev)

@@ -829,7 +829,9 @@ typedef struct ovhip_job_params {        /* picture-level side information; HOST
     /* != 0: the flush also derives the TMVP plane cells of the refined units (ovhip_tmvp_cells_launch) and brings them back
      * with the refined vectors: ovhip_job_tmvp_cells().  nb_ctb_w of the plane = ceil(picture width / CTU size). */
     uint32_t tmvp_cells;
-    uint32_t pad_;
+    /* != 0: wait_events are waited for ON THE HOST (hipEventSynchronize on the flushing thread, after the uploads have been
+     * enqueued) instead of being put into the stream: before_launch without a callback into the caller's language. */
+    uint32_t wait_on_host;
 } ovhip_job_params;
 
 typedef struct ovhip_job_stats {         /* what the last flush moved and launched */

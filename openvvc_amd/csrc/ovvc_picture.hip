@@ -476,7 +476,10 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
     OV_HIP(ctx, hipEventRecord(j->ev_h2d, ctx->stream));
     // everything below reads or writes pictures: behind the pictures this one depends on
     for (uint32_t i = 0; i < pr->n_wait_events; ++i)
-        if (pr->wait_events && pr->wait_events[i]) OV_HIP(ctx, hipStreamWaitEvent(ctx->stream, (hipEvent_t)pr->wait_events[i], 0));
+        if (pr->wait_events && pr->wait_events[i]) {
+            if (pr->wait_on_host) OV_HIP(ctx, hipEventSynchronize((hipEvent_t)pr->wait_events[i]));
+            else OV_HIP(ctx, hipStreamWaitEvent(ctx->stream, (hipEvent_t)pr->wait_events[i], 0));
+        }
     if (pr->before_launch && pr->before_launch(pr->before_launch_user))
         return ov_fail(ctx, OVHIP_EINVAL, "ovhip_job_flush: before_launch callback failed", hipSuccess);
 
