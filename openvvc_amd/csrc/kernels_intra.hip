@@ -43,7 +43,7 @@ struct IntraLds {
     int      par[16];                    // CCLM neighbour samples / MIP boundary
     short    ang[32], inv_ang[32];       // the angle tables, staged by load_tables() next to the task load (not behind it)
     signed char fc[32][4];
-    uint16_t pred[1024];                 // the strip's predicted samples
+    __attribute__((aligned(16))) uint16_t pred[1024];               // the strip's predicted samples
 };
 #define STRIP 1024
 #define NPL   (STRIP / 64)
@@ -996,20 +996,36 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
         wave_sync();
     }
     FPROBE(4);
-    auto sample = [&](int i, int p) {
-        int v = res_only ? dv[i] : s.pred[p - st.p0];
-        if (ciip_wt) v = (v * ciip_wt + dv[i] * (4 - ciip_wt) + 2) >> 2;
-        if (has_res) v = ov_clip_bd(v + (scaled ? res_scale(rv[i], scale) : rv[i]));
-        return (uint32_t)v;
+    // epilogue of a run of n samples (registers i0 .. i0 + n - 1): prediction out of LDS in ONE read, then blend / residual / clip
+    // with the wave-uniform decisions outside the per-sample work (a chain of read-wait-branch per sample cost 0.8 us of the hop)
+    auto finish = [&](int i0, int p, int n, int *v) {
+        if (res_only) {
+            for (int e = 0; e < n; ++e) v[e] = dv[i0 + e];
+        } else if (n == 8) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(&s.pred[p - st.p0]);
+            const uint32_t qq[4] = { q.x, q.y, q.z, q.w };
+            for (int e = 0; e < 8; ++e) v[e] = (int)((qq[e >> 1] >> (16 * (e & 1))) & 0xffff);
+        } else if (n == 4) {
+            const uint2 q = *reinterpret_cast<const uint2 *>(&s.pred[p - st.p0]);
+            const uint32_t qq[2] = { q.x, q.y };
+            for (int e = 0; e < 4; ++e) v[e] = (int)((qq[e >> 1] >> (16 * (e & 1))) & 0xffff);
+        } else v[0] = s.pred[p - st.p0];
+        if (ciip_wt) for (int e = 0; e < n; ++e) v[e] = (v[e] * ciip_wt + dv[i0 + e] * (4 - ciip_wt) + 2) >> 2;
+        if (has_res) {
+            if (scaled) for (int e = 0; e < n; ++e) v[e] = ov_clip_bd(v[e] + res_scale(rv[i0 + e], scale));
+            else        for (int e = 0; e < n; ++e) v[e] = ov_clip_bd(v[e] + rv[i0 + e]);
+        }
     };
     if (l2g == 3) {
 #pragma unroll
         for (int j = 0; j < FJ8; ++j) {
             const int p = p_of(8 * j), x = p & (w - 1), y = p >> l2w;
             if (p >= st.p1) break;
+            int v[8];
+            finish(8 * j, p, 8, v);
             flow_u4 q;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) q[e] = sample(8 * j + 2 * e, p + 2 * e) | (sample(8 * j + 2 * e + 1, p + 2 * e + 1) << 16);
+            for (int e = 0; e < 4; ++e) q[e] = (uint32_t)v[2 * e] | ((uint32_t)v[2 * e + 1] << 16);
             asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst + y * dstride + x), "v"(q) : "memory");      // write-through
         }
     } else if (l2g == 2) {
@@ -1017,9 +1033,11 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
         for (int j = 0; j < FJ4; ++j) {
             const int p = p_of(4 * j), x = p & (w - 1), y = p >> l2w;
             if (p >= st.p1) break;
+            int v[4];
+            finish(4 * j, p, 4, v);
             flow_u2 q;
 #pragma unroll
-            for (int e = 0; e < 2; ++e) q[e] = sample(4 * j + 2 * e, p + 2 * e) | (sample(4 * j + 2 * e + 1, p + 2 * e + 1) << 16);
+            for (int e = 0; e < 2; ++e) q[e] = (uint32_t)v[2 * e] | ((uint32_t)v[2 * e + 1] << 16);
             asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(dst + y * dstride + x), "v"(q) : "memory");
         }
     } else {
@@ -1027,7 +1045,9 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
         for (int i = 0; i < FNPL; ++i) {
             const int p = p_of(i), x = p & (w - 1), y = p >> l2w;
             if (p >= st.p1) break;
-            __hip_atomic_store(dst + y * dstride + x, (uint16_t)sample(i, p), RLX_AGENT);
+            int v[1];
+            finish(i, p, 1, v);
+            __hip_atomic_store(dst + y * dstride + x, (uint16_t)v[0], RLX_AGENT);
         }
     }
     FPROBE(5);
