@@ -96,29 +96,40 @@ __device__ __forceinline__ void fetch_refs(IntraLds &s, const Acc acc, int x0, i
     const bool none = !corner && !avl_abv && !avl_lft;
     const int la = min(mrl + avl_abv * unit, na - 1), ll = min(mrl + avl_lft * unit, nl - 1);   // last available sample per arm
     const int ax1 = cx + mrl + 1, ay1 = cy, lx1 = cx, ly1 = cy + mrl + 1;   // first sample of each arm's block part
-    for (int k = lane; k < na + 24; k += 64) {
-        const int kk = min(k, na - 1);
-        int sx = cx + kk, sy = cy;
-        if (kk <= mrl) {
-            if (!corner) { const bool fa = (mrl == 0 && avl_abv && avl_lft) || !avl_lft; sx = fa ? ax1 : lx1; sy = fa ? ay1 : ly1; }
-        } else if (((kk - mrl - 1) >> l2u) >= avl_abv) {
-            if (avl_abv) sx = cx + la;
-            else if (corner) sx = cx + mrl;
-            else { sx = lx1; sy = ly1; }
+    // (na + 24 and nl + 24 are at most 2 * 64 + 4 + 24 = 156: three samples per lane and arm.)  ALL loads of both arms go out before the
+    // first one is waited for -- a loop that loads, waits and stores per iteration costs one memory round trip per iteration and arm
+    // Lanes past the end of an arm load its last sample again: every load is unconditional (a load inside a divergent branch is
+    // waited for at the branch's end, which serialises the round trips), the coordinates are selected without branches.
+    int va[3], vl[3];
+    if (none) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) va[i] = vl[i] = 1 << (OV_BD - 1);
+    } else {
+        const bool fa0 = (mrl == 0 && avl_abv && avl_lft) || !avl_lft;                 // corner part of the above arm without a corner: whose first sample
+        const int cax = corner ? 0 : (fa0 ? ax1 : lx1), cay = fa0 ? ay1 : ly1;           // (x used only when !corner)
+        const int eax = avl_abv ? cx + la : (corner ? cx + mrl : lx1), eay = (avl_abv || corner) ? cy : ly1;     // past the available part
+        const int clx = avl_lft ? lx1 : ax1, cly = avl_lft ? ly1 : ay1;
+        const int elx = (avl_lft || corner) ? cx : ax1, ely = avl_lft ? cy + ll : (corner ? cy + mrl : ay1);
+        int ax_[3], ay_[3], lx_[3], ly_[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int k = lane + 64 * i;
+            const int ka = min(k, na - 1), kl = min(k, nl - 1);
+            const bool a_corner = ka <= mrl, a_avail = ((ka - mrl - 1) >> l2u) < avl_abv;
+            ax_[i] = a_corner ? (corner ? cx + ka : cax) : (a_avail ? cx + ka : eax);
+            ay_[i] = a_corner ? (corner ? cy : cay) : (a_avail ? cy : eay);
+            const bool l_corner = kl <= mrl, l_avail = ((kl - mrl - 1) >> l2u) < avl_lft;
+            lx_[i] = l_corner ? (corner ? cx : clx) : (l_avail ? cx : elx);
+            ly_[i] = l_corner ? (corner ? cy + kl : cly) : (l_avail ? cy + kl : ely);
         }
-        s.abv[IR_NEG + k] = (uint16_t)(none ? 1 << (OV_BD - 1) : acc.ld(sx, sy));
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { va[i] = acc.ld(ax_[i], ay_[i]); vl[i] = acc.ld(lx_[i], ly_[i]); }
     }
-    for (int k = lane; k < nl + 24; k += 64) {
-        const int kk = min(k, nl - 1);
-        int sx = cx, sy = cy + kk;
-        if (kk <= mrl) {
-            if (!corner) { sx = avl_lft ? lx1 : ax1; sy = avl_lft ? ly1 : ay1; }
-        } else if (((kk - mrl - 1) >> l2u) >= avl_lft) {
-            if (avl_lft) sy = cy + ll;
-            else if (corner) sy = cy + mrl;
-            else { sx = ax1; sy = ay1; }
-        }
-        s.lft[IR_NEG + k] = (uint16_t)(none ? 1 << (OV_BD - 1) : acc.ld(sx, sy));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int k = lane + 64 * i;
+        if (k < na + 24) s.abv[IR_NEG + k] = (uint16_t)va[i];
+        if (k < nl + 24) s.lft[IR_NEG + k] = (uint16_t)vl[i];
     }
 }
 
