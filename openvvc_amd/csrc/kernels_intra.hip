@@ -451,9 +451,10 @@ struct LmcsWnd { uint16_t bnd[17]; int min_idx, max_idx, crs_offset; };
 template <class Acc>
 __device__ __forceinline__ int region_scale(const Acc ya, const ovhip_lmcs_region &g, const LmcsWnd &wnd, int lane)
 {
-    int sum = 0;
-    if (g.n_abv) sum += ya.ld(g.x + min(lane, 4 * g.n_abv - 1), g.y - 1);
-    if (g.n_lft) sum += ya.ld(g.x - 1, g.y + min(lane, 4 * g.n_lft - 1));
+    // both loads unconditional (see k_lmcs_scale): a side that does not exist reads the region's own first sample and is dropped
+    const int va = ya.ld(g.n_abv ? g.x + min(lane, 4 * g.n_abv - 1) : g.x, g.n_abv ? g.y - 1 : g.y);
+    const int vl = ya.ld(g.n_lft ? g.x - 1 : g.x, g.n_lft ? g.y + min(lane, 4 * g.n_lft - 1) : g.y);
+    int sum = (g.n_abv ? va : 0) + (g.n_lft ? vl : 0);
 #pragma unroll
     for (int m = 32; m; m >>= 1) sum += __shfl_xor(sum, m);
     const int nb_units = (g.n_abv ? 16 : 0) + (g.n_lft ? 16 : 0);

@@ -25,16 +25,14 @@ __global__ __launch_bounds__(64) void k_lmcs_scale(ovhip_pic pic, const ovhip_lm
     if (g.ordered) return;                                    // luma around it comes from ordered tasks: k_intra_level derives it
     const int lane = threadIdx.x;
     // the reference sums sample k of every unit into luma_sum[k & 3]; only the total is used
-    int sum = 0;
     const uint16_t *src = pic.y + (size_t)g.y * pic.stride_y + g.x;
-    if (g.n_abv) {
-        const int navail = 4 * g.n_abv;                       // samples actually read; the rest repeats the last one
-        sum += src[-pic.stride_y + min(lane, navail - 1)];
-    }
-    if (g.n_lft) {
-        const int navail = 4 * g.n_lft;
-        sum += src[(size_t)min(lane, navail - 1) * pic.stride_y - 1];
-    }
+    // both loads unconditional (a side that does not exist reads the region's own first sample and is dropped): inside the
+    // branches they were two round trips, one after the other
+    const int na = 4 * g.n_abv, nl = 4 * g.n_lft;            // samples actually read; the rest repeats the last one
+    const long oa = g.n_abv ? (long)min(lane, na - 1) - pic.stride_y : 0;
+    const long ol = g.n_lft ? (long)min(lane, nl - 1) * pic.stride_y - 1 : 0;
+    const int va = src[oa], vl = src[ol];
+    int sum = (g.n_abv ? va : 0) + (g.n_lft ? vl : 0);
 #pragma unroll
     for (int m = 32; m; m >>= 1) sum += __shfl_xor(sum, m);
     if (lane == 0) {
