@@ -376,7 +376,9 @@ __device__ LmPar lm_params(int min_l, int min_c, int max_c, int v, int l2rng)
 
 // cross-component linear model (rcn_intra_cclm.c:56-880, the non-collocated variant), one chroma plane.  The up to four
 // neighbour positions are sampled by lanes 0..3 in parallel (above positions first, as the reference orders them).
-template <class Acc>
+// NP: samples per lane of a strip (the caller's strip size / 64).  All loads -- the block's down-sampled luma and the
+// neighbour taps the parameters come from -- are issued before the first one is waited for, none of them inside a divergent branch.
+template <int NP, class Acc>
 __device__ __forceinline__ void pred_cclm(IntraLds &s, const Acc ya, const Acc ca, const ovhip_itask &t, int log2_ctu, const Strip st, int lane)
 {
     const int l2w = t.log2_w, w = 1 << l2w, h = 1 << t.log2_h, x0 = t.x, y0 = t.y;
@@ -391,20 +393,30 @@ __device__ __forceinline__ void pred_cclm(IntraLds &s, const Acc ya, const Acc c
     } else if (mode == 69 && abv_avail) { const int len = t.avl_abv << 1; n_abv = min(len, 4); abv_step = max(1, len >> 2); }
     else if (mode == 68 && lft_avail) { const int len = t.avl_lft << 1; n_lft = min(len, 4); lft_step = max(1, len >> 2); }
     const int n = n_abv + n_lft;
-    if (lane < n) {
-        int v, c;
-        if (lane < n_abv) {
-            const int pos = (abv_step >> 1) + lane * abv_step, qx = pos << 1;
-            const int pl = pos == 0 && !lft_avail;
-            v = first_line ? (2 + Y(qx - !pl, -1) + 2 * Y(qx, -1) + Y(qx + 1, -1)) >> 2
-                           : (4 + Y(qx - !pl, -2) + 2 * Y(qx, -2) + Y(qx + 1, -2) + Y(qx - !pl, -1) + 2 * Y(qx, -1) + Y(qx + 1, -1)) >> 3;
-            c = ca.ld(x0 + pos, y0 - 1);
-        } else {
-            const int pos = (lft_step >> 1) + (lane - n_abv) * lft_step, qy = pos * 2;
-            v = (4 + 2 * Y(-2, qy) + Y(-1, qy) + Y(-3, qy) + 2 * Y(-2, qy + 1) + Y(-1, qy + 1) + Y(-3, qy + 1)) >> 3;
-            c = ca.ld(x0 - 1, y0 + pos);
-        }
-        s.par[lane] = v; s.par[4 + lane] = c;
+    // the strip's down-sampled luma (lanes past the end of the strip repeat its last sample)
+    int dsv[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int p = min(st.p0 + lane + 64 * q, st.p1 - 1);
+        const int i = p & (w - 1), j = p >> l2w;
+        const int pl = i == 0 && !lft_avail;
+        dsv[q] = (4 + Y(2 * i + 1, 2 * j) + Y(2 * i - !pl, 2 * j) + 2 * Y(2 * i, 2 * j) + 2 * Y(2 * i, 2 * j + 1) + Y(2 * i + 1, 2 * j + 1)
+                  + Y(2 * i - !pl, 2 * j + 1)) >> 3;
+    }
+    if (n) {
+        // neighbour `ln` (lanes >= n repeat the last one): six luma taps with weights 1 2 1 / 1 2 1 -- above: columns qx - 1 .. qx + 1
+        // of rows -2 and -1 (the CTU's first line has row -1 only: taken twice, the same value); left: columns -3 .. -1 of rows qy,
+        // qy + 1 -- and the chroma sample beside the block
+        const int ln = min(lane, n - 1);
+        const bool is_abv = ln < n_abv;
+        const int pos = is_abv ? (abv_step >> 1) + ln * abv_step : (lft_step >> 1) + (ln - n_abv) * lft_step;
+        const int q2 = pos << 1, pl = pos == 0 && !lft_avail;
+        const int r2 = first_line ? -1 : -2;
+        const int x0_ = is_abv ? q2 - !pl : -3, x1_ = is_abv ? q2 : -2, x2_ = is_abv ? q2 + 1 : -1;
+        const int ya_ = is_abv ? r2 : q2, yb_ = is_abv ? -1 : q2 + 1;
+        const int v = (4 + Y(x0_, ya_) + 2 * Y(x1_, ya_) + Y(x2_, ya_) + Y(x0_, yb_) + 2 * Y(x1_, yb_) + Y(x2_, yb_)) >> 3;
+        const int c = ca.ld(is_abv ? x0 + pos : x0 - 1, is_abv ? y0 - 1 : y0 + pos);
+        if (lane < n) { s.par[lane] = v; s.par[4 + lane] = c; }
     }
     wave_sync();
     LmPar pp = { 0, 1 << (OV_BD - 1), 0 };
@@ -435,12 +447,10 @@ __device__ __forceinline__ void pred_cclm(IntraLds &s, const Acc ya, const Acc c
             pp = lm_params(min_l, min_c, max_c, v, l2r);
         }
     }
-    for (int p = st.p0 + lane; p < st.p1; p += 64) {
-        const int i = p & (w - 1), j = p >> l2w;
-        const int pl = i == 0 && !lft_avail;
-        const int v = (4 + Y(2 * i + 1, 2 * j) + Y(2 * i - !pl, 2 * j) + 2 * Y(2 * i, 2 * j) + 2 * Y(2 * i, 2 * j + 1) + Y(2 * i + 1, 2 * j + 1)
-                       + Y(2 * i - !pl, 2 * j + 1)) >> 3;
-        s.pred[p - st.p0] = (uint16_t)ov_clip_bd(((v * pp.a) >> pp.shift) + pp.b);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int p = st.p0 + lane + 64 * q;
+        if (p < st.p1) s.pred[p - st.p0] = (uint16_t)ov_clip_bd(((dsv[q] * pp.a) >> pp.shift) + pp.b);
     }
 #undef Y
 }
@@ -520,7 +530,7 @@ __global__ __launch_bounds__(64) void k_intra_level(ovhip_pic pic, ovhip_pic res
             else pred_regular(s, t, true, st, lane);
         } else {
             const PlaneAcc ca = { pl, pic.stride_c };
-            if (t.mode >= 67) pred_cclm(s, ya, ca, t, log2_ctu, st, lane);
+            if (t.mode >= 67) pred_cclm<NPL>(s, ya, ca, t, log2_ctu, st, lane);
             else {
                 fetch_refs(s, ca, t.x, t.y, w, h, 2, t.flags & OVHIP_IF_CORNER, t.avl_abv, t.avl_lft, 0, lane);
                 wave_sync();
@@ -636,7 +646,7 @@ __device__ void ctu_item(CtuLds &L, IntraLds &s, const ovhip_itask &t, int strip
             else pred_regular(s, t, true, st, lane);
         } else {
             const TileAcc ca = { &L.tc[comp][0][0], L.top_c[comp], CT_CS, X0 >> 1, Y0 >> 1 };
-            if (t.mode >= 67) pred_cclm(s, ya, ca, t, log2_ctu, st, lane);
+            if (t.mode >= 67) pred_cclm<NPL>(s, ya, ca, t, log2_ctu, st, lane);
             else {
                 fetch_refs(s, ca, t.x, t.y, w, h, 2, t.flags & OVHIP_IF_CORNER, t.avl_abv, t.avl_lft, 0, lane);
                 wave_sync();
@@ -998,7 +1008,7 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
             else pred_regular(s, t, true, st, lane);
         } else {
             const AgentAcc ca = { pl, pic.stride_c };
-            if (lm) pred_cclm(s, ya, ca, t, log2_ctu, st, lane);
+            if (lm) pred_cclm<FNPL>(s, ya, ca, t, log2_ctu, st, lane);
             else {
                 fetch_refs(s, ca, t.x, t.y, w, h, 2, t.flags & OVHIP_IF_CORNER, t.avl_abv, t.avl_lft, 0, lane);
                 wave_sync();
