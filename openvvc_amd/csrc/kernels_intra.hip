@@ -324,10 +324,14 @@ __device__ void pred_mip(IntraLds &s, const ovhip_itask &t, const Strip st, int 
     const int l2rw = red ? 2 : min(l2w, 3), l2rh = red ? 2 : min(l2h, 3);
     const uint8_t *mat = (l2w == 2 && l2h == 2) ? ovt_mip_4x4 + t.mode * 64 : (red ? ovt_mip_8x8 + t.mode * 128 : ovt_mip_16x16 + t.mode * 512);
     const int sx = 2 * nb, nred = 1 << (l2rw + l2rh);
+    // the lane's matrix row as two dwords, unconditionally (lanes past the reduced block read row 0; a 4-column row reads its dword
+    // twice): byte loads inside `if (k < sx)` were four round trips one after the other
+    const uint8_t *mrow = mat + (lane < nred ? lane : 0) * sx;
+    const uint32_t m0 = *reinterpret_cast<const uint32_t *>(mrow), m1 = *reinterpret_cast<const uint32_t *>(mrow + (sx == 8 ? 4 : 0));
     if (lane < nred) {
         int v = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) if (k < sx) v += bnd[k] * mat[lane * sx + k];
+        for (int k = 0; k < 8; ++k) if (k < sx) v += bnd[k] * (int)(((k < 4 ? m0 : m1) >> (8 * (k & 3))) & 0xff);
         v = ov_clip_bd(((v + rnd_mip) >> 6) + in_off);
         // reduced prediction in raster order of the (transposed back) block
         const int pos = tr ? ((lane & ((1 << l2rh) - 1)) << l2rw) + (lane >> l2rh) : lane;
@@ -878,48 +882,37 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
     // accesses -- a write-through store is one fabric write whatever its size, and 2-byte ones cost 12x the time per byte
     const int l2g = w >= 8 ? 3 : (w == 4 ? 2 : 0);
     auto p_of = [&](int i) { return st.p0 + (((lane + 64 * (i >> l2g)) << l2g) | (i & ((1 << l2g) - 1))); };
-    int rv[FREG], dv[FREG];
+    // (raw vectors: unpacked in the epilogue, so that nothing waits for these loads before the dependency wait has ended)
+    flow_u4 rq8[FJ8], dq8[FJ8];
+    flow_u2 rq4[FJ4], dq4[FJ4];
+    int rv1[FNPL], dv1[FNPL];
 #pragma unroll
-    for (int i = 0; i < FREG; ++i) { rv[i] = 0; dv[i] = 0; }
+    for (int j = 0; j < FJ8; ++j) { rq8[j] = 0; dq8[j] = 0; }
+#pragma unroll
+    for (int j = 0; j < FJ4; ++j) { rq4[j] = 0; dq4[j] = 0; }
+#pragma unroll
+    for (int i = 0; i < FNPL; ++i) { rv1[i] = 0; dv1[i] = 0; }
     if (!region && (has_res || need_d)) {
         if (l2g == 3) {
 #pragma unroll
             for (int j = 0; j < FJ8; ++j) {
-                const int p = p_of(8 * j), x = p & (w - 1), y = p >> l2w;
-                if (p >= st.p1) break;
-                if (has_res) {
-                    const flow_u4 q = *reinterpret_cast<const flow_u4 *>(rp + y * rstride + x);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) rv[8 * j + e] = ((res_mask >> ((x + e) >> res_l2pb)) & 1) ? (int)(int16_t)(q[e >> 1] >> (16 * (e & 1))) : 0;
-                }
-                if (need_d) {
-                    const flow_u4 q = *reinterpret_cast<const flow_u4 *>(dst + y * dstride + x);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) dv[8 * j + e] = (int)((q[e >> 1] >> (16 * (e & 1))) & 0xffff);
-                }
+                const int p = min(p_of(8 * j), st.p1 - 8), x = p & (w - 1), y = p >> l2w;       // lanes past the strip re-read its last run
+                if (has_res) rq8[j] = *reinterpret_cast<const flow_u4 *>(rp + y * rstride + x);
+                if (need_d) dq8[j] = *reinterpret_cast<const flow_u4 *>(dst + y * dstride + x);
             }
         } else if (l2g == 2) {
 #pragma unroll
             for (int j = 0; j < FJ4; ++j) {
-                const int p = p_of(4 * j), x = p & (w - 1), y = p >> l2w;
-                if (p >= st.p1) break;
-                if (has_res) {
-                    const flow_u2 q = *reinterpret_cast<const flow_u2 *>(rp + y * rstride + x);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) rv[4 * j + e] = ((res_mask >> ((x + e) >> res_l2pb)) & 1) ? (int)(int16_t)(q[e >> 1] >> (16 * (e & 1))) : 0;
-                }
-                if (need_d) {
-                    const flow_u2 q = *reinterpret_cast<const flow_u2 *>(dst + y * dstride + x);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) dv[4 * j + e] = (int)((q[e >> 1] >> (16 * (e & 1))) & 0xffff);
-                }
+                const int p = min(p_of(4 * j), st.p1 - 4), x = p & (w - 1), y = p >> l2w;
+                if (has_res) rq4[j] = *reinterpret_cast<const flow_u2 *>(rp + y * rstride + x);
+                if (need_d) dq4[j] = *reinterpret_cast<const flow_u2 *>(dst + y * dstride + x);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < FNPL; ++i) {
-                const int p = p_of(i), x = p & (w - 1), y = p >> l2w;
-                rv[i] = (has_res && p < st.p1 && ((res_mask >> (x >> res_l2pb)) & 1)) ? rp[y * rstride + x] : 0;     // residuals: the launches before
-                dv[i] = (need_d && p < st.p1) ? dst[y * dstride + x] : 0;                                               // inter prediction: likewise
+                const int p = min(p_of(i), st.p1 - 1), x = p & (w - 1), y = p >> l2w;
+                if (has_res) rv1[i] = rp[y * rstride + x];                       // residuals: the launches before
+                if (need_d) dv1[i] = dst[y * dstride + x];                       // inter prediction: likewise
             }
         }
     }
@@ -1020,9 +1013,18 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
     FPROBE(4);
     // epilogue of a run of n samples (registers i0 .. i0 + n - 1): prediction out of LDS in ONE read, then blend / residual / clip
     // with the wave-uniform decisions outside the per-sample work (a chain of read-wait-branch per sample cost 0.8 us of the hop)
-    auto finish = [&](int i0, int p, int n, int *v) {
+    // (j: the run's index among the lane's runs; x: its first column, for the ISP partitions' residual mask)
+    auto finish = [&](int j, int p, int x, int n, int *v) {
+        int rv[8], dv[8];
+        for (int e = 0; e < n; ++e) {
+            const uint32_t rw = n == 8 ? rq8[j][e >> 1] : (n == 4 ? rq4[j][e >> 1] : (uint32_t)rv1[j]);
+            const uint32_t dw = n == 8 ? dq8[j][e >> 1] : (n == 4 ? dq4[j][e >> 1] : (uint32_t)dv1[j]);
+            const int r = n == 1 ? (int)(int16_t)rw : (int)(int16_t)(rw >> (16 * (e & 1)));
+            rv[e] = ((res_mask >> ((x + e) >> res_l2pb)) & 1) ? r : 0;
+            dv[e] = n == 1 ? (int)(dw & 0xffff) : (int)((dw >> (16 * (e & 1))) & 0xffff);
+        }
         if (res_only) {
-            for (int e = 0; e < n; ++e) v[e] = dv[i0 + e];
+            for (int e = 0; e < n; ++e) v[e] = dv[e];
         } else if (n == 8) {
             const uint4 q = *reinterpret_cast<const uint4 *>(&s.pred[p - st.p0]);
             const uint32_t qq[4] = { q.x, q.y, q.z, q.w };
@@ -1032,10 +1034,10 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
             const uint32_t qq[2] = { q.x, q.y };
             for (int e = 0; e < 4; ++e) v[e] = (int)((qq[e >> 1] >> (16 * (e & 1))) & 0xffff);
         } else v[0] = s.pred[p - st.p0];
-        if (ciip_wt) for (int e = 0; e < n; ++e) v[e] = (v[e] * ciip_wt + dv[i0 + e] * (4 - ciip_wt) + 2) >> 2;
+        if (ciip_wt) for (int e = 0; e < n; ++e) v[e] = (v[e] * ciip_wt + dv[e] * (4 - ciip_wt) + 2) >> 2;
         if (has_res) {
-            if (scaled) for (int e = 0; e < n; ++e) v[e] = ov_clip_bd(v[e] + res_scale(rv[i0 + e], scale));
-            else        for (int e = 0; e < n; ++e) v[e] = ov_clip_bd(v[e] + rv[i0 + e]);
+            if (scaled) for (int e = 0; e < n; ++e) v[e] = ov_clip_bd(v[e] + res_scale(rv[e], scale));
+            else        for (int e = 0; e < n; ++e) v[e] = ov_clip_bd(v[e] + rv[e]);
         }
     };
     if (l2g == 3) {
@@ -1044,7 +1046,7 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
             const int p = p_of(8 * j), x = p & (w - 1), y = p >> l2w;
             if (p >= st.p1) break;
             int v[8];
-            finish(8 * j, p, 8, v);
+            finish(j, p, x, 8, v);
             flow_u4 q;
 #pragma unroll
             for (int e = 0; e < 4; ++e) q[e] = (uint32_t)v[2 * e] | ((uint32_t)v[2 * e + 1] << 16);
@@ -1056,7 +1058,7 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
             const int p = p_of(4 * j), x = p & (w - 1), y = p >> l2w;
             if (p >= st.p1) break;
             int v[4];
-            finish(4 * j, p, 4, v);
+            finish(j, p, x, 4, v);
             flow_u2 q;
 #pragma unroll
             for (int e = 0; e < 2; ++e) q[e] = (uint32_t)v[2 * e] | ((uint32_t)v[2 * e + 1] << 16);
@@ -1068,7 +1070,7 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
             const int p = p_of(i), x = p & (w - 1), y = p >> l2w;
             if (p >= st.p1) break;
             int v[1];
-            finish(i, p, 1, v);
+            finish(i, p, x, 1, v);
             __hip_atomic_store(dst + y * dstride + x, (uint16_t)v[0], RLX_AGENT);
         }
     }
