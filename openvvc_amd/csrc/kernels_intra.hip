@@ -990,7 +990,10 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
         return;
     }
     const bool scaled = !luma && (t.flags & OVHIP_IF_RES_SCALE);
-    const int scale = scaled ? ((t.flags & OVHIP_IF_SCALE_IDX) ? (int)__hip_atomic_load(scales + t.c_scale, RLX_AGENT) : t.c_scale) : 0;
+    // (the derived scale is requested here and first looked at in the epilogue: no wait in front of the reference fetch)
+    const bool scale_idx = scaled && (t.flags & OVHIP_IF_SCALE_IDX);
+    int scale_ld = 0;
+    if (scale_idx) scale_ld = (int)__hip_atomic_load(scales + t.c_scale, RLX_AGENT);
     if (!res_only) {
         if (luma) {
             if (t.flags & OVHIP_IF_ISP) fetch_refs_isp(s, ya, t, lane);
@@ -1013,6 +1016,7 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
     FPROBE(4);
     // epilogue of a run of n samples (registers i0 .. i0 + n - 1): prediction out of LDS in ONE read, then blend / residual / clip
     // with the wave-uniform decisions outside the per-sample work (a chain of read-wait-branch per sample cost 0.8 us of the hop)
+    const int scale = scale_idx ? scale_ld : (scaled ? (int)t.c_scale : 0);
     // (j: the run's index among the lane's runs; x: its first column, for the ISP partitions' residual mask)
     auto finish = [&](int j, int p, int x, int n, int *v) {
         int rv[8], dv[8];
