@@ -211,6 +211,18 @@ __device__ __forceinline__ void lmcs_inverse_rows(const ovhip_pic &pic, const ui
 // a 4 KB slice of LDS.  EVERY path runs the same four barriers, whatever the block needs (LFNST, BDPCM, nothing): that is
 // what lets four waves with four different small blocks share a 256-thread workgroup (k_itx_all); a wave without a
 // block (valid = false) only keeps the barriers company.
+// A one-wave block (NT == 64) exchanges data between its lanes through its own slice of LDS only: program order of the wave's DS
+// instructions + a compiler fence is a barrier for it (as in kernels_intra.hip); four-wave blocks need the workgroup barrier.
+template <int NT>
+__device__ __forceinline__ void block_sync()
+{
+    if (NT == 64) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else __syncthreads();
+}
+
 template <int NT>
 __device__ __forceinline__ void itx_block(const ovhip_pic &pic, const ResDelta &rd, const ovhip_tb_cmd &c, bool valid, const int16_t *__restrict__ arena,
                                           const int16_t *__restrict__ lmcs_scales, int ablate, int lane, int16_t *lds)
@@ -307,7 +319,7 @@ __device__ __forceinline__ void itx_block(const ovhip_pic &pic, const ResDelta &
             }
         }
     }
-    __syncthreads();                                   // barrier 1: tiles staged
+    block_sync<NT>();                                  // barrier 1: tiles staged
 
     ResidualSink sink;
     sink.dst = ov_plane(pic, c.plane, sink.stride) + c.y * sink.stride + c.x;
@@ -368,7 +380,7 @@ __device__ __forceinline__ void itx_block(const ovhip_pic &pic, const ResDelta &
             for (int y = 1; y < tb_h; ++y) { acc = ov_clip3(acc + s_coef[y * tb_w + lane], -(1 << 15), (1 << 15) - 1); s_coef[y * tb_w + lane] = (int16_t)acc; }
         }
     }
-    __syncthreads();                                   // barrier 2
+    block_sync<NT>();                                  // barrier 2
     if (lf) {
         const int tr_flag = (c.lfnst >> 4) & 1;
         if (lane < nout) {
@@ -384,7 +396,7 @@ __device__ __forceinline__ void itx_block(const ovhip_pic &pic, const ResDelta &
     } else if (bd && kind == OVHIP_TB_TS) {
         for (int i = lane; i < tb_w * tb_h; i += NT) s_coef[i] = (int16_t)dequant1(s_coef[i], c.dq_scale, c.dq_shift, c.dq_neg);
     }
-    __syncthreads();                                   // barrier 3
+    block_sync<NT>();                                  // barrier 3
     const int ts = tile_stride(kh);
     if (tr) {
         nb_row = min(nb_row, tb_w);
@@ -403,7 +415,7 @@ __device__ __forceinline__ void itx_block(const ovhip_pic &pic, const ResDelta &
             s_tmp[lane] = (int16_t)ov_clip16((acc + (1 << (20 - OV_BD))) >> (20 - OV_BD + 1));
         }
     }
-    __syncthreads();                                   // barrier 4
+    block_sync<NT>();                                  // barrier 4
     if (tr) {
         // ---- horizontal pass (shift 20 - bitdepth) fused with K4; columns >= nb_row of tmp are zero: not read ----
         const int k2 = min(nb_row, kh);
