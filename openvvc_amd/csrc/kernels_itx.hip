@@ -211,6 +211,26 @@ __device__ __forceinline__ void lmcs_inverse_rows(const ovhip_pic &pic, const ui
 // a 4 KB slice of LDS.  EVERY path runs the same four barriers, whatever the block needs (LFNST, BDPCM, nothing): that is
 // what lets four waves with four different small blocks share a 256-thread workgroup (k_itx_all); a wave without a
 // block (valid = false) only keeps the barriers company.
+// where a block's residual goes: the plane(s) of the command, or the residual picture for blocks of ordered tasks
+__device__ __forceinline__ ResidualSink make_sink(const ovhip_pic &pic, const ResDelta &rd, const ovhip_tb_cmd &c, const int16_t *__restrict__ lmcs_scales)
+{
+    ResidualSink sink;
+    sink.dst = ov_plane(pic, c.plane, sink.stride) + c.y * sink.stride + c.x;
+    sink.mode = c.res_mode;
+    sink.dst2 = nullptr; sink.stride2 = 0; sink.mode2 = c.res_mode2;
+    if (c.plane2 != 0xff) sink.dst2 = ov_plane(pic, c.plane2, sink.stride2) + c.y * sink.stride2 + c.x;
+    if (c.res_mode & OVHIP_RES_STORE) {
+        const long long d1 = c.plane == 0 ? rd.d[0] : (c.plane == 1 ? rd.d[1] : rd.d[2]);
+        sink.dst = reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(sink.dst) + d1);
+        if (sink.dst2) {
+            const long long d2 = c.plane2 == 0 ? rd.d[0] : (c.plane2 == 1 ? rd.d[1] : rd.d[2]);
+            sink.dst2 = reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(sink.dst2) + d2);
+        }
+    }
+    sink.scale = (c.res_mode & OVHIP_RES_SCALE_IDX) ? lmcs_scales[c.c_scale] : c.c_scale;   // device-derived chroma scale (K11)
+    return sink;
+}
+
 // A one-wave block (NT == 64) exchanges data between its lanes through its own slice of LDS only: program order of the wave's DS
 // instructions + a compiler fence is a barrier for it (as in kernels_intra.hip); four-wave blocks need the workgroup barrier.
 template <int NT>
@@ -233,6 +253,39 @@ __device__ __forceinline__ void itx_block(const ovhip_pic &pic, const ResDelta &
     const bool raster = c.kind & OVHIP_TB_FLAG_RASTER, bdpcm = c.kind & OVHIP_TB_FLAG_BDPCM;
     const int cw = min(tb_w, 32), ch = min(tb_h, 32);
     const int16_t *src = arena + c.coef_off;
+
+    // ---- DC-only blocks (a quarter of the blocks of an inter picture): inverse_dct_ii_dc (rcn_transform.c:576-598) needs the
+    //      one coefficient -- no tiles, no cores, no LDS.  One-wave blocks only: four-wave blocks meet at workgroup barriers ----
+    if (NT == 64 && kind == OVHIP_TB_DC && !ablate) {
+        if (!valid) return;
+        const bool have = raster || (c.sig_sb_map & 1);              // (an empty first sub-block is staged as zeros, not de-quantised)
+        const int lvl = have ? (int)src[0] : 0;
+        const int c0 = (!have || bdpcm) ? lvl : dequant1(lvl, c.dq_scale, c.dq_shift, c.dq_neg);
+        const int flat_val = ov_clip16(((((int)(int16_t)c0 + 1) >> 1) + (1 << (14 - OV_BD - 1))) >> (14 - OV_BD));
+        const ResidualSink sink = make_sink(pic, rd, c, lmcs_scales);
+        for (int i0 = lane; i0 < tb_w * tb_h; i0 += 4 * NT) {
+            int old[4], old2[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + NT * q;
+                if (i < tb_w * tb_h) {
+                    const int x = i & (tb_w - 1), y = i >> log2_w;
+                    old[q] = sink.dst[y * sink.stride + x];
+                    old2[q] = sink.dst2 ? (int)sink.dst2[y * sink.stride2 + x] : 0;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + NT * q;
+                if (i < tb_w * tb_h) {
+                    const int x = i & (tb_w - 1), y = i >> log2_w;
+                    sink.dst[y * sink.stride + x] = (uint16_t)residual1(old[q], flat_val, sink.mode, sink.scale);
+                    if (sink.dst2) sink.dst2[y * sink.stride2 + x] = (uint16_t)residual1(old2[q], flat_val, sink.mode2, sink.scale);
+                }
+            }
+        }
+        return;
+    }
 
     // ---- K1 loads first: the lane's 4x4 sub-block of levels (HBM), then the transform cores (L2-resident tables,
     //      only what this block needs), so that both round trips overlap ----
@@ -321,20 +374,7 @@ __device__ __forceinline__ void itx_block(const ovhip_pic &pic, const ResDelta &
     }
     block_sync<NT>();                                  // barrier 1: tiles staged
 
-    ResidualSink sink;
-    sink.dst = ov_plane(pic, c.plane, sink.stride) + c.y * sink.stride + c.x;
-    sink.mode = c.res_mode;
-    sink.dst2 = nullptr; sink.stride2 = 0; sink.mode2 = c.res_mode2;
-    if (c.plane2 != 0xff) sink.dst2 = ov_plane(pic, c.plane2, sink.stride2) + c.y * sink.stride2 + c.x;
-    if (c.res_mode & OVHIP_RES_STORE) {
-        const long long d1 = c.plane == 0 ? rd.d[0] : (c.plane == 1 ? rd.d[1] : rd.d[2]);
-        sink.dst = reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(sink.dst) + d1);
-        if (sink.dst2) {
-            const long long d2 = c.plane2 == 0 ? rd.d[0] : (c.plane2 == 1 ? rd.d[1] : rd.d[2]);
-            sink.dst2 = reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(sink.dst2) + d2);
-        }
-    }
-    sink.scale = (c.res_mode & OVHIP_RES_SCALE_IDX) ? lmcs_scales[c.c_scale] : c.c_scale;   // device-derived chroma scale (K11)
+    const ResidualSink sink = make_sink(pic, rd, c, lmcs_scales);
 
     if (ablate & 4) valid = false;
     const bool tr = valid && is_tr, lf = tr && (c.lfnst & 1), bd = valid && !is_tr && bdpcm;
