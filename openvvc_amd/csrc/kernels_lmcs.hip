@@ -15,6 +15,7 @@
 namespace {
 
 struct LmcsWnd { uint16_t bnd[17]; int min_idx, max_idx, crs_offset; };
+#define LMCS_ROWS 4
 
 __global__ __launch_bounds__(64) void k_lmcs_scale(ovhip_pic pic, const ovhip_lmcs_region *__restrict__ regs, uint32_t n,
                                                    LmcsWnd wnd, int16_t *__restrict__ scales)
@@ -56,16 +57,30 @@ __global__ __launch_bounds__(256) void k_lmcs_inverse(ovhip_pic pic, const uint1
     __syncthreads();
     const int nvx = pic.w >> 3;                               // full 8-sample vectors per row
     const int tail = pic.w & 7;
-    for (int y = blockIdx.y; y < pic.h; y += gridDim.y) {
-        uint16_t *row = pic.y + (size_t)y * pic.stride_y;
+    // a workgroup takes LMCS_ROWS rows at a time (the LUT staged once for 16 KB of samples instead of once per row segment); a
+    // lane's vectors of all rows are requested before the first one is mapped
+    for (int y0 = blockIdx.y * LMCS_ROWS; y0 < pic.h; y0 += gridDim.y * LMCS_ROWS) {
         for (int v = blockIdx.x * 256 + threadIdx.x; v < nvx; v += gridDim.x * 256) {
-            uint4 q = *reinterpret_cast<uint4 *>(row + 8 * v);
-            uint32_t *d = reinterpret_cast<uint32_t *>(&q);
+            uint4 q[LMCS_ROWS];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) d[k] = s_lut[d[k] & 1023] | ((uint32_t)s_lut[(d[k] >> 16) & 1023] << 16);
-            *reinterpret_cast<uint4 *>(row + 8 * v) = q;
+            for (int r = 0; r < LMCS_ROWS; ++r) {
+                const int y = min(y0 + r, pic.h - 1);
+                q[r] = *reinterpret_cast<const uint4 *>(pic.y + (size_t)y * pic.stride_y + 8 * v);
+            }
+#pragma unroll
+            for (int r = 0; r < LMCS_ROWS; ++r) {
+                if (y0 + r >= pic.h) break;
+                uint32_t *d = reinterpret_cast<uint32_t *>(&q[r]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) d[k] = s_lut[d[k] & 1023] | ((uint32_t)s_lut[(d[k] >> 16) & 1023] << 16);
+                *reinterpret_cast<uint4 *>(pic.y + (size_t)(y0 + r) * pic.stride_y + 8 * v) = q[r];
+            }
         }
-        if (tail && blockIdx.x == 0 && threadIdx.x < tail) row[8 * nvx + threadIdx.x] = s_lut[row[8 * nvx + threadIdx.x] & 1023];
+        if (tail && blockIdx.x == 0 && threadIdx.x < tail)
+            for (int r = 0; r < LMCS_ROWS && y0 + r < pic.h; ++r) {
+                uint16_t *row = pic.y + (size_t)(y0 + r) * pic.stride_y;
+                row[8 * nvx + threadIdx.x] = s_lut[row[8 * nvx + threadIdx.x] & 1023];
+            }
     }
 }
 
@@ -93,7 +108,8 @@ extern "C" int ovhip_lmcs_inverse_launch(ovhip_ctx *ctx, const ovhip_pic *pic, c
     if ((pic->stride_y & 7) || ((uintptr_t)pic->y & 15))
         return ov_fail(ctx, OVHIP_EINVAL, "ovhip_lmcs_inverse_launch: luma plane must be 16-byte aligned with stride % 8 == 0", hipSuccess);
     const int nvx = pic->w >> 3;
-    dim3 grid((nvx + 255) / 256 > 0 ? (nvx + 255) / 256 : 1, pic->h < 2048 ? pic->h : 2048);
+    const int row_groups = (pic->h + LMCS_ROWS - 1) / LMCS_ROWS;
+    dim3 grid((nvx + 255) / 256 > 0 ? (nvx + 255) / 256 : 1, row_groups < 4096 ? row_groups : 4096);
     hipLaunchKernelGGL(k_lmcs_inverse, grid, dim3(256), 0, ctx->stream, *pic, d_bwd_lut);
     OV_LAUNCH_CHECK(ctx, "k_lmcs_inverse");
     return OVHIP_OK;
