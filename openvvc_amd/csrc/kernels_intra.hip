@@ -825,18 +825,21 @@ struct FlowState { unsigned *y, *c[2], *reg; int w4; };
 #define FJ4    ((FSTRIP + 255) / 256)
 #define FREG   (8 * FJ8 > FNPL ? 8 * FJ8 : FNPL)
 
-__global__ __launch_bounds__(64) void k_intra_flow_prepare(const ovhip_itask *__restrict__ tasks, uint32_t n, FlowState fs, unsigned epoch)
+// 16 lanes per task, 16 tasks per workgroup (one 64-lane workgroup per task was 16k tiny workgroups for a B picture: 10 us)
+__global__ __launch_bounds__(256) void k_intra_flow_prepare(const ovhip_itask *__restrict__ tasks, uint32_t n, FlowState fs, unsigned epoch)
 {
-    if (blockIdx.x >= n) return;
-    const ovhip_itask t = tasks[blockIdx.x];
-    const int lane = threadIdx.x;
+    const uint32_t ti = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (ti >= n) return;
+    const ovhip_itask t = tasks[ti];
+    const int lane = threadIdx.x & 15;
     const unsigned mark = 2 * epoch;
     if (t.kind == OVHIP_IT_REGION) { if (lane == 0) fs.reg[t.c_scale] = mark; return; }
     const bool luma = t.kind == OVHIP_IT_LUMA;
     const int sh = luma ? 2 : 1, w = 1 << t.log2_w, h = 1 << t.log2_h;
     const int ux0 = t.x >> sh, uy0 = t.y >> sh, nx = max(1, w >> sh), ny = max(1, h >> sh);
-    for (int i = lane; i < nx * ny; i += 64) {
-        const int u = (uy0 + i / nx) * fs.w4 + ux0 + i % nx;
+    const int l2nx = 31 - __clz(nx);
+    for (int i = lane; i < nx * ny; i += 16) {
+        const int u = (uy0 + (i >> l2nx)) * fs.w4 + ux0 + (i & (nx - 1));
         if (luma) fs.y[u] = mark;
         else {
             if (t.kind == OVHIP_IT_CHROMA || (t.flags & OVHIP_IF_RES_CB)) fs.c[0][u] = mark;
@@ -1213,7 +1216,7 @@ extern "C" int ovhip_intra_flow_launch(ovhip_ctx *ctx, const ovhip_pic *pic, con
     fs.w4 = (pic->w + 3) / 4;
     fs.y = d_state + SYNC_FLAGS; fs.c[0] = fs.y + nu; fs.c[1] = fs.c[0] + nu; fs.reg = fs.c[1] + nu;
     if (prepare) {
-        hipLaunchKernelGGL(k_intra_flow_prepare, dim3(n_tasks), dim3(64), 0, ctx->stream, d_tasks, n_tasks, fs, epoch);
+        hipLaunchKernelGGL(k_intra_flow_prepare, dim3((n_tasks + 15) / 16), dim3(256), 0, ctx->stream, d_tasks, n_tasks, fs, epoch);
         OV_LAUNCH_CHECK(ctx, "k_intra_flow_prepare");
     }
 #ifdef OVHIP_CTU_PROBE
