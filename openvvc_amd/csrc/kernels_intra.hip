@@ -813,11 +813,82 @@ __global__ __launch_bounds__(256) void k_intra_ctu(ovhip_pic pic, ovhip_pic res,
 // marks its own units.  No launch boundary per level, no cold fetch of the task record on the critical path (the workgroup
 // has it long before its inputs are ready).  Forward progress: an item waits only for items of a LOWER level = lower index;
 // workgroups start in index order on this hardware, nothing promises it -- the wait is bounded and aborts the launch.
+// (bit 15 of a luma sample: FLOW_TAG below; every reader of the picture inside the flow launch drops it)
 struct AgentAcc {
     const uint16_t *p; int stride;
-    __device__ __forceinline__ int ld(int x, int y) const { return __hip_atomic_load(p + y * stride + x, RLX_AGENT); }
+    __device__ __forceinline__ int ld(int x, int y) const { return __hip_atomic_load(p + y * stride + x, RLX_AGENT) & 0x7fff; }
 };
 struct FlowState { unsigned *y, *c[2], *reg; int w4; };
+// Luma hand-over inside the flow launch: DATA-TAGGED samples.  A luma item stores its samples with bit 15 set (10-bit samples leave
+// it free) and a luma item that needs them polls the reference samples themselves until the bit is there: the flag round trips
+// (drain the stores, mark the units, the consumer's poll, THEN its loads of the data) shrink to the one trip of the data.  Every
+// luma sample the pass starts with is clean (written by this picture's motion compensation / transform launches or by a previous
+// picture's filters), so the bit alone says "an ordered task of this picture has written this".  Whether a reference sample will
+// carry it is the unit's state word (set by k_intra_flow_prepare, never polled).  The units are still marked written afterwards:
+// chroma items (CCLM), scale regions and ISP partitions keep waiting on the words.  The bit is gone after the ordered pass: the
+// inverse luma mapping indexes its table with the low 10 bits, pictures without LMCS get k_flow_untag.
+#define FLOW_TAG 0x8000u
+
+// reference arms of a regular luma block out of tagged samples (the coordinates exactly as fetch_refs picks them).  false: gave up.
+__device__ __forceinline__ bool fetch_refs_tagged(IntraLds &s, const uint16_t *py, int stride, const FlowState &fs, unsigned epoch, unsigned *sync,
+                                                  int x0, int y0, int w, int h, bool corner, int avl_abv, int avl_lft, int mrl, int lane)
+{
+    const int unit = 4, l2u = 2;
+    const int na = 2 * w + mrl + 1, nl = 2 * h + mrl + 1;
+    const int cx = x0 - 1 - mrl, cy = y0 - 1 - mrl;
+    const bool none = !corner && !avl_abv && !avl_lft;
+    const int la = min(mrl + avl_abv * unit, na - 1), ll = min(mrl + avl_lft * unit, nl - 1);
+    const int ax1 = cx + mrl + 1, ay1 = cy, lx1 = cx, ly1 = cy + mrl + 1;
+    int v[6];
+    bool ok = true;
+    if (none) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) v[i] = 1 << (OV_BD - 1);
+    } else {
+        const bool fa0 = (mrl == 0 && avl_abv && avl_lft) || !avl_lft;
+        const int cax = corner ? 0 : (fa0 ? ax1 : lx1), cay = fa0 ? ay1 : ly1;
+        const int eax = avl_abv ? cx + la : (corner ? cx + mrl : lx1), eay = (avl_abv || corner) ? cy : ly1;
+        const int clx = avl_lft ? lx1 : ax1, cly = avl_lft ? ly1 : ay1;
+        const int elx = (avl_lft || corner) ? cx : ax1, ely = avl_lft ? cy + ll : (corner ? cy + mrl : ay1);
+        const uint16_t *src[6];
+        bool expect[6];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int k = lane + 64 * i;
+            const int ka = min(k, na - 1), kl = min(k, nl - 1);
+            const bool a_corner = ka <= mrl, a_avail = ((ka - mrl - 1) >> l2u) < avl_abv;
+            const int ax = a_corner ? (corner ? cx + ka : cax) : (a_avail ? cx + ka : eax);
+            const int ay = a_corner ? (corner ? cy : cay) : (a_avail ? cy : eay);
+            const bool l_corner = kl <= mrl, l_avail = ((kl - mrl - 1) >> l2u) < avl_lft;
+            const int lx = l_corner ? (corner ? cx : clx) : (l_avail ? cx : elx);
+            const int ly = l_corner ? (corner ? cy + kl : cly) : (l_avail ? cy + kl : ely);
+            src[2 * i] = py + ay * stride + ax; src[2 * i + 1] = py + ly * stride + lx;
+            // will an ordered task of this picture write the sample?  (2 * epoch: it will; 2 * epoch + 1: it has)
+            expect[2 * i] = (__hip_atomic_load(fs.y + (ay >> 2) * fs.w4 + (ax >> 2), RLX_AGENT) >> 1) == epoch;
+            expect[2 * i + 1] = (__hip_atomic_load(fs.y + (ly >> 2) * fs.w4 + (lx >> 2), RLX_AGENT) >> 1) == epoch;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) v[i] = __hip_atomic_load(src[i], RLX_AGENT);
+        unsigned spins = 0;
+        for (;;) {
+            bool miss = false;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) miss |= expect[i] && !(v[i] & FLOW_TAG);
+            if (!__any(miss)) break;
+            if (__any(++spins > SPIN_LIMIT || __hip_atomic_load(sync, RLX_AGENT) != 0)) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(4);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) if (expect[i] && !(v[i] & FLOW_TAG)) v[i] = __hip_atomic_load(src[i], RLX_AGENT);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int k = lane + 64 * i;
+        if (k < na + 24) s.abv[IR_NEG + k] = (uint16_t)(v[2 * i] & 0x7fff);
+        if (k < nl + 24) s.lft[IR_NEG + k] = (uint16_t)(v[2 * i + 1] & 0x7fff);
+    }
+    return ok;
+}
 #define FLOW_MAX_FP 448
 #define FSTRIP 256                          // samples per item: one wave predicts a 1024-sample strip in ~2 us, the critical path of a hop
 #define FNPL   (FSTRIP / 64)
@@ -846,6 +917,17 @@ __global__ __launch_bounds__(256) void k_intra_flow_prepare(const ovhip_itask *_
             if (t.kind == OVHIP_IT_CHROMA || (t.flags & OVHIP_IF_RES_CR)) fs.c[1][u] = mark;
         }
     }
+}
+
+// The luma blocks the flow launch wrote, without their hand-over bit (pictures without LMCS: nothing else would drop it)
+__global__ __launch_bounds__(64) void k_flow_untag(ovhip_pic pic, const ovhip_itask *__restrict__ tasks, uint32_t n)
+{
+    if (blockIdx.x >= n) return;
+    const ovhip_itask t = tasks[blockIdx.x];
+    if (t.kind != OVHIP_IT_LUMA) return;
+    const int l2w = t.log2_w, w = 1 << l2w, npx = w << t.log2_h;
+    uint16_t *dst = pic.y + t.y * pic.stride_y + t.x;
+    for (int p = threadIdx.x; p < npx; p += 64) { uint16_t *q = dst + (p >> l2w) * pic.stride_y + (p & (w - 1)); *q = *q & 0x3ff; }
 }
 
 typedef uint32_t flow_u4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -933,12 +1015,14 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
         if (g.n_abv) add_run(fs.y, g.x >> 2, (g.y >> 2) - 1, g.n_abv, 1, 0);
         if (g.n_lft) add_run(fs.y, (g.x >> 2) - 1, g.y >> 2, g.n_lft, 0, 1);
     } else if (luma) {
-        const bool isp = t.flags & OVHIP_IF_ISP;
-        const int ux = t.x >> 2, uy = t.y >> 2, uxa = isp ? (t.x - t.isp_off_x) >> 2 : ux, uyl = isp ? (t.y - t.isp_off_y) >> 2 : uy;
-        if (t.flags & OVHIP_IF_CORNER) add_run(fs.y, uxa - 1, uy - 1, 1, 1, 0);
-        if (isp && (t.flags & OVHIP_IF_CORNER_L)) add_run(fs.y, ux - 1, uyl - 1, 1, 1, 0);
-        add_run(fs.y, uxa, uy - 1, t.avl_abv, 1, 0);
-        add_run(fs.y, ux - 1, uyl, t.avl_lft, 0, 1);
+        // (regular luma blocks wait on the tagged reference samples themselves, fetch_refs_tagged below: nothing to poll here)
+        if (t.flags & OVHIP_IF_ISP) {
+            const int ux = t.x >> 2, uy = t.y >> 2, uxa = (t.x - t.isp_off_x) >> 2, uyl = (t.y - t.isp_off_y) >> 2;
+            if (t.flags & OVHIP_IF_CORNER) add_run(fs.y, uxa - 1, uy - 1, 1, 1, 0);
+            if (t.flags & OVHIP_IF_CORNER_L) add_run(fs.y, ux - 1, uyl - 1, 1, 1, 0);
+            add_run(fs.y, uxa, uy - 1, t.avl_abv, 1, 0);
+            add_run(fs.y, ux - 1, uyl, t.avl_lft, 0, 1);
+        }
     } else {
         unsigned *fc = fs.c[comp];
         const int ux = t.x >> 1, uy = t.y >> 1, nux = max(1, w >> 1), nuy = max(1, h >> 1);
@@ -1000,7 +1084,14 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
     if (!res_only) {
         if (luma) {
             if (t.flags & OVHIP_IF_ISP) fetch_refs_isp(s, ya, t, lane);
-            else fetch_refs(s, ya, t.x, t.y, w, h, 4, t.flags & OVHIP_IF_CORNER, t.avl_abv, t.avl_lft, (t.flags & OVHIP_IF_MIP) ? 0 : t.mrl_idx, lane);
+            else if (!fetch_refs_tagged(s, pic.y, pic.stride_y, fs, epoch, sync, t.x, t.y, w, h, t.flags & OVHIP_IF_CORNER, t.avl_abv, t.avl_lft,
+                                        (t.flags & OVHIP_IF_MIP) ? 0 : t.mrl_idx, lane)) {
+                if (lane == 0) {
+                    __hip_atomic_store(sync, 1u + blockIdx.x, RLX_AGENT);
+                    if (abort_mirror) __hip_atomic_store(abort_mirror, 1u + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                return;
+            }
             wave_sync();
             FPROBE(3);
             if (t.flags & OVHIP_IF_MIP) pred_mip(s, t, st, lane);
@@ -1020,6 +1111,7 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
     // epilogue of a run of n samples (registers i0 .. i0 + n - 1): prediction out of LDS in ONE read, then blend / residual / clip
     // with the wave-uniform decisions outside the per-sample work (a chain of read-wait-branch per sample cost 0.8 us of the hop)
     const int scale = scale_idx ? scale_ld : (scaled ? (int)t.c_scale : 0);
+    const uint32_t tag2 = luma ? (FLOW_TAG | (FLOW_TAG << 16)) : 0u;          // luma leaves tagged (see FLOW_TAG)
     // (j: the run's index among the lane's runs; x: its first column, for the ISP partitions' residual mask)
     auto finish = [&](int j, int p, int x, int n, int *v) {
         int rv[8], dv[8];
@@ -1056,7 +1148,7 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
             finish(j, p, x, 8, v);
             flow_u4 q;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) q[e] = (uint32_t)v[2 * e] | ((uint32_t)v[2 * e + 1] << 16);
+            for (int e = 0; e < 4; ++e) q[e] = ((uint32_t)v[2 * e] | ((uint32_t)v[2 * e + 1] << 16)) | tag2;
             asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst + y * dstride + x), "v"(q) : "memory");      // write-through
         }
     } else if (l2g == 2) {
@@ -1068,7 +1160,7 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
             finish(j, p, x, 4, v);
             flow_u2 q;
 #pragma unroll
-            for (int e = 0; e < 2; ++e) q[e] = (uint32_t)v[2 * e] | ((uint32_t)v[2 * e + 1] << 16);
+            for (int e = 0; e < 2; ++e) q[e] = ((uint32_t)v[2 * e] | ((uint32_t)v[2 * e + 1] << 16)) | tag2;
             asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(dst + y * dstride + x), "v"(q) : "memory");
         }
     } else {
@@ -1078,7 +1170,7 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
             if (p >= st.p1) break;
             int v[1];
             finish(i, p, x, 1, v);
-            __hip_atomic_store(dst + y * dstride + x, (uint16_t)v[0], RLX_AGENT);
+            __hip_atomic_store(dst + y * dstride + x, (uint16_t)(v[0] | (tag2 & 0xffff)), RLX_AGENT);
         }
     }
     FPROBE(5);
@@ -1226,5 +1318,18 @@ extern "C" int ovhip_intra_flow_launch(ovhip_ctx *ctx, const ovhip_pic *pic, con
     hipLaunchKernelGGL(k_intra_flow, dim3(n_items), dim3(64), 0, ctx->stream, *pic, *res, d_tasks, d_items, n_items, d_regions, wnd, d_scales, log2_ctu_s, fs,
                        epoch, d_state, abort_mirror, nap);
     OV_LAUNCH_CHECK(ctx, "k_intra_flow");
+    return OVHIP_OK;
+}
+
+// After the flow launches of a picture WITHOUT the inverse luma mapping (ovhip_lmcs_inverse_launch drops the hand-over bit of the
+// luma samples as a side effect of its table lookup): clears it in the blocks of the luma tasks.  d_tasks: as ovhip_intra_flow_launch.
+extern "C" int ovhip_intra_flow_untag_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_itask *d_tasks, uint32_t n_tasks)
+{
+    if (!ctx || !pic) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
+    if (!n_tasks) return OVHIP_OK;
+    if (!d_tasks) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_intra_flow_untag_launch: bad arguments", hipSuccess);
+    hipLaunchKernelGGL(k_flow_untag, dim3(n_tasks), dim3(64), 0, ctx->stream, *pic, d_tasks, n_tasks);
+    OV_LAUNCH_CHECK(ctx, "k_flow_untag");
     return OVHIP_OK;
 }

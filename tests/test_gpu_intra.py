@@ -172,3 +172,23 @@ def test_second_pass_after_an_abandoned_flow_launch(ctx, monkeypatch):
     job.flush(dst, refs, None); job.wait()
     assert job.stats().n_ordered_retries == 0
     assert np.array_equal(dst.download()[0], ref.y)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,seed,frac", [(416, 240, 11, 1.0), (832, 480, 12, 0.3)])
+def test_picture_with_intra_without_lmcs(ctx, w, h, seed, frac):
+    """The flow launch hands luma over with a tag bit that the inverse luma mapping drops; a picture without LMCS has no such pass
+    and gets the bit cleared by k_flow_untag: I and B pictures without LMCS == the oracle."""
+    tools = tuple(t for t in synth.INTRA_TOOLS if t != "lmcs")
+    wl = synth.make_workload(w, h, seed, tools=tools, intra_frac=frac)
+    assert wl.lmcs is None and wl.stats["n_itasks"] > 50
+    job = engine.Job(ctx, w, h)
+    refs = [ctx.upload_pic(*r) for r in wl.refs]
+    dst = ctx.new_pic(w, h)
+    job.load_workload(wl)
+    job.flush(dst, refs, None)
+    job.wait()
+    got = dst.download()
+    ref = oracle_pipeline.decode(wl)
+    for name, a, b in (("Y", got[0], ref.y), ("Cb", got[1], ref.cb), ("Cr", got[2], ref.cr)):
+        assert np.array_equal(a, b), f"{w}x{h} without LMCS: plane {name}: {int((a != b).sum())} samples differ (max {int(a.max())})"
