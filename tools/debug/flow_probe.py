@@ -60,13 +60,14 @@ for k in luma:
     if int(tt["flags"]) & capi.IF_CORNER: prods.add(owner[y - 1, x - 1])
     prods.discard(-1)
     if not prods: continue
-    last7 = max(p[q][7] for q in prods); last6 = max(p[q][6] for q in prods)
-    if last7 < r[1]: continue                      # inputs were ready before this item looked: not on a critical hop
+    last7 = max(p[q][7] for q in prods); last6 = max(p[q][6] for q in prods); last5 = max(p[q][5] for q in prods)
+    if last5 < r[1]: continue                      # inputs were on their way before this item looked: not on a critical hop
     waited += 1
     area.setdefault((int(tt["log2_w"]) + int(tt["log2_h"]), "mip" if int(tt["flags"]) & capi.IF_MIP else ("pl/dc" if int(tt["mode"]) < 2 else "ang")), []).append((r[3] - r[2], r[4] - r[3], r[5] - r[4], r[6] - r[5], r[7] - r[6], r[2] - last7))
     ph["poll begin->ready"].append(r[2] - r[1]); ph["ready->refs"].append(r[3] - r[2]); ph["refs->pred"].append(r[4] - r[3])
     ph["pred->issued"].append(r[5] - r[4]); ph["issued->acked"].append(r[6] - r[5]); ph["acked->marked"].append(r[7] - r[6])
     ph["producer marked->ready"].append(r[2] - last7); ph["producer acked->ready"].append(r[2] - last6)
+    ph.setdefault("producer stores issued->refs in LDS (tagged hand-over)", []).append(r[3] - last5)
 print("luma items that waited for their last producer:", waited, "of", len(luma))
 for name, v in ph.items():
     v = us(np.array(v))
