@@ -763,9 +763,10 @@ size_t ovhip_intra_flow_items(const ovhip_itask *sorted, size_t n, uint32_t *ite
 int  ovhip_intra_flow_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_pic *res, const ovhip_itask *d_tasks, uint32_t n_tasks,
                              const uint32_t *d_items, uint32_t n_items, const ovhip_lmcs_region *d_regions, const ovhip_lmcs_luts *luts,
                              int16_t *d_scales, int32_t log2_ctu_s, uint32_t *d_state, uint32_t epoch, uint32_t *abort_mirror, int32_t prepare);
-/* The flow launch hands luma samples from task to task with bit 15 set (kernels_intra.hip, FLOW_TAG); ovhip_lmcs_inverse_launch
- * drops it as a side effect.  A picture WITHOUT LMCS calls this after its flow launches and before anything else reads the luma. */
-int  ovhip_intra_flow_untag_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_itask *d_tasks, uint32_t n_tasks);
+/* The flow launch hands samples from task to task with bit 15 set (kernels_intra.hip, FLOW_TAG).  This clears it in the blocks the
+ * ordered tasks wrote: after the picture's flow launches, before anything else reads the picture.  with_luma == 0: chroma blocks
+ * only -- ovhip_lmcs_inverse_launch drops the bit of every luma sample as a side effect of its table lookup. */
+int  ovhip_intra_flow_untag_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_itask *d_tasks, uint32_t n_tasks, int32_t with_luma);
 /* planes->* are DEVICE pointers.  Filters `pic` in place: all vertical edges, then all horizontal. */
 int  ovhip_dbf_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_dbf_planes *planes);
 /* Same filter driven by the compact lists of ovhip_dbf_compact (DEVICE pointers). */

@@ -378,7 +378,7 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_job_last_stats": (C.c_int, [vp, P(JobStats)]),
         "ovhip_job_time_stage": (C.c_int, [vp, C.c_int]),
         "ovhip_job_stage_time": (C.c_int, [vp, P(C.c_double), P(C.c_uint64)]),
-        "ovhip_intra_flow_untag_launch": (C.c_int, [vp, P(Pic), vp, u32]),
+        "ovhip_intra_flow_untag_launch": (C.c_int, [vp, P(Pic), vp, u32, i32]),
         "ovhip_tmvp_cells_launch": (C.c_int, [vp, vp, u32, vp, i32, i32, vp]),
         "ovhip_job_tmvp_cells": (vp, [vp, P(C.c_size_t)]),
         "ovhip_output_bytes": (C.c_size_t, [i32, i32, P(Window)]),

@@ -830,10 +830,11 @@ struct FlowState { unsigned *y, *c[2], *reg; int w4; };
 #define FLOW_TAG 0x8000u
 
 // reference arms of a regular luma block out of tagged samples (the coordinates exactly as fetch_refs picks them).  false: gave up.
-__device__ __forceinline__ bool fetch_refs_tagged(IntraLds &s, const uint16_t *py, int stride, const FlowState &fs, unsigned epoch, unsigned *sync,
-                                                  int x0, int y0, int w, int h, bool corner, int avl_abv, int avl_lft, int mrl, int lane)
+// (luma: unit 4, state words fs.y; a chroma plane: unit 2, its own words -- a 2x2 chroma unit is the 4x4 luma unit)
+__device__ __forceinline__ bool fetch_refs_tagged(IntraLds &s, const uint16_t *py, int stride, const unsigned *state, int w4, unsigned epoch, unsigned *sync,
+                                                  int unit, int x0, int y0, int w, int h, bool corner, int avl_abv, int avl_lft, int mrl, int lane)
 {
-    const int unit = 4, l2u = 2;
+    const int l2u = unit == 4 ? 2 : 1;
     const int na = 2 * w + mrl + 1, nl = 2 * h + mrl + 1;
     const int cx = x0 - 1 - mrl, cy = y0 - 1 - mrl;
     const bool none = !corner && !avl_abv && !avl_lft;
@@ -864,8 +865,8 @@ __device__ __forceinline__ bool fetch_refs_tagged(IntraLds &s, const uint16_t *p
             const int ly = l_corner ? (corner ? cy + kl : cly) : (l_avail ? cy + kl : ely);
             src[2 * i] = py + ay * stride + ax; src[2 * i + 1] = py + ly * stride + lx;
             // will an ordered task of this picture write the sample?  (2 * epoch: it will; 2 * epoch + 1: it has)
-            expect[2 * i] = (__hip_atomic_load(fs.y + (ay >> 2) * fs.w4 + (ax >> 2), RLX_AGENT) >> 1) == epoch;
-            expect[2 * i + 1] = (__hip_atomic_load(fs.y + (ly >> 2) * fs.w4 + (lx >> 2), RLX_AGENT) >> 1) == epoch;
+            expect[2 * i] = (__hip_atomic_load(state + (ay >> l2u) * w4 + (ax >> l2u), RLX_AGENT) >> 1) == epoch;
+            expect[2 * i + 1] = (__hip_atomic_load(state + (ly >> l2u) * w4 + (lx >> l2u), RLX_AGENT) >> 1) == epoch;
         }
 #pragma unroll
         for (int i = 0; i < 6; ++i) v[i] = __hip_atomic_load(src[i], RLX_AGENT);
@@ -919,15 +920,21 @@ __global__ __launch_bounds__(256) void k_intra_flow_prepare(const ovhip_itask *_
     }
 }
 
-// The luma blocks the flow launch wrote, without their hand-over bit (pictures without LMCS: nothing else would drop it)
-__global__ __launch_bounds__(64) void k_flow_untag(ovhip_pic pic, const ovhip_itask *__restrict__ tasks, uint32_t n)
+// The blocks the flow launch wrote, without their hand-over bit: the chroma blocks always, the luma blocks when nothing else drops it
+// (pictures without LMCS)
+__global__ __launch_bounds__(64) void k_flow_untag(ovhip_pic pic, const ovhip_itask *__restrict__ tasks, uint32_t n, int with_luma)
 {
     if (blockIdx.x >= n) return;
     const ovhip_itask t = tasks[blockIdx.x];
-    if (t.kind != OVHIP_IT_LUMA) return;
+    if (t.kind == OVHIP_IT_REGION || (t.kind == OVHIP_IT_LUMA && !with_luma)) return;
     const int l2w = t.log2_w, w = 1 << l2w, npx = w << t.log2_h;
-    uint16_t *dst = pic.y + t.y * pic.stride_y + t.x;
-    for (int p = threadIdx.x; p < npx; p += 64) { uint16_t *q = dst + (p >> l2w) * pic.stride_y + (p & (w - 1)); *q = *q & 0x3ff; }
+    const bool luma = t.kind == OVHIP_IT_LUMA;
+    const int stride = luma ? pic.stride_y : pic.stride_c;
+    for (int c = 0; c < (luma ? 1 : 2); ++c) {
+        if (!luma && t.kind == OVHIP_IT_RES_C && !(t.flags & (c ? OVHIP_IF_RES_CR : OVHIP_IF_RES_CB))) continue;
+        uint16_t *dst = (luma ? pic.y : (c ? pic.cr : pic.cb)) + t.y * stride + t.x;
+        for (int p = threadIdx.x; p < npx; p += 64) { uint16_t *q = dst + (p >> l2w) * stride + (p & (w - 1)); *q = *q & 0x3ff; }
+    }
 }
 
 typedef uint32_t flow_u4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -1033,11 +1040,7 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
                 for (int r = 0; r < nuy && nfp < FLOW_MAX_FP; ++r) add_run(fs.y, ux, uy + r, nux, 1, 0);
                 if (t.avl_lft) { add_run(fs.y, ux - 1, uy - (t.avl_abv ? 1 : 0), max(nl, nuy) + (t.avl_abv ? 1 : 0), 0, 1); add_run(fc, ux - 1, uy, nl, 0, 1); }
                 if (t.avl_abv) { add_run(fs.y, ux, uy - 1, max(na, nux), 1, 0); add_run(fc, ux, uy - 1, na, 1, 0); }
-            } else {
-                if (t.flags & OVHIP_IF_CORNER) add_run(fc, ux - 1, uy - 1, 1, 1, 0);
-                add_run(fc, ux, uy - 1, t.avl_abv, 1, 0);
-                add_run(fc, ux - 1, uy, t.avl_lft, 0, 1);
-            }
+            }      // (the other chroma modes wait on their tagged reference samples, like luma)
         }
         if ((t.flags & OVHIP_IF_RES_SCALE) && (t.flags & OVHIP_IF_SCALE_IDX)) add_run(fs.reg, t.c_scale, 0, 1, 1, 0);
     }
@@ -1084,7 +1087,7 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
     if (!res_only) {
         if (luma) {
             if (t.flags & OVHIP_IF_ISP) fetch_refs_isp(s, ya, t, lane);
-            else if (!fetch_refs_tagged(s, pic.y, pic.stride_y, fs, epoch, sync, t.x, t.y, w, h, t.flags & OVHIP_IF_CORNER, t.avl_abv, t.avl_lft,
+            else if (!fetch_refs_tagged(s, pic.y, pic.stride_y, fs.y, w4, epoch, sync, 4, t.x, t.y, w, h, t.flags & OVHIP_IF_CORNER, t.avl_abv, t.avl_lft,
                                         (t.flags & OVHIP_IF_MIP) ? 0 : t.mrl_idx, lane)) {
                 if (lane == 0) {
                     __hip_atomic_store(sync, 1u + blockIdx.x, RLX_AGENT);
@@ -1100,7 +1103,13 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
             const AgentAcc ca = { pl, pic.stride_c };
             if (lm) pred_cclm<FNPL>(s, ya, ca, t, log2_ctu, st, lane);
             else {
-                fetch_refs(s, ca, t.x, t.y, w, h, 2, t.flags & OVHIP_IF_CORNER, t.avl_abv, t.avl_lft, 0, lane);
+                if (!fetch_refs_tagged(s, pl, pic.stride_c, fs.c[comp], w4, epoch, sync, 2, t.x, t.y, w, h, t.flags & OVHIP_IF_CORNER, t.avl_abv, t.avl_lft, 0, lane)) {
+                    if (lane == 0) {
+                        __hip_atomic_store(sync, 1u + blockIdx.x, RLX_AGENT);
+                        if (abort_mirror) __hip_atomic_store(abort_mirror, 1u + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    return;
+                }
                 wave_sync();
                 pred_regular(s, t, false, st, lane);
             }
@@ -1111,7 +1120,7 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
     // epilogue of a run of n samples (registers i0 .. i0 + n - 1): prediction out of LDS in ONE read, then blend / residual / clip
     // with the wave-uniform decisions outside the per-sample work (a chain of read-wait-branch per sample cost 0.8 us of the hop)
     const int scale = scale_idx ? scale_ld : (scaled ? (int)t.c_scale : 0);
-    const uint32_t tag2 = luma ? (FLOW_TAG | (FLOW_TAG << 16)) : 0u;          // luma leaves tagged (see FLOW_TAG)
+    const uint32_t tag2 = FLOW_TAG | (FLOW_TAG << 16);                         // every sample leaves tagged (see FLOW_TAG)
     // (j: the run's index among the lane's runs; x: its first column, for the ISP partitions' residual mask)
     auto finish = [&](int j, int p, int x, int n, int *v) {
         int rv[8], dv[8];
@@ -1323,13 +1332,13 @@ extern "C" int ovhip_intra_flow_launch(ovhip_ctx *ctx, const ovhip_pic *pic, con
 
 // After the flow launches of a picture WITHOUT the inverse luma mapping (ovhip_lmcs_inverse_launch drops the hand-over bit of the
 // luma samples as a side effect of its table lookup): clears it in the blocks of the luma tasks.  d_tasks: as ovhip_intra_flow_launch.
-extern "C" int ovhip_intra_flow_untag_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_itask *d_tasks, uint32_t n_tasks)
+extern "C" int ovhip_intra_flow_untag_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_itask *d_tasks, uint32_t n_tasks, int32_t with_luma)
 {
     if (!ctx || !pic) return OVHIP_EINVAL;
     OV_DEVICE(ctx);
     if (!n_tasks) return OVHIP_OK;
     if (!d_tasks) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_intra_flow_untag_launch: bad arguments", hipSuccess);
-    hipLaunchKernelGGL(k_flow_untag, dim3(n_tasks), dim3(64), 0, ctx->stream, *pic, d_tasks, n_tasks);
+    hipLaunchKernelGGL(k_flow_untag, dim3(n_tasks), dim3(64), 0, ctx->stream, *pic, d_tasks, n_tasks, with_luma);
     OV_LAUNCH_CHECK(ctx, "k_flow_untag");
     return OVHIP_OK;
 }
