@@ -767,6 +767,9 @@ int  ovhip_intra_flow_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_p
  * ordered tasks wrote: after the picture's flow launches, before anything else reads the picture.  with_luma == 0: chroma blocks
  * only -- ovhip_lmcs_inverse_launch drops the bit of every luma sample as a side effect of its table lookup. */
 int  ovhip_intra_flow_untag_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_itask *d_tasks, uint32_t n_tasks, int32_t with_luma);
+/* ovhip_lmcs_inverse_launch + ovhip_intra_flow_untag_launch(with_luma = 0) in ONE launch (a picture with LMCS whose ordered pass
+ * ran as flow launches). */
+int  ovhip_lmcs_inverse_untag_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const uint16_t *d_bwd_lut, const ovhip_itask *d_tasks, uint32_t n_tasks);
 /* planes->* are DEVICE pointers.  Filters `pic` in place: all vertical edges, then all horizontal. */
 int  ovhip_dbf_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_dbf_planes *planes);
 /* Same filter driven by the compact lists of ovhip_dbf_compact (DEVICE pointers). */

@@ -920,25 +920,40 @@ __global__ __launch_bounds__(256) void k_intra_flow_prepare(const ovhip_itask *_
     }
 }
 
+typedef uint32_t flow_u4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t flow_u2 __attribute__((ext_vector_type(2), aligned(4)));
 // The blocks the flow launch wrote, without their hand-over bit: the chroma blocks always, the luma blocks when nothing else drops it
 // (pictures without LMCS)
-__global__ __launch_bounds__(64) void k_flow_untag(ovhip_pic pic, const ovhip_itask *__restrict__ tasks, uint32_t n, int with_luma)
+__global__ __launch_bounds__(256) void k_flow_untag(ovhip_pic pic, const ovhip_itask *__restrict__ tasks, uint32_t n, int with_luma)
 {
-    if (blockIdx.x >= n) return;
-    const ovhip_itask t = tasks[blockIdx.x];
+    // 16 lanes per task, 16 tasks per workgroup; a lane clears runs of 4 samples (8 bytes) -- blocks narrower than 4: of 2
+    const uint32_t ti = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (ti >= n) return;
+    const ovhip_itask t = tasks[ti];
     if (t.kind == OVHIP_IT_REGION || (t.kind == OVHIP_IT_LUMA && !with_luma)) return;
+    const int lane = threadIdx.x & 15;
     const int l2w = t.log2_w, w = 1 << l2w, npx = w << t.log2_h;
     const bool luma = t.kind == OVHIP_IT_LUMA;
     const int stride = luma ? pic.stride_y : pic.stride_c;
     for (int c = 0; c < (luma ? 1 : 2); ++c) {
         if (!luma && t.kind == OVHIP_IT_RES_C && !(t.flags & (c ? OVHIP_IF_RES_CR : OVHIP_IF_RES_CB))) continue;
         uint16_t *dst = (luma ? pic.y : (c ? pic.cr : pic.cb)) + t.y * stride + t.x;
-        for (int p = threadIdx.x; p < npx; p += 64) { uint16_t *q = dst + (p >> l2w) * stride + (p & (w - 1)); *q = *q & 0x3ff; }
+        if (w >= 4) {
+            for (int p = 4 * lane; p < npx; p += 64) {
+                flow_u2 *q = reinterpret_cast<flow_u2 *>(dst + (p >> l2w) * stride + (p & (w - 1)));
+                flow_u2 v = *q; v[0] &= 0x03ff03ffu; v[1] &= 0x03ff03ffu; *q = v;
+            }
+        } else if (w == 2) {
+            for (int p = 2 * lane; p < npx; p += 32) {
+                uint32_t *q = reinterpret_cast<uint32_t *>(dst + (p >> l2w) * stride + (p & (w - 1)));
+                *q &= 0x03ff03ffu;
+            }
+        } else {
+            for (int p = lane; p < npx; p += 16) { uint16_t *q = dst + (p >> l2w) * stride + (p & (w - 1)); *q = *q & 0x3ff; }
+        }
     }
 }
 
-typedef uint32_t flow_u4 __attribute__((ext_vector_type(4), aligned(4)));
-typedef uint32_t flow_u2 __attribute__((ext_vector_type(2), aligned(4)));
 struct FlowLds { IntraLds s; unsigned *fp[FLOW_MAX_FP]; int abort; };
 
 __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res, const ovhip_itask *__restrict__ tasks, const uint32_t *__restrict__ items,
@@ -1338,7 +1353,7 @@ extern "C" int ovhip_intra_flow_untag_launch(ovhip_ctx *ctx, const ovhip_pic *pi
     OV_DEVICE(ctx);
     if (!n_tasks) return OVHIP_OK;
     if (!d_tasks) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_intra_flow_untag_launch: bad arguments", hipSuccess);
-    hipLaunchKernelGGL(k_flow_untag, dim3(n_tasks), dim3(64), 0, ctx->stream, *pic, d_tasks, n_tasks, with_luma);
+    hipLaunchKernelGGL(k_flow_untag, dim3((n_tasks + 15) / 16), dim3(256), 0, ctx->stream, *pic, d_tasks, n_tasks, with_luma);
     OV_LAUNCH_CHECK(ctx, "k_flow_untag");
     return OVHIP_OK;
 }

@@ -50,8 +50,40 @@ __global__ __launch_bounds__(64) void k_lmcs_scale(ovhip_pic pic, const ovhip_lm
     }
 }
 
-__global__ __launch_bounds__(256) void k_lmcs_inverse(ovhip_pic pic, const uint16_t *__restrict__ lut)
+typedef uint32_t lm_u2 __attribute__((ext_vector_type(2), aligned(4)));
+
+// k_flow_untag's body (kernels_intra.hip) for the chroma blocks of the ordered tasks: rides in the inverse-mapping launch of a picture
+// whose ordered pass ran as flow launches (one kernel boundary less between the ordered pass and the deblocking filter)
+__device__ __forceinline__ void untag_chroma_tasks(const ovhip_pic &pic, const ovhip_itask *__restrict__ tasks, uint32_t n, uint32_t wg)
 {
+    const uint32_t ti = wg * 16 + (threadIdx.x >> 4);
+    if (ti >= n) return;
+    const ovhip_itask t = tasks[ti];
+    if (t.kind == OVHIP_IT_REGION || t.kind == OVHIP_IT_LUMA) return;          // (the mapping itself drops the bit of every luma sample)
+    const int lane = threadIdx.x & 15;
+    const int l2w = t.log2_w, w = 1 << l2w, npx = w << t.log2_h, stride = pic.stride_c;
+    for (int c = 0; c < 2; ++c) {
+        if (t.kind == OVHIP_IT_RES_C && !(t.flags & (c ? OVHIP_IF_RES_CR : OVHIP_IF_RES_CB))) continue;
+        uint16_t *dst = (c ? pic.cr : pic.cb) + t.y * stride + t.x;
+        if (w >= 4) {
+            for (int p = 4 * lane; p < npx; p += 64) {
+                lm_u2 *q = reinterpret_cast<lm_u2 *>(dst + (p >> l2w) * stride + (p & (w - 1)));
+                lm_u2 v = *q; v[0] &= 0x03ff03ffu; v[1] &= 0x03ff03ffu; *q = v;
+            }
+        } else if (w == 2) {
+            for (int p = 2 * lane; p < npx; p += 32) *reinterpret_cast<uint32_t *>(dst + (p >> l2w) * stride + (p & (w - 1))) &= 0x03ff03ffu;
+        } else {
+            for (int p = lane; p < npx; p += 16) { uint16_t *q = dst + (p >> l2w) * stride + (p & (w - 1)); *q = *q & 0x3ff; }
+        }
+    }
+}
+
+// grid.y = rows_y row groups of the mapping + the workgroups of the chroma un-tag (grid.x of them per y)
+__global__ __launch_bounds__(256) void k_lmcs_inverse(ovhip_pic pic, const uint16_t *__restrict__ lut, uint32_t rows_y,
+                                                      const ovhip_itask *__restrict__ tasks, uint32_t n_tasks)
+{
+    if (blockIdx.y >= rows_y) { untag_chroma_tasks(pic, tasks, n_tasks, (blockIdx.y - rows_y) * gridDim.x + blockIdx.x); return; }
+
     __shared__ uint16_t s_lut[1024];
     for (int i = threadIdx.x; i < 512; i += 256) reinterpret_cast<uint32_t *>(s_lut)[i] = reinterpret_cast<const uint32_t *>(lut)[i];
     __syncthreads();
@@ -59,7 +91,7 @@ __global__ __launch_bounds__(256) void k_lmcs_inverse(ovhip_pic pic, const uint1
     const int tail = pic.w & 7;
     // a workgroup takes LMCS_ROWS rows at a time (the LUT staged once for 16 KB of samples instead of once per row segment); a
     // lane's vectors of all rows are requested before the first one is mapped
-    for (int y0 = blockIdx.y * LMCS_ROWS; y0 < pic.h; y0 += gridDim.y * LMCS_ROWS) {
+    for (int y0 = blockIdx.y * LMCS_ROWS; y0 < pic.h; y0 += rows_y * LMCS_ROWS) {
         for (int v = blockIdx.x * 256 + threadIdx.x; v < nvx; v += gridDim.x * 256) {
             uint4 q[LMCS_ROWS];
 #pragma unroll
@@ -101,7 +133,7 @@ extern "C" int ovhip_lmcs_scale_launch(ovhip_ctx *ctx, const ovhip_pic *pic, con
     return OVHIP_OK;
 }
 
-extern "C" int ovhip_lmcs_inverse_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const uint16_t *d_bwd_lut)
+static int lmcs_inverse_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const uint16_t *d_bwd_lut, const ovhip_itask *d_tasks, uint32_t n_tasks, const char *who)
 {
     if (!ctx || !pic || !d_bwd_lut) return OVHIP_EINVAL;
     OV_DEVICE(ctx);
@@ -109,8 +141,23 @@ extern "C" int ovhip_lmcs_inverse_launch(ovhip_ctx *ctx, const ovhip_pic *pic, c
         return ov_fail(ctx, OVHIP_EINVAL, "ovhip_lmcs_inverse_launch: luma plane must be 16-byte aligned with stride % 8 == 0", hipSuccess);
     const int nvx = pic->w >> 3;
     const int row_groups = (pic->h + LMCS_ROWS - 1) / LMCS_ROWS;
-    dim3 grid((nvx + 255) / 256 > 0 ? (nvx + 255) / 256 : 1, row_groups < 4096 ? row_groups : 4096);
-    hipLaunchKernelGGL(k_lmcs_inverse, grid, dim3(256), 0, ctx->stream, *pic, d_bwd_lut);
-    OV_LAUNCH_CHECK(ctx, "k_lmcs_inverse");
+    const uint32_t gx = (nvx + 255) / 256 > 0 ? (nvx + 255) / 256 : 1, rows_y = row_groups < 4096 ? row_groups : 4096;
+    const uint32_t untag_wgs = d_tasks ? (n_tasks + 15) / 16 : 0;
+    hipLaunchKernelGGL(k_lmcs_inverse, dim3(gx, rows_y + (untag_wgs + gx - 1) / gx), dim3(256), 0, ctx->stream, *pic, d_bwd_lut, rows_y, d_tasks, d_tasks ? n_tasks : 0u);
+    OV_LAUNCH_CHECK(ctx, who);
     return OVHIP_OK;
+}
+
+extern "C" int ovhip_lmcs_inverse_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const uint16_t *d_bwd_lut)
+{
+    return lmcs_inverse_launch(ctx, pic, d_bwd_lut, nullptr, 0, "k_lmcs_inverse");
+}
+
+// The inverse mapping of a picture whose ordered pass ran as flow launches: the same launch also clears the hand-over bit
+// (ovhip_intra_flow_untag_launch) in the chroma blocks of the ordered tasks d_tasks[n_tasks] (DEVICE); the mapping itself drops it
+// from every luma sample.
+extern "C" int ovhip_lmcs_inverse_untag_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const uint16_t *d_bwd_lut, const ovhip_itask *d_tasks, uint32_t n_tasks)
+{
+    if (n_tasks && !d_tasks) return OVHIP_EINVAL;
+    return lmcs_inverse_launch(ctx, pic, d_bwd_lut, n_tasks ? d_tasks : nullptr, n_tasks, "k_lmcs_inverse (+ chroma un-tag)");
 }

@@ -616,8 +616,9 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
             }
         }
         const bool inverse = pr->lmcs && (stages & OVHIP_STAGE_ITX);
-        if (by_flow && n_items) { CHK(ovhip_intra_flow_untag_launch(ctx, dst, d_it, (uint32_t)n_it, !inverse)); j->st.n_launches++; }
-        if (inverse) { CHK(ovhip_lmcs_inverse_launch(ctx, dst, d_bwd)); j->st.n_launches++; }
+        // the flow launches leave a hand-over bit in what they wrote: dropped by the inverse mapping's launch, or by one of its own
+        if (inverse) { CHK(ovhip_lmcs_inverse_untag_launch(ctx, dst, d_bwd, d_it, by_flow && n_items ? (uint32_t)n_it : 0u)); j->st.n_launches++; }
+        else if (by_flow && n_items) { CHK(ovhip_intra_flow_untag_launch(ctx, dst, d_it, (uint32_t)n_it, 1)); j->st.n_launches++; }
     }
     // ---- in-loop filters ----
     if (stages & OVHIP_STAGE_DBF) {
