@@ -767,6 +767,12 @@ int  ovhip_intra_flow_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_p
  * ordered tasks wrote: after the picture's flow launches, before anything else reads the picture.  with_luma == 0: chroma blocks
  * only -- ovhip_lmcs_inverse_launch drops the bit of every luma sample as a side effect of its table lookup. */
 int  ovhip_intra_flow_untag_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_itask *d_tasks, uint32_t n_tasks, int32_t with_luma);
+/* ovhip_lmcs_scale_launch + the state words of the picture's flow launch (ovhip_intra_flow_launch's prepare step) in ONE launch:
+ * d_tasks[n_tasks] = the level-sorted ordered tasks (DEVICE), d_state / epoch as for ovhip_intra_flow_launch, whose launches of
+ * this picture are then called with prepare = 0. */
+int  ovhip_lmcs_scale_prepare_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_lmcs_region *d_regions, uint32_t n_regions,
+                                     const ovhip_lmcs_luts *luts, int16_t *d_scales, const ovhip_itask *d_tasks, uint32_t n_tasks,
+                                     uint32_t *d_state, uint32_t epoch);
 /* ovhip_lmcs_inverse_launch + ovhip_intra_flow_untag_launch(with_luma = 0) in ONE launch (a picture with LMCS whose ordered pass
  * ran as flow launches). */
 int  ovhip_lmcs_inverse_untag_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const uint16_t *d_bwd_lut, const ovhip_itask *d_tasks, uint32_t n_tasks);

@@ -378,6 +378,7 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_job_last_stats": (C.c_int, [vp, P(JobStats)]),
         "ovhip_job_time_stage": (C.c_int, [vp, C.c_int]),
         "ovhip_job_stage_time": (C.c_int, [vp, P(C.c_double), P(C.c_uint64)]),
+        "ovhip_lmcs_scale_prepare_launch": (C.c_int, [vp, P(Pic), vp, u32, vp, vp, vp, u32, vp, u32]),
         "ovhip_lmcs_inverse_untag_launch": (C.c_int, [vp, P(Pic), vp, vp, u32]),
         "ovhip_intra_flow_untag_launch": (C.c_int, [vp, P(Pic), vp, u32, i32]),
         "ovhip_tmvp_cells_launch": (C.c_int, [vp, vp, u32, vp, i32, i32, vp]),
@@ -413,7 +414,7 @@ EXPORTED_SYMBOLS = [
     "ovhip_rec_itask_levels", "ovhip_rec_isp_cu", "ovhip_isp_geometry", "ovhip_rec_itasks_by_ctu", "ovhip_rec_set_ctu_size", "ovhip_job_bind", "ovhip_job_create", "ovhip_job_destroy", "ovhip_job_recorder", "ovhip_job_begin",
     "ovhip_job_flush", "ovhip_job_wait", "ovhip_job_refined_mvs", "ovhip_job_dmvr_rows", "ovhip_job_last_stats", "ovhip_job_time_stage", "ovhip_job_stage_time",
     "ovhip_output_bytes", "ovhip_output_rows", "ovhip_output_pack_launch", "ovhip_output_row_md5_launch", "ovhip_pic_output", "ovhip_pic_digest",
-    "ovhip_md5_init", "ovhip_md5_update", "ovhip_md5_final", "ovhip_tmvp_cells_launch", "ovhip_job_tmvp_cells", "ovhip_intra_flow_untag_launch", "ovhip_lmcs_inverse_untag_launch",
+    "ovhip_md5_init", "ovhip_md5_update", "ovhip_md5_final", "ovhip_tmvp_cells_launch", "ovhip_job_tmvp_cells", "ovhip_intra_flow_untag_launch", "ovhip_lmcs_inverse_untag_launch", "ovhip_lmcs_scale_prepare_launch",
 ]
 
 

@@ -19,6 +19,7 @@
 // LDS only.  int16 / int32 arithmetic, no MFMA: per-sample stencils.
 #include <stdlib.h>
 #include "ovvc_common.hip.h"
+#include "flow_state.hip.h"
 #define OVT_ATTR __device__
 #include "vvc_mip_tables.h"
 
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(64) void k_intra_level(ovhip_pic pic, ovhip_pic res
 #define CT_YS    (4 + CT_S)                 // luma tile row: 4 border samples + the CTU
 #define CT_CS    (4 + CT_S / 2)
 #define CT_CHUNK 128                        // tasks staged in LDS at a time
-#define SYNC_FLAGS 16                       // sync[0] = abort code; flags from word 16
+#define SYNC_FLAGS OVHIP_FLOW_SYNC_WORDS     // sync[0] = abort code; flags from word 16
 #define SPIN_LIMIT (1u << 17)              // polls before a workgroup gives up (>= 40 ms; a legitimate wait is a few ms): ovhip_job_wait then decodes the picture per level
 
 struct CtuLds {
@@ -818,7 +819,7 @@ struct AgentAcc {
     const uint16_t *p; int stride;
     __device__ __forceinline__ int ld(int x, int y) const { return __hip_atomic_load(p + y * stride + x, RLX_AGENT) & 0x7fff; }
 };
-struct FlowState { unsigned *y, *c[2], *reg; int w4; };
+// (FlowState and flow_prepare_task: flow_state.hip.h)
 // Luma hand-over inside the flow launch: DATA-TAGGED samples.  A luma item stores its samples with bit 15 set (10-bit samples leave
 // it free) and a luma item that needs them polls the reference samples themselves until the bit is there: the flag round trips
 // (drain the stores, mark the units, the consumer's poll, THEN its loads of the data) shrink to the one trip of the data.  Every
@@ -901,23 +902,7 @@ __device__ __forceinline__ bool fetch_refs_tagged(IntraLds &s, const uint16_t *p
 __global__ __launch_bounds__(256) void k_intra_flow_prepare(const ovhip_itask *__restrict__ tasks, uint32_t n, FlowState fs, unsigned epoch)
 {
     const uint32_t ti = blockIdx.x * 16 + (threadIdx.x >> 4);
-    if (ti >= n) return;
-    const ovhip_itask t = tasks[ti];
-    const int lane = threadIdx.x & 15;
-    const unsigned mark = 2 * epoch;
-    if (t.kind == OVHIP_IT_REGION) { if (lane == 0) fs.reg[t.c_scale] = mark; return; }
-    const bool luma = t.kind == OVHIP_IT_LUMA;
-    const int sh = luma ? 2 : 1, w = 1 << t.log2_w, h = 1 << t.log2_h;
-    const int ux0 = t.x >> sh, uy0 = t.y >> sh, nx = max(1, w >> sh), ny = max(1, h >> sh);
-    const int l2nx = 31 - __clz(nx);
-    for (int i = lane; i < nx * ny; i += 16) {
-        const int u = (uy0 + (i >> l2nx)) * fs.w4 + ux0 + (i & (nx - 1));
-        if (luma) fs.y[u] = mark;
-        else {
-            if (t.kind == OVHIP_IT_CHROMA || (t.flags & OVHIP_IF_RES_CB)) fs.c[0][u] = mark;
-            if (t.kind == OVHIP_IT_CHROMA || (t.flags & OVHIP_IF_RES_CR)) fs.c[1][u] = mark;
-        }
-    }
+    if (ti < n) flow_prepare_task(tasks[ti], fs, epoch, threadIdx.x & 15);
 }
 
 typedef uint32_t flow_u4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -1327,10 +1312,7 @@ extern "C" int ovhip_intra_flow_launch(ovhip_ctx *ctx, const ovhip_pic *pic, con
     LmcsWnd wnd;
     memset(&wnd, 0, sizeof(wnd));
     if (luts) { memcpy(wnd.bnd, luts->wnd_bnd, sizeof(wnd.bnd)); wnd.min_idx = luts->min_idx; wnd.max_idx = luts->max_idx; wnd.crs_offset = luts->crs_offset; }
-    FlowState fs;
-    const size_t nu = (size_t)((pic->w + 3) / 4) * ((pic->h + 3) / 4);
-    fs.w4 = (pic->w + 3) / 4;
-    fs.y = d_state + SYNC_FLAGS; fs.c[0] = fs.y + nu; fs.c[1] = fs.c[0] + nu; fs.reg = fs.c[1] + nu;
+    const FlowState fs = flow_state_of(d_state, pic->w, pic->h);
     if (prepare) {
         hipLaunchKernelGGL(k_intra_flow_prepare, dim3((n_tasks + 15) / 16), dim3(256), 0, ctx->stream, d_tasks, n_tasks, fs, epoch);
         OV_LAUNCH_CHECK(ctx, "k_intra_flow_prepare");

@@ -11,17 +11,26 @@
 //                    vector of 8 samples per lane, LUT (2 KB) staged in LDS.  Pure HBM stream: 2 bytes
 //                    read + 2 bytes written per luma sample.
 #include "ovvc_common.hip.h"
+#include "flow_state.hip.h"
 
 namespace {
 
 struct LmcsWnd { uint16_t bnd[17]; int min_idx, max_idx, crs_offset; };
 #define LMCS_ROWS 4
 
+// Workgroups [0, n): one chroma-scale region each.  Workgroups beyond: rider -- the state words of the flow launch of the ordered
+// pass (k_intra_flow_prepare's work, four tasks per workgroup), when the picture has one: a launch of its own was 9 us of the
+// picture's launch chain.
 __global__ __launch_bounds__(64) void k_lmcs_scale(ovhip_pic pic, const ovhip_lmcs_region *__restrict__ regs, uint32_t n,
-                                                   LmcsWnd wnd, int16_t *__restrict__ scales)
+                                                   LmcsWnd wnd, int16_t *__restrict__ scales, const ovhip_itask *__restrict__ tasks,
+                                                   uint32_t n_tasks, FlowState fs, unsigned epoch)
 {
     const uint32_t bid = blockIdx.x;
-    if (bid >= n) return;
+    if (bid >= n) {
+        const uint32_t ti = (bid - n) * 4 + (threadIdx.x >> 4);
+        if (ti < n_tasks) flow_prepare_task(tasks[ti], fs, epoch, threadIdx.x & 15);
+        return;
+    }
     const ovhip_lmcs_region g = regs[bid];
     if (g.ordered) return;                                    // luma around it comes from ordered tasks: k_intra_level derives it
     const int lane = threadIdx.x;
@@ -118,19 +127,39 @@ __global__ __launch_bounds__(256) void k_lmcs_inverse(ovhip_pic pic, const uint1
 
 } // namespace
 
-extern "C" int ovhip_lmcs_scale_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_lmcs_region *d_regions,
-                                       uint32_t n_regions, const ovhip_lmcs_luts *luts, int16_t *d_scales)
+static int lmcs_scale_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_lmcs_region *d_regions, uint32_t n_regions, const ovhip_lmcs_luts *luts,
+                             int16_t *d_scales, const ovhip_itask *d_tasks, uint32_t n_tasks, uint32_t *d_state, uint32_t epoch)
 {
     if (!ctx || !pic || !luts) return OVHIP_EINVAL;
     OV_DEVICE(ctx);
-    if (!n_regions) return OVHIP_OK;
-    if (!d_regions || !d_scales) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_lmcs_scale_launch: null buffer", hipSuccess);
+    if (!n_regions && !n_tasks) return OVHIP_OK;
+    if (n_regions && (!d_regions || !d_scales)) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_lmcs_scale_launch: null buffer", hipSuccess);
+    if (n_tasks && (!d_tasks || !d_state || !epoch)) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_lmcs_scale_prepare_launch: bad arguments", hipSuccess);
     LmcsWnd w;
     for (int i = 0; i < 17; ++i) w.bnd[i] = luts->wnd_bnd[i];
     w.min_idx = luts->min_idx; w.max_idx = luts->max_idx; w.crs_offset = luts->crs_offset;
-    hipLaunchKernelGGL(k_lmcs_scale, dim3(n_regions), dim3(64), 0, ctx->stream, *pic, d_regions, n_regions, w, d_scales);
-    OV_LAUNCH_CHECK(ctx, "k_lmcs_scale");
+    FlowState fs;
+    memset(&fs, 0, sizeof(fs));
+    if (n_tasks) fs = flow_state_of(d_state, pic->w, pic->h);
+    hipLaunchKernelGGL(k_lmcs_scale, dim3(n_regions + (n_tasks + 3) / 4), dim3(64), 0, ctx->stream, *pic, d_regions, n_regions, w, d_scales, d_tasks, n_tasks, fs, epoch);
+    OV_LAUNCH_CHECK(ctx, n_tasks ? "k_lmcs_scale (+ flow state words)" : "k_lmcs_scale");
     return OVHIP_OK;
+}
+
+extern "C" int ovhip_lmcs_scale_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_lmcs_region *d_regions,
+                                       uint32_t n_regions, const ovhip_lmcs_luts *luts, int16_t *d_scales)
+{
+    return lmcs_scale_launch(ctx, pic, d_regions, n_regions, luts, d_scales, nullptr, 0, nullptr, 0);
+}
+
+// ovhip_lmcs_scale_launch + the state words of the picture's flow launch (what ovhip_intra_flow_launch does first when called with
+// prepare != 0) in ONE launch: d_tasks[n_tasks] = the level-sorted ordered tasks, d_state / epoch as for ovhip_intra_flow_launch,
+// whose launches of this picture are then called with prepare = 0.
+extern "C" int ovhip_lmcs_scale_prepare_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_lmcs_region *d_regions, uint32_t n_regions,
+                                               const ovhip_lmcs_luts *luts, int16_t *d_scales, const ovhip_itask *d_tasks, uint32_t n_tasks,
+                                               uint32_t *d_state, uint32_t epoch)
+{
+    return lmcs_scale_launch(ctx, pic, d_regions, n_regions, luts, d_scales, d_tasks, n_tasks, d_state, epoch);
 }
 
 static int lmcs_inverse_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const uint16_t *d_bwd_lut, const ovhip_itask *d_tasks, uint32_t n_tasks, const char *who)

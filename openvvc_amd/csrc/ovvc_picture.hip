@@ -520,6 +520,25 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
         }
         if (n_ciip) { CHK(ovhip_ciip_launch(ctx, dst, intra, (const ovhip_ciip_unit *)DEV(B_CIIP), (uint32_t)n_ciip)); j->st.n_launches++; }
     }
+    // ---- the flow launch of the ordered pass: state block, abort word, this picture's epoch (before the residual stage: the
+    //      chroma-scale launch prepares the state words as a rider) ----
+    int flow_prepared = 0;
+    const ovhip_itask *d_it_early = (const ovhip_itask *)j->dev[B_ITASK].p;
+    if ((stages & OVHIP_STAGE_INTRA) && by_flow && n_items) {
+        if (!j->d_flow) {
+            const size_t words = ovhip_intra_flow_words(j->w, j->h);
+            OV_HIP(ctx, hipMalloc((void **)&j->d_flow, words * sizeof(uint32_t)));
+            OV_HIP(ctx, hipMemsetAsync(j->d_flow, 0, words * sizeof(uint32_t), ctx->stream));
+        }
+        if (!j->abort_host) {
+            j->abort_host = (uint32_t *)pinned_alloc(nullptr, 64);
+            if (!j->abort_host) return ov_fail(ctx, OVHIP_ENOMEM, "ovhip_job_flush: pinned abort word", hipSuccess);
+            *j->abort_host = 0;
+        }
+        if (++j->epoch >= 0x7ffffff0u) j->epoch = 1;
+        // test hook: behave as if a workgroup of this picture's flow launch had given up (ovhip_job_wait's second pass)
+        if (getenv("OVHIP_TEST_FORCE_SECOND_PASS") && j->n_retries == 0) *(volatile uint32_t *)j->abort_host = 1;
+    }
     // ---- residual: luma blocks, chroma-scale derivation on the reconstructed luma, chroma blocks (+ inverse mapping) ----
     if (stages & OVHIP_STAGE_ITX) {
         const ovhip_tb_cmd *d_tb = (const ovhip_tb_cmd *)j->dev[B_TB].p;
@@ -534,6 +553,11 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
         if (n_reg) {
             if (!pr->lmcs) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_job_flush: chroma-scale regions recorded without LMCS tables", hipSuccess);
             StageTimer t_(j, OVHIP_TIME_LMCS_SCALE);
+            if ((stages & OVHIP_STAGE_INTRA) && by_flow && n_items) {
+                CHK(ovhip_lmcs_scale_prepare_launch(ctx, dst, (const ovhip_lmcs_region *)DEV(B_REG), (uint32_t)n_reg, pr->lmcs,
+                                                    (int16_t *)j->dev[B_SCALE].p, d_it_early, (uint32_t)n_it, j->d_flow, j->epoch));
+                flow_prepared = 1;
+            } else
             CHK(ovhip_lmcs_scale_launch(ctx, dst, (const ovhip_lmcs_region *)DEV(B_REG), (uint32_t)n_reg, pr->lmcs,
                                         (int16_t *)j->dev[B_SCALE].p));
             j->st.n_launches++;
@@ -575,19 +599,6 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
             j->st.n_launches++;
         }
         if (by_flow && n_items) {
-            if (!j->d_flow) {
-                const size_t words = ovhip_intra_flow_words(j->w, j->h);
-                OV_HIP(ctx, hipMalloc((void **)&j->d_flow, words * sizeof(uint32_t)));
-                OV_HIP(ctx, hipMemsetAsync(j->d_flow, 0, words * sizeof(uint32_t), ctx->stream));
-            }
-            if (!j->abort_host) {
-                j->abort_host = (uint32_t *)pinned_alloc(nullptr, 64);
-                if (!j->abort_host) return ov_fail(ctx, OVHIP_ENOMEM, "ovhip_job_flush: pinned abort word", hipSuccess);
-                *j->abort_host = 0;
-            }
-            if (++j->epoch >= 0x7ffffff0u) j->epoch = 1;
-            // test hook: behave as if a workgroup of this picture's flow launch had given up (ovhip_job_wait's second pass)
-            if (getenv("OVHIP_TEST_FORCE_SECOND_PASS") && j->n_retries == 0) *(volatile uint32_t *)j->abort_host = 1;
             // in chunks of whole levels, at least FLOW_CHUNK items each.  The workgroups of a launch are resident and polling while
             // they wait, each holding 9 KB of LDS the other pictures' kernels then do not get; a chunk bounds that, but every
             // chunk boundary is a drain of the dependency front (measured at 4K, 16 pictures in flight: 1024 items 1724 fps,
@@ -595,7 +606,7 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
             // (OVHIP_FLOW_CHUNK: tuning knob, read once)
             static const size_t FLOW_CHUNK = getenv("OVHIP_FLOW_CHUNK") && atol(getenv("OVHIP_FLOW_CHUNK")) > 0 ? (size_t)atol(getenv("OVHIP_FLOW_CHUNK")) : 8192;
             size_t a = 0;
-            int first = 1;
+            int first = !flow_prepared;
             while (a < n_items) {
                 size_t b = a + FLOW_CHUNK < n_items ? a + FLOW_CHUNK : n_items;
                 while (b < n_items && it[j->items_host[b] & 0xffffff].level == it[j->items_host[b - 1] & 0xffffff].level) ++b;
