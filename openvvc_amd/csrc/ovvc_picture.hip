@@ -600,11 +600,12 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
         }
         if (by_flow && n_items) {
             // in chunks of whole levels, at least FLOW_CHUNK items each.  The workgroups of a launch are resident and polling while
-            // they wait, each holding 9 KB of LDS the other pictures' kernels then do not get; a chunk bounds that, but every
-            // chunk boundary is a drain of the dependency front (measured at 4K, 16 pictures in flight: 1024 items 1724 fps,
-            // 2048 1856, 4096 1896, 8192 1937, one launch 1943)
+            // they wait, each holding 9 KB of LDS the other pictures' kernels then do not get; a chunk bounds what ONE launch can
+            // pile up, but every chunk boundary is a drain of the dependency front and a launch on the picture's chain (measured
+            // at 4K, 16 pictures in flight, flag hand-over: 1024 items 1724 pictures/s, 2048 1856, 4096 1896, 8192 1937, one launch
+            // 1943; tagged hand-over: 8192 2617, 16384 2676, 32768 2709 -- a B picture is one launch, an I picture four)
             // (OVHIP_FLOW_CHUNK: tuning knob, read once)
-            static const size_t FLOW_CHUNK = getenv("OVHIP_FLOW_CHUNK") && atol(getenv("OVHIP_FLOW_CHUNK")) > 0 ? (size_t)atol(getenv("OVHIP_FLOW_CHUNK")) : 8192;
+            static const size_t FLOW_CHUNK = getenv("OVHIP_FLOW_CHUNK") && atol(getenv("OVHIP_FLOW_CHUNK")) > 0 ? (size_t)atol(getenv("OVHIP_FLOW_CHUNK")) : 32768;
             size_t a = 0;
             int first = !flow_prepared;
             while (a < n_items) {
