@@ -1318,7 +1318,7 @@ extern "C" int ovhip_intra_flow_launch(ovhip_ctx *ctx, const ovhip_pic *pic, con
         OV_LAUNCH_CHECK(ctx, "k_intra_flow_prepare");
     }
 #ifdef OVHIP_CTU_PROBE
-    if (prepare && hipMemcpyToSymbolAsync(HIP_SYMBOL(g_probe_items), &d_items, sizeof(d_items), 0, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return OVHIP_ELAUNCH;
+    if (hipMemcpyToSymbolAsync(HIP_SYMBOL(g_probe_items), &d_items, sizeof(d_items), 0, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return OVHIP_ELAUNCH;
 #endif
     const int nap = 0;          // poll back-off variant: 0 = s_sleep 4 between polls (16 the same; 64 and exponential back-off measured 6 % slower)
     hipLaunchKernelGGL(k_intra_flow, dim3(n_items), dim3(64), 0, ctx->stream, *pic, *res, d_tasks, d_items, n_items, d_regions, wnd, d_scales, log2_ctu_s, fs,

@@ -5,6 +5,8 @@ import sys, ctypes as C, shutil, os
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import numpy as np
 from openvvc_amd import capi
+import os
+os.environ["OVHIP_FLOW_CHUNK"] = "100000000"          # one flow launch per picture: the stamps are indexed from the launch's first item
 capi.LIB_PATH = capi.LIB_PATH.with_name("libovvc_hip_probe.so")
 from openvvc_amd import engine, synth
 W, H = 3840, 2160
@@ -79,3 +81,11 @@ print("by log2 area, kind: n, ready->refs, refs->pred, pred->issued, issued->ack
 for k in sorted(area):
     a = np.array(area[k]) / 100.0
     print(" ", k, len(a), np.round(np.median(a, axis=0), 2).tolist())
+
+# when does each plane finish?  (is the chroma chain behind the luma chain?)
+kinds = np.array([int(t[i]["kind"]) for i, s_, c_ in items])
+comp = np.array([c_ for i, s_, c_ in items])
+end = p[:, 7]
+for name, m in (("luma", kinds == capi.IT_LUMA), ("chroma Cb", (kinds == capi.IT_CHROMA) & (comp == 0)), ("chroma Cr", (kinds == capi.IT_CHROMA) & (comp == 1))):
+    e = end[m & (end > 0)]
+    print(f"last {name} item marked at {us(e.max() - t0):9.1f} us; 99 % of them by {us(np.percentile(e, 99) - t0):9.1f} us")
