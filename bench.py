@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--gop-rotation", type=int, default=1,
                     help="GOPs of picture sets / destination buffers in the rotation: with 1 a picture of GOP g + 1 overwrites the buffer of the same "
                          "position of GOP g and waits for its readers, which bounds the look-ahead to one GOP whatever --in-flight says")
+    ap.add_argument("--check", type=int, default=0, metavar="N",
+                    help="after the measurement: decode the first N pictures of the stream twice from the same start -- --in-flight pictures at a "
+                         "time, then one at a time -- and compare the device digests (ovhip_pic_digest) of every picture")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="N > 1: weak = every rank decodes --steps pictures (the stream grows with N); strong = the stream is --steps pictures in total, "
                          "its GOPs dealt to the ranks (each rank times --steps / N pictures)")
@@ -199,7 +202,7 @@ def main():
     gop_base = [0]                                 # GOPs this rank has decoded so far (keeps the key-buffer rotation going)
     keep_work = []
 
-    def run_steps(n, resident=False):
+    def run_steps(n, resident=False, digests=None):
         """The next n pictures of this rank's share of the stream, in decoding order.  One host thread per picture in flight,
         each with its own HIP stream; a thread that became free takes the next picture (the reference's frame threads,
         ovdec.c:188-248) and, like the shim's flush_picture, waits for it before it takes another.  A picture starts when the
@@ -286,6 +289,11 @@ def main():
                 t_iss = time.perf_counter()
                 st.job.wait()
                 second_passes[0] += int(st.job.stats().n_ordered_retries)
+                if digests is not None:
+                    out = (C.c_uint8 * 16)()
+                    win = capi.Window(0, 0, 0, 0)
+                    ctxs[slot]._chk(ctxs[slot].lib.ovhip_pic_digest(ctxs[slot].h, C.byref(buf[p.idx][1].s), C.byref(win), out), "pic_digest")
+                    digests[p.idx] = bytes(out)
             if args.trace_gop:
                 trace.append((p.idx, p.poc, p.layer, slot, t_pull, t_dep, t_bind, t_iss, time.perf_counter()))
 
@@ -443,6 +451,28 @@ def main():
     dt_res = timed(min(args.steps, 120), resident=True)
     fps_res = world * min(args.steps, 120) / dt_res
 
+    check = None
+    if args.check > 0 and world == 1:
+        def from_the_start():
+            gop_base[0] = 0
+            for k, (_t, pk) in enumerate(bufs_key):
+                pk.upload(*wls[0].refs[k % n_ref_slots])
+            torch.cuda.synchronize(dev)
+        da, db = {}, {}
+        from_the_start()
+        run_steps(args.check, digests=da)
+        barrier()
+        from_the_start()
+        one_at_a_time[0] = True
+        run_steps(args.check, digests=db)
+        one_at_a_time[0] = False
+        barrier()
+        bad = [i for i in da if da[i] != db.get(i)]
+        check = {"pictures": len(da), "differ": len(bad), "distinct_digests": len(set(da.values())),
+                 "what": f"{S} pictures in flight vs one at a time, same stream from the same start, ovhip_pic_digest of every picture"}
+        if bad:
+            raise SystemExit(f"bench --check: pictures {sorted(bad)[:16]} decode differently with {S} pictures in flight")
+
     if rank == 0:
         algs = [algorithmic_bytes(wl, FB) for wl in wls]
         use = np.bincount([len(wls) - 1 if (j == 0 and G % IP == 0) else j % n_b for j in range(K)], minlength=len(wls)).astype(np.float64)
@@ -523,6 +553,7 @@ def main():
                        "intra_levels_per_i_picture": wls[-1].stats["n_ilevels"],
                        "h2d_bytes_per_step": int(mean_stat("h2d_bytes")), "d2h_bytes_per_step": int(mean_stat("d2h_bytes")),
                        "ordered_pass_second_passes": second_passes[0],
+                       "check": check,
                        "launches_per_step": round((int(all_stats[0].n_launches) + (IP - 1) * int(js.n_launches)) / IP, 1),
                        "h2d_copies_per_step": round(mean_stat("n_h2d"), 1),
                        "launches_per_b_picture": int(js.n_launches),
