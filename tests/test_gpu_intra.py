@@ -192,3 +192,25 @@ def test_picture_with_intra_without_lmcs(ctx, w, h, seed, frac):
     ref = oracle_pipeline.decode(wl)
     for name, a, b in (("Y", got[0], ref.y), ("Cb", got[1], ref.cb), ("Cr", got[2], ref.cr)):
         assert np.array_equal(a, b), f"{w}x{h} without LMCS: plane {name}: {int((a != b).sum())} samples differ (max {int(a.max())})"
+
+
+@pytest.mark.gpu
+def test_4k_intra_picture_matches_oracle(ctx):
+    """The configuration the stream's time hangs on: a 3840x2160 picture with every CU intra (69k ordered tasks, ~2100 levels)
+    through the flow launches (tagged hand-over, four launches of 32768 items, riders) == the oracle, decoded three times into the
+    same buffers (a new epoch each time, the previous picture's samples underneath)."""
+    w, h = 3840, 2160
+    wl = synth.make_workload(w, h, 0x268, tools=synth.INTRA_TOOLS, intra_frac=1.0)
+    assert wl.stats["n_ilevels"] > 1500
+    ref = oracle_pipeline.decode(wl)
+    job = engine.Job(ctx, w, h)
+    dst = ctx.new_pic(w, h)
+    for rep in range(3):
+        job.load_workload(wl)
+        job.flush(dst, [], None)
+        job.wait()
+        assert job.stats().n_ordered_retries == 0
+        got = dst.download()
+        for name, a, b in (("Y", got[0], ref.y), ("Cb", got[1], ref.cb), ("Cr", got[2], ref.cr)):
+            assert np.array_equal(a, b), f"4K I picture, decode {rep}: plane {name}: {int((a != b).sum())} samples differ"
+        job.begin()
