@@ -92,7 +92,7 @@ def algorithmic_bytes(wl, S):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=240)
+    ap.add_argument("--steps", type=int, default=256, help="pictures timed (default: four intra periods)")
     ap.add_argument("--warmup", type=int, default=24)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
