@@ -668,7 +668,7 @@ int  ovhip_malloc(ovhip_ctx *ctx, size_t bytes, void **dptr);
 int  ovhip_free(ovhip_ctx *ctx, void *dptr);
 int  ovhip_h2d(ovhip_ctx *ctx, void *dptr, const void *host, size_t bytes);
 int  ovhip_d2h(ovhip_ctx *ctx, void *host, const void *dptr, size_t bytes);
-int  ovhip_pic_alloc(ovhip_ctx *ctx, int32_t w, int32_t h, ovhip_pic *pic);
+int  ovhip_pic_alloc(ovhip_ctx *ctx, int32_t w, int32_t h, ovhip_pic *pic);   /* three tight planes, zero-filled, complete on return */
 int  ovhip_pic_free(ovhip_ctx *ctx, ovhip_pic *pic);
 int  ovhip_pic_upload(ovhip_ctx *ctx, const ovhip_pic *pic, const uint16_t *y, const uint16_t *cb,
                       const uint16_t *cr, int32_t host_stride_y, int32_t host_stride_c);
@@ -765,7 +765,9 @@ int  ovhip_intra_flow_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_p
                              int16_t *d_scales, int32_t log2_ctu_s, uint32_t *d_state, uint32_t epoch, uint32_t *abort_mirror, int32_t prepare);
 /* The flow launch hands samples from task to task with bit 15 set (kernels_intra.hip, FLOW_TAG).  This clears it in the blocks the
  * ordered tasks wrote: after the picture's flow launches, before anything else reads the picture.  with_luma == 0: chroma blocks
- * only -- ovhip_lmcs_inverse_launch drops the bit of every luma sample as a side effect of its table lookup. */
+ * only -- ovhip_lmcs_inverse_launch drops the bit of every luma sample as a side effect of its table lookup.
+ * On ENTRY to the flow launch no sample of `pic` may carry bit 15: true for every picture ovhip_pic_alloc returned (zero-filled)
+ * that was only written by this library or by ovhip_pic_upload of real (<= 15-bit) samples since. */
 int  ovhip_intra_flow_untag_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_itask *d_tasks, uint32_t n_tasks, int32_t with_luma);
 /* ovhip_lmcs_scale_launch + the state words of the picture's flow launch (ovhip_intra_flow_launch's prepare step) in ONE launch:
  * d_tasks[n_tasks] = the level-sorted ordered tasks (DEVICE), d_state / epoch as for ovhip_intra_flow_launch, whose launches of

@@ -144,6 +144,11 @@ int ovhip_pic_alloc(ovhip_ctx *ctx, int32_t w, int32_t h, ovhip_pic *pic)
     void *base = nullptr;
     hipError_t e = hipMalloc(&base, ysz + 2 * csz);
     if (e != hipSuccess) return ov_fail(ctx, OVHIP_ENOMEM, "hipMalloc(picture)", e);
+    // zero-filled, and complete before the call returns (any context's stream may decode into it next): the ordered intra pass
+    // hands samples over by their bit 15, so a destination picture must not carry that bit in on entry -- recycled device memory can
+    e = hipMemsetAsync(base, 0, ysz + 2 * csz, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(base); return ov_fail(ctx, OVHIP_ELAUNCH, "hipMemset(picture)", e); }
     pic->y = (uint16_t *)base;
     pic->cb = (uint16_t *)((char *)base + ysz);
     pic->cr = (uint16_t *)((char *)base + ysz + csz);

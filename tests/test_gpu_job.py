@@ -126,3 +126,43 @@ def test_stage_mask_and_filters_off(ctx):
         for name, a, b in (("Y", got[0], ref.y), ("Cb", got[1], ref.cb), ("Cr", got[2], ref.cr)):
             assert np.array_equal(a, b), f"stages {names}: plane {name} differs"
     job.close()
+
+
+@pytest.mark.parametrize("on_host", [1, 0])
+def test_picture_waits_for_its_reference_picture(built_lib, on_host):
+    """Two pictures on two streams, the second one predicted from the first: ovhip_job_params.wait_events orders its launches
+    behind the first picture's completion event -- on the host inside the flush (wait_on_host, what the stream bench does) or as a
+    stream wait -- while its uploads are already under way.  Picture 2 == the oracle decoding it from the oracle's picture 1."""
+    import ctypes as C
+    import torch
+    w, h = 832, 480
+    dev = torch.device("cuda", 0)
+    c1, c2 = engine.Context(0), engine.Context(0)
+    s1 = torch.cuda.ExternalStream(c1.stream, device=dev)
+    wl1 = synth.make_workload(w, h, 0x51, tools=synth.INTRA_TOOLS, intra_frac=0.2)
+    wl2 = synth.make_workload(w, h, 0x52, tools=synth.INTRA_TOOLS, intra_frac=0.2)
+    ref1 = oracle_pipeline.decode(wl1)
+    wl2.refs[0] = (ref1.y.copy(), ref1.cb.copy(), ref1.cr.copy())          # picture 2's first reference = decoded picture 1
+    ref2 = oracle_pipeline.decode(wl2)
+    refs1 = [c1.upload_pic(*r) for r in wl1.refs]
+    dst1, dst2 = c1.new_pic(w, h), c2.new_pic(w, h)
+    refs2 = [dst1] + [c2.upload_pic(*r) for r in wl2.refs[1:]]
+    j1, j2 = engine.Job(c1, w, h), engine.Job(c2, w, h)
+    for rep in range(3):
+        j1.load_workload(wl1)
+        j2.load_workload(wl2)
+        j1.flush(dst1, refs1, None)
+        ev = torch.cuda.Event()
+        s1.record_event(ev)
+        handles = (C.c_void_p * 1)(ev.cuda_event)
+        j2.params.wait_events = C.cast(handles, C.POINTER(C.c_void_p))
+        j2.params.n_wait_events = 1
+        j2.params.wait_on_host = on_host
+        j2.flush(dst2, refs2, None)
+        j2.wait()
+        j1.wait()
+        got = dst2.download()
+        for name, a, b in (("Y", got[0], ref2.y), ("Cb", got[1], ref2.cb), ("Cr", got[2], ref2.cr)):
+            assert np.array_equal(a, b), f"picture 2 (on_host={on_host}, decode {rep}): plane {name}: {int((a != b).sum())} samples differ"
+        j1.begin(); j2.begin()
+    j1.close(); j2.close(); c1.close(); c2.close()
