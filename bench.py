@@ -73,7 +73,7 @@ def algorithmic_bytes(wl, S):
         return int((planes * a * (2 + 2) + np.where(pred, planes * arms * 2, 0) + np.where(lm, 8 * a, 0)).sum() + t.nbytes)
 
     fused = wl.mc_units[((wl.mc_units["flags"] & 128) == 0) & (wl.mc_units["aux"] != 0)]
-    ev, eh = capi.dbf_compact(wl.dbf_planes, 0), capi.dbf_compact(wl.dbf_planes, 1)
+    ev, eh = wl.dbf_edges
     alf_tables = sum(np.asarray(wl.alf[k]).nbytes for k, _ in capi.ALF_TABLES)
     return {
         "mc": 3 * (nref_area(wl.mc_units) + area(wl.mc_units) + area(fused)) + wl.mc_units.nbytes,

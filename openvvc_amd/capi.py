@@ -169,6 +169,16 @@ ALF_TABLES = (("ctus", ALF_CTU_DTYPE), ("luma_coeff", np.int16), ("luma_clip", n
 
 DBF_CTU_SIZE = 8 * (49 * 6 + 33 * 12) + 3 * 34 * 33 + 2 * 2 + 2 + 3 + 2 + 1 + 4 * 2
 DBF_CTU_SIZE = (DBF_CTU_SIZE + 7) & ~7          # struct alignment (uint64 members)
+_M49, _M33 = ("<u8", (49,)), ("<u8", (33,))
+DBF_CTU_DTYPE = np.dtype(                      # ovhip_dbf_ctu, field by field
+    [(n, *_M49) for n in ("ctb_bound_ver", "ctb_bound_hor", "ctb_bound_ver_c", "ctb_bound_hor_c", "aff_edg_ver", "aff_edg_hor")]
+    + [(n, *_M33) for n in ("bs2_ver", "bs2_hor", "bs2c_ver", "bs2c_hor", "bs1_ver", "bs1_hor", "bs1cb_ver", "bs1cb_hor",
+                            "bs1cr_ver", "bs1cr_hor", "affine_ver", "affine_hor")]
+    + [(n, "u1", (34 * 33,)) for n in ("qp_y", "qp_cb", "qp_cr")]
+    + [("beta_offset", "<i2"), ("tc_offset", "<i2"), ("disable_v", "u1"), ("disable_h", "u1"), ("log2_ctu_s", "u1"),
+       ("last_x", "u1"), ("last_y", "u1"), ("ctu_lft", "u1"), ("ctu_abv", "u1"), ("pad", "u1"),
+       ("ctu_w", "<u2"), ("ctu_h", "<u2"), ("ctb_x", "<u2"), ("ctb_y", "<u2")], align=True)
+assert DBF_CTU_DTYPE.itemsize == DBF_CTU_SIZE, (DBF_CTU_DTYPE.itemsize, DBF_CTU_SIZE)
 DBF_PLANE_NAMES = ("luma_v", "luma_h", "cb_v", "cr_v", "cb_h", "cr_h")
 
 

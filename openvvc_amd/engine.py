@@ -319,8 +319,8 @@ class ResidentPicture:
         self.tb_cmds = ctx.upload(wl.tb_cmds)
         self.coefs = ctx.upload(wl.coefs)
         self.dbf_planes = DevDbfPlanes(ctx, wl.dbf_planes)
-        self.dbf_v = ctx.upload(capi.dbf_compact(wl.dbf_planes, 0))
-        self.dbf_h = ctx.upload(capi.dbf_compact(wl.dbf_planes, 1))
+        self.dbf_v = ctx.upload(wl.dbf_edges[0])              # the lists ovhip_rec_dbf_ctu emitted CTU by CTU
+        self.dbf_h = ctx.upload(wl.dbf_edges[1])
         self.sao_params = ctx.upload(wl.sao_params)
         self.alf = DevAlf(ctx, wl.alf, wl.w, wl.h, log2_ctu)
         self.bufs = [self.mc_units, self.tb_cmds, self.coefs, self.sao_params, self.dbf_v, self.dbf_h]
@@ -456,7 +456,7 @@ class Job:
         for which, arr in ((capi.REC_COEF, wl.coefs), (capi.REC_TB, wl.tb_cmds), (capi.REC_MC, wl.mc_units),
                            (capi.REC_MCX, wl.mcx_units), (capi.REC_AFF, wl.aff_units), (capi.REC_SIDE, wl.aff_side),
                            (capi.REC_REGION, wl.lmcs_regions), (capi.REC_CIIP, wl.ciip_units), (capi.REC_ITASK, wl.itasks),
-                           (capi.REC_EDGE_V, capi.dbf_compact(wl.dbf_planes, 0)), (capi.REC_EDGE_H, capi.dbf_compact(wl.dbf_planes, 1))):
+                           (capi.REC_EDGE_V, wl.dbf_edges[0]), (capi.REC_EDGE_H, wl.dbf_edges[1])):
             if arr is not None and len(arr):
                 r.append_raw(which, arr)
         offs = capi.DbfOffsets()

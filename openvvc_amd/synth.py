@@ -97,7 +97,9 @@ class Workload:
     intra: tuple = None
     lmcs: "capi.LmcsLuts" = None    # None: LMCS off
     lmcs_regions: np.ndarray = None
-    dbf_planes: dict = None         # picture-level deblocking edge planes (include/ovvc_hip.h)
+    dbf_ctus: np.ndarray = None     # capi.DBF_CTU_DTYPE: what df.rcn_dbf_ctu receives, CTU by CTU
+    dbf_planes: dict = None         # picture-level deblocking edge planes ovhip_rec_dbf_ctu derived (include/ovvc_hip.h)
+    dbf_edges: list = None          # [vertical, horizontal] edge lists it emitted (capi.DBF_EDGE_DTYPE)
     sao_params: np.ndarray = None   # capi.SAO_CTU_DTYPE per CTU
     alf: dict = None                # ALF tables + per-CTU parameters
     itasks: np.ndarray = None       # capi.ITASK_DTYPE, decoding order: intra / CIIP / ordered-scale tasks (None: none)
@@ -441,7 +443,8 @@ def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6
     if lmcs_on:
         wl.lmcs = _lmcs_tables(rs)
         wl.lmcs_regions = rec.lmcs_regions()
-    wl.dbf_planes = make_dbf_planes(rs, w, h, cus)
+    wl.dbf_ctus = make_dbf_ctus(rs, w, h, cus)
+    wl.dbf_planes, wl.dbf_edges = record_dbf(rec, wl.dbf_ctus)
     wl.sao_params = make_sao_params(rs, w, h)
     wl.alf = make_alf(rs, w, h)
     u, ux, ua = wl.mc_units, wl.mcx_units, wl.aff_units
@@ -468,26 +471,20 @@ def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6
 # --------------------------------------------------------------------------------------------
 # in-loop filter side information (deblocking edge planes, SAO / ALF parameters)
 # --------------------------------------------------------------------------------------------
-def _edge_runs(E: np.ndarray):
-    """E[r, i] = an edge lies at the LEFT side of unit i (E[:, 0] is the picture border).  Returns the
-    distance in units to the previous edge (dP) and to the next edge or picture end (dQ)."""
-    n = E.shape[1]
-    idx = np.where(E, np.arange(n)[None, :], -1)
-    prev_incl = np.maximum.accumulate(idx, axis=1)                  # last edge at or before i
-    prev = np.concatenate([np.full((E.shape[0], 1), 0), prev_incl[:, :-1]], axis=1)   # strictly before i
-    idx2 = np.where(E, np.arange(n)[None, :], n)
-    nxt_incl = np.minimum.accumulate(idx2[:, ::-1], axis=1)[:, ::-1]
-    nxt = np.concatenate([nxt_incl[:, 1:], np.full((E.shape[0], 1), n)], axis=1)       # strictly after i
-    ar = np.arange(n)[None, :]
-    return ar - prev, nxt - ar
+def _pack_bits(win):
+    """win[bit, entry] (bool) -> uint64[entry]: one mask word per entry."""
+    sh = np.arange(win.shape[0], dtype=np.uint64)[:, None]
+    return (win.astype(np.uint64) << sh).sum(axis=0, dtype=np.uint64)
 
 
-def make_dbf_planes(rs, w, h, cus, ctu=128):
-    """Picture-level deblocking edge planes for a synthetic partition, following the rules the
-    reference derives per CTU (rcn_df.c:1890-1938): bS 1 on CU/TU edges with coded residual or motion
-    difference (random per CU), bS 2 around a few "intra" CUs, filter length 1 next to 4-sample
-    blocks, 7 on 16-sample-aligned edges of blocks >= 32 samples (3 at CTU-row tops for the P side), else 3;
-    chroma edges on the 8-sample grid, "large" when no other edge lies within 3 units."""
+def make_dbf_ctus(rs, w, h, cus, ctu=128):
+    """What df.rcn_dbf_ctu would receive for a synthetic partition, CTU by CTU in decoding order: capi.DBF_CTU_DTYPE records
+    (ovhip_dbf_ctu = the CTU's struct DBFInfo arrays after dbf_load_info()'s neighbour rotation, drv_lines.c:618-761, same
+    element layout -- see ovvc_record_dbf.c for the indexing).  Rules of the synthetic picture: CU boundaries and the 64-sample
+    transform grid are edges; bS 2 around a few "intra" CUs, bS 1 where either side has (random) residual / motion difference, per
+    component for chroma; one QP per CU.  Columns right of / rows below the CTU are still empty when the slot runs, the left /
+    above neighbours' last units are there.  The edge lists, filter lengths, average QPs and the chroma "large" decisions come
+    out of ovhip_rec_dbf_ctu -- nothing of that is derived here."""
     w4, h4 = (w + 3) // 4, (h + 3) // 4
     cu_id = np.zeros((h4, w4), np.int32)
     n = len(cus)
@@ -498,43 +495,68 @@ def make_dbf_planes(rs, w, h, cus, ctu=128):
     flag1 = rs.random_sample(n) < 0.55           # residual / motion difference -> bS 1
     flag1c = rs.random_sample(n) < 0.35
     intra = rs.random_sample(n) < 0.04           # bS 2
-    ux = np.arange(w4)[None, :]
-    uy = np.arange(h4)[:, None]
-    out = {"w4": w4, "h4": h4, "beta_offset": 0, "tc_offset": 0}
-    for d, name in ((0, "v"), (1, "h")):
+    PAD, FAR = 8, 56                             # units of margin before / after the picture in the padded arrays
+
+    def padded(m, dtype=bool):
+        out = np.zeros((h4 + PAD + FAR, w4 + PAD + FAR), dtype)
+        out[PAD:PAD + h4, PAD:PAD + w4] = m
+        return out
+
+    maps = {}
+    for d, name in ((0, "ver"), (1, "hor")):
         ids = cu_id if d == 0 else cu_id.T
-        pos = (ux if d == 0 else uy.T) + np.zeros_like(ids)       # coordinate across the edge, in units
-        left = np.concatenate([ids[:, :1], ids[:, :-1]], axis=1)
-        E = (ids != left) | ((pos % 16) == 0)                       # CU edges + 64-sample TU grid
-        E[:, 0] = True
-        dP, dQ = _edge_runs(E)
-        edge = E.copy(); edge[:, 0] = False                        # the picture border is never filtered
-        bs2 = edge & (intra[ids] | intra[left])
-        bs1 = edge & (flag1[ids] | flag1[left]) & ~bs2
-        bs = np.where(bs2, 2, np.where(bs1, 1, 0))
-        qp = (qp_cu[ids] + qp_cu[left] + 1) >> 1
-        small = (dP == 1) | (dQ == 1)
-        aligned = (pos % 4) == 0
-        ctu_top = (pos % (ctu // 4)) == 0 if d == 1 else np.zeros_like(aligned)
-        lp = np.where(small, 1, np.where((dP >= 8) & aligned & ~ctu_top, 7, 3))
-        lq = np.where(small, 1, np.where((dQ >= 8) & aligned, 7, 3))
-        word = np.where(bs > 0, bs | (lp << 2) | (lq << 5) | (qp << 8), 0).astype(np.uint16)
-        out["luma_" + name] = np.ascontiguousarray(word if d == 0 else word.T)
-        # chroma: 8-sample grid, bS 2 or (bS 1 of the component and "large")
-        on_grid = (pos % 2) == 0
-        large = (dP >= 4) & (dQ >= 4)
-        for comp, cname in ((0, "cb"), (1, "cr")):
-            f1c = flag1c if comp == 0 else ~flag1c & flag1
-            b1 = edge & (f1c[ids] | f1c[left])
-            on = on_grid & (bs2 | (b1 & large))
-            qpc = np.maximum((qp_cu[ids] + qp_cu[left] + 1 >> 1) - 1 - comp, 0)
-            cw = np.where(on, 1 | np.where(bs2, 2, 0) | np.where(large, 4, 0) | np.where(ctu_top, 8, 0) | (qpc << 8), 0)
-            cw = cw.astype(np.uint16)
-            if d == 0:
-                out[cname + "_v"] = np.ascontiguousarray(cw[:, ::2])
-            else:
-                out[cname + "_h"] = np.ascontiguousarray(cw.T[::2, :])
+        pos = np.arange(ids.shape[1])[None, :] + np.zeros_like(ids)
+        prev = np.concatenate([ids[:, :1], ids[:, :-1]], axis=1)
+        bound = (ids != prev) | ((pos % 16) == 0)
+        edge = bound.copy(); edge[:, 0] = False                    # the picture border carries no strength
+        either = lambda f: f[ids] | f[prev]
+        planes = {"bound": bound, "bs2": edge & either(intra), "bs1": edge & either(flag1),
+                  "bs1cb": edge & either(flag1c), "bs1cr": edge & either(~flag1c & flag1)}
+        for k, m in planes.items():
+            maps[k + "_" + name] = padded(m if d == 0 else m.T)
+    maps["bound_ver"][PAD:PAD + h4, PAD + w4] = True               # the picture's right / bottom border bounds its last blocks
+    maps["bound_hor"][PAD + h4, PAD:PAD + w4] = True
+    qp = {"qp_y": padded(qp_cu[cu_id], np.uint8), "qp_cb": padded(np.maximum(qp_cu[cu_id] - 1, 0), np.uint8),
+          "qp_cr": padded(np.maximum(qp_cu[cu_id] - 2, 0), np.uint8)}
+
+    nb = ctu >> 2
+    ncx, ncy = (w + ctu - 1) // ctu, (h + ctu - 1) // ctu
+    out = np.zeros(ncx * ncy, capi.DBF_CTU_DTYPE)
+    for cy in range(ncy):
+        for cx in range(ncx):
+            c = out[cy * ncx + cx]
+            ux0, uy0 = cx * nb, cy * nb
+            cw, ch = min(ctu, w - cx * ctu), min(ctu, h - cy * ctu)
+            nw, nh = cw >> 2, ch >> 2
+            # masks of vertical edges: entry 8 + i = unit column i, bit j = unit row j
+            rows = slice(PAD + uy0, PAD + uy0 + nh)
+            ver = lambda m, n_ent, first: _pack_bits(np.where(np.arange(first, first + n_ent)[None, :] <= nw,
+                                                              m[rows, PAD + ux0 + first:PAD + ux0 + first + n_ent], False))
+            # masks of horizontal edges: entry 8 + i = unit row i, bit k = unit column k - 2 (two units of the left neighbour)
+            cols = slice(PAD + ux0 - 2, PAD + ux0 + nw)
+            hor = lambda m, n_ent, first: _pack_bits(np.where(np.arange(first, first + n_ent)[:, None] <= nh,
+                                                              m[PAD + uy0 + first:PAD + uy0 + first + n_ent, cols], False).T)
+            for dst, src in (("ctb_bound_ver", "bound_ver"), ("ctb_bound_ver_c", "bound_ver")):
+                c[dst] = ver(maps[src], 49, -8)
+            for dst, src in (("ctb_bound_hor", "bound_hor"), ("ctb_bound_hor_c", "bound_hor")):
+                c[dst] = hor(maps[src], 49, -8)
+            for dst, src in (("bs2", "bs2"), ("bs2c", "bs2"), ("bs1", "bs1"), ("bs1cb", "bs1cb"), ("bs1cr", "bs1cr")):
+                c[dst + "_ver"] = ver(maps[src + "_ver"], 33, 0)
+                c[dst + "_hor"] = hor(maps[src + "_hor"], 33, 0)
+            for k, m in qp.items():                                  # 33 rows (the one above first) x 34 columns (two to the left)
+                c[k] = m[PAD + uy0 - 1:PAD + uy0 + 32, PAD + ux0 - 2:PAD + ux0 + 32].reshape(-1)
+            c["log2_ctu_s"] = ctu.bit_length() - 1
+            c["last_x"], c["last_y"] = cx == ncx - 1, cy == ncy - 1
+            c["ctu_lft"], c["ctu_abv"] = cx > 0, cy > 0
+            c["ctu_w"], c["ctu_h"], c["ctb_x"], c["ctb_y"] = cw, ch, cx, cy
     return out
+
+
+def record_dbf(rec, ctus):
+    """The CTUs through ovhip_rec_dbf_ctu: (dense edge planes for the oracle, [vertical, horizontal] edge lists as emitted)."""
+    for c in ctus:
+        rec.dbf_ctu(c.tobytes())
+    return rec.dbf_planes(), [rec.dbf_edges(0)[0], rec.dbf_edges(1)[0]]
 
 
 def make_sao_params(rs, w, h, ctu=128):

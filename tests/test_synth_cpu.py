@@ -28,6 +28,28 @@ def test_workload_has_every_tool_and_oracle_is_deterministic(built_lib):
     assert md5(base) != md5(a)
 
 
+def test_deblocking_goes_through_the_ctu_recorder(built_lib):
+    """The synthetic picture hands ovhip_rec_dbf_ctu the CTU-local maps df.rcn_dbf_ctu receives (synth.make_dbf_ctus); the edge
+    lists the engine uploads are what that call emitted, the planes the oracle filters from hold exactly those segments, and
+    the CTU seams lose nothing (horizontal edges of a CTU's last two unit columns come with its right neighbour)."""
+    for w, h in ((416, 240), (832, 480), (200, 136)):                  # the last one: truncated CTUs in both directions
+        wl = synth.make_workload(w, h, 0x77)
+        assert len(wl.dbf_ctus) == ((w + 127) // 128) * ((h + 127) // 128)
+        key = ["comp", "uy", "ux"]
+        for d in (0, 1):
+            emitted, compact = np.sort(wl.dbf_edges[d], order=key), np.sort(capi.dbf_compact(wl.dbf_planes, d), order=key)
+            assert len(emitted) and np.array_equal(emitted, compact), (w, h, d)
+        # every CU boundary inside the picture whose two sides differ in a strength-giving property is an edge somewhere:
+        # at least the 64-sample grid lines and all eight phases of the unit columns / rows carry edges
+        on_v, on_h = (wl.dbf_planes["luma_v"] & 3) > 0, (wl.dbf_planes["luma_h"] & 3) > 0
+        assert not on_v[:, 0].any() and not on_h[0, :].any()            # never on the picture border
+        if w >= 416:
+            assert all(on_h[:, c::32].any() for c in range(32)) and all(on_v[r::32, :].any() for r in range(32))
+        lp = (wl.dbf_planes["luma_h"] >> 2) & 7
+        assert (lp[::32][on_h[::32]] <= 3).all()                        # CTU-row tops: the P side keeps 3 lines (one line buffer)
+        assert set(np.unique(lp[on_h])) <= {1, 2, 3, 5, 7} and (lp[on_h] == 7).any()
+
+
 def test_lmcs_chroma_scales_follow_the_luma(built_lib):
     wl = synth.make_workload(416, 240, 3)
     refs = [HostPic(wl.w, wl.h, *r) for r in wl.refs]
