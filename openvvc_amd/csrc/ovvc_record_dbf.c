@@ -138,22 +138,28 @@ ovhip_rec_dbf_ctu(ovhip_recorder *r, const ovhip_dbf_ctu *c)
     const int hbits = nb_w + (c->last_x ? 2 : 0);
     const uint64_t hmask = hbits >= 64 ? ~0ull : ((1ull << hbits) - 1);
 
-    /* ---------------- luma, vertical edges (vvc_dbf_ctu_hor) ---------------- */
+    /* ---------------- luma, vertical edges (vvc_dbf_ctu_hor) ----------------
+     * The masks are per unit column; the segments leave row by row (neighbours in the list = neighbours in a picture row: the
+     * lanes of a wave of k_dbf_list<0> then share cache lines; column by column costs the device 30 % more time and traffic). */
     if (!c->disable_h) {
         const uint64_t *edg = &c->ctb_bound_ver[8], *sb = &c->aff_edg_ver[8];
-        for (int i = skip_v; i < nb_w; ++i) {
-            uint64_t m = (edg[i] | sb[i]) & vmask & (c->bs2_ver[i] | c->bs1_ver[i]);
-            if (!m) continue;
-            struct edge_ctx e;
-            edge_context(&e, edg, sb, i, 1);
-            while (m) {
-                int j = __builtin_ctzll(m);
-                m &= m - 1;
-                uint64_t pos = 1ull << j;
+        uint64_t todo[32], any = 0;
+        struct edge_ctx ctx[32];
+        for (int i = 0; i < nb_w; ++i) {
+            todo[i] = i < skip_v ? 0 : (edg[i] | sb[i]) & vmask & (c->bs2_ver[i] | c->bs1_ver[i]);
+            if (todo[i]) edge_context(&ctx[i], edg, sb, i, 1);
+            any |= todo[i];
+        }
+        while (any) {
+            const int j = __builtin_ctzll(any);
+            any &= any - 1;
+            const uint64_t pos = 1ull << j;
+            for (int i = skip_v; i < nb_w; ++i) {
+                if (!(todo[i] & pos)) continue;
                 int bs = 1 + !!(c->bs2_ver[i] & pos);
                 const uint8_t *q = &c->qp_y[36 + i + 34 * j];
                 int qp = (q[-1] + q[0] + 1) >> 1, lp, lq;
-                filter_length(&e, c->affine_ver[i], c->affine_ver[i + 1], pos, &lp, &lq);
+                filter_length(&ctx[i], c->affine_ver[i], c->affine_ver[i + 1], pos, &lp, &lq);
                 int ux = ux0 + i, uy = uy0 + j;
                 if (ux < w4 && uy < h4 && emit_edge(r, 0, 0, ux, uy, OVHIP_DBF_LUMA(bs, lp, lq, qp & 255), oi,
                                                     dense ? &r->dbf_luma_v[uy * w4 + ux] : NULL)) return OVHIP_ENOMEM;
@@ -182,7 +188,7 @@ ovhip_rec_dbf_ctu(ovhip_recorder *r, const ovhip_dbf_ctu *c)
             }
         }
     }
-    /* ---------------- chroma, vertical edges on the 8-sample grid (vvc_dbf_chroma_hor) ---------------- */
+    /* ---------------- chroma, vertical edges on the 8-sample grid (vvc_dbf_chroma_hor), row by row as well ---------------- */
     if (!c->disable_h) {
         const uint64_t *tab = &c->ctb_bound_ver_c[8];
         const int nb_vedge = (nb_w + 3) >> 2;
@@ -190,21 +196,26 @@ ovhip_rec_dbf_ctu(ovhip_recorder *r, const ovhip_dbf_ctu *c)
             const uint64_t *bs1v = comp ? c->bs1cr_ver : c->bs1cb_ver;
             const uint8_t *qpm = comp ? c->qp_cr : c->qp_cb;
             uint16_t *plane = comp ? r->dbf_cr_v : r->dbf_cb_v;
-            for (int i = skip_v; i < nb_vedge; ++i) {
+            uint64_t todo[8], large[8], any = 0;
+            for (int i = 0; i < nb_vedge; ++i) {
                 const int idx = i << 2;
-                uint64_t bs2 = c->bs2c_ver[idx], bs1 = bs1v[idx];
-                uint64_t m = tab[idx] & vmask & (bs2 | bs1);
-                if (!m) continue;
-                uint64_t large = large_from_ngh(&tab[idx]);
-                m &= bs2 | (bs1 & large);
-                while (m) {
-                    int j = __builtin_ctzll(m);
-                    m &= m - 1;
+                const uint64_t bs2 = c->bs2c_ver[idx], bs1 = bs1v[idx];
+                todo[i] = i < skip_v ? 0 : tab[idx] & vmask & (bs2 | bs1);
+                large[i] = todo[i] ? large_from_ngh(&tab[idx]) : 0;
+                todo[i] &= bs2 | (bs1 & large[i]);
+                any |= todo[i];
+            }
+            while (any) {
+                const int j = __builtin_ctzll(any);
+                any &= any - 1;
+                for (int i = skip_v; i < nb_vedge; ++i) {
+                    if (!((todo[i] >> j) & 1)) continue;
+                    const int idx = i << 2;
                     const uint8_t *q = &qpm[36 + idx + 34 * j];
                     int qp = (q[-1] + q[0] + 1) >> 1;
                     int ux = ux0 + idx, uy = uy0 + j;
-                    const uint16_t word = (uint16_t)(OVHIP_DBF_C_ON | (((bs2 >> j) & 1) ? OVHIP_DBF_C_BS2 : 0)
-                                                     | (((large >> j) & 1) ? OVHIP_DBF_C_LARGE : 0) | ((qp & 255) << 8));
+                    const uint16_t word = (uint16_t)(OVHIP_DBF_C_ON | (((c->bs2c_ver[idx] >> j) & 1) ? OVHIP_DBF_C_BS2 : 0)
+                                                     | (((large[i] >> j) & 1) ? OVHIP_DBF_C_LARGE : 0) | ((qp & 255) << 8));
                     if (ux < w4 && uy < h4 && emit_edge(r, 0, 1 + comp, ux, uy, word, oi,
                                                         dense ? &plane[uy * w4c + (ux >> 1)] : NULL)) return OVHIP_ENOMEM;
                 }
