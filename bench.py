@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--seed", type=int, default=0x266)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-isolated-survey", action="store_true",
+                    help="skip the one-picture-in-flight survey: every launch of the process then runs in the timed configuration "
+                         "(what tools/profile_round.sh traces, so that rocprofv3's per-kernel averages are of that configuration)")
     ap.add_argument("--in-flight", type=int, default=16, help="pictures in flight per GPU (one HIP stream + one host thread each)")
     ap.add_argument("--contents", type=int, default=2, help="distinct recorded pictures (seeds) among the sets")
     ap.add_argument("--intra-frac", type=float, default=0.12, help="share of intra CUs in the B pictures")
@@ -420,7 +423,7 @@ def main():
     # the same groups with ONE picture in flight (same rotation, nothing resident): what a launch takes when it has the device
     # to itself -- the timed configuration stretches every launch by the 15 other pictures it shares the device with
     isolated = {}
-    if rank == 0 or world > 1:
+    if (rank == 0 or world > 1) and not args.no_isolated_survey:
         one_at_a_time[0] = True
         for name in present:
             if name == "h2d":
@@ -482,7 +485,7 @@ def main():
         alg = {k: float(sum(u * a[k] for u, a in zip(use, algs))) for k in algs[0]}
         alg = {k: v for k, v in alg.items() if k in kern}
         achieved = alg[dom] / dom_avg / 1e9
-        traffic = None
+        traffic = rocprof_avg = None
         try:
             tj = json.loads((ROOT / "profiles" / "traffic.json").read_text())
             if tj["workload"] == {"width": W, "height": H, "seed": args.seed}:
@@ -491,11 +494,18 @@ def main():
                 # a launch group = one dispatch, except the ordered pass: one per level, averaged over the intra period
                 per_group = (wls[-1].stats["n_ilevels"] + (IP - 1) * wls[0].stats["n_ilevels"]) / IP if dom == "intra" else 1
                 traffic = int(sum(2 * k["fetch_kib"] + k["write_kib"] for k in ks) * 1024 * per_group)
+                if dom != "intra" and all("trace_avg_us" in k for k in ks):
+                    rocprof_avg = round(sum(k["trace_avg_us"] for k in ks), 2)
         except (OSError, KeyError, ValueError):
             traffic = None
         roofline = {"bound": "hbm", "kernel": KNAME[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                     "avg_launch_us": round(dom_avg * 1e6, 2),
+                    # the committed rocprofv3 --kernel-trace average of the same command (profiles/, every launch in the timed
+                    # configuration): execution only -- the HIP events of avg_launch_us also see the dispatch waiting in its
+                    # hardware queue behind the other streams' packets
+                    "rocprof_avg_launch_us": rocprof_avg,
+                    "frac_at_rocprof_duration": round(alg[dom] / rocprof_avg / 1e3 / HBM_PEAK_GBPS, 5) if rocprof_avg else None,
                     "picked_from": "survey in the timed configuration (same rotation and pictures in flight)",
                     "survey_launch_us": {k: round(v * 1e6, 2) for k, v in survey.items()},
                     "frac_per_kernel": {k: round(alg[k] / kern[k] / 1e9 / HBM_PEAK_GBPS, 5) for k in alg},
