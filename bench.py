@@ -166,7 +166,7 @@ def main():
     comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
 
     def torch_pic(ctx, planes=None):
-        t = torch.empty(H * W * 3 // 2, dtype=torch.int16, device=dev)
+        t = torch.zeros(H * W * 3 // 2, dtype=torch.int16, device=dev)     # zero-filled like ovhip_pic_alloc's: no sample may carry bit 15 in
         ysz, csz = H * W, (H // 2) * (W // 2)
         s = capi.Pic(t.data_ptr(), t.data_ptr() + 2 * ysz, t.data_ptr() + 2 * (ysz + csz), W, H, W, W // 2)
         p = engine.DevPic(ctx, s, owns=False)
