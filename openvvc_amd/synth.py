@@ -14,6 +14,8 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
+LM_FRAC = 0.35      # share of intra chroma blocks predicted by a cross-component linear model (LM / MDLM)
+
 from . import capi
 
 DEFAULT_SEED = 0x266
@@ -363,7 +365,7 @@ def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6
                             td.cu_flags |= (1 << 8) | (vert << 10); td.tr_skip_mask = 0x10; td.cu_mts_flag = 0
                         # chroma: derived (= luma mode), one of the fixed modes, or a cross-component linear model
                         cq = rs.random_sample()
-                        if cq < 0.35:
+                        if cq < LM_FRAC:
                             cm = int(rs.randint(67, 70))
                             ext = min(1 << (tl2w - 1), 1 << (tl2h - 1))
                             if cm == 67:

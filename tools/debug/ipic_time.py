@@ -4,6 +4,7 @@ sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np
 from openvvc_amd import capi, engine, synth
 w, h = 3840, 2160
+if len(sys.argv) > 1: synth.LM_FRAC = float(sys.argv[1])       # e.g. 0: no cross-component chroma blocks
 ctx = engine.Context(0)
 wl = synth.make_workload(w, h, 0x266, tools=synth.INTRA_TOOLS, intra_frac=1.0)
 print("tasks", wl.stats["n_itasks"], "levels", wl.stats["n_ilevels"])
