@@ -18,7 +18,9 @@ in flight per GPU (one HIP stream + one host thread each: the reference's frame 
 
 N > 1: one process per GPU, a GOP per GPU; the only picture of a GOP another GPU needs is its key picture, sent to the owner
 of the next GOP with RCCL point-to-point on a communication stream (no collective on the data path, nothing waited for on the
-host).  Every rank decodes --steps pictures: the stream grows with N ("weak").
+host).  A step = one intra period of the stream (--intra-period pictures: every step is the same work, so any --steps measures
+the steady state; a picture count that is not a multiple of it would over- or under-represent the I picture, which the stream
+fully exposes).  Every rank decodes --steps intra periods: the stream grows with N ("weak").
 
 Prints ONE JSON line on rank 0 (contract in the task statement).
 """
@@ -92,8 +94,10 @@ def algorithmic_bytes(wl, S):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256, help="pictures timed (default: four intra periods)")
-    ap.add_argument("--warmup", type=int, default=24)
+    ap.add_argument("--steps", type=int, default=4,
+                    help="timed steps; a step = one intra period of the stream (--intra-period pictures: its I picture and the B "
+                         "pictures of its GOPs), so that every step is the same work and any count measures the steady state")
+    ap.add_argument("--warmup", type=int, default=1, help="untimed steps before (intra periods)")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--seed", type=int, default=0x266)
@@ -117,8 +121,8 @@ def main():
                     help="after the measurement: decode the first N pictures of the stream twice from the same start -- --in-flight pictures at a "
                          "time, then one at a time -- and compare the device digests (ovhip_pic_digest) of every picture")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="N > 1: weak = every rank decodes --steps pictures (the stream grows with N); strong = the stream is --steps pictures in total, "
-                         "its GOPs dealt to the ranks (each rank times --steps / N pictures)")
+                    help="N > 1: weak = every rank decodes --steps intra periods (the stream grows with N); strong = the stream is --steps intra "
+                         "periods in total, its GOPs dealt to the ranks (each rank times 1/N of the pictures)")
     ap.add_argument("--host-threads", type=int, default=-1, help="host threads issuing the flushes (-1: one per picture in flight)")
     args = ap.parse_args()
 
@@ -149,6 +153,7 @@ def main():
     S = max(1, args.in_flight)
     G = args.gop                                   # pictures per GOP = picture sets of the rotation
     IP = args.intra_period
+    PPS = IP if IP > 0 else G                      # pictures per step: one intra period (its I picture + the B pictures of its GOPs)
     K = G
     tools = synth.INTRA_TOOLS if args.intra_frac > 0 else synth.ALL_TOOLS
     wls = [synth.make_workload(W, H, args.seed + 1000 * c + rank, tools=tools, intra_frac=args.intra_frac)
@@ -395,7 +400,7 @@ def main():
             tot += s; cnt += n
         return tot / max(cnt, 1)
 
-    run_steps(max(args.warmup, (2 if key_b else 1) * K * max(R, NK if key_b else 1)))            # every picture set flushed at least once
+    run_steps(max(args.warmup * PPS, (2 if key_b else 1) * K * max(R, NK if key_b else 1)))      # every picture set flushed at least once
     barrier()
     all_stats = [st.job.stats() for st in sets]          # of full (non-resident) flushes
     flush_stats = all_stats[-1]                          # a B picture
@@ -412,7 +417,7 @@ def main():
     survey = {}
     for name in present:
         set_timer(name)
-        run_steps(2 * K)
+        run_steps(3 * PPS)               # three intra periods per group: the pick is steadier than with one
         barrier()
         survey[name] = read_timer()
     kern = {k: v for k, v in survey.items() if k != "h2d"}
@@ -440,19 +445,20 @@ def main():
 
     # ---- timed region: EXACTLY --steps decode steps, only the dominant launch group bracketed
     set_timer(dom)
-    # weak: --steps pictures per rank; strong: --steps pictures in total (whole GOPs per rank would be the real deal; the rank's
-    # share is rounded down and the total says what was decoded)
-    steps_rank = args.steps if (world == 1 or args.scaling == "weak") else max(1, args.steps // world)
+    # a step = PPS pictures = one intra period.  weak: --steps intra periods per rank, each rank its own stream; strong: --steps
+    # intra periods of ONE stream in total, its GOPs dealt to the ranks (the rank's share is rounded down to whole pictures and
+    # the total says what was decoded)
+    strong = world > 1 and args.scaling == "strong"
+    steps_rank = args.steps * PPS if not strong else max(1, args.steps * PPS // world)          # pictures this rank decodes
     dt = timed(steps_rank)
     dom_avg = read_timer()
     set_timer(None)
-    strong = world > 1 and args.scaling == "strong"
-    ms_per_step = dt * 1e3 / (world * steps_rank if strong else steps_rank)       # strong: a step = one picture of THE stream
+    ms_per_step = dt * 1e3 / args.steps
     fps = world * steps_rank / dt
 
     # secondary figure: the round-1 measurement (device-resident replay of the same command buffers, no H2D / D2H)
-    dt_res = timed(min(args.steps, 120), resident=True)
-    fps_res = world * min(args.steps, 120) / dt_res
+    dt_res = timed(min(steps_rank, 120), resident=True)
+    fps_res = world * min(steps_rank, 120) / dt_res
 
     check = None
     if args.check > 0 and world == 1:
@@ -551,7 +557,7 @@ def main():
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None, "dtype": "u16 samples / int16 coefficients / int32 accumulate", "data": "synthetic",
-            "config": {"pictures_per_rank": steps_rank,
+            "config": {"pictures_per_step": PPS, "pictures_per_rank": steps_rank,
                        "workload": f"{W}x{H} 10-bit 4:2:0 synthetic recorded random-access stream (BASELINE configs[3]): GOP {G} "
                                    f"(hierarchical B, JVET decoding order), intra period {IP}: per GOP {G - 1} B pictures with "
                                    f"{args.intra_frac:.0%} intra CUs + the key picture ({'I' if G % IP == 0 else 'I every ' + str(IP // G) + ' GOPs, else B'}); "

@@ -49,6 +49,16 @@ def gop_decode_order(gop_size: int) -> list:
     return out
 
 
+def gop_owner(g: int, world: int, gops_per_intra_period: int = 1) -> int:
+    """GOP g -> rank.  Every block of `world` consecutive GOPs goes once around the ranks.  The GOPs whose key picture is an I
+    picture come every gops_per_intra_period-th (every second one in the CTC setting) and an I picture costs as much as twenty B
+    pictures: when that period and `world` share a factor, g % world would hand all of them to the same ranks, so the start of
+    the round moves by one rank per block."""
+    from math import gcd
+    shift = g // world if gcd(world, max(1, gops_per_intra_period)) > 1 else 0
+    return (g + shift) % world
+
+
 def build_stream(n_gops: int, gop_size: int = 32, intra_period: int = 32, world: int = 1, refs_per_list: int = 2) -> list:
     """The pictures of an RA stream in decoding order with their reference pictures, owners and cross-GPU sends."""
     assert intra_period % gop_size == 0
@@ -70,7 +80,7 @@ def build_stream(n_gops: int, gop_size: int = 32, intra_period: int = 32, world:
                 after = sorted(p for p in ok if p > poc)[:refs_per_list]
                 refs = [decoded[p] for p in before] + [decoded[p] for p in after]
             idx = len(pics)
-            pics.append(Picture(idx, g, poc, layer, intra, refs, g % world))
+            pics.append(Picture(idx, g, poc, layer, intra, refs, gop_owner(g, world, intra_period // gop_size)))
             by_poc[poc] = idx
             decoded[poc] = idx                               # ... and its own pictures decoded so far
             layer_of[poc] = layer

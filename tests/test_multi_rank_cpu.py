@@ -54,7 +54,11 @@ def test_schedule_is_consistent(world, gop_size, intra_period):
     assert all(pics[i].layer == 0 for i, _, _ in tr)
     if world > 1:
         assert len(tr) == 3 * world + 1 - 1 + (1 if world > 1 else 0) or len(tr) <= 3 * world + 1
-        assert all((d - s) % world == 1 or pics[i].gop == -1 for i, s, d in tr)
+        # a key picture goes to the owner of the NEXT GOP, and only there (none when that is its own rank)
+        assert all(pics[i].gop == -1 or (d == gop.gop_owner(pics[i].gop + 1, world, intra_period // gop_size) and d != s) for i, s, d in tr)
+        # the GOPs with an I picture are spread evenly: no rank decodes more than one of them more than another
+        n_i = [sum(1 for p in pics if p.intra and p.gop >= 0 and p.owner == r) for r in range(world)]
+        assert max(n_i) - min(n_i) <= 1, n_i
     else:
         assert not tr
     # frame-level parallelism: with a GOP per GPU the dependency chain is the key pictures only where they are not intra

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
-cmd="python $R/bench.py --steps 128 --warmup 32 --no-cpu-baseline --no-isolated-survey"   # every launch in the timed configuration: the averages below are of that configuration
+cmd="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-isolated-survey"   # every launch in the timed configuration: the averages below are of that configuration
 rocprofv3 --kernel-trace --stats -d $O/prof_${tag}_trace -o ${tag} -- $cmd > $O/${tag}_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $O/prof_${tag}_f -o ${tag} -- $cmd > $O/${tag}_f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/prof_${tag}_w -o ${tag} -- $cmd > $O/${tag}_w.log 2>&1

@@ -7,7 +7,7 @@ for spec in "$@"; do
   for v in $vals; do
     rm -f openvvc_amd/csrc/build/$file.o
     make -s -C openvvc_amd/csrc EXTRA="-DOV_WPE_$tag=$v" >/dev/null 2>&1 || { echo "$tag=$v build failed"; continue; }
-    python bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
+    python bench.py --steps 1 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); s=d['roofline']['survey_launch_us']
 print('$tag=$v', d['value'], {k: s[k] for k in s})"
