@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define OVHIP_ABI_VERSION 5
+#define OVHIP_ABI_VERSION 6
 
 /* ---- error codes (negative, in the spirit of libovvc/overror.h:40-45) ---- */
 #define OVHIP_OK        0
@@ -43,6 +43,7 @@ extern "C" {
 #define OVHIP_EINVAL   (-3)  /* malformed command / argument                      */
 #define OVHIP_ELAUNCH  (-4)  /* kernel launch or execution error (see last_error) */
 #define OVHIP_EUNSUP   (-5)  /* tool outside the supported hot path (e.g. RPR)    */
+#define OVHIP_EREF     (-6)  /* a reference picture failed to decode, or the DPB was shut down while waiting for it */
 
 /* ---- transform types: same numbering as enum DCTType, rcn_structures.h:87-93 ---- */
 enum { OVHIP_DST_VII = 0, OVHIP_DCT_VIII = 1, OVHIP_DCT_II = 2 };
@@ -668,6 +669,9 @@ int  ovhip_malloc(ovhip_ctx *ctx, size_t bytes, void **dptr);
 int  ovhip_free(ovhip_ctx *ctx, void *dptr);
 int  ovhip_h2d(ovhip_ctx *ctx, void *dptr, const void *host, size_t bytes);
 int  ovhip_d2h(ovhip_ctx *ctx, void *host, const void *dptr, size_t bytes);
+/* page-locked host memory (DMA source / target: output frames, recorder arrays); NULL on failure */
+void *ovhip_host_alloc(size_t bytes);
+void  ovhip_host_free(void *p);
 int  ovhip_pic_alloc(ovhip_ctx *ctx, int32_t w, int32_t h, ovhip_pic *pic);   /* three tight planes, zero-filled, complete on return */
 int  ovhip_pic_free(ovhip_ctx *ctx, ovhip_pic *pic);
 int  ovhip_pic_upload(ovhip_ctx *ctx, const ovhip_pic *pic, const uint16_t *y, const uint16_t *cb,
@@ -939,6 +943,229 @@ int  ovhip_tmvp_cells_launch(ovhip_ctx *ctx, const ovhip_mc_unit *d_units, uint3
 /* After ovhip_job_wait of a flush with ovhip_job_params.tmvp_cells != 0: the cells of the picture's refined units (4 per
  * unit, recorder order), valid until the job's next begin. */
 const ovhip_tmvp_cell *ovhip_job_tmvp_cells(ovhip_job *job, size_t *n_entries);
+
+
+/* ====================================================================================
+ * Frame threads and the device DPB (reference-independent; what shim/rcn_hip.c and the stream driver below are thin
+ * callers of).
+ *
+ * The reference decodes pictures on frame threads (ovdec_select_subdec, ovdec.c:188-248); a picture's frame lives in the DPB
+ * from ovdpb_init_picture until the last picture referencing it and the output process have dropped it (dpb.c), and a frame
+ * thread that needs rows of a reference picture waits on that picture's progress (ovdpb_synchro_ref_decoded_ctus,
+ * dpb.c:1242-1270; rcn_inter.c:131-146), which the producer reports per CTU row (ovdpb_report_decoded_ctu_line,
+ * dpb.c:1309-1323; slicedec.c:934-956).  On the device a picture is decoded by ONE flush at the end of its parse, so the
+ * progress mask collapses to one transition per picture:
+ *
+ *   ovhip_dpb_begin    (rcn_attach_frame_buff)        DECODING: a device picture for `key` on device `dev`
+ *   ovhip_dpb_publish  (after ovhip_job_wait)         DONE / FAILED: every waiter is released.  ONLY ovhip_job_wait marks a
+ *                                                     picture complete: it may decode the picture a second time (ordered pass),
+ *                                                     so nothing recorded after ovhip_job_flush is a "picture done" signal
+ *   ovhip_dpb_acquire  (ovdpb_frame_synchro)          blocks until `key` is DONE (OVHIP_EREF if it FAILED), pins it, returns
+ *                                                     the picture as device `dev` sees it
+ *   ovhip_dpb_unpin                                   the reader's own decode has completed
+ *   ovhip_dpb_release  (frame unreferenced)           the slot and its device memory return to the pool once nobody has it pinned
+ *
+ * `key` is opaque (the shim passes the OVFrame pointer).  A key handed to ovhip_dpb_begin while an older picture still owns it
+ * releases that picture first: the reference's frame pool re-uses an OVFrame only after every reference to it was dropped.
+ *
+ * Several devices in ONE process (north_star: frames shard one per GPU, mirroring --framethr): a picture is decoded on its
+ * `home` device; a device whose queued pictures list it (ovhip_dpb_want, called when such a picture BEGINS, i.e. as soon as its
+ * reference lists are known -- slicedec.c:1250-1256) receives a copy over xGMI as soon as it is DONE: hipMemcpyPeerAsync on the
+ * destination device's copy stream, one event per copy; ovhip_dpb_acquire hands the event to the reader, which waits for it
+ * after its own uploads are under way.  Devices that never list the picture never receive it.
+ * ---------------------------------------------------------------------------------- */
+typedef struct ovhip_dpb ovhip_dpb;
+
+/* Memory / copy back-end of a DPB.  ovhip_dpb_create installs the HIP one; ovhip_dpb_create_ex lets a test supply its own
+ * (the state machine is plain C + pthreads and is exercised without a GPU that way; it never computes samples). */
+typedef struct ovhip_dpb_ops {
+    void *user;
+    int  (*pic_alloc)(void *user, int dev, int32_t w, int32_t h, ovhip_pic *pic);        /* zero-filled, complete on return    */
+    void (*pic_free)(void *user, int dev, ovhip_pic *pic);
+    /* src (home device src_dev, complete) -> dst (dst_dev).  *event: handle for copy_wait / copy_done, or NULL = done already */
+    int  (*copy_start)(void *user, int dst_dev, const ovhip_pic *dst, int src_dev, const ovhip_pic *src, void **event);
+    int  (*copy_wait)(void *user, int dst_dev, void *event);                               /* blocks the calling thread          */
+    void (*copy_done)(void *user, int dst_dev, void *event);                               /* the handle is no longer needed     */
+    /* a picture whose last decode FAILED goes back to the pool: make it safe to decode into (no sample may carry bit 15) */
+    int  (*pic_clear)(void *user, int dev, const ovhip_pic *pic);
+} ovhip_dpb_ops;
+
+#define OVHIP_MAX_DEVICES 16
+typedef struct ovhip_dpb_stats {
+    uint32_t n_live, n_pool;             /* pictures owned by a key (home + copies) / waiting in the free pools            */
+    uint64_t n_begin, n_alloc, n_recycled, n_copies, copy_bytes, n_failed;
+    uint64_t n_waits;                    /* acquire calls that had to block                                                */
+} ovhip_dpb_stats;
+
+/* devices[i] = HIP device ordinal of logical device i (the same ordinal may appear twice: two logical devices on one GPU,
+ * the peer copy is then a device-to-device copy -- how the multi-device path is tested on a one-GPU box). */
+int  ovhip_dpb_create(ovhip_dpb **out, const int *devices, int n_devices);
+int  ovhip_dpb_create_ex(ovhip_dpb **out, int n_devices, const ovhip_dpb_ops *ops);
+void ovhip_dpb_destroy(ovhip_dpb *d);            /* frees every device picture; no thread may be inside a DPB call */
+int  ovhip_dpb_n_devices(const ovhip_dpb *d);
+int  ovhip_dpb_device(const ovhip_dpb *d, int dev);                 /* HIP ordinal of logical device dev, <0 if none     */
+int  ovhip_dpb_begin(ovhip_dpb *d, const void *key, int dev, int32_t w, int32_t h, ovhip_pic *pic);
+int  ovhip_dpb_want(ovhip_dpb *d, const void *key, int dev);
+/* status 0: DONE, else FAILED (latched error of the producer): every exit path of a producer publishes */
+int  ovhip_dpb_publish(ovhip_dpb *d, const void *key, int status);
+/* *event (may be NULL when dev is the home device): a copy_wait handle the caller waits for before it reads pic, or NULL */
+int  ovhip_dpb_acquire(ovhip_dpb *d, const void *key, int dev, ovhip_pic *pic, void **event);
+int  ovhip_dpb_wait_copy(ovhip_dpb *d, int dev, void *event);
+int  ovhip_dpb_unpin(ovhip_dpb *d, const void *key);
+int  ovhip_dpb_release(ovhip_dpb *d, const void *key);
+/* The home picture of a DONE key, without blocking (output path): OVHIP_EINVAL unknown, OVHIP_EREF not (yet) decoded. */
+int  ovhip_dpb_lookup(ovhip_dpb *d, const void *key, int *home_dev, ovhip_pic *pic);
+/* Wakes every waiter with OVHIP_EREF and makes every later wait fail at once (decoder teardown after an error). */
+void ovhip_dpb_shutdown(ovhip_dpb *d);
+int  ovhip_dpb_get_stats(ovhip_dpb *d, ovhip_dpb_stats *out);
+
+/* ------------------------------------------------------------------------------------
+ * Frame thread: one context (HIP stream) + one picture job on one logical device of a DPB -- what the shim keeps per
+ * OVCTUDec.  Call order per picture:
+ *
+ *   ovhip_frame_begin(key)          rcn_attach_frame_buff: DPB slot + ovhip_job_begin, empty reference table
+ *   ovhip_frame_ref(ref_key)        first use of a reference picture: its index in the table the recorded units carry
+ *                                   (ovhip_pu_desc.ref0 / ref1); tells the DPB this device wants it
+ *   ... the slots record into ovhip_frame_recorder() ...
+ *   ovhip_frame_dmvr_rows()         every alf.rcn_alf_filter_line: waits for the references, eager refinement (see
+ *                                   ovhip_job_dmvr_rows)
+ *   ovhip_frame_submit(params)      last row: uploads; waits for the references (host) while they run; launches;
+ *                                   ovhip_job_wait (incl. its second pass); optional output; THEN publishes -- on every
+ *                                   exit path, with the error if there was one -- and unpins the references
+ * ---------------------------------------------------------------------------------- */
+typedef struct ovhip_frame ovhip_frame;
+
+enum { OVHIP_OUT_NONE = 0,     /* the picture stays on the device (readers: ovhip_dpb_lookup + ovhip_pic_output / _digest) */
+       OVHIP_OUT_DIGEST = 1,   /* + ovhip_pic_digest into ovhip_frame_output.digest (16 bytes leave the device)           */
+       OVHIP_OUT_PLANES = 2,   /* + the three planes into caller memory (the OVFrame: dectest.c:372-409 reads it there)   */
+       OVHIP_OUT_PACKED = 3 }; /* + crop + pack on the device, ONE D2H into caller memory (ovhip_output_bytes() bytes)    */
+typedef struct ovhip_frame_output {
+    int32_t  mode;                       /* OVHIP_OUT_*                                                                    */
+    ovhip_window window;                 /* DIGEST / PACKED                                                                */
+    uint16_t *y, *cb, *cr; int32_t stride_y, stride_c;    /* PLANES: host pointers, strides in samples                     */
+    void    *packed;                     /* PACKED: host pointer                                                           */
+    uint8_t  digest[16];                 /* DIGEST: result                                                                 */
+} ovhip_frame_output;
+
+int  ovhip_frame_create(ovhip_dpb *dpb, int dev, int32_t w, int32_t h, ovhip_frame **out);
+void ovhip_frame_destroy(ovhip_frame *f);
+ovhip_ctx      *ovhip_frame_ctx(ovhip_frame *f);
+ovhip_job      *ovhip_frame_job(ovhip_frame *f);
+ovhip_recorder *ovhip_frame_recorder(ovhip_frame *f);
+int  ovhip_frame_begin(ovhip_frame *f, const void *key);
+int  ovhip_frame_ref(ovhip_frame *f, const void *ref_key);          /* index (0..15) or <0 */
+/* Same without the search for an existing entry: the table entry `slot` (= the number of entries so far) is ref_key, which may
+ * already sit in another entry (a recorded picture whose units index a fixed table). */
+int  ovhip_frame_ref_at(ovhip_frame *f, int slot, const void *ref_key);
+int64_t ovhip_frame_dmvr_rows(ovhip_frame *f);
+/* job: NULL = the frame's own job (the shim); else a job holding an already recorded picture of the same size, which is bound to
+ * this frame's context for the flush (the stream driver's pre-recorded pictures).  intra: as ovhip_job_flush.  out: NULL =
+ * OVHIP_OUT_NONE.  Returns the picture's status (what was published). */
+int  ovhip_frame_submit(ovhip_frame *f, ovhip_job *job, const ovhip_pic *intra, const ovhip_job_params *params, ovhip_frame_output *out);
+/* A picture that cannot be submitted (latched recorder error, unsupported tool): publishes it as FAILED so that no reader
+ * waits for it for ever. */
+int  ovhip_frame_fail(ovhip_frame *f, int status);
+const char *ovhip_frame_last_error(const ovhip_frame *f);
+
+/* ------------------------------------------------------------------------------------
+ * Call log: the arguments of the recorder entry points of one picture (descriptors + the coefficient blocks they point to,
+ * in the reference's layout), serialised in call order -- the compact pre-parsed form of a picture.  ovhip_calllog_replay
+ * issues the same calls again: what a parse thread does per picture minus CABAC, used by the stream driver to put the
+ * recorder into the timed region and by tools/micro/rec_throughput.c.
+ * ---------------------------------------------------------------------------------- */
+typedef struct ovhip_calllog ovhip_calllog;
+ovhip_calllog *ovhip_calllog_create(void);
+void   ovhip_calllog_destroy(ovhip_calllog *log);
+void   ovhip_calllog_reset(ovhip_calllog *log);
+const void *ovhip_calllog_data(const ovhip_calllog *log, size_t *bytes);
+/* While a log is attached every ovhip_rec_tu / _tu_intra / _isp_cu / _pu / _affine_cu / _lmcs_region / _dbf_ctu /
+ * _set_ctu_size call on `rec` is appended to it (NULL detaches). */
+void   ovhip_rec_set_calllog(ovhip_recorder *rec, ovhip_calllog *log);
+/* Re-issues the calls of a serialised log on rec.  Returns the number of calls or <0 (first failing call's code). */
+int64_t ovhip_calllog_replay(const void *data, size_t bytes, ovhip_recorder *rec);
+
+/* ------------------------------------------------------------------------------------
+ * Stream driver: decodes a whole stream of recorded pictures with N frame threads per device, in C (pthreads) -- the frame
+ * thread pool of the reference (ovdec.c:188-248, --framethr) for the device path, and the timed region of bench.py.
+ * Pictures are listed in DECODING order; a free thread of a picture's device takes the next picture of that device, records
+ * it (OVHIP_STREAM_RECORD: replay of its call log into the thread's own job, as a parse thread would) or takes its
+ * pre-recorded job, waits for its reference pictures (DPB), submits, publishes.  A picture is released from the DPB when the
+ * last picture that lists it and the output thread are done with it.
+ * ---------------------------------------------------------------------------------- */
+#define OVHIP_STREAM_MAX_REFS 8
+typedef struct ovhip_stream_content {      /* one recorded picture, shared by every stream picture that shows it */
+    const void *calllog; size_t calllog_bytes;        /* OVHIP_STREAM_RECORD                                         */
+    ovhip_job_params params;                          /* picture-level tables (host pointers, stay valid)            */
+    uint32_t n_ref_slots;                             /* size of the reference table its units index (ref0 / ref1)    */
+} ovhip_stream_content;
+
+typedef struct ovhip_stream_pic {
+    uint32_t content;                      /* index into contents[]                                                 */
+    uint32_t job;                          /* pre-recorded mode: index into jobs[] (a job is in flight once at a time) */
+    int32_t  poc;                          /* output order                                                          */
+    uint16_t device;                       /* logical device it is decoded on                                       */
+    uint16_t n_refs;
+    uint32_t refs[OVHIP_STREAM_MAX_REFS];  /* indices (decoding order, < own) of its reference pictures: table slot k = refs[k % n_refs] */
+    int32_t  owner;                        /* rank that decodes it (multi-process); != rank: arrives through xfer.recv   */
+    uint32_t send_mask;                    /* ranks (bit r) it is sent to after decoding                            */
+} ovhip_stream_pic;
+
+typedef struct ovhip_stream_xfer {         /* multi-process exchange (one process per GPU): callbacks of the host harness */
+    void *user;
+    int (*send)(void *user, uint32_t idx, const ovhip_pic *pic, int dst_rank);     /* returns when the buffer may be reused */
+    int (*recv)(void *user, uint32_t idx, const ovhip_pic *pic, int src_rank);     /* returns when the data is in place     */
+} ovhip_stream_xfer;
+
+enum { OVHIP_STREAM_RECORD = 1,            /* record every picture from its call log inside the run (else: pre-recorded jobs) */
+       OVHIP_STREAM_DIGESTS = 2,           /* per-picture ovhip_pic_digest into result digests (16 bytes per picture)        */
+       OVHIP_STREAM_RESIDENT = 4,          /* measurement: flushes replay the device copies (OVHIP_STAGE_RESIDENT)           */
+       OVHIP_STREAM_KEEP = 8,              /* do not release pictures at the end of the run (the next run continues the stream) */
+       OVHIP_STREAM_HOLD_ALL = 32,         /* (with OVHIP_STREAM_KEEP, given to the run that starts the stream) no picture is released before the
+                                            * stream ends: every picture stays readable through ovhip_stream_key (tests)           */
+       OVHIP_STREAM_FILE_MD5 = 16 };       /* OVHIP_OUT_PACKED: also hash the frames on the host (MD5 runs at ~0.6 GB/s per core: 40 ms per 4K
+                                            * frame -- for conformance checks, not for throughput runs)                          */
+
+typedef struct ovhip_stream_cfg {
+    int32_t w, h;
+    uint32_t flags;                        /* OVHIP_STREAM_*                                                         */
+    int32_t threads_per_device;            /* frame threads (= pictures in flight) per logical device               */
+    int32_t output;                        /* OVHIP_OUT_NONE / _DIGEST / _PACKED: an output thread takes the pictures in POC order */
+    ovhip_window window;
+    uint32_t extra_stages;                 /* OR-ed into every flush's stage mask (OVHIP_STAGE_INTRA_LEVELS ...)     */
+    int32_t rank;                          /* this process's rank (pictures with owner != rank are received)         */
+    const ovhip_stream_xfer *xfer;         /* NULL: single process                                                   */
+} ovhip_stream_cfg;
+
+typedef struct ovhip_stream_result {
+    double   seconds;                      /* first picture taken .. last picture published and devices idle        */
+    uint64_t n_decoded, n_second_passes, n_received, n_sent;
+    uint64_t out_frames, out_bytes;
+    uint8_t  out_md5[16];                  /* OVHIP_OUT_PACKED + OVHIP_STREAM_FILE_MD5: MD5 of the concatenated frames in output order
+                                            * = md5sum of the file dectest would write (CI/checkMD5.sh); OVHIP_OUT_DIGEST: MD5
+                                            * over the pictures' digests (a private fingerprint)                            */
+    double   record_seconds;               /* OVHIP_STREAM_RECORD: time spent replaying call logs, summed over threads */
+    int32_t  status;                       /* 0 or the first error                                                   */
+    char     error[192];
+} ovhip_stream_result;
+
+typedef struct ovhip_stream ovhip_stream;
+/* jobs: pre-recorded pictures (n_jobs may be 0 with OVHIP_STREAM_RECORD in every run).  The DPB, contents, jobs stay the
+ * caller's.  Creates threads_per_device frames per device. */
+int  ovhip_stream_create(ovhip_stream **out, ovhip_dpb *dpb, const ovhip_stream_cfg *cfg, const ovhip_stream_content *contents,
+                         uint32_t n_contents, ovhip_job *const *jobs, uint32_t n_jobs);
+void ovhip_stream_destroy(ovhip_stream *s);
+/* Decodes pics[first .. first + n) of the stream pics[0 .. n_total) (indices and refs are positions in `pics`).  A call with
+ * the same pics / n_total and first != 0 CONTINUES the stream of the previous call (which must have run with OVHIP_STREAM_KEEP:
+ * its pictures are still in the DPB); anything else starts a new stream.  digests: n * 16 bytes or NULL.  flags: OVHIP_STREAM_*
+ * of this run, OR-ed with the configuration's. */
+int  ovhip_stream_run(ovhip_stream *s, const ovhip_stream_pic *pics, uint32_t n_total, uint32_t first, uint32_t n, uint32_t flags,
+                      uint8_t *digests, ovhip_stream_result *res);
+ovhip_frame *ovhip_stream_frame(ovhip_stream *s, int dev, int thread);
+/* The DPB key of picture idx of the current stream (valid while the run that decoded it kept it: OVHIP_STREAM_KEEP). */
+const void *ovhip_stream_key(const ovhip_stream *s, uint32_t idx);
+/* test hook: the next flush of `job` that has a flow launch is ABORTED for real (the device's abort word is set before the
+ * launch, so the first pass leaves the picture incomplete) -- ovhip_job_wait must then produce the picture with its second pass */
+int  ovhip_job_test_abort_next_flow(ovhip_job *job);
 
 #ifdef __cplusplus
 }

@@ -17,8 +17,8 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libovvc_hip.so"
 
 # ---- constants (include/ovvc_hip.h) ----
-OVHIP_ABI_VERSION = 5
-OVHIP_OK, OVHIP_ENODEV, OVHIP_ENOMEM, OVHIP_EINVAL, OVHIP_ELAUNCH, OVHIP_EUNSUP = 0, -1, -2, -3, -4, -5
+OVHIP_ABI_VERSION = 6
+OVHIP_OK, OVHIP_ENODEV, OVHIP_ENOMEM, OVHIP_EINVAL, OVHIP_ELAUNCH, OVHIP_EUNSUP, OVHIP_EREF = 0, -1, -2, -3, -4, -5, -6
 DST_VII, DCT_VIII, DCT_II = 0, 1, 2
 TB_TR, TB_DC, TB_TS, TB_TS_RAW = 0, 1, 2, 3
 TB_FLAG_RASTER = 0x80
@@ -266,6 +266,66 @@ class Window(C.Structure):
     _fields_ = [("offset_lft", C.c_uint16), ("offset_rgt", C.c_uint16), ("offset_abv", C.c_uint16), ("offset_blw", C.c_uint16)]
 
 
+# ---- frame threads, device DPB, stream driver (include/ovvc_hip.h) ----
+DPB_PIC_ALLOC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int32, C.c_int32, C.POINTER(Pic))
+DPB_PIC_FREE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(Pic))
+DPB_COPY_START_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(Pic), C.c_int, C.POINTER(Pic), C.POINTER(C.c_void_p))
+DPB_COPY_WAIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)
+DPB_COPY_DONE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p)
+DPB_PIC_CLEAR_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(Pic))
+
+
+class DpbOps(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("pic_alloc", DPB_PIC_ALLOC_FN), ("pic_free", DPB_PIC_FREE_FN),
+                ("copy_start", DPB_COPY_START_FN), ("copy_wait", DPB_COPY_WAIT_FN), ("copy_done", DPB_COPY_DONE_FN),
+                ("pic_clear", DPB_PIC_CLEAR_FN)]
+
+
+class DpbStats(C.Structure):
+    _fields_ = [("n_live", C.c_uint32), ("n_pool", C.c_uint32), ("n_begin", C.c_uint64), ("n_alloc", C.c_uint64),
+                ("n_recycled", C.c_uint64), ("n_copies", C.c_uint64), ("copy_bytes", C.c_uint64), ("n_failed", C.c_uint64),
+                ("n_waits", C.c_uint64)]
+
+
+OUT_NONE, OUT_DIGEST, OUT_PLANES, OUT_PACKED = 0, 1, 2, 3
+
+
+class FrameOutput(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("window", Window), ("y", C.c_void_p), ("cb", C.c_void_p), ("cr", C.c_void_p),
+                ("stride_y", C.c_int32), ("stride_c", C.c_int32), ("packed", C.c_void_p), ("digest", C.c_uint8 * 16)]
+
+
+STREAM_MAX_REFS = 8
+STREAM_RECORD, STREAM_DIGESTS, STREAM_RESIDENT, STREAM_KEEP, STREAM_FILE_MD5, STREAM_HOLD_ALL = 1, 2, 4, 8, 16, 32
+
+
+class StreamContent(C.Structure):
+    _fields_ = [("calllog", C.c_void_p), ("calllog_bytes", C.c_size_t), ("params", JobParams), ("n_ref_slots", C.c_uint32)]
+
+
+class StreamPic(C.Structure):
+    _fields_ = [("content", C.c_uint32), ("job", C.c_uint32), ("poc", C.c_int32), ("device", C.c_uint16), ("n_refs", C.c_uint16),
+                ("refs", C.c_uint32 * STREAM_MAX_REFS), ("owner", C.c_int32), ("send_mask", C.c_uint32)]
+
+
+XFER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.POINTER(Pic), C.c_int)
+
+
+class StreamXfer(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("send", XFER_FN), ("recv", XFER_FN)]
+
+
+class StreamCfg(C.Structure):
+    _fields_ = [("w", C.c_int32), ("h", C.c_int32), ("flags", C.c_uint32), ("threads_per_device", C.c_int32), ("output", C.c_int32),
+                ("window", Window), ("extra_stages", C.c_uint32), ("rank", C.c_int32), ("xfer", C.POINTER(StreamXfer))]
+
+
+class StreamResult(C.Structure):
+    _fields_ = [("seconds", C.c_double), ("n_decoded", C.c_uint64), ("n_second_passes", C.c_uint64), ("n_received", C.c_uint64),
+                ("n_sent", C.c_uint64), ("out_frames", C.c_uint64), ("out_bytes", C.c_uint64), ("out_md5", C.c_uint8 * 16),
+                ("record_seconds", C.c_double), ("status", C.c_int32), ("error", C.c_char * 192)]
+
+
 class Md5State(C.Structure):
     _fields_ = [("h", C.c_uint32 * 4), ("n_bytes", C.c_uint64), ("buf", C.c_uint8 * 64)]
 
@@ -402,6 +462,47 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_md5_init": (None, [P(Md5State)]),
         "ovhip_md5_update": (None, [P(Md5State), vp, C.c_size_t]),
         "ovhip_md5_final": (None, [P(Md5State), vp]),
+        "ovhip_host_alloc": (vp, [C.c_size_t]),
+        "ovhip_host_free": (None, [vp]),
+        "ovhip_job_test_abort_next_flow": (C.c_int, [vp]),
+        "ovhip_dpb_create": (C.c_int, [P(vp), P(C.c_int), C.c_int]),
+        "ovhip_dpb_create_ex": (C.c_int, [P(vp), C.c_int, P(DpbOps)]),
+        "ovhip_dpb_destroy": (None, [vp]),
+        "ovhip_dpb_n_devices": (C.c_int, [vp]),
+        "ovhip_dpb_device": (C.c_int, [vp, C.c_int]),
+        "ovhip_dpb_begin": (C.c_int, [vp, vp, C.c_int, i32, i32, P(Pic)]),
+        "ovhip_dpb_want": (C.c_int, [vp, vp, C.c_int]),
+        "ovhip_dpb_publish": (C.c_int, [vp, vp, C.c_int]),
+        "ovhip_dpb_acquire": (C.c_int, [vp, vp, C.c_int, P(Pic), P(vp)]),
+        "ovhip_dpb_wait_copy": (C.c_int, [vp, C.c_int, vp]),
+        "ovhip_dpb_unpin": (C.c_int, [vp, vp]),
+        "ovhip_dpb_release": (C.c_int, [vp, vp]),
+        "ovhip_dpb_lookup": (C.c_int, [vp, vp, P(C.c_int), P(Pic)]),
+        "ovhip_dpb_shutdown": (None, [vp]),
+        "ovhip_dpb_get_stats": (C.c_int, [vp, P(DpbStats)]),
+        "ovhip_frame_create": (C.c_int, [vp, C.c_int, i32, i32, P(vp)]),
+        "ovhip_frame_destroy": (None, [vp]),
+        "ovhip_frame_ctx": (vp, [vp]),
+        "ovhip_frame_job": (vp, [vp]),
+        "ovhip_frame_recorder": (vp, [vp]),
+        "ovhip_frame_begin": (C.c_int, [vp, vp]),
+        "ovhip_frame_ref": (C.c_int, [vp, vp]),
+        "ovhip_frame_ref_at": (C.c_int, [vp, C.c_int, vp]),
+        "ovhip_frame_dmvr_rows": (C.c_int64, [vp]),
+        "ovhip_frame_submit": (C.c_int, [vp, vp, P(Pic), P(JobParams), P(FrameOutput)]),
+        "ovhip_frame_fail": (C.c_int, [vp, C.c_int]),
+        "ovhip_frame_last_error": (C.c_char_p, [vp]),
+        "ovhip_calllog_create": (vp, []),
+        "ovhip_calllog_destroy": (None, [vp]),
+        "ovhip_calllog_reset": (None, [vp]),
+        "ovhip_calllog_data": (vp, [vp, P(C.c_size_t)]),
+        "ovhip_rec_set_calllog": (None, [vp, vp]),
+        "ovhip_calllog_replay": (C.c_int64, [vp, C.c_size_t, vp]),
+        "ovhip_stream_create": (C.c_int, [P(vp), vp, P(StreamCfg), P(StreamContent), u32, P(vp), u32]),
+        "ovhip_stream_destroy": (None, [vp]),
+        "ovhip_stream_run": (C.c_int, [vp, P(StreamPic), u32, u32, u32, u32, vp, P(StreamResult)]),
+        "ovhip_stream_frame": (vp, [vp, C.c_int, C.c_int]),
+        "ovhip_stream_key": (vp, [vp, u32]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)          # AttributeError = missing export: fail loudly
@@ -425,6 +526,14 @@ EXPORTED_SYMBOLS = [
     "ovhip_job_flush", "ovhip_job_wait", "ovhip_job_refined_mvs", "ovhip_job_dmvr_rows", "ovhip_job_last_stats", "ovhip_job_time_stage", "ovhip_job_stage_time",
     "ovhip_output_bytes", "ovhip_output_rows", "ovhip_output_pack_launch", "ovhip_output_row_md5_launch", "ovhip_pic_output", "ovhip_pic_digest",
     "ovhip_md5_init", "ovhip_md5_update", "ovhip_md5_final", "ovhip_tmvp_cells_launch", "ovhip_job_tmvp_cells", "ovhip_intra_flow_untag_launch", "ovhip_lmcs_inverse_untag_launch", "ovhip_lmcs_scale_prepare_launch",
+    "ovhip_host_alloc", "ovhip_host_free", "ovhip_job_test_abort_next_flow",
+    "ovhip_dpb_create", "ovhip_dpb_create_ex", "ovhip_dpb_destroy", "ovhip_dpb_n_devices", "ovhip_dpb_device", "ovhip_dpb_begin", "ovhip_dpb_want",
+    "ovhip_dpb_publish", "ovhip_dpb_acquire", "ovhip_dpb_wait_copy", "ovhip_dpb_unpin", "ovhip_dpb_release", "ovhip_dpb_lookup", "ovhip_dpb_shutdown",
+    "ovhip_dpb_get_stats",
+    "ovhip_frame_create", "ovhip_frame_destroy", "ovhip_frame_ctx", "ovhip_frame_job", "ovhip_frame_recorder", "ovhip_frame_begin", "ovhip_frame_ref",
+    "ovhip_frame_ref_at", "ovhip_frame_dmvr_rows", "ovhip_frame_submit", "ovhip_frame_fail", "ovhip_frame_last_error",
+    "ovhip_calllog_create", "ovhip_calllog_destroy", "ovhip_calllog_reset", "ovhip_calllog_data", "ovhip_rec_set_calllog", "ovhip_calllog_replay",
+    "ovhip_stream_create", "ovhip_stream_destroy", "ovhip_stream_run", "ovhip_stream_frame", "ovhip_stream_key",
 ]
 
 
@@ -451,6 +560,28 @@ class Recorder:
 
     def reset(self):
         self.lib.ovhip_rec_reset(self.h)
+
+    def start_calllog(self):
+        """Every recorder call from now on is also serialised (ovhip_rec_set_calllog); take_calllog() returns the bytes."""
+        self._log = self.lib.ovhip_calllog_create()
+        self.lib.ovhip_rec_set_calllog(self.h, self._log)
+
+    def take_calllog(self) -> np.ndarray:
+        n = C.c_size_t()
+        p = self.lib.ovhip_calllog_data(self._log, C.byref(n))
+        if not p and n.value:
+            raise MemoryError("call log")
+        out = np.frombuffer((C.c_char * n.value).from_address(p), dtype=np.uint8).copy() if n.value else np.zeros(0, np.uint8)
+        self.lib.ovhip_rec_set_calllog(self.h, None)
+        self.lib.ovhip_calllog_destroy(self._log)
+        self._log = None
+        return out
+
+    def replay(self, log: np.ndarray) -> int:
+        n = self.lib.ovhip_calllog_replay(log.ctypes.data, log.nbytes, self.h)
+        if n < 0:
+            raise ValueError(f"ovhip_calllog_replay -> {n}")
+        return int(n)
 
     def tu(self, st: TuState, d: TuDesc) -> int:
         r = self.lib.ovhip_rec_tu(self.h, C.byref(st), C.byref(d))

@@ -174,12 +174,12 @@ extern "C" int ovhip_pic_output(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhi
     OV_DEVICE(ctx);
     const size_t bytes = ovhip_output_bytes(pic->w, pic->h, win);
     if (!bytes) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_pic_output: bad picture / window", hipSuccess);
-    uint16_t *d = nullptr;
-    OV_HIP(ctx, hipMalloc((void **)&d, bytes));
-    int r = ovhip_output_pack_launch(ctx, pic, win, d);
+    int r = ov_scratch(ctx, bytes, 0);
+    if (r) return r;
+    uint16_t *d = (uint16_t *)ctx->scratch_d;
+    r = ovhip_output_pack_launch(ctx, pic, win, d);
     if (!r && hipMemcpyAsync(host_dst, d, bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) r = ov_fail(ctx, OVHIP_ENODEV, "ovhip_pic_output: D2H", hipGetLastError());
     if (!r && hipStreamSynchronize(ctx->stream) != hipSuccess) r = ov_fail(ctx, OVHIP_ELAUNCH, "ovhip_pic_output", hipGetLastError());
-    (void)hipFree(d);
     return r;
 }
 
@@ -189,13 +189,12 @@ extern "C" int ovhip_pic_digest(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhi
     OV_DEVICE(ctx);
     const size_t rows = ovhip_output_rows(pic->w, pic->h, win);
     if (!rows) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_pic_digest: bad picture / window", hipSuccess);
-    uint8_t *d = nullptr, *hbuf = (uint8_t *)malloc(rows * 16);
-    if (!hbuf) return ov_fail(ctx, OVHIP_ENOMEM, "ovhip_pic_digest", hipSuccess);
-    if (hipMalloc((void **)&d, rows * 16) != hipSuccess) { free(hbuf); return ov_fail(ctx, OVHIP_ENOMEM, "ovhip_pic_digest", hipGetLastError()); }
-    int r = ovhip_output_row_md5_launch(ctx, pic, win, d);
+    int r = ov_scratch(ctx, rows * 16, rows * 16);
+    if (r) return r;
+    uint8_t *d = (uint8_t *)ctx->scratch_d, *hbuf = (uint8_t *)ctx->scratch_h;
+    r = ovhip_output_row_md5_launch(ctx, pic, win, d);
     if (!r && hipMemcpyAsync(hbuf, d, rows * 16, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) r = ov_fail(ctx, OVHIP_ENODEV, "ovhip_pic_digest: D2H", hipGetLastError());
     if (!r && hipStreamSynchronize(ctx->stream) != hipSuccess) r = ov_fail(ctx, OVHIP_ELAUNCH, "ovhip_pic_digest", hipGetLastError());
     if (!r) { ovhip_md5_state st; ovhip_md5_init(&st); ovhip_md5_update(&st, hbuf, rows * 16); ovhip_md5_final(&st, out); }
-    (void)hipFree(d); free(hbuf);
     return r;
 }

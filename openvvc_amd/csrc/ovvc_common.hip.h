@@ -25,6 +25,10 @@ struct ovhip_ctx {
     hipEvent_t ev_fork, ev_lane[OV_MAX_LANES];
     int lane_used[OV_MAX_LANES];
     int have_events;
+    // grow-only scratch of the synchronous conveniences (ovhip_pic_output / _digest): a hipMalloc + hipFree pair per call would
+    // synchronise the whole device every time a picture is output
+    void *scratch_d; size_t scratch_d_cap;
+    void *scratch_h; size_t scratch_h_cap;       // page-locked
     char err[256];
 };
 
@@ -48,6 +52,25 @@ static inline int ov_fail(ovhip_ctx *ctx, int code, const char *what, hipError_t
         hipError_t e__ = hipSetDevice((ctx)->device);                         \
         if (e__ != hipSuccess) return ov_fail((ctx), OVHIP_ENODEV, "hipSetDevice", e__); \
     } while (0)
+
+static inline int ov_scratch(ovhip_ctx *ctx, size_t dev_bytes, size_t host_bytes)
+{
+    if (dev_bytes > ctx->scratch_d_cap) {
+        if (ctx->scratch_d) (void)hipFree(ctx->scratch_d);
+        ctx->scratch_d = nullptr; ctx->scratch_d_cap = 0;
+        hipError_t e = hipMalloc(&ctx->scratch_d, dev_bytes);
+        if (e != hipSuccess) return ov_fail(ctx, OVHIP_ENOMEM, "hipMalloc(scratch)", e);
+        ctx->scratch_d_cap = dev_bytes;
+    }
+    if (host_bytes > ctx->scratch_h_cap) {
+        if (ctx->scratch_h) (void)hipHostFree(ctx->scratch_h);
+        ctx->scratch_h = nullptr; ctx->scratch_h_cap = 0;
+        hipError_t e = hipHostMalloc(&ctx->scratch_h, host_bytes, hipHostMallocDefault);
+        if (e != hipSuccess) return ov_fail(ctx, OVHIP_ENOMEM, "hipHostMalloc(scratch)", e);
+        ctx->scratch_h_cap = host_bytes;
+    }
+    return OVHIP_OK;
+}
 
 #define OV_LAUNCH_CHECK(ctx, name)                                            \
     do {                                                                      \

@@ -1,0 +1,383 @@
+/* ovvc_dpb.c -- device-side mirror of the decoded picture buffer (include/ovvc_hip.h, "Frame threads and the device DPB").
+ *
+ * Plain C + pthreads: the state machine only.  Memory and copies go through ovhip_dpb_ops (HIP back-end: ovvc_dpb_hip.hip), so
+ * the waits, the release / re-use rules and the multi-device bookkeeping are exercised without a GPU (tests/test_dpb_cpu.py).
+ *
+ * What it mirrors in the reference (restated, nothing copied):
+ *   ovdpb_init_picture / ovdpb_unref_pic            libovvc/dpb.c       picture enters / leaves the DPB
+ *   ovdpb_report_decoded_ctu_line                   dpb.c:1309-1323     producer publishes progress (here: once, the whole picture)
+ *   ovdpb_synchro_ref_decoded_ctus                  dpb.c:1242-1270     consumer waits for it (rcn_inter.c:131-146)
+ *   frame pool re-use of an OVFrame                 ovframepool.c       a key may come back for a new picture once unreferenced
+ */
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include "ovvc_hip.h"
+#include "ovvc_dpb_priv.h"
+
+enum { S_FREE = 0, S_DECODING, S_DONE, S_FAILED };
+enum { C_NONE = 0, C_STARTED };
+
+struct dpb_copy { ovhip_pic pic; int state; void *event; };
+
+struct dpb_slot {
+    const void *key;
+    int state, status;
+    int home;
+    int32_t w, h;
+    ovhip_pic pic;
+    int pins, released;
+    uint32_t want;
+    uint64_t serial;
+    struct dpb_copy copy[OVHIP_MAX_DEVICES];
+};
+
+struct pool_ent { ovhip_pic pic; int32_t w, h; };
+
+struct ovhip_dpb {
+    pthread_mutex_t mtx;
+    pthread_cond_t cnd;
+    int n_dev;
+    int hipdev[OVHIP_MAX_DEVICES];
+    ovhip_dpb_ops ops;
+    void *hip_user;                       /* owned HIP back-end state (ovhip_dpb_create), NULL with caller ops */
+    struct dpb_slot *slots; size_t n_slots;
+    struct pool_ent *pool[OVHIP_MAX_DEVICES]; size_t n_pool[OVHIP_MAX_DEVICES], cap_pool[OVHIP_MAX_DEVICES];
+    int shutdown;
+    uint64_t serial;
+    ovhip_dpb_stats st;
+};
+
+/* ---- free pools (per logical device; same-size pictures are re-used, others are freed when they get in the way) ---- */
+static int
+pool_push(ovhip_dpb *d, int dev, const ovhip_pic *pic, int32_t w, int32_t h)
+{
+    if (d->n_pool[dev] == d->cap_pool[dev]) {
+        size_t nc = d->cap_pool[dev] ? 2 * d->cap_pool[dev] : 16;
+        struct pool_ent *q = (struct pool_ent *)realloc(d->pool[dev], nc * sizeof(*q));
+        if (!q) { ovhip_pic tmp = *pic; d->ops.pic_free(d->ops.user, dev, &tmp); return OVHIP_ENOMEM; }
+        d->pool[dev] = q; d->cap_pool[dev] = nc;
+    }
+    struct pool_ent *e = &d->pool[dev][d->n_pool[dev]++];
+    e->pic = *pic; e->w = w; e->h = h;
+    d->st.n_pool++;
+    return OVHIP_OK;
+}
+
+static int
+pool_pop(ovhip_dpb *d, int dev, int32_t w, int32_t h, ovhip_pic *pic)
+{
+    for (size_t i = d->n_pool[dev]; i-- > 0;) {
+        struct pool_ent *e = &d->pool[dev][i];
+        if (e->w == w && e->h == h) {
+            *pic = e->pic;
+            *e = d->pool[dev][--d->n_pool[dev]];
+            d->st.n_pool--; d->st.n_recycled++;
+            return OVHIP_OK;
+        }
+    }
+    /* a resolution change: pictures of the old size only hold memory */
+    while (d->n_pool[dev]) {
+        struct pool_ent *e = &d->pool[dev][--d->n_pool[dev]];
+        d->ops.pic_free(d->ops.user, dev, &e->pic);
+        d->st.n_pool--;
+    }
+    int r = d->ops.pic_alloc(d->ops.user, dev, w, h, pic);
+    if (r == OVHIP_OK) d->st.n_alloc++;
+    return r;
+}
+
+static struct dpb_slot *
+find(ovhip_dpb *d, const void *key)
+{
+    for (size_t i = 0; i < d->n_slots; ++i)
+        if (d->slots[i].state != S_FREE && d->slots[i].key == key) return &d->slots[i];
+    return NULL;
+}
+
+/* the slot's pictures go back to the pools (mutex held; nobody has it pinned) */
+static void
+reclaim(ovhip_dpb *d, struct dpb_slot *s)
+{
+    if (s->state == S_FAILED || s->state == S_DECODING) {
+        /* an incomplete decode may have left hand-over bits in the samples (ovhip_intra_flow_untag_launch) */
+        if (d->ops.pic_clear) (void)d->ops.pic_clear(d->ops.user, s->home, &s->pic);
+    }
+    (void)pool_push(d, s->home, &s->pic, s->w, s->h);
+    d->st.n_live--;
+    for (int k = 0; k < d->n_dev; ++k) {
+        struct dpb_copy *c = &s->copy[k];
+        if (c->state == C_NONE) continue;
+        if (c->event) {
+            (void)d->ops.copy_wait(d->ops.user, k, c->event);          /* a copy nobody waited for may still be running */
+            if (d->ops.copy_done) d->ops.copy_done(d->ops.user, k, c->event);
+        }
+        (void)pool_push(d, k, &c->pic, s->w, s->h);
+        d->st.n_live--;
+        c->state = C_NONE; c->event = NULL;
+    }
+    s->state = S_FREE; s->key = NULL; s->pins = 0; s->released = 0; s->want = 0;
+}
+
+/* DONE picture -> device k (mutex held) */
+static int
+start_copy(ovhip_dpb *d, struct dpb_slot *s, int k)
+{
+    struct dpb_copy *c = &s->copy[k];
+    if (k == s->home || c->state != C_NONE) return OVHIP_OK;
+    int r = pool_pop(d, k, s->w, s->h, &c->pic);
+    if (r != OVHIP_OK) return r;
+    c->event = NULL;
+    r = d->ops.copy_start(d->ops.user, k, &c->pic, s->home, &s->pic, &c->event);
+    if (r != OVHIP_OK) { (void)pool_push(d, k, &c->pic, s->w, s->h); return r; }
+    c->state = C_STARTED;
+    d->st.n_live++; d->st.n_copies++;
+    d->st.copy_bytes += (uint64_t)s->w * s->h * 3;
+    return OVHIP_OK;
+}
+
+int
+ovhip_dpb_create_ex(ovhip_dpb **out, int n_devices, const ovhip_dpb_ops *ops)
+{
+    if (!out || !ops || n_devices < 1 || n_devices > OVHIP_MAX_DEVICES || !ops->pic_alloc || !ops->pic_free || !ops->copy_start || !ops->copy_wait)
+        return OVHIP_EINVAL;
+    *out = NULL;
+    ovhip_dpb *d = (ovhip_dpb *)calloc(1, sizeof(*d));
+    if (!d) return OVHIP_ENOMEM;
+    pthread_mutex_init(&d->mtx, NULL);
+    pthread_cond_init(&d->cnd, NULL);
+    d->n_dev = n_devices; d->ops = *ops;
+    for (int i = 0; i < OVHIP_MAX_DEVICES; ++i) d->hipdev[i] = -1;
+    *out = d;
+    return OVHIP_OK;
+}
+
+int
+ovhip_dpb_create(ovhip_dpb **out, const int *devices, int n_devices)
+{
+    if (!out || !devices || n_devices < 1 || n_devices > OVHIP_MAX_DEVICES) return OVHIP_EINVAL;
+    ovhip_dpb_ops ops;
+    void *user = NULL;
+    int r = ovhip_dpb_hip_ops_(devices, n_devices, &ops, &user);
+    if (r != OVHIP_OK) return r;
+    r = ovhip_dpb_create_ex(out, n_devices, &ops);
+    if (r != OVHIP_OK) { ovhip_dpb_hip_ops_free_(user); return r; }
+    (*out)->hip_user = user;
+    for (int i = 0; i < n_devices; ++i) (*out)->hipdev[i] = devices[i];
+    return OVHIP_OK;
+}
+
+void
+ovhip_dpb_destroy(ovhip_dpb *d)
+{
+    if (!d) return;
+    pthread_mutex_lock(&d->mtx);
+    for (size_t i = 0; i < d->n_slots; ++i)
+        if (d->slots[i].state != S_FREE) { d->slots[i].pins = 0; reclaim(d, &d->slots[i]); }
+    for (int k = 0; k < d->n_dev; ++k) {
+        for (size_t i = 0; i < d->n_pool[k]; ++i) d->ops.pic_free(d->ops.user, k, &d->pool[k][i].pic);
+        free(d->pool[k]);
+    }
+    pthread_mutex_unlock(&d->mtx);
+    free(d->slots);
+    if (d->hip_user) ovhip_dpb_hip_ops_free_(d->hip_user);
+    pthread_cond_destroy(&d->cnd);
+    pthread_mutex_destroy(&d->mtx);
+    free(d);
+}
+
+int ovhip_dpb_n_devices(const ovhip_dpb *d) { return d ? d->n_dev : 0; }
+int ovhip_dpb_device(const ovhip_dpb *d, int dev) { return d && dev >= 0 && dev < d->n_dev ? d->hipdev[dev] : -1; }
+
+int
+ovhip_dpb_begin(ovhip_dpb *d, const void *key, int dev, int32_t w, int32_t h, ovhip_pic *pic)
+{
+    if (!d || !key || !pic || dev < 0 || dev >= d->n_dev || w <= 0 || h <= 0) return OVHIP_EINVAL;
+    int r = OVHIP_OK;
+    pthread_mutex_lock(&d->mtx);
+    struct dpb_slot *s = find(d, key);
+    if (s) {
+        /* the key comes back for a new picture: the host DPB re-uses a frame only once it is unreferenced */
+        if (s->pins) { pthread_mutex_unlock(&d->mtx); return OVHIP_EINVAL; }
+        reclaim(d, s);
+    } else {
+        for (size_t i = 0; i < d->n_slots && !s; ++i) if (d->slots[i].state == S_FREE) s = &d->slots[i];
+        if (!s) {
+            const size_t nc = d->n_slots ? 2 * d->n_slots : 32;
+            struct dpb_slot *q = (struct dpb_slot *)realloc(d->slots, nc * sizeof(*q));
+            if (!q) { pthread_mutex_unlock(&d->mtx); return OVHIP_ENOMEM; }
+            memset(q + d->n_slots, 0, (nc - d->n_slots) * sizeof(*q));
+            d->slots = q; s = &q[d->n_slots]; d->n_slots = nc;
+        }
+    }
+    memset(s, 0, sizeof(*s));
+    r = pool_pop(d, dev, w, h, &s->pic);
+    if (r == OVHIP_OK) {
+        s->key = key; s->state = S_DECODING; s->home = dev; s->w = w; s->h = h; s->serial = ++d->serial;
+        *pic = s->pic;
+        d->st.n_live++; d->st.n_begin++;
+    }
+    pthread_mutex_unlock(&d->mtx);
+    return r;
+}
+
+int
+ovhip_dpb_want(ovhip_dpb *d, const void *key, int dev)
+{
+    if (!d || !key || dev < 0 || dev >= d->n_dev) return OVHIP_EINVAL;
+    int r = OVHIP_OK;
+    pthread_mutex_lock(&d->mtx);
+    struct dpb_slot *s = find(d, key);
+    if (!s) r = OVHIP_EINVAL;
+    else if (dev != s->home) {
+        s->want |= 1u << dev;
+        if (s->state == S_DONE) r = start_copy(d, s, dev);
+    }
+    pthread_mutex_unlock(&d->mtx);
+    return r;
+}
+
+int
+ovhip_dpb_publish(ovhip_dpb *d, const void *key, int status)
+{
+    if (!d || !key) return OVHIP_EINVAL;
+    int r = OVHIP_OK;
+    pthread_mutex_lock(&d->mtx);
+    struct dpb_slot *s = find(d, key);
+    if (!s || s->state != S_DECODING) r = OVHIP_EINVAL;
+    else {
+        s->state = status ? S_FAILED : S_DONE;
+        s->status = status;
+        if (status) d->st.n_failed++;
+        /* push: exactly the devices whose queued pictures list this one */
+        for (int k = 0; k < d->n_dev && !status; ++k)
+            if ((s->want >> k) & 1) { int q = start_copy(d, s, k); if (q != OVHIP_OK && r == OVHIP_OK) r = q; }
+        if (s->released && !s->pins) reclaim(d, s);
+    }
+    pthread_cond_broadcast(&d->cnd);
+    pthread_mutex_unlock(&d->mtx);
+    return r;
+}
+
+int
+ovhip_dpb_acquire(ovhip_dpb *d, const void *key, int dev, ovhip_pic *pic, void **event)
+{
+    if (!d || !key || !pic || dev < 0 || dev >= d->n_dev) return OVHIP_EINVAL;
+    if (event) *event = NULL;
+    int r = OVHIP_OK;
+    pthread_mutex_lock(&d->mtx);
+    struct dpb_slot *s = find(d, key);
+    if (!s) { pthread_mutex_unlock(&d->mtx); return OVHIP_EINVAL; }
+    const uint64_t serial = s->serial;
+    int waited = 0;
+    while (s && s->serial == serial && s->state == S_DECODING && !d->shutdown) {
+        waited = 1;
+        pthread_cond_wait(&d->cnd, &d->mtx);
+        s = find(d, key);                                   /* the slot array may have moved */
+    }
+    d->st.n_waits += waited;
+    if (!s || s->serial != serial || d->shutdown || s->state != S_DONE) r = OVHIP_EREF;
+    else if (dev == s->home) { *pic = s->pic; s->pins++; }
+    else {
+        r = start_copy(d, s, dev);
+        if (r == OVHIP_OK) {
+            if (!event && s->copy[dev].event) {
+                /* a caller without a place for the handle waits right here */
+                void *ev = s->copy[dev].event;
+                s->pins++;
+                pthread_mutex_unlock(&d->mtx);
+                r = d->ops.copy_wait(d->ops.user, dev, ev);
+                pthread_mutex_lock(&d->mtx);
+                s = find(d, key);
+                if (s && s->serial == serial) { if (r != OVHIP_OK) s->pins--; else *pic = s->copy[dev].pic; }
+                pthread_mutex_unlock(&d->mtx);
+                return r;
+            }
+            *pic = s->copy[dev].pic;
+            if (event) *event = s->copy[dev].event;
+            s->pins++;
+        }
+    }
+    pthread_mutex_unlock(&d->mtx);
+    return r;
+}
+
+int
+ovhip_dpb_wait_copy(ovhip_dpb *d, int dev, void *event)
+{
+    if (!d || dev < 0 || dev >= d->n_dev) return OVHIP_EINVAL;
+    return event ? d->ops.copy_wait(d->ops.user, dev, event) : OVHIP_OK;
+}
+
+int
+ovhip_dpb_unpin(ovhip_dpb *d, const void *key)
+{
+    if (!d || !key) return OVHIP_EINVAL;
+    int r = OVHIP_OK;
+    pthread_mutex_lock(&d->mtx);
+    struct dpb_slot *s = find(d, key);
+    if (!s || s->pins <= 0) r = OVHIP_EINVAL;
+    else if (--s->pins == 0 && s->released && s->state != S_DECODING) reclaim(d, s);
+    pthread_mutex_unlock(&d->mtx);
+    return r;
+}
+
+int
+ovhip_dpb_release(ovhip_dpb *d, const void *key)
+{
+    if (!d || !key) return OVHIP_EINVAL;
+    int r = OVHIP_OK;
+    pthread_mutex_lock(&d->mtx);
+    struct dpb_slot *s = find(d, key);
+    if (!s) r = OVHIP_EINVAL;
+    else {
+        s->released = 1;
+        /* a picture still being decoded is reclaimed by its publish, a pinned one by its last unpin */
+        if (!s->pins && s->state != S_DECODING) reclaim(d, s);
+    }
+    pthread_mutex_unlock(&d->mtx);
+    return r;
+}
+
+int
+ovhip_dpb_lookup(ovhip_dpb *d, const void *key, int *home_dev, ovhip_pic *pic)
+{
+    if (!d || !key || !pic) return OVHIP_EINVAL;
+    int r = OVHIP_OK;
+    pthread_mutex_lock(&d->mtx);
+    struct dpb_slot *s = find(d, key);
+    if (!s) r = OVHIP_EINVAL;
+    else if (s->state != S_DONE) r = OVHIP_EREF;
+    else { *pic = s->pic; if (home_dev) *home_dev = s->home; }
+    pthread_mutex_unlock(&d->mtx);
+    return r;
+}
+
+void
+ovhip_dpb_shutdown(ovhip_dpb *d)
+{
+    if (!d) return;
+    pthread_mutex_lock(&d->mtx);
+    d->shutdown = 1;
+    pthread_cond_broadcast(&d->cnd);
+    pthread_mutex_unlock(&d->mtx);
+}
+
+/* the stream driver re-arms a DPB it shut down after a failed run */
+void
+ovhip_dpb_rearm_(ovhip_dpb *d)
+{
+    pthread_mutex_lock(&d->mtx);
+    d->shutdown = 0;
+    pthread_mutex_unlock(&d->mtx);
+}
+
+int
+ovhip_dpb_get_stats(ovhip_dpb *d, ovhip_dpb_stats *out)
+{
+    if (!d || !out) return OVHIP_EINVAL;
+    pthread_mutex_lock(&d->mtx);
+    *out = d->st;
+    pthread_mutex_unlock(&d->mtx);
+    return OVHIP_OK;
+}

@@ -39,6 +39,9 @@ void ovhip_ctx_destroy(ovhip_ctx *ctx)
         if (ctx->have_events) (void)hipEventDestroy(ctx->ev_lane[i]);
     }
     if (ctx->have_events) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->scratch_d || ctx->scratch_h) (void)hipSetDevice(ctx->device);
+    if (ctx->scratch_d) (void)hipFree(ctx->scratch_d);
+    if (ctx->scratch_h) (void)hipHostFree(ctx->scratch_h);
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->main_stream);
     free(ctx);
 }
@@ -132,6 +135,15 @@ int ovhip_d2h(ovhip_ctx *ctx, void *host, const void *dptr, size_t bytes)
     }
     return OVHIP_OK;
 }
+
+/* page-locked host memory for buffers the device reads or writes by DMA (output frames, call logs) */
+void *ovhip_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    return hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+}
+
+void ovhip_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 int ovhip_pic_alloc(ovhip_ctx *ctx, int32_t w, int32_t h, ovhip_pic *pic)
 {

@@ -38,6 +38,7 @@ struct ovhip_job {
     int32_t *mv_host; size_t mv_cap;     // pinned: refined vectors, 4 int32 per refined unit
     struct { int valid, has_intra; ovhip_pic dst, refs[16], intra; uint32_t n_refs; ovhip_job_params pr; } again;   // the last flush's arguments
     uint32_t n_retries;                  // second passes of the last picture (ovhip_job_wait)
+    int test_abort;                      // ovhip_job_test_abort_next_flow
     ovhip_tmvp_cell *tmvp_host; size_t tmvp_cap, n_tmvp;   // pinned: TMVP plane cells of the refined units (ovhip_job_params.tmvp_cells)
     size_t n_mv;                         // units covered by the last flush / eager pass
     size_t dmvr_first;                   // refined units [0, dmvr_first) already went through the eager search
@@ -331,15 +332,26 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
     // what a second flush of the same picture needs (ovhip_job_wait re-runs the picture with one launch per level when the
     // flow launch gave up): the pictures by value, the parameter block as the caller passed it (its tables stay the caller's
     // until ovhip_job_wait has returned)
-    j->again.valid = n_refs <= 16;
+    j->again.valid = 0;
+    j->n_retries = 0;
+    const int r = job_flush_impl(j, dst, refs, n_refs, intra, pr);
+    // (after the flush: a before_launch callback may be what fills refs[] -- ovhip_frame_submit resolves the reference pictures
+    // there, while the uploads already run)
+    j->again.valid = r == OVHIP_OK && n_refs <= 16;
     j->again.dst = *dst;
     for (uint32_t i = 0; i < n_refs && i < 16; ++i) j->again.refs[i] = refs[i];
     j->again.n_refs = n_refs;
     j->again.has_intra = intra != nullptr;
     if (intra) j->again.intra = *intra;
     j->again.pr = *pr;
-    j->n_retries = 0;
-    return job_flush_impl(j, dst, refs, n_refs, intra, pr);
+    return r;
+}
+
+int ovhip_job_test_abort_next_flow(ovhip_job *j)
+{
+    if (!j) return OVHIP_EINVAL;
+    j->test_abort = 1;
+    return OVHIP_OK;
 }
 
 static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs, const ovhip_pic *intra,
@@ -536,8 +548,13 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
             *j->abort_host = 0;
         }
         if (++j->epoch >= 0x7ffffff0u) j->epoch = 1;
-        // test hook: behave as if a workgroup of this picture's flow launch had given up (ovhip_job_wait's second pass)
-        if (getenv("OVHIP_TEST_FORCE_SECOND_PASS") && j->n_retries == 0) *(volatile uint32_t *)j->abort_host = 1;
+        // test hook (ovhip_job_test_abort_next_flow): the abort word is set on the device BEFORE the launch, so every item that has to
+        // wait for another gives up at once -- a real abandoned first pass, picture incomplete and partly tagged
+        if (j->test_abort && j->n_retries == 0) {
+            j->test_abort = 0;
+            OV_HIP(ctx, hipMemsetAsync(j->d_flow, 0xff, sizeof(uint32_t), ctx->stream));
+            *(volatile uint32_t *)j->abort_host = 1;
+        }
     }
     // ---- residual: luma blocks, chroma-scale derivation on the reconstructed luma, chroma blocks (+ inverse mapping) ----
     if (stages & OVHIP_STAGE_ITX) {

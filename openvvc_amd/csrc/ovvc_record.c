@@ -407,6 +407,7 @@ ovhip_rec_isp_cu(ovhip_recorder *r, const ovhip_tu_state *st, const ovhip_isp_de
 {
     if (!r || !st || !cu || cu->log2_cb_w < 2 || cu->log2_cb_w > 6 || cu->log2_cb_h < 2 || cu->log2_cb_h > 6 || cu->log2_cb_w + cu->log2_cb_h < 5)
         return OVHIP_EINVAL;
+    if (r->log) ovhip_calllog_isp_(r->log, st, cu);
     const size_t n0 = r->n_tb, c0 = r->n_coef, t0 = r->n_itask;
     int32_t l2p, n_pb, l2pred, n_pred;
     ovhip_isp_geometry(cu->log2_cb_w, cu->log2_cb_h, cu->vertical, &l2p, &n_pb, &l2pred, &n_pred);
@@ -479,6 +480,7 @@ int
 ovhip_rec_tu_intra(ovhip_recorder *r, const ovhip_tu_state *st, const ovhip_tu_desc *tu, const ovhip_itask *intra_l, const ovhip_itask *intra_c)
 {
     if (!r || !st || !tu) return OVHIP_EINVAL;
+    if (r->log) ovhip_calllog_tu_(r->log, st, tu, intra_l, intra_c);
     const size_t n0 = r->n_tb, c0 = r->n_coef, t0 = r->n_itask;
     int ret;
     ovhip_tb_cmd *c;
@@ -789,6 +791,7 @@ rec_pu_gpm(ovhip_recorder *r, const ovhip_pu_desc *pu)
 int
 ovhip_rec_pu(ovhip_recorder *r, const ovhip_pu_desc *pu)
 {
+    if (r->log) ovhip_calllog_pu_(r->log, pu);
     int pw = 1 << pu->log2_w, ph = 1 << pu->log2_h;
     int dir = pu->inter_dir & 3;
     if (!dir) return OVHIP_EINVAL;
@@ -851,6 +854,7 @@ ovhip_rec_affine_cu(ovhip_recorder *r, const ovhip_affine_desc *cu)
     const int cw = 1 << cu->log2_w, ch = 1 << cu->log2_h;
     int dir = cu->inter_dir & 3;
     if (!dir || cw < 8 || ch < 8 || !cu->mv0 || !cu->mv1 || cu->mv_stride < (cw >> 2)) return OVHIP_EINVAL;
+    if (r->log) ovhip_calllog_affine_(r->log, cu);
     if (dir != 3 && (dir & 2)) dir = 2;
 
     int8_t w0 = 4, w1 = 4;
@@ -929,6 +933,7 @@ int
 ovhip_rec_lmcs_region(ovhip_recorder *r, int32_t x0, int32_t y0, uint32_t abv_mask, uint32_t lft_mask)
 {
     if (x0 < 0 || y0 < 0 || x0 >= r->pic_w || y0 >= r->pic_h || r->n_reg >= 32767) return OVHIP_EINVAL;
+    if (r->log) ovhip_calllog_region_(r->log, x0, y0, abv_mask, lft_mask);
     if (grow((void **)&r->reg, &r->cap_reg, r->n_reg + 1, sizeof(*r->reg))) return OVHIP_ENOMEM;
     ovhip_lmcs_region *g = &r->reg[r->n_reg];
     memset(g, 0, sizeof(*g));
@@ -979,6 +984,7 @@ int
 ovhip_rec_ciip(ovhip_recorder *r, int32_t x0, int32_t y0, int32_t log2_w, int32_t log2_h, int32_t mode_abv, int32_t mode_lft)
 {
     if (x0 < 0 || y0 < 0 || log2_w < 2 || log2_h < 2 || log2_w > 6 || log2_h > 6) return OVHIP_EINVAL;
+    if (r->log) ovhip_calllog_ciip_(r->log, x0, y0, log2_w, log2_h, mode_abv, mode_lft);
     if (grow((void **)&r->ciip, &r->cap_ciip, r->n_ciip + 1, sizeof(*r->ciip))) return OVHIP_ENOMEM;
     ovhip_ciip_unit *u = &r->ciip[r->n_ciip++];
     /* OV_INTRA = 2, OV_MIP = 4 (cu_utils.h:132-139) */

@@ -122,6 +122,7 @@ ovhip_rec_dbf_ctu(ovhip_recorder *r, const ovhip_dbf_ctu *c)
 {
     if (!r || !c) return OVHIP_EINVAL;
     if (c->log2_ctu_s < 5 || c->log2_ctu_s > 7) return OVHIP_EINVAL;
+    if (r->log) ovhip_calllog_dbf_(r->log, c);
     if (dbf_alloc(r)) return OVHIP_ENOMEM;
     const int oi = offset_index(r, c->beta_offset, c->tc_offset);
     if (oi < 0) return OVHIP_EUNSUP;         /* more than OVHIP_DBF_MAX_OFFSETS distinct slice offset pairs */

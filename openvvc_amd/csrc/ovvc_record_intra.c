@@ -169,6 +169,7 @@ int
 ovhip_rec_set_ctu_size(ovhip_recorder *r, int32_t log2_ctu_s)
 {
     if (!r || log2_ctu_s < 5 || log2_ctu_s > 7) return OVHIP_EINVAL;
+    if (r->log) ovhip_calllog_ctu_size_(r->log, log2_ctu_s);
     r->log2_ctu = log2_ctu_s;
     return OVHIP_OK;
 }

@@ -36,7 +36,18 @@ struct ovhip_recorder {
     int log2_ctu;                       /* CTU size the tasks' ctu_deps refer to (ovhip_rec_set_ctu_size; 7 by default) */
     int scan_cx, scan_cy; uint32_t scan_deps, region_deps;
     uint16_t *reg_level; size_t cap_reglvl;     /* level of each chroma-scale region (0: derived by the unordered launch) */
+    ovhip_calllog *log;                 /* ovhip_rec_set_calllog: every entry-point call is also serialised there */
 };
+
+/* ovvc_calllog.c */
+void ovhip_calllog_tu_(ovhip_calllog *l, const ovhip_tu_state *st, const ovhip_tu_desc *tu, const ovhip_itask *il, const ovhip_itask *ic);
+void ovhip_calllog_isp_(ovhip_calllog *l, const ovhip_tu_state *st, const ovhip_isp_desc *cu);
+void ovhip_calllog_pu_(ovhip_calllog *l, const ovhip_pu_desc *pu);
+void ovhip_calllog_affine_(ovhip_calllog *l, const ovhip_affine_desc *cu);
+void ovhip_calllog_region_(ovhip_calllog *l, int32_t x0, int32_t y0, uint32_t abv, uint32_t lft);
+void ovhip_calllog_dbf_(ovhip_calllog *l, const ovhip_dbf_ctu *c);
+void ovhip_calllog_ciip_(ovhip_calllog *l, int32_t x0, int32_t y0, int32_t log2_w, int32_t log2_h, int32_t mode_abv, int32_t mode_lft);
+void ovhip_calllog_ctu_size_(ovhip_calllog *l, int32_t log2_ctu_s);
 
 int  ovhip_rec_intra_reset_(ovhip_recorder *r);
 void ovhip_rec_intra_free_(ovhip_recorder *r);

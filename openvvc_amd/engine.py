@@ -516,6 +516,10 @@ class Job:
             return np.zeros(0, capi.TMVP_CELL_DTYPE)
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (n.value * capi.TMVP_CELL_DTYPE.itemsize,)).view(capi.TMVP_CELL_DTYPE).copy()
 
+    def test_abort_next_flow(self):
+        """test hook: the next flush's flow launch is abandoned for real (ovhip_job_test_abort_next_flow)"""
+        self.ctx._chk(self.lib.ovhip_job_test_abort_next_flow(self.j), "job_test_abort_next_flow")
+
     def stats(self) -> "capi.JobStats":
         s = capi.JobStats()
         self.lib.ovhip_job_last_stats(self.j, C.byref(s))
@@ -529,3 +533,170 @@ class Job:
         s, n = C.c_double(), C.c_uint64()
         self.ctx._chk(self.lib.ovhip_job_stage_time(self.j, C.byref(s), C.byref(n)), "job_stage_time")
         return s.value * 1e-3, n.value
+
+
+class Dpb:
+    """Device mirror of the decoded picture buffer (ovhip_dpb_*): `devices` = HIP ordinals of the logical devices."""
+
+    def __init__(self, devices=(0,), ops: "capi.DpbOps | None" = None, n_devices: int | None = None):
+        self.lib = capi.load()
+        h = C.c_void_p()
+        if ops is not None:
+            self._ops = ops
+            r = self.lib.ovhip_dpb_create_ex(C.byref(h), n_devices or 1, C.byref(ops))
+        else:
+            arr = (C.c_int * len(devices))(*devices)
+            r = self.lib.ovhip_dpb_create(C.byref(h), arr, len(devices))
+        if r != 0:
+            raise EngineError(f"ovhip_dpb_create: {r} (no HIP device? the DPB has no CPU back-end outside the tests' own)")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.ovhip_dpb_destroy(self.h)
+            self.h = None
+
+    def stats(self) -> "capi.DpbStats":
+        st = capi.DpbStats()
+        self.lib.ovhip_dpb_get_stats(self.h, C.byref(st))
+        return st
+
+    def begin(self, key: int, dev: int, w: int, h: int) -> "capi.Pic":
+        pic = capi.Pic()
+        r = self.lib.ovhip_dpb_begin(self.h, C.c_void_p(key), dev, w, h, C.byref(pic))
+        if r != 0:
+            raise EngineError(f"ovhip_dpb_begin: {r}")
+        return pic
+
+    def lookup(self, key: int) -> "tuple[int, capi.Pic]":
+        pic, dev = capi.Pic(), C.c_int()
+        r = self.lib.ovhip_dpb_lookup(self.h, C.c_void_p(key), C.byref(dev), C.byref(pic))
+        if r != 0:
+            raise EngineError(f"ovhip_dpb_lookup: {r}")
+        return dev.value, pic
+
+
+class Frame:
+    """One frame thread (ovhip_frame_*): context + job on a logical device of a DPB."""
+
+    def __init__(self, dpb: Dpb, dev: int, w: int, h: int):
+        self.lib, self.dpb, self.w, self.h = dpb.lib, dpb, w, h
+        f = C.c_void_p()
+        r = self.lib.ovhip_frame_create(dpb.h, dev, w, h, C.byref(f))
+        if r != 0:
+            raise EngineError(f"ovhip_frame_create: {r}")
+        self.f = f
+
+    def _chk(self, r, what):
+        if r < 0:
+            raise EngineError(f"{what}: {r}: {self.lib.ovhip_frame_last_error(self.f).decode()}")
+        return r
+
+    def close(self):
+        if self.f:
+            self.lib.ovhip_frame_destroy(self.f)
+            self.f = None
+
+    def begin(self, key: int):
+        self._chk(self.lib.ovhip_frame_begin(self.f, C.c_void_p(key)), "frame_begin")
+
+    def ref(self, key: int) -> int:
+        return self._chk(self.lib.ovhip_frame_ref(self.f, C.c_void_p(key)), "frame_ref")
+
+    def ref_at(self, slot: int, key: int) -> int:
+        return self._chk(self.lib.ovhip_frame_ref_at(self.f, slot, C.c_void_p(key)), "frame_ref_at")
+
+    def recorder(self) -> "capi.Recorder":
+        r = capi.Recorder.__new__(capi.Recorder)
+        r.lib, r.h, r._keep = self.lib, self.lib.ovhip_frame_recorder(self.f), []
+        if not r.h:
+            raise EngineError("ovhip_frame_recorder")
+        r.close = lambda: None                                     # owned by the frame's job
+        return r
+
+    def dmvr_rows(self) -> int:
+        return int(self._chk(self.lib.ovhip_frame_dmvr_rows(self.f), "frame_dmvr_rows"))
+
+    def submit(self, params: "capi.JobParams", job: "Job | None" = None, out: "capi.FrameOutput | None" = None, check: bool = True) -> int:
+        r = self.lib.ovhip_frame_submit(self.f, job.j if job is not None else None, None, C.byref(params), C.byref(out) if out is not None else None)
+        return self._chk(r, "frame_submit") if check else r
+
+    def fail(self, status: int = -3):
+        self.lib.ovhip_frame_fail(self.f, status)
+
+    def job(self) -> "Job":
+        """the frame's own job as an engine.Job view (not owned)"""
+        j = Job.__new__(Job)
+        ctx = Context.__new__(Context)
+        ctx.lib, ctx.h, ctx._bufs = self.lib, C.c_void_p(self.lib.ovhip_frame_ctx(self.f)), []
+        j.ctx, j.lib, j.w, j.h, j.j, j._keep = ctx, self.lib, self.w, self.h, C.c_void_p(self.lib.ovhip_frame_job(self.f)), {}
+        j.rec = self.recorder()
+        return j
+
+
+class Stream:
+    """The C stream driver (ovhip_stream_*): frame threads per device decoding a list of pictures in decoding order.
+
+    contents: list of dicts {"params": capi.JobParams, "calllog": np.ndarray | None, "n_ref_slots": int}; jobs: engine.Job list
+    (pre-recorded pictures).  Everything referenced stays alive as long as this object."""
+
+    def __init__(self, dpb: Dpb, w: int, h: int, contents: list, jobs: list = (), threads_per_device: int = 1, flags: int = 0,
+                 output: int = 0, window=(0, 0, 0, 0), extra_stages: int = 0, rank: int = 0, xfer: "capi.StreamXfer | None" = None):
+        self.lib, self.dpb = dpb.lib, dpb
+        self._contents = (capi.StreamContent * len(contents))()
+        self._keep = [contents, jobs, xfer]
+        for i, c in enumerate(contents):
+            sc = self._contents[i]
+            log = c.get("calllog")
+            sc.calllog = log.ctypes.data if log is not None else None
+            sc.calllog_bytes = log.nbytes if log is not None else 0
+            sc.params = c["params"]
+            sc.n_ref_slots = c.get("n_ref_slots", 2)
+        self._jobs = (C.c_void_p * max(1, len(jobs)))(*[j.j for j in jobs])
+        cfg = capi.StreamCfg()
+        cfg.w, cfg.h, cfg.flags, cfg.threads_per_device, cfg.output = w, h, flags, threads_per_device, output
+        cfg.window = capi.Window(*window)
+        cfg.extra_stages, cfg.rank = extra_stages, rank
+        cfg.xfer = C.pointer(xfer) if xfer is not None else None
+        self.cfg = cfg
+        s = C.c_void_p()
+        r = self.lib.ovhip_stream_create(C.byref(s), dpb.h, C.byref(cfg), self._contents, len(contents), self._jobs, len(jobs))
+        if r != 0:
+            raise EngineError(f"ovhip_stream_create: {r}")
+        self.s = s
+
+    def close(self):
+        if self.s:
+            self.lib.ovhip_stream_destroy(self.s)
+            self.s = None
+
+    def picture(self, idx: int, ctx: "Context") -> "DevPic":
+        """the device picture of stream picture idx (kept by OVHIP_STREAM_KEEP), as a DevPic on ctx for download()"""
+        key = self.lib.ovhip_stream_key(self.s, idx)
+        _dev, pic = self.dpb.lookup(key)
+        return DevPic(ctx, pic, owns=False)
+
+    @staticmethod
+    def pics_array(pics: list):
+        """pics: list of dicts (content, job, poc, device, refs, owner, send_mask) -> (capi.StreamPic * n)"""
+        arr = (capi.StreamPic * max(1, len(pics)))()
+        for i, p in enumerate(pics):
+            a = arr[i]
+            a.content, a.job, a.poc, a.device = p.get("content", 0), p.get("job", 0), p.get("poc", i), p.get("device", 0)
+            refs = list(p.get("refs", ()))
+            assert len(refs) <= capi.STREAM_MAX_REFS
+            a.n_refs = len(refs)
+            for k, r in enumerate(refs):
+                a.refs[k] = r
+            a.owner, a.send_mask = p.get("owner", 0), p.get("send_mask", 0)
+        return arr
+
+    def run(self, arr, n_total: int, first: int, n: int, flags: int = 0, digests: bool = False, check: bool = True):
+        """-> (capi.StreamResult, digests uint8 [n, 16] | None)"""
+        res = capi.StreamResult()
+        dg = np.zeros((n, 16), np.uint8) if digests else None
+        r = self.lib.ovhip_stream_run(self.s, arr, n_total, first, n, flags | (capi.STREAM_DIGESTS if digests else 0),
+                                      dg.ctypes.data if dg is not None else None, C.byref(res))
+        if r != 0 and check:
+            raise EngineError(f"ovhip_stream_run: {r}: {res.error.decode(errors='replace')}")
+        return res, dg

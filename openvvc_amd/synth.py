@@ -105,6 +105,7 @@ class Workload:
     sao_params: np.ndarray = None   # capi.SAO_CTU_DTYPE per CTU
     alf: dict = None                # ALF tables + per-CTU parameters
     itasks: np.ndarray = None       # capi.ITASK_DTYPE, decoding order: intra / CIIP / ordered-scale tasks (None: none)
+    calllog: np.ndarray = None      # uint8: the recorder calls that produced all of the above, serialised (ovhip_calllog_replay)
     stats: dict = field(default_factory=dict)
 
     @property
@@ -147,7 +148,7 @@ INTRA_TOOLS = ALL_TOOLS + ("intra",)
 
 
 def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6, cbf_y: float = 0.5,
-                  cbf_c: float = 0.3, mv_range_px: int = 64, tools=ALL_TOOLS, intra_frac: float = 0.12) -> Workload:
+                  cbf_c: float = 0.3, mv_range_px: int = 64, tools=ALL_TOOLS, intra_frac: float = 0.12, calllog: bool = False) -> Workload:
     """tools: subset of ALL_TOOLS.  Rates follow JVET CTC random-access statistics in spirit: of the
     bi-predicted CUs that satisfy check_bdof() (vcl_coding_unit.c:2019-2027) and whose references lie on
     opposite sides of the picture, ~45 % use BDOF alone and ~35 % DMVR (+BDOF); ~8 % of the CUs >= 16x16
@@ -164,6 +165,8 @@ def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6
     cus = partition(rs, w, h, max_cu=64 if ("intra" in set(tools) and intra_frac >= 1.0) else 128)      # an I picture: intra CUs are at most 64x64
     n = len(cus)
     rec = capi.Recorder(w, h)
+    if calllog:
+        rec.start_calllog()
     lw, lh = cus[:, 2], cus[:, 3]
 
     inter_dir = np.where(rs.random_sample(n) < bi_frac, 3, rs.randint(1, 3, size=n)).astype(np.int32)
@@ -447,6 +450,8 @@ def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6
         wl.lmcs_regions = rec.lmcs_regions()
     wl.dbf_ctus = make_dbf_ctus(rs, w, h, cus)
     wl.dbf_planes, wl.dbf_edges = record_dbf(rec, wl.dbf_ctus)
+    if calllog:
+        wl.calllog = rec.take_calllog()
     wl.sao_params = make_sao_params(rs, w, h)
     wl.alf = make_alf(rs, w, h)
     u, ux, ua = wl.mc_units, wl.mcx_units, wl.aff_units

@@ -157,10 +157,9 @@ def test_second_pass_after_an_abandoned_flow_launch(ctx, monkeypatch):
     refs = [ctx.upload_pic(*r) for r in wl.refs]
     dst = ctx.new_pic(w, h)
     job.load_workload(wl)
-    monkeypatch.setenv("OVHIP_TEST_FORCE_SECOND_PASS", "1")
+    job.test_abort_next_flow()            # the first pass is abandoned for real: the device's abort word is set before the launch
     job.flush(dst, refs, None)
     job.wait()
-    monkeypatch.delenv("OVHIP_TEST_FORCE_SECOND_PASS")
     assert job.stats().n_ordered_retries == 1
     got = dst.download()
     ref, mvs = oracle_pipeline.decode(wl, want_mvs=True)
@@ -214,3 +213,30 @@ def test_4k_intra_picture_matches_oracle(ctx):
         for name, a, b in (("Y", got[0], ref.y), ("Cb", got[1], ref.cb), ("Cr", got[2], ref.cr)):
             assert np.array_equal(a, b), f"4K I picture, decode {rep}: plane {name}: {int((a != b).sum())} samples differ"
         job.begin()
+
+
+@pytest.mark.gpu
+def test_4k_b_picture_with_intra_matches_oracle(ctx):
+    """the picture type bench.py times -- 3840x2160, every coding tool, 12 % of the CUs intra in clusters (the
+    bench's own seed) -- at ITS size against the oracle: all stages, the refined vectors, and a second decode into the same
+    buffers through a real abandoned first pass."""
+    w, h = 3840, 2160
+    wl = synth.make_workload(w, h, 0x266, tools=synth.INTRA_TOOLS, intra_frac=0.12)
+    assert wl.stats["n_itasks"] > 5000 and wl.stats["cu_modes"]["intra"] > 500 and wl.stats["n_mcx_units"] > 1000
+    ref, mvs = oracle_pipeline.decode(wl, want_mvs=True)
+    job = engine.Job(ctx, w, h)
+    refs = [ctx.upload_pic(*r) for r in wl.refs]
+    dst = ctx.new_pic(w, h)
+    for rep in range(2):
+        job.load_workload(wl)
+        if rep:
+            job.test_abort_next_flow()
+        job.flush(dst, refs, None)
+        job.wait()
+        assert job.stats().n_ordered_retries == rep
+        got = dst.download()
+        for name, a, b in (("Y", got[0], ref.y), ("Cb", got[1], ref.cb), ("Cr", got[2], ref.cr)):
+            assert np.array_equal(a, b), f"4K B picture with intra, decode {rep}: plane {name}: {int((a != b).sum())} samples differ"
+        assert np.array_equal(job.refined_mvs(), mvs)
+        job.begin()
+    job.close()
