@@ -1,26 +1,28 @@
 #!/usr/bin/env python
-"""bench.py -- decoded frames/s of the MI355X rcn back-end, one DECODE STEP per picture.
+"""bench.py -- decoded frames/s of the MI355X rcn back-end on a random-access stream, timed region in C.
 
-A "step" is what the reference-side shim does at the end of a parsed picture (shim/rcn_hip.c flush_picture ->
-ovhip_job_flush, all in C): asynchronous H2D of the picture's recorded command buffers + coefficient arena + deblocking
-edge lists + filter parameters out of page-locked memory, the launch chain of the whole rcn path (prediction incl.
-BDOF / DMVR / affine-PROF / GPM / CIIP + LMCS, inverse quantisation / LFNST / transforms + residual, deblocking, SAO,
-ALF / CC-ALF; intra prediction of the picture's intra CUs as a dependency-ordered pass), and the D2H of the DMVR-refined
-motion vectors.  The workload is a synthetic recorded 3840x2160 10-bit 4:2:0 random-access stream (BASELINE.json
-configs[3]): B pictures with `--intra-frac` of their CUs intra, and `--i-sets` of the picture sets an I picture.
+A "step" is one intra period of a synthetic recorded 3840x2160 10-bit 4:2:0 random-access stream (BASELINE.json configs[3]):
+its I picture and the B pictures of its GOPs (openvvc_amd/gop.py: GOP `--gop`, hierarchical B in the JVET decoding order, an I
+picture every `--intra-period`), every picture decoded the way the reference-side shim decodes it (shim/rcn_hip.c ->
+ovhip_frame_submit): H2D of the picture's recorded command buffers out of page-locked memory, the launch chain of the whole rcn
+path (prediction incl. BDOF / DMVR / affine-PROF / GPM / CIIP + LMCS, inverse quantisation / LFNST / transforms + residual, the
+ordered intra pass, deblocking, SAO, ALF / CC-ALF), D2H of the DMVR-refined vectors, ovhip_job_wait, the picture's digest
+(`--output`), and only THEN its publication to the pictures that reference it (device DPB, ovvc_dpb.c).
 
-The steps are the pictures of a random-access stream in decoding order (openvvc_amd/gop.py: GOP `--gop`, hierarchical B, an I
-picture every `--intra-period`): a picture's reference pictures ARE the decoded pictures its reference lists name, so a picture
-starts when they are done (stream events) -- the dependency structure a decoder's frame threads live with.  Nothing is
-replayed out of cache: every position of the GOP has its own command buffers, job and destination picture (distinct addresses,
-`--contents` distinct recorded pictures; working set several times the 256 MiB Infinity Cache).  `--in-flight S` pictures are
-in flight per GPU (one HIP stream + one host thread each: the reference's frame threads, ovdec.c:188-248).
+The timed region is ONE call into the library: ovhip_stream_run (openvvc_amd/csrc/ovvc_stream.c) -- `--in-flight` frame threads
+(pthreads, one HIP stream each: the reference's frame threads, ovdec.c:188-248) take the pictures in decoding order; a picture's
+reference pictures ARE the decoded pictures its reference lists name; an output thread takes finished pictures in POC order.
+Python builds the stream description before and reads the result after; it is not in the loop.
 
-N > 1: one process per GPU, a GOP per GPU; the only picture of a GOP another GPU needs is its key picture, sent to the owner
-of the next GOP with RCCL point-to-point on a communication stream (no collective on the data path, nothing waited for on the
-host).  A step = one intra period of the stream (--intra-period pictures: every step is the same work, so any --steps measures
-the steady state; a picture count that is not a multiple of it would over- or under-represent the I picture, which the stream
-fully exposes).  Every rank decodes --steps intra periods: the stream grows with N ("weak").
+Variants measured beside the headline figure (same stream, same library call, `config.variants`):
+  output none / digest / frame   nothing leaves the device / per-picture MD5 fingerprint (16 B) / crop + pack + D2H of the 24.9 MB frame
+  recorded_in_run                the recorder inside the timed region: every frame thread replays the picture's call log
+                                 (ovhip_calllog_replay = every ovhip_rec_* call a parse thread makes) into its own job first
+
+N > 1 (torchrun, one process per GPU): a GOP per rank; the key picture of a GOP goes to the owner of the next GOP -- the driver's
+comm thread calls back into torch.distributed (RCCL point-to-point), one transfer per GOP, no collective on the data path.
+`--local-devices N`: ONE process drives N logical devices instead (device DPB with event-ordered hipMemcpyPeerAsync), the
+reference's --framethr model.
 
 Prints ONE JSON line on rank 0 (contract in the task statement).
 """
@@ -103,27 +105,35 @@ def main():
     ap.add_argument("--seed", type=int, default=0x266)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-isolated-survey", action="store_true",
-                    help="skip the one-picture-in-flight survey: every launch of the process then runs in the timed configuration "
+                    help="skip the one-picture-in-flight survey and the variants: every launch of the process then runs in the timed configuration "
                          "(what tools/profile_round.sh traces, so that rocprofv3's per-kernel averages are of that configuration)")
-    ap.add_argument("--in-flight", type=int, default=16, help="pictures in flight per GPU (one HIP stream + one host thread each)")
-    ap.add_argument("--contents", type=int, default=2, help="distinct recorded pictures (seeds) among the sets")
+    ap.add_argument("--in-flight", type=int, default=16, help="frame threads (= pictures in flight) per device: pthreads of the C stream driver, one HIP stream each")
+    ap.add_argument("--contents", type=int, default=2, help="distinct recorded B pictures (seeds)")
     ap.add_argument("--intra-frac", type=float, default=0.12, help="share of intra CUs in the B pictures")
-    ap.add_argument("--gop", type=int, default=32, help="GOP size (hierarchical B, JVET random-access decoding order) = picture sets of the rotation")
+    ap.add_argument("--gop", type=int, default=32, help="GOP size (hierarchical B, JVET random-access decoding order)")
     ap.add_argument("--intra-period", type=int, default=64, help="every key picture at a multiple of this POC is an I picture (a multiple of --gop; JVET CTC: about one second, 64 at 50 / 60 Hz)")
-    ap.add_argument("--intra-ctu", action="store_true", help="ordered pass as the one-launch CTU wavefront instead of one launch per level")
+    ap.add_argument("--intra-ctu", action="store_true", help="ordered pass as the one-launch CTU wavefront")
     ap.add_argument("--intra-levels", action="store_true", help="ordered pass as one launch per level instead of one launch with per-unit dependency flags")
-    ap.add_argument("--device-waits", action="store_true", help="reference pictures as stream waits (barrier packets) instead of host waits before the launches")
-    ap.add_argument("--trace-gop", action="store_true", help="debug: host timeline of the pictures of the last run on stderr")
-    ap.add_argument("--gop-rotation", type=int, default=1,
-                    help="GOPs of picture sets / destination buffers in the rotation: with 1 a picture of GOP g + 1 overwrites the buffer of the same "
-                         "position of GOP g and waits for its readers, which bounds the look-ahead to one GOP whatever --in-flight says")
-    ap.add_argument("--check", type=int, default=0, metavar="N",
-                    help="after the measurement: decode the first N pictures of the stream twice from the same start -- --in-flight pictures at a "
-                         "time, then one at a time -- and compare the device digests (ovhip_pic_digest) of every picture")
+    ap.add_argument("--job-rotation", type=int, default=3,
+                    help="GOPs of pre-recorded picture jobs in the rotation (a job = the page-locked command buffers of one stream position + its device "
+                         "copies, in flight once at a time): bounds how far ahead of the oldest picture in flight the frame threads can run")
+    ap.add_argument("--output", choices=("none", "digest", "frame"), default="digest",
+                    help="what leaves the device per picture INSIDE the timed region: nothing / its MD5 fingerprint (per-row MD5 on the device, 16 bytes "
+                         "out) / the cropped, packed frame (one D2H of 24.9 MB at 4K into page-locked memory)")
+    ap.add_argument("--check", type=int, default=6, metavar="N",
+                    help="after the measurement: the first N pictures of the stream (I picture first) decoded by the ORACLE one at a time, each from the "
+                         "oracle's own reference pictures, against the device's digests of the same pictures decoded --in-flight at a time; and the "
+                         "first two GOPs in flight vs one at a time (0: skip)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="N > 1: weak = every rank decodes --steps intra periods (the stream grows with N); strong = the stream is --steps intra "
-                         "periods in total, its GOPs dealt to the ranks (each rank times 1/N of the pictures)")
-    ap.add_argument("--host-threads", type=int, default=-1, help="host threads issuing the flushes (-1: one per picture in flight)")
+                         "periods in total, its GOPs dealt to the ranks")
+    ap.add_argument("--dealing", choices=("gop", "picture"), default="gop",
+                    help="N > 1 / --local-devices: a GOP per device (one transfer per GOP) or picture k -> device k mod N (SURVEY 8e as written: one transfer "
+                         "per reference edge that crosses devices)")
+    ap.add_argument("--local-devices", type=int, default=1,
+                    help="ONE process driving this many logical devices (device DPB + hipMemcpyPeerAsync); with --same-gpu all of them on GPU 0")
+    ap.add_argument("--same-gpu", action="store_true")
+    ap.add_argument("--record-threads", type=str, default="1,4,16", help="frame-thread counts of the recorded_in_run variant")
     args = ap.parse_args()
 
     import torch
@@ -136,7 +146,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU fallback")
     # OVVC_BENCH_DEBUG_GLOO=1 (development only): all ranks on GPU 0, pictures exchanged through host memory over gloo -- runs
-    # the N > 1 control flow (schedule, communication thread, events) on a one-GPU box.  Never set by the driver.
+    # the N > 1 control flow (schedule, comm thread, callbacks) on a one-GPU box.  Never set by the driver.
     debug_gloo = os.environ.get("OVVC_BENCH_DEBUG_GLOO") == "1"
     if debug_gloo:
         local_rank = 0
@@ -144,385 +154,406 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if debug_gloo:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group("gloo" if debug_gloo else "nccl", **({} if debug_gloo else {"device_id": dev}))
 
     W, H = args.width, args.height
     S = max(1, args.in_flight)
-    G = args.gop                                   # pictures per GOP = picture sets of the rotation
-    IP = args.intra_period
-    PPS = IP if IP > 0 else G                      # pictures per step: one intra period (its I picture + the B pictures of its GOPs)
-    K = G
+    G, IP = args.gop, args.intra_period
+    assert IP % G == 0
+    PPS = IP
+    L = max(1, args.local_devices) if world == 1 else 1
+    hip_devices = [local_rank if (args.same_gpu or world > 1) else k for k in range(L)] if L > 1 else [local_rank]
+
     tools = synth.INTRA_TOOLS if args.intra_frac > 0 else synth.ALL_TOOLS
-    wls = [synth.make_workload(W, H, args.seed + 1000 * c + rank, tools=tools, intra_frac=args.intra_frac)
-           for c in range(max(1, min(args.contents, K)))]
+    want_log = not args.no_isolated_survey
+    wls = [synth.make_workload(W, H, args.seed + 1000 * c + rank, tools=tools, intra_frac=args.intra_frac, calllog=want_log)
+           for c in range(max(1, args.contents))]
     n_b = len(wls)
-    wls.append(synth.make_workload(W, H, args.seed + 7777 + rank, tools=synth.INTRA_TOOLS, intra_frac=1.0))      # the I picture
+    wls.append(synth.make_workload(W, H, args.seed + 7777 + rank, tools=synth.INTRA_TOOLS, intra_frac=1.0, calllog=want_log))      # the I picture
     FB = wls[0].frame_bytes
-    n_ref_slots = len(wls[0].refs)
 
-    # ---- the stream: an RA sequence of GOPs (openvvc_amd/gop.py), GOP g decoded by rank g mod world.  Position j of the
-    # GOP's decoding order <-> picture set j (own command buffers, job, destination picture at its own address); the key
-    # picture (j = 0) rotates over three buffers because the previous GOP's pictures still read the previous key.
-    ctxs = [engine.Context(local_rank) for _ in range(S)]
-    ext = [torch.cuda.ExternalStream(c.stream, device=dev) for c in ctxs]
-    comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+    # ---- library objects: device DPB, pre-recorded jobs (R GOPs of stream positions, + the I / key pictures), stream drivers ----
+    ctx0 = engine.Context(hip_devices[0])
+    dpb = engine.Dpb(tuple(hip_devices))
+    R = max(2, args.job_rotation)
+    n_jobs = R * G
+    keep = []
 
-    def torch_pic(ctx, planes=None):
-        t = torch.zeros(H * W * 3 // 2, dtype=torch.int16, device=dev)     # zero-filled like ovhip_pic_alloc's: no sample may carry bit 15 in
-        ysz, csz = H * W, (H // 2) * (W // 2)
-        s = capi.Pic(t.data_ptr(), t.data_ptr() + 2 * ysz, t.data_ptr() + 2 * (ysz + csz), W, H, W, W // 2)
-        p = engine.DevPic(ctx, s, owns=False)
-        if planes is not None:
-            p.upload(*planes)
-        return t, p
+    class K:
+        def __init__(self):
+            self._keep = {}
 
-    class Set:
-        pass
+    def params_of(wl):
+        k = K(); keep.append(k)
+        return engine.Job.make_params(k, wl)
 
-    def new_job(wl):
-        st = Set()
-        st.wl = wl
-        st.job = engine.Job(ctxs[0], W, H)
-        st.job.load_workload(wl)
-        st.lock = threading.Lock()
-        return st
-
-    order = gop.gop_decode_order(G)
-    R = max(1, args.gop_rotation)                                                            # GOPs in the rotation
-    NK = R + 2                                                                               # key pictures alive at a time
-    sets = [new_job(wls[n_b]) if j % K == 0 else new_job(wls[j % n_b]) for j in range(R * K)]     # position 0: the key picture as I picture
-    key_i = [sets[0]] + [new_job(wls[n_b]) for _ in range(NK - 1)]                           # consecutive key pictures overlap: own jobs
-    key_b = [new_job(wls[0]) for _ in range(NK)] if IP > G else None                         # ... and as inter key pictures
-    all_jobs = sets + key_i[1:] + (key_b if key_b else [])
-    bufs_b = [torch_pic(ctxs[0]) for _ in range(R * K)]                # destination of GOP position j (j >= 1) of rotation slot r: [r * K + j]
-    bufs_key = [torch_pic(ctxs[0], wls[0].refs[k % n_ref_slots]) for k in range(NK)]
-    bufs_recv = [torch_pic(ctxs[0], wls[0].refs[k % n_ref_slots]) for k in range(2)] if world > 1 else []
-    torch.cuda.synchronize(dev)
-    working_set = (R * K + NK + len(bufs_recv)) * FB + len(all_jobs) * FB            # destinations + each job's SAO picture
-
+    contents = [{"params": params_of(wl), "calllog": wl.calllog, "n_ref_slots": len(wl.refs)} for wl in wls]
     lv = capi.STAGE_INTRA_CTU if args.intra_ctu else (capi.STAGE_INTRA_LEVELS if args.intra_levels else 0)
-    nthreads = S if args.host_threads < 0 else max(1, min(args.host_threads, S))
-    second_passes = [0]            # pictures ovhip_job_wait had to decode a second time (flow launch gave up), whole run
-    one_at_a_time = [False]        # survey of the kernels alone on the device: one host thread, one picture in flight
-    gop_base = [0]                                 # GOPs this rank has decoded so far (keeps the key-buffer rotation going)
-    keep_work = []
 
-    def run_steps(n, resident=False, digests=None):
-        """The next n pictures of this rank's share of the stream, in decoding order.  One host thread per picture in flight,
-        each with its own HIP stream; a thread that became free takes the next picture (the reference's frame threads,
-        ovdec.c:188-248) and, like the shim's flush_picture, waits for it before it takes another.  A picture starts when the
-        pictures of its reference lists are decoded (stream events; RCCL point-to-point for a key picture decoded on another
-        GPU), and not before the readers of the buffer it overwrites are done."""
-        n_gops_rank = (n + G - 1) // G
-        pics = gop.build_stream(n_gops_rank * world, G, IP, world)
-        mine = [p for p in pics if p.owner == rank and p.gop >= 0][:n]
-        first_gop = gop_base[0]
-        gop_base[0] += n_gops_rank
-        # buffers: picture idx -> (tensor, DevPic)
-        buf = {}
-        local_gop = lambda p: first_gop + p.gop // world
+    def content_of(p):
+        """stream picture -> recorded content: I pictures show the I content; B pictures rotate over the B contents by stream position"""
+        return n_b if p.intra else (p.idx % n_b)
+
+    # a job per stream position modulo the rotation.  The job of position j holds ONE content for ever (its page-locked arrays are
+    # loaded once): position -> content must be periodic with the rotation.  I pictures sit at idx = 1 + k * PPS: give them jobs of their own.
+    n_ijobs = 3
+    job_content = [j % n_b for j in range(n_jobs)] + [n_b] * n_ijobs
+    jobs = []
+    for c in job_content:
+        j = engine.Job(ctx0, W, H)
+        j.load_workload(wls[c])
+        jobs.append(j)
+
+    def build(n_gops_total, world_=1, dealing="gop", n_dev=1):
+        pics = gop.build_stream(n_gops_total, G, IP, world_)
+        if dealing == "picture" and max(world_, n_dev) > 1:
+            m = max(world_, n_dev)
+            for p in pics:
+                p.owner = p.idx % m if world_ > 1 else 0
+            for p in pics:
+                p.sends = []
+            for p in pics:
+                for r in p.refs:
+                    q = pics[r]
+                    if q.owner != p.owner and p.owner not in q.sends:
+                        q.sends.append(p.owner)
+        out, n_i = [], 0
         for p in pics:
-            if p.gop < 0:
-                # the picture before the first GOP: for rank 0 the key buffer its previous GOP left, else whatever is there
-                if rank == 0:
-                    buf[p.idx] = bufs_key[(first_gop - 1) % NK]
-            elif p.owner == rank:
-                buf[p.idx] = bufs_key[local_gop(p) % NK] if p.layer == 0 else bufs_b[(local_gop(p) % R) * K + order.index((p.poc - p.gop * G, p.layer))]
-            elif rank in p.sends:
-                buf[p.idx] = bufs_recv[(first_gop + (p.gop + 1) // world) % 2]
-        # who reads what (on this rank), who occupied a buffer before
-        readers = {}
-        for p in mine:
-            for r in p.refs:
-                readers.setdefault(r, []).append(p.idx)
-        prog = gop.rank_program(pics, rank)
-        issued = {p.idx: threading.Event() for p in pics}
-        done_ev = {}
-        prev_occ, occ = {}, {}
-        for op in prog:
-            if op[0] in ("decode", "recv") and op[1] in buf:
-                key = buf[op[1]][0].data_ptr()
-                if key in occ:
-                    prev_occ[op[1]] = occ[key]
-                occ[key] = op[1]
-        for p in pics:
-            if p.gop < 0 or (p.owner != rank and rank not in p.sends) or p.idx not in [q.idx for q in mine] and p.owner == rank:
-                issued[p.idx].set()                   # not part of this run: final already
-        mine_idx = {p.idx for p in mine}
-        errs = []
+            if p.intra:
+                job = n_jobs + n_i % n_ijobs
+                n_i += 1
+                content = n_b
+            else:
+                job = p.idx % n_jobs
+                content = job_content[job]
+            device = 0
+            if n_dev > 1:
+                device = (p.idx % n_dev) if dealing == "picture" else (gop.gop_owner(max(p.gop, 0), n_dev, IP // G))
+            out.append({"content": content, "job": job, "poc": p.poc, "refs": p.refs[:capi.STREAM_MAX_REFS], "device": device,
+                        "owner": p.owner, "send_mask": sum(1 << d for d in p.sends)})
+        return pics, out
 
-        def wait_for(stream, idxs, collect=None):
-            """Host: until the producers' flushes have been enqueued.  Device: `stream` behind their completion events -- or,
-            with `collect`, the events are handed to the flush, which waits for them after its uploads."""
-            for q in idxs:
-                if q in mine_idx or (pics[q].owner != rank and q in buf):
-                    issued[q].wait()
-                    ev = done_ev.get(q)
-                    if ev is not None:
-                        if collect is not None:
-                            collect.append(ev)
-                        else:
-                            stream.wait_event(ev)
+    OUT = {"none": capi.OUT_NONE, "digest": capi.OUT_DIGEST, "frame": capi.OUT_PACKED}
 
-        def decode(p, slot):
-            t_pull = time.perf_counter()
-            j = order.index((p.poc - p.gop * G, p.layer))
-            st = sets[(local_gop(p) % R) * K + j] if j else (key_i[local_gop(p) % NK] if (p.intra or key_b is None) else key_b[local_gop(p) % NK])
-            stream = ext[slot]
-            evs = []
-            wait_for(stream, p.refs, evs)
-            if p.idx in prev_occ:
-                wait_for(stream, [prev_occ[p.idx]] + readers.get(prev_occ[p.idx], []), evs)
-            refs = [buf[p.refs[k % len(p.refs)]][1] for k in range(n_ref_slots)] if p.refs else []
-            t_dep = time.perf_counter()
-            with st.lock:
-                st.job.bind(ctxs[slot])
-                t_bind = time.perf_counter()
-                st.job.params.stages = ((capi.STAGE_ALL | capi.STAGE_RESIDENT) if resident else capi.STAGE_ALL) | lv
-                # the frame thread waits for its reference pictures itself (ovdpb_frame_synchro), after its uploads are under way:
-                # on the host, in the flush (wait_on_host) -- or, --device-waits, as barriers in the stream
-                handles = (C.c_void_p * max(1, len(evs)))(*[e.cuda_event for e in evs])
-                st.job.params.wait_events = C.cast(handles, C.POINTER(C.c_void_p))
-                st.job.params.n_wait_events = len(evs)
-                st.job.params.wait_on_host = 0 if args.device_waits else 1
-                st.job.params.before_launch = None
-                st.job.flush(buf[p.idx][1], refs, None)
-                ev = torch.cuda.Event()
-                stream.record_event(ev)
-                done_ev[p.idx] = ev
-                issued[p.idx].set()
-                t_iss = time.perf_counter()
-                st.job.wait()
-                second_passes[0] += int(st.job.stats().n_ordered_retries)
-                if digests is not None:
-                    out = (C.c_uint8 * 16)()
-                    win = capi.Window(0, 0, 0, 0)
-                    ctxs[slot]._chk(ctxs[slot].lib.ovhip_pic_digest(ctxs[slot].h, C.byref(buf[p.idx][1].s), C.byref(win), out), "pic_digest")
-                    digests[p.idx] = bytes(out)
-            if args.trace_gop:
-                trace.append((p.idx, p.poc, p.layer, slot, t_pull, t_dep, t_bind, t_iss, time.perf_counter()))
+    def new_stream(threads, output="none", flags=0, xfer=None, use_jobs=True):
+        return engine.Stream(dpb, W, H, contents, jobs if use_jobs else [], threads_per_device=threads, flags=flags, output=OUT[output],
+                             extra_stages=lv, rank=rank, xfer=xfer)
 
-        nxt, nlock = [0], threading.Lock()
+    # ---- multi-process exchange: the driver's comm thread calls back here, one call per transferred picture ----
+    xfer = None
+    n_xfer_bytes = [0]
+    if world > 1:
+        stage = torch.empty(FB // 2 + 512, dtype=torch.int16, device=dev)       # one allocation = the picture's three planes
+        pic_bytes = lambda p: ((p.w * p.h * 2 + 255) & ~255) + 2 * (((p.w // 2) * (p.h // 2) * 2 + 255) & ~255)
+        assert pic_bytes(type("P", (), {"w": W, "h": H})) <= stage.numel() * 2
 
-        def worker(slot):
+        def _send(user, idx, pic, dst):
             try:
-                while True:
-                    with nlock:
-                        i = nxt[0]
-                        nxt[0] += 1
-                    if i >= len(mine):
-                        return
-                    decode(mine[i], slot)
+                nb = pic_bytes(pic[0])
+                ctx0._chk(ctx0.lib.ovhip_d2d(ctx0.h, stage.data_ptr(), pic[0].y, nb), "d2d")
+                t = stage[:nb // 2]
+                dist.send(t.cpu() if debug_gloo else t, dst)
+                torch.cuda.synchronize(dev)
+                n_xfer_bytes[0] += nb
+                return 0
             except Exception as e:          # noqa: BLE001
-                errs.append(e)
-                for evt in issued.values():
-                    evt.set()
+                print(f"rank {rank}: send of picture {idx} failed: {e}", file=sys.stderr)
+                return -4
 
-        def comm():
-            """This rank's sends and receives in the global transfer order, on the communication stream; nothing is waited
-            for on the host except that the producing flush has been enqueued."""
+        def _recv(user, idx, pic, src):
             try:
-                with torch.cuda.stream(comm_stream):
-                    for op in prog:
-                        if op[0] == "send" and op[1] in mine_idx:
-                            wait_for(comm_stream, [op[1]])
-                            if debug_gloo:
-                                comm_stream.synchronize()
-                                dist.send(buf[op[1]][0].cpu(), op[2])
-                                continue
-                            keep_work.append(dist.isend(buf[op[1]][0], op[2]))
-                        elif op[0] == "recv" and op[1] in buf and any(op[1] in q.refs for q in mine):
-                            if op[1] in prev_occ:
-                                wait_for(comm_stream, [prev_occ[op[1]]] + readers.get(prev_occ[op[1]], []))
-                            if debug_gloo:
-                                comm_stream.synchronize()
-                                t_host = torch.empty(buf[op[1]][0].shape, dtype=torch.int16)
-                                dist.recv(t_host, op[2])
-                                buf[op[1]][0].copy_(t_host)
-                            else:
-                                w = dist.irecv(buf[op[1]][0], op[2])
-                                w.wait()      # NCCL: orders the communication stream behind the transfer, the host does not block
-                                keep_work.append(w)
-                            ev = torch.cuda.Event()
-                            comm_stream.record_event(ev)
-                            done_ev[op[1]] = ev
-                            issued[op[1]].set()
+                nb = pic_bytes(pic[0])
+                t = stage[:nb // 2]
+                if debug_gloo:
+                    th = torch.empty(nb // 2, dtype=torch.int16)
+                    dist.recv(th, src)
+                    t.copy_(th)
+                else:
+                    dist.recv(t, src)
+                torch.cuda.synchronize(dev)
+                ctx0._chk(ctx0.lib.ovhip_d2d(ctx0.h, pic[0].y, stage.data_ptr(), nb), "d2d")
+                return 0
             except Exception as e:          # noqa: BLE001
-                errs.append(e)
-                for evt in issued.values():
-                    evt.set()
+                print(f"rank {rank}: receive of picture {idx} failed: {e}", file=sys.stderr)
+                return -4
 
-        trace = []
-        th = [threading.Thread(target=worker, args=(s,)) for s in range(1 if one_at_a_time[0] else nthreads)]
-        if world > 1:
-            th.append(threading.Thread(target=comm))
-        [t.start() for t in th]
-        [t.join() for t in th]
-        del keep_work[:-64]
-        if errs:
-            raise errs[0]
-        if args.trace_gop and rank == 0:
-            t0 = min(t[4] for t in trace)
-            for t in sorted(trace)[:2 * G]:
-                print("pic %3d poc %3d L%d slot %2d  pull %7.2f  deps %7.2f  bound %7.2f  issued %7.2f  done %7.2f ms" %
-                      (t[0], t[1], t[2], t[3], *[(x - t0) * 1e3 for x in t[4:]]), file=sys.stderr)
+        xfer = capi.StreamXfer(None, capi.XFER_FN(_send), capi.XFER_FN(_recv))
 
     def barrier():
         if world > 1:
             dist.barrier()
-        for c in ctxs:
-            c.sync()
         torch.cuda.synchronize(dev)
 
-    def timed(n, resident=False):
-        barrier()
-        t0 = time.perf_counter()
-        run_steps(n, resident)
-        barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=None if debug_gloo else dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
+    # ---- the local stream (this process alone): warm-up, surveys, variants, check ----
+    n_loc_gops = (args.warmup + 3 * 11 + 8) * (IP // G) + 8
+    lpics, lspics = build(n_loc_gops, 1, args.dealing, L)
+    larr = engine.Stream.pics_array(lspics)
+    NL = len(lspics)
+    st_main = new_stream(S)
+    cur = [0]
+
+    def run_local(st, n, flags=0, digests=False):
+        """the next n pictures of the local stream on stream driver st"""
+        assert cur[0] + n <= NL, "local stream exhausted"
+        res, dg = st.run(larr, NL, cur[0], n, flags=flags | capi.STREAM_KEEP, digests=digests)
+        cur[0] += n
+        return res, dg
+
+    second_passes = [0]
+
+    def count(res):
+        second_passes[0] += int(res.n_second_passes)
+        return res
+
+    # warm-up: every job flushed at least once, every buffer of the DPB pool allocated
+    count(run_local(st_main, 1 + max(args.warmup * PPS, n_jobs + G))[0])
+    barrier()
+    all_stats = [j.stats() for j in jobs]
+    flush_stats = all_stats[0]
+    mean_stat = lambda f: float(np.mean([getattr(a, f) for a in all_stats[:n_jobs]]))
 
     def set_timer(name):
-        for st in all_jobs:
-            st.job.time_stage(name)
+        for j in jobs:
+            j.time_stage(name)
 
     def read_timer():
         tot, cnt = 0.0, 0
-        for st in all_jobs:
-            s, n = st.job.stage_time()
+        for j in jobs:
+            s, n = j.stage_time()
             tot += s; cnt += n
         return tot / max(cnt, 1)
 
-    run_steps(max(args.warmup * PPS, (2 if key_b else 1) * K * max(R, NK if key_b else 1)))      # every picture set flushed at least once
-    barrier()
-    all_stats = [st.job.stats() for st in sets]          # of full (non-resident) flushes
-    flush_stats = all_stats[-1]                          # a B picture
-    mean_stat = lambda f: float(np.mean([getattr(a, f) for a in all_stats]))
-
-    # ---- untimed survey IN THE TIMED CONFIGURATION (same rotation, same pictures in flight): each launch group bracketed
-    # in turn by a HIP-event pair on its stream (bracketing all of them at once would cost ~80 us of stream time per picture)
-    stats0 = flush_stats
+    # ---- untimed survey IN THE TIMED CONFIGURATION (same jobs, same pictures in flight): each launch group bracketed in turn
+    # by a HIP-event pair on its stream (bracketing all of them at once would cost ~80 us of stream time per picture)
     present = ["mc", "mcxa", "itx_luma", "lmcs_scale", "itx_chroma", "intra", "dbf", "sao", "alf", "h2d"]
-    if not stats0.n_regions:
+    if not flush_stats.n_regions:
         present.remove("lmcs_scale")
-    if not any(len(w.itasks) for w in wls):
+    if not any(w.itasks is not None and len(w.itasks) for w in wls):
         present.remove("intra")
     survey = {}
     for name in present:
         set_timer(name)
-        run_steps(3 * PPS)               # three intra periods per group: the pick is steadier than with one
-        barrier()
+        count(run_local(st_main, 2 * PPS)[0])
         survey[name] = read_timer()
     kern = {k: v for k, v in survey.items() if k != "h2d"}
-    # The roofline kernel = the largest launch group among the kernels the HBM roofline applies to.  The ordered pass is a
-    # dependency chain (DESIGN 4.1): hops x latency per hop, neither bytes nor flops bound it; it is reported beside the roofline
-    # ("ordered_pass"), not as its subject.
-    dom = max((k for k in kern if k != "intra"), key=kern.get)
-    # the same groups with ONE picture in flight (same rotation, nothing resident): what a launch takes when it has the device
-    # to itself -- the timed configuration stretches every launch by the 15 other pictures it shares the device with
+    # the roofline's subject = the launch group with the largest stream time, whatever it is (r2 left the ordered pass out)
+    dom = max(kern, key=kern.get)
+    stream_dom = max((k for k in kern if k != "intra"), key=kern.get)
     isolated = {}
-    if (rank == 0 or world > 1) and not args.no_isolated_survey:
-        one_at_a_time[0] = True
+    variants = {}
+    if not args.no_isolated_survey:
+        # the same groups with ONE picture in flight: what a launch takes when it has the device to itself
+        st_one = new_stream(1)
         for name in present:
             if name == "h2d":
                 continue
             set_timer(name)
-            run_steps(K)
-            barrier()
+            r1, _ = st_one.run(larr, NL, 0, 1 + 2 * G, flags=0)
             isolated[name] = read_timer()
-        one_at_a_time[0] = False
+        set_timer(None)
+        st_one.close()
     if world > 1:
         pick = torch.tensor([present.index(dom)], dtype=torch.int64, device=None if debug_gloo else dev)
         dist.broadcast(pick, 0)
         dom = present[int(pick.item())]
 
-    # ---- timed region: EXACTLY --steps decode steps, only the dominant launch group bracketed
+    # ---- timed region: EXACTLY --steps steps, one library call, only the dominant launch group bracketed ----
     set_timer(dom)
-    # a step = PPS pictures = one intra period.  weak: --steps intra periods per rank, each rank its own stream; strong: --steps
-    # intra periods of ONE stream in total, its GOPs dealt to the ranks (the rank's share is rounded down to whole pictures and
-    # the total says what was decoded)
     strong = world > 1 and args.scaling == "strong"
-    steps_rank = args.steps * PPS if not strong else max(1, args.steps * PPS // world)          # pictures this rank decodes
-    dt = timed(steps_rank)
+    if world > 1:
+        st_main.close()
+        gops_rank = args.steps * (IP // G) if not strong else max(1, args.steps * (IP // G) // world)
+        warm_gops = max(1, args.warmup) * (IP // G)
+        tpics, tspics = build((warm_gops + gops_rank) * world, world, args.dealing, 1)
+        tarr = engine.Stream.pics_array(tspics)
+        NT = len(tspics)
+        st_t = new_stream(S, output=args.output, xfer=xfer)
+        n_warm = 1 + warm_gops * world * G
+        res, _ = st_t.run(tarr, NT, 0, n_warm, flags=capi.STREAM_KEEP)
+        barrier()
+        t0 = time.perf_counter()
+        res, _ = st_t.run(tarr, NT, n_warm, NT - n_warm, flags=capi.STREAM_KEEP)
+        barrier()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device=None if debug_gloo else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        n_timed_rank = int(res.n_decoded)
+        n_timed_all = NT - n_warm
+        xfers = [int(res.n_sent), int(res.n_received)]
+        count(res)
+    else:
+        st_t = new_stream(S, output=args.output) if args.output != "none" else st_main
+        if st_t is not st_main:
+            # continue the SAME stream on the driver that has the output thread: the pictures st_main kept are in the DPB under its
+            # keys, so this driver starts a stream of its own -- one I picture, then warm-up of its own
+            cur_t = [0]
+            tpics, tspics = build((max(1, args.warmup) + args.steps) * (IP // G), 1, args.dealing, L)
+            tarr = engine.Stream.pics_array(tspics)
+            NT = len(tspics)
+            n_warm = 1 + max(1, args.warmup) * PPS
+            st_t.run(tarr, NT, 0, n_warm, flags=capi.STREAM_KEEP)
+        else:
+            tarr, NT, n_warm = larr, NL, cur[0]
+        barrier()
+        t0 = time.perf_counter()
+        res, _ = st_t.run(tarr, NT, n_warm, args.steps * PPS, flags=capi.STREAM_KEEP)
+        barrier()
+        dt = time.perf_counter() - t0
+        if st_t is st_main:
+            cur[0] += args.steps * PPS
+        n_timed_rank = n_timed_all = args.steps * PPS
+        assert int(res.n_decoded) == n_timed_rank
+        xfers = [0, 0]
+        count(res)
     dom_avg = read_timer()
     set_timer(None)
     ms_per_step = dt * 1e3 / args.steps
-    fps = world * steps_rank / dt
+    fps = n_timed_all / dt
+    lib_seconds = float(res.seconds)
+    dpb_stats = dpb.stats()
+    if world > 1:
+        st_main = new_stream(S)
+        cur[0] = 0
+        lpics, lspics = build(n_loc_gops, 1, args.dealing, 1)
+        larr = engine.Stream.pics_array(lspics); NL = len(lspics)
+        count(run_local(st_main, 1 + G)[0])
 
-    # secondary figure: the round-1 measurement (device-resident replay of the same command buffers, no H2D / D2H)
-    dt_res = timed(min(steps_rank, 120), resident=True)
-    fps_res = world * min(steps_rank, 120) / dt_res
+    # ---- variants: the same stream through the same call with other things inside the timed region ----
+    def timed_variant(st, n_pics, flags=0, warm=True):
+        arr, n = larr, NL
+        first = 0
+        nw = 1 + G
+        st.run(arr, n, 0, nw, flags=flags | capi.STREAM_KEEP)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        r, _ = st.run(arr, n, nw, n_pics, flags=flags | capi.STREAM_KEEP)
+        torch.cuda.synchronize(dev)
+        return n_pics / (time.perf_counter() - t0), r
 
+    fps_res = None
+    if rank == 0 and not args.no_isolated_survey:
+        nv = 2 * PPS
+        for mode in ("none", "digest", "frame"):
+            if mode == args.output and world == 1:
+                variants["output_" + mode] = round(fps, 1)
+                continue
+            stv = new_stream(S, output=mode)
+            f, r = timed_variant(stv, nv)
+            variants["output_" + mode] = round(f, 1)
+            if mode == "frame":
+                variants["output_frame_d2h_GBps"] = round(f * FB / 1e9, 2)
+            stv.close()
+        # the device-resident replay of the same command buffers (no H2D / D2H): r1's measurement, inputs resident in HBM
+        f, r = timed_variant(st_main, nv, flags=capi.STREAM_RESIDENT)
+        fps_res = f
+        rec = {}
+        for t in [int(x) for x in args.record_threads.split(",") if x]:
+            stv = new_stream(t, output=args.output, flags=capi.STREAM_RECORD, use_jobs=False)
+            n = max(G, min(nv, 24 * t))
+            f, r = timed_variant(stv, n)
+            rec[str(t)] = {"fps": round(f, 1), "record_ms_per_picture": round(1e3 * r.record_seconds / max(1, n + 1 + G), 3)}
+            stv.close()
+        variants["recorded_in_run"] = {"what": "recorder_in_timed_region: true -- every frame thread replays the picture's call log (all ovhip_rec_* "
+                                               "calls of the picture: what a parse thread does minus CABAC) into its own job, then submits; fps by number of "
+                                               "frame threads", "by_threads": rec}
+    barrier()
+
+    # ---- check: the device against the oracle on the first pictures of the stream; in flight vs one at a time on two GOPs ----
     check = None
-    if args.check > 0 and world == 1:
-        def from_the_start():
-            gop_base[0] = 0
-            for k, (_t, pk) in enumerate(bufs_key):
-                pk.upload(*wls[0].refs[k % n_ref_slots])
-            torch.cuda.synchronize(dev)
-        da, db = {}, {}
-        from_the_start()
-        run_steps(args.check, digests=da)
-        barrier()
-        from_the_start()
-        one_at_a_time[0] = True
-        run_steps(args.check, digests=db)
-        one_at_a_time[0] = False
-        barrier()
-        bad = [i for i in da if da[i] != db.get(i)]
-        check = {"pictures": len(da), "differ": len(bad), "distinct_digests": len(set(da.values())),
-                 "what": f"{S} pictures in flight vs one at a time, same stream from the same start, ovhip_pic_digest of every picture"}
-        if bad:
-            raise SystemExit(f"bench --check: pictures {sorted(bad)[:16]} decode differently with {S} pictures in flight")
+    if args.check > 0 and rank == 0:
+        sys.path.insert(0, str(ROOT / "oracle"))
+        import oracle_pipeline
+        import ovvc_oracle_output as oo
+        nck = min(args.check, 1 + G)
+        stc = new_stream(S)
+        n2 = 1 + 2 * G
+        _, dga = stc.run(larr, NL, 0, n2, digests=True)
+        st1 = new_stream(1)
+        _, dgb = st1.run(larr, NL, 0, n2, digests=True)
+        st1.close(); stc.close()
+        differ_self = int((dga != dgb).any(axis=1).sum())
+        planes, differ = [], 0
+        t0 = time.perf_counter()
+        for i in range(nck):
+            p = lspics[i]
+            wl = wls[p["content"]]
+            saved = list(wl.refs)
+            if p["refs"]:
+                for k in range(len(wl.refs)):
+                    wl.refs[k] = planes[p["refs"][k % len(p["refs"])]] if p["refs"][k % len(p["refs"])] < len(planes) else None
+            if any(r is None for r in wl.refs):
+                wl.refs[:] = saved
+                break
+            o = oracle_pipeline.decode(wl)
+            wl.refs[:] = saved
+            planes.append((o.y, o.cb, o.cr))
+            differ += bytes(dga[i]) != oo.picture_digest(o.y, o.cb, o.cr)
+        check = {"pictures_vs_oracle": len(planes), "differ": differ + differ_self,
+                 "oracle_seconds": round(time.perf_counter() - t0, 1),
+                 "pictures_in_flight_vs_one_at_a_time": n2, "differ_in_flight": differ_self,
+                 "what": f"the first {len(planes)} pictures of the stream (decoding order: I picture, then the first GOP's top layers) decoded by the "
+                         f"oracle one at a time from its OWN reference pictures vs the device's digests with {S} pictures in flight; and {n2} pictures "
+                         f"{S} in flight vs one at a time"}
+        if differ or differ_self:
+            raise SystemExit(f"bench --check: {differ} pictures differ from the oracle, {differ_self} differ between in-flight counts")
 
     if rank == 0:
         algs = [algorithmic_bytes(wl, FB) for wl in wls]
-        use = np.bincount([len(wls) - 1 if (j == 0 and G % IP == 0) else j % n_b for j in range(K)], minlength=len(wls)).astype(np.float64)
-        if IP > G:
-            use[len(wls) - 1] *= G / IP; use[0] += 1.0 - G / IP
+        use = np.zeros(len(wls))
+        for p in lspics[1:1 + 4 * PPS]:
+            use[p["content"]] += 1
         use /= use.sum()
         alg = {k: float(sum(u * a[k] for u, a in zip(use, algs))) for k in algs[0]}
         alg = {k: v for k, v in alg.items() if k in kern}
-        achieved = alg[dom] / dom_avg / 1e9
-        traffic = rocprof_avg = None
+        tj = None
         try:
             tj = json.loads((ROOT / "profiles" / "traffic.json").read_text())
-            if tj["workload"] == {"width": W, "height": H, "seed": args.seed}:
-                names = [n.strip() for n in KNAME[dom].split("(")[0].split("+")]
-                ks = [tj["kernels"][n] for n in names]
-                # a launch group = one dispatch, except the ordered pass: one per level, averaged over the intra period
-                per_group = (wls[-1].stats["n_ilevels"] + (IP - 1) * wls[0].stats["n_ilevels"]) / IP if dom == "intra" else 1
-                traffic = int(sum(2 * k["fetch_kib"] + k["write_kib"] for k in ks) * 1024 * per_group)
-                if dom != "intra" and all("trace_avg_us" in k for k in ks):
-                    rocprof_avg = round(sum(k["trace_avg_us"] for k in ks), 2)
+            if tj["workload"] != {"width": W, "height": H, "seed": args.seed}:
+                tj = None
         except (OSError, KeyError, ValueError):
-            traffic = None
-        roofline = {"bound": "hbm", "kernel": KNAME[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                    "avg_launch_us": round(dom_avg * 1e6, 2),
-                    # the committed rocprofv3 --kernel-trace average of the same command (profiles/, every launch in the timed
-                    # configuration): execution only -- the HIP events of avg_launch_us also see the dispatch waiting in its
-                    # hardware queue behind the other streams' packets (DESIGN 5)
-                    "rocprof_avg_launch_us": rocprof_avg,
-                    "frac_at_rocprof_duration": round(alg[dom] / rocprof_avg / 1e3 / HBM_PEAK_GBPS, 5) if rocprof_avg else None,
-                    "picked_from": "survey in the timed configuration (same rotation and pictures in flight)",
+            tj = None
+
+        def traffic_of(name):
+            """(HBM bytes per launch group from the committed PMC passes, rocprofv3 kernel-trace average us) or (None, None)"""
+            if tj is None:
+                return None, None
+            try:
+                names = [n.strip() for n in KNAME[name].split("(")[0].split("+")]
+                ks = [tj["kernels"][n] for n in names]
+                per_pic = 1.0
+                if name == "intra":
+                    # the ordered pass: the counters are per dispatch, a picture has several (flow chunks); averaged over the stream
+                    per_pic = ks[0]["dispatches"] / max(1, tj["kernels"]["k_alf"]["dispatches"])
+                t = int(sum(2 * k["fetch_kib"] + k["write_kib"] for k in ks) * 1024 * per_pic)
+                avg = round(sum(k["trace_avg_us"] for k in ks) * per_pic, 2) if all("trace_avg_us" in k for k in ks) else None
+                return t, avg
+            except (KeyError, ZeroDivisionError):
+                return None, None
+
+        def roof(name, avg_s):
+            tr, ravg = traffic_of(name)
+            a = alg[name] / avg_s / 1e9
+            d = {"kernel": KNAME[name], "achieved": round(a, 2), "frac": round(a / HBM_PEAK_GBPS, 5), "avg_launch_us": round(avg_s * 1e6, 2),
+                 "traffic": tr, "rocprof_avg_launch_us": ravg,
+                 "frac_at_rocprof_duration": round(alg[name] / ravg / 1e3 / HBM_PEAK_GBPS, 5) if ravg else None,
+                 "frac_isolated": round(alg[name] / isolated[name] / 1e9 / HBM_PEAK_GBPS, 5) if name in isolated and isolated[name] > 0 else None}
+            return d
+
+        rd = roof(dom, dom_avg)
+        roofline = {"bound": "hbm", "kernel": rd["kernel"], "achieved": rd["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": rd["frac"],
+                    "traffic": rd["traffic"], "avg_launch_us": rd["avg_launch_us"], "rocprof_avg_launch_us": rd["rocprof_avg_launch_us"],
+                    "frac_at_rocprof_duration": rd["frac_at_rocprof_duration"], "frac_isolated": rd["frac_isolated"],
+                    "picked_from": "survey in the timed configuration (same jobs and pictures in flight): the launch group with the largest stream time "
+                                   "per picture, the ordered pass included"
+                                   + ("; it is a dependency chain (levels x latency per level, DESIGN 4.1): per launch = per picture" if dom == "intra" else ""),
+                    "largest_streaming_kernel": roof(stream_dom, kern[stream_dom]) if stream_dom != dom else None,
                     "survey_launch_us": {k: round(v * 1e6, 2) for k, v in survey.items()},
-                    "frac_per_kernel": {k: round(alg[k] / kern[k] / 1e9 / HBM_PEAK_GBPS, 5) for k in alg},
+                    "frac_per_kernel": {k: round(alg[k] / kern[k] / 1e9 / HBM_PEAK_GBPS, 5) for k in alg if kern[k] > 0},
                     "isolated_launch_us": {k: round(v * 1e6, 2) for k, v in isolated.items()},
-                    "frac_isolated_per_kernel": {k: round(alg[k] / isolated[k] / 1e9 / HBM_PEAK_GBPS, 5) for k in alg if k in isolated and k != "intra"},
-                    "frac_isolated": round(alg[dom] / isolated[dom] / 1e9 / HBM_PEAK_GBPS, 5) if dom in isolated else None,
-                    "ordered_pass": ({"kernel": KNAME["intra"], "bound": "latency (dependency chain, DESIGN 4.1)",
-                                      "avg_us_per_picture_timed": round(kern["intra"] * 1e6, 2),
-                                      "avg_us_per_picture_isolated": round(isolated.get("intra", 0.0) * 1e6, 2),
-                                      "levels_per_i_picture": int(wls[-1].stats["n_ilevels"]), "levels_per_b_picture": int(wls[0].stats["n_ilevels"])}
-                                     if "intra" in kern else None),
+                    "frac_isolated_per_kernel": {k: round(alg[k] / isolated[k] / 1e9 / HBM_PEAK_GBPS, 5) for k in alg if k in isolated and isolated[k] > 0},
+                    "ordered_pass": ({"levels_per_i_picture": int(wls[-1].stats["n_ilevels"]), "levels_per_b_picture": int(wls[0].stats["n_ilevels"]),
+                                      "us_per_level_i_picture_isolated": None} if "intra" in kern else None),
                     "algorithmic_bytes": {k: int(v) for k, v in alg.items()},
                     "frame_frac": round(sum(alg.values()) * fps / world / 1e9 / HBM_PEAK_GBPS, 5)}
 
@@ -541,28 +572,37 @@ def main():
             [t.start() for t in th]
             [t.join() for t in th]
             t_all = time.perf_counter() - t1
+            cal = _calibration()
             cpu = {"value": round(nthr / t_all, 3), "unit": "frames/s", "cores": nthr, "kind": "port",
                    "value_1_thread": round(1.0 / t_one, 4),
                    "sample": f"oracle/liboracle.so (scalar C restatement of the rcn path) decoding the same {W}x{H} recorded "
                              f"picture: once on 1 thread ({t_one:.2f} s), then {nthr} pictures on {nthr} threads, one picture "
                              f"per thread as the reference's frame threads do ({t_all:.2f} s); {ncpu} logical cores present",
-                   "calibration": _calibration()}
+                   "calibration": cal}
+            est = _reference_estimates(cal, nthr / t_all)
+            if est:
+                cpu.update(est)
 
         st = wls[0].stats
         js = flush_stats
         out = {
             "metric": "decoded frames/sec, full rcn back-end decode step (H2D of the recorded picture + MC incl. BDOF/DMVR/"
-                      "affine-PROF/GPM/CIIP + LMCS + inverse transform + ordered intra pass + deblocking + SAO + ALF/CC-ALF + D2H of refined MVs), "
-                      "4K 10-bit RA recorded picture, bit-exact vs oracle",
+                      "affine-PROF/GPM/CIIP + LMCS + inverse transform + ordered intra pass + deblocking + SAO + ALF/CC-ALF + D2H of refined MVs "
+                      "+ wait + per-picture digest + publication to the device DPB), 4K 10-bit RA recorded stream, bit-exact vs oracle",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None, "dtype": "u16 samples / int16 coefficients / int32 accumulate", "data": "synthetic",
-            "config": {"pictures_per_step": PPS, "pictures_per_rank": steps_rank,
+            "config": {"pictures_per_step": PPS, "pictures_timed": n_timed_all, "pictures_timed_this_rank": n_timed_rank,
                        "workload": f"{W}x{H} 10-bit 4:2:0 synthetic recorded random-access stream (BASELINE configs[3]): GOP {G} "
                                    f"(hierarchical B, JVET decoding order), intra period {IP}: per GOP {G - 1} B pictures with "
                                    f"{args.intra_frac:.0%} intra CUs + the key picture ({'I' if G % IP == 0 else 'I every ' + str(IP // G) + ' GOPs, else B'}); "
-                                   f"reference pictures = the decoded pictures of the GOP structure; seeds "
-                                   f"{[hex(w.seed) for w in wls]}, per-picture flush in C (ovhip_job_flush)",
+                                   f"reference pictures = the decoded pictures of the GOP structure (device DPB); seeds "
+                                   f"{[hex(w.seed) for w in wls]}",
+                       "timed_region": "one call of ovhip_stream_run (C, pthreads): frame threads take the pictures in decoding order, "
+                                       "ovhip_frame_submit each (uploads -> host wait for the reference pictures -> launches -> ovhip_job_wait -> output -> publish)",
+                       "timed_region_library_seconds": round(lib_seconds, 4),
+                       "output": args.output, "recorder_in_timed_region": False,
+                       "variants": variants,
                        "gop_size": G, "intra_period": IP,
                        "dependency_critical_path_pictures": round(gop.critical_path(gop.build_stream(4 * world, G, IP, world)), 1),
                        "intra_tasks_per_b_picture": st["n_itasks"], "intra_levels_per_b_picture": st["n_ilevels"],
@@ -570,24 +610,24 @@ def main():
                        "h2d_bytes_per_step": int(mean_stat("h2d_bytes")), "d2h_bytes_per_step": int(mean_stat("d2h_bytes")),
                        "ordered_pass_second_passes": second_passes[0],
                        "check": check,
-                       "launches_per_step": round((int(all_stats[0].n_launches) + (IP - 1) * int(js.n_launches)) / IP, 1),
-                       "h2d_copies_per_step": round(mean_stat("n_h2d"), 1),
                        "launches_per_b_picture": int(js.n_launches),
-                       "launches_per_i_picture": int(all_stats[0].n_launches),
-                       "distinct_pictures": K, "distinct_contents": len(wls), "working_set_bytes": int(working_set),
-                       "pictures_in_flight_per_gpu": S,
-                       "host_threads": nthreads,
-                       "picture_assignment": "decoding order; a free host thread takes the next picture, waits (stream events) for "
-                                             "its reference pictures, flushes it and waits for it (as the shim does)",
-                       "recorder_in_timed_region": False,
+                       "launches_per_i_picture": int(all_stats[n_jobs].n_launches),
+                       "h2d_copies_per_step": round(mean_stat("n_h2d"), 1),
+                       "pre_recorded_jobs": len(jobs), "distinct_contents": len(wls),
+                       "working_set_bytes": int((dpb_stats.n_live + dpb_stats.n_pool) * FB + len(jobs) * FB),
+                       "dpb": {"device_pictures_allocated": int(dpb_stats.n_alloc), "begun": int(dpb_stats.n_begin), "recycled": int(dpb_stats.n_recycled),
+                               "peer_copies": int(dpb_stats.n_copies), "waits_for_a_reference": int(dpb_stats.n_waits)},
+                       "pictures_in_flight_per_gpu": S, "host_threads": S, "local_devices": L,
+                       "picture_assignment": "decoding order; a free frame thread (pthread, own HIP stream) takes the next picture of its device",
                        "n_cu": st["n_cu"], "cu_modes": st["cu_modes"], "n_mc_units": st["n_mc_units"],
                        "n_mcx_units": st["n_mcx_units"], "n_aff_units": st["n_aff_units"], "n_tb_cmds": st["n_tb_cmds"],
                        "r_bar": round(st["r_bar"], 3), "coef_bytes": st["coef_bytes"],
                        "frame_algorithmic_bytes": int(sum(alg.values())),
-                       "resident_replay_fps": round(fps_res, 2),
-                       "parallelism": f"{S} pictures in flight per GPU" + (f"; a GOP per GPU over {world} GPUs, the key picture of a GOP "
-                                      "sent to the owner of the next GOP with RCCL point-to-point on a communication stream (no "
-                                      "collective, nothing waited for on the host)" if world > 1 else "")},
+                       "resident_replay_fps": round(fps_res, 2) if fps_res else None,
+                       "transfers_this_rank": {"sent": xfers[0], "received": xfers[1], "bytes_sent": n_xfer_bytes[0]},
+                       "parallelism": f"{S} pictures in flight per GPU" + (f"; {args.dealing} dealing over {world} GPUs (one process per GPU), pictures other ranks "
+                                      "list sent with RCCL point-to-point from the driver's comm thread (no collective)" if world > 1 else "")
+                                      + (f"; ONE process, {L} logical devices ({args.dealing} dealing), reference pictures by event-ordered hipMemcpyPeerAsync" if L > 1 else "")},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
@@ -597,11 +637,32 @@ def main():
 
 
 def _calibration():
-    """Reference scalar C vs the oracle port on identical slot-level cases, timed in the build container (committed; the
+    """Reference scalar C (and SIMD) vs the oracle port on identical slot-level cases, timed in the build container (committed; the
     reference does not travel to the GPU box)."""
     try:
         return json.loads((ROOT / "profiles" / "cpu_calibration.json").read_text())
     except (OSError, ValueError):
+        return None
+
+
+def _reference_estimates(cal, port_fps):
+    """port frames/s -> what the reference's scalar / SIMD slots would reach on the same host: the port's time is split over the stages
+    in the proportions the port spends there on a 4K B picture (profiles/cpu_calibration.json: picture_share), each stage divided by its
+    measured port-over-reference ratio."""
+    try:
+        share = cal["picture_share"]
+        st = cal["stages"]
+        out = {}
+        for key, name in (("port_over_reference", "reference_scalar_estimate"), ("port_over_reference_simd", "reference_simd_estimate")):
+            if not all(key in st[k] for k in share):
+                continue
+            t = sum(share[k] / st[k][key] for k in share)
+            out[name] = round(port_fps / t, 2)
+        if out:
+            out["estimate_method"] = ("value x (sum over stages of the port's time share / measured port-over-reference ratio)^-1, ratios from "
+                                      "profiles/cpu_calibration.json (reference's own slots timed in the build container on the fixture cases)")
+        return out
+    except (KeyError, TypeError, ZeroDivisionError):
         return None
 
 

@@ -669,6 +669,7 @@ int  ovhip_malloc(ovhip_ctx *ctx, size_t bytes, void **dptr);
 int  ovhip_free(ovhip_ctx *ctx, void *dptr);
 int  ovhip_h2d(ovhip_ctx *ctx, void *dptr, const void *host, size_t bytes);
 int  ovhip_d2h(ovhip_ctx *ctx, void *host, const void *dptr, size_t bytes);
+int  ovhip_d2d(ovhip_ctx *ctx, void *dst, const void *src, size_t bytes);     /* synchronous */
 /* page-locked host memory (DMA source / target: output frames, recorder arrays); NULL on failure */
 void *ovhip_host_alloc(size_t bytes);
 void  ovhip_host_free(void *p);
@@ -866,7 +867,8 @@ ovhip_recorder *ovhip_job_recorder(ovhip_job *job);
 /* Waits until the previous flush no longer reads the recorder's arrays, then resets the recorder. */
 int  ovhip_job_begin(ovhip_job *job);
 /* Issues the job's next flushes on another context (= HIP stream) of the same device: a frame thread that became free takes
- * over a picture.  Waits for the job's previous flush first. */
+ * over a picture.  Waits for the job's previous flush first.  ctx == NULL: back to the context the job was created on -- a job must
+ * not stay bound to a context that may be destroyed before it (ovhip_frame_submit returns a borrowed job this way). */
 int  ovhip_job_bind(ovhip_job *job, ovhip_ctx *ctx);
 /* dst: the picture being decoded; refs[n_refs]: the table ovhip_pu_desc.ref0/ref1 index; intra: picture with the
  * caller's planar prediction for fused CIIP blends, or NULL.  All DEVICE pictures of the job's size. */
@@ -1030,8 +1032,9 @@ int  ovhip_dpb_get_stats(ovhip_dpb *d, ovhip_dpb_stats *out);
  *   ovhip_frame_dmvr_rows()         every alf.rcn_alf_filter_line: waits for the references, eager refinement (see
  *                                   ovhip_job_dmvr_rows)
  *   ovhip_frame_submit(params)      last row: uploads; waits for the references (host) while they run; launches;
- *                                   ovhip_job_wait (incl. its second pass); optional output; THEN publishes -- on every
- *                                   exit path, with the error if there was one -- and unpins the references
+ *                                   ovhip_job_wait (incl. its second pass); THEN publishes -- on every exit path, with the
+ *                                   error if there was one -- and unpins the references; then the optional output (the
+ *                                   picture's readers do not wait for it)
  * ---------------------------------------------------------------------------------- */
 typedef struct ovhip_frame ovhip_frame;
 

@@ -462,6 +462,7 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_md5_init": (None, [P(Md5State)]),
         "ovhip_md5_update": (None, [P(Md5State), vp, C.c_size_t]),
         "ovhip_md5_final": (None, [P(Md5State), vp]),
+        "ovhip_d2d": (C.c_int, [vp, vp, vp, C.c_size_t]),
         "ovhip_host_alloc": (vp, [C.c_size_t]),
         "ovhip_host_free": (None, [vp]),
         "ovhip_job_test_abort_next_flow": (C.c_int, [vp]),
@@ -526,7 +527,7 @@ EXPORTED_SYMBOLS = [
     "ovhip_job_flush", "ovhip_job_wait", "ovhip_job_refined_mvs", "ovhip_job_dmvr_rows", "ovhip_job_last_stats", "ovhip_job_time_stage", "ovhip_job_stage_time",
     "ovhip_output_bytes", "ovhip_output_rows", "ovhip_output_pack_launch", "ovhip_output_row_md5_launch", "ovhip_pic_output", "ovhip_pic_digest",
     "ovhip_md5_init", "ovhip_md5_update", "ovhip_md5_final", "ovhip_tmvp_cells_launch", "ovhip_job_tmvp_cells", "ovhip_intra_flow_untag_launch", "ovhip_lmcs_inverse_untag_launch", "ovhip_lmcs_scale_prepare_launch",
-    "ovhip_host_alloc", "ovhip_host_free", "ovhip_job_test_abort_next_flow",
+    "ovhip_host_alloc", "ovhip_host_free", "ovhip_d2d", "ovhip_job_test_abort_next_flow",
     "ovhip_dpb_create", "ovhip_dpb_create_ex", "ovhip_dpb_destroy", "ovhip_dpb_n_devices", "ovhip_dpb_device", "ovhip_dpb_begin", "ovhip_dpb_want",
     "ovhip_dpb_publish", "ovhip_dpb_acquire", "ovhip_dpb_wait_copy", "ovhip_dpb_unpin", "ovhip_dpb_release", "ovhip_dpb_lookup", "ovhip_dpb_shutdown",
     "ovhip_dpb_get_stats",

@@ -51,6 +51,7 @@ static inline int ov_fail(ovhip_ctx *ctx, int code, const char *what, hipError_t
     do {                                                                      \
         hipError_t e__ = hipSetDevice((ctx)->device);                         \
         if (e__ != hipSuccess) return ov_fail((ctx), OVHIP_ENODEV, "hipSetDevice", e__); \
+        (void)hipGetLastError();   /* the last-error slot is per thread and sticky: what OV_LAUNCH_CHECK reads must be this entry point's */ \
     } while (0)
 
 static inline int ov_scratch(ovhip_ctx *ctx, size_t dev_bytes, size_t host_bytes)

@@ -4,6 +4,37 @@
 #include "ovvc_common.hip.h"
 #include <stdlib.h>
 
+#include <pthread.h>
+
+// Streams are pooled per device, never destroyed while the process lives: an event keeps a reference to the stream it was last
+// recorded on, and on this runtime hipEventSynchronize on an event whose stream has been destroyed fails ("operation not permitted
+// when stream is capturing", tools/micro/event_after_stream_destroy.hip) -- a job's completion event must survive the frame
+// thread (context) that last flushed it.  Creating a stream also costs milliseconds; a frame thread pool that comes and goes
+// (one per sequence) gets them back at once.
+namespace {
+enum { POOL_DEVS = 64, POOL_CAP = 512 };
+pthread_mutex_t g_pool_mtx = PTHREAD_MUTEX_INITIALIZER;
+hipStream_t g_pool[POOL_DEVS][POOL_CAP];
+int g_pool_n[POOL_DEVS];
+
+hipError_t stream_get(int device, hipStream_t *out)
+{
+    pthread_mutex_lock(&g_pool_mtx);
+    if (device < POOL_DEVS && g_pool_n[device] > 0) { *out = g_pool[device][--g_pool_n[device]]; pthread_mutex_unlock(&g_pool_mtx); return hipSuccess; }
+    pthread_mutex_unlock(&g_pool_mtx);
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
+void stream_put(int device, hipStream_t s)
+{
+    pthread_mutex_lock(&g_pool_mtx);
+    const bool kept = device < POOL_DEVS && g_pool_n[device] < POOL_CAP;
+    if (kept) g_pool[device][g_pool_n[device]++] = s;
+    pthread_mutex_unlock(&g_pool_mtx);
+    if (!kept) (void)hipStreamDestroy(s);
+}
+} // namespace
+
 extern "C" {
 
 int ovhip_abi_version(void) { return OVHIP_ABI_VERSION; }
@@ -23,7 +54,7 @@ int ovhip_ctx_create(ovhip_ctx **out, int device, void *stream)
     if (stream) {
         ctx->stream = (hipStream_t)stream;
     } else {
-        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { free(ctx); return OVHIP_ENODEV; }
+        if (stream_get(device, &ctx->stream) != hipSuccess) { free(ctx); return OVHIP_ENODEV; }
         ctx->owns_stream = 1;
     }
     ctx->main_stream = ctx->stream;
@@ -34,15 +65,17 @@ int ovhip_ctx_create(ovhip_ctx **out, int device, void *stream)
 void ovhip_ctx_destroy(ovhip_ctx *ctx)
 {
     if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    // (whatever is still queued on the streams completes before they are handed to the next context)
     for (int i = 0; i < OV_MAX_LANES; ++i) {
-        if (ctx->lane[i]) (void)hipStreamDestroy(ctx->lane[i]);
+        if (ctx->lane[i]) { (void)hipStreamSynchronize(ctx->lane[i]); stream_put(ctx->device, ctx->lane[i]); }
         if (ctx->have_events) (void)hipEventDestroy(ctx->ev_lane[i]);
     }
     if (ctx->have_events) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->scratch_d || ctx->scratch_h) (void)hipSetDevice(ctx->device);
     if (ctx->scratch_d) (void)hipFree(ctx->scratch_d);
     if (ctx->scratch_h) (void)hipHostFree(ctx->scratch_h);
-    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->main_stream);
+    if (ctx->owns_stream) { (void)hipStreamSynchronize(ctx->main_stream); stream_put(ctx->device, ctx->main_stream); }
     free(ctx);
 }
 
@@ -61,7 +94,7 @@ int ovhip_ctx_fork(ovhip_ctx *ctx, int k)
         for (int i = 0; i < OV_MAX_LANES; ++i) OV_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_lane[i], hipEventDisableTiming));
         ctx->have_events = 1;
     }
-    if (!ctx->lane[k]) OV_HIP(ctx, hipStreamCreateWithFlags(&ctx->lane[k], hipStreamNonBlocking));
+    if (!ctx->lane[k]) OV_HIP(ctx, stream_get(ctx->device, &ctx->lane[k]));
     // every fork orders the lane behind everything enqueued on the main stream so far (header contract), also a
     // second fork(k) before the join
     OV_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->main_stream));
@@ -144,6 +177,18 @@ void *ovhip_host_alloc(size_t bytes)
 }
 
 void ovhip_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+/* device-to-device copy on the context's stream, complete on return (a picture to / from a staging buffer of the host harness) */
+int ovhip_d2d(ovhip_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (!ctx || (bytes && (!dst || !src))) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
+    if (bytes) {
+        OV_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        OV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return OVHIP_OK;
+}
 
 int ovhip_pic_alloc(ovhip_ctx *ctx, int32_t w, int32_t h, ovhip_pic *pic)
 {

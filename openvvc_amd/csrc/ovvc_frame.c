@@ -4,7 +4,7 @@
  * headers: context + job + the picture's place in the device DPB + its reference table, and the ORDER of a picture's end:
  *
  *     uploads enqueued -> wait for the reference pictures (host) -> launches -> ovhip_job_wait (incl. its second pass)
- *     -> output (optional) -> publish -> unpin the references
+ *     -> publish + unpin the references -> output (optional; after the wait, never before: r2 downloaded first)
  *
  * The reference's order for the same events: slicedec.c:934-956 (filters of the last rows, then ovdpb_report_decoded_ctu_line),
  * rcn_inter.c:131-146 (a reader waits for its reference's rows), dectest.c:372-409 (the application reads the frame after the
@@ -198,6 +198,12 @@ ovhip_frame_submit(ovhip_frame *f, ovhip_job *job, const ovhip_pic *intra, const
         int q = ovhip_job_wait(j);
         if (q != OVHIP_OK && r == OVHIP_OK) r = fail(f, q, "ovhip_job_wait");
     }
+    /* a borrowed job goes back to its own context: this frame (and its context) may be destroyed before the job */
+    if (job) { int q = ovhip_job_bind(job, NULL); if (q != OVHIP_OK && r == OVHIP_OK) r = fail(f, q, "ovhip_job_bind(home)"); }
+    if (f->status) r = f->status;         /* the first error, e.g. a failed reference rather than "callback failed" */
+    /* the picture is complete: its readers go on while this thread copies it out (the output only reads; whoever keeps the key
+     * alive -- the decoder's DPB, the stream driver's hold -- does so until this call returns) */
+    (void)publish(f, r);
     if (r == OVHIP_OK && out && out->mode != OVHIP_OUT_NONE) {
         switch (out->mode) {
         case OVHIP_OUT_DIGEST: r = ovhip_pic_digest(f->ctx, &f->dst, &out->window, out->digest); break;
@@ -207,7 +213,5 @@ ovhip_frame_submit(ovhip_frame *f, ovhip_job *job, const ovhip_pic *intra, const
         }
         if (r != OVHIP_OK) fail(f, r, "picture output");
     }
-    if (f->status) r = f->status;         /* the first error, e.g. a failed reference rather than "callback failed" */
-    (void)publish(f, r);
     return r;
 }

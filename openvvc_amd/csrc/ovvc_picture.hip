@@ -25,6 +25,7 @@ struct ParamLayout { size_t sao, alf_ctus, lcoef, lclip, ccoef, cclip, cc, fwd, 
 
 struct ovhip_job {
     ovhip_ctx *ctx;
+    ovhip_ctx *home;                     // the context the job was created on (ovhip_job_bind(job, NULL) returns to it)
     int32_t w, h;
     ovhip_recorder *rec;
     DevBuf dev[B_COUNT];
@@ -154,7 +155,7 @@ int ovhip_job_create(ovhip_ctx *ctx, int32_t w, int32_t h, ovhip_job **out)
     *out = nullptr;
     ovhip_job *j = (ovhip_job *)calloc(1, sizeof(*j));
     if (!j) return OVHIP_ENOMEM;
-    j->ctx = ctx; j->w = w; j->h = h; j->t_stage = -1;
+    j->ctx = ctx; j->home = ctx; j->w = w; j->h = h; j->t_stage = -1;
     const ovhip_allocator al = { pinned_alloc, pinned_free, nullptr };
     j->rec = ovhip_rec_create_ex(w, h, &al);
     if (!j->rec) { free(j); return OVHIP_ENOMEM; }
@@ -202,10 +203,15 @@ int ovhip_job_begin(ovhip_job *j)
 
 int ovhip_job_bind(ovhip_job *j, ovhip_ctx *ctx)
 {
-    if (!j || !ctx) return OVHIP_EINVAL;
-    if (ctx->device != j->ctx->device) return ov_fail(j->ctx, OVHIP_EINVAL, "ovhip_job_bind: context of another device", hipSuccess);
-    OV_DEVICE(j->ctx);
-    if (j->flushed) OV_HIP(j->ctx, hipEventSynchronize(j->ev_done));
+    if (!j) return OVHIP_EINVAL;
+    if (!ctx) ctx = j->home;             // back to the context it was created on (which outlives it by contract)
+    // (errors go to the context the caller holds)
+    if (ctx->device != j->ctx->device) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_job_bind: context of another device", hipSuccess);
+    OV_DEVICE(ctx);
+    if (j->flushed) {
+        hipError_t e = hipEventSynchronize(j->ev_done);
+        if (e != hipSuccess) return ov_fail(ctx, OVHIP_ELAUNCH, "ovhip_job_bind: hipEventSynchronize(previous flush)", e);
+    }
     j->ctx = ctx;
     return OVHIP_OK;
 }

@@ -42,6 +42,10 @@ struct ovhip_stream {
     uintptr_t key_base;
     uint32_t *holds;                      /* per picture: decode / receive + local readers + output + sends still to come */
     unsigned char *alive;                 /* begun in the DPB and not released yet */
+    unsigned char *begun;                 /* has entered the DPB at some point (the output / comm threads wait for that before they
+                                           * ask the DPB for it: a key the DPB never saw is an error there, not a wait) */
+    pthread_mutex_t begun_mtx; pthread_cond_t begun_cnd;
+    uint8_t *dg;                          /* OVHIP_OUT_DIGEST: the pictures' digests, computed by their frame threads (begun[idx] == 2: there) */
 };
 
 struct dev_queue { uint32_t *order; uint32_t n, next; pthread_mutex_t take; };
@@ -76,6 +80,30 @@ run_fail(struct run_state *rs, int code, const char *what, const char *detail)
     pthread_mutex_unlock(&rs->mtx);
     rs->abort = 1;
     ovhip_dpb_shutdown(rs->s->dpb);        /* nobody keeps waiting for a picture that will not come */
+    pthread_mutex_lock(&rs->s->begun_mtx);
+    pthread_cond_broadcast(&rs->s->begun_cnd);
+    pthread_mutex_unlock(&rs->s->begun_mtx);
+}
+
+static void
+mark_begun(ovhip_stream *s, uint32_t idx)
+{
+    pthread_mutex_lock(&s->begun_mtx);
+    s->alive[idx] = 1; s->begun[idx] = 1;
+    pthread_cond_broadcast(&s->begun_cnd);
+    pthread_mutex_unlock(&s->begun_mtx);
+}
+
+/* 0 once picture idx has entered the DPB, != 0 when the run was aborted first */
+static int
+wait_begun(struct run_state *rs, uint32_t idx)
+{
+    ovhip_stream *s = rs->s;
+    pthread_mutex_lock(&s->begun_mtx);
+    while (!s->begun[idx] && !rs->abort) pthread_cond_wait(&s->begun_cnd, &s->begun_mtx);
+    const int ok = s->begun[idx];
+    pthread_mutex_unlock(&s->begun_mtx);
+    return !ok;
 }
 
 static void
@@ -105,8 +133,8 @@ release_stream(ovhip_stream *s)
 {
     for (uint32_t i = 0; i < s->n_total; ++i)
         if (s->alive && s->alive[i]) { s->alive[i] = 0; (void)ovhip_dpb_release(s->dpb, key_of(s, i)); }
-    free(s->holds); free(s->alive);
-    s->holds = NULL; s->alive = NULL;
+    free(s->holds); free(s->alive); free(s->begun); free(s->dg);
+    s->holds = NULL; s->alive = NULL; s->begun = NULL; s->dg = NULL;
     s->key_base += (uintptr_t)s->n_total + 1;
     s->pics = NULL; s->n_total = 0;
 }
@@ -117,7 +145,9 @@ adopt_stream(ovhip_stream *s, const ovhip_stream_pic *pics, uint32_t n_total, ui
     release_stream(s);
     s->holds = (uint32_t *)calloc(n_total ? n_total : 1, sizeof(uint32_t));
     s->alive = (unsigned char *)calloc(n_total ? n_total : 1, 1);
-    if (!s->holds || !s->alive) return OVHIP_ENOMEM;
+    s->begun = (unsigned char *)calloc(n_total ? n_total : 1, 1);
+    s->dg = (uint8_t *)calloc(n_total ? n_total : 1, 16);
+    if (!s->holds || !s->alive || !s->begun || !s->dg) return OVHIP_ENOMEM;
     for (uint32_t i = 0; i < n_total; ++i) {
         const ovhip_stream_pic *p = &pics[i];
         if (p->content >= s->n_contents || p->device >= (uint32_t)s->n_dev || p->n_refs > OVHIP_STREAM_MAX_REFS) return OVHIP_EINVAL;
@@ -150,7 +180,7 @@ decode_picture(struct run_state *rs, ovhip_frame *f, uint32_t idx, int job_locke
     ovhip_job *job = record ? NULL : s->jobs[p->job];
     int r = ovhip_frame_begin(f, key_of(s, idx));
     if (r != OVHIP_OK) { run_fail(rs, r, "ovhip_frame_begin", ovhip_frame_last_error(f)); goto out; }
-    s->alive[idx] = 1;
+    mark_begun(s, idx);
     for (uint32_t k = 0; p->n_refs && k < c->n_ref_slots && r >= 0; ++k) r = ovhip_frame_ref_at(f, (int)k, key_of(s, p->refs[k % p->n_refs]));
     if (r < 0) { (void)ovhip_frame_fail(f, r); run_fail(rs, r, "ovhip_frame_ref_at", ovhip_frame_last_error(f)); goto out; }
     if (record) {
@@ -168,11 +198,20 @@ decode_picture(struct run_state *rs, ovhip_frame *f, uint32_t idx, int job_locke
         if (pr.stages == STAGE_ALL) pr.stages = 0;
         ovhip_frame_output out;
         memset(&out, 0, sizeof(out));
-        out.mode = (rs->flags & OVHIP_STREAM_DIGESTS) ? OVHIP_OUT_DIGEST : OVHIP_OUT_NONE;
+        /* the fingerprint is taken by the picture's own frame thread, after the picture was published (16 threads hash 16 pictures;
+         * the output thread only puts them in output order) */
+        out.mode = ((rs->flags & OVHIP_STREAM_DIGESTS) || s->cfg.output == OVHIP_OUT_DIGEST) ? OVHIP_OUT_DIGEST : OVHIP_OUT_NONE;
         out.window = s->cfg.window;
         r = ovhip_frame_submit(f, job, NULL, &pr, &out);
         if (r != OVHIP_OK) { run_fail(rs, r, "ovhip_frame_submit", ovhip_frame_last_error(f)); goto out; }
-        if (out.mode == OVHIP_OUT_DIGEST && rs->digests) memcpy(rs->digests + 16 * (size_t)(idx - rs->first), out.digest, 16);
+        if (out.mode == OVHIP_OUT_DIGEST) {
+            if (rs->digests) memcpy(rs->digests + 16 * (size_t)(idx - rs->first), out.digest, 16);
+            pthread_mutex_lock(&s->begun_mtx);
+            memcpy(s->dg + 16 * (size_t)idx, out.digest, 16);
+            s->begun[idx] = 2;
+            pthread_cond_broadcast(&s->begun_cnd);
+            pthread_mutex_unlock(&s->begun_mtx);
+        }
         ovhip_job_stats st;
         if (ovhip_job_last_stats(job ? job : ovhip_frame_job(f), &st) == OVHIP_OK) {
             pthread_mutex_lock(&rs->mtx);
@@ -226,19 +265,25 @@ output_thread(void *argp)
         const uint32_t idx = rs->out_order[k];
         const ovhip_stream_pic *p = &rs->pics[idx];
         ovhip_pic pic;
+        if (s->cfg.output == OVHIP_OUT_DIGEST) {
+            pthread_mutex_lock(&s->begun_mtx);
+            while (s->begun[idx] != 2 && !rs->abort) pthread_cond_wait(&s->begun_cnd, &s->begun_mtx);
+            const int ok = s->begun[idx] == 2;
+            pthread_mutex_unlock(&s->begun_mtx);
+            if (!ok) break;
+            ovhip_md5_update(&rs->md5, s->dg + 16 * (size_t)idx, 16);
+            rs->res->out_bytes += 16; rs->res->out_frames++;
+            drop_hold(s, idx);
+            continue;
+        }
+        if (wait_begun(rs, idx)) break;
         int r = ovhip_dpb_acquire(s->dpb, key_of(s, idx), p->device, &pic, NULL);
         if (r != OVHIP_OK) { if (!rs->abort) run_fail(rs, r, "output: picture not available", ""); break; }
         ovhip_ctx *ctx = s->out_ctx[p->device];
-        if (s->cfg.output == OVHIP_OUT_PACKED) {
-            r = ovhip_pic_output(ctx, &pic, &s->cfg.window, s->out_host);
-            if (r == OVHIP_OK) {
-                if (rs->flags & OVHIP_STREAM_FILE_MD5) ovhip_md5_update(&rs->md5, s->out_host, s->out_host_bytes);
-                rs->res->out_bytes += s->out_host_bytes;
-            }
-        } else {
-            uint8_t dg[16];
-            r = ovhip_pic_digest(ctx, &pic, &s->cfg.window, dg);
-            if (r == OVHIP_OK) { ovhip_md5_update(&rs->md5, dg, 16); rs->res->out_bytes += 16; }
+        r = ovhip_pic_output(ctx, &pic, &s->cfg.window, s->out_host);
+        if (r == OVHIP_OK) {
+            if (rs->flags & OVHIP_STREAM_FILE_MD5) ovhip_md5_update(&rs->md5, s->out_host, s->out_host_bytes);
+            rs->res->out_bytes += s->out_host_bytes;
         }
         (void)ovhip_dpb_unpin(s->dpb, key_of(s, idx));
         if (r != OVHIP_OK) { run_fail(rs, r, "output", ovhip_last_error(ctx)); break; }
@@ -261,6 +306,7 @@ comm_thread(void *argp)
         if (p->owner == rank) {
             if (!p->send_mask) continue;
             ovhip_pic pic;
+            if (wait_begun(rs, idx)) break;
             int r = ovhip_dpb_acquire(s->dpb, key_of(s, idx), p->device, &pic, NULL);
             if (r != OVHIP_OK) { if (!rs->abort) run_fail(rs, r, "send: picture not available", ""); break; }
             for (uint32_t m = p->send_mask; m && r == OVHIP_OK; m &= m - 1) {
@@ -275,7 +321,7 @@ comm_thread(void *argp)
             const int dev = 0;           /* one process per GPU: its only device */
             int r = ovhip_dpb_begin(s->dpb, key_of(s, idx), dev, s->cfg.w, s->cfg.h, &pic);
             if (r != OVHIP_OK) { run_fail(rs, r, "recv: ovhip_dpb_begin", ""); break; }
-            s->alive[idx] = 1;
+            mark_begun(s, idx);
             r = x->recv(x->user, idx, &pic, p->owner);
             (void)ovhip_dpb_publish(s->dpb, key_of(s, idx), r);
             if (r != OVHIP_OK) { run_fail(rs, r, "xfer.recv", ""); break; }
@@ -296,9 +342,12 @@ ovhip_stream_create(ovhip_stream **out, ovhip_dpb *dpb, const ovhip_stream_cfg *
     *out = NULL;
     ovhip_stream *s = (ovhip_stream *)calloc(1, sizeof(*s));
     if (!s) return OVHIP_ENOMEM;
+    pthread_mutex_init(&s->begun_mtx, NULL); pthread_cond_init(&s->begun_cnd, NULL);
     s->dpb = dpb; s->cfg = *cfg; s->contents = contents; s->n_contents = n_contents; s->jobs = jobs; s->n_jobs = n_jobs;
     s->n_dev = ovhip_dpb_n_devices(dpb); s->tpd = cfg->threads_per_device;
-    s->key_base = 0x100000;
+    /* several stream objects may share one DPB (bench.py: one per configuration): each gets a key space of its own */
+    static uintptr_t next_space = 1;
+    s->key_base = __atomic_fetch_add(&next_space, 1, __ATOMIC_RELAXED) << 40;
     int r = OVHIP_OK;
     s->frames = (ovhip_frame **)calloc((size_t)s->n_dev * s->tpd, sizeof(*s->frames));
     s->out_ctx = (ovhip_ctx **)calloc((size_t)s->n_dev, sizeof(*s->out_ctx));
@@ -306,9 +355,9 @@ ovhip_stream_create(ovhip_stream **out, ovhip_dpb *dpb, const ovhip_stream_cfg *
     if (!s->frames || !s->out_ctx || !s->job_mtx) r = OVHIP_ENOMEM;
     for (uint32_t i = 0; i < n_jobs && r == OVHIP_OK; ++i) pthread_mutex_init(&s->job_mtx[i], NULL);
     for (int i = 0; i < s->n_dev * s->tpd && r == OVHIP_OK; ++i) r = ovhip_frame_create(dpb, i / s->tpd, cfg->w, cfg->h, &s->frames[i]);
-    if (cfg->output != OVHIP_OUT_NONE) {
+    if (cfg->output == OVHIP_OUT_PACKED) {
         for (int k = 0; k < s->n_dev && r == OVHIP_OK; ++k) r = ovhip_ctx_create(&s->out_ctx[k], ovhip_dpb_device(dpb, k), NULL);
-        if (r == OVHIP_OK && cfg->output == OVHIP_OUT_PACKED) {
+        if (r == OVHIP_OK) {
             s->out_host_bytes = ovhip_output_bytes(cfg->w, cfg->h, &cfg->window);
             s->out_host = s->out_host_bytes ? ovhip_host_alloc(s->out_host_bytes) : NULL;
             if (!s->out_host) r = s->out_host_bytes ? OVHIP_ENOMEM : OVHIP_EINVAL;
@@ -329,6 +378,7 @@ ovhip_stream_destroy(ovhip_stream *s)
     ovhip_host_free(s->out_host);
     for (uint32_t i = 0; s->job_mtx && i < s->n_jobs; ++i) pthread_mutex_destroy(&s->job_mtx[i]);
     free(s->frames); free(s->out_ctx); free(s->job_mtx);
+    pthread_cond_destroy(&s->begun_cnd); pthread_mutex_destroy(&s->begun_mtx);
     free(s);
 }
 

@@ -83,9 +83,9 @@ struct hip_entry {
     const OVCTUDec *key;
     struct RCNFunctions scalar;          /* the table as the scalar fill left it */
     uint8_t ict_type, lmcs_flag;
-    ovhip_recorder *rec;                 /* job's recorder, or the bound one in record-only mode */
+    ovhip_recorder *rec;                 /* the frame thread's recorder, or the bound one in record-only mode */
     int record_only;
-    ovhip_ctx *ctx; ovhip_job *job;
+    ovhip_frame *fr; int dev;            /* this OVCTUDec's frame thread on the device path (include/ovvc_hip.h) and its logical device */
     int pic_w, pic_h, log2_ctu, nb_ctu_w, nb_ctu_h;
     const OVFrame *frame;                /* picture being decoded */
     int err;
@@ -114,9 +114,17 @@ struct hip_entry {
 static struct hip_entry *g_entries[256];
 static pthread_mutex_t g_mtx = PTHREAD_MUTEX_INITIALIZER;
 
+/* Every slot call starts here (the table has no user pointer).  The common case -- the same OVCTUDec as this thread's last call,
+ * no entry released since -- is two thread-local compares; only a miss takes the mutex and scans (r2: mutex + scan on every call). */
+static unsigned g_entries_gen;
+static __thread const OVCTUDec *tls_key;
+static __thread struct hip_entry *tls_entry;
+static __thread unsigned tls_gen;
+
 static struct hip_entry *
 entry_of(const OVCTUDec *c, int create)
 {
+    if (tls_key == c && tls_entry && tls_gen == __atomic_load_n(&g_entries_gen, __ATOMIC_ACQUIRE)) return tls_entry;
     struct hip_entry *e = NULL;
     int free_slot = -1;
     pthread_mutex_lock(&g_mtx);
@@ -126,8 +134,9 @@ entry_of(const OVCTUDec *c, int create)
     }
     if (!e && create && free_slot >= 0) {
         e = calloc(1, sizeof(*e));
-        if (e) { e->key = c; g_entries[free_slot] = e; }
+        if (e) { e->key = c; e->dev = -1; g_entries[free_slot] = e; }
     }
+    tls_key = c; tls_entry = e; tls_gen = g_entries_gen;
     pthread_mutex_unlock(&g_mtx);
     return e;
 }
@@ -137,7 +146,7 @@ latch(struct hip_entry *e, int code, const char *what)
 {
     if (code >= 0 || e->err) return;
     e->err = code;
-    ov_log(NULL, OVLOG_ERROR, "rcn_hip: %s failed (%d)%s%s\n", what, code, e->ctx ? ": " : "", e->ctx ? ovhip_last_error(e->ctx) : "");
+    ov_log(NULL, OVLOG_ERROR, "rcn_hip: %s failed (%d)%s%s\n", what, code, e->fr ? ": " : "", e->fr ? ovhip_frame_last_error(e->fr) : "");
 }
 
 static inline OVCTUDec *ctudec_of_lmcs(struct LMCSInfo *li) { return (OVCTUDec *)((char *)li - offsetof(OVCTUDec, lmcs_info)); }
@@ -149,6 +158,11 @@ ref_slot(struct hip_entry *e, const OVPicture *p)
     for (int i = 0; i < e->n_refs; ++i) if (e->refs[i] == p) return i;
     if (e->n_refs >= 16) { latch(e, OVHIP_EUNSUP, "more than 16 distinct reference pictures"); return 0; }
     e->refs[e->n_refs] = p;
+    /* the frame thread keeps the same table (order of first use), keyed by the OVFrame: the device DPB hands the picture over */
+    if (e->fr && !e->record_only) {
+        const int k = ovhip_frame_ref(e->fr, p->frame);
+        if (k != e->n_refs) latch(e, k < 0 ? k : OVHIP_EINVAL, "ovhip_frame_ref");
+    }
     return e->n_refs++;
 }
 
@@ -1064,94 +1078,85 @@ hip_alf_filter_line(OVCTUDec *const c, const struct RectEntryInfo *const einfo, 
         e->alf_on = 1;
     }
     if (e->record_only) return;
-    /* eager DMVR: rows up to this one */
-    if (e->n_patch > e->dmvr_done && e->job) {
-        ovhip_pic refs[16];
-        /* (reference pictures are complete on the device before any of their rows was published to this thread) */
-        int n = 0;
-        extern int rcn_hip_device_refs_(struct hip_entry *, ovhip_pic *, int *);
-        if (rcn_hip_device_refs_(e, refs, &n) == 0) {
-            const size_t first = e->dmvr_done;
-            int64_t done = ovhip_job_dmvr_rows(e->job, refs, (uint32_t)n);
-            if (done < 0) latch(e, (int)done, "ovhip_job_dmvr_rows");
-            else {
-                size_t nm = 0;
-                const int32_t *mv = ovhip_job_refined_mvs(e->job, &nm);
-                ovhip_shim_apply_refined_mvs(c, mv, first, (size_t)done - first);
-                e->dmvr_done = (size_t)done;
-            }
+    /* eager DMVR: rows up to this one (ovhip_frame_dmvr_rows waits for the reference pictures, as rcn_inter_synchronization does
+     * for the rows a prediction reads, rcn_inter.c:131-146 -- here: until they are complete on this device) */
+    if (e->n_patch > e->dmvr_done && e->fr && !e->err) {
+        const size_t first = e->dmvr_done;
+        const int64_t done = ovhip_frame_dmvr_rows(e->fr);
+        if (done < 0) latch(e, (int)done, "ovhip_frame_dmvr_rows");
+        else {
+            size_t nm = 0;
+            const int32_t *mv = ovhip_job_refined_mvs(ovhip_frame_job(e->fr), &nm);
+            ovhip_shim_apply_refined_mvs(c, mv, first, (size_t)done - first);
+            e->dmvr_done = (size_t)done;
         }
     }
     if (ctb_y == einfo->nb_ctu_h - 1) flush_picture(e, c);
 }
 
 /* ------------------------------------------------------------------------------------ picture begin / flush / plumbing */
-/* Device pictures of the decoder's frames: process-wide mirror of the DPB, keyed by OVFrame. */
-#define DPB_SLOTS 64
-static struct { const OVFrame *frame; ovhip_pic pic; int w, h; int submitted; } g_dpb[DPB_SLOTS];
+/* The device half lives in libovvc_hip.so (ovvc_dpb.c, ovvc_frame.c): a process-wide device DPB keyed by the OVFrame pointer and
+ * one ovhip_frame (context + job) per OVCTUDec.  This file only maps the decoder's events onto it:
+ *   rcn_attach_frame_buff            -> ovhip_frame_begin(frame)
+ *   first use of a reference picture -> ovhip_frame_ref(ref->frame)          (ref_slot above)
+ *   alf.rcn_alf_filter_line, per row -> ovhip_frame_dmvr_rows
+ *   ... of the picture's last row    -> ovhip_frame_submit: uploads, wait for the references, launches, ovhip_job_wait, publish, output
+ *   latched error                    -> ovhip_frame_fail: the picture's readers are released with an error, nobody hangs
+ * Devices: OVVC_HIP_DEVICES="0,1,..." (default: OVVC_HIP_DEVICE or 0).  Frame thread k decodes on device k mod N -- pictures shard
+ * one per GPU as the sub-decoders take them (ovdec_select_subdec, ovdec.c:188-248); a reference picture decoded on another device
+ * arrives by an event-ordered peer copy the DPB starts as soon as it is done. */
+static ovhip_dpb *g_dpb;
+static int g_n_dev = 1, g_next_dev, g_n_entries, g_out_mode = OVHIP_OUT_PLANES;
+static ovhip_ctx *g_out_ctx[OVHIP_MAX_DEVICES];
 static pthread_mutex_t g_dpb_mtx = PTHREAD_MUTEX_INITIALIZER;
-static pthread_cond_t g_dpb_cnd = PTHREAD_COND_INITIALIZER;
 
 static int
-dpb_slot(struct hip_entry *e, const OVFrame *f, int create)
+dpb_get(struct hip_entry *e)
 {
-    int slot = -1, free_slot = -1;
+    int r = OVHIP_OK;
     pthread_mutex_lock(&g_dpb_mtx);
-    for (int i = 0; i < DPB_SLOTS; ++i) {
-        if (g_dpb[i].frame == f) { slot = i; break; }
-        if (!g_dpb[i].frame && free_slot < 0) free_slot = i;
+    if (!g_dpb) {
+        int devs[OVHIP_MAX_DEVICES], n = 0;
+        const char *list = getenv("OVVC_HIP_DEVICES"), *one = getenv("OVVC_HIP_DEVICE"), *om = getenv("OVVC_HIP_OUTPUT");
+        if (list) { for (const char *p = list; *p && n < OVHIP_MAX_DEVICES;) { devs[n++] = atoi(p); while (*p && *p != ',') ++p; if (*p) ++p; } }
+        if (!n) devs[n++] = one ? atoi(one) : 0;
+        /* OVVC_HIP_OUTPUT=none: the application takes its frames through ovhip_shim_frame_output / _digest and the 24.9 MB copy of
+         * every 4K picture into the OVFrame is skipped; default: the OVFrame is filled, an unmodified dectest.c:372-409 works */
+        if (om && !strcmp(om, "none")) g_out_mode = OVHIP_OUT_NONE;
+        r = ovhip_dpb_create(&g_dpb, devs, n);
+        if (r == OVHIP_OK) g_n_dev = n; else g_dpb = NULL;
     }
-    if (slot < 0 && create && free_slot >= 0) {
-        slot = free_slot;
-        if (!g_dpb[slot].pic.y || g_dpb[slot].w != e->pic_w || g_dpb[slot].h != e->pic_h) {
-            if (g_dpb[slot].pic.y) ovhip_pic_free(e->ctx, &g_dpb[slot].pic);
-            if (ovhip_pic_alloc(e->ctx, e->pic_w, e->pic_h, &g_dpb[slot].pic) != OVHIP_OK) slot = -1;
-            else { g_dpb[slot].w = e->pic_w; g_dpb[slot].h = e->pic_h; }
-        }
-        if (slot >= 0) g_dpb[slot].frame = f;
-    }
-    if (slot >= 0 && create) g_dpb[slot].submitted = 0;
+    if (r == OVHIP_OK && e->dev < 0) { e->dev = g_next_dev++ % g_n_dev; g_n_entries++; }
     pthread_mutex_unlock(&g_dpb_mtx);
-    return slot;
+    return r;
 }
 
-int
-rcn_hip_device_refs_(struct hip_entry *e, ovhip_pic *refs, int *n)
-{
-    for (int i = 0; i < e->n_refs; ++i) {
-        const int s = dpb_slot(e, e->refs[i]->frame, 0);
-        if (s < 0) { latch(e, OVHIP_EINVAL, "reference picture was not decoded on this device"); return -1; }
-        /* the device analogue of ovdpb_synchro_ref_decoded_ctus (dpb.c:1242-1270): wait until the producer thread has
-         * SUBMITTED the picture; its launches are then ordered before ours because every context's flush ends in
-         * ovhip_job_wait before the producer publishes (see flush_picture) */
-        pthread_mutex_lock(&g_dpb_mtx);
-        while (!g_dpb[s].submitted) pthread_cond_wait(&g_dpb_cnd, &g_dpb_mtx);
-        pthread_mutex_unlock(&g_dpb_mtx);
-        refs[i] = g_dpb[s].pic;
-    }
-    *n = e->n_refs;
-    return 0;
-}
+void ovhip_shim_set_output(int mode) { g_out_mode = mode == OVHIP_OUT_NONE ? OVHIP_OUT_NONE : OVHIP_OUT_PLANES; }
+
+/* The host DPB dropped its last reference to the frame (ovframe_unref reaching zero): the device picture goes back to the pool.
+ * Optional -- a frame pointer that comes back for a new picture is recycled implicitly -- but it frees device memory earlier. */
+void ovhip_shim_frame_released(const OVFrame *frame) { if (g_dpb && frame) (void)ovhip_dpb_release(g_dpb, frame); }
 
 /* Output path: what examples/dectest.c:372-409 (write_decoded_frame_to_file) copies out of the OVFrame plane by plane, taken
  * from the device picture of that frame instead -- cropped to frame->output_window and packed by one launch, fetched with
  * one D2H; or only fingerprinted (MD5 over the per-row MD5 digests computed on the device), nothing but 16 bytes leaving. */
-static int
-dpb_find_decoded(const OVFrame *f, ovhip_pic *pic)
-{
-    int found = 0;
-    pthread_mutex_lock(&g_dpb_mtx);
-    for (int i = 0; i < DPB_SLOTS; ++i)
-        if (g_dpb[i].frame == f && g_dpb[i].submitted) { *pic = g_dpb[i].pic; found = 1; break; }
-    pthread_mutex_unlock(&g_dpb_mtx);
-    return found;
-}
-
 static ovhip_window
 frame_window(const OVFrame *f)
 {
     ovhip_window w = { f->output_window.offset_lft, f->output_window.offset_rgt, f->output_window.offset_abv, f->output_window.offset_blw };
     return w;
+}
+
+static ovhip_ctx *
+out_ctx_of(const OVFrame *frame, ovhip_pic *pic)
+{
+    int dev = 0;
+    if (!g_dpb || !frame || ovhip_dpb_lookup(g_dpb, frame, &dev, pic) != OVHIP_OK) return NULL;
+    pthread_mutex_lock(&g_dpb_mtx);
+    if (!g_out_ctx[dev] && ovhip_ctx_create(&g_out_ctx[dev], ovhip_dpb_device(g_dpb, dev), NULL) != OVHIP_OK) g_out_ctx[dev] = NULL;
+    ovhip_ctx *ctx = g_out_ctx[dev];
+    pthread_mutex_unlock(&g_dpb_mtx);
+    return ctx;
 }
 
 size_t
@@ -1161,35 +1166,38 @@ ovhip_shim_frame_bytes(const OVFrame *frame)
     return ovhip_output_bytes(frame->width, frame->height, &w);
 }
 
+/* (one application thread at a time per device: the output contexts are not locked) */
 int
 ovhip_shim_frame_output(const OVCTUDec *c, const OVFrame *frame, void *dst)
 {
-    struct hip_entry *e = entry_of(c, 0);
+    (void)c;
     ovhip_pic pic;
-    if (!e || !e->ctx || !frame || !dst || !dpb_find_decoded(frame, &pic)) return OVHIP_EINVAL;
+    ovhip_ctx *ctx = dst ? out_ctx_of(frame, &pic) : NULL;
+    if (!ctx) return OVHIP_EINVAL;
     const ovhip_window w = frame_window(frame);
-    return ovhip_pic_output(e->ctx, &pic, &w, dst);
+    return ovhip_pic_output(ctx, &pic, &w, dst);
 }
 
 int
 ovhip_shim_frame_digest(const OVCTUDec *c, const OVFrame *frame, uint8_t out[16])
 {
-    struct hip_entry *e = entry_of(c, 0);
+    (void)c;
     ovhip_pic pic;
-    if (!e || !e->ctx || !frame || !out || !dpb_find_decoded(frame, &pic)) return OVHIP_EINVAL;
+    ovhip_ctx *ctx = out ? out_ctx_of(frame, &pic) : NULL;
+    if (!ctx) return OVHIP_EINVAL;
     const ovhip_window w = frame_window(frame);
-    return ovhip_pic_digest(e->ctx, &pic, &w, out);
+    return ovhip_pic_digest(ctx, &pic, &w, out);
 }
 
 static void
 flush_picture(struct hip_entry *e, OVCTUDec *c)
 {
-    if (!e->job || e->err) return;
-    ovhip_pic refs[16];
-    int n_refs = 0;
-    if (e->n_refs && rcn_hip_device_refs_(e, refs, &n_refs)) return;
-    const int slot = dpb_slot(e, e->frame, 0);
-    if (slot < 0) { latch(e, OVHIP_EINVAL, "current picture has no device buffer"); return; }
+    if (!e->fr) return;
+    if (e->err) {
+        /*  every exit path publishes: a picture that cannot be decoded releases its readers with an error */
+        (void)ovhip_frame_fail(e->fr, e->err);
+        return;
+    }
     ovhip_job_params pr;
     memset(&pr, 0, sizeof(pr));
     pr.lmcs = (c->lmcs_info.lmcs_enabled_flag && e->have_luts) ? &e->luts : NULL;
@@ -1202,28 +1210,24 @@ flush_picture(struct hip_entry *e, OVCTUDec *c)
         pr.alf_cc_coeff = &e->alf_cc[0][0][0];
     }
     pr.log2_ctu_s = e->log2_ctu;
-    ovhip_pic dst = g_dpb[slot].pic;
-    latch(e, ovhip_job_flush(e->job, &dst, n_refs ? refs : NULL, (uint32_t)n_refs, NULL, &pr), "ovhip_job_flush");
-    /* the decoder's output path and any host-side reader expect the samples in the OVFrame (dectest.c:372-409) */
-    if (!e->err) {
-        const OVFrame *f = e->frame;
-        latch(e, ovhip_pic_download(e->ctx, &dst, (uint16_t *)f->data[0], (uint16_t *)f->data[1], (uint16_t *)f->data[2],
-                                    (int32_t)(f->linesize[0] / 2), (int32_t)(f->linesize[1] / 2)), "ovhip_pic_download");
-    }
-    latch(e, ovhip_job_wait(e->job), "ovhip_job_wait");
+    /* the decoder's own output path and any host-side reader expect the samples in the OVFrame (dectest.c:372-409): copied out
+     * AFTER ovhip_job_wait (which may decode the picture a second time) and after the picture was published to its readers */
+    ovhip_frame_output out;
+    memset(&out, 0, sizeof(out));
+    const OVFrame *f = e->frame;
+    out.mode = g_out_mode;
+    out.y = (uint16_t *)f->data[0]; out.cb = (uint16_t *)f->data[1]; out.cr = (uint16_t *)f->data[2];
+    out.stride_y = (int32_t)(f->linesize[0] / 2); out.stride_c = (int32_t)(f->linesize[1] / 2);
+    latch(e, ovhip_frame_submit(e->fr, NULL, NULL, &pr, &out), "ovhip_frame_submit");
     /* remaining refined vectors (last row) */
     size_t nm = 0;
-    const int32_t *mv = ovhip_job_refined_mvs(e->job, &nm);
-    if (mv && nm > e->dmvr_done) ovhip_shim_apply_refined_mvs(c, mv, e->dmvr_done, nm - e->dmvr_done);
+    const int32_t *mv = ovhip_job_refined_mvs(ovhip_frame_job(e->fr), &nm);
+    if (!e->err && mv && nm > e->dmvr_done) ovhip_shim_apply_refined_mvs(c, mv, e->dmvr_done, nm - e->dmvr_done);
     e->dmvr_done = nm;
-    pthread_mutex_lock(&g_dpb_mtx);
-    g_dpb[slot].submitted = 1;
-    pthread_cond_broadcast(&g_dpb_cnd);
-    pthread_mutex_unlock(&g_dpb_mtx);
 }
 
 static void
-begin_picture(struct hip_entry *e, const OVFrame *f)
+begin_picture(struct hip_entry *e, const OVFrame *f, const struct RectEntryInfo *einfo)
 {
     e->frame = f;
     e->err = 0;
@@ -1235,20 +1239,36 @@ begin_picture(struct hip_entry *e, const OVFrame *f)
     if (e->rec && e->key->part_ctx) (void)ovhip_rec_set_ctu_size(e->rec, e->key->part_ctx->log2_ctu_s);
     if (e->n_ctu) { memset(e->sao, 0, e->n_ctu * sizeof(*e->sao)); memset(e->alf, 0, e->n_ctu * sizeof(*e->alf)); }
     if (e->record_only) { ovhip_rec_reset(e->rec); return; }
-    if (!e->ctx) {
-        const char *dev = getenv("OVVC_HIP_DEVICE");
-        int r = ovhip_ctx_create(&e->ctx, dev ? atoi(dev) : 0, NULL);
-        if (r != OVHIP_OK) { e->ctx = NULL; latch(e, r, "ovhip_ctx_create (the HIP back-end has no CPU fallback)"); return; }
+    /* one device job = one picture: a picture cut into several rect entries (tiles, `-e 2`; slicedec.c:636-657, ovthreads.c:93-114)
+     * would begin and flush the same device picture from two threads -- refused before anything is begun */
+    if (einfo && e->key->part_ctx) {
+        const int l2 = e->key->part_ctx->log2_ctu_s;
+        const int nw = ((int)f->width + (1 << l2) - 1) >> l2, nh = ((int)f->height + (1 << l2) - 1) >> l2;
+        if (einfo->ctb_x || einfo->ctb_y || einfo->nb_ctu_w != nw || einfo->nb_ctu_h != nh) {
+            latch(e, OVHIP_EUNSUP, "picture with more than one rect entry (tiles / entry threads)");
+            if (e->fr) { ovhip_frame_destroy(e->fr); e->fr = NULL; e->rec = NULL; }
+            return;
+        }
     }
-    if (e->job && (e->pic_w != (int)f->width || e->pic_h != (int)f->height)) { ovhip_job_destroy(e->job); e->job = NULL; e->rec = NULL; }
+    int r = dpb_get(e);
+    if (r != OVHIP_OK) { latch(e, r, "ovhip_dpb_create (the HIP back-end has no CPU fallback)"); return; }
+    if (e->fr && (e->pic_w != (int)f->width || e->pic_h != (int)f->height)) { ovhip_frame_destroy(e->fr); e->fr = NULL; e->rec = NULL; }
     e->pic_w = f->width; e->pic_h = f->height;
-    if (!e->job) {
-        int r = ovhip_job_create(e->ctx, e->pic_w, e->pic_h, &e->job);
-        if (r != OVHIP_OK) { e->job = NULL; latch(e, r, "ovhip_job_create"); return; }
-        e->rec = ovhip_job_recorder(e->job);
+    if (!e->fr) {
+        r = ovhip_frame_create(g_dpb, e->dev, e->pic_w, e->pic_h, &e->fr);
+        if (r != OVHIP_OK) { e->fr = NULL; latch(e, r, "ovhip_frame_create"); return; }
     }
-    latch(e, ovhip_job_begin(e->job), "ovhip_job_begin");
-    if (dpb_slot(e, f, 1) < 0) latch(e, OVHIP_ENOMEM, "device picture");
+    latch(e, ovhip_frame_begin(e->fr, f), "ovhip_frame_begin");
+    e->rec = ovhip_frame_recorder(e->fr);
+    if (!e->rec) { latch(e, OVHIP_ENOMEM, "ovhip_frame_recorder"); return; }
+    (void)ovhip_rec_set_ctu_size(e->rec, e->key->part_ctx ? e->key->part_ctx->log2_ctu_s : 7);
+    /* the slice's reference lists are known now (slicedec.c:1250-1256): a device that did not decode them asks for them before
+     * the first prediction unit is parsed */
+    const struct InterDRVCtx *ic = &e->key->drv_ctx.inter_ctx;
+    if (g_n_dev > 1 && e->key->tmp_slice_type != 2) {
+        for (int i = 0; i < ic->nb_active_ref0 && i < 16; ++i) if (ic->rpl0[i] && ic->rpl0[i]->frame) (void)ovhip_dpb_want(g_dpb, ic->rpl0[i]->frame, e->dev);
+        for (int i = 0; i < ic->nb_active_ref1 && i < 16; ++i) if (ic->rpl1[i] && ic->rpl1[i]->frame) (void)ovhip_dpb_want(g_dpb, ic->rpl1[i]->frame, e->dev);
+    }
 }
 
 /* rcn_attach_frame_buff (rcn_structures.h:622-623; rcn_ctu.c:570-594) = begin picture for this entry thread */
@@ -1260,7 +1280,7 @@ hip_attach_frame_buff(struct OVRCNCtx *const rcn_ctx, const OVFrame *const f, co
     if (!e) return;
     /* the scalar attach keeps rcn_ctx->frame_buff / frame_start valid for every host-side reader */
     e->scalar.rcn_attach_frame_buff(rcn_ctx, f, einfo, log2_ctb_s);
-    begin_picture(e, f);
+    begin_picture(e, f, einfo);
 }
 
 /* CTU scratch <-> frame copies, intra line buffer, filter-region halo (rcn_structures.h:595-626; rcn_ctu.c:41-626): the
@@ -1338,7 +1358,7 @@ int
 ovhip_shim_bind_recorder(const OVCTUDec *c, ovhip_recorder *rec, int pic_w, int pic_h)
 {
     struct hip_entry *e = entry_of(c, 0);
-    if (!e || !rec || e->job) return OVHIP_EINVAL;
+    if (!e || !rec || e->fr) return OVHIP_EINVAL;
     e->rec = rec; e->record_only = 1; e->pic_w = pic_w; e->pic_h = pic_h;
     if (c->part_ctx) (void)ovhip_rec_set_ctu_size(rec, c->part_ctx->log2_ctu_s);
     e->err = 0; e->n_refs = 0; e->pend.kind = PEND_NONE;
@@ -1403,10 +1423,18 @@ ovhip_shim_release(const OVCTUDec *c)
     pthread_mutex_lock(&g_mtx);
     for (int i = 0; i < 256; ++i)
         if (g_entries[i] && g_entries[i]->key == c) { e = g_entries[i]; g_entries[i] = NULL; break; }
+    __atomic_add_fetch(&g_entries_gen, 1, __ATOMIC_RELEASE);        /* every thread's cached entry pointer is void now */
     pthread_mutex_unlock(&g_mtx);
     if (!e) return;
-    if (e->job) ovhip_job_destroy(e->job);
-    if (e->ctx) ovhip_ctx_destroy(e->ctx);
+    if (e->fr) ovhip_frame_destroy(e->fr);
     free(e->sao); free(e->alf); free(e->patch);
+    /* the last frame thread of the process takes the device DPB (every device picture) with it */
+    pthread_mutex_lock(&g_dpb_mtx);
+    if (e->dev >= 0 && --g_n_entries == 0 && g_dpb) {
+        for (int k = 0; k < OVHIP_MAX_DEVICES; ++k) if (g_out_ctx[k]) { ovhip_ctx_destroy(g_out_ctx[k]); g_out_ctx[k] = NULL; }
+        ovhip_dpb_destroy(g_dpb);
+        g_dpb = NULL; g_next_dev = 0;
+    }
+    pthread_mutex_unlock(&g_dpb_mtx);
     free(e);
 }

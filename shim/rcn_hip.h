@@ -50,6 +50,14 @@ const struct ovhip_alf_ctu *ovhip_shim_alf_params(const struct OVCTUDec *ctudec,
 const int16_t *ovhip_shim_alf_table(const struct OVCTUDec *ctudec, int which /* 0 luma coeff, 1 luma clip, 2 chroma coeff, 3 chroma clip, 4 cc */, size_t *n);
 const struct ovhip_lmcs_luts *ovhip_shim_lmcs(const struct OVCTUDec *ctudec);
 void ovhip_shim_release(const struct OVCTUDec *ctudec);
+/* What the last alf.rcn_alf_filter_line of a picture copies into the OVFrame after the picture is complete: OVHIP_OUT_PLANES
+ * (default: an unmodified application reads the frame there, dectest.c:372-409) or OVHIP_OUT_NONE (the application takes its
+ * frames through ovhip_shim_frame_output / _digest: no 24.9 MB copy per 4K picture).  Also: environment OVVC_HIP_OUTPUT=none. */
+void ovhip_shim_set_output(int mode);
+/* Optional hook for ovframe_unref() reaching zero: the frame's device picture returns to the pool at once (otherwise when the
+ * frame pointer comes back for a new picture). */
+struct Frame;
+void ovhip_shim_frame_released(const struct Frame *frame);
 
 /* ---- output path (replaces the plane-by-plane copy-out of examples/dectest.c:372-409) ---- */
 struct Frame;

@@ -159,21 +159,23 @@ def test_continued_stream_and_dpb_churn(built_lib):
     wls = _contents(w, h, (11, 12, 13), 14)
     pics = gop.build_stream(6, 16, 32, 1)
     spics = _stream_pics(pics, 3)
-    for p in spics:
-        p["job"] = p["job"] % 40
+    # 40 jobs in rotation for the B pictures (a job holds one content for ever: job k <-> content k % 3), two for the I pictures
+    n_i = 0
+    for p, q in zip(spics, pics):
+        if q.intra:
+            p["job"], p["content"] = 40 + n_i % 2, 3
+            n_i += 1
+        else:
+            p["job"] = q.idx % 40
+            p["content"] = p["job"] % 3
+    planes = _oracle_stream(wls, spics)
     ctx = engine.Context(0)
     dpb = engine.Dpb((0,))
     jobs = []
-    for k in range(40):
+    for k in range(42):
         j = engine.Job(ctx, w, h)
+        j.load_workload(wls[k % 3 if k < 40 else 3])
         jobs.append(j)
-    # job k holds the content of every picture that maps to it: pictures 40 apart must show the same content
-    for i, p in enumerate(spics):
-        if i >= 40:
-            p["content"] = spics[i - 40]["content"]
-    planes = _oracle_stream(wls, spics)
-    for k in range(40):
-        jobs[k].load_workload(wls[spics[k]["content"]])
     st = engine.Stream(dpb, w, h, _make_contents(wls), jobs, threads_per_device=8)
     arr = st.pics_array(spics)
     n = len(spics)
@@ -213,7 +215,8 @@ def test_two_logical_devices_in_one_process(built_lib):
     for i in range(len(spics)):
         assert bytes(dg[i]) == oo.picture_digest(*planes[i]), f"picture {i} (device {spics[i]['device']})"
     stats = dpb.stats()
-    cross = len({(r, p["device"]) for p in spics for r in p["refs"] if spics[r]["device"] != p["device"]})
+    used = lambda p: {p["refs"][k % len(p["refs"])] for k in range(2)} if p["refs"] else set()        # the table has two entries
+    cross = len({(r, p["device"]) for p in spics for r in used(p) if spics[r]["device"] != p["device"]})
     assert stats.n_copies == cross, (stats.n_copies, cross)        # one copy per (picture, device that lists it), none else
     assert stats.copy_bytes == cross * w * h * 3
     st.close(); [j.close() for j in jobs]; dpb.close(); ctx.close()
