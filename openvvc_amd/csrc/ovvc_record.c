@@ -106,7 +106,8 @@ ovhip_rec_grow_(ovhip_recorder *r, void **p, size_t *cap, size_t need, size_t el
     *p = q; *cap = nc;
     return 0;
 }
-#define grow(p, cap, need, elem) ovhip_rec_grow_(r, p, cap, need, elem)
+/* (the capacity test inline: the call is the rare path -- it used to be a PLT call per appended element) */
+#define grow(p, cap, need, elem) ((need) <= *(cap) ? 0 : ovhip_rec_grow_(r, p, cap, need, elem))
 
 /* Bulk append of already-recorded commands (replaying a stored command stream: fixtures, benchmarks, a picture
  * recorded by another recorder).  Offsets inside the commands (coef_off, side_off, region indices) are taken as they

@@ -91,18 +91,15 @@ filter_length(const struct edge_ctx *e, uint64_t aff_p, uint64_t aff_q, uint64_t
 static uint64_t large_from_ngh(const uint64_t *m) { return ~(m[-1] | m[1] | m[-2] | m[2] | m[-3] | m[3]); }
 
 /* One segment: into the compact list the device kernel consumes (never an edge ON the picture boundary, the rule
- * ovhip_dbf_compact applies too) and, when kept, into the dense plane. */
-static int
+ * ovhip_dbf_compact applies too) and, when kept, into the dense plane.  The lists have room for a whole CTU's segments when
+ * this runs (ovhip_rec_dbf_ctu reserves it once): no capacity test per segment. */
+static inline void
 emit_edge(ovhip_recorder *r, int dir, int comp, int ux, int uy, uint16_t word, int off_idx, uint16_t *plane_word)
 {
     if (plane_word) *plane_word = word;
-    if ((dir ? uy : ux) == 0) return 0;
-    ovhip_dbf_edge **list = dir ? &r->edge_h : &r->edge_v;
-    size_t *n = dir ? &r->n_edge_h : &r->n_edge_v, *cap = dir ? &r->cap_edge_h : &r->cap_edge_v;
-    if (ovhip_rec_grow_(r, (void **)list, cap, *n + 1, sizeof(ovhip_dbf_edge))) return -1;
-    ovhip_dbf_edge e = { (uint16_t)ux, (uint16_t)uy, word, (uint8_t)comp, (uint8_t)off_idx };
-    (*list)[(*n)++] = e;
-    return 0;
+    if ((dir ? uy : ux) == 0) return;
+    const ovhip_dbf_edge e = { (uint16_t)ux, (uint16_t)uy, word, (uint8_t)comp, (uint8_t)off_idx };
+    if (dir) r->edge_h[r->n_edge_h++] = e; else r->edge_v[r->n_edge_v++] = e;
 }
 
 /* The (beta, tc) offsets are slice-level state (slicedec.c:1416-1417): every distinct pair of the picture gets an index
@@ -124,6 +121,11 @@ ovhip_rec_dbf_ctu(ovhip_recorder *r, const ovhip_dbf_ctu *c)
     if (c->log2_ctu_s < 5 || c->log2_ctu_s > 7) return OVHIP_EINVAL;
     if (r->log) ovhip_calllog_dbf_(r->log, c);
     if (dbf_alloc(r)) return OVHIP_ENOMEM;
+    /* at most one luma segment per 4x4 unit and one per chroma plane and 8x4 / 4x8 unit, per direction */
+    enum { CTU_EDGES = 32 * 32 + 2 * 8 * 32 };
+    if ((r->n_edge_v + CTU_EDGES > r->cap_edge_v && ovhip_rec_grow_(r, (void **)&r->edge_v, &r->cap_edge_v, r->n_edge_v + CTU_EDGES, sizeof(ovhip_dbf_edge)))
+        || (r->n_edge_h + CTU_EDGES > r->cap_edge_h && ovhip_rec_grow_(r, (void **)&r->edge_h, &r->cap_edge_h, r->n_edge_h + CTU_EDGES, sizeof(ovhip_dbf_edge))))
+        return OVHIP_ENOMEM;
     const int oi = offset_index(r, c->beta_offset, c->tc_offset);
     if (oi < 0) return OVHIP_EUNSUP;         /* more than OVHIP_DBF_MAX_OFFSETS distinct slice offset pairs */
     /* the dense planes (legacy launch) carry ONE pair: only valid while the picture has a single one */
@@ -144,26 +146,28 @@ ovhip_rec_dbf_ctu(ovhip_recorder *r, const ovhip_dbf_ctu *c)
      * lanes of a wave of k_dbf_list<0> then share cache lines; column by column costs the device 30 % more time and traffic). */
     if (!c->disable_h) {
         const uint64_t *edg = &c->ctb_bound_ver[8], *sb = &c->aff_edg_ver[8];
-        uint64_t todo[32], any = 0;
+        uint64_t todo[32];
+        uint32_t row[32];                       /* the same bits transposed: row[j] bit i = column i has a segment in unit row j */
         struct edge_ctx ctx[32];
-        for (int i = 0; i < nb_w; ++i) {
-            todo[i] = i < skip_v ? 0 : (edg[i] | sb[i]) & vmask & (c->bs2_ver[i] | c->bs1_ver[i]);
-            if (todo[i]) edge_context(&ctx[i], edg, sb, i, 1);
-            any |= todo[i];
+        memset(row, 0, sizeof(row));
+        for (int i = skip_v; i < nb_w; ++i) {
+            uint64_t m = todo[i] = (edg[i] | sb[i]) & vmask & (c->bs2_ver[i] | c->bs1_ver[i]);
+            if (!m) continue;
+            edge_context(&ctx[i], edg, sb, i, 1);
+            while (m) { row[__builtin_ctzll(m)] |= 1u << i; m &= m - 1; }
         }
-        while (any) {
-            const int j = __builtin_ctzll(any);
-            any &= any - 1;
+        for (int j = 0; j < nb_h && j < 32; ++j) {
             const uint64_t pos = 1ull << j;
-            for (int i = skip_v; i < nb_w; ++i) {
-                if (!(todo[i] & pos)) continue;
-                int bs = 1 + !!(c->bs2_ver[i] & pos);
+            const int uy = uy0 + j;
+            if (uy >= h4) break;
+            for (uint32_t rm = row[j]; rm; rm &= rm - 1) {
+                const int i = __builtin_ctz(rm), ux = ux0 + i;
+                if (ux >= w4) break;
+                const int bs = 1 + !!(c->bs2_ver[i] & pos);
                 const uint8_t *q = &c->qp_y[36 + i + 34 * j];
                 int qp = (q[-1] + q[0] + 1) >> 1, lp, lq;
                 filter_length(&ctx[i], c->affine_ver[i], c->affine_ver[i + 1], pos, &lp, &lq);
-                int ux = ux0 + i, uy = uy0 + j;
-                if (ux < w4 && uy < h4 && emit_edge(r, 0, 0, ux, uy, OVHIP_DBF_LUMA(bs, lp, lq, qp & 255), oi,
-                                                    dense ? &r->dbf_luma_v[uy * w4 + ux] : NULL)) return OVHIP_ENOMEM;
+                emit_edge(r, 0, 0, ux, uy, OVHIP_DBF_LUMA(bs, lp, lq, qp & 255), oi, dense ? &r->dbf_luma_v[uy * w4 + ux] : NULL);
             }
         }
     }
@@ -184,8 +188,7 @@ ovhip_rec_dbf_ctu(ovhip_recorder *r, const ovhip_dbf_ctu *c)
                 int qp = (q[0] + q[34] + 1) >> 1, lp, lq;
                 filter_length(&e, c->affine_hor[i], c->affine_hor[i + 1], pos, &lp, &lq);
                 int ux = ux0 + k - 2, uy = uy0 + i;
-                if (ux >= 0 && ux < w4 && uy < h4 && emit_edge(r, 1, 0, ux, uy, OVHIP_DBF_LUMA(bs, lp, lq, qp & 255), oi,
-                                                               dense ? &r->dbf_luma_h[uy * w4 + ux] : NULL)) return OVHIP_ENOMEM;
+                if (ux >= 0 && ux < w4 && uy < h4) emit_edge(r, 1, 0, ux, uy, OVHIP_DBF_LUMA(bs, lp, lq, qp & 255), oi, dense ? &r->dbf_luma_h[uy * w4 + ux] : NULL);
             }
         }
     }
@@ -197,30 +200,32 @@ ovhip_rec_dbf_ctu(ovhip_recorder *r, const ovhip_dbf_ctu *c)
             const uint64_t *bs1v = comp ? c->bs1cr_ver : c->bs1cb_ver;
             const uint8_t *qpm = comp ? c->qp_cr : c->qp_cb;
             uint16_t *plane = comp ? r->dbf_cr_v : r->dbf_cb_v;
-            uint64_t todo[8], large[8], any = 0;
-            for (int i = 0; i < nb_vedge; ++i) {
+            uint64_t todo[8], large[8];
+            uint8_t row[32];
+            memset(row, 0, sizeof(row));
+            for (int i = skip_v; i < nb_vedge; ++i) {
                 const int idx = i << 2;
                 const uint64_t bs2 = c->bs2c_ver[idx], bs1 = bs1v[idx];
-                todo[i] = i < skip_v ? 0 : tab[idx] & vmask & (bs2 | bs1);
-                large[i] = todo[i] ? large_from_ngh(&tab[idx]) : 0;
-                todo[i] &= bs2 | (bs1 & large[i]);
-                any |= todo[i];
+                uint64_t m = tab[idx] & vmask & (bs2 | bs1);
+                large[i] = m ? large_from_ngh(&tab[idx]) : 0;
+                m &= bs2 | (bs1 & large[i]);
+                todo[i] = m;
+                while (m) { row[__builtin_ctzll(m)] |= (uint8_t)(1u << i); m &= m - 1; }
             }
-            while (any) {
-                const int j = __builtin_ctzll(any);
-                any &= any - 1;
-                for (int i = skip_v; i < nb_vedge; ++i) {
-                    if (!((todo[i] >> j) & 1)) continue;
-                    const int idx = i << 2;
+            for (int j = 0; j < nb_h && j < 32; ++j) {
+                const int uy = uy0 + j;
+                if (uy >= h4) break;
+                for (uint32_t rm = row[j]; rm; rm &= rm - 1) {
+                    const int i = __builtin_ctz(rm), idx = i << 2, ux = ux0 + idx;
+                    if (ux >= w4) break;
                     const uint8_t *q = &qpm[36 + idx + 34 * j];
-                    int qp = (q[-1] + q[0] + 1) >> 1;
-                    int ux = ux0 + idx, uy = uy0 + j;
+                    const int qp = (q[-1] + q[0] + 1) >> 1;
                     const uint16_t word = (uint16_t)(OVHIP_DBF_C_ON | (((c->bs2c_ver[idx] >> j) & 1) ? OVHIP_DBF_C_BS2 : 0)
                                                      | (((large[i] >> j) & 1) ? OVHIP_DBF_C_LARGE : 0) | ((qp & 255) << 8));
-                    if (ux < w4 && uy < h4 && emit_edge(r, 0, 1 + comp, ux, uy, word, oi,
-                                                        dense ? &plane[uy * w4c + (ux >> 1)] : NULL)) return OVHIP_ENOMEM;
+                    emit_edge(r, 0, 1 + comp, ux, uy, word, oi, dense ? &plane[uy * w4c + (ux >> 1)] : NULL);
                 }
             }
+            (void)todo;
         }
     }
     /* ---------------- chroma, horizontal edges (vvc_dbf_chroma_ver), shifted 2 units left ---------------- */
@@ -247,8 +252,7 @@ ovhip_rec_dbf_ctu(ovhip_recorder *r, const ovhip_dbf_ctu *c)
                     const uint16_t word = (uint16_t)(OVHIP_DBF_C_ON | (((bs2 >> k) & 1) ? OVHIP_DBF_C_BS2 : 0)
                                                      | (((large >> k) & 1) ? OVHIP_DBF_C_LARGE : 0)
                                                      | (i == 0 ? OVHIP_DBF_C_CTB_B : 0) | ((qp & 255) << 8));
-                    if (ux >= 0 && ux < w4 && uy < h4 && emit_edge(r, 1, 1 + comp, ux, uy, word, oi,
-                                                                   dense ? &plane[(uy >> 1) * w4 + ux] : NULL)) return OVHIP_ENOMEM;
+                    if (ux >= 0 && ux < w4 && uy < h4) emit_edge(r, 1, 1 + comp, ux, uy, word, oi, dense ? &plane[(uy >> 1) * w4 + ux] : NULL);
                 }
             }
         }

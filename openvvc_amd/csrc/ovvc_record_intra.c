@@ -111,7 +111,7 @@ int
 ovhip_rec_itask_add_(ovhip_recorder *r, const ovhip_itask *in, uint16_t extra_level)
 {
     if (maps_ready(r)) return OVHIP_ENOMEM;
-    if (ovhip_rec_grow_(r, (void **)&r->itask, &r->cap_itask, r->n_itask + 1, sizeof(ovhip_itask))) return OVHIP_ENOMEM;
+    if (r->n_itask + 1 > r->cap_itask && ovhip_rec_grow_(r, (void **)&r->itask, &r->cap_itask, r->n_itask + 1, sizeof(ovhip_itask))) return OVHIP_ENOMEM;
     ovhip_itask t = *in;
     const int w = 1 << t.log2_w, h = 1 << t.log2_h;
     int m = extra_level, k;
