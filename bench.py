@@ -175,7 +175,9 @@ def main():
     # ---- library objects: device DPB, pre-recorded jobs (R GOPs of stream positions, + the I / key pictures), stream drivers ----
     ctx0 = engine.Context(hip_devices[0])
     dpb = engine.Dpb(tuple(hip_devices))
-    R = max(2, args.job_rotation)
+    # (with several devices each may sit on a GOP of its own: a job shared by two GOPs that are in flight at once could be held by the
+    # later one while the earlier one, which it waits for through the key pictures, needs it)
+    R = max(2, args.job_rotation, L + 2)
     n_jobs = R * G
     keep = []
 

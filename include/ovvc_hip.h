@@ -1010,7 +1010,10 @@ int  ovhip_dpb_begin(ovhip_dpb *d, const void *key, int dev, int32_t w, int32_t 
 int  ovhip_dpb_want(ovhip_dpb *d, const void *key, int dev);
 /* status 0: DONE, else FAILED (latched error of the producer): every exit path of a producer publishes */
 int  ovhip_dpb_publish(ovhip_dpb *d, const void *key, int status);
-/* *event (may be NULL when dev is the home device): a copy_wait handle the caller waits for before it reads pic, or NULL */
+/* *event (may be NULL when dev is the home device): a copy_wait handle the caller waits for before it reads pic, or NULL.
+ * A key nobody has begun YET is waited for as well (frame threads start in decoding order but run on their own), for at most
+ * ovhip_dpb_set_unknown_key_timeout milliseconds (default 10000; 0: do not wait) -- then OVHIP_EINVAL. */
+void ovhip_dpb_set_unknown_key_timeout(ovhip_dpb *d, int ms);
 int  ovhip_dpb_acquire(ovhip_dpb *d, const void *key, int dev, ovhip_pic *pic, void **event);
 int  ovhip_dpb_wait_copy(ovhip_dpb *d, int dev, void *event);
 int  ovhip_dpb_unpin(ovhip_dpb *d, const void *key);

@@ -9,8 +9,10 @@
  *   ovdpb_synchro_ref_decoded_ctus                  dpb.c:1242-1270     consumer waits for it (rcn_inter.c:131-146)
  *   frame pool re-use of an OVFrame                 ovframepool.c       a key may come back for a new picture once unreferenced
  */
+#include <errno.h>
 #include <pthread.h>
 #include <stdlib.h>
+#include <time.h>
 #include <string.h>
 #include "ovvc_hip.h"
 #include "ovvc_dpb_priv.h"
@@ -44,6 +46,7 @@ struct ovhip_dpb {
     struct dpb_slot *slots; size_t n_slots;
     struct pool_ent *pool[OVHIP_MAX_DEVICES]; size_t n_pool[OVHIP_MAX_DEVICES], cap_pool[OVHIP_MAX_DEVICES];
     int shutdown;
+    int unknown_ms;                       /* how long ovhip_dpb_acquire waits for a key nobody has begun yet */
     uint64_t serial;
     ovhip_dpb_stats st;
 };
@@ -147,6 +150,7 @@ ovhip_dpb_create_ex(ovhip_dpb **out, int n_devices, const ovhip_dpb_ops *ops)
     pthread_mutex_init(&d->mtx, NULL);
     pthread_cond_init(&d->cnd, NULL);
     d->n_dev = n_devices; d->ops = *ops;
+    d->unknown_ms = 10000;
     for (int i = 0; i < OVHIP_MAX_DEVICES; ++i) d->hipdev[i] = -1;
     *out = d;
     return OVHIP_OK;
@@ -216,6 +220,7 @@ ovhip_dpb_begin(ovhip_dpb *d, const void *key, int dev, int32_t w, int32_t h, ov
         s->key = key; s->state = S_DECODING; s->home = dev; s->w = w; s->h = h; s->serial = ++d->serial;
         *pic = s->pic;
         d->st.n_live++; d->st.n_begin++;
+        pthread_cond_broadcast(&d->cnd);                 /* a reader may already be waiting for this key to appear */
     }
     pthread_mutex_unlock(&d->mtx);
     return r;
@@ -267,9 +272,22 @@ ovhip_dpb_acquire(ovhip_dpb *d, const void *key, int dev, ovhip_pic *pic, void *
     int r = OVHIP_OK;
     pthread_mutex_lock(&d->mtx);
     struct dpb_slot *s = find(d, key);
-    if (!s) { pthread_mutex_unlock(&d->mtx); return OVHIP_EINVAL; }
-    const uint64_t serial = s->serial;
     int waited = 0;
+    if (!s && d->unknown_ms > 0) {
+        /* Frame threads start in decoding order but run on their own: a reader can get here before the thread that decodes its
+         * reference picture has begun it.  Wait for the key to appear -- bounded: a key that never appears is an error */
+        struct timespec until;
+        clock_gettime(CLOCK_REALTIME, &until);
+        until.tv_sec += d->unknown_ms / 1000; until.tv_nsec += (long)(d->unknown_ms % 1000) * 1000000L;
+        if (until.tv_nsec >= 1000000000L) { until.tv_sec++; until.tv_nsec -= 1000000000L; }
+        while (!s && !d->shutdown) {
+            waited = 1;
+            if (pthread_cond_timedwait(&d->cnd, &d->mtx, &until) == ETIMEDOUT) { s = find(d, key); break; }
+            s = find(d, key);
+        }
+    }
+    if (!s) { d->st.n_waits += waited; pthread_mutex_unlock(&d->mtx); return d->shutdown ? OVHIP_EREF : OVHIP_EINVAL; }
+    const uint64_t serial = s->serial;
     while (s && s->serial == serial && s->state == S_DECODING && !d->shutdown) {
         waited = 1;
         pthread_cond_wait(&d->cnd, &d->mtx);
@@ -351,6 +369,15 @@ ovhip_dpb_lookup(ovhip_dpb *d, const void *key, int *home_dev, ovhip_pic *pic)
     else { *pic = s->pic; if (home_dev) *home_dev = s->home; }
     pthread_mutex_unlock(&d->mtx);
     return r;
+}
+
+void
+ovhip_dpb_set_unknown_key_timeout(ovhip_dpb *d, int ms)
+{
+    if (!d) return;
+    pthread_mutex_lock(&d->mtx);
+    d->unknown_ms = ms < 0 ? 0 : ms;
+    pthread_mutex_unlock(&d->mtx);
 }
 
 void

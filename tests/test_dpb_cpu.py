@@ -113,9 +113,28 @@ def test_reader_waits_for_publish_and_only_for_publish(dpb):
     assert r == 0 and p2.y == pa.y and _stats(lib, h).n_waits == 1
     assert lib.ovhip_dpb_unpin(h, C.c_void_p(1)) == 0 and lib.ovhip_dpb_unpin(h, C.c_void_p(1)) == 0
     assert lib.ovhip_dpb_unpin(h, C.c_void_p(1)) == capi.OVHIP_EINVAL
-    # unknown key / publish twice
-    assert _acquire(lib, h, 99)[0] == capi.OVHIP_EINVAL
+    # unknown key (waited for, for a bounded time) / publish twice
+    lib.ovhip_dpb_set_unknown_key_timeout(h, 50)
+    t0 = time.perf_counter()
+    assert _acquire(lib, h, 99)[0] == capi.OVHIP_EINVAL and 0.04 < time.perf_counter() - t0 < 2.0
     assert lib.ovhip_dpb_publish(h, C.c_void_p(1), 0) == capi.OVHIP_EINVAL
+
+
+def test_reader_may_arrive_before_the_picture_is_begun(dpb):
+    """Frame threads start in decoding order but run on their own: the reader of a picture can reach the DPB before the thread
+    that decodes it has begun it (seen with two logical devices, each with its own queue).  The DPB waits for the key."""
+    lib, h, mem = dpb
+    got = {}
+    t = threading.Thread(target=lambda: got.update(r=_acquire(lib, h, 7)))
+    t.start()
+    time.sleep(0.1)
+    assert not got
+    r, pic = _begin(lib, h, 7)
+    time.sleep(0.05)
+    assert not got, "begun is not done"
+    assert lib.ovhip_dpb_publish(h, C.c_void_p(7), 0) == 0
+    t.join(5)
+    assert got["r"][0] == 0 and got["r"][1].y == pic.y
 
 
 def test_failed_producer_releases_its_readers_with_an_error(dpb):
@@ -189,6 +208,7 @@ def test_pinned_picture_survives_release_until_unpin(dpb):
     r, p2 = _begin(lib, h, 2)
     assert r == 0 and p2.y != pic.y
     assert lib.ovhip_dpb_unpin(h, C.c_void_p(1)) == 0                      # last reader gone -> reclaimed
+    lib.ovhip_dpb_set_unknown_key_timeout(h, 0)
     assert _acquire(lib, h, 1)[0] == capi.OVHIP_EINVAL
     r, p3 = _begin(lib, h, 3)
     assert r == 0 and p3.y == pic.y, "the reclaimed buffer is the next one handed out"
