@@ -134,6 +134,11 @@ def main():
                     help="ONE process driving this many logical devices (device DPB + hipMemcpyPeerAsync); with --same-gpu all of them on GPU 0")
     ap.add_argument("--same-gpu", action="store_true")
     ap.add_argument("--record-threads", type=str, default="1,4,16", help="frame-thread counts of the recorded_in_run variant")
+    ap.add_argument("--intra-lookahead", type=int, default=64,
+                    help="pictures: one more frame thread per device starts pictures WITHOUT reference pictures (I pictures) up to this many pictures "
+                         "before their turn in decoding order (0: strictly in order)")
+    ap.add_argument("--intra-priority", type=int, default=0, help="HIP stream priority of that thread (0 default, -1 high, 1 low)")
+    ap.add_argument("--ahead-chunk", type=int, default=16384, help="ordered pass of the pictures that thread starts early: paced launches of this many items (0: as every picture)")
     args = ap.parse_args()
 
     import torch
@@ -236,10 +241,12 @@ def main():
         return pics, out
 
     OUT = {"none": capi.OUT_NONE, "digest": capi.OUT_DIGEST, "frame": capi.OUT_PACKED}
+    lookahead = max(0, args.intra_lookahead)
 
     def new_stream(threads, output="none", flags=0, xfer=None, use_jobs=True):
         return engine.Stream(dpb, W, H, contents, jobs if use_jobs else [], threads_per_device=threads, flags=flags, output=OUT[output],
-                             extra_stages=lv, rank=rank, xfer=xfer)
+                             extra_stages=lv, rank=rank, xfer=xfer, intra_lookahead=lookahead if threads > 1 else 0,
+                             intra_stream_priority=args.intra_priority, ahead_chunk_items=args.ahead_chunk)
 
     # ---- multi-process exchange: the driver's comm thread calls back here, one call per transferred picture ----
     xfer = None
@@ -619,7 +626,8 @@ def main():
                        "working_set_bytes": int((dpb_stats.n_live + dpb_stats.n_pool) * FB + len(jobs) * FB),
                        "dpb": {"device_pictures_allocated": int(dpb_stats.n_alloc), "begun": int(dpb_stats.n_begin), "recycled": int(dpb_stats.n_recycled),
                                "peer_copies": int(dpb_stats.n_copies), "waits_for_a_reference": int(dpb_stats.n_waits)},
-                       "pictures_in_flight_per_gpu": S, "host_threads": S, "local_devices": L,
+                       "pictures_in_flight_per_gpu": S, "host_threads": S + (1 if lookahead else 0), "local_devices": L,
+                       "intra_lookahead_pictures": lookahead,
                        "picture_assignment": "decoding order; a free frame thread (pthread, own HIP stream) takes the next picture of its device",
                        "n_cu": st["n_cu"], "cu_modes": st["cu_modes"], "n_mc_units": st["n_mc_units"],
                        "n_mcx_units": st["n_mcx_units"], "n_aff_units": st["n_aff_units"], "n_tb_cmds": st["n_tb_cmds"],

@@ -655,6 +655,8 @@ typedef struct ovhip_ctx ovhip_ctx;
 int  ovhip_abi_version(void);
 /* stream: a hipStream_t the caller owns (e.g. torch's current stream) or NULL to create one. */
 int  ovhip_ctx_create(ovhip_ctx **out, int device, void *stream);
+/* stream == NULL: a new stream of the given priority (0: default; the runtime clamps to its range) */
+int  ovhip_ctx_create_prio(ovhip_ctx **out, int device, int stream_priority);
 void ovhip_ctx_destroy(ovhip_ctx *ctx);
 int  ovhip_ctx_sync(ovhip_ctx *ctx);
 const char *ovhip_last_error(const ovhip_ctx *ctx);
@@ -762,12 +764,13 @@ int  ovhip_intra_ctu_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_pi
  * epoch, abort_mirror and the bounded waits as for ovhip_intra_ctu_launch (d_state[0] = abort word).  The items may be launched
  * in several calls (consecutive ranges that end on level boundaries, same epoch): prepare != 0 only on the first, which marks the
  * units of ALL n_tasks tasks.  Fewer workgroups resident and polling at a time leave LDS and issue slots to the kernels of the
- * other pictures in flight. */
+ * other pictures in flight: wg_per_cu (3..16; 0 = as many as fit) caps the workgroups of this launch a compute unit holds. */
 size_t ovhip_intra_flow_words(int32_t width, int32_t height);
 size_t ovhip_intra_flow_items(const ovhip_itask *sorted, size_t n, uint32_t *items, size_t cap);
 int  ovhip_intra_flow_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_pic *res, const ovhip_itask *d_tasks, uint32_t n_tasks,
                              const uint32_t *d_items, uint32_t n_items, const ovhip_lmcs_region *d_regions, const ovhip_lmcs_luts *luts,
-                             int16_t *d_scales, int32_t log2_ctu_s, uint32_t *d_state, uint32_t epoch, uint32_t *abort_mirror, int32_t prepare);
+                             int16_t *d_scales, int32_t log2_ctu_s, uint32_t *d_state, uint32_t epoch, uint32_t *abort_mirror, int32_t prepare,
+                             int32_t wg_per_cu);
 /* The flow launch hands samples from task to task with bit 15 set (kernels_intra.hip, FLOW_TAG).  This clears it in the blocks the
  * ordered tasks wrote: after the picture's flow launches, before anything else reads the picture.  with_luma == 0: chroma blocks
  * only -- ovhip_lmcs_inverse_launch drops the bit of every luma sample as a side effect of its table lookup.
@@ -852,6 +855,11 @@ typedef struct ovhip_job_params {        /* picture-level side information; HOST
     /* != 0: wait_events are waited for ON THE HOST (hipEventSynchronize on the flushing thread, after the uploads have been
      * enqueued) instead of being put into the stream: before_launch without a callback into the caller's language. */
     uint32_t wait_on_host;
+    /* The ordered pass's flow launches of this picture: items per launch (0: the default, 32768) and, != 0, the host waits for a
+     * launch before it issues the next.  A hardware queue runs the packets of the streams it serves in order: an I picture's pass
+     * as one multi-millisecond kernel holds up every stream that shares its queue; paced chunks let them in between.  For a
+     * picture nobody waits for yet (ovhip_stream_cfg.intra_lookahead). */
+    uint32_t flow_chunk_items, flow_paced;
 } ovhip_job_params;
 
 typedef struct ovhip_job_stats {         /* what the last flush moved and launched */
@@ -902,11 +910,17 @@ int  ovhip_job_stage_time(ovhip_job *job, double *sum_ms, uint64_t *count);
  * applies them (luma offsets are twice that).
  *
  * Digest: the reference's CI hashes the output FILE (CI/checkMD5.sh, md5sum); MD5 is a serial chain, so a whole frame
- * cannot be hashed by more than one lane.  ovhip_output_row_md5_launch hashes every cropped ROW independently (RFC
- * 1321 MD5 of the row's bytes, one lane per row); ovhip_pic_digest() returns the MD5 of the concatenated row digests
- * (Y rows, Cb rows, Cr rows): a per-picture fingerprint any host can recompute from the written file with
- * hashlib/md5sum per row, without the 25 MB frame leaving the device.  ovhip_md5_* is the plain host MD5 for callers
- * that do want the file's md5sum from the packed frames.
+ * cannot be hashed by more than one lane, and a frame per lane of the host is ~40 ms at 4K.  Two things are offered instead:
+ *   ovhip_pic_digest()           a per-picture FINGERPRINT, computed on the device, 16 bytes leaving it: a three-level MD5 tree over
+ *                                the cropped frame -- leaf = MD5 of each 1024-byte piece of a cropped row (the last piece of a row
+ *                                shorter), row = MD5 of the row's leaf digests, band = MD5 of the digests of 32 consecutive rows of
+ *                                one plane (the last band of a plane shorter), picture = MD5 of the band digests in the order Y, Cb,
+ *                                Cr (that last step on the host).  Any host can recompute it from the written file with hashlib
+ *                                (oracle/ovvc_oracle_output.py: picture_digest); it is NOT the md5sum of the frame.
+ *   ovhip_md5_* over ovhip_pic_output() frames    the plain host MD5 for callers that want the FILE's md5sum from the packed frames
+ *                                (ovhip_stream_run with OVHIP_OUT_PACKED + OVHIP_STREAM_FILE_MD5 does exactly that).
+ * ovhip_output_row_md5_launch (one plain MD5 per cropped row, one lane each) is the building block the first version of the
+ * fingerprint used; it stays for callers that want per-row digests (~200 us per 4K picture: 120 chained blocks per lane).
  * ---------------------------------------------------------------------------------- */
 typedef struct ovhip_window { uint16_t offset_lft, offset_rgt, offset_abv, offset_blw; } ovhip_window;
 /* Bytes of the cropped frame / number of cropped rows (luma + 2 x chroma); 0 if the window leaves nothing. */
@@ -916,8 +930,11 @@ size_t ovhip_output_rows(int32_t w, int32_t h, const ovhip_window *win);
 int  ovhip_output_pack_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_window *win, uint16_t *d_out);
 /* d_digests: DEVICE, 16 bytes per cropped row in the order Y rows, Cb rows, Cr rows.  Asynchronous. */
 int  ovhip_output_row_md5_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_window *win, uint8_t *d_digests);
-/* Synchronous conveniences: pack + one D2H into host_dst (ovhip_output_bytes() bytes, pinned or pageable); row
- * digests + D2H + MD5 over them into out[16]. */
+/* d_digests: DEVICE, 16 bytes per band (ovhip_output_bands()): the band level of the digest tree above.  Asynchronous. */
+size_t ovhip_output_bands(int32_t w, int32_t h, const ovhip_window *win);
+int  ovhip_output_tree_md5_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_window *win, uint8_t *d_digests);
+/* Synchronous conveniences: pack + one D2H into host_dst (ovhip_output_bytes() bytes, pinned or pageable); the digest tree
+ * + D2H of the band digests + MD5 over them into out[16]. */
 int  ovhip_pic_output(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_window *win, void *host_dst);
 int  ovhip_pic_digest(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_window *win, uint8_t out[16]);
 /* Host MD5 (RFC 1321). */
@@ -1054,6 +1071,8 @@ typedef struct ovhip_frame_output {
 } ovhip_frame_output;
 
 int  ovhip_frame_create(ovhip_dpb *dpb, int dev, int32_t w, int32_t h, ovhip_frame **out);
+/* stream_priority: of the frame's HIP stream (0 default, < 0 higher, > 0 lower); another priority = another hardware queue */
+int  ovhip_frame_create_ex(ovhip_dpb *dpb, int dev, int32_t w, int32_t h, int stream_priority, ovhip_frame **out);
 void ovhip_frame_destroy(ovhip_frame *f);
 ovhip_ctx      *ovhip_frame_ctx(ovhip_frame *f);
 ovhip_job      *ovhip_frame_job(ovhip_frame *f);
@@ -1140,6 +1159,12 @@ typedef struct ovhip_stream_cfg {
     uint32_t extra_stages;                 /* OR-ed into every flush's stage mask (OVHIP_STAGE_INTRA_LEVELS ...)     */
     int32_t rank;                          /* this process's rank (pictures with owner != rank are received)         */
     const ovhip_stream_xfer *xfer;         /* NULL: single process                                                   */
+    /* > 0: one more frame thread per device that takes pictures WITHOUT reference pictures (intra pictures) up to this many
+     * pictures before their turn in decoding order -- such a picture is a dependency chain of milliseconds (ordered pass) that
+     * everything after it waits for; started early it runs beside the pictures before it.  One extra picture buffer, no latency. */
+    int32_t intra_lookahead;
+    int32_t intra_stream_priority;         /* HIP stream priority of that thread's context (0 default, < 0 higher, > 0 lower)  */
+    int32_t ahead_chunk_items;             /* > 0: its pictures' ordered pass in paced launches of this many items (ovhip_job_params.flow_paced) */
 } ovhip_stream_cfg;
 
 typedef struct ovhip_stream_result {

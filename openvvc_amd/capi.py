@@ -192,7 +192,8 @@ class JobParams(C.Structure):
                 ("alf_luma_coeff", C.c_void_p), ("alf_luma_clip", C.c_void_p),
                 ("alf_chroma_coeff", C.c_void_p), ("alf_chroma_clip", C.c_void_p), ("alf_cc_coeff", C.c_void_p),
                 ("log2_ctu_s", C.c_int32), ("stages", C.c_uint32), ("wait_events", C.POINTER(C.c_void_p)), ("n_wait_events", C.c_uint32),
-                ("before_launch", C.c_void_p), ("before_launch_user", C.c_void_p), ("tmvp_cells", C.c_uint32), ("wait_on_host", C.c_uint32)]
+                ("before_launch", C.c_void_p), ("before_launch_user", C.c_void_p), ("tmvp_cells", C.c_uint32), ("wait_on_host", C.c_uint32),
+                ("flow_chunk_items", C.c_uint32), ("flow_paced", C.c_uint32)]
 
 
 BEFORE_LAUNCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
@@ -317,7 +318,8 @@ class StreamXfer(C.Structure):
 
 class StreamCfg(C.Structure):
     _fields_ = [("w", C.c_int32), ("h", C.c_int32), ("flags", C.c_uint32), ("threads_per_device", C.c_int32), ("output", C.c_int32),
-                ("window", Window), ("extra_stages", C.c_uint32), ("rank", C.c_int32), ("xfer", C.POINTER(StreamXfer))]
+                ("window", Window), ("extra_stages", C.c_uint32), ("rank", C.c_int32), ("xfer", C.POINTER(StreamXfer)),
+                ("intra_lookahead", C.c_int32), ("intra_stream_priority", C.c_int32), ("ahead_chunk_items", C.c_int32)]
 
 
 class StreamResult(C.Structure):
@@ -425,7 +427,7 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_intra_sync_words": (C.c_size_t, [i32, i32, i32]),
         "ovhip_intra_flow_words": (C.c_size_t, [i32, i32]),
         "ovhip_intra_flow_items": (C.c_size_t, [vp, C.c_size_t, vp, C.c_size_t]),
-        "ovhip_intra_flow_launch": (C.c_int, [vp, P(Pic), P(Pic), vp, u32, vp, u32, vp, vp, vp, i32, vp, u32, vp, i32]),
+        "ovhip_intra_flow_launch": (C.c_int, [vp, P(Pic), P(Pic), vp, u32, vp, u32, vp, vp, vp, i32, vp, u32, vp, i32, i32]),
         "ovhip_intra_ctu_launch": (C.c_int, [vp, P(Pic), P(Pic), vp, vp, u32, vp, vp, vp, i32, vp, u32, vp]),
         "ovhip_rec_itask_levels": (u32, [vp]),
         "ovhip_rec_isp_cu": (C.c_int, [vp, vp, vp]),
@@ -457,6 +459,8 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_output_rows": (C.c_size_t, [i32, i32, P(Window)]),
         "ovhip_output_pack_launch": (C.c_int, [vp, P(Pic), P(Window), vp]),
         "ovhip_output_row_md5_launch": (C.c_int, [vp, P(Pic), P(Window), vp]),
+        "ovhip_output_bands": (C.c_size_t, [i32, i32, P(Window)]),
+        "ovhip_output_tree_md5_launch": (C.c_int, [vp, P(Pic), P(Window), vp]),
         "ovhip_pic_output": (C.c_int, [vp, P(Pic), P(Window), vp]),
         "ovhip_pic_digest": (C.c_int, [vp, P(Pic), P(Window), vp]),
         "ovhip_md5_init": (None, [P(Md5State)]),
@@ -483,6 +487,8 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_dpb_shutdown": (None, [vp]),
         "ovhip_dpb_get_stats": (C.c_int, [vp, P(DpbStats)]),
         "ovhip_frame_create": (C.c_int, [vp, C.c_int, i32, i32, P(vp)]),
+        "ovhip_frame_create_ex": (C.c_int, [vp, C.c_int, i32, i32, C.c_int, P(vp)]),
+        "ovhip_ctx_create_prio": (C.c_int, [P(vp), C.c_int, C.c_int]),
         "ovhip_frame_destroy": (None, [vp]),
         "ovhip_frame_ctx": (vp, [vp]),
         "ovhip_frame_job": (vp, [vp]),
@@ -526,13 +532,13 @@ EXPORTED_SYMBOLS = [
     "ovhip_dmvr_search_launch", "ovhip_rec_append_raw", "ovhip_rec_set_dbf_offsets", "ovhip_rec_tu_intra", "ovhip_rec_itasks", "ovhip_rec_itasks_sorted", "ovhip_itx_launch_classes_res", "ovhip_intra_level_launch", "ovhip_intra_level_geom", "ovhip_intra_sync_words", "ovhip_intra_ctu_launch", "ovhip_intra_flow_words", "ovhip_intra_flow_items", "ovhip_intra_flow_launch",
     "ovhip_rec_itask_levels", "ovhip_rec_isp_cu", "ovhip_isp_geometry", "ovhip_rec_itasks_by_ctu", "ovhip_rec_set_ctu_size", "ovhip_job_bind", "ovhip_job_create", "ovhip_job_destroy", "ovhip_job_recorder", "ovhip_job_begin",
     "ovhip_job_flush", "ovhip_job_wait", "ovhip_job_refined_mvs", "ovhip_job_dmvr_rows", "ovhip_job_last_stats", "ovhip_job_time_stage", "ovhip_job_stage_time",
-    "ovhip_output_bytes", "ovhip_output_rows", "ovhip_output_pack_launch", "ovhip_output_row_md5_launch", "ovhip_pic_output", "ovhip_pic_digest",
+    "ovhip_output_bytes", "ovhip_output_rows", "ovhip_output_pack_launch", "ovhip_output_row_md5_launch", "ovhip_output_bands", "ovhip_output_tree_md5_launch", "ovhip_pic_output", "ovhip_pic_digest",
     "ovhip_md5_init", "ovhip_md5_update", "ovhip_md5_final", "ovhip_tmvp_cells_launch", "ovhip_job_tmvp_cells", "ovhip_intra_flow_untag_launch", "ovhip_lmcs_inverse_untag_launch", "ovhip_lmcs_scale_prepare_launch",
     "ovhip_host_alloc", "ovhip_host_free", "ovhip_d2d", "ovhip_job_test_abort_next_flow",
     "ovhip_dpb_create", "ovhip_dpb_create_ex", "ovhip_dpb_destroy", "ovhip_dpb_n_devices", "ovhip_dpb_device", "ovhip_dpb_begin", "ovhip_dpb_want",
     "ovhip_dpb_publish", "ovhip_dpb_acquire", "ovhip_dpb_wait_copy", "ovhip_dpb_set_unknown_key_timeout", "ovhip_dpb_unpin", "ovhip_dpb_release", "ovhip_dpb_lookup", "ovhip_dpb_shutdown",
     "ovhip_dpb_get_stats",
-    "ovhip_frame_create", "ovhip_frame_destroy", "ovhip_frame_ctx", "ovhip_frame_job", "ovhip_frame_recorder", "ovhip_frame_begin", "ovhip_frame_ref",
+    "ovhip_frame_create", "ovhip_frame_create_ex", "ovhip_ctx_create_prio", "ovhip_frame_destroy", "ovhip_frame_ctx", "ovhip_frame_job", "ovhip_frame_recorder", "ovhip_frame_begin", "ovhip_frame_ref",
     "ovhip_frame_ref_at", "ovhip_frame_dmvr_rows", "ovhip_frame_submit", "ovhip_frame_fail", "ovhip_frame_last_error",
     "ovhip_calllog_create", "ovhip_calllog_destroy", "ovhip_calllog_reset", "ovhip_calllog_data", "ovhip_rec_set_calllog", "ovhip_calllog_replay",
     "ovhip_stream_create", "ovhip_stream_destroy", "ovhip_stream_run", "ovhip_stream_frame", "ovhip_stream_key",

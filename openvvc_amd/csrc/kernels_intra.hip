@@ -1302,7 +1302,8 @@ extern "C" size_t ovhip_intra_flow_words(int32_t width, int32_t height)
 // epoch as for ovhip_intra_ctu_launch (d_state[0] = abort word, abort_mirror likewise).
 extern "C" int ovhip_intra_flow_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_pic *res, const ovhip_itask *d_tasks, uint32_t n_tasks,
                                        const uint32_t *d_items, uint32_t n_items, const ovhip_lmcs_region *d_regions, const ovhip_lmcs_luts *luts,
-                                       int16_t *d_scales, int32_t log2_ctu_s, uint32_t *d_state, uint32_t epoch, uint32_t *abort_mirror, int32_t prepare)
+                                       int16_t *d_scales, int32_t log2_ctu_s, uint32_t *d_state, uint32_t epoch, uint32_t *abort_mirror, int32_t prepare,
+                                       int32_t wg_per_cu)
 {
     if (!ctx || !pic || !res) return OVHIP_EINVAL;
     OV_DEVICE(ctx);
@@ -1321,7 +1322,18 @@ extern "C" int ovhip_intra_flow_launch(ovhip_ctx *ctx, const ovhip_pic *pic, con
     if (hipMemcpyToSymbolAsync(HIP_SYMBOL(g_probe_items), &d_items, sizeof(d_items), 0, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return OVHIP_ELAUNCH;
 #endif
     const int nap = 0;          // poll back-off variant: 0 = s_sleep 4 between polls (16 the same; 64 and exponential back-off measured 6 % slower)
-    hipLaunchKernelGGL(k_intra_flow, dim3(n_items), dim3(64), 0, ctx->stream, *pic, *res, d_tasks, d_items, n_items, d_regions, wnd, d_scales, log2_ctu_s, fs,
+    // Residency cap: a workgroup of this kernel that waits for its inputs sits on its compute unit, polling.  A picture whose ordered
+    // pass is a long thin chain (an I picture: ~2100 levels of ~50 items) needs a few hundred of them resident, not the ~4400 the
+    // device takes -- which leave the other pictures in flight no LDS and no wave slots (a k_alf beside an I picture's pass: 1-2 ms
+    // instead of 46 us).  Unused dynamic LDS is the lever: wg_per_cu workgroups of this launch fit a compute unit's 160 KB.
+    size_t dyn = 0;
+    if (wg_per_cu > 0 && wg_per_cu < 17) {
+        const size_t per_wg = (160u << 10) / (size_t)wg_per_cu, fixed = sizeof(FlowLds) + 1024;
+        dyn = per_wg > fixed ? per_wg - fixed : 0;
+        if (dyn > (64u << 10) - fixed) dyn = (64u << 10) - fixed;                    // one workgroup's allocation limit without opting in
+        dyn &= ~(size_t)511;
+    }
+    hipLaunchKernelGGL(k_intra_flow, dim3(n_items), dim3(64), dyn, ctx->stream, *pic, *res, d_tasks, d_items, n_items, d_regions, wnd, d_scales, log2_ctu_s, fs,
                        epoch, d_state, abort_mirror, nap);
     OV_LAUNCH_CHECK(ctx, "k_intra_flow");
     return OVHIP_OK;

@@ -80,16 +80,10 @@ __device__ __forceinline__ void md5_block(uint32_t h[4], const uint32_t m[16])
     h[0] += a; h[1] += b; h[2] += c; h[3] += d;
 }
 
-// One lane per cropped row: the row's samples are its message (2 bytes each, little endian).  A wave reads 64 rows side by side;
-// every lane walks its own row, which stays in the L1 of the compute unit between its loads.
-__global__ __launch_bounds__(64) void k_output_row_md5(OutGeom g, uint8_t *__restrict__ digests)
+// MD5 of n samples (2 bytes each, little endian) starting at src
+__device__ __forceinline__ void md5_samples(const uint16_t *src, int n, uint32_t h[4])
 {
-    const size_t row = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (row >= g.rows) return;
-    const int c = row >= g.first_row[2] ? 2 : (row >= g.first_row[1] ? 1 : 0);
-    const uint16_t *src = g.src[c] + (row - g.first_row[c]) * (size_t)g.stride[c];
-    const int n = g.w[c];
-    uint32_t h[4] = { 0x67452301u, 0xefcdab89u, 0x98badcfeu, 0x10325476u };
+    h[0] = 0x67452301u; h[1] = 0xefcdab89u; h[2] = 0x98badcfeu; h[3] = 0x10325476u;
     uint32_t m[16];
     int s = 0;
     if (((uintptr_t)src & 3) == 0) {
@@ -123,8 +117,76 @@ __global__ __launch_bounds__(64) void k_output_row_md5(OutGeom g, uint8_t *__res
     }
     m[14] = (uint32_t)bits; m[15] = (uint32_t)(bits >> 32);
     md5_block(h, m);
+}
+
+// MD5 of nd 16-byte digests held as words (LDS)
+__device__ __forceinline__ void md5_digests(const uint32_t *w, int nd, uint32_t h[4])
+{
+    h[0] = 0x67452301u; h[1] = 0xefcdab89u; h[2] = 0x98badcfeu; h[3] = 0x10325476u;
+    uint32_t m[16];
+    int d = 0;
+    for (; d + 4 <= nd; d += 4) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) m[i] = w[4 * d + i];
+        md5_block(h, m);
+    }
+    const int rem = nd - d;                       // 0..3 digests = 0..48 bytes: the padding always fits this block
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m[i] = i < 4 * rem ? w[4 * d + i] : (i == 4 * rem ? 0x80u : 0u);
+    const uint64_t bits = (uint64_t)nd * 128;
+    m[14] = (uint32_t)bits; m[15] = (uint32_t)(bits >> 32);
+    md5_block(h, m);
+}
+
+// One lane per cropped row: the row's samples are its message.  A wave reads 64 rows side by side;
+// every lane walks its own row, which stays in the L1 of the compute unit between its loads.
+__global__ __launch_bounds__(64) void k_output_row_md5(OutGeom g, uint8_t *__restrict__ digests)
+{
+    const size_t row = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (row >= g.rows) return;
+    const int c = row >= g.first_row[2] ? 2 : (row >= g.first_row[1] ? 1 : 0);
+    uint32_t h[4];
+    md5_samples(g.src[c] + (row - g.first_row[c]) * (size_t)g.stride[c], g.w[c], h);
     uint32_t *o = reinterpret_cast<uint32_t *>(digests + row * 16);
     o[0] = h[0]; o[1] = h[1]; o[2] = h[2]; o[3] = h[3];
+}
+
+// The picture's fingerprint as a three-level MD5 tree (include/ovvc_hip.h, "Digest"): MD5 is a serial chain, a whole row per lane is
+// 120 chained blocks at 4K (the one-lane-per-row kernel above takes ~200 us, on every picture's stream).  Leaves = the 1024-byte
+// pieces of every cropped row (16 blocks), then one digest per row over its pieces' digests, then one per band of 32 rows: a
+// 256-thread workgroup per band does all three levels through LDS.  The host hashes the band digests (2 KB at 4K).
+#define DG_SEG   512          /* samples per leaf (1024 bytes) */
+#define DG_BAND  32           /* rows per band                  */
+#define DG_MAXSEG 32          /* leaves per row: rows up to 16384 samples */
+__global__ __launch_bounds__(256) void k_output_tree_md5(OutGeom g, uint32_t nb0, uint32_t nb1, uint8_t *__restrict__ digests)
+{
+    __shared__ uint32_t s_d0[DG_BAND * DG_MAXSEG * 4];
+    __shared__ uint32_t s_d1[DG_BAND * 4];
+    const uint32_t band = blockIdx.x;                      // bands of Y, then Cb, then Cr
+    const int c = band >= nb0 + nb1 ? 2 : (band >= nb0 ? 1 : 0);
+    const int r0 = (int)(band - (c == 2 ? nb0 + nb1 : (c == 1 ? nb0 : 0))) * DG_BAND;
+    const int nrows = min(DG_BAND, g.h[c] - r0), w = g.w[c], nseg = (w + DG_SEG - 1) / DG_SEG;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < nrows * nseg; i += 256) {
+        const int r = i / nseg, k = i - r * nseg;
+        uint32_t h[4];
+        md5_samples(g.src[c] + (size_t)(r0 + r) * g.stride[c] + k * DG_SEG, min(DG_SEG, w - k * DG_SEG), h);
+        uint32_t *o = s_d0 + (r * DG_MAXSEG + k) * 4;
+        o[0] = h[0]; o[1] = h[1]; o[2] = h[2]; o[3] = h[3];
+    }
+    __syncthreads();
+    if (tid < nrows) {
+        uint32_t h[4];
+        md5_digests(s_d0 + tid * DG_MAXSEG * 4, nseg, h);
+        s_d1[4 * tid] = h[0]; s_d1[4 * tid + 1] = h[1]; s_d1[4 * tid + 2] = h[2]; s_d1[4 * tid + 3] = h[3];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t h[4];
+        md5_digests(s_d1, nrows, h);
+        uint32_t *o = reinterpret_cast<uint32_t *>(digests + (size_t)band * 16);
+        o[0] = h[0]; o[1] = h[1]; o[2] = h[2]; o[3] = h[3];
+    }
 }
 
 } // namespace
@@ -183,18 +245,40 @@ extern "C" int ovhip_pic_output(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhi
     return r;
 }
 
+// Bands of the digest tree: 16 bytes each in d_digests (Y bands, Cb bands, Cr bands).
+extern "C" size_t ovhip_output_bands(int32_t w, int32_t h, const ovhip_window *win)
+{
+    OutGeom g;
+    if (w <= 0 || h <= 0 || (w & 1) || (h & 1) || !out_geom(w, h, win, nullptr, g) || g.w[0] > DG_SEG * DG_MAXSEG) return 0;
+    return (size_t)(g.h[0] + DG_BAND - 1) / DG_BAND + 2 * (size_t)((g.h[1] + DG_BAND - 1) / DG_BAND);
+}
+
+extern "C" int ovhip_output_tree_md5_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_window *win, uint8_t *d_digests)
+{
+    if (!ctx || !pic) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
+    OutGeom g;
+    if (!d_digests || ((uintptr_t)d_digests & 3) || pic->w <= 0 || pic->h <= 0 || (pic->w & 1) || (pic->h & 1) || !out_geom(pic->w, pic->h, win, pic, g)
+        || g.w[0] > DG_SEG * DG_MAXSEG)
+        return ov_fail(ctx, OVHIP_EINVAL, "ovhip_output_tree_md5_launch: bad picture / window", hipSuccess);
+    const uint32_t nb0 = (uint32_t)((g.h[0] + DG_BAND - 1) / DG_BAND), nb1 = (uint32_t)((g.h[1] + DG_BAND - 1) / DG_BAND);
+    hipLaunchKernelGGL(k_output_tree_md5, dim3(nb0 + 2 * nb1), dim3(256), 0, ctx->stream, g, nb0, nb1, d_digests);
+    OV_LAUNCH_CHECK(ctx, "k_output_tree_md5");
+    return OVHIP_OK;
+}
+
 extern "C" int ovhip_pic_digest(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_window *win, uint8_t out[16])
 {
     if (!ctx || !pic || !out) return OVHIP_EINVAL;
     OV_DEVICE(ctx);
-    const size_t rows = ovhip_output_rows(pic->w, pic->h, win);
-    if (!rows) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_pic_digest: bad picture / window", hipSuccess);
-    int r = ov_scratch(ctx, rows * 16, rows * 16);
+    const size_t nb = ovhip_output_bands(pic->w, pic->h, win);
+    if (!nb) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_pic_digest: bad picture / window", hipSuccess);
+    int r = ov_scratch(ctx, nb * 16, nb * 16);
     if (r) return r;
     uint8_t *d = (uint8_t *)ctx->scratch_d, *hbuf = (uint8_t *)ctx->scratch_h;
-    r = ovhip_output_row_md5_launch(ctx, pic, win, d);
-    if (!r && hipMemcpyAsync(hbuf, d, rows * 16, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) r = ov_fail(ctx, OVHIP_ENODEV, "ovhip_pic_digest: D2H", hipGetLastError());
+    r = ovhip_output_tree_md5_launch(ctx, pic, win, d);
+    if (!r && hipMemcpyAsync(hbuf, d, nb * 16, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) r = ov_fail(ctx, OVHIP_ENODEV, "ovhip_pic_digest: D2H", hipGetLastError());
     if (!r && hipStreamSynchronize(ctx->stream) != hipSuccess) r = ov_fail(ctx, OVHIP_ELAUNCH, "ovhip_pic_digest", hipGetLastError());
-    if (!r) { ovhip_md5_state st; ovhip_md5_init(&st); ovhip_md5_update(&st, hbuf, rows * 16); ovhip_md5_final(&st, out); }
+    if (!r) { ovhip_md5_state st; ovhip_md5_init(&st); ovhip_md5_update(&st, hbuf, nb * 16); ovhip_md5_final(&st, out); }
     return r;
 }

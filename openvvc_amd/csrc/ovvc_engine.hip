@@ -62,6 +62,24 @@ int ovhip_ctx_create(ovhip_ctx **out, int device, void *stream)
     return OVHIP_OK;
 }
 
+int ovhip_ctx_create_prio(ovhip_ctx **out, int device, int stream_priority)
+{
+    if (!out) return OVHIP_EINVAL;
+    if (!stream_priority) return ovhip_ctx_create(out, device, nullptr);
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return OVHIP_ENODEV;
+    if (hipSetDevice(device) != hipSuccess) return OVHIP_ENODEV;
+    int lo = 0, hi = 0;                                        // numerically: hi <= lo (higher priority = smaller number)
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    const int p = stream_priority < 0 ? hi : lo;
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, p) != hipSuccess) return OVHIP_ENODEV;
+    // (not pooled: the context owns it through the caller-stream path, and returns it to nobody -- destroyed with the process)
+    int r = ovhip_ctx_create(out, device, (void *)s);
+    if (r != OVHIP_OK) (void)hipStreamDestroy(s);
+    return r;
+}
+
 void ovhip_ctx_destroy(ovhip_ctx *ctx)
 {
     if (!ctx) return;

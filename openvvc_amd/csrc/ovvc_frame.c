@@ -40,8 +40,10 @@ fail(ovhip_frame *f, int code, const char *what)
     return code;
 }
 
+int ovhip_frame_create(ovhip_dpb *dpb, int dev, int32_t w, int32_t h, ovhip_frame **out) { return ovhip_frame_create_ex(dpb, dev, w, h, 0, out); }
+
 int
-ovhip_frame_create(ovhip_dpb *dpb, int dev, int32_t w, int32_t h, ovhip_frame **out)
+ovhip_frame_create_ex(ovhip_dpb *dpb, int dev, int32_t w, int32_t h, int stream_priority, ovhip_frame **out)
 {
     if (!dpb || !out || dev < 0 || dev >= ovhip_dpb_n_devices(dpb) || w <= 0 || h <= 0) return OVHIP_EINVAL;
     *out = NULL;
@@ -50,7 +52,7 @@ ovhip_frame_create(ovhip_dpb *dpb, int dev, int32_t w, int32_t h, ovhip_frame **
     ovhip_frame *f = (ovhip_frame *)calloc(1, sizeof(*f));
     if (!f) return OVHIP_ENOMEM;
     f->dpb = dpb; f->dev = dev; f->w = w; f->h = h;
-    int r = ovhip_ctx_create(&f->ctx, hipdev, NULL);
+    int r = stream_priority ? ovhip_ctx_create_prio(&f->ctx, hipdev, stream_priority) : ovhip_ctx_create(&f->ctx, hipdev, NULL);
     if (r != OVHIP_OK) { free(f); return r; }
     *out = f;
     return OVHIP_OK;

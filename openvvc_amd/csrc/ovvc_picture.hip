@@ -629,17 +629,30 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
             // 1943; tagged hand-over: 8192 2617, 16384 2676, 32768 2709 -- a B picture is one launch, an I picture four)
             // (OVHIP_FLOW_CHUNK: tuning knob, read once)
             static const size_t FLOW_CHUNK = getenv("OVHIP_FLOW_CHUNK") && atol(getenv("OVHIP_FLOW_CHUNK")) > 0 ? (size_t)atol(getenv("OVHIP_FLOW_CHUNK")) : 32768;
+            // how many workgroups of the launch a compute unit may hold (ovhip_intra_flow_launch): a few levels' worth of items resident is
+            // all the chain can use; a B picture's wide levels get everything (measured on the stream of bench.py, 16 in flight, I pictures
+            // started early: no cap 2847, 8 levels' worth 2907, 4 levels' worth 2940 - 3054 pictures/s)
+            int wg_per_cu = 0;
+            {
+                static const long CAP = getenv("OVHIP_FLOW_RESIDENT") ? atol(getenv("OVHIP_FLOW_RESIDENT")) : 4;      // levels' worth; 0: no cap
+                const size_t width = n_items / (n_lv ? n_lv : 1) + 1;
+                const size_t want = CAP > 0 ? (size_t)CAP * width : 0;
+                if (want) { const size_t per_cu = (want + (size_t)ctx->num_cus - 1) / (size_t)ctx->num_cus; wg_per_cu = per_cu < 3 ? 3 : (per_cu >= 17 ? 0 : (int)per_cu); }
+            }
             size_t a = 0;
             int first = !flow_prepared;
+            const size_t chunk = pr->flow_chunk_items ? pr->flow_chunk_items : FLOW_CHUNK;
             while (a < n_items) {
-                size_t b = a + FLOW_CHUNK < n_items ? a + FLOW_CHUNK : n_items;
+                size_t b = a + chunk < n_items ? a + chunk : n_items;
                 while (b < n_items && it[j->items_host[b] & 0xffffff].level == it[j->items_host[b - 1] & 0xffffff].level) ++b;
                 CHK(ovhip_intra_flow_launch(ctx, dst, &j->res, d_it, (uint32_t)n_it, (const uint32_t *)j->dev[B_IITEM].p + a, (uint32_t)(b - a),
                                             (const ovhip_lmcs_region *)DEV(B_REG), pr->lmcs, (int16_t *)j->dev[B_SCALE].p, log2_ctu, j->d_flow, j->epoch,
-                                            j->abort_host, first));
+                                            j->abort_host, first, wg_per_cu));
                 j->st.n_launches += 1 + first;
                 first = 0;
                 a = b;
+                // paced: the streams that share this stream's hardware queue get their packets in between two chunks
+                if (pr->flow_paced && a < n_items) OV_HIP(ctx, hipStreamSynchronize(ctx->stream));
             }
         }
         for (uint32_t l = 0; by_level && !by_flow && l < n_lv; ++l) {

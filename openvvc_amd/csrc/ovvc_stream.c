@@ -33,7 +33,7 @@ struct ovhip_stream {
     const ovhip_stream_content *contents; uint32_t n_contents;
     ovhip_job *const *jobs; uint32_t n_jobs;
     pthread_mutex_t *job_mtx;
-    int n_dev, tpd;
+    int n_dev, tpd, n_reg;                /* frames per device: n_reg in-order frame threads + (tpd - n_reg) look-ahead threads */
     ovhip_frame **frames;                 /* [n_dev * tpd] */
     ovhip_ctx **out_ctx;                  /* output thread: one context per device */
     void *out_host; size_t out_host_bytes;
@@ -48,7 +48,7 @@ struct ovhip_stream {
     uint8_t *dg;                          /* OVHIP_OUT_DIGEST: the pictures' digests, computed by their frame threads (begun[idx] == 2: there) */
 };
 
-struct dev_queue { uint32_t *order; uint32_t n, next; pthread_mutex_t take; };
+struct dev_queue { uint32_t *order; unsigned char *taken; uint32_t n, next; pthread_mutex_t take; pthread_cond_t moved; };
 
 struct run_state {
     ovhip_stream *s;
@@ -80,6 +80,9 @@ run_fail(struct run_state *rs, int code, const char *what, const char *detail)
     pthread_mutex_unlock(&rs->mtx);
     rs->abort = 1;
     ovhip_dpb_shutdown(rs->s->dpb);        /* nobody keeps waiting for a picture that will not come */
+    for (int k = 0; rs->q && k < rs->s->n_dev; ++k) {
+        pthread_mutex_lock(&rs->q[k].take); pthread_cond_broadcast(&rs->q[k].moved); pthread_mutex_unlock(&rs->q[k].take);
+    }
     pthread_mutex_lock(&rs->s->begun_mtx);
     pthread_cond_broadcast(&rs->s->begun_cnd);
     pthread_mutex_unlock(&rs->s->begun_mtx);
@@ -171,7 +174,7 @@ adopt_stream(ovhip_stream *s, const ovhip_stream_pic *pics, uint32_t n_total, ui
 
 /* ---------------------------------------------------------------- frame threads */
 static void
-decode_picture(struct run_state *rs, ovhip_frame *f, uint32_t idx, int job_locked)
+decode_picture(struct run_state *rs, ovhip_frame *f, uint32_t idx, int job_locked, int ahead)
 {
     ovhip_stream *s = rs->s;
     const ovhip_stream_pic *p = &rs->pics[idx];
@@ -196,6 +199,7 @@ decode_picture(struct run_state *rs, ovhip_frame *f, uint32_t idx, int job_locke
         ovhip_job_params pr = c->params;
         pr.stages = (pr.stages ? pr.stages : STAGE_ALL) | s->cfg.extra_stages | ((rs->flags & OVHIP_STREAM_RESIDENT) ? OVHIP_STAGE_RESIDENT : 0);
         if (pr.stages == STAGE_ALL) pr.stages = 0;
+        if (ahead && s->cfg.ahead_chunk_items) { pr.flow_chunk_items = (uint32_t)s->cfg.ahead_chunk_items; pr.flow_paced = 1; }
         ovhip_frame_output out;
         memset(&out, 0, sizeof(out));
         /* the fingerprint is taken by the picture's own frame thread, after the picture was published (16 threads hash 16 pictures;
@@ -238,10 +242,24 @@ frame_thread(void *argp)
     ovhip_stream *s = rs->s;
     struct dev_queue *q = &rs->q[a->dev];
     ovhip_frame *f = s->frames[a->dev * s->tpd + a->t];
+    const int ahead = a->t >= s->n_reg;            /* a look-ahead thread: pictures WITHOUT reference pictures, before their turn */
     for (;;) {
         pthread_mutex_lock(&q->take);
-        if (rs->abort || q->next >= q->n) { pthread_mutex_unlock(&q->take); break; }
-        const uint32_t idx = q->order[q->next++];
+        uint32_t idx = 0;
+        int have = 0;
+        while (!have) {
+            while (q->next < q->n && q->taken[q->next]) ++q->next;
+            if (rs->abort || q->next >= q->n) break;
+            if (!ahead) { q->taken[q->next] = 1; idx = q->order[q->next++]; have = 1; pthread_cond_broadcast(&q->moved); break; }
+            /* An intra picture depends on nothing: started up to intra_lookahead pictures before its turn in decoding order it runs
+             * beside the pictures that precede it, instead of in front of the pictures that wait for it (what a decoder with that
+             * many frame threads would do by itself; here one thread and one picture buffer do it) */
+            const uint32_t lim = q->next + (uint32_t)s->cfg.intra_lookahead < q->n ? q->next + (uint32_t)s->cfg.intra_lookahead : q->n;
+            for (uint32_t k = q->next; k < lim && !have; ++k)
+                if (!q->taken[k] && rs->pics[q->order[k]].n_refs == 0) { q->taken[k] = 1; idx = q->order[k]; have = 1; }
+            if (!have) pthread_cond_wait(&q->moved, &q->take);          /* the window moves when the in-order threads take pictures */
+        }
+        if (!have) { pthread_cond_broadcast(&q->moved); pthread_mutex_unlock(&q->take); break; }
         int locked = 0;
         if (!(rs->flags & OVHIP_STREAM_RECORD)) {
             /* a pre-recorded job is in flight once at a time; taken in decoding order (still under the queue's lock), so a
@@ -250,7 +268,7 @@ frame_thread(void *argp)
             locked = 1;
         }
         pthread_mutex_unlock(&q->take);
-        decode_picture(rs, f, idx, locked);
+        decode_picture(rs, f, idx, locked, ahead);
     }
     return NULL;
 }
@@ -344,7 +362,8 @@ ovhip_stream_create(ovhip_stream **out, ovhip_dpb *dpb, const ovhip_stream_cfg *
     if (!s) return OVHIP_ENOMEM;
     pthread_mutex_init(&s->begun_mtx, NULL); pthread_cond_init(&s->begun_cnd, NULL);
     s->dpb = dpb; s->cfg = *cfg; s->contents = contents; s->n_contents = n_contents; s->jobs = jobs; s->n_jobs = n_jobs;
-    s->n_dev = ovhip_dpb_n_devices(dpb); s->tpd = cfg->threads_per_device;
+    s->n_dev = ovhip_dpb_n_devices(dpb); s->n_reg = cfg->threads_per_device;
+    s->tpd = s->n_reg + (cfg->intra_lookahead > 0 ? 1 : 0);
     /* several stream objects may share one DPB (bench.py: one per configuration): each gets a key space of its own */
     static uintptr_t next_space = 1;
     s->key_base = __atomic_fetch_add(&next_space, 1, __ATOMIC_RELAXED) << 40;
@@ -354,7 +373,10 @@ ovhip_stream_create(ovhip_stream **out, ovhip_dpb *dpb, const ovhip_stream_cfg *
     s->job_mtx = (pthread_mutex_t *)calloc(n_jobs ? n_jobs : 1, sizeof(*s->job_mtx));
     if (!s->frames || !s->out_ctx || !s->job_mtx) r = OVHIP_ENOMEM;
     for (uint32_t i = 0; i < n_jobs && r == OVHIP_OK; ++i) pthread_mutex_init(&s->job_mtx[i], NULL);
-    for (int i = 0; i < s->n_dev * s->tpd && r == OVHIP_OK; ++i) r = ovhip_frame_create(dpb, i / s->tpd, cfg->w, cfg->h, &s->frames[i]);
+    /* (a look-ahead thread's launches go to a stream of another priority = a hardware queue of its own: an I picture's ordered pass
+     * is one kernel of several milliseconds, and a hardware queue runs its streams' packets in order) */
+    for (int i = 0; i < s->n_dev * s->tpd && r == OVHIP_OK; ++i)
+        r = ovhip_frame_create_ex(dpb, i / s->tpd, cfg->w, cfg->h, (i % s->tpd) >= s->n_reg ? cfg->intra_stream_priority : 0, &s->frames[i]);
     if (cfg->output == OVHIP_OUT_PACKED) {
         for (int k = 0; k < s->n_dev && r == OVHIP_OK; ++k) r = ovhip_ctx_create(&s->out_ctx[k], ovhip_dpb_device(dpb, k), NULL);
         if (r == OVHIP_OK) {
@@ -428,9 +450,10 @@ ovhip_stream_run(ovhip_stream *s, const ovhip_stream_pic *pics, uint32_t n_total
     struct thread_arg *ta = (struct thread_arg *)calloc((size_t)nthr, sizeof(*ta));
     r = rs.q && rs.out_order && th && ta ? OVHIP_OK : OVHIP_ENOMEM;
     for (int k = 0; k < s->n_dev && r == OVHIP_OK; ++k) {
-        pthread_mutex_init(&rs.q[k].take, NULL);
+        pthread_mutex_init(&rs.q[k].take, NULL); pthread_cond_init(&rs.q[k].moved, NULL);
         rs.q[k].order = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
-        if (!rs.q[k].order) r = OVHIP_ENOMEM;
+        rs.q[k].taken = (unsigned char *)calloc(n ? n : 1, 1);
+        if (!rs.q[k].order || !rs.q[k].taken) r = OVHIP_ENOMEM;
     }
     if (r == OVHIP_OK) {
         for (uint32_t i = first; i < first + n; ++i) {
@@ -458,7 +481,7 @@ ovhip_stream_run(ovhip_stream *s, const ovhip_stream_pic *pics, uint32_t n_total
         res->status = r;
     }
     if (rs.abort) ovhip_dpb_rearm_(s->dpb);
-    for (int k = 0; rs.q && k < s->n_dev; ++k) { free(rs.q[k].order); pthread_mutex_destroy(&rs.q[k].take); }
+    for (int k = 0; rs.q && k < s->n_dev; ++k) { free(rs.q[k].order); free(rs.q[k].taken); pthread_cond_destroy(&rs.q[k].moved); pthread_mutex_destroy(&rs.q[k].take); }
     free(rs.q); free(rs.out_order); free(th); free(ta);
     pthread_mutex_destroy(&rs.mtx);
     if (res->status || !(flags & OVHIP_STREAM_KEEP)) release_stream(s);

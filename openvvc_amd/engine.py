@@ -641,7 +641,8 @@ class Stream:
     (pre-recorded pictures).  Everything referenced stays alive as long as this object."""
 
     def __init__(self, dpb: Dpb, w: int, h: int, contents: list, jobs: list = (), threads_per_device: int = 1, flags: int = 0,
-                 output: int = 0, window=(0, 0, 0, 0), extra_stages: int = 0, rank: int = 0, xfer: "capi.StreamXfer | None" = None):
+                 output: int = 0, window=(0, 0, 0, 0), extra_stages: int = 0, rank: int = 0, xfer: "capi.StreamXfer | None" = None,
+                 intra_lookahead: int = 0, intra_stream_priority: int = 0, ahead_chunk_items: int = 0):
         self.lib, self.dpb = dpb.lib, dpb
         self._contents = (capi.StreamContent * len(contents))()
         self._keep = [contents, jobs, xfer]
@@ -658,6 +659,7 @@ class Stream:
         cfg.window = capi.Window(*window)
         cfg.extra_stages, cfg.rank = extra_stages, rank
         cfg.xfer = C.pointer(xfer) if xfer is not None else None
+        cfg.intra_lookahead, cfg.intra_stream_priority, cfg.ahead_chunk_items = intra_lookahead, intra_stream_priority, ahead_chunk_items
         self.cfg = cfg
         s = C.c_void_p()
         r = self.lib.ovhip_stream_create(C.byref(s), dpb.h, C.byref(cfg), self._contents, len(contents), self._jobs, len(jobs))
