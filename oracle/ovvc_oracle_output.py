@@ -1,6 +1,10 @@
 """TEST INFRASTRUCTURE -- CPU restatement of the reference's output path, for checking the device output path only (tests/,
 smoke).  Never imported by the product.
 
+PARITY UNPINNED for this leg: examples/dectest.c includes ovversion.h, which only the reference's build system generates (version.sh);
+the file cannot be compiled here without writing a stand-in for it, so write_decoded_frame_to_file was never run -- this restatement
+is pinned by nothing but its reading of the source.  It is ten lines of slicing:
+
 write_decoded_frame_to_file (examples/dectest.c:372-409): the window offsets of OVFrame.output_window are in chroma sample
 units (luma: twice, :383-388); every component writes frame_h rows of frame_w 16-bit little-endian samples starting at
 (win_left, win_top) (:389-397); without a window the three planes are written whole (:399-405) -- the same bytes.

@@ -2080,6 +2080,9 @@ main(int argc, char **argv)
     const char *dir = argc > 1 ? argv[1] : "../tests/golden";
     const char *only = argc > 2 ? argv[2] : NULL;
     if (only && !strcmp(only, "shim")) { g_shim = 1; only = argc > 3 ? argv[3] : NULL; }
+    /* "simd": the same generators through the reference's SSE4.1 / AVX2 slots (`gen_golden <scratch dir> simd` rewrites the
+     * fixtures from them -- byte-identical to the scalar ones if the reference's back-ends agree; `... simd time` times them) */
+    if (only && !strcmp(only, "simd")) { g_simd = 1; only = argc > 3 ? argv[3] : NULL; }
     if (only && !strcmp(only, "time")) {
         /* five passes over the generators, the best time per stage; fixtures go to `dir` (use a scratch directory) */
         double best[TS_N];

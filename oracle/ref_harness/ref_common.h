@@ -57,9 +57,74 @@ void rcn_init_inter_functions_10(struct RCNFunctions *);
 void rcn_init_ibc_10(struct RCNFunctions *);
 void rcn_init_cclm_functions_10(struct RCNFunctions *);
 
+/* the initialisers of the reference's x86 back-end (prototypes as in libovvc/x86/rcn_sse.h:39-54, rcn_avx2.h:38-47; those headers
+ * include the autoconf-generated ovconfig.h and cannot be included here) */
+void rcn_init_mc_functions_sse(struct RCNFunctions *const);
+void rcn_init_tr_functions_sse(struct RCNFunctions *const);
+void rcn_init_dc_planar_functions_sse(struct RCNFunctions *const);
+void rcn_init_ict_functions_sse(struct RCNFunctions *, uint8_t type);
+void rcn_init_alf_functions_sse(struct RCNFunctions *);
+void rcn_init_cclm_functions_sse(struct RCNFunctions *);
+void rcn_init_lfnst_functions_sse(struct RCNFunctions *);
+void rcn_init_mip_functions_sse(struct RCNFunctions *const);
+void rcn_init_dmvr_functions_sse(struct RCNFunctions *const);
+void rcn_init_prof_functions_sse(struct RCNFunctions *const);
+void rcn_init_bdof_functions_sse(struct RCNFunctions *const);
+void rcn_init_ciip_functions_sse(struct RCNFunctions *const);
+void rcn_init_df_functions_sse(struct RCNFunctions *const);
+void rcn_init_intra_angular_functions_10_sse(struct RCNFunctions *);
+void rcn_init_dequant_sse(struct RCNFunctions *);
+void rcn_init_alf_functions_avx2(struct RCNFunctions *);
+void rcn_init_sao_functions_avx2(struct RCNFunctions *);
+void rcn_init_ict_functions_avx2(struct RCNFunctions *, uint8_t type);
+void rcn_init_mip_functions_avx2(struct RCNFunctions *const);
+void rcn_init_prof_functions_avx2(struct RCNFunctions *const);
+void rcn_init_bdof_functions_avx2(struct RCNFunctions *const);
+void rcn_init_dmvr_functions_avx2(struct RCNFunctions *const);
+void rcn_init_ciip_functions_avx2(struct RCNFunctions *const);
+void rcn_init_mc_functions_avx2(struct RCNFunctions *const);
+void rcn_init_intra_angular_functions_10_avx2(struct RCNFunctions *);
+/* != 0: the reference's SSE4.1 / AVX2 overrides on top of the scalar table, in the order of rcn.c:216-254 (all but
+ * rcn_init_sao_functions_sse, whose file needs the autoconf-generated ovconfig.h and is not built here) */
+static int g_simd;
+
 /* same call sequence as rcn_init_functions() (rcn.c:151-180) for bitdepth 10, scalar */
+static void ref_fill_table_scalar(struct RCNFunctions *f, uint8_t ict_type, uint8_t lmcs_flag);
 static void
 ref_fill_table(struct RCNFunctions *f, uint8_t ict_type, uint8_t lmcs_flag)
+{
+    ref_fill_table_scalar(f, ict_type, lmcs_flag);
+    if (!g_simd) return;
+    if (!__builtin_cpu_supports("sse4.1") || !__builtin_cpu_supports("avx2")) { fprintf(stderr, "simd: this CPU has no SSE4.1 / AVX2\n"); exit(1); }
+    rcn_init_mc_functions_sse(f);
+    rcn_init_tr_functions_sse(f);
+    rcn_init_dc_planar_functions_sse(f);
+    rcn_init_ict_functions_sse(f, ict_type);
+    rcn_init_lfnst_functions_sse(f);
+    rcn_init_mip_functions_sse(f);
+    rcn_init_alf_functions_sse(f);
+    rcn_init_dmvr_functions_sse(f);
+    rcn_init_prof_functions_sse(f);
+    rcn_init_bdof_functions_sse(f);
+    rcn_init_ciip_functions_sse(f);
+    rcn_init_df_functions_sse(f);
+    rcn_init_intra_angular_functions_10_sse(f);
+    rcn_init_dequant_sse(f);
+    rcn_init_cclm_functions_sse(f);                  /* lm_chroma_enabled && !sps_chroma_vertical_collocated_flag (rcn.c:233-237) */
+    rcn_init_alf_functions_avx2(f);
+    rcn_init_sao_functions_avx2(f);
+    rcn_init_ict_functions_avx2(f, ict_type);
+    rcn_init_mip_functions_avx2(f);
+    rcn_init_ciip_functions_avx2(f);
+    rcn_init_mc_functions_avx2(f);
+    rcn_init_dmvr_functions_avx2(f);
+    rcn_init_prof_functions_avx2(f);
+    rcn_init_bdof_functions_avx2(f);
+    rcn_init_intra_angular_functions_10_avx2(f);
+}
+
+static void
+ref_fill_table_scalar(struct RCNFunctions *f, uint8_t ict_type, uint8_t lmcs_flag)
 {
     rcn_init_ctu_buffs_10(f);
     rcn_init_mc_functions_10(f);

@@ -37,6 +37,9 @@ def main():
     with tempfile.TemporaryDirectory() as d:
         out = subprocess.run([str(ROOT / "oracle" / "_ref" / "gen_golden"), d, "time"], capture_output=True, text=True, check=True)
     ref = json.loads(out.stdout.strip().splitlines()[-1])
+    with tempfile.TemporaryDirectory() as d:
+        out = subprocess.run([str(ROOT / "oracle" / "_ref" / "gen_golden"), d, "simd", "time"], capture_output=True, text=True, check=True)
+    simd = json.loads(out.stdout.strip().splitlines()[-1])
     port = {}
     # itx: the 425 rcn_tu_st / rcn_tu_c cases
     pic, cmds, coefs, _, _ = golden_cases.itx_cases()
@@ -62,7 +65,25 @@ def main():
     tasks = np.frombuffer(g["task"].tobytes(), dtype=capi.ITASK_DTYPE)
     ip = HostPic(g["pic_y"].shape[1], g["pic_y"].shape[0], g["pic_y"], g["pic_cb"], g["pic_cr"])
     port["intra"] = best(lambda: oracle_lib.intra_tasks(ip, tasks))
-    stages = {k: {"reference_s": round(ref[k], 6), "port_s": round(port[k], 6), "port_over_reference": round(port[k] / ref[k], 3)} for k in port if k in ref}
+    stages = {k: {"reference_s": round(ref[k], 6), "reference_simd_s": round(simd[k], 6), "port_s": round(port[k], 6),
+                  "port_over_reference": round(port[k] / ref[k], 3), "port_over_reference_simd": round(port[k] / simd[k], 3)} for k in port if k in ref}
+    # where the port spends its time on the picture bench.py's cpu_baseline decodes (a B picture with every tool, 12 % intra CUs;
+    # 1920x1080 here, the shares do not depend on the size): cumulative stage masks, differences
+    import oracle_pipeline
+    from openvvc_amd import synth
+    wl = synth.make_workload(1920, 1080, 0x266, tools=synth.INTRA_TOOLS, intra_frac=0.12)
+    cum, prev, share = [], 0.0, {}
+    for k, name in enumerate(oracle_pipeline.STAGES):
+        t = best(lambda: oracle_pipeline.decode(wl, stages=oracle_pipeline.STAGES[:k + 1]), 3)
+        share[name] = max(t - prev, 0.0)
+        prev = t
+    # the "itx" stage of such a picture contains the ordered intra pass: split it with the stand-alone intra timing ratio
+    wl0 = synth.make_workload(1920, 1080, 0x266, tools=synth.ALL_TOOLS, intra_frac=0.0)
+    t_itx0 = best(lambda: oracle_pipeline.decode(wl0, stages=("mc", "itx")), 3) - best(lambda: oracle_pipeline.decode(wl0, stages=("mc",)), 3)
+    intra_part = max(share["itx"] - t_itx0, 0.0)
+    share["intra"] = intra_part; share["itx"] = share["itx"] - intra_part
+    tot = sum(share.values())
+    share = {k: round(v / tot, 4) for k, v in share.items()}
     cpu = ""
     try:
         cpu = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
@@ -71,11 +92,16 @@ def main():
     json.dump({"what": "seconds inside the reference's scalar slots (oracle/_ref/gen_golden time: rcn_tu_st / rcn_tu_c, rcn_mcp_b*, "
                        "df.rcn_dbf_ctu, sao.rcn_sao_filter_line, alf.rcn_alf_filter_line, intra_pred*) vs seconds inside the oracle "
                        "port (oracle/liboracle.so) on the same cases of tests/golden/*.ovg; one thread, best of five",
-               "host": cpu, "cores_present": os.cpu_count(), "stages": stages,
+               "host": cpu, "cores_present": os.cpu_count(), "stages": stages, "picture_share": share,
+               "simd": "the reference's x86 back-end (libovvc/x86/*_sse.c, *_avx2.c, -msse4.1 -mavx2 -DBITDEPTH=10) installed over the scalar table in "
+                       "the order of rcn.c:216-254 by `gen_golden <dir> simd time`; rcn_sao_sse.c needs the autoconf-generated ovconfig.h and is not "
+                       "built (SAO runs the AVX2 override).  Its results are NOT byte-identical to the scalar slots on every harness case: "
+                       "`gen_golden <dir> simd` reproduces dbf / gpm / intra / lmcs / mc / mca / mcx.ovg byte for byte and differs on alf / sao / itx / "
+                       "intra_ctu / isp.ovg (the harness draws out-of-range corner inputs); the scalar slots stay the oracle",
                "note": "port_over_reference > 1: the port is slower than the reference's scalar C on that stage, i.e. bench.py's "
-                       "cpu_baseline UNDERSTATES what the reference's scalar path would reach by about that factor; the reference's "
-                       "SIMD back-ends (SSE4 / AVX2, rcn.c:214-299) are not built here (x86 intrinsics need -msse4.1 / -mavx2 and "
-                       "their own dispatch) and are faster still"}, sys.stdout, indent=1)
+                       "cpu_baseline UNDERSTATES what the reference's scalar path would reach by about that factor, and its SIMD "
+                       "path by port_over_reference_simd; bench.py prints both estimates (reference_scalar_estimate, "
+                       "reference_simd_estimate = value / sum over stages of picture_share / ratio)"}, sys.stdout, indent=1)
     print()
 
 
