@@ -134,11 +134,13 @@ def main():
                     help="ONE process driving this many logical devices (device DPB + hipMemcpyPeerAsync); with --same-gpu all of them on GPU 0")
     ap.add_argument("--same-gpu", action="store_true")
     ap.add_argument("--record-threads", type=str, default="1,4,16", help="frame-thread counts of the recorded_in_run variant")
+    ap.add_argument("--trace", type=str, default="", help="debug: write the per-picture timeline of the timed region (taken / submitted / published, thread) to this file")
     ap.add_argument("--intra-lookahead", type=int, default=64,
                     help="pictures: one more frame thread per device starts pictures WITHOUT reference pictures (I pictures) up to this many pictures "
                          "before their turn in decoding order (0: strictly in order)")
     ap.add_argument("--intra-priority", type=int, default=0, help="HIP stream priority of that thread (0 default, -1 high, 1 low)")
-    ap.add_argument("--ahead-chunk", type=int, default=16384, help="ordered pass of the pictures that thread starts early: paced launches of this many items (0: as every picture)")
+    ap.add_argument("--ahead-own-queue", type=int, default=1, help="1: the look-ahead thread's stream gets a hardware queue no in-order thread's stream shares (probed at start)")
+    ap.add_argument("--ahead-chunk", type=int, default=0, help="ordered pass of the pictures that thread starts early: paced launches of this many items (0: as every picture)")
     args = ap.parse_args()
 
     import torch
@@ -246,7 +248,8 @@ def main():
     def new_stream(threads, output="none", flags=0, xfer=None, use_jobs=True):
         return engine.Stream(dpb, W, H, contents, jobs if use_jobs else [], threads_per_device=threads, flags=flags, output=OUT[output],
                              extra_stages=lv, rank=rank, xfer=xfer, intra_lookahead=lookahead if threads > 1 else 0,
-                             intra_stream_priority=args.intra_priority, ahead_chunk_items=args.ahead_chunk)
+                             intra_stream_priority=args.intra_priority, ahead_chunk_items=args.ahead_chunk,
+                             ahead_own_queue=args.ahead_own_queue if threads > 1 else 0)
 
     # ---- multi-process exchange: the driver's comm thread calls back here, one call per transferred picture ----
     xfer = None
@@ -403,10 +406,13 @@ def main():
             n_warm = 1 + max(1, args.warmup) * PPS
             st_t.run(tarr, NT, 0, n_warm, flags=capi.STREAM_KEEP)
         else:
-            tarr, NT, n_warm = larr, NL, cur[0]
+            tarr, NT, n_warm, tspics = larr, NL, cur[0], lspics
         barrier()
         t0 = time.perf_counter()
-        res, _ = st_t.run(tarr, NT, n_warm, args.steps * PPS, flags=capi.STREAM_KEEP)
+        trace = np.zeros((args.steps * PPS, 4)) if args.trace else None
+        res, _ = st_t.run(tarr, NT, n_warm, args.steps * PPS, flags=capi.STREAM_KEEP, trace=trace)
+        if trace is not None:
+            np.save(args.trace, np.concatenate([trace, np.array([[len(tspics[n_warm + i]["refs"]), tspics[n_warm + i]["poc"], n_warm + i, 0] for i in range(len(trace))], float)], axis=1))
         barrier()
         dt = time.perf_counter() - t0
         if st_t is st_main:
@@ -417,6 +423,7 @@ def main():
         count(res)
     dom_avg = read_timer()
     set_timer(None)
+    q_moved, q_sharing = st_t.queue_info()
     ms_per_step = dt * 1e3 / args.steps
     fps = n_timed_all / dt
     lib_seconds = float(res.seconds)
@@ -628,6 +635,7 @@ def main():
                                "peer_copies": int(dpb_stats.n_copies), "waits_for_a_reference": int(dpb_stats.n_waits)},
                        "pictures_in_flight_per_gpu": S, "host_threads": S + (1 if lookahead else 0), "local_devices": L,
                        "intra_lookahead_pictures": lookahead,
+                       "lookahead_thread_hw_queue": {"streams_replaced": q_moved, "in_order_streams_still_sharing_it": q_sharing} if lookahead else None,
                        "picture_assignment": "decoding order; a free frame thread (pthread, own HIP stream) takes the next picture of its device",
                        "n_cu": st["n_cu"], "cu_modes": st["cu_modes"], "n_mc_units": st["n_mc_units"],
                        "n_mcx_units": st["n_mcx_units"], "n_aff_units": st["n_aff_units"], "n_tb_cmds": st["n_tb_cmds"],

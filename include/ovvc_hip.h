@@ -658,6 +658,10 @@ int  ovhip_ctx_create(ovhip_ctx **out, int device, void *stream);
 /* stream == NULL: a new stream of the given priority (0: default; the runtime clamps to its range) */
 int  ovhip_ctx_create_prio(ovhip_ctx **out, int device, int stream_priority);
 void ovhip_ctx_destroy(ovhip_ctx *ctx);
+/* 1 if the streams of the two (idle) contexts are served by the same hardware queue, 0 if not (measured: ~2 ms), < 0 error; and a
+ * fresh stream for a context whose stream is in the wrong company (see ovvc_engine.hip) */
+int  ovhip_ctx_shares_queue(ovhip_ctx *a, ovhip_ctx *b);
+int  ovhip_ctx_new_stream(ovhip_ctx *ctx);
 int  ovhip_ctx_sync(ovhip_ctx *ctx);
 const char *ovhip_last_error(const ovhip_ctx *ctx);
 /* Overlap of independent launches inside one stage: route the following launches to side stream k (1..3), or back
@@ -1165,6 +1169,8 @@ typedef struct ovhip_stream_cfg {
     int32_t intra_lookahead;
     int32_t intra_stream_priority;         /* HIP stream priority of that thread's context (0 default, < 0 higher, > 0 lower)  */
     int32_t ahead_chunk_items;             /* > 0: its pictures' ordered pass in paced launches of this many items (ovhip_job_params.flow_paced) */
+    int32_t ahead_own_queue;               /* != 0: at creation, streams of in-order threads that share that thread's hardware queue are replaced
+                                            * until none does (ovhip_ctx_shares_queue; ~2 ms per probe)                                     */
 } ovhip_stream_cfg;
 
 typedef struct ovhip_stream_result {
@@ -1177,6 +1183,9 @@ typedef struct ovhip_stream_result {
     double   record_seconds;               /* OVHIP_STREAM_RECORD: time spent replaying call logs, summed over threads */
     int32_t  status;                       /* 0 or the first error                                                   */
     char     error[192];
+    /* in: NULL, or room for 4 doubles per picture of the run -- seconds since the run began at which the picture was taken by a
+     * frame thread, entered ovhip_frame_submit, was published (left it), and the thread's index in the 4th (analysis of stalls) */
+    double  *trace;
 } ovhip_stream_result;
 
 typedef struct ovhip_stream ovhip_stream;
@@ -1192,6 +1201,8 @@ void ovhip_stream_destroy(ovhip_stream *s);
 int  ovhip_stream_run(ovhip_stream *s, const ovhip_stream_pic *pics, uint32_t n_total, uint32_t first, uint32_t n, uint32_t flags,
                       uint8_t *digests, ovhip_stream_result *res);
 ovhip_frame *ovhip_stream_frame(ovhip_stream *s, int dev, int thread);
+/* ahead_own_queue: streams replaced at creation / in-order streams that still share the look-ahead thread's hardware queue */
+int  ovhip_stream_queue_info(const ovhip_stream *s, int *moved, int *sharing);
 /* The DPB key of picture idx of the current stream (valid while the run that decoded it kept it: OVHIP_STREAM_KEEP). */
 const void *ovhip_stream_key(const ovhip_stream *s, uint32_t idx);
 /* test hook: the next flush of `job` that has a flow launch is ABORTED for real (the device's abort word is set before the

@@ -319,13 +319,13 @@ class StreamXfer(C.Structure):
 class StreamCfg(C.Structure):
     _fields_ = [("w", C.c_int32), ("h", C.c_int32), ("flags", C.c_uint32), ("threads_per_device", C.c_int32), ("output", C.c_int32),
                 ("window", Window), ("extra_stages", C.c_uint32), ("rank", C.c_int32), ("xfer", C.POINTER(StreamXfer)),
-                ("intra_lookahead", C.c_int32), ("intra_stream_priority", C.c_int32), ("ahead_chunk_items", C.c_int32)]
+                ("intra_lookahead", C.c_int32), ("intra_stream_priority", C.c_int32), ("ahead_chunk_items", C.c_int32), ("ahead_own_queue", C.c_int32)]
 
 
 class StreamResult(C.Structure):
     _fields_ = [("seconds", C.c_double), ("n_decoded", C.c_uint64), ("n_second_passes", C.c_uint64), ("n_received", C.c_uint64),
                 ("n_sent", C.c_uint64), ("out_frames", C.c_uint64), ("out_bytes", C.c_uint64), ("out_md5", C.c_uint8 * 16),
-                ("record_seconds", C.c_double), ("status", C.c_int32), ("error", C.c_char * 192)]
+                ("record_seconds", C.c_double), ("status", C.c_int32), ("error", C.c_char * 192), ("trace", C.c_void_p)]
 
 
 class Md5State(C.Structure):
@@ -397,6 +397,8 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_ctx_create": (C.c_int, [P(vp), C.c_int, vp]),
         "ovhip_ctx_destroy": (None, [vp]),
         "ovhip_ctx_sync": (C.c_int, [vp]),
+        "ovhip_ctx_shares_queue": (C.c_int, [vp, vp]),
+        "ovhip_ctx_new_stream": (C.c_int, [vp]),
         "ovhip_ctx_fork": (C.c_int, [vp, C.c_int]),
         "ovhip_ctx_join": (C.c_int, [vp]),
         "ovhip_last_error": (C.c_char_p, [vp]),
@@ -510,6 +512,7 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_stream_destroy": (None, [vp]),
         "ovhip_stream_run": (C.c_int, [vp, P(StreamPic), u32, u32, u32, u32, vp, P(StreamResult)]),
         "ovhip_stream_frame": (vp, [vp, C.c_int, C.c_int]),
+        "ovhip_stream_queue_info": (C.c_int, [vp, P(C.c_int), P(C.c_int)]),
         "ovhip_stream_key": (vp, [vp, u32]),
     }
     for name, (res, args) in sigs.items():
@@ -525,7 +528,7 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
 EXPORTED_SYMBOLS = [
     "ovhip_abi_version", "ovhip_rec_create", "ovhip_rec_destroy", "ovhip_rec_reset", "ovhip_rec_tu",
     "ovhip_rec_pu", "ovhip_rec_dbf_ctu", "ovhip_rec_dbf_planes", "ovhip_dbf_launch", "ovhip_sao_launch", "ovhip_alf_launch", "ovhip_rec_tb_cmds", "ovhip_rec_coefs", "ovhip_rec_mc_units", "ovhip_rec_mcx_units", "ovhip_mcx_launch", "ovhip_rec_affine_cu", "ovhip_rec_transform_tree", "ovhip_rec_lmcs_region", "ovhip_dbf_compact", "ovhip_rec_dbf_mv_prepass", "ovhip_dbf_launch_edges", "ovhip_rec_ciip", "ovhip_ciip_weight", "ovhip_rec_ciip_units", "ovhip_ciip_launch", "ovhip_rec_lmcs_regions", "ovhip_rec_tb_cmds_split", "ovhip_itx_launch_classes", "ovhip_itx_launch_chroma_lmcs", "ovhip_lmcs_build", "ovhip_lmcs_scale_launch", "ovhip_lmcs_inverse_launch", "ovhip_rec_aff_units", "ovhip_rec_aff_side", "ovhip_mca_launch", "ovhip_mcxa_launch", "ovhip_ctx_create",
-    "ovhip_ctx_destroy", "ovhip_ctx_sync", "ovhip_ctx_fork", "ovhip_ctx_join", "ovhip_last_error", "ovhip_ctx_stream", "ovhip_malloc",
+    "ovhip_ctx_destroy", "ovhip_ctx_sync", "ovhip_ctx_shares_queue", "ovhip_ctx_new_stream", "ovhip_ctx_fork", "ovhip_ctx_join", "ovhip_last_error", "ovhip_ctx_stream", "ovhip_malloc",
     "ovhip_free", "ovhip_h2d", "ovhip_d2h", "ovhip_pic_alloc", "ovhip_pic_free", "ovhip_pic_upload",
     "ovhip_pic_download", "ovhip_itx_launch", "ovhip_mc_launch",
     "ovhip_rec_create_ex", "ovhip_rec_set_dense_dbf_planes", "ovhip_rec_dbf_edges", "ovhip_dbf_launch_edges_ex",
@@ -541,7 +544,7 @@ EXPORTED_SYMBOLS = [
     "ovhip_frame_create", "ovhip_frame_create_ex", "ovhip_ctx_create_prio", "ovhip_frame_destroy", "ovhip_frame_ctx", "ovhip_frame_job", "ovhip_frame_recorder", "ovhip_frame_begin", "ovhip_frame_ref",
     "ovhip_frame_ref_at", "ovhip_frame_dmvr_rows", "ovhip_frame_submit", "ovhip_frame_fail", "ovhip_frame_last_error",
     "ovhip_calllog_create", "ovhip_calllog_destroy", "ovhip_calllog_reset", "ovhip_calllog_data", "ovhip_rec_set_calllog", "ovhip_calllog_replay",
-    "ovhip_stream_create", "ovhip_stream_destroy", "ovhip_stream_run", "ovhip_stream_frame", "ovhip_stream_key",
+    "ovhip_stream_create", "ovhip_stream_destroy", "ovhip_stream_run", "ovhip_stream_frame", "ovhip_stream_key", "ovhip_stream_queue_info",
 ]
 
 

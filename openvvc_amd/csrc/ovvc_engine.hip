@@ -35,9 +35,62 @@ void stream_put(int device, hipStream_t s)
 }
 } // namespace
 
+__global__ void k_spin(unsigned long long ticks, unsigned *sink)
+{
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    if (sink && ticks == ~0ull) *sink = 1;
+}
+__global__ void k_nop(unsigned *sink) { if (sink && threadIdx.x == 12345) *sink = 1; }
+
 extern "C" {
 
 int ovhip_abi_version(void) { return OVHIP_ABI_VERSION; }
+
+/* Do the streams of two contexts share a hardware queue?  The runtime spreads its streams over GPU_MAX_HW_QUEUES (4) hardware
+ * queues, and a hardware queue runs the packets of its streams in order: a kernel of several milliseconds on one stream (an I
+ * picture's ordered pass) holds up every stream that shares its queue.  Nothing in the API says which stream got which queue, so it
+ * is measured: a 1.5 ms spin kernel on a, an empty kernel on b right behind it -- if b's kernel only completes when a's has, they
+ * share.  1: share, 0: do not, < 0: error.  Both contexts idle, same device. */
+int ovhip_ctx_shares_queue(ovhip_ctx *a, ovhip_ctx *b)
+{
+    if (!a || !b || a->device != b->device) return OVHIP_EINVAL;
+    if (a->stream == b->stream) return 1;
+    OV_DEVICE(a);
+    OV_HIP(a, hipStreamSynchronize(a->stream));
+    OV_HIP(a, hipStreamSynchronize(b->stream));
+    hipEvent_t ea, eb;
+    OV_HIP(a, hipEventCreateWithFlags(&ea, hipEventDisableTiming));
+    OV_HIP(a, hipEventCreateWithFlags(&eb, hipEventDisableTiming));
+    hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, a->stream, (unsigned *)nullptr);       // (first launches of a process also load the code object)
+    hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, b->stream, (unsigned *)nullptr);
+    (void)hipStreamSynchronize(a->stream); (void)hipStreamSynchronize(b->stream);
+    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, a->stream, 150000ull, (unsigned *)nullptr);     // wall_clock64: 100 MHz -> 1.5 ms
+    (void)hipEventRecord(ea, a->stream);
+    hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, b->stream, (unsigned *)nullptr);
+    (void)hipEventRecord(eb, b->stream);
+    hipError_t e = hipEventSynchronize(eb);
+    const int shared = e == hipSuccess && hipEventQuery(ea) == hipSuccess;       // a's spin was over when b's empty kernel completed
+    (void)hipEventSynchronize(ea);
+    (void)hipGetLastError();
+    (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
+    return e == hipSuccess ? shared : ov_fail(a, OVHIP_ELAUNCH, "ovhip_ctx_shares_queue", e);
+}
+
+/* Gives the context another stream (its own is parked in the pool): what a caller does with a context whose stream shares a
+ * hardware queue with one it must not be held up by. */
+int ovhip_ctx_new_stream(ovhip_ctx *ctx)
+{
+    if (!ctx || !ctx->owns_stream) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
+    OV_HIP(ctx, hipStreamSynchronize(ctx->main_stream));
+    hipStream_t s = nullptr;
+    OV_HIP(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));          // a NEW one: the pool would hand the old one back
+    stream_put(ctx->device, ctx->main_stream);
+    if (ctx->stream == ctx->main_stream) ctx->stream = s;
+    ctx->main_stream = s;
+    return OVHIP_OK;
+}
 
 int ovhip_ctx_create(ovhip_ctx **out, int device, void *stream)
 {

@@ -45,6 +45,7 @@ struct ovhip_stream {
     unsigned char *begun;                 /* has entered the DPB at some point (the output / comm threads wait for that before they
                                            * ask the DPB for it: a key the DPB never saw is an error there, not a wait) */
     pthread_mutex_t begun_mtx; pthread_cond_t begun_cnd;
+    int n_moved, n_sharing;               /* streams replaced to clear the look-ahead thread's hardware queue / still sharing it */
     uint8_t *dg;                          /* OVHIP_OUT_DIGEST: the pictures' digests, computed by their frame threads (begun[idx] == 2: there) */
 };
 
@@ -61,6 +62,7 @@ struct run_state {
     volatile int abort;
     uint32_t *out_order; uint32_t n_out;
     ovhip_md5_state md5;
+    double t0; double *trace;
 };
 
 struct thread_arg { struct run_state *rs; int dev, t; };
@@ -174,8 +176,10 @@ adopt_stream(ovhip_stream *s, const ovhip_stream_pic *pics, uint32_t n_total, ui
 
 /* ---------------------------------------------------------------- frame threads */
 static void
-decode_picture(struct run_state *rs, ovhip_frame *f, uint32_t idx, int job_locked, int ahead)
+decode_picture(struct run_state *rs, ovhip_frame *f, uint32_t idx, int job_locked, int ahead, int thread)
 {
+    double *tr = rs->trace ? rs->trace + 4 * (size_t)(idx - rs->first) : NULL;
+    if (tr) { tr[0] = now_s() - rs->t0; tr[3] = (double)thread; }
     ovhip_stream *s = rs->s;
     const ovhip_stream_pic *p = &rs->pics[idx];
     const ovhip_stream_content *c = &s->contents[p->content];
@@ -206,7 +210,9 @@ decode_picture(struct run_state *rs, ovhip_frame *f, uint32_t idx, int job_locke
          * the output thread only puts them in output order) */
         out.mode = ((rs->flags & OVHIP_STREAM_DIGESTS) || s->cfg.output == OVHIP_OUT_DIGEST) ? OVHIP_OUT_DIGEST : OVHIP_OUT_NONE;
         out.window = s->cfg.window;
+        if (tr) tr[1] = now_s() - rs->t0;
         r = ovhip_frame_submit(f, job, NULL, &pr, &out);
+        if (tr) tr[2] = now_s() - rs->t0;
         if (r != OVHIP_OK) { run_fail(rs, r, "ovhip_frame_submit", ovhip_frame_last_error(f)); goto out; }
         if (out.mode == OVHIP_OUT_DIGEST) {
             if (rs->digests) memcpy(rs->digests + 16 * (size_t)(idx - rs->first), out.digest, 16);
@@ -268,7 +274,7 @@ frame_thread(void *argp)
             locked = 1;
         }
         pthread_mutex_unlock(&q->take);
-        decode_picture(rs, f, idx, locked, ahead);
+        decode_picture(rs, f, idx, locked, ahead, a->dev * s->tpd + a->t);
     }
     return NULL;
 }
@@ -377,6 +383,17 @@ ovhip_stream_create(ovhip_stream **out, ovhip_dpb *dpb, const ovhip_stream_cfg *
      * is one kernel of several milliseconds, and a hardware queue runs its streams' packets in order) */
     for (int i = 0; i < s->n_dev * s->tpd && r == OVHIP_OK; ++i)
         r = ovhip_frame_create_ex(dpb, i / s->tpd, cfg->w, cfg->h, (i % s->tpd) >= s->n_reg ? cfg->intra_stream_priority : 0, &s->frames[i]);
+    /* The look-ahead thread's stream gets a hardware queue to itself: an in-order thread whose stream shares it would sit behind an
+     * I picture's ordered pass for milliseconds.  Which stream got which queue is measured (ovhip_ctx_shares_queue); a frame in the
+     * wrong company takes new streams until it is out of it (the runtime deals its queues round robin: a few tries). */
+    for (int k = 0; k < s->n_dev && r == OVHIP_OK && s->tpd > s->n_reg && cfg->ahead_own_queue; ++k) {
+        ovhip_ctx *ahead = ovhip_frame_ctx(s->frames[k * s->tpd + s->n_reg]);
+        for (int t = 0; t < s->n_reg; ++t) {
+            ovhip_ctx *c = ovhip_frame_ctx(s->frames[k * s->tpd + t]);
+            for (int tries = 0; tries < 12 && ovhip_ctx_shares_queue(ahead, c) == 1; ++tries) { if (ovhip_ctx_new_stream(c) != OVHIP_OK) break; s->n_moved++; }
+            if (ovhip_ctx_shares_queue(ahead, c) == 1) s->n_sharing++;
+        }
+    }
     if (cfg->output == OVHIP_OUT_PACKED) {
         for (int k = 0; k < s->n_dev && r == OVHIP_OK; ++k) r = ovhip_ctx_create(&s->out_ctx[k], ovhip_dpb_device(dpb, k), NULL);
         if (r == OVHIP_OK) {
@@ -404,6 +421,14 @@ ovhip_stream_destroy(ovhip_stream *s)
     free(s);
 }
 
+int ovhip_stream_queue_info(const ovhip_stream *s, int *moved, int *sharing)
+{
+    if (!s) return OVHIP_EINVAL;
+    if (moved) *moved = s->n_moved;
+    if (sharing) *sharing = s->n_sharing;
+    return OVHIP_OK;
+}
+
 ovhip_frame *
 ovhip_stream_frame(ovhip_stream *s, int dev, int thread)
 {
@@ -425,7 +450,9 @@ ovhip_stream_run(ovhip_stream *s, const ovhip_stream_pic *pics, uint32_t n_total
                  ovhip_stream_result *res)
 {
     if (!s || !pics || !res || first > n_total || n > n_total - first) return OVHIP_EINVAL;
+    double *trace = res->trace;
     memset(res, 0, sizeof(*res));
+    res->trace = trace;
     flags |= s->cfg.flags;
     if (!(flags & OVHIP_STREAM_RECORD)) {
         if (!s->n_jobs) return OVHIP_EINVAL;
@@ -465,6 +492,7 @@ ovhip_stream_run(ovhip_stream *s, const ovhip_stream_pic *pics, uint32_t n_total
         qsort_r(rs.out_order, rs.n_out, sizeof(uint32_t), cmp_out, (void *)pics);
         int started = 0, aux = 0;
         const double t0 = now_s();
+        rs.t0 = t0; rs.trace = trace;
         for (int i = 0; i < nthr; ++i) {
             ta[i].rs = &rs; ta[i].dev = i / s->tpd; ta[i].t = i % s->tpd;
             if (pthread_create(&th[i], NULL, frame_thread, &ta[i])) { run_fail(&rs, OVHIP_ENOMEM, "pthread_create", ""); break; }

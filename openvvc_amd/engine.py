@@ -642,7 +642,7 @@ class Stream:
 
     def __init__(self, dpb: Dpb, w: int, h: int, contents: list, jobs: list = (), threads_per_device: int = 1, flags: int = 0,
                  output: int = 0, window=(0, 0, 0, 0), extra_stages: int = 0, rank: int = 0, xfer: "capi.StreamXfer | None" = None,
-                 intra_lookahead: int = 0, intra_stream_priority: int = 0, ahead_chunk_items: int = 0):
+                 intra_lookahead: int = 0, intra_stream_priority: int = 0, ahead_chunk_items: int = 0, ahead_own_queue: int = 0):
         self.lib, self.dpb = dpb.lib, dpb
         self._contents = (capi.StreamContent * len(contents))()
         self._keep = [contents, jobs, xfer]
@@ -660,6 +660,7 @@ class Stream:
         cfg.extra_stages, cfg.rank = extra_stages, rank
         cfg.xfer = C.pointer(xfer) if xfer is not None else None
         cfg.intra_lookahead, cfg.intra_stream_priority, cfg.ahead_chunk_items = intra_lookahead, intra_stream_priority, ahead_chunk_items
+        cfg.ahead_own_queue = ahead_own_queue
         self.cfg = cfg
         s = C.c_void_p()
         r = self.lib.ovhip_stream_create(C.byref(s), dpb.h, C.byref(cfg), self._contents, len(contents), self._jobs, len(jobs))
@@ -671,6 +672,12 @@ class Stream:
         if self.s:
             self.lib.ovhip_stream_destroy(self.s)
             self.s = None
+
+    def queue_info(self):
+        """(streams replaced to clear the look-ahead thread's hardware queue, in-order streams still sharing it)"""
+        a, b = C.c_int(), C.c_int()
+        self.lib.ovhip_stream_queue_info(self.s, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def picture(self, idx: int, ctx: "Context") -> "DevPic":
         """the device picture of stream picture idx (kept by OVHIP_STREAM_KEEP), as a DevPic on ctx for download()"""
@@ -693,9 +700,11 @@ class Stream:
             a.owner, a.send_mask = p.get("owner", 0), p.get("send_mask", 0)
         return arr
 
-    def run(self, arr, n_total: int, first: int, n: int, flags: int = 0, digests: bool = False, check: bool = True):
-        """-> (capi.StreamResult, digests uint8 [n, 16] | None)"""
+    def run(self, arr, n_total: int, first: int, n: int, flags: int = 0, digests: bool = False, check: bool = True, trace=None):
+        """-> (capi.StreamResult, digests uint8 [n, 16] | None); trace: float64 [n, 4] filled with (taken, submit, published, thread)"""
         res = capi.StreamResult()
+        if trace is not None:
+            res.trace = trace.ctypes.data
         dg = np.zeros((n, 16), np.uint8) if digests else None
         r = self.lib.ovhip_stream_run(self.s, arr, n_total, first, n, flags | (capi.STREAM_DIGESTS if digests else 0),
                                       dg.ctypes.data if dg is not None else None, C.byref(res))
