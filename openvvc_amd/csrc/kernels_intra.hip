@@ -1337,8 +1337,16 @@ extern "C" int ovhip_intra_flow_launch(ovhip_ctx *ctx, const ovhip_pic *pic, con
     if (wg_per_cu > 0 && wg_per_cu < 17) {
         const size_t per_wg = (160u << 10) / (size_t)wg_per_cu, fixed = sizeof(FlowLds) + 1024;
         dyn = per_wg > fixed ? per_wg - fixed : 0;
-        if (dyn > (64u << 10) - fixed) dyn = (64u << 10) - fixed;                    // one workgroup's allocation limit without opting in
         dyn &= ~(size_t)511;
+        if (dyn + fixed > (64u << 10)) {
+            // more than the default limit of one workgroup: opt in once (gfx950: 160 KB of LDS per compute unit, all of it allocatable)
+            static int opted = 0;
+            if (!opted) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_intra_flow), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((160u << 10) - fixed)) == hipSuccess) opted = 1;
+                else { opted = -1; (void)hipGetLastError(); }
+            }
+            if (opted < 0) dyn = ((64u << 10) - fixed) & ~(size_t)511;
+        }
     }
     hipLaunchKernelGGL(k_intra_flow, dim3(n_items), dim3(64), dyn, ctx->stream, *pic, *res, d_tasks, d_items, n_items, d_regions, wnd, d_scales, log2_ctu_s, fs,
                        epoch, d_state, abort_mirror, nap);

@@ -631,10 +631,12 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
             static const size_t FLOW_CHUNK = getenv("OVHIP_FLOW_CHUNK") && atol(getenv("OVHIP_FLOW_CHUNK")) > 0 ? (size_t)atol(getenv("OVHIP_FLOW_CHUNK")) : 32768;
             // how many workgroups of the launch a compute unit may hold (ovhip_intra_flow_launch): a few levels' worth of items resident is
             // all the chain can use; a B picture's wide levels get everything (measured on the stream of bench.py, 16 in flight, I pictures
-            // started early: no cap 2847, 8 levels' worth 2907, 4 levels' worth 2940 - 3054 pictures/s)
+            // started early: no cap 2847 - 2925, 8 levels' worth 2907 - 3460 pictures/s).  Never fewer than 3 per compute unit: a workgroup
+            // that asks for more than a third of the LDS finds no compute unit to start on while the other pictures' kernels hold theirs
+            // (1 per compute unit: the resident items' bounded waits expire, 30 - 60 second passes per run)
             int wg_per_cu = 0;
             {
-                static const long CAP = getenv("OVHIP_FLOW_RESIDENT") ? atol(getenv("OVHIP_FLOW_RESIDENT")) : 4;      // levels' worth; 0: no cap
+                static const long CAP = getenv("OVHIP_FLOW_RESIDENT") ? atol(getenv("OVHIP_FLOW_RESIDENT")) : 8;      // levels' worth; 0: no cap
                 const size_t width = n_items / (n_lv ? n_lv : 1) + 1;
                 const size_t want = CAP > 0 ? (size_t)CAP * width : 0;
                 if (want) { const size_t per_cu = (want + (size_t)ctx->num_cus - 1) / (size_t)ctx->num_cus; wg_per_cu = per_cu < 3 ? 3 : (per_cu >= 17 ? 0 : (int)per_cu); }
