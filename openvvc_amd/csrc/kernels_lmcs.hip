@@ -94,19 +94,30 @@ __global__ __launch_bounds__(256) void k_lmcs_inverse(ovhip_pic pic, const uint1
     if (blockIdx.y >= rows_y) { untag_chroma_tasks(pic, tasks, n_tasks, (blockIdx.y - rows_y) * gridDim.x + blockIdx.x); return; }
 
     __shared__ uint16_t s_lut[1024];
-    for (int i = threadIdx.x; i < 512; i += 256) reinterpret_cast<uint32_t *>(s_lut)[i] = reinterpret_cast<const uint32_t *>(lut)[i];
-    __syncthreads();
     const int nvx = pic.w >> 3;                               // full 8-sample vectors per row
     const int tail = pic.w & 7;
-    // a workgroup takes LMCS_ROWS rows at a time (the LUT staged once for 16 KB of samples instead of once per row segment); a
-    // lane's vectors of all rows are requested before the first one is mapped
-    for (int y0 = blockIdx.y * LMCS_ROWS; y0 < pic.h; y0 += rows_y * LMCS_ROWS) {
-        for (int v = blockIdx.x * 256 + threadIdx.x; v < nvx; v += gridDim.x * 256) {
-            uint4 q[LMCS_ROWS];
+    // a workgroup takes LMCS_ROWS rows at a time (the LUT staged once for 16 KB of samples instead of once per row segment).  The
+    // lane's vectors of its FIRST row group are requested before the table is staged: the two round trips (table, samples) overlap
+    // instead of following each other behind the barrier (20 -> see DESIGN 4 us per 4K picture, where this launch stands alone behind
+    // the ordered pass)
+    const int y00 = blockIdx.y * LMCS_ROWS, v00 = blockIdx.x * 256 + threadIdx.x;
+    uint4 q0[LMCS_ROWS];
+    const bool first = y00 < pic.h && v00 < nvx;
+    if (first) {
 #pragma unroll
-            for (int r = 0; r < LMCS_ROWS; ++r) {
-                const int y = min(y0 + r, pic.h - 1);
-                q[r] = *reinterpret_cast<const uint4 *>(pic.y + (size_t)y * pic.stride_y + 8 * v);
+        for (int r = 0; r < LMCS_ROWS; ++r) q0[r] = *reinterpret_cast<const uint4 *>(pic.y + (size_t)min(y00 + r, pic.h - 1) * pic.stride_y + 8 * v00);
+    }
+    for (int i = threadIdx.x; i < 512; i += 256) reinterpret_cast<uint32_t *>(s_lut)[i] = reinterpret_cast<const uint32_t *>(lut)[i];
+    __syncthreads();
+    for (int y0 = y00; y0 < pic.h; y0 += rows_y * LMCS_ROWS) {
+        for (int v = v00; v < nvx; v += gridDim.x * 256) {
+            uint4 q[LMCS_ROWS];
+            if (y0 == y00 && v == v00) {
+#pragma unroll
+                for (int r = 0; r < LMCS_ROWS; ++r) q[r] = q0[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < LMCS_ROWS; ++r) q[r] = *reinterpret_cast<const uint4 *>(pic.y + (size_t)min(y0 + r, pic.h - 1) * pic.stride_y + 8 * v);
             }
 #pragma unroll
             for (int r = 0; r < LMCS_ROWS; ++r) {
