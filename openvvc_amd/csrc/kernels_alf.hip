@@ -309,10 +309,8 @@ __device__ __forceinline__ void alf_luma_tile(const ovhip_pic &dst, const ovhip_
 }
 
 // one 32x32 tile of chroma plane `comp` (1 Cb, 2 Cr)
-#define CCW 80          /* CC-ALF luma window in LDS: 66 rows (2 * 32 + 1 above + 1 below) of 80 samples (8 left of the tile's 64, 8 right) */
-#define CCH 66
 __device__ __forceinline__ void alf_chroma_tile(const ovhip_pic &dst, const ovhip_pic &src, const ovhip_alf_pic &alf, int nb_ctu_w,
-                                                int tile0, int comp, uint16_t *s_t, uint16_t *s_cc)
+                                                int tile0, int comp, uint16_t *s_t)
 {
     const int W = src.w, H = src.h, Wc = W >> 1, Hc = H >> 1;
     const int tid = threadIdx.x;
@@ -326,11 +324,6 @@ __device__ __forceinline__ void alf_chroma_tile(const ovhip_pic &dst, const ovhi
     const uint16_t *sp = comp == 1 ? src.cb : src.cr;
     uint16_t *dp = comp == 1 ? dst.cb : dst.cr;
 
-    const bool cc_inside = tx0 > 0 && ty0 > 0 && tx0 + TL < Wc && ty0 + TL < Hc;
-    // CC-ALF reads 7 luma samples around (2x, 2y) per chroma sample: for a tile away from the picture border the co-located 66 x 66 luma
-    // window goes through LDS once (16-byte loads: 660 of them) instead of 28 two-byte loads per lane through L1 / L2 (the kernel's
-    // fetch traffic was 2.6x its algorithmic bytes; the launch time did not move: 46.0 -> 46.2 us, it is not bound by these loads)
-    const bool cc_lds = cc_idx && cc_inside && !(src.stride_y & 7);
     if (on) {
         // 36 rows x 40 samples (tile + halo, 4 samples left so that a row is five 16-byte groups)
         if (tx0 >= LPAD && tx0 + TL + LPAD <= Wc && ty0 >= CH && ty0 + TL + CH <= Hc && !(src.stride_c & 7)) {
@@ -346,15 +339,8 @@ __device__ __forceinline__ void alf_chroma_tile(const ovhip_pic &dst, const ovhi
                 s_t[i] = sp[sy * src.stride_c + sx];
             }
         }
+        __syncthreads();
     }
-    if (cc_lds) {
-        const uint16_t *lp = src.y + (size_t)(2 * ty0 - 1) * src.stride_y + 2 * tx0 - 8;
-        for (int i = tid; i < CCH * (CCW / 8); i += 256) {
-            const int yy = i / (CCW / 8), q = i - yy * (CCW / 8);
-            *reinterpret_cast<uint4 *>(s_cc + yy * CCW + 8 * q) = *reinterpret_cast<const uint4 *>(lp + (size_t)yy * src.stride_y + 8 * q);
-        }
-    }
-    if (on || cc_lds) __syncthreads();
 
     const int ctu_y0 = (ty0 * 2) & ~(ctu - 1);           // luma row of the CTU
     const bool truncated = ctu_y0 + ctu > H;
@@ -394,6 +380,7 @@ __device__ __forceinline__ void alf_chroma_tile(const ovhip_pic &dst, const ovhi
         if (pos == vbpos - 2 || pos == vbpos + 1) r3 = r1;
         else if (pos == vbpos - 1 || pos == vbpos) r1 = r2 = r3 = 0;
     }
+    const bool cc_inside = tx0 > 0 && ty0 > 0 && tx0 + TL < Wc && ty0 + TL < Hc;
     // 5 rows of the 12-sample group lx0-4 .. lx0+7 as 8-byte LDS reads (see alf_luma_tile)
     uint32_t r0[6], p1[6], m1[6], p2[2], m2[2];
     int cmin = 0x7fff, fsum = 0;
@@ -419,17 +406,6 @@ __device__ __forceinline__ void alf_chroma_tile(const ovhip_pic &dst, const ovhi
         f2[i] = alf_dup(fc[i]);
         c2[i] = alf_dup(cl[i]);
         nc2[i] = __builtin_bit_cast(uint32_t, (alf_s2)(0) - __builtin_bit_cast(alf_s2, c2[i]));
-    }
-    uint32_t cca[6], cc0[6], cc1[6], cc3[6];
-    if (cc_lds) {
-        // window column of luma column 2 (tx0 + lx0) - 4: 8 + 2 lx0 - 4 (a multiple of 4 samples: 8-byte LDS reads)
-        const uint16_t *cb_ = s_cc + (2 * ly + 1) * CCW + 2 * lx0 + 4;
-        auto crow = [&](int dy, uint32_t d6[6]) {
-            const uint2 *q = reinterpret_cast<const uint2 *>(cb_ + dy * CCW);
-            const uint2 a = q[0], b_ = q[1], c_ = q[2];
-            d6[0] = a.x; d6[1] = a.y; d6[2] = b_.x; d6[3] = b_.y; d6[4] = c_.x; d6[5] = c_.y;
-        };
-        crow(r2, cca); crow(0, cc0); crow(r1, cc1); crow(r3, cc3);
     }
 #define S6(d6, c) ((((c) + 4) & 1) ? (int)((d6)[((c) + 4) >> 1] >> 16) : (int)((d6)[((c) + 4) >> 1] & 0xffff))
 #define S2(d2, c) (((c) & 1) ? (int)((d2)[(c) >> 1] >> 16) : (int)((d2)[(c) >> 1] & 0xffff))
@@ -462,19 +438,7 @@ __device__ __forceinline__ void alf_chroma_tile(const ovhip_pic &dst, const ovhi
         if (cc_idx) {
             const int Lx = ox << 1, Ly = oy << 1;
             int cy, sum = 0;
-            if (cc_lds) {
-                // rows Ly + r2, Ly, Ly + r1, Ly + r3 of the window (row 0 = luma row 2 ty0 - 1), the 12 samples 2 lx0 - 4 .. 2 lx0 + 7 of each
-                // were read into registers before the loop (cca / cc0 / cc1 / cc3); sample i sits at column 2 i of the group
-                const int c = 2 * i;
-                cy = S6(cc0, c);
-                sum += cf[0] * (S6(cca, c) - cy);
-                sum += cf[1] * (S6(cc0, c - 1) - cy);
-                sum += cf[2] * (S6(cc0, c + 1) - cy);
-                sum += cf[3] * (S6(cc1, c - 1) - cy);
-                sum += cf[4] * (S6(cc1, c) - cy);
-                sum += cf[5] * (S6(cc1, c + 1) - cy);
-                sum += cf[6] * (S6(cc3, c) - cy);
-            } else if (cc_inside) {                                     // (stride not a multiple of 8: through L1 / L2, no clamping)
+            if (cc_inside) {                                            // tile away from the picture border: no clamping
                 const uint16_t *lp = src.y + Ly * src.stride_y + Lx;
                 cy = lp[0];
                 sum += cf[0] * ((int)lp[r2 * src.stride_y] - cy);
@@ -521,12 +485,10 @@ __global__ __launch_bounds__(256) OV_OCC_ALF void k_alf(ovhip_pic dst, ovhip_pic
 {
     __shared__ __attribute__((aligned(16))) uint16_t s_t[(LW > CW ? LW : CW) * LWS];
     __shared__ uint8_t s_cls[64];
-    // luma tiles: one row pair's Laplacian sums per lane (4 KB); chroma tiles: the CC-ALF luma window (10.3 KB) -- never both
-    __shared__ __attribute__((aligned(16))) uint16_t s_x[CCH * CCW];
-    static_assert(sizeof(uint16_t) * CCH * CCW >= sizeof(uint4) * 256, "s_sum fits the CC-ALF window's LDS");
+    __shared__ __attribute__((aligned(16))) uint4 s_sum[256];          // luma classification: one row pair's Laplacian sums per lane
     const int b = blockIdx.x;
-    if (b < nl) alf_luma_tile(dst, src, alf, nb_ctu_w, b, s_t, s_cls, reinterpret_cast<uint4 *>(s_x));
-    else        alf_chroma_tile(dst, src, alf, nb_ctu_w, (b - nl) % nc, 1 + (b - nl) / nc, s_t, s_x);
+    if (b < nl) alf_luma_tile(dst, src, alf, nb_ctu_w, b, s_t, s_cls, s_sum);
+    else        alf_chroma_tile(dst, src, alf, nb_ctu_w, (b - nl) % nc, 1 + (b - nl) / nc, s_t);
 }
 
 } // namespace

@@ -1516,6 +1516,33 @@ gen_sao(const char *dir)
         snprintf(nm, 32, "p%d_params", pi); gfile_array(&g, nm, T_U8, mine, 2, d2);
         fprintf(stderr, "sao.ovg: picture %d %dx%d (%d CTUs)\n", pi, W, H, nx * ny);
     }
+    if (g_shim) {
+        /* a picture cut into TWO rect entries (tile columns: ovthreads.c:112-114 hands each entry to its own OVCTUDec), record-only:
+         * the shim keeps one recorder per OVCTUDec and would flush each entry as if it were the picture, so it has to latch
+         * OVHIP_EUNSUP at the first slot that sees the entry's geometry -- and keep it latched for the second entry's decoder */
+        const int W = 384, H = 136, nx = 3, ny = 2;
+        int32_t codes[2];
+        for (int en = 0; en < 2; ++en) {
+            OVFrame *f = harness_frame(W, H);
+            OVCTUDec *c = ref_new_ctudec(0, 0);
+            shim_bind(c, W, H, 0, 0);
+            c->pic_w = W; c->pic_h = H;
+            c->rcn_ctx.frame_start = f;
+            harness_alloc_filter_buffers(&c->rcn_ctx, nx, 3, 7);
+            c->sao_info.sao_luma_flag = 1; c->sao_info.chroma_format_idc = 1;
+            c->sao_info.sao_params = calloc(nx * ny, sizeof(SAOParamsCtu));
+            struct RectEntryInfo einfo;
+            memset(&einfo, 0, sizeof(einfo));
+            einfo.ctb_x = en ? 2 : 0; einfo.nb_ctu_w = en ? 1 : 2; einfo.nb_ctu_h = ny;
+            c->ctb_y = 0;
+            c->rcn_funcs.sao.rcn_sao_first_pix_rows(c, &einfo, 0);
+            codes[en] = ovhip_shim_last_error(c);
+            if (codes[en] != OVHIP_EUNSUP) { fprintf(stderr, "shim: entry %d of a two-entry picture was not refused (code %d)\n", en, codes[en]); exit(1); }
+        }
+        uint32_t d1 = 2;
+        gfile_array(&g, "two_entries_latched", T_I32, codes, 1, &d1);
+        fprintf(stderr, "shim_sao.ovg: two rect entries refused (%d, %d)\n", codes[0], codes[1]);
+    }
     gfile_close(&g);
 }
 

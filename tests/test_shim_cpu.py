@@ -251,6 +251,14 @@ def test_shim_filter_slots_match_reference(built_lib):
             assert ga[f"p{i}_{k}"].tobytes() == gr[f"p{i}_{k}"].tobytes(), f"alf picture {i} {k}"
 
 
+def test_shim_refuses_a_picture_of_two_rect_entries(built_lib):
+    """A picture cut into two rect entries (tile columns; the reference gives each entry its own OVCTUDec, ovthreads.c:112-114) is
+    refused by the installed slots: the harness drove `sao.rcn_sao_first_pix_rows` with the einfo of each entry (record-only) and
+    stored what `ovhip_shim_last_error` latched -- OVHIP_EUNSUP for both, not a half-picture flush."""
+    g = golden_io.load("shim_sao.ovg")
+    assert [int(v) for v in g["two_entries_latched"]] == [capi.OVHIP_EUNSUP, capi.OVHIP_EUNSUP]
+
+
 def intra_ctu_cases():
     """(start picture planes, [(dual, expected Y / Cb / Cr of the CTU at (128, 128))]) from intra_ctu.ovg."""
     g = golden_io.load("intra_ctu.ovg")
