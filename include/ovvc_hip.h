@@ -897,6 +897,16 @@ const int32_t *ovhip_job_refined_mvs(ovhip_job *job, size_t *n_units);
 /* Search-only pass over the refined units [first, current count) that carry OVHIP_MC_DMVR; synchronous: when it
  * returns the vectors are in ovhip_job_refined_mvs()[first..].  Returns the new `first` (= unit count) or <0. */
 int64_t ovhip_job_dmvr_rows(ovhip_job *job, const ovhip_pic *refs, uint32_t n_refs);
+/* The same pass in two halves, so that the search of one CTU row runs while the next row is parsed (slicedec.c:934-956 reports
+ * row y - 1 after row y has been parsed: a pass begun at the end of row y - 1 is collected right before that report).
+ *   _begin    enqueues: units [first, count) up, search, vectors down -- and, with log2_ctu_s != 0, the entries of the picture's
+ *             collocated motion plane they belong to (ovhip_tmvp_cells_launch; 4 per unit, recorder order) -- then an event.
+ *             Does not block.  Collects a pass still in flight first.  Returns the unit count it covers, or <0.
+ *   _collect  waits for that event (one D2H of vectors + one of plane entries per row, both asynchronous until here); returns the
+ *             number of units whose results are valid: ovhip_job_refined_mvs()[.. 4 n], ovhip_job_tmvp_cells()[.. 4 n].  0 passes
+ *             pending: returns at once.  ovhip_job_flush collects by itself. */
+int64_t ovhip_job_dmvr_rows_begin(ovhip_job *job, const ovhip_pic *refs, uint32_t n_refs, int32_t log2_ctu_s);
+int64_t ovhip_job_dmvr_rows_collect(ovhip_job *job);
 int  ovhip_job_last_stats(const ovhip_job *job, ovhip_job_stats *out);
 /* Measurement: bracket ONE launch group of every following flush with a HIP-event pair on the launch stream (stage -1:
  * off) and read back the accumulated duration.  A pair costs a few microseconds of stream time, hence one at a time. */
@@ -1053,8 +1063,9 @@ int  ovhip_dpb_get_stats(ovhip_dpb *d, ovhip_dpb_stats *out);
  *   ovhip_frame_ref(ref_key)        first use of a reference picture: its index in the table the recorded units carry
  *                                   (ovhip_pu_desc.ref0 / ref1); tells the DPB this device wants it
  *   ... the slots record into ovhip_frame_recorder() ...
- *   ovhip_frame_dmvr_rows()         every alf.rcn_alf_filter_line: waits for the references, eager refinement (see
- *                                   ovhip_job_dmvr_rows)
+ *   ovhip_frame_dmvr_rows_collect() every alf.rcn_alf_filter_line: the refined vectors / plane entries of the rows parsed before
+ *   ovhip_frame_dmvr_rows_begin()   the last one; then the pass over the row just parsed is enqueued (waits for the references
+ *                                   first) and runs while the next row is parsed (ovhip_frame_dmvr_rows: both at once)
  *   ovhip_frame_submit(params)      last row: uploads; waits for the references (host) while they run; launches;
  *                                   ovhip_job_wait (incl. its second pass); THEN publishes -- on every exit path, with the
  *                                   error if there was one -- and unpins the references; then the optional output (the
@@ -1087,6 +1098,11 @@ int  ovhip_frame_ref(ovhip_frame *f, const void *ref_key);          /* index (0.
  * already sit in another entry (a recorded picture whose units index a fixed table). */
 int  ovhip_frame_ref_at(ovhip_frame *f, int slot, const void *ref_key);
 int64_t ovhip_frame_dmvr_rows(ovhip_frame *f);
+/* The two halves (ovhip_job_dmvr_rows_begin / _collect): _begin waits for the picture's reference pictures on the host (as
+ * ovhip_frame_dmvr_rows does: only a published picture is complete, its ordered pass may run a second time), then enqueues the pass
+ * over the units recorded so far and returns; _collect before the row those units belong to is reported decoded. */
+int64_t ovhip_frame_dmvr_rows_begin(ovhip_frame *f, int32_t log2_ctu_s);
+int64_t ovhip_frame_dmvr_rows_collect(ovhip_frame *f);
 /* job: NULL = the frame's own job (the shim); else a job holding an already recorded picture of the same size, which is bound to
  * this frame's context for the flush (the stream driver's pre-recorded pictures).  intra: as ovhip_job_flush.  out: NULL =
  * OVHIP_OUT_NONE.  Returns the picture's status (what was published). */

@@ -449,6 +449,8 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_job_wait": (C.c_int, [vp]),
         "ovhip_job_refined_mvs": (vp, [vp, P(C.c_size_t)]),
         "ovhip_job_dmvr_rows": (C.c_int64, [vp, P(Pic), u32]),
+        "ovhip_job_dmvr_rows_begin": (C.c_int64, [vp, P(Pic), u32, i32]),
+        "ovhip_job_dmvr_rows_collect": (C.c_int64, [vp]),
         "ovhip_job_last_stats": (C.c_int, [vp, P(JobStats)]),
         "ovhip_job_time_stage": (C.c_int, [vp, C.c_int]),
         "ovhip_job_stage_time": (C.c_int, [vp, P(C.c_double), P(C.c_uint64)]),
@@ -499,6 +501,8 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_frame_ref": (C.c_int, [vp, vp]),
         "ovhip_frame_ref_at": (C.c_int, [vp, C.c_int, vp]),
         "ovhip_frame_dmvr_rows": (C.c_int64, [vp]),
+        "ovhip_frame_dmvr_rows_begin": (C.c_int64, [vp, i32]),
+        "ovhip_frame_dmvr_rows_collect": (C.c_int64, [vp]),
         "ovhip_frame_submit": (C.c_int, [vp, vp, P(Pic), P(JobParams), P(FrameOutput)]),
         "ovhip_frame_fail": (C.c_int, [vp, C.c_int]),
         "ovhip_frame_last_error": (C.c_char_p, [vp]),
@@ -534,7 +538,7 @@ EXPORTED_SYMBOLS = [
     "ovhip_rec_create_ex", "ovhip_rec_set_dense_dbf_planes", "ovhip_rec_dbf_edges", "ovhip_dbf_launch_edges_ex",
     "ovhip_dmvr_search_launch", "ovhip_rec_append_raw", "ovhip_rec_set_dbf_offsets", "ovhip_rec_tu_intra", "ovhip_rec_itasks", "ovhip_rec_itasks_sorted", "ovhip_itx_launch_classes_res", "ovhip_intra_level_launch", "ovhip_intra_level_geom", "ovhip_intra_sync_words", "ovhip_intra_ctu_launch", "ovhip_intra_flow_words", "ovhip_intra_flow_items", "ovhip_intra_flow_launch",
     "ovhip_rec_itask_levels", "ovhip_rec_isp_cu", "ovhip_isp_geometry", "ovhip_rec_itasks_by_ctu", "ovhip_rec_set_ctu_size", "ovhip_job_bind", "ovhip_job_create", "ovhip_job_destroy", "ovhip_job_recorder", "ovhip_job_begin",
-    "ovhip_job_flush", "ovhip_job_wait", "ovhip_job_refined_mvs", "ovhip_job_dmvr_rows", "ovhip_job_last_stats", "ovhip_job_time_stage", "ovhip_job_stage_time",
+    "ovhip_job_flush", "ovhip_job_wait", "ovhip_job_refined_mvs", "ovhip_job_dmvr_rows", "ovhip_job_dmvr_rows_begin", "ovhip_job_dmvr_rows_collect", "ovhip_job_last_stats", "ovhip_job_time_stage", "ovhip_job_stage_time",
     "ovhip_output_bytes", "ovhip_output_rows", "ovhip_output_pack_launch", "ovhip_output_row_md5_launch", "ovhip_output_bands", "ovhip_output_tree_md5_launch", "ovhip_pic_output", "ovhip_pic_digest",
     "ovhip_md5_init", "ovhip_md5_update", "ovhip_md5_final", "ovhip_tmvp_cells_launch", "ovhip_job_tmvp_cells", "ovhip_intra_flow_untag_launch", "ovhip_lmcs_inverse_untag_launch", "ovhip_lmcs_scale_prepare_launch",
     "ovhip_host_alloc", "ovhip_host_free", "ovhip_d2d", "ovhip_job_test_abort_next_flow",
@@ -542,7 +546,7 @@ EXPORTED_SYMBOLS = [
     "ovhip_dpb_publish", "ovhip_dpb_acquire", "ovhip_dpb_wait_copy", "ovhip_dpb_set_unknown_key_timeout", "ovhip_dpb_unpin", "ovhip_dpb_release", "ovhip_dpb_lookup", "ovhip_dpb_shutdown",
     "ovhip_dpb_get_stats",
     "ovhip_frame_create", "ovhip_frame_create_ex", "ovhip_ctx_create_prio", "ovhip_frame_destroy", "ovhip_frame_ctx", "ovhip_frame_job", "ovhip_frame_recorder", "ovhip_frame_begin", "ovhip_frame_ref",
-    "ovhip_frame_ref_at", "ovhip_frame_dmvr_rows", "ovhip_frame_submit", "ovhip_frame_fail", "ovhip_frame_last_error",
+    "ovhip_frame_ref_at", "ovhip_frame_dmvr_rows", "ovhip_frame_dmvr_rows_begin", "ovhip_frame_dmvr_rows_collect", "ovhip_frame_submit", "ovhip_frame_fail", "ovhip_frame_last_error",
     "ovhip_calllog_create", "ovhip_calllog_destroy", "ovhip_calllog_reset", "ovhip_calllog_data", "ovhip_rec_set_calllog", "ovhip_calllog_replay",
     "ovhip_stream_create", "ovhip_stream_destroy", "ovhip_stream_run", "ovhip_stream_frame", "ovhip_stream_key", "ovhip_stream_queue_info",
 ]

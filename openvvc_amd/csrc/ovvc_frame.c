@@ -163,6 +163,36 @@ ovhip_frame_dmvr_rows(ovhip_frame *f)
     return n;
 }
 
+int64_t
+ovhip_frame_dmvr_rows_begin(ovhip_frame *f, int32_t log2_ctu_s)
+{
+    if (!f || !f->live || !f->job) return OVHIP_EINVAL;
+    /* the references are needed (and waited for) only if a unit the pass would cover is a DMVR unit: rows of BDOF-only units do not
+     * stop the parse */
+    int64_t c = ovhip_job_dmvr_rows_collect(f->job);
+    if (c < 0) { fail(f, (int)c, "ovhip_job_dmvr_rows_collect"); return c; }
+    size_t nu = 0;
+    const ovhip_mc_unit *u = ovhip_rec_mcx_units(ovhip_job_recorder(f->job), &nu);
+    int any = 0;
+    for (size_t i = (size_t)c; i < nu && !any; ++i) any = (u[i].flags & OVHIP_MC_DMVR) != 0;
+    if (any) {
+        int r = acquire_refs(f);
+        if (r != OVHIP_OK) return r;
+    }
+    int64_t n = ovhip_job_dmvr_rows_begin(f->job, f->ref_pic, (uint32_t)f->n_refs, log2_ctu_s);
+    if (n < 0) fail(f, (int)n, "ovhip_job_dmvr_rows_begin");
+    return n;
+}
+
+int64_t
+ovhip_frame_dmvr_rows_collect(ovhip_frame *f)
+{
+    if (!f || !f->live || !f->job) return OVHIP_EINVAL;
+    int64_t n = ovhip_job_dmvr_rows_collect(f->job);
+    if (n < 0) fail(f, (int)n, "ovhip_job_dmvr_rows_collect");
+    return n;
+}
+
 static int
 publish(ovhip_frame *f, int status)
 {

@@ -43,6 +43,8 @@ struct ovhip_job {
     ovhip_tmvp_cell *tmvp_host; size_t tmvp_cap, n_tmvp;   // pinned: TMVP plane cells of the refined units (ovhip_job_params.tmvp_cells)
     size_t n_mv;                         // units covered by the last flush / eager pass
     size_t dmvr_first;                   // refined units [0, dmvr_first) already went through the eager search
+    size_t rows_end; int rows_pending;   // an eager pass is in flight: it covers [.., rows_end), ev_rows follows its copies
+    hipEvent_t ev_rows;
     hipEvent_t ev_h2d, ev_done;
     int flushed;                         // ev_* recorded at least once
     const void *packed_prev[24];         // where the last full flush placed the arrays that rode in the parameter block
@@ -163,6 +165,7 @@ int ovhip_job_create(ovhip_ctx *ctx, int32_t w, int32_t h, ovhip_job **out)
     int r = ovhip_pic_alloc(ctx, w, h, &j->tmp);
     if (r == OVHIP_OK && hipEventCreateWithFlags(&j->ev_h2d, hipEventDisableTiming) != hipSuccess) r = OVHIP_ENODEV;
     if (r == OVHIP_OK && hipEventCreateWithFlags(&j->ev_done, hipEventDisableTiming) != hipSuccess) r = OVHIP_ENODEV;
+    if (r == OVHIP_OK && hipEventCreateWithFlags(&j->ev_rows, hipEventDisableTiming) != hipSuccess) r = OVHIP_ENODEV;
     if (r != OVHIP_OK) { ovhip_job_destroy(j); return r; }
     *out = j;
     return OVHIP_OK;
@@ -184,6 +187,7 @@ void ovhip_job_destroy(ovhip_job *j)
     for (int k = 0; k < 32; ++k) for (int q = 0; q < 2; ++q) if (j->t_ev[k][q]) (void)hipEventDestroy(j->t_ev[k][q]);
     if (j->ev_h2d) (void)hipEventDestroy(j->ev_h2d);
     if (j->ev_done) (void)hipEventDestroy(j->ev_done);
+    if (j->ev_rows) { if (j->rows_pending) (void)hipEventSynchronize(j->ev_rows); (void)hipEventDestroy(j->ev_rows); }
     ovhip_rec_destroy(j->rec);
     free(j);
 }
@@ -196,8 +200,9 @@ int ovhip_job_begin(ovhip_job *j)
     OV_DEVICE(j->ctx);
     // the DMA engines may still be reading the recorder's arrays and the parameter staging block
     if (j->flushed) OV_HIP(j->ctx, hipEventSynchronize(j->ev_h2d));
+    if (j->rows_pending) { OV_HIP(j->ctx, hipEventSynchronize(j->ev_rows)); j->rows_pending = 0; }
     ovhip_rec_reset(j->rec);
-    j->dmvr_first = 0; j->n_mv = 0;
+    j->dmvr_first = 0; j->n_mv = 0; j->n_tmvp = 0; j->rows_end = 0;
     return OVHIP_OK;
 }
 
@@ -293,9 +298,26 @@ int ovhip_job_stage_time(ovhip_job *j, double *sum_ms, uint64_t *count)
     return OVHIP_OK;
 }
 
-int64_t ovhip_job_dmvr_rows(ovhip_job *j, const ovhip_pic *refs, uint32_t n_refs)
+int64_t ovhip_job_dmvr_rows_collect(ovhip_job *j)
 {
     if (!j) return OVHIP_EINVAL;
+    if (j->rows_pending) {
+        ovhip_ctx *ctx = j->ctx;
+        OV_DEVICE(ctx);
+        hipError_t e = hipEventSynchronize(j->ev_rows);
+        j->rows_pending = 0;
+        if (e != hipSuccess) return ov_fail(ctx, OVHIP_ELAUNCH, "hipEventSynchronize(dmvr rows)", e);
+        if (j->rows_end > j->n_mv) j->n_mv = j->rows_end;
+    }
+    return (int64_t)j->rows_end;
+}
+
+int64_t ovhip_job_dmvr_rows_begin(ovhip_job *j, const ovhip_pic *refs, uint32_t n_refs, int32_t log2_ctu_s)
+{
+    if (!j) return OVHIP_EINVAL;
+    // one pass in flight: the pinned result arrays may have to grow, and they keep the recorder's indexing
+    const int64_t c = ovhip_job_dmvr_rows_collect(j);
+    if (c < 0) return c;
     ovhip_ctx *ctx = j->ctx;
     OV_DEVICE(ctx);
     size_t n = 0;
@@ -307,12 +329,15 @@ int64_t ovhip_job_dmvr_rows(ovhip_job *j, const ovhip_pic *refs, uint32_t n_refs
     if (any) {
         // the device copy of the unit list and the vector buffer keep the recorder's indexing: [first, n) lands at first
         CHK(pinned_reserve(j, (void **)&j->mv_host, &j->mv_cap, n * 16));
-        if (j->dev[B_MCX].cap < n * sizeof(ovhip_mc_unit) || j->dev[B_MV].cap < n * 16) {
+        if (log2_ctu_s) CHK(pinned_reserve(j, (void **)&j->tmvp_host, &j->tmvp_cap, 4 * n * sizeof(ovhip_tmvp_cell)));
+        if (j->dev[B_MCX].cap < n * sizeof(ovhip_mc_unit) || j->dev[B_MV].cap < n * 16 ||
+            (log2_ctu_s && j->dev[B_TMVP].cap < 4 * n * sizeof(ovhip_tmvp_cell))) {
             // grow to the picture's upper bound at once so that earlier rows' results are never moved: one refined unit
             // covers at least 8x8 luma samples
             const size_t ub = (size_t)((j->w + 7) / 8) * ((j->h + 7) / 8);
             CHK(dev_reserve(j, B_MCX, (ub > n ? ub : n) * sizeof(ovhip_mc_unit)));
             CHK(dev_reserve(j, B_MV, (ub > n ? ub : n) * 16));
+            if (log2_ctu_s) CHK(dev_reserve(j, B_TMVP, 4 * (ub > n ? ub : n) * sizeof(ovhip_tmvp_cell)));
         }
         char *d_units = (char *)j->dev[B_MCX].p + first * sizeof(ovhip_mc_unit);
         int32_t *d_mv = (int32_t *)j->dev[B_MV].p + 4 * first;
@@ -320,12 +345,34 @@ int64_t ovhip_job_dmvr_rows(ovhip_job *j, const ovhip_pic *refs, uint32_t n_refs
         ovhip_pic geom = j->tmp;
         CHK(ovhip_dmvr_search_launch(ctx, &geom, refs, n_refs, (const ovhip_mc_unit *)d_units, (uint32_t)(n - first), d_mv));
         OV_HIP(ctx, hipMemcpyAsync(j->mv_host + 4 * first, d_mv, (n - first) * 16, hipMemcpyDeviceToHost, ctx->stream));
-        hipError_t e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) return ov_fail(ctx, OVHIP_ELAUNCH, "hipStreamSynchronize(dmvr rows)", e);
-        if (n > j->n_mv) j->n_mv = n;
+        if (log2_ctu_s) {
+            // the same vectors as entries of the picture's collocated motion plane: what the caller patches before it publishes
+            // the row (4 entries per unit, recorder order)
+            ovhip_tmvp_cell *d_cells = (ovhip_tmvp_cell *)j->dev[B_TMVP].p + 4 * first;
+            CHK(ovhip_tmvp_cells_launch(ctx, (const ovhip_mc_unit *)d_units, (uint32_t)(n - first), d_mv, log2_ctu_s,
+                                        (j->w + (1 << log2_ctu_s) - 1) >> log2_ctu_s, d_cells));
+            OV_HIP(ctx, hipMemcpyAsync(j->tmvp_host + 4 * first, d_cells, 4 * (n - first) * sizeof(ovhip_tmvp_cell), hipMemcpyDeviceToHost,
+                                       ctx->stream));
+            j->n_tmvp = 4 * n;
+        }
+        OV_HIP(ctx, hipEventRecord(j->ev_rows, ctx->stream));
+        j->rows_pending = 1;
+    }
+    else if (log2_ctu_s) {
+        // no DMVR unit among them: their plane entries are all "none" (the caller indexes the entries by unit)
+        CHK(pinned_reserve(j, (void **)&j->tmvp_host, &j->tmvp_cap, 4 * n * sizeof(ovhip_tmvp_cell)));
+        for (size_t i = 4 * first; i < 4 * n; ++i) { j->tmvp_host[i] = ovhip_tmvp_cell{}; j->tmvp_host[i].cell = OVHIP_TMVP_NONE; }
+        j->n_tmvp = 4 * n;
     }
     j->dmvr_first = n;
+    j->rows_end = n;
     return (int64_t)n;
+}
+
+int64_t ovhip_job_dmvr_rows(ovhip_job *j, const ovhip_pic *refs, uint32_t n_refs)
+{
+    const int64_t n = ovhip_job_dmvr_rows_begin(j, refs, n_refs, 0);
+    return n < 0 ? n : ovhip_job_dmvr_rows_collect(j);
 }
 
 static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs, const ovhip_pic *intra,
@@ -366,6 +413,8 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
     ovhip_ctx *ctx = j->ctx;
     OV_DEVICE(ctx);
     if (dst->w != j->w || dst->h != j->h) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_job_flush: picture size differs from the job's", hipSuccess);
+    // an eager pass nobody collected (ovhip_job_dmvr_rows_begin): its copies land in arrays this flush may re-allocate
+    { const int64_t c_ = ovhip_job_dmvr_rows_collect(j); if (c_ < 0) return (int)c_; }
     const uint32_t stages = pr->stages ? pr->stages : 0xffffffffu;
     const int log2_ctu = pr->log2_ctu_s ? pr->log2_ctu_s : 7;
     if (log2_ctu < 5 || log2_ctu > 7) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_job_flush: log2_ctu_s", hipSuccess);

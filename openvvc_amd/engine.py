@@ -501,6 +501,20 @@ class Job:
             self.ctx._chk(int(n), "job_dmvr_rows")
         return int(n)
 
+    def dmvr_rows_begin(self, refs: list, log2_ctu: int = 0) -> int:
+        """enqueue the eager pass over the refined units recorded since the last one (log2_ctu != 0: + their TMVP plane entries)"""
+        arr = (capi.Pic * max(len(refs), 1))(*[r.s for r in refs])
+        n = self.lib.ovhip_job_dmvr_rows_begin(self.j, arr, len(refs), log2_ctu)
+        if n < 0:
+            self.ctx._chk(int(n), "job_dmvr_rows_begin")
+        return int(n)
+
+    def dmvr_rows_collect(self) -> int:
+        n = self.lib.ovhip_job_dmvr_rows_collect(self.j)
+        if n < 0:
+            self.ctx._chk(int(n), "job_dmvr_rows_collect")
+        return int(n)
+
     def refined_mvs(self) -> np.ndarray:
         n = C.c_size_t()
         p = self.lib.ovhip_job_refined_mvs(self.j, C.byref(n))
@@ -616,6 +630,12 @@ class Frame:
 
     def dmvr_rows(self) -> int:
         return int(self._chk(self.lib.ovhip_frame_dmvr_rows(self.f), "frame_dmvr_rows"))
+
+    def dmvr_rows_begin(self, log2_ctu: int = 7) -> int:
+        return int(self._chk(self.lib.ovhip_frame_dmvr_rows_begin(self.f, log2_ctu), "frame_dmvr_rows_begin"))
+
+    def dmvr_rows_collect(self) -> int:
+        return int(self._chk(self.lib.ovhip_frame_dmvr_rows_collect(self.f), "frame_dmvr_rows_collect"))
 
     def submit(self, params: "capi.JobParams", job: "Job | None" = None, out: "capi.FrameOutput | None" = None, check: bool = True) -> int:
         r = self.lib.ovhip_frame_submit(self.f, job.j if job is not None else None, None, C.byref(params), C.byref(out) if out is not None else None)

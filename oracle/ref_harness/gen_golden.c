@@ -603,7 +603,17 @@ gen_mcx(const char *dir)
                         int32_t fake[64 * 4];
                         for (int u = 0; u < nu; ++u) for (int k = 0; k < 4; ++k) fake[4 * u + k] = 100000 + (int32_t)n_cases * 1000 + u * 8 + k;
                         memset(pl0.mvs, 0, (size_t)pln_stride * 16 * nb_ctb_h * sizeof(OVMV)); memset(pl1.mvs, 0, (size_t)pln_stride * 16 * nb_ctb_h * sizeof(OVMV));
-                        ovhip_shim_apply_refined_mvs(c, fake, 0, nu);
+                        {
+                            /* the plane entries as the device derives them (k_tmvp_cells; its CPU restatement here: the harness runs
+                             * without a GPU, tests/test_gpu_shim_replay.py holds the kernel to the same entries) */
+                            extern void oracle_tmvp_cells(const ovhip_mc_unit *, uint32_t, const int32_t *, int, int, ovhip_tmvp_cell *);
+                            size_t n_rec = 0;
+                            const ovhip_mc_unit *ru = ovhip_rec_mcx_units(ovhip_shim_recorder(c), &n_rec);
+                            if ((int)n_rec != nu) { fprintf(stderr, "shim: %zu refined units recorded, %d expected (case %u)\n", n_rec, nu, n_cases); exit(1); }
+                            static ovhip_tmvp_cell cells[64 * 4];
+                            oracle_tmvp_cells(ru, (uint32_t)nu, fake, 7, pln_stride / 16, cells);
+                            ovhip_shim_apply_tmvp_cells(c, cells, 4 * (size_t)nu);
+                        }
                         int32_t checked = 0, bad = 0;
                         static OVMV exp0[16 * 16], exp1[16 * 16];      /* the CTU-local tmvp_mv[] arrays of the caller */
                         memset(exp0, 0, sizeof(exp0)); memset(exp1, 0, sizeof(exp1));

@@ -77,7 +77,6 @@ extern int transform_unit_c(OVCTUDec *const, unsigned int, unsigned int, unsigne
 /* ------------------------------------------------------------------------------------ side table */
 enum { PEND_NONE = 0, PEND_AFFINE, PEND_BDOF };
 
-struct dmvr_patch { OVMV *dst0[4], *dst1[4]; uint8_t n; };
 
 struct hip_entry {
     const OVCTUDec *key;
@@ -93,8 +92,9 @@ struct hip_entry {
     ovhip_lmcs_luts luts; int have_luts, lmcs_region_live;
     ovhip_sao_ctu *sao; ovhip_alf_ctu *alf; size_t n_ctu; int sao_on, alf_on;
     int16_t alf_cc[2][4][8];
-    struct dmvr_patch *patch; size_t n_patch, cap_patch;     /* one per refined unit recorded (n == 0: not a DMVR unit) */
-    size_t dmvr_done;                    /* refined units whose vectors are already applied */
+    size_t n_refined;                    /* refined units recorded (BDOF and DMVR: the index space of the device's results)      */
+    size_t dmvr_done;                    /* ... whose vectors are already in the picture's TMVP planes                            */
+    size_t row_mark;                     /* ... recorded when the last row-end hook ran                                           */
     /* prediction calls being collected into one CU */
     struct {
         int kind, x0, y0, n, cols, rows_done, cur_col;
@@ -791,48 +791,28 @@ hip_rcn_dmvr_mv_refine(OVCTUDec *const c, struct OVBuffInfo dst, uint8_t x0, uin
     latch(e, r, "ovhip_rec_pu(dmvr)");
     ovhip_rec_mcx_units(e->rec, &n_after);
     if (r < 0 || n_after != n_before + 1) return 0;
-    /* one refined unit <-> where its vectors live in the picture's TMVP planes (8x8 grid): the caller writes
-     * tmvp_mv[l].mvs[((x0 + 7) >> 3) + ((y0 + 7) >> 3) * 16] and its right / lower neighbours for 16-wide / 16-high
-     * blocks; tmvp_store_mv copies row i of that 16x16 array to plane->mvs + ctb_offset + i * pln_stride */
-    if (n_after > e->cap_patch) {
-        size_t nc = e->cap_patch ? e->cap_patch * 2 : 1024;
-        while (nc < n_after) nc *= 2;
-        struct dmvr_patch *q = realloc(e->patch, nc * sizeof(*q));
-        if (!q) { latch(e, OVHIP_ENOMEM, "dmvr patch list"); return 0; }
-        memset(q + e->cap_patch, 0, (nc - e->cap_patch) * sizeof(*q));
-        e->patch = q; e->cap_patch = nc;
-    }
-    for (size_t i = e->n_patch; i < n_after; ++i) e->patch[i].n = 0;
-    struct dmvr_patch *p = &e->patch[n_before];
-    const struct MVPlane *pl0 = ic->tmvp_ctx.plane0, *pl1 = ic->tmvp_ctx.plane1;
-    if (pl0 && pl1 && pl0->mvs && pl1->mvs) {
-        const int nb_tmvp = (1 << c->part_ctx->log2_ctu_s) >> 3;
-        const int32_t stride = nb_tmvp * c->nb_ctb_pic_w;
-        const int32_t ctb_off = (c->ctb_x + c->ctb_y * stride) * nb_tmvp;
-        const int ux = (x0 + 7) >> 3, uy = (y0 + 7) >> 3;
-        for (int dy = 0; dy <= (log2_pu_h > 3); ++dy)
-            for (int dx = 0; dx <= (log2_pu_w > 3); ++dx) {
-                if (ux + dx >= nb_tmvp || uy + dy >= nb_tmvp) continue;       /* outside what tmvp_store_mv copies */
-                p->dst0[p->n] = pl0->mvs + ctb_off + (uy + dy) * stride + ux + dx;
-                p->dst1[p->n] = pl1->mvs + ctb_off + (uy + dy) * stride + ux + dx;
-                p->n++;
-            }
-    }
-    e->n_patch = n_after;
+    /* where the unit's vectors live in the picture's TMVP planes (8x8 grid) is derived on the device from the unit itself
+     * (ovhip_tmvp_cells_launch: the caller writes tmvp_mv[l].mvs[((x0 + 7) >> 3) + ((y0 + 7) >> 3) * 16] and its right / lower
+     * neighbours for 16-wide / 16-high blocks, tmvp_store_mv copies row i of that array to plane->mvs + ctb_offset + i * pln_stride);
+     * r2 kept eight host pointers per unit here */
+    e->n_refined = n_after;
     return 0;      /* disable_bdof: unused by the caller (vcl_coding_unit.c:2621) */
 }
 
+/* Entries of the picture's collocated motion planes as the device derived them (ovhip_job_tmvp_cells: 4 per refined unit, cell =
+ * index into MVPlane.mvs, OVHIP_TMVP_NONE = unused / not a DMVR unit / outside what tmvp_store_mv copies): x and y of both lists. */
 int
-ovhip_shim_apply_refined_mvs(OVCTUDec *c, const int32_t *mv, size_t first, size_t n)
+ovhip_shim_apply_tmvp_cells(OVCTUDec *c, const ovhip_tmvp_cell *cells, size_t n_entries)
 {
-    struct hip_entry *e = entry_of(c, 0);
-    if (!e || !mv) return OVHIP_EINVAL;
-    for (size_t i = first; i < first + n && i < e->n_patch; ++i) {
-        const struct dmvr_patch *p = &e->patch[i];
-        for (int k = 0; k < p->n; ++k) {
-            p->dst0[k]->x = mv[4 * i + 0]; p->dst0[k]->y = mv[4 * i + 1];
-            p->dst1[k]->x = mv[4 * i + 2]; p->dst1[k]->y = mv[4 * i + 3];
-        }
+    if (!c || (!cells && n_entries)) return OVHIP_EINVAL;
+    const struct InterDRVCtx *ic = &c->drv_ctx.inter_ctx;
+    const struct MVPlane *pl0 = ic->tmvp_ctx.plane0, *pl1 = ic->tmvp_ctx.plane1;
+    if (!pl0 || !pl1 || !pl0->mvs || !pl1->mvs) return OVHIP_OK;         /* the picture keeps no motion field */
+    for (size_t i = 0; i < n_entries; ++i) {
+        const ovhip_tmvp_cell *q = &cells[i];
+        if (q->cell == OVHIP_TMVP_NONE) continue;
+        pl0->mvs[q->cell].x = q->mv0x; pl0->mvs[q->cell].y = q->mv0y;
+        pl1->mvs[q->cell].x = q->mv1x; pl1->mvs[q->cell].y = q->mv1y;
     }
     return OVHIP_OK;
 }
@@ -1045,15 +1025,50 @@ hip_sao_filter_line(OVCTUDec *const c, const struct RectEntryInfo *const einfo, 
     sao_row(e, c, einfo, ctb_y + 1);
 }
 
+static void dmvr_rows_step(struct hip_entry *e, OVCTUDec *c, int final);
+
 static void
 hip_sao_first_pix_rows(OVCTUDec *const c, const struct RectEntryInfo *const einfo, uint16_t ctb_y)
 {
     ENTER(c);
+    /* the only hook that runs at the end of row 0 (slicedec.c:934-941): the eager DMVR pass over that row starts here */
+    if (!e->record_only && einfo->nb_ctu_h > 1) dmvr_rows_step(e, c, 0);
     if (!c->sao_info.sao_luma_flag && !c->sao_info.sao_chroma_flag) return;
     sao_row(e, c, einfo, ctb_y);
 }
 
 static void flush_picture(struct hip_entry *e, OVCTUDec *c);
+
+/* Eager DMVR, one step per row-end hook.  decode_ctu_line reports row y - 1 after row y has been parsed (slicedec.c:934-956), and
+ * every reader of the collocated motion field (TMVP of later pictures, drv_mvp.c:281-345) must find refined vectors in a reported
+ * row.  So: collect the pass enqueued at the end of the row before (search + vectors + plane entries: one asynchronous D2H each, it
+ * ran while this row was parsed), patch the planes, enqueue the pass over the row just parsed.  The last row, and rows no hook ran
+ * after, are refined synchronously.  ovhip_frame_dmvr_rows_begin waits for the picture's references on the host the first time a
+ * row holds a DMVR unit (rcn_inter_synchronization waits per block, rcn_inter.c:131-146). */
+static void
+dmvr_rows_step(struct hip_entry *e, OVCTUDec *c, int final)
+{
+    if (!e->fr || e->err) return;
+    const size_t now = e->n_refined;
+    if (now == e->dmvr_done) { e->row_mark = now; return; }
+    int64_t done = ovhip_frame_dmvr_rows_collect(e->fr);
+    if (done >= 0 && (final || (size_t)done < e->row_mark)) {
+        done = ovhip_frame_dmvr_rows_begin(e->fr, e->log2_ctu);
+        if (done >= 0) done = ovhip_frame_dmvr_rows_collect(e->fr);
+    }
+    if (done < 0) { latch(e, (int)done, "ovhip_frame_dmvr_rows"); return; }
+    if ((size_t)done > e->dmvr_done) {
+        size_t n = 0;
+        const ovhip_tmvp_cell *cells = ovhip_job_tmvp_cells(ovhip_frame_job(e->fr), &n);
+        if (cells && n >= 4 * (size_t)done) ovhip_shim_apply_tmvp_cells(c, cells + 4 * e->dmvr_done, 4 * ((size_t)done - e->dmvr_done));
+        e->dmvr_done = (size_t)done;
+    }
+    if (!final && now > (size_t)done) {
+        const int64_t r = ovhip_frame_dmvr_rows_begin(e->fr, e->log2_ctu);
+        if (r < 0) latch(e, (int)r, "ovhip_frame_dmvr_rows_begin");
+    }
+    e->row_mark = now;
+}
 
 /* alf.rcn_alf_filter_line (rcn_structures.h:333; rcn_alf.c:1285-1433): the LAST slot call before a CTU row is published
  * (slicedec.c:934-956).  Captures the row's ALF parameters, refines the DMVR vectors recorded so far (so that the row's
@@ -1078,19 +1093,7 @@ hip_alf_filter_line(OVCTUDec *const c, const struct RectEntryInfo *const einfo, 
         e->alf_on = 1;
     }
     if (e->record_only) return;
-    /* eager DMVR: rows up to this one (ovhip_frame_dmvr_rows waits for the reference pictures, as rcn_inter_synchronization does
-     * for the rows a prediction reads, rcn_inter.c:131-146 -- here: until they are complete on this device) */
-    if (e->n_patch > e->dmvr_done && e->fr && !e->err) {
-        const size_t first = e->dmvr_done;
-        const int64_t done = ovhip_frame_dmvr_rows(e->fr);
-        if (done < 0) latch(e, (int)done, "ovhip_frame_dmvr_rows");
-        else {
-            size_t nm = 0;
-            const int32_t *mv = ovhip_job_refined_mvs(ovhip_frame_job(e->fr), &nm);
-            ovhip_shim_apply_refined_mvs(c, mv, first, (size_t)done - first);
-            e->dmvr_done = (size_t)done;
-        }
-    }
+    dmvr_rows_step(e, c, ctb_y == einfo->nb_ctu_h - 1);
     if (ctb_y == einfo->nb_ctu_h - 1) flush_picture(e, c);
 }
 
@@ -1218,12 +1221,8 @@ flush_picture(struct hip_entry *e, OVCTUDec *c)
     out.mode = g_out_mode;
     out.y = (uint16_t *)f->data[0]; out.cb = (uint16_t *)f->data[1]; out.cr = (uint16_t *)f->data[2];
     out.stride_y = (int32_t)(f->linesize[0] / 2); out.stride_c = (int32_t)(f->linesize[1] / 2);
+    /* (every refined vector is in the TMVP planes already: dmvr_rows_step(final) ran in the hook that called this) */
     latch(e, ovhip_frame_submit(e->fr, NULL, NULL, &pr, &out), "ovhip_frame_submit");
-    /* remaining refined vectors (last row) */
-    size_t nm = 0;
-    const int32_t *mv = ovhip_job_refined_mvs(ovhip_frame_job(e->fr), &nm);
-    if (!e->err && mv && nm > e->dmvr_done) ovhip_shim_apply_refined_mvs(c, mv, e->dmvr_done, nm - e->dmvr_done);
-    e->dmvr_done = nm;
 }
 
 static void
@@ -1234,7 +1233,7 @@ begin_picture(struct hip_entry *e, const OVFrame *f, const struct RectEntryInfo 
     e->n_refs = 0;
     e->sao_on = e->alf_on = 0;
     e->lmcs_region_live = 0;
-    e->n_patch = 0; e->dmvr_done = 0;
+    e->n_refined = 0; e->dmvr_done = 0; e->row_mark = 0;
     e->pend.kind = PEND_NONE; e->aff_c_live = 0; e->ciip.live = 0;
     if (e->rec && e->key->part_ctx) (void)ovhip_rec_set_ctu_size(e->rec, e->key->part_ctx->log2_ctu_s);
     if (e->n_ctu) { memset(e->sao, 0, e->n_ctu * sizeof(*e->sao)); memset(e->alf, 0, e->n_ctu * sizeof(*e->alf)); }
@@ -1379,7 +1378,7 @@ void
 ovhip_shim_new_picture_for_test(OVCTUDec *c)
 {
     struct hip_entry *e = entry_of(c, 0);
-    if (e && e->record_only) { e->n_patch = 0; e->dmvr_done = 0; }
+    if (e && e->record_only) { e->n_refined = 0; e->dmvr_done = 0; e->row_mark = 0; }
 }
 
 ovhip_recorder *ovhip_shim_recorder(const OVCTUDec *c) { struct hip_entry *e = entry_of(c, 0); return e ? e->rec : NULL; }
@@ -1427,7 +1426,7 @@ ovhip_shim_release(const OVCTUDec *c)
     pthread_mutex_unlock(&g_mtx);
     if (!e) return;
     if (e->fr) ovhip_frame_destroy(e->fr);
-    free(e->sao); free(e->alf); free(e->patch);
+    free(e->sao); free(e->alf);
     /* the last frame thread of the process takes the device DPB (every device picture) with it */
     pthread_mutex_lock(&g_dpb_mtx);
     if (e->dev >= 0 && --g_n_entries == 0 && g_dpb) {

@@ -36,11 +36,12 @@ int  ovhip_shim_ref_pictures(const struct OVCTUDec *ctudec, const void **out, in
 void ovhip_shim_flush_pending(struct OVCTUDec *ctudec);
 /* First error latched since the picture began (0 = none; negative OVHIP_E*): the slots return void. */
 int  ovhip_shim_last_error(const struct OVCTUDec *ctudec);
-/* The refined motion vectors of refined units [first, first + n) (4 int32 each: mv0x, mv0y, mv1x, mv1y), as
- * ovhip_job_refined_mvs() returns them: written into the decoder's TMVP motion storage where the reference's caller
- * stores what rcn_dmvr_mv_refine returned (vcl_coding_unit.c:2629-2645; drv_lines.c:270-330).  Called by the shim's
- * own alf.rcn_alf_filter_line hook; exposed for the record-only harness. */
-int  ovhip_shim_apply_refined_mvs(struct OVCTUDec *ctudec, const int32_t *mv, size_t first, size_t n);
+/* Entries of the picture's collocated motion planes (ovhip_job_tmvp_cells(): 4 per refined unit, derived on the device from the
+ * units and the refined vectors) written where the reference's caller + tmvp_store_mv put what rcn_dmvr_mv_refine returned
+ * (vcl_coding_unit.c:2629-2645; drv_lines.c:270-330).  Called by the shim's own row-end hooks; exposed for the record-only
+ * harness. */
+struct ovhip_tmvp_cell;
+int  ovhip_shim_apply_tmvp_cells(struct OVCTUDec *ctudec, const struct ovhip_tmvp_cell *cells, size_t n_entries);
 /* Picture-level side information the filter slots collected (valid until the next picture begins). */
 struct ovhip_sao_ctu;
 struct ovhip_alf_ctu;

@@ -6,6 +6,7 @@ import threading
 import numpy as np
 import pytest
 
+import oracle_lib
 import oracle_pipeline
 from openvvc_amd import capi, engine, synth
 
@@ -76,6 +77,46 @@ def test_job_eager_dmvr_rows(ctx):
     assert np.array_equal(early2[is_dmvr], final[is_dmvr])
     assert (final[is_dmvr] != np.stack([ux["mv0x"], ux["mv0y"], ux["mv1x"], ux["mv1y"]], axis=1)[is_dmvr]).any()
     _check(wl, dst.download(), "after eager rows")
+    job.close()
+
+
+def test_job_eager_dmvr_rows_in_two_halves(ctx):
+    """ovhip_job_dmvr_rows_begin / _collect, the way the shim's row-end hooks use them: a pass is enqueued at the end of a CTU row
+    and collected at the end of the next, more units having been recorded in between; vectors AND the TMVP plane entries of every
+    pass equal the oracle's for the final vectors of the full flush (entries of DMVR units; the others are OVHIP_TMVP_NONE)."""
+    w, h = 832, 480
+    wl = synth.make_workload(w, h, 5)
+    job = engine.Job(ctx, w, h)
+    refs = [ctx.upload_pic(*r) for r in wl.refs]
+    intra = ctx.upload_pic(*wl.intra) if wl.intra is not None else None
+    dst = ctx.new_pic(w, h)
+    job.begin()
+    ux = wl.mcx_units
+    cuts = [0, len(ux) // 5, len(ux) // 2, len(ux) - 7, len(ux)]
+    assert cuts[1] > 10
+    assert job.dmvr_rows_collect() == 0                               # nothing pending: returns at once
+    seen = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        job.rec.append_raw(capi.REC_MCX, ux[a:b])                     # "the next row is parsed" ...
+        done = job.dmvr_rows_collect()                                # ... then the pass of the row before is collected
+        assert done == a
+        seen.append((done, job.refined_mvs()[:done].copy(), job.tmvp_cells()[:4 * done].copy()))
+        assert job.dmvr_rows_begin(refs, 7) == b                      # and the pass over the new units enqueued
+    assert job.dmvr_rows_collect() == len(ux)
+    mv_rows, cells_rows = job.refined_mvs().copy(), job.tmvp_cells().copy()
+    job.load_workload(wl)
+    job.params.tmvp_cells = 1
+    job.flush(dst, refs, intra)
+    job.wait()
+    final, cells = job.refined_mvs(), job.tmvp_cells()
+    is_dmvr = (ux["flags"] & 64) != 0
+    assert is_dmvr.sum() > 10
+    assert np.array_equal(mv_rows[is_dmvr], final[is_dmvr])
+    want = oracle_lib.tmvp_cells(ux, final, 7, (w + 127) // 128)
+    assert np.array_equal(cells, want) and np.array_equal(cells_rows, want)
+    for done, mv, ce in seen:
+        assert np.array_equal(mv[is_dmvr[:done]], final[:done][is_dmvr[:done]]) and np.array_equal(ce, want[:4 * done])
+    _check(wl, dst.download(), "after eager rows in two halves")
     job.close()
 
 

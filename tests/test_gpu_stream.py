@@ -9,6 +9,7 @@ from pathlib import Path
 import numpy as np
 import pytest
 
+import oracle_lib
 import oracle_pipeline
 from openvvc_amd import capi, engine, gop, synth
 
@@ -302,8 +303,14 @@ def test_frame_api_as_the_shim_uses_it(built_lib):
         f1.job().test_abort_next_flow()                             # the download must see the SECOND pass (r2 downloaded before the wait)
         f1.submit(engine.Job.make_params(k1, wl1), out=out1)
         assert np.array_equal(y, p1.y) and np.array_equal(cb, p1.cb) and np.array_equal(cr, p1.cr)
-        n = f2.dmvr_rows()                                          # eager refinement: needs picture 1 complete
-        assert n == len(wl2.mcx_units)
+        # eager refinement in two halves, as the shim's row-end hooks run it: needs picture 1 complete
+        assert f2.dmvr_rows_collect() == 0
+        assert f2.dmvr_rows_begin(7) == len(wl2.mcx_units)
+        assert f2.dmvr_rows_collect() == len(wl2.mcx_units)
+        is_dmvr = (wl2.mcx_units["flags"] & 64) != 0
+        assert is_dmvr.sum() > 5 and np.array_equal(f2.job().refined_mvs()[is_dmvr], mvs[is_dmvr])
+        assert np.array_equal(f2.job().tmvp_cells(), oracle_lib.tmvp_cells(wl2.mcx_units, mvs, 7, (w + 127) // 128))
+        assert f2.dmvr_rows() == len(wl2.mcx_units)                 # the synchronous form: nothing new
         out2 = capi.FrameOutput()
         out2.mode = capi.OUT_DIGEST
         f2.submit(engine.Job.make_params(k2, wl2), out=out2)

@@ -26,7 +26,7 @@ def test_shim_builds_against_reference_headers(built_lib):
     export the installer with the signature of rcn_init_functions()."""
     subprocess.check_call(["make", "-C", str(ROOT / "shim")], stdout=subprocess.DEVNULL)
     out = subprocess.run(["nm", "-D", "--defined-only", str(ROOT / "shim" / "_build" / "librcn_hip.so")], capture_output=True, text=True, check=True).stdout
-    for sym in ("rcn_init_functions_hip", "ovhip_shim_bind_recorder", "ovhip_shim_apply_refined_mvs"):
+    for sym in ("rcn_init_functions_hip", "ovhip_shim_bind_recorder", "ovhip_shim_apply_tmvp_cells"):
         assert f" T {sym}" in out, sym
 
 
@@ -120,7 +120,7 @@ def test_shim_mcp_slots_match_reference(built_lib):
 
 def test_shim_refined_slots_match_reference(built_lib):
     """rcn_bdof_mcp_l (+ rcn_mcp_b_c) and rcn_dmvr_mv_refine through the installed table, incl. the refined vectors; the
-    harness has already checked that ovhip_shim_apply_refined_mvs writes exactly the TMVP plane entries the reference's
+    harness has already checked that ovhip_shim_apply_tmvp_cells writes exactly the TMVP plane entries the reference's
     caller + tmvp_store_mv write (mv_patch_checked = entries compared per DMVR case)."""
     refs, descs, exp_off, exp, exp_mv = golden_cases.mcx_cases()
     s = ShimStream("shim_mcx.ovg")
