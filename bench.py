@@ -427,6 +427,11 @@ def main():
     ms_per_step = dt * 1e3 / args.steps
     fps = n_timed_all / dt
     lib_seconds = float(res.seconds)
+    # host wall time per picture inside the frame threads (summed over threads / pictures): where a frame thread spends its time
+    nd = max(1, int(res.n_decoded))
+    host_us = {k: round(1e6 * float(res.host_seconds[i]) / nd, 1)
+               for i, k in enumerate(("class_split_and_parameter_block", "enqueue_copies", "wait_for_reference_pictures", "enqueue_launches",
+                                      "job_wait_publish_output"))}
     dpb_stats = dpb.stats()
     if world > 1:
         st_main = new_stream(S)
@@ -617,6 +622,7 @@ def main():
                        "timed_region": "one call of ovhip_stream_run (C, pthreads): frame threads take the pictures in decoding order, "
                                        "ovhip_frame_submit each (uploads -> host wait for the reference pictures -> launches -> ovhip_job_wait -> output -> publish)",
                        "timed_region_library_seconds": round(lib_seconds, 4),
+                       "frame_thread_host_us_per_picture": host_us,
                        "output": args.output, "recorder_in_timed_region": False,
                        "variants": variants,
                        "gop_size": G, "intra_period": IP,

@@ -871,6 +871,9 @@ typedef struct ovhip_job_stats {         /* what the last flush moved and launch
     uint32_t n_launches, n_h2d;
     uint32_t n_tb, n_mc, n_mcx, n_aff, n_edges_v, n_edges_h, n_regions, n_itasks, n_ilevels;
     uint32_t n_ordered_retries;          /* 1: ovhip_job_wait decoded the picture a second time, one launch per level (see there) */
+    /* host wall time of the flush call by phase, microseconds: class split + parameter block; enqueueing the copies; the
+     * before_launch callback + wait events (the frame thread waiting for its reference pictures); enqueueing the launches */
+    uint32_t host_us_prepare, host_us_upload, host_us_wait, host_us_launch;
 } ovhip_job_stats;
 
 int  ovhip_job_create(ovhip_ctx *ctx, int32_t pic_w, int32_t pic_h, ovhip_job **out);
@@ -1197,6 +1200,8 @@ typedef struct ovhip_stream_result {
                                             * = md5sum of the file dectest would write (CI/checkMD5.sh); OVHIP_OUT_DIGEST: MD5
                                             * over the pictures' digests (a private fingerprint)                            */
     double   record_seconds;               /* OVHIP_STREAM_RECORD: time spent replaying call logs, summed over threads */
+    /* host seconds summed over the frame threads: the four phases of ovhip_job_stats.host_us_*, then inside ovhip_job_wait */
+    double   host_seconds[5];
     int32_t  status;                       /* 0 or the first error                                                   */
     char     error[192];
     /* in: NULL, or room for 4 doubles per picture of the run -- seconds since the run began at which the picture was taken by a

@@ -203,7 +203,8 @@ class JobStats(C.Structure):
     _fields_ = [("h2d_bytes", C.c_uint64), ("d2h_bytes", C.c_uint64), ("n_launches", C.c_uint32), ("n_h2d", C.c_uint32),
                 ("n_tb", C.c_uint32), ("n_mc", C.c_uint32), ("n_mcx", C.c_uint32), ("n_aff", C.c_uint32),
                 ("n_edges_v", C.c_uint32), ("n_edges_h", C.c_uint32), ("n_regions", C.c_uint32),
-                ("n_itasks", C.c_uint32), ("n_ilevels", C.c_uint32), ("n_ordered_retries", C.c_uint32)]
+                ("n_itasks", C.c_uint32), ("n_ilevels", C.c_uint32), ("n_ordered_retries", C.c_uint32),
+                ("host_us_prepare", C.c_uint32), ("host_us_upload", C.c_uint32), ("host_us_wait", C.c_uint32), ("host_us_launch", C.c_uint32)]
 
 
 TMVP_CELL_DTYPE = np.dtype([("cell", "<u4"), ("mv0x", "<i4"), ("mv0y", "<i4"), ("mv1x", "<i4"), ("mv1y", "<i4")])
@@ -325,7 +326,8 @@ class StreamCfg(C.Structure):
 class StreamResult(C.Structure):
     _fields_ = [("seconds", C.c_double), ("n_decoded", C.c_uint64), ("n_second_passes", C.c_uint64), ("n_received", C.c_uint64),
                 ("n_sent", C.c_uint64), ("out_frames", C.c_uint64), ("out_bytes", C.c_uint64), ("out_md5", C.c_uint8 * 16),
-                ("record_seconds", C.c_double), ("status", C.c_int32), ("error", C.c_char * 192), ("trace", C.c_void_p)]
+                ("record_seconds", C.c_double), ("host_seconds", C.c_double * 5), ("status", C.c_int32), ("error", C.c_char * 192),
+                ("trace", C.c_void_p)]
 
 
 class Md5State(C.Structure):

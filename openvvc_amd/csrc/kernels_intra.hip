@@ -895,7 +895,10 @@ __device__ __forceinline__ bool fetch_refs_tagged(IntraLds &s, const uint16_t *p
 #define OVHIP_FLOW_PRIO 3
 #endif
 #define FLOW_MAX_FP 448
-#define FSTRIP 256                          // samples per item: one wave predicts a 1024-sample strip in ~2 us, the critical path of a hop
+#ifndef FSTRIP
+#define FSTRIP 256
+#endif
+// FSTRIP: samples per item: one wave predicts a 1024-sample strip in ~2 us, the critical path of a hop
 #define FNPL   (FSTRIP / 64)
 #define FJ8    ((FSTRIP + 511) / 512)        // runs of 8 / of 4 samples per lane
 #define FJ4    ((FSTRIP + 255) / 256)
@@ -959,7 +962,7 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
     load_tables(s, lane);
     const uint32_t item = items[blockIdx.x];
     const ovhip_itask t = tasks[item & 0xffffff];
-    const int strip = (item >> 24) & 0xf, comp = (item >> 28) & 1;
+    const int strip = (item >> 24) & 0x1f, comp = (item >> 29) & 1;
     const int l2w = t.log2_w, w = 1 << l2w, h = 1 << t.log2_h, npx = w * h;
     const bool luma = t.kind == OVHIP_IT_LUMA, region = t.kind == OVHIP_IT_REGION, res_only = t.kind == OVHIP_IT_RES_C;
     const bool lm = t.kind == OVHIP_IT_CHROMA && t.mode >= 67 && !(t.flags & OVHIP_IF_BDPCM);
@@ -1291,8 +1294,9 @@ extern "C" size_t ovhip_intra_flow_items(const ovhip_itask *sorted, size_t n, ui
         if (t.kind == OVHIP_IT_REGION) { if (k < cap) items[k] = (uint32_t)i; ++k; continue; }
         if (t.kind == OVHIP_IT_LUMA && t.log2_h < 2) return 0;
         const int npx = 1 << (t.log2_w + t.log2_h), strips = (npx + FSTRIP - 1) / FSTRIP, comps = t.kind == OVHIP_IT_LUMA ? 1 : 2;
+        if (strips > 32) return 0;                                   // the item word has five bits for the strip (a 64x64 block: 16)
         for (int st = 0; st < strips; ++st)
-            for (int c = 0; c < comps; ++c) { if (k < cap) items[k] = (uint32_t)i | ((uint32_t)st << 24) | ((uint32_t)c << 28); ++k; }
+            for (int c = 0; c < comps; ++c) { if (k < cap) items[k] = (uint32_t)i | ((uint32_t)st << 24) | ((uint32_t)c << 29); ++k; }
     }
     return k <= cap ? k : 0;
 }

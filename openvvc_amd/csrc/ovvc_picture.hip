@@ -106,6 +106,13 @@ int pinned_reserve(ovhip_job *j, void **p, size_t *cap, size_t bytes)
 
 #define CHK(x) do { int r__ = (x); if (r__ != OVHIP_OK) return r__; } while (0)
 
+double host_now_us()
+{
+    timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return 1e6 * (double)t.tv_sec + 1e-3 * (double)t.tv_nsec;
+}
+
 int t_collect(ovhip_job *j, int k)
 {
     if (!j->t_pending[k]) return OVHIP_OK;
@@ -421,6 +428,7 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
     const size_t n_ctu = (size_t)((j->w + (1 << log2_ctu) - 1) >> log2_ctu) * ((j->h + (1 << log2_ctu) - 1) >> log2_ctu);
     memset(&j->st, 0, sizeof(j->st));
     j->st.n_ordered_retries = j->n_retries;
+    const double t_flush0 = host_now_us();
     j->resident = (stages & OVHIP_STAGE_RESIDENT) && pr->stages;
     ovhip_recorder *rec = j->rec;
 
@@ -514,6 +522,7 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
         if (pr->lmcs) { memcpy(ph + L.fwd, pr->lmcs->fwd_lut, 2048); memcpy(ph + L.bwd, pr->lmcs->bwd_lut, 2048); }
     }
 
+    const double t_flush1 = host_now_us();
     // ---- H2D (asynchronous DMA out of page-locked memory, in stage order so that prediction can start early) ----
     {
     StageTimer t_(j, OVHIP_TIME_H2D);
@@ -541,6 +550,7 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
     if (j->resident) memcpy(packed, j->packed_prev, sizeof(packed)); else memcpy(j->packed_prev, packed, sizeof(packed));
     auto DEV = [&](int k) -> const void * { return packed[k] ? packed[k] : j->dev[k].p; };
     OV_HIP(ctx, hipEventRecord(j->ev_h2d, ctx->stream));
+    const double t_flush2 = host_now_us();
     // everything below reads or writes pictures: behind the pictures this one depends on
     for (uint32_t i = 0; i < pr->n_wait_events; ++i)
         if (pr->wait_events && pr->wait_events[i]) {
@@ -549,6 +559,9 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
         }
     if (pr->before_launch && pr->before_launch(pr->before_launch_user))
         return ov_fail(ctx, OVHIP_EINVAL, "ovhip_job_flush: before_launch callback failed", hipSuccess);
+    const double t_flush3 = host_now_us();
+    j->st.host_us_prepare = (uint32_t)(t_flush1 - t_flush0); j->st.host_us_upload = (uint32_t)(t_flush2 - t_flush1);
+    j->st.host_us_wait = (uint32_t)(t_flush3 - t_flush2);
 
     const char *dp = (const char *)j->dev[B_PARAM].p;
     const uint16_t *d_fwd = pr->lmcs ? (const uint16_t *)(dp + L.fwd) : nullptr;
@@ -750,6 +763,7 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
     }
     OV_HIP(ctx, hipEventRecord(j->ev_done, ctx->stream));
     j->flushed = 1;
+    j->st.host_us_launch = (uint32_t)(host_now_us() - t_flush3);
     return OVHIP_OK;
 }
 

@@ -211,7 +211,9 @@ decode_picture(struct run_state *rs, ovhip_frame *f, uint32_t idx, int job_locke
         out.mode = ((rs->flags & OVHIP_STREAM_DIGESTS) || s->cfg.output == OVHIP_OUT_DIGEST) ? OVHIP_OUT_DIGEST : OVHIP_OUT_NONE;
         out.window = s->cfg.window;
         if (tr) tr[1] = now_s() - rs->t0;
+        const double t_sub = now_s();
         r = ovhip_frame_submit(f, job, NULL, &pr, &out);
+        const double dt_sub = now_s() - t_sub;
         if (tr) tr[2] = now_s() - rs->t0;
         if (r != OVHIP_OK) { run_fail(rs, r, "ovhip_frame_submit", ovhip_frame_last_error(f)); goto out; }
         if (out.mode == OVHIP_OUT_DIGEST) {
@@ -226,6 +228,9 @@ decode_picture(struct run_state *rs, ovhip_frame *f, uint32_t idx, int job_locke
         if (ovhip_job_last_stats(job ? job : ovhip_frame_job(f), &st) == OVHIP_OK) {
             pthread_mutex_lock(&rs->mtx);
             rs->res->n_decoded++; rs->res->n_second_passes += st.n_ordered_retries;
+            const double ph[4] = { 1e-6 * st.host_us_prepare, 1e-6 * st.host_us_upload, 1e-6 * st.host_us_wait, 1e-6 * st.host_us_launch };
+            for (int k = 0; k < 4; ++k) rs->res->host_seconds[k] += ph[k];
+            rs->res->host_seconds[4] += dt_sub - ph[0] - ph[1] - ph[2] - ph[3];      /* ovhip_job_wait, publish, output */
             pthread_mutex_unlock(&rs->mtx);
         }
     }
