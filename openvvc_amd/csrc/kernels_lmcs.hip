@@ -16,7 +16,9 @@
 namespace {
 
 struct LmcsWnd { uint16_t bnd[17]; int min_idx, max_idx, crs_offset; };
+#ifndef LMCS_ROWS
 #define LMCS_ROWS 4
+#endif
 
 // Workgroups [0, n): one chroma-scale region each.  Workgroups beyond: rider -- the state words of the flow launch of the ordered
 // pass (k_intra_flow_prepare's work, four tasks per workgroup), when the picture has one: a launch of its own was 9 us of the
@@ -62,27 +64,53 @@ __global__ __launch_bounds__(64) void k_lmcs_scale(ovhip_pic pic, const ovhip_lm
 typedef uint32_t lm_u2 __attribute__((ext_vector_type(2), aligned(4)));
 
 // k_flow_untag's body (kernels_intra.hip) for the chroma blocks of the ordered tasks: rides in the inverse-mapping launch of a picture
-// whose ordered pass ran as flow launches (one kernel boundary less between the ordered pass and the deblocking filter)
+// whose ordered pass ran as flow launches (one kernel boundary less between the ordered pass and the deblocking filter).
+// One wave per task, four tasks per workgroup; a lane's loads of BOTH planes go out before anything is stored: with 16 lanes per task
+// and a load - and - store round trip per 64 samples and plane the rider was 8.6 of the launch's 16.7 us (the mapping alone: 8.0).
+#define UNTAG_TASKS_PER_WG 4
 __device__ __forceinline__ void untag_chroma_tasks(const ovhip_pic &pic, const ovhip_itask *__restrict__ tasks, uint32_t n, uint32_t wg)
 {
-    const uint32_t ti = wg * 16 + (threadIdx.x >> 4);
+    const uint32_t ti = wg * UNTAG_TASKS_PER_WG + (threadIdx.x >> 6);
     if (ti >= n) return;
     const ovhip_itask t = tasks[ti];
     if (t.kind == OVHIP_IT_REGION || t.kind == OVHIP_IT_LUMA) return;          // (the mapping itself drops the bit of every luma sample)
-    const int lane = threadIdx.x & 15;
+    const int lane = threadIdx.x & 63;
     const int l2w = t.log2_w, w = 1 << l2w, npx = w << t.log2_h, stride = pic.stride_c;
-    for (int c = 0; c < 2; ++c) {
-        if (t.kind == OVHIP_IT_RES_C && !(t.flags & (c ? OVHIP_IF_RES_CR : OVHIP_IF_RES_CB))) continue;
-        uint16_t *dst = (c ? pic.cr : pic.cb) + t.y * stride + t.x;
-        if (w >= 4) {
-            for (int p = 4 * lane; p < npx; p += 64) {
-                lm_u2 *q = reinterpret_cast<lm_u2 *>(dst + (p >> l2w) * stride + (p & (w - 1)));
-                lm_u2 v = *q; v[0] &= 0x03ff03ffu; v[1] &= 0x03ff03ffu; *q = v;
+    const bool res_only = t.kind == OVHIP_IT_RES_C;
+    const bool on0 = !res_only || (t.flags & OVHIP_IF_RES_CB), on1 = !res_only || (t.flags & OVHIP_IF_RES_CR);
+    uint16_t *const d0 = pic.cb + t.y * stride + t.x, *const d1 = pic.cr + t.y * stride + t.x;
+    if (w >= 4) {
+        for (int base = 0; base < npx; base += 1024) {
+            lm_u2 v0[4], v1[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int p = base + 4 * lane + 256 * k;
+                const int o = (p >> l2w) * stride + (p & (w - 1));
+                if (p < npx && on0) v0[k] = *reinterpret_cast<const lm_u2 *>(d0 + o);
+                if (p < npx && on1) v1[k] = *reinterpret_cast<const lm_u2 *>(d1 + o);
             }
-        } else if (w == 2) {
-            for (int p = 2 * lane; p < npx; p += 32) *reinterpret_cast<uint32_t *>(dst + (p >> l2w) * stride + (p & (w - 1))) &= 0x03ff03ffu;
-        } else {
-            for (int p = lane; p < npx; p += 16) { uint16_t *q = dst + (p >> l2w) * stride + (p & (w - 1)); *q = *q & 0x3ff; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int p = base + 4 * lane + 256 * k;
+                const int o = (p >> l2w) * stride + (p & (w - 1));
+                if (p < npx && on0) { lm_u2 v = v0[k]; v[0] &= 0x03ff03ffu; v[1] &= 0x03ff03ffu; *reinterpret_cast<lm_u2 *>(d0 + o) = v; }
+                if (p < npx && on1) { lm_u2 v = v1[k]; v[0] &= 0x03ff03ffu; v[1] &= 0x03ff03ffu; *reinterpret_cast<lm_u2 *>(d1 + o) = v; }
+            }
+        }
+    } else if (w == 2) {
+        for (int p = 2 * lane; p < npx; p += 128) {
+            const int o = (p >> l2w) * stride + (p & (w - 1));
+            uint32_t a = 0, b = 0;
+            if (on0) a = *reinterpret_cast<const uint32_t *>(d0 + o);
+            if (on1) b = *reinterpret_cast<const uint32_t *>(d1 + o);
+            if (on0) *reinterpret_cast<uint32_t *>(d0 + o) = a & 0x03ff03ffu;
+            if (on1) *reinterpret_cast<uint32_t *>(d1 + o) = b & 0x03ff03ffu;
+        }
+    } else {
+        for (int p = lane; p < npx; p += 64) {
+            const int o = (p >> l2w) * stride + (p & (w - 1));
+            if (on0) d0[o] = d0[o] & 0x3ff;
+            if (on1) d1[o] = d1[o] & 0x3ff;
         }
     }
 }
@@ -91,7 +119,11 @@ __device__ __forceinline__ void untag_chroma_tasks(const ovhip_pic &pic, const o
 __global__ __launch_bounds__(256) void k_lmcs_inverse(ovhip_pic pic, const uint16_t *__restrict__ lut, uint32_t rows_y,
                                                       const ovhip_itask *__restrict__ tasks, uint32_t n_tasks)
 {
-    if (blockIdx.y >= rows_y) { untag_chroma_tasks(pic, tasks, n_tasks, (blockIdx.y - rows_y) * gridDim.x + blockIdx.x); return; }
+    // the un-tag workgroups come FIRST in the grid: they are short read-modify-writes of scattered chroma blocks (latency), and
+    // started last they were the tail of the launch behind the streaming part
+    const uint32_t untag_y = gridDim.y - rows_y;
+    if (blockIdx.y < untag_y) { untag_chroma_tasks(pic, tasks, n_tasks, blockIdx.y * gridDim.x + blockIdx.x); return; }
+    const uint32_t by = blockIdx.y - untag_y;
 
     __shared__ uint16_t s_lut[1024];
     const int nvx = pic.w >> 3;                               // full 8-sample vectors per row
@@ -100,7 +132,7 @@ __global__ __launch_bounds__(256) void k_lmcs_inverse(ovhip_pic pic, const uint1
     // lane's vectors of its FIRST row group are requested before the table is staged: the two round trips (table, samples) overlap
     // instead of following each other behind the barrier (20 -> see DESIGN 4 us per 4K picture, where this launch stands alone behind
     // the ordered pass)
-    const int y00 = blockIdx.y * LMCS_ROWS, v00 = blockIdx.x * 256 + threadIdx.x;
+    const int y00 = (int)by * LMCS_ROWS, v00 = blockIdx.x * 256 + threadIdx.x;
     uint4 q0[LMCS_ROWS];
     const bool first = y00 < pic.h && v00 < nvx;
     if (first) {
@@ -182,7 +214,7 @@ static int lmcs_inverse_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const uint1
     const int nvx = pic->w >> 3;
     const int row_groups = (pic->h + LMCS_ROWS - 1) / LMCS_ROWS;
     const uint32_t gx = (nvx + 255) / 256 > 0 ? (nvx + 255) / 256 : 1, rows_y = row_groups < 4096 ? row_groups : 4096;
-    const uint32_t untag_wgs = d_tasks ? (n_tasks + 15) / 16 : 0;
+    const uint32_t untag_wgs = d_tasks ? (n_tasks + UNTAG_TASKS_PER_WG - 1) / UNTAG_TASKS_PER_WG : 0;
     hipLaunchKernelGGL(k_lmcs_inverse, dim3(gx, rows_y + (untag_wgs + gx - 1) / gx), dim3(256), 0, ctx->stream, *pic, d_bwd_lut, rows_y, d_tasks, d_tasks ? n_tasks : 0u);
     OV_LAUNCH_CHECK(ctx, who);
     return OVHIP_OK;
