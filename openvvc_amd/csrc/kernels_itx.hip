@@ -141,10 +141,10 @@ typedef short short2v __attribute__((ext_vector_type(2)));
 // for i < lines, j < n; both operands are k-contiguous (kmax is rounded up to 4: the operands are zero there).
 // Lane = one output.  FINAL = false: store int16 to dst[j * dstride + i] (pass 1: the transposed tile pass 2
 // reads).  FINAL = true: fuse K4, the residual add into the frame (pass 2: lanes j -> contiguous frame addresses).
-template <bool FINAL, int NT>
-__device__ __forceinline__ void tr_pass_lds(const int16_t *src, int sstride, const int16_t *core, int cstride, int log2n,
-                                             int kmax, int lines, int shift, int16_t *dst, int dstride, int lane,
-                                             const ResidualSink &sink)
+template <bool FINAL, int NT, int NK4>
+__device__ __forceinline__ void tr_pass_lds_n(const int16_t *src, int sstride, const int16_t *core, int cstride, int log2n,
+                                               int kmax, int lines, int shift, int16_t *dst, int dstride, int lane,
+                                               const ResidualSink &sink)
 {
     const int n = 1 << log2n;
     const int ntask = lines << log2n;
@@ -161,6 +161,18 @@ __device__ __forceinline__ void tr_pass_lds(const int16_t *src, int sstride, con
         const int2 *sp = reinterpret_cast<const int2 *>(src + i * sstride);
         const int2 *cp = reinterpret_cast<const int2 *>(core + j * cstride);
         int acc = 0;
+        if (NK4 > 0) {
+            // the common lengths with the loop gone: all operand reads in flight, then the dot products (the loop's counter, compare
+            // and branch were as many scalar instructions as the loop had vector ones)
+            int2 a[NK4 > 0 ? NK4 : 1], m[NK4 > 0 ? NK4 : 1];
+#pragma unroll
+            for (int k4 = 0; k4 < NK4; ++k4) { a[k4] = sp[k4]; m[k4] = cp[k4]; }
+#pragma unroll
+            for (int k4 = 0; k4 < NK4; ++k4) {
+                acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a[k4].x), __builtin_bit_cast(short2v, m[k4].x), acc, false);
+                acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a[k4].y), __builtin_bit_cast(short2v, m[k4].y), acc, false);
+            }
+        } else
         for (int k4 = 0; k4 < nk4; ++k4) {
             const int2 a = sp[k4], m = cp[k4];
             acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a.x), __builtin_bit_cast(short2v, m.x), acc, false);
@@ -174,6 +186,19 @@ __device__ __forceinline__ void tr_pass_lds(const int16_t *src, int sstride, con
             if (sink.dst2) sink.dst2[i * sink.stride2 + j] = (uint16_t)residual1(old2, r, sink.mode2, sink.scale);
         }
     }
+}
+
+template <bool FINAL, int NT>
+__device__ __forceinline__ void tr_pass_lds(const int16_t *src, int sstride, const int16_t *core, int cstride, int log2n,
+                                             int kmax, int lines, int shift, int16_t *dst, int dstride, int lane,
+                                             const ResidualSink &sink)
+{
+    // kmax is wave-uniform (a field of the command / the block's significance map)
+    const int nk4 = (kmax + 3) >> 2;
+    if (nk4 == 1)      tr_pass_lds_n<FINAL, NT, 1>(src, sstride, core, cstride, log2n, kmax, lines, shift, dst, dstride, lane, sink);
+    else if (nk4 == 2) tr_pass_lds_n<FINAL, NT, 2>(src, sstride, core, cstride, log2n, kmax, lines, shift, dst, dstride, lane, sink);
+    else if (nk4 == 4) tr_pass_lds_n<FINAL, NT, 4>(src, sstride, core, cstride, log2n, kmax, lines, shift, dst, dstride, lane, sink);
+    else               tr_pass_lds_n<FINAL, NT, 0>(src, sstride, core, cstride, log2n, kmax, lines, shift, dst, dstride, lane, sink);
 }
 
 // Rider of the chroma launch: inverse LMCS mapping of the luma plane (rcn_lmcs_reshape_backward, rcn_lmcs.c:219-231) by

@@ -1,4 +1,4 @@
-for v in "-DLMCS_NOUNTAG" ""; do
-  touch openvvc_amd/csrc/kernels_lmcs.hip; make -C openvvc_amd/csrc -j16 EXTRA="$v" > /dev/null 2>&1 || { echo build failed; continue; }
-  echo "== $v"; bash tools/kbench_trace.sh kbv 2>&1 | grep -E "k_lmcs_inverse"
+for v in 0 1 2 3; do
+  export OVHIP_ITX_ABLATE=$v
+  echo "== ablate $v"; bash tools/kbench_trace.sh kbv 2>&1 | grep -E "k_itx_all"
 done
