@@ -767,14 +767,16 @@ int  ovhip_intra_ctu_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_pi
  * helper; 0 = the picture cannot take this path).  d_state: ovhip_intra_flow_words() words of device memory zeroed once;
  * epoch, abort_mirror and the bounded waits as for ovhip_intra_ctu_launch (d_state[0] = abort word).  The items may be launched
  * in several calls (consecutive ranges that end on level boundaries, same epoch): prepare != 0 only on the first, which marks the
- * units of ALL n_tasks tasks.  Fewer workgroups resident and polling at a time leave LDS and issue slots to the kernels of the
- * other pictures in flight: wg_per_cu (3..16; 0 = as many as fit) caps the workgroups of this launch a compute unit holds. */
+ * units of ALL n_tasks tasks.  n_workers: the launch has that many workgroups and workgroup b takes the items b, b + n_workers, ...
+ * in turn -- the bound on the pollers of this launch (wave slots the kernels of the other pictures in flight do not get, and what
+ * has to fit the device beside the other flow launches for the forward-progress argument to hold); 0 or >= n_items: one workgroup
+ * per item. */
 size_t ovhip_intra_flow_words(int32_t width, int32_t height);
 size_t ovhip_intra_flow_items(const ovhip_itask *sorted, size_t n, uint32_t *items, size_t cap);
 int  ovhip_intra_flow_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_pic *res, const ovhip_itask *d_tasks, uint32_t n_tasks,
                              const uint32_t *d_items, uint32_t n_items, const ovhip_lmcs_region *d_regions, const ovhip_lmcs_luts *luts,
                              int16_t *d_scales, int32_t log2_ctu_s, uint32_t *d_state, uint32_t epoch, uint32_t *abort_mirror, int32_t prepare,
-                             int32_t wg_per_cu);
+                             int32_t n_workers);
 /* The flow launch hands samples from task to task with bit 15 set (kernels_intra.hip, FLOW_TAG).  This clears it in the blocks the
  * ordered tasks wrote: after the picture's flow launches, before anything else reads the picture.  with_luma == 0: chroma blocks
  * only -- ovhip_lmcs_inverse_launch drops the bit of every luma sample as a side effect of its table lookup.
@@ -929,8 +931,8 @@ int  ovhip_job_stage_time(ovhip_job *job, double *sum_ms, uint64_t *count);
  * Digest: the reference's CI hashes the output FILE (CI/checkMD5.sh, md5sum); MD5 is a serial chain, so a whole frame
  * cannot be hashed by more than one lane, and a frame per lane of the host is ~40 ms at 4K.  Two things are offered instead:
  *   ovhip_pic_digest()           a per-picture FINGERPRINT, computed on the device, 16 bytes leaving it: a three-level MD5 tree over
- *                                the cropped frame -- leaf = MD5 of each 1024-byte piece of a cropped row (the last piece of a row
- *                                shorter), row = MD5 of the row's leaf digests, band = MD5 of the digests of 32 consecutive rows of
+ *                                the cropped frame -- leaf = MD5 of each 512-byte piece of a cropped row (the last piece of a row
+ *                                shorter), row = MD5 of the row's leaf digests, band = MD5 of the digests of 8 consecutive rows of
  *                                one plane (the last band of a plane shorter), picture = MD5 of the band digests in the order Y, Cb,
  *                                Cr (that last step on the host).  Any host can recompute it from the written file with hashlib
  *                                (oracle/ovvc_oracle_output.py: picture_digest); it is NOT the md5sum of the frame.

@@ -595,7 +595,7 @@ __device__ u64 *g_probe;
 // the same switch stamps the phases of every item of the flow launch (tools/debug/flow_probe.py): 8 stamps per item
 #ifdef OVHIP_CTU_PROBE
 __device__ const uint32_t *g_probe_items;      // the picture's first item: launches of later chunks index the stamps from it
-#define FPROBE(k) do { if (lane == 0 && g_probe) g_probe[(size_t)(items + blockIdx.x - g_probe_items) * 8 + (k)] = wall_clock64(); } while (0)
+#define FPROBE(k) do { if (lane == 0 && g_probe) g_probe[(size_t)(items + bid - g_probe_items) * 8 + (k)] = wall_clock64(); } while (0)
 #else
 #define FPROBE(k) do { } while (0)
 #endif
@@ -960,7 +960,15 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
     __builtin_amdgcn_s_setprio(OVHIP_FLOW_PRIO);
     const int lane = threadIdx.x;
     load_tables(s, lane);
-    const uint32_t item = items[blockIdx.x];
+    // The workgroups of the launch are WORKERS: worker b takes the items b, b + W, b + 2 W, ... (W = gridDim.x) in ascending order.
+    // An item waits only for items of lower index, so the lowest unfinished item always belongs to a worker that is working on it or
+    // will be once it is resident: no deadlock as long as the W workers of a launch all become resident, which they do when the
+    // launches in flight ask for fewer wave slots than the device has -- W is the bound on this launch's pollers (r2 launched one
+    // workgroup per item: the device filled with the pollers of levels far ahead, which starved the kernels of the other pictures and
+    // each other; r3 first capped them with LDS they did not use, which took that LDS from everybody else).
+    for (uint32_t bid = blockIdx.x; bid < n_items; bid += gridDim.x) {
+    if (bid != blockIdx.x) wave_sync();                    // the tiles of the item before are dead
+    const uint32_t item = items[bid];
     const ovhip_itask t = tasks[item & 0xffffff];
     const int strip = (item >> 24) & 0x1f, comp = (item >> 29) & 1;
     const int l2w = t.log2_w, w = 1 << l2w, h = 1 << t.log2_h, npx = w * h;
@@ -970,7 +978,7 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
     const int w4 = fs.w4;
     Strip st; st.p0 = strip * FSTRIP; st.p1 = min(npx, st.p0 + FSTRIP);
     const bool has_res = t.flags & (luma ? OVHIP_IF_RES_Y : (comp ? OVHIP_IF_RES_CR : OVHIP_IF_RES_CB));
-    if (res_only && !has_res) return;
+    if (res_only && !has_res) continue;
 
     // ---- what does not depend on the other ordered tasks (residual, inter prediction): requested before the wait ----
     uint16_t *pl = luma ? pic.y : (comp ? pic.cr : pic.cb);
@@ -1087,7 +1095,7 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(fs.reg + t.c_scale, pending + 1, RLX_AGENT);
         }
-        return;
+        continue;
     }
     const bool scaled = !luma && (t.flags & OVHIP_IF_RES_SCALE);
     // (the derived scale is requested here and first looked at in the epilogue: no wait in front of the reference fetch)
@@ -1204,6 +1212,7 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
         for (int i = lane; i < nx * ny; i += 64) __hip_atomic_store(fb + (uy0 + (i >> l2nx)) * w4 + ux0 + (i & (nx - 1)), pending + 1, RLX_AGENT);
     }
     FPROBE(7);
+    }   // next item of this worker
 }
 
 } // namespace
@@ -1314,7 +1323,7 @@ extern "C" size_t ovhip_intra_flow_words(int32_t width, int32_t height)
 extern "C" int ovhip_intra_flow_launch(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhip_pic *res, const ovhip_itask *d_tasks, uint32_t n_tasks,
                                        const uint32_t *d_items, uint32_t n_items, const ovhip_lmcs_region *d_regions, const ovhip_lmcs_luts *luts,
                                        int16_t *d_scales, int32_t log2_ctu_s, uint32_t *d_state, uint32_t epoch, uint32_t *abort_mirror, int32_t prepare,
-                                       int32_t wg_per_cu)
+                                       int32_t n_workers)
 {
     if (!ctx || !pic || !res) return OVHIP_EINVAL;
     OV_DEVICE(ctx);
@@ -1333,26 +1342,9 @@ extern "C" int ovhip_intra_flow_launch(ovhip_ctx *ctx, const ovhip_pic *pic, con
     if (hipMemcpyToSymbolAsync(HIP_SYMBOL(g_probe_items), &d_items, sizeof(d_items), 0, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return OVHIP_ELAUNCH;
 #endif
     const int nap = 0;          // poll back-off variant: 0 = s_sleep 4 between polls (16 the same; 64 and exponential back-off measured 6 % slower)
-    // Residency cap: a workgroup of this kernel that waits for its inputs sits on its compute unit, polling.  A picture whose ordered
-    // pass is a long thin chain (an I picture: ~2100 levels of ~50 items) needs a few hundred of them resident, not the ~4400 the
-    // device takes -- which leave the other pictures in flight no LDS and no wave slots (a k_alf beside an I picture's pass: 1-2 ms
-    // instead of 46 us).  Unused dynamic LDS is the lever: wg_per_cu workgroups of this launch fit a compute unit's 160 KB.
-    size_t dyn = 0;
-    if (wg_per_cu > 0 && wg_per_cu < 17) {
-        const size_t per_wg = (160u << 10) / (size_t)wg_per_cu, fixed = sizeof(FlowLds) + 1024;
-        dyn = per_wg > fixed ? per_wg - fixed : 0;
-        dyn &= ~(size_t)511;
-        if (dyn + fixed > (64u << 10)) {
-            // more than the default limit of one workgroup: opt in once (gfx950: 160 KB of LDS per compute unit, all of it allocatable)
-            static int opted = 0;
-            if (!opted) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_intra_flow), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((160u << 10) - fixed)) == hipSuccess) opted = 1;
-                else { opted = -1; (void)hipGetLastError(); }
-            }
-            if (opted < 0) dyn = ((64u << 10) - fixed) & ~(size_t)511;
-        }
-    }
-    hipLaunchKernelGGL(k_intra_flow, dim3(n_items), dim3(64), dyn, ctx->stream, *pic, *res, d_tasks, d_items, n_items, d_regions, wnd, d_scales, log2_ctu_s, fs,
+    // n_workers workgroups take the items in turn (k_intra_flow); 0 or >= n_items: one workgroup per item
+    const uint32_t grid = (n_workers > 0 && (uint32_t)n_workers < n_items) ? (uint32_t)n_workers : n_items;
+    hipLaunchKernelGGL(k_intra_flow, dim3(grid), dim3(64), 0, ctx->stream, *pic, *res, d_tasks, d_items, n_items, d_regions, wnd, d_scales, log2_ctu_s, fs,
                        epoch, d_state, abort_mirror, nap);
     OV_LAUNCH_CHECK(ctx, "k_intra_flow");
     return OVHIP_OK;

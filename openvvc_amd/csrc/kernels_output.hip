@@ -152,13 +152,16 @@ __global__ __launch_bounds__(64) void k_output_row_md5(OutGeom g, uint8_t *__res
 }
 
 // The picture's fingerprint as a three-level MD5 tree (include/ovvc_hip.h, "Digest"): MD5 is a serial chain, a whole row per lane is
-// 120 chained blocks at 4K (the one-lane-per-row kernel above takes ~200 us, on every picture's stream).  Leaves = the 1024-byte
-// pieces of every cropped row (16 blocks), then one digest per row over its pieces' digests, then one per band of 32 rows: a
-// 256-thread workgroup per band does all three levels through LDS.  The host hashes the band digests (2 KB at 4K).
-#define DG_SEG   512          /* samples per leaf (1024 bytes) */
-#define DG_BAND  32           /* rows per band                  */
-#define DG_MAXSEG 32          /* leaves per row: rows up to 16384 samples */
-__global__ __launch_bounds__(256) void k_output_tree_md5(OutGeom g, uint32_t nb0, uint32_t nb1, uint8_t *__restrict__ digests)
+// 120 chained blocks at 4K (the one-lane-per-row kernel above takes ~200 us, on every picture's stream).  Leaves = the 512-byte
+// pieces of every cropped row (8 + 1 blocks), then one digest per row over its pieces' digests (4 blocks at 4K), then one per band of
+// 8 rows (3 blocks): a 128-thread workgroup per band does all three levels through LDS -- 16 chained blocks and 540 workgroups at
+// 4K (the first shape, 1024-byte leaves and bands of 32 rows: 28 chained blocks, 136 workgroups on 256 compute units).  The host
+// hashes the band digests (8.6 KB at 4K).
+#define DG_SEG   256          /* samples per leaf (512 bytes)  */
+#define DG_BAND  8            /* rows per band                  */
+#define DG_MAXSEG 64          /* leaves per row: rows up to 16384 samples */
+#define DG_NT    128
+__global__ __launch_bounds__(DG_NT) void k_output_tree_md5(OutGeom g, uint32_t nb0, uint32_t nb1, uint8_t *__restrict__ digests)
 {
     __shared__ uint32_t s_d0[DG_BAND * DG_MAXSEG * 4];
     __shared__ uint32_t s_d1[DG_BAND * 4];
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(256) void k_output_tree_md5(OutGeom g, uint32_t nb0
     const int r0 = (int)(band - (c == 2 ? nb0 + nb1 : (c == 1 ? nb0 : 0))) * DG_BAND;
     const int nrows = min(DG_BAND, g.h[c] - r0), w = g.w[c], nseg = (w + DG_SEG - 1) / DG_SEG;
     const int tid = threadIdx.x;
-    for (int i = tid; i < nrows * nseg; i += 256) {
+    for (int i = tid; i < nrows * nseg; i += DG_NT) {
         const int r = i / nseg, k = i - r * nseg;
         uint32_t h[4];
         md5_samples(g.src[c] + (size_t)(r0 + r) * g.stride[c] + k * DG_SEG, min(DG_SEG, w - k * DG_SEG), h);
@@ -262,7 +265,7 @@ extern "C" int ovhip_output_tree_md5_launch(ovhip_ctx *ctx, const ovhip_pic *pic
         || g.w[0] > DG_SEG * DG_MAXSEG)
         return ov_fail(ctx, OVHIP_EINVAL, "ovhip_output_tree_md5_launch: bad picture / window", hipSuccess);
     const uint32_t nb0 = (uint32_t)((g.h[0] + DG_BAND - 1) / DG_BAND), nb1 = (uint32_t)((g.h[1] + DG_BAND - 1) / DG_BAND);
-    hipLaunchKernelGGL(k_output_tree_md5, dim3(nb0 + 2 * nb1), dim3(256), 0, ctx->stream, g, nb0, nb1, d_digests);
+    hipLaunchKernelGGL(k_output_tree_md5, dim3(nb0 + 2 * nb1), dim3(DG_NT), 0, ctx->stream, g, nb0, nb1, d_digests);
     OV_LAUNCH_CHECK(ctx, "k_output_tree_md5");
     return OVHIP_OK;
 }

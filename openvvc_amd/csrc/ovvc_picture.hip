@@ -684,25 +684,19 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
             j->st.n_launches++;
         }
         if (by_flow && n_items) {
-            // in chunks of whole levels, at least FLOW_CHUNK items each.  The workgroups of a launch are resident and polling while
-            // they wait, each holding 9 KB of LDS the other pictures' kernels then do not get; a chunk bounds what ONE launch can
-            // pile up, but every chunk boundary is a drain of the dependency front and a launch on the picture's chain (measured
-            // at 4K, 16 pictures in flight, flag hand-over: 1024 items 1724 pictures/s, 2048 1856, 4096 1896, 8192 1937, one launch
-            // 1943; tagged hand-over: 8192 2617, 16384 2676, 32768 2709 -- a B picture is one launch, an I picture four)
-            // (OVHIP_FLOW_CHUNK: tuning knob, read once)
-            static const size_t FLOW_CHUNK = getenv("OVHIP_FLOW_CHUNK") && atol(getenv("OVHIP_FLOW_CHUNK")) > 0 ? (size_t)atol(getenv("OVHIP_FLOW_CHUNK")) : 32768;
-            // how many workgroups of the launch a compute unit may hold (ovhip_intra_flow_launch): a few levels' worth of items resident is
-            // all the chain can use; a B picture's wide levels get everything (measured on the stream of bench.py, 16 in flight, I pictures
-            // started early: no cap 2847 - 2925, 8 levels' worth 2907 - 3460 pictures/s).  Never fewer than 3 per compute unit: a workgroup
-            // that asks for more than a third of the LDS finds no compute unit to start on while the other pictures' kernels hold theirs
-            // (1 per compute unit: the resident items' bounded waits expire, 30 - 60 second passes per run)
-            int wg_per_cu = 0;
-            {
-                static const long CAP = getenv("OVHIP_FLOW_RESIDENT") ? atol(getenv("OVHIP_FLOW_RESIDENT")) : 8;      // levels' worth; 0: no cap
-                const size_t width = n_items / (n_lv ? n_lv : 1) + 1;
-                const size_t want = CAP > 0 ? (size_t)CAP * width : 0;
-                if (want) { const size_t per_cu = (want + (size_t)ctx->num_cus - 1) / (size_t)ctx->num_cus; wg_per_cu = per_cu < 3 ? 3 : (per_cu >= 17 ? 0 : (int)per_cu); }
-            }
+            // ONE launch of W persistent workers (k_intra_flow): worker b takes the items b, b + W, ... in level order.  W bounds the
+            // pollers of the launch, and the launches in flight together must fit the device for the forward-progress argument (an item
+            // waits only for lower items; the lowest unfinished item's worker is resident or will be): the kernel holds 109 VGPRs = 16
+            // waves per compute unit, HIP runs the process's streams on 4 hardware queues, so W = 16 CUs / 4 = 1024 on MI355X.
+            // Measured on the stream of bench.py (pictures/s, second passes): one workgroup per item 2834-2890 / 0 (the device full of
+            // the pollers of levels far ahead); W = 512 3280-3320 / 0; 1024 3353-3490 / 0; 2048 1561 / 9; 4096 35 / 1168 -- above
+            // the bound the launches starve each other, exactly as the argument says.  Alone, a B picture's wide levels want more
+            // workers (its pass: 104 us with a workgroup per item, 156 with 1024 workers, 229 with 512); beside other pictures that
+            // does not show.  GPU_MAX_HW_QUEUES = 8 with W = 512: 3000-3060 / 0, no gain.  (OVHIP_FLOW_WORKERS, OVHIP_FLOW_CHUNK:
+            // tuning knobs, read once; chunked launches -- whole levels per launch -- remain for ovhip_job_params.flow_chunk_items)
+            static const size_t FLOW_CHUNK = getenv("OVHIP_FLOW_CHUNK") && atol(getenv("OVHIP_FLOW_CHUNK")) > 0 ? (size_t)atol(getenv("OVHIP_FLOW_CHUNK")) : ((size_t)1 << 30);
+            static const long WORKERS = getenv("OVHIP_FLOW_WORKERS") ? atol(getenv("OVHIP_FLOW_WORKERS")) : -1;
+            const int n_workers = WORKERS >= 0 ? (int)WORKERS : 4 * ctx->num_cus;
             size_t a = 0;
             int first = !flow_prepared;
             const size_t chunk = pr->flow_chunk_items ? pr->flow_chunk_items : FLOW_CHUNK;
@@ -711,7 +705,7 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
                 while (b < n_items && it[j->items_host[b] & 0xffffff].level == it[j->items_host[b - 1] & 0xffffff].level) ++b;
                 CHK(ovhip_intra_flow_launch(ctx, dst, &j->res, d_it, (uint32_t)n_it, (const uint32_t *)j->dev[B_IITEM].p + a, (uint32_t)(b - a),
                                             (const ovhip_lmcs_region *)DEV(B_REG), pr->lmcs, (int16_t *)j->dev[B_SCALE].p, log2_ctu, j->d_flow, j->epoch,
-                                            j->abort_host, first, wg_per_cu));
+                                            j->abort_host, first, n_workers));
                 j->st.n_launches += 1 + first;
                 first = 0;
                 a = b;

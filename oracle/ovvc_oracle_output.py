@@ -36,13 +36,13 @@ def row_digests(y, cb, cr, window=(0, 0, 0, 0)) -> np.ndarray:
 
 
 def picture_digest(y, cb, cr, window=(0, 0, 0, 0)) -> bytes:
-    """the library's per-picture fingerprint (include/ovvc_hip.h, "Digest"): leaf = MD5 of each 1024-byte piece of a cropped row,
-    row = MD5 of its leaf digests, band = MD5 of the digests of 32 consecutive rows of a plane, picture = MD5 of the band digests"""
+    """the library's per-picture fingerprint (include/ovvc_hip.h, "Digest"): leaf = MD5 of each 512-byte piece of a cropped row,
+    row = MD5 of its leaf digests, band = MD5 of the digests of 8 consecutive rows of a plane, picture = MD5 of the band digests"""
     bands = []
     for p in cropped_planes(y, cb, cr, window):
         rows = []
         for row in p:
             b = np.ascontiguousarray(row, dtype="<u2").tobytes()
-            rows.append(hashlib.md5(b"".join(hashlib.md5(b[o:o + 1024]).digest() for o in range(0, len(b), 1024))).digest())
-        bands += [hashlib.md5(b"".join(rows[o:o + 32])).digest() for o in range(0, len(rows), 32)]
+            rows.append(hashlib.md5(b"".join(hashlib.md5(b[o:o + 512]).digest() for o in range(0, len(b), 512))).digest())
+        bands += [hashlib.md5(b"".join(rows[o:o + 8])).digest() for o in range(0, len(rows), 8)]
     return hashlib.md5(b"".join(bands)).digest()
