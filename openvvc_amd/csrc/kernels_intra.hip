@@ -573,6 +573,9 @@ __global__ __launch_bounds__(64) void k_intra_level(ovhip_pic pic, ovhip_pic res
 #define CT_CS    (4 + CT_S / 2)
 #define CT_CHUNK 128                        // tasks staged in LDS at a time
 #define SYNC_FLAGS OVHIP_FLOW_SYNC_WORDS     // sync[0] = abort code; flags from word 16
+#ifndef FLOW_POLL_GAP
+#define FLOW_POLL_GAP 3                    // s_sleep units (64 clocks) between the two polls a waiting item keeps in flight
+#endif
 #define SPIN_LIMIT (1u << 17)              // polls before a workgroup gives up (>= 40 ms; a legitimate wait is a few ms): ovhip_job_wait then decodes the picture per level
 
 struct CtuLds {
@@ -595,9 +598,15 @@ __device__ u64 *g_probe;
 // the same switch stamps the phases of every item of the flow launch (tools/debug/flow_probe.py): 8 stamps per item
 #ifdef OVHIP_CTU_PROBE
 __device__ const uint32_t *g_probe_items;      // the picture's first item: launches of later chunks index the stamps from it
-#define FPROBE(k) do { if (lane == 0 && g_probe) g_probe[(size_t)(items + bid - g_probe_items) * 8 + (k)] = wall_clock64(); } while (0)
+// stamps are kept in registers and written once, behind the item's last one: a store per stamp (with the two loads of its
+// address) put ~0.2 us of probe into every phase it closed
+#define FPROBE(k) do { fprobe_[k] = wall_clock64(); \
+                       if ((k) == 7 && lane == 0 && g_probe) { u64 *o_ = g_probe + (size_t)(items + bid - g_probe_items) * 8; \
+                                                                for (int q_ = 0; q_ < 8; ++q_) o_[q_] = fprobe_[q_]; } } while (0)
+#define FPROBE_DECL u64 fprobe_[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }
 #else
 #define FPROBE(k) do { } while (0)
+#define FPROBE_DECL do { } while (0)
 #endif
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
@@ -869,18 +878,39 @@ __device__ __forceinline__ bool fetch_refs_tagged(IntraLds &s, const uint16_t *p
             expect[2 * i] = (__hip_atomic_load(state + (ay >> l2u) * w4 + (ax >> l2u), RLX_AGENT) >> 1) == epoch;
             expect[2 * i + 1] = (__hip_atomic_load(state + (ly >> l2u) * w4 + (lx >> l2u), RLX_AGENT) >> 1) == epoch;
         }
+        // Two polls in flight, half a round trip apart (loads return in order: waiting for the older one leaves the younger in flight):
+        // a poll completes every ~0.3 us instead of every round trip + nap (~0.65 us), so a producer's store is seen ~0.15 us after it
+        // lands instead of ~0.33 -- on every hop of the chain.  Every poll re-reads all six samples (a tagged sample stays tagged).
+        auto missing = [&](const int *q) { bool m = false;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) v[i] = __hip_atomic_load(src[i], RLX_AGENT);
+                                           for (int i = 0; i < 6; ++i) m |= expect[i] && !(q[i] & FLOW_TAG);
+                                           return __any(m); };
+        int va[6], vb[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) va[i] = __hip_atomic_load(src[i], RLX_AGENT);
+        __builtin_amdgcn_s_sleep(FLOW_POLL_GAP);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) vb[i] = __hip_atomic_load(src[i], RLX_AGENT);
         unsigned spins = 0;
+        // (a ring of N polls written as a loop over arrays measured slower than this -- 2.55 us per level with two, 2.81 with three, 3.09
+        // with four against 2.32: every generation still in flight when the samples arrive is waited for by whatever needs its registers)
         for (;;) {
-            bool miss = false;
+            if (!missing(va)) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) miss |= expect[i] && !(v[i] & FLOW_TAG);
-            if (!__any(miss)) break;
-            if (__any(++spins > SPIN_LIMIT || __hip_atomic_load(sync, RLX_AGENT) != 0)) { ok = false; break; }
-            __builtin_amdgcn_s_sleep(4);
+                for (int i = 0; i < 6; ++i) v[i] = va[i];
+                break;
+            }
+            const unsigned stop = __hip_atomic_load(sync, RLX_AGENT);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) if (expect[i] && !(v[i] & FLOW_TAG)) v[i] = __hip_atomic_load(src[i], RLX_AGENT);
+            for (int i = 0; i < 6; ++i) va[i] = __hip_atomic_load(src[i], RLX_AGENT);              // (behind the poll in vb)
+            if (!missing(vb)) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) v[i] = vb[i];                                          // (the poll in va is left to arrive)
+                break;
+            }
+            if (__any(++spins > SPIN_LIMIT || stop != 0)) { ok = false; break; }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) vb[i] = __hip_atomic_load(src[i], RLX_AGENT);              // (behind the poll in va)
         }
     }
 #pragma unroll
@@ -968,6 +998,7 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
     // each other; r3 first capped them with LDS they did not use, which took that LDS from everybody else).
     for (uint32_t bid = blockIdx.x; bid < n_items; bid += gridDim.x) {
     if (bid != blockIdx.x) wave_sync();                    // the tiles of the item before are dead
+    FPROBE_DECL;
     const uint32_t item = items[bid];
     const ovhip_itask t = tasks[item & 0xffffff];
     const int strip = (item >> 24) & 0x1f, comp = (item >> 29) & 1;
@@ -1069,12 +1100,17 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
         for (int i = lane; i < nfp; i += 64) {
             unsigned *f = L.fp[i];
             unsigned spins = 0;
-            while (__hip_atomic_load(f, RLX_AGENT) == pending) {
-                if (++spins > SPIN_LIMIT || __hip_atomic_load(sync, RLX_AGENT) != 0) { ok = false; break; }
+            unsigned cur = __hip_atomic_load(f, RLX_AGENT);
+            while (cur == pending) {
+                if (++spins > SPIN_LIMIT) { ok = false; break; }
                 if (nap == 0) __builtin_amdgcn_s_sleep(4);
                 else if (nap == 1) __builtin_amdgcn_s_sleep(16);
                 else if (nap == 2) __builtin_amdgcn_s_sleep(64);
                 else { if (spins < 8) __builtin_amdgcn_s_sleep(4); else if (spins < 32) __builtin_amdgcn_s_sleep(16); else __builtin_amdgcn_s_sleep(64); }
+                // (the abort word and the state word in ONE round trip)
+                const unsigned stop = __hip_atomic_load(sync, RLX_AGENT);
+                cur = __hip_atomic_load(f, RLX_AGENT);
+                if (stop != 0) { ok = false; break; }
             }
         }
         if (!__all(ok)) {
@@ -1166,16 +1202,36 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
             else        for (int e = 0; e < n; ++e) v[e] = ov_clip_bd(v[e] + rv[e]);
         }
     };
+    // The plain case -- prediction (+ residual), no blend, no residual scale, every sample of the run carries the residual -- on
+    // sample PAIRS: clip(pred + res) = min(max(sat16(pred + res), 0), 1023) is a saturating packed add and two packed min / max
+    // (4 instructions per pair against ~20 unpacked ones: a lone wave issues an instruction every ~4.5 ns and this is the chain's tail)
+    const bool plain = !ciip_wt && !res_only && !scaled && res_mask == 0xff;
+    auto pk_clip_add = [&](uint32_t pred2, uint32_t res2) {
+        uint32_t r;
+        asm("v_pk_add_i16 %0, %1, %2 clamp\n\tv_pk_max_i16 %0, %0, 0\n\tv_pk_min_i16 %0, %0, %3" : "=&v"(r) : "v"(pred2), "v"(res2), "v"(0x03ff03ffu));
+        return r;
+    };
     if (l2g == 3) {
 #pragma unroll
         for (int j = 0; j < FJ8; ++j) {
             const int p = p_of(8 * j), x = p & (w - 1), y = p >> l2w;
             if (p >= st.p1) break;
-            int v[8];
-            finish(j, p, x, 8, v);
             flow_u4 q;
+            if (plain) {
+                const uint4 pq = *reinterpret_cast<const uint4 *>(&s.pred[p - st.p0]);
+                q[0] = pq.x; q[1] = pq.y; q[2] = pq.z; q[3] = pq.w;
+                if (has_res) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) q[e] = ((uint32_t)v[2 * e] | ((uint32_t)v[2 * e + 1] << 16)) | tag2;
+                    for (int e = 0; e < 4; ++e) q[e] = pk_clip_add(q[e], rq8[j][e]);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) q[e] |= tag2;
+            } else {
+                int v[8];
+                finish(j, p, x, 8, v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) q[e] = ((uint32_t)v[2 * e] | ((uint32_t)v[2 * e + 1] << 16)) | tag2;
+            }
             asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst + y * dstride + x), "v"(q) : "memory");      // write-through
         }
     } else if (l2g == 2) {
@@ -1183,11 +1239,18 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
         for (int j = 0; j < FJ4; ++j) {
             const int p = p_of(4 * j), x = p & (w - 1), y = p >> l2w;
             if (p >= st.p1) break;
-            int v[4];
-            finish(j, p, x, 4, v);
             flow_u2 q;
+            if (plain) {
+                const uint2 pq = *reinterpret_cast<const uint2 *>(&s.pred[p - st.p0]);
+                q[0] = pq.x; q[1] = pq.y;
+                if (has_res) { q[0] = pk_clip_add(q[0], rq4[j][0]); q[1] = pk_clip_add(q[1], rq4[j][1]); }
+                q[0] |= tag2; q[1] |= tag2;
+            } else {
+                int v[4];
+                finish(j, p, x, 4, v);
 #pragma unroll
-            for (int e = 0; e < 2; ++e) q[e] = ((uint32_t)v[2 * e] | ((uint32_t)v[2 * e + 1] << 16)) | tag2;
+                for (int e = 0; e < 2; ++e) q[e] = ((uint32_t)v[2 * e] | ((uint32_t)v[2 * e + 1] << 16)) | tag2;
+            }
             asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(dst + y * dstride + x), "v"(q) : "memory");
         }
     } else {
