@@ -975,7 +975,11 @@ __global__ __launch_bounds__(256) void k_flow_untag(ovhip_pic pic, const ovhip_i
     }
 }
 
-struct FlowLds { IntraLds s; unsigned *fp[FLOW_MAX_FP]; int abort; };
+// (fp: the state words an item polls, as word offsets from the state block: 7 KB of LDS per workgroup instead of 8.9.  The 109 VGPRs
+//  hold the kernel at 16 workgroups per compute unit; amdgpu_waves_per_eu(5, 8) gives 96 VGPRs = 20 per compute unit = room for
+//  1280 workers per launch, measured: the B picture's pass 157 -> 142 us alone, the I picture's 2.32 -> 2.44 us per level, the stream
+//  the same within its noise -- not taken)
+struct FlowLds { IntraLds s; uint32_t fp[FLOW_MAX_FP]; int abort; };
 
 __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res, const ovhip_itask *__restrict__ tasks, const uint32_t *__restrict__ items,
                                                    uint32_t n_items, const ovhip_lmcs_region *__restrict__ regs, LmcsWnd wnd, int16_t *scales,
@@ -1063,7 +1067,7 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
     auto add_run = [&](unsigned *base, int ux, int uy, int count, int dx, int dy) {
         // count units from (ux, uy) in steps of (dx, dy); clipped to the table (count is wave-uniform)
         count = min(count, FLOW_MAX_FP - nfp);
-        for (int i = lane; i < count; i += 64) L.fp[nfp + i] = base + (uy + i * dy) * w4 + ux + i * dx;
+        for (int i = lane; i < count; i += 64) L.fp[nfp + i] = (uint32_t)(base - sync) + (uint32_t)((uy + i * dy) * w4 + ux + i * dx);
         nfp += max(count, 0);
     };
     if (region) {
@@ -1098,7 +1102,7 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
     {
         bool ok = true;
         for (int i = lane; i < nfp; i += 64) {
-            unsigned *f = L.fp[i];
+            unsigned *f = sync + L.fp[i];
             unsigned spins = 0;
             unsigned cur = __hip_atomic_load(f, RLX_AGENT);
             while (cur == pending) {
