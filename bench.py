@@ -133,7 +133,7 @@ def main():
     ap.add_argument("--local-devices", type=int, default=1,
                     help="ONE process driving this many logical devices (device DPB + hipMemcpyPeerAsync); with --same-gpu all of them on GPU 0")
     ap.add_argument("--same-gpu", action="store_true")
-    ap.add_argument("--record-threads", type=str, default="1,4,16", help="frame-thread counts of the recorded_in_run variant")
+    ap.add_argument("--record-threads", type=str, default="1,4,16,32", help="frame-thread counts of the recorded_in_run variant")
     ap.add_argument("--trace", type=str, default="", help="debug: write the per-picture timeline of the timed region (taken / submitted / published, thread) to this file")
     ap.add_argument("--intra-lookahead", type=int, default=64,
                     help="pictures: one more frame thread per device starts pictures WITHOUT reference pictures (I pictures) up to this many pictures "
@@ -443,8 +443,11 @@ def main():
     # ---- variants: the same stream through the same call with other things inside the timed region ----
     def timed_variant(st, n_pics, flags=0, warm=True):
         arr, n = larr, NL
-        first = 0
-        nw = 1 + G
+        # warm-up: the I picture + one whole intra period, as the headline run has it -- the timed pictures then start on an intra
+        # period's boundary with the look-ahead thread a whole period ahead (33 pictures of warm-up put the first timed I picture 31
+        # pictures away and made "output none" read 10-15 % below "digest", which does strictly more)
+        nw = 1 + PPS
+        assert nw + n_pics <= n, "local stream too short for a variant"
         st.run(arr, n, 0, nw, flags=flags | capi.STREAM_KEEP)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
@@ -454,7 +457,7 @@ def main():
 
     fps_res = None
     if rank == 0 and not args.no_isolated_survey:
-        nv = 2 * PPS
+        nv = 4 * PPS
         for mode in ("none", "digest", "frame"):
             if mode == args.output and world == 1:
                 variants["output_" + mode] = round(fps, 1)
