@@ -573,6 +573,9 @@ __global__ __launch_bounds__(64) void k_intra_level(ovhip_pic pic, ovhip_pic res
 #define CT_CS    (4 + CT_S / 2)
 #define CT_CHUNK 128                        // tasks staged in LDS at a time
 #define SYNC_FLAGS OVHIP_FLOW_SYNC_WORDS     // sync[0] = abort code; flags from word 16
+#ifndef OVHIP_FLOW_PRIO
+#define OVHIP_FLOW_PRIO 3
+#endif
 #ifndef FLOW_POLL_GAP
 #define FLOW_POLL_GAP 3                    // s_sleep units (64 clocks) between the two polls a waiting item keeps in flight
 #endif
@@ -894,12 +897,17 @@ __device__ __forceinline__ bool fetch_refs_tagged(IntraLds &s, const uint16_t *p
         unsigned spins = 0;
         // (a ring of N polls written as a loop over arrays measured slower than this -- 2.55 us per level with two, 2.81 with three, 3.09
         // with four against 2.32: every generation still in flight when the samples arrive is waited for by whatever needs its registers)
+        // (a waiting item polls at the lowest issue priority: the polls of the ~1000 workers that are levels ahead of the front must not
+        //  take issue slots from the kernels of the other pictures -- the launch runs at OVHIP_FLOW_PRIO for what follows the arrival;
+        //  on the stream of bench.py the difference is inside the noise: 3243-3462 without, 3309-3406 with)
+        bool lowered = false;
         for (;;) {
             if (!missing(va)) {
 #pragma unroll
                 for (int i = 0; i < 6; ++i) v[i] = va[i];
                 break;
             }
+            if (!lowered) { __builtin_amdgcn_s_setprio(0); lowered = true; }
             const unsigned stop = __hip_atomic_load(sync, RLX_AGENT);
 #pragma unroll
             for (int i = 0; i < 6; ++i) va[i] = __hip_atomic_load(src[i], RLX_AGENT);              // (behind the poll in vb)
@@ -912,6 +920,7 @@ __device__ __forceinline__ bool fetch_refs_tagged(IntraLds &s, const uint16_t *p
 #pragma unroll
             for (int i = 0; i < 6; ++i) vb[i] = __hip_atomic_load(src[i], RLX_AGENT);              // (behind the poll in va)
         }
+        if (lowered) __builtin_amdgcn_s_setprio(OVHIP_FLOW_PRIO);
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -921,9 +930,6 @@ __device__ __forceinline__ bool fetch_refs_tagged(IntraLds &s, const uint16_t *p
     }
     return ok;
 }
-#ifndef OVHIP_FLOW_PRIO
-#define OVHIP_FLOW_PRIO 3
-#endif
 #define FLOW_MAX_FP 448
 #ifndef FSTRIP
 #define FSTRIP 256
