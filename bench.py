@@ -433,6 +433,32 @@ def main():
                for i, k in enumerate(("class_split_and_parameter_block", "enqueue_copies", "wait_for_reference_pictures", "enqueue_launches",
                                       "job_wait_publish_output"))}
     dpb_stats = dpb.stats()
+    xfer_bytes_main = n_xfer_bytes[0]
+    # ---- the OTHER dealing of pictures to devices on the same kind of stream (both are implemented in the C driver):
+    #      two intra periods per device, warmed by one ----
+    other_dealing = None
+    if world > 1 or L > 1:
+        od = "picture" if args.dealing == "gop" else "gop"
+        ndev = world if world > 1 else L
+        og_warm, og = (IP // G) * ndev, 2 * (IP // G) * ndev
+        opics, ospics = build(og_warm + og, world, od, 1 if world > 1 else L)
+        oarr = engine.Stream.pics_array(ospics)
+        st_o = new_stream(S, output=args.output, xfer=xfer)
+        on_warm = 1 + og_warm * G
+        st_o.run(oarr, len(ospics), 0, on_warm, flags=capi.STREAM_KEEP)
+        barrier()
+        t0 = time.perf_counter()
+        ores, _ = st_o.run(oarr, len(ospics), on_warm, len(ospics) - on_warm, flags=capi.STREAM_KEEP)
+        barrier()
+        odt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([odt], dtype=torch.float64, device=None if debug_gloo else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            odt = float(t.item())
+        other_dealing = {"dealing": od, "fps": round((len(ospics) - on_warm) / odt, 1), "pictures": len(ospics) - on_warm,
+                         "pictures_sent_by_this_rank": int(ores.n_sent), "peer_copies": int(dpb.stats().n_copies) - int(dpb_stats.n_copies)}
+        count(ores)
+        st_o.close()
     if world > 1:
         st_main = new_stream(S)
         cur[0] = 0
@@ -626,6 +652,8 @@ def main():
                                        "ovhip_frame_submit each (uploads -> host wait for the reference pictures -> launches -> ovhip_job_wait -> output -> publish)",
                        "timed_region_library_seconds": round(lib_seconds, 4),
                        "frame_thread_host_us_per_picture": host_us,
+                       "dealing": args.dealing if (world > 1 or L > 1) else None,
+                       "other_dealing": other_dealing,
                        "output": args.output, "recorder_in_timed_region": False,
                        "variants": variants,
                        "gop_size": G, "intra_period": IP,
@@ -651,7 +679,7 @@ def main():
                        "r_bar": round(st["r_bar"], 3), "coef_bytes": st["coef_bytes"],
                        "frame_algorithmic_bytes": int(sum(alg.values())),
                        "resident_replay_fps": round(fps_res, 2) if fps_res else None,
-                       "transfers_this_rank": {"sent": xfers[0], "received": xfers[1], "bytes_sent": n_xfer_bytes[0]},
+                       "transfers_this_rank": {"sent": xfers[0], "received": xfers[1], "bytes_sent": xfer_bytes_main},
                        "parallelism": f"{S} pictures in flight per GPU" + (f"; {args.dealing} dealing over {world} GPUs (one process per GPU), pictures other ranks "
                                       "list sent with RCCL point-to-point from the driver's comm thread (no collective)" if world > 1 else "")
                                       + (f"; ONE process, {L} logical devices ({args.dealing} dealing), reference pictures by event-ordered hipMemcpyPeerAsync" if L > 1 else "")},
