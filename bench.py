@@ -118,7 +118,7 @@ def main():
                     help="GOPs of pre-recorded picture jobs in the rotation (a job = the page-locked command buffers of one stream position + its device "
                          "copies, in flight once at a time): bounds how far ahead of the oldest picture in flight the frame threads can run")
     ap.add_argument("--output", choices=("none", "digest", "frame"), default="digest",
-                    help="what leaves the device per picture INSIDE the timed region: nothing / its MD5 fingerprint (per-row MD5 on the device, 16 bytes "
+                    help="what leaves the device per picture INSIDE the timed region: nothing / its MD5-tree fingerprint (computed on the device, 16 bytes "
                          "out) / the cropped, packed frame (one D2H of 24.9 MB at 4K into page-locked memory)")
     ap.add_argument("--check", type=int, default=6, metavar="N",
                     help="after the measurement: the first N pictures of the stream (I picture first) decoded by the ORACLE one at a time, each from the "

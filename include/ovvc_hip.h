@@ -861,8 +861,8 @@ typedef struct ovhip_job_params {        /* picture-level side information; HOST
     /* != 0: wait_events are waited for ON THE HOST (hipEventSynchronize on the flushing thread, after the uploads have been
      * enqueued) instead of being put into the stream: before_launch without a callback into the caller's language. */
     uint32_t wait_on_host;
-    /* The ordered pass's flow launches of this picture: items per launch (0: the default, 32768) and, != 0, the host waits for a
-     * launch before it issues the next.  A hardware queue runs the packets of the streams it serves in order: an I picture's pass
+    /* The ordered pass's flow launches of this picture: items per launch (0: the default -- ONE launch of persistent workers for the
+     * whole picture, ovhip_intra_flow_launch) and, != 0, the host waits for a launch before it issues the next.  A hardware queue runs the packets of the streams it serves in order: an I picture's pass
      * as one multi-millisecond kernel holds up every stream that shares its queue; paced chunks let them in between.  For a
      * picture nobody waits for yet (ovhip_stream_cfg.intra_lookahead). */
     uint32_t flow_chunk_items, flow_paced;

@@ -266,7 +266,7 @@ class DevPic:
         return out
 
     def digest(self, window=(0, 0, 0, 0)) -> bytes:
-        """MD5 over the per-row MD5 digests (computed on the device) of the cropped frame"""
+        """the picture's fingerprint: an MD5 tree over the cropped frame computed on the device (include/ovvc_hip.h, "Digest")"""
         win = capi.Window(*window)
         out = (C.c_uint8 * 16)()
         self.ctx._chk(self.ctx.lib.ovhip_pic_digest(self.ctx.h, C.byref(self.s), C.byref(win), out), "pic_digest")
