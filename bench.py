@@ -133,6 +133,7 @@ def main():
     ap.add_argument("--local-devices", type=int, default=1,
                     help="ONE process driving this many logical devices (device DPB + hipMemcpyPeerAsync); with --same-gpu all of them on GPU 0")
     ap.add_argument("--same-gpu", action="store_true")
+    ap.add_argument("--both-dealings", action="store_true", help="N > 1: also measure the other dealing (config.other_dealing)")
     ap.add_argument("--record-threads", type=str, default="1,4,16,32", help="frame-thread counts of the recorded_in_run variant")
     ap.add_argument("--trace", type=str, default="", help="debug: write the per-picture timeline of the timed region (taken / submitted / published, thread) to this file")
     ap.add_argument("--intra-lookahead", type=int, default=64,
@@ -437,7 +438,10 @@ def main():
     # ---- the OTHER dealing of pictures to devices on the same kind of stream (both are implemented in the C driver):
     #      two intra periods per device, warmed by one ----
     other_dealing = None
-    if world > 1 or L > 1:
+    # (one process per GPU: only on request or with --scaling strong -- the driver's weak-scaling runs are the first execution of the
+    #  RCCL exchange on real devices, and the picture-interleaved dealing sends a picture per picture: the headline run is not put at
+    #  the mercy of a second, much heavier exchange)
+    if L > 1 or (world > 1 and (args.both_dealings or args.scaling == "strong")):
         od = "picture" if args.dealing == "gop" else "gop"
         ndev = world if world > 1 else L
         og_warm, og = (IP // G) * ndev, 2 * (IP // G) * ndev
