@@ -88,6 +88,18 @@ filter_length(const struct edge_ctx *e, uint64_t aff_p, uint64_t aff_q, uint64_t
     if (e->large_q & pos) *lq = (aff_q & pos) ? 5 : 7;
 }
 
+/* in-place transpose of a 32 x 32 bit matrix (row r = word r, column c = bit c): five rounds of masked block swaps */
+static void
+transpose32(uint32_t a[32])
+{
+    uint32_t m = 0x0000ffffu;
+    for (int j = 16; j; j >>= 1, m ^= m << j)
+        for (int k = 0; k < 32; k = (k + j + 1) & ~j) {
+            const uint32_t t = ((a[k] >> j) ^ a[k + j]) & m;
+            a[k] ^= t << j; a[k + j] ^= t;
+        }
+}
+
 static uint64_t large_from_ngh(const uint64_t *m) { return ~(m[-1] | m[1] | m[-2] | m[2] | m[-3] | m[3]); }
 
 /* One segment: into the compact list the device kernel consumes (never an edge ON the picture boundary, the rule
@@ -146,16 +158,15 @@ ovhip_rec_dbf_ctu(ovhip_recorder *r, const ovhip_dbf_ctu *c)
      * lanes of a wave of k_dbf_list<0> then share cache lines; column by column costs the device 30 % more time and traffic). */
     if (!c->disable_h) {
         const uint64_t *edg = &c->ctb_bound_ver[8], *sb = &c->aff_edg_ver[8];
-        uint64_t todo[32];
-        uint32_t row[32];                       /* the same bits transposed: row[j] bit i = column i has a segment in unit row j */
+        uint32_t row[32];                       /* the column masks transposed: row[j] bit i = column i has a segment in unit row j */
         struct edge_ctx ctx[32];
         memset(row, 0, sizeof(row));
         for (int i = skip_v; i < nb_w; ++i) {
-            uint64_t m = todo[i] = (edg[i] | sb[i]) & vmask & (c->bs2_ver[i] | c->bs1_ver[i]);
-            if (!m) continue;
-            edge_context(&ctx[i], edg, sb, i, 1);
-            while (m) { row[__builtin_ctzll(m)] |= 1u << i; m &= m - 1; }
+            const uint64_t m = (edg[i] | sb[i]) & vmask & (c->bs2_ver[i] | c->bs1_ver[i]);
+            row[i] = (uint32_t)m;               /* (a CTU has at most 32 unit rows) */
+            if (m) edge_context(&ctx[i], edg, sb, i, 1);
         }
+        transpose32(row);                       /* 160 word operations instead of one read-modify-write per segment (~770 per CTU) */
         for (int j = 0; j < nb_h && j < 32; ++j) {
             const uint64_t pos = 1ull << j;
             const int uy = uy0 + j;
