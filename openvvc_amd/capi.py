@@ -193,7 +193,7 @@ class JobParams(C.Structure):
                 ("alf_chroma_coeff", C.c_void_p), ("alf_chroma_clip", C.c_void_p), ("alf_cc_coeff", C.c_void_p),
                 ("log2_ctu_s", C.c_int32), ("stages", C.c_uint32), ("wait_events", C.POINTER(C.c_void_p)), ("n_wait_events", C.c_uint32),
                 ("before_launch", C.c_void_p), ("before_launch_user", C.c_void_p), ("tmvp_cells", C.c_uint32), ("wait_on_host", C.c_uint32),
-                ("flow_chunk_items", C.c_uint32), ("flow_paced", C.c_uint32)]
+                ("flow_chunk_items", C.c_uint32), ("flow_paced", C.c_uint32), ("flow_workers", C.c_uint32)]
 
 
 BEFORE_LAUNCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)

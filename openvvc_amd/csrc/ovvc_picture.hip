@@ -696,7 +696,7 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
             // tuning knobs, read once; chunked launches -- whole levels per launch -- remain for ovhip_job_params.flow_chunk_items)
             static const size_t FLOW_CHUNK = getenv("OVHIP_FLOW_CHUNK") && atol(getenv("OVHIP_FLOW_CHUNK")) > 0 ? (size_t)atol(getenv("OVHIP_FLOW_CHUNK")) : ((size_t)1 << 30);
             static const long WORKERS = getenv("OVHIP_FLOW_WORKERS") ? atol(getenv("OVHIP_FLOW_WORKERS")) : -1;
-            const int n_workers = WORKERS >= 0 ? (int)WORKERS : 4 * ctx->num_cus;
+            const int n_workers = pr->flow_workers ? (int)pr->flow_workers : (WORKERS >= 0 ? (int)WORKERS : 4 * ctx->num_cus);
             size_t a = 0;
             int first = !flow_prepared;
             const size_t chunk = pr->flow_chunk_items ? pr->flow_chunk_items : FLOW_CHUNK;

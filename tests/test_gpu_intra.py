@@ -174,6 +174,29 @@ def test_second_pass_after_an_abandoned_flow_launch(ctx, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("workers", [1, 3, 64, 100000])
+def test_flow_launch_with_few_workers(ctx, workers):
+    """The ordered pass as W persistent workers (ovhip_job_params.flow_workers): worker b takes the items b, b + W, ... in level
+    order.  ONE worker walks the whole chain by itself, three wait for each other across hundreds of items each, 100000 is one
+    workgroup per item: an I picture and a B picture with intra CUs == the oracle every time, no second pass."""
+    for w, h, seed, frac in ((416, 240, 21, 1.0), (832, 480, 22, 0.25)):
+        wl = synth.make_workload(w, h, seed, tools=synth.INTRA_TOOLS, intra_frac=frac)
+        job = engine.Job(ctx, w, h)
+        refs = [ctx.upload_pic(*r) for r in wl.refs]
+        dst = ctx.new_pic(w, h)
+        job.load_workload(wl)
+        job.params.flow_workers = workers
+        job.flush(dst, refs, None)
+        job.wait()
+        assert job.stats().n_ordered_retries == 0
+        got = dst.download()
+        ref = oracle_pipeline.decode(wl)
+        for name, a, b in (("Y", got[0], ref.y), ("Cb", got[1], ref.cb), ("Cr", got[2], ref.cr)):
+            assert np.array_equal(a, b), f"{w}x{h}, {workers} workers: plane {name}: {int((a != b).sum())} samples differ"
+        job.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("w,h,seed,frac", [(416, 240, 11, 1.0), (832, 480, 12, 0.3)])
 def test_picture_with_intra_without_lmcs(ctx, w, h, seed, frac):
     """The flow launch hands luma over with a tag bit that the inverse luma mapping drops; a picture without LMCS has no such pass
