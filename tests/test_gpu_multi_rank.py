@@ -1,0 +1,40 @@
+"""GPU: the one-process-per-GPU path of the stream driver (ovhip_stream_xfer callbacks on the C communication thread) executed by two
+ranks -- on ONE GPU, pictures exchanged through host memory over gloo (OVVC_BENCH_DEBUG_GLOO=1: gpurun boxes have one GPU; the RCCL
+leg of the same callbacks first runs on the driver's multi-GPU node).  Both dealings; every rank's pictures are checked against the
+oracle / the one-at-a-time decode by bench.py --check inside the run."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _run(dealing, port):
+    env = dict(os.environ, OVVC_BENCH_DEBUG_GLOO="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--width", "832", "--height", "480", "--no-cpu-baseline",
+           "--no-isolated-survey", "--check", "3", "--dealing", dealing, "--both-dealings"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dealing,port", [("gop", 29611), ("picture", 29612)])
+def test_two_ranks_on_one_gpu(built_lib, dealing, port):
+    d = _run(dealing, port)
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["dealing"] == dealing and c["ordered_pass_second_passes"] == 0
+    assert c["check"]["differ"] == 0 and c["check"]["differ_in_flight"] == 0
+    assert c["transfers_this_rank"]["sent"] > 0 and c["transfers_this_rank"]["bytes_sent"] > 0
+    assert c["other_dealing"]["dealing"] != dealing and c["other_dealing"]["fps"] > 0
+    # the picture-interleaved dealing moves (nearly) a picture per picture, a GOP per GPU one picture per GOP
+    sent_pic = c["transfers_this_rank"]["sent"] if dealing == "picture" else c["other_dealing"]["pictures_sent_by_this_rank"]
+    sent_gop = c["transfers_this_rank"]["sent"] if dealing == "gop" else c["other_dealing"]["pictures_sent_by_this_rank"]
+    assert sent_pic > 4 * sent_gop
