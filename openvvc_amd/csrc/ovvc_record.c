@@ -871,6 +871,10 @@ ovhip_rec_affine_cu(ovhip_recorder *r, const ovhip_affine_desc *cu)
         if (grow((void **)&r->aff_side, &r->cap_side, r->n_side + 32, sizeof(int32_t))) return OVHIP_ENOMEM;
         prof_off = (uint32_t)r->n_side;
         memcpy(r->aff_side + r->n_side, cu->dmv_scale, 128);
+        /* h / v tables of a list PROF is not applied to: uninitialised in the caller (compute_prof_dmv_scale runs per refined
+         * list, drv_affine_mvp.c:3325-3340); never read on the device, recorded as zeros */
+        if (!(cu->prof_dir & 1)) memset(r->aff_side + r->n_side, 0, 64);
+        if (!(cu->prof_dir & 2)) memset(r->aff_side + r->n_side + 16, 0, 64);
         r->n_side += 32;
     }
 
@@ -897,6 +901,10 @@ ovhip_rec_affine_cu(ovhip_recorder *r, const ovhip_affine_desc *cu)
                 for (int sx = 0; sx < uw; sx += 4) {
                     const int k = ((uy + sy) >> 2) * cu->mv_stride + ((ux + sx) >> 2);
                     int32_t m[4] = { cu->mv0[2 * k], cu->mv0[2 * k + 1], cu->mv1[2 * k], cu->mv1[2 * k + 1] };
+                    /* the list a uni-predicted CU does not use: whatever the caller's OVMV held (found by the chained stream
+                     * fixture: stack words of the reference's affine drivers) -- never read on the device, never recorded */
+                    if (!(dir & 1)) m[0] = m[1] = 0;
+                    if (!(dir & 2)) m[2] = m[3] = 0;
                     /* rcn_mcp_b_l's identical-motion shortcut; rcn_prof_mcp_b_l has none (rcn_inter.c:2864-2918) */
                     if (!cu->prof_dir && dir == 3 && cu->poc0 == cu->poc1 && m[0] == m[2] && m[1] == m[3])
                         u->ident_l |= (uint16_t)(1u << ((sy >> 2) * (uw >> 2) + (sx >> 2)));
@@ -909,8 +917,9 @@ ovhip_rec_affine_cu(ovhip_recorder *r, const ovhip_affine_desc *cu)
             for (int sy = 0; sy < uh; sy += 8) {
                 for (int sx = 0; sx < uw; sx += 8) {
                     const int k = ((uy + sy) >> 2) * cu->mv_stride + ((ux + sx) >> 2), k2 = k + cu->mv_stride + 1;
-                    int32_t m[4] = { cu->mv0[2 * k] + cu->mv0[2 * k2], cu->mv0[2 * k + 1] + cu->mv0[2 * k2 + 1],
-                                     cu->mv1[2 * k] + cu->mv1[2 * k2], cu->mv1[2 * k + 1] + cu->mv1[2 * k2 + 1] };
+                    int32_t m[4] = { 0, 0, 0, 0 };
+                    if (dir & 1) { m[0] = cu->mv0[2 * k] + cu->mv0[2 * k2]; m[1] = cu->mv0[2 * k + 1] + cu->mv0[2 * k2 + 1]; }
+                    if (dir & 2) { m[2] = cu->mv1[2 * k] + cu->mv1[2 * k2]; m[3] = cu->mv1[2 * k + 1] + cu->mv1[2 * k2 + 1]; }
                     for (int c = 0; c < 4; ++c) { m[c] += m[c] < 0; m[c] >>= 1; }
                     if (dir == 3 && cu->poc0 == cu->poc1 && m[0] == m[2] && m[1] == m[3])
                         u->ident_c |= (uint8_t)(1u << ((sy >> 3) * (uw >> 3) + (sx >> 3)));

@@ -1,0 +1,534 @@
+/* gen_pipe.c -- TEST INFRASTRUCTURE (this container only).
+ *
+ * A reference-driven CHAINED mini-stream: the reference's own slice decoder (libovvc/slicedec.c: slicedec_init_slice_tools ->
+ * slicedec_decode_rect_entry -> decode_ctu_line / decode_ctu_last_line -> decode_ctu / decode_truncated_ctu -> coding_quadtree /
+ * dual_tree -> coding_unit / prediction_unit / transform_unit -> the rcn slots, with the reference's own CTU scratch, intra line,
+ * SAO / ALF line buffers, dbf_store_info / dbf_load_info, store_inter_maps, TMVP planes) decodes a few 416x240 pictures -- 4 x 2 CTUs,
+ * last column 32 wide, last row 112 high: SURVEY.md 8 "C1" geometry -- each from the pictures decoded before it.
+ *
+ * What the harness supplies instead of the parts of the decoder that cannot be built here (ovdec.c / rcn.c / ovmem.c / ovutils.c
+ * include the autoconf-generated ovconfig.h; no .266 stream exists on disk):
+ *   - parameter sets as filled structs (OVSPS / OVPPS / OVPH / OVSH / OVAPS with the tool set of the JVET CTC random-access
+ *     configuration) handed to the reference's own decinit_update_params();
+ *   - pictures, reference lists and collocated-picture info as filled OVPicture structs (what dpb.c derives from the RPL syntax);
+ *   - every buffer the decoder would take from ov_malloc (line buffers, filter buffers, motion planes), calloc'ed with the sizes
+ *     the reference's init functions use (cited below);
+ *   - the SLICE DATA: seeded pseudo-random bytes.  The reference's CABAC engine turns uniformly random bits into syntax elements
+ *     distributed by its own context models, so the parse is a legal-syntax random walk through the reference's real caller code:
+ *     partitions, modes, motion vectors (merge / MMVD / AMVP / affine / SbTMVP / GPM / CIIP / SMVD / BCW / AMVR), residuals
+ *     (dependent quantisation, MTS, LFNST, SBT, ISP, transform skip, BDPCM, JCCR), SAO / ALF / CC-ALF CTU parameters.
+ *   - rcn_init_functions(): rcn.c is not built, the table is filled by the same per-file initialisers in the same order
+ *     (ref_common.h: ref_fill_table, as for every other fixture); in "shim" mode followed by rcn_init_functions_hip() --
+ *     exactly the binding INTEGRATION.md section 1 adds to rcn.c.  slicedec.c is compiled as part of this file (it is included
+ *     from where it lies, so that its static entry points can be called); the one symbol it takes from rcn.c is redirected here.
+ *
+ * Reference mode  -> tests/golden/pipe.ovg      : every picture's final frame (after deblocking, SAO, ALF) and the vectors every
+ *                                                 rcn_dmvr_mv_refine call returned.
+ * Shim mode       -> tests/golden/shim_pipe.ovg : what the INSTALLED slots recorded for the same pictures (one command stream per
+ *                                                 picture + its picture-level parameters).  tests/ decode picture k from the
+ *                                                 pictures THEY decoded before and must end with the reference's bytes.
+ * The same process runs the reference pass first in both modes: the shim's DMVR slot returns unrefined vectors in record-only
+ * mode (the device refines them later), so the harness hands the caller the vectors the reference pass
+ * produced for the same call -- "the device answered in time" -- and the parse of the later pictures (TMVP) stays the same.
+ */
+#define rcn_init_functions gp_rcn_init_functions
+#include "ref_common.h"
+#include "ovvc_hip.h"
+#include "shim_stream.h"
+#include "nvcl.h"
+#include "nvcl_structures.h"
+#include "decinit.h"
+#include "ovdec_internal.h"
+#include <pthread.h>
+
+#include "slicedec.c"        /* /root/reference/libovvc/slicedec.c, compiled where it lies (-I$(R)) */
+
+/* private to rcn_lmcs.c:75-81 (the harness only needs its size: rcn_init_lmcs would take it from ov_malloc) */
+struct LMCSLUTs { OVSample fwd_lut[1024]; OVSample bwd_lut[1024]; OVSample wnd_bnd[17]; };
+
+/* ------------------------------------------------------------------------------------------------ the table */
+typedef uint8_t (*dmvr_fn)(OVCTUDec *const, struct OVBuffInfo, uint8_t, uint8_t, uint8_t, uint8_t, OVMV *, OVMV *, uint8_t, uint8_t, uint8_t);
+static dmvr_fn g_dmvr_inner;
+static gbuf g_dmvr_log = { .type = T_I32 };         /* per call: x, y (picture, luma), log2 w, log2 h, mv0 in, mv1 in, mv0 out, mv1 out */
+static size_t g_dmvr_pos;                           /* shim pass: next entry of the reference pass's log */
+static int g_pass_shim;
+static int g_isp_64x2;                              /* the reference's result for 64x2 ISP partitions is undefined (gen_golden.c, gen_isp) */
+
+static uint8_t
+gp_dmvr(OVCTUDec *const c, struct OVBuffInfo dst, uint8_t x0, uint8_t y0, uint8_t l2w, uint8_t l2h, OVMV *mv0, OVMV *mv1,
+        uint8_t ref_idx0, uint8_t ref_idx1, uint8_t apply_bdof)
+{
+    const int32_t in[8] = { (c->ctb_x << 7) + x0, (c->ctb_y << 7) + y0, l2w, l2h, mv0->x, mv0->y, mv1->x, mv1->y };
+    const uint8_t r = g_dmvr_inner(c, dst, x0, y0, l2w, l2h, mv0, mv1, ref_idx0, ref_idx1, apply_bdof);
+    if (!g_pass_shim) {
+        int32_t rec[12];
+        memcpy(rec, in, sizeof(in));
+        rec[8] = mv0->x; rec[9] = mv0->y; rec[10] = mv1->x; rec[11] = mv1->y;
+        gbuf_push(&g_dmvr_log, rec, 12);
+        return r;
+    }
+    const int32_t *want = (const int32_t *)g_dmvr_log.data + 12 * g_dmvr_pos;
+    if (12 * (g_dmvr_pos + 1) > g_dmvr_log.n || memcmp(want, in, sizeof(in))) {
+        fprintf(stderr, "gen_pipe: shim pass: DMVR call %zu is not the reference pass's call (the parse diverged)\n", g_dmvr_pos);
+        exit(1);
+    }
+    mv0->x = want[8]; mv0->y = want[9]; mv1->x = want[10]; mv1->y = want[11];
+    ++g_dmvr_pos;
+    return r;
+}
+
+typedef void (*isp_fn)(OVCTUDec *const, unsigned int, unsigned int, unsigned int, unsigned int, uint8_t, const struct ISPTUInfo *const);
+static isp_fn g_isp_h_inner;
+static void
+gp_isp_h(OVCTUDec *const c, unsigned int x0, unsigned int y0, unsigned int l2w, unsigned int l2h, uint8_t mode, const struct ISPTUInfo *const tu)
+{
+    if (l2w == 6 && l2h == 3) g_isp_64x2++;
+    g_isp_h_inner(c, x0, y0, l2w, l2h, mode, tu);
+}
+
+typedef void (*gpm_fn)(OVCTUDec *const, struct VVCGPM *, int, int, int, int);
+static gpm_fn g_gpm_inner;
+static void
+gp_gpm(OVCTUDec *const c, struct VVCGPM *g, int x0, int y0, int l2w, int l2h)
+{
+    if (getenv("GP_TRACE"))
+        fprintf(stderr, "    gpm %s ctb %d,%d at %d,%d %dx%d split %d dir %d/%d mv0 %d,%d ref %d bcw %d mv1 %d,%d ref %d\n", g_pass_shim ? "shim" : "ref", c->ctb_x, c->ctb_y,
+                x0, y0, 1 << l2w, 1 << l2h, g->split_dir, g->inter_dir0, g->inter_dir1, g->mv0.x, g->mv0.y, g->mv0.ref_idx, g->mv0.bcw_idx_plus1, g->mv1.x, g->mv1.y, g->mv1.ref_idx);
+    g_gpm_inner(c, g, x0, y0, l2w, l2h);
+}
+
+/* rcn.c:147-180 for 10-bit, + the MI355X override block when the shim pass runs */
+void
+gp_rcn_init_functions(struct RCNFunctions *f, uint8_t ict_type, uint8_t lm_chroma_enabled, uint8_t vcolloc, uint8_t lmcs_flag, uint8_t bitdepth)
+{
+    if (bitdepth != 10 || !lm_chroma_enabled || vcolloc) { fprintf(stderr, "gen_pipe: table variant not restated\n"); exit(1); }
+    ref_fill_table(f, ict_type, lmcs_flag);
+    if (g_pass_shim) rcn_init_functions_hip(f, ict_type, lm_chroma_enabled, vcolloc, lmcs_flag, bitdepth);
+    g_dmvr_inner = f->rcn_dmvr_mv_refine; f->rcn_dmvr_mv_refine = &gp_dmvr;
+    if (getenv("GP_TRACE")) { g_gpm_inner = f->rcn_gpm_b; f->rcn_gpm_b = &gp_gpm; }
+    g_isp_h_inner = (isp_fn)f->tmp.recon_isp_subtree_h; f->tmp.recon_isp_subtree_h = (void *)&gp_isp_h;
+}
+
+/* ------------------------------------------------------------------------------------------------ parameter sets */
+struct gp_seq {
+    int w, h, nb_ctb_w, nb_ctb_h;
+    OVSPS sps; OVPPS pps; OVPH ph; OVSH sh;
+    OVAPS aps_alf[4], aps_lmcs;
+    OVNVCLCtx nvcl;
+    OVPS ps;
+};
+
+static void
+rand_alf_aps(OVALFData *a)          /* as gen_golden.c, gen_alf */
+{
+    memset(a, 0, sizeof(*a));
+    int nf = rnd_range(1, 25);
+    a->alf_luma_num_filters_signalled_minus1 = nf - 1;
+    a->alf_luma_clip_flag = rnd_range(0, 1);
+    for (int c = 0; c < 25; ++c) a->alf_luma_coeff_delta_idx[c] = rnd_range(0, nf - 1);
+    for (int f = 0; f < 25; ++f) for (int k = 0; k < 12; ++k) {
+        a->alf_luma_coeff[f][k] = (int16_t)(rnd_range(0, 7) == 0 ? rnd_range(-60, 60) : rnd_range(-12, 12));
+        a->alf_luma_clip_idx[f][k] = rnd_range(0, 3);
+    }
+    a->alf_chroma_clip_flag = rnd_range(0, 1);
+    a->alf_chroma_num_alt_filters_minus1 = rnd_range(0, 7);
+    for (int f = 0; f < 8; ++f) for (int k = 0; k < 6; ++k) {
+        a->alf_chroma_coeff[f][k] = (int16_t)(rnd_range(0, 7) == 0 ? rnd_range(-60, 60) : rnd_range(-12, 12));
+        a->alf_chroma_clip_idx[f][k] = rnd_range(0, 3);
+    }
+    a->alf_cc_cb_filters_signalled_minus1 = 3; a->alf_cc_cr_filters_signalled_minus1 = 3;
+    for (int c = 0; c < 2; ++c) for (int f = 0; f < 4; ++f) for (int k = 0; k < 7; ++k) {
+        int m = rnd_range(0, 5);
+        int v = m == 0 ? 0 : 1 << (m - 1);
+        a->alf_cc_mapped_coeff[c][f][k] = (int16_t)(rnd_range(0, 1) ? -v : v);
+    }
+}
+
+/* The sequence-level tool set: JVET CTC random access (VTM encoder_randomaccess_vtm.cfg), 10-bit 4:2:0, CTU 128. */
+static void
+seq_init(struct gp_seq *s, int w, int h, int variant)
+{
+    memset(s, 0, sizeof(*s));
+    s->w = w; s->h = h; s->nb_ctb_w = (w + 127) >> 7; s->nb_ctb_h = (h + 127) >> 7;
+    OVSPS *sps = &s->sps;
+    sps->sps_chroma_format_idc = 1;
+    sps->sps_log2_ctu_size_minus5 = 2;
+    sps->sps_pic_width_max_in_luma_samples = w; sps->sps_pic_height_max_in_luma_samples = h;
+    sps->sps_bitdepth_minus8 = 2;
+    sps->sps_log2_min_luma_coding_block_size_minus2 = 0;
+    sps->sps_log2_diff_min_qt_min_cb_intra_slice_luma = 1;  sps->sps_max_mtt_hierarchy_depth_intra_slice_luma = 3;
+    sps->sps_log2_diff_max_bt_min_qt_intra_slice_luma = 2;  sps->sps_log2_diff_max_tt_min_qt_intra_slice_luma = 2;
+    sps->sps_qtbtt_dual_tree_intra_flag = variant != 1;
+    sps->sps_log2_diff_min_qt_min_cb_intra_slice_chroma = 1; sps->sps_max_mtt_hierarchy_depth_intra_slice_chroma = 3;
+    sps->sps_log2_diff_max_bt_min_qt_intra_slice_chroma = 3; sps->sps_log2_diff_max_tt_min_qt_intra_slice_chroma = 2;
+    sps->sps_log2_diff_min_qt_min_cb_inter_slice = 1;        sps->sps_max_mtt_hierarchy_depth_inter_slice = 3;
+    sps->sps_log2_diff_max_bt_min_qt_inter_slice = 4;        sps->sps_log2_diff_max_tt_min_qt_inter_slice = 3;
+    sps->sps_max_luma_transform_size_64_flag = 1;
+    sps->sps_transform_skip_enabled_flag = 1; sps->sps_log2_transform_skip_max_size_minus2 = 3; sps->sps_bdpcm_enabled_flag = 1;
+    sps->sps_mts_enabled_flag = 1; sps->sps_explicit_mts_intra_enabled_flag = variant != 1; sps->sps_explicit_mts_inter_enabled_flag = variant == 1;
+    sps->sps_lfnst_enabled_flag = 1;
+    sps->sps_joint_cbcr_enabled_flag = 1;
+    sps->sps_same_qp_table_for_chroma_flag = 1;
+    sps->sps_qp_table_start_minus26[0] = -9; sps->sps_num_points_in_qp_table_minus1[0] = 2;     /* 17 22 34 42 -> 17 23 35 39 */
+    sps->sps_delta_qp_in_val_minus1[0][0] = 4; sps->sps_delta_qp_in_val_minus1[0][1] = 11; sps->sps_delta_qp_in_val_minus1[0][2] = 7;
+    sps->sps_delta_qp_diff_val[0][0] = 4 ^ 6;  sps->sps_delta_qp_diff_val[0][1] = 11 ^ 12;    sps->sps_delta_qp_diff_val[0][2] = 7 ^ 4;
+    sps->sps_sao_enabled_flag = 1; sps->sps_alf_enabled_flag = 1; sps->sps_ccalf_enabled_flag = 1; sps->sps_lmcs_enabled_flag = 1;
+    sps->sps_temporal_mvp_enabled_flag = 1; sps->sps_sbtmvp_enabled_flag = 1; sps->sps_amvr_enabled_flag = 1;
+    sps->sps_bdof_enabled_flag = 1; sps->sps_smvd_enabled_flag = 1; sps->sps_dmvr_enabled_flag = 1;
+    sps->sps_mmvd_enabled_flag = 1; sps->sps_mmvd_fullpel_only_enabled_flag = 0;
+    sps->sps_six_minus_max_num_merge_cand = 0;
+    sps->sps_sbt_enabled_flag = 1;
+    sps->sps_affine_enabled_flag = 1; sps->sps_five_minus_max_num_subblock_merge_cand = 0; sps->sps_6param_affine_enabled_flag = 1;
+    sps->sps_affine_amvr_enabled_flag = 1; sps->sps_affine_prof_enabled_flag = 1;
+    sps->sps_bcw_enabled_flag = 1; sps->sps_ciip_enabled_flag = 1;
+    sps->sps_gpm_enabled_flag = 1; sps->sps_max_num_merge_cand_minus_max_num_gpm_cand = 1;
+    rcn_init_gpm_params();                         /* what the SPS reader does when it meets the flag (nvcl_nal_sps.c:580-583) */
+    sps->sps_isp_enabled_flag = 1; sps->sps_mrl_enabled_flag = 1; sps->sps_mip_enabled_flag = 1; sps->sps_cclm_enabled_flag = 1;
+    sps->sps_chroma_horizontal_collocated_flag = 1; sps->sps_chroma_vertical_collocated_flag = 0;
+    sps->sps_ibc_enabled_flag = 0;
+    sps->sps_dep_quant_enabled_flag = 1; sps->sps_sign_data_hiding_enabled_flag = 1;
+
+    OVPPS *pps = &s->pps;
+    pps->pps_pic_width_in_luma_samples = w; pps->pps_pic_height_in_luma_samples = h;
+    pps->pps_log2_ctu_size_minus5 = 2;
+    pps->pps_no_pic_partition_flag = 1;
+    pps->pps_init_qp_minus26 = 0;
+    pps->pps_cu_qp_delta_enabled_flag = variant == 1;
+    pps->pps_cb_qp_offset = variant == 1 ? 1 : 0; pps->pps_cr_qp_offset = variant == 1 ? -1 : 0;
+    pps->pps_joint_cbcr_qp_offset_value = 0;
+
+    for (int i = 0; i < 4; ++i) { s->aps_alf[i].aps_adaptation_parameter_set_id = i; rand_alf_aps(&s->aps_alf[i].aps_alf_data); }
+    struct OVLMCSData *ld = &s->aps_lmcs.aps_lmcs_data;
+    ld->lmcs_min_bin_idx = 1; ld->lmcs_delta_max_bin_idx = 2;
+    for (int i = 0; i < 16; ++i) { ld->lmcs_delta_abs_cw[i] = rnd_range(0, 24); ld->lmcs_delta_sign_cw_flag[i] = rnd_range(0, 1); }
+    ld->lmcs_delta_abs_crs = rnd_range(0, 5); ld->lmcs_delta_sign_crs_flag = rnd_range(0, 1);
+
+    s->nvcl.sps_list[0] = sps; s->nvcl.pps_list[0] = pps;
+    for (int i = 0; i < 4; ++i) s->nvcl.alf_aps_list[i] = &s->aps_alf[i];
+    s->nvcl.lmcs_aps_list[0] = &s->aps_lmcs;
+    s->nvcl.ph = &s->ph; s->nvcl.sh = &s->sh;
+}
+
+/* picture- and slice-level syntax of one picture (what nvcl_ph_read / nvcl_sh_read would have filled) */
+static void
+pic_headers(struct gp_seq *s, int slice_type, int qp, int n_ref0, int n_ref1, int tmvp, int col_from_l0, int lmcs)
+{
+    OVPH *ph = &s->ph; OVSH *sh = &s->sh;
+    memset(ph, 0, sizeof(*ph)); memset(sh, 0, sizeof(*sh));
+    ph->ph_inter_slice_allowed_flag = slice_type != 2; ph->ph_intra_slice_allowed_flag = 1;
+    ph->ph_lmcs_enabled_flag = lmcs; ph->ph_lmcs_aps_id = 0; ph->ph_chroma_residual_scale_flag = lmcs;
+    ph->ph_temporal_mvp_enabled_flag = tmvp; ph->ph_collocated_from_l0_flag = col_from_l0; ph->ph_collocated_ref_idx = 0;
+    ph->ph_joint_cbcr_sign_flag = rnd_range(0, 1);
+    ph->ph_mmvd_fullpel_only_flag = 0; ph->ph_mvd_l1_zero_flag = 0;
+    ph->ph_cu_qp_delta_subdiv_intra_slice = 2; ph->ph_cu_qp_delta_subdiv_inter_slice = 2;
+    ph->ph_qp_delta = 0;
+    sh->sh_slice_type = slice_type;
+    sh->sh_qp_delta = qp - 26;
+    sh->sh_alf_enabled_flag = 1; sh->sh_num_alf_aps_ids_luma = 2; sh->sh_alf_aps_id_luma[0] = 0; sh->sh_alf_aps_id_luma[1] = 1;
+    sh->sh_alf_cb_enabled_flag = 1; sh->sh_alf_cr_enabled_flag = 1; sh->sh_alf_aps_id_chroma = 2;
+    sh->sh_alf_cc_cb_enabled_flag = 1; sh->sh_alf_cc_cb_aps_id = 3; sh->sh_alf_cc_cr_enabled_flag = 1; sh->sh_alf_cc_cr_aps_id = 3;
+    sh->sh_lmcs_used_flag = lmcs;
+    sh->sh_sao_luma_used_flag = 1; sh->sh_sao_chroma_used_flag = 1;
+    /* debugging aids (never set when the committed fixtures are made): switch in-loop filter stages off */
+    if (getenv("GP_NO_SAO")) sh->sh_sao_luma_used_flag = sh->sh_sao_chroma_used_flag = 0;
+    if (getenv("GP_NO_ALF")) sh->sh_alf_enabled_flag = sh->sh_alf_cb_enabled_flag = sh->sh_alf_cr_enabled_flag = sh->sh_alf_cc_cb_enabled_flag = sh->sh_alf_cc_cr_enabled_flag = 0;
+    if (getenv("GP_NO_DBF")) sh->sh_deblocking_filter_disabled_flag = 1;
+    sh->sh_collocated_from_l0_flag = col_from_l0;
+    sh->sh_dep_quant_used_flag = rnd_range(0, 3) != 0; sh->sh_sign_data_hiding_used_flag = !sh->sh_dep_quant_used_flag;
+    sh->sh_luma_beta_offset_div2 = rnd_range(-2, 2); sh->sh_luma_tc_offset_div2 = rnd_range(-2, 2);
+    sh->hrpl.rpl_h0.rpl_data.num_ref_active_entries = n_ref0;
+    sh->hrpl.rpl_h1.rpl_data.num_ref_active_entries = n_ref1;
+}
+
+/* ------------------------------------------------------------------------------------------------ pictures */
+static OVPicture *
+gp_new_picture(const struct gp_seq *s, int poc)
+{
+    OVPicture *p = ref_new_picture(s->w, s->h, poc);
+    /* ovdpb_init_decoded_ctus (dpb.c:1272-1295) */
+    p->decoded_ctus.mask_h = s->nb_ctb_h; p->decoded_ctus.mask_w = (s->nb_ctb_w >> 6) + 1;
+    p->decoded_ctus.mask = calloc(s->nb_ctb_h, sizeof(uint64_t *));
+    for (int i = 0; i < s->nb_ctb_h; ++i) p->decoded_ctus.mask[i] = calloc(p->decoded_ctus.mask_w, 8);
+    pthread_mutex_init(&p->internal.ref_mtx, NULL); pthread_cond_init(&p->internal.ref_cnd, NULL);
+    p->decoded_ctus.ref_mtx = &p->internal.ref_mtx; p->decoded_ctus.ref_cnd = &p->internal.ref_cnd;
+    /* mvpool.c:52-82: one OVMV per 8x8 block, one direction word per 4-sample row of every CTU */
+    const size_t n_ctb = (size_t)s->nb_ctb_w * s->nb_ctb_h;
+    p->mv_plane0.mvs = calloc(n_ctb * 16 * 16, sizeof(OVMV)); p->mv_plane0.dirs = calloc(n_ctb * 32, 8);
+    p->mv_plane1.mvs = calloc(n_ctb * 16 * 16, sizeof(OVMV)); p->mv_plane1.dirs = calloc(n_ctb * 32, 8);
+    return p;
+}
+
+/* reference lists + what init_tmvp_info / tmvp_set_mv_scales (dpb.c:951-1062) derive from them */
+static void
+gp_set_refs(OVPicture *p, OVPicture **l0, int n0, OVPicture **l1, int n1, int tmvp, int col_from_l0)
+{
+    memset(p->rpl0, 0, sizeof(p->rpl0)); memset(p->rpl1, 0, sizeof(p->rpl1));
+    memset(&p->rpl_info0, 0, sizeof(p->rpl_info0)); memset(&p->rpl_info1, 0, sizeof(p->rpl_info1));
+    for (int i = 0; i < n0; ++i) { p->rpl0[i] = l0[i]; p->rpl_info0.ref_info[i].type = ST_REF; p->rpl_info0.ref_info[i].poc = l0[i]->poc; }
+    for (int i = 0; i < n1; ++i) { p->rpl1[i] = l1[i]; p->rpl_info1.ref_info[i].type = ST_REF; p->rpl_info1.ref_info[i].poc = l1[i]->poc; }
+    p->rpl_info0.nb_refs = p->rpl_info0.nb_active_refs = n0; p->rpl_info1.nb_refs = p->rpl_info1.nb_active_refs = n1;
+    for (int i = 0; i < n0; ++i) p->tmvp.dist_ref_0[i] = p->poc - l0[i]->poc;
+    for (int i = 0; i < n1; ++i) p->tmvp.dist_ref_1[i] = p->poc - l1[i]->poc;
+    p->tmvp.collocated_ref = NULL;
+    if (tmvp && (n0 || n1)) {
+        const OVPicture *col = col_from_l0 ? l0[0] : l1[0];
+        p->tmvp.collocated_ref = col;
+        p->tmvp.col_info.ref_idx_rpl0 = col_from_l0 ? 0 : -1; p->tmvp.col_info.ref_idx_rpl1 = col_from_l0 ? -1 : 0;
+        for (int i = 0; i < 16; ++i) {
+            if (col_from_l0 && p->rpl1[i] == col) p->tmvp.col_info.ref_idx_rpl1 = i;
+            if (!col_from_l0 && p->rpl0[i] == col) p->tmvp.col_info.ref_idx_rpl0 = i;
+        }
+        for (int i = 0; i < col->rpl_info0.nb_refs; ++i) p->tmvp.dist_col_0[i] = col->poc - col->rpl_info0.ref_info[i].poc;
+        for (int i = 0; i < col->rpl_info1.nb_refs; ++i) p->tmvp.dist_col_1[i] = col->poc - col->rpl_info1.ref_info[i].poc;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ slice decoder + entry decoder */
+static void
+gp_alloc_lines(OVSliceDec *sl, const struct gp_seq *s)
+{
+    /* init_cabac_lines (slicedec.c:357-391): one byte per 4-sample unit of the picture width, one tile row */
+    const int nb_pb = s->nb_ctb_w << 5;
+    for (int k = 0; k < 2; ++k) {
+        sl->cabac_lines[k].qt_depth_map_x = calloc(nb_pb, 1); sl->cabac_lines[k].log2_cu_w_map_x = calloc(nb_pb, 1); sl->cabac_lines[k].cu_mode_x = calloc(nb_pb, 1);
+    }
+    /* init_drv_lines (drv_lines.c:772-817): nb_ctb_pic_w + 2 per tile column, one tile row */
+    const int nb_ctb = s->nb_ctb_w + 2, nb_pb2 = nb_ctb << 5, n_in = 32 * nb_ctb + 2;
+    struct DRVLines *l = &sl->drv_lines;
+    l->inter_lines.mv0 = calloc((size_t)32 * n_in, sizeof(OVMV)); l->inter_lines.mv1 = calloc((size_t)32 * n_in, sizeof(OVMV));
+    l->inter_lines.dir0 = calloc(n_in, 4); l->inter_lines.dir1 = calloc(n_in, 4); l->inter_lines.affine = calloc(n_in, 4);
+    l->inter_lines.aff_info = calloc(n_in, sizeof(struct AffineInfo));
+    struct DBFLines *d = &l->dbf_lines;
+    d->qp_x_map = calloc(32 * nb_pb2 + 1, 1); d->qp_x_map_cb = calloc(32 * nb_pb2 + 1, 1); d->qp_x_map_cr = calloc(32 * nb_pb2 + 1, 1);
+    d->small_map = calloc(nb_ctb + 1, 8); d->large_map_c = calloc(nb_ctb + 1, 8);
+    d->dbf_bs1_hor = calloc(nb_ctb + 1, 8); d->dbf_bs1_hor_cb = calloc(nb_ctb + 1, 8); d->dbf_bs1_hor_cr = calloc(nb_ctb + 1, 8);
+    d->dbf_bs2_hor = calloc(nb_ctb + 1, 8); d->dbf_bs2_hor_c = calloc(nb_ctb + 1, 8); d->dbf_affine = calloc(nb_ctb + 1, 8);
+    l->ibc_lines.mv = calloc((size_t)32 * n_in, sizeof(IBCMV)); l->ibc_lines.map = calloc(n_in, 4);
+    l->intra_luma_x = calloc(nb_pb2, 1);
+}
+
+static OVCTUDec *
+gp_new_ctudec(const struct gp_seq *s)
+{
+    OVCTUDec *c = NULL;
+    if (posix_memalign((void **)&c, 64, sizeof(*c))) abort();
+    memset(c, 0, sizeof(*c));
+    c->rcn_ctx.ctudec = c;
+    const int n_ctb = s->nb_ctb_w * s->nb_ctb_h;
+    /* ctudec_init_in_loop_filters (ctudec.c:104-150) allocates these on first use; rcn_init_lmcs (rcn_lmcs.c:347-349) likewise */
+    c->sao_info.sao_params = calloc(n_ctb, sizeof(SAOParamsCtu));
+    c->alf_info.ctb_alf_params = calloc(n_ctb, sizeof(ALFParamsCtu));
+    c->alf_info.ctb_cc_alf_filter_idx[0] = calloc(n_ctb, 1); c->alf_info.ctb_cc_alf_filter_idx[1] = calloc(n_ctb, 1);
+    c->lmcs_info.luts = calloc(1, sizeof(struct LMCSLUTs));
+    /* rcn_alloc_filter_buffers / rcn_alloc_intra_line_buff (rcn_ctu.c:512-551, :231-244; slicedec.c:1318-1323) */
+    struct OVFilterBuffers *fb = &c->rcn_ctx.filter_buffers;
+    const int margin = 3;
+    fb->margin = margin;
+    for (int comp = 0; comp < 3; ++comp) {
+        const int ratio = comp ? 2 : 1;
+        fb->filter_region_w[comp] = 128 / ratio; fb->filter_region_h[comp] = 128 / ratio;
+        fb->filter_region_stride[comp] = 128 / ratio + 2 * margin;
+        fb->filter_region_offset[comp] = margin * fb->filter_region_stride[comp] + margin;
+        fb->filter_region[comp] = calloc(fb->filter_region_stride[comp] * (fb->filter_region_h[comp] + 2 * margin + 1), sizeof(OVSample));
+        fb->saved_cols[comp] = calloc(fb->filter_region_h[comp] * margin, sizeof(OVSample));
+        fb->saved_rows_stride[comp] = s->nb_ctb_w * 128 / ratio;
+        fb->saved_rows_sao[comp] = calloc(margin * fb->saved_rows_stride[comp], sizeof(OVSample));
+        fb->saved_rows_alf[comp] = calloc(margin * fb->saved_rows_stride[comp], sizeof(OVSample));
+    }
+    struct OVBuffInfo *il = &c->rcn_ctx.intra_line_buff;
+    il->stride = (s->nb_ctb_w + 2) << 7; il->stride_c = il->stride >> 1;
+    il->y = calloc(il->stride, sizeof(OVSample)); il->cb = calloc(il->stride_c, sizeof(OVSample)); il->cr = calloc(il->stride_c, sizeof(OVSample));
+    c->prev_nb_ctu_w_rect_entry = s->nb_ctb_w;
+    return c;
+}
+
+/* ------------------------------------------------------------------------------------------------ the stream */
+#define GP_MAX_PIC 8
+struct gp_pic_desc { int poc, slice_type, qp, l0[2], n0, l1[2], n1, tmvp, col_from_l0, lmcs; };
+
+struct gp_out {
+    gbuf frames;                               /* uint16: every picture's y, cb, cr */
+    gbuf info;                                 /* int32 per picture: poc, slice type, qp, n0, l0[2], n1, l1[2], tmvp, first / end DMVR call */
+    struct shim_stream S;
+    gbuf sao, alf, tab[5], luts, offs, refmap, pflags;
+};
+
+static uint8_t *g_payload;
+#define GP_PAYLOAD (1 << 20)
+
+static void
+run_stream(struct gp_seq *s, const struct gp_pic_desc *desc, int n_pic, uint32_t seed, struct gp_out *out)
+{
+    OVPicture *pics[GP_MAX_PIC];
+    OVSliceDec sl;
+    memset(&sl, 0, sizeof(sl));
+    gp_alloc_lines(&sl, s);
+    OVCTUDec *c = gp_new_ctudec(s);
+    if (g_pass_shim) {
+        /* the entry exists once the table has been installed; bind a recorder to it (record-only: no device in this container) */
+        gp_rcn_init_functions(&c->rcn_funcs, 0, 1, 0, 1, 10);
+        c->part_ctx = &g_part;
+        ovhip_recorder *r = ovhip_rec_create(s->w, s->h);
+        if (!r || ovhip_shim_bind_recorder(c, r, s->w, s->h)) { fprintf(stderr, "gen_pipe: shim bind failed\n"); exit(1); }
+    }
+    for (int k = 0; k < n_pic; ++k) {
+        const struct gp_pic_desc *d = &desc[k];
+        g_seed = seed + 977 * k;
+        /* slice data: seeded bytes; the first byte keeps the arithmetic decoder's start condition (vcl_cabac.c:960) */
+        for (int i = 0; i < GP_PAYLOAD; ++i) g_payload[i] = (uint8_t)(rnd32() >> 7);
+        g_payload[0] &= 0x7f;
+        pics[k] = gp_new_picture(s, d->poc);
+        OVPicture *l0[2] = { d->n0 > 0 ? pics[d->l0[0]] : NULL, d->n0 > 1 ? pics[d->l0[1]] : NULL };
+        OVPicture *l1[2] = { d->n1 > 0 ? pics[d->l1[0]] : NULL, d->n1 > 1 ? pics[d->l1[1]] : NULL };
+        gp_set_refs(pics[k], l0, d->n0, l1, d->n1, d->tmvp, d->col_from_l0);
+        pic_headers(s, d->slice_type, d->qp, d->n0, d->n1, d->tmvp, d->col_from_l0, d->lmcs);
+        s->ps.ph = NULL; s->ps.sh = NULL;               /* new headers in the same structs */
+        if (decinit_update_params(&s->ps, &s->nvcl) < 0) { fprintf(stderr, "gen_pipe: decinit_update_params failed\n"); exit(1); }
+        s->ps.sh_info.rbsp_entry[0] = g_payload; s->ps.sh_info.rbsp_entry[1] = g_payload + GP_PAYLOAD;
+        sl.pic = pics[k]; sl.active_params = &s->ps; sl.slice_type = d->slice_type;
+        slicedec_init_lines(&sl, &s->ps);
+        slicedec_update_entry_decoder(&sl, c);
+        const size_t dm0 = g_pass_shim ? g_dmvr_pos : g_dmvr_log.n / 12;
+        slicedec_decode_rect_entry(&sl, c, &s->ps, 0);
+        ovdpb_report_decoded_frame(pics[k]);
+        const size_t dm1 = g_pass_shim ? g_dmvr_pos : g_dmvr_log.n / 12;
+        fprintf(stderr, "  picture %d: POC %d %s qp %d, %zu DMVR calls\n", k, d->poc, d->slice_type == 2 ? "I" : d->slice_type == 1 ? "P" : "B", d->qp, dm1 - dm0);
+        if (!g_pass_shim) {
+            const OVFrame *f = pics[k]->frame;
+            gbuf_push(&out->frames, f->data[0], (size_t)s->w * s->h);
+            gbuf_push(&out->frames, f->data[1], (size_t)s->w * s->h / 4);
+            gbuf_push(&out->frames, f->data[2], (size_t)s->w * s->h / 4);
+            int32_t info[14] = { d->poc, d->slice_type, d->qp, d->n0, d->l0[0], d->l0[1], d->n1, d->l1[0], d->l1[1], d->tmvp, (int32_t)dm0, (int32_t)dm1, d->lmcs, 0 };
+            gbuf_push(&out->info, info, 14);
+            continue;
+        }
+        /* shim pass: what the installed slots recorded for this picture */
+        if (ovhip_shim_last_error(c)) { fprintf(stderr, "gen_pipe: picture %d: the shim latched %d\n", k, ovhip_shim_last_error(c)); exit(1); }
+        size_t nc = 0, nt = 0;
+        const int n_ctb = s->nb_ctb_w * s->nb_ctb_h;
+        /* a picture without SAO / ALF: all-off parameters (the flush would get no table at all) */
+        const ovhip_sao_ctu *sp = ovhip_shim_sao_params(c, &nc);
+        if (sp && nc != (size_t)n_ctb) { fprintf(stderr, "gen_pipe: picture %d: SAO parameters of %zu CTUs\n", k, nc); exit(1); }
+        void *zero = calloc(n_ctb, sizeof(*sp) > sizeof(ovhip_alf_ctu) ? sizeof(*sp) : sizeof(ovhip_alf_ctu));
+        gbuf_push(&out->sao, sp ? (const void *)sp : zero, n_ctb * sizeof(*sp));
+        const ovhip_alf_ctu *ap = ovhip_shim_alf_params(c, &nc);
+        if (ap && nc != (size_t)n_ctb) { fprintf(stderr, "gen_pipe: picture %d: ALF parameters of %zu CTUs\n", k, nc); exit(1); }
+        gbuf_push(&out->alf, ap ? (const void *)ap : zero, n_ctb * sizeof(*ap));
+        free(zero);
+        for (int t = 0; t < 5; ++t) { const int16_t *tp = ovhip_shim_alf_table(c, t, &nt); gbuf_push(&out->tab[t], tp, nt); }
+        const ovhip_lmcs_luts *lu = ovhip_shim_lmcs(c);
+        ovhip_lmcs_luts none;
+        memset(&none, 0, sizeof(none));
+        gbuf_push(&out->luts, (d->lmcs && lu) ? lu : &none, sizeof(none));
+        ovhip_dbf_offsets offs;
+        size_t ne = 0;
+        (void)ovhip_rec_dbf_edges(ovhip_shim_recorder(c), 0, &ne, &offs);
+        gbuf_push(&out->offs, &offs, sizeof(offs));
+        const void *rp[16];
+        int32_t map[16];
+        const int np = ovhip_shim_ref_pictures(c, rp, 16);
+        for (int i = 0; i < 16; ++i) { map[i] = -1; for (int q = 0; i < np && q < k; ++q) if ((const void *)pics[q] == rp[i]) map[i] = q; }
+        gbuf_push(&out->refmap, map, 16);
+        int32_t pf[4] = { d->lmcs, np, c->lmcs_info.lmcs_enabled_flag, c->lmcs_info.scale_c_flag };
+        gbuf_push(&out->pflags, pf, 4);
+        shim_case_end(c, &out->S, "pipe picture");
+    }
+}
+
+int
+gp_main(int argc, char **argv)
+{
+    const char *dir = argc > 1 ? argv[1] : "../tests/golden";
+    int want_shim = 0, variant = 0, W = 416, H = 240, dqp = 0;
+    uint32_t seed = 0x266 + 31337;
+    const char *name = "pipe";
+    /* gen_pipe <dir> [shim] [name <fixture name>] [seed <n>] [variant <0|1>] [qp <delta on every picture's QP>] [size <w> <h>] */
+    for (int i = 2; i < argc; ++i) {
+        if (!strcmp(argv[i], "shim")) want_shim = 1;
+        else if (!strcmp(argv[i], "name") && i + 1 < argc) name = argv[++i];
+        else if (!strcmp(argv[i], "seed") && i + 1 < argc) seed = (uint32_t)strtoul(argv[++i], NULL, 0);
+        else if (!strcmp(argv[i], "variant") && i + 1 < argc) variant = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "qp") && i + 1 < argc) dqp = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "size") && i + 2 < argc) { W = atoi(argv[i + 1]); H = atoi(argv[i + 2]); i += 2; }
+        else { fprintf(stderr, "gen_pipe: unknown argument %s\n", argv[i]); return 2; }
+    }
+    if (W % 8 || H % 8 || W > 1024 || H > 1024) { fprintf(stderr, "gen_pipe: size\n"); return 2; }
+    if (posix_memalign((void **)&g_payload, 64, GP_PAYLOAD)) abort();
+    /* decoding order of a small hierarchical GOP: I0, B8 (two lists to the I picture), B4 (between them: DMVR / BDOF / SMVD
+     * have a past and a future reference, TMVP from B8), B2, P6 */
+    struct gp_pic_desc gop[5] = {
+        { .poc = 0, .slice_type = 2, .qp = 30, .lmcs = 1 },
+        { .poc = 8, .slice_type = 0, .qp = 33, .l0 = { 0 }, .n0 = 1, .l1 = { 0 }, .n1 = 1, .tmvp = 0, .col_from_l0 = 1, .lmcs = 1 },
+        { .poc = 4, .slice_type = 0, .qp = 35, .l0 = { 0, 1 }, .n0 = 2, .l1 = { 1, 0 }, .n1 = 2, .tmvp = 1, .col_from_l0 = 0, .lmcs = 1 },
+        { .poc = 2, .slice_type = 0, .qp = 37, .l0 = { 0, 2 }, .n0 = 2, .l1 = { 2, 1 }, .n1 = 2, .tmvp = 1, .col_from_l0 = 0, .lmcs = 0 },
+        { .poc = 6, .slice_type = 1, .qp = 37, .l0 = { 2, 0 }, .n0 = 2, .n1 = 0, .tmvp = 1, .col_from_l0 = 1, .lmcs = 1 },
+    };
+    const int n_pic = 5;
+    for (int k = 0; k < n_pic; ++k) gop[k].qp += dqp;
+    struct gp_out out;
+    memset(&out, 0, sizeof(out));
+    out.frames.type = T_U16; out.info.type = T_I32; out.sao.type = T_U8; out.alf.type = T_U8; out.luts.type = T_U8; out.offs.type = T_U8;
+    out.refmap.type = T_I32; out.pflags.type = T_I32;
+    for (int t = 0; t < 5; ++t) out.tab[t].type = T_I16;
+    shim_stream_init(&out.S);
+
+    struct gp_seq seq;
+    for (g_pass_shim = 0; g_pass_shim <= want_shim; ++g_pass_shim) {
+        g_seed = 0x266 + 4242;
+        seq_init(&seq, W, H, variant);
+        fprintf(stderr, "gen_pipe: %s pass\n", g_pass_shim ? "shim" : "reference");
+        run_stream(&seq, gop, n_pic, seed, &out);
+    }
+    if (g_isp_64x2) { fprintf(stderr, "gen_pipe: the stream holds %d 64x2 ISP partitions (reference result undefined): pick another seed\n", g_isp_64x2); return 1; }
+
+    if (!want_shim) {
+        char fn[256];
+        snprintf(fn, sizeof(fn), "%s.ovg", name);
+        gfile g = gfile_open(dir, fn);
+        uint32_t d2[2] = { (uint32_t)n_pic, 14 };
+        gfile_array(&g, "info", T_I32, out.info.data, 2, d2);
+        int32_t geo[4] = { W, H, n_pic, 7 };
+        uint32_t d1 = 4;
+        gfile_array(&g, "geometry", T_I32, geo, 1, &d1);
+        gfile_buf(&g, "frames", &out.frames);
+        d2[0] = (uint32_t)(g_dmvr_log.n / 12); d2[1] = 12;
+        gfile_array(&g, "dmvr", T_I32, g_dmvr_log.data ? g_dmvr_log.data : (const void *)"", 2, d2);
+        gfile_close(&g);
+        fprintf(stderr, "%s: %d pictures %dx%d, %u DMVR calls\n", fn, n_pic, W, H, d2[0]);
+        return 0;
+    }
+    /* shim_pipe.ovg: shim_stream_write's container (one case per picture) + the picture-level parameters the flush would take */
+    {
+        static const char *nm[SHIM_NARR] = { "tb", "coef", "mc", "mcx", "aff", "side", "region", "ciip", "edge_v", "edge_h", "itask" };
+        struct shim_stream *S = &out.S;
+        char fn[256];
+        snprintf(fn, sizeof(fn), "shim_%s.ovg", name);
+        gfile g = gfile_open(dir, fn);
+        uint32_t end[SHIM_NARR], d2[2];
+        for (int i = 0; i < SHIM_NARR; ++i) {
+            const size_t es = shim_elem(i) / g_tsize[S->arr[i].type];
+            end[i] = (uint32_t)(S->arr[i].n / es);
+            d2[0] = end[i]; d2[1] = (uint32_t)es;
+            gfile_array(&g, nm[i], S->arr[i].type, S->arr[i].data ? S->arr[i].data : (const void *)"", 2, d2);
+        }
+        gbuf_push(&S->off, end, SHIM_NARR);
+        d2[0] = S->n_cases + 1; d2[1] = SHIM_NARR;
+        gfile_array(&g, "case_off", T_U32, S->off.data, 2, d2);
+        const uint32_t n_ctb = (uint32_t)(seq.nb_ctb_w * seq.nb_ctb_h);
+        uint32_t d3[3] = { (uint32_t)n_pic, n_ctb, sizeof(ovhip_sao_ctu) };
+        gfile_array(&g, "sao", T_U8, out.sao.data, 3, d3);
+        d3[2] = sizeof(ovhip_alf_ctu);
+        gfile_array(&g, "alf_ctus", T_U8, out.alf.data, 3, d3);
+        static const char *tn[5] = { "luma_coeff", "luma_clip", "chroma_coeff", "chroma_clip", "cc_coeff" };
+        for (int t = 0; t < 5; ++t) { d2[0] = (uint32_t)n_pic; d2[1] = (uint32_t)(out.tab[t].n / n_pic); gfile_array(&g, tn[t], T_I16, out.tab[t].data, 2, d2); }
+        d2[0] = (uint32_t)n_pic; d2[1] = sizeof(ovhip_lmcs_luts); gfile_array(&g, "luts", T_U8, out.luts.data, 2, d2);
+        d2[1] = sizeof(ovhip_dbf_offsets);                        gfile_array(&g, "dbf_offsets", T_I8, out.offs.data, 2, d2);
+        d2[1] = 16;                                               gfile_array(&g, "ref_map", T_I32, out.refmap.data, 2, d2);
+        d2[1] = 4;                                                gfile_array(&g, "pic_flags", T_I32, out.pflags.data, 2, d2);
+        gfile_close(&g);
+        fprintf(stderr, "%s: %u pictures", fn, S->n_cases);
+        for (int i = 0; i < SHIM_NARR; ++i) if (end[i]) fprintf(stderr, ", %u %s", end[i], nm[i]);
+        fprintf(stderr, "\n");
+    }
+    return 0;
+}

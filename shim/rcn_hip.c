@@ -329,6 +329,19 @@ record_tu(struct hip_entry *e, OVCTUDec *c, int tree, int x0, int y0, int log2_w
     latch(e, ovhip_rec_tu_intra(e->rec, &st, &d, task_l, task_c), "ovhip_rec_tu_intra");
 }
 
+/* rcn_jcbcr (rcn_transform_tree.c:840-847): a joint Cb-Cr block with both cbf bits set is deblocked with the JOINT chroma QP --
+ * the scalar orchestrator overwrites the two chroma QP maps the caller filled (vcl_transform_unit.c:1110-1112) for the block's area
+ * (x0, y0, size in LUMA samples).  Found by the chained stream fixture (tests/golden/pipe_b.ovg: pps_cb_qp_offset != pps_cr_qp_offset). */
+static void
+jcbcr_qp_maps(OVCTUDec *c, int x0, int y0, int log2_w, int log2_h, uint8_t cbf_mask)
+{
+    if ((cbf_mask & 0x8) && (cbf_mask & 0x3) == 0x3) {
+        const uint8_t qp = (uint8_t)(c->dequant_joint_cb_cr.qp - c->qp_ctx.qp_bd_offset);
+        dbf_fill_qp_map(&c->dbf_info.qp_map_cb, x0, y0, log2_w, log2_h, qp);
+        dbf_fill_qp_map(&c->dbf_info.qp_map_cr, x0, y0, log2_w, log2_h, qp);
+    }
+}
+
 /* rcn_tu_st (rcn_transform_tree.c:1228-1301) with the luma task rcn_intra_tu made before it (or a CIIP CU's two tasks) */
 static void
 tu_st_common(struct hip_entry *e, OVCTUDec *c, int x0, int y0, int log2_tb_w, int log2_tb_h, CUFlags cu_flags, uint8_t cbf_mask,
@@ -361,6 +374,7 @@ tu_st_common(struct hip_entry *e, OVCTUDec *c, int x0, int y0, int log2_tb_w, in
     }
     fill_ctb_bound(&c->dbf_info, x0, y0, log2_tb_w, log2_tb_h);
     fill_ctb_bound_c(&c->dbf_info, x0, y0, log2_tb_w, log2_tb_h);
+    jcbcr_qp_maps(c, x0, y0, log2_tb_w, log2_tb_h, cbf_mask);
 }
 
 /* tmp.rcn_tu_st (rcn_structures.h:481-486): called through the table by the SBT paths (vcl_transform_unit.c:1113-1299) */
@@ -395,6 +409,7 @@ hip_rcn_tu_c(OVCTUDec *const c, uint8_t x0, uint8_t y0, uint8_t log2_tb_w, uint8
             if (cbf_mask & 0x1) fill_bs_map(&c->dbf_info.bs1_map_cr, x0 << 1, y0 << 1, log2_tb_w + 1, log2_tb_h + 1);
         }
     }
+    jcbcr_qp_maps(c, x0 << 1, y0 << 1, log2_tb_w + 1, log2_tb_h + 1, cbf_mask);
 }
 
 /* tmp.rcn_transform_tree (rcn_structures.h:464-468; rcn_transform_tree.c:1454-1518): the walker calls its leaves

@@ -23,7 +23,7 @@ class ShimStream:
         self.arr = {k: np.frombuffer(np.ascontiguousarray(g[k]).tobytes(), dtype=DTYPES[k]) for k in ARRAYS}
         self.off = g["case_off"]
         self.n = self.off.shape[0] - 1
-        self.ref_map = [int(v) for v in g["ref_map"]] if "ref_map" in g else []
+        self.ref_map = [int(v) for v in g["ref_map"]] if "ref_map" in g and g["ref_map"].ndim == 1 else []
 
     def case(self, i: int) -> dict:
         """The arrays the slots recorded for case i (offsets inside them are relative to the case)."""

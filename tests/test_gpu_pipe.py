@@ -1,0 +1,93 @@
+"""GPU: the chained streams the reference's slice decoder produced (tests/golden/pipe*.ovg, test_pipe_cpu.py) through the HIP
+engine and the C ABI: every picture decoded on the device FROM THE DEVICE'S OWN earlier pictures must equal the reference's frame
+byte for byte; DMVR's refined vectors must equal what rcn_dmvr_mv_refine returned."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import pipe_cases
+from openvvc_amd import capi, engine
+
+pytestmark = pytest.mark.gpu
+STREAMS = ("pipe", "pipe_b")
+
+
+def _load(rec, lib, wl):
+    """a recorded picture into a (job's / frame's) recorder: what Job.load_workload does after its begin"""
+    for which, arr in ((capi.REC_COEF, wl.coefs), (capi.REC_TB, wl.tb_cmds), (capi.REC_MC, wl.mc_units), (capi.REC_MCX, wl.mcx_units),
+                       (capi.REC_AFF, wl.aff_units), (capi.REC_SIDE, wl.aff_side), (capi.REC_REGION, wl.lmcs_regions),
+                       (capi.REC_CIIP, wl.ciip_units), (capi.REC_ITASK, wl.itasks), (capi.REC_EDGE_V, wl.dbf_edges[0]), (capi.REC_EDGE_H, wl.dbf_edges[1])):
+        if arr is not None and len(arr):
+            rec.append_raw(which, arr)
+    offs = capi.DbfOffsets()
+    for i in range(8):
+        offs.beta[i], offs.tc[i] = wl.dbf_planes["beta_offset"], wl.dbf_planes["tc_offset"]
+    assert lib.ovhip_rec_set_dbf_offsets(rec.h, C.byref(offs), 1) == 0
+
+
+class _Keep:
+    def __init__(self):
+        self._keep = {}
+
+
+def _check(name, k, got, P, mvs, wl):
+    for plane, a, b in zip("Y Cb Cr".split(), got, P.frames[k]):
+        assert np.array_equal(a, b), f"{name} picture {k} plane {plane}: {int((a != b).sum())} samples differ from the reference"
+    calls = P.dmvr_calls(k)
+    is_dmvr = (wl.mcx_units["flags"] & 64) != 0
+    assert is_dmvr.sum() == len(calls)
+    if len(calls):
+        assert np.array_equal(mvs[is_dmvr], calls[:, 8:12]), f"{name} picture {k}: refined vectors differ from rcn_dmvr_mv_refine's"
+
+
+@pytest.mark.parametrize("name", STREAMS)
+def test_job_chain_on_the_device_equals_the_reference_slice_decoder(built_lib, name):
+    """ovhip_job_flush per picture; the reference pictures are the device pictures of the jobs before"""
+    P = pipe_cases.Pipe(name)
+    ctx = engine.Context(0)
+    dev, host = {}, {}
+    for k in range(P.n):
+        wl = P.workload(k, {i: None for i in range(k)})          # (the references are bound on the device below)
+        job = engine.Job(ctx, P.w, P.h)
+        job.begin()
+        _load(job.rec, job.lib, wl)
+        dst = ctx.new_pic(P.w, P.h)
+        job.flush(dst, [dev[i] for i in P.ref_indices(k)], None, params=job.make_params(wl))
+        job.wait()
+        host[k] = dst.download()
+        _check(name, k, host[k], P, job.refined_mvs(), wl)
+        assert job.stats().n_ordered_retries == 0
+        dev[k] = dst
+        job.close()
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", STREAMS)
+def test_frame_api_chain_equals_the_reference_slice_decoder(built_lib, name):
+    """the calls shim/rcn_hip.c makes per picture (ovhip_frame_begin / _ref / recorder / _dmvr_rows_* / _submit) on two frame
+    objects taking the pictures in turn; references come out of the device DPB by key; eager DMVR rows before the submit"""
+    P = pipe_cases.Pipe(name)
+    dpb = engine.Dpb((0,))
+    frames = [engine.Frame(dpb, 0, P.w, P.h), engine.Frame(dpb, 0, P.w, P.h)]
+    key = lambda k: 0xF000 + 16 * k
+    for k in range(P.n):
+        f = frames[k & 1]
+        wl = P.workload(k, {i: None for i in range(k)})
+        f.begin(key(k))
+        for slot, i in enumerate(P.ref_indices(k)):
+            assert f.ref(key(i)) == slot
+        rec = f.recorder()
+        _load(rec, f.lib, wl)
+        if len(wl.mcx_units):
+            assert f.dmvr_rows_begin(P.log2_ctu) == len(wl.mcx_units)
+            assert f.dmvr_rows_collect() == len(wl.mcx_units)
+        keep = _Keep()
+        out = capi.FrameOutput()
+        y, cb, cr = np.zeros((P.h, P.w), np.uint16), np.zeros((P.h // 2, P.w // 2), np.uint16), np.zeros((P.h // 2, P.w // 2), np.uint16)
+        out.mode, out.y, out.cb, out.cr, out.stride_y, out.stride_c = capi.OUT_PLANES, y.ctypes.data, cb.ctypes.data, cr.ctypes.data, P.w, P.w // 2
+        f.submit(engine.Job.make_params(keep, wl), out=out)
+        _check(name, k, (y, cb, cr), P, f.job().refined_mvs(), wl)
+    for f in frames:
+        f.close()
+    dpb.close()
