@@ -1048,6 +1048,14 @@ int  ovhip_dpb_n_devices(const ovhip_dpb *d);
 int  ovhip_dpb_device(const ovhip_dpb *d, int dev);                 /* HIP ordinal of logical device dev, <0 if none     */
 int  ovhip_dpb_begin(ovhip_dpb *d, const void *key, int dev, int32_t w, int32_t h, ovhip_pic *pic);
 int  ovhip_dpb_want(ovhip_dpb *d, const void *key, int dev);
+/* The same with the caller's picture identity (`tag`, 0 = none; the shim: coded video sequence + POC of the OVPicture).  The frame
+ * pool recycles OVFrame pointers and frame threads run on their own: a reader can ask for key F while F's slot still holds the
+ * PREVIOUS picture that lived in F (DONE), because the thread decoding the new one has not reached rcn_attach_frame_buff yet.  With
+ * tags, a slot whose tag differs from the reader's is "not begun yet": ovhip_dpb_acquire_tag waits for the right picture (bounded
+ * like an unknown key), ovhip_dpb_want_tag is remembered until ovhip_dpb_begin_tag(key, tag) picks it up. */
+int  ovhip_dpb_begin_tag(ovhip_dpb *d, const void *key, uint64_t tag, int dev, int32_t w, int32_t h, ovhip_pic *pic);
+int  ovhip_dpb_want_tag(ovhip_dpb *d, const void *key, uint64_t tag, int dev);
+int  ovhip_dpb_acquire_tag(ovhip_dpb *d, const void *key, uint64_t tag, int dev, ovhip_pic *pic, void **event);
 /* status 0: DONE, else FAILED (latched error of the producer): every exit path of a producer publishes */
 int  ovhip_dpb_publish(ovhip_dpb *d, const void *key, int status);
 /* *event (may be NULL when dev is the home device): a copy_wait handle the caller waits for before it reads pic, or NULL.
@@ -1103,6 +1111,8 @@ ovhip_job      *ovhip_frame_job(ovhip_frame *f);
 ovhip_recorder *ovhip_frame_recorder(ovhip_frame *f);
 int  ovhip_frame_begin(ovhip_frame *f, const void *key);
 int  ovhip_frame_ref(ovhip_frame *f, const void *ref_key);          /* index (0..15) or <0 */
+int  ovhip_frame_begin_tag(ovhip_frame *f, const void *key, uint64_t tag);       /* with the picture identity: ovhip_dpb_begin_tag */
+int  ovhip_frame_ref_tag(ovhip_frame *f, const void *ref_key, uint64_t tag);
 /* Same without the search for an existing entry: the table entry `slot` (= the number of entries so far) is ref_key, which may
  * already sit in another entry (a recorded picture whose units index a fixed table). */
 int  ovhip_frame_ref_at(ovhip_frame *f, int slot, const void *ref_key);

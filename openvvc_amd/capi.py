@@ -483,6 +483,9 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_dpb_device": (C.c_int, [vp, C.c_int]),
         "ovhip_dpb_begin": (C.c_int, [vp, vp, C.c_int, i32, i32, P(Pic)]),
         "ovhip_dpb_want": (C.c_int, [vp, vp, C.c_int]),
+        "ovhip_dpb_begin_tag": (C.c_int, [vp, vp, C.c_uint64, C.c_int, i32, i32, P(Pic)]),
+        "ovhip_dpb_want_tag": (C.c_int, [vp, vp, C.c_uint64, C.c_int]),
+        "ovhip_dpb_acquire_tag": (C.c_int, [vp, vp, C.c_uint64, C.c_int, P(Pic), P(vp)]),
         "ovhip_dpb_publish": (C.c_int, [vp, vp, C.c_int]),
         "ovhip_dpb_acquire": (C.c_int, [vp, vp, C.c_int, P(Pic), P(vp)]),
         "ovhip_dpb_wait_copy": (C.c_int, [vp, C.c_int, vp]),
@@ -501,6 +504,8 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_frame_recorder": (vp, [vp]),
         "ovhip_frame_begin": (C.c_int, [vp, vp]),
         "ovhip_frame_ref": (C.c_int, [vp, vp]),
+        "ovhip_frame_begin_tag": (C.c_int, [vp, vp, C.c_uint64]),
+        "ovhip_frame_ref_tag": (C.c_int, [vp, vp, C.c_uint64]),
         "ovhip_frame_ref_at": (C.c_int, [vp, C.c_int, vp]),
         "ovhip_frame_dmvr_rows": (C.c_int64, [vp]),
         "ovhip_frame_dmvr_rows_begin": (C.c_int64, [vp, i32]),
@@ -546,7 +551,7 @@ EXPORTED_SYMBOLS = [
     "ovhip_host_alloc", "ovhip_host_free", "ovhip_d2d", "ovhip_job_test_abort_next_flow",
     "ovhip_dpb_create", "ovhip_dpb_create_ex", "ovhip_dpb_destroy", "ovhip_dpb_n_devices", "ovhip_dpb_device", "ovhip_dpb_begin", "ovhip_dpb_want",
     "ovhip_dpb_publish", "ovhip_dpb_acquire", "ovhip_dpb_wait_copy", "ovhip_dpb_set_unknown_key_timeout", "ovhip_dpb_unpin", "ovhip_dpb_release", "ovhip_dpb_lookup", "ovhip_dpb_shutdown",
-    "ovhip_dpb_get_stats",
+    "ovhip_dpb_get_stats", "ovhip_dpb_begin_tag", "ovhip_dpb_want_tag", "ovhip_dpb_acquire_tag", "ovhip_frame_begin_tag", "ovhip_frame_ref_tag",
     "ovhip_frame_create", "ovhip_frame_create_ex", "ovhip_ctx_create_prio", "ovhip_frame_destroy", "ovhip_frame_ctx", "ovhip_frame_job", "ovhip_frame_recorder", "ovhip_frame_begin", "ovhip_frame_ref",
     "ovhip_frame_ref_at", "ovhip_frame_dmvr_rows", "ovhip_frame_dmvr_rows_begin", "ovhip_frame_dmvr_rows_collect", "ovhip_frame_submit", "ovhip_frame_fail", "ovhip_frame_last_error",
     "ovhip_calllog_create", "ovhip_calllog_destroy", "ovhip_calllog_reset", "ovhip_calllog_data", "ovhip_rec_set_calllog", "ovhip_calllog_replay",

@@ -31,6 +31,7 @@ struct dpb_slot {
     int pins, released;
     uint32_t want;
     uint64_t serial;
+    uint64_t tag;                         /* caller's picture identity (0: none): a recycled key with another tag is another picture */
     struct dpb_copy copy[OVHIP_MAX_DEVICES];
 };
 
@@ -48,6 +49,7 @@ struct ovhip_dpb {
     int shutdown;
     int unknown_ms;                       /* how long ovhip_dpb_acquire waits for a key nobody has begun yet */
     uint64_t serial;
+    struct { const void *key; uint64_t tag; uint32_t devs; } pend[64]; int n_pend;      /* wants for pictures nobody has begun yet */
     ovhip_dpb_stats st;
 };
 
@@ -96,6 +98,16 @@ find(ovhip_dpb *d, const void *key)
     for (size_t i = 0; i < d->n_slots; ++i)
         if (d->slots[i].state != S_FREE && d->slots[i].key == key) return &d->slots[i];
     return NULL;
+}
+
+/* The reader names the PICTURE it means (tag != 0): a slot that holds the key for another picture -- the frame pool handed the
+ * OVFrame to a new picture whose frame thread has not begun it yet, and the slot still shows the previous, DONE picture -- is
+ * "not there yet", exactly like an unknown key (predicting from the stale picture was silent). */
+static struct dpb_slot *
+find_tag(ovhip_dpb *d, const void *key, uint64_t tag)
+{
+    struct dpb_slot *s = find(d, key);
+    return s && tag && s->tag && s->tag != tag ? NULL : s;
 }
 
 /* the slot's pictures go back to the pools (mutex held; nobody has it pinned) */
@@ -193,8 +205,10 @@ ovhip_dpb_destroy(ovhip_dpb *d)
 int ovhip_dpb_n_devices(const ovhip_dpb *d) { return d ? d->n_dev : 0; }
 int ovhip_dpb_device(const ovhip_dpb *d, int dev) { return d && dev >= 0 && dev < d->n_dev ? d->hipdev[dev] : -1; }
 
+int ovhip_dpb_begin(ovhip_dpb *d, const void *key, int dev, int32_t w, int32_t h, ovhip_pic *pic) { return ovhip_dpb_begin_tag(d, key, 0, dev, w, h, pic); }
+
 int
-ovhip_dpb_begin(ovhip_dpb *d, const void *key, int dev, int32_t w, int32_t h, ovhip_pic *pic)
+ovhip_dpb_begin_tag(ovhip_dpb *d, const void *key, uint64_t tag, int dev, int32_t w, int32_t h, ovhip_pic *pic)
 {
     if (!d || !key || !pic || dev < 0 || dev >= d->n_dev || w <= 0 || h <= 0) return OVHIP_EINVAL;
     int r = OVHIP_OK;
@@ -217,7 +231,14 @@ ovhip_dpb_begin(ovhip_dpb *d, const void *key, int dev, int32_t w, int32_t h, ov
     memset(s, 0, sizeof(*s));
     r = pool_pop(d, dev, w, h, &s->pic);
     if (r == OVHIP_OK) {
-        s->key = key; s->state = S_DECODING; s->home = dev; s->w = w; s->h = h; s->serial = ++d->serial;
+        s->key = key; s->tag = tag; s->state = S_DECODING; s->home = dev; s->w = w; s->h = h; s->serial = ++d->serial;
+        /* devices that asked for this picture before it existed */
+        for (int i = 0; i < d->n_pend;) {
+            if (d->pend[i].key == key && (!tag || !d->pend[i].tag || d->pend[i].tag == tag)) {
+                s->want |= d->pend[i].devs & ~(1u << dev);
+                d->pend[i] = d->pend[--d->n_pend];
+            } else ++i;
+        }
         *pic = s->pic;
         d->st.n_live++; d->st.n_begin++;
         pthread_cond_broadcast(&d->cnd);                 /* a reader may already be waiting for this key to appear */
@@ -226,14 +247,22 @@ ovhip_dpb_begin(ovhip_dpb *d, const void *key, int dev, int32_t w, int32_t h, ov
     return r;
 }
 
+int ovhip_dpb_want(ovhip_dpb *d, const void *key, int dev) { return ovhip_dpb_want_tag(d, key, 0, dev); }
+
 int
-ovhip_dpb_want(ovhip_dpb *d, const void *key, int dev)
+ovhip_dpb_want_tag(ovhip_dpb *d, const void *key, uint64_t tag, int dev)
 {
     if (!d || !key || dev < 0 || dev >= d->n_dev) return OVHIP_EINVAL;
     int r = OVHIP_OK;
     pthread_mutex_lock(&d->mtx);
-    struct dpb_slot *s = find(d, key);
-    if (!s) r = OVHIP_EINVAL;
+    struct dpb_slot *s = find_tag(d, key, tag);
+    if (!s) {
+        /* not begun yet (its frame thread is behind): remembered, ovhip_dpb_begin picks it up (the request was lost) */
+        int i = 0;
+        while (i < d->n_pend && !(d->pend[i].key == key && d->pend[i].tag == tag)) ++i;
+        if (i == d->n_pend && d->n_pend < 64) { d->pend[i].key = key; d->pend[i].tag = tag; d->pend[i].devs = 0; d->n_pend++; }
+        if (i < d->n_pend) d->pend[i].devs |= 1u << dev; else r = OVHIP_EINVAL;
+    }
     else if (dev != s->home) {
         s->want |= 1u << dev;
         if (s->state == S_DONE) r = start_copy(d, s, dev);
@@ -264,14 +293,16 @@ ovhip_dpb_publish(ovhip_dpb *d, const void *key, int status)
     return r;
 }
 
+int ovhip_dpb_acquire(ovhip_dpb *d, const void *key, int dev, ovhip_pic *pic, void **event) { return ovhip_dpb_acquire_tag(d, key, 0, dev, pic, event); }
+
 int
-ovhip_dpb_acquire(ovhip_dpb *d, const void *key, int dev, ovhip_pic *pic, void **event)
+ovhip_dpb_acquire_tag(ovhip_dpb *d, const void *key, uint64_t tag, int dev, ovhip_pic *pic, void **event)
 {
     if (!d || !key || !pic || dev < 0 || dev >= d->n_dev) return OVHIP_EINVAL;
     if (event) *event = NULL;
     int r = OVHIP_OK;
     pthread_mutex_lock(&d->mtx);
-    struct dpb_slot *s = find(d, key);
+    struct dpb_slot *s = find_tag(d, key, tag);
     int waited = 0;
     if (!s && d->unknown_ms > 0) {
         /* Frame threads start in decoding order but run on their own: a reader can get here before the thread that decodes its
@@ -282,8 +313,8 @@ ovhip_dpb_acquire(ovhip_dpb *d, const void *key, int dev, ovhip_pic *pic, void *
         if (until.tv_nsec >= 1000000000L) { until.tv_sec++; until.tv_nsec -= 1000000000L; }
         while (!s && !d->shutdown) {
             waited = 1;
-            if (pthread_cond_timedwait(&d->cnd, &d->mtx, &until) == ETIMEDOUT) { s = find(d, key); break; }
-            s = find(d, key);
+            if (pthread_cond_timedwait(&d->cnd, &d->mtx, &until) == ETIMEDOUT) { s = find_tag(d, key, tag); break; }
+            s = find_tag(d, key, tag);
         }
     }
     if (!s) { d->st.n_waits += waited; pthread_mutex_unlock(&d->mtx); return d->shutdown ? OVHIP_EREF : OVHIP_EINVAL; }

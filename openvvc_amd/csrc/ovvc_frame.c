@@ -24,7 +24,7 @@ struct ovhip_frame {
     ovhip_ctx *ctx;
     ovhip_job *job;                       /* own job, created on first use */
     const void *key; ovhip_pic dst; int live;
-    const void *ref_key[MAX_REFS]; ovhip_pic ref_pic[MAX_REFS]; void *ref_ev[MAX_REFS]; unsigned char ref_pinned[MAX_REFS];
+    const void *ref_key[MAX_REFS]; uint64_t ref_tag[MAX_REFS]; ovhip_pic ref_pic[MAX_REFS]; void *ref_ev[MAX_REFS]; unsigned char ref_pinned[MAX_REFS];
     int n_refs;
     int status;
     char err[192];
@@ -88,14 +88,16 @@ ovhip_frame_job(ovhip_frame *f)
 ovhip_recorder *ovhip_frame_recorder(ovhip_frame *f) { ovhip_job *j = ovhip_frame_job(f); return j ? ovhip_job_recorder(j) : NULL; }
 const char *ovhip_frame_last_error(const ovhip_frame *f) { return f ? f->err : "no frame"; }
 
+int ovhip_frame_begin(ovhip_frame *f, const void *key) { return ovhip_frame_begin_tag(f, key, 0); }
+
 int
-ovhip_frame_begin(ovhip_frame *f, const void *key)
+ovhip_frame_begin_tag(ovhip_frame *f, const void *key, uint64_t tag)
 {
     if (!f || !key) return OVHIP_EINVAL;
     /* a picture that was begun and never submitted must not leave its readers waiting */
     if (f->live) (void)ovhip_frame_fail(f, OVHIP_EINVAL);
     f->status = 0; f->err[0] = 0; f->n_refs = 0;
-    int r = ovhip_dpb_begin(f->dpb, key, f->dev, f->w, f->h, &f->dst);
+    int r = ovhip_dpb_begin_tag(f->dpb, key, tag, f->dev, f->w, f->h, &f->dst);
     if (r != OVHIP_OK) return fail(f, r, "ovhip_dpb_begin");
     f->key = key; f->live = 1;
     if (f->job) {
@@ -105,17 +107,19 @@ ovhip_frame_begin(ovhip_frame *f, const void *key)
     return OVHIP_OK;
 }
 
+int ovhip_frame_ref(ovhip_frame *f, const void *ref_key) { return ovhip_frame_ref_tag(f, ref_key, 0); }
+
 int
-ovhip_frame_ref(ovhip_frame *f, const void *ref_key)
+ovhip_frame_ref_tag(ovhip_frame *f, const void *ref_key, uint64_t tag)
 {
     if (!f || !ref_key || !f->live) return OVHIP_EINVAL;
     for (int i = 0; i < f->n_refs; ++i) if (f->ref_key[i] == ref_key) return i;
     if (f->n_refs >= MAX_REFS) return fail(f, OVHIP_EUNSUP, "more than 16 distinct reference pictures");
     const int i = f->n_refs++;
-    f->ref_key[i] = ref_key; f->ref_pinned[i] = 0; f->ref_ev[i] = NULL;
+    f->ref_key[i] = ref_key; f->ref_tag[i] = tag; f->ref_pinned[i] = 0; f->ref_ev[i] = NULL;
     memset(&f->ref_pic[i], 0, sizeof(f->ref_pic[i]));
     /* as soon as the reference lists are known: a picture decoded on another device is pushed here when it is done */
-    (void)ovhip_dpb_want(f->dpb, ref_key, f->dev);
+    (void)ovhip_dpb_want_tag(f->dpb, ref_key, tag, f->dev);
     return i;
 }
 
@@ -125,7 +129,7 @@ ovhip_frame_ref_at(ovhip_frame *f, int slot, const void *ref_key)
     if (!f || !ref_key || !f->live || slot != f->n_refs) return OVHIP_EINVAL;
     if (f->n_refs >= MAX_REFS) return fail(f, OVHIP_EUNSUP, "more than 16 reference table entries");
     f->n_refs++;
-    f->ref_key[slot] = ref_key; f->ref_pinned[slot] = 0; f->ref_ev[slot] = NULL;
+    f->ref_key[slot] = ref_key; f->ref_tag[slot] = 0; f->ref_pinned[slot] = 0; f->ref_ev[slot] = NULL;
     memset(&f->ref_pic[slot], 0, sizeof(f->ref_pic[slot]));
     (void)ovhip_dpb_want(f->dpb, ref_key, f->dev);
     return slot;
@@ -137,7 +141,7 @@ acquire_refs(ovhip_frame *f)
 {
     for (int i = 0; i < f->n_refs; ++i) {
         if (f->ref_pinned[i]) continue;
-        int r = ovhip_dpb_acquire(f->dpb, f->ref_key[i], f->dev, &f->ref_pic[i], &f->ref_ev[i]);
+        int r = ovhip_dpb_acquire_tag(f->dpb, f->ref_key[i], f->ref_tag[i], f->dev, &f->ref_pic[i], &f->ref_ev[i]);
         if (r != OVHIP_OK) return fail(f, r, r == OVHIP_EREF ? "a reference picture failed to decode" : "reference picture unknown to the device DPB");
         f->ref_pinned[i] = 1;
     }

@@ -575,9 +575,9 @@ class Dpb:
         self.lib.ovhip_dpb_get_stats(self.h, C.byref(st))
         return st
 
-    def begin(self, key: int, dev: int, w: int, h: int) -> "capi.Pic":
+    def begin(self, key: int, dev: int, w: int, h: int, tag: int = 0) -> "capi.Pic":
         pic = capi.Pic()
-        r = self.lib.ovhip_dpb_begin(self.h, C.c_void_p(key), dev, w, h, C.byref(pic))
+        r = self.lib.ovhip_dpb_begin_tag(self.h, C.c_void_p(key), tag, dev, w, h, C.byref(pic))
         if r != 0:
             raise EngineError(f"ovhip_dpb_begin: {r}")
         return pic
@@ -611,11 +611,11 @@ class Frame:
             self.lib.ovhip_frame_destroy(self.f)
             self.f = None
 
-    def begin(self, key: int):
-        self._chk(self.lib.ovhip_frame_begin(self.f, C.c_void_p(key)), "frame_begin")
+    def begin(self, key: int, tag: int = 0):
+        self._chk(self.lib.ovhip_frame_begin_tag(self.f, C.c_void_p(key), tag), "frame_begin")
 
-    def ref(self, key: int) -> int:
-        return self._chk(self.lib.ovhip_frame_ref(self.f, C.c_void_p(key)), "frame_ref")
+    def ref(self, key: int, tag: int = 0) -> int:
+        return self._chk(self.lib.ovhip_frame_ref_tag(self.f, C.c_void_p(key), tag), "frame_ref")
 
     def ref_at(self, slot: int, key: int) -> int:
         return self._chk(self.lib.ovhip_frame_ref_at(self.f, slot, C.c_void_p(key)), "frame_ref_at")

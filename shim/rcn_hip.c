@@ -28,6 +28,7 @@
 #include "dbf_utils.h"
 #include "slicedec.h"
 #include "nvcl_structures.h"
+#include "ovdec_internal.h"          /* struct MVPlane */
 #include "ovlog.h"
 
 #include "ovvc_hip.h"
@@ -152,6 +153,10 @@ latch(struct hip_entry *e, int code, const char *what)
 static inline OVCTUDec *ctudec_of_lmcs(struct LMCSInfo *li) { return (OVCTUDec *)((char *)li - offsetof(OVCTUDec, lmcs_info)); }
 
 /* ------------------------------------------------------------------------------------ helpers */
+/* Identity of a picture for the device DPB, beside its OVFrame pointer (which the frame pool hands to one picture after another):
+ * coded video sequence + picture order count, never 0 (include/ovvc_hip.h, ovhip_dpb_begin_tag) */
+static inline uint64_t pic_tag(const OVPicture *p) { return (((uint64_t)p->cvs_id << 32) | (uint32_t)p->poc) + 1; }
+
 static int
 ref_slot(struct hip_entry *e, const OVPicture *p)
 {
@@ -160,7 +165,7 @@ ref_slot(struct hip_entry *e, const OVPicture *p)
     e->refs[e->n_refs] = p;
     /* the frame thread keeps the same table (order of first use), keyed by the OVFrame: the device DPB hands the picture over */
     if (e->fr && !e->record_only) {
-        const int k = ovhip_frame_ref(e->fr, p->frame);
+        const int k = ovhip_frame_ref_tag(e->fr, p->frame, pic_tag(p));
         if (k != e->n_refs) latch(e, k < 0 ? k : OVHIP_EINVAL, "ovhip_frame_ref");
     }
     return e->n_refs++;
@@ -1152,7 +1157,9 @@ dpb_get(struct hip_entry *e)
 void ovhip_shim_set_output(int mode) { g_out_mode = mode == OVHIP_OUT_NONE ? OVHIP_OUT_NONE : OVHIP_OUT_PLANES; }
 
 /* The host DPB dropped its last reference to the frame (ovframe_unref reaching zero): the device picture goes back to the pool.
- * Optional -- a frame pointer that comes back for a new picture is recycled implicitly -- but it frees device memory earlier. */
+ * Frees device memory earlier; not needed for correctness -- a frame pointer that comes back for a new picture recycles its slot,
+ * and readers name the picture they mean by its tag (pic_tag above), so a slot that still shows the previous owner of the
+ * OVFrame is waited past, never read. */
 void ovhip_shim_frame_released(const OVFrame *frame) { if (g_dpb && frame) (void)ovhip_dpb_release(g_dpb, frame); }
 
 /* Output path: what examples/dectest.c:372-409 (write_decoded_frame_to_file) copies out of the OVFrame plane by plane, taken
@@ -1272,7 +1279,11 @@ begin_picture(struct hip_entry *e, const OVFrame *f, const struct RectEntryInfo 
         r = ovhip_frame_create(g_dpb, e->dev, e->pic_w, e->pic_h, &e->fr);
         if (r != OVHIP_OK) { e->fr = NULL; latch(e, r, "ovhip_frame_create"); return; }
     }
-    latch(e, ovhip_frame_begin(e->fr, f), "ovhip_frame_begin");
+    /* the OVPicture being decoded: tmvp_entry_init (slicedec.c:1085-1099, called before rcn_attach_frame_buff) left pointers to its
+     * motion planes in the CTU decoder -- the table's prototypes never hand the picture itself over */
+    const struct MVPlane *pl0 = e->key->drv_ctx.inter_ctx.tmvp_ctx.plane0;
+    const OVPicture *cur = pl0 ? (const OVPicture *)((const char *)pl0 - offsetof(OVPicture, mv_plane0)) : NULL;
+    latch(e, ovhip_frame_begin_tag(e->fr, f, cur && cur->frame == f ? pic_tag(cur) : 0), "ovhip_frame_begin");
     e->rec = ovhip_frame_recorder(e->fr);
     if (!e->rec) { latch(e, OVHIP_ENOMEM, "ovhip_frame_recorder"); return; }
     (void)ovhip_rec_set_ctu_size(e->rec, e->key->part_ctx ? e->key->part_ctx->log2_ctu_s : 7);
@@ -1280,8 +1291,8 @@ begin_picture(struct hip_entry *e, const OVFrame *f, const struct RectEntryInfo 
      * the first prediction unit is parsed */
     const struct InterDRVCtx *ic = &e->key->drv_ctx.inter_ctx;
     if (g_n_dev > 1 && e->key->tmp_slice_type != 2) {
-        for (int i = 0; i < ic->nb_active_ref0 && i < 16; ++i) if (ic->rpl0[i] && ic->rpl0[i]->frame) (void)ovhip_dpb_want(g_dpb, ic->rpl0[i]->frame, e->dev);
-        for (int i = 0; i < ic->nb_active_ref1 && i < 16; ++i) if (ic->rpl1[i] && ic->rpl1[i]->frame) (void)ovhip_dpb_want(g_dpb, ic->rpl1[i]->frame, e->dev);
+        for (int i = 0; i < ic->nb_active_ref0 && i < 16; ++i) if (ic->rpl0[i] && ic->rpl0[i]->frame) (void)ovhip_dpb_want_tag(g_dpb, ic->rpl0[i]->frame, pic_tag(ic->rpl0[i]), e->dev);
+        for (int i = 0; i < ic->nb_active_ref1 && i < 16; ++i) if (ic->rpl1[i] && ic->rpl1[i]->frame) (void)ovhip_dpb_want_tag(g_dpb, ic->rpl1[i]->frame, pic_tag(ic->rpl1[i]), e->dev);
     }
 }
 

@@ -308,3 +308,45 @@ def test_gop_of_readers_and_writers_under_threads(dpb):
     assert not errs, errs[0]
     st = _stats(lib, h)
     assert st.n_begin == len(pics) and st.n_live == 0 and st.n_copies > 0
+
+
+def test_recycled_key_is_not_mistaken_for_the_new_picture(dpb):
+    """ The frame pool hands OVFrame F to a new picture while F's slot still shows the previous, DONE picture; the reader
+    of the NEW picture arrives before its frame thread has begun it.  With the picture's tag the reader waits for the right picture
+    instead of predicting from the stale one; without a tag the old behaviour (any picture under the key) is kept."""
+    lib, h, mem = dpb
+    F = 0x51
+    pic = capi.Pic()
+    assert lib.ovhip_dpb_begin_tag(h, C.c_void_p(F), 1001, 0, 64, 32, C.byref(pic)) == 0
+    old_y = pic.y
+    assert lib.ovhip_dpb_publish(h, C.c_void_p(F), 0) == 0
+    got = {}
+
+    def reader():
+        p, ev = capi.Pic(), C.c_void_p()
+        got["r"] = lib.ovhip_dpb_acquire_tag(h, C.c_void_p(F), 1002, 0, C.byref(p), C.byref(ev))
+        got["y"] = p.y
+
+    t = threading.Thread(target=reader)
+    t.start()
+    time.sleep(0.15)
+    assert "r" not in got, "the reader of picture 1002 must not be handed picture 1001"
+    # a device that will read the new picture asks for it before it exists: remembered
+    assert lib.ovhip_dpb_want_tag(h, C.c_void_p(F), 1002, 1) == 0
+    assert lib.ovhip_dpb_begin_tag(h, C.c_void_p(F), 1002, 0, 64, 32, C.byref(pic)) == 0
+    time.sleep(0.05)
+    assert "r" not in got, "... nor before it is published"
+    n_copies = _stats(lib, h).n_copies
+    assert lib.ovhip_dpb_publish(h, C.c_void_p(F), 0) == 0
+    t.join(5)
+    assert got["r"] == 0 and got["y"] == pic.y
+    assert _stats(lib, h).n_copies == n_copies + 1, "the early want of device 1 was carried to the new picture"
+    assert lib.ovhip_dpb_unpin(h, C.c_void_p(F)) == 0
+    # a reader that names the picture that is there gets it at once; so does an untagged reader
+    p2, ev = capi.Pic(), C.c_void_p()
+    assert lib.ovhip_dpb_acquire_tag(h, C.c_void_p(F), 1002, 0, C.byref(p2), C.byref(ev)) == 0 and p2.y == pic.y
+    assert lib.ovhip_dpb_acquire(h, C.c_void_p(F), 0, C.byref(p2), C.byref(ev)) == 0 and p2.y == pic.y
+    assert lib.ovhip_dpb_unpin(h, C.c_void_p(F)) == 0 and lib.ovhip_dpb_unpin(h, C.c_void_p(F)) == 0
+    # the picture never comes: bounded wait, then an error -- never the stale picture
+    lib.ovhip_dpb_set_unknown_key_timeout(h, 100)
+    assert lib.ovhip_dpb_acquire_tag(h, C.c_void_p(F), 1003, 0, C.byref(p2), C.byref(ev)) == capi.OVHIP_EINVAL
