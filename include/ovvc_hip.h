@@ -1102,6 +1102,22 @@ typedef struct ovhip_frame_output {
     uint8_t  digest[16];                 /* DIGEST: result                                                                 */
 } ovhip_frame_output;
 
+/* Event trace of the frame layer: one record per ovhip_frame_* call that changes a picture's state, for every frame of the process
+ * -- WHEN a caller (the shim's hooks under the decoder's events, slicedec.c:934-956) begins a picture, names its references, runs
+ * the eager DMVR rows, submits.  a / b: BEGIN: logical device; REF: table index; DMVR_*: refined units recorded so far (b of
+ * DMVR_BEGIN: the pass covers a DMVR unit = the references were waited for); SUBMIT: refined units recorded, reference count;
+ * FAIL: status.  result = what the call returned.  On a DPB made with ovhip_dpb_create_ex (no device) ovhip_frame_create makes DRY
+ * frames: the same state machine, DPB calls, waits and trace, nothing launched -- how the shim's device half runs in a container
+ * without a GPU (oracle/ref_harness/gen_pipe.c "device" mode -> tests/golden/shim_pipe_dev.ovg, replayed on a GPU by
+ * tests/test_gpu_pipe.py). */
+enum { OVHIP_FE_BEGIN = 1, OVHIP_FE_REF, OVHIP_FE_DMVR_ROWS, OVHIP_FE_DMVR_BEGIN, OVHIP_FE_DMVR_COLLECT, OVHIP_FE_SUBMIT, OVHIP_FE_FAIL };
+typedef struct ovhip_frame_event {
+    uint32_t op; int32_t frame;          /* OVHIP_FE_*; the frame object, numbered in creation order                      */
+    uint64_t key, tag;
+    int64_t  a, b, result;
+} ovhip_frame_event;
+void ovhip_frame_set_trace(void (*sink)(void *user, const ovhip_frame_event *ev), void *user);    /* NULL: off */
+
 int  ovhip_frame_create(ovhip_dpb *dpb, int dev, int32_t w, int32_t h, ovhip_frame **out);
 /* stream_priority: of the frame's HIP stream (0 default, < 0 higher, > 0 lower); another priority = another hardware queue */
 int  ovhip_frame_create_ex(ovhip_dpb *dpb, int dev, int32_t w, int32_t h, int stream_priority, ovhip_frame **out);

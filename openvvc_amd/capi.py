@@ -179,6 +179,11 @@ DBF_CTU_DTYPE = np.dtype(                      # ovhip_dbf_ctu, field by field
        ("last_x", "u1"), ("last_y", "u1"), ("ctu_lft", "u1"), ("ctu_abv", "u1"), ("pad", "u1"),
        ("ctu_w", "<u2"), ("ctu_h", "<u2"), ("ctb_x", "<u2"), ("ctb_y", "<u2")], align=True)
 assert DBF_CTU_DTYPE.itemsize == DBF_CTU_SIZE, (DBF_CTU_DTYPE.itemsize, DBF_CTU_SIZE)
+FE_BEGIN, FE_REF, FE_DMVR_ROWS, FE_DMVR_BEGIN, FE_DMVR_COLLECT, FE_SUBMIT, FE_FAIL = range(1, 8)
+FRAME_EVENT_DTYPE = np.dtype([("op", "<u4"), ("frame", "<i4"), ("key", "<u8"), ("tag", "<u8"), ("a", "<i8"), ("b", "<i8"), ("result", "<i8")])
+assert FRAME_EVENT_DTYPE.itemsize == 48
+FRAME_TRACE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+
 DBF_PLANE_NAMES = ("luma_v", "luma_h", "cb_v", "cr_v", "cb_h", "cr_h")
 
 
@@ -504,6 +509,7 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_frame_recorder": (vp, [vp]),
         "ovhip_frame_begin": (C.c_int, [vp, vp]),
         "ovhip_frame_ref": (C.c_int, [vp, vp]),
+        "ovhip_frame_set_trace": (None, [vp, vp]),
         "ovhip_frame_begin_tag": (C.c_int, [vp, vp, C.c_uint64]),
         "ovhip_frame_ref_tag": (C.c_int, [vp, vp, C.c_uint64]),
         "ovhip_frame_ref_at": (C.c_int, [vp, C.c_int, vp]),
@@ -551,7 +557,7 @@ EXPORTED_SYMBOLS = [
     "ovhip_host_alloc", "ovhip_host_free", "ovhip_d2d", "ovhip_job_test_abort_next_flow",
     "ovhip_dpb_create", "ovhip_dpb_create_ex", "ovhip_dpb_destroy", "ovhip_dpb_n_devices", "ovhip_dpb_device", "ovhip_dpb_begin", "ovhip_dpb_want",
     "ovhip_dpb_publish", "ovhip_dpb_acquire", "ovhip_dpb_wait_copy", "ovhip_dpb_set_unknown_key_timeout", "ovhip_dpb_unpin", "ovhip_dpb_release", "ovhip_dpb_lookup", "ovhip_dpb_shutdown",
-    "ovhip_dpb_get_stats", "ovhip_dpb_begin_tag", "ovhip_dpb_want_tag", "ovhip_dpb_acquire_tag", "ovhip_frame_begin_tag", "ovhip_frame_ref_tag",
+    "ovhip_dpb_get_stats", "ovhip_dpb_begin_tag", "ovhip_dpb_want_tag", "ovhip_dpb_acquire_tag", "ovhip_frame_begin_tag", "ovhip_frame_ref_tag", "ovhip_frame_set_trace",
     "ovhip_frame_create", "ovhip_frame_create_ex", "ovhip_ctx_create_prio", "ovhip_frame_destroy", "ovhip_frame_ctx", "ovhip_frame_job", "ovhip_frame_recorder", "ovhip_frame_begin", "ovhip_frame_ref",
     "ovhip_frame_ref_at", "ovhip_frame_dmvr_rows", "ovhip_frame_dmvr_rows_begin", "ovhip_frame_dmvr_rows_collect", "ovhip_frame_submit", "ovhip_frame_fail", "ovhip_frame_last_error",
     "ovhip_calllog_create", "ovhip_calllog_destroy", "ovhip_calllog_reset", "ovhip_calllog_data", "ovhip_rec_set_calllog", "ovhip_calllog_replay",

@@ -21,14 +21,52 @@ struct ovhip_frame {
     ovhip_dpb *dpb;
     int dev;
     int32_t w, h;
+    int id;                               /* creation order: the frame's name in the event trace */
     ovhip_ctx *ctx;
     ovhip_job *job;                       /* own job, created on first use */
+    /* dry frame (a DPB on a test back-end, no device): the same state machine and the same DPB calls, nothing launched.  Its own
+     * plain recorder takes the picture's commands; the eager-DMVR counters move as the device's would. */
+    int dry;
+    ovhip_recorder *dry_rec;
+    int64_t dry_pending, dry_done;
     const void *key; ovhip_pic dst; int live;
     const void *ref_key[MAX_REFS]; uint64_t ref_tag[MAX_REFS]; ovhip_pic ref_pic[MAX_REFS]; void *ref_ev[MAX_REFS]; unsigned char ref_pinned[MAX_REFS];
     int n_refs;
     int status;
     char err[192];
 };
+
+/* ---- event trace (include/ovvc_hip.h, ovhip_frame_set_trace): WHEN a caller (shim/rcn_hip.c) makes its frame-level calls ---- */
+static void (*g_trace)(void *user, const ovhip_frame_event *ev);
+static void *g_trace_user;
+static int g_next_id;
+
+void
+ovhip_frame_set_trace(void (*sink)(void *user, const ovhip_frame_event *ev), void *user)
+{
+    g_trace_user = user;
+    __atomic_store_n(&g_trace, sink, __ATOMIC_RELEASE);
+}
+
+static void
+trace(const ovhip_frame *f, uint32_t op, const void *key, uint64_t tag, int64_t a, int64_t b, int64_t result)
+{
+    void (*sink)(void *, const ovhip_frame_event *) = __atomic_load_n(&g_trace, __ATOMIC_ACQUIRE);
+    if (!sink) return;
+    ovhip_frame_event ev;
+    memset(&ev, 0, sizeof(ev));
+    ev.op = op; ev.frame = f->id; ev.key = (uint64_t)(uintptr_t)key; ev.tag = tag; ev.a = a; ev.b = b; ev.result = result;
+    sink(g_trace_user, &ev);
+}
+
+static size_t
+n_refined_units(ovhip_frame *f)
+{
+    size_t n = 0;
+    ovhip_recorder *r = ovhip_frame_recorder(f);
+    if (r) (void)ovhip_rec_mcx_units(r, &n);
+    return n;
+}
 
 static int
 fail(ovhip_frame *f, int code, const char *what)
@@ -48,10 +86,19 @@ ovhip_frame_create_ex(ovhip_dpb *dpb, int dev, int32_t w, int32_t h, int stream_
     if (!dpb || !out || dev < 0 || dev >= ovhip_dpb_n_devices(dpb) || w <= 0 || h <= 0) return OVHIP_EINVAL;
     *out = NULL;
     const int hipdev = ovhip_dpb_device(dpb, dev);
-    if (hipdev < 0) return OVHIP_ENODEV;          /* a DPB on a test back-end has no device to decode on */
     ovhip_frame *f = (ovhip_frame *)calloc(1, sizeof(*f));
     if (!f) return OVHIP_ENOMEM;
     f->dpb = dpb; f->dev = dev; f->w = w; f->h = h;
+    f->id = __atomic_fetch_add(&g_next_id, 1, __ATOMIC_RELAXED);
+    if (hipdev < 0) {
+        /* a DPB on a test back-end has no device to decode on: a dry frame (the caller's sequence of frame-level calls is the
+         * subject, tests/test_shim_device_cpu.py); pictures "decode" to whatever the back-end's pic_alloc handed out */
+        f->dry = 1;
+        f->dry_rec = ovhip_rec_create(w, h);
+        if (!f->dry_rec) { free(f); return OVHIP_ENOMEM; }
+        *out = f;
+        return OVHIP_OK;
+    }
     int r = stream_priority ? ovhip_ctx_create_prio(&f->ctx, hipdev, stream_priority) : ovhip_ctx_create(&f->ctx, hipdev, NULL);
     if (r != OVHIP_OK) { free(f); return r; }
     *out = f;
@@ -71,7 +118,8 @@ ovhip_frame_destroy(ovhip_frame *f)
     if (!f) return;
     if (f->live) (void)ovhip_frame_fail(f, OVHIP_EINVAL);
     if (f->job) ovhip_job_destroy(f->job);
-    ovhip_ctx_destroy(f->ctx);
+    if (f->dry_rec) ovhip_rec_destroy(f->dry_rec);
+    if (f->ctx) ovhip_ctx_destroy(f->ctx);
     free(f);
 }
 
@@ -80,12 +128,18 @@ ovhip_ctx *ovhip_frame_ctx(ovhip_frame *f) { return f ? f->ctx : NULL; }
 ovhip_job *
 ovhip_frame_job(ovhip_frame *f)
 {
-    if (!f) return NULL;
+    if (!f || f->dry) return NULL;
     if (!f->job && fail(f, ovhip_job_create(f->ctx, f->w, f->h, &f->job), "ovhip_job_create") != OVHIP_OK) f->job = NULL;
     return f->job;
 }
 
-ovhip_recorder *ovhip_frame_recorder(ovhip_frame *f) { ovhip_job *j = ovhip_frame_job(f); return j ? ovhip_job_recorder(j) : NULL; }
+ovhip_recorder *
+ovhip_frame_recorder(ovhip_frame *f)
+{
+    if (f && f->dry) return f->dry_rec;
+    ovhip_job *j = ovhip_frame_job(f);
+    return j ? ovhip_job_recorder(j) : NULL;
+}
 const char *ovhip_frame_last_error(const ovhip_frame *f) { return f ? f->err : "no frame"; }
 
 int ovhip_frame_begin(ovhip_frame *f, const void *key) { return ovhip_frame_begin_tag(f, key, 0); }
@@ -98,8 +152,10 @@ ovhip_frame_begin_tag(ovhip_frame *f, const void *key, uint64_t tag)
     if (f->live) (void)ovhip_frame_fail(f, OVHIP_EINVAL);
     f->status = 0; f->err[0] = 0; f->n_refs = 0;
     int r = ovhip_dpb_begin_tag(f->dpb, key, tag, f->dev, f->w, f->h, &f->dst);
+    trace(f, OVHIP_FE_BEGIN, key, tag, f->dev, 0, r);
     if (r != OVHIP_OK) return fail(f, r, "ovhip_dpb_begin");
     f->key = key; f->live = 1;
+    if (f->dry) { ovhip_rec_reset(f->dry_rec); f->dry_pending = f->dry_done = 0; }
     if (f->job) {
         r = ovhip_job_begin(f->job);
         if (r != OVHIP_OK) { fail(f, r, "ovhip_job_begin"); (void)ovhip_frame_fail(f, r); return r; }
@@ -120,6 +176,7 @@ ovhip_frame_ref_tag(ovhip_frame *f, const void *ref_key, uint64_t tag)
     memset(&f->ref_pic[i], 0, sizeof(f->ref_pic[i]));
     /* as soon as the reference lists are known: a picture decoded on another device is pushed here when it is done */
     (void)ovhip_dpb_want_tag(f->dpb, ref_key, tag, f->dev);
+    trace(f, OVHIP_FE_REF, ref_key, tag, i, 0, i);
     return i;
 }
 
@@ -159,41 +216,48 @@ static int before_launch_cb(void *user) { return acquire_refs((ovhip_frame *)use
 int64_t
 ovhip_frame_dmvr_rows(ovhip_frame *f)
 {
-    if (!f || !f->live || !f->job) return OVHIP_EINVAL;
+    if (!f || !f->live || (!f->job && !f->dry)) return OVHIP_EINVAL;
     int r = acquire_refs(f);
     if (r != OVHIP_OK) return r;
-    int64_t n = ovhip_job_dmvr_rows(f->job, f->ref_pic, (uint32_t)f->n_refs);
+    int64_t n;
+    if (f->dry) n = f->dry_done = f->dry_pending = (int64_t)n_refined_units(f);
+    else n = ovhip_job_dmvr_rows(f->job, f->ref_pic, (uint32_t)f->n_refs);
     if (n < 0) fail(f, (int)n, "ovhip_job_dmvr_rows");
+    trace(f, OVHIP_FE_DMVR_ROWS, f->key, 0, (int64_t)n_refined_units(f), 0, n);
     return n;
 }
 
 int64_t
 ovhip_frame_dmvr_rows_begin(ovhip_frame *f, int32_t log2_ctu_s)
 {
-    if (!f || !f->live || !f->job) return OVHIP_EINVAL;
+    if (!f || !f->live || (!f->job && !f->dry)) return OVHIP_EINVAL;
     /* the references are needed (and waited for) only if a unit the pass would cover is a DMVR unit: rows of BDOF-only units do not
      * stop the parse */
-    int64_t c = ovhip_job_dmvr_rows_collect(f->job);
+    int64_t c = f->dry ? (f->dry_done = f->dry_pending) : ovhip_job_dmvr_rows_collect(f->job);
     if (c < 0) { fail(f, (int)c, "ovhip_job_dmvr_rows_collect"); return c; }
     size_t nu = 0;
-    const ovhip_mc_unit *u = ovhip_rec_mcx_units(ovhip_job_recorder(f->job), &nu);
+    const ovhip_mc_unit *u = ovhip_rec_mcx_units(ovhip_frame_recorder(f), &nu);
     int any = 0;
     for (size_t i = (size_t)c; i < nu && !any; ++i) any = (u[i].flags & OVHIP_MC_DMVR) != 0;
     if (any) {
         int r = acquire_refs(f);
         if (r != OVHIP_OK) return r;
     }
-    int64_t n = ovhip_job_dmvr_rows_begin(f->job, f->ref_pic, (uint32_t)f->n_refs, log2_ctu_s);
+    int64_t n;
+    if (f->dry) n = f->dry_pending = (int64_t)nu;
+    else n = ovhip_job_dmvr_rows_begin(f->job, f->ref_pic, (uint32_t)f->n_refs, log2_ctu_s);
     if (n < 0) fail(f, (int)n, "ovhip_job_dmvr_rows_begin");
+    trace(f, OVHIP_FE_DMVR_BEGIN, f->key, 0, (int64_t)nu, any, n);
     return n;
 }
 
 int64_t
 ovhip_frame_dmvr_rows_collect(ovhip_frame *f)
 {
-    if (!f || !f->live || !f->job) return OVHIP_EINVAL;
-    int64_t n = ovhip_job_dmvr_rows_collect(f->job);
+    if (!f || !f->live || (!f->job && !f->dry)) return OVHIP_EINVAL;
+    int64_t n = f->dry ? (f->dry_done = f->dry_pending) : ovhip_job_dmvr_rows_collect(f->job);
     if (n < 0) fail(f, (int)n, "ovhip_job_dmvr_rows_collect");
+    trace(f, OVHIP_FE_DMVR_COLLECT, f->key, 0, (int64_t)n_refined_units(f), 0, n);
     return n;
 }
 
@@ -212,6 +276,7 @@ ovhip_frame_fail(ovhip_frame *f, int status)
 {
     if (!f) return OVHIP_EINVAL;
     if (!f->status) f->status = status ? status : OVHIP_EINVAL;
+    trace(f, OVHIP_FE_FAIL, f->key, 0, f->status, 0, 0);
     return publish(f, f->status);
 }
 
@@ -221,6 +286,14 @@ ovhip_frame_submit(ovhip_frame *f, ovhip_job *job, const ovhip_pic *intra, const
     if (!f || !params || !f->live) return OVHIP_EINVAL;
     int r = f->status;                    /* a latched recorder error: the picture is published as failed, never launched */
     ovhip_job *j = job ? job : f->job;
+    if (f->dry) {
+        /* dry: the same waits and the same publication, no launches, no output */
+        if (r == OVHIP_OK) r = acquire_refs(f);
+        trace(f, OVHIP_FE_SUBMIT, f->key, 0, (int64_t)n_refined_units(f), f->n_refs, r);
+        (void)publish(f, r);
+        return r;
+    }
+    trace(f, OVHIP_FE_SUBMIT, f->key, 0, (int64_t)n_refined_units(f), f->n_refs, r);
     if (r == OVHIP_OK && !j) r = fail(f, OVHIP_EINVAL, "ovhip_frame_submit: nothing was recorded");
     if (r == OVHIP_OK && job) r = fail(f, ovhip_job_bind(job, f->ctx), "ovhip_job_bind");
     if (r == OVHIP_OK) {

@@ -27,7 +27,13 @@
  * Shim mode       -> tests/golden/shim_pipe.ovg : what the INSTALLED slots recorded for the same pictures (one command stream per
  *                                                 picture + its picture-level parameters).  tests/ decode picture k from the
  *                                                 pictures THEY decoded before and must end with the reference's bytes.
- * The same process runs the reference pass first in both modes: the shim's DMVR slot returns unrefined vectors in record-only
+ * Device mode     -> tests/golden/shim_pipe_dev.ovg : the shim NOT in record-only mode but with its device half live -- begin_picture,
+ *                                                 dpb_get, ref_slot -> ovhip_frame_ref, dmvr_rows_step, flush_picture -- over a device
+ *                                                 DPB on a test memory back-end (ovhip_dpb_create_ex) whose frames are dry (nothing
+ *                                                 is launched; include/ovvc_hip.h, ovhip_frame_set_trace).  The fixture is the
+ *                                                 interleaved log of the decoder's row-end events and the frame-level calls the shim
+ *                                                 made under them; what its recorder held must equal the shim mode's stream.
+ * The same process runs the reference pass first in all modes: the shim's DMVR slot returns unrefined vectors in record-only
  * mode (the device refines them later), so the harness hands the caller the vectors the reference pass
  * produced for the same call -- "the device answered in time" -- and the parse of the later pictures (TMVP) stays the same.
  */
@@ -54,12 +60,26 @@ static size_t g_dmvr_pos;                           /* shim pass: next entry of 
 static int g_pass_shim;
 static int g_isp_64x2;                              /* the reference's result for 64x2 ISP partitions is undefined (gen_golden.c, gen_isp) */
 
+/* ---- device mode: the decoder's events the shim hangs its frame-level calls on, interleaved with those calls ---- */
+enum { GP_EV_ATTACH = 100, GP_EV_SAO_FIRST, GP_EV_ALF_LINE, GP_EV_HOOK_END, GP_EV_DMVR_SLOT };
+static gbuf g_events = { .type = T_U8 };
+static void
+gp_event(uint32_t op, int64_t a, int64_t b)
+{
+    ovhip_frame_event ev;
+    memset(&ev, 0, sizeof(ev));
+    ev.op = op; ev.frame = -1; ev.a = a; ev.b = b;
+    gbuf_push(&g_events, &ev, sizeof(ev));
+}
+static void gp_trace_sink(void *user, const ovhip_frame_event *ev) { (void)user; gbuf_push(&g_events, ev, sizeof(*ev)); }
+
 static uint8_t
 gp_dmvr(OVCTUDec *const c, struct OVBuffInfo dst, uint8_t x0, uint8_t y0, uint8_t l2w, uint8_t l2h, OVMV *mv0, OVMV *mv1,
         uint8_t ref_idx0, uint8_t ref_idx1, uint8_t apply_bdof)
 {
     const int32_t in[8] = { (c->ctb_x << 7) + x0, (c->ctb_y << 7) + y0, l2w, l2h, mv0->x, mv0->y, mv1->x, mv1->y };
     const uint8_t r = g_dmvr_inner(c, dst, x0, y0, l2w, l2h, mv0, mv1, ref_idx0, ref_idx1, apply_bdof);
+    if (g_pass_shim == 2) gp_event(GP_EV_DMVR_SLOT, in[0], in[1]);
     if (!g_pass_shim) {
         int32_t rec[12];
         memcpy(rec, in, sizeof(in));
@@ -86,6 +106,23 @@ gp_isp_h(OVCTUDec *const c, unsigned int x0, unsigned int y0, unsigned int l2w, 
     g_isp_h_inner(c, x0, y0, l2w, l2h, mode, tu);
 }
 
+static void (*g_attach_inner)(struct OVRCNCtx *const, const OVFrame *const, const struct RectEntryInfo *const, uint8_t);
+static void (*g_sao_first_inner)(OVCTUDec *const, const struct RectEntryInfo *const, uint16_t);
+static void (*g_alf_line_inner)(OVCTUDec *const, const struct RectEntryInfo *const, uint16_t);
+static void gp_attach(struct OVRCNCtx *const r, const OVFrame *const f, const struct RectEntryInfo *const e, uint8_t l2)
+{ gp_event(GP_EV_ATTACH, e->nb_ctu_w, e->nb_ctu_h); g_attach_inner(r, f, e, l2); gp_event(GP_EV_HOOK_END, GP_EV_ATTACH, 0); }
+static void gp_sao_first(OVCTUDec *const c, const struct RectEntryInfo *const e, uint16_t y)
+{ gp_event(GP_EV_SAO_FIRST, y, e->nb_ctu_h); g_sao_first_inner(c, e, y); gp_event(GP_EV_HOOK_END, GP_EV_SAO_FIRST, y); }
+static void gp_alf_line(OVCTUDec *const c, const struct RectEntryInfo *const e, uint16_t y)
+{ gp_event(GP_EV_ALF_LINE, y, e->nb_ctu_h); g_alf_line_inner(c, e, y); gp_event(GP_EV_HOOK_END, GP_EV_ALF_LINE, y); }
+
+/* test memory back-end of the device DPB: a "picture" is a number */
+static int fm_next = 0x1000;
+static int fm_alloc(void *u, int dev, int32_t w, int32_t h, ovhip_pic *pic) { (void)u; (void)dev; memset(pic, 0, sizeof(*pic)); pic->y = (uint16_t *)(uintptr_t)(fm_next += 0x100); pic->w = w; pic->h = h; pic->stride_y = w; pic->stride_c = w / 2; return 0; }
+static void fm_free(void *u, int dev, ovhip_pic *pic) { (void)u; (void)dev; (void)pic; }
+static int fm_copy_start(void *u, int dd, const ovhip_pic *dst, int sd, const ovhip_pic *src, void **ev) { (void)u; (void)dd; (void)dst; (void)sd; (void)src; *ev = NULL; return 0; }
+static int fm_copy_wait(void *u, int dev, void *ev) { (void)u; (void)dev; (void)ev; return 0; }
+
 typedef void (*gpm_fn)(OVCTUDec *const, struct VVCGPM *, int, int, int, int);
 static gpm_fn g_gpm_inner;
 static void
@@ -106,6 +143,11 @@ gp_rcn_init_functions(struct RCNFunctions *f, uint8_t ict_type, uint8_t lm_chrom
     if (g_pass_shim) rcn_init_functions_hip(f, ict_type, lm_chroma_enabled, vcolloc, lmcs_flag, bitdepth);
     g_dmvr_inner = f->rcn_dmvr_mv_refine; f->rcn_dmvr_mv_refine = &gp_dmvr;
     if (getenv("GP_TRACE")) { g_gpm_inner = f->rcn_gpm_b; f->rcn_gpm_b = &gp_gpm; }
+    if (g_pass_shim == 2) {
+        g_attach_inner = f->rcn_attach_frame_buff; f->rcn_attach_frame_buff = &gp_attach;
+        g_sao_first_inner = f->sao.rcn_sao_first_pix_rows; f->sao.rcn_sao_first_pix_rows = &gp_sao_first;
+        g_alf_line_inner = f->alf.rcn_alf_filter_line; f->alf.rcn_alf_filter_line = &gp_alf_line;
+    }
     g_isp_h_inner = (isp_fn)f->tmp.recon_isp_subtree_h; f->tmp.recon_isp_subtree_h = (void *)&gp_isp_h;
 }
 
@@ -349,7 +391,7 @@ struct gp_pic_desc { int poc, slice_type, qp, l0[2], n0, l1[2], n1, tmvp, col_fr
 struct gp_out {
     gbuf frames;                               /* uint16: every picture's y, cb, cr */
     gbuf info;                                 /* int32 per picture: poc, slice type, qp, n0, l0[2], n1, l1[2], tmvp, first / end DMVR call */
-    struct shim_stream S;
+    struct shim_stream S, S2;                  /* S2: the device pass's recorder contents (must equal S) */
     gbuf sao, alf, tab[5], luts, offs, refmap, pflags;
 };
 
@@ -364,12 +406,21 @@ run_stream(struct gp_seq *s, const struct gp_pic_desc *desc, int n_pic, uint32_t
     memset(&sl, 0, sizeof(sl));
     gp_alloc_lines(&sl, s);
     OVCTUDec *c = gp_new_ctudec(s);
-    if (g_pass_shim) {
+    ovhip_dpb *dpb = NULL;
+    if (g_pass_shim == 1) {
         /* the entry exists once the table has been installed; bind a recorder to it (record-only: no device in this container) */
         gp_rcn_init_functions(&c->rcn_funcs, 0, 1, 0, 1, 10);
         c->part_ctx = &g_part;
         ovhip_recorder *r = ovhip_rec_create(s->w, s->h);
         if (!r || ovhip_shim_bind_recorder(c, r, s->w, s->h)) { fprintf(stderr, "gen_pipe: shim bind failed\n"); exit(1); }
+    } else if (g_pass_shim == 2) {
+        /* the device half live: the shim's own begin_picture / flush_picture over a DPB without a device (dry frames) */
+        ovhip_dpb_ops ops;
+        memset(&ops, 0, sizeof(ops));
+        ops.pic_alloc = fm_alloc; ops.pic_free = fm_free; ops.copy_start = fm_copy_start; ops.copy_wait = fm_copy_wait;
+        if (ovhip_dpb_create_ex(&dpb, 1, &ops)) { fprintf(stderr, "gen_pipe: ovhip_dpb_create_ex failed\n"); exit(1); }
+        ovhip_shim_set_dpb(dpb);
+        ovhip_frame_set_trace(gp_trace_sink, NULL);
     }
     for (int k = 0; k < n_pic; ++k) {
         const struct gp_pic_desc *d = &desc[k];
@@ -406,6 +457,7 @@ run_stream(struct gp_seq *s, const struct gp_pic_desc *desc, int n_pic, uint32_t
         if (ovhip_shim_last_error(c)) { fprintf(stderr, "gen_pipe: picture %d: the shim latched %d\n", k, ovhip_shim_last_error(c)); exit(1); }
         size_t nc = 0, nt = 0;
         const int n_ctb = s->nb_ctb_w * s->nb_ctb_h;
+        if (g_pass_shim == 2) goto stream_only;
         /* a picture without SAO / ALF: all-off parameters (the flush would get no table at all) */
         const ovhip_sao_ctu *sp = ovhip_shim_sao_params(c, &nc);
         if (sp && nc != (size_t)n_ctb) { fprintf(stderr, "gen_pipe: picture %d: SAO parameters of %zu CTUs\n", k, nc); exit(1); }
@@ -431,20 +483,34 @@ run_stream(struct gp_seq *s, const struct gp_pic_desc *desc, int n_pic, uint32_t
         gbuf_push(&out->refmap, map, 16);
         int32_t pf[4] = { d->lmcs, np, c->lmcs_info.lmcs_enabled_flag, c->lmcs_info.scale_c_flag };
         gbuf_push(&out->pflags, pf, 4);
-        shim_case_end(c, &out->S, "pipe picture");
+    stream_only:
+        shim_case_end(c, g_pass_shim == 2 ? &out->S2 : &out->S, "pipe picture");
+        if (g_pass_shim == 2) {
+            /* keys -> picture numbers: the fixture must not hold this run's pointers */
+            ovhip_frame_event *ev = (ovhip_frame_event *)g_events.data;
+            for (size_t i = 0; i < g_events.n / sizeof(*ev); ++i) {
+                if (ev[i].frame < 0 || ev[i].key < 0x10000) continue;
+                int64_t idx = -1;
+                for (int q = 0; q <= k; ++q) if ((uint64_t)(uintptr_t)pics[q]->frame == ev[i].key) idx = q;
+                if (idx < 0) { fprintf(stderr, "gen_pipe: device pass: a frame-level call names a key that is no picture of the stream\n"); exit(1); }
+                ev[i].key = (uint64_t)idx;
+            }
+        }
     }
+    if (g_pass_shim == 2) { ovhip_frame_set_trace(NULL, NULL); ovhip_shim_release(c); ovhip_shim_set_dpb(NULL); ovhip_dpb_destroy(dpb); }
 }
 
 int
 gp_main(int argc, char **argv)
 {
     const char *dir = argc > 1 ? argv[1] : "../tests/golden";
-    int want_shim = 0, variant = 0, W = 416, H = 240, dqp = 0;
+    int want_shim = 0, want_dev = 0, variant = 0, W = 416, H = 240, dqp = 0;
     uint32_t seed = 0x266 + 31337;
     const char *name = "pipe";
-    /* gen_pipe <dir> [shim] [name <fixture name>] [seed <n>] [variant <0|1>] [qp <delta on every picture's QP>] [size <w> <h>] */
+    /* gen_pipe <dir> [shim | device] [name <fixture name>] [seed <n>] [variant <0|1>] [qp <delta on every picture's QP>] [size <w> <h>] */
     for (int i = 2; i < argc; ++i) {
         if (!strcmp(argv[i], "shim")) want_shim = 1;
+        else if (!strcmp(argv[i], "device")) want_shim = want_dev = 1;
         else if (!strcmp(argv[i], "name") && i + 1 < argc) name = argv[++i];
         else if (!strcmp(argv[i], "seed") && i + 1 < argc) seed = (uint32_t)strtoul(argv[++i], NULL, 0);
         else if (!strcmp(argv[i], "variant") && i + 1 < argc) variant = atoi(argv[++i]);
@@ -470,13 +536,14 @@ gp_main(int argc, char **argv)
     out.frames.type = T_U16; out.info.type = T_I32; out.sao.type = T_U8; out.alf.type = T_U8; out.luts.type = T_U8; out.offs.type = T_U8;
     out.refmap.type = T_I32; out.pflags.type = T_I32;
     for (int t = 0; t < 5; ++t) out.tab[t].type = T_I16;
-    shim_stream_init(&out.S);
+    shim_stream_init(&out.S); shim_stream_init(&out.S2);
 
     struct gp_seq seq;
-    for (g_pass_shim = 0; g_pass_shim <= want_shim; ++g_pass_shim) {
+    for (g_pass_shim = 0; g_pass_shim <= want_shim + want_dev; ++g_pass_shim) {
         g_seed = 0x266 + 4242;
+        g_dmvr_pos = 0;
         seq_init(&seq, W, H, variant);
-        fprintf(stderr, "gen_pipe: %s pass\n", g_pass_shim ? "shim" : "reference");
+        fprintf(stderr, "gen_pipe: %s pass\n", g_pass_shim == 2 ? "device (dry)" : g_pass_shim ? "shim" : "reference");
         run_stream(&seq, gop, n_pic, seed, &out);
     }
     if (g_isp_64x2) { fprintf(stderr, "gen_pipe: the stream holds %d 64x2 ISP partitions (reference result undefined): pick another seed\n", g_isp_64x2); return 1; }
@@ -495,6 +562,26 @@ gp_main(int argc, char **argv)
         gfile_array(&g, "dmvr", T_I32, g_dmvr_log.data ? g_dmvr_log.data : (const void *)"", 2, d2);
         gfile_close(&g);
         fprintf(stderr, "%s: %d pictures %dx%d, %u DMVR calls\n", fn, n_pic, W, H, d2[0]);
+        return 0;
+    }
+    if (want_dev) {
+        /* the device half recorded what record-only mode recorded */
+        for (int i = 0; i < SHIM_NARR; ++i) {
+            const size_t bytes = out.S.arr[i].n * g_tsize[out.S.arr[i].type];
+            if (out.S.arr[i].n != out.S2.arr[i].n || (bytes && memcmp(out.S.arr[i].data, out.S2.arr[i].data, bytes))) {
+                fprintf(stderr, "gen_pipe: device pass: recorder array %d differs from the record-only pass\n", i); return 1;
+            }
+        }
+        char fn[256];
+        snprintf(fn, sizeof(fn), "shim_%s_dev.ovg", name);
+        gfile g = gfile_open(dir, fn);
+        uint32_t d2[2] = { (uint32_t)(g_events.n / sizeof(ovhip_frame_event)), sizeof(ovhip_frame_event) };
+        gfile_array(&g, "events", T_U8, g_events.data, 2, d2);
+        int32_t geo[4] = { W, H, n_pic, 7 };
+        uint32_t d1 = 4;
+        gfile_array(&g, "geometry", T_I32, geo, 1, &d1);
+        gfile_close(&g);
+        fprintf(stderr, "%s: %u events\n", fn, d2[0]);
         return 0;
     }
     /* shim_pipe.ovg: shim_stream_write's container (one case per picture) + the picture-level parameters the flush would take */

@@ -1072,7 +1072,7 @@ dmvr_rows_step(struct hip_entry *e, OVCTUDec *c, int final)
     const size_t now = e->n_refined;
     if (now == e->dmvr_done) { e->row_mark = now; return; }
     int64_t done = ovhip_frame_dmvr_rows_collect(e->fr);
-    if (done >= 0 && (final || (size_t)done < e->row_mark)) {
+    if (done >= 0 && (size_t)done < now && (final || (size_t)done < e->row_mark)) {
         done = ovhip_frame_dmvr_rows_begin(e->fr, e->log2_ctu);
         if (done >= 0) done = ovhip_frame_dmvr_rows_collect(e->fr);
     }
@@ -1129,7 +1129,7 @@ hip_alf_filter_line(OVCTUDec *const c, const struct RectEntryInfo *const einfo, 
  * one per GPU as the sub-decoders take them (ovdec_select_subdec, ovdec.c:188-248); a reference picture decoded on another device
  * arrives by an event-ordered peer copy the DPB starts as soon as it is done. */
 static ovhip_dpb *g_dpb;
-static int g_n_dev = 1, g_next_dev, g_n_entries, g_out_mode = OVHIP_OUT_PLANES;
+static int g_n_dev = 1, g_next_dev, g_n_entries, g_out_mode = OVHIP_OUT_PLANES, g_dpb_external;
 static ovhip_ctx *g_out_ctx[OVHIP_MAX_DEVICES];
 static pthread_mutex_t g_dpb_mtx = PTHREAD_MUTEX_INITIALIZER;
 
@@ -1152,6 +1152,18 @@ dpb_get(struct hip_entry *e)
     if (r == OVHIP_OK && e->dev < 0) { e->dev = g_next_dev++ % g_n_dev; g_n_entries++; }
     pthread_mutex_unlock(&g_dpb_mtx);
     return r;
+}
+
+/* The application owns the device DPB (several decoders sharing one; a test back-end made with ovhip_dpb_create_ex): call before the
+ * first picture.  NULL: back to the DPB the shim creates itself from OVVC_HIP_DEVICES. */
+void
+ovhip_shim_set_dpb(struct ovhip_dpb *dpb)
+{
+    pthread_mutex_lock(&g_dpb_mtx);
+    g_dpb = dpb; g_dpb_external = dpb != NULL;
+    g_n_dev = dpb ? ovhip_dpb_n_devices(dpb) : 1;
+    g_next_dev = 0;
+    pthread_mutex_unlock(&g_dpb_mtx);
 }
 
 void ovhip_shim_set_output(int mode) { g_out_mode = mode == OVHIP_OUT_NONE ? OVHIP_OUT_NONE : OVHIP_OUT_PLANES; }
@@ -1455,7 +1467,7 @@ ovhip_shim_release(const OVCTUDec *c)
     free(e->sao); free(e->alf);
     /* the last frame thread of the process takes the device DPB (every device picture) with it */
     pthread_mutex_lock(&g_dpb_mtx);
-    if (e->dev >= 0 && --g_n_entries == 0 && g_dpb) {
+    if (e->dev >= 0 && --g_n_entries == 0 && g_dpb && !g_dpb_external) {
         for (int k = 0; k < OVHIP_MAX_DEVICES; ++k) if (g_out_ctx[k]) { ovhip_ctx_destroy(g_out_ctx[k]); g_out_ctx[k] = NULL; }
         ovhip_dpb_destroy(g_dpb);
         g_dpb = NULL; g_next_dev = 0;

@@ -55,6 +55,8 @@ void ovhip_shim_release(const struct OVCTUDec *ctudec);
  * (default: an unmodified application reads the frame there, dectest.c:372-409) or OVHIP_OUT_NONE (the application takes its
  * frames through ovhip_shim_frame_output / _digest: no 24.9 MB copy per 4K picture).  Also: environment OVVC_HIP_OUTPUT=none. */
 void ovhip_shim_set_output(int mode);
+struct ovhip_dpb;
+void ovhip_shim_set_dpb(struct ovhip_dpb *dpb);          /* the application's device DPB instead of the shim's own */
 /* Optional hook for ovframe_unref() reaching zero: the frame's device picture returns to the pool at once (otherwise when the
  * frame pointer comes back for a new picture). */
 struct Frame;

@@ -91,3 +91,53 @@ def test_frame_api_chain_equals_the_reference_slice_decoder(built_lib, name):
     for f in frames:
         f.close()
     dpb.close()
+
+
+@pytest.mark.parametrize("name", STREAMS)
+def test_replay_of_the_shims_device_mode_call_log(built_lib, name):
+    """tests/golden/shim_pipe*_dev.ovg: the ovhip_frame_* calls the shim's device half made under the reference's slice decoder
+    (dry, in the build container; tests/test_shim_device_cpu.py), replayed here call for call on the real frame layer -- the eager
+    DMVR passes with exactly the units that had been recorded when the shim started them -- and the pictures must be the
+    reference's."""
+    import golden_io
+    P = pipe_cases.Pipe(name)
+    ev = np.frombuffer(golden_io.load(f"shim_{name}_dev.ovg")["events"].tobytes(), capi.FRAME_EVENT_DTYPE)
+    dpb = engine.Dpb((0,))
+    f = engine.Frame(dpb, 0, P.w, P.h)
+    key = lambda k: 0xE000 + 16 * k
+    cur, wl, rec, n_mcx_in, n_done = None, None, None, 0, 0
+    for e in ev:
+        op = int(e["op"])
+        if op == capi.FE_BEGIN:
+            cur = int(e["key"])
+            wl = P.workload(cur, {i: None for i in range(cur)})
+            f.begin(key(cur), int(e["tag"]))
+            rec, n_mcx_in = f.recorder(), 0
+        elif op == capi.FE_REF:
+            assert f.ref(key(int(e["key"])), int(e["tag"])) == int(e["result"])
+        elif op in (capi.FE_DMVR_BEGIN, capi.FE_DMVR_COLLECT, capi.FE_SUBMIT):
+            upto = int(e["a"])                                   # refined units the shim had recorded at this call
+            if upto > n_mcx_in:
+                rec.append_raw(capi.REC_MCX, wl.mcx_units[n_mcx_in:upto]); n_mcx_in = upto
+            if op == capi.FE_DMVR_BEGIN:
+                assert f.dmvr_rows_begin(P.log2_ctu) == int(e["result"])
+            elif op == capi.FE_DMVR_COLLECT:
+                n_done = f.dmvr_rows_collect()
+                assert n_done <= n_mcx_in                        # (a dry frame completes a pass at once; the device when it does)
+            else:
+                assert n_mcx_in == len(wl.mcx_units)
+                rest = pipe_cases.Workload(**{**wl.__dict__, "mcx_units": wl.mcx_units[:0]})
+                _load(rec, f.lib, rest)
+                keep = _Keep()
+                out = capi.FrameOutput()
+                y, cb, cr = np.zeros((P.h, P.w), np.uint16), np.zeros((P.h // 2, P.w // 2), np.uint16), np.zeros((P.h // 2, P.w // 2), np.uint16)
+                out.mode, out.y, out.cb, out.cr, out.stride_y, out.stride_c = capi.OUT_PLANES, y.ctypes.data, cb.ctypes.data, cr.ctypes.data, P.w, P.w // 2
+                f.submit(engine.Job.make_params(keep, wl), out=out)
+                _check(name, cur, (y, cb, cr), P, f.job().refined_mvs(), wl)
+                # the plane entries the eager passes delivered = the oracle's for the refined vectors (what the shim patches into the
+                # picture's collocated motion field before the row is reported)
+                if len(wl.mcx_units):
+                    import oracle_lib
+                    assert np.array_equal(f.job().tmvp_cells(), oracle_lib.tmvp_cells(wl.mcx_units, f.job().refined_mvs(), P.log2_ctu, (P.w + 127) // 128))
+    assert cur == P.n - 1
+    f.close(); dpb.close()

@@ -9,7 +9,7 @@ shim_pipe*.ovg hold what the installed slots of shim/rcn_hip.c recorded while th
 Here the oracle decodes picture k of the recorded stream from the pictures IT decoded before and must end, byte for byte, with
 the reference's frames -- deblocking after the inverse luma mapping, SAO on deblocked samples across CTU corners, ALF / CC-ALF with
 its virtual boundaries over SAO output, CIIP / intra blocks next to inter CUs, DMVR's refined vectors feeding the next pictures'
-temporal candidates, ragged last CTU column and row (416x240: 32 wide / 112 high; 264x136: 8 / 8)."""
+temporal candidates, ragged last CTU column and row (416x240: 4 x 2 CTUs, 32 wide / 112 high; 264x392: 3 x 4 CTUs, 8 / 8)."""
 import subprocess
 from pathlib import Path
 
@@ -53,7 +53,7 @@ def test_oracle_chain_equals_the_reference_slice_decoder(built_lib, name):
         seen["res_store"] += int((wl.tb_cmds["res_mode"] != 0).sum())
     # the parse is a random walk through the reference's caller code: the prediction families must have come up
     least = {"pipe": dict(mc=1000, gpm=50, mcx=400, dmvr=400, bdof=400, aff=200, prof=100, itask=700, region=80, tb=500, res_store=300, ciip=4),
-             "pipe_b": dict(mc=400, mcx=100, dmvr=100, aff=60, itask=250, region=40, tb=150)}[name]
+             "pipe_b": dict(mc=800, mcx=400, dmvr=300, aff=150, itask=300, region=80, tb=300)}[name]
     for key, n in least.items():
         assert seen[key] >= n, (name, key, seen)
     if name == "pipe":
@@ -81,9 +81,10 @@ def test_pipe_fixtures_regenerate_identically(built_lib, tmp_path):
     """pipe*.ovg / shim_pipe*.ovg are what the harness makes from the reference's sources and the current shim + recorder."""
     subprocess.check_call(["make", "-C", str(ROOT / "oracle")], stdout=subprocess.DEVNULL)
     gen = str(ROOT / "oracle" / "_ref" / "gen_pipe")
-    extra = {"pipe": [], "pipe_b": "name pipe_b seed 19 variant 1 size 264 136".split()}
+    extra = {"pipe": [], "pipe_b": "name pipe_b seed 3 variant 1 size 264 392".split()}
     for name in STREAMS:
         subprocess.check_call([gen, str(tmp_path)] + extra[name], stderr=subprocess.DEVNULL)
         subprocess.check_call([gen, str(tmp_path), "shim"] + extra[name], stderr=subprocess.DEVNULL)
-        for f in (f"{name}.ovg", f"shim_{name}.ovg"):
+        subprocess.check_call([gen, str(tmp_path), "device"] + extra[name], stderr=subprocess.DEVNULL)
+        for f in (f"{name}.ovg", f"shim_{name}.ovg", f"shim_{name}_dev.ovg"):
             assert (tmp_path / f).read_bytes() == (ROOT / "tests" / "golden" / f).read_bytes(), f
