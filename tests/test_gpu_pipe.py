@@ -138,6 +138,10 @@ def test_replay_of_the_shims_device_mode_call_log(built_lib, name):
                 # picture's collocated motion field before the row is reported)
                 if len(wl.mcx_units):
                     import oracle_lib
-                    assert np.array_equal(f.job().tmvp_cells(), oracle_lib.tmvp_cells(wl.mcx_units, f.job().refined_mvs(), P.log2_ctu, (P.w + 127) // 128))
+                    got = f.job().tmvp_cells()
+                    want = oracle_lib.tmvp_cells(wl.mcx_units, f.job().refined_mvs(), P.log2_ctu, (P.w + 127) // 128)
+                    used = want["cell"] != capi.TMVP_NONE
+                    assert np.array_equal(got["cell"], want["cell"]) and np.array_equal(got[used], want[used])
+                    assert used.sum() >= ((wl.mcx_units["flags"] & 64) != 0).sum()
     assert cur == P.n - 1
     f.close(); dpb.close()
