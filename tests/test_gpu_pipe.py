@@ -105,7 +105,7 @@ def test_replay_of_the_shims_device_mode_call_log(built_lib, name):
     dpb = engine.Dpb((0,))
     f = engine.Frame(dpb, 0, P.w, P.h)
     key = lambda k: 0xE000 + 16 * k
-    cur, wl, rec, n_mcx_in, n_done = None, None, None, 0, 0
+    cur, wl, rec, n_mcx_in, n_done, cells = None, None, None, 0, 0, None
     for e in ev:
         op = int(e["op"])
         if op == capi.FE_BEGIN:
@@ -123,6 +123,7 @@ def test_replay_of_the_shims_device_mode_call_log(built_lib, name):
                 assert f.dmvr_rows_begin(P.log2_ctu) == int(e["result"])
             elif op == capi.FE_DMVR_COLLECT:
                 n_done = f.dmvr_rows_collect()
+                cells = f.job().tmvp_cells()
                 assert n_done <= n_mcx_in                        # (a dry frame completes a pass at once; the device when it does)
             else:
                 assert n_mcx_in == len(wl.mcx_units)
@@ -134,14 +135,14 @@ def test_replay_of_the_shims_device_mode_call_log(built_lib, name):
                 out.mode, out.y, out.cb, out.cr, out.stride_y, out.stride_c = capi.OUT_PLANES, y.ctypes.data, cb.ctypes.data, cr.ctypes.data, P.w, P.w // 2
                 f.submit(engine.Job.make_params(keep, wl), out=out)
                 _check(name, cur, (y, cb, cr), P, f.job().refined_mvs(), wl)
-                # the plane entries the eager passes delivered = the oracle's for the refined vectors (what the shim patches into the
-                # picture's collocated motion field before the row is reported)
+                # the plane entries the eager passes delivered (read BEFORE the submit, as the shim's dmvr_rows_step does) = the
+                # oracle's for the refined vectors: what gets patched into the picture's collocated motion field before a row is reported
                 if len(wl.mcx_units):
                     import oracle_lib
-                    got = f.job().tmvp_cells()
+                    assert n_done == len(wl.mcx_units) and len(cells) == 4 * n_done
                     want = oracle_lib.tmvp_cells(wl.mcx_units, f.job().refined_mvs(), P.log2_ctu, (P.w + 127) // 128)
                     used = want["cell"] != capi.TMVP_NONE
-                    assert np.array_equal(got["cell"], want["cell"]) and np.array_equal(got[used], want[used])
+                    assert np.array_equal(cells["cell"], want["cell"]) and np.array_equal(cells[used], want[used])
                     assert used.sum() >= ((wl.mcx_units["flags"] & 64) != 0).sum()
     assert cur == P.n - 1
     f.close(); dpb.close()
