@@ -507,10 +507,11 @@ gp_main(int argc, char **argv)
     int want_shim = 0, want_dev = 0, variant = 0, W = 416, H = 240, dqp = 0;
     uint32_t seed = 0x266 + 31337;
     const char *name = "pipe";
-    /* gen_pipe <dir> [shim | device] [name <fixture name>] [seed <n>] [variant <0|1>] [qp <delta on every picture's QP>] [size <w> <h>] */
+    /* gen_pipe <dir> [shim | device | simd] [name <fixture name>] [seed <n>] [variant <0|1>] [qp <delta on every picture's QP>] [size <w> <h>] */
     for (int i = 2; i < argc; ++i) {
         if (!strcmp(argv[i], "shim")) want_shim = 1;
         else if (!strcmp(argv[i], "device")) want_shim = want_dev = 1;
+        else if (!strcmp(argv[i], "simd")) g_simd = 1;        /* the reference pass through the reference's SSE4.1 / AVX2 back-end (ref_common.h) */
         else if (!strcmp(argv[i], "name") && i + 1 < argc) name = argv[++i];
         else if (!strcmp(argv[i], "seed") && i + 1 < argc) seed = (uint32_t)strtoul(argv[++i], NULL, 0);
         else if (!strcmp(argv[i], "variant") && i + 1 < argc) variant = atoi(argv[++i]);

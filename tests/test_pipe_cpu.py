@@ -88,3 +88,11 @@ def test_pipe_fixtures_regenerate_identically(built_lib, tmp_path):
         subprocess.check_call([gen, str(tmp_path), "device"] + extra[name], stderr=subprocess.DEVNULL)
         for f in (f"{name}.ovg", f"shim_{name}.ovg", f"shim_{name}_dev.ovg"):
             assert (tmp_path / f).read_bytes() == (ROOT / "tests" / "golden" / f).read_bytes(), f
+    # A second witness for the legal-syntax stream: the reference's own SSE4.1 / AVX2 back-end (installed over the scalar table in
+    # rcn.c:216-254's order) decodes `pipe` to the same bytes as its scalar slots.  (Not so on 264-wide pictures: chroma rows of
+    # 132 samples -- its vector stores run 4 samples past the row's end into the next row's left edge; the scalar slots stay the
+    # oracle, as for the fixtures of test_oracle_golden.py.)
+    simd = tmp_path / "simd"
+    simd.mkdir()
+    subprocess.check_call([gen, str(simd), "simd"], stderr=subprocess.DEVNULL)
+    assert (simd / "pipe.ovg").read_bytes() == (ROOT / "tests" / "golden" / "pipe.ovg").read_bytes()
