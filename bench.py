@@ -153,6 +153,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU fallback")
+    if world == 1 and args.gpus > 1 and args.local_devices == 1:
+        # `python bench.py --gpus N` without torch.distributed.run: ONE process drives N devices through the C stream driver (device
+        # DPB, reference pictures by hipMemcpyPeerAsync) -- never a silent one-GPU run that prints n_gpus: 1
+        args.local_devices = args.gpus
+    if world > 1 and args.gpus not in (1, world):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if world == 1 and args.local_devices > 1 and not args.same_gpu and torch.cuda.device_count() < args.local_devices:
+        raise SystemExit(f"bench.py: {args.local_devices} devices asked for, {torch.cuda.device_count()} visible (--same-gpu puts the logical devices on GPU 0)")
     # OVVC_BENCH_DEBUG_GLOO=1 (development only): all ranks on GPU 0, pictures exchanged through host memory over gloo -- runs
     # the N > 1 control flow (schedule, comm thread, callbacks) on a one-GPU box.  Never set by the driver.
     debug_gloo = os.environ.get("OVVC_BENCH_DEBUG_GLOO") == "1"
@@ -208,11 +216,16 @@ def main():
     # loaded once): position -> content must be periodic with the rotation.  I pictures sit at idx = 1 + k * PPS: give them jobs of their own.
     n_ijobs = 3
     job_content = [j % n_b for j in range(n_jobs)] + [n_b] * n_ijobs
+    # a job's device buffers live on the device of the context it was created on (ovhip_job_bind refuses another device): one set of
+    # pre-recorded jobs per logical device, device d's set at [d * JPD, (d + 1) * JPD)
+    JPD = n_jobs + n_ijobs
+    ctxs = [ctx0] + [engine.Context(hip_devices[d]) for d in range(1, L)]
     jobs = []
-    for c in job_content:
-        j = engine.Job(ctx0, W, H)
-        j.load_workload(wls[c])
-        jobs.append(j)
+    for d in range(L):
+        for c in job_content:
+            j = engine.Job(ctxs[d], W, H)
+            j.load_workload(wls[c])
+            jobs.append(j)
 
     def build(n_gops_total, world_=1, dealing="gop", n_dev=1):
         pics = gop.build_stream(n_gops_total, G, IP, world_)
@@ -229,6 +242,9 @@ def main():
                         q.sends.append(p.owner)
         out, n_i = [], 0
         for p in pics:
+            device = 0
+            if n_dev > 1:
+                device = (p.idx % n_dev) if dealing == "picture" else (gop.gop_owner(max(p.gop, 0), n_dev, IP // G))
             if p.intra:
                 job = n_jobs + n_i % n_ijobs
                 n_i += 1
@@ -236,9 +252,7 @@ def main():
             else:
                 job = p.idx % n_jobs
                 content = job_content[job]
-            device = 0
-            if n_dev > 1:
-                device = (p.idx % n_dev) if dealing == "picture" else (gop.gop_owner(max(p.gop, 0), n_dev, IP // G))
+            job += device * JPD
             out.append({"content": content, "job": job, "poc": p.poc, "refs": p.refs[:capi.STREAM_MAX_REFS], "device": device,
                         "owner": p.owner, "send_mask": sum(1 << d for d in p.sends)})
         return pics, out
@@ -298,7 +312,7 @@ def main():
         torch.cuda.synchronize(dev)
 
     # ---- the local stream (this process alone): warm-up, surveys, variants, check ----
-    n_loc_gops = (args.warmup + 3 * 11 + 8) * (IP // G) + 8
+    n_loc_gops = (args.warmup + 3 * 11 + 8) * (IP // G) + 8 + (args.steps + max(1, args.warmup)) * (IP // G) * (L - 1)
     lpics, lspics = build(n_loc_gops, 1, args.dealing, L)
     larr = engine.Stream.pics_array(lspics)
     NL = len(lspics)
@@ -380,6 +394,7 @@ def main():
         tpics, tspics = build((warm_gops + gops_rank) * world, world, args.dealing, 1)
         tarr = engine.Stream.pics_array(tspics)
         NT = len(tspics)
+        step_fps = []
         st_t = new_stream(S, output=args.output, xfer=xfer)
         n_warm = 1 + warm_gops * world * G
         res, _ = st_t.run(tarr, NT, 0, n_warm, flags=capi.STREAM_KEEP)
@@ -401,24 +416,30 @@ def main():
             # continue the SAME stream on the driver that has the output thread: the pictures st_main kept are in the DPB under its
             # keys, so this driver starts a stream of its own -- one I picture, then warm-up of its own
             cur_t = [0]
-            tpics, tspics = build((max(1, args.warmup) + args.steps) * (IP // G), 1, args.dealing, L)
+            tpics, tspics = build((max(1, args.warmup) + args.steps) * (IP // G) * L, 1, args.dealing, L)
             tarr = engine.Stream.pics_array(tspics)
             NT = len(tspics)
-            n_warm = 1 + max(1, args.warmup) * PPS
+            n_warm = 1 + max(1, args.warmup) * PPS * L
             st_t.run(tarr, NT, 0, n_warm, flags=capi.STREAM_KEEP)
         else:
             tarr, NT, n_warm, tspics = larr, NL, cur[0], lspics
+        # (L logical devices: weak scaling -- a step is one intra period PER DEVICE, L x PPS pictures)
         barrier()
         t0 = time.perf_counter()
-        trace = np.zeros((args.steps * PPS, 4)) if args.trace else None
-        res, _ = st_t.run(tarr, NT, n_warm, args.steps * PPS, flags=capi.STREAM_KEEP, trace=trace)
-        if trace is not None:
-            np.save(args.trace, np.concatenate([trace, np.array([[len(tspics[n_warm + i]["refs"]), tspics[n_warm + i]["poc"], n_warm + i, 0] for i in range(len(trace))], float)], axis=1))
+        trace = np.zeros((args.steps * PPS * L, 4))
+        res, _ = st_t.run(tarr, NT, n_warm, args.steps * PPS * L, flags=capi.STREAM_KEEP, trace=trace)
         barrier()
         dt = time.perf_counter() - t0
+        if args.trace:
+            np.save(args.trace, np.concatenate([trace, np.array([[len(tspics[n_warm + i]["refs"]), tspics[n_warm + i]["poc"], n_warm + i, 0] for i in range(len(trace))], float)], axis=1))
+        # the rate of every step of the timed region (publication times of the driver's timeline; tools/debug/step_rates.py)
+        pub = np.sort(trace[:, 2])
+        edges = pub[PPS * L - 1::PPS * L][:args.steps]
+        sdur = np.diff(np.concatenate([[0.0], edges]))
+        step_fps = [PPS * L / d for d in sdur if d > 0]
         if st_t is st_main:
-            cur[0] += args.steps * PPS
-        n_timed_rank = n_timed_all = args.steps * PPS
+            cur[0] += args.steps * PPS * L
+        n_timed_rank = n_timed_all = args.steps * PPS * L
         assert int(res.n_decoded) == n_timed_rank
         xfers = [0, 0]
         count(res)
@@ -609,7 +630,12 @@ def main():
                     "ordered_pass": ({"levels_per_i_picture": int(wls[-1].stats["n_ilevels"]), "levels_per_b_picture": int(wls[0].stats["n_ilevels"]),
                                       "us_per_level_i_picture_isolated": None} if "intra" in kern else None),
                     "algorithmic_bytes": {k: int(v) for k, v in alg.items()},
-                    "frame_frac": round(sum(alg.values()) * fps / world / 1e9 / HBM_PEAK_GBPS, 5)}
+                    "frame_frac": round(sum(alg.values()) * fps / max(world, L) / 1e9 / HBM_PEAK_GBPS, 5),
+                    # SURVEY 8(d) as written: B_frame = (r_bar + 7) S + C, C = coefficients + commands consumed (the sum above also counts
+                    # the read-modify-write of the transform's residual add and the inverse luma mapping's pass)
+                    "frame_bytes_8d": int((float(np.dot(use, [w.stats["r_bar"] for w in wls])) + 7) * FB + float(np.dot(use, [w.stats["coef_bytes"] + 32 * (w.stats["n_tb_cmds"] + w.stats["n_mc_units"] + w.stats["n_mcx_units"] + w.stats["n_aff_units"]) for w in wls]))),
+                    "frame_frac_8d": None}
+        roofline["frame_frac_8d"] = round(roofline["frame_bytes_8d"] * fps / max(world, L) / 1e9 / HBM_PEAK_GBPS, 5)
 
         cpu = None
         if not args.no_cpu_baseline:
@@ -620,20 +646,26 @@ def main():
             t_one = time.perf_counter() - t1
             # all host cores: frame-level parallelism (one picture per thread, the reference's --framethr), bounded sample
             ncpu = os.cpu_count() or 1
-            nthr = max(1, min(ncpu, 64))
-            t1 = time.perf_counter()
-            th = [threading.Thread(target=oracle_pipeline.decode, args=(wl0,)) for _ in range(nthr)]
-            [t.start() for t in th]
-            [t.join() for t in th]
-            t_all = time.perf_counter() - t1
+
+            def threads_fps(n):
+                t1 = time.perf_counter()
+                th = [threading.Thread(target=oracle_pipeline.decode, args=(wl0,)) for _ in range(n)]
+                [t.start() for t in th]
+                [t.join() for t in th]
+                return n / (time.perf_counter() - t1), time.perf_counter() - t1
+
+            # every logical core of the host ("1 thread and all host cores"); the 64-thread figure of the earlier rounds beside it
+            nthr = ncpu
+            f_all, t_all = threads_fps(nthr)
+            f_64 = threads_fps(64)[0] if ncpu > 64 else f_all
             cal = _calibration()
-            cpu = {"value": round(nthr / t_all, 3), "unit": "frames/s", "cores": nthr, "kind": "port",
-                   "value_1_thread": round(1.0 / t_one, 4),
+            cpu = {"value": round(f_all, 3), "unit": "frames/s", "cores": nthr, "kind": "port",
+                   "value_1_thread": round(1.0 / t_one, 4), "value_64_threads": round(f_64, 3),
                    "sample": f"oracle/liboracle.so (scalar C restatement of the rcn path) decoding the same {W}x{H} recorded "
                              f"picture: once on 1 thread ({t_one:.2f} s), then {nthr} pictures on {nthr} threads, one picture "
                              f"per thread as the reference's frame threads do ({t_all:.2f} s); {ncpu} logical cores present",
                    "calibration": cal}
-            est = _reference_estimates(cal, nthr / t_all)
+            est = _reference_estimates(cal, f_all)
             if est:
                 cpu.update(est)
 
@@ -643,10 +675,12 @@ def main():
             "metric": "decoded frames/sec, full rcn back-end decode step (H2D of the recorded picture + MC incl. BDOF/DMVR/"
                       "affine-PROF/GPM/CIIP + LMCS + inverse transform + ordered intra pass + deblocking + SAO + ALF/CC-ALF + D2H of refined MVs "
                       "+ wait + per-picture digest + publication to the device DPB), 4K 10-bit RA recorded stream, bit-exact vs oracle",
-            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world if world > 1 else L, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None, "dtype": "u16 samples / int16 coefficients / int32 accumulate", "data": "synthetic",
-            "config": {"pictures_per_step": PPS, "pictures_timed": n_timed_all, "pictures_timed_this_rank": n_timed_rank,
+            "config": {"pictures_per_step": PPS * (L if world == 1 else 1), "pictures_timed": n_timed_all,
+                       "step_fps": ({"min": round(min(step_fps), 1), "median": round(float(np.median(step_fps)), 1), "max": round(max(step_fps), 1),
+                                     "what": "pictures/s of each of the timed steps (from the publication times of the driver's own timeline)"} if step_fps else None), "pictures_timed_this_rank": n_timed_rank,
                        "workload": f"{W}x{H} 10-bit 4:2:0 synthetic recorded random-access stream (BASELINE configs[3]): GOP {G} "
                                    f"(hierarchical B, JVET decoding order), intra period {IP}: per GOP {G - 1} B pictures with "
                                    f"{args.intra_frac:.0%} intra CUs + the key picture ({'I' if G % IP == 0 else 'I every ' + str(IP // G) + ' GOPs, else B'}); "
@@ -658,7 +692,9 @@ def main():
                        "frame_thread_host_us_per_picture": host_us,
                        "dealing": args.dealing if (world > 1 or L > 1) else None,
                        "other_dealing": other_dealing,
-                       "output": args.output, "recorder_in_timed_region": False,
+                       "output": args.output + (" (per picture a PRIVATE tree fingerprint leaves the device: MD5 of MD5s over 512-byte pieces of the cropped rows, "
+                                                "DESIGN 4.2 -- not the MD5 of the file dectest would write; that one is ovhip_stream's FILE_MD5 mode)" if args.output == "digest" else ""),
+                       "recorder_in_timed_region": False,
                        "variants": variants,
                        "gop_size": G, "intra_period": IP,
                        "dependency_critical_path_pictures": round(gop.critical_path(gop.build_stream(4 * world, G, IP, world)), 1),

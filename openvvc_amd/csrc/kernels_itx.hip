@@ -549,7 +549,11 @@ __global__ __launch_bounds__(256) OV_OCC_ITX void k_itx_all(ovhip_pic pic, const
 static int itx_ablate()
 {
     static int cfg_ablate = -1;
-    if (cfg_ablate < 0) { const char *a = getenv("OVHIP_ITX_ABLATE"); cfg_ablate = a ? atoi(a) : 0; }   // profiling knob
+#ifdef OVHIP_TUNING          // experiment knobs read the environment only in tuning builds (make EXTRA=-DOVHIP_TUNING): a stray variable
+    if (cfg_ablate < 0) { const char *a = getenv("OVHIP_ITX_ABLATE"); cfg_ablate = a ? atoi(a) : 0; }   // must not change a decoder's results
+#else
+    cfg_ablate = 0;
+#endif
     return cfg_ablate;
 }
 

@@ -348,7 +348,11 @@ extern "C" int ovhip_mc_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip
     }
     for (uint32_t i = n_refs; i < MC_MAX_REFS; ++i) t.p[i] = refs[0];
     static int cfg_xcd = -1;
+#ifdef OVHIP_TUNING
     if (cfg_xcd < 0) { const char *x = getenv("OVHIP_MC_XCD"); cfg_xcd = x ? atoi(x) : 1; }   // experiment knob: XCD-aware unit order
+#else
+    cfg_xcd = 1;
+#endif
     // one single-wave workgroup per unit (measured faster than a resident grid-stride grid).  Units with a fused CIIP
     // blend read `intra`; without such units the argument is never dereferenced.
     hipLaunchKernelGGL(k_mc2, dim3(n_units), dim3(64), 0, ctx->stream, *dst, t, d_units, n_units, d_lmcs_fwd_lut, cfg_xcd,

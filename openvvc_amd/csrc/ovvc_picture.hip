@@ -39,7 +39,7 @@ struct ovhip_job {
     int32_t *mv_host; size_t mv_cap;     // pinned: refined vectors, 4 int32 per refined unit
     struct { int valid, has_intra; ovhip_pic dst, refs[16], intra; uint32_t n_refs; ovhip_job_params pr; } again;   // the last flush's arguments
     uint32_t n_retries;                  // second passes of the last picture (ovhip_job_wait)
-    int test_abort;                      // ovhip_job_test_abort_next_flow
+    int test_abort, test_abort_seen;     // ovhip_job_test_abort_next_flow (a forced abort does not count as evidence of starvation)
     ovhip_tmvp_cell *tmvp_host; size_t tmvp_cap, n_tmvp;   // pinned: TMVP plane cells of the refined units (ovhip_job_params.tmvp_cells)
     size_t n_mv;                         // units covered by the last flush / eager pass
     size_t dmvr_first;                   // refined units [0, dmvr_first) already went through the eager search
@@ -55,6 +55,8 @@ struct ovhip_job {
     hipEvent_t t_ev[32][2]; uint8_t t_pending[32]; int t_next;
     double t_sum_ms; uint64_t t_count;
 };
+
+static int g_flow_shift;                 // workers of a flow launch = (4 x CUs) >> g_flow_shift: grows with every launch that was abandoned
 
 namespace {
 
@@ -244,6 +246,8 @@ int ovhip_job_wait(ovhip_job *j)
         // the picture again with one launch per level -- no workgroup of such a launch waits for another -- from the recorder's
         // arrays, which are untouched until the next ovhip_job_begin.  Every sample of dst is rewritten by a flush.
         *(volatile uint32_t *)j->abort_host = 0;
+        if (!j->test_abort_seen && __atomic_load_n(&g_flow_shift, __ATOMIC_RELAXED) < 4) __atomic_fetch_add(&g_flow_shift, 1, __ATOMIC_RELAXED);
+        j->test_abort_seen = 0;
         if (j->d_sync) (void)hipMemset(j->d_sync, 0, sizeof(uint32_t));
         if (j->d_flow) (void)hipMemset(j->d_flow, 0, sizeof(uint32_t));
         if (j->again.valid && j->n_retries == 0) {
@@ -619,7 +623,7 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
         // test hook (ovhip_job_test_abort_next_flow): the abort word is set on the device BEFORE the launch, so every item that has to
         // wait for another gives up at once -- a real abandoned first pass, picture incomplete and partly tagged
         if (j->test_abort && j->n_retries == 0) {
-            j->test_abort = 0;
+            j->test_abort = 0; j->test_abort_seen = 1;
             OV_HIP(ctx, hipMemsetAsync(j->d_flow, 0xff, sizeof(uint32_t), ctx->stream));
             *(volatile uint32_t *)j->abort_host = 1;
         }
@@ -694,9 +698,18 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
             // workers (its pass: 104 us with a workgroup per item, 156 with 1024 workers, 229 with 512); beside other pictures that
             // does not show.  GPU_MAX_HW_QUEUES = 8 with W = 512: 3000-3060 / 0, no gain.  (OVHIP_FLOW_WORKERS, OVHIP_FLOW_CHUNK:
             // tuning knobs, read once; chunked launches -- whole levels per launch -- remain for ovhip_job_params.flow_chunk_items)
+#ifdef OVHIP_TUNING
             static const size_t FLOW_CHUNK = getenv("OVHIP_FLOW_CHUNK") && atol(getenv("OVHIP_FLOW_CHUNK")) > 0 ? (size_t)atol(getenv("OVHIP_FLOW_CHUNK")) : ((size_t)1 << 30);
             static const long WORKERS = getenv("OVHIP_FLOW_WORKERS") ? atol(getenv("OVHIP_FLOW_WORKERS")) : -1;
-            const int n_workers = pr->flow_workers ? (int)pr->flow_workers : (WORKERS >= 0 ? (int)WORKERS : 4 * ctx->num_cus);
+#else
+            static const size_t FLOW_CHUNK = (size_t)1 << 30;
+            static const long WORKERS = -1;
+#endif
+            //  the 4 x CUs default assumes 4 hardware queues and 16 resident waves per CU; where that does not hold (another
+            // GPU_MAX_HW_QUEUES, another process on the GPU) flow launches starve each other and pictures fall into second passes:
+            // every abandoned launch halves the default for the launches that follow (g_flow_shift, down to CUs / 4)
+            int n_workers = pr->flow_workers ? (int)pr->flow_workers : (WORKERS >= 0 ? (int)WORKERS : (4 * ctx->num_cus) >> __atomic_load_n(&g_flow_shift, __ATOMIC_RELAXED));
+            if (n_workers < 1) n_workers = 1;
             size_t a = 0;
             int first = !flow_prepared;
             const size_t chunk = pr->flow_chunk_items ? pr->flow_chunk_items : FLOW_CHUNK;

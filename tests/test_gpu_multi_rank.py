@@ -46,3 +46,23 @@ def test_two_ranks_on_one_gpu(built_lib, dealing):
     sent_pic = c["transfers_this_rank"]["sent"] if dealing == "picture" else c["other_dealing"]["pictures_sent_by_this_rank"]
     sent_gop = c["transfers_this_rank"]["sent"] if dealing == "gop" else c["other_dealing"]["pictures_sent_by_this_rank"]
     assert sent_pic > 4 * sent_gop
+
+
+@pytest.mark.gpu
+def test_gpus_flag_without_torchrun_drives_that_many_devices(built_lib):
+    """`python bench.py --gpus 2` launched WITHOUT torch.distributed.run (WORLD_SIZE unset) must not decode on one GPU and print
+    n_gpus: 1: it takes the one-process path (C stream driver over two logical devices, a set of pre-recorded jobs per device, peer
+    copies through the device DPB) -- here both on GPU 0 (--same-gpu) -- and says n_gpus: 2; with more devices than visible it refuses."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--same-gpu", "--steps", "1", "--warmup", "1", "--width", "832", "--height", "480",
+           "--no-cpu-baseline", "--no-isolated-survey", "--check", "3"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["local_devices"] == 2 and d["scaling"] == "weak"
+    assert c["pictures_timed"] == 2 * 64 and c["pictures_per_step"] == 2 * 64 and c["check"]["differ"] == 0
+    assert c["dpb"]["peer_copies"] > 0 and c["other_dealing"]["dealing"] == "picture" and c["other_dealing"]["peer_copies"] > c["dpb"]["peer_copies"]
+    assert c["step_fps"]["min"] > 0
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "64", "--steps", "1"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "devices asked for" in p.stderr
