@@ -104,6 +104,10 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--seed", type=int, default=0x266)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference-stream", action="store_true",
+                    help="skip the leg on the stream the REFERENCE's own slice decoder parses and decodes (oracle/_ref/gen_pipe, prebuilt from "
+                         "/root/reference in the build container): its scalar / SIMD decode rate on this host's cores = cpu_baseline kind "
+                         "\"reference\", and the same nine 3840x2160 pictures through the HIP engine compared byte for byte with the reference's frames")
     ap.add_argument("--no-isolated-survey", action="store_true",
                     help="skip the one-picture-in-flight survey and the variants: every launch of the process then runs in the timed configuration "
                          "(what tools/profile_round.sh traces, so that rocprofv3's per-kernel averages are of that configuration)")
@@ -573,6 +577,12 @@ def main():
         if differ or differ_self:
             raise SystemExit(f"bench --check: {differ} pictures differ from the oracle, {differ_self} differ between in-flight counts")
 
+    ref_stream = None
+    if rank == 0 and not args.no_reference_stream and (W, H) == (3840, 2160):
+        ref_stream = reference_stream_on_device(engine, capi, ctx0, W, H, 9, 10)
+        if ref_stream and (ref_stream["samples_differing_from_the_reference"] or ref_stream["refined_vectors_differing"]):
+            raise SystemExit(f"bench: the reference's stream decodes differently on the device: {ref_stream}")
+
     if rank == 0:
         algs = [algorithmic_bytes(wl, FB) for wl in wls]
         use = np.zeros(len(wls))
@@ -668,6 +678,20 @@ def main():
             est = _reference_estimates(cal, f_all)
             if est:
                 cpu.update(est)
+            if not args.no_reference_stream and (W, H) == (3840, 2160):
+                ref = reference_cpu_rates(W, H, 9, ncpu)
+                if ref:
+                    # the reference itself on this host's cores (north_star): the headline cpu_baseline; the port's figures stay beside it
+                    port = {k: cpu[k] for k in ("value", "cores", "value_1_thread", "value_64_threads", "sample") if k in cpu}
+                    cpu = {"value": ref["scalar"]["fps_all_cores"], "unit": "frames/s", "cores": ncpu, "kind": "reference",
+                           "value_1_thread": ref["scalar"]["fps_1_process"],
+                           "simd": ref["simd"], "scalar": ref["scalar"],
+                           "sample": f"oracle/_ref/gen_pipe time: the reference's own slice decoder (parse + reconstruction + in-loop filters; libovvc "
+                                     f"compiled from /root/reference in the build container, scalar slots) on its chained stream of 9 {W}x{H} pictures: one "
+                                     f"process alone, then {ncpu} processes at once (one per logical core, each its own stream -- frame-level parallelism); "
+                                     "`simd` = the same through the reference's SSE4.1 / AVX2 back-end.  The stream is the one config.reference_stream decodes "
+                                     "on the GPU; the headline `value` is measured on the synthetic recorded stream of config.workload",
+                           "port": port, "calibration": cal}
 
         st = wls[0].stats
         js = flush_stats
@@ -703,6 +727,7 @@ def main():
                        "h2d_bytes_per_step": int(mean_stat("h2d_bytes")), "d2h_bytes_per_step": int(mean_stat("d2h_bytes")),
                        "ordered_pass_second_passes": second_passes[0],
                        "check": check,
+                       "reference_stream": ref_stream,
                        "launches_per_b_picture": int(js.n_launches),
                        "launches_per_i_picture": int(all_stats[n_jobs].n_launches),
                        "h2d_copies_per_step": round(mean_stat("n_h2d"), 1),
@@ -730,6 +755,105 @@ def main():
     if world > 1:
         dist.destroy_process_group()
 
+
+
+GEN_PIPE = ROOT / "oracle" / "_ref" / "gen_pipe"
+
+
+def reference_cpu_rates(W, H, n_pics, ncpu):
+    """The reference's OWN slice decoder (libovvc/slicedec.c + the rcn slots, compiled from /root/reference where it lay; oracle/ref_harness/
+    gen_pipe.c) decoding its chained stream of n_pics WxH pictures: one process on one core, then one process per logical core (each its own
+    stream, seeds differ: frame-level parallelism as --framethr gives it), scalar slots and the x86 SSE4.1 / AVX2 back-end.
+    -> dict or None when the prebuilt harness is not there."""
+    import subprocess
+    if not GEN_PIPE.exists():
+        return None
+
+    def batch(n, simd):
+        cmds = [[str(GEN_PIPE), "/tmp", "time", "size", str(W), str(H), "pics", str(n_pics), "seed", str(1000 + i)] + (["simd"] if simd else []) for i in range(n)]
+        t0 = time.perf_counter()
+        ps = [subprocess.Popen(c, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for c in cmds]
+        outs = [p.communicate()[0] for p in ps]
+        wall = time.perf_counter() - t0
+        if any(p.returncode != 0 for p in ps):
+            return None
+        inner = [json.loads(o.strip().splitlines()[-1])["seconds"] for o in outs]
+        return {"fps": n * n_pics / wall, "wall_s": wall, "fps_inside_decoder_mean_per_process": float(np.mean([n_pics / x for x in inner]))}
+
+    out = {}
+    try:
+        # a process holds its pictures (9 frames + motion planes) and the slice data: ~0.35 GB at 4K -- stay far below the host's free memory
+        avail = next((int(l.split()[1]) * 1024 for l in open("/proc/meminfo") if l.startswith("MemAvailable")), 0)
+        per = int(W * H * 3 * n_pics * 1.3 + W * H * 2 * 2)
+        ncpu = max(1, min(ncpu, int(0.4 * avail / per))) if avail else min(ncpu, 32)
+        for simd in (0, 1):
+            one, alln = batch(1, simd), batch(ncpu, simd)
+            if one is None or alln is None:
+                return None
+            out["simd" if simd else "scalar"] = {"fps_1_process": round(one["fps_inside_decoder_mean_per_process"], 3), "fps_all_cores": round(alln["fps"], 2),
+                                                 "processes": ncpu, "wall_s": round(alln["wall_s"], 2),
+                                                 "fps_per_process_under_load": round(alln["fps_inside_decoder_mean_per_process"], 3)}
+    except (OSError, ValueError, KeyError, IndexError):
+        return None
+    return out
+
+
+def reference_stream_on_device(engine, capi, ctx, W, H, n_pics, reps):
+    """The same stream through the HIP engine: gen_pipe writes the reference's frames and what the installed shim slots recorded; every
+    picture is decoded on the device from the DEVICE's earlier pictures (ovhip_job_flush / _wait: uploads included) and compared byte for
+    byte with the reference's frame; then the chain is timed, one picture in flight."""
+    import subprocess, tempfile, shutil
+    import ctypes as C
+    import pipe_cases
+    if not GEN_PIPE.exists():
+        return None
+    d = tempfile.mkdtemp(prefix="ovvc_refstream_")
+    try:
+        base = [str(GEN_PIPE), d]
+        tail = ["size", str(W), str(H), "pics", str(n_pics)]
+        subprocess.check_call(base + tail, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        subprocess.check_call(base + ["shim"] + tail, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        P = pipe_cases.Pipe("pipe", d)
+    except (OSError, subprocess.CalledProcessError):
+        shutil.rmtree(d, ignore_errors=True)
+        return None
+    shutil.rmtree(d, ignore_errors=True)
+    jobs, wls, dst = [], [], []
+    for k in range(P.n):
+        wl = P.workload(k, {i: None for i in range(k)})
+        j = engine.Job(ctx, P.w, P.h)
+        j.load_workload(wl)
+        jobs.append(j); wls.append(wl); dst.append(ctx.new_pic(P.w, P.h))
+
+    def chain():
+        for k in range(P.n):
+            jobs[k].flush(dst[k], [dst[i] for i in P.ref_indices(k)], None)
+            jobs[k].wait()
+
+    chain()
+    differ, mv_differ = 0, 0
+    for k in range(P.n):
+        got = dst[k].download()
+        differ += int(sum(int((a != b).sum()) for a, b in zip(got, P.frames[k])))
+        calls = P.dmvr_calls(k)
+        if len(calls):
+            is_dmvr = (wls[k].mcx_units["flags"] & 64) != 0
+            mv_differ += int((jobs[k].refined_mvs()[is_dmvr] != calls[:, 8:12]).any(axis=1).sum())
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        chain()
+    dt = time.perf_counter() - t0
+    n_units = {k: int(sum(len(getattr(w, a)) for w in wls)) for k, a in (("mc", "mc_units"), ("refined", "mcx_units"), ("affine", "aff_units"), ("transform_blocks", "tb_cmds"))}
+    n_units["ordered_tasks"] = int(sum(0 if w.itasks is None else len(w.itasks) for w in wls))
+    n_units["dmvr_calls"] = int(len(P.dmvr))
+    for j in jobs:
+        j.close()
+    return {"pictures": P.n, "width": P.w, "height": P.h, "samples_differing_from_the_reference": differ, "refined_vectors_differing": mv_differ,
+            "fps_one_picture_in_flight": round(P.n * reps / dt, 1), "units": n_units,
+            "what": "oracle/_ref/gen_pipe (the reference's slicedec.c compiled where it lay, driven over seeded slice data: DESIGN 2) decoded "
+                    f"{P.n} chained {P.w}x{P.h} pictures (I B B B P b b b b of a GOP of 8) with the reference's scalar slots and recorded the "
+                    "same parse through the installed shim slots; here the recorded stream went through ovhip_job_flush picture by picture, each "
+                    "from the device's own earlier pictures, and every frame and every DMVR vector was compared with the reference's"}
 
 def _calibration():
     """Reference scalar C (and SIMD) vs the oracle port on identical slot-level cases, timed in the build container (committed; the

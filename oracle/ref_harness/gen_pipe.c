@@ -46,6 +46,7 @@
 #include "decinit.h"
 #include "ovdec_internal.h"
 #include <pthread.h>
+#include <time.h>
 
 #include "slicedec.c"        /* /root/reference/libovvc/slicedec.c, compiled where it lies (-I$(R)) */
 
@@ -385,7 +386,7 @@ gp_new_ctudec(const struct gp_seq *s)
 }
 
 /* ------------------------------------------------------------------------------------------------ the stream */
-#define GP_MAX_PIC 8
+#define GP_MAX_PIC 9
 struct gp_pic_desc { int poc, slice_type, qp, l0[2], n0, l1[2], n1, tmvp, col_from_l0, lmcs; };
 
 struct gp_out {
@@ -396,7 +397,11 @@ struct gp_out {
 };
 
 static uint8_t *g_payload;
-#define GP_PAYLOAD (1 << 20)
+static size_t g_payload_bytes = 1 << 20;           /* slice data per picture: 1 MiB covers 1024x1024 many times over; "size" scales it */
+#define GP_PAYLOAD g_payload_bytes
+static int g_time_only;                            /* "time" mode: nothing is kept */
+static double g_decode_seconds;                    /* "time" mode: wall time inside slicedec_decode_rect_entry */
+static inline double gp_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
 
 static void
 run_stream(struct gp_seq *s, const struct gp_pic_desc *desc, int n_pic, uint32_t seed, struct gp_out *out)
@@ -426,7 +431,7 @@ run_stream(struct gp_seq *s, const struct gp_pic_desc *desc, int n_pic, uint32_t
         const struct gp_pic_desc *d = &desc[k];
         g_seed = seed + 977 * k;
         /* slice data: seeded bytes; the first byte keeps the arithmetic decoder's start condition (vcl_cabac.c:960) */
-        for (int i = 0; i < GP_PAYLOAD; ++i) g_payload[i] = (uint8_t)(rnd32() >> 7);
+        for (size_t i = 0; i < GP_PAYLOAD; ++i) g_payload[i] = (uint8_t)(rnd32() >> 7);
         g_payload[0] &= 0x7f;
         pics[k] = gp_new_picture(s, d->poc);
         OVPicture *l0[2] = { d->n0 > 0 ? pics[d->l0[0]] : NULL, d->n0 > 1 ? pics[d->l0[1]] : NULL };
@@ -440,10 +445,14 @@ run_stream(struct gp_seq *s, const struct gp_pic_desc *desc, int n_pic, uint32_t
         slicedec_init_lines(&sl, &s->ps);
         slicedec_update_entry_decoder(&sl, c);
         const size_t dm0 = g_pass_shim ? g_dmvr_pos : g_dmvr_log.n / 12;
+        const double t_dec = gp_now();
         slicedec_decode_rect_entry(&sl, c, &s->ps, 0);
+        g_decode_seconds += gp_now() - t_dec;
         ovdpb_report_decoded_frame(pics[k]);
+        if ((size_t)(c->cabac_ctx ? 0 : 0)) {}
         const size_t dm1 = g_pass_shim ? g_dmvr_pos : g_dmvr_log.n / 12;
         fprintf(stderr, "  picture %d: POC %d %s qp %d, %zu DMVR calls\n", k, d->poc, d->slice_type == 2 ? "I" : d->slice_type == 1 ? "P" : "B", d->qp, dm1 - dm0);
+        if (!g_pass_shim && g_time_only) continue;
         if (!g_pass_shim) {
             const OVFrame *f = pics[k]->frame;
             gbuf_push(&out->frames, f->data[0], (size_t)s->w * s->h);
@@ -504,10 +513,10 @@ int
 gp_main(int argc, char **argv)
 {
     const char *dir = argc > 1 ? argv[1] : "../tests/golden";
-    int want_shim = 0, want_dev = 0, variant = 0, W = 416, H = 240, dqp = 0;
+    int want_shim = 0, want_dev = 0, want_time = 0, variant = 0, W = 416, H = 240, dqp = 0, n_pic = 5;
     uint32_t seed = 0x266 + 31337;
     const char *name = "pipe";
-    /* gen_pipe <dir> [shim | device | simd] [name <fixture name>] [seed <n>] [variant <0|1>] [qp <delta on every picture's QP>] [size <w> <h>] */
+    /* gen_pipe <dir> [shim | device | simd] [name <fixture name>] [seed <n>] [variant <0|1>] [qp <delta on every picture's QP>] [size <w> <h>] [pics <1..9>] [time] */
     for (int i = 2; i < argc; ++i) {
         if (!strcmp(argv[i], "shim")) want_shim = 1;
         else if (!strcmp(argv[i], "device")) want_shim = want_dev = 1;
@@ -516,21 +525,27 @@ gp_main(int argc, char **argv)
         else if (!strcmp(argv[i], "seed") && i + 1 < argc) seed = (uint32_t)strtoul(argv[++i], NULL, 0);
         else if (!strcmp(argv[i], "variant") && i + 1 < argc) variant = atoi(argv[++i]);
         else if (!strcmp(argv[i], "qp") && i + 1 < argc) dqp = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "pics") && i + 1 < argc) n_pic = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "time")) want_time = g_time_only = 1;       /* reference pass only; prints pictures and seconds inside the slice decoder */
         else if (!strcmp(argv[i], "size") && i + 2 < argc) { W = atoi(argv[i + 1]); H = atoi(argv[i + 2]); i += 2; }
         else { fprintf(stderr, "gen_pipe: unknown argument %s\n", argv[i]); return 2; }
     }
-    if (W % 8 || H % 8 || W > 1024 || H > 1024) { fprintf(stderr, "gen_pipe: size\n"); return 2; }
+    if (W % 8 || H % 8 || W < 136 || H < 136 || W > 4096 || H > 2304 || n_pic < 1 || n_pic > GP_MAX_PIC) { fprintf(stderr, "gen_pipe: size / pics\n"); return 2; }
+    while (g_payload_bytes < (size_t)W * H * 2) g_payload_bytes <<= 1;          /* 16 bits per sample: far above any slice's need */
     if (posix_memalign((void **)&g_payload, 64, GP_PAYLOAD)) abort();
-    /* decoding order of a small hierarchical GOP: I0, B8 (two lists to the I picture), B4 (between them: DMVR / BDOF / SMVD
-     * have a past and a future reference, TMVP from B8), B2, P6 */
-    struct gp_pic_desc gop[5] = {
+    /* decoding order of a hierarchical GOP of 8: I0, B8 (two lists to the I picture), B4 (between them: DMVR / BDOF / SMVD have a past
+     * and a future reference, TMVP from B8), B2, P6; with "pics 9" the rest of the GOP: b1, b3, b5, b7 */
+    struct gp_pic_desc gop[GP_MAX_PIC + 1] = {
         { .poc = 0, .slice_type = 2, .qp = 30, .lmcs = 1 },
         { .poc = 8, .slice_type = 0, .qp = 33, .l0 = { 0 }, .n0 = 1, .l1 = { 0 }, .n1 = 1, .tmvp = 0, .col_from_l0 = 1, .lmcs = 1 },
         { .poc = 4, .slice_type = 0, .qp = 35, .l0 = { 0, 1 }, .n0 = 2, .l1 = { 1, 0 }, .n1 = 2, .tmvp = 1, .col_from_l0 = 0, .lmcs = 1 },
         { .poc = 2, .slice_type = 0, .qp = 37, .l0 = { 0, 2 }, .n0 = 2, .l1 = { 2, 1 }, .n1 = 2, .tmvp = 1, .col_from_l0 = 0, .lmcs = 0 },
         { .poc = 6, .slice_type = 1, .qp = 37, .l0 = { 2, 0 }, .n0 = 2, .n1 = 0, .tmvp = 1, .col_from_l0 = 1, .lmcs = 1 },
+        { .poc = 1, .slice_type = 0, .qp = 38, .l0 = { 0, 3 }, .n0 = 2, .l1 = { 3, 2 }, .n1 = 2, .tmvp = 1, .col_from_l0 = 0, .lmcs = 1 },
+        { .poc = 3, .slice_type = 0, .qp = 38, .l0 = { 3, 0 }, .n0 = 2, .l1 = { 2, 4 }, .n1 = 2, .tmvp = 1, .col_from_l0 = 1, .lmcs = 1 },
+        { .poc = 5, .slice_type = 0, .qp = 38, .l0 = { 2, 3 }, .n0 = 2, .l1 = { 4, 1 }, .n1 = 2, .tmvp = 1, .col_from_l0 = 0, .lmcs = 1 },
+        { .poc = 7, .slice_type = 0, .qp = 38, .l0 = { 4, 2 }, .n0 = 2, .l1 = { 1, 4 }, .n1 = 2, .tmvp = 1, .col_from_l0 = 1, .lmcs = 1 },
     };
-    const int n_pic = 5;
     for (int k = 0; k < n_pic; ++k) gop[k].qp += dqp;
     struct gp_out out;
     memset(&out, 0, sizeof(out));
@@ -546,6 +561,10 @@ gp_main(int argc, char **argv)
         seq_init(&seq, W, H, variant);
         fprintf(stderr, "gen_pipe: %s pass\n", g_pass_shim == 2 ? "device (dry)" : g_pass_shim ? "shim" : "reference");
         run_stream(&seq, gop, n_pic, seed, &out);
+    }
+    if (want_time) {
+        printf("{\"pictures\": %d, \"width\": %d, \"height\": %d, \"seconds\": %.6f, \"simd\": %d, \"isp_64x2\": %d}\n", n_pic, W, H, g_decode_seconds, g_simd, g_isp_64x2);
+        return 0;
     }
     if (g_isp_64x2) { fprintf(stderr, "gen_pipe: the stream holds %d 64x2 ISP partitions (reference result undefined): pick another seed\n", g_isp_64x2); return 1; }
 

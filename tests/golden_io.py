@@ -7,8 +7,8 @@ GOLDEN = Path(__file__).resolve().parent / "golden"
 _DT = {0: "u1", 1: "<i2", 2: "<u2", 3: "<i4", 4: "<u4", 5: "<u8", 6: "i1"}
 
 
-def load(name: str) -> dict:
-    raw = (GOLDEN / name).read_bytes()
+def load(name: str, directory=None) -> dict:
+    raw = (Path(directory) / name if directory is not None else GOLDEN / name).read_bytes()
     magic, n = struct.unpack_from("<II", raw, 0)
     assert magic == 0x3147564F, "not an OVG1 file"
     off, out = 8, {}

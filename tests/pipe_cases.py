@@ -20,8 +20,9 @@ from shim_cases import ShimStream
 
 
 class Pipe:
-    def __init__(self, name="pipe"):
-        g = golden_io.load(f"{name}.ovg")
+    def __init__(self, name="pipe", directory=None):
+        """directory: where <name>.ovg / shim_<name>.ovg lie (default tests/golden; bench.py: a stream gen_pipe just made)"""
+        g = golden_io.load(f"{name}.ovg", directory)
         self.w, self.h, self.n, self.log2_ctu = (int(v) for v in g["geometry"])
         self.info = g["info"]                      # poc, slice type, qp, n0, l0[2], n1, l1[2], tmvp, first / end DMVR call, lmcs
         self.dmvr = g["dmvr"]                      # x, y, log2 w, log2 h, mv0 in, mv1 in, mv0 out, mv1 out
@@ -31,7 +32,7 @@ class Pipe:
             f = fr[k * s * 3 // 2:(k + 1) * s * 3 // 2]
             self.frames.append((f[:s].reshape(self.h, self.w), f[s:s * 5 // 4].reshape(self.h // 2, self.w // 2),
                                 f[s * 5 // 4:].reshape(self.h // 2, self.w // 2)))
-        self.s = ShimStream(f"shim_{name}.ovg")
+        self.s = ShimStream(f"shim_{name}.ovg", directory)
         assert self.s.n == self.n
         self.g = self.s.g
 

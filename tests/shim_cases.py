@@ -17,8 +17,8 @@ DTYPES = {"tb": capi.TB_CMD_DTYPE, "coef": np.dtype("<i2"), "mc": capi.MC_UNIT_D
 
 
 class ShimStream:
-    def __init__(self, name: str):
-        g = golden_io.load(name)
+    def __init__(self, name: str, directory=None):
+        g = golden_io.load(name, directory)
         self.g = g
         self.arr = {k: np.frombuffer(np.ascontiguousarray(g[k]).tobytes(), dtype=DTYPES[k]) for k in ARRAYS}
         self.off = g["case_off"]

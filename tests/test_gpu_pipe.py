@@ -146,3 +146,23 @@ def test_replay_of_the_shims_device_mode_call_log(built_lib, name):
                     assert used.sum() >= ((wl.mcx_units["flags"] & 64) != 0).sum()
     assert cur == P.n - 1
     f.close(); dpb.close()
+
+
+def test_full_size_stream_of_the_reference_slice_decoder(built_lib):
+    """BASELINE's full size: the prebuilt harness (oracle/_ref/gen_pipe: the reference's slicedec.c + rcn slots, compiled in the build
+    container; it travels with the snapshot, /root/reference does not) decodes nine chained 3840x2160 pictures HERE and records the same
+    parse through the installed shim slots; the HIP engine must reproduce all nine frames and every DMVR vector (bench.py's
+    config.reference_stream leg, with one repetition)."""
+    import importlib.util
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    if not (root / "oracle" / "_ref" / "gen_pipe").exists():
+        pytest.skip("oracle/_ref/gen_pipe is built only where /root/reference exists")
+    spec = importlib.util.spec_from_file_location("bench", root / "bench.py")
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    ctx = engine.Context(0)
+    r = bench.reference_stream_on_device(engine, capi, ctx, 3840, 2160, 9, 1)
+    ctx.close()
+    assert r is not None and r["pictures"] == 9
+    assert r["samples_differing_from_the_reference"] == 0 and r["refined_vectors_differing"] == 0
+    assert r["units"]["dmvr_calls"] > 20000 and r["units"]["ordered_tasks"] > 20000 and r["units"]["affine"] > 5000
