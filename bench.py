@@ -770,14 +770,21 @@ def reference_cpu_rates(W, H, n_pics, ncpu):
         return None
 
     def batch(n, simd):
-        cmds = [[str(GEN_PIPE), "/tmp", "time", "size", str(W), str(H), "pics", str(n_pics), "seed", str(1000 + i)] + (["simd"] if simd else []) for i in range(n)]
+        # seeds 1000 .. 1255 were run in the build container; 1247 makes the REFERENCE fault in put_vvc_qpel_v under rcn_dmvr_mv_refine (a block on
+        # the bottom picture border with far-away vectors: its window runs past the emulated border buffer) -- the parse is a random walk
+        # through legal syntax, not an encoder's choice of vectors.  That seed is replaced.
+        seed = lambda i: 2000 if i == 247 else 1000 + i
+        cmds = [[str(GEN_PIPE), "/tmp", "time", "size", str(W), str(H), "pics", str(n_pics), "seed", str(seed(i))] + (["simd"] if simd else []) for i in range(n)]
         t0 = time.perf_counter()
-        ps = [subprocess.Popen(c, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for c in cmds]
-        outs = [p.communicate()[0] for p in ps]
+        ps = [subprocess.Popen(c, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for c in cmds]
+        outs = [p.communicate() for p in ps]
         wall = time.perf_counter() - t0
-        if any(p.returncode != 0 for p in ps):
+        ok = [o[0] for p, o in zip(ps, outs) if p.returncode == 0 and o[0].strip().startswith("{")]
+        if len(ok) < n:
+            bad = next((p.returncode, o[1][-300:]) for p, o in zip(ps, outs) if p.returncode != 0 or not o[0].strip().startswith("{"))
+            print(f"bench: reference_cpu_rates: {n - len(ok)} of {n} gen_pipe processes failed, first: rc {bad[0]}: {bad[1]}", file=sys.stderr)
             return None
-        inner = [json.loads(o.strip().splitlines()[-1])["seconds"] for o in outs]
+        inner = [json.loads(o.strip().splitlines()[-1])["seconds"] for o in ok]
         return {"fps": n * n_pics / wall, "wall_s": wall, "fps_inside_decoder_mean_per_process": float(np.mean([n_pics / x for x in inner]))}
 
     out = {}
