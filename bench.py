@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--seed", type=int, default=0x266)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-numa-bind", action="store_true", help="do not restrict the process to the CPUs of the GPU's NUMA node (one-GPU runs)")
     ap.add_argument("--no-reference-stream", action="store_true",
                     help="skip the leg on the stream the REFERENCE's own slice decoder parses and decodes (oracle/_ref/gen_pipe, prebuilt from "
                          "/root/reference in the build container): its scalar / SIMD decode rate on this host's cores = cpu_baseline kind "
@@ -172,6 +173,8 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    all_cpus = os.sched_getaffinity(0)
+    numa = _bind_to_gpu_numa_node(torch, local_rank) if not args.no_numa_bind and world * max(1, args.local_devices) == 1 else None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo" if debug_gloo else "nccl", **({} if debug_gloo else {"device_id": dev}))
@@ -649,6 +652,7 @@ def main():
 
         cpu = None
         if not args.no_cpu_baseline:
+            os.sched_setaffinity(0, all_cpus)            # the CPU legs use every core of the host
             import oracle_pipeline
             wl0 = wls[0]
             t1 = time.perf_counter()
@@ -735,6 +739,7 @@ def main():
                        "working_set_bytes": int((dpb_stats.n_live + dpb_stats.n_pool) * FB + len(jobs) * FB),
                        "dpb": {"device_pictures_allocated": int(dpb_stats.n_alloc), "begun": int(dpb_stats.n_begin), "recycled": int(dpb_stats.n_recycled),
                                "peer_copies": int(dpb_stats.n_copies), "waits_for_a_reference": int(dpb_stats.n_waits)},
+                       "numa_binding": numa,
                        "pictures_in_flight_per_gpu": S, "host_threads": S + (1 if lookahead else 0), "local_devices": L,
                        "intra_lookahead_pictures": lookahead,
                        "lookahead_thread_hw_queue": {"streams_replaced": q_moved, "in_order_streams_still_sharing_it": q_sharing} if lookahead else None,
@@ -861,6 +866,29 @@ def reference_stream_on_device(engine, capi, ctx, W, H, n_pics, reps):
                     f"{P.n} chained {P.w}x{P.h} pictures (I B B B P b b b b of a GOP of 8) with the reference's scalar slots and recorded the "
                     "same parse through the installed shim slots; here the recorded stream went through ovhip_job_flush picture by picture, each "
                     "from the device's own earlier pictures, and every frame and every DMVR vector was compared with the reference's"}
+
+def _bind_to_gpu_numa_node(torch, idx):
+    """Frame threads and their page-locked command buffers on the CPUs / memory of the GPU's own NUMA node: the recorder arrays are
+    written by a frame thread and read by the GPU's DMA engines; across sockets every access is remote (the recorded_in_run variant
+    lost a third of its rate from 16 to 32 threads, VERDICT r3 #4).  -> {"node": n, "cpus": k} or None."""
+    try:
+        p = torch.cuda.get_device_properties(idx)
+        bdf = f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if len(cpus) < 8:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return {"node": node, "cpus": len(cpus)}
+    except (OSError, ValueError, AttributeError):
+        return None
+
 
 def _calibration():
     """Reference scalar C (and SIMD) vs the oracle port on identical slot-level cases, timed in the build container (committed; the
