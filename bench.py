@@ -104,7 +104,10 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--seed", type=int, default=0x266)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-numa-bind", action="store_true", help="do not restrict the process to the CPUs of the GPU's NUMA node (one-GPU runs)")
+    ap.add_argument("--numa-bind", action="store_true",
+                    help="restrict the process to the CPUs of the GPU's NUMA node (one-GPU runs).  Measured, no gain: 2916 vs 2847 pictures/s (noise), the "
+                         "recorded_in_run variant with 32 threads 2080 bound vs 2677 unbound -- the recorder's slow-down with the thread count is not "
+                         "remote memory")
     ap.add_argument("--no-reference-stream", action="store_true",
                     help="skip the leg on the stream the REFERENCE's own slice decoder parses and decodes (oracle/_ref/gen_pipe, prebuilt from "
                          "/root/reference in the build container): its scalar / SIMD decode rate on this host's cores = cpu_baseline kind "
@@ -174,7 +177,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     all_cpus = os.sched_getaffinity(0)
-    numa = _bind_to_gpu_numa_node(torch, local_rank) if not args.no_numa_bind and world * max(1, args.local_devices) == 1 else None
+    numa = _bind_to_gpu_numa_node(torch, local_rank) if args.numa_bind and world * max(1, args.local_devices) == 1 else None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo" if debug_gloo else "nccl", **({} if debug_gloo else {"device_id": dev}))
