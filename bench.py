@@ -692,7 +692,7 @@ def main():
                     port = {k: cpu[k] for k in ("value", "cores", "value_1_thread", "value_64_threads", "sample") if k in cpu}
                     cpu = {"value": ref["scalar"]["fps_all_cores"], "unit": "frames/s", "cores": ncpu, "kind": "reference",
                            "value_1_thread": ref["scalar"]["fps_1_process"],
-                           "simd": ref["simd"], "scalar": ref["scalar"],
+                           "simd": ref["simd"], "scalar": ref["scalar"], "host_side_with_the_shim": ref.get("parse_and_record"),
                            "sample": f"oracle/_ref/gen_pipe time: the reference's own slice decoder (parse + reconstruction + in-loop filters; libovvc "
                                      f"compiled from /root/reference in the build container, scalar slots) on its chained stream of 9 {W}x{H} pictures: one "
                                      f"process alone, then {ncpu} processes at once (one per logical core, each its own stream -- frame-level parallelism); "
@@ -808,6 +808,14 @@ def reference_cpu_rates(W, H, n_pics, ncpu):
             out["simd" if simd else "scalar"] = {"fps_1_process": round(one["fps_inside_decoder_mean_per_process"], 3), "fps_all_cores": round(alln["fps"], 2),
                                                  "processes": ncpu, "wall_s": round(alln["wall_s"], 2),
                                                  "fps_per_process_under_load": round(alln["fps_inside_decoder_mean_per_process"], 3)}
+        # the host side of a decoder WITH the shim installed: the reference's parser + the installed slots recording (no reconstruction on
+        # the host) -- what one frame thread has to do per picture before it can submit it (the caller side)
+        p = subprocess.run([str(GEN_PIPE), "/tmp", "time", "shim", "size", str(W), str(H), "pics", str(n_pics)], capture_output=True, text=True)
+        if p.returncode == 0 and p.stdout.strip().startswith("{"):
+            j = json.loads(p.stdout.strip().splitlines()[-1])
+            out["parse_and_record"] = {"fps_1_thread": round(n_pics / j["seconds_shim_record_only"], 2),
+                                       "what": "slicedec.c's parse (CABAC, partitioning, motion-vector derivation) with the installed shim slots recording, "
+                                               "one thread, pictures/s: the rate at which ONE frame thread of a real decoder can feed the device"}
     except (OSError, ValueError, KeyError, IndexError):
         return None
     return out
