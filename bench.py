@@ -278,6 +278,7 @@ def main():
 
     # ---- multi-process exchange: the driver's comm thread calls back here, one call per transferred picture ----
     xfer = None
+    rccl = None
     n_xfer_bytes = [0]
     if world > 1:
         stage = torch.empty(FB // 2 + 512, dtype=torch.int16, device=dev)       # one allocation = the picture's three planes
@@ -315,6 +316,26 @@ def main():
                 return -4
 
         xfer = capi.StreamXfer(None, capi.XFER_FN(_send), capi.XFER_FN(_recv))
+        # The product path: RCCL point-to-point inside the C library (ovvc_rccl.hip: ncclSend / ncclRecv of the three planes in one
+        # group per picture, issued by the driver's comm thread on a stream of its own); bench.py only carries rank 0's ncclUniqueId to
+        # the other ranks.  The Python callbacks above stay as the fall-back (and are what OVVC_BENCH_DEBUG_GLOO runs on one GPU).
+        rccl = None
+        if not debug_gloo and os.environ.get("OVVC_BENCH_PY_XFER") != "1":
+            try:
+                uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+                if rank == 0:
+                    uid.copy_(torch.frombuffer(bytearray(engine.RcclTransport.unique_id()), dtype=torch.uint8))
+                dist.broadcast(uid, 0)
+                rccl = engine.RcclTransport(bytes(uid.cpu().numpy().tobytes()), rank, world, local_rank)
+                xfer = rccl.xfer
+            except Exception as e:          # noqa: BLE001
+                print(f"rank {rank}: RCCL transport not available ({e}): pictures go through torch.distributed", file=sys.stderr)
+                rccl = None
+        ok = torch.tensor([1 if rccl is not None else 0], dtype=torch.int32, device=None if debug_gloo else dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if not int(ok.item()) and rccl is not None:          # every rank or none
+            rccl.close(); rccl = None
+            xfer = capi.StreamXfer(None, capi.XFER_FN(_send), capi.XFER_FN(_recv))
 
     def barrier():
         if world > 1:
@@ -752,7 +773,9 @@ def main():
                        "r_bar": round(st["r_bar"], 3), "coef_bytes": st["coef_bytes"],
                        "frame_algorithmic_bytes": int(sum(alg.values())),
                        "resident_replay_fps": round(fps_res, 2) if fps_res else None,
-                       "transfers_this_rank": {"sent": xfers[0], "received": xfers[1], "bytes_sent": xfer_bytes_main},
+                       "transfers_this_rank": {"sent": xfers[0], "received": xfers[1], "bytes_sent": xfer_bytes_main if (world == 1 or rccl is None) else rccl.stats()["bytes_sent"],
+                                               "transport": ("RCCL ncclSend / ncclRecv in the C comm thread (ovvc_rccl.hip)" if world > 1 and rccl is not None else
+                                                             "torch.distributed callbacks" if world > 1 else None)},
                        "parallelism": f"{S} pictures in flight per GPU" + (f"; {args.dealing} dealing over {world} GPUs (one process per GPU), pictures other ranks "
                                       "list sent with RCCL point-to-point from the driver's comm thread (no collective)" if world > 1 else "")
                                       + (f"; ONE process, {L} logical devices ({args.dealing} dealing), reference pictures by event-ordered hipMemcpyPeerAsync" if L > 1 else "")},

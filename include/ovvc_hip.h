@@ -1196,6 +1196,19 @@ typedef struct ovhip_stream_xfer {         /* multi-process exchange (one proces
     int (*recv)(void *user, uint32_t idx, const ovhip_pic *pic, int src_rank);     /* returns when the data is in place     */
 } ovhip_stream_xfer;
 
+/* RCCL transport (ovvc_rccl.hip): a ready-made ovhip_stream_xfer for one process per GPU -- the three planes of a picture as ncclSend /
+ * ncclRecv in ONE ncclGroup per picture on a stream of its own, issued by the stream driver's communication thread; no collective.
+ * librccl.so is opened at run time.  The launcher hands every rank the 128-byte ncclUniqueId rank 0 made (ovhip_rccl_unique_id),
+ * e.g. through torch.distributed's broadcast (bench.py) or MPI.  ovhip_rccl_self_exchange: a one-rank check of the same path. */
+typedef struct ovhip_rccl ovhip_rccl;
+int  ovhip_rccl_unique_id(uint8_t out[128]);
+int  ovhip_rccl_create(ovhip_rccl **out, const uint8_t unique_id[128], int rank, int world, int hip_device);
+void ovhip_rccl_destroy(ovhip_rccl *r);
+const ovhip_stream_xfer *ovhip_rccl_xfer(ovhip_rccl *r);
+const char *ovhip_rccl_last_error(const ovhip_rccl *r);
+int  ovhip_rccl_stats(const ovhip_rccl *r, uint64_t out[4]);      /* pictures sent, bytes sent, pictures received, bytes received */
+int  ovhip_rccl_self_exchange(ovhip_rccl *r, const ovhip_pic *src, const ovhip_pic *dst);
+
 enum { OVHIP_STREAM_RECORD = 1,            /* record every picture from its call log inside the run (else: pre-recorded jobs) */
        OVHIP_STREAM_DIGESTS = 2,           /* per-picture ovhip_pic_digest into result digests (16 bytes per picture)        */
        OVHIP_STREAM_RESIDENT = 4,          /* measurement: flushes replay the device copies (OVHIP_STAGE_RESIDENT)           */

@@ -510,6 +510,13 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_frame_begin": (C.c_int, [vp, vp]),
         "ovhip_frame_ref": (C.c_int, [vp, vp]),
         "ovhip_frame_set_trace": (None, [vp, vp]),
+        "ovhip_rccl_unique_id": (C.c_int, [vp]),
+        "ovhip_rccl_create": (C.c_int, [P(vp), vp, C.c_int, C.c_int, C.c_int]),
+        "ovhip_rccl_destroy": (None, [vp]),
+        "ovhip_rccl_xfer": (vp, [vp]),
+        "ovhip_rccl_last_error": (C.c_char_p, [vp]),
+        "ovhip_rccl_stats": (C.c_int, [vp, P(C.c_uint64)]),
+        "ovhip_rccl_self_exchange": (C.c_int, [vp, P(Pic), P(Pic)]),
         "ovhip_frame_begin_tag": (C.c_int, [vp, vp, C.c_uint64]),
         "ovhip_frame_ref_tag": (C.c_int, [vp, vp, C.c_uint64]),
         "ovhip_frame_ref_at": (C.c_int, [vp, C.c_int, vp]),
@@ -558,6 +565,7 @@ EXPORTED_SYMBOLS = [
     "ovhip_dpb_create", "ovhip_dpb_create_ex", "ovhip_dpb_destroy", "ovhip_dpb_n_devices", "ovhip_dpb_device", "ovhip_dpb_begin", "ovhip_dpb_want",
     "ovhip_dpb_publish", "ovhip_dpb_acquire", "ovhip_dpb_wait_copy", "ovhip_dpb_set_unknown_key_timeout", "ovhip_dpb_unpin", "ovhip_dpb_release", "ovhip_dpb_lookup", "ovhip_dpb_shutdown",
     "ovhip_dpb_get_stats", "ovhip_dpb_begin_tag", "ovhip_dpb_want_tag", "ovhip_dpb_acquire_tag", "ovhip_frame_begin_tag", "ovhip_frame_ref_tag", "ovhip_frame_set_trace",
+    "ovhip_rccl_unique_id", "ovhip_rccl_create", "ovhip_rccl_destroy", "ovhip_rccl_xfer", "ovhip_rccl_last_error", "ovhip_rccl_stats", "ovhip_rccl_self_exchange",
     "ovhip_frame_create", "ovhip_frame_create_ex", "ovhip_ctx_create_prio", "ovhip_frame_destroy", "ovhip_frame_ctx", "ovhip_frame_job", "ovhip_frame_recorder", "ovhip_frame_begin", "ovhip_frame_ref",
     "ovhip_frame_ref_at", "ovhip_frame_dmvr_rows", "ovhip_frame_dmvr_rows_begin", "ovhip_frame_dmvr_rows_collect", "ovhip_frame_submit", "ovhip_frame_fail", "ovhip_frame_last_error",
     "ovhip_calllog_create", "ovhip_calllog_destroy", "ovhip_calllog_reset", "ovhip_calllog_data", "ovhip_rec_set_calllog", "ovhip_calllog_replay",

@@ -268,14 +268,19 @@ __device__ __forceinline__ void block_sync()
     } else __syncthreads();
 }
 
-template <int NT>
+// LW / LH >= 0: the block's shape as a compile-time constant (k_itx_all dispatches the common shapes of the one-wave class on the
+// wave-uniform command: tile carve-up, strides, chunk counts and every loop bound below then fold -- the generic body executed more
+// scalar than vector instructions, profiles/r03d_pmc_sq.txt).  PLAIN: the command is a transform block off the arena's 4x4
+// sub-blocks without LFNST (what nearly every block is): the raster / transform-skip / BDPCM / LFNST / DC arms are not compiled in.
+template <int NT, int LW = -1, int LH = -1, bool PLAIN = false>
 __device__ __forceinline__ void itx_block(const ovhip_pic &pic, const ResDelta &rd, const ovhip_tb_cmd &c, bool valid, const int16_t *__restrict__ arena,
                                           const int16_t *__restrict__ lmcs_scales, int ablate, int lane, int16_t *lds)
 {
-    const int log2_w = c.log2_w, log2_h = c.log2_h;
+    const int log2_w = LW >= 0 ? LW : c.log2_w, log2_h = LH >= 0 ? LH : c.log2_h;
     const int tb_w = 1 << log2_w, tb_h = 1 << log2_h;
-    const int kind = c.kind & 0x3f;
-    const bool raster = c.kind & OVHIP_TB_FLAG_RASTER, bdpcm = c.kind & OVHIP_TB_FLAG_BDPCM;
+    const int kind = PLAIN ? (int)OVHIP_TB_TR : (c.kind & 0x3f);
+    const bool raster = PLAIN ? false : (bool)(c.kind & OVHIP_TB_FLAG_RASTER), bdpcm = PLAIN ? false : (bool)(c.kind & OVHIP_TB_FLAG_BDPCM);
+    if (PLAIN) ablate = 0;
     const int cw = min(tb_w, 32), ch = min(tb_h, 32);
     const int16_t *src = arena + c.coef_off;
 
@@ -402,7 +407,7 @@ __device__ __forceinline__ void itx_block(const ovhip_pic &pic, const ResDelta &
     const ResidualSink sink = make_sink(pic, rd, c, lmcs_scales);
 
     if (ablate & 4) valid = false;
-    const bool tr = valid && is_tr, lf = tr && (c.lfnst & 1), bd = valid && !is_tr && bdpcm;
+    const bool tr = valid && is_tr, lf = !PLAIN && tr && (c.lfnst & 1), bd = valid && !is_tr && bdpcm;
     int nb_row = 0, nb_col = 0;
     if (tr) {
         if (raster) {
@@ -445,7 +450,7 @@ __device__ __forceinline__ void itx_block(const ovhip_pic &pic, const ResDelta &
             for (int y = 1; y < tb_h; ++y) { acc = ov_clip3(acc + s_coef[y * tb_w + lane], -(1 << 15), (1 << 15) - 1); s_coef[y * tb_w + lane] = (int16_t)acc; }
         }
     }
-    block_sync<NT>();                                  // barrier 2
+    if (!PLAIN) block_sync<NT>();                      // barrier 2 (a PLAIN block is a one-wave block: its barriers are its own)
     if (lf) {
         const int tr_flag = (c.lfnst >> 4) & 1;
         if (lane < nout) {
@@ -461,7 +466,7 @@ __device__ __forceinline__ void itx_block(const ovhip_pic &pic, const ResDelta &
     } else if (bd && kind == OVHIP_TB_TS) {
         for (int i = lane; i < tb_w * tb_h; i += NT) s_coef[i] = (int16_t)dequant1(s_coef[i], c.dq_scale, c.dq_shift, c.dq_neg);
     }
-    block_sync<NT>();                                  // barrier 3
+    if (!PLAIN) block_sync<NT>();                      // barrier 3
     const int ts = tile_stride(kh);
     if (tr) {
         nb_row = min(nb_row, tb_w);
@@ -537,8 +542,19 @@ __global__ __launch_bounds__(256) OV_OCC_ITX void k_itx_all(ovhip_pic pic, const
         const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // wave-uniform: the command stays in SGPRs
         const uint32_t i = ov_xcd_slot(b - n_large, n_quads) * 4 + w;
         const bool valid = i < n_small;
-        itx_block<64>(pic, rd, cmds[n_large + (valid ? i : 0)], valid, arena, lmcs_scales, ablate, threadIdx.x & 63,
-                      lds + w * ITX_LDS_SLICE);
+        const ovhip_tb_cmd &c = cmds[n_large + (valid ? i : 0)];
+        int16_t *const slice = lds + w * ITX_LDS_SLICE;
+        const int lane = threadIdx.x & 63;
+        // one-wave blocks synchronise inside their wave only (block_sync<64>): each wave may take its own path
+        const bool plain = valid && !ablate && (c.kind & 0x3f) == OVHIP_TB_TR && !(c.kind & (OVHIP_TB_FLAG_RASTER | OVHIP_TB_FLAG_BDPCM)) && !(c.lfnst & 1);
+        const int shape = plain ? (c.log2_w << 3 | c.log2_h) : -1;
+#define ITX_SHAPE(lw, lh) case (lw) << 3 | (lh): itx_block<64, lw, lh, true>(pic, rd, c, true, arena, lmcs_scales, 0, lane, slice); break;
+        switch (shape) {
+        ITX_SHAPE(2, 2) ITX_SHAPE(3, 2) ITX_SHAPE(2, 3) ITX_SHAPE(3, 3) ITX_SHAPE(4, 2) ITX_SHAPE(2, 4) ITX_SHAPE(4, 3) ITX_SHAPE(3, 4)
+        ITX_SHAPE(4, 4) ITX_SHAPE(5, 2) ITX_SHAPE(2, 5) ITX_SHAPE(5, 3) ITX_SHAPE(3, 5)
+        default: itx_block<64>(pic, rd, c, valid, arena, lmcs_scales, ablate, lane, slice);
+        }
+#undef ITX_SHAPE
     } else {
         lmcs_inverse_rows<256>(pic, lmcs_inv_lut, b - n_large - n_quads, n_extra, reinterpret_cast<uint16_t *>(lds));
     }

@@ -678,7 +678,8 @@ class Stream:
         cfg.w, cfg.h, cfg.flags, cfg.threads_per_device, cfg.output = w, h, flags, threads_per_device, output
         cfg.window = capi.Window(*window)
         cfg.extra_stages, cfg.rank = extra_stages, rank
-        cfg.xfer = C.pointer(xfer) if xfer is not None else None
+        # a capi.StreamXfer of Python callbacks, or the address of a C one (RcclTransport.xfer: ovhip_rccl_xfer)
+        cfg.xfer = (C.cast(C.c_void_p(xfer), C.POINTER(capi.StreamXfer)) if isinstance(xfer, int) else C.pointer(xfer)) if xfer is not None else None
         cfg.intra_lookahead, cfg.intra_stream_priority, cfg.ahead_chunk_items = intra_lookahead, intra_stream_priority, ahead_chunk_items
         cfg.ahead_own_queue = ahead_own_queue
         self.cfg = cfg
@@ -731,3 +732,43 @@ class Stream:
         if r != 0 and check:
             raise EngineError(f"ovhip_stream_run: {r}: {res.error.decode(errors='replace')}")
         return res, dg
+
+
+class RcclTransport:
+    """ovhip_rccl_*: the stream driver's multi-process exchange over RCCL point-to-point (one process per GPU)."""
+
+    def __init__(self, unique_id: bytes, rank: int, world: int, hip_device: int):
+        self.lib = capi.load()
+        h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        r = self.lib.ovhip_rccl_create(C.byref(h), buf, rank, world, hip_device)
+        if r != 0:
+            raise EngineError(f"ovhip_rccl_create: {r}")
+        self.h = h
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        r = capi.load().ovhip_rccl_unique_id(buf)
+        if r != 0:
+            raise EngineError(f"ovhip_rccl_unique_id: {r}")
+        return bytes(buf)
+
+    @property
+    def xfer(self) -> int:
+        return int(self.lib.ovhip_rccl_xfer(self.h))
+
+    def stats(self) -> dict:
+        out = (C.c_uint64 * 4)()
+        self.lib.ovhip_rccl_stats(self.h, out)
+        return {"pictures_sent": int(out[0]), "bytes_sent": int(out[1]), "pictures_received": int(out[2]), "bytes_received": int(out[3])}
+
+    def self_exchange(self, src: "DevPic", dst: "DevPic"):
+        r = self.lib.ovhip_rccl_self_exchange(self.h, C.byref(src.s), C.byref(dst.s))
+        if r != 0:
+            raise EngineError(f"ovhip_rccl_self_exchange: {r}: {self.lib.ovhip_rccl_last_error(self.h).decode()}")
+
+    def close(self):
+        if self.h:
+            self.lib.ovhip_rccl_destroy(self.h)
+            self.h = None

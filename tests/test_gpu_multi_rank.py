@@ -66,3 +66,23 @@ def test_gpus_flag_without_torchrun_drives_that_many_devices(built_lib):
     assert c["step_fps"]["min"] > 0
     p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "64", "--steps", "1"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and "devices asked for" in p.stderr
+
+
+@pytest.mark.gpu
+def test_rccl_transport_on_one_rank(built_lib):
+    """The product's multi-process exchange (ovvc_rccl.hip: librccl opened at run time, ncclCommInitRank, the three planes of a picture as
+    ncclSend / ncclRecv in one ncclGroup on the transport's own stream) on a one-GPU box: a communicator of ONE rank sends a picture to
+    itself.  (Two ranks on one GPU are refused by RCCL -- "Duplicate GPU detected" -- so the two-rank tests above exchange through gloo.)"""
+    import numpy as np
+    from openvvc_amd import engine
+    ctx = engine.Context(0)
+    t = engine.RcclTransport(engine.RcclTransport.unique_id(), 0, 1, 0)
+    rs = np.random.RandomState(7)
+    w, h = 416, 240
+    y, cb, cr = (rs.randint(0, 1024, size=s).astype(np.uint16) for s in ((h, w), (h // 2, w // 2), (h // 2, w // 2)))
+    src, dst = ctx.upload_pic(y, cb, cr), ctx.new_pic(w, h)
+    ctx.sync()
+    t.self_exchange(src, dst)
+    gy, gcb, gcr = dst.download()
+    assert np.array_equal(gy, y) and np.array_equal(gcb, cb) and np.array_equal(gcr, cr)
+    t.close(); ctx.close()
