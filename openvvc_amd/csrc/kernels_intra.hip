@@ -578,7 +578,9 @@ __global__ __launch_bounds__(64) void k_intra_level(ovhip_pic pic, ovhip_pic res
 #endif
 #ifndef FLOW_POLL_GAP
 #define FLOW_NAP_HALF_LEVEL 24             // s_sleep units (64 clocks): two of them ~1.3 us, a bit more than half the best hop of the chain
-#define FLOW_NAP_MAX_LEVELS 12
+#ifndef FLOW_NAP_MAX_LEVELS
+#define FLOW_NAP_MAX_LEVELS 12             // (0: no nap -- the comparison build of tools/ipic_traffic.sh)
+#endif
 #define FLOW_POLL_GAP 3                    // s_sleep units (64 clocks) between the two polls a waiting item keeps in flight
 #endif
 #define SPIN_LIMIT (1u << 17)              // polls before a workgroup gives up (>= 40 ms; a legitimate wait is a few ms): ovhip_job_wait then decodes the picture per level
