@@ -411,6 +411,7 @@ struct gp_out {
 static uint8_t *g_payload;
 static size_t g_payload_bytes = 1 << 20;           /* slice data per picture: 1 MiB covers 1024x1024 many times over; "size" scales it */
 #define GP_PAYLOAD g_payload_bytes
+static int g_null_shim;
 static int g_time_only;                            /* "time" mode: nothing is kept */
 static double g_decode_seconds_pass[3];            /* ... per pass: reference slots / installed shim slots (record-only) */
 static double g_decode_seconds;                    /* "time" mode: wall time inside slicedec_decode_rect_entry */
@@ -430,7 +431,7 @@ run_stream(struct gp_seq *s, const struct gp_pic_desc *desc, int n_pic, uint32_t
         gp_rcn_init_functions(&c->rcn_funcs, 0, 1, 0, 1, 10);
         c->part_ctx = &g_part;
         ovhip_recorder *r = ovhip_rec_create(s->w, s->h);
-        if (!r || ovhip_shim_bind_recorder(c, r, s->w, s->h)) { fprintf(stderr, "gen_pipe: shim bind failed\n"); exit(1); }
+        if (!g_null_shim && (!r || ovhip_shim_bind_recorder(c, r, s->w, s->h))) { fprintf(stderr, "gen_pipe: shim bind failed\n"); exit(1); }
     } else if (g_pass_shim == 2) {
         /* the device half live: the shim's own begin_picture / flush_picture over a DPB without a device (dry frames) */
         ovhip_dpb_ops ops;
@@ -466,7 +467,7 @@ run_stream(struct gp_seq *s, const struct gp_pic_desc *desc, int n_pic, uint32_t
         if ((size_t)(c->cabac_ctx ? 0 : 0)) {}
         const size_t dm1 = g_pass_shim ? g_dmvr_pos : g_dmvr_log.n / 12;
         fprintf(stderr, "  picture %d: POC %d %s qp %d, %zu DMVR calls\n", k, d->poc, d->slice_type == 2 ? "I" : d->slice_type == 1 ? "P" : "B", d->qp, dm1 - dm0);
-        if (g_time_only) { if (g_pass_shim) { ovhip_shim_flush_pending(c); if (ovhip_shim_last_error(c)) { fprintf(stderr, "gen_pipe: picture %d: the shim latched %d\n", k, ovhip_shim_last_error(c)); exit(1); } } continue; }
+        if (g_time_only) { if (g_pass_shim && !g_null_shim) { ovhip_shim_flush_pending(c); if (ovhip_shim_last_error(c)) { fprintf(stderr, "gen_pipe: picture %d: the shim latched %d\n", k, ovhip_shim_last_error(c)); exit(1); } } continue; }
         if (!g_pass_shim) {
             const OVFrame *f = pics[k]->frame;
             gbuf_push(&out->frames, f->data[0], (size_t)s->w * s->h);
@@ -553,6 +554,7 @@ gp_main(int argc, char **argv)
         else if (!strcmp(argv[i], "variant") && i + 1 < argc) variant = atoi(argv[++i]);
         else if (!strcmp(argv[i], "qp") && i + 1 < argc) dqp = atoi(argv[++i]);
         else if (!strcmp(argv[i], "pics") && i + 1 < argc) n_pic = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "null")) g_null_shim = 1;      /* with "time shim": the installed slots without a recorder = the parse alone */
         else if (!strcmp(argv[i], "time")) want_time = g_time_only = 1;       /* reference pass only; prints pictures and seconds inside the slice decoder */
         else if (!strcmp(argv[i], "size") && i + 2 < argc) { W = atoi(argv[i + 1]); H = atoi(argv[i + 2]); i += 2; }
         else { fprintf(stderr, "gen_pipe: unknown argument %s\n", argv[i]); return 2; }
