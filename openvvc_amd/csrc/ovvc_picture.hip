@@ -709,6 +709,20 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
             // GPU_MAX_HW_QUEUES, another process on the GPU) flow launches starve each other and pictures fall into second passes:
             // every abandoned launch halves the default for the launches that follow (g_flow_shift, down to CUs / 4)
             int n_workers = pr->flow_workers ? (int)pr->flow_workers : (WORKERS >= 0 ? (int)WORKERS : (4 * ctx->num_cus) >> __atomic_load_n(&g_flow_shift, __ATOMIC_RELAXED));
+            if (!pr->flow_workers && WORKERS < 0) {
+                // No more workers than the picture's widest level can use (round 4): a worker beyond that only ever holds an item that is
+                // levels ahead of the front -- and its wave slot, registers and LDS are then missing to the kernels of the pictures beside
+                // this one for as long as the pass runs.  An I picture has ~100 items per level and runs 5 ms: 4 x CUs = 1024 workers
+                // gave 2830-2930 pictures/s on bench.py's stream, 128-512 gave 3000-3150 (tools/sweep_ipic_workers.sh); a B picture's
+                // levels are 1000+ items wide and keep the full count.
+                size_t widest = 0, run = 0;
+                for (size_t q = 0; q < n_items; ++q) {
+                    run = (q && it[j->items_host[q] & 0xffffff].level == it[j->items_host[q - 1] & 0xffffff].level) ? run + 1 : 1;
+                    if (run > widest) widest = run;
+                }
+                const int want = (int)((2 * widest + 63) & ~(size_t)63);
+                if (want < n_workers) n_workers = want < 64 ? 64 : want;
+            }
             if (n_workers < 1) n_workers = 1;
             size_t a = 0;
             int first = !flow_prepared;
