@@ -275,9 +275,9 @@ def main():
     OUT = {"none": capi.OUT_NONE, "digest": capi.OUT_DIGEST, "frame": capi.OUT_PACKED}
     lookahead = max(0, args.intra_lookahead)
 
-    def new_stream(threads, output="none", flags=0, xfer=None, use_jobs=True):
+    def new_stream(threads, output="none", flags=0, xfer=None, use_jobs=True, ahead=None):
         return engine.Stream(dpb, W, H, contents, jobs if use_jobs else [], threads_per_device=threads, flags=flags, output=OUT[output],
-                             extra_stages=lv, rank=rank, xfer=xfer, intra_lookahead=lookahead if threads > 1 else 0,
+                             extra_stages=lv, rank=rank, xfer=xfer, intra_lookahead=(lookahead if ahead is None else ahead) if threads > 1 else 0,
                              intra_stream_priority=args.intra_priority, ahead_chunk_items=args.ahead_chunk,
                              ahead_own_queue=args.ahead_own_queue if threads > 1 else 0)
 
@@ -555,6 +555,12 @@ def main():
             if mode == "frame":
                 variants["output_frame_d2h_GBps"] = round(f * FB / 1e9, 2)
             stv.close()
+        # strictly in decoding order (no look-ahead thread: the reference's frame threads take NAL units in order, ovdec.c:188-248): every
+        # I picture's dependency chain is then in the way of the pictures behind it
+        stv = new_stream(S, output=args.output, ahead=0)
+        f, r = timed_variant(stv, nv)
+        variants["in_order_no_lookahead"] = round(f, 1)
+        stv.close()
         # the device-resident replay of the same command buffers (no H2D / D2H): r1's measurement, inputs resident in HBM
         f, r = timed_variant(st_main, nv, flags=capi.STREAM_RESIDENT)
         fps_res = f
