@@ -13,7 +13,7 @@
 
 enum { CL_CTU_SIZE = 1, CL_TU, CL_ISP, CL_PU, CL_AFF, CL_REGION, CL_DBF, CL_CIIP };
 
-struct ovhip_calllog { unsigned char *data; size_t n, cap; int oom; };
+struct ovhip_calllog { unsigned char *data; size_t n, cap; int oom; };   /* oom: the log is unusable (allocation failed or a call could not be written down): _data returns NULL */
 
 struct cl_tu {
     ovhip_tu_state st;
@@ -121,7 +121,7 @@ void
 ovhip_calllog_affine_(ovhip_calllog *l, const ovhip_affine_desc *cu)
 {
     const int nx = (1 << cu->log2_w) >> 2, ny = (1 << cu->log2_h) >> 2;
-    if (!cu->mv0 || !cu->mv1 || cu->log2_w > 7 || cu->log2_h > 7) return;
+    if (!cu->mv0 || !cu->mv1 || cu->log2_w < 2 || cu->log2_h < 2 || cu->log2_w > 7 || cu->log2_h > 7) { l->oom = 1; return; }   /* (ovhip_rec_affine_cu refuses these) */
     unsigned char *p = cl_open(l, CL_AFF, sizeof(*cu) + 2 * (size_t)nx * ny * 8);
     if (!p) return;
     ovhip_affine_desc *q = (ovhip_affine_desc *)p;
@@ -177,37 +177,60 @@ ovhip_calllog_replay(const void *data, size_t bytes, ovhip_recorder *rec)
         if ((size_t)(end - p) < 8) { r = OVHIP_EINVAL; break; }
         memcpy(hdr, p, 8);
         const unsigned char *q = p + 8;
-        if (hdr[1] > (size_t)(end - q)) { r = OVHIP_EINVAL; break; }
+        if (hdr[1] > (size_t)(end - q) || (hdr[1] & 7)) { r = OVHIP_EINVAL; break; }
+        /* A log is a byte buffer from a file or another process: every record's fixed part, and every extent derived from its
+         * fields (coefficient blocks, sub-block vectors), must lie inside the payload before a recorder call reads through it. */
+        const size_t len = hdr[1];
+#define CL_NEED(bytes_) if (len < (size_t)(bytes_)) { r = OVHIP_EINVAL; break; }
         switch (hdr[0]) {
-        case CL_CTU_SIZE: { int32_t v; memcpy(&v, q, 4); r = ovhip_rec_set_ctu_size(rec, v); break; }
+        case CL_CTU_SIZE: { int32_t v; CL_NEED(4) memcpy(&v, q, 4); r = ovhip_rec_set_ctu_size(rec, v); break; }
         case CL_TU: {
+            CL_NEED(sizeof(struct cl_tu))
             const struct cl_tu *t = (const struct cl_tu *)q;
             ovhip_tu_desc d = t->tu;
+            if (d.log2_tb_w > 7 || d.log2_tb_h > 7 || t->has_l > 1 || t->has_c > 1) { r = OVHIP_EINVAL; break; }
             const int16_t *coefs = (const int16_t *)(q + sizeof(*t));
-            for (int c = 0; c < 3; ++c) d.coef[c] = t->tu.coef[c] ? coefs + ((uintptr_t)t->tu.coef[c] - 1) : NULL;
+            const size_t have = (len - sizeof(*t)) / 2;
+            int ok = 1;
+            for (int c = 0; c < 3; ++c) {
+                const uintptr_t o = (uintptr_t)t->tu.coef[c];
+                if (!o) { d.coef[c] = NULL; continue; }
+                if (o - 1 > have || tu_coef_extent(&d, c) > have - (o - 1)) { ok = 0; break; }
+                d.coef[c] = coefs + (o - 1);
+            }
+            if (!ok) { r = OVHIP_EINVAL; break; }
             r = ovhip_rec_tu_intra(rec, &t->st, &d, t->has_l ? &t->tl : NULL, t->has_c ? &t->tc : NULL);
             break;
         }
         case CL_ISP: {
+            CL_NEED(sizeof(struct cl_isp))
             const struct cl_isp *t = (const struct cl_isp *)q;
             ovhip_isp_desc d = t->cu;
-            d.coef = (const int16_t *)(q + sizeof(*t));
+            if (d.log2_cb_w > 7 || d.log2_cb_h > 7) { r = OVHIP_EINVAL; break; }
+            const size_t have = (len - sizeof(*t)) / 2, want = (size_t)1 << (d.log2_cb_w + d.log2_cb_h);
+            if (have >= want) d.coef = (const int16_t *)(q + sizeof(*t));
+            else if (have < 4) d.coef = NULL;                    /* written without coefficients (only the record's padding follows) */
+            else { r = OVHIP_EINVAL; break; }
             r = ovhip_rec_isp_cu(rec, &t->st, &d);
             break;
         }
-        case CL_PU: r = ovhip_rec_pu(rec, (const ovhip_pu_desc *)q); break;
+        case CL_PU: CL_NEED(sizeof(ovhip_pu_desc)) r = ovhip_rec_pu(rec, (const ovhip_pu_desc *)q); break;
         case CL_AFF: {
+            CL_NEED(sizeof(ovhip_affine_desc))
             ovhip_affine_desc d = *(const ovhip_affine_desc *)q;
+            if (d.log2_w < 2 || d.log2_h < 2 || d.log2_w > 7 || d.log2_h > 7) { r = OVHIP_EINVAL; break; }
             const int nx = (1 << d.log2_w) >> 2, ny = (1 << d.log2_h) >> 2;
-            d.mv0 = (const int32_t *)(q + sizeof(d)); d.mv1 = d.mv0 + 2 * nx * ny;
+            CL_NEED(sizeof(d) + 16 * (size_t)nx * ny)
+            d.mv0 = (const int32_t *)(q + sizeof(d)); d.mv1 = d.mv0 + 2 * nx * ny; d.mv_stride = nx;
             r = ovhip_rec_affine_cu(rec, &d);
             break;
         }
-        case CL_REGION: { const struct cl_region *g = (const struct cl_region *)q; r = ovhip_rec_lmcs_region(rec, g->x0, g->y0, g->abv, g->lft); break; }
-        case CL_DBF: r = ovhip_rec_dbf_ctu(rec, (const ovhip_dbf_ctu *)q); break;
-        case CL_CIIP: { const struct cl_ciip *g = (const struct cl_ciip *)q; r = ovhip_rec_ciip(rec, g->x0, g->y0, g->log2_w, g->log2_h, g->mode_abv, g->mode_lft); break; }
+        case CL_REGION: { CL_NEED(sizeof(struct cl_region)) const struct cl_region *g = (const struct cl_region *)q; r = ovhip_rec_lmcs_region(rec, g->x0, g->y0, g->abv, g->lft); break; }
+        case CL_DBF: CL_NEED(sizeof(ovhip_dbf_ctu)) r = ovhip_rec_dbf_ctu(rec, (const ovhip_dbf_ctu *)q); break;
+        case CL_CIIP: { CL_NEED(sizeof(struct cl_ciip)) const struct cl_ciip *g = (const struct cl_ciip *)q; r = ovhip_rec_ciip(rec, g->x0, g->y0, g->log2_w, g->log2_h, g->mode_abv, g->mode_lft); break; }
         default: r = OVHIP_EINVAL;
         }
+#undef CL_NEED
         p = q + hdr[1];
         ++n;
     }

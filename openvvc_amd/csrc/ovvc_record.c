@@ -406,7 +406,8 @@ ovhip_isp_geometry(int32_t log2_cb_w, int32_t log2_cb_h, int32_t vertical, int32
 int
 ovhip_rec_isp_cu(ovhip_recorder *r, const ovhip_tu_state *st, const ovhip_isp_desc *cu)
 {
-    if (!r || !st || !cu || cu->log2_cb_w < 2 || cu->log2_cb_w > 6 || cu->log2_cb_h < 2 || cu->log2_cb_h > 6 || cu->log2_cb_w + cu->log2_cb_h < 5)
+    if (!r || !st || !cu || cu->log2_cb_w < 2 || cu->log2_cb_w > 6 || cu->log2_cb_h < 2 || cu->log2_cb_h > 6 || cu->log2_cb_w + cu->log2_cb_h < 5
+        || (cu->cbf_mask && !cu->coef))
         return OVHIP_EINVAL;
     if (r->log) ovhip_calllog_isp_(r->log, st, cu);
     const size_t n0 = r->n_tb, c0 = r->n_coef, t0 = r->n_itask;

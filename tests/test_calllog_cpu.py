@@ -41,3 +41,55 @@ def test_truncated_or_foreign_log_is_refused(built_lib):
     with pytest.raises(ValueError):
         rec.replay(bad)
     rec.close()
+
+
+def _records(log):
+    """(offset, type, payload bytes) of every record"""
+    out, o = [], 0
+    while o < len(log):
+        t, n = (int(v) for v in np.frombuffer(log[o:o + 8].tobytes(), np.uint32))
+        out.append((o, t, n)); o += 8 + n
+    return out
+
+
+def test_a_record_shorter_than_what_its_fields_imply_is_refused(built_lib):
+    """A log comes from a file or another process: a record whose payload is shorter than its fixed part, or than the coefficient
+    blocks / sub-block vectors its fields call for, must stop the replay with an error -- not be read through."""
+    wl = synth.make_workload(416, 240, 9, tools=synth.INTRA_TOOLS, intra_frac=0.3, calllog=True)
+    log = wl.calllog
+    recs = _records(log)
+    u32 = lambda v: np.frombuffer(np.uint32(v).tobytes(), np.uint8)
+    first = {}
+    for o, t, n in recs:
+        first.setdefault(t, (o, n))
+    assert {2, 4, 5} <= set(first), sorted(first)                              # TU, PU, affine came up
+    rec = capi.Recorder(416, 240)
+
+    def refused(buf):
+        rec.reset()
+        with pytest.raises(ValueError):
+            rec.replay(buf)
+
+    for t, (o, n) in sorted(first.items()):
+        if t == 1:
+            continue
+        cut = log[:o + 16].copy()                                              # the log ends 8 payload bytes into this record:
+        cut[o + 4:o + 8] = u32(8)                                              # below every type's fixed part
+        refused(cut)
+        odd = log[:o + 8 + n].copy()                                           # a payload length that is not a multiple of 8
+        odd[o + 4:o + 8] = u32(n - 4)
+        refused(odd)
+    o, n = max(((o, n) for o, t, n in recs if t == 2), key=lambda v: v[1])     # the TU carrying the most coefficients,
+    short = log[:o + 8 + n - 64].copy()                                        # its last block cut
+    short[o + 4:o + 8] = u32(n - 64)
+    refused(short)
+    o, n = max(((o, n) for o, t, n in recs if t == 5), key=lambda v: v[1])     # an affine CU without its last sub-block vectors
+    short = log[:o + 8 + n - 16].copy()
+    short[o + 4:o + 8] = u32(n - 16)
+    refused(short)
+    big = log[:o + 8 + n].copy()                                               # ... and one claiming a 256 x 256 CU
+    big[o + 8 + 4] = 8
+    refused(big)
+    rec.reset()
+    assert rec.replay(log) == len(recs)                                        # the intact log still replays
+    rec.close()
