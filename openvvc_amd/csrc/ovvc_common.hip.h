@@ -20,6 +20,7 @@ struct ovhip_ctx {
     int num_cus;                   // compute units of the device (sizes the resident grids of the pipelined kernels)
     hipStream_t stream;            // the stream launches go to: the main stream, or a side lane after ovhip_ctx_fork
     int owns_stream;
+    int owns_prio_stream;       /* main_stream was made by ovhip_ctx_create_prio: destroyed (never pooled) with the context */
     hipStream_t main_stream;       // what the caller passed / what ctx_create made
     hipStream_t lane[OV_MAX_LANES];// side streams for independent launches of one stage (created on first use)
     hipEvent_t ev_fork, ev_lane[OV_MAX_LANES];

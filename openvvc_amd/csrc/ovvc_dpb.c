@@ -36,6 +36,9 @@ struct dpb_slot {
 };
 
 struct pool_ent { ovhip_pic pic; int32_t w, h; };
+/* a reclaimed picture that needs a blocking step before it may be handed out again: a copy into it may still run (event), or an
+ * abandoned decode left hand-over bits in it (clear) */
+struct limbo_ent { ovhip_pic pic; int dev; int32_t w, h; void *event; int clear; };
 
 struct ovhip_dpb {
     pthread_mutex_t mtx;
@@ -49,6 +52,7 @@ struct ovhip_dpb {
     int shutdown;
     int unknown_ms;                       /* how long ovhip_dpb_acquire waits for a key nobody has begun yet */
     uint64_t serial;
+    struct limbo_ent *limbo; size_t n_limbo, cap_limbo;       /* finish_deferred() takes these to the pools OUTSIDE the mutex */
     struct { const void *key; uint64_t tag; uint32_t devs; } pend[64]; int n_pend;      /* wants for pictures nobody has begun yet */
     ovhip_dpb_stats st;
 };
@@ -110,24 +114,71 @@ find_tag(ovhip_dpb *d, const void *key, uint64_t tag)
     return s && tag && s->tag && s->tag != tag ? NULL : s;
 }
 
+/* the blocking part of giving a picture back: wait for the copy into it / clear it (no mutex needed) */
+static void
+settle(ovhip_dpb *d, const struct limbo_ent *e)
+{
+    if (e->event) {
+        (void)d->ops.copy_wait(d->ops.user, e->dev, e->event);          /* a copy nobody waited for may still be running */
+        if (d->ops.copy_done) d->ops.copy_done(d->ops.user, e->dev, e->event);
+    }
+    if (e->clear && d->ops.pic_clear) (void)d->ops.pic_clear(d->ops.user, e->dev, &e->pic);
+}
+
+/* mutex held: the picture goes to its pool -- at once when nothing has to be waited for, else through the limbo list, which the
+ * public call that got here empties after it has dropped the mutex (event waits, clears and the allocations behind
+ * them ran under the DPB's one lock and stalled every begin / acquire / publish of every device) */
+static void
+give_back(ovhip_dpb *d, int dev, const ovhip_pic *pic, int32_t w, int32_t h, void *event, int clear)
+{
+    if (!event && !(clear && d->ops.pic_clear)) { (void)pool_push(d, dev, pic, w, h); return; }
+    struct limbo_ent e = { *pic, dev, w, h, event, clear };
+    if (d->n_limbo == d->cap_limbo) {
+        const size_t nc = d->cap_limbo ? 2 * d->cap_limbo : 16;
+        struct limbo_ent *q = (struct limbo_ent *)realloc(d->limbo, nc * sizeof(*q));
+        if (!q) { settle(d, &e); (void)pool_push(d, dev, pic, w, h); return; }      /* no memory for the list: the old, blocking way */
+        d->limbo = q; d->cap_limbo = nc;
+    }
+    d->limbo[d->n_limbo++] = e;
+}
+
+/* mutex NOT held */
+static void
+finish_deferred(ovhip_dpb *d)
+{
+    pthread_mutex_lock(&d->mtx);
+    struct limbo_ent *l = d->limbo;
+    const size_t n = d->n_limbo;
+    d->limbo = NULL; d->n_limbo = d->cap_limbo = 0;
+    pthread_mutex_unlock(&d->mtx);
+    if (!n) { free(l); return; }
+    for (size_t i = 0; i < n; ++i) settle(d, &l[i]);
+    pthread_mutex_lock(&d->mtx);
+    for (size_t i = 0; i < n; ++i) (void)pool_push(d, l[i].dev, &l[i].pic, l[i].w, l[i].h);
+    pthread_mutex_unlock(&d->mtx);
+    free(l);
+}
+
+/* leaves the mutex; settles what the call put into limbo */
+static void
+unlock_and_finish(ovhip_dpb *d)
+{
+    const int pending = d->n_limbo > 0;
+    pthread_mutex_unlock(&d->mtx);
+    if (pending) finish_deferred(d);
+}
+
 /* the slot's pictures go back to the pools (mutex held; nobody has it pinned) */
 static void
 reclaim(ovhip_dpb *d, struct dpb_slot *s)
 {
-    if (s->state == S_FAILED || s->state == S_DECODING) {
-        /* an incomplete decode may have left hand-over bits in the samples (ovhip_intra_flow_untag_launch) */
-        if (d->ops.pic_clear) (void)d->ops.pic_clear(d->ops.user, s->home, &s->pic);
-    }
-    (void)pool_push(d, s->home, &s->pic, s->w, s->h);
+    /* an incomplete decode may have left hand-over bits in the samples (ovhip_intra_flow_untag_launch) */
+    give_back(d, s->home, &s->pic, s->w, s->h, NULL, s->state == S_FAILED || s->state == S_DECODING);
     d->st.n_live--;
     for (int k = 0; k < d->n_dev; ++k) {
         struct dpb_copy *c = &s->copy[k];
         if (c->state == C_NONE) continue;
-        if (c->event) {
-            (void)d->ops.copy_wait(d->ops.user, k, c->event);          /* a copy nobody waited for may still be running */
-            if (d->ops.copy_done) d->ops.copy_done(d->ops.user, k, c->event);
-        }
-        (void)pool_push(d, k, &c->pic, s->w, s->h);
+        give_back(d, k, &c->pic, s->w, s->h, c->event, 0);
         d->st.n_live--;
         c->state = C_NONE; c->event = NULL;
     }
@@ -190,12 +241,14 @@ ovhip_dpb_destroy(ovhip_dpb *d)
     pthread_mutex_lock(&d->mtx);
     for (size_t i = 0; i < d->n_slots; ++i)
         if (d->slots[i].state != S_FREE) { d->slots[i].pins = 0; reclaim(d, &d->slots[i]); }
+    unlock_and_finish(d);
+    pthread_mutex_lock(&d->mtx);
     for (int k = 0; k < d->n_dev; ++k) {
         for (size_t i = 0; i < d->n_pool[k]; ++i) d->ops.pic_free(d->ops.user, k, &d->pool[k][i].pic);
         free(d->pool[k]);
     }
     pthread_mutex_unlock(&d->mtx);
-    free(d->slots);
+    free(d->slots); free(d->limbo);
     if (d->hip_user) ovhip_dpb_hip_ops_free_(d->hip_user);
     pthread_cond_destroy(&d->cnd);
     pthread_mutex_destroy(&d->mtx);
@@ -218,7 +271,16 @@ ovhip_dpb_begin_tag(ovhip_dpb *d, const void *key, uint64_t tag, int dev, int32_
         /* the key comes back for a new picture: the host DPB re-uses a frame only once it is unreferenced */
         if (s->pins) { pthread_mutex_unlock(&d->mtx); return OVHIP_EINVAL; }
         reclaim(d, s);
-    } else {
+        if (d->n_limbo) {
+            /* its buffers need a wait or a clear first: outside the mutex, then they are in the pools for the pop below */
+            unlock_and_finish(d);
+            pthread_mutex_lock(&d->mtx);
+            s = find(d, key);                            /* (nobody else begins this key; a racing begin is the caller's error) */
+            if (s) { pthread_mutex_unlock(&d->mtx); return OVHIP_EINVAL; }
+        }
+    }
+    if (!s || s->state != S_FREE) {
+        s = NULL;
         for (size_t i = 0; i < d->n_slots && !s; ++i) if (d->slots[i].state == S_FREE) s = &d->slots[i];
         if (!s) {
             const size_t nc = d->n_slots ? 2 * d->n_slots : 32;
@@ -289,7 +351,7 @@ ovhip_dpb_publish(ovhip_dpb *d, const void *key, int status)
         if (s->released && !s->pins) reclaim(d, s);
     }
     pthread_cond_broadcast(&d->cnd);
-    pthread_mutex_unlock(&d->mtx);
+    unlock_and_finish(d);
     return r;
 }
 
@@ -367,7 +429,7 @@ ovhip_dpb_unpin(ovhip_dpb *d, const void *key)
     struct dpb_slot *s = find(d, key);
     if (!s || s->pins <= 0) r = OVHIP_EINVAL;
     else if (--s->pins == 0 && s->released && s->state != S_DECODING) reclaim(d, s);
-    pthread_mutex_unlock(&d->mtx);
+    unlock_and_finish(d);
     return r;
 }
 
@@ -384,7 +446,7 @@ ovhip_dpb_release(ovhip_dpb *d, const void *key)
         /* a picture still being decoded is reclaimed by its publish, a pinned one by its last unpin */
         if (!s->pins && s->state != S_DECODING) reclaim(d, s);
     }
-    pthread_mutex_unlock(&d->mtx);
+    unlock_and_finish(d);
     return r;
 }
 

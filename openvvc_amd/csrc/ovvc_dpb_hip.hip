@@ -20,6 +20,14 @@ struct HipDpb {
     unsigned char peer[OVHIP_MAX_DEVICES][OVHIP_MAX_DEVICES];      // peer access dst <- src enabled (by logical device)
 };
 
+// The DPB's memory calls run on whatever thread released / began a picture -- often a frame thread bound to ANOTHER device: they
+// leave the caller's current device as they found it.
+struct DeviceScope {
+    int prev = -1;
+    DeviceScope() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 size_t plane_bytes(int32_t w, int32_t h, size_t *ysz, size_t *csz)
 {
     *ysz = ((size_t)w * h * 2 + 255) & ~(size_t)255;
@@ -37,6 +45,7 @@ int hd_stream(HipDpb *u, int k, hipStream_t *s)
 
 int hd_pic_alloc(void *user, int k, int32_t w, int32_t h, ovhip_pic *pic)
 {
+    DeviceScope keep;
     HipDpb *u = (HipDpb *)user;
     if ((w & 1) || (h & 1)) return OVHIP_EINVAL;
     hipStream_t s;
@@ -58,6 +67,7 @@ int hd_pic_alloc(void *user, int k, int32_t w, int32_t h, ovhip_pic *pic)
 
 void hd_pic_free(void *user, int k, ovhip_pic *pic)
 {
+    DeviceScope keep;
     HipDpb *u = (HipDpb *)user;
     if (hipSetDevice(u->dev[k]) == hipSuccess && pic->y) (void)hipFree(pic->y);
     memset(pic, 0, sizeof(*pic));
@@ -65,6 +75,7 @@ void hd_pic_free(void *user, int k, ovhip_pic *pic)
 
 int hd_pic_clear(void *user, int k, const ovhip_pic *pic)
 {
+    DeviceScope keep;
     HipDpb *u = (HipDpb *)user;
     hipStream_t s;
     int r = hd_stream(u, k, &s);
@@ -77,6 +88,7 @@ int hd_pic_clear(void *user, int k, const ovhip_pic *pic)
 
 int hd_copy_start(void *user, int kd, const ovhip_pic *dst, int ks, const ovhip_pic *src, void **event)
 {
+    DeviceScope keep;
     HipDpb *u = (HipDpb *)user;
     hipStream_t s;
     int r = hd_stream(u, kd, &s);
@@ -105,6 +117,7 @@ int hd_copy_start(void *user, int kd, const ovhip_pic *dst, int ks, const ovhip_
 
 int hd_copy_wait(void *user, int kd, void *event)
 {
+    DeviceScope keep;
     HipDpb *u = (HipDpb *)user;
     if (hipSetDevice(u->dev[kd]) != hipSuccess) return OVHIP_ENODEV;
     return hipEventSynchronize((hipEvent_t)event) == hipSuccess ? OVHIP_OK : OVHIP_ELAUNCH;
@@ -112,6 +125,7 @@ int hd_copy_wait(void *user, int kd, void *event)
 
 void hd_copy_done(void *user, int kd, void *event)
 {
+    DeviceScope keep;
     HipDpb *u = (HipDpb *)user;
     if (hipSetDevice(u->dev[kd]) == hipSuccess) (void)hipEventDestroy((hipEvent_t)event);
 }

@@ -127,9 +127,10 @@ int ovhip_ctx_create_prio(ovhip_ctx **out, int device, int stream_priority)
     const int p = stream_priority < 0 ? hi : lo;
     hipStream_t s = nullptr;
     if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, p) != hipSuccess) return OVHIP_ENODEV;
-    // (not pooled: the context owns it through the caller-stream path, and returns it to nobody -- destroyed with the process)
+    // not pooled (the pool's streams are default-priority and interchangeable): the context owns it and destroys it
     int r = ovhip_ctx_create(out, device, (void *)s);
     if (r != OVHIP_OK) (void)hipStreamDestroy(s);
+    else (*out)->owns_prio_stream = 1;
     return r;
 }
 
@@ -147,6 +148,7 @@ void ovhip_ctx_destroy(ovhip_ctx *ctx)
     if (ctx->scratch_d) (void)hipFree(ctx->scratch_d);
     if (ctx->scratch_h) (void)hipHostFree(ctx->scratch_h);
     if (ctx->owns_stream) { (void)hipStreamSynchronize(ctx->main_stream); stream_put(ctx->device, ctx->main_stream); }
+    if (ctx->owns_prio_stream) { (void)hipStreamSynchronize(ctx->main_stream); (void)hipStreamDestroy(ctx->main_stream); }
     free(ctx);
 }
 

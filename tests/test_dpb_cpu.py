@@ -350,3 +350,45 @@ def test_recycled_key_is_not_mistaken_for_the_new_picture(dpb):
     # the picture never comes: bounded wait, then an error -- never the stale picture
     lib.ovhip_dpb_set_unknown_key_timeout(h, 100)
     assert lib.ovhip_dpb_acquire_tag(h, C.c_void_p(F), 1003, 0, C.byref(p2), C.byref(ev)) == capi.OVHIP_EINVAL
+
+
+def test_waits_and_clears_of_a_reclaim_run_outside_the_dpb_lock(dpb):
+    """giving a picture back may have to wait for a copy nobody waited for, or clear an abandoned decode.  Those calls
+    block on the device -- while they run, another thread must get through the DPB (here: ovhip_dpb_get_stats from a second thread,
+    from inside the memory back-end's copy_wait / pic_clear)."""
+    lib, h, mem = dpb
+    seen = []
+
+    def probe(what):
+        ok = []
+        t = threading.Thread(target=lambda: ok.append(_stats(lib, h).n_begin))
+        t.start(); t.join(5)
+        seen.append((what, bool(ok)))
+
+    wait0, clear0 = mem.copy_wait, mem.pic_clear
+    def copy_wait(user, dev, event):
+        probe("wait"); return wait0(user, dev, event)
+    def pic_clear(user, dev, pic):
+        probe("clear"); return clear0(user, dev, pic)
+    mem.ops.copy_wait = capi.DPB_COPY_WAIT_FN(copy_wait)
+    mem.ops.pic_clear = capi.DPB_PIC_CLEAR_FN(pic_clear)
+    h2 = C.c_void_p()
+    assert lib.ovhip_dpb_create_ex(C.byref(h2), 2, C.byref(mem.ops)) == 0
+    h_saved, h = h, h2
+    try:
+        # a copy nobody waited for, released
+        assert _begin(lib, h, 1, dev=0)[0] == 0 and lib.ovhip_dpb_want(h, C.c_void_p(1), 1) == 0
+        assert lib.ovhip_dpb_publish(h, C.c_void_p(1), 0) == 0
+        assert lib.ovhip_dpb_release(h, C.c_void_p(1)) == 0
+        assert ("wait", True) in seen, seen
+        assert all(v == "done" for v in mem.events.values())                    # closed when the call returns
+        # an abandoned decode whose key comes back: cleared outside the lock, and the cleared buffer is the one handed out
+        r, p = _begin(lib, h, 2, dev=0)
+        assert r == 0
+        r, q = _begin(lib, h, 2, dev=0)
+        assert r == 0 and ("clear", True) in seen, seen
+        assert q.y == p.y and ("clear", 0, p.y) in mem.log
+        assert not [s for s in seen if not s[1]], seen
+    finally:
+        lib.ovhip_dpb_destroy(h2)
+        h = h_saved
