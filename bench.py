@@ -847,7 +847,10 @@ def reference_cpu_rates(W, H, n_pics, ncpu):
         def shim_seconds(extra):
             best = None
             for _ in range(3):
-                p = subprocess.run([str(GEN_PIPE), "/tmp", "time", "shim"] + extra + ["size", str(W), str(H), "pics", str(n_pics)], capture_output=True, text=True)
+                # "null": no recorder bound; the slots must not find a device either (they would decode on it): a device index that does
+                # not exist makes the shim latch at its first picture and every slot return at its top = the parse alone
+                env = dict(os.environ, OVVC_HIP_DEVICE="9999") if extra else None
+                p = subprocess.run([str(GEN_PIPE), "/tmp", "time", "shim"] + extra + ["size", str(W), str(H), "pics", str(n_pics)], capture_output=True, text=True, env=env)
                 if p.returncode != 0 or not p.stdout.strip().startswith("{"):
                     return None
                 v = json.loads(p.stdout.strip().splitlines()[-1])["seconds_shim_record_only"]
