@@ -317,11 +317,22 @@ int ovhip_rec_dbf_mv_prepass(ovhip_dbf_ctu *ctu, const ovhip_dbf_mv_ctx *mv);
  * (rcn_sao.c:119-188, :190-293).
  * ---------------------------------------------------------------------------------- */
 enum { OVHIP_SAO_OFF = 0, OVHIP_SAO_BAND = 1, OVHIP_SAO_EDGE = 2 };   /* = SAO_NOT_APPLIED / SAO_BAND / SAO_EDGE */
+/* Sides of a CTU that are borders of its RECT ENTRY (tile) inside the picture: the reference filters a rect entry on its own
+ * (slicedec.c:636-657) -- is_border comes from the entry-local CTU index (rcn_sao.c:211-214, :253-257; rcn_alf.c:1313-1318): SAO
+ * leaves a sample whose neighbour lies across such a side unmodified, ALF / CC-ALF pad across it as at the picture border
+ * (rcn_extend_filter_region, rcn_ctu.c:361-508).  All zero in a picture of one entry.  ONE_ROW: the entry is a single CTU row
+ * high (its first 6-row band is then filtered with the BOTTOM flag set, rcn_sao.c:262). */
+#define OVHIP_BORDER_LEFT    1
+#define OVHIP_BORDER_RIGHT   2
+#define OVHIP_BORDER_UPPER   4
+#define OVHIP_BORDER_BOTTOM  8
+#define OVHIP_BORDER_ONE_ROW 16
 typedef struct ovhip_sao_ctu {
     uint8_t type[3];          /* per component Y, Cb, Cr                                  */
     uint8_t band_position[3]; /* first of the 4 consecutive bands (of 32)                  */
     uint8_t eo_class[3];      /* 0 horizontal, 1 vertical, 2 45 deg (135 in spec), 3 other diagonal */
-    uint8_t pad[3];
+    uint8_t border;           /* OVHIP_BORDER_*                                            */
+    uint8_t pad[2];
     int16_t offset_val[3][5]; /* band: [0..3]; edge: indexed by 2 + sign(c-a) + sign(c-b) */
     uint8_t pad2[2];
 } ovhip_sao_ctu;
@@ -342,7 +353,8 @@ typedef struct ovhip_alf_ctu {
     uint8_t luma_set;         /* ctb_alf_idx: 0..15 fixed sets, 16.. APS sets                     */
     uint8_t cb_alt, cr_alt;   /* chroma alternative filter index                                  */
     uint8_t cc_cb_idx, cc_cr_idx; /* ctb_cc_alf_filter_idx (0 = off, else filter idx + 1)         */
-    uint8_t pad[2];
+    uint8_t border;           /* OVHIP_BORDER_* (rect-entry borders inside the picture)            */
+    uint8_t pad;
 } ovhip_alf_ctu;
 
 typedef struct ovhip_alf_pic {

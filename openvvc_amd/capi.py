@@ -149,12 +149,13 @@ class DbfPlanes(C.Structure):
                 ("beta_offset", C.c_int16), ("tc_offset", C.c_int16)]
 
 
-SAO_CTU_DTYPE = np.dtype([("type", "u1", 3), ("band_position", "u1", 3), ("eo_class", "u1", 3), ("pad", "u1", 3),
+SAO_CTU_DTYPE = np.dtype([("type", "u1", 3), ("band_position", "u1", 3), ("eo_class", "u1", 3), ("border", "u1"), ("pad", "u1", 2),
                           ("offset_val", "<i2", (3, 5)), ("pad2", "u1", 2)])
 assert SAO_CTU_DTYPE.itemsize == 44
 
 ALF_CTU_DTYPE = np.dtype([("flags", "u1"), ("luma_set", "u1"), ("cb_alt", "u1"), ("cr_alt", "u1"),
-                          ("cc_cb_idx", "u1"), ("cc_cr_idx", "u1"), ("pad", "u1", 2)])
+                          ("cc_cb_idx", "u1"), ("cc_cr_idx", "u1"), ("border", "u1"), ("pad", "u1")])
+BORDER_LEFT, BORDER_RIGHT, BORDER_UPPER, BORDER_BOTTOM, BORDER_ONE_ROW = 1, 2, 4, 8, 16   # OVHIP_BORDER_*
 ALF_LUMA_SET_SIZE = 4 * 25 * 13
 
 

@@ -36,6 +36,20 @@ namespace {
 #define CH 2            /* chroma halo             */
 #define CW (TL + 2 * CH)
 
+// The rectangle a CTU's filter windows are clamped to: the picture, cut at the sides of the CTU that are borders of its rect entry
+// (tile; ovhip_alf_ctu.border): the reference pads there exactly as at the picture border (rcn_extend_filter_region with the
+// entry-local is_border, rcn_alf.c:1313-1318).  (x0, y0) = the CTU's origin, s = its size, in samples of the plane.
+struct AlfRect { int x0, y0, x1, y1; };
+__device__ __forceinline__ AlfRect alf_clamp_rect(int border, int x0, int y0, int s, int w, int h)
+{
+    AlfRect r = { 0, 0, w - 1, h - 1 };
+    if (border & OVHIP_BORDER_LEFT) r.x0 = x0;
+    if (border & OVHIP_BORDER_UPPER) r.y0 = y0;
+    if (border & OVHIP_BORDER_RIGHT) r.x1 = min(r.x1, x0 + s - 1);
+    if (border & OVHIP_BORDER_BOTTOM) r.y1 = min(r.y1, y0 + s - 1);
+    return r;
+}
+
 __device__ __forceinline__ int alf_clipd(int clip, int ref, int a, int b)
 {
     return ov_clip3(a - ref, -clip, clip) + ov_clip3(b - ref, -clip, clip);
@@ -116,16 +130,17 @@ __device__ __forceinline__ void alf_luma_tile(const ovhip_pic &dst, const ovhip_
     }
 
     // 38 rows x 40 samples (tile + halo, 4 samples left so that the row is five 16-byte groups)
-    if (tx0 >= LPAD && tx0 + TL + LPAD <= W && ty0 >= LH && ty0 + TL + LH <= H && !(src.stride_y & 7)) {
+    const AlfRect rc = alf_clamp_rect(c.border, tx0 & ~(ctu - 1), ty0 & ~(ctu - 1), ctu, W, H);
+    if (tx0 >= rc.x0 + LPAD && tx0 + TL + LPAD <= rc.x1 + 1 && ty0 >= rc.y0 + LH && ty0 + TL + LH <= rc.y1 + 1 && !(src.stride_y & 7)) {
         if (tid < LW * 5) {                                           // interior tile: one 16-byte load per lane
             const int yy = tid / 5, q = tid - yy * 5;
             *reinterpret_cast<uint4 *>(s_t + yy * LWS + 8 * q) =
                 *reinterpret_cast<const uint4 *>(src.y + (ty0 + yy - LH) * src.stride_y + tx0 - LPAD + 8 * q);
         }
     } else {
-        for (int i = tid; i < LW * LWS; i += 256) {                   // picture border: clamped coordinates
+        for (int i = tid; i < LW * LWS; i += 256) {                   // picture / rect-entry border: clamped coordinates
             const int yy = i / LWS, xx = i - yy * LWS;
-            const int sy = ov_clip3(ty0 + yy - LH, 0, H - 1), sx = ov_clip3(tx0 + xx - LPAD, 0, W - 1);
+            const int sy = ov_clip3(ty0 + yy - LH, rc.y0, rc.y1), sx = ov_clip3(tx0 + xx - LPAD, rc.x0, rc.x1);
             s_t[i] = src.y[sy * src.stride_y + sx];
         }
     }
@@ -324,9 +339,10 @@ __device__ __forceinline__ void alf_chroma_tile(const ovhip_pic &dst, const ovhi
     const uint16_t *sp = comp == 1 ? src.cb : src.cr;
     uint16_t *dp = comp == 1 ? dst.cb : dst.cr;
 
+    const AlfRect rcc = alf_clamp_rect(c.border, tx0 & ~(ctuc - 1), ty0 & ~(ctuc - 1), ctuc, Wc, Hc);
     if (on) {
         // 36 rows x 40 samples (tile + halo, 4 samples left so that a row is five 16-byte groups)
-        if (tx0 >= LPAD && tx0 + TL + LPAD <= Wc && ty0 >= CH && ty0 + TL + CH <= Hc && !(src.stride_c & 7)) {
+        if (tx0 >= rcc.x0 + LPAD && tx0 + TL + LPAD <= rcc.x1 + 1 && ty0 >= rcc.y0 + CH && ty0 + TL + CH <= rcc.y1 + 1 && !(src.stride_c & 7)) {
             if (tid < CW * 5) {
                 const int yy = tid / 5, q = tid - yy * 5;
                 *reinterpret_cast<uint4 *>(s_t + yy * LWS + 8 * q) =
@@ -335,7 +351,7 @@ __device__ __forceinline__ void alf_chroma_tile(const ovhip_pic &dst, const ovhi
         } else {
             for (int i = tid; i < CW * LWS; i += 256) {
                 const int yy = i / LWS, xx = i - yy * LWS;
-                const int sy = ov_clip3(ty0 + yy - CH, 0, Hc - 1), sx = ov_clip3(tx0 + xx - LPAD, 0, Wc - 1);
+                const int sy = ov_clip3(ty0 + yy - CH, rcc.y0, rcc.y1), sx = ov_clip3(tx0 + xx - LPAD, rcc.x0, rcc.x1);
                 s_t[i] = sp[sy * src.stride_c + sx];
             }
         }
@@ -380,7 +396,8 @@ __device__ __forceinline__ void alf_chroma_tile(const ovhip_pic &dst, const ovhi
         if (pos == vbpos - 2 || pos == vbpos + 1) r3 = r1;
         else if (pos == vbpos - 1 || pos == vbpos) r1 = r2 = r3 = 0;
     }
-    const bool cc_inside = tx0 > 0 && ty0 > 0 && tx0 + TL < Wc && ty0 + TL < Hc;
+    const bool cc_inside = tx0 > rcc.x0 && ty0 > rcc.y0 && tx0 + TL <= rcc.x1 && ty0 + TL <= rcc.y1;
+    const AlfRect rcl = { 2 * rcc.x0, 2 * rcc.y0, min(2 * rcc.x1 + 1, W - 1), min(2 * rcc.y1 + 1, H - 1) };      // the same rectangle in luma samples
     // 5 rows of the 12-sample group lx0-4 .. lx0+7 as 8-byte LDS reads (see alf_luma_tile)
     uint32_t r0[6], p1[6], m1[6], p2[2], m2[2];
     int cmin = 0x7fff, fsum = 0;
@@ -449,7 +466,7 @@ __device__ __forceinline__ void alf_chroma_tile(const ovhip_pic &dst, const ovhi
                 sum += cf[5] * ((int)lp[r1 * src.stride_y + 1] - cy);
                 sum += cf[6] * ((int)lp[r3 * src.stride_y] - cy);
             } else {
-#define LU(dx, dy) ((int)src.y[ov_clip3(Ly + (dy), 0, H - 1) * src.stride_y + ov_clip3(Lx + (dx), 0, W - 1)])
+#define LU(dx, dy) ((int)src.y[ov_clip3(Ly + (dy), rcl.y0, rcl.y1) * src.stride_y + ov_clip3(Lx + (dx), rcl.x0, rcl.x1)])
                 cy = LU(0, 0);
                 sum += cf[0] * (LU(0, r2) - cy);
                 sum += cf[1] * (LU(-1, 0) - cy);

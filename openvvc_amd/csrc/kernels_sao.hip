@@ -65,7 +65,15 @@ __global__ __launch_bounds__(256) void k_sao(ovhip_pic dst, ovhip_pic src, const
             const int dxa = eo == 1 ? 0 : (eo == 3 ? 1 : -1), dya = eo == 0 ? 0 : -1;
             // last term: quirk of the reference for pictures of a single CTU row (rcn_sao.c:262): the first
             // 6-row band is processed with the BOTTOM border flag, its last row is skipped
-            const bool rowskip = eo != 0 && (y == 0 || y == h - 1 || (src.h <= (1 << log2_ctu) && y == (6 >> sh) - 1));
+            // borders of the CTU's rect entry (tile) inside the picture count like the picture's (is_border from the entry-local CTU
+            // index, rcn_sao.c:211-214, :253-257): ovhip_sao_ctu.border, zero in a picture of one entry
+            const int bd = p->border, cs = 1 << l2;
+            const int cy0 = y & ~(cs - 1), cx0 = x0 & ~(cs - 1);
+            const int cx1 = min(cx0 + cs, w) - 1;
+            const bool rowskip = eo != 0 && (y == 0 || y == h - 1 || (src.h <= (1 << log2_ctu) && y == (6 >> sh) - 1) ||
+                                             ((bd & OVHIP_BORDER_UPPER) && y == cy0) || ((bd & OVHIP_BORDER_BOTTOM) && y == min(cy0 + cs, h) - 1) ||
+                                             ((bd & OVHIP_BORDER_ONE_ROW) && y == cy0 + (6 >> sh) - 1));
+            const int skip_l = (bd & OVHIP_BORDER_LEFT) ? cx0 : -1, skip_r = (bd & OVHIP_BORDER_RIGHT) ? cx1 : -1;
             if (!rowskip) {
                 const int of0 = p->offset_val[c][0], of1 = p->offset_val[c][1], of2 = p->offset_val[c][2],
                           of3 = p->offset_val[c][3], of4 = p->offset_val[c][4];
@@ -80,7 +88,7 @@ __global__ __launch_bounds__(256) void k_sao(ovhip_pic dst, ovhip_pic src, const
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int x = x0 + i;
-                    if (i < n && !(eo != 1 && (x == 0 || x == w - 1))) {
+                    if (i < n && !(eo != 1 && (x == 0 || x == w - 1 || x == skip_l || x == skip_r))) {
                         const int a = ra[1 + i + dxa], b = rb[1 + i - dxa];
                         const int idx = 2 + (v[i] > a) - (v[i] < a) + (v[i] > b) - (v[i] < b);
                         const int off = idx == 0 ? of0 : idx == 1 ? of1 : idx == 2 ? of2 : idx == 3 ? of3 : of4;

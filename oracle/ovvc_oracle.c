@@ -1005,7 +1005,9 @@ void oracle_dbf(const oracle_pic *pic, const ovhip_dbf_planes *pl)
  * ================================================================================== */
 /* sao_band_filter / sao_edge_filter / rcn_sao_ctu, rcn_sao.c:46-188.  Picture-level restatement:
  * every sample uses the parameters of the CTU that contains it; samples on the picture border
- * whose class neighbour lies outside are left unfiltered (the is_border row/column skips). */
+ * whose class neighbour lies outside are left unfiltered (the is_border row/column skips).  Borders of a rect entry (tile) inside
+ * the picture count like the picture's: is_border comes from the ENTRY-local CTU index (rcn_sao.c:211-214, :253-257), carried
+ * per CTU in ovhip_sao_ctu.border. */
 void oracle_sao(const oracle_pic *dst, const oracle_pic *src, const ovhip_sao_ctu *prm, int log2_ctu)
 {
     static const int8_t pos[4][2][2] = { { { -1, 0 }, { 1, 0 } }, { { 0, -1 }, { 0, 1 } }, { { -1, -1 }, { 1, 1 } }, { { 1, -1 }, { -1, 1 } } };
@@ -1028,8 +1030,14 @@ void oracle_sao(const oracle_pic *dst, const oracle_pic *src, const ovhip_sao_ct
                     if (k < 4) o = clip_bd(v + p->offset_val[c][k]);
                 } else if (p->type[c] == OVHIP_SAO_EDGE) {
                     const int eo = p->eo_class[c];
+                    const int b = p->border, cs = 1 << l2;
+                    const int cx0 = x & ~(cs - 1), cy0 = y & ~(cs - 1);
+                    const int cx1 = (cx0 + cs < w ? cx0 + cs : w) - 1, cy1 = (cy0 + cs < h ? cy0 + cs : h) - 1;
                     const int skip = (eo != 1 && (x == 0 || x == w - 1)) || (eo != 0 && (y == 0 || y == h - 1))
-                                     || (one_row && eo != 0 && y == (6 >> sh) - 1);
+                                     || (one_row && eo != 0 && y == (6 >> sh) - 1)
+                                     || (eo != 1 && (((b & OVHIP_BORDER_LEFT) && x == cx0) || ((b & OVHIP_BORDER_RIGHT) && x == cx1)))
+                                     || (eo != 0 && (((b & OVHIP_BORDER_UPPER) && y == cy0) || ((b & OVHIP_BORDER_BOTTOM) && y == cy1)
+                                                     || ((b & OVHIP_BORDER_ONE_ROW) && y == cy0 + (6 >> sh) - 1)));
                     if (!skip) {
                         const int a = s[(y + pos[eo][0][1]) * ss + x + pos[eo][0][0]];
                         const int b = s[(y + pos[eo][1][1]) * ss + x + pos[eo][1][0]];
@@ -1053,9 +1061,22 @@ typedef struct oracle_alf {       /* host twin of ovhip_alf_pic */
     int32_t log2_ctu_s;
 } oracle_alf;
 
-static inline int px(const uint16_t *p, int stride, int w, int h, int x, int y)
+/* The rectangle the filter windows of a CTU's samples are clamped to: the picture, cut at those sides of the CTU that are borders
+ * of its rect entry (tile) -- rcn_extend_filter_region pads there as it does at the picture border (rcn_ctu.c:361-508 with the
+ * entry-local is_border of rcn_alf.c:1313-1318).  A window never reaches further than the neighbouring CTU. */
+typedef struct { int x0, y0, x1, y1; } alf_rect;
+static alf_rect alf_clamp_rect(int border, int cx0, int cy0, int ctu, int w, int h)
 {
-    return p[clip3i(y, 0, h - 1) * stride + clip3i(x, 0, w - 1)];
+    alf_rect r = { 0, 0, w - 1, h - 1 };
+    if (border & OVHIP_BORDER_LEFT) r.x0 = cx0;
+    if (border & OVHIP_BORDER_UPPER) r.y0 = cy0;
+    if ((border & OVHIP_BORDER_RIGHT) && cx0 + ctu - 1 < r.x1) r.x1 = cx0 + ctu - 1;
+    if ((border & OVHIP_BORDER_BOTTOM) && cy0 + ctu - 1 < r.y1) r.y1 = cy0 + ctu - 1;
+    return r;
+}
+static inline int pxr(const uint16_t *p, int stride, const alf_rect *r, int x, int y)
+{
+    return p[clip3i(y, r->y0, r->y1) * stride + clip3i(x, r->x0, r->x1)];
 }
 
 /* alf_derive_filter_idx, rcn_alf.c:283-345 */
@@ -1080,28 +1101,27 @@ static void alf_filter_idx(uint32_t sum_h, uint32_t sum_v, uint32_t sum_d, uint3
 /* Laplacians of one row pair (r, r+1) over the 8 columns bx-2..bx+5, sub-sampled on the (r+c) even
  * lattice; `above` / `below` are the rows used as vertical neighbours of r and r+1
  * (rcn_alf_classif_{vbnd,novbnd}, rcn_alf.c:347-704) */
-static void alf_lap_pair(const uint16_t *p, int stride, int w, int h, int bx, int r, int above, int below, uint32_t s[4])
+static void alf_lap_pair(const uint16_t *p, int stride, const alf_rect *rc, int bx, int r, int above, int below, uint32_t s[4])
 {
     for (int k = 0; k < 4; ++k) {
         int c0 = bx - 2 + 2 * k, c1 = c0 + 1;
-        int y1 = px(p, stride, w, h, c0, r) << 1, y2 = px(p, stride, w, h, c1, r + 1) << 1;
-        s[0] += abs(y1 - px(p, stride, w, h, c0, above) - px(p, stride, w, h, c0, r + 1))            /* V */
-              + abs(y2 - px(p, stride, w, h, c1, r) - px(p, stride, w, h, c1, below));
-        s[1] += abs(y1 - px(p, stride, w, h, c0 + 1, r) - px(p, stride, w, h, c0 - 1, r))            /* H */
-              + abs(y2 - px(p, stride, w, h, c1 + 1, r + 1) - px(p, stride, w, h, c1 - 1, r + 1));
-        s[2] += abs(y1 - px(p, stride, w, h, c0 - 1, above) - px(p, stride, w, h, c0 + 1, r + 1))    /* D0 */
-              + abs(y2 - px(p, stride, w, h, c1 - 1, r) - px(p, stride, w, h, c1 + 1, below));
-        s[3] += abs(y1 - px(p, stride, w, h, c0 - 1, r + 1) - px(p, stride, w, h, c0 + 1, above))    /* D1 */
-              + abs(y2 - px(p, stride, w, h, c1 - 1, below) - px(p, stride, w, h, c1 + 1, r));
+        int y1 = pxr(p, stride, rc, c0, r) << 1, y2 = pxr(p, stride, rc, c1, r + 1) << 1;
+        s[0] += abs(y1 - pxr(p, stride, rc, c0, above) - pxr(p, stride, rc, c0, r + 1))            /* V */
+              + abs(y2 - pxr(p, stride, rc, c1, r) - pxr(p, stride, rc, c1, below));
+        s[1] += abs(y1 - pxr(p, stride, rc, c0 + 1, r) - pxr(p, stride, rc, c0 - 1, r))            /* H */
+              + abs(y2 - pxr(p, stride, rc, c1 + 1, r + 1) - pxr(p, stride, rc, c1 - 1, r + 1));
+        s[2] += abs(y1 - pxr(p, stride, rc, c0 - 1, above) - pxr(p, stride, rc, c0 + 1, r + 1))    /* D0 */
+              + abs(y2 - pxr(p, stride, rc, c1 - 1, r) - pxr(p, stride, rc, c1 + 1, below));
+        s[3] += abs(y1 - pxr(p, stride, rc, c0 - 1, r + 1) - pxr(p, stride, rc, c0 + 1, above))    /* D1 */
+              + abs(y2 - pxr(p, stride, rc, c1 - 1, below) - pxr(p, stride, rc, c1 + 1, r));
     }
 }
 
 /* vb: virtual-boundary row in CTU-LOCAL luma rows as the reference derives it -- ctu_h - 4 for a
  * full-height CTU, pic_h for a truncated one (rcn_alf.c:722, :1346); it is compared with CTU-local
  * rows, so for truncated CTUs it only ever matches in pictures of a single CTU row. */
-static void alf_classify_block(const oracle_pic *src, int bx, int by, int vb, int ctu_y0, int *cls, int *tr)
+static void alf_classify_block(const oracle_pic *src, const alf_rect *rc, int bx, int by, int vb, int ctu_y0, int *cls, int *tr)
 {
-    const int w = src->w, h = src->h;
     const int lby = by - ctu_y0;
     uint32_t s[4] = { 0, 0, 0, 0 };
     int first = 0, last = 3, is_vb = 0;
@@ -1112,7 +1132,7 @@ static void alf_classify_block(const oracle_pic *src, int bx, int by, int vb, in
         int above = r - 1, below = r + 2;
         if (r - ctu_y0 + 2 == vb) below = r + 1;       /* pair (vb-2, vb-1): row vb is not available */
         if (r - ctu_y0 == vb)     above = r;           /* pair (vb, vb+1): row vb-1 is not available */
-        alf_lap_pair(src->y, src->stride_y, w, h, bx, r, above, below, s);
+        alf_lap_pair(src->y, src->stride_y, rc, bx, r, above, below, s);
     }
     alf_filter_idx(s[1], s[0], s[2], s[3], is_vb, cls, tr);
 }
@@ -1141,7 +1161,8 @@ void oracle_alf_run(const oracle_pic *dst, const oracle_pic *src, const oracle_a
                 /* check_virtual_bound, rcn_alf.c:1274-1283: selects alf.luma[1] (VB variant) */
                 const int req_vb = (last_local < vb && last_local >= vb - 4) || (last_local >= vb && last_local <= vb + 3);
                 int cls, tr;
-                alf_classify_block(src, x & ~3, y & ~3, vb, ctu_y0, &cls, &tr);
+                const alf_rect rc = alf_clamp_rect(c->border, (x / ctu) * ctu, ctu_y0, ctu, W, H);
+                alf_classify_block(src, &rc, x & ~3, y & ~3, vb, ctu_y0, &cls, &tr);
                 const int16_t *f = a->luma_coeff + c->luma_set * OVHIP_ALF_LUMA_SET_SIZE + tr * 25 * 13 + cls * 13;
                 const int16_t *cl = a->luma_clip + c->luma_set * OVHIP_ALF_LUMA_SET_SIZE + tr * 25 * 13 + cls * 13;
                 int d = 3, near = 0;
@@ -1153,7 +1174,7 @@ void oracle_alf_run(const oracle_pic *dst, const oracle_pic *src, const oracle_a
                 }
                 const int o1 = d < 1 ? d : 1, o2 = d < 2 ? d : 2, o3 = d < 3 ? d : 3;
                 const uint16_t *p = src->y; const int st = src->stride_y;
-#define L(dx, dy) px(p, st, W, H, x + (dx), y + (dy))
+#define L(dx, dy) pxr(p, st, &rc, x + (dx), y + (dy))
                 int sum = 0;
                 sum += f[0] * alf_clipd(cl[0], cur, L(0, o3), L(0, -o3));
                 sum += f[1] * alf_clipd(cl[1], cur, L(1, o2), L(-1, -o2));
@@ -1187,6 +1208,7 @@ void oracle_alf_run(const oracle_pic *dst, const oracle_pic *src, const oracle_a
                 const int truncated = ctu_y0 + ctu > H;
                 const int cur = p[y * st + x];
                 int out = cur;
+                const alf_rect rcc = alf_clamp_rect(c->border, (x / ctuc) * ctuc, (y / ctuc) * ctuc, ctuc, Wc, Hc);
                 if (c->flags & (comp == 1 ? 2 : 1)) {
                     const int alt = comp == 1 ? c->cb_alt : c->cr_alt;
                     const int16_t *f = a->chroma_coeff + alt * 7, *cl = a->chroma_clip + alt * 7;
@@ -1197,7 +1219,7 @@ void oracle_alf_run(const oracle_pic *dst, const oracle_pic *src, const oracle_a
                     else if (ly >= vb && ly <= vb + 1) d = ly - vb;
                     const int near = (ly == vb - 1) || (ly == vb);
                     const int o1 = d < 1 ? d : 1, o2 = d < 2 ? d : 2;
-#define Cc(dx, dy) px(p, st, Wc, Hc, x + (dx), y + (dy))
+#define Cc(dx, dy) pxr(p, st, &rcc, x + (dx), y + (dy))
                     int sum = 0;
                     sum += f[0] * alf_clipd(cl[0], cur, Cc(0, o2), Cc(0, -o2));
                     sum += f[1] * alf_clipd(cl[1], cur, Cc(1, o1), Cc(-1, -o1));
@@ -1220,7 +1242,8 @@ void oracle_alf_run(const oracle_pic *dst, const oracle_pic *src, const oracle_a
                     if (pos == vbpos - 2 || pos == vbpos + 1) r3 = r1;
                     else if (pos == vbpos - 1 || pos == vbpos) r1 = r2 = r3 = 0;
                     const int lx = x << 1, lyy = y << 1;
-#define Ly(dx, dy) px(src->y, src->stride_y, W, H, lx + (dx), lyy + (dy))
+                    const alf_rect rcl = alf_clamp_rect(c->border, (x / ctuc) * ctu, ctu_y0, ctu, W, H);
+#define Ly(dx, dy) pxr(src->y, src->stride_y, &rcl, lx + (dx), lyy + (dy))
                     const int cy = Ly(0, 0);
                     int sum = 0;
                     sum += f[0] * (Ly(0, r2) - cy);

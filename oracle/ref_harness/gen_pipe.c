@@ -62,6 +62,7 @@ static dmvr_fn g_dmvr_inner;
 static gbuf g_dmvr_log = { .type = T_I32 };         /* per call: x, y (picture, luma), log2 w, log2 h, mv0 in, mv1 in, mv0 out, mv1 out */
 static size_t g_dmvr_pos;                           /* shim pass: next entry of the reference pass's log */
 static int g_pass_shim;
+static int g_tile_cols = 1, g_tile_rows = 1;         /* "tiles C R": C x R rect entries per picture, decoded one after the other on ONE OVCTUDec (slicedec.c:649-653) */
 static int g_isp_64x2;                              /* the reference's result for 64x2 ISP partitions is undefined (gen_golden.c, gen_isp) */
 
 /* ---- device mode: the decoder's events the shim hangs its frame-level calls on, interleaved with those calls ---- */
@@ -238,6 +239,18 @@ seq_init(struct gp_seq *s, int w, int h, int variant)
     pps->pps_pic_width_in_luma_samples = w; pps->pps_pic_height_in_luma_samples = h;
     pps->pps_log2_ctu_size_minus5 = 2;
     pps->pps_no_pic_partition_flag = 1;
+    if (g_tile_cols * g_tile_rows > 1) {
+        /* tiles: uniform columns / rows, the last one takes what is left (what pps_read derives from the explicit widths;
+         * nvcl_nal_pps.c) -- dec_init.c:369-404 reads exactly these fields.  One rect entry per tile (slicedec.c:636-657). */
+        const int nw = (w + 127) >> 7, nh = (h + 127) >> 7;
+        if (g_tile_cols > nw || g_tile_rows > nh) { fprintf(stderr, "gen_pipe: more tiles than CTUs\n"); exit(2); }
+        pps->pps_no_pic_partition_flag = 0;
+        pps->pps_num_tile_columns_minus1 = g_tile_cols - 1; pps->pps_num_tile_rows_minus1 = g_tile_rows - 1;
+        const int cw = (nw + g_tile_cols - 1) / g_tile_cols, ch = (nh + g_tile_rows - 1) / g_tile_rows;
+        for (int i = 0, left = nw; i < g_tile_cols; ++i) { const int n = i == g_tile_cols - 1 ? left : (cw < left - (g_tile_cols - 1 - i) ? cw : left - (g_tile_cols - 1 - i)); pps->pps_tile_column_width_minus1[i] = n - 1; left -= n; }
+        for (int i = 0, left = nh; i < g_tile_rows; ++i) { const int n = i == g_tile_rows - 1 ? left : (ch < left - (g_tile_rows - 1 - i) ? ch : left - (g_tile_rows - 1 - i)); pps->pps_tile_row_height_minus1[i] = n - 1; left -= n; }
+        pps->pps_loop_filter_across_tiles_enabled_flag = 0;        /* (never read by the reference: a rect entry is filtered on its own) */
+    }
     pps->pps_init_qp_minus26 = 0;
     pps->pps_cu_qp_delta_enabled_flag = variant == 1;
     pps->pps_cb_qp_offset = variant == 1 ? 1 : 0; pps->pps_cr_qp_offset = variant == 1 ? -1 : 0;
@@ -342,13 +355,13 @@ gp_set_refs(OVPicture *p, OVPicture **l0, int n0, OVPicture **l1, int n1, int tm
 static void
 gp_alloc_lines(OVSliceDec *sl, const struct gp_seq *s)
 {
-    /* init_cabac_lines (slicedec.c:357-391): one byte per 4-sample unit of the picture width, one tile row */
-    const int nb_pb = s->nb_ctb_w << 5;
+    /* init_cabac_lines (slicedec.c:357-391): one byte per 4-sample unit of the picture width, per tile row */
+    const int nb_pb = (s->nb_ctb_w << 5) * g_tile_rows;
     for (int k = 0; k < 2; ++k) {
         sl->cabac_lines[k].qt_depth_map_x = calloc(nb_pb, 1); sl->cabac_lines[k].log2_cu_w_map_x = calloc(nb_pb, 1); sl->cabac_lines[k].cu_mode_x = calloc(nb_pb, 1);
     }
-    /* init_drv_lines (drv_lines.c:772-817): nb_ctb_pic_w + 2 per tile column, one tile row */
-    const int nb_ctb = s->nb_ctb_w + 2, nb_pb2 = nb_ctb << 5, n_in = 32 * nb_ctb + 2;
+    /* init_drv_lines (drv_lines.c:772-817): nb_ctb_pic_w + 2 per tile column, per tile row */
+    const int nb_ctb = (s->nb_ctb_w + 2 * g_tile_cols) * g_tile_rows, nb_pb2 = nb_ctb << 5, n_in = 32 * nb_ctb + 2;
     struct DRVLines *l = &sl->drv_lines;
     l->inter_lines.mv0 = calloc((size_t)32 * n_in, sizeof(OVMV)); l->inter_lines.mv1 = calloc((size_t)32 * n_in, sizeof(OVMV));
     l->inter_lines.dir0 = calloc(n_in, 4); l->inter_lines.dir1 = calloc(n_in, 4); l->inter_lines.affine = calloc(n_in, 4);
@@ -454,13 +467,20 @@ run_stream(struct gp_seq *s, const struct gp_pic_desc *desc, int n_pic, uint32_t
         pic_headers(s, d->slice_type, d->qp, d->n0, d->n1, d->tmvp, d->col_from_l0, d->lmcs);
         s->ps.ph = NULL; s->ps.sh = NULL;               /* new headers in the same structs */
         if (decinit_update_params(&s->ps, &s->nvcl) < 0) { fprintf(stderr, "gen_pipe: decinit_update_params failed\n"); exit(1); }
-        s->ps.sh_info.rbsp_entry[0] = g_payload; s->ps.sh_info.rbsp_entry[1] = g_payload + GP_PAYLOAD;
+        /* one rect entry per tile, each with its own stretch of the slice data (decinit_set_entry_points, dec_init.c:320-366) */
+        const int n_entries = g_tile_cols * g_tile_rows;
+        const size_t per_entry = (GP_PAYLOAD / n_entries) & ~(size_t)63;
+        for (int i = 0; i < n_entries; ++i) { s->ps.sh_info.rbsp_entry[i] = g_payload + i * per_entry; g_payload[i * per_entry] &= 0x7f; }
+        s->ps.sh_info.rbsp_entry[n_entries] = g_payload + n_entries * per_entry;
         sl.pic = pics[k]; sl.active_params = &s->ps; sl.slice_type = d->slice_type;
         slicedec_init_lines(&sl, &s->ps);
-        slicedec_update_entry_decoder(&sl, c);
         const size_t dm0 = g_pass_shim ? g_dmvr_pos : g_dmvr_log.n / 12;
         const double t_dec = gp_now();
-        slicedec_decode_rect_entry(&sl, c, &s->ps, 0);
+        for (int i = 0; i < n_entries; ++i) {
+            /* slicedec_decode_rect_entries without entry threads (slicedec.c:649-653) */
+            slicedec_update_entry_decoder(&sl, c);
+            slicedec_decode_rect_entry(&sl, c, &s->ps, i);
+        }
         g_decode_seconds += gp_now() - t_dec;
         g_decode_seconds_pass[g_pass_shim] += gp_now() - t_dec;
         ovdpb_report_decoded_frame(pics[k]);
@@ -539,7 +559,7 @@ gp_on_segv(int sig)
 int
 gp_main(int argc, char **argv)
 {
-    signal(SIGSEGV, gp_on_segv); signal(SIGBUS, gp_on_segv); signal(SIGFPE, gp_on_segv);
+    signal(SIGSEGV, gp_on_segv); signal(SIGBUS, gp_on_segv); signal(SIGFPE, gp_on_segv); signal(SIGABRT, gp_on_segv);
     const char *dir = argc > 1 ? argv[1] : "../tests/golden";
     int want_shim = 0, want_dev = 0, want_time = 0, variant = 0, W = 416, H = 240, dqp = 0, n_pic = 5;
     uint32_t seed = 0x266 + 31337;
@@ -557,6 +577,7 @@ gp_main(int argc, char **argv)
         else if (!strcmp(argv[i], "null")) g_null_shim = 1;      /* with "time shim": the installed slots without a recorder = the parse alone */
         else if (!strcmp(argv[i], "time")) want_time = g_time_only = 1;       /* reference pass only; prints pictures and seconds inside the slice decoder */
         else if (!strcmp(argv[i], "size") && i + 2 < argc) { W = atoi(argv[i + 1]); H = atoi(argv[i + 2]); i += 2; }
+        else if (!strcmp(argv[i], "tiles") && i + 2 < argc) { g_tile_cols = atoi(argv[i + 1]); g_tile_rows = atoi(argv[i + 2]); i += 2; }
         else { fprintf(stderr, "gen_pipe: unknown argument %s\n", argv[i]); return 2; }
     }
     if (W % 8 || H % 8 || W < 136 || H < 136 || W > 4096 || H > 2304 || n_pic < 1 || n_pic > GP_MAX_PIC) { fprintf(stderr, "gen_pipe: size / pics\n"); return 2; }

@@ -88,6 +88,8 @@ struct hip_entry {
     ovhip_frame *fr; int dev;            /* this OVCTUDec's frame thread on the device path (include/ovvc_hip.h) and its logical device */
     int pic_w, pic_h, log2_ctu, nb_ctu_w, nb_ctu_h;
     const OVFrame *frame;                /* picture being decoded */
+    int ctus_left;                       /* CTUs of that picture whose rect entries (tiles) have not ended yet: 0 = no picture open      */
+    int whole_pic_entry;                 /* the entry being decoded covers the picture (no tile borders inside)                          */
     int err;
     const OVPicture *refs[16]; int n_refs;
     ovhip_lmcs_luts luts; int have_luts, lmcs_region_live;
@@ -1000,10 +1002,11 @@ static void hip_rcn_dbf_truncated_ctu(const struct OVRCNCtx *const r, struct DBF
 static int
 params_alloc(struct hip_entry *e, const OVCTUDec *c, const struct RectEntryInfo *einfo)
 {
+    /* the arrays cover the PICTURE; a rect entry (tile) fills its own CTUs (slicedec.c:484-514: ctb_x / ctb_y = its origin) */
     const int l2 = c->part_ctx->log2_ctu_s;
     const int nw = (e->pic_w + (1 << l2) - 1) >> l2, nh = (e->pic_h + (1 << l2) - 1) >> l2;
-    if (einfo->ctb_x || einfo->ctb_y || einfo->nb_ctu_w != nw || einfo->nb_ctu_h != nh) {
-        latch(e, OVHIP_EUNSUP, "rect entry smaller than the picture (tiles)");
+    if (einfo->ctb_x + einfo->nb_ctu_w > nw || einfo->ctb_y + einfo->nb_ctu_h > nh) {
+        latch(e, OVHIP_EINVAL, "rect entry outside the picture");
         return -1;
     }
     e->log2_ctu = l2; e->nb_ctu_w = nw; e->nb_ctu_h = nh;
@@ -1016,6 +1019,19 @@ params_alloc(struct hip_entry *e, const OVCTUDec *c, const struct RectEntryInfo 
     return 0;
 }
 
+/* The in-loop filters of a rect entry stop at its borders: SAO leaves the samples whose neighbour lies outside alone and ALF pads
+ * (is_border from the ENTRY-local CTU index, rcn_sao.c:211-214, rcn_alf.c:1313-1318; rcn_extend_filter_region, rcn_ctu.c:361-508).
+ * The device filters the whole picture at once: every CTU carries which of its sides are such borders.  A picture of one entry
+ * carries none (its borders are the picture's, which the kernels know). */
+static uint8_t
+entry_borders(const struct hip_entry *e, const struct RectEntryInfo *einfo, int x, int y)
+{
+    if (e->whole_pic_entry) return 0;
+    return (uint8_t)((x == 0 ? OVHIP_BORDER_LEFT : 0) | (x == einfo->nb_ctu_w - 1 ? OVHIP_BORDER_RIGHT : 0) |
+                     (y == 0 ? OVHIP_BORDER_UPPER : 0) | (y == einfo->nb_ctu_h - 1 ? OVHIP_BORDER_BOTTOM : 0) |
+                     (einfo->nb_ctu_h == 1 ? OVHIP_BORDER_ONE_ROW : 0));
+}
+
 static void
 sao_row(struct hip_entry *e, const OVCTUDec *c, const struct RectEntryInfo *einfo, int ctb_y)
 {
@@ -1023,8 +1039,9 @@ sao_row(struct hip_entry *e, const OVCTUDec *c, const struct RectEntryInfo *einf
     const struct SAOInfo *si = &c->sao_info;
     for (int x = 0; x < einfo->nb_ctu_w; ++x) {
         const SAOParamsCtu *s = &si->sao_params[ctb_y * einfo->nb_ctu_w + x];
-        ovhip_sao_ctu *o = &e->sao[ctb_y * e->nb_ctu_w + x];
+        ovhip_sao_ctu *o = &e->sao[(einfo->ctb_y + ctb_y) * e->nb_ctu_w + einfo->ctb_x + x];
         memset(o, 0, sizeof(*o));
+        o->border = entry_borders(e, einfo, x, ctb_y);
         for (int k = 0; k < (si->chroma_format_idc ? 3 : 1); ++k) {
             o->type[k] = s->type_idx[k]; o->band_position[k] = s->band_position[k]; o->eo_class[k] = s->eo_class[k];
             memcpy(o->offset_val[k], s->offset_val[k], sizeof(o->offset_val[k]));
@@ -1103,18 +1120,27 @@ hip_alf_filter_line(OVCTUDec *const c, const struct RectEntryInfo *const einfo, 
         for (int x = 0; x < einfo->nb_ctu_w; ++x) {
             const int i = ctb_y * einfo->nb_ctu_w + x;
             const ALFParamsCtu *p = &ai->ctb_alf_params[i];
-            ovhip_alf_ctu *o = &e->alf[i];
+            ovhip_alf_ctu *o = &e->alf[(einfo->ctb_y + ctb_y) * e->nb_ctu_w + einfo->ctb_x + x];
             o->flags = p->ctb_alf_flag; o->luma_set = p->ctb_alf_idx; o->cb_alt = p->cb_alternative; o->cr_alt = p->cr_alternative;
             o->cc_cb_idx = ai->cc_alf_cb_enabled_flag ? ai->ctb_cc_alf_filter_idx[0][i] : 0;
             o->cc_cr_idx = ai->cc_alf_cr_enabled_flag ? ai->ctb_cc_alf_filter_idx[1][i] : 0;
+            o->border = entry_borders(e, einfo, x, ctb_y);
         }
         if (ai->aps_cc_alf_data_cb) memcpy(e->alf_cc[0], ai->aps_cc_alf_data_cb->alf_cc_mapped_coeff[0], sizeof(e->alf_cc[0]));
         if (ai->aps_cc_alf_data_cr) memcpy(e->alf_cc[1], ai->aps_cc_alf_data_cr->alf_cc_mapped_coeff[1], sizeof(e->alf_cc[1]));
         e->alf_on = 1;
     }
+    /* the entry's last row: with it the last of the picture's rect entries ends the picture (ovthreads.c:93-114: the last entry
+     * job to finish calls slicedec_finish_decoding) */
+    int last = 0;
+    if (ctb_y == einfo->nb_ctu_h - 1) {
+        e->ctus_left -= einfo->nb_ctu_w * einfo->nb_ctu_h;
+        last = e->ctus_left <= 0;
+        if (last) e->ctus_left = 0;
+    }
     if (e->record_only) return;
-    dmvr_rows_step(e, c, ctb_y == einfo->nb_ctu_h - 1);
-    if (ctb_y == einfo->nb_ctu_h - 1) flush_picture(e, c);
+    dmvr_rows_step(e, c, last);
+    if (last) flush_picture(e, c);
 }
 
 /* ------------------------------------------------------------------------------------ picture begin / flush / plumbing */
@@ -1262,7 +1288,31 @@ flush_picture(struct hip_entry *e, OVCTUDec *c)
 static void
 begin_picture(struct hip_entry *e, const OVFrame *f, const struct RectEntryInfo *einfo)
 {
+    /* One device job = one picture.  A picture cut into rect entries (tiles; slicedec.c:636-657) attaches the frame once per entry:
+     * the entries that follow the first on the SAME OVCTUDec (one entry thread: slicedec.c:649-653 runs them in turn) go on recording
+     * into the picture's job, and the last one to end submits it (hip_alf_filter_line).  Entries of one picture on SEVERAL OVCTUDecs
+     * (`-e 2`, ovthreads.c:93-114) would need their recorders merged: refused, the picture fails loudly. */
+    int nw = 0, nh = 0, first = 1;
+    e->whole_pic_entry = 1;
+    if (einfo && e->key->part_ctx) {
+        const int l2 = e->key->part_ctx->log2_ctu_s;
+        const int pw = e->record_only ? e->pic_w : (int)f->width, ph = e->record_only ? e->pic_h : (int)f->height;
+        nw = (pw + (1 << l2) - 1) >> l2; nh = (ph + (1 << l2) - 1) >> l2;
+        first = !einfo->ctb_x && !einfo->ctb_y;
+        e->whole_pic_entry = first && einfo->nb_ctu_w == nw && einfo->nb_ctu_h == nh;
+    }
+    if (!first) {
+        if (e->frame != f || e->ctus_left <= 0 || !e->rec) {
+            latch(e, OVHIP_EUNSUP, "rect entry of a picture whose first entry this OVCTUDec did not decode (entry threads > 1)");
+            if (!e->record_only && e->fr) { ovhip_frame_destroy(e->fr); e->fr = NULL; e->rec = NULL; }
+            return;
+        }
+        e->lmcs_region_live = 0;
+        e->pend.kind = PEND_NONE; e->aff_c_live = 0; e->ciip.live = 0;
+        return;
+    }
     e->frame = f;
+    e->ctus_left = nw * nh;
     e->err = 0;
     e->n_refs = 0;
     e->sao_on = e->alf_on = 0;
@@ -1272,17 +1322,6 @@ begin_picture(struct hip_entry *e, const OVFrame *f, const struct RectEntryInfo 
     if (e->rec && e->key->part_ctx) (void)ovhip_rec_set_ctu_size(e->rec, e->key->part_ctx->log2_ctu_s);
     if (e->n_ctu) { memset(e->sao, 0, e->n_ctu * sizeof(*e->sao)); memset(e->alf, 0, e->n_ctu * sizeof(*e->alf)); }
     if (e->record_only) { ovhip_rec_reset(e->rec); return; }
-    /* one device job = one picture: a picture cut into several rect entries (tiles, `-e 2`; slicedec.c:636-657, ovthreads.c:93-114)
-     * would begin and flush the same device picture from two threads -- refused before anything is begun */
-    if (einfo && e->key->part_ctx) {
-        const int l2 = e->key->part_ctx->log2_ctu_s;
-        const int nw = ((int)f->width + (1 << l2) - 1) >> l2, nh = ((int)f->height + (1 << l2) - 1) >> l2;
-        if (einfo->ctb_x || einfo->ctb_y || einfo->nb_ctu_w != nw || einfo->nb_ctu_h != nh) {
-            latch(e, OVHIP_EUNSUP, "picture with more than one rect entry (tiles / entry threads)");
-            if (e->fr) { ovhip_frame_destroy(e->fr); e->fr = NULL; e->rec = NULL; }
-            return;
-        }
-    }
     int r = dpb_get(e);
     if (r != OVHIP_OK) { latch(e, r, "ovhip_dpb_create (the HIP back-end has no CPU fallback)"); return; }
     if (e->fr && (e->pic_w != (int)f->width || e->pic_h != (int)f->height)) { ovhip_frame_destroy(e->fr); e->fr = NULL; e->rec = NULL; }

@@ -10,7 +10,7 @@ import pipe_cases
 from openvvc_amd import capi, engine
 
 pytestmark = pytest.mark.gpu
-STREAMS = ("pipe", "pipe_b")
+STREAMS = ("pipe", "pipe_b", "tiles", "tiles_b")       # tiles*: every picture cut into 2 x 2 rect entries (test_pipe_cpu.py)
 
 
 def _load(rec, lib, wl):

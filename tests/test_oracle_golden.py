@@ -210,8 +210,8 @@ def test_fixtures_regenerate_from_the_compiled_reference(tmp_path):
     if not gen.exists() or not (root / "oracle" / "_ref" / "libovvcref.so").exists():
         pytest.skip("compiled reference not present")
     subprocess.check_call([str(gen), str(tmp_path)], stderr=subprocess.DEVNULL)
-    # shim_*: test_shim_cpu.py; pipe*: the chained streams of gen_pipe, test_pipe_cpu.py
-    names = sorted(p.name for p in (root / "tests" / "golden").glob("*.ovg") if not p.name.startswith(("shim_", "pipe")))
+    # shim_*: test_shim_cpu.py; pipe* / tiles*: the chained streams of gen_pipe, test_pipe_cpu.py
+    names = sorted(p.name for p in (root / "tests" / "golden").glob("*.ovg") if not p.name.startswith(("shim_", "pipe", "tiles")))
     assert len(names) >= 9
     for n in names:
         assert (tmp_path / n).read_bytes() == (root / "tests" / "golden" / n).read_bytes(), f"{n} differs from a fresh run of the reference"

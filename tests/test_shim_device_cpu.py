@@ -117,3 +117,43 @@ def test_dry_frames_trace_through_the_c_abi(built_lib):
     assert ops == [(capi.FE_BEGIN, 0x10), (capi.FE_BEGIN, 0x20), (capi.FE_REF, 0x10), (capi.FE_DMVR_BEGIN, 0x20), (capi.FE_DMVR_COLLECT, 0x20),
                    (capi.FE_SUBMIT, 0x10), (capi.FE_SUBMIT, 0x20)]
     assert log[1]["frame"] == log[0]["frame"] + 1 and any(e[0] == "copy" for e in mem.log), "the reference went to device 1"
+
+
+@pytest.mark.parametrize("name", ("tiles", "tiles_b"))
+def test_rect_entries_of_a_picture_share_one_device_job(built_lib, name):
+    """Tiles (slicedec.c:636-657; one entry after the other on one OVCTUDec, :649-653): rcn_attach_frame_buff runs once per rect
+    entry, the device picture is begun ONCE (in the first entry's attach) and submitted ONCE -- in the alf line hook of the last row
+    of the picture's LAST entry (ovthreads.c:93-114: the last entry to finish ends the picture); the eager DMVR passes run under the
+    row hooks of every entry."""
+    P = pipe_cases.Pipe(name)
+    ev = events(name)
+    begins = [i for i, e in enumerate(ev) if e["op"] == capi.FE_BEGIN]
+    assert len(begins) == P.n
+    bounds = [b - 1 for b in begins] + [len(ev)]                           # (the BEGIN sits inside its ATTACH hook)
+    rows_of_entry = (2, 2, 2, 2) if name == "tiles" else (1, 1, 1, 1)
+    for k in range(P.n):
+        pe = ev[bounds[k]:bounds[k + 1]]
+        ops = [int(e["op"]) for e in pe]
+        assert ops.count(ATTACH) == 4 and ops[0] == ATTACH and ops[1] == capi.FE_BEGIN and int(pe[1]["key"]) == k
+        assert ops.count(capi.FE_BEGIN) == 1 and ops.count(capi.FE_SUBMIT) == 1 and ops.count(capi.FE_FAIL) == 0
+        # per entry: attach, first_pix_rows(0), alf lines 0 .. rows - 1 (entry-local rows)
+        hooks = [(int(e["op"]), int(e["a"])) for e in pe if e["op"] in (ATTACH, SAO_FIRST, ALF_LINE)]
+        want = []
+        for r in rows_of_entry:
+            want += [(ATTACH, hooks[len(want)][1]), (SAO_FIRST, 0)] + [(ALF_LINE, y) for y in range(r)]
+        assert hooks == want
+        # the submit: inside the very last hook of the picture, with every refined unit through the eager passes
+        depth, last_hook, n_hook = 0, None, 0
+        for e in pe:
+            op = int(e["op"])
+            if op in (ATTACH, SAO_FIRST, ALF_LINE):
+                depth += 1; n_hook += 1; last_hook = n_hook
+            elif op == HOOK_END:
+                depth -= 1
+            elif op == capi.FE_SUBMIT:
+                assert depth == 1 and last_hook == len(hooks) and int(e["result"]) == 0
+                assert int(e["a"]) == len(P.s.case(k)["mcx"])
+            elif op in (capi.FE_DMVR_BEGIN, capi.FE_DMVR_COLLECT):
+                assert depth == 1
+        refs = pe[[o == capi.FE_REF for o in ops]]
+        assert [int(r["key"]) for r in refs] == P.ref_indices(k)
