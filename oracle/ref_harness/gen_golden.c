@@ -1527,9 +1527,10 @@ gen_sao(const char *dir)
         fprintf(stderr, "sao.ovg: picture %d %dx%d (%d CTUs)\n", pi, W, H, nx * ny);
     }
     if (g_shim) {
-        /* a picture cut into TWO rect entries (tile columns: ovthreads.c:112-114 hands each entry to its own OVCTUDec), record-only:
-         * the shim keeps one recorder per OVCTUDec and would flush each entry as if it were the picture, so it has to latch
-         * OVHIP_EUNSUP at the first slot that sees the entry's geometry -- and keep it latched for the second entry's decoder */
+        /* a picture cut into TWO rect entries (tile columns) with each entry on its OWN OVCTUDec (entry threads: ovthreads.c:112-114),
+         * record-only: the shim keeps one recorder per OVCTUDec.  The entry that starts the picture is taken; the one whose
+         * OVCTUDec never saw the picture's first entry has nobody to record into and must latch OVHIP_EUNSUP at its attach (the
+         * entries of a picture in turn on ONE OVCTUDec are the supported form: gen_pipe's tiles streams). */
         const int W = 384, H = 136, nx = 3, ny = 2;
         int32_t codes[2];
         for (int en = 0; en < 2; ++en) {
@@ -1545,13 +1546,14 @@ gen_sao(const char *dir)
             memset(&einfo, 0, sizeof(einfo));
             einfo.ctb_x = en ? 2 : 0; einfo.nb_ctu_w = en ? 1 : 2; einfo.nb_ctu_h = ny;
             c->ctb_y = 0;
+            c->rcn_funcs.rcn_attach_frame_buff(&c->rcn_ctx, f, &einfo, 7);
             c->rcn_funcs.sao.rcn_sao_first_pix_rows(c, &einfo, 0);
             codes[en] = ovhip_shim_last_error(c);
-            if (codes[en] != OVHIP_EUNSUP) { fprintf(stderr, "shim: entry %d of a two-entry picture was not refused (code %d)\n", en, codes[en]); exit(1); }
+            if (codes[en] != (en ? OVHIP_EUNSUP : 0)) { fprintf(stderr, "shim: entry %d of a two-OVCTUDec picture: code %d\n", en, codes[en]); exit(1); }
         }
         uint32_t d1 = 2;
         gfile_array(&g, "two_entries_latched", T_I32, codes, 1, &d1);
-        fprintf(stderr, "shim_sao.ovg: two rect entries refused (%d, %d)\n", codes[0], codes[1]);
+        fprintf(stderr, "shim_sao.ovg: two rect entries on two OVCTUDecs: first taken, second refused (%d, %d)\n", codes[0], codes[1]);
     }
     gfile_close(&g);
 }

@@ -1010,6 +1010,7 @@ params_alloc(struct hip_entry *e, const OVCTUDec *c, const struct RectEntryInfo 
         return -1;
     }
     e->log2_ctu = l2; e->nb_ctu_w = nw; e->nb_ctu_h = nh;
+    e->whole_pic_entry = !einfo->ctb_x && !einfo->ctb_y && einfo->nb_ctu_w == nw && einfo->nb_ctu_h == nh;
     if (e->n_ctu != (size_t)nw * nh) {
         free(e->sao); free(e->alf);
         e->n_ctu = (size_t)nw * nh;

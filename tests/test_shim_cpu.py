@@ -251,12 +251,13 @@ def test_shim_filter_slots_match_reference(built_lib):
             assert ga[f"p{i}_{k}"].tobytes() == gr[f"p{i}_{k}"].tobytes(), f"alf picture {i} {k}"
 
 
-def test_shim_refuses_a_picture_of_two_rect_entries(built_lib):
-    """A picture cut into two rect entries (tile columns; the reference gives each entry its own OVCTUDec, ovthreads.c:112-114) is
-    refused by the installed slots: the harness drove `sao.rcn_sao_first_pix_rows` with the einfo of each entry (record-only) and
-    stored what `ovhip_shim_last_error` latched -- OVHIP_EUNSUP for both, not a half-picture flush."""
+def test_shim_refuses_rect_entries_spread_over_two_ctu_decoders(built_lib):
+    """A picture cut into two rect entries (tile columns) with each entry on its OWN OVCTUDec (entry threads, ovthreads.c:112-114):
+    the harness attached the frame and drove `sao.rcn_sao_first_pix_rows` with each entry's einfo (record-only) and stored what
+    `ovhip_shim_last_error` latched.  The entry that starts the picture is taken; the OVCTUDec that never saw the picture's first
+    entry latches OVHIP_EUNSUP -- not a half-picture flush.  (Entries in turn on one OVCTUDec: tests/test_pipe_cpu.py, tiles.)"""
     g = golden_io.load("shim_sao.ovg")
-    assert [int(v) for v in g["two_entries_latched"]] == [capi.OVHIP_EUNSUP, capi.OVHIP_EUNSUP]
+    assert [int(v) for v in g["two_entries_latched"]] == [0, capi.OVHIP_EUNSUP]
 
 
 def intra_ctu_cases():
