@@ -563,6 +563,13 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
         }
     if (pr->before_launch && pr->before_launch(pr->before_launch_user))
         return ov_fail(ctx, OVHIP_EINVAL, "ovhip_job_flush: before_launch callback failed", hipSuccess);
+#ifdef OVHIP_TUNING
+    static const int X_H2D_HOSTWAIT = getenv("OVHIP_X_H2D_HOSTWAIT") ? atoi(getenv("OVHIP_X_H2D_HOSTWAIT")) : 0;
+    static const int X_MV_D2H = getenv("OVHIP_X_MV_D2H") ? atoi(getenv("OVHIP_X_MV_D2H")) : 1;       // 0: skipped, 1: on the main stream, 2: on a side stream
+    if (X_H2D_HOSTWAIT && !j->resident) OV_HIP(ctx, hipEventSynchronize(j->ev_h2d));
+#else
+    const int X_MV_D2H = 1;
+#endif
     const double t_flush3 = host_now_us();
     j->st.host_us_prepare = (uint32_t)(t_flush1 - t_flush0); j->st.host_us_upload = (uint32_t)(t_flush2 - t_flush1);
     j->st.host_us_wait = (uint32_t)(t_flush3 - t_flush2);
@@ -584,9 +591,11 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
                                   (const int32_t *)DEV(B_SIDE), d_fwd));
             j->st.n_launches++;
         }
-        if (n_mcx && !j->resident) {
+        if (n_mcx && !j->resident && X_MV_D2H) {
             // refined vectors back to the host as early as the stream allows (the decoder's TMVP field needs them)
+            if (X_MV_D2H == 2) CHK(ovhip_ctx_fork(ctx, 1));
             OV_HIP(ctx, hipMemcpyAsync(j->mv_host, j->dev[B_MV].p, n_mcx * 16, hipMemcpyDeviceToHost, ctx->stream));
+            if (X_MV_D2H == 2) CHK(ovhip_ctx_fork(ctx, 0));
             j->st.d2h_bytes += n_mcx * 16;
         }
         j->n_mv = n_mcx;
@@ -782,6 +791,7 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
     } else if (sao_on) {
         CHK(copy_pic(ctx, dst, &j->tmp));
     }
+    if (X_MV_D2H == 2) CHK(ovhip_ctx_join(ctx));
     OV_HIP(ctx, hipEventRecord(j->ev_done, ctx->stream));
     j->flushed = 1;
     j->st.host_us_launch = (uint32_t)(host_now_us() - t_flush3);
