@@ -116,6 +116,9 @@ def main():
                     help="skip the one-picture-in-flight survey and the variants: every launch of the process then runs in the timed configuration "
                          "(what tools/profile_round.sh traces, so that rocprofv3's per-kernel averages are of that configuration)")
     ap.add_argument("--in-flight", type=int, default=16, help="frame threads (= pictures in flight) per device: pthreads of the C stream driver, one HIP stream each")
+    ap.add_argument("--priority-readers", type=int, default=0, help="> 0: pictures referenced by at least this many later pictures run on a high-priority stream")
+    ap.add_argument("--leaf-low", type=int, default=0, help="1: pictures nobody references run on a low-priority stream")
+    ap.add_argument("--exec-slots", type=int, default=0, help="execution gate of the device DPB: pictures per device between 'references done' and 'complete' at a time, oldest first (0: no gate)")
     ap.add_argument("--contents", type=int, default=2, help="distinct recorded B pictures (seeds)")
     ap.add_argument("--intra-frac", type=float, default=0.12, help="share of intra CUs in the B pictures")
     ap.add_argument("--gop", type=int, default=32, help="GOP size (hierarchical B, JVET random-access decoding order)")
@@ -203,6 +206,8 @@ def main():
     # ---- library objects: device DPB, pre-recorded jobs (R GOPs of stream positions, + the I / key pictures), stream drivers ----
     ctx0 = engine.Context(hip_devices[0])
     dpb = engine.Dpb(tuple(hip_devices))
+    if args.exec_slots:
+        dpb.lib.ovhip_dpb_set_exec_slots(dpb.h, args.exec_slots)
     # (with several devices each may sit on a GOP of its own: a job shared by two GOPs that are in flight at once could be held by the
     # later one while the earlier one, which it waits for through the key pictures, needs it)
     R = max(2, args.job_rotation, L + 2)
@@ -280,7 +285,8 @@ def main():
         return engine.Stream(dpb, W, H, contents, jobs if use_jobs else [], threads_per_device=threads, flags=flags, output=OUT[output],
                              extra_stages=lv, rank=rank, xfer=xfer, intra_lookahead=(lookahead if ahead is None else ahead) if threads > 1 else 0,
                              intra_stream_priority=args.intra_priority, ahead_chunk_items=args.ahead_chunk,
-                             ahead_own_queue=args.ahead_own_queue if threads > 1 else 0)
+                             ahead_own_queue=args.ahead_own_queue if threads > 1 else 0,
+                             priority_readers=args.priority_readers, leaf_low=args.leaf_low)
 
     # ---- multi-process exchange: the driver's comm thread calls back here, one call per transferred picture ----
     xfer = None
@@ -380,11 +386,16 @@ def main():
         for j in jobs:
             j.time_stage(name)
 
+    last_ipic_time = [None]
+
     def read_timer():
-        tot, cnt = 0.0, 0
-        for j in jobs:
+        tot, cnt, itot, icnt = 0.0, 0, 0.0, 0
+        for k, j in enumerate(jobs):
             s, n = j.stage_time()
             tot += s; cnt += n
+            if k % JPD >= n_jobs:                     # the I pictures' jobs
+                itot += s; icnt += n
+        last_ipic_time[0] = itot / icnt if icnt else None
         return tot / max(cnt, 1)
 
     # ---- untimed survey IN THE TIMED CONFIGURATION (same jobs, same pictures in flight): each launch group bracketed in turn
@@ -404,6 +415,7 @@ def main():
     dom = max(kern, key=kern.get)
     stream_dom = max((k for k in kern if k != "intra"), key=kern.get)
     isolated = {}
+    ipic_isolated_s = None
     variants = {}
     if not args.no_isolated_survey:
         # the same groups with ONE picture in flight: what a launch takes when it has the device to itself
@@ -414,6 +426,8 @@ def main():
             set_timer(name)
             r1, _ = st_one.run(larr, NL, 0, 1 + 2 * G, flags=0)
             isolated[name] = read_timer()
+            if name == "intra":
+                ipic_isolated_s = last_ipic_time[0]
         set_timer(None)
         st_one.close()
     if world > 1:
@@ -469,6 +483,8 @@ def main():
         dt = time.perf_counter() - t0
         if args.trace:
             np.save(args.trace, np.concatenate([trace, np.array([[len(tspics[n_warm + i]["refs"]), tspics[n_warm + i]["poc"], n_warm + i, 0] for i in range(len(trace))], float)], axis=1))
+            # + the reference pictures (indices in decoding order, -1 padded): tools/debug/dep_latency.py
+            np.save(args.trace + ".refs.npy", np.array([(list(tspics[n_warm + i]["refs"]) + [-1] * 8)[:8] for i in range(len(trace))], np.int64))
         # the rate of every step of the timed region (publication times of the driver's timeline; tools/debug/step_rates.py)
         pub = np.sort(trace[:, 2])
         edges = pub[PPS * L - 1::PPS * L][:args.steps]
@@ -677,7 +693,8 @@ def main():
                     "isolated_launch_us": {k: round(v * 1e6, 2) for k, v in isolated.items()},
                     "frac_isolated_per_kernel": {k: round(alg[k] / isolated[k] / 1e9 / HBM_PEAK_GBPS, 5) for k in alg if k in isolated and isolated[k] > 0},
                     "ordered_pass": ({"levels_per_i_picture": int(wls[-1].stats["n_ilevels"]), "levels_per_b_picture": int(wls[0].stats["n_ilevels"]),
-                                      "us_per_level_i_picture_isolated": None} if "intra" in kern else None),
+                                      "us_per_level_i_picture_isolated": round(ipic_isolated_s * 1e6 / max(1, int(wls[-1].stats["n_ilevels"])), 3) if ipic_isolated_s else None,
+                                      "i_picture_pass_isolated_us": round(ipic_isolated_s * 1e6, 1) if ipic_isolated_s else None} if "intra" in kern else None),
                     "algorithmic_bytes": {k: int(v) for k, v in alg.items()},
                     "frame_frac": round(sum(alg.values()) * fps / max(world, L) / 1e9 / HBM_PEAK_GBPS, 5),
                     # SURVEY 8(d) as written: B_frame = (r_bar + 7) S + C, C = coefficients + commands consumed (the sum above also counts
@@ -776,7 +793,7 @@ def main():
                        "dpb": {"device_pictures_allocated": int(dpb_stats.n_alloc), "begun": int(dpb_stats.n_begin), "recycled": int(dpb_stats.n_recycled),
                                "peer_copies": int(dpb_stats.n_copies), "waits_for_a_reference": int(dpb_stats.n_waits)},
                        "numa_binding": numa,
-                       "pictures_in_flight_per_gpu": S, "host_threads": S + (1 if lookahead else 0), "local_devices": L,
+                       "pictures_in_flight_per_gpu": S, "execution_slots_per_gpu": args.exec_slots or None, "host_threads": S + (1 if lookahead else 0), "local_devices": L,
                        "intra_lookahead_pictures": lookahead,
                        "lookahead_thread_hw_queue": {"streams_replaced": q_moved, "in_order_streams_still_sharing_it": q_sharing} if lookahead else None,
                        "picture_assignment": "decoding order; a free frame thread (pthread, own HIP stream) takes the next picture of its device",

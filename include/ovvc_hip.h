@@ -669,6 +669,9 @@ int  ovhip_abi_version(void);
 int  ovhip_ctx_create(ovhip_ctx **out, int device, void *stream);
 /* stream == NULL: a new stream of the given priority (0: default; the runtime clamps to its range) */
 int  ovhip_ctx_create_prio(ovhip_ctx **out, int device, int stream_priority);
+/* from here on the context's launches go to a stream of another priority (level < 0 high, 0 the context's own, > 0 low); waits for
+ * what is enqueued first: to be called between pictures */
+int  ovhip_ctx_use_priority(ovhip_ctx *ctx, int level);
 void ovhip_ctx_destroy(ovhip_ctx *ctx);
 /* 1 if the streams of the two (idle) contexts are served by the same hardware queue, 0 if not (measured: ~2 ms), < 0 error; and a
  * fresh stream for a context whose stream is in the wrong company (see ovvc_engine.hip) */
@@ -1082,6 +1085,12 @@ int  ovhip_dpb_release(ovhip_dpb *d, const void *key);
 int  ovhip_dpb_lookup(ovhip_dpb *d, const void *key, int *home_dev, ovhip_pic *pic);
 /* Wakes every waiter with OVHIP_EREF and makes every later wait fail at once (decoder teardown after an error). */
 void ovhip_dpb_shutdown(ovhip_dpb *d);
+/* Execution gate (0 = off, default): at most `slots` pictures per device between "reference pictures done" and "complete"; of the
+ * pictures waiting at the gate the one begun first goes first.  Frame threads can then hold MORE pictures than the device should
+ * run at once -- their uploads and reference waits happen early, off the critical path of the pictures others wait for -- which is
+ * what frame threads that parse are for in the reference (ovdec.c:188-248: a sub-decoder holds its picture through parse and
+ * reconstruction).  Pictures without reference pictures do not take a slot.  ovhip_frame_submit enters and leaves. */
+void ovhip_dpb_set_exec_slots(ovhip_dpb *d, int slots);
 int  ovhip_dpb_get_stats(ovhip_dpb *d, ovhip_dpb_stats *out);
 
 /* ------------------------------------------------------------------------------------
@@ -1247,6 +1256,11 @@ typedef struct ovhip_stream_cfg {
     int32_t ahead_chunk_items;             /* > 0: its pictures' ordered pass in paced launches of this many items (ovhip_job_params.flow_paced) */
     int32_t ahead_own_queue;               /* != 0: at creation, streams of in-order threads that share that thread's hardware queue are replaced
                                             * until none does (ovhip_ctx_shares_queue; ~2 ms per probe)                                     */
+    /* Stream priorities by a picture's place in the dependency graph (ovhip_ctx_use_priority).  priority_readers > 0: a picture that
+     * at least this many later pictures of the stream reference runs on a high-priority stream -- the low temporal layers of a
+     * random-access GOP, which everything else waits for; leaf_low != 0: a picture nobody references runs on a low-priority one. */
+    int32_t priority_readers;
+    int32_t leaf_low;
 } ovhip_stream_cfg;
 
 typedef struct ovhip_stream_result {

@@ -278,9 +278,10 @@ extern "C" int ovhip_pic_digest(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhi
     if (!nb) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_pic_digest: bad picture / window", hipSuccess);
     int r = ov_scratch(ctx, nb * 16, nb * 16);
     if (r) return r;
-    uint8_t *d = (uint8_t *)ctx->scratch_d, *hbuf = (uint8_t *)ctx->scratch_h;
-    r = ovhip_output_tree_md5_launch(ctx, pic, win, d);
-    if (!r && hipMemcpyAsync(hbuf, d, nb * 16, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) r = ov_fail(ctx, OVHIP_ENODEV, "ovhip_pic_digest: D2H", hipGetLastError());
+    // the band digests are stored straight into page-locked host memory by the kernel (write-only, 16 bytes per band): no DMA hop
+    // between the kernel and the host's wait
+    uint8_t *hbuf = (uint8_t *)ctx->scratch_h;
+    r = ovhip_output_tree_md5_launch(ctx, pic, win, hbuf);
     if (!r && hipStreamSynchronize(ctx->stream) != hipSuccess) r = ov_fail(ctx, OVHIP_ELAUNCH, "ovhip_pic_digest", hipGetLastError());
     if (!r) { ovhip_md5_state st; ovhip_md5_init(&st); ovhip_md5_update(&st, hbuf, nb * 16); ovhip_md5_final(&st, out); }
     return r;

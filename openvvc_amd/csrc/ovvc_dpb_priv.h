@@ -9,6 +9,9 @@ extern "C" {
 int  ovhip_dpb_hip_ops_(const int *devices, int n_devices, ovhip_dpb_ops *ops, void **user);
 void ovhip_dpb_hip_ops_free_(void *user);
 void ovhip_dpb_rearm_(ovhip_dpb *d);
+/* the execution gate (ovhip_dpb_set_exec_slots): 1 = a slot was taken (ovhip_dpb_exec_leave gives it back), 0 = no gate */
+int  ovhip_dpb_exec_enter(ovhip_dpb *d, const void *key, int dev);
+void ovhip_dpb_exec_leave(ovhip_dpb *d, int dev);
 #ifdef __cplusplus
 }
 #endif

@@ -134,6 +134,28 @@ int ovhip_ctx_create_prio(ovhip_ctx **out, int device, int stream_priority)
     return r;
 }
 
+/* The context's launches go to a stream of another priority from here on (level < 0: high, 0: the context's own stream, > 0: low).
+ * Only between pictures: everything enqueued so far is waited for first.  A decoder raises the pictures other pictures wait for --
+ * the low temporal layers of a random-access GOP -- above the leaf pictures that fill the device beside them. */
+int ovhip_ctx_use_priority(ovhip_ctx *ctx, int level)
+{
+    if (!ctx) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
+    const int k = level < 0 ? 1 : level > 0 ? 2 : 0;
+    if (k == ctx->prio_now) return OVHIP_OK;
+    OV_HIP(ctx, hipStreamSynchronize(ctx->main_stream));
+    if (!ctx->prio_stream[0]) ctx->prio_stream[0] = ctx->main_stream;
+    if (!ctx->prio_stream[k]) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        OV_HIP(ctx, hipStreamCreateWithPriority(&ctx->prio_stream[k], hipStreamNonBlocking, k == 1 ? hi : lo));
+    }
+    if (ctx->stream == ctx->main_stream) ctx->stream = ctx->prio_stream[k];
+    ctx->main_stream = ctx->prio_stream[k];
+    ctx->prio_now = k;
+    return OVHIP_OK;
+}
+
 void ovhip_ctx_destroy(ovhip_ctx *ctx)
 {
     if (!ctx) return;
@@ -147,6 +169,12 @@ void ovhip_ctx_destroy(ovhip_ctx *ctx)
     if (ctx->scratch_d || ctx->scratch_h) (void)hipSetDevice(ctx->device);
     if (ctx->scratch_d) (void)hipFree(ctx->scratch_d);
     if (ctx->scratch_h) (void)hipHostFree(ctx->scratch_h);
+    if (ctx->prio_stream[0]) {
+        // back to the context's own stream; the streams of the other priorities are destroyed with the context
+        (void)hipStreamSynchronize(ctx->main_stream);
+        ctx->main_stream = ctx->prio_stream[0];
+        for (int k = 1; k < 3; ++k) if (ctx->prio_stream[k]) (void)hipStreamDestroy(ctx->prio_stream[k]);
+    }
     if (ctx->owns_stream) { (void)hipStreamSynchronize(ctx->main_stream); stream_put(ctx->device, ctx->main_stream); }
     if (ctx->owns_prio_stream) { (void)hipStreamSynchronize(ctx->main_stream); (void)hipStreamDestroy(ctx->main_stream); }
     free(ctx);

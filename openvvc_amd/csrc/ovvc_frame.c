@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "ovvc_hip.h"
+#include "ovvc_dpb_priv.h"
 
 #define MAX_REFS 16
 
@@ -26,6 +27,7 @@ struct ovhip_frame {
     ovhip_job *job;                       /* own job, created on first use */
     /* dry frame (a DPB on a test back-end, no device): the same state machine and the same DPB calls, nothing launched.  Its own
      * plain recorder takes the picture's commands; the eager-DMVR counters move as the device's would. */
+    int in_gate;                          /* holds one of the device's execution slots (ovhip_dpb_set_exec_slots) */
     int dry;
     ovhip_recorder *dry_rec;
     int64_t dry_pending, dry_done;
@@ -211,7 +213,16 @@ acquire_refs(ovhip_frame *f)
     return OVHIP_OK;
 }
 
-static int before_launch_cb(void *user) { return acquire_refs((ovhip_frame *)user) != OVHIP_OK; }
+static int
+before_launch_cb(void *user)
+{
+    ovhip_frame *f = (ovhip_frame *)user;
+    if (acquire_refs(f) != OVHIP_OK) return 1;
+    /* the execution gate of the device (ovhip_dpb_set_exec_slots): pictures that depend on others; a picture without references is
+     * the look-ahead thread's, started early precisely to run beside the others */
+    if (f->n_refs) f->in_gate = ovhip_dpb_exec_enter(f->dpb, f->key, f->dev) == 1;
+    return 0;
+}
 
 int64_t
 ovhip_frame_dmvr_rows(ovhip_frame *f)
@@ -305,6 +316,7 @@ ovhip_frame_submit(ovhip_frame *f, ovhip_job *job, const ovhip_pic *intra, const
         if (r != OVHIP_OK) fail(f, r, "ovhip_job_flush");
         /* ONLY the wait marks the picture complete: it may run the ordered pass a second time */
         int q = ovhip_job_wait(j);
+        if (f->in_gate) { ovhip_dpb_exec_leave(f->dpb, f->dev); f->in_gate = 0; }
         if (q != OVHIP_OK && r == OVHIP_OK) r = fail(f, q, "ovhip_job_wait");
     }
     /* a borrowed job goes back to its own context: this frame (and its context) may be destroyed before the job */

@@ -49,6 +49,7 @@ struct ovhip_job {
     int flushed;                         // ev_* recorded at least once
     const void *packed_prev[24];         // where the last full flush placed the arrays that rode in the parameter block
     int resident;                        // this flush reuses the device copies of the previous one (OVHIP_STAGE_RESIDENT)
+    hipStream_t up_stream;               // while a flush enqueues its uploads on a shared upload lane: that lane's stream
     ovhip_job_stats st;
     // optional: HIP-event bracket around ONE launch group of the flush (ovhip_job_time_stage)
     int t_stage;                         // OVHIP_TIME_* or -1
@@ -59,6 +60,24 @@ struct ovhip_job {
 static int g_flow_shift;                 // workers of a flow launch = (4 x CUs) >> g_flow_shift: grows with every launch that was abandoned
 
 namespace {
+
+// Small results that the host reads after the picture is complete (refined vectors, TMVP plane entries) leave the device from a
+// kernel that stores into page-locked host memory: a hipMemcpyAsync between two kernels of a picture's chain is a round trip
+// compute queue -> DMA engine -> compute queue with the hardware queue (shared by four pictures' streams) held at the barrier.
+__global__ __launch_bounds__(256) void k_store_host(uint4 *__restrict__ dst, const uint4 *__restrict__ src, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+int store_host(ovhip_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes)
+{
+    const size_t n = (bytes + 15) / 16;                 // (both buffers are allocated in multiples of 16 bytes)
+    if (!n) return OVHIP_OK;
+    hipLaunchKernelGGL(k_store_host, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint4 *)dst_host, (const uint4 *)src_dev, n);
+    OV_LAUNCH_CHECK(ctx, "k_store_host");
+    return OVHIP_OK;
+}
 
 void *pinned_alloc(void *user, size_t bytes)
 {
@@ -83,13 +102,37 @@ int dev_reserve(ovhip_job *j, int k, size_t bytes)
     return OVHIP_OK;
 }
 
+// Upload lanes: the pictures in flight on a device do not each copy on their own stream (16 streams copying at once get two thirds of
+// what 1-4 get out of the link, tools/micro/h2d_concurrent.py) -- a flush takes one of a few per-device copy streams for the time it
+// enqueues its copies (FIFO under the lane's mutex) and the frame thread waits for them on the host, as it does for its reference
+// pictures, before it enqueues the launches.
+struct UploadLane { hipStream_t s; pthread_mutex_t m; };
+UploadLane g_up[64][8];
+pthread_mutex_t g_up_mtx = PTHREAD_MUTEX_INITIALIZER;
+unsigned g_up_next[64];
+
+UploadLane *upload_lane(int device, int n_lanes)
+{
+    if (device < 0 || device >= 64 || n_lanes <= 0) return nullptr;
+    if (n_lanes > 8) n_lanes = 8;
+    pthread_mutex_lock(&g_up_mtx);
+    const unsigned k = g_up_next[device]++ % (unsigned)n_lanes;
+    UploadLane *l = &g_up[device][k];
+    if (!l->s) {
+        if (hipStreamCreateWithFlags(&l->s, hipStreamNonBlocking) != hipSuccess) { l->s = nullptr; l = nullptr; }
+        else pthread_mutex_init(&l->m, nullptr);
+    }
+    pthread_mutex_unlock(&g_up_mtx);
+    return l;
+}
+
 int h2d(ovhip_job *j, int k, const void *host, size_t bytes)
 {
     if (!bytes) return OVHIP_OK;
     if (j->resident) return j->dev[k].cap >= bytes ? OVHIP_OK : ov_fail(j->ctx, OVHIP_EINVAL, "resident flush before a full one", hipSuccess);
     int r = dev_reserve(j, k, bytes);
     if (r) return r;
-    OV_HIP(j->ctx, hipMemcpyAsync(j->dev[k].p, host, bytes, hipMemcpyHostToDevice, j->ctx->stream));
+    OV_HIP(j->ctx, hipMemcpyAsync(j->dev[k].p, host, bytes, hipMemcpyHostToDevice, j->up_stream ? j->up_stream : j->ctx->stream));
     j->st.h2d_bytes += bytes; j->st.n_h2d++;
     return OVHIP_OK;
 }
@@ -107,6 +150,13 @@ int pinned_reserve(ovhip_job *j, void **p, size_t *cap, size_t bytes)
 }
 
 #define CHK(x) do { int r__ = (x); if (r__ != OVHIP_OK) return r__; } while (0)
+
+#ifndef OVHIP_PACK_LIMIT
+#define OVHIP_PACK_LIMIT (128 << 10)     /* bytes: arrays up to this size ride in the staging block */
+#endif
+#ifndef OVHIP_UPLOAD_LANES
+#define OVHIP_UPLOAD_LANES 0             /* shared copy streams per device (0: every picture copies on its own stream) */
+#endif
 
 double host_now_us()
 {
@@ -355,15 +405,14 @@ int64_t ovhip_job_dmvr_rows_begin(ovhip_job *j, const ovhip_pic *refs, uint32_t 
         OV_HIP(ctx, hipMemcpyAsync(d_units, u + first, (n - first) * sizeof(ovhip_mc_unit), hipMemcpyHostToDevice, ctx->stream));
         ovhip_pic geom = j->tmp;
         CHK(ovhip_dmvr_search_launch(ctx, &geom, refs, n_refs, (const ovhip_mc_unit *)d_units, (uint32_t)(n - first), d_mv));
-        OV_HIP(ctx, hipMemcpyAsync(j->mv_host + 4 * first, d_mv, (n - first) * 16, hipMemcpyDeviceToHost, ctx->stream));
+        CHK(store_host(ctx, j->mv_host + 4 * first, d_mv, (n - first) * 16));
         if (log2_ctu_s) {
             // the same vectors as entries of the picture's collocated motion plane: what the caller patches before it publishes
             // the row (4 entries per unit, recorder order)
             ovhip_tmvp_cell *d_cells = (ovhip_tmvp_cell *)j->dev[B_TMVP].p + 4 * first;
             CHK(ovhip_tmvp_cells_launch(ctx, (const ovhip_mc_unit *)d_units, (uint32_t)(n - first), d_mv, log2_ctu_s,
                                         (j->w + (1 << log2_ctu_s) - 1) >> log2_ctu_s, d_cells));
-            OV_HIP(ctx, hipMemcpyAsync(j->tmvp_host + 4 * first, d_cells, 4 * (n - first) * sizeof(ovhip_tmvp_cell), hipMemcpyDeviceToHost,
-                                       ctx->stream));
+            CHK(store_host(ctx, j->tmvp_host + 4 * first, d_cells, 4 * (n - first) * sizeof(ovhip_tmvp_cell)));
             j->n_tmvp = 4 * n;
         }
         OV_HIP(ctx, hipEventRecord(j->ev_rows, ctx->stream));
@@ -498,10 +547,19 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
     L.cc = put(alf_on ? 2 * 4 * 8 * 2 : 0);
     L.fwd = put(pr->lmcs ? 2048 : 0);
     L.bwd = put(pr->lmcs ? 2048 : 0);
-    // every DMA has ~10 us of fixed latency on this platform (tools/micro/h2d_rate.py: 5.6 MB as one copy 107 us, as eleven
-    // 216 us): arrays below PACK_LIMIT ride in the staging block instead of getting a copy of their own
-    const size_t PACK_LIMIT = 128 << 10;
+    // Uploads are what the stream is bound by once the kernels are fast (round 4, tools/micro/h2d_concurrent.py on the GPU box: a 4K
+    // picture's 8.7 MB in 10 copies on 16 streams at once = 3600 pictures/s of DMA and nothing else; one copy ~20 us of fixed cost;
+    // 16 streams copying at once reach 31-38 GB/s where 1-4 reach 52-56).  So: arrays up to PACK_LIMIT ride in the staging block (one
+    // host memcpy each, out of the recorder's page-locked arrays), the few larger ones get a copy of their own.
+#ifdef OVHIP_TUNING
+    static const size_t PACK_LIMIT = getenv("OVHIP_X_PACK_LIMIT") ? (size_t)atol(getenv("OVHIP_X_PACK_LIMIT")) : (size_t)OVHIP_PACK_LIMIT;
+#else
+    const size_t PACK_LIMIT = OVHIP_PACK_LIMIT;
+#endif
     struct Small { const void *host; size_t bytes; int buf; size_t at; } small[] = {
+        { mc, n_mc * sizeof(*mc), B_MC, 0 }, { tb, n_tb * sizeof(*tb), B_TB, 0 }, { coef, n_coef * sizeof(*coef), B_COEF, 0 },
+        { it, n_it * sizeof(*it), B_ITASK, 0 }, { ictu, n_ictu * sizeof(*ictu), B_ICTU, 0 },
+        { j->items_host, by_flow ? n_items * sizeof(uint32_t) : 0, B_IITEM, 0 },
         { mcx, n_mcx * sizeof(*mcx), B_MCX, 0 }, { ciip, n_ciip * sizeof(*ciip), B_CIIP, 0 }, { aff, n_aff * sizeof(*aff), B_AFF, 0 },
         { side, n_side * sizeof(*side), B_SIDE, 0 }, { reg, n_reg * sizeof(*reg), B_REG, 0 },
         { ev, (stages & OVHIP_STAGE_DBF) ? n_ev * sizeof(*ev) : 0, B_EV, 0 }, { eh, (stages & OVHIP_STAGE_DBF) ? n_eh * sizeof(*eh) : 0, B_EH, 0 },
@@ -528,19 +586,25 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
 
     const double t_flush1 = host_now_us();
     // ---- H2D (asynchronous DMA out of page-locked memory, in stage order so that prediction can start early) ----
+#ifdef OVHIP_TUNING
+    static const int N_UP = getenv("OVHIP_X_UPLOAD_STREAMS") ? atoi(getenv("OVHIP_X_UPLOAD_STREAMS")) : OVHIP_UPLOAD_LANES;
+#else
+    const int N_UP = OVHIP_UPLOAD_LANES;
+#endif
+    UploadLane *lane = j->resident ? nullptr : upload_lane(ctx->device, N_UP);
+    struct LaneHold {                      // the lane is held while this flush enqueues its copies
+        ovhip_job *j; UploadLane *l;
+        LaneHold(ovhip_job *j_, UploadLane *l_) : j(j_), l(l_) { if (l) { pthread_mutex_lock(&l->m); j->up_stream = l->s; } }
+        void release() { if (l) { j->up_stream = nullptr; pthread_mutex_unlock(&l->m); l = nullptr; } }
+        ~LaneHold() { release(); }
+    } hold(j, lane);
     {
     StageTimer t_(j, OVHIP_TIME_H2D);
     CHK(h2d(j, B_PARAM, j->param_host, L.total));
-    CHK(h2d(j, B_MC, mc, n_mc * sizeof(*mc)));
     if (n_mcx) {
         CHK(dev_reserve(j, B_MV, n_mcx * 16));
         CHK(pinned_reserve(j, (void **)&j->mv_host, &j->mv_cap, n_mcx * 16));
     }
-    CHK(h2d(j, B_TB, tb, n_tb * sizeof(*tb)));
-    CHK(h2d(j, B_COEF, coef, n_coef * sizeof(*coef)));
-    CHK(h2d(j, B_ITASK, it, n_it * sizeof(*it)));
-    CHK(h2d(j, B_ICTU, ictu, n_ictu * sizeof(*ictu)));
-    if (by_flow) CHK(h2d(j, B_IITEM, j->items_host, n_items * sizeof(uint32_t)));
     if (n_reg) CHK(dev_reserve(j, B_SCALE, n_reg * 2));
     // (refined units that went through the eager per-row search are uploaded again with the rest: the list is small and
     // the full kernel repeats the search with the identical result)
@@ -553,7 +617,8 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
     // a resident replay re-uses the placement of the flush before it
     if (j->resident) memcpy(packed, j->packed_prev, sizeof(packed)); else memcpy(j->packed_prev, packed, sizeof(packed));
     auto DEV = [&](int k) -> const void * { return packed[k] ? packed[k] : j->dev[k].p; };
-    OV_HIP(ctx, hipEventRecord(j->ev_h2d, ctx->stream));
+    OV_HIP(ctx, hipEventRecord(j->ev_h2d, lane ? lane->s : ctx->stream));
+    hold.release();
     const double t_flush2 = host_now_us();
     // everything below reads or writes pictures: behind the pictures this one depends on
     for (uint32_t i = 0; i < pr->n_wait_events; ++i)
@@ -565,11 +630,13 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
         return ov_fail(ctx, OVHIP_EINVAL, "ovhip_job_flush: before_launch callback failed", hipSuccess);
 #ifdef OVHIP_TUNING
     static const int X_H2D_HOSTWAIT = getenv("OVHIP_X_H2D_HOSTWAIT") ? atoi(getenv("OVHIP_X_H2D_HOSTWAIT")) : 0;
-    static const int X_MV_D2H = getenv("OVHIP_X_MV_D2H") ? atoi(getenv("OVHIP_X_MV_D2H")) : 1;       // 0: skipped, 1: on the main stream, 2: on a side stream
+    static const int X_MV_D2H = getenv("OVHIP_X_MV_D2H") ? atoi(getenv("OVHIP_X_MV_D2H")) : 3;       // 0: skipped, 1: DMA on the picture's stream, 3: stored by a kernel
     if (X_H2D_HOSTWAIT && !j->resident) OV_HIP(ctx, hipEventSynchronize(j->ev_h2d));
 #else
-    const int X_MV_D2H = 1;
+    const int X_MV_D2H = 3;
 #endif
+    // uploads that went through a lane: nothing on this picture's stream orders the launches behind them
+    if (lane) OV_HIP(ctx, hipEventSynchronize(j->ev_h2d));
     const double t_flush3 = host_now_us();
     j->st.host_us_prepare = (uint32_t)(t_flush1 - t_flush0); j->st.host_us_upload = (uint32_t)(t_flush2 - t_flush1);
     j->st.host_us_wait = (uint32_t)(t_flush3 - t_flush2);
@@ -582,7 +649,7 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
     // ---- prediction ----
     if (stages & OVHIP_STAGE_MC) {
         { StageTimer t_(j, OVHIP_TIME_MC);
-        CHK(ovhip_mc_launch(ctx, dst, refs, n_refs, (const ovhip_mc_unit *)j->dev[B_MC].p, (uint32_t)n_mc, d_fwd, intra)); }
+        CHK(ovhip_mc_launch(ctx, dst, refs, n_refs, (const ovhip_mc_unit *)DEV(B_MC), (uint32_t)n_mc, d_fwd, intra)); }
         j->st.n_launches += n_mc != 0;
         if (n_mcx || n_aff) {
             StageTimer t_(j, OVHIP_TIME_MCXA);
@@ -593,9 +660,9 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
         }
         if (n_mcx && !j->resident && X_MV_D2H) {
             // refined vectors back to the host as early as the stream allows (the decoder's TMVP field needs them)
-            if (X_MV_D2H == 2) CHK(ovhip_ctx_fork(ctx, 1));
-            OV_HIP(ctx, hipMemcpyAsync(j->mv_host, j->dev[B_MV].p, n_mcx * 16, hipMemcpyDeviceToHost, ctx->stream));
-            if (X_MV_D2H == 2) CHK(ovhip_ctx_fork(ctx, 0));
+            // (round 4: as a DMA between k_mcxa and the residual kernels it cost the stream 7 % -- tools/x_mvd2h.sh: 2963 -> 3177 pictures/s)
+            if (X_MV_D2H == 3) CHK(store_host(ctx, j->mv_host, j->dev[B_MV].p, n_mcx * 16));
+            else OV_HIP(ctx, hipMemcpyAsync(j->mv_host, j->dev[B_MV].p, n_mcx * 16, hipMemcpyDeviceToHost, ctx->stream));
             j->st.d2h_bytes += n_mcx * 16;
         }
         j->n_mv = n_mcx;
@@ -607,7 +674,7 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
             CHK(pinned_reserve(j, (void **)&j->tmvp_host, &j->tmvp_cap, bytes));
             CHK(ovhip_tmvp_cells_launch(ctx, (const ovhip_mc_unit *)DEV(B_MCX), (uint32_t)n_mcx, (const int32_t *)j->dev[B_MV].p, log2_ctu,
                                         (j->w + (1 << log2_ctu) - 1) >> log2_ctu, (ovhip_tmvp_cell *)j->dev[B_TMVP].p));
-            OV_HIP(ctx, hipMemcpyAsync(j->tmvp_host, j->dev[B_TMVP].p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+            CHK(store_host(ctx, j->tmvp_host, j->dev[B_TMVP].p, bytes));
             j->st.n_launches++; j->st.d2h_bytes += bytes;
             j->n_tmvp = 4 * n_mcx;
         }
@@ -616,7 +683,7 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
     // ---- the flow launch of the ordered pass: state block, abort word, this picture's epoch (before the residual stage: the
     //      chroma-scale launch prepares the state words as a rider) ----
     int flow_prepared = 0;
-    const ovhip_itask *d_it_early = (const ovhip_itask *)j->dev[B_ITASK].p;
+    const ovhip_itask *d_it_early = (const ovhip_itask *)DEV(B_ITASK);
     if ((stages & OVHIP_STAGE_INTRA) && by_flow && n_items) {
         if (!j->d_flow) {
             const size_t words = ovhip_intra_flow_words(j->w, j->h);
@@ -639,8 +706,8 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
     }
     // ---- residual: luma blocks, chroma-scale derivation on the reconstructed luma, chroma blocks (+ inverse mapping) ----
     if (stages & OVHIP_STAGE_ITX) {
-        const ovhip_tb_cmd *d_tb = (const ovhip_tb_cmd *)j->dev[B_TB].p;
-        const int16_t *d_coef = (const int16_t *)j->dev[B_COEF].p;
+        const ovhip_tb_cmd *d_tb = (const ovhip_tb_cmd *)DEV(B_TB);
+        const int16_t *d_coef = (const int16_t *)DEV(B_COEF);
         if (cls[0] + cls[1]) {
             StageTimer t_(j, OVHIP_TIME_ITX_LUMA);
             if (ordered) CHK(ovhip_itx_launch_classes_res(ctx, dst, &j->res, d_tb, (uint32_t)cls[0], (uint32_t)cls[1], d_coef, nullptr));
@@ -678,7 +745,7 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
     // (a workgroup per CTU with tasks, CTU samples in LDS, neighbour CTUs chained by flags); then the inverse luma mapping ----
     if (ordered) {
         StageTimer t_(j, OVHIP_TIME_INTRA);
-        const ovhip_itask *d_it = (const ovhip_itask *)j->dev[B_ITASK].p;
+        const ovhip_itask *d_it = (const ovhip_itask *)DEV(B_ITASK);
         if (!by_level) {
             if (!j->d_sync) {
                 const size_t words = ovhip_intra_sync_words(j->w, j->h, 5);          // the smallest CTU: enough for every size
@@ -691,7 +758,7 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
                 *j->abort_host = 0;
             }
             if (++j->epoch >= 0x7ffffff0u) j->epoch = 1;
-            CHK(ovhip_intra_ctu_launch(ctx, dst, &j->res, d_it, (const ovhip_ictu *)j->dev[B_ICTU].p, (uint32_t)n_ictu,
+            CHK(ovhip_intra_ctu_launch(ctx, dst, &j->res, d_it, (const ovhip_ictu *)DEV(B_ICTU), (uint32_t)n_ictu,
                                        (const ovhip_lmcs_region *)DEV(B_REG), pr->lmcs, (int16_t *)j->dev[B_SCALE].p, log2_ctu, j->d_sync, j->epoch,
                                        j->abort_host));
             j->st.n_launches++;
@@ -739,7 +806,7 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
             while (a < n_items) {
                 size_t b = a + chunk < n_items ? a + chunk : n_items;
                 while (b < n_items && it[j->items_host[b] & 0xffffff].level == it[j->items_host[b - 1] & 0xffffff].level) ++b;
-                CHK(ovhip_intra_flow_launch(ctx, dst, &j->res, d_it, (uint32_t)n_it, (const uint32_t *)j->dev[B_IITEM].p + a, (uint32_t)(b - a),
+                CHK(ovhip_intra_flow_launch(ctx, dst, &j->res, d_it, (uint32_t)n_it, (const uint32_t *)DEV(B_IITEM) + a, (uint32_t)(b - a),
                                             (const ovhip_lmcs_region *)DEV(B_REG), pr->lmcs, (int16_t *)j->dev[B_SCALE].p, log2_ctu, j->d_flow, j->epoch,
                                             j->abort_host, first, n_workers));
                 j->st.n_launches += 1 + first;
@@ -791,7 +858,6 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
     } else if (sao_on) {
         CHK(copy_pic(ctx, dst, &j->tmp));
     }
-    if (X_MV_D2H == 2) CHK(ovhip_ctx_join(ctx));
     OV_HIP(ctx, hipEventRecord(j->ev_done, ctx->stream));
     j->flushed = 1;
     j->st.host_us_launch = (uint32_t)(host_now_us() - t_flush3);

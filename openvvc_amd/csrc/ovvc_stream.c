@@ -41,6 +41,7 @@ struct ovhip_stream {
     const ovhip_stream_pic *pics; uint32_t n_total;
     uintptr_t key_base;
     uint32_t *holds;                      /* per picture: decode / receive + local readers + output + sends still to come */
+    uint8_t *readers;                     /* per picture: later local pictures that reference it (saturating): its stream priority */
     unsigned char *alive;                 /* begun in the DPB and not released yet */
     unsigned char *begun;                 /* has entered the DPB at some point (the output / comm threads wait for that before they
                                            * ask the DPB for it: a key the DPB never saw is an error there, not a wait) */
@@ -138,7 +139,8 @@ release_stream(ovhip_stream *s)
 {
     for (uint32_t i = 0; i < s->n_total; ++i)
         if (s->alive && s->alive[i]) { s->alive[i] = 0; (void)ovhip_dpb_release(s->dpb, key_of(s, i)); }
-    free(s->holds); free(s->alive); free(s->begun); free(s->dg);
+    free(s->holds); free(s->alive); free(s->begun); free(s->dg); free(s->readers);
+    s->readers = NULL;
     s->holds = NULL; s->alive = NULL; s->begun = NULL; s->dg = NULL;
     s->key_base += (uintptr_t)s->n_total + 1;
     s->pics = NULL; s->n_total = 0;
@@ -152,7 +154,8 @@ adopt_stream(ovhip_stream *s, const ovhip_stream_pic *pics, uint32_t n_total, ui
     s->alive = (unsigned char *)calloc(n_total ? n_total : 1, 1);
     s->begun = (unsigned char *)calloc(n_total ? n_total : 1, 1);
     s->dg = (uint8_t *)calloc(n_total ? n_total : 1, 16);
-    if (!s->holds || !s->alive || !s->begun || !s->dg) return OVHIP_ENOMEM;
+    s->readers = (uint8_t *)calloc(n_total ? n_total : 1, 1);
+    if (!s->holds || !s->alive || !s->begun || !s->dg || !s->readers) return OVHIP_ENOMEM;
     for (uint32_t i = 0; i < n_total; ++i) {
         const ovhip_stream_pic *p = &pics[i];
         if (p->content >= s->n_contents || p->device >= (uint32_t)s->n_dev || p->n_refs > OVHIP_STREAM_MAX_REFS) return OVHIP_EINVAL;
@@ -161,7 +164,7 @@ adopt_stream(ovhip_stream *s, const ovhip_stream_pic *pics, uint32_t n_total, ui
         const int nr = distinct_refs(p, refs);
         for (int k = 0; k < nr; ++k) {
             if (refs[k] >= i) return OVHIP_EINVAL;                  /* decoding order: references come first */
-            if (local) s->holds[refs[k]]++;
+            if (local) { s->holds[refs[k]]++; if (s->readers[refs[k]] < 255) s->readers[refs[k]]++; }
         }
         if (local) {
             s->holds[i] += 1 + (s->cfg.output != OVHIP_OUT_NONE) + ((flags & OVHIP_STREAM_HOLD_ALL) != 0);
@@ -210,6 +213,12 @@ decode_picture(struct run_state *rs, ovhip_frame *f, uint32_t idx, int job_locke
          * the output thread only puts them in output order) */
         out.mode = ((rs->flags & OVHIP_STREAM_DIGESTS) || s->cfg.output == OVHIP_OUT_DIGEST) ? OVHIP_OUT_DIGEST : OVHIP_OUT_NONE;
         out.window = s->cfg.window;
+        if ((s->cfg.priority_readers > 0 || s->cfg.leaf_low) && p->n_refs) {
+            const int nr = s->readers[idx];
+            const int level = (s->cfg.priority_readers > 0 && nr >= s->cfg.priority_readers) ? -1 : (s->cfg.leaf_low && nr == 0) ? 1 : 0;
+            r = ovhip_ctx_use_priority(ovhip_frame_ctx(f), level);
+            if (r != OVHIP_OK) { (void)ovhip_frame_fail(f, r); run_fail(rs, r, "ovhip_ctx_use_priority", ovhip_frame_last_error(f)); goto out; }
+        }
         if (tr) tr[1] = now_s() - rs->t0;
         const double t_sub = now_s();
         r = ovhip_frame_submit(f, job, NULL, &pr, &out);

@@ -10,6 +10,7 @@ for m in normal resident; do
   rocprofv3 --kernel-trace --memory-copy-trace --stats -d $O/prof_x_$m -o x -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-reference-stream --no-isolated-survey --check 0 $extra > $O/x_$m.log 2>&1
   db=$(find $O/prof_x_$m -name "*_results.db" | head -1)
   [ -n "$db" ] && python $R/tools/rocprof_summary.py $db > $O/x_trace_$m.txt 2>&1
+  [ -n "$db" ] && python $R/tools/trace_gaps.py $db > $O/x_gaps_$m.txt 2>&1; cat $O/x_gaps_$m.txt
   tail -1 $O/x_$m.log | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$m', d['value'], d['config']['step_fps'])"
