@@ -477,12 +477,12 @@ def main():
         # (L logical devices: weak scaling -- a step is one intra period PER DEVICE, L x PPS pictures)
         barrier()
         t0 = time.perf_counter()
-        trace = np.zeros((args.steps * PPS * L, 4))
+        trace = np.zeros((args.steps * PPS * L, 8))
         res, _ = st_t.run(tarr, NT, n_warm, args.steps * PPS * L, flags=capi.STREAM_KEEP | (capi.STREAM_RESIDENT if args.debug_resident else 0), trace=trace)
         barrier()
         dt = time.perf_counter() - t0
         if args.trace:
-            np.save(args.trace, np.concatenate([trace, np.array([[len(tspics[n_warm + i]["refs"]), tspics[n_warm + i]["poc"], n_warm + i, 0] for i in range(len(trace))], float)], axis=1))
+            np.save(args.trace, np.concatenate([trace, np.array([[len(tspics[n_warm + i]["refs"]), tspics[n_warm + i]["poc"], n_warm + i, 0] for i in range(len(trace))], float)], axis=1))     # columns 8..11
             # + the reference pictures (indices in decoding order, -1 padded): tools/debug/dep_latency.py
             np.save(args.trace + ".refs.npy", np.array([(list(tspics[n_warm + i]["refs"]) + [-1] * 8)[:8] for i in range(len(trace))], np.int64))
         # the rate of every step of the timed region (publication times of the driver's timeline; tools/debug/step_rates.py)

@@ -1275,8 +1275,10 @@ typedef struct ovhip_stream_result {
     double   host_seconds[5];
     int32_t  status;                       /* 0 or the first error                                                   */
     char     error[192];
-    /* in: NULL, or room for 4 doubles per picture of the run -- seconds since the run began at which the picture was taken by a
-     * frame thread, entered ovhip_frame_submit, was published (left it), and the thread's index in the 4th (analysis of stalls) */
+    /* in: NULL, or room for 8 doubles per picture of the run -- seconds since the run began at which the picture was taken by a
+     * frame thread, entered ovhip_frame_submit, was published (left it); the thread's index; then: its reference pictures were in
+     * the thread's hands (uploads enqueued, references acquired), its launches were enqueued, ovhip_frame_submit returned (after
+     * the output); one spare (analysis of stalls: tools/debug/dep_latency.py) */
     double  *trace;
 } ovhip_stream_result;
 

@@ -12,6 +12,9 @@ void ovhip_dpb_rearm_(ovhip_dpb *d);
 /* the execution gate (ovhip_dpb_set_exec_slots): 1 = a slot was taken (ovhip_dpb_exec_leave gives it back), 0 = no gate */
 int  ovhip_dpb_exec_enter(ovhip_dpb *d, const void *key, int dev);
 void ovhip_dpb_exec_leave(ovhip_dpb *d, int dev);
+/* CLOCK_MONOTONIC seconds at which the frame's last picture was complete on the device / published (the stream driver's timeline) */
+double ovhip_frame_published_at(const ovhip_frame *f);
+double ovhip_frame_done_at(const ovhip_frame *f);
 #ifdef __cplusplus
 }
 #endif

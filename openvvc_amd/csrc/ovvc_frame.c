@@ -13,10 +13,13 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include "ovvc_hip.h"
 #include "ovvc_dpb_priv.h"
 
 #define MAX_REFS 16
+
+static double mono_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 
 struct ovhip_frame {
     ovhip_dpb *dpb;
@@ -28,6 +31,7 @@ struct ovhip_frame {
     /* dry frame (a DPB on a test back-end, no device): the same state machine and the same DPB calls, nothing launched.  Its own
      * plain recorder takes the picture's commands; the eager-DMVR counters move as the device's would. */
     int in_gate;                          /* holds one of the device's execution slots (ovhip_dpb_set_exec_slots) */
+    double done_at, published_at;         /* CLOCK_MONOTONIC seconds: ovhip_job_wait returned / the picture was published (stall analysis) */
     int dry;
     ovhip_recorder *dry_rec;
     int64_t dry_pending, dry_done;
@@ -126,6 +130,8 @@ ovhip_frame_destroy(ovhip_frame *f)
 }
 
 ovhip_ctx *ovhip_frame_ctx(ovhip_frame *f) { return f ? f->ctx : NULL; }
+double ovhip_frame_published_at(const ovhip_frame *f) { return f ? f->published_at : 0.0; }
+double ovhip_frame_done_at(const ovhip_frame *f) { return f ? f->done_at : 0.0; }
 
 ovhip_job *
 ovhip_frame_job(ovhip_frame *f)
@@ -278,6 +284,7 @@ publish(ovhip_frame *f, int status)
     if (!f->live) return OVHIP_EINVAL;
     f->live = 0;
     int r = ovhip_dpb_publish(f->dpb, f->key, status);
+    f->published_at = mono_s();
     unpin_refs(f);
     return r;
 }
@@ -316,6 +323,7 @@ ovhip_frame_submit(ovhip_frame *f, ovhip_job *job, const ovhip_pic *intra, const
         if (r != OVHIP_OK) fail(f, r, "ovhip_job_flush");
         /* ONLY the wait marks the picture complete: it may run the ordered pass a second time */
         int q = ovhip_job_wait(j);
+        f->done_at = mono_s();
         if (f->in_gate) { ovhip_dpb_exec_leave(f->dpb, f->dev); f->in_gate = 0; }
         if (q != OVHIP_OK && r == OVHIP_OK) r = fail(f, q, "ovhip_job_wait");
     }

@@ -181,7 +181,7 @@ adopt_stream(ovhip_stream *s, const ovhip_stream_pic *pics, uint32_t n_total, ui
 static void
 decode_picture(struct run_state *rs, ovhip_frame *f, uint32_t idx, int job_locked, int ahead, int thread)
 {
-    double *tr = rs->trace ? rs->trace + 4 * (size_t)(idx - rs->first) : NULL;
+    double *tr = rs->trace ? rs->trace + 8 * (size_t)(idx - rs->first) : NULL;
     if (tr) { tr[0] = now_s() - rs->t0; tr[3] = (double)thread; }
     ovhip_stream *s = rs->s;
     const ovhip_stream_pic *p = &rs->pics[idx];
@@ -223,7 +223,7 @@ decode_picture(struct run_state *rs, ovhip_frame *f, uint32_t idx, int job_locke
         const double t_sub = now_s();
         r = ovhip_frame_submit(f, job, NULL, &pr, &out);
         const double dt_sub = now_s() - t_sub;
-        if (tr) tr[2] = now_s() - rs->t0;
+        if (tr) { tr[6] = now_s() - rs->t0; tr[2] = tr[6]; }
         if (r != OVHIP_OK) { run_fail(rs, r, "ovhip_frame_submit", ovhip_frame_last_error(f)); goto out; }
         if (out.mode == OVHIP_OUT_DIGEST) {
             if (rs->digests) memcpy(rs->digests + 16 * (size_t)(idx - rs->first), out.digest, 16);
@@ -238,6 +238,12 @@ decode_picture(struct run_state *rs, ovhip_frame *f, uint32_t idx, int job_locke
             pthread_mutex_lock(&rs->mtx);
             rs->res->n_decoded++; rs->res->n_second_passes += st.n_ordered_retries;
             const double ph[4] = { 1e-6 * st.host_us_prepare, 1e-6 * st.host_us_upload, 1e-6 * st.host_us_wait, 1e-6 * st.host_us_launch };
+            if (tr) {
+                tr[4] = tr[1] + ph[0] + ph[1] + ph[2];           /* references in hand */
+                tr[5] = tr[4] + ph[3];                            /* launches enqueued */
+                tr[2] = ovhip_frame_published_at(f) - rs->t0;     /* published (before the output) */
+                tr[7] = ovhip_frame_done_at(f) - rs->t0;          /* complete on the device (ovhip_job_wait returned) */
+            }
             for (int k = 0; k < 4; ++k) rs->res->host_seconds[k] += ph[k];
             rs->res->host_seconds[4] += dt_sub - ph[0] - ph[1] - ph[2] - ph[3];      /* ovhip_job_wait, publish, output */
             pthread_mutex_unlock(&rs->mtx);

@@ -724,7 +724,7 @@ class Stream:
         return arr
 
     def run(self, arr, n_total: int, first: int, n: int, flags: int = 0, digests: bool = False, check: bool = True, trace=None):
-        """-> (capi.StreamResult, digests uint8 [n, 16] | None); trace: float64 [n, 4] filled with (taken, submit, published, thread)"""
+        """-> (capi.StreamResult, digests uint8 [n, 16] | None); trace: float64 [n, 8] filled with (taken, submit, published, thread, references in hand, launches enqueued, submit returned, complete on the device)"""
         res = capi.StreamResult()
         if trace is not None:
             res.trace = trace.ctypes.data

@@ -6,7 +6,7 @@ python tools/debug/dep_latency.py gpurun_out/trace.npy"""
 import sys
 import numpy as np
 t = np.load(sys.argv[1]); refs = np.load(sys.argv[1] + ".refs.npy")
-take, sub, pub, thr, nrefs, poc, idx = (t[:, i] for i in range(7))
+take, sub, pub, thr, inhand, launched, returned, done, nrefs, poc, idx = (t[:, i] for i in range(11))
 n = len(t)
 first = int(idx[0])
 pub_of = {int(idx[i]): pub[i] for i in range(n)}
@@ -35,3 +35,19 @@ for l in sorted(set(layer)):
     m = (layer == l) & ~I
     if m.any():
         print(f"  layer {l}: {m.sum():4d} pictures, waited for refs {100 * waited[m].mean():3.0f} %, latency after ready {1e3 * after[m].mean():.2f} ms (median {1e3 * np.median(after[m]):.2f})")
+
+# ---- where the latency after ready goes (pictures that waited for their references) ----
+m = waited & ~I
+print("pictures that waited for their references, mean ms:")
+print(f"  last reference published -> this thread has its references (wake-up)   {1e3 * (inhand - ready_refs)[m].mean():.3f}  (median {1e3 * np.median((inhand - ready_refs)[m]):.3f})")
+print(f"  -> launches enqueued                                                    {1e3 * (launched - inhand)[m].mean():.3f}")
+print(f"  -> complete on the device (ovhip_job_wait returned)                     {1e3 * (done - launched)[m].mean():.3f}  (median {1e3 * np.median((done - launched)[m]):.3f})")
+print(f"  -> published                                                            {1e3 * (pub - done)[m].mean():.3f}")
+print(f"  -> output done, thread free                                             {1e3 * (returned - pub)[m].mean():.3f}")
+m = ~waited & ~I
+if m.any():
+    print("pictures whose references were done when they were taken, mean ms:")
+    print(f"  taken -> references in hand (prepare, uploads enqueued)                 {1e3 * (inhand - take)[m].mean():.3f}")
+    print(f"  -> launches enqueued                                                    {1e3 * (launched - inhand)[m].mean():.3f}")
+    print(f"  -> complete on the device (uploads + kernels)                           {1e3 * (done - launched)[m].mean():.3f}")
+    print(f"  -> published                                                            {1e3 * (pub - done)[m].mean():.3f}")

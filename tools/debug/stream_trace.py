@@ -2,7 +2,7 @@
 import sys
 import numpy as np
 t = np.load(sys.argv[1])
-take, sub, pub, thr, nrefs, poc, idx = t[:, 0], t[:, 1], t[:, 2], t[:, 3], t[:, 4], t[:, 5], t[:, 6]
+take, sub, pub, thr, nrefs, poc, idx = t[:, 0], t[:, 1], t[:, 2], t[:, 3], t[:, 8], t[:, 9], t[:, 10]
 n = len(t)
 dur = pub - sub
 total = pub.max()

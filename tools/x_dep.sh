@@ -1,6 +1,6 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}
-for m in normal resident; do
+for m in normal; do
   extra=""; [ $m = resident ] && extra="--debug-resident"
   python $R/bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-reference-stream --no-isolated-survey --check 0 --trace $R/gpurun_out/trace_$m.npy $extra 2>/dev/null | python -c "
 import json,sys
