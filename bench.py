@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--in-flight", type=int, default=16, help="frame threads (= pictures in flight) per device: pthreads of the C stream driver, one HIP stream each")
     ap.add_argument("--priority-readers", type=int, default=0, help="> 0: pictures referenced by at least this many later pictures run on a high-priority stream")
     ap.add_argument("--leaf-low", type=int, default=0, help="1: pictures nobody references run on a low-priority stream")
+    ap.add_argument("--upload-ahead", type=int, default=16, help="uploader threads run the prepare + upload half of the next N pictures' flushes ahead of the frame threads (0: every frame thread uploads its own picture when it takes it)")
     ap.add_argument("--exec-slots", type=int, default=0, help="execution gate of the device DPB: pictures per device between 'references done' and 'complete' at a time, oldest first (0: no gate)")
     ap.add_argument("--contents", type=int, default=2, help="distinct recorded B pictures (seeds)")
     ap.add_argument("--intra-frac", type=float, default=0.12, help="share of intra CUs in the B pictures")
@@ -286,7 +287,8 @@ def main():
                              extra_stages=lv, rank=rank, xfer=xfer, intra_lookahead=(lookahead if ahead is None else ahead) if threads > 1 else 0,
                              intra_stream_priority=args.intra_priority, ahead_chunk_items=args.ahead_chunk,
                              ahead_own_queue=args.ahead_own_queue if threads > 1 else 0,
-                             priority_readers=args.priority_readers, leaf_low=args.leaf_low)
+                             priority_readers=args.priority_readers, leaf_low=args.leaf_low,
+                             upload_ahead=args.upload_ahead if use_jobs and not (flags & capi.STREAM_RECORD) else 0)
 
     # ---- multi-process exchange: the driver's comm thread calls back here, one call per transferred picture ----
     xfer = None
@@ -793,7 +795,7 @@ def main():
                        "dpb": {"device_pictures_allocated": int(dpb_stats.n_alloc), "begun": int(dpb_stats.n_begin), "recycled": int(dpb_stats.n_recycled),
                                "peer_copies": int(dpb_stats.n_copies), "waits_for_a_reference": int(dpb_stats.n_waits)},
                        "numa_binding": numa,
-                       "pictures_in_flight_per_gpu": S, "execution_slots_per_gpu": args.exec_slots or None, "host_threads": S + (1 if lookahead else 0), "local_devices": L,
+                       "pictures_in_flight_per_gpu": S, "execution_slots_per_gpu": args.exec_slots or None, "pictures_uploaded_ahead": args.upload_ahead, "host_threads": S + (1 if lookahead else 0), "local_devices": L,
                        "intra_lookahead_pictures": lookahead,
                        "lookahead_thread_hw_queue": {"streams_replaced": q_moved, "in_order_streams_still_sharing_it": q_sharing} if lookahead else None,
                        "picture_assignment": "decoding order; a free frame thread (pthread, own HIP stream) takes the next picture of its device",

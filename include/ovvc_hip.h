@@ -910,6 +910,13 @@ int  ovhip_job_bind(ovhip_job *job, ovhip_ctx *ctx);
  * caller's planar prediction for fused CIIP blends, or NULL.  All DEVICE pictures of the job's size. */
 int  ovhip_job_flush(ovhip_job *job, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs,
                      const ovhip_pic *intra, const ovhip_job_params *params);
+/* The host half of the job's next flush (class split, level sort, item list, staging block) and its uploads, NOW, on one of the
+ * device's upload lanes instead of the picture's stream.  The next ovhip_job_flush with the same stages uploads nothing: it waits
+ * for these uploads on the host just before it enqueues its launches.  Nothing of the job may be in flight and the recorder must
+ * not change until that flush.  (ovhip_stream_cfg.upload_ahead: the stream driver's uploader threads run this ahead of the frame
+ * threads, so that pictures which do not have to wait for reference pictures do not pay their upload on the path every later
+ * picture waits for.) */
+int  ovhip_job_upload_ahead(ovhip_job *job, const ovhip_job_params *params);
 /* Waits for the flush.  If the ordered pass's flow launch gave up (bounded wait of a workgroup for its inputs: the launches of
  * several pictures can starve each other of compute-unit slots), the picture is decoded a second time right here with one
  * launch per level, from the recorder's arrays: ovhip_job_params' tables and the pictures passed to ovhip_job_flush must
@@ -1261,6 +1268,9 @@ typedef struct ovhip_stream_cfg {
      * random-access GOP, which everything else waits for; leaf_low != 0: a picture nobody references runs on a low-priority one. */
     int32_t priority_readers;
     int32_t leaf_low;
+    /* > 0 (pre-recorded jobs only): two uploader threads per device run ovhip_job_upload_ahead for the pictures up to this many
+     * places ahead of the next picture a frame thread will take, in decoding order */
+    int32_t upload_ahead;
 } ovhip_stream_cfg;
 
 typedef struct ovhip_stream_result {

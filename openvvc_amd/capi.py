@@ -327,7 +327,7 @@ class StreamCfg(C.Structure):
     _fields_ = [("w", C.c_int32), ("h", C.c_int32), ("flags", C.c_uint32), ("threads_per_device", C.c_int32), ("output", C.c_int32),
                 ("window", Window), ("extra_stages", C.c_uint32), ("rank", C.c_int32), ("xfer", C.POINTER(StreamXfer)),
                 ("intra_lookahead", C.c_int32), ("intra_stream_priority", C.c_int32), ("ahead_chunk_items", C.c_int32), ("ahead_own_queue", C.c_int32),
-                ("priority_readers", C.c_int32), ("leaf_low", C.c_int32)]
+                ("priority_readers", C.c_int32), ("leaf_low", C.c_int32), ("upload_ahead", C.c_int32)]
 
 
 class StreamResult(C.Structure):
@@ -503,6 +503,7 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_dpb_shutdown": (None, [vp]),
         "ovhip_dpb_set_exec_slots": (None, [vp, C.c_int]),
         "ovhip_ctx_use_priority": (C.c_int, [vp, C.c_int]),
+        "ovhip_job_upload_ahead": (C.c_int, [vp, C.POINTER(JobParams)]),
         "ovhip_dpb_get_stats": (C.c_int, [vp, P(DpbStats)]),
         "ovhip_frame_create": (C.c_int, [vp, C.c_int, i32, i32, P(vp)]),
         "ovhip_frame_create_ex": (C.c_int, [vp, C.c_int, i32, i32, C.c_int, P(vp)]),
@@ -567,7 +568,7 @@ EXPORTED_SYMBOLS = [
     "ovhip_md5_init", "ovhip_md5_update", "ovhip_md5_final", "ovhip_tmvp_cells_launch", "ovhip_job_tmvp_cells", "ovhip_intra_flow_untag_launch", "ovhip_lmcs_inverse_untag_launch", "ovhip_lmcs_scale_prepare_launch",
     "ovhip_host_alloc", "ovhip_host_free", "ovhip_d2d", "ovhip_job_test_abort_next_flow",
     "ovhip_dpb_create", "ovhip_dpb_create_ex", "ovhip_dpb_destroy", "ovhip_dpb_n_devices", "ovhip_dpb_device", "ovhip_dpb_begin", "ovhip_dpb_want",
-    "ovhip_dpb_publish", "ovhip_dpb_acquire", "ovhip_dpb_wait_copy", "ovhip_dpb_set_unknown_key_timeout", "ovhip_dpb_unpin", "ovhip_dpb_release", "ovhip_dpb_lookup", "ovhip_dpb_shutdown", "ovhip_dpb_set_exec_slots", "ovhip_ctx_use_priority",
+    "ovhip_dpb_publish", "ovhip_dpb_acquire", "ovhip_dpb_wait_copy", "ovhip_dpb_set_unknown_key_timeout", "ovhip_dpb_unpin", "ovhip_dpb_release", "ovhip_dpb_lookup", "ovhip_dpb_shutdown", "ovhip_dpb_set_exec_slots", "ovhip_ctx_use_priority", "ovhip_job_upload_ahead",
     "ovhip_dpb_get_stats", "ovhip_dpb_begin_tag", "ovhip_dpb_want_tag", "ovhip_dpb_acquire_tag", "ovhip_frame_begin_tag", "ovhip_frame_ref_tag", "ovhip_frame_set_trace",
     "ovhip_rccl_unique_id", "ovhip_rccl_create", "ovhip_rccl_destroy", "ovhip_rccl_xfer", "ovhip_rccl_last_error", "ovhip_rccl_stats", "ovhip_rccl_self_exchange",
     "ovhip_frame_create", "ovhip_frame_create_ex", "ovhip_ctx_create_prio", "ovhip_frame_destroy", "ovhip_frame_ctx", "ovhip_frame_job", "ovhip_frame_recorder", "ovhip_frame_begin", "ovhip_frame_ref",

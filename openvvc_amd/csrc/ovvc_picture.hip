@@ -50,6 +50,14 @@ struct ovhip_job {
     const void *packed_prev[24];         // where the last full flush placed the arrays that rode in the parameter block
     int resident;                        // this flush reuses the device copies of the previous one (OVHIP_STAGE_RESIDENT)
     hipStream_t up_stream;               // while a flush enqueues its uploads on a shared upload lane: that lane's stream
+    // ovhip_job_upload_ahead: the host half of a flush (class split, level sort, item list, staging block) and its uploads were done
+    // ahead of the flush, on an upload lane; the flush restores what they produced and waits for ev_h2d on the host
+    struct {
+        int valid; uint32_t stages;
+        const ovhip_tb_cmd *tb; size_t cls[4], n_tb;
+        const ovhip_itask *it; size_t n_it, n_ictu; uint32_t n_lv; const uint32_t *lv_start; const ovhip_ictu *ictu;
+        size_t n_items; int by_flow;
+    } ahead;
     ovhip_job_stats st;
     // optional: HIP-event bracket around ONE launch group of the flush (ovhip_job_time_stage)
     int t_stage;                         // OVHIP_TIME_* or -1
@@ -258,7 +266,8 @@ int ovhip_job_begin(ovhip_job *j)
     if (!j) return OVHIP_EINVAL;
     OV_DEVICE(j->ctx);
     // the DMA engines may still be reading the recorder's arrays and the parameter staging block
-    if (j->flushed) OV_HIP(j->ctx, hipEventSynchronize(j->ev_h2d));
+    if (j->flushed || j->ahead.valid) OV_HIP(j->ctx, hipEventSynchronize(j->ev_h2d));
+    j->ahead.valid = 0;
     if (j->rows_pending) { OV_HIP(j->ctx, hipEventSynchronize(j->ev_rows)); j->rows_pending = 0; }
     ovhip_rec_reset(j->rec);
     j->dmvr_first = 0; j->n_mv = 0; j->n_tmvp = 0; j->rows_end = 0;
@@ -281,7 +290,7 @@ int ovhip_job_bind(ovhip_job *j, ovhip_ctx *ctx)
 }
 
 static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs, const ovhip_pic *intra,
-                          const ovhip_job_params *pr);
+                          const ovhip_job_params *pr, int upload_only = 0);
 
 int ovhip_job_wait(ovhip_job *j)
 {
@@ -436,7 +445,7 @@ int64_t ovhip_job_dmvr_rows(ovhip_job *j, const ovhip_pic *refs, uint32_t n_refs
 }
 
 static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs, const ovhip_pic *intra,
-                          const ovhip_job_params *pr);
+                          const ovhip_job_params *pr, int upload_only);
 
 int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs, const ovhip_pic *intra,
                     const ovhip_job_params *pr)
@@ -460,6 +469,24 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
     return r;
 }
 
+/* The host half of the next flush of this job (class split, level sort, item list, staging block) and its uploads, now: on one of
+ * the device's upload lanes, not on a picture's stream.  The next ovhip_job_flush with the same stages restores what this call
+ * produced, waits for the uploads on the host just before it enqueues its launches, and uploads nothing.  For a caller that knows
+ * which pictures come next (the stream driver's uploader threads, decoding order): the pictures that do not have to wait for
+ * reference pictures -- the low layers of a GOP, which everything else waits for -- no longer pay their upload on that path.
+ * Nothing of the job may be in flight; the recorder must not change until the flush. */
+int ovhip_job_upload_ahead(ovhip_job *j, const ovhip_job_params *pr)
+{
+    if (!j || !pr) return OVHIP_EINVAL;
+    if (j->ahead.valid) return OVHIP_OK;
+    if (j->flushed) {
+        OV_DEVICE(j->ctx);
+        hipError_t e = hipEventSynchronize(j->ev_done);          // (the device buffers of the job are free)
+        if (e != hipSuccess) return ov_fail(j->ctx, OVHIP_ELAUNCH, "ovhip_job_upload_ahead: previous flush", e);
+    }
+    return job_flush_impl(j, nullptr, nullptr, 0, nullptr, pr, 1);
+}
+
 int ovhip_job_test_abort_next_flow(ovhip_job *j)
 {
     if (!j) return OVHIP_EINVAL;
@@ -468,11 +495,11 @@ int ovhip_job_test_abort_next_flow(ovhip_job *j)
 }
 
 static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs, const ovhip_pic *intra,
-                          const ovhip_job_params *pr)
+                          const ovhip_job_params *pr, int upload_only)
 {
     ovhip_ctx *ctx = j->ctx;
     OV_DEVICE(ctx);
-    if (dst->w != j->w || dst->h != j->h) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_job_flush: picture size differs from the job's", hipSuccess);
+    if (!upload_only && (dst->w != j->w || dst->h != j->h)) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_job_flush: picture size differs from the job's", hipSuccess);
     // an eager pass nobody collected (ovhip_job_dmvr_rows_begin): its copies land in arrays this flush may re-allocate
     { const int64_t c_ = ovhip_job_dmvr_rows_collect(j); if (c_ < 0) return (int)c_; }
     const uint32_t stages = pr->stages ? pr->stages : 0xffffffffu;
@@ -484,10 +511,16 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
     const double t_flush0 = host_now_us();
     j->resident = (stages & OVHIP_STAGE_RESIDENT) && pr->stages;
     ovhip_recorder *rec = j->rec;
+    // the host half and the uploads were done ahead (ovhip_job_upload_ahead) for exactly these stages: restored, not repeated
+    const bool ahead = !upload_only && j->ahead.valid && !j->resident && j->ahead.stages == stages;
+    if (!ahead) j->ahead.valid = 0;
+    const bool no_upload = j->resident || ahead;
 
     // ---- host: class split of the transform blocks (luma first; big / small), recorder arrays ----
     size_t cls[4] = { 0, 0, 0, 0 }, n_tb = 0, n_coef = 0, n_mc = 0, n_mcx = 0, n_aff = 0, n_side = 0, n_reg = 0, n_ev = 0, n_eh = 0;
-    const ovhip_tb_cmd *tb = ovhip_rec_tb_cmds_split(rec, cls, &n_tb);
+    const ovhip_tb_cmd *tb;
+    if (ahead) { tb = j->ahead.tb; n_tb = j->ahead.n_tb; memcpy(cls, j->ahead.cls, sizeof(cls)); }
+    else tb = ovhip_rec_tb_cmds_split(rec, cls, &n_tb);
     if (!tb && n_tb) return ov_fail(ctx, OVHIP_ENOMEM, "ovhip_rec_tb_cmds_split", hipSuccess);
     const int16_t *coef = ovhip_rec_coefs(rec, &n_coef);
     const ovhip_mc_unit *mc = ovhip_rec_mc_units(rec, &n_mc);
@@ -497,17 +530,20 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
     const ovhip_lmcs_region *reg = ovhip_rec_lmcs_regions(rec, &n_reg);
     size_t n_ciip = 0;
     const ovhip_ciip_unit *ciip = ovhip_rec_ciip_units(rec, &n_ciip);
-    if (n_ciip && !intra)
+    if (n_ciip && !intra && !upload_only)
         return ov_fail(ctx, OVHIP_EUNSUP, "ovhip_job_flush: CIIP blend units recorded but no picture with their intra prediction", hipSuccess);
     // ordered tasks: grouped by CTU for the one-launch pass, or sorted by level for one launch per level
     size_t n_it = 0, n_ictu = 0; uint32_t n_lv = 0; const uint32_t *lv_start = nullptr; const ovhip_ictu *ictu = nullptr;
     const int by_ctu = pr->stages && (stages & OVHIP_STAGE_INTRA_CTU);
     int by_flow = !by_ctu && !(pr->stages && (stages & OVHIP_STAGE_INTRA_LEVELS));
     const int by_level = !by_ctu;          // the flow launch also takes the level-sorted list
-    const ovhip_itask *it = by_level ? ovhip_rec_itasks_sorted(rec, &n_it, &lv_start, &n_lv)
-                                     : ovhip_rec_itasks_by_ctu(rec, pr->log2_ctu_s ? pr->log2_ctu_s : 7, &n_it, &ictu, &n_ictu);
+    const ovhip_itask *it;
+    if (ahead) { it = j->ahead.it; n_it = j->ahead.n_it; lv_start = j->ahead.lv_start; n_lv = j->ahead.n_lv; ictu = j->ahead.ictu; n_ictu = j->ahead.n_ictu; }
+    else it = by_level ? ovhip_rec_itasks_sorted(rec, &n_it, &lv_start, &n_lv)
+                       : ovhip_rec_itasks_by_ctu(rec, pr->log2_ctu_s ? pr->log2_ctu_s : 7, &n_it, &ictu, &n_ictu);
     size_t n_items = 0;
-    if (by_flow && n_it) {
+    if (ahead) { n_items = j->ahead.n_items; by_flow = j->ahead.by_flow; }
+    else if (by_flow && n_it) {
         if (j->items_cap < 4 * n_it + 16) {
             pinned_free(nullptr, j->items_host);
             j->items_cap = 8 * n_it + 1024;
@@ -522,7 +558,7 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
     if (!(stages & OVHIP_STAGE_INTRA)) { n_it = 0; n_lv = 0; n_ictu = 0; }
     const int ordered = n_it != 0;       // a picture with an ordered pass keeps its luma in the mapped domain until the pass has run
     if (ordered && !j->res.y) CHK(ovhip_pic_alloc(ctx, j->w, j->h, &j->res));
-    if (ordered && (dst->stride_y != j->res.stride_y || dst->stride_c != j->res.stride_c))
+    if (ordered && !upload_only && (dst->stride_y != j->res.stride_y || dst->stride_c != j->res.stride_c))
         return ov_fail(ctx, OVHIP_EUNSUP, "ovhip_job_flush: pictures with ordered tasks need tight planes (stride = width)", hipSuccess);
     j->st.n_itasks = (uint32_t)n_it; j->st.n_ilevels = n_lv;
     ovhip_dbf_offsets offs;
@@ -568,7 +604,7 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
     const void *packed[24] = { nullptr };           // device address of a packed array (inside the parameter block)
     for (auto &sm : small) if (sm.bytes && sm.bytes <= PACK_LIMIT && !j->resident) sm.at = put(sm.bytes) + 1;
     L.total = o;
-    if (L.total) {
+    if (L.total && !ahead) {
         CHK(pinned_reserve(j, (void **)&j->param_host, &j->param_cap, L.total));
         char *ph = j->param_host;
         for (auto &sm : small) if (sm.at) memcpy(ph + sm.at - 1, sm.host, sm.bytes);
@@ -591,14 +627,16 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
 #else
     const int N_UP = OVHIP_UPLOAD_LANES;
 #endif
-    UploadLane *lane = j->resident ? nullptr : upload_lane(ctx->device, N_UP);
+    // (uploads ahead of the flush have no picture stream of their own: always through a lane)
+    UploadLane *lane = no_upload ? nullptr : upload_lane(ctx->device, upload_only && N_UP < 1 ? 2 : N_UP);
+    if (upload_only && !lane) return ov_fail(ctx, OVHIP_ENODEV, "ovhip_job_upload_ahead: no upload lane", hipSuccess);
     struct LaneHold {                      // the lane is held while this flush enqueues its copies
         ovhip_job *j; UploadLane *l;
         LaneHold(ovhip_job *j_, UploadLane *l_) : j(j_), l(l_) { if (l) { pthread_mutex_lock(&l->m); j->up_stream = l->s; } }
         void release() { if (l) { j->up_stream = nullptr; pthread_mutex_unlock(&l->m); l = nullptr; } }
         ~LaneHold() { release(); }
     } hold(j, lane);
-    {
+    if (!ahead) {
     StageTimer t_(j, OVHIP_TIME_H2D);
     CHK(h2d(j, B_PARAM, j->param_host, L.total));
     if (n_mcx) {
@@ -614,11 +652,19 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
         else CHK(h2d(j, sm.buf, sm.host, sm.bytes));
     }
     }
-    // a resident replay re-uses the placement of the flush before it
-    if (j->resident) memcpy(packed, j->packed_prev, sizeof(packed)); else memcpy(j->packed_prev, packed, sizeof(packed));
+    // a resident replay / a flush whose uploads ran ahead re-uses the placement of the flush (or upload) before it
+    if (no_upload) memcpy(packed, j->packed_prev, sizeof(packed)); else memcpy(j->packed_prev, packed, sizeof(packed));
     auto DEV = [&](int k) -> const void * { return packed[k] ? packed[k] : j->dev[k].p; };
-    OV_HIP(ctx, hipEventRecord(j->ev_h2d, lane ? lane->s : ctx->stream));
+    if (!ahead) OV_HIP(ctx, hipEventRecord(j->ev_h2d, lane ? lane->s : ctx->stream));
     hold.release();
+    if (upload_only) {
+        j->ahead.stages = stages;
+        j->ahead.tb = tb; j->ahead.n_tb = n_tb; memcpy(j->ahead.cls, cls, sizeof(cls));
+        j->ahead.it = it; j->ahead.n_it = n_it; j->ahead.n_ictu = n_ictu; j->ahead.n_lv = n_lv; j->ahead.lv_start = lv_start; j->ahead.ictu = ictu;
+        j->ahead.n_items = n_items; j->ahead.by_flow = by_flow;
+        j->ahead.valid = 1;
+        return OVHIP_OK;
+    }
     const double t_flush2 = host_now_us();
     // everything below reads or writes pictures: behind the pictures this one depends on
     for (uint32_t i = 0; i < pr->n_wait_events; ++i)
@@ -636,7 +682,8 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
     const int X_MV_D2H = 3;
 #endif
     // uploads that went through a lane: nothing on this picture's stream orders the launches behind them
-    if (lane) OV_HIP(ctx, hipEventSynchronize(j->ev_h2d));
+    if (lane || ahead) OV_HIP(ctx, hipEventSynchronize(j->ev_h2d));
+    j->ahead.valid = 0;
     const double t_flush3 = host_now_us();
     j->st.host_us_prepare = (uint32_t)(t_flush1 - t_flush0); j->st.host_us_upload = (uint32_t)(t_flush2 - t_flush1);
     j->st.host_us_wait = (uint32_t)(t_flush3 - t_flush2);

@@ -50,7 +50,8 @@ struct ovhip_stream {
     uint8_t *dg;                          /* OVHIP_OUT_DIGEST: the pictures' digests, computed by their frame threads (begun[idx] == 2: there) */
 };
 
-struct dev_queue { uint32_t *order; unsigned char *taken; uint32_t n, next; pthread_mutex_t take; pthread_cond_t moved; };
+struct dev_queue { uint32_t *order; unsigned char *taken; unsigned char *ahead; uint32_t n, next; pthread_mutex_t take; pthread_cond_t moved; };
+/* ahead[k]: an uploader thread has claimed position k (ovhip_stream_cfg.upload_ahead) */
 
 struct run_state {
     ovhip_stream *s;
@@ -178,6 +179,18 @@ adopt_stream(ovhip_stream *s, const ovhip_stream_pic *pics, uint32_t n_total, ui
 }
 
 /* ---------------------------------------------------------------- frame threads */
+/* the parameter block of a picture's flush (the uploader threads pass the same to ovhip_job_upload_ahead) */
+static ovhip_job_params
+picture_params(const struct run_state *rs, const ovhip_stream_content *c, int ahead)
+{
+    const ovhip_stream *s = rs->s;
+    ovhip_job_params pr = c->params;
+    pr.stages = (pr.stages ? pr.stages : STAGE_ALL) | s->cfg.extra_stages | ((rs->flags & OVHIP_STREAM_RESIDENT) ? OVHIP_STAGE_RESIDENT : 0);
+    if (pr.stages == STAGE_ALL) pr.stages = 0;
+    if (ahead && s->cfg.ahead_chunk_items) { pr.flow_chunk_items = (uint32_t)s->cfg.ahead_chunk_items; pr.flow_paced = 1; }
+    return pr;
+}
+
 static void
 decode_picture(struct run_state *rs, ovhip_frame *f, uint32_t idx, int job_locked, int ahead, int thread)
 {
@@ -203,10 +216,7 @@ decode_picture(struct run_state *rs, ovhip_frame *f, uint32_t idx, int job_locke
         if (nc < 0) { (void)ovhip_frame_fail(f, (int)nc); run_fail(rs, (int)nc, "ovhip_calllog_replay", ""); goto out; }
     }
     {
-        ovhip_job_params pr = c->params;
-        pr.stages = (pr.stages ? pr.stages : STAGE_ALL) | s->cfg.extra_stages | ((rs->flags & OVHIP_STREAM_RESIDENT) ? OVHIP_STAGE_RESIDENT : 0);
-        if (pr.stages == STAGE_ALL) pr.stages = 0;
-        if (ahead && s->cfg.ahead_chunk_items) { pr.flow_chunk_items = (uint32_t)s->cfg.ahead_chunk_items; pr.flow_paced = 1; }
+        ovhip_job_params pr = picture_params(rs, c, ahead);
         ovhip_frame_output out;
         memset(&out, 0, sizeof(out));
         /* the fingerprint is taken by the picture's own frame thread, after the picture was published (16 threads hash 16 pictures;
@@ -295,6 +305,43 @@ frame_thread(void *argp)
         }
         pthread_mutex_unlock(&q->take);
         decode_picture(rs, f, idx, locked, ahead, a->dev * s->tpd + a->t);
+    }
+    return NULL;
+}
+
+/* ---------------------------------------------------------------- uploader threads */
+/* ovhip_stream_cfg.upload_ahead: the prepare + upload half of the flushes of the pictures just ahead of the frame threads, in
+ * decoding order (ovhip_job_upload_ahead).  A picture's job is only touched while nobody holds it (trylock: a picture in flight on
+ * the same job keeps it), the frame thread that takes the picture later finds the uploads done or under way. */
+static void *
+uploader_thread(void *argp)
+{
+    struct thread_arg *a = (struct thread_arg *)argp;
+    struct run_state *rs = a->rs;
+    ovhip_stream *s = rs->s;
+    struct dev_queue *q = &rs->q[a->dev];
+    const uint32_t window = (uint32_t)s->cfg.upload_ahead;
+    for (;;) {
+        pthread_mutex_lock(&q->take);
+        uint32_t k = 0;
+        int have = 0;
+        while (!have) {
+            if (rs->abort || q->next >= q->n) break;
+            /* (position q->next itself is about to be taken: leave it to its frame thread) */
+            const uint32_t lo = q->next + 1, hi = lo + window < q->n ? lo + window : q->n;
+            for (uint32_t i = lo; i < hi && !have; ++i)
+                if (!q->taken[i] && !q->ahead[i] && rs->pics[q->order[i]].n_refs) { q->ahead[i] = 1; k = i; have = 1; }
+            if (!have) pthread_cond_wait(&q->moved, &q->take);
+        }
+        pthread_mutex_unlock(&q->take);
+        if (!have) break;
+        const ovhip_stream_pic *p = &rs->pics[q->order[k]];
+        if (pthread_mutex_trylock(&s->job_mtx[p->job])) continue;
+        if (!q->taken[k]) {
+            const ovhip_job_params pr = picture_params(rs, &s->contents[p->content], 0);
+            (void)ovhip_job_upload_ahead(s->jobs[p->job], &pr);          /* (a failure leaves the job as it was: the flush uploads) */
+        }
+        pthread_mutex_unlock(&s->job_mtx[p->job]);
     }
     return NULL;
 }
@@ -493,14 +540,16 @@ ovhip_stream_run(ovhip_stream *s, const ovhip_stream_pic *pics, uint32_t n_total
     rs.q = (struct dev_queue *)calloc((size_t)s->n_dev, sizeof(*rs.q));
     rs.out_order = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
     const int nthr = s->n_dev * s->tpd;
-    pthread_t *th = (pthread_t *)calloc((size_t)nthr + 2, sizeof(*th));
-    struct thread_arg *ta = (struct thread_arg *)calloc((size_t)nthr, sizeof(*ta));
+    const int n_up = (s->cfg.upload_ahead > 0 && !(flags & (OVHIP_STREAM_RECORD | OVHIP_STREAM_RESIDENT))) ? 2 * s->n_dev : 0;
+    pthread_t *th = (pthread_t *)calloc((size_t)nthr + 2 + (size_t)n_up, sizeof(*th));
+    struct thread_arg *ta = (struct thread_arg *)calloc((size_t)nthr + (size_t)n_up, sizeof(*ta));
     r = rs.q && rs.out_order && th && ta ? OVHIP_OK : OVHIP_ENOMEM;
     for (int k = 0; k < s->n_dev && r == OVHIP_OK; ++k) {
         pthread_mutex_init(&rs.q[k].take, NULL); pthread_cond_init(&rs.q[k].moved, NULL);
         rs.q[k].order = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
         rs.q[k].taken = (unsigned char *)calloc(n ? n : 1, 1);
-        if (!rs.q[k].order || !rs.q[k].taken) r = OVHIP_ENOMEM;
+        rs.q[k].ahead = (unsigned char *)calloc(n ? n : 1, 1);
+        if (!rs.q[k].order || !rs.q[k].taken || !rs.q[k].ahead) r = OVHIP_ENOMEM;
     }
     if (r == OVHIP_OK) {
         for (uint32_t i = first; i < first + n; ++i) {
@@ -518,6 +567,10 @@ ovhip_stream_run(ovhip_stream *s, const ovhip_stream_pic *pics, uint32_t n_total
             if (pthread_create(&th[i], NULL, frame_thread, &ta[i])) { run_fail(&rs, OVHIP_ENOMEM, "pthread_create", ""); break; }
             ++started;
         }
+        for (int i = 0; i < n_up && !rs.abort; ++i) {
+            ta[nthr + i].rs = &rs; ta[nthr + i].dev = i / 2; ta[nthr + i].t = i % 2;
+            if (!pthread_create(&th[nthr + aux], NULL, uploader_thread, &ta[nthr + i])) ++aux;
+        }
         if (rs.n_out && !rs.abort && !pthread_create(&th[nthr + aux], NULL, output_thread, &rs)) ++aux;
         if (s->cfg.xfer && !rs.abort && !pthread_create(&th[nthr + aux], NULL, comm_thread, &rs)) ++aux;
         for (int i = 0; i < started; ++i) pthread_join(th[i], NULL);
@@ -529,7 +582,7 @@ ovhip_stream_run(ovhip_stream *s, const ovhip_stream_pic *pics, uint32_t n_total
         res->status = r;
     }
     if (rs.abort) ovhip_dpb_rearm_(s->dpb);
-    for (int k = 0; rs.q && k < s->n_dev; ++k) { free(rs.q[k].order); free(rs.q[k].taken); pthread_cond_destroy(&rs.q[k].moved); pthread_mutex_destroy(&rs.q[k].take); }
+    for (int k = 0; rs.q && k < s->n_dev; ++k) { free(rs.q[k].order); free(rs.q[k].taken); free(rs.q[k].ahead); pthread_cond_destroy(&rs.q[k].moved); pthread_mutex_destroy(&rs.q[k].take); }
     free(rs.q); free(rs.out_order); free(th); free(ta);
     pthread_mutex_destroy(&rs.mtx);
     if (res->status || !(flags & OVHIP_STREAM_KEEP)) release_stream(s);
