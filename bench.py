@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--in-flight", type=int, default=16, help="frame threads (= pictures in flight) per device: pthreads of the C stream driver, one HIP stream each")
     ap.add_argument("--priority-readers", type=int, default=0, help="> 0: pictures referenced by at least this many later pictures run on a high-priority stream")
     ap.add_argument("--leaf-low", type=int, default=0, help="1: pictures nobody references run on a low-priority stream")
-    ap.add_argument("--upload-ahead", type=int, default=16, help="uploader threads run the prepare + upload half of the next N pictures' flushes ahead of the frame threads (0: every frame thread uploads its own picture when it takes it)")
+    ap.add_argument("--upload-ahead", type=int, default=0, help="uploader threads run the prepare + upload half of the next N pictures' flushes ahead of the frame threads (0: every frame thread uploads its own picture when it takes it)")
     ap.add_argument("--exec-slots", type=int, default=0, help="execution gate of the device DPB: pictures per device between 'references done' and 'complete' at a time, oldest first (0: no gate)")
     ap.add_argument("--contents", type=int, default=2, help="distinct recorded B pictures (seeds)")
     ap.add_argument("--intra-frac", type=float, default=0.12, help="share of intra CUs in the B pictures")

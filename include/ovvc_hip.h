@@ -1268,7 +1268,7 @@ typedef struct ovhip_stream_cfg {
      * random-access GOP, which everything else waits for; leaf_low != 0: a picture nobody references runs on a low-priority one. */
     int32_t priority_readers;
     int32_t leaf_low;
-    /* > 0 (pre-recorded jobs only): two uploader threads per device run ovhip_job_upload_ahead for the pictures up to this many
+    /* > 0 (pre-recorded jobs only): four uploader threads per device run ovhip_job_upload_ahead for the pictures up to this many
      * places ahead of the next picture a frame thread will take, in decoding order */
     int32_t upload_ahead;
 } ovhip_stream_cfg;

@@ -628,7 +628,7 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
     const int N_UP = OVHIP_UPLOAD_LANES;
 #endif
     // (uploads ahead of the flush have no picture stream of their own: always through a lane)
-    UploadLane *lane = no_upload ? nullptr : upload_lane(ctx->device, upload_only && N_UP < 1 ? 2 : N_UP);
+    UploadLane *lane = no_upload ? nullptr : upload_lane(ctx->device, upload_only && N_UP < 1 ? 4 : N_UP);
     if (upload_only && !lane) return ov_fail(ctx, OVHIP_ENODEV, "ovhip_job_upload_ahead: no upload lane", hipSuccess);
     struct LaneHold {                      // the lane is held while this flush enqueues its copies
         ovhip_job *j; UploadLane *l;

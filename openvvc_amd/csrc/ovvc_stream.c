@@ -23,6 +23,7 @@
 #include "ovvc_hip.h"
 #include "ovvc_dpb_priv.h"
 
+#define UPLOADERS 4                     /* uploader threads per device (ovhip_stream_cfg.upload_ahead) */
 #define STAGE_ALL (OVHIP_STAGE_MC | OVHIP_STAGE_ITX | OVHIP_STAGE_DBF | OVHIP_STAGE_SAO | OVHIP_STAGE_ALF | OVHIP_STAGE_INTRA)
 
 struct run_state;
@@ -327,8 +328,10 @@ uploader_thread(void *argp)
         int have = 0;
         while (!have) {
             if (rs->abort || q->next >= q->n) break;
-            /* (position q->next itself is about to be taken: leave it to its frame thread) */
-            const uint32_t lo = q->next + 1, hi = lo + window < q->n ? lo + window : q->n;
+            /* (the next positions are about to be taken -- six: 2 ms at 3000 pictures/s, an upload is enqueued in 0.6 -- and are left
+             * to their frame threads: a frame thread that takes a picture whose job an uploader holds waits for it with the queue
+             * locked, and every other thread with it) */
+            const uint32_t lo = q->next + 6, hi = lo + window < q->n ? lo + window : q->n;
             for (uint32_t i = lo; i < hi && !have; ++i)
                 if (!q->taken[i] && !q->ahead[i] && rs->pics[q->order[i]].n_refs) { q->ahead[i] = 1; k = i; have = 1; }
             if (!have) pthread_cond_wait(&q->moved, &q->take);
@@ -540,7 +543,8 @@ ovhip_stream_run(ovhip_stream *s, const ovhip_stream_pic *pics, uint32_t n_total
     rs.q = (struct dev_queue *)calloc((size_t)s->n_dev, sizeof(*rs.q));
     rs.out_order = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
     const int nthr = s->n_dev * s->tpd;
-    const int n_up = (s->cfg.upload_ahead > 0 && !(flags & (OVHIP_STREAM_RECORD | OVHIP_STREAM_RESIDENT))) ? 2 * s->n_dev : 0;
+    /* (one uploader prepares and enqueues ~1600 pictures/s: four per device stay ahead of 16 frame threads) */
+    const int n_up = (s->cfg.upload_ahead > 0 && !(flags & (OVHIP_STREAM_RECORD | OVHIP_STREAM_RESIDENT))) ? UPLOADERS * s->n_dev : 0;
     pthread_t *th = (pthread_t *)calloc((size_t)nthr + 2 + (size_t)n_up, sizeof(*th));
     struct thread_arg *ta = (struct thread_arg *)calloc((size_t)nthr + (size_t)n_up, sizeof(*ta));
     r = rs.q && rs.out_order && th && ta ? OVHIP_OK : OVHIP_ENOMEM;
@@ -568,7 +572,7 @@ ovhip_stream_run(ovhip_stream *s, const ovhip_stream_pic *pics, uint32_t n_total
             ++started;
         }
         for (int i = 0; i < n_up && !rs.abort; ++i) {
-            ta[nthr + i].rs = &rs; ta[nthr + i].dev = i / 2; ta[nthr + i].t = i % 2;
+            ta[nthr + i].rs = &rs; ta[nthr + i].dev = i / UPLOADERS; ta[nthr + i].t = i % UPLOADERS;
             if (!pthread_create(&th[nthr + aux], NULL, uploader_thread, &ta[nthr + i])) ++aux;
         }
         if (rs.n_out && !rs.abort && !pthread_create(&th[nthr + aux], NULL, output_thread, &rs)) ++aux;
