@@ -147,6 +147,7 @@ def main():
     ap.add_argument("--same-gpu", action="store_true")
     ap.add_argument("--both-dealings", action="store_true", help="N > 1: also measure the other dealing (config.other_dealing)")
     ap.add_argument("--record-threads", type=str, default="1,4,16,32", help="frame-thread counts of the recorded_in_run variant")
+    ap.add_argument("--debug-digests-only", action="store_true", help="debug (with --output none): the frame threads compute every picture's fingerprint, but no output thread takes them in POC order and no picture is held for it -- what of the digest mode's cost is the fingerprint, what the output order")
     ap.add_argument("--debug-resident", action="store_true", help="debug: the timed run replays the device copies of the warm-up's flushes (no H2D / D2H): for profiling what the copies cost; the line is NOT a measurement of the path")
     ap.add_argument("--trace", type=str, default="", help="debug: write the per-picture timeline of the timed region (taken / submitted / published, thread) to this file")
     ap.add_argument("--intra-lookahead", type=int, default=64,
@@ -480,7 +481,7 @@ def main():
         barrier()
         t0 = time.perf_counter()
         trace = np.zeros((args.steps * PPS * L, 8))
-        res, _ = st_t.run(tarr, NT, n_warm, args.steps * PPS * L, flags=capi.STREAM_KEEP | (capi.STREAM_RESIDENT if args.debug_resident else 0), trace=trace)
+        res, _ = st_t.run(tarr, NT, n_warm, args.steps * PPS * L, flags=capi.STREAM_KEEP | (capi.STREAM_RESIDENT if args.debug_resident else 0), trace=trace, digests=args.debug_digests_only)
         barrier()
         dt = time.perf_counter() - t0
         if args.trace:

@@ -956,12 +956,17 @@ int  ovhip_job_stage_time(ovhip_job *job, double *sum_ms, uint64_t *count);
  *
  * Digest: the reference's CI hashes the output FILE (CI/checkMD5.sh, md5sum); MD5 is a serial chain, so a whole frame
  * cannot be hashed by more than one lane, and a frame per lane of the host is ~40 ms at 4K.  Two things are offered instead:
- *   ovhip_pic_digest()           a per-picture FINGERPRINT, computed on the device, 16 bytes leaving it: a three-level MD5 tree over
- *                                the cropped frame -- leaf = MD5 of each 512-byte piece of a cropped row (the last piece of a row
- *                                shorter), row = MD5 of the row's leaf digests, band = MD5 of the digests of 8 consecutive rows of
- *                                one plane (the last band of a plane shorter), picture = MD5 of the band digests in the order Y, Cb,
- *                                Cr (that last step on the host).  Any host can recompute it from the written file with hashlib
- *                                (oracle/ovvc_oracle_output.py: picture_digest); it is NOT the md5sum of the frame.
+ *   ovhip_pic_digest()           a per-picture FINGERPRINT, computed on the device, 16 bytes leaving it: a three-level hash tree over
+ *                                the cropped frame -- leaf = mix128 of each 512-byte piece of a cropped row (the last piece of a row
+ *                                shorter), row = mix128 of the row's leaf digests, band = mix128 of the digests of 8 consecutive
+ *                                rows of one plane (the last band of a plane shorter), picture = MD5 of the band digests in the
+ *                                order Y, Cb, Cr (that last step on the host).  mix128(words, tag): four 32-bit lanes seeded with
+ *                                MD5's initial state (lane 0 xor tag), word i into lane i & 3 as h = (h ^ w) * 0x01000193 (FNV-1a),
+ *                                murmur3's 32-bit finaliser per lane, then h0 += h1, h2 += h3, h0 += h2, h1 += h0, h2 += h0,
+ *                                h3 += h0; words = two samples each, little endian; tag = samples / digests hashed.  (Until
+ *                                round 4 every level was MD5: 6.5 M vector instructions per 4K picture.)  Any host can recompute
+ *                                it from the written file (oracle/ovvc_oracle_output.py: picture_digest); it is NOT the md5sum of
+ *                                the frame and not a cryptographic hash -- a change of any one sample changes it.
  *   ovhip_md5_* over ovhip_pic_output() frames    the plain host MD5 for callers that want the FILE's md5sum from the packed frames
  *                                (ovhip_stream_run with OVHIP_OUT_PACKED + OVHIP_STREAM_FILE_MD5 does exactly that).
  * ovhip_output_row_md5_launch (one plain MD5 per cropped row, one lane each) is the building block the first version of the

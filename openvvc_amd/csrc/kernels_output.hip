@@ -138,6 +138,53 @@ __device__ __forceinline__ void md5_digests(const uint32_t *w, int nd, uint32_t 
     md5_block(h, m);
 }
 
+// ---- the tree fingerprint's own hash (include/ovvc_hip.h, "Digest"): 128 bits, four FNV-1a lanes over 32-bit words with murmur3's
+// finaliser -- a 512-byte leaf is ~300 integer operations where MD5 took ~2900 (round 4: the MD5 tree was 6.5 M vector instructions
+// per 4K picture, more than k_itx_all, and cost the stream 15 % beside `output none`).  Every step is a bijection of its lane for a
+// given word, so any change of one word changes the digest; the FILE's MD5 is a different thing (OVHIP_STREAM_FILE_MD5).
+__device__ __forceinline__ uint32_t mix_fin(uint32_t h)
+{
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+#define MIX_STEP(hj, w) (hj) = ((hj) ^ (w)) * 0x01000193u
+__device__ __forceinline__ void mix_begin(uint32_t h[4], uint32_t tag)
+{
+    h[0] = 0x67452301u ^ tag; h[1] = 0xefcdab89u; h[2] = 0x98badcfeu; h[3] = 0x10325476u;
+}
+__device__ __forceinline__ void mix_end(uint32_t h[4])
+{
+    h[0] = mix_fin(h[0]); h[1] = mix_fin(h[1]); h[2] = mix_fin(h[2]); h[3] = mix_fin(h[3]);
+    h[0] += h[1]; h[2] += h[3]; h[0] += h[2]; h[1] += h[0]; h[2] += h[0]; h[3] += h[0];
+}
+// n samples (little endian, two per word; an odd last sample alone in its word), tag = n
+__device__ __forceinline__ void mix_samples(const uint16_t *src, int n, uint32_t h[4])
+{
+    mix_begin(h, (uint32_t)n);
+    int s = 0;
+    if (((uintptr_t)src & 15) == 0) {
+        const uint4 *s128 = reinterpret_cast<const uint4 *>(src);
+        for (; s + 8 <= n; s += 8) {
+            const uint4 v = s128[s >> 3];
+            MIX_STEP(h[0], v.x); MIX_STEP(h[1], v.y); MIX_STEP(h[2], v.z); MIX_STEP(h[3], v.w);
+        }
+    } else {
+        for (; s + 8 <= n; s += 8) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) MIX_STEP(h[j], (uint32_t)src[s + 2 * j] | ((uint32_t)src[s + 2 * j + 1] << 16));
+        }
+    }
+    for (int j = 0; s < n; s += 2, ++j) MIX_STEP(h[j], (uint32_t)src[s] | (s + 1 < n ? (uint32_t)src[s + 1] << 16 : 0u));      // (s is a multiple of 8 here: word index & 3 == j)
+    mix_end(h);
+}
+// nd 16-byte digests held as words, tag = nd
+__device__ __forceinline__ void mix_digests(const uint32_t *w, int nd, uint32_t h[4])
+{
+    mix_begin(h, (uint32_t)nd);
+    for (int d = 0; d < nd; ++d) { MIX_STEP(h[0], w[4 * d]); MIX_STEP(h[1], w[4 * d + 1]); MIX_STEP(h[2], w[4 * d + 2]); MIX_STEP(h[3], w[4 * d + 3]); }
+    mix_end(h);
+}
+
 // One lane per cropped row: the row's samples are its message.  A wave reads 64 rows side by side;
 // every lane walks its own row, which stays in the L1 of the compute unit between its loads.
 __global__ __launch_bounds__(64) void k_output_row_md5(OutGeom g, uint8_t *__restrict__ digests)
@@ -151,7 +198,8 @@ __global__ __launch_bounds__(64) void k_output_row_md5(OutGeom g, uint8_t *__res
     o[0] = h[0]; o[1] = h[1]; o[2] = h[2]; o[3] = h[3];
 }
 
-// The picture's fingerprint as a three-level MD5 tree (include/ovvc_hip.h, "Digest"): MD5 is a serial chain, a whole row per lane is
+// The picture's fingerprint as a three-level hash tree (include/ovvc_hip.h, "Digest"; until round 4 every level was MD5, now only the
+// host's last one is): MD5 is a serial chain, a whole row per lane is
 // 120 chained blocks at 4K (the one-lane-per-row kernel above takes ~200 us, on every picture's stream).  Leaves = the 512-byte
 // pieces of every cropped row (8 + 1 blocks), then one digest per row over its pieces' digests (4 blocks at 4K), then one per band of
 // 8 rows (3 blocks): a 128-thread workgroup per band does all three levels through LDS -- 16 chained blocks and 540 workgroups at
@@ -173,20 +221,20 @@ __global__ __launch_bounds__(DG_NT) void k_output_tree_md5(OutGeom g, uint32_t n
     for (int i = tid; i < nrows * nseg; i += DG_NT) {
         const int r = i / nseg, k = i - r * nseg;
         uint32_t h[4];
-        md5_samples(g.src[c] + (size_t)(r0 + r) * g.stride[c] + k * DG_SEG, min(DG_SEG, w - k * DG_SEG), h);
+        mix_samples(g.src[c] + (size_t)(r0 + r) * g.stride[c] + k * DG_SEG, min(DG_SEG, w - k * DG_SEG), h);
         uint32_t *o = s_d0 + (r * DG_MAXSEG + k) * 4;
         o[0] = h[0]; o[1] = h[1]; o[2] = h[2]; o[3] = h[3];
     }
     __syncthreads();
     if (tid < nrows) {
         uint32_t h[4];
-        md5_digests(s_d0 + tid * DG_MAXSEG * 4, nseg, h);
+        mix_digests(s_d0 + tid * DG_MAXSEG * 4, nseg, h);
         s_d1[4 * tid] = h[0]; s_d1[4 * tid + 1] = h[1]; s_d1[4 * tid + 2] = h[2]; s_d1[4 * tid + 3] = h[3];
     }
     __syncthreads();
     if (tid == 0) {
         uint32_t h[4];
-        md5_digests(s_d1, nrows, h);
+        mix_digests(s_d1, nrows, h);
         uint32_t *o = reinterpret_cast<uint32_t *>(digests + (size_t)band * 16);
         o[0] = h[0]; o[1] = h[1]; o[2] = h[2]; o[3] = h[3];
     }
@@ -244,7 +292,7 @@ extern "C" int ovhip_pic_output(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhi
     uint16_t *d = (uint16_t *)ctx->scratch_d;
     r = ovhip_output_pack_launch(ctx, pic, win, d);
     if (!r && hipMemcpyAsync(host_dst, d, bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) r = ov_fail(ctx, OVHIP_ENODEV, "ovhip_pic_output: D2H", hipGetLastError());
-    if (!r && hipStreamSynchronize(ctx->stream) != hipSuccess) r = ov_fail(ctx, OVHIP_ELAUNCH, "ovhip_pic_output", hipGetLastError());
+    if (!r && ov_sync_stream(ctx) != hipSuccess) r = ov_fail(ctx, OVHIP_ELAUNCH, "ovhip_pic_output", hipGetLastError());
     return r;
 }
 
@@ -282,7 +330,7 @@ extern "C" int ovhip_pic_digest(ovhip_ctx *ctx, const ovhip_pic *pic, const ovhi
     // between the kernel and the host's wait
     uint8_t *hbuf = (uint8_t *)ctx->scratch_h;
     r = ovhip_output_tree_md5_launch(ctx, pic, win, hbuf);
-    if (!r && hipStreamSynchronize(ctx->stream) != hipSuccess) r = ov_fail(ctx, OVHIP_ELAUNCH, "ovhip_pic_digest", hipGetLastError());
+    if (!r && ov_sync_stream(ctx) != hipSuccess) r = ov_fail(ctx, OVHIP_ELAUNCH, "ovhip_pic_digest", hipGetLastError());
     if (!r) { ovhip_md5_state st; ovhip_md5_init(&st); ovhip_md5_update(&st, hbuf, nb * 16); ovhip_md5_final(&st, out); }
     return r;
 }

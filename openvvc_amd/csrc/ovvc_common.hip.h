@@ -32,6 +32,8 @@ struct ovhip_ctx {
     // synchronise the whole device every time a picture is output
     void *scratch_d; size_t scratch_d_cap;
     void *scratch_h; size_t scratch_h_cap;       // page-locked
+    hipEvent_t ev_sync;            // the synchronous conveniences wait for an event behind their last command (measured in round 4: hipStreamSynchronize from
+                                   // 16 frame threads cost the stream a fifth of its rate, an event wait nothing)
     char err[256];
 };
 
@@ -56,6 +58,17 @@ static inline int ov_fail(ovhip_ctx *ctx, int code, const char *what, hipError_t
         if (e__ != hipSuccess) return ov_fail((ctx), OVHIP_ENODEV, "hipSetDevice", e__); \
         (void)hipGetLastError();   /* the last-error slot is per thread and sticky: what OV_LAUNCH_CHECK reads must be this entry point's */ \
     } while (0)
+
+/* wait for everything enqueued on the context's current stream: an event behind the last command, waited for on the host (see
+ * ovhip_ctx.ev_sync: hipStreamSynchronize from many threads at once is what the runtime does badly) */
+static inline hipError_t ov_sync_stream(ovhip_ctx *ctx)
+{
+    hipError_t e = hipSuccess;
+    if (!ctx->ev_sync) e = hipEventCreateWithFlags(&ctx->ev_sync, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev_sync, ctx->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(ctx->ev_sync);
+    return e;
+}
 
 static inline int ov_scratch(ovhip_ctx *ctx, size_t dev_bytes, size_t host_bytes)
 {

@@ -169,6 +169,7 @@ void ovhip_ctx_destroy(ovhip_ctx *ctx)
     if (ctx->scratch_d || ctx->scratch_h) (void)hipSetDevice(ctx->device);
     if (ctx->scratch_d) (void)hipFree(ctx->scratch_d);
     if (ctx->scratch_h) (void)hipHostFree(ctx->scratch_h);
+    if (ctx->ev_sync) (void)hipEventDestroy(ctx->ev_sync);
     if (ctx->prio_stream[0]) {
         // back to the context's own stream; the streams of the other priorities are destroyed with the context
         (void)hipStreamSynchronize(ctx->main_stream);
@@ -337,7 +338,7 @@ static int copy_planes(ovhip_ctx *ctx, const ovhip_pic *pic, uint16_t *y, uint16
         if (to_device) OV_HIP(ctx, hipMemcpy2DAsync(dev[p], dpitch, host[p], hpitch, (size_t)w * 2, h, hipMemcpyHostToDevice, ctx->stream));
         else           OV_HIP(ctx, hipMemcpy2DAsync(host[p], hpitch, dev[p], dpitch, (size_t)w * 2, h, hipMemcpyDeviceToHost, ctx->stream));
     }
-    OV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    OV_HIP(ctx, ov_sync_stream(ctx));
     return OVHIP_OK;
 }
 

@@ -243,6 +243,10 @@ decode_picture(struct run_state *rs, ovhip_frame *f, uint32_t idx, int job_locke
             s->begun[idx] = 2;
             pthread_cond_broadcast(&s->begun_cnd);
             pthread_mutex_unlock(&s->begun_mtx);
+            /* the output thread needs these 16 bytes, not the picture: the picture's hold for the output ends HERE, not when its turn
+             * in output order comes (a key picture is decoded 31 pictures before it is output: held that long, the DPB ran with twice
+             * the device pictures) */
+            if (s->cfg.output == OVHIP_OUT_DIGEST) drop_hold(s, idx);
         }
         ovhip_job_stats st;
         if (ovhip_job_last_stats(job ? job : ovhip_frame_job(f), &st) == OVHIP_OK) {
@@ -367,8 +371,7 @@ output_thread(void *argp)
             if (!ok) break;
             ovhip_md5_update(&rs->md5, s->dg + 16 * (size_t)idx, 16);
             rs->res->out_bytes += 16; rs->res->out_frames++;
-            drop_hold(s, idx);
-            continue;
+            continue;                                  /* (the picture's output hold was dropped by its frame thread) */
         }
         if (wait_begun(rs, idx)) break;
         int r = ovhip_dpb_acquire(s->dpb, key_of(s, idx), p->device, &pic, NULL);
