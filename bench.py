@@ -881,7 +881,10 @@ def reference_cpu_rates(W, H, n_pics, ncpu):
         t_rec, t_parse = shim_seconds([]), shim_seconds(["null"])
         if t_rec and t_parse:
             out["parse_and_record"] = {"fps_1_thread": round(n_pics / t_rec, 2), "parse_alone_fps_1_thread": round(n_pics / t_parse, 2),
-                                       "recording_share_of_host_time": round(max(0.0, 1 - t_parse / t_rec), 3),
+                                       # (the slots have effects the parser reads back -- bS maps, DMVR vectors, LMCS state: without a recorder they
+                                       #  return at their top and the parse itself takes other paths; where "parse alone" comes out SLOWER than
+                                       #  parse + record the split is not meaningful on this host and is not reported)
+                                       "recording_share_of_host_time": round(1 - t_parse / t_rec, 3) if t_parse < t_rec else None,
                                        "what": "slicedec.c's parse (CABAC, partitioning, motion-vector derivation) with the installed shim slots recording, "
                                                "one thread, pictures/s: the rate at which ONE frame thread of a real decoder can feed the device"}
     except (OSError, ValueError, KeyError, IndexError):
