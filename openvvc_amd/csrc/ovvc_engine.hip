@@ -17,6 +17,29 @@ pthread_mutex_t g_pool_mtx = PTHREAD_MUTEX_INITIALIZER;
 hipStream_t g_pool[POOL_DEVS][POOL_CAP];
 int g_pool_n[POOL_DEVS];
 
+// Streams of another priority (ovhip_ctx_create_prio, ovhip_ctx_use_priority) are pooled too, per device and class (0 high, 1 low):
+// NEVER destroyed -- an event last recorded on a destroyed stream (a job's ev_done: jobs outlive the frames that flush them) makes
+// hipEventSynchronize fail with "operation not permitted on an event last recorded in a capturing stream".
+hipStream_t g_prio_pool[POOL_DEVS][2][64];
+int g_prio_n[POOL_DEVS][2];
+
+hipError_t prio_stream_get(int device, int cls, hipStream_t *out)
+{
+    pthread_mutex_lock(&g_pool_mtx);
+    if (device < POOL_DEVS && g_prio_n[device][cls] > 0) { *out = g_prio_pool[device][cls][--g_prio_n[device][cls]]; pthread_mutex_unlock(&g_pool_mtx); return hipSuccess; }
+    pthread_mutex_unlock(&g_pool_mtx);
+    int lo = 0, hi = 0;                                        // numerically: hi <= lo (higher priority = smaller number)
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    return hipStreamCreateWithPriority(out, hipStreamNonBlocking, cls == 0 ? hi : lo);
+}
+
+void prio_stream_put(int device, int cls, hipStream_t s)
+{
+    pthread_mutex_lock(&g_pool_mtx);
+    if (device < POOL_DEVS && g_prio_n[device][cls] < 64) g_prio_pool[device][cls][g_prio_n[device][cls]++] = s;
+    pthread_mutex_unlock(&g_pool_mtx);                         // (a full pool: the stream object is left alone, not destroyed)
+}
+
 hipError_t stream_get(int device, hipStream_t *out)
 {
     pthread_mutex_lock(&g_pool_mtx);
@@ -122,15 +145,13 @@ int ovhip_ctx_create_prio(ovhip_ctx **out, int device, int stream_priority)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return OVHIP_ENODEV;
     if (hipSetDevice(device) != hipSuccess) return OVHIP_ENODEV;
-    int lo = 0, hi = 0;                                        // numerically: hi <= lo (higher priority = smaller number)
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    const int p = stream_priority < 0 ? hi : lo;
+    const int cls = stream_priority < 0 ? 0 : 1;
     hipStream_t s = nullptr;
-    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, p) != hipSuccess) return OVHIP_ENODEV;
-    // not pooled (the pool's streams are default-priority and interchangeable): the context owns it and destroys it
+    if (prio_stream_get(device, cls, &s) != hipSuccess) return OVHIP_ENODEV;
+    // (pooled by class: the context gives it back when it is destroyed)
     int r = ovhip_ctx_create(out, device, (void *)s);
-    if (r != OVHIP_OK) (void)hipStreamDestroy(s);
-    else (*out)->owns_prio_stream = 1;
+    if (r != OVHIP_OK) prio_stream_put(device, cls, s);
+    else (*out)->owns_prio_stream = 1 + cls;
     return r;
 }
 
@@ -145,11 +166,7 @@ int ovhip_ctx_use_priority(ovhip_ctx *ctx, int level)
     if (k == ctx->prio_now) return OVHIP_OK;
     OV_HIP(ctx, hipStreamSynchronize(ctx->main_stream));
     if (!ctx->prio_stream[0]) ctx->prio_stream[0] = ctx->main_stream;
-    if (!ctx->prio_stream[k]) {
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        OV_HIP(ctx, hipStreamCreateWithPriority(&ctx->prio_stream[k], hipStreamNonBlocking, k == 1 ? hi : lo));
-    }
+    if (!ctx->prio_stream[k]) OV_HIP(ctx, prio_stream_get(ctx->device, k - 1, &ctx->prio_stream[k]));
     if (ctx->stream == ctx->main_stream) ctx->stream = ctx->prio_stream[k];
     ctx->main_stream = ctx->prio_stream[k];
     ctx->prio_now = k;
@@ -174,10 +191,10 @@ void ovhip_ctx_destroy(ovhip_ctx *ctx)
         // back to the context's own stream; the streams of the other priorities are destroyed with the context
         (void)hipStreamSynchronize(ctx->main_stream);
         ctx->main_stream = ctx->prio_stream[0];
-        for (int k = 1; k < 3; ++k) if (ctx->prio_stream[k]) (void)hipStreamDestroy(ctx->prio_stream[k]);
+        for (int k = 1; k < 3; ++k) if (ctx->prio_stream[k]) { (void)hipStreamSynchronize(ctx->prio_stream[k]); prio_stream_put(ctx->device, k - 1, ctx->prio_stream[k]); }
     }
     if (ctx->owns_stream) { (void)hipStreamSynchronize(ctx->main_stream); stream_put(ctx->device, ctx->main_stream); }
-    if (ctx->owns_prio_stream) { (void)hipStreamSynchronize(ctx->main_stream); (void)hipStreamDestroy(ctx->main_stream); }
+    if (ctx->owns_prio_stream) { (void)hipStreamSynchronize(ctx->main_stream); prio_stream_put(ctx->device, ctx->owns_prio_stream - 1, ctx->main_stream); }
     free(ctx);
 }
 

@@ -366,3 +366,35 @@ def test_uploads_ahead_of_the_frame_threads_give_the_same_pictures(built_lib):
     got = dst.download()
     assert np.array_equal(got[0], want.y) and np.array_equal(got[1], want.cb)
     [j.close() for j in jobs]; dpb.close(); ctx.close()
+
+
+def test_execution_gate_and_stream_priorities_change_nothing_but_the_schedule(built_lib):
+    """ovhip_dpb_set_exec_slots (at most N pictures of a device between "references done" and "complete", oldest first) and
+    ovhip_stream_cfg.priority_readers / leaf_low (pictures other pictures wait for on a high-priority stream, leaf pictures on a
+    low-priority one): the same pictures as the oracle's, more frame threads than slots, and the gate's slots all given back."""
+    w, h = 832, 480
+    wls = _contents(w, h, (0x266, 0x1266, 0x2266), 0x9266)
+    pics = gop.build_stream(2, 16, 32, 1)
+    spics = _stream_pics(pics, 3)
+    planes = _oracle_stream(wls, spics)
+    ctx = engine.Context(0)
+    dpb = engine.Dpb((0,))
+    jobs = _jobs_for(ctx, wls, spics, w, h)
+    for slots, readers, leaf_low in ((3, 0, 0), (0, 1, 1), (2, 2, 0)):
+        dpb.lib.ovhip_dpb_set_exec_slots(dpb.h, slots)
+        st = engine.Stream(dpb, w, h, _make_contents(wls), jobs, threads_per_device=8, priority_readers=readers, leaf_low=leaf_low)
+        arr = st.pics_array(spics)
+        for rep in range(2):
+            res, dg = st.run(arr, len(spics), 0, len(spics), flags=capi.STREAM_KEEP | capi.STREAM_HOLD_ALL, digests=True)
+            assert res.status == 0 and res.n_decoded == len(spics)
+            for i in range(len(spics)):
+                assert bytes(dg[i]) == oo.picture_digest(*planes[i]), (slots, readers, leaf_low, rep, i)
+        st.close()
+    dpb.lib.ovhip_dpb_set_exec_slots(dpb.h, 1)
+    # a gate of ONE slot still lets a whole stream through (nobody kept a slot)
+    st = engine.Stream(dpb, w, h, _make_contents(wls), jobs, threads_per_device=4)
+    res, dg = st.run(st.pics_array(spics), len(spics), 0, len(spics), flags=capi.STREAM_KEEP | capi.STREAM_HOLD_ALL, digests=True)
+    assert res.status == 0 and bytes(dg[-1]) == oo.picture_digest(*planes[-1])
+    st.close()
+    dpb.lib.ovhip_dpb_set_exec_slots(dpb.h, 0)
+    [j.close() for j in jobs]; dpb.close(); ctx.close()
