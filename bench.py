@@ -154,6 +154,7 @@ def main():
                     help="pictures: one more frame thread per device starts pictures WITHOUT reference pictures (I pictures) up to this many pictures "
                          "before their turn in decoding order (0: strictly in order)")
     ap.add_argument("--ipic-workers", type=int, default=0, help="persistent workers of an I picture's ordered pass (0: the library's default, 4 x compute units)")
+    ap.add_argument("--bpic-workers", type=int, default=0, help="persistent workers of a B picture's ordered pass (0: the library's default)")
     ap.add_argument("--intra-priority", type=int, default=0, help="HIP stream priority of that thread (0 default, -1 high, 1 low)")
     ap.add_argument("--ahead-own-queue", type=int, default=1, help="1: the look-ahead thread's stream gets a hardware queue no in-order thread's stream shares (probed at start)")
     ap.add_argument("--ahead-chunk", type=int, default=0, help="ordered pass of the pictures that thread starts early: paced launches of this many items (0: as every picture)")
@@ -228,7 +229,7 @@ def main():
 
     # the I picture's ordered pass has ~100 items per level: --ipic-workers persistent workers instead of the default 4 x CUs leave the wave
     # slots, registers and LDS of the others to the B pictures' kernels beside it for the 5 ms it runs
-    contents = [{"params": params_of(wl, args.ipic_workers if i == len(wls) - 1 else 0), "calllog": wl.calllog, "n_ref_slots": len(wl.refs)} for i, wl in enumerate(wls)]
+    contents = [{"params": params_of(wl, args.ipic_workers if i == len(wls) - 1 else args.bpic_workers), "calllog": wl.calllog, "n_ref_slots": len(wl.refs)} for i, wl in enumerate(wls)]
     lv = capi.STAGE_INTRA_CTU if args.intra_ctu else (capi.STAGE_INTRA_LEVELS if args.intra_levels else 0)
 
     def content_of(p):

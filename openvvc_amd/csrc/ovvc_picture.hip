@@ -65,7 +65,7 @@ struct ovhip_job {
     double t_sum_ms; uint64_t t_count;
 };
 
-static int g_flow_shift;                 // workers of a flow launch = (4 x CUs) >> g_flow_shift: grows with every launch that was abandoned
+static int g_flow_shift;                 // workers of a flow launch = (6 x CUs) >> g_flow_shift: grows with every launch that was abandoned
 
 namespace {
 
@@ -831,7 +831,11 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
             //  the 4 x CUs default assumes 4 hardware queues and 16 resident waves per CU; where that does not hold (another
             // GPU_MAX_HW_QUEUES, another process on the GPU) flow launches starve each other and pictures fall into second passes:
             // every abandoned launch halves the default for the launches that follow (g_flow_shift, down to CUs / 4)
-            int n_workers = pr->flow_workers ? (int)pr->flow_workers : (WORKERS >= 0 ? (int)WORKERS : (4 * ctx->num_cus) >> __atomic_load_n(&g_flow_shift, __ATOMIC_RELAXED));
+            // Round 4: 6 x CUs (1536).  The argument above sized 4 x CUs for four launches of the full count side by side; since the
+            // widest-level rule below an I picture's launch holds ~256 workers, and B launches of 1536 were never abandoned in 4600
+            // pictures (tools/sweep_bpic_workers.sh, interleaved, six runs each: 1024 workers 3220 pictures/s, 1536 3308, 2048 2-10
+            // second passes per run); an abandoned launch still halves the default (g_flow_shift).
+            int n_workers = pr->flow_workers ? (int)pr->flow_workers : (WORKERS >= 0 ? (int)WORKERS : (6 * ctx->num_cus) >> __atomic_load_n(&g_flow_shift, __ATOMIC_RELAXED));
             if (!pr->flow_workers && WORKERS < 0) {
                 // No more workers than the picture's widest level can use (round 4): a worker beyond that only ever holds an item that is
                 // levels ahead of the front -- and its wave slot, registers and LDS are then missing to the kernels of the pictures beside
