@@ -881,9 +881,10 @@ typedef struct ovhip_job_params {        /* picture-level side information; HOST
      * as one multi-millisecond kernel holds up every stream that shares its queue; paced chunks let them in between.  For a
      * picture nobody waits for yet (ovhip_stream_cfg.intra_lookahead). */
     uint32_t flow_chunk_items, flow_paced;
-    /* Workers of a flow launch (ovhip_intra_flow_launch: n_workers); 0: the default, 4 per compute unit -- a quarter of what the
-     * device holds of that kernel, for the 4 hardware queues HIP gives a process.  A process that raises GPU_MAX_HW_QUEUES lowers this
-     * in proportion (8 queues: 2 per compute unit); the sum over the flow launches that can run at once must fit the device. */
+    /* Workers of a flow launch (ovhip_intra_flow_launch: n_workers); 0: the default -- 6 per compute unit, and never more than twice the
+     * picture's widest level (an I picture: ~256).  The flow launches that run at once (one per hardware queue: 4 for a HIP process)
+     * should fit the device, 16 per compute unit of that kernel; a launch that had to be abandoned halves the default for the
+     * launches that follow.  A process that raises GPU_MAX_HW_QUEUES lowers this in proportion. */
     uint32_t flow_workers;
 } ovhip_job_params;
 
