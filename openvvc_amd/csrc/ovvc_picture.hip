@@ -698,14 +698,18 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
         { StageTimer t_(j, OVHIP_TIME_MC);
         CHK(ovhip_mc_launch(ctx, dst, refs, n_refs, (const ovhip_mc_unit *)DEV(B_MC), (uint32_t)n_mc, d_fwd, intra)); }
         j->st.n_launches += n_mc != 0;
+        // Nothing on the device reads the refined vectors unless the TMVP entries are asked for: k_mcxa then stores them (one 16-byte
+        // store per unit) straight into the page-locked array the host reads -- not even k_store_host's launch is left
+        const bool mv_direct = n_mcx && !pr->tmvp_cells && !j->resident && X_MV_D2H == 3;
         if (n_mcx || n_aff) {
             StageTimer t_(j, OVHIP_TIME_MCXA);
             CHK(ovhip_mcxa_launch(ctx, dst, refs, n_refs, (const ovhip_mc_unit *)DEV(B_MCX), (uint32_t)n_mcx,
-                                  (int32_t *)j->dev[B_MV].p, (const ovhip_aff_unit *)DEV(B_AFF), (uint32_t)n_aff,
+                                  mv_direct ? j->mv_host : (int32_t *)j->dev[B_MV].p, (const ovhip_aff_unit *)DEV(B_AFF), (uint32_t)n_aff,
                                   (const int32_t *)DEV(B_SIDE), d_fwd));
             j->st.n_launches++;
         }
-        if (n_mcx && !j->resident && X_MV_D2H) {
+        if (mv_direct) j->st.d2h_bytes += n_mcx * 16;
+        else if (n_mcx && !j->resident && X_MV_D2H) {
             // refined vectors back to the host as early as the stream allows (the decoder's TMVP field needs them)
             // (round 4: as a DMA between k_mcxa and the residual kernels it cost the stream 7 % -- tools/x_mvd2h.sh: 2963 -> 3177 pictures/s)
             if (X_MV_D2H == 3) CHK(store_host(ctx, j->mv_host, j->dev[B_MV].p, n_mcx * 16));
