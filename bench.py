@@ -893,7 +893,7 @@ def reference_cpu_rates(W, H, n_pics, ncpu):
     return out
 
 
-def reference_stream_on_device(engine, capi, ctx, W, H, n_pics, reps):
+def reference_stream_on_device(engine, capi, ctx, W, H, n_pics, reps, extra=()):
     """The same stream through the HIP engine: gen_pipe writes the reference's frames and what the installed shim slots recorded; every
     picture is decoded on the device from the DEVICE's earlier pictures (ovhip_job_flush / _wait: uploads included) and compared byte for
     byte with the reference's frame; then the chain is timed, one picture in flight."""
@@ -905,7 +905,7 @@ def reference_stream_on_device(engine, capi, ctx, W, H, n_pics, reps):
     d = tempfile.mkdtemp(prefix="ovvc_refstream_")
     try:
         base = [str(GEN_PIPE), d]
-        tail = ["size", str(W), str(H), "pics", str(n_pics)]
+        tail = ["size", str(W), str(H), "pics", str(n_pics)] + [str(a) for a in extra]        # (extra: gen_pipe's seed / variant / qp / tiles arguments)
         subprocess.check_call(base + tail, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         subprocess.check_call(base + ["shim"] + tail, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         P = pipe_cases.Pipe("pipe", d)
