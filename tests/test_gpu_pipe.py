@@ -166,3 +166,23 @@ def test_full_size_stream_of_the_reference_slice_decoder(built_lib):
     assert r is not None and r["pictures"] == 9
     assert r["samples_differing_from_the_reference"] == 0 and r["refined_vectors_differing"] == 0
     assert r["units"]["dmvr_calls"] > 20000 and r["units"]["ordered_tasks"] > 20000 and r["units"]["affine"] > 5000
+
+
+@pytest.mark.parametrize("w,h,extra", [(832, 480, ("tiles", 3, 2, "seed", 4242)), (416, 240, ("variant", 1, "tiles", 4, 1, "seed", 77)),
+                                       (1920, 1080, ("seed", 31))])
+def test_fresh_streams_of_the_reference_slice_decoder(built_lib, w, h, extra):
+    """streams nobody has looked at (other seeds / tilings / sizes than the fixtures: tools/gpu_pipe_sweep.py runs hundreds): decoded
+    HERE by the prebuilt harness and by the HIP engine, compared frame by frame and vector by vector"""
+    import importlib.util
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    if not (root / "oracle" / "_ref" / "gen_pipe").exists():
+        pytest.skip("oracle/_ref/gen_pipe is built only where /root/reference exists")
+    spec = importlib.util.spec_from_file_location("bench", root / "bench.py")
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    ctx = engine.Context(0)
+    r = bench.reference_stream_on_device(engine, capi, ctx, w, h, 5, 0, extra=extra)
+    ctx.close()
+    assert r is not None and r["pictures"] == 5
+    assert r["samples_differing_from_the_reference"] == 0 and r["refined_vectors_differing"] == 0
+    assert r["units"]["dmvr_calls"] > 100 and r["units"]["ordered_tasks"] > 100
