@@ -523,6 +523,45 @@ __device__ __forceinline__ void itx_block(const ovhip_pic &pic, const ResDelta &
     }
 }
 
+// Sixteen lanes per 4x4 block, sixteen blocks per workgroup: the "tiny" tail of a small class (ovhip_rec_tb_cmds_split_tiny_: plain
+// 4x4 transform blocks and 4x4 DC blocks -- a quarter of a 4K picture's blocks, nearly all of them chroma).  A wave of its own per
+// such block left 48 lanes idle and paid a block's scalar work (command decode, sink, core lookup) for 16 samples; here the command
+// is per-lane data, lane (r, q) of a block produces ONE value in each pass, and the two 4-point passes go through 64 bytes of LDS
+// per block.  Arithmetic = itx_block's: de-quantise, vertical pass >> 7 with the int16 clip, horizontal pass >> (20 - bitdepth),
+// residual1 into the frame (or the residual picture).
+__device__ __forceinline__ void itx_tiny(const ovhip_pic &pic, const ResDelta &rd, const ovhip_tb_cmd *__restrict__ cmds, uint32_t i, bool valid,
+                                         const int16_t *__restrict__ arena, const int16_t *__restrict__ lmcs_scales, int16_t *s /* 32 entries */, int l)
+{
+    const ovhip_tb_cmd c = cmds[valid ? i : 0];
+    const int r = l >> 2, q = l & 3;
+    const int16_t *src = arena + c.coef_off;
+    const bool sig = c.sig_sb_map & 1;
+    // (both forms are computed by every lane -- a wave holds blocks of both kinds, and the fences stay outside divergent code)
+    const int co = sig ? dequant1((int)src[r * 4 + q], c.dq_scale, c.dq_shift, c.dq_neg) : 0;
+    s[q * 4 + r] = (int16_t)co;                                   // [column][row], as pass 1 reads it
+    block_sync<64>();
+    const int16_t *cv = tr_core(c.tr_v, 2) + r * 8, *chz = tr_core(c.tr_h, 2) + q * 8;
+    int acc = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc += (int)s[q * 4 + k] * (int)cv[k];              // output row r of coefficient column q
+    s[16 + r * 4 + q] = (int16_t)ov_clip16((acc + 64) >> 7);
+    block_sync<64>();
+    acc = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc += (int)s[16 + r * 4 + k] * (int)chz[k];        // output column q of row r
+    int res = ov_clip16((acc + (1 << (20 - OV_BD - 1))) >> (20 - OV_BD));
+    if (c.kind == OVHIP_TB_DC) {
+        // inverse_dct_ii_dc (rcn_transform.c:576-598) on the block's first coefficient (lane 0 of the block staged it at s[0])
+        res = ov_clip16(((((int)s[0] + 1) >> 1) + (1 << (14 - OV_BD - 1))) >> (14 - OV_BD));
+    }
+    if (!valid) return;
+    const ResidualSink sink = make_sink(pic, rd, c, lmcs_scales);
+    const int old = sink.dst[r * sink.stride + q];
+    const int old2 = sink.dst2 ? (int)sink.dst2[r * sink.stride2 + q] : 0;
+    sink.dst[r * sink.stride + q] = (uint16_t)residual1(old, res, sink.mode, sink.scale);
+    if (sink.dst2) sink.dst2[r * sink.stride2 + q] = (uint16_t)residual1(old2, res, sink.mode2, sink.scale);
+}
+
 // ONE launch for a sorted command list (ovhip_rec_tb_cmds_split): workgroups [0, n_large) take one block of any size
 // each, four waves on it; the next ceil(n_small / 4) take FOUR blocks <= 16x16 each, one per wave, each wave with its own
 // 2.5 KB slice of LDS; n_extra more are the inverse-LMCS rider.  (Big and small blocks used to be two launches: the
@@ -530,10 +569,12 @@ __device__ __forceinline__ void itx_block(const ovhip_pic &pic, const ResDelta &
 __global__ __launch_bounds__(256) OV_OCC_ITX void k_itx_all(ovhip_pic pic, const ovhip_tb_cmd *__restrict__ cmds, uint32_t n_large,
                                                   uint32_t n_small, const int16_t *__restrict__ arena,
                                                   const int16_t *__restrict__ lmcs_scales, int ablate,
-                                                  const uint16_t *__restrict__ lmcs_inv_lut, uint32_t n_extra, ResDelta rd)
+                                                  const uint16_t *__restrict__ lmcs_inv_lut, uint32_t n_extra, ResDelta rd, uint32_t n_tiny)
 {
     __shared__ __attribute__((aligned(16))) int16_t lds[ITX_LDS_BIG > 4 * ITX_LDS_SLICE ? ITX_LDS_BIG : 4 * ITX_LDS_SLICE];
-    const uint32_t b = blockIdx.x, n_quads = (n_small + 3) >> 2;
+    // the last n_tiny of the n_small commands are 4x4 blocks taken sixteen to a workgroup (workgroups behind the quads)
+    const uint32_t n_wave = n_small - n_tiny, n_t16 = (n_tiny + 15) >> 4;
+    const uint32_t b = blockIdx.x, n_quads = (n_wave + 3) >> 2;
     // XCD-aware order (see k_mc2): each XCD takes a contiguous chunk of the sorted list, so blocks that share frame
     // cache lines meet in one L2
     if (b < n_large) {
@@ -541,7 +582,7 @@ __global__ __launch_bounds__(256) OV_OCC_ITX void k_itx_all(ovhip_pic pic, const
     } else if (b < n_large + n_quads) {
         const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // wave-uniform: the command stays in SGPRs
         const uint32_t i = ov_xcd_slot(b - n_large, n_quads) * 4 + w;
-        const bool valid = i < n_small;
+        const bool valid = i < n_wave;
         const ovhip_tb_cmd &c = cmds[n_large + (valid ? i : 0)];
         int16_t *const slice = lds + w * ITX_LDS_SLICE;
         const int lane = threadIdx.x & 63;
@@ -555,8 +596,12 @@ __global__ __launch_bounds__(256) OV_OCC_ITX void k_itx_all(ovhip_pic pic, const
         default: itx_block<64>(pic, rd, c, valid, arena, lmcs_scales, ablate, lane, slice);
         }
 #undef ITX_SHAPE
+    } else if (b < n_large + n_quads + n_t16) {
+        const uint32_t blk = threadIdx.x >> 4;
+        const uint32_t i = ov_xcd_slot(b - n_large - n_quads, n_t16) * 16 + blk;
+        itx_tiny(pic, rd, cmds + n_large + n_wave, i, i < n_tiny, arena, lmcs_scales, lds + 32 * blk, (int)(threadIdx.x & 15));
     } else {
-        lmcs_inverse_rows<256>(pic, lmcs_inv_lut, b - n_large - n_quads, n_extra, reinterpret_cast<uint16_t *>(lds));
+        lmcs_inverse_rows<256>(pic, lmcs_inv_lut, b - n_large - n_quads - n_t16, n_extra, reinterpret_cast<uint16_t *>(lds));
     }
 }
 
@@ -574,8 +619,10 @@ static int itx_ablate()
 }
 
 static int itx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_tb_cmd *d_cmds, uint32_t n_large, uint32_t n_small,
-                      const int16_t *d_coefs, const int16_t *d_lmcs_scales, const uint16_t *d_bwd_lut, const ovhip_pic *res = nullptr)
+                      const int16_t *d_coefs, const int16_t *d_lmcs_scales, const uint16_t *d_bwd_lut, const ovhip_pic *res = nullptr,
+                      uint32_t n_tiny = 0)
 {
+    if (n_tiny > n_small) return ov_fail(ctx, OVHIP_EINVAL, "itx launch: more tiny blocks than small ones", hipSuccess);
     ResDelta rd = { { 0, 0, 0 } };
     if (res) {
         if (res->w != dst->w || res->h != dst->h || res->stride_y != dst->stride_y || res->stride_c != dst->stride_c)
@@ -585,10 +632,11 @@ static int itx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_tb_cmd *
     // one workgroup per big block / per four small blocks measured faster than a resident grid-stride grid (79 vs 119 us
     // at 4K; and again with the next block's loads software-pipelined: the kernel is issue-bound, not latency-bound)
     const uint32_t n_extra = d_bwd_lut ? (uint32_t)(dst->h + 3) / 4 : 0;      // the inverse-LMCS rider: four luma rows per workgroup
-    const uint32_t grid = n_large + (n_small + 3) / 4 + n_extra;
+    if (itx_ablate()) n_tiny = 0;                          // (the ablation switches are the wave-per-block body's)
+    const uint32_t grid = n_large + (n_small - n_tiny + 3) / 4 + (n_tiny + 15) / 16 + n_extra;
     if (!grid) return OVHIP_OK;
     hipLaunchKernelGGL(k_itx_all, dim3(grid), dim3(256), 0, ctx->stream, *dst, d_cmds, n_large, n_small, d_coefs,
-                       d_lmcs_scales, itx_ablate(), d_bwd_lut, n_extra, rd);
+                       d_lmcs_scales, itx_ablate(), d_bwd_lut, n_extra, rd, n_tiny);
     OV_LAUNCH_CHECK(ctx, "k_itx_all");
     return OVHIP_OK;
 }
@@ -625,6 +673,21 @@ extern "C" int ovhip_itx_launch_chroma_lmcs(ovhip_ctx *ctx, const ovhip_pic *dst
     if ((dst->stride_y & 7) || ((uintptr_t)dst->y & 15))
         return ov_fail(ctx, OVHIP_EINVAL, "ovhip_itx_launch_chroma_lmcs: luma plane must be 16-byte aligned with stride % 8 == 0", hipSuccess);
     return itx_launch(ctx, dst, d_cmds, n_large, n_small, d_coefs, d_lmcs_scales, d_bwd_lut);
+}
+
+/* library-internal (the picture job): any of the three launches above with the tiny tail of the small class named
+ * (ovhip_rec_tb_cmds_split_tiny_); res / d_bwd_lut NULL when not used */
+extern "C" int ovhip_itx_launch_ex_(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *res, const ovhip_tb_cmd *d_cmds,
+                                    uint32_t n_large, uint32_t n_small, uint32_t n_tiny, const int16_t *d_coefs,
+                                    const int16_t *d_lmcs_scales, const uint16_t *d_bwd_lut)
+{
+    if (!ctx || !dst) return OVHIP_EINVAL;
+    OV_DEVICE(ctx);
+    if (!n_large && !n_small && !d_bwd_lut) return OVHIP_OK;
+    if ((n_large || n_small) && (!d_cmds || !d_coefs)) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_itx_launch_ex_: null buffer", hipSuccess);
+    if (d_bwd_lut && ((dst->stride_y & 7) || ((uintptr_t)dst->y & 15)))
+        return ov_fail(ctx, OVHIP_EINVAL, "ovhip_itx_launch_ex_: luma plane must be 16-byte aligned with stride % 8 == 0", hipSuccess);
+    return itx_launch(ctx, dst, d_cmds, n_large, n_small, d_coefs, d_lmcs_scales, d_bwd_lut, res, n_tiny);
 }
 
 extern "C" int ovhip_itx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_tb_cmd *d_cmds,

@@ -54,7 +54,7 @@ struct ovhip_job {
     // ahead of the flush, on an upload lane; the flush restores what they produced and waits for ev_h2d on the host
     struct {
         int valid; uint32_t stages;
-        const ovhip_tb_cmd *tb; size_t cls[4], n_tb;
+        const ovhip_tb_cmd *tb; size_t cls[4], tiny[4], n_tb;
         const ovhip_itask *it; size_t n_it, n_ictu; uint32_t n_lv; const uint32_t *lv_start; const ovhip_ictu *ictu;
         size_t n_items; int by_flow;
     } ahead;
@@ -156,6 +156,10 @@ int pinned_reserve(ovhip_job *j, void **p, size_t *cap, size_t bytes)
     *p = q; *cap = nc;
     return OVHIP_OK;
 }
+
+extern "C" const ovhip_tb_cmd *ovhip_rec_tb_cmds_split_tiny_(ovhip_recorder *r, size_t counts[4], size_t tiny[4], size_t *n);
+extern "C" int ovhip_itx_launch_ex_(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *res, const ovhip_tb_cmd *d_cmds, uint32_t n_large,
+                                    uint32_t n_small, uint32_t n_tiny, const int16_t *d_coefs, const int16_t *d_lmcs_scales, const uint16_t *d_bwd_lut);
 
 #define CHK(x) do { int r__ = (x); if (r__ != OVHIP_OK) return r__; } while (0)
 
@@ -519,8 +523,9 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
     // ---- host: class split of the transform blocks (luma first; big / small), recorder arrays ----
     size_t cls[4] = { 0, 0, 0, 0 }, n_tb = 0, n_coef = 0, n_mc = 0, n_mcx = 0, n_aff = 0, n_side = 0, n_reg = 0, n_ev = 0, n_eh = 0;
     const ovhip_tb_cmd *tb;
-    if (ahead) { tb = j->ahead.tb; n_tb = j->ahead.n_tb; memcpy(cls, j->ahead.cls, sizeof(cls)); }
-    else tb = ovhip_rec_tb_cmds_split(rec, cls, &n_tb);
+    size_t tiny[4] = { 0, 0, 0, 0 };                 // the 4x4 blocks at the end of each class (sixteen to a workgroup)
+    if (ahead) { tb = j->ahead.tb; n_tb = j->ahead.n_tb; memcpy(cls, j->ahead.cls, sizeof(cls)); memcpy(tiny, j->ahead.tiny, sizeof(tiny)); }
+    else tb = ovhip_rec_tb_cmds_split_tiny_(rec, cls, tiny, &n_tb);
     if (!tb && n_tb) return ov_fail(ctx, OVHIP_ENOMEM, "ovhip_rec_tb_cmds_split", hipSuccess);
     const int16_t *coef = ovhip_rec_coefs(rec, &n_coef);
     const ovhip_mc_unit *mc = ovhip_rec_mc_units(rec, &n_mc);
@@ -659,7 +664,7 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
     hold.release();
     if (upload_only) {
         j->ahead.stages = stages;
-        j->ahead.tb = tb; j->ahead.n_tb = n_tb; memcpy(j->ahead.cls, cls, sizeof(cls));
+        j->ahead.tb = tb; j->ahead.n_tb = n_tb; memcpy(j->ahead.cls, cls, sizeof(cls)); memcpy(j->ahead.tiny, tiny, sizeof(tiny));
         j->ahead.it = it; j->ahead.n_it = n_it; j->ahead.n_ictu = n_ictu; j->ahead.n_lv = n_lv; j->ahead.lv_start = lv_start; j->ahead.ictu = ictu;
         j->ahead.n_items = n_items; j->ahead.by_flow = by_flow;
         j->ahead.valid = 1;
@@ -761,9 +766,7 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
         const int16_t *d_coef = (const int16_t *)DEV(B_COEF);
         if (cls[0] + cls[1]) {
             StageTimer t_(j, OVHIP_TIME_ITX_LUMA);
-            if (ordered) CHK(ovhip_itx_launch_classes_res(ctx, dst, &j->res, d_tb, (uint32_t)cls[0], (uint32_t)cls[1], d_coef, nullptr));
-            else
-            CHK(ovhip_itx_launch_classes(ctx, dst, d_tb, (uint32_t)cls[0], (uint32_t)cls[1], d_coef, nullptr));
+            CHK(ovhip_itx_launch_ex_(ctx, dst, ordered ? &j->res : nullptr, d_tb, (uint32_t)cls[0], (uint32_t)cls[1], (uint32_t)tiny[1], d_coef, nullptr, nullptr));
             j->st.n_launches++;
         }
         if (n_reg) {
@@ -781,12 +784,11 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
         const ovhip_tb_cmd *d_tbc = d_tb + cls[0] + cls[1];
         StageTimer t_(j, OVHIP_TIME_ITX_CHROMA);
         if (pr->lmcs && cls[3] && !ordered) {
-            CHK(ovhip_itx_launch_chroma_lmcs(ctx, dst, d_tbc, (uint32_t)cls[2], (uint32_t)cls[3], d_coef, d_scales, d_bwd));
+            CHK(ovhip_itx_launch_ex_(ctx, dst, nullptr, d_tbc, (uint32_t)cls[2], (uint32_t)cls[3], (uint32_t)tiny[3], d_coef, d_scales, d_bwd));
             j->st.n_launches++;
         } else {
             if (cls[2] + cls[3]) {
-                if (ordered) CHK(ovhip_itx_launch_classes_res(ctx, dst, &j->res, d_tbc, (uint32_t)cls[2], (uint32_t)cls[3], d_coef, d_scales));
-                else CHK(ovhip_itx_launch_classes(ctx, dst, d_tbc, (uint32_t)cls[2], (uint32_t)cls[3], d_coef, d_scales));
+                CHK(ovhip_itx_launch_ex_(ctx, dst, ordered ? &j->res : nullptr, d_tbc, (uint32_t)cls[2], (uint32_t)cls[3], (uint32_t)tiny[3], d_coef, d_scales, nullptr));
                 j->st.n_launches++;
             }
             if (pr->lmcs && !ordered) { CHK(ovhip_lmcs_inverse_launch(ctx, dst, d_bwd)); j->st.n_launches++; }
