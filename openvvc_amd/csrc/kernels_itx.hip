@@ -523,35 +523,41 @@ __device__ __forceinline__ void itx_block(const ovhip_pic &pic, const ResDelta &
     }
 }
 
-// Sixteen lanes per 4x4 block, sixteen blocks per workgroup: the "tiny" tail of a small class (ovhip_rec_tb_cmds_split_tiny_: plain
-// 4x4 transform blocks and 4x4 DC blocks -- a quarter of a 4K picture's blocks, nearly all of them chroma).  A wave of its own per
-// such block left 48 lanes idle and paid a block's scalar work (command decode, sink, core lookup) for 16 samples; here the command
-// is per-lane data, lane (r, q) of a block produces ONE value in each pass, and the two 4-point passes go through 64 bytes of LDS
-// per block.  Arithmetic = itx_block's: de-quantise, vertical pass >> 7 with the int16 clip, horizontal pass >> (20 - bitdepth),
-// residual1 into the frame (or the residual picture).
+// One lane per sample, 256 / (w x h) blocks per workgroup: the "tiny" tail of a small class (ovhip_rec_tb_cmds_split_tiny_: plain
+// 4x4, 8x4 and 4x8 transform blocks and DC blocks of those shapes -- over a third of a 4K picture's blocks, nearly all of them chroma).
+// A wave of its own per such block left 48 / 32 lanes idle and paid a block's scalar work (command decode, sink, core lookup) for
+// 16 / 32 samples; here the command is per-lane data, lane (r, q) of a block produces ONE value in each pass, and the two passes go
+// through 4 x w x h bytes of LDS per block.  Arithmetic = itx_block's: de-quantise, vertical pass >> 7 with the int16 clip, horizontal
+// pass >> (20 - bitdepth), residual1 into the frame (or the residual picture).  (Columns / rows the significance map rules out are
+// computed as the zeros they are.)
+template <int LW, int LH>
 __device__ __forceinline__ void itx_tiny(const ovhip_pic &pic, const ResDelta &rd, const ovhip_tb_cmd *__restrict__ cmds, uint32_t i, bool valid,
-                                         const int16_t *__restrict__ arena, const int16_t *__restrict__ lmcs_scales, int16_t *s /* 32 entries */, int l)
+                                         const int16_t *__restrict__ arena, const int16_t *__restrict__ lmcs_scales, int16_t *s /* 2 w h entries */, int l)
 {
+    constexpr int W = 1 << LW, H = 1 << LH, N = W * H;
     const ovhip_tb_cmd c = cmds[valid ? i : 0];
-    const int r = l >> 2, q = l & 3;
-    const int16_t *src = arena + c.coef_off;
-    const bool sig = c.sig_sb_map & 1;
+    const int r = l >> LW, q = l & (W - 1);
+    // the 4x4 sub-block that holds coefficient (r, q): bit sb_y * 8 + sb_x of the map, its rank among the set bits = its place in the arena
+    const int bit = (r >> 2) * 8 + (q >> 2);
+    const bool sig = (c.sig_sb_map >> bit) & 1;
+    const int rank = __popcll(c.sig_sb_map & ((1ull << bit) - 1));
+    const int16_t *src = arena + c.coef_off + rank * 16 + (r & 3) * 4 + (q & 3);
     // (both forms are computed by every lane -- a wave holds blocks of both kinds, and the fences stay outside divergent code)
-    const int co = sig ? dequant1((int)src[r * 4 + q], c.dq_scale, c.dq_shift, c.dq_neg) : 0;
-    s[q * 4 + r] = (int16_t)co;                                   // [column][row], as pass 1 reads it
+    const int co = sig ? dequant1((int)src[0], c.dq_scale, c.dq_shift, c.dq_neg) : 0;
+    s[q * H + r] = (int16_t)co;                                   // [column][row], as pass 1 reads it
     block_sync<64>();
-    const int16_t *cv = tr_core(c.tr_v, 2) + r * 8, *chz = tr_core(c.tr_h, 2) + q * 8;
+    const int16_t *cv = tr_core(c.tr_v, LH) + r * 8, *chz = tr_core(c.tr_h, LW) + q * 8;       // (4- and 8-point cores: rows of 8)
     int acc = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc += (int)s[q * 4 + k] * (int)cv[k];              // output row r of coefficient column q
-    s[16 + r * 4 + q] = (int16_t)ov_clip16((acc + 64) >> 7);
+    for (int k = 0; k < H; ++k) acc += (int)s[q * H + k] * (int)cv[k];              // output row r of coefficient column q
+    s[N + r * W + q] = (int16_t)ov_clip16((acc + 64) >> 7);
     block_sync<64>();
     acc = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc += (int)s[16 + r * 4 + k] * (int)chz[k];        // output column q of row r
+    for (int k = 0; k < W; ++k) acc += (int)s[N + r * W + k] * (int)chz[k];         // output column q of row r
     int res = ov_clip16((acc + (1 << (20 - OV_BD - 1))) >> (20 - OV_BD));
     if (c.kind == OVHIP_TB_DC) {
-        // inverse_dct_ii_dc (rcn_transform.c:576-598) on the block's first coefficient (lane 0 of the block staged it at s[0])
+        // inverse_dct_ii_dc (rcn_transform.c:576-598) on the block's first coefficient (the block's lane 0 staged it at s[0])
         res = ov_clip16(((((int)s[0] + 1) >> 1) + (1 << (14 - OV_BD - 1))) >> (14 - OV_BD));
     }
     if (!valid) return;
@@ -562,6 +568,9 @@ __device__ __forceinline__ void itx_tiny(const ovhip_pic &pic, const ResDelta &r
     if (sink.dst2) sink.dst2[r * sink.stride2 + q] = (uint16_t)residual1(old2, res, sink.mode2, sink.scale);
 }
 
+// the tiny tail of a small class, shape by shape: counts of ovhip_rec_tb_cmds_split_tiny_ (8x8, 4x8, 8x4, 4x4 in list order)
+struct TinyCounts { uint32_t n[4]; };
+
 // ONE launch for a sorted command list (ovhip_rec_tb_cmds_split): workgroups [0, n_large) take one block of any size
 // each, four waves on it; the next ceil(n_small / 4) take FOUR blocks <= 16x16 each, one per wave, each wave with its own
 // 2.5 KB slice of LDS; n_extra more are the inverse-LMCS rider.  (Big and small blocks used to be two launches: the
@@ -569,11 +578,14 @@ __device__ __forceinline__ void itx_tiny(const ovhip_pic &pic, const ResDelta &r
 __global__ __launch_bounds__(256) OV_OCC_ITX void k_itx_all(ovhip_pic pic, const ovhip_tb_cmd *__restrict__ cmds, uint32_t n_large,
                                                   uint32_t n_small, const int16_t *__restrict__ arena,
                                                   const int16_t *__restrict__ lmcs_scales, int ablate,
-                                                  const uint16_t *__restrict__ lmcs_inv_lut, uint32_t n_extra, ResDelta rd, uint32_t n_tiny)
+                                                  const uint16_t *__restrict__ lmcs_inv_lut, uint32_t n_extra, ResDelta rd, TinyCounts tc)
 {
     __shared__ __attribute__((aligned(16))) int16_t lds[ITX_LDS_BIG > 4 * ITX_LDS_SLICE ? ITX_LDS_BIG : 4 * ITX_LDS_SLICE];
-    // the last n_tiny of the n_small commands are 4x4 blocks taken sixteen to a workgroup (workgroups behind the quads)
-    const uint32_t n_wave = n_small - n_tiny, n_t16 = (n_tiny + 15) >> 4;
+    // the last commands of the n_small are tiny blocks, a lane per sample (workgroups behind the quads): 4x8 and 8x4 blocks eight to a
+    // workgroup, 4x4 blocks sixteen
+    const uint32_t n_tiny = tc.n[0] + tc.n[1] + tc.n[2] + tc.n[3];
+    const uint32_t gq = (tc.n[0] + 3) >> 2, g0 = (tc.n[1] + 7) >> 3, g1 = (tc.n[2] + 7) >> 3, g2 = (tc.n[3] + 15) >> 4, n_tg = gq + g0 + g1 + g2;
+    const uint32_t n_wave = n_small - n_tiny;
     const uint32_t b = blockIdx.x, n_quads = (n_wave + 3) >> 2;
     // XCD-aware order (see k_mc2): each XCD takes a contiguous chunk of the sorted list, so blocks that share frame
     // cache lines meet in one L2
@@ -596,12 +608,25 @@ __global__ __launch_bounds__(256) OV_OCC_ITX void k_itx_all(ovhip_pic pic, const
         default: itx_block<64>(pic, rd, c, valid, arena, lmcs_scales, ablate, lane, slice);
         }
 #undef ITX_SHAPE
-    } else if (b < n_large + n_quads + n_t16) {
-        const uint32_t blk = threadIdx.x >> 4;
-        const uint32_t i = ov_xcd_slot(b - n_large - n_quads, n_t16) * 16 + blk;
-        itx_tiny(pic, rd, cmds + n_large + n_wave, i, i < n_tiny, arena, lmcs_scales, lds + 32 * blk, (int)(threadIdx.x & 15));
+    } else if (b < n_large + n_quads + n_tg) {
+        uint32_t g = b - n_large - n_quads;
+        const ovhip_tb_cmd *base = cmds + n_large + n_wave;
+        if (g < gq) {
+            const uint32_t blk = threadIdx.x >> 6, i = ov_xcd_slot(g, gq) * 4 + blk;
+            itx_tiny<3, 3>(pic, rd, base, i, i < tc.n[0], arena, lmcs_scales, lds + 128 * blk, (int)(threadIdx.x & 63));
+        } else if ((g -= gq) < g0) {
+            const uint32_t blk = threadIdx.x >> 5, i = ov_xcd_slot(g, g0) * 8 + blk;
+            itx_tiny<2, 3>(pic, rd, base + tc.n[0], i, i < tc.n[1], arena, lmcs_scales, lds + 64 * blk, (int)(threadIdx.x & 31));
+        } else if ((g -= g0) < g1) {
+            const uint32_t blk = threadIdx.x >> 5, i = ov_xcd_slot(g, g1) * 8 + blk;
+            itx_tiny<3, 2>(pic, rd, base + tc.n[0] + tc.n[1], i, i < tc.n[2], arena, lmcs_scales, lds + 64 * blk, (int)(threadIdx.x & 31));
+        } else {
+            g -= g1;
+            const uint32_t blk = threadIdx.x >> 4, i = ov_xcd_slot(g, g2) * 16 + blk;
+            itx_tiny<2, 2>(pic, rd, base + tc.n[0] + tc.n[1] + tc.n[2], i, i < tc.n[3], arena, lmcs_scales, lds + 32 * blk, (int)(threadIdx.x & 15));
+        }
     } else {
-        lmcs_inverse_rows<256>(pic, lmcs_inv_lut, b - n_large - n_quads - n_t16, n_extra, reinterpret_cast<uint16_t *>(lds));
+        lmcs_inverse_rows<256>(pic, lmcs_inv_lut, b - n_large - n_quads - n_tg, n_extra, reinterpret_cast<uint16_t *>(lds));
     }
 }
 
@@ -620,9 +645,10 @@ static int itx_ablate()
 
 static int itx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_tb_cmd *d_cmds, uint32_t n_large, uint32_t n_small,
                       const int16_t *d_coefs, const int16_t *d_lmcs_scales, const uint16_t *d_bwd_lut, const ovhip_pic *res = nullptr,
-                      uint32_t n_tiny = 0)
+                      const uint32_t *tiny3 = nullptr)
 {
-    if (n_tiny > n_small) return ov_fail(ctx, OVHIP_EINVAL, "itx launch: more tiny blocks than small ones", hipSuccess);
+    TinyCounts tc = { { tiny3 ? tiny3[0] : 0u, tiny3 ? tiny3[1] : 0u, tiny3 ? tiny3[2] : 0u, tiny3 ? tiny3[3] : 0u } };
+    if ((uint64_t)tc.n[0] + tc.n[1] + tc.n[2] + tc.n[3] > n_small) return ov_fail(ctx, OVHIP_EINVAL, "itx launch: more tiny blocks than small ones", hipSuccess);
     ResDelta rd = { { 0, 0, 0 } };
     if (res) {
         if (res->w != dst->w || res->h != dst->h || res->stride_y != dst->stride_y || res->stride_c != dst->stride_c)
@@ -632,11 +658,12 @@ static int itx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_tb_cmd *
     // one workgroup per big block / per four small blocks measured faster than a resident grid-stride grid (79 vs 119 us
     // at 4K; and again with the next block's loads software-pipelined: the kernel is issue-bound, not latency-bound)
     const uint32_t n_extra = d_bwd_lut ? (uint32_t)(dst->h + 3) / 4 : 0;      // the inverse-LMCS rider: four luma rows per workgroup
-    if (itx_ablate()) n_tiny = 0;                          // (the ablation switches are the wave-per-block body's)
-    const uint32_t grid = n_large + (n_small - n_tiny + 3) / 4 + (n_tiny + 15) / 16 + n_extra;
+    if (itx_ablate()) tc.n[0] = tc.n[1] = tc.n[2] = tc.n[3] = 0;    // (the ablation switches are the wave-per-block body's)
+    const uint32_t n_tiny = tc.n[0] + tc.n[1] + tc.n[2] + tc.n[3];
+    const uint32_t grid = n_large + (n_small - n_tiny + 3) / 4 + (tc.n[0] + 3) / 4 + (tc.n[1] + 7) / 8 + (tc.n[2] + 7) / 8 + (tc.n[3] + 15) / 16 + n_extra;
     if (!grid) return OVHIP_OK;
     hipLaunchKernelGGL(k_itx_all, dim3(grid), dim3(256), 0, ctx->stream, *dst, d_cmds, n_large, n_small, d_coefs,
-                       d_lmcs_scales, itx_ablate(), d_bwd_lut, n_extra, rd, n_tiny);
+                       d_lmcs_scales, itx_ablate(), d_bwd_lut, n_extra, rd, tc);
     OV_LAUNCH_CHECK(ctx, "k_itx_all");
     return OVHIP_OK;
 }
@@ -678,7 +705,7 @@ extern "C" int ovhip_itx_launch_chroma_lmcs(ovhip_ctx *ctx, const ovhip_pic *dst
 /* library-internal (the picture job): any of the three launches above with the tiny tail of the small class named
  * (ovhip_rec_tb_cmds_split_tiny_); res / d_bwd_lut NULL when not used */
 extern "C" int ovhip_itx_launch_ex_(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *res, const ovhip_tb_cmd *d_cmds,
-                                    uint32_t n_large, uint32_t n_small, uint32_t n_tiny, const int16_t *d_coefs,
+                                    uint32_t n_large, uint32_t n_small, const uint32_t tiny3[4], const int16_t *d_coefs,
                                     const int16_t *d_lmcs_scales, const uint16_t *d_bwd_lut)
 {
     if (!ctx || !dst) return OVHIP_EINVAL;
@@ -687,7 +714,7 @@ extern "C" int ovhip_itx_launch_ex_(ovhip_ctx *ctx, const ovhip_pic *dst, const 
     if ((n_large || n_small) && (!d_cmds || !d_coefs)) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_itx_launch_ex_: null buffer", hipSuccess);
     if (d_bwd_lut && ((dst->stride_y & 7) || ((uintptr_t)dst->y & 15)))
         return ov_fail(ctx, OVHIP_EINVAL, "ovhip_itx_launch_ex_: luma plane must be 16-byte aligned with stride % 8 == 0", hipSuccess);
-    return itx_launch(ctx, dst, d_cmds, n_large, n_small, d_coefs, d_lmcs_scales, d_bwd_lut, res, n_tiny);
+    return itx_launch(ctx, dst, d_cmds, n_large, n_small, d_coefs, d_lmcs_scales, d_bwd_lut, res, tiny3);
 }
 
 extern "C" int ovhip_itx_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_tb_cmd *d_cmds,

@@ -54,7 +54,7 @@ struct ovhip_job {
     // ahead of the flush, on an upload lane; the flush restores what they produced and waits for ev_h2d on the host
     struct {
         int valid; uint32_t stages;
-        const ovhip_tb_cmd *tb; size_t cls[4], tiny[4], n_tb;
+        const ovhip_tb_cmd *tb; size_t cls[4], tiny[4][4], n_tb;
         const ovhip_itask *it; size_t n_it, n_ictu; uint32_t n_lv; const uint32_t *lv_start; const ovhip_ictu *ictu;
         size_t n_items; int by_flow;
     } ahead;
@@ -157,9 +157,9 @@ int pinned_reserve(ovhip_job *j, void **p, size_t *cap, size_t bytes)
     return OVHIP_OK;
 }
 
-extern "C" const ovhip_tb_cmd *ovhip_rec_tb_cmds_split_tiny_(ovhip_recorder *r, size_t counts[4], size_t tiny[4], size_t *n);
+extern "C" const ovhip_tb_cmd *ovhip_rec_tb_cmds_split_tiny_(ovhip_recorder *r, size_t counts[4], size_t tiny[4][4], size_t *n);
 extern "C" int ovhip_itx_launch_ex_(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *res, const ovhip_tb_cmd *d_cmds, uint32_t n_large,
-                                    uint32_t n_small, uint32_t n_tiny, const int16_t *d_coefs, const int16_t *d_lmcs_scales, const uint16_t *d_bwd_lut);
+                                    uint32_t n_small, const uint32_t tiny3[4], const int16_t *d_coefs, const int16_t *d_lmcs_scales, const uint16_t *d_bwd_lut);
 
 #define CHK(x) do { int r__ = (x); if (r__ != OVHIP_OK) return r__; } while (0)
 
@@ -523,7 +523,7 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
     // ---- host: class split of the transform blocks (luma first; big / small), recorder arrays ----
     size_t cls[4] = { 0, 0, 0, 0 }, n_tb = 0, n_coef = 0, n_mc = 0, n_mcx = 0, n_aff = 0, n_side = 0, n_reg = 0, n_ev = 0, n_eh = 0;
     const ovhip_tb_cmd *tb;
-    size_t tiny[4] = { 0, 0, 0, 0 };                 // the 4x4 blocks at the end of each class (sixteen to a workgroup)
+    size_t tiny[4][4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };      // the tiny blocks at the end of each class (a lane per sample)
     if (ahead) { tb = j->ahead.tb; n_tb = j->ahead.n_tb; memcpy(cls, j->ahead.cls, sizeof(cls)); memcpy(tiny, j->ahead.tiny, sizeof(tiny)); }
     else tb = ovhip_rec_tb_cmds_split_tiny_(rec, cls, tiny, &n_tb);
     if (!tb && n_tb) return ov_fail(ctx, OVHIP_ENOMEM, "ovhip_rec_tb_cmds_split", hipSuccess);
@@ -764,9 +764,11 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
     if (stages & OVHIP_STAGE_ITX) {
         const ovhip_tb_cmd *d_tb = (const ovhip_tb_cmd *)DEV(B_TB);
         const int16_t *d_coef = (const int16_t *)DEV(B_COEF);
+        const uint32_t t_luma[4] = { (uint32_t)tiny[1][0], (uint32_t)tiny[1][1], (uint32_t)tiny[1][2], (uint32_t)tiny[1][3] };
+        const uint32_t t_chroma[4] = { (uint32_t)tiny[3][0], (uint32_t)tiny[3][1], (uint32_t)tiny[3][2], (uint32_t)tiny[3][3] };
         if (cls[0] + cls[1]) {
             StageTimer t_(j, OVHIP_TIME_ITX_LUMA);
-            CHK(ovhip_itx_launch_ex_(ctx, dst, ordered ? &j->res : nullptr, d_tb, (uint32_t)cls[0], (uint32_t)cls[1], (uint32_t)tiny[1], d_coef, nullptr, nullptr));
+            CHK(ovhip_itx_launch_ex_(ctx, dst, ordered ? &j->res : nullptr, d_tb, (uint32_t)cls[0], (uint32_t)cls[1], t_luma, d_coef, nullptr, nullptr));
             j->st.n_launches++;
         }
         if (n_reg) {
@@ -784,11 +786,11 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
         const ovhip_tb_cmd *d_tbc = d_tb + cls[0] + cls[1];
         StageTimer t_(j, OVHIP_TIME_ITX_CHROMA);
         if (pr->lmcs && cls[3] && !ordered) {
-            CHK(ovhip_itx_launch_ex_(ctx, dst, nullptr, d_tbc, (uint32_t)cls[2], (uint32_t)cls[3], (uint32_t)tiny[3], d_coef, d_scales, d_bwd));
+            CHK(ovhip_itx_launch_ex_(ctx, dst, nullptr, d_tbc, (uint32_t)cls[2], (uint32_t)cls[3], t_chroma, d_coef, d_scales, d_bwd));
             j->st.n_launches++;
         } else {
             if (cls[2] + cls[3]) {
-                CHK(ovhip_itx_launch_ex_(ctx, dst, ordered ? &j->res : nullptr, d_tbc, (uint32_t)cls[2], (uint32_t)cls[3], (uint32_t)tiny[3], d_coef, d_scales, nullptr));
+                CHK(ovhip_itx_launch_ex_(ctx, dst, ordered ? &j->res : nullptr, d_tbc, (uint32_t)cls[2], (uint32_t)cls[3], t_chroma, d_coef, d_scales, nullptr));
                 j->st.n_launches++;
             }
             if (pr->lmcs && !ordered) { CHK(ovhip_lmcs_inverse_launch(ctx, dst, d_bwd)); j->st.n_launches++; }

@@ -973,34 +973,40 @@ ovhip_rec_lmcs_region(ovhip_recorder *r, int32_t x0, int32_t y0, uint32_t abv_ma
 
 ACCESSOR(ovhip_lmcs_region, ovhip_rec_lmcs_regions, reg, n_reg)
 
-/* tiny[k]: how many commands at the END of class k are "tiny" -- plain 4x4 blocks (OVHIP_TB_TR without LFNST off the arena's
- * sub-blocks, or OVHIP_TB_DC), which k_itx_all takes SIXTEEN to a workgroup, sixteen lanes each, instead of a wave each (a quarter of
- * a 4K picture's blocks are 4x4 chroma blocks).  Library-internal (the picture job); ovhip_rec_tb_cmds_split is the same order. */
+/* tiny[k][0 .. 3]: how many commands at the END of class k are "tiny" -- plain 8x8, 4x8, 8x4, 4x4 blocks (in that order in the list:
+ * OVHIP_TB_TR without LFNST off the arena's sub-blocks, or OVHIP_TB_DC), which k_itx_all takes a lane per sample, 4 / 8 / 8 / 16 blocks
+ * to a workgroup, with the command as per-lane data (over half of a 4K picture's blocks).  Library-internal (the picture job);
+ * ovhip_rec_tb_cmds_split is the same order. */
 const ovhip_tb_cmd *
-ovhip_rec_tb_cmds_split_tiny_(ovhip_recorder *r, size_t counts[4], size_t tiny[4], size_t *n)
+ovhip_rec_tb_cmds_split_tiny_(ovhip_recorder *r, size_t counts[4], size_t tiny[4][4], size_t *n)
 {
-    size_t start[8], cnt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, k;
+    size_t start[20], cnt[20], k;
     *n = r->n_tb;
-    counts[0] = counts[1] = counts[2] = counts[3] = 0;
-    tiny[0] = tiny[1] = tiny[2] = tiny[3] = 0;
+    memset(cnt, 0, sizeof(cnt)); memset(counts, 0, 4 * sizeof(size_t)); memset(tiny, 0, 16 * sizeof(size_t));
     if (!r->n_tb) return r->tb;
     if (grow((void **)&r->tb_split, &r->cap_split, r->n_tb, sizeof(ovhip_tb_cmd))) { *n = 0; return NULL; }
     /* "small" = what one wavefront and a 4 KB slice of LDS take: at most 256 samples, no side above 32 */
 #define TB_CLASS(c) (((c)->plane != 0) * 2 + ((c)->log2_w + (c)->log2_h <= 8 && (c)->log2_w <= 5 && (c)->log2_h <= 5))
-#define TB_TINY(c) ((c)->log2_w == 2 && (c)->log2_h == 2 && ((c)->kind == OVHIP_TB_DC || ((c)->kind == OVHIP_TB_TR && !((c)->lfnst & 1))))
-    for (size_t i = 0; i < r->n_tb; ++i) cnt[2 * TB_CLASS(&r->tb[i]) + TB_TINY(&r->tb[i])]++;
-    for (k = 0, start[0] = 0; k < 7; ++k) start[k + 1] = start[k] + cnt[k];
-    for (size_t i = 0; i < r->n_tb; ++i) r->tb_split[start[2 * TB_CLASS(&r->tb[i]) + TB_TINY(&r->tb[i])]++] = r->tb[i];
+    /* 0: a wave of its own through the general body; 1: 8x8, 2: 4x8, 3: 8x4, 4: 4x4 */
+#define TB_SHAPE(c) (((c)->kind == OVHIP_TB_DC || ((c)->kind == OVHIP_TB_TR && !((c)->lfnst & 1))) ? \
+                     ((c)->log2_w == 3 && (c)->log2_h == 3 ? 1 : (c)->log2_w == 2 && (c)->log2_h == 3 ? 2 : \
+                      (c)->log2_w == 3 && (c)->log2_h == 2 ? 3 : (c)->log2_w == 2 && (c)->log2_h == 2 ? 4 : 0) : 0)
+    for (size_t i = 0; i < r->n_tb; ++i) cnt[5 * TB_CLASS(&r->tb[i]) + TB_SHAPE(&r->tb[i])]++;
+    for (k = 0, start[0] = 0; k < 19; ++k) start[k + 1] = start[k] + cnt[k];
+    for (size_t i = 0; i < r->n_tb; ++i) r->tb_split[start[5 * TB_CLASS(&r->tb[i]) + TB_SHAPE(&r->tb[i])]++] = r->tb[i];
 #undef TB_CLASS
-#undef TB_TINY
-    for (k = 0; k < 4; ++k) { counts[k] = cnt[2 * k] + cnt[2 * k + 1]; tiny[k] = cnt[2 * k + 1]; }
+#undef TB_SHAPE
+    for (k = 0; k < 4; ++k) {
+        counts[k] = cnt[5 * k] + cnt[5 * k + 1] + cnt[5 * k + 2] + cnt[5 * k + 3] + cnt[5 * k + 4];
+        for (int q = 0; q < 4; ++q) tiny[k][q] = cnt[5 * k + 1 + q];
+    }
     return r->tb_split;
 }
 
 const ovhip_tb_cmd *
 ovhip_rec_tb_cmds_split(ovhip_recorder *r, size_t counts[4], size_t *n)
 {
-    size_t tiny[4];
+    size_t tiny[4][4];
     return ovhip_rec_tb_cmds_split_tiny_(r, counts, tiny, n);
 }
 

@@ -68,14 +68,16 @@ def test_tb_class_split_is_a_stable_partition(built_lib):
     o = np.cumsum((0,) + k)
     assert luma[:o[2]].all() and not luma[o[2]:].any()
     assert big[o[0]:o[1]].all() and not big[o[1]:o[2]].any() and big[o[2]:o[3]].all() and not big[o[3]:o[4]].any()
-    # inside every class: the 4x4 blocks k_itx_all takes sixteen to a workgroup (plain transform blocks without LFNST, DC blocks) come
-    # last; both parts are stable -- coefficient offsets stay ascending (recording order)
-    tiny = (c["log2_w"] == 2) & (c["log2_h"] == 2) & ((c["kind"] == capi.TB_DC) | ((c["kind"] == capi.TB_TR) & ((c["lfnst"] & 1) == 0)))
+    # inside every class: the blocks k_itx_all takes a lane per sample (plain 8x8 / 4x8 / 8x4 / 4x4 transform blocks without LFNST, DC blocks of
+    # those shapes) come last, shape by shape in that order; every run is stable -- coefficient offsets stay ascending (recording order)
+    plain = (c["kind"] == capi.TB_DC) | ((c["kind"] == capi.TB_TR) & ((c["lfnst"] & 1) == 0))
+    shape = np.where(plain & (c["log2_w"] == 3) & (c["log2_h"] == 3), 1, np.where(plain & (c["log2_w"] == 2) & (c["log2_h"] == 3), 2,
+                     np.where(plain & (c["log2_w"] == 3) & (c["log2_h"] == 2), 3, np.where(plain & (c["log2_w"] == 2) & (c["log2_h"] == 2), 4, 0))))
+    tiny = shape != 0
     for a, b in zip(o[:-1], o[1:]):
-        t = tiny[a:b]
-        n_t = int(t.sum())
-        assert not t[:b - a - n_t].any() and t[b - a - n_t:].all()
-        for part in (c["coef_off"][a:b - n_t], c["coef_off"][b - n_t:b]):
+        assert (np.diff(shape[a:b]) >= 0).all()                                  # wave blocks, then 8x8, 4x8, 8x4, 4x4
+        for k in range(5):
+            part = c["coef_off"][a:b][shape[a:b] == k]
             assert (np.diff(part.astype(np.int64)) > 0).all()
     assert tiny.sum() > 20
 
