@@ -530,11 +530,37 @@ __device__ __forceinline__ void itx_block(const ovhip_pic &pic, const ResDelta &
 // through 4 x w x h bytes of LDS per block.  Arithmetic = itx_block's: de-quantise, vertical pass >> 7 with the int16 clip, horizontal
 // pass >> (20 - bitdepth), residual1 into the frame (or the residual picture).  (Columns / rows the significance map rules out are
 // computed as the zeros they are.)
+// dot product of K (4, 8) int16 pairs, both operands k-contiguous and 8 / 16-byte aligned; terms from kmax on are zero by
+// construction (kmax a multiple of 4: the significance map works in 4x4 sub-blocks)
+template <int K>
+__device__ __forceinline__ int itx_dot(const int16_t *a, const int16_t *b, int kmax)
+{
+    int acc = 0;
+    if (K == 4) {
+        const uint2 x = *reinterpret_cast<const uint2 *>(a), y = *reinterpret_cast<const uint2 *>(b);
+        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, x.x), __builtin_bit_cast(short2v, y.x), acc, false);
+        acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, x.y), __builtin_bit_cast(short2v, y.y), acc, false);
+    } else {
+#pragma unroll
+        for (int k = 0; k < K; k += 8) {
+            if (k < kmax) {
+                const uint4 x = *reinterpret_cast<const uint4 *>(a + k), y = *reinterpret_cast<const uint4 *>(b + k);
+                acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, x.x), __builtin_bit_cast(short2v, y.x), acc, false);
+                acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, x.y), __builtin_bit_cast(short2v, y.y), acc, false);
+                acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, x.z), __builtin_bit_cast(short2v, y.z), acc, false);
+                acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, x.w), __builtin_bit_cast(short2v, y.w), acc, false);
+            }
+        }
+    }
+    return acc;
+}
+
 template <int LW, int LH>
 __device__ __forceinline__ void itx_tiny(const ovhip_pic &pic, const ResDelta &rd, const ovhip_tb_cmd *__restrict__ cmds, uint32_t i, bool valid,
                                          const int16_t *__restrict__ arena, const int16_t *__restrict__ lmcs_scales, int16_t *s /* 2 w h entries */, int l)
 {
     constexpr int W = 1 << LW, H = 1 << LH, N = W * H;
+    static_assert(N <= 64 && W <= 8 && H <= 8, "a block is at most one wave: its fences are the wave's (tried with 16-point shapes behind workgroup barriers: slower)");
     const ovhip_tb_cmd c = cmds[valid ? i : 0];
     const int r = l >> LW, q = l & (W - 1);
     // the 4x4 sub-block that holds coefficient (r, q): bit sb_y * 8 + sb_x of the map, its rank among the set bits = its place in the arena
@@ -546,15 +572,11 @@ __device__ __forceinline__ void itx_tiny(const ovhip_pic &pic, const ResDelta &r
     const int co = sig ? dequant1((int)src[0], c.dq_scale, c.dq_shift, c.dq_neg) : 0;
     s[q * H + r] = (int16_t)co;                                   // [column][row], as pass 1 reads it
     block_sync<64>();
-    const int16_t *cv = tr_core(c.tr_v, LH) + r * 8, *chz = tr_core(c.tr_h, LW) + q * 8;       // (4- and 8-point cores: rows of 8)
-    int acc = 0;
-#pragma unroll
-    for (int k = 0; k < H; ++k) acc += (int)s[q * H + k] * (int)cv[k];              // output row r of coefficient column q
+    // (4- and 8-point cores: rows of 8; coefficient rows / columns the significance map rules out are the zeros they are)
+    int acc = itx_dot<H>(s + q * H, tr_core(c.tr_v, LH) + r * 8, H);                 // output row r of coefficient column q
     s[N + r * W + q] = (int16_t)ov_clip16((acc + 64) >> 7);
     block_sync<64>();
-    acc = 0;
-#pragma unroll
-    for (int k = 0; k < W; ++k) acc += (int)s[N + r * W + k] * (int)chz[k];         // output column q of row r
+    acc = itx_dot<W>(s + N + r * W, tr_core(c.tr_h, LW) + q * 8, W);                // output column q of row r
     int res = ov_clip16((acc + (1 << (20 - OV_BD - 1))) >> (20 - OV_BD));
     if (c.kind == OVHIP_TB_DC) {
         // inverse_dct_ii_dc (rcn_transform.c:576-598) on the block's first coefficient (the block's lane 0 staged it at s[0])
