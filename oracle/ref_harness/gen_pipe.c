@@ -33,9 +33,18 @@
  *                                                 is launched; include/ovvc_hip.h, ovhip_frame_set_trace).  The fixture is the
  *                                                 interleaved log of the decoder's row-end events and the frame-level calls the shim
  *                                                 made under them; what its recorder held must equal the shim mode's stream.
- * The same process runs the reference pass first in all modes: the shim's DMVR slot returns unrefined vectors in record-only
- * mode (the device refines them later), so the harness hands the caller the vectors the reference pass
- * produced for the same call -- "the device answered in time" -- and the parse of the later pictures (TMVP) stays the same.
+ * Live mode       -> no fixture, a JSON line    : the shim as a decoder would run it -- its own device DPB on the real GPU
+ *                                                 (OVVC_HIP_DEVICES), ovhip_frame_submit launching, OVHIP_OUT_PLANES into the OVFrame --
+ *                                                 on N frame threads (one OVSliceDec + OVCTUDec each, pictures taken in decoding order
+ *                                                 as ovdec_select_subdec hands NAL units to free sub-decoders, ovdec.c:188-248), the
+ *                                                 collocated motion field read under the reference's row synchronisation
+ *                                                 (drv_mvp.c:281-294; dpb.c:1242-1323).  NOTHING is fed back from the reference pass: the DMVR
+ *                                                 slot returns what the shim returns and the TMVP planes hold what the DEVICE delivered
+ *                                                 through ovhip_frame_dmvr_rows_collect before the row was reported.  Every picture's
+ *                                                 OVFrame and both motion planes are compared with the reference pass in this process.
+ * The same process runs the reference pass first in all modes.  In the shim and device (dry) modes the shim's DMVR slot returns
+ * unrefined vectors and no device refines them, so there the harness hands the caller the vectors the
+ * reference pass produced for the same call and the parse of the later pictures (TMVP) stays the same; the live mode does not.
  */
 #define rcn_init_functions gp_rcn_init_functions
 #include "ref_common.h"
@@ -60,8 +69,9 @@ struct LMCSLUTs { OVSample fwd_lut[1024]; OVSample bwd_lut[1024]; OVSample wnd_b
 typedef uint8_t (*dmvr_fn)(OVCTUDec *const, struct OVBuffInfo, uint8_t, uint8_t, uint8_t, uint8_t, OVMV *, OVMV *, uint8_t, uint8_t, uint8_t);
 static dmvr_fn g_dmvr_inner;
 static gbuf g_dmvr_log = { .type = T_I32 };         /* per call: x, y (picture, luma), log2 w, log2 h, mv0 in, mv1 in, mv0 out, mv1 out */
-static size_t g_dmvr_pos;                           /* shim pass: next entry of the reference pass's log */
-static int g_pass_shim;
+static __thread size_t g_dmvr_pos;                  /* shim pass: next entry of the reference pass's log (per frame thread: set to the picture's first call) */
+static int g_pass_shim;                             /* 0 reference slots, 1 installed slots record-only, 2 device half on dry frames, 3 live on the GPU */
+static int g_threads;                               /* "threads N": frame threads of the device / live pass (0: the one-thread loop of the fixtures) */
 static int g_tile_cols = 1, g_tile_rows = 1;         /* "tiles C R": C x R rect entries per picture, decoded one after the other on ONE OVCTUDec (slicedec.c:649-653) */
 static int g_isp_64x2;                              /* the reference's result for 64x2 ISP partitions is undefined (gen_golden.c, gen_isp) */
 
@@ -84,7 +94,8 @@ gp_dmvr(OVCTUDec *const c, struct OVBuffInfo dst, uint8_t x0, uint8_t y0, uint8_
 {
     const int32_t in[8] = { (c->ctb_x << 7) + x0, (c->ctb_y << 7) + y0, l2w, l2h, mv0->x, mv0->y, mv1->x, mv1->y };
     const uint8_t r = g_dmvr_inner(c, dst, x0, y0, l2w, l2h, mv0, mv1, ref_idx0, ref_idx1, apply_bdof);
-    if (g_pass_shim == 2) gp_event(GP_EV_DMVR_SLOT, in[0], in[1]);
+    if (g_pass_shim == 2 && !g_threads) gp_event(GP_EV_DMVR_SLOT, in[0], in[1]);
+    if (g_pass_shim == 3) return r;                 /* live: what the installed slot returned; the device delivers the refined vectors */
     if (!g_pass_shim) {
         int32_t rec[12];
         memcpy(rec, in, sizeof(in));
@@ -107,7 +118,7 @@ static isp_fn g_isp_h_inner;
 static void
 gp_isp_h(OVCTUDec *const c, unsigned int x0, unsigned int y0, unsigned int l2w, unsigned int l2h, uint8_t mode, const struct ISPTUInfo *const tu)
 {
-    if (l2w == 6 && l2h == 3) g_isp_64x2++;
+    if (l2w == 6 && l2h == 3) __atomic_fetch_add(&g_isp_64x2, 1, __ATOMIC_RELAXED);
     g_isp_h_inner(c, x0, y0, l2w, l2h, mode, tu);
 }
 
@@ -121,9 +132,13 @@ static void gp_sao_first(OVCTUDec *const c, const struct RectEntryInfo *const e,
 static void gp_alf_line(OVCTUDec *const c, const struct RectEntryInfo *const e, uint16_t y)
 { gp_event(GP_EV_ALF_LINE, y, e->nb_ctu_h); g_alf_line_inner(c, e, y); gp_event(GP_EV_HOOK_END, GP_EV_ALF_LINE, y); }
 
+static void gp_t_attach(struct OVRCNCtx *const r, const OVFrame *const f, const struct RectEntryInfo *const e, uint8_t l2);
+static void gp_t_sao_first(OVCTUDec *const c, const struct RectEntryInfo *const e, uint16_t y);
+static void gp_t_alf_line(OVCTUDec *const c, const struct RectEntryInfo *const e, uint16_t y);
+
 /* test memory back-end of the device DPB: a "picture" is a number */
 static int fm_next = 0x1000;
-static int fm_alloc(void *u, int dev, int32_t w, int32_t h, ovhip_pic *pic) { (void)u; (void)dev; memset(pic, 0, sizeof(*pic)); pic->y = (uint16_t *)(uintptr_t)(fm_next += 0x100); pic->w = w; pic->h = h; pic->stride_y = w; pic->stride_c = w / 2; return 0; }
+static int fm_alloc(void *u, int dev, int32_t w, int32_t h, ovhip_pic *pic) { (void)u; (void)dev; memset(pic, 0, sizeof(*pic)); pic->y = (uint16_t *)(uintptr_t)__atomic_add_fetch(&fm_next, 0x100, __ATOMIC_RELAXED); pic->w = w; pic->h = h; pic->stride_y = w; pic->stride_c = w / 2; return 0; }
 static void fm_free(void *u, int dev, ovhip_pic *pic) { (void)u; (void)dev; (void)pic; }
 static int fm_copy_start(void *u, int dd, const ovhip_pic *dst, int sd, const ovhip_pic *src, void **ev) { (void)u; (void)dd; (void)dst; (void)sd; (void)src; *ev = NULL; return 0; }
 static int fm_copy_wait(void *u, int dev, void *ev) { (void)u; (void)dev; (void)ev; return 0; }
@@ -148,7 +163,11 @@ gp_rcn_init_functions(struct RCNFunctions *f, uint8_t ict_type, uint8_t lm_chrom
     if (g_pass_shim) rcn_init_functions_hip(f, ict_type, lm_chroma_enabled, vcolloc, lmcs_flag, bitdepth);
     g_dmvr_inner = f->rcn_dmvr_mv_refine; f->rcn_dmvr_mv_refine = &gp_dmvr;
     if (getenv("GP_TRACE")) { g_gpm_inner = f->rcn_gpm_b; f->rcn_gpm_b = &gp_gpm; }
-    if (g_pass_shim == 2) {
+    if (g_pass_shim >= 2 && g_threads) {
+        g_attach_inner = f->rcn_attach_frame_buff; f->rcn_attach_frame_buff = &gp_t_attach;
+        g_sao_first_inner = f->sao.rcn_sao_first_pix_rows; f->sao.rcn_sao_first_pix_rows = &gp_t_sao_first;
+        g_alf_line_inner = f->alf.rcn_alf_filter_line; f->alf.rcn_alf_filter_line = &gp_t_alf_line;
+    } else if (g_pass_shim == 2) {
         g_attach_inner = f->rcn_attach_frame_buff; f->rcn_attach_frame_buff = &gp_attach;
         g_sao_first_inner = f->sao.rcn_sao_first_pix_rows; f->sao.rcn_sao_first_pix_rows = &gp_sao_first;
         g_alf_line_inner = f->alf.rcn_alf_filter_line; f->alf.rcn_alf_filter_line = &gp_alf_line;
@@ -411,7 +430,7 @@ gp_new_ctudec(const struct gp_seq *s)
 }
 
 /* ------------------------------------------------------------------------------------------------ the stream */
-#define GP_MAX_PIC 9
+#define GP_MAX_PIC 257                                /* I + 32 GOPs of 8 */
 struct gp_pic_desc { int poc, slice_type, qp, l0[2], n0, l1[2], n1, tmvp, col_from_l0, lmcs; };
 
 struct gp_out {
@@ -421,6 +440,17 @@ struct gp_out {
     gbuf sao, alf, tab[5], luts, offs, refmap, pflags;
 };
 
+/* What the reference pass leaves behind for the passes that run on frame threads: the picture's slice data, its picture / slice
+ * header (own copies: pic_headers draws from the seeded generator, which only the main thread may touch), its first DMVR call in
+ * the log, and the decoded picture itself (frame + both collocated motion planes) as the thing to compare with. */
+struct gp_kept {
+    uint8_t *payload;
+    OVPH ph; OVSH sh; OVNVCLCtx nvcl; OVPS ps;
+    size_t dm0, dm1;
+    OVPicture *ref_pic;                            /* reference pass */
+    OVPicture *pic;                                /* threaded pass */
+};
+static struct gp_kept *g_kept;
 static uint8_t *g_payload;
 static size_t g_payload_bytes = 1 << 20;           /* slice data per picture: 1 MiB covers 1024x1024 many times over; "size" scales it */
 #define GP_PAYLOAD g_payload_bytes
@@ -457,6 +487,7 @@ run_stream(struct gp_seq *s, const struct gp_pic_desc *desc, int n_pic, uint32_t
     for (int k = 0; k < n_pic; ++k) {
         const struct gp_pic_desc *d = &desc[k];
         g_seed = seed + 977 * k;
+        if (g_threads && !g_pass_shim && posix_memalign((void **)&g_payload, 64, GP_PAYLOAD)) abort();      /* kept: the frame threads parse the same bytes */
         /* slice data: seeded bytes; the first byte keeps the arithmetic decoder's start condition (vcl_cabac.c:960) */
         for (size_t i = 0; i < GP_PAYLOAD; ++i) g_payload[i] = (uint8_t)(rnd32() >> 7);
         g_payload[0] &= 0x7f;
@@ -465,6 +496,11 @@ run_stream(struct gp_seq *s, const struct gp_pic_desc *desc, int n_pic, uint32_t
         OVPicture *l1[2] = { d->n1 > 0 ? pics[d->l1[0]] : NULL, d->n1 > 1 ? pics[d->l1[1]] : NULL };
         gp_set_refs(pics[k], l0, d->n0, l1, d->n1, d->tmvp, d->col_from_l0);
         pic_headers(s, d->slice_type, d->qp, d->n0, d->n1, d->tmvp, d->col_from_l0, d->lmcs);
+        if (g_threads && !g_pass_shim) {
+            struct gp_kept *kp = &g_kept[k];
+            kp->payload = g_payload; kp->ph = s->ph; kp->sh = s->sh; kp->nvcl = s->nvcl; kp->nvcl.ph = &kp->ph; kp->nvcl.sh = &kp->sh;
+            kp->ref_pic = pics[k];
+        }
         s->ps.ph = NULL; s->ps.sh = NULL;               /* new headers in the same structs */
         if (decinit_update_params(&s->ps, &s->nvcl) < 0) { fprintf(stderr, "gen_pipe: decinit_update_params failed\n"); exit(1); }
         /* one rect entry per tile, each with its own stretch of the slice data (decinit_set_entry_points, dec_init.c:320-366) */
@@ -486,8 +522,10 @@ run_stream(struct gp_seq *s, const struct gp_pic_desc *desc, int n_pic, uint32_t
         ovdpb_report_decoded_frame(pics[k]);
         if ((size_t)(c->cabac_ctx ? 0 : 0)) {}
         const size_t dm1 = g_pass_shim ? g_dmvr_pos : g_dmvr_log.n / 12;
-        fprintf(stderr, "  picture %d: POC %d %s qp %d, %zu DMVR calls\n", k, d->poc, d->slice_type == 2 ? "I" : d->slice_type == 1 ? "P" : "B", d->qp, dm1 - dm0);
+        if (g_threads && !g_pass_shim) { g_kept[k].dm0 = dm0; g_kept[k].dm1 = dm1; }
+        if (!g_threads || n_pic <= 9) fprintf(stderr, "  picture %d: POC %d %s qp %d, %zu DMVR calls\n", k, d->poc, d->slice_type == 2 ? "I" : d->slice_type == 1 ? "P" : "B", d->qp, dm1 - dm0);
         if (g_time_only) { if (g_pass_shim && !g_null_shim) { ovhip_shim_flush_pending(c); if (ovhip_shim_last_error(c)) { fprintf(stderr, "gen_pipe: picture %d: the shim latched %d\n", k, ovhip_shim_last_error(c)); exit(1); } } continue; }
+        if (!g_pass_shim && g_threads) continue;            /* the picture itself is kept (g_kept[k].ref_pic) */
         if (!g_pass_shim) {
             const OVFrame *f = pics[k]->frame;
             gbuf_push(&out->frames, f->data[0], (size_t)s->w * s->h);
@@ -544,6 +582,182 @@ run_stream(struct gp_seq *s, const struct gp_pic_desc *desc, int n_pic, uint32_t
     if (g_pass_shim == 2) { ovhip_frame_set_trace(NULL, NULL); ovhip_shim_release(c); ovhip_shim_set_dpb(NULL); ovhip_dpb_destroy(dpb); }
 }
 
+
+/* ------------------------------------------------------------------------------------------------ frame threads (device / live passes)
+ * What ovdec.c:188-248 + ovthreads.c do for the reference: N sub-decoders, each with its own OVSliceDec and OVCTUDec; the next picture
+ * in decoding order goes to the next free one; a picture's readers wait for its CTU rows (dpb.c:1242-1323). */
+static void
+gp_synchro(const OVPicture *const ref_pic, int tl_ctu_x, int tl_ctu_y, int br_ctu_x, int br_ctu_y)
+{
+    /* ovdpb_synchro_ref_decoded_ctus (dpb.c:1242-1270; static there): wait until the reported-rows mask covers the rectangle */
+    const struct PicDecodedCtusInfo *dc = &ref_pic->decoded_ctus;
+    pthread_mutex_lock(dc->ref_mtx);
+    for (;;) {
+        int ok = 1;
+        for (int y = tl_ctu_y; y <= br_ctu_y && ok; ++y)
+            for (int x = tl_ctu_x; x <= br_ctu_x && ok; ++x) ok = (int)((dc->mask[y][x >> 6] >> (x & 63)) & 1);
+        if (ok) break;
+        pthread_cond_wait(dc->ref_cnd, dc->ref_mtx);
+    }
+    pthread_mutex_unlock(dc->ref_mtx);
+}
+
+struct gp_thread {
+    pthread_t th; int id;
+    struct gp_seq *s; const struct gp_pic_desc *desc; int n_pic;
+    OVSliceDec sl; OVCTUDec *c;
+    double t_busy, t_hooks;                     /* seconds with a picture in hand / of them inside the row-end and attach hooks (device waits, flush) */
+    int n_done, err, frames_differing;
+    uint64_t samples_differing, mv_cells_differing, mv_cells_compared;
+};
+static int g_next_pic;
+static int *g_readers_left;                     /* pictures still to read picture k (+ 1: its own comparison) */
+static __thread struct gp_thread *tls_thread;
+
+static void gp_t_attach(struct OVRCNCtx *const r, const OVFrame *const f, const struct RectEntryInfo *const e, uint8_t l2)
+{ const double t0 = gp_now(); g_attach_inner(r, f, e, l2); if (tls_thread) tls_thread->t_hooks += gp_now() - t0; }
+static void gp_t_sao_first(OVCTUDec *const c, const struct RectEntryInfo *const e, uint16_t y)
+{ const double t0 = gp_now(); g_sao_first_inner(c, e, y); if (tls_thread) tls_thread->t_hooks += gp_now() - t0; }
+static void gp_t_alf_line(OVCTUDec *const c, const struct RectEntryInfo *const e, uint16_t y)
+{ const double t0 = gp_now(); g_alf_line_inner(c, e, y); if (tls_thread) tls_thread->t_hooks += gp_now() - t0; }
+
+/* the decoder dropped its last reference to the frame (ovframe_unref reaching zero): the one-line call INTEGRATION.md section 3 adds */
+static void
+gp_reader_done(int k)
+{
+    if (__atomic_sub_fetch(&g_readers_left[k], 1, __ATOMIC_ACQ_REL) == 0 && g_pass_shim == 3) ovhip_shim_frame_released(g_kept[k].pic->frame);
+}
+
+static void
+gp_compare(struct gp_thread *t, const struct gp_seq *s, int k)
+{
+    const OVPicture *a = g_kept[k].pic, *b = g_kept[k].ref_pic;
+    uint64_t nd = 0, nm = 0, nc = 0;
+    if (g_pass_shim == 3) {
+        for (int p = 0; p < 3; ++p) {
+            const size_t n = (size_t)(p ? s->w / 2 : s->w) * (size_t)(p ? s->h / 2 : s->h);
+            const uint16_t *x = (const uint16_t *)a->frame->data[p], *y = (const uint16_t *)b->frame->data[p];
+            if (memcmp(x, y, n * 2)) for (size_t i = 0; i < n; ++i) nd += x[i] != y[i];
+        }
+    }
+    /* the collocated motion field as its readers see it (tmvp_store_mv, drv_lines.c:270-330; load_ctb_tmvp, drv_mvp.c:298-345): per CTU 32
+     * direction words (column of 4-sample units -> bit 1 + row) and 16 x 16 cells of 8x8 samples, a cell being meaningful when the
+     * direction bit of its top-left unit is set.  Cells whose bit is clear hold whatever the OVCTUDec's CTU-local array held before --
+     * another picture's vectors, which depend on the pictures that OVCTUDec happened to decode -- and nobody reads them. */
+    const size_t n_ctb = (size_t)s->nb_ctb_w * s->nb_ctb_h;
+    const int pln_stride = 16 * s->nb_ctb_w;
+    for (int l = 0; l < 2; ++l) {
+        const struct MVPlane *pa = l ? &a->mv_plane1 : &a->mv_plane0, *pb = l ? &b->mv_plane1 : &b->mv_plane0;
+        nm += memcmp(pa->dirs, pb->dirs, n_ctb * 32 * 8) != 0;
+        for (int cy = 0; cy < s->nb_ctb_h; ++cy) for (int cx = 0; cx < s->nb_ctb_w; ++cx) {
+            const uint64_t *dirs = pb->dirs + (size_t)(cx + cy * s->nb_ctb_w) * 32;
+            for (int uy = 0; uy < 16; ++uy) for (int ux = 0; ux < 16; ++ux) {
+                if (!((dirs[2 * ux] >> (2 * uy + 1)) & 1)) continue;          /* vfield: bit 0 is the row above the CTU */
+                const size_t i = (size_t)(cx + cy * pln_stride) * 16 + (size_t)uy * pln_stride + ux;
+                const int df = pa->mvs[i].x != pb->mvs[i].x || pa->mvs[i].y != pb->mvs[i].y || pa->mvs[i].ref_idx != pb->mvs[i].ref_idx;
+                if (df && nm < 8 && getenv("GP_TRACE_MV")) fprintf(stderr, "    pic %d list %d cell %zu: (%d, %d, ref %d) vs reference (%d, %d, ref %d)\n", k, l, i, pa->mvs[i].x, pa->mvs[i].y, pa->mvs[i].ref_idx, pb->mvs[i].x, pb->mvs[i].y, pb->mvs[i].ref_idx);
+                nm += df; nc++;
+            }
+        }
+    }
+    t->samples_differing += nd; t->mv_cells_differing += nm; t->mv_cells_compared += nc; t->frames_differing += nd != 0;
+    if (nd || nm) fprintf(stderr, "gen_pipe: picture %d (POC %d): %llu samples, %llu collocated-motion entries differ from the reference pass\n", k, a->poc,
+                          (unsigned long long)nd, (unsigned long long)nm);
+}
+
+static void
+gp_decode_kept(struct gp_thread *t, int k)
+{
+    struct gp_kept *kp = &g_kept[k];
+    const struct gp_pic_desc *d = &t->desc[k];
+    memset(&kp->ps, 0, sizeof(kp->ps));
+    if (decinit_update_params(&kp->ps, &kp->nvcl) < 0) { fprintf(stderr, "gen_pipe: decinit_update_params failed\n"); exit(1); }
+    const int n_entries = g_tile_cols * g_tile_rows;
+    const size_t per_entry = (GP_PAYLOAD / n_entries) & ~(size_t)63;
+    for (int i = 0; i <= n_entries; ++i) kp->ps.sh_info.rbsp_entry[i] = kp->payload + i * per_entry;
+    t->sl.pic = kp->pic; t->sl.active_params = &kp->ps; t->sl.slice_type = d->slice_type;
+    slicedec_init_lines(&t->sl, &kp->ps);
+    g_dmvr_pos = kp->dm0;
+    for (int i = 0; i < n_entries; ++i) {
+        slicedec_update_entry_decoder(&t->sl, t->c);
+        slicedec_decode_rect_entry(&t->sl, t->c, &kp->ps, i);
+    }
+    ovdpb_report_decoded_frame(kp->pic);
+    if (g_pass_shim == 2 && g_dmvr_pos != kp->dm1) { fprintf(stderr, "gen_pipe: picture %d made %zu DMVR calls, the reference pass %zu\n", k, g_dmvr_pos - kp->dm0, kp->dm1 - kp->dm0); exit(1); }
+    if (g_pass_shim == 2) ovhip_shim_flush_pending(t->c);
+    const int e = ovhip_shim_last_error(t->c);
+    if (e) { fprintf(stderr, "gen_pipe: picture %d: the shim latched %d\n", k, e); if (!t->err) t->err = e; }
+    gp_compare(t, t->s, k);
+    for (int i = 0; i < d->n0; ++i) gp_reader_done(d->l0[i]);
+    for (int i = 0; i < d->n1; ++i) gp_reader_done(d->l1[i]);
+    gp_reader_done(k);
+    t->n_done++;
+}
+
+static void *
+gp_worker(void *arg)
+{
+    struct gp_thread *t = (struct gp_thread *)arg;
+    tls_thread = t;
+    for (;;) {
+        const int k = __atomic_fetch_add(&g_next_pic, 1, __ATOMIC_RELAXED);
+        if (k >= t->n_pic) break;
+        const double t0 = gp_now();
+        gp_decode_kept(t, k);
+        t->t_busy += gp_now() - t0;
+    }
+    return NULL;
+}
+
+/* returns the wall time of the pass; the per-thread sums land in *tot */
+static double
+run_stream_threads(struct gp_seq *s, const struct gp_pic_desc *desc, int n_pic, int n_threads, struct gp_thread *tot)
+{
+    ovhip_dpb *dpb = NULL;
+    if (g_pass_shim == 2) {
+        ovhip_dpb_ops ops;
+        memset(&ops, 0, sizeof(ops));
+        ops.pic_alloc = fm_alloc; ops.pic_free = fm_free; ops.copy_start = fm_copy_start; ops.copy_wait = fm_copy_wait;
+        if (ovhip_dpb_create_ex(&dpb, 1, &ops)) { fprintf(stderr, "gen_pipe: ovhip_dpb_create_ex failed\n"); exit(1); }
+        ovhip_shim_set_dpb(dpb);
+    }
+    /* the pictures exist as objects before any thread runs (the decoder's DPB makes them when it reads the slice header: ovdpb_init_picture) */
+    g_readers_left = calloc(n_pic, sizeof(int));
+    for (int k = 0; k < n_pic; ++k) {
+        const struct gp_pic_desc *d = &desc[k];
+        OVPicture *p = g_kept[k].pic = gp_new_picture(s, d->poc);
+        atomic_init(&p->idx_function, 1);
+        p->ovdpb_frame_synchro[1] = gp_synchro;
+        OVPicture *l0[2] = { d->n0 > 0 ? g_kept[d->l0[0]].pic : NULL, d->n0 > 1 ? g_kept[d->l0[1]].pic : NULL };
+        OVPicture *l1[2] = { d->n1 > 0 ? g_kept[d->l1[0]].pic : NULL, d->n1 > 1 ? g_kept[d->l1[1]].pic : NULL };
+        gp_set_refs(p, l0, d->n0, l1, d->n1, d->tmvp, d->col_from_l0);
+        g_readers_left[k] += 1;
+        for (int i = 0; i < d->n0; ++i) g_readers_left[d->l0[i]]++;
+        for (int i = 0; i < d->n1; ++i) g_readers_left[d->l1[i]]++;
+    }
+    struct gp_thread *th = calloc(n_threads, sizeof(*th));
+    for (int i = 0; i < n_threads; ++i) {
+        th[i].id = i; th[i].s = s; th[i].desc = desc; th[i].n_pic = n_pic;
+        gp_alloc_lines(&th[i].sl, s);
+        th[i].c = gp_new_ctudec(s);
+    }
+    g_next_pic = 0;
+    const double t0 = gp_now();
+    for (int i = 0; i < n_threads; ++i) if (pthread_create(&th[i].th, NULL, gp_worker, &th[i])) { perror("pthread_create"); exit(1); }
+    for (int i = 0; i < n_threads; ++i) pthread_join(th[i].th, NULL);
+    const double wall = gp_now() - t0;
+    memset(tot, 0, sizeof(*tot));
+    for (int i = 0; i < n_threads; ++i) {
+        tot->t_busy += th[i].t_busy; tot->t_hooks += th[i].t_hooks; tot->n_done += th[i].n_done; tot->frames_differing += th[i].frames_differing;
+        tot->samples_differing += th[i].samples_differing; tot->mv_cells_differing += th[i].mv_cells_differing; tot->mv_cells_compared += th[i].mv_cells_compared;
+        if (th[i].err && !tot->err) tot->err = th[i].err;
+        ovhip_shim_release(th[i].c);                  /* the frame thread's device context and job; the last one takes the shim's DPB with it */
+    }
+    if (g_pass_shim == 2) { ovhip_shim_set_dpb(NULL); ovhip_dpb_destroy(dpb); }
+    free(th);
+    return wall;
+}
+
 /* a crash inside the reference on a stream it was never written for (the parse is a random walk): say where, exit 3 */
 static void
 gp_on_segv(int sig)
@@ -561,13 +775,16 @@ gp_main(int argc, char **argv)
 {
     signal(SIGSEGV, gp_on_segv); signal(SIGBUS, gp_on_segv); signal(SIGFPE, gp_on_segv); signal(SIGABRT, gp_on_segv);
     const char *dir = argc > 1 ? argv[1] : "../tests/golden";
-    int want_shim = 0, want_dev = 0, want_time = 0, variant = 0, W = 416, H = 240, dqp = 0, n_pic = 5;
+    int want_shim = 0, want_dev = 0, want_live = 0, want_time = 0, variant = 0, W = 416, H = 240, dqp = 0, n_pic = 5;
     uint32_t seed = 0x266 + 31337;
     const char *name = "pipe";
-    /* gen_pipe <dir> [shim | device | simd] [name <fixture name>] [seed <n>] [variant <0|1>] [qp <delta on every picture's QP>] [size <w> <h>] [pics <1..9>] [time] */
+    /* gen_pipe <dir> [shim | device | live | simd] [threads <n>] [name <fixture name>] [seed <n>] [variant <0|1>] [qp <delta on every picture's QP>]
+     *          [size <w> <h>] [pics <1..257>] [time] */
     for (int i = 2; i < argc; ++i) {
         if (!strcmp(argv[i], "shim")) want_shim = 1;
         else if (!strcmp(argv[i], "device")) want_shim = want_dev = 1;
+        else if (!strcmp(argv[i], "live")) want_live = 1;      /* the shim on the real device, on frame threads; compares in process, prints a JSON line */
+        else if (!strcmp(argv[i], "threads") && i + 1 < argc) g_threads = atoi(argv[++i]);
         else if (!strcmp(argv[i], "simd")) g_simd = 1;        /* the reference pass through the reference's SSE4.1 / AVX2 back-end (ref_common.h) */
         else if (!strcmp(argv[i], "name") && i + 1 < argc) name = argv[++i];
         else if (!strcmp(argv[i], "seed") && i + 1 < argc) seed = (uint32_t)strtoul(argv[++i], NULL, 0);
@@ -581,11 +798,14 @@ gp_main(int argc, char **argv)
         else { fprintf(stderr, "gen_pipe: unknown argument %s\n", argv[i]); return 2; }
     }
     if (W % 8 || H % 8 || W < 136 || H < 136 || W > 4096 || H > 2304 || n_pic < 1 || n_pic > GP_MAX_PIC) { fprintf(stderr, "gen_pipe: size / pics\n"); return 2; }
+    if (want_live && !g_threads) g_threads = 1;
+    if (g_threads < 0 || g_threads > 64 || (g_threads && !want_live && !want_dev) || (g_threads && want_time)) { fprintf(stderr, "gen_pipe: threads\n"); return 2; }
+    if (g_threads) g_kept = calloc(n_pic, sizeof(*g_kept));
     while (g_payload_bytes < (size_t)W * H * 2) g_payload_bytes <<= 1;          /* 16 bits per sample: far above any slice's need */
-    if (posix_memalign((void **)&g_payload, 64, GP_PAYLOAD)) abort();
+    if (!g_threads && posix_memalign((void **)&g_payload, 64, GP_PAYLOAD)) abort();
     /* decoding order of a hierarchical GOP of 8: I0, B8 (two lists to the I picture), B4 (between them: DMVR / BDOF / SMVD have a past
      * and a future reference, TMVP from B8), B2, P6; with "pics 9" the rest of the GOP: b1, b3, b5, b7 */
-    struct gp_pic_desc gop[GP_MAX_PIC + 1] = {
+    static struct gp_pic_desc gop[GP_MAX_PIC + 1] = {
         { .poc = 0, .slice_type = 2, .qp = 30, .lmcs = 1 },
         { .poc = 8, .slice_type = 0, .qp = 33, .l0 = { 0 }, .n0 = 1, .l1 = { 0 }, .n1 = 1, .tmvp = 0, .col_from_l0 = 1, .lmcs = 1 },
         { .poc = 4, .slice_type = 0, .qp = 35, .l0 = { 0, 1 }, .n0 = 2, .l1 = { 1, 0 }, .n1 = 2, .tmvp = 1, .col_from_l0 = 0, .lmcs = 1 },
@@ -596,6 +816,19 @@ gp_main(int argc, char **argv)
         { .poc = 5, .slice_type = 0, .qp = 38, .l0 = { 2, 3 }, .n0 = 2, .l1 = { 4, 1 }, .n1 = 2, .tmvp = 1, .col_from_l0 = 0, .lmcs = 1 },
         { .poc = 7, .slice_type = 0, .qp = 38, .l0 = { 4, 2 }, .n0 = 2, .l1 = { 1, 4 }, .n1 = 2, .tmvp = 1, .col_from_l0 = 1, .lmcs = 1 },
     };
+    /* "pics" beyond 9: further GOPs of 8 with the same structure, each from the key picture before it: picture j (1..8) of GOP g is
+     * picture j of the table with its references moved along -- entry 0 (the I picture) becomes the previous GOP's key picture, entry
+     * e > 0 becomes e + 8 g -- and 8 g added to its POC; key pictures after the first have a motion field to take TMVP from */
+    for (int k = 9; k < n_pic; ++k) {
+        const int g = (k - 1) / 8, j = (k - 1) % 8 + 1;
+        gop[k] = gop[j];
+        gop[k].poc += 8 * g;
+        for (int i = 0; i < 2; ++i) {
+            gop[k].l0[i] = gop[j].l0[i] ? gop[j].l0[i] + 8 * g : 1 + 8 * (g - 1);
+            gop[k].l1[i] = gop[j].l1[i] ? gop[j].l1[i] + 8 * g : 1 + 8 * (g - 1);
+        }
+        if (j == 1) gop[k].tmvp = 1;
+    }
     for (int k = 0; k < n_pic; ++k) gop[k].qp += dqp;
     struct gp_out out;
     memset(&out, 0, sizeof(out));
@@ -604,7 +837,30 @@ gp_main(int argc, char **argv)
     for (int t = 0; t < 5; ++t) out.tab[t].type = T_I16;
     shim_stream_init(&out.S); shim_stream_init(&out.S2);
 
-    struct gp_seq seq;
+    static struct gp_seq seq;
+    if (g_threads) {
+        /* reference pass, then ONE pass on frame threads -- dry frames ("device threads N": the shim, the DPB's state machine and this
+         * harness under several threads, no GPU) or live -- over the slice data and headers the reference pass kept */
+        g_seed = 0x266 + 4242;
+        seq_init(&seq, W, H, variant);
+        fprintf(stderr, "gen_pipe: reference pass\n");
+        const double tr0 = gp_now();
+        run_stream(&seq, gop, n_pic, seed, &out);
+        const double t_ref = gp_now() - tr0;
+        if (g_isp_64x2) { fprintf(stderr, "gen_pipe: the stream holds %d 64x2 ISP partitions (reference result undefined): pick another seed\n", g_isp_64x2); return 1; }
+        g_pass_shim = want_live ? 3 : 2;
+        fprintf(stderr, "gen_pipe: %s pass, %d frame thread%s\n", want_live ? "live" : "device (dry)", g_threads, g_threads > 1 ? "s" : "");
+        struct gp_thread tot;
+        const double wall = run_stream_threads(&seq, gop, n_pic, g_threads, &tot);
+        printf("{\"mode\": \"%s\", \"frame_threads\": %d, \"pictures\": %d, \"width\": %d, \"height\": %d, \"seconds\": %.6f, \"pictures_per_second\": %.3f, "
+               "\"pictures_decoded\": %d, \"shim_error\": %d, \"frames_differing\": %d, \"samples_differing\": %llu, \"collocated_motion_entries_differing\": %llu, \"collocated_motion_entries_compared\": %llu, "
+               "\"dmvr_calls\": %zu, \"thread_seconds_with_a_picture\": %.6f, \"thread_seconds_in_row_end_and_attach_hooks\": %.6f, "
+               "\"reference_pass_seconds_inside_slicedec\": %.6f, \"reference_pass_seconds\": %.6f}\n",
+               want_live ? "live" : "device_dry_threads", g_threads, n_pic, W, H, wall, n_pic / wall, tot.n_done, tot.err, tot.frames_differing,
+               (unsigned long long)tot.samples_differing, (unsigned long long)tot.mv_cells_differing, (unsigned long long)tot.mv_cells_compared, g_dmvr_log.n / 12, tot.t_busy, tot.t_hooks,
+               g_decode_seconds_pass[0], t_ref);
+        return (tot.err || tot.samples_differing || tot.mv_cells_differing || tot.n_done != n_pic) ? 1 : 0;
+    }
     for (g_pass_shim = 0; g_pass_shim <= want_shim + want_dev; ++g_pass_shim) {
         g_seed = 0x266 + 4242;
         g_dmvr_pos = 0;

@@ -830,6 +830,13 @@ ovhip_shim_apply_tmvp_cells(OVCTUDec *c, const ovhip_tmvp_cell *cells, size_t n_
     const struct InterDRVCtx *ic = &c->drv_ctx.inter_ctx;
     const struct MVPlane *pl0 = ic->tmvp_ctx.plane0, *pl1 = ic->tmvp_ctx.plane1;
     if (!pl0 || !pl1 || !pl0->mvs || !pl1->mvs) return OVHIP_OK;         /* the picture keeps no motion field */
+    if (getenv("OVVC_HIP_TRACE_TMVP")) {
+        size_t nz = 0, nn = 0;
+        for (size_t i = 0; i < n_entries; ++i) { nn += cells[i].cell != OVHIP_TMVP_NONE; nz += cells[i].cell != OVHIP_TMVP_NONE && !cells[i].mv0x && !cells[i].mv0y && !cells[i].mv1x && !cells[i].mv1y; }
+        fprintf(stderr, "    tmvp patch ctudec %p: %zu entries, %zu used, %zu of them all-zero; first used:", (void *)c, n_entries, nn, nz);
+        for (size_t i = 0, k = 0; i < n_entries && k < 3; ++i) if (cells[i].cell != OVHIP_TMVP_NONE) { fprintf(stderr, " [%u: %d %d %d %d]", cells[i].cell, cells[i].mv0x, cells[i].mv0y, cells[i].mv1x, cells[i].mv1y); ++k; }
+        fprintf(stderr, "\n");
+    }
     for (size_t i = 0; i < n_entries; ++i) {
         const ovhip_tmvp_cell *q = &cells[i];
         if (q->cell == OVHIP_TMVP_NONE) continue;
@@ -1097,8 +1104,10 @@ dmvr_rows_step(struct hip_entry *e, OVCTUDec *c, int final)
     if (done < 0) { latch(e, (int)done, "ovhip_frame_dmvr_rows"); return; }
     if ((size_t)done > e->dmvr_done) {
         size_t n = 0;
-        const ovhip_tmvp_cell *cells = ovhip_job_tmvp_cells(ovhip_frame_job(e->fr), &n);
-        if (cells && n >= 4 * (size_t)done) ovhip_shim_apply_tmvp_cells(c, cells + 4 * e->dmvr_done, 4 * ((size_t)done - e->dmvr_done));
+        ovhip_job *job = ovhip_frame_job(e->fr);                 /* (NULL: a dry frame -- nothing computes, nothing to patch) */
+        const ovhip_tmvp_cell *cells = job ? ovhip_job_tmvp_cells(job, &n) : NULL;
+        if (job && (!cells || n < 4 * (size_t)done)) { latch(e, OVHIP_EINVAL, "the eager DMVR pass delivered no collocated-motion entries"); return; }
+        if (cells) ovhip_shim_apply_tmvp_cells(c, cells + 4 * e->dmvr_done, 4 * ((size_t)done - e->dmvr_done));
         e->dmvr_done = (size_t)done;
     }
     if (!final && now > (size_t)done) {
@@ -1313,6 +1322,10 @@ begin_picture(struct hip_entry *e, const OVFrame *f, const struct RectEntryInfo 
         return;
     }
     e->frame = f;
+    /* the CTU size is needed by the first row-end hook already (dmvr_rows_step -> the plane entries of the row's refined units): found by
+     * the live decode on several frame threads -- a frame thread whose FIRST picture had DMVR units in CTU row 0 asked for the entries
+     * with log2_ctu_s == 0, got none, and left that row's collocated motion vectors unrefined (params_alloc used to be the only writer) */
+    if (e->key->part_ctx) e->log2_ctu = e->key->part_ctx->log2_ctu_s;
     e->ctus_left = nw * nh;
     e->err = 0;
     e->n_refs = 0;
