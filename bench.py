@@ -116,10 +116,6 @@ def main():
                     help="skip the one-picture-in-flight survey and the variants: every launch of the process then runs in the timed configuration "
                          "(what tools/profile_round.sh traces, so that rocprofv3's per-kernel averages are of that configuration)")
     ap.add_argument("--in-flight", type=int, default=16, help="frame threads (= pictures in flight) per device: pthreads of the C stream driver, one HIP stream each")
-    ap.add_argument("--priority-readers", type=int, default=0, help="> 0: pictures referenced by at least this many later pictures run on a high-priority stream")
-    ap.add_argument("--leaf-low", type=int, default=0, help="1: pictures nobody references run on a low-priority stream")
-    ap.add_argument("--upload-ahead", type=int, default=0, help="uploader threads run the prepare + upload half of the next N pictures' flushes ahead of the frame threads (0: every frame thread uploads its own picture when it takes it)")
-    ap.add_argument("--exec-slots", type=int, default=0, help="execution gate of the device DPB: pictures per device between 'references done' and 'complete' at a time, oldest first (0: no gate)")
     ap.add_argument("--contents", type=int, default=2, help="distinct recorded B pictures (seeds)")
     ap.add_argument("--intra-frac", type=float, default=0.12, help="share of intra CUs in the B pictures")
     ap.add_argument("--gop", type=int, default=32, help="GOP size (hierarchical B, JVET random-access decoding order)")
@@ -155,9 +151,7 @@ def main():
                          "before their turn in decoding order (0: strictly in order)")
     ap.add_argument("--ipic-workers", type=int, default=0, help="persistent workers of an I picture's ordered pass (0: the library's default, 4 x compute units)")
     ap.add_argument("--bpic-workers", type=int, default=0, help="persistent workers of a B picture's ordered pass (0: the library's default)")
-    ap.add_argument("--intra-priority", type=int, default=0, help="HIP stream priority of that thread (0 default, -1 high, 1 low)")
     ap.add_argument("--ahead-own-queue", type=int, default=1, help="1: the look-ahead thread's stream gets a hardware queue no in-order thread's stream shares (probed at start)")
-    ap.add_argument("--ahead-chunk", type=int, default=0, help="ordered pass of the pictures that thread starts early: paced launches of this many items (0: as every picture)")
     args = ap.parse_args()
 
     import torch
@@ -209,8 +203,6 @@ def main():
     # ---- library objects: device DPB, pre-recorded jobs (R GOPs of stream positions, + the I / key pictures), stream drivers ----
     ctx0 = engine.Context(hip_devices[0])
     dpb = engine.Dpb(tuple(hip_devices))
-    if args.exec_slots:
-        dpb.lib.ovhip_dpb_set_exec_slots(dpb.h, args.exec_slots)
     # (with several devices each may sit on a GOP of its own: a job shared by two GOPs that are in flight at once could be held by the
     # later one while the earlier one, which it waits for through the key pictures, needs it)
     R = max(2, args.job_rotation, L + 2)
@@ -287,10 +279,7 @@ def main():
     def new_stream(threads, output="none", flags=0, xfer=None, use_jobs=True, ahead=None):
         return engine.Stream(dpb, W, H, contents, jobs if use_jobs else [], threads_per_device=threads, flags=flags, output=OUT[output],
                              extra_stages=lv, rank=rank, xfer=xfer, intra_lookahead=(lookahead if ahead is None else ahead) if threads > 1 else 0,
-                             intra_stream_priority=args.intra_priority, ahead_chunk_items=args.ahead_chunk,
-                             ahead_own_queue=args.ahead_own_queue if threads > 1 else 0,
-                             priority_readers=args.priority_readers, leaf_low=args.leaf_low,
-                             upload_ahead=args.upload_ahead if use_jobs and not (flags & capi.STREAM_RECORD) else 0)
+                             ahead_own_queue=args.ahead_own_queue if threads > 1 else 0)
 
     # ---- multi-process exchange: the driver's comm thread calls back here, one call per transferred picture ----
     xfer = None
@@ -797,7 +786,7 @@ def main():
                        "dpb": {"device_pictures_allocated": int(dpb_stats.n_alloc), "begun": int(dpb_stats.n_begin), "recycled": int(dpb_stats.n_recycled),
                                "peer_copies": int(dpb_stats.n_copies), "waits_for_a_reference": int(dpb_stats.n_waits)},
                        "numa_binding": numa,
-                       "pictures_in_flight_per_gpu": S, "execution_slots_per_gpu": args.exec_slots or None, "pictures_uploaded_ahead": args.upload_ahead, "host_threads": S + (1 if lookahead else 0), "local_devices": L,
+                       "pictures_in_flight_per_gpu": S, "host_threads": S + (1 if lookahead else 0), "local_devices": L,
                        "intra_lookahead_pictures": lookahead,
                        "lookahead_thread_hw_queue": {"streams_replaced": q_moved, "in_order_streams_still_sharing_it": q_sharing} if lookahead else None,
                        "picture_assignment": "decoding order; a free frame thread (pthread, own HIP stream) takes the next picture of its device",

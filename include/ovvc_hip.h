@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define OVHIP_ABI_VERSION 6
+#define OVHIP_ABI_VERSION 7
 
 /* ---- error codes (negative, in the spirit of libovvc/overror.h:40-45) ---- */
 #define OVHIP_OK        0
@@ -667,11 +667,6 @@ typedef struct ovhip_ctx ovhip_ctx;
 int  ovhip_abi_version(void);
 /* stream: a hipStream_t the caller owns (e.g. torch's current stream) or NULL to create one. */
 int  ovhip_ctx_create(ovhip_ctx **out, int device, void *stream);
-/* stream == NULL: a new stream of the given priority (0: default; the runtime clamps to its range) */
-int  ovhip_ctx_create_prio(ovhip_ctx **out, int device, int stream_priority);
-/* from here on the context's launches go to a stream of another priority (level < 0 high, 0 the context's own, > 0 low); waits for
- * what is enqueued first: to be called between pictures */
-int  ovhip_ctx_use_priority(ovhip_ctx *ctx, int level);
 void ovhip_ctx_destroy(ovhip_ctx *ctx);
 /* 1 if the streams of the two (idle) contexts are served by the same hardware queue, 0 if not (measured: ~2 ms), < 0 error; and a
  * fresh stream for a context whose stream is in the wrong company (see ovvc_engine.hip) */
@@ -876,11 +871,6 @@ typedef struct ovhip_job_params {        /* picture-level side information; HOST
     /* != 0: wait_events are waited for ON THE HOST (hipEventSynchronize on the flushing thread, after the uploads have been
      * enqueued) instead of being put into the stream: before_launch without a callback into the caller's language. */
     uint32_t wait_on_host;
-    /* The ordered pass's flow launches of this picture: items per launch (0: the default -- ONE launch of persistent workers for the
-     * whole picture, ovhip_intra_flow_launch) and, != 0, the host waits for a launch before it issues the next.  A hardware queue runs the packets of the streams it serves in order: an I picture's pass
-     * as one multi-millisecond kernel holds up every stream that shares its queue; paced chunks let them in between.  For a
-     * picture nobody waits for yet (ovhip_stream_cfg.intra_lookahead). */
-    uint32_t flow_chunk_items, flow_paced;
     /* Workers of a flow launch (ovhip_intra_flow_launch: n_workers); 0: the default -- 6 per compute unit, and never more than twice the
      * picture's widest level (an I picture: ~256).  The flow launches that run at once (one per hardware queue: 4 for a HIP process)
      * should fit the device, 16 per compute unit of that kernel; a launch that had to be abandoned halves the default for the
@@ -893,6 +883,7 @@ typedef struct ovhip_job_stats {         /* what the last flush moved and launch
     uint32_t n_launches, n_h2d;
     uint32_t n_tb, n_mc, n_mcx, n_aff, n_edges_v, n_edges_h, n_regions, n_itasks, n_ilevels;
     uint32_t n_ordered_retries;          /* 1: ovhip_job_wait decoded the picture a second time, one launch per level (see there) */
+    uint32_t flow_shift;                 /* the device's default worker count is 6 x CUs >> this: + 1 per abandoned flow launch (max 4), - 1 per 512 clean ones */
     /* host wall time of the flush call by phase, microseconds: class split + parameter block; enqueueing the copies; the
      * before_launch callback + wait events (the frame thread waiting for its reference pictures); enqueueing the launches */
     uint32_t host_us_prepare, host_us_upload, host_us_wait, host_us_launch;
@@ -911,13 +902,6 @@ int  ovhip_job_bind(ovhip_job *job, ovhip_ctx *ctx);
  * caller's planar prediction for fused CIIP blends, or NULL.  All DEVICE pictures of the job's size. */
 int  ovhip_job_flush(ovhip_job *job, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs,
                      const ovhip_pic *intra, const ovhip_job_params *params);
-/* The host half of the job's next flush (class split, level sort, item list, staging block) and its uploads, NOW, on one of the
- * device's upload lanes instead of the picture's stream.  The next ovhip_job_flush with the same stages uploads nothing: it waits
- * for these uploads on the host just before it enqueues its launches.  Nothing of the job may be in flight and the recorder must
- * not change until that flush.  (ovhip_stream_cfg.upload_ahead: the stream driver's uploader threads run this ahead of the frame
- * threads, so that pictures which do not have to wait for reference pictures do not pay their upload on the path every later
- * picture waits for.) */
-int  ovhip_job_upload_ahead(ovhip_job *job, const ovhip_job_params *params);
 /* Waits for the flush.  If the ordered pass's flow launch gave up (bounded wait of a workgroup for its inputs: the launches of
  * several pictures can starve each other of compute-unit slots), the picture is decoded a second time right here with one
  * launch per level, from the recorder's arrays: ovhip_job_params' tables and the pictures passed to ovhip_job_flush must
@@ -1098,12 +1082,6 @@ int  ovhip_dpb_release(ovhip_dpb *d, const void *key);
 int  ovhip_dpb_lookup(ovhip_dpb *d, const void *key, int *home_dev, ovhip_pic *pic);
 /* Wakes every waiter with OVHIP_EREF and makes every later wait fail at once (decoder teardown after an error). */
 void ovhip_dpb_shutdown(ovhip_dpb *d);
-/* Execution gate (0 = off, default): at most `slots` pictures per device between "reference pictures done" and "complete"; of the
- * pictures waiting at the gate the one begun first goes first.  Frame threads can then hold MORE pictures than the device should
- * run at once -- their uploads and reference waits happen early, off the critical path of the pictures others wait for -- which is
- * what frame threads that parse are for in the reference (ovdec.c:188-248: a sub-decoder holds its picture through parse and
- * reconstruction).  Pictures without reference pictures do not take a slot.  ovhip_frame_submit enters and leaves. */
-void ovhip_dpb_set_exec_slots(ovhip_dpb *d, int slots);
 int  ovhip_dpb_get_stats(ovhip_dpb *d, ovhip_dpb_stats *out);
 
 /* ------------------------------------------------------------------------------------
@@ -1153,8 +1131,6 @@ typedef struct ovhip_frame_event {
 void ovhip_frame_set_trace(void (*sink)(void *user, const ovhip_frame_event *ev), void *user);    /* NULL: off */
 
 int  ovhip_frame_create(ovhip_dpb *dpb, int dev, int32_t w, int32_t h, ovhip_frame **out);
-/* stream_priority: of the frame's HIP stream (0 default, < 0 higher, > 0 lower); another priority = another hardware queue */
-int  ovhip_frame_create_ex(ovhip_dpb *dpb, int dev, int32_t w, int32_t h, int stream_priority, ovhip_frame **out);
 void ovhip_frame_destroy(ovhip_frame *f);
 ovhip_ctx      *ovhip_frame_ctx(ovhip_frame *f);
 ovhip_job      *ovhip_frame_job(ovhip_frame *f);
@@ -1265,18 +1241,8 @@ typedef struct ovhip_stream_cfg {
      * pictures before their turn in decoding order -- such a picture is a dependency chain of milliseconds (ordered pass) that
      * everything after it waits for; started early it runs beside the pictures before it.  One extra picture buffer, no latency. */
     int32_t intra_lookahead;
-    int32_t intra_stream_priority;         /* HIP stream priority of that thread's context (0 default, < 0 higher, > 0 lower)  */
-    int32_t ahead_chunk_items;             /* > 0: its pictures' ordered pass in paced launches of this many items (ovhip_job_params.flow_paced) */
     int32_t ahead_own_queue;               /* != 0: at creation, streams of in-order threads that share that thread's hardware queue are replaced
                                             * until none does (ovhip_ctx_shares_queue; ~2 ms per probe)                                     */
-    /* Stream priorities by a picture's place in the dependency graph (ovhip_ctx_use_priority).  priority_readers > 0: a picture that
-     * at least this many later pictures of the stream reference runs on a high-priority stream -- the low temporal layers of a
-     * random-access GOP, which everything else waits for; leaf_low != 0: a picture nobody references runs on a low-priority one. */
-    int32_t priority_readers;
-    int32_t leaf_low;
-    /* > 0 (pre-recorded jobs only): four uploader threads per device run ovhip_job_upload_ahead for the pictures up to this many
-     * places ahead of the next picture a frame thread will take, in decoding order */
-    int32_t upload_ahead;
 } ovhip_stream_cfg;
 
 typedef struct ovhip_stream_result {

@@ -17,7 +17,7 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libovvc_hip.so"
 
 # ---- constants (include/ovvc_hip.h) ----
-OVHIP_ABI_VERSION = 6
+OVHIP_ABI_VERSION = 7
 OVHIP_OK, OVHIP_ENODEV, OVHIP_ENOMEM, OVHIP_EINVAL, OVHIP_ELAUNCH, OVHIP_EUNSUP, OVHIP_EREF = 0, -1, -2, -3, -4, -5, -6
 DST_VII, DCT_VIII, DCT_II = 0, 1, 2
 TB_TR, TB_DC, TB_TS, TB_TS_RAW = 0, 1, 2, 3
@@ -199,7 +199,7 @@ class JobParams(C.Structure):
                 ("alf_chroma_coeff", C.c_void_p), ("alf_chroma_clip", C.c_void_p), ("alf_cc_coeff", C.c_void_p),
                 ("log2_ctu_s", C.c_int32), ("stages", C.c_uint32), ("wait_events", C.POINTER(C.c_void_p)), ("n_wait_events", C.c_uint32),
                 ("before_launch", C.c_void_p), ("before_launch_user", C.c_void_p), ("tmvp_cells", C.c_uint32), ("wait_on_host", C.c_uint32),
-                ("flow_chunk_items", C.c_uint32), ("flow_paced", C.c_uint32), ("flow_workers", C.c_uint32)]
+                ("flow_workers", C.c_uint32)]
 
 
 BEFORE_LAUNCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
@@ -209,7 +209,7 @@ class JobStats(C.Structure):
     _fields_ = [("h2d_bytes", C.c_uint64), ("d2h_bytes", C.c_uint64), ("n_launches", C.c_uint32), ("n_h2d", C.c_uint32),
                 ("n_tb", C.c_uint32), ("n_mc", C.c_uint32), ("n_mcx", C.c_uint32), ("n_aff", C.c_uint32),
                 ("n_edges_v", C.c_uint32), ("n_edges_h", C.c_uint32), ("n_regions", C.c_uint32),
-                ("n_itasks", C.c_uint32), ("n_ilevels", C.c_uint32), ("n_ordered_retries", C.c_uint32),
+                ("n_itasks", C.c_uint32), ("n_ilevels", C.c_uint32), ("n_ordered_retries", C.c_uint32), ("flow_shift", C.c_uint32),
                 ("host_us_prepare", C.c_uint32), ("host_us_upload", C.c_uint32), ("host_us_wait", C.c_uint32), ("host_us_launch", C.c_uint32)]
 
 
@@ -326,8 +326,7 @@ class StreamXfer(C.Structure):
 class StreamCfg(C.Structure):
     _fields_ = [("w", C.c_int32), ("h", C.c_int32), ("flags", C.c_uint32), ("threads_per_device", C.c_int32), ("output", C.c_int32),
                 ("window", Window), ("extra_stages", C.c_uint32), ("rank", C.c_int32), ("xfer", C.POINTER(StreamXfer)),
-                ("intra_lookahead", C.c_int32), ("intra_stream_priority", C.c_int32), ("ahead_chunk_items", C.c_int32), ("ahead_own_queue", C.c_int32),
-                ("priority_readers", C.c_int32), ("leaf_low", C.c_int32), ("upload_ahead", C.c_int32)]
+                ("intra_lookahead", C.c_int32), ("ahead_own_queue", C.c_int32)]
 
 
 class StreamResult(C.Structure):
@@ -501,13 +500,8 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_dpb_release": (C.c_int, [vp, vp]),
         "ovhip_dpb_lookup": (C.c_int, [vp, vp, P(C.c_int), P(Pic)]),
         "ovhip_dpb_shutdown": (None, [vp]),
-        "ovhip_dpb_set_exec_slots": (None, [vp, C.c_int]),
-        "ovhip_ctx_use_priority": (C.c_int, [vp, C.c_int]),
-        "ovhip_job_upload_ahead": (C.c_int, [vp, C.POINTER(JobParams)]),
         "ovhip_dpb_get_stats": (C.c_int, [vp, P(DpbStats)]),
         "ovhip_frame_create": (C.c_int, [vp, C.c_int, i32, i32, P(vp)]),
-        "ovhip_frame_create_ex": (C.c_int, [vp, C.c_int, i32, i32, C.c_int, P(vp)]),
-        "ovhip_ctx_create_prio": (C.c_int, [P(vp), C.c_int, C.c_int]),
         "ovhip_frame_destroy": (None, [vp]),
         "ovhip_frame_ctx": (vp, [vp]),
         "ovhip_frame_job": (vp, [vp]),
@@ -568,10 +562,10 @@ EXPORTED_SYMBOLS = [
     "ovhip_md5_init", "ovhip_md5_update", "ovhip_md5_final", "ovhip_tmvp_cells_launch", "ovhip_job_tmvp_cells", "ovhip_intra_flow_untag_launch", "ovhip_lmcs_inverse_untag_launch", "ovhip_lmcs_scale_prepare_launch",
     "ovhip_host_alloc", "ovhip_host_free", "ovhip_d2d", "ovhip_job_test_abort_next_flow",
     "ovhip_dpb_create", "ovhip_dpb_create_ex", "ovhip_dpb_destroy", "ovhip_dpb_n_devices", "ovhip_dpb_device", "ovhip_dpb_begin", "ovhip_dpb_want",
-    "ovhip_dpb_publish", "ovhip_dpb_acquire", "ovhip_dpb_wait_copy", "ovhip_dpb_set_unknown_key_timeout", "ovhip_dpb_unpin", "ovhip_dpb_release", "ovhip_dpb_lookup", "ovhip_dpb_shutdown", "ovhip_dpb_set_exec_slots", "ovhip_ctx_use_priority", "ovhip_job_upload_ahead",
+    "ovhip_dpb_publish", "ovhip_dpb_acquire", "ovhip_dpb_wait_copy", "ovhip_dpb_set_unknown_key_timeout", "ovhip_dpb_unpin", "ovhip_dpb_release", "ovhip_dpb_lookup", "ovhip_dpb_shutdown",
     "ovhip_dpb_get_stats", "ovhip_dpb_begin_tag", "ovhip_dpb_want_tag", "ovhip_dpb_acquire_tag", "ovhip_frame_begin_tag", "ovhip_frame_ref_tag", "ovhip_frame_set_trace",
     "ovhip_rccl_unique_id", "ovhip_rccl_create", "ovhip_rccl_destroy", "ovhip_rccl_xfer", "ovhip_rccl_last_error", "ovhip_rccl_stats", "ovhip_rccl_self_exchange",
-    "ovhip_frame_create", "ovhip_frame_create_ex", "ovhip_ctx_create_prio", "ovhip_frame_destroy", "ovhip_frame_ctx", "ovhip_frame_job", "ovhip_frame_recorder", "ovhip_frame_begin", "ovhip_frame_ref",
+    "ovhip_frame_create", "ovhip_frame_destroy", "ovhip_frame_ctx", "ovhip_frame_job", "ovhip_frame_recorder", "ovhip_frame_begin", "ovhip_frame_ref",
     "ovhip_frame_ref_at", "ovhip_frame_dmvr_rows", "ovhip_frame_dmvr_rows_begin", "ovhip_frame_dmvr_rows_collect", "ovhip_frame_submit", "ovhip_frame_fail", "ovhip_frame_last_error",
     "ovhip_calllog_create", "ovhip_calllog_destroy", "ovhip_calllog_reset", "ovhip_calllog_data", "ovhip_rec_set_calllog", "ovhip_calllog_replay",
     "ovhip_stream_create", "ovhip_stream_destroy", "ovhip_stream_run", "ovhip_stream_frame", "ovhip_stream_key", "ovhip_stream_queue_info",

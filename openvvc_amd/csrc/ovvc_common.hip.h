@@ -20,10 +20,7 @@ struct ovhip_ctx {
     int num_cus;                   // compute units of the device (sizes the resident grids of the pipelined kernels)
     hipStream_t stream;            // the stream launches go to: the main stream, or a side lane after ovhip_ctx_fork
     int owns_stream;
-    int owns_prio_stream;       /* main_stream came from the priority-stream pool (ovhip_ctx_create_prio): 1 + class, given back with the context */
     hipStream_t main_stream;       // what the caller passed / what ctx_create made
-    hipStream_t prio_stream[3];    // ovhip_ctx_use_priority: [0] the context's own stream, [1] a high-, [2] a low-priority one (created on first use)
-    int prio_now;
     hipStream_t lane[OV_MAX_LANES];// side streams for independent launches of one stage (created on first use)
     hipEvent_t ev_fork, ev_lane[OV_MAX_LANES];
     int lane_used[OV_MAX_LANES];

@@ -52,9 +52,6 @@ struct ovhip_dpb {
     int shutdown;
     int unknown_ms;                       /* how long ovhip_dpb_acquire waits for a key nobody has begun yet */
     uint64_t serial;
-    /* execution gate: at most exec_slots pictures of a device between "references done" and "complete" at a time, oldest first */
-    int exec_slots, exec_running[OVHIP_MAX_DEVICES];
-    uint64_t exec_wait[OVHIP_MAX_DEVICES][64]; int n_exec_wait[OVHIP_MAX_DEVICES];
     struct limbo_ent *limbo; size_t n_limbo, cap_limbo;       /* finish_deferred() takes these to the pools OUTSIDE the mutex */
     struct { const void *key; uint64_t tag; uint32_t devs; } pend[64]; int n_pend;      /* wants for pictures nobody has begun yet */
     ovhip_dpb_stats st;
@@ -325,8 +322,14 @@ ovhip_dpb_want_tag(ovhip_dpb *d, const void *key, uint64_t tag, int dev)
         /* not begun yet (its frame thread is behind): remembered, ovhip_dpb_begin picks it up (the request was lost) */
         int i = 0;
         while (i < d->n_pend && !(d->pend[i].key == key && d->pend[i].tag == tag)) ++i;
-        if (i == d->n_pend && d->n_pend < 64) { d->pend[i].key = key; d->pend[i].tag = tag; d->pend[i].devs = 0; d->n_pend++; }
-        if (i < d->n_pend) d->pend[i].devs |= 1u << dev; else r = OVHIP_EINVAL;
+        if (i == d->n_pend && d->n_pend == 64) {
+            /* full of wants for pictures that were never begun (a decoder that skipped them): the oldest goes (the table
+             * filled up for good and every later early want was lost) */
+            memmove(&d->pend[0], &d->pend[1], 63 * sizeof(d->pend[0]));
+            i = --d->n_pend;
+        }
+        if (i == d->n_pend) { d->pend[i].key = key; d->pend[i].tag = tag; d->pend[i].devs = 0; d->n_pend++; }
+        d->pend[i].devs |= 1u << dev;
     }
     else if (dev != s->home) {
         s->want |= 1u << dev;
@@ -473,56 +476,6 @@ ovhip_dpb_set_unknown_key_timeout(ovhip_dpb *d, int ms)
     if (!d) return;
     pthread_mutex_lock(&d->mtx);
     d->unknown_ms = ms < 0 ? 0 : ms;
-    pthread_mutex_unlock(&d->mtx);
-}
-
-/* Execution gate.  A frame thread holds a picture from the moment it takes it -- uploads, the wait for its reference pictures --
- * but the device serves the pictures that are RUNNING: with the gate on, a picture whose references are done enters only when fewer
- * than `slots` pictures of its device are between here and their completion, and of the pictures waiting at the gate the one begun
- * first (decoding order: the one others are most likely to wait for) goes first.  More pictures can then be held early (their uploads
- * off everybody's critical path) without more kernels fighting over the device.  0 (default): no gate. */
-void
-ovhip_dpb_set_exec_slots(ovhip_dpb *d, int slots)
-{
-    if (!d) return;
-    pthread_mutex_lock(&d->mtx);
-    d->exec_slots = slots > 0 ? slots : 0;
-    pthread_cond_broadcast(&d->cnd);
-    pthread_mutex_unlock(&d->mtx);
-}
-
-int
-ovhip_dpb_exec_enter(ovhip_dpb *d, const void *key, int dev)
-{
-    if (!d || dev < 0 || dev >= d->n_dev) return OVHIP_EINVAL;
-    pthread_mutex_lock(&d->mtx);
-    if (!d->exec_slots) { pthread_mutex_unlock(&d->mtx); return 0; }
-    struct dpb_slot *s = key ? find(d, key) : NULL;
-    const uint64_t me = s ? s->serial : ++d->serial;
-    int nw = d->n_exec_wait[dev];
-    if (nw >= 64) { pthread_mutex_unlock(&d->mtx); return 0; }            /* (more waiters than the list holds: let it through) */
-    d->exec_wait[dev][nw] = me; d->n_exec_wait[dev] = nw + 1;
-    for (;;) {
-        uint64_t oldest = ~(uint64_t)0;
-        for (int i = 0; i < d->n_exec_wait[dev]; ++i) if (d->exec_wait[dev][i] < oldest) oldest = d->exec_wait[dev][i];
-        if (d->shutdown || !d->exec_slots || (d->exec_running[dev] < d->exec_slots && oldest == me)) break;
-        pthread_cond_wait(&d->cnd, &d->mtx);
-    }
-    for (int i = 0; i < d->n_exec_wait[dev]; ++i)
-        if (d->exec_wait[dev][i] == me) { d->exec_wait[dev][i] = d->exec_wait[dev][--d->n_exec_wait[dev]]; break; }
-    d->exec_running[dev]++;
-    pthread_cond_broadcast(&d->cnd);                   /* the next oldest may go as well */
-    pthread_mutex_unlock(&d->mtx);
-    return 1;
-}
-
-void
-ovhip_dpb_exec_leave(ovhip_dpb *d, int dev)
-{
-    if (!d || dev < 0 || dev >= d->n_dev) return;
-    pthread_mutex_lock(&d->mtx);
-    if (d->exec_running[dev] > 0) d->exec_running[dev]--;
-    pthread_cond_broadcast(&d->cnd);
     pthread_mutex_unlock(&d->mtx);
 }
 

@@ -9,9 +9,6 @@ extern "C" {
 int  ovhip_dpb_hip_ops_(const int *devices, int n_devices, ovhip_dpb_ops *ops, void **user);
 void ovhip_dpb_hip_ops_free_(void *user);
 void ovhip_dpb_rearm_(ovhip_dpb *d);
-/* the execution gate (ovhip_dpb_set_exec_slots): 1 = a slot was taken (ovhip_dpb_exec_leave gives it back), 0 = no gate */
-int  ovhip_dpb_exec_enter(ovhip_dpb *d, const void *key, int dev);
-void ovhip_dpb_exec_leave(ovhip_dpb *d, int dev);
 /* CLOCK_MONOTONIC seconds at which the frame's last picture was complete on the device / published (the stream driver's timeline) */
 double ovhip_frame_published_at(const ovhip_frame *f);
 double ovhip_frame_done_at(const ovhip_frame *f);

@@ -17,29 +17,6 @@ pthread_mutex_t g_pool_mtx = PTHREAD_MUTEX_INITIALIZER;
 hipStream_t g_pool[POOL_DEVS][POOL_CAP];
 int g_pool_n[POOL_DEVS];
 
-// Streams of another priority (ovhip_ctx_create_prio, ovhip_ctx_use_priority) are pooled too, per device and class (0 high, 1 low):
-// NEVER destroyed -- an event last recorded on a destroyed stream (a job's ev_done: jobs outlive the frames that flush them) makes
-// hipEventSynchronize fail with "operation not permitted on an event last recorded in a capturing stream".
-hipStream_t g_prio_pool[POOL_DEVS][2][64];
-int g_prio_n[POOL_DEVS][2];
-
-hipError_t prio_stream_get(int device, int cls, hipStream_t *out)
-{
-    pthread_mutex_lock(&g_pool_mtx);
-    if (device < POOL_DEVS && g_prio_n[device][cls] > 0) { *out = g_prio_pool[device][cls][--g_prio_n[device][cls]]; pthread_mutex_unlock(&g_pool_mtx); return hipSuccess; }
-    pthread_mutex_unlock(&g_pool_mtx);
-    int lo = 0, hi = 0;                                        // numerically: hi <= lo (higher priority = smaller number)
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    return hipStreamCreateWithPriority(out, hipStreamNonBlocking, cls == 0 ? hi : lo);
-}
-
-void prio_stream_put(int device, int cls, hipStream_t s)
-{
-    pthread_mutex_lock(&g_pool_mtx);
-    if (device < POOL_DEVS && g_prio_n[device][cls] < 64) g_prio_pool[device][cls][g_prio_n[device][cls]++] = s;
-    pthread_mutex_unlock(&g_pool_mtx);                         // (a full pool: the stream object is left alone, not destroyed)
-}
-
 hipError_t stream_get(int device, hipStream_t *out)
 {
     pthread_mutex_lock(&g_pool_mtx);
@@ -138,41 +115,6 @@ int ovhip_ctx_create(ovhip_ctx **out, int device, void *stream)
     return OVHIP_OK;
 }
 
-int ovhip_ctx_create_prio(ovhip_ctx **out, int device, int stream_priority)
-{
-    if (!out) return OVHIP_EINVAL;
-    if (!stream_priority) return ovhip_ctx_create(out, device, nullptr);
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return OVHIP_ENODEV;
-    if (hipSetDevice(device) != hipSuccess) return OVHIP_ENODEV;
-    const int cls = stream_priority < 0 ? 0 : 1;
-    hipStream_t s = nullptr;
-    if (prio_stream_get(device, cls, &s) != hipSuccess) return OVHIP_ENODEV;
-    // (pooled by class: the context gives it back when it is destroyed)
-    int r = ovhip_ctx_create(out, device, (void *)s);
-    if (r != OVHIP_OK) prio_stream_put(device, cls, s);
-    else (*out)->owns_prio_stream = 1 + cls;
-    return r;
-}
-
-/* The context's launches go to a stream of another priority from here on (level < 0: high, 0: the context's own stream, > 0: low).
- * Only between pictures: everything enqueued so far is waited for first.  A decoder raises the pictures other pictures wait for --
- * the low temporal layers of a random-access GOP -- above the leaf pictures that fill the device beside them. */
-int ovhip_ctx_use_priority(ovhip_ctx *ctx, int level)
-{
-    if (!ctx) return OVHIP_EINVAL;
-    OV_DEVICE(ctx);
-    const int k = level < 0 ? 1 : level > 0 ? 2 : 0;
-    if (k == ctx->prio_now) return OVHIP_OK;
-    OV_HIP(ctx, hipStreamSynchronize(ctx->main_stream));
-    if (!ctx->prio_stream[0]) ctx->prio_stream[0] = ctx->main_stream;
-    if (!ctx->prio_stream[k]) OV_HIP(ctx, prio_stream_get(ctx->device, k - 1, &ctx->prio_stream[k]));
-    if (ctx->stream == ctx->main_stream) ctx->stream = ctx->prio_stream[k];
-    ctx->main_stream = ctx->prio_stream[k];
-    ctx->prio_now = k;
-    return OVHIP_OK;
-}
-
 void ovhip_ctx_destroy(ovhip_ctx *ctx)
 {
     if (!ctx) return;
@@ -187,14 +129,7 @@ void ovhip_ctx_destroy(ovhip_ctx *ctx)
     if (ctx->scratch_d) (void)hipFree(ctx->scratch_d);
     if (ctx->scratch_h) (void)hipHostFree(ctx->scratch_h);
     if (ctx->ev_sync) (void)hipEventDestroy(ctx->ev_sync);
-    if (ctx->prio_stream[0]) {
-        // back to the context's own stream; the streams of the other priorities are destroyed with the context
-        (void)hipStreamSynchronize(ctx->main_stream);
-        ctx->main_stream = ctx->prio_stream[0];
-        for (int k = 1; k < 3; ++k) if (ctx->prio_stream[k]) { (void)hipStreamSynchronize(ctx->prio_stream[k]); prio_stream_put(ctx->device, k - 1, ctx->prio_stream[k]); }
-    }
     if (ctx->owns_stream) { (void)hipStreamSynchronize(ctx->main_stream); stream_put(ctx->device, ctx->main_stream); }
-    if (ctx->owns_prio_stream) { (void)hipStreamSynchronize(ctx->main_stream); prio_stream_put(ctx->device, ctx->owns_prio_stream - 1, ctx->main_stream); }
     free(ctx);
 }
 

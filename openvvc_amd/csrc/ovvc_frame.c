@@ -30,7 +30,6 @@ struct ovhip_frame {
     ovhip_job *job;                       /* own job, created on first use */
     /* dry frame (a DPB on a test back-end, no device): the same state machine and the same DPB calls, nothing launched.  Its own
      * plain recorder takes the picture's commands; the eager-DMVR counters move as the device's would. */
-    int in_gate;                          /* holds one of the device's execution slots (ovhip_dpb_set_exec_slots) */
     double done_at, published_at;         /* CLOCK_MONOTONIC seconds: ovhip_job_wait returned / the picture was published (stall analysis) */
     int dry;
     ovhip_recorder *dry_rec;
@@ -84,10 +83,8 @@ fail(ovhip_frame *f, int code, const char *what)
     return code;
 }
 
-int ovhip_frame_create(ovhip_dpb *dpb, int dev, int32_t w, int32_t h, ovhip_frame **out) { return ovhip_frame_create_ex(dpb, dev, w, h, 0, out); }
-
 int
-ovhip_frame_create_ex(ovhip_dpb *dpb, int dev, int32_t w, int32_t h, int stream_priority, ovhip_frame **out)
+ovhip_frame_create(ovhip_dpb *dpb, int dev, int32_t w, int32_t h, ovhip_frame **out)
 {
     if (!dpb || !out || dev < 0 || dev >= ovhip_dpb_n_devices(dpb) || w <= 0 || h <= 0) return OVHIP_EINVAL;
     *out = NULL;
@@ -105,7 +102,7 @@ ovhip_frame_create_ex(ovhip_dpb *dpb, int dev, int32_t w, int32_t h, int stream_
         *out = f;
         return OVHIP_OK;
     }
-    int r = stream_priority ? ovhip_ctx_create_prio(&f->ctx, hipdev, stream_priority) : ovhip_ctx_create(&f->ctx, hipdev, NULL);
+    int r = ovhip_ctx_create(&f->ctx, hipdev, NULL);
     if (r != OVHIP_OK) { free(f); return r; }
     *out = f;
     return OVHIP_OK;
@@ -223,11 +220,7 @@ static int
 before_launch_cb(void *user)
 {
     ovhip_frame *f = (ovhip_frame *)user;
-    if (acquire_refs(f) != OVHIP_OK) return 1;
-    /* the execution gate of the device (ovhip_dpb_set_exec_slots): pictures that depend on others; a picture without references is
-     * the look-ahead thread's, started early precisely to run beside the others */
-    if (f->n_refs) f->in_gate = ovhip_dpb_exec_enter(f->dpb, f->key, f->dev) == 1;
-    return 0;
+    return acquire_refs(f) != OVHIP_OK;
 }
 
 int64_t
@@ -324,7 +317,6 @@ ovhip_frame_submit(ovhip_frame *f, ovhip_job *job, const ovhip_pic *intra, const
         /* ONLY the wait marks the picture complete: it may run the ordered pass a second time */
         int q = ovhip_job_wait(j);
         f->done_at = mono_s();
-        if (f->in_gate) { ovhip_dpb_exec_leave(f->dpb, f->dev); f->in_gate = 0; }
         if (q != OVHIP_OK && r == OVHIP_OK) r = fail(f, q, "ovhip_job_wait");
     }
     /* a borrowed job goes back to its own context: this frame (and its context) may be destroyed before the job */

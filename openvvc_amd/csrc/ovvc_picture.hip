@@ -39,6 +39,7 @@ struct ovhip_job {
     int32_t *mv_host; size_t mv_cap;     // pinned: refined vectors, 4 int32 per refined unit
     struct { int valid, has_intra; ovhip_pic dst, refs[16], intra; uint32_t n_refs; ovhip_job_params pr; } again;   // the last flush's arguments
     uint32_t n_retries;                  // second passes of the last picture (ovhip_job_wait)
+    int flow_launched;                   // the last flush had a flow launch (ovhip_job_wait: a clean one counts towards the decay of g_flow_shift)
     int test_abort, test_abort_seen;     // ovhip_job_test_abort_next_flow (a forced abort does not count as evidence of starvation)
     ovhip_tmvp_cell *tmvp_host; size_t tmvp_cap, n_tmvp;   // pinned: TMVP plane cells of the refined units (ovhip_job_params.tmvp_cells)
     size_t n_mv;                         // units covered by the last flush / eager pass
@@ -49,15 +50,6 @@ struct ovhip_job {
     int flushed;                         // ev_* recorded at least once
     const void *packed_prev[24];         // where the last full flush placed the arrays that rode in the parameter block
     int resident;                        // this flush reuses the device copies of the previous one (OVHIP_STAGE_RESIDENT)
-    hipStream_t up_stream;               // while a flush enqueues its uploads on a shared upload lane: that lane's stream
-    // ovhip_job_upload_ahead: the host half of a flush (class split, level sort, item list, staging block) and its uploads were done
-    // ahead of the flush, on an upload lane; the flush restores what they produced and waits for ev_h2d on the host
-    struct {
-        int valid; uint32_t stages;
-        const ovhip_tb_cmd *tb; size_t cls[4], tiny[4][4], n_tb;
-        const ovhip_itask *it; size_t n_it, n_ictu; uint32_t n_lv; const uint32_t *lv_start; const ovhip_ictu *ictu;
-        size_t n_items; int by_flow;
-    } ahead;
     ovhip_job_stats st;
     // optional: HIP-event bracket around ONE launch group of the flush (ovhip_job_time_stage)
     int t_stage;                         // OVHIP_TIME_* or -1
@@ -65,7 +57,12 @@ struct ovhip_job {
     double t_sum_ms; uint64_t t_count;
 };
 
-static int g_flow_shift;                 // workers of a flow launch = (6 x CUs) >> g_flow_shift: grows with every launch that was abandoned
+// workers of a flow launch = (6 x CUs) >> g_flow_shift[device]: grows with every launch of that device that was abandoned (co-resident
+// flow launches starving each other: another GPU_MAX_HW_QUEUES, another process on the GPU) and decays again -- one step per
+// FLOW_DECAY pictures whose flow launch went through -- so that one transient event does not halve the device's pictures for the life of
+// the process; ovhip_job_stats.flow_shift reports it
+enum { FLOW_DEVS = 64, FLOW_DECAY = 512 };
+static int g_flow_shift[FLOW_DEVS], g_flow_clean[FLOW_DEVS];
 
 namespace {
 
@@ -110,37 +107,13 @@ int dev_reserve(ovhip_job *j, int k, size_t bytes)
     return OVHIP_OK;
 }
 
-// Upload lanes: the pictures in flight on a device do not each copy on their own stream (16 streams copying at once get two thirds of
-// what 1-4 get out of the link, tools/micro/h2d_concurrent.py) -- a flush takes one of a few per-device copy streams for the time it
-// enqueues its copies (FIFO under the lane's mutex) and the frame thread waits for them on the host, as it does for its reference
-// pictures, before it enqueues the launches.
-struct UploadLane { hipStream_t s; pthread_mutex_t m; };
-UploadLane g_up[64][8];
-pthread_mutex_t g_up_mtx = PTHREAD_MUTEX_INITIALIZER;
-unsigned g_up_next[64];
-
-UploadLane *upload_lane(int device, int n_lanes)
-{
-    if (device < 0 || device >= 64 || n_lanes <= 0) return nullptr;
-    if (n_lanes > 8) n_lanes = 8;
-    pthread_mutex_lock(&g_up_mtx);
-    const unsigned k = g_up_next[device]++ % (unsigned)n_lanes;
-    UploadLane *l = &g_up[device][k];
-    if (!l->s) {
-        if (hipStreamCreateWithFlags(&l->s, hipStreamNonBlocking) != hipSuccess) { l->s = nullptr; l = nullptr; }
-        else pthread_mutex_init(&l->m, nullptr);
-    }
-    pthread_mutex_unlock(&g_up_mtx);
-    return l;
-}
-
 int h2d(ovhip_job *j, int k, const void *host, size_t bytes)
 {
     if (!bytes) return OVHIP_OK;
     if (j->resident) return j->dev[k].cap >= bytes ? OVHIP_OK : ov_fail(j->ctx, OVHIP_EINVAL, "resident flush before a full one", hipSuccess);
     int r = dev_reserve(j, k, bytes);
     if (r) return r;
-    OV_HIP(j->ctx, hipMemcpyAsync(j->dev[k].p, host, bytes, hipMemcpyHostToDevice, j->up_stream ? j->up_stream : j->ctx->stream));
+    OV_HIP(j->ctx, hipMemcpyAsync(j->dev[k].p, host, bytes, hipMemcpyHostToDevice, j->ctx->stream));
     j->st.h2d_bytes += bytes; j->st.n_h2d++;
     return OVHIP_OK;
 }
@@ -165,9 +138,6 @@ extern "C" int ovhip_itx_launch_ex_(ovhip_ctx *ctx, const ovhip_pic *dst, const 
 
 #ifndef OVHIP_PACK_LIMIT
 #define OVHIP_PACK_LIMIT (128 << 10)     /* bytes: arrays up to this size ride in the staging block */
-#endif
-#ifndef OVHIP_UPLOAD_LANES
-#define OVHIP_UPLOAD_LANES 0             /* shared copy streams per device (0: every picture copies on its own stream) */
 #endif
 
 double host_now_us()
@@ -270,8 +240,7 @@ int ovhip_job_begin(ovhip_job *j)
     if (!j) return OVHIP_EINVAL;
     OV_DEVICE(j->ctx);
     // the DMA engines may still be reading the recorder's arrays and the parameter staging block
-    if (j->flushed || j->ahead.valid) OV_HIP(j->ctx, hipEventSynchronize(j->ev_h2d));
-    j->ahead.valid = 0;
+    if (j->flushed) OV_HIP(j->ctx, hipEventSynchronize(j->ev_h2d));
     if (j->rows_pending) { OV_HIP(j->ctx, hipEventSynchronize(j->ev_rows)); j->rows_pending = 0; }
     ovhip_rec_reset(j->rec);
     j->dmvr_first = 0; j->n_mv = 0; j->n_tmvp = 0; j->rows_end = 0;
@@ -294,7 +263,7 @@ int ovhip_job_bind(ovhip_job *j, ovhip_ctx *ctx)
 }
 
 static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs, const ovhip_pic *intra,
-                          const ovhip_job_params *pr, int upload_only = 0);
+                          const ovhip_job_params *pr);
 
 int ovhip_job_wait(ovhip_job *j)
 {
@@ -309,7 +278,11 @@ int ovhip_job_wait(ovhip_job *j)
         // the picture again with one launch per level -- no workgroup of such a launch waits for another -- from the recorder's
         // arrays, which are untouched until the next ovhip_job_begin.  Every sample of dst is rewritten by a flush.
         *(volatile uint32_t *)j->abort_host = 0;
-        if (!j->test_abort_seen && __atomic_load_n(&g_flow_shift, __ATOMIC_RELAXED) < 4) __atomic_fetch_add(&g_flow_shift, 1, __ATOMIC_RELAXED);
+        const int fd = j->ctx->device & (FLOW_DEVS - 1);
+        if (!j->test_abort_seen) {
+            if (__atomic_load_n(&g_flow_shift[fd], __ATOMIC_RELAXED) < 4) __atomic_fetch_add(&g_flow_shift[fd], 1, __ATOMIC_RELAXED);
+            __atomic_store_n(&g_flow_clean[fd], 0, __ATOMIC_RELAXED);
+        }
         j->test_abort_seen = 0;
         if (j->d_sync) (void)hipMemset(j->d_sync, 0, sizeof(uint32_t));
         if (j->d_flow) (void)hipMemset(j->d_flow, 0, sizeof(uint32_t));
@@ -325,6 +298,14 @@ int ovhip_job_wait(ovhip_job *j)
             return OVHIP_OK;
         }
         return ov_fail(j->ctx, OVHIP_ELAUNCH, "ordered pass: a CTU's bounded wait for its neighbours expired (picture incomplete)", hipSuccess);
+    }
+    if (j->flow_launched) {
+        const int fd = j->ctx->device & (FLOW_DEVS - 1);
+        j->flow_launched = 0;
+        if (__atomic_load_n(&g_flow_shift[fd], __ATOMIC_RELAXED) > 0 && __atomic_add_fetch(&g_flow_clean[fd], 1, __ATOMIC_RELAXED) >= FLOW_DECAY) {
+            __atomic_store_n(&g_flow_clean[fd], 0, __ATOMIC_RELAXED);
+            __atomic_fetch_sub(&g_flow_shift[fd], 1, __ATOMIC_RELAXED);
+        }
     }
     return OVHIP_OK;
 }
@@ -449,7 +430,7 @@ int64_t ovhip_job_dmvr_rows(ovhip_job *j, const ovhip_pic *refs, uint32_t n_refs
 }
 
 static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs, const ovhip_pic *intra,
-                          const ovhip_job_params *pr, int upload_only);
+                          const ovhip_job_params *pr);
 
 int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs, const ovhip_pic *intra,
                     const ovhip_job_params *pr)
@@ -473,24 +454,6 @@ int ovhip_job_flush(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, u
     return r;
 }
 
-/* The host half of the next flush of this job (class split, level sort, item list, staging block) and its uploads, now: on one of
- * the device's upload lanes, not on a picture's stream.  The next ovhip_job_flush with the same stages restores what this call
- * produced, waits for the uploads on the host just before it enqueues its launches, and uploads nothing.  For a caller that knows
- * which pictures come next (the stream driver's uploader threads, decoding order): the pictures that do not have to wait for
- * reference pictures -- the low layers of a GOP, which everything else waits for -- no longer pay their upload on that path.
- * Nothing of the job may be in flight; the recorder must not change until the flush. */
-int ovhip_job_upload_ahead(ovhip_job *j, const ovhip_job_params *pr)
-{
-    if (!j || !pr) return OVHIP_EINVAL;
-    if (j->ahead.valid) return OVHIP_OK;
-    if (j->flushed) {
-        OV_DEVICE(j->ctx);
-        hipError_t e = hipEventSynchronize(j->ev_done);          // (the device buffers of the job are free)
-        if (e != hipSuccess) return ov_fail(j->ctx, OVHIP_ELAUNCH, "ovhip_job_upload_ahead: previous flush", e);
-    }
-    return job_flush_impl(j, nullptr, nullptr, 0, nullptr, pr, 1);
-}
-
 int ovhip_job_test_abort_next_flow(ovhip_job *j)
 {
     if (!j) return OVHIP_EINVAL;
@@ -499,11 +462,11 @@ int ovhip_job_test_abort_next_flow(ovhip_job *j)
 }
 
 static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs, const ovhip_pic *intra,
-                          const ovhip_job_params *pr, int upload_only)
+                          const ovhip_job_params *pr)
 {
     ovhip_ctx *ctx = j->ctx;
     OV_DEVICE(ctx);
-    if (!upload_only && (dst->w != j->w || dst->h != j->h)) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_job_flush: picture size differs from the job's", hipSuccess);
+    if ((dst->w != j->w || dst->h != j->h)) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_job_flush: picture size differs from the job's", hipSuccess);
     // an eager pass nobody collected (ovhip_job_dmvr_rows_begin): its copies land in arrays this flush may re-allocate
     { const int64_t c_ = ovhip_job_dmvr_rows_collect(j); if (c_ < 0) return (int)c_; }
     const uint32_t stages = pr->stages ? pr->stages : 0xffffffffu;
@@ -515,17 +478,13 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
     const double t_flush0 = host_now_us();
     j->resident = (stages & OVHIP_STAGE_RESIDENT) && pr->stages;
     ovhip_recorder *rec = j->rec;
-    // the host half and the uploads were done ahead (ovhip_job_upload_ahead) for exactly these stages: restored, not repeated
-    const bool ahead = !upload_only && j->ahead.valid && !j->resident && j->ahead.stages == stages;
-    if (!ahead) j->ahead.valid = 0;
-    const bool no_upload = j->resident || ahead;
+    const bool no_upload = j->resident;
 
     // ---- host: class split of the transform blocks (luma first; big / small), recorder arrays ----
     size_t cls[4] = { 0, 0, 0, 0 }, n_tb = 0, n_coef = 0, n_mc = 0, n_mcx = 0, n_aff = 0, n_side = 0, n_reg = 0, n_ev = 0, n_eh = 0;
     const ovhip_tb_cmd *tb;
     size_t tiny[4][4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };      // the tiny blocks at the end of each class (a lane per sample)
-    if (ahead) { tb = j->ahead.tb; n_tb = j->ahead.n_tb; memcpy(cls, j->ahead.cls, sizeof(cls)); memcpy(tiny, j->ahead.tiny, sizeof(tiny)); }
-    else tb = ovhip_rec_tb_cmds_split_tiny_(rec, cls, tiny, &n_tb);
+    tb = ovhip_rec_tb_cmds_split_tiny_(rec, cls, tiny, &n_tb);
     if (!tb && n_tb) return ov_fail(ctx, OVHIP_ENOMEM, "ovhip_rec_tb_cmds_split", hipSuccess);
     const int16_t *coef = ovhip_rec_coefs(rec, &n_coef);
     const ovhip_mc_unit *mc = ovhip_rec_mc_units(rec, &n_mc);
@@ -535,7 +494,7 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
     const ovhip_lmcs_region *reg = ovhip_rec_lmcs_regions(rec, &n_reg);
     size_t n_ciip = 0;
     const ovhip_ciip_unit *ciip = ovhip_rec_ciip_units(rec, &n_ciip);
-    if (n_ciip && !intra && !upload_only)
+    if (n_ciip && !intra)
         return ov_fail(ctx, OVHIP_EUNSUP, "ovhip_job_flush: CIIP blend units recorded but no picture with their intra prediction", hipSuccess);
     // ordered tasks: grouped by CTU for the one-launch pass, or sorted by level for one launch per level
     size_t n_it = 0, n_ictu = 0; uint32_t n_lv = 0; const uint32_t *lv_start = nullptr; const ovhip_ictu *ictu = nullptr;
@@ -543,12 +502,10 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
     int by_flow = !by_ctu && !(pr->stages && (stages & OVHIP_STAGE_INTRA_LEVELS));
     const int by_level = !by_ctu;          // the flow launch also takes the level-sorted list
     const ovhip_itask *it;
-    if (ahead) { it = j->ahead.it; n_it = j->ahead.n_it; lv_start = j->ahead.lv_start; n_lv = j->ahead.n_lv; ictu = j->ahead.ictu; n_ictu = j->ahead.n_ictu; }
-    else it = by_level ? ovhip_rec_itasks_sorted(rec, &n_it, &lv_start, &n_lv)
+    it = by_level ? ovhip_rec_itasks_sorted(rec, &n_it, &lv_start, &n_lv)
                        : ovhip_rec_itasks_by_ctu(rec, pr->log2_ctu_s ? pr->log2_ctu_s : 7, &n_it, &ictu, &n_ictu);
     size_t n_items = 0;
-    if (ahead) { n_items = j->ahead.n_items; by_flow = j->ahead.by_flow; }
-    else if (by_flow && n_it) {
+    if (by_flow && n_it) {
         if (j->items_cap < 4 * n_it + 16) {
             pinned_free(nullptr, j->items_host);
             j->items_cap = 8 * n_it + 1024;
@@ -563,7 +520,7 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
     if (!(stages & OVHIP_STAGE_INTRA)) { n_it = 0; n_lv = 0; n_ictu = 0; }
     const int ordered = n_it != 0;       // a picture with an ordered pass keeps its luma in the mapped domain until the pass has run
     if (ordered && !j->res.y) CHK(ovhip_pic_alloc(ctx, j->w, j->h, &j->res));
-    if (ordered && !upload_only && (dst->stride_y != j->res.stride_y || dst->stride_c != j->res.stride_c))
+    if (ordered && (dst->stride_y != j->res.stride_y || dst->stride_c != j->res.stride_c))
         return ov_fail(ctx, OVHIP_EUNSUP, "ovhip_job_flush: pictures with ordered tasks need tight planes (stride = width)", hipSuccess);
     j->st.n_itasks = (uint32_t)n_it; j->st.n_ilevels = n_lv;
     ovhip_dbf_offsets offs;
@@ -609,7 +566,7 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
     const void *packed[24] = { nullptr };           // device address of a packed array (inside the parameter block)
     for (auto &sm : small) if (sm.bytes && sm.bytes <= PACK_LIMIT && !j->resident) sm.at = put(sm.bytes) + 1;
     L.total = o;
-    if (L.total && !ahead) {
+    if (L.total) {
         CHK(pinned_reserve(j, (void **)&j->param_host, &j->param_cap, L.total));
         char *ph = j->param_host;
         for (auto &sm : small) if (sm.at) memcpy(ph + sm.at - 1, sm.host, sm.bytes);
@@ -627,21 +584,7 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
 
     const double t_flush1 = host_now_us();
     // ---- H2D (asynchronous DMA out of page-locked memory, in stage order so that prediction can start early) ----
-#ifdef OVHIP_TUNING
-    static const int N_UP = getenv("OVHIP_X_UPLOAD_STREAMS") ? atoi(getenv("OVHIP_X_UPLOAD_STREAMS")) : OVHIP_UPLOAD_LANES;
-#else
-    const int N_UP = OVHIP_UPLOAD_LANES;
-#endif
-    // (uploads ahead of the flush have no picture stream of their own: always through a lane)
-    UploadLane *lane = no_upload ? nullptr : upload_lane(ctx->device, upload_only && N_UP < 1 ? 4 : N_UP);
-    if (upload_only && !lane) return ov_fail(ctx, OVHIP_ENODEV, "ovhip_job_upload_ahead: no upload lane", hipSuccess);
-    struct LaneHold {                      // the lane is held while this flush enqueues its copies
-        ovhip_job *j; UploadLane *l;
-        LaneHold(ovhip_job *j_, UploadLane *l_) : j(j_), l(l_) { if (l) { pthread_mutex_lock(&l->m); j->up_stream = l->s; } }
-        void release() { if (l) { j->up_stream = nullptr; pthread_mutex_unlock(&l->m); l = nullptr; } }
-        ~LaneHold() { release(); }
-    } hold(j, lane);
-    if (!ahead) {
+    {
     StageTimer t_(j, OVHIP_TIME_H2D);
     CHK(h2d(j, B_PARAM, j->param_host, L.total));
     if (n_mcx) {
@@ -657,19 +600,10 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
         else CHK(h2d(j, sm.buf, sm.host, sm.bytes));
     }
     }
-    // a resident replay / a flush whose uploads ran ahead re-uses the placement of the flush (or upload) before it
+    // a resident replay re-uses the placement of the flush before it
     if (no_upload) memcpy(packed, j->packed_prev, sizeof(packed)); else memcpy(j->packed_prev, packed, sizeof(packed));
     auto DEV = [&](int k) -> const void * { return packed[k] ? packed[k] : j->dev[k].p; };
-    if (!ahead) OV_HIP(ctx, hipEventRecord(j->ev_h2d, lane ? lane->s : ctx->stream));
-    hold.release();
-    if (upload_only) {
-        j->ahead.stages = stages;
-        j->ahead.tb = tb; j->ahead.n_tb = n_tb; memcpy(j->ahead.cls, cls, sizeof(cls)); memcpy(j->ahead.tiny, tiny, sizeof(tiny));
-        j->ahead.it = it; j->ahead.n_it = n_it; j->ahead.n_ictu = n_ictu; j->ahead.n_lv = n_lv; j->ahead.lv_start = lv_start; j->ahead.ictu = ictu;
-        j->ahead.n_items = n_items; j->ahead.by_flow = by_flow;
-        j->ahead.valid = 1;
-        return OVHIP_OK;
-    }
+    OV_HIP(ctx, hipEventRecord(j->ev_h2d, ctx->stream));
     const double t_flush2 = host_now_us();
     // everything below reads or writes pictures: behind the pictures this one depends on
     for (uint32_t i = 0; i < pr->n_wait_events; ++i)
@@ -686,9 +620,6 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
 #else
     const int X_MV_D2H = 3;
 #endif
-    // uploads that went through a lane: nothing on this picture's stream orders the launches behind them
-    if (lane || ahead) OV_HIP(ctx, hipEventSynchronize(j->ev_h2d));
-    j->ahead.valid = 0;
     const double t_flush3 = host_now_us();
     j->st.host_us_prepare = (uint32_t)(t_flush1 - t_flush0); j->st.host_us_upload = (uint32_t)(t_flush2 - t_flush1);
     j->st.host_us_wait = (uint32_t)(t_flush3 - t_flush2);
@@ -827,13 +758,10 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
             // the pollers of levels far ahead); W = 512 3280-3320 / 0; 1024 3353-3490 / 0; 2048 1561 / 9; 4096 35 / 1168 -- above
             // the bound the launches starve each other, exactly as the argument says.  Alone, a B picture's wide levels want more
             // workers (its pass: 104 us with a workgroup per item, 156 with 1024 workers, 229 with 512); beside other pictures that
-            // does not show.  GPU_MAX_HW_QUEUES = 8 with W = 512: 3000-3060 / 0, no gain.  (OVHIP_FLOW_WORKERS, OVHIP_FLOW_CHUNK:
-            // tuning knobs, read once; chunked launches -- whole levels per launch -- remain for ovhip_job_params.flow_chunk_items)
+            // does not show.  GPU_MAX_HW_QUEUES = 8 with W = 512: 3000-3060 / 0, no gain.  (OVHIP_FLOW_WORKERS: a tuning knob, read once)
 #ifdef OVHIP_TUNING
-            static const size_t FLOW_CHUNK = getenv("OVHIP_FLOW_CHUNK") && atol(getenv("OVHIP_FLOW_CHUNK")) > 0 ? (size_t)atol(getenv("OVHIP_FLOW_CHUNK")) : ((size_t)1 << 30);
             static const long WORKERS = getenv("OVHIP_FLOW_WORKERS") ? atol(getenv("OVHIP_FLOW_WORKERS")) : -1;
 #else
-            static const size_t FLOW_CHUNK = (size_t)1 << 30;
             static const long WORKERS = -1;
 #endif
             //  the 4 x CUs default assumes 4 hardware queues and 16 resident waves per CU; where that does not hold (another
@@ -843,7 +771,7 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
             // widest-level rule below an I picture's launch holds ~256 workers, and B launches of 1536 were never abandoned in 4600
             // pictures (tools/sweep_bpic_workers.sh, interleaved, six runs each: 1024 workers 3220 pictures/s, 1536 3308, 2048 2-10
             // second passes per run); an abandoned launch still halves the default (g_flow_shift).
-            int n_workers = pr->flow_workers ? (int)pr->flow_workers : (WORKERS >= 0 ? (int)WORKERS : (6 * ctx->num_cus) >> __atomic_load_n(&g_flow_shift, __ATOMIC_RELAXED));
+            int n_workers = pr->flow_workers ? (int)pr->flow_workers : (WORKERS >= 0 ? (int)WORKERS : (6 * ctx->num_cus) >> __atomic_load_n(&g_flow_shift[ctx->device & (FLOW_DEVS - 1)], __ATOMIC_RELAXED));
             if (!pr->flow_workers && WORKERS < 0) {
                 // No more workers than the picture's widest level can use (round 4): a worker beyond that only ever holds an item that is
                 // levels ahead of the front -- and its wave slot, registers and LDS are then missing to the kernels of the pictures beside
@@ -859,21 +787,12 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
                 if (want < n_workers) n_workers = want < 64 ? 64 : want;
             }
             if (n_workers < 1) n_workers = 1;
-            size_t a = 0;
-            int first = !flow_prepared;
-            const size_t chunk = pr->flow_chunk_items ? pr->flow_chunk_items : FLOW_CHUNK;
-            while (a < n_items) {
-                size_t b = a + chunk < n_items ? a + chunk : n_items;
-                while (b < n_items && it[j->items_host[b] & 0xffffff].level == it[j->items_host[b - 1] & 0xffffff].level) ++b;
-                CHK(ovhip_intra_flow_launch(ctx, dst, &j->res, d_it, (uint32_t)n_it, (const uint32_t *)DEV(B_IITEM) + a, (uint32_t)(b - a),
-                                            (const ovhip_lmcs_region *)DEV(B_REG), pr->lmcs, (int16_t *)j->dev[B_SCALE].p, log2_ctu, j->d_flow, j->epoch,
-                                            j->abort_host, first, n_workers));
-                j->st.n_launches += 1 + first;
-                first = 0;
-                a = b;
-                // paced: the streams that share this stream's hardware queue get their packets in between two chunks
-                if (pr->flow_paced && a < n_items) OV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            }
+            CHK(ovhip_intra_flow_launch(ctx, dst, &j->res, d_it, (uint32_t)n_it, (const uint32_t *)DEV(B_IITEM), (uint32_t)n_items,
+                                        (const ovhip_lmcs_region *)DEV(B_REG), pr->lmcs, (int16_t *)j->dev[B_SCALE].p, log2_ctu, j->d_flow, j->epoch,
+                                        j->abort_host, !flow_prepared, n_workers));
+            j->st.n_launches += 1 + !flow_prepared;
+            j->flow_launched = 1;
+            j->st.flow_shift = (uint32_t)__atomic_load_n(&g_flow_shift[ctx->device & (FLOW_DEVS - 1)], __ATOMIC_RELAXED);
         }
         for (uint32_t l = 0; by_level && !by_flow && l < n_lv; ++l) {
             const uint32_t a = lv_start[l], b = lv_start[l + 1];

@@ -14,8 +14,18 @@
 #include <stdlib.h>
 #include <string.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include <pthread.h>
 #include "ovvc_hip.h"
+
+// The few types and constants of rccl.h this file needs, declared here: the library must build on a ROCm install without the RCCL
+// development headers -- the functions themselves come from dlsym.  (ncclUniqueId is 128 opaque bytes, ncclComm_t an
+// opaque pointer, the enumerators below are fixed by NCCL's ABI: nccl.h "ncclResult_t", "ncclDataType_t".)
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+enum { ncclSuccess = 0 };
+enum { ncclUint8 = 1 };
 
 struct ovhip_rccl {
     void *lib;
@@ -34,15 +44,18 @@ struct ovhip_rccl {
     char err[192];
 };
 
+// one handle per process, opened on first use and kept (RCCL keeps threads and device state of its own: it is never unloaded)
 static void *open_rccl(char *err, size_t cap)
 {
+    static void *g_handle;
+    static pthread_mutex_t g_mtx = PTHREAD_MUTEX_INITIALIZER;
     static const char *names[] = { "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so" };
-    for (unsigned i = 0; i < sizeof(names) / sizeof(names[0]); ++i) {
-        void *h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
-        if (h) return h;
-    }
-    snprintf(err, cap, "librccl.so: %s", dlerror());
-    return nullptr;
+    pthread_mutex_lock(&g_mtx);
+    for (unsigned i = 0; !g_handle && i < sizeof(names) / sizeof(names[0]); ++i) g_handle = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+    if (!g_handle) snprintf(err, cap, "librccl.so: %s", dlerror());
+    void *h = g_handle;
+    pthread_mutex_unlock(&g_mtx);
+    return h;
 }
 
 extern "C" int ovhip_rccl_unique_id(uint8_t out[128])

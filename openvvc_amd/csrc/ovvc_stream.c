@@ -23,7 +23,6 @@
 #include "ovvc_hip.h"
 #include "ovvc_dpb_priv.h"
 
-#define UPLOADERS 4                     /* uploader threads per device (ovhip_stream_cfg.upload_ahead) */
 #define STAGE_ALL (OVHIP_STAGE_MC | OVHIP_STAGE_ITX | OVHIP_STAGE_DBF | OVHIP_STAGE_SAO | OVHIP_STAGE_ALF | OVHIP_STAGE_INTRA)
 
 struct run_state;
@@ -42,7 +41,6 @@ struct ovhip_stream {
     const ovhip_stream_pic *pics; uint32_t n_total;
     uintptr_t key_base;
     uint32_t *holds;                      /* per picture: decode / receive + local readers + output + sends still to come */
-    uint8_t *readers;                     /* per picture: later local pictures that reference it (saturating): its stream priority */
     unsigned char *alive;                 /* begun in the DPB and not released yet */
     unsigned char *begun;                 /* has entered the DPB at some point (the output / comm threads wait for that before they
                                            * ask the DPB for it: a key the DPB never saw is an error there, not a wait) */
@@ -51,8 +49,7 @@ struct ovhip_stream {
     uint8_t *dg;                          /* OVHIP_OUT_DIGEST: the pictures' digests, computed by their frame threads (begun[idx] == 2: there) */
 };
 
-struct dev_queue { uint32_t *order; unsigned char *taken; unsigned char *ahead; uint32_t n, next; pthread_mutex_t take; pthread_cond_t moved; };
-/* ahead[k]: an uploader thread has claimed position k (ovhip_stream_cfg.upload_ahead) */
+struct dev_queue { uint32_t *order; unsigned char *taken; uint32_t n, next; pthread_mutex_t take; pthread_cond_t moved; };
 
 struct run_state {
     ovhip_stream *s;
@@ -141,8 +138,7 @@ release_stream(ovhip_stream *s)
 {
     for (uint32_t i = 0; i < s->n_total; ++i)
         if (s->alive && s->alive[i]) { s->alive[i] = 0; (void)ovhip_dpb_release(s->dpb, key_of(s, i)); }
-    free(s->holds); free(s->alive); free(s->begun); free(s->dg); free(s->readers);
-    s->readers = NULL;
+    free(s->holds); free(s->alive); free(s->begun); free(s->dg);
     s->holds = NULL; s->alive = NULL; s->begun = NULL; s->dg = NULL;
     s->key_base += (uintptr_t)s->n_total + 1;
     s->pics = NULL; s->n_total = 0;
@@ -156,8 +152,7 @@ adopt_stream(ovhip_stream *s, const ovhip_stream_pic *pics, uint32_t n_total, ui
     s->alive = (unsigned char *)calloc(n_total ? n_total : 1, 1);
     s->begun = (unsigned char *)calloc(n_total ? n_total : 1, 1);
     s->dg = (uint8_t *)calloc(n_total ? n_total : 1, 16);
-    s->readers = (uint8_t *)calloc(n_total ? n_total : 1, 1);
-    if (!s->holds || !s->alive || !s->begun || !s->dg || !s->readers) return OVHIP_ENOMEM;
+    if (!s->holds || !s->alive || !s->begun || !s->dg) return OVHIP_ENOMEM;
     for (uint32_t i = 0; i < n_total; ++i) {
         const ovhip_stream_pic *p = &pics[i];
         if (p->content >= s->n_contents || p->device >= (uint32_t)s->n_dev || p->n_refs > OVHIP_STREAM_MAX_REFS) return OVHIP_EINVAL;
@@ -166,7 +161,7 @@ adopt_stream(ovhip_stream *s, const ovhip_stream_pic *pics, uint32_t n_total, ui
         const int nr = distinct_refs(p, refs);
         for (int k = 0; k < nr; ++k) {
             if (refs[k] >= i) return OVHIP_EINVAL;                  /* decoding order: references come first */
-            if (local) { s->holds[refs[k]]++; if (s->readers[refs[k]] < 255) s->readers[refs[k]]++; }
+            if (local) s->holds[refs[k]]++;
         }
         if (local) {
             s->holds[i] += 1 + (s->cfg.output != OVHIP_OUT_NONE) + ((flags & OVHIP_STREAM_HOLD_ALL) != 0);
@@ -180,15 +175,14 @@ adopt_stream(ovhip_stream *s, const ovhip_stream_pic *pics, uint32_t n_total, ui
 }
 
 /* ---------------------------------------------------------------- frame threads */
-/* the parameter block of a picture's flush (the uploader threads pass the same to ovhip_job_upload_ahead) */
+/* the parameter block of a picture's flush */
 static ovhip_job_params
-picture_params(const struct run_state *rs, const ovhip_stream_content *c, int ahead)
+picture_params(const struct run_state *rs, const ovhip_stream_content *c)
 {
     const ovhip_stream *s = rs->s;
     ovhip_job_params pr = c->params;
     pr.stages = (pr.stages ? pr.stages : STAGE_ALL) | s->cfg.extra_stages | ((rs->flags & OVHIP_STREAM_RESIDENT) ? OVHIP_STAGE_RESIDENT : 0);
     if (pr.stages == STAGE_ALL) pr.stages = 0;
-    if (ahead && s->cfg.ahead_chunk_items) { pr.flow_chunk_items = (uint32_t)s->cfg.ahead_chunk_items; pr.flow_paced = 1; }
     return pr;
 }
 
@@ -217,19 +211,13 @@ decode_picture(struct run_state *rs, ovhip_frame *f, uint32_t idx, int job_locke
         if (nc < 0) { (void)ovhip_frame_fail(f, (int)nc); run_fail(rs, (int)nc, "ovhip_calllog_replay", ""); goto out; }
     }
     {
-        ovhip_job_params pr = picture_params(rs, c, ahead);
+        ovhip_job_params pr = picture_params(rs, c);
         ovhip_frame_output out;
         memset(&out, 0, sizeof(out));
         /* the fingerprint is taken by the picture's own frame thread, after the picture was published (16 threads hash 16 pictures;
          * the output thread only puts them in output order) */
         out.mode = ((rs->flags & OVHIP_STREAM_DIGESTS) || s->cfg.output == OVHIP_OUT_DIGEST) ? OVHIP_OUT_DIGEST : OVHIP_OUT_NONE;
         out.window = s->cfg.window;
-        if ((s->cfg.priority_readers > 0 || s->cfg.leaf_low) && p->n_refs) {
-            const int nr = s->readers[idx];
-            const int level = (s->cfg.priority_readers > 0 && nr >= s->cfg.priority_readers) ? -1 : (s->cfg.leaf_low && nr == 0) ? 1 : 0;
-            r = ovhip_ctx_use_priority(ovhip_frame_ctx(f), level);
-            if (r != OVHIP_OK) { (void)ovhip_frame_fail(f, r); run_fail(rs, r, "ovhip_ctx_use_priority", ovhip_frame_last_error(f)); goto out; }
-        }
         if (tr) tr[1] = now_s() - rs->t0;
         const double t_sub = now_s();
         r = ovhip_frame_submit(f, job, NULL, &pr, &out);
@@ -310,45 +298,6 @@ frame_thread(void *argp)
         }
         pthread_mutex_unlock(&q->take);
         decode_picture(rs, f, idx, locked, ahead, a->dev * s->tpd + a->t);
-    }
-    return NULL;
-}
-
-/* ---------------------------------------------------------------- uploader threads */
-/* ovhip_stream_cfg.upload_ahead: the prepare + upload half of the flushes of the pictures just ahead of the frame threads, in
- * decoding order (ovhip_job_upload_ahead).  A picture's job is only touched while nobody holds it (trylock: a picture in flight on
- * the same job keeps it), the frame thread that takes the picture later finds the uploads done or under way. */
-static void *
-uploader_thread(void *argp)
-{
-    struct thread_arg *a = (struct thread_arg *)argp;
-    struct run_state *rs = a->rs;
-    ovhip_stream *s = rs->s;
-    struct dev_queue *q = &rs->q[a->dev];
-    const uint32_t window = (uint32_t)s->cfg.upload_ahead;
-    for (;;) {
-        pthread_mutex_lock(&q->take);
-        uint32_t k = 0;
-        int have = 0;
-        while (!have) {
-            if (rs->abort || q->next >= q->n) break;
-            /* (the next positions are about to be taken -- six: 2 ms at 3000 pictures/s, an upload is enqueued in 0.6 -- and are left
-             * to their frame threads: a frame thread that takes a picture whose job an uploader holds waits for it with the queue
-             * locked, and every other thread with it) */
-            const uint32_t lo = q->next + 6, hi = lo + window < q->n ? lo + window : q->n;
-            for (uint32_t i = lo; i < hi && !have; ++i)
-                if (!q->taken[i] && !q->ahead[i] && rs->pics[q->order[i]].n_refs) { q->ahead[i] = 1; k = i; have = 1; }
-            if (!have) pthread_cond_wait(&q->moved, &q->take);
-        }
-        pthread_mutex_unlock(&q->take);
-        if (!have) break;
-        const ovhip_stream_pic *p = &rs->pics[q->order[k]];
-        if (pthread_mutex_trylock(&s->job_mtx[p->job])) continue;
-        if (!q->taken[k]) {
-            const ovhip_job_params pr = picture_params(rs, &s->contents[p->content], 0);
-            (void)ovhip_job_upload_ahead(s->jobs[p->job], &pr);          /* (a failure leaves the job as it was: the flush uploads) */
-        }
-        pthread_mutex_unlock(&s->job_mtx[p->job]);
     }
     return NULL;
 }
@@ -452,10 +401,8 @@ ovhip_stream_create(ovhip_stream **out, ovhip_dpb *dpb, const ovhip_stream_cfg *
     s->job_mtx = (pthread_mutex_t *)calloc(n_jobs ? n_jobs : 1, sizeof(*s->job_mtx));
     if (!s->frames || !s->out_ctx || !s->job_mtx) r = OVHIP_ENOMEM;
     for (uint32_t i = 0; i < n_jobs && r == OVHIP_OK; ++i) pthread_mutex_init(&s->job_mtx[i], NULL);
-    /* (a look-ahead thread's launches go to a stream of another priority = a hardware queue of its own: an I picture's ordered pass
-     * is one kernel of several milliseconds, and a hardware queue runs its streams' packets in order) */
     for (int i = 0; i < s->n_dev * s->tpd && r == OVHIP_OK; ++i)
-        r = ovhip_frame_create_ex(dpb, i / s->tpd, cfg->w, cfg->h, (i % s->tpd) >= s->n_reg ? cfg->intra_stream_priority : 0, &s->frames[i]);
+        r = ovhip_frame_create(dpb, i / s->tpd, cfg->w, cfg->h, &s->frames[i]);
     /* The look-ahead thread's stream gets a hardware queue to itself: an in-order thread whose stream shares it would sit behind an
      * I picture's ordered pass for milliseconds.  Which stream got which queue is measured (ovhip_ctx_shares_queue); a frame in the
      * wrong company takes new streams until it is out of it (the runtime deals its queues round robin: a few tries). */
@@ -546,17 +493,14 @@ ovhip_stream_run(ovhip_stream *s, const ovhip_stream_pic *pics, uint32_t n_total
     rs.q = (struct dev_queue *)calloc((size_t)s->n_dev, sizeof(*rs.q));
     rs.out_order = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
     const int nthr = s->n_dev * s->tpd;
-    /* (one uploader prepares and enqueues ~1600 pictures/s: four per device stay ahead of 16 frame threads) */
-    const int n_up = (s->cfg.upload_ahead > 0 && !(flags & (OVHIP_STREAM_RECORD | OVHIP_STREAM_RESIDENT))) ? UPLOADERS * s->n_dev : 0;
-    pthread_t *th = (pthread_t *)calloc((size_t)nthr + 2 + (size_t)n_up, sizeof(*th));
-    struct thread_arg *ta = (struct thread_arg *)calloc((size_t)nthr + (size_t)n_up, sizeof(*ta));
+    pthread_t *th = (pthread_t *)calloc((size_t)nthr + 2, sizeof(*th));
+    struct thread_arg *ta = (struct thread_arg *)calloc((size_t)nthr, sizeof(*ta));
     r = rs.q && rs.out_order && th && ta ? OVHIP_OK : OVHIP_ENOMEM;
     for (int k = 0; k < s->n_dev && r == OVHIP_OK; ++k) {
         pthread_mutex_init(&rs.q[k].take, NULL); pthread_cond_init(&rs.q[k].moved, NULL);
         rs.q[k].order = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
         rs.q[k].taken = (unsigned char *)calloc(n ? n : 1, 1);
-        rs.q[k].ahead = (unsigned char *)calloc(n ? n : 1, 1);
-        if (!rs.q[k].order || !rs.q[k].taken || !rs.q[k].ahead) r = OVHIP_ENOMEM;
+        if (!rs.q[k].order || !rs.q[k].taken) r = OVHIP_ENOMEM;
     }
     if (r == OVHIP_OK) {
         for (uint32_t i = first; i < first + n; ++i) {
@@ -574,10 +518,6 @@ ovhip_stream_run(ovhip_stream *s, const ovhip_stream_pic *pics, uint32_t n_total
             if (pthread_create(&th[i], NULL, frame_thread, &ta[i])) { run_fail(&rs, OVHIP_ENOMEM, "pthread_create", ""); break; }
             ++started;
         }
-        for (int i = 0; i < n_up && !rs.abort; ++i) {
-            ta[nthr + i].rs = &rs; ta[nthr + i].dev = i / UPLOADERS; ta[nthr + i].t = i % UPLOADERS;
-            if (!pthread_create(&th[nthr + aux], NULL, uploader_thread, &ta[nthr + i])) ++aux;
-        }
         if (rs.n_out && !rs.abort && !pthread_create(&th[nthr + aux], NULL, output_thread, &rs)) ++aux;
         if (s->cfg.xfer && !rs.abort && !pthread_create(&th[nthr + aux], NULL, comm_thread, &rs)) ++aux;
         for (int i = 0; i < started; ++i) pthread_join(th[i], NULL);
@@ -589,7 +529,7 @@ ovhip_stream_run(ovhip_stream *s, const ovhip_stream_pic *pics, uint32_t n_total
         res->status = r;
     }
     if (rs.abort) ovhip_dpb_rearm_(s->dpb);
-    for (int k = 0; rs.q && k < s->n_dev; ++k) { free(rs.q[k].order); free(rs.q[k].taken); free(rs.q[k].ahead); pthread_cond_destroy(&rs.q[k].moved); pthread_mutex_destroy(&rs.q[k].take); }
+    for (int k = 0; rs.q && k < s->n_dev; ++k) { free(rs.q[k].order); free(rs.q[k].taken); pthread_cond_destroy(&rs.q[k].moved); pthread_mutex_destroy(&rs.q[k].take); }
     free(rs.q); free(rs.out_order); free(th); free(ta);
     pthread_mutex_destroy(&rs.mtx);
     if (res->status || !(flags & OVHIP_STREAM_KEEP)) release_stream(s);

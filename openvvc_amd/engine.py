@@ -662,8 +662,7 @@ class Stream:
 
     def __init__(self, dpb: Dpb, w: int, h: int, contents: list, jobs: list = (), threads_per_device: int = 1, flags: int = 0,
                  output: int = 0, window=(0, 0, 0, 0), extra_stages: int = 0, rank: int = 0, xfer: "capi.StreamXfer | None" = None,
-                 intra_lookahead: int = 0, intra_stream_priority: int = 0, ahead_chunk_items: int = 0, ahead_own_queue: int = 0,
-                 priority_readers: int = 0, leaf_low: int = 0, upload_ahead: int = 0):
+                 intra_lookahead: int = 0, ahead_own_queue: int = 0):
         self.lib, self.dpb = dpb.lib, dpb
         self._contents = (capi.StreamContent * len(contents))()
         self._keep = [contents, jobs, xfer]
@@ -681,9 +680,7 @@ class Stream:
         cfg.extra_stages, cfg.rank = extra_stages, rank
         # a capi.StreamXfer of Python callbacks, or the address of a C one (RcclTransport.xfer: ovhip_rccl_xfer)
         cfg.xfer = (C.cast(C.c_void_p(xfer), C.POINTER(capi.StreamXfer)) if isinstance(xfer, int) else C.pointer(xfer)) if xfer is not None else None
-        cfg.intra_lookahead, cfg.intra_stream_priority, cfg.ahead_chunk_items = intra_lookahead, intra_stream_priority, ahead_chunk_items
-        cfg.ahead_own_queue = ahead_own_queue
-        cfg.priority_readers, cfg.leaf_low, cfg.upload_ahead = priority_readers, leaf_low, upload_ahead
+        cfg.intra_lookahead, cfg.ahead_own_queue = intra_lookahead, ahead_own_queue
         self.cfg = cfg
         s = C.c_void_p()
         r = self.lib.ovhip_stream_create(C.byref(s), dpb.h, C.byref(cfg), self._contents, len(contents), self._jobs, len(jobs))

@@ -71,7 +71,8 @@ static dmvr_fn g_dmvr_inner;
 static gbuf g_dmvr_log = { .type = T_I32 };         /* per call: x, y (picture, luma), log2 w, log2 h, mv0 in, mv1 in, mv0 out, mv1 out */
 static __thread size_t g_dmvr_pos;                  /* shim pass: next entry of the reference pass's log (per frame thread: set to the picture's first call) */
 static int g_pass_shim;                             /* 0 reference slots, 1 installed slots record-only, 2 device half on dry frames, 3 live on the GPU */
-static int g_threads;                               /* "threads N": frame threads of the device / live pass (0: the one-thread loop of the fixtures) */
+static int g_threads;                               /* "threads N[,M,...]": frame threads of the device / live pass (0: the one-thread loop of the fixtures); a list = one pass each */
+static int g_thread_list[16], g_n_thread_list;
 static int g_tile_cols = 1, g_tile_rows = 1;         /* "tiles C R": C x R rect entries per picture, decoded one after the other on ONE OVCTUDec (slicedec.c:649-653) */
 static int g_isp_64x2;                              /* the reference's result for 64x2 ISP partitions is undefined (gen_golden.c, gen_isp) */
 
@@ -586,20 +587,24 @@ run_stream(struct gp_seq *s, const struct gp_pic_desc *desc, int n_pic, uint32_t
 /* ------------------------------------------------------------------------------------------------ frame threads (device / live passes)
  * What ovdec.c:188-248 + ovthreads.c do for the reference: N sub-decoders, each with its own OVSliceDec and OVCTUDec; the next picture
  * in decoding order goes to the next free one; a picture's readers wait for its CTU rows (dpb.c:1242-1323). */
+static void gp_sync_waited(double seconds);
 static void
 gp_synchro(const OVPicture *const ref_pic, int tl_ctu_x, int tl_ctu_y, int br_ctu_x, int br_ctu_y)
 {
     /* ovdpb_synchro_ref_decoded_ctus (dpb.c:1242-1270; static there): wait until the reported-rows mask covers the rectangle */
     const struct PicDecodedCtusInfo *dc = &ref_pic->decoded_ctus;
+    double t0 = 0;
     pthread_mutex_lock(dc->ref_mtx);
     for (;;) {
         int ok = 1;
         for (int y = tl_ctu_y; y <= br_ctu_y && ok; ++y)
             for (int x = tl_ctu_x; x <= br_ctu_x && ok; ++x) ok = (int)((dc->mask[y][x >> 6] >> (x & 63)) & 1);
         if (ok) break;
+        if (t0 == 0) t0 = gp_now();
         pthread_cond_wait(dc->ref_cnd, dc->ref_mtx);
     }
     pthread_mutex_unlock(dc->ref_mtx);
+    if (t0 != 0) gp_sync_waited(gp_now() - t0);
 }
 
 struct gp_thread {
@@ -607,12 +612,16 @@ struct gp_thread {
     struct gp_seq *s; const struct gp_pic_desc *desc; int n_pic;
     OVSliceDec sl; OVCTUDec *c;
     double t_busy, t_hooks;                     /* seconds with a picture in hand / of them inside the row-end and attach hooks (device waits, flush) */
+    double t_sync;                              /* ... waiting for CTU rows of the collocated picture (tmvp_inter_synchronization) */
+    double t_shim_hooks, t_shim_device; uint64_t n_shim_calls;      /* the shim's own profile (ovhip_shim_get_profile), "profile" */
     int n_done, err, frames_differing;
     uint64_t samples_differing, mv_cells_differing, mv_cells_compared;
 };
 static int g_next_pic;
 static int *g_readers_left;                     /* pictures still to read picture k (+ 1: its own comparison) */
 static __thread struct gp_thread *tls_thread;
+static void gp_sync_waited(double seconds) { if (tls_thread) tls_thread->t_sync += seconds; }
+static int g_profile, g_noout;
 
 static void gp_t_attach(struct OVRCNCtx *const r, const OVFrame *const f, const struct RectEntryInfo *const e, uint8_t l2)
 { const double t0 = gp_now(); g_attach_inner(r, f, e, l2); if (tls_thread) tls_thread->t_hooks += gp_now() - t0; }
@@ -621,19 +630,14 @@ static void gp_t_sao_first(OVCTUDec *const c, const struct RectEntryInfo *const 
 static void gp_t_alf_line(OVCTUDec *const c, const struct RectEntryInfo *const e, uint16_t y)
 { const double t0 = gp_now(); g_alf_line_inner(c, e, y); if (tls_thread) tls_thread->t_hooks += gp_now() - t0; }
 
-/* the decoder dropped its last reference to the frame (ovframe_unref reaching zero): the one-line call INTEGRATION.md section 3 adds */
-static void
-gp_reader_done(int k)
-{
-    if (__atomic_sub_fetch(&g_readers_left[k], 1, __ATOMIC_ACQ_REL) == 0 && g_pass_shim == 3) ovhip_shim_frame_released(g_kept[k].pic->frame);
-}
+static void gp_reader_done(int k);
 
 static void
 gp_compare(struct gp_thread *t, const struct gp_seq *s, int k)
 {
     const OVPicture *a = g_kept[k].pic, *b = g_kept[k].ref_pic;
     uint64_t nd = 0, nm = 0, nc = 0;
-    if (g_pass_shim == 3) {
+    if (g_pass_shim == 3 && !g_noout) {
         for (int p = 0; p < 3; ++p) {
             const size_t n = (size_t)(p ? s->w / 2 : s->w) * (size_t)(p ? s->h / 2 : s->h);
             const uint16_t *x = (const uint16_t *)a->frame->data[p], *y = (const uint16_t *)b->frame->data[p];
@@ -694,22 +698,73 @@ gp_decode_kept(struct gp_thread *t, int k)
     t->n_done++;
 }
 
+/* ---- the decoder's frame pool (ovframepool.c): a picture gets its OVFrame when a frame thread takes it (ovdpb_init_picture, when the
+ * slice header has been read) and gives it back when the last picture that references it and the output are done with it -- the NEXT
+ * picture to be taken gets that very OVFrame.  The shim keys the device DPB by the OVFrame pointer + (cvs, POC): this is what makes
+ * a recycled key meet its previous owner's slot (include/ovvc_hip.h, ovhip_dpb_begin_tag). */
+static pthread_mutex_t g_take_mtx = PTHREAD_MUTEX_INITIALIZER;
+static OVFrame *g_frame_pool[GP_MAX_PIC]; static int g_n_frame_pool, g_frames_made, g_frames_recycled;
+static int g_no_release;                         /* "norelease": the decoder never tells the shim that a frame was dropped (ovhip_shim_frame_released is optional) */
+static int g_reps = 1, g_rep;                    /* "reps R": the stream R times on the same frame threads (contexts, jobs, recorders warm); the last one is timed */
+static pthread_barrier_t g_bar;
+
+static OVFrame *
+gp_frame_get(const struct gp_seq *s)
+{
+    if (g_n_frame_pool) { g_frames_recycled++; return g_frame_pool[--g_n_frame_pool]; }
+    OVFrame *f = calloc(1, sizeof(*f));
+    f->width = s->w; f->height = s->h;
+    f->linesize[0] = (size_t)s->w * 2; f->linesize[1] = f->linesize[2] = (size_t)(s->w / 2) * 2;
+    for (int k = 0; k < 3; ++k) {                 /* 16 rows of slack on both sides, as gp_new_picture */
+        const size_t wk = (size_t)(k ? s->w / 2 : s->w), hk = (size_t)(k ? s->h / 2 : s->h);
+        f->data[k] = (uint8_t *)calloc(wk * (hk + 32), 2) + wk * 16 * 2;
+    }
+    g_frames_made++;
+    return f;
+}
+
+static void
+gp_reader_done(int k)
+{
+    if (__atomic_sub_fetch(&g_readers_left[k], 1, __ATOMIC_ACQ_REL)) return;
+    /* the decoder dropped its last reference to the frame (ovframe_unref reaching zero): the one-line call INTEGRATION.md section 3 adds,
+     * then the frame is the pool's again */
+    OVFrame *f = g_kept[k].pic->frame;
+    if (g_pass_shim == 3 && !g_no_release) ovhip_shim_frame_released(f);
+    pthread_mutex_lock(&g_take_mtx);
+    g_frame_pool[g_n_frame_pool++] = f;
+    pthread_mutex_unlock(&g_take_mtx);
+}
+
 static void *
 gp_worker(void *arg)
 {
     struct gp_thread *t = (struct gp_thread *)arg;
     tls_thread = t;
-    for (;;) {
-        const int k = __atomic_fetch_add(&g_next_pic, 1, __ATOMIC_RELAXED);
-        if (k >= t->n_pic) break;
-        const double t0 = gp_now();
-        gp_decode_kept(t, k);
-        t->t_busy += gp_now() - t0;
+    for (int rep = 0; rep < g_reps; ++rep) {
+        pthread_barrier_wait(&g_bar);                                   /* the main thread has made the repetition's pictures */
+        t->t_busy = t->t_hooks = t->t_sync = 0; t->n_done = 0;
+        if (g_profile && g_pass_shim == 3) { ovhip_shim_profile pr; (void)ovhip_shim_get_profile(t->c, &pr, 1); }
+        for (;;) {
+            pthread_mutex_lock(&g_take_mtx);
+            const int k = g_next_pic < t->n_pic ? g_next_pic++ : -1;
+            if (k >= 0) g_kept[k].pic->frame = gp_frame_get(t->s);
+            pthread_mutex_unlock(&g_take_mtx);
+            if (k < 0) break;
+            const double t0 = gp_now();
+            gp_decode_kept(t, k);
+            t->t_busy += gp_now() - t0;
+        }
+        if (g_profile && g_pass_shim == 3) {
+            ovhip_shim_profile pr;
+            if (ovhip_shim_get_profile(t->c, &pr, 0) == 0) { t->t_shim_hooks = pr.seconds_in_hooks; t->t_shim_device = pr.seconds_device; t->n_shim_calls = pr.n_calls; }
+        }
+        pthread_barrier_wait(&g_bar);
     }
     return NULL;
 }
 
-/* returns the wall time of the pass; the per-thread sums land in *tot */
+/* returns the wall time of the (last repetition of the) pass; the per-thread sums land in *tot */
 static double
 run_stream_threads(struct gp_seq *s, const struct gp_pic_desc *desc, int n_pic, int n_threads, struct gp_thread *tot)
 {
@@ -721,33 +776,58 @@ run_stream_threads(struct gp_seq *s, const struct gp_pic_desc *desc, int n_pic, 
         if (ovhip_dpb_create_ex(&dpb, 1, &ops)) { fprintf(stderr, "gen_pipe: ovhip_dpb_create_ex failed\n"); exit(1); }
         ovhip_shim_set_dpb(dpb);
     }
-    /* the pictures exist as objects before any thread runs (the decoder's DPB makes them when it reads the slice header: ovdpb_init_picture) */
-    g_readers_left = calloc(n_pic, sizeof(int));
-    for (int k = 0; k < n_pic; ++k) {
-        const struct gp_pic_desc *d = &desc[k];
-        OVPicture *p = g_kept[k].pic = gp_new_picture(s, d->poc);
-        atomic_init(&p->idx_function, 1);
-        p->ovdpb_frame_synchro[1] = gp_synchro;
-        OVPicture *l0[2] = { d->n0 > 0 ? g_kept[d->l0[0]].pic : NULL, d->n0 > 1 ? g_kept[d->l0[1]].pic : NULL };
-        OVPicture *l1[2] = { d->n1 > 0 ? g_kept[d->l1[0]].pic : NULL, d->n1 > 1 ? g_kept[d->l1[1]].pic : NULL };
-        gp_set_refs(p, l0, d->n0, l1, d->n1, d->tmvp, d->col_from_l0);
-        g_readers_left[k] += 1;
-        for (int i = 0; i < d->n0; ++i) g_readers_left[d->l0[i]]++;
-        for (int i = 0; i < d->n1; ++i) g_readers_left[d->l1[i]]++;
-    }
     struct gp_thread *th = calloc(n_threads, sizeof(*th));
     for (int i = 0; i < n_threads; ++i) {
         th[i].id = i; th[i].s = s; th[i].desc = desc; th[i].n_pic = n_pic;
         gp_alloc_lines(&th[i].sl, s);
         th[i].c = gp_new_ctudec(s);
     }
-    g_next_pic = 0;
-    const double t0 = gp_now();
+    pthread_barrier_init(&g_bar, NULL, n_threads + 1);
+    g_readers_left = calloc(n_pic, sizeof(int));
+    g_frames_made = g_frames_recycled = 0;
     for (int i = 0; i < n_threads; ++i) if (pthread_create(&th[i].th, NULL, gp_worker, &th[i])) { perror("pthread_create"); exit(1); }
+    double wall = 0;
+    for (g_rep = 0; g_rep < g_reps; ++g_rep) {
+        /* the pictures exist as objects before any thread runs (the decoder's DPB makes them when it reads the slice header:
+         * ovdpb_init_picture); their frames come from the pool when a thread takes them.  A repetition is a new coded video sequence:
+         * the same POCs are other pictures (pic_tag in the shim) */
+        for (int k = 0; k < n_pic; ++k) {
+            const struct gp_pic_desc *d = &desc[k];
+            OVPicture *p = g_kept[k].pic = gp_new_picture(s, d->poc);
+            for (int q = 0; q < 3; ++q) { const size_t wk = (size_t)(q ? s->w / 2 : s->w); free(p->frame->data[q] - wk * 16 * 2); }
+            free(p->frame); p->frame = NULL;
+            p->cvs_id = (uint16_t)g_rep;
+            atomic_init(&p->idx_function, 1);
+            p->ovdpb_frame_synchro[1] = gp_synchro;
+            OVPicture *l0[2] = { d->n0 > 0 ? g_kept[d->l0[0]].pic : NULL, d->n0 > 1 ? g_kept[d->l0[1]].pic : NULL };
+            OVPicture *l1[2] = { d->n1 > 0 ? g_kept[d->l1[0]].pic : NULL, d->n1 > 1 ? g_kept[d->l1[1]].pic : NULL };
+            gp_set_refs(p, l0, d->n0, l1, d->n1, d->tmvp, d->col_from_l0);
+            g_readers_left[k] = 1;
+        }
+        for (int k = 0; k < n_pic; ++k) {
+            const struct gp_pic_desc *d = &desc[k];
+            for (int i = 0; i < d->n0; ++i) g_readers_left[d->l0[i]]++;
+            for (int i = 0; i < d->n1; ++i) g_readers_left[d->l1[i]]++;
+        }
+        g_next_pic = 0;
+        const double t0 = gp_now();
+        pthread_barrier_wait(&g_bar);
+        pthread_barrier_wait(&g_bar);
+        wall = gp_now() - t0;
+        for (int k = 0; k < n_pic; ++k) {
+            OVPicture *p = g_kept[k].pic;
+            for (int i = 0; i < s->nb_ctb_h; ++i) free(p->decoded_ctus.mask[i]);
+            free(p->decoded_ctus.mask);
+            free(p->mv_plane0.mvs); free(p->mv_plane0.dirs); free(p->mv_plane1.mvs); free(p->mv_plane1.dirs);
+            free(p);
+            g_kept[k].pic = NULL;
+        }
+    }
     for (int i = 0; i < n_threads; ++i) pthread_join(th[i].th, NULL);
-    const double wall = gp_now() - t0;
+    pthread_barrier_destroy(&g_bar);
     memset(tot, 0, sizeof(*tot));
     for (int i = 0; i < n_threads; ++i) {
+        tot->t_sync += th[i].t_sync; tot->t_shim_hooks += th[i].t_shim_hooks; tot->t_shim_device += th[i].t_shim_device; tot->n_shim_calls += th[i].n_shim_calls;
         tot->t_busy += th[i].t_busy; tot->t_hooks += th[i].t_hooks; tot->n_done += th[i].n_done; tot->frames_differing += th[i].frames_differing;
         tot->samples_differing += th[i].samples_differing; tot->mv_cells_differing += th[i].mv_cells_differing; tot->mv_cells_compared += th[i].mv_cells_compared;
         if (th[i].err && !tot->err) tot->err = th[i].err;
@@ -755,6 +835,12 @@ run_stream_threads(struct gp_seq *s, const struct gp_pic_desc *desc, int n_pic, 
     }
     if (g_pass_shim == 2) { ovhip_shim_set_dpb(NULL); ovhip_dpb_destroy(dpb); }
     free(th);
+    while (g_n_frame_pool) {
+        OVFrame *f = g_frame_pool[--g_n_frame_pool];
+        for (int q = 0; q < 3; ++q) { const size_t wk = (size_t)(q ? s->w / 2 : s->w); free(f->data[q] - wk * 16 * 2); }
+        free(f);
+    }
+    free(g_readers_left); g_readers_left = NULL;
     return wall;
 }
 
@@ -783,8 +869,15 @@ gp_main(int argc, char **argv)
     for (int i = 2; i < argc; ++i) {
         if (!strcmp(argv[i], "shim")) want_shim = 1;
         else if (!strcmp(argv[i], "device")) want_shim = want_dev = 1;
+        else if (!strcmp(argv[i], "reps") && i + 1 < argc) g_reps = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "norelease")) g_no_release = 1;
+        else if (!strcmp(argv[i], "profile")) g_profile = 1;      /* live: the shim's own split of a frame thread's time (ovhip_shim_set_profile) */
+        else if (!strcmp(argv[i], "noout")) g_noout = 1;          /* live: OVHIP_OUT_NONE -- the pictures stay on the device (no copy into the OVFrame, frames not compared) */
         else if (!strcmp(argv[i], "live")) want_live = 1;      /* the shim on the real device, on frame threads; compares in process, prints a JSON line */
-        else if (!strcmp(argv[i], "threads") && i + 1 < argc) g_threads = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "threads") && i + 1 < argc) {
+            for (const char *q = argv[++i]; *q && g_n_thread_list < 16;) { g_thread_list[g_n_thread_list++] = atoi(q); while (*q && *q != ',') ++q; if (*q) ++q; }
+            g_threads = g_n_thread_list ? g_thread_list[0] : 0;
+        }
         else if (!strcmp(argv[i], "simd")) g_simd = 1;        /* the reference pass through the reference's SSE4.1 / AVX2 back-end (ref_common.h) */
         else if (!strcmp(argv[i], "name") && i + 1 < argc) name = argv[++i];
         else if (!strcmp(argv[i], "seed") && i + 1 < argc) seed = (uint32_t)strtoul(argv[++i], NULL, 0);
@@ -798,7 +891,8 @@ gp_main(int argc, char **argv)
         else { fprintf(stderr, "gen_pipe: unknown argument %s\n", argv[i]); return 2; }
     }
     if (W % 8 || H % 8 || W < 136 || H < 136 || W > 4096 || H > 2304 || n_pic < 1 || n_pic > GP_MAX_PIC) { fprintf(stderr, "gen_pipe: size / pics\n"); return 2; }
-    if (want_live && !g_threads) g_threads = 1;
+    if (want_live && !g_threads) { g_threads = 1; g_thread_list[0] = 1; g_n_thread_list = 1; }
+    for (int i = 0; i < g_n_thread_list; ++i) if (g_thread_list[i] < 1 || g_thread_list[i] > 64) { fprintf(stderr, "gen_pipe: threads\n"); return 2; }
     if (g_threads < 0 || g_threads > 64 || (g_threads && !want_live && !want_dev) || (g_threads && want_time)) { fprintf(stderr, "gen_pipe: threads\n"); return 2; }
     if (g_threads) g_kept = calloc(n_pic, sizeof(*g_kept));
     while (g_payload_bytes < (size_t)W * H * 2) g_payload_bytes <<= 1;          /* 16 bits per sample: far above any slice's need */
@@ -849,17 +943,27 @@ gp_main(int argc, char **argv)
         const double t_ref = gp_now() - tr0;
         if (g_isp_64x2) { fprintf(stderr, "gen_pipe: the stream holds %d 64x2 ISP partitions (reference result undefined): pick another seed\n", g_isp_64x2); return 1; }
         g_pass_shim = want_live ? 3 : 2;
-        fprintf(stderr, "gen_pipe: %s pass, %d frame thread%s\n", want_live ? "live" : "device (dry)", g_threads, g_threads > 1 ? "s" : "");
-        struct gp_thread tot;
-        const double wall = run_stream_threads(&seq, gop, n_pic, g_threads, &tot);
-        printf("{\"mode\": \"%s\", \"frame_threads\": %d, \"pictures\": %d, \"width\": %d, \"height\": %d, \"seconds\": %.6f, \"pictures_per_second\": %.3f, "
-               "\"pictures_decoded\": %d, \"shim_error\": %d, \"frames_differing\": %d, \"samples_differing\": %llu, \"collocated_motion_entries_differing\": %llu, \"collocated_motion_entries_compared\": %llu, "
-               "\"dmvr_calls\": %zu, \"thread_seconds_with_a_picture\": %.6f, \"thread_seconds_in_row_end_and_attach_hooks\": %.6f, "
-               "\"reference_pass_seconds_inside_slicedec\": %.6f, \"reference_pass_seconds\": %.6f}\n",
-               want_live ? "live" : "device_dry_threads", g_threads, n_pic, W, H, wall, n_pic / wall, tot.n_done, tot.err, tot.frames_differing,
-               (unsigned long long)tot.samples_differing, (unsigned long long)tot.mv_cells_differing, (unsigned long long)tot.mv_cells_compared, g_dmvr_log.n / 12, tot.t_busy, tot.t_hooks,
-               g_decode_seconds_pass[0], t_ref);
-        return (tot.err || tot.samples_differing || tot.mv_cells_differing || tot.n_done != n_pic) ? 1 : 0;
+        if (want_live && g_profile) ovhip_shim_set_profile(1);
+        if (want_live && g_noout) ovhip_shim_set_output(OVHIP_OUT_NONE);
+        int bad = 0;
+        for (int li = 0; li < g_n_thread_list; ++li) {
+            g_threads = g_thread_list[li];
+            fprintf(stderr, "gen_pipe: %s pass, %d frame thread%s\n", want_live ? "live" : "device (dry)", g_threads, g_threads > 1 ? "s" : "");
+            struct gp_thread tot;
+            const double wall = run_stream_threads(&seq, gop, n_pic, g_threads, &tot);
+            printf("{\"mode\": \"%s\", \"frame_threads\": %d, \"pictures\": %d, \"width\": %d, \"height\": %d, \"seconds\": %.6f, \"pictures_per_second\": %.3f, "
+                   "\"pictures_decoded\": %d, \"shim_error\": %d, \"frames_differing\": %d, \"samples_differing\": %llu, \"collocated_motion_entries_differing\": %llu, \"collocated_motion_entries_compared\": %llu, "
+                   "\"dmvr_calls\": %zu, \"thread_seconds_with_a_picture\": %.6f, \"thread_seconds_in_row_end_and_attach_hooks\": %.6f, "
+                   "\"reference_pass_seconds_inside_slicedec\": %.6f, \"reference_pass_seconds\": %.6f, \"repetitions\": %d, \"host_frames_made\": %d, \"host_frames_recycled\": %d, \"output\": \"%s\", "
+                   "\"thread_seconds_waiting_for_collocated_rows\": %.6f, \"shim_profile\": %d, \"thread_seconds_in_shim_hooks\": %.6f, \"thread_seconds_in_shim_device_half\": %.6f, \"shim_hook_calls\": %llu}\n",
+                   want_live ? "live" : "device_dry_threads", g_threads, n_pic, W, H, wall, n_pic / wall, tot.n_done, tot.err, tot.frames_differing,
+                   (unsigned long long)tot.samples_differing, (unsigned long long)tot.mv_cells_differing, (unsigned long long)tot.mv_cells_compared, g_dmvr_log.n / 12, tot.t_busy, tot.t_hooks,
+                   g_decode_seconds_pass[0], t_ref, g_reps, g_frames_made, g_frames_recycled, g_noout ? "none" : "planes into the OVFrame",
+                   tot.t_sync, g_profile, tot.t_shim_hooks, tot.t_shim_device, (unsigned long long)tot.n_shim_calls);
+            fflush(stdout);
+            bad |= tot.err || tot.samples_differing || tot.mv_cells_differing || tot.n_done != n_pic;
+        }
+        return bad;
     }
     for (g_pass_shim = 0; g_pass_shim <= want_shim + want_dev; ++g_pass_shim) {
         g_seed = 0x266 + 4242;

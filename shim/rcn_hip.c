@@ -109,10 +109,25 @@ struct hip_entry {
     /* the luma of an affine CU has been recorded (with its chroma): the rcn_mcp_b_c(3,3) calls of the SAME CU that follow
      * carry nothing new.  Rectangle in CTU-local luma samples; any other slot call ends it. */
     int aff_c_live, aff_c_x0, aff_c_y0, aff_c_x1, aff_c_y1;
+    struct { int depth; uint64_t t0, ticks_hooks, ticks_device, n_calls; } prof;
     /* a CIIP CU whose planar tasks wait for the CU's transform unit (which carries their residual); closed without one by
      * the next slot call that is not that transform unit */
     struct { int live, x0, y0, log2_w, log2_h, has_c; ovhip_itask tl, tc; } ciip;
 };
+
+/* ---- where a frame thread's time goes inside the back-end (ovhip_shim_set_profile): every installed hook brackets itself; the
+ * device half (begin_picture, dmvr_rows_step, flush_picture: waits for reference pictures, launches, ovhip_job_wait, the copy into the
+ * OVFrame) is counted apart from the recording.  Off: one predictable branch per hook. */
+static int g_prof_on;
+#if defined(__x86_64__)
+static inline uint64_t prof_tick(void) { return __builtin_ia32_rdtsc(); }
+#else
+#include <time.h>
+static inline uint64_t prof_tick(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (uint64_t)t.tv_sec * 1000000000ull + (uint64_t)t.tv_nsec; }
+#endif
+#include <time.h>
+static uint64_t g_prof_tick0; static double g_prof_s0;
+static double prof_now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 
 static struct hip_entry *g_entries[256];
 static pthread_mutex_t g_mtx = PTHREAD_MUTEX_INITIALIZER;
@@ -151,6 +166,20 @@ latch(struct hip_entry *e, int code, const char *what)
     e->err = code;
     ov_log(NULL, OVLOG_ERROR, "rcn_hip: %s failed (%d)%s%s\n", what, code, e->fr ? ": " : "", e->fr ? ovhip_frame_last_error(e->fr) : "");
 }
+
+struct prof_scope { struct hip_entry *e; };
+static inline struct prof_scope
+prof_enter(struct hip_entry *e)
+{
+    struct prof_scope p = { NULL };
+    if (g_prof_on && e) { p.e = e; if (e->prof.depth++ == 0) { e->prof.t0 = prof_tick(); e->prof.n_calls++; } }
+    return p;
+}
+static inline void prof_leave(struct prof_scope *p) { if (p->e && --p->e->prof.depth == 0) p->e->prof.ticks_hooks += prof_tick() - p->e->prof.t0; }
+#define PROF(e) struct prof_scope prof_scope_ __attribute__((cleanup(prof_leave))) = prof_enter(e)
+/* the device half inside a hook */
+#define PROF_DEVICE_BEGIN(e) const uint64_t prof_dev_t0_ = g_prof_on ? prof_tick() : 0
+#define PROF_DEVICE_END(e)   do { if (g_prof_on) (e)->prof.ticks_device += prof_tick() - prof_dev_t0_; } while (0)
 
 static inline OVCTUDec *ctudec_of_lmcs(struct LMCSInfo *li) { return (OVCTUDec *)((char *)li - offsetof(OVCTUDec, lmcs_info)); }
 
@@ -206,6 +235,7 @@ static void ciip_close(struct hip_entry *e, OVCTUDec *c);
 #define ENTER(c)                                               \
     struct hip_entry *e = entry_of((c), 0);                    \
     if (!e || !e->rec) return;                                 \
+    PROF(e);                                                   \
     e->aff_c_live = 0;                                         \
     if (e->ciip.live) ciip_close(e, (OVCTUDec *)(c));          \
     if (e->pend.kind) pend_close(e, (OVCTUDec *)(c))
@@ -451,6 +481,7 @@ hip_rcn_transform_tree(OVCTUDec *const c, uint8_t x0, uint8_t y0, uint8_t log2_t
         hip_rcn_tu_c(c, x0, y0, log2_tb_w, log2_tb_h, cu_flags, tu->cbf_mask, tu);
     } else {
         struct hip_entry *e = entry_of(c, 0);
+        PROF(e);
         if (e && e->rec) {
             ovhip_itask tl;
             const ovhip_itask *task_l = NULL, *task_c = NULL;
@@ -549,6 +580,7 @@ hip_rcn_ibc(OVCTUDec *const c, int16_t x0, int16_t y0, uint8_t log2_cu_w, uint8_
 {
     (void)x0; (void)y0; (void)log2_cu_w; (void)log2_cu_h; (void)log2_ctu_s; (void)mv;
     struct hip_entry *e = entry_of(c, 0);
+    PROF(e);
     if (e) latch(e, OVHIP_EUNSUP, "intra block copy (IBC) coding unit");
 }
 
@@ -689,6 +721,7 @@ hip_rcn_mcp_b_l(OVCTUDec *const c, struct OVBuffInfo dst, struct InterDRVCtx *co
 {
     (void)dst; (void)part_ctx;
     struct hip_entry *e = entry_of(c, 0);
+    PROF(e);
     if (!e || !e->rec) return;
     if (log2_pb_w == 2 && log2_pb_h == 2) { pend_affine_add(e, c, x0, y0, mv0, mv1, inter_dir, ref_idx0, ref_idx1, 0, NULL); return; }
     if (e->pend.kind) pend_close(e, c);
@@ -708,6 +741,7 @@ hip_rcn_prof_mcp_b_l(OVCTUDec *const c, struct OVBuffInfo dst, struct InterDRVCt
 {
     (void)dst; (void)ic; (void)part_ctx; (void)log2_pb_w; (void)log2_pb_h;
     struct hip_entry *e = entry_of(c, 0);
+    PROF(e);
     if (!e || !e->rec) return;
     pend_affine_add(e, c, x0, y0, mv0, mv1, inter_dir, ref_idx0, ref_idx1, prof_dir, prof_info);
 }
@@ -721,6 +755,7 @@ hip_rcn_mcp_b_c(OVCTUDec *const c, struct OVBuffInfo dst, struct InterDRVCtx *co
 {
     (void)dst; (void)part_ctx;
     struct hip_entry *e = entry_of(c, 0);
+    PROF(e);
     if (!e || !e->rec) return;
     if (e->pend.kind == PEND_AFFINE && log2_pb_w == 3 && log2_pb_h == 3 && (int)x0 == e->pend.x0 && (int)y0 == e->pend.y0) {
         /* first chroma call of the affine CU being collected closes its luma; the recorder derives the chroma vectors
@@ -768,6 +803,7 @@ hip_rcn_bdof_mcp_l(OVCTUDec *const c, struct OVBuffInfo dst, uint8_t x0, uint8_t
 {
     (void)dst;
     struct hip_entry *e = entry_of(c, 0);
+    PROF(e);
     if (!e || !e->rec) return;
     e->aff_c_live = 0;
     if (e->pend.kind == PEND_BDOF && (e->pend.n >= 64 || log2_pu_w != e->pend.bl2w || log2_pu_h != e->pend.bl2h || mv0.x != e->pend.bmv0.x
@@ -798,6 +834,7 @@ hip_rcn_dmvr_mv_refine(OVCTUDec *const c, struct OVBuffInfo dst, uint8_t x0, uin
 {
     (void)dst;
     struct hip_entry *e = entry_of(c, 0);
+    PROF(e);
     if (!e || !e->rec) return 0;
     e->aff_c_live = 0;
     if (e->pend.kind) pend_close(e, c);
@@ -912,6 +949,7 @@ hip_rcn_init_lmcs(struct LMCSInfo *li, const struct OVLMCSData *const ld)
 {
     OVCTUDec *c = ctudec_of_lmcs(li);
     struct hip_entry *e = entry_of(c, 0);
+    PROF(e);
     if (!e) return;
     e->scalar.rcn_init_lmcs(li, ld);
     ovhip_lmcs_data hd;
@@ -1096,11 +1134,13 @@ dmvr_rows_step(struct hip_entry *e, OVCTUDec *c, int final)
     if (!e->fr || e->err) return;
     const size_t now = e->n_refined;
     if (now == e->dmvr_done) { e->row_mark = now; return; }
+    PROF_DEVICE_BEGIN(e);
     int64_t done = ovhip_frame_dmvr_rows_collect(e->fr);
     if (done >= 0 && (size_t)done < now && (final || (size_t)done < e->row_mark)) {
         done = ovhip_frame_dmvr_rows_begin(e->fr, e->log2_ctu);
         if (done >= 0) done = ovhip_frame_dmvr_rows_collect(e->fr);
     }
+    PROF_DEVICE_END(e);
     if (done < 0) { latch(e, (int)done, "ovhip_frame_dmvr_rows"); return; }
     if ((size_t)done > e->dmvr_done) {
         size_t n = 0;
@@ -1111,7 +1151,9 @@ dmvr_rows_step(struct hip_entry *e, OVCTUDec *c, int final)
         e->dmvr_done = (size_t)done;
     }
     if (!final && now > (size_t)done) {
+        PROF_DEVICE_BEGIN(e);
         const int64_t r = ovhip_frame_dmvr_rows_begin(e->fr, e->log2_ctu);
+        PROF_DEVICE_END(e);
         if (r < 0) latch(e, (int)r, "ovhip_frame_dmvr_rows_begin");
     }
     e->row_mark = now;
@@ -1292,7 +1334,9 @@ flush_picture(struct hip_entry *e, OVCTUDec *c)
     out.y = (uint16_t *)f->data[0]; out.cb = (uint16_t *)f->data[1]; out.cr = (uint16_t *)f->data[2];
     out.stride_y = (int32_t)(f->linesize[0] / 2); out.stride_c = (int32_t)(f->linesize[1] / 2);
     /* (every refined vector is in the TMVP planes already: dmvr_rows_step(final) ran in the hook that called this) */
+    PROF_DEVICE_BEGIN(e);
     latch(e, ovhip_frame_submit(e->fr, NULL, NULL, &pr, &out), "ovhip_frame_submit");
+    PROF_DEVICE_END(e);
 }
 
 static void
@@ -1336,6 +1380,7 @@ begin_picture(struct hip_entry *e, const OVFrame *f, const struct RectEntryInfo 
     if (e->rec && e->key->part_ctx) (void)ovhip_rec_set_ctu_size(e->rec, e->key->part_ctx->log2_ctu_s);
     if (e->n_ctu) { memset(e->sao, 0, e->n_ctu * sizeof(*e->sao)); memset(e->alf, 0, e->n_ctu * sizeof(*e->alf)); }
     if (e->record_only) { ovhip_rec_reset(e->rec); return; }
+    PROF_DEVICE_BEGIN(e);
     int r = dpb_get(e);
     if (r != OVHIP_OK) { latch(e, r, "ovhip_dpb_create (the HIP back-end has no CPU fallback)"); return; }
     if (e->fr && (e->pic_w != (int)f->width || e->pic_h != (int)f->height)) { ovhip_frame_destroy(e->fr); e->fr = NULL; e->rec = NULL; }
@@ -1350,6 +1395,7 @@ begin_picture(struct hip_entry *e, const OVFrame *f, const struct RectEntryInfo 
     const OVPicture *cur = pl0 ? (const OVPicture *)((const char *)pl0 - offsetof(OVPicture, mv_plane0)) : NULL;
     latch(e, ovhip_frame_begin_tag(e->fr, f, cur && cur->frame == f ? pic_tag(cur) : 0), "ovhip_frame_begin");
     e->rec = ovhip_frame_recorder(e->fr);
+    PROF_DEVICE_END(e);
     if (!e->rec) { latch(e, OVHIP_ENOMEM, "ovhip_frame_recorder"); return; }
     (void)ovhip_rec_set_ctu_size(e->rec, e->key->part_ctx ? e->key->part_ctx->log2_ctu_s : 7);
     /* the slice's reference lists are known now (slicedec.c:1250-1256): a device that did not decode them asks for them before
@@ -1367,6 +1413,7 @@ hip_attach_frame_buff(struct OVRCNCtx *const rcn_ctx, const OVFrame *const f, co
 {
     OVCTUDec *c = rcn_ctx->ctudec;
     struct hip_entry *e = entry_of(c, 0);
+    PROF(e);
     if (!e) return;
     /* the scalar attach keeps rcn_ctx->frame_buff / frame_start valid for every host-side reader */
     e->scalar.rcn_attach_frame_buff(rcn_ctx, f, einfo, log2_ctb_s);
@@ -1444,6 +1491,28 @@ rcn_init_functions_hip(struct RCNFunctions *f, uint8_t ict_type, uint8_t lm_chro
 }
 
 /* ------------------------------------------------------------------------------------ management */
+void
+ovhip_shim_set_profile(int on)
+{
+    if (on && !g_prof_on) { g_prof_tick0 = prof_tick(); g_prof_s0 = prof_now_s(); }
+    g_prof_on = on != 0;
+}
+
+int
+ovhip_shim_get_profile(const OVCTUDec *c, ovhip_shim_profile *out, int reset)
+{
+    struct hip_entry *e = entry_of(c, 0);
+    if (!e || !out) return OVHIP_EINVAL;
+    const double dt = prof_now_s() - g_prof_s0;
+    const uint64_t dtick = prof_tick() - g_prof_tick0;
+    const double s_per_tick = dtick ? dt / (double)dtick : 0.0;           /* (rdtsc calibrated against CLOCK_MONOTONIC over the profile's life) */
+    out->seconds_in_hooks = (double)e->prof.ticks_hooks * s_per_tick;
+    out->seconds_device = (double)e->prof.ticks_device * s_per_tick;
+    out->n_calls = e->prof.n_calls;
+    if (reset) memset(&e->prof, 0, sizeof(e->prof));
+    return OVHIP_OK;
+}
+
 int
 ovhip_shim_bind_recorder(const OVCTUDec *c, ovhip_recorder *rec, int pic_w, int pic_h)
 {

@@ -51,6 +51,13 @@ const struct ovhip_alf_ctu *ovhip_shim_alf_params(const struct OVCTUDec *ctudec,
 const int16_t *ovhip_shim_alf_table(const struct OVCTUDec *ctudec, int which /* 0 luma coeff, 1 luma clip, 2 chroma coeff, 3 chroma clip, 4 cc */, size_t *n);
 const struct ovhip_lmcs_luts *ovhip_shim_lmcs(const struct OVCTUDec *ctudec);
 void ovhip_shim_release(const struct OVCTUDec *ctudec);
+/* Where a frame thread's time goes inside the back-end: wall seconds this OVCTUDec spent in the installed hooks since the profile was
+ * switched on (or last reset), the part of them in the device half (picture begin, eager DMVR rows, the submit: waits for reference
+ * pictures, launches, ovhip_job_wait, the copy into the OVFrame), and the number of outermost hook calls.  Recording = the difference.
+ * Off (default): one branch per hook. */
+typedef struct ovhip_shim_profile { double seconds_in_hooks, seconds_device; uint64_t n_calls; } ovhip_shim_profile;
+void ovhip_shim_set_profile(int on);
+int  ovhip_shim_get_profile(const struct OVCTUDec *ctudec, ovhip_shim_profile *out, int reset);
 /* What the last alf.rcn_alf_filter_line of a picture copies into the OVFrame after the picture is complete: OVHIP_OUT_PLANES
  * (default: an unmodified application reads the frame there, dectest.c:372-409) or OVHIP_OUT_NONE (the application takes its
  * frames through ovhip_shim_frame_output / _digest: no 24.9 MB copy per 4K picture).  Also: environment OVVC_HIP_OUTPUT=none. */

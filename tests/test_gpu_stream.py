@@ -326,75 +326,3 @@ def test_frame_api_as_the_shim_uses_it(built_lib):
     r = f2.submit(engine.Job.make_params(k3, wl2), check=False)
     assert r == capi.OVHIP_EREF
     f1.close(); f2.close(); dpb.close()
-
-
-def test_uploads_ahead_of_the_frame_threads_give_the_same_pictures(built_lib):
-    """ovhip_stream_cfg.upload_ahead: uploader threads run the prepare + upload half of the next pictures' flushes
-    (ovhip_job_upload_ahead) ahead of the frame threads; the flush then restores what they produced and uploads nothing.  Same
-    pictures as the oracle's, run after run on the same jobs, with fewer frame threads than the window is wide (jobs whose
-    picture is in flight are left alone) -- and a flush with OTHER stages than the upload was made for uploads again."""
-    w, h = 832, 480
-    wls = _contents(w, h, (0x266, 0x1266, 0x2266), 0x9266)
-    pics = gop.build_stream(2, 16, 32, 1)
-    spics = _stream_pics(pics, 3)
-    planes = _oracle_stream(wls, spics)
-    ctx = engine.Context(0)
-    dpb = engine.Dpb((0,))
-    jobs = _jobs_for(ctx, wls, spics, w, h)
-    for threads, window in ((8, 8), (3, 12)):
-        st = engine.Stream(dpb, w, h, _make_contents(wls), jobs, threads_per_device=threads, upload_ahead=window)
-        arr = st.pics_array(spics)
-        for rep in range(2):
-            res, dg = st.run(arr, len(spics), 0, len(spics), flags=capi.STREAM_KEEP | capi.STREAM_HOLD_ALL, digests=True)
-            assert res.status == 0 and res.n_decoded == len(spics)
-            _compare(st, ctx, planes, range(len(spics)), f"upload ahead {window}, {threads} threads, decode {rep}")
-        h2d = [j.stats().h2d_bytes for j in jobs]
-        assert sum(1 for b in h2d if b == 0) >= len(jobs) // 2, "most flushes found their uploads done"
-        st.close()
-    # the job-level call by hand: upload ahead for the full pipeline, then a flush WITHOUT the in-loop filters -> it must upload itself
-    wl = wls[0]
-    job = jobs[[p["content"] for p in spics].index(0)]
-    full = job.make_params(wl)
-    assert job.lib.ovhip_job_upload_ahead(job.j, C.byref(full)) == 0
-    refs = [ctx.upload_pic(*r) for r in wl.refs]
-    dst = ctx.new_pic(w, h)
-    part = job.make_params(wl)
-    part.stages = capi.STAGE_MC | capi.STAGE_ITX | capi.STAGE_INTRA
-    job.flush(dst, refs, None, params=part); job.wait()
-    assert job.stats().h2d_bytes > 0
-    want = oracle_pipeline.decode(wl, stages=("mc", "itx"))
-    got = dst.download()
-    assert np.array_equal(got[0], want.y) and np.array_equal(got[1], want.cb)
-    [j.close() for j in jobs]; dpb.close(); ctx.close()
-
-
-def test_execution_gate_and_stream_priorities_change_nothing_but_the_schedule(built_lib):
-    """ovhip_dpb_set_exec_slots (at most N pictures of a device between "references done" and "complete", oldest first) and
-    ovhip_stream_cfg.priority_readers / leaf_low (pictures other pictures wait for on a high-priority stream, leaf pictures on a
-    low-priority one): the same pictures as the oracle's, more frame threads than slots, and the gate's slots all given back."""
-    w, h = 832, 480
-    wls = _contents(w, h, (0x266, 0x1266, 0x2266), 0x9266)
-    pics = gop.build_stream(2, 16, 32, 1)
-    spics = _stream_pics(pics, 3)
-    planes = _oracle_stream(wls, spics)
-    ctx = engine.Context(0)
-    dpb = engine.Dpb((0,))
-    jobs = _jobs_for(ctx, wls, spics, w, h)
-    for slots, readers, leaf_low in ((3, 0, 0), (0, 1, 1), (2, 2, 0)):
-        dpb.lib.ovhip_dpb_set_exec_slots(dpb.h, slots)
-        st = engine.Stream(dpb, w, h, _make_contents(wls), jobs, threads_per_device=8, priority_readers=readers, leaf_low=leaf_low)
-        arr = st.pics_array(spics)
-        for rep in range(2):
-            res, dg = st.run(arr, len(spics), 0, len(spics), flags=capi.STREAM_KEEP | capi.STREAM_HOLD_ALL, digests=True)
-            assert res.status == 0 and res.n_decoded == len(spics)
-            for i in range(len(spics)):
-                assert bytes(dg[i]) == oo.picture_digest(*planes[i]), (slots, readers, leaf_low, rep, i)
-        st.close()
-    dpb.lib.ovhip_dpb_set_exec_slots(dpb.h, 1)
-    # a gate of ONE slot still lets a whole stream through (nobody kept a slot)
-    st = engine.Stream(dpb, w, h, _make_contents(wls), jobs, threads_per_device=4)
-    res, dg = st.run(st.pics_array(spics), len(spics), 0, len(spics), flags=capi.STREAM_KEEP | capi.STREAM_HOLD_ALL, digests=True)
-    assert res.status == 0 and bytes(dg[-1]) == oo.picture_digest(*planes[-1])
-    st.close()
-    dpb.lib.ovhip_dpb_set_exec_slots(dpb.h, 0)
-    [j.close() for j in jobs]; dpb.close(); ctx.close()
