@@ -112,6 +112,9 @@ def main():
                     help="skip the leg on the stream the REFERENCE's own slice decoder parses and decodes (oracle/_ref/gen_pipe, prebuilt from "
                          "/root/reference in the build container): its scalar / SIMD decode rate on this host's cores = cpu_baseline kind "
                          "\"reference\", and the same nine 3840x2160 pictures through the HIP engine compared byte for byte with the reference's frames")
+    ap.add_argument("--no-live-decoder", action="store_true",
+                    help="skip the leg in which the reference's slice decoder + parser drive the installed shim on this GPU on 1 .. 16 frame threads "
+                         "(oracle/_ref/gen_pipe live): decoded pictures/s with parsing inside, compared with the reference pass in process")
     ap.add_argument("--no-isolated-survey", action="store_true",
                     help="skip the one-picture-in-flight survey and the variants: every launch of the process then runs in the timed configuration "
                          "(what tools/profile_round.sh traces, so that rocprofv3's per-kernel averages are of that configuration)")
@@ -631,6 +634,12 @@ def main():
         if ref_stream and (ref_stream["samples_differing_from_the_reference"] or ref_stream["refined_vectors_differing"]):
             raise SystemExit(f"bench: the reference's stream decodes differently on the device: {ref_stream}")
 
+    live = None
+    if rank == 0 and not args.no_reference_stream and not args.no_live_decoder and (W, H) == (3840, 2160):
+        live = live_decoder_rates(W, H)
+        if live and not live["bit_exact"]:
+            raise SystemExit(f"bench: the live decode differs from the reference pass: {live}")
+
     if rank == 0:
         algs = [algorithmic_bytes(wl, FB) for wl in wls]
         use = np.zeros(len(wls))
@@ -778,6 +787,7 @@ def main():
                        "ordered_pass_second_passes": second_passes[0],
                        "check": check,
                        "reference_stream": ref_stream,
+                       "live_decoder": live,
                        "launches_per_b_picture": int(js.n_launches),
                        "launches_per_i_picture": int(all_stats[n_jobs].n_launches),
                        "h2d_copies_per_step": round(mean_stat("n_h2d"), 1),
@@ -879,6 +889,70 @@ def reference_cpu_rates(W, H, n_pics, ncpu):
                                                "one thread, pictures/s: the rate at which ONE frame thread of a real decoder can feed the device"}
     except (OSError, ValueError, KeyError, IndexError):
         return None
+    return out
+
+
+def live_decoder_rates(W, H, n_pics=33, threads=(1, 2, 4, 8, 16), reps=3):
+    """A LIVE decode on this GPU (oracle/ref_harness/gen_pipe.c "live", tests/test_gpu_live.py): the reference's own slice decoder + parser
+    (libovvc/slicedec.c, vcl_*.c) drive the INSTALLED shim -- its own device DPB, ovhip_frame_submit launching, every picture copied into
+    its OVFrame -- on N frame threads over a chained stream (I + GOPs of 8, seeded slice data), the DMVR slot returning what the shim
+    returns and the collocated motion planes holding what the device delivered.  Every frame and every meaningful collocated-motion
+    entry is compared with the reference pass (scalar slots, one thread) inside the harness.  The stream is decoded `reps` times on the
+    same frame threads (contexts, jobs, page-locked arrays warm); the last repetition is the one reported.
+    -> dict or None when the prebuilt harness is not there."""
+    import subprocess
+    if not GEN_PIPE.exists():
+        return None
+
+    def run(tl, extra):
+        cmd = [str(GEN_PIPE), "/tmp", "live", "threads", ",".join(str(t) for t in tl), "size", str(W), str(H), "pics", str(n_pics), "reps", str(reps), "profile"] + extra
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        except (OSError, subprocess.TimeoutExpired):
+            return None
+        rows = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+        if len(rows) != len(tl):
+            print(f"bench: live_decoder_rates: gen_pipe rc {p.returncode}: {p.stderr[-400:]}", file=sys.stderr)
+            return None
+        return rows, p.returncode
+
+    def summary(d):
+        n = d["pictures"]
+        ms = lambda k: 1e3 * d[k] / n
+        held, sync = ms("thread_seconds_with_a_picture"), ms("thread_seconds_waiting_for_collocated_rows")
+        hooks, dev = ms("thread_seconds_in_shim_hooks"), ms("thread_seconds_in_shim_device_half")
+        # the profile brackets every outermost hook call with two time-stamp reads: their cost is measured by the harness and taken out
+        over = 1e3 * d.get("shim_profile_overhead_seconds_per_call", 0.0) * d["shim_hook_calls"] / n
+        rec = max(0.0, hooks - dev - over)
+        parse = max(0.0, held - sync - hooks)
+        r = lambda v: round(v, 2)
+        return {"pictures_per_second": round(d["pictures_per_second"], 1),
+                "frame_thread_ms_per_picture": {"holding_a_picture": r(held), "parse": r(parse), "recording": r(rec), "profile_overhead": r(over),
+                                                "device_half_incl_waits_for_reference_pictures": r(dev), "waiting_for_collocated_rows": r(sync)},
+                "shares_of_a_frame_threads_time": {"parse": r(parse / held), "recording": r(rec / held), "device_half_and_waits": r((dev + sync) / held)},
+                "shim_hook_calls_per_picture": d["shim_hook_calls"] // n}
+
+    a = run(threads, [])
+    if a is None:
+        return None
+    b = run((threads[0], threads[-1]), ["noout"])
+    rows, rc = a
+    out = {"what": "the reference's slice decoder + parser driving the installed shim on this GPU (gen_pipe live): decoded pictures/s WITH parsing, recording, "
+                   "uploads, device decode, the eager DMVR rows and the copy of every picture into its OVFrame inside; frames and collocated motion planes "
+                   "compared with the reference pass in the same process",
+           "stream": {"pictures": n_pics, "width": W, "height": H, "structure": "I + GOPs of 8 (I B8 B4 B2 P6 b1 b3 b5 b7, then B16 ...), seeded slice data: the parse is a "
+                      "random walk through legal syntax (DESIGN 2): more and smaller coding units than an encoder would choose", "dmvr_calls": rows[0]["dmvr_calls"],
+                      "repetitions_on_warm_frame_threads": reps},
+           "bit_exact": rc == 0 and all(d["samples_differing"] == 0 and d["collocated_motion_entries_differing"] == 0 and d["shim_error"] == 0 and d["pictures_decoded"] == n_pics for d in rows),
+           "samples_compared": int(W * H * 3 // 2 * n_pics), "collocated_motion_entries_compared": rows[0]["collocated_motion_entries_compared"] // reps,
+           "host_frames_recycled": rows[0]["host_frames_recycled"],
+           "by_frame_threads": {str(d["frame_threads"]): summary(d) for d in rows},
+           "reference_scalar_decoder_same_stream_one_thread_fps": round(n_pics / rows[0]["reference_pass_seconds_inside_slicedec"], 2)}
+    if b is not None:
+        out["output_none"] = {"what": "the same with OVHIP_OUT_NONE (pictures stay on the device; an application takes them through ovhip_shim_frame_output / _digest): "
+                                      "collocated motion planes compared, frames not",
+                              "by_frame_threads": {str(d["frame_threads"]): summary(d) for d in b[0]}}
+        out["bit_exact"] = out["bit_exact"] and b[1] == 0
     return out
 
 

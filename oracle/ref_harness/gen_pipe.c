@@ -622,6 +622,7 @@ static int *g_readers_left;                     /* pictures still to read pictur
 static __thread struct gp_thread *tls_thread;
 static void gp_sync_waited(double seconds) { if (tls_thread) tls_thread->t_sync += seconds; }
 static int g_profile, g_noout;
+static double g_prof_overhead;
 
 static void gp_t_attach(struct OVRCNCtx *const r, const OVFrame *const f, const struct RectEntryInfo *const e, uint8_t l2)
 { const double t0 = gp_now(); g_attach_inner(r, f, e, l2); if (tls_thread) tls_thread->t_hooks += gp_now() - t0; }
@@ -757,7 +758,7 @@ gp_worker(void *arg)
         }
         if (g_profile && g_pass_shim == 3) {
             ovhip_shim_profile pr;
-            if (ovhip_shim_get_profile(t->c, &pr, 0) == 0) { t->t_shim_hooks = pr.seconds_in_hooks; t->t_shim_device = pr.seconds_device; t->n_shim_calls = pr.n_calls; }
+            if (ovhip_shim_get_profile(t->c, &pr, 0) == 0) { t->t_shim_hooks = pr.seconds_in_hooks; t->t_shim_device = pr.seconds_device; t->n_shim_calls = pr.n_calls; g_prof_overhead = pr.seconds_overhead_per_call; }
         }
         pthread_barrier_wait(&g_bar);
     }
@@ -955,11 +956,11 @@ gp_main(int argc, char **argv)
                    "\"pictures_decoded\": %d, \"shim_error\": %d, \"frames_differing\": %d, \"samples_differing\": %llu, \"collocated_motion_entries_differing\": %llu, \"collocated_motion_entries_compared\": %llu, "
                    "\"dmvr_calls\": %zu, \"thread_seconds_with_a_picture\": %.6f, \"thread_seconds_in_row_end_and_attach_hooks\": %.6f, "
                    "\"reference_pass_seconds_inside_slicedec\": %.6f, \"reference_pass_seconds\": %.6f, \"repetitions\": %d, \"host_frames_made\": %d, \"host_frames_recycled\": %d, \"output\": \"%s\", "
-                   "\"thread_seconds_waiting_for_collocated_rows\": %.6f, \"shim_profile\": %d, \"thread_seconds_in_shim_hooks\": %.6f, \"thread_seconds_in_shim_device_half\": %.6f, \"shim_hook_calls\": %llu}\n",
+                   "\"thread_seconds_waiting_for_collocated_rows\": %.6f, \"shim_profile\": %d, \"thread_seconds_in_shim_hooks\": %.6f, \"thread_seconds_in_shim_device_half\": %.6f, \"shim_hook_calls\": %llu, \"shim_profile_overhead_seconds_per_call\": %.3e}\n",
                    want_live ? "live" : "device_dry_threads", g_threads, n_pic, W, H, wall, n_pic / wall, tot.n_done, tot.err, tot.frames_differing,
                    (unsigned long long)tot.samples_differing, (unsigned long long)tot.mv_cells_differing, (unsigned long long)tot.mv_cells_compared, g_dmvr_log.n / 12, tot.t_busy, tot.t_hooks,
                    g_decode_seconds_pass[0], t_ref, g_reps, g_frames_made, g_frames_recycled, g_noout ? "none" : "planes into the OVFrame",
-                   tot.t_sync, g_profile, tot.t_shim_hooks, tot.t_shim_device, (unsigned long long)tot.n_shim_calls);
+                   tot.t_sync, g_profile, tot.t_shim_hooks, tot.t_shim_device, (unsigned long long)tot.n_shim_calls, g_prof_overhead);
             fflush(stdout);
             bad |= tot.err || tot.samples_differing || tot.mv_cells_differing || tot.n_done != n_pic;
         }

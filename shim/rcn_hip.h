@@ -55,7 +55,10 @@ void ovhip_shim_release(const struct OVCTUDec *ctudec);
  * switched on (or last reset), the part of them in the device half (picture begin, eager DMVR rows, the submit: waits for reference
  * pictures, launches, ovhip_job_wait, the copy into the OVFrame), and the number of outermost hook calls.  Recording = the difference.
  * Off (default): one branch per hook. */
-typedef struct ovhip_shim_profile { double seconds_in_hooks, seconds_device; uint64_t n_calls; } ovhip_shim_profile;
+typedef struct ovhip_shim_profile {
+    double seconds_in_hooks, seconds_device; uint64_t n_calls;
+    double seconds_overhead_per_call;      /* what the profile's own bracket adds to seconds_in_hooks per call (two time-stamp reads), measured */
+} ovhip_shim_profile;
 void ovhip_shim_set_profile(int on);
 int  ovhip_shim_get_profile(const struct OVCTUDec *ctudec, ovhip_shim_profile *out, int reset);
 /* What the last alf.rcn_alf_filter_line of a picture copies into the OVFrame after the picture is complete: OVHIP_OUT_PLANES
