@@ -904,8 +904,8 @@ def live_decoder_rates(W, H, n_pics=33, threads=(1, 2, 4, 8, 16), reps=3):
     if not GEN_PIPE.exists():
         return None
 
-    def run(tl, extra):
-        cmd = [str(GEN_PIPE), "/tmp", "live", "threads", ",".join(str(t) for t in tl), "size", str(W), str(H), "pics", str(n_pics), "reps", str(reps), "profile"] + extra
+    def run(tl, extra, exe=GEN_PIPE):
+        cmd = [str(exe), "/tmp", "live", "threads", ",".join(str(t) for t in tl), "size", str(W), str(H), "pics", str(n_pics), "reps", str(reps), "profile"] + extra
         try:
             p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
         except (OSError, subprocess.TimeoutExpired):
@@ -948,6 +948,14 @@ def live_decoder_rates(W, H, n_pics=33, threads=(1, 2, 4, 8, 16), reps=3):
            "host_frames_recycled": rows[0]["host_frames_recycled"],
            "by_frame_threads": {str(d["frame_threads"]): summary(d) for d in rows},
            "reference_scalar_decoder_same_stream_one_thread_fps": round(n_pics / rows[0]["reference_pass_seconds_inside_slicedec"], 2)}
+    patched = ROOT / "oracle" / "_ref" / "patched" / "gen_pipe"
+    c = run((threads[0], threads[-1]), [], patched) if patched.exists() else None
+    if c is not None:
+        out["patched_caller"] = {"what": "the same with shim/caller.patch applied to the reference (SURVEY 8f-2: the caller hands over whole BDOF / DMVR / affine coding units -- "
+                                         "rcn_cu_inter_b, rcn_affine_cu -> ovhip_rec_cu_inter -- instead of one slot call per <= 16x16 / 4x4 block; the shim's stitching is not compiled): "
+                                         "frames and collocated motion planes compared with the UNPATCHED reference pass",
+                                 "by_frame_threads": {str(d["frame_threads"]): summary(d) for d in c[0]}}
+        out["bit_exact"] = out["bit_exact"] and c[1] == 0 and all(d["samples_differing"] == 0 and d["collocated_motion_entries_differing"] == 0 for d in c[0])
     if b is not None:
         out["output_none"] = {"what": "the same with OVHIP_OUT_NONE (pictures stay on the device; an application takes them through ovhip_shim_frame_output / _digest): "
                                       "collocated motion planes compared, frames not",

@@ -604,6 +604,10 @@ const ovhip_itask *ovhip_rec_itasks_by_ctu(ovhip_recorder *rec, int32_t log2_ctu
 int   ovhip_rec_transform_tree(ovhip_recorder *rec, const ovhip_tu_state *st, const ovhip_tt_desc *tt);
 int   ovhip_rec_pu(ovhip_recorder *rec, const ovhip_pu_desc *pu);
 int   ovhip_rec_affine_cu(ovhip_recorder *rec, const ovhip_affine_desc *cu);
+/* One inter coding unit in ONE call, whatever its kind (what a recorder-friendly caller hands over per CU, shim/caller.patch):
+ * exactly one of pu (rcn_mcp_b; with refine flags the whole BDOF / DMVR coding unit, cut here as vcl_coding_unit.c:2450-2472 / :2598-2668
+ * cut it; GPM) and aff (an affine coding unit) is non-NULL.  Returns what ovhip_rec_pu / ovhip_rec_affine_cu return. */
+int   ovhip_rec_cu_inter(ovhip_recorder *rec, const ovhip_pu_desc *pu, const ovhip_affine_desc *aff);
 /* rcn_ciip_weighted_sum: mode_abv / mode_lft = part_map.cu_mode_x[x_right >> log2_min_cb] /
  * cu_mode_y[y_bottom >> log2_min_cb] as enum CUMode (cu_utils.h:132-139). */
 int   ovhip_rec_ciip(ovhip_recorder *rec, int32_t x0, int32_t y0, int32_t log2_w, int32_t log2_h,
@@ -636,6 +640,21 @@ int64_t ovhip_dbf_compact(const ovhip_dbf_planes *planes, int dir, ovhip_dbf_edg
 
 /* Convert one CTU's deblocking maps into the picture-level edge planes.  Returns 0 or <0. */
 int   ovhip_rec_dbf_ctu(ovhip_recorder *rec, const ovhip_dbf_ctu *ctu);
+/* The same for n consecutive CTUs (a CTU row; n = 1 for a caller that keeps ONE struct DBFInfo, as the reference does) with the maps
+ * read IN PLACE: ovhip_dbf_view = ovhip_dbf_ctu with every array by pointer -- into the caller's struct DBFInfo (ctudec.h:130-170;
+ * same element layout: ctb_bound_* / aff_edg_* 49 words, bs* / affine_* 33 words, qp_* 34 x 33 bytes = struct DBFQPMap.hor) -- instead
+ * of a 9 KB descriptor filled and copied per CTU.  ovhip_rec_dbf_mv_prepass_view: the MV-based pre-pass on the caller's
+ * own bs1 maps (what the scalar slot does to dbf_info->bs1_map), no write-back copy. */
+typedef struct ovhip_dbf_view {
+    const uint64_t *ctb_bound_ver, *ctb_bound_hor, *ctb_bound_ver_c, *ctb_bound_hor_c, *aff_edg_ver, *aff_edg_hor;
+    const uint64_t *bs2_ver, *bs2_hor, *bs2c_ver, *bs2c_hor, *bs1_ver, *bs1_hor, *bs1cb_ver, *bs1cb_hor, *bs1cr_ver, *bs1cr_hor, *affine_ver, *affine_hor;
+    const uint8_t  *qp_y, *qp_cb, *qp_cr;
+    int16_t  beta_offset, tc_offset;
+    uint8_t  disable_v, disable_h, log2_ctu_s, last_x, last_y, ctu_lft, ctu_abv, pad;
+    uint16_t ctu_w, ctu_h, ctb_x, ctb_y;
+} ovhip_dbf_view;
+int   ovhip_rec_dbf_row(ovhip_recorder *rec, const ovhip_dbf_view *ctus, size_t n);
+int   ovhip_rec_dbf_mv_prepass_view(const ovhip_dbf_view *ctu, uint64_t *bs1_ver, uint64_t *bs1_hor, const ovhip_dbf_mv_ctx *mv);
 /* Host copies of the edge planes (pointers valid until the next reset/destroy). */
 int   ovhip_rec_dbf_planes(const ovhip_recorder *rec, ovhip_dbf_planes *out);
 /* Bulk append of already-recorded commands to an EMPTY recorder (replay of a stored command stream). */

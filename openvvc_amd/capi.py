@@ -180,6 +180,18 @@ DBF_CTU_DTYPE = np.dtype(                      # ovhip_dbf_ctu, field by field
        ("last_x", "u1"), ("last_y", "u1"), ("ctu_lft", "u1"), ("ctu_abv", "u1"), ("pad", "u1"),
        ("ctu_w", "<u2"), ("ctu_h", "<u2"), ("ctb_x", "<u2"), ("ctb_y", "<u2")], align=True)
 assert DBF_CTU_DTYPE.itemsize == DBF_CTU_SIZE, (DBF_CTU_DTYPE.itemsize, DBF_CTU_SIZE)
+
+
+class DbfView(C.Structure):
+    """ovhip_dbf_view: ovhip_dbf_ctu with every array by pointer (into the caller's struct DBFInfo)"""
+    _fields_ = [(n, C.c_void_p) for n in ("ctb_bound_ver", "ctb_bound_hor", "ctb_bound_ver_c", "ctb_bound_hor_c", "aff_edg_ver", "aff_edg_hor",
+                                          "bs2_ver", "bs2_hor", "bs2c_ver", "bs2c_hor", "bs1_ver", "bs1_hor", "bs1cb_ver", "bs1cb_hor",
+                                          "bs1cr_ver", "bs1cr_hor", "affine_ver", "affine_hor", "qp_y", "qp_cb", "qp_cr")] + \
+               [("beta_offset", C.c_int16), ("tc_offset", C.c_int16), ("disable_v", C.c_uint8), ("disable_h", C.c_uint8), ("log2_ctu_s", C.c_uint8),
+                ("last_x", C.c_uint8), ("last_y", C.c_uint8), ("ctu_lft", C.c_uint8), ("ctu_abv", C.c_uint8), ("pad", C.c_uint8),
+                ("ctu_w", C.c_uint16), ("ctu_h", C.c_uint16), ("ctb_x", C.c_uint16), ("ctb_y", C.c_uint16)]
+
+
 FE_BEGIN, FE_REF, FE_DMVR_ROWS, FE_DMVR_BEGIN, FE_DMVR_COLLECT, FE_SUBMIT, FE_FAIL = range(1, 8)
 FRAME_EVENT_DTYPE = np.dtype([("op", "<u4"), ("frame", "<i4"), ("key", "<u8"), ("tag", "<u8"), ("a", "<i8"), ("b", "<i8"), ("result", "<i8")])
 assert FRAME_EVENT_DTYPE.itemsize == 48
@@ -376,6 +388,9 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_rec_tu": (C.c_int, [vp, P(TuState), P(TuDesc)]),
         "ovhip_rec_pu": (C.c_int, [vp, P(PuDesc)]),
         "ovhip_rec_dbf_ctu": (C.c_int, [vp, vp]),
+        "ovhip_rec_dbf_row": (C.c_int, [vp, vp, C.c_size_t]),
+        "ovhip_rec_dbf_mv_prepass_view": (C.c_int, [vp, vp, vp, vp]),
+        "ovhip_rec_cu_inter": (C.c_int, [vp, vp, vp]),
         "ovhip_rec_dbf_planes": (C.c_int, [vp, P(DbfPlanes)]),
         "ovhip_dbf_launch": (C.c_int, [vp, P(Pic), P(DbfPlanes)]),
         "ovhip_sao_launch": (C.c_int, [vp, P(Pic), P(Pic), vp, i32]),
@@ -550,7 +565,7 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
 
 EXPORTED_SYMBOLS = [
     "ovhip_abi_version", "ovhip_rec_create", "ovhip_rec_destroy", "ovhip_rec_reset", "ovhip_rec_tu",
-    "ovhip_rec_pu", "ovhip_rec_dbf_ctu", "ovhip_rec_dbf_planes", "ovhip_dbf_launch", "ovhip_sao_launch", "ovhip_alf_launch", "ovhip_rec_tb_cmds", "ovhip_rec_coefs", "ovhip_rec_mc_units", "ovhip_rec_mcx_units", "ovhip_mcx_launch", "ovhip_rec_affine_cu", "ovhip_rec_transform_tree", "ovhip_rec_lmcs_region", "ovhip_dbf_compact", "ovhip_rec_dbf_mv_prepass", "ovhip_dbf_launch_edges", "ovhip_rec_ciip", "ovhip_ciip_weight", "ovhip_rec_ciip_units", "ovhip_ciip_launch", "ovhip_rec_lmcs_regions", "ovhip_rec_tb_cmds_split", "ovhip_itx_launch_classes", "ovhip_itx_launch_chroma_lmcs", "ovhip_lmcs_build", "ovhip_lmcs_scale_launch", "ovhip_lmcs_inverse_launch", "ovhip_rec_aff_units", "ovhip_rec_aff_side", "ovhip_mca_launch", "ovhip_mcxa_launch", "ovhip_ctx_create",
+    "ovhip_rec_pu", "ovhip_rec_cu_inter", "ovhip_rec_dbf_row", "ovhip_rec_dbf_mv_prepass_view", "ovhip_rec_dbf_ctu", "ovhip_rec_dbf_planes", "ovhip_dbf_launch", "ovhip_sao_launch", "ovhip_alf_launch", "ovhip_rec_tb_cmds", "ovhip_rec_coefs", "ovhip_rec_mc_units", "ovhip_rec_mcx_units", "ovhip_mcx_launch", "ovhip_rec_affine_cu", "ovhip_rec_transform_tree", "ovhip_rec_lmcs_region", "ovhip_dbf_compact", "ovhip_rec_dbf_mv_prepass", "ovhip_dbf_launch_edges", "ovhip_rec_ciip", "ovhip_ciip_weight", "ovhip_rec_ciip_units", "ovhip_ciip_launch", "ovhip_rec_lmcs_regions", "ovhip_rec_tb_cmds_split", "ovhip_itx_launch_classes", "ovhip_itx_launch_chroma_lmcs", "ovhip_lmcs_build", "ovhip_lmcs_scale_launch", "ovhip_lmcs_inverse_launch", "ovhip_rec_aff_units", "ovhip_rec_aff_side", "ovhip_mca_launch", "ovhip_mcxa_launch", "ovhip_ctx_create",
     "ovhip_ctx_destroy", "ovhip_ctx_sync", "ovhip_ctx_shares_queue", "ovhip_ctx_new_stream", "ovhip_ctx_fork", "ovhip_ctx_join", "ovhip_last_error", "ovhip_ctx_stream", "ovhip_malloc",
     "ovhip_free", "ovhip_h2d", "ovhip_d2h", "ovhip_pic_alloc", "ovhip_pic_free", "ovhip_pic_upload",
     "ovhip_pic_download", "ovhip_itx_launch", "ovhip_mc_launch",

@@ -791,6 +791,13 @@ rec_pu_gpm(ovhip_recorder *r, const ovhip_pu_desc *pu)
 }
 
 int
+ovhip_rec_cu_inter(ovhip_recorder *r, const ovhip_pu_desc *pu, const ovhip_affine_desc *aff)
+{
+    if (!r || !pu == !aff) return OVHIP_EINVAL;
+    return pu ? ovhip_rec_pu(r, pu) : ovhip_rec_affine_cu(r, aff);
+}
+
+int
 ovhip_rec_pu(ovhip_recorder *r, const ovhip_pu_desc *pu)
 {
     if (r->log) ovhip_calllog_pu_(r->log, pu);

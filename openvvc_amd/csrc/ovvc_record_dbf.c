@@ -126,12 +126,77 @@ offset_index(ovhip_recorder *r, int beta, int tc)
     return r->n_dbf_off++;
 }
 
+/* the maps of one CTU by pointer: what ovhip_rec_dbf_row takes, and what ovhip_rec_dbf_ctu makes of its by-value descriptor */
+static void
+view_of(ovhip_dbf_view *v, const ovhip_dbf_ctu *c)
+{
+    v->ctb_bound_ver = c->ctb_bound_ver; v->ctb_bound_hor = c->ctb_bound_hor; v->ctb_bound_ver_c = c->ctb_bound_ver_c; v->ctb_bound_hor_c = c->ctb_bound_hor_c;
+    v->aff_edg_ver = c->aff_edg_ver; v->aff_edg_hor = c->aff_edg_hor;
+    v->bs2_ver = c->bs2_ver; v->bs2_hor = c->bs2_hor; v->bs2c_ver = c->bs2c_ver; v->bs2c_hor = c->bs2c_hor;
+    v->bs1_ver = c->bs1_ver; v->bs1_hor = c->bs1_hor; v->bs1cb_ver = c->bs1cb_ver; v->bs1cb_hor = c->bs1cb_hor; v->bs1cr_ver = c->bs1cr_ver; v->bs1cr_hor = c->bs1cr_hor;
+    v->affine_ver = c->affine_ver; v->affine_hor = c->affine_hor;
+    v->qp_y = c->qp_y; v->qp_cb = c->qp_cb; v->qp_cr = c->qp_cr;
+    v->beta_offset = c->beta_offset; v->tc_offset = c->tc_offset; v->disable_v = c->disable_v; v->disable_h = c->disable_h;
+    v->log2_ctu_s = c->log2_ctu_s; v->last_x = c->last_x; v->last_y = c->last_y; v->ctu_lft = c->ctu_lft; v->ctu_abv = c->ctu_abv; v->pad = 0;
+    v->ctu_w = c->ctu_w; v->ctu_h = c->ctu_h; v->ctb_x = c->ctb_x; v->ctb_y = c->ctb_y;
+}
+
+/* (the call log stores descriptors by value) */
+static void
+ctu_of(ovhip_dbf_ctu *c, const ovhip_dbf_view *v)
+{
+    memset(c, 0, sizeof(*c));
+    memcpy(c->ctb_bound_ver, v->ctb_bound_ver, sizeof(c->ctb_bound_ver)); memcpy(c->ctb_bound_hor, v->ctb_bound_hor, sizeof(c->ctb_bound_hor));
+    memcpy(c->ctb_bound_ver_c, v->ctb_bound_ver_c, sizeof(c->ctb_bound_ver_c)); memcpy(c->ctb_bound_hor_c, v->ctb_bound_hor_c, sizeof(c->ctb_bound_hor_c));
+    memcpy(c->aff_edg_ver, v->aff_edg_ver, sizeof(c->aff_edg_ver)); memcpy(c->aff_edg_hor, v->aff_edg_hor, sizeof(c->aff_edg_hor));
+    memcpy(c->bs2_ver, v->bs2_ver, sizeof(c->bs2_ver)); memcpy(c->bs2_hor, v->bs2_hor, sizeof(c->bs2_hor));
+    memcpy(c->bs2c_ver, v->bs2c_ver, sizeof(c->bs2c_ver)); memcpy(c->bs2c_hor, v->bs2c_hor, sizeof(c->bs2c_hor));
+    memcpy(c->bs1_ver, v->bs1_ver, sizeof(c->bs1_ver)); memcpy(c->bs1_hor, v->bs1_hor, sizeof(c->bs1_hor));
+    memcpy(c->bs1cb_ver, v->bs1cb_ver, sizeof(c->bs1cb_ver)); memcpy(c->bs1cb_hor, v->bs1cb_hor, sizeof(c->bs1cb_hor));
+    memcpy(c->bs1cr_ver, v->bs1cr_ver, sizeof(c->bs1cr_ver)); memcpy(c->bs1cr_hor, v->bs1cr_hor, sizeof(c->bs1cr_hor));
+    memcpy(c->affine_ver, v->affine_ver, sizeof(c->affine_ver)); memcpy(c->affine_hor, v->affine_hor, sizeof(c->affine_hor));
+    memcpy(c->qp_y, v->qp_y, sizeof(c->qp_y)); memcpy(c->qp_cb, v->qp_cb, sizeof(c->qp_cb)); memcpy(c->qp_cr, v->qp_cr, sizeof(c->qp_cr));
+    c->beta_offset = v->beta_offset; c->tc_offset = v->tc_offset; c->disable_v = v->disable_v; c->disable_h = v->disable_h;
+    c->log2_ctu_s = v->log2_ctu_s; c->last_x = v->last_x; c->last_y = v->last_y; c->ctu_lft = v->ctu_lft; c->ctu_abv = v->ctu_abv;
+    c->ctu_w = v->ctu_w; c->ctu_h = v->ctu_h; c->ctb_x = v->ctb_x; c->ctb_y = v->ctb_y;
+}
+
+static int rec_dbf_view(ovhip_recorder *r, const ovhip_dbf_view *c);
+
 int
 ovhip_rec_dbf_ctu(ovhip_recorder *r, const ovhip_dbf_ctu *c)
 {
     if (!r || !c) return OVHIP_EINVAL;
     if (c->log2_ctu_s < 5 || c->log2_ctu_s > 7) return OVHIP_EINVAL;
     if (r->log) ovhip_calllog_dbf_(r->log, c);
+    ovhip_dbf_view v;
+    view_of(&v, c);
+    return rec_dbf_view(r, &v);
+}
+
+/* df.rcn_dbf_ctu for n consecutive CTUs (a CTU row, or n = 1), their maps read IN PLACE out of the caller's struct DBFInfo: no 9 KB
+ * descriptor is filled and copied per CTU (510 of them per 4K picture).  The segments leave in the order ovhip_rec_dbf_ctu emits
+ * them, CTU by CTU. */
+int
+ovhip_rec_dbf_row(ovhip_recorder *r, const ovhip_dbf_view *ctus, size_t n)
+{
+    if (!r || (!ctus && n)) return OVHIP_EINVAL;
+    for (size_t i = 0; i < n; ++i) {
+        const ovhip_dbf_view *c = &ctus[i];
+        if (c->log2_ctu_s < 5 || c->log2_ctu_s > 7 || !c->ctb_bound_ver || !c->ctb_bound_hor || !c->ctb_bound_ver_c || !c->ctb_bound_hor_c || !c->aff_edg_ver
+            || !c->aff_edg_hor || !c->bs2_ver || !c->bs2_hor || !c->bs2c_ver || !c->bs2c_hor || !c->bs1_ver || !c->bs1_hor || !c->bs1cb_ver || !c->bs1cb_hor
+            || !c->bs1cr_ver || !c->bs1cr_hor || !c->affine_ver || !c->affine_hor || !c->qp_y || !c->qp_cb || !c->qp_cr)
+            return OVHIP_EINVAL;
+        if (r->log) { ovhip_dbf_ctu tmp; ctu_of(&tmp, c); ovhip_calllog_dbf_(r->log, &tmp); }
+        const int q = rec_dbf_view(r, c);
+        if (q != OVHIP_OK) return q;
+    }
+    return OVHIP_OK;
+}
+
+static int
+rec_dbf_view(ovhip_recorder *r, const ovhip_dbf_view *c)
+{
     if (dbf_alloc(r)) return OVHIP_ENOMEM;
     /* at most one luma segment per 4x4 unit and one per chroma plane and 8x4 / 4x8 unit, per direction */
     enum { CTU_EDGES = 32 * 32 + 2 * 8 * 32 };
@@ -404,22 +469,39 @@ mv_edges(const ovhip_dbf_mv_ctx *c, int dir, int pos, int n_units, uint64_t todo
     return ((out | keep) << sh) & todo;
 }
 
+static int
+mv_prepass(uint64_t *bs1_ver, uint64_t *bs1_hor, const uint64_t *bs2_ver, const uint64_t *bs2_hor, const uint64_t *aff_edg_ver, const uint64_t *aff_edg_hor,
+           int log2_ctu_s, int ctu_w, int ctu_h, const ovhip_dbf_mv_ctx *mv)
+{
+    if (!mv || !mv->mvs0 || !mv->mvs1 || mv->mv_bytes < 9) return OVHIP_EINVAL;
+    const int full = 1 << log2_ctu_s;
+    const int nb_w = (ctu_w && ctu_w < full ? ctu_w : full) >> 2;
+    const int nb_h = (ctu_h && ctu_h < full ? ctu_h : full) >> 2;
+    for (int i = 0; i < nb_h; ++i) {                                   /* dbf_ctu_preproc_h */
+        const uint64_t edges = mv->cu_edge_hor[i] | aff_edg_hor[8 + i];
+        const uint64_t todo = edges ^ ((bs2_hor[i] | bs1_hor[i]) & edges);
+        if (todo) bs1_hor[i] |= mv_edges(mv, 1, i, nb_w, todo);
+    }
+    for (int i = 0; i < nb_w; ++i) {                                   /* dbf_ctu_preproc_v */
+        const uint64_t edges = mv->cu_edge_ver[i] | aff_edg_ver[8 + i];
+        const uint64_t todo = edges ^ ((bs2_ver[i] | bs1_ver[i]) & edges);
+        if (todo) bs1_ver[i] |= mv_edges(mv, 0, i, nb_h, todo);
+    }
+    return OVHIP_OK;
+}
+
 int
 ovhip_rec_dbf_mv_prepass(ovhip_dbf_ctu *ctu, const ovhip_dbf_mv_ctx *mv)
 {
-    if (!ctu || !mv || !mv->mvs0 || !mv->mvs1 || mv->mv_bytes < 9) return OVHIP_EINVAL;
-    const int full = 1 << ctu->log2_ctu_s;
-    const int nb_w = (ctu->ctu_w && ctu->ctu_w < full ? ctu->ctu_w : full) >> 2;
-    const int nb_h = (ctu->ctu_h && ctu->ctu_h < full ? ctu->ctu_h : full) >> 2;
-    for (int i = 0; i < nb_h; ++i) {                                   /* dbf_ctu_preproc_h */
-        const uint64_t edges = mv->cu_edge_hor[i] | ctu->aff_edg_hor[8 + i];
-        const uint64_t todo = edges ^ ((ctu->bs2_hor[i] | ctu->bs1_hor[i]) & edges);
-        if (todo) ctu->bs1_hor[i] |= mv_edges(mv, 1, i, nb_w, todo);
-    }
-    for (int i = 0; i < nb_w; ++i) {                                   /* dbf_ctu_preproc_v */
-        const uint64_t edges = mv->cu_edge_ver[i] | ctu->aff_edg_ver[8 + i];
-        const uint64_t todo = edges ^ ((ctu->bs2_ver[i] | ctu->bs1_ver[i]) & edges);
-        if (todo) ctu->bs1_ver[i] |= mv_edges(mv, 0, i, nb_h, todo);
-    }
-    return OVHIP_OK;
+    if (!ctu) return OVHIP_EINVAL;
+    return mv_prepass(ctu->bs1_ver, ctu->bs1_hor, ctu->bs2_ver, ctu->bs2_hor, ctu->aff_edg_ver, ctu->aff_edg_hor, ctu->log2_ctu_s, ctu->ctu_w, ctu->ctu_h, mv);
+}
+
+/* the same on the caller's own maps (what the scalar slot does to dbf_info->bs1_map): bs1_ver / bs1_hor = the two writable arrays
+ * the view's bs1_ver / bs1_hor point at */
+int
+ovhip_rec_dbf_mv_prepass_view(const ovhip_dbf_view *v, uint64_t *bs1_ver, uint64_t *bs1_hor, const ovhip_dbf_mv_ctx *mv)
+{
+    if (!v || !bs1_ver || !bs1_hor || !v->bs2_ver || !v->bs2_hor || !v->aff_edg_ver || !v->aff_edg_hor) return OVHIP_EINVAL;
+    return mv_prepass(bs1_ver, bs1_hor, v->bs2_ver, v->bs2_hor, v->aff_edg_ver, v->aff_edg_hor, v->log2_ctu_s, v->ctu_w, v->ctu_h, mv);
 }

@@ -893,6 +893,11 @@ gp_main(int argc, char **argv)
     }
     if (W % 8 || H % 8 || W < 136 || H < 136 || W > 4096 || H > 2304 || n_pic < 1 || n_pic > GP_MAX_PIC) { fprintf(stderr, "gen_pipe: size / pics\n"); return 2; }
     if (want_live && !g_threads) { g_threads = 1; g_thread_list[0] = 1; g_n_thread_list = 1; }
+#ifdef OVVC_HIP_CALLER_PATCH
+    /* the patched caller never comes through rcn_dmvr_mv_refine: nothing can be fed back from the reference pass, so the modes that
+     * record without a device (whose later pictures' parse needs the refined vectors) do not exist here */
+    if (!want_live && !want_time) { fprintf(stderr, "gen_pipe (caller patch): live and time modes only\n"); return 2; }
+#endif
     for (int i = 0; i < g_n_thread_list; ++i) if (g_thread_list[i] < 1 || g_thread_list[i] > 64) { fprintf(stderr, "gen_pipe: threads\n"); return 2; }
     if (g_threads < 0 || g_threads > 64 || (g_threads && !want_live && !want_dev) || (g_threads && want_time)) { fprintf(stderr, "gen_pipe: threads\n"); return 2; }
     if (g_threads) g_kept = calloc(n_pic, sizeof(*g_kept));

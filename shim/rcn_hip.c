@@ -42,14 +42,22 @@
  * The table is embedded by value in OVCTUDec; a back-end compiled against another layout would scribble over the
  * decoder.  Measured on the reference: 744 pointer-sized slots. */
 _Static_assert(sizeof(void *) == 8, "LP64 only");
-_Static_assert(sizeof(struct RCNFunctions) == 5952, "struct RCNFunctions layout changed: re-check every override below");
+#ifdef OVVC_HIP_CALLER_PATCH
+#define HIP_TABLE_BYTES (5952 + 2 * sizeof(void *))          /* shim/caller.patch: rcn_cu_inter_b, rcn_affine_cu appended */
+_Static_assert(offsetof(struct RCNFunctions, rcn_cu_inter_b) == 5952 && offsetof(struct RCNFunctions, rcn_affine_cu) == 5960, "the patch's two slots close the table");
+#else
+#define HIP_TABLE_BYTES 5952
+#endif
+_Static_assert(sizeof(struct RCNFunctions) == HIP_TABLE_BYTES, "struct RCNFunctions layout changed: re-check every override below");
 _Static_assert(offsetof(struct RCNFunctions, mc_l) == 0, "mc_l is the first member");
-_Static_assert(offsetof(struct RCNFunctions, rcn_gpm_b) == 5952 - 3 * sizeof(void *), "rcn_gpm_b, rcn_ibc_l, rcn_ibc_c close the table");
+_Static_assert(offsetof(struct RCNFunctions, rcn_gpm_b) == 5952 - 3 * sizeof(void *), "rcn_gpm_b, rcn_ibc_l, rcn_ibc_c close the (unpatched) table");
 _Static_assert(offsetof(struct RCNFunctions, rcn_dmvr_mv_refine) + 12 * sizeof(void *) == 5952, "12 prediction slots at the end");
 _Static_assert(offsetof(struct RCNFunctions, tmp) + sizeof(struct TMPBDCompat) + 4 * sizeof(void *) == offsetof(struct RCNFunctions, rcn_update_ctu_border),
                "tmp (dequant + transform-tree orchestrators) is followed by the four intra_pred* slots");
 _Static_assert(sizeof(OVMV) == 12 && offsetof(OVMV, y) == 4 && offsetof(OVMV, ref_idx) == 8, "OVMV layout (ovhip_dbf_mv_ctx.mv_bytes)");
 _Static_assert(sizeof(((struct DBFInfo *)0)->ctb_bound_ver) == sizeof(((ovhip_dbf_ctu *)0)->ctb_bound_ver), "DBFInfo edge maps");
+_Static_assert(sizeof(((struct DBFInfo *)0)->aff_edg_ver) == 49 * sizeof(uint64_t) && sizeof(((struct DBFInfo *)0)->ctb_bound_hor_c) == 49 * sizeof(uint64_t), "DBFInfo edge maps (ovhip_dbf_view)");
+_Static_assert(offsetof(struct DBFQPMap, hor) == 0 || sizeof(((struct DBFQPMap *)0)->hor) == 34 * 33, "DBFQPMap.hor = 34 x 33 bytes (ovhip_dbf_view.qp_*)");
 _Static_assert(sizeof(struct DBFQPMap) == sizeof(((ovhip_dbf_ctu *)0)->qp_y), "DBFInfo QP maps");
 _Static_assert(sizeof(struct DBFMap) == 2 * 33 * sizeof(uint64_t), "DBFMap = ver[33] + hor[33]");
 
@@ -627,6 +635,7 @@ hip_rcn_mcp(OVCTUDec *const c, struct OVBuffInfo dst, int x0, int y0, int log2_p
     latch(e, ovhip_rec_pu(e->rec, &d), "ovhip_rec_pu");
 }
 
+#ifndef OVVC_HIP_CALLER_PATCH
 /* ---- CUs the reference's callers cut into sub-block calls: collected back into one descriptor ---- */
 static void
 pend_close(struct hip_entry *e, OVCTUDec *c)
@@ -858,6 +867,90 @@ hip_rcn_dmvr_mv_refine(OVCTUDec *const c, struct OVBuffInfo dst, uint8_t x0, uin
     return 0;      /* disable_bdof: unused by the caller (vcl_coding_unit.c:2621) */
 }
 
+#else  /* OVVC_HIP_CALLER_PATCH: the caller hands over whole coding units (shim/caller.patch) -- nothing to stitch */
+static void pend_close(struct hip_entry *e, OVCTUDec *c) { (void)e; (void)c; }
+
+/* rcn_cu_inter_b (shim/caller.patch): a bi-predicted coding unit with BDOF and / or DMVR, where the unpatched caller makes one
+ * rcn_bdof_mcp_l / rcn_dmvr_mv_refine call per <= 16x16 block and one rcn_mcp_b_c call (vcl_coding_unit.c:2450-2472, :2598-2668).
+ * The recorder cuts it the same way (ovhip_rec_cu_inter -> rec_pu_refined).  DMVR: the caller stores nothing into its collocated
+ * motion arrays here (the unrefined vectors drv_merge_mvp_b wrote stay); the refined ones are patched into the picture's planes by
+ * the row-end hooks, exactly as on the unpatched path (dmvr_rows_step). */
+static void
+hip_rcn_cu_inter_b(OVCTUDec *const c, const OVMV mv0, const OVMV mv1, unsigned int x0, unsigned int y0, unsigned int log2_cb_w,
+                   unsigned int log2_cb_h, uint8_t inter_dir, uint8_t ref_idx0, uint8_t ref_idx1, uint8_t refine)
+{
+    ENTER(c);
+    struct InterDRVCtx *ic = &c->drv_ctx.inter_ctx;
+    ovhip_pu_desc d;
+    OVMV m0 = mv0, m1 = mv1;
+    m0.ref_idx = (int8_t)ref_idx0; m1.ref_idx = (int8_t)ref_idx1;
+    fill_pu(e, c, &d, x0, y0, log2_cb_w, log2_cb_h, inter_dir, m0, m1, ic->rpl0[ref_idx0], ic->rpl1[ref_idx1]);
+    d.refine = (uint8_t)(((refine & 1) ? OVHIP_PU_BDOF : 0) | ((refine & 2) ? OVHIP_PU_DMVR : 0));
+    const int r = ovhip_rec_cu_inter(e->rec, &d, NULL);
+    latch(e, r, "ovhip_rec_cu_inter");
+    if (r >= 0 && (refine & 2)) { size_t n = 0; ovhip_rec_mcx_units(e->rec, &n); e->n_refined = n; }
+}
+
+/* rcn_affine_cu (shim/caller.patch): an affine coding unit, where the unpatched drivers make one rcn_mcp_b_l / rcn_prof_mcp_b_l call
+ * per 4x4 luma block and one rcn_mcp_b_c call per 8x8 luma area (drv_affine_mvp.c:3264-3411): the sub-block motion field is read
+ * where the driver left it (inter_ctx->mv_ctx0 / mv_ctx1, 34 vectors per row). */
+static void
+hip_rcn_affine_cu(OVCTUDec *const c, struct InterDRVCtx *const ic, uint8_t x0, uint8_t y0, uint8_t log2_cu_w, uint8_t log2_cu_h,
+                  uint8_t inter_dir, uint8_t prof_dir, const struct PROFInfo *const prof)
+{
+    ENTER(c);
+    const int l2 = c->part_ctx->log2_ctu_s, cols = (1 << log2_cu_w) >> 2, rows = (1 << log2_cu_h) >> 2;
+    const OVMV *b0 = &ic->mv_ctx0.mvs[MV_POS(x0 >> 2, y0 >> 2)], *b1 = &ic->mv_ctx1.mvs[MV_POS(x0 >> 2, y0 >> 2)];
+    const uint8_t ref_idx0 = (uint8_t)b0->ref_idx, ref_idx1 = (uint8_t)b1->ref_idx;
+    for (int i = 0; i < rows; ++i)
+        for (int j = 0; j < cols; ++j) {
+            const int k = (i * 32 + j) * 2;
+            e->pend.mv0[k] = b0[i * 34 + j].x; e->pend.mv0[k + 1] = b0[i * 34 + j].y;
+            e->pend.mv1[k] = b1[i * 34 + j].x; e->pend.mv1[k + 1] = b1[i * 34 + j].y;
+        }
+    ovhip_affine_desc d;
+    memset(&d, 0, sizeof(d));
+    d.x0 = (uint16_t)((c->ctb_x << l2) + x0); d.y0 = (uint16_t)((c->ctb_y << l2) + y0);
+    d.log2_w = log2_cu_w; d.log2_h = log2_cu_h;
+    d.inter_dir = inter_dir; d.bcw_idx_plus1 = b0->bcw_idx_plus1; d.prof_dir = prof_dir;
+    d.lmcs = c->lmcs_info.lmcs_enabled_flag;
+    const OVPicture *p0 = (inter_dir & 1) ? ic->rpl0[ref_idx0] : NULL, *p1 = (inter_dir & 2) ? ic->rpl1[ref_idx1] : NULL;
+    if (p0) { d.ref0 = (uint8_t)ref_slot(e, p0); d.poc0 = p0->poc; }
+    if (p1) { d.ref1 = (uint8_t)ref_slot(e, p1); d.poc1 = p1->poc; }
+    if (!p0) { d.ref0 = d.ref1; d.poc0 = d.poc1 + 1; }
+    if (!p1) { d.ref1 = d.ref0; d.poc1 = d.poc0 + 1; }
+    d.mv_stride = 32; d.mv0 = e->pend.mv0; d.mv1 = e->pend.mv1;
+    if (prof) {
+        memcpy(d.dmv_scale[0], prof->dmv_scale_h_0, 32); memcpy(d.dmv_scale[1], prof->dmv_scale_v_0, 32);
+        memcpy(d.dmv_scale[2], prof->dmv_scale_h_1, 32); memcpy(d.dmv_scale[3], prof->dmv_scale_v_1, 32);
+    }
+    latch(e, ovhip_rec_cu_inter(e->rec, NULL, &d), "ovhip_rec_cu_inter(affine)");
+}
+
+/* the five slots only the unpatched callers reach (sub-block calls of affine / BDOF / DMVR coding units) */
+static void
+hip_unreached(OVCTUDec *const c, const char *slot)
+{
+    struct hip_entry *e = entry_of(c, 0);
+    if (e) latch(e, OVHIP_EINVAL, slot);
+}
+static void hip_rcn_mcp_b_l(OVCTUDec *const c, struct OVBuffInfo dst, struct InterDRVCtx *const ic, const OVPartInfo *const part_ctx, const OVMV mv0,
+                            const OVMV mv1, unsigned int x0, unsigned int y0, unsigned int l2w, unsigned int l2h, uint8_t dir, uint8_t r0, uint8_t r1)
+{ (void)dst; (void)ic; (void)part_ctx; (void)mv0; (void)mv1; (void)x0; (void)y0; (void)l2w; (void)l2h; (void)dir; (void)r0; (void)r1; hip_unreached(c, "rcn_mcp_b_l called by a patched caller"); }
+static void hip_rcn_mcp_b_c(OVCTUDec *const c, struct OVBuffInfo dst, struct InterDRVCtx *const ic, const OVPartInfo *const part_ctx, const OVMV mv0,
+                            const OVMV mv1, unsigned int x0, unsigned int y0, unsigned int l2w, unsigned int l2h, uint8_t dir, uint8_t r0, uint8_t r1)
+{ (void)dst; (void)ic; (void)part_ctx; (void)mv0; (void)mv1; (void)x0; (void)y0; (void)l2w; (void)l2h; (void)dir; (void)r0; (void)r1; hip_unreached(c, "rcn_mcp_b_c called by a patched caller"); }
+static void hip_rcn_prof_mcp_b_l(OVCTUDec *const c, struct OVBuffInfo dst, struct InterDRVCtx *const ic, const OVPartInfo *const part_ctx, const OVMV mv0,
+                                 const OVMV mv1, unsigned int x0, unsigned int y0, unsigned int l2w, unsigned int l2h, uint8_t dir, uint8_t r0, uint8_t r1,
+                                 uint8_t prof_dir, const struct PROFInfo *const prof)
+{ (void)dst; (void)ic; (void)part_ctx; (void)mv0; (void)mv1; (void)x0; (void)y0; (void)l2w; (void)l2h; (void)dir; (void)r0; (void)r1; (void)prof_dir; (void)prof; hip_unreached(c, "rcn_prof_mcp_b_l called by a patched caller"); }
+static void hip_rcn_bdof_mcp_l(OVCTUDec *const c, struct OVBuffInfo dst, uint8_t x0, uint8_t y0, uint8_t l2w, uint8_t l2h, OVMV mv0, OVMV mv1, uint8_t r0, uint8_t r1)
+{ (void)dst; (void)x0; (void)y0; (void)l2w; (void)l2h; (void)mv0; (void)mv1; (void)r0; (void)r1; hip_unreached(c, "rcn_bdof_mcp_l called by a patched caller"); }
+static uint8_t hip_rcn_dmvr_mv_refine(OVCTUDec *const c, struct OVBuffInfo dst, uint8_t x0, uint8_t y0, uint8_t l2w, uint8_t l2h, OVMV *mv0, OVMV *mv1,
+                                      uint8_t r0, uint8_t r1, uint8_t apply_bdof)
+{ (void)dst; (void)x0; (void)y0; (void)l2w; (void)l2h; (void)mv0; (void)mv1; (void)r0; (void)r1; (void)apply_bdof; hip_unreached(c, "rcn_dmvr_mv_refine called by a patched caller"); return 0; }
+#endif /* OVVC_HIP_CALLER_PATCH */
+
 /* Entries of the picture's collocated motion planes as the device derived them (ovhip_job_tmvp_cells: 4 per refined unit, cell =
  * index into MVPlane.mvs, OVHIP_TMVP_NONE = unused / not a DMVR unit / outside what tmvp_store_mv copies): x and y of both lists. */
 int
@@ -983,27 +1076,20 @@ static void hip_noop_reshape(OVSample *dst, ptrdiff_t stride, const struct LMCSL
 { (void)dst; (void)stride; (void)luts; (void)w; (void)h; }
 
 /* ------------------------------------------------------------------------------------ deblocking */
+/* The CTU's maps are read where they lie in the decoder's struct DBFInfo (ovhip_dbf_view: same element layout, include/ovvc_hip.h); r3 / r4
+ * filled and copied a 9 KB descriptor per CTU. */
 static void
-snapshot_dbf(ovhip_dbf_ctu *o, const struct DBFInfo *d)
+view_dbf(ovhip_dbf_view *o, const struct DBFInfo *d)
 {
-    memset(o, 0, sizeof(*o));
-    memcpy(o->ctb_bound_ver, d->ctb_bound_ver, sizeof(o->ctb_bound_ver));
-    memcpy(o->ctb_bound_hor, d->ctb_bound_hor, sizeof(o->ctb_bound_hor));
-    memcpy(o->ctb_bound_ver_c, d->ctb_bound_ver_c, sizeof(o->ctb_bound_ver_c));
-    memcpy(o->ctb_bound_hor_c, d->ctb_bound_hor_c, sizeof(o->ctb_bound_hor_c));
-    memcpy(o->aff_edg_ver, d->aff_edg_ver, sizeof(o->aff_edg_ver));
-    memcpy(o->aff_edg_hor, d->aff_edg_hor, sizeof(o->aff_edg_hor));
-    memcpy(o->bs2_ver, d->bs2_map.ver, sizeof(o->bs2_ver));          memcpy(o->bs2_hor, d->bs2_map.hor, sizeof(o->bs2_hor));
-    memcpy(o->bs2c_ver, d->bs2_map_c.ver, sizeof(o->bs2c_ver));      memcpy(o->bs2c_hor, d->bs2_map_c.hor, sizeof(o->bs2c_hor));
-    memcpy(o->bs1_ver, d->bs1_map.ver, sizeof(o->bs1_ver));          memcpy(o->bs1_hor, d->bs1_map.hor, sizeof(o->bs1_hor));
-    memcpy(o->bs1cb_ver, d->bs1_map_cb.ver, sizeof(o->bs1cb_ver));   memcpy(o->bs1cb_hor, d->bs1_map_cb.hor, sizeof(o->bs1cb_hor));
-    memcpy(o->bs1cr_ver, d->bs1_map_cr.ver, sizeof(o->bs1cr_ver));   memcpy(o->bs1cr_hor, d->bs1_map_cr.hor, sizeof(o->bs1cr_hor));
-    memcpy(o->affine_ver, d->affine_map.ver, sizeof(o->affine_ver)); memcpy(o->affine_hor, d->affine_map.hor, sizeof(o->affine_hor));
-    memcpy(o->qp_y, d->qp_map_y.hor, sizeof(o->qp_y));
-    memcpy(o->qp_cb, d->qp_map_cb.hor, sizeof(o->qp_cb));
-    memcpy(o->qp_cr, d->qp_map_cr.hor, sizeof(o->qp_cr));
+    o->ctb_bound_ver = d->ctb_bound_ver; o->ctb_bound_hor = d->ctb_bound_hor; o->ctb_bound_ver_c = d->ctb_bound_ver_c; o->ctb_bound_hor_c = d->ctb_bound_hor_c;
+    o->aff_edg_ver = d->aff_edg_ver; o->aff_edg_hor = d->aff_edg_hor;
+    o->bs2_ver = d->bs2_map.ver; o->bs2_hor = d->bs2_map.hor; o->bs2c_ver = d->bs2_map_c.ver; o->bs2c_hor = d->bs2_map_c.hor;
+    o->bs1_ver = d->bs1_map.ver; o->bs1_hor = d->bs1_map.hor; o->bs1cb_ver = d->bs1_map_cb.ver; o->bs1cb_hor = d->bs1_map_cb.hor;
+    o->bs1cr_ver = d->bs1_map_cr.ver; o->bs1cr_hor = d->bs1_map_cr.hor; o->affine_ver = d->affine_map.ver; o->affine_hor = d->affine_map.hor;
+    o->qp_y = d->qp_map_y.hor; o->qp_cb = d->qp_map_cb.hor; o->qp_cr = d->qp_map_cr.hor;
     o->beta_offset = d->beta_offset; o->tc_offset = d->tc_offset;
     o->disable_v = d->disable_v; o->disable_h = d->disable_h;
+    o->pad = 0;
 }
 
 static void
@@ -1011,16 +1097,16 @@ dbf_ctu(const struct OVRCNCtx *const r, struct DBFInfo *const dbf, uint8_t log2_
 {
     OVCTUDec *c = r->ctudec;
     ENTER(c);
-    ovhip_dbf_ctu s;
-    snapshot_dbf(&s, dbf);
+    ovhip_dbf_view s;
+    view_dbf(&s, dbf);
     s.log2_ctu_s = log2_ctu_s; s.last_x = last_x; s.last_y = last_y;
     s.ctu_lft = !!(c->ctu_ngh_flags & CTU_LFT_FLG); s.ctu_abv = !!(c->ctu_ngh_flags & CTU_UP_FLG);
     s.ctu_w = (uint16_t)ctu_w; s.ctu_h = (uint16_t)ctu_h;
     s.ctb_x = c->ctb_x; s.ctb_y = c->ctb_y;
     if (c->tmp_slice_type != 2) {
         /* P / B slices: the slot's own MV-based boundary-strength pre-pass (dbf_ctu_preproc_v/_h, rcn_df.c:1821-1874;
-         * static there) on the CTU's motion grids.  The scalar slot also leaves the result in dbf_info->bs1_map, which
-         * dbf_store_info() carries to the neighbouring CTUs (slicedec.c:872-877): write it back. */
+         * static there) on the CTU's motion grids, straight into dbf_info->bs1_map as the scalar slot leaves it:
+         * dbf_store_info() carries it to the neighbouring CTUs (slicedec.c:872-877). */
         const struct InterDRVCtx *ic = &c->drv_ctx.inter_ctx;
         ovhip_dbf_mv_ctx mc;
         memset(&mc, 0, sizeof(mc));
@@ -1030,10 +1116,9 @@ dbf_ctu(const struct OVRCNCtx *const r, struct DBFInfo *const dbf, uint8_t log2_
         if (dbf->ibc_ctx) { memcpy(mc.ibc_h, dbf->ibc_ctx->ctu_map.hfield, sizeof(mc.ibc_h)); memcpy(mc.ibc_v, dbf->ibc_ctx->ctu_map.vfield, sizeof(mc.ibc_v)); }
         memcpy(mc.dist_ref0, ic->dist_ref_0, sizeof(mc.dist_ref0)); memcpy(mc.dist_ref1, ic->dist_ref_1, sizeof(mc.dist_ref1));
         mc.mvs0 = ic->mv_ctx0.mvs; mc.mvs1 = ic->mv_ctx1.mvs; mc.mv_bytes = sizeof(OVMV);
-        latch(e, ovhip_rec_dbf_mv_prepass(&s, &mc), "ovhip_rec_dbf_mv_prepass");
-        memcpy(dbf->bs1_map.ver, s.bs1_ver, sizeof(s.bs1_ver)); memcpy(dbf->bs1_map.hor, s.bs1_hor, sizeof(s.bs1_hor));
+        latch(e, ovhip_rec_dbf_mv_prepass_view(&s, dbf->bs1_map.ver, dbf->bs1_map.hor, &mc), "ovhip_rec_dbf_mv_prepass");
     }
-    latch(e, ovhip_rec_dbf_ctu(e->rec, &s), "ovhip_rec_dbf_ctu");
+    latch(e, ovhip_rec_dbf_row(e->rec, &s, 1), "ovhip_rec_dbf_row");
 }
 
 /* df.rcn_dbf_ctu / df.rcn_dbf_truncated_ctu (rcn_structures.h:408-413; rcn_df.c:2169-2231) */
@@ -1466,6 +1551,10 @@ rcn_init_functions_hip(struct RCNFunctions *f, uint8_t ict_type, uint8_t lm_chro
     f->rcn_prof_mcp_b_l = &hip_rcn_prof_mcp_b_l;
     f->rcn_bdof_mcp_l = &hip_rcn_bdof_mcp_l;
     f->rcn_dmvr_mv_refine = &hip_rcn_dmvr_mv_refine;
+#ifdef OVVC_HIP_CALLER_PATCH
+    f->rcn_cu_inter_b = &hip_rcn_cu_inter_b;
+    f->rcn_affine_cu = &hip_rcn_affine_cu;
+#endif
     f->rcn_gpm_b = &hip_rcn_gpm_b;
     f->rcn_ciip_b = &hip_rcn_ciip_b;
     f->rcn_ciip = &hip_rcn_ciip;

@@ -90,3 +90,36 @@ def test_live_decode_of_four_gops_on_eight_threads():
     while the leaves of the previous one still run; device pictures released as their last reader finishes"""
     r = live(8, "size", 832, 480, "pics", 33)
     check(r, 33, 8)
+
+
+# ---- the same with shim/caller.patch applied to the reference (SURVEY 8f-2: a recorder-friendly caller): oracle/_ref/patched/gen_pipe is the
+# harness built against the patched rcn_structures.h / vcl_coding_unit.c / drv_affine_mvp.c, the shim with -DOVVC_HIP_CALLER_PATCH.  The caller
+# then hands over whole BDOF / DMVR / affine coding units (rcn_cu_inter_b, rcn_affine_cu -> ovhip_rec_cu_inter): a third of the hook calls,
+# no stitching in the shim -- and the same pictures and collocated motion planes as the UNPATCHED reference pass, bit for bit.
+GEN_PIPE_PATCHED = ROOT / "oracle" / "_ref" / "patched" / "gen_pipe"
+
+
+def live_patched(threads, *args, timeout=900):
+    if not GEN_PIPE_PATCHED.exists():
+        pytest.skip("oracle/_ref/patched/gen_pipe is built only where /root/reference exists")
+    cmd = [str(GEN_PIPE_PATCHED), "/tmp", "live", "threads", str(threads), "profile"] + [str(a) for a in args]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert lines and p.returncode == 0, f"patched gen_pipe live rc {p.returncode}:\n{p.stdout[-1500:]}\n{p.stderr[-3000:]}"
+    return json.loads(lines[-1])
+
+
+@pytest.mark.parametrize("threads", (1, 4))
+@pytest.mark.parametrize("name", sorted(STREAMS))
+def test_live_decode_with_the_patched_caller_fixture_streams(name, threads):
+    args = STREAMS[name]
+    check(live_patched(threads, *args), int(args[args.index("pics") + 1]), threads)
+
+
+@pytest.mark.parametrize("w,h,threads,pics", [(1920, 1080, 4, 17), (3840, 2160, 1, 9), (3840, 2160, 8, 17)])
+def test_live_decode_with_the_patched_caller(w, h, threads, pics):
+    r = live_patched(threads, "size", w, h, "pics", pics, "seed", 31, timeout=1500)
+    check(r, pics, threads)
+    u = live(threads, "size", w, h, "pics", pics, "seed", 31, "profile", timeout=1500)
+    # whole coding units instead of <= 16x16 / 4x4 sub-block calls: far fewer hook calls for the same pictures
+    assert r["shim_hook_calls"] * 2 < u["shim_hook_calls"]
