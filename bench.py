@@ -287,6 +287,7 @@ def main():
     # ---- multi-process exchange: the driver's comm thread calls back here, one call per transferred picture ----
     xfer = None
     rccl = None
+    rank_accounts = None
     n_xfer_bytes = [0]
     if world > 1:
         stage = torch.empty(FB // 2 + 512, dtype=torch.int16, device=dev)       # one allocation = the picture's three planes
@@ -457,6 +458,18 @@ def main():
         n_timed_all = NT - n_warm
         xfers = [int(res.n_sent), int(res.n_received)]
         count(res)
+        # ---- every rank's own account of the timed run, gathered so that ONE line checks itself: what each rank decoded,
+        #      sent and received (the driver's counters and, with RCCL, the transport's own byte counts), and what the picture dealing says it
+        #      should have -- the first hardware record of the multi-GPU path must not need a second run to be believed
+        exp_sent = sum(bin(int(p["send_mask"])).count("1") for p in tspics[n_warm:] if p["owner"] == rank)
+        mine = {"rank": rank, "hip_device": local_rank if not args.same_gpu else 0, "pictures_decoded": int(res.n_decoded),
+                "pictures_sent": int(res.n_sent), "pictures_received": int(res.n_received), "pictures_sent_expected_from_the_dealing": exp_sent,
+                "transport": "rccl" if rccl is not None else "torch.distributed callbacks",
+                "rccl": rccl.stats() if rccl is not None else None, "rccl_ranks_in_communicator": world if rccl is not None else None,
+                "seconds_inside_the_c_driver": round(float(res.seconds), 6), "second_passes": int(res.n_second_passes), "status": int(res.status)}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        rank_accounts = gathered
     else:
         st_t = new_stream(S, output=args.output) if args.output != "none" else st_main
         if st_t is not st_main:
@@ -805,6 +818,13 @@ def main():
                        "r_bar": round(st["r_bar"], 3), "coef_bytes": st["coef_bytes"],
                        "frame_algorithmic_bytes": int(sum(alg.values())),
                        "resident_replay_fps": round(fps_res, 2) if fps_res else None,
+                       "ranks": rank_accounts,
+                       "exchange_consistent": (None if rank_accounts is None else bool(
+                           sum(a["pictures_sent"] for a in rank_accounts) == sum(a["pictures_received"] for a in rank_accounts)
+                           and all(a["pictures_sent"] == a["pictures_sent_expected_from_the_dealing"] and a["status"] == 0 for a in rank_accounts)
+                           and sum(a["pictures_decoded"] for a in rank_accounts) == n_timed_all
+                           and (all(a["rccl"] is None for a in rank_accounts)
+                                or sum(a["rccl"]["bytes_sent"] for a in rank_accounts) == sum(a["rccl"]["bytes_received"] for a in rank_accounts)))),
                        "transfers_this_rank": {"sent": xfers[0], "received": xfers[1], "bytes_sent": xfer_bytes_main if (world == 1 or rccl is None) else rccl.stats()["bytes_sent"],
                                                "transport": ("RCCL ncclSend / ncclRecv in the C comm thread (ovvc_rccl.hip)" if world > 1 and rccl is not None else
                                                              "torch.distributed callbacks" if world > 1 else None)},

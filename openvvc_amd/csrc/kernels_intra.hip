@@ -1102,10 +1102,18 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
     } else if (luma) {
         // (regular luma blocks wait on the tagged reference samples themselves, fetch_refs_tagged below: nothing to poll here)
         if (t.flags & OVHIP_IF_ISP) {
-            const int ux = t.x >> 2, uy = t.y >> 2, uxa = (t.x - t.isp_off_x) >> 2, uyl = (t.y - t.isp_off_y) >> 2;
-            if (t.flags & OVHIP_IF_CORNER) add_run(fs.y, uxa - 1, uy - 1, 1, 1, 0);
+            // the above arm lies in row t.y - 1: unit row uya -- the row of units above this block, or, for a partition less than a unit
+            // high that does not start a unit row (8x2 / 16x1 ... partitions: rows 2-3 / 1, 2, 3 of the unit), the block's OWN unit row
+            const int ux = t.x >> 2, uya = (t.y - 1) >> 2, uxa = (t.x - t.isp_off_x) >> 2, uyl = (t.y - t.isp_off_y) >> 2;
+            if (t.flags & OVHIP_IF_CORNER) add_run(fs.y, uxa - 1, uya, 1, 1, 0);
             if (t.flags & OVHIP_IF_CORNER_L) add_run(fs.y, ux - 1, uyl - 1, 1, 1, 0);
-            add_run(fs.y, uxa, uy - 1, t.avl_abv, 1, 0);
+            if (t.y & 3) {
+                // inside the coding unit's columns that row is the partition before this one, in the same units as this block: their
+                // word turns "written" only with the unit's LAST partition (below), so the samples themselves are waited for (thin_row);
+                // right of the coding unit the arm runs through units of its own
+                const int ncu = (1 << t.isp_log2_cb_w) >> 2;
+                if ((int)t.avl_abv > ncu) add_run(fs.y, uxa + ncu, uya, (int)t.avl_abv - ncu, 1, 0);
+            } else add_run(fs.y, uxa, uya, t.avl_abv, 1, 0);
             add_run(fs.y, ux - 1, uyl, t.avl_lft, 0, 1);
         }
     } else {
@@ -1169,6 +1177,28 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
     if (scale_idx) scale_ld = (int)__hip_atomic_load(scales + t.c_scale, RLX_AGENT);
     if (!res_only) {
         if (luma) {
+            if ((t.flags & OVHIP_IF_ISP) && (t.y & 3)) {
+                // thin_row: the last row of the partition above (same coding unit, same 4x4 units as this block) arrives TAGGED -- every
+                // luma item stores its samples with FLOW_TAG -- and is polled itself, as fetch_refs_tagged polls a regular block's arms
+                const int cbw = 1 << t.isp_log2_cb_w;
+                const uint16_t *row = pic.y + (t.y - 1) * pic.stride_y + (t.x - t.isp_off_x);
+                unsigned spins = 0;
+                bool ok = true;
+                for (;;) {
+                    const unsigned v = lane < cbw ? (unsigned)__hip_atomic_load(row + lane, RLX_AGENT) : FLOW_TAG;
+                    if (!__any(!(v & FLOW_TAG))) break;
+                    const unsigned stop = __hip_atomic_load(sync, RLX_AGENT);
+                    if (__any(++spins > SPIN_LIMIT || stop != 0)) { ok = false; break; }
+                    __builtin_amdgcn_s_sleep(FLOW_POLL_GAP);
+                }
+                if (!ok) {
+                    if (lane == 0) {
+                        __hip_atomic_store(sync, 1u + blockIdx.x, RLX_AGENT);
+                        if (abort_mirror) __hip_atomic_store(abort_mirror, 1u + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    return;
+                }
+            }
             if (t.flags & OVHIP_IF_ISP) fetch_refs_isp(s, ya, t, lane);
             else if (!fetch_refs_tagged(s, pic.y, pic.stride_y, fs.y, w4, epoch, sync, 4, t.x, t.y, w, h, t.flags & OVHIP_IF_CORNER, t.avl_abv, t.avl_lft,
                                         (t.flags & OVHIP_IF_MIP) ? 0 : t.mrl_idx, lane)) {
@@ -1301,7 +1331,10 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
         const int ux0 = t.x >> sh, uy0 = (t.y + y0s) >> sh, nx = max(1, w >> sh), ny = max(1, (y1s - y0s) >> sh);
         unsigned *fb = luma ? fs.y : fs.c[comp];
         const int l2nx = ilog2(nx);                                             // block widths are powers of two
-        for (int i = lane; i < nx * ny; i += 64) __hip_atomic_store(fb + (uy0 + (i >> l2nx)) * w4 + ux0 + (i & (nx - 1)), pending + 1, RLX_AGENT);
+        // (a luma partition less than a unit high that does not END its unit row leaves the words alone: the unit is written when the
+        //  partition holding its last row is -- word readers: CCLM items, chroma-scale regions, ISP arms outside their coding unit)
+        const bool unit_done = !(luma && h < 4 && ((t.y + h) & 3));
+        for (int i = lane; unit_done && i < nx * ny; i += 64) __hip_atomic_store(fb + (uy0 + (i >> l2nx)) * w4 + ux0 + (i & (nx - 1)), pending + 1, RLX_AGENT);
     }
     FPROBE(7);
     }   // next item of this worker
@@ -1383,9 +1416,10 @@ extern "C" int ovhip_intra_ctu_launch(ovhip_ctx *ctx, const ovhip_pic *pic, cons
     return OVHIP_OK;
 }
 
-// Items of the flow launch from the level-sorted tasks (HOST): one per (task, 1024-sample strip, plane).  Returns the count
-// (<= cap) or 0 when the picture cannot take this path (a prediction block less than a unit high: horizontal ISP partitions of 1 or
-// 2 rows share a state word with their neighbours).
+// Items of the flow launch from the level-sorted tasks (HOST): one per (task, FSTRIP-sample strip, plane).  Returns the count
+// (<= cap) or 0 when the picture cannot take this path (more tasks or strips than an item word holds).  (Until round 5 a prediction
+// block less than a unit high -- horizontal ISP partitions of 1 or 2 rows, which share a state word with the partitions around them --
+// sent the whole picture to the per-level launches; they now hand over inside the unit by tagged samples, see k_intra_flow.)
 extern "C" size_t ovhip_intra_flow_items(const ovhip_itask *sorted, size_t n, uint32_t *items, size_t cap)
 {
     size_t k = 0;
@@ -1393,7 +1427,6 @@ extern "C" size_t ovhip_intra_flow_items(const ovhip_itask *sorted, size_t n, ui
         const ovhip_itask &t = sorted[i];
         if (i >= (1u << 24)) return 0;
         if (t.kind == OVHIP_IT_REGION) { if (k < cap) items[k] = (uint32_t)i; ++k; continue; }
-        if (t.kind == OVHIP_IT_LUMA && t.log2_h < 2) return 0;
         const int npx = 1 << (t.log2_w + t.log2_h), strips = (npx + FSTRIP - 1) / FSTRIP, comps = t.kind == OVHIP_IT_LUMA ? 1 : 2;
         if (strips > 32) return 0;                                   // the item word has five bits for the strip (a 64x64 block: 16)
         for (int st = 0; st < strips; ++st)

@@ -513,7 +513,7 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
             if (!j->items_host) { j->items_cap = 0; return ov_fail(ctx, OVHIP_ENOMEM, "ovhip_job_flush: item list", hipSuccess); }
         }
         n_items = ovhip_intra_flow_items(it, n_it, j->items_host, j->items_cap);
-        if (!n_items) by_flow = 0;           // a block less than a unit high: per-level launches
+        if (!n_items) by_flow = 0;           // more tasks / strips than an item word holds: per-level launches
     }
     if (!it && ovhip_rec_itask_levels(rec)) return ov_fail(ctx, OVHIP_ENOMEM, "ovhip_job_flush: sorting the ordered tasks", hipSuccess);
     if (!by_level) n_lv = ovhip_rec_itask_levels(rec);

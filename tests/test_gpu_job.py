@@ -147,9 +147,11 @@ def test_context_used_from_another_thread(ctx):
     _check(wl, out["planes"], "flush from a second thread")
 
 
-def test_stage_mask_and_filters_off(ctx):
-    """stages mask / SAO and ALF switched off: dst always holds the result of the last stage that ran."""
-    w, h = 416, 240
+@pytest.mark.parametrize("w,h", [(416, 240), (1920, 1080)])
+def test_stage_mask_and_filters_off(ctx, w, h):
+    """stages mask / SAO and ALF switched off: dst always holds the result of the last stage that ran.  1920x1080 with only the prediction
+    and transform stages on the device is BASELINE configs[1] at its stated size (inverse transform + MC on the GPU, the in-loop filters
+    left to the host), compared with the oracle's picture after the same stages."""
     wl = synth.make_workload(w, h, 21)
     job = engine.Job(ctx, w, h)
     refs = [ctx.upload_pic(*r) for r in wl.refs]

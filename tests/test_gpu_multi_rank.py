@@ -41,6 +41,10 @@ def test_two_ranks_on_one_gpu(built_lib, dealing):
     assert d["n_gpus"] == 2 and c["dealing"] == dealing and c["ordered_pass_second_passes"] == 0
     assert c["check"]["differ"] == 0 and c["check"]["differ_in_flight"] == 0
     assert c["transfers_this_rank"]["sent"] > 0 and c["transfers_this_rank"]["bytes_sent"] > 0
+    # the line checks itself: every rank's account of the timed run is in it (what it decoded, sent, received; what the dealing says it
+    # should have sent), and the sums agree
+    assert len(c["ranks"]) == 2 and [a["rank"] for a in c["ranks"]] == [0, 1] and c["exchange_consistent"] is True
+    assert all(a["pictures_sent"] == a["pictures_sent_expected_from_the_dealing"] and a["pictures_decoded"] > 0 for a in c["ranks"])
     assert c["other_dealing"]["dealing"] != dealing and c["other_dealing"]["fps"] > 0
     # the picture-interleaved dealing moves (nearly) a picture per picture, a GOP per GPU one picture per GOP
     sent_pic = c["transfers_this_rank"]["sent"] if dealing == "picture" else c["other_dealing"]["pictures_sent_by_this_rank"]

@@ -219,6 +219,7 @@ def test_shim_isp_cus_gpu(ctx):
     job = engine.Job(ctx, w, h)
     dst = ctx.new_pic(w, h)
     bad = []
+    thin_on_flow = 0
     for i, (x, y, l2w, l2h, vertical, mode, bits, off) in enumerate(info):
         c = s.case(i)
         dst.upload(base, cb, cb)
@@ -229,6 +230,13 @@ def test_shim_isp_cus_gpu(ctx):
         p = capi.JobParams()
         p.log2_ctu_s = 7
         p.stages = capi.STAGE_ITX | capi.STAGE_INTRA | (0, capi.STAGE_INTRA_CTU, capi.STAGE_INTRA_LEVELS)[i % 3]
+        if i % 3 == 0:
+            # the default path is the flow launch for EVERY one of them -- also the partitions less than a unit high (8x2, 16x1 ...: until
+            # round 5 one of those sent the whole picture to the per-level launches)
+            t, _ = job.rec.itasks_sorted()
+            items = np.zeros(4 * len(t) + 16, np.uint32)
+            assert ctx.lib.ovhip_intra_flow_items(t.ctypes.data, len(t), items.ctypes.data, len(items)) > 0
+            thin_on_flow += int(((t["kind"] == capi.IT_LUMA) & (t["log2_h"] < 2)).any())
         job.flush(dst, [], None, params=p)
         job.wait()
         yy = dst.download()[0]
@@ -237,6 +245,7 @@ def test_shim_isp_cus_gpu(ctx):
             bad.append((i, bw, bh, int(vertical), int(mode), hex(int(bits))))
     job.close()
     assert not bad, f"{len(bad)} / {len(info)} ISP CUs differ from the reference on the GPU, first: {bad[:10]}"
+    assert thin_on_flow >= 10, thin_on_flow
 
 
 @pytest.mark.gpu
