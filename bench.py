@@ -643,7 +643,7 @@ def main():
 
     ref_stream = None
     if rank == 0 and not args.no_reference_stream and (W, H) == (3840, 2160):
-        ref_stream = reference_stream_on_device(engine, capi, ctx0, W, H, 9, 10)
+        ref_stream = reference_stream_on_device(engine, capi, ctx0, W, H, 17, 8)
         if ref_stream and (ref_stream["samples_differing_from_the_reference"] or ref_stream["refined_vectors_differing"]):
             raise SystemExit(f"bench: the reference's stream decodes differently on the device: {ref_stream}")
 
@@ -1029,13 +1029,41 @@ def reference_stream_on_device(engine, capi, ctx, W, H, n_pics, reps, extra=()):
     for _ in range(reps):
         chain()
     dt = time.perf_counter() - t0
+    # ---- the same pictures through the C stream driver with 16 pictures in flight (next to the synthetic figure): the
+    #      stream = `copies` independent repetitions of the recorded pictures, a repetition's pictures referencing that repetition's own
+    #      earlier pictures; jobs are shared between repetitions (a job is in flight once at a time), digests of every repetition's
+    #      pictures must equal those of the one-at-a-time chain above
+    in_flight = None
+    try:
+        dpb = engine.Dpb((0,))
+        contents = []
+        for k in range(P.n):
+            contents.append({"params": jobs[k].params, "calllog": None, "n_ref_slots": max(1, len(P.ref_indices(k)))})
+        copies = max(2, min(8, reps))
+        spics = []
+        for c in range(copies):
+            for k in range(P.n):
+                spics.append({"content": k, "job": k, "poc": c * 1000 + int(P.info[k][0]), "device": 0, "refs": [c * P.n + r for r in P.ref_indices(k)]})
+        st = engine.Stream(dpb, P.w, P.h, contents, jobs, threads_per_device=16)
+        arr = engine.Stream.pics_array(spics)
+        want = [dst[k].digest() for k in range(P.n)]
+        res, dg = st.run(arr, len(spics), 0, len(spics), digests=True)            # warm (and checked)
+        bad = sum(1 for i in range(len(spics)) if bytes(dg[i]) != want[i % P.n])
+        t0 = time.perf_counter()
+        res, _ = st.run(arr, len(spics), 0, len(spics))
+        dt16 = time.perf_counter() - t0
+        in_flight = {"pictures_in_flight": 16, "fps": round(len(spics) / dt16, 1), "pictures": len(spics), "independent_repetitions_of_the_stream": copies,
+                     "digests_differing_from_the_one_at_a_time_chain": bad, "second_passes": int(res.n_second_passes)}
+        st.close(); dpb.close()
+    except Exception as e:                                                           # noqa: BLE001  (a secondary figure must not take the line down)
+        in_flight = {"error": repr(e)[:300]}
     n_units = {k: int(sum(len(getattr(w, a)) for w in wls)) for k, a in (("mc", "mc_units"), ("refined", "mcx_units"), ("affine", "aff_units"), ("transform_blocks", "tb_cmds"))}
     n_units["ordered_tasks"] = int(sum(0 if w.itasks is None else len(w.itasks) for w in wls))
     n_units["dmvr_calls"] = int(len(P.dmvr))
     for j in jobs:
         j.close()
     return {"pictures": P.n, "width": P.w, "height": P.h, "samples_differing_from_the_reference": differ, "refined_vectors_differing": mv_differ,
-            "fps_one_picture_in_flight": round(P.n * reps / dt, 1), "units": n_units,
+            "fps_one_picture_in_flight": round(P.n * reps / dt, 1) if reps else None, "stream_driver_16_in_flight": in_flight, "units": n_units,
             "what": "oracle/_ref/gen_pipe (the reference's slicedec.c compiled where it lay, driven over seeded slice data: DESIGN 2) decoded "
                     f"{P.n} chained {P.w}x{P.h} pictures (I B B B P b b b b of a GOP of 8) with the reference's scalar slots and recorded the "
                     "same parse through the installed shim slots; here the recorded stream went through ovhip_job_flush picture by picture, each "
