@@ -95,6 +95,14 @@ class AffineDesc(C.Structure):
                 ("mv_stride", C.c_int32), ("mv0", C.c_void_p), ("mv1", C.c_void_p), ("dmv_scale", (C.c_int16 * 16) * 4)]
 
 
+class IspDesc(C.Structure):
+    """ovhip_isp_desc: one intra-sub-partition CU as tmp.recon_isp_subtree_v / _h receive it"""
+    _fields_ = [("x0", C.c_uint16), ("y0", C.c_uint16), ("log2_cb_w", C.c_uint8), ("log2_cb_h", C.c_uint8), ("vertical", C.c_uint8),
+                ("intra_mode", C.c_uint8), ("cbf_mask", C.c_uint8), ("lfnst_flag", C.c_uint8), ("lfnst_idx", C.c_uint8), ("mts_enabled", C.c_uint8),
+                ("corner", C.c_uint8 * 4), ("avl_abv", C.c_uint8 * 4), ("avl_lft", C.c_uint8 * 4), ("last_pos", C.c_uint16 * 4),
+                ("sig_sb_map", C.c_uint64 * 4), ("coef", C.c_void_p)]
+
+
 class LmcsData(C.Structure):
     _fields_ = [("min_bin_idx", C.c_uint8), ("delta_max_bin_idx", C.c_uint8), ("crs_offset", C.c_int16),
                 ("cw_delta", C.c_int16 * 16)]
@@ -681,6 +689,18 @@ class Recorder:
         if r < 0:
             raise ValueError(f"ovhip_rec_transform_tree -> {r}")
         return r
+
+    def isp_cu(self, st: TuState, d: IspDesc) -> int:
+        r = self.lib.ovhip_rec_isp_cu(self.h, C.byref(st), C.byref(d))
+        if r < 0:
+            raise ValueError(f"ovhip_rec_isp_cu -> {r}")
+        return r
+
+    def isp_geometry(self, log2_w: int, log2_h: int, vertical: int):
+        """(log2 partition size, partitions, log2 prediction-call size, prediction calls) of an ISP CU"""
+        a, b, c, d = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        self.lib.ovhip_isp_geometry(log2_w, log2_h, vertical, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+        return a.value, b.value, c.value, d.value
 
     def pu(self, d: PuDesc) -> int:
         r = self.lib.ovhip_rec_pu(self.h, C.byref(d))

@@ -15,6 +15,8 @@ from dataclasses import dataclass, field
 import numpy as np
 
 LM_FRAC = 0.35      # share of intra chroma blocks predicted by a cross-component linear model (LM / MDLM)
+ISP_FRAC = 0.08     # share of the eligible intra CUs coded with intra sub-partitions (the reference decoder's random-walk streams, tests/golden/
+                    # shim_pipe*.ovg: 31 of 581 and 21 of 219 intra CUs; a third of their prediction calls are 1 or 2 rows high)
 
 from . import capi
 
@@ -144,7 +146,9 @@ def _lmcs_tables(rs) -> "capi.LmcsLuts":
 ALL_TOOLS = ("bdof", "dmvr", "affine", "gpm", "ciip", "lmcs")
 # + "intra": intra CUs (intra_frac of the CUs <= 64x64; 1.0 = an I picture) predicted on the device in dependency order,
 # and CIIP's planar part computed there too instead of being read from a caller-supplied picture
-INTRA_TOOLS = ALL_TOOLS + ("intra",)
+# + "isp": ISP_FRAC of those CUs as intra-sub-partition CUs (tmp.recon_isp_subtree_v / _h -> ovhip_rec_isp_cu): 2 or 4 partitions predicted
+# and reconstructed one after the other, horizontal ones down to 1 and 2 rows
+INTRA_TOOLS = ALL_TOOLS + ("intra", "isp")
 
 
 def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6, cbf_y: float = 0.5,
@@ -281,6 +285,10 @@ def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6
     bufs = [np.zeros(32 * 32, np.int16) for _ in range(3)]
     w4, h4 = (w + 3) // 4, (h + 3) // 4
     done = np.zeros((h4 + 1, w4 + 1), bool)          # decoding progress on the 4x4 grid (what the progress bit-fields hold)
+    isp_on = dev_intra and "isp" in tools
+    isp = capi.IspDesc()
+    isp_buf = np.zeros(64 * 64, np.int16)
+    n_isp = 0
 
     def avail(ux, uy, nw, nh):
         """(corner, units available above from ux, units available left from uy): neighbours decoded before this block"""
@@ -331,6 +339,7 @@ def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6
                 elif max(tl2w, tl2h) <= 5 and r[4] < 0.13 and (cbf & 0x10):
                     td.tr_skip_mask = 0x10
                 task_l = task_c = None
+                cu_isp = False
                 if cu_intra or cu_ciip:
                     ux, uy, nw, nh = (x + tx) >> 2, (y + ty) >> 2, (1 << tl2w) >> 2, (1 << tl2h) >> 2
                     corner, a_abv, a_lft = avail(ux, uy, nw, nh)
@@ -353,6 +362,70 @@ def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6
                         lmode = 0 if q[0] < 0.25 else 1 if q[0] < 0.35 else int(rs.randint(2, 67))
                         st.intra_mode = lmode
                         task_l.mode = lmode
+                        isp_vertical = int(rs.randint(0, 2))
+                        cu_isp = (isp_on and q[3] < ISP_FRAC and l2w <= 6 and l2h <= 6 and l2w + l2h >= 5
+                                  and not (l2w == 6 and l2h == 3 and not isp_vertical))     # (64x2 partitions: refused, the reference's result is undefined)
+                        if cu_isp:
+                            # ---- intra sub-partitions (recon_isp_subtree_v / _h, rcn_transform_tree.c:1087-1205): the luma of the CU in one
+                            #      recorder call; the caller has marked the CU in the progress field before (vcl_transform_unit.c:1878), so the
+                            #      partitions see each other; its chroma follows as a chroma transform unit (rcn_tu_c) ----
+                            done[y >> 2:(y + (1 << l2h)) >> 2, x >> 2:(x + (1 << l2w)) >> 2] = True
+                            l2p, n_pb, l2pred, n_pred = rec.isp_geometry(l2w, l2h, isp_vertical)
+                            isp.x0, isp.y0, isp.log2_cb_w, isp.log2_cb_h, isp.vertical, isp.intra_mode = x, y, l2w, l2h, isp_vertical, lmode
+                            isp.lfnst_flag = isp.lfnst_idx = 0; isp.mts_enabled = 1
+                            nb_a, nb_l = ((2 << l2w) >> 2) + 1, ((2 << l2h) >> 2) + 1
+                            for k in range(min(n_pred, 4)):
+                                off = k << l2pred
+                                px, py, off_y = (x + off, y, 0) if isp_vertical else (x, y + off, off)
+                                row, col = (py >> 2) - 1 + (1 if off_y % 4 else 0), (px >> 2) - 1
+                                ma = sum(1 << j for j in range(nb_a + 1)
+                                         if row >= 0 and 0 <= (x >> 2) - 1 + j < w4 and done[row, (x >> 2) - 1 + j])
+                                ml = sum(1 << j for j in range(nb_l + 1)
+                                         if col >= 0 and 0 <= (y >> 2) - 1 + j < h4 and done[(y >> 2) - 1 + j, col])
+                                isp.corner[k] = (ma & 1) | ((ml & 1) << 1)
+                                isp.avl_abv[k], isp.avl_lft[k] = (ma >> 1).bit_length(), (ml >> 1).bit_length()
+                            l2tw, l2th = (l2p, l2h) if isp_vertical else (l2w, l2p)
+                            tbn = 1 << (l2tw + l2th)
+                            isp_buf[:n_pb * tbn] = 0
+                            cbfm = int(rs.randint(1, 1 << n_pb))
+                            for i in range(n_pb):
+                                isp.last_pos[i] = 0x0101; isp.sig_sb_map[i] = 1
+                                if not (cbfm >> (n_pb - 1 - i)) & 1:
+                                    continue
+                                pbuf = isp_buf[i * tbn:(i + 1) * tbn]
+                                if l2tw < 2 or l2th < 2:                     # 1xN / 2xN / Nx1 / Nx2: the whole block raster
+                                    kk = min(tbn, int(rs.randint(1, 5)))
+                                    pbuf[rs.randint(0, min(tbn, 8), size=kk)] = coef_pool[pool_pos:pool_pos + kk]
+                                    pool_pos = (pool_pos + kk) % (len(coef_pool) - 4096)
+                                else:                                        # sub-block storage, row of sub-blocks = min(32, width) * 4
+                                    stride = min(32, 1 << l2tw)
+                                    vals = coef_pool[pool_pos:pool_pos + 16].copy(); pool_pos = (pool_pos + 16) % (len(coef_pool) - 4096)
+                                    vals[rs.random_sample(16) > 0.5] = 0
+                                    pbuf[0:16] = vals
+                                    m = 1
+                                    if (1 << l2tw) >= 8 and rs.random_sample() < 0.4:
+                                        vals = coef_pool[pool_pos:pool_pos + 16].copy(); pool_pos = (pool_pos + 16) % (len(coef_pool) - 4096)
+                                        vals[rs.random_sample(16) > 0.3] = 0
+                                        pbuf[16:32] = vals; m |= 2
+                                    if (1 << l2th) >= 8 and rs.random_sample() < 0.4:
+                                        vals = coef_pool[pool_pos:pool_pos + 16].copy(); pool_pos = (pool_pos + 16) % (len(coef_pool) - 4096)
+                                        vals[rs.random_sample(16) > 0.3] = 0
+                                        pbuf[4 * stride:4 * stride + 16] = vals; m |= 1 << 8
+                                    if pbuf[0] == 0:
+                                        pbuf[0] = 1
+                                    isp.sig_sb_map[i] = m
+                            isp.cbf_mask = cbfm
+                            isp.coef = isp_buf.ctypes.data
+                            st.qp_y = qp; st.qp_cb = qp - 1; st.qp_cr = qp - 1; st.qp_jcbcr = qp - 2
+                            st.qp_y_skip = max(qp, 16); st.qp_cb_skip = st.qp_cr_skip = st.qp_jcbcr_skip = max(qp - 1, 16)
+                            rec.isp_cu(st, isp)
+                            n_isp += 1
+                            # the CU's chroma: a chroma transform unit of its own (tree 2: position and size in chroma samples)
+                            task_l = None
+                            cbf &= ~0x10
+                            td.tree = 2; td.x0, td.y0, td.log2_tb_w, td.log2_tb_h = x >> 1, y >> 1, tl2w - 1, tl2h - 1
+                            td.cbf_mask = cbf; td.tr_skip_mask = 0; td.cu_mts_flag = 0
+                            q[1] = 1.0                                       # (no MIP / MRL / BDPCM with ISP)
                         if q[1] < 0.08:                                      # matrix-based intra prediction
                             n_mip = 16 if (tl2w == 2 and tl2h == 2) else 8 if (tl2h == 2 or tl2w == 2 or (tl2h <= 3 and tl2w <= 3)) else 6
                             task_l.flags |= capi.IF_MIP | (capi.IF_MIP_TR if q[2] < 0.5 else 0)
@@ -459,7 +532,7 @@ def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6
     nref = lambda a: np.where(a["dir"] == 3, 2, 1)
     tot = area(u).sum() + area(ux).sum() + area(ua).sum()
     wl.stats = {
-        "n_cu": int(n), "n_tu": int(n_tu), "n_mc_units": int(len(u)), "n_mcx_units": int(len(ux)),
+        "n_cu": int(n), "n_tu": int(n_tu), "n_isp_cus": int(n_isp), "n_mc_units": int(len(u)), "n_mcx_units": int(len(ux)),
         "n_aff_units": int(len(ua)), "n_ciip_units": int(len(wl.ciip_units)), "n_tb_cmds": int(len(wl.tb_cmds)),
         "n_luma_cmds": int(n_luma), "n_lmcs_regions": 0 if wl.lmcs_regions is None else int(len(wl.lmcs_regions)),
         "cu_modes": {k: int((mode == v).sum()) for k, v in (("plain", PLAIN), ("bdof", BDOF), ("dmvr", DMVR), ("affine", AFFINE), ("gpm", GPM), ("ciip", CIIP))
