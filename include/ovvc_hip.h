@@ -1094,6 +1094,9 @@ int  ovhip_dpb_publish(ovhip_dpb *d, const void *key, int status);
  * ovhip_dpb_set_unknown_key_timeout milliseconds (default 10000; 0: do not wait) -- then OVHIP_EINVAL. */
 void ovhip_dpb_set_unknown_key_timeout(ovhip_dpb *d, int ms);
 int  ovhip_dpb_acquire(ovhip_dpb *d, const void *key, int dev, ovhip_pic *pic, void **event);
+/* 1: the picture is DONE (an acquire would not wait for its decode), 0: not yet (unknown key, another picture under it, DECODING),
+ * OVHIP_EREF: it failed.  Never blocks. */
+int  ovhip_dpb_poll_tag(ovhip_dpb *d, const void *key, uint64_t tag);
 int  ovhip_dpb_wait_copy(ovhip_dpb *d, int dev, void *event);
 int  ovhip_dpb_unpin(ovhip_dpb *d, const void *key);
 int  ovhip_dpb_release(ovhip_dpb *d, const void *key);
@@ -1165,6 +1168,9 @@ int64_t ovhip_frame_dmvr_rows(ovhip_frame *f);
 /* The two halves (ovhip_job_dmvr_rows_begin / _collect): _begin waits for the picture's reference pictures on the host (as
  * ovhip_frame_dmvr_rows does: only a published picture is complete, its ordered pass may run a second time), then enqueues the pass
  * over the units recorded so far and returns; _collect before the row those units belong to is reported decoded. */
+/* 1: every reference picture named so far is complete (and now pinned: _begin / _submit will not wait for a decode), 0: not yet, < 0: one
+ * failed.  Never waits for a decode: a caller that can go on parsing asks this before it starts a row pass. */
+int  ovhip_frame_refs_ready(ovhip_frame *f);
 int64_t ovhip_frame_dmvr_rows_begin(ovhip_frame *f, int32_t log2_ctu_s);
 int64_t ovhip_frame_dmvr_rows_collect(ovhip_frame *f);
 /* job: NULL = the frame's own job (the shim); else a job holding an already recorded picture of the same size, which is bound to

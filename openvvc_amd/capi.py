@@ -518,6 +518,8 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_dpb_publish": (C.c_int, [vp, vp, C.c_int]),
         "ovhip_dpb_acquire": (C.c_int, [vp, vp, C.c_int, P(Pic), P(vp)]),
         "ovhip_dpb_wait_copy": (C.c_int, [vp, C.c_int, vp]),
+        "ovhip_dpb_poll_tag": (C.c_int, [vp, vp, C.c_uint64]),
+        "ovhip_frame_refs_ready": (C.c_int, [vp]),
         "ovhip_dpb_set_unknown_key_timeout": (None, [vp, C.c_int]),
         "ovhip_dpb_unpin": (C.c_int, [vp, vp]),
         "ovhip_dpb_release": (C.c_int, [vp, vp]),
@@ -585,7 +587,7 @@ EXPORTED_SYMBOLS = [
     "ovhip_md5_init", "ovhip_md5_update", "ovhip_md5_final", "ovhip_tmvp_cells_launch", "ovhip_job_tmvp_cells", "ovhip_intra_flow_untag_launch", "ovhip_lmcs_inverse_untag_launch", "ovhip_lmcs_scale_prepare_launch",
     "ovhip_host_alloc", "ovhip_host_free", "ovhip_d2d", "ovhip_job_test_abort_next_flow",
     "ovhip_dpb_create", "ovhip_dpb_create_ex", "ovhip_dpb_destroy", "ovhip_dpb_n_devices", "ovhip_dpb_device", "ovhip_dpb_begin", "ovhip_dpb_want",
-    "ovhip_dpb_publish", "ovhip_dpb_acquire", "ovhip_dpb_wait_copy", "ovhip_dpb_set_unknown_key_timeout", "ovhip_dpb_unpin", "ovhip_dpb_release", "ovhip_dpb_lookup", "ovhip_dpb_shutdown",
+    "ovhip_dpb_publish", "ovhip_dpb_acquire", "ovhip_dpb_wait_copy", "ovhip_dpb_poll_tag", "ovhip_frame_refs_ready", "ovhip_dpb_set_unknown_key_timeout", "ovhip_dpb_unpin", "ovhip_dpb_release", "ovhip_dpb_lookup", "ovhip_dpb_shutdown",
     "ovhip_dpb_get_stats", "ovhip_dpb_begin_tag", "ovhip_dpb_want_tag", "ovhip_dpb_acquire_tag", "ovhip_frame_begin_tag", "ovhip_frame_ref_tag", "ovhip_frame_set_trace",
     "ovhip_rccl_unique_id", "ovhip_rccl_create", "ovhip_rccl_destroy", "ovhip_rccl_xfer", "ovhip_rccl_last_error", "ovhip_rccl_stats", "ovhip_rccl_self_exchange",
     "ovhip_frame_create", "ovhip_frame_destroy", "ovhip_frame_ctx", "ovhip_frame_job", "ovhip_frame_recorder", "ovhip_frame_begin", "ovhip_frame_ref",

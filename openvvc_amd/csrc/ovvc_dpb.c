@@ -419,6 +419,19 @@ ovhip_dpb_acquire_tag(ovhip_dpb *d, const void *key, uint64_t tag, int dev, ovhi
     return r;
 }
 
+/* Is the picture there?  1: DONE (ovhip_dpb_acquire_tag would not block on the decode), 0: not yet -- unknown key, another picture under
+ * the key, still DECODING -- OVHIP_EREF: it FAILED / the DPB was shut down.  Never blocks. */
+int
+ovhip_dpb_poll_tag(ovhip_dpb *d, const void *key, uint64_t tag)
+{
+    if (!d || !key) return OVHIP_EINVAL;
+    pthread_mutex_lock(&d->mtx);
+    const struct dpb_slot *s = find_tag(d, key, tag);
+    const int r = d->shutdown ? OVHIP_EREF : !s ? 0 : s->state == S_DONE ? 1 : s->state == S_FAILED ? OVHIP_EREF : 0;
+    pthread_mutex_unlock(&d->mtx);
+    return r;
+}
+
 int
 ovhip_dpb_wait_copy(ovhip_dpb *d, int dev, void *event)
 {

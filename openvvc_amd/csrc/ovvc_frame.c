@@ -216,6 +216,23 @@ acquire_refs(ovhip_frame *f)
     return OVHIP_OK;
 }
 
+/* 1: every reference picture named so far is complete (acquired and pinned: ovhip_frame_dmvr_rows_begin / ovhip_frame_submit will not
+ * wait for a decode), 0: not yet, < 0: one of them failed.  Never waits for a decode -- what a caller that may go on parsing asks before
+ * it starts the eager DMVR rows (shim/rcn_hip.c with the caller patch: the CTU rows are then reported later instead of the parse
+ * stopping here). */
+int
+ovhip_frame_refs_ready(ovhip_frame *f)
+{
+    if (!f || !f->live) return OVHIP_EINVAL;
+    for (int i = 0; i < f->n_refs; ++i) {
+        if (f->ref_pinned[i]) continue;
+        const int r = ovhip_dpb_poll_tag(f->dpb, f->ref_key[i], f->ref_tag[i]);
+        if (r <= 0) return r < 0 ? fail(f, r, "a reference picture failed to decode") : 0;
+    }
+    const int r = acquire_refs(f);
+    return r == OVHIP_OK ? 1 : r;
+}
+
 static int
 before_launch_cb(void *user)
 {

@@ -43,8 +43,9 @@
  * decoder.  Measured on the reference: 744 pointer-sized slots. */
 _Static_assert(sizeof(void *) == 8, "LP64 only");
 #ifdef OVVC_HIP_CALLER_PATCH
-#define HIP_TABLE_BYTES (5952 + 2 * sizeof(void *))          /* shim/caller.patch: rcn_cu_inter_b, rcn_affine_cu appended */
-_Static_assert(offsetof(struct RCNFunctions, rcn_cu_inter_b) == 5952 && offsetof(struct RCNFunctions, rcn_affine_cu) == 5960, "the patch's two slots close the table");
+#define HIP_TABLE_BYTES (5952 + 3 * sizeof(void *))          /* shim/caller.patch: rcn_cu_inter_b, rcn_affine_cu, rcn_report_ctu_line appended */
+_Static_assert(offsetof(struct RCNFunctions, rcn_cu_inter_b) == 5952 && offsetof(struct RCNFunctions, rcn_affine_cu) == 5960
+               && offsetof(struct RCNFunctions, rcn_report_ctu_line) == 5968, "the patch's three slots close the table");
 #else
 #define HIP_TABLE_BYTES 5952
 #endif
@@ -118,6 +119,11 @@ struct hip_entry {
      * carry nothing new.  Rectangle in CTU-local luma samples; any other slot call ends it. */
     int aff_c_live, aff_c_x0, aff_c_y0, aff_c_x1, aff_c_y1;
     struct { int depth; uint64_t t0, ticks_hooks, ticks_device, n_calls; } prof;
+#ifdef OVVC_HIP_CALLER_PATCH
+    /* CTU-row reports held back until the row's collocated motion vectors are final (rcn_report_ctu_line, shim/caller.patch) */
+    struct { OVPicture *pic; int y, x0, x1; size_t need; } reports[160];
+    int n_reports; size_t report_need; uint64_t n_reports_deferred;
+#endif
     /* a CIIP CU whose planar tasks wait for the CU's transform unit (which carries their residual); closed without one by
      * the next slot call that is not that transform unit */
     struct { int live, x0, y0, log2_w, log2_h, has_c; ovhip_itask tl, tc; } ciip;
@@ -1227,6 +1233,7 @@ static void flush_picture(struct hip_entry *e, OVCTUDec *c);
  * ran while this row was parsed), patch the planes, enqueue the pass over the row just parsed.  The last row, and rows no hook ran
  * after, are refined synchronously.  ovhip_frame_dmvr_rows_begin waits for the picture's references on the host the first time a
  * row holds a DMVR unit (rcn_inter_synchronization waits per block, rcn_inter.c:131-146). */
+#ifndef OVVC_HIP_CALLER_PATCH
 static void
 dmvr_rows_step(struct hip_entry *e, OVCTUDec *c, int final)
 {
@@ -1257,6 +1264,84 @@ dmvr_rows_step(struct hip_entry *e, OVCTUDec *c, int final)
     }
     e->row_mark = now;
 }
+
+#else
+/* With the caller patch the back-end owns the CTU-row reports (rcn_report_ctu_line), so the parse does NOT stop at the first row that
+ * holds a DMVR unit until every reference picture has been reconstructed: a row pass is started only when the references are complete
+ * (ovhip_frame_refs_ready never waits for a decode), the reports of rows whose vectors are not final yet are queued, and every later
+ * hook -- and the picture's last one, which does wait -- issues what has become final.  The parse of a picture then overlaps the
+ * reconstruction of its reference pictures, as the reference's row-granular synchronisation lets it (rcn_inter.c:131-146): the frame
+ * threads' critical path is no longer the SUM of the parses along the GOP's dependency chain. */
+static void
+apply_done_cells(struct hip_entry *e, OVCTUDec *c, int64_t done)
+{
+    if (done < 0) { latch(e, (int)done, "ovhip_frame_dmvr_rows"); return; }
+    if ((size_t)done <= e->dmvr_done) return;
+    size_t n = 0;
+    ovhip_job *job = ovhip_frame_job(e->fr);                 /* (NULL: a dry frame -- nothing computes, nothing to patch) */
+    const ovhip_tmvp_cell *cells = job ? ovhip_job_tmvp_cells(job, &n) : NULL;
+    if (job && (!cells || n < 4 * (size_t)done)) { latch(e, OVHIP_EINVAL, "the eager DMVR pass delivered no collocated-motion entries"); return; }
+    if (cells) ovhip_shim_apply_tmvp_cells(c, cells + 4 * e->dmvr_done, 4 * ((size_t)done - e->dmvr_done));
+    e->dmvr_done = (size_t)done;
+}
+
+static void
+issue_reports(struct hip_entry *e, int all)
+{
+    int k = 0;
+    while (k < e->n_reports && (all || e->reports[k].need <= e->dmvr_done)) {
+        ovdpb_report_decoded_ctu_line(e->reports[k].pic, e->reports[k].y, e->reports[k].x0, e->reports[k].x1);
+        ++k;
+    }
+    if (k) { memmove(e->reports, e->reports + k, (size_t)(e->n_reports - k) * sizeof(e->reports[0])); e->n_reports -= k; }
+}
+
+static int g_blocking_rows;          /* OVVC_HIP_BLOCKING_ROWS: the decoder reports its rows itself, every row hook waits (the A / B of the above) */
+
+static void
+dmvr_rows_step(struct hip_entry *e, OVCTUDec *c, int final)
+{
+    if (!e->fr) return;
+    final |= g_blocking_rows;
+    /* the report(s) that follow this hook publish the rows parsed before the PREVIOUS hook ran: their refined units */
+    e->report_need = e->row_mark;
+    const size_t now = e->n_refined;
+    if (!e->err && now != e->dmvr_done) {
+        PROF_DEVICE_BEGIN(e);
+        /* (a pass in flight began when its references were complete: this waits for device time only) */
+        int64_t done = ovhip_frame_dmvr_rows_collect(e->fr);
+        if (done >= 0 && (size_t)done < now) {
+            const int ready = final ? 1 : ovhip_frame_refs_ready(e->fr);
+            if (ready < 0) done = ready;
+            else if (ready) {
+                done = ovhip_frame_dmvr_rows_begin(e->fr, e->log2_ctu);      /* final: waits for the reference pictures here */
+                if (done >= 0) done = final ? ovhip_frame_dmvr_rows_collect(e->fr) : (int64_t)e->dmvr_done;     /* else: collected by the next hook */
+            }
+        }
+        PROF_DEVICE_END(e);
+        apply_done_cells(e, c, done);
+    }
+    e->row_mark = now;
+    issue_reports(e, e->err != 0 || final);        /* (a failed picture's rows are reported: nobody may hang on it) */
+}
+
+/* rcn_report_ctu_line (shim/caller.patch; slicedec.c:934-956, :1058-1073): the decoder's ovdpb_report_decoded_ctu_line, made when the
+ * row's collocated motion vectors are final -- at once in pictures without DMVR units and whenever the device has already answered */
+static void
+hip_rcn_report_ctu_line(OVCTUDec *const c, OVPicture *const pic, int y_ctu, int xmin_ctu, int xmax_ctu)
+{
+    struct hip_entry *e = entry_of(c, 0);
+    if (!e || e->record_only || !e->fr || e->err || (!e->n_reports && e->report_need <= e->dmvr_done)
+        || e->n_reports == (int)(sizeof(e->reports) / sizeof(e->reports[0]))) {
+        if (e && e->n_reports) { dmvr_rows_step(e, c, 1); issue_reports(e, 1); }       /* (queue full: wait, as the unpatched path does) */
+        ovdpb_report_decoded_ctu_line(pic, y_ctu, xmin_ctu, xmax_ctu);
+        return;
+    }
+    e->reports[e->n_reports].pic = pic; e->reports[e->n_reports].y = y_ctu; e->reports[e->n_reports].x0 = xmin_ctu; e->reports[e->n_reports].x1 = xmax_ctu;
+    e->reports[e->n_reports].need = e->report_need;
+    e->n_reports++; e->n_reports_deferred++;
+}
+#endif
 
 /* alf.rcn_alf_filter_line (rcn_structures.h:333; rcn_alf.c:1285-1433): the LAST slot call before a CTU row is published
  * (slicedec.c:934-956).  Captures the row's ALF parameters, refines the DMVR vectors recorded so far (so that the row's
@@ -1475,6 +1560,10 @@ begin_picture(struct hip_entry *e, const OVFrame *f, const struct RectEntryInfo 
     e->sao_on = e->alf_on = 0;
     e->lmcs_region_live = 0;
     e->n_refined = 0; e->dmvr_done = 0; e->row_mark = 0;
+#ifdef OVVC_HIP_CALLER_PATCH
+    if (e->n_reports) issue_reports(e, 1);             /* (a picture that never reached its last row: its readers must not hang) */
+    e->report_need = 0;
+#endif
     e->pend.kind = PEND_NONE; e->aff_c_live = 0; e->ciip.live = 0;
     if (e->rec && e->key->part_ctx) (void)ovhip_rec_set_ctu_size(e->rec, e->key->part_ctx->log2_ctu_s);
     if (e->n_ctu) { memset(e->sao, 0, e->n_ctu * sizeof(*e->sao)); memset(e->alf, 0, e->n_ctu * sizeof(*e->alf)); }
@@ -1568,6 +1657,8 @@ rcn_init_functions_hip(struct RCNFunctions *f, uint8_t ict_type, uint8_t lm_chro
 #ifdef OVVC_HIP_CALLER_PATCH
     f->rcn_cu_inter_b = &hip_rcn_cu_inter_b;
     f->rcn_affine_cu = &hip_rcn_affine_cu;
+    g_blocking_rows = getenv("OVVC_HIP_BLOCKING_ROWS") != NULL;
+    f->rcn_report_ctu_line = g_blocking_rows ? NULL : &hip_rcn_report_ctu_line;      /* (NULL: the decoder reports by itself, the row hooks wait) */
 #endif
     f->rcn_gpm_b = &hip_rcn_gpm_b;
     f->rcn_ciip_b = &hip_rcn_ciip_b;
