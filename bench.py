@@ -756,6 +756,9 @@ def main():
                     # the reference itself on this host's cores (north_star): the headline cpu_baseline; the port's figures stay beside it
                     port = {k: cpu[k] for k in ("value", "cores", "value_1_thread", "value_64_threads", "sample") if k in cpu}
                     cpu = {"value": ref["scalar"]["fps_all_cores"], "unit": "frames/s", "cores": ncpu, "kind": "reference",
+                           "measured_on": "the reference decoder's own chained stream (config.reference_stream / config.live_decoder: parse included), NOT the "
+                                          "synthetic recorded stream the headline `value` is measured on: compare it with config.live_decoder (same stream, "
+                                          "parse included on both sides) and config.reference_stream, not with `value`",
                            "value_1_thread": ref["scalar"]["fps_1_process"],
                            "simd": ref["simd"], "scalar": ref["scalar"], "host_side_with_the_shim": ref.get("parse_and_record"),
                            "sample": f"oracle/_ref/gen_pipe time: the reference's own slice decoder (parse + reconstruction + in-loop filters; libovvc "
@@ -796,7 +799,8 @@ def main():
                        "dependency_critical_path_pictures": round(gop.critical_path(gop.build_stream(4 * world, G, IP, world)), 1),
                        "intra_tasks_per_b_picture": st["n_itasks"], "intra_levels_per_b_picture": st["n_ilevels"],
                        "intra_levels_per_i_picture": wls[-1].stats["n_ilevels"],
-                       "h2d_bytes_per_step": int(mean_stat("h2d_bytes")), "d2h_bytes_per_step": int(mean_stat("d2h_bytes")),
+                       "h2d_bytes_per_picture": int(mean_stat("h2d_bytes")), "d2h_bytes_per_picture": int(mean_stat("d2h_bytes")),
+                       "h2d_bytes_per_step": int(mean_stat("h2d_bytes")) * PPS * L, "h2d_GBps_in_the_timed_region": round(mean_stat("h2d_bytes") * fps / 1e9, 2),
                        "ordered_pass_second_passes": second_passes[0],
                        "check": check,
                        "reference_stream": ref_stream,

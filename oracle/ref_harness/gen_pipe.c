@@ -74,6 +74,7 @@ static int g_pass_shim;                             /* 0 reference slots, 1 inst
 static int g_threads;                               /* "threads N[,M,...]": frame threads of the device / live pass (0: the one-thread loop of the fixtures); a list = one pass each */
 static int g_thread_list[16], g_n_thread_list;
 static int g_tile_cols = 1, g_tile_rows = 1;         /* "tiles C R": C x R rect entries per picture, decoded one after the other on ONE OVCTUDec (slicedec.c:649-653) */
+static int g_no_isp;                                /* "noisp": sps_isp_enabled_flag = 0 (long 4K streams: some 64x8 CU is split into 64x2 partitions in nearly every one) */
 static int g_isp_64x2;                              /* the reference's result for 64x2 ISP partitions is undefined (gen_golden.c, gen_isp) */
 
 /* ---- device mode: the decoder's events the shim hangs its frame-level calls on, interleaved with those calls ---- */
@@ -94,7 +95,7 @@ gp_dmvr(OVCTUDec *const c, struct OVBuffInfo dst, uint8_t x0, uint8_t y0, uint8_
         uint8_t ref_idx0, uint8_t ref_idx1, uint8_t apply_bdof)
 {
     const int32_t in[8] = { (c->ctb_x << 7) + x0, (c->ctb_y << 7) + y0, l2w, l2h, mv0->x, mv0->y, mv1->x, mv1->y };
-    const uint8_t r = g_dmvr_inner(c, dst, x0, y0, l2w, l2h, mv0, mv1, ref_idx0, ref_idx1, apply_bdof);
+    const uint8_t r = __atomic_load_n(&g_dmvr_inner, __ATOMIC_RELAXED)(c, dst, x0, y0, l2w, l2h, mv0, mv1, ref_idx0, ref_idx1, apply_bdof);
     if (g_pass_shim == 2 && !g_threads) gp_event(GP_EV_DMVR_SLOT, in[0], in[1]);
     if (g_pass_shim == 3) return r;                 /* live: what the installed slot returned; the device delivers the refined vectors */
     if (!g_pass_shim) {
@@ -120,7 +121,7 @@ static void
 gp_isp_h(OVCTUDec *const c, unsigned int x0, unsigned int y0, unsigned int l2w, unsigned int l2h, uint8_t mode, const struct ISPTUInfo *const tu)
 {
     if (l2w == 6 && l2h == 3) __atomic_fetch_add(&g_isp_64x2, 1, __ATOMIC_RELAXED);
-    g_isp_h_inner(c, x0, y0, l2w, l2h, mode, tu);
+    __atomic_load_n(&g_isp_h_inner, __ATOMIC_RELAXED)(c, x0, y0, l2w, l2h, mode, tu);
 }
 
 static void (*g_attach_inner)(struct OVRCNCtx *const, const OVFrame *const, const struct RectEntryInfo *const, uint8_t);
@@ -162,18 +163,21 @@ gp_rcn_init_functions(struct RCNFunctions *f, uint8_t ict_type, uint8_t lm_chrom
     if (bitdepth != 10 || !lm_chroma_enabled || vcolloc) { fprintf(stderr, "gen_pipe: table variant not restated\n"); exit(1); }
     ref_fill_table(f, ict_type, lmcs_flag);
     if (g_pass_shim) rcn_init_functions_hip(f, ict_type, lm_chroma_enabled, vcolloc, lmcs_flag, bitdepth);
-    g_dmvr_inner = f->rcn_dmvr_mv_refine; f->rcn_dmvr_mv_refine = &gp_dmvr;
-    if (getenv("GP_TRACE")) { g_gpm_inner = f->rcn_gpm_b; f->rcn_gpm_b = &gp_gpm; }
+    /* (every frame thread fills its own table with the same slots: the "inner" pointers are the same values, stored relaxed) */
+#define GP_WRAP(inner, slot, wrapper) do { __atomic_store_n(&(inner), (slot), __ATOMIC_RELAXED); (slot) = (wrapper); } while (0)
+    GP_WRAP(g_dmvr_inner, f->rcn_dmvr_mv_refine, &gp_dmvr);
+    if (getenv("GP_TRACE")) GP_WRAP(g_gpm_inner, f->rcn_gpm_b, &gp_gpm);
     if (g_pass_shim >= 2 && g_threads) {
-        g_attach_inner = f->rcn_attach_frame_buff; f->rcn_attach_frame_buff = &gp_t_attach;
-        g_sao_first_inner = f->sao.rcn_sao_first_pix_rows; f->sao.rcn_sao_first_pix_rows = &gp_t_sao_first;
-        g_alf_line_inner = f->alf.rcn_alf_filter_line; f->alf.rcn_alf_filter_line = &gp_t_alf_line;
+        GP_WRAP(g_attach_inner, f->rcn_attach_frame_buff, &gp_t_attach);
+        GP_WRAP(g_sao_first_inner, f->sao.rcn_sao_first_pix_rows, &gp_t_sao_first);
+        GP_WRAP(g_alf_line_inner, f->alf.rcn_alf_filter_line, &gp_t_alf_line);
     } else if (g_pass_shim == 2) {
-        g_attach_inner = f->rcn_attach_frame_buff; f->rcn_attach_frame_buff = &gp_attach;
-        g_sao_first_inner = f->sao.rcn_sao_first_pix_rows; f->sao.rcn_sao_first_pix_rows = &gp_sao_first;
-        g_alf_line_inner = f->alf.rcn_alf_filter_line; f->alf.rcn_alf_filter_line = &gp_alf_line;
+        GP_WRAP(g_attach_inner, f->rcn_attach_frame_buff, &gp_attach);
+        GP_WRAP(g_sao_first_inner, f->sao.rcn_sao_first_pix_rows, &gp_sao_first);
+        GP_WRAP(g_alf_line_inner, f->alf.rcn_alf_filter_line, &gp_alf_line);
     }
-    g_isp_h_inner = (isp_fn)f->tmp.recon_isp_subtree_h; f->tmp.recon_isp_subtree_h = (void *)&gp_isp_h;
+    { isp_fn cur = (isp_fn)f->tmp.recon_isp_subtree_h; __atomic_store_n(&g_isp_h_inner, cur, __ATOMIC_RELAXED); f->tmp.recon_isp_subtree_h = (void *)&gp_isp_h; }
+#undef GP_WRAP
 }
 
 /* ------------------------------------------------------------------------------------------------ parameter sets */
@@ -250,7 +254,7 @@ seq_init(struct gp_seq *s, int w, int h, int variant)
     sps->sps_bcw_enabled_flag = 1; sps->sps_ciip_enabled_flag = 1;
     sps->sps_gpm_enabled_flag = 1; sps->sps_max_num_merge_cand_minus_max_num_gpm_cand = 1;
     rcn_init_gpm_params();                         /* what the SPS reader does when it meets the flag (nvcl_nal_sps.c:580-583) */
-    sps->sps_isp_enabled_flag = 1; sps->sps_mrl_enabled_flag = 1; sps->sps_mip_enabled_flag = 1; sps->sps_cclm_enabled_flag = 1;
+    sps->sps_isp_enabled_flag = !g_no_isp; sps->sps_mrl_enabled_flag = 1; sps->sps_mip_enabled_flag = 1; sps->sps_cclm_enabled_flag = 1;
     sps->sps_chroma_horizontal_collocated_flag = 1; sps->sps_chroma_vertical_collocated_flag = 0;
     sps->sps_ibc_enabled_flag = 0;
     sps->sps_dep_quant_enabled_flag = 1; sps->sps_sign_data_hiding_enabled_flag = 1;
@@ -625,11 +629,11 @@ static int g_profile, g_noout;
 static double g_prof_overhead;
 
 static void gp_t_attach(struct OVRCNCtx *const r, const OVFrame *const f, const struct RectEntryInfo *const e, uint8_t l2)
-{ const double t0 = gp_now(); g_attach_inner(r, f, e, l2); if (tls_thread) tls_thread->t_hooks += gp_now() - t0; }
+{ const double t0 = gp_now(); __atomic_load_n(&g_attach_inner, __ATOMIC_RELAXED)(r, f, e, l2); if (tls_thread) tls_thread->t_hooks += gp_now() - t0; }
 static void gp_t_sao_first(OVCTUDec *const c, const struct RectEntryInfo *const e, uint16_t y)
-{ const double t0 = gp_now(); g_sao_first_inner(c, e, y); if (tls_thread) tls_thread->t_hooks += gp_now() - t0; }
+{ const double t0 = gp_now(); __atomic_load_n(&g_sao_first_inner, __ATOMIC_RELAXED)(c, e, y); if (tls_thread) tls_thread->t_hooks += gp_now() - t0; }
 static void gp_t_alf_line(OVCTUDec *const c, const struct RectEntryInfo *const e, uint16_t y)
-{ const double t0 = gp_now(); g_alf_line_inner(c, e, y); if (tls_thread) tls_thread->t_hooks += gp_now() - t0; }
+{ const double t0 = gp_now(); __atomic_load_n(&g_alf_line_inner, __ATOMIC_RELAXED)(c, e, y); if (tls_thread) tls_thread->t_hooks += gp_now() - t0; }
 
 static void gp_reader_done(int k);
 
@@ -862,15 +866,17 @@ gp_main(int argc, char **argv)
 {
     signal(SIGSEGV, gp_on_segv); signal(SIGBUS, gp_on_segv); signal(SIGFPE, gp_on_segv); signal(SIGABRT, gp_on_segv);
     const char *dir = argc > 1 ? argv[1] : "../tests/golden";
-    int want_shim = 0, want_dev = 0, want_live = 0, want_time = 0, variant = 0, W = 416, H = 240, dqp = 0, n_pic = 5;
+    int want_shim = 0, want_dev = 0, want_live = 0, want_time = 0, variant = 0, W = 416, H = 240, dqp = 0, n_pic = 5, gop_size = 0;
     uint32_t seed = 0x266 + 31337;
     const char *name = "pipe";
-    /* gen_pipe <dir> [shim | device | live | simd] [threads <n>] [name <fixture name>] [seed <n>] [variant <0|1>] [qp <delta on every picture's QP>]
+    /* gen_pipe <dir> [shim | device | live | simd] [threads <n>[,<m>...]] [reps <n>] [gop <8|16|32>] [profile] [noout] [norelease] [name <fixture name>] [seed <n>] [variant <0|1>] [qp <delta on every picture's QP>]
      *          [size <w> <h>] [pics <1..257>] [time] */
     for (int i = 2; i < argc; ++i) {
         if (!strcmp(argv[i], "shim")) want_shim = 1;
         else if (!strcmp(argv[i], "device")) want_shim = want_dev = 1;
         else if (!strcmp(argv[i], "reps") && i + 1 < argc) g_reps = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "gop") && i + 1 < argc) gop_size = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "noisp")) g_no_isp = 1;
         else if (!strcmp(argv[i], "norelease")) g_no_release = 1;
         else if (!strcmp(argv[i], "profile")) g_profile = 1;      /* live: the shim's own split of a frame thread's time (ovhip_shim_set_profile) */
         else if (!strcmp(argv[i], "noout")) g_noout = 1;          /* live: OVHIP_OUT_NONE -- the pictures stay on the device (no copy into the OVFrame, frames not compared) */
@@ -893,6 +899,7 @@ gp_main(int argc, char **argv)
     }
     if (W % 8 || H % 8 || W < 136 || H < 136 || W > 4096 || H > 2304 || n_pic < 1 || n_pic > GP_MAX_PIC) { fprintf(stderr, "gen_pipe: size / pics\n"); return 2; }
     if (want_live && !g_threads) { g_threads = 1; g_thread_list[0] = 1; g_n_thread_list = 1; }
+    if (gop_size && ((gop_size != 8 && gop_size != 16 && gop_size != 32) || (!g_threads && !want_time))) { fprintf(stderr, "gen_pipe: gop 8 | 16 | 32, with threads or time\n"); return 2; }
 #ifdef OVVC_HIP_CALLER_PATCH
     /* the patched caller never comes through rcn_dmvr_mv_refine: nothing can be fed back from the reference pass, so the modes that
      * record without a device (whose later pictures' parse needs the refined vectors) do not exist here */
@@ -928,6 +935,34 @@ gp_main(int argc, char **argv)
             gop[k].l1[i] = gop[j].l1[i] ? gop[j].l1[i] + 8 * g : 1 + 8 * (g - 1);
         }
         if (j == 1) gop[k].tmvp = 1;
+    }
+    if (gop_size) {
+        /* "gop G" (live / time modes): a hierarchical-B random-access stream of GOPs of G = 8 / 16 / 32 pictures in depth-first decoding
+         * order, as the JVET CTC random-access configuration codes them (GOP 32: 32 16 8 4 2 1 3 6 5 7 12 ...): the key picture from the
+         * previous key picture, every other picture from the two pictures it lies between -- up to G / 2 pictures of the last layer
+         * are independent of each other, which is the parallelism frame threads live on.  Pictures beyond the last whole GOP are dropped. */
+        int n = 1, prev_key = 0;
+        struct { int lo, hi, lo_poc, hi_poc, depth; } stack[64];
+        while (n + gop_size <= n_pic) {
+            const int base = gop[prev_key].poc, key = n;
+            gop[n++] = (struct gp_pic_desc){ .poc = base + gop_size, .slice_type = 0, .qp = 33, .l0 = { prev_key }, .n0 = 1, .l1 = { prev_key }, .n1 = 1,
+                                             .tmvp = prev_key != 0, .col_from_l0 = 1, .lmcs = 1 };
+            int sp = 0;
+            stack[sp].lo = prev_key; stack[sp].hi = key; stack[sp].lo_poc = base; stack[sp].hi_poc = base + gop_size; stack[sp].depth = 1; ++sp;
+            while (sp) {
+                --sp;
+                const int lo = stack[sp].lo, hi = stack[sp].hi, lp = stack[sp].lo_poc, hp = stack[sp].hi_poc, d = stack[sp].depth;
+                if (hp - lp < 2) continue;
+                const int mid = n;
+                gop[n++] = (struct gp_pic_desc){ .poc = (lp + hp) / 2, .slice_type = 0, .qp = 34 + d, .l0 = { lo, hi }, .n0 = 2, .l1 = { hi, lo }, .n1 = 2,
+                                                 .tmvp = 1, .col_from_l0 = d & 1, .lmcs = 1 };
+                /* depth first, the earlier half first: push the later half below it */
+                stack[sp].lo = mid; stack[sp].hi = hi; stack[sp].lo_poc = (lp + hp) / 2; stack[sp].hi_poc = hp; stack[sp].depth = d + 1; ++sp;
+                stack[sp].lo = lo; stack[sp].hi = mid; stack[sp].lo_poc = lp; stack[sp].hi_poc = (lp + hp) / 2; stack[sp].depth = d + 1; ++sp;
+            }
+            prev_key = key;
+        }
+        n_pic = n;
     }
     for (int k = 0; k < n_pic; ++k) gop[k].qp += dqp;
     struct gp_out out;
