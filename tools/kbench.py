@@ -20,10 +20,13 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--reps", type=int, default=40)
     ap.add_argument("--ipic", action="store_true", help="also the 4K I picture (ordered pass)")
+    ap.add_argument("--isp-frac", type=float, default=None, help="share of the eligible intra CUs coded with ISP (default: synth.ISP_FRAC)")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     args = ap.parse_args()
     W, H = args.width, args.height
+    if args.isp_frac is not None:
+        synth.ISP_FRAC = args.isp_frac
     ctx = engine.Context(0)
     wl = synth.make_workload(W, H, 0x266, tools=synth.INTRA_TOOLS, intra_frac=0.12)
     alg = bench.algorithmic_bytes(wl, wl.frame_bytes)
@@ -71,7 +74,7 @@ def main():
             ji.flush(dst, [], None); ji.wait()
         s, n = ji.stage_time()
         lv = wi.stats["n_ilevels"]
-        print(f"I picture: ordered pass {s / n * 1e3:.3f} ms, {lv} levels -> {s / n * 1e6 / lv:.2f} us per level; retries {ji.stats().n_ordered_retries}")
+        print(f"I picture ({wi.stats.get('n_isp_cus', 0)} ISP CUs): ordered pass {s / n * 1e3:.3f} ms, {lv} levels -> {s / n * 1e6 / lv:.2f} us per level; retries {ji.stats().n_ordered_retries}")
         if not args.no_check:
             ref = oracle_pipeline.decode(wi)
             got = dst.download()
