@@ -503,9 +503,15 @@ __global__ __launch_bounds__(256) OV_OCC_ALF void k_alf(ovhip_pic dst, ovhip_pic
     __shared__ __attribute__((aligned(16))) uint16_t s_t[(LW > CW ? LW : CW) * LWS];
     __shared__ uint8_t s_cls[64];
     __shared__ __attribute__((aligned(16))) uint4 s_sum[256];          // luma classification: one row pair's Laplacian sums per lane
+    // XCD-aware tile order: every XCD takes one contiguous band of each plane's tiles (raster order), the same band of all three,
+    // so the halo rows and columns neighbouring tiles share -- and the luma a chroma tile's CC-ALF taps read -- come out of ONE L2
+    // (dealt round-robin, neighbouring tiles ran on different XCDs: every halo was fetched from memory once per XCD that needed it)
     const int b = blockIdx.x;
-    if (b < nl) alf_luma_tile(dst, src, alf, nb_ctu_w, b, s_t, s_cls, s_sum);
-    else        alf_chroma_tile(dst, src, alf, nb_ctu_w, (b - nl) % nc, 1 + (b - nl) / nc, s_t);
+    if (b < nl) alf_luma_tile(dst, src, alf, nb_ctu_w, (int)ov_xcd_slot_at(b, 0, nl), s_t, s_cls, s_sum);
+    else {
+        const int comp = 1 + (b - nl) / nc;
+        alf_chroma_tile(dst, src, alf, nb_ctu_w, (int)ov_xcd_slot_at(b, nl + (comp - 1) * nc, nc), comp, s_t);
+    }
 }
 
 } // namespace

@@ -385,7 +385,8 @@ template <int DIR>
 __global__ __launch_bounds__(256) OV_OCC_DBF void k_dbf_list(ovhip_pic pic, const ovhip_dbf_edge *__restrict__ edges, uint32_t n,
                                                   uint64_t tc_pack, uint64_t beta_pack)
 {
-    const uint32_t tid = blockIdx.x * 256 + threadIdx.x;
+    // XCD-aware order (ov_xcd_slot): the list is in decoding order, an XCD takes one contiguous chunk of it = a band of the picture
+    const uint32_t tid = ov_xcd_slot(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     const uint32_t ei = tid >> 2;
     const int l = tid & 3;
     if (ei >= n) return;                                   // whole quads leave together

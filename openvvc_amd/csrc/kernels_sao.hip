@@ -34,7 +34,9 @@ __global__ __launch_bounds__(256) void k_sao(ovhip_pic dst, ovhip_pic src, const
     // (plane, tile): luma tiles first, then Cb, then Cr; one tile per workgroup (single pass: `continue` leaves the tile)
     for (int t = blockIdx.x; t < tiles_y + 2 * tiles_c; t = tiles_y + 2 * tiles_c) {
         const int c = t < tiles_y ? 0 : (t < tiles_y + tiles_c ? 1 : 2);
-        const int tt = t - (c == 0 ? 0 : (c == 1 ? tiles_y : tiles_y + tiles_c));
+        // XCD-aware tile order (ov_xcd_slot_at): an XCD takes one contiguous band of each plane, the band k_alf's workgroups on the same
+        // XCD read next; the rows above and below a tile come out of the L2 that fetched them for the neighbouring tile
+        const int tt = (int)ov_xcd_slot_at(t, c == 0 ? 0 : (c == 1 ? tiles_y : tiles_y + tiles_c), c == 0 ? tiles_y : tiles_c);
         const int sh = c ? 1 : 0;
         const int w = src.w >> sh, h = src.h >> sh, l2 = log2_ctu - sh;
         const int ntx = (w + SAO_TW - 1) / SAO_TW;

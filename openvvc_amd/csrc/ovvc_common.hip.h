@@ -102,6 +102,21 @@ __device__ __forceinline__ uint32_t ov_xcd_slot(uint32_t i, uint32_t n)
     return k * base + (k < rem ? k : rem) + j;
 }
 
+// The same for the workgroups [first, first + n) of a larger grid (several planes' tiles in one launch): workgroup b runs on XCD
+// b % 8 whatever `first` is, and XCD k takes the k-th contiguous chunk of THIS range's items -- the k-th band of every plane, so the
+// planes' bands an XCD works on lie on top of each other (a chroma tile's CC-ALF taps read the luma band its own L2 holds).
+__device__ __forceinline__ uint32_t ov_xcd_slot_at(uint32_t b, uint32_t first, uint32_t n)
+{
+    const uint32_t i = b - first, k = b % OV_NUM_XCD, f = first % OV_NUM_XCD;
+    uint32_t start = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < OV_NUM_XCD; ++q) {           // workgroups of the range on the XCDs before k
+        const uint32_t r = (q + OV_NUM_XCD - f) % OV_NUM_XCD;                   // XCD q's first workgroup of the range is first + r
+        if (q < k) start += (n + OV_NUM_XCD - 1 - r) / OV_NUM_XCD;
+    }
+    return start + i / OV_NUM_XCD;
+}
+
 // row * stride for sample addressing: both fit 24 bits, and v_mul_i32_i24 / v_mad_i32_i24 are full rate where the 32-bit
 // v_mul_lo_u32 takes four issue slots
 __device__ __forceinline__ int ov_rowoff(int row, int stride) { return __mul24(row, stride); }
