@@ -14,7 +14,7 @@ from pathlib import Path
 import numpy as np
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "libovvc_hip.so"
+LIB_PATH = _PKG / os.environ.get("OVVC_HIP_LIB_NAME", "libovvc_hip.so")      # (the variable: A / B runs of kernel variants, tools/ only)
 
 # ---- constants (include/ovvc_hip.h) ----
 OVHIP_ABI_VERSION = 7
