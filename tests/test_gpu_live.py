@@ -123,3 +123,15 @@ def test_live_decode_with_the_patched_caller(w, h, threads, pics):
     u = live(threads, "size", w, h, "pics", pics, "seed", 31, "profile", timeout=1500)
     # whole coding units instead of <= 16x16 / 4x4 sub-block calls: far fewer hook calls for the same pictures
     assert r["shim_hook_calls"] * 2 < u["shim_hook_calls"]
+
+
+@pytest.mark.parametrize("patched", (False, True))
+@pytest.mark.parametrize("gop,threads,pics", [(16, 8, 33), (32, 16, 33)])
+def test_live_decode_of_deep_hierarchies_with_recycled_frames(gop, threads, pics, patched):
+    """GOPs of 16 / 32 (five / six levels of references, decoded depth first) on more frame threads than the hierarchy is deep, the stream
+    decoded three times by the same warm threads: every OVFrame comes back from the pool under a new picture while device pictures of
+    the repetition before are still being released (the device DPB's tags keep a recycled key from matching a stale entry)"""
+    run = live_patched if patched else live
+    r = run(threads, "size", 832, 480, "pics", pics, "gop", gop, "reps", 3, "seed", 11)
+    check(r, pics, threads)
+    assert r["host_frames_recycled"] > pics          # (three repetitions over a pool much smaller than 3 x pics)
