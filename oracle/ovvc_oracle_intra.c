@@ -221,7 +221,7 @@ pred_regular(const uint16_t *plane, int stride, const ovhip_itask *t, int is_lum
     const int l2w = t->log2_w, l2h = t->log2_h, w = 1 << l2w, h = 1 << l2h;
     const int mrl = is_luma ? t->mrl_idx : 0;
     const int unit = is_luma ? 4 : 2;
-    static ref_bufs R, F;
+    static _Thread_local ref_bufs R, F;       /* (bench.py runs one decode per host thread) */
     uint16_t *abv = R.a + REF_PAD, *lft = R.l + REF_PAD;
     fetch_refs(plane, stride, t->x, t->y, w, h, unit, !!(t->flags & OVHIP_IF_CORNER), t->avl_abv, t->avl_lft, mrl, abv, lft);
     const int bdpcm = !!(t->flags & OVHIP_IF_BDPCM);
@@ -301,11 +301,13 @@ pred_isp(const uint16_t *plane, int stride, const ovhip_itask *t, uint16_t *out)
     const int l2w = t->log2_w, l2h = t->log2_h, w = 1 << l2w, h = 1 << l2h;
     const int cbw = 1 << t->isp_log2_cb_w, cbh = 1 << t->isp_log2_cb_h, ox = t->isp_off_x, oy = t->isp_off_y;
     const int ca = !!(t->flags & OVHIP_IF_CORNER), cl = !!(t->flags & OVHIP_IF_CORNER_L);
-    static ref_bufs R;
+    static _Thread_local ref_bufs R;
     uint16_t *abv = R.a + REF_PAD, *lft = R.l + REF_PAD;
     const uint16_t *here = plane + t->y * stride + t->x;
-    isp_arm(here - stride - ox - 1, 1, cbw, w, ox, ca, t->avl_abv, cl || t->avl_lft, here[-1], abv);
-    isp_arm(here - (oy + 1) * stride - 1, stride, cbh, h, oy, cl, t->avl_lft, ca || t->avl_abv, here[-stride], lft);
+    /* (the other arm's first sample is used only when that arm has anything: not read at the picture's left column / top row, where
+     *  it would lie in front of the plane) */
+    isp_arm(here - stride - ox - 1, 1, cbw, w, ox, ca, t->avl_abv, cl || t->avl_lft, t->x ? here[-1] : 0, abv);
+    isp_arm(here - (oy + 1) * stride - 1, stride, cbh, h, oy, cl, t->avl_lft, ca || t->avl_abv, t->y ? here[-stride] : 0, lft);
     const int pdpc_ok = l2h > 1;                       /* rcn_intra.c:608, :618; cubic_v / cubic_h: log2_pb_h > 1 */
     int mode = t->mode;
     if (mode == 0) { pred_planar(abv, lft, l2w, l2h, pdpc_ok, out); return; }
@@ -347,7 +349,7 @@ pred_mip(const uint16_t *plane, int stride, const ovhip_itask *t, uint16_t *out)
 {
     const int l2w = t->log2_w, l2h = t->log2_h, w = 1 << l2w;
     const int tr = !!(t->flags & OVHIP_IF_MIP_TR), mode = t->mode;
-    static ref_bufs R;
+    static _Thread_local ref_bufs R;
     uint16_t *abv = R.a + REF_PAD, *lft = R.l + REF_PAD;
     fetch_refs(plane, stride, t->x, t->y, w, 1 << l2h, 4, !!(t->flags & OVHIP_IF_CORNER), t->avl_abv, t->avl_lft, 0, abv, lft);
     const int l2b = 1 << ((l2w > 2) || (l2h > 2));               /* log2 of the reduced boundary length per side: 1 or 2 */
@@ -526,7 +528,7 @@ void
 oracle_intra_tasks(const oracle_pic *pic, const oracle_res *res, const ovhip_itask *tasks, uint32_t n, const ovhip_lmcs_region *regs,
                    const ovhip_lmcs_luts *luts, int16_t *scales, int log2_ctu)
 {
-    static uint16_t pa[128 * 128], pb[128 * 128];
+    static _Thread_local uint16_t pa[128 * 128], pb[128 * 128];
     for (uint32_t i = 0; i < n; ++i) {
         const ovhip_itask *t = &tasks[i];
         const int w = 1 << t->log2_w, h = 1 << t->log2_h;
