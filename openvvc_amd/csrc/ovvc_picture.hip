@@ -47,6 +47,7 @@ struct ovhip_job {
     size_t rows_end; int rows_pending;   // an eager pass is in flight: it covers [.., rows_end), ev_rows follows its copies
     hipEvent_t ev_rows;
     hipEvent_t ev_h2d, ev_done;
+    int flow_on_device;                  // the last full flush uploaded the flow launch's item list (a resident replay may use it)
     int flushed;                         // ev_* recorded at least once
     const void *packed_prev[24];         // where the last full flush placed the arrays that rode in the parameter block
     int resident;                        // this flush reuses the device copies of the previous one (OVHIP_STAGE_RESIDENT)
@@ -500,6 +501,9 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
     size_t n_it = 0, n_ictu = 0; uint32_t n_lv = 0; const uint32_t *lv_start = nullptr; const ovhip_ictu *ictu = nullptr;
     const int by_ctu = pr->stages && (stages & OVHIP_STAGE_INTRA_CTU);
     int by_flow = !by_ctu && !(pr->stages && (stages & OVHIP_STAGE_INTRA_LEVELS));
+    // a resident replay runs from what the last FULL flush left on the device: after a second pass (ovhip_job_wait: per-level launches,
+    // no item list in the parameter block) that is a picture without the flow launch's items
+    if (j->resident && by_flow && !j->flow_on_device) by_flow = 0;
     const int by_level = !by_ctu;          // the flow launch also takes the level-sorted list
     const ovhip_itask *it;
     it = by_level ? ovhip_rec_itasks_sorted(rec, &n_it, &lv_start, &n_lv)
@@ -601,7 +605,7 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
     }
     }
     // a resident replay re-uses the placement of the flush before it
-    if (no_upload) memcpy(packed, j->packed_prev, sizeof(packed)); else memcpy(j->packed_prev, packed, sizeof(packed));
+    if (no_upload) memcpy(packed, j->packed_prev, sizeof(packed)); else { memcpy(j->packed_prev, packed, sizeof(packed)); j->flow_on_device = by_flow && n_items; }
     auto DEV = [&](int k) -> const void * { return packed[k] ? packed[k] : j->dev[k].p; };
     OV_HIP(ctx, hipEventRecord(j->ev_h2d, ctx->stream));
     const double t_flush2 = host_now_us();

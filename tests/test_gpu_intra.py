@@ -174,6 +174,38 @@ def test_second_pass_after_an_abandoned_flow_launch(ctx, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_resident_replay_after_a_second_pass(ctx):
+    """A resident replay (OVHIP_STAGE_RESIDENT: no uploads, the device copies of the last full flush) of a job whose last full flush was
+    a SECOND pass: that flush uploaded no item list for the flow launch (per-level launches), so the replay must not take the flow
+    launch either.  (Round 5: bench.py's resident variant failed with "ovhip_intra_flow_launch: bad arguments" in one run of ten --
+    whenever a picture of the main run had fallen into a second pass.)"""
+    w, h = 832, 480
+    wl = synth.make_workload(w, h, 0x31, tools=synth.INTRA_TOOLS, intra_frac=0.3)
+    job = engine.Job(ctx, w, h)
+    refs = [ctx.upload_pic(*r) for r in wl.refs]
+    dst = ctx.new_pic(w, h)
+    job.load_workload(wl)
+    job.test_abort_next_flow()
+    job.flush(dst, refs, None); job.wait()
+    assert job.stats().n_ordered_retries == 1
+    ref = oracle_pipeline.decode(wl)
+    res = job.make_params(wl, stages=capi.STAGE_ALL | capi.STAGE_RESIDENT)
+    for _ in range(2):
+        dst2 = ctx.new_pic(w, h)
+        job.flush(dst2, refs, None, params=res); job.wait()
+        got = dst2.download()
+        for name, a, b in (("Y", got[0], ref.y), ("Cb", got[1], ref.cb), ("Cr", got[2], ref.cr)):
+            assert np.array_equal(a, b), f"resident replay after a second pass: plane {name}: {int((a != b).sum())} samples differ"
+    # a full flush brings the flow launch back, and a replay of THAT takes it too
+    job.begin(); job.load_workload(wl)
+    job.flush(dst, refs, None); job.wait()
+    assert job.stats().n_ordered_retries == 0
+    job.flush(dst, refs, None, params=res); job.wait()
+    assert job.stats().n_ordered_retries == 0 and np.array_equal(dst.download()[0], ref.y)
+    job.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("workers", [1, 3, 64, 100000])
 def test_flow_launch_with_few_workers(ctx, workers):
     """The ordered pass as W persistent workers (ovhip_job_params.flow_workers): worker b takes the items b, b + W, ... in level
