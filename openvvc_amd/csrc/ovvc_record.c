@@ -817,6 +817,11 @@ ovhip_rec_pu(ovhip_recorder *r, const ovhip_pu_desc *pu)
     int32_t x_min = -((pw + 3 + pu->x0) << 4),    y_min = -((ph + 3 + pu->y0) << 4);
     int32_t mv0x = clip3(pu->mv0x, x_min, x_max), mv0y = clip3(pu->mv0y, y_min, y_max);
     int32_t mv1x = clip3(pu->mv1x, x_min, x_max), mv1y = clip3(pu->mv1y, y_min, y_max);
+    /* the list a uni-predicted unit does not use: the caller's fields hold whatever was there (found with AddressSanitizer's malloc
+     * fill: the same parse recorded different bytes) -- nothing reads them, but what is uploaded is a function of the stream only */
+    uint8_t ref0 = pu->ref0, ref1 = pu->ref1;
+    if (!(dir & 1)) { mv0x = mv0y = 0; ref0 = 0; }
+    if (!(dir & 2)) { mv1x = mv1y = 0; ref1 = 0; }
 
     int8_t w0 = 4, w1 = 4;
     if (dir == 3 && pu->bcw_idx_plus1 != 0 && pu->bcw_idx_plus1 != 3) {
@@ -843,7 +848,7 @@ ovhip_rec_pu(ovhip_recorder *r, const ovhip_pu_desc *pu)
             u->x = (uint16_t)(pu->x0 + ux); u->y = (uint16_t)(pu->y0 + uy);
             u->w = (uint8_t)uw; u->h = (uint8_t)uh;
             u->dir = (uint8_t)dir; u->flags = flags;
-            u->ref0 = pu->ref0; u->ref1 = pu->ref1;
+            u->ref0 = ref0; u->ref1 = ref1;
             u->w0 = w0; u->w1 = w1;
             u->mv0x = mv0x; u->mv0y = mv0y; u->mv1x = mv1x; u->mv1y = mv1y;
             /* fused CIIP blend (rcn_ciip_weighted_sum): chroma of a CU 4 luma samples wide keeps the inter prediction */
