@@ -983,6 +983,30 @@ def live_decoder_rates(W, H, n_pics=33, threads=(1, 2, 4, 8, 16), reps=3):
                                          "frames and collocated motion planes compared with the UNPATCHED reference pass",
                                  "by_frame_threads": {str(d["frame_threads"]): summary(d) for d in c[0]}}
         out["bit_exact"] = out["bit_exact"] and c[1] == 0 and all(d["samples_differing"] == 0 and d["collocated_motion_entries_differing"] == 0 for d in c[0])
+    # the steady state: the figures above are one short stream (start-up and tail of 33 pictures on up to 16 threads); a random-access
+    # sequence with an intra period of 64 decoded continuously -- I + two GOPs of 32, four such sequences back to back (gen_pipe `cont`:
+    # the frame threads take the next intra period's pictures while the tail of the one before still decodes), 260 pictures
+    def steady(exe):
+        cmd = [str(exe), "/tmp", "live", "threads", "16,32", "size", str(W), str(H), "pics", "65", "gop", "32", "noisp", "seed", "31337", "cont", "4", "reps", "2"]
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        except (OSError, subprocess.TimeoutExpired):
+            return None
+        rows = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+        if len(rows) != 2 or p.returncode:
+            print(f"bench: live_decoder_rates: steady state: gen_pipe rc {p.returncode}: {p.stderr[-400:]}", file=sys.stderr)
+            return None
+        return {str(d["frame_threads"]): {"pictures_per_second": round(d["pictures_per_second"], 1), "pictures": d["pictures"],
+                                          "bit_exact": d["samples_differing"] == 0 and d["collocated_motion_entries_differing"] == 0 and d["shim_error"] == 0 and d["pictures_decoded"] == d["pictures"],
+                                          "share_of_a_frame_threads_time_waiting_for_collocated_rows": round(d["thread_seconds_waiting_for_collocated_rows"] / max(1e-9, d["thread_seconds_with_a_picture"]), 2)}
+                for d in rows}
+    ss = {"unpatched_caller": steady(GEN_PIPE), "patched_caller": steady(patched) if patched.exists() else None}
+    if ss["unpatched_caller"] or ss["patched_caller"]:
+        ss["what"] = ("a random-access sequence decoded continuously: I + two GOPs of 32 (65 pictures, seeded slice data, ISP off: nearly every such 4K "
+                      "stream holds a 64x2 ISP partition, whose result the reference itself leaves undefined), four of them back to back = 260 pictures "
+                      "with an I picture every 65, on 16 and 32 frame threads; every frame and collocated motion entry compared with the reference pass")
+        out["steady_state"] = ss
+        out["bit_exact"] = out["bit_exact"] and all(v["bit_exact"] for side in (ss["unpatched_caller"], ss["patched_caller"]) if side for v in side.values())
     if b is not None:
         out["output_none"] = {"what": "the same with OVHIP_OUT_NONE (pictures stay on the device; an application takes them through ovhip_shim_frame_output / _digest): "
                                       "collocated motion planes compared, frames not",

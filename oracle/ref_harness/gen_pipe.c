@@ -450,7 +450,7 @@ struct gp_out {
  * the log, and the decoded picture itself (frame + both collocated motion planes) as the thing to compare with. */
 struct gp_kept {
     uint8_t *payload;
-    OVPH ph; OVSH sh; OVNVCLCtx nvcl; OVPS ps;
+    OVPH ph; OVSH sh; OVNVCLCtx nvcl;
     size_t dm0, dm1;
     OVPicture *ref_pic;                            /* reference pass */
     OVPicture *pic;                                /* threaded pass */
@@ -615,6 +615,8 @@ struct gp_thread {
     pthread_t th; int id;
     struct gp_seq *s; const struct gp_pic_desc *desc; int n_pic;
     OVSliceDec sl; OVCTUDec *c;
+    OVPS ps;                                    /* the active parameter sets of the picture in hand (a kept picture may be decoded by
+                                                 * several threads at once: "cont") */
     double t_busy, t_hooks;                     /* seconds with a picture in hand / of them inside the row-end and attach hooks (device waits, flush) */
     double t_sync;                              /* ... waiting for CTU rows of the collocated picture (tmvp_inter_synchronization) */
     double t_shim_hooks, t_shim_device; uint64_t n_shim_calls;      /* the shim's own profile (ovhip_shim_get_profile), "profile" */
@@ -679,17 +681,17 @@ gp_decode_kept(struct gp_thread *t, int k)
 {
     struct gp_kept *kp = &g_kept[k];
     const struct gp_pic_desc *d = &t->desc[k];
-    memset(&kp->ps, 0, sizeof(kp->ps));
-    if (decinit_update_params(&kp->ps, &kp->nvcl) < 0) { fprintf(stderr, "gen_pipe: decinit_update_params failed\n"); exit(1); }
+    memset(&t->ps, 0, sizeof(t->ps));
+    if (decinit_update_params(&t->ps, &kp->nvcl) < 0) { fprintf(stderr, "gen_pipe: decinit_update_params failed\n"); exit(1); }
     const int n_entries = g_tile_cols * g_tile_rows;
     const size_t per_entry = (GP_PAYLOAD / n_entries) & ~(size_t)63;
-    for (int i = 0; i <= n_entries; ++i) kp->ps.sh_info.rbsp_entry[i] = kp->payload + i * per_entry;
-    t->sl.pic = kp->pic; t->sl.active_params = &kp->ps; t->sl.slice_type = d->slice_type;
-    slicedec_init_lines(&t->sl, &kp->ps);
+    for (int i = 0; i <= n_entries; ++i) t->ps.sh_info.rbsp_entry[i] = kp->payload + i * per_entry;
+    t->sl.pic = kp->pic; t->sl.active_params = &t->ps; t->sl.slice_type = d->slice_type;
+    slicedec_init_lines(&t->sl, &t->ps);
     g_dmvr_pos = kp->dm0;
     for (int i = 0; i < n_entries; ++i) {
         slicedec_update_entry_decoder(&t->sl, t->c);
-        slicedec_decode_rect_entry(&t->sl, t->c, &kp->ps, i);
+        slicedec_decode_rect_entry(&t->sl, t->c, &t->ps, i);
     }
     ovdpb_report_decoded_frame(kp->pic);
     if (g_pass_shim == 2 && g_dmvr_pos != kp->dm1) { fprintf(stderr, "gen_pipe: picture %d made %zu DMVR calls, the reference pass %zu\n", k, g_dmvr_pos - kp->dm0, kp->dm1 - kp->dm0); exit(1); }
@@ -710,6 +712,9 @@ gp_decode_kept(struct gp_thread *t, int k)
 static pthread_mutex_t g_take_mtx = PTHREAD_MUTEX_INITIALIZER;
 static OVFrame *g_frame_pool[GP_MAX_PIC]; static int g_n_frame_pool, g_frames_made, g_frames_recycled;
 static int g_no_release;                         /* "norelease": the decoder never tells the shim that a frame was dropped (ovhip_shim_frame_released is optional) */
+static int g_cont = 1;                           /* "cont C": the stream C times BACK TO BACK as one sequence of C x pics pictures (C coded video sequences: the frame threads
+                                                  * take the next copy's pictures while the tail of the one before still decodes -- the steady state a short stream's start-up and
+                                                  * tail hide; one reference pass serves every copy) */
 static int g_reps = 1, g_rep;                    /* "reps R": the stream R times on the same frame threads (contexts, jobs, recorders warm); the last one is timed */
 static pthread_barrier_t g_bar;
 
@@ -801,7 +806,7 @@ run_stream_threads(struct gp_seq *s, const struct gp_pic_desc *desc, int n_pic, 
             OVPicture *p = g_kept[k].pic = gp_new_picture(s, d->poc);
             for (int q = 0; q < 3; ++q) { const size_t wk = (size_t)(q ? s->w / 2 : s->w); free(p->frame->data[q] - wk * 16 * 2); }
             free(p->frame); p->frame = NULL;
-            p->cvs_id = (uint16_t)g_rep;
+            p->cvs_id = (uint16_t)(g_rep * g_cont + k / (n_pic / g_cont));
             atomic_init(&p->idx_function, 1);
             p->ovdpb_frame_synchro[1] = gp_synchro;
             OVPicture *l0[2] = { d->n0 > 0 ? g_kept[d->l0[0]].pic : NULL, d->n0 > 1 ? g_kept[d->l0[1]].pic : NULL };
@@ -869,12 +874,13 @@ gp_main(int argc, char **argv)
     int want_shim = 0, want_dev = 0, want_live = 0, want_time = 0, variant = 0, W = 416, H = 240, dqp = 0, n_pic = 5, gop_size = 0;
     uint32_t seed = 0x266 + 31337;
     const char *name = "pipe";
-    /* gen_pipe <dir> [shim | device | live | simd] [threads <n>[,<m>...]] [reps <n>] [gop <8|16|32>] [profile] [noout] [norelease] [name <fixture name>] [seed <n>] [variant <0|1>] [qp <delta on every picture's QP>]
+    /* gen_pipe <dir> [shim | device | live | simd] [threads <n>[,<m>...]] [reps <n>] [cont <copies back to back>] [gop <8|16|32>] [profile] [noout] [norelease] [name <fixture name>] [seed <n>] [variant <0|1>] [qp <delta on every picture's QP>]
      *          [size <w> <h>] [pics <1..257>] [time] */
     for (int i = 2; i < argc; ++i) {
         if (!strcmp(argv[i], "shim")) want_shim = 1;
         else if (!strcmp(argv[i], "device")) want_shim = want_dev = 1;
         else if (!strcmp(argv[i], "reps") && i + 1 < argc) g_reps = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "cont") && i + 1 < argc) g_cont = atoi(argv[++i]);
         else if (!strcmp(argv[i], "gop") && i + 1 < argc) gop_size = atoi(argv[++i]);
         else if (!strcmp(argv[i], "noisp")) g_no_isp = 1;
         else if (!strcmp(argv[i], "norelease")) g_no_release = 1;
@@ -987,20 +993,39 @@ gp_main(int argc, char **argv)
         if (want_live && g_profile) ovhip_shim_set_profile(1);
         if (want_live && g_noout) ovhip_shim_set_output(OVHIP_OUT_NONE);
         int bad = 0;
+        const int n_one = n_pic;
+        struct gp_pic_desc *gop_all = gop;
+        if (g_cont > 1) {
+            /* the kept pictures and their descriptions, C times: copy c's pictures reference copy c's pictures */
+            g_kept = realloc(g_kept, (size_t)n_one * g_cont * sizeof(*g_kept));
+            gop_all = calloc((size_t)n_one * g_cont, sizeof(*gop_all));
+            if (!g_kept || !gop_all) { fprintf(stderr, "gen_pipe: cont: out of memory\n"); return 1; }
+            for (int c = 0; c < g_cont; ++c)
+                for (int k = 0; k < n_one; ++k) {
+                    struct gp_kept *kp = &g_kept[c * n_one + k];
+                    if (c) *kp = g_kept[k];
+                    kp->nvcl.ph = &kp->ph; kp->nvcl.sh = &kp->sh;          /* (the array has moved) */
+                    struct gp_pic_desc d = gop[k];
+                    for (int q = 0; q < d.n0; ++q) d.l0[q] += c * n_one;
+                    for (int q = 0; q < d.n1; ++q) d.l1[q] += c * n_one;
+                    gop_all[c * n_one + k] = d;
+                }
+            n_pic = n_one * g_cont;
+        }
         for (int li = 0; li < g_n_thread_list; ++li) {
             g_threads = g_thread_list[li];
             fprintf(stderr, "gen_pipe: %s pass, %d frame thread%s\n", want_live ? "live" : "device (dry)", g_threads, g_threads > 1 ? "s" : "");
             struct gp_thread tot;
-            const double wall = run_stream_threads(&seq, gop, n_pic, g_threads, &tot);
+            const double wall = run_stream_threads(&seq, gop_all, n_pic, g_threads, &tot);
             printf("{\"mode\": \"%s\", \"frame_threads\": %d, \"pictures\": %d, \"width\": %d, \"height\": %d, \"seconds\": %.6f, \"pictures_per_second\": %.3f, "
                    "\"pictures_decoded\": %d, \"shim_error\": %d, \"frames_differing\": %d, \"samples_differing\": %llu, \"collocated_motion_entries_differing\": %llu, \"collocated_motion_entries_compared\": %llu, "
                    "\"dmvr_calls\": %zu, \"thread_seconds_with_a_picture\": %.6f, \"thread_seconds_in_row_end_and_attach_hooks\": %.6f, "
                    "\"reference_pass_seconds_inside_slicedec\": %.6f, \"reference_pass_seconds\": %.6f, \"repetitions\": %d, \"host_frames_made\": %d, \"host_frames_recycled\": %d, \"output\": \"%s\", "
-                   "\"thread_seconds_waiting_for_collocated_rows\": %.6f, \"shim_profile\": %d, \"thread_seconds_in_shim_hooks\": %.6f, \"thread_seconds_in_shim_device_half\": %.6f, \"shim_hook_calls\": %llu, \"shim_profile_overhead_seconds_per_call\": %.3e}\n",
+                   "\"thread_seconds_waiting_for_collocated_rows\": %.6f, \"shim_profile\": %d, \"thread_seconds_in_shim_hooks\": %.6f, \"thread_seconds_in_shim_device_half\": %.6f, \"shim_hook_calls\": %llu, \"shim_profile_overhead_seconds_per_call\": %.3e, \"copies_back_to_back\": %d}\n",
                    want_live ? "live" : "device_dry_threads", g_threads, n_pic, W, H, wall, n_pic / wall, tot.n_done, tot.err, tot.frames_differing,
                    (unsigned long long)tot.samples_differing, (unsigned long long)tot.mv_cells_differing, (unsigned long long)tot.mv_cells_compared, g_dmvr_log.n / 12, tot.t_busy, tot.t_hooks,
                    g_decode_seconds_pass[0], t_ref, g_reps, g_frames_made, g_frames_recycled, g_noout ? "none" : "planes into the OVFrame",
-                   tot.t_sync, g_profile, tot.t_shim_hooks, tot.t_shim_device, (unsigned long long)tot.n_shim_calls, g_prof_overhead);
+                   tot.t_sync, g_profile, tot.t_shim_hooks, tot.t_shim_device, (unsigned long long)tot.n_shim_calls, g_prof_overhead, g_cont);
             fflush(stdout);
             bad |= tot.err || tot.samples_differing || tot.mv_cells_differing || tot.n_done != n_pic;
         }

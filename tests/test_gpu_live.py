@@ -135,3 +135,14 @@ def test_live_decode_of_deep_hierarchies_with_recycled_frames(gop, threads, pics
     r = run(threads, "size", 832, 480, "pics", pics, "gop", gop, "reps", 3, "seed", 11)
     check(r, pics, threads)
     assert r["host_frames_recycled"] > pics          # (three repetitions over a pool much smaller than 3 x pics)
+
+
+@pytest.mark.parametrize("patched", (False, True))
+def test_live_decode_of_sequences_back_to_back(patched):
+    """`cont 4`: four coded video sequences (I + GOPs of 8 each) as ONE stream of 68 pictures -- the frame threads take the next sequence's
+    pictures while the tail of the one before still decodes (the steady state bench.py's config.live_decoder.steady_state measures); every
+    copy's frames and collocated motion planes are compared with the one reference pass"""
+    run = live_patched if patched else live
+    r = run(8, "size", 832, 480, "pics", 17, "cont", 4, "reps", 2)
+    check(r, 68, 8)
+    assert r["copies_back_to_back"] == 4

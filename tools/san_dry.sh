@@ -29,6 +29,7 @@ run() { ./gen_pipe $T "$@" > run.log 2>&1 || { echo "gen_pipe $* failed:"; tail 
         echo "gen_pipe $*: $n reports"; [ "$n" = 0 ] || grep -E -A6 "WARNING: ThreadSanitizer|ERROR: AddressSanitizer|runtime error" run.log | head -30; }
 total=0
 run device threads 8 pics 33 size 832 480 reps 2
+run device threads 8 pics 17 size 832 480 cont 4
 if [ $SAN != thread ]; then
   run device threads 4 pics 5 seed 5 size 264 392 tiles 2 2
   run device threads 16 pics 33 size 832 480 gop 32 reps 2 seed 11
