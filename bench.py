@@ -644,14 +644,17 @@ def main():
         if differ or differ_self:
             raise SystemExit(f"bench --check: {differ} pictures differ from the oracle, {differ_self} differ between in-flight counts")
 
+    # the legs beside the headline (the reference's stream on the device, the live decoder, the CPU baseline): at N = 1 only -- at N > 1
+    # the other ranks would sit idle behind rank 0 for minutes, and the figures would be the N = 1 run's again
+    one_gpu = world == 1 and L == 1
     ref_stream = None
-    if rank == 0 and not args.no_reference_stream and (W, H) == (3840, 2160):
+    if rank == 0 and one_gpu and not args.no_reference_stream and (W, H) == (3840, 2160):
         ref_stream = reference_stream_on_device(engine, capi, ctx0, W, H, 17, 8)
         if ref_stream and (ref_stream["samples_differing_from_the_reference"] or ref_stream["refined_vectors_differing"]):
             raise SystemExit(f"bench: the reference's stream decodes differently on the device: {ref_stream}")
 
     live = None
-    if rank == 0 and not args.no_reference_stream and not args.no_live_decoder and (W, H) == (3840, 2160):
+    if rank == 0 and one_gpu and not args.no_reference_stream and not args.no_live_decoder and (W, H) == (3840, 2160):
         live = live_decoder_rates(W, H)
         if live and not live["bit_exact"]:
             raise SystemExit(f"bench: the live decode differs from the reference pass: {live}")
@@ -722,7 +725,7 @@ def main():
         roofline["frame_frac_8d"] = round(roofline["frame_bytes_8d"] * fps / max(world, L) / 1e9 / HBM_PEAK_GBPS, 5)
 
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and one_gpu:
             os.sched_setaffinity(0, all_cpus)            # the CPU legs use every core of the host
             import oracle_pipeline
             wl0 = wls[0]
