@@ -1180,12 +1180,17 @@ __global__ __launch_bounds__(64) void k_intra_flow(ovhip_pic pic, ovhip_pic res,
             if ((t.flags & OVHIP_IF_ISP) && (t.y & 3)) {
                 // thin_row: the last row of the partition above (same coding unit, same 4x4 units as this block) arrives TAGGED -- every
                 // luma item stores its samples with FLOW_TAG -- and is polled itself, as fetch_refs_tagged polls a regular block's arms
+                //  EVERY row the earlier partitions wrote into this partition's unit row, not only the last one: the partition
+                // holding the unit's last row marks the unit "written" for the word readers (CCLM items, chroma-scale regions, ISP arms of
+                // other coding units), who then read all four rows -- so all of them must have been observed by the marker
                 const int cbw = 1 << t.isp_log2_cb_w;
-                const uint16_t *row = pic.y + (t.y - 1) * pic.stride_y + (t.x - t.isp_off_x);
+                const int ry0 = (int)t.y & ~3, nry = (int)t.y - ry0;          // 1 .. 3 rows
+                const uint16_t *row = pic.y + ry0 * pic.stride_y + (t.x - t.isp_off_x);
                 unsigned spins = 0;
                 bool ok = true;
                 for (;;) {
-                    const unsigned v = lane < cbw ? (unsigned)__hip_atomic_load(row + lane, RLX_AGENT) : FLOW_TAG;
+                    unsigned v = FLOW_TAG;
+                    for (int rr = 0; rr < nry; ++rr) v &= lane < cbw ? (unsigned)__hip_atomic_load(row + rr * pic.stride_y + lane, RLX_AGENT) : FLOW_TAG;
                     if (!__any(!(v & FLOW_TAG))) break;
                     const unsigned stop = __hip_atomic_load(sync, RLX_AGENT);
                     if (__any(++spins > SPIN_LIMIT || stop != 0)) { ok = false; break; }

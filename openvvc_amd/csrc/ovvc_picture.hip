@@ -64,6 +64,11 @@ struct ovhip_job {
 // the process; ovhip_job_stats.flow_shift reports it
 enum { FLOW_DEVS = 64, FLOW_DECAY = 512 };
 static int g_flow_shift[FLOW_DEVS], g_flow_clean[FLOW_DEVS];
+static inline int flow_shift_of(int device)          // clamped where it is read: a shift count is never negative, never above 4
+{
+    const int s = __atomic_load_n(&g_flow_shift[device & (FLOW_DEVS - 1)], __ATOMIC_RELAXED);
+    return s < 0 ? 0 : s > 4 ? 4 : s;
+}
 
 namespace {
 
@@ -287,6 +292,7 @@ int ovhip_job_wait(ovhip_job *j)
         j->test_abort_seen = 0;
         if (j->d_sync) (void)hipMemset(j->d_sync, 0, sizeof(uint32_t));
         if (j->d_flow) (void)hipMemset(j->d_flow, 0, sizeof(uint32_t));
+        j->flow_launched = 0;                //  an abandoned launch is not a clean one for the decay below
         if (j->again.valid && j->n_retries == 0) {
             j->n_retries = 1;
             ovhip_job_params pr = j->again.pr;
@@ -303,9 +309,12 @@ int ovhip_job_wait(ovhip_job *j)
     if (j->flow_launched) {
         const int fd = j->ctx->device & (FLOW_DEVS - 1);
         j->flow_launched = 0;
-        if (__atomic_load_n(&g_flow_shift[fd], __ATOMIC_RELAXED) > 0 && __atomic_add_fetch(&g_flow_clean[fd], 1, __ATOMIC_RELAXED) >= FLOW_DECAY) {
+        //  exactly ONE thread takes the step -- the one whose increment lands on FLOW_DECAY -- and the shift never goes
+        // below zero (two threads that both saw ">= FLOW_DECAY" used to subtract twice: 1 -> -1, a negative shift count)
+        if (__atomic_load_n(&g_flow_shift[fd], __ATOMIC_RELAXED) > 0 && __atomic_add_fetch(&g_flow_clean[fd], 1, __ATOMIC_RELAXED) == FLOW_DECAY) {
             __atomic_store_n(&g_flow_clean[fd], 0, __ATOMIC_RELAXED);
-            __atomic_fetch_sub(&g_flow_shift[fd], 1, __ATOMIC_RELAXED);
+            int cur = __atomic_load_n(&g_flow_shift[fd], __ATOMIC_RELAXED);
+            while (cur > 0 && !__atomic_compare_exchange_n(&g_flow_shift[fd], &cur, cur - 1, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
         }
     }
     return OVHIP_OK;
@@ -775,7 +784,7 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
             // widest-level rule below an I picture's launch holds ~256 workers, and B launches of 1536 were never abandoned in 4600
             // pictures (tools/sweep_bpic_workers.sh, interleaved, six runs each: 1024 workers 3220 pictures/s, 1536 3308, 2048 2-10
             // second passes per run); an abandoned launch still halves the default (g_flow_shift).
-            int n_workers = pr->flow_workers ? (int)pr->flow_workers : (WORKERS >= 0 ? (int)WORKERS : (6 * ctx->num_cus) >> __atomic_load_n(&g_flow_shift[ctx->device & (FLOW_DEVS - 1)], __ATOMIC_RELAXED));
+            int n_workers = pr->flow_workers ? (int)pr->flow_workers : (WORKERS >= 0 ? (int)WORKERS : (6 * ctx->num_cus) >> flow_shift_of(ctx->device));
             if (!pr->flow_workers && WORKERS < 0) {
                 // No more workers than the picture's widest level can use (round 4): a worker beyond that only ever holds an item that is
                 // levels ahead of the front -- and its wave slot, registers and LDS are then missing to the kernels of the pictures beside
@@ -796,7 +805,7 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
                                         j->abort_host, !flow_prepared, n_workers));
             j->st.n_launches += 1 + !flow_prepared;
             j->flow_launched = 1;
-            j->st.flow_shift = (uint32_t)__atomic_load_n(&g_flow_shift[ctx->device & (FLOW_DEVS - 1)], __ATOMIC_RELAXED);
+            j->st.flow_shift = (uint32_t)flow_shift_of(ctx->device);
         }
         for (uint32_t l = 0; by_level && !by_flow && l < n_lv; ++l) {
             const uint32_t a = lv_start[l], b = lv_start[l + 1];

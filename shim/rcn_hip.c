@@ -980,13 +980,15 @@ ovhip_shim_apply_tmvp_cells(OVCTUDec *c, const ovhip_tmvp_cell *cells, size_t n_
     const struct InterDRVCtx *ic = &c->drv_ctx.inter_ctx;
     const struct MVPlane *pl0 = ic->tmvp_ctx.plane0, *pl1 = ic->tmvp_ctx.plane1;
     if (!pl0 || !pl1 || !pl0->mvs || !pl1->mvs) return OVHIP_OK;         /* the picture keeps no motion field */
-    if (getenv("OVVC_HIP_TRACE_TMVP")) {
+#ifdef OVVC_HIP_DEBUG_TMVP          /* debug scaffolding: compiled out of the product (it used to getenv() in every row hook) */
+    {
         size_t nz = 0, nn = 0;
         for (size_t i = 0; i < n_entries; ++i) { nn += cells[i].cell != OVHIP_TMVP_NONE; nz += cells[i].cell != OVHIP_TMVP_NONE && !cells[i].mv0x && !cells[i].mv0y && !cells[i].mv1x && !cells[i].mv1y; }
         fprintf(stderr, "    tmvp patch ctudec %p: %zu entries, %zu used, %zu of them all-zero; first used:", (void *)c, n_entries, nn, nz);
         for (size_t i = 0, k = 0; i < n_entries && k < 3; ++i) if (cells[i].cell != OVHIP_TMVP_NONE) { fprintf(stderr, " [%u: %d %d %d %d]", cells[i].cell, cells[i].mv0x, cells[i].mv0y, cells[i].mv1x, cells[i].mv1y); ++k; }
         fprintf(stderr, "\n");
     }
+#endif
     for (size_t i = 0; i < n_entries; ++i) {
         const ovhip_tmvp_cell *q = &cells[i];
         if (q->cell == OVHIP_TMVP_NONE) continue;

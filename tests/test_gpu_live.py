@@ -28,7 +28,7 @@ GEN_PIPE = ROOT / "oracle" / "_ref" / "gen_pipe"
 
 def live(threads, *args, timeout=900):
     if not GEN_PIPE.exists():
-        pytest.skip("oracle/_ref/gen_pipe is built only where /root/reference exists")
+        pytest.fail("oracle/_ref/gen_pipe is missing: the prebuilt harness (make -C oracle, in the build container) must travel with the snapshot -- a GPU run without it would silently drop the live / full-size parity tests")
     cmd = [str(GEN_PIPE), "/tmp", "live", "threads", str(threads)] + [str(a) for a in args]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -101,7 +101,7 @@ GEN_PIPE_PATCHED = ROOT / "oracle" / "_ref" / "patched" / "gen_pipe"
 
 def live_patched(threads, *args, timeout=900):
     if not GEN_PIPE_PATCHED.exists():
-        pytest.skip("oracle/_ref/patched/gen_pipe is built only where /root/reference exists")
+        pytest.fail("oracle/_ref/patched/gen_pipe is missing: the prebuilt patched-caller harness (make -C oracle patched) must travel with the snapshot")
     cmd = [str(GEN_PIPE_PATCHED), "/tmp", "live", "threads", str(threads), "profile"] + [str(a) for a in args]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
