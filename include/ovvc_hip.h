@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define OVHIP_ABI_VERSION 7
+#define OVHIP_ABI_VERSION 8
 
 /* ---- error codes (negative, in the spirit of libovvc/overror.h:40-45) ---- */
 #define OVHIP_OK        0
@@ -943,6 +943,36 @@ int64_t ovhip_job_dmvr_rows(ovhip_job *job, const ovhip_pic *refs, uint32_t n_re
 int64_t ovhip_job_dmvr_rows_begin(ovhip_job *job, const ovhip_pic *refs, uint32_t n_refs, int32_t log2_ctu_s);
 int64_t ovhip_job_dmvr_rows_collect(ovhip_job *job);
 int  ovhip_job_last_stats(const ovhip_job *job, ovhip_job_stats *out);
+/* ---- Band-wise submission: the picture enters the device while it is still being parsed (slicedec.c:815-975 reconstructs a CTU row
+ * right after parsing it; dpb.c:1309-1323 reports it; a dependent picture runs a few rows behind, rcn_inter.c:131-146).
+ *
+ * ovhip_job_band() takes everything recorded since the previous call as one band of CTU rows ending at luma row `row_end` (a CTU-row
+ * boundary; the recorder's arrays are in decoding order, so a band is a slice of every array) and enqueues, without waiting:
+ *   the band's slices in ONE upload; its prediction, residuals and ordered pass; and, ONE BAND LATE, the filters: inverse luma mapping
+ *   and deblocking of the band before it (intra prediction of a band reads the unfiltered bottom row of the band above -- the
+ *   reference's saved lines, rcn_ctu.c:246-510), then the SAO and ALF rows that deblocking made final.  With `last` != 0 the call
+ *   completes the picture (row_end = the picture's height).
+ * upto: counts of the recorder's arrays that end the band (NULL: everything recorded so far -- the live decoder; a replay of a
+ * recorded picture passes the counts at each CTU-row boundary).  refs: every picture the band's units read must be final in the rows
+ * they reach -- the caller's business (ovhip_frame_band: the device DPB's row progress).  params: lmcs / log2_ctu_s / stages as for
+ * ovhip_job_flush (the same in every call of a picture); sao / alf_* must be valid for the CTU rows the call's filters cover: rows
+ * < row_end - 64 (SAO), < row_end - 128 (ALF) of the PREVIOUS band's end -- what the reference's row hooks have delivered by then
+ * (slicedec.c:934-956).  Pictures with stand-alone CIIP units are refused (OVHIP_EUNSUP): the shim never records them.
+ * ovhip_job_wait() waits for everything enqueued; a picture whose ordered pass gave up FAILS (no second pass: its bands may have been
+ * read).  ovhip_job_begin() starts the next picture as before.
+ * ovhip_job_band_progress(): the picture rows [0, rows_final) are final once `event` (a hipEvent_t behind the last filter launch
+ * enqueued so far; NULL: nothing yet) has completed and *abort_word (page-locked; the job's, for its lifetime) is still 0. */
+typedef struct ovhip_band_counts { uint32_t n_tb, n_coef, n_mc, n_mcx, n_aff, n_side, n_reg, n_itask, n_edge_v, n_edge_h; } ovhip_band_counts;
+void ovhip_rec_counts(const ovhip_recorder *rec, ovhip_band_counts *out);
+int  ovhip_job_band(ovhip_job *job, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs, const ovhip_job_params *params,
+                    const ovhip_band_counts *upto, int32_t row_end, int32_t last);
+int  ovhip_job_band_active(const ovhip_job *job);
+int  ovhip_job_band_progress(ovhip_job *job, int32_t *rows_final, void **event, const volatile uint32_t **abort_word);
+/* row windows of the two frame-wide filters (rows: multiples of 64, or the picture's height) */
+int  ovhip_sao_launch_rows(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *src, const ovhip_sao_ctu *d_params, int32_t log2_ctu_s,
+                           int32_t row0, int32_t row1);
+int  ovhip_alf_launch_rows(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *src, const ovhip_alf_pic *alf, int32_t row0, int32_t row1);
+
 /* Measurement: bracket ONE launch group of every following flush with a HIP-event pair on the launch stream (stage -1:
  * off) and read back the accumulated duration.  A pair costs a few microseconds of stream time, hence one at a time. */
 enum { OVHIP_TIME_MC = 0, OVHIP_TIME_MCXA, OVHIP_TIME_ITX_LUMA, OVHIP_TIME_LMCS_SCALE, OVHIP_TIME_ITX_CHROMA, OVHIP_TIME_DBF,

@@ -17,7 +17,7 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / os.environ.get("OVVC_HIP_LIB_NAME", "libovvc_hip.so")      # (the variable: A / B runs of kernel variants, tools/ only)
 
 # ---- constants (include/ovvc_hip.h) ----
-OVHIP_ABI_VERSION = 7
+OVHIP_ABI_VERSION = 8
 OVHIP_OK, OVHIP_ENODEV, OVHIP_ENOMEM, OVHIP_EINVAL, OVHIP_ELAUNCH, OVHIP_EUNSUP, OVHIP_EREF = 0, -1, -2, -3, -4, -5, -6
 DST_VII, DCT_VIII, DCT_II = 0, 1, 2
 TB_TR, TB_DC, TB_TS, TB_TS_RAW = 0, 1, 2, 3
@@ -210,6 +210,11 @@ DBF_PLANE_NAMES = ("luma_v", "luma_h", "cb_v", "cr_v", "cb_h", "cr_h")
 
 class DbfOffsets(C.Structure):
     _fields_ = [("beta", C.c_int8 * 8), ("tc", C.c_int8 * 8)]
+
+
+class BandCounts(C.Structure):
+    """ovhip_band_counts: lengths of the recorder's arrays where a band of CTU rows ends (ovhip_job_band)"""
+    _fields_ = [(n, C.c_uint32) for n in ("n_tb", "n_coef", "n_mc", "n_mcx", "n_aff", "n_side", "n_reg", "n_itask", "n_edge_v", "n_edge_h")]
 
 
 class JobParams(C.Structure):
@@ -477,6 +482,12 @@ def load(path: os.PathLike | None = None) -> C.CDLL:
         "ovhip_job_recorder": (vp, [vp]),
         "ovhip_job_begin": (C.c_int, [vp]),
         "ovhip_job_flush": (C.c_int, [vp, P(Pic), P(Pic), u32, P(Pic), P(JobParams)]),
+        "ovhip_job_band": (C.c_int, [vp, P(Pic), P(Pic), u32, P(JobParams), P(BandCounts), i32, i32]),
+        "ovhip_job_band_active": (C.c_int, [vp]),
+        "ovhip_job_band_progress": (C.c_int, [vp, P(i32), P(vp), P(vp)]),
+        "ovhip_rec_counts": (None, [vp, P(BandCounts)]),
+        "ovhip_sao_launch_rows": (C.c_int, [vp, P(Pic), P(Pic), vp, i32, i32, i32]),
+        "ovhip_alf_launch_rows": (C.c_int, [vp, P(Pic), P(Pic), P(AlfPic), i32, i32]),
         "ovhip_job_wait": (C.c_int, [vp]),
         "ovhip_job_refined_mvs": (vp, [vp, P(C.c_size_t)]),
         "ovhip_job_dmvr_rows": (C.c_int64, [vp, P(Pic), u32]),
@@ -582,6 +593,7 @@ EXPORTED_SYMBOLS = [
     "ovhip_rec_create_ex", "ovhip_rec_set_dense_dbf_planes", "ovhip_rec_dbf_edges", "ovhip_dbf_launch_edges_ex",
     "ovhip_dmvr_search_launch", "ovhip_rec_append_raw", "ovhip_rec_set_dbf_offsets", "ovhip_rec_tu_intra", "ovhip_rec_itasks", "ovhip_rec_itasks_sorted", "ovhip_itx_launch_classes_res", "ovhip_intra_level_launch", "ovhip_intra_level_geom", "ovhip_intra_sync_words", "ovhip_intra_ctu_launch", "ovhip_intra_flow_words", "ovhip_intra_flow_items", "ovhip_intra_flow_launch",
     "ovhip_rec_itask_levels", "ovhip_rec_isp_cu", "ovhip_isp_geometry", "ovhip_rec_itasks_by_ctu", "ovhip_rec_set_ctu_size", "ovhip_job_bind", "ovhip_job_create", "ovhip_job_destroy", "ovhip_job_recorder", "ovhip_job_begin",
+    "ovhip_job_band", "ovhip_job_band_active", "ovhip_job_band_progress", "ovhip_rec_counts", "ovhip_sao_launch_rows", "ovhip_alf_launch_rows",
     "ovhip_job_flush", "ovhip_job_wait", "ovhip_job_refined_mvs", "ovhip_job_dmvr_rows", "ovhip_job_dmvr_rows_begin", "ovhip_job_dmvr_rows_collect", "ovhip_job_last_stats", "ovhip_job_time_stage", "ovhip_job_stage_time",
     "ovhip_output_bytes", "ovhip_output_rows", "ovhip_output_pack_launch", "ovhip_output_row_md5_launch", "ovhip_output_bands", "ovhip_output_tree_md5_launch", "ovhip_pic_output", "ovhip_pic_digest",
     "ovhip_md5_init", "ovhip_md5_update", "ovhip_md5_final", "ovhip_tmvp_cells_launch", "ovhip_job_tmvp_cells", "ovhip_intra_flow_untag_launch", "ovhip_lmcs_inverse_untag_launch", "ovhip_lmcs_scale_prepare_launch",

@@ -498,7 +498,7 @@ __device__ __forceinline__ void alf_chroma_tile(const ovhip_pic &dst, const ovhi
 
 // Luma and both chroma planes in ONE launch (they only share their input): workgroups [0, nl) take luma tiles,
 // [nl, nl + 2 * nc) the Cb then Cr tiles.  One kernel boundary less, and the chroma tiles fill the luma tail.
-__global__ __launch_bounds__(256) OV_OCC_ALF void k_alf(ovhip_pic dst, ovhip_pic src, ovhip_alf_pic alf, int nb_ctu_w, int nl, int nc)
+__global__ __launch_bounds__(256) OV_OCC_ALF void k_alf(ovhip_pic dst, ovhip_pic src, ovhip_alf_pic alf, int nb_ctu_w, int nl, int nc, int t0_l, int t0_c)
 {
     __shared__ __attribute__((aligned(16))) uint16_t s_t[(LW > CW ? LW : CW) * LWS];
     __shared__ uint8_t s_cls[64];
@@ -507,26 +507,40 @@ __global__ __launch_bounds__(256) OV_OCC_ALF void k_alf(ovhip_pic dst, ovhip_pic
     // so the halo rows and columns neighbouring tiles share -- and the luma a chroma tile's CC-ALF taps read -- come out of ONE L2
     // (dealt round-robin, neighbouring tiles ran on different XCDs: every halo was fetched from memory once per XCD that needed it)
     const int b = blockIdx.x;
-    if (b < nl) alf_luma_tile(dst, src, alf, nb_ctu_w, (int)ov_xcd_slot_at(b, 0, nl), s_t, s_cls, s_sum);
+    // (t0_l / t0_c: first tile of the launch's row window in the luma / a chroma plane, ovhip_alf_launch_rows; 0 for a whole picture)
+    if (b < nl) alf_luma_tile(dst, src, alf, nb_ctu_w, t0_l + (int)ov_xcd_slot_at(b, 0, nl), s_t, s_cls, s_sum);
     else {
         const int comp = 1 + (b - nl) / nc;
-        alf_chroma_tile(dst, src, alf, nb_ctu_w, (int)ov_xcd_slot_at(b, nl + (comp - 1) * nc, nc), comp, s_t);
+        alf_chroma_tile(dst, src, alf, nb_ctu_w, t0_c + (int)ov_xcd_slot_at(b, nl + (comp - 1) * nc, nc), comp, s_t);
     }
 }
 
 } // namespace
 
-extern "C" int ovhip_alf_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *src, const ovhip_alf_pic *alf)
+// Rows [row0, row1) of the picture (luma rows; both multiples of 64 = one chroma tile row, or row1 = the picture's height): the
+// band-wise picture job (ovvc_picture.hip).  Reads src (the SAO output) rows row0 - 3 .. row1 + 2 -- luma taps and the 4x4
+// classification windows; the chroma tiles' CC-ALF taps reach luma row row1 -- and writes dst rows [row0, row1) only.
+extern "C" int ovhip_alf_launch_rows(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *src, const ovhip_alf_pic *alf, int32_t row0, int32_t row1)
 {
     if (!ctx || !dst || !src || !alf) return OVHIP_EINVAL;
     OV_DEVICE(ctx);
     if (dst->w != src->w || dst->h != src->h || dst->y == src->y || alf->log2_ctu_s < 6 || alf->log2_ctu_s > 7 ||
         !alf->ctus || !alf->luma_coeff || !alf->luma_clip || !alf->chroma_coeff || !alf->chroma_clip || !alf->cc_coeff)
         return ov_fail(ctx, OVHIP_EINVAL, "ovhip_alf_launch: bad pictures / parameter tables", hipSuccess);
+    if (row0 < 0 || row1 > src->h || row0 > row1 || (row0 & 63) || ((row1 & 63) && row1 != src->h))
+        return ov_fail(ctx, OVHIP_EINVAL, "ovhip_alf_launch_rows: row window", hipSuccess);
+    if (row0 == row1) return OVHIP_OK;
     const int nb_ctu_w = (src->w + (1 << alf->log2_ctu_s) - 1) >> alf->log2_ctu_s;
-    const int nl = ((src->w + TL - 1) / TL) * ((src->h + TL - 1) / TL);
-    const int nc = ((src->w / 2 + TL - 1) / TL) * ((src->h / 2 + TL - 1) / TL);
-    hipLaunchKernelGGL(k_alf, dim3(nl + 2 * nc), dim3(256), 0, ctx->stream, *dst, *src, *alf, nb_ctu_w, nl, nc);
+    const int ntx_l = (src->w + TL - 1) / TL, ntx_c = (src->w / 2 + TL - 1) / TL;
+    const int ty0_l = row0 / TL, ty1_l = (row1 + TL - 1) / TL, ty0_c = (row0 / 2) / TL, ty1_c = (row1 / 2 + TL - 1) / TL;
+    const int nl = ntx_l * (ty1_l - ty0_l), nc = ntx_c * (ty1_c - ty0_c);
+    hipLaunchKernelGGL(k_alf, dim3(nl + 2 * nc), dim3(256), 0, ctx->stream, *dst, *src, *alf, nb_ctu_w, nl, nc, ty0_l * ntx_l, ty0_c * ntx_c);
     OV_LAUNCH_CHECK(ctx, "k_alf");
     return OVHIP_OK;
+}
+
+extern "C" int ovhip_alf_launch(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *src, const ovhip_alf_pic *alf)
+{
+    if (!src) return OVHIP_EINVAL;
+    return ovhip_alf_launch_rows(ctx, dst, src, alf, 0, src->h);
 }

@@ -12,6 +12,7 @@
 extern "C" int ovhip_dmvr_search_launch(ovhip_ctx *ctx, const ovhip_pic *geom, const ovhip_pic *refs, uint32_t n_refs,
                                         const ovhip_mc_unit *d_units, uint32_t n_units, int32_t *d_mv_out);
 
+struct BandState;
 namespace {
 
 struct DevBuf { void *p; size_t cap; };
@@ -52,11 +53,17 @@ struct ovhip_job {
     const void *packed_prev[24];         // where the last full flush placed the arrays that rode in the parameter block
     int resident;                        // this flush reuses the device copies of the previous one (OVHIP_STAGE_RESIDENT)
     ovhip_job_stats st;
+    struct BandState *bs;                // band-wise submission (ovhip_job_band): allocated with the first band of the job's life
     // optional: HIP-event bracket around ONE launch group of the flush (ovhip_job_time_stage)
     int t_stage;                         // OVHIP_TIME_* or -1
     hipEvent_t t_ev[32][2]; uint8_t t_pending[32]; int t_next;
     double t_sum_ms; uint64_t t_count;
 };
+
+static void band_free(ovhip_job *j);
+static int  band_reset(ovhip_job *j);
+static int  band_active(const ovhip_job *j);
+static int  band_wait_done(ovhip_job *j);
 
 // workers of a flow launch = (6 x CUs) >> g_flow_shift[device]: grows with every launch of that device that was abandoned (co-resident
 // flow launches starving each other: another GPU_MAX_HW_QUEUES, another process on the GPU) and decays again -- one step per
@@ -235,6 +242,7 @@ void ovhip_job_destroy(ovhip_job *j)
     if (j->ev_h2d) (void)hipEventDestroy(j->ev_h2d);
     if (j->ev_done) (void)hipEventDestroy(j->ev_done);
     if (j->ev_rows) { if (j->rows_pending) (void)hipEventSynchronize(j->ev_rows); (void)hipEventDestroy(j->ev_rows); }
+    band_free(j);
     ovhip_rec_destroy(j->rec);
     free(j);
 }
@@ -248,6 +256,7 @@ int ovhip_job_begin(ovhip_job *j)
     // the DMA engines may still be reading the recorder's arrays and the parameter staging block
     if (j->flushed) OV_HIP(j->ctx, hipEventSynchronize(j->ev_h2d));
     if (j->rows_pending) { OV_HIP(j->ctx, hipEventSynchronize(j->ev_rows)); j->rows_pending = 0; }
+    { const int rb = band_reset(j); if (rb != OVHIP_OK) return rb; }
     ovhip_rec_reset(j->rec);
     j->dmvr_first = 0; j->n_mv = 0; j->n_tmvp = 0; j->rows_end = 0;
     return OVHIP_OK;
@@ -278,6 +287,7 @@ int ovhip_job_wait(ovhip_job *j)
     if (!j->flushed) return OVHIP_OK;
     hipError_t e = hipEventSynchronize(j->ev_done);
     if (e != hipSuccess) return ov_fail(j->ctx, OVHIP_ELAUNCH, "hipEventSynchronize(job)", e);
+    if (band_active(j)) return band_wait_done(j);
     if (j->abort_host && *(volatile uint32_t *)j->abort_host) {
         // a workgroup of the ordered pass gave up waiting for its inputs (workgroups of several pictures' flow launches can
         // fill the compute units with pollers whose producers then find no slot): the picture is incomplete.  Re-arm, and decode
@@ -856,3 +866,499 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
 }
 
 } // extern "C"
+
+// =====================================================================================================================================
+// Band-wise submission: a picture enters the device while it is still being parsed.
+//
+// The reference reconstructs a CTU row right after parsing it and reports it (slicedec.c:815-975, dpb.c:1309-1323); a picture that
+// references it runs a few rows behind (rcn_inter.c:131-146).  ovhip_job_flush takes a picture when its parse has ENDED, so every level
+// of a GOP's reference hierarchy cost a whole parse plus a whole launch chain.  Here the recorder's arrays are cut at CTU-row bands:
+//
+//     ovhip_job_band(k)   = upload of band k's slices (ONE copy out of a staging block) + recon(k) + tail(k - 1) [+ tail(k) if last]
+//     recon(k)            = MC -> refined / affine MC -> luma residual -> chroma-scale regions -> chroma residual -> ordered pass,
+//                           the picture-wide launches over the band's slice of every list
+//     tail(k)             = inverse luma mapping of the band's rows (+ un-tag) -> deblocking of the band's edge lists (V then H)
+//                           -> SAO rows [.., s1) -> ALF rows [.., a1)
+//
+// tail(k) runs behind recon(k + 1): intra prediction of band k + 1 reads the UNFILTERED, still mapped bottom row of band k (the
+// reference keeps saved lines for this, rcn_ctu.c:246-510).  The horizontal edge on the boundary between k and k + 1 belongs to band
+// k + 1's lists and changes up to 7 rows above it, so after tail(k) the rows < end_k - 8 are final for the deblocking; SAO then runs up
+// to the last multiple of 64 rows below that (its edge classes read one row further), ALF up to the last multiple of 64 that keeps its
+// 3-row reach and the classification windows inside the SAO output: s1 = end_k - 64, a1 = end_k - 128 for CTU-row bands.  Every launch
+// reads exactly the samples the picture-wide launch reads, so the fixtures' parity carries over (tests/test_gpu_bands.py: bands of one
+// CTU row, of two, and one band = the whole picture give identical pictures).
+//
+// Indices inside the commands (coefficient / side-arena offsets, region numbers) stay what the recorder wrote: the band's slice is
+// addressed through a pointer moved back by the slice's first index.  The flow launches of the bands never wait for an item of another
+// launch (stream order), and the workers of all band launches in flight are accounted against the device's wave slots (flow budget
+// below), so that every launch's workers can be resident: the bounded waits cannot expire by starvation.  If one does anyway the
+// picture FAILS (the rows already published to readers cannot be taken back); ovhip_job_wait reports it.
+// =====================================================================================================================================
+extern "C" void ovhip_rec_tb_split_range_(const ovhip_recorder *r, size_t first, size_t n, ovhip_tb_cmd *out, size_t counts[4], size_t tiny[4][4]);
+extern "C" int  ovhip_rec_itasks_sorted_range_(const ovhip_recorder *r, size_t first, size_t n, ovhip_itask *out, uint32_t *level_start, size_t cap, uint32_t *n_levels);
+extern "C" int  ovhip_sao_launch_rows(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *src, const ovhip_sao_ctu *d_params, int32_t log2_ctu_s, int32_t row0, int32_t row1);
+extern "C" int  ovhip_alf_launch_rows(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *src, const ovhip_alf_pic *alf, int32_t row0, int32_t row1);
+
+enum { MAX_BANDS = 96, ARENA_CHUNKS = 16, BAND_LEVELS = 4096 };
+struct ArenaChunk { char *host, *dev; size_t cap, used; };
+struct BandRec {
+    int32_t row0, row1;
+    ovhip_band_counts c0, c1;
+    const ovhip_itask *d_it; uint32_t n_it; int tagged;          // the band's ordered tasks on the device; tagged: a flow launch wrote them
+    const ovhip_dbf_edge *d_ev, *d_eh; uint32_t n_ev, n_eh;
+    int flow_charge;                                             // workers charged to the device's flow budget until ev_recon is seen
+    int32_t rows_final;                                          // picture rows final once this band's tail has run
+};
+struct BandState {
+    int active, n, tails, closed, failed;
+    ovhip_pic dst;
+    ovhip_band_counts cur;
+    int32_t row_prev, dbf_rows, sao_rows, alf_rows, rows_final;
+    int log2_ctu, sao_on, alf_on, filters_latched;
+    uint32_t stages;
+    const uint16_t *d_fwd, *d_bwd; int lmcs_up;                   // LMCS tables: in the first band's block
+    ovhip_alf_pic d_alf; int alf_up;                              // ALF picture-level tables: in the block of the first call that has them
+    ovhip_lmcs_luts luts; int have_luts;
+    ovhip_dbf_offsets offs;
+    ArenaChunk chunk[ARENA_CHUNKS]; int n_chunks, cur_chunk;
+    BandRec band[MAX_BANDS];
+    hipEvent_t ev_recon[MAX_BANDS], ev_tail[MAX_BANDS];
+    uint32_t level_start[BAND_LEVELS + 2];
+    void *last_event; int32_t last_rows;                          // what ovhip_job_band_progress hands out
+};
+
+// ---- flow budget: the workers of the band flow launches in flight on a device never exceed the wave slots k_intra_flow can hold
+// there (16 one-wave workgroups per compute unit, three quarters of them: the whole-picture launches of I pictures run beside).  A
+// launch is charged when it is enqueued and released when its job sees the event behind it -- so every charged launch's workers can
+// be resident together and no worker waits for a workgroup that cannot start.
+static int g_band_flow_inflight[FLOW_DEVS];
+static int band_flow_take(ovhip_ctx *ctx, int want)
+{
+    const int fd = ctx->device & (FLOW_DEVS - 1), cap = 12 * ctx->num_cus;
+    int cur = __atomic_load_n(&g_band_flow_inflight[fd], __ATOMIC_RELAXED);
+    for (;;) {
+        int give = cap - cur < want ? cap - cur : want;
+        give &= ~63;
+        if (give < 64) return 0;
+        if (__atomic_compare_exchange_n(&g_band_flow_inflight[fd], &cur, cur + give, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) return give;
+    }
+}
+static void band_flow_give(ovhip_ctx *ctx, int n) { if (n) __atomic_fetch_sub(&g_band_flow_inflight[ctx->device & (FLOW_DEVS - 1)], n, __ATOMIC_RELAXED); }
+
+// the charges of bands whose reconstruction has completed go back (in order: a later band's launches are behind the earlier ones')
+static void band_flow_reclaim(ovhip_job *j, int wait)
+{
+    BandState *bs = j->bs;
+    for (int b = 0; bs && b < bs->n; ++b) {
+        BandRec &B = bs->band[b];
+        if (!B.flow_charge) continue;
+        if (wait) (void)hipEventSynchronize(bs->ev_recon[b]);
+        else if (hipEventQuery(bs->ev_recon[b]) != hipSuccess) { (void)hipGetLastError(); break; }
+        band_flow_give(j->ctx, B.flow_charge);
+        B.flow_charge = 0;
+    }
+}
+
+static int band_active(const ovhip_job *j) { return j->bs && j->bs->active; }
+
+static void band_free(ovhip_job *j)
+{
+    BandState *bs = j->bs;
+    if (!bs) return;
+    band_flow_reclaim(j, 1);
+    for (int i = 0; i < bs->n_chunks; ++i) { pinned_free(nullptr, bs->chunk[i].host); if (bs->chunk[i].dev) (void)hipFree(bs->chunk[i].dev); }
+    for (int i = 0; i < MAX_BANDS; ++i) { if (bs->ev_recon[i]) (void)hipEventDestroy(bs->ev_recon[i]); if (bs->ev_tail[i]) (void)hipEventDestroy(bs->ev_tail[i]); }
+    free(bs);
+    j->bs = nullptr;
+}
+
+// ovhip_job_begin: the previous picture's uploads have ended (ev_h2d); the arena starts over -- as ONE chunk if the last picture needed several
+static int band_reset(ovhip_job *j)
+{
+    BandState *bs = j->bs;
+    if (!bs) return OVHIP_OK;
+    band_flow_reclaim(j, 1);
+    if (bs->n_chunks > 1) {
+        size_t total = 0;
+        if (j->flushed) OV_HIP(j->ctx, hipEventSynchronize(j->ev_done));        // the launches read the device halves
+        for (int i = 0; i < bs->n_chunks; ++i) { total += bs->chunk[i].cap; pinned_free(nullptr, bs->chunk[i].host); if (bs->chunk[i].dev) (void)hipFree(bs->chunk[i].dev); }
+        memset(bs->chunk, 0, sizeof(bs->chunk));
+        bs->n_chunks = 0;
+        total += total / 4;
+        bs->chunk[0].host = (char *)pinned_alloc(nullptr, total);
+        if (!bs->chunk[0].host) return ov_fail(j->ctx, OVHIP_ENOMEM, "band arena (pinned)", hipSuccess);
+        if (hipMalloc((void **)&bs->chunk[0].dev, total) != hipSuccess) { pinned_free(nullptr, bs->chunk[0].host); bs->chunk[0].host = nullptr; return ov_fail(j->ctx, OVHIP_ENOMEM, "band arena (device)", hipSuccess); }
+        bs->chunk[0].cap = total; bs->n_chunks = 1;
+    }
+    for (int i = 0; i < bs->n_chunks; ++i) bs->chunk[i].used = 0;
+    bs->cur_chunk = 0;
+    bs->active = 0; bs->n = 0; bs->tails = 0; bs->closed = 0; bs->failed = 0;
+    return OVHIP_OK;
+}
+
+// a block of `bytes` in the arena: the same offset in a page-locked host chunk and in its device twin (one copy moves it)
+static int arena_take(ovhip_job *j, size_t bytes, char **host, char **dev)
+{
+    BandState *bs = j->bs;
+    bytes = (bytes + 255) & ~(size_t)255;
+    for (;;) {
+        if (bs->cur_chunk < bs->n_chunks) {
+            ArenaChunk &c = bs->chunk[bs->cur_chunk];
+            if (c.cap - c.used >= bytes) { *host = c.host + c.used; *dev = c.dev + c.used; c.used += bytes; return OVHIP_OK; }
+            bs->cur_chunk++;
+            continue;
+        }
+        if (bs->n_chunks == ARENA_CHUNKS) return ov_fail(j->ctx, OVHIP_ENOMEM, "band arena: too many chunks", hipSuccess);
+        // first chunk: ~ a 4K B picture's arrays (they sum to 9 MB); later ones double
+        size_t cap = bs->n_chunks ? 2 * bs->chunk[bs->n_chunks - 1].cap : ((size_t)j->w * j->h * 3 / 2 < ((size_t)4 << 20) ? (size_t)4 << 20 : (size_t)j->w * j->h * 3 / 2);
+        while (cap < bytes) cap *= 2;
+        ArenaChunk &c = bs->chunk[bs->n_chunks];
+        c.host = (char *)pinned_alloc(nullptr, cap);
+        if (!c.host) return ov_fail(j->ctx, OVHIP_ENOMEM, "band arena (pinned)", hipSuccess);
+        if (hipMalloc((void **)&c.dev, cap) != hipSuccess) { pinned_free(nullptr, c.host); c.host = nullptr; return ov_fail(j->ctx, OVHIP_ENOMEM, "band arena (device)", hipSuccess); }
+        c.cap = cap; c.used = 0;
+        bs->n_chunks++;
+    }
+}
+
+static int band_wait_done(ovhip_job *j)
+{
+    BandState *bs = j->bs;
+    band_flow_reclaim(j, 1);
+    if (j->abort_host && *(volatile uint32_t *)j->abort_host) {
+        *(volatile uint32_t *)j->abort_host = 0;
+        if (j->d_flow) (void)hipMemset(j->d_flow, 0, sizeof(uint32_t));
+        bs->failed = 1;
+        return ov_fail(j->ctx, OVHIP_ELAUNCH, "band-wise picture: a bounded wait of the ordered pass expired (picture incomplete; its bands may have been read)", hipSuccess);
+    }
+    return bs->failed ? ov_fail(j->ctx, OVHIP_ELAUNCH, "band-wise picture failed", hipSuccess) : OVHIP_OK;
+}
+
+static inline int32_t floor64(int32_t v) { return v <= 0 ? 0 : v & ~63; }
+
+extern "C" int ovhip_job_band_active(const ovhip_job *j) { return j && band_active(j); }
+
+extern "C" int ovhip_job_band_progress(ovhip_job *j, int32_t *rows_final, void **event, const volatile uint32_t **abort_word)
+{
+    if (!j || !rows_final) return OVHIP_EINVAL;
+    *rows_final = 0;
+    if (event) *event = nullptr;
+    if (abort_word) *abort_word = j->abort_host;
+    if (!band_active(j)) return OVHIP_OK;
+    *rows_final = j->bs->last_rows;
+    if (event) *event = j->bs->last_event;
+    return OVHIP_OK;
+}
+
+extern "C" int ovhip_job_band(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs, const ovhip_job_params *pr,
+                   const ovhip_band_counts *upto, int32_t row_end, int32_t last)
+{
+    if (!j || !dst || !pr) return OVHIP_EINVAL;
+    ovhip_ctx *ctx = j->ctx;
+    OV_DEVICE(ctx);
+    if (dst->w != j->w || dst->h != j->h) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_job_band: picture size differs from the job's", hipSuccess);
+    if (dst->stride_y != j->tmp.stride_y || dst->stride_c != j->tmp.stride_c)
+        return ov_fail(ctx, OVHIP_EUNSUP, "ovhip_job_band: tight planes only (stride = width)", hipSuccess);
+    if (!j->bs) {
+        j->bs = (BandState *)calloc(1, sizeof(BandState));
+        if (!j->bs) return OVHIP_ENOMEM;
+    }
+    BandState *bs = j->bs;
+    ovhip_recorder *rec = j->rec;
+    const int log2_ctu = pr->log2_ctu_s ? pr->log2_ctu_s : 7;
+    if (log2_ctu < 5 || log2_ctu > 7) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_job_band: log2_ctu_s", hipSuccess);
+    if (bs->closed) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_job_band: the picture's last band was already submitted", hipSuccess);
+    if (last) row_end = j->h;
+    if (row_end > j->h) row_end = j->h;
+    const int first_band = !bs->active;
+    if (first_band) {
+        // an eager DMVR pass nobody collected must not be in flight over a re-allocation (as ovhip_job_flush)
+        memset(&j->st, 0, sizeof(j->st));
+        bs->active = 1; bs->n = 0; bs->tails = 0; bs->closed = 0; bs->failed = 0;
+        bs->dst = *dst; bs->row_prev = 0; bs->dbf_rows = bs->sao_rows = bs->alf_rows = bs->rows_final = 0;
+        memset(&bs->cur, 0, sizeof(bs->cur));
+        bs->log2_ctu = log2_ctu; bs->filters_latched = 0; bs->lmcs_up = 0; bs->alf_up = 0; bs->have_luts = 0;
+        bs->stages = pr->stages ? pr->stages : 0xffffffffu;
+        bs->last_event = nullptr; bs->last_rows = 0;
+        j->again.valid = 0; j->n_retries = 0; j->n_mv = 0; j->n_tmvp = 0;
+        if (!j->res.y) CHK(ovhip_pic_alloc(ctx, j->w, j->h, &j->res));
+        if (!j->d_flow) {
+            const size_t words = ovhip_intra_flow_words(j->w, j->h);
+            OV_HIP(ctx, hipMalloc((void **)&j->d_flow, words * sizeof(uint32_t)));
+            OV_HIP(ctx, hipMemsetAsync(j->d_flow, 0, words * sizeof(uint32_t), ctx->stream));
+        }
+        if (!j->abort_host) {
+            j->abort_host = (uint32_t *)pinned_alloc(nullptr, 64);
+            if (!j->abort_host) return ov_fail(ctx, OVHIP_ENOMEM, "ovhip_job_band: pinned abort word", hipSuccess);
+            *j->abort_host = 0;
+        }
+        if (++j->epoch >= 0x7ffffff0u) j->epoch = 1;
+        CHK(dev_reserve(j, B_SCALE, 65536));                               // 32767 regions at most (ovhip_rec_lmcs_region)
+        CHK(dev_reserve(j, B_CLASS, (size_t)((j->w + 3) / 4) * ((j->h + 3) / 4)));
+    }
+    if (!(dst->y == bs->dst.y) || log2_ctu != bs->log2_ctu) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_job_band: another picture than the first band's", hipSuccess);
+    if (row_end < bs->row_prev || (!last && (row_end & ((1 << log2_ctu) - 1)) && row_end != j->h))
+        return ov_fail(ctx, OVHIP_EINVAL, "ovhip_job_band: row_end must be a CTU-row boundary not above the previous band's", hipSuccess);
+    if (bs->n >= MAX_BANDS) return ov_fail(ctx, OVHIP_EUNSUP, "ovhip_job_band: too many bands", hipSuccess);
+    const uint32_t stages = bs->stages;
+    band_flow_reclaim(j, 0);
+
+    // ---- the band's slices ----
+    ovhip_band_counts c1;
+    ovhip_rec_counts(rec, &c1);
+    if (upto) {
+        const uint32_t *u = &upto->n_tb, *m = &c1.n_tb, *lo = &bs->cur.n_tb;
+        for (int i = 0; i < 10; ++i) if (u[i] > m[i] || u[i] < lo[i]) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_job_band: counts outside the recorded arrays", hipSuccess);
+        c1 = *upto;
+    }
+    const ovhip_band_counts c0 = bs->cur;
+    const int b = bs->n;
+    BandRec &B = bs->band[b];
+    memset(&B, 0, sizeof(B));
+    B.row0 = bs->row_prev; B.row1 = row_end; B.c0 = c0; B.c1 = c1;
+    size_t dummy = 0;
+    if (ovhip_rec_ciip_units(rec, &dummy) && dummy) return ov_fail(ctx, OVHIP_EUNSUP, "ovhip_job_band: stand-alone CIIP blend units (a second picture with the caller's intra prediction)", hipSuccess);
+    const size_t n_tb = c1.n_tb - c0.n_tb, n_coef = c1.n_coef - c0.n_coef, n_mc = c1.n_mc - c0.n_mc, n_mcx = c1.n_mcx - c0.n_mcx,
+                 n_aff = c1.n_aff - c0.n_aff, n_side = c1.n_side - c0.n_side, n_reg = c1.n_reg - c0.n_reg, n_it_all = c1.n_itask - c0.n_itask,
+                 n_ev = (stages & OVHIP_STAGE_DBF) ? c1.n_edge_v - c0.n_edge_v : 0, n_eh = (stages & OVHIP_STAGE_DBF) ? c1.n_edge_h - c0.n_edge_h : 0;
+    const size_t n_it = (stages & OVHIP_STAGE_INTRA) ? n_it_all : 0;
+    const ovhip_itask *it_all = ovhip_rec_itasks(rec, &dummy);
+    // flow items of the band: counted first (the count does not depend on the order), built after the sort
+    size_t n_items = 0; int by_flow = n_it != 0 && !(pr->stages && (stages & OVHIP_STAGE_INTRA_LEVELS));
+    for (size_t i = 0; i < n_it && by_flow; ++i) {
+        const ovhip_itask &t = it_all[c0.n_itask + i];
+        if (t.kind == OVHIP_IT_REGION) { ++n_items; continue; }
+        const int npx = 1 << (t.log2_w + t.log2_h), strips = (npx + 255) / 256;          // (FSTRIP = 256, kernels_intra.hip)
+        if (strips > 32) by_flow = 0;
+        n_items += (size_t)strips * (t.kind == OVHIP_IT_LUMA ? 1 : 2);
+    }
+    if (!by_flow) n_items = 0;
+
+    // ---- which tails this call runs, and the filter rows they make final ----
+    const int t_first = bs->tails, t_end = last ? b + 1 : b;          // tails [t_first, t_end)
+    if (t_end > t_first && !bs->filters_latched) {
+        bs->sao_on = pr->sao && (stages & OVHIP_STAGE_SAO); bs->alf_on = pr->alf_ctus && (stages & OVHIP_STAGE_ALF);
+        bs->filters_latched = 1;
+    }
+    if (bs->filters_latched && (bs->sao_on != (pr->sao && (stages & OVHIP_STAGE_SAO)) || bs->alf_on != (pr->alf_ctus && (stages & OVHIP_STAGE_ALF))))
+        return ov_fail(ctx, OVHIP_EINVAL, "ovhip_job_band: SAO / ALF switched on or off inside a picture", hipSuccess);
+    const int sao_on = bs->filters_latched && bs->sao_on, alf_on = bs->filters_latched && bs->alf_on;
+    if (alf_on && (!pr->alf_luma_coeff || !pr->alf_luma_clip || !pr->alf_chroma_coeff || !pr->alf_chroma_clip || !pr->alf_cc_coeff))
+        return ov_fail(ctx, OVHIP_EINVAL, "ovhip_job_band: ALF tables missing", hipSuccess);
+    int32_t dbf_new = bs->dbf_rows, sao_new = bs->sao_rows, alf_new = bs->alf_rows;
+    if (t_end > t_first) {
+        const int32_t E = t_end - 1 == b ? row_end : bs->band[t_end - 1].row1;
+        const bool fin = last != 0;
+        dbf_new = fin ? j->h : ((stages & OVHIP_STAGE_DBF) ? (E - 8 > dbf_new ? E - 8 : dbf_new) : E);
+        // the second stage (SAO, or the copy that stands in for it) reads one row below its window; the third (ALF, or the copy back)
+        // three rows below its own -- and the second stage's next window re-reads the row above it, which the third must leave alone
+        sao_new = fin ? j->h : (floor64(dbf_new - 1) > sao_new ? floor64(dbf_new - 1) : sao_new);
+        alf_new = fin ? j->h : (floor64(sao_new - 3) > alf_new ? floor64(sao_new - 3) : alf_new);
+    }
+    const int nb_ctu_w = (j->w + (1 << log2_ctu) - 1) >> log2_ctu;
+    const int sao_r0 = bs->sao_rows >> log2_ctu, sao_r1 = sao_new > bs->sao_rows ? ((sao_new - 1) >> log2_ctu) + 1 : sao_r0;
+    const int alf_r0 = bs->alf_rows >> log2_ctu, alf_r1 = alf_new > bs->alf_rows ? ((alf_new - 1) >> log2_ctu) + 1 : alf_r0;
+    const size_t n_sao = sao_on ? (size_t)(sao_r1 - sao_r0) * nb_ctu_w : 0, n_alf = alf_on ? (size_t)(alf_r1 - alf_r0) * nb_ctu_w : 0;
+
+    // ---- one staging block: layout ----
+    size_t o = 0;
+    auto put = [&o](size_t bytes) { size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
+    const bool lmcs_now = pr->lmcs && !bs->lmcs_up, alf_now = alf_on && !bs->alf_up;
+    const size_t o_fwd = put(lmcs_now ? 2048 : 0), o_bwd = put(lmcs_now ? 2048 : 0);
+    const size_t o_lco = put(alf_now ? 24 * OVHIP_ALF_LUMA_SET_SIZE * 2 : 0), o_lcl = put(alf_now ? 24 * OVHIP_ALF_LUMA_SET_SIZE * 2 : 0),
+                 o_cco = put(alf_now ? 8 * 7 * 2 : 0), o_ccl = put(alf_now ? 8 * 7 * 2 : 0), o_cc = put(alf_now ? 2 * 4 * 8 * 2 : 0);
+    const size_t o_tb = put(n_tb * sizeof(ovhip_tb_cmd)), o_coef = put(n_coef * 2), o_mc = put(n_mc * sizeof(ovhip_mc_unit)),
+                 o_mcx = put(n_mcx * sizeof(ovhip_mc_unit)), o_aff = put(n_aff * sizeof(ovhip_aff_unit)), o_side = put(n_side * 4),
+                 o_reg = put(n_reg * sizeof(ovhip_lmcs_region)), o_it = put(n_it * sizeof(ovhip_itask)), o_items = put(n_items * 4),
+                 o_ev = put(n_ev * sizeof(ovhip_dbf_edge)), o_eh = put(n_eh * sizeof(ovhip_dbf_edge)),
+                 o_sao = put(n_sao * sizeof(ovhip_sao_ctu)), o_alf = put(n_alf * sizeof(ovhip_alf_ctu));
+    const size_t upload_bytes = o;
+    const size_t o_mv = put(n_mcx * 16);                                // device only: the refined vectors k_mcxa leaves (nobody reads them here)
+    char *hb = nullptr, *db = nullptr;
+    if (o) CHK(arena_take(j, o, &hb, &db));
+
+    // ---- fill it ----
+    size_t cls[4] = { 0, 0, 0, 0 }, tiny[4][4] = { { 0 } };
+    if (n_tb) ovhip_rec_tb_split_range_(rec, c0.n_tb, n_tb, (ovhip_tb_cmd *)(hb + o_tb), cls, tiny);
+    uint32_t n_lv = 0; int have_levels = 0;
+    if (n_it) have_levels = ovhip_rec_itasks_sorted_range_(rec, c0.n_itask, n_it, (ovhip_itask *)(hb + o_it), bs->level_start, BAND_LEVELS + 2, &n_lv) == 0;
+    if (n_it && !have_levels && !by_flow) return ov_fail(ctx, OVHIP_EUNSUP, "ovhip_job_band: a band with more levels than the table holds and blocks the flow launch cannot take", hipSuccess);
+    if (n_items) {
+        const size_t k = ovhip_intra_flow_items((const ovhip_itask *)(hb + o_it), n_it, (uint32_t *)(hb + o_items), n_items);
+        if (k != n_items) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_job_band: flow item count", hipSuccess);
+    }
+    {
+        size_t n;
+        if (n_coef) memcpy(hb + o_coef, ovhip_rec_coefs(rec, &n) + c0.n_coef, n_coef * 2);
+        if (n_mc) memcpy(hb + o_mc, ovhip_rec_mc_units(rec, &n) + c0.n_mc, n_mc * sizeof(ovhip_mc_unit));
+        if (n_mcx) memcpy(hb + o_mcx, ovhip_rec_mcx_units(rec, &n) + c0.n_mcx, n_mcx * sizeof(ovhip_mc_unit));
+        if (n_aff) memcpy(hb + o_aff, ovhip_rec_aff_units(rec, &n) + c0.n_aff, n_aff * sizeof(ovhip_aff_unit));
+        if (n_side) memcpy(hb + o_side, ovhip_rec_aff_side(rec, &n) + c0.n_side, n_side * 4);
+        if (n_reg) memcpy(hb + o_reg, ovhip_rec_lmcs_regions(rec, &n) + c0.n_reg, n_reg * sizeof(ovhip_lmcs_region));
+        ovhip_dbf_offsets offs;
+        const ovhip_dbf_edge *ev = ovhip_rec_dbf_edges(rec, 0, &n, &offs), *eh = ovhip_rec_dbf_edges(rec, 1, &n, nullptr);
+        bs->offs = offs;
+        if (n_ev) memcpy(hb + o_ev, ev + c0.n_edge_v, n_ev * sizeof(ovhip_dbf_edge));
+        if (n_eh) memcpy(hb + o_eh, eh + c0.n_edge_h, n_eh * sizeof(ovhip_dbf_edge));
+        if (n_sao) memcpy(hb + o_sao, pr->sao + (size_t)sao_r0 * nb_ctu_w, n_sao * sizeof(ovhip_sao_ctu));
+        if (n_alf) memcpy(hb + o_alf, pr->alf_ctus + (size_t)alf_r0 * nb_ctu_w, n_alf * sizeof(ovhip_alf_ctu));
+        if (lmcs_now) { memcpy(hb + o_fwd, pr->lmcs->fwd_lut, 2048); memcpy(hb + o_bwd, pr->lmcs->bwd_lut, 2048); }
+        if (alf_now) {
+            memcpy(hb + o_lco, pr->alf_luma_coeff, 24 * OVHIP_ALF_LUMA_SET_SIZE * 2); memcpy(hb + o_lcl, pr->alf_luma_clip, 24 * OVHIP_ALF_LUMA_SET_SIZE * 2);
+            memcpy(hb + o_cco, pr->alf_chroma_coeff, 8 * 7 * 2); memcpy(hb + o_ccl, pr->alf_chroma_clip, 8 * 7 * 2);
+            memcpy(hb + o_cc, pr->alf_cc_coeff, 2 * 4 * 8 * 2);
+        }
+    }
+    if (upload_bytes) {
+        OV_HIP(ctx, hipMemcpyAsync(db, hb, upload_bytes, hipMemcpyHostToDevice, ctx->stream));
+        j->st.h2d_bytes += upload_bytes; j->st.n_h2d++;
+    }
+    OV_HIP(ctx, hipEventRecord(j->ev_h2d, ctx->stream));
+    if (lmcs_now) { bs->d_fwd = (const uint16_t *)(db + o_fwd); bs->d_bwd = (const uint16_t *)(db + o_bwd); bs->lmcs_up = 1; bs->luts = *pr->lmcs; bs->have_luts = 1; }
+    if (alf_now) {
+        bs->d_alf.luma_coeff = (const int16_t *)(db + o_lco); bs->d_alf.luma_clip = (const int16_t *)(db + o_lcl);
+        bs->d_alf.chroma_coeff = (const int16_t *)(db + o_cco); bs->d_alf.chroma_clip = (const int16_t *)(db + o_ccl);
+        bs->d_alf.cc_coeff = (const int16_t *)(db + o_cc);
+        bs->d_alf.class_scratch = (uint8_t *)j->dev[B_CLASS].p; bs->d_alf.log2_ctu_s = log2_ctu;
+        bs->alf_up = 1;
+    }
+    if (pr->lmcs && !bs->lmcs_up) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_job_band: LMCS tables", hipSuccess);
+    const ovhip_lmcs_luts *luts = pr->lmcs ? &bs->luts : nullptr;
+    const uint16_t *d_fwd = pr->lmcs ? bs->d_fwd : nullptr, *d_bwd = pr->lmcs ? bs->d_bwd : nullptr;
+    int16_t *d_scales = (int16_t *)j->dev[B_SCALE].p;
+    // the band's slices through pointers moved back by the slice's first index: the commands' own indices stay what the recorder wrote
+    const ovhip_lmcs_region *d_reg = (const ovhip_lmcs_region *)(db + o_reg);
+    const ovhip_lmcs_region *d_reg_g = d_reg - c0.n_reg;
+    const int16_t *d_coef_g = (const int16_t *)(db + o_coef) - c0.n_coef;
+    const int32_t *d_side_g = (const int32_t *)(db + o_side) - c0.n_side;
+    const ovhip_itask *d_it = (const ovhip_itask *)(db + o_it);
+    B.d_it = d_it; B.n_it = (uint32_t)n_it;
+    B.d_ev = (const ovhip_dbf_edge *)(db + o_ev); B.n_ev = (uint32_t)n_ev; B.d_eh = (const ovhip_dbf_edge *)(db + o_eh); B.n_eh = (uint32_t)n_eh;
+    j->st.n_tb += (uint32_t)n_tb; j->st.n_mc += (uint32_t)n_mc; j->st.n_mcx += (uint32_t)n_mcx; j->st.n_aff += (uint32_t)n_aff;
+    j->st.n_edges_v += (uint32_t)n_ev; j->st.n_edges_h += (uint32_t)n_eh; j->st.n_regions += (uint32_t)n_reg; j->st.n_itasks += (uint32_t)n_it; j->st.n_ilevels += n_lv;
+
+    // ---- recon(b) ----
+    if (stages & OVHIP_STAGE_MC) {
+        if (n_mc) { CHK(ovhip_mc_launch(ctx, dst, refs, n_refs, (const ovhip_mc_unit *)(db + o_mc), (uint32_t)n_mc, d_fwd, nullptr)); j->st.n_launches++; }
+        if (n_mcx || n_aff) {
+            CHK(ovhip_mcxa_launch(ctx, dst, refs, n_refs, (const ovhip_mc_unit *)(db + o_mcx), (uint32_t)n_mcx, (int32_t *)(db + o_mv),
+                                  (const ovhip_aff_unit *)(db + o_aff), (uint32_t)n_aff, d_side_g, d_fwd));
+            j->st.n_launches++;
+        }
+    }
+    int flow_workers = 0;
+    if (by_flow && n_items) {
+        // workers: no more than the band's widest level can use, no more than the device's budget has left (else: one launch per level)
+        size_t widest = 0, run = 0;
+        const ovhip_itask *hs = (const ovhip_itask *)(hb + o_it); const uint32_t *items = (const uint32_t *)(hb + o_items);
+        for (size_t q = 0; q < n_items; ++q) {
+            run = (q && hs[items[q] & 0xffffff].level == hs[items[q - 1] & 0xffffff].level) ? run + 1 : 1;
+            if (run > widest) widest = run;
+        }
+        int want = pr->flow_workers ? (int)pr->flow_workers : (int)((2 * widest + 63) & ~(size_t)63);
+        const int most = (6 * ctx->num_cus) >> flow_shift_of(ctx->device);
+        if (want > most) want = most;
+        if (want < 64) want = 64;
+        flow_workers = band_flow_take(ctx, (want + 63) & ~63);
+        if (!flow_workers) { by_flow = 0; if (!have_levels) return ov_fail(ctx, OVHIP_EUNSUP, "ovhip_job_band: flow budget exhausted and no level table", hipSuccess); }
+        B.flow_charge = flow_workers;
+    }
+    int flow_prepared = 0;
+    if (stages & OVHIP_STAGE_ITX) {
+        const ovhip_tb_cmd *d_tb = (const ovhip_tb_cmd *)(db + o_tb);
+        const uint32_t t_luma[4] = { (uint32_t)tiny[1][0], (uint32_t)tiny[1][1], (uint32_t)tiny[1][2], (uint32_t)tiny[1][3] };
+        const uint32_t t_chroma[4] = { (uint32_t)tiny[3][0], (uint32_t)tiny[3][1], (uint32_t)tiny[3][2], (uint32_t)tiny[3][3] };
+        if (cls[0] + cls[1]) { CHK(ovhip_itx_launch_ex_(ctx, dst, &j->res, d_tb, (uint32_t)cls[0], (uint32_t)cls[1], t_luma, d_coef_g, nullptr, nullptr)); j->st.n_launches++; }
+        if (n_reg) {
+            if (!luts) return ov_fail(ctx, OVHIP_EINVAL, "ovhip_job_band: chroma-scale regions recorded without LMCS tables", hipSuccess);
+            if (by_flow && n_items) {
+                CHK(ovhip_lmcs_scale_prepare_launch(ctx, dst, d_reg, (uint32_t)n_reg, luts, d_scales + c0.n_reg, d_it, (uint32_t)n_it, j->d_flow, j->epoch));
+                flow_prepared = 1;
+            } else CHK(ovhip_lmcs_scale_launch(ctx, dst, d_reg, (uint32_t)n_reg, luts, d_scales + c0.n_reg));
+            j->st.n_launches++;
+        }
+        if (cls[2] + cls[3]) {
+            CHK(ovhip_itx_launch_ex_(ctx, dst, &j->res, d_tb + cls[0] + cls[1], (uint32_t)cls[2], (uint32_t)cls[3], t_chroma, d_coef_g, d_scales, nullptr));
+            j->st.n_launches++;
+        }
+    }
+    if (n_it) {
+        if (by_flow && n_items) {
+            CHK(ovhip_intra_flow_launch(ctx, dst, &j->res, d_it, (uint32_t)n_it, (const uint32_t *)(db + o_items), (uint32_t)n_items, d_reg_g, luts, d_scales,
+                                        log2_ctu, j->d_flow, j->epoch, j->abort_host, !flow_prepared, flow_workers));
+            j->st.n_launches += 1 + !flow_prepared;
+            B.tagged = 1;
+        } else {
+            // one launch per level: its kernels read plain samples -- the band above must not carry the flow launches' hand-over bit any more
+            if (b > 0 && bs->band[b - 1].tagged && bs->tails < b) {
+                CHK(ovhip_intra_flow_untag_launch(ctx, dst, bs->band[b - 1].d_it, bs->band[b - 1].n_it, 1));
+                bs->band[b - 1].tagged = 2;                          // (un-tagged early; the tail's own un-tag is then idempotent)
+                j->st.n_launches++;
+            }
+            const ovhip_itask *hs = (const ovhip_itask *)(hb + o_it);
+            for (uint32_t l = 0; l < n_lv; ++l) {
+                const uint32_t a = bs->level_start[l], e = bs->level_start[l + 1];
+                if (e > a) {
+                    CHK(ovhip_intra_level_launch(ctx, dst, &j->res, d_it + a, e - a, d_reg_g, luts, d_scales, log2_ctu, ovhip_intra_level_geom(hs + a, e - a)));
+                    j->st.n_launches++;
+                }
+            }
+        }
+    }
+    if (!bs->ev_recon[b]) OV_HIP(ctx, hipEventCreateWithFlags(&bs->ev_recon[b], hipEventDisableTiming));
+    OV_HIP(ctx, hipEventRecord(bs->ev_recon[b], ctx->stream));
+    bs->n = b + 1; bs->cur = c1; bs->row_prev = row_end;
+
+    // ---- tails: inverse luma mapping + un-tag, deblocking, per band; then the SAO / ALF rows they made final, once ----
+    for (int t = t_first; t < t_end; ++t) {
+        BandRec &T = bs->band[t];
+        if (T.row1 > T.row0) {
+            const bool inverse = pr->lmcs && (stages & OVHIP_STAGE_ITX);
+            if (inverse) {
+                ovhip_pic view = *dst;                                // the band's luma rows; the chroma un-tag takes picture coordinates
+                view.y = dst->y + (size_t)T.row0 * dst->stride_y; view.h = T.row1 - T.row0;
+                CHK(ovhip_lmcs_inverse_untag_launch(ctx, &view, d_bwd, T.d_it, T.tagged ? T.n_it : 0u));
+                j->st.n_launches++;
+            } else if (T.tagged == 1 && T.n_it) { CHK(ovhip_intra_flow_untag_launch(ctx, dst, T.d_it, T.n_it, 1)); j->st.n_launches++; }
+        }
+        if ((stages & OVHIP_STAGE_DBF) && (T.n_ev || T.n_eh)) {
+            CHK(ovhip_dbf_launch_edges_ex(ctx, dst, T.d_ev, T.n_ev, T.d_eh, T.n_eh, &bs->offs));
+            j->st.n_launches += (T.n_ev != 0) + (T.n_eh != 0);
+        }
+    }
+    if (t_end > t_first) {
+        const ovhip_sao_ctu *d_sao = sao_on ? (const ovhip_sao_ctu *)(db + o_sao) - (size_t)sao_r0 * nb_ctu_w : nullptr;
+        ovhip_alf_pic ap = bs->d_alf;
+        ap.ctus = alf_on ? (const ovhip_alf_ctu *)(db + o_alf) - (size_t)alf_r0 * nb_ctu_w : nullptr;
+        auto copy_rows = [&](const ovhip_pic *d, const ovhip_pic *s_, int32_t r0, int32_t r1) -> int {
+            if (r1 <= r0) return OVHIP_OK;
+            OV_HIP(ctx, hipMemcpyAsync(d->y + (size_t)r0 * d->stride_y, s_->y + (size_t)r0 * s_->stride_y, (size_t)(r1 - r0) * d->stride_y * 2, hipMemcpyDeviceToDevice, ctx->stream));
+            const int32_t c0_ = r0 / 2, c1_ = r1 == j->h ? j->h / 2 : r1 / 2;
+            OV_HIP(ctx, hipMemcpyAsync(d->cb + (size_t)c0_ * d->stride_c, s_->cb + (size_t)c0_ * s_->stride_c, (size_t)(c1_ - c0_) * d->stride_c * 2, hipMemcpyDeviceToDevice, ctx->stream));
+            OV_HIP(ctx, hipMemcpyAsync(d->cr + (size_t)c0_ * d->stride_c, s_->cr + (size_t)c0_ * s_->stride_c, (size_t)(c1_ - c0_) * d->stride_c * 2, hipMemcpyDeviceToDevice, ctx->stream));
+            return OVHIP_OK;
+        };
+        if (sao_new > bs->sao_rows) {
+            if (sao_on) { CHK(ovhip_sao_launch_rows(ctx, &j->tmp, dst, d_sao, log2_ctu, bs->sao_rows, sao_new)); j->st.n_launches++; }
+            else if (alf_on) CHK(copy_rows(&j->tmp, dst, bs->sao_rows, sao_new));
+        }
+        if (alf_new > bs->alf_rows) {
+            if (alf_on) { CHK(ovhip_alf_launch_rows(ctx, dst, &j->tmp, &ap, bs->alf_rows, alf_new)); j->st.n_launches++; }
+            else if (sao_on) CHK(copy_rows(dst, &j->tmp, bs->alf_rows, alf_new));
+        }
+        bs->dbf_rows = dbf_new; bs->sao_rows = sao_new; bs->alf_rows = alf_new;
+        bs->rows_final = (sao_on || alf_on) ? alf_new : dbf_new;
+        bs->tails = t_end;
+        const int te = t_end - 1;
+        bs->band[te].rows_final = bs->rows_final;
+        if (!bs->ev_tail[te]) OV_HIP(ctx, hipEventCreateWithFlags(&bs->ev_tail[te], hipEventDisableTiming));
+        OV_HIP(ctx, hipEventRecord(bs->ev_tail[te], ctx->stream));
+        bs->last_event = (void *)bs->ev_tail[te]; bs->last_rows = bs->rows_final;
+    }
+    // (behind every band: ovhip_job_wait / _begin / _destroy wait for what has been enqueued, whether or not the picture was completed)
+    OV_HIP(ctx, hipEventRecord(j->ev_done, ctx->stream));
+    j->flushed = 1; j->flow_launched = 0;
+    if (last) bs->closed = 1;
+    return OVHIP_OK;
+}
+

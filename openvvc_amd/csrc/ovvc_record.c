@@ -86,6 +86,18 @@ ACCESSOR(ovhip_mc_unit, ovhip_rec_mcx_units, mcx, n_mcx)
 ACCESSOR(ovhip_aff_unit, ovhip_rec_aff_units, aff, n_aff)
 ACCESSOR(int32_t, ovhip_rec_aff_side, aff_side, n_side)
 
+/* lengths of the arrays a band of CTU rows is cut from (ovhip_job_band) */
+void
+ovhip_rec_counts(const ovhip_recorder *r, ovhip_band_counts *out)
+{
+    if (!out) return;
+    memset(out, 0, sizeof(*out));
+    if (!r) return;
+    out->n_tb = (uint32_t)r->n_tb; out->n_coef = (uint32_t)r->n_coef; out->n_mc = (uint32_t)r->n_mc; out->n_mcx = (uint32_t)r->n_mcx;
+    out->n_aff = (uint32_t)r->n_aff; out->n_side = (uint32_t)r->n_side; out->n_reg = (uint32_t)r->n_reg; out->n_itask = (uint32_t)r->n_itask;
+    out->n_edge_v = (uint32_t)r->n_edge_v; out->n_edge_h = (uint32_t)r->n_edge_h;
+}
+
 /* Arrays grow geometrically; with a caller-supplied allocator (pinned host memory in the engine, so that the flush
  * is plain asynchronous DMA) growth is allocate + copy + free, since such memory cannot be realloc'ed. */
 int
@@ -989,29 +1001,38 @@ ACCESSOR(ovhip_lmcs_region, ovhip_rec_lmcs_regions, reg, n_reg)
  * OVHIP_TB_TR without LFNST off the arena's sub-blocks, or OVHIP_TB_DC), which k_itx_all takes a lane per sample, 4 / 8 / 8 / 16 blocks
  * to a workgroup, with the command as per-lane data (over half of a 4K picture's blocks).  Library-internal (the picture job);
  * ovhip_rec_tb_cmds_split is the same order. */
-const ovhip_tb_cmd *
-ovhip_rec_tb_cmds_split_tiny_(ovhip_recorder *r, size_t counts[4], size_t tiny[4][4], size_t *n)
+/* the same split of the commands [first, first + n) into `out` (n entries; the picture job's staging block of a band) */
+void
+ovhip_rec_tb_split_range_(const ovhip_recorder *r, size_t first, size_t n, ovhip_tb_cmd *out, size_t counts[4], size_t tiny[4][4])
 {
     size_t start[20], cnt[20], k;
-    *n = r->n_tb;
+    const ovhip_tb_cmd *tb = r->tb + first;
     memset(cnt, 0, sizeof(cnt)); memset(counts, 0, 4 * sizeof(size_t)); memset(tiny, 0, 16 * sizeof(size_t));
-    if (!r->n_tb) return r->tb;
-    if (grow((void **)&r->tb_split, &r->cap_split, r->n_tb, sizeof(ovhip_tb_cmd))) { *n = 0; return NULL; }
     /* "small" = what one wavefront and a 4 KB slice of LDS take: at most 256 samples, no side above 32 */
 #define TB_CLASS(c) (((c)->plane != 0) * 2 + ((c)->log2_w + (c)->log2_h <= 8 && (c)->log2_w <= 5 && (c)->log2_h <= 5))
     /* 0: a wave of its own through the general body; 1: 8x8, 2: 4x8, 3: 8x4, 4: 4x4 */
 #define TB_SHAPE(c) (((c)->kind == OVHIP_TB_DC || ((c)->kind == OVHIP_TB_TR && !((c)->lfnst & 1))) ? \
                      ((c)->log2_w == 3 && (c)->log2_h == 3 ? 1 : (c)->log2_w == 2 && (c)->log2_h == 3 ? 2 : \
                       (c)->log2_w == 3 && (c)->log2_h == 2 ? 3 : (c)->log2_w == 2 && (c)->log2_h == 2 ? 4 : 0) : 0)
-    for (size_t i = 0; i < r->n_tb; ++i) cnt[5 * TB_CLASS(&r->tb[i]) + TB_SHAPE(&r->tb[i])]++;
+    for (size_t i = 0; i < n; ++i) cnt[5 * TB_CLASS(&tb[i]) + TB_SHAPE(&tb[i])]++;
     for (k = 0, start[0] = 0; k < 19; ++k) start[k + 1] = start[k] + cnt[k];
-    for (size_t i = 0; i < r->n_tb; ++i) r->tb_split[start[5 * TB_CLASS(&r->tb[i]) + TB_SHAPE(&r->tb[i])]++] = r->tb[i];
+    for (size_t i = 0; i < n; ++i) out[start[5 * TB_CLASS(&tb[i]) + TB_SHAPE(&tb[i])]++] = tb[i];
 #undef TB_CLASS
 #undef TB_SHAPE
     for (k = 0; k < 4; ++k) {
         counts[k] = cnt[5 * k] + cnt[5 * k + 1] + cnt[5 * k + 2] + cnt[5 * k + 3] + cnt[5 * k + 4];
         for (int q = 0; q < 4; ++q) tiny[k][q] = cnt[5 * k + 1 + q];
     }
+}
+
+const ovhip_tb_cmd *
+ovhip_rec_tb_cmds_split_tiny_(ovhip_recorder *r, size_t counts[4], size_t tiny[4][4], size_t *n)
+{
+    *n = r->n_tb;
+    memset(counts, 0, 4 * sizeof(size_t)); memset(tiny, 0, 16 * sizeof(size_t));
+    if (!r->n_tb) return r->tb;
+    if (grow((void **)&r->tb_split, &r->cap_split, r->n_tb, sizeof(ovhip_tb_cmd))) { *n = 0; return NULL; }
+    ovhip_rec_tb_split_range_(r, 0, r->n_tb, r->tb_split, counts, tiny);
     return r->tb_split;
 }
 

@@ -223,6 +223,39 @@ ovhip_rec_itasks_sorted(ovhip_recorder *r, size_t *n, const uint32_t **level_sta
     return r->itask_sorted;
 }
 
+/* The tasks [first, first + n) sorted by level into `out` (the picture job's staging block of a band of CTU rows).  level_start
+ * (caller's array of cap entries): entry l = first task of the band's l-th level value in use ... entry *n_levels = n; levels the
+ * band does not hold take no entry.  Returns 0, or -1 when cap is too small (the caller falls back to one flow launch, which needs
+ * no table). */
+int
+ovhip_rec_itasks_sorted_range_(const ovhip_recorder *r, size_t first, size_t n, ovhip_itask *out, uint32_t *level_start, size_t cap, uint32_t *n_levels)
+{
+    *n_levels = 0;
+    if (!n) return 0;
+    const ovhip_itask *t = r->itask + first;
+    uint32_t minl = 0xffffffffu, maxl = 0;
+    for (size_t i = 0; i < n; ++i) { if (t[i].level < minl) minl = t[i].level; if (t[i].level > maxl) maxl = t[i].level; }
+    const size_t span = (size_t)(maxl - minl) + 1;
+    /* counting sort over the band's level range (levels are uint16: at most 64 K counters, on the heap of the caller's table when it
+     * fits, else a scratch allocation) */
+    uint32_t *cnt = (uint32_t *)calloc(span + 1, sizeof(uint32_t));
+    if (!cnt) return -1;
+    for (size_t i = 0; i < n; ++i) cnt[t[i].level - minl]++;
+    uint32_t acc = 0, nl = 0;
+    int fits = 1;
+    for (size_t l = 0; l < span; ++l) {
+        const uint32_t c = cnt[l];
+        cnt[l] = acc;
+        if (c) { if (nl < cap) level_start[nl] = acc; else fits = 0; ++nl; }
+        acc += c;
+    }
+    if (nl < cap) level_start[nl] = acc; else fits = 0;
+    for (size_t i = 0; i < n; ++i) out[cnt[t[i].level - minl]++] = t[i];
+    free(cnt);
+    *n_levels = nl;
+    return fits ? 0 : -1;
+}
+
 /* Grouped by CTU for the one-launch ordered pass (k_intra_ctu): counting sort of the level-sorted list by CTU index, so a
  * CTU's tasks stay in level order, decoding order inside a level. */
 const ovhip_itask *

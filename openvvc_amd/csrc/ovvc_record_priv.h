@@ -58,6 +58,10 @@ uint16_t ovhip_rec_region_level_(ovhip_recorder *r, int32_t x0, int32_t y0, int 
 int  ovhip_rec_grow_(ovhip_recorder *r, void **p, size_t *cap, size_t need, size_t elem);
 void ovhip_rec_free_(ovhip_recorder *r, void *p);
 
+/* band-wise submission (ovvc_picture.hip): class split / level sort of a RANGE of the recorded commands into the caller's buffer */
+void ovhip_rec_tb_split_range_(const ovhip_recorder *r, size_t first, size_t n, ovhip_tb_cmd *out, size_t counts[4], size_t tiny[4][4]);
+int  ovhip_rec_itasks_sorted_range_(const ovhip_recorder *r, size_t first, size_t n, ovhip_itask *out, uint32_t *level_start, size_t cap, uint32_t *n_levels);
+
 void ovhip_rec_dbf_reset_(ovhip_recorder *r);
 void ovhip_rec_dbf_free_(ovhip_recorder *r);
 #endif

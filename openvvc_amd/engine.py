@@ -489,6 +489,26 @@ class Job:
     def wait(self):
         self.ctx._chk(self.lib.ovhip_job_wait(self.j), "job_wait")
 
+    def band(self, dst: "DevPic", refs: list, row_end: int, last: bool = False, upto: "capi.BandCounts | None" = None, params=None):
+        """ovhip_job_band: what was recorded since the previous call (or up to `upto`) as one band of CTU rows ending at row_end"""
+        arr = (capi.Pic * max(len(refs), 1))(*[r.s for r in refs])
+        self.ctx._chk(self.lib.ovhip_job_band(self.j, C.byref(dst.s), arr, len(refs), C.byref(params if params is not None else self.params),
+                                              C.byref(upto) if upto is not None else None, row_end, int(last)), "job_band")
+
+    def band_progress(self) -> int:
+        rows = C.c_int32()
+        self.ctx._chk(self.lib.ovhip_job_band_progress(self.j, C.byref(rows), None, None), "job_band_progress")
+        return rows.value
+
+    def flush_in_bands(self, wl, dst: "DevPic", refs: list, ctu_rows_per_band: int = 1, log2_ctu: int = 7, params=None):
+        """A recorded picture (load_workload(wl) before) submitted band by band, as the live decoder's row hooks do while the picture is
+        parsed: the counts of every array at each band's last CTU row come from the commands' positions (the arrays are in decoding order)."""
+        rows = list(range(ctu_rows_per_band << log2_ctu, self.h, ctu_rows_per_band << log2_ctu))
+        cuts = band_counts(wl, rows, log2_ctu)
+        for r, c in zip(rows, cuts):
+            self.band(dst, refs, r, False, c, params)
+        self.band(dst, refs, self.h, True, None, params)
+
     def bind(self, ctx: "Context"):
         """The next flushes go to ctx's stream (a free frame thread takes the picture over)."""
         self.ctx._chk(self.lib.ovhip_job_bind(self.j, ctx.h), "job_bind")
@@ -547,6 +567,44 @@ class Job:
         s, n = C.c_double(), C.c_uint64()
         self.ctx._chk(self.lib.ovhip_job_stage_time(self.j, C.byref(s), C.byref(n)), "job_stage_time")
         return s.value * 1e-3, n.value
+
+
+def band_counts(wl, rows, log2_ctu: int = 7) -> list:
+    """capi.BandCounts of a recorded picture at each luma row of `rows` (CTU-row boundaries): how many entries of every array belong
+    to the CTU rows above it.  The arrays must be in decoding order (CTU rows ascending) -- checked."""
+    def cut(ctu_row, what):
+        ctu_row = np.asarray(ctu_row, np.int64)
+        if len(ctu_row) > 1 and (np.diff(ctu_row) < 0).any():
+            raise EngineError(f"band_counts: {what} are not in CTU-row order")
+        return [int(np.searchsorted(ctu_row, r >> log2_ctu, side="left")) for r in rows]
+
+    def arr(a, dt):
+        return np.zeros(0, dt) if a is None or not len(a) else np.asarray(a).view(dt).reshape(-1)
+
+    tb, mc, mcx = arr(wl.tb_cmds, capi.TB_CMD_DTYPE), arr(wl.mc_units, capi.MC_UNIT_DTYPE), arr(wl.mcx_units, capi.MC_UNIT_DTYPE)
+    aff, reg, it = arr(wl.aff_units, capi.AFF_UNIT_DTYPE), arr(wl.lmcs_regions, capi.LMCS_REGION_DTYPE), arr(wl.itasks, capi.ITASK_DTYPE)
+    ev, eh = arr(wl.dbf_edges[0], capi.DBF_EDGE_DTYPE), arr(wl.dbf_edges[1], capi.DBF_EDGE_DTYPE)
+    n_coef = 0 if wl.coefs is None else len(wl.coefs)
+    n_side = 0 if wl.aff_side is None else len(wl.aff_side)
+    tb_row = (tb["y"].astype(np.int64) << (tb["plane"] != 0)) >> log2_ctu
+    it_chroma = (it["kind"] == capi.IT_CHROMA) | (it["kind"] == capi.IT_RES_C)
+    it_row = (it["y"].astype(np.int64) << it_chroma) >> log2_ctu
+    k_tb, k_mc, k_mcx = cut(tb_row, "transform blocks"), cut(mc["y"] >> log2_ctu, "MC units"), cut(mcx["y"] >> log2_ctu, "refined units")
+    k_aff, k_reg, k_it = cut(aff["y"] >> log2_ctu, "affine units"), cut(reg["y"] >> log2_ctu, "regions"), cut(it_row, "ordered tasks")
+    # an edge's uy counts units of 4 LUMA samples in every plane (the 4x4-luma grid of the deblocking maps)
+    k_ev = cut((ev["uy"].astype(np.int64) << 2) >> log2_ctu, "vertical edges")
+    k_eh = cut((eh["uy"].astype(np.int64) << 2) >> log2_ctu, "horizontal edges")
+    out = []
+    for i in range(len(rows)):
+        c = capi.BandCounts()
+        c.n_tb, c.n_mc, c.n_mcx, c.n_aff, c.n_reg, c.n_itask, c.n_edge_v, c.n_edge_h = k_tb[i], k_mc[i], k_mcx[i], k_aff[i], k_reg[i], k_it[i], k_ev[i], k_eh[i]
+        # the arenas are appended with the commands that own their entries: a band's share ends where the next band's first owner starts
+        later = tb["coef_off"][k_tb[i]:]
+        c.n_coef = int(later.min()) if len(later) else n_coef
+        la = aff[k_aff[i]:]
+        c.n_side = int(min(la["side_off"].min(), la["prof_off"][(la["flags"] & 1) != 0].min(initial=0xffffffff))) if len(la) else n_side
+        out.append(c)
+    return out
 
 
 class Dpb:
