@@ -1091,6 +1091,10 @@ typedef struct ovhip_dpb_ops {
     void (*copy_done)(void *user, int dst_dev, void *event);                               /* the handle is no longer needed     */
     /* a picture whose last decode FAILED goes back to the pool: make it safe to decode into (no sample may carry bit 15) */
     int  (*pic_clear)(void *user, int dev, const ovhip_pic *pic);
+    /* row progress (ovhip_dpb_post_rows): the handles are the producer's (hipEvent_t behind a band's last filter launch); query: 1 =
+     * completed, 0 = not yet, < 0 error; wait blocks the calling thread.  NULL (test back-ends): a posted record counts as completed. */
+    int  (*event_query)(void *user, int dev, void *event);
+    int  (*event_wait)(void *user, int dev, void *event);
 } ovhip_dpb_ops;
 
 #define OVHIP_MAX_DEVICES 16
@@ -1127,6 +1131,18 @@ int  ovhip_dpb_acquire(ovhip_dpb *d, const void *key, int dev, ovhip_pic *pic, v
 /* 1: the picture is DONE (an acquire would not wait for its decode), 0: not yet (unknown key, another picture under it, DECODING),
  * OVHIP_EREF: it failed.  Never blocks. */
 int  ovhip_dpb_poll_tag(ovhip_dpb *d, const void *key, uint64_t tag);
+/* ---- row progress: the device analogue of ovdpb_report_decoded_ctu_line / ovdpb_synchro_ref_decoded_ctus (dpb.c:1309-1323, :1242-1270)
+ * for the pictures a band-wise job decodes (ovhip_job_band).
+ * ovhip_dpb_post_rows (producer, picture DECODING): the picture's rows [0, rows) are final once `event` has completed and
+ *   *abort_word (NULL: none) still reads 0.  Records are kept in order; rows must not decrease.
+ * ovhip_dpb_rows_tag (reader): are the rows [0, need_rows) of the picture there for device dev?  1: yes -- *pic is the picture on dev
+ *   (pin != 0: pinned, as by ovhip_dpb_acquire_tag; unpin with ovhip_dpb_unpin), *event (may be NULL) a transfer the caller still has
+ *   to wait for (ovhip_dpb_wait_copy) when the picture was decoded on another device; 0: not yet (never with block != 0); OVHIP_EREF:
+ *   the picture FAILED or the DPB was shut down.  A picture decoded on ANOTHER device is there only when it is complete (its transfer
+ *   is picture-granular); need_rows >= the picture's height means the whole picture.  block != 0 waits -- for the producer's records
+ *   on the DPB's condition variable, for a record's event through event_wait. */
+int  ovhip_dpb_post_rows(ovhip_dpb *d, const void *key, int32_t rows, void *event, const volatile uint32_t *abort_word);
+int  ovhip_dpb_rows_tag(ovhip_dpb *d, const void *key, uint64_t tag, int dev, int32_t need_rows, int block, int pin, ovhip_pic *pic, void **event);
 int  ovhip_dpb_wait_copy(ovhip_dpb *d, int dev, void *event);
 int  ovhip_dpb_unpin(ovhip_dpb *d, const void *key);
 int  ovhip_dpb_release(ovhip_dpb *d, const void *key);
@@ -1174,7 +1190,8 @@ typedef struct ovhip_frame_output {
  * frames: the same state machine, DPB calls, waits and trace, nothing launched -- how the shim's device half runs in a container
  * without a GPU (oracle/ref_harness/gen_pipe.c "device" mode -> tests/golden/shim_pipe_dev.ovg, replayed on a GPU by
  * tests/test_gpu_pipe.py). */
-enum { OVHIP_FE_BEGIN = 1, OVHIP_FE_REF, OVHIP_FE_DMVR_ROWS, OVHIP_FE_DMVR_BEGIN, OVHIP_FE_DMVR_COLLECT, OVHIP_FE_SUBMIT, OVHIP_FE_FAIL };
+enum { OVHIP_FE_BEGIN = 1, OVHIP_FE_REF, OVHIP_FE_DMVR_ROWS, OVHIP_FE_DMVR_BEGIN, OVHIP_FE_DMVR_COLLECT, OVHIP_FE_SUBMIT, OVHIP_FE_FAIL,
+       OVHIP_FE_BAND /* a = row_end, b = last, result: 1 the band went to the device, 0 left to the next call, < 0 error */ };
 typedef struct ovhip_frame_event {
     uint32_t op; int32_t frame;          /* OVHIP_FE_*; the frame object, numbered in creation order                      */
     uint64_t key, tag;
@@ -1209,6 +1226,16 @@ int64_t ovhip_frame_dmvr_rows_collect(ovhip_frame *f);
 int  ovhip_frame_submit(ovhip_frame *f, ovhip_job *job, const ovhip_pic *intra, const ovhip_job_params *params, ovhip_frame_output *out);
 /* A picture that cannot be submitted (latched recorder error, unsupported tool): publishes it as FAILED so that no reader
  * waits for it for ever. */
+/* ---- band-wise submission (the picture enters the device while it is parsed; see ovhip_job_band) ----
+ * ovhip_frame_set_band_mode(f, 1): ovhip_frame_refs_ready / ovhip_frame_dmvr_rows_begin then ask the device DPB for the ROWS the units
+ *   in question read (ovhip_dpb_rows_tag) instead of whole reference pictures.
+ * ovhip_frame_band(f, params, row_end, last, out): everything recorded since the last band that went, as a band ending at the CTU-row
+ *   boundary row_end.  Returns 1: enqueued (and the rows it made final posted to the DPB), 0: a reference picture does not have the rows
+ *   yet -- nothing was enqueued, the next call takes this band's units too (never with last != 0, which waits), < 0: error.  With last
+ *   != 0 the call completes the picture exactly as ovhip_frame_submit does: wait, publish, output. */
+int  ovhip_frame_set_band_mode(ovhip_frame *f, int on);
+int  ovhip_frame_band(ovhip_frame *f, const ovhip_job_params *params, int32_t row_end, int32_t last, ovhip_frame_output *out);
+int  ovhip_frame_band_stats(const ovhip_frame *f, int32_t *n_bands, int32_t *n_deferred);
 int  ovhip_frame_fail(ovhip_frame *f, int status);
 const char *ovhip_frame_last_error(const ovhip_frame *f);
 

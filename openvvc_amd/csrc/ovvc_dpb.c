@@ -19,6 +19,7 @@
 
 enum { S_FREE = 0, S_DECODING, S_DONE, S_FAILED };
 enum { C_NONE = 0, C_STARTED };
+enum { PROG_MAX = 8 };
 
 struct dpb_copy { ovhip_pic pic; int state; void *event; };
 
@@ -33,6 +34,11 @@ struct dpb_slot {
     uint64_t serial;
     uint64_t tag;                         /* caller's picture identity (0: none): a recycled key with another tag is another picture */
     struct dpb_copy copy[OVHIP_MAX_DEVICES];
+    /* row progress of a picture that is decoded band by band (ovhip_dpb_post_rows): rows_final = what has been SEEN complete; prog[] =
+     * the producer's records not seen complete yet, oldest first */
+    int32_t rows_final;
+    struct { int32_t rows; void *event; } prog[PROG_MAX]; int n_prog;
+    const volatile uint32_t *abort_word;
 };
 
 struct pool_ent { ovhip_pic pic; int32_t w, h; };
@@ -415,6 +421,107 @@ ovhip_dpb_acquire_tag(ovhip_dpb *d, const void *key, uint64_t tag, int dev, ovhi
             s->pins++;
         }
     }
+    pthread_mutex_unlock(&d->mtx);
+    return r;
+}
+
+/* ---- row progress ---- */
+int
+ovhip_dpb_post_rows(ovhip_dpb *d, const void *key, int32_t rows, void *event, const volatile uint32_t *abort_word)
+{
+    if (!d || !key || rows < 0) return OVHIP_EINVAL;
+    int r = OVHIP_OK;
+    pthread_mutex_lock(&d->mtx);
+    struct dpb_slot *s = find(d, key);
+    if (!s || s->state != S_DECODING) r = OVHIP_EINVAL;
+    else {
+        const int32_t last = s->n_prog ? s->prog[s->n_prog - 1].rows : s->rows_final;
+        if (rows < last) r = OVHIP_EINVAL;
+        else if (rows > last || (s->n_prog && event)) {
+            s->abort_word = abort_word;
+            /* the table is full (readers have not looked for a while), or the same rows behind a later event: the newest record takes the
+             * place of the one before it -- an event recorded later on the producer's stream completes after the earlier one */
+            if (s->n_prog == PROG_MAX || (s->n_prog && rows == last)) s->n_prog--;
+            s->prog[s->n_prog].rows = rows; s->prog[s->n_prog].event = event;
+            s->n_prog++;
+            if (!d->ops.event_query && !event) { s->rows_final = rows; s->n_prog = 0; }
+            pthread_cond_broadcast(&d->cnd);
+        }
+    }
+    pthread_mutex_unlock(&d->mtx);
+    return r;
+}
+
+/* mutex held: take the records whose events have completed (in order) */
+static int
+advance_rows(ovhip_dpb *d, struct dpb_slot *s)
+{
+    while (s->n_prog) {
+        int done = 1;
+        if (s->prog[0].event && d->ops.event_query) done = d->ops.event_query(d->ops.user, s->home, s->prog[0].event);
+        if (done < 0) return done;
+        if (!done) break;
+        if (s->abort_word && *s->abort_word) break;          /* the producer's ordered pass gave up: it will fail the picture */
+        s->rows_final = s->prog[0].rows;
+        memmove(&s->prog[0], &s->prog[1], (size_t)(--s->n_prog) * sizeof(s->prog[0]));
+    }
+    return OVHIP_OK;
+}
+
+int
+ovhip_dpb_rows_tag(ovhip_dpb *d, const void *key, uint64_t tag, int dev, int32_t need_rows, int block, int pin, ovhip_pic *pic, void **event)
+{
+    if (!d || !key || !pic || dev < 0 || dev >= d->n_dev) return OVHIP_EINVAL;
+    if (event) *event = NULL;
+    int r = 0, waited = 0;
+    pthread_mutex_lock(&d->mtx);
+    struct timespec until;
+    int have_until = 0;
+    for (;;) {
+        if (d->shutdown) { r = OVHIP_EREF; break; }
+        struct dpb_slot *s = find_tag(d, key, tag);
+        if (!s) {
+            /* not begun yet: its frame thread is behind (bounded, as in ovhip_dpb_acquire_tag) */
+            if (!block) break;
+            if (d->unknown_ms <= 0) { r = OVHIP_EINVAL; break; }
+            if (!have_until) {
+                clock_gettime(CLOCK_REALTIME, &until);
+                until.tv_sec += d->unknown_ms / 1000; until.tv_nsec += (long)(d->unknown_ms % 1000) * 1000000L;
+                if (until.tv_nsec >= 1000000000L) { until.tv_sec++; until.tv_nsec -= 1000000000L; }
+                have_until = 1;
+            }
+            waited = 1;
+            if (pthread_cond_timedwait(&d->cnd, &d->mtx, &until) == ETIMEDOUT && !find_tag(d, key, tag)) { r = OVHIP_EINVAL; break; }
+            continue;
+        }
+        if (s->state == S_FAILED) { r = OVHIP_EREF; break; }
+        if (s->state == S_DONE) {
+            if (dev == s->home) { *pic = s->pic; if (pin) s->pins++; r = 1; break; }
+            r = start_copy(d, s, dev);
+            if (r == OVHIP_OK) { *pic = s->copy[dev].pic; if (event) *event = s->copy[dev].event; if (pin) s->pins++; r = 1; }
+            break;
+        }
+        /* DECODING */
+        if (dev == s->home && need_rows < s->h) {
+            const int q = advance_rows(d, s);
+            if (q < 0) { r = q; break; }
+            if (s->rows_final >= need_rows) { *pic = s->pic; if (pin) s->pins++; r = 1; break; }
+        }
+        if (!block) break;
+        waited = 1;
+        /* a record that covers the rows: wait for its event outside the mutex; else for the producer's next record / its publication */
+        void *ev = NULL;
+        if (dev == s->home && need_rows < s->h && d->ops.event_wait && !(s->abort_word && *s->abort_word))
+            for (int i = 0; i < s->n_prog && !ev; ++i) if (s->prog[i].rows >= need_rows) ev = s->prog[i].event;
+        if (ev) {
+            const int home = s->home;
+            pthread_mutex_unlock(&d->mtx);
+            const int q = d->ops.event_wait(d->ops.user, home, ev);
+            pthread_mutex_lock(&d->mtx);
+            if (q != OVHIP_OK) { r = q; break; }
+        } else pthread_cond_wait(&d->cnd, &d->mtx);
+    }
+    d->st.n_waits += waited;
     pthread_mutex_unlock(&d->mtx);
     return r;
 }

@@ -130,6 +130,22 @@ void hd_copy_done(void *user, int kd, void *event)
     if (hipSetDevice(u->dev[kd]) == hipSuccess) (void)hipEventDestroy((hipEvent_t)event);
 }
 
+// row progress: the producer's events (recorded on its job's stream; any thread may ask)
+int hd_event_query(void *user, int k, void *event)
+{
+    (void)user; (void)k;
+    const hipError_t e = hipEventQuery((hipEvent_t)event);
+    if (e == hipSuccess) return 1;
+    (void)hipGetLastError();
+    return e == hipErrorNotReady ? 0 : OVHIP_ELAUNCH;
+}
+
+int hd_event_wait(void *user, int k, void *event)
+{
+    (void)user; (void)k;
+    return hipEventSynchronize((hipEvent_t)event) == hipSuccess ? OVHIP_OK : OVHIP_ELAUNCH;
+}
+
 } // namespace
 
 extern "C" int ovhip_dpb_hip_ops_(const int *devices, int n_devices, ovhip_dpb_ops *ops, void **user)
@@ -144,6 +160,7 @@ extern "C" int ovhip_dpb_hip_ops_(const int *devices, int n_devices, ovhip_dpb_o
     ops->user = u;
     ops->pic_alloc = hd_pic_alloc; ops->pic_free = hd_pic_free; ops->pic_clear = hd_pic_clear;
     ops->copy_start = hd_copy_start; ops->copy_wait = hd_copy_wait; ops->copy_done = hd_copy_done;
+    ops->event_query = hd_event_query; ops->event_wait = hd_event_wait;
     *user = u;
     return OVHIP_OK;
 }

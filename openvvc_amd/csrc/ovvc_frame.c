@@ -39,6 +39,11 @@ struct ovhip_frame {
     int n_refs;
     int status;
     char err[192];
+    /* band-wise submission (ovhip_frame_band): what has been handed to the job so far, how many rows were posted to the DPB */
+    int band_mode;
+    ovhip_band_counts band_prev;
+    int32_t band_row_prev, band_rows_posted, dry_row_prev2;
+    int n_bands, n_deferred;
 };
 
 /* ---- event trace (include/ovvc_hip.h, ovhip_frame_set_trace): WHEN a caller (shim/rcn_hip.c) makes its frame-level calls ---- */
@@ -160,6 +165,8 @@ ovhip_frame_begin_tag(ovhip_frame *f, const void *key, uint64_t tag)
     trace(f, OVHIP_FE_BEGIN, key, tag, f->dev, 0, r);
     if (r != OVHIP_OK) return fail(f, r, "ovhip_dpb_begin");
     f->key = key; f->live = 1;
+    memset(&f->band_prev, 0, sizeof(f->band_prev));
+    f->band_row_prev = f->band_rows_posted = f->dry_row_prev2 = 0; f->n_bands = f->n_deferred = 0;
     if (f->dry) { ovhip_rec_reset(f->dry_rec); f->dry_pending = f->dry_done = 0; }
     if (f->job) {
         r = ovhip_job_begin(f->job);
@@ -220,10 +227,26 @@ acquire_refs(ovhip_frame *f)
  * wait for a decode), 0: not yet, < 0: one of them failed.  Never waits for a decode -- what a caller that may go on parsing asks before
  * it starts the eager DMVR rows (shim/rcn_hip.c with the caller patch: the CTU rows are then reported later instead of the parse
  * stopping here). */
+static int refs_rows_ready(ovhip_frame *f, const int32_t *need, int block);
+static void units_need_rows(ovhip_frame *f, const ovhip_band_counts *c0, const ovhip_band_counts *c1, int only_dmvr, int32_t *need);
+
 int
 ovhip_frame_refs_ready(ovhip_frame *f)
 {
     if (!f || !f->live) return OVHIP_EINVAL;
+    if (f->band_mode) {
+        /* row-granular: the rows the DMVR units recorded since the last eager pass reach in each reference picture (rcn_inter.c:131-146
+         * waits for exactly those, per block) */
+        ovhip_band_counts c0, c1;
+        int32_t need[MAX_REFS];
+        memset(&c0, 0, sizeof(c0));
+        ovhip_rec_counts(ovhip_frame_recorder(f), &c1);
+        const int64_t done = f->dry ? f->dry_done : (f->job ? ovhip_job_dmvr_rows_collect(f->job) : 0);
+        if (done < 0) return fail(f, (int)done, "ovhip_job_dmvr_rows_collect");
+        c0.n_mcx = (uint32_t)done; c0.n_mc = c1.n_mc; c0.n_aff = c1.n_aff;
+        units_need_rows(f, &c0, &c1, 1, need);
+        return refs_rows_ready(f, need, 0);
+    }
     for (int i = 0; i < f->n_refs; ++i) {
         if (f->ref_pinned[i]) continue;
         const int r = ovhip_dpb_poll_tag(f->dpb, f->ref_key[i], f->ref_tag[i]);
@@ -266,7 +289,16 @@ ovhip_frame_dmvr_rows_begin(ovhip_frame *f, int32_t log2_ctu_s)
     const ovhip_mc_unit *u = ovhip_rec_mcx_units(ovhip_frame_recorder(f), &nu);
     int any = 0;
     for (size_t i = (size_t)c; i < nu && !any; ++i) any = (u[i].flags & OVHIP_MC_DMVR) != 0;
-    if (any) {
+    if (any && f->band_mode) {
+        ovhip_band_counts c0, c1;
+        int32_t need[MAX_REFS];
+        memset(&c0, 0, sizeof(c0));
+        ovhip_rec_counts(ovhip_frame_recorder(f), &c1);
+        c0.n_mcx = (uint32_t)c; c0.n_mc = c1.n_mc; c0.n_aff = c1.n_aff;
+        units_need_rows(f, &c0, &c1, 1, need);
+        int r = refs_rows_ready(f, need, 1);
+        if (r < 0) return r;
+    } else if (any) {
         int r = acquire_refs(f);
         if (r != OVHIP_OK) return r;
     }
@@ -352,4 +384,161 @@ ovhip_frame_submit(ovhip_frame *f, ovhip_job *job, const ovhip_pic *intra, const
         if (r != OVHIP_OK) fail(f, r, "picture output");
     }
     return r;
+}
+
+/* ------------------------------------------------------------------------------------------------ band-wise submission
+ * ovhip_job_band under the device DPB's row progress: a band goes to the device when the rows its units read are final in every
+ * reference picture (the producer's posted records, seen complete on the HOST: no barrier enters the stream); a band that is not
+ * there yet is simply left to the next call, which takes everything recorded since the last band that went -- the parse never waits,
+ * except in the picture's last call.  Mirrors rcn_inter_synchronization (rcn_inter.c:131-146) + ovdpb_report_decoded_ctu_line
+ * (dpb.c:1309-1323) at band granularity. */
+int
+ovhip_frame_set_band_mode(ovhip_frame *f, int on)
+{
+    if (!f) return OVHIP_EINVAL;
+    f->band_mode = on != 0;
+    return OVHIP_OK;
+}
+
+/* luma rows [0, need[i]) of reference i are read by the units [c0, c1) (0: not used): the unit's last row + the vertical vector +
+ * 8 rows -- the 8-tap window's 4 rows below, DMVR's 2-sample search range, BDOF's extension, and the chroma windows (2 chroma rows
+ * = 4 luma rows below the co-located row) all stay inside it */
+static void
+units_need_rows(ovhip_frame *f, const ovhip_band_counts *c0, const ovhip_band_counts *c1, int only_dmvr, int32_t *need)
+{
+    ovhip_recorder *rec = ovhip_frame_recorder(f);
+    size_t n = 0;
+    for (int i = 0; i < MAX_REFS; ++i) need[i] = 0;
+    if (!rec) return;
+#define NEED(ref, y_last, mvy) do { int32_t v_ = (int32_t)(y_last) + ((mvy) >> 4) + 1 + 8; if (v_ < 1) v_ = 1; if (v_ > f->h) v_ = f->h; \
+                                    if ((ref) < MAX_REFS && need[ref] < v_) need[ref] = v_; } while (0)
+    for (int pass = 0; pass < 2; ++pass) {
+        const ovhip_mc_unit *u = pass ? ovhip_rec_mcx_units(rec, &n) : ovhip_rec_mc_units(rec, &n);
+        const size_t a = pass ? c0->n_mcx : c0->n_mc, b = pass ? c1->n_mcx : c1->n_mc;
+        for (size_t i = a; i < b && i < n; ++i) {
+            if (only_dmvr && !(u[i].flags & OVHIP_MC_DMVR)) continue;
+            const int y_last = u[i].y + u[i].h - 1;
+            if (u[i].dir & 1) NEED(u[i].ref0, y_last, u[i].mv0y);
+            if (u[i].dir & 2) NEED(u[i].ref1, y_last, u[i].mv1y);
+        }
+    }
+    if (!only_dmvr) {
+        const ovhip_aff_unit *au = ovhip_rec_aff_units(rec, &n);
+        size_t ns = 0;
+        const int32_t *side = ovhip_rec_aff_side(rec, &ns);
+        for (size_t i = c0->n_aff; i < c1->n_aff && i < n; ++i) {
+            const int n_sub = (au[i].w / 4) * (au[i].h / 4) + (au[i].w / 8) * (au[i].h / 8);
+            const int y_last = au[i].y + au[i].h - 1;
+            int32_t m0 = -(1 << 30), m1 = -(1 << 30);
+            for (int k = 0; k < n_sub && (size_t)au[i].side_off + 4 * (size_t)k + 3 < ns; ++k) {
+                const int32_t *q = side + au[i].side_off + 4 * k;
+                if (q[1] > m0) m0 = q[1];
+                if (q[3] > m1) m1 = q[3];
+            }
+            if (m0 == -(1 << 30)) m0 = m1 = f->h * 16;                 /* (no vectors found: the whole picture) */
+            if (au[i].dir & 1) NEED(au[i].ref0, y_last, m0);
+            if (au[i].dir & 2) NEED(au[i].ref1, y_last, m1);
+        }
+    }
+#undef NEED
+}
+
+/* 1: every reference has the rows (pinned, f->ref_pic[] filled), 0: not yet (block == 0 only), < 0: error */
+static int
+refs_rows_ready(ovhip_frame *f, const int32_t *need, int block)
+{
+    for (int i = 0; i < f->n_refs; ++i) {
+        /* a table entry none of these units reads stays a placeholder of the right geometry (the launchers check every entry of the
+         * table; no unit of the launch indexes this one): the picture being decoded itself */
+        if (!need[i]) { if (!f->ref_pinned[i]) f->ref_pic[i] = f->dst; continue; }
+        void *ev = NULL;
+        ovhip_pic pic;
+        int r = ovhip_dpb_rows_tag(f->dpb, f->ref_key[i], f->ref_tag[i], f->dev, need[i], block, !f->ref_pinned[i], &pic, &ev);
+        if (r < 0) return fail(f, r, r == OVHIP_EREF ? "a reference picture failed to decode" : "reference picture unknown to the device DPB");
+        if (!r) return 0;
+        f->ref_pic[i] = pic; f->ref_pinned[i] = 1;
+        if (ev) {
+            r = ovhip_dpb_wait_copy(f->dpb, f->dev, ev);
+            if (r != OVHIP_OK) return fail(f, r, "transfer of a reference picture");
+        }
+    }
+    return 1;
+}
+
+/* rows a band-wise job has made final once the band ending at `prev_end` has had its filters (ovvc_picture.hip: deblocking
+ * leaves the 8 rows above a band's end to the next band, SAO and ALF follow in steps of 64 rows) -- what a dry frame posts */
+static int32_t
+dry_rows_after(int32_t prev_end)
+{
+    int32_t v = prev_end - 8 - 1;
+    v = v <= 0 ? 0 : v & ~63;
+    v -= 3;
+    return v <= 0 ? 0 : v & ~63;
+}
+
+int
+ovhip_frame_band(ovhip_frame *f, const ovhip_job_params *params, int32_t row_end, int32_t last, ovhip_frame_output *out)
+{
+    if (!f || !params || !f->live) return OVHIP_EINVAL;
+    int r = f->status;
+    if (r != OVHIP_OK) {
+        /* a latched error: nothing more goes to the device; the last call publishes the picture as failed */
+        trace(f, OVHIP_FE_BAND, f->key, 0, row_end, last, r);
+        if (last) (void)publish(f, r);
+        return r;
+    }
+    if (last) row_end = f->h;
+    if (row_end > f->h) row_end = f->h;
+    ovhip_job *j = f->dry ? NULL : ovhip_frame_job(f);
+    if (!f->dry && !j) return fail(f, OVHIP_EINVAL, "ovhip_frame_band: no job");
+    ovhip_band_counts now;
+    ovhip_rec_counts(ovhip_frame_recorder(f), &now);
+    int32_t need[MAX_REFS];
+    units_need_rows(f, &f->band_prev, &now, 0, need);
+    r = refs_rows_ready(f, need, last != 0);
+    if (r < 0) { trace(f, OVHIP_FE_BAND, f->key, 0, row_end, last, r); if (last) (void)publish(f, r); return r; }
+    if (!r) { f->n_deferred++; trace(f, OVHIP_FE_BAND, f->key, 0, row_end, last, 0); return 0; }
+    int32_t rows = 0; void *ev = NULL; const volatile uint32_t *abw = NULL;
+    if (f->dry) {
+        rows = last ? f->h : dry_rows_after(f->band_row_prev);
+        r = OVHIP_OK;
+    } else {
+        r = ovhip_job_band(j, &f->dst, f->ref_pic, (uint32_t)f->n_refs, params, NULL, row_end, last);
+        if (r != OVHIP_OK) fail(f, r, "ovhip_job_band");
+        else (void)ovhip_job_band_progress(j, &rows, &ev, &abw);
+    }
+    f->band_prev = now; f->band_row_prev = row_end; f->n_bands++;
+    trace(f, OVHIP_FE_BAND, f->key, 0, row_end, last, r == OVHIP_OK ? 1 : r);
+    if (r == OVHIP_OK && !last && rows > f->band_rows_posted) {
+        (void)ovhip_dpb_post_rows(f->dpb, f->key, rows, ev, abw);
+        f->band_rows_posted = rows;
+    }
+    if (!last) return r == OVHIP_OK ? 1 : r;
+    /* the picture's end: as ovhip_frame_submit -- only the wait marks it complete */
+    if (r == OVHIP_OK && !f->dry) {
+        int q = ovhip_job_wait(j);
+        f->done_at = mono_s();
+        if (q != OVHIP_OK) r = fail(f, q, "ovhip_job_wait");
+    }
+    if (f->status) r = f->status;
+    (void)publish(f, r);
+    if (r == OVHIP_OK && !f->dry && out && out->mode != OVHIP_OUT_NONE) {
+        switch (out->mode) {
+        case OVHIP_OUT_DIGEST: r = ovhip_pic_digest(f->ctx, &f->dst, &out->window, out->digest); break;
+        case OVHIP_OUT_PLANES: r = ovhip_pic_download(f->ctx, &f->dst, out->y, out->cb, out->cr, out->stride_y, out->stride_c); break;
+        case OVHIP_OUT_PACKED: r = ovhip_pic_output(f->ctx, &f->dst, &out->window, out->packed); break;
+        default: r = OVHIP_EINVAL;
+        }
+        if (r != OVHIP_OK) fail(f, r, "picture output");
+    }
+    return r == OVHIP_OK ? 1 : r;
+}
+
+int
+ovhip_frame_band_stats(const ovhip_frame *f, int32_t *n_bands, int32_t *n_deferred)
+{
+    if (!f) return OVHIP_EINVAL;
+    if (n_bands) *n_bands = f->n_bands;
+    if (n_deferred) *n_deferred = f->n_deferred;
+    return OVHIP_OK;
 }

@@ -1072,7 +1072,6 @@ extern "C" int ovhip_job_band(ovhip_job *j, const ovhip_pic *dst, const ovhip_pi
     if (row_end > j->h) row_end = j->h;
     const int first_band = !bs->active;
     if (first_band) {
-        // an eager DMVR pass nobody collected must not be in flight over a re-allocation (as ovhip_job_flush)
         memset(&j->st, 0, sizeof(j->st));
         bs->active = 1; bs->n = 0; bs->tails = 0; bs->closed = 0; bs->failed = 0;
         bs->dst = *dst; bs->row_prev = 0; bs->dbf_rows = bs->sao_rows = bs->alf_rows = bs->rows_final = 0;
@@ -1080,7 +1079,7 @@ extern "C" int ovhip_job_band(ovhip_job *j, const ovhip_pic *dst, const ovhip_pi
         bs->log2_ctu = log2_ctu; bs->filters_latched = 0; bs->lmcs_up = 0; bs->alf_up = 0; bs->have_luts = 0;
         bs->stages = pr->stages ? pr->stages : 0xffffffffu;
         bs->last_event = nullptr; bs->last_rows = 0;
-        j->again.valid = 0; j->n_retries = 0; j->n_mv = 0; j->n_tmvp = 0;
+        j->again.valid = 0; j->n_retries = 0;       // (n_mv / n_tmvp: the eager DMVR rows' -- a pass may have run before the first band)
         if (!j->res.y) CHK(ovhip_pic_alloc(ctx, j->w, j->h, &j->res));
         if (!j->d_flow) {
             const size_t words = ovhip_intra_flow_words(j->w, j->h);

@@ -619,7 +619,7 @@ struct gp_thread {
                                                  * several threads at once: "cont") */
     double t_busy, t_hooks;                     /* seconds with a picture in hand / of them inside the row-end and attach hooks (device waits, flush) */
     double t_sync;                              /* ... waiting for CTU rows of the collocated picture (tmvp_inter_synchronization) */
-    double t_shim_hooks, t_shim_device; uint64_t n_shim_calls;      /* the shim's own profile (ovhip_shim_get_profile), "profile" */
+    double t_shim_hooks, t_shim_device; uint64_t n_shim_calls; uint32_t bands_sent, bands_deferred;      /* the shim's own profile (ovhip_shim_get_profile), "profile" */
     int n_done, err, frames_differing;
     uint64_t samples_differing, mv_cells_differing, mv_cells_compared;
 };
@@ -627,7 +627,7 @@ static int g_next_pic;
 static int *g_readers_left;                     /* pictures still to read picture k (+ 1: its own comparison) */
 static __thread struct gp_thread *tls_thread;
 static void gp_sync_waited(double seconds) { if (tls_thread) tls_thread->t_sync += seconds; }
-static int g_profile, g_noout;
+static int g_profile, g_noout, g_bands = -1;
 static double g_prof_overhead;
 
 static void gp_t_attach(struct OVRCNCtx *const r, const OVFrame *const f, const struct RectEntryInfo *const e, uint8_t l2)
@@ -765,6 +765,7 @@ gp_worker(void *arg)
             gp_decode_kept(t, k);
             t->t_busy += gp_now() - t0;
         }
+        ovhip_shim_band_stats(t->c, &t->bands_sent, &t->bands_deferred);
         if (g_profile && g_pass_shim == 3) {
             ovhip_shim_profile pr;
             if (ovhip_shim_get_profile(t->c, &pr, 0) == 0) { t->t_shim_hooks = pr.seconds_in_hooks; t->t_shim_device = pr.seconds_device; t->n_shim_calls = pr.n_calls; g_prof_overhead = pr.seconds_overhead_per_call; }
@@ -838,6 +839,7 @@ run_stream_threads(struct gp_seq *s, const struct gp_pic_desc *desc, int n_pic, 
     memset(tot, 0, sizeof(*tot));
     for (int i = 0; i < n_threads; ++i) {
         tot->t_sync += th[i].t_sync; tot->t_shim_hooks += th[i].t_shim_hooks; tot->t_shim_device += th[i].t_shim_device; tot->n_shim_calls += th[i].n_shim_calls;
+        tot->bands_sent += th[i].bands_sent; tot->bands_deferred += th[i].bands_deferred;
         tot->t_busy += th[i].t_busy; tot->t_hooks += th[i].t_hooks; tot->n_done += th[i].n_done; tot->frames_differing += th[i].frames_differing;
         tot->samples_differing += th[i].samples_differing; tot->mv_cells_differing += th[i].mv_cells_differing; tot->mv_cells_compared += th[i].mv_cells_compared;
         if (th[i].err && !tot->err) tot->err = th[i].err;
@@ -886,6 +888,7 @@ gp_main(int argc, char **argv)
         else if (!strcmp(argv[i], "norelease")) g_no_release = 1;
         else if (!strcmp(argv[i], "profile")) g_profile = 1;      /* live: the shim's own split of a frame thread's time (ovhip_shim_set_profile) */
         else if (!strcmp(argv[i], "noout")) g_noout = 1;          /* live: OVHIP_OUT_NONE -- the pictures stay on the device (no copy into the OVFrame, frames not compared) */
+        else if (!strcmp(argv[i], "bands") && i + 1 < argc) g_bands = atoi(argv[++i]);      /* CTU rows per band (ovhip_shim_set_bands); default: the shim's */
         else if (!strcmp(argv[i], "live")) want_live = 1;      /* the shim on the real device, on frame threads; compares in process, prints a JSON line */
         else if (!strcmp(argv[i], "threads") && i + 1 < argc) {
             for (const char *q = argv[++i]; *q && g_n_thread_list < 16;) { g_thread_list[g_n_thread_list++] = atoi(q); while (*q && *q != ',') ++q; if (*q) ++q; }
@@ -992,6 +995,7 @@ gp_main(int argc, char **argv)
         g_pass_shim = want_live ? 3 : 2;
         if (want_live && g_profile) ovhip_shim_set_profile(1);
         if (want_live && g_noout) ovhip_shim_set_output(OVHIP_OUT_NONE);
+        if (g_bands >= 0) ovhip_shim_set_bands(g_bands);
         int bad = 0;
         const int n_one = n_pic;
         struct gp_pic_desc *gop_all = gop;
@@ -1021,16 +1025,17 @@ gp_main(int argc, char **argv)
                    "\"pictures_decoded\": %d, \"shim_error\": %d, \"frames_differing\": %d, \"samples_differing\": %llu, \"collocated_motion_entries_differing\": %llu, \"collocated_motion_entries_compared\": %llu, "
                    "\"dmvr_calls\": %zu, \"thread_seconds_with_a_picture\": %.6f, \"thread_seconds_in_row_end_and_attach_hooks\": %.6f, "
                    "\"reference_pass_seconds_inside_slicedec\": %.6f, \"reference_pass_seconds\": %.6f, \"repetitions\": %d, \"host_frames_made\": %d, \"host_frames_recycled\": %d, \"output\": \"%s\", "
-                   "\"thread_seconds_waiting_for_collocated_rows\": %.6f, \"shim_profile\": %d, \"thread_seconds_in_shim_hooks\": %.6f, \"thread_seconds_in_shim_device_half\": %.6f, \"shim_hook_calls\": %llu, \"shim_profile_overhead_seconds_per_call\": %.3e, \"copies_back_to_back\": %d}\n",
+                   "\"thread_seconds_waiting_for_collocated_rows\": %.6f, \"shim_profile\": %d, \"thread_seconds_in_shim_hooks\": %.6f, \"thread_seconds_in_shim_device_half\": %.6f, \"shim_hook_calls\": %llu, \"shim_profile_overhead_seconds_per_call\": %.3e, \"copies_back_to_back\": %d, \"bands_sent\": %u, \"bands_left_to_a_later_hook\": %u}\n",
                    want_live ? "live" : "device_dry_threads", g_threads, n_pic, W, H, wall, n_pic / wall, tot.n_done, tot.err, tot.frames_differing,
                    (unsigned long long)tot.samples_differing, (unsigned long long)tot.mv_cells_differing, (unsigned long long)tot.mv_cells_compared, g_dmvr_log.n / 12, tot.t_busy, tot.t_hooks,
                    g_decode_seconds_pass[0], t_ref, g_reps, g_frames_made, g_frames_recycled, g_noout ? "none" : "planes into the OVFrame",
-                   tot.t_sync, g_profile, tot.t_shim_hooks, tot.t_shim_device, (unsigned long long)tot.n_shim_calls, g_prof_overhead, g_cont);
+                   tot.t_sync, g_profile, tot.t_shim_hooks, tot.t_shim_device, (unsigned long long)tot.n_shim_calls, g_prof_overhead, g_cont, tot.bands_sent, tot.bands_deferred);
             fflush(stdout);
             bad |= tot.err || tot.samples_differing || tot.mv_cells_differing || tot.n_done != n_pic;
         }
         return bad;
     }
+    ovhip_shim_set_bands(g_bands >= 0 ? g_bands : 0);     /* (the committed device-mode fixtures hold the whole-picture call sequence) */
     for (g_pass_shim = 0; g_pass_shim <= want_shim + want_dev; ++g_pass_shim) {
         g_seed = 0x266 + 4242;
         g_dmvr_pos = 0;

@@ -107,6 +107,8 @@ struct hip_entry {
     size_t n_refined;                    /* refined units recorded (BDOF and DMVR: the index space of the device's results)      */
     size_t dmvr_done;                    /* ... whose vectors are already in the picture's TMVP planes                            */
     size_t row_mark;                     /* ... recorded when the last row-end hook ran                                           */
+    int band_on;                         /* this picture goes to the device band by band (ovhip_frame_band), not at its end        */
+    uint32_t n_bands_sent, n_bands_deferred;
     /* prediction calls being collected into one CU */
     struct {
         int kind, x0, y0, n, cols, rows_done, cur_col;
@@ -1216,6 +1218,7 @@ hip_sao_filter_line(OVCTUDec *const c, const struct RectEntryInfo *const einfo, 
 }
 
 static void dmvr_rows_step(struct hip_entry *e, OVCTUDec *c, int final);
+static void band_step(struct hip_entry *e, OVCTUDec *c, int rows_parsed);
 
 static void
 hip_sao_first_pix_rows(OVCTUDec *const c, const struct RectEntryInfo *const einfo, uint16_t ctb_y)
@@ -1223,8 +1226,8 @@ hip_sao_first_pix_rows(OVCTUDec *const c, const struct RectEntryInfo *const einf
     ENTER(c);
     /* the only hook that runs at the end of row 0 (slicedec.c:934-941): the eager DMVR pass over that row starts here */
     if (!e->record_only && einfo->nb_ctu_h > 1) dmvr_rows_step(e, c, 0);
-    if (!c->sao_info.sao_luma_flag && !c->sao_info.sao_chroma_flag) return;
-    sao_row(e, c, einfo, ctb_y);
+    if (c->sao_info.sao_luma_flag || c->sao_info.sao_chroma_flag) sao_row(e, c, einfo, ctb_y);
+    if (!e->record_only && einfo->nb_ctu_h > 1) band_step(e, c, 1);
 }
 
 static void flush_picture(struct hip_entry *e, OVCTUDec *c);
@@ -1379,6 +1382,9 @@ hip_alf_filter_line(OVCTUDec *const c, const struct RectEntryInfo *const einfo, 
     if (e->record_only) return;
     dmvr_rows_step(e, c, last);
     if (last) flush_picture(e, c);
+    /* this hook runs at the end of CTU row ctb_y + 1 (decode_ctu_line, slicedec.c:934-956) -- except for the picture's last two lines,
+     * which both run at its end: the band of the second to last is left to the flush that follows at once */
+    else if (ctb_y + 2 < einfo->nb_ctu_h) band_step(e, c, ctb_y + 2);
 }
 
 /* ------------------------------------------------------------------------------------ picture begin / flush / plumbing */
@@ -1490,6 +1496,60 @@ ovhip_shim_frame_digest(const OVCTUDec *c, const OVFrame *frame, uint8_t out[16]
     return ovhip_pic_digest(ctx, &pic, &w, out);
 }
 
+/* picture-level side information of the flush / of a band.  by_flags: the filters are on when the slice says so (a band is submitted
+ * before every row's hooks have run; the parameter arrays hold what the hooks have delivered, which is what the band's filters reach) */
+static void
+picture_params(struct hip_entry *e, OVCTUDec *c, ovhip_job_params *pr, int by_flags)
+{
+    memset(pr, 0, sizeof(*pr));
+    pr->lmcs = (c->lmcs_info.lmcs_enabled_flag && e->have_luts) ? &e->luts : NULL;
+    const struct ALFInfo *ai = &c->alf_info;
+    const int sao_on = by_flags ? (c->sao_info.sao_luma_flag || c->sao_info.sao_chroma_flag) && e->sao : e->sao_on;
+    const int alf_on = by_flags ? (ai->alf_luma_enabled_flag || ai->alf_cb_enabled_flag || ai->alf_cr_enabled_flag) && e->alf : e->alf_on;
+    pr->sao = sao_on ? e->sao : NULL;
+    if (alf_on) {
+        const RCNALF *ra = &c->alf_info.rcn_alf;
+        if (by_flags) {
+            if (ai->aps_cc_alf_data_cb) memcpy(e->alf_cc[0], ai->aps_cc_alf_data_cb->alf_cc_mapped_coeff[0], sizeof(e->alf_cc[0]));
+            if (ai->aps_cc_alf_data_cr) memcpy(e->alf_cc[1], ai->aps_cc_alf_data_cr->alf_cc_mapped_coeff[1], sizeof(e->alf_cc[1]));
+        }
+        pr->alf_ctus = e->alf;
+        pr->alf_luma_coeff = &ra->filter_coeff_dec[0][0]; pr->alf_luma_clip = &ra->filter_clip_dec[0][0];
+        pr->alf_chroma_coeff = &ra->chroma_coeff_final[0][0]; pr->alf_chroma_clip = &ra->chroma_clip_final[0][0];
+        pr->alf_cc_coeff = &e->alf_cc[0][0][0];
+    }
+    pr->log2_ctu_s = e->log2_ctu;
+}
+
+/* Band-wise submission (ovhip_frame_band; OVVC_HIP_BANDS = CTU rows per band, 0 = off): at the end of every g_band_rows-th CTU row
+ * what has been recorded since the last band goes to the device -- upload, prediction, residuals, ordered pass at once; the filters one
+ * band late -- while the parse goes on; the rows the band's filters made final are posted to the device DPB, where the frame threads
+ * that reference this picture see them (slicedec.c:815-975 + dpb.c:1309-1323 do this per CTU row on the host).  A band whose
+ * reference rows are not there yet is left to the next hook; only the picture's end waits. */
+static int g_band_rows = 1, g_band_rows_set;
+/* CTU rows per band; 0: every picture is submitted at its end (ovhip_frame_submit).  Overrides OVVC_HIP_BANDS. */
+void ovhip_shim_set_bands(int ctu_rows_per_band) { g_band_rows = ctu_rows_per_band < 0 ? 0 : ctu_rows_per_band; g_band_rows_set = 1; }
+void
+ovhip_shim_band_stats(const OVCTUDec *c, uint32_t *sent, uint32_t *deferred)
+{
+    struct hip_entry *e = entry_of(c, 0);
+    if (sent) *sent = e ? e->n_bands_sent : 0;
+    if (deferred) *deferred = e ? e->n_bands_deferred : 0;
+}
+
+static void
+band_step(struct hip_entry *e, OVCTUDec *c, int rows_parsed)
+{
+    if (!e->band_on || !e->fr || e->err || g_band_rows <= 0 || rows_parsed % g_band_rows) return;
+    ovhip_job_params pr;
+    picture_params(e, c, &pr, 1);
+    PROF_DEVICE_BEGIN(e);
+    const int r = ovhip_frame_band(e->fr, &pr, rows_parsed << e->log2_ctu, 0, NULL);
+    PROF_DEVICE_END(e);
+    if (r < 0) latch(e, r, "ovhip_frame_band");
+    else if (r) e->n_bands_sent++; else e->n_bands_deferred++;
+}
+
 static void
 flush_picture(struct hip_entry *e, OVCTUDec *c)
 {
@@ -1500,17 +1560,7 @@ flush_picture(struct hip_entry *e, OVCTUDec *c)
         return;
     }
     ovhip_job_params pr;
-    memset(&pr, 0, sizeof(pr));
-    pr.lmcs = (c->lmcs_info.lmcs_enabled_flag && e->have_luts) ? &e->luts : NULL;
-    pr.sao = e->sao_on ? e->sao : NULL;
-    if (e->alf_on) {
-        const RCNALF *ra = &c->alf_info.rcn_alf;
-        pr.alf_ctus = e->alf;
-        pr.alf_luma_coeff = &ra->filter_coeff_dec[0][0]; pr.alf_luma_clip = &ra->filter_clip_dec[0][0];
-        pr.alf_chroma_coeff = &ra->chroma_coeff_final[0][0]; pr.alf_chroma_clip = &ra->chroma_clip_final[0][0];
-        pr.alf_cc_coeff = &e->alf_cc[0][0][0];
-    }
-    pr.log2_ctu_s = e->log2_ctu;
+    picture_params(e, c, &pr, e->band_on);
     /* the decoder's own output path and any host-side reader expect the samples in the OVFrame (dectest.c:372-409): copied out
      * AFTER ovhip_job_wait (which may decode the picture a second time) and after the picture was published to its readers */
     ovhip_frame_output out;
@@ -1521,7 +1571,8 @@ flush_picture(struct hip_entry *e, OVCTUDec *c)
     out.stride_y = (int32_t)(f->linesize[0] / 2); out.stride_c = (int32_t)(f->linesize[1] / 2);
     /* (every refined vector is in the TMVP planes already: dmvr_rows_step(final) ran in the hook that called this) */
     PROF_DEVICE_BEGIN(e);
-    latch(e, ovhip_frame_submit(e->fr, NULL, NULL, &pr, &out), "ovhip_frame_submit");
+    if (e->band_on) { const int r = ovhip_frame_band(e->fr, &pr, e->pic_h, 1, &out); latch(e, r < 0 ? r : OVHIP_OK, "ovhip_frame_band (last)"); e->n_bands_sent++; }
+    else latch(e, ovhip_frame_submit(e->fr, NULL, NULL, &pr, &out), "ovhip_frame_submit");
     PROF_DEVICE_END(e);
 }
 
@@ -1585,6 +1636,11 @@ begin_picture(struct hip_entry *e, const OVFrame *f, const struct RectEntryInfo 
     const OVPicture *cur = pl0 ? (const OVPicture *)((const char *)pl0 - offsetof(OVPicture, mv_plane0)) : NULL;
     latch(e, ovhip_frame_begin_tag(e->fr, f, cur && cur->frame == f ? pic_tag(cur) : 0), "ovhip_frame_begin");
     e->rec = ovhip_frame_recorder(e->fr);
+    /* band by band: pictures of one rect entry with inter slices.  An I picture's ordered pass is one dependency chain through the
+     * whole picture (the wavefront crosses the CTU rows): cut into bands it would run row after row; it is submitted whole, its
+     * readers see it when it is complete -- their bands are simply left to later hooks until then */
+    e->band_on = g_band_rows > 0 && e->whole_pic_entry && e->key->tmp_slice_type != 2;
+    (void)ovhip_frame_set_band_mode(e->fr, e->band_on);
     PROF_DEVICE_END(e);
     if (!e->rec) { latch(e, OVHIP_ENOMEM, "ovhip_frame_recorder"); return; }
     (void)ovhip_rec_set_ctu_size(e->rec, e->key->part_ctx ? e->key->part_ctx->log2_ctu_s : 7);
@@ -1656,6 +1712,7 @@ rcn_init_functions_hip(struct RCNFunctions *f, uint8_t ict_type, uint8_t lm_chro
     f->rcn_prof_mcp_b_l = &hip_rcn_prof_mcp_b_l;
     f->rcn_bdof_mcp_l = &hip_rcn_bdof_mcp_l;
     f->rcn_dmvr_mv_refine = &hip_rcn_dmvr_mv_refine;
+    if (!g_band_rows_set && getenv("OVVC_HIP_BANDS")) g_band_rows = atoi(getenv("OVVC_HIP_BANDS"));
 #ifdef OVVC_HIP_CALLER_PATCH
     f->rcn_cu_inter_b = &hip_rcn_cu_inter_b;
     f->rcn_affine_cu = &hip_rcn_affine_cu;

@@ -65,6 +65,10 @@ int  ovhip_shim_get_profile(const struct OVCTUDec *ctudec, ovhip_shim_profile *o
  * (default: an unmodified application reads the frame there, dectest.c:372-409) or OVHIP_OUT_NONE (the application takes its
  * frames through ovhip_shim_frame_output / _digest: no 24.9 MB copy per 4K picture).  Also: environment OVVC_HIP_OUTPUT=none. */
 void ovhip_shim_set_output(int mode);
+/* Band-wise submission (ovhip_frame_band): CTU rows per band; 0 = every picture goes to the device at its end (ovhip_frame_submit).
+ * Default 1; environment OVVC_HIP_BANDS.  Pictures with intra slices and pictures cut into rect entries are always submitted whole. */
+void ovhip_shim_set_bands(int ctu_rows_per_band);
+void ovhip_shim_band_stats(const struct OVCTUDec *ctudec, uint32_t *bands_sent, uint32_t *bands_deferred);
 struct ovhip_dpb;
 void ovhip_shim_set_dpb(struct ovhip_dpb *dpb);          /* the application's device DPB instead of the shim's own */
 /* Optional hook for ovframe_unref() reaching zero: the frame's device picture returns to the pool at once (otherwise when the
