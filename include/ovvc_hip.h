@@ -941,6 +941,7 @@ int64_t ovhip_job_dmvr_rows(ovhip_job *job, const ovhip_pic *refs, uint32_t n_re
  *             number of units whose results are valid: ovhip_job_refined_mvs()[.. 4 n], ovhip_job_tmvp_cells()[.. 4 n].  0 passes
  *             pending: returns at once.  ovhip_job_flush collects by itself. */
 int64_t ovhip_job_dmvr_rows_begin(ovhip_job *job, const ovhip_pic *refs, uint32_t n_refs, int32_t log2_ctu_s);
+int64_t ovhip_job_dmvr_rows_begin_upto(ovhip_job *job, const ovhip_pic *refs, uint32_t n_refs, int32_t log2_ctu_s, size_t upto_units);   /* units [.., upto) only */
 int64_t ovhip_job_dmvr_rows_collect(ovhip_job *job);
 int  ovhip_job_last_stats(const ovhip_job *job, ovhip_job_stats *out);
 /* ---- Band-wise submission: the picture enters the device while it is still being parsed (slicedec.c:815-975 reconstructs a CTU row
@@ -967,6 +968,7 @@ void ovhip_rec_counts(const ovhip_recorder *rec, ovhip_band_counts *out);
 int  ovhip_job_band(ovhip_job *job, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs, const ovhip_job_params *params,
                     const ovhip_band_counts *upto, int32_t row_end, int32_t last);
 int  ovhip_job_band_active(const ovhip_job *job);
+int  ovhip_job_band_busy(ovhip_job *job);          /* 1: the last band's reconstruction is still running (never blocks) */
 int  ovhip_job_band_progress(ovhip_job *job, int32_t *rows_final, void **event, const volatile uint32_t **abort_word);
 /* row windows of the two frame-wide filters (rows: multiples of 64, or the picture's height) */
 int  ovhip_sao_launch_rows(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *src, const ovhip_sao_ctu *d_params, int32_t log2_ctu_s,
@@ -1219,6 +1221,7 @@ int64_t ovhip_frame_dmvr_rows(ovhip_frame *f);
  * failed.  Never waits for a decode: a caller that can go on parsing asks this before it starts a row pass. */
 int  ovhip_frame_refs_ready(ovhip_frame *f);
 int64_t ovhip_frame_dmvr_rows_begin(ovhip_frame *f, int32_t log2_ctu_s);
+int64_t ovhip_frame_dmvr_rows_begin_upto(ovhip_frame *f, int32_t log2_ctu_s, size_t upto_units);
 int64_t ovhip_frame_dmvr_rows_collect(ovhip_frame *f);
 /* job: NULL = the frame's own job (the shim); else a job holding an already recorded picture of the same size, which is bound to
  * this frame's context for the flush (the stream driver's pre-recorded pictures).  intra: as ovhip_job_flush.  out: NULL =
@@ -1235,6 +1238,11 @@ int  ovhip_frame_submit(ovhip_frame *f, ovhip_job *job, const ovhip_pic *intra, 
  *   != 0 the call completes the picture exactly as ovhip_frame_submit does: wait, publish, output. */
 int  ovhip_frame_set_band_mode(ovhip_frame *f, int on);
 int  ovhip_frame_band(ovhip_frame *f, const ovhip_job_params *params, int32_t row_end, int32_t last, ovhip_frame_output *out);
+/* The same for a picture whose parse is AHEAD of its reference pictures (it has been recorded further than row_end): the band ends at the
+ * recorder's array lengths `upto` (ovhip_rec_counts taken when row_end had just been parsed), and with block != 0 the call waits for the
+ * reference rows instead of returning 0 -- how the picture's last hook works through the rows its references had not reached while it was
+ * parsed, row by row as they arrive, so that ITS rows reach ITS readers as early (never the picture's last band: use ovhip_frame_band). */
+int  ovhip_frame_band_upto(ovhip_frame *f, const ovhip_job_params *params, int32_t row_end, const ovhip_band_counts *upto, int32_t block);
 int  ovhip_frame_band_stats(const ovhip_frame *f, int32_t *n_bands, int32_t *n_deferred);
 int  ovhip_frame_fail(ovhip_frame *f, int status);
 const char *ovhip_frame_last_error(const ovhip_frame *f);

@@ -104,7 +104,7 @@ __device__ __forceinline__ void filter_idx(uint32_t sum_h, uint32_t sum_v, uint3
 
 // one 32x32 luma tile (workgroup `tile0` of the luma part of k_alf)
 __device__ __forceinline__ void alf_luma_tile(const ovhip_pic &dst, const ovhip_pic &src, const ovhip_alf_pic &alf, int nb_ctu_w,
-                                              int tile0, uint16_t *s_t, uint8_t *s_cls, uint4 *s_sum)
+                                              int tile0, uint16_t *s_t, uint8_t *s_cls, uint4 *s_sum, int row0, int row1)
 {
 
     const int W = src.w, H = src.h;
@@ -122,7 +122,7 @@ __device__ __forceinline__ void alf_luma_tile(const ovhip_pic &dst, const ovhip_
     const int ox = tx0 + bx, oy = ty0 + by + r;
 
     if (!on) {          // ALF off for this CTU: plain copy (dst is a separate picture)
-        if (oy < H) {
+        if (oy < H && oy >= row0 && oy < row1) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) if (ox + i < W) dst.y[oy * dst.stride_y + ox + i] = src.y[oy * src.stride_y + ox + i];
         }
@@ -217,7 +217,7 @@ __device__ __forceinline__ void alf_luma_tile(const ovhip_pic &dst, const ovhip_
     }
     __syncthreads();
 
-    if (oy >= H) continue;
+    if (oy >= H || oy < row0 || oy >= row1) continue;          // (row0, row1: the launch's row window; a 4x4 block lies inside or outside)
     const int ct = s_cls[b];
     const int cls = ct & 31, tr = ct >> 5;
     const int16_t *f = alf.luma_coeff + c.luma_set * OVHIP_ALF_LUMA_SET_SIZE + tr * 25 * 13 + cls * 13;
@@ -325,7 +325,7 @@ __device__ __forceinline__ void alf_luma_tile(const ovhip_pic &dst, const ovhip_
 
 // one 32x32 tile of chroma plane `comp` (1 Cb, 2 Cr)
 __device__ __forceinline__ void alf_chroma_tile(const ovhip_pic &dst, const ovhip_pic &src, const ovhip_alf_pic &alf, int nb_ctu_w,
-                                                int tile0, int comp, uint16_t *s_t)
+                                                int tile0, int comp, uint16_t *s_t, int row0, int row1)
 {
     const int W = src.w, H = src.h, Wc = W >> 1, Hc = H >> 1;
     const int tid = threadIdx.x;
@@ -375,7 +375,7 @@ __device__ __forceinline__ void alf_chroma_tile(const ovhip_pic &dst, const ovhi
     // lane: 4 consecutive samples of one row: row = tid >> 3 (0..31), x segment = (tid & 7) * 4
     const int ly = tid >> 3, lx0 = (tid & 7) * 4;
     const int oy = ty0 + ly;
-    if (oy >= Hc) continue;
+    if (oy >= Hc || oy < (row0 >> 1) || oy >= (row1 >> 1)) continue;
     int o1 = 1, o2 = 2;
     bool near = false;
     if (on) {
@@ -498,7 +498,7 @@ __device__ __forceinline__ void alf_chroma_tile(const ovhip_pic &dst, const ovhi
 
 // Luma and both chroma planes in ONE launch (they only share their input): workgroups [0, nl) take luma tiles,
 // [nl, nl + 2 * nc) the Cb then Cr tiles.  One kernel boundary less, and the chroma tiles fill the luma tail.
-__global__ __launch_bounds__(256) OV_OCC_ALF void k_alf(ovhip_pic dst, ovhip_pic src, ovhip_alf_pic alf, int nb_ctu_w, int nl, int nc, int t0_l, int t0_c)
+__global__ __launch_bounds__(256) OV_OCC_ALF void k_alf(ovhip_pic dst, ovhip_pic src, ovhip_alf_pic alf, int nb_ctu_w, int nl, int nc, int t0_l, int t0_c, int row0, int row1)
 {
     __shared__ __attribute__((aligned(16))) uint16_t s_t[(LW > CW ? LW : CW) * LWS];
     __shared__ uint8_t s_cls[64];
@@ -508,18 +508,19 @@ __global__ __launch_bounds__(256) OV_OCC_ALF void k_alf(ovhip_pic dst, ovhip_pic
     // (dealt round-robin, neighbouring tiles ran on different XCDs: every halo was fetched from memory once per XCD that needed it)
     const int b = blockIdx.x;
     // (t0_l / t0_c: first tile of the launch's row window in the luma / a chroma plane, ovhip_alf_launch_rows; 0 for a whole picture)
-    if (b < nl) alf_luma_tile(dst, src, alf, nb_ctu_w, t0_l + (int)ov_xcd_slot_at(b, 0, nl), s_t, s_cls, s_sum);
+    if (b < nl) alf_luma_tile(dst, src, alf, nb_ctu_w, t0_l + (int)ov_xcd_slot_at(b, 0, nl), s_t, s_cls, s_sum, row0, row1);
     else {
         const int comp = 1 + (b - nl) / nc;
-        alf_chroma_tile(dst, src, alf, nb_ctu_w, t0_c + (int)ov_xcd_slot_at(b, nl + (comp - 1) * nc, nc), comp, s_t);
+        alf_chroma_tile(dst, src, alf, nb_ctu_w, t0_c + (int)ov_xcd_slot_at(b, nl + (comp - 1) * nc, nc), comp, s_t, row0, row1);
     }
 }
 
 } // namespace
 
-// Rows [row0, row1) of the picture (luma rows; both multiples of 64 = one chroma tile row, or row1 = the picture's height): the
-// band-wise picture job (ovvc_picture.hip).  Reads src (the SAO output) rows row0 - 3 .. row1 + 2 -- luma taps and the 4x4
-// classification windows; the chroma tiles' CC-ALF taps reach luma row row1 -- and writes dst rows [row0, row1) only.
+// Rows [row0, row1) of the picture (luma rows; both multiples of 8, or row1 = the picture's height): the band-wise picture job
+// (ovvc_picture.hip).  Reads src (the SAO output) rows row0 - 3 .. row1 + 2 -- luma taps and the 4x4 classification windows; the
+// chroma tiles' CC-ALF taps reach luma row row1 -- and writes dst rows [row0, row1) only: the tiles the window cuts are staged and
+// classified whole (what lies outside it may not be final: its results are dropped), the stores of the rows outside are skipped.
 extern "C" int ovhip_alf_launch_rows(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *src, const ovhip_alf_pic *alf, int32_t row0, int32_t row1)
 {
     if (!ctx || !dst || !src || !alf) return OVHIP_EINVAL;
@@ -527,14 +528,14 @@ extern "C" int ovhip_alf_launch_rows(ovhip_ctx *ctx, const ovhip_pic *dst, const
     if (dst->w != src->w || dst->h != src->h || dst->y == src->y || alf->log2_ctu_s < 6 || alf->log2_ctu_s > 7 ||
         !alf->ctus || !alf->luma_coeff || !alf->luma_clip || !alf->chroma_coeff || !alf->chroma_clip || !alf->cc_coeff)
         return ov_fail(ctx, OVHIP_EINVAL, "ovhip_alf_launch: bad pictures / parameter tables", hipSuccess);
-    if (row0 < 0 || row1 > src->h || row0 > row1 || (row0 & 63) || ((row1 & 63) && row1 != src->h))
+    if (row0 < 0 || row1 > src->h || row0 > row1 || (row0 & 7) || ((row1 & 7) && row1 != src->h))
         return ov_fail(ctx, OVHIP_EINVAL, "ovhip_alf_launch_rows: row window", hipSuccess);
     if (row0 == row1) return OVHIP_OK;
     const int nb_ctu_w = (src->w + (1 << alf->log2_ctu_s) - 1) >> alf->log2_ctu_s;
     const int ntx_l = (src->w + TL - 1) / TL, ntx_c = (src->w / 2 + TL - 1) / TL;
     const int ty0_l = row0 / TL, ty1_l = (row1 + TL - 1) / TL, ty0_c = (row0 / 2) / TL, ty1_c = (row1 / 2 + TL - 1) / TL;
     const int nl = ntx_l * (ty1_l - ty0_l), nc = ntx_c * (ty1_c - ty0_c);
-    hipLaunchKernelGGL(k_alf, dim3(nl + 2 * nc), dim3(256), 0, ctx->stream, *dst, *src, *alf, nb_ctu_w, nl, nc, ty0_l * ntx_l, ty0_c * ntx_c);
+    hipLaunchKernelGGL(k_alf, dim3(nl + 2 * nc), dim3(256), 0, ctx->stream, *dst, *src, *alf, nb_ctu_w, nl, nc, ty0_l * ntx_l, ty0_c * ntx_c, row0, row1);
     OV_LAUNCH_CHECK(ctx, "k_alf");
     return OVHIP_OK;
 }

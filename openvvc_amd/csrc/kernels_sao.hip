@@ -28,7 +28,7 @@ __device__ __forceinline__ void load8(const uint16_t *p, bool vec, int n, int v[
 }
 
 __global__ __launch_bounds__(256) void k_sao(ovhip_pic dst, ovhip_pic src, const ovhip_sao_ctu *__restrict__ prm,
-                                              int log2_ctu, int nb_ctu_w, int tiles_y, int tiles_c, int ty0_y, int ty0_c)
+                                              int log2_ctu, int nb_ctu_w, int tiles_y, int tiles_c, int ty0_y, int ty0_c, int row0, int row1)
 {
     const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;          // 8 lanes x 8 samples per row, 32 rows
     // (plane, tile): luma tiles first, then Cb, then Cr; one tile per workgroup (single pass: `continue` leaves the tile)
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k_sao(ovhip_pic dst, ovhip_pic src, const
         const int ntx = (w + SAO_TW - 1) / SAO_TW;
         // (ty0_*: first tile row of the launch's row window, ovhip_sao_launch_rows; 0 for a whole picture)
         const int x0 = (tt % ntx) * SAO_TW + tx * 8, y = (tt / ntx + (c ? ty0_c : ty0_y)) * SAO_TH + ty;
-        if (x0 >= w || y >= h) continue;
+        if (x0 >= w || y >= h || y < (row0 >> sh) || y >= (row1 >> sh)) continue;      // (row0, row1: the launch's row window, luma rows)
         int ss, ds;
         const uint16_t *s = ov_plane(src, c, ss) + y * ss;
         uint16_t *d = ov_plane(dst, c, ds) + y * ds;
@@ -113,9 +113,10 @@ __global__ __launch_bounds__(256) void k_sao(ovhip_pic dst, ovhip_pic src, const
 
 } // namespace
 
-// Rows [row0, row1) of the picture (luma rows; both multiples of 64 = one chroma tile row, or row1 = the picture's height): what the
-// band-wise picture job runs behind the deblocking of a band (ovvc_picture.hip).  Reads src rows row0 - 1 .. row1 (the edge classes'
-// neighbours), writes dst rows [row0, row1) only.  The samples are computed exactly as by the whole-picture launch.
+// Rows [row0, row1) of the picture (luma rows; both multiples of 8, or row1 = the picture's height): what the band-wise picture job
+// runs behind the deblocking of a band (ovvc_picture.hip).  Reads src rows row0 - 1 .. row1 (the edge classes' neighbours), writes dst
+// rows [row0, row1) only -- the lanes of a tile's rows outside the window leave at once.  The samples are computed exactly as by the
+// whole-picture launch.
 extern "C" int ovhip_sao_launch_rows(ovhip_ctx *ctx, const ovhip_pic *dst, const ovhip_pic *src,
                                      const ovhip_sao_ctu *d_params, int32_t log2_ctu_s, int32_t row0, int32_t row1)
 {
@@ -123,7 +124,7 @@ extern "C" int ovhip_sao_launch_rows(ovhip_ctx *ctx, const ovhip_pic *dst, const
     OV_DEVICE(ctx);
     if (dst->w != src->w || dst->h != src->h || dst->y == src->y || log2_ctu_s < 5 || log2_ctu_s > 7)
         return ov_fail(ctx, OVHIP_EINVAL, "ovhip_sao_launch: bad pictures / CTU size", hipSuccess);
-    if (row0 < 0 || row1 > src->h || row0 > row1 || (row0 & 63) || ((row1 & 63) && row1 != src->h))
+    if (row0 < 0 || row1 > src->h || row0 > row1 || (row0 & 7) || ((row1 & 7) && row1 != src->h))
         return ov_fail(ctx, OVHIP_EINVAL, "ovhip_sao_launch_rows: row window", hipSuccess);
     if (row0 == row1) return OVHIP_OK;
     const int nb_ctu_w = (src->w + (1 << log2_ctu_s) - 1) >> log2_ctu_s;
@@ -134,7 +135,7 @@ extern "C" int ovhip_sao_launch_rows(ovhip_ctx *ctx, const ovhip_pic *dst, const
     const int total = tiles_y + 2 * tiles_c;
     // one workgroup per tile (measured: 18.7 us; a resident grid of 2048 workgroups 22.4 us, 1024: 26.5 us)
     hipLaunchKernelGGL(k_sao, dim3(total), dim3(256), 0, ctx->stream, *dst, *src, d_params,
-                       log2_ctu_s, nb_ctu_w, tiles_y, tiles_c, ty0_y, ty0_c);
+                       log2_ctu_s, nb_ctu_w, tiles_y, tiles_c, ty0_y, ty0_c, row0, row1);
     OV_LAUNCH_CHECK(ctx, "k_sao");
     return OVHIP_OK;
 }

@@ -44,7 +44,12 @@ struct ovhip_frame {
     ovhip_band_counts band_prev;
     int32_t band_row_prev, band_rows_posted, dry_row_prev2;
     int n_bands, n_deferred;
+    /* OVVC_HIP_FRAME_PROF=1: where the frame-level calls spend their wall time, printed when the frame is destroyed (seconds) */
+    double pt_collect, pt_rows_begin, pt_band_refs, pt_band_job, pt_final_refs, pt_job_wait, pt_output, pt_submit; int pn_pics;
 };
+static int g_frame_prof = -1;
+#define PT0() const double pt0_ = g_frame_prof > 0 ? mono_s() : 0.0
+#define PT(acc) do { if (g_frame_prof > 0) (acc) += mono_s() - pt0_; } while (0)
 
 /* ---- event trace (include/ovvc_hip.h, ovhip_frame_set_trace): WHEN a caller (shim/rcn_hip.c) makes its frame-level calls ---- */
 static void (*g_trace)(void *user, const ovhip_frame_event *ev);
@@ -98,6 +103,7 @@ ovhip_frame_create(ovhip_dpb *dpb, int dev, int32_t w, int32_t h, ovhip_frame **
     if (!f) return OVHIP_ENOMEM;
     f->dpb = dpb; f->dev = dev; f->w = w; f->h = h;
     f->id = __atomic_fetch_add(&g_next_id, 1, __ATOMIC_RELAXED);
+    if (g_frame_prof < 0) g_frame_prof = getenv("OVVC_HIP_FRAME_PROF") != NULL;
     if (hipdev < 0) {
         /* a DPB on a test back-end has no device to decode on: a dry frame (the caller's sequence of frame-level calls is the
          * subject, tests/test_shim_device_cpu.py); pictures "decode" to whatever the back-end's pic_alloc handed out */
@@ -125,6 +131,10 @@ ovhip_frame_destroy(ovhip_frame *f)
 {
     if (!f) return;
     if (f->live) (void)ovhip_frame_fail(f, OVHIP_EINVAL);
+    if (g_frame_prof > 0 && f->pn_pics)
+        fprintf(stderr, "frame %d: %d pictures, ms per picture: dmvr collect %.3f, dmvr begin %.3f, band refs check %.3f, band enqueue %.3f, last band: refs wait %.3f, job wait %.3f, output %.3f; whole submit %.3f\n",
+                f->id, f->pn_pics, 1e3 * f->pt_collect / f->pn_pics, 1e3 * f->pt_rows_begin / f->pn_pics, 1e3 * f->pt_band_refs / f->pn_pics, 1e3 * f->pt_band_job / f->pn_pics,
+                1e3 * f->pt_final_refs / f->pn_pics, 1e3 * f->pt_job_wait / f->pn_pics, 1e3 * f->pt_output / f->pn_pics, 1e3 * f->pt_submit / f->pn_pics);
     if (f->job) ovhip_job_destroy(f->job);
     if (f->dry_rec) ovhip_rec_destroy(f->dry_rec);
     if (f->ctx) ovhip_ctx_destroy(f->ctx);
@@ -277,16 +287,20 @@ ovhip_frame_dmvr_rows(ovhip_frame *f)
     return n;
 }
 
+int64_t ovhip_frame_dmvr_rows_begin(ovhip_frame *f, int32_t log2_ctu_s) { return ovhip_frame_dmvr_rows_begin_upto(f, log2_ctu_s, (size_t)-1); }
+
 int64_t
-ovhip_frame_dmvr_rows_begin(ovhip_frame *f, int32_t log2_ctu_s)
+ovhip_frame_dmvr_rows_begin_upto(ovhip_frame *f, int32_t log2_ctu_s, size_t upto)
 {
     if (!f || !f->live || (!f->job && !f->dry)) return OVHIP_EINVAL;
     /* the references are needed (and waited for) only if a unit the pass would cover is a DMVR unit: rows of BDOF-only units do not
      * stop the parse */
+    PT0();
     int64_t c = f->dry ? (f->dry_done = f->dry_pending) : ovhip_job_dmvr_rows_collect(f->job);
     if (c < 0) { fail(f, (int)c, "ovhip_job_dmvr_rows_collect"); return c; }
     size_t nu = 0;
     const ovhip_mc_unit *u = ovhip_rec_mcx_units(ovhip_frame_recorder(f), &nu);
+    if (nu > upto) nu = upto;
     int any = 0;
     for (size_t i = (size_t)c; i < nu && !any; ++i) any = (u[i].flags & OVHIP_MC_DMVR) != 0;
     if (any && f->band_mode) {
@@ -294,7 +308,7 @@ ovhip_frame_dmvr_rows_begin(ovhip_frame *f, int32_t log2_ctu_s)
         int32_t need[MAX_REFS];
         memset(&c0, 0, sizeof(c0));
         ovhip_rec_counts(ovhip_frame_recorder(f), &c1);
-        c0.n_mcx = (uint32_t)c; c0.n_mc = c1.n_mc; c0.n_aff = c1.n_aff;
+        c0.n_mcx = (uint32_t)c; c0.n_mc = c1.n_mc; c0.n_aff = c1.n_aff; c1.n_mcx = (uint32_t)nu;
         units_need_rows(f, &c0, &c1, 1, need);
         int r = refs_rows_ready(f, need, 1);
         if (r < 0) return r;
@@ -303,8 +317,9 @@ ovhip_frame_dmvr_rows_begin(ovhip_frame *f, int32_t log2_ctu_s)
         if (r != OVHIP_OK) return r;
     }
     int64_t n;
-    if (f->dry) n = f->dry_pending = (int64_t)nu;
-    else n = ovhip_job_dmvr_rows_begin(f->job, f->ref_pic, (uint32_t)f->n_refs, log2_ctu_s);
+    if (f->dry) n = f->dry_pending = (int64_t)nu > f->dry_pending ? (int64_t)nu : f->dry_pending;
+    else n = ovhip_job_dmvr_rows_begin_upto(f->job, f->ref_pic, (uint32_t)f->n_refs, log2_ctu_s, upto);
+    PT(f->pt_rows_begin);
     if (n < 0) fail(f, (int)n, "ovhip_job_dmvr_rows_begin");
     trace(f, OVHIP_FE_DMVR_BEGIN, f->key, 0, (int64_t)nu, any, n);
     return n;
@@ -314,7 +329,9 @@ int64_t
 ovhip_frame_dmvr_rows_collect(ovhip_frame *f)
 {
     if (!f || !f->live || (!f->job && !f->dry)) return OVHIP_EINVAL;
+    PT0();
     int64_t n = f->dry ? (f->dry_done = f->dry_pending) : ovhip_job_dmvr_rows_collect(f->job);
+    PT(f->pt_collect);
     if (n < 0) fail(f, (int)n, "ovhip_job_dmvr_rows_collect");
     trace(f, OVHIP_FE_DMVR_COLLECT, f->key, 0, (int64_t)n_refined_units(f), 0, n);
     return n;
@@ -344,6 +361,7 @@ int
 ovhip_frame_submit(ovhip_frame *f, ovhip_job *job, const ovhip_pic *intra, const ovhip_job_params *params, ovhip_frame_output *out)
 {
     if (!f || !params || !f->live) return OVHIP_EINVAL;
+    PT0();
     int r = f->status;                    /* a latched recorder error: the picture is published as failed, never launched */
     ovhip_job *j = job ? job : f->job;
     if (f->dry) {
@@ -383,6 +401,7 @@ ovhip_frame_submit(ovhip_frame *f, ovhip_job *job, const ovhip_pic *intra, const
         }
         if (r != OVHIP_OK) fail(f, r, "picture output");
     }
+    PT(f->pt_submit); f->pn_pics += !f->band_mode;
     return r;
 }
 
@@ -465,19 +484,31 @@ refs_rows_ready(ovhip_frame *f, const int32_t *need, int block)
     return 1;
 }
 
-/* rows a band-wise job has made final once the band ending at `prev_end` has had its filters (ovvc_picture.hip: deblocking
- * leaves the 8 rows above a band's end to the next band, SAO and ALF follow in steps of 64 rows) -- what a dry frame posts */
+/* rows a band-wise job has made final once the band ending at `end` has had its filters (ovvc_picture.hip: deblocking leaves
+ * the 8 rows above a band's end to the next band, SAO and ALF follow in steps of 8 rows) -- what a dry frame posts */
 static int32_t
-dry_rows_after(int32_t prev_end)
+dry_rows_after(int32_t end)
 {
-    int32_t v = prev_end - 8 - 1;
-    v = v <= 0 ? 0 : v & ~63;
+    int32_t v = end - 8 - 1;
+    v = v <= 0 ? 0 : v & ~7;
     v -= 3;
-    return v <= 0 ? 0 : v & ~63;
+    return v <= 0 ? 0 : v & ~7;
 }
 
-int
-ovhip_frame_band(ovhip_frame *f, const ovhip_job_params *params, int32_t row_end, int32_t last, ovhip_frame_output *out)
+static int frame_band(ovhip_frame *f, const ovhip_job_params *params, int32_t row_end, int32_t last, ovhip_frame_output *out, const ovhip_band_counts *upto, int block);
+
+int ovhip_frame_band(ovhip_frame *f, const ovhip_job_params *params, int32_t row_end, int32_t last, ovhip_frame_output *out)
+{
+    return frame_band(f, params, row_end, last, out, NULL, last != 0);
+}
+
+int ovhip_frame_band_upto(ovhip_frame *f, const ovhip_job_params *params, int32_t row_end, const ovhip_band_counts *upto, int32_t block)
+{
+    return frame_band(f, params, row_end, 0, NULL, upto, block != 0);
+}
+
+static int
+frame_band(ovhip_frame *f, const ovhip_job_params *params, int32_t row_end, int32_t last, ovhip_frame_output *out, const ovhip_band_counts *upto, int block)
 {
     if (!f || !params || !f->live) return OVHIP_EINVAL;
     int r = f->status;
@@ -491,19 +522,31 @@ ovhip_frame_band(ovhip_frame *f, const ovhip_job_params *params, int32_t row_end
     if (row_end > f->h) row_end = f->h;
     ovhip_job *j = f->dry ? NULL : ovhip_frame_job(f);
     if (!f->dry && !j) return fail(f, OVHIP_EINVAL, "ovhip_frame_band: no job");
+    /* the device is behind (the band before this one is still being reconstructed): this band is left to the next call, which takes
+     * its rows too -- fewer, fuller launches when the device is the slower side; an I picture's wavefront then spans the rows */
+    if (!block && j && f->n_bands && ovhip_job_band_busy(j)) { f->n_deferred++; trace(f, OVHIP_FE_BAND, f->key, 0, row_end, last, 0); return 0; }
     ovhip_band_counts now;
     ovhip_rec_counts(ovhip_frame_recorder(f), &now);
+    if (upto) {
+        const uint32_t *u = &upto->n_tb, *m = &now.n_tb, *lo = &f->band_prev.n_tb;
+        for (int i = 0; i < 10; ++i) if (u[i] > m[i] || u[i] < lo[i]) return fail(f, OVHIP_EINVAL, "ovhip_frame_band_upto: counts outside what has been recorded since the last band");
+        now = *upto;
+    }
     int32_t need[MAX_REFS];
+    { PT0();
     units_need_rows(f, &f->band_prev, &now, 0, need);
-    r = refs_rows_ready(f, need, last != 0);
+    r = refs_rows_ready(f, need, block);
+    if (last) PT(f->pt_final_refs); else PT(f->pt_band_refs); }
     if (r < 0) { trace(f, OVHIP_FE_BAND, f->key, 0, row_end, last, r); if (last) (void)publish(f, r); return r; }
     if (!r) { f->n_deferred++; trace(f, OVHIP_FE_BAND, f->key, 0, row_end, last, 0); return 0; }
     int32_t rows = 0; void *ev = NULL; const volatile uint32_t *abw = NULL;
     if (f->dry) {
-        rows = last ? f->h : dry_rows_after(f->band_row_prev);
+        rows = last ? f->h : dry_rows_after(row_end);
         r = OVHIP_OK;
     } else {
-        r = ovhip_job_band(j, &f->dst, f->ref_pic, (uint32_t)f->n_refs, params, NULL, row_end, last);
+        PT0();
+        r = ovhip_job_band(j, &f->dst, f->ref_pic, (uint32_t)f->n_refs, params, upto, row_end, last);
+        PT(f->pt_band_job);
         if (r != OVHIP_OK) fail(f, r, "ovhip_job_band");
         else (void)ovhip_job_band_progress(j, &rows, &ev, &abw);
     }
@@ -516,19 +559,24 @@ ovhip_frame_band(ovhip_frame *f, const ovhip_job_params *params, int32_t row_end
     if (!last) return r == OVHIP_OK ? 1 : r;
     /* the picture's end: as ovhip_frame_submit -- only the wait marks it complete */
     if (r == OVHIP_OK && !f->dry) {
+        PT0();
         int q = ovhip_job_wait(j);
+        PT(f->pt_job_wait);
         f->done_at = mono_s();
         if (q != OVHIP_OK) r = fail(f, q, "ovhip_job_wait");
     }
     if (f->status) r = f->status;
     (void)publish(f, r);
+    f->pn_pics++;
     if (r == OVHIP_OK && !f->dry && out && out->mode != OVHIP_OUT_NONE) {
+        PT0();
         switch (out->mode) {
         case OVHIP_OUT_DIGEST: r = ovhip_pic_digest(f->ctx, &f->dst, &out->window, out->digest); break;
         case OVHIP_OUT_PLANES: r = ovhip_pic_download(f->ctx, &f->dst, out->y, out->cb, out->cr, out->stride_y, out->stride_c); break;
         case OVHIP_OUT_PACKED: r = ovhip_pic_output(f->ctx, &f->dst, &out->window, out->packed); break;
         default: r = OVHIP_EINVAL;
         }
+        PT(f->pt_output);
         if (r != OVHIP_OK) fail(f, r, "picture output");
     }
     return r == OVHIP_OK ? 1 : r;

@@ -387,7 +387,15 @@ int64_t ovhip_job_dmvr_rows_collect(ovhip_job *j)
     return (int64_t)j->rows_end;
 }
 
+int64_t ovhip_job_dmvr_rows_begin_upto(ovhip_job *j, const ovhip_pic *refs, uint32_t n_refs, int32_t log2_ctu_s, size_t upto);
 int64_t ovhip_job_dmvr_rows_begin(ovhip_job *j, const ovhip_pic *refs, uint32_t n_refs, int32_t log2_ctu_s)
+{
+    return ovhip_job_dmvr_rows_begin_upto(j, refs, n_refs, log2_ctu_s, (size_t)-1);
+}
+
+/* the same over the refined units [.., upto) only (a caller that works through a parsed picture row by row as its reference
+ * pictures' rows arrive: shim/rcn_hip.c final_progressive) */
+int64_t ovhip_job_dmvr_rows_begin_upto(ovhip_job *j, const ovhip_pic *refs, uint32_t n_refs, int32_t log2_ctu_s, size_t upto)
 {
     if (!j) return OVHIP_EINVAL;
     // one pass in flight: the pinned result arrays may have to grow, and they keep the recorder's indexing
@@ -397,8 +405,9 @@ int64_t ovhip_job_dmvr_rows_begin(ovhip_job *j, const ovhip_pic *refs, uint32_t 
     OV_DEVICE(ctx);
     size_t n = 0;
     const ovhip_mc_unit *u = ovhip_rec_mcx_units(j->rec, &n);
+    if (n > upto) n = upto;
     const size_t first = j->dmvr_first;
-    if (n <= first) return (int64_t)n;
+    if (n <= first) return (int64_t)first;
     int any = 0;
     for (size_t i = first; i < n && !any; ++i) any = (u[i].flags & OVHIP_MC_DMVR) != 0;
     if (any) {
@@ -925,7 +934,35 @@ struct BandState {
     hipEvent_t ev_recon[MAX_BANDS], ev_tail[MAX_BANDS];
     uint32_t level_start[BAND_LEVELS + 2];
     void *last_event; int32_t last_rows;                          // what ovhip_job_band_progress hands out
+    uint16_t *keep; int keep_valid;                               // device: the previous band's bottom row before / after its filters (4 w samples)
 };
+
+// The bottom row of a band as the band below must see it.  Intra prediction, the cross-component model and the chroma-scale
+// derivation of band k + 1 read the row above it UNFILTERED and in the mapped domain (the reference keeps saved lines for this,
+// rcn_ctu.c:246-510), but band k's filters run with band k, so that its rows are final one band earlier: the row (luma row end - 1,
+// chroma rows end / 2 - 1) is set aside before the filters and put back for the time band k + 1 is reconstructed.  Nobody else reads
+// it meanwhile: rows within 8 of a band's end are not final -- not posted to readers, not reached by SAO / ALF -- before the
+// deblocking of the band below has run.  mode 0: keep_unf <- picture; 1: keep_fil <- picture, picture <- keep_unf (& mask);
+// 2: picture <- keep_fil.  keep = [unf: Y w | Cb w/2 | Cr w/2][fil: the same].
+__global__ __launch_bounds__(256) void k_band_row(ovhip_pic pic, uint16_t *keep, int row_y, int mode, unsigned mask)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, w = pic.w, wc = w >> 1;
+    if (i >= 2 * w) return;
+    uint16_t *p = i < w ? pic.y + (size_t)row_y * pic.stride_y + i
+                        : (i < w + wc ? pic.cb + (size_t)(row_y >> 1) * pic.stride_c + (i - w) : pic.cr + (size_t)(row_y >> 1) * pic.stride_c + (i - w - wc));
+    uint16_t *unf = keep + i, *fil = keep + 2 * w + i;
+    if (mode == 0) *unf = *p;
+    else if (mode == 1) { *fil = *p; *p = (uint16_t)(*unf & mask); }
+    else *p = *fil;
+}
+static int band_row(ovhip_job *j, const ovhip_pic *pic, int row_y, int mode, unsigned mask)
+{
+    hipLaunchKernelGGL(k_band_row, dim3((2 * pic->w + 255) / 256), dim3(256), 0, j->ctx->stream, *pic, j->bs->keep, row_y, mode, mask);
+    OV_LAUNCH_CHECK(j->ctx, "k_band_row");
+    j->st.n_launches++;
+    return OVHIP_OK;
+}
+
 
 // ---- flow budget: the workers of the band flow launches in flight on a device never exceed the wave slots k_intra_flow can hold
 // there (16 one-wave workgroups per compute unit, three quarters of them: the whole-picture launches of I pictures run beside).  A
@@ -968,6 +1005,7 @@ static void band_free(ovhip_job *j)
     band_flow_reclaim(j, 1);
     for (int i = 0; i < bs->n_chunks; ++i) { pinned_free(nullptr, bs->chunk[i].host); if (bs->chunk[i].dev) (void)hipFree(bs->chunk[i].dev); }
     for (int i = 0; i < MAX_BANDS; ++i) { if (bs->ev_recon[i]) (void)hipEventDestroy(bs->ev_recon[i]); if (bs->ev_tail[i]) (void)hipEventDestroy(bs->ev_tail[i]); }
+    if (bs->keep) (void)hipFree(bs->keep);
     free(bs);
     j->bs = nullptr;
 }
@@ -1034,9 +1072,21 @@ static int band_wait_done(ovhip_job *j)
     return bs->failed ? ov_fail(j->ctx, OVHIP_ELAUNCH, "band-wise picture failed", hipSuccess) : OVHIP_OK;
 }
 
-static inline int32_t floor64(int32_t v) { return v <= 0 ? 0 : v & ~63; }
+static inline int32_t floor8(int32_t v) { return v <= 0 ? 0 : v & ~7; }
 
 extern "C" int ovhip_job_band_active(const ovhip_job *j) { return j && band_active(j); }
+
+// 1: the reconstruction of the last band submitted is still running on the device.  A caller that is ahead of the device leaves its
+// next band to a later hook (it then covers more CTU rows): the launches stay few and full when the device is the slower side -- and
+// an I picture, whose ordered pass is one dependency chain per band, keeps its wavefront across as many rows as the parse has delivered
+extern "C" int ovhip_job_band_busy(ovhip_job *j)
+{
+    if (!j || !band_active(j) || !j->bs->n) return 0;
+    (void)hipSetDevice(j->ctx->device);
+    if (hipEventQuery(j->bs->ev_recon[j->bs->n - 1]) == hipSuccess) return 0;
+    (void)hipGetLastError();
+    return 1;
+}
 
 extern "C" int ovhip_job_band_progress(ovhip_job *j, int32_t *rows_final, void **event, const volatile uint32_t **abort_word)
 {
@@ -1078,7 +1128,8 @@ extern "C" int ovhip_job_band(ovhip_job *j, const ovhip_pic *dst, const ovhip_pi
         memset(&bs->cur, 0, sizeof(bs->cur));
         bs->log2_ctu = log2_ctu; bs->filters_latched = 0; bs->lmcs_up = 0; bs->alf_up = 0; bs->have_luts = 0;
         bs->stages = pr->stages ? pr->stages : 0xffffffffu;
-        bs->last_event = nullptr; bs->last_rows = 0;
+        bs->last_event = nullptr; bs->last_rows = 0; bs->keep_valid = 0;
+        if (!bs->keep) OV_HIP(ctx, hipMalloc((void **)&bs->keep, (size_t)4 * j->w * sizeof(uint16_t)));
         j->again.valid = 0; j->n_retries = 0;       // (n_mv / n_tmvp: the eager DMVR rows' -- a pass may have run before the first band)
         if (!j->res.y) CHK(ovhip_pic_alloc(ctx, j->w, j->h, &j->res));
         if (!j->d_flow) {
@@ -1134,7 +1185,7 @@ extern "C" int ovhip_job_band(ovhip_job *j, const ovhip_pic *dst, const ovhip_pi
     if (!by_flow) n_items = 0;
 
     // ---- which tails this call runs, and the filter rows they make final ----
-    const int t_first = bs->tails, t_end = last ? b + 1 : b;          // tails [t_first, t_end)
+    const int t_first = bs->tails, t_end = b + 1;                     // tails [t_first, t_end): this band's (see "bottom row" below)
     if (t_end > t_first && !bs->filters_latched) {
         bs->sao_on = pr->sao && (stages & OVHIP_STAGE_SAO); bs->alf_on = pr->alf_ctus && (stages & OVHIP_STAGE_ALF);
         bs->filters_latched = 1;
@@ -1151,8 +1202,8 @@ extern "C" int ovhip_job_band(ovhip_job *j, const ovhip_pic *dst, const ovhip_pi
         dbf_new = fin ? j->h : ((stages & OVHIP_STAGE_DBF) ? (E - 8 > dbf_new ? E - 8 : dbf_new) : E);
         // the second stage (SAO, or the copy that stands in for it) reads one row below its window; the third (ALF, or the copy back)
         // three rows below its own -- and the second stage's next window re-reads the row above it, which the third must leave alone
-        sao_new = fin ? j->h : (floor64(dbf_new - 1) > sao_new ? floor64(dbf_new - 1) : sao_new);
-        alf_new = fin ? j->h : (floor64(sao_new - 3) > alf_new ? floor64(sao_new - 3) : alf_new);
+        sao_new = fin ? j->h : (floor8(dbf_new - 1) > sao_new ? floor8(dbf_new - 1) : sao_new);
+        alf_new = fin ? j->h : (floor8(sao_new - 3) > alf_new ? floor8(sao_new - 3) : alf_new);
     }
     const int nb_ctu_w = (j->w + (1 << log2_ctu) - 1) >> log2_ctu;
     const int sao_r0 = bs->sao_rows >> log2_ctu, sao_r1 = sao_new > bs->sao_rows ? ((sao_new - 1) >> log2_ctu) + 1 : sao_r0;
@@ -1262,6 +1313,10 @@ extern "C" int ovhip_job_band(ovhip_job *j, const ovhip_pic *dst, const ovhip_pi
         if (!flow_workers) { by_flow = 0; if (!have_levels) return ov_fail(ctx, OVHIP_EUNSUP, "ovhip_job_band: flow budget exhausted and no level table", hipSuccess); }
         B.flow_charge = flow_workers;
     }
+    // the row above the band as the band's reconstruction must see it (k_band_row): unfiltered, mapped -- and without the hand-over bit
+    // when the readers are the per-level kernels, which take samples as they are
+    const bool swap_row = b > 0 && bs->keep_valid && (n_it || n_reg) && B.row0 > 0;
+    if (swap_row) CHK(band_row(j, dst, B.row0 - 1, 1, (by_flow && n_items) ? 0xffffu : 0x03ffu));
     int flow_prepared = 0;
     if (stages & OVHIP_STAGE_ITX) {
         const ovhip_tb_cmd *d_tb = (const ovhip_tb_cmd *)(db + o_tb);
@@ -1304,6 +1359,8 @@ extern "C" int ovhip_job_band(ovhip_job *j, const ovhip_pic *dst, const ovhip_pi
             }
         }
     }
+    if (swap_row) CHK(band_row(j, dst, B.row0 - 1, 2, 0));
+    if (!last && B.row1 > B.row0) { CHK(band_row(j, dst, B.row1 - 1, 0, 0)); bs->keep_valid = 1; }
     if (!bs->ev_recon[b]) OV_HIP(ctx, hipEventCreateWithFlags(&bs->ev_recon[b], hipEventDisableTiming));
     OV_HIP(ctx, hipEventRecord(bs->ev_recon[b], ctx->stream));
     bs->n = b + 1; bs->cur = c1; bs->row_prev = row_end;

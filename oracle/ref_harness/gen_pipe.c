@@ -628,6 +628,10 @@ static int *g_readers_left;                     /* pictures still to read pictur
 static __thread struct gp_thread *tls_thread;
 static void gp_sync_waited(double seconds) { if (tls_thread) tls_thread->t_sync += seconds; }
 static int g_profile, g_noout, g_bands = -1;
+/* "timeline": one line per picture of the last repetition on stderr -- which thread took it when, how long its decode call took, how
+ * much of that it waited for collocated rows / spent in the row-end hooks, when the in-process comparison ended */
+static int g_timeline; static double g_tl_t0;
+static struct gp_tl { int thread; double take, decoded, compared, sync, hooks; } g_tl[4096];
 static double g_prof_overhead;
 
 static void gp_t_attach(struct OVRCNCtx *const r, const OVFrame *const f, const struct RectEntryInfo *const e, uint8_t l2)
@@ -698,7 +702,9 @@ gp_decode_kept(struct gp_thread *t, int k)
     if (g_pass_shim == 2) ovhip_shim_flush_pending(t->c);
     const int e = ovhip_shim_last_error(t->c);
     if (e) { fprintf(stderr, "gen_pipe: picture %d: the shim latched %d\n", k, e); if (!t->err) t->err = e; }
+    if (g_timeline) { g_tl[k].decoded = gp_now() - g_tl_t0; }
     gp_compare(t, t->s, k);
+    if (g_timeline) { g_tl[k].compared = gp_now() - g_tl_t0; }
     for (int i = 0; i < d->n0; ++i) gp_reader_done(d->l0[i]);
     for (int i = 0; i < d->n1; ++i) gp_reader_done(d->l1[i]);
     gp_reader_done(k);
@@ -761,9 +767,11 @@ gp_worker(void *arg)
             if (k >= 0) g_kept[k].pic->frame = gp_frame_get(t->s);
             pthread_mutex_unlock(&g_take_mtx);
             if (k < 0) break;
-            const double t0 = gp_now();
+            const double t0 = gp_now(), sy0 = t->t_sync, hk0 = t->t_hooks;
+            if (g_timeline) { g_tl[k].thread = t->id; g_tl[k].take = t0 - g_tl_t0; }
             gp_decode_kept(t, k);
             t->t_busy += gp_now() - t0;
+            if (g_timeline) { g_tl[k].sync = t->t_sync - sy0; g_tl[k].hooks = t->t_hooks - hk0; }
         }
         ovhip_shim_band_stats(t->c, &t->bands_sent, &t->bands_deferred);
         if (g_profile && g_pass_shim == 3) {
@@ -822,9 +830,14 @@ run_stream_threads(struct gp_seq *s, const struct gp_pic_desc *desc, int n_pic, 
         }
         g_next_pic = 0;
         const double t0 = gp_now();
+        g_tl_t0 = t0;
         pthread_barrier_wait(&g_bar);
         pthread_barrier_wait(&g_bar);
         wall = gp_now() - t0;
+        if (g_timeline && g_rep == g_reps - 1)
+            for (int k = 0; k < n_pic; ++k)
+                fprintf(stderr, "timeline pic %3d poc %3d type %d thr %2d take %7.2f decoded %7.2f compared %7.2f ms | in decode: waited for collocated rows %6.2f, row-end hooks %6.2f\n",
+                        k, desc[k].poc, desc[k].slice_type, g_tl[k].thread, 1e3 * g_tl[k].take, 1e3 * g_tl[k].decoded, 1e3 * g_tl[k].compared, 1e3 * g_tl[k].sync, 1e3 * g_tl[k].hooks);
         for (int k = 0; k < n_pic; ++k) {
             OVPicture *p = g_kept[k].pic;
             for (int i = 0; i < s->nb_ctb_h; ++i) free(p->decoded_ctus.mask[i]);
@@ -888,6 +901,7 @@ gp_main(int argc, char **argv)
         else if (!strcmp(argv[i], "norelease")) g_no_release = 1;
         else if (!strcmp(argv[i], "profile")) g_profile = 1;      /* live: the shim's own split of a frame thread's time (ovhip_shim_set_profile) */
         else if (!strcmp(argv[i], "noout")) g_noout = 1;          /* live: OVHIP_OUT_NONE -- the pictures stay on the device (no copy into the OVFrame, frames not compared) */
+        else if (!strcmp(argv[i], "timeline")) g_timeline = 1;
         else if (!strcmp(argv[i], "bands") && i + 1 < argc) g_bands = atoi(argv[++i]);      /* CTU rows per band (ovhip_shim_set_bands); default: the shim's */
         else if (!strcmp(argv[i], "live")) want_live = 1;      /* the shim on the real device, on frame threads; compares in process, prints a JSON line */
         else if (!strcmp(argv[i], "threads") && i + 1 < argc) {

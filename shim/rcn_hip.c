@@ -88,6 +88,7 @@ extern int transform_unit_c(OVCTUDec *const, unsigned int, unsigned int, unsigne
 enum { PEND_NONE = 0, PEND_AFFINE, PEND_BDOF };
 
 
+#define MAX_MARKS 136          /* CTU rows of a picture: 8192 / 64 + some */
 struct hip_entry {
     const OVCTUDec *key;
     struct RCNFunctions scalar;          /* the table as the scalar fill left it */
@@ -109,6 +110,9 @@ struct hip_entry {
     size_t row_mark;                     /* ... recorded when the last row-end hook ran                                           */
     int band_on;                         /* this picture goes to the device band by band (ovhip_frame_band), not at its end        */
     uint32_t n_bands_sent, n_bands_deferred;
+    /* what had been recorded when CTU row y had just been parsed (y = index: rows_parsed - 1): the picture's last hook works through
+     * the rows its reference pictures had not reached during the parse with these (final_progressive) */
+    struct { ovhip_band_counts counts; size_t n_refined; } marks[MAX_MARKS]; int n_marks, rows_sent;
     /* prediction calls being collected into one CU */
     struct {
         int kind, x0, y0, n, cols, rows_done, cur_col;
@@ -1218,7 +1222,8 @@ hip_sao_filter_line(OVCTUDec *const c, const struct RectEntryInfo *const einfo, 
 }
 
 static void dmvr_rows_step(struct hip_entry *e, OVCTUDec *c, int final);
-static void band_step(struct hip_entry *e, OVCTUDec *c, int rows_parsed);
+static void band_step(struct hip_entry *e, OVCTUDec *c, const struct RectEntryInfo *einfo, int rows_parsed);
+static void final_progressive(struct hip_entry *e, OVCTUDec *c);
 
 static void
 hip_sao_first_pix_rows(OVCTUDec *const c, const struct RectEntryInfo *const einfo, uint16_t ctb_y)
@@ -1227,7 +1232,7 @@ hip_sao_first_pix_rows(OVCTUDec *const c, const struct RectEntryInfo *const einf
     /* the only hook that runs at the end of row 0 (slicedec.c:934-941): the eager DMVR pass over that row starts here */
     if (!e->record_only && einfo->nb_ctu_h > 1) dmvr_rows_step(e, c, 0);
     if (c->sao_info.sao_luma_flag || c->sao_info.sao_chroma_flag) sao_row(e, c, einfo, ctb_y);
-    if (!e->record_only && einfo->nb_ctu_h > 1) band_step(e, c, 1);
+    if (!e->record_only && einfo->nb_ctu_h > 1) band_step(e, c, einfo, 1);
 }
 
 static void flush_picture(struct hip_entry *e, OVCTUDec *c);
@@ -1348,6 +1353,26 @@ hip_rcn_report_ctu_line(OVCTUDec *const c, OVPicture *const pic, int y_ctu, int 
 }
 #endif
 
+/* the ALF parameters of CTU row ctb_y of the entry (parsed with the row's CTUs: valid once the row has been parsed) */
+static void
+alf_row(struct hip_entry *e, const OVCTUDec *c, const struct RectEntryInfo *einfo, int ctb_y)
+{
+    const struct ALFInfo *ai = &c->alf_info;
+    if (ctb_y < 0 || ctb_y >= einfo->nb_ctu_h || !(ai->alf_luma_enabled_flag || ai->alf_cb_enabled_flag || ai->alf_cr_enabled_flag)) return;
+    for (int x = 0; x < einfo->nb_ctu_w; ++x) {
+        const int i = ctb_y * einfo->nb_ctu_w + x;
+        const ALFParamsCtu *p = &ai->ctb_alf_params[i];
+        ovhip_alf_ctu *o = &e->alf[(einfo->ctb_y + ctb_y) * e->nb_ctu_w + einfo->ctb_x + x];
+        o->flags = p->ctb_alf_flag; o->luma_set = p->ctb_alf_idx; o->cb_alt = p->cb_alternative; o->cr_alt = p->cr_alternative;
+        o->cc_cb_idx = ai->cc_alf_cb_enabled_flag ? ai->ctb_cc_alf_filter_idx[0][i] : 0;
+        o->cc_cr_idx = ai->cc_alf_cr_enabled_flag ? ai->ctb_cc_alf_filter_idx[1][i] : 0;
+        o->border = entry_borders(e, einfo, x, ctb_y);
+    }
+    if (ai->aps_cc_alf_data_cb) memcpy(e->alf_cc[0], ai->aps_cc_alf_data_cb->alf_cc_mapped_coeff[0], sizeof(e->alf_cc[0]));
+    if (ai->aps_cc_alf_data_cr) memcpy(e->alf_cc[1], ai->aps_cc_alf_data_cr->alf_cc_mapped_coeff[1], sizeof(e->alf_cc[1]));
+    e->alf_on = 1;
+}
+
 /* alf.rcn_alf_filter_line (rcn_structures.h:333; rcn_alf.c:1285-1433): the LAST slot call before a CTU row is published
  * (slicedec.c:934-956).  Captures the row's ALF parameters, refines the DMVR vectors recorded so far (so that the row's
  * TMVP field is final), and for the last row of the picture runs the flush. */
@@ -1355,22 +1380,8 @@ static void
 hip_alf_filter_line(OVCTUDec *const c, const struct RectEntryInfo *const einfo, uint16_t ctb_y)
 {
     ENTER(c);
-    const struct ALFInfo *ai = &c->alf_info;
     if (params_alloc(e, c, einfo)) return;
-    if (ai->alf_luma_enabled_flag || ai->alf_cb_enabled_flag || ai->alf_cr_enabled_flag) {
-        for (int x = 0; x < einfo->nb_ctu_w; ++x) {
-            const int i = ctb_y * einfo->nb_ctu_w + x;
-            const ALFParamsCtu *p = &ai->ctb_alf_params[i];
-            ovhip_alf_ctu *o = &e->alf[(einfo->ctb_y + ctb_y) * e->nb_ctu_w + einfo->ctb_x + x];
-            o->flags = p->ctb_alf_flag; o->luma_set = p->ctb_alf_idx; o->cb_alt = p->cb_alternative; o->cr_alt = p->cr_alternative;
-            o->cc_cb_idx = ai->cc_alf_cb_enabled_flag ? ai->ctb_cc_alf_filter_idx[0][i] : 0;
-            o->cc_cr_idx = ai->cc_alf_cr_enabled_flag ? ai->ctb_cc_alf_filter_idx[1][i] : 0;
-            o->border = entry_borders(e, einfo, x, ctb_y);
-        }
-        if (ai->aps_cc_alf_data_cb) memcpy(e->alf_cc[0], ai->aps_cc_alf_data_cb->alf_cc_mapped_coeff[0], sizeof(e->alf_cc[0]));
-        if (ai->aps_cc_alf_data_cr) memcpy(e->alf_cc[1], ai->aps_cc_alf_data_cr->alf_cc_mapped_coeff[1], sizeof(e->alf_cc[1]));
-        e->alf_on = 1;
-    }
+    alf_row(e, c, einfo, ctb_y);
     /* the entry's last row: with it the last of the picture's rect entries ends the picture (ovthreads.c:93-114: the last entry
      * job to finish calls slicedec_finish_decoding) */
     int last = 0;
@@ -1380,11 +1391,12 @@ hip_alf_filter_line(OVCTUDec *const c, const struct RectEntryInfo *const einfo, 
         if (last) e->ctus_left = 0;
     }
     if (e->record_only) return;
+    if (last) final_progressive(e, c);
     dmvr_rows_step(e, c, last);
     if (last) flush_picture(e, c);
     /* this hook runs at the end of CTU row ctb_y + 1 (decode_ctu_line, slicedec.c:934-956) -- except for the picture's last two lines,
      * which both run at its end: the band of the second to last is left to the flush that follows at once */
-    else if (ctb_y + 2 < einfo->nb_ctu_h) band_step(e, c, ctb_y + 2);
+    else if (ctb_y + 2 < einfo->nb_ctu_h) band_step(e, c, einfo, ctb_y + 2);
 }
 
 /* ------------------------------------------------------------------------------------ picture begin / flush / plumbing */
@@ -1521,12 +1533,14 @@ picture_params(struct hip_entry *e, OVCTUDec *c, ovhip_job_params *pr, int by_fl
     pr->log2_ctu_s = e->log2_ctu;
 }
 
-/* Band-wise submission (ovhip_frame_band; OVVC_HIP_BANDS = CTU rows per band, 0 = off): at the end of every g_band_rows-th CTU row
+/* Band-wise submission (ovhip_frame_band; OVVC_HIP_BANDS = CTU rows per band; 0 = off, the DEFAULT: measured on the live decoder at 4K
+ * -- DESIGN 12 -- whole-picture submission is faster at every band size: a band is ~13 launches, a picture of 17 bands ~220 instead of
+ * 11, and the host side of a launch is what a frame thread's device half consists of): at the end of every g_band_rows-th CTU row
  * what has been recorded since the last band goes to the device -- upload, prediction, residuals, ordered pass at once; the filters one
  * band late -- while the parse goes on; the rows the band's filters made final are posted to the device DPB, where the frame threads
  * that reference this picture see them (slicedec.c:815-975 + dpb.c:1309-1323 do this per CTU row on the host).  A band whose
  * reference rows are not there yet is left to the next hook; only the picture's end waits. */
-static int g_band_rows = 1, g_band_rows_set;
+static int g_band_rows = 0, g_band_rows_set, g_band_intra = 1, g_band_inter = 1;
 /* CTU rows per band; 0: every picture is submitted at its end (ovhip_frame_submit).  Overrides OVVC_HIP_BANDS. */
 void ovhip_shim_set_bands(int ctu_rows_per_band) { g_band_rows = ctu_rows_per_band < 0 ? 0 : ctu_rows_per_band; g_band_rows_set = 1; }
 void
@@ -1538,17 +1552,67 @@ ovhip_shim_band_stats(const OVCTUDec *c, uint32_t *sent, uint32_t *deferred)
 }
 
 static void
-band_step(struct hip_entry *e, OVCTUDec *c, int rows_parsed)
+band_step(struct hip_entry *e, OVCTUDec *c, const struct RectEntryInfo *einfo, int rows_parsed)
 {
-    if (!e->band_on || !e->fr || e->err || g_band_rows <= 0 || rows_parsed % g_band_rows) return;
+    if (!e->band_on || !e->fr || e->err || g_band_rows <= 0) return;
+    if (rows_parsed >= 1 && rows_parsed <= MAX_MARKS && e->n_marks == rows_parsed - 1) {
+        ovhip_rec_counts(e->rec, &e->marks[rows_parsed - 1].counts);
+        e->marks[rows_parsed - 1].n_refined = e->n_refined;
+        e->n_marks = rows_parsed;
+    }
+    if (rows_parsed % g_band_rows) return;
+    /* the band's filters reach into the row just parsed: its ALF parameters (the row's own hook runs a row later, slicedec.c:934-956)
+     * and, for row 0, the SAO parameters are there -- parsed with the row's CTUs */
+    if (params_alloc(e, c, einfo)) return;
+    for (int y = rows_parsed - g_band_rows; y < rows_parsed; ++y) alf_row(e, c, einfo, y);
+    if (c->sao_info.sao_luma_flag || c->sao_info.sao_chroma_flag) sao_row(e, c, einfo, rows_parsed - 1);
     ovhip_job_params pr;
     picture_params(e, c, &pr, 1);
     PROF_DEVICE_BEGIN(e);
     const int r = ovhip_frame_band(e->fr, &pr, rows_parsed << e->log2_ctu, 0, NULL);
     PROF_DEVICE_END(e);
     if (r < 0) latch(e, r, "ovhip_frame_band");
-    else if (r) e->n_bands_sent++; else e->n_bands_deferred++;
+    else if (r) { e->n_bands_sent++; e->rows_sent = rows_parsed; } else e->n_bands_deferred++;
 }
+
+#ifdef OVVC_HIP_CALLER_PATCH
+static void apply_done_cells(struct hip_entry *e, OVCTUDec *c, int64_t done);
+static void issue_reports(struct hip_entry *e, int all);
+/* The picture's last hook, when its parse ran AHEAD of its reference pictures (with the caller patch the parse never waits for a
+ * reference: the rows' reports were queued, their bands left to later hooks).  Instead of waiting for the reference pictures to be
+ * complete and then doing everything at once, the rows are worked through in order as the references' rows arrive (ovhip_dpb_rows_tag
+ * blocks per row): the DMVR vectors of the row's units, the row's report (its readers' parse goes on), the row's band (its readers'
+ * bands go on) -- so that a chain of pictures that each trail their references by a few rows stays a chain of a few rows per link,
+ * whatever the parse speeds (rcn_inter.c:131-146 + dpb.c:1309-1323 give the reference's frame threads the same behaviour). */
+static void
+final_progressive(struct hip_entry *e, OVCTUDec *c)
+{
+    if (!e->band_on || !e->fr || e->err || !e->n_refs) return;
+    ovhip_job_params pr;
+    picture_params(e, c, &pr, 1);
+    PROF_DEVICE_BEGIN(e);
+    for (int y = e->rows_sent; y < e->n_marks && !e->err; ++y) {
+        const size_t units = e->marks[y].n_refined;
+        if (units > e->dmvr_done) {
+            int64_t done = ovhip_frame_dmvr_rows_collect(e->fr);
+            if (done >= 0 && (size_t)done < units) {
+                done = ovhip_frame_dmvr_rows_begin_upto(e->fr, e->log2_ctu, units);        /* waits for the rows these units read */
+                if (done >= 0) done = ovhip_frame_dmvr_rows_collect(e->fr);
+            }
+            apply_done_cells(e, c, done);
+        }
+        issue_reports(e, 0);
+        if ((y + 1) % g_band_rows == 0 && !e->err) {
+            const int r = ovhip_frame_band_upto(e->fr, &pr, (y + 1) << e->log2_ctu, &e->marks[y].counts, 1);
+            if (r < 0) latch(e, r, "ovhip_frame_band_upto");
+            else { e->n_bands_sent++; e->rows_sent = y + 1; }
+        }
+    }
+    PROF_DEVICE_END(e);
+}
+#else
+static void final_progressive(struct hip_entry *e, OVCTUDec *c) { (void)e; (void)c; }
+#endif
 
 static void
 flush_picture(struct hip_entry *e, OVCTUDec *c)
@@ -1636,10 +1700,12 @@ begin_picture(struct hip_entry *e, const OVFrame *f, const struct RectEntryInfo 
     const OVPicture *cur = pl0 ? (const OVPicture *)((const char *)pl0 - offsetof(OVPicture, mv_plane0)) : NULL;
     latch(e, ovhip_frame_begin_tag(e->fr, f, cur && cur->frame == f ? pic_tag(cur) : 0), "ovhip_frame_begin");
     e->rec = ovhip_frame_recorder(e->fr);
-    /* band by band: pictures of one rect entry with inter slices.  An I picture's ordered pass is one dependency chain through the
-     * whole picture (the wavefront crosses the CTU rows): cut into bands it would run row after row; it is submitted whole, its
-     * readers see it when it is complete -- their bands are simply left to later hooks until then */
-    e->band_on = g_band_rows > 0 && e->whole_pic_entry && e->key->tmp_slice_type != 2;
+    /* band by band: pictures of one rect entry.  (An I picture's ordered pass is one dependency chain per band, so its bands follow each
+     * other on the device; ovhip_frame_band leaves a band to the next hook while the one before is still being reconstructed, so the
+     * bands of a picture that is parsed faster than the device decodes it grow until the wavefront spans the rows again.)
+     * OVVC_HIP_BANDS_INTRA=0: I pictures whole. */
+    e->band_on = g_band_rows > 0 && e->whole_pic_entry && (e->key->tmp_slice_type == 2 ? g_band_intra : g_band_inter);
+    e->n_marks = 0; e->rows_sent = 0;
     (void)ovhip_frame_set_band_mode(e->fr, e->band_on);
     PROF_DEVICE_END(e);
     if (!e->rec) { latch(e, OVHIP_ENOMEM, "ovhip_frame_recorder"); return; }
@@ -1713,6 +1779,8 @@ rcn_init_functions_hip(struct RCNFunctions *f, uint8_t ict_type, uint8_t lm_chro
     f->rcn_bdof_mcp_l = &hip_rcn_bdof_mcp_l;
     f->rcn_dmvr_mv_refine = &hip_rcn_dmvr_mv_refine;
     if (!g_band_rows_set && getenv("OVVC_HIP_BANDS")) g_band_rows = atoi(getenv("OVVC_HIP_BANDS"));
+    if (getenv("OVVC_HIP_BANDS_INTRA")) g_band_intra = atoi(getenv("OVVC_HIP_BANDS_INTRA"));
+    if (getenv("OVVC_HIP_BANDS_INTER")) g_band_inter = atoi(getenv("OVVC_HIP_BANDS_INTER"));
 #ifdef OVVC_HIP_CALLER_PATCH
     f->rcn_cu_inter_b = &hip_rcn_cu_inter_b;
     f->rcn_affine_cu = &hip_rcn_affine_cu;

@@ -66,7 +66,8 @@ int  ovhip_shim_get_profile(const struct OVCTUDec *ctudec, ovhip_shim_profile *o
  * frames through ovhip_shim_frame_output / _digest: no 24.9 MB copy per 4K picture).  Also: environment OVVC_HIP_OUTPUT=none. */
 void ovhip_shim_set_output(int mode);
 /* Band-wise submission (ovhip_frame_band): CTU rows per band; 0 = every picture goes to the device at its end (ovhip_frame_submit).
- * Default 1; environment OVVC_HIP_BANDS.  Pictures with intra slices and pictures cut into rect entries are always submitted whole. */
+ * Default 0 (whole pictures: faster on the live decoder at every band size); environment OVVC_HIP_BANDS.  Pictures cut into
+ * rect entries are always submitted whole. */
 void ovhip_shim_set_bands(int ctu_rows_per_band);
 void ovhip_shim_band_stats(const struct OVCTUDec *ctudec, uint32_t *bands_sent, uint32_t *bands_deferred);
 struct ovhip_dpb;

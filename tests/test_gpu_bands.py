@@ -127,7 +127,7 @@ def test_band_rows_become_final_in_order(ctx):
         ctx.sync()
         final = job.band_progress()
         seen.append(final)
-        assert final <= max(0, r - 128 - 128) and final % 64 == 0
+        assert final == max(0, r - 24) and final % 8 == 0          # deblocking leaves the 8 rows above a band's end, SAO / ALF follow in steps of 8
         got = dst.download()
         _same([got[0][:final], got[1][:final // 2], got[2][:final // 2]], [whole[0][:final], whole[1][:final // 2], whole[2][:final // 2]],
               f"rows reported final after the band ending at {r}")

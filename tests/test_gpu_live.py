@@ -146,3 +146,30 @@ def test_live_decode_of_sequences_back_to_back(patched):
     r = run(8, "size", 832, 480, "pics", 17, "cont", 4, "reps", 2)
     check(r, 68, 8)
     assert r["copies_back_to_back"] == 4
+
+
+# ---- band-wise submission (ovhip_frame_band; OFF by default -- whole pictures are faster on this decoder): the picture enters the
+# device CTU row by CTU row while it is parsed, its rows are posted to the device DPB as their filters finish, dependent pictures' bands and
+# eager DMVR rows go when the rows they read are final, and a picture whose parse ran ahead of its references works through its rows in its
+# last hook as they arrive.  Same bar: every frame and every collocated motion entry equals the reference pass.
+@pytest.mark.parametrize("bands", (1, 2))
+@pytest.mark.parametrize("threads", (1, 4))
+@pytest.mark.parametrize("name", sorted(STREAMS))
+def test_live_decode_band_by_band_fixture_streams(name, threads, bands):
+    args = STREAMS[name]
+    n = int(args[args.index("pics") + 1])
+    r = live(threads, *args, "bands", bands)
+    check(r, n, threads)
+    if "tiles" not in name:
+        assert r["bands_sent"] >= n - 1              # (pictures cut into rect entries go whole)
+    check(live_patched(threads, *args, "bands", bands), n, threads)
+
+
+@pytest.mark.parametrize("w,h,threads,pics,bands", [(1920, 1080, 4, 17, 1), (3840, 2160, 8, 17, 1), (3840, 2160, 16, 33, 3), (832, 480, 8, 33, 1)])
+def test_live_decode_band_by_band(w, h, threads, pics, bands):
+    """deep hierarchies on more threads than the hierarchy is wide: bands left to later hooks, the last hook working through the rows as the
+    references deliver them (final_progressive), I pictures band by band under the device-is-behind rule"""
+    for fn in (live_patched, live):
+        r = fn(threads, "size", w, h, "pics", pics, "seed", 31, "bands", bands, timeout=1500)
+        check(r, pics, threads)
+        assert r["bands_sent"] > pics

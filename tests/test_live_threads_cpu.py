@@ -34,3 +34,12 @@ def test_frame_threads_on_dry_frames(args):
         assert r["collocated_motion_entries_differing"] == 0 and r["collocated_motion_entries_compared"] > 1000
         if r["frame_threads"] == 1:
             assert r["host_frames_recycled"] > 0          # the pool handed frames out again: keys came back to the DPB
+
+
+@pytest.mark.parametrize("bands", (1, 2))
+def test_frame_threads_on_dry_frames_band_by_band(bands):
+    """the same with band-wise submission switched on (ovhip_frame_band on dry frames: the DPB's row progress, bands left to later hooks,
+    the eager DMVR rows' row-granular readiness): the parse of every picture still sees the reference pass's DMVR vectors in time"""
+    for r in dry("1,4,8", "pics", 33, "size", 832, 480, "bands", bands):
+        assert r["pictures_decoded"] == 33 and r["shim_error"] == 0 and r["collocated_motion_entries_differing"] == 0
+        assert r["bands_sent"] > 33
