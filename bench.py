@@ -843,6 +843,13 @@ def main():
                                       + (f"; ONE process, {L} logical devices ({args.dealing} dealing), reference pictures by event-ordered hipMemcpyPeerAsync" if L > 1 else "")},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            # how reference pictures travel between GPUs in THIS run, at the top level: a reader of the first multi-GPU
+            # record must not have to infer it from the launch command
+            "transport": (None if world * L == 1 else
+                          f"RCCL ncclSend / ncclRecv, point-to-point, {world} ranks in one communicator (one process per GPU; ovvc_rccl.hip)" if world > 1 and rccl is not None else
+                          f"torch.distributed ({'gloo, debug' if debug_gloo else 'nccl'}) send / recv callbacks, {world} ranks (RCCL transport of the C library not available)" if world > 1 else
+                          f"hipMemcpyPeerAsync, event-ordered, ONE process driving {L} devices (python bench.py --gpus {L} without a launcher: no RCCL rank "
+                          "exists in this run; launch with `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` for the RCCL transport)"),
         }
         print(json.dumps(out))
     if world > 1:
@@ -944,6 +951,11 @@ def live_decoder_rates(W, H, n_pics=33, threads=(1, 2, 4, 8, 16), reps=3):
         if len(rows) != len(tl):
             print(f"bench: live_decoder_rates: gen_pipe rc {p.returncode}: {p.stderr[-400:]}", file=sys.stderr)
             return None
+        # "timeline": per picture of the LAST thread count's last repetition, when its decode call returned (ms from the start)
+        import re
+        tline = {int(m.group(1)): float(m.group(2)) for m in re.finditer(r"timeline pic\s+(\d+) poc\s+\d+ type \d thr\s+\d+ take\s+[\d.]+ decoded\s+([\d.]+)", p.stderr)}
+        if tline:
+            rows[-1]["_first_picture_decoded_ms"] = tline.get(0)
         return rows, p.returncode
 
     def summary(d):
@@ -962,7 +974,7 @@ def live_decoder_rates(W, H, n_pics=33, threads=(1, 2, 4, 8, 16), reps=3):
                 "shares_of_a_frame_threads_time": {"parse": r(parse / held), "recording": r(rec / held), "device_half_and_waits": r((dev + sync) / held)},
                 "shim_hook_calls_per_picture": d["shim_hook_calls"] // n}
 
-    a = run(threads, [])
+    a = run(threads, ["timeline"])
     if a is None:
         return None
     b = run((threads[0], threads[-1]), ["noout"])
@@ -978,6 +990,16 @@ def live_decoder_rates(W, H, n_pics=33, threads=(1, 2, 4, 8, 16), reps=3):
            "host_frames_recycled": rows[0]["host_frames_recycled"],
            "by_frame_threads": {str(d["frame_threads"]): summary(d) for d in rows},
            "reference_scalar_decoder_same_stream_one_thread_fps": round(n_pics / rows[0]["reference_pass_seconds_inside_slicedec"], 2)}
+    # what bounds a SHORT stream: its I picture.  The parse of the random walk's 4K I picture (the reference's own parser, one thread)
+    # takes longer than everything else of the stream on 16 threads; no picture of the stream can be complete before it is
+    i_ms = rows[-1].pop("_first_picture_decoded_ms", None)
+    if i_ms:
+        out["the_i_picture"] = {"decode_call_returned_after_ms": round(i_ms, 1), "frame_threads": rows[-1]["frame_threads"],
+                                "whole_stream_ms": round(1e3 * rows[-1]["seconds"], 1),
+                                "pictures_per_second_if_everything_else_were_free": round(n_pics / (1e-3 * i_ms), 1),
+                                "what": "gen_pipe timeline: when the frame thread that took picture 0 (the I picture) returned from the reference's "
+                                        "slicedec_decode_rect_entry -- parse (the reference's CABAC + syntax code on one thread) + the shim's hooks.  Every "
+                                        "other picture of the stream depends on it: the stream's rate cannot exceed pictures / this time whatever the back-end does"}
     patched = ROOT / "oracle" / "_ref" / "patched" / "gen_pipe"
     c = run((threads[0], threads[-1]), [], patched) if patched.exists() else None
     if c is not None:
@@ -986,6 +1008,18 @@ def live_decoder_rates(W, H, n_pics=33, threads=(1, 2, 4, 8, 16), reps=3):
                                          "frames and collocated motion planes compared with the UNPATCHED reference pass",
                                  "by_frame_threads": {str(d["frame_threads"]): summary(d) for d in c[0]}}
         out["bit_exact"] = out["bit_exact"] and c[1] == 0 and all(d["samples_differing"] == 0 and d["collocated_motion_entries_differing"] == 0 for d in c[0])
+    # band-wise submission (ovhip_frame_band; OVVC_HIP_BANDS, OFF by default): the same stream with every picture entering the device CTU row by
+    # CTU row while it is parsed -- recorded beside the default so that the choice of the default is a measurement
+    bw = run((threads[-1],), ["bands", "1"], patched if patched.exists() else GEN_PIPE)
+    if bw is not None:
+        d = bw[0][0]
+        out["band_wise_submission"] = {"what": "the same stream, patched caller when built, bands of ONE CTU row (gen_pipe `bands 1` = OVVC_HIP_BANDS=1): upload + "
+                                               "prediction + residuals + ordered pass of a band at the end of its CTU row, its filters with it, rows posted to the device "
+                                               "DPB, dependent pictures' bands and eager DMVR rows going when the rows they read are final",
+                                       "frame_threads": d["frame_threads"], "summary": summary(d), "bands_sent": d.get("bands_sent"), "bands_left_to_a_later_hook": d.get("bands_left_to_a_later_hook"),
+                                       "bit_exact": bw[1] == 0 and d["samples_differing"] == 0 and d["collocated_motion_entries_differing"] == 0 and d["shim_error"] == 0,
+                                       "default": "off: whole-picture submission is faster on this decoder at every band size (DESIGN 12, profiles/r06_live_*)"}
+        out["bit_exact"] = out["bit_exact"] and out["band_wise_submission"]["bit_exact"]
     # the steady state: the figures above are one short stream (start-up and tail of 33 pictures on up to 16 threads); a random-access
     # sequence with an intra period of 64 decoded continuously -- I + two GOPs of 32, four such sequences back to back (gen_pipe `cont`:
     # the frame threads take the next intra period's pictures while the tail of the one before still decodes), 260 pictures

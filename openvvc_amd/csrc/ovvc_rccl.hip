@@ -31,6 +31,8 @@ struct ovhip_rccl {
     void *lib;
     ncclComm_t comm;
     hipStream_t stream;
+    hipEvent_t ev_done;            // behind a picture's group: the comm thread waits for THIS, not for the stream (ovvc_common.hip.h: hipStreamSynchronize
+                                   // from several threads at once is what the runtime does badly; an event wait costs nothing)
     int device, rank, world;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
     ncclResult_t (*CommDestroy)(ncclComm_t);
@@ -92,8 +94,13 @@ static int exchange(ovhip_rccl *r, const ovhip_pic *src, const ovhip_pic *dst, i
     }
     const ncclResult_t e2 = r->GroupEnd();
     if (e != ncclSuccess || e2 != ncclSuccess) return rfail(r, "ncclSend / ncclRecv", e != ncclSuccess ? e : e2, hipSuccess);
-    const hipError_t h = hipStreamSynchronize(r->stream);
-    if (h != hipSuccess) return rfail(r, "hipStreamSynchronize(transport)", ncclSuccess, h);
+    // the callbacks of ovhip_stream_xfer are synchronous by contract (the driver's comm thread publishes the picture to the device DPB when
+    // the call returns): an event behind the group, waited for on the host
+    hipError_t h = hipSuccess;
+    if (!r->ev_done) h = hipEventCreateWithFlags(&r->ev_done, hipEventDisableTiming);
+    if (h == hipSuccess) h = hipEventRecord(r->ev_done, r->stream);
+    if (h == hipSuccess) h = hipEventSynchronize(r->ev_done);
+    if (h != hipSuccess) return rfail(r, "event behind the picture's group (transport)", ncclSuccess, h);
     return OVHIP_OK;
 }
 
@@ -147,6 +154,7 @@ extern "C" void ovhip_rccl_destroy(ovhip_rccl *r)
     if (!r) return;
     (void)hipSetDevice(r->device);
     if (r->comm) (void)r->CommDestroy(r->comm);
+    if (r->ev_done) (void)hipEventDestroy(r->ev_done);
     (void)hipStreamDestroy(r->stream);
     free(r);
 }
