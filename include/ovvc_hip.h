@@ -949,16 +949,19 @@ int  ovhip_job_last_stats(const ovhip_job *job, ovhip_job_stats *out);
  *
  * ovhip_job_band() takes everything recorded since the previous call as one band of CTU rows ending at luma row `row_end` (a CTU-row
  * boundary; the recorder's arrays are in decoding order, so a band is a slice of every array) and enqueues, without waiting:
- *   the band's slices in ONE upload; its prediction, residuals and ordered pass; and, ONE BAND LATE, the filters: inverse luma mapping
- *   and deblocking of the band before it (intra prediction of a band reads the unfiltered bottom row of the band above -- the
- *   reference's saved lines, rcn_ctu.c:246-510), then the SAO and ALF rows that deblocking made final.  With `last` != 0 the call
- *   completes the picture (row_end = the picture's height).
+ *   the band's slices in ONE upload; its prediction, residuals and ordered pass; and the band's own filters: inverse luma mapping and
+ *   deblocking of its rows (the horizontal edge on the boundary to the band ABOVE is in this band's lists: after the call the rows
+ *   < row_end - 8 are final for the deblocking), then the SAO and ALF rows that made final -- all but the band's last 24 rows.  Intra
+ *   prediction of the band BELOW reads this band's bottom row unfiltered (the reference's saved lines, rcn_ctu.c:246-510): the row is
+ *   set aside before the filters and put back while the band below is reconstructed.  With `last` != 0 the call completes the picture
+ *   (row_end = the picture's height).
  * upto: counts of the recorder's arrays that end the band (NULL: everything recorded so far -- the live decoder; a replay of a
  * recorded picture passes the counts at each CTU-row boundary).  refs: every picture the band's units read must be final in the rows
  * they reach -- the caller's business (ovhip_frame_band: the device DPB's row progress).  params: lmcs / log2_ctu_s / stages as for
  * ovhip_job_flush (the same in every call of a picture); sao / alf_* must be valid for the CTU rows the call's filters cover: rows
- * < row_end - 64 (SAO), < row_end - 128 (ALF) of the PREVIOUS band's end -- what the reference's row hooks have delivered by then
- * (slicedec.c:934-956).  Pictures with stand-alone CIIP units are refused (OVHIP_EUNSUP): the shim never records them.
+ * < row_end - 16 (SAO), < row_end - 24 (ALF), i.e. the CTU rows of the band itself -- parsed with the band (the shim takes them in
+ * band_step: the reference's own ALF hook of a row runs a row later, slicedec.c:934-956).  Pictures with stand-alone CIIP units are
+ * refused (OVHIP_EUNSUP): the shim never records them.
  * ovhip_job_wait() waits for everything enqueued; a picture whose ordered pass gave up FAILS (no second pass: its bands may have been
  * read).  ovhip_job_begin() starts the next picture as before.
  * ovhip_job_band_progress(): the picture rows [0, rows_final) are final once `event` (a hipEvent_t behind the last filter launch

@@ -883,19 +883,20 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
 // references it runs a few rows behind (rcn_inter.c:131-146).  ovhip_job_flush takes a picture when its parse has ENDED, so every level
 // of a GOP's reference hierarchy cost a whole parse plus a whole launch chain.  Here the recorder's arrays are cut at CTU-row bands:
 //
-//     ovhip_job_band(k)   = upload of band k's slices (ONE copy out of a staging block) + recon(k) + tail(k - 1) [+ tail(k) if last]
+//     ovhip_job_band(k)   = upload of band k's slices (ONE copy out of a staging block) + recon(k) + tail(k)
 //     recon(k)            = MC -> refined / affine MC -> luma residual -> chroma-scale regions -> chroma residual -> ordered pass,
 //                           the picture-wide launches over the band's slice of every list
 //     tail(k)             = inverse luma mapping of the band's rows (+ un-tag) -> deblocking of the band's edge lists (V then H)
 //                           -> SAO rows [.., s1) -> ALF rows [.., a1)
 //
-// tail(k) runs behind recon(k + 1): intra prediction of band k + 1 reads the UNFILTERED, still mapped bottom row of band k (the
-// reference keeps saved lines for this, rcn_ctu.c:246-510).  The horizontal edge on the boundary between k and k + 1 belongs to band
-// k + 1's lists and changes up to 7 rows above it, so after tail(k) the rows < end_k - 8 are final for the deblocking; SAO then runs up
-// to the last multiple of 64 rows below that (its edge classes read one row further), ALF up to the last multiple of 64 that keeps its
-// 3-row reach and the classification windows inside the SAO output: s1 = end_k - 64, a1 = end_k - 128 for CTU-row bands.  Every launch
-// reads exactly the samples the picture-wide launch reads, so the fixtures' parity carries over (tests/test_gpu_bands.py: bands of one
-// CTU row, of two, and one band = the whole picture give identical pictures).
+// The horizontal edge on the boundary between bands k - 1 and k belongs to band k's lists and changes up to 7 rows above it, so after
+// tail(k) the rows < end_k - 8 are final for the deblocking; SAO then runs up to the last multiple of 8 rows below that (its edge
+// classes read one row further), ALF up to the last multiple of 8 that keeps its 3-row reach and the classification windows inside the
+// SAO output: s1 = end_k - 16, a1 = end_k - 24 for CTU-row bands (the tiles a window cuts are staged whole, rows outside it are not
+// stored).  Intra prediction of band k + 1 reads the UNFILTERED, still mapped bottom row of band k (the reference keeps saved lines for
+// this, rcn_ctu.c:246-510): k_band_row below sets it aside before tail(k) and puts it back for recon(k + 1).  Every launch reads exactly
+// the samples the picture-wide launch reads, so the fixtures' parity carries over (tests/test_gpu_bands.py: bands of one CTU row, of
+// two, of three and one band = the whole picture give identical pictures).
 //
 // Indices inside the commands (coefficient / side-arena offsets, region numbers) stay what the recorder wrote: the band's slice is
 // addressed through a pointer moved back by the slice's first index.  The flow launches of the bands never wait for an item of another

@@ -392,3 +392,125 @@ def test_waits_and_clears_of_a_reclaim_run_outside_the_dpb_lock(dpb):
     finally:
         lib.ovhip_dpb_destroy(h2)
         h = h_saved
+
+
+# ---- row progress (ovhip_dpb_post_rows / ovhip_dpb_rows_tag): the device analogue of ovdpb_report_decoded_ctu_line /
+# ovdpb_synchro_ref_decoded_ctus (dpb.c:1309-1323, :1242-1270) for pictures a band-wise job decodes ----
+class FakeMemEvents(FakeMem):
+    """+ event_query / event_wait: an event is an integer the test completes by hand"""
+
+    def __init__(self):
+        super().__init__()
+        self.done_events, self.waited, self.cv = set(), [], threading.Condition()
+        self.ops.event_query = capi.DPB_EVENT_FN(self.event_query)
+        self.ops.event_wait = capi.DPB_EVENT_FN(self.event_wait)
+
+    def event_query(self, user, dev, event):
+        with self.cv:
+            return 1 if event in self.done_events else 0
+
+    def event_wait(self, user, dev, event):
+        with self.cv:
+            self.waited.append(event)
+            self.cv.wait_for(lambda: event in self.done_events, timeout=5)
+            return 0 if event in self.done_events else -4
+
+    def complete(self, event):
+        with self.cv:
+            self.done_events.add(event)
+            self.cv.notify_all()
+
+
+@pytest.fixture()
+def dpb_ev(built_lib):
+    mem = FakeMemEvents()
+    h = C.c_void_p()
+    assert built_lib.ovhip_dpb_create_ex(C.byref(h), 2, C.byref(mem.ops)) == 0
+    yield built_lib, h, mem
+    built_lib.ovhip_dpb_destroy(h)
+    assert not mem.live
+
+
+def _rows(lib, h, key, need, dev=0, block=0, pin=0, tag=0):
+    pic, ev = capi.Pic(), C.c_void_p()
+    r = lib.ovhip_dpb_rows_tag(h, C.c_void_p(key), tag, dev, need, block, pin, C.byref(pic), C.byref(ev))
+    return r, pic, ev.value
+
+
+def test_rows_become_readable_when_their_event_has_completed_in_order(dpb_ev):
+    lib, h, mem = dpb_ev
+    r, pa = _begin(lib, h, 1, w=64, hh=512)
+    assert r == 0
+    assert _rows(lib, h, 1, 100)[0] == 0, "nothing posted: not there"
+    assert _rows(lib, h, 99, 100)[0] == 0, "a key nobody has begun: not there (never an error for a non-blocking reader)"
+    assert lib.ovhip_dpb_post_rows(h, C.c_void_p(1), 104, C.c_void_p(11), None) == 0
+    assert lib.ovhip_dpb_post_rows(h, C.c_void_p(1), 232, C.c_void_p(12), None) == 0
+    assert lib.ovhip_dpb_post_rows(h, C.c_void_p(1), 200, C.c_void_p(13), None) == -3, "rows never go back"
+    assert _rows(lib, h, 1, 100)[0] == 0, "posted, event not completed"
+    mem.complete(12)
+    assert _rows(lib, h, 1, 100)[0] == 0, "records are taken in order: the earlier event has not completed"
+    mem.complete(11)
+    r, pic, ev = _rows(lib, h, 1, 232, pin=1)
+    assert r == 1 and pic.y == pa.y and ev is None
+    assert _rows(lib, h, 1, 233)[0] == 0 and _rows(lib, h, 1, 512)[0] == 0, "the whole picture: only when it is published"
+    assert _rows(lib, h, 1, 100, dev=1)[0] == 0, "another device gets the picture when it is complete (the transfer is picture-granular)"
+    assert lib.ovhip_dpb_publish(h, C.c_void_p(1), 0) == 0
+    assert _rows(lib, h, 1, 512)[0] == 1
+    r, pic, ev = _rows(lib, h, 1, 100, dev=1)
+    assert r == 1 and ev is not None and pic.y != pa.y, "published: the other device gets its copy and the transfer's event"
+    assert lib.ovhip_dpb_unpin(h, C.c_void_p(1)) == 0
+
+
+def test_a_blocking_reader_waits_for_the_record_then_for_its_event(dpb_ev):
+    lib, h, mem = dpb_ev
+    assert _begin(lib, h, 7, w=64, hh=512)[0] == 0
+    got = {}
+
+    def reader():
+        got["r"] = _rows(lib, h, 7, 200, block=1, pin=1)[0]
+
+    t = threading.Thread(target=reader)
+    t.start()
+    time.sleep(0.1)
+    assert "r" not in got
+    assert lib.ovhip_dpb_post_rows(h, C.c_void_p(7), 104, C.c_void_p(21), None) == 0      # not enough rows: keeps waiting on the DPB
+    mem.complete(21)
+    time.sleep(0.1)
+    assert "r" not in got and not mem.waited
+    assert lib.ovhip_dpb_post_rows(h, C.c_void_p(7), 232, C.c_void_p(22), None) == 0      # enough: now it waits for THAT record's event
+    time.sleep(0.1)
+    assert "r" not in got and mem.waited == [22]
+    mem.complete(22)
+    t.join(5)
+    assert got["r"] == 1
+    assert lib.ovhip_dpb_unpin(h, C.c_void_p(7)) == 0
+    assert lib.ovhip_dpb_publish(h, C.c_void_p(7), 0) == 0
+
+
+def test_rows_of_a_picture_whose_ordered_pass_gave_up_are_not_handed_out(dpb_ev):
+    lib, h, mem = dpb_ev
+    assert _begin(lib, h, 3, w=64, hh=512)[0] == 0
+    abort = C.c_uint32(0)
+    assert lib.ovhip_dpb_post_rows(h, C.c_void_p(3), 104, C.c_void_p(31), C.byref(abort)) == 0
+    abort.value = 5                      # the producer's flow launch wrote its abort word before the event completed
+    mem.complete(31)
+    assert _rows(lib, h, 3, 64)[0] == 0, "completed event, abort word set: the rows are not final"
+    got = {}
+    t = threading.Thread(target=lambda: got.setdefault("r", _rows(lib, h, 3, 64, block=1)[0]))
+    t.start()
+    time.sleep(0.1)
+    assert "r" not in got
+    assert lib.ovhip_dpb_publish(h, C.c_void_p(3), -4) == 0          # the producer fails the picture
+    t.join(5)
+    assert got["r"] == -6
+
+
+def test_a_full_record_table_keeps_the_newest_record(dpb_ev):
+    lib, h, mem = dpb_ev
+    assert _begin(lib, h, 5, w=64, hh=4096)[0] == 0
+    for k in range(20):                  # more records than the table holds, none seen complete
+        assert lib.ovhip_dpb_post_rows(h, C.c_void_p(5), 100 * (k + 1), C.c_void_p(100 + k), None) == 0
+    for k in range(20):
+        mem.complete(100 + k)
+    assert _rows(lib, h, 5, 2000)[0] == 1 and _rows(lib, h, 5, 2001)[0] == 0
+    assert lib.ovhip_dpb_publish(h, C.c_void_p(5), 0) == 0

@@ -1,7 +1,8 @@
 """GPU: band-wise submission (ovhip_job_band, include/ovvc_hip.h) -- a picture handed to the device band of CTU rows by band of CTU
 rows, as the live decoder's row hooks do while the picture is still being parsed (slicedec.c:815-975: the reference reconstructs a CTU
-row right after parsing it).  A band's prediction / residual / ordered pass run at once, its inverse luma mapping and deblocking one
-band late (intra prediction of the band below reads its unfiltered bottom row), SAO and ALF over the rows that deblocking made final.
+row right after parsing it).  A band's prediction / residual / ordered pass and its own filters run at once (inverse luma mapping,
+deblocking, SAO and ALF over the rows the deblocking made final: all but the last 24 of the band); the band's unfiltered bottom row is
+set aside for the intra prediction of the band below (the reference's saved lines, rcn_ctu.c:246-510).
 
 Bar: bit-exact.  Bands of one CTU row, of two, of three and ONE band = the whole picture give the picture ovhip_job_flush gives, which is
 the oracle's (and, through the fixtures, the reference's)."""
