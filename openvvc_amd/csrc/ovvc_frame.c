@@ -48,8 +48,9 @@ struct ovhip_frame {
     double pt_collect, pt_rows_begin, pt_band_refs, pt_band_job, pt_final_refs, pt_job_wait, pt_output, pt_submit; int pn_pics;
 };
 static int g_frame_prof = -1;
-#define PT0() const double pt0_ = g_frame_prof > 0 ? mono_s() : 0.0
-#define PT(acc) do { if (g_frame_prof > 0) (acc) += mono_s() - pt0_; } while (0)
+#define PT_ON() (__atomic_load_n(&g_frame_prof, __ATOMIC_RELAXED) > 0)
+#define PT0() const double pt0_ = PT_ON() ? mono_s() : 0.0
+#define PT(acc) do { if (PT_ON()) (acc) += mono_s() - pt0_; } while (0)
 
 /* ---- event trace (include/ovvc_hip.h, ovhip_frame_set_trace): WHEN a caller (shim/rcn_hip.c) makes its frame-level calls ---- */
 static void (*g_trace)(void *user, const ovhip_frame_event *ev);
@@ -103,7 +104,7 @@ ovhip_frame_create(ovhip_dpb *dpb, int dev, int32_t w, int32_t h, ovhip_frame **
     if (!f) return OVHIP_ENOMEM;
     f->dpb = dpb; f->dev = dev; f->w = w; f->h = h;
     f->id = __atomic_fetch_add(&g_next_id, 1, __ATOMIC_RELAXED);
-    if (g_frame_prof < 0) g_frame_prof = getenv("OVVC_HIP_FRAME_PROF") != NULL;
+    if (__atomic_load_n(&g_frame_prof, __ATOMIC_RELAXED) < 0) __atomic_store_n(&g_frame_prof, getenv("OVVC_HIP_FRAME_PROF") != NULL, __ATOMIC_RELAXED);
     if (hipdev < 0) {
         /* a DPB on a test back-end has no device to decode on: a dry frame (the caller's sequence of frame-level calls is the
          * subject, tests/test_shim_device_cpu.py); pictures "decode" to whatever the back-end's pic_alloc handed out */
@@ -131,7 +132,7 @@ ovhip_frame_destroy(ovhip_frame *f)
 {
     if (!f) return;
     if (f->live) (void)ovhip_frame_fail(f, OVHIP_EINVAL);
-    if (g_frame_prof > 0 && f->pn_pics)
+    if (PT_ON() && f->pn_pics)
         fprintf(stderr, "frame %d: %d pictures, ms per picture: dmvr collect %.3f, dmvr begin %.3f, band refs check %.3f, band enqueue %.3f, last band: refs wait %.3f, job wait %.3f, output %.3f; whole submit %.3f\n",
                 f->id, f->pn_pics, 1e3 * f->pt_collect / f->pn_pics, 1e3 * f->pt_rows_begin / f->pn_pics, 1e3 * f->pt_band_refs / f->pn_pics, 1e3 * f->pt_band_job / f->pn_pics,
                 1e3 * f->pt_final_refs / f->pn_pics, 1e3 * f->pt_job_wait / f->pn_pics, 1e3 * f->pt_output / f->pn_pics, 1e3 * f->pt_submit / f->pn_pics);

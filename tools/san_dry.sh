@@ -30,6 +30,8 @@ run() { ./gen_pipe $T "$@" > run.log 2>&1 || { echo "gen_pipe $* failed:"; tail 
 total=0
 run device threads 8 pics 33 size 832 480 reps 2
 run device threads 8 pics 17 size 832 480 cont 4
+run device threads 8 pics 33 size 832 480 reps 2 bands 1          # band-wise submission: the DPB's row progress, bands left to later hooks
+run device threads 16 pics 33 size 832 480 gop 32 bands 2 seed 11
 if [ $SAN != thread ]; then
   run device threads 4 pics 5 seed 5 size 264 392 tiles 2 2
   run device threads 16 pics 33 size 832 480 gop 32 reps 2 seed 11
