@@ -1,14 +1,14 @@
 #!/bin/bash
 # Timing-dependent half of the boundary, many seeds: `gen_pipe live` (and the patched-caller build) over seeded streams of several sizes
 # and GOP structures on 3..16 frame threads; every frame and collocated motion entry is compared with the reference pass in-process.
-#   gpurun -- bash tools/live_sweep.sh [first_seed] [count]
-R=${GRAFT_REPO_ROOT:-/root/repo}; s0=${1:-100}; n=${2:-24}; fail=0; runs=0
+#   gpurun -- bash tools/live_sweep.sh [first_seed] [count] [extra gen_pipe words, e.g. bands 1]
+R=${GRAFT_REPO_ROOT:-/root/repo}; s0=${1:-100}; n=${2:-24}; shift 2 2>/dev/null; extra="$*"; fail=0; runs=0
 for ((s = s0; s < s0 + n; ++s)); do
   case $((s % 4)) in 0) geo="size 416 240 pics 17";; 1) geo="size 832 480 pics 17 gop 16";; 2) geo="size 264 392 tiles 2 2 pics 9";; 3) geo="size 1920 1080 pics 9";; esac
   thr=$((3 + s % 14))
   for g in $R/oracle/_ref/gen_pipe $R/oracle/_ref/patched/gen_pipe; do
     [[ $g == *patched* && $geo == *tiles* ]] && continue
-    out=$(timeout 600 $g /tmp live threads $thr seed $s $geo reps 2 2>/tmp/live_sweep.err | grep '^{' | tail -1); rc=$?
+    out=$(timeout 600 $g /tmp live threads $thr seed $s $geo reps 2 $extra 2>/tmp/live_sweep.err | grep '^{' | tail -1); rc=$?
     runs=$((runs + 1))
     if ! echo "$out" | grep -q '"shim_error": 0, "frames_differing": 0, "samples_differing": 0, "collocated_motion_entries_differing": 0'; then
       # a stream the reference itself cannot take (64x2 ISP partitions, refused with OVHIP_EUNSUP) is not a failure of the comparison
@@ -17,4 +17,4 @@ for ((s = s0; s < s0 + n; ++s)); do
     fi
   done
 done
-echo "live sweep: $runs runs, $fail failures"
+echo "live sweep ($extra): $runs runs, $fail failures"
