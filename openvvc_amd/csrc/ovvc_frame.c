@@ -46,6 +46,7 @@ struct ovhip_frame {
     int n_bands, n_deferred;
     /* OVVC_HIP_FRAME_PROF=1: where the frame-level calls spend their wall time, printed when the frame is destroyed (seconds) */
     double pt_collect, pt_rows_begin, pt_band_refs, pt_band_job, pt_final_refs, pt_job_wait, pt_output, pt_submit; int pn_pics;
+    double pt_fl_prepare, pt_fl_upload, pt_fl_refs, pt_fl_launch;      /* ovhip_job_flush by phase (ovhip_job_stats.host_us_*) */
 };
 static int g_frame_prof = -1;
 #define PT_ON() (__atomic_load_n(&g_frame_prof, __ATOMIC_RELAXED) > 0)
@@ -133,9 +134,10 @@ ovhip_frame_destroy(ovhip_frame *f)
     if (!f) return;
     if (f->live) (void)ovhip_frame_fail(f, OVHIP_EINVAL);
     if (PT_ON() && f->pn_pics)
-        fprintf(stderr, "frame %d: %d pictures, ms per picture: dmvr collect %.3f, dmvr begin %.3f, band refs check %.3f, band enqueue %.3f, last band: refs wait %.3f, job wait %.3f, output %.3f; whole submit %.3f\n",
+        fprintf(stderr, "frame %d: %d pictures, ms per picture: dmvr collect %.3f, dmvr begin %.3f, band refs check %.3f, band enqueue %.3f, last band: refs wait %.3f, job wait %.3f, output %.3f; whole submit %.3f (flush: prepare %.3f, uploads %.3f, reference wait %.3f, launches %.3f)\n",
                 f->id, f->pn_pics, 1e3 * f->pt_collect / f->pn_pics, 1e3 * f->pt_rows_begin / f->pn_pics, 1e3 * f->pt_band_refs / f->pn_pics, 1e3 * f->pt_band_job / f->pn_pics,
-                1e3 * f->pt_final_refs / f->pn_pics, 1e3 * f->pt_job_wait / f->pn_pics, 1e3 * f->pt_output / f->pn_pics, 1e3 * f->pt_submit / f->pn_pics);
+                1e3 * f->pt_final_refs / f->pn_pics, 1e3 * f->pt_job_wait / f->pn_pics, 1e3 * f->pt_output / f->pn_pics, 1e3 * f->pt_submit / f->pn_pics,
+                1e3 * f->pt_fl_prepare / f->pn_pics, 1e3 * f->pt_fl_upload / f->pn_pics, 1e3 * f->pt_fl_refs / f->pn_pics, 1e3 * f->pt_fl_launch / f->pn_pics);
     if (f->job) ovhip_job_destroy(f->job);
     if (f->dry_rec) ovhip_rec_destroy(f->dry_rec);
     if (f->ctx) ovhip_ctx_destroy(f->ctx);
@@ -382,8 +384,14 @@ ovhip_frame_submit(ovhip_frame *f, ovhip_job *job, const ovhip_pic *intra, const
         pr.before_launch = before_launch_cb; pr.before_launch_user = f;
         r = ovhip_job_flush(j, &f->dst, f->ref_pic, (uint32_t)f->n_refs, intra, &pr);
         if (r != OVHIP_OK) fail(f, r, "ovhip_job_flush");
+        if (PT_ON()) {
+            ovhip_job_stats st;
+            if (ovhip_job_last_stats(j, &st) == OVHIP_OK) { f->pt_fl_prepare += 1e-6 * st.host_us_prepare; f->pt_fl_upload += 1e-6 * st.host_us_upload; f->pt_fl_refs += 1e-6 * st.host_us_wait; f->pt_fl_launch += 1e-6 * st.host_us_launch; }
+        }
         /* ONLY the wait marks the picture complete: it may run the ordered pass a second time */
+        const double tw0 = PT_ON() ? mono_s() : 0.0;
         int q = ovhip_job_wait(j);
+        if (PT_ON()) f->pt_job_wait += mono_s() - tw0;
         f->done_at = mono_s();
         if (q != OVHIP_OK && r == OVHIP_OK) r = fail(f, q, "ovhip_job_wait");
     }
@@ -394,12 +402,14 @@ ovhip_frame_submit(ovhip_frame *f, ovhip_job *job, const ovhip_pic *intra, const
      * alive -- the decoder's DPB, the stream driver's hold -- does so until this call returns) */
     (void)publish(f, r);
     if (r == OVHIP_OK && out && out->mode != OVHIP_OUT_NONE) {
+        const double to0 = PT_ON() ? mono_s() : 0.0;
         switch (out->mode) {
         case OVHIP_OUT_DIGEST: r = ovhip_pic_digest(f->ctx, &f->dst, &out->window, out->digest); break;
         case OVHIP_OUT_PLANES: r = ovhip_pic_download(f->ctx, &f->dst, out->y, out->cb, out->cr, out->stride_y, out->stride_c); break;
         case OVHIP_OUT_PACKED: r = ovhip_pic_output(f->ctx, &f->dst, &out->window, out->packed); break;
         default: r = OVHIP_EINVAL;
         }
+        if (PT_ON()) f->pt_output += mono_s() - to0;
         if (r != OVHIP_OK) fail(f, r, "picture output");
     }
     PT(f->pt_submit); f->pn_pics += !f->band_mode;
