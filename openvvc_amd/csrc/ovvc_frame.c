@@ -535,6 +535,9 @@ frame_band(ovhip_frame *f, const ovhip_job_params *params, int32_t row_end, int3
     if (!f->dry && !j) return fail(f, OVHIP_EINVAL, "ovhip_frame_band: no job");
     /* the device is behind (the band before this one is still being reconstructed): this band is left to the next call, which takes
      * its rows too -- fewer, fuller launches when the device is the slower side; an I picture's wavefront then spans the rows */
+    /* (a picture of more CTU rows than the job keeps bands -- 8K with 32-sample CTUs -- goes on in fewer, larger bands: the rest is
+     * left to the last call) */
+    if (!last && f->n_bands >= 90) { f->n_deferred++; trace(f, OVHIP_FE_BAND, f->key, 0, row_end, last, 0); return 0; }
     if (!block && j && f->n_bands && ovhip_job_band_busy(j)) { f->n_deferred++; trace(f, OVHIP_FE_BAND, f->key, 0, row_end, last, 0); return 0; }
     ovhip_band_counts now;
     ovhip_rec_counts(ovhip_frame_recorder(f), &now);
