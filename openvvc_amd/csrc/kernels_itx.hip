@@ -368,9 +368,10 @@ __device__ __forceinline__ void itx_block(const ovhip_pic &pic, const ResDelta &
             // (blocks narrower than 4): transposed, rows padded with zeros to the 4 values a pass step reads
             for (int i = lane; i < tb_w * tb_h; i += NT) {
                 const int x = i & (tb_w - 1), y = i >> log2_w;
-                // (a 64-point transform reads its first 32 inputs only: rows 32..63 of a 2x64 ISP block are not staged)
-                if (y < ch) s_coef[x * cs + y] = (int16_t)dequant1(src[i], c.dq_scale, c.dq_shift, c.dq_neg);
-                if (tb_h < 4 && y == 0) { s_coef[x * cs + 2] = 0; s_coef[x * cs + 3] = 0; }
+                // (a 64-point transform reads its first 32 inputs only: rows 32..63 of a 2x64 ISP block, columns 32..63 of a 64x2 one are
+                //  not staged)
+                if (y < ch && x < cw) s_coef[x * cs + y] = (int16_t)dequant1(src[i], c.dq_scale, c.dq_shift, c.dq_neg);
+                if (tb_h < 4 && y == 0 && x < cw) { s_coef[x * cs + 2] = 0; s_coef[x * cs + 3] = 0; }
             }
         } else {
             for (int i = lane; i < tb_w * tb_h; i += NT)

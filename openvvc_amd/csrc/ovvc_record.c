@@ -426,9 +426,12 @@ ovhip_rec_isp_cu(ovhip_recorder *r, const ovhip_tu_state *st, const ovhip_isp_de
     int32_t l2p, n_pb, l2pred, n_pred;
     ovhip_isp_geometry(cu->log2_cb_w, cu->log2_cb_h, cu->vertical, &l2p, &n_pb, &l2pred, &n_pred);
     const int l2tw = cu->vertical ? l2p : cu->log2_cb_w, l2th = cu->vertical ? cu->log2_cb_h : l2p;     /* transform block */
-    /* 64x2 partitions: the reference de-quantises them with a row stride of 32 and transforms with 64 (rcn_Xx2_tb,
-     * rcn_transform_tree.c:985-1009; dequant_tb :119-132): its result depends on memory nothing wrote */
-    if (l2tw == 6 && l2th == 1 && cu->cbf_mask) return OVHIP_EUNSUP;
+    /* 64x2 partitions (a 64x8 CU split horizontally): the reference de-quantises them with a row stride of 32 and transforms with 64
+     * (rcn_Xx2_tb, rcn_transform_tree.c:985-1009; dequant_tb :119-132) -- its result depends on memory nothing wrote, so there is no
+     * reference result to be equal to.  They are reconstructed as H.266 defines them (8.7.4: a 64-point transform has 32 coded
+     * columns, the rest is zero): the two coded rows of 32 (what the parser delivers) are laid out as raster rows of 64.
+     * PARITY UNPINNED for these blocks: checked against a restatement of the specification, tests/test_gpu_edge_cases.py */
+    const int thin64 = l2tw == 6 && l2th == 1;
     const int pb = 1 << l2p;
     /* transform types (:1110-1111, :1180-1181) */
     const int long_dst = cu->mts_enabled;
@@ -471,6 +474,12 @@ ovhip_rec_isp_cu(ovhip_recorder *r, const ovhip_tu_state *st, const ovhip_isp_de
             /* rcn_2xX_tb / rcn_1xX_tb / rcn_Xx2_tb / rcn_Xx1_tb (:919-1061): the whole block raster, de-quantised as a whole */
             c->kind |= OVHIP_TB_FLAG_RASTER;
             c->sig_sb_map = cu->sig_sb_map[i];
+            if (thin64) {
+                int16_t wide[128];
+                memset(wide, 0, sizeof(wide));
+                memcpy(wide, src, 32 * sizeof(int16_t)); memcpy(wide + 64, src + 32, 32 * sizeof(int16_t));
+                if (capture_raster(r, wide, 128, &c->coef_off)) { ret = OVHIP_ENOMEM; goto fail; }
+            } else
             if (capture_raster(r, src, 1 << (l2tw + l2th), &c->coef_off)) { ret = OVHIP_ENOMEM; goto fail; }
         } else {
             /* rcn_isp_tu (:869-917): sub-block storage, optional LFNST (which forces DCT-II), never the DC shortcut */

@@ -152,7 +152,8 @@ INTRA_TOOLS = ALL_TOOLS + ("intra", "isp")
 
 
 def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6, cbf_y: float = 0.5,
-                  cbf_c: float = 0.3, mv_range_px: int = 64, tools=ALL_TOOLS, intra_frac: float = 0.12, calllog: bool = False) -> Workload:
+                  cbf_c: float = 0.3, mv_range_px: int = 64, tools=ALL_TOOLS, intra_frac: float = 0.12, calllog: bool = False,
+                  isp_64x2: bool = False) -> Workload:
     """tools: subset of ALL_TOOLS.  Rates follow JVET CTC random-access statistics in spirit: of the
     bi-predicted CUs that satisfy check_bdof() (vcl_coding_unit.c:2019-2027) and whose references lie on
     opposite sides of the picture, ~45 % use BDOF alone and ~35 % DMVR (+BDOF); ~8 % of the CUs >= 16x16
@@ -364,7 +365,9 @@ def make_workload(w: int, h: int, seed: int = DEFAULT_SEED, bi_frac: float = 0.6
                         task_l.mode = lmode
                         isp_vertical = int(rs.randint(0, 2))
                         cu_isp = (isp_on and q[3] < ISP_FRAC and l2w <= 6 and l2h <= 6 and l2w + l2h >= 5
-                                  and not (l2w == 6 and l2h == 3 and not isp_vertical))     # (64x2 partitions: refused, the reference's result is undefined)
+                                  # 64x2 partitions (a 64x8 CU split horizontally): the reference's result is undefined, the back-end follows the
+                                  # specification (ovvc_record.c); kept out of the default workloads so that they stay what earlier rounds measured
+                                  and (isp_64x2 or not (l2w == 6 and l2h == 3 and not isp_vertical)))
                         if cu_isp:
                             # ---- intra sub-partitions (recon_isp_subtree_v / _h, rcn_transform_tree.c:1087-1205): the luma of the CU in one
                             #      recorder call; the caller has marked the CU in the progress field before (vcl_transform_unit.c:1878), so the

@@ -10,6 +10,11 @@
  * reference itself: tests/golden/ fixtures are produced by oracle/ref_harness/gen_golden.c
  * driving the reference's own orchestrators (rcn_tu_st, rcn_mcp_b, ...) from
  * oracle/_ref/libovvcref.so, and tests/test_oracle_golden.py checks this file against them.
+ *
+ * ONE block shape is PARITY UNPINNED: the 64x2 transform blocks of a 64x8 coding unit split into intra sub-partitions.  The
+ * reference's own result for them is undefined (rcn_Xx2_tb, rcn_transform_tree.c:985-1009, reads memory nothing wrote); itx_one
+ * below takes the 32 coded columns and nothing else, as H.266 8.7.4 defines it, and tests/spec_isp64x2.py -- a restatement of
+ * 8.7.3 / 8.7.4 for that shape -- is what checks it (tests/test_edge_cases_cpu.py).
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -157,8 +162,13 @@ static void itx_one(const oracle_pic *pic, const ovhip_tb_cmd *c, const int16_t 
 
     memset(coef, 0, sizeof(int16_t) * cw * ch);
     if (raster) {
-        for (int i = 0; i < tb_w * tb_h; ++i)
-            coef[i] = (kind == OVHIP_TB_TS_RAW || bdpcm) ? src[i] : dequant1(src[i], c->dq_scale, c->dq_shift, c->dq_neg);
+        /* raster rows of tb_w; what lies outside the coded extent (rows 32.. of a 2x64 block, columns 32.. of a 64x2 one: zero by
+         * H.266 8.7.4) is not taken */
+        for (int y = 0; y < ch; ++y)
+            for (int x = 0; x < cw; ++x) {
+                const int16_t v = src[y * tb_w + x];
+                coef[y * cw + x] = (kind == OVHIP_TB_TS_RAW || bdpcm) ? v : dequant1(v, c->dq_scale, c->dq_shift, c->dq_neg);
+            }
     } else {
         uint64_t map = c->sig_sb_map;
         int n = 0;

@@ -75,6 +75,8 @@ static int g_threads;                               /* "threads N[,M,...]": fram
 static int g_thread_list[16], g_n_thread_list;
 static int g_tile_cols = 1, g_tile_rows = 1;         /* "tiles C R": C x R rect entries per picture, decoded one after the other on ONE OVCTUDec (slicedec.c:649-653) */
 static int g_no_isp;                                /* "noisp": sps_isp_enabled_flag = 0 (long 4K streams: some 64x8 CU is split into 64x2 partitions in nearly every one) */
+static int g_allow_64x2;                            /* "allow64x2" (live): a stream that holds 64x2 ISP partitions is decoded all the same -- the back-end follows H.266 there, the reference pass
+                                                     * whatever its stack held: frames that differ are counted and reported, not an error (no reference result exists for them) */
 static int g_isp_64x2;                              /* the reference's result for 64x2 ISP partitions is undefined (gen_golden.c, gen_isp) */
 
 /* ---- device mode: the decoder's events the shim hangs its frame-level calls on, interleaved with those calls ---- */
@@ -902,6 +904,7 @@ gp_main(int argc, char **argv)
         else if (!strcmp(argv[i], "profile")) g_profile = 1;      /* live: the shim's own split of a frame thread's time (ovhip_shim_set_profile) */
         else if (!strcmp(argv[i], "noout")) g_noout = 1;          /* live: OVHIP_OUT_NONE -- the pictures stay on the device (no copy into the OVFrame, frames not compared) */
         else if (!strcmp(argv[i], "timeline")) g_timeline = 1;
+        else if (!strcmp(argv[i], "allow64x2")) g_allow_64x2 = 1;
         else if (!strcmp(argv[i], "bands") && i + 1 < argc) g_bands = atoi(argv[++i]);      /* CTU rows per band (ovhip_shim_set_bands); default: the shim's */
         else if (!strcmp(argv[i], "live")) want_live = 1;      /* the shim on the real device, on frame threads; compares in process, prints a JSON line */
         else if (!strcmp(argv[i], "threads") && i + 1 < argc) {
@@ -1005,7 +1008,8 @@ gp_main(int argc, char **argv)
         const double tr0 = gp_now();
         run_stream(&seq, gop, n_pic, seed, &out);
         const double t_ref = gp_now() - tr0;
-        if (g_isp_64x2) { fprintf(stderr, "gen_pipe: the stream holds %d 64x2 ISP partitions (reference result undefined): pick another seed\n", g_isp_64x2); return 1; }
+        if (g_isp_64x2 && !(g_allow_64x2 && want_live)) { fprintf(stderr, "gen_pipe: the stream holds %d 64x2 ISP partitions (reference result undefined): pick another seed\n", g_isp_64x2); return 1; }
+        const int n_64x2_ref = g_isp_64x2;
         g_pass_shim = want_live ? 3 : 2;
         if (want_live && g_profile) ovhip_shim_set_profile(1);
         if (want_live && g_noout) ovhip_shim_set_output(OVHIP_OUT_NONE);
@@ -1039,13 +1043,14 @@ gp_main(int argc, char **argv)
                    "\"pictures_decoded\": %d, \"shim_error\": %d, \"frames_differing\": %d, \"samples_differing\": %llu, \"collocated_motion_entries_differing\": %llu, \"collocated_motion_entries_compared\": %llu, "
                    "\"dmvr_calls\": %zu, \"thread_seconds_with_a_picture\": %.6f, \"thread_seconds_in_row_end_and_attach_hooks\": %.6f, "
                    "\"reference_pass_seconds_inside_slicedec\": %.6f, \"reference_pass_seconds\": %.6f, \"repetitions\": %d, \"host_frames_made\": %d, \"host_frames_recycled\": %d, \"output\": \"%s\", "
-                   "\"thread_seconds_waiting_for_collocated_rows\": %.6f, \"shim_profile\": %d, \"thread_seconds_in_shim_hooks\": %.6f, \"thread_seconds_in_shim_device_half\": %.6f, \"shim_hook_calls\": %llu, \"shim_profile_overhead_seconds_per_call\": %.3e, \"copies_back_to_back\": %d, \"bands_sent\": %u, \"bands_left_to_a_later_hook\": %u}\n",
+                   "\"thread_seconds_waiting_for_collocated_rows\": %.6f, \"shim_profile\": %d, \"thread_seconds_in_shim_hooks\": %.6f, \"thread_seconds_in_shim_device_half\": %.6f, \"shim_hook_calls\": %llu, \"shim_profile_overhead_seconds_per_call\": %.3e, \"copies_back_to_back\": %d, \"bands_sent\": %u, \"bands_left_to_a_later_hook\": %u, \"coding_units_split_into_64x2_isp_partitions\": %d}\n",
                    want_live ? "live" : "device_dry_threads", g_threads, n_pic, W, H, wall, n_pic / wall, tot.n_done, tot.err, tot.frames_differing,
                    (unsigned long long)tot.samples_differing, (unsigned long long)tot.mv_cells_differing, (unsigned long long)tot.mv_cells_compared, g_dmvr_log.n / 12, tot.t_busy, tot.t_hooks,
                    g_decode_seconds_pass[0], t_ref, g_reps, g_frames_made, g_frames_recycled, g_noout ? "none" : "planes into the OVFrame",
-                   tot.t_sync, g_profile, tot.t_shim_hooks, tot.t_shim_device, (unsigned long long)tot.n_shim_calls, g_prof_overhead, g_cont, tot.bands_sent, tot.bands_deferred);
+                   tot.t_sync, g_profile, tot.t_shim_hooks, tot.t_shim_device, (unsigned long long)tot.n_shim_calls, g_prof_overhead, g_cont, tot.bands_sent, tot.bands_deferred, n_64x2_ref);
             fflush(stdout);
-            bad |= tot.err || tot.samples_differing || tot.mv_cells_differing || tot.n_done != n_pic;
+            /* (with 64x2 partitions in the stream the reference pass is not a reference: only errors count) */
+            bad |= tot.err || tot.n_done != n_pic || (!n_64x2_ref && (tot.samples_differing || tot.mv_cells_differing));
         }
         return bad;
     }
