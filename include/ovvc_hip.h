@@ -911,6 +911,12 @@ typedef struct ovhip_job_stats {         /* what the last flush moved and launch
 int  ovhip_job_create(ovhip_ctx *ctx, int32_t pic_w, int32_t pic_h, ovhip_job **out);
 void ovhip_job_destroy(ovhip_job *job);
 ovhip_recorder *ovhip_job_recorder(ovhip_job *job);
+/* Sizes every buffer of the job -- the recorder's page-locked arrays, the device copies, the staging blocks -- for a picture of the
+ * job's size up front, so that no picture of a running decoder meets a growth (a growth of a device buffer is a device-wide
+ * synchronisation, of a page-locked array an allocation + copy + free of 0.1-1.4 ms).  ovhip_frame_job() calls it for a frame thread's
+ * job; ~30 MB page-locked + ~30 MB device memory at 4K. */
+int  ovhip_job_reserve_for_picture(ovhip_job *job);
+int  ovhip_rec_reserve_for_picture(ovhip_recorder *rec);
 /* Waits until the previous flush no longer reads the recorder's arrays, then resets the recorder. */
 int  ovhip_job_begin(ovhip_job *job);
 /* Issues the job's next flushes on another context (= HIP stream) of the same device: a frame thread that became free takes

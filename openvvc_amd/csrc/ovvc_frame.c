@@ -152,7 +152,11 @@ ovhip_job *
 ovhip_frame_job(ovhip_frame *f)
 {
     if (!f || f->dry) return NULL;
-    if (!f->job && fail(f, ovhip_job_create(f->ctx, f->w, f->h, &f->job), "ovhip_job_create") != OVHIP_OK) f->job = NULL;
+    if (!f->job) {
+        if (fail(f, ovhip_job_create(f->ctx, f->w, f->h, &f->job), "ovhip_job_create") != OVHIP_OK) f->job = NULL;
+        /* a frame thread's job: sized for its pictures now, not grown picture by picture (OVVC_HIP_NO_RESERVE=1: the A / B) */
+        else if (!getenv("OVVC_HIP_NO_RESERVE") && fail(f, ovhip_job_reserve_for_picture(f->job), "ovhip_job_reserve_for_picture") != OVHIP_OK) { ovhip_job_destroy(f->job); f->job = NULL; }
+    }
     return f->job;
 }
 

@@ -97,11 +97,17 @@ int store_host(ovhip_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes
     return OVHIP_OK;
 }
 
+double host_now_us();
+int grow_trace() { static int on = -1; if (on < 0) on = getenv("OVVC_HIP_GROW_TRACE") != nullptr; return on; }
+
 void *pinned_alloc(void *user, size_t bytes)
 {
     (void)user;
     void *p = nullptr;
-    return hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+    const double t0 = grow_trace() ? host_now_us() : 0.0;
+    const bool ok = hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) == hipSuccess;
+    if (grow_trace()) fprintf(stderr, "grow: pinned %zu bytes at %.3f ms, took %.3f ms\n", bytes, 1e-3 * t0, 1e-3 * (host_now_us() - t0));
+    return ok ? p : nullptr;
 }
 void pinned_free(void *user, void *p) { (void)user; if (p) (void)hipHostFree(p); }
 
@@ -112,9 +118,11 @@ int dev_reserve(ovhip_job *j, int k, size_t bytes)
     size_t nc = b.cap ? b.cap : (size_t)1 << 16;
     while (nc < bytes) nc *= 2;
     // growth is rare (first pictures of a sequence); hipFree synchronises the device, which is what makes it safe here
+    const double t0 = grow_trace() ? host_now_us() : 0.0;
     if (b.p) OV_HIP(j->ctx, hipFree(b.p));
     b.p = nullptr; b.cap = 0;
     hipError_t e = hipMalloc(&b.p, nc);
+    if (grow_trace()) fprintf(stderr, "grow: device buffer %d to %zu bytes at %.3f ms, took %.3f ms\n", k, nc, 1e-3 * t0, 1e-3 * (host_now_us() - t0));
     if (e != hipSuccess) return ov_fail(j->ctx, OVHIP_ENOMEM, "hipMalloc(job buffer)", e);
     b.cap = nc;
     return OVHIP_OK;
@@ -248,6 +256,39 @@ void ovhip_job_destroy(ovhip_job *j)
 }
 
 ovhip_recorder *ovhip_job_recorder(ovhip_job *j) { return j ? j->rec : nullptr; }
+
+/* Every buffer of the job sized for a picture of its size NOW (the recorder's page-locked arrays, ovhip_rec_reserve_for_picture; the
+ * device copies; the staging blocks), so that no picture of a running decoder meets a growth: a device buffer that grows is hipFree
+ * (a device-wide synchronisation) + hipMalloc, a page-locked one hipHostMalloc + copy + hipHostFree.  What a frame thread's job does
+ * when it is created (ovhip_frame_job); a harness that keeps a hundred pre-recorded jobs does not call it.  ~30 MB of page-locked
+ * and ~30 MB of device memory at 4K. */
+int ovhip_job_reserve_for_picture(ovhip_job *j)
+{
+    if (!j) return OVHIP_EINVAL;
+    OV_DEVICE(j->ctx);
+    if (ovhip_rec_reserve_for_picture(j->rec) != OVHIP_OK) return ov_fail(j->ctx, OVHIP_ENOMEM, "ovhip_rec_reserve_for_picture", hipSuccess);
+    const size_t P = (size_t)j->w * j->h;
+    const struct { int k; size_t bytes; } want[] = {
+        { B_TB, (P / 64 + 1024) * sizeof(ovhip_tb_cmd) }, { B_COEF, (P / 2 + 1024) * 2 }, { B_MC, (P / 128 + 1024) * sizeof(ovhip_mc_unit) },
+        { B_MCX, (P / 256 + 1024) * sizeof(ovhip_mc_unit) }, { B_MV, (P / 256 + 1024) * 16 }, { B_AFF, (P / 1024 + 256) * sizeof(ovhip_aff_unit) },
+        { B_SIDE, (P / 6 + 1024) * 4 }, { B_REG, (P / 4096 + 64) * sizeof(ovhip_lmcs_region) }, { B_SCALE, 65536 },
+        { B_EV, (P / 32 + 2048) * sizeof(ovhip_dbf_edge) }, { B_EH, (P / 32 + 2048) * sizeof(ovhip_dbf_edge) }, { B_PARAM, P / 4 + ((size_t)1 << 20) },
+        { B_CLASS, (size_t)((j->w + 3) / 4) * ((j->h + 3) / 4) }, { B_ITASK, (P / 64 + 1024) * sizeof(ovhip_itask) }, { B_IITEM, (P / 32 + 1024) * 4 },
+        { B_TMVP, 4 * (P / 256 + 1024) * sizeof(ovhip_tmvp_cell) },
+    };
+    for (const auto &q : want) CHK(dev_reserve(j, q.k, q.bytes));
+    CHK(pinned_reserve(j, (void **)&j->param_host, &j->param_cap, P / 4 + ((size_t)1 << 20)));
+    CHK(pinned_reserve(j, (void **)&j->mv_host, &j->mv_cap, (P / 256 + 1024) * 16));
+    CHK(pinned_reserve(j, (void **)&j->tmvp_host, &j->tmvp_cap, 4 * (P / 256 + 1024) * sizeof(ovhip_tmvp_cell)));
+    if (j->items_cap < P / 32 + 1024) {
+        pinned_free(nullptr, j->items_host);
+        j->items_cap = P / 32 + 1024;
+        j->items_host = (uint32_t *)pinned_alloc(nullptr, j->items_cap * sizeof(uint32_t));
+        if (!j->items_host) { j->items_cap = 0; return ov_fail(j->ctx, OVHIP_ENOMEM, "ovhip_job_reserve_for_picture: item list", hipSuccess); }
+    }
+    if (!j->res.y) CHK(ovhip_pic_alloc(j->ctx, j->w, j->h, &j->res));
+    return OVHIP_OK;
+}
 
 int ovhip_job_begin(ovhip_job *j)
 {

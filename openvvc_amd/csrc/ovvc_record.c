@@ -77,6 +77,32 @@ ovhip_rec_reset(ovhip_recorder *r)
 
 void ovhip_rec_set_dense_dbf_planes(ovhip_recorder *r, int on) { if (r) r->dense_planes = !!on; }
 
+/* Capacity for a picture of the recorder's size up front, so that recording never has to grow an array: with a page-locked allocator a
+ * growth is hipHostMalloc + copy + hipHostFree (0.1-1.4 ms each, measured on the live decoder: 113 of them, 37 ms, inside ONE timed
+ * repetition of a 33-picture stream -- every frame thread meets its first I picture, its first P picture ... at some point).  Sized
+ * from what 4K pictures of the seeded streams record (I pictures: 80 k ordered tasks, 8 MB of coefficients), with P = w x h:
+ * 30 MB at 4K (the side arena of the affine units alone 5.5: the seeded streams are affine-heavy).  Arrays still grow past this if a picture needs it. */
+int
+ovhip_rec_reserve_for_picture(ovhip_recorder *r)
+{
+    if (!r) return OVHIP_EINVAL;
+    const size_t P = (size_t)r->pic_w * r->pic_h;
+    int bad = 0;
+    bad |= ovhip_rec_grow_(r, (void **)&r->coef, &r->cap_coef, P / 2 + 1024, sizeof(int16_t));
+    bad |= ovhip_rec_grow_(r, (void **)&r->tb, &r->cap_tb, P / 64 + 1024, sizeof(ovhip_tb_cmd));
+    bad |= ovhip_rec_grow_(r, (void **)&r->tb_split, &r->cap_split, P / 64 + 1024, sizeof(ovhip_tb_cmd));
+    bad |= ovhip_rec_grow_(r, (void **)&r->mc, &r->cap_mc, P / 128 + 1024, sizeof(ovhip_mc_unit));
+    bad |= ovhip_rec_grow_(r, (void **)&r->mcx, &r->cap_mcx, P / 256 + 1024, sizeof(ovhip_mc_unit));
+    bad |= ovhip_rec_grow_(r, (void **)&r->aff, &r->cap_aff, P / 1024 + 256, sizeof(ovhip_aff_unit));
+    bad |= ovhip_rec_grow_(r, (void **)&r->aff_side, &r->cap_side, P / 6 + 1024, sizeof(int32_t));
+    bad |= ovhip_rec_grow_(r, (void **)&r->reg, &r->cap_reg, P / 4096 + 64, sizeof(ovhip_lmcs_region));
+    bad |= ovhip_rec_grow_(r, (void **)&r->edge_v, &r->cap_edge_v, P / 32 + 2048, sizeof(ovhip_dbf_edge));
+    bad |= ovhip_rec_grow_(r, (void **)&r->edge_h, &r->cap_edge_h, P / 32 + 2048, sizeof(ovhip_dbf_edge));
+    bad |= ovhip_rec_grow_(r, (void **)&r->itask, &r->cap_itask, P / 64 + 1024, sizeof(ovhip_itask));
+    bad |= ovhip_rec_grow_(r, (void **)&r->itask_sorted, &r->cap_isorted, P / 64 + 1024, sizeof(ovhip_itask));
+    return bad ? OVHIP_ENOMEM : OVHIP_OK;
+}
+
 #define ACCESSOR(type, name, arr, cnt) \
     const type *name(const ovhip_recorder *r, size_t *n) { if (!r || !n) return NULL; *n = r->cnt; return r->arr; }
 ACCESSOR(ovhip_tb_cmd, ovhip_rec_tb_cmds, tb, n_tb)

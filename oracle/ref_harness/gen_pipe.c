@@ -833,6 +833,7 @@ run_stream_threads(struct gp_seq *s, const struct gp_pic_desc *desc, int n_pic, 
         g_next_pic = 0;
         const double t0 = gp_now();
         g_tl_t0 = t0;
+        if (g_timeline) fprintf(stderr, "repetition %d starts at %.3f ms (CLOCK_MONOTONIC)\n", g_rep, 1e3 * t0);
         pthread_barrier_wait(&g_bar);
         pthread_barrier_wait(&g_bar);
         wall = gp_now() - t0;
