@@ -977,6 +977,7 @@ void ovhip_rec_counts(const ovhip_recorder *rec, ovhip_band_counts *out);
 int  ovhip_job_band(ovhip_job *job, const ovhip_pic *dst, const ovhip_pic *refs, uint32_t n_refs, const ovhip_job_params *params,
                     const ovhip_band_counts *upto, int32_t row_end, int32_t last);
 int  ovhip_job_band_active(const ovhip_job *job);
+int  ovhip_job_band_reserve(ovhip_job *job);        /* the band path's staging arena + side buffers now instead of in the first band */
 int  ovhip_job_band_busy(ovhip_job *job);          /* 1: the last band's reconstruction is still running (never blocks) */
 int  ovhip_job_band_progress(ovhip_job *job, int32_t *rows_final, void **event, const volatile uint32_t **abort_word);
 /* row windows of the two frame-wide filters (rows: multiples of 64, or the picture's height) */

@@ -607,7 +607,7 @@ EXPORTED_SYMBOLS = [
     "ovhip_dmvr_search_launch", "ovhip_rec_append_raw", "ovhip_rec_set_dbf_offsets", "ovhip_rec_tu_intra", "ovhip_rec_itasks", "ovhip_rec_itasks_sorted", "ovhip_itx_launch_classes_res", "ovhip_intra_level_launch", "ovhip_intra_level_geom", "ovhip_intra_sync_words", "ovhip_intra_ctu_launch", "ovhip_intra_flow_words", "ovhip_intra_flow_items", "ovhip_intra_flow_launch",
     "ovhip_rec_itask_levels", "ovhip_rec_isp_cu", "ovhip_isp_geometry", "ovhip_rec_itasks_by_ctu", "ovhip_rec_set_ctu_size", "ovhip_job_bind", "ovhip_job_create", "ovhip_job_destroy", "ovhip_job_recorder", "ovhip_job_begin",
     "ovhip_frame_band", "ovhip_frame_band_upto", "ovhip_frame_dmvr_rows_begin_upto", "ovhip_job_dmvr_rows_begin_upto", "ovhip_frame_set_band_mode", "ovhip_frame_band_stats", "ovhip_dpb_post_rows", "ovhip_dpb_rows_tag",
-    "ovhip_job_band", "ovhip_job_band_active", "ovhip_job_band_busy", "ovhip_job_reserve_for_picture", "ovhip_rec_reserve_for_picture", "ovhip_job_band_progress", "ovhip_rec_counts", "ovhip_sao_launch_rows", "ovhip_alf_launch_rows",
+    "ovhip_job_band", "ovhip_job_band_active", "ovhip_job_band_busy", "ovhip_job_band_reserve", "ovhip_job_reserve_for_picture", "ovhip_rec_reserve_for_picture", "ovhip_job_band_progress", "ovhip_rec_counts", "ovhip_sao_launch_rows", "ovhip_alf_launch_rows",
     "ovhip_job_flush", "ovhip_job_wait", "ovhip_job_refined_mvs", "ovhip_job_dmvr_rows", "ovhip_job_dmvr_rows_begin", "ovhip_job_dmvr_rows_collect", "ovhip_job_last_stats", "ovhip_job_time_stage", "ovhip_job_stage_time",
     "ovhip_output_bytes", "ovhip_output_rows", "ovhip_output_pack_launch", "ovhip_output_row_md5_launch", "ovhip_output_bands", "ovhip_output_tree_md5_launch", "ovhip_pic_output", "ovhip_pic_digest",
     "ovhip_md5_init", "ovhip_md5_update", "ovhip_md5_final", "ovhip_tmvp_cells_launch", "ovhip_job_tmvp_cells", "ovhip_intra_flow_untag_launch", "ovhip_lmcs_inverse_untag_launch", "ovhip_lmcs_scale_prepare_launch",

@@ -431,6 +431,7 @@ ovhip_frame_set_band_mode(ovhip_frame *f, int on)
 {
     if (!f) return OVHIP_EINVAL;
     f->band_mode = on != 0;
+    if (on && !f->dry && f->job && !getenv("OVVC_HIP_NO_RESERVE")) return fail(f, ovhip_job_band_reserve(f->job), "ovhip_job_band_reserve");
     return OVHIP_OK;
 }
 

@@ -1118,6 +1118,32 @@ static inline int32_t floor8(int32_t v) { return v <= 0 ? 0 : v & ~7; }
 
 extern "C" int ovhip_job_band_active(const ovhip_job *j) { return j && band_active(j); }
 
+// the band arena's first chunk and the bottom-row buffer now, not in the first band of the job's first band-wise picture (what
+// ovhip_frame_set_band_mode(f, 1) asks for: a frame thread's job is sized when it is created, see ovhip_job_reserve_for_picture)
+extern "C" int ovhip_job_band_reserve(ovhip_job *j)
+{
+    if (!j) return OVHIP_EINVAL;
+    OV_DEVICE(j->ctx);
+    if (!j->bs) {
+        j->bs = (BandState *)calloc(1, sizeof(BandState));
+        if (!j->bs) return OVHIP_ENOMEM;
+    }
+    BandState *bs = j->bs;
+    if (!bs->n_chunks) {
+        char *h = nullptr, *d = nullptr;
+        CHK(arena_take(j, 1, &h, &d));
+        bs->chunk[0].used = 0; bs->cur_chunk = 0;
+    }
+    if (!bs->keep) OV_HIP(j->ctx, hipMalloc((void **)&bs->keep, (size_t)4 * j->w * sizeof(uint16_t)));
+    if (!j->res.y) CHK(ovhip_pic_alloc(j->ctx, j->w, j->h, &j->res));
+    if (!j->d_flow) {
+        const size_t words = ovhip_intra_flow_words(j->w, j->h);
+        OV_HIP(j->ctx, hipMalloc((void **)&j->d_flow, words * sizeof(uint32_t)));
+        OV_HIP(j->ctx, hipMemsetAsync(j->d_flow, 0, words * sizeof(uint32_t), j->ctx->stream));
+    }
+    return OVHIP_OK;
+}
+
 // 1: the reconstruction of the last band submitted is still running on the device.  A caller that is ahead of the device leaves its
 // next band to a later hook (it then covers more CTU rows): the launches stay few and full when the device is the slower side -- and
 // an I picture, whose ordered pass is one dependency chain per band, keeps its wavefront across as many rows as the parse has delivered
