@@ -644,6 +644,8 @@ static void gp_t_alf_line(OVCTUDec *const c, const struct RectEntryInfo *const e
 { const double t0 = gp_now(); __atomic_load_n(&g_alf_line_inner, __ATOMIC_RELAXED)(c, e, y); if (tls_thread) tls_thread->t_hooks += gp_now() - t0; }
 
 static void gp_reader_done(int k);
+static int gp_out_threads_on(void);
+static void gp_out_push_fwd(int k);
 
 static void
 gp_compare(struct gp_thread *t, const struct gp_seq *s, int k)
@@ -705,11 +707,13 @@ gp_decode_kept(struct gp_thread *t, int k)
     const int e = ovhip_shim_last_error(t->c);
     if (e) { fprintf(stderr, "gen_pipe: picture %d: the shim latched %d\n", k, e); if (!t->err) t->err = e; }
     if (g_timeline) { g_tl[k].decoded = gp_now() - g_tl_t0; }
-    gp_compare(t, t->s, k);
-    if (g_timeline) { g_tl[k].compared = gp_now() - g_tl_t0; }
+    if (!gp_out_threads_on()) {
+        gp_compare(t, t->s, k);
+        if (g_timeline) { g_tl[k].compared = gp_now() - g_tl_t0; }
+    }
     for (int i = 0; i < d->n0; ++i) gp_reader_done(d->l0[i]);
     for (int i = 0; i < d->n1; ++i) gp_reader_done(d->l1[i]);
-    gp_reader_done(k);
+    if (gp_out_threads_on()) gp_out_push_fwd(k); else gp_reader_done(k);
     t->n_done++;
 }
 
@@ -754,6 +758,40 @@ gp_reader_done(int k)
     pthread_mutex_unlock(&g_take_mtx);
 }
 
+/* "outthreads N": the comparison of a decoded picture with the reference pass (and the release of its frame) is done by N OUTPUT
+ * threads, not by the frame thread that decoded it -- as in the reference's own application, where the frame threads never touch a
+ * picture's output (dectest's main thread takes the frames from ovdec_receive_picture and writes them, dectest.c:372-409).  The timed
+ * region ends when every picture has been compared.  Default 0: the frame thread compares (what every figure before round 6 measured). */
+static int g_out_threads;
+static struct { pthread_mutex_t mtx; pthread_cond_t cnd; int q[4096]; int head, tail, done, quit; } g_outq = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER };
+static void
+gp_out_push(int k)
+{
+    pthread_mutex_lock(&g_outq.mtx);
+    g_outq.q[g_outq.tail++ & 4095] = k;
+    pthread_cond_broadcast(&g_outq.cnd);
+    pthread_mutex_unlock(&g_outq.mtx);
+}
+static void *
+gp_out_worker(void *arg)
+{
+    struct gp_thread *t = (struct gp_thread *)arg;          /* (its counters only) */
+    for (;;) {
+        pthread_mutex_lock(&g_outq.mtx);
+        while (g_outq.head == g_outq.tail && !g_outq.quit) pthread_cond_wait(&g_outq.cnd, &g_outq.mtx);
+        if (g_outq.head == g_outq.tail) { pthread_mutex_unlock(&g_outq.mtx); return NULL; }
+        const int k = g_outq.q[g_outq.head++ & 4095];
+        pthread_mutex_unlock(&g_outq.mtx);
+        gp_compare(t, t->s, k);
+        if (g_timeline) g_tl[k].compared = gp_now() - g_tl_t0;
+        gp_reader_done(k);
+        pthread_mutex_lock(&g_outq.mtx);
+        g_outq.done++;
+        pthread_cond_broadcast(&g_outq.cnd);
+        pthread_mutex_unlock(&g_outq.mtx);
+    }
+}
+
 static void *
 gp_worker(void *arg)
 {
@@ -785,6 +823,9 @@ gp_worker(void *arg)
     return NULL;
 }
 
+static int gp_out_threads_on(void) { return g_out_threads > 0 && g_pass_shim == 3; }
+static void gp_out_push_fwd(int k) { gp_out_push(k); }
+
 /* returns the wall time of the (last repetition of the) pass; the per-thread sums land in *tot */
 static double
 run_stream_threads(struct gp_seq *s, const struct gp_pic_desc *desc, int n_pic, int n_threads, struct gp_thread *tot)
@@ -807,6 +848,12 @@ run_stream_threads(struct gp_seq *s, const struct gp_pic_desc *desc, int n_pic, 
     g_readers_left = calloc(n_pic, sizeof(int));
     g_frames_made = g_frames_recycled = 0;
     for (int i = 0; i < n_threads; ++i) if (pthread_create(&th[i].th, NULL, gp_worker, &th[i])) { perror("pthread_create"); exit(1); }
+    struct gp_thread *oth = NULL;
+    if (gp_out_threads_on()) {
+        oth = calloc(g_out_threads, sizeof(*oth));
+        g_outq.head = g_outq.tail = g_outq.done = g_outq.quit = 0;
+        for (int i = 0; i < g_out_threads; ++i) { oth[i].id = 1000 + i; oth[i].s = s; if (pthread_create(&oth[i].th, NULL, gp_out_worker, &oth[i])) { perror("pthread_create"); exit(1); } }
+    }
     double wall = 0;
     for (g_rep = 0; g_rep < g_reps; ++g_rep) {
         /* the pictures exist as objects before any thread runs (the decoder's DPB makes them when it reads the slice header:
@@ -836,6 +883,11 @@ run_stream_threads(struct gp_seq *s, const struct gp_pic_desc *desc, int n_pic, 
         if (g_timeline) fprintf(stderr, "repetition %d starts at %.3f ms (CLOCK_MONOTONIC)\n", g_rep, 1e3 * t0);
         pthread_barrier_wait(&g_bar);
         pthread_barrier_wait(&g_bar);
+        if (gp_out_threads_on()) {                                   /* the timed region ends when every picture has been compared */
+            pthread_mutex_lock(&g_outq.mtx);
+            while (g_outq.done < (g_rep + 1) * n_pic) pthread_cond_wait(&g_outq.cnd, &g_outq.mtx);
+            pthread_mutex_unlock(&g_outq.mtx);
+        }
         wall = gp_now() - t0;
         if (g_timeline && g_rep == g_reps - 1)
             for (int k = 0; k < n_pic; ++k)
@@ -853,6 +905,15 @@ run_stream_threads(struct gp_seq *s, const struct gp_pic_desc *desc, int n_pic, 
     for (int i = 0; i < n_threads; ++i) pthread_join(th[i].th, NULL);
     pthread_barrier_destroy(&g_bar);
     memset(tot, 0, sizeof(*tot));
+    if (oth) {
+        pthread_mutex_lock(&g_outq.mtx); g_outq.quit = 1; pthread_cond_broadcast(&g_outq.cnd); pthread_mutex_unlock(&g_outq.mtx);
+        for (int i = 0; i < g_out_threads; ++i) {
+            pthread_join(oth[i].th, NULL);
+            tot->frames_differing += oth[i].frames_differing; tot->samples_differing += oth[i].samples_differing;
+            tot->mv_cells_differing += oth[i].mv_cells_differing; tot->mv_cells_compared += oth[i].mv_cells_compared;
+        }
+        free(oth);
+    }
     for (int i = 0; i < n_threads; ++i) {
         tot->t_sync += th[i].t_sync; tot->t_shim_hooks += th[i].t_shim_hooks; tot->t_shim_device += th[i].t_shim_device; tot->n_shim_calls += th[i].n_shim_calls;
         tot->bands_sent += th[i].bands_sent; tot->bands_deferred += th[i].bands_deferred;
@@ -906,6 +967,7 @@ gp_main(int argc, char **argv)
         else if (!strcmp(argv[i], "noout")) g_noout = 1;          /* live: OVHIP_OUT_NONE -- the pictures stay on the device (no copy into the OVFrame, frames not compared) */
         else if (!strcmp(argv[i], "timeline")) g_timeline = 1;
         else if (!strcmp(argv[i], "allow64x2")) g_allow_64x2 = 1;
+        else if (!strcmp(argv[i], "outthreads") && i + 1 < argc) g_out_threads = atoi(argv[++i]);
         else if (!strcmp(argv[i], "bands") && i + 1 < argc) g_bands = atoi(argv[++i]);      /* CTU rows per band (ovhip_shim_set_bands); default: the shim's */
         else if (!strcmp(argv[i], "live")) want_live = 1;      /* the shim on the real device, on frame threads; compares in process, prints a JSON line */
         else if (!strcmp(argv[i], "threads") && i + 1 < argc) {
@@ -1044,11 +1106,11 @@ gp_main(int argc, char **argv)
                    "\"pictures_decoded\": %d, \"shim_error\": %d, \"frames_differing\": %d, \"samples_differing\": %llu, \"collocated_motion_entries_differing\": %llu, \"collocated_motion_entries_compared\": %llu, "
                    "\"dmvr_calls\": %zu, \"thread_seconds_with_a_picture\": %.6f, \"thread_seconds_in_row_end_and_attach_hooks\": %.6f, "
                    "\"reference_pass_seconds_inside_slicedec\": %.6f, \"reference_pass_seconds\": %.6f, \"repetitions\": %d, \"host_frames_made\": %d, \"host_frames_recycled\": %d, \"output\": \"%s\", "
-                   "\"thread_seconds_waiting_for_collocated_rows\": %.6f, \"shim_profile\": %d, \"thread_seconds_in_shim_hooks\": %.6f, \"thread_seconds_in_shim_device_half\": %.6f, \"shim_hook_calls\": %llu, \"shim_profile_overhead_seconds_per_call\": %.3e, \"copies_back_to_back\": %d, \"bands_sent\": %u, \"bands_left_to_a_later_hook\": %u, \"coding_units_split_into_64x2_isp_partitions\": %d}\n",
+                   "\"thread_seconds_waiting_for_collocated_rows\": %.6f, \"shim_profile\": %d, \"thread_seconds_in_shim_hooks\": %.6f, \"thread_seconds_in_shim_device_half\": %.6f, \"shim_hook_calls\": %llu, \"shim_profile_overhead_seconds_per_call\": %.3e, \"copies_back_to_back\": %d, \"bands_sent\": %u, \"bands_left_to_a_later_hook\": %u, \"coding_units_split_into_64x2_isp_partitions\": %d, \"output_threads\": %d}\n",
                    want_live ? "live" : "device_dry_threads", g_threads, n_pic, W, H, wall, n_pic / wall, tot.n_done, tot.err, tot.frames_differing,
                    (unsigned long long)tot.samples_differing, (unsigned long long)tot.mv_cells_differing, (unsigned long long)tot.mv_cells_compared, g_dmvr_log.n / 12, tot.t_busy, tot.t_hooks,
                    g_decode_seconds_pass[0], t_ref, g_reps, g_frames_made, g_frames_recycled, g_noout ? "none" : "planes into the OVFrame",
-                   tot.t_sync, g_profile, tot.t_shim_hooks, tot.t_shim_device, (unsigned long long)tot.n_shim_calls, g_prof_overhead, g_cont, tot.bands_sent, tot.bands_deferred, n_64x2_ref);
+                   tot.t_sync, g_profile, tot.t_shim_hooks, tot.t_shim_device, (unsigned long long)tot.n_shim_calls, g_prof_overhead, g_cont, tot.bands_sent, tot.bands_deferred, n_64x2_ref, gp_out_threads_on() ? g_out_threads : 0);
             fflush(stdout);
             /* (with 64x2 partitions in the stream the reference pass is not a reference: only errors count) */
             bad |= tot.err || tot.n_done != n_pic || (!n_64x2_ref && (tot.samples_differing || tot.mv_cells_differing));
