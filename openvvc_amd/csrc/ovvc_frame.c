@@ -154,8 +154,10 @@ ovhip_frame_job(ovhip_frame *f)
     if (!f || f->dry) return NULL;
     if (!f->job) {
         if (fail(f, ovhip_job_create(f->ctx, f->w, f->h, &f->job), "ovhip_job_create") != OVHIP_OK) f->job = NULL;
-        /* a frame thread's job: sized for its pictures now, not grown picture by picture (OVVC_HIP_NO_RESERVE=1: the A / B) */
-        else if (!getenv("OVVC_HIP_NO_RESERVE") && fail(f, ovhip_job_reserve_for_picture(f->job), "ovhip_job_reserve_for_picture") != OVHIP_OK) { ovhip_job_destroy(f->job); f->job = NULL; }
+        /* a frame thread's job: sized for its pictures now, not grown picture by picture (OVVC_HIP_NO_RESERVE=1: the A / B).  The
+         * reservation is an optimisation: when it cannot be had (page-locked memory is short) the buffers grow with the pictures as they
+         * did before, and a picture that then does not fit fails with the allocation's own error */
+        else if (!getenv("OVVC_HIP_NO_RESERVE")) (void)ovhip_job_reserve_for_picture(f->job);
     }
     return f->job;
 }
