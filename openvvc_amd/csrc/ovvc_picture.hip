@@ -48,6 +48,7 @@ struct ovhip_job {
     size_t rows_end; int rows_pending;   // an eager pass is in flight: it covers [.., rows_end), ev_rows follows its copies
     hipEvent_t ev_rows;
     hipEvent_t ev_h2d, ev_done;
+    hipEvent_t ev_up0; hipStream_t up;   // uploads on one of the device's shared upload streams (upload_stream_for): up != NULL during such a flush
     int flow_on_device;                  // the last full flush uploaded the flow launch's item list (a resident replay may use it)
     int flushed;                         // ev_* recorded at least once
     const void *packed_prev[24];         // where the last full flush placed the arrays that rode in the parameter block
@@ -128,13 +129,36 @@ int dev_reserve(ovhip_job *j, int k, size_t bytes)
     return OVHIP_OK;
 }
 
+// The uploads of all pictures of a device on a FEW shared streams instead of every picture's own (tools/micro/h2d_concurrent.py, round 4:
+// 16 streams copying at once reach 31-38 GB/s, 1-4 streams 52-56): a picture's copies go to one of the device's upload streams, dealt
+// round-robin per flush, and the picture's own stream waits for the event behind them.  Measured on the headline stream, interleaved
+// runs on one box (tools/debug/ab_upload_streams.sh; LABBOOK 12): own stream 3309 +- 73 pictures/s, two upload streams 3506 +- 25; on
+// a second box 3336 / 3419 (three: 3427, four: 3247, eight: 3366).  OVVC_HIP_UPLOAD_STREAMS=0: every picture uploads on its own stream.
+enum { UP_DEVS = 64, UP_MAX = 8 };
+static pthread_mutex_t g_up_mtx = PTHREAD_MUTEX_INITIALIZER;
+static hipStream_t g_up[UP_DEVS][UP_MAX];
+static unsigned g_up_next[UP_DEVS];
+static int g_up_n = -1;
+static hipStream_t upload_stream_for(ovhip_job *j)
+{
+    if (g_up_n < 0) { const char *e = getenv("OVVC_HIP_UPLOAD_STREAMS"); int n = e ? atoi(e) : 2; __atomic_store_n(&g_up_n, n < 0 ? 0 : n > UP_MAX ? UP_MAX : n, __ATOMIC_RELAXED); }
+    const int n = __atomic_load_n(&g_up_n, __ATOMIC_RELAXED), dev = j->ctx->device;
+    if (n <= 0 || dev < 0 || dev >= UP_DEVS || j->t_stage >= 0) return nullptr;
+    pthread_mutex_lock(&g_up_mtx);
+    const unsigned k = g_up_next[dev]++ % (unsigned)n;
+    if (!g_up[dev][k] && hipStreamCreateWithFlags(&g_up[dev][k], hipStreamNonBlocking) != hipSuccess) g_up[dev][k] = nullptr;
+    hipStream_t st = g_up[dev][k];
+    pthread_mutex_unlock(&g_up_mtx);
+    return st;
+}
+
 int h2d(ovhip_job *j, int k, const void *host, size_t bytes)
 {
     if (!bytes) return OVHIP_OK;
     if (j->resident) return j->dev[k].cap >= bytes ? OVHIP_OK : ov_fail(j->ctx, OVHIP_EINVAL, "resident flush before a full one", hipSuccess);
     int r = dev_reserve(j, k, bytes);
     if (r) return r;
-    OV_HIP(j->ctx, hipMemcpyAsync(j->dev[k].p, host, bytes, hipMemcpyHostToDevice, j->ctx->stream));
+    OV_HIP(j->ctx, hipMemcpyAsync(j->dev[k].p, host, bytes, hipMemcpyHostToDevice, j->up ? j->up : j->ctx->stream));
     j->st.h2d_bytes += bytes; j->st.n_h2d++;
     return OVHIP_OK;
 }
@@ -228,6 +252,7 @@ int ovhip_job_create(ovhip_ctx *ctx, int32_t w, int32_t h, ovhip_job **out)
     if (r == OVHIP_OK && hipEventCreateWithFlags(&j->ev_h2d, hipEventDisableTiming) != hipSuccess) r = OVHIP_ENODEV;
     if (r == OVHIP_OK && hipEventCreateWithFlags(&j->ev_done, hipEventDisableTiming) != hipSuccess) r = OVHIP_ENODEV;
     if (r == OVHIP_OK && hipEventCreateWithFlags(&j->ev_rows, hipEventDisableTiming) != hipSuccess) r = OVHIP_ENODEV;
+    if (r == OVHIP_OK && hipEventCreateWithFlags(&j->ev_up0, hipEventDisableTiming) != hipSuccess) r = OVHIP_ENODEV;
     if (r != OVHIP_OK) { ovhip_job_destroy(j); return r; }
     *out = j;
     return OVHIP_OK;
@@ -249,6 +274,7 @@ void ovhip_job_destroy(ovhip_job *j)
     for (int k = 0; k < 32; ++k) for (int q = 0; q < 2; ++q) if (j->t_ev[k][q]) (void)hipEventDestroy(j->t_ev[k][q]);
     if (j->ev_h2d) (void)hipEventDestroy(j->ev_h2d);
     if (j->ev_done) (void)hipEventDestroy(j->ev_done);
+    if (j->ev_up0) (void)hipEventDestroy(j->ev_up0);
     if (j->ev_rows) { if (j->rows_pending) (void)hipEventSynchronize(j->ev_rows); (void)hipEventDestroy(j->ev_rows); }
     band_free(j);
     ovhip_rec_destroy(j->rec);
@@ -657,6 +683,14 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
 
     const double t_flush1 = host_now_us();
     // ---- H2D (asynchronous DMA out of page-locked memory, in stage order so that prediction can start early) ----
+    j->up = (j->resident || no_upload) ? nullptr : upload_stream_for(j);
+    if (j->up) {
+        // behind whatever this job's stream still holds (the previous picture's launches read the buffers the copies overwrite; the
+        // eager refinement rows of this picture): with a frame thread that waits for its picture before it takes the next, long complete
+        hipError_t e0 = hipEventRecord(j->ev_up0, ctx->stream);
+        if (e0 == hipSuccess) e0 = hipStreamWaitEvent(j->up, j->ev_up0, 0);
+        if (e0 != hipSuccess) { j->up = nullptr; return ov_fail(ctx, OVHIP_ENODEV, "ovhip_job_flush: upload stream", e0); }
+    }
     {
     StageTimer t_(j, OVHIP_TIME_H2D);
     CHK(h2d(j, B_PARAM, j->param_host, L.total));
@@ -676,7 +710,11 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
     // a resident replay re-uses the placement of the flush before it
     if (no_upload) memcpy(packed, j->packed_prev, sizeof(packed)); else { memcpy(j->packed_prev, packed, sizeof(packed)); j->flow_on_device = by_flow && n_items; }
     auto DEV = [&](int k) -> const void * { return packed[k] ? packed[k] : j->dev[k].p; };
-    OV_HIP(ctx, hipEventRecord(j->ev_h2d, ctx->stream));
+    if (j->up) {
+        hipStream_t up = j->up; j->up = nullptr;
+        OV_HIP(ctx, hipEventRecord(j->ev_h2d, up));
+        OV_HIP(ctx, hipStreamWaitEvent(ctx->stream, j->ev_h2d, 0));
+    } else OV_HIP(ctx, hipEventRecord(j->ev_h2d, ctx->stream));
     const double t_flush2 = host_now_us();
     // everything below reads or writes pictures: behind the pictures this one depends on
     for (uint32_t i = 0; i < pr->n_wait_events; ++i)
