@@ -182,7 +182,9 @@ extern "C" int ovhip_itx_launch_ex_(ovhip_ctx *ctx, const ovhip_pic *dst, const 
 #define CHK(x) do { int r__ = (x); if (r__ != OVHIP_OK) return r__; } while (0)
 
 #ifndef OVHIP_PACK_LIMIT
-#define OVHIP_PACK_LIMIT (128 << 10)     /* bytes: arrays up to this size ride in the staging block */
+#define OVHIP_PACK_LIMIT (1 << 20)       /* bytes: arrays up to this size ride in the staging block (round 6, uploads on shared streams:
+                                          * 128 KB 3414 +- 147 / 3491 +- 79, 1 MB 3492 +- 69 / 3566 +- 49, 2 MB 3456, everything 3440 pictures/s;
+                                          * tools/debug/ab_pack_limit.sh) */
 #endif
 
 double host_now_us()
@@ -298,12 +300,12 @@ int ovhip_job_reserve_for_picture(ovhip_job *j)
         { B_TB, (P / 64 + 1024) * sizeof(ovhip_tb_cmd) }, { B_COEF, (P / 2 + 1024) * 2 }, { B_MC, (P / 128 + 1024) * sizeof(ovhip_mc_unit) },
         { B_MCX, (P / 256 + 1024) * sizeof(ovhip_mc_unit) }, { B_MV, (P / 256 + 1024) * 16 }, { B_AFF, (P / 1024 + 256) * sizeof(ovhip_aff_unit) },
         { B_SIDE, (P / 6 + 1024) * 4 }, { B_REG, (P / 4096 + 64) * sizeof(ovhip_lmcs_region) }, { B_SCALE, 65536 },
-        { B_EV, (P / 32 + 2048) * sizeof(ovhip_dbf_edge) }, { B_EH, (P / 32 + 2048) * sizeof(ovhip_dbf_edge) }, { B_PARAM, P / 4 + ((size_t)1 << 20) },
+        { B_EV, (P / 32 + 2048) * sizeof(ovhip_dbf_edge) }, { B_EH, (P / 32 + 2048) * sizeof(ovhip_dbf_edge) }, { B_PARAM, P / 2 + ((size_t)2 << 20) },
         { B_CLASS, (size_t)((j->w + 3) / 4) * ((j->h + 3) / 4) }, { B_ITASK, (P / 64 + 1024) * sizeof(ovhip_itask) }, { B_IITEM, (P / 32 + 1024) * 4 },
         { B_TMVP, 4 * (P / 256 + 1024) * sizeof(ovhip_tmvp_cell) },
     };
     for (const auto &q : want) CHK(dev_reserve(j, q.k, q.bytes));
-    CHK(pinned_reserve(j, (void **)&j->param_host, &j->param_cap, P / 4 + ((size_t)1 << 20)));
+    CHK(pinned_reserve(j, (void **)&j->param_host, &j->param_cap, P / 2 + ((size_t)2 << 20)));
     CHK(pinned_reserve(j, (void **)&j->mv_host, &j->mv_cap, (P / 256 + 1024) * 16));
     CHK(pinned_reserve(j, (void **)&j->tmvp_host, &j->tmvp_cap, 4 * (P / 256 + 1024) * sizeof(ovhip_tmvp_cell)));
     if (j->items_cap < P / 32 + 1024) {
