@@ -48,7 +48,7 @@ struct ovhip_job {
     size_t rows_end; int rows_pending;   // an eager pass is in flight: it covers [.., rows_end), ev_rows follows its copies
     hipEvent_t ev_rows;
     hipEvent_t ev_h2d, ev_done;
-    hipEvent_t ev_up0; hipStream_t up;   // uploads on one of the device's shared upload streams (upload_stream_for): up != NULL during such a flush
+    hipStream_t up;                      // uploads on one of the device's shared upload streams (upload_stream_for): up != NULL during such a flush
     int flow_on_device;                  // the last full flush uploaded the flow launch's item list (a resident replay may use it)
     int flushed;                         // ev_* recorded at least once
     const void *packed_prev[24];         // where the last full flush placed the arrays that rode in the parameter block
@@ -139,10 +139,10 @@ static pthread_mutex_t g_up_mtx = PTHREAD_MUTEX_INITIALIZER;
 static hipStream_t g_up[UP_DEVS][UP_MAX];
 static unsigned g_up_next[UP_DEVS];
 static int g_up_n = -1;
+static int upload_stream_count();
 static hipStream_t upload_stream_for(ovhip_job *j)
 {
-    if (g_up_n < 0) { const char *e = getenv("OVVC_HIP_UPLOAD_STREAMS"); int n = e ? atoi(e) : 2; __atomic_store_n(&g_up_n, n < 0 ? 0 : n > UP_MAX ? UP_MAX : n, __ATOMIC_RELAXED); }
-    const int n = __atomic_load_n(&g_up_n, __ATOMIC_RELAXED), dev = j->ctx->device;
+    const int n = upload_stream_count(), dev = j->ctx->device;
     if (n <= 0 || dev < 0 || dev >= UP_DEVS || j->t_stage >= 0) return nullptr;
     pthread_mutex_lock(&g_up_mtx);
     const unsigned k = g_up_next[dev]++ % (unsigned)n;
@@ -150,6 +150,15 @@ static hipStream_t upload_stream_for(ovhip_job *j)
     hipStream_t st = g_up[dev][k];
     pthread_mutex_unlock(&g_up_mtx);
     return st;
+}
+
+static int upload_stream_count()
+{
+    if (__atomic_load_n(&g_up_n, __ATOMIC_RELAXED) < 0) {
+        const char *e = getenv("OVVC_HIP_UPLOAD_STREAMS"); const int n = e ? atoi(e) : 2;
+        __atomic_store_n(&g_up_n, n < 0 ? 0 : n > UP_MAX ? UP_MAX : n, __ATOMIC_RELAXED);
+    }
+    return __atomic_load_n(&g_up_n, __ATOMIC_RELAXED);
 }
 
 int h2d(ovhip_job *j, int k, const void *host, size_t bytes)
@@ -254,7 +263,6 @@ int ovhip_job_create(ovhip_ctx *ctx, int32_t w, int32_t h, ovhip_job **out)
     if (r == OVHIP_OK && hipEventCreateWithFlags(&j->ev_h2d, hipEventDisableTiming) != hipSuccess) r = OVHIP_ENODEV;
     if (r == OVHIP_OK && hipEventCreateWithFlags(&j->ev_done, hipEventDisableTiming) != hipSuccess) r = OVHIP_ENODEV;
     if (r == OVHIP_OK && hipEventCreateWithFlags(&j->ev_rows, hipEventDisableTiming) != hipSuccess) r = OVHIP_ENODEV;
-    if (r == OVHIP_OK && hipEventCreateWithFlags(&j->ev_up0, hipEventDisableTiming) != hipSuccess) r = OVHIP_ENODEV;
     if (r != OVHIP_OK) { ovhip_job_destroy(j); return r; }
     *out = j;
     return OVHIP_OK;
@@ -276,7 +284,6 @@ void ovhip_job_destroy(ovhip_job *j)
     for (int k = 0; k < 32; ++k) for (int q = 0; q < 2; ++q) if (j->t_ev[k][q]) (void)hipEventDestroy(j->t_ev[k][q]);
     if (j->ev_h2d) (void)hipEventDestroy(j->ev_h2d);
     if (j->ev_done) (void)hipEventDestroy(j->ev_done);
-    if (j->ev_up0) (void)hipEventDestroy(j->ev_up0);
     if (j->ev_rows) { if (j->rows_pending) (void)hipEventSynchronize(j->ev_rows); (void)hipEventDestroy(j->ev_rows); }
     band_free(j);
     ovhip_rec_destroy(j->rec);
@@ -687,10 +694,15 @@ static int job_flush_impl(ovhip_job *j, const ovhip_pic *dst, const ovhip_pic *r
     // ---- H2D (asynchronous DMA out of page-locked memory, in stage order so that prediction can start early) ----
     j->up = (j->resident || no_upload) ? nullptr : upload_stream_for(j);
     if (j->up) {
-        // behind whatever this job's stream still holds (the previous picture's launches read the buffers the copies overwrite; the
-        // eager refinement rows of this picture): with a frame thread that waits for its picture before it takes the next, long complete
-        hipError_t e0 = hipEventRecord(j->ev_up0, ctx->stream);
-        if (e0 == hipSuccess) e0 = hipStreamWaitEvent(j->up, j->ev_up0, 0);
+        // The copies overwrite buffers the previous picture's launches and this picture's eager refinement rows read: the upload stream
+        // waits for THEIR events (ev_done: the end of the last flush; ev_rows: the end of an eager pass not collected yet) -- with a frame
+        // thread that waits for its picture before it takes the next, both long complete.  NOT for a fresh marker on the picture's own
+        // stream: a marker queues behind whatever other streams put into the same hardware queue (17 streams share 4: an I picture's
+        // 7 ms ordered pass, a 0.8 ms frame download), and the shared upload stream would hold up every picture behind it (measured:
+        // the in-order variant 2309 -> 1476, frames leaving the device 1247 -> 1022 pictures/s with such a marker)
+        hipError_t e0 = hipSuccess;
+        if (j->flushed) e0 = hipStreamWaitEvent(j->up, j->ev_done, 0);
+        if (e0 == hipSuccess && j->rows_pending) e0 = hipStreamWaitEvent(j->up, j->ev_rows, 0);
         if (e0 != hipSuccess) { j->up = nullptr; return ov_fail(ctx, OVHIP_ENODEV, "ovhip_job_flush: upload stream", e0); }
     }
     {
@@ -1155,6 +1167,40 @@ static int band_wait_done(ovhip_job *j)
 }
 
 static inline int32_t floor8(int32_t v) { return v <= 0 ? 0 : v & ~7; }
+
+/* (internal, ovvc_stream.c) The device's upload streams out of the hardware queue of `keep_clear`'s stream -- the look-ahead thread's: the event
+ * behind a picture's copies is a packet of the upload stream's hardware queue, and behind an I picture's ordered pass it would arrive
+ * milliseconds late for every picture whose copies follow.  An upload stream that shares the queue is replaced (the old one stays
+ * alive: events may refer to it).  Returns the number still sharing, or < 0. */
+extern "C" int ovhip_upload_streams_clear_of_(ovhip_ctx *keep_clear)
+{
+    if (!keep_clear) return OVHIP_EINVAL;
+    const int n = upload_stream_count(), dev = keep_clear->device;
+    if (n <= 0 || dev < 0 || dev >= UP_DEVS) return 0;
+    OV_DEVICE(keep_clear);
+    int sharing = 0;
+    for (int k = 0; k < n; ++k) {
+        pthread_mutex_lock(&g_up_mtx);
+        if (!g_up[dev][k] && hipStreamCreateWithFlags(&g_up[dev][k], hipStreamNonBlocking) != hipSuccess) g_up[dev][k] = nullptr;
+        hipStream_t st = g_up[dev][k];
+        pthread_mutex_unlock(&g_up_mtx);
+        if (!st) continue;
+        for (int tries = 0; tries < 12; ++tries) {
+            ovhip_ctx tmp; memset(&tmp, 0, sizeof(tmp)); tmp.device = dev; tmp.stream = st;
+            const int q = ovhip_ctx_shares_queue(keep_clear, &tmp);
+            if (q != 1) { st = q == 0 ? st : nullptr; break; }
+            hipStream_t fresh = nullptr;
+            if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) { st = nullptr; break; }
+            st = fresh;
+            if (tries == 11) st = nullptr;
+        }
+        if (!st) { ++sharing; continue; }
+        pthread_mutex_lock(&g_up_mtx);
+        g_up[dev][k] = st;
+        pthread_mutex_unlock(&g_up_mtx);
+    }
+    return sharing;
+}
 
 extern "C" int ovhip_job_band_active(const ovhip_job *j) { return j && band_active(j); }
 

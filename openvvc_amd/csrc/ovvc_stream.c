@@ -27,6 +27,8 @@
 
 struct run_state;
 
+int ovhip_upload_streams_clear_of_(ovhip_ctx *keep_clear);     /* ovvc_picture.hip */
+
 struct ovhip_stream {
     ovhip_dpb *dpb;
     ovhip_stream_cfg cfg;
@@ -413,6 +415,8 @@ ovhip_stream_create(ovhip_stream **out, ovhip_dpb *dpb, const ovhip_stream_cfg *
             for (int tries = 0; tries < 12 && ovhip_ctx_shares_queue(ahead, c) == 1; ++tries) { if (ovhip_ctx_new_stream(c) != OVHIP_OK) break; s->n_moved++; }
             if (ovhip_ctx_shares_queue(ahead, c) == 1) s->n_sharing++;
         }
+        /* the device's shared upload streams likewise: the event behind a picture's copies must not queue behind an I picture */
+        { const int q = ovhip_upload_streams_clear_of_(ahead); if (q > 0) s->n_sharing += q; }
     }
     if (cfg->output == OVHIP_OUT_PACKED) {
         for (int k = 0; k < s->n_dev && r == OVHIP_OK; ++k) r = ovhip_ctx_create(&s->out_ctx[k], ovhip_dpb_device(dpb, k), NULL);
